@@ -1,0 +1,8 @@
+"""hgx: MI355X-native allele-compatibility scoring + EM abundance estimation.
+
+Drop-in for the per-locus hot path of HISAT-genotype
+(hisatgenotype_typing_core.typing / hisatgenotype_typing_common.single_abundance).
+Compute runs in hand-written HIP kernels (csrc/) reached through the C-ABI in
+include/hgx.h; there is no CPU fallback: a missing/unbuildable extension raises.
+"""
+__version__ = "0.1.0"

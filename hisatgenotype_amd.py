@@ -1,0 +1,12 @@
+"""Import alias: the package directory is ``hisat-genotype_amd/`` (not a valid Python
+identifier), so this loader registers it in ``sys.modules`` as ``hisatgenotype_amd``."""
+import importlib.util as _u
+import os as _os
+import sys as _sys
+
+_dir = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "hisat-genotype_amd")
+_spec = _u.spec_from_file_location("hisatgenotype_amd", _os.path.join(_dir, "__init__.py"),
+                                   submodule_search_locations=[_dir])
+_mod = _u.module_from_spec(_spec)
+_sys.modules["hisatgenotype_amd"] = _mod
+_spec.loader.exec_module(_mod)
