@@ -1,0 +1,62 @@
+"""Build libhgx.so (HIP kernels + C-ABI + host front-end) in-tree for gfx950.
+
+hipcc cross-compiles without a GPU, so this also runs in the build container.  The shared object
+lands next to the sources (hisat-genotype_amd/csrc/libhgx.so), is git-ignored and travels to the
+GPU box with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(CSRC, "libhgx.so")
+ARCH = "gfx950"
+
+
+def _sources():
+    out = []
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".cpp")):
+            out.append(os.path.join(CSRC, f))
+    return out
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = _sources() + [os.path.join(ROOT, "include", "hgx.h")]
+    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in _sources():
+        obj = src.rsplit(".", 1)[0] + ".o"
+        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
+                and os.path.getmtime(obj) > os.path.getmtime(os.path.join(ROOT, "include", "hgx.h"))):
+            objs.append(obj)
+            continue
+        cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+               "-I", CSRC, "-Wall", "-Wno-unused-result", "-c", src, "-o", obj]
+        if src.endswith(".hip"):
+            cmd.insert(1, "--offload-arch=" + ARCH)
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

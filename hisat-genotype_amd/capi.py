@@ -1,0 +1,144 @@
+"""ctypes binding of libhgx.so (include/hgx.h).  No fallback: if the library is missing or a
+call fails, an exception is raised."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libhgx.so")
+
+VAR_INSERTION, VAR_SINGLE, VAR_DELETION = 0, 1, 2
+BASE_KIND = {"hla": 0, "codis": 1, "genome": 2}
+
+
+class HgxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libhgx error %d: %s" % (code, msg))
+        self.code = code
+
+
+class HgxKeyError(HgxError, KeyError):
+    """The reference raises KeyError at this point (EM quirk Q6)."""
+
+
+class Piece(C.Structure):
+    _fields_ = [("mask_off", C.c_uint32), ("lo_word", C.c_uint16), ("n_words", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+PIECE_DTYPE = np.dtype([("mask_off", np.uint32), ("lo_word", np.uint16), ("n_words", np.uint8), ("reserved", np.uint8)])
+
+
+class LocusDesc(C.Structure):
+    _fields_ = [("base_kind", C.c_int32), ("backbone_len", C.c_int32), ("backbone", C.c_char_p),
+                ("n_vars", C.c_int32), ("var_pos", C.c_void_p), ("var_type", C.c_void_p), ("var_len", C.c_void_p),
+                ("var_base", C.c_void_p), ("var_linked", C.c_void_p), ("var_name_pool", C.c_char_p),
+                ("var_ins_pool", C.c_char_p), ("n_alleles", C.c_int32), ("link_off", C.c_void_p),
+                ("link_allele", C.c_void_p), ("n_link_order", C.c_int32), ("link_order", C.c_void_p),
+                ("n_exons", C.c_int32), ("exons", C.c_void_p), ("allele_len", C.c_void_p), ("name_rank", C.c_void_p)]
+
+
+class ParseOpts(C.Structure):
+    _fields_ = [("num_editdist", C.c_int32), ("error_correction", C.c_int32), ("allow_discordant", C.c_int32),
+                ("simulation", C.c_int32), ("base_locus", C.c_int32), ("keep_trace", C.c_int32)]
+
+
+# every symbol include/hgx.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "hgx_last_error", "hgx_version", "hgx_device_count", "hgx_set_device", "hgx_dev_alloc", "hgx_dev_free",
+    "hgx_memcpy_h2d", "hgx_memcpy_d2h", "hgx_memset", "hgx_stream_sync", "hgx_a_pad", "hgx_index_create",
+    "hgx_index_destroy", "hgx_index_dims", "hgx_index_device_bits", "hgx_piece_compat", "hgx_pair_classes",
+    "hgx_score_pairs", "hgx_dedup_classes", "hgx_classes_destroy", "hgx_classes_dims", "hgx_classes_device",
+    "hgx_classes_to_host", "hgx_classes_from_host", "hgx_allele_counts", "hgx_em", "hgx_locus_create",
+    "hgx_locus_destroy", "hgx_locus_dims", "hgx_locus_tables", "hgx_index_from_locus",
+    "hgx_locus_alternatives_text", "hgx_batch_destroy", "hgx_batch_dims", "hgx_batch_arrays",
+    "hgx_batch_from_haplotypes", "hgx_parse_sam", "hgx_batch_trace_text", "hgx_batch_pileup",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libhgx.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.hgx_last_error.restype = C.c_char_p
+        _lib.hgx_a_pad.restype = C.c_int32
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().hgx_last_error().decode(errors="replace")
+        if rc == -4:
+            raise HgxKeyError(rc, msg)
+        raise HgxError(rc, msg)
+
+
+def ptr(a):
+    if a is None:
+        return None
+    if isinstance(a, DevArray):
+        return C.c_void_p(a.ptr)
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def a_pad(n_alleles):
+    return int(lib().hgx_a_pad(C.c_int32(n_alleles)))
+
+
+def device_count():
+    n = C.c_int(0)
+    check(lib().hgx_device_count(C.byref(n)))
+    return n.value
+
+
+def set_device(dev):
+    check(lib().hgx_set_device(C.c_int(dev)))
+
+
+class DevArray:
+    """A typed device allocation owned by Python (hipMalloc through the C-ABI)."""
+
+    def __init__(self, shape, dtype):
+        self.shape = tuple(int(x) for x in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(lib().hgx_dev_alloc(C.byref(p), C.c_size_t(self.nbytes)))
+        self.ptr = p.value
+
+    @staticmethod
+    def from_host(arr, stream=None):
+        arr = np.ascontiguousarray(arr)
+        d = DevArray(arr.shape, arr.dtype)
+        if arr.nbytes:
+            check(lib().hgx_memcpy_h2d(C.c_void_p(d.ptr), ptr(arr), C.c_size_t(arr.nbytes), stream))
+        return d
+
+    def to_host(self, stream=None):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if self.nbytes:
+            check(lib().hgx_memcpy_d2h(ptr(out), C.c_void_p(self.ptr), C.c_size_t(self.nbytes), stream))
+        return out
+
+    def zero(self, stream=None):
+        check(lib().hgx_memset(C.c_void_p(self.ptr), 0, C.c_size_t(self.nbytes), stream))
+
+    def free(self):
+        if self.ptr:
+            lib().hgx_dev_free(C.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sync(stream=None):
+    check(lib().hgx_stream_sync(stream))

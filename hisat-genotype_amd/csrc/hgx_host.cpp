@@ -1,0 +1,268 @@
+// hgx_host.cpp -- host side of libhgx: locus tables (8a-0) and haplotype -> piece-mask reduction
+// (the host half of add_count, typing_core.py:626-677).  Plain C++; no device code here.
+#include <algorithm>
+#include <cstring>
+#include <map>
+
+#include "hgx_internal.hpp"
+
+extern "C" int hgx_locus_create(hgx_locus **out, const hgx_locus_desc *d) {
+    HARGCHK(out && d && d->backbone && d->backbone_len > 0 && d->n_vars >= 0 && d->n_alleles > 0);
+    HARGCHK(d->n_vars == 0 || (d->var_pos && d->var_type && d->var_len && d->var_base && d->var_linked &&
+                               d->var_name_pool && d->var_ins_pool && d->link_off && d->link_allele));
+    HARGCHK(d->n_exons == 0 || d->exons);
+    hgx_locus *L = new hgx_locus();
+    L->base_kind = d->base_kind;
+    L->backbone.assign(d->backbone, d->backbone + d->backbone_len);
+    const int V = L->V = d->n_vars;
+    L->pos.assign(d->var_pos, d->var_pos + V);
+    L->type.assign(d->var_type, d->var_type + V);
+    L->len.assign(d->var_len, d->var_len + V);
+    L->base.assign(d->var_base, d->var_base + V);
+    L->linked.assign(d->var_linked, d->var_linked + V);
+    L->right.resize(V);
+    L->maxright.resize(V);
+    const char *np = d->var_name_pool, *ip = d->var_ins_pool;
+    int cur = -1;
+    for (int v = 0; v < V; ++v) {
+        L->name.emplace_back(np);
+        np += L->name.back().size() + 1;
+        L->ins.emplace_back(ip);
+        ip += L->ins.back().size() + 1;
+        L->name_to_var[L->name.back()] = v;
+        if (v > 0 && L->pos[v] < L->pos[v - 1]) {
+            hgx_set_error("variants must be sorted by position (gene_var_list order)");
+            delete L;
+            return HGX_EINVAL;
+        }
+        L->right[v] = L->type[v] == HGX_VAR_DELETION ? L->pos[v] + L->len[v] - 1 : L->pos[v];
+        cur = std::max(cur, L->right[v]);                          // core:396-401
+        L->maxright[v] = cur;
+    }
+    const int A = L->A = d->n_alleles;
+    L->a_pad = hgx_a_pad(A);
+    L->w64 = L->a_pad / 64;
+    L->n_words = std::max(1, (V + 31) / 32);
+    if (L->n_words > 65535) {
+        hgx_set_error("too many variants (%d)", V);
+        delete L;
+        return HGX_EINVAL;
+    }
+    L->link_off.assign(d->link_off ? d->link_off : nullptr, d->link_off ? d->link_off + V + 1 : nullptr);
+    if (V == 0) L->link_off.assign(1, 0);
+    L->link_allele.assign(d->link_allele, d->link_allele + L->link_off[V]);
+    for (int e = 0; e < d->n_exons; ++e) L->exons.push_back({d->exons[2 * e], d->exons[2 * e + 1]});
+    if (d->allele_len) L->allele_len.assign(d->allele_len, d->allele_len + A);
+    if (d->name_rank) L->name_rank.assign(d->name_rank, d->name_rank + A);
+
+    // link bit matrix, word-major
+    L->link_bits.assign((size_t)L->n_words * L->a_pad, 0u);
+    std::vector<int32_t> n_av(A, 0);
+    for (int v = 0; v < V; ++v) {
+        for (int k = L->link_off[v]; k < L->link_off[v + 1]; ++k) {
+            const int a = L->link_allele[k];
+            if (a < 0 || a >= A) {
+                hgx_set_error("link_allele out of range");
+                delete L;
+                return HGX_EINVAL;
+            }
+            uint32_t &w = L->link_bits[(size_t)(v >> 5) * L->a_pad + a];
+            if (!((w >> (v & 31)) & 1u)) n_av[a]++;
+            w |= 1u << (v & 31);
+        }
+    }
+    // allele -> variants in gene_var_list order (core:476-487)
+    L->av_off.assign(A + 1, 0);
+    for (int a = 0; a < A; ++a) L->av_off[a + 1] = L->av_off[a] + n_av[a];
+    L->av_var.resize(L->av_off[A]);
+    {
+        std::vector<int32_t> fill(L->av_off.begin(), L->av_off.end() - 1);
+        // iterate variant-major so each allele's list comes out position-sorted
+        for (int v = 0; v < V; ++v) {
+            const uint32_t *row = &L->link_bits[(size_t)(v >> 5) * L->a_pad];
+            for (int k = L->link_off[v]; k < L->link_off[v + 1]; ++k) {
+                const int a = L->link_allele[k];
+                if ((row[a] >> (v & 31)) & 1u) {
+                    // guard against a duplicated allele inside one Links entry
+                    if (fill[a] > L->av_off[a] && L->av_var[fill[a] - 1] == v) continue;
+                    L->av_var[fill[a]++] = v;
+                }
+            }
+        }
+    }
+    // exonic variants (core:67-78) and representative alleles (core:86-115)
+    L->exonic.assign(V, 0);
+    for (int v = 0; v < V; ++v)
+        for (auto &e : L->exons)
+            if (L->pos[v] >= e[0] && L->right[v] <= e[1]) L->exonic[v] = 1;
+    L->rep_of.assign(A, -1);
+    {
+        // alleles in order of first appearance scanning Links (dict order) restricted to exonic variants
+        std::vector<int32_t> order;
+        std::vector<uint8_t> seen(A, 0);
+        std::vector<std::vector<int32_t>> evars(A);
+        std::vector<int32_t> lo;
+        if (d->link_order && d->n_link_order > 0) lo.assign(d->link_order, d->link_order + d->n_link_order);
+        else for (int v = 0; v < V; ++v) if (L->linked[v]) lo.push_back(v);
+        for (int v : lo) {
+            if (v < 0 || v >= V || !L->exonic[v]) continue;
+            for (int k = L->link_off[v]; k < L->link_off[v + 1]; ++k) {
+                const int a = L->link_allele[k];
+                if (!seen[a]) { seen[a] = 1; order.push_back(a); }
+                evars[a].push_back(v);
+            }
+        }
+        std::map<std::vector<int32_t>, int32_t> group_rep;
+        for (int a : order) {
+            auto &vs = evars[a];
+            std::sort(vs.begin(), vs.end());
+            vs.erase(std::unique(vs.begin(), vs.end()), vs.end());
+            auto it = group_rep.find(vs);
+            if (it == group_rep.end()) { group_rep.emplace(vs, a); L->rep_of[a] = a; }
+            else L->rep_of[a] = it->second;
+        }
+    }
+    L->exon_mask.assign(L->w64, 0ull);
+    L->gene_mask.assign(L->w64, 0ull);
+    for (int a = 0; a < A; ++a) {
+        L->gene_mask[a >> 6] |= 1ull << (a & 63);
+        if (L->rep_of[a] == a) L->exon_mask[a >> 6] |= 1ull << (a & 63);
+    }
+    *out = L;
+    return HGX_OK;
+}
+
+extern "C" int hgx_locus_destroy(hgx_locus *loc) { delete loc; return HGX_OK; }
+
+extern "C" int hgx_locus_dims(const hgx_locus *L, int32_t *na, int32_t *ap, int32_t *nv, int32_t *nw) {
+    HARGCHK(L);
+    if (na) *na = L->A;
+    if (ap) *ap = L->a_pad;
+    if (nv) *nv = L->V;
+    if (nw) *nw = L->n_words;
+    return HGX_OK;
+}
+
+extern "C" int hgx_locus_tables(const hgx_locus *L, uint32_t *bits, uint64_t *em, uint64_t *gm, int32_t *rep_of) {
+    HARGCHK(L);
+    if (bits) memcpy(bits, L->link_bits.data(), L->link_bits.size() * 4);
+    if (em) memcpy(em, L->exon_mask.data(), L->exon_mask.size() * 8);
+    if (gm) memcpy(gm, L->gene_mask.data(), L->gene_mask.size() * 8);
+    if (rep_of) memcpy(rep_of, L->rep_of.data(), L->rep_of.size() * 4);
+    return HGX_OK;
+}
+
+extern "C" int hgx_index_from_locus(hgx_index **out, const hgx_locus *L) {
+    HARGCHK(out && L);
+    return hgx_index_create(out, L->A, L->V, L->link_bits.data(), L->exon_mask.data(), L->gene_mask.data());
+}
+
+// ---------------------------------------------------------------------------------------------
+// piece -> masks.  P = the piece's own known, linked variants (core:642-647).  M = known, linked
+// variants outside the piece's id list whose left or right end lies in [left, right]; the
+// reference finds them scanning down from lower_bound(right + 1) until the prefix-max right end
+// drops below `left` (core:651-670) -- every variant above the start has pos > right and every
+// variant below the stop has right end < left, so the scan bounds never change the set.
+// ---------------------------------------------------------------------------------------------
+int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &L, int32_t left, int32_t right, const int32_t *ids, int32_t n_ids) {
+    const int V = L.V;
+    int lo_w = 0x7fffffff, hi_w = -1;
+    // first pass: word range
+    auto touch = [&](int v) { lo_w = std::min(lo_w, v >> 5); hi_w = std::max(hi_w, v >> 5); };
+    for (int i = 0; i < n_ids; ++i) {
+        const int v = ids[i];
+        if (v >= 0 && v < V && L.linked[v]) touch(v);
+    }
+    int j = V ? std::min(lower_bound_pos(L.pos, right + 1), V - 1) : -1;
+    const int j_top = j;
+    auto in_ids = [&](int v) { for (int i = 0; i < n_ids; ++i) if (ids[i] == v) return true; return false; };
+    for (; j >= 0 && L.maxright[j] >= left; --j) {
+        if (!L.linked[j] || in_ids(j)) continue;
+        if ((L.pos[j] >= left && L.pos[j] <= right) || (L.right[j] >= left && L.right[j] <= right)) touch(j);
+    }
+    PieceKey key;
+    if (hi_w < 0) { lo_w = 0; hi_w = 0; }
+    if (hi_w - lo_w + 1 > 255) {
+        hgx_set_error("piece spans %d variant words (> 255)", hi_w - lo_w + 1);
+        return -1;
+    }
+    key.lo = (uint16_t)lo_w;
+    key.nw = (uint8_t)(hi_w - lo_w + 1);
+    key.masks.assign(2 * (size_t)key.nw, 0u);
+    for (int i = 0; i < n_ids; ++i) {
+        const int v = ids[i];
+        if (v >= 0 && v < V && L.linked[v]) {
+            key.masks[2 * ((v >> 5) - lo_w)] |= 1u << (v & 31);
+            key.masks[2 * ((v >> 5) - lo_w) + 1] |= 1u << (v & 31);
+        }
+    }
+    for (j = j_top; j >= 0 && L.maxright[j] >= left; --j) {
+        if (!L.linked[j] || in_ids(j)) continue;
+        if ((L.pos[j] >= left && L.pos[j] <= right) || (L.right[j] >= left && L.right[j] <= right))
+            key.masks[2 * ((j >> 5) - lo_w)] |= 1u << (j & 31);
+    }
+    auto it = b.lookup.find(key);
+    if (it != b.lookup.end()) return it->second;
+    const uint32_t id = (uint32_t)b.pieces.size();
+    hgx_piece pc;
+    pc.mask_off = (uint32_t)b.masks.size();
+    pc.lo_word = key.lo;
+    pc.n_words = key.nw;
+    pc.reserved = 0;
+    b.pieces.push_back(pc);
+    b.masks.insert(b.masks.end(), key.masks.begin(), key.masks.end());
+    b.lookup.emplace(std::move(key), id);
+    return id;
+}
+
+extern "C" int hgx_batch_from_haplotypes(hgx_batch **out, const hgx_locus *L, int32_t n_pairs, const int32_t *pair_off,
+                                         const uint8_t *level, const int32_t *left, const int32_t *right,
+                                         const int32_t *id_off, const int32_t *ids) {
+    HARGCHK(out && L && n_pairs >= 0 && pair_off);
+    hgx_batch *b = new hgx_batch();
+    for (int p = 0; p < n_pairs; ++p) {
+        int n_lvl[2] = {0, 0};
+        for (int q = pair_off[p]; q < pair_off[p + 1]; ++q) {
+            if (left[q] > right[q]) {
+                hgx_set_error("piece with left > right (the reference asserts, core:638)");
+                delete b;
+                return HGX_EPARSE;
+            }
+            const int64_t id = hgx_intern_piece(*b, *L, left[q], right[q], ids + id_off[q], id_off[q + 1] - id_off[q]);
+            if (id < 0) { delete b; return HGX_EINVAL; }
+            const uint32_t lv = level[q] ? 1u : 0u;
+            if (++n_lvl[lv] > 255) {
+                hgx_set_error("more than 255 pieces for one pair and level");
+                delete b;
+                return HGX_EINVAL;
+            }
+            b->pair_ref.push_back((uint32_t)id | (lv << 31));
+        }
+        b->pair_off.push_back((int32_t)b->pair_ref.size());
+    }
+    *out = b;
+    return HGX_OK;
+}
+
+extern "C" int hgx_batch_destroy(hgx_batch *b) { delete b; return HGX_OK; }
+
+extern "C" int hgx_batch_dims(const hgx_batch *b, int32_t *n_pieces, int64_t *n_mask_u32, int32_t *n_pairs, int64_t *n_refs,
+                              int32_t *n_reads) {
+    HARGCHK(b);
+    if (n_pieces) *n_pieces = (int32_t)b->pieces.size();
+    if (n_mask_u32) *n_mask_u32 = (int64_t)b->masks.size();
+    if (n_pairs) *n_pairs = (int32_t)b->pair_off.size() - 1;
+    if (n_refs) *n_refs = (int64_t)b->pair_ref.size();
+    if (n_reads) *n_reads = b->n_reads;
+    return HGX_OK;
+}
+
+extern "C" int hgx_batch_arrays(const hgx_batch *b, const hgx_piece **pieces, const uint32_t **masks, const int32_t **pair_off,
+                                const uint32_t **pair_ref) {
+    HARGCHK(b);
+    if (pieces) *pieces = b->pieces.data();
+    if (masks) *masks = b->masks.data();
+    if (pair_off) *pair_off = b->pair_off.data();
+    if (pair_ref) *pair_ref = b->pair_ref.data();
+    return HGX_OK;
+}

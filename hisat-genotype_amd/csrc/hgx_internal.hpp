@@ -1,0 +1,105 @@
+// hgx_internal.hpp -- host-side data model shared by the front-end translation units.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "hgx.h"
+
+extern "C" void hgx_set_error(const char *fmt, ...);
+
+#define HARGCHK(cond)                                                                  \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            hgx_set_error("invalid argument: %s (%s:%d)", #cond, __FILE__, __LINE__);  \
+            return HGX_EINVAL;                                                         \
+        }                                                                              \
+    } while (0)
+
+// One equivalent spelling around a deletion: coordinates + variant indices
+// ("529-hv8-hv22-606" of typing_common.py:1421 with ids as indices).
+struct AltHt {
+    int32_t left, right;
+    std::vector<int32_t> vars;
+    bool operator==(const AltHt &o) const { return left == o.left && right == o.right && vars == o.vars; }
+};
+struct AltEntry {
+    AltHt key;
+    std::vector<AltHt> alts;   // set semantics, insertion order irrelevant
+};
+
+struct hgx_locus {
+    int32_t base_kind = 0;
+    std::string backbone;
+    int32_t V = 0;
+    std::vector<int32_t> pos, right, len;
+    std::vector<uint8_t> type, linked;
+    std::vector<char> base;
+    std::vector<std::string> name, ins;
+    std::unordered_map<std::string, int32_t> name_to_var;
+    int32_t A = 0, a_pad = 0, n_words = 1, w64 = 0;
+    std::vector<int32_t> link_off, link_allele;
+    std::vector<int32_t> maxright;               // prefix max of right ends (core:393-401)
+    std::vector<std::array<int32_t, 2>> exons;
+    std::vector<uint8_t> exonic;
+    std::vector<int32_t> av_off, av_var;         // allele -> variants in gene_var_list order (core:476-487)
+    std::vector<int32_t> rep_of;                 // allele -> representative allele or -1 (core:86-115)
+    std::vector<uint64_t> exon_mask, gene_mask;
+    std::vector<uint32_t> link_bits;             // [n_words][a_pad]
+    std::vector<int32_t> allele_len, name_rank;
+    // alternatives (common:1424-1657), sorted by anchor position like Alts_left_list / Alts_right_list
+    std::vector<AltEntry> alts_left, alts_right;
+    bool alts_built = false;
+
+    bool carries(int32_t allele, int32_t v) const {
+        return (link_bits[(size_t)(v >> 5) * a_pad + allele] >> (v & 31)) & 1u;
+    }
+};
+
+// typing_common.py:406-422 on the position column of the (static) variant list
+inline int32_t lower_bound_pos(const std::vector<int32_t> &pos, int32_t key) {
+    int32_t low = 0, high = (int32_t)pos.size();
+    while (low < high) {
+        int32_t m = (low + high) / 2;
+        if (pos[m] < key) low = m + 1;
+        else high = m;
+    }
+    return low;
+}
+
+struct PieceKey {
+    uint16_t lo;
+    uint8_t nw;
+    std::vector<uint32_t> masks;   // MP0,P0,MP1,P1,...
+    bool operator==(const PieceKey &o) const { return lo == o.lo && nw == o.nw && masks == o.masks; }
+};
+struct PieceKeyHash {
+    size_t operator()(const PieceKey &k) const {
+        uint64_t h = 1469598103934665603ull ^ k.lo ^ ((uint64_t)k.nw << 16);
+        for (uint32_t m : k.masks) { h ^= m; h *= 1099511628211ull; h ^= h >> 29; }
+        return (size_t)h;
+    }
+};
+
+struct TraceRec {
+    std::string text;
+};
+
+struct hgx_batch {
+    std::vector<hgx_piece> pieces;
+    std::vector<uint32_t> masks;
+    std::vector<int32_t> pair_off{0};
+    std::vector<uint32_t> pair_ref;
+    int32_t n_reads = 0;
+    std::unordered_map<PieceKey, uint32_t, PieceKeyHash> lookup;
+    std::vector<TraceRec> trace;
+    std::vector<uint8_t> nt_set;        // [L] 4-bit masks
+    std::vector<uint32_t> counts;       // [L][6]
+};
+
+// piece "left-ids-right" -> index of the distinct piece in the batch (creates it if new). < 0 on error.
+int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &loc, int32_t left, int32_t right, const int32_t *ids, int32_t n_ids);
+// alternatives tables (defined in hgx_sam.cpp)
+int hgx_build_alternatives(hgx_locus &loc);

@@ -1,0 +1,127 @@
+"""Device side of the hot path: piece scoring, class dedup, allele counts and EM on the MI355X.
+
+Thin, explicit wrappers over the C-ABI (include/hgx.h); every call runs hand-written HIP kernels in
+libhgx.so.  There is no CPU fallback here -- a missing library or a failing call raises.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import DevArray
+
+
+class DeviceBatch:
+    """A front-end batch resident in HBM (distinct pieces, masks, per-pair refs)."""
+
+    def __init__(self, batch, stream=None):
+        self.n_pieces, self.n_pairs, self.n_refs, self.n_reads = batch.n_pieces, batch.n_pairs, batch.n_refs, batch.n_reads
+        self.pieces = DevArray.from_host(batch.pieces if batch.n_pieces else np.zeros(1, capi.PIECE_DTYPE), stream)
+        self.masks = DevArray.from_host(batch.masks if batch.n_mask_u32 else np.zeros(2, np.uint32), stream)
+        self.pair_off = DevArray.from_host(batch.pair_off, stream)
+        self.pair_ref = DevArray.from_host(batch.pair_ref if batch.n_refs else np.zeros(1, np.uint32), stream)
+        # algorithmic byte model inputs
+        self.sum_piece_words = int(batch.pieces["n_words"].astype(np.int64).sum()) if batch.n_pieces else 0
+
+
+class ScoreBuffers:
+    """Output/scratch buffers of one scoring pass, reusable across steps."""
+
+    def __init__(self, locus, dbatch, exon=True):
+        w64 = locus.w64
+        n = max(dbatch.n_pairs, 1)
+        self.compat = DevArray((max(dbatch.n_pieces, 1), w64), np.uint64)
+        self.gene_bits = DevArray((n, w64), np.uint64)
+        self.gene_hash = DevArray(n, np.uint64)
+        self.exon_bits = DevArray((n, w64), np.uint64) if exon else None
+        self.exon_hash = DevArray(n, np.uint64) if exon else None
+
+
+def score_pairs(locus, dbatch, bufs, stream=None):
+    """8a-5/6: pieces x alleles -> per-pair class rows (+ hashes) for the exon and gene levels."""
+    L = capi.lib()
+    capi.check(L.hgx_score_pairs(locus.index(), capi.ptr(dbatch.pieces), capi.ptr(dbatch.masks), C.c_int32(dbatch.n_pieces),
+                                 capi.ptr(dbatch.pair_off), capi.ptr(dbatch.pair_ref), C.c_int32(dbatch.n_pairs),
+                                 capi.ptr(bufs.compat), capi.ptr(bufs.exon_bits), capi.ptr(bufs.gene_bits),
+                                 capi.ptr(bufs.exon_hash), capi.ptr(bufs.gene_hash), stream))
+
+
+class Classes:
+    """Distinct compatibility classes in first-seen order (Gene_cmpt / Gene_exons_cmpt as a bit matrix)."""
+
+    def __init__(self, handle):
+        self.h = handle
+        n, ap = C.c_int32(), C.c_int32()
+        capi.check(capi.lib().hgx_classes_dims(self.h, C.byref(n), C.byref(ap)))
+        self.n_classes, self.a_pad = n.value, ap.value
+        self.w64 = self.a_pad // 64
+
+    @staticmethod
+    def dedup(rows, n_rows, a_pad, hashes=None, weights=None, and_mask=None, stream=None):
+        """8a-7: group rows by content (optionally AND and_mask first; empty rows dropped)."""
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_dedup_classes(C.byref(h), capi.ptr(rows), capi.ptr(hashes), capi.ptr(weights),
+                                                 C.c_int64(n_rows), C.c_int32(a_pad), capi.ptr(and_mask), stream))
+        return Classes(h)
+
+    @staticmethod
+    def from_host(bits, counts, a_pad):
+        bits = np.ascontiguousarray(bits, np.uint64)
+        counts = np.ascontiguousarray(counts, np.int64)
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_classes_from_host(C.byref(h), capi.ptr(bits), capi.ptr(counts), C.c_int32(len(counts)),
+                                                     C.c_int32(a_pad)))
+        return Classes(h)
+
+    def device_ptrs(self):
+        b, c, f = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        capi.check(capi.lib().hgx_classes_device(self.h, C.byref(b), C.byref(c), C.byref(f)))
+        return b.value, c.value, f.value
+
+    def to_host(self):
+        bits = np.zeros((self.n_classes, self.w64), np.uint64)
+        cnt = np.zeros(self.n_classes, np.int64)
+        first = np.zeros(self.n_classes, np.int64)
+        capi.check(capi.lib().hgx_classes_to_host(self.h, capi.ptr(bits), capi.ptr(cnt), capi.ptr(first)))
+        return bits, cnt, first
+
+    def allele_counts(self):
+        """Gene_counts (core:1187-1190) and, per allele, the first class containing it."""
+        cnt = np.zeros(self.a_pad, np.int64)
+        first = np.zeros(self.a_pad, np.int32)
+        capi.check(capi.lib().hgx_allele_counts(self.h, capi.ptr(cnt), capi.ptr(first)))
+        return cnt, first
+
+    def em(self, n_alleles, remove_low=False, lengths=None, stream=None):
+        """8a-8: single_abundance.  Returns (prob[n_alleles] with -1 for absent alleles, n_iter)."""
+        prob = np.zeros(n_alleles, np.float64)
+        it = C.c_int32(0)
+        ln = None if lengths is None else np.ascontiguousarray(lengths, np.int32)
+        capi.check(capi.lib().hgx_em(self.h, C.c_int32(n_alleles), C.c_int32(1 if remove_low else 0), capi.ptr(ln),
+                                     capi.ptr(prob), C.byref(it), stream))
+        return prob, it.value
+
+    def close(self):
+        if self.h:
+            capi.lib().hgx_classes_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _RawDev:
+    """Borrowed device pointer (e.g. the class matrix owned by a Classes handle)."""
+
+    def __init__(self, p):
+        self.ptr = p
+
+
+def em_order(first_class, name_rank, present):
+    """Insertion order of the EM's dict (common:1300-1305): alleles by (first class containing them,
+    position inside that class' sorted key)."""
+    idx = [a for a in range(len(present)) if present[a]]
+    return sorted(idx, key=lambda a: (first_class[a], name_rank[a]))

@@ -1,0 +1,223 @@
+"""Packed locus (8a-0): turns the reference's per-gene dicts into the arrays libhgx consumes.
+
+Mirrors the per-locus set-up of typing() (hisatgenotype_typing_core.py:384-401, 476-491, 559-569):
+``Genes / Gene_names / Vars / Var_list / Links / refGene_loci`` in, a host ``hgx_locus`` (variant
+tables, allele->variant lists, exon representatives, alternatives) and a device ``hgx_index``
+(word-major link bit matrix + level masks) out.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+_TYPE = {"insertion": capi.VAR_INSERTION, "single": capi.VAR_SINGLE, "deletion": capi.VAR_DELETION}
+
+
+class Batch:
+    """Host-side result of the front-end for one locus: distinct pieces + per-pair references."""
+
+    def __init__(self, handle):
+        self.h = handle
+        L = capi.lib()
+        np_, nm, npairs, nrefs, nreads = C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64(), C.c_int32()
+        capi.check(L.hgx_batch_dims(self.h, C.byref(np_), C.byref(nm), C.byref(npairs), C.byref(nrefs), C.byref(nreads)))
+        self.n_pieces, self.n_mask_u32, self.n_pairs = np_.value, nm.value, npairs.value
+        self.n_refs, self.n_reads = nrefs.value, nreads.value
+        pp, pm, po, pr = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        capi.check(L.hgx_batch_arrays(self.h, C.byref(pp), C.byref(pm), C.byref(po), C.byref(pr)))
+
+        def view(p, n, dt):
+            if n == 0 or not p.value:
+                return np.zeros(0, dtype=dt)
+            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(p.value)
+            return np.frombuffer(buf, dtype=dt, count=n).copy()
+
+        self.pieces = view(pp, self.n_pieces, capi.PIECE_DTYPE)
+        self.masks = view(pm, self.n_mask_u32, np.uint32)
+        self.pair_off = view(po, self.n_pairs + 1, np.int32)
+        self.pair_ref = view(pr, self.n_refs, np.uint32)
+
+    def trace_text(self):
+        L = capi.lib()
+        need = C.c_size_t(0)
+        capi.check(L.hgx_batch_trace_text(self.h, None, C.c_size_t(0), C.byref(need)))
+        buf = C.create_string_buffer(need.value + 1)
+        capi.check(L.hgx_batch_trace_text(self.h, buf, C.c_size_t(need.value + 1), C.byref(need)))
+        return buf.value.decode()
+
+    def pileup(self, length):
+        nt = np.zeros(length, dtype=np.uint8)
+        cnt = np.zeros((length, 6), dtype=np.uint32)
+        capi.check(capi.lib().hgx_batch_pileup(self.h, capi.ptr(nt), capi.ptr(cnt)))
+        return nt, cnt
+
+    def close(self):
+        if self.h:
+            capi.lib().hgx_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PackedLocus:
+    """One gene's index.  ``names`` = Gene_names[gene] without the backbone (allele index order)."""
+
+    def __init__(self, gene, base_fname, ref_seq, Vars, Var_list, Links, Gene_names, Gene_lengths, exons,
+                 Genes_keys=None):
+        self.gene, self.base_fname = gene, base_fname
+        self.ref_seq = ref_seq
+        names = [n for n in Gene_names if n.find("BACKBONE") == -1 and
+                 not (base_fname == "genome" and n.find("GRCh38") != -1)]
+        if Genes_keys is not None:
+            names = [n for n in names if n in Genes_keys]
+        self.names = names
+        self.aidx = {n: i for i, n in enumerate(names)}
+        A = len(names)
+        V = len(Var_list)
+        self.var_ids = [vid for _, vid in Var_list]
+        self.var_index = {vid: i for i, vid in enumerate(self.var_ids)}
+        pos = np.zeros(V, np.int32)
+        typ = np.zeros(V, np.uint8)
+        ln = np.ones(V, np.int32)
+        base = np.zeros(V, np.uint8)
+        linked = np.zeros(V, np.uint8)
+        ins = []
+        off = np.zeros(V + 1, np.int32)
+        flat = []
+        for i, vid in enumerate(self.var_ids):
+            t, p, d = Vars[vid]
+            pos[i] = p
+            typ[i] = _TYPE[t]
+            if t == "deletion":
+                ln[i] = int(d)
+                ins.append("")
+            elif t == "insertion":
+                ln[i] = len(d)
+                ins.append(d)
+            else:
+                base[i] = ord(d)
+                ins.append("")
+            if vid in Links:
+                linked[i] = 1
+                flat += [self.aidx[a] for a in Links[vid] if a in self.aidx]
+            off[i + 1] = len(flat)
+        link_order = np.array([self.var_index[v] for v in Links.keys() if v in self.var_index] or [0], np.int32)
+        n_link_order = sum(1 for v in Links.keys() if v in self.var_index)
+        rank = np.zeros(A, np.int32)
+        for r, i in enumerate(sorted(range(A), key=lambda i: names[i])):
+            rank[i] = r
+        lengths = np.array([Gene_lengths[n] for n in names], np.int32)
+        ex = np.array(exons, np.int32).reshape(-1, 2) if len(exons) else np.zeros((0, 2), np.int32)
+        self.name_rank, self.allele_len = rank, lengths
+        self._keep = dict(pos=pos, typ=typ, ln=ln, base=base, linked=linked, off=off,
+                          flat=np.array(flat or [0], np.int32), link_order=link_order, ex=np.ascontiguousarray(ex),
+                          rank=rank, lengths=lengths,
+                          names_pool=("\0".join(self.var_ids) + "\0").encode(), ins_pool=("\0".join(ins) + "\0").encode(),
+                          bb=ref_seq.encode())
+        k = self._keep
+        d = capi.LocusDesc(capi.BASE_KIND.get(base_fname, 3), len(ref_seq), k["bb"], V, capi.ptr(pos), capi.ptr(typ),
+                           capi.ptr(ln), capi.ptr(base), capi.ptr(linked), k["names_pool"], k["ins_pool"], A,
+                           capi.ptr(off), capi.ptr(k["flat"]), n_link_order, capi.ptr(link_order), len(ex),
+                           capi.ptr(k["ex"]), capi.ptr(lengths), capi.ptr(rank))
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_locus_create(C.byref(h), C.byref(d)))
+        self.h = h
+        na, ap, nv, nw = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        capi.check(capi.lib().hgx_locus_dims(self.h, C.byref(na), C.byref(ap), C.byref(nv), C.byref(nw)))
+        self.n_alleles, self.a_pad, self.n_vars, self.n_words = na.value, ap.value, nv.value, nw.value
+        self.w64 = self.a_pad // 64
+        self._tables = None
+        self._index = None
+
+    # ---- constructors -------------------------------------------------------------------------
+    @classmethod
+    def from_reference_dicts(cls, gene, base_fname, refGenes, Genes, Gene_names, Gene_lengths, refGene_loci, Vars,
+                             Var_list, Links):
+        ref_allele = refGenes[gene]
+        return cls(gene, base_fname, Genes[gene][ref_allele], Vars.get(gene, {}), Var_list.get(gene, []), Links,
+                   Gene_names[gene], Gene_lengths[gene], refGene_loci[gene][-2], set(Genes[gene].keys()))
+
+    @classmethod
+    def from_synth(cls, locus):
+        d = locus.reference_dicts()
+        return cls.from_reference_dicts(locus.gene, locus.base_fname, d["refGenes"], d["Genes"], d["Gene_names"],
+                                        d["Gene_lengths"], d["refGene_loci"], d["Vars"], d["Var_list"], d["Links"])
+
+    # ---- derived tables -------------------------------------------------------------------------
+    def tables(self):
+        if self._tables is None:
+            bits = np.zeros((self.n_words, self.a_pad), np.uint32)
+            em = np.zeros(self.w64, np.uint64)
+            gm = np.zeros(self.w64, np.uint64)
+            rep = np.zeros(self.n_alleles, np.int32)
+            capi.check(capi.lib().hgx_locus_tables(self.h, capi.ptr(bits), capi.ptr(em), capi.ptr(gm), capi.ptr(rep)))
+            self._tables = dict(link_bits=bits, exon_mask=em, gene_mask=gm, rep_of=rep)
+        return self._tables
+
+    def rep_groups(self):
+        """allele_rep_groups (core:86-115) as {rep index: [member indices in first-met order]}."""
+        rep = self.tables()["rep_of"]
+        groups = {}
+        # members are listed in the order get_rep_alleles met them = order of first appearance scanning Links;
+        # the hand-off only uses the groups as sets (core:1745-1749), so index order is sufficient
+        for a, r in enumerate(rep):
+            if r >= 0:
+                groups.setdefault(int(r), []).append(a)
+        return groups
+
+    def index(self):
+        """Device-resident hgx_index (created on first use on the current device)."""
+        if self._index is None:
+            h = C.c_void_p()
+            capi.check(capi.lib().hgx_index_from_locus(C.byref(h), self.h))
+            self._index = h
+        return self._index
+
+    def alternatives_text(self):
+        need = C.c_size_t(0)
+        capi.check(capi.lib().hgx_locus_alternatives_text(self.h, None, C.c_size_t(0), C.byref(need)))
+        buf = C.create_string_buffer(need.value + 1)
+        capi.check(capi.lib().hgx_locus_alternatives_text(self.h, buf, C.c_size_t(need.value + 1), C.byref(need)))
+        return buf.value.decode()
+
+    # ---- front-end ---------------------------------------------------------------------------------
+    def batch_from_haplotypes(self, pair_off, level, left, right, id_off, ids):
+        pair_off = np.ascontiguousarray(pair_off, np.int32)
+        level = np.ascontiguousarray(level, np.uint8)
+        left = np.ascontiguousarray(left, np.int32)
+        right = np.ascontiguousarray(right, np.int32)
+        id_off = np.ascontiguousarray(id_off, np.int32)
+        ids = np.ascontiguousarray(ids if len(ids) else [0], np.int32)
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_batch_from_haplotypes(C.byref(h), self.h, C.c_int32(len(pair_off) - 1), capi.ptr(pair_off),
+                                                        capi.ptr(level), capi.ptr(left), capi.ptr(right), capi.ptr(id_off),
+                                                        capi.ptr(ids)))
+        return Batch(h)
+
+    def parse_sam(self, sam_text, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False,
+                  base_locus=0, keep_trace=False):
+        data = sam_text if isinstance(sam_text, (bytes, bytearray)) else sam_text.encode()
+        o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus,
+                           int(keep_trace))
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_parse_sam(C.byref(h), self.h, data, C.c_size_t(len(data)), C.byref(o)))
+        return Batch(h)
+
+    def close(self):
+        if self._index is not None:
+            capi.lib().hgx_index_destroy(self._index)
+            self._index = None
+        if self.h:
+            capi.lib().hgx_locus_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

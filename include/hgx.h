@@ -62,9 +62,11 @@ int hgx_stream_sync(void *stream);
  * Alleles are Gene_names[gene] minus the backbone, in that order (index 0..n_alleles-1);
  * variants are gene_var_list order (sorted by position).  link_bits is word-major:
  * link_bits[w * a_pad + a] bit (v & 31) of word w = v >> 5 is set iff allele a carries
- * variant v (Links[var_id] contains the allele).  a_pad = n_alleles rounded up to 64.   */
+ * variant v (Links[var_id] contains the allele).  a_pad = n_alleles rounded up to 256
+ * (use hgx_a_pad()).                                                                     */
 typedef struct hgx_index hgx_index;
 
+int32_t hgx_a_pad(int32_t n_alleles);
 int hgx_index_create(hgx_index **out,
                      int32_t n_alleles, int32_t n_vars,
                      const uint32_t *link_bits_host,      /* [n_words][a_pad]                 */
@@ -77,30 +79,48 @@ int hgx_index_device_bits(const hgx_index *ix, void **dev_bits, size_t *bytes);
 
 /* ---- 8a-5 / 8a-6: read-pair x allele compatibility -> class bitsets --------------------
  * Replaces add_count (typing_core.py:626-677) + add_stat (core:1171-1236) for a batch of
- * pairs.  A piece is one add_count call: the caller has already reduced the haplotype
- * string "left-id-..-right" to bit masks over variant words [lo_word, lo_word + n_words):
+ * pairs.  A *piece* is the argument of one add_count call with the haplotype string
+ * "left-id-..-right" already reduced to bit masks over variant words [lo_word, lo_word+n_words):
  *   masks[mask_off + 2*i]     = MP word i : known variants overlapping [left,right] (core:651-670) OR'ed with P
  *   masks[mask_off + 2*i + 1] = P  word i : the piece's own known variants (core:642-647)
  * allele a is compatible  <=>  for every i: (link_bits[lo_word+i][a] & MP_i) == P_i.
- * Per pair and level: count[a] = #compatible pieces; class = {a in level mask : count[a] == max count}
- * (max over the level's alleles, including 0: quirk Q4, core:1177-1190).
- * Outputs (device): class bitsets, one row of a_pad/64 uint64 per pair and level, and a
- * 64-bit content hash per row used by hgx_dedup_classes.                                 */
+ * Identical pieces recur thousands of times in a read set, so the caller passes the table of
+ * DISTINCT pieces once and every pair refers to its pieces by index:
+ *   pair_ref[k] = piece index | (level << 31),  k in [pair_off[p], pair_off[p+1])
+ * (one ref per add_count call, duplicates allowed: they count twice, as in the reference).
+ * Per pair and level: count[a] = #refs whose piece is compatible with a; class = {a in the
+ * level's allele mask : count[a] == max count} (max including 0: quirk Q4, core:1177-1190);
+ * at most 255 refs per pair and level.
+ * Outputs (device): class bitsets, one row of a_pad/64 uint64 per pair and level, and a 64-bit
+ * content hash per row (all-zero row <=> hash 0xFFFFFFFFFFFFFFFF) for hgx_dedup_classes.      */
 typedef struct hgx_piece {
     uint32_t mask_off;   /* index into masks[] (in uint32 units)          */
     uint16_t lo_word;    /* first 32-variant word covered                 */
     uint8_t  n_words;    /* number of words covered (>= 1)                */
-    uint8_t  level;      /* HGX_LEVEL_EXON or HGX_LEVEL_GENE              */
+    uint8_t  reserved;
 } hgx_piece;
 
+/* stage 1: compat_dev[piece][a_pad/64] = bitset of alleles compatible with each distinct piece */
+int hgx_piece_compat(const hgx_index *ix, const hgx_piece *pieces_dev, const uint32_t *masks_dev,
+                     int32_t n_pieces, uint64_t *compat_dev, void *stream);
+
+/* stage 2: one wavefront per pair combines its pieces' rows into the two class rows */
+int hgx_pair_classes(const hgx_index *ix, const uint64_t *compat_dev,
+                     const int32_t *pair_off_dev,         /* [n_pairs + 1] into pair_ref       */
+                     const uint32_t *pair_ref_dev, int32_t n_pairs,
+                     uint64_t *exon_bits_dev,             /* [n_pairs][a_pad/64] or NULL       */
+                     uint64_t *gene_bits_dev,             /* [n_pairs][a_pad/64] or NULL       */
+                     uint64_t *exon_hash_dev,             /* [n_pairs] or NULL                 */
+                     uint64_t *gene_hash_dev,             /* [n_pairs] or NULL                 */
+                     void *stream);
+
+/* both stages; compat_scratch_dev must hold n_pieces * a_pad/64 uint64 */
 int hgx_score_pairs(const hgx_index *ix,
-                    const hgx_piece *pieces_dev, const uint32_t *masks_dev,
-                    const int32_t *pair_off_dev,          /* [n_pairs + 1] into pieces         */
-                    int32_t n_pairs,
-                    uint64_t *exon_bits_dev,              /* [n_pairs][a_pad/64] or NULL       */
-                    uint64_t *gene_bits_dev,              /* [n_pairs][a_pad/64] or NULL       */
-                    uint64_t *exon_hash_dev,              /* [n_pairs] or NULL                 */
-                    uint64_t *gene_hash_dev,              /* [n_pairs] or NULL                 */
+                    const hgx_piece *pieces_dev, const uint32_t *masks_dev, int32_t n_pieces,
+                    const int32_t *pair_off_dev, const uint32_t *pair_ref_dev, int32_t n_pairs,
+                    uint64_t *compat_scratch_dev,
+                    uint64_t *exon_bits_dev, uint64_t *gene_bits_dev,
+                    uint64_t *exon_hash_dev, uint64_t *gene_hash_dev,
                     void *stream);
 
 /* ---- 8a-7: class dedup -------------------------------------------------------------------
@@ -138,6 +158,83 @@ int hgx_allele_counts(const hgx_classes *c, int64_t *count_host, int32_t *first_
 int hgx_em(const hgx_classes *c, int32_t n_alleles,
            int32_t remove_low, const int32_t *allele_len_or_null /* host [n_alleles] */,
            double *prob_host, int32_t *n_iter_host, void *stream);
+
+/* ---- host front-end: locus tables, SAM -> pieces (8a-0 .. 8a-4) ----------------------------
+ * The part of typing() that precedes scoring is index-heavy string logic with no data
+ * parallelism per record; it runs on the host in C++ and hands the device the distinct-piece
+ * table plus per-pair piece references.                                                      */
+#define HGX_BASE_HLA    0
+#define HGX_BASE_CODIS  1
+#define HGX_BASE_GENOME 2
+#define HGX_BASE_OTHER  3
+
+typedef struct hgx_locus_desc {
+    int32_t base_kind;               /* HGX_BASE_*  (base_fname of the reference)                        */
+    int32_t backbone_len;
+    const char *backbone;            /* ref_seq = Genes[gene][ref_allele]                  core:386       */
+    int32_t n_vars;                  /* gene_var_list order                                                */
+    const int32_t *var_pos;
+    const uint8_t *var_type;         /* HGX_VAR_*                                                          */
+    const int32_t *var_len;          /* deletion length / insertion length / 1                             */
+    const char *var_base;            /* alt base of a single, 0 otherwise                                  */
+    const uint8_t *var_linked;       /* var_id in Links                                                    */
+    const char *var_name_pool;       /* ids ("hv123"), '\0' separated, var order                           */
+    const char *var_ins_pool;        /* inserted bases of insertions, '\0' separated, var order ("" else)  */
+    int32_t n_alleles;               /* Gene_names[gene] minus the backbone, that order                    */
+    const int32_t *link_off;         /* CSR [n_vars+1]: Links[var] -> allele indices (file order)          */
+    const int32_t *link_allele;
+    int32_t n_link_order;            /* variant indices in Links dict order (rep selection, core:86-115)  */
+    const int32_t *link_order;
+    int32_t n_exons;
+    const int32_t *exons;            /* [n_exons][2] inclusive                                             */
+    const int32_t *allele_len;       /* Gene_lengths                                                       */
+    const int32_t *name_rank;        /* rank of each allele name in sorted(name) order                    */
+} hgx_locus_desc;
+
+typedef struct hgx_locus hgx_locus;
+int hgx_locus_create(hgx_locus **out, const hgx_locus_desc *desc);
+int hgx_locus_destroy(hgx_locus *loc);
+/* derived tables: a_pad, n_words; rep_of[a] = representative allele of a's exon group or -1
+ * (get_rep_alleles, core:86-115); masks are a_pad/64 words; link_bits is [n_words][a_pad]      */
+int hgx_locus_dims(const hgx_locus *loc, int32_t *n_alleles, int32_t *a_pad, int32_t *n_vars, int32_t *n_words);
+int hgx_locus_tables(const hgx_locus *loc, uint32_t *link_bits, uint64_t *exon_mask, uint64_t *gene_mask,
+                     int32_t *rep_of);
+int hgx_index_from_locus(hgx_index **out, const hgx_locus *loc);
+/* number of entries / dump of the alternatives tables (get_alternatives, common:1424-1657) as text
+ * "L\tkey\talt\n" / "R\tkey\talt\n" lines -- test and debugging aid                              */
+int hgx_locus_alternatives_text(const hgx_locus *loc, char *buf, size_t cap, size_t *needed);
+
+/* A batch = what one locus' read stream reduces to: distinct pieces + masks, and per pair the
+ * piece refs (exon-level refs and gene-level refs, bit 31 = level).                           */
+typedef struct hgx_batch hgx_batch;
+int hgx_batch_destroy(hgx_batch *b);
+int hgx_batch_dims(const hgx_batch *b, int32_t *n_pieces, int64_t *n_mask_u32, int32_t *n_pairs, int64_t *n_refs,
+                   int32_t *n_reads);
+int hgx_batch_arrays(const hgx_batch *b, const hgx_piece **pieces, const uint32_t **masks, const int32_t **pair_off,
+                     const uint32_t **pair_ref);
+
+/* integer haplotypes -> batch.  Piece q of pair p (q in [pair_off[p], pair_off[p+1])) is the
+ * add_count argument "left-ids-right" with ids = variant indices (-1 for nv / unknown ids).    */
+int hgx_batch_from_haplotypes(hgx_batch **out, const hgx_locus *loc, int32_t n_pairs, const int32_t *pair_off,
+                              const uint8_t *piece_level, const int32_t *piece_left, const int32_t *piece_right,
+                              const int32_t *piece_id_off, const int32_t *piece_ids);
+
+typedef struct hgx_parse_opts {
+    int32_t num_editdist;       /* --num-editdist, default 2                      args:294 */
+    int32_t error_correction;   /* default 1                                      args:324 */
+    int32_t allow_discordant;   /* default 0 (forced 1 for single-end)            args:334 */
+    int32_t simulation;         /* read id = QNAME up to the first '|'            core:808 */
+    int32_t base_locus;         /* subtracted from POS                            core:814 */
+    int32_t keep_trace;         /* record per-read intermediates for hgx_batch_trace_text   */
+} hgx_parse_opts;
+
+/* SAM text (name-grouped, i.e. the stream after `sort -k1,1 -s`, core:458-468) -> batch.
+ * Replaces typing_core.py:800-1406 + get_mpileup (common:1059-1134).                        */
+int hgx_parse_sam(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts);
+/* per kept record: "cmp_list2 \t cmp_left \t cmp_right \t left alts \t right alts" (keep_trace) */
+int hgx_batch_trace_text(const hgx_batch *b, char *buf, size_t cap, size_t *needed);
+/* pileup nt_set per backbone position as a 4-bit mask A=1,C=2,G=4,T=8 and counts[L][6] (A,C,G,T,N,D) */
+int hgx_batch_pileup(const hgx_batch *b, uint8_t *nt_set, uint32_t *counts);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,176 @@
+"""GPU parity: the HIP path (through the C-ABI) against the C oracle and the golden vectors."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import tables
+from hisatgenotype_amd import engine, locus as hl
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(orc, name):
+    fx = gu.load(name)
+    loc = fx["_locus"]
+    t = tables.oracle_tables(loc)
+    pl = hl.PackedLocus.from_synth(loc)
+    arrs = tables.pieces_from_pairs(fx["pairs"], t["var_index"])
+    batch = pl.batch_from_haplotypes(*arrs)
+    L = orc.make_locus(t)
+    eb, gb, gc, fp = orc.score_pairs(L, t["exon_keys"], t["gene_keys"], *arrs)
+    return fx, loc, t, pl, batch, (eb, gb, gc, fp)
+
+
+@pytest.mark.parametrize("name", gu.ALL)
+def test_score_pairs_bit_exact(orc, name):
+    fx, loc, t, pl, batch, (eb, gb, gc, fp) = _setup(orc, name)
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    w = (t["n_alleles"] + 63) // 64
+    got_g = bufs.gene_bits.to_host()[:batch.n_pairs]
+    got_e = bufs.exon_bits.to_host()[:batch.n_pairs]
+    assert np.array_equal(got_g[:, :w], gb) and not got_g[:, w:].any()
+    if loc.base_fname == "hla":
+        assert np.array_equal(got_e[:, :w], eb) and not got_e[:, w:].any()
+    # golden classes straight from the reference
+    A = t["n_alleles"]
+    for i, p in enumerate(fx["pairs"]):
+        assert np.array_equal(got_g[i, :w], gu.class_bits(fx, p["gene_cls"], A))
+    # identical rows <=> identical hashes on this data
+    gh = bufs.gene_hash.to_host()[:batch.n_pairs]
+    keys = {}
+    for i in range(batch.n_pairs):
+        k = got_g[i].tobytes()
+        assert keys.setdefault(k, gh[i]) == gh[i]
+    assert len(set(keys.values())) == len(keys)
+
+
+@pytest.mark.parametrize("name", gu.ALL)
+def test_dedup_counts_em(orc, name):
+    fx, loc, t, pl, batch, (eb, gb, gc, fp) = _setup(orc, name)
+    hla = loc.base_fname == "hla"
+    A = t["n_alleles"]
+    w = (A + 63) // 64
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    # gene level: dedup + Gene_counts + tie order
+    gcl = engine.Classes.dedup(bufs.gene_bits, batch.n_pairs, pl.a_pad, hashes=bufs.gene_hash)
+    ub, uc, fr = orc.dedup(gb)
+    hb, hc, hf = gcl.to_host()
+    assert np.array_equal(hb[:, :w], ub) and np.array_equal(hc, uc) and np.array_equal(hf, fr)
+    cnt, first = gcl.allele_counts()
+    assert np.array_equal(cnt[:A], gc)
+    first_pair = np.where(first[:A] >= 0, hf[np.clip(first[:A], 0, None)], -1)
+    assert np.array_equal(first_pair, fp)
+    # EM calls recorded from the reference
+    lengths = pl.allele_len
+    level_rows = bufs.exon_bits if hla else bufs.gene_bits
+    level_hash = bufs.exon_hash if hla else bufs.gene_hash
+    cl0 = engine.Classes.dedup(level_rows, batch.n_pairs, pl.a_pad, hashes=level_hash)
+    em0 = fx["em"][0]
+    assert cl0.n_classes == len(em0["cmpt"])
+    b0, c0, _ = cl0.to_host()
+    for k, (cid, n) in enumerate(em0["cmpt"]):
+        assert np.array_equal(b0[k, :w], gu.class_bits(fx, cid, A)) and c0[k] == n
+    for em in fx["em"]:
+        rows = np.zeros((len(em["cmpt"]), pl.w64), np.uint64)
+        for k, (cid, n) in enumerate(em["cmpt"]):
+            rows[k, :w] = gu.class_bits(fx, cid, A)
+        cl = engine.Classes.from_host(rows, [n for _, n in em["cmpt"]], pl.a_pad)
+        prob, it = cl.em(A, em["remove_low"], lengths if em["use_length"] else None)
+        assert it == em["n_iter"]
+        exp = {a: float(p) for a, p in em["result"]}
+        for a in range(A):
+            n = t["names"][a]
+            if n in exp:
+                assert abs(prob[a] - exp[n]) <= 1e-9, (n, prob[a], exp[n])   # north_star tolerance is 1e-5
+            else:
+                assert prob[a] == -1.0
+
+
+def test_filtered_dedup_matches_oracle(orc):
+    fx, loc, t, pl, batch, (eb, gb, gc, fp) = _setup(orc, "hla_mid_real")
+    A = t["n_alleles"]
+    w = (A + 63) // 64
+    ub, uc, _ = orc.dedup(gb)
+    rng = np.random.RandomState(5)
+    mask = np.zeros(pl.w64, np.uint64)
+    keep = rng.rand(A) < 0.3
+    for a in np.nonzero(keep)[0]:
+        mask[a >> 6] |= np.uint64(1) << np.uint64(a & 63)
+    exp_b, exp_c, _ = orc.dedup(ub, weight=uc, and_mask=mask[:w])
+    rows = np.zeros((len(ub), pl.w64), np.uint64)
+    rows[:, :w] = ub
+    d_rows = engine.DevArray.from_host(rows)
+    d_w = engine.DevArray.from_host(uc)
+    d_m = engine.DevArray.from_host(mask)
+    cl = engine.Classes.dedup(d_rows, len(ub), pl.a_pad, weights=d_w, and_mask=d_m)
+    hb, hc, _ = cl.to_host()
+    assert np.array_equal(hb[:, :w], exp_b) and np.array_equal(hc, exp_c)
+
+
+def test_random_pieces_large(orc):
+    """Seeded random haplotypes (many of them impossible: zero-compatible pairs, quirk Q4) on a mid-size locus."""
+    from hisatgenotype_amd import synth
+    loc = synth.make_hla_like_locus(n_alleles=1500, n_vars=1800, seed=77, unlinked_vars=6)
+    t = tables.oracle_tables(loc)
+    pl = hl.PackedLocus.from_synth(loc)
+    rng = np.random.RandomState(3)
+    V = len(loc.var_ids)
+    pair_off, level, left, right, id_off, ids = [0], [], [], [], [0], []
+    names = [n for n in loc.allele_names[1:] if n in loc.allele_vars]
+    for p in range(3000):
+        for m in range(rng.randint(0, 4)):
+            l = rng.randint(0, len(loc.backbone) - 160)
+            r = l + rng.randint(1, 150)
+            a = names[rng.randint(len(names))]
+            vs = [v for v in loc.allele_vars[a] if l <= loc.var_pos[v] <= r]
+            if rng.rand() < 0.2 and vs:
+                vs = vs[:-1]                      # drop a variant: usually incompatible with a
+            if rng.rand() < 0.1:
+                vs = vs + [int(rng.randint(V))]   # random extra variant
+            if rng.rand() < 0.1:
+                vs = vs + [-1]                    # novel id
+            for lv in ((0, 1) if rng.rand() < 0.7 else (1,)):
+                level.append(lv); left.append(l); right.append(r)
+                ids += vs
+                id_off.append(len(ids))
+        pair_off.append(len(level))
+    arrs = (np.array(pair_off, np.int32), np.array(level, np.uint8), np.array(left, np.int32), np.array(right, np.int32),
+            np.array(id_off, np.int32), np.array(ids, np.int32))
+    L = orc.make_locus(t)
+    eb, gb, gc, fp = orc.score_pairs(L, t["exon_keys"], t["gene_keys"], *arrs)
+    batch = pl.batch_from_haplotypes(*arrs)
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    w = (t["n_alleles"] + 63) // 64
+    assert np.array_equal(bufs.gene_bits.to_host()[:, :w], gb)
+    assert np.array_equal(bufs.exon_bits.to_host()[:, :w], eb)
+    cl = engine.Classes.dedup(bufs.exon_bits, batch.n_pairs, pl.a_pad, hashes=bufs.exon_hash)
+    ub, uc, fr = orc.dedup(eb)
+    hb, hc, hf = cl.to_host()
+    assert np.array_equal(hb[:, :w], ub) and np.array_equal(hc, uc) and np.array_equal(hf, fr)
+    # EM on these classes vs the C oracle (same iteration count, weights within 1e-9)
+    classes = []
+    for row in ub:
+        idx = []
+        for wd, word in enumerate(row):
+            word = int(word)
+            while word:
+                b = (word & -word).bit_length() - 1
+                idx.append(64 * wd + b)
+                word &= word - 1
+        classes.append(sorted(idx, key=lambda a: pl.name_rank[a]))
+    for low, ln in ((False, None), (True, pl.allele_len)):
+        oa, op, it = orc.single_abundance(t["n_alleles"], classes, uc, low, ln)
+        prob, git = cl.em(t["n_alleles"], low, ln)
+        assert git == it
+        exp = dict(zip(oa.tolist(), op.tolist()))
+        for a in range(t["n_alleles"]):
+            if a in exp:
+                assert abs(prob[a] - exp[a]) <= 1e-9
+            else:
+                assert prob[a] == -1.0
