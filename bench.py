@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- typed reads/s of the hot path at HLA-A (BASELINE.json configs[1]) on N MI355X of one node.
+
+A step = one pass of the hot path over one sample's read set that is already resident in HBM as the
+front-end's piece batch: piece x allele compatibility -> per-pair class rows -> class dedup (gene and exon
+level) -> Gene_counts -> EM #1 -> exon->gene hand-off -> EM #2 -> abundances.
+N > 1: one process per GPU (torchrun), every rank types its own synthetic sample of the same locus (weak
+scaling, no data-path collective); the shared locus index is broadcast once from rank 0 over RCCL.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md section 6 for the byte model behind `roofline`).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import hisatgenotype_amd as hgx  # noqa: E402
+from hisatgenotype_amd import capi, engine, synth, typing as htyping  # noqa: E402
+from hisatgenotype_amd import locus as hl  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=500000, help="read pairs per sample (1M reads = configs[1])")
+    ap.add_argument("--alleles", type=int, default=7000)
+    ap.add_argument("--vars", type=int, default=2500)
+    ap.add_argument("--err", type=float, default=0.002)
+    ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs of the same workload timed on the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def step(pl, batch, db, bufs, ev=None):
+    """One pass of the hot path.  Returns (LocusResult, seconds spent in the EM calls)."""
+    res = htyping.LocusResult()
+    res.num_reads, res.num_pairs = batch.n_reads, batch.n_pairs
+    L = capi.lib()
+    import ctypes as C
+    capi.check(L.hgx_piece_compat(pl.index(), capi.ptr(db.pieces), capi.ptr(db.masks), C.c_int32(db.n_pieces),
+                                  capi.ptr(bufs.compat), None))
+    if ev:
+        ev[0].record()
+    capi.check(L.hgx_pair_classes(pl.index(), capi.ptr(bufs.compat), capi.ptr(db.pair_off), capi.ptr(db.pair_ref),
+                                  C.c_int32(db.n_pairs), capi.ptr(bufs.exon_bits), capi.ptr(bufs.gene_bits),
+                                  capi.ptr(bufs.exon_hash), capi.ptr(bufs.gene_hash), None))
+    if ev:
+        ev[1].record()
+    return htyping._type_batch(pl, batch, res, True, dbatch=db, bufs=bufs, scored=True)
+
+
+def cpu_baseline(loc, sam, n_pairs):
+    """The C oracle (1 core) on the first n_pairs pairs of the same workload: scoring + dedup + EM."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orclib
+    import orc_pipeline
+    import pyref
+    import tables
+    orc = orclib.load()
+    lines = sam.split("\n", 2 * n_pairs)[:2 * n_pairs]
+    sub = "\n".join(lines) + "\n"
+    rl = pyref.RefLocus(loc)
+    rl.score = False                      # front-end only: the haplotypes of each pair
+    t0 = time.perf_counter()
+    fe = rl.run(sub)
+    t_front = time.perf_counter() - t0
+    t = tables.oracle_tables(loc)
+    arrs = tables.pieces_from_pairs(fe["pairs"], t["var_index"])
+    lengths = np.array([loc.allele_length(n) for n in t["names"]], dtype=np.int32)
+    out = orc_pipeline.run(orc, t, arrs, loc.base_fname == "hla", lengths)
+    secs = out["t_score"] + out["t_dedup"] + out["t_em"]
+    # pure-Python restatement (closest to the reference's own speed) on a much smaller slice
+    n_py = min(150, n_pairs)
+    rl2 = pyref.RefLocus(loc)
+    t0 = time.perf_counter()
+    r2 = rl2.run("\n".join(lines[:2 * n_py]) + "\n")
+    t_py = time.perf_counter() - t0
+    return {
+        "value": round(fe["num_reads"] / secs, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+        "sample": "first %d pairs (%d reads) of the same synthetic HLA-A read set; C oracle scoring %.2fs + dedup %.2fs + EM %.2fs "
+                  "(%d outer iterations); front-end excluded on both sides" % (
+                      n_pairs, fe["num_reads"], out["t_score"], out["t_dedup"], out["t_em"], out["n_iter"]),
+        "em_iters_per_s": round(out["n_iter"] / max(out["t_em"], 1e-9), 2),
+        "python_port_reads_per_s": round(r2["num_reads"] / t_py, 1),
+        "python_port_sample": "oracle/pyref.py end to end (front-end included) on the first %d pairs" % n_py,
+    }, out
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    capi.set_device(local_rank)
+
+    # ---- set-up (untimed): locus, index broadcast, reads, front-end, upload --------------------------------
+    t_setup = time.perf_counter()
+    loc = synth.make_hla_like_locus(n_alleles=args.alleles, n_vars=args.vars, seed=101)
+    pl = hl.PackedLocus.from_synth(loc)
+    if world > 1:
+        from hisatgenotype_amd import dist as hdist
+        hdist.broadcast_index(pl, src=0)          # rank 0's packed link matrix reaches every GPU over RCCL/xGMI
+    else:
+        pl.index()
+    sample = synth.pick_sample(loc, 101 + rank)
+    sam = synth.simulate_sam_fast(loc, sample, args.pairs, err_rate=args.err, seed=100 + rank)
+    t0 = time.perf_counter()
+    batch = pl.parse_sam(sam)
+    t_parse = time.perf_counter() - t0
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db, exon=True)
+    if rank != 0 or args.no_cpu_baseline or world > 1:
+        sam_keep = None
+    else:
+        sam_keep = sam
+    del sam
+    t_setup = time.perf_counter() - t_setup
+
+    for _ in range(args.warmup):
+        res = step(pl, batch, db, bufs)
+    capi.sync()
+    if dist is not None:
+        dist.barrier()
+    ev = [(capi.Event(), capi.Event()) for _ in range(args.steps)]
+    t_em = 0.0
+    n_em_iter = 0
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        res = step(pl, batch, db, bufs, ev[k])
+        t_em += res.t_em
+        n_em_iter += sum(e["n_iter"] for e in res.em)
+    capi.sync()
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize()
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        rr = torch.tensor([float(batch.n_reads)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        total_reads = float(rr.item())
+    else:
+        total_reads = float(batch.n_reads)
+
+    if rank == 0:
+        # dominant kernel: k_pair_classes (one wavefront per pair).  Algorithmic bytes per launch:
+        #   reads  n_refs * a_pad/8 (one compat row per ref) + 4*n_refs + 4*(n_pairs+1)
+        #   writes n_pairs * 2 levels * (a_pad/8 + 8)
+        row = pl.a_pad // 8
+        alg_bytes = batch.n_refs * row + 4 * batch.n_refs + 4 * (batch.n_pairs + 1) + batch.n_pairs * 2 * (row + 8)
+        ms = [a.elapsed_ms(b) for a, b in ev]
+        avg_ms = sum(ms) / len(ms)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_pair_classes.json")
+        if os.path.exists(tf):
+            try:
+                tj = json.load(open(tf))
+                if tj.get("n_pairs") == batch.n_pairs and tj.get("a_pad") == pl.a_pad:
+                    traffic = tj["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "typed reads/sec at HLA-A (~7k alleles, 2x150bp)",
+            "value": round(total_reads * args.steps / elapsed, 1),
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64 bitsets, f64 EM",
+            "data": "synthetic",
+            "em_iters_per_s": round(n_em_iter / max(t_em, 1e-9), 1),
+            "config": {
+                "workload": "configs[1]: HLA-A-like locus, %d simulated 2x150bp reads per GPU, %d alleles, %d variants" % (
+                    batch.n_reads, pl.n_alleles, pl.n_vars),
+                "pairs_per_gpu": batch.n_pairs, "distinct_pieces": batch.n_pieces, "piece_refs": batch.n_refs,
+                "exon_classes": res.em[0]["n_classes"] if res.em else 0,
+                "gene_classes_after_handoff": res.em[1]["n_classes"] if len(res.em) > 1 else 0,
+                "em_outer_iterations_per_step": n_em_iter // max(args.steps, 1),
+                "top2": [a for a, _ in res.gene_prob[:2]], "true_alleles": sample,
+                "parallelism": "1 sample per GPU (samples/loci shard, no data-path collective)",
+                "input": "front-end piece batch resident in HBM (host C++ front-end: %.0f reads/s on 1 core, not timed)" % (
+                    batch.n_reads / t_parse),
+                "setup_s": round(t_setup, 1),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_pair_classes", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "alg_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4),
+            },
+        }
+        if sam_keep is not None:
+            cb, _ = cpu_baseline(loc, sam_keep, min(args.cpu_pairs, batch.n_pairs))
+            out["cpu_baseline"] = cb
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -6,3 +6,6 @@ Compute runs in hand-written HIP kernels (csrc/) reached through the C-ABI in
 include/hgx.h; there is no CPU fallback: a missing/unbuildable extension raises.
 """
 __version__ = "0.1.0"
+
+from .typing import single_abundance, type_locus, typing, report_lines  # noqa: E402,F401
+from .locus import PackedLocus  # noqa: E402,F401

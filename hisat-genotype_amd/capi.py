@@ -46,7 +46,8 @@ class ParseOpts(C.Structure):
 # every symbol include/hgx.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "hgx_last_error", "hgx_version", "hgx_device_count", "hgx_set_device", "hgx_dev_alloc", "hgx_dev_free",
-    "hgx_memcpy_h2d", "hgx_memcpy_d2h", "hgx_memset", "hgx_stream_sync", "hgx_a_pad", "hgx_index_create",
+    "hgx_memcpy_h2d", "hgx_memcpy_d2h", "hgx_memset", "hgx_stream_sync", "hgx_event_create", "hgx_event_destroy",
+    "hgx_event_record", "hgx_event_elapsed_ms", "hgx_a_pad", "hgx_index_create",
     "hgx_index_destroy", "hgx_index_dims", "hgx_index_device_bits", "hgx_piece_compat", "hgx_pair_classes",
     "hgx_score_pairs", "hgx_dedup_classes", "hgx_classes_destroy", "hgx_classes_dims", "hgx_classes_device",
     "hgx_classes_to_host", "hgx_classes_from_host", "hgx_allele_counts", "hgx_em", "hgx_locus_create",
@@ -81,7 +82,7 @@ def check(rc):
 def ptr(a):
     if a is None:
         return None
-    if isinstance(a, DevArray):
+    if hasattr(a, "ptr") and not hasattr(a, "ctypes"):      # DevArray or a borrowed device pointer
         return C.c_void_p(a.ptr)
     return a.ctypes.data_as(C.c_void_p)
 
@@ -142,3 +143,26 @@ class DevArray:
 
 def sync(stream=None):
     check(lib().hgx_stream_sync(stream))
+
+
+class Event:
+    """hipEvent on a stream (timing of individual kernels)."""
+
+    def __init__(self):
+        p = C.c_void_p()
+        check(lib().hgx_event_create(C.byref(p)))
+        self.h = p
+
+    def record(self, stream=None):
+        check(lib().hgx_event_record(self.h, stream))
+
+    def elapsed_ms(self, stop):
+        ms = C.c_float(0)
+        check(lib().hgx_event_elapsed_ms(self.h, stop.h, C.byref(ms)))
+        return ms.value
+
+    def __del__(self):
+        try:
+            lib().hgx_event_destroy(self.h)
+        except Exception:
+            pass

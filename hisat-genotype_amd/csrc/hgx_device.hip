@@ -71,6 +71,21 @@ extern "C" int hgx_memset(void *d, int v, size_t n, void *st) {
     return HGX_OK;
 }
 extern "C" int hgx_stream_sync(void *st) { HIPCHK(hipStreamSynchronize((hipStream_t)st)); return HGX_OK; }
+extern "C" int hgx_event_create(void **ev) {
+    ARGCHK(ev != nullptr);
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    *ev = (void *)e;
+    return HGX_OK;
+}
+extern "C" int hgx_event_destroy(void *ev) { if (ev) HIPCHK(hipEventDestroy((hipEvent_t)ev)); return HGX_OK; }
+extern "C" int hgx_event_record(void *ev, void *st) { HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)st)); return HGX_OK; }
+extern "C" int hgx_event_elapsed_ms(void *a, void *b, float *ms) {
+    ARGCHK(a && b && ms);
+    HIPCHK(hipEventSynchronize((hipEvent_t)b));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b));
+    return HGX_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers

@@ -527,3 +527,114 @@ def pick_sample(locus: Locus, seed: int, n: int = 2, with_siblings: bool = True)
     rng = random.Random(seed)
     cand = [a for a in locus.allele_names[1:] if a in locus.allele_vars]
     return sorted(rng.sample(cand, n))
+
+
+# --------------------------------------------------------------------------------------
+# fast read simulator for bench-size inputs (event based: O(variants in the read), not O(read length))
+# --------------------------------------------------------------------------------------
+class _FastAllele:
+    def __init__(self, locus: Locus, name: str):
+        import bisect
+        self.bisect = bisect
+        m = AlleleMap(locus, name)
+        self.seq = m.seq
+        self.bpos = np.asarray(m.bpos, dtype=np.int64)
+        # events in allele coordinates: (allele index, kind, var index); deletions sit before base i
+        ev = [(i, 0, v) for i, v in enumerate(m.vid) if v >= 0] + [(i, 1, v) for i, v in m.dels.items()]
+        ev.sort(key=lambda e: (e[0], -e[1]))      # a deletion before base i precedes a single at base i
+        self.ev_pos = [e[0] for e in ev]
+        self.ev = ev
+        self.is_var = set(i for i, v in enumerate(m.vid) if v >= 0)
+        self.locus = locus
+
+    def align(self, start: int, read_len: int, err_pos):
+        """(pos0, cigar_str, seq, md, zs, nm) of allele bases [start, start+read_len) with substitution
+        errors at the given allele offsets (never on variant bases)."""
+        loc, bb = self.locus, self.locus.backbone
+        end = start + read_len
+        lo = self.bisect.bisect_left(self.ev_pos, start)
+        hi = self.bisect.bisect_left(self.ev_pos, end)
+        events = []
+        for k in range(lo, hi):
+            i, kind, v = self.ev[k]
+            if kind == 1 and i == start:
+                continue                      # deletion in front of the first base is outside the read
+            events.append((i, -1 if kind == 1 else 0, v))
+        seq = self.seq[start:end]
+        if err_pos:
+            s = list(seq)
+            for e in err_pos:
+                if e in self.is_var:
+                    continue
+                alt = _BASES[(_BASES.index(s[e - start]) + 1 + (e % 3)) % 4]
+                s[e - start] = alt
+                events.append((e, 1, -1))
+            seq = "".join(s)
+            events.sort(key=lambda x: (x[0], x[1]))
+        cigar, md, zs = [], [], []
+        nm = 0
+        m_run = 0            # current M run
+        md_run = 0
+        zs_gap = 0
+        cur = start
+        for i, kind, v in events:
+            n = i - cur       # matching bases before the event
+            m_run += n; md_run += n; zs_gap += n
+            cur = i
+            if kind == -1:    # known deletion before base i
+                dl = int(loc.var_data[v]); p = loc.var_pos[v]
+                cigar.append("%dM%dD" % (m_run, dl)); m_run = 0
+                md.append("%d^%s" % (md_run, bb[p:p + dl])); md_run = 0
+                zs.append("%d|D|%s" % (zs_gap, loc.var_ids[v])); zs_gap = 0
+            else:
+                p = int(self.bpos[i])
+                md.append("%d%s" % (md_run, bb[p])); md_run = 0
+                m_run += 1
+                cur = i + 1
+                if kind == 0:
+                    zs.append("%d|S|%s" % (zs_gap, loc.var_ids[v])); zs_gap = 0
+                else:
+                    nm += 1
+                    zs_gap += 1
+        n = end - cur
+        m_run += n; md_run += n
+        cigar.append("%dM" % m_run)
+        md.append("%d" % md_run)
+        return int(self.bpos[start]), "".join(cigar), seq, "".join(md), ",".join(zs), nm
+
+
+def simulate_sam_fast(locus: Locus, sample_alleles: Sequence[str], n_pairs: int, read_len: int = 150,
+                      frag_len: Tuple[int, int] = (350, 450), err_rate: float = 0.0, seed: int = 1) -> str:
+    """Name-grouped SAM text for ``n_pairs`` random fragments (same dialect as ``sam_text``); sized for
+    the 1M-read bench configuration (about 15 us per read)."""
+    rng = np.random.RandomState(seed)
+    maps = [_FastAllele(locus, a) for a in sample_alleles]
+    which = rng.randint(0, len(maps), n_pairs)
+    flen = rng.randint(frag_len[0], frag_len[1] + 1, n_pairs)
+    u = rng.random_sample(n_pairs)
+    orient = rng.random_sample(n_pairs) < 0.5
+    n_err = rng.binomial(read_len, err_rate, (n_pairs, 2)) if err_rate > 0 else None
+    rname = locus.ref_allele
+    qual = "I" * read_len
+    out = []
+    for k in range(n_pairs):
+        m = maps[which[k]]
+        fl = int(flen[k])
+        s = int(u[k] * (len(m.seq) - fl + 1))
+        recs = []
+        for j, st in enumerate((s, s + fl - read_len)):
+            errs = None
+            if n_err is not None and n_err[k, j]:
+                errs = sorted(set(int(x) for x in rng.randint(st, st + read_len, n_err[k, j])))
+            recs.append(m.align(st, read_len, errs))
+        qname = "r%07d" % (k + 1)
+        for j, (pos, cigar, seq, md, zs, nm) in enumerate(recs):
+            leftmost = j == 0
+            first = leftmost == bool(orient[k])
+            flag = 0x1 | 0x2 | (0x40 if first else 0x80) | (0x20 if leftmost else 0x10)
+            tags = "NM:i:%d\tMD:Z:%s\t" % (nm, md)
+            if zs:
+                tags += "Zs:Z:%s\t" % zs
+            out.append("%s\t%d\t%s\t%d\t60\t%s\t=\t%d\t0\t%s\t%s\t%sNH:i:1\tYT:Z:CP" % (
+                qname, flag, rname, pos + 1, cigar, recs[1 - j][0] + 1, seq, qual, tags))
+    return "\n".join(out) + "\n"

@@ -1,0 +1,292 @@
+"""Drop-in mirrors of the reference's entry points for the hot path.
+
+  single_abundance(Gene_cmpt, remove_low_abundance_allele=False, Gene_length={})
+        same signature / return value as hisatgenotype_typing_common.single_abundance (common:1282-1410);
+        can be assigned over it (``typing_common.single_abundance = hgx.single_abundance``).
+  type_locus(packed_locus, sam_text, ...)
+        the per-locus body of typing() (typing_core.py:370-2122 minus assembly): SAM stream in,
+        counts / classes / abundances / report lines out.  Scoring, dedup and EM run on the GPU.
+  typing(...)
+        same 38-parameter signature as hisatgenotype_typing_core.typing (core:249-286); writes the same
+        report file and returns ``test_passed`` in simulation mode.
+
+Nothing here computes the hot path on the CPU: all of it goes through libhgx (HIP kernels).
+"""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+from . import capi, engine
+from .locus import PackedLocus
+
+
+def _sorted_result(prob, order):
+    """[[allele index, prob]] for present alleles in dict order, then the reference's stable
+    descending sort (common:1408-1409)."""
+    lst = [[a, float(prob[a])] for a in order]
+    return sorted(lst, key=lambda x: x[1], reverse=True)
+
+
+def _em_on_classes(classes, n_alleles, name_rank, remove_low, lengths, stream=None):
+    prob, n_iter = classes.em(n_alleles, remove_low, lengths, stream)
+    _, first = classes.allele_counts()
+    order = engine.em_order(first[:n_alleles], name_rank, prob >= 0.0)
+    return _sorted_result(prob, order), n_iter
+
+
+def single_abundance(Gene_cmpt, remove_low_abundance_allele=False, Gene_length={}):
+    """EM abundance of alleles from compatibility classes ``{'a-b-c': count}`` (drop-in, GPU)."""
+    names, idx = [], {}
+    split = []
+    for key in Gene_cmpt.keys():
+        al = key.split("-")
+        for a in al:
+            if a not in idx:
+                idx[a] = len(names)
+                names.append(a)
+        split.append(al)
+    A = len(names)
+    if A == 0:
+        return []
+    ap = capi.a_pad(A)
+    bits = np.zeros((len(split), ap // 64), np.uint64)
+    for c, al in enumerate(split):
+        ii = np.fromiter((idx[a] for a in al), np.int64, len(al))
+        np.bitwise_or.at(bits[c], ii >> 6, np.uint64(1) << (ii & 63).astype(np.uint64))
+    counts = np.fromiter(Gene_cmpt.values(), np.int64, len(split))
+    lengths = None
+    if len(Gene_length) > 0:
+        lengths = np.array([Gene_length[a] for a in names], np.int32)
+    cl = engine.Classes.from_host(bits, counts, ap)
+    try:
+        prob, _ = cl.em(A, bool(remove_low_abundance_allele), lengths)
+    finally:
+        cl.close()
+    # allele index == first-appearance order here, which is the dict order of the reference
+    res = [[names[a], float(prob[a])] for a in range(A) if prob[a] >= 0.0]
+    return sorted(res, key=lambda x: x[1], reverse=True)
+
+
+class LocusResult:
+    def __init__(self):
+        self.num_reads = self.num_pairs = 0
+        self.counts_sorted = []     # [[allele name, count]] (core:1650-1651)
+        self.exon_classes = None    # (bits[C][w64], counts[C]) host copies, first-seen order
+        self.gene_classes = None
+        self.em = []                # [{'n_classes', 'remove_low', 'use_length', 'result', 'n_iter'}]
+        self.gene_prob = []         # final [[allele name, prob]] (core:1732-1789)
+        self.n_pieces = self.n_refs = 0
+        self.t_em = 0.0             # seconds spent inside the EM calls (bench)
+
+
+def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discordant=False,
+               remove_low_abundance_alleles=True, simulation=False, base_locus=0, keep_classes=False, stream=None):
+    """Per-locus typing: the reference's loop body with the O(alleles) work on the GPU."""
+    res = LocusResult()
+    batch = pl.parse_sam(sam_text, num_editdist=num_editdist, error_correction=error_correction,
+                         allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus)
+    res.num_reads, res.num_pairs = batch.n_reads, batch.n_pairs
+    res.n_pieces, res.n_refs = batch.n_pieces, batch.n_refs
+    if batch.n_reads <= 0:                                  # core:1589-1590
+        return res
+    return _type_batch(pl, batch, res, remove_low_abundance_alleles, keep_classes, stream)
+
+
+def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dbatch=None, bufs=None, scored=False):
+    hla = pl.base_fname == "hla"
+    A, names = pl.n_alleles, pl.names
+    db = dbatch if dbatch is not None else engine.DeviceBatch(batch, stream)
+    bufs = bufs if bufs is not None else engine.ScoreBuffers(pl, db, exon=hla)
+    if not scored:
+        engine.score_pairs(pl, db, bufs, stream)
+    # ---- Gene_counts (core:1187-1190, 1650-1651) --------------------------------------------------
+    gcl = engine.Classes.dedup(bufs.gene_bits, db.n_pairs, pl.a_pad, hashes=bufs.gene_hash, stream=stream)
+    cnt, first = gcl.allele_counts()
+    fr = np.zeros(gcl.n_classes, np.int64)                     # first pair of every class
+    capi.check(capi.lib().hgx_classes_to_host(gcl.h, None, None, capi.ptr(fr)))
+    counted = [a for a in range(A) if cnt[a] > 0]
+    counted.sort(key=lambda a: (fr[first[a]], a))               # dict insertion order of Gene_counts
+    counted.sort(key=lambda a: -cnt[a])                          # stable, descending
+    res.counts_sorted = [[names[a], int(cnt[a])] for a in counted]
+    if keep_classes:
+        res.gene_classes = gcl.to_host()[:2]
+
+    def run_em(classes, low, lengths):
+        t0 = time.perf_counter()
+        out, n_iter = _em_on_classes(classes, A, pl.name_rank, low, lengths, stream)
+        res.t_em += time.perf_counter() - t0
+        res.em.append({"n_classes": classes.n_classes, "remove_low": bool(low), "use_length": lengths is not None,
+                       "result": [[names[a], p] for a, p in out], "n_iter": n_iter})
+        return out
+
+    if hla:
+        ecl = engine.Classes.dedup(bufs.exon_bits, db.n_pairs, pl.a_pad, hashes=bufs.exon_hash, stream=stream)
+        if keep_classes:
+            res.exon_classes = ecl.to_host()[:2]
+        exon_prob = gene_prob = run_em(ecl, remove_low, None)                    # core:1732-1737
+        groups = pl.rep_groups()
+        exon_alleles, psum = set(), 0.0
+        for i, (a, p) in enumerate(exon_prob):                                   # core:1739-1749
+            if i >= 10 and p < 0.03:
+                break
+            g = groups.get(a, [a])
+            if len(g) <= 1:
+                continue
+            psum += p
+            exon_alleles |= set(g)
+        if exon_alleles:                                                         # core:1752-1782
+            mask = np.zeros(pl.w64, np.uint64)
+            for a in exon_alleles:
+                mask[a >> 6] |= np.uint64(1) << np.uint64(a & 63)
+            d_mask = capi.DevArray.from_host(mask, stream)
+            gb, gc, _ = gcl.device_ptrs()
+            g2 = engine.Classes.dedup(engine._RawDev(gb), gcl.n_classes, pl.a_pad, weights=engine._RawDev(gc),
+                                      and_mask=d_mask, stream=stream)
+            gp = run_em(g2, True, pl.allele_len)
+            comb = {}
+            for a, p in exon_prob:
+                if a not in exon_alleles:
+                    comb[a] = p
+            for a, p in gp:
+                comb[a] = p * psum
+            gene_prob = sorted([[a, p] for a, p in comb.items()], key=lambda x: x[1], reverse=True)
+            g2.close()
+        ecl.close()
+    else:
+        if gcl.n_classes <= 1:                                                   # core:1784-1787 (quirk Q3)
+            if gcl.n_classes == 1:
+                raise TypeError("'dict_keys' object is not subscriptable (reference quirk Q3, typing_core.py:1787)")
+            gene_prob = []
+        else:
+            gene_prob = run_em(gcl, False, None)
+    res.gene_prob = [[names[a], p] for a, p in gene_prob]
+    gcl.close()
+    return res
+
+
+def report_lines(res, simulation=False, true_alleles=(), output_allele_counts=False, best_alleles=False):
+    """Report body (core:1593, 1650-1677, 2076-2121)."""
+    out = ["\t\t\t%d reads and %d pairs are aligned" % (res.num_reads, res.num_pairs)]
+    for i, (a, c) in enumerate(res.counts_sorted):
+        if simulation:
+            found = False
+            for t in true_alleles:
+                if a == t:
+                    out.append("\t\t\t*** %d ranked %s (count: %d)" % (i + 1, t, c))
+                    found = True
+            if i < 5 and not found:
+                out.append("\t\t\t\t%d %s (count: %d)" % (i + 1, a, c))
+        else:
+            out.append("\t\t\t\t%d %s (count: %d)" % (i + 1, a, c))
+            if i >= 9 and not output_allele_counts:
+                break
+    out.append("\n")
+    success = [False] * len(true_alleles)
+    found_list = [False] * len(true_alleles)
+    for i, (a, p) in enumerate(res.gene_prob):
+        if p < 0.01:
+            break
+        found = False
+        if simulation:
+            for k, t in enumerate(true_alleles):
+                if a == t:
+                    out.append("\t\t\t*** %d ranked %s (abundance: %.2f%%)" % (i + 1, t, p * 100.0))
+                    if i < len(success):
+                        success[i] = True
+                    found_list[k] = True
+                    found = True
+            if False not in found_list and i >= 10:
+                break
+        if not found:
+            out.append("\t\t\t\t%d ranked %s (abundance: %.2f%%)" % (i + 1, a, p * 100.0))
+            if best_alleles and i < 2:
+                out.append("SingleModel %s (abundance: %.2f%%)" % (a, p * 100.0))
+        if not simulation and i >= 9:
+            break
+        if i >= 19:
+            break
+    return out, success
+
+
+def read_alignment_text(alignment_fname, region=None):
+    """The record stream the reference's loop consumes: ``samtools view F [region]`` piped through
+    ``sort -k1,1 -s`` (core:436-468).  SAM text files are read directly (no samtools needed)."""
+    with open(alignment_fname, "rb") as f:
+        head = f.read(4)
+    if head[:2] == b"\x1f\x8b" or head == b"BAM\x01":
+        cmd = ["samtools", "view", alignment_fname] + ([region] if region else [])
+        data = subprocess.check_output(cmd)
+    else:
+        with open(alignment_fname, "rb") as f:
+            data = f.read()
+    lines = [l for l in data.split(b"\n") if l and not l.startswith(b"@")]
+    lines.sort(key=lambda l: l.split(None, 1)[0])      # stable; bytewise like LC_ALL=C sort -k1,1 -s
+    return b"\n".join(lines) + b"\n"
+
+
+def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partial, partial_alleles, refGenes, Genes,
+           Gene_names, Gene_lengths, refGene_loci, Vars, Var_list, Links, aligners, num_editdist, assembly, output_base,
+           error_correction, keep_alignment, allow_discordant, type_primary_exons, remove_low_abundance_alleles,
+           display_alleles, fastq, read_fname, alignment_fname, num_frag_list, read_len, fragment_len, threads,
+           best_alleles, verbose, assembly_verbose, out_dir, dbversion, output_allele_counts, test_i=0):
+    """Same contract as hisatgenotype_typing_core.typing (core:249-286) for graph alignments that already
+    exist (``alignment_fname``): writes ``<out_dir>/<output_base>-<base>.<id>.report``; returns
+    ``test_passed`` in simulation mode.  Aligning reads (hisat2) and --assembly are outside this path."""
+    if assembly:
+        raise NotImplementedError("--assembly (assembly graph) is outside the accelerated path")
+    if alignment_fname == "":
+        raise NotImplementedError("read alignment (hisat2) is outside the accelerated path: pass alignment_fname")
+    base_fname = full_path_base_fname.split("/")[-1]
+    report_base = "%s/%s-%s." % (out_dir, output_base, base_fname)
+    test_passed = {}
+    if simulation:
+        core_fid = str(test_i + 1)
+        report_base += "test-"
+    else:
+        core_fid = "_".join(read_fname[0].split("/")[-1].split(".")[:-1])
+    report_base += core_fid
+    with open("%s.report" % report_base, "w") as report_file:
+        msg_out = [sys.stderr, report_file] if (verbose or assembly_verbose or simulation) else [report_file]
+
+        def say(s):
+            for f_ in msg_out:
+                print(s, file=f_)
+
+        say("# VERSIONS:")
+        say("# HISAT-genotype hot path: hgx %s (MI355X)" % __import__("hisatgenotype_amd").__version__)
+        say("# Database - %s" % dbversion)
+        say("# COMMAND:\n%s" % " ".join(sys.argv))
+        for aligner, index_type in aligners:
+            if index_type != "graph":
+                raise NotImplementedError("only graph alignments are on the accelerated path")
+            say("\n\t\t%s %s" % (aligner, index_type))
+            for test_Gene_names in locus_list:
+                gene = test_Gene_names[0].split("*")[0] if simulation else test_Gene_names
+                pl = PackedLocus.from_reference_dicts(gene, base_fname, refGenes, Genes, Gene_names, Gene_lengths,
+                                                      refGene_loci, Vars, Var_list, Links)
+                region, base_locus = None, 0
+                if genotype_genome != "":
+                    _, chr_, left, right = refGene_loci[gene][:4]
+                    region, base_locus = "%s:%d-%d" % (chr_, left + 1, right + 1), left
+                sam = read_alignment_text(alignment_fname, region)
+                res = type_locus(pl, sam, num_editdist=num_editdist, error_correction=error_correction,
+                                 allow_discordant=allow_discordant,
+                                 remove_low_abundance_alleles=remove_low_abundance_alleles, simulation=simulation,
+                                 base_locus=base_locus)
+                pl.close()
+                if res.num_reads <= 0:
+                    continue
+                lines, success = report_lines(res, simulation, test_Gene_names if simulation else (),
+                                              output_allele_counts, best_alleles)
+                for l in lines:
+                    say(l)
+                if simulation:
+                    for ok in success:
+                        if ok:
+                            key = "%s %s" % (aligner, index_type)
+                            test_passed[key] = test_passed.get(key, 0) + 1
+    if simulation:
+        return test_passed

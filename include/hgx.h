@@ -56,6 +56,11 @@ int hgx_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stre
 int hgx_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);
 int hgx_memset(void *dev_dst, int value, size_t bytes, void *stream);
 int hgx_stream_sync(void *stream);
+/* HIP events on a stream, for timing individual kernels from a ctypes caller */
+int hgx_event_create(void **event);
+int hgx_event_destroy(void *event);
+int hgx_event_record(void *event, void *stream);
+int hgx_event_elapsed_ms(void *start_event, void *stop_event, float *ms);   /* synchronises on stop */
 
 /* ---- 8a-0: packed locus index ---------------------------------------------------------
  * Replaces the per-locus dict building of typing_core.py:384-401, 476-491, 559-569.

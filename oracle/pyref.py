@@ -602,6 +602,7 @@ class RefLocus:
         self.list_r = self.alts.sorted_list(False)
         self.novel = 0
         self.trace = None          # optional list collecting per-record intermediates
+        self.score = True          # False: front-end only (collect the pairs' haplotypes, skip add_count/EM)
 
     # -- novel variants (core:404-431) ------------------------------------------------------
     def _add_novel(self, vtype, pos, data):
@@ -915,10 +916,15 @@ class RefLocus:
             pieces_e, pieces_g = [], []
             for ht in lhts | rhts:
                 for eh in self.exon_pieces(ht):
-                    self.add_count(per_exon, eh)
+                    if self.score:
+                        self.add_count(per_exon, eh)
                     pieces_e.append(eh)
-                self.add_count(per_gene, ht)
+                if self.score:
+                    self.add_count(per_gene, ht)
                 pieces_g.append(ht)
+            if not self.score:
+                pair_log.append({"exon": sorted(pieces_e), "gene": sorted(pieces_g)})
+                return
             ke = ""
             if hla:
                 ke = self.add_stat(exons_cmpt, exons_counts, per_exon, self.rep_set)
@@ -1020,7 +1026,7 @@ class RefLocus:
 
         res = dict(num_reads=num_reads, num_pairs=num_pairs, pairs=pair_log, exons_cmpt=exons_cmpt,
                    gene_cmpt=gene_cmpt, gene_counts=gene_counts, em=[])
-        if num_reads <= 0:
+        if num_reads <= 0 or not self.score:
             return res
         res["counts_sorted"] = sorted([[a, c] for a, c in gene_counts.items()], key=lambda x: x[1], reverse=True)
 

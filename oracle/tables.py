@@ -1,11 +1,10 @@
-"""Integer tables of a locus for the C oracle, derived with the Python oracle (test-side only)."""
+"""Integer tables of a locus for the C oracle, derived with the Python oracle.  TEST INFRASTRUCTURE."""
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import pyref  # noqa: E402
 
 
@@ -37,7 +36,9 @@ def oracle_tables(locus):
 
 def pieces_from_pairs(pairs, var_index):
     """golden/pyref pair log -> flat piece arrays for orc_score_pairs."""
-    from golden_util import parse_ht
+    def parse_ht(ht, var_index):
+        f = ht.split("-")
+        return int(f[0]), int(f[-1]), [var_index.get(v, -1) if v.startswith("hv") else -1 for v in f[1:-1]]
     pair_off, level, left, right, id_off, ids = [0], [], [], [], [0], []
     for p in pairs:
         for lvl, key in ((0, "exon"), (1, "gene")):

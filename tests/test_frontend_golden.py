@@ -1,0 +1,94 @@
+"""Host front-end of libhgx (SAM -> pieces, C++) against vectors recorded from the real reference.
+CPU only: device entry points are not called; the class check evaluates the masks with numpy."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import tables
+from hisatgenotype_amd import locus as hl
+from test_host_pieces import _numpy_classes
+
+
+def _parse(fx, keep_trace=True):
+    o = fx["options"]
+    pl = hl.PackedLocus.from_synth(fx["_locus"])
+    batch = pl.parse_sam(fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
+                         allow_discordant=o["allow_discordant"], simulation=o["simulation"], keep_trace=keep_trace)
+    return pl, batch
+
+
+def _fmt_record(rec):
+    parts = []
+    for c in rec["cmp"]:
+        s = "%s:%d:%d" % (c[0], c[1], c[2])
+        if c[0] != "match":
+            s += ":" + c[3]
+        parts.append(s)
+    cl, cr, la, ra = rec["iad"]
+    return "%s\t%d\t%d\t%s\t%s" % (",".join(parts), cl, cr, ";".join(sorted(la)), ";".join(sorted(ra)))
+
+
+@pytest.mark.parametrize("name", gu.ALL)
+def test_alternatives_and_pileup(name):
+    fx = gu.load(name)
+    pl, batch = _parse(fx, keep_trace=False)
+    got = {"L": {}, "R": {}}
+    for line in pl.alternatives_text().splitlines():
+        d, k, a = line.split("\t")
+        got[d].setdefault(k, set()).add(a)
+    assert {k: sorted(v) for k, v in got["L"].items()} == fx["alts"]["left"]
+    assert {k: sorted(v) for k, v in got["R"].items()} == fx["alts"]["right"]
+    nt, cnt = batch.pileup(len(fx["_locus"].backbone))
+    exp_sets = fx["mpileup"]["nt_set"]
+    for i in range(len(nt)):
+        s = "".join(b for k, b in enumerate("ACGT") if nt[i] & (1 << k))
+        assert s == exp_sets[i], i
+        exp = fx["mpileup"]["counts"][i]
+        for k, b in enumerate("ACGT"):
+            assert cnt[i, k] == exp.get(b, 0)
+        assert cnt[i, 5] == exp.get("D", 0)
+        assert cnt[i, 4] == sum(v for b, v in exp.items() if b not in "ACGTD")
+
+
+@pytest.mark.parametrize("name", gu.ALL)
+def test_records_pieces_classes(name):
+    fx = gu.load(name)
+    pl, batch = _parse(fx)
+    assert batch.n_reads == len(fx["records"])
+    assert batch.n_pairs == len(fx["pairs"])
+    got = batch.trace_text().splitlines()
+    assert len(got) == len(fx["records"])
+    for g, rec in zip(got, fx["records"]):
+        assert g == _fmt_record(rec)
+    # number of add_count calls per pair and level (core:1250-1270)
+    for p, exp in enumerate(fx["pairs"]):
+        refs = batch.pair_ref[batch.pair_off[p]:batch.pair_off[p + 1]]
+        assert int((refs >> 31).sum()) == len(exp["gene"])
+        if fx["_locus"].base_fname == "hla":
+            assert int((refs >> 31 == 0).sum()) == len(exp["exon"])
+    # classes implied by the pieces == classes recorded from the reference
+    t = tables.oracle_tables(fx["_locus"])
+    A = t["n_alleles"]
+    w = (A + 63) // 64
+    got_e, got_g = _numpy_classes(pl, batch)
+    for p, exp in enumerate(fx["pairs"]):
+        assert np.array_equal(got_g[p, :w], gu.class_bits(fx, exp["gene_cls"], A)), p
+        if fx["_locus"].base_fname == "hla":
+            assert np.array_equal(got_e[p, :w], gu.class_bits(fx, exp["exon_cls"], A)), p
+
+
+def test_missing_nm_tag_is_an_error():
+    """Quirk Q8: the reference raises on a record without NM; the front-end reports it instead of guessing."""
+    from hisatgenotype_amd import capi
+    fx = gu.load("hla_small_pair")
+    pl = hl.PackedLocus.from_synth(fx["_locus"])
+    bad = "\n".join(l.replace("NM:i:", "XM:i:") for l in fx["sam"].split("\n")[:4]) + "\n"
+    with pytest.raises(capi.HgxError):
+        pl.parse_sam(bad, simulation=True)
+
+
+def test_empty_input():
+    fx = gu.load("hla_small_pair")
+    pl = hl.PackedLocus.from_synth(fx["_locus"])
+    b = pl.parse_sam("")
+    assert b.n_pairs == 0 and b.n_reads == 0 and b.n_pieces == 0

@@ -1,0 +1,97 @@
+"""End-to-end on the GPU: SAM text -> report, against the reference's recorded outputs and the Python oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import hisatgenotype_amd as hgx
+from hisatgenotype_amd import locus as hl, synth
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import pyref  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+EM_TOL = 1e-5      # north_star: EM float weights within 1e-5 (observed: ~1e-15)
+
+
+def _check_em(got, exp_result, exp_iter):
+    assert got["n_iter"] == exp_iter
+    assert [a for a, _ in got["result"]] == [a for a, _ in exp_result]
+    for (a, p), (_, q) in zip(got["result"], exp_result):
+        assert abs(p - float(q)) <= EM_TOL
+        assert abs(p - float(q)) <= 1e-9
+
+
+@pytest.mark.parametrize("name", gu.ALL)
+def test_type_locus_matches_reference(name):
+    fx = gu.load(name)
+    o = fx["options"]
+    pl = hl.PackedLocus.from_synth(fx["_locus"])
+    res = hgx.type_locus(pl, fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
+                         allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
+                         simulation=o["simulation"])
+    assert res.num_reads == len(fx["records"]) and res.num_pairs == len(fx["pairs"])
+    assert len(res.em) == len(fx["em"])
+    for got, exp in zip(res.em, fx["em"]):
+        assert got["n_classes"] == len(exp["cmpt"])
+        assert got["remove_low"] == exp["remove_low"] and got["use_length"] == exp["use_length"]
+        _check_em(got, exp["result"], exp["n_iter"])
+    lines, _ = hgx.report_lines(res, o["simulation"], o["sample"] if o["simulation"] else (), True)
+    keep = lambda ls: [l for l in ls if "aligned" in l or "ranked" in l or "(count:" in l]
+    assert keep(lines) == keep(fx["report"].split("\n"))
+
+
+@pytest.mark.parametrize("name", ["hla_small_pair", "hla_mid_real", "codis_like"])
+def test_single_abundance_dropin(name):
+    """hgx.single_abundance takes the reference's dict-of-strings and returns its list-of-lists."""
+    fx = gu.load(name)
+    loc = fx["_locus"]
+    lengths = {n: loc.allele_length(n) for n in loc.allele_names[1:]}
+    for em in fx["em"]:
+        cmpt = {gu.class_key(fx, cid): n for cid, n in em["cmpt"]}
+        out = hgx.single_abundance(cmpt, em["remove_low"], lengths if em["use_length"] else {})
+        assert [a for a, _ in out] == [a for a, _ in em["result"]]
+        for (a, p), (_, q) in zip(out, em["result"]):
+            assert abs(p - float(q)) <= 1e-9
+
+
+def test_seeded_mid_size_against_python_oracle():
+    """Bigger than the fixtures (the reference cannot run on the GPU box): compare with oracle/pyref.py."""
+    loc = synth.make_hla_like_locus(n_alleles=900, n_vars=1500, seed=202, unlinked_vars=3)
+    sample = synth.pick_sample(loc, 7)
+    al = synth.simulate_pairs(loc, sample, 1200, err_rate=0.004, seed=11, softclip_frac=0.03, novel_del_frac=0.02,
+                              multi_hit_frac=0.01, dup_frac=0.01)
+    sam = synth.sam_text(loc, al)
+    rl = pyref.RefLocus(loc)
+    exp = rl.run(sam)
+    pl = hl.PackedLocus.from_synth(loc)
+    res = hgx.type_locus(pl, sam)
+    assert (res.num_reads, res.num_pairs) == (exp["num_reads"], exp["num_pairs"])
+    assert res.counts_sorted == exp["counts_sorted"]
+    assert len(res.em) == len(exp["em"])
+    for got, e in zip(res.em, exp["em"]):
+        _check_em(got, e["result"], e["n_iter"])
+    assert [a for a, _ in res.gene_prob[:2]] == [a for a, _ in exp["gene_prob"][:2]]
+    for (a, p), (b, q) in zip(res.gene_prob, exp["gene_prob"]):
+        assert a == b and abs(p - q) <= 1e-9
+
+
+def test_typing_signature_writes_report(tmp_path):
+    """typing() keeps the reference's 38-parameter signature and report file naming."""
+    fx = gu.load("hla_small_pair")
+    loc = fx["_locus"]
+    d = loc.reference_dicts()
+    bam = tmp_path / "syn.sam"
+    bam.write_text(fx["sam"])
+    passed = hgx.typing(True, str(tmp_path / "hla"), [fx["options"]["sample"]], "", True, set(), d["refGenes"],
+                        d["Genes"], d["Gene_names"], d["Gene_lengths"], d["refGene_loci"], d["Vars"], d["Var_list"],
+                        d["Links"], [["hisat2", "graph"]], 2, False, "assembly_graph", True, True, False, False, True,
+                        [], False, ["r1.fa", "r2.fa"], str(bam), [], 100, 350, 1, False, 0, False, str(tmp_path),
+                        "NONE", True, 0)
+    rep = (tmp_path / "assembly_graph-hla.test-1.report").read_text()
+    keep = lambda ls: [l for l in ls if "aligned" in l or "ranked" in l or "(count:" in l]
+    assert keep(rep.split("\n")) == keep(fx["report"].split("\n"))
+    assert passed == {"hisat2 graph": 2}
