@@ -21,7 +21,8 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 import hisatgenotype_amd as hgx  # noqa: E402
-from hisatgenotype_amd import capi, engine, synth, typing as htyping  # noqa: E402
+from hisatgenotype_amd import capi, engine, synth  # noqa: E402
+htyping = sys.modules["hisatgenotype_amd.typing"]   # the module (the package also exports the typing() function)
 from hisatgenotype_amd import locus as hl  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
