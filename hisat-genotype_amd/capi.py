@@ -46,7 +46,7 @@ class ParseOpts(C.Structure):
 # every symbol include/hgx.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "hgx_last_error", "hgx_version", "hgx_device_count", "hgx_set_device", "hgx_dev_alloc", "hgx_dev_free",
-    "hgx_memcpy_h2d", "hgx_memcpy_d2h", "hgx_memset", "hgx_stream_sync", "hgx_event_create", "hgx_event_destroy",
+    "hgx_memcpy_h2d", "hgx_memcpy_d2h", "hgx_memset", "hgx_stream_sync", "hgx_pool_trim", "hgx_event_create", "hgx_event_destroy",
     "hgx_event_record", "hgx_event_elapsed_ms", "hgx_a_pad", "hgx_index_create",
     "hgx_index_destroy", "hgx_index_dims", "hgx_index_device_bits", "hgx_piece_compat", "hgx_pair_classes",
     "hgx_score_pairs", "hgx_dedup_classes", "hgx_classes_destroy", "hgx_classes_dims", "hgx_classes_device",

@@ -1,0 +1,98 @@
+// hgx_common.hpp -- shared by the device translation units of libhgx (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+
+#include "hgx.h"
+
+extern "C" void hgx_set_error(const char *fmt, ...);
+
+#define HIPCHK(expr)                                                                   \
+    do {                                                                               \
+        hipError_t e_ = (expr);                                                        \
+        if (e_ != hipSuccess) {                                                        \
+            hgx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return HGX_EHIP;                                                           \
+        }                                                                              \
+    } while (0)
+#define ARGCHK(cond)                                                                   \
+    do {                                                                               \
+        if (!(cond)) {                                                                 \
+            hgx_set_error("invalid argument: %s (%s:%d)", #cond, __FILE__, __LINE__);  \
+            return HGX_EINVAL;                                                         \
+        }                                                                              \
+    } while (0)
+
+// caching device allocator (hgx_device.hip): hipMalloc/hipFree are far too slow for per-step scratch
+void *hgx_pool_alloc(size_t bytes);
+void hgx_pool_free(void *p);
+
+struct hgx_index {
+    int32_t n_alleles, a_pad, n_vars, n_words, w64;
+    uint32_t *d_bits;
+    uint64_t *d_exon_mask, *d_gene_mask;
+};
+
+struct hgx_classes {
+    int32_t n_classes, a_pad, w64, c64;
+    uint64_t *d_bits;        // [n_classes][w64]
+    int64_t *d_count;        // [n_classes]
+    int64_t *d_first_row;    // [n_classes]
+    uint64_t *d_bitsT;       // lazily built [a_pad][c64]
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) hgx_pool_free(p); }
+    int alloc(size_t n) { p = hgx_pool_alloc(n); return p ? 0 : -1; }
+    template <class T> T *as() { return (T *)p; }
+};
+#define ALLOC(buf, bytes)                                              \
+    do {                                                               \
+        if ((buf).alloc(bytes)) {                                      \
+            hgx_set_error("device allocation of %zu bytes failed", (size_t)(bytes));   \
+            return HGX_ENOMEM;                                         \
+        }                                                              \
+    } while (0)
+
+static inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+int hgx_ensure_transposed(hgx_classes *c, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+#define HGX_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {   // splitmix64 finaliser
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    x ^= x >> 31;
+    return x;
+}
+__device__ __forceinline__ uint64_t word_hash(uint64_t w, int idx) {
+    return w ? mix64(w + 0x9e3779b97f4a7c15ull * (uint64_t)(idx + 1)) : 0ull;
+}
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ uint64_t finish_hash(uint64_t h, bool nonzero) {
+    if (!nonzero) return HGX_EMPTY_KEY;
+    return h == HGX_EMPTY_KEY ? HGX_EMPTY_KEY - 1 : h;
+}
+

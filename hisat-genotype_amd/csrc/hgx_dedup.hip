@@ -1,0 +1,284 @@
+// hgx_dedup.hip -- class dedup (8a-7), bit-matrix transpose and Gene_counts for libhgx (gfx950).
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "hgx_common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// 8a-7 class dedup: hash (optional AND mask) -> radix sort -> run heads -> exact verify ->
+// first-seen order -> gather.
+// ------------------------------------------------------------------------------------------------
+
+// one wavefront per row: hash of (row & mask)
+__global__ __launch_bounds__(256) void k_hash_rows(const uint64_t *__restrict__ rows, long n_rows, int w64,
+                                                   const uint64_t *__restrict__ mask, uint64_t *__restrict__ hash) {
+    const int lane = threadIdx.x & 63;
+    const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= n_rows) return;
+    uint64_t h = 0;
+    bool nz = false;
+    for (int w = lane; w < w64; w += 64) {
+        uint64_t x = rows[(size_t)row * w64 + w];
+        if (mask) x &= mask[w];
+        h += word_hash(x, w);
+        nz = nz || x != 0;
+    }
+    h = wave_sum_u64(h);
+    const bool any_nz = __any(nz);
+    if (lane == 0) hash[row] = finish_hash(h, any_nz);
+}
+
+__global__ void k_iota(uint32_t *v, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+
+// head[i] = 1 if sorted key i starts a run of a non-empty key
+// (empty rows carry the largest key and sort last: *n_valid = number of non-empty rows)
+__global__ void k_heads(const uint64_t *__restrict__ key, long n, uint32_t *__restrict__ head, uint32_t *__restrict__ n_valid) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key[i];
+    head[i] = (k != HGX_EMPTY_KEY && (i == 0 || key[i - 1] != k)) ? 1u : 0u;
+    if (k != HGX_EMPTY_KEY && (i == n - 1 || key[i + 1] == HGX_EMPTY_KEY)) *n_valid = (uint32_t)(i + 1);
+}
+
+// for every run head: remember where the run starts and which original row is its first member
+__global__ void k_run_starts(const uint32_t *__restrict__ head, const uint32_t *__restrict__ cls, const uint32_t *__restrict__ idx,
+                             long n, uint32_t *__restrict__ run_start, uint32_t *__restrict__ run_first) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    run_start[cls[i]] = (uint32_t)i;
+    run_first[cls[i]] = idx[i];   // stable sort => smallest original row of the run
+}
+
+// run weight = sum of member weights (prefix sums) ; unit weights => run length
+__global__ void k_run_counts(const uint32_t *__restrict__ run_start, int n_runs, long n_valid, const int64_t *__restrict__ wsum,
+                             int64_t *__restrict__ run_count) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_runs) return;
+    const long b = run_start[r];
+    const long e = (r + 1 < n_runs) ? (long)run_start[r + 1] : n_valid;
+    if (wsum) run_count[r] = wsum[e - 1] - (b ? wsum[b - 1] : 0);
+    else run_count[r] = e - b;
+}
+
+__global__ void k_gather_weights(const int64_t *__restrict__ w, const uint32_t *__restrict__ idx, long n, int64_t *__restrict__ out) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = w[idx[i]];
+}
+
+// exact check: every member row equals its run's first row (under the mask)
+__global__ __launch_bounds__(256) void k_verify(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
+                                                const uint32_t *__restrict__ idx, const uint32_t *__restrict__ cls,
+                                                const uint32_t *__restrict__ head, const uint32_t *__restrict__ run_first,
+                                                long n_valid, int *__restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= n_valid || head[i]) return;
+    const uint64_t *a = rows + (size_t)idx[i] * w64;
+    const uint64_t *b = rows + (size_t)run_first[cls[i] - 1] * w64;   // non-head: exclusive scan counts its own head
+    bool diff = false;
+    for (int w = lane; w < w64; w += 64) {
+        uint64_t x = a[w], y = b[w];
+        if (mask) { x &= mask[w]; y &= mask[w]; }
+        diff = diff || x != y;
+    }
+    if (__any(diff) && lane == 0) atomicOr(bad, 1);
+}
+
+// out[c] = rows[first_row[c]] & mask
+__global__ __launch_bounds__(256) void k_gather_rows(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
+                                                     const uint32_t *__restrict__ first_sorted, const uint32_t *__restrict__ run_sorted,
+                                                     const int64_t *__restrict__ run_count, int n_classes,
+                                                     uint64_t *__restrict__ out_bits, int64_t *__restrict__ out_count,
+                                                     int64_t *__restrict__ out_first) {
+    const int lane = threadIdx.x & 63;
+    const long c = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (c >= n_classes) return;
+    const uint64_t *src = rows + (size_t)first_sorted[c] * w64;
+    for (int w = lane; w < w64; w += 64) {
+        uint64_t x = src[w];
+        if (mask) x &= mask[w];
+        out_bits[(size_t)c * w64 + w] = x;
+    }
+    if (lane == 0) {
+        out_count[c] = run_count[run_sorted[c]];
+        out_first[c] = first_sorted[c];
+    }
+}
+
+
+extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const uint64_t *row_hash, const int64_t *row_weight,
+                                 int64_t n_rows, int32_t a_pad, const uint64_t *and_mask, void *stream) {
+    ARGCHK(out && n_rows >= 0 && a_pad > 0 && a_pad % 512 == 0);
+    ARGCHK(n_rows < (1ll << 31));
+    hipStream_t st = (hipStream_t)stream;
+    const int w64 = a_pad / 64;
+    hgx_classes *cl = new hgx_classes();
+    cl->a_pad = a_pad; cl->w64 = w64; cl->n_classes = 0; cl->c64 = 0;
+    cl->d_bits = nullptr; cl->d_count = nullptr; cl->d_first_row = nullptr; cl->d_bitsT = nullptr;
+    *out = cl;
+    if (n_rows == 0) return HGX_OK;
+    ARGCHK(rows);
+    const long n = n_rows;
+    DevBuf b_hash, b_key, b_idx0, b_idx, b_head, b_cls, b_tmp, b_bad;
+    const uint64_t *keys_in = row_hash;
+    if (!row_hash || and_mask) {   // hashes of masked rows must be recomputed
+        ALLOC(b_hash, n * 8);
+        hipLaunchKernelGGL(k_hash_rows, dim3(nblk(n, 4)), dim3(256), 0, st, rows, n, w64, and_mask, b_hash.as<uint64_t>());
+        keys_in = b_hash.as<uint64_t>();
+    }
+    ALLOC(b_key, n * 8); ALLOC(b_idx0, n * 4); ALLOC(b_idx, n * 4); ALLOC(b_head, n * 4); ALLOC(b_cls, n * 4); ALLOC(b_bad, 8);
+    hipLaunchKernelGGL(k_iota, dim3(nblk(n, 256)), dim3(256), 0, st, b_idx0.as<uint32_t>(), n);
+    size_t tmp_bytes = 0, t2 = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, b_key.as<uint64_t>(), b_idx0.as<uint32_t>(),
+                                              b_idx.as<uint32_t>(), (int)n, 0, 64, st));
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, b_head.as<uint32_t>(), b_cls.as<uint32_t>(), (int)n, st));
+    tmp_bytes = std::max(tmp_bytes, t2);
+    HIPCHK(hipcub::DeviceScan::InclusiveSum(nullptr, t2, (int64_t *)nullptr, (int64_t *)nullptr, (int)n, st));
+    tmp_bytes = std::max(tmp_bytes, t2);
+    ALLOC(b_tmp, tmp_bytes);
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tmp_bytes, keys_in, b_key.as<uint64_t>(), b_idx0.as<uint32_t>(),
+                                              b_idx.as<uint32_t>(), (int)n, 0, 64, st));
+    HIPCHK(hipMemsetAsync(b_bad.p, 0, 8, st));   // [0] collision flag, [1] n_valid
+    hipLaunchKernelGGL(k_heads, dim3(nblk(n, 256)), dim3(256), 0, st, b_key.as<uint64_t>(), n, b_head.as<uint32_t>(),
+                       b_bad.as<uint32_t>() + 1);
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_head.as<uint32_t>(), b_cls.as<uint32_t>(), (int)n, st));
+    uint32_t last_cls = 0, last_head = 0, nv32 = 0;
+    HIPCHK(hipMemcpyAsync(&last_cls, b_cls.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&last_head, b_head.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&nv32, b_bad.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int n_runs = (int)(last_cls + last_head);
+    if (n_runs == 0) return HGX_OK;
+    const long n_valid = nv32;
+    DevBuf b_rs, b_rf, b_rc, b_ws, b_w;
+    ALLOC(b_rs, (size_t)n_runs * 4); ALLOC(b_rf, (size_t)n_runs * 4); ALLOC(b_rc, (size_t)n_runs * 8);
+    hipLaunchKernelGGL(k_run_starts, dim3(nblk(n, 256)), dim3(256), 0, st, b_head.as<uint32_t>(), b_cls.as<uint32_t>(),
+                       b_idx.as<uint32_t>(), n, b_rs.as<uint32_t>(), b_rf.as<uint32_t>());
+    const int64_t *wsum = nullptr;
+    if (row_weight) {
+        ALLOC(b_w, n * 8); ALLOC(b_ws, n * 8);
+        hipLaunchKernelGGL(k_gather_weights, dim3(nblk(n, 256)), dim3(256), 0, st, row_weight, b_idx.as<uint32_t>(), n, b_w.as<int64_t>());
+        HIPCHK(hipcub::DeviceScan::InclusiveSum(b_tmp.p, tmp_bytes, b_w.as<int64_t>(), b_ws.as<int64_t>(), (int)n, st));
+        wsum = b_ws.as<int64_t>();
+    }
+    hipLaunchKernelGGL(k_run_counts, dim3(nblk(n_runs, 256)), dim3(256), 0, st, b_rs.as<uint32_t>(), n_runs, n_valid, wsum,
+                       b_rc.as<int64_t>());
+    hipLaunchKernelGGL(k_verify, dim3(nblk(n_valid, 4)), dim3(256), 0, st, rows, w64, and_mask, b_idx.as<uint32_t>(),
+                       b_cls.as<uint32_t>(), b_head.as<uint32_t>(), b_rf.as<uint32_t>(), n_valid, b_bad.as<int>());
+    // first-seen order: sort runs by their first row
+    DevBuf b_fs, b_rid0, b_rid, b_tmp2;
+    ALLOC(b_fs, (size_t)n_runs * 4); ALLOC(b_rid0, (size_t)n_runs * 4); ALLOC(b_rid, (size_t)n_runs * 4);
+    hipLaunchKernelGGL(k_iota, dim3(nblk(n_runs, 256)), dim3(256), 0, st, b_rid0.as<uint32_t>(), (long)n_runs);
+    size_t tb2 = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, b_rf.as<uint32_t>(), b_fs.as<uint32_t>(), b_rid0.as<uint32_t>(),
+                                              b_rid.as<uint32_t>(), n_runs, 0, 32, st));
+    ALLOC(b_tmp2, tb2);
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp2.p, tb2, b_rf.as<uint32_t>(), b_fs.as<uint32_t>(), b_rid0.as<uint32_t>(),
+                                              b_rid.as<uint32_t>(), n_runs, 0, 32, st));
+    cl->d_bits = (decltype(cl->d_bits))hgx_pool_alloc((size_t)n_runs * w64 * 8);
+    if (!cl->d_bits) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    cl->d_count = (decltype(cl->d_count))hgx_pool_alloc((size_t)n_runs * 8);
+    if (!cl->d_count) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    cl->d_first_row = (decltype(cl->d_first_row))hgx_pool_alloc((size_t)n_runs * 8);
+    if (!cl->d_first_row) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    hipLaunchKernelGGL(k_gather_rows, dim3(nblk(n_runs, 4)), dim3(256), 0, st, rows, w64, and_mask, b_fs.as<uint32_t>(),
+                       b_rid.as<uint32_t>(), b_rc.as<int64_t>(), n_runs, cl->d_bits, cl->d_count, cl->d_first_row);
+    int bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, b_bad.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    cl->n_classes = n_runs;
+    if (bad) {
+        hgx_set_error("64-bit class hash collision detected by the exact verify pass");
+        return HGX_ECOLLISION;
+    }
+    return HGX_OK;
+}
+
+extern "C" int hgx_classes_destroy(hgx_classes *c) {
+    if (!c) return HGX_OK;
+    hgx_pool_free(c->d_bits); hgx_pool_free(c->d_count); hgx_pool_free(c->d_first_row); hgx_pool_free(c->d_bitsT);
+    delete c;
+    return HGX_OK;
+}
+extern "C" int hgx_classes_dims(const hgx_classes *c, int32_t *n, int32_t *a_pad) {
+    ARGCHK(c);
+    if (n) *n = c->n_classes;
+    if (a_pad) *a_pad = c->a_pad;
+    return HGX_OK;
+}
+extern "C" int hgx_classes_device(const hgx_classes *c, void **bits, void **count, void **first_row) {
+    ARGCHK(c);
+    if (bits) *bits = c->d_bits;
+    if (count) *count = c->d_count;
+    if (first_row) *first_row = c->d_first_row;
+    return HGX_OK;
+}
+extern "C" int hgx_classes_to_host(const hgx_classes *c, uint64_t *bits, int64_t *count, int64_t *first_row) {
+    ARGCHK(c);
+    if (c->n_classes == 0) return HGX_OK;
+    if (bits) HIPCHK(hipMemcpy(bits, c->d_bits, (size_t)c->n_classes * c->w64 * 8, hipMemcpyDeviceToHost));
+    if (count) HIPCHK(hipMemcpy(count, c->d_count, (size_t)c->n_classes * 8, hipMemcpyDeviceToHost));
+    if (first_row) HIPCHK(hipMemcpy(first_row, c->d_first_row, (size_t)c->n_classes * 8, hipMemcpyDeviceToHost));
+    return HGX_OK;
+}
+extern "C" int hgx_classes_from_host(hgx_classes **out, const uint64_t *bits, const int64_t *count, int32_t n_classes, int32_t a_pad) {
+    ARGCHK(out && n_classes >= 0 && a_pad > 0 && a_pad % 512 == 0);
+    hgx_classes *cl = new hgx_classes();
+    cl->a_pad = a_pad; cl->w64 = a_pad / 64; cl->n_classes = n_classes; cl->c64 = 0;
+    cl->d_bits = nullptr; cl->d_count = nullptr; cl->d_first_row = nullptr; cl->d_bitsT = nullptr;
+    *out = cl;
+    if (n_classes == 0) return HGX_OK;
+    ARGCHK(bits && count);
+    cl->d_bits = (decltype(cl->d_bits))hgx_pool_alloc((size_t)n_classes * cl->w64 * 8);
+    if (!cl->d_bits) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    cl->d_count = (decltype(cl->d_count))hgx_pool_alloc((size_t)n_classes * 8);
+    if (!cl->d_count) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    cl->d_first_row = (decltype(cl->d_first_row))hgx_pool_alloc((size_t)n_classes * 8);
+    if (!cl->d_first_row) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    HIPCHK(hipMemcpy(cl->d_bits, bits, (size_t)n_classes * cl->w64 * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(cl->d_count, count, (size_t)n_classes * 8, hipMemcpyHostToDevice));
+    std::vector<int64_t> fr(n_classes);
+    for (int i = 0; i < n_classes; ++i) fr[i] = i;
+    HIPCHK(hipMemcpy(cl->d_first_row, fr.data(), (size_t)n_classes * 8, hipMemcpyHostToDevice));
+    return HGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bit-matrix transpose [C][w64] -> [a_pad][c64]: one wavefront per 64x64 tile; lane r loads row r's
+// word, then 64 ballots peel the columns.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_transpose(const uint64_t *__restrict__ bits, int n_classes, int w64, int c64,
+                                                   uint64_t *__restrict__ bitsT) {
+    const int lane = threadIdx.x & 63;
+    const long tile = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long n_tiles = (long)c64 * w64;
+    if (tile >= n_tiles) return;
+    const int cw = (int)(tile / w64), aw = (int)(tile % w64);
+    const int c = cw * 64 + lane;
+    const uint64_t x = (c < n_classes) ? bits[(size_t)c * w64 + aw] : 0ull;
+    uint64_t mine = 0;
+#pragma unroll 8
+    for (int b = 0; b < 64; ++b) {
+        const uint64_t col = __ballot((x >> b) & 1ull);
+        if (lane == b) mine = col;
+    }
+    bitsT[(size_t)(aw * 64 + lane) * c64 + cw] = mine;
+}
+
+int hgx_ensure_transposed(hgx_classes *c, hipStream_t st) {
+    if (c->d_bitsT || c->n_classes == 0) return HGX_OK;
+    c->c64 = ((c->n_classes + 63) / 64 + 7) / 8 * 8;   // row stride of the transposed matrix: multiple of 8 words, zero padded
+    c->d_bitsT = (decltype(c->d_bitsT))hgx_pool_alloc((size_t)c->a_pad * c->c64 * 8);
+    if (!c->d_bitsT) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    const long tiles = (long)c->c64 * c->w64;
+    hipLaunchKernelGGL(k_transpose, dim3(nblk(tiles, 4)), dim3(256), 0, st, c->d_bits, c->n_classes, c->w64, c->c64, c->d_bitsT);
+    HIPCHK(hipGetLastError());
+    return HGX_OK;
+}
+

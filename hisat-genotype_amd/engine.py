@@ -123,5 +123,7 @@ class _RawDev:
 def em_order(first_class, name_rank, present):
     """Insertion order of the EM's dict (common:1300-1305): alleles by (first class containing them,
     position inside that class' sorted key)."""
-    idx = [a for a in range(len(present)) if present[a]]
-    return sorted(idx, key=lambda a: (first_class[a], name_rank[a]))
+    idx = np.nonzero(np.asarray(present))[0]
+    fc = np.asarray(first_class)[idx]
+    nr = np.asarray(name_rank)[idx]
+    return idx[np.lexsort((nr, fc))].tolist()

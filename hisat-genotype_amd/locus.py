@@ -161,6 +161,8 @@ class PackedLocus:
 
     def rep_groups(self):
         """allele_rep_groups (core:86-115) as {rep index: [member indices in first-met order]}."""
+        if getattr(self, "_rep_groups", None) is not None:
+            return self._rep_groups
         rep = self.tables()["rep_of"]
         groups = {}
         # members are listed in the order get_rep_alleles met them = order of first appearance scanning Links;
@@ -168,6 +170,7 @@ class PackedLocus:
         for a, r in enumerate(rep):
             if r >= 0:
                 groups.setdefault(int(r), []).append(a)
+        self._rep_groups = groups
         return groups
 
     def index(self):

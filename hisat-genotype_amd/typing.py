@@ -107,10 +107,13 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
     cnt, first = gcl.allele_counts()
     fr = np.zeros(gcl.n_classes, np.int64)                     # first pair of every class
     capi.check(capi.lib().hgx_classes_to_host(gcl.h, None, None, capi.ptr(fr)))
-    counted = [a for a in range(A) if cnt[a] > 0]
-    counted.sort(key=lambda a: (fr[first[a]], a))               # dict insertion order of Gene_counts
-    counted.sort(key=lambda a: -cnt[a])                          # stable, descending
-    res.counts_sorted = [[names[a], int(cnt[a])] for a in counted]
+    cnt_a, first_a = cnt[:A], first[:A]
+    counted = np.nonzero(cnt_a > 0)[0]
+    # dict insertion order of Gene_counts = (first pair that counted the allele, Gene_names order); then the
+    # reference's stable descending sort on the count (core:1650-1651)
+    ins = fr[first_a[counted]]
+    counted = counted[np.lexsort((counted, ins, -cnt_a[counted]))]
+    res.counts_sorted = [[names[a], int(cnt_a[a])] for a in counted]
     if keep_classes:
         res.gene_classes = gcl.to_host()[:2]
 

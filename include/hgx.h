@@ -56,6 +56,8 @@ int hgx_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stre
 int hgx_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);
 int hgx_memset(void *dev_dst, int value, size_t bytes, void *stream);
 int hgx_stream_sync(void *stream);
+/* the library caches device scratch allocations between calls; this returns them to the driver */
+int hgx_pool_trim(void);
 /* HIP events on a stream, for timing individual kernels from a ctypes caller */
 int hgx_event_create(void **event);
 int hgx_event_destroy(void *event);
@@ -67,7 +69,7 @@ int hgx_event_elapsed_ms(void *start_event, void *stop_event, float *ms);   /* s
  * Alleles are Gene_names[gene] minus the backbone, in that order (index 0..n_alleles-1);
  * variants are gene_var_list order (sorted by position).  link_bits is word-major:
  * link_bits[w * a_pad + a] bit (v & 31) of word w = v >> 5 is set iff allele a carries
- * variant v (Links[var_id] contains the allele).  a_pad = n_alleles rounded up to 256
+ * variant v (Links[var_id] contains the allele).  a_pad = n_alleles rounded up to 512
  * (use hgx_a_pad()).                                                                     */
 typedef struct hgx_index hgx_index;
 

@@ -27,7 +27,7 @@ def test_version_and_error_string():
     lib = capi.lib()
     assert lib.hgx_version() >= 100
     assert isinstance(lib.hgx_last_error(), bytes)
-    assert capi.a_pad(7000) == 7168 and capi.a_pad(256) == 256 and capi.a_pad(1) == 256
+    assert capi.a_pad(7000) == 7168 and capi.a_pad(512) == 512 and capi.a_pad(1) == 512
 
 
 def test_invalid_arguments_are_reported_not_crashed():
