@@ -30,6 +30,11 @@ __global__ __launch_bounds__(256) void k_hash_rows(const uint64_t *__restrict__ 
     if (lane == 0) hash[row] = finish_hash(h, any_nz);
 }
 
+__global__ void k_pack_meta(const uint32_t *last_cls, const uint32_t *last_head, uint32_t *meta) {
+    meta[2] = *last_cls;
+    meta[3] = *last_head;
+}
+
 __global__ void k_iota(uint32_t *v, long n) {
     long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = (uint32_t)i;
@@ -131,7 +136,7 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
         hipLaunchKernelGGL(k_hash_rows, dim3(nblk(n, 4)), dim3(256), 0, st, rows, n, w64, and_mask, b_hash.as<uint64_t>());
         keys_in = b_hash.as<uint64_t>();
     }
-    ALLOC(b_key, n * 8); ALLOC(b_idx0, n * 4); ALLOC(b_idx, n * 4); ALLOC(b_head, n * 4); ALLOC(b_cls, n * 4); ALLOC(b_bad, 8);
+    ALLOC(b_key, n * 8); ALLOC(b_idx0, n * 4); ALLOC(b_idx, n * 4); ALLOC(b_head, n * 4); ALLOC(b_cls, n * 4); ALLOC(b_bad, 16);
     hipLaunchKernelGGL(k_iota, dim3(nblk(n, 256)), dim3(256), 0, st, b_idx0.as<uint32_t>(), n);
     size_t tmp_bytes = 0, t2 = 0;
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, b_key.as<uint64_t>(), b_idx0.as<uint32_t>(),
@@ -143,15 +148,17 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
     ALLOC(b_tmp, tmp_bytes);
     HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tmp_bytes, keys_in, b_key.as<uint64_t>(), b_idx0.as<uint32_t>(),
                                               b_idx.as<uint32_t>(), (int)n, 0, 64, st));
-    HIPCHK(hipMemsetAsync(b_bad.p, 0, 8, st));   // [0] collision flag, [1] n_valid
+    HIPCHK(hipMemsetAsync(b_bad.p, 0, 16, st));   // [0] collision flag, [1] n_valid, [2] last scan value, [3] last head
     hipLaunchKernelGGL(k_heads, dim3(nblk(n, 256)), dim3(256), 0, st, b_key.as<uint64_t>(), n, b_head.as<uint32_t>(),
                        b_bad.as<uint32_t>() + 1);
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_head.as<uint32_t>(), b_cls.as<uint32_t>(), (int)n, st));
-    uint32_t last_cls = 0, last_head = 0, nv32 = 0;
-    HIPCHK(hipMemcpyAsync(&last_cls, b_cls.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&last_head, b_head.as<uint32_t>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&nv32, b_bad.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, st));
+    // one small D2H: [flag, n_valid, last exclusive-scan value, last head flag]
+    hipLaunchKernelGGL(k_pack_meta, dim3(1), dim3(1), 0, st, b_cls.as<uint32_t>() + (n - 1), b_head.as<uint32_t>() + (n - 1),
+                       b_bad.as<uint32_t>());
+    uint32_t meta[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(meta, b_bad.p, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const uint32_t last_cls = meta[2], last_head = meta[3], nv32 = meta[1];
     const int n_runs = (int)(last_cls + last_head);
     if (n_runs == 0) return HGX_OK;
     const long n_valid = nv32;

@@ -191,7 +191,8 @@ extern "C" int hgx_index_device_bits(const hgx_index *ix, void **p, size_t *byte
 // ------------------------------------------------------------------------------------------------
 // 8a-5 stage 1: piece x allele compatibility.  compat(a) <=> AND_i ((bits[lo+i][a] & MP_i) == P_i)
 // One wavefront per (piece, 16 x 64 alleles): lane = allele, masks are wave-uniform (SGPRs), each
-// word row is a 256-byte coalesced load, the 64 verdicts leave as one __ballot word.
+// word row is a 256-byte coalesced load, the 64 verdicts leave as one __ballot word.  Any piece order is
+// correct; tables sorted by lo_word (as the front-end emits them) get L1 reuse of the index rows.
 // ------------------------------------------------------------------------------------------------
 #define PC_GROUPS 16
 __global__ __launch_bounds__(256) void k_piece_compat(const uint32_t *__restrict__ bits, int a_pad,
@@ -200,9 +201,11 @@ __global__ __launch_bounds__(256) void k_piece_compat(const uint32_t *__restrict
                                                       uint64_t *__restrict__ compat, int w64, int chunks) {
     const int lane = threadIdx.x & 63;
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int piece = (int)(wave / chunks);
-    const int chunk = (int)(wave % chunks);
-    if (piece >= n_pieces) return;
+    // chunk-major: consecutive waves score consecutive pieces (the front-end sorts the table by lo_word) against the
+    // SAME 1024-allele column block, so a CU's L1 keeps serving the few index rows they share
+    const int chunk = (int)(wave / n_pieces);
+    const int piece = (int)(wave % n_pieces);
+    if (chunk >= chunks) return;
     const hgx_piece pc = pieces[piece];
     const int lo = __builtin_amdgcn_readfirstlane((int)pc.lo_word);
     const int nw = __builtin_amdgcn_readfirstlane((int)pc.n_words);
@@ -255,13 +258,25 @@ __device__ __forceinline__ void class_for_level(const uint64_t *__restrict__ com
     for (int k = 0; k < NP; ++k)
 #pragma unroll
         for (int s = 0; s < KW; ++s) plane[k][s] = 0;
-    for (int r = r0; r < r1; ++r) {
-        const uint32_t ref = __builtin_amdgcn_readfirstlane(refs[r]);
-        if ((ref >> 31) != level) continue;
-        const uint64_t *row = compat + (size_t)(ref & 0x7fffffffu) * w64;
+    // software pipeline: the next matching ref's row is in flight while the current one is added
+    auto next_ref = [&](int r) {
+        while (r < r1 && ((uint32_t)__builtin_amdgcn_readfirstlane(refs[r]) >> 31) != level) ++r;
+        return r;
+    };
+    auto load_row = [&](int r, uint64_t (&x)[KW]) {
+        const uint64_t *row = compat + (size_t)((uint32_t)__builtin_amdgcn_readfirstlane(refs[r]) & 0x7fffffffu) * w64;
+#pragma unroll
+        for (int s = 0; s < KW; ++s) x[s] = (lane + 64 * s < w64) ? row[lane + 64 * s] : 0ull;
+    };
+    uint64_t cur[KW], nxt[KW];
+    int r = next_ref(r0);
+    if (r < r1) load_row(r, cur);
+    while (r < r1) {
+        const int rn = next_ref(r + 1);
+        if (rn < r1) load_row(rn, nxt);
         uint64_t carry[KW];
 #pragma unroll
-        for (int s = 0; s < KW; ++s) carry[s] = (lane + 64 * s < w64) ? row[lane + 64 * s] : 0ull;
+        for (int s = 0; s < KW; ++s) carry[s] = cur[s];
 #pragma unroll
         for (int k = 0; k < NP; ++k)
 #pragma unroll
@@ -270,6 +285,9 @@ __device__ __forceinline__ void class_for_level(const uint64_t *__restrict__ com
                 plane[k][s] ^= carry[s];
                 carry[s] = t;
             }
+#pragma unroll
+        for (int s = 0; s < KW; ++s) cur[s] = nxt[s];
+        r = rn;
     }
     uint64_t cand[KW];
 #pragma unroll

@@ -29,6 +29,8 @@ enum {
     S_KEYERR = 3,
     S_DONE = 4,
     S_ITER = 5,
+    S_NROWS = 6,     // rows passes that really ran (not gated / past convergence)
+    S_NCOLS = 7,
     S_N = 8
 };
 
@@ -151,7 +153,8 @@ __global__ __launch_bounds__(BLOCK) void k_bitmatvec(const uint64_t *__restrict_
         for (int e = tid; e < n_k; e += BLOCK) if (vec_pres[e]) s += vec[e];
         tot = block_sum(s, sh);
     }
-    if (MODE == MODE_ROWS && blockIdx.x == 0 && tid == 0) scal[S_TOT_A] = tot;
+    if (MODE == MODE_ROWS && blockIdx.x == 0 && tid == 0) { scal[S_TOT_A] = tot; scal[S_NROWS] += 1.0; }
+    if (MODE == MODE_COLS && blockIdx.x == 0 && tid == 0) scal[S_NCOLS] += 1.0;
     if (MODE == MODE_COLS) tot = scal[S_TOT_A];
     __syncthreads();
     // Wave w owns KPT consecutive 64-bit words of every row chunk (elements 64*(KPT*w + k) + lane), fetched with
@@ -363,7 +366,29 @@ __global__ void k_counts_out(const double *__restrict__ sum, const double *__res
     out_first[a] = first[a] < 1e300 ? (int32_t)first[a] : -1;
 }
 
+// Per-kernel timing for bench.py's roofline object.  When enabled (hgx_em_set_timing) every bit-mat-vec launch of
+// hgx_em is bracketed by HIP events on its stream; totals accumulate per kernel instantiation until reset.
+struct PassStats { double ms = 0; int64_t launches = 0, executed = 0, bytes = 0; };
+thread_local PassStats g_stats[4];   // [0] <8,ROWS> [1] <16,ROWS> [2] <8,COLS> [3] <16,COLS>
+thread_local int g_timing = 0;
+struct Timed { hipEvent_t a, b; int slot; };
+
 }   // namespace
+
+extern "C" int hgx_em_set_timing(int on) {
+    g_timing = on;
+    for (auto &s : g_stats) s = PassStats();
+    return HGX_OK;
+}
+// slot: 0 <8,ROWS>, 1 <16,ROWS>, 2 <8,COLS>, 3 <16,COLS>
+extern "C" int hgx_em_get_timing(int slot, double *ms_total, int64_t *launches, int64_t *executed, int64_t *bytes_total) {
+    ARGCHK(slot >= 0 && slot < 4);
+    if (ms_total) *ms_total = g_stats[slot].ms;
+    if (launches) *launches = g_stats[slot].launches;
+    if (executed) *executed = g_stats[slot].executed;
+    if (bytes_total) *bytes_total = g_stats[slot].bytes;
+    return HGX_OK;
+}
 
 extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len,
                       double *prob_host, int32_t *n_iter_host, void *stream) {
@@ -397,11 +422,29 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
     const MatVec rows{c->d_bits, C, c->w64, A};
     const MatVec cols{c->d_bitsT, A, c->c64, C};
 
+    std::vector<Timed> timed;
+    const int slot_rows = A <= 8 * BLOCK ? 0 : 1, slot_cols = C <= 8 * BLOCK ? 2 : 3;
+    auto stamp = [&](int slot, bool begin) {
+        if (!g_timing) return;
+        if (begin) {
+            Timed t;
+            (void)hipEventCreate(&t.a);
+            (void)hipEventCreate(&t.b);
+            t.slot = slot;
+            (void)hipEventRecord(t.a, st);
+            timed.push_back(t);
+        } else (void)hipEventRecord(timed.back().b, st);
+    };
     // one application of the EM map: (vec, pres_v) -> (q_out, pres_out)
     auto next_prob = [&](const double *vec, const uint8_t *pres_v, int x_mode, double *q_out, uint8_t *pres_out, int gate) -> int {
+        stamp(slot_rows, true);
         int r = launch_matvec<MODE_ROWS>(rows, st, vec, pres_v, x_mode, c->d_count, nullptr, nullptr, nullptr, wc, nullptr, scal, gate);
+        stamp(slot_rows, false);
         if (r) return r;
-        return launch_matvec<MODE_COLS>(cols, st, wc, nullptr, x_mode == 2 ? 2 : 0, nullptr, vec, pres_v, d_len, q_out, pres_out, scal, gate);
+        stamp(slot_cols, true);
+        r = launch_matvec<MODE_COLS>(cols, st, wc, nullptr, x_mode == 2 ? 2 : 0, nullptr, vec, pres_v, d_len, q_out, pres_out, scal, gate);
+        stamp(slot_cols, false);
+        return r;
     };
     // initial mass sum_c n_c / |S_c|, normalised (common:1299-1309)
     rc = next_prob(p, pr, 2, p, pr, 0);
@@ -420,6 +463,22 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         HIPCHK(hipMemcpyAsync(h_scal, scal, S_N * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (h_scal[S_DONE] != 0.0) break;
+    }
+    if (g_timing) {
+        const int64_t rows_bytes = (int64_t)C * c->w64 * 8 + (int64_t)A * 9 + (int64_t)C * 16;
+        const int64_t cols_bytes = (int64_t)A * c->c64 * 8 + (int64_t)C * 8 + (int64_t)A * 26;
+        for (auto &t : timed) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, t.a, t.b);
+            g_stats[t.slot].ms += ms;
+            g_stats[t.slot].launches += 1;
+            (void)hipEventDestroy(t.a);
+            (void)hipEventDestroy(t.b);
+        }
+        g_stats[slot_rows].executed += (int64_t)h_scal[S_NROWS];
+        g_stats[slot_rows].bytes += (int64_t)h_scal[S_NROWS] * rows_bytes;
+        g_stats[slot_cols].executed += (int64_t)h_scal[S_NCOLS];
+        g_stats[slot_cols].bytes += (int64_t)h_scal[S_NCOLS] * cols_bytes;
     }
     if (h_scal[S_KEYERR] != 0.0) {
         hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");

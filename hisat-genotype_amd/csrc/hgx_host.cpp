@@ -215,6 +215,32 @@ int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &L, int32_t left, int32_t
     return id;
 }
 
+// Order the distinct-piece table by first covered word (then width) and renumber the refs: consecutive pieces then
+// share an index window, which is what the LDS-tiled compatibility kernel exploits.  Masks are re-packed in the same order.
+void hgx_finalize_batch(hgx_batch &b) {
+    const size_t n = b.pieces.size();
+    std::vector<uint32_t> order(n), new_id(n);
+    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        if (b.pieces[x].lo_word != b.pieces[y].lo_word) return b.pieces[x].lo_word < b.pieces[y].lo_word;
+        return b.pieces[x].n_words < b.pieces[y].n_words;
+    });
+    std::vector<hgx_piece> np(n);
+    std::vector<uint32_t> nm;
+    nm.reserve(b.masks.size());
+    for (size_t k = 0; k < n; ++k) {
+        const hgx_piece &src = b.pieces[order[k]];
+        new_id[order[k]] = (uint32_t)k;
+        np[k] = src;
+        np[k].mask_off = (uint32_t)nm.size();
+        nm.insert(nm.end(), b.masks.begin() + src.mask_off, b.masks.begin() + src.mask_off + 2 * (size_t)src.n_words);
+    }
+    b.pieces.swap(np);
+    b.masks.swap(nm);
+    for (auto &r : b.pair_ref) r = (r & 0x80000000u) | new_id[r & 0x7fffffffu];
+    b.lookup.clear();
+}
+
 extern "C" int hgx_batch_from_haplotypes(hgx_batch **out, const hgx_locus *L, int32_t n_pairs, const int32_t *pair_off,
                                          const uint8_t *level, const int32_t *left, const int32_t *right,
                                          const int32_t *id_off, const int32_t *ids) {
@@ -240,6 +266,7 @@ extern "C" int hgx_batch_from_haplotypes(hgx_batch **out, const hgx_locus *L, in
         }
         b->pair_off.push_back((int32_t)b->pair_ref.size());
     }
+    hgx_finalize_batch(*b);
     *out = b;
     return HGX_OK;
 }

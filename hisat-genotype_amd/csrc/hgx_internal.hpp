@@ -101,5 +101,6 @@ struct hgx_batch {
 
 // piece "left-ids-right" -> index of the distinct piece in the batch (creates it if new). < 0 on error.
 int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &loc, int32_t left, int32_t right, const int32_t *ids, int32_t n_ids);
+void hgx_finalize_batch(hgx_batch &b);
 // alternatives tables (defined in hgx_sam.cpp)
 int hgx_build_alternatives(hgx_locus &loc);

@@ -1043,6 +1043,7 @@ extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *s
             have_prev = true;
         }
         if (have_prev) P.flush(hts);
+        hgx_finalize_batch(*B);
     } catch (const RefError &e) {
         hgx_set_error("the reference would fail on this input: %s", e.what());
         delete B;

@@ -127,3 +127,17 @@ def em_order(first_class, name_rank, present):
     fc = np.asarray(first_class)[idx]
     nr = np.asarray(name_rank)[idx]
     return idx[np.lexsort((nr, fc))].tolist()
+
+
+def em_set_timing(on):
+    capi.check(capi.lib().hgx_em_set_timing(C.c_int(1 if on else 0)))
+
+
+def em_get_timing():
+    """{kernel name: (ms_total, launches, executed, bytes_total)} accumulated since em_set_timing(True)."""
+    out = {}
+    for slot, name in enumerate(("k_bitmatvec<8,ROWS>", "k_bitmatvec<16,ROWS>", "k_bitmatvec<8,COLS>", "k_bitmatvec<16,COLS>")):
+        ms, n, ex, by = C.c_double(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        capi.check(capi.lib().hgx_em_get_timing(C.c_int(slot), C.byref(ms), C.byref(n), C.byref(ex), C.byref(by)))
+        out[name] = (ms.value, n.value, ex.value, by.value)
+    return out

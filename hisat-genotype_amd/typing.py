@@ -73,13 +73,22 @@ def single_abundance(Gene_cmpt, remove_low_abundance_allele=False, Gene_length={
 class LocusResult:
     def __init__(self):
         self.num_reads = self.num_pairs = 0
-        self.counts_sorted = []     # [[allele name, count]] (core:1650-1651)
+        self._names = None
+        self.counts_order = None    # allele indices ranked like the reference's sorted Gene_counts (core:1650-1651)
+        self.counts = None          # Gene_counts per allele index
         self.exon_classes = None    # (bits[C][w64], counts[C]) host copies, first-seen order
         self.gene_classes = None
         self.em = []                # [{'n_classes', 'remove_low', 'use_length', 'result', 'n_iter'}]
         self.gene_prob = []         # final [[allele name, prob]] (core:1732-1789)
         self.n_pieces = self.n_refs = 0
         self.t_em = 0.0             # seconds spent inside the EM calls (bench)
+
+    @property
+    def counts_sorted(self):
+        """[[allele name, count]] in the reference's print order (materialised on demand)."""
+        if self.counts_order is None:
+            return []
+        return [[self._names[a], int(self.counts[a])] for a in self.counts_order]
 
 
 def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discordant=False,
@@ -113,7 +122,7 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
     # reference's stable descending sort on the count (core:1650-1651)
     ins = fr[first_a[counted]]
     counted = counted[np.lexsort((counted, ins, -cnt_a[counted]))]
-    res.counts_sorted = [[names[a], int(cnt_a[a])] for a in counted]
+    res._names, res.counts_order, res.counts = names, counted, cnt_a
     if keep_classes:
         res.gene_classes = gcl.to_host()[:2]
 

@@ -107,7 +107,8 @@ typedef struct hgx_piece {
     uint8_t  reserved;
 } hgx_piece;
 
-/* stage 1: compat_dev[piece][a_pad/64] = bitset of alleles compatible with each distinct piece */
+/* stage 1: compat_dev[piece][a_pad/64] = bitset of alleles compatible with each distinct piece.  Any piece order
+ * is correct; tables sorted by lo_word (hgx_parse_sam / hgx_batch_from_haplotypes emit them so) run fastest. */
 int hgx_piece_compat(const hgx_index *ix, const hgx_piece *pieces_dev, const uint32_t *masks_dev,
                      int32_t n_pieces, uint64_t *compat_dev, void *stream);
 
@@ -242,6 +243,13 @@ int hgx_parse_sam(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t
 int hgx_batch_trace_text(const hgx_batch *b, char *buf, size_t cap, size_t *needed);
 /* pileup nt_set per backbone position as a 4-bit mask A=1,C=2,G=4,T=8 and counts[L][6] (A,C,G,T,N,D) */
 int hgx_batch_pileup(const hgx_batch *b, uint8_t *nt_set, uint32_t *counts);
+
+/* Kernel timing for roofline reports.  hgx_em_set_timing(1) makes hgx_em bracket every bit-mat-vec launch with HIP
+ * events on its stream and (re)starts the per-thread totals; slot 0 = k_bitmatvec<8,ROWS>, 1 = <16,ROWS>, 2 = <8,COLS>,
+ * 3 = <16,COLS>.  `executed` counts the launches that did work (not gated / past convergence) and bytes_total their
+ * algorithmic bytes (bit matrix once + dense vectors).                                                              */
+int hgx_em_set_timing(int on);
+int hgx_em_get_timing(int slot, double *ms_total, int64_t *launches, int64_t *executed, int64_t *bytes_total);
 
 #ifdef __cplusplus
 }

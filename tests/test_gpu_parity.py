@@ -174,3 +174,45 @@ def test_random_pieces_large(orc):
                 assert abs(prob[a] - exp[a]) <= 1e-9
             else:
                 assert prob[a] == -1.0
+
+
+@pytest.mark.parametrize("name", ["hla_7000", "codis_like"])
+def test_piece_compat_any_piece_order(orc, name):
+    """Stage 1 is order independent: a shuffled piece table gives the same rows (permuted)."""
+    import ctypes as C
+    from hisatgenotype_amd import capi
+    fx, loc, t, pl, batch, _ = _setup(orc, name)
+    L = capi.lib()
+    assert np.all(np.diff(batch.pieces["lo_word"].astype(np.int64)) >= 0)      # the front-end emits window-sorted tables
+    d_masks = engine.DevArray.from_host(batch.masks)
+    perm = np.random.RandomState(1).permutation(batch.n_pieces)
+    out = []
+    for pieces in (batch.pieces, batch.pieces[perm]):
+        d_p = engine.DevArray.from_host(np.ascontiguousarray(pieces))
+        a = engine.DevArray((batch.n_pieces, pl.w64), np.uint64)
+        capi.check(L.hgx_piece_compat(pl.index(), capi.ptr(d_p), capi.ptr(d_masks), C.c_int32(batch.n_pieces), capi.ptr(a), None))
+        out.append(a.to_host())
+    assert np.array_equal(out[0][perm], out[1])
+
+
+def test_empty_and_degenerate_inputs(orc):
+    """Zero pairs, pairs without pieces, and a locus whose exon level has no representatives."""
+    from hisatgenotype_amd import synth
+    loc = synth.make_hla_like_locus(n_alleles=70, n_vars=90, seed=4)
+    pl = hl.PackedLocus.from_synth(loc)
+    empty = pl.batch_from_haplotypes(np.zeros(1, np.int32), [], [], [], np.zeros(1, np.int32), [])
+    assert empty.n_pairs == 0
+    cl = engine.Classes.dedup(engine.DevArray((1, pl.w64), np.uint64), 0, pl.a_pad)
+    assert cl.n_classes == 0
+    prob, it = cl.em(pl.n_alleles)
+    assert it == 0 and np.all(prob == -1.0)
+    # three pairs with no piece at all: every level's class is its whole allele mask (quirk Q4)
+    b = pl.batch_from_haplotypes(np.zeros(4, np.int32), [], [], [], np.zeros(1, np.int32), [])
+    db = engine.DeviceBatch(b)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    t = pl.tables()
+    assert np.array_equal(bufs.gene_bits.to_host(), np.tile(t["gene_mask"], (3, 1)))
+    assert np.array_equal(bufs.exon_bits.to_host(), np.tile(t["exon_mask"], (3, 1)))
+    gcl = engine.Classes.dedup(bufs.gene_bits, 3, pl.a_pad, hashes=bufs.gene_hash)
+    assert gcl.n_classes == 1 and gcl.to_host()[1][0] == 3
