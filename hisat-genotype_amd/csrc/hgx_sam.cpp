@@ -14,6 +14,7 @@
 // Variant ids are integers: [0,V) known ("hv*"), V+k the k-th novel variant ("nv<k>"), -1 "unknown".
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <set>
 #include <stdexcept>
@@ -753,7 +754,25 @@ struct Parser {
     }
 
     // ---- pair flush (core:1238-1291): haplotypes -> piece refs --------------------------------------------
-    void flush(std::set<Ht> &hts) {
+    // choose_pairs (core:680-716): keep the mate haplotype pairs whose inner distance is closest to the expected one
+    static void choose_pairs(std::set<Ht> &lh, std::set<Ht> &rh, long expected) {
+        if (lh.empty() || rh.empty() || std::max(lh.size(), rh.size()) < 2) return;
+        long best = -1;
+        std::set<Ht> nl, nr;
+        for (const Ht &l : lh)
+            for (const Ht &r : rh) {
+                const long inter = l.right < r.right ? (long)r.left - l.right - 1 : (long)l.left - r.right - 1;
+                const long cur = std::labs(expected - inter);
+                if (best < 0 || cur < best) { best = cur; nl.clear(); nr.clear(); }
+                if (cur == best) { nl.insert(l); nr.insert(r); }
+            }
+        lh.swap(nl);
+        rh.swap(nr);
+    }
+
+    void flush(const std::set<Ht> &lh, const std::set<Ht> &rh) {
+        std::set<Ht> hts(lh);
+        hts.insert(rh.begin(), rh.end());
         std::vector<Ht> ex;
         std::vector<int32_t> ids;
         std::vector<uint32_t> exon_refs, gene_refs;
@@ -786,7 +805,7 @@ struct Fields {
     const char *cigar;
     const char *seq; size_t seq_len;
     const char *zs, *md;
-    bool has_nm, has_nh;
+    bool has_nm, has_nh, yt_cp;
     long nm, nh;
 };
 
@@ -796,7 +815,7 @@ static bool split_line(char *line, char *end, Fields &f) {
     int nc = 0;
     char *p = line;
     f.zs = f.md = nullptr;
-    f.has_nm = f.has_nh = false;
+    f.has_nm = f.has_nh = f.yt_cp = false;
     f.nm = f.nh = 0;
     while (p < end) {
         while (p < end && (*p == '\t' || *p == ' ' || *p == '\r')) ++p;
@@ -810,6 +829,7 @@ static bool split_line(char *line, char *end, Fields &f) {
             else if (tok[0] == 'M' && tok[1] == 'D') f.md = tok + 5;
             else if (tok[0] == 'N' && tok[1] == 'M') { f.has_nm = true; f.nm = strtol(tok + 5, nullptr, 10); }
             else if (tok[0] == 'N' && tok[1] == 'H') { f.has_nh = true; f.nh = strtol(tok + 5, nullptr, 10); }
+            else if (tok[0] == 'Y' && tok[1] == 'T') f.yt_cp = strcmp(tok + 5, "CP") == 0;
         }
     }
     if (nc < 11) return false;
@@ -956,7 +976,7 @@ extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *s
         // pass 2: the streaming loop
         Parser P(L, *opts, *B);
         std::unordered_set<std::string> seen_l, seen_r, seen_u;
-        std::set<Ht> hts;   // left | right positive haplotypes of the current pair (set union, core:1250-1251)
+        std::set<Ht> lhts, rhts;   // left / right positive haplotypes of the current pair (united at the flush, core:1250-1251)
         std::string prev_id;
         bool have_prev = false;
         std::vector<Cmp> cl, c2;
@@ -991,8 +1011,9 @@ extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *s
             if (!P.decode(pos, f.cigar, read, f.zs, f.md, cl)) continue;
             B->n_reads++;
             if (!have_prev || read_id != prev_id) {
-                if (have_prev) P.flush(hts);
-                hts.clear();
+                if (have_prev) P.flush(lhts, rhts);
+                lhts.clear();
+                rhts.clear();
             }
             // cmp_list2 (core:1351-1368)
             c2.clear();
@@ -1018,7 +1039,7 @@ extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *s
                     h.ids = l.ids;
                     h.ids.insert(h.ids.end(), mid.begin(), mid.end());
                     h.ids.insert(h.ids.end(), r.ids.begin(), r.ids.end());
-                    hts.insert(std::move(h));
+                    (is_left ? lhts : rhts).insert(std::move(h));
                 }
             if (opts->keep_trace) {
                 std::string t;
@@ -1042,7 +1063,47 @@ extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *s
             prev_id = read_id;
             have_prev = true;
         }
-        if (have_prev) P.flush(hts);
+        if (have_prev) {
+            if (opts->codis_choose_pairs) {                         // core:1547-1552 (CODIS locus D18S51 only)
+                // get_pair_interdist (common:1187-1265): median inner distance of unique concordant pairs
+                std::vector<long> dists;
+                std::string prev;
+                bool hp = false;
+                std::vector<std::pair<long, long>> rd;
+                for (size_t i = 0; i < recs.size(); ++i) {
+                    if (!ok[i]) continue;
+                    const Fields &f = recs[i];
+                    if (f.flag & 0x4) continue;
+                    size_t idlen = f.qname_len;
+                    if (opts->simulation) {
+                        const char *bar = (const char *)memchr(f.qname, '|', f.qname_len);
+                        if (bar) idlen = bar - f.qname;
+                    }
+                    if (!f.has_nh || f.nh > 1 || !f.yt_cp) continue;
+                    std::string id(f.qname, idlen);
+                    if (hp && id != prev) {
+                        if (rd.size() == 2)
+                            dists.push_back(rd[0].first <= rd[1].first ? rd[1].first - rd[0].second - 1 : rd[0].first - rd[1].second - 1);
+                        rd.clear();
+                    }
+                    long right = f.pos;
+                    for (const char *p = f.cigar; *p;) {
+                        char *e;
+                        const long n = strtol(p, &e, 10);
+                        if (e == p || !*e) break;
+                        if (*e == 'M' || *e == 'N' || *e == 'D') right += n;
+                        p = e + 1;
+                    }
+                    rd.push_back({(long)f.pos, right - 1});
+                    prev = id;
+                    hp = true;
+                }
+                std::sort(dists.begin(), dists.end());
+                const long expected = dists.empty() ? -1 : dists[dists.size() / 2];
+                Parser::choose_pairs(lhts, rhts, expected);
+            }
+            P.flush(lhts, rhts);
+        }
         hgx_finalize_batch(*B);
     } catch (const RefError &e) {
         hgx_set_error("the reference would fail on this input: %s", e.what());

@@ -147,7 +147,7 @@ def make_hla_like_locus(gene: str = "A", n_alleles: int = 7000, length: int = 35
                         seed: int = 101, sibling_frac: float = 0.35, deletion_frac: float = 0.07,
                         multi_allelic_frac: float = 0.03, n_backbone_equal: int = 1,
                         exons=None, primary_exons=None, var_id_base: int = 0,
-                        unlinked_vars: int = 0) -> Locus:
+                        unlinked_vars: int = 0, insertion_frac: float = 0.0) -> Locus:
     """HLA-A-like locus following SURVEY.md section 8d: ``n_vars`` sites in [30, L-30),
     93 % single / 7 % short deletions, carrier spectrum 70 % U[1,3], 20 % U[4,50],
     10 % U[2 %, 30 %] of the alleles; ``sibling_frac`` of the alleles are intron-only
@@ -181,7 +181,11 @@ def make_hla_like_locus(gene: str = "A", n_alleles: int = 7000, length: int = 35
     for p in sites:
         if p in blocked:
             continue
-        if rng.random() < deletion_frac:
+        if insertion_frac > 0 and rng.random() < insertion_frac:
+            raw.append((p, "insertion", "".join(rng.choice(_BASES) for _ in range(rng.randint(1, 3)))))
+            blocked.add(p)
+            blocked.add(p + 1)
+        elif rng.random() < deletion_frac:
             dl = rng.randint(1, 4)
             if any((p + k) in blocked for k in range(dl)) or p + dl >= hi:
                 dl = 1
@@ -202,6 +206,9 @@ def make_hla_like_locus(gene: str = "A", n_alleles: int = 7000, length: int = 35
             for k in range(int(d)):
                 del_cover.add(p + k)
     raw = [(p, t, d) for (p, t, d) in raw if t == "deletion" or p not in del_cover]
+    # no insertion directly behind a deletion's last base (would give adjacent D and I ops)
+    del_next = set(p + int(d) for p, t, d in raw if t == "deletion")
+    raw = [(p, t, d) for (p, t, d) in raw if not (t == "insertion" and (p in del_next or p in del_cover))]
     order = {"insertion": 0, "single": 1, "deletion": 2}
     raw.sort(key=lambda x: (x[0], order[x[1]], x[2]))
 
@@ -337,6 +344,7 @@ class AlleleMap:
         bpos: List[int] = []
         vid: List[int] = []
         dels: Dict[int, int] = {}   # allele index i -> deletion var index between base i-1 and i
+        ins: Dict[int, int] = {}    # allele index i -> insertion var index if base i is an inserted base
         prev = 0
         for vi in locus.allele_vars.get(name, []):
             t, p, d = locus.var_type[vi], locus.var_pos[vi], locus.var_data[vi]
@@ -349,18 +357,22 @@ class AlleleMap:
                 dels[len(seq)] = vi
                 prev = p + int(d)
             else:
-                raise NotImplementedError("insertions are not synthesised")
+                # inserted bases sit in front of backbone base p (typing_core.py:2228-2231)
+                for ch in d:
+                    seq.append(ch); bpos.append(p); vid.append(-1); ins[len(seq) - 1] = vi
+                prev = p
         if prev < len(bb):
             seq.extend(bb[prev:]); bpos.extend(range(prev, len(bb))); vid.extend([-1] * (len(bb) - prev))
         self.seq = "".join(seq)
         self.bpos = bpos
         self.vid = vid
         self.dels = dels
+        self.ins = ins
         self.locus = locus
 
 
 def _align_read(amap: AlleleMap, start: int, read_len: int, rng: random.Random, err_rate: float,
-                softclip: Tuple[int, int] = (0, 0), novel_del_at: int = -1):
+                softclip: Tuple[int, int] = (0, 0), novel_del_at: int = -1, novel_ins_at: int = -1):
     """Truth alignment of allele bases [start, start+read_len) against the backbone."""
     loc = amap.locus
     bb = loc.backbone
@@ -386,7 +398,31 @@ def _align_read(amap: AlleleMap, start: int, read_len: int, rng: random.Random, 
         read.append(rng.choice(_BASES))
     if sc_l:
         push("S", sc_l)
+    ins_map = getattr(amap, "ins", {})
+    # never start or stop inside a known insertion (an aligner would soft-clip or report a partial, novel one)
+    while i0 in ins_map and i0 < i1:
+        i0 += 1
+    while (i1 - 1) in ins_map and i1 > i0:
+        i1 -= 1
     for i in range(i0, i1):
+        if i in ins_map:
+            # known insertion: CIGAR I, Zs "gap|I|id" once per run; the consumer advances read_pos over the
+            # inserted bases but not Zs_pos (core:994-1001), so they count into the NEXT item's gap
+            vi = ins_map[i]
+            if (i - 1) not in ins_map or ins_map[i - 1] != vi or i == i0:
+                zs.append("%d|I|%s" % (zs_gap, loc.var_ids[vi])); zs_gap = 0
+            read.append(amap.seq[i])
+            push("I")
+            zs_gap += 1
+            last_was_del = False
+            continue
+        if i == novel_ins_at and i > i0 + 5 and i + 5 < i1 and not last_was_del and amap.vid[i] < 0 and i not in amap.dels:
+            k = rng.randint(1, 2)
+            for _ in range(k):
+                read.append(rng.choice(_BASES))
+            push("I", k)
+            nm += k
+            zs_gap += k
         if i > i0 and i in amap.dels:
             vi = amap.dels[i]
             dl = int(loc.var_data[vi])
@@ -440,7 +476,7 @@ def simulate_pairs(locus: Locus, sample_alleles: Sequence[str], n_pairs: int, re
                    simulation_names: bool = False, softclip_frac: float = 0.0, novel_del_frac: float = 0.0,
                    tile_interval: Optional[int] = None, single_end: bool = False,
                    multi_hit_frac: float = 0.0, discordant_frac: float = 0.0,
-                   unaligned_frac: float = 0.0, dup_frac: float = 0.0) -> List[Alignment]:
+                   unaligned_frac: float = 0.0, dup_frac: float = 0.0, novel_ins_frac: float = 0.0) -> List[Alignment]:
     """Draw fragments from the sample's alleles and return truth alignments, two per pair.
 
     ``tile_interval``: if set, fragments start every ``tile_interval`` bases of each allele
@@ -474,7 +510,10 @@ def simulate_pairs(locus: Locus, sample_alleles: Sequence[str], n_pairs: int, re
             nd = -1
             if novel_del_frac > 0 and rng.random() < novel_del_frac:
                 nd = st + rng.randint(20, read_len - 20)
-            pos, cigar, seq, md, zs, nm = _align_read(m, st, read_len, rng, err_rate, sc, nd)
+            ni = -1
+            if novel_ins_frac > 0 and rng.random() < novel_ins_frac:
+                ni = st + rng.randint(20, read_len - 20)
+            pos, cigar, seq, md, zs, nm = _align_read(m, st, read_len, rng, err_rate, sc, nd, ni)
             recs.append((pos, cigar, seq, md, zs, nm, is_leftmost))
         for j, (pos, cigar, seq, md, zs, nm, is_leftmost) in enumerate(recs):
             if single_end:

@@ -234,6 +234,7 @@ typedef struct hgx_parse_opts {
     int32_t simulation;         /* read id = QNAME up to the first '|'            core:808 */
     int32_t base_locus;         /* subtracted from POS                            core:814 */
     int32_t keep_trace;         /* record per-read intermediates for hgx_batch_trace_text   */
+    int32_t codis_choose_pairs; /* base codis && gene == "D18S51": choose_pairs at the final flush (core:1547-1552) */
 } hgx_parse_opts;
 
 /* SAM text (name-grouped, i.e. the stream after `sort -k1,1 -s`, core:458-468) -> batch.

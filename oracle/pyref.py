@@ -565,6 +565,60 @@ def single_abundance(Gene_cmpt, remove_low=False, Gene_length=None, stats=None):
     return sorted([[a, p] for a, p in prob.items()], key=lambda x: x[1], reverse=True)
 
 
+def pair_interdist(lines, simulation):
+    """Median inner distance of uniquely, concordantly aligned mates (typing_common.py:1187-1265)."""
+    dists, prev, reads = [], None, []
+    for l in lines:
+        c = l.split()
+        read_id, flag, pos, cigar_str = c[0], int(c[1]), int(c[3]), c[5]
+        if flag & 0x4:
+            continue
+        if simulation:
+            read_id = read_id.split("|")[0]
+        NH, YT = None, ""
+        for col in c[11:]:
+            if col.startswith("NH"):
+                NH = int(col[5:])
+            elif col.startswith("YT"):
+                YT = col[5:]
+        if NH is None or NH > 1 or YT != "CP":
+            continue
+        if prev is not None and read_id != prev:
+            if len(reads) == 2:
+                (l1, r1), (l2, r2) = reads
+                dists.append(l2 - r1 - 1 if l1 <= l2 else l1 - r2 - 1)
+            reads = []
+        right = pos
+        for cg in _CIGAR_RE.findall(cigar_str):
+            if cg[-1] in "MND":
+                right += int(cg[:-1])
+        reads.append([pos, right - 1])
+        prev = read_id
+    dists.sort()
+    return dists[len(dists) // 2] if dists else -1
+
+
+def choose_pairs(lhts, rhts, expected):
+    """Keep the mate haplotype pairs whose inner distance is closest to the expected one (typing_core.py:680-716)."""
+    if len(lhts) > 0 and len(rhts) > 0 and max(len(lhts), len(rhts)) >= 2:
+        best, picked = None, []
+        for lh in lhts:
+            f = lh.split("-")
+            ll, lr = int(f[0]), int(f[-1])
+            for rh in rhts:
+                g = rh.split("-")
+                rl, rr = int(g[0]), int(g[-1])
+                inter = rl - lr - 1 if lr < rr else ll - rr - 1
+                cur = abs(expected - inter)
+                if best is None or best > cur:
+                    best, picked = cur, [[lh, rh]]
+                elif best == cur:
+                    picked.append([lh, rh])
+        lhts = {a for a, _ in picked}
+        rhts = {b for _, b in picked}
+    return lhts, rhts
+
+
 class RefLocus:
     """Per-locus state + the streaming loop of typing() for one locus."""
 
@@ -902,6 +956,7 @@ class RefLocus:
             recs.append((int(c[1]), int(c[3]) - (base_locus + 1), c[5], c[9]))
         counts, nt_sets = pileup(recs, len(self.ref_seq), o["allow_discordant"])
         self.pileup_counts, self.nt_sets = counts, nt_sets
+        interdist = pair_interdist(lines, o["simulation"]) if self.base == "codis" else None   # core:451-456
 
         hla = self.base == "hla"
         exons_cmpt, gene_cmpt, exons_counts, gene_counts = {}, {}, {}, {}
@@ -1022,6 +1077,8 @@ class RefLocus:
             prev_id = read_id
         if prev_id is not None:
             num_pairs += 1
+            if self.base == "codis" and self.gene == "D18S51":                      # core:1547-1552
+                lhts, rhts = choose_pairs(lhts, rhts, interdist)
             flush()
 
         res = dict(num_reads=num_reads, num_pairs=num_pairs, pairs=pair_log, exons_cmpt=exons_cmpt,

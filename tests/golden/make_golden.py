@@ -335,6 +335,16 @@ def hla_novel_sample():
 
 
 @scenario
+def hla_insertions():
+    """Known insertions (CIGAR I + Zs gap|I|id), novel insertions and deletions, soft clips."""
+    loc = synth.make_hla_like_locus(n_alleles=120, n_vars=500, seed=31, insertion_frac=0.08, deletion_frac=0.1)
+    sample = synth.pick_sample(loc, 3)
+    al = synth.simulate_pairs(loc, sample, 500, err_rate=0.003, seed=4, novel_ins_frac=0.05, novel_del_frac=0.03,
+                              softclip_frac=0.05)
+    return dict(locus=loc, sample=sample, al=al, simulation=False)
+
+
+@scenario
 def hla_7000():
     loc = synth.make_hla_like_locus(n_alleles=7000, n_vars=2500, seed=101)
     sample = synth.pick_sample(loc, 101)
@@ -349,6 +359,18 @@ def codis_like():
     sample = ["D8S1179*10", "D8S1179*13"]
     al = synth.simulate_pairs(loc, sample, 0, read_len=100, frag_len=(250, 250), seed=10,
                               simulation_names=True, tile_interval=3)
+    return dict(locus=loc, sample=sample, al=al, simulation=True, read_len=100, frag_len=250)
+
+
+@scenario
+def codis_d18s51():
+    """CODIS locus D18S51: the only place choose_pairs / get_pair_interdist act (final flush, core:1547-1552).
+    The tiling makes the name-sorted LAST pair ("9|...") end inside the repeat, so it has 14 alternative haplotypes
+    that choose_pairs cuts down to the pair matching the median inner distance."""
+    loc = synth.make_str_like_locus(gene="D18S51", unit="AGAA", max_repeats=22, min_repeats=9, flank=180, seed=2)
+    sample = ["D18S51*12", "D18S51*17"]
+    al = synth.simulate_pairs(loc, sample, 0, read_len=100, frag_len=(250, 250), seed=2, simulation_names=True,
+                              tile_interval=12)
     return dict(locus=loc, sample=sample, al=al, simulation=True, read_len=100, frag_len=250)
 
 

@@ -10,7 +10,7 @@ from hisatgenotype_amd import synth
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL = ["hla_small_pair", "hla_small_single", "hla_errors_filters", "hla_mid_real", "hla_keep_low",
-       "hla_single_end", "hla_novel_sample", "hla_7000", "codis_like"]
+       "hla_single_end", "hla_novel_sample", "hla_insertions", "hla_7000", "codis_like", "codis_d18s51"]
 SMALL = [n for n in ALL if n != "hla_7000"]
 
 
