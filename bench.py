@@ -221,8 +221,8 @@ def main():
                 "em_outer_iterations_per_step": n_em_iter // max(args.steps, 1),
                 "top2": [a for a, _ in res.gene_prob[:2]], "true_alleles": sample,
                 "parallelism": "1 sample per GPU (samples/loci shard, no data-path collective)",
-                "input": "front-end piece batch resident in HBM (host C++ front-end: %.0f reads/s on 1 core, not timed)" % (
-                    batch.n_reads / t_parse),
+                "input": "front-end piece batch resident in HBM (host C++ front-end: %.0f reads/s on %d host threads, not timed)" % (
+                    batch.n_reads / t_parse, os.cpu_count() or 1),
                 "setup_s": round(t_setup, 1),
             },
             "roofline": {

@@ -41,7 +41,7 @@ class LocusDesc(C.Structure):
 class ParseOpts(C.Structure):
     _fields_ = [("num_editdist", C.c_int32), ("error_correction", C.c_int32), ("allow_discordant", C.c_int32),
                 ("simulation", C.c_int32), ("base_locus", C.c_int32), ("keep_trace", C.c_int32),
-                ("codis_choose_pairs", C.c_int32)]
+                ("codis_choose_pairs", C.c_int32), ("n_threads", C.c_int32)]
 
 
 # every symbol include/hgx.h declares (checked by tests/test_capi_symbols.py)

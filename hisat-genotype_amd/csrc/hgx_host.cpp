@@ -30,6 +30,21 @@ extern "C" int hgx_locus_create(hgx_locus **out, const hgx_locus_desc *d) {
         L->ins.emplace_back(ip);
         ip += L->ins.back().size() + 1;
         L->name_to_var[L->name.back()] = v;
+        {
+            const std::string &nm = L->name.back();
+            if (nm.size() > 2 && nm.size() < 10 && nm[0] == 'h' && nm[1] == 'v') {
+                long num = 0;
+                bool digits = true;
+                for (size_t k = 2; k < nm.size(); ++k) {
+                    if (nm[k] < '0' || nm[k] > '9') { digits = false; break; }
+                    num = num * 10 + (nm[k] - '0');
+                }
+                if (digits && num < 50000000 && !(nm.size() > 3 && nm[2] == '0')) {
+                    if ((size_t)num >= L->hv_index.size()) L->hv_index.resize(num + 1, -1);
+                    L->hv_index[num] = v;
+                }
+            }
+        }
         if (v > 0 && L->pos[v] < L->pos[v - 1]) {
             hgx_set_error("variants must be sorted by position (gene_var_list order)");
             delete L;
@@ -122,6 +137,9 @@ extern "C" int hgx_locus_create(hgx_locus **out, const hgx_locus_desc *d) {
             else L->rep_of[a] = it->second;
         }
     }
+    L->linked_bits.assign(L->n_words, 0u);
+    for (int v = 0; v < V; ++v)
+        if (L->linked[v]) L->linked_bits[v >> 5] |= 1u << (v & 31);
     L->exon_mask.assign(L->w64, 0ull);
     L->gene_mask.assign(L->w64, 0ull);
     for (int a = 0; a < A; ++a) {
@@ -164,55 +182,90 @@ extern "C" int hgx_index_from_locus(hgx_index **out, const hgx_locus *L) {
 // drops below `left` (core:651-670) -- every variant above the start has pos > right and every
 // variant below the stop has right end < left, so the scan bounds never change the set.
 // ---------------------------------------------------------------------------------------------
-int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &L, int32_t left, int32_t right, const int32_t *ids, int32_t n_ids) {
-    const int V = L.V;
-    int lo_w = 0x7fffffff, hi_w = -1;
-    // first pass: word range
-    auto touch = [&](int v) { lo_w = std::min(lo_w, v >> 5); hi_w = std::max(hi_w, v >> 5); };
-    for (int i = 0; i < n_ids; ++i) {
-        const int v = ids[i];
-        if (v >= 0 && v < V && L.linked[v]) touch(v);
-    }
-    int j = V ? std::min(lower_bound_pos(L.pos, right + 1), V - 1) : -1;
-    const int j_top = j;
-    auto in_ids = [&](int v) { for (int i = 0; i < n_ids; ++i) if (ids[i] == v) return true; return false; };
-    for (; j >= 0 && L.maxright[j] >= left; --j) {
-        if (!L.linked[j] || in_ids(j)) continue;
-        if ((L.pos[j] >= left && L.pos[j] <= right) || (L.right[j] >= left && L.right[j] <= right)) touch(j);
-    }
-    PieceKey key;
-    if (hi_w < 0) { lo_w = 0; hi_w = 0; }
-    if (hi_w - lo_w + 1 > 255) {
-        hgx_set_error("piece spans %d variant words (> 255)", hi_w - lo_w + 1);
-        return -1;
-    }
-    key.lo = (uint16_t)lo_w;
-    key.nw = (uint8_t)(hi_w - lo_w + 1);
-    key.masks.assign(2 * (size_t)key.nw, 0u);
-    for (int i = 0; i < n_ids; ++i) {
-        const int v = ids[i];
-        if (v >= 0 && v < V && L.linked[v]) {
-            key.masks[2 * ((v >> 5) - lo_w)] |= 1u << (v & 31);
-            key.masks[2 * ((v >> 5) - lo_w) + 1] |= 1u << (v & 31);
+uint32_t hgx_intern_masks(hgx_batch &b, uint16_t lo, uint8_t nw, const uint32_t *m) {
+    PieceTable &T = b.table;
+    if (T.slot.empty()) T.slot.assign(1024, -1);
+    if ((T.used + 1) * 2 > T.slot.size()) {                 // grow + rehash from the piece list
+        std::vector<int32_t> ns(T.slot.size() * 2, -1);
+        const size_t mask = ns.size() - 1;
+        for (size_t id = 0; id < b.pieces.size(); ++id) {
+            const hgx_piece &pc = b.pieces[id];
+            size_t h = PieceTable::hash(pc.lo_word, pc.n_words, &b.masks[pc.mask_off]) & mask;
+            while (ns[h] >= 0) h = (h + 1) & mask;
+            ns[h] = (int32_t)id;
         }
+        T.slot.swap(ns);
     }
-    for (j = j_top; j >= 0 && L.maxright[j] >= left; --j) {
-        if (!L.linked[j] || in_ids(j)) continue;
-        if ((L.pos[j] >= left && L.pos[j] <= right) || (L.right[j] >= left && L.right[j] <= right))
-            key.masks[2 * ((j >> 5) - lo_w)] |= 1u << (j & 31);
+    const size_t mask = T.slot.size() - 1;
+    size_t h = PieceTable::hash(lo, nw, m) & mask;
+    for (;;) {
+        const int32_t id = T.slot[h];
+        if (id < 0) break;
+        const hgx_piece &pc = b.pieces[id];
+        if (pc.lo_word == lo && pc.n_words == nw && memcmp(&b.masks[pc.mask_off], m, 8 * (size_t)nw) == 0) return (uint32_t)id;
+        h = (h + 1) & mask;
     }
-    auto it = b.lookup.find(key);
-    if (it != b.lookup.end()) return it->second;
     const uint32_t id = (uint32_t)b.pieces.size();
     hgx_piece pc;
     pc.mask_off = (uint32_t)b.masks.size();
-    pc.lo_word = key.lo;
-    pc.n_words = key.nw;
+    pc.lo_word = lo;
+    pc.n_words = nw;
     pc.reserved = 0;
     b.pieces.push_back(pc);
-    b.masks.insert(b.masks.end(), key.masks.begin(), key.masks.end());
-    b.lookup.emplace(std::move(key), id);
+    b.masks.insert(b.masks.end(), m, m + 2 * (size_t)nw);
+    T.slot[h] = (int32_t)id;
+    T.used++;
     return id;
+}
+
+int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &L, int32_t left, int32_t right, const int32_t *ids, int32_t n_ids) {
+    // MP = M | P: M only holds linked variants and the linked members of `ids` are exactly P, so excluding the piece's
+    // own ids from the span scan (core:655-657) and OR-ing P back in is the same set.  Variants with pos in
+    // [left, right] are one contiguous index range [i0, i1) of the position-sorted list; the only others are variants
+    // starting before `left` whose right end reaches into the span (bounded by the prefix-max right end).
+    const int V = L.V;
+    const int i0 = lower_bound_pos(L.pos, left), i1 = lower_bound_pos(L.pos, right + 1);
+    int lo_v = 0x7fffffff, hi_v = -1;
+    if (i1 > i0) { lo_v = i0; hi_v = i1 - 1; }
+    int extra[64], n_extra = 0;
+    for (int j = i0 - 1; j >= 0 && L.maxright[j] >= left; --j) {
+        if (L.linked[j] && L.right[j] >= left && L.right[j] <= right) {
+            if (n_extra < 64) extra[n_extra++] = j;
+            else { hgx_set_error("too many spanning variants"); return -1; }
+            lo_v = std::min(lo_v, j);
+            hi_v = std::max(hi_v, j);
+        }
+    }
+    for (int i = 0; i < n_ids; ++i) {
+        const int v = ids[i];
+        if (v >= 0 && v < V && L.linked[v]) { lo_v = std::min(lo_v, v); hi_v = std::max(hi_v, v); }
+    }
+    int lo_w = 0, hi_w = 0;
+    if (hi_v >= 0) { lo_w = lo_v >> 5; hi_w = hi_v >> 5; }
+    const int nw = hi_w - lo_w + 1;
+    if (nw > 255) {
+        hgx_set_error("piece spans %d variant words (> 255)", nw);
+        return -1;
+    }
+    uint32_t buf[512];
+    memset(buf, 0, 8 * (size_t)nw);
+    if (i1 > i0) {                                               // linked variants of the index range, word at a time
+        for (int w = i0 >> 5; w <= (i1 - 1) >> 5; ++w) {
+            uint32_t m = 0xffffffffu;
+            if (w == (i0 >> 5)) m &= 0xffffffffu << (i0 & 31);
+            if (w == ((i1 - 1) >> 5)) m &= 0xffffffffu >> (31 - ((i1 - 1) & 31));
+            buf[2 * (w - lo_w)] |= m & L.linked_bits[w];
+        }
+    }
+    for (int k = 0; k < n_extra; ++k) buf[2 * ((extra[k] >> 5) - lo_w)] |= 1u << (extra[k] & 31);
+    for (int i = 0; i < n_ids; ++i) {
+        const int v = ids[i];
+        if (v >= 0 && v < V && L.linked[v]) {
+            buf[2 * ((v >> 5) - lo_w)] |= 1u << (v & 31);
+            buf[2 * ((v >> 5) - lo_w) + 1] |= 1u << (v & 31);
+        }
+    }
+    return hgx_intern_masks(b, (uint16_t)lo_w, (uint8_t)nw, buf);
 }
 
 // Order the distinct-piece table by first covered word (then width) and renumber the refs: consecutive pieces then
@@ -238,7 +291,7 @@ void hgx_finalize_batch(hgx_batch &b) {
     b.pieces.swap(np);
     b.masks.swap(nm);
     for (auto &r : b.pair_ref) r = (r & 0x80000000u) | new_id[r & 0x7fffffffu];
-    b.lookup.clear();
+    b.table.clear();
 }
 
 extern "C" int hgx_batch_from_haplotypes(hgx_batch **out, const hgx_locus *L, int32_t n_pairs, const int32_t *pair_off,

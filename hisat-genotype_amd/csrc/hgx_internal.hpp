@@ -39,6 +39,7 @@ struct hgx_locus {
     std::vector<char> base;
     std::vector<std::string> name, ins;
     std::unordered_map<std::string, int32_t> name_to_var;
+    std::vector<int32_t> hv_index;               // "hv<n>" -> variant index (-1 if absent); fast path of the Zs id lookup
     int32_t A = 0, a_pad = 0, n_words = 1, w64 = 0;
     std::vector<int32_t> link_off, link_allele;
     std::vector<int32_t> maxright;               // prefix max of right ends (core:393-401)
@@ -48,6 +49,7 @@ struct hgx_locus {
     std::vector<int32_t> rep_of;                 // allele -> representative allele or -1 (core:86-115)
     std::vector<uint64_t> exon_mask, gene_mask;
     std::vector<uint32_t> link_bits;             // [n_words][a_pad]
+    std::vector<uint32_t> linked_bits;           // [n_words] variants present in Links
     std::vector<int32_t> allele_len, name_rank;
     // alternatives (common:1424-1657), sorted by anchor position like Alts_left_list / Alts_right_list
     std::vector<AltEntry> alts_left, alts_right;
@@ -69,18 +71,17 @@ inline int32_t lower_bound_pos(const std::vector<int32_t> &pos, int32_t key) {
     return low;
 }
 
-struct PieceKey {
-    uint16_t lo;
-    uint8_t nw;
-    std::vector<uint32_t> masks;   // MP0,P0,MP1,P1,...
-    bool operator==(const PieceKey &o) const { return lo == o.lo && nw == o.nw && masks == o.masks; }
-};
-struct PieceKeyHash {
-    size_t operator()(const PieceKey &k) const {
-        uint64_t h = 1469598103934665603ull ^ k.lo ^ ((uint64_t)k.nw << 16);
-        for (uint32_t m : k.masks) { h ^= m; h *= 1099511628211ull; h ^= h >> 29; }
-        return (size_t)h;
+// Distinct-piece table: open addressing over piece ids, keys compared against the batch's own mask pool
+// (no allocation per lookup: the front-end interns a few pieces per read pair).
+struct PieceTable {
+    std::vector<int32_t> slot;     // piece id or -1
+    size_t used = 0;
+    static uint64_t hash(uint16_t lo, uint8_t nw, const uint32_t *m) {
+        uint64_t h = 1469598103934665603ull ^ lo ^ ((uint64_t)nw << 16);
+        for (int i = 0; i < 2 * (int)nw; ++i) { h ^= m[i]; h *= 1099511628211ull; h ^= h >> 29; }
+        return h;
     }
+    void clear() { slot.clear(); used = 0; }
 };
 
 struct TraceRec {
@@ -93,7 +94,7 @@ struct hgx_batch {
     std::vector<int32_t> pair_off{0};
     std::vector<uint32_t> pair_ref;
     int32_t n_reads = 0;
-    std::unordered_map<PieceKey, uint32_t, PieceKeyHash> lookup;
+    PieceTable table;
     std::vector<TraceRec> trace;
     std::vector<uint8_t> nt_set;        // [L] 4-bit masks
     std::vector<uint32_t> counts;       // [L][6]
@@ -101,6 +102,8 @@ struct hgx_batch {
 
 // piece "left-ids-right" -> index of the distinct piece in the batch (creates it if new). < 0 on error.
 int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &loc, int32_t left, int32_t right, const int32_t *ids, int32_t n_ids);
+// find-or-insert a piece given its word range and (MP,P) mask words
+uint32_t hgx_intern_masks(hgx_batch &b, uint16_t lo, uint8_t nw, const uint32_t *m);
 void hgx_finalize_batch(hgx_batch &b);
 // alternatives tables (defined in hgx_sam.cpp)
 int hgx_build_alternatives(hgx_locus &loc);

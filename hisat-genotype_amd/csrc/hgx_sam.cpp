@@ -18,7 +18,11 @@
 #include <cstring>
 #include <set>
 #include <stdexcept>
+#include <atomic>
+#include <chrono>
+#include <memory>
 #include <string>
+#include <thread>
 #include <unordered_set>
 
 #include "hgx_internal.hpp"
@@ -213,7 +217,15 @@ struct Parser {
     std::vector<AltRec> alt_l, alt_r;
     std::vector<int> alt_l_pos, alt_r_pos;
 
-    Parser(const hgx_locus &l, const hgx_parse_opts &opts, hgx_batch &b) : L(l), o(opts), B(b) {
+    const hgx_batch &PILE;   // pileup tables (nt_set, counts) shared by all chunks
+    struct ZsItem { int gap; char type; int id; };
+    std::vector<ZsItem> zs_buf;                       // per-record scratch, reused
+    std::vector<std::pair<char, int>> ops_buf;
+    std::vector<Cmp> ec_buf;
+    std::vector<Ht> ex_buf, union_buf;
+    std::vector<int32_t> ids_buf;
+    std::vector<uint32_t> eref_buf, gref_buf;
+    Parser(const hgx_locus &l, const hgx_parse_opts &opts, hgx_batch &b, const hgx_batch &pile) : L(l), o(opts), B(b), PILE(pile) {
         for (auto &e : L.alts_left) {
             AltRec r;
             r.key_ht.push_back(e.key.left);
@@ -288,14 +300,18 @@ struct Parser {
     }
 
     // ---- error_correct (core:119-243) over the cmp entries of one M op ------------------------------
-    static int nt_bit(char c) { return c == 'A' ? 1 : c == 'C' ? 2 : c == 'G' ? 4 : c == 'T' ? 8 : 0; }
+    static int nt_bit(char c) {
+        static const struct Lut { uint8_t t[256]; Lut() { memset(t, 0, 256); t['A'] = 1; t['C'] = 2; t['G'] = 4; t['T'] = 8; } } lut;
+        return lut.t[(unsigned char)c];
+    }
     static char single_nt(int mask) { return mask == 1 ? 'A' : mask == 2 ? 'C' : mask == 4 ? 'G' : 'T'; }
 
     int error_correct(std::string &read, int read_pos, std::vector<Cmp> &cl, size_t start) {
         const std::string &ref = L.backbone;
         const int n_ref = (int)ref.size();
         int ncorr = 0;
-        std::vector<Cmp> out;
+        std::vector<Cmp> &out = ec_buf;
+        out.clear();
         bool stopped = false;
         for (size_t i = start; i < cl.size(); ++i) {
             Cmp c = cl[i];
@@ -309,7 +325,7 @@ struct Parser {
                 for (int j = 0; j < c.len; ++j) {
                     if (read_pos + j >= (int)read.size() || c.pos + j >= n_ref) continue;
                     char b = read[read_pos + j];
-                    const int s = B.nt_set[c.pos + j];
+                    const int s = PILE.nt_set[c.pos + j];
                     if (s != 0 && !(s & nt_bit(b))) {
                         b = (s & (s - 1)) ? 'N' : single_nt(s);
                         read[read_pos + j] = b;
@@ -325,7 +341,7 @@ struct Parser {
                 if (last < c.len) out.push_back(Cmp{T_MATCH, c.pos + last, c.len - last, -2});
             } else {
                 char b = read[read_pos];
-                const int s = B.nt_set[c.pos];
+                const int s = PILE.nt_set[c.pos];
                 if (s != 0 && !(s & nt_bit(b))) {
                     b = (s & (s - 1)) ? 'N' : single_nt(s);
                     read[read_pos] = b;
@@ -347,8 +363,8 @@ struct Parser {
 
     // ---- one record -> cmp_list (core:876-1164).  Returns false if the record is dropped. -----------
     bool decode(int pos, const char *cigar, std::string &read, const char *zs_str, const char *md, std::vector<Cmp> &cl) {
-        struct ZsItem { int gap; char type; int id; };
-        std::vector<ZsItem> zs;
+        std::vector<ZsItem> &zs = zs_buf;
+        zs.clear();
         if (zs_str && *zs_str) {
             const char *p = zs_str;
             while (*p) {
@@ -360,10 +376,22 @@ struct Parser {
                 p += 3;
                 const char *q = p;
                 while (*q && *q != ',') ++q;
-                std::string name(p, q);
-                auto it = L.name_to_var.find(name);
-                if (it == L.name_to_var.end()) throw RefError("KeyError: Zs variant id not in the locus");
-                z.id = it->second;
+                z.id = -1;
+                if (q - p > 2 && p[0] == 'h' && p[1] == 'v' && !(q - p > 3 && p[2] == '0')) {   // "hv<n>": direct table
+                    long num = 0;
+                    bool digits = true;
+                    for (const char *c = p + 2; c < q; ++c) {
+                        if (*c < '0' || *c > '9') { digits = false; break; }
+                        num = num * 10 + (*c - '0');
+                        if (num > 100000000) { digits = false; break; }
+                    }
+                    if (digits && (size_t)num < L.hv_index.size()) z.id = L.hv_index[num];
+                }
+                if (z.id < 0) {
+                    auto it = L.name_to_var.find(std::string(p, q));
+                    if (it == L.name_to_var.end()) throw RefError("KeyError: Zs variant id not in the locus");
+                    z.id = it->second;
+                }
                 zs.push_back(z);
                 p = *q ? q + 1 : q;
             }
@@ -378,7 +406,8 @@ struct Parser {
         bool bad = false;
         int clip0 = 0, clip1 = 0;
         cl.clear();
-        std::vector<std::pair<char, int>> ops;
+        std::vector<std::pair<char, int>> &ops = ops_buf;
+        ops.clear();
         for (const char *p = cigar; *p;) {
             char *e;
             long n = strtol(p, &e, 10);
@@ -452,7 +481,7 @@ struct Parser {
                 } else id = lookup(gp, HGX_VAR_DELETION, n);
                 cl.push_back(Cmp{T_DELETION, gp, n, id});
                 if (gp < (int)L.backbone.size()) {                  // artificial-deletion check (core:1064-1077)
-                    const uint32_t *c = &B.counts[(size_t)gp * 6];
+                    const uint32_t *c = &PILE.counts[(size_t)gp * 6];
                     const uint64_t dc = c[5], nc = (uint64_t)c[0] + c[1] + c[2] + c[3] + c[4];
                     if (L.base_kind == HGX_BASE_HLA && dc * 6 < nc) bad = true;
                 }
@@ -755,27 +784,33 @@ struct Parser {
 
     // ---- pair flush (core:1238-1291): haplotypes -> piece refs --------------------------------------------
     // choose_pairs (core:680-716): keep the mate haplotype pairs whose inner distance is closest to the expected one
-    static void choose_pairs(std::set<Ht> &lh, std::set<Ht> &rh, long expected) {
+    static void choose_pairs(std::vector<Ht> &lh, std::vector<Ht> &rh, long expected) {
         if (lh.empty() || rh.empty() || std::max(lh.size(), rh.size()) < 2) return;
         long best = -1;
-        std::set<Ht> nl, nr;
+        std::vector<Ht> nl, nr;
+        auto add = [](std::vector<Ht> &v, const Ht &h) { if (std::find(v.begin(), v.end(), h) == v.end()) v.push_back(h); };
         for (const Ht &l : lh)
             for (const Ht &r : rh) {
                 const long inter = l.right < r.right ? (long)r.left - l.right - 1 : (long)l.left - r.right - 1;
                 const long cur = std::labs(expected - inter);
                 if (best < 0 || cur < best) { best = cur; nl.clear(); nr.clear(); }
-                if (cur == best) { nl.insert(l); nr.insert(r); }
+                if (cur == best) { add(nl, l); add(nr, r); }
             }
         lh.swap(nl);
         rh.swap(nr);
     }
 
-    void flush(const std::set<Ht> &lh, const std::set<Ht> &rh) {
-        std::set<Ht> hts(lh);
-        hts.insert(rh.begin(), rh.end());
-        std::vector<Ht> ex;
-        std::vector<int32_t> ids;
-        std::vector<uint32_t> exon_refs, gene_refs;
+    // pair flush (core:1238-1291): the set union of the mates' haplotypes -> piece refs
+    void flush(const std::vector<Ht> &lh, const std::vector<Ht> &rh) {
+        std::vector<Ht> &hts = union_buf;
+        hts.clear();
+        for (const Ht &h : lh) hts.push_back(h);
+        for (const Ht &h : rh) if (std::find(hts.begin(), hts.end(), h) == hts.end()) hts.push_back(h);
+        std::vector<Ht> &ex = ex_buf;
+        std::vector<int32_t> &ids = ids_buf;
+        std::vector<uint32_t> &exon_refs = eref_buf, &gene_refs = gref_buf;
+        exon_refs.clear();
+        gene_refs.clear();
         auto intern = [&](const Ht &h) -> uint32_t {
             if (h.left > h.right) throw RefError("assert left <= right");
             ids.assign(h.ids.begin(), h.ids.end());
@@ -905,112 +940,75 @@ extern "C" int hgx_locus_alternatives_text(const hgx_locus *Lc, char *buf, size_
     return HGX_OK;
 }
 
-extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts) {
-    HARGCHK(out && Lc && (sam || n_bytes == 0) && opts);
-    hgx_locus &L = *const_cast<hgx_locus *>(Lc);
-    hgx_batch *B = new hgx_batch();
+namespace {
+
+// read id of a record: QNAME, or QNAME up to the first '|' in simulation mode (core:808-809)
+inline size_t read_id_len(const Fields &f, bool simulation) {
+    if (simulation) {
+        const char *bar = (const char *)memchr(f.qname, '|', f.qname_len);
+        if (bar) return (size_t)(bar - f.qname);
+    }
+    return f.qname_len;
+}
+
+struct ChunkResult {
+    hgx_batch local;
+    std::string error;
+    int error_code = 0;
+};
+
+// The streaming loop (core:800-1587) over records [i0, i1).  Chunks start at read-id boundaries of the name-grouped
+// stream, so pairs, the duplicate-mate filters and the flush protocol never straddle two chunks.
+void process_chunk(const hgx_locus &L, const hgx_parse_opts &o, const std::vector<Fields> &recs, const std::vector<uint8_t> &ok,
+                   size_t i0, size_t i1, const hgx_batch &pile, bool is_last, long expected_interdist, ChunkResult &out) {
+    hgx_batch &B = out.local;
     try {
-        hgx_build_alternatives(L);
-        const int n_ref = (int)L.backbone.size();
-        std::vector<char> text(sam, sam + n_bytes);
-        text.push_back('\n');
-        // line table
-        std::vector<std::pair<char *, char *>> lines;
-        {
-            char *p = text.data(), *end = text.data() + text.size();
-            while (p < end) {
-                char *e = (char *)memchr(p, '\n', end - p);
-                if (!e) e = end;
-                if (e > p && *p != '@') lines.push_back({p, e});
-                p = e + 1;
-            }
-        }
-        std::vector<Fields> recs(lines.size());
-        std::vector<uint8_t> ok(lines.size(), 0);
-        for (size_t i = 0; i < lines.size(); ++i) {
-            *lines[i].second = 0;
-            ok[i] = split_line(lines[i].first, lines[i].second, recs[i]) ? 1 : 0;
-        }
-        // pass 1: pileup over all records (common:1076-1134)
-        B->counts.assign((size_t)n_ref * 6, 0u);
-        B->nt_set.assign(n_ref, 0);
-        for (size_t i = 0; i < recs.size(); ++i) {
-            if (!ok[i]) continue;
-            const Fields &f = recs[i];
-            if (f.flag & 0x4) continue;
-            const int pos = f.pos - (opts->base_locus + 1);
-            if (pos < 0) continue;
-            if (!opts->allow_discordant && !(f.flag & 0x2)) continue;
-            int rp = 0, gp = pos;
-            for (const char *p = f.cigar; *p;) {
-                char *e;
-                const long n = strtol(p, &e, 10);
-                if (e == p || !*e) break;
-                const char op = *e;
-                if (op == 'M' || op == 'D') {
-                    for (long j = 0; j < n; ++j) {
-                        if (gp + j >= n_ref) break;
-                        int slot = 5;
-                        if (op == 'M') {
-                            if ((size_t)(rp + j) >= f.seq_len) throw RefError("IndexError: read shorter than CIGAR");
-                            const char c = f.seq[rp + j];
-                            slot = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
-                        }
-                        B->counts[(size_t)(gp + j) * 6 + slot]++;
-                    }
-                }
-                if (op == 'M' || op == 'N' || op == 'D') gp += (int)n;
-                if (op == 'M' || op == 'I' || op == 'S') rp += (int)n;
-                p = e + 1;
-            }
-        }
-        for (int i = 0; i < n_ref; ++i) {
-            const uint32_t *c = &B->counts[(size_t)i * 6];
-            const uint64_t tot = (uint64_t)c[0] + c[1] + c[2] + c[3] + c[4] + c[5];
-            int m = 0;
-            if (tot >= 20)
-                for (int k = 0; k < 4; ++k)
-                    if ((double)c[k] >= (double)tot * 0.2 || c[k] >= 7) m |= 1 << k;
-            B->nt_set[i] = (uint8_t)m;
-        }
-        // pass 2: the streaming loop
-        Parser P(L, *opts, *B);
-        std::unordered_set<std::string> seen_l, seen_r, seen_u;
-        std::set<Ht> lhts, rhts;   // left / right positive haplotypes of the current pair (united at the flush, core:1250-1251)
-        std::string prev_id;
+        Parser P(L, o, B, pile);
+        // The stream is name-grouped, so the reference's global left/right/unpaired id sets (core:857-872) reduce to
+        // three flags per group of equal read ids.
+        const char *grp = nullptr;
+        size_t grp_len = 0;
+        bool g_l = false, g_r = false, g_u = false;
+        std::vector<Ht> lhts, rhts;   // left / right positive haplotypes of the current pair (united at the flush, core:1250-1251)
+        const char *prev_id = nullptr;
+        size_t prev_len = 0;
         bool have_prev = false;
+        std::vector<int> mid;
         std::vector<Cmp> cl, c2;
         std::vector<Parser::AltSide> lset, rset;
         std::string read;
-        for (size_t i = 0; i < recs.size(); ++i) {
+        for (size_t i = i0; i < i1; ++i) {
             if (!ok[i]) continue;
             const Fields &f = recs[i];
-            size_t idlen = f.qname_len;
-            if (opts->simulation) {
-                const char *bar = (const char *)memchr(f.qname, '|', f.qname_len);
-                if (bar) idlen = bar - f.qname;
+            const size_t idlen = read_id_len(f, o.simulation != 0);
+            if (!grp || grp_len != idlen || memcmp(grp, f.qname, idlen) != 0) {
+                grp = f.qname;
+                grp_len = idlen;
+                g_l = g_r = g_u = false;
             }
-            const int pos = f.pos - (opts->base_locus + 1);
+            const int pos = f.pos - (o.base_locus + 1);
             if (pos < 0) continue;
             if (f.flag & 0x4) continue;
             if (!f.has_nm || !f.has_nh) throw RefError("TypeError: record without NM/NH tag (quirk Q8)");
-            if (f.nm > opts->num_editdist) continue;
+            if (f.nm > o.num_editdist) continue;
             if (f.nh > 1) continue;
-            if (!opts->allow_discordant && !(f.flag & 0x2)) continue;
-            std::string read_id(f.qname, idlen);
+            if (!o.allow_discordant && !(f.flag & 0x2)) continue;
             const bool is_left = (f.flag & 0x40) != 0;
             if (is_left) {
-                if (!seen_l.insert(read_id).second) continue;
+                if (g_l) continue;
+                g_l = true;
             } else if (f.flag & 0x80) {
-                if (!seen_r.insert(read_id).second) continue;
+                if (g_r) continue;
+                g_r = true;
             } else {
-                if (!opts->allow_discordant) throw RefError("assert allow_discordant");
-                if (!seen_u.insert(read_id).second) continue;
+                if (!o.allow_discordant) throw RefError("assert allow_discordant");
+                if (g_u) continue;
+                g_u = true;
             }
             read.assign(f.seq, f.seq_len);
             if (!P.decode(pos, f.cigar, read, f.zs, f.md, cl)) continue;
-            B->n_reads++;
-            if (!have_prev || read_id != prev_id) {
+            B.n_reads++;
+            if (!have_prev || prev_len != idlen || memcmp(prev_id, f.qname, idlen) != 0) {
                 if (have_prev) P.flush(lhts, rhts);
                 lhts.clear();
                 rhts.clear();
@@ -1028,7 +1026,7 @@ extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *s
             }
             int cleft, cright;
             P.ambiguous(c2, cleft, cright, lset, rset);
-            std::vector<int> mid;
+            mid.clear();
             for (int k = cleft; k <= cright; ++k)
                 if (c2[k].type != T_MATCH) mid.push_back(c2[k].id);
             for (auto &l : lset)
@@ -1039,9 +1037,10 @@ extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *s
                     h.ids = l.ids;
                     h.ids.insert(h.ids.end(), mid.begin(), mid.end());
                     h.ids.insert(h.ids.end(), r.ids.begin(), r.ids.end());
-                    (is_left ? lhts : rhts).insert(std::move(h));
+                    std::vector<Ht> &dst = is_left ? lhts : rhts;
+                    if (std::find(dst.begin(), dst.end(), h) == dst.end()) dst.push_back(std::move(h));
                 }
-            if (opts->keep_trace) {
+            if (o.keep_trace) {
                 std::string t;
                 for (size_t k = 0; k < c2.size(); ++k) {
                     if (k) t += ',';
@@ -1058,53 +1057,243 @@ extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *s
                 for (size_t k = 0; k < ls.size(); ++k) t += (k ? ";" : "") + ls[k];
                 t += '\t';
                 for (size_t k = 0; k < rs.size(); ++k) t += (k ? ";" : "") + rs[k];
-                B->trace.push_back(TraceRec{t});
+                B.trace.push_back(TraceRec{t});
             }
-            prev_id = read_id;
+            prev_id = f.qname;
+            prev_len = idlen;
             have_prev = true;
         }
         if (have_prev) {
-            if (opts->codis_choose_pairs) {                         // core:1547-1552 (CODIS locus D18S51 only)
-                // get_pair_interdist (common:1187-1265): median inner distance of unique concordant pairs
-                std::vector<long> dists;
-                std::string prev;
-                bool hp = false;
-                std::vector<std::pair<long, long>> rd;
-                for (size_t i = 0; i < recs.size(); ++i) {
-                    if (!ok[i]) continue;
-                    const Fields &f = recs[i];
-                    if (f.flag & 0x4) continue;
-                    size_t idlen = f.qname_len;
-                    if (opts->simulation) {
-                        const char *bar = (const char *)memchr(f.qname, '|', f.qname_len);
-                        if (bar) idlen = bar - f.qname;
-                    }
-                    if (!f.has_nh || f.nh > 1 || !f.yt_cp) continue;
-                    std::string id(f.qname, idlen);
-                    if (hp && id != prev) {
-                        if (rd.size() == 2)
-                            dists.push_back(rd[0].first <= rd[1].first ? rd[1].first - rd[0].second - 1 : rd[0].first - rd[1].second - 1);
-                        rd.clear();
-                    }
-                    long right = f.pos;
-                    for (const char *p = f.cigar; *p;) {
-                        char *e;
-                        const long n = strtol(p, &e, 10);
-                        if (e == p || !*e) break;
-                        if (*e == 'M' || *e == 'N' || *e == 'D') right += n;
-                        p = e + 1;
-                    }
-                    rd.push_back({(long)f.pos, right - 1});
-                    prev = id;
-                    hp = true;
-                }
-                std::sort(dists.begin(), dists.end());
-                const long expected = dists.empty() ? -1 : dists[dists.size() / 2];
-                Parser::choose_pairs(lhts, rhts, expected);
-            }
+            if (is_last && o.codis_choose_pairs) Parser::choose_pairs(lhts, rhts, expected_interdist);   // core:1547-1552
             P.flush(lhts, rhts);
         }
+    } catch (const RefError &e) {
+        out.error = std::string("the reference would fail on this input: ") + e.what();
+        out.error_code = HGX_EPARSE;
+    } catch (const std::exception &e) {
+        out.error = e.what();
+        out.error_code = HGX_EINVAL;
+    }
+}
+
+// get_pair_interdist (common:1187-1265): median inner distance of unique concordant pairs (CODIS D18S51 only)
+long pair_interdist(const std::vector<Fields> &recs, const std::vector<uint8_t> &ok, bool simulation) {
+    std::vector<long> dists;
+    std::string prev;
+    bool hp = false;
+    std::vector<std::pair<long, long>> rd;
+    for (size_t i = 0; i < recs.size(); ++i) {
+        if (!ok[i]) continue;
+        const Fields &f = recs[i];
+        if (f.flag & 0x4) continue;
+        if (!f.has_nh || f.nh > 1 || !f.yt_cp) continue;
+        std::string id(f.qname, read_id_len(f, simulation));
+        if (hp && id != prev) {
+            if (rd.size() == 2)
+                dists.push_back(rd[0].first <= rd[1].first ? rd[1].first - rd[0].second - 1 : rd[0].first - rd[1].second - 1);
+            rd.clear();
+        }
+        long right = f.pos;
+        for (const char *p = f.cigar; *p;) {
+            char *e;
+            const long n = strtol(p, &e, 10);
+            if (e == p || !*e) break;
+            if (*e == 'M' || *e == 'N' || *e == 'D') right += n;
+            p = e + 1;
+        }
+        rd.push_back({(long)f.pos, right - 1});
+        prev = id;
+        hp = true;
+    }
+    std::sort(dists.begin(), dists.end());
+    return dists.empty() ? -1 : dists[dists.size() / 2];
+}
+
+template <class F>
+void parallel_for(int n_threads, size_t n, F fn) {   // fn(thread, begin, end)
+    if (n_threads <= 1 || n < 2) { fn(0, (size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + n_threads - 1) / n_threads;
+    for (int t = 0; t < n_threads; ++t) {
+        const size_t b = std::min(n, per * t), e = std::min(n, per * (t + 1));
+        th.emplace_back([=] { fn(t, b, e); });
+    }
+    for (auto &x : th) x.join();
+}
+
+}   // namespace
+
+extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts) {
+    HARGCHK(out && Lc && (sam || n_bytes == 0) && opts);
+    hgx_locus &L = *const_cast<hgx_locus *>(Lc);
+    hgx_batch *B = new hgx_batch();
+    try {
+        const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t_prev = now();
+        auto lap = [&](const char *what) {
+            if (!prof) return;
+            const double t = now();
+            fprintf(stderr, "[hgx_parse_sam] %-22s %8.1f ms\n", what, (t - t_prev) * 1e3);
+            t_prev = t;
+        };
+        hgx_build_alternatives(L);
+        lap("alternatives");
+        const int n_ref = (int)L.backbone.size();
+        int n_threads = opts->n_threads > 0 ? opts->n_threads : (int)std::thread::hardware_concurrency();
+        n_threads = std::max(1, std::min(n_threads, 64));
+        if (opts->keep_trace) n_threads = 1;                // traces (and novel-variant numbering) follow stream order
+        // private, writable copy of the text (tokens are NUL-terminated in place) + line table, both in parallel
+        std::unique_ptr<char[]> text_mem(new char[n_bytes + 1]);      // not value-initialised: filled by the copy below
+        struct { char *p; size_t n; char *data() { return p; } size_t size() const { return n; } } text{text_mem.get(), n_bytes + 1};
+        text.p[n_bytes] = '\n';
+        std::vector<std::pair<char *, char *>> lines;
+        {
+            const int nt = n_bytes > (8u << 20) ? n_threads : 1;
+            std::vector<std::vector<std::pair<char *, char *>>> part(nt);
+            parallel_for(nt, n_bytes + 1, [&](int t, size_t b0, size_t e0) {
+                if (e0 > b0) memcpy(text.data() + b0, b0 < n_bytes ? sam + b0 : "\n", std::min(e0, n_bytes) - b0);
+            });
+            parallel_for(nt, n_bytes + 1, [&](int t, size_t b0, size_t e0) {
+                // this thread owns the lines that START in [b0, e0)
+                char *base = text.data(), *end = text.data() + text.size();
+                char *p = base + b0;
+                if (b0 > 0) {                       // skip the tail of a line owned by the previous range
+                    char *q = (char *)memchr(p - 1, '\n', end - (p - 1));
+                    p = q ? q + 1 : end;
+                }
+                while (p < base + e0 && p < end) {
+                    char *e = (char *)memchr(p, '\n', end - p);
+                    if (!e) e = end;
+                    if (e > p && *p != '@') part[t].push_back({p, e});
+                    p = e + 1;
+                }
+            });
+            size_t tot = 0;
+            for (auto &v : part) tot += v.size();
+            lines.reserve(tot);
+            for (auto &v : part) lines.insert(lines.end(), v.begin(), v.end());
+        }
+        const size_t n = lines.size();
+        if (n < 20000) n_threads = 1;
+        lap("copy + line table");
+        std::vector<Fields> recs(n);
+        std::vector<uint8_t> ok(n, 0);
+        // field split + pass 1 (pileup over all records, common:1076-1134), both embarrassingly parallel over lines
+        std::vector<std::vector<uint32_t>> tcounts(n_threads);
+        std::vector<std::string> terr(n_threads);
+        parallel_for(n_threads, n, [&](int t, size_t b, size_t e) {
+            std::vector<uint32_t> &cnt = tcounts[t];
+            cnt.assign((size_t)n_ref * 6, 0u);
+            for (size_t i = b; i < e; ++i) {
+                *lines[i].second = 0;
+                ok[i] = split_line(lines[i].first, lines[i].second, recs[i]) ? 1 : 0;
+                if (!ok[i]) continue;
+                const Fields &f = recs[i];
+                if (f.flag & 0x4) continue;
+                const int pos = f.pos - (opts->base_locus + 1);
+                if (pos < 0) continue;
+                if (!opts->allow_discordant && !(f.flag & 0x2)) continue;
+                int rp = 0, gp = pos;
+                for (const char *p = f.cigar; *p;) {
+                    char *q;
+                    const long len = strtol(p, &q, 10);
+                    if (q == p || !*q) break;
+                    const char op = *q;
+                    if (op == 'M' || op == 'D') {
+                        for (long j = 0; j < len; ++j) {
+                            if (gp + j >= n_ref) break;
+                            int slot = 5;
+                            if (op == 'M') {
+                                if ((size_t)(rp + j) >= f.seq_len) { terr[t] = "IndexError: read shorter than CIGAR"; break; }
+                                const char c = f.seq[rp + j];
+                                slot = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+                            }
+                            cnt[(size_t)(gp + j) * 6 + slot]++;
+                        }
+                    }
+                    if (op == 'M' || op == 'N' || op == 'D') gp += (int)len;
+                    if (op == 'M' || op == 'I' || op == 'S') rp += (int)len;
+                    p = q + 1;
+                }
+            }
+        });
+        lap("split + pileup");
+        for (auto &e : terr) if (!e.empty()) throw RefError(e);
+        B->counts.assign((size_t)n_ref * 6, 0u);
+        B->nt_set.assign(n_ref, 0);
+        for (auto &cnt : tcounts)
+            if (!cnt.empty())
+                for (size_t k = 0; k < B->counts.size(); ++k) B->counts[k] += cnt[k];
+        for (int i = 0; i < n_ref; ++i) {
+            const uint32_t *c = &B->counts[(size_t)i * 6];
+            const uint64_t tot = (uint64_t)c[0] + c[1] + c[2] + c[3] + c[4] + c[5];
+            int m = 0;
+            if (tot >= 20)
+                for (int k = 0; k < 4; ++k)
+                    if ((double)c[k] >= (double)tot * 0.2 || c[k] >= 7) m |= 1 << k;
+            B->nt_set[i] = (uint8_t)m;
+        }
+        const long expected = opts->codis_choose_pairs ? pair_interdist(recs, ok, opts->simulation != 0) : -1;
+        // pass 2: chunks that start where the read id changes
+        const int n_chunks = n_threads == 1 ? 1 : n_threads * 4;
+        std::vector<size_t> cut{0};
+        for (int c = 1; c < n_chunks; ++c) {
+            size_t i = std::max(cut.back(), n * c / n_chunks);
+            while (i < n && i > 0) {
+                if (ok[i] && ok[i - 1]) {
+                    const size_t la = read_id_len(recs[i], opts->simulation != 0), lb = read_id_len(recs[i - 1], opts->simulation != 0);
+                    if (la != lb || memcmp(recs[i].qname, recs[i - 1].qname, la) != 0) break;
+                }
+                ++i;
+            }
+            if (i > cut.back() && i < n) cut.push_back(i);
+        }
+        cut.push_back(n);
+        const size_t nc = cut.size() - 1;
+        std::vector<ChunkResult> res(nc);
+        lap("pileup merge + cuts");
+        {
+            std::atomic<size_t> next{0};
+            auto worker = [&]() {
+                for (;;) {
+                    const size_t c = next.fetch_add(1);
+                    if (c >= nc) break;
+                    process_chunk(L, *opts, recs, ok, cut[c], cut[c + 1], *B, c + 1 == nc, expected, res[c]);
+                }
+            };
+            if (n_threads == 1) worker();
+            else {
+                std::vector<std::thread> th;
+                for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
+                for (auto &x : th) x.join();
+            }
+        }
+        for (auto &r : res)
+            if (r.error_code) {
+                hgx_set_error("%s", r.error.c_str());
+                const int code = r.error_code;
+                delete B;
+                return code;
+            }
+        lap("streaming loop");
+        // merge in stream order: re-intern each chunk's distinct pieces, renumber its refs
+        for (auto &r : res) {
+            hgx_batch &lb = r.local;
+            std::vector<uint32_t> remap(lb.pieces.size());
+            for (size_t k = 0; k < lb.pieces.size(); ++k) {
+                const hgx_piece &pc = lb.pieces[k];
+                remap[k] = hgx_intern_masks(*B, pc.lo_word, pc.n_words, &lb.masks[pc.mask_off]);
+            }
+            const int32_t base = (int32_t)B->pair_ref.size();
+            for (uint32_t ref : lb.pair_ref) B->pair_ref.push_back((ref & 0x80000000u) | remap[ref & 0x7fffffffu]);
+            for (size_t k = 1; k < lb.pair_off.size(); ++k) B->pair_off.push_back(base + lb.pair_off[k]);
+            B->n_reads += lb.n_reads;
+            for (auto &t : lb.trace) B->trace.push_back(std::move(t));
+        }
+        lap("merge");
         hgx_finalize_batch(*B);
+        lap("finalize");
     } catch (const RefError &e) {
         hgx_set_error("the reference would fail on this input: %s", e.what());
         delete B;

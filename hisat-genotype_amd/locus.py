@@ -203,10 +203,10 @@ class PackedLocus:
         return Batch(h)
 
     def parse_sam(self, sam_text, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False,
-                  base_locus=0, keep_trace=False):
+                  base_locus=0, keep_trace=False, n_threads=0):
         data = sam_text if isinstance(sam_text, (bytes, bytearray)) else sam_text.encode()
         o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus,
-                           int(keep_trace), int(self.base_fname == "codis" and self.gene == "D18S51"))
+                           int(keep_trace), int(self.base_fname == "codis" and self.gene == "D18S51"), int(n_threads))
         h = C.c_void_p()
         capi.check(capi.lib().hgx_parse_sam(C.byref(h), self.h, data, C.c_size_t(len(data)), C.byref(o)))
         return Batch(h)

@@ -235,6 +235,7 @@ typedef struct hgx_parse_opts {
     int32_t base_locus;         /* subtracted from POS                            core:814 */
     int32_t keep_trace;         /* record per-read intermediates for hgx_batch_trace_text   */
     int32_t codis_choose_pairs; /* base codis && gene == "D18S51": choose_pairs at the final flush (core:1547-1552) */
+    int32_t n_threads;          /* host threads for the front-end; 0 = all hardware threads                   */
 } hgx_parse_opts;
 
 /* SAM text (name-grouped, i.e. the stream after `sort -k1,1 -s`, core:458-468) -> batch.
