@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--err", type=float, default=0.002)
     ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (profiling runs)")
     return ap.parse_args()
 
 
@@ -105,7 +106,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    if world > 1:
+    use_dist = world > 1 or bool(os.environ.get("HGX_FORCE_DIST"))     # the latter exercises the RCCL path on one GPU
+    if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
@@ -116,7 +118,7 @@ def main():
     t_setup = time.perf_counter()
     loc = synth.make_hla_like_locus(n_alleles=args.alleles, n_vars=args.vars, seed=101)
     pl = hl.PackedLocus.from_synth(loc)
-    if world > 1:
+    if use_dist:
         from hisatgenotype_amd import dist as hdist
         hdist.broadcast_index(pl, src=0)          # rank 0's packed link matrix reaches every GPU over RCCL/xGMI
     else:
@@ -128,7 +130,7 @@ def main():
     t_parse = time.perf_counter() - t0
     db = engine.DeviceBatch(batch)
     bufs = engine.ScoreBuffers(pl, db, exon=True)
-    if rank != 0 or args.no_cpu_baseline or world > 1:
+    if rank != 0 or args.no_cpu_baseline or use_dist:
         sam_keep = None
     else:
         sam_keep = sam
@@ -141,7 +143,7 @@ def main():
     if dist is not None:
         dist.barrier()
     ev = [(capi.Event(), capi.Event(), capi.Event()) for _ in range(args.steps)]
-    engine.em_set_timing(True)        # HIP events around every EM mat-vec launch of the timed region
+    engine.em_set_timing(not args.no_kernel_timing)        # HIP events around every EM mat-vec launch of the timed region
     t_em = 0.0
     n_em_iter = 0
     t0 = time.perf_counter()

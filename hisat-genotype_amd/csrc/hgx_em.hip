@@ -15,6 +15,7 @@
 // The host enqueues iterations in batches without waiting: every kernel starts by reading a device-side
 // `done` word, so iterations queued past convergence fall through in a few microseconds.
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 #include "hgx_common.hpp"
@@ -63,6 +64,20 @@ __device__ __forceinline__ double block_max(double v, double *sh) {
 }
 
 enum { MODE_ROWS = 0, MODE_COLS = 1, MODE_SUM = 2, MODE_MIN = 3 };
+
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+
+// 64-byte scalar load issued by hand so that it can stay in flight across the masked adds of the previous rows
+__device__ __forceinline__ u32x16 sload16(const void *p) {
+    u32x16 r;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(p) : "memory");
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void swait(u32x16 (&v)[N]) {
+    if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v[0]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v[0]), "+s"(v[1]));
+}
 
 // acc (op)= x on the lanes whose bit is set in the wave-uniform 64-bit `word`: the word goes straight into
 // EXEC, so one matrix word costs ONE vector instruction (plus two scalar ones) instead of shift/and/select.
@@ -134,20 +149,60 @@ __global__ __launch_bounds__(BLOCK) void k_bitmatvec(const uint64_t *__restrict_
                                                      double *__restrict__ y, uint8_t *__restrict__ pres_out,
                                                      double *__restrict__ scal, int gate /* 0 always, 1 needs S_FLAG */) {
     constexpr bool MIN = MODE == MODE_MIN;
+    constexpr bool EM = MODE == MODE_ROWS || MODE == MODE_COLS;
     __shared__ double sh[NWAVE];
     __shared__ double part[MAX_RPB][NWAVE];
-    if (MODE == MODE_ROWS || MODE == MODE_COLS) {
-        if (scal[S_DONE] != 0.0) return;
-        if (gate && scal[S_FLAG] == 0.0) return;
-    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int row0 = blockIdx.x * rows_per_block;
     const int nrow = min(rows_per_block, n_rows - row0);
+    // Everything the kernel will need from memory besides the matrix is requested up front, before the convergence
+    // gate is even known: the state words, this thread's epilogue operands and its vector elements.  These launches
+    // are short, so dependent round trips to memory are what they cost.
+    double st_done = 0.0, st_flag = 1.0, tot = 1.0;
+    if (EM) { st_done = scal[S_DONE]; st_flag = scal[S_FLAG]; }
+    if (MODE == MODE_COLS) tot = scal[S_TOT_A];
+    double e_count = 0.0, e_q = 0.0, e_len = 1.0;
+    bool e_pres = true;
+    if (tid < nrow) {
+        const int row = row0 + tid;
+        if (MODE == MODE_ROWS) e_count = (double)count[row];
+        if (MODE == MODE_COLS) {
+            if (x_mode != 2) { e_q = q_in[row]; e_pres = pres_in[row] != 0; }
+            if (len) e_len = len[row];
+        }
+    }
+    double x[KPT];
+    auto load_x = [&](int k0) {
+#pragma unroll
+        for (int k = 0; k < KPT; ++k) {
+            const int e = k0 + 64 * (KPT * wv + k) + lane;
+            double v = MIN ? __builtin_inf() : 0.0;
+            if (e < n_k) {
+                if (MODE == MODE_ROWS) v = (x_mode == 2) ? 1.0 : (vec_pres[e] ? vec[e] : 0.0);
+                else if (MODE == MODE_COLS) v = vec[e];
+                else if (MODE == MODE_SUM) v = (double)count[e];
+                else v = (double)e;
+            }
+            x[k] = v;
+        }
+    };
+    load_x(0);
     if (nrow <= 0) return;
+    if (EM) {
+        if (st_done != 0.0) return;
+        if (gate && st_flag == 0.0) return;
+    }
+    if (MODE == MODE_COLS && x_mode != 2) {
+        // rows (alleles) that are not present produce 0 whatever the matrix says: a block without a present row is done
+        if (!__syncthreads_or(tid < nrow && e_pres)) {
+            if (tid < nrow) { y[row0 + tid] = 0.0; pres_out[row0 + tid] = 0; }
+            if (blockIdx.x == 0 && tid == 0) scal[S_NCOLS] += 1.0;
+            return;
+        }
+    }
     // every (row, wave) slot of `part` is owned by one lane of that wave: no cross-wave traffic before the final barrier
     for (int i = tid; i < MAX_RPB * NWAVE; i += BLOCK) (&part[0][0])[i] = MIN ? __builtin_inf() : 0.0;
-    double tot = 1.0;
     if (MODE == MODE_ROWS && x_mode == 1) {
         double s = 0.0;
         for (int e = tid; e < n_k; e += BLOCK) if (vec_pres[e]) s += vec[e];
@@ -155,42 +210,53 @@ __global__ __launch_bounds__(BLOCK) void k_bitmatvec(const uint64_t *__restrict_
     }
     if (MODE == MODE_ROWS && blockIdx.x == 0 && tid == 0) { scal[S_TOT_A] = tot; scal[S_NROWS] += 1.0; }
     if (MODE == MODE_COLS && blockIdx.x == 0 && tid == 0) scal[S_NCOLS] += 1.0;
-    if (MODE == MODE_COLS) tot = scal[S_TOT_A];
     __syncthreads();
     // Wave w owns KPT consecutive 64-bit words of every row chunk (elements 64*(KPT*w + k) + lane), fetched with
     // one 64-byte scalar load per 8 words.  No validity tests in the hot loop: addresses are clamped into the
     // (8-word padded, zero filled) row and out-of-range elements carry x = 0 (+inf for MIN), so whatever bits a
     // clamped load returns contribute nothing.
-    struct W8 { uint64_t w[8]; };
     for (int k0 = 0; k0 < n_k; k0 += KPT * BLOCK) {
-        double x[KPT];
+        if (k0 > 0) load_x(k0);
+        if (MODE == MODE_ROWS && x_mode == 1) {
 #pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const int e = k0 + 64 * (KPT * wv + k) + lane;
-            double v = MIN ? __builtin_inf() : 0.0;
-            if (e < n_k) {
-                if (MODE == MODE_ROWS) v = (x_mode == 2) ? 1.0 : (vec_pres[e] ? vec[e] / tot : 0.0);
-                else if (MODE == MODE_COLS) v = vec[e];
-                else if (MODE == MODE_SUM) v = (double)count[e];
-                else v = (double)e;
-            }
-            x[k] = v;
+            for (int k = 0; k < KPT; ++k) x[k] = x[k] / tot;
         }
         const int wbase = min((k0 >> 6) + KPT * wv, n_words - KPT);
+        // Row words arrive through the scalar cache (64 bytes per s_load_dwordx16).  SMEM returns out of order, so the
+        // only safe wait is lgkmcnt(0); to keep the loads off the critical path the batch of 8 rows is walked in halves:
+        // while one half is being applied (EXEC-masked adds) the next half's loads are already in flight.
+        constexpr int RH = KPT == 8 ? 2 : 1;               // rows per half: 32 SGPRs of matrix words in each buffer
+        constexpr int L16 = KPT / 8;                        // 64-byte loads per row
         for (int rb = 0; rb < nrow; rb += RB) {
             double acc[RB];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) {
-                acc[r] = MIN ? __builtin_inf() : 0.0;
-                const uint64_t *brow = B + (size_t)min(row0 + rb + r, n_rows - 1) * n_words + wbase;
+            for (int r = 0; r < RB; ++r) acc[r] = MIN ? __builtin_inf() : 0.0;
+            u32x16 buf[2][RH * L16];
+            auto issue = [&](int half, u32x16 (&dst)[RH * L16]) {
 #pragma unroll
-                for (int h = 0; h < KPT / 8; ++h) {
-                    const W8 ww = *reinterpret_cast<const W8 *>(brow + 8 * h);
+                for (int i = 0; i < RH; ++i) {
+                    const uint64_t *brow = B + (size_t)min(row0 + rb + half * RH + i, n_rows - 1) * n_words + wbase;
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        if (MIN) masked_min(acc[r], x[8 * h + k], ww.w[k]);
-                        else masked_add(acc[r], x[8 * h + k], ww.w[k]);
-                    }
+                    for (int h = 0; h < L16; ++h) dst[i * L16 + h] = sload16(brow + 8 * h);
+                }
+            };
+            issue(0, buf[0]);
+#pragma unroll
+            for (int half = 0; half < RB / RH; ++half) {
+                u32x16(&cur)[RH * L16] = buf[half & 1];
+                swait(cur);
+                if (half + 1 < RB / RH) issue(half + 1, buf[(half + 1) & 1]);
+#pragma unroll
+                for (int i = 0; i < RH; ++i) {
+                    const int r = half * RH + i;
+#pragma unroll
+                    for (int h = 0; h < L16; ++h)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const uint64_t word = ((uint64_t)cur[i * L16 + h][2 * k + 1] << 32) | cur[i * L16 + h][2 * k];
+                            if (MIN) masked_min(acc[r], x[8 * h + k], word);
+                            else masked_add(acc[r], x[8 * h + k], word);
+                        }
                 }
             }
             const double s = reduce8<MIN>(acc, lane);
@@ -207,14 +273,14 @@ __global__ __launch_bounds__(BLOCK) void k_bitmatvec(const uint64_t *__restrict_
         for (int i = 1; i < NWAVE; ++i) t = comb<MIN>(t, part[tid][i]);
         const int row = row0 + tid;
         if (MODE == MODE_ROWS) {
-            y[row] = t > 0.0 ? (double)count[row] / t : 0.0;
+            y[row] = t > 0.0 ? e_count / t : 0.0;
         } else if (MODE == MODE_COLS) {
             const bool init = x_mode == 2;
-            const bool in = init || pres_in[row];
+            const bool in = init || e_pres;
             double v = 0.0;
             if (in && t > 0.0) {
-                v = init ? t : (q_in[row] / tot) * t;
-                if (len) v = v / len[row];
+                v = init ? t : (e_q / tot) * t;
+                if (len) v = v / e_len;
             }
             y[row] = v;
             pres_out[row] = (in && t > 0.0) ? 1 : 0;
@@ -224,40 +290,91 @@ __global__ __launch_bounds__(BLOCK) void k_bitmatvec(const uint64_t *__restrict_
     }
 }
 
+// N block-wide sums with a single barrier pair (fixed summation order: identical in every launch)
+template <int N>
+__device__ __forceinline__ void block_sum_n(double (&v)[N], double (*sh)[NWAVE]) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int n = 0; n < N; ++n) v[n] = wave_sum_f64(v[n]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int n = 0; n < N; ++n) sh[n][wv] = v[n];
+    __syncthreads();
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < NWAVE; ++i) t += sh[n][i];
+        v[n] = t;
+    }
+}
+
+constexpr int EPT = 8;     // vector elements per thread kept in registers by the single-workgroup kernels (a_pad <= 8192)
+
 // SQUAREM extrapolation (common:1361-1380).  p = pq (normalised already), p1 = q1/sum(q1), p2 = q2/sum(q2).
 // Writes q2 <- max(0, p - 2 g r + g^2 v) (used raw by the third map) when sum v^2 > 0.
+// One workgroup; every operand is read once into registers, two reduction rounds.
 __global__ __launch_bounds__(BLOCK) void k_em_squarem(const double *__restrict__ p, const uint8_t *__restrict__ pres,
                                                       const double *__restrict__ q1, const uint8_t *__restrict__ pres1,
                                                       double *__restrict__ q2, uint8_t *__restrict__ pres2, int a_pad,
                                                       double *__restrict__ scal) {
-    __shared__ double sh[NWAVE];
-    if (scal[S_DONE] != 0.0) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int a = threadIdx.x; a < a_pad; a += BLOCK) {
-        if (pres1[a]) s1 += q1[a];
-        if (pres2[a]) s2 += q2[a];
+    __shared__ double sh[3][NWAVE];
+    const double done = scal[S_DONE];
+    double vp[EPT], v1[EPT], v2[EPT];
+    uint8_t f0[EPT], f1[EPT], f2[EPT];
+    const bool small = a_pad <= EPT * BLOCK;
+    double red[2] = {0.0, 0.0};
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int a = threadIdx.x + BLOCK * k;
+            const bool in = a < a_pad;
+            f0[k] = in ? pres[a] : 0; f1[k] = in ? pres1[a] : 0; f2[k] = in ? pres2[a] : 0;
+            vp[k] = in ? p[a] : 0.0; v1[k] = in ? q1[a] : 0.0; v2[k] = in ? q2[a] : 0.0;
+        }
     }
-    const double tot1 = block_sum(s1, sh), tot2 = block_sum(s2, sh);
-    double sr = 0.0, sv = 0.0, key = 0.0;
-    for (int a = threadIdx.x; a < a_pad; a += BLOCK) {
-        if (!pres[a]) continue;
-        if (!pres1[a] || !pres2[a]) { key = 1.0; continue; }
-        const double p1 = q1[a] / tot1, p2 = q2[a] / tot2;
-        const double r = p1 - p[a];
+    if (done != 0.0) return;
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) { if (f1[k]) red[0] += v1[k]; if (f2[k]) red[1] += v2[k]; }
+    } else {
+        for (int a = threadIdx.x; a < a_pad; a += BLOCK) { if (pres1[a]) red[0] += q1[a]; if (pres2[a]) red[1] += q2[a]; }
+    }
+    block_sum_n<2>(red, sh);
+    const double tot1 = red[0], tot2 = red[1];
+    double acc[3] = {0.0, 0.0, 0.0};   // sum r^2, sum v^2, key error
+    auto term = [&](bool a0, bool a1, bool a2, double x0, double x1, double x2) {
+        if (!a0) return;
+        if (!a1 || !a2) { acc[2] = 1.0; return; }
+        const double p1 = x1 / tot1, p2 = x2 / tot2;
+        const double r = p1 - x0;
         const double v = p2 - p1 - r;
-        sr += r * r;
-        sv += v * v;
+        acc[0] += r * r;
+        acc[1] += v * v;
+    };
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) term(f0[k], f1[k], f2[k], vp[k], v1[k], v2[k]);
+    } else {
+        for (int a = threadIdx.x; a < a_pad; a += BLOCK) term(pres[a], pres1[a], pres2[a], p[a], q1[a], q2[a]);
     }
-    const double tsr = block_sum(sr, sh), tsv = block_sum(sv, sh), tkey = block_sum(key, sh);
+    block_sum_n<3>(acc, sh);
+    const double tsr = acc[0], tsv = acc[1], tkey = acc[2];
     if (tsv > 0.0 && tkey == 0.0) {
         const double g = -sqrt(tsr / tsv);
-        for (int a = threadIdx.x; a < a_pad; a += BLOCK) {
-            if (!pres[a]) continue;
-            const double p1 = q1[a] / tot1, p2 = q2[a] / tot2;
-            const double r = p1 - p[a];
+        auto upd = [&](int a, double x0, double x1, double x2) {
+            const double p1 = x1 / tot1, p2 = x2 / tot2;
+            const double r = p1 - x0;
             const double v = p2 - p1 - r;
-            q2[a] = fmax(0.0, p[a] - 2 * g * r + g * g * v);
+            q2[a] = fmax(0.0, x0 - 2 * g * r + g * g * v);
             pres2[a] = 1;
+        };
+        if (small) {
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) if (f0[k]) upd(threadIdx.x + BLOCK * k, vp[k], v1[k], v2[k]);
+        } else {
+            for (int a = threadIdx.x; a < a_pad; a += BLOCK) if (pres[a]) upd(a, p[a], q1[a], q2[a]);
         }
     }
     if (threadIdx.x == 0) {
@@ -272,30 +389,64 @@ __global__ __launch_bounds__(BLOCK) void k_em_advance(double *__restrict__ p, ui
                                                       const double *__restrict__ q1, const uint8_t *__restrict__ pres1,
                                                       const double *__restrict__ q3, const uint8_t *__restrict__ pres3,
                                                       int a_pad, int remove_low, double *__restrict__ scal) {
-    __shared__ double sh[NWAVE];
-    if (scal[S_DONE] != 0.0) return;
-    const bool ext = scal[S_FLAG] != 0.0;
+    __shared__ double sh[2][NWAVE];
+    __shared__ double shm[NWAVE];
+    const double done = scal[S_DONE], flag = scal[S_FLAG], it_d = scal[S_ITER];
+    // both candidate sources are fetched before the flag is known (one memory round trip instead of two)
+    double vp[EPT], va[EPT], vb[EPT];
+    uint8_t f0[EPT], fa[EPT], fb[EPT];
+    const bool small = a_pad <= EPT * BLOCK;
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int a = threadIdx.x + BLOCK * k;
+            const bool in = a < a_pad;
+            f0[k] = in ? pres[a] : 0; fa[k] = in ? pres1[a] : 0; fb[k] = in ? pres3[a] : 0;
+            vp[k] = in ? p[a] : 0.0; va[k] = in ? q1[a] : 0.0; vb[k] = in ? q3[a] : 0.0;
+        }
+    }
+    if (done != 0.0) return;
+    const bool ext = flag != 0.0;
     const double *qn = ext ? q3 : q1;
     const uint8_t *prn = ext ? pres3 : pres1;
-    double s = 0.0;
-    for (int a = threadIdx.x; a < a_pad; a += BLOCK) if (prn[a]) s += qn[a];
-    const double tot = block_sum(s, sh);
-    double d = 0.0, mx = 0.0;
-    for (int a = threadIdx.x; a < a_pad; a += BLOCK) {
-        const double pn = prn[a] ? qn[a] / tot : 0.0;
-        if (pres[a]) d += prn[a] ? fabs(p[a] - pn) : p[a];
-        if (prn[a]) mx = fmax(mx, pn);
+    double s[1] = {0.0};
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) { const bool pr_ = ext ? fb[k] : fa[k]; if (pr_) s[0] += ext ? vb[k] : va[k]; }
+    } else {
+        for (int a = threadIdx.x; a < a_pad; a += BLOCK) if (prn[a]) s[0] += qn[a];
     }
-    const double td = block_sum(d, sh);
-    const double tm = block_max(mx, sh);
-    const int iter = (int)scal[S_ITER];
+    block_sum_n<1>(s, sh);
+    const double tot = s[0];
+    double d[1] = {0.0}, mx = 0.0;
+    auto term = [&](bool a0, bool an, double x0, double xn) {
+        const double pn = an ? xn / tot : 0.0;
+        if (a0) d[0] += an ? fabs(x0 - pn) : x0;
+        if (an) mx = fmax(mx, pn);
+    };
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) term(f0[k], ext ? fb[k] : fa[k], vp[k], ext ? vb[k] : va[k]);
+    } else {
+        for (int a = threadIdx.x; a < a_pad; a += BLOCK) term(pres[a], prn[a], p[a], qn[a]);
+    }
+    const double tm = block_max(mx, shm);
+    block_sum_n<1>(d, sh);
+    const double td = d[0];
+    const int iter = (int)it_d;
     const bool prune = remove_low && iter >= 10;
-    for (int a = threadIdx.x; a < a_pad; a += BLOCK) {
-        const double pn = prn[a] ? qn[a] / tot : 0.0;
-        bool keep = prn[a];
+    auto store = [&](int a, bool an, double xn) {
+        const double pn = an ? xn / tot : 0.0;
+        bool keep = an;
         if (prune && keep) keep = pn >= tm / 10.0;
         pres[a] = keep ? 1 : 0;
         p[a] = keep ? pn : 0.0;
+    };
+    if (small) {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) { const int a = threadIdx.x + BLOCK * k; if (a < a_pad) store(a, ext ? fb[k] : fa[k], ext ? vb[k] : va[k]); }
+    } else {
+        for (int a = threadIdx.x; a < a_pad; a += BLOCK) store(a, prn[a], qn[a]);
     }
     if (threadIdx.x == 0) {
         scal[S_DIFF] = td;
@@ -333,12 +484,204 @@ __global__ __launch_bounds__(BLOCK) void k_em_finish(const double *__restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Whole EM in ONE workgroup for small problems (C <= SMALL_C classes, a_pad <= 8192): the exon->gene hand-off EM and
+// STR loci have a few dozen classes, where eight launches per iteration cost far more than the arithmetic.
+// Same step sequence and summation structure as the multi-launch path; vectors live in registers (thread = the
+// elements 64*(8*wave + k) + lane), the class matrix is read row-major for both halves of the map.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SMALL_C = 64;
+
+struct SmallVec {
+    double v[EPT];
+    uint32_t pres;      // bit k: element k present
+};
+
+__device__ __forceinline__ double sv_total(const SmallVec &a, double (*sh)[NWAVE]) {
+    double s[1] = {0.0};
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) if ((a.pres >> k) & 1u) s[0] += a.v[k];
+    block_sum_n<1>(s, sh);
+    return s[0];
+}
+
+// out = T(in): in is used as in.v[k] / scale.  Rows half through LDS partials, columns half thread-local.
+__device__ __forceinline__ void small_map(const uint64_t *__restrict__ B, int C, int n_words, const int64_t *__restrict__ count,
+                                          const double *__restrict__ len_reg, bool use_len, const SmallVec &in, double scale,
+                                          bool init, SmallVec &out, double (*part)[NWAVE], double *wc, int wv, int lane,
+                                          int wbase, uint32_t valid) {
+    // `valid` bit k: this thread really owns element k (waves past the matrix width read clamped words: their x is 0)
+    double x[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const bool ok = (valid >> k) & 1u;
+        x[k] = !ok ? 0.0 : (init ? 1.0 : (((in.pres >> k) & 1u) ? in.v[k] / scale : 0.0));
+    }
+    for (int c = 0; c < C; ++c) {
+        u32x16 w[1];
+        w[0] = sload16(B + (size_t)c * n_words + wbase);
+        swait(w);
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) masked_add(acc, x[k], ((uint64_t)w[0][2 * k + 1] << 32) | w[0][2 * k]);
+        acc = wave_sum_f64(acc);
+        if (lane == 0) part[c][wv] = acc;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < NWAVE; ++i) t += part[threadIdx.x][i];
+        wc[threadIdx.x] = t > 0.0 ? (double)count[threadIdx.x] / t : 0.0;
+    }
+    __syncthreads();
+    double acc[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) acc[k] = 0.0;
+    for (int c = 0; c < C; ++c) {
+        u32x16 w[1];
+        w[0] = sload16(B + (size_t)c * n_words + wbase);
+        const double wv_c = wc[c];
+        swait(w);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) masked_add(acc[k], wv_c, ((uint64_t)w[0][2 * k + 1] << 32) | w[0][2 * k]);
+    }
+    out.pres = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const bool in_k = ((valid >> k) & 1u) && (init || ((in.pres >> k) & 1u));
+        double v = 0.0;
+        if (in_k && acc[k] > 0.0) {
+            v = init ? acc[k] : (in.v[k] / scale) * acc[k];
+            if (use_len) v = v / len_reg[k];
+            out.pres |= 1u << k;
+        }
+        out.v[k] = v;
+    }
+    __syncthreads();          // part / wc are reused by the next application
+}
+
+__global__ __launch_bounds__(BLOCK) void k_em_small(const uint64_t *__restrict__ B, int C, int n_words, int a_pad,
+                                                    const int64_t *__restrict__ count, const double *__restrict__ len,
+                                                    int remove_low, double *__restrict__ out, double *__restrict__ scal) {
+    __shared__ double sh[3][NWAVE];
+    __shared__ double shm[NWAVE];
+    __shared__ double part[SMALL_C][NWAVE];
+    __shared__ double wc[SMALL_C];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wbase = min(8 * wv, n_words - 8);
+    const bool own = 8 * wv + 8 <= n_words;                 // waves beyond the matrix width own no elements
+    double len_reg[EPT];
+    int elem[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        elem[k] = 64 * (8 * wv + k) + lane;
+        len_reg[k] = (len && own && elem[k] < a_pad) ? len[elem[k]] : 1.0;
+    }
+    const bool use_len = len != nullptr;
+    uint32_t valid = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) if (own && elem[k] < a_pad) valid |= 1u << k;
+    SmallVec p, q1, q2, q3, none;
+    none.pres = 0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) none.v[k] = 0.0;
+    small_map(B, C, n_words, count, len_reg, use_len, none, 1.0, true, p, part, wc, wv, lane, wbase, valid);   // common:1299-1305
+    double tot = sv_total(p, sh);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) p.v[k] = ((p.pres >> k) & 1u) ? p.v[k] / tot : 0.0;
+    int iter = 0;
+    double diff = 1.0;
+    bool keyerr = false;
+    while (diff > 0.0001 && iter < 1000) {
+        small_map(B, C, n_words, count, len_reg, use_len, p, 1.0, false, q1, part, wc, wv, lane, wbase, valid);
+        const double tot1 = sv_total(q1, sh);
+        small_map(B, C, n_words, count, len_reg, use_len, q1, tot1, false, q2, part, wc, wv, lane, wbase, valid);
+        const double tot2 = sv_total(q2, sh);
+        double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            if (!((p.pres >> k) & 1u)) continue;
+            if (!((q1.pres >> k) & 1u) || !((q2.pres >> k) & 1u)) { acc[2] = 1.0; continue; }
+            const double p1 = q1.v[k] / tot1, p2 = q2.v[k] / tot2;
+            const double r = p1 - p.v[k];
+            const double v = p2 - p1 - r;
+            acc[0] += r * r;
+            acc[1] += v * v;
+        }
+        block_sum_n<3>(acc, sh);
+        if (acc[2] != 0.0) { keyerr = true; break; }
+        const SmallVec *pn = &q1;
+        double totn = tot1;
+        if (acc[1] > 0.0) {
+            const double g = -sqrt(acc[0] / acc[1]);
+#pragma unroll
+            for (int k = 0; k < EPT; ++k) {
+                if (!((p.pres >> k) & 1u)) continue;
+                const double p1 = q1.v[k] / tot1, p2 = q2.v[k] / tot2;
+                const double r = p1 - p.v[k];
+                const double v = p2 - p1 - r;
+                q2.v[k] = fmax(0.0, p.v[k] - 2 * g * r + g * g * v);
+                q2.pres |= 1u << k;
+            }
+            small_map(B, C, n_words, count, len_reg, use_len, q2, 1.0, false, q3, part, wc, wv, lane, wbase, valid);
+            pn = &q3;
+            totn = sv_total(q3, sh);
+        }
+        double d[1] = {0.0}, mx = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const bool an = (pn->pres >> k) & 1u;
+            const double x = an ? pn->v[k] / totn : 0.0;
+            if ((p.pres >> k) & 1u) d[0] += an ? fabs(p.v[k] - x) : p.v[k];
+            if (an) mx = fmax(mx, x);
+        }
+        const double tm = block_max(mx, shm);
+        block_sum_n<1>(d, sh);
+        diff = d[0];
+        const bool prune = remove_low && iter >= 10;
+        uint32_t np = 0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const bool an = (pn->pres >> k) & 1u;
+            const double x = an ? pn->v[k] / totn : 0.0;
+            bool keep = an;
+            if (prune && keep) keep = x >= tm / 10.0;
+            p.v[k] = keep ? x : 0.0;
+            if (keep) np |= 1u << k;
+        }
+        p.pres = np;
+        iter += 1;
+    }
+    // final select_alleles + normalise (common:1402-1407)
+    double mx = 0.0;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) if ((p.pres >> k) & 1u) mx = fmax(mx, p.v[k]);
+    const double tm = block_max(mx, shm);
+    double s[1] = {0.0};
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const bool keep = ((p.pres >> k) & 1u) && (!remove_low || p.v[k] >= tm / 10.0);
+        if (keep) s[0] += use_len ? p.v[k] / len_reg[k] : p.v[k];
+    }
+    block_sum_n<1>(s, sh);
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const bool keep = ((p.pres >> k) & 1u) && (!remove_low || p.v[k] >= tm / 10.0);
+        if ((valid >> k) & 1u) out[elem[k]] = keep ? (use_len ? p.v[k] / len_reg[k] / s[0] : p.v[k] / s[0]) : -1.0;
+    }
+    if (tid == 0) { scal[S_ITER] = (double)iter; scal[S_KEYERR] = keyerr ? 1.0 : 0.0; scal[S_DONE] = 1.0; }
+}
+
 struct MatVec {
     const uint64_t *B;
     int n_rows, n_words, n_k;
 };
 
 inline int rows_per_block(int n_rows) {
+    static const int forced = getenv("HGX_RPB") ? atoi(getenv("HGX_RPB")) : 0;     // tuning aid
+    if (forced >= RB && forced <= MAX_RPB && forced % RB == 0) return forced;
     int rpb = ((n_rows + 511) / 512 + RB - 1) / RB * RB;
     return std::max(RB, std::min(MAX_RPB, rpb));
 }
@@ -399,6 +742,34 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
     if (n_iter_host) *n_iter_host = 0;
     if (C == 0) {
         for (int a = 0; a < n_alleles; ++a) prob_host[a] = -1.0;
+        return HGX_OK;
+    }
+    if (C <= SMALL_C && A <= EPT * BLOCK && !getenv("HGX_EM_NO_SMALL")) {
+        // single-workgroup path: one launch, one sync
+        DevBuf b_len, b_scal, b_out;
+        ALLOC(b_scal, S_N * 8); ALLOC(b_out, A * 8);
+        double *d_len = nullptr;
+        if (allele_len) {
+            std::vector<double> l(A, 1.0);
+            for (int a = 0; a < n_alleles; ++a) l[a] = (double)allele_len[a];
+            ALLOC(b_len, A * 8);
+            HIPCHK(hipMemcpyAsync(b_len.p, l.data(), A * 8, hipMemcpyHostToDevice, st));
+            d_len = b_len.as<double>();
+        }
+        hipLaunchKernelGGL(k_em_small, dim3(1), dim3(BLOCK), 0, st, c->d_bits, C, c->w64, A, c->d_count, d_len, remove_low ? 1 : 0,
+                           b_out.as<double>(), b_scal.as<double>());
+        HIPCHK(hipGetLastError());
+        std::vector<double> out(A);
+        double h_scal[S_N];
+        HIPCHK(hipMemcpyAsync(out.data(), b_out.p, A * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_scal, b_scal.p, S_N * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h_scal[S_KEYERR] != 0.0) {
+            hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
+            return HGX_EKEY;
+        }
+        for (int a = 0; a < n_alleles; ++a) prob_host[a] = out[a];
+        if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
         return HGX_OK;
     }
     int rc = hgx_ensure_transposed(c, st);

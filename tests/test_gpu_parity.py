@@ -216,3 +216,25 @@ def test_empty_and_degenerate_inputs(orc):
     assert np.array_equal(bufs.exon_bits.to_host(), np.tile(t["exon_mask"], (3, 1)))
     gcl = engine.Classes.dedup(bufs.gene_bits, 3, pl.a_pad, hashes=bufs.gene_hash)
     assert gcl.n_classes == 1 and gcl.to_host()[1][0] == 3
+
+
+def test_em_single_workgroup_path_equals_multi_launch_path(orc):
+    """Problems with <= 64 classes run in one workgroup (k_em_small); both paths must agree to rounding."""
+    import os
+    fx, loc, t, pl, batch, (eb, gb, gc, fp) = _setup(orc, "hla_mid_real")
+    A = t["n_alleles"]
+    w = (A + 63) // 64
+    ub, uc, _ = orc.dedup(eb)
+    rows = np.zeros((40, pl.w64), np.uint64)
+    rows[:, :w] = ub[:40]
+    cl = engine.Classes.from_host(rows, uc[:40], pl.a_pad)
+    for low, ln in ((False, None), (True, pl.allele_len), (True, None)):
+        p_small, it_small = cl.em(A, low, ln)
+        os.environ["HGX_EM_NO_SMALL"] = "1"
+        try:
+            p_big, it_big = cl.em(A, low, ln)
+        finally:
+            del os.environ["HGX_EM_NO_SMALL"]
+        assert it_small == it_big
+        assert np.array_equal(p_small < 0, p_big < 0)
+        assert np.max(np.abs(p_small - p_big)) <= 1e-12

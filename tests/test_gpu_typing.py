@@ -95,3 +95,85 @@ def test_typing_signature_writes_report(tmp_path):
     keep = lambda ls: [l for l in ls if "aligned" in l or "ranked" in l or "(count:" in l]
     assert keep(rep.split("\n")) == keep(fx["report"].split("\n"))
     assert passed == {"hisat2 graph": 2}
+
+
+def _compare_with_pyref(loc, sam, **opts):
+    rl = pyref.RefLocus(loc, **opts)
+    exp = rl.run(sam)
+    pl = hl.PackedLocus.from_synth(loc)
+    res = hgx.type_locus(pl, sam, simulation=opts.get("simulation", False))
+    assert (res.num_reads, res.num_pairs) == (exp["num_reads"], exp["num_pairs"])
+    assert res.counts_sorted == exp["counts_sorted"]            # integer compatibility counts: bit-exact, same tie order
+    assert len(res.em) == len(exp["em"])
+    for got, e in zip(res.em, exp["em"]):
+        _check_em(got, e["result"], e["n_iter"])
+    assert [a for a, _ in res.gene_prob] == [a for a, _ in exp["gene_prob"]]
+    for (a, p), (b, q) in zip(res.gene_prob, exp["gene_prob"]):
+        assert abs(p - q) <= 1e-9
+    return res
+
+
+def test_class1_panel_three_loci():
+    """BASELINE configs[2] shape at test size: three class-I-like loci of different sizes, each typed independently."""
+    specs = [("A", 600, 3569, 1300, 0), ("B", 800, 4081, 1500, 5000), ("C", 500, 4305, 1200, 10000)]
+    for k, (gene, n_all, length, n_vars, base) in enumerate(specs):
+        loc = synth.make_hla_like_locus(gene=gene, n_alleles=n_all, length=length, n_vars=n_vars, seed=300 + k, var_id_base=base)
+        sample = synth.pick_sample(loc, 40 + k)
+        al = synth.simulate_pairs(loc, sample, 500, err_rate=0.003, seed=50 + k)
+        res = _compare_with_pyref(loc, synth.sam_text(loc, al))
+        assert {a for a, _ in res.gene_prob[:2]} == set(sample)      # identical (and correct) top-2 calls
+
+
+def test_codis_panel_bit_exact():
+    """BASELINE configs[4] shape at test size: several STR loci (all-deletion alleles, many alternative alignments),
+    including D18S51 with its choose_pairs special case."""
+    panel = [("D8S1179", "TCTA", 19, 7), ("D18S51", "AGAA", 22, 9), ("TH01", "AATG", 12, 5), ("FGA", "CTTT", 30, 16)]
+    for k, (gene, unit, mx, mn) in enumerate(panel):
+        loc = synth.make_str_like_locus(gene=gene, unit=unit, max_repeats=mx, min_repeats=mn, flank=170, seed=60 + k,
+                                        var_id_base=100 * k)
+        sample = ["%s*%d" % (gene, mn + 2), "%s*%d" % (gene, mx - 3)]
+        al = synth.simulate_pairs(loc, sample, 0, read_len=100, frag_len=(250, 250), seed=70 + k, simulation_names=True,
+                                  tile_interval=4)
+        _compare_with_pyref(loc, synth.sam_text(loc, al), simulation=True)
+
+
+def test_half_million_reads_properties():
+    """Size-independent properties at (half of) the bench size, where no oracle finishes in seconds."""
+    import numpy as np
+    from hisatgenotype_amd import engine
+    loc = synth.make_hla_like_locus(n_alleles=7000, n_vars=2500, seed=101)
+    sample = synth.pick_sample(loc, 101)
+    sam = synth.simulate_sam_fast(loc, sample, 250000, err_rate=0.002, seed=100)
+    pl = hl.PackedLocus.from_synth(loc)
+    batch = pl.parse_sam(sam)
+    assert batch.n_pairs >= 249000 and batch.n_refs > batch.n_pieces
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    gcl = engine.Classes.dedup(bufs.gene_bits, db.n_pairs, pl.a_pad, hashes=bufs.gene_hash)
+    bits, cnt, first = gcl.to_host()
+    assert cnt.sum() == batch.n_pairs                      # every pair lands in exactly one class
+    assert np.all(np.diff(first) > 0)                      # classes come out in first-seen order
+    assert len({r.tobytes() for r in bits}) == len(bits)   # and are distinct
+    # dedup is idempotent: the class matrix deduplicated again (weights = counts) is itself
+    d_w = engine.DevArray.from_host(cnt)
+    b_ptr, _, _ = gcl.device_ptrs()
+    again = engine.Classes.dedup(engine._RawDev(b_ptr), gcl.n_classes, pl.a_pad, weights=d_w)
+    b2, c2, _ = again.to_host()
+    assert np.array_equal(b2, bits) and np.array_equal(c2, cnt)
+    # Gene_counts = column sums of the weighted class matrix
+    ac, _ = gcl.allele_counts()
+    col = np.zeros(pl.a_pad, np.int64)
+    for w in range(pl.w64):
+        wb = bits[:, w]
+        for b in range(64):
+            col[64 * w + b] = int(cnt[(wb >> np.uint64(b)) & np.uint64(1) == 1].sum())
+    assert np.array_equal(ac, col) and ac.max() <= batch.n_pairs
+    # the whole path: abundances are a distribution and the two true alleles win
+    res = hgx.type_locus(pl, sam)
+    assert abs(sum(p for _, p in res.gene_prob) - 1.0) < 1e-9
+    assert {a for a, _ in res.gene_prob[:2]} == set(sample)
+    # re-scoring gives identical rows and hashes (deterministic kernels)
+    rows1, h1 = bufs.gene_bits.to_host(), bufs.gene_hash.to_host()
+    engine.score_pairs(pl, db, bufs)
+    assert np.array_equal(rows1, bufs.gene_bits.to_host()) and np.array_equal(h1, bufs.gene_hash.to_host())
