@@ -1,0 +1,62 @@
+"""Callers of the hot path: a `genotyping_locus` with the reference's signature, and a panel runner
+that shards independent (sample, locus) tasks over the GPUs of a node.
+
+`genotyping_locus` mirrors typing_core.genotyping_locus (typing_core.py:2278-2691) for the part that leads to the
+accelerated path: a stand-alone index (`<ix_dir>/<base_fname>.*`, read with hisatgenotype_amd.indexio) and existing
+alignments.  Downloading/building databases, HISAT2 alignment, read simulation and the assembly graph are not on this
+path and raise NotImplementedError with the reference line they correspond to.
+"""
+import os
+
+from . import indexio
+from .locus import PackedLocus
+from .typing import read_alignment_text, type_locus, typing
+
+
+def genotyping_locus(base_fname, locus_list, genotype_genome, ix_dir, only_locus_list, partial, aligners, read_fname, fastq,
+                     alignment_fname, threads, simulate_interval, read_len, fragment_len, best_alleles, num_editdist,
+                     perbase_errorrate, perbase_snprate, skip_fragment_regions, assembly, output_base, error_correction,
+                     keep_alignment, discordant, type_primary_exons, remove_low_abundance_alleles, display_alleles, verbose,
+                     assembly_verbose, out_dir, output_allele_counts, debug_instr):
+    """Same 32 parameters as the reference (typing_core.py:2278-2309)."""
+    assert isinstance(base_fname, str) and "," not in base_fname
+    assert os.path.exists(ix_dir)
+    simulation = (read_fname == [] and alignment_fname == "")
+    if simulation:
+        raise NotImplementedError("simulation self-test needs simulate_reads + HISAT2 (typing_core.py:2488-2648)")
+    if genotype_genome:
+        raise NotImplementedError("genotype-genome indexes need samtools faidx (typing_core.py:2175-2195)")
+    if alignment_fname == "":
+        raise NotImplementedError("read alignment needs HISAT2 (typing_common.py:985-1056): pass alignment_fname")
+    ix = indexio.load_index(ix_dir, base_fname)
+    if len(locus_list) == 0:
+        locus_list = list(ix["refGene_loci"].keys())
+    return typing(False, os.path.join(ix_dir, base_fname), locus_list, "", partial, ix["partial_alleles"], ix["refGenes"],
+                  ix["Genes"], ix["Gene_names"], ix["Gene_lengths"], ix["refGene_loci"], ix["Vars"], ix["Var_list"],
+                  ix["Links"], aligners, num_editdist, assembly, output_base, error_correction, keep_alignment, discordant,
+                  type_primary_exons, remove_low_abundance_alleles, display_alleles, fastq, read_fname, alignment_fname, [],
+                  read_len, fragment_len, threads, best_alleles, verbose, assembly_verbose, out_dir, ix["dbversion"],
+                  output_allele_counts)
+
+
+def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, **typing_opts):
+    """Type independent (sample_id, gene, sam_text_or_path) tasks; rank `rank` of `world` handles its share
+    (deterministic greedy split, no communication).  `index` is the dict from indexio.load_index.
+    Returns {(sample_id, gene): LocusResult} for this rank's tasks."""
+    from . import dist as hdist
+    mine = hdist.shard(list(tasks), rank, world, weights)
+    packed = {}
+    out = {}
+    for sample_id, gene, sam in mine:
+        if gene not in packed:
+            packed[gene] = PackedLocus.from_reference_dicts(gene, base_fname, index["refGenes"], index["Genes"],
+                                                            index["Gene_names"], index["Gene_lengths"], index["refGene_loci"],
+                                                            index["Vars"], index["Var_list"], index["Links"])
+        if isinstance(sam, (bytes, bytearray)) or "\t" in sam:
+            text = sam
+        else:
+            text = read_alignment_text(sam)
+        out[(sample_id, gene)] = type_locus(packed[gene], text, **typing_opts)
+    for pl in packed.values():
+        pl.close()
+    return out

@@ -1,0 +1,160 @@
+"""Readers for the on-disk typing index that `hisatgenotype_extract_vars` writes.
+
+Formats (one record per line, tab separated unless noted), as consumed by the reference:
+  <base>.locus        allele_name chrom left right length exon_str strand      typing_common.py:279-309
+                      (genotype-genome variant: gene allele_name chrom left right exon_str strand)
+                      exon_str = "l-r,l-r,..." with a trailing "p" on primary exons
+  <base>.snp          var_id type allele_name pos data                          typing_common.py:339-368
+  <base>.link         var_id <tab or space> allele allele ...                   typing_common.py:388-403
+  <base>.allele       allele_name                                               typing_core.py:2416-2418
+  <base>.partial      allele_name                                               typing_core.py:2420-2422
+  <base>_backbone.fa  FASTA, one backbone allele per gene                       typing_common.py:313-334
+
+`load_index` assembles the dict arguments `typing()` takes, the way `genotyping_locus` does for a stand-alone
+(non genotype-genome) index (typing_core.py:2399-2480), without spelling out the ~7 000 allele sequences: only
+their names and lengths are needed on this path.
+"""
+import os
+
+
+def read_locus(fname, isgenome=False, target="", refGenes=None, refGene_loci=None):
+    refGenes = {} if refGenes is None else refGenes
+    refGene_loci = {} if refGene_loci is None else refGene_loci
+    with open(fname) as f:
+        lines = f.read().strip("\n").split("\n")
+    for line in lines:
+        if not line:
+            continue
+        fields = line.split()
+        if isgenome:
+            gene, gene_name, chrom, left, right, exon_str, strand = fields
+            if gene.lower() != target:
+                continue
+        else:
+            gene_name, chrom, left, right, _, exon_str, strand = fields
+        g = gene_name.split("*")[0]
+        if g in refGenes:
+            raise ValueError("duplicate gene %s in %s" % (g, fname))
+        refGenes[g] = gene_name
+        exons, primary = [], []
+        for ex in exon_str.split(","):
+            is_p = ex.endswith("p")
+            if is_p:
+                ex = ex[:-1]
+            l, r = ex.split("-")
+            exons.append([int(l), int(r)])
+            if is_p:
+                primary.append([int(l), int(r)])
+        refGene_loci[g] = [gene_name, chrom, int(left), int(right), exons, primary]
+    return refGenes, refGene_loci
+
+
+def read_allele_seq(fname, dic=None, genes=False):
+    dic = {} if dic is None else dic
+    with open(fname) as f:
+        chunks = f.read().strip("\n").split(">")[1:]
+    for ch in chunks:
+        ix = ch.find("\n")
+        name, seq = ch[:ix], ch[ix:].replace("\n", "")
+        tgt = dic.setdefault(name.split("*")[0], {}) if genes else dic
+        if name in tgt:
+            raise ValueError("non-unique sequence name: %s" % name)
+        tgt[name] = seq
+    return dic
+
+
+def read_variants(fname, genes=True):
+    vardata, varlist = {}, {}
+    with open(fname) as f:
+        lines = f.read().strip("\n").split("\n")
+    for line in lines:
+        if not line:
+            continue
+        var_id, var_type, name, pos, var = line.split("\t")
+        if var_type == "Deletion":          # (the reference compares against a capitalised literal that never occurs)
+            var = int(var)
+        pos = int(pos)
+        gene = name.split("*")[0] if genes else name
+        vardata.setdefault(gene, {})
+        varlist.setdefault(gene, [])
+        if genes:
+            if var_id in vardata[gene]:
+                raise ValueError("duplicate variant id %s" % var_id)
+            vardata[gene][var_id] = [var_type, pos, var]
+            varlist[gene].append([pos, var_id])
+        else:
+            varlist[gene].append([pos, var_type, var, var_id])
+    for gene in varlist:
+        varlist[gene].sort(key=lambda x: x[0])
+    return (vardata, varlist) if genes else varlist
+
+
+def read_links(fname):
+    links = {}
+    with open(fname) as f:
+        lines = f.read().strip("\n").split("\n")
+    for line in lines:
+        if not line:
+            continue
+        fields = line.replace(" ", "\t").split("\t")
+        if fields[0] in links:
+            raise ValueError("duplicate link id %s" % fields[0])
+        links[fields[0]] = fields[1:]
+    return links
+
+
+def read_names(fname):
+    if not os.path.exists(fname):
+        return []
+    with open(fname) as f:
+        return [l.strip() for l in f if l.strip()]
+
+
+def _allele_length(backbone_len, var_ids, Vars):
+    n = backbone_len
+    for v in var_ids:
+        t, _, d = Vars[v]
+        if t == "deletion":
+            n -= int(d)
+        elif t == "insertion":
+            n += len(d)
+    return n
+
+
+def load_index(ix_dir, base_fname):
+    """Dict arguments of typing() for a stand-alone index `<ix_dir>/<base_fname>.*`.
+
+    ``Genes[gene]`` maps every allele name to None except the backbone (its sequence); ``Gene_names`` follows the
+    reference's order (backbone, alleles by first appearance scanning Var_list x Links, then alleles equal to the
+    backbone -- the reference iterates a set there, quirk Q7; here they come sorted)."""
+    full = os.path.join(ix_dir, base_fname)
+    alleles = read_names(full + ".allele")
+    partial_alleles = set(read_names(full + ".partial"))
+    refGenes, refGene_loci = read_locus(full + ".locus", False, base_fname)
+    Vars, Var_list = read_variants(full + ".snp", True)
+    Links = read_links(full + ".link")
+    backbones = read_allele_seq(full + "_backbone.fa", {}, True)
+    Genes, Gene_names, Gene_lengths = {}, {}, {}
+    for gene in refGene_loci:
+        Vars.setdefault(gene, {})
+        Var_list.setdefault(gene, [])
+    for gene, bb in backbones.items():
+        (bname, bseq), = bb.items()
+        per_allele = {}
+        for _, vid in Var_list.get(gene, []):
+            for a in Links.get(vid, []):
+                per_allele.setdefault(a, []).append(vid)
+        names = [bname] + list(per_allele.keys())
+        if len(names) <= 1:
+            names.append("%s*GRCh38" % gene)
+        seen = set(names)
+        for a in sorted(x for x in alleles if x.split("*")[0] == gene and x not in seen):
+            names.append(a)
+        Genes[gene] = {n: None for n in names}
+        Genes[gene][bname] = bseq
+        Gene_names[gene] = names
+        Gene_lengths[gene] = {n: _allele_length(len(bseq), per_allele.get(n, []), Vars.get(gene, {})) for n in names}
+    dbversion = open(full + ".version").read() if os.path.exists(full + ".version") else "NONE"
+    return dict(refGenes=refGenes, refGene_loci=refGene_loci, Genes=Genes, Gene_names=Gene_names, Gene_lengths=Gene_lengths,
+                Vars=Vars, Var_list=Var_list, Links=Links, partial_alleles=partial_alleles, alleles=set(alleles),
+                dbversion=dbversion)

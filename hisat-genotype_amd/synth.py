@@ -677,3 +677,26 @@ def simulate_sam_fast(locus: Locus, sample_alleles: Sequence[str], n_pairs: int,
             out.append("%s\t%d\t%s\t%d\t60\t%s\t=\t%d\t0\t%s\t%s\t%sNH:i:1\tYT:Z:CP" % (
                 qname, flag, rname, pos + 1, cigar, recs[1 - j][0] + 1, seq, qual, tags))
     return "\n".join(out) + "\n"
+
+
+def write_index(loci: Sequence[Locus], ix_dir: str, base_fname: str) -> None:
+    """Write loci as the index files the reference reads (formats: hisatgenotype_amd.indexio docstring;
+    writer side in the reference: typing_process.py:1055-1108)."""
+    import os
+    os.makedirs(ix_dir, exist_ok=True)
+    full = os.path.join(ix_dir, base_fname)
+    with open(full + "_backbone.fa", "w") as fa, open(full + ".locus", "w") as lo, open(full + ".snp", "w") as sn, \
+            open(full + ".link", "w") as li, open(full + ".allele", "w") as al, open(full + ".partial", "w") as pa:
+        for loc in loci:
+            fa.write(">%s\n" % loc.ref_allele)
+            for i in range(0, len(loc.backbone), 60):
+                fa.write(loc.backbone[i:i + 60] + "\n")
+            prim = {tuple(e) for e in loc.primary_exons}
+            exon_str = ",".join("%d-%d%s" % (e[0], e[1], "p" if tuple(e) in prim else "") for e in loc.exons)
+            lo.write("%s\t6\t0\t%d\t%d\t%s\t+\n" % (loc.ref_allele, len(loc.backbone) - 1, len(loc.backbone), exon_str))
+            for i, vid in enumerate(loc.var_ids):
+                sn.write("%s\t%s\t%s\t%d\t%s\n" % (vid, loc.var_type[i], loc.ref_allele, loc.var_pos[i], loc.var_data[i]))
+            for vid, alleles in loc.links.items():
+                li.write("%s\t%s\n" % (vid, " ".join(alleles)))
+            for name in loc.allele_names[1:]:
+                al.write(name + "\n")

@@ -177,3 +177,42 @@ def test_half_million_reads_properties():
     rows1, h1 = bufs.gene_bits.to_host(), bufs.gene_hash.to_host()
     engine.score_pairs(pl, db, bufs)
     assert np.array_equal(rows1, bufs.gene_bits.to_host()) and np.array_equal(h1, bufs.gene_hash.to_host())
+
+
+def test_genotyping_locus_from_index_files(tmp_path):
+    """8f-2: the reference's 32-parameter genotyping_locus on a stand-alone index directory + SAM file."""
+    fx = gu.load("hla_mid_real")
+    loc = fx["_locus"]
+    synth.write_index([loc], str(tmp_path / "ix"), "hla")
+    sam = tmp_path / "sample1.sam"
+    sam.write_text(fx["sam"])
+    hgx.genotyping_locus("hla", ["A"], "", str(tmp_path / "ix"), [], True, [["hisat2", "graph"]], ["sample1.fq"], True,
+                         str(sam), 1, 10, 150, 400, False, 2, 0.0, 0.0, [], False, "assembly_graph", True, True, False,
+                         False, True, [], 0, False, str(tmp_path), True, {})
+    rep = (tmp_path / "assembly_graph-hla.sample1.report").read_text()
+    keep = lambda ls: [l for l in ls if "aligned" in l or "ranked" in l or "(count:" in l]
+    assert keep(rep.split("\n")) == keep(fx["report"].split("\n"))
+
+
+def test_run_panel_shards_tasks(tmp_path):
+    """Config-4 shape at test size: samples x loci as independent tasks, split over two 'ranks' without communication."""
+    from hisatgenotype_amd import indexio
+    loci = [synth.make_hla_like_locus(gene=g, n_alleles=120, n_vars=300, seed=70 + i, var_id_base=1000 * i)
+            for i, g in enumerate(("A", "B", "DRB1"))]
+    synth.write_index(loci, str(tmp_path), "hla")
+    ix = indexio.load_index(str(tmp_path), "hla")
+    tasks, truth = [], {}
+    for s in range(4):
+        for loc in loci:
+            sample = synth.pick_sample(loc, 10 * s + 1)
+            sam = synth.simulate_sam_fast(loc, sample, 300, err_rate=0.002, seed=s)
+            tasks.append((s, loc.gene, sam))
+            truth[(s, loc.gene)] = set(sample)
+    got = {}
+    for rank in range(2):
+        part = hgx.run_panel(tasks, ix, "hla", rank=rank, world=2)
+        assert not set(part) & set(got)
+        got.update(part)
+    assert set(got) == set(truth)
+    for key, res in got.items():
+        assert {a for a, _ in res.gene_prob[:2]} == truth[key]
