@@ -59,6 +59,14 @@ extern "C" int hgx_memset(void *d, int v, size_t n, void *st) {
     return HGX_OK;
 }
 extern "C" int hgx_stream_sync(void *st) { HIPCHK(hipStreamSynchronize((hipStream_t)st)); return HGX_OK; }
+extern "C" int hgx_stream_create(void **st) {
+    ARGCHK(st != nullptr);
+    hipStream_t s;
+    HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *st = (void *)s;
+    return HGX_OK;
+}
+extern "C" int hgx_stream_destroy(void *st) { if (st) HIPCHK(hipStreamDestroy((hipStream_t)st)); return HGX_OK; }
 extern "C" int hgx_event_create(void **ev) {
     ARGCHK(ev != nullptr);
     hipEvent_t e;

@@ -715,6 +715,13 @@ struct PassStats { double ms = 0; int64_t launches = 0, executed = 0, bytes = 0;
 thread_local PassStats g_stats[4];   // [0] <8,ROWS> [1] <16,ROWS> [2] <8,COLS> [3] <16,COLS>
 thread_local int g_timing = 0;
 struct Timed { hipEvent_t a, b; int slot; };
+thread_local std::vector<hipEvent_t> g_event_pool;     // recycled HIP events (creating one per launch is not free)
+inline hipEvent_t pool_event() {
+    if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreateWithFlags(&e, hipEventDefault);
+    return e;
+}
 
 }   // namespace
 
@@ -799,8 +806,8 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         if (!g_timing) return;
         if (begin) {
             Timed t;
-            (void)hipEventCreate(&t.a);
-            (void)hipEventCreate(&t.b);
+            t.a = pool_event();
+            t.b = pool_event();
             t.slot = slot;
             (void)hipEventRecord(t.a, st);
             timed.push_back(t);
@@ -812,10 +819,8 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         int r = launch_matvec<MODE_ROWS>(rows, st, vec, pres_v, x_mode, c->d_count, nullptr, nullptr, nullptr, wc, nullptr, scal, gate);
         stamp(slot_rows, false);
         if (r) return r;
-        stamp(slot_cols, true);
         r = launch_matvec<MODE_COLS>(cols, st, wc, nullptr, x_mode == 2 ? 2 : 0, nullptr, vec, pres_v, d_len, q_out, pres_out, scal, gate);
-        stamp(slot_cols, false);
-        return r;
+        return r;   // only the rows pass (the kernel with the largest aggregate time) is bracketed: every event costs ~1.5 us
     };
     // initial mass sum_c n_c / |S_c|, normalised (common:1299-1309)
     rc = next_prob(p, pr, 2, p, pr, 0);
@@ -843,8 +848,8 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
             (void)hipEventElapsedTime(&ms, t.a, t.b);
             g_stats[t.slot].ms += ms;
             g_stats[t.slot].launches += 1;
-            (void)hipEventDestroy(t.a);
-            (void)hipEventDestroy(t.b);
+            g_event_pool.push_back(t.a);
+            g_event_pool.push_back(t.b);
         }
         g_stats[slot_rows].executed += (int64_t)h_scal[S_NROWS];
         g_stats[slot_rows].bytes += (int64_t)h_scal[S_NROWS] * rows_bytes;
@@ -867,25 +872,31 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
 
 // Gene_counts (typing_core.py:1187-1190): per allele the summed count of the classes containing it, and the first
 // such class (dict insertion order for ties) -- two passes of the bit mat-vec over the transposed class matrix.
+extern "C" int hgx_allele_counts_on(const hgx_classes *cc, int64_t *count_host, int32_t *first_host, void *stream);
 extern "C" int hgx_allele_counts(const hgx_classes *cc, int64_t *count_host, int32_t *first_host) {
+    return hgx_allele_counts_on(cc, count_host, first_host, nullptr);
+}
+extern "C" int hgx_allele_counts_on(const hgx_classes *cc, int64_t *count_host, int32_t *first_host, void *stream) {
     ARGCHK(cc && count_host && first_host);
+    hipStream_t st = (hipStream_t)stream;
     hgx_classes *c = const_cast<hgx_classes *>(cc);
     const int A = c->a_pad;
     if (c->n_classes == 0) {
         for (int a = 0; a < A; ++a) { count_host[a] = 0; first_host[a] = -1; }
         return HGX_OK;
     }
-    int rc = hgx_ensure_transposed(c, nullptr);
+    int rc = hgx_ensure_transposed(c, st);
     if (rc) return rc;
     DevBuf b_s, b_f, b_c, b_i;
     ALLOC(b_s, (size_t)A * 8); ALLOC(b_f, (size_t)A * 8); ALLOC(b_c, (size_t)A * 8); ALLOC(b_i, (size_t)A * 4);
     const MatVec cols{c->d_bitsT, A, c->c64, c->n_classes};
-    launch_matvec<MODE_SUM>(cols, nullptr, nullptr, nullptr, 0, c->d_count, nullptr, nullptr, nullptr, b_s.as<double>(), nullptr, nullptr, 0);
-    launch_matvec<MODE_MIN>(cols, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, b_f.as<double>(), nullptr, nullptr, 0);
-    hipLaunchKernelGGL(k_counts_out, dim3(nblk(A, 256)), dim3(256), 0, nullptr, b_s.as<double>(), b_f.as<double>(), A,
+    launch_matvec<MODE_SUM>(cols, st, nullptr, nullptr, 0, c->d_count, nullptr, nullptr, nullptr, b_s.as<double>(), nullptr, nullptr, 0);
+    launch_matvec<MODE_MIN>(cols, st, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, b_f.as<double>(), nullptr, nullptr, 0);
+    hipLaunchKernelGGL(k_counts_out, dim3(nblk(A, 256)), dim3(256), 0, st, b_s.as<double>(), b_f.as<double>(), A,
                        b_c.as<int64_t>(), b_i.as<int32_t>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(count_host, b_c.p, (size_t)A * 8, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(first_host, b_i.p, (size_t)A * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(count_host, b_c.p, (size_t)A * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(first_host, b_i.p, (size_t)A * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     return HGX_OK;
 }

@@ -85,11 +85,11 @@ class Classes:
         capi.check(capi.lib().hgx_classes_to_host(self.h, capi.ptr(bits), capi.ptr(cnt), capi.ptr(first)))
         return bits, cnt, first
 
-    def allele_counts(self):
+    def allele_counts(self, stream=None):
         """Gene_counts (core:1187-1190) and, per allele, the first class containing it."""
         cnt = np.zeros(self.a_pad, np.int64)
         first = np.zeros(self.a_pad, np.int32)
-        capi.check(capi.lib().hgx_allele_counts(self.h, capi.ptr(cnt), capi.ptr(first)))
+        capi.check(capi.lib().hgx_allele_counts_on(self.h, capi.ptr(cnt), capi.ptr(first), stream))
         return cnt, first
 
     def em(self, n_alleles, remove_low=False, lengths=None, stream=None):

@@ -15,6 +15,7 @@ Nothing here computes the hot path on the CPU: all of it goes through libhgx (HI
 import os
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -112,19 +113,51 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
     if not scored:
         engine.score_pairs(pl, db, bufs, stream)
     # ---- Gene_counts (core:1187-1190, 1650-1651) --------------------------------------------------
-    gcl = engine.Classes.dedup(bufs.gene_bits, db.n_pairs, pl.a_pad, hashes=bufs.gene_hash, stream=stream)
-    cnt, first = gcl.allele_counts()
-    fr = np.zeros(gcl.n_classes, np.int64)                     # first pair of every class
-    capi.check(capi.lib().hgx_classes_to_host(gcl.h, None, None, capi.ptr(fr)))
-    cnt_a, first_a = cnt[:A], first[:A]
-    counted = np.nonzero(cnt_a > 0)[0]
-    # dict insertion order of Gene_counts = (first pair that counted the allele, Gene_names order); then the
-    # reference's stable descending sort on the count (core:1650-1651)
-    ins = fr[first_a[counted]]
-    counted = counted[np.lexsort((counted, ins, -cnt_a[counted]))]
-    res._names, res.counts_order, res.counts = names, counted, cnt_a
-    if keep_classes:
-        res.gene_classes = gcl.to_host()[:2]
+    # The gene-level side (dedup -> counts -> ranking) is independent of the exon-level EM until the hand-off, and the
+    # EM is a long chain of short launches that leaves most of the GPU idle: for HLA the two run concurrently, the gene
+    # side on a worker thread with its own non-blocking stream.
+    gene = {}
+
+    def gene_side(st):
+        gcl_ = engine.Classes.dedup(bufs.gene_bits, db.n_pairs, pl.a_pad, hashes=bufs.gene_hash, stream=st)
+        cnt, first = gcl_.allele_counts(st)
+        fr = np.zeros(gcl_.n_classes, np.int64)                     # first pair of every class
+        capi.check(capi.lib().hgx_classes_to_host(gcl_.h, None, None, capi.ptr(fr)))
+        cnt_a, first_a = cnt[:A], first[:A]
+        counted = np.nonzero(cnt_a > 0)[0]
+        # dict insertion order of Gene_counts = (first pair that counted the allele, Gene_names order); then the
+        # reference's stable descending sort on the count (core:1650-1651)
+        ins = fr[first_a[counted]]
+        counted = counted[np.lexsort((counted, ins, -cnt_a[counted]))]
+        gene.update(gcl=gcl_, counted=counted, cnt=cnt_a)
+
+    worker = None
+    if hla and stream is None and db.n_pairs >= 4096:
+        capi.sync(stream)                                       # class rows are complete before either side reads them
+        dev = capi.current_device()
+        err = []
+
+        def run():
+            try:
+                capi.set_device(dev)
+                gene_side(capi.get_stream(1))
+            except BaseException as e:      # re-raised on the main thread
+                err.append(e)
+
+        worker = threading.Thread(target=run)
+        worker.start()
+    else:
+        gene_side(stream)
+
+    def finish_gene():
+        if worker is not None:
+            worker.join()
+            if err:
+                raise err[0]
+        res._names, res.counts_order, res.counts = names, gene["counted"], gene["cnt"]
+        if keep_classes:
+            res.gene_classes = gene["gcl"].to_host()[:2]
+        return gene["gcl"]
 
     def run_em(classes, low, lengths):
         t0 = time.perf_counter()
@@ -135,10 +168,14 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
         return out
 
     if hla:
-        ecl = engine.Classes.dedup(bufs.exon_bits, db.n_pairs, pl.a_pad, hashes=bufs.exon_hash, stream=stream)
+        em_stream = capi.get_stream(0) if worker is not None else stream
+        ecl = engine.Classes.dedup(bufs.exon_bits, db.n_pairs, pl.a_pad, hashes=bufs.exon_hash, stream=em_stream)
         if keep_classes:
             res.exon_classes = ecl.to_host()[:2]
+        stream_saved, stream = stream, em_stream
         exon_prob = gene_prob = run_em(ecl, remove_low, None)                    # core:1732-1737
+        stream = stream_saved
+        gcl = finish_gene()
         groups = pl.rep_groups()
         exon_alleles, psum = set(), 0.0
         for i, (a, p) in enumerate(exon_prob):                                   # core:1739-1749
@@ -168,6 +205,7 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
             g2.close()
         ecl.close()
     else:
+        gcl = finish_gene()
         if gcl.n_classes <= 1:                                                   # core:1784-1787 (quirk Q3)
             if gcl.n_classes == 1:
                 raise TypeError("'dict_keys' object is not subscriptable (reference quirk Q3, typing_core.py:1787)")

@@ -56,6 +56,9 @@ int hgx_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stre
 int hgx_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);
 int hgx_memset(void *dev_dst, int value, size_t bytes, void *stream);
 int hgx_stream_sync(void *stream);
+/* non-blocking HIP streams so that independent stages (exon-level EM / gene-level counts) can overlap */
+int hgx_stream_create(void **stream);
+int hgx_stream_destroy(void *stream);
 /* the library caches device scratch allocations between calls; this returns them to the driver */
 int hgx_pool_trim(void);
 /* HIP events on a stream, for timing individual kernels from a ctypes caller */
@@ -156,6 +159,7 @@ int hgx_classes_from_host(hgx_classes **out, const uint64_t *bits_host, const in
  * class contains it, and the index of the first class (in first-seen order) containing it
  * (-1 if none) -- that is the dict insertion order used to break count ties.             */
 int hgx_allele_counts(const hgx_classes *c, int64_t *count_host, int32_t *first_class_host);
+int hgx_allele_counts_on(const hgx_classes *c, int64_t *count_host, int32_t *first_class_host, void *stream);
 
 /* ---- 8a-8: EM abundance ------------------------------------------------------------------
  * Replaces single_abundance (typing_common.py:1282-1410): SQUAREM-accelerated EM in FP64,
@@ -247,7 +251,8 @@ int hgx_batch_trace_text(const hgx_batch *b, char *buf, size_t cap, size_t *need
 int hgx_batch_pileup(const hgx_batch *b, uint8_t *nt_set, uint32_t *counts);
 
 /* Kernel timing for roofline reports.  hgx_em_set_timing(1) makes hgx_em bracket every bit-mat-vec launch with HIP
- * events on its stream and (re)starts the per-thread totals; slot 0 = k_bitmatvec<8,ROWS>, 1 = <16,ROWS>, 2 = <8,COLS>,
+ * events on its stream (rows-pass launches only: the kernel with the largest aggregate time; each event costs ~1.5 us)
+ * and (re)starts the per-thread totals; slot 0 = k_bitmatvec<8,ROWS>, 1 = <16,ROWS>, 2 = <8,COLS>,
  * 3 = <16,COLS>.  `executed` counts the launches that did work (not gated / past convergence) and bytes_total their
  * algorithmic bytes (bit matrix once + dense vectors).                                                              */
 int hgx_em_set_timing(int on);
