@@ -41,6 +41,7 @@ struct hgx_classes {
     int64_t *d_count;        // [n_classes]
     int64_t *d_first_row;    // [n_classes]
     uint64_t *d_bitsT;       // lazily built [a_pad][c64]
+    uint64_t *d_prow = nullptr, *d_pcol = nullptr;   // lazily built MFMA-operand orders of bits / bitsT (hgx_em.hip)
 };
 
 struct DevBuf {

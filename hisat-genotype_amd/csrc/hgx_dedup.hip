@@ -210,6 +210,7 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
 extern "C" int hgx_classes_destroy(hgx_classes *c) {
     if (!c) return HGX_OK;
     hgx_pool_free(c->d_bits); hgx_pool_free(c->d_count); hgx_pool_free(c->d_first_row); hgx_pool_free(c->d_bitsT);
+    hgx_pool_free(c->d_prow); hgx_pool_free(c->d_pcol);
     delete c;
     return HGX_OK;
 }

@@ -485,6 +485,249 @@ __global__ __launch_bounds__(BLOCK) void k_em_finish(const double *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// MFMA form of the bit mat-vec (rocprof: the EXEC-masked VALU kernel above is issue bound -- one vector instruction per
+// 64 matrix bits and a 10-step cross-lane reduction per 8 rows -- and is the largest aggregate kernel of the step).
+// y = B x is evaluated EXACTLY in integers on the matrix cores:
+//   * x (>= 0) is turned into 119-bit fixed point relative to 2^ceil(log2 max x), as sixteen planes of balanced
+//     base-256 digits X_n[k] in [-128, 127] (the int8 operands are signed);
+//   * the 0/1 matrix is expanded on the fly to int8 (16 bits -> 16 bytes per lane and MFMA);
+//   * v_mfma_i32_16x16x64_i8 accumulates  D[row][n] = sum_k B[row][k] * X_n[k]  in int32 (exact: K * 255 < 2^31);
+//   * y[row] = sum_n D[row][n] * 2^(8n) * 2^(e - 128), rounded once to FP64.
+// Operand maps (probed with tools/mfma_layout_test.hip): lane l holds A[row = l&15][k = 16*(l>>4)+j] and
+// B[k = 16*(l>>4)+j][col = l&15] in byte j of its 128-bit operand; D[row = 4*(l>>4)+reg][col = l&15].
+// The matrix is pre-permuted once per class set (k_permute_mfma) so that a wave fetches the 16-bit slices of four
+// K-steps as ONE coalesced 8-byte-per-lane load; the byte planes live in LDS (stride chosen conflict free for
+// ds_read_b128).  A workgroup = 4 waves = 64 matrix rows; K is walked in chunks of 8192 elements.
+// ------------------------------------------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr int MF_BLOCK = 256;
+constexpr int MF_WAVES = MF_BLOCK / 64;
+constexpr int MF_KC = 4096;                 // elements per LDS chunk (66 KB of planes: two workgroups per CU)
+constexpr int MF_STRIDE = MF_KC + 32;       // plane stride in bytes: (stride / 16) % 16 == 2 -> no bank conflicts
+constexpr int MF_NP = 16;                   // byte planes (128-bit fixed point)
+
+// P[(tile * n_super + u) * 64 + lane] = the four 16-bit slices (K-steps 4u .. 4u+3) lane (row = lane&15, h = lane>>4)
+// feeds to the MFMA: slice q = bits [16h, 16h+16) of word 4u+q of row 16*tile + row.
+__global__ __launch_bounds__(256) void k_permute_mfma(const uint64_t *__restrict__ B, int n_rows, int n_words, int n_super,
+                                                      long total, uint64_t *__restrict__ P) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    const long tu = i >> 6;
+    const int u = (int)(tu % n_super);
+    const long tile = tu / n_super;
+    const long row = tile * 16 + (lane & 15);
+    const int h = lane >> 4;
+    uint64_t v = 0;
+    if (row < n_rows) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int w = 4 * u + q;
+            const uint64_t word = w < n_words ? B[(size_t)row * n_words + w] : 0ull;
+            v |= ((word >> (16 * h)) & 0xFFFFull) << (16 * q);
+        }
+    }
+    P[i] = v;
+}
+
+// 16 bits -> 16 bytes of 0/1 (4 dwords): nibble * 0x00204081 spreads its four bits to bit 0 of each byte
+__device__ __forceinline__ v4i expand16(uint32_t bits) {
+    v4i r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (int)((((bits >> (4 * i)) & 0xFu) * 0x00204081u) & 0x01010101u);
+    return r;
+}
+
+// byte transpose of a 4x4 byte block: in: a,b,c,d (one dword per element), out[j] = byte j of (a,b,c,d)
+__device__ __forceinline__ void transpose4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t (&out)[4]) {
+    const uint32_t ab_lo = __builtin_amdgcn_perm(b, a, 0x05010400u);   // a0 b0 a1 b1
+    const uint32_t ab_hi = __builtin_amdgcn_perm(b, a, 0x07030602u);   // a2 b2 a3 b3
+    const uint32_t cd_lo = __builtin_amdgcn_perm(d, c, 0x05010400u);
+    const uint32_t cd_hi = __builtin_amdgcn_perm(d, c, 0x07030602u);
+    out[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u);          // a0 b0 c0 d0
+    out[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);          // a1 b1 c1 d1
+    out[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u);
+    out[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
+}
+
+// x >= 0 as fixed point X = floor(x * 2^(1141 - exm)) < 2^119 (`exm` = biased exponent of the maximum), written in
+// BALANCED base-256 digits d_n in [-128, 127] (X = sum d_n 256^n) because the int8 MFMA operands are signed:
+// add 0x80 to every byte with carry propagation, then flip each byte's top bit.
+__device__ __forceinline__ void to_fixed128(double x, int exm, uint32_t (&d)[4]) {
+    const uint64_t bits = (uint64_t)__double_as_longlong(x);
+    const int ex = (int)((bits >> 52) & 0x7FF);
+    uint64_t lo = 0, hi = 0;
+    if (ex != 0) {                                   // zero / subnormal inputs contribute nothing
+        const uint64_t m = (bits & 0xFFFFFFFFFFFFFull) | (1ull << 52);
+        const int sh = ex - exm + 66;                // x == max -> top bit at position 118
+        if (sh >= 64) hi = m << (sh - 64);
+        else if (sh > 0) { lo = m << sh; hi = m >> (64 - sh); }
+        else if (sh > -53) lo = m >> (-sh);
+    }
+    const uint64_t c = 0x8080808080808080ull;
+    const uint64_t lo2 = lo + c;
+    const uint64_t hi2 = hi + c + (lo2 < lo ? 1ull : 0ull);
+    lo = lo2 ^ c;
+    hi = hi2 ^ c;
+    d[0] = (uint32_t)lo; d[1] = (uint32_t)(lo >> 32); d[2] = (uint32_t)hi; d[3] = (uint32_t)(hi >> 32);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(MF_BLOCK) void k_mfma_matvec(const uint64_t *__restrict__ P, int n_rows, int n_super, int n_k,
+                                                          const double *__restrict__ vec, const uint8_t *__restrict__ vec_pres,
+                                                          int x_mode /* rows: 0 raw, 1 normalise, 2 ones */,
+                                                          const int64_t *__restrict__ count, const double *__restrict__ q_in,
+                                                          const uint8_t *__restrict__ pres_in, const double *__restrict__ len,
+                                                          double *__restrict__ y, uint8_t *__restrict__ pres_out,
+                                                          double *__restrict__ scal, int gate) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t planes[];      // [MF_NP][MF_STRIDE]
+    __shared__ double sh[2][NWAVE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, h = lane >> 4;
+    const long tile = (long)blockIdx.x * MF_WAVES + wv;
+    const int row_base = (int)(tile * 16) + 4 * h;             // rows row_base .. +3 end up in this lane (if n == 0)
+    double st_done = scal[S_DONE], st_flag = scal[S_FLAG], tot = 1.0;
+    if (MODE == MODE_COLS) tot = scal[S_TOT_A];
+    double e_a[4] = {0, 0, 0, 0}, e_len[4] = {1, 1, 1, 1};
+    bool e_pres[4] = {true, true, true, true};
+    if (n == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row_base + r;
+            if (row < n_rows) {
+                if (MODE == MODE_ROWS) e_a[r] = (double)count[row];
+                else {
+                    if (x_mode != 2) { e_a[r] = q_in[row]; e_pres[r] = pres_in[row] != 0; }
+                    if (len) e_len[r] = len[row];
+                }
+            }
+        }
+    }
+    if (st_done != 0.0) return;
+    if (gate && st_flag == 0.0) return;
+    // ---- pass over the vector: maximum (fixed-point scale) and, for the normalising rows pass, the total ----------
+    auto value = [&](int e) -> double {
+        if (e >= n_k) return 0.0;
+        if (MODE == MODE_ROWS) return x_mode == 2 ? 1.0 : (vec_pres[e] ? vec[e] : 0.0);
+        return vec[e];
+    };
+    double mx = 0.0, sm = 0.0;
+    for (int e = tid; e < n_k; e += MF_BLOCK) {
+        const double v = value(e);
+        mx = fmax(mx, v);
+        sm += v;
+    }
+    {
+        // block max and sum (fixed order)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
+        sm = wave_sum_f64(sm);
+        __syncthreads();
+        if (lane == 0) { sh[0][wv] = mx; sh[1][wv] = sm; }
+        __syncthreads();
+        mx = sh[0][0]; sm = 0.0;
+#pragma unroll
+        for (int i = 0; i < MF_WAVES; ++i) { mx = fmax(mx, sh[0][i]); sm += sh[1][i]; }
+    }
+    if (MODE == MODE_ROWS && x_mode == 1) tot = sm;
+    if (MODE == MODE_ROWS && blockIdx.x == 0 && tid == 0) { scal[S_TOT_A] = tot; scal[S_NROWS] += 1.0; }
+    if (MODE == MODE_COLS && blockIdx.x == 0 && tid == 0) scal[S_NCOLS] += 1.0;
+    const int exm = (int)(((uint64_t)__double_as_longlong(mx) >> 52) & 0x7FF);     // 0 if the vector is all zero
+    // four independent accumulators (one per K-step of a slice group): no MFMA waits for the previous one
+    v4i acc4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc4[q] = v4i{0, 0, 0, 0};
+    const uint64_t *Pt = P + (size_t)tile * n_super * 64 + lane;
+    const bool tile_ok = tile * 16 < n_rows;
+    for (int c0 = 0; c0 < n_k; c0 += MF_KC) {
+        // ---- byte planes of this chunk: a thread converts 4 consecutive elements and writes one dword per plane --------
+        for (int g = tid; g < MF_KC / 4; g += MF_BLOCK) {
+            uint32_t d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) to_fixed128(value(c0 + 4 * g + i), exm, d[i]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t t[4];
+                transpose4(d[0][j], d[1][j], d[2][j], d[3][j], t);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) *reinterpret_cast<uint32_t *>(planes + (size_t)(4 * j + b) * MF_STRIDE + 4 * g) = t[b];
+            }
+        }
+        __syncthreads();
+        if (tile_ok) {
+            const int u0 = c0 / 256;
+            const int u1 = min(n_super, (c0 + MF_KC) / 256);
+            const uint8_t *bp = planes + (size_t)n * MF_STRIDE + 16 * h;
+            // software pipeline: slice group and plane fragments of the NEXT group are fetched while this one multiplies
+            uint64_t cur = 0ull;
+            v4i bf[4];
+            if (u0 < u1) {
+                cur = Pt[(size_t)u0 * 64];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bf[q] = *reinterpret_cast<const v4i *>(bp + 64 * q);
+            }
+            for (int u = u0; u < u1; ++u) {
+                uint64_t nxt = 0ull;
+                v4i nb[4];
+                if (u + 1 < u1) {
+                    nxt = Pt[(size_t)(u + 1) * 64];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) nb[q] = *reinterpret_cast<const v4i *>(bp + 64 * (4 * (u + 1 - u0) + q));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) nb[q] = v4i{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const v4i a = expand16((uint32_t)(cur >> (16 * q)) & 0xFFFFu);
+                    acc4[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bf[q], acc4[q], 0, 0, 0);
+                }
+                cur = nxt;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bf[q] = nb[q];
+            }
+        }
+        __syncthreads();            // planes are rebuilt for the next chunk
+    }
+    v4i acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = acc4[0][r] + acc4[1][r] + acc4[2][r] + acc4[3][r];
+    // ---- combine the planes: lane (n, h) holds D[4h + r][n]; y[row] = 2^(exm-1141) * sum_n D * 2^(8n) -----------------
+    double t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        double v = exm ? ldexp((double)acc[r], 8 * n + exm - 1141) : 0.0;
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        t[r] = v;
+    }
+    if (n == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = row_base + r;
+            if (row >= n_rows) continue;
+            if (MODE == MODE_ROWS) {
+                const double s = (x_mode == 1) ? t[r] / tot : t[r];
+                y[row] = s > 0.0 ? e_a[r] / s : 0.0;
+            } else {
+                const bool init = x_mode == 2;
+                const bool in = init || e_pres[r];
+                double v = 0.0;
+                if (in && t[r] > 0.0) {
+                    v = init ? t[r] : (e_a[r] / tot) * t[r];
+                    if (len) v = v / e_len[r];
+                }
+                y[row] = v;
+                pres_out[row] = (in && t[r] > 0.0) ? 1 : 0;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Whole EM in ONE workgroup for small problems (C <= SMALL_C classes, a_pad <= 8192): the exon->gene hand-off EM and
 // STR loci have a few dozen classes, where eight launches per iteration cost far more than the arithmetic.
 // Same step sequence and summation structure as the multi-launch path; vectors live in registers (thread = the
@@ -517,15 +760,25 @@ __device__ __forceinline__ void small_map(const uint64_t *__restrict__ B, int C,
         const bool ok = (valid >> k) & 1u;
         x[k] = !ok ? 0.0 : (init ? 1.0 : (((in.pres >> k) & 1u) ? in.v[k] / scale : 0.0));
     }
-    for (int c = 0; c < C; ++c) {
-        u32x16 w[1];
-        w[0] = sload16(B + (size_t)c * n_words + wbase);
-        swait(w);
-        double acc = 0.0;
+    auto row_word = [&](uint64_t mine, int k) -> uint64_t {      // word k of this wave's 8-word slice, as a scalar
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), k) << 32) |
+               (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
+    };
+    for (int c0 = 0; c0 < C; c0 += RB) {                            // eight classes per cross-lane reduction
+        double acc[RB];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) masked_add(acc, x[k], ((uint64_t)w[0][2 * k + 1] << 32) | w[0][2 * k]);
-        acc = wave_sum_f64(acc);
-        if (lane == 0) part[c][wv] = acc;
+        for (int r = 0; r < RB; ++r) {
+            acc[r] = 0.0;
+            const int c = min(c0 + r, C - 1);
+            const uint64_t mine = B[(size_t)c * n_words + wbase + (lane & 7)];     // B is the LDS copy of the class matrix
+#pragma unroll
+            for (int k = 0; k < 8; ++k) masked_add(acc[r], x[k], row_word(mine, k));
+        }
+        const double s8 = reduce8<false>(acc, lane);
+        if ((lane & 7) == 0) {
+            const int r = c0 + ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
+            if (r < C) part[r][wv] = s8;
+        }
     }
     __syncthreads();
     if ((int)threadIdx.x < C) {
@@ -539,12 +792,10 @@ __device__ __forceinline__ void small_map(const uint64_t *__restrict__ B, int C,
 #pragma unroll
     for (int k = 0; k < EPT; ++k) acc[k] = 0.0;
     for (int c = 0; c < C; ++c) {
-        u32x16 w[1];
-        w[0] = sload16(B + (size_t)c * n_words + wbase);
+        const uint64_t mine = B[(size_t)c * n_words + wbase + (lane & 7)];
         const double wv_c = wc[c];
-        swait(w);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) masked_add(acc[k], wv_c, ((uint64_t)w[0][2 * k + 1] << 32) | w[0][2 * k]);
+        for (int k = 0; k < 8; ++k) masked_add(acc[k], wv_c, row_word(mine, k));
     }
     out.pres = 0;
 #pragma unroll
@@ -561,9 +812,15 @@ __device__ __forceinline__ void small_map(const uint64_t *__restrict__ B, int C,
     __syncthreads();          // part / wc are reused by the next application
 }
 
-__global__ __launch_bounds__(BLOCK) void k_em_small(const uint64_t *__restrict__ B, int C, int n_words, int a_pad,
+__global__ __launch_bounds__(BLOCK) void k_em_small(const uint64_t *__restrict__ Bg, int C, int n_words, int a_pad,
                                                     const int64_t *__restrict__ count, const double *__restrict__ len,
                                                     int remove_low, double *__restrict__ out, double *__restrict__ scal) {
+    // the class matrix (<= 64 x 128 words) is copied into LDS once: every map application walks all of it twice, and from
+    // one workgroup each global round trip would be fully exposed
+    extern __shared__ __attribute__((aligned(16))) uint64_t Bl[];
+    for (int i = threadIdx.x; i < C * n_words; i += BLOCK) Bl[i] = Bg[i];
+    __syncthreads();
+    const uint64_t *B = Bl;
     __shared__ double sh[3][NWAVE];
     __shared__ double shm[NWAVE];
     __shared__ double part[SMALL_C][NWAVE];
@@ -677,7 +934,35 @@ __global__ __launch_bounds__(BLOCK) void k_em_small(const uint64_t *__restrict__
 struct MatVec {
     const uint64_t *B;
     int n_rows, n_words, n_k;
+    const uint64_t *P = nullptr;    // MFMA operand order of B (k_permute_mfma), or nullptr -> VALU kernel
+    int n_super = 0;
 };
+
+int g_backend = 0;                  // 0 auto, 1 VALU (EXEC-masked FP64), 2 MFMA (int8 fixed point)
+
+inline bool use_mfma(const MatVec &m) {
+    if (!m.P) return false;
+    if (g_backend == 1) return false;
+    if (g_backend == 2) return true;
+    return false;   // auto: at one-sample problem sizes the VALU kernel is faster; MFMA is opt-in
+}
+
+template <int MODE>
+int launch_mfma(const MatVec &m, hipStream_t st, const double *vec, const uint8_t *vec_pres, int x_mode, const int64_t *count,
+                const double *q_in, const uint8_t *pres_in, const double *len, double *y, uint8_t *pres_out, double *scal,
+                int gate) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)MF_NP * MF_STRIDE;
+    if (!attr_set) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma_matvec<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+        attr_set = true;
+    }
+    const int grid = (m.n_rows + 16 * MF_WAVES - 1) / (16 * MF_WAVES);
+    hipLaunchKernelGGL((k_mfma_matvec<MODE>), dim3(grid), dim3(MF_BLOCK), lds, st, m.P, m.n_rows, m.n_super, m.n_k, vec, vec_pres,
+                       x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate);
+    return HGX_OK;
+}
 
 inline int rows_per_block(int n_rows) {
     static const int forced = getenv("HGX_RPB") ? atoi(getenv("HGX_RPB")) : 0;     // tuning aid
@@ -690,6 +975,10 @@ template <int MODE>
 int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint8_t *vec_pres, int x_mode,
                   const int64_t *count, const double *q_in, const uint8_t *pres_in, const double *len, double *y,
                   uint8_t *pres_out, double *scal, int gate) {
+    if constexpr (MODE == MODE_ROWS || MODE == MODE_COLS) {
+        if (use_mfma(m))
+            return launch_mfma<MODE>(m, st, vec, vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate);
+    }
     const int rpb = rows_per_block(m.n_rows);
     const int grid = (m.n_rows + rpb - 1) / rpb;
     if (m.n_k <= 8 * BLOCK)
@@ -724,6 +1013,12 @@ inline hipEvent_t pool_event() {
 }
 
 }   // namespace
+
+extern "C" int hgx_em_set_backend(int backend) {
+    ARGCHK(backend >= 0 && backend <= 2);
+    g_backend = backend;
+    return HGX_OK;
+}
 
 extern "C" int hgx_em_set_timing(int on) {
     g_timing = on;
@@ -763,7 +1058,14 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
             HIPCHK(hipMemcpyAsync(b_len.p, l.data(), A * 8, hipMemcpyHostToDevice, st));
             d_len = b_len.as<double>();
         }
-        hipLaunchKernelGGL(k_em_small, dim3(1), dim3(BLOCK), 0, st, c->d_bits, C, c->w64, A, c->d_count, d_len, remove_low ? 1 : 0,
+        const size_t lds = (size_t)C * c->w64 * 8;
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_small), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       SMALL_C * (EPT * BLOCK / 64) * 8));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_em_small, dim3(1), dim3(BLOCK), lds, st, c->d_bits, C, c->w64, A, c->d_count, d_len, remove_low ? 1 : 0,
                            b_out.as<double>(), b_scal.as<double>());
         HIPCHK(hipGetLastError());
         std::vector<double> out(A);
@@ -797,8 +1099,27 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
     uint8_t *pr = b_pr.as<uint8_t>(), *pr1 = b_pr1.as<uint8_t>(), *pr2 = b_pr2.as<uint8_t>(), *pr3 = b_pr3.as<uint8_t>();
     double *wc = b_wc.as<double>(), *scal = b_scal.as<double>();
     HIPCHK(hipMemsetAsync(scal, 0, S_N * 8, st));
-    const MatVec rows{c->d_bits, C, c->w64, A};
-    const MatVec cols{c->d_bitsT, A, c->c64, C};
+    MatVec rows{c->d_bits, C, c->w64, A};
+    MatVec cols{c->d_bitsT, A, c->c64, C};
+    if (g_backend == 2 && A >= 512 && C >= 64) {
+        // MFMA operand order of both matrices, built once per class set
+        auto permute = [&](const uint64_t *Bm, int n_rows, int n_words, uint64_t **dst) -> int {
+            const int n_super = n_words / 4;
+            const long tiles = (n_rows + 15) / 16;
+            const long tiles_pad = (tiles + MF_WAVES - 1) / MF_WAVES * MF_WAVES;     // whole workgroups
+            const long total = tiles_pad * n_super * 64;
+            if (!*dst) {
+                *dst = (uint64_t *)hgx_pool_alloc((size_t)total * 8);
+                if (!*dst) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+                hipLaunchKernelGGL(k_permute_mfma, dim3(nblk(total, 256)), dim3(256), 0, st, Bm, n_rows, n_words, n_super, total, *dst);
+            }
+            return HGX_OK;
+        };
+        if ((rc = permute(c->d_bits, C, c->w64, &c->d_prow))) return rc;
+        if ((rc = permute(c->d_bitsT, A, c->c64, &c->d_pcol))) return rc;
+        rows.P = c->d_prow; rows.n_super = c->w64 / 4;
+        cols.P = c->d_pcol; cols.n_super = c->c64 / 4;
+    }
 
     std::vector<Timed> timed;
     const int slot_rows = A <= 8 * BLOCK ? 0 : 1, slot_cols = C <= 8 * BLOCK ? 2 : 3;
@@ -898,5 +1219,64 @@ extern "C" int hgx_allele_counts_on(const hgx_classes *cc, int64_t *count_host, 
     HIPCHK(hipMemcpyAsync(count_host, b_c.p, (size_t)A * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(first_host, b_i.p, (size_t)A * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    return HGX_OK;
+}
+
+// Test aid: one rows pass (s_c -> w_c = n_c / s_c) or cols pass (t_a) of the EM map with a chosen backend.
+//   which = 0: y[c] = count[c] / sum_a B[c][a] x[a]   (x: a_pad doubles)      -> n_classes doubles
+//   which = 1: y[a] = sum_c B[c][a] x[c]              (x: n_classes doubles)  -> a_pad doubles
+extern "C" int hgx_debug_matvec(const hgx_classes *cc, int which, int backend, const double *x_host, double *y_host) {
+    ARGCHK(cc && x_host && y_host && (which == 0 || which == 1) && backend >= 1 && backend <= 2);
+    hgx_classes *c = const_cast<hgx_classes *>(cc);
+    const int A = c->a_pad, C = c->n_classes;
+    ARGCHK(C > 0);
+    int rc = hgx_ensure_transposed(c, nullptr);
+    if (rc) return rc;
+    const int nx = which == 0 ? A : C, ny = which == 0 ? C : A;
+    DevBuf b_x, b_y, b_pr, b_pr2, b_scal, b_q;
+    ALLOC(b_x, (size_t)nx * 8); ALLOC(b_y, (size_t)ny * 8); ALLOC(b_pr, (size_t)std::max(nx, ny)); ALLOC(b_pr2, (size_t)std::max(nx, ny));
+    ALLOC(b_scal, S_N * 8); ALLOC(b_q, (size_t)ny * 8);
+    HIPCHK(hipMemcpy(b_x.p, x_host, (size_t)nx * 8, hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(b_pr.p, 1, (size_t)std::max(nx, ny)));
+    HIPCHK(hipMemset(b_scal.p, 0, S_N * 8));
+    std::vector<double> ones(ny, 1.0);
+    HIPCHK(hipMemcpy(b_q.p, ones.data(), (size_t)ny * 8, hipMemcpyHostToDevice));
+    double one = 1.0;
+    HIPCHK(hipMemcpy(b_scal.as<double>() + S_TOT_A, &one, 8, hipMemcpyHostToDevice));
+    MatVec m = which == 0 ? MatVec{c->d_bits, C, c->w64, A} : MatVec{c->d_bitsT, A, c->c64, C};
+    DevBuf b_P;
+    if (backend == 2) {
+        const int n_super = m.n_words / 4;
+        const long tiles = (m.n_rows + 15) / 16;
+        const long tiles_pad = (tiles + MF_WAVES - 1) / MF_WAVES * MF_WAVES;
+        const long total = tiles_pad * n_super * 64;
+        ALLOC(b_P, (size_t)total * 8);
+        hipLaunchKernelGGL(k_permute_mfma, dim3(nblk(total, 256)), dim3(256), 0, nullptr, m.B, m.n_rows, m.n_words, n_super, total,
+                           b_P.as<uint64_t>());
+        m.P = b_P.as<uint64_t>();
+        m.n_super = n_super;
+    }
+    const int saved = g_backend;
+    g_backend = backend;
+    const int reps = getenv("HGX_DBG_REPS") ? atoi(getenv("HGX_DBG_REPS")) : 1;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, nullptr);
+    for (int rep = 0; rep < reps; ++rep)
+    if (which == 0)
+        rc = launch_matvec<MODE_ROWS>(m, nullptr, b_x.as<double>(), b_pr.as<uint8_t>(), 0, c->d_count, nullptr, nullptr, nullptr,
+                                      b_y.as<double>(), nullptr, b_scal.as<double>(), 0);
+    else   // q_in = 1, tot = 1, present everywhere: y = t
+        rc = launch_matvec<MODE_COLS>(m, nullptr, b_x.as<double>(), nullptr, 0, nullptr, b_q.as<double>(), b_pr.as<uint8_t>(), nullptr,
+                                      b_y.as<double>(), b_pr2.as<uint8_t>(), b_scal.as<double>(), 0);
+    g_backend = saved;
+    (void)hipEventRecord(e1, nullptr);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (reps > 1) fprintf(stderr, "[hgx_debug_matvec] which=%d backend=%d: %.2f us per launch\n", which, backend, ms * 1e3 / reps);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(y_host, b_y.p, (size_t)ny * 8, hipMemcpyDeviceToHost));
     return HGX_OK;
 }

@@ -141,3 +141,8 @@ def em_get_timing():
         capi.check(capi.lib().hgx_em_get_timing(C.c_int(slot), C.byref(ms), C.byref(n), C.byref(ex), C.byref(by)))
         out[name] = (ms.value, n.value, ex.value, by.value)
     return out
+
+
+def em_set_backend(backend):
+    """0 = auto, 1 = EXEC-masked FP64 VALU mat-vec, 2 = int8 MFMA mat-vec (128-bit fixed point)."""
+    capi.check(capi.lib().hgx_em_set_backend(C.c_int(backend)))

@@ -255,6 +255,11 @@ int hgx_batch_pileup(const hgx_batch *b, uint8_t *nt_set, uint32_t *counts);
  * and (re)starts the per-thread totals; slot 0 = k_bitmatvec<8,ROWS>, 1 = <16,ROWS>, 2 = <8,COLS>,
  * 3 = <16,COLS>.  `executed` counts the launches that did work (not gated / past convergence) and bytes_total their
  * algorithmic bytes (bit matrix once + dense vectors).                                                              */
+/* mat-vec backend of hgx_em: 0 = auto (MFMA for large problems), 1 = EXEC-masked FP64 VALU kernel, 2 = int8 MFMA kernel */
+int hgx_em_set_backend(int backend);
+/* test aid: one rows pass (which = 0: y[c] = count[c] / sum_a B[c][a] x[a]) or cols pass (which = 1: y[a] = sum_c
+ * B[c][a] x[c]) with backend 1 or 2; x and y are host arrays of a_pad / n_classes doubles                        */
+int hgx_debug_matvec(const hgx_classes *c, int which, int backend, const double *x_host, double *y_host);
 int hgx_em_set_timing(int on);
 int hgx_em_get_timing(int slot, double *ms_total, int64_t *launches, int64_t *executed, int64_t *bytes_total);
 

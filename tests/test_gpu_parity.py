@@ -238,3 +238,40 @@ def test_em_single_workgroup_path_equals_multi_launch_path(orc):
         assert it_small == it_big
         assert np.array_equal(p_small < 0, p_big < 0)
         assert np.max(np.abs(p_small - p_big)) <= 1e-12
+
+
+@pytest.mark.parametrize("name", ["hla_7000", "hla_mid_real"])
+def test_em_mfma_backend_equals_fp64_backend(orc, name):
+    """The int8-MFMA mat-vec (exact integer accumulation of 128-bit fixed-point planes) against the FP64 VALU mat-vec:
+    same iteration counts, abundances equal to rounding, on the reference's recorded EM inputs and on a big random one."""
+    fx, loc, t, pl, batch, (eb, gb, gc, fp) = _setup(orc, name)
+    A = t["n_alleles"]
+    w = (A + 63) // 64
+    cases = []
+    for em in fx["em"]:
+        rows = np.zeros((len(em["cmpt"]), pl.w64), np.uint64)
+        for k, (cid, n) in enumerate(em["cmpt"]):
+            rows[k, :w] = gu.class_bits(fx, cid, A)
+        cases.append((rows, np.array([n for _, n in em["cmpt"]], np.int64), em["remove_low"], em["use_length"]))
+    rng = np.random.RandomState(9)
+    big = np.zeros((3000, pl.w64), np.uint64)
+    dens = rng.choice([0.002, 0.05, 0.6], size=3000)
+    for k in range(3000):
+        m = rng.rand(A) < dens[k]
+        m[rng.randint(A)] = True
+        big[k, :w] = np.packbits(np.pad(m, (0, 64 * w - A)), bitorder="little").view(np.uint64)
+    cases.append((big, rng.randint(1, 500, 3000).astype(np.int64), True, False))
+    cases.append((big, rng.randint(1, 500, 3000).astype(np.int64), False, True))
+    try:
+        for rows, counts, low, use_len in cases:
+            cl = engine.Classes.from_host(rows, counts, pl.a_pad)
+            ln = pl.allele_len if use_len else None
+            engine.em_set_backend(1)
+            p1, it1 = cl.em(A, low, ln)
+            engine.em_set_backend(2)
+            p2, it2 = cl.em(A, low, ln)
+            assert it1 == it2
+            assert np.array_equal(p1 < 0, p2 < 0)
+            assert np.max(np.abs(p1 - p2)) <= 1e-11, np.max(np.abs(p1 - p2))
+    finally:
+        engine.em_set_backend(0)
