@@ -267,8 +267,14 @@ def read_alignment_text(alignment_fname, region=None):
     with open(alignment_fname, "rb") as f:
         head = f.read(4)
     if head[:2] == b"\x1f\x8b" or head == b"BAM\x01":
-        cmd = ["samtools", "view", alignment_fname] + ([region] if region else [])
-        data = subprocess.check_output(cmd)
+        # BAM: decoded in-process (no samtools on the GPU box); region "chr:left-right" is 1-based inclusive
+        from . import bamio
+        reg = None
+        if region:
+            name, span = region.rsplit(":", 1)
+            lo, hi = span.split("-")
+            reg = (name, int(lo) - 1, int(hi) - 1)
+        data = ("\n".join(bamio.read_bam(alignment_fname, reg)) + "\n").encode()
     else:
         with open(alignment_fname, "rb") as f:
             data = f.read()

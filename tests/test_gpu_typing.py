@@ -216,3 +216,21 @@ def test_run_panel_shards_tasks(tmp_path):
     assert set(got) == set(truth)
     for key, res in got.items():
         assert {a for a, _ in res.gene_prob[:2]} == truth[key]
+
+
+def test_typing_reads_bam_without_samtools(tmp_path):
+    """8f-3: the alignment may be a BAM; it is decoded in-process and name-grouped like `samtools view | sort -k1,1 -s`."""
+    from hisatgenotype_amd import bamio
+    fx = gu.load("hla_mid_real")
+    loc = fx["_locus"]
+    d = loc.reference_dicts()
+    lines = [l for l in fx["sam"].split("\n") if l]
+    lines.sort(key=lambda l: int(l.split("\t")[3]))                     # coordinate-sorted, as a real BAM would be
+    bam = tmp_path / "sample.bam"
+    bamio.write_bam(str(bam), "\n".join(lines) + "\n", [(loc.ref_allele, len(loc.backbone))])
+    hgx.typing(False, str(tmp_path / "hla"), ["A"], "", True, set(), d["refGenes"], d["Genes"], d["Gene_names"], d["Gene_lengths"],
+               d["refGene_loci"], d["Vars"], d["Var_list"], d["Links"], [["hisat2", "graph"]], 2, False, "assembly_graph", True, True,
+               False, False, True, [], False, ["sample.fq"], str(bam), [], 150, 400, 1, False, 0, False, str(tmp_path), "NONE", True)
+    rep = (tmp_path / "assembly_graph-hla.sample.report").read_text()
+    keep = lambda ls: [l for l in ls if "aligned" in l or "ranked" in l or "(count:" in l]
+    assert keep(rep.split("\n")) == keep(fx["report"].split("\n"))
