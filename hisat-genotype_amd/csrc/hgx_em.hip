@@ -931,6 +931,161 @@ __global__ __launch_bounds__(BLOCK) void k_em_small(const uint64_t *__restrict__
     if (tid == 0) { scal[S_ITER] = (double)iter; scal[S_KEYERR] = keyerr ? 1.0 : 0.0; scal[S_DONE] = 1.0; }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Whole EM in ONE WAVEFRONT when at most 64 classes involve at most 64 distinct alleles (the exon->gene hand-off EM,
+// STR loci): the alleles that occur at all are renumbered 0..A'-1, lane j is allele j AND class j at the same time, the
+// class matrix becomes 64-bit row masks (per class, over alleles) and column masks (per allele, over classes) held
+// in registers, and both halves of the map are loops of <= 64 "broadcast one scalar, add it under an EXEC mask" steps.
+// No LDS traffic, no barriers, one launch.  scal[S_FALLBACK] = 1 if more than 64 alleles occur (caller falls back).
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t lane_u64(uint64_t v, int l) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+}
+// acc += sx on the lanes selected by `mask`; sx is a wave-uniform double passed in scalar registers
+__device__ __forceinline__ void masked_add_s(double &acc, uint64_t sx_bits, uint64_t mask) {
+    uint64_t saved;
+    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tv_add_f64 %[a], %[a], %[x]\n\ts_mov_b64 exec, %[sv]"
+                 : [a] "+v"(acc), [sv] "=&s"(saved)
+                 : [x] "s"(sx_bits), [m] "s"(mask)
+                 : "scc");
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+struct WaveEM {
+    uint64_t R, K;        // as class `lane`: members over alleles; as allele `lane`: classes containing it
+    double n;             // class count (0 for lanes >= C)
+    double len;           // allele length (1 if unused)
+    int C, A1;
+};
+
+// out = T(x / scale) restricted to `in_pres`; returns the presence of every allele-lane in out_pres
+__device__ __forceinline__ double wave_map(const WaveEM &E, double x, bool in_pres, double scale, bool init, bool use_len,
+                                           bool &out_pres) {
+    const double xs = init ? 1.0 : (in_pres ? x / scale : 0.0);
+    double s = 0.0;
+    for (int j = 0; j < E.A1; ++j) {                        // rows half: lane = class, broadcast allele j
+        const uint64_t xj = lane_u64((uint64_t)__double_as_longlong(xs), j);
+        masked_add_s(s, xj, lane_u64(E.K, j));
+    }
+    const double w = s > 0.0 ? E.n / s : 0.0;
+    double t = 0.0;
+    for (int c = 0; c < E.C; ++c) {                         // cols half: lane = allele, broadcast class c
+        const uint64_t wc = lane_u64((uint64_t)__double_as_longlong(w), c);
+        masked_add_s(t, wc, lane_u64(E.R, c));
+    }
+    const bool in = init || in_pres;
+    double v = 0.0;
+    out_pres = in && t > 0.0;
+    if (out_pres) {
+        v = init ? t : xs * t;
+        if (use_len) v = v / E.len;
+    }
+    return v;
+}
+
+constexpr int S_FALLBACK = 6;       // (re-uses the S_NROWS word: the wave kernel launches no mat-vec)
+
+__global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, int C, int n_words, int a_pad,
+                                                const int64_t *__restrict__ count, const double *__restrict__ len,
+                                                int remove_low, double *__restrict__ out, double *__restrict__ scal) {
+    __shared__ int gidx[64];
+    const int lane = threadIdx.x;
+    // ---- which alleles occur at all ------------------------------------------------------------------------
+    uint64_t u0 = 0, u1 = 0;
+    const bool h0 = lane < n_words, h1 = lane + 64 < n_words;
+    for (int c = 0; c < C; ++c) {
+        if (h0) u0 |= B[(size_t)c * n_words + lane];
+        if (h1) u1 |= B[(size_t)c * n_words + lane + 64];
+    }
+    const int c0 = __popcll(u0), c1 = __popcll(u1);
+    int inc0 = c0, inc1 = c1;                               // inclusive scans over lanes
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int a = __shfl_up(inc0, d, 64), b = __shfl_up(inc1, d, 64);
+        if (lane >= d) { inc0 += a; inc1 += b; }
+    }
+    const int tot0 = __shfl(inc0, 63, 64), tot1 = __shfl(inc1, 63, 64);
+    const int A1 = tot0 + tot1;
+    if (A1 > 64 || n_words > 128) {
+        if (lane == 0) { scal[S_FALLBACK] = 1.0; scal[S_DONE] = 1.0; }
+        return;
+    }
+    {
+        int id = inc0 - c0;
+        for (uint64_t m = u0; m; m &= m - 1) gidx[id++] = 64 * lane + __builtin_ctzll(m);
+        id = tot0 + inc1 - c1;
+        for (uint64_t m = u1; m; m &= m - 1) gidx[id++] = 64 * (lane + 64) + __builtin_ctzll(m);
+    }
+    __syncthreads();
+    const int g = lane < A1 ? gidx[lane] : 0;
+    // ---- row and column masks ----------------------------------------------------------------------------------
+    WaveEM E;
+    E.R = 0; E.K = 0; E.C = C; E.A1 = A1;
+    for (int c = 0; c < C; ++c) {
+        const bool bit = lane < A1 && ((B[(size_t)c * n_words + (g >> 6)] >> (g & 63)) & 1ull);
+        const uint64_t row = __ballot(bit);
+        if (lane == c) E.R = row;
+        if (bit) E.K |= 1ull << c;
+    }
+    E.n = lane < C ? (double)count[lane] : 0.0;
+    const bool use_len = len != nullptr;
+    E.len = (use_len && lane < A1) ? len[g] : 1.0;
+    // ---- EM (common:1299-1410) ----------------------------------------------------------------------------------
+    bool pr, pr1, pr2, pr3;
+    double p = wave_map(E, 0.0, false, 1.0, true, use_len, pr);
+    double tot = wave_sum_f64(pr ? p : 0.0);
+    p = pr ? p / tot : 0.0;
+    int iter = 0;
+    double diff = 1.0;
+    bool keyerr = false;
+    while (diff > 0.0001 && iter < 1000) {
+        const double q1 = wave_map(E, p, pr, 1.0, false, use_len, pr1);
+        const double tot1 = wave_sum_f64(pr1 ? q1 : 0.0);
+        double q2 = wave_map(E, q1, pr1, tot1, false, use_len, pr2);
+        const double tot2 = wave_sum_f64(pr2 ? q2 : 0.0);
+        double r = 0.0, v = 0.0;
+        bool bad = pr && (!pr1 || !pr2);
+        if (pr && !bad) {
+            const double p1 = q1 / tot1, p2 = q2 / tot2;
+            r = p1 - p;
+            v = p2 - p1 - r;
+        }
+        if (__any(bad)) { keyerr = true; break; }
+        const double sr = wave_sum_f64(r * r), sv = wave_sum_f64(v * v);
+        double pn;
+        bool prn;
+        if (sv > 0.0) {
+            const double gm = -sqrt(sr / sv);
+            if (pr) { q2 = fmax(0.0, p - 2 * gm * r + gm * gm * v); pr2 = true; }
+            const double q3 = wave_map(E, q2, pr2, 1.0, false, use_len, pr3);
+            const double tot3 = wave_sum_f64(pr3 ? q3 : 0.0);
+            prn = pr3;
+            pn = prn ? q3 / tot3 : 0.0;
+        } else {
+            prn = pr1;
+            pn = prn ? q1 / tot1 : 0.0;
+        }
+        diff = wave_sum_f64(pr ? (prn ? fabs(p - pn) : p) : 0.0);
+        const double mx = wave_max_f64(prn ? pn : 0.0);
+        bool keep = prn;
+        if (remove_low && iter >= 10 && keep) keep = pn >= mx / 10.0;
+        pr = keep;
+        p = keep ? pn : 0.0;
+        iter += 1;
+    }
+    const double mx = wave_max_f64(pr ? p : 0.0);
+    const bool keep = pr && (!remove_low || p >= mx / 10.0);
+    const double tl = wave_sum_f64(keep ? (use_len ? p / E.len : p) : 0.0);
+    for (int a = lane; a < a_pad; a += 64) out[a] = -1.0;
+    __syncthreads();
+    if (lane < A1 && keep) out[g] = use_len ? p / E.len / tl : p / tl;
+    if (lane == 0) { scal[S_ITER] = (double)iter; scal[S_KEYERR] = keyerr ? 1.0 : 0.0; scal[S_DONE] = 1.0; }
+}
+
 struct MatVec {
     const uint64_t *B;
     int n_rows, n_words, n_k;
@@ -1045,6 +1200,37 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
     if (C == 0) {
         for (int a = 0; a < n_alleles; ++a) prob_host[a] = -1.0;
         return HGX_OK;
+    }
+    if (C <= 64 && c->w64 <= 128 && !getenv("HGX_EM_NO_SMALL") && !getenv("HGX_EM_NO_WAVE")) {
+        // single-wavefront path (<= 64 classes over <= 64 distinct alleles); falls through if more alleles occur
+        DevBuf b_len, b_scal, b_out;
+        ALLOC(b_scal, S_N * 8); ALLOC(b_out, A * 8);
+        double *d_len = nullptr;
+        if (allele_len) {
+            std::vector<double> l(A, 1.0);
+            for (int a = 0; a < n_alleles; ++a) l[a] = (double)allele_len[a];
+            ALLOC(b_len, A * 8);
+            HIPCHK(hipMemcpyAsync(b_len.p, l.data(), A * 8, hipMemcpyHostToDevice, st));
+            d_len = b_len.as<double>();
+        }
+        HIPCHK(hipMemsetAsync(b_scal.p, 0, S_N * 8, st));
+        hipLaunchKernelGGL(k_em_wave, dim3(1), dim3(64), 0, st, c->d_bits, C, c->w64, A, c->d_count, d_len, remove_low ? 1 : 0,
+                           b_out.as<double>(), b_scal.as<double>());
+        HIPCHK(hipGetLastError());
+        std::vector<double> out(A);
+        double h_scal[S_N];
+        HIPCHK(hipMemcpyAsync(out.data(), b_out.p, A * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_scal, b_scal.p, S_N * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h_scal[S_FALLBACK] == 0.0) {
+            if (h_scal[S_KEYERR] != 0.0) {
+                hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
+                return HGX_EKEY;
+            }
+            for (int a = 0; a < n_alleles; ++a) prob_host[a] = out[a];
+            if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
+            return HGX_OK;
+        }
     }
     if (C <= SMALL_C && A <= EPT * BLOCK && !getenv("HGX_EM_NO_SMALL")) {
         // single-workgroup path: one launch, one sync

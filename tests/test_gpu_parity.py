@@ -240,6 +240,51 @@ def test_em_single_workgroup_path_equals_multi_launch_path(orc):
         assert np.max(np.abs(p_small - p_big)) <= 1e-12
 
 
+def test_em_single_wavefront_path_matches_oracle_and_other_paths(orc):
+    """<= 64 classes over <= 64 distinct alleles (hand-off EM, STR loci) run in one wavefront (k_em_wave).  Random
+    problems scattered over a wide allele range: same iteration count and abundances as the C oracle and as the
+    single-workgroup path; 65 distinct alleles must fall through to the other paths and still agree."""
+    import os
+    rng = np.random.RandomState(31)
+    for trial in range(24):
+        A = int(rng.choice([40, 700, 7000]))
+        a_pad = engine.capi.a_pad(A)
+        w64 = a_pad // 64
+        n_used = 65 if trial == 23 else int(rng.randint(1, 65))
+        n_used = min(n_used, A)
+        used = np.sort(rng.choice(A, n_used, replace=False))
+        C_ = int(rng.randint(1, 65))
+        classes, rows = [], np.zeros((C_, w64), np.uint64)
+        for c in range(C_):
+            k = int(rng.randint(1, max(2, min(n_used, 12))))
+            mem = np.sort(rng.choice(used, min(k, n_used), replace=False))
+            if trial == 23 and c == 0:
+                mem = used
+            classes.append([int(a) for a in mem])
+            for a in mem:
+                rows[c, a >> 6] |= np.uint64(1) << np.uint64(a & 63)
+        counts = rng.randint(1, 300, C_).astype(np.int64)
+        lengths = rng.randint(200, 3500, A).astype(np.int32)
+        cl = engine.Classes.from_host(rows, counts, a_pad)
+        for low, ln in ((True, None), (False, lengths), (True, lengths)):
+            try:
+                oa, op, oit = orc.single_abundance(A, classes, counts, low, ln)
+            except KeyError:
+                continue
+            p_w, it_w = cl.em(A, low, ln)
+            os.environ["HGX_EM_NO_WAVE"] = "1"
+            try:
+                p_s, it_s = cl.em(A, low, ln)
+            finally:
+                del os.environ["HGX_EM_NO_WAVE"]
+            assert it_w == oit == it_s, (trial, it_w, oit, it_s)
+            exp = np.full(A, -1.0)
+            exp[oa] = op
+            assert np.array_equal(p_w < 0, exp < 0)
+            assert np.max(np.abs(p_w - exp)) <= 1e-9
+            assert np.max(np.abs(p_w - p_s)) <= 1e-9
+
+
 @pytest.mark.parametrize("name", ["hla_7000", "hla_mid_real"])
 def test_em_mfma_backend_equals_fp64_backend(orc, name):
     """The int8-MFMA mat-vec (exact integer accumulation of 128-bit fixed-point planes) against the FP64 VALU mat-vec:
