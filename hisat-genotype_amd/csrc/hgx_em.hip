@@ -32,7 +32,9 @@ enum {
     S_ITER = 5,
     S_NROWS = 6,     // rows passes that really ran (not gated / past convergence)
     S_NCOLS = 7,
-    S_N = 8
+    S_NPRES = 8,     // alleles still in the estimate after the last advance
+    S_TAIL = 9,      // 1 = the compact tail kernel finished the EM, -1 = it could not take over
+    S_N = 10
 };
 
 constexpr int BLOCK = 1024;
@@ -435,12 +437,14 @@ __global__ __launch_bounds__(BLOCK) void k_em_advance(double *__restrict__ p, ui
     const double td = d[0];
     const int iter = (int)it_d;
     const bool prune = remove_low && iter >= 10;
+    double kept[1] = {0.0};
     auto store = [&](int a, bool an, double xn) {
         const double pn = an ? xn / tot : 0.0;
         bool keep = an;
         if (prune && keep) keep = pn >= tm / 10.0;
         pres[a] = keep ? 1 : 0;
         p[a] = keep ? pn : 0.0;
+        if (keep) kept[0] += 1.0;
     };
     if (small) {
 #pragma unroll
@@ -448,7 +452,9 @@ __global__ __launch_bounds__(BLOCK) void k_em_advance(double *__restrict__ p, ui
     } else {
         for (int a = threadIdx.x; a < a_pad; a += BLOCK) store(a, prn[a], qn[a]);
     }
+    block_sum_n<1>(kept, sh);
     if (threadIdx.x == 0) {
+        scal[S_NPRES] = kept[0];
         scal[S_DIFF] = td;
         scal[S_ITER] = (double)(iter + 1);
         if (!(td > 0.0001) || iter + 1 >= 1000) scal[S_DONE] = 1.0;
@@ -987,6 +993,56 @@ __device__ __forceinline__ double wave_map(const WaveEM &E, double x, bool in_pr
     return v;
 }
 
+// The SQUAREM loop + final selection (common:1311-1410) on one wavefront, starting from estimate (p, pr) at iteration
+// `iter`; lane j < E.A1 writes its allele's result to out[g] (the caller pre-fills out with -1).
+__device__ __forceinline__ void wave_em_run(const WaveEM &E, double p, bool pr, int iter, int remove_low, bool use_len, int g,
+                                            double *__restrict__ out, double *__restrict__ scal) {
+    const int lane = threadIdx.x & 63;
+    bool pr1, pr2, pr3;
+    double diff = 1.0;
+    bool keyerr = false;
+    while (diff > 0.0001 && iter < 1000) {
+        const double q1 = wave_map(E, p, pr, 1.0, false, use_len, pr1);
+        const double tot1 = wave_sum_f64(pr1 ? q1 : 0.0);
+        double q2 = wave_map(E, q1, pr1, tot1, false, use_len, pr2);
+        const double tot2 = wave_sum_f64(pr2 ? q2 : 0.0);
+        double r = 0.0, v = 0.0;
+        const bool bad = pr && (!pr1 || !pr2);
+        if (pr && !bad) {
+            const double p1 = q1 / tot1, p2 = q2 / tot2;
+            r = p1 - p;
+            v = p2 - p1 - r;
+        }
+        if (__any(bad)) { keyerr = true; break; }
+        const double sr = wave_sum_f64(r * r), sv = wave_sum_f64(v * v);
+        double pn;
+        bool prn;
+        if (sv > 0.0) {
+            const double gm = -sqrt(sr / sv);
+            if (pr) { q2 = fmax(0.0, p - 2 * gm * r + gm * gm * v); pr2 = true; }
+            const double q3 = wave_map(E, q2, pr2, 1.0, false, use_len, pr3);
+            const double tot3 = wave_sum_f64(pr3 ? q3 : 0.0);
+            prn = pr3;
+            pn = prn ? q3 / tot3 : 0.0;
+        } else {
+            prn = pr1;
+            pn = prn ? q1 / tot1 : 0.0;
+        }
+        diff = wave_sum_f64(pr ? (prn ? fabs(p - pn) : p) : 0.0);
+        const double mx = wave_max_f64(prn ? pn : 0.0);
+        bool keep = prn;
+        if (remove_low && iter >= 10 && keep) keep = pn >= mx / 10.0;
+        pr = keep;
+        p = keep ? pn : 0.0;
+        iter += 1;
+    }
+    const double mx = wave_max_f64(pr ? p : 0.0);
+    const bool keep = pr && (!remove_low || p >= mx / 10.0);
+    const double tl = wave_sum_f64(keep ? (use_len ? p / E.len : p) : 0.0);
+    if (lane < E.A1 && keep) out[g] = use_len ? p / E.len / tl : p / tl;
+    if (lane == 0) { scal[S_ITER] = (double)iter; scal[S_KEYERR] = keyerr ? 1.0 : 0.0; scal[S_DONE] = 1.0; }
+}
+
 constexpr int S_FALLBACK = 6;       // (re-uses the S_NROWS word: the wave kernel launches no mat-vec)
 
 __global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, int C, int n_words, int a_pad,
@@ -1035,55 +1091,112 @@ __global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, 
     const bool use_len = len != nullptr;
     E.len = (use_len && lane < A1) ? len[g] : 1.0;
     // ---- EM (common:1299-1410) ----------------------------------------------------------------------------------
-    bool pr, pr1, pr2, pr3;
+    bool pr;
     double p = wave_map(E, 0.0, false, 1.0, true, use_len, pr);
-    double tot = wave_sum_f64(pr ? p : 0.0);
+    const double tot = wave_sum_f64(pr ? p : 0.0);
     p = pr ? p / tot : 0.0;
-    int iter = 0;
-    double diff = 1.0;
-    bool keyerr = false;
-    while (diff > 0.0001 && iter < 1000) {
-        const double q1 = wave_map(E, p, pr, 1.0, false, use_len, pr1);
-        const double tot1 = wave_sum_f64(pr1 ? q1 : 0.0);
-        double q2 = wave_map(E, q1, pr1, tot1, false, use_len, pr2);
-        const double tot2 = wave_sum_f64(pr2 ? q2 : 0.0);
-        double r = 0.0, v = 0.0;
-        bool bad = pr && (!pr1 || !pr2);
-        if (pr && !bad) {
-            const double p1 = q1 / tot1, p2 = q2 / tot2;
-            r = p1 - p;
-            v = p2 - p1 - r;
-        }
-        if (__any(bad)) { keyerr = true; break; }
-        const double sr = wave_sum_f64(r * r), sv = wave_sum_f64(v * v);
-        double pn;
-        bool prn;
-        if (sv > 0.0) {
-            const double gm = -sqrt(sr / sv);
-            if (pr) { q2 = fmax(0.0, p - 2 * gm * r + gm * gm * v); pr2 = true; }
-            const double q3 = wave_map(E, q2, pr2, 1.0, false, use_len, pr3);
-            const double tot3 = wave_sum_f64(pr3 ? q3 : 0.0);
-            prn = pr3;
-            pn = prn ? q3 / tot3 : 0.0;
-        } else {
-            prn = pr1;
-            pn = prn ? q1 / tot1 : 0.0;
-        }
-        diff = wave_sum_f64(pr ? (prn ? fabs(p - pn) : p) : 0.0);
-        const double mx = wave_max_f64(prn ? pn : 0.0);
-        bool keep = prn;
-        if (remove_low && iter >= 10 && keep) keep = pn >= mx / 10.0;
-        pr = keep;
-        p = keep ? pn : 0.0;
-        iter += 1;
-    }
-    const double mx = wave_max_f64(pr ? p : 0.0);
-    const bool keep = pr && (!remove_low || p >= mx / 10.0);
-    const double tl = wave_sum_f64(keep ? (use_len ? p / E.len : p) : 0.0);
     for (int a = lane; a < a_pad; a += 64) out[a] = -1.0;
     __syncthreads();
-    if (lane < A1 && keep) out[g] = use_len ? p / E.len / tl : p / tl;
-    if (lane == 0) { scal[S_ITER] = (double)iter; scal[S_KEYERR] = keyerr ? 1.0 : 0.0; scal[S_DONE] = 1.0; }
+    wave_em_run(E, p, pr, 0, remove_low, use_len, g, out, scal);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Compact tail of a big EM.  Once pruning (common:1338-1346) has left <= 64 alleles in the estimate -- alleles never
+// come back -- every class collapses to a 64-bit mask over the survivors, classes with equal masks merge (their counts
+// add exactly) and, if <= 64 distinct masks remain, the rest of the EM runs on ONE wavefront (wave_em_run) in this
+// launch instead of eight kernel launches over the whole matrix per iteration.
+// One workgroup: survivors list -> per-class masks merged in an LDS hash table -> wave 0 sorts the masks (the summation
+// order must not depend on the insertion race) and iterates.  scal[S_TAIL] = -1 if the masks do not fit.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TAIL_SLOTS = 2048;
+
+__global__ __launch_bounds__(BLOCK) void k_em_tail(const uint64_t *__restrict__ B, int C, int n_words, int a_pad,
+                                                   const int64_t *__restrict__ count, const double *__restrict__ p,
+                                                   const uint8_t *__restrict__ pres, const double *__restrict__ len,
+                                                   int remove_low, double *__restrict__ out, double *__restrict__ scal) {
+    __shared__ int gidx[64], gsort[64];
+    __shared__ int n_g, n_keys, n_list;
+    __shared__ unsigned long long keys[TAIL_SLOTS], cnts[TAIL_SLOTS];
+    __shared__ unsigned long long lk[64], lc[64];
+    const int tid = threadIdx.x;
+    if (tid == 0) { n_g = 0; n_keys = 0; n_list = 0; }
+    for (int i = tid; i < TAIL_SLOTS; i += BLOCK) { keys[i] = 0; cnts[i] = 0; }
+    __syncthreads();
+    for (int a = tid; a < a_pad; a += BLOCK) {
+        if (pres[a]) {
+            const int k = atomicAdd(&n_g, 1);
+            if (k < 64) gidx[k] = a;
+        } else out[a] = -1.0;
+    }
+    __syncthreads();
+    const int A1 = n_g;
+    if (A1 > 64 || A1 == 0) {
+        if (tid == 0) scal[S_TAIL] = -1.0;
+        return;
+    }
+    if (tid < A1) {                                          // ascending allele order
+        const int mine = gidx[tid];
+        int rank = 0;
+        for (int j = 0; j < A1; ++j) rank += gidx[j] < mine;
+        gsort[rank] = mine;
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += BLOCK) {
+        const uint64_t *row = B + (size_t)c * n_words;
+        unsigned long long m = 0;
+        for (int j = 0; j < A1; ++j) {
+            const int g = gsort[j];
+            m |= ((row[g >> 6] >> (g & 63)) & 1ull) << j;
+        }
+        if (m == 0) continue;
+        if (*(volatile int *)&n_keys > 64) break;
+        unsigned h = (unsigned)(mix64(m) & (TAIL_SLOTS - 1));
+        for (;;) {
+            const unsigned long long old = atomicCAS(&keys[h], 0ull, m);
+            if (old == 0ull) atomicAdd(&n_keys, 1);
+            if (old == 0ull || old == m) { atomicAdd(&cnts[h], (unsigned long long)count[c]); break; }
+            h = (h + 1) & (TAIL_SLOTS - 1);
+        }
+    }
+    __syncthreads();
+    const int C1 = n_keys;
+    if (C1 > 64) {
+        if (tid == 0) scal[S_TAIL] = -1.0;
+        return;
+    }
+    if (tid >= 64) return;
+    const int lane = tid;
+    for (int i = lane; i < TAIL_SLOTS; i += 64) {
+        if (keys[i]) {
+            const int k = atomicAdd(&n_list, 1);
+            lk[k] = keys[i];
+            lc[k] = cnts[i];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long myk = lane < C1 ? lk[lane] : ~0ull, myc = lane < C1 ? lc[lane] : 0ull;
+    int rank = 0;
+    for (int j = 0; j < C1; ++j) rank += lk[j] < myk;
+    // move (key, count) to lane `rank`
+    WaveEM E;
+    E.R = 0; E.K = 0; E.n = 0.0; E.C = C1; E.A1 = A1;
+    for (int j = 0; j < C1; ++j) {
+        const int rj = __builtin_amdgcn_readlane(rank, j);
+        const uint64_t kj = lane_u64(myk, j), cj = lane_u64(myc, j);
+        if (lane == rj) { E.R = kj; E.n = (double)(long long)cj; }
+    }
+    for (int j = 0; j < A1; ++j) {
+        const uint64_t col = __ballot((E.R >> j) & 1ull);
+        if (lane == j) E.K = col;
+    }
+    const int g = lane < A1 ? gsort[lane] : 0;
+    const bool use_len = len != nullptr;
+    E.len = (use_len && lane < A1) ? len[g] : 1.0;
+    const double x = lane < A1 ? p[g] : 0.0;
+    if (lane < A1) out[g] = -1.0;
+    if (lane == 0) scal[S_TAIL] = 1.0;
+    wave_em_run(E, x, lane < A1, (int)scal[S_ITER], remove_low, use_len, g, out, scal);
 }
 
 struct MatVec {
@@ -1335,8 +1448,15 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
     hipLaunchKernelGGL(k_em_init_norm, dim3(1), dim3(BLOCK), 0, st, p, pr, A);
     double h_scal[S_N];
     const int batch = 4;
+    int launched_iters = 0;
+    double tail_failed_at = 1e300;
+    bool tail_done = false;
+    const bool use_tail = !getenv("HGX_EM_NO_TAIL");
     for (;;) {
-        for (int b = 0; b < batch; ++b) {
+        // with pruning, look at the survivor count right after the first pruning iteration (iteration index 10)
+        const int nb = (use_tail && remove_low && launched_iters < 11) ? std::min(batch, 11 - launched_iters) : batch;
+        launched_iters += nb;
+        for (int b = 0; b < nb; ++b) {
             if ((rc = next_prob(p, pr, 0, q1, pr1, 0))) return rc;        // Gene_prob_next  (p is used raw)
             if ((rc = next_prob(q1, pr1, 1, q2, pr2, 0))) return rc;      // Gene_prob_next2 (normalised on the fly)
             hipLaunchKernelGGL(k_em_squarem, dim3(1), dim3(BLOCK), 0, st, p, pr, q1, pr1, q2, pr2, A, scal);
@@ -1346,6 +1466,17 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         HIPCHK(hipMemcpyAsync(h_scal, scal, S_N * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (h_scal[S_DONE] != 0.0) break;
+        if (use_tail && h_scal[S_NPRES] <= 64.0 && h_scal[S_NPRES] < tail_failed_at) {
+            // few survivors: finish on one wavefront (k_em_tail) unless too many distinct class masks remain
+            hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bits, C, c->w64, A, c->d_count, p, pr, d_len,
+                               remove_low ? 1 : 0, b_out.as<double>(), scal);
+            const double rows_ran = h_scal[S_NROWS], cols_ran = h_scal[S_NCOLS];
+            HIPCHK(hipMemcpyAsync(h_scal, scal, S_N * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            h_scal[S_NROWS] = rows_ran; h_scal[S_NCOLS] = cols_ran;
+            if (h_scal[S_TAIL] == 1.0) { tail_done = true; break; }
+            tail_failed_at = h_scal[S_NPRES];
+        }
     }
     if (g_timing) {
         const int64_t rows_bytes = (int64_t)C * c->w64 * 8 + (int64_t)A * 9 + (int64_t)C * 16;
@@ -1367,7 +1498,7 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
         return HGX_EKEY;
     }
-    hipLaunchKernelGGL(k_em_finish, dim3(1), dim3(BLOCK), 0, st, p, pr, d_len, A, remove_low ? 1 : 0, b_out.as<double>());
+    if (!tail_done) hipLaunchKernelGGL(k_em_finish, dim3(1), dim3(BLOCK), 0, st, p, pr, d_len, A, remove_low ? 1 : 0, b_out.as<double>());
     HIPCHK(hipGetLastError());
     std::vector<double> out(A);
     HIPCHK(hipMemcpyAsync(out.data(), b_out.p, A * 8, hipMemcpyDeviceToHost, st));

@@ -285,6 +285,44 @@ def test_em_single_wavefront_path_matches_oracle_and_other_paths(orc):
             assert np.max(np.abs(p_w - p_s)) <= 1e-9
 
 
+def test_em_compact_tail_equals_full_iterations(orc):
+    """After pruning leaves <= 64 alleles the EM finishes on one wavefront over merged 64-bit class masks (k_em_tail).
+    Same iteration count and abundances as iterating over the whole matrix, and as the C oracle."""
+    import os
+    rng = np.random.RandomState(77)
+    for A, C_ in ((900, 400), (7000, 3000), (3000, 9000)):
+        a_pad = engine.capi.a_pad(A)
+        w64 = a_pad // 64
+        truth = rng.choice(A, 3, replace=False)
+        classes, rows = [], np.zeros((C_, w64), np.uint64)
+        for c in range(C_):
+            k = int(rng.randint(1, 40))
+            mem = set(int(a) for a in rng.choice(A, k, replace=False))
+            if rng.rand() < 0.8:
+                mem.add(int(truth[rng.randint(3)]))
+            mem = sorted(mem)
+            classes.append(mem)
+            for a in mem:
+                rows[c, a >> 6] |= np.uint64(1) << np.uint64(a & 63)
+        counts = rng.randint(1, 50, C_).astype(np.int64)
+        lengths = rng.randint(2000, 3500, A).astype(np.int32)
+        cl = engine.Classes.from_host(rows, counts, a_pad)
+        for low, ln in ((True, None), (True, lengths)):
+            oa, op, oit = orc.single_abundance(A, classes, counts, low, ln)
+            p_t, it_t = cl.em(A, low, ln)
+            os.environ["HGX_EM_NO_TAIL"] = "1"
+            try:
+                p_f, it_f = cl.em(A, low, ln)
+            finally:
+                del os.environ["HGX_EM_NO_TAIL"]
+            assert it_t == it_f == oit, (A, C_, it_t, it_f, oit)
+            assert oit > 11                                   # the tail really took over
+            exp = np.full(A, -1.0)
+            exp[oa] = op
+            assert np.array_equal(p_t < 0, exp < 0) and np.array_equal(p_f < 0, exp < 0)
+            assert np.max(np.abs(p_t - exp)) <= 1e-9 and np.max(np.abs(p_t - p_f)) <= 1e-9
+
+
 @pytest.mark.parametrize("name", ["hla_7000", "hla_mid_real"])
 def test_em_mfma_backend_equals_fp64_backend(orc, name):
     """The int8-MFMA mat-vec (exact integer accumulation of 128-bit fixed-point planes) against the FP64 VALU mat-vec:
