@@ -41,7 +41,13 @@ struct hgx_classes {
     int64_t *d_count;        // [n_classes]
     int64_t *d_first_row;    // [n_classes]
     uint64_t *d_bitsT;       // lazily built [a_pad][c64]
-    uint64_t *d_prow = nullptr, *d_pcol = nullptr;   // lazily built MFMA-operand orders of bits / bitsT (hgx_em.hip)
+    uint64_t *d_prow = nullptr, *d_pcol = nullptr;   // lazily built MFMA-operand orders of the compact matrices (hgx_em.hip)
+    // lazily built by the EM (hgx_em.hip): the matrices restricted to the alleles that occur in some class
+    int32_t n_act = -1, a1p = 0;                     // active alleles, padded to a multiple of 512
+    int32_t *d_act = nullptr;                        // [n_act] ascending allele ids
+    uint64_t *d_bitsC = nullptr;                     // [c64 * 64][a1p / 64]  (rows >= n_classes are zero)
+    uint64_t *d_bitsTC = nullptr;                    // [a1p][c64]
+    int32_t *h_act = nullptr;                        // host copy of d_act (new[])
 };
 
 struct DevBuf {

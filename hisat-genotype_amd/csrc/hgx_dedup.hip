@@ -211,6 +211,8 @@ extern "C" int hgx_classes_destroy(hgx_classes *c) {
     if (!c) return HGX_OK;
     hgx_pool_free(c->d_bits); hgx_pool_free(c->d_count); hgx_pool_free(c->d_first_row); hgx_pool_free(c->d_bitsT);
     hgx_pool_free(c->d_prow); hgx_pool_free(c->d_pcol);
+    hgx_pool_free(c->d_act); hgx_pool_free(c->d_bitsC); hgx_pool_free(c->d_bitsTC);
+    delete[] c->h_act;
     delete c;
     return HGX_OK;
 }

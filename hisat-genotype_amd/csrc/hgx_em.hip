@@ -1199,6 +1199,49 @@ __global__ __launch_bounds__(BLOCK) void k_em_tail(const uint64_t *__restrict__ 
     wave_em_run(E, x, lane < A1, (int)scal[S_ITER], remove_low, use_len, g, out, scal);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Active-allele compaction.  At the exon level only group representatives occur in classes (core:86-115), so a third
+// or more of the allele columns are all-zero; the EM matrices are restricted to the alleles that occur at all.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_row_any(const uint64_t *__restrict__ BT, int n_rows, int c64, uint8_t *__restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= n_rows) return;
+    uint64_t o = 0;
+    for (int w = lane; w < c64; w += 64) o |= BT[(size_t)row * c64 + w];
+    const uint64_t any = __ballot(o != 0);
+    if (lane == 0) flag[row] = any ? 1 : 0;
+}
+// ascending ids of the flagged rows (one workgroup; n is a few thousand)
+__global__ __launch_bounds__(BLOCK) void k_compact_ids(const uint8_t *__restrict__ flag, int n, int32_t *__restrict__ act,
+                                                       int32_t *__restrict__ n_act) {
+    __shared__ int wtot[NWAVE];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (n + BLOCK - 1) / BLOCK, lo = tid * per, hi = min(n, lo + per);
+    int cnt = 0;
+    for (int a = lo; a < hi; ++a) cnt += flag[a];
+    int inc = cnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wtot[wv] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < wv; ++i) base += wtot[i];
+    int id = base + inc - cnt;
+    for (int a = lo; a < hi; ++a) if (flag[a]) act[id++] = a;
+    if (tid == BLOCK - 1) *n_act = id;
+}
+__global__ __launch_bounds__(256) void k_gather_rows_T(const uint64_t *__restrict__ BT, int c64, const int32_t *__restrict__ act,
+                                                       int n_act, long total, uint64_t *__restrict__ BTc) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = (int)(i / c64), w = (int)(i % c64);
+    BTc[i] = j < n_act ? BT[(size_t)act[j] * c64 + w] : 0ull;
+}
+
 struct MatVec {
     const uint64_t *B;
     int n_rows, n_words, n_k;
@@ -1282,6 +1325,41 @@ inline hipEvent_t pool_event() {
 
 }   // namespace
 
+// bit-matrix transpose kernel of hgx_dedup.hip: [n_rows][w_in] -> [w_in * 64][w_out]
+__global__ void k_transpose(const uint64_t *bits, int n_classes, int w64, int c64, uint64_t *bitsT);
+
+static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
+    if (c->n_act >= 0) return HGX_OK;
+    int rc = hgx_ensure_transposed(c, st);
+    if (rc) return rc;
+    const int A = c->a_pad;
+    DevBuf b_flag, b_n;
+    ALLOC(b_flag, A); ALLOC(b_n, 4);
+    c->d_act = (int32_t *)hgx_pool_alloc((size_t)A * 4);
+    if (!c->d_act) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    HIPCHK(hipMemsetAsync(c->d_act, 0, (size_t)A * 4, st));
+    hipLaunchKernelGGL(k_row_any, dim3(nblk((long)A * 64, 256)), dim3(256), 0, st, c->d_bitsT, A, c->c64, b_flag.as<uint8_t>());
+    hipLaunchKernelGGL(k_compact_ids, dim3(1), dim3(BLOCK), 0, st, b_flag.as<uint8_t>(), A, c->d_act, b_n.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    c->h_act = new int32_t[A];
+    int32_t n = 0;
+    HIPCHK(hipMemcpyAsync(c->h_act, c->d_act, (size_t)A * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&n, b_n.p, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    const int a1p = std::max(512, (n + 511) / 512 * 512);
+    c->d_bitsTC = (uint64_t *)hgx_pool_alloc((size_t)a1p * c->c64 * 8);
+    c->d_bitsC = (uint64_t *)hgx_pool_alloc((size_t)c->c64 * 64 * (a1p / 64) * 8);
+    if (!c->d_bitsTC || !c->d_bitsC) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    const long total = (long)a1p * c->c64;
+    hipLaunchKernelGGL(k_gather_rows_T, dim3(nblk(total, 256)), dim3(256), 0, st, c->d_bitsT, c->c64, c->d_act, n, total, c->d_bitsTC);
+    const long tiles = (long)(a1p / 64) * c->c64;
+    hipLaunchKernelGGL(k_transpose, dim3(nblk(tiles, 4)), dim3(256), 0, st, c->d_bitsTC, a1p, c->c64, a1p / 64, c->d_bitsC);
+    HIPCHK(hipGetLastError());
+    c->a1p = a1p;
+    c->n_act = n;
+    return HGX_OK;
+}
+
 extern "C" int hgx_em_set_backend(int backend) {
     ARGCHK(backend >= 0 && backend <= 2);
     g_backend = backend;
@@ -1308,7 +1386,8 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
     ARGCHK(cc && prob_host && n_alleles > 0 && n_alleles <= cc->a_pad);
     hgx_classes *c = const_cast<hgx_classes *>(cc);
     hipStream_t st = (hipStream_t)stream;
-    const int A = c->a_pad, C = c->n_classes;
+    int A = c->a_pad;
+    const int C = c->n_classes;
     if (n_iter_host) *n_iter_host = 0;
     if (C == 0) {
         for (int a = 0; a < n_alleles; ++a) prob_host[a] = -1.0;
@@ -1380,15 +1459,19 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
         return HGX_OK;
     }
-    int rc = hgx_ensure_transposed(c, st);
+    int rc = hgx_ensure_compact(c, st);
     if (rc) return rc;
+    // from here on every vector lives in the compact allele space: element j is allele c->h_act[j]
+    const int A_full = A;
+    A = c->a1p;
+    const int w64c = A / 64;
     DevBuf b_p, b_q1, b_q2, b_q3, b_wc, b_pr, b_pr1, b_pr2, b_pr3, b_len, b_scal, b_out;
     ALLOC(b_p, A * 8); ALLOC(b_q1, A * 8); ALLOC(b_q2, A * 8); ALLOC(b_q3, A * 8); ALLOC(b_out, A * 8);
     ALLOC(b_wc, (size_t)C * 8); ALLOC(b_pr, A); ALLOC(b_pr1, A); ALLOC(b_pr2, A); ALLOC(b_pr3, A); ALLOC(b_scal, S_N * 8);
     double *d_len = nullptr;
     if (allele_len) {
         std::vector<double> l(A, 1.0);
-        for (int a = 0; a < n_alleles; ++a) l[a] = (double)allele_len[a];
+        for (int j = 0; j < c->n_act; ++j) if (c->h_act[j] < n_alleles) l[j] = (double)allele_len[c->h_act[j]];
         ALLOC(b_len, A * 8);
         HIPCHK(hipMemcpyAsync(b_len.p, l.data(), A * 8, hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1398,8 +1481,8 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
     uint8_t *pr = b_pr.as<uint8_t>(), *pr1 = b_pr1.as<uint8_t>(), *pr2 = b_pr2.as<uint8_t>(), *pr3 = b_pr3.as<uint8_t>();
     double *wc = b_wc.as<double>(), *scal = b_scal.as<double>();
     HIPCHK(hipMemsetAsync(scal, 0, S_N * 8, st));
-    MatVec rows{c->d_bits, C, c->w64, A};
-    MatVec cols{c->d_bitsT, A, c->c64, C};
+    MatVec rows{c->d_bitsC, C, w64c, A};
+    MatVec cols{c->d_bitsTC, A, c->c64, C};
     if (g_backend == 2 && A >= 512 && C >= 64) {
         // MFMA operand order of both matrices, built once per class set
         auto permute = [&](const uint64_t *Bm, int n_rows, int n_words, uint64_t **dst) -> int {
@@ -1414,9 +1497,9 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
             }
             return HGX_OK;
         };
-        if ((rc = permute(c->d_bits, C, c->w64, &c->d_prow))) return rc;
-        if ((rc = permute(c->d_bitsT, A, c->c64, &c->d_pcol))) return rc;
-        rows.P = c->d_prow; rows.n_super = c->w64 / 4;
+        if ((rc = permute(c->d_bitsC, C, w64c, &c->d_prow))) return rc;
+        if ((rc = permute(c->d_bitsTC, A, c->c64, &c->d_pcol))) return rc;
+        rows.P = c->d_prow; rows.n_super = w64c / 4;
         cols.P = c->d_pcol; cols.n_super = c->c64 / 4;
     }
 
@@ -1468,7 +1551,7 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         if (h_scal[S_DONE] != 0.0) break;
         if (use_tail && h_scal[S_NPRES] <= 64.0 && h_scal[S_NPRES] < tail_failed_at) {
             // few survivors: finish on one wavefront (k_em_tail) unless too many distinct class masks remain
-            hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bits, C, c->w64, A, c->d_count, p, pr, d_len,
+            hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsC, C, w64c, A, c->d_count, p, pr, d_len,
                                remove_low ? 1 : 0, b_out.as<double>(), scal);
             const double rows_ran = h_scal[S_NROWS], cols_ran = h_scal[S_NCOLS];
             HIPCHK(hipMemcpyAsync(h_scal, scal, S_N * 8, hipMemcpyDeviceToHost, st));
@@ -1479,7 +1562,7 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         }
     }
     if (g_timing) {
-        const int64_t rows_bytes = (int64_t)C * c->w64 * 8 + (int64_t)A * 9 + (int64_t)C * 16;
+        const int64_t rows_bytes = (int64_t)C * w64c * 8 + (int64_t)A * 9 + (int64_t)C * 16;
         const int64_t cols_bytes = (int64_t)A * c->c64 * 8 + (int64_t)C * 8 + (int64_t)A * 26;
         for (auto &t : timed) {
             float ms = 0.f;
@@ -1503,7 +1586,9 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
     std::vector<double> out(A);
     HIPCHK(hipMemcpyAsync(out.data(), b_out.p, A * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    for (int a = 0; a < n_alleles; ++a) prob_host[a] = out[a];
+    for (int a = 0; a < n_alleles; ++a) prob_host[a] = -1.0;
+    for (int j = 0; j < c->n_act; ++j) if (c->h_act[j] < n_alleles) prob_host[c->h_act[j]] = out[j];
+    (void)A_full;
     if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
     return HGX_OK;
 }
