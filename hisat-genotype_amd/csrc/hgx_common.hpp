@@ -48,6 +48,7 @@ struct hgx_classes {
     uint64_t *d_bitsC = nullptr;                     // [c64 * 64][a1p / 64]  (rows >= n_classes are zero)
     uint64_t *d_bitsTC = nullptr;                    // [a1p][c64]
     int32_t *h_act = nullptr;                        // host copy of d_act (new[])
+    uint64_t *d_wrow = nullptr, *d_wcol = nullptr;   // word-transposed compact matrices [a1p/64][c64*64], [c64][a1p]
 };
 
 struct DevBuf {

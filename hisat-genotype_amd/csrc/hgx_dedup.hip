@@ -212,6 +212,7 @@ extern "C" int hgx_classes_destroy(hgx_classes *c) {
     hgx_pool_free(c->d_bits); hgx_pool_free(c->d_count); hgx_pool_free(c->d_first_row); hgx_pool_free(c->d_bitsT);
     hgx_pool_free(c->d_prow); hgx_pool_free(c->d_pcol);
     hgx_pool_free(c->d_act); hgx_pool_free(c->d_bitsC); hgx_pool_free(c->d_bitsTC);
+    hgx_pool_free(c->d_wrow); hgx_pool_free(c->d_wcol);
     delete[] c->h_act;
     delete c;
     return HGX_OK;

@@ -1242,14 +1242,182 @@ __global__ __launch_bounds__(256) void k_gather_rows_T(const uint64_t *__restric
     BTc[i] = j < n_act ? BT[(size_t)act[j] * c64 + w] : 0ull;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Table-lookup form of the bit mat-vec ("four Russians").  The EXEC-masked kernel above spends one vector instruction
+// (plus two scalar ones and a share of a cross-lane reduction) per 64 matrix bits of ONE row; here a lane owns a row
+// and consumes 8 matrix bits per LDS lookup:
+//   * K is cut into slabs of 512 elements = 64 groups of 8; a workgroup (slab, chunk of 1024 rows) first tabulates the
+//     256 subset sums of every group of its slab (128 KB of LDS, ~1.3 additions per entry),
+//   * then every lane walks its row's 8 words of the slab -- the matrix is stored word-transposed, M[k_word][row],
+//     so a wave reads 512 contiguous bytes per word -- and adds table[group][byte]; all-zero words are skipped per wave,
+//   * the per-slab partial sums go to memory and the LAST workgroup of a row chunk to finish (device-scope counter)
+//     adds them in slab order and applies the same epilogue as k_bitmatvec.
+// Summation order is fixed (groups ascending, slabs ascending), so results are reproducible from launch to launch.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int LUT_G = 64;                  // groups per slab
+constexpr int LUT_SLAB = LUT_G * 8;        // elements per slab
+constexpr size_t LUT_LDS = (size_t)(LUT_G * 256 + LUT_SLAB) * 8;
+
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void k_lutmatvec(const uint64_t *__restrict__ M, int N, int Npad, int n_k,
+                                                     const double *__restrict__ vec, const uint8_t *__restrict__ vec_pres,
+                                                     int x_mode, const int64_t *__restrict__ count,
+                                                     const double *__restrict__ q_in, const uint8_t *__restrict__ pres_in,
+                                                     const double *__restrict__ len, double *__restrict__ y,
+                                                     uint8_t *__restrict__ pres_out, double *__restrict__ scal, int gate,
+                                                     double *__restrict__ part, unsigned *__restrict__ counters, int abl) {
+    extern __shared__ double lds[];
+    double *T = lds;                        // [LUT_G][256]
+    double *xs = lds + LUT_G * 256;         // [LUT_SLAB]
+    __shared__ double sh[NWAVE];
+    __shared__ int is_last;
+    const int tid = threadIdx.x;
+    const int slab = blockIdx.x, chunk = blockIdx.y, n_slabs = gridDim.x;
+    const int n = chunk * BLOCK + tid;
+    const double st_done = scal[S_DONE], st_flag = scal[S_FLAG];
+    double tot = 1.0;
+    if (MODE == MODE_COLS) tot = scal[S_TOT_A];
+    // this slab's matrix words of my row: requested before anything else
+    uint64_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = n < Npad ? M[(size_t)(slab * 8 + i) * Npad + n] : 0ull;
+    double xv = 0.0;
+    if (tid < LUT_SLAB) {
+        const int e = slab * LUT_SLAB + tid;
+        if (e < n_k) {
+            if (MODE == MODE_ROWS) xv = (x_mode == 2) ? 1.0 : (vec_pres[e] ? vec[e] : 0.0);
+            else xv = vec[e];
+        }
+    }
+    if (st_done != 0.0) return;
+    if (gate && st_flag == 0.0) return;
+    if (MODE == MODE_COLS && x_mode != 2) {
+        // a chunk without a present allele produces zeros whatever the matrix says (every workgroup of the chunk agrees)
+        if (!__syncthreads_or(n < N && pres_in[n] != 0)) {
+            if (slab == 0 && n < N) { y[n] = 0.0; pres_out[n] = 0; }
+            if (slab == 0 && chunk == 0 && tid == 0) scal[S_NCOLS] += 1.0;
+            return;
+        }
+    }
+    if (MODE == MODE_ROWS && x_mode == 1) {
+        double s = 0.0;
+        for (int e = tid; e < n_k; e += BLOCK) if (vec_pres[e]) s += vec[e];
+        tot = block_sum(s, sh);
+        xv = xv / tot;
+    }
+    if (slab == 0 && chunk == 0 && tid == 0) {
+        if (MODE == MODE_ROWS) { scal[S_TOT_A] = tot; scal[S_NROWS] += 1.0; }
+        else scal[S_NCOLS] += 1.0;
+    }
+    if (tid < LUT_SLAB) xs[tid] = xv;
+    __syncthreads();
+    if (!(abl & 2))
+    {   // subset sums: thread = (group, low nibble); the 16 high nibbles are unrolled
+        const int g = tid >> 4, lo = tid & 15;
+        const double x0 = xs[8 * g], x1 = xs[8 * g + 1], x2 = xs[8 * g + 2], x3 = xs[8 * g + 3];
+        const double x4 = xs[8 * g + 4], x5 = xs[8 * g + 5], x6 = xs[8 * g + 6], x7 = xs[8 * g + 7];
+        const double L = (((lo & 1 ? x0 : 0.0) + (lo & 2 ? x1 : 0.0)) + (lo & 4 ? x2 : 0.0)) + (lo & 8 ? x3 : 0.0);
+        double *Tg = T + g * 256 + lo;
+#pragma unroll
+        for (int hi = 0; hi < 16; ++hi) {
+            const double H = (((hi & 1 ? x4 : 0.0) + (hi & 2 ? x5 : 0.0)) + (hi & 4 ? x6 : 0.0)) + (hi & 8 ? x7 : 0.0);
+            Tg[hi * 16] = L + H;
+        }
+    }
+    __syncthreads();
+    double acc = 0.0;
+    if (!(abl & 4))
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (__ballot(w[i] != 0ull) == 0ull) continue;
+        const uint32_t wl = (uint32_t)w[i], wh = (uint32_t)(w[i] >> 32);
+        const double *Ti = T + i * 8 * 256;
+        acc += Ti[0 * 256 + (wl & 255u)];
+        acc += Ti[1 * 256 + ((wl >> 8) & 255u)];
+        acc += Ti[2 * 256 + ((wl >> 16) & 255u)];
+        acc += Ti[3 * 256 + (wl >> 24)];
+        acc += Ti[4 * 256 + (wh & 255u)];
+        acc += Ti[5 * 256 + ((wh >> 8) & 255u)];
+        acc += Ti[6 * 256 + ((wh >> 16) & 255u)];
+        acc += Ti[7 * 256 + (wh >> 24)];
+    }
+    // ---- the last workgroup of this row chunk to finish adds the slabs ------------------------------------------
+    // No device-wide fence (a release fence at agent scope writes the whole L2 back: ~100 us measured).  Instead the
+    // partials are device-scope atomic stores (written through to memory, past this XCD's L2), the workgroup waits for
+    // its own stores to complete, then one device-scope atomic bumps the chunk's counter; the workgroup that draws
+    // the last ticket reads the partials with device-scope loads (never cached in its L2 during this launch).
+    if (n < Npad)
+        __hip_atomic_store((unsigned long long *)&part[(size_t)slab * Npad + n], (unsigned long long)__double_as_longlong(acc),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (abl & 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&counters[chunk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = old == (unsigned)(n_slabs - 1);
+        if (is_last) __hip_atomic_store(&counters[chunk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    if (n < N) {
+        double t = 0.0;
+        for (int s0 = 0; s0 < n_slabs; s0 += 8) {           // eight loads in flight, added in slab order
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                v[k] = s0 + k < n_slabs
+                           ? __longlong_as_double((long long)__hip_atomic_load((unsigned long long *)&part[(size_t)(s0 + k) * Npad + n],
+                                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                           : 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t += v[k];
+        }
+        if (MODE == MODE_ROWS) {
+            y[n] = t > 0.0 ? (double)count[n] / t : 0.0;
+        } else {
+            const bool init = x_mode == 2;
+            const bool in = init || pres_in[n] != 0;
+            double v = 0.0;
+            if (in && t > 0.0) {
+                v = init ? t : (q_in[n] / tot) * t;
+                if (len) v = v / len[n];
+            }
+            y[n] = v;
+            pres_out[n] = (in && t > 0.0) ? 1 : 0;
+        }
+    }
+}
+
+// u64-element transpose: out[c][r] = in[r][c]  (in [n_rows][n_cols])
+__global__ __launch_bounds__(256) void k_word_transpose(const uint64_t *__restrict__ in, int n_rows, int n_cols,
+                                                        uint64_t *__restrict__ out) {
+    __shared__ uint64_t tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int k = ty; k < 32; k += 8) {
+        const int r = r0 + k, c = c0 + tx;
+        tile[k][tx] = (r < n_rows && c < n_cols) ? in[(size_t)r * n_cols + c] : 0ull;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, r = r0 + tx;
+        if (c < n_cols && r < n_rows) out[(size_t)c * n_rows + r] = tile[tx][k];
+    }
+}
+
 struct MatVec {
     const uint64_t *B;
     int n_rows, n_words, n_k;
     const uint64_t *P = nullptr;    // MFMA operand order of B (k_permute_mfma), or nullptr -> VALU kernel
     int n_super = 0;
+    const uint64_t *M = nullptr;    // word-transposed B [n_words][n_pad] for the table-lookup kernel, or nullptr
+    int n_pad = 0;
+    double *part = nullptr;         // [n_words / 8][n_pad] slab partials
+    unsigned *counters = nullptr;   // [ceil(n_rows / 1024)], zero between launches
 };
 
-int g_backend = 0;                  // 0 auto, 1 VALU (EXEC-masked FP64), 2 MFMA (int8 fixed point)
+int g_backend = 0;                  // 0 auto, 1 VALU (EXEC-masked FP64), 2 MFMA (int8 fixed point), 3 table lookup
 
 inline bool use_mfma(const MatVec &m) {
     if (!m.P) return false;
@@ -1289,6 +1457,18 @@ int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint
     if constexpr (MODE == MODE_ROWS || MODE == MODE_COLS) {
         if (use_mfma(m))
             return launch_mfma<MODE>(m, st, vec, vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate);
+        if (m.M) {
+            static bool attr_set = false;
+            if (!attr_set) {
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lutmatvec<MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LUT_LDS));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((k_lutmatvec<MODE>), dim3(m.n_words / 8, (m.n_rows + BLOCK - 1) / BLOCK), dim3(BLOCK), LUT_LDS, st, m.M,
+                               m.n_rows, m.n_pad, m.n_k, vec, vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate,
+                               m.part, m.counters, getenv("HGX_LUT_ABL") ? atoi(getenv("HGX_LUT_ABL")) : 0);
+            return HGX_OK;
+        }
     }
     const int rpb = rows_per_block(m.n_rows);
     const int grid = (m.n_rows + rpb - 1) / rpb;
@@ -1361,7 +1541,7 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
 }
 
 extern "C" int hgx_em_set_backend(int backend) {
-    ARGCHK(backend >= 0 && backend <= 2);
+    ARGCHK(backend >= 0 && backend <= 3);
     g_backend = backend;
     return HGX_OK;
 }
@@ -1503,6 +1683,24 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         cols.P = c->d_pcol; cols.n_super = c->c64 / 4;
     }
 
+    DevBuf b_part, b_cnt;
+    if (g_backend == 0 || g_backend == 3) {
+        // table-lookup kernels: word-transposed copies of both matrices, built once per class set
+        const int Cp = c->c64 * 64;
+        if (!c->d_wrow) {
+            c->d_wrow = (uint64_t *)hgx_pool_alloc((size_t)w64c * Cp * 8);
+            c->d_wcol = (uint64_t *)hgx_pool_alloc((size_t)c->c64 * A * 8);
+            if (!c->d_wrow || !c->d_wcol) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+            hipLaunchKernelGGL(k_word_transpose, dim3((w64c + 31) / 32, (Cp + 31) / 32), dim3(256), 0, st, c->d_bitsC, Cp, w64c, c->d_wrow);
+            hipLaunchKernelGGL(k_word_transpose, dim3((c->c64 + 31) / 32, (A + 31) / 32), dim3(256), 0, st, c->d_bitsTC, A, c->c64, c->d_wcol);
+        }
+        const size_t n_part = std::max((size_t)(w64c / 8) * Cp, (size_t)(c->c64 / 8) * A);
+        const size_t n_cnt = (size_t)std::max((C + BLOCK - 1) / BLOCK, (A + BLOCK - 1) / BLOCK);
+        ALLOC(b_part, n_part * 8); ALLOC(b_cnt, n_cnt * 4);
+        HIPCHK(hipMemsetAsync(b_cnt.p, 0, n_cnt * 4, st));
+        rows.M = c->d_wrow; rows.n_pad = Cp; rows.part = b_part.as<double>(); rows.counters = b_cnt.as<unsigned>();
+        cols.M = c->d_wcol; cols.n_pad = A; cols.part = b_part.as<double>(); cols.counters = b_cnt.as<unsigned>();
+    }
     std::vector<Timed> timed;
     const int slot_rows = A <= 8 * BLOCK ? 0 : 1, slot_cols = C <= 8 * BLOCK ? 2 : 3;
     auto stamp = [&](int slot, bool begin) {
@@ -1628,7 +1826,7 @@ extern "C" int hgx_allele_counts_on(const hgx_classes *cc, int64_t *count_host, 
 //   which = 0: y[c] = count[c] / sum_a B[c][a] x[a]   (x: a_pad doubles)      -> n_classes doubles
 //   which = 1: y[a] = sum_c B[c][a] x[c]              (x: n_classes doubles)  -> a_pad doubles
 extern "C" int hgx_debug_matvec(const hgx_classes *cc, int which, int backend, const double *x_host, double *y_host) {
-    ARGCHK(cc && x_host && y_host && (which == 0 || which == 1) && backend >= 1 && backend <= 2);
+    ARGCHK(cc && x_host && y_host && (which == 0 || which == 1) && backend >= 1 && backend <= 3);
     hgx_classes *c = const_cast<hgx_classes *>(cc);
     const int A = c->a_pad, C = c->n_classes;
     ARGCHK(C > 0);
@@ -1657,6 +1855,16 @@ extern "C" int hgx_debug_matvec(const hgx_classes *cc, int which, int backend, c
                            b_P.as<uint64_t>());
         m.P = b_P.as<uint64_t>();
         m.n_super = n_super;
+    }
+    DevBuf b_M, b_part, b_cnt;
+    if (backend == 3) {
+        ALLOC(b_M, (size_t)m.n_words * m.n_rows * 8);
+        hipLaunchKernelGGL(k_word_transpose, dim3((m.n_words + 31) / 32, (m.n_rows + 31) / 32), dim3(256), 0, nullptr, m.B, m.n_rows,
+                           m.n_words, b_M.as<uint64_t>());
+        ALLOC(b_part, (size_t)(m.n_words / 8) * m.n_rows * 8);
+        ALLOC(b_cnt, (size_t)((m.n_rows + BLOCK - 1) / BLOCK) * 4);
+        HIPCHK(hipMemset(b_cnt.p, 0, (size_t)((m.n_rows + BLOCK - 1) / BLOCK) * 4));
+        m.M = b_M.as<uint64_t>(); m.n_pad = m.n_rows; m.part = b_part.as<double>(); m.counters = b_cnt.as<unsigned>();
     }
     const int saved = g_backend;
     g_backend = backend;

@@ -324,8 +324,9 @@ def test_em_compact_tail_equals_full_iterations(orc):
 
 
 @pytest.mark.parametrize("name", ["hla_7000", "hla_mid_real"])
-def test_em_mfma_backend_equals_fp64_backend(orc, name):
-    """The int8-MFMA mat-vec (exact integer accumulation of 128-bit fixed-point planes) against the FP64 VALU mat-vec:
+def test_em_backends_agree(orc, name):
+    """The int8-MFMA mat-vec (exact integer accumulation of 128-bit fixed-point planes) and the table-lookup mat-vec
+    (256 subset sums per group of 8 columns, one LDS lookup per 8 matrix bits) against the EXEC-masked FP64 VALU mat-vec:
     same iteration counts, abundances equal to rounding, on the reference's recorded EM inputs and on a big random one."""
     fx, loc, t, pl, batch, (eb, gb, gc, fp) = _setup(orc, name)
     A = t["n_alleles"]
@@ -351,10 +352,11 @@ def test_em_mfma_backend_equals_fp64_backend(orc, name):
             ln = pl.allele_len if use_len else None
             engine.em_set_backend(1)
             p1, it1 = cl.em(A, low, ln)
-            engine.em_set_backend(2)
-            p2, it2 = cl.em(A, low, ln)
-            assert it1 == it2
-            assert np.array_equal(p1 < 0, p2 < 0)
-            assert np.max(np.abs(p1 - p2)) <= 1e-11, np.max(np.abs(p1 - p2))
+            for backend in (2, 3):                      # int8 MFMA, table lookup
+                engine.em_set_backend(backend)
+                p2, it2 = cl.em(A, low, ln)
+                assert it1 == it2, (backend, it1, it2)
+                assert np.array_equal(p1 < 0, p2 < 0)
+                assert np.max(np.abs(p1 - p2)) <= 1e-11, (backend, np.max(np.abs(p1 - p2)))
     finally:
         engine.em_set_backend(0)

@@ -12,7 +12,7 @@ cl = engine.Classes.from_host(bits, counts, ap)
 x = np.zeros(ap); x[:A] = rng.rand(A)
 xc = rng.rand(Cn)
 os.environ["HGX_DBG_REPS"] = "50"
-for backend in (1, 2):
+for backend in [int(b) for b in os.environ.get('BACKENDS', '1,3').split(',')]:
     for which, xx, ny in ((0, x, Cn), (1, xc, ap)):
         y = np.zeros(ny)
         capi.check(capi.lib().hgx_debug_matvec(cl.h, which, backend, capi.ptr(xx), capi.ptr(y)))
