@@ -234,16 +234,116 @@ __global__ __launch_bounds__(256) void k_piece_compat(const uint32_t *__restrict
     if (lane < g_end) compat[(size_t)piece * w64 + chunk * PC_GROUPS + lane] = mine;
 }
 
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled form (the one hgx_piece_compat launches).  The kernel above re-reads the index rows of a piece's
+// word range from L2 for every piece (rocprof: ~9 TB/s of L2 traffic, the whole 0.8 ms); here a workgroup
+// = 1024 alleles x 256 consecutive pieces stages what they share once:
+//   * the pieces' descriptors and (MP, P) mask words            -> LDS (broadcast reads in the loop),
+//   * the index rows of the window of <= 12 variant words the pieces cover -> LDS tile[word][allele]
+//     (the front-end sorts pieces by lo_word, so 256 neighbours span one or two words plus their length);
+//   * thread = allele: per piece and word one conflict-free ds_read_b32 + xor + and-or, the 64 verdicts of
+//     a wave leave as a ballot that lane (piece mod 64) keeps; one store per 64 pieces.
+// Pieces that do not fit the current window start a new one (any piece order stays correct).
+// ------------------------------------------------------------------------------------------------
+#define PT_W 12
+#define PT_PB 256
+#define PT_NW 8
+__global__ __launch_bounds__(1024) void k_piece_compat_tiled(const uint32_t *__restrict__ bits, int a_pad, int n_index_words,
+                                                             const hgx_piece *__restrict__ pieces,
+                                                             const uint32_t *__restrict__ masks, int n_pieces,
+                                                             uint64_t *__restrict__ compat, int w64) {
+    __shared__ uint32_t tile[PT_W][1024];
+    __shared__ uint32_t smask[PT_PB][2 * PT_NW];
+    __shared__ int s_lo[PT_PB], s_nw[PT_PB];
+    __shared__ int s_end;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int chunk = blockIdx.y;
+    const int p0 = blockIdx.x * PT_PB;
+    const int np = min(PT_PB, n_pieces - p0);
+    {   // stage descriptors and masks: thread = (piece, quarter of its 16 mask words)
+        const int p = tid >> 2, q = tid & 3;
+        if (p < np) {
+            const hgx_piece pc = pieces[p0 + p];
+            const int nw2 = 2 * (int)pc.n_words;
+            if (q == 0) { s_lo[p] = pc.lo_word; s_nw[p] = pc.n_words; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = 4 * q + k;
+                smask[p][i] = i < nw2 ? masks[pc.mask_off + i] : 0u;
+            }
+        }
+    }
+    __syncthreads();
+    const int a = chunk * 1024 + tid;
+    const int wslot = chunk * 16 + wv;            // this wave's 64-allele word of the compat row
+    int cur = 0;
+    while (cur < np) {
+        if (s_nw[cur] > PT_NW) {
+            // a piece wider than the staging area (long deletions / dense variant runs): straight from the index
+            const hgx_piece pc = pieces[p0 + cur];
+            const uint32_t *m = masks + pc.mask_off;
+            bool ok = true;
+            for (int i = 0; i < (int)pc.n_words; ++i) {
+                const uint32_t r = a < a_pad ? bits[(size_t)(pc.lo_word + i) * a_pad + a] : 0u;
+                ok = ok && ((r & m[2 * i]) == m[2 * i + 1]);
+            }
+            const uint64_t b = __ballot(ok);
+            if (lane == 0 && wslot < w64) compat[(size_t)(p0 + cur) * w64 + wslot] = b;
+            ++cur;
+            continue;
+        }
+        const int win_lo = s_lo[cur];
+        if (tid == 0) s_end = np;
+        __syncthreads();
+        if (tid >= cur && tid < np) {
+            const int l = s_lo[tid];
+            if (l < win_lo || s_nw[tid] > PT_NW || l + s_nw[tid] - win_lo > PT_W) atomicMin(&s_end, tid);
+        }
+#pragma unroll
+        for (int i = 0; i < PT_W; ++i) {
+            const int w = win_lo + i;
+            tile[i][tid] = (w < n_index_words && a < a_pad) ? bits[(size_t)w * a_pad + a] : 0u;
+        }
+        __syncthreads();
+        const int end = s_end;
+        for (int b0 = cur; b0 < end; b0 += 64) {
+            uint64_t mine = 0;
+            const int b1 = min(end, b0 + 64);
+            for (int p = b0; p < b1; ++p) {
+                const int off = __builtin_amdgcn_readfirstlane(s_lo[p]) - win_lo;
+                const int nw = __builtin_amdgcn_readfirstlane(s_nw[p]);
+                uint32_t bad = 0;
+#pragma unroll
+                for (int i = 0; i < PT_NW; ++i) {
+                    if (i < nw) bad |= (tile[off + i][tid] ^ smask[p][2 * i + 1]) & smask[p][2 * i];
+                }
+                const uint64_t b = __ballot(bad == 0);
+                if (lane == p - b0) mine = b;
+            }
+            if (b0 + lane < b1 && wslot < w64) compat[(size_t)(p0 + b0 + lane) * w64 + wslot] = mine;
+        }
+        __syncthreads();
+        cur = end;
+    }
+}
+
 extern "C" int hgx_piece_compat(const hgx_index *ix, const hgx_piece *pieces, const uint32_t *masks, int32_t n_pieces,
                                 uint64_t *compat, void *stream) {
     ARGCHK(ix && n_pieces >= 0);
     if (n_pieces == 0) return HGX_OK;
     ARGCHK(pieces && masks && compat);
-    const int chunks = (ix->w64 + PC_GROUPS - 1) / PC_GROUPS;
-    const long waves = (long)n_pieces * chunks;
-    const long blocks = (waves + 3) / 4;
-    hipLaunchKernelGGL(k_piece_compat, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ix->d_bits, ix->a_pad,
-                       pieces, masks, n_pieces, compat, ix->w64, chunks);
+    static const bool untiled = getenv("HGX_PIECE_UNTILED") != nullptr;     // the L2-served kernel, kept for comparison
+    if (untiled) {
+        const int chunks = (ix->w64 + PC_GROUPS - 1) / PC_GROUPS;
+        const long waves = (long)n_pieces * chunks;
+        const long blocks = (waves + 3) / 4;
+        hipLaunchKernelGGL(k_piece_compat, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ix->d_bits, ix->a_pad,
+                           pieces, masks, n_pieces, compat, ix->w64, chunks);
+    } else {
+        hipLaunchKernelGGL(k_piece_compat_tiled, dim3((n_pieces + PT_PB - 1) / PT_PB, (ix->a_pad + 1023) / 1024), dim3(1024), 0,
+                           (hipStream_t)stream, ix->d_bits, ix->a_pad, ix->n_words, pieces, masks, n_pieces, compat, ix->w64);
+    }
     HIPCHK(hipGetLastError());
     return HGX_OK;
 }

@@ -125,6 +125,8 @@ def test_random_pieces_large(orc):
         for m in range(rng.randint(0, 4)):
             l = rng.randint(0, len(loc.backbone) - 160)
             r = l + rng.randint(1, 150)
+            if rng.rand() < 0.05:                 # a wide piece: more than 8 variant words (k_piece_compat's direct path)
+                r = min(len(loc.backbone) - 1, l + rng.randint(400, 2500))
             a = names[rng.randint(len(names))]
             vs = [v for v in loc.allele_vars[a] if l <= loc.var_pos[v] <= r]
             if rng.rand() < 0.2 and vs:
