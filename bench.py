@@ -170,7 +170,7 @@ def main():
 
     if rank == 0:
         # Per-kernel achieved rates from HIP events recorded inside the timed region (byte models: DESIGN.md section 5).
-        #  k_bitmatvec (EM rows / cols pass): the bit matrix once + its dense vectors -- dominant by aggregate time
+        #  k_lutmatvec<0> (EM rows pass): the compact class bit matrix once + its dense vectors
         #  k_pair_classes: n_refs compat rows read + 2 class rows (+ hash) written per pair + refs/offsets
         #  k_piece_compat: n_words x a_pad x 4 index bytes read + one compat row written per distinct piece
         row = pl.a_pad // 8

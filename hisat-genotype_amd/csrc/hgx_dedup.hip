@@ -94,6 +94,35 @@ __global__ __launch_bounds__(256) void k_verify(const uint64_t *__restrict__ row
     if (__any(diff) && lane == 0) atomicOr(bad, 1);
 }
 
+// streaming form of the exact check: rows are visited in their ORIGINAL order (sequential 16-byte-per-lane reads of the
+// big array), each against the first row of its run (a few thousand distinct rows: cache resident)
+__global__ void k_head_of(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ cls, const uint32_t *__restrict__ head,
+                          const uint32_t *__restrict__ run_first, long n_valid, long n, uint32_t *__restrict__ head_of) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t row = idx[i];
+    head_of[row] = (i < n_valid && !head[i]) ? run_first[cls[i] - 1] : row;
+}
+__global__ __launch_bounds__(256) void k_verify_stream(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
+                                                       const uint32_t *__restrict__ head_of, long n, int *__restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const long r = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= n) return;
+    const uint32_t h = head_of[r];
+    if (h == (uint32_t)r) return;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 *a = (const u64x2 *)(rows + (size_t)r * w64);
+    const u64x2 *b = (const u64x2 *)(rows + (size_t)h * w64);
+    const u64x2 *m = (const u64x2 *)mask;
+    bool diff = false;
+    for (int w = lane; w < w64 / 2; w += 64) {
+        u64x2 x = a[w], y = b[w];
+        if (mask) { x &= m[w]; y &= m[w]; }
+        diff = diff || x.x != y.x || x.y != y.y;
+    }
+    if (__any(diff) && lane == 0) atomicOr(bad, 1);
+}
+
 // out[c] = rows[first_row[c]] & mask
 __global__ __launch_bounds__(256) void k_gather_rows(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
                                                      const uint32_t *__restrict__ first_sorted, const uint32_t *__restrict__ run_sorted,
@@ -175,8 +204,18 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
     }
     hipLaunchKernelGGL(k_run_counts, dim3(nblk(n_runs, 256)), dim3(256), 0, st, b_rs.as<uint32_t>(), n_runs, n_valid, wsum,
                        b_rc.as<int64_t>());
-    hipLaunchKernelGGL(k_verify, dim3(nblk(n_valid, 4)), dim3(256), 0, st, rows, w64, and_mask, b_idx.as<uint32_t>(),
-                       b_cls.as<uint32_t>(), b_head.as<uint32_t>(), b_rf.as<uint32_t>(), n_valid, b_bad.as<int>());
+    static const bool sorted_verify = getenv("HGX_VERIFY_SORTED") != nullptr;      // the hash-order walk, for comparison
+    DevBuf b_ho;
+    if (sorted_verify) {
+        hipLaunchKernelGGL(k_verify, dim3(nblk(n_valid, 4)), dim3(256), 0, st, rows, w64, and_mask, b_idx.as<uint32_t>(),
+                           b_cls.as<uint32_t>(), b_head.as<uint32_t>(), b_rf.as<uint32_t>(), n_valid, b_bad.as<int>());
+    } else {
+        ALLOC(b_ho, (size_t)n * 4);
+        hipLaunchKernelGGL(k_head_of, dim3(nblk(n, 256)), dim3(256), 0, st, b_idx.as<uint32_t>(), b_cls.as<uint32_t>(),
+                           b_head.as<uint32_t>(), b_rf.as<uint32_t>(), n_valid, n, b_ho.as<uint32_t>());
+        hipLaunchKernelGGL(k_verify_stream, dim3(nblk(n, 4)), dim3(256), 0, st, rows, w64, and_mask, b_ho.as<uint32_t>(), n,
+                           b_bad.as<int>());
+    }
     // first-seen order: sort runs by their first row
     DevBuf b_fs, b_rid0, b_rid, b_tmp2;
     ALLOC(b_fs, (size_t)n_runs * 4); ALLOC(b_rid0, (size_t)n_runs * 4); ALLOC(b_rid, (size_t)n_runs * 4);

@@ -357,6 +357,41 @@ extern "C" int hgx_piece_compat(const hgx_index *ix, const hgx_piece *pieces, co
 // ever materialising a count.
 // ------------------------------------------------------------------------------------------------
 #define NP 8
+// arg-max set of the bit-sliced counters under the level mask, its row hash, and the stores
+template <int KW>
+__device__ __forceinline__ void emit_class(const uint64_t (&plane)[NP][KW], int w64, const uint64_t *__restrict__ mask,
+                                           uint64_t *__restrict__ out_row, uint64_t *__restrict__ out_hash, int lane) {
+    uint64_t cand[KW];
+#pragma unroll
+    for (int s = 0; s < KW; ++s) cand[s] = (lane + 64 * s < w64) ? mask[lane + 64 * s] : 0ull;
+#pragma unroll
+    for (int k = NP - 1; k >= 0; --k) {
+        bool nz = false;
+#pragma unroll
+        for (int s = 0; s < KW; ++s) nz = nz || ((cand[s] & plane[k][s]) != 0);
+        if (__any(nz)) {
+#pragma unroll
+            for (int s = 0; s < KW; ++s) cand[s] &= plane[k][s];
+        }
+    }
+    uint64_t h = 0;
+    bool nz = false;
+#pragma unroll
+    for (int s = 0; s < KW; ++s) {
+        const int w = lane + 64 * s;
+        if (w < w64) {
+            if (out_row) out_row[w] = cand[s];
+            h += word_hash(cand[s], w);
+            nz = nz || cand[s] != 0;
+        }
+    }
+    if (out_hash) {
+        h = wave_sum_u64(h);
+        const bool any_nz = __any(nz);
+        if (lane == 0) *out_hash = finish_hash(h, any_nz);
+    }
+}
+
 template <int KW>
 __device__ __forceinline__ void class_for_level(const uint64_t *__restrict__ compat, int w64, const uint32_t *__restrict__ refs,
                                                 int r0, int r1, uint32_t level, const uint64_t *__restrict__ mask,
@@ -397,35 +432,7 @@ __device__ __forceinline__ void class_for_level(const uint64_t *__restrict__ com
         for (int s = 0; s < KW; ++s) cur[s] = nxt[s];
         r = rn;
     }
-    uint64_t cand[KW];
-#pragma unroll
-    for (int s = 0; s < KW; ++s) cand[s] = (lane + 64 * s < w64) ? mask[lane + 64 * s] : 0ull;
-#pragma unroll
-    for (int k = NP - 1; k >= 0; --k) {
-        bool nz = false;
-#pragma unroll
-        for (int s = 0; s < KW; ++s) nz = nz || ((cand[s] & plane[k][s]) != 0);
-        if (__any(nz)) {
-#pragma unroll
-            for (int s = 0; s < KW; ++s) cand[s] &= plane[k][s];
-        }
-    }
-    uint64_t h = 0;
-    bool nz = false;
-#pragma unroll
-    for (int s = 0; s < KW; ++s) {
-        const int w = lane + 64 * s;
-        if (w < w64) {
-            if (out_row) out_row[w] = cand[s];
-            h += word_hash(cand[s], w);
-            nz = nz || cand[s] != 0;
-        }
-    }
-    if (out_hash) {
-        h = wave_sum_u64(h);
-        const bool any_nz = __any(nz);
-        if (lane == 0) *out_hash = finish_hash(h, any_nz);
-    }
+    emit_class<KW>(plane, w64, mask, out_row, out_hash, lane);
 }
 
 template <int KW>

@@ -136,13 +136,19 @@ def em_set_timing(on):
 def em_get_timing():
     """{kernel name: (ms_total, launches, executed, bytes_total)} accumulated since em_set_timing(True)."""
     out = {}
-    for slot, name in enumerate(("k_bitmatvec<8,ROWS>", "k_bitmatvec<16,ROWS>", "k_bitmatvec<8,COLS>", "k_bitmatvec<16,COLS>")):
-        ms, n, ex, by = C.c_double(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        capi.check(capi.lib().hgx_em_get_timing(C.c_int(slot), C.byref(ms), C.byref(n), C.byref(ex), C.byref(by)))
-        out[name] = (ms.value, n.value, ex.value, by.value)
+    # slots 0/1 = rows pass (vector <= 8192 / larger), 2/3 = cols pass; the default (table-lookup) backend runs both sizes
+    # with the same kernel, k_lutmatvec<0> / k_lutmatvec<1> in rocprofv3's naming
+    for name, slots in (("k_lutmatvec<0>", (0, 1)), ("k_lutmatvec<1>", (2, 3))):
+        tot = [0.0, 0, 0, 0]
+        for slot in slots:
+            ms, n, ex, by = C.c_double(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)
+            capi.check(capi.lib().hgx_em_get_timing(C.c_int(slot), C.byref(ms), C.byref(n), C.byref(ex), C.byref(by)))
+            tot[0] += ms.value; tot[1] += n.value; tot[2] += ex.value; tot[3] += by.value
+        out[name] = tuple(tot)
     return out
 
 
 def em_set_backend(backend):
-    """0 = auto, 1 = EXEC-masked FP64 VALU mat-vec, 2 = int8 MFMA mat-vec (128-bit fixed point)."""
+    """0 = auto (table lookup), 1 = EXEC-masked FP64 VALU mat-vec, 2 = int8 MFMA mat-vec (128-bit fixed point),
+    3 = table-lookup mat-vec (256 subset sums per 8 columns in LDS)."""
     capi.check(capi.lib().hgx_em_set_backend(C.c_int(backend)))

@@ -252,10 +252,11 @@ int hgx_batch_pileup(const hgx_batch *b, uint8_t *nt_set, uint32_t *counts);
 
 /* Kernel timing for roofline reports.  hgx_em_set_timing(1) makes hgx_em bracket every bit-mat-vec launch with HIP
  * events on its stream (rows-pass launches only: the kernel with the largest aggregate time; each event costs ~1.5 us)
- * and (re)starts the per-thread totals; slot 0 = k_bitmatvec<8,ROWS>, 1 = <16,ROWS>, 2 = <8,COLS>,
- * 3 = <16,COLS>.  `executed` counts the launches that did work (not gated / past convergence) and bytes_total their
+ * and (re)starts the per-thread totals; slots 0/1 = rows pass (vector of <= 8192 / more elements), 2/3 = cols pass
+ * (k_lutmatvec<0> / <1> with the default backend).  `executed` counts the launches that did work (not gated / past convergence) and bytes_total their
  * algorithmic bytes (bit matrix once + dense vectors).                                                              */
-/* mat-vec backend of hgx_em: 0 = auto (MFMA for large problems), 1 = EXEC-masked FP64 VALU kernel, 2 = int8 MFMA kernel */
+/* mat-vec backend of hgx_em: 0 = auto (table lookup), 1 = EXEC-masked FP64 VALU kernel, 2 = int8 MFMA kernel,
+ * 3 = table-lookup kernel (256 subset sums per 8 matrix columns in LDS; one lookup per 8 matrix bits) */
 int hgx_em_set_backend(int backend);
 /* test aid: one rows pass (which = 0: y[c] = count[c] / sum_a B[c][a] x[a]) or cols pass (which = 1: y[a] = sum_c
  * B[c][a] x[c]) with backend 1 or 2; x and y are host arrays of a_pad / n_classes doubles                        */
