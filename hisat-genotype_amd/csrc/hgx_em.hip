@@ -1389,6 +1389,333 @@ __global__ __launch_bounds__(BLOCK) void k_lutmatvec(const uint64_t *__restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Persistent EM (opt-in, HGX_EM_PERSIST=1; see the measurement note in hgx_em).  With the table-lookup mat-vec a whole
+// SQUAREM iteration is ~50 us of work spread over eight launches.  k_em_persist keeps one workgroup per CU resident and runs
+// `n_iters` complete iterations (and optionally the initial estimate) in ONE launch:
+//   * the six mat-vec passes of an iteration are the same (slab, chunk) work items as k_lutmatvec, dealt round-robin
+//     to the resident workgroups; the last workgroup of a row chunk still adds the slab partials;
+//   * passes are separated by a device-wide barrier: one device-scope atomic per workgroup and a bounded spin
+//     (abort flag instead of a hang if the grid is ever not co-resident);
+//   * the vector steps (normalisation totals, SQUAREM extrapolation, prob_diff, pruning) are done by the workgroups
+//     that own an allele chunk, through per-chunk partial sums in memory, added in chunk order by everyone;
+//   * every value that crosses workgroups is written and read with device-scope (L2-bypassing) accesses;
+//     "allele not in the dict" is encoded as -1 in the vectors, so there are no separate presence arrays.
+// ------------------------------------------------------------------------------------------------------------
+struct PkArgs {
+    const uint64_t *Mr, *Mc;          // word-transposed matrices [w64c][Cp], [c64][A]
+    int C, Cp, A;                     // classes, padded classes, compact padded alleles
+    int nsr, ncr, nsc, ncc;           // slabs / row chunks of the rows pass and of the cols pass
+    const int64_t *count;
+    const double *len;
+    double *p, *q1, *q2, *q3, *wc, *part, *ctot, *red, *scal;
+    unsigned *chunk_cnt, *bar;
+    int *abort_flag;
+    int remove_low, n_iters, do_init;
+};
+
+__device__ __forceinline__ double pk_ld(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void pk_st(double *p, double v) {
+    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// own stores complete (they are write-through device-scope stores) before anything that follows
+__device__ __forceinline__ void pk_flush() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+constexpr long PK_SPIN_LIMIT = 400000;      // ~0.5 s: a lost workgroup becomes an error code, never a hung GPU
+
+// returns true if the launch must be abandoned
+__device__ __forceinline__ bool pk_barrier(const PkArgs &a, unsigned &target, int *s_abort) {
+    pk_flush();
+    __syncthreads();
+    target += gridDim.x;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long spins = 0;
+        int ab = 0;
+        while ((int)(__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(4);
+            ++spins;
+            if (spins > PK_SPIN_LIMIT) { __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ab = 1; break; }
+            if ((spins & 255) == 0 && __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
+        }
+        *s_abort = ab;
+    }
+    __syncthreads();
+    return *s_abort != 0;
+}
+
+// 256 subset sums of each of the 64 groups of xs[] (see k_lutmatvec)
+__device__ __forceinline__ void lut_build(const double *xs, double *T, int tid) {
+    const int g = tid >> 4, lo = tid & 15;
+    const double x0 = xs[8 * g], x1 = xs[8 * g + 1], x2 = xs[8 * g + 2], x3 = xs[8 * g + 3];
+    const double x4 = xs[8 * g + 4], x5 = xs[8 * g + 5], x6 = xs[8 * g + 6], x7 = xs[8 * g + 7];
+    const double L = (((lo & 1 ? x0 : 0.0) + (lo & 2 ? x1 : 0.0)) + (lo & 4 ? x2 : 0.0)) + (lo & 8 ? x3 : 0.0);
+    double *Tg = T + g * 256 + lo;
+#pragma unroll
+    for (int hi = 0; hi < 16; ++hi) {
+        const double H = (((hi & 1 ? x4 : 0.0) + (hi & 2 ? x5 : 0.0)) + (hi & 4 ? x6 : 0.0)) + (hi & 8 ? x7 : 0.0);
+        Tg[hi * 16] = L + H;
+    }
+}
+__device__ __forceinline__ double lut_row(const double *T, const uint64_t (&w)[8]) {
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (__ballot(w[i] != 0ull) == 0ull) continue;
+        const uint32_t wl = (uint32_t)w[i], wh = (uint32_t)(w[i] >> 32);
+        const double *Ti = T + i * 8 * 256;
+        acc += Ti[0 * 256 + (wl & 255u)];
+        acc += Ti[1 * 256 + ((wl >> 8) & 255u)];
+        acc += Ti[2 * 256 + ((wl >> 16) & 255u)];
+        acc += Ti[3 * 256 + (wl >> 24)];
+        acc += Ti[4 * 256 + (wh & 255u)];
+        acc += Ti[5 * 256 + ((wh >> 8) & 255u)];
+        acc += Ti[6 * 256 + ((wh >> 16) & 255u)];
+        acc += Ti[7 * 256 + (wh >> 24)];
+    }
+    return acc;
+}
+// slab partials of one row, added in slab order (eight loads in flight)
+__device__ __forceinline__ double pk_sum_part(const double *part, int n_slabs, size_t stride, int n) {
+    double t = 0.0;
+    for (int s0 = 0; s0 < n_slabs; s0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = s0 + k < n_slabs ? pk_ld(&part[(size_t)(s0 + k) * stride + n]) : 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += v[k];
+    }
+    return t;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_em_persist(PkArgs a) {
+    extern __shared__ double lds[];
+    double *T = lds;
+    double *xs = lds + LUT_G * 256;
+    __shared__ double sh[3][NWAVE];
+    __shared__ double shm[NWAVE];
+    __shared__ int is_last, s_abort;
+    const int tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
+    unsigned target = 0;
+    double n_maps = 0.0;
+
+    // this workgroup's ticket for a row chunk: true for the last of the chunk's n_slabs workgroups
+    auto last_of_chunk = [&](int chunk, int n_slabs) -> bool {
+        pk_flush();
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned old = __hip_atomic_fetch_add(&a.chunk_cnt[chunk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            is_last = old == (unsigned)(n_slabs - 1);
+            if (is_last) __hip_atomic_store(&a.chunk_cnt[chunk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        return is_last != 0;
+    };
+    // w_c = n_c / sum_{j in c} x_j   with x = src / scale (absent alleles contribute 0), or all ones (init)
+    auto rows_pass = [&](const double *src, double scale, bool init) {
+        for (int item = b; item < a.nsr * a.ncr; item += G) {
+            const int chunk = item / a.nsr, slab = item % a.nsr;
+            const int n = chunk * BLOCK + tid;
+            uint64_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = n < a.Cp ? a.Mr[(size_t)(slab * 8 + i) * a.Cp + n] : 0ull;
+            double xv = 0.0;
+            if (tid < LUT_SLAB) {
+                const int e = slab * LUT_SLAB + tid;
+                if (e < a.A) {
+                    if (init) xv = 1.0;
+                    else { const double v = pk_ld(src + e); xv = v >= 0.0 ? v / scale : 0.0; }
+                }
+            }
+            __syncthreads();                       // the previous item's lookups are done with T
+            if (tid < LUT_SLAB) xs[tid] = xv;
+            __syncthreads();
+            lut_build(xs, T, tid);
+            __syncthreads();
+            const double acc = lut_row(T, w);
+            if (n < a.Cp) pk_st(&a.part[(size_t)slab * a.Cp + n], acc);
+            if (last_of_chunk(chunk, a.nsr) && n < a.C) {
+                const double t = pk_sum_part(a.part, a.nsr, a.Cp, n);
+                pk_st(&a.wc[n], t > 0.0 ? (double)a.count[n] / t : 0.0);
+            }
+        }
+    };
+    // out_j = x_j * sum_{c containing j} w_c / len_j for alleles in the dict (x = in / in_scale), -1 otherwise
+    auto cols_pass = [&](const double *in, double in_scale, double *out, int slot, bool init) {
+        for (int item = b; item < a.nsc * a.ncc; item += G) {
+            const int chunk = item / a.nsc, slab = item % a.nsc;
+            const int j = chunk * BLOCK + tid;
+            uint64_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] = j < a.A ? a.Mc[(size_t)(slab * 8 + i) * a.A + j] : 0ull;
+            double xv = 0.0;
+            if (tid < LUT_SLAB) {
+                const int e = slab * LUT_SLAB + tid;
+                if (e < a.C) xv = pk_ld(a.wc + e);
+            }
+            __syncthreads();
+            if (tid < LUT_SLAB) xs[tid] = xv;
+            __syncthreads();
+            lut_build(xs, T, tid);
+            __syncthreads();
+            const double acc = lut_row(T, w);
+            if (j < a.A) pk_st(&a.part[(size_t)slab * a.A + j], acc);
+            if (last_of_chunk(chunk, a.nsc)) {
+                double v = -1.0;
+                if (j < a.A) {
+                    const double t = pk_sum_part(a.part, a.nsc, a.A, j);
+                    const double xin = init ? 0.0 : pk_ld(in + j);
+                    if ((init || xin >= 0.0) && t > 0.0) {
+                        v = init ? t : (xin / in_scale) * t;
+                        if (a.len) v = v / a.len[j];
+                    }
+                    pk_st(out + j, v);
+                }
+                double s[1] = {v >= 0.0 ? v : 0.0};
+                block_sum_n<1>(s, sh);
+                if (tid == 0) pk_st(&a.ctot[slot * a.ncc + chunk], s[0]);
+            }
+        }
+        n_maps += 1.0;
+    };
+    auto total = [&](int slot) {
+        double t = 0.0;
+        for (int ch = 0; ch < a.ncc; ++ch) t += pk_ld(&a.ctot[slot * a.ncc + ch]);
+        return t;
+    };
+#define PK_BARRIER() do { if (pk_barrier(a, target, &s_abort)) return; } while (0)
+
+    const int j = b * BLOCK + tid;                   // my allele in the vector steps (workgroups b < ncc)
+    const bool vec_wg = b < a.ncc;
+    int iter = (int)a.scal[S_ITER];
+    if (a.do_init) {                                  // initial estimate (common:1299-1309)
+        rows_pass(nullptr, 1.0, true);
+        PK_BARRIER();
+        cols_pass(nullptr, 1.0, a.p, 0, true);
+        PK_BARRIER();
+        const double tot0 = total(0);
+        if (vec_wg && j < a.A) {
+            const double v = pk_ld(a.p + j);
+            pk_st(a.p + j, v >= 0.0 ? v / tot0 : -1.0);
+        }
+        PK_BARRIER();
+    }
+    bool done = false;
+    double td = 0.0, flag_d = 0.0;
+    for (int it = 0; it < a.n_iters && !done; ++it) {
+        rows_pass(a.p, 1.0, false);
+        PK_BARRIER();
+        cols_pass(a.p, 1.0, a.q1, 0, false);
+        PK_BARRIER();
+        const double tot1 = total(0);
+        rows_pass(a.q1, tot1, false);
+        PK_BARRIER();
+        cols_pass(a.q1, tot1, a.q2, 1, false);
+        PK_BARRIER();
+        const double tot2 = total(1);
+        // SQUAREM (common:1361-1380)
+        double x0 = -1.0, r = 0.0, v = 0.0;
+        if (vec_wg) {
+            double acc[3] = {0.0, 0.0, 0.0};
+            if (j < a.A) {
+                x0 = pk_ld(a.p + j);
+                if (x0 >= 0.0) {
+                    const double x1 = pk_ld(a.q1 + j), x2 = pk_ld(a.q2 + j);
+                    if (x1 < 0.0 || x2 < 0.0) acc[2] = 1.0;
+                    else {
+                        const double p1 = x1 / tot1, p2 = x2 / tot2;
+                        r = p1 - x0;
+                        v = p2 - p1 - r;
+                        acc[0] = r * r;
+                        acc[1] = v * v;
+                    }
+                }
+            }
+            block_sum_n<3>(acc, sh);
+            if (tid == 0) { pk_st(&a.red[b * 4 + 0], acc[0]); pk_st(&a.red[b * 4 + 1], acc[1]); pk_st(&a.red[b * 4 + 2], acc[2]); }
+        }
+        PK_BARRIER();
+        double sr = 0.0, sv = 0.0, key = 0.0;
+        for (int ch = 0; ch < a.ncc; ++ch) { sr += pk_ld(&a.red[ch * 4 + 0]); sv += pk_ld(&a.red[ch * 4 + 1]); key += pk_ld(&a.red[ch * 4 + 2]); }
+        if (key != 0.0) {                             // the reference raises KeyError here (quirk Q6)
+            if (b == 0 && tid == 0) { a.scal[S_KEYERR] = 1.0; a.scal[S_DONE] = 1.0; a.scal[S_ITER] = (double)iter; }
+            return;
+        }
+        const bool ext = sv > 0.0;
+        double tot3 = 1.0;
+        if (ext) {
+            const double g = -sqrt(sr / sv);
+            if (vec_wg && j < a.A && x0 >= 0.0) pk_st(a.q2 + j, fmax(0.0, x0 - 2 * g * r + g * g * v));
+            PK_BARRIER();
+            rows_pass(a.q2, 1.0, false);
+            PK_BARRIER();
+            cols_pass(a.q2, 1.0, a.q3, 2, false);
+            PK_BARRIER();
+            tot3 = total(2);
+        }
+        // prob_diff (common:1272-1279), pruning (common:1338-1346), stopping rule (common:1351)
+        const double *qn = ext ? a.q3 : a.q1;
+        const double totn = ext ? tot3 : tot1;
+        double pn = 0.0;
+        bool an = false;
+        if (vec_wg) {
+            double d[1] = {0.0}, mx = 0.0;
+            if (j < a.A) {
+                const double xn = pk_ld(qn + j);
+                an = xn >= 0.0;
+                pn = an ? xn / totn : 0.0;
+                if (x0 >= 0.0) d[0] = an ? fabs(x0 - pn) : x0;
+                if (an) mx = pn;
+            }
+            const double tm_wg = block_max(mx, shm);
+            block_sum_n<1>(d, sh);
+            if (tid == 0) { pk_st(&a.red[b * 4 + 0], d[0]); pk_st(&a.red[b * 4 + 1], tm_wg); }
+        }
+        PK_BARRIER();
+        td = 0.0;
+        double tm = 0.0;
+        for (int ch = 0; ch < a.ncc; ++ch) { td += pk_ld(&a.red[ch * 4 + 0]); tm = fmax(tm, pk_ld(&a.red[ch * 4 + 1])); }
+        const bool prune = a.remove_low && iter >= 10;
+        if (vec_wg) {
+            bool keep = an;
+            if (prune && keep) keep = pn >= tm / 10.0;
+            if (j < a.A) pk_st(a.p + j, keep ? pn : -1.0);
+            double kept[1] = {keep ? 1.0 : 0.0};
+            block_sum_n<1>(kept, sh);
+            if (tid == 0) pk_st(&a.red[b * 4 + 3], kept[0]);
+        }
+        iter += 1;
+        flag_d = ext ? 1.0 : 0.0;
+        done = !(td > 0.0001) || iter >= 1000;
+        PK_BARRIER();
+    }
+    if (b == 0 && tid == 0) {
+        double kept = 0.0;
+        for (int ch = 0; ch < a.ncc; ++ch) kept += pk_ld(&a.red[ch * 4 + 3]);
+        a.scal[S_NPRES] = kept;
+        a.scal[S_DIFF] = td;
+        a.scal[S_FLAG] = flag_d;
+        a.scal[S_ITER] = (double)iter;
+        a.scal[S_DONE] = done ? 1.0 : 0.0;
+        a.scal[S_NROWS] += n_maps;
+        a.scal[S_NCOLS] += n_maps;
+    }
+#undef PK_BARRIER
+}
+
+// (p with -1 for absent) <-> (p, presence bytes) for the kernels that finish or take over the EM
+__global__ void k_pk_unpack(const double *__restrict__ packed, int n, double *__restrict__ p, uint8_t *__restrict__ pres) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = packed[i];
+    pres[i] = v >= 0.0 ? 1 : 0;
+    p[i] = v >= 0.0 ? v : 0.0;
+}
+
 // u64-element transpose: out[c][r] = in[r][c]  (in [n_rows][n_cols])
 __global__ __launch_bounds__(256) void k_word_transpose(const uint64_t *__restrict__ in, int n_rows, int n_cols,
                                                         uint64_t *__restrict__ out) {
@@ -1700,6 +2027,111 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         HIPCHK(hipMemsetAsync(b_cnt.p, 0, n_cnt * 4, st));
         rows.M = c->d_wrow; rows.n_pad = Cp; rows.part = b_part.as<double>(); rows.counters = b_cnt.as<unsigned>();
         cols.M = c->d_wcol; cols.n_pad = A; cols.part = b_part.as<double>(); cols.counters = b_cnt.as<unsigned>();
+    }
+    if (rows.M && getenv("HGX_EM_PERSIST")) {
+        // ---- persistent path: whole iterations per launch (k_em_persist).  Opt-in: measured on MI355X it is not faster
+        // than one launch per pass (a device-wide barrier across the 8 XCDs costs about what a kernel boundary costs,
+        // ~5-8 us, and an iteration needs 10 of them plus 6 chunk tickets): 124 us vs 125 us per iteration. ----------
+        static int n_cu = 0, occ = 0;
+        if (!n_cu) {
+            int dev = 0;
+            HIPCHK(hipGetDevice(&dev));
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, dev));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_persist), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LUT_LDS));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_em_persist, BLOCK, LUT_LDS));
+            n_cu = prop.multiProcessorCount;
+        }
+        PkArgs a;
+        a.Mr = rows.M; a.Mc = cols.M; a.C = C; a.Cp = c->c64 * 64; a.A = A;
+        a.nsr = w64c / 8; a.ncr = (C + BLOCK - 1) / BLOCK; a.nsc = c->c64 / 8; a.ncc = (A + BLOCK - 1) / BLOCK;
+        const int items = std::max(a.nsr * a.ncr, a.nsc * a.ncc);
+        const int G = std::min(items, std::max(1, occ) * n_cu);
+        if (occ >= 1 && G >= a.ncc) {
+            DevBuf b_aux, b_sync;
+            ALLOC(b_aux, (size_t)(7 * a.ncc) * 8); ALLOC(b_sync, 16);
+            HIPCHK(hipMemsetAsync(b_sync.p, 0, 16, st));
+            a.count = c->d_count; a.len = d_len;
+            a.p = p; a.q1 = q1; a.q2 = q2; a.q3 = q3; a.wc = wc; a.part = rows.part;
+            a.ctot = b_aux.as<double>(); a.red = b_aux.as<double>() + 3 * a.ncc; a.scal = scal;
+            a.chunk_cnt = rows.counters; a.bar = b_sync.as<unsigned>(); a.abort_flag = (int *)(b_sync.as<unsigned>() + 1);
+            a.remove_low = remove_low ? 1 : 0;
+            const int64_t pair_bytes = ((int64_t)C * w64c * 8 + (int64_t)A * 8 + (int64_t)C * 16) +
+                                       ((int64_t)A * c->c64 * 8 + (int64_t)C * 8 + (int64_t)A * 24);
+            double h_scal[S_N];
+            int h_sync[4] = {0, 0, 0, 0};
+            bool first = true, tail_done = false;
+            double tail_failed_at = 1e300;
+            const bool use_tail = !getenv("HGX_EM_NO_TAIL");
+            std::vector<Timed> timed;
+            double *pu = nullptr;
+            DevBuf b_pu;
+            ALLOC(b_pu, A * 8);
+            pu = b_pu.as<double>();
+            for (;;) {
+                a.do_init = first ? 1 : 0;
+                a.n_iters = (first && use_tail && remove_low) ? 11 : 4;     // pruning starts at iteration 10: look at the survivors
+                first = false;
+                if (g_timing) {
+                    Timed t;
+                    t.a = pool_event(); t.b = pool_event(); t.slot = 0;
+                    (void)hipEventRecord(t.a, st);
+                    timed.push_back(t);
+                }
+                HIPCHK(hipMemsetAsync(b_sync.p, 0, 4, st));          // the barrier counter starts at 0 in every launch
+                hipLaunchKernelGGL(k_em_persist, dim3(G), dim3(BLOCK), LUT_LDS, st, a);
+                if (g_timing) (void)hipEventRecord(timed.back().b, st);
+                HIPCHK(hipGetLastError());
+                HIPCHK(hipMemcpyAsync(h_scal, scal, S_N * 8, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipMemcpyAsync(h_sync, b_sync.p, 16, hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                if (h_sync[1] != 0) {
+                    hgx_set_error("persistent EM: device-wide barrier timed out (grid of %d workgroups not co-resident?)", G);
+                    return HGX_EHIP;
+                }
+                if (h_scal[S_DONE] != 0.0) break;
+                if (use_tail && h_scal[S_NPRES] <= 64.0 && h_scal[S_NPRES] < tail_failed_at) {
+                    hipLaunchKernelGGL(k_pk_unpack, dim3(nblk(A, 256)), dim3(256), 0, st, p, A, pu, pr);
+                    hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsC, C, w64c, A, c->d_count, pu, pr, d_len,
+                                       remove_low ? 1 : 0, b_out.as<double>(), scal);
+                    const double maps_ran = h_scal[S_NROWS];
+                    HIPCHK(hipMemcpyAsync(h_scal, scal, S_N * 8, hipMemcpyDeviceToHost, st));
+                    HIPCHK(hipStreamSynchronize(st));
+                    h_scal[S_NROWS] = maps_ran;
+                    if (h_scal[S_TAIL] == 1.0) { tail_done = true; break; }
+                    tail_failed_at = h_scal[S_NPRES];
+                }
+            }
+            if (g_timing) {
+                for (auto &t : timed) {
+                    float ms = 0.f;
+                    (void)hipEventElapsedTime(&ms, t.a, t.b);
+                    g_stats[0].ms += ms;
+                    g_stats[0].launches += 1;
+                    g_event_pool.push_back(t.a);
+                    g_event_pool.push_back(t.b);
+                }
+                g_stats[0].executed += (int64_t)h_scal[S_NROWS];
+                g_stats[0].bytes += (int64_t)h_scal[S_NROWS] * pair_bytes;
+            }
+            if (h_scal[S_KEYERR] != 0.0) {
+                hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
+                return HGX_EKEY;
+            }
+            if (!tail_done) {
+                hipLaunchKernelGGL(k_pk_unpack, dim3(nblk(A, 256)), dim3(256), 0, st, p, A, pu, pr);
+                hipLaunchKernelGGL(k_em_finish, dim3(1), dim3(BLOCK), 0, st, pu, pr, d_len, A, remove_low ? 1 : 0, b_out.as<double>());
+            }
+            HIPCHK(hipGetLastError());
+            std::vector<double> out(A);
+            HIPCHK(hipMemcpyAsync(out.data(), b_out.p, A * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int al = 0; al < n_alleles; ++al) prob_host[al] = -1.0;
+            for (int jj = 0; jj < c->n_act; ++jj) if (c->h_act[jj] < n_alleles) prob_host[c->h_act[jj]] = out[jj];
+            if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
+            return HGX_OK;
+        }
     }
     std::vector<Timed> timed;
     const int slot_rows = A <= 8 * BLOCK ? 0 : 1, slot_cols = C <= 8 * BLOCK ? 2 : 3;

@@ -354,11 +354,17 @@ def test_em_backends_agree(orc, name):
             ln = pl.allele_len if use_len else None
             engine.em_set_backend(1)
             p1, it1 = cl.em(A, low, ln)
-            for backend in (2, 3):                      # int8 MFMA, table lookup
+            import os
+            for backend, persist in ((2, False), (3, False), (3, True)):   # int8 MFMA; table lookup: one launch per pass / persistent kernel
                 engine.em_set_backend(backend)
-                p2, it2 = cl.em(A, low, ln)
-                assert it1 == it2, (backend, it1, it2)
+                if persist:
+                    os.environ["HGX_EM_PERSIST"] = "1"
+                try:
+                    p2, it2 = cl.em(A, low, ln)
+                finally:
+                    os.environ.pop("HGX_EM_PERSIST", None)
+                assert it1 == it2, (backend, persist, it1, it2)
                 assert np.array_equal(p1 < 0, p2 < 0)
-                assert np.max(np.abs(p1 - p2)) <= 1e-11, (backend, np.max(np.abs(p1 - p2)))
+                assert np.max(np.abs(p1 - p2)) <= 1e-11, (backend, persist, np.max(np.abs(p1 - p2)))
     finally:
         engine.em_set_backend(0)
