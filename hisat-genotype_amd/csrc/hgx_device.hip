@@ -356,9 +356,9 @@ extern "C" int hgx_piece_compat(const hgx_index *ix, const hgx_piece *pieces, co
 // which leaves exactly {a : count[a] == max count} -- add_stat's class (core:1177-1190) -- without
 // ever materialising a count.
 // ------------------------------------------------------------------------------------------------
-#define NP 8
+// NP = number of counter planes: 2 when the pair has <= 3 refs (nearly every pair), 4 up to 15, 8 up to 255
 // arg-max set of the bit-sliced counters under the level mask, its row hash, and the stores
-template <int KW>
+template <int KW, int NP>
 __device__ __forceinline__ void emit_class(const uint64_t (&plane)[NP][KW], int w64, const uint64_t *__restrict__ mask,
                                            uint64_t *__restrict__ out_row, uint64_t *__restrict__ out_hash, int lane) {
     uint64_t cand[KW];
@@ -392,7 +392,7 @@ __device__ __forceinline__ void emit_class(const uint64_t (&plane)[NP][KW], int 
     }
 }
 
-template <int KW>
+template <int KW, int NP>
 __device__ __forceinline__ void class_for_level(const uint64_t *__restrict__ compat, int w64, const uint32_t *__restrict__ refs,
                                                 int r0, int r1, uint32_t level, const uint64_t *__restrict__ mask,
                                                 uint64_t *__restrict__ out_row, uint64_t *__restrict__ out_hash, int lane) {
@@ -432,7 +432,7 @@ __device__ __forceinline__ void class_for_level(const uint64_t *__restrict__ com
         for (int s = 0; s < KW; ++s) cur[s] = nxt[s];
         r = rn;
     }
-    emit_class<KW>(plane, w64, mask, out_row, out_hash, lane);
+    emit_class<KW, NP>(plane, w64, mask, out_row, out_hash, lane);
 }
 
 template <int KW>
@@ -447,12 +447,21 @@ __global__ __launch_bounds__(256) void k_pair_classes(const uint64_t *__restrict
     if (pair >= n_pairs) return;
     const int r0 = __builtin_amdgcn_readfirstlane(pair_off[pair]);
     const int r1 = __builtin_amdgcn_readfirstlane(pair_off[pair + 1]);
-    if (exon_bits || exon_hash)
-        class_for_level<KW>(compat, w64, refs, r0, r1, 0u, exon_mask, exon_bits ? exon_bits + (size_t)pair * w64 : nullptr,
-                            exon_hash ? exon_hash + pair : nullptr, lane);
-    if (gene_bits || gene_hash)
-        class_for_level<KW>(compat, w64, refs, r0, r1, 1u, gene_mask, gene_bits ? gene_bits + (size_t)pair * w64 : nullptr,
-                            gene_hash ? gene_hash + pair : nullptr, lane);
+    // counts never exceed the pair's number of refs: pick the narrowest counter that holds it (wave-uniform)
+    const int n_refs = r1 - r0;
+#define HGX_LEVELS(NP_)                                                                                                          \
+    do {                                                                                                                         \
+        if (exon_bits || exon_hash)                                                                                              \
+            class_for_level<KW, NP_>(compat, w64, refs, r0, r1, 0u, exon_mask, exon_bits ? exon_bits + (size_t)pair * w64 : nullptr, \
+                                     exon_hash ? exon_hash + pair : nullptr, lane);                                              \
+        if (gene_bits || gene_hash)                                                                                              \
+            class_for_level<KW, NP_>(compat, w64, refs, r0, r1, 1u, gene_mask, gene_bits ? gene_bits + (size_t)pair * w64 : nullptr, \
+                                     gene_hash ? gene_hash + pair : nullptr, lane);                                              \
+    } while (0)
+    if (n_refs <= 3) HGX_LEVELS(2);
+    else if (n_refs <= 15) HGX_LEVELS(4);
+    else HGX_LEVELS(8);
+#undef HGX_LEVELS
 }
 
 extern "C" int hgx_pair_classes(const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off, const uint32_t *refs,
