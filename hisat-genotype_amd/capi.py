@@ -48,7 +48,7 @@ class ParseOpts(C.Structure):
 SYMBOLS = [
     "hgx_last_error", "hgx_version", "hgx_device_count", "hgx_set_device", "hgx_dev_alloc", "hgx_dev_free",
     "hgx_memcpy_h2d", "hgx_memcpy_d2h", "hgx_memset", "hgx_stream_sync", "hgx_stream_create", "hgx_stream_destroy", "hgx_pool_trim", "hgx_event_create", "hgx_event_destroy",
-    "hgx_event_record", "hgx_event_elapsed_ms", "hgx_a_pad", "hgx_index_create",
+    "hgx_event_record", "hgx_stream_wait_event", "hgx_event_elapsed_ms", "hgx_a_pad", "hgx_index_create",
     "hgx_index_destroy", "hgx_index_dims", "hgx_index_device_bits", "hgx_piece_compat", "hgx_pair_classes",
     "hgx_score_pairs", "hgx_dedup_classes", "hgx_classes_destroy", "hgx_classes_dims", "hgx_classes_device",
     "hgx_classes_to_host", "hgx_classes_from_host", "hgx_allele_counts", "hgx_allele_counts_on", "hgx_em", "hgx_em_set_backend", "hgx_debug_matvec", "hgx_em_set_timing", "hgx_em_get_timing", "hgx_locus_create",
@@ -177,6 +177,10 @@ class Event:
 
     def record(self, stream=None):
         check(lib().hgx_event_record(self.h, stream))
+
+    def make_wait(self, stream):
+        """Work queued on `stream` from now on waits for this event (device-side dependency, no host sync)."""
+        check(lib().hgx_stream_wait_event(stream, self.h))
 
     def elapsed_ms(self, stop):
         ms = C.c_float(0)

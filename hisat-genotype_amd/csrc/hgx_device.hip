@@ -76,6 +76,7 @@ extern "C" int hgx_event_create(void **ev) {
 }
 extern "C" int hgx_event_destroy(void *ev) { if (ev) HIPCHK(hipEventDestroy((hipEvent_t)ev)); return HGX_OK; }
 extern "C" int hgx_event_record(void *ev, void *st) { HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)st)); return HGX_OK; }
+extern "C" int hgx_stream_wait_event(void *st, void *ev) { HIPCHK(hipStreamWaitEvent((hipStream_t)st, (hipEvent_t)ev, 0)); return HGX_OK; }
 extern "C" int hgx_event_elapsed_ms(void *a, void *b, float *ms) {
     ARGCHK(a && b && ms);
     HIPCHK(hipEventSynchronize((hipEvent_t)b));

@@ -105,6 +105,16 @@ def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discor
     return _type_batch(pl, batch, res, remove_low_abundance_alleles, keep_classes, stream)
 
 
+_tls = threading.local()
+
+
+def _fork_event():
+    ev = getattr(_tls, "fork_event", None)
+    if ev is None:
+        ev = _tls.fork_event = capi.Event()
+    return ev
+
+
 def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dbatch=None, bufs=None, scored=False):
     hla = pl.base_fname == "hla"
     A, names = pl.n_alleles, pl.names
@@ -133,7 +143,11 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
 
     worker = None
     if hla and stream is None and db.n_pairs >= 4096:
-        capi.sync(stream)                                       # class rows are complete before either side reads them
+        # class rows are complete before either side reads them: a device-side dependency, the host keeps running ahead
+        ev = _fork_event()
+        ev.record(stream)
+        ev.make_wait(capi.get_stream(0))
+        ev.make_wait(capi.get_stream(1))
         dev = capi.current_device()
         err = []
 

@@ -65,6 +65,7 @@ int hgx_pool_trim(void);
 int hgx_event_create(void **event);
 int hgx_event_destroy(void *event);
 int hgx_event_record(void *event, void *stream);
+int hgx_stream_wait_event(void *stream, void *event);   /* work queued on `stream` afterwards waits for `event`; no host sync */
 int hgx_event_elapsed_ms(void *start_event, void *stop_event, float *ms);   /* synchronises on stop */
 
 /* ---- 8a-0: packed locus index ---------------------------------------------------------
