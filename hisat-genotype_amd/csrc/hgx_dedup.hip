@@ -145,6 +145,164 @@ __global__ __launch_bounds__(256) void k_gather_rows(const uint64_t *__restrict_
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Hash-table form of the dedup (default).  Sorting 500 k 64-bit keys costs ~25 short library launches; the dict
+// semantics the reference needs -- {class: count} in first-seen order -- fall out of one insert pass:
+//   k_ht_insert   a workgroup of 1024 rows first merges equal keys in an LDS table (min row, summed weight; the hot
+//                 classes hold a fifth of all rows, so un-merged global atomics would serialise on a few addresses),
+//                 then one global insert (CAS on the key, min on the first row, add on the count) per distinct key;
+//   k_ht_mark     flags the first row of every class; an exclusive scan of the flags over the ROWS is the class id in
+//                 first-seen order (= Python dict order);
+//   k_ht_finalize class id -> first row, count;   k_verify_ht: exact check of every row against its class' first row
+//                 (streaming, original order);   k_ht_gather: class rows.
+// min / add / CAS are order independent, so the result is deterministic.
+// ------------------------------------------------------------------------------------------------
+#define HT_LDS_SLOTS 2048
+#define HT_NONE 0xFFFFFFFFu
+
+__device__ __forceinline__ uint32_t ht_global_insert(unsigned long long *keys, uint32_t tmask, uint64_t key) {
+    uint32_t h = (uint32_t)key & tmask;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&keys[h], (unsigned long long)HGX_EMPTY_KEY, (unsigned long long)key);
+        if (old == HGX_EMPTY_KEY || old == key) return h;
+        h = (h + 1) & tmask;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_ht_insert(const uint64_t *__restrict__ hash, const int64_t *__restrict__ weight, long n,
+                                                    unsigned long long *__restrict__ keys, uint32_t *__restrict__ first,
+                                                    unsigned long long *__restrict__ cnt, uint32_t tmask,
+                                                    uint32_t *__restrict__ slot_of) {
+    __shared__ unsigned long long lkey[HT_LDS_SLOTS], lcnt[HT_LDS_SLOTS];
+    __shared__ uint32_t lmin[HT_LDS_SLOTS], lg[HT_LDS_SLOTS];
+    const int tid = threadIdx.x;
+    for (int s = tid; s < HT_LDS_SLOTS; s += 1024) { lkey[s] = HGX_EMPTY_KEY; lcnt[s] = 0; lmin[s] = HT_NONE; }
+    __syncthreads();
+    const long i = (long)blockIdx.x * 1024 + tid;
+    const uint64_t key = i < n ? hash[i] : HGX_EMPTY_KEY;
+    const bool valid = key != HGX_EMPTY_KEY;
+    uint32_t ls = 0;
+    if (valid) {
+        ls = (uint32_t)(key >> 40) & (HT_LDS_SLOTS - 1);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&lkey[ls], (unsigned long long)HGX_EMPTY_KEY, (unsigned long long)key);
+            if (old == HGX_EMPTY_KEY || old == key) break;
+            ls = (ls + 1) & (HT_LDS_SLOTS - 1);
+        }
+        atomicMin(&lmin[ls], (uint32_t)i);
+        atomicAdd(&lcnt[ls], (unsigned long long)(weight ? weight[i] : 1));
+    }
+    __syncthreads();
+    for (int s = tid; s < HT_LDS_SLOTS; s += 1024) {
+        if (lkey[s] != HGX_EMPTY_KEY) {
+            const uint32_t g = ht_global_insert(keys, tmask, lkey[s]);
+            atomicMin(&first[g], lmin[s]);
+            atomicAdd(&cnt[g], lcnt[s]);
+            lg[s] = g;
+        }
+    }
+    __syncthreads();
+    if (i < n) slot_of[i] = valid ? lg[ls] : HT_NONE;
+}
+__global__ void k_ht_mark(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ first, long T,
+                          uint32_t *__restrict__ is_first) {
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < T && keys[s] != HGX_EMPTY_KEY) is_first[first[s]] = 1u;
+}
+__global__ void k_ht_finalize(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ first,
+                              const unsigned long long *__restrict__ cnt, long T, const uint32_t *__restrict__ rank,
+                              int64_t *__restrict__ out_first, int64_t *__restrict__ out_count) {
+    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= T || keys[s] == HGX_EMPTY_KEY) return;
+    const uint32_t c = rank[first[s]];
+    out_first[c] = (int64_t)first[s];
+    out_count[c] = (int64_t)cnt[s];
+}
+__global__ __launch_bounds__(256) void k_verify_ht(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
+                                                   const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ first, long n,
+                                                   int *__restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const long r = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (r >= n) return;
+    const uint32_t sl = slot_of[r];
+    if (sl == HT_NONE) return;
+    const uint32_t h = first[sl];
+    if (h == (uint32_t)r) return;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 *a = (const u64x2 *)(rows + (size_t)r * w64);
+    const u64x2 *b = (const u64x2 *)(rows + (size_t)h * w64);
+    const u64x2 *m = (const u64x2 *)mask;
+    bool diff = false;
+    for (int w = lane; w < w64 / 2; w += 64) {
+        u64x2 x = a[w], y = b[w];
+        if (mask) { x &= m[w]; y &= m[w]; }
+        diff = diff || x.x != y.x || x.y != y.y;
+    }
+    if (__any(diff) && lane == 0) atomicOr(bad, 1);
+}
+__global__ __launch_bounds__(256) void k_ht_gather(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
+                                                   const int64_t *__restrict__ out_first, int n_classes,
+                                                   uint64_t *__restrict__ out_bits) {
+    const int lane = threadIdx.x & 63;
+    const long c = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (c >= n_classes) return;
+    const uint64_t *src = rows + (size_t)out_first[c] * w64;
+    for (int w = lane; w < w64; w += 64) {
+        uint64_t x = src[w];
+        if (mask) x &= mask[w];
+        out_bits[(size_t)c * w64 + w] = x;
+    }
+}
+__global__ void k_ht_meta(const uint32_t *last_rank, const uint32_t *last_flag, uint32_t *meta) { meta[1] = *last_rank + *last_flag; }
+
+static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_t *keys_in, const int64_t *row_weight, long n,
+                            int w64, const uint64_t *and_mask, hipStream_t st) {
+    long T = 1024;
+    while (T < 2 * n) T <<= 1;
+    DevBuf b_keys, b_first, b_cnt, b_slot, b_flag, b_rank, b_tmp, b_meta;
+    ALLOC(b_keys, (size_t)T * 8); ALLOC(b_first, (size_t)T * 4); ALLOC(b_cnt, (size_t)T * 8);
+    ALLOC(b_slot, (size_t)n * 4); ALLOC(b_flag, (size_t)n * 4); ALLOC(b_rank, (size_t)n * 4); ALLOC(b_meta, 16);
+    size_t tmp_bytes = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
+    ALLOC(b_tmp, tmp_bytes);
+    HIPCHK(hipMemsetAsync(b_keys.p, 0xFF, (size_t)T * 8, st));
+    HIPCHK(hipMemsetAsync(b_first.p, 0xFF, (size_t)T * 4, st));
+    HIPCHK(hipMemsetAsync(b_cnt.p, 0, (size_t)T * 8, st));
+    HIPCHK(hipMemsetAsync(b_flag.p, 0, (size_t)n * 4, st));
+    HIPCHK(hipMemsetAsync(b_meta.p, 0, 16, st));                 // [0] collision flag, [1] number of classes
+    hipLaunchKernelGGL(k_ht_insert, dim3(nblk(n, 1024)), dim3(1024), 0, st, keys_in, row_weight, n, b_keys.as<unsigned long long>(),
+                       b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1), b_slot.as<uint32_t>());
+    hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,
+                       b_flag.as<uint32_t>());
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
+    hipLaunchKernelGGL(k_ht_meta, dim3(1), dim3(1), 0, st, b_rank.as<uint32_t>() + (n - 1), b_flag.as<uint32_t>() + (n - 1),
+                       b_meta.as<uint32_t>());
+    // the exact check does not need the class count: queue it before the one D2H that sizes the output
+    hipLaunchKernelGGL(k_verify_ht, dim3(nblk(n, 4)), dim3(256), 0, st, rows, w64, and_mask, b_slot.as<uint32_t>(),
+                       b_first.as<uint32_t>(), n, b_meta.as<int>());
+    uint32_t meta[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(meta, b_meta.p, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipGetLastError());
+    if (meta[0]) {
+        hgx_set_error("64-bit class hash collision detected by the exact verify pass");
+        return HGX_ECOLLISION;
+    }
+    const int n_runs = (int)meta[1];
+    if (n_runs == 0) return HGX_OK;
+    cl->d_bits = (decltype(cl->d_bits))hgx_pool_alloc((size_t)n_runs * w64 * 8);
+    cl->d_count = (decltype(cl->d_count))hgx_pool_alloc((size_t)n_runs * 8);
+    cl->d_first_row = (decltype(cl->d_first_row))hgx_pool_alloc((size_t)n_runs * 8);
+    if (!cl->d_bits || !cl->d_count || !cl->d_first_row) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    hipLaunchKernelGGL(k_ht_finalize, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(),
+                       b_cnt.as<unsigned long long>(), T, b_rank.as<uint32_t>(), cl->d_first_row, cl->d_count);
+    hipLaunchKernelGGL(k_ht_gather, dim3(nblk(n_runs, 4)), dim3(256), 0, st, rows, w64, and_mask, cl->d_first_row, n_runs, cl->d_bits);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));      // the scratch buffers above go back to the pool on return
+    cl->n_classes = n_runs;
+    return HGX_OK;
+}
+
 extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const uint64_t *row_hash, const int64_t *row_weight,
                                  int64_t n_rows, int32_t a_pad, const uint64_t *and_mask, void *stream) {
     ARGCHK(out && n_rows >= 0 && a_pad > 0 && a_pad % 512 == 0);
@@ -165,6 +323,8 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
         hipLaunchKernelGGL(k_hash_rows, dim3(nblk(n, 4)), dim3(256), 0, st, rows, n, w64, and_mask, b_hash.as<uint64_t>());
         keys_in = b_hash.as<uint64_t>();
     }
+    static const bool sort_path = getenv("HGX_DEDUP_SORT") != nullptr;       // the radix-sort form, kept for comparison
+    if (!sort_path) return dedup_hash_table(cl, rows, keys_in, row_weight, n, w64, and_mask, st);
     ALLOC(b_key, n * 8); ALLOC(b_idx0, n * 4); ALLOC(b_idx, n * 4); ALLOC(b_head, n * 4); ALLOC(b_cls, n * 4); ALLOC(b_bad, 16);
     hipLaunchKernelGGL(k_iota, dim3(nblk(n, 256)), dim3(256), 0, st, b_idx0.as<uint32_t>(), n);
     size_t tmp_bytes = 0, t2 = 0;
