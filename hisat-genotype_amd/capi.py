@@ -47,11 +47,11 @@ class ParseOpts(C.Structure):
 # every symbol include/hgx.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "hgx_last_error", "hgx_version", "hgx_device_count", "hgx_set_device", "hgx_dev_alloc", "hgx_dev_free",
-    "hgx_memcpy_h2d", "hgx_memcpy_d2h", "hgx_memset", "hgx_stream_sync", "hgx_stream_create", "hgx_stream_destroy", "hgx_pool_trim", "hgx_event_create", "hgx_event_destroy",
+    "hgx_memcpy_h2d", "hgx_memcpy_d2h", "hgx_memset", "hgx_stream_sync", "hgx_stream_create", "hgx_stream_create_prio", "hgx_stream_destroy", "hgx_pool_trim", "hgx_event_create", "hgx_event_destroy",
     "hgx_event_record", "hgx_stream_wait_event", "hgx_event_elapsed_ms", "hgx_a_pad", "hgx_index_create",
     "hgx_index_destroy", "hgx_index_dims", "hgx_index_device_bits", "hgx_piece_compat", "hgx_pair_classes",
     "hgx_score_pairs", "hgx_dedup_classes", "hgx_classes_destroy", "hgx_classes_dims", "hgx_classes_device",
-    "hgx_classes_to_host", "hgx_classes_from_host", "hgx_allele_counts", "hgx_allele_counts_on", "hgx_em", "hgx_em_set_backend", "hgx_debug_matvec", "hgx_em_set_timing", "hgx_em_get_timing", "hgx_locus_create",
+    "hgx_classes_to_host", "hgx_classes_from_host", "hgx_allele_counts", "hgx_allele_counts_on", "hgx_first_classes", "hgx_em", "hgx_em_set_backend", "hgx_debug_matvec", "hgx_em_set_timing", "hgx_em_get_timing", "hgx_locus_create",
     "hgx_locus_destroy", "hgx_locus_dims", "hgx_locus_tables", "hgx_index_from_locus",
     "hgx_locus_alternatives_text", "hgx_batch_destroy", "hgx_batch_dims", "hgx_batch_arrays",
     "hgx_batch_from_haplotypes", "hgx_parse_sam", "hgx_batch_trace_text", "hgx_batch_pileup",
@@ -114,11 +114,12 @@ def current_device():
 
 
 def get_stream(i):
-    """A cached non-blocking stream of the current device (created on first use)."""
+    """A cached non-blocking stream of the current device (created on first use).  Stream 0 (the EM chain: short
+    dependent launches on the critical path) has the highest priority, stream 1 (overlapped side work) the lowest."""
     key = (_current_device, i)
     if key not in _streams:
         p = C.c_void_p()
-        check(lib().hgx_stream_create(C.byref(p)))
+        check(lib().hgx_stream_create_prio(C.byref(p), C.c_int(1 if i == 0 else 0)))
         _streams[key] = p
     return _streams[key]
 

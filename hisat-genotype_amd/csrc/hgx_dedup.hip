@@ -204,6 +204,13 @@ __global__ __launch_bounds__(1024) void k_ht_insert(const uint64_t *__restrict__
     __syncthreads();
     if (i < n) slot_of[i] = valid ? lg[ls] : HT_NONE;
 }
+__global__ void k_ht_init(unsigned long long *__restrict__ keys, uint32_t *__restrict__ first, unsigned long long *__restrict__ cnt,
+                          long T, uint32_t *__restrict__ flag, long n, uint32_t *__restrict__ meta) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < T) { keys[i] = HGX_EMPTY_KEY; first[i] = HT_NONE; cnt[i] = 0; }
+    if (i < n) flag[i] = 0;
+    if (i < 4) meta[i] = 0;
+}
 __global__ void k_ht_mark(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ first, long T,
                           uint32_t *__restrict__ is_first) {
     const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -265,11 +272,9 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     size_t tmp_bytes = 0;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
     ALLOC(b_tmp, tmp_bytes);
-    HIPCHK(hipMemsetAsync(b_keys.p, 0xFF, (size_t)T * 8, st));
-    HIPCHK(hipMemsetAsync(b_first.p, 0xFF, (size_t)T * 4, st));
-    HIPCHK(hipMemsetAsync(b_cnt.p, 0, (size_t)T * 8, st));
-    HIPCHK(hipMemsetAsync(b_flag.p, 0, (size_t)n * 4, st));
-    HIPCHK(hipMemsetAsync(b_meta.p, 0, 16, st));                 // [0] collision flag, [1] number of classes
+    // one launch instead of five memsets: table = empty, flags = 0, meta = {collision flag, number of classes} = 0
+    hipLaunchKernelGGL(k_ht_init, dim3(nblk(std::max(T, n), 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(),
+                       b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), T, b_flag.as<uint32_t>(), n, b_meta.as<uint32_t>());
     hipLaunchKernelGGL(k_ht_insert, dim3(nblk(n, 1024)), dim3(1024), 0, st, keys_in, row_weight, n, b_keys.as<unsigned long long>(),
                        b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1), b_slot.as<uint32_t>());
     hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,

@@ -66,6 +66,15 @@ extern "C" int hgx_stream_create(void **st) {
     *st = (void *)s;
     return HGX_OK;
 }
+extern "C" int hgx_stream_create_prio(void **st, int high_priority) {
+    ARGCHK(st != nullptr);
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    hipStream_t s;
+    HIPCHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? greatest : least));
+    *st = (void *)s;
+    return HGX_OK;
+}
 extern "C" int hgx_stream_destroy(void *st) { if (st) HIPCHK(hipStreamDestroy((hipStream_t)st)); return HGX_OK; }
 extern "C" int hgx_event_create(void **ev) {
     ARGCHK(ev != nullptr);

@@ -2241,6 +2241,44 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
     return HGX_OK;
 }
 
+// first class containing an allele, for a handful of alleles: one workgroup per allele walks the allele's bit column
+__global__ __launch_bounds__(256) void k_first_classes(const uint64_t *__restrict__ B, int n_classes, int w64,
+                                                       const int32_t *__restrict__ alleles, int32_t *__restrict__ first) {
+    __shared__ int best;
+    const int a = alleles[blockIdx.x];
+    if (threadIdx.x == 0) best = n_classes;
+    __syncthreads();
+    const int word = a >> 6;
+    const uint64_t bit = 1ull << (a & 63);
+    for (int c0 = 0; c0 < n_classes; c0 += 256) {
+        const int c = c0 + threadIdx.x;
+        const bool hit = c < n_classes && (B[(size_t)c * w64 + word] & bit);
+        if (__syncthreads_or(hit)) {
+            if (hit) atomicMin(&best, c);
+            __syncthreads();
+            break;
+        }
+    }
+    if (threadIdx.x == 0) first[blockIdx.x] = best < n_classes ? best : -1;
+}
+
+extern "C" int hgx_first_classes(const hgx_classes *c, const int32_t *alleles_host, int32_t n, int32_t *first_host, void *stream) {
+    ARGCHK(c && n >= 0);
+    if (n == 0) return HGX_OK;
+    ARGCHK(alleles_host && first_host);
+    for (int i = 0; i < n; ++i) ARGCHK(alleles_host[i] >= 0 && alleles_host[i] < c->a_pad);
+    if (c->n_classes == 0) { for (int i = 0; i < n; ++i) first_host[i] = -1; return HGX_OK; }
+    hipStream_t st = (hipStream_t)stream;
+    DevBuf b_a, b_f;
+    ALLOC(b_a, (size_t)n * 4); ALLOC(b_f, (size_t)n * 4);
+    HIPCHK(hipMemcpyAsync(b_a.p, alleles_host, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_first_classes, dim3(n), dim3(256), 0, st, c->d_bits, c->n_classes, c->w64, b_a.as<int32_t>(), b_f.as<int32_t>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(first_host, b_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return HGX_OK;
+}
+
 // Gene_counts (typing_core.py:1187-1190): per allele the summed count of the classes containing it, and the first
 // such class (dict insertion order for ties) -- two passes of the bit mat-vec over the transposed class matrix.
 extern "C" int hgx_allele_counts_on(const hgx_classes *cc, int64_t *count_host, int32_t *first_host, void *stream);

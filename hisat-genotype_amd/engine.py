@@ -92,6 +92,14 @@ class Classes:
         capi.check(capi.lib().hgx_allele_counts_on(self.h, capi.ptr(cnt), capi.ptr(first), stream))
         return cnt, first
 
+    def first_classes(self, alleles, stream=None):
+        """First class (dict order) containing each of a few alleles (-1 if none)."""
+        al = np.ascontiguousarray(alleles, np.int32)
+        out = np.full(len(al), -1, np.int32)
+        if len(al):
+            capi.check(capi.lib().hgx_first_classes(self.h, capi.ptr(al), C.c_int32(len(al)), capi.ptr(out), stream))
+        return out
+
     def em(self, n_alleles, remove_low=False, lengths=None, stream=None):
         """8a-8: single_abundance.  Returns (prob[n_alleles] with -1 for absent alleles, n_iter)."""
         prob = np.zeros(n_alleles, np.float64)

@@ -33,8 +33,14 @@ def _sorted_result(prob, order):
 
 def _em_on_classes(classes, n_alleles, name_rank, remove_low, lengths, stream=None):
     prob, n_iter = classes.em(n_alleles, remove_low, lengths, stream)
-    _, first = classes.allele_counts()
-    order = engine.em_order(first[:n_alleles], name_rank, prob >= 0.0)
+    present = np.nonzero(prob >= 0.0)[0]
+    if len(present) <= 256:
+        # dict insertion order of the survivors (common:1300-1305): first class containing each, then name order
+        fc = classes.first_classes(present, stream)
+        order = present[np.lexsort((np.asarray(name_rank)[present], fc))].tolist()
+    else:
+        _, first = classes.allele_counts(stream)
+        order = engine.em_order(first[:n_alleles], name_rank, prob >= 0.0)
     return _sorted_result(prob, order), n_iter
 
 
@@ -202,8 +208,8 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
             exon_alleles |= set(g)
         if exon_alleles:                                                         # core:1752-1782
             mask = np.zeros(pl.w64, np.uint64)
-            for a in exon_alleles:
-                mask[a >> 6] |= np.uint64(1) << np.uint64(a & 63)
+            ea = np.fromiter(exon_alleles, np.int64, len(exon_alleles))
+            np.bitwise_or.at(mask, ea >> 6, np.uint64(1) << (ea & 63).astype(np.uint64))
             d_mask = capi.DevArray.from_host(mask, stream)
             gb, gc, _ = gcl.device_ptrs()
             g2 = engine.Classes.dedup(engine._RawDev(gb), gcl.n_classes, pl.a_pad, weights=engine._RawDev(gc),

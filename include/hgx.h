@@ -58,6 +58,7 @@ int hgx_memset(void *dev_dst, int value, size_t bytes, void *stream);
 int hgx_stream_sync(void *stream);
 /* non-blocking HIP streams so that independent stages (exon-level EM / gene-level counts) can overlap */
 int hgx_stream_create(void **stream);
+int hgx_stream_create_prio(void **stream, int high_priority);   /* non-blocking stream at the device's highest / lowest priority */
 int hgx_stream_destroy(void *stream);
 /* the library caches device scratch allocations between calls; this returns them to the driver */
 int hgx_pool_trim(void);
@@ -161,6 +162,9 @@ int hgx_classes_from_host(hgx_classes **out, const uint64_t *bits_host, const in
  * (-1 if none) -- that is the dict insertion order used to break count ties.             */
 int hgx_allele_counts(const hgx_classes *c, int64_t *count_host, int32_t *first_class_host);
 int hgx_allele_counts_on(const hgx_classes *c, int64_t *count_host, int32_t *first_class_host, void *stream);
+/* first class (dict order) containing each of a FEW given alleles, -1 if none: the tie order of the EM's result list
+ * (common:1300-1305) without the full Gene_counts pass */
+int hgx_first_classes(const hgx_classes *c, const int32_t *alleles_host, int32_t n, int32_t *first_class_host, void *stream);
 
 /* ---- 8a-8: EM abundance ------------------------------------------------------------------
  * Replaces single_abundance (typing_common.py:1282-1410): SQUAREM-accelerated EM in FP64,
