@@ -40,27 +40,76 @@ def parse_args():
     ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (profiling runs)")
+    ap.add_argument("--inflight", type=int, default=1,
+                    help="samples typed concurrently per GPU (host threads with their own streams and class-row buffers; "
+                         "the EM of one sample is a chain of short launches that leaves the GPU to the scoring of the next)")
     return ap.parse_args()
 
 
-def step(pl, batch, db, bufs, ev=None):
-    """One pass of the hot path.  Returns (LocusResult, seconds spent in the EM calls)."""
+def step(pl, batch, db, bufs, ev=None, stream=None):
+    """One pass of the hot path on `stream` (None = the default stream).  Returns the LocusResult."""
     res = htyping.LocusResult()
     res.num_reads, res.num_pairs = batch.n_reads, batch.n_pairs
     L = capi.lib()
     import ctypes as C
     if ev:
-        ev[2].record()
+        ev[2].record(stream)
     capi.check(L.hgx_piece_compat(pl.index(), capi.ptr(db.pieces), capi.ptr(db.masks), C.c_int32(db.n_pieces),
-                                  capi.ptr(bufs.compat), None))
+                                  capi.ptr(bufs.compat), stream))
     if ev:
-        ev[0].record()
+        ev[0].record(stream)
     capi.check(L.hgx_pair_classes(pl.index(), capi.ptr(bufs.compat), capi.ptr(db.pair_off), capi.ptr(db.pair_ref),
                                   C.c_int32(db.n_pairs), capi.ptr(bufs.exon_bits), capi.ptr(bufs.gene_bits),
-                                  capi.ptr(bufs.exon_hash), capi.ptr(bufs.gene_hash), None))
+                                  capi.ptr(bufs.exon_hash), capi.ptr(bufs.gene_hash), stream))
     if ev:
-        ev[1].record()
-    return htyping._type_batch(pl, batch, res, True, dbatch=db, bufs=bufs, scored=True)
+        ev[1].record(stream)
+    return htyping._type_batch(pl, batch, res, True, dbatch=db, bufs=bufs, scored=True, stream=stream, overlap=True)
+
+
+def run_steps(pl, batch, db, bufs_list, n_steps, ev_list, timing, local_rank):
+    """n_steps passes shared by len(bufs_list) host threads (one sample in flight per thread).  Returns
+    (last LocusResult, EM seconds summed, EM iterations summed, merged per-kernel timing)."""
+    import threading
+    lock = threading.Lock()
+    state = {"next": 0, "t_em": 0.0, "n_iter": 0, "res": None, "timing": {}, "err": None}
+
+    def work(bufs, own_stream):
+        try:
+            capi.set_device(local_rank)
+            stream = capi.get_stream(2) if own_stream else None
+            engine.em_set_timing(timing)
+            while True:
+                with lock:
+                    k = state["next"]
+                    if k >= n_steps:
+                        break
+                    state["next"] = k + 1
+                res = step(pl, batch, db, bufs, ev_list[k] if ev_list else None, stream)
+                with lock:
+                    state["t_em"] += res.t_em
+                    state["n_iter"] += sum(e["n_iter"] for e in res.em)
+                    state["res"] = res
+            capi.sync(stream)
+            if timing:
+                with lock:
+                    for name, v in engine.em_get_timing().items():
+                        acc = state["timing"].setdefault(name, [0.0, 0, 0, 0])
+                        for i in range(4):
+                            acc[i] += v[i]
+        except BaseException as e:     # re-raised on the main thread
+            state["err"] = e
+
+    if len(bufs_list) == 1:
+        work(bufs_list[0], False)
+    else:
+        threads = [threading.Thread(target=work, args=(b, True)) for b in bufs_list]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if state["err"] is not None:
+        raise state["err"]
+    return state["res"], state["t_em"], state["n_iter"], state["timing"]
 
 
 def cpu_baseline(loc, sam, n_pairs):
@@ -129,7 +178,7 @@ def main():
     batch = pl.parse_sam(sam)
     t_parse = time.perf_counter() - t0
     db = engine.DeviceBatch(batch)
-    bufs = engine.ScoreBuffers(pl, db, exon=True)
+    bufs_list = [engine.ScoreBuffers(pl, db, exon=True) for _ in range(max(1, args.inflight))]
     if rank != 0 or args.no_cpu_baseline or use_dist:
         sam_keep = None
     else:
@@ -137,20 +186,14 @@ def main():
     del sam
     t_setup = time.perf_counter() - t_setup
 
-    for _ in range(args.warmup):
-        res = step(pl, batch, db, bufs)
+    run_steps(pl, batch, db, bufs_list, max(args.warmup, len(bufs_list) if args.warmup else 0), None, False, local_rank)
     capi.sync()
     if dist is not None:
         dist.barrier()
     ev = [(capi.Event(), capi.Event(), capi.Event()) for _ in range(args.steps)]
-    engine.em_set_timing(not args.no_kernel_timing)        # HIP events around every EM mat-vec launch of the timed region
-    t_em = 0.0
-    n_em_iter = 0
+    timing = not args.no_kernel_timing                     # HIP events around a sample of the EM mat-vec launches
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        res = step(pl, batch, db, bufs, ev[k])
-        t_em += res.t_em
-        n_em_iter += sum(e["n_iter"] for e in res.em)
+    res, t_em, n_em_iter, em_timing = run_steps(pl, batch, db, bufs_list, args.steps, ev, timing, local_rank)
     capi.sync()
     if dist is not None:
         import torch
@@ -180,7 +223,7 @@ def main():
         cp_ms = sum(e[2].elapsed_ms(e[0]) for e in ev) / len(ev)
         gbs = lambda b, ms: (b / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
         kernels = {}
-        for name, (ms, n, ex, by) in engine.em_get_timing().items():
+        for name, (ms, n, ex, by) in em_timing.items():
             if n:
                 # HIP events bracket a sample (first 8 ungated rows + cols passes of every EM call); the aggregate per
                 # step extrapolates the sample average to every pass that ran (device-side counter)
@@ -224,7 +267,7 @@ def main():
                 "gene_classes_after_handoff": res.em[1]["n_classes"] if len(res.em) > 1 else 0,
                 "em_outer_iterations_per_step": n_em_iter // max(args.steps, 1),
                 "top2": [a for a, _ in res.gene_prob[:2]], "true_alleles": sample,
-                "parallelism": "1 sample per GPU (samples/loci shard, no data-path collective)",
+                "parallelism": "samples/loci shard over GPUs with no data-path collective; %d sample(s) in flight per GPU" % len(bufs_list),
                 "input": "front-end piece batch resident in HBM (host C++ front-end: %.0f reads/s on %d host threads, not timed)" % (
                     batch.n_reads / t_parse, os.cpu_count() or 1),
                 "setup_s": round(t_setup, 1),

@@ -1,6 +1,7 @@
 """ctypes binding of libhgx.so (include/hgx.h).  No fallback: if the library is missing or a
 call fails, an exception is raised."""
 import ctypes as C
+import threading
 import os
 
 import numpy as np
@@ -116,7 +117,7 @@ def current_device():
 def get_stream(i):
     """A cached non-blocking stream of the current device (created on first use).  Stream 0 (the EM chain: short
     dependent launches on the critical path) has the highest priority, stream 1 (overlapped side work) the lowest."""
-    key = (_current_device, i)
+    key = (_current_device, threading.get_ident(), i)        # per host thread: concurrent samples never share a stream
     if key not in _streams:
         p = C.c_void_p()
         check(lib().hgx_stream_create_prio(C.byref(p), C.c_int(1 if i == 0 else 0)))

@@ -1203,45 +1203,6 @@ __global__ __launch_bounds__(BLOCK) void k_em_tail(const uint64_t *__restrict__ 
 // Active-allele compaction.  At the exon level only group representatives occur in classes (core:86-115), so a third
 // or more of the allele columns are all-zero; the EM matrices are restricted to the alleles that occur at all.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_row_any(const uint64_t *__restrict__ BT, int n_rows, int c64, uint8_t *__restrict__ flag) {
-    const int lane = threadIdx.x & 63;
-    const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (row >= n_rows) return;
-    uint64_t o = 0;
-    for (int w = lane; w < c64; w += 64) o |= BT[(size_t)row * c64 + w];
-    const uint64_t any = __ballot(o != 0);
-    if (lane == 0) flag[row] = any ? 1 : 0;
-}
-// ascending ids of the flagged rows (one workgroup; n is a few thousand)
-__global__ __launch_bounds__(BLOCK) void k_compact_ids(const uint8_t *__restrict__ flag, int n, int32_t *__restrict__ act,
-                                                       int32_t *__restrict__ n_act) {
-    __shared__ int wtot[NWAVE];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int per = (n + BLOCK - 1) / BLOCK, lo = tid * per, hi = min(n, lo + per);
-    int cnt = 0;
-    for (int a = lo; a < hi; ++a) cnt += flag[a];
-    int inc = cnt;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
-    }
-    if (lane == 63) wtot[wv] = inc;
-    __syncthreads();
-    int base = 0;
-    for (int i = 0; i < wv; ++i) base += wtot[i];
-    int id = base + inc - cnt;
-    for (int a = lo; a < hi; ++a) if (flag[a]) act[id++] = a;
-    if (tid == BLOCK - 1) *n_act = id;
-}
-__global__ __launch_bounds__(256) void k_gather_rows_T(const uint64_t *__restrict__ BT, int c64, const int32_t *__restrict__ act,
-                                                       int n_act, long total, uint64_t *__restrict__ BTc) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int j = (int)(i / c64), w = (int)(i % c64);
-    BTc[i] = j < n_act ? BT[(size_t)act[j] * c64 + w] : 0ull;
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // Table-lookup form of the bit mat-vec ("four Russians").  The EXEC-masked kernel above spends one vector instruction
 // (plus two scalar ones and a share of a cross-lane reduction) per 64 matrix bits of ONE row; here a lane owns a row
@@ -1845,33 +1806,81 @@ inline hipEvent_t pool_event() {
 // bit-matrix transpose kernel of hgx_dedup.hip: [n_rows][w_in] -> [w_in * 64][w_out]
 __global__ void k_transpose(const uint64_t *bits, int n_classes, int w64, int c64, uint64_t *bitsT);
 
+// OR of all class rows: which alleles occur at all (LDS merge, then one global atomic per word and workgroup)
+__global__ __launch_bounds__(256) void k_col_or(const uint64_t *__restrict__ B, long n_words_total, int w64,
+                                                unsigned long long *__restrict__ mask) {
+    extern __shared__ unsigned long long lm[];
+    for (int w = threadIdx.x; w < w64; w += 256) lm[w] = 0ull;
+    __syncthreads();
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_words_total; i += stride) {
+        const uint64_t x = B[i];
+        if (x) atomicOr(&lm[(int)(i % w64)], (unsigned long long)x);
+    }
+    __syncthreads();
+    for (int w = threadIdx.x; w < w64; w += 256) if (lm[w]) atomicOr(&mask[w], lm[w]);
+}
+// bit transpose [C][w64] -> [a1p][c64] that keeps only the active alleles: row of allele (w, b) = base[w] + rank of b
+// among the active bits of word w.  One wavefront per 64 x 64 tile (cf. k_transpose).
+__global__ __launch_bounds__(256) void k_transpose_compact(const uint64_t *__restrict__ bits, int n_classes, int w64, int c64,
+                                                           const unsigned long long *__restrict__ mask,
+                                                           const int32_t *__restrict__ base, uint64_t *__restrict__ bitsTC) {
+    const int lane = threadIdx.x & 63;
+    const long tile = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long n_tiles = (long)c64 * w64;
+    if (tile >= n_tiles) return;
+    const int cw = (int)(tile / w64), aw = (int)(tile % w64);
+    const uint64_t m = mask[aw];
+    if (m == 0ull) return;
+    const int c = cw * 64 + lane;
+    const uint64_t x = (c < n_classes) ? bits[(size_t)c * w64 + aw] : 0ull;
+    uint64_t mine = 0;
+    for (uint64_t mm = m; mm; mm &= mm - 1) {
+        const int b = __builtin_ctzll(mm);
+        const uint64_t col = __ballot((x >> b) & 1ull);
+        if (lane == b) mine = col;
+    }
+    if ((m >> lane) & 1ull) {
+        const int j = base[aw] + __popcll(m & ((1ull << lane) - 1ull));
+        bitsTC[(size_t)j * c64 + cw] = mine;
+    }
+}
+
 static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
     if (c->n_act >= 0) return HGX_OK;
-    int rc = hgx_ensure_transposed(c, st);
-    if (rc) return rc;
-    const int A = c->a_pad;
-    DevBuf b_flag, b_n;
-    ALLOC(b_flag, A); ALLOC(b_n, 4);
-    c->d_act = (int32_t *)hgx_pool_alloc((size_t)A * 4);
-    if (!c->d_act) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
-    HIPCHK(hipMemsetAsync(c->d_act, 0, (size_t)A * 4, st));
-    hipLaunchKernelGGL(k_row_any, dim3(nblk((long)A * 64, 256)), dim3(256), 0, st, c->d_bitsT, A, c->c64, b_flag.as<uint8_t>());
-    hipLaunchKernelGGL(k_compact_ids, dim3(1), dim3(BLOCK), 0, st, b_flag.as<uint8_t>(), A, c->d_act, b_n.as<int32_t>());
+    const int A = c->a_pad, w64 = c->w64, C = c->n_classes;
+    c->c64 = ((C + 63) / 64 + 7) / 8 * 8;            // row stride of the transposed matrices: multiple of 8 words, zero padded
+    DevBuf b_mask, b_base;
+    ALLOC(b_mask, (size_t)w64 * 8); ALLOC(b_base, (size_t)w64 * 4);
+    HIPCHK(hipMemsetAsync(b_mask.p, 0, (size_t)w64 * 8, st));
+    hipLaunchKernelGGL(k_col_or, dim3(256), dim3(256), (size_t)w64 * 8, st, c->d_bits, (long)C * w64, w64, b_mask.as<unsigned long long>());
     HIPCHK(hipGetLastError());
+    std::vector<uint64_t> h_mask(w64);
+    HIPCHK(hipMemcpyAsync(h_mask.data(), b_mask.p, (size_t)w64 * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<int32_t> h_base(w64);
     c->h_act = new int32_t[A];
     int32_t n = 0;
-    HIPCHK(hipMemcpyAsync(c->h_act, c->d_act, (size_t)A * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(&n, b_n.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    for (int w = 0; w < w64; ++w) {
+        h_base[w] = n;
+        for (uint64_t m = h_mask[w]; m; m &= m - 1) c->h_act[n++] = 64 * w + __builtin_ctzll(m);
+    }
     const int a1p = std::max(512, (n + 511) / 512 * 512);
+    c->d_act = (int32_t *)hgx_pool_alloc((size_t)A * 4);
     c->d_bitsTC = (uint64_t *)hgx_pool_alloc((size_t)a1p * c->c64 * 8);
     c->d_bitsC = (uint64_t *)hgx_pool_alloc((size_t)c->c64 * 64 * (a1p / 64) * 8);
-    if (!c->d_bitsTC || !c->d_bitsC) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
-    const long total = (long)a1p * c->c64;
-    hipLaunchKernelGGL(k_gather_rows_T, dim3(nblk(total, 256)), dim3(256), 0, st, c->d_bitsT, c->c64, c->d_act, n, total, c->d_bitsTC);
+    if (!c->d_act || !c->d_bitsTC || !c->d_bitsC) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    HIPCHK(hipMemcpyAsync(b_base.p, h_base.data(), (size_t)w64 * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(c->d_act, c->h_act, (size_t)std::max(n, 1) * 4, hipMemcpyHostToDevice, st));
+    // padding rows [n, a1p) stay zero
+    HIPCHK(hipMemsetAsync(c->d_bitsTC + (size_t)n * c->c64, 0, (size_t)(a1p - n) * c->c64 * 8, st));
+    const long tiles_in = (long)c->c64 * w64;
+    hipLaunchKernelGGL(k_transpose_compact, dim3(nblk(tiles_in, 4)), dim3(256), 0, st, c->d_bits, C, w64, c->c64,
+                       b_mask.as<unsigned long long>(), b_base.as<int32_t>(), c->d_bitsTC);
     const long tiles = (long)(a1p / 64) * c->c64;
     hipLaunchKernelGGL(k_transpose, dim3(nblk(tiles, 4)), dim3(256), 0, st, c->d_bitsTC, a1p, c->c64, a1p / 64, c->d_bitsC);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));        // b_mask / b_base / the host staging vectors are released on return
     c->a1p = a1p;
     c->n_act = n;
     return HGX_OK;

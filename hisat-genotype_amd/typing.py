@@ -121,7 +121,7 @@ def _fork_event():
     return ev
 
 
-def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dbatch=None, bufs=None, scored=False):
+def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dbatch=None, bufs=None, scored=False, overlap=None):
     hla = pl.base_fname == "hla"
     A, names = pl.n_alleles, pl.names
     db = dbatch if dbatch is not None else engine.DeviceBatch(batch, stream)
@@ -148,19 +148,22 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
         gene.update(gcl=gcl_, counted=counted, cnt=cnt_a)
 
     worker = None
-    if hla and stream is None and db.n_pairs >= 4096:
+    if overlap is None:
+        overlap = stream is None
+    if hla and overlap and db.n_pairs >= 4096:
         # class rows are complete before either side reads them: a device-side dependency, the host keeps running ahead
         ev = _fork_event()
         ev.record(stream)
-        ev.make_wait(capi.get_stream(0))
-        ev.make_wait(capi.get_stream(1))
+        em_stream_, gene_stream_ = capi.get_stream(0), capi.get_stream(1)     # this host thread's pair of side streams
+        ev.make_wait(em_stream_)
+        ev.make_wait(gene_stream_)
         dev = capi.current_device()
         err = []
 
         def run():
             try:
                 capi.set_device(dev)
-                gene_side(capi.get_stream(1))
+                gene_side(gene_stream_)
             except BaseException as e:      # re-raised on the main thread
                 err.append(e)
 
@@ -188,7 +191,7 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
         return out
 
     if hla:
-        em_stream = capi.get_stream(0) if worker is not None else stream
+        em_stream = em_stream_ if worker is not None else stream
         ecl = engine.Classes.dedup(bufs.exon_bits, db.n_pairs, pl.a_pad, hashes=bufs.exon_hash, stream=em_stream)
         if keep_classes:
             res.exon_classes = ecl.to_host()[:2]
