@@ -258,7 +258,9 @@ __global__ __launch_bounds__(256) void k_piece_compat(const uint32_t *__restrict
 #define PT_W 12
 #define PT_PB 256
 #define PT_NW 8
-__global__ __launch_bounds__(1024) void k_piece_compat_tiled(const uint32_t *__restrict__ bits, int a_pad, int n_index_words,
+#define PT_T 512              // threads per workgroup: every thread scores TWO alleles (tid and tid + 512) per piece, so the
+                              // broadcast mask reads, descriptor broadcasts and loop control are paid once per 128 alleles
+__global__ __launch_bounds__(PT_T) void k_piece_compat_tiled(const uint32_t *__restrict__ bits, int a_pad, int n_index_words,
                                                              const hgx_piece *__restrict__ pieces,
                                                              const uint32_t *__restrict__ masks, int n_pieces,
                                                              uint64_t *__restrict__ compat, int w64) {
@@ -271,8 +273,8 @@ __global__ __launch_bounds__(1024) void k_piece_compat_tiled(const uint32_t *__r
     const int chunk = blockIdx.y;
     const int p0 = blockIdx.x * PT_PB;
     const int np = min(PT_PB, n_pieces - p0);
-    {   // stage descriptors and masks: thread = (piece, quarter of its 16 mask words)
-        const int p = tid >> 2, q = tid & 3;
+    for (int t = tid; t < PT_PB * 4; t += PT_T) {   // stage descriptors and masks: t = (piece, quarter of its 16 mask words)
+        const int p = t >> 2, q = t & 3;
         if (p < np) {
             const hgx_piece pc = pieces[p0 + p];
             const int nw2 = 2 * (int)pc.n_words;
@@ -285,21 +287,24 @@ __global__ __launch_bounds__(1024) void k_piece_compat_tiled(const uint32_t *__r
         }
     }
     __syncthreads();
-    const int a = chunk * 1024 + tid;
-    const int wslot = chunk * 16 + wv;            // this wave's 64-allele word of the compat row
+    const int a0 = chunk * 1024 + tid, a1 = a0 + PT_T;
+    const int wslot0 = chunk * 16 + wv, wslot1 = wslot0 + PT_T / 64;   // this wave's two 64-allele words of the compat row
     int cur = 0;
     while (cur < np) {
         if (s_nw[cur] > PT_NW) {
             // a piece wider than the staging area (long deletions / dense variant runs): straight from the index
             const hgx_piece pc = pieces[p0 + cur];
             const uint32_t *m = masks + pc.mask_off;
-            bool ok = true;
+            bool ok0 = true, ok1 = true;
             for (int i = 0; i < (int)pc.n_words; ++i) {
-                const uint32_t r = a < a_pad ? bits[(size_t)(pc.lo_word + i) * a_pad + a] : 0u;
-                ok = ok && ((r & m[2 * i]) == m[2 * i + 1]);
+                const uint32_t r0 = a0 < a_pad ? bits[(size_t)(pc.lo_word + i) * a_pad + a0] : 0u;
+                const uint32_t r1 = a1 < a_pad ? bits[(size_t)(pc.lo_word + i) * a_pad + a1] : 0u;
+                ok0 = ok0 && ((r0 & m[2 * i]) == m[2 * i + 1]);
+                ok1 = ok1 && ((r1 & m[2 * i]) == m[2 * i + 1]);
             }
-            const uint64_t b = __ballot(ok);
-            if (lane == 0 && wslot < w64) compat[(size_t)(p0 + cur) * w64 + wslot] = b;
+            const uint64_t b0 = __ballot(ok0), b1 = __ballot(ok1);
+            if (lane == 0 && wslot0 < w64) compat[(size_t)(p0 + cur) * w64 + wslot0] = b0;
+            if (lane == 0 && wslot1 < w64) compat[(size_t)(p0 + cur) * w64 + wslot1] = b1;
             ++cur;
             continue;
         }
@@ -313,25 +318,54 @@ __global__ __launch_bounds__(1024) void k_piece_compat_tiled(const uint32_t *__r
 #pragma unroll
         for (int i = 0; i < PT_W; ++i) {
             const int w = win_lo + i;
-            tile[i][tid] = (w < n_index_words && a < a_pad) ? bits[(size_t)w * a_pad + a] : 0u;
+            tile[i][tid] = (w < n_index_words && a0 < a_pad) ? bits[(size_t)w * a_pad + a0] : 0u;
+            tile[i][tid + PT_T] = (w < n_index_words && a1 < a_pad) ? bits[(size_t)w * a_pad + a1] : 0u;
         }
         __syncthreads();
         const int end = s_end;
-        for (int b0 = cur; b0 < end; b0 += 64) {
-            uint64_t mine = 0;
-            const int b1 = min(end, b0 + 64);
-            for (int p = b0; p < b1; ++p) {
-                const int off = __builtin_amdgcn_readfirstlane(s_lo[p]) - win_lo;
-                const int nw = __builtin_amdgcn_readfirstlane(s_nw[p]);
-                uint32_t bad = 0;
-#pragma unroll
-                for (int i = 0; i < PT_NW; ++i) {
-                    if (i < nw) bad |= (tile[off + i][tid] ^ smask[p][2 * i + 1]) & smask[p][2 * i];
+        for (int g0 = cur; g0 < end; g0 += 64) {
+            const int cnt = min(end, g0 + 64) - g0;
+            // the group's descriptors, one piece per lane: no LDS round trip for them inside the piece loop
+            const int d_off = lane < cnt ? s_lo[g0 + lane] - win_lo : 0;
+            const int d_nw = lane < cnt ? s_nw[g0 + lane] : 1;
+            uint32_t m0lo = 0, m0hi = 0, m1lo = 0, m1hi = 0;
+            for (int k = 0; k < cnt; ++k) {
+                const int off = __builtin_amdgcn_readlane(d_off, k);
+                const int nw = __builtin_amdgcn_readlane(d_nw, k);
+                const uint32_t *trow = &tile[off][tid];
+                const uint2 *mk = (const uint2 *)&smask[g0 + k][0];
+                uint32_t bad0, bad1;
+                // straight-line per width: all LDS reads of the piece are issued together, then one wait
+                switch (nw) {
+#define PT_CASE(N)                                                                                                     \
+    case N: {                                                                                                          \
+        uint32_t r0[N], r1[N];                                                                                         \
+        uint2 m[N];                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < N; ++i) { r0[i] = trow[i * 1024]; r1[i] = trow[i * 1024 + PT_T]; m[i] = mk[i]; } \
+        bad0 = 0; bad1 = 0;                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < N; ++i) { bad0 |= (r0[i] ^ m[i].y) & m[i].x; bad1 |= (r1[i] ^ m[i].y) & m[i].x; } \
+    } break;
+                    PT_CASE(1) PT_CASE(2) PT_CASE(3) PT_CASE(4) PT_CASE(5) PT_CASE(6) PT_CASE(7)
+                    default: PT_CASE(8)
+#undef PT_CASE
                 }
-                const uint64_t b = __ballot(bad == 0);
-                if (lane == p - b0) mine = b;
+                const uint64_t b0 = __ballot(bad0 == 0), b1 = __ballot(bad1 == 0);
+                // lane k keeps the verdict words of piece k: EXEC = 1 << k around four moves (no compare + selects)
+                {
+                    uint64_t saved;
+                    asm volatile("s_mov_b64 %[sv], exec\n\ts_lshl_b64 exec, 1, %[k]\n\tv_mov_b32 %[a], %[sa]\n\tv_mov_b32 %[b], %[sb]\n\t"
+                                 "v_mov_b32 %[c], %[sc]\n\tv_mov_b32 %[d], %[sd]\n\ts_mov_b64 exec, %[sv]"
+                                 : [a] "+v"(m0lo), [b] "+v"(m0hi), [c] "+v"(m1lo), [d] "+v"(m1hi), [sv] "=&s"(saved)
+                                 : [sa] "s"((uint32_t)b0), [sb] "s"((uint32_t)(b0 >> 32)), [sc] "s"((uint32_t)b1),
+                                   [sd] "s"((uint32_t)(b1 >> 32)), [k] "s"(k)
+                                 : "scc");
+                }
             }
-            if (b0 + lane < b1 && wslot < w64) compat[(size_t)(p0 + b0 + lane) * w64 + wslot] = mine;
+            if (lane < cnt) {
+                uint64_t *row = compat + (size_t)(p0 + g0 + lane) * w64;
+                if (wslot0 < w64) row[wslot0] = ((uint64_t)m0hi << 32) | m0lo;
+                if (wslot1 < w64) row[wslot1] = ((uint64_t)m1hi << 32) | m1lo;
+            }
         }
         __syncthreads();
         cur = end;
@@ -351,7 +385,7 @@ extern "C" int hgx_piece_compat(const hgx_index *ix, const hgx_piece *pieces, co
         hipLaunchKernelGGL(k_piece_compat, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ix->d_bits, ix->a_pad,
                            pieces, masks, n_pieces, compat, ix->w64, chunks);
     } else {
-        hipLaunchKernelGGL(k_piece_compat_tiled, dim3((n_pieces + PT_PB - 1) / PT_PB, (ix->a_pad + 1023) / 1024), dim3(1024), 0,
+        hipLaunchKernelGGL(k_piece_compat_tiled, dim3((n_pieces + PT_PB - 1) / PT_PB, (ix->a_pad + 1023) / 1024), dim3(PT_T), 0,
                            (hipStream_t)stream, ix->d_bits, ix->a_pad, ix->n_words, pieces, masks, n_pieces, compat, ix->w64);
     }
     HIPCHK(hipGetLastError());
