@@ -286,8 +286,8 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     hipLaunchKernelGGL(k_verify_ht, dim3(nblk(n, 4)), dim3(256), 0, st, rows, w64, and_mask, b_slot.as<uint32_t>(),
                        b_first.as<uint32_t>(), n, b_meta.as<int>());
     uint32_t meta[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(meta, b_meta.p, 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
     HIPCHK(hipGetLastError());
     if (meta[0]) {
         hgx_set_error("64-bit class hash collision detected by the exact verify pass");
@@ -303,7 +303,7 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
                        b_cnt.as<unsigned long long>(), T, b_rank.as<uint32_t>(), cl->d_first_row, cl->d_count);
     hipLaunchKernelGGL(k_ht_gather, dim3(nblk(n_runs, 4)), dim3(256), 0, st, rows, w64, and_mask, cl->d_first_row, n_runs, cl->d_bits);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));      // the scratch buffers above go back to the pool on return
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }      // the scratch buffers above go back to the pool on return
     cl->n_classes = n_runs;
     return HGX_OK;
 }
@@ -350,8 +350,8 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
     hipLaunchKernelGGL(k_pack_meta, dim3(1), dim3(1), 0, st, b_cls.as<uint32_t>() + (n - 1), b_head.as<uint32_t>() + (n - 1),
                        b_bad.as<uint32_t>());
     uint32_t meta[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(meta, b_bad.p, 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { int rc_ = hgx_d2h(meta, b_bad.p, 16, st); if (rc_) return rc_; }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
     const uint32_t last_cls = meta[2], last_head = meta[3], nv32 = meta[1];
     const int n_runs = (int)(last_cls + last_head);
     if (n_runs == 0) return HGX_OK;
@@ -400,8 +400,8 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
     hipLaunchKernelGGL(k_gather_rows, dim3(nblk(n_runs, 4)), dim3(256), 0, st, rows, w64, and_mask, b_fs.as<uint32_t>(),
                        b_rid.as<uint32_t>(), b_rc.as<int64_t>(), n_runs, cl->d_bits, cl->d_count, cl->d_first_row);
     int bad = 0;
-    HIPCHK(hipMemcpyAsync(&bad, b_bad.p, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { int rc_ = hgx_d2h(&bad, b_bad.p, 4, st); if (rc_) return rc_; }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
     HIPCHK(hipGetLastError());
     cl->n_classes = n_runs;
     if (bad) {

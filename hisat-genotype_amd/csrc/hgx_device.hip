@@ -37,6 +37,72 @@ extern "C" int hgx_version(void) { return 100; }
 
 
 extern "C" int hgx_device_count(int *n) { HIPCHK(hipGetDeviceCount(n)); return HGX_OK; }
+// ---- pinned staging (see hgx_common.hpp) -------------------------------------------------------------------
+namespace {
+struct Staging {
+    char *buf = nullptr;
+    size_t cap = 0, used = 0;
+    struct Pending { void *dst; const char *src; size_t n; };
+    std::vector<Pending> pending;
+    std::vector<hipStream_t> streams;       // streams with staged transfers in flight (almost always exactly one)
+    void note(hipStream_t st) {
+        for (auto s : streams) if (s == st) return;
+        streams.push_back(st);
+    }
+    // buffers are recycled through a process-wide free list: short-lived worker threads (one per typed sample) must not
+    // pay hipHostMalloc / hipHostFree, which serialise with every other thread's launches inside the runtime
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static std::vector<char *> &free_list() { static std::vector<char *> v; return v; }
+    ~Staging() {
+        if (buf) { std::lock_guard<std::mutex> g(mu()); free_list().push_back(buf); }
+    }
+    char *take(size_t n) {
+        const size_t need = (n + 63) & ~(size_t)63;
+        if (!buf) {
+            cap = 1u << 20;
+            {
+                std::lock_guard<std::mutex> g(mu());
+                if (!free_list().empty()) { buf = free_list().back(); free_list().pop_back(); }
+            }
+            if (!buf && hipHostMalloc((void **)&buf, cap) != hipSuccess) { buf = nullptr; cap = 0; return nullptr; }
+        }
+        if (used + need > cap) return nullptr;
+        char *r = buf + used;
+        used += need;
+        return r;
+    }
+};
+thread_local Staging g_stage;
+constexpr size_t STAGE_MAX = 256u << 10;      // larger transfers go directly (the staging hop no longer dominates)
+}  // namespace
+
+int hgx_d2h(void *dst, const void *src, size_t n, hipStream_t st) {
+    char *s = n <= STAGE_MAX ? g_stage.take(n) : nullptr;
+    if (!s) { HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, st)); return HGX_OK; }
+    HIPCHK(hipMemcpyAsync(s, src, n, hipMemcpyDeviceToHost, st));
+    g_stage.pending.push_back({dst, s, n});
+    g_stage.note(st);
+    return HGX_OK;
+}
+int hgx_h2d(void *dst, const void *src, size_t n, hipStream_t st) {
+    char *s = n <= STAGE_MAX ? g_stage.take(n) : nullptr;
+    if (!s) { HIPCHK(hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st)); return HGX_OK; }
+    memcpy(s, src, n);                            // the region stays reserved until this thread's next hgx_sync
+    HIPCHK(hipMemcpyAsync(dst, s, n, hipMemcpyHostToDevice, st));
+    g_stage.note(st);
+    return HGX_OK;
+}
+int hgx_sync(hipStream_t st) {
+    HIPCHK(hipStreamSynchronize(st));
+    // the staging buffer is recycled below: transfers this thread staged on OTHER streams must be complete too
+    for (auto s2 : g_stage.streams) if (s2 != st) HIPCHK(hipStreamSynchronize(s2));
+    g_stage.streams.clear();
+    for (auto &p : g_stage.pending) memcpy(p.dst, p.src, p.n);
+    g_stage.pending.clear();
+    g_stage.used = 0;
+    return HGX_OK;
+}
+
 extern "C" int hgx_set_device(int dev) { HIPCHK(hipSetDevice(dev)); return HGX_OK; }
 extern "C" int hgx_dev_alloc(void **p, size_t bytes) {
     ARGCHK(p != nullptr);
@@ -45,20 +111,18 @@ extern "C" int hgx_dev_alloc(void **p, size_t bytes) {
 }
 extern "C" int hgx_dev_free(void *p) { if (p) HIPCHK(hipFree(p)); return HGX_OK; }
 extern "C" int hgx_memcpy_h2d(void *d, const void *s, size_t n, void *st) {
-    HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st));
-    HIPCHK(hipStreamSynchronize((hipStream_t)st));
-    return HGX_OK;
+    int rc = hgx_h2d(d, s, n, (hipStream_t)st);
+    return rc ? rc : hgx_sync((hipStream_t)st);
 }
 extern "C" int hgx_memcpy_d2h(void *d, const void *s, size_t n, void *st) {
-    HIPCHK(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st));
-    HIPCHK(hipStreamSynchronize((hipStream_t)st));
-    return HGX_OK;
+    int rc = hgx_d2h(d, s, n, (hipStream_t)st);
+    return rc ? rc : hgx_sync((hipStream_t)st);
 }
 extern "C" int hgx_memset(void *d, int v, size_t n, void *st) {
     HIPCHK(hipMemsetAsync(d, v, n, (hipStream_t)st));
     return HGX_OK;
 }
-extern "C" int hgx_stream_sync(void *st) { HIPCHK(hipStreamSynchronize((hipStream_t)st)); return HGX_OK; }
+extern "C" int hgx_stream_sync(void *st) { return hgx_sync((hipStream_t)st); }
 extern "C" int hgx_stream_create(void **st) {
     ARGCHK(st != nullptr);
     hipStream_t s;

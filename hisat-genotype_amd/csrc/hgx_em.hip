@@ -1856,8 +1856,8 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
     hipLaunchKernelGGL(k_col_or, dim3(256), dim3(256), (size_t)w64 * 8, st, c->d_bits, (long)C * w64, w64, b_mask.as<unsigned long long>());
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> h_mask(w64);
-    HIPCHK(hipMemcpyAsync(h_mask.data(), b_mask.p, (size_t)w64 * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { int rc_ = hgx_d2h(h_mask.data(), b_mask.p, (size_t)w64 * 8, st); if (rc_) return rc_; }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
     std::vector<int32_t> h_base(w64);
     c->h_act = new int32_t[A];
     int32_t n = 0;
@@ -1870,8 +1870,8 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
     c->d_bitsTC = (uint64_t *)hgx_pool_alloc((size_t)a1p * c->c64 * 8);
     c->d_bitsC = (uint64_t *)hgx_pool_alloc((size_t)c->c64 * 64 * (a1p / 64) * 8);
     if (!c->d_act || !c->d_bitsTC || !c->d_bitsC) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
-    HIPCHK(hipMemcpyAsync(b_base.p, h_base.data(), (size_t)w64 * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(c->d_act, c->h_act, (size_t)std::max(n, 1) * 4, hipMemcpyHostToDevice, st));
+    { int rc_ = hgx_h2d(b_base.p, h_base.data(), (size_t)w64 * 4, st); if (rc_) return rc_; }
+    { int rc_ = hgx_h2d(c->d_act, c->h_act, (size_t)std::max(n, 1) * 4, st); if (rc_) return rc_; }
     // padding rows [n, a1p) stay zero
     HIPCHK(hipMemsetAsync(c->d_bitsTC + (size_t)n * c->c64, 0, (size_t)(a1p - n) * c->c64 * 8, st));
     const long tiles_in = (long)c->c64 * w64;
@@ -1880,7 +1880,7 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
     const long tiles = (long)(a1p / 64) * c->c64;
     hipLaunchKernelGGL(k_transpose, dim3(nblk(tiles, 4)), dim3(256), 0, st, c->d_bitsTC, a1p, c->c64, a1p / 64, c->d_bitsC);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));        // b_mask / b_base / the host staging vectors are released on return
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }        // b_mask / b_base / the host staging vectors are released on return
     c->a1p = a1p;
     c->n_act = n;
     return HGX_OK;
@@ -1928,7 +1928,7 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
             std::vector<double> l(A, 1.0);
             for (int a = 0; a < n_alleles; ++a) l[a] = (double)allele_len[a];
             ALLOC(b_len, A * 8);
-            HIPCHK(hipMemcpyAsync(b_len.p, l.data(), A * 8, hipMemcpyHostToDevice, st));
+            { int rc_ = hgx_h2d(b_len.p, l.data(), A * 8, st); if (rc_) return rc_; }
             d_len = b_len.as<double>();
         }
         HIPCHK(hipMemsetAsync(b_scal.p, 0, S_N * 8, st));
@@ -1937,9 +1937,9 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         HIPCHK(hipGetLastError());
         std::vector<double> out(A);
         double h_scal[S_N];
-        HIPCHK(hipMemcpyAsync(out.data(), b_out.p, A * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_scal, b_scal.p, S_N * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
+        { int rc_ = hgx_d2h(h_scal, b_scal.p, S_N * 8, st); if (rc_) return rc_; }
+        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
         if (h_scal[S_FALLBACK] == 0.0) {
             if (h_scal[S_KEYERR] != 0.0) {
                 hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
@@ -1959,7 +1959,7 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
             std::vector<double> l(A, 1.0);
             for (int a = 0; a < n_alleles; ++a) l[a] = (double)allele_len[a];
             ALLOC(b_len, A * 8);
-            HIPCHK(hipMemcpyAsync(b_len.p, l.data(), A * 8, hipMemcpyHostToDevice, st));
+            { int rc_ = hgx_h2d(b_len.p, l.data(), A * 8, st); if (rc_) return rc_; }
             d_len = b_len.as<double>();
         }
         const size_t lds = (size_t)C * c->w64 * 8;
@@ -1974,9 +1974,9 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         HIPCHK(hipGetLastError());
         std::vector<double> out(A);
         double h_scal[S_N];
-        HIPCHK(hipMemcpyAsync(out.data(), b_out.p, A * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(h_scal, b_scal.p, S_N * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
+        { int rc_ = hgx_d2h(h_scal, b_scal.p, S_N * 8, st); if (rc_) return rc_; }
+        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
         if (h_scal[S_KEYERR] != 0.0) {
             hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
             return HGX_EKEY;
@@ -1999,8 +1999,8 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         std::vector<double> l(A, 1.0);
         for (int j = 0; j < c->n_act; ++j) if (c->h_act[j] < n_alleles) l[j] = (double)allele_len[c->h_act[j]];
         ALLOC(b_len, A * 8);
-        HIPCHK(hipMemcpyAsync(b_len.p, l.data(), A * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
+        { int rc_ = hgx_h2d(b_len.p, l.data(), A * 8, st); if (rc_) return rc_; }
+        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
         d_len = b_len.as<double>();
     }
     double *p = b_p.as<double>(), *q1 = b_q1.as<double>(), *q2 = b_q2.as<double>(), *q3 = b_q3.as<double>();
@@ -2102,9 +2102,9 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
                 hipLaunchKernelGGL(k_em_persist, dim3(G), dim3(BLOCK), LUT_LDS, st, a);
                 if (g_timing) (void)hipEventRecord(timed.back().b, st);
                 HIPCHK(hipGetLastError());
-                HIPCHK(hipMemcpyAsync(h_scal, scal, S_N * 8, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipMemcpyAsync(h_sync, b_sync.p, 16, hipMemcpyDeviceToHost, st));
-                HIPCHK(hipStreamSynchronize(st));
+                { int rc_ = hgx_d2h(h_scal, scal, S_N * 8, st); if (rc_) return rc_; }
+                { int rc_ = hgx_d2h(h_sync, b_sync.p, 16, st); if (rc_) return rc_; }
+                { int rc_ = hgx_sync(st); if (rc_) return rc_; }
                 if (h_sync[1] != 0) {
                     hgx_set_error("persistent EM: device-wide barrier timed out (grid of %d workgroups not co-resident?)", G);
                     return HGX_EHIP;
@@ -2115,8 +2115,8 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
                     hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsC, C, w64c, A, c->d_count, pu, pr, d_len,
                                        remove_low ? 1 : 0, b_out.as<double>(), scal);
                     const double maps_ran = h_scal[S_NROWS];
-                    HIPCHK(hipMemcpyAsync(h_scal, scal, S_N * 8, hipMemcpyDeviceToHost, st));
-                    HIPCHK(hipStreamSynchronize(st));
+                    { int rc_ = hgx_d2h(h_scal, scal, S_N * 8, st); if (rc_) return rc_; }
+                    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
                     h_scal[S_NROWS] = maps_ran;
                     if (h_scal[S_TAIL] == 1.0) { tail_done = true; break; }
                     tail_failed_at = h_scal[S_NPRES];
@@ -2144,8 +2144,8 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
             }
             HIPCHK(hipGetLastError());
             std::vector<double> out(A);
-            HIPCHK(hipMemcpyAsync(out.data(), b_out.p, A * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
+            { int rc_ = hgx_sync(st); if (rc_) return rc_; }
             for (int al = 0; al < n_alleles; ++al) prob_host[al] = -1.0;
             for (int jj = 0; jj < c->n_act; ++jj) if (c->h_act[jj] < n_alleles) prob_host[c->h_act[jj]] = out[jj];
             if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
@@ -2193,8 +2193,14 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
     bool tail_done = false;
     const bool use_tail = !getenv("HGX_EM_NO_TAIL");
     for (;;) {
-        // with pruning, look at the survivor count right after the first pruning iteration (iteration index 10)
-        const int nb = (use_tail && remove_low && launched_iters < 11) ? std::min(batch, 11 - launched_iters) : batch;
+        // with pruning, look at the survivor count right after the first pruning iteration (iteration index 10).
+        // A first batch of 4 tells whether the EM is still far from converged (diff 10x above the stopping rule); if so the
+        // remaining 7 iterations up to that point go out in one batch: every host sync is a ~40 us bubble in the chain.
+        int nb = batch;
+        if (use_tail && remove_low && launched_iters < 11) {
+            nb = std::min(batch, 11 - launched_iters);
+            if (launched_iters == batch && h_scal[S_DIFF] > 0.001) nb = 11 - launched_iters;
+        }
         launched_iters += nb;
         for (int b = 0; b < nb; ++b) {
             if ((rc = next_prob(p, pr, 0, q1, pr1, 0))) return rc;        // Gene_prob_next  (p is used raw)
@@ -2203,16 +2209,16 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
             if ((rc = next_prob(q2, pr2, 0, q3, pr3, 1))) return rc;      // only if extrapolated
             hipLaunchKernelGGL(k_em_advance, dim3(1), dim3(BLOCK), 0, st, p, pr, q1, pr1, q3, pr3, A, remove_low ? 1 : 0, scal);
         }
-        HIPCHK(hipMemcpyAsync(h_scal, scal, S_N * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        { int rc_ = hgx_d2h(h_scal, scal, S_N * 8, st); if (rc_) return rc_; }
+        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
         if (h_scal[S_DONE] != 0.0) break;
         if (use_tail && h_scal[S_NPRES] <= 64.0 && h_scal[S_NPRES] < tail_failed_at) {
             // few survivors: finish on one wavefront (k_em_tail) unless too many distinct class masks remain
             hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsC, C, w64c, A, c->d_count, p, pr, d_len,
                                remove_low ? 1 : 0, b_out.as<double>(), scal);
             const double rows_ran = h_scal[S_NROWS], cols_ran = h_scal[S_NCOLS];
-            HIPCHK(hipMemcpyAsync(h_scal, scal, S_N * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
+            { int rc_ = hgx_d2h(h_scal, scal, S_N * 8, st); if (rc_) return rc_; }
+            { int rc_ = hgx_sync(st); if (rc_) return rc_; }
             h_scal[S_NROWS] = rows_ran; h_scal[S_NCOLS] = cols_ran;
             if (h_scal[S_TAIL] == 1.0) { tail_done = true; break; }
             tail_failed_at = h_scal[S_NPRES];
@@ -2241,8 +2247,8 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
     if (!tail_done) hipLaunchKernelGGL(k_em_finish, dim3(1), dim3(BLOCK), 0, st, p, pr, d_len, A, remove_low ? 1 : 0, b_out.as<double>());
     HIPCHK(hipGetLastError());
     std::vector<double> out(A);
-    HIPCHK(hipMemcpyAsync(out.data(), b_out.p, A * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
     for (int a = 0; a < n_alleles; ++a) prob_host[a] = -1.0;
     for (int j = 0; j < c->n_act; ++j) if (c->h_act[j] < n_alleles) prob_host[c->h_act[j]] = out[j];
     (void)A_full;
@@ -2280,11 +2286,11 @@ extern "C" int hgx_first_classes(const hgx_classes *c, const int32_t *alleles_ho
     hipStream_t st = (hipStream_t)stream;
     DevBuf b_a, b_f;
     ALLOC(b_a, (size_t)n * 4); ALLOC(b_f, (size_t)n * 4);
-    HIPCHK(hipMemcpyAsync(b_a.p, alleles_host, (size_t)n * 4, hipMemcpyHostToDevice, st));
+    { int rc_ = hgx_h2d(b_a.p, alleles_host, (size_t)n * 4, st); if (rc_) return rc_; }
     hipLaunchKernelGGL(k_first_classes, dim3(n), dim3(256), 0, st, c->d_bits, c->n_classes, c->w64, b_a.as<int32_t>(), b_f.as<int32_t>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(first_host, b_f.p, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { int rc_ = hgx_d2h(first_host, b_f.p, (size_t)n * 4, st); if (rc_) return rc_; }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
     return HGX_OK;
 }
 
@@ -2313,9 +2319,9 @@ extern "C" int hgx_allele_counts_on(const hgx_classes *cc, int64_t *count_host, 
     hipLaunchKernelGGL(k_counts_out, dim3(nblk(A, 256)), dim3(256), 0, st, b_s.as<double>(), b_f.as<double>(), A,
                        b_c.as<int64_t>(), b_i.as<int32_t>());
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(count_host, b_c.p, (size_t)A * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(first_host, b_i.p, (size_t)A * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { int rc_ = hgx_d2h(count_host, b_c.p, (size_t)A * 8, st); if (rc_) return rc_; }
+    { int rc_ = hgx_d2h(first_host, b_i.p, (size_t)A * 4, st); if (rc_) return rc_; }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
     return HGX_OK;
 }
 
