@@ -260,6 +260,21 @@ __global__ __launch_bounds__(256) void k_ht_gather(const uint64_t *__restrict__ 
         out_bits[(size_t)c * w64 + w] = x;
     }
 }
+__global__ __launch_bounds__(256) void k_ht_gather_slots(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
+                                                         const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ first,
+                                                         const uint32_t *__restrict__ rank, long T, uint64_t *__restrict__ out_bits) {
+    const int lane = threadIdx.x & 63;
+    const long s = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (s >= T || keys[s] == HGX_EMPTY_KEY) return;
+    const uint32_t f = first[s];
+    const uint64_t *src = rows + (size_t)f * w64;
+    uint64_t *dst = out_bits + (size_t)rank[f] * w64;
+    for (int w = lane; w < w64; w += 64) {
+        uint64_t x = src[w];
+        if (mask) x &= mask[w];
+        dst[w] = x;
+    }
+}
 __global__ void k_ht_meta(const uint32_t *last_rank, const uint32_t *last_flag, uint32_t *meta) { meta[1] = *last_rank + *last_flag; }
 
 static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_t *keys_in, const int64_t *row_weight, long n,
@@ -282,28 +297,42 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
     hipLaunchKernelGGL(k_ht_meta, dim3(1), dim3(1), 0, st, b_rank.as<uint32_t>() + (n - 1), b_flag.as<uint32_t>() + (n - 1),
                        b_meta.as<uint32_t>());
-    // the exact check does not need the class count: queue it before the one D2H that sizes the output
+    // the exact check does not need the class count: queue it before the D2H that sizes the output
     hipLaunchKernelGGL(k_verify_ht, dim3(nblk(n, 4)), dim3(256), 0, st, rows, w64, and_mask, b_slot.as<uint32_t>(),
                        b_first.as<uint32_t>(), n, b_meta.as<int>());
     uint32_t meta[4] = {0, 0, 0, 0};
-    { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
-    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+    // Small inputs (the hand-off dedup: a few thousand gene classes) size the output for the worst case and finish in
+    // ONE host round trip; large ones first learn the class count (the worst case would be the whole input again).
+    const bool one_trip = n <= 65536;
+    int n_alloc = (int)n;
+    if (!one_trip) {
+        { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
+        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+        HIPCHK(hipGetLastError());
+        if (meta[0]) {
+            hgx_set_error("64-bit class hash collision detected by the exact verify pass");
+            return HGX_ECOLLISION;
+        }
+        n_alloc = (int)meta[1];
+        if (n_alloc == 0) return HGX_OK;
+    }
+    cl->d_bits = (decltype(cl->d_bits))hgx_pool_alloc((size_t)n_alloc * w64 * 8);
+    cl->d_count = (decltype(cl->d_count))hgx_pool_alloc((size_t)n_alloc * 8);
+    cl->d_first_row = (decltype(cl->d_first_row))hgx_pool_alloc((size_t)n_alloc * 8);
+    if (!cl->d_bits || !cl->d_count || !cl->d_first_row) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    hipLaunchKernelGGL(k_ht_finalize, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(),
+                       b_cnt.as<unsigned long long>(), T, b_rank.as<uint32_t>(), cl->d_first_row, cl->d_count);
+    // gather per table slot (class id = rank of the slot's first row): needs no host-side class count
+    hipLaunchKernelGGL(k_ht_gather_slots, dim3(nblk(T, 4)), dim3(256), 0, st, rows, w64, and_mask, b_keys.as<unsigned long long>(),
+                       b_first.as<uint32_t>(), b_rank.as<uint32_t>(), T, cl->d_bits);
     HIPCHK(hipGetLastError());
+    if (one_trip) { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }      // also: the scratch buffers above go back to the pool on return
     if (meta[0]) {
         hgx_set_error("64-bit class hash collision detected by the exact verify pass");
         return HGX_ECOLLISION;
     }
     const int n_runs = (int)meta[1];
-    if (n_runs == 0) return HGX_OK;
-    cl->d_bits = (decltype(cl->d_bits))hgx_pool_alloc((size_t)n_runs * w64 * 8);
-    cl->d_count = (decltype(cl->d_count))hgx_pool_alloc((size_t)n_runs * 8);
-    cl->d_first_row = (decltype(cl->d_first_row))hgx_pool_alloc((size_t)n_runs * 8);
-    if (!cl->d_bits || !cl->d_count || !cl->d_first_row) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
-    hipLaunchKernelGGL(k_ht_finalize, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(),
-                       b_cnt.as<unsigned long long>(), T, b_rank.as<uint32_t>(), cl->d_first_row, cl->d_count);
-    hipLaunchKernelGGL(k_ht_gather, dim3(nblk(n_runs, 4)), dim3(256), 0, st, rows, w64, and_mask, cl->d_first_row, n_runs, cl->d_bits);
-    HIPCHK(hipGetLastError());
-    { int rc_ = hgx_sync(st); if (rc_) return rc_; }      // the scratch buffers above go back to the pool on return
     cl->n_classes = n_runs;
     return HGX_OK;
 }

@@ -1047,7 +1047,8 @@ constexpr int S_FALLBACK = 6;       // (re-uses the S_NROWS word: the wave kerne
 
 __global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, int C, int n_words, int a_pad,
                                                 const int64_t *__restrict__ count, const double *__restrict__ len,
-                                                int remove_low, double *__restrict__ out, double *__restrict__ scal) {
+                                                int remove_low, double *__restrict__ out, double *__restrict__ scal,
+                                                int32_t *__restrict__ first_out) {
     __shared__ int gidx[64];
     const int lane = threadIdx.x;
     // ---- which alleles occur at all ------------------------------------------------------------------------
@@ -1096,6 +1097,7 @@ __global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, 
     const double tot = wave_sum_f64(pr ? p : 0.0);
     p = pr ? p / tot : 0.0;
     for (int a = lane; a < a_pad; a += 64) out[a] = -1.0;
+    if (first_out && lane < A1) first_out[g] = E.K ? __builtin_ctzll(E.K) : -1;     // first class (dict order) containing the allele
     __syncthreads();
     wave_em_run(E, p, pr, 0, remove_low, use_len, g, out, scal);
 }
@@ -1907,9 +1909,24 @@ extern "C" int hgx_em_get_timing(int slot, double *ms_total, int64_t *launches, 
     return HGX_OK;
 }
 
+static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len, double *prob_host,
+                   int32_t *first_host, int32_t *n_iter_host, void *stream);
+__global__ void k_first_set_rows(const uint64_t *BT, int n_rows, int c64, int32_t *first);
+
 extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len,
                       double *prob_host, int32_t *n_iter_host, void *stream) {
+    return em_impl(cc, n_alleles, remove_low, allele_len, prob_host, nullptr, n_iter_host, stream);
+}
+extern "C" int hgx_em_ordered(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len,
+                              double *prob_host, int32_t *first_class_host, int32_t *n_iter_host, void *stream) {
+    ARGCHK(first_class_host);
+    return em_impl(cc, n_alleles, remove_low, allele_len, prob_host, first_class_host, n_iter_host, stream);
+}
+
+static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len, double *prob_host,
+                   int32_t *first_host, int32_t *n_iter_host, void *stream) {
     ARGCHK(cc && prob_host && n_alleles > 0 && n_alleles <= cc->a_pad);
+    if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = -1;
     hgx_classes *c = const_cast<hgx_classes *>(cc);
     hipStream_t st = (hipStream_t)stream;
     int A = c->a_pad;
@@ -1932,11 +1949,19 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
             d_len = b_len.as<double>();
         }
         HIPCHK(hipMemsetAsync(b_scal.p, 0, S_N * 8, st));
+        DevBuf b_first;
+        std::vector<int32_t> h_first;
+        if (first_host) {
+            ALLOC(b_first, (size_t)A * 4);
+            HIPCHK(hipMemsetAsync(b_first.p, 0xFF, (size_t)A * 4, st));
+            h_first.resize(A);
+        }
         hipLaunchKernelGGL(k_em_wave, dim3(1), dim3(64), 0, st, c->d_bits, C, c->w64, A, c->d_count, d_len, remove_low ? 1 : 0,
-                           b_out.as<double>(), b_scal.as<double>());
+                           b_out.as<double>(), b_scal.as<double>(), first_host ? b_first.as<int32_t>() : nullptr);
         HIPCHK(hipGetLastError());
         std::vector<double> out(A);
         double h_scal[S_N];
+        if (first_host) { int rc_ = hgx_d2h(h_first.data(), b_first.p, (size_t)A * 4, st); if (rc_) return rc_; }
         { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
         { int rc_ = hgx_d2h(h_scal, b_scal.p, S_N * 8, st); if (rc_) return rc_; }
         { int rc_ = hgx_sync(st); if (rc_) return rc_; }
@@ -1946,10 +1971,23 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
                 return HGX_EKEY;
             }
             for (int a = 0; a < n_alleles; ++a) prob_host[a] = out[a];
+            if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = h_first[a];
             if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
             return HGX_OK;
         }
     }
+    // helper for the paths that do not carry the first-class information: look it up for the survivors afterwards
+    auto first_for_present = [&]() -> int {
+        if (!first_host) return HGX_OK;
+        std::vector<int32_t> al;
+        for (int a = 0; a < n_alleles; ++a) if (prob_host[a] >= 0.0) al.push_back(a);
+        if (al.empty()) return HGX_OK;
+        std::vector<int32_t> f(al.size());
+        int rc_ = hgx_first_classes(cc, al.data(), (int32_t)al.size(), f.data(), stream);
+        if (rc_) return rc_;
+        for (size_t i = 0; i < al.size(); ++i) first_host[al[i]] = f[i];
+        return HGX_OK;
+    };
     if (C <= SMALL_C && A <= EPT * BLOCK && !getenv("HGX_EM_NO_SMALL")) {
         // single-workgroup path: one launch, one sync
         DevBuf b_len, b_scal, b_out;
@@ -1983,7 +2021,7 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
         }
         for (int a = 0; a < n_alleles; ++a) prob_host[a] = out[a];
         if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
-        return HGX_OK;
+        return first_for_present();
     }
     int rc = hgx_ensure_compact(c, st);
     if (rc) return rc;
@@ -2144,10 +2182,19 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
             }
             HIPCHK(hipGetLastError());
             std::vector<double> out(A);
+            DevBuf b_fc;
+            std::vector<int32_t> h_fc;
+            if (first_host) {
+                ALLOC(b_fc, (size_t)A * 4);
+                h_fc.resize(A);
+                hipLaunchKernelGGL(k_first_set_rows, dim3(nblk((long)A * 64, 256)), dim3(256), 0, st, c->d_bitsTC, A, c->c64, b_fc.as<int32_t>());
+                { int rc_ = hgx_d2h(h_fc.data(), b_fc.p, (size_t)A * 4, st); if (rc_) return rc_; }
+            }
             { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
             { int rc_ = hgx_sync(st); if (rc_) return rc_; }
             for (int al = 0; al < n_alleles; ++al) prob_host[al] = -1.0;
             for (int jj = 0; jj < c->n_act; ++jj) if (c->h_act[jj] < n_alleles) prob_host[c->h_act[jj]] = out[jj];
+            if (first_host) for (int jj = 0; jj < c->n_act; ++jj) if (c->h_act[jj] < n_alleles) first_host[c->h_act[jj]] = h_fc[jj];
             if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
             return HGX_OK;
         }
@@ -2247,13 +2294,42 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
     if (!tail_done) hipLaunchKernelGGL(k_em_finish, dim3(1), dim3(BLOCK), 0, st, p, pr, d_len, A, remove_low ? 1 : 0, b_out.as<double>());
     HIPCHK(hipGetLastError());
     std::vector<double> out(A);
+    DevBuf b_fc;
+    std::vector<int32_t> h_fc;
+    if (first_host) {
+        ALLOC(b_fc, (size_t)A * 4);
+        h_fc.resize(A);
+        hipLaunchKernelGGL(k_first_set_rows, dim3(nblk((long)A * 64, 256)), dim3(256), 0, st, c->d_bitsTC, A, c->c64, b_fc.as<int32_t>());
+        { int rc_ = hgx_d2h(h_fc.data(), b_fc.p, (size_t)A * 4, st); if (rc_) return rc_; }
+    }
     { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
     { int rc_ = hgx_sync(st); if (rc_) return rc_; }
     for (int a = 0; a < n_alleles; ++a) prob_host[a] = -1.0;
     for (int j = 0; j < c->n_act; ++j) if (c->h_act[j] < n_alleles) prob_host[c->h_act[j]] = out[j];
+    if (first_host) for (int j = 0; j < c->n_act; ++j) if (c->h_act[j] < n_alleles) first_host[c->h_act[j]] = h_fc[j];
     (void)A_full;
     if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
     return HGX_OK;
+}
+
+// first class containing each compact allele = first set bit of its row in the transposed matrix (one wavefront per row)
+__global__ __launch_bounds__(256) void k_first_set_rows(const uint64_t *__restrict__ BT, int n_rows, int c64, int32_t *__restrict__ first) {
+    const int lane = threadIdx.x & 63;
+    const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= n_rows) return;
+    int best = 0x7fffffff;
+    for (int w0 = 0; w0 < c64; w0 += 64) {
+        const int w = w0 + lane;
+        const uint64_t x = w < c64 ? BT[(size_t)row * c64 + w] : 0ull;
+        const uint64_t hit = __ballot(x != 0ull);
+        if (hit) {
+            const int l = __builtin_ctzll(hit);
+            const uint64_t xl = lane_u64(x, l);
+            best = 64 * (w0 + l) + __builtin_ctzll(xl);
+            break;
+        }
+    }
+    if (lane == 0) first[row] = best == 0x7fffffff ? -1 : best;
 }
 
 // first class containing an allele, for a handful of alleles: one workgroup per allele walks the allele's bit column

@@ -109,6 +109,16 @@ class Classes:
                                      capi.ptr(prob), C.byref(it), stream))
         return prob, it.value
 
+    def em_ordered(self, n_alleles, remove_low=False, lengths=None, stream=None):
+        """em() plus, for every allele of the result, the first class containing it (the tie order of the result list)."""
+        prob = np.zeros(n_alleles, np.float64)
+        first = np.zeros(n_alleles, np.int32)
+        it = C.c_int32(0)
+        ln = None if lengths is None else np.ascontiguousarray(lengths, np.int32)
+        capi.check(capi.lib().hgx_em_ordered(self.h, C.c_int32(n_alleles), C.c_int32(1 if remove_low else 0), capi.ptr(ln),
+                                             capi.ptr(prob), capi.ptr(first), C.byref(it), stream))
+        return prob, first, it.value
+
     def close(self):
         if self.h:
             capi.lib().hgx_classes_destroy(self.h)

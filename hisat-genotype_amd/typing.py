@@ -32,15 +32,10 @@ def _sorted_result(prob, order):
 
 
 def _em_on_classes(classes, n_alleles, name_rank, remove_low, lengths, stream=None):
-    prob, n_iter = classes.em(n_alleles, remove_low, lengths, stream)
+    prob, first, n_iter = classes.em_ordered(n_alleles, remove_low, lengths, stream)
     present = np.nonzero(prob >= 0.0)[0]
-    if len(present) <= 256:
-        # dict insertion order of the survivors (common:1300-1305): first class containing each, then name order
-        fc = classes.first_classes(present, stream)
-        order = present[np.lexsort((np.asarray(name_rank)[present], fc))].tolist()
-    else:
-        _, first = classes.allele_counts(stream)
-        order = engine.em_order(first[:n_alleles], name_rank, prob >= 0.0)
+    # dict insertion order of the survivors (common:1300-1305): first class containing each, then name order
+    order = present[np.lexsort((np.asarray(name_rank)[present], first[present]))].tolist()
     return _sorted_result(prob, order), n_iter
 
 

@@ -175,6 +175,11 @@ int hgx_first_classes(const hgx_classes *c, const int32_t *alleles_host, int32_t
 int hgx_em(const hgx_classes *c, int32_t n_alleles,
            int32_t remove_low, const int32_t *allele_len_or_null /* host [n_alleles] */,
            double *prob_host, int32_t *n_iter_host, void *stream);
+/* same, and first_class_host[a] = first class (dict order) containing allele a for the alleles in the returned dict
+ * (-1 elsewhere): with name order this is the insertion order of the reference's result dict (common:1300-1305),
+ * i.e. the tie order of its final stable sort -- delivered with the abundances, no second pass or sync */
+int hgx_em_ordered(const hgx_classes *c, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len_or_null,
+                   double *prob_host, int32_t *first_class_host, int32_t *n_iter_host, void *stream);
 
 /* ---- host front-end: locus tables, SAM -> pieces (8a-0 .. 8a-4) ----------------------------
  * The part of typing() that precedes scoring is index-heavy string logic with no data
