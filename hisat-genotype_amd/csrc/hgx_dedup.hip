@@ -322,9 +322,11 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     if (!cl->d_bits || !cl->d_count || !cl->d_first_row) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
     hipLaunchKernelGGL(k_ht_finalize, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(),
                        b_cnt.as<unsigned long long>(), T, b_rank.as<uint32_t>(), cl->d_first_row, cl->d_count);
-    // gather per table slot (class id = rank of the slot's first row): needs no host-side class count
-    hipLaunchKernelGGL(k_ht_gather_slots, dim3(nblk(T, 4)), dim3(256), 0, st, rows, w64, and_mask, b_keys.as<unsigned long long>(),
-                       b_first.as<uint32_t>(), b_rank.as<uint32_t>(), T, cl->d_bits);
+    if (one_trip)      // gather per table slot (class id = rank of the slot's first row): needs no host-side class count
+        hipLaunchKernelGGL(k_ht_gather_slots, dim3(nblk(T, 4)), dim3(256), 0, st, rows, w64, and_mask, b_keys.as<unsigned long long>(),
+                           b_first.as<uint32_t>(), b_rank.as<uint32_t>(), T, cl->d_bits);
+    else
+        hipLaunchKernelGGL(k_ht_gather, dim3(nblk(n_alloc, 4)), dim3(256), 0, st, rows, w64, and_mask, cl->d_first_row, n_alloc, cl->d_bits);
     HIPCHK(hipGetLastError());
     if (one_trip) { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
     { int rc_ = hgx_sync(st); if (rc_) return rc_; }      // also: the scratch buffers above go back to the pool on return

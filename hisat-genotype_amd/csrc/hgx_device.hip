@@ -104,12 +104,21 @@ int hgx_sync(hipStream_t st) {
 }
 
 extern "C" int hgx_set_device(int dev) { HIPCHK(hipSetDevice(dev)); return HGX_OK; }
+void *hgx_pool_alloc(size_t bytes);
+void hgx_pool_free(void *p);
 extern "C" int hgx_dev_alloc(void **p, size_t bytes) {
     ARGCHK(p != nullptr);
-    HIPCHK(hipMalloc(p, bytes ? bytes : 8));
+    if (bytes <= (16u << 20)) {
+        // small buffers (masks, vectors, per-sample tables) come from the caching pool: hipMalloc / hipFree cost tens of
+        // microseconds and hipFree synchronises the whole device, which would stall every other sample in flight
+        *p = hgx_pool_alloc(bytes);
+        if (!*p) { hgx_set_error("device allocation of %zu bytes failed", bytes); return HGX_ENOMEM; }
+        return HGX_OK;
+    }
+    HIPCHK(hipMalloc(p, bytes));
     return HGX_OK;
 }
-extern "C" int hgx_dev_free(void *p) { if (p) HIPCHK(hipFree(p)); return HGX_OK; }
+extern "C" int hgx_dev_free(void *p) { hgx_pool_free(p); return HGX_OK; }   // pool blocks are recycled, foreign ones hipFree'd
 extern "C" int hgx_memcpy_h2d(void *d, const void *s, size_t n, void *st) {
     int rc = hgx_h2d(d, s, n, (hipStream_t)st);
     return rc ? rc : hgx_sync((hipStream_t)st);

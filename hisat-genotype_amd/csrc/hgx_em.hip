@@ -2045,6 +2045,14 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     uint8_t *pr = b_pr.as<uint8_t>(), *pr1 = b_pr1.as<uint8_t>(), *pr2 = b_pr2.as<uint8_t>(), *pr3 = b_pr3.as<uint8_t>();
     double *wc = b_wc.as<double>(), *scal = b_scal.as<double>();
     HIPCHK(hipMemsetAsync(scal, 0, S_N * 8, st));
+    // tie order of the result (first class containing each allele): independent of the EM, queued before it
+    DevBuf b_fc;
+    std::vector<int32_t> h_fc;
+    if (first_host) {
+        ALLOC(b_fc, (size_t)A * 4);
+        h_fc.resize(A);
+        hipLaunchKernelGGL(k_first_set_rows, dim3(nblk((long)A * 64, 256)), dim3(256), 0, st, c->d_bitsTC, A, c->c64, b_fc.as<int32_t>());
+    }
     MatVec rows{c->d_bitsC, C, w64c, A};
     MatVec cols{c->d_bitsTC, A, c->c64, C};
     if (g_backend == 2 && A >= 512 && C >= 64) {
@@ -2182,14 +2190,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             }
             HIPCHK(hipGetLastError());
             std::vector<double> out(A);
-            DevBuf b_fc;
-            std::vector<int32_t> h_fc;
-            if (first_host) {
-                ALLOC(b_fc, (size_t)A * 4);
-                h_fc.resize(A);
-                hipLaunchKernelGGL(k_first_set_rows, dim3(nblk((long)A * 64, 256)), dim3(256), 0, st, c->d_bitsTC, A, c->c64, b_fc.as<int32_t>());
-                { int rc_ = hgx_d2h(h_fc.data(), b_fc.p, (size_t)A * 4, st); if (rc_) return rc_; }
-            }
+            if (first_host) { int rc_ = hgx_d2h(h_fc.data(), b_fc.p, (size_t)A * 4, st); if (rc_) return rc_; }
             { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
             { int rc_ = hgx_sync(st); if (rc_) return rc_; }
             for (int al = 0; al < n_alleles; ++al) prob_host[al] = -1.0;
@@ -2294,14 +2295,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     if (!tail_done) hipLaunchKernelGGL(k_em_finish, dim3(1), dim3(BLOCK), 0, st, p, pr, d_len, A, remove_low ? 1 : 0, b_out.as<double>());
     HIPCHK(hipGetLastError());
     std::vector<double> out(A);
-    DevBuf b_fc;
-    std::vector<int32_t> h_fc;
-    if (first_host) {
-        ALLOC(b_fc, (size_t)A * 4);
-        h_fc.resize(A);
-        hipLaunchKernelGGL(k_first_set_rows, dim3(nblk((long)A * 64, 256)), dim3(256), 0, st, c->d_bitsTC, A, c->c64, b_fc.as<int32_t>());
-        { int rc_ = hgx_d2h(h_fc.data(), b_fc.p, (size_t)A * 4, st); if (rc_) return rc_; }
-    }
+    if (first_host) { int rc_ = hgx_d2h(h_fc.data(), b_fc.p, (size_t)A * 4, st); if (rc_) return rc_; }
     { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
     { int rc_ = hgx_sync(st); if (rc_) return rc_; }
     for (int a = 0; a < n_alleles; ++a) prob_host[a] = -1.0;
