@@ -359,7 +359,7 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
         hipLaunchKernelGGL(k_hash_rows, dim3(nblk(n, 4)), dim3(256), 0, st, rows, n, w64, and_mask, b_hash.as<uint64_t>());
         keys_in = b_hash.as<uint64_t>();
     }
-    static const bool sort_path = getenv("HGX_DEDUP_SORT") != nullptr;       // the radix-sort form, kept for comparison
+    const bool sort_path = getenv("HGX_DEDUP_SORT") != nullptr;      // the radix-sort form, kept for comparison
     if (!sort_path) return dedup_hash_table(cl, rows, keys_in, row_weight, n, w64, and_mask, st);
     ALLOC(b_key, n * 8); ALLOC(b_idx0, n * 4); ALLOC(b_idx, n * 4); ALLOC(b_head, n * 4); ALLOC(b_cls, n * 4); ALLOC(b_bad, 16);
     hipLaunchKernelGGL(k_iota, dim3(nblk(n, 256)), dim3(256), 0, st, b_idx0.as<uint32_t>(), n);
@@ -400,7 +400,7 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
     }
     hipLaunchKernelGGL(k_run_counts, dim3(nblk(n_runs, 256)), dim3(256), 0, st, b_rs.as<uint32_t>(), n_runs, n_valid, wsum,
                        b_rc.as<int64_t>());
-    static const bool sorted_verify = getenv("HGX_VERIFY_SORTED") != nullptr;      // the hash-order walk, for comparison
+    const bool sorted_verify = getenv("HGX_VERIFY_SORTED") != nullptr;      // the hash-order walk, for comparison
     DevBuf b_ho;
     if (sorted_verify) {
         hipLaunchKernelGGL(k_verify, dim3(nblk(n_valid, 4)), dim3(256), 0, st, rows, w64, and_mask, b_idx.as<uint32_t>(),

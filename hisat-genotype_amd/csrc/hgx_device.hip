@@ -450,7 +450,7 @@ extern "C" int hgx_piece_compat(const hgx_index *ix, const hgx_piece *pieces, co
     ARGCHK(ix && n_pieces >= 0);
     if (n_pieces == 0) return HGX_OK;
     ARGCHK(pieces && masks && compat);
-    static const bool untiled = getenv("HGX_PIECE_UNTILED") != nullptr;     // the L2-served kernel, kept for comparison
+    const bool untiled = getenv("HGX_PIECE_UNTILED") != nullptr;     // the L2-served kernel, kept for comparison
     if (untiled) {
         const int chunks = (ix->w64 + PC_GROUPS - 1) / PC_GROUPS;
         const long waves = (long)n_pieces * chunks;

@@ -1920,7 +1920,10 @@ extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_l
 extern "C" int hgx_em_ordered(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len,
                               double *prob_host, int32_t *first_class_host, int32_t *n_iter_host, void *stream) {
     ARGCHK(first_class_host);
-    return em_impl(cc, n_alleles, remove_low, allele_len, prob_host, first_class_host, n_iter_host, stream);
+    const int rc = em_impl(cc, n_alleles, remove_low, allele_len, prob_host, first_class_host, n_iter_host, stream);
+    if (rc == HGX_OK)
+        for (int a = 0; a < n_alleles; ++a) if (prob_host[a] < 0.0) first_class_host[a] = -1;     // only the returned dict's alleles
+    return rc;
 }
 
 static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len, double *prob_host,

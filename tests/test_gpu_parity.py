@@ -189,12 +189,78 @@ def test_piece_compat_any_piece_order(orc, name):
     d_masks = engine.DevArray.from_host(batch.masks)
     perm = np.random.RandomState(1).permutation(batch.n_pieces)
     out = []
-    for pieces in (batch.pieces, batch.pieces[perm]):
+    import os
+    for pieces, untiled in ((batch.pieces, False), (batch.pieces[perm], False), (batch.pieces, True)):
         d_p = engine.DevArray.from_host(np.ascontiguousarray(pieces))
         a = engine.DevArray((batch.n_pieces, pl.w64), np.uint64)
-        capi.check(L.hgx_piece_compat(pl.index(), capi.ptr(d_p), capi.ptr(d_masks), C.c_int32(batch.n_pieces), capi.ptr(a), None))
+        if untiled:
+            os.environ["HGX_PIECE_UNTILED"] = "1"          # the kernel that reads the index rows straight from L2
+        try:
+            capi.check(L.hgx_piece_compat(pl.index(), capi.ptr(d_p), capi.ptr(d_masks), C.c_int32(batch.n_pieces), capi.ptr(a), None))
+        finally:
+            os.environ.pop("HGX_PIECE_UNTILED", None)
         out.append(a.to_host())
     assert np.array_equal(out[0][perm], out[1])
+    assert np.array_equal(out[0], out[2])
+
+
+@pytest.mark.parametrize("name", ["hla_7000", "hla_errors_filters", "codis_d18s51"])
+def test_dedup_sort_path_equals_hash_table_path(orc, name):
+    """The radix-sort dedup (kept for comparison) and the hash-table dedup give the same classes, counts and order,
+    with and without weights / AND mask."""
+    import os
+    fx, loc, t, pl, batch, _ = _setup(orc, name)
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    rng = np.random.RandomState(5)
+    weights = engine.DevArray.from_host(rng.randint(1, 9, batch.n_pairs).astype(np.int64))
+    mask = np.zeros(pl.w64, np.uint64)
+    mask[: max(1, pl.w64 // 3)] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    d_mask = engine.DevArray.from_host(mask)
+    for kw in ({"hashes": bufs.gene_hash}, {"weights": weights}, {"and_mask": d_mask, "weights": weights}):
+        res = []
+        for sort in (False, True):
+            if sort:
+                os.environ["HGX_DEDUP_SORT"] = "1"
+            try:
+                cl = engine.Classes.dedup(bufs.gene_bits, batch.n_pairs, pl.a_pad, **kw)
+            finally:
+                os.environ.pop("HGX_DEDUP_SORT", None)
+            res.append(cl.to_host())
+            cl.close()
+        for x, y in zip(res[0], res[1]):
+            assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("name", ["hla_7000", "hla_mid_real", "codis_like"])
+def test_em_ordered_and_first_classes_match_counts_pass(orc, name):
+    """hgx_em_ordered's first-class output (the tie order of the result list) and hgx_first_classes agree with the full
+    Gene_counts pass (hgx_allele_counts) on every path: single wavefront, single workgroup, compact multi-launch + tail."""
+    import os
+    fx, loc, t, pl, batch, _ = _setup(orc, name)
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    A = t["n_alleles"]
+    rows, hashes = (bufs.exon_bits, bufs.exon_hash) if loc.base_fname == "hla" else (bufs.gene_bits, bufs.gene_hash)
+    cl = engine.Classes.dedup(rows, batch.n_pairs, pl.a_pad, hashes=hashes)
+    _, first_full = cl.allele_counts()
+    some = np.random.RandomState(2).choice(A, min(A, 40), replace=False).astype(np.int32)
+    assert np.array_equal(cl.first_classes(some), first_full[some])
+    for env in ({}, {"HGX_EM_NO_WAVE": "1"}, {"HGX_EM_NO_SMALL": "1"}):
+        os.environ.update(env)
+        try:
+            prob, first, it = cl.em_ordered(A, True, None)
+            prob2, it2 = cl.em(A, True, None)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        assert it == it2 and np.array_equal(prob, prob2)
+        present = prob >= 0
+        assert present.any()
+        assert np.array_equal(first[present], first_full[:A][present])
+        assert np.all(first[~present] == -1)
 
 
 def test_empty_and_degenerate_inputs(orc):

@@ -234,3 +234,39 @@ def test_typing_reads_bam_without_samtools(tmp_path):
     rep = (tmp_path / "assembly_graph-hla.sample.report").read_text()
     keep = lambda ls: [l for l in ls if "aligned" in l or "ranked" in l or "(count:" in l]
     assert keep(rep.split("\n")) == keep(fx["report"].split("\n"))
+
+
+def test_concurrent_samples_give_identical_results():
+    """Two host threads typing two samples at the same time on one GPU (own streams, own class-row buffers, shared locus
+    index and pool) get exactly what they get one after the other."""
+    import threading
+    from hisatgenotype_amd import synth, locus as hl, engine, capi
+    ht = sys.modules["hisatgenotype_amd.typing"]        # the module (the package also exports the typing() function)
+    loc = synth.make_hla_like_locus(n_alleles=900, n_vars=700, seed=12)
+    pl = hl.PackedLocus.from_synth(loc)
+    pl.index()
+    batches = []
+    for seed in (3, 4):
+        sample = synth.pick_sample(loc, seed)
+        sam = synth.simulate_sam_fast(loc, sample, 6000, err_rate=0.002, seed=seed)
+        batches.append(pl.parse_sam(sam))
+
+    def run(batch, out, own_stream):
+        capi.set_device(capi.current_device())
+        res = ht.LocusResult()
+        res.num_reads, res.num_pairs = batch.n_reads, batch.n_pairs
+        st = capi.get_stream(2) if own_stream else None
+        r = ht._type_batch(pl, batch, res, True, stream=st, overlap=True)
+        out.append((r.gene_prob, [e["n_iter"] for e in r.em], r.counts_sorted[:10]))
+
+    seq = []
+    for b in batches:
+        run(b, seq, False)
+    for _ in range(3):
+        outs = [[], []]
+        ths = [threading.Thread(target=run, args=(b, o, True)) for b, o in zip(batches, outs)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert outs[0][0] == seq[0] and outs[1][0] == seq[1]
