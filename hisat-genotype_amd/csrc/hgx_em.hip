@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <vector>
 
+#include <hip/hip_ext.h>
+
 #include "hgx_common.hpp"
 
 namespace {
@@ -1750,6 +1752,10 @@ inline int rows_per_block(int n_rows) {
     return std::max(RB, std::min(MAX_RPB, rpb));
 }
 
+// events that the next table-lookup launch attaches to its own dispatch (hipExtLaunchKernelGGL: the runtime timestamps the
+// kernel's begin and end, like rocprofv3 does, instead of bracketing it with separately queued event records)
+thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+
 template <int MODE>
 int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint8_t *vec_pres, int x_mode,
                   const int64_t *count, const double *q_in, const uint8_t *pres_in, const double *len, double *y,
@@ -1764,9 +1770,16 @@ int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LUT_LDS));
                 attr_set = true;
             }
-            hipLaunchKernelGGL((k_lutmatvec<MODE>), dim3(m.n_words / 8, (m.n_rows + BLOCK - 1) / BLOCK), dim3(BLOCK), LUT_LDS, st, m.M,
-                               m.n_rows, m.n_pad, m.n_k, vec, vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate,
-                               m.part, m.counters, getenv("HGX_LUT_ABL") ? atoi(getenv("HGX_LUT_ABL")) : 0);
+            if (g_ev_start) {
+                hipExtLaunchKernelGGL((k_lutmatvec<MODE>), dim3(m.n_words / 8, (m.n_rows + BLOCK - 1) / BLOCK), dim3(BLOCK), LUT_LDS, st,
+                                      g_ev_start, g_ev_stop, 0, m.M, m.n_rows, m.n_pad, m.n_k, vec, vec_pres, x_mode, count, q_in, pres_in,
+                                      len, y, pres_out, scal, gate, m.part, m.counters, 0);
+                g_ev_start = g_ev_stop = nullptr;
+            } else {
+                hipLaunchKernelGGL((k_lutmatvec<MODE>), dim3(m.n_words / 8, (m.n_rows + BLOCK - 1) / BLOCK), dim3(BLOCK), LUT_LDS, st, m.M,
+                                   m.n_rows, m.n_pad, m.n_k, vec, vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate,
+                                   m.part, m.counters, getenv("HGX_LUT_ABL") ? atoi(getenv("HGX_LUT_ABL")) : 0);
+            }
             return HGX_OK;
         }
     }
@@ -2205,22 +2218,27 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     }
     std::vector<Timed> timed;
     const int slot_rows = A <= 8 * BLOCK ? 0 : 1, slot_cols = C <= 8 * BLOCK ? 2 : 3;
-    // every event costs ~2.5 us of launch gap: only the first 8 ungated rows passes of a call are bracketed
-    int n_stamped = 0;
+    // timing sample: every 4th ungated rows pass of a call and the cols pass that follows it
+    int n_stamped = 0, n_rows_seen = 0;
     bool stamping = false;
     auto stamp = [&](int slot, bool begin, int gate) {
         if (!g_timing) return;
         if (begin) {
-            stamping = gate == 0 && n_stamped < 16;          // 8 rows + 8 cols passes
+            if (slot == slot_rows) {
+                stamping = gate == 0 && (n_rows_seen++ % 4) == 0;
+            } else {
+                stamping = gate == 0;                        // called with gate 0 only right after a timed rows pass
+            }
             if (!stamping) return;
             ++n_stamped;
             Timed t;
             t.a = pool_event();
             t.b = pool_event();
             t.slot = slot;
-            (void)hipEventRecord(t.a, st);
+            if (rows.M) { g_ev_start = t.a; g_ev_stop = t.b; }          // attached to the dispatch itself
+            else (void)hipEventRecord(t.a, st);
             timed.push_back(t);
-        } else if (stamping) (void)hipEventRecord(timed.back().b, st);
+        } else if (stamping && !rows.M) (void)hipEventRecord(timed.back().b, st);
     };
     // one application of the EM map: (vec, pres_v) -> (q_out, pres_out)
     auto next_prob = [&](const double *vec, const uint8_t *pres_v, int x_mode, double *q_out, uint8_t *pres_out, int gate) -> int {
