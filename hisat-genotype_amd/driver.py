@@ -39,15 +39,18 @@ def genotyping_locus(base_fname, locus_list, genotype_genome, ix_dir, only_locus
                   output_allele_counts)
 
 
-def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, **typing_opts):
+def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, ix_dir=None, **typing_opts):
     """Type independent (sample_id, gene, sam_text_or_path) tasks; rank `rank` of `world` handles its share
-    (deterministic greedy split, no communication).  `index` is the dict from indexio.load_index.
+    (deterministic greedy split, no communication).  `index` is the dict from indexio.load_index; with `ix_dir` the
+    packed loci come through the binary cache next to the index files (indexio.packed_locus).
     Returns {(sample_id, gene): LocusResult} for this rank's tasks."""
     from . import dist as hdist
     mine = hdist.shard(list(tasks), rank, world, weights)
     packed = {}
     out = {}
     for sample_id, gene, sam in mine:
+        if gene not in packed and ix_dir is not None:
+            packed[gene] = indexio.packed_locus(ix_dir, base_fname, gene, index)
         if gene not in packed:
             packed[gene] = PackedLocus.from_reference_dicts(gene, base_fname, index["refGenes"], index["Genes"],
                                                             index["Gene_names"], index["Gene_lengths"], index["refGene_loci"],

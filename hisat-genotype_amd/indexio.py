@@ -158,3 +158,26 @@ def load_index(ix_dir, base_fname):
     return dict(refGenes=refGenes, refGene_loci=refGene_loci, Genes=Genes, Gene_names=Gene_names, Gene_lengths=Gene_lengths,
                 Vars=Vars, Var_list=Var_list, Links=Links, partial_alleles=partial_alleles, alleles=set(alleles),
                 dbversion=dbversion)
+
+
+def packed_locus(ix_dir, base_fname, gene, index=None, use_cache=True):
+    """PackedLocus of `gene`, through the packed binary cache `<ix_dir>/<base_fname>.<gene>.hgx.npz`: the
+    cache is used when it is newer than every text file of the index, rebuilt (and rewritten, best effort) otherwise."""
+    from .locus import PackedLocus
+    full = os.path.join(ix_dir, base_fname)
+    cache = "%s.%s.hgx.npz" % (full, gene)
+    sources = [full + ext for ext in (".snp", ".link", ".locus", ".allele", ".partial", "_backbone.fa") if os.path.exists(full + ext)]
+    if use_cache and os.path.exists(cache) and all(os.path.getmtime(cache) >= os.path.getmtime(f) for f in sources):
+        try:
+            return PackedLocus.load_cache(cache)
+        except Exception:
+            pass                                  # stale or foreign file: rebuild below
+    ix = index if index is not None else load_index(ix_dir, base_fname)
+    pl = PackedLocus.from_reference_dicts(gene, base_fname, ix["refGenes"], ix["Genes"], ix["Gene_names"], ix["Gene_lengths"],
+                                          ix["refGene_loci"], ix["Vars"], ix["Var_list"], ix["Links"])
+    if use_cache:
+        try:
+            pl.save_cache(cache)
+        except OSError:
+            pass                                  # read-only index directory
+    return pl

@@ -119,11 +119,17 @@ class PackedLocus:
                           rank=rank, lengths=lengths,
                           names_pool=("\0".join(self.var_ids) + "\0").encode(), ins_pool=("\0".join(ins) + "\0").encode(),
                           bb=ref_seq.encode())
+        self._n_link_order = n_link_order
+        self._finish_init()
+
+    def _finish_init(self):
+        """Build the native locus (hgx_locus_create) from the packed arrays in self._keep."""
         k = self._keep
-        d = capi.LocusDesc(capi.BASE_KIND.get(base_fname, 3), len(ref_seq), k["bb"], V, capi.ptr(pos), capi.ptr(typ),
-                           capi.ptr(ln), capi.ptr(base), capi.ptr(linked), k["names_pool"], k["ins_pool"], A,
-                           capi.ptr(off), capi.ptr(k["flat"]), n_link_order, capi.ptr(link_order), len(ex),
-                           capi.ptr(k["ex"]), capi.ptr(lengths), capi.ptr(rank))
+        A, V = len(self.names), len(self.var_ids)
+        d = capi.LocusDesc(capi.BASE_KIND.get(self.base_fname, 3), len(self.ref_seq), k["bb"], V, capi.ptr(k["pos"]),
+                           capi.ptr(k["typ"]), capi.ptr(k["ln"]), capi.ptr(k["base"]), capi.ptr(k["linked"]), k["names_pool"],
+                           k["ins_pool"], A, capi.ptr(k["off"]), capi.ptr(k["flat"]), self._n_link_order,
+                           capi.ptr(k["link_order"]), len(k["ex"]), capi.ptr(k["ex"]), capi.ptr(k["lengths"]), capi.ptr(k["rank"]))
         h = C.c_void_p()
         capi.check(capi.lib().hgx_locus_create(C.byref(h), C.byref(d)))
         self.h = h
@@ -133,6 +139,41 @@ class PackedLocus:
         self.w64 = self.a_pad // 64
         self._tables = None
         self._index = None
+
+    # ---- packed binary cache -----------------------------------------------------------
+    CACHE_VERSION = 1
+
+    def save_cache(self, path):
+        """Write the packed form of this locus (everything hgx_locus_create consumes) as one .npz file: loading it skips
+        the text parsers and the per-allele / per-variant dict walks of the constructor."""
+        k = self._keep
+        np.savez_compressed(
+            path, version=np.int32(self.CACHE_VERSION), gene=np.array(self.gene), base_fname=np.array(self.base_fname),
+            ref_seq=np.frombuffer(k["bb"], np.uint8), names=np.array("\0".join(self.names)),
+            names_pool=np.frombuffer(k["names_pool"], np.uint8), ins_pool=np.frombuffer(k["ins_pool"], np.uint8),
+            n_link_order=np.int32(self._n_link_order),
+            **{n: k[n] for n in ("pos", "typ", "ln", "base", "linked", "off", "flat", "link_order", "ex", "rank", "lengths")})
+
+    @classmethod
+    def load_cache(cls, path):
+        z = np.load(path, allow_pickle=False)
+        if int(z["version"]) != cls.CACHE_VERSION:
+            raise ValueError("index cache %s has version %d, expected %d" % (path, int(z["version"]), cls.CACHE_VERSION))
+        self = cls.__new__(cls)
+        self.gene, self.base_fname = str(z["gene"]), str(z["base_fname"])
+        self.ref_seq = z["ref_seq"].tobytes().decode()
+        self.names = str(z["names"]).split("\0") if str(z["names"]) else []
+        self.aidx = {n: i for i, n in enumerate(self.names)}
+        names_pool = z["names_pool"].tobytes()
+        self.var_ids = names_pool.decode().split("\0")[:-1] if len(z["pos"]) else []
+        self.var_index = {vid: i for i, vid in enumerate(self.var_ids)}
+        self._keep = {n: np.ascontiguousarray(z[n]) for n in
+                      ("pos", "typ", "ln", "base", "linked", "off", "flat", "link_order", "ex", "rank", "lengths")}
+        self._keep.update(names_pool=names_pool, ins_pool=z["ins_pool"].tobytes(), bb=self.ref_seq.encode())
+        self.name_rank, self.allele_len = self._keep["rank"], self._keep["lengths"]
+        self._n_link_order = int(z["n_link_order"])
+        self._finish_init()
+        return self
 
     # ---- constructors -------------------------------------------------------------------------
     @classmethod

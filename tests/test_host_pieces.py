@@ -73,3 +73,29 @@ def test_piece_dedup_is_effective():
     batch = pl.batch_from_haplotypes(*tables.pieces_from_pairs(fx["pairs"], t["var_index"]))
     assert batch.n_refs > batch.n_pieces   # identical add_count arguments are stored once
     assert batch.pair_off[-1] == batch.n_refs
+
+
+def test_packed_index_cache_round_trip(tmp_path):
+    """PackedLocus.save_cache / load_cache (SURVEY 8f-1 "packed binary cache"): identical derived tables, alternatives and
+    front-end output, for an HLA-like locus with insertions and for a CODIS-like one."""
+    from hisatgenotype_amd import synth, locus as hl
+    for k, loc in enumerate((synth.make_hla_like_locus(n_alleles=200, n_vars=180, seed=8, insertion_frac=0.05),
+                             synth.make_str_like_locus(seed=3))):
+        pl = hl.PackedLocus.from_synth(loc)
+        path = str(tmp_path / ("locus%d.npz" % k))
+        pl.save_cache(path)
+        p2 = hl.PackedLocus.load_cache(path)
+        assert (p2.gene, p2.base_fname, p2.names, p2.var_ids, p2.ref_seq) == (pl.gene, pl.base_fname, pl.names, pl.var_ids, pl.ref_seq)
+        t1, t2 = pl.tables(), p2.tables()
+        assert all(np.array_equal(t1[x], t2[x]) for x in t1)
+        assert np.array_equal(pl.allele_len, p2.allele_len) and np.array_equal(pl.name_rank, p2.name_rank)
+        assert pl.alternatives_text() == p2.alternatives_text()
+        sample = synth.pick_sample(loc, 5)
+        if k == 0:
+            sam = synth.simulate_sam_fast(loc, sample, 300, err_rate=0.002, seed=9)
+        else:
+            sam = synth.sam_text(loc, synth.simulate_pairs(loc, sample, 150, read_len=100, frag_len=(250, 250), seed=9))
+        b1, b2 = pl.parse_sam(sam), p2.parse_sam(sam)
+        assert (b1.n_reads, b1.n_pairs, b1.n_pieces) == (b2.n_reads, b2.n_pairs, b2.n_pieces)
+        assert np.array_equal(b1.pieces, b2.pieces) and np.array_equal(b1.masks, b2.masks)
+        assert np.array_equal(b1.pair_off, b2.pair_off) and np.array_equal(b1.pair_ref, b2.pair_ref)

@@ -40,3 +40,25 @@ def test_packed_locus_from_index_files(tmp_path):
     for k in t1:
         assert np.array_equal(t1[k], t2[k]), k
     assert np.array_equal(p1.allele_len, p2.allele_len)
+
+
+def test_packed_locus_cache_next_to_index(tmp_path):
+    """indexio.packed_locus writes `<base>.<gene>.hgx.npz` on first use and serves the identical locus from it afterwards;
+    touching an index file invalidates it."""
+    import os, time
+    import numpy as np
+    from hisatgenotype_amd import synth, indexio
+    loc = synth.make_hla_like_locus(n_alleles=120, n_vars=100, seed=21)
+    synth.write_index([loc], str(tmp_path), "hla")
+    gene = loc.gene
+    a = indexio.packed_locus(str(tmp_path), "hla", gene)
+    cache = os.path.join(str(tmp_path), "hla.%s.hgx.npz" % gene)
+    assert os.path.exists(cache)
+    b = indexio.packed_locus(str(tmp_path), "hla", gene)
+    assert a.names == b.names and a.var_ids == b.var_ids
+    ta, tb = a.tables(), b.tables()
+    assert all(np.array_equal(ta[k], tb[k]) for k in ta)
+    m0 = os.path.getmtime(cache)
+    os.utime(os.path.join(str(tmp_path), "hla.snp"), (time.time() + 5, time.time() + 5))   # index changed after the cache was written
+    indexio.packed_locus(str(tmp_path), "hla", gene)
+    assert os.path.getmtime(cache) >= m0          # rebuilt from the text files and rewritten
