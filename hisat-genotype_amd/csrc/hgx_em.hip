@@ -1223,6 +1223,37 @@ constexpr int LUT_G = 64;                  // groups per slab
 constexpr int LUT_SLAB = LUT_G * 8;        // elements per slab
 constexpr size_t LUT_LDS = (size_t)(LUT_G * 256 + LUT_SLAB) * 8;
 
+// 256 subset sums of each of the 64 groups of xs[] (see k_lutmatvec)
+__device__ __forceinline__ void lut_build(const double *xs, double *T, int tid) {
+    const int g = tid >> 4, lo = tid & 15;
+    const double x0 = xs[8 * g], x1 = xs[8 * g + 1], x2 = xs[8 * g + 2], x3 = xs[8 * g + 3];
+    const double x4 = xs[8 * g + 4], x5 = xs[8 * g + 5], x6 = xs[8 * g + 6], x7 = xs[8 * g + 7];
+    const double L = (((lo & 1 ? x0 : 0.0) + (lo & 2 ? x1 : 0.0)) + (lo & 4 ? x2 : 0.0)) + (lo & 8 ? x3 : 0.0);
+    double *Tg = T + g * 256 + lo;
+#pragma unroll
+    for (int hi = 0; hi < 16; ++hi) {
+        const double H = (((hi & 1 ? x4 : 0.0) + (hi & 2 ? x5 : 0.0)) + (hi & 4 ? x6 : 0.0)) + (hi & 8 ? x7 : 0.0);
+        Tg[hi * 16] = L + H;
+    }
+}
+__device__ __forceinline__ double lut_row(const double *T, const uint64_t (&w)[8]) {
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (__ballot(w[i] != 0ull) == 0ull) continue;
+        const uint32_t wl = (uint32_t)w[i], wh = (uint32_t)(w[i] >> 32);
+        const double *Ti = T + i * 8 * 256;
+        acc += Ti[0 * 256 + (wl & 255u)];
+        acc += Ti[1 * 256 + ((wl >> 8) & 255u)];
+        acc += Ti[2 * 256 + ((wl >> 16) & 255u)];
+        acc += Ti[3 * 256 + (wl >> 24)];
+        acc += Ti[4 * 256 + (wh & 255u)];
+        acc += Ti[5 * 256 + ((wh >> 8) & 255u)];
+        acc += Ti[6 * 256 + ((wh >> 16) & 255u)];
+        acc += Ti[7 * 256 + (wh >> 24)];
+    }
+    return acc;
+}
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_lutmatvec(const uint64_t *__restrict__ M, int N, int Npad, int n_k,
                                                      const double *__restrict__ vec, const uint8_t *__restrict__ vec_pres,
@@ -1230,7 +1261,12 @@ __global__ __launch_bounds__(BLOCK) void k_lutmatvec(const uint64_t *__restrict_
                                                      const double *__restrict__ q_in, const uint8_t *__restrict__ pres_in,
                                                      const double *__restrict__ len, double *__restrict__ y,
                                                      uint8_t *__restrict__ pres_out, double *__restrict__ scal, int gate,
-                                                     double *__restrict__ part, unsigned *__restrict__ counters, int abl) {
+                                                     double *__restrict__ part, unsigned *__restrict__ counters,
+                                                     const double *__restrict__ src_part, int src_slabs, int src_pad,
+                                                     const int64_t *__restrict__ src_count, int defer_combine) {
+    // src_part   (COLS): the rows pass left its slab partials uncombined (defer_combine); this kernel's prologue adds them
+    //            for the 512 classes of its slab -- w_c = n_c / sum of the partials, in slab order -- instead of reading w
+    // defer_combine (ROWS): store the slab partials and stop: no ticket, no last-workgroup tail (~4 us of the launch)
     extern __shared__ double lds[];
     double *T = lds;                        // [LUT_G][256]
     double *xs = lds + LUT_G * 256;         // [LUT_SLAB]
@@ -1251,7 +1287,17 @@ __global__ __launch_bounds__(BLOCK) void k_lutmatvec(const uint64_t *__restrict_
         const int e = slab * LUT_SLAB + tid;
         if (e < n_k) {
             if (MODE == MODE_ROWS) xv = (x_mode == 2) ? 1.0 : (vec_pres[e] ? vec[e] : 0.0);
-            else xv = vec[e];
+            else if (src_part) {
+                double sp = 0.0;
+                for (int k0 = 0; k0 < src_slabs; k0 += 16) {      // sixteen loads in flight, added in slab order
+                    double v[16];
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) v[k] = k0 + k < src_slabs ? src_part[(size_t)(k0 + k) * src_pad + e] : 0.0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) sp += v[k];
+                }
+                xv = sp > 0.0 ? (double)src_count[e] / sp : 0.0;
+            } else xv = vec[e];
         }
     }
     // epilogue operands of my row (only the chunk's last workgroup uses them; asking now takes them off its critical path)
@@ -1286,35 +1332,12 @@ __global__ __launch_bounds__(BLOCK) void k_lutmatvec(const uint64_t *__restrict_
     }
     if (tid < LUT_SLAB) xs[tid] = xv;
     __syncthreads();
-    if (!(abl & 2))
-    {   // subset sums: thread = (group, low nibble); the 16 high nibbles are unrolled
-        const int g = tid >> 4, lo = tid & 15;
-        const double x0 = xs[8 * g], x1 = xs[8 * g + 1], x2 = xs[8 * g + 2], x3 = xs[8 * g + 3];
-        const double x4 = xs[8 * g + 4], x5 = xs[8 * g + 5], x6 = xs[8 * g + 6], x7 = xs[8 * g + 7];
-        const double L = (((lo & 1 ? x0 : 0.0) + (lo & 2 ? x1 : 0.0)) + (lo & 4 ? x2 : 0.0)) + (lo & 8 ? x3 : 0.0);
-        double *Tg = T + g * 256 + lo;
-#pragma unroll
-        for (int hi = 0; hi < 16; ++hi) {
-            const double H = (((hi & 1 ? x4 : 0.0) + (hi & 2 ? x5 : 0.0)) + (hi & 4 ? x6 : 0.0)) + (hi & 8 ? x7 : 0.0);
-            Tg[hi * 16] = L + H;
-        }
-    }
+    lut_build(xs, T, tid);              // subset sums: thread = (group, low nibble); the 16 high nibbles are unrolled
     __syncthreads();
-    double acc = 0.0;
-    if (!(abl & 4))
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (__ballot(w[i] != 0ull) == 0ull) continue;
-        const uint32_t wl = (uint32_t)w[i], wh = (uint32_t)(w[i] >> 32);
-        const double *Ti = T + i * 8 * 256;
-        acc += Ti[0 * 256 + (wl & 255u)];
-        acc += Ti[1 * 256 + ((wl >> 8) & 255u)];
-        acc += Ti[2 * 256 + ((wl >> 16) & 255u)];
-        acc += Ti[3 * 256 + (wl >> 24)];
-        acc += Ti[4 * 256 + (wh & 255u)];
-        acc += Ti[5 * 256 + ((wh >> 8) & 255u)];
-        acc += Ti[6 * 256 + ((wh >> 16) & 255u)];
-        acc += Ti[7 * 256 + (wh >> 24)];
+    const double acc = lut_row(T, w);
+    if (MODE == MODE_ROWS && defer_combine) {
+        if (n < Npad) part[(size_t)slab * Npad + n] = acc;       // the cols pass adds the slabs (kernel boundary = visibility)
+        return;
     }
     // ---- the last workgroup of this row chunk to finish adds the slabs ------------------------------------------
     // No device-wide fence (a release fence at agent scope writes the whole L2 back: ~100 us measured).  Instead the
@@ -1324,7 +1347,6 @@ __global__ __launch_bounds__(BLOCK) void k_lutmatvec(const uint64_t *__restrict_
     if (n < Npad)
         __hip_atomic_store((unsigned long long *)&part[(size_t)slab * Npad + n], (unsigned long long)__double_as_longlong(acc),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (abl & 1) return;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -1423,37 +1445,6 @@ __device__ __forceinline__ bool pk_barrier(const PkArgs &a, unsigned &target, in
     return *s_abort != 0;
 }
 
-// 256 subset sums of each of the 64 groups of xs[] (see k_lutmatvec)
-__device__ __forceinline__ void lut_build(const double *xs, double *T, int tid) {
-    const int g = tid >> 4, lo = tid & 15;
-    const double x0 = xs[8 * g], x1 = xs[8 * g + 1], x2 = xs[8 * g + 2], x3 = xs[8 * g + 3];
-    const double x4 = xs[8 * g + 4], x5 = xs[8 * g + 5], x6 = xs[8 * g + 6], x7 = xs[8 * g + 7];
-    const double L = (((lo & 1 ? x0 : 0.0) + (lo & 2 ? x1 : 0.0)) + (lo & 4 ? x2 : 0.0)) + (lo & 8 ? x3 : 0.0);
-    double *Tg = T + g * 256 + lo;
-#pragma unroll
-    for (int hi = 0; hi < 16; ++hi) {
-        const double H = (((hi & 1 ? x4 : 0.0) + (hi & 2 ? x5 : 0.0)) + (hi & 4 ? x6 : 0.0)) + (hi & 8 ? x7 : 0.0);
-        Tg[hi * 16] = L + H;
-    }
-}
-__device__ __forceinline__ double lut_row(const double *T, const uint64_t (&w)[8]) {
-    double acc = 0.0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (__ballot(w[i] != 0ull) == 0ull) continue;
-        const uint32_t wl = (uint32_t)w[i], wh = (uint32_t)(w[i] >> 32);
-        const double *Ti = T + i * 8 * 256;
-        acc += Ti[0 * 256 + (wl & 255u)];
-        acc += Ti[1 * 256 + ((wl >> 8) & 255u)];
-        acc += Ti[2 * 256 + ((wl >> 16) & 255u)];
-        acc += Ti[3 * 256 + (wl >> 24)];
-        acc += Ti[4 * 256 + (wh & 255u)];
-        acc += Ti[5 * 256 + ((wh >> 8) & 255u)];
-        acc += Ti[6 * 256 + ((wh >> 16) & 255u)];
-        acc += Ti[7 * 256 + (wh >> 24)];
-    }
-    return acc;
-}
 // slab partials of one row, added in slab order (eight loads in flight)
 __device__ __forceinline__ double pk_sum_part(const double *part, int n_slabs, size_t stride, int n) {
     double t = 0.0;
@@ -1717,6 +1708,11 @@ struct MatVec {
     int n_pad = 0;
     double *part = nullptr;         // [n_words / 8][n_pad] slab partials
     unsigned *counters = nullptr;   // [ceil(n_rows / 1024)], zero between launches
+    // table-lookup EM only: the rows pass leaves its partials for the cols pass to add (see k_lutmatvec)
+    int defer_combine = 0;
+    const double *src_part = nullptr;
+    int src_slabs = 0, src_pad = 0;
+    const int64_t *src_count = nullptr;
 };
 
 int g_backend = 0;                  // 0 auto, 1 VALU (EXEC-masked FP64), 2 MFMA (int8 fixed point), 3 table lookup
@@ -1773,12 +1769,13 @@ int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint
             if (g_ev_start) {
                 hipExtLaunchKernelGGL((k_lutmatvec<MODE>), dim3(m.n_words / 8, (m.n_rows + BLOCK - 1) / BLOCK), dim3(BLOCK), LUT_LDS, st,
                                       g_ev_start, g_ev_stop, 0, m.M, m.n_rows, m.n_pad, m.n_k, vec, vec_pres, x_mode, count, q_in, pres_in,
-                                      len, y, pres_out, scal, gate, m.part, m.counters, 0);
+                                      len, y, pres_out, scal, gate, m.part, m.counters, m.src_part, m.src_slabs, m.src_pad, m.src_count,
+                                      m.defer_combine);
                 g_ev_start = g_ev_stop = nullptr;
             } else {
                 hipLaunchKernelGGL((k_lutmatvec<MODE>), dim3(m.n_words / 8, (m.n_rows + BLOCK - 1) / BLOCK), dim3(BLOCK), LUT_LDS, st, m.M,
                                    m.n_rows, m.n_pad, m.n_k, vec, vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate,
-                                   m.part, m.counters, getenv("HGX_LUT_ABL") ? atoi(getenv("HGX_LUT_ABL")) : 0);
+                                   m.part, m.counters, m.src_part, m.src_slabs, m.src_pad, m.src_count, m.defer_combine);
             }
             return HGX_OK;
         }
@@ -2091,7 +2088,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         cols.P = c->d_pcol; cols.n_super = c->c64 / 4;
     }
 
-    DevBuf b_part, b_cnt;
+    DevBuf b_part, b_part_c, b_cnt;
     if (g_backend == 0 || g_backend == 3) {
         // table-lookup kernels: word-transposed copies of both matrices, built once per class set
         const int Cp = c->c64 * 64;
@@ -2102,12 +2099,17 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             hipLaunchKernelGGL(k_word_transpose, dim3((w64c + 31) / 32, (Cp + 31) / 32), dim3(256), 0, st, c->d_bitsC, Cp, w64c, c->d_wrow);
             hipLaunchKernelGGL(k_word_transpose, dim3((c->c64 + 31) / 32, (A + 31) / 32), dim3(256), 0, st, c->d_bitsTC, A, c->c64, c->d_wcol);
         }
-        const size_t n_part = std::max((size_t)(w64c / 8) * Cp, (size_t)(c->c64 / 8) * A);
+        const size_t n_part_r = (size_t)(w64c / 8) * Cp, n_part_c = (size_t)(c->c64 / 8) * A;
         const size_t n_cnt = (size_t)std::max((C + BLOCK - 1) / BLOCK, (A + BLOCK - 1) / BLOCK);
-        ALLOC(b_part, n_part * 8); ALLOC(b_cnt, n_cnt * 4);
+        ALLOC(b_part, std::max(n_part_r, n_part_c) * 8); ALLOC(b_part_c, n_part_c * 8); ALLOC(b_cnt, n_cnt * 4);
         HIPCHK(hipMemsetAsync(b_cnt.p, 0, n_cnt * 4, st));
         rows.M = c->d_wrow; rows.n_pad = Cp; rows.part = b_part.as<double>(); rows.counters = b_cnt.as<unsigned>();
-        cols.M = c->d_wcol; cols.n_pad = A; cols.part = b_part.as<double>(); cols.counters = b_cnt.as<unsigned>();
+        cols.M = c->d_wcol; cols.n_pad = A; cols.part = b_part_c.as<double>(); cols.counters = b_cnt.as<unsigned>();
+        if (!getenv("HGX_EM_PERSIST") && !getenv("HGX_EM_NO_DEFER")) {
+            // the rows pass stops at its slab partials; the cols pass turns them into w_c in its prologue
+            rows.defer_combine = 1;
+            cols.src_part = rows.part; cols.src_slabs = w64c / 8; cols.src_pad = Cp; cols.src_count = c->d_count;
+        }
     }
     if (rows.M && getenv("HGX_EM_PERSIST")) {
         // ---- persistent path: whole iterations per launch (k_em_persist).  Opt-in: measured on MI355X it is not faster
