@@ -1387,6 +1387,167 @@ __global__ __launch_bounds__(BLOCK) void k_lutmatvec(const uint64_t *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Rows pass with the preceding VECTOR step folded into its prologue (table-lookup EM, vectors <= 8192 elements).
+// SQUAREM (k_em_squarem) and the advance step (k_em_advance) are single-workgroup kernels of ~10 us each -- launch floor
+// plus four dependent round trips for 4 608 elements -- sitting between the mat-vec launches of every iteration.
+// Here EVERY workgroup of the following rows pass recomputes the step's reductions itself (same element-to-thread
+// map and summation order as the standalone kernels, so the same bits) while its matrix words are in flight:
+//   FM = 0: SQUAREM on (p, q1, q2) -> x = extrapolated q2' (raw); no extrapolation / key error -> the map is skipped
+//   FM = 1: prob_diff + pruning on (p, q1 | q3) -> x = new p (raw); converged -> nothing else runs
+// The chunk-0 workgroup of each slab writes its 512 elements of the step's output vector (a SEPARATE buffer: the
+// other workgroups are still reading the inputs), workgroup (0,0) writes the next state words to scal_out -- the
+// launch itself only reads scal_in, so no workgroup can observe a half-updated state.
+// ------------------------------------------------------------------------------------------------------------
+struct FuseArgs {
+    const double *q1, *qb;            // q1 and (FM 0: q2 | FM 1: q3)
+    const uint8_t *pr1, *prb;
+    double *out;                      // FM 0: q2' | FM 1: new p
+    uint8_t *out_pres;
+    const double *scal_in;
+    double *scal_out;
+    int remove_low;
+};
+
+template <int FM>
+__global__ __launch_bounds__(BLOCK) void k_lut_rows_fused(const uint64_t *__restrict__ M, int Npad, int n_k,
+                                                          const double *__restrict__ p, const uint8_t *__restrict__ pr,
+                                                          FuseArgs fz, double *__restrict__ part) {
+    extern __shared__ double lds[];
+    double *T = lds;
+    double *xs = lds + LUT_G * 256;
+    __shared__ double shf[3][NWAVE];
+    __shared__ double shm[NWAVE];
+    const int tid = threadIdx.x;
+    const int slab = blockIdx.x, chunk = blockIdx.y;
+    const int n = chunk * BLOCK + tid;
+    const double st_done = fz.scal_in[S_DONE], st_flag = fz.scal_in[S_FLAG], it_d = fz.scal_in[S_ITER];
+    uint64_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = n < Npad ? M[(size_t)(slab * 8 + i) * Npad + n] : 0ull;
+    // the whole vectors, element tid + 1024 k in register k (as in k_em_squarem / k_em_advance)
+    double vp[EPT], v1[EPT], vb[EPT];
+    uint8_t f0[EPT], f1[EPT], fb[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+        const int a = tid + BLOCK * k;
+        const bool in = a < n_k;
+        f0[k] = in ? pr[a] : 0; f1[k] = in ? fz.pr1[a] : 0; fb[k] = in ? fz.prb[a] : 0;
+        vp[k] = in ? p[a] : 0.0; v1[k] = in ? fz.q1[a] : 0.0; vb[k] = in ? fz.qb[a] : 0.0;
+    }
+    // my element of this slab
+    const int e = slab * LUT_SLAB + tid;
+    const bool e_in = tid < LUT_SLAB && e < n_k;
+    const double e0 = e_in ? p[e] : 0.0, e1 = e_in ? fz.q1[e] : 0.0, eb = e_in ? fz.qb[e] : 0.0;
+    const bool g0 = e_in && pr[e], g1 = e_in && fz.pr1[e], gb = e_in && fz.prb[e];
+    const bool lead = slab == 0 && chunk == 0 && tid == 0;
+    auto carry_state = [&]() {
+        for (int i = 0; i < S_N; ++i) fz.scal_out[i] = fz.scal_in[i];
+    };
+    if (st_done != 0.0) {
+        // already finished: carry the state words -- and, for the advance form, the estimate -- into the buffers the host
+        // switches to after every fused launch
+        if (lead) carry_state();
+        if (FM == 1 && chunk == 0 && e_in) { fz.out[e] = e0; fz.out_pres[e] = g0 ? 1 : 0; }
+        return;
+    }
+    double xv = 0.0;
+    if (FM == 0) {
+        // ---- SQUAREM (common:1361-1380), arithmetic of k_em_squarem ----
+        double red[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) { if (f1[k]) red[0] += v1[k]; if (fb[k]) red[1] += vb[k]; }
+        block_sum_n<2>(red, shf);
+        const double tot1 = red[0], tot2 = red[1];
+        double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            if (!f0[k]) continue;
+            if (!f1[k] || !fb[k]) { acc[2] = 1.0; continue; }
+            const double p1 = v1[k] / tot1, p2 = vb[k] / tot2;
+            const double r = p1 - vp[k];
+            const double v = p2 - p1 - r;
+            acc[0] += r * r;
+            acc[1] += v * v;
+        }
+        block_sum_n<3>(acc, shf);
+        const double tsr = acc[0], tsv = acc[1], tkey = acc[2];
+        const bool ext = tsv > 0.0 && tkey == 0.0;
+        if (lead) {
+            carry_state();
+            fz.scal_out[S_FLAG] = ext ? 1.0 : 0.0;
+            if (tkey != 0.0) { fz.scal_out[S_KEYERR] = 1.0; fz.scal_out[S_DONE] = 1.0; }
+            fz.scal_out[S_TOT_A] = 1.0;
+        }
+        if (!ext) return;                                   // the third map is skipped (or the EM stops on the key error)
+        const double g = -sqrt(tsr / tsv);
+        double val = eb;
+        bool present = gb;
+        if (g0) {
+            const double p1 = e1 / tot1, p2 = eb / tot2;
+            const double r = p1 - e0;
+            const double v = p2 - p1 - r;
+            val = fmax(0.0, e0 - 2 * g * r + g * g * v);
+            present = true;
+        }
+        xv = present ? val : 0.0;
+        if (chunk == 0 && e_in) { fz.out[e] = val; fz.out_pres[e] = present ? 1 : 0; }
+    } else {
+        // ---- prob_diff (common:1272-1279), pruning (common:1338-1346), stopping rule (common:1351): k_em_advance ----
+        const bool ext = st_flag != 0.0;
+        double s1[1] = {0.0};
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) { const bool pr_ = ext ? fb[k] : f1[k]; if (pr_) s1[0] += ext ? vb[k] : v1[k]; }
+        block_sum_n<1>(s1, shf);
+        const double tot = s1[0];
+        double d[1] = {0.0}, mx = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const bool an = ext ? fb[k] : f1[k];
+            const double pn = an ? (ext ? vb[k] : v1[k]) / tot : 0.0;
+            if (f0[k]) d[0] += an ? fabs(vp[k] - pn) : vp[k];
+            if (an) mx = fmax(mx, pn);
+        }
+        const double tm = block_max(mx, shm);
+        block_sum_n<1>(d, shf);
+        const double td = d[0];
+        const int iter = (int)it_d;
+        const bool prune = fz.remove_low && iter >= 10;
+        double kept[1] = {0.0};
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const bool an = ext ? fb[k] : f1[k];
+            const double pn = an ? (ext ? vb[k] : v1[k]) / tot : 0.0;
+            bool keep = an;
+            if (prune && keep) keep = pn >= tm / 10.0;
+            if (keep) kept[0] += 1.0;
+        }
+        block_sum_n<1>(kept, shf);
+        const bool done = !(td > 0.0001) || iter + 1 >= 1000;
+        if (lead) {
+            carry_state();
+            fz.scal_out[S_NPRES] = kept[0];
+            fz.scal_out[S_DIFF] = td;
+            fz.scal_out[S_ITER] = (double)(iter + 1);
+            if (done) fz.scal_out[S_DONE] = 1.0;
+            fz.scal_out[S_TOT_A] = 1.0;
+        }
+        const bool an = ext ? gb : g1;
+        const double pn = an ? (ext ? eb : e1) / tot : 0.0;
+        bool keep = an;
+        if (prune && keep) keep = pn >= tm / 10.0;
+        xv = keep ? pn : 0.0;
+        if (chunk == 0 && e_in) { fz.out[e] = keep ? pn : 0.0; fz.out_pres[e] = keep ? 1 : 0; }
+        if (done) return;                                   // the new estimate is written; nothing else runs
+    }
+    if (tid < LUT_SLAB) xs[tid] = xv;
+    __syncthreads();
+    lut_build(xs, T, tid);
+    __syncthreads();
+    const double acc2 = lut_row(T, w);
+    if (n < Npad) part[(size_t)slab * Npad + n] = acc2;      // the cols pass adds the slabs
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Persistent EM (opt-in, HGX_EM_PERSIST=1; see the measurement note in hgx_em).  With the table-lookup mat-vec a whole
 // SQUAREM iteration is ~50 us of work spread over eight launches.  k_em_persist keeps one workgroup per CU resident and runs
 // `n_iters` complete iterations (and optionally the initial estimate) in ONE launch:
@@ -2263,6 +2424,32 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     double tail_failed_at = 1e300;
     bool tail_done = false;
     const bool use_tail = !getenv("HGX_EM_NO_TAIL");
+    // ---- fused vector steps (k_lut_rows_fused): ping-pong estimate, extrapolated vector and state words -----------
+    const bool fuse = rows.defer_combine && A <= EPT * BLOCK && !getenv("HGX_EM_NO_FUSE");
+    DevBuf b_palt, b_pralt, b_q2x, b_prx, b_scal2;
+    double *p_alt = nullptr, *q2x = nullptr, *scal_alt = nullptr;
+    uint8_t *pr_alt = nullptr, *prx = nullptr;
+    if (fuse) {
+        ALLOC(b_palt, A * 8); ALLOC(b_pralt, A); ALLOC(b_q2x, A * 8); ALLOC(b_prx, A); ALLOC(b_scal2, S_N * 8);
+        p_alt = b_palt.as<double>(); pr_alt = b_pralt.as<uint8_t>(); q2x = b_q2x.as<double>(); prx = b_prx.as<uint8_t>();
+        scal_alt = b_scal2.as<double>();
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut_rows_fused<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LUT_LDS));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut_rows_fused<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)LUT_LDS));
+            attr_set = true;
+        }
+    }
+    auto rows_fused = [&](int fm, const double *qb, const uint8_t *prb, double *out_v, uint8_t *out_p) -> int {
+        FuseArgs fz{q1, qb, pr1, prb, out_v, out_p, scal, scal_alt, remove_low ? 1 : 0};
+        const dim3 grid(rows.n_words / 8, (rows.n_rows + BLOCK - 1) / BLOCK);
+        if (fm == 0) hipLaunchKernelGGL(k_lut_rows_fused<0>, grid, dim3(BLOCK), LUT_LDS, st, rows.M, rows.n_pad, A, p, pr, fz, rows.part);
+        else hipLaunchKernelGGL(k_lut_rows_fused<1>, grid, dim3(BLOCK), LUT_LDS, st, rows.M, rows.n_pad, A, p, pr, fz, rows.part);
+        std::swap(scal, scal_alt);           // every later launch reads the state this one wrote
+        return HGX_OK;
+    };
     for (;;) {
         // with pruning, look at the survivor count right after the first pruning iteration (iteration index 10).
         // A first batch of 4 tells whether the EM is still far from converged (diff 10x above the stopping rule); if so the
@@ -2274,6 +2461,23 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         }
         launched_iters += nb;
         for (int b = 0; b < nb; ++b) {
+            if (fuse) {
+                // six launches per iteration: SQUAREM and the advance step ride in the prologue of the rows pass that follows
+                if (b == 0) {
+                    if ((rc = next_prob(p, pr, 0, q1, pr1, 0))) return rc;
+                } else {
+                    if ((rc = rows_fused(1, q3, pr3, p_alt, pr_alt))) return rc;      // advance of the previous iteration + rows(p)
+                    std::swap(p, p_alt);
+                    std::swap(pr, pr_alt);
+                    if ((rc = launch_matvec<MODE_COLS>(cols, st, wc, nullptr, 0, nullptr, p, pr, d_len, q1, pr1, scal, 0))) return rc;
+                }
+                if ((rc = next_prob(q1, pr1, 1, q2, pr2, 0))) return rc;
+                if ((rc = rows_fused(0, q2, pr2, q2x, prx))) return rc;               // SQUAREM + rows(q2')
+                if ((rc = launch_matvec<MODE_COLS>(cols, st, wc, nullptr, 0, nullptr, q2x, prx, d_len, q3, pr3, scal, 1))) return rc;
+                if (b == nb - 1)   // the host looks at the state after the batch: close it with the standalone step
+                    hipLaunchKernelGGL(k_em_advance, dim3(1), dim3(BLOCK), 0, st, p, pr, q1, pr1, q3, pr3, A, remove_low ? 1 : 0, scal);
+                continue;
+            }
             if ((rc = next_prob(p, pr, 0, q1, pr1, 0))) return rc;        // Gene_prob_next  (p is used raw)
             if ((rc = next_prob(q1, pr1, 1, q2, pr2, 0))) return rc;      // Gene_prob_next2 (normalised on the fly)
             hipLaunchKernelGGL(k_em_squarem, dim3(1), dim3(BLOCK), 0, st, p, pr, q1, pr1, q2, pr2, A, scal);
