@@ -263,6 +263,53 @@ def test_em_ordered_and_first_classes_match_counts_pass(orc, name):
         assert np.all(first[~present] == -1)
 
 
+def test_more_than_8192_alleles(orc):
+    """9 100 alleles (HLA-B today): three 64-word groups per class row (the KW = 4 pair kernel), EM vectors longer than
+    the register-cached 8 192 (strided SQUAREM / advance kernels, no fused prologue, no single-workgroup EM).  End to end
+    through the front-end against the C oracle: class rows bit-exact, dedup exact, EM with the same iteration count."""
+    from hisatgenotype_amd import synth
+    loc = synth.make_hla_like_locus(n_alleles=9100, n_vars=2300, seed=31)
+    t = tables.oracle_tables(loc)
+    pl = hl.PackedLocus.from_synth(loc)
+    assert pl.a_pad > 8192
+    sample = synth.pick_sample(loc, 8)
+    sam = synth.simulate_sam_fast(loc, sample, 4000, err_rate=0.002, seed=13)
+    import pyref
+    rl = pyref.RefLocus(loc)
+    rl.score = False
+    fe = rl.run(sam)
+    arrs = tables.pieces_from_pairs(fe["pairs"], t["var_index"])
+    L = orc.make_locus(t)
+    eb, gb, gc, fp = orc.score_pairs(L, t["exon_keys"], t["gene_keys"], *arrs)
+    batch = pl.parse_sam(sam)
+    assert batch.n_pairs == len(fe["pairs"])
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    A = t["n_alleles"]
+    w = (A + 63) // 64
+    assert np.array_equal(bufs.gene_bits.to_host()[:batch.n_pairs, :w], gb)
+    assert np.array_equal(bufs.exon_bits.to_host()[:batch.n_pairs, :w], eb)
+    cl = engine.Classes.dedup(bufs.exon_bits, batch.n_pairs, pl.a_pad, hashes=bufs.exon_hash)
+    ub, uc, fr = orc.dedup(eb)
+    hb, hc, hf = cl.to_host()
+    assert np.array_equal(hb[:, :w], ub) and np.array_equal(hc, uc) and np.array_equal(hf, fr)
+    cnt, _ = engine.Classes.dedup(bufs.gene_bits, batch.n_pairs, pl.a_pad, hashes=bufs.gene_hash).allele_counts()
+    assert np.array_equal(cnt[:A], gc)
+    classes = []
+    for row in ub:
+        bits = np.unpackbits(row.view(np.uint8), bitorder="little")
+        classes.append(sorted(np.nonzero(bits)[0].tolist(), key=lambda a: pl.name_rank[a]))
+    for low in (True, False):
+        oa, op, it = orc.single_abundance(A, classes, uc, low, None)
+        prob, git = cl.em(A, low, None)
+        assert git == it
+        exp = np.full(A, -1.0)
+        exp[oa] = op
+        assert np.array_equal(prob < 0, exp < 0)
+        assert np.max(np.abs(prob - exp)) <= 1e-9
+
+
 def test_empty_and_degenerate_inputs(orc):
     """Zero pairs, pairs without pieces, and a locus whose exon level has no representatives."""
     from hisatgenotype_amd import synth
