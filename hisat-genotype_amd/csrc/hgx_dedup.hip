@@ -225,25 +225,36 @@ __global__ void k_ht_finalize(const unsigned long long *__restrict__ keys, const
     out_first[c] = (int64_t)first[s];
     out_count[c] = (int64_t)cnt[s];
 }
+// Four rows per wavefront, their dependent loads (slot -> first row of the class -> row words) issued level by level: with one
+// row per wave the kernel is a chain of three memory round trips per row and runs at a quarter of the bandwidth.
 __global__ __launch_bounds__(256) void k_verify_ht(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
                                                    const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ first, long n,
                                                    int *__restrict__ bad) {
+    constexpr int R = 4;
     const int lane = threadIdx.x & 63;
-    const long r = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (r >= n) return;
-    const uint32_t sl = slot_of[r];
-    if (sl == HT_NONE) return;
-    const uint32_t h = first[sl];
-    if (h == (uint32_t)r) return;
+    const long r0 = (((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * R;
+    if (r0 >= n) return;
+    uint32_t sl[R], h[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) sl[k] = r0 + k < n ? slot_of[r0 + k] : HT_NONE;
+#pragma unroll
+    for (int k = 0; k < R; ++k) h[k] = sl[k] != HT_NONE ? first[sl[k]] : 0u;
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    const u64x2 *a = (const u64x2 *)(rows + (size_t)r * w64);
-    const u64x2 *b = (const u64x2 *)(rows + (size_t)h * w64);
     const u64x2 *m = (const u64x2 *)mask;
     bool diff = false;
     for (int w = lane; w < w64 / 2; w += 64) {
-        u64x2 x = a[w], y = b[w];
-        if (mask) { x &= m[w]; y &= m[w]; }
-        diff = diff || x.x != y.x || x.y != y.y;
+        u64x2 x[R], y[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            const bool live = sl[k] != HT_NONE && h[k] != (uint32_t)(r0 + k);
+            x[k] = live ? ((const u64x2 *)(rows + (size_t)(r0 + k) * w64))[w] : u64x2{0, 0};
+            y[k] = live ? ((const u64x2 *)(rows + (size_t)h[k] * w64))[w] : u64x2{0, 0};
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) {
+            if (mask) { x[k] &= m[w]; y[k] &= m[w]; }
+            diff = diff || x[k].x != y[k].x || x[k].y != y[k].y;
+        }
     }
     if (__any(diff) && lane == 0) atomicOr(bad, 1);
 }
@@ -298,7 +309,7 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     hipLaunchKernelGGL(k_ht_meta, dim3(1), dim3(1), 0, st, b_rank.as<uint32_t>() + (n - 1), b_flag.as<uint32_t>() + (n - 1),
                        b_meta.as<uint32_t>());
     // the exact check does not need the class count: queue it before the D2H that sizes the output
-    hipLaunchKernelGGL(k_verify_ht, dim3(nblk(n, 4)), dim3(256), 0, st, rows, w64, and_mask, b_slot.as<uint32_t>(),
+    hipLaunchKernelGGL(k_verify_ht, dim3(nblk((n + 3) / 4, 4)), dim3(256), 0, st, rows, w64, and_mask, b_slot.as<uint32_t>(),
                        b_first.as<uint32_t>(), n, b_meta.as<int>());
     uint32_t meta[4] = {0, 0, 0, 0};
     // Small inputs (the hand-off dedup: a few thousand gene classes) size the output for the worst case and finish in
