@@ -310,6 +310,38 @@ def test_more_than_8192_alleles(orc):
         assert np.max(np.abs(prob - exp)) <= 1e-9
 
 
+@pytest.mark.parametrize("n_rows", [3000, 70000])
+def test_forged_hash_collision_is_detected(orc, n_rows):
+    """The exact verify pass: two DIFFERENT rows given the same 64-bit key must be reported (HGX_ECOLLISION), never merged --
+    in the hash-table form (one-round-trip and two-round-trip sizes) and in the radix-sort form; honest keys pass."""
+    import os
+    from hisatgenotype_amd import capi
+    a_pad = 1024
+    w64 = a_pad // 64
+    rng = np.random.RandomState(11)
+    base = rng.randint(0, 2 ** 63, size=(40, w64), dtype=np.int64).astype(np.uint64)
+    pick = rng.randint(0, 40, n_rows)
+    rows = base[pick].copy()
+    keys = (pick.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+    d_rows = engine.DevArray.from_host(rows)
+    for sort in (False, True):
+        if sort:
+            os.environ["HGX_DEDUP_SORT"] = "1"
+        try:
+            cl = engine.Classes.dedup(d_rows, n_rows, a_pad, hashes=engine.DevArray.from_host(keys))
+            assert cl.n_classes == len(set(pick.tolist()))
+            cl.close()
+            victim = n_rows - 7                               # one row changes a bit but keeps its key
+            forged = rows.copy()
+            forged[victim, 3] ^= np.uint64(1) << np.uint64(17)
+            d_forged = engine.DevArray.from_host(forged)
+            with pytest.raises(capi.HgxError) as ei:
+                engine.Classes.dedup(d_forged, n_rows, a_pad, hashes=engine.DevArray.from_host(keys))
+            assert ei.value.code == -5                        # HGX_ECOLLISION
+        finally:
+            os.environ.pop("HGX_DEDUP_SORT", None)
+
+
 def test_empty_and_degenerate_inputs(orc):
     """Zero pairs, pairs without pieces, and a locus whose exon level has no representatives."""
     from hisatgenotype_amd import synth
