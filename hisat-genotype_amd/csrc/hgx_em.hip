@@ -1997,7 +1997,8 @@ __global__ __launch_bounds__(256) void k_col_or(const uint64_t *__restrict__ B, 
 // among the active bits of word w.  One wavefront per 64 x 64 tile (cf. k_transpose).
 __global__ __launch_bounds__(256) void k_transpose_compact(const uint64_t *__restrict__ bits, int n_classes, int w64, int c64,
                                                            const unsigned long long *__restrict__ mask,
-                                                           const int32_t *__restrict__ base, uint64_t *__restrict__ bitsTC) {
+                                                           const int32_t *__restrict__ base, uint64_t *__restrict__ bitsTC,
+                                                           uint64_t *__restrict__ wcol, int a1p) {
     const int lane = threadIdx.x & 63;
     const long tile = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long n_tiles = (long)c64 * w64;
@@ -2016,7 +2017,30 @@ __global__ __launch_bounds__(256) void k_transpose_compact(const uint64_t *__res
     if ((m >> lane) & 1ull) {
         const int j = base[aw] + __popcll(m & ((1ull << lane) - 1ull));
         bitsTC[(size_t)j * c64 + cw] = mine;
+        wcol[(size_t)cw * a1p + j] = mine;              // the same word in the word-transposed copy (k_lutmatvec's cols pass)
     }
+}
+
+// second transpose of the set-up: compact [a1p][c64] -> class-major [c64 * 64][a1p / 64], written twice: row-major (tail
+// kernel, MFMA order) and word-transposed (k_lutmatvec's rows pass)
+__global__ __launch_bounds__(256) void k_transpose_dual(const uint64_t *__restrict__ bitsTC, int a1p, int c64,
+                                                        uint64_t *__restrict__ bitsC, uint64_t *__restrict__ wrow) {
+    const int lane = threadIdx.x & 63;
+    const long tile = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int w64c = a1p / 64;
+    const long n_tiles = (long)w64c * c64;
+    if (tile >= n_tiles) return;
+    const int aw = (int)(tile / c64), cw = (int)(tile % c64);          // 64 alleles x 64 classes
+    const uint64_t x = bitsTC[(size_t)(aw * 64 + lane) * c64 + cw];
+    uint64_t mine = 0;
+#pragma unroll 8
+    for (int b = 0; b < 64; ++b) {
+        const uint64_t col = __ballot((x >> b) & 1ull);
+        if (lane == b) mine = col;
+    }
+    const size_t cls = (size_t)cw * 64 + lane;
+    bitsC[cls * w64c + aw] = mine;
+    wrow[(size_t)aw * ((size_t)c64 * 64) + cls] = mine;
 }
 
 static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
@@ -2042,16 +2066,19 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
     c->d_act = (int32_t *)hgx_pool_alloc((size_t)A * 4);
     c->d_bitsTC = (uint64_t *)hgx_pool_alloc((size_t)a1p * c->c64 * 8);
     c->d_bitsC = (uint64_t *)hgx_pool_alloc((size_t)c->c64 * 64 * (a1p / 64) * 8);
-    if (!c->d_act || !c->d_bitsTC || !c->d_bitsC) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    c->d_wrow = (uint64_t *)hgx_pool_alloc((size_t)(a1p / 64) * c->c64 * 64 * 8);
+    c->d_wcol = (uint64_t *)hgx_pool_alloc((size_t)c->c64 * a1p * 8);
+    if (!c->d_act || !c->d_bitsTC || !c->d_bitsC || !c->d_wrow || !c->d_wcol) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
     { int rc_ = hgx_h2d(b_base.p, h_base.data(), (size_t)w64 * 4, st); if (rc_) return rc_; }
     { int rc_ = hgx_h2d(c->d_act, c->h_act, (size_t)std::max(n, 1) * 4, st); if (rc_) return rc_; }
-    // padding rows [n, a1p) stay zero
+    // padding rows [n, a1p) stay zero (in the word-transposed copy they are scattered columns: clear it whole)
     HIPCHK(hipMemsetAsync(c->d_bitsTC + (size_t)n * c->c64, 0, (size_t)(a1p - n) * c->c64 * 8, st));
+    if (a1p > n) HIPCHK(hipMemsetAsync(c->d_wcol, 0, (size_t)c->c64 * a1p * 8, st));
     const long tiles_in = (long)c->c64 * w64;
     hipLaunchKernelGGL(k_transpose_compact, dim3(nblk(tiles_in, 4)), dim3(256), 0, st, c->d_bits, C, w64, c->c64,
-                       b_mask.as<unsigned long long>(), b_base.as<int32_t>(), c->d_bitsTC);
+                       b_mask.as<unsigned long long>(), b_base.as<int32_t>(), c->d_bitsTC, c->d_wcol, a1p);
     const long tiles = (long)(a1p / 64) * c->c64;
-    hipLaunchKernelGGL(k_transpose, dim3(nblk(tiles, 4)), dim3(256), 0, st, c->d_bitsTC, a1p, c->c64, a1p / 64, c->d_bitsC);
+    hipLaunchKernelGGL(k_transpose_dual, dim3(nblk(tiles, 4)), dim3(256), 0, st, c->d_bitsTC, a1p, c->c64, c->d_bitsC, c->d_wrow);
     HIPCHK(hipGetLastError());
     { int rc_ = hgx_sync(st); if (rc_) return rc_; }        // b_mask / b_base / the host staging vectors are released on return
     c->a1p = a1p;
