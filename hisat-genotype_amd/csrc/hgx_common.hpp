@@ -55,6 +55,7 @@ struct hgx_classes {
     uint64_t *d_bitsTC = nullptr;                    // [a1p][c64]
     int32_t *h_act = nullptr;                        // host copy of d_act (new[])
     uint64_t *d_wrow = nullptr, *d_wcol = nullptr;   // word-transposed compact matrices [a1p/64][c64*64], [c64][a1p]
+    void *d_setup0 = nullptr, *d_setup1 = nullptr;   // small tables the set-up kernels read (kept so that no sync is needed)
 };
 
 struct DevBuf {

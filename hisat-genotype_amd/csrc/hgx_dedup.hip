@@ -459,6 +459,7 @@ extern "C" int hgx_classes_destroy(hgx_classes *c) {
     hgx_pool_free(c->d_prow); hgx_pool_free(c->d_pcol);
     hgx_pool_free(c->d_act); hgx_pool_free(c->d_bitsC); hgx_pool_free(c->d_bitsTC);
     hgx_pool_free(c->d_wrow); hgx_pool_free(c->d_wcol);
+    hgx_pool_free(c->d_setup0); hgx_pool_free(c->d_setup1);
     delete[] c->h_act;
     delete c;
     return HGX_OK;

@@ -2047,8 +2047,11 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
     if (c->n_act >= 0) return HGX_OK;
     const int A = c->a_pad, w64 = c->w64, C = c->n_classes;
     c->c64 = ((C + 63) / 64 + 7) / 8 * 8;            // row stride of the transposed matrices: multiple of 8 words, zero padded
+    // the mask / base tables are read by kernels queued below: they stay with the class set instead of forcing a sync here
     DevBuf b_mask, b_base;
     ALLOC(b_mask, (size_t)w64 * 8); ALLOC(b_base, (size_t)w64 * 4);
+    c->d_setup0 = b_mask.p; c->d_setup1 = b_base.p;
+    struct Release { DevBuf &a, &b; ~Release() { a.p = nullptr; b.p = nullptr; } } release{b_mask, b_base};   // owned by *c from here on
     HIPCHK(hipMemsetAsync(b_mask.p, 0, (size_t)w64 * 8, st));
     hipLaunchKernelGGL(k_col_or, dim3(256), dim3(256), (size_t)w64 * 8, st, c->d_bits, (long)C * w64, w64, b_mask.as<unsigned long long>());
     HIPCHK(hipGetLastError());
@@ -2080,7 +2083,6 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
     const long tiles = (long)(a1p / 64) * c->c64;
     hipLaunchKernelGGL(k_transpose_dual, dim3(nblk(tiles, 4)), dim3(256), 0, st, c->d_bitsTC, a1p, c->c64, c->d_bitsC, c->d_wrow);
     HIPCHK(hipGetLastError());
-    { int rc_ = hgx_sync(st); if (rc_) return rc_; }        // b_mask / b_base / the host staging vectors are released on return
     c->a1p = a1p;
     c->n_act = n;
     return HGX_OK;
