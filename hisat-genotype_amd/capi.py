@@ -48,7 +48,7 @@ class ParseOpts(C.Structure):
 # every symbol include/hgx.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "hgx_last_error", "hgx_version", "hgx_device_count", "hgx_set_device", "hgx_dev_alloc", "hgx_dev_free",
-    "hgx_memcpy_h2d", "hgx_memcpy_d2h", "hgx_memset", "hgx_stream_sync", "hgx_stream_create", "hgx_stream_create_prio", "hgx_stream_destroy", "hgx_pool_trim", "hgx_event_create", "hgx_event_destroy",
+    "hgx_memcpy_h2d", "hgx_memcpy_h2d_async", "hgx_memcpy_d2h", "hgx_memset", "hgx_stream_sync", "hgx_stream_create", "hgx_stream_create_prio", "hgx_stream_destroy", "hgx_pool_trim", "hgx_event_create", "hgx_event_destroy",
     "hgx_event_record", "hgx_stream_wait_event", "hgx_event_elapsed_ms", "hgx_a_pad", "hgx_index_create",
     "hgx_index_destroy", "hgx_index_dims", "hgx_index_device_bits", "hgx_piece_compat", "hgx_pair_classes",
     "hgx_score_pairs", "hgx_dedup_classes", "hgx_classes_destroy", "hgx_classes_dims", "hgx_classes_device",
@@ -137,11 +137,14 @@ class DevArray:
         self.ptr = p.value
 
     @staticmethod
-    def from_host(arr, stream=None):
+    def from_host(arr, stream=None, sync=True):
+        """Upload `arr`.  sync=False: no host round trip (small arrays are staged through pinned memory and travel in
+        stream order; the result may only be used on `stream`)."""
         arr = np.ascontiguousarray(arr)
         d = DevArray(arr.shape, arr.dtype)
         if arr.nbytes:
-            check(lib().hgx_memcpy_h2d(C.c_void_p(d.ptr), ptr(arr), C.c_size_t(arr.nbytes), stream))
+            fn = lib().hgx_memcpy_h2d if sync else lib().hgx_memcpy_h2d_async
+            check(fn(C.c_void_p(d.ptr), ptr(arr), C.c_size_t(arr.nbytes), stream))
         return d
 
     def to_host(self, stream=None):

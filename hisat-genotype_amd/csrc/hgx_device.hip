@@ -123,6 +123,10 @@ extern "C" int hgx_memcpy_h2d(void *d, const void *s, size_t n, void *st) {
     int rc = hgx_h2d(d, s, n, (hipStream_t)st);
     return rc ? rc : hgx_sync((hipStream_t)st);
 }
+extern "C" int hgx_memcpy_h2d_async(void *d, const void *s, size_t n, void *st) {
+    if (n > STAGE_MAX) return hgx_memcpy_h2d(d, s, n, st);
+    return hgx_h2d(d, s, n, (hipStream_t)st);
+}
 extern "C" int hgx_memcpy_d2h(void *d, const void *s, size_t n, void *st) {
     int rc = hgx_d2h(d, s, n, (hipStream_t)st);
     return rc ? rc : hgx_sync((hipStream_t)st);

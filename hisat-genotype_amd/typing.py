@@ -210,7 +210,7 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
             mask = np.zeros(pl.w64, np.uint64)
             ea = np.fromiter(exon_alleles, np.int64, len(exon_alleles))
             np.bitwise_or.at(mask, ea >> 6, np.uint64(1) << (ea & 63).astype(np.uint64))
-            d_mask = capi.DevArray.from_host(mask, stream)
+            d_mask = capi.DevArray.from_host(mask, stream, sync=False)
             gb, gc, _ = gcl.device_ptrs()
             g2 = engine.Classes.dedup(engine._RawDev(gb), gcl.n_classes, pl.a_pad, weights=engine._RawDev(gc),
                                       and_mask=d_mask, stream=stream)

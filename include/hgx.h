@@ -53,6 +53,9 @@ int hgx_set_device(int dev);
 int hgx_dev_alloc(void **dev_ptr, size_t bytes);
 int hgx_dev_free(void *dev_ptr);
 int hgx_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stream);
+/* host -> device without a host sync: the bytes are copied into this thread's pinned staging buffer before the call returns
+ * (the caller's buffer is free at once) and travel in stream order.  Falls back to the synchronous form above 256 KB. */
+int hgx_memcpy_h2d_async(void *dst_dev, const void *src_host, size_t bytes, void *stream);
 int hgx_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);
 int hgx_memset(void *dev_dst, int value, size_t bytes, void *stream);
 int hgx_stream_sync(void *stream);
