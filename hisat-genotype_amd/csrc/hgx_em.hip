@@ -2095,8 +2095,9 @@ extern "C" int hgx_em_set_backend(int backend) {
 }
 
 extern "C" int hgx_em_set_timing(int on) {
+    ARGCHK(on >= 0 && on <= 2);
+    if (on && !g_timing) for (auto &s : g_stats) s = PassStats();      // totals restart when timing is switched on
     g_timing = on;
-    for (auto &s : g_stats) s = PassStats();
     return HGX_OK;
 }
 // slot: 0 <8,ROWS>, 1 <16,ROWS>, 2 <8,COLS>, 3 <16,COLS>
@@ -2410,19 +2411,17 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     }
     std::vector<Timed> timed;
     const int slot_rows = A <= 8 * BLOCK ? 0 : 1, slot_cols = C <= 8 * BLOCK ? 2 : 3;
-    // timing sample: every 4th ungated rows pass of a call and the cols pass that follows it
-    int n_stamped = 0, n_rows_seen = 0;
+    // timing: g_timing == 1 samples every 4th ungated rows pass of a call and the cols pass that follows it; g_timing == 2
+    // times every plain rows / cols pass (bench.py turns it on for the last steps of the timed region only)
+    int n_rows_seen = 0;
     bool stamping = false;
     auto stamp = [&](int slot, bool begin, int gate) {
         if (!g_timing) return;
         if (begin) {
-            if (slot == slot_rows) {
-                stamping = gate == 0 && (n_rows_seen++ % 4) == 0;
-            } else {
-                stamping = gate == 0;                        // called with gate 0 only right after a timed rows pass
-            }
+            if (g_timing == 2) stamping = true;
+            else if (slot == slot_rows) stamping = gate == 0 && (n_rows_seen++ % 4) == 0;
+            else stamping = gate == 0;                       // called with gate 0 only right after a timed rows pass
             if (!stamping) return;
-            ++n_stamped;
             Timed t;
             t.a = pool_event();
             t.b = pool_event();
@@ -2432,16 +2431,20 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             timed.push_back(t);
         } else if (stamping && !rows.M) (void)hipEventRecord(timed.back().b, st);
     };
+    auto cols_pass = [&](const double *vec, const uint8_t *pres_v, int x_mode, double *q_out, uint8_t *pres_out, int gate,
+                         bool after_timed_rows) -> int {
+        stamp(slot_cols, true, (g_timing == 2 || after_timed_rows) ? 0 : 1);
+        const int r = launch_matvec<MODE_COLS>(cols, st, wc, nullptr, x_mode == 2 ? 2 : 0, nullptr, vec, pres_v, d_len, q_out, pres_out, scal, gate);
+        stamp(slot_cols, false, gate);
+        return r;
+    };
     // one application of the EM map: (vec, pres_v) -> (q_out, pres_out)
     auto next_prob = [&](const double *vec, const uint8_t *pres_v, int x_mode, double *q_out, uint8_t *pres_out, int gate) -> int {
         stamp(slot_rows, true, gate);
         int r = launch_matvec<MODE_ROWS>(rows, st, vec, pres_v, x_mode, c->d_count, nullptr, nullptr, nullptr, wc, nullptr, scal, gate);
         stamp(slot_rows, false, gate);
         if (r) return r;
-        stamp(slot_cols, true, stamping ? 0 : 1);          // the cols pass of a timed rows pass is timed too
-        r = launch_matvec<MODE_COLS>(cols, st, wc, nullptr, x_mode == 2 ? 2 : 0, nullptr, vec, pres_v, d_len, q_out, pres_out, scal, gate);
-        stamp(slot_cols, false, gate);
-        return r;   // only the rows pass (the kernel with the largest aggregate time) is bracketed: every event costs ~1.5 us
+        return cols_pass(vec, pres_v, x_mode, q_out, pres_out, gate, stamping);
     };
     // initial mass sum_c n_c / |S_c|, normalised (common:1299-1309)
     rc = next_prob(p, pr, 2, p, pr, 0);
@@ -2498,11 +2501,11 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
                     if ((rc = rows_fused(1, q3, pr3, p_alt, pr_alt))) return rc;      // advance of the previous iteration + rows(p)
                     std::swap(p, p_alt);
                     std::swap(pr, pr_alt);
-                    if ((rc = launch_matvec<MODE_COLS>(cols, st, wc, nullptr, 0, nullptr, p, pr, d_len, q1, pr1, scal, 0))) return rc;
+                    if ((rc = cols_pass(p, pr, 0, q1, pr1, 0, false))) return rc;
                 }
                 if ((rc = next_prob(q1, pr1, 1, q2, pr2, 0))) return rc;
                 if ((rc = rows_fused(0, q2, pr2, q2x, prx))) return rc;               // SQUAREM + rows(q2')
-                if ((rc = launch_matvec<MODE_COLS>(cols, st, wc, nullptr, 0, nullptr, q2x, prx, d_len, q3, pr3, scal, 1))) return rc;
+                if ((rc = cols_pass(q2x, prx, 0, q3, pr3, 1, false))) return rc;
                 if (b == nb - 1)   // the host looks at the state after the batch: close it with the standalone step
                     hipLaunchKernelGGL(k_em_advance, dim3(1), dim3(BLOCK), 0, st, p, pr, q1, pr1, q3, pr3, A, remove_low ? 1 : 0, scal);
                 continue;

@@ -148,7 +148,8 @@ def em_order(first_class, name_rank, present):
 
 
 def em_set_timing(on):
-    capi.check(capi.lib().hgx_em_set_timing(C.c_int(1 if on else 0)))
+    """0 / False = off (totals kept), 1 / True = sampled passes, 2 = every plain mat-vec pass."""
+    capi.check(capi.lib().hgx_em_set_timing(C.c_int(int(on))))
 
 
 def em_get_timing():

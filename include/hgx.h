@@ -263,11 +263,12 @@ int hgx_batch_trace_text(const hgx_batch *b, char *buf, size_t cap, size_t *need
 /* pileup nt_set per backbone position as a 4-bit mask A=1,C=2,G=4,T=8 and counts[L][6] (A,C,G,T,N,D) */
 int hgx_batch_pileup(const hgx_batch *b, uint8_t *nt_set, uint32_t *counts);
 
-/* Kernel timing for roofline reports.  hgx_em_set_timing(1) makes hgx_em bracket every bit-mat-vec launch with HIP
- * events on its stream (rows-pass launches only: the kernel with the largest aggregate time; each event costs ~1.5 us)
- * and (re)starts the per-thread totals; slots 0/1 = rows pass (vector of <= 8192 / more elements), 2/3 = cols pass
- * (k_lutmatvec<0> / <1> with the default backend).  `executed` counts the launches that did work (not gated / past convergence) and bytes_total their
- * algorithmic bytes (bit matrix once + dense vectors).                                                              */
+/* Kernel timing for roofline reports.  hgx_em_set_timing(1) makes hgx_em time a sample of its table-lookup mat-vec launches
+ * (every 4th ungated rows pass and the cols pass after it), hgx_em_set_timing(2) every plain rows / cols pass, with events
+ * attached to the dispatch itself (hipExtLaunchKernelGGL: kernel begin / end, as rocprofv3 measures).  Switching timing on
+ * restarts the per-thread totals; 0 switches it off and keeps them.  Slots 0/1 = rows pass (vector of <= 8192 / more elements),
+ * 2/3 = cols pass (k_lutmatvec<0> / <1> with the default backend).  `executed` counts the plain passes that ran while timing was
+ * on (device-side counter) and bytes_total the algorithmic bytes of the timed ones (bit matrix once + dense vectors).       */
 /* mat-vec backend of hgx_em: 0 = auto (table lookup), 1 = EXEC-masked FP64 VALU kernel, 2 = int8 MFMA kernel,
  * 3 = table-lookup kernel (256 subset sums per 8 matrix columns in LDS; one lookup per 8 matrix bits) */
 int hgx_em_set_backend(int backend);
