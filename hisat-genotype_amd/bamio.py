@@ -65,7 +65,7 @@ def _decode_tags(buf, p, end):
             fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[st]
             vals = struct.unpack_from("<%d%s" % (cnt, fmt), buf, p + 5)
             p += 5 + cnt * struct.calcsize(fmt)
-            out.append("%s:B:%s,%s" % (tag, st, ",".join(str(v) for v in vals)))
+            out.append("%s:B:%s,%s" % (tag, st, ",".join(("%g" % v) if st == "f" else str(v) for v in vals)))
         else:
             raise ValueError("unknown BAM tag type %r" % t)
     return out

@@ -1,0 +1,419 @@
+// hgx_bam.cpp -- alignment ingestion without samtools, host side of libhgx.
+//
+// The reference pipes `samtools view <file> [chr:left-right]` through `sort -k1,1 -s` (typing_core.py:436-468) and feeds the
+// text to its loop.  hgx_read_alignments produces exactly that record stream from a SAM text file or a BAM file:
+//   * BGZF (SAM/BAM specification v1, section 4.1): blocks are independent deflate streams -> inflated in parallel (zlib),
+//     CRC32 + ISIZE checked;
+//   * BAM records (section 4.2) -> SAM text lines, in parallel over record ranges: the eleven mandatory fields and the tags of
+//     types A c C s S i I f Z H B (floats as %g, like samtools);
+//   * header lines dropped, optional region filter (reference name, 0-based POS in [left, right], as the Python reader does);
+//   * name grouping: STABLE sort of the records by QNAME, bytewise (LC_ALL=C `sort -k1,1 -s`): parallel chunk sorts + merges.
+// hisat-genotype_amd/bamio.py is the pure-Python statement of the same formats; tests compare the two byte for byte.
+#include <zlib.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "hgx_internal.hpp"
+
+namespace {
+
+template <class F>
+void par_for(int n_threads, size_t n, F fn) {      // fn(thread, begin, end) over [0, n) in contiguous ranges
+    n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, n));
+    if (n_threads == 1) { fn(0, (size_t)0, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; ++t) {
+        const size_t b = n * t / n_threads, e = n * (t + 1) / n_threads;
+        th.emplace_back([=] { fn(t, b, e); });
+    }
+    for (auto &x : th) x.join();
+}
+
+inline uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+inline uint32_t rd32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline int32_t rdi32(const unsigned char *p) { return (int32_t)rd32(p); }
+
+struct Block { size_t in_off, in_len, out_off, out_len; uint32_t crc; };
+
+// inflate every BGZF block of `data` into one buffer
+int bgzf_inflate(const std::vector<unsigned char> &data, int n_threads, std::vector<unsigned char> &out) {
+    std::vector<Block> blocks;
+    size_t off = 0, total = 0;
+    const size_t n = data.size();
+    while (off < n) {
+        if (off + 18 > n || data[off] != 0x1f || data[off + 1] != 0x8b || data[off + 2] != 8 || !(data[off + 3] & 4)) {
+            hgx_set_error("not a BGZF block at offset %zu", off);
+            return HGX_EPARSE;
+        }
+        const unsigned xlen = rd16(&data[off + 10]);
+        if (off + 12 + xlen > n) { hgx_set_error("truncated BGZF header at offset %zu", off); return HGX_EPARSE; }
+        long bsize = -1;
+        for (size_t p = off + 12; p + 4 <= off + 12 + xlen;) {
+            const unsigned slen = rd16(&data[p + 2]);
+            if (data[p] == 66 && data[p + 1] == 67 && slen == 2) bsize = rd16(&data[p + 4]);
+            p += 4 + slen;
+        }
+        if (bsize < 0) { hgx_set_error("BGZF block without BC subfield at offset %zu", off); return HGX_EPARSE; }
+        const size_t blen = (size_t)bsize + 1;
+        if (off + blen > n || blen < 12 + xlen + 8) { hgx_set_error("truncated BGZF block at offset %zu", off); return HGX_EPARSE; }
+        Block b;
+        b.in_off = off + 12 + xlen;
+        b.in_len = blen - 12 - xlen - 8;
+        b.crc = rd32(&data[off + blen - 8]);
+        b.out_len = rd32(&data[off + blen - 4]);
+        b.out_off = total;
+        total += b.out_len;
+        blocks.push_back(b);
+        off += blen;
+    }
+    out.resize(total);
+    std::vector<int> bad(std::max(1, n_threads), 0);
+    par_for(n_threads, blocks.size(), [&](int t, size_t b0, size_t b1) {
+        for (size_t i = b0; i < b1; ++i) {
+            const Block &b = blocks[i];
+            if (b.out_len == 0) continue;
+            z_stream zs;
+            memset(&zs, 0, sizeof zs);
+            if (inflateInit2(&zs, -15) != Z_OK) { bad[t] = 1; return; }
+            zs.next_in = const_cast<unsigned char *>(&data[b.in_off]);
+            zs.avail_in = (uInt)b.in_len;
+            zs.next_out = &out[b.out_off];
+            zs.avail_out = (uInt)b.out_len;
+            const int rc = inflate(&zs, Z_FINISH);
+            inflateEnd(&zs);
+            if (rc != Z_STREAM_END || zs.total_out != b.out_len ||
+                (uint32_t)crc32(crc32(0L, Z_NULL, 0), &out[b.out_off], (uInt)b.out_len) != b.crc) { bad[t] = 1; return; }
+        }
+    });
+    for (int v : bad) if (v) { hgx_set_error("corrupt BGZF block (inflate / CRC32 / ISIZE mismatch)"); return HGX_EPARSE; }
+    return HGX_OK;
+}
+
+void put_int(std::string &s, long long v) {
+    char buf[24];
+    int n = snprintf(buf, sizeof buf, "%lld", v);
+    s.append(buf, (size_t)n);
+}
+
+// one BAM record (after its block_size word) -> SAM text line (no newline)
+bool bam_record_text(const unsigned char *r, size_t len, const std::vector<std::string> &refs, std::string &s) {
+    static const char CIG[] = "MIDNSHP=X", SEQ[] = "=ACMGRSVTWYHKDBN";
+    if (len < 32) return false;
+    const int32_t ref_id = rdi32(r), pos = rdi32(r + 4);
+    const unsigned l_rn = r[8], mapq = r[9];
+    const unsigned n_cig = rd16(r + 12), flag = rd16(r + 14);
+    const int32_t l_seq = rdi32(r + 16), nref = rdi32(r + 20), npos = rdi32(r + 24), tlen = rdi32(r + 28);
+    size_t q = 32;
+    if (l_rn == 0 || l_seq < 0 || q + l_rn + 4ull * n_cig + (size_t)(l_seq + 1) / 2 + (size_t)l_seq > len) return false;
+    s.append((const char *)r + q, l_rn - 1);
+    q += l_rn;
+    s.push_back('\t'); put_int(s, flag);
+    s.push_back('\t');
+    if (ref_id >= 0 && (size_t)ref_id < refs.size()) s += refs[ref_id]; else s.push_back('*');
+    s.push_back('\t'); put_int(s, (long long)pos + 1);
+    s.push_back('\t'); put_int(s, mapq);
+    s.push_back('\t');
+    if (n_cig == 0) s.push_back('*');
+    for (unsigned k = 0; k < n_cig; ++k) {
+        const uint32_t v = rd32(r + q + 4 * k);
+        put_int(s, v >> 4);
+        s.push_back((v & 15) < 9 ? CIG[v & 15] : '?');
+    }
+    q += 4ull * n_cig;
+    s.push_back('\t');
+    if (nref < 0) s.push_back('*');
+    else if (nref == ref_id) s.push_back('=');
+    else if ((size_t)nref < refs.size()) s += refs[nref];
+    else s.push_back('*');
+    s.push_back('\t'); put_int(s, (long long)npos + 1);
+    s.push_back('\t'); put_int(s, tlen);
+    s.push_back('\t');
+    if (l_seq == 0) s.push_back('*');
+    else {
+        const size_t at = s.size();
+        s.resize(at + (size_t)l_seq);
+        char *d = &s[at];
+        for (int32_t i = 0; i + 1 < l_seq; i += 2) {
+            const unsigned b = r[q + i / 2];
+            d[i] = SEQ[b >> 4];
+            d[i + 1] = SEQ[b & 15];
+        }
+        if (l_seq & 1) d[l_seq - 1] = SEQ[r[q + l_seq / 2] >> 4];
+    }
+    q += (size_t)(l_seq + 1) / 2;
+    s.push_back('\t');
+    if (l_seq == 0 || r[q] == 0xff) s.push_back('*');
+    else {
+        const size_t at = s.size();
+        s.resize(at + (size_t)l_seq);
+        char *d = &s[at];
+        for (int32_t i = 0; i < l_seq; ++i) d[i] = (char)(r[q + i] + 33);
+    }
+    q += (size_t)l_seq;
+    while (q + 3 <= len) {          // tags
+        s.push_back('\t');
+        s.append((const char *)r + q, 2);
+        const char t = (char)r[q + 2];
+        q += 3;
+        auto need = [&](size_t k) { return q + k <= len; };
+        char buf[40];
+        switch (t) {
+            case 'A': if (!need(1)) return false; s += ":A:"; s.push_back((char)r[q]); q += 1; break;
+            case 'c': if (!need(1)) return false; s += ":i:"; put_int(s, (int8_t)r[q]); q += 1; break;
+            case 'C': if (!need(1)) return false; s += ":i:"; put_int(s, r[q]); q += 1; break;
+            case 's': if (!need(2)) return false; s += ":i:"; put_int(s, (int16_t)rd16(r + q)); q += 2; break;
+            case 'S': if (!need(2)) return false; s += ":i:"; put_int(s, rd16(r + q)); q += 2; break;
+            case 'i': if (!need(4)) return false; s += ":i:"; put_int(s, rdi32(r + q)); q += 4; break;
+            case 'I': if (!need(4)) return false; s += ":i:"; put_int(s, rd32(r + q)); q += 4; break;
+            case 'f': {
+                if (!need(4)) return false;
+                float f; const uint32_t u = rd32(r + q); memcpy(&f, &u, 4);
+                s += ":f:"; s.append(buf, (size_t)snprintf(buf, sizeof buf, "%g", f)); q += 4;
+            } break;
+            case 'Z': case 'H': {
+                const void *e = memchr(r + q, 0, len - q);
+                if (!e) return false;
+                s.push_back(':'); s.push_back(t); s.push_back(':');
+                s.append((const char *)r + q, (const unsigned char *)e - (r + q));
+                q = (size_t)((const unsigned char *)e - r) + 1;
+            } break;
+            case 'B': {
+                if (!need(5)) return false;
+                const char st = (char)r[q];
+                const uint32_t cnt = rd32(r + q + 1);
+                q += 5;
+                const size_t w = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0;
+                if (!w || !need(w * (size_t)cnt)) return false;
+                s += ":B:"; s.push_back(st);
+                for (uint32_t k = 0; k < cnt; ++k, q += w) {
+                    s.push_back(',');
+                    switch (st) {
+                        case 'c': put_int(s, (int8_t)r[q]); break;
+                        case 'C': put_int(s, r[q]); break;
+                        case 's': put_int(s, (int16_t)rd16(r + q)); break;
+                        case 'S': put_int(s, rd16(r + q)); break;
+                        case 'i': put_int(s, rdi32(r + q)); break;
+                        case 'I': put_int(s, rd32(r + q)); break;
+                        default: {
+                            float f; const uint32_t u = rd32(r + q); memcpy(&f, &u, 4);
+                            s.append(buf, (size_t)snprintf(buf, sizeof buf, "%g", f));
+                        }
+                    }
+                }
+            } break;
+            default: return false;
+        }
+    }
+    return q == len;
+}
+
+struct Line { const char *p; uint32_t len, klen; uint64_t key; };     // klen = QNAME length, key = its first 8 bytes, big endian
+
+inline bool line_less(const Line &a, const Line &b) {
+    if (a.key != b.key) return a.key < b.key;
+    const uint32_t m = std::min(a.klen, b.klen);
+    if (m > 8) { const int c = memcmp(a.p + 8, b.p + 8, m - 8); if (c) return c < 0; }
+    return a.klen < b.klen;
+}
+
+void make_line(const char *p, size_t len, Line &l) {
+    const char *tab = (const char *)memchr(p, '\t', len);
+    const size_t k = tab ? (size_t)(tab - p) : len;
+    l.p = p; l.len = (uint32_t)len; l.klen = (uint32_t)k;
+    uint64_t key = 0;
+    for (size_t i = 0; i < 8; ++i) key = (key << 8) | (i < k ? (unsigned char)p[i] : 0);
+    l.key = key;
+}
+
+// stable sort by QNAME: sorted chunks, then rounds of pairwise stable merges
+void sort_lines(std::vector<Line> &v, int n_threads) {
+    const size_t n = v.size();
+    int T = 1;
+    while (T * 2 <= n_threads && n / (size_t)(T * 2) >= 50000) T *= 2;
+    if (T == 1) { std::stable_sort(v.begin(), v.end(), line_less); return; }
+    std::vector<size_t> cut(T + 1);
+    for (int t = 0; t <= T; ++t) cut[t] = n * t / T;
+    par_for(T, (size_t)T, [&](int, size_t b, size_t e) {
+        for (size_t t = b; t < e; ++t) std::stable_sort(v.begin() + cut[t], v.begin() + cut[t + 1], line_less);
+    });
+    std::vector<Line> tmp(n);
+    std::vector<Line> *src = &v, *dst = &tmp;
+    for (int width = 1; width < T; width *= 2) {
+        const int pairs = T / (2 * width);
+        par_for(pairs, (size_t)pairs, [&](int, size_t b, size_t e) {
+            for (size_t k = b; k < e; ++k) {
+                const size_t lo = cut[2 * k * width], mid = cut[(2 * k + 1) * width], hi = cut[(2 * k + 2) * width];
+                std::merge(src->begin() + lo, src->begin() + mid, src->begin() + mid, src->begin() + hi, dst->begin() + lo, line_less);
+            }
+        });
+        std::swap(src, dst);
+    }
+    if (src != &v) v.swap(*src);
+}
+
+}   // namespace
+
+extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int32_t region_left0, int32_t region_right0,
+                                   int32_t n_threads, char **text_out, size_t *n_bytes_out) {
+    HARGCHK(path && text_out && n_bytes_out);
+    *text_out = nullptr;
+    *n_bytes_out = 0;
+    try {
+        if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+        n_threads = std::max(1, std::min(n_threads, 64));
+        const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
+        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t_prev = now();
+        auto lap = [&](const char *what) {
+            if (!prof) return;
+            const double t = now();
+            fprintf(stderr, "[hgx_read_alignments] %-18s %8.1f ms\n", what, (t - t_prev) * 1e3);
+            t_prev = t;
+        };
+        std::vector<unsigned char> data;
+        {
+            FILE *f = fopen(path, "rb");
+            if (!f) { hgx_set_error("cannot open %s", path); return HGX_EINVAL; }
+            fseek(f, 0, SEEK_END);
+            const long sz = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            data.resize(sz > 0 ? (size_t)sz : 0);
+            const size_t got = data.empty() ? 0 : fread(data.data(), 1, data.size(), f);
+            fclose(f);
+            if (got != data.size()) { hgx_set_error("short read on %s", path); return HGX_EINVAL; }
+        }
+        lap("read file");
+        std::vector<unsigned char> raw;
+        if (data.size() >= 2 && data[0] == 0x1f && data[1] == 0x8b) {
+            const int rc = bgzf_inflate(data, n_threads, raw);
+            if (rc) return rc;
+            std::vector<unsigned char>().swap(data);
+        } else raw.swap(data);
+
+        lap("inflate");
+        std::vector<std::string> chunks;           // text produced from BAM records (kept alive for the Line pointers)
+        std::vector<Line> lines;
+        if (raw.size() >= 4 && memcmp(raw.data(), "BAM\1", 4) == 0) {
+            const size_t n = raw.size();
+            if (n < 12) { hgx_set_error("truncated BAM header"); return HGX_EPARSE; }
+            size_t p = 8 + (size_t)rd32(&raw[4]);
+            if (p + 4 > n) { hgx_set_error("truncated BAM header"); return HGX_EPARSE; }
+            const uint32_t n_ref = rd32(&raw[p]);
+            p += 4;
+            std::vector<std::string> refs;
+            for (uint32_t i = 0; i < n_ref; ++i) {
+                if (p + 4 > n) { hgx_set_error("truncated BAM reference list"); return HGX_EPARSE; }
+                const uint32_t l_name = rd32(&raw[p]);
+                if (l_name == 0 || p + 4 + l_name + 4 > n) { hgx_set_error("truncated BAM reference list"); return HGX_EPARSE; }
+                refs.emplace_back((const char *)&raw[p + 4], l_name - 1);
+                p += 4 + l_name + 4;
+            }
+            int region_id = -2;
+            if (region_ref) {
+                region_id = -3;                                   // names no reference: nothing passes
+                for (size_t i = 0; i < refs.size(); ++i) if (refs[i] == region_ref) { region_id = (int)i; break; }
+            }
+            std::vector<std::pair<size_t, uint32_t>> recs;     // (offset after block_size, length)
+            while (p < n) {
+                if (p + 4 > n) { hgx_set_error("truncated BAM record at offset %zu", p); return HGX_EPARSE; }
+                const uint32_t bs = rd32(&raw[p]);
+                if (bs < 32 || p + 4 + bs > n) { hgx_set_error("truncated BAM record at offset %zu", p); return HGX_EPARSE; }
+                bool keep = true;
+                if (region_ref) {
+                    const int32_t rid = rdi32(&raw[p + 4]), pos = rdi32(&raw[p + 8]);
+                    keep = rid == region_id && pos >= region_left0 && pos <= region_right0;
+                }
+                if (keep) recs.push_back({p + 4, bs});
+                p += 4 + (size_t)bs;
+            }
+            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, recs.size() / 2000 + 1));
+            chunks.resize(T);
+            std::vector<std::vector<uint32_t>> ends(T);
+            std::vector<int> bad(T, 0);
+            par_for(T, recs.size(), [&](int t, size_t b, size_t e) {
+                std::string &s = chunks[t];
+                s.reserve((e - b) * 420);
+                ends[t].reserve(e - b);
+                for (size_t i = b; i < e; ++i) {
+                    if (!bam_record_text(&raw[recs[i].first], recs[i].second, refs, s)) { bad[t] = 1; return; }
+                    if (s.size() > 0xFFFFFFFFull) { bad[t] = 2; return; }
+                    ends[t].push_back((uint32_t)s.size());
+                }
+            });
+            for (int v : bad) if (v) { hgx_set_error(v == 2 ? "BAM chunk too large" : "malformed BAM record"); return HGX_EPARSE; }
+            lines.resize(recs.size());
+            size_t k = 0;
+            for (int t = 0; t < T; ++t) {
+                uint32_t prev = 0;
+                for (uint32_t en : ends[t]) {
+                    make_line(chunks[t].data() + prev, en - prev, lines[k++]);
+                    prev = en;
+                }
+            }
+        } else {
+            // SAM text: records = non-empty lines that do not start with '@'
+            const char *base = (const char *)raw.data(), *end = base + raw.size();
+            const char *p = base;
+            while (p < end) {
+                const char *e = (const char *)memchr(p, '\n', (size_t)(end - p));
+                if (!e) e = end;
+                size_t len = (size_t)(e - p);
+                if (len && p[len - 1] == '\r') --len;
+                if (len && *p != '@') {
+                    bool keep = true;
+                    if (region_ref) {           // RNAME = 3rd field, POS = 4th (1-based)
+                        const char *f1 = (const char *)memchr(p, '\t', len);
+                        const char *f2 = f1 ? (const char *)memchr(f1 + 1, '\t', len - (size_t)(f1 + 1 - p)) : nullptr;
+                        const char *f3 = f2 ? (const char *)memchr(f2 + 1, '\t', len - (size_t)(f2 + 1 - p)) : nullptr;
+                        keep = false;
+                        if (f3) {
+                            const size_t rl = (size_t)(f3 - f2 - 1);
+                            if (rl == strlen(region_ref) && memcmp(f2 + 1, region_ref, rl) == 0) {
+                                const long pos0 = strtol(f3 + 1, nullptr, 10) - 1;
+                                keep = pos0 >= region_left0 && pos0 <= region_right0;
+                            }
+                        }
+                    }
+                    if (keep) { Line l; make_line(p, len, l); lines.push_back(l); }
+                }
+                p = e + 1;
+            }
+        }
+        lap("decode / split");
+        sort_lines(lines, n_threads);
+        lap("name sort");
+        size_t total = 0;
+        std::vector<size_t> offs(lines.size() + 1, 0);
+        for (size_t i = 0; i < lines.size(); ++i) { offs[i] = total; total += (size_t)lines[i].len + 1; }
+        offs[lines.size()] = total;
+        char *out = (char *)malloc(total + 1);
+        if (!out) { hgx_set_error("out of memory (%zu bytes)", total); return HGX_ENOMEM; }
+        par_for(n_threads, lines.size(), [&](int, size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                memcpy(out + offs[i], lines[i].p, lines[i].len);
+                out[offs[i] + lines[i].len] = '\n';
+            }
+        });
+        out[total] = 0;
+        lap("emit");
+        *text_out = out;
+        *n_bytes_out = total;
+        return HGX_OK;
+    } catch (const std::exception &e) {
+        hgx_set_error("hgx_read_alignments: %s", e.what());
+        return HGX_ENOMEM;
+    }
+}
+
+extern "C" int hgx_free_text(char *text) {
+    free(text);
+    return HGX_OK;
+}

@@ -281,19 +281,30 @@ def report_lines(res, simulation=False, true_alleles=(), output_allele_counts=Fa
     return out, success
 
 
-def read_alignment_text(alignment_fname, region=None):
+def read_alignment_text(alignment_fname, region=None, n_threads=0, native=True):
     """The record stream the reference's loop consumes: ``samtools view F [region]`` piped through
-    ``sort -k1,1 -s`` (core:436-468).  SAM text files are read directly (no samtools needed)."""
+    ``sort -k1,1 -s`` (core:436-468), as bytes.  SAM text and BAM files are read by the native reader of libhgx
+    (hgx_read_alignments: parallel BGZF inflate, BAM decode and name grouping; no samtools needed).  ``native=False``
+    uses the pure-Python statement of the same formats (bamio.py), kept for tests."""
+    reg = None
+    if region:
+        name, span = region.rsplit(":", 1)          # "chr:left-right", 1-based inclusive
+        lo, hi = span.split("-")
+        reg = (name, int(lo) - 1, int(hi) - 1)
+    if native:
+        import ctypes as C
+        text, nbytes = C.c_void_p(), C.c_size_t(0)
+        capi.check(capi.lib().hgx_read_alignments(alignment_fname.encode(), reg[0].encode() if reg else None,
+                                                  C.c_int32(reg[1] if reg else 0), C.c_int32(reg[2] if reg else 0),
+                                                  C.c_int32(n_threads), C.byref(text), C.byref(nbytes)))
+        try:
+            return C.string_at(text.value, nbytes.value)
+        finally:
+            capi.lib().hgx_free_text(text)
     with open(alignment_fname, "rb") as f:
         head = f.read(4)
     if head[:2] == b"\x1f\x8b" or head == b"BAM\x01":
-        # BAM: decoded in-process (no samtools on the GPU box); region "chr:left-right" is 1-based inclusive
         from . import bamio
-        reg = None
-        if region:
-            name, span = region.rsplit(":", 1)
-            lo, hi = span.split("-")
-            reg = (name, int(lo) - 1, int(hi) - 1)
         data = ("\n".join(bamio.read_bam(alignment_fname, reg)) + "\n").encode()
     else:
         with open(alignment_fname, "rb") as f:

@@ -258,6 +258,17 @@ typedef struct hgx_parse_opts {
 /* SAM text (name-grouped, i.e. the stream after `sort -k1,1 -s`, core:458-468) -> batch.
  * Replaces typing_core.py:800-1406 + get_mpileup (common:1059-1134).                        */
 int hgx_parse_sam(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts);
+
+/* ---- 8f-3: alignment ingestion without samtools --------------------------------------------------------
+ * The record stream the reference's loop consumes -- `samtools view <file> [chr:left-right]` piped through
+ * `sort -k1,1 -s` (typing_core.py:436-468) -- from a SAM text file or a BAM file: BGZF blocks inflated in parallel (zlib),
+ * BAM records decoded to SAM text (mandatory fields + tags A c C s S i I f Z H B), header lines dropped, records of
+ * reference `region_ref_or_null` with 0-based POS in [region_left0, region_right0] kept (NULL = all), then grouped by a
+ * STABLE bytewise sort on QNAME.  *text_out is a malloc'ed, NUL-terminated buffer of *n_bytes_out bytes (every record ends
+ * in '\n'), ready for hgx_parse_sam; release it with hgx_free_text.  n_threads <= 0: all host threads (at most 64). */
+int hgx_read_alignments(const char *path, const char *region_ref_or_null, int32_t region_left0, int32_t region_right0,
+                        int32_t n_threads, char **text_out, size_t *n_bytes_out);
+int hgx_free_text(char *text);
 /* per kept record: "cmp_list2 \t cmp_left \t cmp_right \t left alts \t right alts" (keep_trace) */
 int hgx_batch_trace_text(const hgx_batch *b, char *buf, size_t cap, size_t *needed);
 /* pileup nt_set per backbone position as a 4-bit mask A=1,C=2,G=4,T=8 and counts[L][6] (A,C,G,T,N,D) */

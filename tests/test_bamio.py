@@ -53,3 +53,91 @@ def test_corrupt_block_is_detected(tmp_path):
     except (ValueError, zlib.error):
         return
     raise AssertionError("corruption not detected")
+
+
+def _native_vs_python(path, region=None, n_threads=0):
+    from hisatgenotype_amd.typing import read_alignment_text
+    a = read_alignment_text(path, region, n_threads=n_threads, native=True)
+    b = read_alignment_text(path, region, native=False)
+    assert a == b
+    return a
+
+
+def test_native_reader_equals_python_reader(tmp_path):
+    """hgx_read_alignments (parallel BGZF inflate + BAM decode + stable name sort in C++) against the pure-Python statement
+    of the formats: byte-identical record streams for BAM (every fixture with its tags, shuffled record order, a region) and
+    for SAM text (headers dropped, CRLF-free), with one thread and with many."""
+    import random
+    from hisatgenotype_amd import capi
+    for name in ("hla_insertions", "hla_errors_filters", "codis_d18s51", "hla_single_end"):
+        fx = gu.load(name)
+        loc = fx["_locus"]
+        lines = [l for l in fx["sam"].split("\n") if l]
+        random.Random(5).shuffle(lines)                    # coordinate-order-like input: the reader has to group by name
+        bam = str(tmp_path / (name + ".bam"))
+        bamio.write_bam(bam, "\n".join(lines) + "\n", [(loc.ref_allele, len(loc.backbone))], block_size=3000)   # many BGZF blocks
+        t1 = _native_vs_python(bam, n_threads=1)
+        assert t1 == _native_vs_python(bam, n_threads=8)
+        assert t1.count(b"\n") == len(lines)
+        reg = "%s:%d-%d" % (loc.ref_allele, 200, 900)
+        sub = _native_vs_python(bam, reg)
+        assert 0 < sub.count(b"\n") < len(lines)
+        sam = str(tmp_path / (name + ".sam"))
+        with open(sam, "w") as f:
+            f.write("@HD\tVN:1.0\n@SQ\tSN:%s\tLN:%d\n" % (loc.ref_allele, len(loc.backbone)) + "\n".join(lines) + "\n")
+        assert _native_vs_python(sam).count(b"\n") == len(lines)
+    # stability: records of one name keep their file order
+    fx = gu.load("hla_small_pair")
+    lines = [l for l in fx["sam"].split("\n") if l]
+    sam = str(tmp_path / "stable.sam")
+    open(sam, "w").write("\n".join(reversed(lines)) + "\n")
+    got = _native_vs_python(sam).decode().split("\n")[:-1]
+    by_name = {}
+    for l in reversed(lines):
+        by_name.setdefault(l.split("\t")[0], []).append(l)
+    exp = [l for n in sorted(by_name, key=lambda s: s.encode()) for l in by_name[n]]
+    assert got == exp
+
+
+def test_native_reader_tags_and_errors(tmp_path):
+    """Every tag type of the BAM specification through both readers; corrupt and truncated files are reported."""
+    import pytest
+    from hisatgenotype_amd import capi
+    from hisatgenotype_amd.typing import read_alignment_text
+    # hand-built record with all tag types (the writer only emits the types HISAT2 uses)
+    refs = [("chr1", 1000)]
+    rec = bytearray()
+    qname = b"r1\0"
+    tags = (b"XAAQ" + b"Xcc" + struct.pack("<b", -5) + b"XCC" + struct.pack("<B", 200) + b"Xss" + struct.pack("<h", -300) +
+            b"XSS" + struct.pack("<H", 60000) + b"Xii" + struct.pack("<i", -70000) + b"XII" + struct.pack("<I", 4000000000) +
+            b"Xff" + struct.pack("<f", 0.1) + b"XZZhello\0" + b"XHH1AE3\0" +
+            b"XBBs" + struct.pack("<I", 3) + struct.pack("<3h", 1, -2, 3) + b"XGBf" + struct.pack("<I", 2) + struct.pack("<2f", 1.5, 0.1))
+    cigar = struct.pack("<2I", (4 << 4) | 0, (2 << 4) | 4)
+    seq = bytes([(1 << 4) | 2, (4 << 4) | 8, (15 << 4) | 1])
+    qual = bytes([30, 31, 32, 33, 34, 35])
+    body = struct.pack("<iiBBHHHiiii", 0, 99, len(qname), 37, 4680, 2, 99, 6, 0, 199, 150) + qname + cigar + seq + qual + tags
+    out = bytearray(b"BAM\x01") + struct.pack("<i", 0) + struct.pack("<i", 1)
+    out += struct.pack("<i", 5) + b"chr1\0" + struct.pack("<i", 1000)
+    out += struct.pack("<i", len(body)) + body
+    path = str(tmp_path / "tags.bam")
+    comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+    cdata = comp.compress(bytes(out)) + comp.flush()
+    with open(path, "wb") as f:
+        f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cdata) + 25) + cdata +
+                struct.pack("<II", zlib.crc32(bytes(out)) & 0xffffffff, len(out)) + bamio._BGZF_EOF)
+    text = _native_vs_python(path).decode()
+    f = text.rstrip("\n").split("\t")
+    assert f[:11] == ["r1", "99", "chr1", "100", "37", "4M2S", "=", "200", "150", "ACGTNA", "?@ABCD"]
+    assert f[11:] == ["XA:A:Q", "Xc:i:-5", "XC:i:200", "Xs:i:-300", "XS:i:60000", "Xi:i:-70000", "XI:i:4000000000", "Xf:f:0.1",
+                      "XZ:Z:hello", "XH:H:1AE3", "XB:B:s,1,-2,3", "XG:B:f,1.5,0.1"]
+    raw = bytearray(open(path, "rb").read())
+    bad = bytearray(raw)
+    bad[40] ^= 0xFF                                       # payload byte: inflate or CRC must notice
+    open(str(tmp_path / "bad.bam"), "wb").write(bytes(bad))
+    with pytest.raises(capi.HgxError):
+        read_alignment_text(str(tmp_path / "bad.bam"))
+    open(str(tmp_path / "cut.bam"), "wb").write(bytes(raw[:60]))
+    with pytest.raises(capi.HgxError):
+        read_alignment_text(str(tmp_path / "cut.bam"))
+    with pytest.raises(capi.HgxError):
+        read_alignment_text(str(tmp_path / "missing.bam"))
