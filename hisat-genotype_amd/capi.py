@@ -55,7 +55,7 @@ SYMBOLS = [
     "hgx_classes_to_host", "hgx_classes_from_host", "hgx_allele_counts", "hgx_allele_counts_on", "hgx_first_classes", "hgx_em", "hgx_em_ordered", "hgx_em_set_backend", "hgx_debug_matvec", "hgx_em_set_timing", "hgx_em_get_timing", "hgx_locus_create",
     "hgx_locus_destroy", "hgx_locus_dims", "hgx_locus_tables", "hgx_index_from_locus",
     "hgx_locus_alternatives_text", "hgx_batch_destroy", "hgx_batch_dims", "hgx_batch_arrays",
-    "hgx_batch_from_haplotypes", "hgx_parse_sam", "hgx_read_alignments", "hgx_free_text", "hgx_batch_trace_text", "hgx_batch_pileup",
+    "hgx_batch_from_haplotypes", "hgx_parse_sam", "hgx_read_alignments", "hgx_free_text", "hgx_parse_alignment_file", "hgx_batch_trace_text", "hgx_batch_pileup",
 ]
 
 _lib = None

@@ -1123,8 +1123,30 @@ void parallel_for(int n_threads, size_t n, F fn) {   // fn(thread, begin, end)
 
 }   // namespace
 
+// `owned` != nullptr: a writable buffer of n_bytes + 1 bytes that the parser may modify in place (no private copy)
+static int parse_text(hgx_batch **out, const hgx_locus *Lc, const char *sam, char *owned, size_t n_bytes, const hgx_parse_opts *opts);
+
 extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts) {
-    HARGCHK(out && Lc && (sam || n_bytes == 0) && opts);
+    return parse_text(out, Lc, sam, nullptr, n_bytes, opts);
+}
+
+extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int32_t region_left0, int32_t region_right0,
+                                   int32_t n_threads, char **text_out, size_t *n_bytes_out);
+
+extern "C" int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *Lc, const char *path, const char *region_ref,
+                                        int32_t region_left0, int32_t region_right0, const hgx_parse_opts *opts) {
+    HARGCHK(out && Lc && path && opts);
+    char *text = nullptr;
+    size_t n = 0;
+    int rc = hgx_read_alignments(path, region_ref, region_left0, region_right0, opts->n_threads, &text, &n);
+    if (rc) return rc;
+    rc = parse_text(out, Lc, nullptr, text, n, opts);        // tokenises the reader's buffer in place
+    free(text);
+    return rc;
+}
+
+static int parse_text(hgx_batch **out, const hgx_locus *Lc, const char *sam, char *owned, size_t n_bytes, const hgx_parse_opts *opts) {
+    HARGCHK(out && Lc && (sam || owned || n_bytes == 0) && opts);
     hgx_locus &L = *const_cast<hgx_locus *>(Lc);
     hgx_batch *B = new hgx_batch();
     try {
@@ -1144,16 +1166,17 @@ extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *s
         n_threads = std::max(1, std::min(n_threads, 64));
         if (opts->keep_trace) n_threads = 1;                // traces (and novel-variant numbering) follow stream order
         // private, writable copy of the text (tokens are NUL-terminated in place) + line table, both in parallel
-        std::unique_ptr<char[]> text_mem(new char[n_bytes + 1]);      // not value-initialised: filled by the copy below
-        struct { char *p; size_t n; char *data() { return p; } size_t size() const { return n; } } text{text_mem.get(), n_bytes + 1};
+        std::unique_ptr<char[]> text_mem(owned ? nullptr : new char[n_bytes + 1]);   // not value-initialised: filled by the copy below
+        struct { char *p; size_t n; char *data() { return p; } size_t size() const { return n; } } text{owned ? owned : text_mem.get(), n_bytes + 1};
         text.p[n_bytes] = '\n';
         std::vector<std::pair<char *, char *>> lines;
         {
             const int nt = n_bytes > (8u << 20) ? n_threads : 1;
             std::vector<std::vector<std::pair<char *, char *>>> part(nt);
-            parallel_for(nt, n_bytes + 1, [&](int t, size_t b0, size_t e0) {
-                if (e0 > b0) memcpy(text.data() + b0, b0 < n_bytes ? sam + b0 : "\n", std::min(e0, n_bytes) - b0);
-            });
+            if (!owned)
+                parallel_for(nt, n_bytes + 1, [&](int t, size_t b0, size_t e0) {
+                    if (e0 > b0) memcpy(text.data() + b0, b0 < n_bytes ? sam + b0 : "\n", std::min(e0, n_bytes) - b0);
+                });
             parallel_for(nt, n_bytes + 1, [&](int t, size_t b0, size_t e0) {
                 // this thread owns the lines that START in [b0, e0)
                 char *base = text.data(), *end = text.data() + text.size();

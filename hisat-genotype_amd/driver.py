@@ -10,7 +10,7 @@ import os
 
 from . import indexio
 from .locus import PackedLocus
-from .typing import read_alignment_text, type_locus, typing
+from .typing import read_alignment_text, type_locus, typing  # noqa: F401
 
 
 def genotyping_locus(base_fname, locus_list, genotype_genome, ix_dir, only_locus_list, partial, aligners, read_fname, fastq,
@@ -56,10 +56,9 @@ def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, ix_dir=No
                                                             index["Gene_names"], index["Gene_lengths"], index["refGene_loci"],
                                                             index["Vars"], index["Var_list"], index["Links"])
         if isinstance(sam, (bytes, bytearray)) or "\t" in sam:
-            text = sam
-        else:
-            text = read_alignment_text(sam)
-        out[(sample_id, gene)] = type_locus(packed[gene], text, **typing_opts)
+            out[(sample_id, gene)] = type_locus(packed[gene], sam, **typing_opts)
+        else:           # a SAM / BAM path: read, grouped and decoded inside libhgx
+            out[(sample_id, gene)] = type_locus(packed[gene], None, alignment_file=sam, **typing_opts)
     for pl in packed.values():
         pl.close()
     return out

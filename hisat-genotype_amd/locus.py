@@ -252,6 +252,22 @@ class PackedLocus:
         capi.check(capi.lib().hgx_parse_sam(C.byref(h), self.h, data, C.c_size_t(len(data)), C.byref(o)))
         return Batch(h)
 
+    def parse_alignment_file(self, path, region=None, num_editdist=2, error_correction=True, allow_discordant=False,
+                             simulation=False, base_locus=0, n_threads=0):
+        """Front-end straight from a SAM / BAM file (hgx_parse_alignment_file): read, inflate, decode, region filter, name
+        grouping and piece extraction without the text ever passing through Python.  region = "chr:left-right" (1-based)."""
+        reg = None
+        if region:
+            name, span = region.rsplit(":", 1)
+            lo, hi = span.split("-")
+            reg = (name.encode(), int(lo) - 1, int(hi) - 1)
+        o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus, 0,
+                           int(self.base_fname == "codis" and self.gene == "D18S51"), int(n_threads))
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_parse_alignment_file(C.byref(h), self.h, path.encode(), reg[0] if reg else None,
+                                                       C.c_int32(reg[1] if reg else 0), C.c_int32(reg[2] if reg else 0), C.byref(o)))
+        return Batch(h)
+
     def close(self):
         if self._index is not None:
             capi.lib().hgx_index_destroy(self._index)

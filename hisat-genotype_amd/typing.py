@@ -94,11 +94,17 @@ class LocusResult:
 
 
 def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discordant=False,
-               remove_low_abundance_alleles=True, simulation=False, base_locus=0, keep_classes=False, stream=None):
-    """Per-locus typing: the reference's loop body with the O(alleles) work on the GPU."""
+               remove_low_abundance_alleles=True, simulation=False, base_locus=0, keep_classes=False, stream=None,
+               alignment_file=None, region=None):
+    """Per-locus typing: the reference's loop body with the O(alleles) work on the GPU.  Input: name-grouped SAM text
+    (`sam_text`), or `alignment_file` (SAM / BAM, optional "chr:left-right" region) read inside libhgx."""
     res = LocusResult()
-    batch = pl.parse_sam(sam_text, num_editdist=num_editdist, error_correction=error_correction,
-                         allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus)
+    if alignment_file is not None:
+        batch = pl.parse_alignment_file(alignment_file, region, num_editdist=num_editdist, error_correction=error_correction,
+                                        allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus)
+    else:
+        batch = pl.parse_sam(sam_text, num_editdist=num_editdist, error_correction=error_correction,
+                             allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus)
     res.num_reads, res.num_pairs = batch.n_reads, batch.n_pairs
     res.n_pieces, res.n_refs = batch.n_pieces, batch.n_refs
     if batch.n_reads <= 0:                                  # core:1589-1590
@@ -358,11 +364,11 @@ def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partia
                 if genotype_genome != "":
                     _, chr_, left, right = refGene_loci[gene][:4]
                     region, base_locus = "%s:%d-%d" % (chr_, left + 1, right + 1), left
-                sam = read_alignment_text(alignment_fname, region)
-                res = type_locus(pl, sam, num_editdist=num_editdist, error_correction=error_correction,
+                # samtools view F [region] piped through sort -k1,1 -s (core:436-468), and the loop's decode: all inside libhgx
+                res = type_locus(pl, None, num_editdist=num_editdist, error_correction=error_correction,
                                  allow_discordant=allow_discordant,
                                  remove_low_abundance_alleles=remove_low_abundance_alleles, simulation=simulation,
-                                 base_locus=base_locus)
+                                 base_locus=base_locus, alignment_file=alignment_fname, region=region)
                 pl.close()
                 if res.num_reads <= 0:
                     continue

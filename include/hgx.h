@@ -269,6 +269,10 @@ int hgx_parse_sam(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t
 int hgx_read_alignments(const char *path, const char *region_ref_or_null, int32_t region_left0, int32_t region_right0,
                         int32_t n_threads, char **text_out, size_t *n_bytes_out);
 int hgx_free_text(char *text);
+/* hgx_read_alignments + hgx_parse_sam in one call: the reader's buffer is tokenised in place (no copy, no trip through the
+ * caller) -- the whole host side from an alignment file to the piece batch */
+int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *loc, const char *path, const char *region_ref_or_null,
+                             int32_t region_left0, int32_t region_right0, const hgx_parse_opts *opts);
 /* per kept record: "cmp_list2 \t cmp_left \t cmp_right \t left alts \t right alts" (keep_trace) */
 int hgx_batch_trace_text(const hgx_batch *b, char *buf, size_t cap, size_t *needed);
 /* pileup nt_set per backbone position as a 4-bit mask A=1,C=2,G=4,T=8 and counts[L][6] (A,C,G,T,N,D) */

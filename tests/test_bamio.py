@@ -141,3 +141,29 @@ def test_native_reader_tags_and_errors(tmp_path):
         read_alignment_text(str(tmp_path / "cut.bam"))
     with pytest.raises(capi.HgxError):
         read_alignment_text(str(tmp_path / "missing.bam"))
+
+
+def test_parse_alignment_file_equals_text_path(tmp_path):
+    """hgx_parse_alignment_file (file -> piece batch inside libhgx) gives exactly the batch of read_alignment_text +
+    parse_sam, from BAM and from SAM text, shuffled record order included."""
+    import random
+    import numpy as np
+    from hisatgenotype_amd import locus as hl
+    from hisatgenotype_amd.typing import read_alignment_text
+    for name in ("hla_errors_filters", "codis_d18s51"):
+        fx = gu.load(name)
+        loc = fx["_locus"]
+        pl = hl.PackedLocus.from_synth(loc)
+        lines = [l for l in fx["sam"].split("\n") if l]
+        random.Random(2).shuffle(lines)
+        bam = str(tmp_path / (name + ".bam"))
+        sam = str(tmp_path / (name + ".sam"))
+        bamio.write_bam(bam, "\n".join(lines) + "\n", [(loc.ref_allele, len(loc.backbone))], block_size=5000)
+        open(sam, "w").write("\n".join(lines) + "\n")
+        sim = bool(fx.get("simulation", False))
+        for path in (bam, sam):
+            a = pl.parse_sam(read_alignment_text(path), simulation=sim)
+            b = pl.parse_alignment_file(path, simulation=sim)
+            assert (a.n_reads, a.n_pairs, a.n_pieces, a.n_refs) == (b.n_reads, b.n_pairs, b.n_pieces, b.n_refs)
+            assert np.array_equal(a.pieces, b.pieces) and np.array_equal(a.masks, b.masks)
+            assert np.array_equal(a.pair_off, b.pair_off) and np.array_equal(a.pair_ref, b.pair_ref)
