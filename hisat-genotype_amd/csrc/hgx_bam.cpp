@@ -9,6 +9,9 @@
 //   * header lines dropped, optional region filter (reference name, 0-based POS in [left, right], as the Python reader does);
 //   * name grouping: STABLE sort of the records by QNAME, bytewise (LC_ALL=C `sort -k1,1 -s`): parallel chunk sorts + merges.
 // hisat-genotype_amd/bamio.py is the pure-Python statement of the same formats; tests compare the two byte for byte.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -17,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -41,10 +45,28 @@ inline uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] <<
 inline uint32_t rd32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline int32_t rdi32(const unsigned char *p) { return (int32_t)rd32(p); }
 
+// byte buffer without value initialisation (hundreds of MB are overwritten right after allocation)
+struct Bytes {
+    unsigned char *p = nullptr;
+    size_t n = 0;
+    Bytes() = default;
+    Bytes(const Bytes &) = delete;
+    Bytes &operator=(const Bytes &) = delete;
+    ~Bytes() { hgx_host_free(p); }
+    void alloc(size_t k) { hgx_host_free(p); p = (unsigned char *)hgx_host_alloc(k ? k : 1); n = k; }
+    void release() { hgx_host_free(p); p = nullptr; n = 0; }
+    void swap(Bytes &o) { std::swap(p, o.p); std::swap(n, o.n); }
+    unsigned char *data() { return p; }
+    const unsigned char *data() const { return p; }
+    size_t size() const { return n; }
+    unsigned char &operator[](size_t i) { return p[i]; }
+    const unsigned char &operator[](size_t i) const { return p[i]; }
+};
+
 struct Block { size_t in_off, in_len, out_off, out_len; uint32_t crc; };
 
 // inflate every BGZF block of `data` into one buffer
-int bgzf_inflate(const std::vector<unsigned char> &data, int n_threads, std::vector<unsigned char> &out) {
+int bgzf_inflate(const Bytes &data, int n_threads, Bytes &out) {
     std::vector<Block> blocks;
     size_t off = 0, total = 0;
     const size_t n = data.size();
@@ -74,7 +96,7 @@ int bgzf_inflate(const std::vector<unsigned char> &data, int n_threads, std::vec
         blocks.push_back(b);
         off += blen;
     }
-    out.resize(total);
+    out.alloc(total);
     std::vector<int> bad(std::max(1, n_threads), 0);
     par_for(n_threads, blocks.size(), [&](int t, size_t b0, size_t b1) {
         for (size_t i = b0; i < b1; ++i) {
@@ -97,14 +119,14 @@ int bgzf_inflate(const std::vector<unsigned char> &data, int n_threads, std::vec
     return HGX_OK;
 }
 
-void put_int(std::string &s, long long v) {
+void put_int(PString &s, long long v) {
     char buf[24];
     int n = snprintf(buf, sizeof buf, "%lld", v);
     s.append(buf, (size_t)n);
 }
 
 // one BAM record (after its block_size word) -> SAM text line (no newline)
-bool bam_record_text(const unsigned char *r, size_t len, const std::vector<std::string> &refs, std::string &s) {
+bool bam_record_text(const unsigned char *r, size_t len, const std::vector<std::string> &refs, PString &s) {
     static const char CIG[] = "MIDNSHP=X", SEQ[] = "=ACMGRSVTWYHKDBN";
     if (len < 32) return false;
     const int32_t ref_id = rdi32(r), pos = rdi32(r + 4);
@@ -117,7 +139,7 @@ bool bam_record_text(const unsigned char *r, size_t len, const std::vector<std::
     q += l_rn;
     s.push_back('\t'); put_int(s, flag);
     s.push_back('\t');
-    if (ref_id >= 0 && (size_t)ref_id < refs.size()) s += refs[ref_id]; else s.push_back('*');
+    if (ref_id >= 0 && (size_t)ref_id < refs.size()) s.append(refs[ref_id].data(), refs[ref_id].size()); else s.push_back('*');
     s.push_back('\t'); put_int(s, (long long)pos + 1);
     s.push_back('\t'); put_int(s, mapq);
     s.push_back('\t');
@@ -131,7 +153,7 @@ bool bam_record_text(const unsigned char *r, size_t len, const std::vector<std::
     s.push_back('\t');
     if (nref < 0) s.push_back('*');
     else if (nref == ref_id) s.push_back('=');
-    else if ((size_t)nref < refs.size()) s += refs[nref];
+    else if ((size_t)nref < refs.size()) s.append(refs[nref].data(), refs[nref].size());
     else s.push_back('*');
     s.push_back('\t'); put_int(s, (long long)npos + 1);
     s.push_back('\t'); put_int(s, tlen);
@@ -278,28 +300,34 @@ extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int
             fprintf(stderr, "[hgx_read_alignments] %-18s %8.1f ms\n", what, (t - t_prev) * 1e3);
             t_prev = t;
         };
-        std::vector<unsigned char> data;
+        Bytes data;
         {
-            FILE *f = fopen(path, "rb");
-            if (!f) { hgx_set_error("cannot open %s", path); return HGX_EINVAL; }
-            fseek(f, 0, SEEK_END);
-            const long sz = ftell(f);
-            fseek(f, 0, SEEK_SET);
-            data.resize(sz > 0 ? (size_t)sz : 0);
-            const size_t got = data.empty() ? 0 : fread(data.data(), 1, data.size(), f);
-            fclose(f);
-            if (got != data.size()) { hgx_set_error("short read on %s", path); return HGX_EINVAL; }
+            const int fd = open(path, O_RDONLY);
+            if (fd < 0) { hgx_set_error("cannot open %s", path); return HGX_EINVAL; }
+            struct stat sb;
+            if (fstat(fd, &sb) != 0 || sb.st_size < 0) { close(fd); hgx_set_error("cannot stat %s", path); return HGX_EINVAL; }
+            data.alloc((size_t)sb.st_size);                    // not zero-filled: every byte is written by the reads below
+            std::vector<int> bad(n_threads, 0);
+            par_for(data.size() > (8u << 20) ? n_threads : 1, data.size(), [&](int t, size_t b, size_t e) {
+                while (b < e) {
+                    const ssize_t got = pread(fd, data.data() + b, e - b, (off_t)b);
+                    if (got <= 0) { bad[t] = 1; return; }
+                    b += (size_t)got;
+                }
+            });
+            close(fd);
+            for (int v : bad) if (v) { hgx_set_error("short read on %s", path); return HGX_EINVAL; }
         }
         lap("read file");
-        std::vector<unsigned char> raw;
+        Bytes raw;
         if (data.size() >= 2 && data[0] == 0x1f && data[1] == 0x8b) {
             const int rc = bgzf_inflate(data, n_threads, raw);
             if (rc) return rc;
-            std::vector<unsigned char>().swap(data);
+            data.release();
         } else raw.swap(data);
 
         lap("inflate");
-        std::vector<std::string> chunks;           // text produced from BAM records (kept alive for the Line pointers)
+        std::vector<PString> chunks;               // text produced from BAM records (kept alive for the Line pointers)
         std::vector<Line> lines;
         if (raw.size() >= 4 && memcmp(raw.data(), "BAM\1", 4) == 0) {
             const size_t n = raw.size();
@@ -324,6 +352,14 @@ extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int
             std::vector<std::pair<size_t, uint32_t>> recs;     // (offset after block_size, length)
             while (p < n) {
                 if (p + 4 > n) { hgx_set_error("truncated BAM record at offset %zu", p); return HGX_EPARSE; }
+                // the walk is a pointer chase through memory other cores just wrote (one cache miss per record, ~120 ns each):
+                // touching the lines a few KB ahead turns it into a streaming read
+                if (p + 8192 < n) {
+                    __builtin_prefetch(&raw[p + 4096]);
+                    __builtin_prefetch(&raw[p + 4096 + 64]);
+                    __builtin_prefetch(&raw[p + 4096 + 128]);
+                    __builtin_prefetch(&raw[p + 4096 + 192]);
+                }
                 const uint32_t bs = rd32(&raw[p]);
                 if (bs < 32 || p + 4 + bs > n) { hgx_set_error("truncated BAM record at offset %zu", p); return HGX_EPARSE; }
                 bool keep = true;
@@ -334,30 +370,29 @@ extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int
                 if (keep) recs.push_back({p + 4, bs});
                 p += 4 + (size_t)bs;
             }
+            lap("  BAM record walk");
             const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, recs.size() / 2000 + 1));
             chunks.resize(T);
-            std::vector<std::vector<uint32_t>> ends(T);
             std::vector<int> bad(T, 0);
+            lines.resize(recs.size());
             par_for(T, recs.size(), [&](int t, size_t b, size_t e) {
-                std::string &s = chunks[t];
+                PString &s = chunks[t];
                 s.reserve((e - b) * 420);
-                ends[t].reserve(e - b);
+                std::vector<uint32_t> ends;
+                ends.reserve(e - b);
                 for (size_t i = b; i < e; ++i) {
                     if (!bam_record_text(&raw[recs[i].first], recs[i].second, refs, s)) { bad[t] = 1; return; }
                     if (s.size() > 0xFFFFFFFFull) { bad[t] = 2; return; }
-                    ends[t].push_back((uint32_t)s.size());
+                    ends.push_back((uint32_t)s.size());
+                }
+                uint32_t prev = 0;                            // the chunk's text no longer moves: its line table
+                for (size_t i = b; i < e; ++i) {
+                    make_line(s.data() + prev, ends[i - b] - prev, lines[i]);
+                    prev = ends[i - b];
                 }
             });
             for (int v : bad) if (v) { hgx_set_error(v == 2 ? "BAM chunk too large" : "malformed BAM record"); return HGX_EPARSE; }
-            lines.resize(recs.size());
-            size_t k = 0;
-            for (int t = 0; t < T; ++t) {
-                uint32_t prev = 0;
-                for (uint32_t en : ends[t]) {
-                    make_line(chunks[t].data() + prev, en - prev, lines[k++]);
-                    prev = en;
-                }
-            }
+            lap("  BAM -> text");
         } else {
             // SAM text: records = non-empty lines that do not start with '@'
             const char *base = (const char *)raw.data(), *end = base + raw.size();
@@ -394,8 +429,7 @@ extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int
         std::vector<size_t> offs(lines.size() + 1, 0);
         for (size_t i = 0; i < lines.size(); ++i) { offs[i] = total; total += (size_t)lines[i].len + 1; }
         offs[lines.size()] = total;
-        char *out = (char *)malloc(total + 1);
-        if (!out) { hgx_set_error("out of memory (%zu bytes)", total); return HGX_ENOMEM; }
+        char *out = (char *)hgx_host_alloc(total + 1);
         par_for(n_threads, lines.size(), [&](int, size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 memcpy(out + offs[i], lines[i].p, lines[i].len);
@@ -414,6 +448,6 @@ extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int
 }
 
 extern "C" int hgx_free_text(char *text) {
-    free(text);
+    hgx_host_free(text);
     return HGX_OK;
 }

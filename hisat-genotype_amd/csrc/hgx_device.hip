@@ -228,7 +228,9 @@ void hgx_pool_free(void *p) {
     if (it == P.size_of.end()) { (void)hipFree(p); return; }
     P.free_blocks.emplace(it->second, p);
 }
+void hgx_host_pool_trim();
 extern "C" int hgx_pool_trim(void) {
+    hgx_host_pool_trim();
     Pool &P = pool();
     std::lock_guard<std::mutex> g(P.mu);
     for (auto &kv : P.free_blocks) { P.size_of.erase(kv.second); (void)hipFree(kv.second); }

@@ -346,3 +346,64 @@ extern "C" int hgx_batch_arrays(const hgx_batch *b, const hgx_piece **pieces, co
     if (pair_ref) *pair_ref = b->pair_ref.data();
     return HGX_OK;
 }
+
+
+// ---- host block pool (declared in hgx_internal.hpp) ------------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <new>
+namespace {
+struct HostPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;      // capacity -> block (header included)
+    size_t held = 0;                                // bytes parked in free_blocks
+};
+constexpr size_t HOST_POOL_MAX_BYTES = 8ull << 30, HOST_POOL_MAX_BLOCKS = 1024;
+HostPool &host_pool() { static HostPool p; return p; }
+struct BlockHeader { size_t cap; uint64_t magic; uint64_t pad[2]; };     // 32 bytes: keeps the payload 32-byte aligned
+constexpr uint64_t HOST_MAGIC = 0x6867785f686f7374ull;
+constexpr size_t HOST_POOL_MIN = 1u << 20;
+}   // namespace
+
+void *hgx_host_alloc(size_t bytes) {
+    const size_t need = bytes + sizeof(BlockHeader);
+    if (need >= HOST_POOL_MIN) {
+        HostPool &P = host_pool();
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.free_blocks.lower_bound(need);
+        if (it != P.free_blocks.end() && it->first <= 2 * need) {
+            void *b = it->second;
+            P.held -= it->first;
+            P.free_blocks.erase(it);
+            return (char *)b + sizeof(BlockHeader);
+        }
+    }
+    const size_t cap = need >= HOST_POOL_MIN ? need + need / 16 : need;      // a little slack so that similar sizes fit later
+    BlockHeader *h = (BlockHeader *)malloc(cap);
+    if (!h) throw std::bad_alloc();
+    h->cap = cap;
+    h->magic = HOST_MAGIC;
+    return (char *)h + sizeof(BlockHeader);
+}
+void hgx_host_free(void *p) {
+    if (!p) return;
+    BlockHeader *h = (BlockHeader *)((char *)p - sizeof(BlockHeader));
+    if (h->magic != HOST_MAGIC) return;               // not ours: leak rather than corrupt
+    if (h->cap >= HOST_POOL_MIN) {
+        HostPool &P = host_pool();
+        std::lock_guard<std::mutex> g(P.mu);
+        if (P.free_blocks.size() < HOST_POOL_MAX_BLOCKS && P.held + h->cap <= HOST_POOL_MAX_BYTES) {
+            P.free_blocks.insert({h->cap, (void *)h});
+            P.held += h->cap;
+            return;
+        }
+    }
+    free(h);
+}
+void hgx_host_pool_trim() {
+    HostPool &P = host_pool();
+    std::lock_guard<std::mutex> g(P.mu);
+    for (auto &kv : P.free_blocks) free(kv.second);
+    P.free_blocks.clear();
+    P.held = 0;
+}

@@ -102,6 +102,24 @@ struct hgx_batch {
 
 // piece "left-ids-right" -> index of the distinct piece in the batch (creates it if new). < 0 on error.
 int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &loc, int32_t left, int32_t right, const int32_t *ids, int32_t n_ids);
+// Host block pool (hgx_host.cpp): the ingestion path allocates and drops several buffers of hundreds of MB per sample; handing
+// them back to the kernel (munmap) and faulting fresh pages in costs more than the work done on them.  Blocks >= 1 MB are kept
+// and reused (best fit within 2x); hgx_pool_trim() releases them.
+void *hgx_host_alloc(size_t bytes);
+void hgx_host_free(void *p);
+void hgx_host_pool_trim();
+template <class T>
+struct HostPoolAlloc {
+    typedef T value_type;
+    HostPoolAlloc() = default;
+    template <class U> HostPoolAlloc(const HostPoolAlloc<U> &) {}
+    T *allocate(size_t n) { return (T *)hgx_host_alloc(n * sizeof(T)); }
+    void deallocate(T *p, size_t) { hgx_host_free(p); }
+    template <class U> bool operator==(const HostPoolAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const HostPoolAlloc<U> &) const { return false; }
+};
+typedef std::basic_string<char, std::char_traits<char>, HostPoolAlloc<char>> PString;
+
 // find-or-insert a piece given its word range and (MP,P) mask words
 uint32_t hgx_intern_masks(hgx_batch &b, uint16_t lo, uint8_t nw, const uint32_t *m);
 void hgx_finalize_batch(hgx_batch &b);

@@ -1132,16 +1132,24 @@ extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *s
 
 extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int32_t region_left0, int32_t region_right0,
                                    int32_t n_threads, char **text_out, size_t *n_bytes_out);
+extern "C" int hgx_free_text(char *text);
 
 extern "C" int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *Lc, const char *path, const char *region_ref,
                                         int32_t region_left0, int32_t region_right0, const hgx_parse_opts *opts) {
     HARGCHK(out && Lc && path && opts);
     char *text = nullptr;
     size_t n = 0;
+    const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     int rc = hgx_read_alignments(path, region_ref, region_left0, region_right0, opts->n_threads, &text, &n);
     if (rc) return rc;
+    const double t1 = now();
     rc = parse_text(out, Lc, nullptr, text, n, opts);        // tokenises the reader's buffer in place
-    free(text);
+    const double t2 = now();
+    hgx_free_text(text);
+    if (prof) fprintf(stderr, "[hgx_parse_alignment_file] read %.1f ms, parse %.1f ms, free %.1f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3,
+                      (now() - t2) * 1e3);
     return rc;
 }
 
@@ -1166,7 +1174,8 @@ static int parse_text(hgx_batch **out, const hgx_locus *Lc, const char *sam, cha
         n_threads = std::max(1, std::min(n_threads, 64));
         if (opts->keep_trace) n_threads = 1;                // traces (and novel-variant numbering) follow stream order
         // private, writable copy of the text (tokens are NUL-terminated in place) + line table, both in parallel
-        std::unique_ptr<char[]> text_mem(owned ? nullptr : new char[n_bytes + 1]);   // not value-initialised: filled by the copy below
+        struct PoolFree { void operator()(char *p) const { hgx_host_free(p); } };
+        std::unique_ptr<char, PoolFree> text_mem(owned ? nullptr : (char *)hgx_host_alloc(n_bytes + 1));   // filled by the copy below
         struct { char *p; size_t n; char *data() { return p; } size_t size() const { return n; } } text{owned ? owned : text_mem.get(), n_bytes + 1};
         text.p[n_bytes] = '\n';
         std::vector<std::pair<char *, char *>> lines;

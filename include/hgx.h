@@ -264,8 +264,8 @@ int hgx_parse_sam(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t
  * `sort -k1,1 -s` (typing_core.py:436-468) -- from a SAM text file or a BAM file: BGZF blocks inflated in parallel (zlib),
  * BAM records decoded to SAM text (mandatory fields + tags A c C s S i I f Z H B), header lines dropped, records of
  * reference `region_ref_or_null` with 0-based POS in [region_left0, region_right0] kept (NULL = all), then grouped by a
- * STABLE bytewise sort on QNAME.  *text_out is a malloc'ed, NUL-terminated buffer of *n_bytes_out bytes (every record ends
- * in '\n'), ready for hgx_parse_sam; release it with hgx_free_text.  n_threads <= 0: all host threads (at most 64). */
+ * STABLE bytewise sort on QNAME.  *text_out is a library-owned (pooled), NUL-terminated buffer of *n_bytes_out bytes (every record ends
+ * in '\n'), ready for hgx_parse_sam; release it with hgx_free_text (not free()).  n_threads <= 0: all host threads (at most 64). */
 int hgx_read_alignments(const char *path, const char *region_ref_or_null, int32_t region_left0, int32_t region_right0,
                         int32_t n_threads, char **text_out, size_t *n_bytes_out);
 int hgx_free_text(char *text);
