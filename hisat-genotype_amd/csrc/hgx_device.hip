@@ -328,13 +328,14 @@ __global__ __launch_bounds__(256) void k_piece_compat(const uint32_t *__restrict
 // word range from L2 for every piece (rocprof: ~9 TB/s of L2 traffic, the whole 0.8 ms); here a workgroup
 // = 1024 alleles x 256 consecutive pieces stages what they share once:
 //   * the pieces' descriptors and (MP, P) mask words            -> LDS (broadcast reads in the loop),
-//   * the index rows of the window of <= 12 variant words the pieces cover -> LDS tile[word][allele]
-//     (the front-end sorts pieces by lo_word, so 256 neighbours span one or two words plus their length);
+//   * the index rows of the window of <= 8 variant words the pieces cover -> LDS tile[word][allele]
+//     (the front-end sorts pieces by lo_word, so 256 neighbours span one or two words plus their length; 8 words keep the
+//     workgroup at 50 KB of LDS = three workgroups per CU, which matters more than the occasional extra window);
 //   * thread = allele: per piece and word one conflict-free ds_read_b32 + xor + and-or, the 64 verdicts of
 //     a wave leave as a ballot that lane (piece mod 64) keeps; one store per 64 pieces.
 // Pieces that do not fit the current window start a new one (any piece order stays correct).
 // ------------------------------------------------------------------------------------------------
-#define PT_W 12
+#define PT_W 8
 #define PT_PB 256
 #define PT_NW 8
 #define PT_T 512              // threads per workgroup: every thread scores TWO alleles (tid and tid + 512) per piece, so the
