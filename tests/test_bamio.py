@@ -167,3 +167,25 @@ def test_parse_alignment_file_equals_text_path(tmp_path):
             assert (a.n_reads, a.n_pairs, a.n_pieces, a.n_refs) == (b.n_reads, b.n_pairs, b.n_pieces, b.n_refs)
             assert np.array_equal(a.pieces, b.pieces) and np.array_equal(a.masks, b.masks)
             assert np.array_equal(a.pair_off, b.pair_off) and np.array_equal(a.pair_ref, b.pair_ref)
+
+
+def test_reader_edge_inputs(tmp_path):
+    """Empty SAM, header-only SAM, header-only BAM -> empty record stream; plain gzip (not BGZF) is refused."""
+    import gzip as gz
+    import pytest
+    from hisatgenotype_amd import capi
+    from hisatgenotype_amd.typing import read_alignment_text
+    p = str(tmp_path / "empty.sam")
+    open(p, "w").write("")
+    assert read_alignment_text(p) == b""
+    p = str(tmp_path / "hdr.sam")
+    open(p, "w").write("@HD\tVN:1.0\n@SQ\tSN:x\tLN:10\n")
+    assert read_alignment_text(p) == b""
+    p = str(tmp_path / "hdr.bam")
+    bamio.write_bam(p, "", [("x", 10)])
+    assert read_alignment_text(p) == b"" and read_alignment_text(p, native=False) in (b"", b"\n")
+    p = str(tmp_path / "plain.sam.gz")
+    with gz.open(p, "wb") as f:
+        f.write(b"r1\t0\tx\t1\t0\t1M\t*\t0\t0\tA\tI\n")
+    with pytest.raises(capi.HgxError):
+        read_alignment_text(p)
