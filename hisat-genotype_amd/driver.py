@@ -39,26 +39,70 @@ def genotyping_locus(base_fname, locus_list, genotype_genome, ix_dir, only_locus
                   output_allele_counts)
 
 
-def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, ix_dir=None, **typing_opts):
+def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, ix_dir=None, inflight=1, **typing_opts):
     """Type independent (sample_id, gene, sam_text_or_path) tasks; rank `rank` of `world` handles its share
     (deterministic greedy split, no communication).  `index` is the dict from indexio.load_index; with `ix_dir` the
-    packed loci come through the binary cache next to the index files (indexio.packed_locus).
+    packed loci come through the binary cache next to the index files (indexio.packed_locus).  `inflight` > 1 types that many
+    tasks concurrently on this rank's GPU (host threads with their own streams): the EM of one sample is a chain of short
+    launches that leaves the GPU to the front-end work and scoring of the next (bench.py --inflight).
     Returns {(sample_id, gene): LocusResult} for this rank's tasks."""
+    import threading
+    from . import capi
     from . import dist as hdist
     mine = hdist.shard(list(tasks), rank, world, weights)
     packed = {}
-    out = {}
-    for sample_id, gene, sam in mine:
-        if gene not in packed and ix_dir is not None:
+    for _, gene, _ in mine:
+        if gene in packed:
+            continue
+        if ix_dir is not None:
             packed[gene] = indexio.packed_locus(ix_dir, base_fname, gene, index)
-        if gene not in packed:
+        else:
             packed[gene] = PackedLocus.from_reference_dicts(gene, base_fname, index["refGenes"], index["Genes"],
                                                             index["Gene_names"], index["Gene_lengths"], index["refGene_loci"],
                                                             index["Vars"], index["Var_list"], index["Links"])
+        packed[gene].index()                     # device index created once, before any worker needs it
+    out = {}
+
+    def one(task, stream):
+        sample_id, gene, sam = task
         if isinstance(sam, (bytes, bytearray)) or "\t" in sam:
-            out[(sample_id, gene)] = type_locus(packed[gene], sam, **typing_opts)
-        else:           # a SAM / BAM path: read, grouped and decoded inside libhgx
-            out[(sample_id, gene)] = type_locus(packed[gene], None, alignment_file=sam, **typing_opts)
+            return (sample_id, gene), type_locus(packed[gene], sam, stream=stream, **typing_opts)
+        # a SAM / BAM path: read, grouped and decoded inside libhgx
+        return (sample_id, gene), type_locus(packed[gene], None, alignment_file=sam, stream=stream, **typing_opts)
+
+    if inflight <= 1 or len(mine) <= 1:
+        for task in mine:
+            k, v = one(task, None)
+            out[k] = v
+    else:
+        lock = threading.Lock()
+        state = {"next": 0, "err": None}
+        dev = capi.current_device()
+
+        def work():
+            try:
+                capi.set_device(dev)
+                stream = capi.get_stream(2)              # this thread's main stream (its side streams are per thread too)
+                while True:
+                    with lock:
+                        i = state["next"]
+                        if i >= len(mine) or state["err"] is not None:
+                            return
+                        state["next"] = i + 1
+                    k, v = one(mine[i], stream)
+                    with lock:
+                        out[k] = v
+            except BaseException as e:                   # re-raised on the calling thread
+                with lock:
+                    state["err"] = e
+
+        threads = [threading.Thread(target=work) for _ in range(min(inflight, len(mine)))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if state["err"] is not None:
+            raise state["err"]
     for pl in packed.values():
         pl.close()
     return out

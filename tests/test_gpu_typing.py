@@ -216,6 +216,11 @@ def test_run_panel_shards_tasks(tmp_path):
     assert set(got) == set(truth)
     for key, res in got.items():
         assert {a for a, _ in res.gene_prob[:2]} == truth[key]
+    # the same panel with three tasks in flight on the GPU: identical results
+    conc = hgx.run_panel(tasks, ix, "hla", inflight=3)
+    assert set(conc) == set(got)
+    for key in got:
+        assert conc[key].gene_prob == got[key].gene_prob and conc[key].counts_sorted == got[key].counts_sorted
 
 
 def test_typing_reads_bam_without_samtools(tmp_path):
