@@ -1204,6 +1204,150 @@ __global__ __launch_bounds__(BLOCK) void k_em_tail(const uint64_t *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Hand-off EM in one launch (core:1752-1782: Gene_cmpt2 = every gene-level class filtered to exon_alleles, empty ones
+// dropped, counts merged; then single_abundance with lengths).  When the filter keeps <= 64 alleles the whole thing --
+// filter, merge, EM -- fits the single-wavefront machinery: every class collapses to a 64-bit mask over the kept alleles,
+// equal masks merge in an LDS hash table (count added, FIRST class index kept), wave 0 orders the merged classes by that
+// first index (= the dict order a dedup of the filtered rows produces, so the sums come out bit-identical to the
+// dedup + k_em_wave path) and runs the EM from the initial estimate.  scal[S_FALLBACK] = 1 if > 64 distinct masks remain.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int S_NCLS = 7;           // (re-uses the S_NCOLS word) number of merged classes
+
+// Several workgroups scan the class rows (one LDS merge table each); every workgroup publishes its <= 64 merged entries with
+// device-scope stores and takes a ticket; the last one merges the published entries and runs the EM (cf. k_lutmatvec's tail).
+struct MaskedEntry { unsigned long long key, cnt; unsigned int first, pad; };
+
+__global__ __launch_bounds__(BLOCK) void k_em_masked(const uint64_t *__restrict__ B, int C, int n_words,
+                                                     const int64_t *__restrict__ count, const int32_t *__restrict__ al, int A1,
+                                                     const double *__restrict__ lenc, int remove_low,
+                                                     double *__restrict__ out, int32_t *__restrict__ first_out,
+                                                     double *__restrict__ scal, MaskedEntry *__restrict__ pub,
+                                                     unsigned *__restrict__ ticket) {
+    __shared__ int n_keys, n_list, is_last;
+    __shared__ unsigned long long keys[TAIL_SLOTS], cnts[TAIL_SLOTS];
+    __shared__ unsigned int firsts[TAIL_SLOTS];
+    __shared__ unsigned long long lk[64], lc[64];
+    __shared__ unsigned int lf[64];
+    __shared__ int sal[64];
+    const int tid = threadIdx.x, nb = gridDim.x, bid = blockIdx.x;
+    auto reset_table = [&]() {
+        if (tid == 0) { n_keys = 0; n_list = 0; }
+        for (int i = tid; i < TAIL_SLOTS; i += BLOCK) { keys[i] = 0; cnts[i] = 0; firsts[i] = 0xFFFFFFFFu; }
+    };
+    auto insert = [&](unsigned long long m, unsigned long long cn, unsigned int fi) {
+        unsigned h = (unsigned)(mix64(m) & (TAIL_SLOTS - 1));
+        for (;;) {
+            const unsigned long long old = atomicCAS(&keys[h], 0ull, m);
+            if (old == 0ull) atomicAdd(&n_keys, 1);
+            if (old == 0ull || old == m) {
+                atomicAdd(&cnts[h], cn);
+                atomicMin(&firsts[h], fi);
+                return;
+            }
+            h = (h + 1) & (TAIL_SLOTS - 1);
+        }
+    };
+    reset_table();
+    if (tid < 64) sal[tid] = tid < A1 ? al[tid] : 0;
+    __syncthreads();
+    const int per = (C + nb - 1) / nb, c_lo = bid * per, c_hi = min(C, c_lo + per);
+    for (int c = c_lo + tid; c < c_hi; c += BLOCK) {
+        const uint64_t *row = B + (size_t)c * n_words;
+        unsigned long long m = 0;
+        for (int j = 0; j < A1; ++j) {
+            const int g = sal[j];
+            m |= ((row[g >> 6] >> (g & 63)) & 1ull) << j;
+        }
+        if (m == 0) continue;
+        if (*(volatile int *)&n_keys > 64) break;
+        insert(m, (unsigned long long)count[c], (unsigned int)c);
+    }
+    __syncthreads();
+    // publish this workgroup's entries (device-scope stores), then the ticket
+    const int mine = n_keys;
+    if (tid < 64) {
+        for (int i = tid; i < TAIL_SLOTS; i += 64) {
+            if (keys[i]) {
+                const int k = atomicAdd(&n_list, 1);
+                if (k < 64) { lk[k] = keys[i]; lc[k] = cnts[i]; lf[k] = firsts[i]; }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        MaskedEntry *e = pub + (size_t)bid * 64 + tid;
+        const bool have = mine <= 64 && tid < mine;
+        __hip_atomic_store(&e->key, have ? lk[tid] : (mine > 64 ? ~0ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&e->cnt, have ? lc[tid] : 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&e->first, have ? lf[tid] : 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = old == (unsigned)(nb - 1);
+    }
+    __syncthreads();
+    if (!is_last) return;
+    // ---- last workgroup: merge what everybody published ----
+    reset_table();
+    __syncthreads();
+    bool overflow = false;
+    for (int i = tid; i < nb * 64; i += BLOCK) {
+        const MaskedEntry *e = pub + i;
+        const unsigned long long k = __hip_atomic_load(&e->key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == ~0ull) { overflow = true; continue; }
+        if (k == 0ull) continue;
+        const unsigned long long cn = __hip_atomic_load(&e->cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int fi = __hip_atomic_load(&e->first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        insert(k, cn, fi);
+    }
+    const int any_over = __syncthreads_or(overflow);
+    const int C1 = n_keys;
+    if (any_over || C1 > 64) {
+        if (tid == 0) { scal[S_FALLBACK] = 1.0; scal[S_DONE] = 1.0; }
+        return;
+    }
+    if (tid >= 64) return;
+    const int lane = tid;
+    for (int i = lane; i < TAIL_SLOTS; i += 64) {
+        if (keys[i]) {
+            const int k = atomicAdd(&n_list, 1);
+            lk[k] = keys[i];
+            lc[k] = cnts[i];
+            lf[k] = firsts[i];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long myk = lane < C1 ? lk[lane] : 0ull, myc = lane < C1 ? lc[lane] : 0ull;
+    const unsigned int myf = lane < C1 ? lf[lane] : 0xFFFFFFFFu;
+    int rank = 0;                                            // first-seen order: rank by the first class index (all distinct)
+    for (int j = 0; j < C1; ++j) rank += lf[j] < myf;
+    WaveEM E;
+    E.R = 0; E.K = 0; E.n = 0.0; E.C = C1; E.A1 = A1;
+    for (int j = 0; j < C1; ++j) {
+        const int rj = __builtin_amdgcn_readlane(rank, j);
+        const uint64_t kj = lane_u64(myk, j), cj = lane_u64(myc, j);
+        if (lane == rj) { E.R = kj; E.n = (double)(long long)cj; }
+    }
+    for (int j = 0; j < A1; ++j) {
+        const uint64_t col = __ballot((E.R >> j) & 1ull);
+        if (lane == j) E.K = col;
+    }
+    const bool use_len = lenc != nullptr;
+    E.len = (use_len && lane < A1) ? lenc[lane] : 1.0;
+    if (lane < A1) { out[lane] = -1.0; first_out[lane] = E.K ? __builtin_ctzll(E.K) : -1; }
+    if (lane == 0) scal[S_NCLS] = (double)C1;
+    bool pr;
+    double p = wave_map(E, 0.0, false, 1.0, true, use_len, pr);
+    const double tot = wave_sum_f64(pr ? p : 0.0);
+    p = pr ? p / tot : 0.0;
+    wave_em_run(E, p, pr, 0, remove_low, use_len, lane, out, scal);      // lane j writes out[j]: the compact result vector
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Active-allele compaction.  At the exon level only group representatives occur in classes (core:86-115), so a third
 // or more of the allele columns are all-zero; the EM matrices are restricted to the alleles that occur at all.
 // ------------------------------------------------------------------------------------------------------------
@@ -2563,6 +2707,80 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     (void)A_full;
     if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
     return HGX_OK;
+}
+
+// Gene_cmpt2 + EM #2 (core:1752-1782) without materialising the filtered class set when <= 64 alleles pass the filter
+extern "C" int hgx_em_masked(const hgx_classes *cc, const uint64_t *mask_host, int32_t n_alleles, int32_t remove_low,
+                             const int32_t *allele_len, double *prob_host, int32_t *first_class_host, int32_t *n_iter_host,
+                             int32_t *n_classes_host, void *stream) {
+    ARGCHK(cc && mask_host && prob_host && first_class_host && n_alleles > 0 && n_alleles <= cc->a_pad);
+    hipStream_t st = (hipStream_t)stream;
+    for (int a = 0; a < n_alleles; ++a) { prob_host[a] = -1.0; first_class_host[a] = -1; }
+    if (n_iter_host) *n_iter_host = 0;
+    if (n_classes_host) *n_classes_host = 0;
+    const int C = cc->n_classes;
+    if (C == 0) return HGX_OK;
+    std::vector<int32_t> al;
+    for (int w = 0; w < cc->w64; ++w)
+        for (uint64_t m = mask_host[w]; m; m &= m - 1) {
+            const int a = 64 * w + __builtin_ctzll(m);
+            if (a < n_alleles) al.push_back(a);
+        }
+    if (al.empty()) return HGX_OK;
+    if (al.size() <= 64 && !getenv("HGX_EM_NO_MASKED")) {
+        const int A1 = (int)al.size();
+        DevBuf b_al, b_len, b_out, b_first, b_scal;
+        ALLOC(b_al, 64 * 4); ALLOC(b_out, 64 * 8); ALLOC(b_first, 64 * 4); ALLOC(b_scal, S_N * 8);
+        { int rc_ = hgx_h2d(b_al.p, al.data(), (size_t)A1 * 4, st); if (rc_) return rc_; }
+        double *d_len = nullptr;
+        if (allele_len) {
+            double l[64];
+            for (int j = 0; j < A1; ++j) l[j] = (double)allele_len[al[j]];
+            ALLOC(b_len, 64 * 8);
+            { int rc_ = hgx_h2d(b_len.p, l, (size_t)A1 * 8, st); if (rc_) return rc_; }
+            d_len = b_len.as<double>();
+        }
+        HIPCHK(hipMemsetAsync(b_scal.p, 0, S_N * 8, st));
+        const int nb = std::max(1, std::min(64, (C + 511) / 512));
+        DevBuf b_pub, b_ticket;
+        ALLOC(b_pub, (size_t)nb * 64 * sizeof(MaskedEntry)); ALLOC(b_ticket, 4);
+        HIPCHK(hipMemsetAsync(b_ticket.p, 0, 4, st));
+        hipLaunchKernelGGL(k_em_masked, dim3(nb), dim3(BLOCK), 0, st, cc->d_bits, C, cc->w64, cc->d_count, b_al.as<int32_t>(), A1, d_len,
+                           remove_low ? 1 : 0, b_out.as<double>(), b_first.as<int32_t>(), b_scal.as<double>(),
+                           (MaskedEntry *)b_pub.p, b_ticket.as<unsigned>());
+        HIPCHK(hipGetLastError());
+        double out[64], h_scal[S_N];
+        int32_t first[64];
+        { int rc_ = hgx_d2h(out, b_out.p, (size_t)A1 * 8, st); if (rc_) return rc_; }
+        { int rc_ = hgx_d2h(first, b_first.p, (size_t)A1 * 4, st); if (rc_) return rc_; }
+        { int rc_ = hgx_d2h(h_scal, b_scal.p, S_N * 8, st); if (rc_) return rc_; }
+        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+        if (h_scal[S_FALLBACK] == 0.0) {
+            if (h_scal[S_KEYERR] != 0.0) {
+                hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
+                return HGX_EKEY;
+            }
+            for (int j = 0; j < A1; ++j) {
+                prob_host[al[j]] = out[j];
+                first_class_host[al[j]] = out[j] >= 0.0 ? first[j] : -1;
+            }
+            if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
+            if (n_classes_host) *n_classes_host = (int)h_scal[S_NCLS];
+            return HGX_OK;
+        }
+    }
+    // general path: materialise the filtered, merged class set and run the ordinary EM on it
+    DevBuf b_mask;
+    ALLOC(b_mask, (size_t)cc->w64 * 8);
+    { int rc_ = hgx_h2d(b_mask.p, mask_host, (size_t)cc->w64 * 8, st); if (rc_) return rc_; }
+    hgx_classes *sub = nullptr;
+    int rc = hgx_dedup_classes(&sub, cc->d_bits, nullptr, cc->d_count, C, cc->a_pad, b_mask.as<uint64_t>(), stream);
+    if (rc == HGX_OK) {
+        if (n_classes_host) *n_classes_host = sub->n_classes;
+        rc = hgx_em_ordered(sub, n_alleles, remove_low, allele_len, prob_host, first_class_host, n_iter_host, stream);
+    }
+    hgx_classes_destroy(sub);
+    return rc;
 }
 
 // first class containing each compact allele = first set bit of its row in the transposed matrix (one wavefront per row)

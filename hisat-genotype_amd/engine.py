@@ -119,6 +119,18 @@ class Classes:
                                              capi.ptr(prob), capi.ptr(first), C.byref(it), stream))
         return prob, first, it.value
 
+    def em_masked(self, mask, n_alleles, remove_low=True, lengths=None, stream=None):
+        """The exon -> gene hand-off (core:1752-1782): EM on this class set filtered to the alleles of `mask` (a_pad/64
+        uint64 words).  Returns (prob, first_class, n_iter, n_merged_classes)."""
+        mask = np.ascontiguousarray(mask, np.uint64)
+        prob = np.zeros(n_alleles, np.float64)
+        first = np.zeros(n_alleles, np.int32)
+        it, nc = C.c_int32(0), C.c_int32(0)
+        ln = None if lengths is None else np.ascontiguousarray(lengths, np.int32)
+        capi.check(capi.lib().hgx_em_masked(self.h, capi.ptr(mask), C.c_int32(n_alleles), C.c_int32(1 if remove_low else 0),
+                                            capi.ptr(ln), capi.ptr(prob), capi.ptr(first), C.byref(it), C.byref(nc), stream))
+        return prob, first, it.value, nc.value
+
     def close(self):
         if self.h:
             capi.lib().hgx_classes_destroy(self.h)

@@ -184,6 +184,14 @@ int hgx_em(const hgx_classes *c, int32_t n_alleles,
 int hgx_em_ordered(const hgx_classes *c, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len_or_null,
                    double *prob_host, int32_t *first_class_host, int32_t *n_iter_host, void *stream);
 
+/* The exon -> gene hand-off in one call (typing_core.py:1752-1782): Gene_cmpt2 = every class of `c` filtered to the alleles of
+ * mask_host (a_pad/64 words), empty ones dropped, equal ones merged with summed counts; then the EM on it (as
+ * hgx_em_ordered).  *n_classes_host = number of merged classes.  With <= 64 alleles in the mask (and <= 64 merged classes)
+ * filter, merge and EM run in ONE launch on one wavefront; otherwise = hgx_dedup_classes(and_mask, weights) + hgx_em_ordered. */
+int hgx_em_masked(const hgx_classes *c, const uint64_t *mask_host, int32_t n_alleles, int32_t remove_low,
+                  const int32_t *allele_len_or_null, double *prob_host, int32_t *first_class_host, int32_t *n_iter_host,
+                  int32_t *n_classes_host, void *stream);
+
 /* ---- host front-end: locus tables, SAM -> pieces (8a-0 .. 8a-4) ----------------------------
  * The part of typing() that precedes scoring is index-heavy string logic with no data
  * parallelism per record; it runs on the host in C++ and hands the device the distinct-piece

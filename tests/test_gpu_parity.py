@@ -342,6 +342,42 @@ def test_forged_hash_collision_is_detected(orc, n_rows):
             os.environ.pop("HGX_DEDUP_SORT", None)
 
 
+@pytest.mark.parametrize("name", ["hla_7000", "hla_mid_real", "hla_errors_filters"])
+def test_em_masked_equals_dedup_then_em(orc, name):
+    """hgx_em_masked (filter gene classes to a set of alleles, merge, EM -- the hand-off, core:1752-1782) against the explicit
+    route dedup(and_mask, weights) + em_ordered: with a small allele set (one-launch kernel), with the kernel switched off, and
+    with > 64 alleles in the mask (general path)."""
+    import os
+    fx, loc, t, pl, batch, _ = _setup(orc, name)
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    A = t["n_alleles"]
+    gcl = engine.Classes.dedup(bufs.gene_bits, batch.n_pairs, pl.a_pad, hashes=bufs.gene_hash)
+    cnt, _ = gcl.allele_counts()
+    top = np.argsort(-cnt[:A], kind="stable")
+    gb, gc, _ = gcl.device_ptrs()
+    for n_keep in (3, 20, 64, 65, 300):
+        keep = np.sort(top[:min(n_keep, A)])
+        mask = np.zeros(pl.w64, np.uint64)
+        np.bitwise_or.at(mask, keep >> 6, np.uint64(1) << (keep & 63).astype(np.uint64))
+        d_mask = engine.DevArray.from_host(mask)
+        sub = engine.Classes.dedup(engine._RawDev(gb), gcl.n_classes, pl.a_pad, weights=engine._RawDev(gc), and_mask=d_mask)
+        p_ref, f_ref, it_ref = sub.em_ordered(A, True, pl.allele_len)
+        for env in ({}, {"HGX_EM_NO_MASKED": "1"}):
+            os.environ.update(env)
+            try:
+                p, f, it, nc = gcl.em_masked(mask, A, True, pl.allele_len)
+            finally:
+                for k in env:
+                    os.environ.pop(k, None)
+            assert it == it_ref and nc == sub.n_classes, (n_keep, env, it, it_ref, nc, sub.n_classes)
+            assert np.array_equal(p < 0, p_ref < 0)
+            assert np.max(np.abs(p - p_ref)) <= 1e-12
+            assert np.array_equal(f, f_ref)
+        sub.close()
+
+
 def test_empty_and_degenerate_inputs(orc):
     """Zero pairs, pairs without pieces, and a locus whose exon level has no representatives."""
     from hisatgenotype_amd import synth
