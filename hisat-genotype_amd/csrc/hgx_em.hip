@@ -2729,32 +2729,26 @@ extern "C" int hgx_em_masked(const hgx_classes *cc, const uint64_t *mask_host, i
     if (al.empty()) return HGX_OK;
     if (al.size() <= 64 && !getenv("HGX_EM_NO_MASKED")) {
         const int A1 = (int)al.size();
-        DevBuf b_al, b_len, b_out, b_first, b_scal;
-        ALLOC(b_al, 64 * 4); ALLOC(b_out, 64 * 8); ALLOC(b_first, 64 * 4); ALLOC(b_scal, S_N * 8);
-        { int rc_ = hgx_h2d(b_al.p, al.data(), (size_t)A1 * 4, st); if (rc_) return rc_; }
-        double *d_len = nullptr;
-        if (allele_len) {
-            double l[64];
-            for (int j = 0; j < A1; ++j) l[j] = (double)allele_len[al[j]];
-            ALLOC(b_len, 64 * 8);
-            { int rc_ = hgx_h2d(b_len.p, l, (size_t)A1 * 8, st); if (rc_) return rc_; }
-            d_len = b_len.as<double>();
-        }
-        HIPCHK(hipMemsetAsync(b_scal.p, 0, S_N * 8, st));
+        // one staging struct each way: [al | len] up, [scal | ticket | out | first] down (one copy + one memset + one copy)
+        struct Up { int32_t al[64]; double len[64]; } up;
+        struct Down { double scal[S_N]; unsigned ticket[2]; double out[64]; int32_t first[64]; } down;
+        for (int j = 0; j < 64; ++j) { up.al[j] = j < A1 ? al[j] : 0; up.len[j] = (allele_len && j < A1) ? (double)allele_len[al[j]] : 1.0; }
+        DevBuf b_up, b_down, b_pub;
+        ALLOC(b_up, sizeof(Up)); ALLOC(b_down, sizeof(Down));
+        { int rc_ = hgx_h2d(b_up.p, &up, sizeof(Up), st); if (rc_) return rc_; }
+        HIPCHK(hipMemsetAsync(b_down.p, 0, offsetof(Down, out), st));
         const int nb = std::max(1, std::min(64, (C + 511) / 512));
-        DevBuf b_pub, b_ticket;
-        ALLOC(b_pub, (size_t)nb * 64 * sizeof(MaskedEntry)); ALLOC(b_ticket, 4);
-        HIPCHK(hipMemsetAsync(b_ticket.p, 0, 4, st));
-        hipLaunchKernelGGL(k_em_masked, dim3(nb), dim3(BLOCK), 0, st, cc->d_bits, C, cc->w64, cc->d_count, b_al.as<int32_t>(), A1, d_len,
-                           remove_low ? 1 : 0, b_out.as<double>(), b_first.as<int32_t>(), b_scal.as<double>(),
-                           (MaskedEntry *)b_pub.p, b_ticket.as<unsigned>());
+        ALLOC(b_pub, (size_t)nb * 64 * sizeof(MaskedEntry));
+        Up *d_up = (Up *)b_up.p;
+        Down *d_down = (Down *)b_down.p;
+        hipLaunchKernelGGL(k_em_masked, dim3(nb), dim3(BLOCK), 0, st, cc->d_bits, C, cc->w64, cc->d_count, d_up->al, A1,
+                           allele_len ? d_up->len : nullptr, remove_low ? 1 : 0, d_down->out, d_down->first, d_down->scal,
+                           (MaskedEntry *)b_pub.p, d_down->ticket);
         HIPCHK(hipGetLastError());
-        double out[64], h_scal[S_N];
-        int32_t first[64];
-        { int rc_ = hgx_d2h(out, b_out.p, (size_t)A1 * 8, st); if (rc_) return rc_; }
-        { int rc_ = hgx_d2h(first, b_first.p, (size_t)A1 * 4, st); if (rc_) return rc_; }
-        { int rc_ = hgx_d2h(h_scal, b_scal.p, S_N * 8, st); if (rc_) return rc_; }
+        { int rc_ = hgx_d2h(&down, b_down.p, sizeof(Down), st); if (rc_) return rc_; }
         { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+        const double *h_scal = down.scal, *out = down.out;
+        const int32_t *first = down.first;
         if (h_scal[S_FALLBACK] == 0.0) {
             if (h_scal[S_KEYERR] != 0.0) {
                 hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
