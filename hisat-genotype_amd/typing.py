@@ -24,11 +24,31 @@ from . import capi, engine
 from .locus import PackedLocus
 
 
+TIE_REL_TOL = 1e-11
+
+
+def _stable_desc(lst):
+    """The reference's ``sorted(..., key=prob, reverse=True)`` (a STABLE sort: equal abundances keep dict insertion order).
+    Alleles the data cannot tell apart come out of the reference's EM bit-identical; here they agree to ~1e-14 only (same
+    arithmetic, different summation order on the GPU), so abundances within a relative 1e-11 of each other count as tied and
+    keep their insertion order, as an exact tie does in the reference."""
+    idx = sorted(range(len(lst)), key=lambda i: -lst[i][1])            # stable on equal values
+    out, i = [], 0
+    while i < len(idx):
+        j = i + 1
+        top = lst[idx[i]][1]
+        while j < len(idx) and top - lst[idx[j]][1] <= TIE_REL_TOL * abs(top):
+            j += 1
+        out.extend(lst[k] for k in sorted(idx[i:j]))                       # the tied run, back in insertion order
+        i = j
+    return out
+
+
 def _sorted_result(prob, order):
     """[[allele index, prob]] for present alleles in dict order, then the reference's stable
     descending sort (common:1408-1409)."""
     lst = [[a, float(prob[a])] for a in order]
-    return sorted(lst, key=lambda x: x[1], reverse=True)
+    return _stable_desc(lst)
 
 
 def _em_on_classes(classes, n_alleles, name_rank, remove_low, lengths, stream=None):
@@ -69,7 +89,7 @@ def single_abundance(Gene_cmpt, remove_low_abundance_allele=False, Gene_length={
         cl.close()
     # allele index == first-appearance order here, which is the dict order of the reference
     res = [[names[a], float(prob[a])] for a in range(A) if prob[a] >= 0.0]
-    return sorted(res, key=lambda x: x[1], reverse=True)
+    return _stable_desc(res)
 
 
 class LocusResult:
@@ -231,7 +251,7 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
                     comb[a] = p
             for a, p in gp:
                 comb[a] = p * psum
-            gene_prob = sorted([[a, p] for a, p in comb.items()], key=lambda x: x[1], reverse=True)
+            gene_prob = _stable_desc([[a, p] for a, p in comb.items()])
         ecl.close()
     else:
         gcl = finish_gene()
