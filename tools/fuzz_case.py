@@ -6,16 +6,17 @@ import hisatgenotype_amd as hgx
 from hisatgenotype_amd import synth, locus as hl
 import pyref
 seed0, k = int(sys.argv[1]), int(sys.argv[2])
+scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 rng = random.Random(seed0 + k)
 if rng.random() < 0.25:
     loc = synth.make_str_like_locus(seed=seed0 + k, max_repeats=rng.randint(8, 18), min_repeats=rng.randint(3, 6))
     sample = synth.pick_sample(loc, seed0 + k)
-    al = synth.simulate_pairs(loc, sample, rng.randint(40, 160), read_len=100, frag_len=(250, 250), seed=k, err_rate=rng.choice([0.0, 0.002]))
+    al = synth.simulate_pairs(loc, sample, scale * rng.randint(40, 160), read_len=100, frag_len=(250, 250), seed=k, err_rate=rng.choice([0.0, 0.002]))
 else:
     loc = synth.make_hla_like_locus(n_alleles=rng.randint(30, 1200), n_vars=rng.randint(60, 900), seed=seed0 + k,
                                     insertion_frac=rng.choice([0.0, 0.03]), unlinked_vars=rng.randint(0, 4))
     sample = synth.pick_sample(loc, seed0 + k)
-    al = synth.simulate_pairs(loc, sample, rng.randint(60, 220), err_rate=rng.choice([0.0, 0.003, 0.01]), seed=k,
+    al = synth.simulate_pairs(loc, sample, scale * rng.randint(60, 220), err_rate=rng.choice([0.0, 0.003, 0.01]), seed=k,
                               softclip_frac=rng.choice([0.0, 0.05]), novel_del_frac=rng.choice([0.0, 0.03]),
                               multi_hit_frac=rng.choice([0.0, 0.02]), dup_frac=rng.choice([0.0, 0.02]),
                               novel_ins_frac=rng.choice([0.0, 0.02]), single_end=rng.random() < 0.15)

@@ -1,5 +1,5 @@
 """Randomised end-to-end parity on the GPU box: type_locus (front-end + HIP path) against oracle/pyref.py (the pinned pure-Python
-restatement of the reference) on freshly seeded loci and read sets.  Usage: tools/fuzz_parity.py [n_cases] [first_seed]"""
+restatement of the reference) on freshly seeded loci and read sets.  Usage: tools/fuzz_parity.py [n_cases] [first_seed] [read-count scale]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,21 +11,23 @@ import pyref
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1       # multiplies the number of read pairs per case
 bad = 0
 ties = 0
+worst = 0.0
 t0 = time.time()
 for k in range(n_cases):
     rng = random.Random(seed0 + k)
     if rng.random() < 0.25:
         loc = synth.make_str_like_locus(seed=seed0 + k, max_repeats=rng.randint(8, 18), min_repeats=rng.randint(3, 6))
         sample = synth.pick_sample(loc, seed0 + k)
-        al = synth.simulate_pairs(loc, sample, rng.randint(40, 160), read_len=100, frag_len=(250, 250), seed=k,
+        al = synth.simulate_pairs(loc, sample, scale * rng.randint(40, 160), read_len=100, frag_len=(250, 250), seed=k,
                                   err_rate=rng.choice([0.0, 0.002]))
     else:
         loc = synth.make_hla_like_locus(n_alleles=rng.randint(30, 1200), n_vars=rng.randint(60, 900), seed=seed0 + k,
                                         insertion_frac=rng.choice([0.0, 0.03]), unlinked_vars=rng.randint(0, 4))
         sample = synth.pick_sample(loc, seed0 + k)
-        al = synth.simulate_pairs(loc, sample, rng.randint(60, 220), err_rate=rng.choice([0.0, 0.003, 0.01]), seed=k,
+        al = synth.simulate_pairs(loc, sample, scale * rng.randint(60, 220), err_rate=rng.choice([0.0, 0.003, 0.01]), seed=k,
                                   softclip_frac=rng.choice([0.0, 0.05]), novel_del_frac=rng.choice([0.0, 0.03]),
                                   multi_hit_frac=rng.choice([0.0, 0.02]), dup_frac=rng.choice([0.0, 0.02]),
                                   novel_ins_frac=rng.choice([0.0, 0.02]), single_end=rng.random() < 0.15)
@@ -67,11 +69,17 @@ for k in range(n_cases):
                     ties += 1
                 else:
                     ok, why = False, "allele order"
-            elif any(abs(p - q) > 1e-9 for (_, p), (_, q) in zip(res.gene_prob, exp["gene_prob"])):
-                ok, why = False, "abundances"
+            else:
+                dev = max([abs(p - q) for (_, p), (_, q) in zip(res.gene_prob, exp["gene_prob"])] or [0.0])
+                worst = max(worst, dev)
+                if dev > 1e-6:                            # north_star: 1e-5; short EMs agree to ~1e-15, a 41-iteration one to 5e-9
+                    ok, why = False, "abundances (max deviation %.2e)" % dev
+                elif dev > 1e-9:
+                    why = "(max abundance deviation %.1e over %s EM iterations)" % (dev, [e["n_iter"] for e in res.em])
     print("case %3d seed %d %-5s A=%-5d reads=%-4s %s %s" % (k, seed0 + k, loc.base_fname, len(loc.allele_names) - 1,
                                                           res.num_reads if res else "-", "ok" if ok else "MISMATCH", why), flush=True)
     bad += 0 if ok else 1
     pl.close()
-print("%d cases, %d mismatches, %d near-tie order differences, %.0f s" % (n_cases, bad, ties, time.time() - t0))
+print("%d cases, %d mismatches, %d near-tie order differences, largest abundance deviation %.2e, %.0f s" % (
+    n_cases, bad, ties, worst, time.time() - t0))
 sys.exit(1 if bad else 0)
