@@ -9,7 +9,8 @@ seed0, k = int(sys.argv[1]), int(sys.argv[2])
 scale = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 rng = random.Random(seed0 + k)
 if rng.random() < 0.25:
-    loc = synth.make_str_like_locus(seed=seed0 + k, max_repeats=rng.randint(8, 18), min_repeats=rng.randint(3, 6))
+    loc = synth.make_str_like_locus(gene=rng.choice(["D8S1179", "D18S51"]), unit=rng.choice(["TCTA", "AGAA"]), seed=seed0 + k,
+                                    max_repeats=rng.randint(8, 18), min_repeats=rng.randint(3, 6))
     sample = synth.pick_sample(loc, seed0 + k)
     al = synth.simulate_pairs(loc, sample, scale * rng.randint(40, 160), read_len=100, frag_len=(250, 250), seed=k, err_rate=rng.choice([0.0, 0.002]))
 else:
