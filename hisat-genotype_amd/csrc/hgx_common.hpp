@@ -56,6 +56,9 @@ struct hgx_classes {
     int32_t *h_act = nullptr;                        // host copy of d_act (new[])
     uint64_t *d_wrow = nullptr, *d_wcol = nullptr;   // word-transposed compact matrices [a1p/64][c64*64], [c64][a1p]
     void *d_setup0 = nullptr, *d_setup1 = nullptr;   // small tables the set-up kernels read (kept so that no sync is needed)
+    hipStream_t made_on = nullptr;                   // stream the kernels that fill this class set were queued on
+    hipEvent_t ready = nullptr;                      // recorded behind them: consumers on OTHER streams wait for it (device side)
+    void *d_keep[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // dedup scratch still read by queued kernels
 };
 
 struct DevBuf {
@@ -71,6 +74,11 @@ struct DevBuf {
             return HGX_ENOMEM;                                         \
         }                                                              \
     } while (0)
+
+// a consumer of class set `c` about to queue work on `st`: order it behind the kernels that are still filling the set
+static inline void hgx_classes_order_after(const hgx_classes *c, hipStream_t st) {
+    if (c && c->ready && st != c->made_on) (void)hipStreamWaitEvent(st, c->ready, 0);
+}
 
 static inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per); }
 

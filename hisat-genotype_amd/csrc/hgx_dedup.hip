@@ -339,11 +339,21 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     else
         hipLaunchKernelGGL(k_ht_gather, dim3(nblk(n_alloc, 4)), dim3(256), 0, st, rows, w64, and_mask, cl->d_first_row, n_alloc, cl->d_bits);
     HIPCHK(hipGetLastError());
-    if (one_trip) { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
-    { int rc_ = hgx_sync(st); if (rc_) return rc_; }      // also: the scratch buffers above go back to the pool on return
-    if (meta[0]) {
-        hgx_set_error("64-bit class hash collision detected by the exact verify pass");
-        return HGX_ECOLLISION;
+    if (one_trip) {
+        { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
+        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+        if (meta[0]) {
+            hgx_set_error("64-bit class hash collision detected by the exact verify pass");
+            return HGX_ECOLLISION;
+        }
+    } else {
+        // large input: class count and collision flag are known since the first round trip; the finalize / gather kernels are
+        // queued, and the scratch they read stays with the class set (freed with it) so that the caller's next launches
+        // follow without another host sync
+        cl->made_on = st;
+        if (hipEventCreateWithFlags(&cl->ready, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(cl->ready, st);
+        DevBuf *keep[] = {&b_keys, &b_first, &b_cnt, &b_slot, &b_flag, &b_rank, &b_tmp, &b_meta};
+        for (int i = 0; i < 8; ++i) { cl->d_keep[i] = keep[i]->p; keep[i]->p = nullptr; }
     }
     const int n_runs = (int)meta[1];
     cl->n_classes = n_runs;
@@ -460,6 +470,8 @@ extern "C" int hgx_classes_destroy(hgx_classes *c) {
     hgx_pool_free(c->d_act); hgx_pool_free(c->d_bitsC); hgx_pool_free(c->d_bitsTC);
     hgx_pool_free(c->d_wrow); hgx_pool_free(c->d_wcol);
     hgx_pool_free(c->d_setup0); hgx_pool_free(c->d_setup1);
+    for (void *p : c->d_keep) hgx_pool_free(p);
+    if (c->ready) (void)hipEventDestroy(c->ready);
     delete[] c->h_act;
     delete c;
     return HGX_OK;
@@ -480,6 +492,7 @@ extern "C" int hgx_classes_device(const hgx_classes *c, void **bits, void **coun
 extern "C" int hgx_classes_to_host(const hgx_classes *c, uint64_t *bits, int64_t *count, int64_t *first_row) {
     ARGCHK(c);
     if (c->n_classes == 0) return HGX_OK;
+    HIPCHK(hipStreamSynchronize(c->made_on));        // the gather kernels of a large dedup may still be queued there
     if (bits) HIPCHK(hipMemcpy(bits, c->d_bits, (size_t)c->n_classes * c->w64 * 8, hipMemcpyDeviceToHost));
     if (count) HIPCHK(hipMemcpy(count, c->d_count, (size_t)c->n_classes * 8, hipMemcpyDeviceToHost));
     if (first_row) HIPCHK(hipMemcpy(first_row, c->d_first_row, (size_t)c->n_classes * 8, hipMemcpyDeviceToHost));

@@ -2274,6 +2274,7 @@ extern "C" int hgx_em_ordered(const hgx_classes *cc, int32_t n_alleles, int32_t 
 static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len, double *prob_host,
                    int32_t *first_host, int32_t *n_iter_host, void *stream) {
     ARGCHK(cc && prob_host && n_alleles > 0 && n_alleles <= cc->a_pad);
+    hgx_classes_order_after(cc, (hipStream_t)stream);
     if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = -1;
     hgx_classes *c = const_cast<hgx_classes *>(cc);
     hipStream_t st = (hipStream_t)stream;
@@ -2715,6 +2716,7 @@ extern "C" int hgx_em_masked(const hgx_classes *cc, const uint64_t *mask_host, i
                              int32_t *n_classes_host, void *stream) {
     ARGCHK(cc && mask_host && prob_host && first_class_host && n_alleles > 0 && n_alleles <= cc->a_pad);
     hipStream_t st = (hipStream_t)stream;
+    hgx_classes_order_after(cc, st);
     for (int a = 0; a < n_alleles; ++a) { prob_host[a] = -1.0; first_class_host[a] = -1; }
     if (n_iter_host) *n_iter_host = 0;
     if (n_classes_host) *n_classes_host = 0;
@@ -2821,6 +2823,7 @@ __global__ __launch_bounds__(256) void k_first_classes(const uint64_t *__restric
 extern "C" int hgx_first_classes(const hgx_classes *c, const int32_t *alleles_host, int32_t n, int32_t *first_host, void *stream) {
     ARGCHK(c && n >= 0);
     if (n == 0) return HGX_OK;
+    hgx_classes_order_after(c, (hipStream_t)stream);
     ARGCHK(alleles_host && first_host);
     for (int i = 0; i < n; ++i) ARGCHK(alleles_host[i] >= 0 && alleles_host[i] < c->a_pad);
     if (c->n_classes == 0) { for (int i = 0; i < n; ++i) first_host[i] = -1; return HGX_OK; }
@@ -2844,6 +2847,7 @@ extern "C" int hgx_allele_counts(const hgx_classes *cc, int64_t *count_host, int
 extern "C" int hgx_allele_counts_on(const hgx_classes *cc, int64_t *count_host, int32_t *first_host, void *stream) {
     ARGCHK(cc && count_host && first_host);
     hipStream_t st = (hipStream_t)stream;
+    hgx_classes_order_after(cc, st);
     hgx_classes *c = const_cast<hgx_classes *>(cc);
     const int A = c->a_pad;
     if (c->n_classes == 0) {
