@@ -1118,6 +1118,11 @@ __global__ __launch_bounds__(BLOCK) void k_em_tail(const uint64_t *__restrict__ 
                                                    const int64_t *__restrict__ count, const double *__restrict__ p,
                                                    const uint8_t *__restrict__ pres, const double *__restrict__ len,
                                                    int remove_low, double *__restrict__ out, double *__restrict__ scal) {
+    // launched speculatively right behind a batch of iterations: nothing to do if that batch already converged
+    if (scal[S_DONE] != 0.0) {
+        if (threadIdx.x == 0) scal[S_TAIL] = -2.0;
+        return;
+    }
     __shared__ int gidx[64], gsort[64];
     __shared__ int n_g, n_keys, n_list;
     __shared__ unsigned long long keys[TAIL_SLOTS], cnts[TAIL_SLOTS];
@@ -2661,10 +2666,20 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             if ((rc = next_prob(q2, pr2, 0, q3, pr3, 1))) return rc;      // only if extrapolated
             hipLaunchKernelGGL(k_em_advance, dim3(1), dim3(BLOCK), 0, st, p, pr, q1, pr1, q3, pr3, A, remove_low ? 1 : 0, scal);
         }
+        // Pruning has started (iteration index >= 10): the compact tail kernel goes out speculatively right behind the batch --
+        // it checks the survivor count itself -- so that batch result and tail result come back in ONE host round trip.
+        const bool spec_tail = use_tail && remove_low && launched_iters >= 11 && tail_failed_at == 1e300;
+        if (spec_tail)
+            hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsC, C, w64c, A, c->d_count, p, pr, d_len,
+                               remove_low ? 1 : 0, b_out.as<double>(), scal);
         { int rc_ = hgx_d2h(h_scal, scal, S_N * 8, st); if (rc_) return rc_; }
         { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+        if (spec_tail) {
+            if (h_scal[S_TAIL] == 1.0) { tail_done = true; break; }
+            if (h_scal[S_TAIL] == -1.0) tail_failed_at = h_scal[S_NPRES];
+        }
         if (h_scal[S_DONE] != 0.0) break;
-        if (use_tail && h_scal[S_NPRES] <= 64.0 && h_scal[S_NPRES] < tail_failed_at) {
+        if (!spec_tail && use_tail && h_scal[S_NPRES] <= 64.0 && h_scal[S_NPRES] < tail_failed_at) {
             // few survivors: finish on one wavefront (k_em_tail) unless too many distinct class masks remain
             hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsC, C, w64c, A, c->d_count, p, pr, d_len,
                                remove_low ? 1 : 0, b_out.as<double>(), scal);
