@@ -47,8 +47,17 @@ def parse_args():
     return ap.parse_args()
 
 
-def step(pl, batch, db, bufs, ev=None, stream=None):
+def step(pl, batch, db, bufs, ev=None, stream=None, heavy_lock=None):
     """One pass of the hot path on `stream` (None = the default stream).  Returns the LocusResult."""
+    held = htyping._HeldOnce(heavy_lock) if heavy_lock is not None else None
+    try:
+        return _step(pl, batch, db, bufs, ev, stream, held)
+    finally:
+        if held is not None:
+            held.release()
+
+
+def _step(pl, batch, db, bufs, ev, stream, heavy_lock):
     res = htyping.LocusResult()
     res.num_reads, res.num_pairs = batch.n_reads, batch.n_pairs
     L = capi.lib()
@@ -64,7 +73,8 @@ def step(pl, batch, db, bufs, ev=None, stream=None):
                                   capi.ptr(bufs.exon_hash), capi.ptr(bufs.gene_hash), stream))
     if ev:
         ev[1].record(stream)
-    return htyping._type_batch(pl, batch, res, True, dbatch=db, bufs=bufs, scored=True, stream=stream, overlap=True)
+    return htyping._type_batch(pl, batch, res, True, dbatch=db, bufs=bufs, scored=True, stream=stream, overlap=True,
+                               heavy_lock=heavy_lock)
 
 
 def run_steps(pl, batch, db, bufs_list, n_steps, ev_list, timing, local_rank):
@@ -72,6 +82,7 @@ def run_steps(pl, batch, db, bufs_list, n_steps, ev_list, timing, local_rank):
     (last LocusResult, EM seconds summed, EM iterations summed, merged per-kernel timing)."""
     import threading
     lock = threading.Lock()
+    heavy = threading.Lock() if len(bufs_list) > 1 else None      # staggers the samples in flight (see _type_batch)
     state = {"next": 0, "t_em": 0.0, "n_iter": 0, "res": None, "timing": {}, "err": None}
 
     def work(bufs, own_stream):
@@ -88,7 +99,7 @@ def run_steps(pl, batch, db, bufs_list, n_steps, ev_list, timing, local_rank):
                 # every EM mat-vec launch of the LAST steps of the timed region is timed (dispatch-attached events); earlier
                 # steps run untimed, so the ~1 us per timed launch does not weigh on the whole region
                 engine.em_set_timing(2 if (timing and k >= n_steps - N_TIMED_STEPS) else 0)
-                res = step(pl, batch, db, bufs, ev_list[k] if ev_list else None, stream)
+                res = step(pl, batch, db, bufs, ev_list[k] if ev_list else None, stream, heavy)
                 with lock:
                     state["t_em"] += res.t_em
                     state["n_iter"] += sum(e["n_iter"] for e in res.em)

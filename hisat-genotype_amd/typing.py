@@ -115,7 +115,7 @@ class LocusResult:
 
 def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discordant=False,
                remove_low_abundance_alleles=True, simulation=False, base_locus=0, keep_classes=False, stream=None,
-               alignment_file=None, region=None):
+               alignment_file=None, region=None, heavy_lock=None):
     """Per-locus typing: the reference's loop body with the O(alleles) work on the GPU.  Input: name-grouped SAM text
     (`sam_text`), or `alignment_file` (SAM / BAM, optional "chr:left-right" region) read inside libhgx."""
     res = LocusResult()
@@ -129,7 +129,26 @@ def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discor
     res.n_pieces, res.n_refs = batch.n_pieces, batch.n_refs
     if batch.n_reads <= 0:                                  # core:1589-1590
         return res
-    return _type_batch(pl, batch, res, remove_low_abundance_alleles, keep_classes, stream)
+    if heavy_lock is None:
+        return _type_batch(pl, batch, res, remove_low_abundance_alleles, keep_classes, stream)
+    held = _HeldOnce(heavy_lock)        # several samples in flight: one bandwidth-bound front at a time (see _type_batch)
+    try:
+        return _type_batch(pl, batch, res, remove_low_abundance_alleles, keep_classes, stream, heavy_lock=held)
+    finally:
+        held.release()
+
+
+class _HeldOnce:
+    """A held lock that is released exactly once (by _type_batch as soon as it can, or by the caller on the way out)."""
+
+    def __init__(self, lock):
+        lock.acquire()
+        self.lock = lock
+
+    def release(self):
+        lock, self.lock = self.lock, None
+        if lock is not None:
+            lock.release()
 
 
 _tls = threading.local()
@@ -142,7 +161,12 @@ def _fork_event():
     return ev
 
 
-def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dbatch=None, bufs=None, scored=False, overlap=None):
+def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dbatch=None, bufs=None, scored=False, overlap=None,
+                heavy_lock=None):
+    """`heavy_lock` (held by the caller on entry, released here): with several samples in flight per GPU, the bandwidth-bound
+    front of the path (scoring, the exon-level dedup) of one sample should not run beside another sample's -- it would only
+    share the HBM -- but beside the other samples' EM phases, which are chains of short launches.  The lock is released as soon
+    as this sample's exon-level classes exist."""
     hla = pl.base_fname == "hla"
     A, names = pl.n_alleles, pl.names
     db = dbatch if dbatch is not None else engine.DeviceBatch(batch, stream)
@@ -216,6 +240,9 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
     if hla:
         em_stream = em_stream_ if worker is not None else stream
         ecl = engine.Classes.dedup(bufs.exon_bits, db.n_pairs, pl.a_pad, hashes=bufs.exon_hash, stream=em_stream)
+        if heavy_lock is not None:
+            heavy_lock.release()
+            heavy_lock = None
         if keep_classes:
             res.exon_classes = ecl.to_host()[:2]
         stream_saved, stream = stream, em_stream
@@ -255,6 +282,9 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
         ecl.close()
     else:
         gcl = finish_gene()
+        if heavy_lock is not None:
+            heavy_lock.release()
+            heavy_lock = None
         if gcl.n_classes <= 1:                                                   # core:1784-1787 (quirk Q3)
             if gcl.n_classes == 1:
                 raise TypeError("'dict_keys' object is not subscriptable (reference quirk Q3, typing_core.py:1787)")
