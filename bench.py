@@ -85,9 +85,11 @@ def run_steps(pl, batch, db, bufs_list, n_steps, ev_list, timing, local_rank):
     heavy = threading.Lock() if len(bufs_list) > 1 else None      # staggers the samples in flight (see _type_batch)
     state = {"next": 0, "t_em": 0.0, "n_iter": 0, "res": None, "timing": {}, "err": None}
 
-    def work(bufs, own_stream):
+    def work(bufs, own_stream, slot=None):
         try:
             capi.set_device(local_rank)
+            if slot is not None:
+                capi.set_stream_slot(slot)           # the warm-up generation of this worker created the streams
             stream = capi.get_stream(2) if own_stream else None
             engine.em_set_timing(0)
             while True:
@@ -117,7 +119,7 @@ def run_steps(pl, batch, db, bufs_list, n_steps, ev_list, timing, local_rank):
     if len(bufs_list) == 1:
         work(bufs_list[0], False)
     else:
-        threads = [threading.Thread(target=work, args=(b, True)) for b in bufs_list]
+        threads = [threading.Thread(target=work, args=(b, True, i)) for i, b in enumerate(bufs_list)]
         for t in threads:
             t.start()
         for t in threads:

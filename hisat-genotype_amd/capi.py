@@ -114,10 +114,20 @@ def current_device():
     return _current_device
 
 
+_slot = threading.local()
+
+
+def set_stream_slot(k):
+    """Streams are cached per (device, slot, index); a slot defaults to the calling thread.  Worker threads that come and go
+    (one generation for warm-up, one for the timed region, ...) name a stable slot so that they reuse the streams -- creating a
+    stream means creating a hardware queue, which costs milliseconds."""
+    _slot.k = ("slot", k)
+
+
 def get_stream(i):
     """A cached non-blocking stream of the current device (created on first use).  Stream 0 (the EM chain: short
     dependent launches on the critical path) has the highest priority, stream 1 (overlapped side work) the lowest."""
-    key = (_current_device, threading.get_ident(), i)        # per host thread: concurrent samples never share a stream
+    key = (_current_device, getattr(_slot, "k", threading.get_ident()), i)     # per host thread (or named slot): samples in flight never share a stream
     if key not in _streams:
         p = C.c_void_p()
         check(lib().hgx_stream_create_prio(C.byref(p), C.c_int(1 if i == 0 else 0)))

@@ -81,9 +81,10 @@ def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, ix_dir=No
         state = {"next": 0, "err": None}
         dev = capi.current_device()
 
-        def work():
+        def work(slot):
             try:
                 capi.set_device(dev)
+                capi.set_stream_slot(slot)               # stable stream set per worker index across calls
                 stream = capi.get_stream(2)              # this thread's main stream (its side streams are per thread too)
                 while True:
                     with lock:
@@ -98,7 +99,7 @@ def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, ix_dir=No
                 with lock:
                     state["err"] = e
 
-        threads = [threading.Thread(target=work) for _ in range(min(inflight, len(mine)))]
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(min(inflight, len(mine)))]
         for t in threads:
             t.start()
         for t in threads:
