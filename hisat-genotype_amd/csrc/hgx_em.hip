@@ -2601,6 +2601,8 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     if (rc) return rc;
     hipLaunchKernelGGL(k_em_init_norm, dim3(1), dim3(BLOCK), 0, st, p, pr, A);
     double h_scal[S_N];
+    std::vector<double> out(A);
+    bool results_fetched = false;         // the speculative tail's results came back with its status word
     const int batch = 4;
     int launched_iters = 0;
     double tail_failed_at = 1e300;
@@ -2672,10 +2674,14 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         if (spec_tail)
             hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsC, C, w64c, A, c->d_count, p, pr, d_len,
                                remove_low ? 1 : 0, b_out.as<double>(), scal);
+        if (spec_tail) {      // if the tail takes over, these ARE the results: fetch them in the same round trip
+            if (first_host) { int rc_ = hgx_d2h(h_fc.data(), b_fc.p, (size_t)A * 4, st); if (rc_) return rc_; }
+            { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
+        }
         { int rc_ = hgx_d2h(h_scal, scal, S_N * 8, st); if (rc_) return rc_; }
         { int rc_ = hgx_sync(st); if (rc_) return rc_; }
         if (spec_tail) {
-            if (h_scal[S_TAIL] == 1.0) { tail_done = true; break; }
+            if (h_scal[S_TAIL] == 1.0) { tail_done = true; results_fetched = true; break; }
             if (h_scal[S_TAIL] == -1.0) tail_failed_at = h_scal[S_NPRES];
         }
         if (h_scal[S_DONE] != 0.0) break;
@@ -2713,10 +2719,11 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     }
     if (!tail_done) hipLaunchKernelGGL(k_em_finish, dim3(1), dim3(BLOCK), 0, st, p, pr, d_len, A, remove_low ? 1 : 0, b_out.as<double>());
     HIPCHK(hipGetLastError());
-    std::vector<double> out(A);
-    if (first_host) { int rc_ = hgx_d2h(h_fc.data(), b_fc.p, (size_t)A * 4, st); if (rc_) return rc_; }
-    { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
-    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+    if (!results_fetched) {
+        if (first_host) { int rc_ = hgx_d2h(h_fc.data(), b_fc.p, (size_t)A * 4, st); if (rc_) return rc_; }
+        { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
+        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+    }
     for (int a = 0; a < n_alleles; ++a) prob_host[a] = -1.0;
     for (int j = 0; j < c->n_act; ++j) if (c->h_act[j] < n_alleles) prob_host[c->h_act[j]] = out[j];
     if (first_host) for (int j = 0; j < c->n_act; ++j) if (c->h_act[j] < n_alleles) first_host[c->h_act[j]] = h_fc[j];
