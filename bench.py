@@ -68,13 +68,10 @@ def _step(pl, batch, db, bufs, ev, stream, heavy_lock):
                                   capi.ptr(bufs.compat), stream))
     if ev:
         ev[0].record(stream)
-    capi.check(L.hgx_pair_classes(pl.index(), capi.ptr(bufs.compat), capi.ptr(db.pair_off), capi.ptr(db.pair_ref),
-                                  C.c_int32(db.n_pairs), capi.ptr(bufs.exon_bits), capi.ptr(bufs.gene_bits),
-                                  capi.ptr(bufs.exon_hash), capi.ptr(bufs.gene_hash), stream))
-    if ev:
-        ev[1].record(stream)
-    return htyping._type_batch(pl, batch, res, True, dbatch=db, bufs=bufs, scored=True, stream=stream, overlap=True,
-                               heavy_lock=heavy_lock)
+    # the exon level goes through hgx_level_classes (pairs grouped by ref list), the gene level's per-pair rows are
+    # computed beside the exon-level EM: both inside _type_batch; ev[3] / ev[1] bracket the per-pair launch
+    return htyping._type_batch(pl, batch, res, True, dbatch=db, bufs=bufs, scored="compat", stream=stream, overlap=True,
+                               heavy_lock=heavy_lock, pc_events=(ev[3], ev[1]) if ev else None)
 
 
 def run_steps(pl, batch, db, bufs_list, n_steps, ev_list, timing, local_rank):
@@ -207,7 +204,7 @@ def main():
     capi.sync()
     if dist is not None:
         dist.barrier()
-    ev = [(capi.Event(), capi.Event(), capi.Event()) for _ in range(args.steps)]
+    ev = [(capi.Event(), capi.Event(), capi.Event(), capi.Event()) for _ in range(args.steps)]
     timing = not args.no_kernel_timing                     # HIP events around a sample of the EM mat-vec launches
     t0 = time.perf_counter()
     res, t_em, n_em_iter, em_timing = run_steps(pl, batch, db, bufs_list, args.steps, ev, timing, local_rank)
@@ -231,12 +228,14 @@ def main():
     if rank == 0:
         # Per-kernel achieved rates from HIP events recorded inside the timed region (byte models: DESIGN.md section 5).
         #  k_lutmatvec<0> (EM rows pass): the compact class bit matrix once + its dense vectors
-        #  k_pair_classes: n_refs compat rows read + 2 class rows (+ hash) written per pair + refs/offsets
+        #  k_pair_classes (the per-pair gene-level launch): the pairs' gene-level compat rows read + 1 class row (+ hash)
+        #                  written per pair + refs/offsets
         #  k_piece_compat: n_words x a_pad x 4 index bytes read + one compat row written per distinct piece
         row = pl.a_pad // 8
-        pc_bytes = batch.n_refs * row + 4 * batch.n_refs + 4 * (batch.n_pairs + 1) + batch.n_pairs * 2 * (row + 8)
+        n_gene_refs = int((np.asarray(batch.pair_ref) >> 31).sum())
+        pc_bytes = n_gene_refs * row + 4 * batch.n_refs + 4 * (batch.n_pairs + 1) + batch.n_pairs * (row + 8)
         cp_bytes = db.sum_piece_words * pl.a_pad * 4 + batch.n_pieces * (row + 8) + db.sum_piece_words * 8
-        pc_ms = sum(e[0].elapsed_ms(e[1]) for e in ev) / len(ev)
+        pc_ms = sum(e[3].elapsed_ms(e[1]) for e in ev) / len(ev)
         cp_ms = sum(e[2].elapsed_ms(e[0]) for e in ev) / len(ev)
         gbs = lambda b, ms: (b / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
         kernels = {}

@@ -58,7 +58,8 @@ struct hgx_classes {
     void *d_setup0 = nullptr, *d_setup1 = nullptr;   // small tables the set-up kernels read (kept so that no sync is needed)
     hipStream_t made_on = nullptr;                   // stream the kernels that fill this class set were queued on
     hipEvent_t ready = nullptr;                      // recorded behind them: consumers on OTHER streams wait for it (device side)
-    void *d_keep[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // dedup scratch still read by queued kernels
+    void *d_keep[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                        nullptr, nullptr, nullptr, nullptr};   // dedup scratch still read by queued kernels
 };
 
 struct DevBuf {
@@ -83,6 +84,9 @@ static inline void hgx_classes_order_after(const hgx_classes *c, hipStream_t st)
 static inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per); }
 
 int hgx_ensure_transposed(hgx_classes *c, hipStream_t st);
+int hgx_pair_classes_sel(const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off, const uint32_t *refs,
+                         const int64_t *sel, int32_t n_pairs, uint64_t *eb, uint64_t *gb, uint64_t *eh,
+                         uint64_t *gh, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------------
 // small device helpers

@@ -157,7 +157,6 @@ __global__ __launch_bounds__(256) void k_gather_rows(const uint64_t *__restrict_
 //                 (streaming, original order);   k_ht_gather: class rows.
 // min / add / CAS are order independent, so the result is deterministic.
 // ------------------------------------------------------------------------------------------------
-#define HT_LDS_SLOTS 2048
 #define HT_NONE 0xFFFFFFFFu
 
 __device__ __forceinline__ uint32_t ht_global_insert(unsigned long long *keys, uint32_t tmask, uint64_t key) {
@@ -169,31 +168,33 @@ __device__ __forceinline__ uint32_t ht_global_insert(unsigned long long *keys, u
     }
 }
 
-__global__ __launch_bounds__(1024) void k_ht_insert(const uint64_t *__restrict__ hash, const int64_t *__restrict__ weight, long n,
+template <int BS>
+__global__ __launch_bounds__(BS) void k_ht_insert(const uint64_t *__restrict__ hash, const int64_t *__restrict__ weight, long n,
                                                     unsigned long long *__restrict__ keys, uint32_t *__restrict__ first,
                                                     unsigned long long *__restrict__ cnt, uint32_t tmask,
                                                     uint32_t *__restrict__ slot_of) {
-    __shared__ unsigned long long lkey[HT_LDS_SLOTS], lcnt[HT_LDS_SLOTS];
-    __shared__ uint32_t lmin[HT_LDS_SLOTS], lg[HT_LDS_SLOTS];
+    constexpr int SLOTS = 2 * BS;
+    __shared__ unsigned long long lkey[SLOTS], lcnt[SLOTS];
+    __shared__ uint32_t lmin[SLOTS], lg[SLOTS];
     const int tid = threadIdx.x;
-    for (int s = tid; s < HT_LDS_SLOTS; s += 1024) { lkey[s] = HGX_EMPTY_KEY; lcnt[s] = 0; lmin[s] = HT_NONE; }
+    for (int s = tid; s < SLOTS; s += BS) { lkey[s] = HGX_EMPTY_KEY; lcnt[s] = 0; lmin[s] = HT_NONE; }
     __syncthreads();
-    const long i = (long)blockIdx.x * 1024 + tid;
+    const long i = (long)blockIdx.x * BS + tid;
     const uint64_t key = i < n ? hash[i] : HGX_EMPTY_KEY;
     const bool valid = key != HGX_EMPTY_KEY;
     uint32_t ls = 0;
     if (valid) {
-        ls = (uint32_t)(key >> 40) & (HT_LDS_SLOTS - 1);
+        ls = (uint32_t)(key >> 40) & (SLOTS - 1);
         for (;;) {
             const unsigned long long old = atomicCAS(&lkey[ls], (unsigned long long)HGX_EMPTY_KEY, (unsigned long long)key);
             if (old == HGX_EMPTY_KEY || old == key) break;
-            ls = (ls + 1) & (HT_LDS_SLOTS - 1);
+            ls = (ls + 1) & (SLOTS - 1);
         }
         atomicMin(&lmin[ls], (uint32_t)i);
         atomicAdd(&lcnt[ls], (unsigned long long)(weight ? weight[i] : 1));
     }
     __syncthreads();
-    for (int s = tid; s < HT_LDS_SLOTS; s += 1024) {
+    for (int s = tid; s < SLOTS; s += BS) {
         if (lkey[s] != HGX_EMPTY_KEY) {
             const uint32_t g = ht_global_insert(keys, tmask, lkey[s]);
             atomicMin(&first[g], lmin[s]);
@@ -288,8 +289,12 @@ __global__ __launch_bounds__(256) void k_ht_gather_slots(const uint64_t *__restr
 }
 __global__ void k_ht_meta(const uint32_t *last_rank, const uint32_t *last_flag, uint32_t *meta) { meta[1] = *last_rank + *last_flag; }
 
+static hgx_classes *new_classes(int32_t a_pad);
+// small_blocks: insert with 256-row workgroups instead of 1024-row ones.  Alone the large ones win (4x fewer global atomics
+// on the hot classes); beside a kernel that fills the chip (hgx_level_classes runs next to the gene level's per-pair rows)
+// a 16-wave workgroup with 48 KB of LDS waits for a whole CU's worth of slots and the insert takes 3-4x longer.
 static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_t *keys_in, const int64_t *row_weight, long n,
-                            int w64, const uint64_t *and_mask, hipStream_t st) {
+                            int w64, const uint64_t *and_mask, hipStream_t st, bool small_blocks = false) {
     long T = 1024;
     while (T < 2 * n) T <<= 1;
     DevBuf b_keys, b_first, b_cnt, b_slot, b_flag, b_rank, b_tmp, b_meta;
@@ -301,8 +306,12 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     // one launch instead of five memsets: table = empty, flags = 0, meta = {collision flag, number of classes} = 0
     hipLaunchKernelGGL(k_ht_init, dim3(nblk(std::max(T, n), 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(),
                        b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), T, b_flag.as<uint32_t>(), n, b_meta.as<uint32_t>());
-    hipLaunchKernelGGL(k_ht_insert, dim3(nblk(n, 1024)), dim3(1024), 0, st, keys_in, row_weight, n, b_keys.as<unsigned long long>(),
-                       b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1), b_slot.as<uint32_t>());
+    if (small_blocks)
+        hipLaunchKernelGGL(k_ht_insert<256>, dim3(nblk(n, 256)), dim3(256), 0, st, keys_in, row_weight, n, b_keys.as<unsigned long long>(),
+                           b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1), b_slot.as<uint32_t>());
+    else
+        hipLaunchKernelGGL(k_ht_insert<1024>, dim3(nblk(n, 1024)), dim3(1024), 0, st, keys_in, row_weight, n, b_keys.as<unsigned long long>(),
+                           b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1), b_slot.as<uint32_t>());
     hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,
                        b_flag.as<uint32_t>());
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
@@ -366,9 +375,7 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
     ARGCHK(n_rows < (1ll << 31));
     hipStream_t st = (hipStream_t)stream;
     const int w64 = a_pad / 64;
-    hgx_classes *cl = new hgx_classes();
-    cl->a_pad = a_pad; cl->w64 = w64; cl->n_classes = 0; cl->c64 = 0;
-    cl->d_bits = nullptr; cl->d_count = nullptr; cl->d_first_row = nullptr; cl->d_bitsT = nullptr;
+    hgx_classes *cl = new_classes(a_pad);
     *out = cl;
     if (n_rows == 0) return HGX_OK;
     ARGCHK(rows);
@@ -460,6 +467,132 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
         hgx_set_error("64-bit class hash collision detected by the exact verify pass");
         return HGX_ECOLLISION;
     }
+    return HGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// hgx_level_classes: pairs -> classes of one level without materialising a row per pair.
+// A pair's class row is a function of its (ordered) list of piece refs at that level, and deep coverage repeats those
+// lists: at HLA-A (1 M reads) 500 k pairs carry 134 k distinct exon-level lists.  So the pairs are first grouped by
+// their ref LIST (8-byte keys, the same hash table as the row dedup, verified list against list), a row is computed
+// for one representative pair per list, and the row dedup runs on those rows with the group sizes as weights.
+// Same result as hgx_pair_classes + hgx_dedup_classes (classes in first-seen order, counts, first pair), with the
+// 896-byte-per-pair row traffic divided by the repeat factor.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_sig_keys(const int32_t *__restrict__ pair_off, const uint32_t *__restrict__ refs, int n_pairs, uint32_t level,
+                           uint64_t *__restrict__ key) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    uint64_t h = 0x243f6a8885a308d3ull;
+    uint32_t cnt = 0;
+    for (int r = pair_off[p]; r < pair_off[p + 1]; ++r) {
+        const uint32_t x = refs[r];
+        if ((x >> 31) != level) continue;
+        h = mix64(h + 0x9e3779b97f4a7c15ull * (uint64_t)((x & 0x7fffffffu) + 1u));     // order dependent on purpose: cheap, and a
+        ++cnt;                                                                         // permuted list merely stays a separate group
+    }
+    h = mix64(h ^ cnt);
+    key[p] = h == HGX_EMPTY_KEY ? HGX_EMPTY_KEY - 1 : h;       // never the "dropped row" key: a pair without refs has a class (Q4)
+}
+// exact check of the grouping: every pair's ref list equals the list of its group's first pair
+__global__ void k_sig_verify(const int32_t *__restrict__ pair_off, const uint32_t *__restrict__ refs, int n_pairs, uint32_t level,
+                             const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ first, int *__restrict__ bad) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n_pairs) return;
+    const uint32_t f = first[slot_of[p]];
+    if (f == (uint32_t)p) return;
+    int a = pair_off[p], b = pair_off[f];
+    const int a1 = pair_off[p + 1], b1 = pair_off[f + 1];
+    bool same = true;
+    for (;;) {
+        while (a < a1 && (refs[a] >> 31) != level) ++a;
+        while (b < b1 && (refs[b] >> 31) != level) ++b;
+        if (a >= a1 || b >= b1) { same = (a >= a1) == (b >= b1); break; }
+        if (refs[a] != refs[b]) { same = false; break; }
+        ++a; ++b;
+    }
+    if (!same) atomicOr(bad, 1);
+}
+__global__ void k_remap_first(int64_t *__restrict__ first_row, int n, const int64_t *__restrict__ sig_first) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) first_row[c] = sig_first[first_row[c]];
+}
+
+static hgx_classes *new_classes(int32_t a_pad) {
+    hgx_classes *cl = new hgx_classes();
+    cl->a_pad = a_pad; cl->w64 = a_pad / 64; cl->n_classes = 0; cl->c64 = 0;
+    cl->d_bits = nullptr; cl->d_count = nullptr; cl->d_first_row = nullptr; cl->d_bitsT = nullptr;
+    return cl;
+}
+
+extern "C" int hgx_level_classes(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
+                                 const uint32_t *refs, int32_t n_pairs, int32_t level, uint64_t *rows_scratch,
+                                 uint64_t *hash_scratch, void *stream) {
+    ARGCHK(out && ix && n_pairs >= 0 && (level == 0 || level == 1));
+    hipStream_t st = (hipStream_t)stream;
+    hgx_classes *cl = new_classes(ix->a_pad);
+    *out = cl;
+    if (n_pairs == 0) return HGX_OK;
+    ARGCHK(compat && pair_off && refs);
+    const long n = n_pairs;
+    const int w64 = ix->w64;
+    DevBuf b_rows, b_hash, b_sfirst, b_scount;      // outlive this call (queued kernels read them): handed to the class set below
+    ALLOC(b_sfirst, (size_t)n * 8); ALLOC(b_scount, (size_t)n * 8);
+    uint32_t meta[4] = {0, 0, 0, 0};
+    {   // ---- stage 1: group the pairs by ref list --------------------------------------------------------------
+        long T = 1024;
+        while (T < 2 * n) T <<= 1;
+        DevBuf b_key, b_keys, b_first, b_cnt, b_slot, b_flag, b_rank, b_tmp, b_meta;
+        ALLOC(b_key, (size_t)n * 8);
+        ALLOC(b_keys, (size_t)T * 8); ALLOC(b_first, (size_t)T * 4); ALLOC(b_cnt, (size_t)T * 8);
+        ALLOC(b_slot, (size_t)n * 4); ALLOC(b_flag, (size_t)n * 4); ALLOC(b_rank, (size_t)n * 4); ALLOC(b_meta, 16);
+        size_t tmp_bytes = 0;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
+        ALLOC(b_tmp, tmp_bytes);
+        hipLaunchKernelGGL(k_sig_keys, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level, b_key.as<uint64_t>());
+        hipLaunchKernelGGL(k_ht_init, dim3(nblk(std::max(T, n), 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(),
+                           b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), T, b_flag.as<uint32_t>(), n, b_meta.as<uint32_t>());
+        hipLaunchKernelGGL(k_ht_insert<256>, dim3(nblk(n, 256)), dim3(256), 0, st, b_key.as<uint64_t>(), (const int64_t *)nullptr, n,
+                           b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1),
+                           b_slot.as<uint32_t>());
+        hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,
+                           b_flag.as<uint32_t>());
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
+        hipLaunchKernelGGL(k_ht_meta, dim3(1), dim3(1), 0, st, b_rank.as<uint32_t>() + (n - 1), b_flag.as<uint32_t>() + (n - 1),
+                           b_meta.as<uint32_t>());
+        hipLaunchKernelGGL(k_sig_verify, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level,
+                           b_slot.as<uint32_t>(), b_first.as<uint32_t>(), b_meta.as<int>());
+        // group id (first-seen order) -> first pair, group size; sized for the worst case so that it is queued before the
+        // round trip and this block's scratch can go back to the pool right after it
+        hipLaunchKernelGGL(k_ht_finalize, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(),
+                           b_cnt.as<unsigned long long>(), T, b_rank.as<uint32_t>(), b_sfirst.as<int64_t>(), b_scount.as<int64_t>());
+        HIPCHK(hipGetLastError());
+        { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
+        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+    }
+    const bool plain = meta[0] != 0;      // two different ref lists with one 64-bit key (never seen): take the per-pair path
+    const long n_sig = plain ? n : (long)meta[1];
+    uint64_t *rows = rows_scratch, *hash = hash_scratch;
+    if (!rows) { ALLOC(b_rows, (size_t)n_sig * w64 * 8); rows = b_rows.as<uint64_t>(); }
+    if (!hash) { ALLOC(b_hash, (size_t)n_sig * 8); hash = b_hash.as<uint64_t>(); }
+    // ---- stage 2: one row per group, row dedup weighted by the group sizes ------------------------------------------
+    int rc = hgx_pair_classes_sel(ix, compat, pair_off, refs, plain ? nullptr : b_sfirst.as<int64_t>(), (int32_t)n_sig,
+                                  level == 0 ? rows : nullptr, level == 1 ? rows : nullptr, level == 0 ? hash : nullptr,
+                                  level == 1 ? hash : nullptr, st);
+    if (rc) return rc;
+    rc = dedup_hash_table(cl, rows, hash, plain ? nullptr : b_scount.as<int64_t>(), n_sig, w64, nullptr, st, true);
+    if (rc) return rc;
+    if (!plain && cl->n_classes > 0)
+        hipLaunchKernelGGL(k_remap_first, dim3(nblk(cl->n_classes, 256)), dim3(256), 0, st, cl->d_first_row, cl->n_classes,
+                           b_sfirst.as<int64_t>());
+    HIPCHK(hipGetLastError());
+    // consumers on other streams wait for `ready`; (re-)record it behind the last kernel queued here
+    cl->made_on = st;
+    if (!cl->ready && hipEventCreateWithFlags(&cl->ready, hipEventDisableTiming) != hipSuccess) cl->ready = nullptr;
+    if (cl->ready) (void)hipEventRecord(cl->ready, st);
+    else { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+    DevBuf *keep[] = {&b_rows, &b_hash, &b_sfirst, &b_scount};
+    for (int i = 0; i < 4; ++i) { cl->d_keep[8 + i] = keep[i]->p; keep[i]->p = nullptr; }
     return HGX_OK;
 }
 

@@ -562,13 +562,17 @@ __device__ __forceinline__ void class_for_level(const uint64_t *__restrict__ com
 template <int KW>
 __global__ __launch_bounds__(256) void k_pair_classes(const uint64_t *__restrict__ compat, int w64,
                                                       const int32_t *__restrict__ pair_off, const uint32_t *__restrict__ refs,
+                                                      const int64_t *__restrict__ sel,
                                                       int n_pairs, const uint64_t *__restrict__ exon_mask,
                                                       const uint64_t *__restrict__ gene_mask, uint64_t *__restrict__ exon_bits,
                                                       uint64_t *__restrict__ gene_bits, uint64_t *__restrict__ exon_hash,
                                                       uint64_t *__restrict__ gene_hash) {
     const int lane = threadIdx.x & 63;
-    const long pair = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (pair >= n_pairs) return;
+    // `out` = output row; with a selection (hgx_level_classes: one representative pair per distinct ref list) the input
+    // pair is sel[out]
+    const long out = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (out >= n_pairs) return;
+    const long pair = sel ? (long)sel[out] : out;
     const int r0 = __builtin_amdgcn_readfirstlane(pair_off[pair]);
     const int r1 = __builtin_amdgcn_readfirstlane(pair_off[pair + 1]);
     // counts never exceed the pair's number of refs: pick the narrowest counter that holds it (wave-uniform)
@@ -576,11 +580,11 @@ __global__ __launch_bounds__(256) void k_pair_classes(const uint64_t *__restrict
 #define HGX_LEVELS(NP_)                                                                                                          \
     do {                                                                                                                         \
         if (exon_bits || exon_hash)                                                                                              \
-            class_for_level<KW, NP_>(compat, w64, refs, r0, r1, 0u, exon_mask, exon_bits ? exon_bits + (size_t)pair * w64 : nullptr, \
-                                     exon_hash ? exon_hash + pair : nullptr, lane);                                              \
+            class_for_level<KW, NP_>(compat, w64, refs, r0, r1, 0u, exon_mask, exon_bits ? exon_bits + (size_t)out * w64 : nullptr, \
+                                     exon_hash ? exon_hash + out : nullptr, lane);                                              \
         if (gene_bits || gene_hash)                                                                                              \
-            class_for_level<KW, NP_>(compat, w64, refs, r0, r1, 1u, gene_mask, gene_bits ? gene_bits + (size_t)pair * w64 : nullptr, \
-                                     gene_hash ? gene_hash + pair : nullptr, lane);                                              \
+            class_for_level<KW, NP_>(compat, w64, refs, r0, r1, 1u, gene_mask, gene_bits ? gene_bits + (size_t)out * w64 : nullptr, \
+                                     gene_hash ? gene_hash + out : nullptr, lane);                                              \
     } while (0)
     if (n_refs <= 3) HGX_LEVELS(2);
     else if (n_refs <= 15) HGX_LEVELS(4);
@@ -588,17 +592,18 @@ __global__ __launch_bounds__(256) void k_pair_classes(const uint64_t *__restrict
 #undef HGX_LEVELS
 }
 
-extern "C" int hgx_pair_classes(const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off, const uint32_t *refs,
-                                int32_t n_pairs, uint64_t *eb, uint64_t *gb, uint64_t *eh, uint64_t *gh, void *stream) {
+// sel: see k_pair_classes (NULL = every pair in order)
+int hgx_pair_classes_sel(const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off, const uint32_t *refs,
+                         const int64_t *sel, int32_t n_pairs, uint64_t *eb, uint64_t *gb, uint64_t *eh,
+                         uint64_t *gh, hipStream_t st) {
     ARGCHK(ix && n_pairs >= 0);
     if (n_pairs == 0) return HGX_OK;
     ARGCHK(compat && pair_off && refs);
     const long blocks = ((long)n_pairs + 3) / 4;
     const int kw = (ix->w64 + 63) / 64;
-    hipStream_t st = (hipStream_t)stream;
 #define LAUNCH_PC(KW_)                                                                                             \
     hipLaunchKernelGGL(k_pair_classes<KW_>, dim3((unsigned)blocks), dim3(256), 0, st, compat, ix->w64, pair_off, refs, \
-                       n_pairs, ix->d_exon_mask, ix->d_gene_mask, eb, gb, eh, gh)
+                       sel, n_pairs, ix->d_exon_mask, ix->d_gene_mask, eb, gb, eh, gh)
     if (kw <= 1) LAUNCH_PC(1);
     else if (kw <= 2) LAUNCH_PC(2);
     else if (kw <= 4) LAUNCH_PC(4);
@@ -610,6 +615,11 @@ extern "C" int hgx_pair_classes(const hgx_index *ix, const uint64_t *compat, con
 #undef LAUNCH_PC
     HIPCHK(hipGetLastError());
     return HGX_OK;
+}
+
+extern "C" int hgx_pair_classes(const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off, const uint32_t *refs,
+                                int32_t n_pairs, uint64_t *eb, uint64_t *gb, uint64_t *eh, uint64_t *gh, void *stream) {
+    return hgx_pair_classes_sel(ix, compat, pair_off, refs, nullptr, n_pairs, eb, gb, eh, gh, (hipStream_t)stream);
 }
 
 extern "C" int hgx_score_pairs(const hgx_index *ix, const hgx_piece *pieces, const uint32_t *masks, int32_t n_pieces,

@@ -46,6 +46,21 @@ def score_pairs(locus, dbatch, bufs, stream=None):
                                  capi.ptr(bufs.exon_hash), capi.ptr(bufs.gene_hash), stream))
 
 
+def piece_compat(locus, dbatch, bufs, stream=None):
+    """8a-5 stage 1 alone: the allele bitset of every distinct piece."""
+    capi.check(capi.lib().hgx_piece_compat(locus.index(), capi.ptr(dbatch.pieces), capi.ptr(dbatch.masks),
+                                           C.c_int32(dbatch.n_pieces), capi.ptr(bufs.compat), stream))
+
+
+def pair_classes(locus, dbatch, bufs, stream=None, exon=True, gene=True):
+    """8a-5/6 stage 2 alone (after piece_compat): per-pair class rows + hashes of the chosen levels."""
+    e, g = exon and bufs.exon_bits is not None, gene
+    capi.check(capi.lib().hgx_pair_classes(locus.index(), capi.ptr(bufs.compat), capi.ptr(dbatch.pair_off),
+                                           capi.ptr(dbatch.pair_ref), C.c_int32(dbatch.n_pairs),
+                                           capi.ptr(bufs.exon_bits) if e else None, capi.ptr(bufs.gene_bits) if g else None,
+                                           capi.ptr(bufs.exon_hash) if e else None, capi.ptr(bufs.gene_hash) if g else None, stream))
+
+
 class Classes:
     """Distinct compatibility classes in first-seen order (Gene_cmpt / Gene_exons_cmpt as a bit matrix)."""
 
@@ -62,6 +77,16 @@ class Classes:
         h = C.c_void_p()
         capi.check(capi.lib().hgx_dedup_classes(C.byref(h), capi.ptr(rows), capi.ptr(hashes), capi.ptr(weights),
                                                  C.c_int64(n_rows), C.c_int32(a_pad), capi.ptr(and_mask), stream))
+        return Classes(h)
+
+    @staticmethod
+    def of_level(locus, dbatch, bufs, level, stream=None):
+        """Classes of one level (0 exon, 1 gene) straight from the piece refs (after piece_compat): hgx_level_classes."""
+        rows, hashes = (bufs.exon_bits, bufs.exon_hash) if level == 0 else (bufs.gene_bits, bufs.gene_hash)
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_level_classes(C.byref(h), locus.index(), capi.ptr(bufs.compat), capi.ptr(dbatch.pair_off),
+                                                 capi.ptr(dbatch.pair_ref), C.c_int32(dbatch.n_pairs), C.c_int32(level),
+                                                 capi.ptr(rows), capi.ptr(hashes), stream))
         return Classes(h)
 
     @staticmethod

@@ -162,8 +162,14 @@ def _fork_event():
 
 
 def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dbatch=None, bufs=None, scored=False, overlap=None,
-                heavy_lock=None):
-    """`heavy_lock` (held by the caller on entry, released here): with several samples in flight per GPU, the bandwidth-bound
+                heavy_lock=None, pc_events=None):
+    """`scored`: False = nothing computed yet; "compat" = the caller queued hgx_piece_compat on `stream`; True = the caller
+    also queued hgx_pair_classes for both levels (the per-pair form).  For HLA-like loci (two levels) the exon-level classes
+    come from hgx_level_classes (pairs grouped by ref list first, HGX_NO_SIG=1 selects the per-pair form) and only the
+    gene-level rows are materialised per pair, beside the exon-level EM.  `pc_events` = (before, after) events recorded
+    around that gene-level hgx_pair_classes launch (bench.py).
+
+    `heavy_lock` (held by the caller on entry, released here): with several samples in flight per GPU, the bandwidth-bound
     front of the path (scoring, the exon-level dedup) of one sample should not run beside another sample's -- it would only
     share the HBM -- but beside the other samples' EM phases, which are chains of short launches.  The lock is released as soon
     as this sample's exon-level classes exist."""
@@ -171,8 +177,18 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
     A, names = pl.n_alleles, pl.names
     db = dbatch if dbatch is not None else engine.DeviceBatch(batch, stream)
     bufs = bufs if bufs is not None else engine.ScoreBuffers(pl, db, exon=hla)
-    if not scored:
-        engine.score_pairs(pl, db, bufs, stream)
+    by_list = hla and scored is not True and not os.environ.get("HGX_NO_SIG")
+    if scored is False:
+        if by_list:
+            engine.piece_compat(pl, db, bufs, stream)
+        else:
+            engine.score_pairs(pl, db, bufs, stream)
+    elif scored == "compat" and not by_list:
+        if pc_events:
+            pc_events[0].record(stream)
+        engine.pair_classes(pl, db, bufs, stream)
+        if pc_events:
+            pc_events[1].record(stream)
     # ---- Gene_counts (core:1187-1190, 1650-1651) --------------------------------------------------
     # The gene-level side (dedup -> counts -> ranking) is independent of the exon-level EM until the hand-off, and the
     # EM is a long chain of short launches that leaves most of the GPU idle: for HLA the two run concurrently, the gene
@@ -180,6 +196,12 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
     gene = {}
 
     def gene_side(st):
+        if by_list:
+            if pc_events:
+                pc_events[0].record(st)
+            engine.pair_classes(pl, db, bufs, st, exon=False)
+            if pc_events:
+                pc_events[1].record(st)
         gcl_ = engine.Classes.dedup(bufs.gene_bits, db.n_pairs, pl.a_pad, hashes=bufs.gene_hash, stream=st)
         cnt, first = gcl_.allele_counts(st)
         fr = np.zeros(gcl_.n_classes, np.int64)                     # first pair of every class
@@ -192,17 +214,28 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
         counted = counted[np.lexsort((counted, ins, -cnt_a[counted]))]
         gene.update(gcl=gcl_, counted=counted, cnt=cnt_a)
 
-    worker = None
     if overlap is None:
         overlap = stream is None
-    if hla and overlap and db.n_pairs >= 4096:
-        # class rows are complete before either side reads them: a device-side dependency, the host keeps running ahead
+    overlap = hla and overlap and db.n_pairs >= 4096
+    if overlap:
+        # scoring is complete before either side reads its output: a device-side dependency, the host keeps running ahead
         ev = _fork_event()
         ev.record(stream)
         em_stream_, gene_stream_ = capi.get_stream(0), capi.get_stream(1)     # this host thread's pair of side streams
         ev.make_wait(em_stream_)
         ev.make_wait(gene_stream_)
+    state = {"worker": None}
+
+    def start_gene(after=None):
+        """Run the gene side: beside the caller on a worker thread + its own stream when overlapping (after the device-side
+        event `after`, if given), otherwise right here."""
+        if not overlap:
+            gene_side(stream)
+            return
         dev = capi.current_device()
+        if after is not None:
+            after.record(em_stream_)
+            after.make_wait(gene_stream_)
 
         def run():
             capi.set_device(dev)
@@ -210,20 +243,21 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
 
         # a fresh thread per sample: measured faster than a pooled executor when several samples are in flight
         from concurrent.futures import Future
-        worker = Future()
+        fut = state["worker"] = Future()
 
         def run_t():
             try:
-                worker.set_result(run())
+                fut.set_result(run())
             except BaseException as e:      # re-raised on the calling thread by worker.result()
-                worker.set_exception(e)
+                fut.set_exception(e)
         threading.Thread(target=run_t).start()
-    else:
-        gene_side(stream)
+
+    if not by_list:
+        start_gene()
 
     def finish_gene():
-        if worker is not None:
-            worker.result()                          # re-raises on this thread
+        if state["worker"] is not None:
+            state["worker"].result()                 # re-raises on this thread
         res._names, res.counts_order, res.counts = names, gene["counted"], gene["cnt"]
         if keep_classes:
             res.gene_classes = gene["gcl"].to_host()[:2]
@@ -238,8 +272,14 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
         return out
 
     if hla:
-        em_stream = em_stream_ if worker is not None else stream
-        ecl = engine.Classes.dedup(bufs.exon_bits, db.n_pairs, pl.a_pad, hashes=bufs.exon_hash, stream=em_stream)
+        em_stream = em_stream_ if overlap else stream
+        if by_list:
+            # the per-pair gene-level rows run beside the exon-level grouping (queueing them behind it, under the EM, was
+            # measured slower: 2.62 vs 2.37 ms -- the EM's short launches then wait for wave slots)
+            start_gene()
+            ecl = engine.Classes.of_level(pl, db, bufs, 0, em_stream)
+        else:
+            ecl = engine.Classes.dedup(bufs.exon_bits, db.n_pairs, pl.a_pad, hashes=bufs.exon_hash, stream=em_stream)
         if heavy_lock is not None:
             heavy_lock.release()
             heavy_lock = None

@@ -160,6 +160,17 @@ int hgx_classes_to_host(const hgx_classes *c, uint64_t *bits_host, int64_t *coun
 int hgx_classes_from_host(hgx_classes **out, const uint64_t *bits_host, const int64_t *count_host,
                           int32_t n_classes, int32_t a_pad);
 
+/* 8a-5/6 stage 2 and 8a-7 in one call for ONE level (0 = exon, 1 = gene): the classes of all pairs in first-seen order with
+ * their pair counts and first pairs -- the same result as hgx_pair_classes + hgx_dedup_classes on that level's rows
+ * (Gene_exons_cmpt / Gene_cmpt, typing_core.py:1177-1190, 1229-1234) -- without a class row per pair: pairs are first
+ * grouped by their list of piece refs (exact, list against list), one row is computed per distinct list and the row
+ * dedup runs on those with the group sizes as weights.  Deep coverage repeats ref lists (3.7x at the exon level of
+ * HLA-A with 1 M reads), and the 896-byte rows are the dominant HBM traffic of the per-pair form.
+ * rows_scratch_dev ([n_pairs][a_pad/64]) / hash_scratch_dev ([n_pairs]) may be NULL (allocated from the pool). */
+int hgx_level_classes(hgx_classes **out, const hgx_index *ix, const uint64_t *compat_dev,
+                      const int32_t *pair_off_dev, const uint32_t *pair_ref_dev, int32_t n_pairs, int32_t level,
+                      uint64_t *rows_scratch_dev, uint64_t *hash_scratch_dev, void *stream);
+
 /* Gene_counts (typing_core.py:1187-1190, 1650-1651): per allele the number of pairs whose
  * class contains it, and the index of the first class (in first-seen order) containing it
  * (-1 if none) -- that is the dict insertion order used to break count ties.             */

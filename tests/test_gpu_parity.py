@@ -549,3 +549,76 @@ def test_em_backends_agree(orc, name):
                 assert np.max(np.abs(p1 - p2)) <= 1e-11, (backend, persist, np.max(np.abs(p1 - p2)))
     finally:
         engine.em_set_backend(0)
+
+
+def _level_equals_per_pair(pl, batch):
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    two = bufs.exon_bits is not None
+    ref = {}
+    if two:
+        ref[0] = engine.Classes.dedup(bufs.exon_bits, batch.n_pairs, pl.a_pad, hashes=bufs.exon_hash)
+    ref[1] = engine.Classes.dedup(bufs.gene_bits, batch.n_pairs, pl.a_pad, hashes=bufs.gene_hash)
+    want = {lv: c.to_host() for lv, c in ref.items()}
+    for lv in want:
+        for scratch in (True, False):
+            b2 = bufs if scratch else type("B", (), {"compat": bufs.compat, "exon_bits": None, "exon_hash": None,
+                                                     "gene_bits": None, "gene_hash": None})()
+            got = engine.Classes.of_level(pl, db, b2, lv)
+            gh = got.to_host()
+            assert got.n_classes == ref[lv].n_classes
+            for x, y in zip(gh, want[lv]):
+                assert np.array_equal(x, y)
+            got.close()
+    for c in ref.values():
+        c.close()
+    return {lv: len(w[1]) for lv, w in want.items()}
+
+
+@pytest.mark.parametrize("name", gu.ALL)
+def test_level_classes_equals_per_pair_rows_then_dedup(orc, name):
+    """hgx_level_classes (pairs grouped by ref list, one row per distinct list, weighted row dedup) gives exactly the classes,
+    counts, order and first pairs of the per-pair form on every golden fixture, with and without caller scratch."""
+    fx, loc, t, pl, batch, _ = _setup(orc, name)
+    _level_equals_per_pair(pl, batch)
+
+
+def test_level_classes_many_ref_lists_and_repeats():
+    """> 65536 distinct ref lists (the dedup's large path behind the grouping), heavy repeats, pairs without refs at a level,
+    the same pieces in another order (a separate group that must merge again at the row level)."""
+    from hisatgenotype_amd import synth
+    loc = synth.make_hla_like_locus(n_alleles=900, n_vars=1500, seed=12)
+    pl = hl.PackedLocus.from_synth(loc)
+    rng = np.random.RandomState(8)
+    names = [n for n in loc.allele_names[1:] if n in loc.allele_vars]
+    protos = []
+    for _ in range(700):                      # distinct pieces to draw from
+        l = rng.randint(0, len(loc.backbone) - 200)
+        r = l + rng.randint(20, 180)
+        a = names[rng.randint(len(names))]
+        vs = [v for v in loc.allele_vars[a] if l <= loc.var_pos[v] <= r]
+        if rng.rand() < 0.15 and vs:
+            vs = vs[1:]
+        protos.append((l, r, vs))
+    pair_off, level, left, right, id_off, ids = [0], [], [], [], [0], []
+    n_pairs = 250000
+    pick = rng.randint(0, len(protos), size=(n_pairs, 3))
+    n_in = rng.randint(0, 4, size=n_pairs)
+    lvl_mode = rng.randint(0, 4, size=n_pairs)
+    for p in range(n_pairs):
+        for m in range(n_in[p]):
+            l, r, vs = protos[pick[p, m]]
+            for lv in ((0, 1), (1,), (0,), (1, 0))[lvl_mode[p]]:
+                level.append(lv); left.append(l); right.append(r)
+                ids += vs
+                id_off.append(len(ids))
+        pair_off.append(len(level))
+    arrs = (np.array(pair_off, np.int32), np.array(level, np.uint8), np.array(left, np.int32), np.array(right, np.int32),
+            np.array(id_off, np.int32), np.array(ids, np.int32))
+    batch = pl.batch_from_haplotypes(*arrs)
+    off, ref = np.asarray(batch.pair_off), np.asarray(batch.pair_ref)
+    lists = {tuple(ref[off[p]:off[p + 1]][(ref[off[p]:off[p + 1]] >> 31) == 1].tolist()) for p in range(n_pairs)}
+    assert len(lists) > 65536
+    n_cls = _level_equals_per_pair(pl, batch)
+    assert n_cls[1] < len(lists)              # different lists, same class: merged by the row dedup
