@@ -525,75 +525,128 @@ static hgx_classes *new_classes(int32_t a_pad) {
     return cl;
 }
 
-extern "C" int hgx_level_classes(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
-                                 const uint32_t *refs, int32_t n_pairs, int32_t level, uint64_t *rows_scratch,
-                                 uint64_t *hash_scratch, void *stream) {
-    ARGCHK(out && ix && n_pairs >= 0 && (level == 0 || level == 1));
+// stage 1: the grouping.  Needs only the pair -> ref lists, not the piece bitsets: callers queue it on its own stream
+// beside hgx_piece_compat (hgx_group_pairs), or let hgx_level_classes do both stages in sequence.
+struct hgx_groups {
+    int32_t n_pairs = 0, level = 0;
+    int64_t n_groups = 0;              // 0 with n_pairs > 0: key collision between different lists (never seen) -> per-pair form
+    int64_t *d_first = nullptr;        // [n_groups] first pair of every group, groups in first-seen order
+    int64_t *d_count = nullptr;        // [n_groups] pairs per group
+};
+
+extern "C" int hgx_groups_destroy(hgx_groups *g) {
+    if (!g) return HGX_OK;
+    hgx_pool_free(g->d_first); hgx_pool_free(g->d_count);
+    delete g;
+    return HGX_OK;
+}
+extern "C" int hgx_groups_dims(const hgx_groups *g, int64_t *n_groups, int32_t *n_pairs) {
+    ARGCHK(g);
+    if (n_groups) *n_groups = g->n_groups;
+    if (n_pairs) *n_pairs = g->n_pairs;
+    return HGX_OK;
+}
+
+extern "C" int hgx_group_pairs(hgx_groups **out, const int32_t *pair_off, const uint32_t *refs, int32_t n_pairs, int32_t level,
+                               void *stream) {
+    ARGCHK(out && n_pairs >= 0 && (level == 0 || level == 1));
+    hipStream_t st = (hipStream_t)stream;
+    hgx_groups *g = new hgx_groups();
+    g->n_pairs = n_pairs; g->level = level;
+    *out = g;
+    if (n_pairs == 0) return HGX_OK;
+    ARGCHK(pair_off && refs);
+    const long n = n_pairs;
+    g->d_first = (int64_t *)hgx_pool_alloc((size_t)n * 8);
+    g->d_count = (int64_t *)hgx_pool_alloc((size_t)n * 8);
+    if (!g->d_first || !g->d_count) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    long T = 1024;
+    while (T < 2 * n) T <<= 1;
+    DevBuf b_key, b_keys, b_first, b_cnt, b_slot, b_flag, b_rank, b_tmp, b_meta;
+    ALLOC(b_key, (size_t)n * 8);
+    ALLOC(b_keys, (size_t)T * 8); ALLOC(b_first, (size_t)T * 4); ALLOC(b_cnt, (size_t)T * 8);
+    ALLOC(b_slot, (size_t)n * 4); ALLOC(b_flag, (size_t)n * 4); ALLOC(b_rank, (size_t)n * 4); ALLOC(b_meta, 16);
+    size_t tmp_bytes = 0;
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
+    ALLOC(b_tmp, tmp_bytes);
+    hipLaunchKernelGGL(k_sig_keys, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level, b_key.as<uint64_t>());
+    hipLaunchKernelGGL(k_ht_init, dim3(nblk(std::max(T, n), 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(),
+                       b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), T, b_flag.as<uint32_t>(), n, b_meta.as<uint32_t>());
+    hipLaunchKernelGGL(k_ht_insert<256>, dim3(nblk(n, 256)), dim3(256), 0, st, b_key.as<uint64_t>(), (const int64_t *)nullptr, n,
+                       b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1),
+                       b_slot.as<uint32_t>());
+    hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,
+                       b_flag.as<uint32_t>());
+    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
+    hipLaunchKernelGGL(k_ht_meta, dim3(1), dim3(1), 0, st, b_rank.as<uint32_t>() + (n - 1), b_flag.as<uint32_t>() + (n - 1),
+                       b_meta.as<uint32_t>());
+    hipLaunchKernelGGL(k_sig_verify, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level,
+                       b_slot.as<uint32_t>(), b_first.as<uint32_t>(), b_meta.as<int>());
+    // group id (first-seen order) -> first pair, group size; sized for the worst case so that it is queued before the round
+    // trip that fetches the group count, and the scratch can go back to the pool right after that
+    hipLaunchKernelGGL(k_ht_finalize, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(),
+                       b_cnt.as<unsigned long long>(), T, b_rank.as<uint32_t>(), g->d_first, g->d_count);
+    HIPCHK(hipGetLastError());
+    uint32_t meta[4] = {0, 0, 0, 0};
+    { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+    g->n_groups = meta[0] ? 0 : (int64_t)meta[1];
+    return HGX_OK;
+}
+
+// stage 2: one row per group, then the row dedup weighted by the group sizes (st must be ordered behind hgx_piece_compat)
+extern "C" int hgx_level_classes_grouped(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
+                                         const uint32_t *refs, const hgx_groups *g, uint64_t *rows_scratch, uint64_t *hash_scratch,
+                                         void *stream) {
+    ARGCHK(out && ix && g);
     hipStream_t st = (hipStream_t)stream;
     hgx_classes *cl = new_classes(ix->a_pad);
     *out = cl;
-    if (n_pairs == 0) return HGX_OK;
+    const long n = g->n_pairs;
+    if (n == 0) return HGX_OK;
     ARGCHK(compat && pair_off && refs);
-    const long n = n_pairs;
-    const int w64 = ix->w64;
-    DevBuf b_rows, b_hash, b_sfirst, b_scount;      // outlive this call (queued kernels read them): handed to the class set below
-    ALLOC(b_sfirst, (size_t)n * 8); ALLOC(b_scount, (size_t)n * 8);
-    uint32_t meta[4] = {0, 0, 0, 0};
-    {   // ---- stage 1: group the pairs by ref list --------------------------------------------------------------
-        long T = 1024;
-        while (T < 2 * n) T <<= 1;
-        DevBuf b_key, b_keys, b_first, b_cnt, b_slot, b_flag, b_rank, b_tmp, b_meta;
-        ALLOC(b_key, (size_t)n * 8);
-        ALLOC(b_keys, (size_t)T * 8); ALLOC(b_first, (size_t)T * 4); ALLOC(b_cnt, (size_t)T * 8);
-        ALLOC(b_slot, (size_t)n * 4); ALLOC(b_flag, (size_t)n * 4); ALLOC(b_rank, (size_t)n * 4); ALLOC(b_meta, 16);
-        size_t tmp_bytes = 0;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
-        ALLOC(b_tmp, tmp_bytes);
-        hipLaunchKernelGGL(k_sig_keys, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level, b_key.as<uint64_t>());
-        hipLaunchKernelGGL(k_ht_init, dim3(nblk(std::max(T, n), 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(),
-                           b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), T, b_flag.as<uint32_t>(), n, b_meta.as<uint32_t>());
-        hipLaunchKernelGGL(k_ht_insert<256>, dim3(nblk(n, 256)), dim3(256), 0, st, b_key.as<uint64_t>(), (const int64_t *)nullptr, n,
-                           b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1),
-                           b_slot.as<uint32_t>());
-        hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,
-                           b_flag.as<uint32_t>());
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
-        hipLaunchKernelGGL(k_ht_meta, dim3(1), dim3(1), 0, st, b_rank.as<uint32_t>() + (n - 1), b_flag.as<uint32_t>() + (n - 1),
-                           b_meta.as<uint32_t>());
-        hipLaunchKernelGGL(k_sig_verify, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level,
-                           b_slot.as<uint32_t>(), b_first.as<uint32_t>(), b_meta.as<int>());
-        // group id (first-seen order) -> first pair, group size; sized for the worst case so that it is queued before the
-        // round trip and this block's scratch can go back to the pool right after it
-        hipLaunchKernelGGL(k_ht_finalize, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(),
-                           b_cnt.as<unsigned long long>(), T, b_rank.as<uint32_t>(), b_sfirst.as<int64_t>(), b_scount.as<int64_t>());
-        HIPCHK(hipGetLastError());
-        { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
-        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-    }
-    const bool plain = meta[0] != 0;      // two different ref lists with one 64-bit key (never seen): take the per-pair path
-    const long n_sig = plain ? n : (long)meta[1];
+    const int w64 = ix->w64, level = g->level;
+    const bool plain = g->n_groups == 0;
+    const long n_rows = plain ? n : (long)g->n_groups;
+    DevBuf b_rows, b_hash;      // read by kernels still queued when this returns: handed to the class set below
     uint64_t *rows = rows_scratch, *hash = hash_scratch;
-    if (!rows) { ALLOC(b_rows, (size_t)n_sig * w64 * 8); rows = b_rows.as<uint64_t>(); }
-    if (!hash) { ALLOC(b_hash, (size_t)n_sig * 8); hash = b_hash.as<uint64_t>(); }
-    // ---- stage 2: one row per group, row dedup weighted by the group sizes ------------------------------------------
-    int rc = hgx_pair_classes_sel(ix, compat, pair_off, refs, plain ? nullptr : b_sfirst.as<int64_t>(), (int32_t)n_sig,
+    if (!rows) { ALLOC(b_rows, (size_t)n_rows * w64 * 8); rows = b_rows.as<uint64_t>(); }
+    if (!hash) { ALLOC(b_hash, (size_t)n_rows * 8); hash = b_hash.as<uint64_t>(); }
+    int rc = hgx_pair_classes_sel(ix, compat, pair_off, refs, plain ? nullptr : g->d_first, (int32_t)n_rows,
                                   level == 0 ? rows : nullptr, level == 1 ? rows : nullptr, level == 0 ? hash : nullptr,
                                   level == 1 ? hash : nullptr, st);
     if (rc) return rc;
-    rc = dedup_hash_table(cl, rows, hash, plain ? nullptr : b_scount.as<int64_t>(), n_sig, w64, nullptr, st, true);
+    rc = dedup_hash_table(cl, rows, hash, plain ? nullptr : g->d_count, n_rows, w64, nullptr, st, true);
     if (rc) return rc;
     if (!plain && cl->n_classes > 0)
-        hipLaunchKernelGGL(k_remap_first, dim3(nblk(cl->n_classes, 256)), dim3(256), 0, st, cl->d_first_row, cl->n_classes,
-                           b_sfirst.as<int64_t>());
+        hipLaunchKernelGGL(k_remap_first, dim3(nblk(cl->n_classes, 256)), dim3(256), 0, st, cl->d_first_row, cl->n_classes, g->d_first);
     HIPCHK(hipGetLastError());
-    // consumers on other streams wait for `ready`; (re-)record it behind the last kernel queued here
+    // consumers on other streams wait for `ready`; (re-)record it behind the last kernel queued here.  The group tables are
+    // read by those kernels: the caller keeps `g` alive until the class set is consumed (or synchronises), see hgx.h.
     cl->made_on = st;
     if (!cl->ready && hipEventCreateWithFlags(&cl->ready, hipEventDisableTiming) != hipSuccess) cl->ready = nullptr;
     if (cl->ready) (void)hipEventRecord(cl->ready, st);
     else { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-    DevBuf *keep[] = {&b_rows, &b_hash, &b_sfirst, &b_scount};
-    for (int i = 0; i < 4; ++i) { cl->d_keep[8 + i] = keep[i]->p; keep[i]->p = nullptr; }
+    DevBuf *keep[] = {&b_rows, &b_hash};
+    for (int i = 0; i < 2; ++i) { cl->d_keep[8 + i] = keep[i]->p; keep[i]->p = nullptr; }
     return HGX_OK;
+}
+
+extern "C" int hgx_level_classes(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
+                                 const uint32_t *refs, int32_t n_pairs, int32_t level, uint64_t *rows_scratch,
+                                 uint64_t *hash_scratch, void *stream) {
+    ARGCHK(out && ix && n_pairs >= 0 && (level == 0 || level == 1));
+    hgx_groups *g = nullptr;
+    int rc = hgx_group_pairs(&g, pair_off, refs, n_pairs, level, stream);
+    if (rc == HGX_OK) rc = hgx_level_classes_grouped(out, ix, compat, pair_off, refs, g, rows_scratch, hash_scratch, stream);
+    else *out = nullptr;
+    if (rc == HGX_OK && *out) {
+        // the group tables travel with the class set (its queued kernels read them)
+        (*out)->d_keep[10] = g->d_first; (*out)->d_keep[11] = g->d_count;
+        g->d_first = nullptr; g->d_count = nullptr;
+    }
+    hgx_groups_destroy(g);
+    return rc;
 }
 
 extern "C" int hgx_classes_destroy(hgx_classes *c) {

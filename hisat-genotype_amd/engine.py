@@ -61,6 +61,27 @@ def pair_classes(locus, dbatch, bufs, stream=None, exon=True, gene=True):
                                            capi.ptr(bufs.exon_hash) if e else None, capi.ptr(bufs.gene_hash) if g else None, stream))
 
 
+class Groups:
+    """Pairs grouped by their list of piece refs at one level (hgx_group_pairs): needs no piece bitsets, so it can be queued on
+    its own stream beside piece_compat.  Keep it alive until the classes made from it have been consumed."""
+
+    def __init__(self, dbatch, level, stream=None):
+        self.h = C.c_void_p()
+        capi.check(capi.lib().hgx_group_pairs(C.byref(self.h), capi.ptr(dbatch.pair_off), capi.ptr(dbatch.pair_ref),
+                                              C.c_int32(dbatch.n_pairs), C.c_int32(level), stream))
+        n = C.c_int64()
+        capi.check(capi.lib().hgx_groups_dims(self.h, C.byref(n), None))
+        self.n_groups, self.level = n.value, level
+
+    def close(self):
+        if self.h:
+            capi.lib().hgx_groups_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+
 class Classes:
     """Distinct compatibility classes in first-seen order (Gene_cmpt / Gene_exons_cmpt as a bit matrix)."""
 
@@ -80,10 +101,17 @@ class Classes:
         return Classes(h)
 
     @staticmethod
-    def of_level(locus, dbatch, bufs, level, stream=None):
-        """Classes of one level (0 exon, 1 gene) straight from the piece refs (after piece_compat): hgx_level_classes."""
+    def of_level(locus, dbatch, bufs, level, stream=None, groups=None):
+        """Classes of one level (0 exon, 1 gene) straight from the piece refs (after piece_compat): hgx_level_classes, or its
+        second step when the pairs were grouped beforehand (`groups`, which must outlive the returned classes' use)."""
         rows, hashes = (bufs.exon_bits, bufs.exon_hash) if level == 0 else (bufs.gene_bits, bufs.gene_hash)
         h = C.c_void_p()
+        if groups is not None:
+            assert groups.level == level
+            capi.check(capi.lib().hgx_level_classes_grouped(C.byref(h), locus.index(), capi.ptr(bufs.compat),
+                                                             capi.ptr(dbatch.pair_off), capi.ptr(dbatch.pair_ref), groups.h,
+                                                             capi.ptr(rows), capi.ptr(hashes), stream))
+            return Classes(h)
         capi.check(capi.lib().hgx_level_classes(C.byref(h), locus.index(), capi.ptr(bufs.compat), capi.ptr(dbatch.pair_off),
                                                  capi.ptr(dbatch.pair_ref), C.c_int32(dbatch.n_pairs), C.c_int32(level),
                                                  capi.ptr(rows), capi.ptr(hashes), stream))

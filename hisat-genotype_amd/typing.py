@@ -217,25 +217,21 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
     if overlap is None:
         overlap = stream is None
     overlap = hla and overlap and db.n_pairs >= 4096
+    pair_groups = None
     if overlap:
         # scoring is complete before either side reads its output: a device-side dependency, the host keeps running ahead
         ev = _fork_event()
         ev.record(stream)
         em_stream_, gene_stream_ = capi.get_stream(0), capi.get_stream(1)     # this host thread's pair of side streams
-        ev.make_wait(em_stream_)
         ev.make_wait(gene_stream_)
     state = {"worker": None}
 
-    def start_gene(after=None):
-        """Run the gene side: beside the caller on a worker thread + its own stream when overlapping (after the device-side
-        event `after`, if given), otherwise right here."""
+    def start_gene():
+        """Run the gene side: beside the caller on a worker thread + its own stream when overlapping, otherwise right here."""
         if not overlap:
             gene_side(stream)
             return
         dev = capi.current_device()
-        if after is not None:
-            after.record(em_stream_)
-            after.make_wait(gene_stream_)
 
         def run():
             capi.set_device(dev)
@@ -252,8 +248,13 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
                 fut.set_exception(e)
         threading.Thread(target=run_t).start()
 
-    if not by_list:
-        start_gene()
+    start_gene()
+    if overlap:
+        if by_list:
+            # grouping the pairs by exon-level ref list does not read the piece bitsets: on the EM stream it runs BESIDE
+            # hgx_piece_compat (queued above on `stream`); only then is that stream ordered behind the scoring
+            pair_groups = engine.Groups(db, 0, em_stream_)
+        ev.make_wait(em_stream_)
 
     def finish_gene():
         if state["worker"] is not None:
@@ -276,8 +277,7 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
         if by_list:
             # the per-pair gene-level rows run beside the exon-level grouping (queueing them behind it, under the EM, was
             # measured slower: 2.62 vs 2.37 ms -- the EM's short launches then wait for wave slots)
-            start_gene()
-            ecl = engine.Classes.of_level(pl, db, bufs, 0, em_stream)
+            ecl = engine.Classes.of_level(pl, db, bufs, 0, em_stream, pair_groups)
         else:
             ecl = engine.Classes.dedup(bufs.exon_bits, db.n_pairs, pl.a_pad, hashes=bufs.exon_hash, stream=em_stream)
         if heavy_lock is not None:
@@ -320,6 +320,8 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
                 comb[a] = p * psum
             gene_prob = _stable_desc([[a, p] for a, p in comb.items()])
         ecl.close()
+        if pair_groups is not None:
+            pair_groups.close()
     else:
         gcl = finish_gene()
         if heavy_lock is not None:

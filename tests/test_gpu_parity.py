@@ -565,8 +565,12 @@ def _level_equals_per_pair(pl, batch):
         for scratch in (True, False):
             b2 = bufs if scratch else type("B", (), {"compat": bufs.compat, "exon_bits": None, "exon_hash": None,
                                                      "gene_bits": None, "gene_hash": None})()
-            got = engine.Classes.of_level(pl, db, b2, lv)
+            groups = None if scratch else engine.Groups(db, lv)         # two-step form (grouping queued separately)
+            got = engine.Classes.of_level(pl, db, b2, lv, groups=groups)
             gh = got.to_host()
+            if groups is not None:
+                assert 0 < groups.n_groups <= batch.n_pairs
+                groups.close()
             assert got.n_classes == ref[lv].n_classes
             for x, y in zip(gh, want[lv]):
                 assert np.array_equal(x, y)
