@@ -532,16 +532,33 @@ struct hgx_groups {
     int64_t n_groups = 0;              // 0 with n_pairs > 0: key collision between different lists (never seen) -> per-pair form
     int64_t *d_first = nullptr;        // [n_groups] first pair of every group, groups in first-seen order
     int64_t *d_count = nullptr;        // [n_groups] pairs per group
+    // hgx_group_pairs only queues; the first call that needs the group count completes it (same host thread)
+    hipStream_t made_on = nullptr;
+    bool finished = true;
+    uint32_t meta[4] = {0, 0, 0, 0};   // {collision flag, number of groups}
+    void *scratch[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
+
+static int groups_finish(hgx_groups *g) {
+    if (g->finished) return HGX_OK;
+    int rc = hgx_sync(g->made_on);      // delivers the staged meta words
+    for (void *&p : g->scratch) { hgx_pool_free(p); p = nullptr; }
+    g->finished = true;
+    if (rc) return rc;
+    g->n_groups = g->meta[0] ? 0 : (int64_t)g->meta[1];
+    return HGX_OK;
+}
 
 extern "C" int hgx_groups_destroy(hgx_groups *g) {
     if (!g) return HGX_OK;
+    (void)groups_finish(g);
     hgx_pool_free(g->d_first); hgx_pool_free(g->d_count);
     delete g;
     return HGX_OK;
 }
-extern "C" int hgx_groups_dims(const hgx_groups *g, int64_t *n_groups, int32_t *n_pairs) {
+extern "C" int hgx_groups_dims(hgx_groups *g, int64_t *n_groups, int32_t *n_pairs) {
     ARGCHK(g);
+    { int rc_ = groups_finish(g); if (rc_) return rc_; }
     if (n_groups) *n_groups = g->n_groups;
     if (n_pairs) *n_pairs = g->n_pairs;
     return HGX_OK;
@@ -552,7 +569,7 @@ extern "C" int hgx_group_pairs(hgx_groups **out, const int32_t *pair_off, const 
     ARGCHK(out && n_pairs >= 0 && (level == 0 || level == 1));
     hipStream_t st = (hipStream_t)stream;
     hgx_groups *g = new hgx_groups();
-    g->n_pairs = n_pairs; g->level = level;
+    g->n_pairs = n_pairs; g->level = level; g->made_on = st;
     *out = g;
     if (n_pairs == 0) return HGX_OK;
     ARGCHK(pair_off && refs);
@@ -582,23 +599,24 @@ extern "C" int hgx_group_pairs(hgx_groups **out, const int32_t *pair_off, const 
                        b_meta.as<uint32_t>());
     hipLaunchKernelGGL(k_sig_verify, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level,
                        b_slot.as<uint32_t>(), b_first.as<uint32_t>(), b_meta.as<int>());
-    // group id (first-seen order) -> first pair, group size; sized for the worst case so that it is queued before the round
-    // trip that fetches the group count, and the scratch can go back to the pool right after that
+    // group id (first-seen order) -> first pair, group size; sized for the worst case: no host-side group count needed yet
     hipLaunchKernelGGL(k_ht_finalize, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(),
                        b_cnt.as<unsigned long long>(), T, b_rank.as<uint32_t>(), g->d_first, g->d_count);
     HIPCHK(hipGetLastError());
-    uint32_t meta[4] = {0, 0, 0, 0};
-    { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
-    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-    g->n_groups = meta[0] ? 0 : (int64_t)meta[1];
+    { int rc_ = hgx_d2h(g->meta, b_meta.p, 16, st); if (rc_) return rc_; }
+    // everything is queued; the scratch stays with the group set until groups_finish
+    DevBuf *keep[] = {&b_key, &b_keys, &b_first, &b_cnt, &b_slot, &b_flag, &b_rank, &b_tmp, &b_meta};
+    for (int i = 0; i < 9; ++i) { g->scratch[i] = keep[i]->p; keep[i]->p = nullptr; }
+    g->finished = false;
     return HGX_OK;
 }
 
 // stage 2: one row per group, then the row dedup weighted by the group sizes (st must be ordered behind hgx_piece_compat)
 extern "C" int hgx_level_classes_grouped(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
-                                         const uint32_t *refs, const hgx_groups *g, uint64_t *rows_scratch, uint64_t *hash_scratch,
+                                         const uint32_t *refs, hgx_groups *g, uint64_t *rows_scratch, uint64_t *hash_scratch,
                                          void *stream) {
     ARGCHK(out && ix && g);
+    { int rc_ = groups_finish(g); if (rc_) { *out = nullptr; return rc_; } }
     hipStream_t st = (hipStream_t)stream;
     hgx_classes *cl = new_classes(ix->a_pad);
     *out = cl;

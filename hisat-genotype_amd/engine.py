@@ -67,11 +67,15 @@ class Groups:
 
     def __init__(self, dbatch, level, stream=None):
         self.h = C.c_void_p()
+        self.level = level
         capi.check(capi.lib().hgx_group_pairs(C.byref(self.h), capi.ptr(dbatch.pair_off), capi.ptr(dbatch.pair_ref),
-                                              C.c_int32(dbatch.n_pairs), C.c_int32(level), stream))
+                                              C.c_int32(dbatch.n_pairs), C.c_int32(level), stream))      # queued, not waited for
+
+    @property
+    def n_groups(self):
         n = C.c_int64()
         capi.check(capi.lib().hgx_groups_dims(self.h, C.byref(n), None))
-        self.n_groups, self.level = n.value, level
+        return n.value
 
     def close(self):
         if self.h:

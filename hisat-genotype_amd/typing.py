@@ -248,12 +248,14 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
                 fut.set_exception(e)
         threading.Thread(target=run_t).start()
 
+    if overlap and by_list:
+        # grouping the pairs by exon-level ref list does not read the piece bitsets: queued on the EM stream right away it runs
+        # BESIDE hgx_piece_compat (queued above on `stream`); the stream is ordered behind the scoring only further down
+        pair_groups = engine.Groups(db, 0, em_stream_)
     start_gene()
     if overlap:
-        if by_list:
-            # grouping the pairs by exon-level ref list does not read the piece bitsets: on the EM stream it runs BESIDE
-            # hgx_piece_compat (queued above on `stream`); only then is that stream ordered behind the scoring
-            pair_groups = engine.Groups(db, 0, em_stream_)
+        if pair_groups is not None:
+            pair_groups.n_groups                     # host wait for the grouping alone: the stream is not yet behind the scoring
         ev.make_wait(em_stream_)
 
     def finish_gene():

@@ -171,16 +171,17 @@ int hgx_level_classes(hgx_classes **out, const hgx_index *ix, const uint64_t *co
                       const int32_t *pair_off_dev, const uint32_t *pair_ref_dev, int32_t n_pairs, int32_t level,
                       uint64_t *rows_scratch_dev, uint64_t *hash_scratch_dev, void *stream);
 /* The same in two steps.  The grouping needs only the pair -> ref lists, not the piece bitsets: queued on its own stream it
- * runs beside hgx_piece_compat (it ends with one host round trip on that stream for the group count).  The second step must
- * be ordered behind hgx_piece_compat and the grouping; `groups` must stay alive until the returned class set has been
- * consumed on the device (destroy it after the EM / hgx_classes_to_host, or after synchronising the stream). */
+ * runs beside hgx_piece_compat.  hgx_group_pairs only QUEUES the work; the first hgx_groups_dims /
+ * hgx_level_classes_grouped call on the same host thread waits for it (one round trip on that stream).  The second step
+ * must be ordered behind hgx_piece_compat; `groups` must stay alive until the returned class set has been consumed on the
+ * device (destroy it after the EM / hgx_classes_to_host, or after synchronising the stream). */
 typedef struct hgx_groups hgx_groups;
 int hgx_group_pairs(hgx_groups **out, const int32_t *pair_off_dev, const uint32_t *pair_ref_dev, int32_t n_pairs,
                     int32_t level, void *stream);
-int hgx_groups_dims(const hgx_groups *g, int64_t *n_groups, int32_t *n_pairs);
+int hgx_groups_dims(hgx_groups *g, int64_t *n_groups, int32_t *n_pairs);
 int hgx_groups_destroy(hgx_groups *g);
 int hgx_level_classes_grouped(hgx_classes **out, const hgx_index *ix, const uint64_t *compat_dev,
-                              const int32_t *pair_off_dev, const uint32_t *pair_ref_dev, const hgx_groups *groups,
+                              const int32_t *pair_off_dev, const uint32_t *pair_ref_dev, hgx_groups *groups,
                               uint64_t *rows_scratch_dev, uint64_t *hash_scratch_dev, void *stream);
 
 /* Gene_counts (typing_core.py:1187-1190, 1650-1651): per allele the number of pairs whose
