@@ -559,7 +559,8 @@ __device__ __forceinline__ void class_for_level(const uint64_t *__restrict__ com
     emit_class<KW, NP>(plane, w64, mask, out_row, out_hash, lane);
 }
 
-template <int KW>
+// SEL: rows for a selection of pairs (one representative per distinct ref list, hgx_level_classes) instead of every pair
+template <int KW, bool SEL>
 __global__ __launch_bounds__(256) void k_pair_classes(const uint64_t *__restrict__ compat, int w64,
                                                       const int32_t *__restrict__ pair_off, const uint32_t *__restrict__ refs,
                                                       const int64_t *__restrict__ sel,
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(256) void k_pair_classes(const uint64_t *__restrict
     // pair is sel[out]
     const long out = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (out >= n_pairs) return;
-    const long pair = sel ? (long)sel[out] : out;
+    const long pair = SEL ? (long)sel[out] : out;
     const int r0 = __builtin_amdgcn_readfirstlane(pair_off[pair]);
     const int r1 = __builtin_amdgcn_readfirstlane(pair_off[pair + 1]);
     // counts never exceed the pair's number of refs: pick the narrowest counter that holds it (wave-uniform)
@@ -601,9 +602,15 @@ int hgx_pair_classes_sel(const hgx_index *ix, const uint64_t *compat, const int3
     ARGCHK(compat && pair_off && refs);
     const long blocks = ((long)n_pairs + 3) / 4;
     const int kw = (ix->w64 + 63) / 64;
-#define LAUNCH_PC(KW_)                                                                                             \
-    hipLaunchKernelGGL(k_pair_classes<KW_>, dim3((unsigned)blocks), dim3(256), 0, st, compat, ix->w64, pair_off, refs, \
-                       sel, n_pairs, ix->d_exon_mask, ix->d_gene_mask, eb, gb, eh, gh)
+#define LAUNCH_PC(KW_)                                                                                                        \
+    do {                                                                                                                      \
+        if (sel)                                                                                                              \
+            hipLaunchKernelGGL((k_pair_classes<KW_, true>), dim3((unsigned)blocks), dim3(256), 0, st, compat, ix->w64, pair_off, \
+                               refs, sel, n_pairs, ix->d_exon_mask, ix->d_gene_mask, eb, gb, eh, gh);                        \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_pair_classes<KW_, false>), dim3((unsigned)blocks), dim3(256), 0, st, compat, ix->w64, pair_off, \
+                               refs, sel, n_pairs, ix->d_exon_mask, ix->d_gene_mask, eb, gb, eh, gh);                        \
+    } while (0)
     if (kw <= 1) LAUNCH_PC(1);
     else if (kw <= 2) LAUNCH_PC(2);
     else if (kw <= 4) LAUNCH_PC(4);
