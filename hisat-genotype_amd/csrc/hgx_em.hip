@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, 
 // ------------------------------------------------------------------------------------------------------------
 constexpr int TAIL_SLOTS = 2048;
 
-__global__ __launch_bounds__(BLOCK) void k_em_tail(const uint64_t *__restrict__ B, int C, int n_words, int a_pad,
+__global__ __launch_bounds__(BLOCK) void k_em_tail(const uint64_t *__restrict__ BT, int C, int c64, int a_pad,
                                                    const int64_t *__restrict__ count, const double *__restrict__ p,
                                                    const uint8_t *__restrict__ pres, const double *__restrict__ len,
                                                    int remove_low, double *__restrict__ out, double *__restrict__ scal) {
@@ -1150,15 +1150,20 @@ __global__ __launch_bounds__(BLOCK) void k_em_tail(const uint64_t *__restrict__ 
         gsort[rank] = mine;
     }
     __syncthreads();
-    for (int c = tid; c < C; c += BLOCK) {
-        const uint64_t *row = B + (size_t)c * n_words;
-        unsigned long long m = 0;
-        for (int j = 0; j < A1; ++j) {
-            const int g = gsort[j];
-            m |= ((row[g >> 6] >> (g & 63)) & 1ull) << j;
-        }
-        if (m == 0) continue;
+    // class masks from the TRANSPOSED matrix: lane j of a wave loads survivor j's word of 64 classes (A1 loads per 64 classes
+    // instead of A1 per class), 64 ballots turn the 64 x A1 bit tile around and lane b ends up with the mask of class 64w + b
+    for (int w = tid >> 6; w < (C + 63) / 64; w += BLOCK / 64) {
+        const int lane = tid & 63;
         if (*(volatile int *)&n_keys > 64) break;
+        const unsigned long long x = lane < A1 ? BT[(size_t)gsort[lane] * c64 + w] : 0ull;
+        unsigned long long m = 0;
+#pragma unroll 8
+        for (int b = 0; b < 64; ++b) {
+            const unsigned long long col = __ballot((x >> b) & 1ull);
+            if (lane == b) m = col;
+        }
+        const int c = w * 64 + lane;
+        if (c >= C || m == 0) continue;
         unsigned h = (unsigned)(mix64(m) & (TAIL_SLOTS - 1));
         for (;;) {
             const unsigned long long old = atomicCAS(&keys[h], 0ull, m);
@@ -2517,7 +2522,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
                 if (h_scal[S_DONE] != 0.0) break;
                 if (use_tail && h_scal[S_NPRES] <= 64.0 && h_scal[S_NPRES] < tail_failed_at) {
                     hipLaunchKernelGGL(k_pk_unpack, dim3(nblk(A, 256)), dim3(256), 0, st, p, A, pu, pr);
-                    hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsC, C, w64c, A, c->d_count, pu, pr, d_len,
+                    hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsTC, C, c->c64, A, c->d_count, pu, pr, d_len,
                                        remove_low ? 1 : 0, b_out.as<double>(), scal);
                     const double maps_ran = h_scal[S_NROWS];
                     { int rc_ = hgx_d2h(h_scal, scal, S_N * 8, st); if (rc_) return rc_; }
@@ -2672,7 +2677,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         // it checks the survivor count itself -- so that batch result and tail result come back in ONE host round trip.
         const bool spec_tail = use_tail && remove_low && launched_iters >= 11 && tail_failed_at == 1e300;
         if (spec_tail)
-            hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsC, C, w64c, A, c->d_count, p, pr, d_len,
+            hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsTC, C, c->c64, A, c->d_count, p, pr, d_len,
                                remove_low ? 1 : 0, b_out.as<double>(), scal);
         if (spec_tail) {      // if the tail takes over, these ARE the results: fetch them in the same round trip
             if (first_host) { int rc_ = hgx_d2h(h_fc.data(), b_fc.p, (size_t)A * 4, st); if (rc_) return rc_; }
@@ -2687,7 +2692,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         if (h_scal[S_DONE] != 0.0) break;
         if (!spec_tail && use_tail && h_scal[S_NPRES] <= 64.0 && h_scal[S_NPRES] < tail_failed_at) {
             // few survivors: finish on one wavefront (k_em_tail) unless too many distinct class masks remain
-            hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsC, C, w64c, A, c->d_count, p, pr, d_len,
+            hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsTC, C, c->c64, A, c->d_count, p, pr, d_len,
                                remove_low ? 1 : 0, b_out.as<double>(), scal);
             const double rows_ran = h_scal[S_NROWS], cols_ran = h_scal[S_NCOLS];
             { int rc_ = hgx_d2h(h_scal, scal, S_N * 8, st); if (rc_) return rc_; }
