@@ -1150,26 +1150,40 @@ __global__ __launch_bounds__(BLOCK) void k_em_tail(const uint64_t *__restrict__ 
         gsort[rank] = mine;
     }
     __syncthreads();
-    // class masks from the TRANSPOSED matrix: lane j of a wave loads survivor j's word of 64 classes (A1 loads per 64 classes
-    // instead of A1 per class), 64 ballots turn the 64 x A1 bit tile around and lane b ends up with the mask of class 64w + b
-    for (int w = tid >> 6; w < (C + 63) / 64; w += BLOCK / 64) {
-        const int lane = tid & 63;
-        if (*(volatile int *)&n_keys > 64) break;
-        const unsigned long long x = lane < A1 ? BT[(size_t)gsort[lane] * c64 + w] : 0ull;
-        unsigned long long m = 0;
-#pragma unroll 8
-        for (int b = 0; b < 64; ++b) {
-            const unsigned long long col = __ballot((x >> b) & 1ull);
-            if (lane == b) m = col;
-        }
-        const int c = w * 64 + lane;
-        if (c >= C || m == 0) continue;
-        unsigned h = (unsigned)(mix64(m) & (TAIL_SLOTS - 1));
-        for (;;) {
-            const unsigned long long old = atomicCAS(&keys[h], 0ull, m);
-            if (old == 0ull) atomicAdd(&n_keys, 1);
-            if (old == 0ull || old == m) { atomicAdd(&cnts[h], (unsigned long long)count[c]); break; }
-            h = (h + 1) & (TAIL_SLOTS - 1);
+    // Class masks from the TRANSPOSED matrix: lane j of a wave loads survivor j's word of 64 classes (A1 loads per 64 classes
+    // instead of A1 per class); the words are then broadcast one survivor at a time (v_readlane) and lane b picks bit b of
+    // each: mask of class 64w + b, A1 x 5 instructions per 64 classes.  One workgroup has only 16 waves to hide memory
+    // latency with, so every wave first issues the loads of TAIL_U class words (matrix words and counts) and then works
+    // through them.  (Measured at C = 16 k, 2 survivors: per-class bit gathers from the row-major matrix 64 us of a 77 us
+    // launch; 64 ballots per class word 28 us; merging equal masks inside the wave before the LDS table 24 us more.)
+    {
+        constexpr int TAIL_U = 8;
+        const int lane = tid & 63, n_cw = (C + 63) / 64;
+        const size_t my_row = lane < A1 ? (size_t)gsort[lane] * c64 : 0;
+        bool full = false;
+        for (int w0 = tid >> 6; w0 < n_cw && !full; w0 += (BLOCK / 64) * TAIL_U) {
+            unsigned long long xs[TAIL_U], cs[TAIL_U];
+#pragma unroll
+            for (int k = 0; k < TAIL_U; ++k) {
+                const int w = w0 + k * (BLOCK / 64), c = w * 64 + lane;
+                xs[k] = (lane < A1 && w < n_cw) ? BT[my_row + w] : 0ull;
+                cs[k] = (w < n_cw && c < C) ? (unsigned long long)count[c] : 0ull;
+            }
+#pragma unroll
+            for (int k = 0; k < TAIL_U; ++k) {
+                if (w0 + k * (BLOCK / 64) >= n_cw) break;
+                if (*(volatile int *)&n_keys > 64) { full = true; break; }
+                unsigned long long m = 0;
+                for (int j = 0; j < A1; ++j) m |= ((lane_u64(xs[k], j) >> lane) & 1ull) << j;
+                if (m == 0) continue;
+                unsigned h = (unsigned)(mix64(m) & (TAIL_SLOTS - 1));
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&keys[h], 0ull, m);
+                    if (old == 0ull) atomicAdd(&n_keys, 1);
+                    if (old == 0ull || old == m) { atomicAdd(&cnts[h], cs[k]); break; }
+                    h = (h + 1) & (TAIL_SLOTS - 1);
+                }
+            }
         }
     }
     __syncthreads();
