@@ -108,15 +108,50 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v, int m) {
     hi = __shfl_xor(hi, m, 64);
     return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor_u64(v, m);
+// Wave-wide butterfly reductions (every lane ends up with the result; fixed association: lane ^ 32, ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 --
+// bit-identical to the __shfl_xor form they replace, checked by tools/wave_reduce_test.hip).  __shfl_xor is a ds_bpermute per
+// 32 bits (an LDS-crossbar round trip, ~100+ cycles each, twelve in a row for one FP64 sum); the same data movement with
+// register-file operations: v_permlane32_swap / v_permlane16_swap (gfx950) for the two cross-row steps, DPP row_ror:8 and
+// row_ror:4 (== lane ^ 4 once lanes i and i ^ 8 agree, which they do after the ^ 8 step of a commutative reduction) and quad_perm
+// for the rest.  The single-wavefront EM kernels spend most of their time in these (nine reductions per iteration).
+template <int CTRL> __device__ __forceinline__ uint64_t dpp_u64(uint64_t b) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, false);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ uint64_t other_half_u64(uint64_t b) {       // value of lane ^ 32
+    auto lo = __builtin_amdgcn_permlane32_swap((int)b, (int)b, false, false);
+    auto hi = __builtin_amdgcn_permlane32_swap((int)(b >> 32), (int)(b >> 32), false, false);
+    const bool up = (threadIdx.x & 32) != 0;
+    return ((uint64_t)(uint32_t)(up ? hi[0] : hi[1]) << 32) | (uint32_t)(up ? lo[0] : lo[1]);
+}
+__device__ __forceinline__ uint64_t other_row_u64(uint64_t b) {        // value of lane ^ 16
+    auto lo = __builtin_amdgcn_permlane16_swap((int)b, (int)b, false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((int)(b >> 32), (int)(b >> 32), false, false);
+    const bool up = (threadIdx.x & 16) != 0;
+    return ((uint64_t)(uint32_t)(up ? hi[0] : hi[1]) << 32) | (uint32_t)(up ? lo[0] : lo[1]);
+}
+// op must be commutative bit for bit (a + b, max of non-negative values): see the row_ror:4 remark above
+template <class T, class Op> __device__ __forceinline__ T wave_butterfly(T v, Op op) {
+    static_assert(sizeof(T) == 8, "64-bit values");
+    auto bits = [](T x) { uint64_t b; __builtin_memcpy(&b, &x, 8); return b; };
+    auto val = [](uint64_t b) { T x; __builtin_memcpy(&x, &b, 8); return x; };
+    v = op(v, val(other_half_u64(bits(v))));
+    v = op(v, val(other_row_u64(bits(v))));
+    v = op(v, val(dpp_u64<0x128>(bits(v))));       // row_ror:8
+    v = op(v, val(dpp_u64<0x124>(bits(v))));       // row_ror:4
+    v = op(v, val(dpp_u64<0x4E>(bits(v))));        // quad_perm [2,3,0,1]
+    v = op(v, val(dpp_u64<0xB1>(bits(v))));        // quad_perm [1,0,3,2]
     return v;
 }
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t v) {
+    return wave_butterfly(v, [](uint64_t a, uint64_t b) { return a + b; });
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    return v;
+    return wave_butterfly(v, [](double a, double b) { return a + b; });
+}
+__device__ __forceinline__ double wave_max_nonneg_f64(double v) {       // operands >= 0, no NaN: fmax is then commutative bit for bit
+    return wave_butterfly(v, [](double a, double b) { return fmax(a, b); });
 }
 __device__ __forceinline__ uint64_t finish_hash(uint64_t h, bool nonzero) {
     if (!nonzero) return HGX_EMPTY_KEY;

@@ -56,8 +56,7 @@ __device__ __forceinline__ double block_sum(double v, double *sh) {
 }
 __device__ __forceinline__ double block_max(double v, double *sh) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
+    v = wave_max_nonneg_f64(v);
     __syncthreads();
     if (lane == 0) sh[wv] = v;
     __syncthreads();
@@ -628,8 +627,7 @@ __global__ __launch_bounds__(MF_BLOCK) void k_mfma_matvec(const uint64_t *__rest
     }
     {
         // block max and sum (fixed order)
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) mx = fmax(mx, __shfl_xor(mx, m, 64));
+        mx = wave_max_nonneg_f64(mx);
         sm = wave_sum_f64(sm);
         __syncthreads();
         if (lane == 0) { sh[0][wv] = mx; sh[1][wv] = sm; }
@@ -949,19 +947,15 @@ __global__ __launch_bounds__(BLOCK) void k_em_small(const uint64_t *__restrict__
 __device__ __forceinline__ uint64_t lane_u64(uint64_t v, int l) {
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l);
 }
-// acc += sx on the lanes selected by `mask`; sx is a wave-uniform double passed in scalar registers
+// acc += sx on the lanes selected by `mask` (both wave-uniform, in scalar registers): the mask register pair is the lane
+// selector of a v_cndmask (sx or +0.0), followed by an unconditional add -- adding +0.0 leaves the non-negative partial sums
+// bit-identical.  An EXEC-masked add (s_and_saveexec / v_add_f64 / restore, as k_bitmatvec does with streamed matrix words)
+// serialises on the EXEC write hazards when it is the whole loop body: 125 cycles per step on the single wave of the small-EM
+// kernels, against ~12 for this form, where the next steps' v_readlanes overlap the dependent adds.
 __device__ __forceinline__ void masked_add_s(double &acc, uint64_t sx_bits, uint64_t mask) {
-    uint64_t saved;
-    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tv_add_f64 %[a], %[a], %[x]\n\ts_mov_b64 exec, %[sv]"
-                 : [a] "+v"(acc), [sv] "=&s"(saved)
-                 : [x] "s"(sx_bits), [m] "s"(mask)
-                 : "scc");
+    acc += __builtin_amdgcn_inverse_ballot_w64(mask) ? __longlong_as_double((long long)sx_bits) : 0.0;
 }
-__device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = fmax(v, __shfl_xor(v, m, 64));
-    return v;
-}
+__device__ __forceinline__ double wave_max_f64(double v) { return wave_max_nonneg_f64(v); }      // abundances: >= 0
 
 struct WaveEM {
     uint64_t R, K;        // as class `lane`: members over alleles; as allele `lane`: classes containing it
