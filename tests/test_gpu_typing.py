@@ -275,3 +275,40 @@ def test_concurrent_samples_give_identical_results():
         for th in ths:
             th.join()
         assert outs[0][0] == seq[0] and outs[1][0] == seq[1]
+
+
+@pytest.mark.parametrize("name", ["hla_small_pair", "hla_mid_real", "hla_errors_filters", "hla_7000"])
+def test_grouped_exon_path_equals_per_pair_path(name, monkeypatch):
+    """type_locus through hgx_level_classes (pairs grouped by exon-level ref list, the default) and through the per-pair rows +
+    dedup (HGX_NO_SIG=1) give the same classes, counts, EM results and report."""
+    fx = gu.load(name)
+    o = fx["options"]
+    pl = hl.PackedLocus.from_synth(fx["_locus"])
+
+    def run():
+        return hgx.type_locus(pl, fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
+                              allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
+                              simulation=o["simulation"], keep_classes=True)
+    a = run()
+    monkeypatch.setenv("HGX_NO_SIG", "1")
+    b = run()
+    assert a.em == b.em and a.gene_prob == b.gene_prob
+    for x, y in zip(a.exon_classes, b.exon_classes):
+        assert np.array_equal(x, y)
+    for x, y in zip(a.gene_classes, b.gene_classes):
+        assert np.array_equal(x, y)
+    assert hgx.report_lines(a, o["simulation"], o["sample"] if o["simulation"] else (), True) == \
+        hgx.report_lines(b, o["simulation"], o["sample"] if o["simulation"] else (), True)
+
+
+def test_grouped_exon_path_equals_per_pair_path_at_size(monkeypatch):
+    """The same at 200 k pairs (overlapped streams, > 65 536 groups): identical EM results, bit for bit."""
+    loc = synth.make_hla_like_locus(n_alleles=7000, n_vars=2500, seed=101)
+    sample = synth.pick_sample(loc, 103)
+    sam = synth.simulate_sam_fast(loc, sample, 200000, err_rate=0.002, seed=7)
+    pl = hl.PackedLocus.from_synth(loc)
+    a = hgx.type_locus(pl, sam)
+    monkeypatch.setenv("HGX_NO_SIG", "1")
+    b = hgx.type_locus(pl, sam)
+    assert a.em == b.em and a.gene_prob == b.gene_prob
+    assert np.array_equal(a.counts, b.counts) and np.array_equal(a.counts_order, b.counts_order)
