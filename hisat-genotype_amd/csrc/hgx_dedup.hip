@@ -369,8 +369,18 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     return HGX_OK;
 }
 
-extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const uint64_t *row_hash, const int64_t *row_weight,
-                                 int64_t n_rows, int32_t a_pad, const uint64_t *and_mask, void *stream) {
+// On failure nothing is handed out: queued work is waited for, the half-built object goes back to the pool, *out = NULL.
+template <class T, class Destroy> static int fail_clean(int rc, T **out, hipStream_t st, Destroy destroy) {
+    if (rc != HGX_OK && out && *out) {
+        (void)hipStreamSynchronize(st);
+        destroy(*out);
+        *out = nullptr;
+    }
+    return rc;
+}
+
+static int dedup_classes_impl(hgx_classes **out, const uint64_t *rows, const uint64_t *row_hash, const int64_t *row_weight,
+                              int64_t n_rows, int32_t a_pad, const uint64_t *and_mask, void *stream) {
     ARGCHK(out && n_rows >= 0 && a_pad > 0 && a_pad % 512 == 0);
     ARGCHK(n_rows < (1ll << 31));
     hipStream_t st = (hipStream_t)stream;
@@ -564,8 +574,8 @@ extern "C" int hgx_groups_dims(hgx_groups *g, int64_t *n_groups, int32_t *n_pair
     return HGX_OK;
 }
 
-extern "C" int hgx_group_pairs(hgx_groups **out, const int32_t *pair_off, const uint32_t *refs, int32_t n_pairs, int32_t level,
-                               void *stream) {
+static int group_pairs_impl(hgx_groups **out, const int32_t *pair_off, const uint32_t *refs, int32_t n_pairs, int32_t level,
+                            void *stream) {
     ARGCHK(out && n_pairs >= 0 && (level == 0 || level == 1));
     hipStream_t st = (hipStream_t)stream;
     hgx_groups *g = new hgx_groups();
@@ -611,12 +621,18 @@ extern "C" int hgx_group_pairs(hgx_groups **out, const int32_t *pair_off, const 
     return HGX_OK;
 }
 
+extern "C" int hgx_group_pairs(hgx_groups **out, const int32_t *pair_off, const uint32_t *refs, int32_t n_pairs, int32_t level,
+                               void *stream) {
+    if (out) *out = nullptr;
+    return fail_clean(group_pairs_impl(out, pair_off, refs, n_pairs, level, stream), out, (hipStream_t)stream, hgx_groups_destroy);
+}
+
 // stage 2: one row per group, then the row dedup weighted by the group sizes (st must be ordered behind hgx_piece_compat)
-extern "C" int hgx_level_classes_grouped(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
-                                         const uint32_t *refs, hgx_groups *g, uint64_t *rows_scratch, uint64_t *hash_scratch,
-                                         void *stream) {
+static int level_classes_grouped_impl(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
+                                      const uint32_t *refs, hgx_groups *g, uint64_t *rows_scratch, uint64_t *hash_scratch,
+                                      void *stream) {
     ARGCHK(out && ix && g);
-    { int rc_ = groups_finish(g); if (rc_) { *out = nullptr; return rc_; } }
+    { int rc_ = groups_finish(g); if (rc_) return rc_; }
     hipStream_t st = (hipStream_t)stream;
     hgx_classes *cl = new_classes(ix->a_pad);
     *out = cl;
@@ -650,14 +666,22 @@ extern "C" int hgx_level_classes_grouped(hgx_classes **out, const hgx_index *ix,
     return HGX_OK;
 }
 
+extern "C" int hgx_level_classes_grouped(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
+                                         const uint32_t *refs, hgx_groups *g, uint64_t *rows_scratch, uint64_t *hash_scratch,
+                                         void *stream) {
+    if (out) *out = nullptr;
+    return fail_clean(level_classes_grouped_impl(out, ix, compat, pair_off, refs, g, rows_scratch, hash_scratch, stream), out,
+                      (hipStream_t)stream, hgx_classes_destroy);
+}
+
 extern "C" int hgx_level_classes(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
                                  const uint32_t *refs, int32_t n_pairs, int32_t level, uint64_t *rows_scratch,
                                  uint64_t *hash_scratch, void *stream) {
     ARGCHK(out && ix && n_pairs >= 0 && (level == 0 || level == 1));
+    *out = nullptr;
     hgx_groups *g = nullptr;
     int rc = hgx_group_pairs(&g, pair_off, refs, n_pairs, level, stream);
     if (rc == HGX_OK) rc = hgx_level_classes_grouped(out, ix, compat, pair_off, refs, g, rows_scratch, hash_scratch, stream);
-    else *out = nullptr;
     if (rc == HGX_OK && *out) {
         // the group tables travel with the class set (its queued kernels read them)
         (*out)->d_keep[10] = g->d_first; (*out)->d_keep[11] = g->d_count;
@@ -665,6 +689,14 @@ extern "C" int hgx_level_classes(hgx_classes **out, const hgx_index *ix, const u
     }
     hgx_groups_destroy(g);
     return rc;
+}
+
+extern "C" int hgx_classes_destroy(hgx_classes *c);
+extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const uint64_t *row_hash, const int64_t *row_weight,
+                                 int64_t n_rows, int32_t a_pad, const uint64_t *and_mask, void *stream) {
+    if (out) *out = nullptr;
+    return fail_clean(dedup_classes_impl(out, rows, row_hash, row_weight, n_rows, a_pad, and_mask, stream), out, (hipStream_t)stream,
+                      hgx_classes_destroy);
 }
 
 extern "C" int hgx_classes_destroy(hgx_classes *c) {
