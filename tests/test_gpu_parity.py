@@ -626,3 +626,32 @@ def test_level_classes_many_ref_lists_and_repeats():
     assert len(lists) > 65536
     n_cls = _level_equals_per_pair(pl, batch)
     assert n_cls[1] < len(lists)              # different lists, same class: merged by the row dedup
+
+
+def test_allele_counts_direct_equals_matvec_form(orc, monkeypatch):
+    """Gene_counts straight from the row-major class matrix (integer column sums + first classes) against the two-pass bit
+    mat-vec over the transposed matrix, on real class sets and on random ones; counts >= 2^24 take the mat-vec form."""
+    fx, loc, t, pl, batch, _ = _setup(orc, "hla_7000")
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    sets = [engine.Classes.dedup(bufs.gene_bits, batch.n_pairs, pl.a_pad, hashes=bufs.gene_hash)]
+    rng = np.random.RandomState(11)
+    for n_cls, density, hi in ((1, 0.5, 100), (37, 0.02, 5), (3000, 0.3, 1 << 20), (700, 0.1, 1 << 30)):
+        bits = np.zeros((n_cls, pl.w64), np.uint64)
+        for w in range(pl.w64):
+            m = rng.rand(n_cls, 64) < density
+            bits[:, w] = (m * (np.uint64(1) << np.arange(64, dtype=np.uint64))).sum(axis=1).astype(np.uint64)
+        cnt = rng.randint(1, hi, n_cls).astype(np.int64)
+        sets.append(engine.Classes.from_host(bits, cnt, pl.a_pad))
+    for cl in sets:
+        got_c, got_f = cl.allele_counts()
+        monkeypatch.setenv("HGX_COUNTS_MATVEC", "1")
+        exp_c, exp_f = cl.allele_counts()
+        monkeypatch.delenv("HGX_COUNTS_MATVEC")
+        assert np.array_equal(got_c, exp_c) and np.array_equal(got_f, exp_f)
+        b, c, _ = cl.to_host()
+        a = int(np.flatnonzero(got_c)[0]) if got_c.any() else 0
+        col = (b[:, a >> 6] >> np.uint64(a & 63)) & np.uint64(1)
+        assert got_c[a] == int(c[col == 1].sum()) and got_f[a] == (int(np.flatnonzero(col)[0]) if col.any() else -1)
+        cl.close()
