@@ -153,6 +153,23 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 __device__ __forceinline__ double wave_max_nonneg_f64(double v) {       // operands >= 0, no NaN: fmax is then commutative bit for bit
     return wave_butterfly(v, [](double a, double b) { return fmax(a, b); });
 }
+// 64 x 64 bit transpose across a wavefront: lane r holds row r; afterwards lane c holds column c (bit r = old bit c of lane r).
+// Six block-swap stages (Hacker's Delight 7-3), the partner lane's word fetched through the register file: v_permlane32_swap,
+// v_permlane16_swap, DPP row_ror:8, row_half_mirror + reversed quads (= lane ^ 4), quad_perm -- ~90 instructions instead of the
+// 64 ballots + selects (~500) the set-up transposes of the EM used.
+__device__ __forceinline__ uint64_t wave_transpose64(uint64_t x) {
+    const int l = threadIdx.x & 63;
+    auto stage = [&](uint64_t t, int j, uint64_t m) {
+        return (l & j) ? ((x & ~m) | ((t >> j) & m)) : ((x & m) | ((t & m) << j));
+    };
+    x = stage(other_half_u64(x), 32, 0x00000000FFFFFFFFull);
+    x = stage(other_row_u64(x), 16, 0x0000FFFF0000FFFFull);
+    x = stage(dpp_u64<0x128>(x), 8, 0x00FF00FF00FF00FFull);                  // row_ror:8 == lane ^ 8
+    x = stage(dpp_u64<0x1B>(dpp_u64<0x141>(x)), 4, 0x0F0F0F0F0F0F0F0Full);   // half-row mirror, then reversed quads == lane ^ 4
+    x = stage(dpp_u64<0x4E>(x), 2, 0x3333333333333333ull);                   // quad_perm [2,3,0,1]
+    x = stage(dpp_u64<0xB1>(x), 1, 0x5555555555555555ull);                   // quad_perm [1,0,3,2]
+    return x;
+}
 __device__ __forceinline__ uint64_t finish_hash(uint64_t h, bool nonzero) {
     if (!nonzero) return HGX_EMPTY_KEY;
     return h == HGX_EMPTY_KEY ? HGX_EMPTY_KEY - 1 : h;

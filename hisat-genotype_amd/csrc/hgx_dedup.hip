@@ -758,7 +758,7 @@ extern "C" int hgx_classes_from_host(hgx_classes **out, const uint64_t *bits, co
 
 // ------------------------------------------------------------------------------------------------
 // bit-matrix transpose [C][w64] -> [a_pad][c64]: one wavefront per 64x64 tile; lane r loads row r's
-// word, then 64 ballots peel the columns.
+// word, wave_transpose64 turns the tile around.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_transpose(const uint64_t *__restrict__ bits, int n_classes, int w64, int c64,
                                                    uint64_t *__restrict__ bitsT) {
@@ -769,13 +769,7 @@ __global__ __launch_bounds__(256) void k_transpose(const uint64_t *__restrict__ 
     const int cw = (int)(tile / w64), aw = (int)(tile % w64);
     const int c = cw * 64 + lane;
     const uint64_t x = (c < n_classes) ? bits[(size_t)c * w64 + aw] : 0ull;
-    uint64_t mine = 0;
-#pragma unroll 8
-    for (int b = 0; b < 64; ++b) {
-        const uint64_t col = __ballot((x >> b) & 1ull);
-        if (lane == b) mine = col;
-    }
-    bitsT[(size_t)(aw * 64 + lane) * c64 + cw] = mine;
+    bitsT[(size_t)(aw * 64 + lane) * c64 + cw] = wave_transpose64(x);
 }
 
 int hgx_ensure_transposed(hgx_classes *c, hipStream_t st) {

@@ -2170,12 +2170,7 @@ __global__ __launch_bounds__(256) void k_transpose_compact(const uint64_t *__res
     if (m == 0ull) return;
     const int c = cw * 64 + lane;
     const uint64_t x = (c < n_classes) ? bits[(size_t)c * w64 + aw] : 0ull;
-    uint64_t mine = 0;
-    for (uint64_t mm = m; mm; mm &= mm - 1) {
-        const int b = __builtin_ctzll(mm);
-        const uint64_t col = __ballot((x >> b) & 1ull);
-        if (lane == b) mine = col;
-    }
+    const uint64_t mine = wave_transpose64(x);
     if ((m >> lane) & 1ull) {
         const int j = base[aw] + __popcll(m & ((1ull << lane) - 1ull));
         bitsTC[(size_t)j * c64 + cw] = mine;
@@ -2194,12 +2189,7 @@ __global__ __launch_bounds__(256) void k_transpose_dual(const uint64_t *__restri
     if (tile >= n_tiles) return;
     const int aw = (int)(tile / c64), cw = (int)(tile % c64);          // 64 alleles x 64 classes
     const uint64_t x = bitsTC[(size_t)(aw * 64 + lane) * c64 + cw];
-    uint64_t mine = 0;
-#pragma unroll 8
-    for (int b = 0; b < 64; ++b) {
-        const uint64_t col = __ballot((x >> b) & 1ull);
-        if (lane == b) mine = col;
-    }
+    const uint64_t mine = wave_transpose64(x);
     const size_t cls = (size_t)cw * 64 + lane;
     bitsC[cls * w64c + aw] = mine;
     wrow[(size_t)aw * ((size_t)c64 * 64) + cls] = mine;
