@@ -1208,10 +1208,7 @@ __global__ __launch_bounds__(BLOCK) void k_em_tail(const uint64_t *__restrict__ 
         const uint64_t kj = lane_u64(myk, j), cj = lane_u64(myc, j);
         if (lane == rj) { E.R = kj; E.n = (double)(long long)cj; }
     }
-    for (int j = 0; j < A1; ++j) {
-        const uint64_t col = __ballot((E.R >> j) & 1ull);
-        if (lane == j) E.K = col;
-    }
+    E.K = wave_transpose64(E.R);              // allele j's classes = column j of the class masks (zero beyond A1 / C1)
     const int g = lane < A1 ? gsort[lane] : 0;
     const bool use_len = len != nullptr;
     E.len = (use_len && lane < A1) ? len[g] : 1.0;
@@ -1350,10 +1347,7 @@ __global__ __launch_bounds__(BLOCK) void k_em_masked(const uint64_t *__restrict_
         const uint64_t kj = lane_u64(myk, j), cj = lane_u64(myc, j);
         if (lane == rj) { E.R = kj; E.n = (double)(long long)cj; }
     }
-    for (int j = 0; j < A1; ++j) {
-        const uint64_t col = __ballot((E.R >> j) & 1ull);
-        if (lane == j) E.K = col;
-    }
+    E.K = wave_transpose64(E.R);              // allele j's classes = column j of the class masks (zero beyond A1 / C1)
     const bool use_len = lenc != nullptr;
     E.len = (use_len && lane < A1) ? lenc[lane] : 1.0;
     if (lane < A1) { out[lane] = -1.0; first_out[lane] = E.K ? __builtin_ctzll(E.K) : -1; }
