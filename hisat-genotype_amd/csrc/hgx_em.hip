@@ -2135,19 +2135,34 @@ inline hipEvent_t pool_event() {
 // bit-matrix transpose kernel of hgx_dedup.hip: [n_rows][w_in] -> [w_in * 64][w_out]
 __global__ void k_transpose(const uint64_t *bits, int n_classes, int w64, int c64, uint64_t *bitsT);
 
-// OR of all class rows: which alleles occur at all (LDS merge, then one global atomic per word and workgroup)
-__global__ __launch_bounds__(256) void k_col_or(const uint64_t *__restrict__ B, long n_words_total, int w64,
+// OR of all class rows: which alleles occur at all.  A workgroup takes a band of rows, thread w ORs word w of every row of the
+// band in a register (consecutive threads read consecutive words; eight rows in flight) and issues one global atomic at the end.
+// (An LDS atomicOr per matrix word -- 1.8 M of them on w64 addresses -- took 20 us.)
+__global__ __launch_bounds__(256) void k_col_or(const uint64_t *__restrict__ B, int n_rows, int w64,
                                                 unsigned long long *__restrict__ mask) {
-    extern __shared__ unsigned long long lm[];
-    for (int w = threadIdx.x; w < w64; w += 256) lm[w] = 0ull;
-    __syncthreads();
-    const long stride = (long)gridDim.x * 256;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n_words_total; i += stride) {
-        const uint64_t x = B[i];
-        if (x) atomicOr(&lm[(int)(i % w64)], (unsigned long long)x);
+    const int per = (n_rows + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * per, r1 = min(n_rows, r0 + per);
+    for (int w = threadIdx.x; w < w64; w += blockDim.x) {
+        uint64_t acc = 0ull;
+        int r = r0;
+        for (; r + 8 <= r1; r += 8) {
+            uint64_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = B[(size_t)(r + k) * w64 + w];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc |= v[k];
+        }
+        for (; r < r1; ++r) acc |= B[(size_t)r * w64 + w];
+        if (acc) atomicOr(&mask[w], (unsigned long long)acc);
     }
-    __syncthreads();
-    for (int w = threadIdx.x; w < w64; w += 256) if (lm[w]) atomicOr(&mask[w], lm[w]);
+}
+// rows [n, a1p) of bitsTC[a1p][c64] and the same entries of its word-transposed copy wcol[c64][a1p]
+__global__ void k_zero_padding(uint64_t *__restrict__ bitsTC, uint64_t *__restrict__ wcol, int n, int a1p, int c64) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)(a1p - n) * c64) return;
+    const int j = n + (int)(i / c64), cw = (int)(i % c64);
+    bitsTC[(size_t)j * c64 + cw] = 0ull;
+    wcol[(size_t)cw * a1p + j] = 0ull;
 }
 // bit transpose [C][w64] -> [a1p][c64] that keeps only the active alleles: row of allele (w, b) = base[w] + rank of b
 // among the active bits of word w.  One wavefront per 64 x 64 tile (cf. k_transpose).
@@ -2199,7 +2214,8 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
     c->d_setup0 = b_mask.p; c->d_setup1 = b_base.p;
     struct Release { DevBuf &a, &b; ~Release() { a.p = nullptr; b.p = nullptr; } } release{b_mask, b_base};   // owned by *c from here on
     HIPCHK(hipMemsetAsync(b_mask.p, 0, (size_t)w64 * 8, st));
-    hipLaunchKernelGGL(k_col_or, dim3(256), dim3(256), (size_t)w64 * 8, st, c->d_bits, (long)C * w64, w64, b_mask.as<unsigned long long>());
+    hipLaunchKernelGGL(k_col_or, dim3(std::min(512, std::max(1, C / 16))), dim3(w64 <= 128 ? 128 : 256), 0, st, c->d_bits, C, w64,
+                       b_mask.as<unsigned long long>());
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> h_mask(w64);
     { int rc_ = hgx_d2h(h_mask.data(), b_mask.p, (size_t)w64 * 8, st); if (rc_) return rc_; }
@@ -2220,9 +2236,10 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
     if (!c->d_act || !c->d_bitsTC || !c->d_bitsC || !c->d_wrow || !c->d_wcol) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
     { int rc_ = hgx_h2d(b_base.p, h_base.data(), (size_t)w64 * 4, st); if (rc_) return rc_; }
     { int rc_ = hgx_h2d(c->d_act, c->h_act, (size_t)std::max(n, 1) * 4, st); if (rc_) return rc_; }
-    // padding rows [n, a1p) stay zero (in the word-transposed copy they are scattered columns: clear it whole)
-    HIPCHK(hipMemsetAsync(c->d_bitsTC + (size_t)n * c->c64, 0, (size_t)(a1p - n) * c->c64 * 8, st));
-    if (a1p > n) HIPCHK(hipMemsetAsync(c->d_wcol, 0, (size_t)c->c64 * a1p * 8, st));
+    // padding rows [n, a1p) stay zero (in the word-transposed copy they are columns [n, a1p) of every row): one small launch
+    if (a1p > n)
+        hipLaunchKernelGGL(k_zero_padding, dim3(nblk((long)(a1p - n) * c->c64, 256)), dim3(256), 0, st, c->d_bitsTC, c->d_wcol, n, a1p,
+                           c->c64);
     const long tiles_in = (long)c->c64 * w64;
     hipLaunchKernelGGL(k_transpose_compact, dim3(nblk(tiles_in, 4)), dim3(256), 0, st, c->d_bits, C, w64, c->c64,
                        b_mask.as<unsigned long long>(), b_base.as<int32_t>(), c->d_bitsTC, c->d_wcol, a1p);
