@@ -2156,6 +2156,25 @@ __global__ __launch_bounds__(256) void k_col_or(const uint64_t *__restrict__ B, 
         if (acc) atomicOr(&mask[w], (unsigned long long)acc);
     }
 }
+// base[w] = number of active alleles in the words before w; act[] = the active alleles in ascending order (w64 <= 512)
+__global__ __launch_bounds__(512) void k_act_from_mask(const unsigned long long *__restrict__ mask, int w64, int32_t *__restrict__ base,
+                                                       int32_t *__restrict__ act) {
+    __shared__ int pc[512];
+    const int w = threadIdx.x;
+    const unsigned long long m = w < w64 ? mask[w] : 0ull;
+    pc[w] = __popcll(m);
+    __syncthreads();
+    for (int d = 1; d < 512; d <<= 1) {                  // inclusive scan
+        const int v = w >= d ? pc[w - d] : 0;
+        __syncthreads();
+        pc[w] += v;
+        __syncthreads();
+    }
+    if (w >= w64) return;
+    int j = pc[w] - __popcll(m);
+    base[w] = j;
+    for (unsigned long long mm = m; mm; mm &= mm - 1) act[j++] = 64 * w + __builtin_ctzll(mm);
+}
 // rows [n, a1p) of bitsTC[a1p][c64] and the same entries of its word-transposed copy wcol[c64][a1p]
 __global__ void k_zero_padding(uint64_t *__restrict__ bitsTC, uint64_t *__restrict__ wcol, int n, int a1p, int c64) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2216,6 +2235,14 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
     HIPCHK(hipMemsetAsync(b_mask.p, 0, (size_t)w64 * 8, st));
     hipLaunchKernelGGL(k_col_or, dim3(std::min(512, std::max(1, C / 16))), dim3(w64 <= 128 ? 128 : 256), 0, st, c->d_bits, C, w64,
                        b_mask.as<unsigned long long>());
+    // the device-side tables that follow from the mask (rank base per word, list of active alleles) are built on the device,
+    // queued behind the OR: the host derives its own copy from the mask it fetches below, and no upload sits between the
+    // round trip and the transposes (an 18 KB host-to-device copy took 29 us of device time plus the gaps around it)
+    c->d_act = (int32_t *)hgx_pool_alloc((size_t)A * 4);
+    if (!c->d_act) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    const bool dev_tables = w64 <= 512;               // (wider allele sets -- beyond the scoring path's limit -- upload the host's copy)
+    if (dev_tables)
+        hipLaunchKernelGGL(k_act_from_mask, dim3(1), dim3(512), 0, st, b_mask.as<unsigned long long>(), w64, b_base.as<int32_t>(), c->d_act);
     HIPCHK(hipGetLastError());
     std::vector<uint64_t> h_mask(w64);
     { int rc_ = hgx_d2h(h_mask.data(), b_mask.p, (size_t)w64 * 8, st); if (rc_) return rc_; }
@@ -2227,15 +2254,16 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
         h_base[w] = n;
         for (uint64_t m = h_mask[w]; m; m &= m - 1) c->h_act[n++] = 64 * w + __builtin_ctzll(m);
     }
+    if (!dev_tables) {
+        { int rc_ = hgx_h2d(b_base.p, h_base.data(), (size_t)w64 * 4, st); if (rc_) return rc_; }
+        { int rc_ = hgx_h2d(c->d_act, c->h_act, (size_t)std::max(n, 1) * 4, st); if (rc_) return rc_; }
+    }
     const int a1p = std::max(512, (n + 511) / 512 * 512);
-    c->d_act = (int32_t *)hgx_pool_alloc((size_t)A * 4);
     c->d_bitsTC = (uint64_t *)hgx_pool_alloc((size_t)a1p * c->c64 * 8);
     c->d_bitsC = (uint64_t *)hgx_pool_alloc((size_t)c->c64 * 64 * (a1p / 64) * 8);
     c->d_wrow = (uint64_t *)hgx_pool_alloc((size_t)(a1p / 64) * c->c64 * 64 * 8);
     c->d_wcol = (uint64_t *)hgx_pool_alloc((size_t)c->c64 * a1p * 8);
     if (!c->d_act || !c->d_bitsTC || !c->d_bitsC || !c->d_wrow || !c->d_wcol) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
-    { int rc_ = hgx_h2d(b_base.p, h_base.data(), (size_t)w64 * 4, st); if (rc_) return rc_; }
-    { int rc_ = hgx_h2d(c->d_act, c->h_act, (size_t)std::max(n, 1) * 4, st); if (rc_) return rc_; }
     // padding rows [n, a1p) stay zero (in the word-transposed copy they are columns [n, a1p) of every row): one small launch
     if (a1p > n)
         hipLaunchKernelGGL(k_zero_padding, dim3(nblk((long)(a1p - n) * c->c64, 256)), dim3(256), 0, st, c->d_bitsTC, c->d_wcol, n, a1p,
