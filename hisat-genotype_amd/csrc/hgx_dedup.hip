@@ -230,7 +230,8 @@ __global__ void k_ht_finalize(const unsigned long long *__restrict__ keys, const
 // row per wave the kernel is a chain of three memory round trips per row and runs at a quarter of the bandwidth.
 __global__ __launch_bounds__(256) void k_verify_ht(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
                                                    const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ first, long n,
-                                                   int *__restrict__ bad) {
+                                                   int *__restrict__ bad, uint32_t *__restrict__ bad_rows = nullptr,
+                                                   uint32_t *__restrict__ n_bad = nullptr) {
     constexpr int R = 4;
     const int lane = threadIdx.x & 63;
     const long r0 = (((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * R;
@@ -257,7 +258,70 @@ __global__ __launch_bounds__(256) void k_verify_ht(const uint64_t *__restrict__ 
             diff = diff || x[k].x != y[k].x || x[k].y != y[k].y;
         }
     }
-    if (__any(diff) && lane == 0) atomicOr(bad, 1);
+    if (!__any(diff)) return;
+    // (never taken with honest keys) some row of the four shares its key with a DIFFERENT row: find out which
+    if (lane == 0) atomicOr(bad, 1);
+    if (!bad_rows) return;
+    for (int k = 0; k < R; ++k) {
+        if (sl[k] == HT_NONE || h[k] == (uint32_t)(r0 + k)) continue;
+        bool d = false;
+        for (int w = lane; w < w64; w += 64) {
+            uint64_t x = rows[(size_t)(r0 + k) * w64 + w], y = rows[(size_t)h[k] * w64 + w];
+            if (mask) { x &= mask[w]; y &= mask[w]; }
+            d = d || x != y;
+        }
+        if (__any(d) && lane == 0) bad_rows[atomicAdd(n_bad, 1u)] = (uint32_t)(r0 + k);
+    }
+}
+// ---- key collisions are resolved, not reported ------------------------------------------------------------------------------
+// A row that differs from the first row of its slot leaves the slot (its weight is taken back) and is inserted again under a
+// salted hash of its content; it is then checked against ITS new slot's first row, and so on for a few rounds.  The slot's first row is never
+// among the leavers (it equals itself), so whichever class owns the smallest row keeps the slot, and the first-seen order is
+// recomputed afterwards.  With the 64-bit row hash this path never runs outside the forged-key tests.
+__global__ __launch_bounds__(256) void k_fix_reinsert(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
+                                                      const uint32_t *__restrict__ bad_rows, uint32_t n_bad,
+                                                      const int64_t *__restrict__ weight, int round,
+                                                      unsigned long long *__restrict__ keys, uint32_t *__restrict__ first,
+                                                      unsigned long long *__restrict__ cnt, uint32_t tmask,
+                                                      uint32_t *__restrict__ slot_of) {
+    // one wavefront per row: the new key is a (salted) hash of the row's CONTENT -- rows that shared a key part ways at once
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (t >= n_bad) return;
+    const uint32_t i = bad_rows[t];
+    uint64_t h = 0;
+    for (int w = lane; w < w64; w += 64) {
+        uint64_t x = rows[(size_t)i * w64 + w];
+        if (mask) x &= mask[w];
+        h += word_hash(x, w);
+    }
+    h = wave_sum_u64(h);
+    if (lane != 0) return;
+    uint64_t key = mix64(h + 0x9e3779b97f4a7c15ull * (uint64_t)round);
+    if (key == HGX_EMPTY_KEY) key = HGX_EMPTY_KEY - 1;
+    const unsigned long long w = (unsigned long long)(weight ? weight[i] : 1);
+    atomicAdd(&cnt[slot_of[i]], 0ull - w);
+    const uint32_t g = ht_global_insert(keys, tmask, key);
+    atomicMin(&first[g], i);
+    atomicAdd(&cnt[g], w);
+    slot_of[i] = g;
+}
+__global__ __launch_bounds__(256) void k_fix_verify(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
+                                                    const uint32_t *__restrict__ bad_rows, uint32_t n_bad,
+                                                    const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ first,
+                                                    uint32_t *__restrict__ still_bad, uint32_t *__restrict__ n_still) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (t >= n_bad) return;
+    const uint32_t i = bad_rows[t], f = first[slot_of[i]];
+    if (f == i) return;
+    bool diff = false;
+    for (int w = lane; w < w64; w += 64) {
+        uint64_t x = rows[(size_t)i * w64 + w], y = rows[(size_t)f * w64 + w];
+        if (mask) { x &= mask[w]; y &= mask[w]; }
+        diff = diff || x != y;
+    }
+    if (__any(diff) && lane == 0) still_bad[atomicAdd(n_still, 1u)] = i;
 }
 __global__ __launch_bounds__(256) void k_ht_gather(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
                                                    const int64_t *__restrict__ out_first, int n_classes,
@@ -297,12 +361,53 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
                             int w64, const uint64_t *and_mask, hipStream_t st, bool small_blocks = false) {
     long T = 1024;
     while (T < 2 * n) T <<= 1;
-    DevBuf b_keys, b_first, b_cnt, b_slot, b_flag, b_rank, b_tmp, b_meta;
+    DevBuf b_keys, b_first, b_cnt, b_slot, b_flag, b_rank, b_tmp, b_meta, b_bad;
     ALLOC(b_keys, (size_t)T * 8); ALLOC(b_first, (size_t)T * 4); ALLOC(b_cnt, (size_t)T * 8);
     ALLOC(b_slot, (size_t)n * 4); ALLOC(b_flag, (size_t)n * 4); ALLOC(b_rank, (size_t)n * 4); ALLOC(b_meta, 16);
+    ALLOC(b_bad, (size_t)n * 4);
     size_t tmp_bytes = 0;
     HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
     ALLOC(b_tmp, tmp_bytes);
+    // first rows of the classes -> flags -> class ids in first-seen order, class count in meta[1]
+    auto number_classes = [&]() -> int {
+        hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,
+                           b_flag.as<uint32_t>());
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
+        hipLaunchKernelGGL(k_ht_meta, dim3(1), dim3(1), 0, st, b_rank.as<uint32_t>() + (n - 1), b_flag.as<uint32_t>() + (n - 1),
+                           b_meta.as<uint32_t>());
+        return HGX_OK;
+    };
+    uint32_t meta[4] = {0, 0, 0, 0};           // {some key collided, number of classes, number of collided rows, -}
+    // rows that share a key with a different row: re-keyed and re-checked (see k_fix_reinsert); classes renumbered; meta refreshed
+    auto resolve_collisions = [&]() -> int {
+        DevBuf b_bad2;
+        ALLOC(b_bad2, (size_t)n * 4);
+        uint32_t *cur = b_bad.as<uint32_t>(), *nxt = b_bad2.as<uint32_t>();
+        uint32_t nb = meta[2];
+        for (int round = 1; round <= 8 && nb; ++round) {
+            HIPCHK(hipMemsetAsync(b_meta.as<uint32_t>() + 2, 0, 4, st));
+            hipLaunchKernelGGL(k_fix_reinsert, dim3(nblk(nb, 4)), dim3(256), 0, st, rows, w64, and_mask, cur, nb, row_weight, round,
+                               b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1),
+                               b_slot.as<uint32_t>());
+            hipLaunchKernelGGL(k_fix_verify, dim3(nblk(nb, 4)), dim3(256), 0, st, rows, w64, and_mask, cur, nb, b_slot.as<uint32_t>(),
+                               b_first.as<uint32_t>(), nxt, b_meta.as<uint32_t>() + 2);
+            HIPCHK(hipGetLastError());
+            { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
+            { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+            nb = meta[2];
+            std::swap(cur, nxt);
+        }
+        if (nb) {
+            hgx_set_error("64-bit class hash collisions not resolved after 8 re-keying rounds (%u rows)", nb);
+            return HGX_ECOLLISION;
+        }
+        HIPCHK(hipMemsetAsync(b_flag.p, 0, (size_t)n * 4, st));
+        { int rc_ = number_classes(); if (rc_) return rc_; }
+        HIPCHK(hipGetLastError());
+        { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
+        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+        return HGX_OK;
+    };
     // one launch instead of five memsets: table = empty, flags = 0, meta = {collision flag, number of classes} = 0
     hipLaunchKernelGGL(k_ht_init, dim3(nblk(std::max(T, n), 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(),
                        b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), T, b_flag.as<uint32_t>(), n, b_meta.as<uint32_t>());
@@ -312,15 +417,10 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     else
         hipLaunchKernelGGL(k_ht_insert<1024>, dim3(nblk(n, 1024)), dim3(1024), 0, st, keys_in, row_weight, n, b_keys.as<unsigned long long>(),
                            b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1), b_slot.as<uint32_t>());
-    hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,
-                       b_flag.as<uint32_t>());
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
-    hipLaunchKernelGGL(k_ht_meta, dim3(1), dim3(1), 0, st, b_rank.as<uint32_t>() + (n - 1), b_flag.as<uint32_t>() + (n - 1),
-                       b_meta.as<uint32_t>());
+    { int rc_ = number_classes(); if (rc_) return rc_; }
     // the exact check does not need the class count: queue it before the D2H that sizes the output
     hipLaunchKernelGGL(k_verify_ht, dim3(nblk((n + 3) / 4, 4)), dim3(256), 0, st, rows, w64, and_mask, b_slot.as<uint32_t>(),
-                       b_first.as<uint32_t>(), n, b_meta.as<int>());
-    uint32_t meta[4] = {0, 0, 0, 0};
+                       b_first.as<uint32_t>(), n, b_meta.as<int>(), b_bad.as<uint32_t>(), b_meta.as<uint32_t>() + 2);
     // Small inputs (the hand-off dedup: a few thousand gene classes) size the output for the worst case and finish in
     // ONE host round trip; large ones first learn the class count (the worst case would be the whole input again).
     const bool one_trip = n <= 65536;
@@ -329,10 +429,7 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
         { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
         { int rc_ = hgx_sync(st); if (rc_) return rc_; }
         HIPCHK(hipGetLastError());
-        if (meta[0]) {
-            hgx_set_error("64-bit class hash collision detected by the exact verify pass");
-            return HGX_ECOLLISION;
-        }
+        if (meta[2]) { int rc_ = resolve_collisions(); if (rc_) return rc_; }
         n_alloc = (int)meta[1];
         if (n_alloc == 0) return HGX_OK;
     }
@@ -351,9 +448,14 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     if (one_trip) {
         { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
         { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-        if (meta[0]) {
-            hgx_set_error("64-bit class hash collision detected by the exact verify pass");
-            return HGX_ECOLLISION;
+        if (meta[2]) {      // collided rows: after re-keying, first rows / counts / class rows are produced again
+            { int rc_ = resolve_collisions(); if (rc_) return rc_; }
+            hipLaunchKernelGGL(k_ht_finalize, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(),
+                               b_cnt.as<unsigned long long>(), T, b_rank.as<uint32_t>(), cl->d_first_row, cl->d_count);
+            hipLaunchKernelGGL(k_ht_gather_slots, dim3(nblk(T, 4)), dim3(256), 0, st, rows, w64, and_mask, b_keys.as<unsigned long long>(),
+                               b_first.as<uint32_t>(), b_rank.as<uint32_t>(), T, cl->d_bits);
+            HIPCHK(hipGetLastError());
+            { int rc_ = hgx_sync(st); if (rc_) return rc_; }
         }
     } else {
         // large input: class count and collision flag are known since the first round trip; the finalize / gather kernels are

@@ -143,8 +143,9 @@ int hgx_score_pairs(const hgx_index *ix,
  * Replaces the Gene_cmpt / Gene_exons_cmpt dict accumulation (typing_core.py:1229-1234) and the
  * Gene_cmpt2 filtering (core:1752-1766): rows (optionally AND'ed with and_mask, empty rows
  * dropped) are grouped by content; groups come out in FIRST-SEEN order (Python dict order)
- * with the summed weight.  Exact: every row is compared with its group's first row (a 64-bit hash
- * collision returns HGX_ECOLLISION).  On any failure the constructors below hand out nothing: *out = NULL. */
+ * with the summed weight.  Exact: every row is compared with its group's first row; rows that share a
+ * 64-bit key with a different row are re-keyed and re-checked (HGX_ECOLLISION only if that fails 8 times,
+ * or from the radix-sort form).  On any failure the constructors below hand out nothing: *out = NULL. */
 typedef struct hgx_classes hgx_classes;   /* device-resident [n_classes][a_pad/64] + counts */
 
 int hgx_dedup_classes(hgx_classes **out,

@@ -312,8 +312,9 @@ def test_more_than_8192_alleles(orc):
 
 @pytest.mark.parametrize("n_rows", [3000, 70000])
 def test_forged_hash_collision_is_detected(orc, n_rows):
-    """The exact verify pass: two DIFFERENT rows given the same 64-bit key must be reported (HGX_ECOLLISION), never merged --
-    in the hash-table form (one-round-trip and two-round-trip sizes) and in the radix-sort form; honest keys pass."""
+    """The exact verify pass: two DIFFERENT rows given the same 64-bit key are never merged -- the hash-table form (one-round-trip
+    and two-round-trip sizes) re-keys the colliding rows and returns exactly the classes honest keys give; the radix-sort form
+    reports HGX_ECOLLISION; honest keys pass."""
     import os
     from hisatgenotype_amd import capi
     a_pad = 1024
@@ -335,9 +336,28 @@ def test_forged_hash_collision_is_detected(orc, n_rows):
             forged = rows.copy()
             forged[victim, 3] ^= np.uint64(1) << np.uint64(17)
             d_forged = engine.DevArray.from_host(forged)
-            with pytest.raises(capi.HgxError) as ei:
-                engine.Classes.dedup(d_forged, n_rows, a_pad, hashes=engine.DevArray.from_host(keys))
-            assert ei.value.code == -5                        # HGX_ECOLLISION
+            if sort:
+                with pytest.raises(capi.HgxError) as ei:
+                    engine.Classes.dedup(d_forged, n_rows, a_pad, hashes=engine.DevArray.from_host(keys))
+                assert ei.value.code == -5                    # HGX_ECOLLISION
+                continue
+            got = engine.Classes.dedup(d_forged, n_rows, a_pad, hashes=engine.DevArray.from_host(keys))
+            os.environ.pop("HGX_DEDUP_SORT", None)
+            want = engine.Classes.dedup(d_forged, n_rows, a_pad)           # keys computed from the rows
+            assert got.n_classes == want.n_classes == len(set(pick.tolist())) + 1
+            for x, y in zip(got.to_host(), want.to_host()):
+                assert np.array_equal(x, y)
+            # many collisions at once, weighted: every third row flips a bit of its own and keeps its (now shared) key
+            many = rows.copy()
+            flip = np.arange(0, n_rows, 3)
+            many[flip, 5] ^= (np.uint64(1) << (flip % 61).astype(np.uint64))
+            wts = engine.DevArray.from_host(rng.randint(1, 6, n_rows).astype(np.int64))
+            d_many = engine.DevArray.from_host(many)
+            got = engine.Classes.dedup(d_many, n_rows, a_pad, hashes=engine.DevArray.from_host(keys), weights=wts)
+            want = engine.Classes.dedup(d_many, n_rows, a_pad, weights=wts)
+            assert got.n_classes == want.n_classes
+            for x, y in zip(got.to_host(), want.to_host()):
+                assert np.array_equal(x, y)
         finally:
             os.environ.pop("HGX_DEDUP_SORT", None)
 
