@@ -593,6 +593,88 @@ __global__ __launch_bounds__(256) void k_pair_classes(const uint64_t *__restrict
 #undef HGX_LEVELS
 }
 
+// One LEVEL, TWO pairs per wavefront (the launches of the typing path).  A wavefront per pair is a chain of dependent round trips --
+// offsets -> refs -> piece rows -- and hides them only through occupancy: 0.28 ms for 500 k pairs at eight waves per SIMD is 4.6 us
+// per wavefront, whatever is taken out of it (row stores, dependent ref loads, the hash: DESIGN.md 5.2).  Here the refs of both pairs
+// sit in the lanes (one vector load each, picked per level with a ballot and broadcast with v_readlane) and every step of the walk
+// has a row of EACH pair in flight, plus the next one of each.
+template <int KW, int NP>
+__device__ __forceinline__ void two_classes(const uint64_t *__restrict__ compat, int w64, uint32_t ref_a, uint32_t ref_b,
+                                            uint64_t todo_a, uint64_t todo_b, const uint64_t *__restrict__ mask,
+                                            uint64_t *__restrict__ row_a, uint64_t *__restrict__ row_b,
+                                            uint64_t *__restrict__ hash_a, uint64_t *__restrict__ hash_b, bool has_b, int lane) {
+    uint64_t pa[NP][KW], pb[NP][KW];
+#pragma unroll
+    for (int k = 0; k < NP; ++k)
+#pragma unroll
+        for (int s = 0; s < KW; ++s) { pa[k][s] = 0; pb[k][s] = 0; }
+    auto load_row = [&](uint32_t myref, uint64_t todo, uint64_t (&x)[KW]) {
+        const uint64_t *row = compat + (size_t)((uint32_t)__builtin_amdgcn_readlane((int)myref, __builtin_ctzll(todo)) & 0x7fffffffu) * w64;
+#pragma unroll
+        for (int s = 0; s < KW; ++s) x[s] = (lane + 64 * s < w64) ? row[lane + 64 * s] : 0ull;
+    };
+    auto ripple = [&](uint64_t (&plane)[NP][KW], const uint64_t (&x)[KW]) {
+        uint64_t carry[KW];
+#pragma unroll
+        for (int s = 0; s < KW; ++s) carry[s] = x[s];
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+#pragma unroll
+            for (int s = 0; s < KW; ++s) {
+                const uint64_t t = plane[k][s] & carry[s];
+                plane[k][s] ^= carry[s];
+                carry[s] = t;
+            }
+    };
+    uint64_t ca[KW], cb[KW], na[KW], nb[KW];
+#pragma unroll
+    for (int s = 0; s < KW; ++s) { ca[s] = 0; cb[s] = 0; na[s] = 0; nb[s] = 0; }
+    if (todo_a) load_row(ref_a, todo_a, ca);
+    if (todo_b) load_row(ref_b, todo_b, cb);
+    while (todo_a | todo_b) {
+        const bool have_a = todo_a != 0, have_b = todo_b != 0;
+        todo_a &= todo_a - 1;                                  // (0 & anything = 0: an exhausted pair stays exhausted)
+        todo_b &= todo_b - 1;
+        if (todo_a) load_row(ref_a, todo_a, na);
+        if (todo_b) load_row(ref_b, todo_b, nb);
+        if (have_a) ripple(pa, ca);
+        if (have_b) ripple(pb, cb);
+#pragma unroll
+        for (int s = 0; s < KW; ++s) { ca[s] = na[s]; cb[s] = nb[s]; }
+    }
+    emit_class<KW, NP>(pa, w64, mask, row_a, hash_a, lane);
+    if (has_b) emit_class<KW, NP>(pb, w64, mask, row_b, hash_b, lane);
+}
+
+template <int KW, bool SEL>
+__global__ __launch_bounds__(256) void k_pair_classes_x2(const uint64_t *__restrict__ compat, int w64,
+                                                         const int32_t *__restrict__ pair_off, const uint32_t *__restrict__ refs,
+                                                         const int64_t *__restrict__ sel, int n_pairs, uint32_t level,
+                                                         const uint64_t *__restrict__ mask, uint64_t *__restrict__ bits,
+                                                         uint64_t *__restrict__ hash) {
+    const int lane = threadIdx.x & 63;
+    const long out_a = (((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 2, out_b = out_a + 1;
+    if (out_a >= n_pairs) return;
+    const bool has_b = out_b < n_pairs;
+    const long pair_a = SEL ? (long)sel[out_a] : out_a;
+    const long pair_b = has_b ? (SEL ? (long)sel[out_b] : out_b) : pair_a;
+    const int r0a = __builtin_amdgcn_readfirstlane(pair_off[pair_a]), r1a = __builtin_amdgcn_readfirstlane(pair_off[pair_a + 1]);
+    const int r0b = __builtin_amdgcn_readfirstlane(pair_off[pair_b]), r1b = __builtin_amdgcn_readfirstlane(pair_off[pair_b + 1]);
+    const int n_a = r1a - r0a, n_b = has_b ? r1b - r0b : 0;
+    uint64_t *row_a = bits ? bits + (size_t)out_a * w64 : nullptr, *row_b = bits ? bits + (size_t)out_b * w64 : nullptr;
+    uint64_t *hash_a = hash ? hash + out_a : nullptr, *hash_b = hash ? hash + out_b : nullptr;
+    if (max(n_a, n_b) > 15) {        // many refs (rare; up to 255 per level): 8-plane counters, one pair after the other
+        class_for_level<KW, 8>(compat, w64, refs, r0a, r1a, level, mask, row_a, hash_a, lane);
+        if (has_b) class_for_level<KW, 8>(compat, w64, refs, r0b, r1b, level, mask, row_b, hash_b, lane);
+        return;
+    }
+    const uint32_t ref_a = lane < n_a ? refs[r0a + lane] : 0u, ref_b = lane < n_b ? refs[r0b + lane] : 0u;
+    const uint64_t todo_a = __ballot(lane < n_a && (ref_a >> 31) == level), todo_b = __ballot(lane < n_b && (ref_b >> 31) == level);
+    const int n_max = max(n_a, n_b);             // counts never exceed the number of refs: narrowest counters that hold them
+    if (n_max <= 3) two_classes<KW, 2>(compat, w64, ref_a, ref_b, todo_a, todo_b, mask, row_a, row_b, hash_a, hash_b, has_b, lane);
+    else two_classes<KW, 4>(compat, w64, ref_a, ref_b, todo_a, todo_b, mask, row_a, row_b, hash_a, hash_b, has_b, lane);
+}
+
 // sel: see k_pair_classes (NULL = every pair in order)
 int hgx_pair_classes_sel(const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off, const uint32_t *refs,
                          const int64_t *sel, int32_t n_pairs, uint64_t *eb, uint64_t *gb, uint64_t *eh,
@@ -602,6 +684,29 @@ int hgx_pair_classes_sel(const hgx_index *ix, const uint64_t *compat, const int3
     ARGCHK(compat && pair_off && refs);
     const long blocks = ((long)n_pairs + 3) / 4;
     const int kw = (ix->w64 + 63) / 64;
+    const bool exon = eb || eh, gene = gb || gh;
+    if (exon != gene && kw <= 8 && !getenv("HGX_PAIR_X1")) {       // one level: two pairs per wavefront
+        const long blocks2 = ((long)n_pairs + 7) / 8;
+        const uint32_t level = gene ? 1u : 0u;
+        const uint64_t *mask = gene ? ix->d_gene_mask : ix->d_exon_mask;
+        uint64_t *bits = gene ? gb : eb, *hash = gene ? gh : eh;
+#define LAUNCH_X2(KW_)                                                                                                        \
+    do {                                                                                                                      \
+        if (sel)                                                                                                              \
+            hipLaunchKernelGGL((k_pair_classes_x2<KW_, true>), dim3((unsigned)blocks2), dim3(256), 0, st, compat, ix->w64, pair_off, \
+                               refs, sel, n_pairs, level, mask, bits, hash);                                                  \
+        else                                                                                                                  \
+            hipLaunchKernelGGL((k_pair_classes_x2<KW_, false>), dim3((unsigned)blocks2), dim3(256), 0, st, compat, ix->w64, pair_off, \
+                               refs, sel, n_pairs, level, mask, bits, hash);                                                  \
+    } while (0)
+        if (kw <= 1) LAUNCH_X2(1);
+        else if (kw <= 2) LAUNCH_X2(2);
+        else if (kw <= 4) LAUNCH_X2(4);
+        else LAUNCH_X2(8);
+#undef LAUNCH_X2
+        HIPCHK(hipGetLastError());
+        return HGX_OK;
+    }
 #define LAUNCH_PC(KW_)                                                                                                        \
     do {                                                                                                                      \
         if (sel)                                                                                                              \

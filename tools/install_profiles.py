@@ -30,7 +30,7 @@ def get(ctr, sub):
         if sub in k:
             return v
 d = json.load(open(f"{src}/bench_default.json"))
-names = {"k_pair_classes": "k_pair_classes<2, false>", "k_piece_compat": "k_piece_compat_tiled", "k_lutmatvec<0>": "k_lutmatvec<0>",
+names = {"k_pair_classes": "k_pair_classes_x2<2, false>", "k_piece_compat": "k_piece_compat_tiled", "k_lutmatvec<0>": "k_lutmatvec<0>",
          "k_lutmatvec<1>": "k_lutmatvec<1>"}
 raw, hb = {}, {}
 for k, sub in names.items():
