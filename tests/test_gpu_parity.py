@@ -571,7 +571,7 @@ def test_em_backends_agree(orc, name):
         engine.em_set_backend(0)
 
 
-def _level_equals_per_pair(pl, batch):
+def _level_equals_per_pair(pl, batch, collided=False):
     db = engine.DeviceBatch(batch)
     bufs = engine.ScoreBuffers(pl, db)
     engine.score_pairs(pl, db, bufs)
@@ -589,7 +589,7 @@ def _level_equals_per_pair(pl, batch):
             got = engine.Classes.of_level(pl, db, b2, lv, groups=groups)
             gh = got.to_host()
             if groups is not None:
-                assert 0 < groups.n_groups <= batch.n_pairs
+                assert (groups.n_groups == 0) if collided else (0 < groups.n_groups <= batch.n_pairs)
                 groups.close()
             assert got.n_classes == ref[lv].n_classes
             for x, y in zip(gh, want[lv]):
@@ -675,3 +675,11 @@ def test_allele_counts_direct_equals_matvec_form(orc, monkeypatch):
         col = (b[:, a >> 6] >> np.uint64(a & 63)) & np.uint64(1)
         assert got_c[a] == int(c[col == 1].sum()) and got_f[a] == (int(np.flatnonzero(col)[0]) if col.any() else -1)
         cl.close()
+
+
+def test_level_classes_falls_back_to_per_pair_rows_on_a_list_key_collision(orc, monkeypatch):
+    """Two different ref lists with one 64-bit list key (never seen; forced here) make hgx_level_classes take the per-pair form:
+    same classes, counts, order and first pairs."""
+    fx, loc, t, pl, batch, _ = _setup(orc, "hla_errors_filters")
+    monkeypatch.setenv("HGX_TEST_GROUP_COLLISION", "1")
+    _level_equals_per_pair(pl, batch, collided=True)
