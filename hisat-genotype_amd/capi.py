@@ -52,7 +52,7 @@ SYMBOLS = [
     "hgx_event_record", "hgx_stream_wait_event", "hgx_event_elapsed_ms", "hgx_a_pad", "hgx_index_create",
     "hgx_index_destroy", "hgx_index_dims", "hgx_index_device_bits", "hgx_piece_compat", "hgx_pair_classes",
     "hgx_score_pairs", "hgx_level_classes", "hgx_group_pairs", "hgx_groups_dims", "hgx_groups_destroy",
-    "hgx_level_classes_grouped", "hgx_dedup_classes", "hgx_classes_destroy", "hgx_classes_dims", "hgx_classes_device",
+    "hgx_level_classes_grouped", "hgx_classes_set_allele_rank", "hgx_dedup_classes", "hgx_classes_destroy", "hgx_classes_dims", "hgx_classes_device",
     "hgx_classes_to_host", "hgx_classes_from_host", "hgx_allele_counts", "hgx_allele_counts_on", "hgx_first_classes", "hgx_em", "hgx_em_ordered", "hgx_em_masked", "hgx_em_set_backend", "hgx_debug_matvec", "hgx_em_set_timing", "hgx_em_get_timing", "hgx_locus_create",
     "hgx_locus_destroy", "hgx_locus_dims", "hgx_locus_tables", "hgx_index_from_locus",
     "hgx_locus_alternatives_text", "hgx_batch_destroy", "hgx_batch_dims", "hgx_batch_arrays",

@@ -54,6 +54,7 @@ struct hgx_classes {
     uint64_t *d_bitsC = nullptr;                     // [c64 * 64][a1p / 64]  (rows >= n_classes are zero)
     uint64_t *d_bitsTC = nullptr;                    // [a1p][c64]
     int32_t *h_act = nullptr;                        // host copy of d_act (new[])
+    int32_t *h_rank = nullptr;                       // name order of the alleles, if the caller supplied it (new[]; hgx_classes_set_allele_rank)
     uint64_t *d_wrow = nullptr, *d_wcol = nullptr;   // word-transposed compact matrices [a1p/64][c64*64], [c64][a1p]
     void *d_setup0 = nullptr, *d_setup1 = nullptr;   // small tables the set-up kernels read (kept so that no sync is needed)
     hipStream_t made_on = nullptr;                   // stream the kernels that fill this class set were queued on

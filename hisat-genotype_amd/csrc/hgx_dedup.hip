@@ -812,6 +812,7 @@ extern "C" int hgx_classes_destroy(hgx_classes *c) {
     for (void *p : c->d_keep) hgx_pool_free(p);
     if (c->ready) (void)hipEventDestroy(c->ready);
     delete[] c->h_act;
+    delete[] c->h_rank;
     delete c;
     return HGX_OK;
 }

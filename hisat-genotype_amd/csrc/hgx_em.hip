@@ -1039,6 +1039,131 @@ __device__ __forceinline__ void wave_em_run(const WaveEM &E, double p, bool pr, 
     if (lane == 0) { scal[S_ITER] = (double)iter; scal[S_KEYERR] = keyerr ? 1.0 : 0.0; scal[S_DONE] = 1.0; }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// The same EM in the REFERENCE'S OWN ORDER of floating-point operations (single wavefront; lanes = alleles in class-key
+// order = name order, classes in dict order): every sum is sequential in the order typing_common.py walks its dicts, every
+// term is formed as the reference forms it (count * prob / alleles_prob), nothing is contracted -- so the result is
+// bit-identical to the reference's, and the decisions it takes on rounding noise (the pruning test p >= max / 10 on an exact
+// 10 : 1 ratio of small rational abundances) come out the same.  Used for the hand-off EM when the caller supplied the
+// alleles' name order; follows oracle/hgx_oracle.c orc_single_abundance line by line.
+// A dict is, per allele-lane: value, membership, position in the insertion order (positions may have gaps after pruning).
+// ------------------------------------------------------------------------------------------------------------
+struct RefDict { double v; bool in; int pos; int npos; };
+
+__device__ __forceinline__ double lane_f64(double v, int l) {
+    return __longlong_as_double((long long)lane_u64((uint64_t)__double_as_longlong(v), l));
+}
+// sum of f over the dict's members in insertion order
+template <class F> __device__ __forceinline__ double ref_seq_sum(const RefDict &d, F f) {
+    const double mine = f();
+    double t = 0.0;
+    for (int r = 0; r < d.npos; ++r) {
+        const uint64_t hit = __ballot(d.in && d.pos == r);
+        if (hit) t = __dadd_rn(t, lane_f64(mine, __builtin_ctzll(hit)));
+    }
+    return t;
+}
+// insertion positions when the dict is filled class by class (dict order), alleles in key order: (first class, lane)
+__device__ __forceinline__ void ref_positions(RefDict &d, uint64_t classes_of_me, int C, int lane) {
+    const int fc = classes_of_me ? __builtin_ctzll(classes_of_me) : 64;
+    int base = 0;
+    d.pos = 0;
+    for (int c = 0; c < C; ++c) {
+        const uint64_t m = __ballot(d.in && fc == c);
+        if (d.in && fc == c) d.pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        base += __popcll(m);
+    }
+    d.npos = base;
+}
+__device__ __forceinline__ void ref_normalize(RefDict &d, bool use_len, double len) {       // common:1285-1297
+    const double total = ref_seq_sum(d, [&]() { return use_len ? __ddiv_rn(d.v, len) : d.v; });
+    if (d.in) d.v = use_len ? __ddiv_rn(__ddiv_rn(d.v, len), total) : __ddiv_rn(d.v, total);
+}
+// Gene_prob_next (common:1311-1336): E.R = members of class `lane`, E.K = classes of allele `lane`, E.n = class counts
+__device__ __forceinline__ RefDict ref_next(const WaveEM &E, const RefDict &prob, bool use_len, int lane) {
+    double s = 0.0;                                            // lane = class: alleles_prob, alleles in key order
+    const uint64_t inmask = __ballot(prob.in);
+    for (int j = 0; j < E.A1; ++j) {
+        const double xj = lane_f64(prob.v, j);
+        if (((inmask >> j) & 1ull) && ((E.R >> j) & 1ull)) s = __dadd_rn(s, xj);
+    }
+    const uint64_t valid = __ballot(lane < E.C && s > 0.0);   // classes with alleles_prob <= 0 are skipped
+    RefDict next;
+    next.v = 0.0;
+    // lane = allele: += count * prob / alleles_prob, classes in dict order.  The quotients of four classes are formed side by
+    // side (a double-precision division is a long dependent chain) and then added in order.
+    for (int c0 = 0; c0 < E.C; c0 += 4) {
+        double term[4];
+        bool on[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = c0 + k;
+            const double sc = lane_f64(s, c & 63), nc = lane_f64(E.n, c & 63);
+            on[k] = c < E.C && ((valid >> c) & 1ull) && prob.in && ((E.K >> c) & 1ull);
+            term[k] = on[k] ? __ddiv_rn(__dmul_rn(nc, prob.v), sc) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (on[k]) next.v = __dadd_rn(next.v, term[k]);
+    }
+    next.in = prob.in && (E.K & valid) != 0ull;
+    if (!next.in) next.v = 0.0;
+    ref_positions(next, E.K & valid, E.C, lane);
+    ref_normalize(next, use_len, E.len);
+    return next;
+}
+__device__ __forceinline__ void ref_select(RefDict &d) {      // common:1338-1346
+    const double mx = wave_max_f64(d.in ? d.v : 0.0);
+    if (d.in && !(d.v >= __ddiv_rn(mx, 10.0))) { d.in = false; d.v = 0.0; }
+}
+__device__ __forceinline__ void ref_em_run(const WaveEM &E, int remove_low, bool use_len, int g, double *__restrict__ out,
+                                           double *__restrict__ scal) {
+    const int lane = threadIdx.x & 63;
+    // initial estimate (common:1300-1309): prob[a] += count / |class| over the classes in dict order
+    const int nal = __popcll(E.R);
+    RefDict prob;
+    prob.v = 0.0;
+    for (int c = 0; c < E.C; ++c) {
+        const double nc = lane_f64(E.n, c);
+        const int nalc = __builtin_amdgcn_readlane(nal, c);
+        if ((E.K >> c) & 1ull) prob.v = __dadd_rn(prob.v, __ddiv_rn(nc, (double)nalc));
+    }
+    prob.in = lane < E.A1 && E.K != 0ull;
+    ref_positions(prob, E.K, E.C, lane);
+    ref_normalize(prob, use_len, E.len);
+    double diff = 1.0;
+    int iter = 0;
+    bool keyerr = false;
+    while (diff > 0.0001 && iter < 1000) {                     // common:1351
+        RefDict next = ref_next(E, prob, use_len, lane);
+        RefDict next2 = ref_next(E, next, use_len, lane);
+        if (__any(prob.in && (!next.in || !next2.in))) { keyerr = true; break; }      // the reference's KeyError (Q6)
+        const double p_r = __dsub_rn(next.v, prob.v);
+        const double p_v = __dsub_rn(__dsub_rn(next2.v, next.v), p_r);
+        // the two sums advance together in the reference's loop; they are independent accumulators
+        const double ssr = ref_seq_sum(prob, [&]() { return __dmul_rn(p_r, p_r); });
+        const double ssv = ref_seq_sum(prob, [&]() { return __dmul_rn(p_v, p_v); });
+        if (ssv > 0.0) {                                       // common:1370-1383
+            const double gamma = -__dsqrt_rn(__ddiv_rn(ssr, ssv));
+            if (prob.in) {
+                const double x = __dadd_rn(__dsub_rn(prob.v, __dmul_rn(__dmul_rn(2.0, gamma), p_r)), __dmul_rn(__dmul_rn(gamma, gamma), p_v));
+                next2.v = 0.0 > x ? 0.0 : x;
+            }
+            next = ref_next(E, next2, use_len, lane);
+        }
+        diff = ref_seq_sum(prob, [&]() { return next.in ? fabs(__dsub_rn(prob.v, next.v)) : prob.v; });     // prob_diff, common:1272-1279
+        prob = next;
+        if (iter >= 10 && remove_low) ref_select(prob);
+        iter += 1;
+    }
+    if (!keyerr) {
+        if (remove_low) ref_select(prob);                      // common:1402-1407
+        ref_normalize(prob, use_len, E.len);
+        if (lane < E.A1 && prob.in) out[g] = prob.v;
+    }
+    if (lane == 0) { scal[S_ITER] = (double)iter; scal[S_KEYERR] = keyerr ? 1.0 : 0.0; scal[S_DONE] = 1.0; }
+}
+
 constexpr int S_FALLBACK = 6;       // (re-uses the S_NROWS word: the wave kernel launches no mat-vec)
 
 __global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, int C, int n_words, int a_pad,
@@ -1237,7 +1362,7 @@ __global__ __launch_bounds__(BLOCK) void k_em_masked(const uint64_t *__restrict_
                                                      const double *__restrict__ lenc, int remove_low,
                                                      double *__restrict__ out, int32_t *__restrict__ first_out,
                                                      double *__restrict__ scal, MaskedEntry *__restrict__ pub,
-                                                     unsigned *__restrict__ ticket) {
+                                                     unsigned *__restrict__ ticket, int exact) {
     __shared__ int n_keys, n_list, is_last;
     __shared__ unsigned long long keys[TAIL_SLOTS], cnts[TAIL_SLOTS];
     __shared__ unsigned int firsts[TAIL_SLOTS];
@@ -1352,6 +1477,10 @@ __global__ __launch_bounds__(BLOCK) void k_em_masked(const uint64_t *__restrict_
     E.len = (use_len && lane < A1) ? lenc[lane] : 1.0;
     if (lane < A1) { out[lane] = -1.0; first_out[lane] = E.K ? __builtin_ctzll(E.K) : -1; }
     if (lane == 0) scal[S_NCLS] = (double)C1;
+    if (exact) {        // alleles arrived in name order: the reference's own summation order (bit-identical results)
+        ref_em_run(E, remove_low, use_len, lane, out, scal);
+        return;
+    }
     bool pr;
     double p = wave_map(E, 0.0, false, 1.0, true, use_len, pr);
     const double tot = wave_sum_f64(pr ? p : 0.0);
@@ -2795,6 +2924,10 @@ extern "C" int hgx_em_masked(const hgx_classes *cc, const uint64_t *mask_host, i
     if (al.empty()) return HGX_OK;
     if (al.size() <= 64 && !getenv("HGX_EM_NO_MASKED")) {
         const int A1 = (int)al.size();
+        // with the alleles' name order at hand the kept alleles go up in that order (= their order inside a class key), and the
+        // single-wavefront EM follows the reference's summation order exactly
+        const bool exact = cc->h_rank != nullptr && !getenv("HGX_EM_NO_EXACT");
+        if (exact) std::sort(al.begin(), al.end(), [&](int32_t x, int32_t y) { return cc->h_rank[x] < cc->h_rank[y]; });
         // one staging struct each way: [al | len] up, [scal | ticket | out | first] down (one copy + one memset + one copy)
         struct Up { int32_t al[64]; double len[64]; } up;
         struct Down { double scal[S_N]; unsigned ticket[2]; double out[64]; int32_t first[64]; } down;
@@ -2809,7 +2942,7 @@ extern "C" int hgx_em_masked(const hgx_classes *cc, const uint64_t *mask_host, i
         Down *d_down = (Down *)b_down.p;
         hipLaunchKernelGGL(k_em_masked, dim3(nb), dim3(BLOCK), 0, st, cc->d_bits, C, cc->w64, cc->d_count, d_up->al, A1,
                            allele_len ? d_up->len : nullptr, remove_low ? 1 : 0, d_down->out, d_down->first, d_down->scal,
-                           (MaskedEntry *)b_pub.p, d_down->ticket);
+                           (MaskedEntry *)b_pub.p, d_down->ticket, exact ? 1 : 0);
         HIPCHK(hipGetLastError());
         { int rc_ = hgx_d2h(&down, b_down.p, sizeof(Down), st); if (rc_) return rc_; }
         { int rc_ = hgx_sync(st); if (rc_) return rc_; }
@@ -2841,6 +2974,18 @@ extern "C" int hgx_em_masked(const hgx_classes *cc, const uint64_t *mask_host, i
     }
     hgx_classes_destroy(sub);
     return rc;
+}
+
+// Name order of the alleles (rank_host[a] = position of allele a's name in sorted order = its place inside a class key,
+// typing_core.py:1229): lets the small EMs sum in the reference's order.  Copied; NULL clears it.
+extern "C" int hgx_classes_set_allele_rank(hgx_classes *c, const int32_t *rank_host, int32_t n) {
+    ARGCHK(c && n >= 0 && n <= c->a_pad);
+    delete[] c->h_rank;
+    c->h_rank = nullptr;
+    if (!rank_host) return HGX_OK;
+    c->h_rank = new int32_t[c->a_pad];
+    for (int a = 0; a < c->a_pad; ++a) c->h_rank[a] = a < n ? rank_host[a] : 0x7fffffff;
+    return HGX_OK;
 }
 
 // first class containing each compact allele = first set bit of its row in the transposed matrix (one wavefront per row)

@@ -104,6 +104,11 @@ class Classes:
                                                  C.c_int64(n_rows), C.c_int32(a_pad), capi.ptr(and_mask), stream))
         return Classes(h)
 
+    def set_allele_rank(self, name_rank):
+        """Name order of the alleles (rank per allele index): lets em_masked follow the reference's summation order exactly."""
+        r = np.ascontiguousarray(name_rank, dtype=np.int32)
+        capi.check(capi.lib().hgx_classes_set_allele_rank(self.h, capi.ptr(r), C.c_int32(len(r))))
+
     @staticmethod
     def of_level(locus, dbatch, bufs, level, stream=None, groups=None):
         """Classes of one level (0 exon, 1 gene) straight from the piece refs (after piece_compat): hgx_level_classes, or its

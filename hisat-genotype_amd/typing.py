@@ -307,6 +307,7 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
             np.bitwise_or.at(mask, ea >> 6, np.uint64(1) << (ea & 63).astype(np.uint64))
             # Gene_cmpt2 (gene classes filtered to exon_alleles, merged) and EM #2 in one call (hgx_em_masked)
             t0 = time.perf_counter()
+            gcl.set_allele_rank(pl.name_rank)
             prob2, first2, n_iter2, n_cls2 = gcl.em_masked(mask, A, True, pl.allele_len, stream)
             res.t_em += time.perf_counter() - t0
             present = np.nonzero(prob2 >= 0.0)[0]

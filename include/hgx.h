@@ -210,6 +210,12 @@ int hgx_em(const hgx_classes *c, int32_t n_alleles,
 int hgx_em_ordered(const hgx_classes *c, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len_or_null,
                    double *prob_host, int32_t *first_class_host, int32_t *n_iter_host, void *stream);
 
+/* Name order of the alleles: rank_host[a] = position of allele a's name among the sorted names (= its place inside a class
+ * key, '-'.join(sorted(names)), typing_core.py:1229).  With it the single-wavefront EM of hgx_em_masked adds in the reference's
+ * own order (dict order of classes, key order of alleles, terms count*prob/alleles_prob) and returns bit-identical abundances;
+ * without it the result is within 1e-9 as everywhere else.  The array is copied; NULL clears it. */
+int hgx_classes_set_allele_rank(hgx_classes *c, const int32_t *rank_host, int32_t n);
+
 /* The exon -> gene hand-off in one call (typing_core.py:1752-1782): Gene_cmpt2 = every class of `c` filtered to the alleles of
  * mask_host (a_pad/64 words), empty ones dropped, equal ones merged with summed counts; then the EM on it (as
  * hgx_em_ordered).  *n_classes_host = number of merged classes.  With <= 64 alleles in the mask (and <= 64 merged classes)
