@@ -1049,6 +1049,10 @@ __device__ __forceinline__ void wave_em_run(const WaveEM &E, double p, bool pr, 
 // A dict is, per allele-lane: value, membership, position in the insertion order (positions may have gaps after pruning).
 // ------------------------------------------------------------------------------------------------------------
 struct RefDict { double v; bool in; int pos; int npos; };
+// Plain operators under contract(off): the compiler must not fuse a - b * c into one FMA (one rounding instead of the
+// reference's two) -- seen as 2e-13 relative differences on 1e-9 abundances after the SQUAREM step.  (HIP's __dadd_rn /
+// __dmul_rn are themselves plain operators defined under the default contraction mode, so they do not help.)
+#pragma clang fp contract(off)
 
 __device__ __forceinline__ double lane_f64(double v, int l) {
     return __longlong_as_double((long long)lane_u64((uint64_t)__double_as_longlong(v), l));
@@ -1059,7 +1063,7 @@ template <class F> __device__ __forceinline__ double ref_seq_sum(const RefDict &
     double t = 0.0;
     for (int r = 0; r < d.npos; ++r) {
         const uint64_t hit = __ballot(d.in && d.pos == r);
-        if (hit) t = __dadd_rn(t, lane_f64(mine, __builtin_ctzll(hit)));
+        if (hit) t = ((t) + (lane_f64(mine, __builtin_ctzll(hit))));
     }
     return t;
 }
@@ -1076,8 +1080,8 @@ __device__ __forceinline__ void ref_positions(RefDict &d, uint64_t classes_of_me
     d.npos = base;
 }
 __device__ __forceinline__ void ref_normalize(RefDict &d, bool use_len, double len) {       // common:1285-1297
-    const double total = ref_seq_sum(d, [&]() { return use_len ? __ddiv_rn(d.v, len) : d.v; });
-    if (d.in) d.v = use_len ? __ddiv_rn(__ddiv_rn(d.v, len), total) : __ddiv_rn(d.v, total);
+    const double total = ref_seq_sum(d, [&]() { return use_len ? ((d.v) / (len)) : d.v; });
+    if (d.in) d.v = use_len ? ((((d.v) / (len))) / (total)) : ((d.v) / (total));
 }
 // Gene_prob_next (common:1311-1336): E.R = members of class `lane`, E.K = classes of allele `lane`, E.n = class counts
 __device__ __forceinline__ RefDict ref_next(const WaveEM &E, const RefDict &prob, bool use_len, int lane) {
@@ -1085,7 +1089,7 @@ __device__ __forceinline__ RefDict ref_next(const WaveEM &E, const RefDict &prob
     const uint64_t inmask = __ballot(prob.in);
     for (int j = 0; j < E.A1; ++j) {
         const double xj = lane_f64(prob.v, j);
-        if (((inmask >> j) & 1ull) && ((E.R >> j) & 1ull)) s = __dadd_rn(s, xj);
+        if (((inmask >> j) & 1ull) && ((E.R >> j) & 1ull)) s = ((s) + (xj));
     }
     const uint64_t valid = __ballot(lane < E.C && s > 0.0);   // classes with alleles_prob <= 0 are skipped
     RefDict next;
@@ -1100,11 +1104,11 @@ __device__ __forceinline__ RefDict ref_next(const WaveEM &E, const RefDict &prob
             const int c = c0 + k;
             const double sc = lane_f64(s, c & 63), nc = lane_f64(E.n, c & 63);
             on[k] = c < E.C && ((valid >> c) & 1ull) && prob.in && ((E.K >> c) & 1ull);
-            term[k] = on[k] ? __ddiv_rn(__dmul_rn(nc, prob.v), sc) : 0.0;
+            term[k] = on[k] ? ((((nc) * (prob.v))) / (sc)) : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (on[k]) next.v = __dadd_rn(next.v, term[k]);
+            if (on[k]) next.v = ((next.v) + (term[k]));
     }
     next.in = prob.in && (E.K & valid) != 0ull;
     if (!next.in) next.v = 0.0;
@@ -1114,7 +1118,7 @@ __device__ __forceinline__ RefDict ref_next(const WaveEM &E, const RefDict &prob
 }
 __device__ __forceinline__ void ref_select(RefDict &d) {      // common:1338-1346
     const double mx = wave_max_f64(d.in ? d.v : 0.0);
-    if (d.in && !(d.v >= __ddiv_rn(mx, 10.0))) { d.in = false; d.v = 0.0; }
+    if (d.in && !(d.v >= ((mx) / (10.0)))) { d.in = false; d.v = 0.0; }
 }
 __device__ __forceinline__ void ref_em_run(const WaveEM &E, int remove_low, bool use_len, int g, double *__restrict__ out,
                                            double *__restrict__ scal) {
@@ -1126,7 +1130,7 @@ __device__ __forceinline__ void ref_em_run(const WaveEM &E, int remove_low, bool
     for (int c = 0; c < E.C; ++c) {
         const double nc = lane_f64(E.n, c);
         const int nalc = __builtin_amdgcn_readlane(nal, c);
-        if ((E.K >> c) & 1ull) prob.v = __dadd_rn(prob.v, __ddiv_rn(nc, (double)nalc));
+        if ((E.K >> c) & 1ull) prob.v = ((prob.v) + (((nc) / ((double)nalc))));
     }
     prob.in = lane < E.A1 && E.K != 0ull;
     ref_positions(prob, E.K, E.C, lane);
@@ -1138,20 +1142,20 @@ __device__ __forceinline__ void ref_em_run(const WaveEM &E, int remove_low, bool
         RefDict next = ref_next(E, prob, use_len, lane);
         RefDict next2 = ref_next(E, next, use_len, lane);
         if (__any(prob.in && (!next.in || !next2.in))) { keyerr = true; break; }      // the reference's KeyError (Q6)
-        const double p_r = __dsub_rn(next.v, prob.v);
-        const double p_v = __dsub_rn(__dsub_rn(next2.v, next.v), p_r);
+        const double p_r = ((next.v) - (prob.v));
+        const double p_v = ((((next2.v) - (next.v))) - (p_r));
         // the two sums advance together in the reference's loop; they are independent accumulators
-        const double ssr = ref_seq_sum(prob, [&]() { return __dmul_rn(p_r, p_r); });
-        const double ssv = ref_seq_sum(prob, [&]() { return __dmul_rn(p_v, p_v); });
+        const double ssr = ref_seq_sum(prob, [&]() { return ((p_r) * (p_r)); });
+        const double ssv = ref_seq_sum(prob, [&]() { return ((p_v) * (p_v)); });
         if (ssv > 0.0) {                                       // common:1370-1383
-            const double gamma = -__dsqrt_rn(__ddiv_rn(ssr, ssv));
+            const double gamma = -sqrt(((ssr) / (ssv)));
             if (prob.in) {
-                const double x = __dadd_rn(__dsub_rn(prob.v, __dmul_rn(__dmul_rn(2.0, gamma), p_r)), __dmul_rn(__dmul_rn(gamma, gamma), p_v));
+                const double x = ((((prob.v) - (((((2.0) * (gamma))) * (p_r))))) + (((((gamma) * (gamma))) * (p_v))));
                 next2.v = 0.0 > x ? 0.0 : x;
             }
             next = ref_next(E, next2, use_len, lane);
         }
-        diff = ref_seq_sum(prob, [&]() { return next.in ? fabs(__dsub_rn(prob.v, next.v)) : prob.v; });     // prob_diff, common:1272-1279
+        diff = ref_seq_sum(prob, [&]() { return next.in ? fabs(((prob.v) - (next.v))) : prob.v; });     // prob_diff, common:1272-1279
         prob = next;
         if (iter >= 10 && remove_low) ref_select(prob);
         iter += 1;
@@ -1164,13 +1168,16 @@ __device__ __forceinline__ void ref_em_run(const WaveEM &E, int remove_low, bool
     if (lane == 0) { scal[S_ITER] = (double)iter; scal[S_KEYERR] = keyerr ? 1.0 : 0.0; scal[S_DONE] = 1.0; }
 }
 
+#pragma clang fp contract(fast)
 constexpr int S_FALLBACK = 6;       // (re-uses the S_NROWS word: the wave kernel launches no mat-vec)
 
 __global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, int C, int n_words, int a_pad,
                                                 const int64_t *__restrict__ count, const double *__restrict__ len,
                                                 int remove_low, double *__restrict__ out, double *__restrict__ scal,
-                                                int32_t *__restrict__ first_out) {
-    __shared__ int gidx[64];
+                                                int32_t *__restrict__ first_out, const int32_t *__restrict__ rank) {
+    // rank != NULL (the alleles' name order): lanes take the alleles in that order and the EM follows the reference's own
+    // order of operations (ref_em_run: bit-identical abundances)
+    __shared__ int gidx[64], gsorted[64];
     const int lane = threadIdx.x;
     // ---- which alleles occur at all ------------------------------------------------------------------------
     uint64_t u0 = 0, u1 = 0;
@@ -1199,7 +1206,18 @@ __global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, 
         for (uint64_t m = u1; m; m &= m - 1) gidx[id++] = 64 * (lane + 64) + __builtin_ctzll(m);
     }
     __syncthreads();
-    const int g = lane < A1 ? gidx[lane] : 0;
+    int g = lane < A1 ? gidx[lane] : 0;
+    if (rank) {                                             // key order = name order
+        const int r = lane < A1 ? rank[g] : 0x7fffffff;
+        int pos = 0;
+        for (int k = 0; k < A1; ++k) {
+            const int rk = __builtin_amdgcn_readlane(r, k);
+            pos += (rk < r) || (rk == r && k < lane);
+        }
+        if (lane < A1) gsorted[pos] = g;
+        __syncthreads();
+        g = lane < A1 ? gsorted[lane] : 0;
+    }
     // ---- row and column masks ----------------------------------------------------------------------------------
     WaveEM E;
     E.R = 0; E.K = 0; E.C = C; E.A1 = A1;
@@ -1213,13 +1231,17 @@ __global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, 
     const bool use_len = len != nullptr;
     E.len = (use_len && lane < A1) ? len[g] : 1.0;
     // ---- EM (common:1299-1410) ----------------------------------------------------------------------------------
+    for (int a = lane; a < a_pad; a += 64) out[a] = -1.0;
+    if (first_out && lane < A1) first_out[g] = E.K ? __builtin_ctzll(E.K) : -1;     // first class (dict order) containing the allele
+    __syncthreads();
+    if (rank) {
+        ref_em_run(E, remove_low, use_len, g, out, scal);
+        return;
+    }
     bool pr;
     double p = wave_map(E, 0.0, false, 1.0, true, use_len, pr);
     const double tot = wave_sum_f64(pr ? p : 0.0);
     p = pr ? p / tot : 0.0;
-    for (int a = lane; a < a_pad; a += 64) out[a] = -1.0;
-    if (first_out && lane < A1) first_out[g] = E.K ? __builtin_ctzll(E.K) : -1;     // first class (dict order) containing the allele
-    __syncthreads();
     wave_em_run(E, p, pr, 0, remove_low, use_len, g, out, scal);
 }
 
@@ -2481,8 +2503,14 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             HIPCHK(hipMemsetAsync(b_first.p, 0xFF, (size_t)A * 4, st));
             h_first.resize(A);
         }
+        DevBuf b_rank;
+        if (c->h_rank && !getenv("HGX_EM_NO_EXACT")) {
+            ALLOC(b_rank, (size_t)A * 4);
+            { int rc_ = hgx_h2d(b_rank.p, c->h_rank, (size_t)A * 4, st); if (rc_) return rc_; }
+        }
         hipLaunchKernelGGL(k_em_wave, dim3(1), dim3(64), 0, st, c->d_bits, C, c->w64, A, c->d_count, d_len, remove_low ? 1 : 0,
-                           b_out.as<double>(), b_scal.as<double>(), first_host ? b_first.as<int32_t>() : nullptr);
+                           b_out.as<double>(), b_scal.as<double>(), first_host ? b_first.as<int32_t>() : nullptr,
+                           b_rank.as<int32_t>());
         HIPCHK(hipGetLastError());
         std::vector<double> out(A);
         double h_scal[S_N];

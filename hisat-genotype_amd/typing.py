@@ -52,6 +52,7 @@ def _sorted_result(prob, order):
 
 
 def _em_on_classes(classes, n_alleles, name_rank, remove_low, lengths, stream=None):
+    classes.set_allele_rank(name_rank)      # small problems are then summed in the reference's own order (bit-identical)
     prob, first, n_iter = classes.em_ordered(n_alleles, remove_low, lengths, stream)
     present = np.nonzero(prob >= 0.0)[0]
     # dict insertion order of the survivors (common:1300-1305): first class containing each, then name order
@@ -84,6 +85,10 @@ def single_abundance(Gene_cmpt, remove_low_abundance_allele=False, Gene_length={
         lengths = np.array([Gene_length[a] for a in names], np.int32)
     cl = engine.Classes.from_host(bits, counts, ap)
     try:
+        if all(al == sorted(al) for al in split):      # keys as the reference builds them: '-'.join(sorted(names))
+            rank = np.zeros(A, np.int32)
+            rank[np.array(sorted(range(A), key=lambda i: names[i]), np.int64)] = np.arange(A, dtype=np.int32)
+            cl.set_allele_rank(rank)
         prob, _ = cl.em(A, bool(remove_low_abundance_allele), lengths)
     finally:
         cl.close()

@@ -211,9 +211,10 @@ int hgx_em_ordered(const hgx_classes *c, int32_t n_alleles, int32_t remove_low, 
                    double *prob_host, int32_t *first_class_host, int32_t *n_iter_host, void *stream);
 
 /* Name order of the alleles: rank_host[a] = position of allele a's name among the sorted names (= its place inside a class
- * key, '-'.join(sorted(names)), typing_core.py:1229).  With it the single-wavefront EM of hgx_em_masked adds in the reference's
- * own order (dict order of classes, key order of alleles, terms count*prob/alleles_prob) and returns bit-identical abundances;
- * without it the result is within 1e-9 as everywhere else.  The array is copied; NULL clears it. */
+ * key, '-'.join(sorted(names)), typing_core.py:1229).  With it the single-wavefront EMs (hgx_em_masked; hgx_em / hgx_em_ordered
+ * on <= 64 classes over <= 64 alleles) add in the reference's own order (dict order of classes, key order of alleles, terms
+ * count*prob/alleles_prob, no contraction) and return bit-identical abundances; without it the result is within 1e-9 as
+ * everywhere else.  The array is copied; NULL clears it. */
 int hgx_classes_set_allele_rank(hgx_classes *c, const int32_t *rank_host, int32_t n);
 
 /* The exon -> gene hand-off in one call (typing_core.py:1752-1782): Gene_cmpt2 = every class of `c` filtered to the alleles of

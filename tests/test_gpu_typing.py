@@ -40,7 +40,8 @@ def test_type_locus_matches_reference(name):
     for k, (got, exp) in enumerate(zip(res.em, fx["em"])):
         assert got["n_classes"] == len(exp["cmpt"])
         assert got["remove_low"] == exp["remove_low"] and got["use_length"] == exp["use_length"]
-        _check_em(got, exp["result"], exp["n_iter"], exact=(k == 1 and got["use_length"]))
+        small = len(exp["cmpt"]) <= 64 and len({a for cid, _ in exp["cmpt"] for a in gu.class_key(fx, cid).split("-")}) <= 64
+        _check_em(got, exp["result"], exp["n_iter"], exact=(k == 1 and got["use_length"]) or small)
     lines, _ = hgx.report_lines(res, o["simulation"], o["sample"] if o["simulation"] else (), True)
     keep = lambda ls: [l for l in ls if "aligned" in l or "ranked" in l or "(count:" in l]
     assert keep(lines) == keep(fx["report"].split("\n"))
@@ -56,8 +57,11 @@ def test_single_abundance_dropin(name):
         cmpt = {gu.class_key(fx, cid): n for cid, n in em["cmpt"]}
         out = hgx.single_abundance(cmpt, em["remove_low"], lengths if em["use_length"] else {})
         assert [a for a, _ in out] == [a for a, _ in em["result"]]
+        small = len(cmpt) <= 64 and len({a for key in cmpt for a in key.split("-")}) <= 64
         for (a, p), (_, q) in zip(out, em["result"]):
             assert abs(p - float(q)) <= 1e-9
+            if small:      # one wavefront, the reference's own summation order
+                assert p == float(q)
 
 
 def test_seeded_mid_size_against_python_oracle():
