@@ -1049,6 +1049,7 @@ __device__ __forceinline__ void wave_em_run(const WaveEM &E, double p, bool pr, 
 // A dict is, per allele-lane: value, membership, position in the insertion order (positions may have gaps after pruning).
 // ------------------------------------------------------------------------------------------------------------
 struct RefDict { double v; bool in; int pos; int npos; };
+struct RefOrder { uint64_t in_mask, cls_mask; int pos, npos; bool set; };      // the insertion order last computed (it rarely changes)
 // Plain operators under contract(off): the compiler must not fuse a - b * c into one FMA (one rounding instead of the
 // reference's two) -- seen as 2e-13 relative differences on 1e-9 abundances after the SQUAREM step.  (HIP's __dadd_rn /
 // __dmul_rn are themselves plain operators defined under the default contraction mode, so they do not help.)
@@ -1084,7 +1085,7 @@ __device__ __forceinline__ void ref_normalize(RefDict &d, bool use_len, double l
     if (d.in) d.v = use_len ? ((((d.v) / (len))) / (total)) : ((d.v) / (total));
 }
 // Gene_prob_next (common:1311-1336): E.R = members of class `lane`, E.K = classes of allele `lane`, E.n = class counts
-__device__ __forceinline__ RefDict ref_next(const WaveEM &E, const RefDict &prob, bool use_len, int lane) {
+__device__ __forceinline__ RefDict ref_next(const WaveEM &E, const RefDict &prob, bool use_len, int lane, RefOrder &ord) {
     double s = 0.0;                                            // lane = class: alleles_prob, alleles in key order
     const uint64_t inmask = __ballot(prob.in);
     for (int j = 0; j < E.A1; ++j) {
@@ -1104,7 +1105,8 @@ __device__ __forceinline__ RefDict ref_next(const WaveEM &E, const RefDict &prob
             const int c = c0 + k;
             const double sc = lane_f64(s, c & 63), nc = lane_f64(E.n, c & 63);
             on[k] = c < E.C && ((valid >> c) & 1ull) && prob.in && ((E.K >> c) & 1ull);
-            term[k] = on[k] ? ((((nc) * (prob.v))) / (sc)) : 0.0;
+            term[k] = (nc * prob.v) / (((valid >> (c & 63)) & 1ull) ? sc : 1.0);      // formed on every lane (no branch between the four
+                                                                                   // division chains); used where on[k]
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -1112,7 +1114,13 @@ __device__ __forceinline__ RefDict ref_next(const WaveEM &E, const RefDict &prob
     }
     next.in = prob.in && (E.K & valid) != 0ull;
     if (!next.in) next.v = 0.0;
-    ref_positions(next, E.K & valid, E.C, lane);
+    // the order depends only on who is in the dict and which classes were walked: re-derive it only when either changed
+    const uint64_t in_mask = __ballot(next.in);
+    if (ord.set && ord.in_mask == in_mask && ord.cls_mask == valid) { next.pos = ord.pos; next.npos = ord.npos; }
+    else {
+        ref_positions(next, E.K & valid, E.C, lane);
+        ord.in_mask = in_mask; ord.cls_mask = valid; ord.pos = next.pos; ord.npos = next.npos; ord.set = true;
+    }
     ref_normalize(next, use_len, E.len);
     return next;
 }
@@ -1138,9 +1146,11 @@ __device__ __forceinline__ void ref_em_run(const WaveEM &E, int remove_low, bool
     double diff = 1.0;
     int iter = 0;
     bool keyerr = false;
+    RefOrder ord;
+    ord.set = false;
     while (diff > 0.0001 && iter < 1000) {                     // common:1351
-        RefDict next = ref_next(E, prob, use_len, lane);
-        RefDict next2 = ref_next(E, next, use_len, lane);
+        RefDict next = ref_next(E, prob, use_len, lane, ord);
+        RefDict next2 = ref_next(E, next, use_len, lane, ord);
         if (__any(prob.in && (!next.in || !next2.in))) { keyerr = true; break; }      // the reference's KeyError (Q6)
         const double p_r = ((next.v) - (prob.v));
         const double p_v = ((((next2.v) - (next.v))) - (p_r));
@@ -1153,7 +1163,7 @@ __device__ __forceinline__ void ref_em_run(const WaveEM &E, int remove_low, bool
                 const double x = ((((prob.v) - (((((2.0) * (gamma))) * (p_r))))) + (((((gamma) * (gamma))) * (p_v))));
                 next2.v = 0.0 > x ? 0.0 : x;
             }
-            next = ref_next(E, next2, use_len, lane);
+            next = ref_next(E, next2, use_len, lane, ord);
         }
         diff = ref_seq_sum(prob, [&]() { return next.in ? fabs(((prob.v) - (next.v))) : prob.v; });     // prob_diff, common:1272-1279
         prob = next;
