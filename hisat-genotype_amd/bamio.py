@@ -9,6 +9,7 @@ synthetic SAM into BAM fixtures.
 Only what the typing path consumes is decoded: the eleven mandatory fields and the tags of types A c C s S i I f Z H B.
 """
 import gzip
+import re
 import struct
 import zlib
 
@@ -71,9 +72,53 @@ def _decode_tags(buf, p, end):
     return out
 
 
-def read_bam(path, region=None):
-    """Decode a BAM file into SAM text lines (no header).  `region` = (ref_name, left0, right0) keeps records of that
-    reference whose 0-based POS lies in [left0, right0], like the reference's ``chr:left-right`` argument to samtools."""
+def parse_region(text):
+    """One samtools region string -> (whole, name, left0, right0): the record matches if RNAME == whole (entire reference)
+    or RNAME == name and its span overlaps [left0, right0].  "name:l-r" is 1-based inclusive; "name:l" and "name:-r" are
+    open-ended; commas may group digits.  name is None when the text after the last ':' is not a span."""
+    name, left0, right0 = None, 0, 1 << 62
+    if ":" in text[1:]:
+        head, span = text.rsplit(":", 1)
+        m = re.fullmatch(r"([0-9,]*)(-([0-9,]*))?", span)
+        if m and span and (m.group(1) or m.group(3)):
+            lo = m.group(1).replace(",", "")
+            hi = (m.group(3) or "").replace(",", "")
+            if (lo or hi) and not (m.group(1) and not lo) and not (m.group(3) and not hi):
+                name = head
+                left0 = max(int(lo) - 1, 0) if lo else 0
+                right0 = int(hi) - 1 if hi else 1 << 62
+    return text, name, left0, right0
+
+
+def normalise_regions(regions):
+    """None / "" / [] -> None (no filter); a string (regions separated by newlines) or a list of strings -> list of
+    parse_region tuples."""
+    if regions is None:
+        return None
+    if isinstance(regions, (str, bytes)):
+        if isinstance(regions, bytes):
+            regions = regions.decode()
+        if regions == "":
+            return None
+        regions = regions.split("\n")
+    return [parse_region(r) for r in regions if r]
+
+
+def region_hit(reg, rname, pos0, end0):
+    whole, name, left0, right0 = reg
+    return rname == whole or (name is not None and rname == name and end0 >= left0 and pos0 <= right0)
+
+
+def cigar_reflen(cigar):
+    """Reference bases consumed by a SAM CIGAR string (M D N = X)."""
+    return sum(int(n) for n, op in re.findall(r"(\d+)([MIDNSHP=X])", cigar) if op in "MDN=X")
+
+
+def read_bam(path, regions=None):
+    """Decode a BAM file into SAM text lines (no header).  `regions` = samtools region strings ("name", "name:left-right";
+    a list, or one string with newlines): the records OVERLAPPING a region (reference span from the CIGAR, one base for
+    unmapped records) come out region after region, like ``samtools view file r1 r2`` (typing_core.py:436-444)."""
+    regs = normalise_regions(regions)
     with open(path, "rb") as f:
         data = f.read()
     raw = b"".join(_bgzf_blocks(data))
@@ -89,6 +134,7 @@ def read_bam(path, region=None):
         refs.append(raw[p + 4:p + 4 + l_name - 1].decode())
         p += 4 + l_name + 4
     lines = []
+    per_region = [[] for _ in (regs or [])]
     n = len(raw)
     while p < n:
         bs = struct.unpack_from("<i", raw, p)[0]
@@ -111,12 +157,24 @@ def read_bam(path, region=None):
         tags = _decode_tags(raw, q, rec_end)
         p = rec_end
         rname = refs[ref_id] if ref_id >= 0 else "*"
-        if region is not None:
-            if rname != region[0] or pos < region[1] or pos > region[2]:
+        hits = None
+        if regs is not None:
+            reflen = 0 if (flag & 4) else sum(int(c[:-1]) for c in cig if c[-1] in "MDN=X")
+            end0 = pos + max(reflen, 1) - 1
+            hits = [g for g, r in enumerate(regs) if ref_id >= 0 and region_hit(r, rname, pos, end0)]
+            if not hits:
                 continue
         rnext = "*" if nref_id < 0 else ("=" if nref_id == ref_id else refs[nref_id])
-        lines.append("\t".join([qname, str(flag), rname, str(pos + 1), str(mapq), "".join(cig) or "*", rnext, str(npos + 1),
-                                str(tlen), seq or "*", qual] + tags))
+        text = "\t".join([qname, str(flag), rname, str(pos + 1), str(mapq), "".join(cig) or "*", rnext, str(npos + 1),
+                          str(tlen), seq or "*", qual] + tags)
+        if hits is None:
+            lines.append(text)
+        else:
+            for g in hits:
+                per_region[g].append(text)
+    if regs is not None:
+        for v in per_region:
+            lines.extend(v)
     return lines
 
 

@@ -6,7 +6,8 @@
 //     CRC32 + ISIZE checked;
 //   * BAM records (section 4.2) -> SAM text lines, in parallel over record ranges: the eleven mandatory fields and the tags of
 //     types A c C s S i I f Z H B (floats as %g, like samtools);
-//   * header lines dropped, optional region filter (reference name, 0-based POS in [left, right], as the Python reader does);
+//   * header lines dropped; optional region list in samtools syntax ("name" or "name:left-right", 1-based inclusive): the records
+//     that OVERLAP a region (reference span from the CIGAR, as `samtools view file r1 r2` selects them), region after region;
 //   * name grouping: STABLE sort of the records by QNAME, bytewise (LC_ALL=C `sort -k1,1 -s`): parallel chunk sorts + merges.
 // hisat-genotype_amd/bamio.py is the pure-Python statement of the same formats; tests compare the two byte for byte.
 #include <fcntl.h>
@@ -281,16 +282,94 @@ void sort_lines(std::vector<Line> &v, int n_threads) {
     if (src != &v) v.swap(*src);
 }
 
+// ---- regions (samtools view syntax) ---------------------------------------------------------------------------------
+// "name" = the whole reference; "name:l-r" / "name:l" / "name:-r" = 1-based inclusive span (commas allowed in numbers).  A string that
+// names a reference as a whole wins over its "name:span" reading (HLA contigs contain ':'), as htslib resolves it.
+struct Region {
+    std::string whole;            // the full string (matches RNAME == whole: entire reference)
+    std::string name;             // part before the last ':' when the rest parses as a span ("" = no such reading)
+    int64_t left0 = 0, right0 = INT64_MAX;
+};
+
+bool parse_span(const char *p, const char *e, int64_t &l0, int64_t &r0) {
+    auto num = [&](const char *&q, int64_t &v) {
+        bool any = false;
+        v = 0;
+        while (q < e && ((*q >= '0' && *q <= '9') || *q == ',')) {
+            if (*q != ',') { v = v * 10 + (*q - '0'); any = true; }
+            ++q;
+        }
+        return any;
+    };
+    int64_t a = 0, b = 0;
+    const bool ha = num(p, a);
+    l0 = ha ? a - 1 : 0;
+    r0 = INT64_MAX;
+    if (p == e) return ha;
+    if (*p != '-') return false;
+    ++p;
+    if (p == e) return ha;                      // "name:l-"
+    if (!num(p, b) || p != e) return false;
+    r0 = b - 1;
+    return true;
+}
+
+std::vector<Region> parse_regions(const char *regions) {
+    std::vector<Region> out;
+    if (!regions) return out;
+    const char *p = regions;
+    while (*p) {
+        const char *e = p;
+        while (*e && *e != '\n') ++e;
+        if (e > p) {
+            Region r;
+            r.whole.assign(p, e);
+            const size_t colon = r.whole.rfind(':');
+            if (colon != std::string::npos && colon > 0) {
+                int64_t l0, r0;
+                if (parse_span(r.whole.data() + colon + 1, r.whole.data() + r.whole.size(), l0, r0)) {
+                    r.name = r.whole.substr(0, colon);
+                    r.left0 = l0 < 0 ? 0 : l0;
+                    r.right0 = r0;
+                }
+            }
+            out.push_back(std::move(r));
+        }
+        p = *e ? e + 1 : e;
+    }
+    return out;
+}
+
+// does a record on reference `rname` spanning [pos0, end0] belong to region r?
+inline bool region_hit(const Region &r, const char *rname, size_t rl, int64_t pos0, int64_t end0) {
+    if (rl == r.whole.size() && memcmp(rname, r.whole.data(), rl) == 0) return true;
+    if (!r.name.empty() && rl == r.name.size() && memcmp(rname, r.name.data(), rl) == 0) return end0 >= r.left0 && pos0 <= r.right0;
+    return false;
+}
+
+// reference bases consumed by a SAM CIGAR string (M D N = X); 0 for "*"
+inline int64_t cigar_text_reflen(const char *p, const char *e) {
+    int64_t n = 0, tot = 0;
+    for (; p < e; ++p) {
+        const char c = *p;
+        if (c >= '0' && c <= '9') { n = n * 10 + (c - '0'); continue; }
+        if (c == 'M' || c == 'D' || c == 'N' || c == '=' || c == 'X') tot += n;
+        n = 0;
+    }
+    return tot;
+}
+
 }   // namespace
 
-extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int32_t region_left0, int32_t region_right0,
-                                   int32_t n_threads, char **text_out, size_t *n_bytes_out) {
+extern "C" int hgx_read_alignments(const char *path, const char *regions, int32_t n_threads, char **text_out, size_t *n_bytes_out) {
     HARGCHK(path && text_out && n_bytes_out);
     *text_out = nullptr;
     *n_bytes_out = 0;
     try {
         if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
         n_threads = std::max(1, std::min(n_threads, 64));
+        const std::vector<Region> regs = parse_regions(regions);
+        const bool filtered = regions != nullptr && regions[0] != 0;      // an empty list after parsing keeps nothing, like an unknown name
         const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         double t_prev = now();
@@ -344,12 +423,7 @@ extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int
                 refs.emplace_back((const char *)&raw[p + 4], l_name - 1);
                 p += 4 + l_name + 4;
             }
-            int region_id = -2;
-            if (region_ref) {
-                region_id = -3;                                   // names no reference: nothing passes
-                for (size_t i = 0; i < refs.size(); ++i) if (refs[i] == region_ref) { region_id = (int)i; break; }
-            }
-            std::vector<std::pair<size_t, uint32_t>> recs;     // (offset after block_size, length)
+            std::vector<std::vector<std::pair<size_t, uint32_t>>> per_region(std::max<size_t>(1, regs.size()));   // (offset after block_size, length)
             while (p < n) {
                 if (p + 4 > n) { hgx_set_error("truncated BAM record at offset %zu", p); return HGX_EPARSE; }
                 // the walk is a pointer chase through memory other cores just wrote (one cache miss per record, ~120 ns each):
@@ -362,14 +436,32 @@ extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int
                 }
                 const uint32_t bs = rd32(&raw[p]);
                 if (bs < 32 || p + 4 + bs > n) { hgx_set_error("truncated BAM record at offset %zu", p); return HGX_EPARSE; }
-                bool keep = true;
-                if (region_ref) {
-                    const int32_t rid = rdi32(&raw[p + 4]), pos = rdi32(&raw[p + 8]);
-                    keep = rid == region_id && pos >= region_left0 && pos <= region_right0;
+                if (!filtered) per_region[0].push_back({p + 4, bs});
+                else {
+                    const unsigned char *r = &raw[p + 4];
+                    const int32_t rid = rdi32(r), pos = rdi32(r + 4);
+                    if (rid >= 0 && (size_t)rid < refs.size()) {
+                        // reference span from the CIGAR (bam_endpos: an unmapped or zero-length record counts as one base)
+                        const uint32_t l_rn = r[8], n_cig = rd16(r + 12), flag = rd16(r + 14);
+                        int64_t reflen = 0;
+                        if (!(flag & 4) && 32 + (size_t)l_rn + 4 * (size_t)n_cig <= bs) {
+                            const unsigned char *c = r + 32 + l_rn;
+                            for (uint32_t k = 0; k < n_cig; ++k) {
+                                const uint32_t v = rd32(c + 4 * k), op = v & 15;
+                                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += v >> 4;
+                            }
+                        }
+                        const int64_t end0 = (int64_t)pos + (reflen > 0 ? reflen : 1) - 1;
+                        const std::string &nm = refs[rid];
+                        for (size_t g = 0; g < regs.size(); ++g)
+                            if (region_hit(regs[g], nm.data(), nm.size(), pos, end0)) per_region[g].push_back({p + 4, bs});
+                    }
                 }
-                if (keep) recs.push_back({p + 4, bs});
                 p += 4 + (size_t)bs;
             }
+            std::vector<std::pair<size_t, uint32_t>> recs;
+            if (per_region.size() == 1) recs.swap(per_region[0]);
+            else for (auto &v : per_region) recs.insert(recs.end(), v.begin(), v.end());      // region after region, file order inside
             lap("  BAM record walk");
             const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, recs.size() / 2000 + 1));
             chunks.resize(T);
@@ -397,30 +489,37 @@ extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int
             // SAM text: records = non-empty lines that do not start with '@'
             const char *base = (const char *)raw.data(), *end = base + raw.size();
             const char *p = base;
+            std::vector<std::vector<Line>> per_region(regs.size() > 1 ? regs.size() : 0);
             while (p < end) {
                 const char *e = (const char *)memchr(p, '\n', (size_t)(end - p));
                 if (!e) e = end;
                 size_t len = (size_t)(e - p);
                 if (len && p[len - 1] == '\r') --len;
                 if (len && *p != '@') {
-                    bool keep = true;
-                    if (region_ref) {           // RNAME = 3rd field, POS = 4th (1-based)
-                        const char *f1 = (const char *)memchr(p, '\t', len);
-                        const char *f2 = f1 ? (const char *)memchr(f1 + 1, '\t', len - (size_t)(f1 + 1 - p)) : nullptr;
-                        const char *f3 = f2 ? (const char *)memchr(f2 + 1, '\t', len - (size_t)(f2 + 1 - p)) : nullptr;
-                        keep = false;
-                        if (f3) {
-                            const size_t rl = (size_t)(f3 - f2 - 1);
-                            if (rl == strlen(region_ref) && memcmp(f2 + 1, region_ref, rl) == 0) {
-                                const long pos0 = strtol(f3 + 1, nullptr, 10) - 1;
-                                keep = pos0 >= region_left0 && pos0 <= region_right0;
-                            }
+                    if (!filtered) { Line l; make_line(p, len, l); lines.push_back(l); }
+                    else {           // FLAG = 2nd field, RNAME = 3rd, POS = 4th (1-based), CIGAR = 6th
+                        const char *f[6];
+                        const char *q = p, *le = p + len;
+                        int nf = 0;
+                        while (nf < 6 && (q = (const char *)memchr(q, '\t', (size_t)(le - q))) != nullptr) f[nf++] = ++q;
+                        if (nf == 6) {
+                            const long flag = strtol(f[0], nullptr, 10);
+                            const int64_t pos0 = strtol(f[2], nullptr, 10) - 1;
+                            const int64_t reflen = (flag & 4) ? 0 : cigar_text_reflen(f[4], f[5] - 1);
+                            const int64_t end0 = pos0 + (reflen > 0 ? reflen : 1) - 1;
+                            const size_t rl = (size_t)(f[2] - 1 - f[1]);
+                            for (size_t g = 0; g < regs.size(); ++g)
+                                if (region_hit(regs[g], f[1], rl, pos0, end0)) {
+                                    Line l;
+                                    make_line(p, len, l);
+                                    if (per_region.empty()) lines.push_back(l); else per_region[g].push_back(l);
+                                }
                         }
                     }
-                    if (keep) { Line l; make_line(p, len, l); lines.push_back(l); }
                 }
                 p = e + 1;
             }
+            for (auto &v : per_region) lines.insert(lines.end(), v.begin(), v.end());
         }
         lap("decode / split");
         sort_lines(lines, n_threads);

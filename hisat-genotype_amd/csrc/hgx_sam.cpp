@@ -1130,19 +1130,18 @@ extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *s
     return parse_text(out, Lc, sam, nullptr, n_bytes, opts);
 }
 
-extern "C" int hgx_read_alignments(const char *path, const char *region_ref, int32_t region_left0, int32_t region_right0,
-                                   int32_t n_threads, char **text_out, size_t *n_bytes_out);
+extern "C" int hgx_read_alignments(const char *path, const char *regions, int32_t n_threads, char **text_out, size_t *n_bytes_out);
 extern "C" int hgx_free_text(char *text);
 
-extern "C" int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *Lc, const char *path, const char *region_ref,
-                                        int32_t region_left0, int32_t region_right0, const hgx_parse_opts *opts) {
+extern "C" int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *Lc, const char *path, const char *regions,
+                                        const hgx_parse_opts *opts) {
     HARGCHK(out && Lc && path && opts);
     char *text = nullptr;
     size_t n = 0;
     const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    int rc = hgx_read_alignments(path, region_ref, region_left0, region_right0, opts->n_threads, &text, &n);
+    int rc = hgx_read_alignments(path, regions, opts->n_threads, &text, &n);
     if (rc) return rc;
     const double t1 = now();
     rc = parse_text(out, Lc, nullptr, text, n, opts);        // tokenises the reader's buffer in place

@@ -70,7 +70,10 @@ def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, ix_dir=No
         if isinstance(sam, (bytes, bytearray)) or "\t" in sam:
             return (sample_id, gene), type_locus(packed[gene], sam, stream=stream, heavy_lock=heavy, **typing_opts)
         # a SAM / BAM path: read, grouped and decoded inside libhgx
-        return (sample_id, gene), type_locus(packed[gene], None, alignment_file=sam, stream=stream, heavy_lock=heavy, **typing_opts)
+        # (the view is restricted to the gene's backbone, as the reference's `samtools view F ref_allele` does, core:443-444)
+        opts = dict(typing_opts)
+        opts.setdefault("regions", [packed[gene].ref_allele])
+        return (sample_id, gene), type_locus(packed[gene], None, alignment_file=sam, stream=stream, heavy_lock=heavy, **opts)
 
     if inflight <= 1 or len(mine) <= 1:
         for task in mine:

@@ -70,6 +70,7 @@ class PackedLocus:
     def __init__(self, gene, base_fname, ref_seq, Vars, Var_list, Links, Gene_names, Gene_lengths, exons,
                  Genes_keys=None):
         self.gene, self.base_fname = gene, base_fname
+        self.ref_allele = gene + "*BACKBONE"        # RNAME of this locus in a graph alignment (refGenes[gene], core:385)
         self.ref_seq = ref_seq
         names = [n for n in Gene_names if n.find("BACKBONE") == -1 and
                  not (base_fname == "genome" and n.find("GRCh38") != -1)]
@@ -149,7 +150,7 @@ class PackedLocus:
         k = self._keep
         np.savez_compressed(
             path, version=np.int32(self.CACHE_VERSION), gene=np.array(self.gene), base_fname=np.array(self.base_fname),
-            ref_seq=np.frombuffer(k["bb"], np.uint8), names=np.array("\0".join(self.names)),
+            ref_allele=np.array(self.ref_allele), ref_seq=np.frombuffer(k["bb"], np.uint8), names=np.array("\0".join(self.names)),
             names_pool=np.frombuffer(k["names_pool"], np.uint8), ins_pool=np.frombuffer(k["ins_pool"], np.uint8),
             n_link_order=np.int32(self._n_link_order),
             **{n: k[n] for n in ("pos", "typ", "ln", "base", "linked", "off", "flat", "link_order", "ex", "rank", "lengths")})
@@ -161,6 +162,7 @@ class PackedLocus:
             raise ValueError("index cache %s has version %d, expected %d" % (path, int(z["version"]), cls.CACHE_VERSION))
         self = cls.__new__(cls)
         self.gene, self.base_fname = str(z["gene"]), str(z["base_fname"])
+        self.ref_allele = str(z["ref_allele"]) if "ref_allele" in z.files else self.gene + "*BACKBONE"
         self.ref_seq = z["ref_seq"].tobytes().decode()
         self.names = str(z["names"]).split("\0") if str(z["names"]) else []
         self.aidx = {n: i for i, n in enumerate(self.names)}
@@ -180,8 +182,10 @@ class PackedLocus:
     def from_reference_dicts(cls, gene, base_fname, refGenes, Genes, Gene_names, Gene_lengths, refGene_loci, Vars,
                              Var_list, Links):
         ref_allele = refGenes[gene]
-        return cls(gene, base_fname, Genes[gene][ref_allele], Vars.get(gene, {}), Var_list.get(gene, []), Links,
+        self = cls(gene, base_fname, Genes[gene][ref_allele], Vars.get(gene, {}), Var_list.get(gene, []), Links,
                    Gene_names[gene], Gene_lengths[gene], refGene_loci[gene][-2], set(Genes[gene].keys()))
+        self.ref_allele = ref_allele
+        return self
 
     @classmethod
     def from_synth(cls, locus):
@@ -252,20 +256,19 @@ class PackedLocus:
         capi.check(capi.lib().hgx_parse_sam(C.byref(h), self.h, data, C.c_size_t(len(data)), C.byref(o)))
         return Batch(h)
 
-    def parse_alignment_file(self, path, region=None, num_editdist=2, error_correction=True, allow_discordant=False,
+    def parse_alignment_file(self, path, regions=None, num_editdist=2, error_correction=True, allow_discordant=False,
                              simulation=False, base_locus=0, n_threads=0):
         """Front-end straight from a SAM / BAM file (hgx_parse_alignment_file): read, inflate, decode, region filter, name
-        grouping and piece extraction without the text ever passing through Python.  region = "chr:left-right" (1-based)."""
-        reg = None
-        if region:
-            name, span = region.rsplit(":", 1)
-            lo, hi = span.split("-")
-            reg = (name.encode(), int(lo) - 1, int(hi) - 1)
+        grouping and piece extraction without the text ever passing through Python.  `regions`: samtools region strings
+        ("name" or "name:left-right", 1-based; a list or one newline-separated string), None = every record."""
+        if regions is not None and not isinstance(regions, (str, bytes)):
+            regions = "\n".join(regions)
+        if isinstance(regions, str):
+            regions = regions.encode()
         o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus, 0,
                            int(self.base_fname == "codis" and self.gene == "D18S51"), int(n_threads))
         h = C.c_void_p()
-        capi.check(capi.lib().hgx_parse_alignment_file(C.byref(h), self.h, path.encode(), reg[0] if reg else None,
-                                                       C.c_int32(reg[1] if reg else 0), C.c_int32(reg[2] if reg else 0), C.byref(o)))
+        capi.check(capi.lib().hgx_parse_alignment_file(C.byref(h), self.h, path.encode(), regions or None, C.byref(o)))
         return Batch(h)
 
     def close(self):

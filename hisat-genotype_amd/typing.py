@@ -120,12 +120,13 @@ class LocusResult:
 
 def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discordant=False,
                remove_low_abundance_alleles=True, simulation=False, base_locus=0, keep_classes=False, stream=None,
-               alignment_file=None, region=None, heavy_lock=None):
+               alignment_file=None, regions=None, heavy_lock=None):
     """Per-locus typing: the reference's loop body with the O(alleles) work on the GPU.  Input: name-grouped SAM text
-    (`sam_text`), or `alignment_file` (SAM / BAM, optional "chr:left-right" region) read inside libhgx."""
+    (`sam_text`), or `alignment_file` (SAM / BAM; `regions` = samtools region strings, see read_alignment_text) read inside
+    libhgx."""
     res = LocusResult()
     if alignment_file is not None:
-        batch = pl.parse_alignment_file(alignment_file, region, num_editdist=num_editdist, error_correction=error_correction,
+        batch = pl.parse_alignment_file(alignment_file, regions, num_editdist=num_editdist, error_correction=error_correction,
                                         allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus)
     else:
         batch = pl.parse_sam(sam_text, num_editdist=num_editdist, error_correction=error_correction,
@@ -390,22 +391,21 @@ def report_lines(res, simulation=False, true_alleles=(), output_allele_counts=Fa
     return out, success
 
 
-def read_alignment_text(alignment_fname, region=None, n_threads=0, native=True):
-    """The record stream the reference's loop consumes: ``samtools view F [region]`` piped through
+def read_alignment_text(alignment_fname, regions=None, n_threads=0, native=True):
+    """The record stream the reference's loop consumes: ``samtools view F [chr:l-r] ref_allele`` piped through
     ``sort -k1,1 -s`` (core:436-468), as bytes.  SAM text and BAM files are read by the native reader of libhgx
-    (hgx_read_alignments: parallel BGZF inflate, BAM decode and name grouping; no samtools needed).  ``native=False``
-    uses the pure-Python statement of the same formats (bamio.py), kept for tests."""
-    reg = None
-    if region:
-        name, span = region.rsplit(":", 1)          # "chr:left-right", 1-based inclusive
-        lo, hi = span.split("-")
-        reg = (name, int(lo) - 1, int(hi) - 1)
+    (hgx_read_alignments: parallel BGZF inflate, BAM decode, region overlap filter and name grouping; no samtools needed).
+    `regions`: samtools region strings (list, or newline-separated), None = every record.  ``native=False`` uses the
+    pure-Python statement of the same formats and rules (bamio.py), kept for tests."""
+    from . import bamio
+    if regions is not None and not isinstance(regions, (str, bytes)):
+        regions = "\n".join(regions)
     if native:
         import ctypes as C
         text, nbytes = C.c_void_p(), C.c_size_t(0)
-        capi.check(capi.lib().hgx_read_alignments(alignment_fname.encode(), reg[0].encode() if reg else None,
-                                                  C.c_int32(reg[1] if reg else 0), C.c_int32(reg[2] if reg else 0),
-                                                  C.c_int32(n_threads), C.byref(text), C.byref(nbytes)))
+        reg = regions.encode() if isinstance(regions, str) else regions
+        capi.check(capi.lib().hgx_read_alignments(alignment_fname.encode(), reg or None, C.c_int32(n_threads),
+                                                  C.byref(text), C.byref(nbytes)))
         try:
             return C.string_at(text.value, nbytes.value)
         finally:
@@ -413,14 +413,27 @@ def read_alignment_text(alignment_fname, region=None, n_threads=0, native=True):
     with open(alignment_fname, "rb") as f:
         head = f.read(4)
     if head[:2] == b"\x1f\x8b" or head == b"BAM\x01":
-        from . import bamio
-        data = ("\n".join(bamio.read_bam(alignment_fname, reg)) + "\n").encode()
+        lines = [l.encode() for l in bamio.read_bam(alignment_fname, regions)]
     else:
         with open(alignment_fname, "rb") as f:
             data = f.read()
-    lines = [l for l in data.split(b"\n") if l and not l.startswith(b"@")]
-    lines.sort(key=lambda l: l.split(None, 1)[0])      # stable; bytewise like LC_ALL=C sort -k1,1 -s
-    return b"\n".join(lines) + b"\n"
+        lines = [l[:-1] if l.endswith(b"\r") else l for l in data.split(b"\n")]
+        lines = [l for l in lines if l and not l.startswith(b"@")]
+        regs = bamio.normalise_regions(regions)
+        if regs is not None:
+            per_region = [[] for _ in regs]
+            for l in lines:
+                f = l.split(b"\t")
+                if len(f) < 7:
+                    continue
+                flag, pos0 = int(f[1]), int(f[3]) - 1
+                reflen = 0 if (flag & 4) else bamio.cigar_reflen(f[5].decode())
+                for g, r in enumerate(regs):
+                    if bamio.region_hit(r, f[2].decode(), pos0, pos0 + max(reflen, 1) - 1):
+                        per_region[g].append(l)
+            lines = [l for v in per_region for l in v]
+    lines.sort(key=lambda l: l.split(b"\t", 1)[0])      # stable; bytewise like LC_ALL=C sort -k1,1 -s
+    return b"".join(l + b"\n" for l in lines)
 
 
 def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partial, partial_alleles, refGenes, Genes,
@@ -463,15 +476,18 @@ def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partia
                 gene = test_Gene_names[0].split("*")[0] if simulation else test_Gene_names
                 pl = PackedLocus.from_reference_dicts(gene, base_fname, refGenes, Genes, Gene_names, Gene_lengths,
                                                       refGene_loci, Vars, Var_list, Links)
-                region, base_locus = None, 0
+                # samtools view F [chr:l-r] ref_allele (core:436-444): the view is ALWAYS restricted to this gene's backbone
+                # sequence -- a multi-locus alignment (hla graph: A, B, C, ... in one BAM) never leaks other genes' reads
+                # into this gene's decode -- and in genotype-genome mode to the locus span on the chromosome as well
+                regions, base_locus = [refGenes[gene]], 0
                 if genotype_genome != "":
                     _, chr_, left, right = refGene_loci[gene][:4]
-                    region, base_locus = "%s:%d-%d" % (chr_, left + 1, right + 1), left
-                # samtools view F [region] piped through sort -k1,1 -s (core:436-468), and the loop's decode: all inside libhgx
+                    regions, base_locus = ["%s:%d-%d" % (chr_, left + 1, right + 1), refGenes[gene]], left
+                # ... piped through sort -k1,1 -s (core:458-468), and the loop's decode: all inside libhgx
                 res = type_locus(pl, None, num_editdist=num_editdist, error_correction=error_correction,
                                  allow_discordant=allow_discordant,
                                  remove_low_abundance_alleles=remove_low_abundance_alleles, simulation=simulation,
-                                 base_locus=base_locus, alignment_file=alignment_fname, region=region)
+                                 base_locus=base_locus, alignment_file=alignment_fname, regions=regions)
                 pl.close()
                 if res.num_reads <= 0:
                     continue

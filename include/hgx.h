@@ -301,19 +301,26 @@ typedef struct hgx_parse_opts {
 int hgx_parse_sam(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts);
 
 /* ---- 8f-3: alignment ingestion without samtools --------------------------------------------------------
- * The record stream the reference's loop consumes -- `samtools view <file> [chr:left-right]` piped through
+ * The record stream the reference's loop consumes -- `samtools view <file> [chr:left-right] <ref_allele>` piped through
  * `sort -k1,1 -s` (typing_core.py:436-468) -- from a SAM text file or a BAM file: BGZF blocks inflated in parallel (zlib),
- * BAM records decoded to SAM text (mandatory fields + tags A c C s S i I f Z H B), header lines dropped, records of
- * reference `region_ref_or_null` with 0-based POS in [region_left0, region_right0] kept (NULL = all), then grouped by a
- * STABLE bytewise sort on QNAME.  *text_out is a library-owned (pooled), NUL-terminated buffer of *n_bytes_out bytes (every record ends
+ * BAM records decoded to SAM text (mandatory fields + tags A c C s S i I f Z H B), header lines dropped, then grouped by a
+ * STABLE bytewise sort on QNAME.
+ * `regions_or_null`: NULL or "" = every record; otherwise one or more regions in samtools syntax separated by '\n' -- "name"
+ * (the whole reference sequence) or "name:left-right" (1-based, inclusive; "name:left" and "name:-right" too).  As with
+ * `samtools view file r1 r2`, the records that OVERLAP a region (reference span taken from the CIGAR; an unmapped or
+ * zero-length record counts as one base at POS) come out region after region, in file order inside a region, before the name
+ * sort; a string that names a reference as a whole wins over its "name:span" reading (HLA contig names contain ':').  The
+ * reference always passes the locus backbone (`alignview_cmd += [ref_allele]`, core:443-444), and in genotype-genome mode
+ * the locus span in front of it (core:438-441): typing() here does the same, so reads of other loci in a multi-locus
+ * alignment never reach this locus' decode.
+ * *text_out is a library-owned (pooled), NUL-terminated buffer of *n_bytes_out bytes (every record ends
  * in '\n'), ready for hgx_parse_sam; release it with hgx_free_text (not free()).  n_threads <= 0: all host threads (at most 64). */
-int hgx_read_alignments(const char *path, const char *region_ref_or_null, int32_t region_left0, int32_t region_right0,
-                        int32_t n_threads, char **text_out, size_t *n_bytes_out);
+int hgx_read_alignments(const char *path, const char *regions_or_null, int32_t n_threads, char **text_out, size_t *n_bytes_out);
 int hgx_free_text(char *text);
 /* hgx_read_alignments + hgx_parse_sam in one call: the reader's buffer is tokenised in place (no copy, no trip through the
  * caller) -- the whole host side from an alignment file to the piece batch */
-int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *loc, const char *path, const char *region_ref_or_null,
-                             int32_t region_left0, int32_t region_right0, const hgx_parse_opts *opts);
+int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *loc, const char *path, const char *regions_or_null,
+                             const hgx_parse_opts *opts);
 /* per kept record: "cmp_list2 \t cmp_left \t cmp_right \t left alts \t right alts" (keep_trace) */
 int hgx_batch_trace_text(const hgx_batch *b, char *buf, size_t cap, size_t *needed);
 /* pileup nt_set per backbone position as a 4-bit mask A=1,C=2,G=4,T=8 and counts[L][6] (A,C,G,T,N,D) */

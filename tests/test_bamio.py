@@ -36,8 +36,18 @@ def test_bam_region_filter_and_sorting(tmp_path):
     text = read_alignment_text(path).decode().split("\n")
     names = [l.split("\t")[0] for l in text if l]
     assert names == sorted(names)                        # sort -k1,1 -s equivalent
-    sub = bamio.read_bam(path, (loc.ref_allele, 1000, 2000))
-    assert sub and all(1000 <= int(l.split("\t")[3]) - 1 <= 2000 for l in sub)
+    sub = bamio.read_bam(path, ["%s:1001-2001" % loc.ref_allele])      # 1-based inclusive = 0-based [1000, 2000]
+    assert sub
+    for l in sub:                                                       # every kept record OVERLAPS the span ...
+        f = l.split("\t")
+        pos0 = int(f[3]) - 1
+        assert pos0 <= 2000 and pos0 + max(bamio.cigar_reflen(f[5]), 1) - 1 >= 1000
+    kept = set(sub)                                                     # ... and every dropped one does not
+    for l in bamio.read_bam(path):
+        if l not in kept:
+            f = l.split("\t")
+            pos0 = int(f[3]) - 1
+            assert pos0 > 2000 or pos0 + max(bamio.cigar_reflen(f[5]), 1) - 1 < 1000
 
 
 def test_corrupt_block_is_detected(tmp_path):
@@ -189,3 +199,91 @@ def test_reader_edge_inputs(tmp_path):
         f.write(b"r1\t0\tx\t1\t0\t1M\t*\t0\t0\tA\tI\n")
     with pytest.raises(capi.HgxError):
         read_alignment_text(p)
+
+
+def _rec(qname, flag, rname, pos1, cigar, seq_len=10):
+    return "\t".join([qname, str(flag), rname, str(pos1), "60", cigar, "*", "0", "0", "A" * seq_len, "I" * seq_len, "NM:i:0"])
+
+
+def test_region_semantics_follow_samtools_view(tmp_path):
+    """`samtools view F r1 r2` (typing_core.py:436-444): records that OVERLAP a region, region after region; a read that
+    starts before `left` but reaches into the span is kept (the POS-only rule dropped it); deletions and skips
+    extend the span, insertions / clips do not; unmapped mates count as one base; a reference whose NAME contains ':' is
+    matched as a whole before any "name:span" reading.  Native reader == Python reader on BAM and on SAM text."""
+    from hisatgenotype_amd.typing import read_alignment_text
+    refs = [("A*BACKBONE", 5000), ("HLA:B*07", 5000), ("chr6", 100000)]
+    recs = [
+        _rec("r01", 0, "chr6", 991, "10M"),            # [990, 999] ends exactly at left0 - 1 of chr6:1001-2000 -> out
+        _rec("r02", 0, "chr6", 992, "10M"),            # [991, 1000] touches left0 = 1000 -> in
+        _rec("r03", 0, "chr6", 985, "5M10D5M"),        # deletion extends the span: [984, 1003] -> in
+        _rec("r04", 0, "chr6", 985, "5M10I5M", 20),    # insertion does not: [984, 993] -> out
+        _rec("r05", 0, "chr6", 2000, "10M"),           # starts at right0 = 1999 -> in
+        _rec("r06", 0, "chr6", 2001, "10M"),           # starts past the span -> out
+        _rec("r07", 4, "chr6", 1500, "*"),             # unmapped, placed at its mate: one base -> in
+        _rec("r08", 0, "chr6", 900, "5S10M200N10M", 25),   # spliced over the left edge -> in
+        _rec("r09", 0, "A*BACKBONE", 100, "10M"),
+        _rec("r10", 0, "HLA:B*07", 100, "10M"),
+        _rec("r11", 0, "HLA:B*07", 3000, "10M"),
+        _rec("r00", 0, "A*BACKBONE", 4000, "10M"),
+    ]
+    text = "\n".join(recs) + "\n"
+    bam, sam = str(tmp_path / "m.bam"), str(tmp_path / "m.sam")
+    bamio.write_bam(bam, text, refs, block_size=300)
+    open(sam, "w").write("".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs) + text)
+
+    def names(path, regions):
+        a = read_alignment_text(path, regions, native=True)
+        assert a == read_alignment_text(path, regions, native=False)
+        return [l.split(b"\t")[0].decode() for l in a.split(b"\n") if l]
+
+    for path in (bam, sam):
+        assert names(path, ["chr6:1001-2000"]) == ["r02", "r03", "r05", "r07", "r08"]
+        assert names(path, ["chr6:1,001-2,000"]) == ["r02", "r03", "r05", "r07", "r08"]
+        assert names(path, ["chr6"]) == ["r01", "r02", "r03", "r04", "r05", "r06", "r07", "r08"]
+        assert names(path, ["chr6:2001"]) == ["r05", "r06"]                 # open end
+        assert names(path, ["chr6:-1000"]) == ["r01", "r02", "r03", "r04", "r08"]  # open start ([0, 999])
+        assert names(path, ["A*BACKBONE"]) == ["r00", "r09"]                # name-sorted after the filter
+        assert names(path, ["HLA:B*07"]) == ["r10", "r11"]                  # ':' inside a name: whole reference
+        assert names(path, ["HLA:B*07:2000-4000"]) == ["r11"]
+        assert names(path, ["chr6:1001-2000", "A*BACKBONE"]) == ["r00", "r02", "r03", "r05", "r07", "r08", "r09"]
+        assert names(path, ["nosuch", "nosuch:1-10"]) == []
+        assert names(path, None) == sorted(r.split("\t")[0] for r in recs)
+    # region after region BEFORE the stable name sort: same-named records keep region order, then file order
+    dup = "\n".join([_rec("q", 0, "chr6", 1500, "10M"), _rec("q", 16, "A*BACKBONE", 7, "10M"), _rec("q", 0, "chr6", 1400, "10M")]) + "\n"
+    bamio.write_bam(bam, dup, refs)
+    for native in (True, False):
+        got = read_alignment_text(bam, ["A*BACKBONE", "chr6:1-5000"], native=native).decode().split("\n")[:-1]
+        assert [(l.split("\t")[2], l.split("\t")[3]) for l in got] == [("A*BACKBONE", "7"), ("chr6", "1500"), ("chr6", "1400")]
+
+
+def test_multi_locus_alignment_is_restricted_to_the_gene_backbone(tmp_path):
+    """typing() must read only the records on this gene's backbone (`alignview_cmd += [ref_allele]`,
+    typing_core.py:443-444).  Two genes in one file: the front-end of gene A sees exactly gene A's records, from BAM and
+    from SAM text, through parse_alignment_file and through the text path."""
+    import numpy as np
+    from hisatgenotype_amd import locus as hl
+    fx = gu.load("hla_small_pair")
+    loc = fx["_locus"]
+    pl = hl.PackedLocus.from_synth(loc)
+    assert pl.ref_allele == loc.ref_allele
+    own = [l for l in fx["sam"].split("\n") if l]
+    other_name = "B*BACKBONE"
+    other = []
+    for l in own:                                         # the same reads, renamed, on another gene's backbone
+        f = l.split("\t")
+        f[0] = "o" + f[0]
+        f[2] = other_name
+        other.append("\t".join(f))
+    mixed = [x for pair in zip(own, other) for x in pair]
+    bam, sam = str(tmp_path / "two.bam"), str(tmp_path / "two.sam")
+    refs = [(loc.ref_allele, len(loc.backbone)), (other_name, len(loc.backbone))]
+    bamio.write_bam(bam, "\n".join(mixed) + "\n", refs, block_size=4000)
+    open(sam, "w").write("\n".join(mixed) + "\n")
+    sim = bool(fx.get("simulation", False))
+    ref = pl.parse_sam("\n".join(own) + "\n", simulation=sim)
+    for path in (bam, sam):
+        got = pl.parse_alignment_file(path, [pl.ref_allele], simulation=sim)
+        assert (got.n_reads, got.n_pairs, got.n_pieces, got.n_refs) == (ref.n_reads, ref.n_pairs, ref.n_pieces, ref.n_refs)
+        assert np.array_equal(got.pieces, ref.pieces) and np.array_equal(got.pair_ref, ref.pair_ref)
+        both = pl.parse_alignment_file(path, None, simulation=sim)          # unfiltered: the other gene's reads leak in
+        assert both.n_reads == 2 * ref.n_reads
