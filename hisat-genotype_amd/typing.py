@@ -441,13 +441,12 @@ def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partia
            error_correction, keep_alignment, allow_discordant, type_primary_exons, remove_low_abundance_alleles,
            display_alleles, fastq, read_fname, alignment_fname, num_frag_list, read_len, fragment_len, threads,
            best_alleles, verbose, assembly_verbose, out_dir, dbversion, output_allele_counts, test_i=0):
-    """Same contract as hisatgenotype_typing_core.typing (core:249-286) for graph alignments that already
-    exist (``alignment_fname``): writes ``<out_dir>/<output_base>-<base>.<id>.report``; returns
-    ``test_passed`` in simulation mode.  Aligning reads (hisat2) and --assembly are outside this path."""
+    """Same contract as hisatgenotype_typing_core.typing (core:249-286): writes
+    ``<out_dir>/<output_base>-<base>.<id>.report``; returns ``test_passed`` in simulation mode.  With
+    ``alignment_fname == ""`` the reads are aligned first (simulate.align_reads: HISAT2 when installed; simulated reads are
+    placed by the alignment their names spell).  --assembly is outside this path."""
     if assembly:
         raise NotImplementedError("--assembly (assembly graph) is outside the accelerated path")
-    if alignment_fname == "":
-        raise NotImplementedError("read alignment (hisat2) is outside the accelerated path: pass alignment_fname")
     base_fname = full_path_base_fname.split("/")[-1]
     report_base = "%s/%s-%s." % (out_dir, output_base, base_fname)
     test_passed = {}
@@ -472,6 +471,14 @@ def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partia
             if index_type != "graph":
                 raise NotImplementedError("only graph alignments are on the accelerated path")
             say("\n\t\t%s %s" % (aligner, index_type))
+            remove_alignment_file = False
+            if alignment_fname == "":                     # core:346-367: align the reads first
+                from . import simulate
+                remove_alignment_file = True
+                alignment_fname = "%s_output.bam" % base_fname if simulation else "%s.bam" % core_fid
+                gegenome = genotype_genome if genotype_genome != "" else full_path_base_fname + "." + index_type
+                simulate.align_reads(aligner, simulation, gegenome, index_type, base_fname, read_fname, fastq, threads,
+                                     alignment_fname, verbose, truth=(Genes, Vars, refGenes))
             for test_Gene_names in locus_list:
                 gene = test_Gene_names[0].split("*")[0] if simulation else test_Gene_names
                 pl = PackedLocus.from_reference_dicts(gene, base_fname, refGenes, Genes, Gene_names, Gene_lengths,
@@ -500,5 +507,9 @@ def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partia
                         if ok:
                             key = "%s %s" % (aligner, index_type)
                             test_passed[key] = test_passed.get(key, 0) + 1
+            if not keep_alignment and remove_alignment_file:                   # core:2144-2145
+                for f in [alignment_fname] + [alignment_fname + ext for ext in (".bai", ".unsorted")]:
+                    if os.path.exists(f):
+                        os.remove(f)
     if simulation:
         return test_passed

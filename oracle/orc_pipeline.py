@@ -35,10 +35,14 @@ def run(orc, t, arrs, hla, lengths, remove_low=True):
     t1 = time.perf_counter()
     gub, guc, _ = orc.dedup(gb)
     n_iter = 0
+    ems = []                     # per single_abundance call: (n_classes, n_iter, [(allele index, prob)])
+    out["gene_classes"] = (gub, guc)
     if hla:
         eub, euc, _ = orc.dedup(eb)
+        out["exon_classes"] = (eub, euc)
         t2 = time.perf_counter()
         exon_prob, it = em_sorted(orc, t, eub, euc, remove_low, None)
+        ems.append((len(euc), it, exon_prob))
         n_iter += it
         gene_prob = exon_prob
         aidx, groups = t["aidx"], t["rep_groups"]
@@ -57,6 +61,7 @@ def run(orc, t, arrs, hla, lengths, remove_low=True):
                 mask[a >> 6] |= np.uint64(1) << np.uint64(a & 63)
             g2b, g2c, _ = orc.dedup(gub, weight=guc, and_mask=mask)
             gp, it = em_sorted(orc, t, g2b, g2c, True, lengths)
+            ems.append((len(g2c), it, gp))
             n_iter += it
             comb = {}
             for a, p in exon_prob:
@@ -68,8 +73,9 @@ def run(orc, t, arrs, hla, lengths, remove_low=True):
     else:
         t2 = time.perf_counter()
         gene_prob, it = em_sorted(orc, t, gub, guc, False, None)
+        ems.append((len(guc), it, gene_prob))
         n_iter += it
     t3 = time.perf_counter()
     out.update(t_score=t1 - t0, t_dedup=t2 - t1, t_em=t3 - t2, n_iter=n_iter, gene_prob=list(gene_prob),
-               gene_counts=gc, first_pair=fp)
+               gene_counts=gc, first_pair=fp, em=ems)
     return out

@@ -30,6 +30,7 @@ import stat
 import subprocess
 import sys
 import tempfile
+import time
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
@@ -354,6 +355,18 @@ def hla_7000():
 
 
 @scenario
+def hla_7000_10k():
+    """BASELINE.json configs[0]: HLA-A-like, ~7 000 alleles, 10 k simulated 2x150 bp reads through the reference's own
+    CPU path.  Lean fixture (SAM, EM calls with their class dicts, report; no per-record traces) + the reference's wall
+    time on this container's CPU: the true-reference baseline of BASELINE.md."""
+    loc = synth.make_hla_like_locus(n_alleles=7000, n_vars=2500, seed=101)
+    sample = synth.pick_sample(loc, 101)
+    sam = synth.simulate_sam_fast(loc, sample, 5000, err_rate=0.002, seed=100)
+    return dict(locus=loc, sample=sample, sam=sam, simulation=False, store_locus=False, lean=True,
+                locus_params=dict(n_alleles=7000, n_vars=2500, seed=101))
+
+
+@scenario
 def codis_like():
     loc = synth.make_str_like_locus()
     sample = ["D8S1179*10", "D8S1179*13"]
@@ -383,13 +396,18 @@ def main():
         for name in names:
             sc = SCENARIOS[name]()
             loc = sc["locus"]
-            sam = synth.sam_text(loc, sc["al"])
+            sam = sc["sam"] if "sam" in sc else synth.sam_text(loc, sc["al"])
+            lean = bool(sc.get("lean"))
+            t_ref = time.perf_counter()
             cap, report, err = run_reference(
                 core, common, loc, sam, simulation=sc["simulation"], sample=sc["sample"],
                 error_correction=sc.get("error_correction", True),
                 allow_discordant=sc.get("allow_discordant", False), remove_low=sc.get("remove_low", True),
                 read_len=sc.get("read_len", 150), frag_len=sc.get("frag_len", 400),
-                workdir=os.path.join(tmp, "work_" + name))
+                workdir=os.path.join(tmp, "work_" + name), profile_closures=not lean)
+            t_ref = time.perf_counter() - t_ref
+            if lean:                         # keep the EM calls and the report only
+                cap.pairs, cap.records, cap.ec, cap.alts, cap.mpileup = [], [], [], None, None
             cls_keys = []
             for p in cap.pairs:
                 cls_keys += [p["cls"].get("exon", ""), p["cls"].get("gene", "")]
@@ -426,6 +444,16 @@ def main():
                 "em": ems,
                 "report": report,
             }
+            if lean:
+                n_rec = sum(1 for l in sam.split("\n") if l)
+                cpu = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")]
+                fx["reference_timing"] = {
+                    "what": "hisatgenotype_typing_core.typing() on this SAM (samtools stub = grep), one process, wrappers on "
+                            "single_abundance / get_mpileup / identify_ambigious_diffs / error_correct only (no profile hook)",
+                    "seconds": round(t_ref, 2), "sam_records": n_rec, "records_per_s": round(n_rec / t_ref, 1),
+                    "cpu": cpu[0] if cpu else "unknown", "cores_used": 1, "python": sys.version.split()[0]}
+                print("   reference wall time %.1f s for %d records = %.1f records/s on %s" % (
+                    t_ref, n_rec, n_rec / t_ref, fx["reference_timing"]["cpu"]))
             out = os.path.join(HERE, name + ".json.gz")
             with gzip.GzipFile(out, "wb", mtime=0) as f:
                 f.write(json.dumps(fx, separators=(",", ":")).encode())
