@@ -47,6 +47,33 @@ def test_type_locus_matches_reference(name):
     assert keep(lines) == keep(fx["report"].split("\n"))
 
 
+def test_config0_ten_thousand_reads_matches_reference():
+    """BASELINE configs[0]: HLA-A-like, 7 000 alleles, 10 k reads -- the run the reference itself needed 109 s for
+    (fixture `hla_7000_10k`, recorded from the real reference with its wall time).  Same classes and counts going into both
+    EM calls, same iteration counts, allele order and abundances, and the same report: with output_allele_counts the
+    report lists EVERY allele with a non-zero count, i.e. the complete integer Gene_counts table."""
+    fx = gu.load("hla_7000_10k")
+    o = fx["options"]
+    pl = hl.PackedLocus.from_synth(fx["_locus"])
+    res = hgx.type_locus(pl, fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
+                         allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
+                         simulation=o["simulation"], keep_classes=True)
+    assert len(res.em) == len(fx["em"]) == 2
+    A = pl.n_alleles
+    for got, exp, (bits, cnt) in zip(res.em, fx["em"], (res.exon_classes, None)):
+        assert got["n_classes"] == len(exp["cmpt"])
+        assert got["remove_low"] == exp["remove_low"] and got["use_length"] == exp["use_length"]
+        _check_em(got, exp["result"], exp["n_iter"], exact=got["use_length"])
+        if bits is not None:           # EM #1's input: the exon-level class dict, bit rows + counts in dict order
+            want = np.stack([gu.class_bits(fx, cid, A) for cid, _ in exp["cmpt"]])
+            assert np.array_equal(bits[:, :want.shape[1]], want) and not bits[:, want.shape[1]:].any()
+            assert cnt.tolist() == [n for _, n in exp["cmpt"]]
+    lines, _ = hgx.report_lines(res, False, (), True)
+    keep = lambda ls: [l for l in ls if "aligned" in l or "ranked" in l or "(count:" in l]
+    assert keep(lines) == keep(fx["report"].split("\n"))
+    assert len([l for l in lines if "(count:" in l]) > 1000
+
+
 @pytest.mark.parametrize("name", ["hla_small_pair", "hla_mid_real", "codis_like"])
 def test_single_abundance_dropin(name):
     """hgx.single_abundance takes the reference's dict-of-strings and returns its list-of-lists."""

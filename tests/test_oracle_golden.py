@@ -104,3 +104,35 @@ def test_filtered_reaccumulation(orc):
     assert len(ub2) == len(exp)
     for k, (cid, cnt) in enumerate(exp):
         assert np.array_equal(ub2[k], gu.class_bits(fx, cid, A)) and uc2[k] == cnt
+
+
+def test_oracle_chain_on_the_10k_read_reference_run():
+    """BASELINE configs[0] at full size (fixture `hla_7000_10k`: the real reference on 10 k reads, 7 000 alleles): the oracle
+    chain the config-sized GPU tests lean on -- pyref front-end feeding the C oracle's add_count / add_stat / dedup /
+    single_abundance / hand-off (tests/oracle_util.py) -- reproduces the reference end to end: read and pair counts, the class
+    dicts going into both EM calls (rows, counts, order), bit-identical abundances, and every (allele, count) line of the
+    report in the reference's order."""
+    import oracle_util as ou
+    fx = gu.load("hla_7000_10k")
+    loc = fx["_locus"]
+    out = ou.oracle_type(loc.to_json(), fx["sam"])
+    head = [l for l in fx["report"].split("\n") if "aligned" in l][0]
+    assert head.strip() == "%d reads and %d pairs are aligned" % (out["num_reads"], out["num_pairs"])
+    names = [n for n in loc.allele_names if "BACKBONE" not in n]
+    A = len(names)
+    assert [(c, it) for c, it, _ in out["em"]] == [(len(e["cmpt"]), e["n_iter"]) for e in fx["em"]]
+    for (c, it, res), e in zip(out["em"], fx["em"]):
+        assert [[a, repr(float(p))] for a, p in res] == e["result"]
+    eb, ec = out["exon_classes"]
+    for k, (cid, n) in enumerate(fx["em"][0]["cmpt"]):
+        assert np.array_equal(eb[k], gu.class_bits(fx, cid, A)) and ec[k] == n
+    gc, fp = out["gene_counts"], out["first_pair"]
+    order = sorted([a for a in range(A) if gc[a] > 0], key=lambda a: (fp[a], a))
+    order = sorted(order, key=lambda a: -gc[a])
+    exp = []
+    for l in fx["report"].split("\n"):
+        if "(count:" in l:
+            f = l.strip().split()
+            exp.append((f[1], int(f[3].rstrip(")"))))
+    assert [(names[a], int(gc[a])) for a in order] == exp and len(exp) > 1000
+    assert fx["reference_timing"]["sam_records"] == 10000 and fx["reference_timing"]["seconds"] > 10
