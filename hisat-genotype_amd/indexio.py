@@ -160,6 +160,132 @@ def load_index(ix_dir, base_fname):
                 dbversion=dbversion)
 
 
+def allele_sequence(index, gene, name):
+    """Sequence of one allele, built from the backbone and the allele's variants the way
+    typing_core.read_Gene_alleles_from_vars does (typing_core.py:2198-2236); `load_index` keeps only names and lengths, the
+    self-test loop of genotyping_locus needs the bases of the few alleles it simulates reads from.  Cached in
+    index["Genes"]."""
+    got = index["Genes"][gene].get(name)
+    if got is not None:
+        return got
+    per = index.get("_allele_vars", {}).get(gene)
+    if per is None:
+        per = {}
+        for _, vid in index["Var_list"].get(gene, []):
+            for a in index["Links"].get(vid, []):
+                per.setdefault(a, []).append(vid)
+        index.setdefault("_allele_vars", {})[gene] = per
+    bb = index["Genes"][gene][index["refGenes"][gene]]
+    gv = index["Vars"].get(gene, {})
+    out, prev = [], 0
+    for vid in per.get(name, []):
+        t, pos, data = gv[vid]
+        assert prev <= pos
+        out.append(bb[prev:pos])
+        if t == "single":
+            out.append(data)
+            prev = pos + 1
+        elif t == "deletion":
+            prev = pos + int(data)
+        else:
+            assert t == "insertion"
+            out.append(data)
+            prev = pos
+    out.append(bb[prev:])
+    seq = "".join(out)
+    index["Genes"][gene][name] = seq
+    return seq
+
+
+def _faidx_fetch(fa_path, chrom, left0, right0):
+    """`samtools faidx <fa> chrom:left-right` (typing_core.py:2175-2195) from the .fai index: name, length, offset, bases per
+    line, bytes per line."""
+    entry = None
+    with open(fa_path + ".fai") as f:
+        for line in f:
+            t = line.rstrip("\n").split("\t")
+            if t[0] == chrom:
+                entry = (int(t[1]), int(t[2]), int(t[3]), int(t[4]))
+                break
+    if entry is None:
+        raise ValueError("%s is not in %s.fai" % (chrom, fa_path))
+    length, offset, per_line, line_bytes = entry
+    right0 = min(right0, length - 1)
+    start = offset + (left0 // per_line) * line_bytes + left0 % per_line
+    end = offset + (right0 // per_line) * line_bytes + right0 % per_line + 1
+    with open(fa_path, "rb") as f:
+        f.seek(start)
+        raw = f.read(end - start)
+    return raw.replace(b"\n", b"").replace(b"\r", b"").decode()
+
+
+def load_genome_index(ix_dir, genotype_genome, base_fname):
+    """Dict arguments of typing() for a genotype-genome index `<ix_dir>/<genotype_genome>.*` restricted to the database
+    `base_fname`, as genotyping_locus assembles them (typing_core.py:2326-2397): `.allele` / `.partial` rows are
+    `family<TAB>name`; `.locus` rows carry the family first and genome coordinates; `.snp` positions are chromosome
+    coordinates, re-based to the locus (read_Gene_vars_genotype_genome, typing_core.py:2238-2275); the backbone of a
+    locus is its span of the genome FASTA (read_backbone_alleles, typing_core.py:2175-2195; here through the .fai index,
+    no samtools)."""
+    full = os.path.join(ix_dir, genotype_genome)
+    alleles, partial_alleles = set(), set()
+    for ext, dst in ((".allele", alleles), (".partial", partial_alleles)):
+        with open(full + ext) as f:
+            for line in f:
+                if not line.strip():
+                    continue
+                family, name = line.strip().split("\t")
+                if family == base_fname:
+                    dst.add(name)
+    refGenes, refGene_loci = read_locus(full + ".locus", True, base_fname)
+    by_chr = {}
+    for gene, v in refGene_loci.items():
+        by_chr.setdefault(v[1], []).append((v[0], v[2], v[3]))
+    Vars, Var_list = {}, {}
+    with open(full + ".snp") as f:
+        for line in f:
+            if not line.strip():
+                continue
+            var_id, var_type, var_chr, pos, data = line.rstrip("\n").split("\t")
+            pos = int(pos)
+            hit = next(((n, l, r) for n, l, r in by_chr.get(var_chr, []) if l <= pos <= r), None)
+            if hit is None:
+                continue
+            gene = hit[0].split("*")[0]
+            gv = Vars.setdefault(gene, {})
+            if var_id in gv:
+                raise ValueError("duplicate variant id %s" % var_id)
+            gv[var_id] = [var_type, pos - hit[1], data]
+            Var_list.setdefault(gene, []).append([pos - hit[1], var_id])
+    for gene in Var_list:
+        Var_list[gene].sort()
+    Links = read_links(full + ".link")
+    Genes, Gene_names, Gene_lengths = {}, {}, {}
+    for gene, (bname, chrom, left, right, _, _) in refGene_loci.items():
+        seq = _faidx_fetch(full + ".fa", chrom, left, right)
+        if len(seq) != right - left + 1:
+            raise ValueError("locus %s reaches past the end of %s" % (gene, chrom))
+        Vars.setdefault(gene, {})
+        Var_list.setdefault(gene, [])
+        per_allele = {}
+        for _, vid in Var_list[gene]:
+            for a in Links.get(vid, []):
+                per_allele.setdefault(a, []).append(vid)
+        names = [bname] + list(per_allele.keys())
+        if len(names) <= 1:
+            names.append("%s*GRCh38" % gene)
+        seen = set(names)
+        for a in sorted(x for x in alleles if x.split("*")[0] == gene and x not in seen):
+            names.append(a)
+        Genes[gene] = {n: None for n in names}
+        Genes[gene][bname] = seq
+        Gene_names[gene] = names
+        Gene_lengths[gene] = {n: _allele_length(len(seq), per_allele.get(n, []), Vars[gene]) for n in names}
+    dbversion = open(full + ".version").read() if os.path.exists(full + ".version") else "NONE"
+    return dict(refGenes=refGenes, refGene_loci=refGene_loci, Genes=Genes, Gene_names=Gene_names, Gene_lengths=Gene_lengths,
+                Vars=Vars, Var_list=Var_list, Links=Links, partial_alleles=partial_alleles, alleles=alleles,
+                dbversion=dbversion)
+
+
 def packed_locus(ix_dir, base_fname, gene, index=None, use_cache=True):
     """PackedLocus of `gene`, through the packed binary cache `<ix_dir>/<base_fname>.<gene>.hgx.npz`: the
     cache is used when it is newer than every text file of the index, rebuilt (and rewritten, best effort) otherwise."""

@@ -700,3 +700,48 @@ def write_index(loci: Sequence[Locus], ix_dir: str, base_fname: str) -> None:
                 li.write("%s\t%s\n" % (vid, " ".join(alleles)))
             for name in loc.allele_names[1:]:
                 al.write(name + "\n")
+
+
+def write_genome_index(loci: Sequence[Locus], ix_dir: str, genome_name: str, family: str, chrom: str = "6",
+                       gap: int = 500, seed: int = 1) -> Dict[str, Tuple[int, int]]:
+    """Write loci as a GENOTYPE-GENOME index `<ix_dir>/<genome_name>.*` (consumer: typing_core.py:2326-2397): one chromosome
+    = random spacer, backbone, spacer, backbone, ...; `.fa` + `.fa.fai`; `.locus` rows `FAMILY allele chrom left right exons
+    strand` in chromosome coordinates; `.snp` positions on the chromosome; `.allele` / `.partial` rows `family<TAB>name`.
+    Returns {gene: (left, right)} (0-based, inclusive)."""
+    import os
+    os.makedirs(ix_dir, exist_ok=True)
+    rng = random.Random(seed)
+    full = os.path.join(ix_dir, genome_name)
+    seq, spans = [], {}
+    pos = 0
+    for loc in loci:
+        spacer = "".join(rng.choice(_BASES) for _ in range(gap))
+        seq.append(spacer)
+        pos += gap
+        spans[loc.gene] = (pos, pos + len(loc.backbone) - 1)
+        seq.append(loc.backbone)
+        pos += len(loc.backbone)
+    seq.append("".join(rng.choice(_BASES) for _ in range(gap)))
+    chrom_seq = "".join(seq)
+    header = ">%s\n" % chrom
+    with open(full + ".fa", "w") as fa:
+        fa.write(header)
+        for i in range(0, len(chrom_seq), 60):
+            fa.write(chrom_seq[i:i + 60] + "\n")
+    with open(full + ".fa.fai", "w") as fai:
+        fai.write("%s\t%d\t%d\t60\t61\n" % (chrom, len(chrom_seq), len(header)))
+    with open(full + ".locus", "w") as lo, open(full + ".snp", "w") as sn, open(full + ".link", "w") as li, \
+            open(full + ".allele", "w") as al, open(full + ".partial", "w") as pa:
+        for loc in loci:
+            left, right = spans[loc.gene]
+            prim = {tuple(e) for e in loc.primary_exons}
+            exon_str = ",".join("%d-%d%s" % (e[0], e[1], "p" if tuple(e) in prim else "") for e in loc.exons)
+            lo.write("%s\t%s\t%s\t%d\t%d\t%s\t+\n" % (family.upper(), loc.ref_allele, chrom, left, right, exon_str))
+            for i, vid in enumerate(loc.var_ids):
+                sn.write("%s\t%s\t%s\t%d\t%s\n" % (vid, loc.var_type[i], chrom, loc.var_pos[i] + left, loc.var_data[i]))
+            for vid, alleles in loc.links.items():
+                li.write("%s\t%s\n" % (vid, " ".join(alleles)))
+            for name in loc.allele_names[1:]:
+                al.write("%s\t%s\n" % (family, name))
+        pa.write("")
+    return spans

@@ -227,6 +227,49 @@ def test_genotyping_locus_from_index_files(tmp_path):
     assert keep(rep.split("\n")) == keep(fx["report"].split("\n"))
 
 
+def test_genotyping_locus_genotype_genome_mode(tmp_path):
+    """8f-2, genotype-genome indexes (typing_core.py:2326-2397, 438-441): two loci embedded in one chromosome, the sample's
+    reads of BOTH loci in one coordinate-sorted BAM on chromosome coordinates.  Each locus must see exactly its own reads
+    (samtools' overlap rule on `chr:left-right`) re-based to the locus, and report what the stand-alone run reports."""
+    from hisatgenotype_amd import bamio
+    a = synth.make_hla_like_locus(gene="A", n_alleles=120, n_vars=320, seed=81, sibling_frac=0.3)
+    b = synth.make_hla_like_locus(gene="B", n_alleles=90, n_vars=260, length=2600, seed=82, var_id_base=7000)
+    ix_dir = str(tmp_path / "ix")
+    spans = synth.write_genome_index([a, b], ix_dir, "genotype_genome", "hla", chrom="6", gap=300, seed=4)
+    lines, expect = [], {}
+    for k, loc in enumerate((a, b)):
+        sample = synth.pick_sample(loc, 60 + k)
+        al = synth.simulate_pairs(loc, sample, 400, err_rate=0.002, seed=90 + k)
+        left = spans[loc.gene][0]
+        for l in synth.sam_text(loc, al, base_locus=left).split("\n"):
+            if l:
+                f = l.split("\t")
+                f[0] = "%s_%s" % (loc.gene, f[0])
+                f[2] = "6"
+                lines.append("\t".join(f))
+        expect[loc.gene] = pyref.RefLocus(loc).run(synth.sam_text(loc, al))
+    lines.sort(key=lambda l: int(l.split("\t")[3]))
+    bam = tmp_path / "wgs.bam"
+    bamio.write_bam(str(bam), "\n".join(lines) + "\n", [("6", spans["B"][1] + 301)])
+    hgx.genotyping_locus("hla", ["A", "B"], "genotype_genome", ix_dir, [], True, [["hisat2", "graph"]], ["wgs.fq"], True,
+                         str(bam), 1, 10, 150, 400, False, 2, 0.0, 0.0, [], False, "assembly_graph", True, True, False,
+                         False, True, [], 0, False, str(tmp_path), True, {})
+    rep = (tmp_path / "assembly_graph-hla.wgs.report").read_text().split("\n")
+    got_counts = [l.strip() for l in rep if "(count:" in l]
+    want_counts = ["%d %s (count: %d)" % (i + 1, n, c) for g in ("A", "B") for i, (n, c) in enumerate(expect[g]["counts_sorted"])]
+    assert got_counts == want_counts
+    aligned = [l.strip() for l in rep if "aligned" in l]
+    assert aligned == ["%d reads and %d pairs are aligned" % (expect[g]["num_reads"], expect[g]["num_pairs"]) for g in ("A", "B")]
+    got_ab = [l.strip() for l in rep if "abundance" in l]
+    want_ab = []
+    for g in ("A", "B"):
+        for i, (n, p) in enumerate(expect[g]["gene_prob"]):
+            if p < 0.01 or i >= 10:
+                break
+            want_ab.append("%d ranked %s (abundance: %.2f%%)" % (i + 1, n, p * 100.0))
+    assert got_ab == want_ab
+
+
 def test_run_panel_shards_tasks(tmp_path):
     """Config-4 shape at test size: samples x loci as independent tasks, split over two 'ranks' without communication."""
     from hisatgenotype_amd import indexio

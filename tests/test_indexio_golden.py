@@ -62,3 +62,28 @@ def test_packed_locus_cache_next_to_index(tmp_path):
     os.utime(os.path.join(str(tmp_path), "hla.snp"), (time.time() + 5, time.time() + 5))   # index changed after the cache was written
     indexio.packed_locus(str(tmp_path), "hla", gene)
     assert os.path.getmtime(cache) >= m0          # rebuilt from the text files and rewritten
+
+
+def test_genome_index_readers_match_reference(tmp_path):
+    """Genotype-genome index (typing_core.py:2326-2397): load_genome_index against the structures the real reference's
+    readers produced from the same files (tests/golden/make_genome_index_golden.py) -- loci in chromosome coordinates,
+    variants re-based to their locus, backbones cut out of the genome FASTA through the .fai index, allele order and lengths;
+    allele_sequence spells out alleles the way read_Gene_alleles_from_vars does."""
+    fx = json.loads(gzip.open(os.path.join(HERE, "golden", "genome_index.json.gz")).read().decode())
+    for name, text in fx["files"].items():
+        (tmp_path / name).write_text(text)
+    ix = indexio.load_genome_index(str(tmp_path), "genotype_genome", "hla")
+    assert ix["refGenes"] == fx["refGenes"]
+    assert ix["refGene_loci"] == fx["refGene_loci"]
+    assert ix["Vars"] == fx["Vars"] and ix["Var_list"] == fx["Var_list"] and ix["Links"] == fx["Links"]
+    assert sorted(ix["alleles"]) == fx["alleles"] and ix["partial_alleles"] == set()
+    for g in fx["Gene_names"]:
+        ref_names = fx["Gene_names"][g]
+        assert ix["Gene_names"][g][:len(ref_names)] == ref_names
+        assert {n: ix["Gene_lengths"][g][n] for n in ref_names} == fx["Gene_lengths"][g]
+        assert ix["Genes"][g][fx["refGenes"][g]] == fx["backbones"][g]
+        left, right = fx["spans"][g]
+        assert ix["refGene_loci"][g][2:4] == [left, right]
+        for n, seq in fx["sample_sequences"][g].items():
+            assert indexio.allele_sequence(ix, g, n) == seq
+    assert indexio.load_genome_index(str(tmp_path), "genotype_genome", "codis")["refGenes"] == {}      # another family: nothing
