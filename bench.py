@@ -47,42 +47,23 @@ def parse_args():
     return ap.parse_args()
 
 
-def step(pl, batch, db, bufs, ev=None, stream=None, heavy_lock=None):
-    """One pass of the hot path on `stream` (None = the default stream).  Returns the LocusResult."""
-    held = htyping._HeldOnce(heavy_lock) if heavy_lock is not None else None
-    try:
-        return _step(pl, batch, db, bufs, ev, stream, held)
-    finally:
-        if held is not None:
-            held.release()
-
-
-def _step(pl, batch, db, bufs, ev, stream, heavy_lock):
+def step(pl, batch, db, ev=None, stream=None, gate=None):
+    """One pass of the hot path on `stream` (None = the default stream): ONE call into libhgx (hgx_type_dbatch) over the
+    piece batch resident in HBM.  `ev` = (compat begin, compat end, pairs begin, pairs end) events.  Returns the LocusResult."""
     res = htyping.LocusResult()
     res.num_reads, res.num_pairs = batch.n_reads, batch.n_pairs
-    L = capi.lib()
-    import ctypes as C
-    if ev:
-        ev[2].record(stream)
-    capi.check(L.hgx_piece_compat(pl.index(), capi.ptr(db.pieces), capi.ptr(db.masks), C.c_int32(db.n_pieces),
-                                  capi.ptr(bufs.compat), stream))
-    if ev:
-        ev[0].record(stream)
-    # the exon level goes through hgx_level_classes (pairs grouped by ref list), the gene level's per-pair rows are
-    # computed beside the exon-level EM: both inside _type_batch; ev[3] / ev[1] bracket the per-pair launch
-    return htyping._type_batch(pl, batch, res, True, dbatch=db, bufs=bufs, scored="compat", stream=stream, overlap=True,
-                               heavy_lock=heavy_lock, pc_events=(ev[3], ev[1]) if ev else None)
+    return htyping._type_batch(pl, batch, res, True, dbatch=db, stream=stream, overlap=True, gate=gate, events=ev)
 
 
-def run_steps(pl, batch, db, bufs_list, n_steps, ev_list, timing, local_rank):
-    """n_steps passes shared by len(bufs_list) host threads (one sample in flight per thread).  Returns
+def run_steps(pl, batch, db, inflight, n_steps, ev_list, timing, local_rank):
+    """n_steps passes shared by `inflight` host threads (one sample in flight per thread).  Returns
     (last LocusResult, EM seconds summed, EM iterations summed, merged per-kernel timing)."""
     import threading
     lock = threading.Lock()
-    heavy = threading.Lock() if len(bufs_list) > 1 else None      # staggers the samples in flight (see _type_batch)
+    gate = engine.Gate() if inflight > 1 else None      # staggers the samples in flight (hgx_type_opts.gate)
     state = {"next": 0, "t_em": 0.0, "n_iter": 0, "res": None, "timing": {}, "err": None}
 
-    def work(bufs, own_stream, slot=None):
+    def work(own_stream, slot=None):
         try:
             capi.set_device(local_rank)
             if slot is not None:
@@ -98,7 +79,7 @@ def run_steps(pl, batch, db, bufs_list, n_steps, ev_list, timing, local_rank):
                 # every EM mat-vec launch of the LAST steps of the timed region is timed (dispatch-attached events); earlier
                 # steps run untimed, so the ~1 us per timed launch does not weigh on the whole region
                 engine.em_set_timing(2 if (timing and k >= n_steps - N_TIMED_STEPS) else 0)
-                res = step(pl, batch, db, bufs, ev_list[k] if ev_list else None, stream, heavy)
+                res = step(pl, batch, db, ev_list[k] if ev_list else None, stream, gate)
                 with lock:
                     state["t_em"] += res.t_em
                     state["n_iter"] += sum(e["n_iter"] for e in res.em)
@@ -113,10 +94,10 @@ def run_steps(pl, batch, db, bufs_list, n_steps, ev_list, timing, local_rank):
         except BaseException as e:     # re-raised on the main thread
             state["err"] = e
 
-    if len(bufs_list) == 1:
-        work(bufs_list[0], False)
+    if inflight <= 1:
+        work(False)
     else:
-        threads = [threading.Thread(target=work, args=(b, True, i)) for i, b in enumerate(bufs_list)]
+        threads = [threading.Thread(target=work, args=(True, i)) for i in range(inflight)]
         for t in threads:
             t.start()
         for t in threads:
@@ -192,7 +173,7 @@ def main():
     batch = pl.parse_sam(sam)
     t_parse = time.perf_counter() - t0
     db = engine.DeviceBatch(batch)
-    bufs_list = [engine.ScoreBuffers(pl, db, exon=True) for _ in range(max(1, args.inflight))]
+    inflight = max(1, args.inflight)
     if rank != 0 or args.no_cpu_baseline or use_dist:
         sam_keep = None
     else:
@@ -200,14 +181,14 @@ def main():
     del sam
     t_setup = time.perf_counter() - t_setup
 
-    run_steps(pl, batch, db, bufs_list, max(args.warmup, len(bufs_list) if args.warmup else 0), None, False, local_rank)
+    run_steps(pl, batch, db, inflight, max(args.warmup, inflight if args.warmup else 0), None, False, local_rank)
     capi.sync()
     if dist is not None:
         dist.barrier()
     ev = [(capi.Event(), capi.Event(), capi.Event(), capi.Event()) for _ in range(args.steps)]
     timing = not args.no_kernel_timing                     # HIP events around a sample of the EM mat-vec launches
     t0 = time.perf_counter()
-    res, t_em, n_em_iter, em_timing = run_steps(pl, batch, db, bufs_list, args.steps, ev, timing, local_rank)
+    res, t_em, n_em_iter, em_timing = run_steps(pl, batch, db, inflight, args.steps, ev, timing, local_rank)
     capi.sync()
     if dist is not None:
         import torch
@@ -232,11 +213,11 @@ def main():
         #                  written per pair + refs/offsets
         #  k_piece_compat: n_words x a_pad x 4 index bytes read + one compat row written per distinct piece
         row = pl.a_pad // 8
-        n_gene_refs = int((np.asarray(batch.pair_ref) >> 31).sum())
+        n_gene_refs = db.n_gene_refs
         pc_bytes = n_gene_refs * row + 4 * batch.n_refs + 4 * (batch.n_pairs + 1) + batch.n_pairs * (row + 8)
         cp_bytes = db.sum_piece_words * pl.a_pad * 4 + batch.n_pieces * (row + 8) + db.sum_piece_words * 8
-        pc_ms = sum(e[3].elapsed_ms(e[1]) for e in ev) / len(ev)
-        cp_ms = sum(e[2].elapsed_ms(e[0]) for e in ev) / len(ev)
+        pc_ms = sum(e[2].elapsed_ms(e[3]) for e in ev) / len(ev)
+        cp_ms = sum(e[0].elapsed_ms(e[1]) for e in ev) / len(ev)
         gbs = lambda b, ms: (b / (ms * 1e-3) / 1e9) if ms > 0 else 0.0
         kernels = {}
         for name, (ms, n, ex, by) in em_timing.items():
@@ -283,7 +264,7 @@ def main():
                 "gene_classes_after_handoff": res.em[1]["n_classes"] if len(res.em) > 1 else 0,
                 "em_outer_iterations_per_step": n_em_iter // max(args.steps, 1),
                 "top2": [a for a, _ in res.gene_prob[:2]], "true_alleles": sample,
-                "parallelism": "samples/loci shard over GPUs with no data-path collective; %d sample(s) in flight per GPU" % len(bufs_list),
+                "parallelism": "samples/loci shard over GPUs with no data-path collective; %d sample(s) in flight per GPU" % inflight,
                 "input": "front-end piece batch resident in HBM (host C++ front-end: %.0f reads/s on %d host threads, not timed)" % (
                     batch.n_reads / t_parse, os.cpu_count() or 1),
                 "setup_s": round(t_setup, 1),

@@ -57,6 +57,9 @@ SYMBOLS = [
     "hgx_locus_destroy", "hgx_locus_dims", "hgx_locus_tables", "hgx_index_from_locus",
     "hgx_locus_alternatives_text", "hgx_batch_destroy", "hgx_batch_dims", "hgx_batch_arrays",
     "hgx_batch_from_haplotypes", "hgx_parse_sam", "hgx_read_alignments", "hgx_free_text", "hgx_parse_alignment_file", "hgx_batch_trace_text", "hgx_batch_pileup",
+    "hgx_dbatch_create", "hgx_dbatch_destroy", "hgx_dbatch_dims", "hgx_gate_create", "hgx_gate_destroy", "hgx_type_dbatch",
+    "hgx_type_batch", "hgx_type_file", "hgx_typing_destroy", "hgx_typing_dims", "hgx_typing_counts", "hgx_typing_em",
+    "hgx_typing_gene_prob", "hgx_typing_classes",
 ]
 
 _lib = None

@@ -1,0 +1,530 @@
+// hgx_type.hip -- the per-locus body of typing() behind ONE C-ABI call (hgx_type_batch / hgx_type_dbatch / hgx_type_file).
+//
+// Replaces typing_core.py:1589-1789 for one locus: Gene_counts and their ranking (core:1187-1190, 1650-1651), the exon-level
+// classes and EM #1 (core:1732-1737), the choice of exon_alleles (core:1739-1749), the hand-off Gene_cmpt2 + EM #2 with allele
+// lengths (core:1752-1782), the combination of the two results and the tie order of the reference's stable sorts.  It only
+// ORCHESTRATES the device entry points of hgx.h (piece compatibility, pair classes, grouping, dedup, allele counts, EM) on
+// two side streams plus the caller's stream; no arithmetic of the hot path happens on the host.
+//
+// Concurrency inside one call (HLA-like loci, >= 4096 pairs): the gene-level side (per-pair rows -> dedup -> Gene_counts ->
+// ranking) runs on its own host thread and low-priority stream beside the exon-level grouping, dedup and EM #1 on a
+// high-priority stream; both start from an event recorded behind hgx_piece_compat on the caller's stream (device-side
+// dependency, the host runs ahead).  Stream pairs are recycled through a process-wide free list, so callers may come from
+// short-lived threads (several samples in flight per GPU).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <thread>
+#include <vector>
+
+#include "hgx_common.hpp"
+#include "hgx_internal.hpp"
+
+struct hgx_dbatch {
+    int32_t n_pieces = 0, n_pairs = 0, n_reads = 0;
+    int64_t n_refs = 0, n_mask_u32 = 0, sum_piece_words = 0, n_gene_refs = 0;
+    hgx_piece *d_pieces = nullptr;
+    uint32_t *d_masks = nullptr;
+    int32_t *d_pair_off = nullptr;
+    uint32_t *d_pair_ref = nullptr;
+};
+
+struct hgx_gate { std::mutex mu; };
+
+namespace {
+
+struct EmOut {
+    int32_t n_classes = 0, n_iter = 0, remove_low = 0, use_length = 0;
+    std::vector<int32_t> allele;
+    std::vector<double> prob;
+};
+
+constexpr double TIE_REL_TOL = 1e-11;
+
+// The reference's `sorted(..., key=prob, reverse=True)` (a STABLE sort: equal abundances keep dict insertion order).  Alleles the
+// data cannot tell apart come out of the reference's EM bit-identical; on the GPU they agree to ~1e-14 only (same arithmetic,
+// another summation order), so abundances within a relative 1e-11 of the run's first count as tied and keep insertion order.
+void stable_desc(std::vector<int32_t> &allele, std::vector<double> &prob) {
+    const size_t n = allele.size();
+    std::vector<size_t> idx(n);
+    std::iota(idx.begin(), idx.end(), (size_t)0);
+    std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) { return prob[a] > prob[b]; });
+    std::vector<size_t> order;
+    order.reserve(n);
+    for (size_t i = 0; i < n;) {
+        size_t j = i + 1;
+        const double top = prob[idx[i]];
+        while (j < n && top - prob[idx[j]] <= TIE_REL_TOL * std::fabs(top)) ++j;
+        const size_t at = order.size();
+        order.insert(order.end(), idx.begin() + i, idx.begin() + j);
+        std::sort(order.begin() + at, order.end());                 // the tied run, back in insertion order
+        i = j;
+    }
+    std::vector<int32_t> a2(n);
+    std::vector<double> p2(n);
+    for (size_t k = 0; k < n; ++k) { a2[k] = allele[order[k]]; p2[k] = prob[order[k]]; }
+    allele.swap(a2);
+    prob.swap(p2);
+}
+
+// [[allele, prob]] of an EM result: survivors in the insertion order of the reference's dict (first class containing the
+// allele, then its place in that class' sorted key: common:1300-1305), then the reference's stable descending sort.
+void sorted_result(const std::vector<double> &prob, const std::vector<int32_t> &first, const int32_t *name_rank, int32_t A, EmOut &o) {
+    std::vector<int32_t> present;
+    for (int32_t a = 0; a < A; ++a) if (prob[a] >= 0.0) present.push_back(a);
+    std::sort(present.begin(), present.end(), [&](int32_t a, int32_t b) {
+        if (first[a] != first[b]) return first[a] < first[b];
+        if (name_rank[a] != name_rank[b]) return name_rank[a] < name_rank[b];
+        return a < b;
+    });
+    o.allele = present;
+    o.prob.resize(present.size());
+    for (size_t k = 0; k < present.size(); ++k) o.prob[k] = prob[present[k]];
+    stable_desc(o.allele, o.prob);
+}
+
+// ---- stream pairs ---------------------------------------------------------------------------------------------------
+struct StreamSet { int dev = -1; hipStream_t em = nullptr, gene = nullptr; hipEvent_t fork = nullptr; };
+std::mutex g_ss_mu;
+std::vector<StreamSet> g_ss_free;
+
+int acquire_streams(StreamSet &s) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> g(g_ss_mu);
+        for (size_t i = 0; i < g_ss_free.size(); ++i)
+            if (g_ss_free[i].dev == dev) { s = g_ss_free[i]; g_ss_free.erase(g_ss_free.begin() + i); return HGX_OK; }
+    }
+    // creating a stream creates a hardware queue (milliseconds): done once per concurrent caller, then recycled.  The EM
+    // chain (short dependent launches on the critical path) gets the highest priority, the overlapped side work the lowest.
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    s.dev = dev;
+    HIPCHK(hipStreamCreateWithPriority(&s.em, hipStreamNonBlocking, greatest));
+    HIPCHK(hipStreamCreateWithPriority(&s.gene, hipStreamNonBlocking, least));
+    HIPCHK(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
+    return HGX_OK;
+}
+void release_streams(const StreamSet &s) {
+    if (s.dev < 0) return;
+    std::lock_guard<std::mutex> g(g_ss_mu);
+    g_ss_free.push_back(s);
+}
+
+struct GateHold {                    // a held gate that is released exactly once
+    hgx_gate *g = nullptr;
+    explicit GateHold(hgx_gate *gate) : g(gate) { if (g) g->mu.lock(); }
+    void release() { if (g) { g->mu.unlock(); g = nullptr; } }
+    ~GateHold() { release(); }
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+}   // namespace
+
+struct hgx_typing {
+    int32_t n_reads = 0, n_pairs = 0, n_pieces = 0, n_alleles = 0;
+    int64_t n_refs = 0;
+    std::vector<int32_t> counted;        // alleles with a non-zero Gene_count, in the reference's print order
+    std::vector<int64_t> cnt;            // Gene_counts per allele index [n_alleles]
+    std::vector<EmOut> em;
+    EmOut gene_prob;                     // final Gene_prob (allele, prob), sorted
+    hgx_classes *exon_cl = nullptr, *gene_cl = nullptr;      // kept alive with keep_classes
+    double t_em = 0.0;
+    char err_thread[512] = "";
+    ~hgx_typing() { hgx_classes_destroy(exon_cl); hgx_classes_destroy(gene_cl); }
+};
+
+// ---- device batch ---------------------------------------------------------------------------------------------------
+extern "C" int hgx_dbatch_destroy(hgx_dbatch *d) {
+    if (!d) return HGX_OK;
+    hgx_pool_free(d->d_pieces); hgx_pool_free(d->d_masks); hgx_pool_free(d->d_pair_off); hgx_pool_free(d->d_pair_ref);
+    delete d;
+    return HGX_OK;
+}
+
+extern "C" int hgx_dbatch_create(hgx_dbatch **out, const hgx_batch *b, void *stream) {
+    ARGCHK(out && b);
+    *out = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    hgx_dbatch *d = new hgx_dbatch();
+    d->n_pieces = (int32_t)b->pieces.size();
+    d->n_pairs = (int32_t)b->pair_off.size() - 1;
+    d->n_reads = b->n_reads;
+    d->n_refs = (int64_t)b->pair_ref.size();
+    d->n_mask_u32 = (int64_t)b->masks.size();
+    for (const auto &p : b->pieces) d->sum_piece_words += p.n_words;
+    for (uint32_t r : b->pair_ref) d->n_gene_refs += r >> 31;
+    auto up = [&](void **dst, const void *src, size_t bytes) -> int {
+        *dst = hgx_pool_alloc(std::max<size_t>(bytes, 16));
+        if (!*dst) { hgx_set_error("device allocation of %zu bytes failed", bytes); return HGX_ENOMEM; }
+        if (bytes) HIPCHK(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st));
+        return HGX_OK;
+    };
+    int rc = up((void **)&d->d_pieces, b->pieces.data(), b->pieces.size() * sizeof(hgx_piece));
+    if (!rc) rc = up((void **)&d->d_masks, b->masks.data(), b->masks.size() * 4);
+    if (!rc) rc = up((void **)&d->d_pair_off, b->pair_off.data(), b->pair_off.size() * 4);
+    if (!rc) rc = up((void **)&d->d_pair_ref, b->pair_ref.data(), b->pair_ref.size() * 4);
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) { hgx_set_error("upload of the piece batch failed"); rc = HGX_EHIP; }
+    if (rc) { hgx_dbatch_destroy(d); return rc; }
+    *out = d;
+    return HGX_OK;
+}
+
+extern "C" int hgx_dbatch_dims(const hgx_dbatch *d, int32_t *n_pieces, int32_t *n_pairs, int64_t *n_refs, int32_t *n_reads,
+                               int64_t *sum_piece_words, int64_t *n_gene_refs) {
+    ARGCHK(d);
+    if (n_pieces) *n_pieces = d->n_pieces;
+    if (n_pairs) *n_pairs = d->n_pairs;
+    if (n_refs) *n_refs = d->n_refs;
+    if (n_reads) *n_reads = d->n_reads;
+    if (sum_piece_words) *sum_piece_words = d->sum_piece_words;
+    if (n_gene_refs) *n_gene_refs = d->n_gene_refs;
+    return HGX_OK;
+}
+
+extern "C" int hgx_gate_create(hgx_gate **g) { ARGCHK(g); *g = new hgx_gate(); return HGX_OK; }
+extern "C" int hgx_gate_destroy(hgx_gate *g) { delete g; return HGX_OK; }
+
+// ---- the per-locus body ---------------------------------------------------------------------------------------------
+namespace {
+
+struct GeneSide {                    // what the gene-level side hands back
+    hgx_classes *gcl = nullptr;
+    std::vector<int32_t> counted;
+    std::vector<int64_t> cnt;
+    int rc = HGX_OK;
+    char err[512] = "";
+};
+
+// Gene_counts (core:1187-1190) and their print order (core:1650-1651): dict insertion order of Gene_counts = (first pair
+// that counted the allele, Gene_names order), then the reference's stable descending sort on the count.
+int gene_side(const hgx_index *ix, const hgx_dbatch *db, const uint64_t *compat, uint64_t *gene_bits, uint64_t *gene_hash,
+              bool rows_ready, const hgx_type_opts *opts, hipStream_t st, GeneSide &g) {
+    int32_t A = 0, a_pad = 0;
+    int rc = hgx_index_dims(ix, &A, &a_pad, nullptr, nullptr);
+    if (rc) return rc;
+    if (!rows_ready) {
+        if (opts->ev_pairs_begin) HIPCHK(hipEventRecord((hipEvent_t)opts->ev_pairs_begin, st));
+        rc = hgx_pair_classes(ix, compat, db->d_pair_off, db->d_pair_ref, db->n_pairs, nullptr, gene_bits, nullptr, gene_hash, st);
+        if (rc) return rc;
+        if (opts->ev_pairs_end) HIPCHK(hipEventRecord((hipEvent_t)opts->ev_pairs_end, st));
+    }
+    rc = hgx_dedup_classes(&g.gcl, gene_bits, gene_hash, nullptr, db->n_pairs, a_pad, nullptr, st);
+    if (rc) return rc;
+    std::vector<int64_t> cnt((size_t)a_pad);
+    std::vector<int32_t> first((size_t)a_pad);
+    rc = hgx_allele_counts_on(g.gcl, cnt.data(), first.data(), st);
+    if (rc) return rc;
+    int32_t C = 0;
+    hgx_classes_dims(g.gcl, &C, nullptr);
+    std::vector<int64_t> fr((size_t)std::max(C, 1));                     // first pair of every class
+    rc = hgx_classes_to_host(g.gcl, nullptr, nullptr, fr.data());
+    if (rc) return rc;
+    g.cnt.assign(cnt.begin(), cnt.begin() + A);
+    for (int32_t a = 0; a < A; ++a) if (cnt[a] > 0) g.counted.push_back(a);
+    std::sort(g.counted.begin(), g.counted.end(), [&](int32_t a, int32_t b) {
+        if (cnt[a] != cnt[b]) return cnt[a] > cnt[b];
+        const int64_t ia = fr[first[a]], ib = fr[first[b]];
+        if (ia != ib) return ia < ib;
+        return a < b;
+    });
+    return HGX_OK;
+}
+
+int run_em(hgx_classes *cl, const hgx_locus *loc, int32_t remove_low, const int32_t *lengths, hipStream_t st, hgx_typing *t) {
+    const int32_t A = loc->A;
+    std::vector<double> prob((size_t)A);
+    std::vector<int32_t> first((size_t)A);
+    int32_t n_iter = 0, C = 0;
+    const double t0 = now_s();
+    int rc = hgx_classes_set_allele_rank(cl, loc->name_rank.data(), A);    // small problems then sum in the reference's own order
+    if (!rc) rc = hgx_em_ordered(cl, A, remove_low, lengths, prob.data(), first.data(), &n_iter, st);
+    t->t_em += now_s() - t0;
+    if (rc) return rc;
+    hgx_classes_dims(cl, &C, nullptr);
+    EmOut o;
+    o.n_classes = C; o.n_iter = n_iter; o.remove_low = remove_low ? 1 : 0; o.use_length = lengths ? 1 : 0;
+    sorted_result(prob, first, loc->name_rank.data(), A, o);
+    t->em.push_back(std::move(o));
+    return HGX_OK;
+}
+
+int type_impl(hgx_typing *t, const hgx_locus *loc, const hgx_index *ix, const hgx_dbatch *db, const hgx_type_opts *opts,
+              hipStream_t stream, StreamSet &ss, GateHold &gate) {
+    int32_t A = 0, a_pad = 0;
+    int rc = hgx_index_dims(ix, &A, &a_pad, nullptr, nullptr);
+    if (rc) return rc;
+    ARGCHK(A == loc->A && a_pad == loc->a_pad);
+    ARGCHK((int32_t)loc->name_rank.size() == A && (int32_t)loc->allele_len.size() == A);
+    const int w64 = a_pad / 64;
+    const bool hla = loc->base_kind == HGX_BASE_HLA;
+    const int32_t n_pairs = db->n_pairs;
+    const bool by_list = hla && !opts->per_pair_exon && !getenv("HGX_NO_SIG");
+    bool overlap = opts->overlap < 0 ? stream == nullptr : opts->overlap != 0;
+    overlap = overlap && hla && n_pairs >= 4096;
+
+    // Order of declaration = reverse order of clean-up on ANY way out: the gene-side thread is joined first, then every stream
+    // that may still have kernels queued is drained, then handles and buffers go back to the pool.
+    DevBuf b_compat, b_gbits, b_ghash, b_ebits, b_ehash;
+    GeneSide gs;
+    hgx_classes *ecl = nullptr;
+    hgx_groups *groups = nullptr;
+    struct Handles {
+        GeneSide &g; hgx_classes *&ecl; hgx_groups *&groups;
+        ~Handles() { hgx_groups_destroy(groups); hgx_classes_destroy(ecl); hgx_classes_destroy(g.gcl); }
+    } handles{gs, ecl, groups};
+    struct Drain {
+        hipStream_t a, b, c;
+        ~Drain() { (void)hipStreamSynchronize(a); if (b) (void)hipStreamSynchronize(b); if (c) (void)hipStreamSynchronize(c); }
+    } drain{stream, overlap ? ss.em : nullptr, overlap ? ss.gene : nullptr};
+    std::thread worker;
+    struct Join {
+        std::thread &w;
+        ~Join() { if (w.joinable()) w.join(); }
+    } join{worker};
+
+    ALLOC(b_compat, (size_t)std::max(db->n_pieces, 1) * w64 * 8);
+    ALLOC(b_gbits, (size_t)std::max(n_pairs, 1) * w64 * 8);
+    ALLOC(b_ghash, (size_t)std::max(n_pairs, 1) * 8);
+    if (hla) {                       // exon-level rows: per pair (HGX_NO_SIG) or scratch for the rows per distinct ref list
+        ALLOC(b_ebits, (size_t)std::max(n_pairs, 1) * w64 * 8);
+        ALLOC(b_ehash, (size_t)std::max(n_pairs, 1) * 8);
+    }
+    uint64_t *compat = b_compat.as<uint64_t>();
+
+    if (opts->ev_compat_begin) HIPCHK(hipEventRecord((hipEvent_t)opts->ev_compat_begin, stream));
+    if (by_list || !hla) {
+        rc = hgx_piece_compat(ix, db->d_pieces, db->d_masks, db->n_pieces, compat, stream);
+        if (rc) return rc;
+        if (opts->ev_compat_end) HIPCHK(hipEventRecord((hipEvent_t)opts->ev_compat_end, stream));
+    }
+    bool rows_ready = false;
+    if (!by_list) {                  // per-pair rows of every level right away
+        if (hla) {
+            rc = hgx_score_pairs(ix, db->d_pieces, db->d_masks, db->n_pieces, db->d_pair_off, db->d_pair_ref, n_pairs, compat,
+                                 b_ebits.as<uint64_t>(), b_gbits.as<uint64_t>(), b_ehash.as<uint64_t>(), b_ghash.as<uint64_t>(), stream);
+            if (opts->ev_compat_end) HIPCHK(hipEventRecord((hipEvent_t)opts->ev_compat_end, stream));
+        } else {
+            rc = hgx_pair_classes(ix, compat, db->d_pair_off, db->d_pair_ref, n_pairs, nullptr, b_gbits.as<uint64_t>(), nullptr,
+                                  b_ghash.as<uint64_t>(), stream);
+        }
+        if (rc) return rc;
+        rows_ready = true;
+    }
+
+    hipStream_t em_stream = stream, gene_stream = stream;
+
+    if (overlap) {
+        em_stream = ss.em;
+        gene_stream = ss.gene;
+        // scoring is complete before either side reads its output: a device-side dependency, the host keeps running ahead
+        HIPCHK(hipEventRecord(ss.fork, stream));
+        HIPCHK(hipStreamWaitEvent(gene_stream, ss.fork, 0));
+        if (by_list) {
+            // grouping the pairs by exon-level ref list does not read the piece bitsets: queued on the EM stream right away
+            // it runs BESIDE hgx_piece_compat; the stream is ordered behind the scoring only further down
+            rc = hgx_group_pairs(&groups, db->d_pair_off, db->d_pair_ref, n_pairs, HGX_LEVEL_EXON, em_stream);
+            if (rc) return rc;
+        }
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        worker = std::thread([&, dev] {
+            if (hipSetDevice(dev) != hipSuccess) { gs.rc = HGX_EHIP; snprintf(gs.err, sizeof(gs.err), "hipSetDevice failed on the gene-side thread"); return; }
+            gs.rc = gene_side(ix, db, compat, b_gbits.as<uint64_t>(), b_ghash.as<uint64_t>(), rows_ready, opts, gene_stream, gs);
+            if (gs.rc) snprintf(gs.err, sizeof(gs.err), "%s", hgx_last_error());
+        });
+        if (groups) {
+            int64_t ng = 0;
+            rc = hgx_groups_dims(groups, &ng, nullptr);          // host wait for the grouping alone
+            if (rc) return rc;
+        }
+        HIPCHK(hipStreamWaitEvent(em_stream, ss.fork, 0));
+    } else {
+        gs.rc = gene_side(ix, db, compat, b_gbits.as<uint64_t>(), b_ghash.as<uint64_t>(), rows_ready, opts, stream, gs);
+        if (gs.rc) return gs.rc;
+    }
+    auto finish_gene = [&]() -> int {
+        if (worker.joinable()) worker.join();
+        if (gs.rc) { hgx_set_error("%s", gs.err[0] ? gs.err : "gene-level side failed"); return gs.rc; }
+        t->counted = gs.counted;
+        t->cnt = gs.cnt;
+        return HGX_OK;
+    };
+
+    if (hla) {
+        if (by_list) {
+            if (groups) rc = hgx_level_classes_grouped(&ecl, ix, compat, db->d_pair_off, db->d_pair_ref, groups, b_ebits.as<uint64_t>(),
+                                                       b_ehash.as<uint64_t>(), em_stream);
+            else rc = hgx_level_classes(&ecl, ix, compat, db->d_pair_off, db->d_pair_ref, n_pairs, HGX_LEVEL_EXON, b_ebits.as<uint64_t>(),
+                                        b_ehash.as<uint64_t>(), em_stream);
+        } else {
+            rc = hgx_dedup_classes(&ecl, b_ebits.as<uint64_t>(), b_ehash.as<uint64_t>(), nullptr, n_pairs, a_pad, nullptr, em_stream);
+        }
+        if (rc) return rc;
+        gate.release();              // several samples in flight: the bandwidth-bound front of this one is through
+        rc = run_em(ecl, loc, opts->remove_low, nullptr, em_stream, t);                          // core:1732-1737
+        if (rc) return rc;
+        rc = finish_gene();
+        if (rc) return rc;
+        const EmOut &e1 = t->em[0];
+        // exon_alleles (core:1739-1749): the members of the exon groups of the leading representatives
+        std::vector<uint8_t> in_exon((size_t)A, 0);
+        std::vector<int32_t> group_size((size_t)A, 0);
+        for (int32_t a = 0; a < A; ++a) if (loc->rep_of[a] >= 0) ++group_size[loc->rep_of[a]];
+        double psum = 0.0;
+        bool any = false;
+        for (size_t i = 0; i < e1.allele.size(); ++i) {
+            const int32_t a = e1.allele[i];
+            const double p = e1.prob[i];
+            if (i >= 10 && p < 0.03) break;
+            if (group_size[a] <= 1) continue;
+            psum += p;
+            for (int32_t m = 0; m < A; ++m) if (loc->rep_of[m] == a) { in_exon[m] = 1; any = true; }
+        }
+        t->gene_prob = e1;
+        if (any) {                                                                               // core:1752-1782
+            std::vector<uint64_t> mask((size_t)w64, 0);
+            for (int32_t a = 0; a < A; ++a) if (in_exon[a]) mask[a >> 6] |= 1ull << (a & 63);
+            std::vector<double> prob2((size_t)A);
+            std::vector<int32_t> first2((size_t)A);
+            int32_t it2 = 0, ncls2 = 0;
+            const double t0 = now_s();
+            rc = hgx_classes_set_allele_rank(gs.gcl, loc->name_rank.data(), A);
+            // Gene_cmpt2 (gene classes filtered to exon_alleles, merged) and EM #2 in one call
+            if (!rc) rc = hgx_em_masked(gs.gcl, mask.data(), A, 1, loc->allele_len.data(), prob2.data(), first2.data(), &it2, &ncls2, stream);
+            t->t_em += now_s() - t0;
+            if (rc) return rc;
+            EmOut e2;
+            e2.n_classes = ncls2; e2.n_iter = it2; e2.remove_low = 1; e2.use_length = 1;
+            sorted_result(prob2, first2, loc->name_rank.data(), A, e2);
+            EmOut comb;                                                   // dict order: exon-level survivors, then EM #2's
+            for (size_t i = 0; i < e1.allele.size(); ++i)
+                if (!in_exon[e1.allele[i]]) { comb.allele.push_back(e1.allele[i]); comb.prob.push_back(e1.prob[i]); }
+            for (size_t i = 0; i < e2.allele.size(); ++i) { comb.allele.push_back(e2.allele[i]); comb.prob.push_back(e2.prob[i] * psum); }
+            stable_desc(comb.allele, comb.prob);
+            t->em.push_back(std::move(e2));
+            t->gene_prob.allele = comb.allele;
+            t->gene_prob.prob = comb.prob;
+        }
+    } else {
+        rc = finish_gene();
+        if (rc) return rc;
+        gate.release();
+        int32_t C = 0;
+        hgx_classes_dims(gs.gcl, &C, nullptr);
+        if (C == 1) {
+            hgx_set_error("'dict_keys' object is not subscriptable (reference quirk Q3, typing_core.py:1787)");
+            return HGX_ETYPE;
+        }
+        if (C > 1) {
+            rc = run_em(gs.gcl, loc, 0, nullptr, stream, t);
+            if (rc) return rc;
+            t->gene_prob = t->em[0];
+        }
+    }
+    if (opts->keep_classes) { t->gene_cl = gs.gcl; gs.gcl = nullptr; t->exon_cl = ecl; ecl = nullptr; }
+    return HGX_OK;
+}
+
+}   // namespace
+
+extern "C" int hgx_typing_destroy(hgx_typing *t) { delete t; return HGX_OK; }
+
+extern "C" int hgx_type_dbatch(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, const hgx_dbatch *db,
+                               const hgx_type_opts *opts, void *stream) {
+    ARGCHK(out && loc && ix && db && opts);
+    *out = nullptr;
+    hgx_typing *t = new hgx_typing();
+    t->n_reads = db->n_reads; t->n_pairs = db->n_pairs; t->n_pieces = db->n_pieces; t->n_refs = db->n_refs; t->n_alleles = loc->A;
+    if (db->n_reads <= 0) { *out = t; return HGX_OK; }                                           // core:1589-1590
+    GateHold gate(opts->gate);
+    StreamSet ss;
+    int rc = acquire_streams(ss);
+    if (!rc) rc = type_impl(t, loc, ix, db, opts, (hipStream_t)stream, ss, gate);
+    release_streams(ss);
+    if (rc) { delete t; return rc; }
+    *out = t;
+    return HGX_OK;
+}
+
+extern "C" int hgx_type_batch(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, const hgx_batch *batch,
+                              const hgx_type_opts *opts, void *stream) {
+    ARGCHK(out && batch);
+    *out = nullptr;
+    hgx_dbatch *db = nullptr;
+    int rc = hgx_dbatch_create(&db, batch, stream);
+    if (rc) return rc;
+    rc = hgx_type_dbatch(out, loc, ix, db, opts, stream);
+    hgx_dbatch_destroy(db);
+    return rc;
+}
+
+extern "C" int hgx_type_file(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, const char *path, const char *regions,
+                             const hgx_parse_opts *popts, const hgx_type_opts *opts, void *stream) {
+    ARGCHK(out && loc && ix && path && popts && opts);
+    *out = nullptr;
+    hgx_batch *b = nullptr;
+    int rc = hgx_parse_alignment_file(&b, loc, path, regions, popts);
+    if (rc) return rc;
+    rc = hgx_type_batch(out, loc, ix, b, opts, stream);
+    hgx_batch_destroy(b);
+    return rc;
+}
+
+extern "C" int hgx_typing_dims(const hgx_typing *t, int32_t *n_reads, int32_t *n_pairs, int32_t *n_pieces, int64_t *n_refs,
+                               int32_t *n_counted, int32_t *n_em, int32_t *n_gene_prob, double *em_seconds) {
+    ARGCHK(t);
+    if (n_reads) *n_reads = t->n_reads;
+    if (n_pairs) *n_pairs = t->n_pairs;
+    if (n_pieces) *n_pieces = t->n_pieces;
+    if (n_refs) *n_refs = t->n_refs;
+    if (n_counted) *n_counted = (int32_t)t->counted.size();
+    if (n_em) *n_em = (int32_t)t->em.size();
+    if (n_gene_prob) *n_gene_prob = (int32_t)t->gene_prob.allele.size();
+    if (em_seconds) *em_seconds = t->t_em;
+    return HGX_OK;
+}
+
+extern "C" int hgx_typing_counts(const hgx_typing *t, int32_t *ranked_allele, int64_t *count_per_allele) {
+    ARGCHK(t);
+    if (ranked_allele && !t->counted.empty()) memcpy(ranked_allele, t->counted.data(), t->counted.size() * 4);
+    if (count_per_allele && !t->cnt.empty()) memcpy(count_per_allele, t->cnt.data(), t->cnt.size() * 8);
+    return HGX_OK;
+}
+
+static int em_out(const EmOut &e, int32_t *n_classes, int32_t *n_iter, int32_t *remove_low, int32_t *use_length, int32_t *n_result,
+                  int32_t *allele, double *prob) {
+    if (n_classes) *n_classes = e.n_classes;
+    if (n_iter) *n_iter = e.n_iter;
+    if (remove_low) *remove_low = e.remove_low;
+    if (use_length) *use_length = e.use_length;
+    if (n_result) *n_result = (int32_t)e.allele.size();
+    if (allele && !e.allele.empty()) memcpy(allele, e.allele.data(), e.allele.size() * 4);
+    if (prob && !e.prob.empty()) memcpy(prob, e.prob.data(), e.prob.size() * 8);
+    return HGX_OK;
+}
+
+extern "C" int hgx_typing_em(const hgx_typing *t, int32_t k, int32_t *n_classes, int32_t *n_iter, int32_t *remove_low,
+                             int32_t *use_length, int32_t *n_result, int32_t *allele, double *prob) {
+    ARGCHK(t && k >= 0 && k < (int32_t)t->em.size());
+    return em_out(t->em[k], n_classes, n_iter, remove_low, use_length, n_result, allele, prob);
+}
+
+extern "C" int hgx_typing_gene_prob(const hgx_typing *t, int32_t *allele, double *prob) {
+    ARGCHK(t);
+    return em_out(t->gene_prob, nullptr, nullptr, nullptr, nullptr, nullptr, allele, prob);
+}
+
+extern "C" int hgx_typing_classes(const hgx_typing *t, int32_t level, const hgx_classes **out) {
+    ARGCHK(t && out && (level == HGX_LEVEL_EXON || level == HGX_LEVEL_GENE));
+    *out = level == HGX_LEVEL_EXON ? t->exon_cl : t->gene_cl;
+    return HGX_OK;
+}

@@ -144,17 +144,18 @@ def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, ix_dir=No
         packed[gene].index()                     # device index created once, before any worker needs it
     out = {}
 
-    heavy = threading.Lock() if inflight > 1 else None       # one bandwidth-bound front (scoring, exon dedup) at a time
+    from . import engine
+    heavy = engine.Gate() if inflight > 1 else None          # one bandwidth-bound front (scoring, exon dedup) at a time
 
     def one(task, stream):
         sample_id, gene, sam = task
         if isinstance(sam, (bytes, bytearray)) or "\t" in sam:
-            return (sample_id, gene), type_locus(packed[gene], sam, stream=stream, heavy_lock=heavy, **typing_opts)
+            return (sample_id, gene), type_locus(packed[gene], sam, stream=stream, gate=heavy, **typing_opts)
         # a SAM / BAM path: read, grouped and decoded inside libhgx
         # (the view is restricted to the gene's backbone, as the reference's `samtools view F ref_allele` does, core:443-444)
         opts = dict(typing_opts)
         opts.setdefault("regions", [packed[gene].ref_allele])
-        return (sample_id, gene), type_locus(packed[gene], None, alignment_file=sam, stream=stream, heavy_lock=heavy, **opts)
+        return (sample_id, gene), type_locus(packed[gene], None, alignment_file=sam, stream=stream, gate=heavy, **opts)
 
     if inflight <= 1 or len(mine) <= 1:
         for task in mine:

@@ -12,16 +12,59 @@ from .capi import DevArray
 
 
 class DeviceBatch:
-    """A front-end batch resident in HBM (distinct pieces, masks, per-pair refs)."""
+    """A front-end batch resident in HBM (distinct pieces, masks, per-pair refs): hgx_dbatch."""
 
     def __init__(self, batch, stream=None):
+        self.h = C.c_void_p()
+        capi.check(capi.lib().hgx_dbatch_create(C.byref(self.h), batch.h, stream))
         self.n_pieces, self.n_pairs, self.n_refs, self.n_reads = batch.n_pieces, batch.n_pairs, batch.n_refs, batch.n_reads
-        self.pieces = DevArray.from_host(batch.pieces if batch.n_pieces else np.zeros(1, capi.PIECE_DTYPE), stream)
-        self.masks = DevArray.from_host(batch.masks if batch.n_mask_u32 else np.zeros(2, np.uint32), stream)
-        self.pair_off = DevArray.from_host(batch.pair_off, stream)
-        self.pair_ref = DevArray.from_host(batch.pair_ref if batch.n_refs else np.zeros(1, np.uint32), stream)
+        spw, ngr = C.c_int64(), C.c_int64()
+        capi.check(capi.lib().hgx_dbatch_dims(self.h, None, None, None, None, C.byref(spw), C.byref(ngr)))
         # algorithmic byte model inputs (DESIGN.md section 5)
-        self.sum_piece_words = int(batch.pieces["n_words"].astype(np.int64).sum()) if batch.n_pieces else 0
+        self.sum_piece_words, self.n_gene_refs = spw.value, ngr.value
+        self._batch = batch
+        self._dev = None
+
+    def _arrays(self):
+        """Separate device copies for the callers that drive the stages one by one (tests, tools)."""
+        if self._dev is None:
+            b = self._batch
+            self._dev = (DevArray.from_host(b.pieces if b.n_pieces else np.zeros(1, capi.PIECE_DTYPE)),
+                         DevArray.from_host(b.masks if b.n_mask_u32 else np.zeros(2, np.uint32)),
+                         DevArray.from_host(b.pair_off),
+                         DevArray.from_host(b.pair_ref if b.n_refs else np.zeros(1, np.uint32)))
+        return self._dev
+
+    pieces = property(lambda self: self._arrays()[0])
+    masks = property(lambda self: self._arrays()[1])
+    pair_off = property(lambda self: self._arrays()[2])
+    pair_ref = property(lambda self: self._arrays()[3])
+
+    def close(self):
+        if self.h:
+            capi.lib().hgx_dbatch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Gate:
+    """hgx_gate: shared by the samples in flight on one GPU; hgx_type_* holds it from entry until the sample's exon-level
+    classes exist, so that one bandwidth-bound front runs at a time, beside the other samples' EM phases."""
+
+    def __init__(self):
+        self.h = C.c_void_p()
+        capi.check(capi.lib().hgx_gate_create(C.byref(self.h)))
+
+    def __del__(self):
+        try:
+            capi.lib().hgx_gate_destroy(self.h)
+        except Exception:
+            pass
 
 
 class ScoreBuffers:
@@ -89,8 +132,9 @@ class Groups:
 class Classes:
     """Distinct compatibility classes in first-seen order (Gene_cmpt / Gene_exons_cmpt as a bit matrix)."""
 
-    def __init__(self, handle):
+    def __init__(self, handle, owned=True):
         self.h = handle
+        self.owned = owned           # False: the handle belongs to an hgx_typing result
         n, ap = C.c_int32(), C.c_int32()
         capi.check(capi.lib().hgx_classes_dims(self.h, C.byref(n), C.byref(ap)))
         self.n_classes, self.a_pad = n.value, ap.value
@@ -194,9 +238,9 @@ class Classes:
         return prob, first, it.value, nc.value
 
     def close(self):
-        if self.h:
+        if self.h and self.owned:
             capi.lib().hgx_classes_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:

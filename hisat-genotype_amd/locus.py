@@ -24,19 +24,28 @@ class Batch:
         capi.check(L.hgx_batch_dims(self.h, C.byref(np_), C.byref(nm), C.byref(npairs), C.byref(nrefs), C.byref(nreads)))
         self.n_pieces, self.n_mask_u32, self.n_pairs = np_.value, nm.value, npairs.value
         self.n_refs, self.n_reads = nrefs.value, nreads.value
-        pp, pm, po, pr = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        capi.check(L.hgx_batch_arrays(self.h, C.byref(pp), C.byref(pm), C.byref(po), C.byref(pr)))
+        self._arrays = None
 
-        def view(p, n, dt):
-            if n == 0 or not p.value:
-                return np.zeros(0, dtype=dt)
-            buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(p.value)
-            return np.frombuffer(buf, dtype=dt, count=n).copy()
+    def _load(self):
+        """Host copies of the batch arrays, made on first use (the typing path never needs them: libhgx uploads its own)."""
+        if self._arrays is None:
+            pp, pm, po, pr = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+            capi.check(capi.lib().hgx_batch_arrays(self.h, C.byref(pp), C.byref(pm), C.byref(po), C.byref(pr)))
 
-        self.pieces = view(pp, self.n_pieces, capi.PIECE_DTYPE)
-        self.masks = view(pm, self.n_mask_u32, np.uint32)
-        self.pair_off = view(po, self.n_pairs + 1, np.int32)
-        self.pair_ref = view(pr, self.n_refs, np.uint32)
+            def view(p, n, dt):
+                if n == 0 or not p.value:
+                    return np.zeros(0, dtype=dt)
+                buf = (C.c_char * (n * np.dtype(dt).itemsize)).from_address(p.value)
+                return np.frombuffer(buf, dtype=dt, count=n).copy()
+
+            self._arrays = (view(pp, self.n_pieces, capi.PIECE_DTYPE), view(pm, self.n_mask_u32, np.uint32),
+                            view(po, self.n_pairs + 1, np.int32), view(pr, self.n_refs, np.uint32))
+        return self._arrays
+
+    pieces = property(lambda self: self._load()[0])
+    masks = property(lambda self: self._load()[1])
+    pair_off = property(lambda self: self._load()[2])
+    pair_ref = property(lambda self: self._load()[3])
 
     def trace_text(self):
         L = capi.lib()

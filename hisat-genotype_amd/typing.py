@@ -12,11 +12,9 @@
 
 Nothing here computes the hot path on the CPU: all of it goes through libhgx (HIP kernels).
 """
+import ctypes as C
 import os
-import subprocess
 import sys
-import threading
-import time
 
 import numpy as np
 
@@ -120,10 +118,10 @@ class LocusResult:
 
 def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discordant=False,
                remove_low_abundance_alleles=True, simulation=False, base_locus=0, keep_classes=False, stream=None,
-               alignment_file=None, regions=None, heavy_lock=None):
+               alignment_file=None, regions=None, gate=None):
     """Per-locus typing: the reference's loop body with the O(alleles) work on the GPU.  Input: name-grouped SAM text
     (`sam_text`), or `alignment_file` (SAM / BAM; `regions` = samtools region strings, see read_alignment_text) read inside
-    libhgx."""
+    libhgx.  `gate` (engine.Gate): shared by the samples in flight on one GPU, see _type_batch."""
     res = LocusResult()
     if alignment_file is not None:
         batch = pl.parse_alignment_file(alignment_file, regions, num_editdist=num_editdist, error_correction=error_correction,
@@ -135,216 +133,70 @@ def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discor
     res.n_pieces, res.n_refs = batch.n_pieces, batch.n_refs
     if batch.n_reads <= 0:                                  # core:1589-1590
         return res
-    if heavy_lock is None:
-        return _type_batch(pl, batch, res, remove_low_abundance_alleles, keep_classes, stream)
-    held = _HeldOnce(heavy_lock)        # several samples in flight: one bandwidth-bound front at a time (see _type_batch)
-    try:
-        return _type_batch(pl, batch, res, remove_low_abundance_alleles, keep_classes, stream, heavy_lock=held)
-    finally:
-        held.release()
+    return _type_batch(pl, batch, res, remove_low_abundance_alleles, keep_classes, stream, gate=gate)
 
 
-class _HeldOnce:
-    """A held lock that is released exactly once (by _type_batch as soon as it can, or by the caller on the way out)."""
-
-    def __init__(self, lock):
-        lock.acquire()
-        self.lock = lock
-
-    def release(self):
-        lock, self.lock = self.lock, None
-        if lock is not None:
-            lock.release()
+class TypeOpts(C.Structure):
+    """hgx_type_opts (include/hgx.h)."""
+    _fields_ = [("remove_low", C.c_int32), ("keep_classes", C.c_int32), ("overlap", C.c_int32), ("per_pair_exon", C.c_int32),
+                ("gate", C.c_void_p), ("ev_compat_begin", C.c_void_p), ("ev_compat_end", C.c_void_p),
+                ("ev_pairs_begin", C.c_void_p), ("ev_pairs_end", C.c_void_p)]
 
 
-_tls = threading.local()
-
-
-def _fork_event():
-    ev = getattr(_tls, "fork_event", None)
-    if ev is None:
-        ev = _tls.fork_event = capi.Event()
-    return ev
-
-
-def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dbatch=None, bufs=None, scored=False, overlap=None,
-                heavy_lock=None, pc_events=None):
-    """`scored`: False = nothing computed yet; "compat" = the caller queued hgx_piece_compat on `stream`; True = the caller
-    also queued hgx_pair_classes for both levels (the per-pair form).  For HLA-like loci (two levels) the exon-level classes
-    come from hgx_level_classes (pairs grouped by ref list first, HGX_NO_SIG=1 selects the per-pair form) and only the
-    gene-level rows are materialised per pair, beside the exon-level EM.  `pc_events` = (before, after) events recorded
-    around that gene-level hgx_pair_classes launch (bench.py).
-
-    `heavy_lock` (held by the caller on entry, released here): with several samples in flight per GPU, the bandwidth-bound
-    front of the path (scoring, the exon-level dedup) of one sample should not run beside another sample's -- it would only
-    share the HBM -- but beside the other samples' EM phases, which are chains of short launches.  The lock is released as soon
-    as this sample's exon-level classes exist."""
-    hla = pl.base_fname == "hla"
-    A, names = pl.n_alleles, pl.names
-    db = dbatch if dbatch is not None else engine.DeviceBatch(batch, stream)
-    bufs = bufs if bufs is not None else engine.ScoreBuffers(pl, db, exon=hla)
-    by_list = hla and scored is not True and not os.environ.get("HGX_NO_SIG")
-    if scored is False:
-        if by_list:
-            engine.piece_compat(pl, db, bufs, stream)
-        else:
-            engine.score_pairs(pl, db, bufs, stream)
-    elif scored == "compat" and not by_list:
-        if pc_events:
-            pc_events[0].record(stream)
-        engine.pair_classes(pl, db, bufs, stream)
-        if pc_events:
-            pc_events[1].record(stream)
-    # ---- Gene_counts (core:1187-1190, 1650-1651) --------------------------------------------------
-    # The gene-level side (dedup -> counts -> ranking) is independent of the exon-level EM until the hand-off, and the
-    # EM is a long chain of short launches that leaves most of the GPU idle: for HLA the two run concurrently, the gene
-    # side on a worker thread with its own non-blocking stream.
-    gene = {}
-
-    def gene_side(st):
-        if by_list:
-            if pc_events:
-                pc_events[0].record(st)
-            engine.pair_classes(pl, db, bufs, st, exon=False)
-            if pc_events:
-                pc_events[1].record(st)
-        gcl_ = engine.Classes.dedup(bufs.gene_bits, db.n_pairs, pl.a_pad, hashes=bufs.gene_hash, stream=st)
-        cnt, first = gcl_.allele_counts(st)
-        fr = np.zeros(gcl_.n_classes, np.int64)                     # first pair of every class
-        capi.check(capi.lib().hgx_classes_to_host(gcl_.h, None, None, capi.ptr(fr)))
-        cnt_a, first_a = cnt[:A], first[:A]
-        counted = np.nonzero(cnt_a > 0)[0]
-        # dict insertion order of Gene_counts = (first pair that counted the allele, Gene_names order); then the
-        # reference's stable descending sort on the count (core:1650-1651)
-        ins = fr[first_a[counted]]
-        counted = counted[np.lexsort((counted, ins, -cnt_a[counted]))]
-        gene.update(gcl=gcl_, counted=counted, cnt=cnt_a)
-
-    if overlap is None:
-        overlap = stream is None
-    overlap = hla and overlap and db.n_pairs >= 4096
-    pair_groups = None
-    if overlap:
-        # scoring is complete before either side reads its output: a device-side dependency, the host keeps running ahead
-        ev = _fork_event()
-        ev.record(stream)
-        em_stream_, gene_stream_ = capi.get_stream(0), capi.get_stream(1)     # this host thread's pair of side streams
-        ev.make_wait(gene_stream_)
-    state = {"worker": None}
-
-    def start_gene():
-        """Run the gene side: beside the caller on a worker thread + its own stream when overlapping, otherwise right here."""
-        if not overlap:
-            gene_side(stream)
-            return
-        dev = capi.current_device()
-
-        def run():
-            capi.set_device(dev)
-            gene_side(gene_stream_)
-
-        # a fresh thread per sample: measured faster than a pooled executor when several samples are in flight
-        from concurrent.futures import Future
-        fut = state["worker"] = Future()
-
-        def run_t():
-            try:
-                fut.set_result(run())
-            except BaseException as e:      # re-raised on the calling thread by worker.result()
-                fut.set_exception(e)
-        threading.Thread(target=run_t).start()
-
-    if overlap and by_list:
-        # grouping the pairs by exon-level ref list does not read the piece bitsets: queued on the EM stream right away it runs
-        # BESIDE hgx_piece_compat (queued above on `stream`); the stream is ordered behind the scoring only further down
-        pair_groups = engine.Groups(db, 0, em_stream_)
-    start_gene()
-    if overlap:
-        if pair_groups is not None:
-            pair_groups.n_groups                     # host wait for the grouping alone: the stream is not yet behind the scoring
-        ev.make_wait(em_stream_)
-
-    def finish_gene():
-        if state["worker"] is not None:
-            state["worker"].result()                 # re-raises on this thread
-        res._names, res.counts_order, res.counts = names, gene["counted"], gene["cnt"]
-        if keep_classes:
-            res.gene_classes = gene["gcl"].to_host()[:2]
-        return gene["gcl"]
-
-    def run_em(classes, low, lengths):
-        t0 = time.perf_counter()
-        out, n_iter = _em_on_classes(classes, A, pl.name_rank, low, lengths, stream)
-        res.t_em += time.perf_counter() - t0
-        res.em.append({"n_classes": classes.n_classes, "remove_low": bool(low), "use_length": lengths is not None,
-                       "result": [[names[a], p] for a, p in out], "n_iter": n_iter})
-        return out
-
-    if hla:
-        em_stream = em_stream_ if overlap else stream
-        if by_list:
-            # the per-pair gene-level rows run beside the exon-level grouping (queueing them behind it, under the EM, was
-            # measured slower: 2.62 vs 2.37 ms -- the EM's short launches then wait for wave slots)
-            ecl = engine.Classes.of_level(pl, db, bufs, 0, em_stream, pair_groups)
-        else:
-            ecl = engine.Classes.dedup(bufs.exon_bits, db.n_pairs, pl.a_pad, hashes=bufs.exon_hash, stream=em_stream)
-        if heavy_lock is not None:
-            heavy_lock.release()
-            heavy_lock = None
-        if keep_classes:
-            res.exon_classes = ecl.to_host()[:2]
-        stream_saved, stream = stream, em_stream
-        exon_prob = gene_prob = run_em(ecl, remove_low, None)                    # core:1732-1737
-        stream = stream_saved
-        gcl = finish_gene()
-        groups = pl.rep_groups()
-        exon_alleles, psum = set(), 0.0
-        for i, (a, p) in enumerate(exon_prob):                                   # core:1739-1749
-            if i >= 10 and p < 0.03:
-                break
-            g = groups.get(a, [a])
-            if len(g) <= 1:
-                continue
-            psum += p
-            exon_alleles |= set(g)
-        if exon_alleles:                                                         # core:1752-1782
-            mask = np.zeros(pl.w64, np.uint64)
-            ea = np.fromiter(exon_alleles, np.int64, len(exon_alleles))
-            np.bitwise_or.at(mask, ea >> 6, np.uint64(1) << (ea & 63).astype(np.uint64))
-            # Gene_cmpt2 (gene classes filtered to exon_alleles, merged) and EM #2 in one call (hgx_em_masked)
-            t0 = time.perf_counter()
-            gcl.set_allele_rank(pl.name_rank)
-            prob2, first2, n_iter2, n_cls2 = gcl.em_masked(mask, A, True, pl.allele_len, stream)
-            res.t_em += time.perf_counter() - t0
-            present = np.nonzero(prob2 >= 0.0)[0]
-            order2 = present[np.lexsort((np.asarray(pl.name_rank)[present], first2[present]))].tolist()
-            gp = _sorted_result(prob2, order2)
-            res.em.append({"n_classes": n_cls2, "remove_low": True, "use_length": True,
-                           "result": [[names[a], p] for a, p in gp], "n_iter": n_iter2})
-            comb = {}
-            for a, p in exon_prob:
-                if a not in exon_alleles:
-                    comb[a] = p
-            for a, p in gp:
-                comb[a] = p * psum
-            gene_prob = _stable_desc([[a, p] for a, p in comb.items()])
-        ecl.close()
-        if pair_groups is not None:
-            pair_groups.close()
-    else:
-        gcl = finish_gene()
-        if heavy_lock is not None:
-            heavy_lock.release()
-            heavy_lock = None
-        if gcl.n_classes <= 1:                                                   # core:1784-1787 (quirk Q3)
-            if gcl.n_classes == 1:
-                raise TypeError("'dict_keys' object is not subscriptable (reference quirk Q3, typing_core.py:1787)")
-            gene_prob = []
-        else:
-            gene_prob = run_em(gcl, False, None)
-    res.gene_prob = [[names[a], p] for a, p in gene_prob]
-    gcl.close()
+def _result_from_handle(h, pl, res, keep_classes):
+    """Copy an hgx_typing result into a LocusResult (allele indices -> names)."""
+    L = capi.lib()
+    names = pl.names
+    n_counted, n_em, n_gp, t_em = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double()
+    capi.check(L.hgx_typing_dims(h, None, None, None, None, C.byref(n_counted), C.byref(n_em), C.byref(n_gp), C.byref(t_em)))
+    order = np.zeros(max(n_counted.value, 1), np.int32)
+    cnt = np.zeros(max(pl.n_alleles, 1), np.int64)
+    capi.check(L.hgx_typing_counts(h, capi.ptr(order), capi.ptr(cnt)))
+    res._names, res.counts_order, res.counts = names, order[:n_counted.value], cnt[:pl.n_alleles]
+    res.t_em = t_em.value
+    res.em = []
+    for k in range(n_em.value):
+        nc, it, low, ln, nr = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        capi.check(L.hgx_typing_em(h, C.c_int32(k), C.byref(nc), C.byref(it), C.byref(low), C.byref(ln), C.byref(nr), None, None))
+        al, pr = np.zeros(max(nr.value, 1), np.int32), np.zeros(max(nr.value, 1), np.float64)
+        capi.check(L.hgx_typing_em(h, C.c_int32(k), None, None, None, None, None, capi.ptr(al), capi.ptr(pr)))
+        res.em.append({"n_classes": nc.value, "remove_low": bool(low.value), "use_length": bool(ln.value),
+                       "result": [[names[a], float(p)] for a, p in zip(al[:nr.value].tolist(), pr[:nr.value].tolist())],
+                       "n_iter": it.value})
+    al, pr = np.zeros(max(n_gp.value, 1), np.int32), np.zeros(max(n_gp.value, 1), np.float64)
+    capi.check(L.hgx_typing_gene_prob(h, capi.ptr(al), capi.ptr(pr)))
+    res.gene_prob = [[names[a], float(p)] for a, p in zip(al[:n_gp.value].tolist(), pr[:n_gp.value].tolist())]
+    if keep_classes:
+        for level, attr in ((0, "exon_classes"), (1, "gene_classes")):
+            ch = C.c_void_p()
+            capi.check(L.hgx_typing_classes(h, C.c_int32(level), C.byref(ch)))
+            if ch:
+                setattr(res, attr, engine.Classes(ch, owned=False).to_host()[:2])
     return res
+
+
+def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dbatch=None, overlap=None, gate=None, events=None):
+    """The per-locus body of typing() for one piece batch: ONE call into libhgx (hgx_type_dbatch / hgx_type_batch, which
+    orchestrate scoring, grouping, dedup, Gene_counts, both EMs and the hand-off on the GPU; typing_core.py:1589-1789).
+    `dbatch`: the batch already resident in HBM (engine.DeviceBatch; bench.py types it repeatedly); `overlap`: None = the
+    library's default (gene side beside the exon-level EM when `stream` is None), else forced; `gate` (engine.Gate): several
+    samples in flight on one GPU take turns with their bandwidth-bound front; `events` = (compat begin, compat end, pairs
+    begin, pairs end) capi.Event objects recorded around hgx_piece_compat and the gene-level hgx_pair_classes launch."""
+    o = TypeOpts(int(bool(remove_low)), int(bool(keep_classes)), -1 if overlap is None else int(bool(overlap)), 0,
+                 gate.h if gate is not None else None, *[(e.h if e is not None else None) for e in (events or (None,) * 4)])
+    h = C.c_void_p()
+    L = capi.lib()
+    if dbatch is not None:
+        rc = L.hgx_type_dbatch(C.byref(h), pl.h, pl.index(), dbatch.h, C.byref(o), stream)
+    else:
+        rc = L.hgx_type_batch(C.byref(h), pl.h, pl.index(), batch.h, C.byref(o), stream)
+    if rc == -7:                                               # HGX_ETYPE: the reference's quirk Q3 (typing_core.py:1787)
+        raise TypeError(L.hgx_last_error().decode(errors="replace"))
+    capi.check(rc)
+    try:
+        return _result_from_handle(h, pl, res, keep_classes)
+    finally:
+        L.hgx_typing_destroy(h)
 
 
 def report_lines(res, simulation=False, true_alleles=(), output_allele_counts=False, best_alleles=False):

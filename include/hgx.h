@@ -33,6 +33,7 @@ extern "C" {
 #define HGX_EKEY         -4   /* reference would raise KeyError (EM quirk Q6, common:1365-1369) */
 #define HGX_ECOLLISION   -5   /* class-hash collision detected by the exact verify pass */
 #define HGX_EPARSE       -6   /* malformed SAM record / reference would assert          */
+#define HGX_ETYPE        -7   /* reference would raise TypeError (quirk Q3: a non-HLA locus with ONE class, typing_core.py:1787) */
 
 /* variant types, order = the reference's id order I < M < D (typing_process.py:275-295) */
 #define HGX_VAR_INSERTION 0
@@ -325,6 +326,55 @@ int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *loc, const char *
 int hgx_batch_trace_text(const hgx_batch *b, char *buf, size_t cap, size_t *needed);
 /* pileup nt_set per backbone position as a 4-bit mask A=1,C=2,G=4,T=8 and counts[L][6] (A,C,G,T,N,D) */
 int hgx_batch_pileup(const hgx_batch *b, uint8_t *nt_set, uint32_t *counts);
+
+/* ---- the per-locus body of typing() in one call --------------------------------------------------------------------
+ * Replaces typing_core.py:1589-1789 for one locus and one sample: Gene_counts and their print order (core:1187-1190,
+ * 1650-1651), the exon-level classes and EM #1 (core:1732-1737), the choice of exon_alleles (core:1739-1749), Gene_cmpt2 +
+ * EM #2 with allele lengths (core:1752-1782), the combination of both results, and the tie orders of the reference's stable
+ * sorts.  Non-HLA bases (codis, ...): gene level only, EM without pruning (core:1784-1789); ONE class there returns
+ * HGX_ETYPE, none an empty result.  The call only orchestrates the device entry points above -- on the caller's stream plus a
+ * recycled pair of side streams and, for >= 4096 pairs of an HLA-like locus, a host thread for the gene-level side that
+ * runs beside the exon-level EM -- and returns when the result is on the host.  `loc` must be the locus `ix` was made from. */
+typedef struct hgx_typing hgx_typing;     /* result of one (sample, locus) */
+typedef struct hgx_dbatch hgx_dbatch;     /* a piece batch resident in HBM */
+typedef struct hgx_gate hgx_gate;         /* see hgx_type_opts.gate */
+typedef struct hgx_type_opts {
+    int32_t remove_low;       /* remove_low_abundance_alleles for EM #1 of an HLA-like locus (args: --keep-low-abundance-alleles clears it) */
+    int32_t keep_classes;     /* keep the exon / gene class sets in the result (hgx_typing_classes)                     */
+    int32_t overlap;          /* -1: overlap the gene side when stream == NULL; 0 / 1: never / always (if >= 4096 pairs)  */
+    int32_t per_pair_exon;    /* exon-level rows per pair + dedup instead of per distinct ref list (same result; tests)   */
+    hgx_gate *gate;           /* several samples in flight on one GPU: held from entry until this sample's exon-level
+                                 classes exist, so that ONE bandwidth-bound front runs at a time, beside the others' EM phases */
+    void *ev_compat_begin, *ev_compat_end;   /* optional hipEvent_t recorded around hgx_piece_compat                      */
+    void *ev_pairs_begin, *ev_pairs_end;     /* ... and around the gene-level hgx_pair_classes launch (bench.py)           */
+} hgx_type_opts;
+
+int hgx_dbatch_create(hgx_dbatch **out, const hgx_batch *b, void *stream);     /* upload; returns when the copy is complete */
+int hgx_dbatch_destroy(hgx_dbatch *d);
+int hgx_dbatch_dims(const hgx_dbatch *d, int32_t *n_pieces, int32_t *n_pairs, int64_t *n_refs, int32_t *n_reads,
+                    int64_t *sum_piece_words, int64_t *n_gene_refs);
+int hgx_gate_create(hgx_gate **g);
+int hgx_gate_destroy(hgx_gate *g);
+
+int hgx_type_dbatch(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, const hgx_dbatch *db,
+                    const hgx_type_opts *opts, void *stream);
+int hgx_type_batch(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, const hgx_batch *batch,
+                   const hgx_type_opts *opts, void *stream);                   /* upload + hgx_type_dbatch */
+/* alignment file -> typing result: hgx_parse_alignment_file + hgx_type_batch (the whole of typing()'s per-locus work) */
+int hgx_type_file(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, const char *path, const char *regions_or_null,
+                  const hgx_parse_opts *parse_opts, const hgx_type_opts *opts, void *stream);
+int hgx_typing_destroy(hgx_typing *t);
+int hgx_typing_dims(const hgx_typing *t, int32_t *n_reads, int32_t *n_pairs, int32_t *n_pieces, int64_t *n_refs,
+                    int32_t *n_counted, int32_t *n_em, int32_t *n_gene_prob, double *em_seconds);
+/* ranked_allele[n_counted]: alleles with a non-zero count in the reference's print order; count_per_allele[n_alleles] */
+int hgx_typing_counts(const hgx_typing *t, int32_t *ranked_allele, int64_t *count_per_allele);
+/* the k-th single_abundance call: its flags and its result list (allele index, abundance) in the reference's order */
+int hgx_typing_em(const hgx_typing *t, int32_t k, int32_t *n_classes, int32_t *n_iter, int32_t *remove_low, int32_t *use_length,
+                  int32_t *n_result, int32_t *allele, double *prob);
+/* final Gene_prob (core:1732-1789): n_gene_prob entries */
+int hgx_typing_gene_prob(const hgx_typing *t, int32_t *allele, double *prob);
+/* with keep_classes: the class sets behind the result (owned by `t`; NULL if that level was not built) */
+int hgx_typing_classes(const hgx_typing *t, int32_t level, const hgx_classes **out);
 
 /* Kernel timing for roofline reports.  hgx_em_set_timing(1) makes hgx_em time a sample of its table-lookup mat-vec launches
  * (every 4th ungated rows pass and the cols pass after it), hgx_em_set_timing(2) every plain rows / cols pass, with events

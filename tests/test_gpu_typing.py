@@ -60,11 +60,12 @@ def test_config0_ten_thousand_reads_matches_reference():
                          simulation=o["simulation"], keep_classes=True)
     assert len(res.em) == len(fx["em"]) == 2
     A = pl.n_alleles
-    for got, exp, (bits, cnt) in zip(res.em, fx["em"], (res.exon_classes, None)):
+    for k, (got, exp) in enumerate(zip(res.em, fx["em"])):
         assert got["n_classes"] == len(exp["cmpt"])
         assert got["remove_low"] == exp["remove_low"] and got["use_length"] == exp["use_length"]
         _check_em(got, exp["result"], exp["n_iter"], exact=got["use_length"])
-        if bits is not None:           # EM #1's input: the exon-level class dict, bit rows + counts in dict order
+        if k == 0:                     # EM #1's input: the exon-level class dict, bit rows + counts in dict order
+            bits, cnt = res.exon_classes
             want = np.stack([gu.class_bits(fx, cid, A) for cid, _ in exp["cmpt"]])
             assert np.array_equal(bits[:, :want.shape[1]], want) and not bits[:, want.shape[1]:].any()
             assert cnt.tolist() == [n for _, n in exp["cmpt"]]
@@ -230,7 +231,9 @@ def test_genotyping_locus_from_index_files(tmp_path):
 def test_genotyping_locus_genotype_genome_mode(tmp_path):
     """8f-2, genotype-genome indexes (typing_core.py:2326-2397, 438-441): two loci embedded in one chromosome, the sample's
     reads of BOTH loci in one coordinate-sorted BAM on chromosome coordinates.  Each locus must see exactly its own reads
-    (samtools' overlap rule on `chr:left-right`) re-based to the locus, and report what the stand-alone run reports."""
+    (samtools' overlap rule on `chr:left-right`) re-based to the locus, and report what the stand-alone run reports.
+    As in the reference, typing() then sees base_fname = the genome's name ("genotype_genome"), not "hla": the report is
+    named after it and the HLA-only exon-level stage is off (typing_core.py:291, 1732)."""
     from hisatgenotype_amd import bamio
     a = synth.make_hla_like_locus(gene="A", n_alleles=120, n_vars=320, seed=81, sibling_frac=0.3)
     b = synth.make_hla_like_locus(gene="B", n_alleles=90, n_vars=260, length=2600, seed=82, var_id_base=7000)
@@ -247,6 +250,7 @@ def test_genotyping_locus_genotype_genome_mode(tmp_path):
                 f[0] = "%s_%s" % (loc.gene, f[0])
                 f[2] = "6"
                 lines.append("\t".join(f))
+        loc.base_fname = "genotype_genome"
         expect[loc.gene] = pyref.RefLocus(loc).run(synth.sam_text(loc, al))
     lines.sort(key=lambda l: int(l.split("\t")[3]))
     bam = tmp_path / "wgs.bam"
@@ -254,7 +258,7 @@ def test_genotyping_locus_genotype_genome_mode(tmp_path):
     hgx.genotyping_locus("hla", ["A", "B"], "genotype_genome", ix_dir, [], True, [["hisat2", "graph"]], ["wgs.fq"], True,
                          str(bam), 1, 10, 150, 400, False, 2, 0.0, 0.0, [], False, "assembly_graph", True, True, False,
                          False, True, [], 0, False, str(tmp_path), True, {})
-    rep = (tmp_path / "assembly_graph-hla.wgs.report").read_text().split("\n")
+    rep = (tmp_path / "assembly_graph-genotype_genome.wgs.report").read_text().split("\n")
     got_counts = [l.strip() for l in rep if "(count:" in l]
     want_counts = ["%d %s (count: %d)" % (i + 1, n, c) for g in ("A", "B") for i, (n, c) in enumerate(expect[g]["counts_sorted"])]
     assert got_counts == want_counts
