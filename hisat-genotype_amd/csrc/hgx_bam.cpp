@@ -31,15 +31,8 @@
 namespace {
 
 template <class F>
-void par_for(int n_threads, size_t n, F fn) {      // fn(thread, begin, end) over [0, n) in contiguous ranges
-    n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, n));
-    if (n_threads == 1) { fn(0, (size_t)0, n); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < n_threads; ++t) {
-        const size_t b = n * t / n_threads, e = n * (t + 1) / n_threads;
-        th.emplace_back([=] { fn(t, b, e); });
-    }
-    for (auto &x : th) x.join();
+void par_for(int n_threads, size_t n, F fn) {      // fn(thread, begin, end) over [0, n) in contiguous ranges, on the worker pool
+    hgx_par_ranges(n_threads, n, fn);
 }
 
 inline uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -97,7 +90,8 @@ int bgzf_inflate(const Bytes &data, int n_threads, Bytes &out) {
         blocks.push_back(b);
         off += blen;
     }
-    out.alloc(total);
+    out.alloc(total + 1);                    // (+1: room for the terminator of a last text line without '\n')
+    out.n = total;
     std::vector<int> bad(std::max(1, n_threads), 0);
     par_for(n_threads, blocks.size(), [&](int t, size_t b0, size_t b1) {
         for (size_t i = b0; i < b1; ++i) {
@@ -238,7 +232,7 @@ bool bam_record_text(const unsigned char *r, size_t len, const std::vector<std::
     return q == len;
 }
 
-struct Line { const char *p; uint32_t len, klen; uint64_t key; };     // klen = QNAME length, key = its first 8 bytes, big endian
+typedef hgx_line Line;           // {p, len, klen = QNAME length, key = its first 8 bytes, big endian}
 
 inline bool line_less(const Line &a, const Line &b) {
     if (a.key != b.key) return a.key < b.key;
@@ -250,7 +244,7 @@ inline bool line_less(const Line &a, const Line &b) {
 void make_line(const char *p, size_t len, Line &l) {
     const char *tab = (const char *)memchr(p, '\t', len);
     const size_t k = tab ? (size_t)(tab - p) : len;
-    l.p = p; l.len = (uint32_t)len; l.klen = (uint32_t)k;
+    l.p = const_cast<char *>(p); l.len = (uint32_t)len; l.klen = (uint32_t)k;
     uint64_t key = 0;
     for (size_t i = 0; i < 8; ++i) key = (key << 8) | (i < k ? (unsigned char)p[i] : 0);
     l.key = key;
@@ -361,142 +355,153 @@ inline int64_t cigar_text_reflen(const char *p, const char *e) {
 
 }   // namespace
 
-extern "C" int hgx_read_alignments(const char *path, const char *regions, int32_t n_threads, char **text_out, size_t *n_bytes_out) {
-    HARGCHK(path && text_out && n_bytes_out);
-    *text_out = nullptr;
-    *n_bytes_out = 0;
-    try {
-        if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
-        n_threads = std::max(1, std::min(n_threads, 64));
-        const std::vector<Region> regs = parse_regions(regions);
-        const bool filtered = regions != nullptr && regions[0] != 0;      // an empty list after parsing keeps nothing, like an unknown name
-        const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
-        auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-        double t_prev = now();
-        auto lap = [&](const char *what) {
-            if (!prof) return;
-            const double t = now();
-            fprintf(stderr, "[hgx_read_alignments] %-18s %8.1f ms\n", what, (t - t_prev) * 1e3);
-            t_prev = t;
-        };
-        Bytes data;
-        {
-            const int fd = open(path, O_RDONLY);
-            if (fd < 0) { hgx_set_error("cannot open %s", path); return HGX_EINVAL; }
-            struct stat sb;
-            if (fstat(fd, &sb) != 0 || sb.st_size < 0) { close(fd); hgx_set_error("cannot stat %s", path); return HGX_EINVAL; }
-            data.alloc((size_t)sb.st_size);                    // not zero-filled: every byte is written by the reads below
-            std::vector<int> bad(n_threads, 0);
-            par_for(data.size() > (8u << 20) ? n_threads : 1, data.size(), [&](int t, size_t b, size_t e) {
-                while (b < e) {
-                    const ssize_t got = pread(fd, data.data() + b, e - b, (off_t)b);
-                    if (got <= 0) { bad[t] = 1; return; }
-                    b += (size_t)got;
-                }
-            });
-            close(fd);
-            for (int v : bad) if (v) { hgx_set_error("short read on %s", path); return HGX_EINVAL; }
+// The reader proper: the records of `path` as a line table, stable-sorted by QNAME, over buffers `out` owns.  Every line is
+// followed by one byte the parser may overwrite (its terminator).
+int hgx_read_alignment_lines(const char *path, const char *regions, int n_threads, hgx_align_lines &out) {
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    n_threads = std::max(1, std::min(n_threads, 512));
+    const std::vector<Region> regs = parse_regions(regions);
+    const bool filtered = regions != nullptr && regions[0] != 0;      // an empty list after parsing keeps nothing, like an unknown name
+    const size_t n_reg = std::max<size_t>(1, regs.size());
+    const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now();
+    auto lap = [&](const char *what) {
+        if (!prof) return;
+        const double t = now();
+        fprintf(stderr, "[hgx_read_alignments] %-18s %8.1f ms\n", what, (t - t_prev) * 1e3);
+        t_prev = t;
+    };
+    Bytes data;
+    {
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) { hgx_set_error("cannot open %s", path); return HGX_EINVAL; }
+        struct stat sb;
+        if (fstat(fd, &sb) != 0 || sb.st_size < 0) { close(fd); hgx_set_error("cannot stat %s", path); return HGX_EINVAL; }
+        data.alloc((size_t)sb.st_size + 1);                // not zero-filled: every byte is written by the reads below
+        data.n = (size_t)sb.st_size;                       // (+1: room for the terminator of a last line without '\n')
+        std::vector<int> bad(n_threads, 0);
+        par_for(data.size() > (8u << 20) ? n_threads : 1, data.size(), [&](int t, size_t b, size_t e) {
+            while (b < e) {
+                const ssize_t got = pread(fd, data.data() + b, e - b, (off_t)b);
+                if (got <= 0) { bad[t] = 1; return; }
+                b += (size_t)got;
+            }
+        });
+        close(fd);
+        for (int v : bad) if (v) { hgx_set_error("short read on %s", path); return HGX_EINVAL; }
+    }
+    lap("read file");
+    Bytes raw;
+    if (data.size() >= 2 && data[0] == 0x1f && data[1] == 0x8b) {
+        const int rc = bgzf_inflate(data, n_threads, raw);
+        if (rc) return rc;
+        data.release();
+    } else raw.swap(data);
+    lap("inflate");
+    std::vector<Line> &lines = out.lines;
+    lines.clear();
+    if (raw.size() >= 4 && memcmp(raw.data(), "BAM\1", 4) == 0) {
+        const size_t n = raw.size();
+        if (n < 12) { hgx_set_error("truncated BAM header"); return HGX_EPARSE; }
+        size_t p = 8 + (size_t)rd32(&raw[4]);
+        if (p + 4 > n) { hgx_set_error("truncated BAM header"); return HGX_EPARSE; }
+        const uint32_t n_ref = rd32(&raw[p]);
+        p += 4;
+        std::vector<std::string> refs;
+        for (uint32_t i = 0; i < n_ref; ++i) {
+            if (p + 4 > n) { hgx_set_error("truncated BAM reference list"); return HGX_EPARSE; }
+            const uint32_t l_name = rd32(&raw[p]);
+            if (l_name == 0 || p + 4 + l_name + 4 > n) { hgx_set_error("truncated BAM reference list"); return HGX_EPARSE; }
+            refs.emplace_back((const char *)&raw[p + 4], l_name - 1);
+            p += 4 + l_name + 4;
         }
-        lap("read file");
-        Bytes raw;
-        if (data.size() >= 2 && data[0] == 0x1f && data[1] == 0x8b) {
-            const int rc = bgzf_inflate(data, n_threads, raw);
-            if (rc) return rc;
-            data.release();
-        } else raw.swap(data);
-
-        lap("inflate");
-        std::vector<PString> chunks;               // text produced from BAM records (kept alive for the Line pointers)
-        std::vector<Line> lines;
-        if (raw.size() >= 4 && memcmp(raw.data(), "BAM\1", 4) == 0) {
-            const size_t n = raw.size();
-            if (n < 12) { hgx_set_error("truncated BAM header"); return HGX_EPARSE; }
-            size_t p = 8 + (size_t)rd32(&raw[4]);
-            if (p + 4 > n) { hgx_set_error("truncated BAM header"); return HGX_EPARSE; }
-            const uint32_t n_ref = rd32(&raw[p]);
-            p += 4;
-            std::vector<std::string> refs;
-            for (uint32_t i = 0; i < n_ref; ++i) {
-                if (p + 4 > n) { hgx_set_error("truncated BAM reference list"); return HGX_EPARSE; }
-                const uint32_t l_name = rd32(&raw[p]);
-                if (l_name == 0 || p + 4 + l_name + 4 > n) { hgx_set_error("truncated BAM reference list"); return HGX_EPARSE; }
-                refs.emplace_back((const char *)&raw[p + 4], l_name - 1);
-                p += 4 + l_name + 4;
+        std::vector<std::vector<std::pair<size_t, uint32_t>>> per_region(n_reg);   // (offset after block_size, length)
+        while (p < n) {
+            if (p + 4 > n) { hgx_set_error("truncated BAM record at offset %zu", p); return HGX_EPARSE; }
+            // the walk is a pointer chase through memory other cores just wrote (one cache miss per record, ~120 ns each):
+            // touching the lines a few KB ahead turns it into a streaming read
+            if (p + 8192 < n) {
+                __builtin_prefetch(&raw[p + 4096]);
+                __builtin_prefetch(&raw[p + 4096 + 64]);
+                __builtin_prefetch(&raw[p + 4096 + 128]);
+                __builtin_prefetch(&raw[p + 4096 + 192]);
             }
-            std::vector<std::vector<std::pair<size_t, uint32_t>>> per_region(std::max<size_t>(1, regs.size()));   // (offset after block_size, length)
-            while (p < n) {
-                if (p + 4 > n) { hgx_set_error("truncated BAM record at offset %zu", p); return HGX_EPARSE; }
-                // the walk is a pointer chase through memory other cores just wrote (one cache miss per record, ~120 ns each):
-                // touching the lines a few KB ahead turns it into a streaming read
-                if (p + 8192 < n) {
-                    __builtin_prefetch(&raw[p + 4096]);
-                    __builtin_prefetch(&raw[p + 4096 + 64]);
-                    __builtin_prefetch(&raw[p + 4096 + 128]);
-                    __builtin_prefetch(&raw[p + 4096 + 192]);
-                }
-                const uint32_t bs = rd32(&raw[p]);
-                if (bs < 32 || p + 4 + bs > n) { hgx_set_error("truncated BAM record at offset %zu", p); return HGX_EPARSE; }
-                if (!filtered) per_region[0].push_back({p + 4, bs});
-                else {
-                    const unsigned char *r = &raw[p + 4];
-                    const int32_t rid = rdi32(r), pos = rdi32(r + 4);
-                    if (rid >= 0 && (size_t)rid < refs.size()) {
-                        // reference span from the CIGAR (bam_endpos: an unmapped or zero-length record counts as one base)
-                        const uint32_t l_rn = r[8], n_cig = rd16(r + 12), flag = rd16(r + 14);
-                        int64_t reflen = 0;
-                        if (!(flag & 4) && 32 + (size_t)l_rn + 4 * (size_t)n_cig <= bs) {
-                            const unsigned char *c = r + 32 + l_rn;
-                            for (uint32_t k = 0; k < n_cig; ++k) {
-                                const uint32_t v = rd32(c + 4 * k), op = v & 15;
-                                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += v >> 4;
-                            }
+            const uint32_t bs = rd32(&raw[p]);
+            if (bs < 32 || p + 4 + bs > n) { hgx_set_error("truncated BAM record at offset %zu", p); return HGX_EPARSE; }
+            if (!filtered) per_region[0].push_back({p + 4, bs});
+            else {
+                const unsigned char *r = &raw[p + 4];
+                const int32_t rid = rdi32(r), pos = rdi32(r + 4);
+                if (rid >= 0 && (size_t)rid < refs.size()) {
+                    // reference span from the CIGAR (bam_endpos: an unmapped or zero-length record counts as one base)
+                    const uint32_t l_rn = r[8], n_cig = rd16(r + 12), flag = rd16(r + 14);
+                    int64_t reflen = 0;
+                    if (!(flag & 4) && 32 + (size_t)l_rn + 4 * (size_t)n_cig <= bs) {
+                        const unsigned char *c = r + 32 + l_rn;
+                        for (uint32_t k = 0; k < n_cig; ++k) {
+                            const uint32_t v = rd32(c + 4 * k), op = v & 15;
+                            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += v >> 4;
                         }
-                        const int64_t end0 = (int64_t)pos + (reflen > 0 ? reflen : 1) - 1;
-                        const std::string &nm = refs[rid];
-                        for (size_t g = 0; g < regs.size(); ++g)
-                            if (region_hit(regs[g], nm.data(), nm.size(), pos, end0)) per_region[g].push_back({p + 4, bs});
                     }
+                    const int64_t end0 = (int64_t)pos + (reflen > 0 ? reflen : 1) - 1;
+                    const std::string &nm = refs[rid];
+                    for (size_t g = 0; g < regs.size(); ++g)
+                        if (region_hit(regs[g], nm.data(), nm.size(), pos, end0)) per_region[g].push_back({p + 4, bs});
                 }
-                p += 4 + (size_t)bs;
             }
-            std::vector<std::pair<size_t, uint32_t>> recs;
-            if (per_region.size() == 1) recs.swap(per_region[0]);
-            else for (auto &v : per_region) recs.insert(recs.end(), v.begin(), v.end());      // region after region, file order inside
-            lap("  BAM record walk");
-            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, recs.size() / 2000 + 1));
-            chunks.resize(T);
-            std::vector<int> bad(T, 0);
-            lines.resize(recs.size());
-            par_for(T, recs.size(), [&](int t, size_t b, size_t e) {
-                PString &s = chunks[t];
-                s.reserve((e - b) * 420);
-                std::vector<uint32_t> ends;
-                ends.reserve(e - b);
-                for (size_t i = b; i < e; ++i) {
-                    if (!bam_record_text(&raw[recs[i].first], recs[i].second, refs, s)) { bad[t] = 1; return; }
-                    if (s.size() > 0xFFFFFFFFull) { bad[t] = 2; return; }
-                    ends.push_back((uint32_t)s.size());
-                }
-                uint32_t prev = 0;                            // the chunk's text no longer moves: its line table
-                for (size_t i = b; i < e; ++i) {
-                    make_line(s.data() + prev, ends[i - b] - prev, lines[i]);
-                    prev = ends[i - b];
-                }
-            });
-            for (int v : bad) if (v) { hgx_set_error(v == 2 ? "BAM chunk too large" : "malformed BAM record"); return HGX_EPARSE; }
-            lap("  BAM -> text");
-        } else {
-            // SAM text: records = non-empty lines that do not start with '@'
-            const char *base = (const char *)raw.data(), *end = base + raw.size();
-            const char *p = base;
-            std::vector<std::vector<Line>> per_region(regs.size() > 1 ? regs.size() : 0);
-            while (p < end) {
+            p += 4 + (size_t)bs;
+        }
+        std::vector<std::pair<size_t, uint32_t>> recs;
+        if (per_region.size() == 1) recs.swap(per_region[0]);
+        else for (auto &v : per_region) recs.insert(recs.end(), v.begin(), v.end());      // region after region, file order inside
+        lap("  BAM record walk");
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, recs.size() / 2000 + 1));
+        out.chunks.clear();
+        out.chunks.resize(T);
+        std::vector<int> bad(T, 0);
+        lines.resize(recs.size());
+        par_for(T, recs.size(), [&](int t, size_t b, size_t e) {
+            PString &s = out.chunks[t];
+            s.reserve((e - b) * 420);
+            std::vector<uint32_t> ends;
+            ends.reserve(e - b);
+            for (size_t i = b; i < e; ++i) {
+                if (!bam_record_text(&raw[recs[i].first], recs[i].second, refs, s)) { bad[t] = 1; return; }
+                if (s.size() > 0xFFFFFFF0ull) { bad[t] = 2; return; }
+                ends.push_back((uint32_t)s.size());
+                s.push_back('\n');                              // the byte after every line belongs to the parser
+            }
+            uint32_t prev = 0;                            // the chunk's text no longer moves: its line table
+            for (size_t i = b; i < e; ++i) {
+                make_line(s.data() + prev, ends[i - b] - prev, lines[i]);
+                prev = ends[i - b] + 1;
+            }
+        });
+        for (int v : bad) if (v) { hgx_set_error(v == 2 ? "BAM chunk too large" : "malformed BAM record"); return HGX_EPARSE; }
+        raw.release();                                    // the records now live as text in out.chunks
+        lap("  BAM -> text");
+    } else {
+        // SAM text: records = non-empty lines that do not start with '@'.  Byte ranges are split among the workers; a worker
+        // owns the lines that START in its range; per worker and region a list, concatenated region-major (file order inside).
+        const char *base = (const char *)raw.data(), *end = base + raw.size();
+        const int nt = raw.size() > (4u << 20) ? n_threads : 1;
+        std::vector<std::vector<std::vector<Line>>> part(nt, std::vector<std::vector<Line>>(n_reg));
+        par_for(nt, raw.size(), [&](int t, size_t b0, size_t e0) {
+            const char *p = base + b0;
+            if (b0 > 0) {                       // skip the tail of a line owned by the previous range
+                const char *q = (const char *)memchr(p - 1, '\n', (size_t)(end - (p - 1)));
+                p = q ? q + 1 : end;
+            }
+            std::vector<std::vector<Line>> &mine = part[t];
+            if (!filtered) mine[0].reserve((e0 - b0) / 300 + 16);
+            while (p < base + e0 && p < end) {
                 const char *e = (const char *)memchr(p, '\n', (size_t)(end - p));
                 if (!e) e = end;
                 size_t len = (size_t)(e - p);
                 if (len && p[len - 1] == '\r') --len;
                 if (len && *p != '@') {
-                    if (!filtered) { Line l; make_line(p, len, l); lines.push_back(l); }
+                    if (!filtered) { Line l; make_line(p, len, l); mine[0].push_back(l); }
                     else {           // FLAG = 2nd field, RNAME = 3rd, POS = 4th (1-based), CIGAR = 6th
                         const char *f[6];
                         const char *q = p, *le = p + len;
@@ -509,34 +514,68 @@ extern "C" int hgx_read_alignments(const char *path, const char *regions, int32_
                             const int64_t end0 = pos0 + (reflen > 0 ? reflen : 1) - 1;
                             const size_t rl = (size_t)(f[2] - 1 - f[1]);
                             for (size_t g = 0; g < regs.size(); ++g)
-                                if (region_hit(regs[g], f[1], rl, pos0, end0)) {
-                                    Line l;
-                                    make_line(p, len, l);
-                                    if (per_region.empty()) lines.push_back(l); else per_region[g].push_back(l);
-                                }
+                                if (region_hit(regs[g], f[1], rl, pos0, end0)) { Line l; make_line(p, len, l); mine[g].push_back(l); }
                         }
                     }
                 }
                 p = e + 1;
             }
-            for (auto &v : per_region) lines.insert(lines.end(), v.begin(), v.end());
-        }
-        lap("decode / split");
-        sort_lines(lines, n_threads);
-        lap("name sort");
+        });
+        // offsets of every (region, worker) list in the final table, then a parallel copy
+        std::vector<size_t> off((size_t)nt * n_reg + 1, 0);
+        size_t tot = 0;
+        for (size_t g = 0; g < n_reg; ++g)
+            for (int t = 0; t < nt; ++t) { off[g * nt + t] = tot; tot += part[t][g].size(); }
+        lines.resize(tot);
+        par_for(nt, (size_t)nt, [&](int, size_t b, size_t e) {
+            for (size_t t = b; t < e; ++t)
+                for (size_t g = 0; g < n_reg; ++g)
+                    if (!part[t][g].empty()) memcpy(&lines[off[g * nt + t]], part[t][g].data(), part[t][g].size() * sizeof(Line));
+        });
+    }
+    lap("decode / split");
+    // an aligner writes its records grouped by read already: a stable sort would not move anything
+    bool sorted = true;
+    {
+        std::vector<int> unsorted(n_threads, 0);
+        par_for(lines.size() > 100000 ? n_threads : 1, lines.size(), [&](int t, size_t b, size_t e) {
+            for (size_t i = std::max<size_t>(b, 1); i < e; ++i)
+                if (line_less(lines[i], lines[i - 1])) { unsorted[t] = 1; return; }
+        });
+        for (int v : unsorted) if (v) sorted = false;
+    }
+    if (!sorted) sort_lines(lines, n_threads);
+    lap(sorted ? "name order check" : "name sort");
+    hgx_host_free(out.raw);
+    out.raw = (char *)raw.p;                 // the line table points into it (SAM text); BAM text lives in out.chunks
+    raw.p = nullptr;
+    raw.n = 0;
+    return HGX_OK;
+}
+
+extern "C" int hgx_read_alignments(const char *path, const char *regions, int32_t n_threads, char **text_out, size_t *n_bytes_out) {
+    HARGCHK(path && text_out && n_bytes_out);
+    *text_out = nullptr;
+    *n_bytes_out = 0;
+    try {
+        hgx_align_lines al;
+        const int rc = hgx_read_alignment_lines(path, regions, n_threads, al);
+        if (rc) return rc;
+        if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+        n_threads = std::max(1, std::min(n_threads, 512));
+        const std::vector<Line> &lines = al.lines;
         size_t total = 0;
         std::vector<size_t> offs(lines.size() + 1, 0);
         for (size_t i = 0; i < lines.size(); ++i) { offs[i] = total; total += (size_t)lines[i].len + 1; }
         offs[lines.size()] = total;
         char *out = (char *)hgx_host_alloc(total + 1);
-        par_for(n_threads, lines.size(), [&](int, size_t b, size_t e) {
+        par_for(total > (8u << 20) ? n_threads : 1, lines.size(), [&](int, size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 memcpy(out + offs[i], lines[i].p, lines[i].len);
                 out[offs[i] + lines[i].len] = '\n';
             }
         });
         out[total] = 0;
-        lap("emit");
         *text_out = out;
         *n_bytes_out = total;
         return HGX_OK;

@@ -268,29 +268,44 @@ int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &L, int32_t left, int32_t
     return hgx_intern_masks(b, (uint16_t)lo_w, (uint8_t)nw, buf);
 }
 
-// Order the distinct-piece table by first covered word (then width) and renumber the refs: consecutive pieces then
-// share an index window, which is what the LDS-tiled compatibility kernel exploits.  Masks are re-packed in the same order.
-void hgx_finalize_batch(hgx_batch &b) {
+// Order the distinct-piece table by first covered word, then width, then CONTENT (hash of the mask words, the words themselves
+// on a hash tie) and renumber the refs.  Consecutive pieces then share an index window, which is what the LDS-tiled
+// compatibility kernel exploits; and the order depends on nothing but the set of pieces, so a batch is the same whatever
+// the number of front-end workers that interned them, in whatever order.  Masks are re-packed in the same order.
+void hgx_finalize_batch(hgx_batch &b, int n_threads) {
     const size_t n = b.pieces.size();
     std::vector<uint32_t> order(n), new_id(n);
-    for (size_t i = 0; i < n; ++i) order[i] = (uint32_t)i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        if (b.pieces[x].lo_word != b.pieces[y].lo_word) return b.pieces[x].lo_word < b.pieces[y].lo_word;
-        return b.pieces[x].n_words < b.pieces[y].n_words;
+    std::vector<uint64_t> hash(n);
+    hgx_par_ranges(n > 20000 ? n_threads : 1, n, [&](int, size_t lo, size_t hi) {
+        for (size_t i = lo; i < hi; ++i) {
+            order[i] = (uint32_t)i;
+            hash[i] = PieceTable::hash(b.pieces[i].lo_word, b.pieces[i].n_words, &b.masks[b.pieces[i].mask_off]);
+        }
+    });
+    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const hgx_piece &px = b.pieces[x], &py = b.pieces[y];
+        if (px.lo_word != py.lo_word) return px.lo_word < py.lo_word;
+        if (px.n_words != py.n_words) return px.n_words < py.n_words;
+        if (hash[x] != hash[y]) return hash[x] < hash[y];
+        return memcmp(&b.masks[px.mask_off], &b.masks[py.mask_off], 8 * (size_t)px.n_words) < 0;
     });
     std::vector<hgx_piece> np(n);
-    std::vector<uint32_t> nm;
-    nm.reserve(b.masks.size());
+    std::vector<uint32_t> nm(b.masks.size());
+    size_t at = 0;
     for (size_t k = 0; k < n; ++k) {
         const hgx_piece &src = b.pieces[order[k]];
         new_id[order[k]] = (uint32_t)k;
         np[k] = src;
-        np[k].mask_off = (uint32_t)nm.size();
-        nm.insert(nm.end(), b.masks.begin() + src.mask_off, b.masks.begin() + src.mask_off + 2 * (size_t)src.n_words);
+        np[k].mask_off = (uint32_t)at;
+        memcpy(&nm[at], &b.masks[src.mask_off], 8 * (size_t)src.n_words);
+        at += 2 * (size_t)src.n_words;
     }
+    nm.resize(at);
     b.pieces.swap(np);
     b.masks.swap(nm);
-    for (auto &r : b.pair_ref) r = (r & 0x80000000u) | new_id[r & 0x7fffffffu];
+    hgx_par_ranges(b.pair_ref.size() > 200000 ? n_threads : 1, b.pair_ref.size(), [&](int, size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; ++k) b.pair_ref[k] = (b.pair_ref[k] & 0x80000000u) | new_id[b.pair_ref[k] & 0x7fffffffu];
+    });
     b.table.clear();
 }
 
@@ -406,4 +421,80 @@ void hgx_host_pool_trim() {
     for (auto &kv : P.free_blocks) free(kv.second);
     P.free_blocks.clear();
     P.held = 0;
+}
+
+// ---- persistent host worker pool (declared in hgx_internal.hpp) -------------------------------------------------
+// The ingestion path runs half a dozen short parallel phases per sample (2-20 ms each); creating 100-250 threads for
+// every phase costs more than some of the phases.  Workers are created once, sleep on a condition variable between
+// phases and are shared by all callers; a caller that finds the pool busy (another sample being parsed at the same
+// time) runs its phase on temporary threads instead of waiting.
+#include <atomic>
+#include <condition_variable>
+#include <thread>
+namespace {
+struct WorkerPool {
+    std::mutex owner;                      // one parallel phase at a time
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::vector<std::thread> workers;
+    const std::function<void(int)> *body = nullptr;
+    uint64_t generation = 0;
+    int want = 0;                          // workers 0 .. want-1 take part in the current phase (as ids 1 .. want)
+    int running = 0;
+    bool stopping = false;
+
+    void loop(int id) {
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_job.wait(lk, [&] { return stopping || generation != seen; });
+            if (stopping) return;
+            seen = generation;
+            if (id >= want) continue;
+            const std::function<void(int)> *fn = body;
+            lk.unlock();
+            (*fn)(id + 1);
+            lk.lock();
+            if (--running == 0) cv_done.notify_one();
+        }
+    }
+    ~WorkerPool() {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            stopping = true;
+        }
+        cv_job.notify_all();
+        for (auto &t : workers) t.join();
+    }
+};
+WorkerPool &worker_pool() { static WorkerPool *p = new WorkerPool(); return *p; }    // leaked on purpose: no join at exit
+}   // namespace
+
+void hgx_run_workers(int n, const std::function<void(int)> &body) {
+    if (n <= 1) { body(0); return; }
+    WorkerPool &P = worker_pool();
+    std::unique_lock<std::mutex> own(P.owner, std::try_to_lock);
+    if (!own.owns_lock()) {                 // pool busy with another caller's phase: temporary threads
+        std::vector<std::thread> th;
+        for (int t = 1; t < n; ++t) th.emplace_back([&body, t] { body(t); });
+        body(0);
+        for (auto &x : th) x.join();
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        while ((int)P.workers.size() < n - 1) {
+            const int id = (int)P.workers.size();
+            P.workers.emplace_back([&P, id] { P.loop(id); });
+        }
+        P.body = &body;
+        P.want = n - 1;
+        P.running = n - 1;
+        ++P.generation;
+    }
+    P.cv_job.notify_all();
+    body(0);
+    std::unique_lock<std::mutex> lk(P.mu);
+    P.cv_done.wait(lk, [&] { return P.running == 0; });
+    P.body = nullptr;
 }

@@ -1,7 +1,10 @@
 // hgx_internal.hpp -- host-side data model shared by the front-end translation units.
 #pragma once
+#include <algorithm>
 #include <array>
+#include <atomic>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -120,8 +123,39 @@ struct HostPoolAlloc {
 };
 typedef std::basic_string<char, std::char_traits<char>, HostPoolAlloc<char>> PString;
 
+// Persistent host worker pool (hgx_host.cpp): body(worker) runs on `n` threads (worker 0 = the caller) and the call returns when
+// all are done.  The helpers below cut [0, n_items) into contiguous ranges / hand out task indices dynamically.
+void hgx_run_workers(int n, const std::function<void(int)> &body);
+template <class F>
+inline void hgx_par_ranges(int n_threads, size_t n_items, F fn) {          // fn(thread, begin, end)
+    n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(n_threads, 1), n_items));
+    if (n_threads == 1) { fn(0, (size_t)0, n_items); return; }
+    hgx_run_workers(n_threads, [&](int t) { fn(t, n_items * (size_t)t / n_threads, n_items * (size_t)(t + 1) / n_threads); });
+}
+template <class F>
+inline void hgx_par_tasks(int n_threads, size_t n_tasks, F fn) {           // fn(thread, task): tasks pulled from a shared counter
+    n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(n_threads, 1), n_tasks));
+    if (n_threads == 1) { for (size_t k = 0; k < n_tasks; ++k) fn(0, k); return; }
+    std::atomic<size_t> next{0};
+    hgx_run_workers(n_threads, [&](int t) { for (size_t k; (k = next.fetch_add(1)) < n_tasks;) fn(t, k); });
+}
+
+// The alignment reader's internal result (hgx_bam.cpp -> hgx_sam.cpp): the records as a line table, stable-sorted by QNAME, over
+// buffers this object owns.  p[len] is a byte the parser may overwrite (the line's terminator).
+struct hgx_line { char *p; uint32_t len, klen; uint64_t key; };     // klen = QNAME length, key = its first 8 bytes, big endian
+struct hgx_align_lines {
+    char *raw = nullptr;                   // SAM text as read (pooled block), or null
+    std::vector<PString> chunks;           // text decoded from BAM records
+    std::vector<hgx_line> lines;
+    hgx_align_lines() = default;
+    hgx_align_lines(const hgx_align_lines &) = delete;
+    hgx_align_lines &operator=(const hgx_align_lines &) = delete;
+    ~hgx_align_lines() { hgx_host_free(raw); }
+};
+int hgx_read_alignment_lines(const char *path, const char *regions, int n_threads, hgx_align_lines &out);
+
 // find-or-insert a piece given its word range and (MP,P) mask words
 uint32_t hgx_intern_masks(hgx_batch &b, uint16_t lo, uint8_t nw, const uint32_t *m);
-void hgx_finalize_batch(hgx_batch &b);
+void hgx_finalize_batch(hgx_batch &b, int n_threads = 1);
 // alternatives tables (defined in hgx_sam.cpp)
 int hgx_build_alternatives(hgx_locus &loc);

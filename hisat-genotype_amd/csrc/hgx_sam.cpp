@@ -201,13 +201,9 @@ struct Ht {
     bool operator==(const Ht &o) const { return left == o.left && right == o.right && ids == o.ids; }
 };
 
-struct Parser {
-    const hgx_locus &L;
-    hgx_parse_opts o;
-    hgx_batch &B;
-    std::vector<Novel> novel;
-    std::unordered_map<uint64_t, int> novel_lookup;   // (type,pos,key) -> id
-    // alternatives with spellings, sorted by anchor
+// The alternatives of a locus with their spellings, sorted by anchor (built from hgx_locus::alts_left / alts_right once per
+// parse; every chunk's Parser reads them).
+struct AltTables {
     struct AltRec {
         int anchor;
         std::string key;
@@ -216,6 +212,42 @@ struct Parser {
     };
     std::vector<AltRec> alt_l, alt_r;
     std::vector<int> alt_l_pos, alt_r_pos;
+    explicit AltTables(const hgx_locus &L) {
+        auto fill = [&](const std::vector<AltEntry> &src, std::vector<AltRec> &dst, bool left) {
+            for (auto &e : src) {
+                AltRec r;
+                r.key_ht.push_back(e.key.left);
+                r.key_ht.insert(r.key_ht.end(), e.key.vars.begin(), e.key.vars.end());
+                r.key_ht.push_back(e.key.right);
+                r.anchor = left ? e.key.right : e.key.left;
+                r.key = AltBuilder::spell(L, r.key_ht);
+                for (auto &a : e.alts) {
+                    HtVec h;
+                    h.push_back(a.left);
+                    h.insert(h.end(), a.vars.begin(), a.vars.end());
+                    h.push_back(a.right);
+                    r.alts.push_back(h);
+                }
+                dst.push_back(std::move(r));
+            }
+        };
+        fill(L.alts_left, alt_l, true);
+        fill(L.alts_right, alt_r, false);
+        for (auto &r : alt_l) alt_l_pos.push_back(r.anchor);
+        for (auto &r : alt_r) alt_r_pos.push_back(r.anchor);
+    }
+};
+
+struct Parser {
+    const hgx_locus &L;
+    hgx_parse_opts o;
+    hgx_batch &B;
+    std::vector<Novel> novel;
+    std::unordered_map<uint64_t, int> novel_lookup;   // (type,pos,key) -> id
+    // alternatives with spellings, sorted by anchor: built once per parse (AltTables) and shared, read-only, by all chunks
+    typedef AltTables::AltRec AltRec;
+    const std::vector<AltRec> &alt_l, &alt_r;
+    const std::vector<int> &alt_l_pos, &alt_r_pos;
 
     const hgx_batch &PILE;   // pileup tables (nt_set, counts) shared by all chunks
     struct ZsItem { int gap; char type; int id; };
@@ -225,42 +257,8 @@ struct Parser {
     std::vector<Ht> ex_buf, union_buf;
     std::vector<int32_t> ids_buf;
     std::vector<uint32_t> eref_buf, gref_buf;
-    Parser(const hgx_locus &l, const hgx_parse_opts &opts, hgx_batch &b, const hgx_batch &pile) : L(l), o(opts), B(b), PILE(pile) {
-        for (auto &e : L.alts_left) {
-            AltRec r;
-            r.key_ht.push_back(e.key.left);
-            r.key_ht.insert(r.key_ht.end(), e.key.vars.begin(), e.key.vars.end());
-            r.key_ht.push_back(e.key.right);
-            r.anchor = e.key.right;
-            r.key = AltBuilder::spell(L, r.key_ht);
-            for (auto &a : e.alts) {
-                HtVec h;
-                h.push_back(a.left);
-                h.insert(h.end(), a.vars.begin(), a.vars.end());
-                h.push_back(a.right);
-                r.alts.push_back(h);
-            }
-            alt_l.push_back(r);
-        }
-        for (auto &e : L.alts_right) {
-            AltRec r;
-            r.key_ht.push_back(e.key.left);
-            r.key_ht.insert(r.key_ht.end(), e.key.vars.begin(), e.key.vars.end());
-            r.key_ht.push_back(e.key.right);
-            r.anchor = e.key.left;
-            r.key = AltBuilder::spell(L, r.key_ht);
-            for (auto &a : e.alts) {
-                HtVec h;
-                h.push_back(a.left);
-                h.insert(h.end(), a.vars.begin(), a.vars.end());
-                h.push_back(a.right);
-                r.alts.push_back(h);
-            }
-            alt_r.push_back(r);
-        }
-        for (auto &r : alt_l) alt_l_pos.push_back(r.anchor);
-        for (auto &r : alt_r) alt_r_pos.push_back(r.anchor);
-    }
+    Parser(const hgx_locus &l, const hgx_parse_opts &opts, hgx_batch &b, const hgx_batch &pile, const AltTables &at)
+        : L(l), o(opts), B(b), alt_l(at.alt_l), alt_r(at.alt_r), alt_l_pos(at.alt_l_pos), alt_r_pos(at.alt_r_pos), PILE(pile) {}
 
     // ---- variant accessors over known + novel ids --------------------------------------------
     int vtype(int id) const { return id < L.V ? L.type[id] : novel[id - L.V].type; }
@@ -959,11 +957,11 @@ struct ChunkResult {
 
 // The streaming loop (core:800-1587) over records [i0, i1).  Chunks start at read-id boundaries of the name-grouped
 // stream, so pairs, the duplicate-mate filters and the flush protocol never straddle two chunks.
-void process_chunk(const hgx_locus &L, const hgx_parse_opts &o, const std::vector<Fields> &recs, const std::vector<uint8_t> &ok,
+void process_chunk(const hgx_locus &L, const hgx_parse_opts &o, const AltTables &alts, const Fields *recs, const uint8_t *ok,
                    size_t i0, size_t i1, const hgx_batch &pile, bool is_last, long expected_interdist, ChunkResult &out) {
     hgx_batch &B = out.local;
     try {
-        Parser P(L, o, B, pile);
+        Parser P(L, o, B, pile, alts);
         // The stream is name-grouped, so the reference's global left/right/unpaired id sets (core:857-872) reduce to
         // three flags per group of equal read ids.
         const char *grp = nullptr;
@@ -1077,12 +1075,12 @@ void process_chunk(const hgx_locus &L, const hgx_parse_opts &o, const std::vecto
 }
 
 // get_pair_interdist (common:1187-1265): median inner distance of unique concordant pairs (CODIS D18S51 only)
-long pair_interdist(const std::vector<Fields> &recs, const std::vector<uint8_t> &ok, bool simulation) {
+long pair_interdist(const Fields *recs, const uint8_t *ok, size_t n_recs, bool simulation) {
     std::vector<long> dists;
     std::string prev;
     bool hp = false;
     std::vector<std::pair<long, long>> rd;
-    for (size_t i = 0; i < recs.size(); ++i) {
+    for (size_t i = 0; i < n_recs; ++i) {
         if (!ok[i]) continue;
         const Fields &f = recs[i];
         if (f.flag & 0x4) continue;
@@ -1109,51 +1107,161 @@ long pair_interdist(const std::vector<Fields> &recs, const std::vector<uint8_t> 
     return dists.empty() ? -1 : dists[dists.size() / 2];
 }
 
-template <class F>
-void parallel_for(int n_threads, size_t n, F fn) {   // fn(thread, begin, end)
-    if (n_threads <= 1 || n < 2) { fn(0, (size_t)0, n); return; }
-    std::vector<std::thread> th;
-    const size_t per = (n + n_threads - 1) / n_threads;
-    for (int t = 0; t < n_threads; ++t) {
-        const size_t b = std::min(n, per * t), e = std::min(n, per * (t + 1));
-        th.emplace_back([=] { fn(t, b, e); });
+// Chunk results -> one batch.  Every chunk interned its pieces into a private table; here the tables are united without a
+// serial pass over them: (1) per chunk, its distinct pieces are bucketed by hash partition; (2) per partition, one worker
+// interns the bucket entries of all chunks (in chunk order) into a partition-private table; (3) partition sizes are
+// prefix-summed into global piece ids; (4) per chunk, refs are renumbered and copied to their place in the united arrays.
+// The ids given here carry no meaning: hgx_finalize_batch orders the table by content, so the batch is the same whatever the
+// number of workers and chunks.
+void merge_chunks(hgx_batch &B, std::vector<ChunkResult> &res, int n_threads) {
+    const size_t nc = res.size();
+    if (nc == 1) {                              // one chunk: its table is the batch's
+        hgx_batch &lb = res[0].local;
+        B.pieces.swap(lb.pieces);
+        B.masks.swap(lb.masks);
+        B.pair_off.swap(lb.pair_off);
+        B.pair_ref.swap(lb.pair_ref);
+        B.n_reads = lb.n_reads;
+        B.trace.swap(lb.trace);
+        return;
     }
-    for (auto &x : th) x.join();
+    const int P = std::max(1, std::min(n_threads, 64));
+    struct Ent { uint32_t local; uint64_t hash; };
+    std::vector<std::vector<std::vector<Ent>>> bucket(nc, std::vector<std::vector<Ent>>(P));     // [chunk][partition]
+    hgx_par_tasks(n_threads, nc, [&](int, size_t c) {
+        const hgx_batch &lb = res[c].local;
+        for (size_t k = 0; k < lb.pieces.size(); ++k) {
+            const hgx_piece &pc = lb.pieces[k];
+            const uint64_t h = PieceTable::hash(pc.lo_word, pc.n_words, &lb.masks[pc.mask_off]);
+            bucket[c][(h >> 40) % P].push_back(Ent{(uint32_t)k, h});
+        }
+    });
+    std::vector<hgx_batch> part(P);                                        // partition-private distinct pieces
+    std::vector<std::vector<uint32_t>> remap(nc);                          // [chunk][local id] -> (partition-local id, patched below)
+    for (size_t c = 0; c < nc; ++c) remap[c].resize(res[c].local.pieces.size());
+    hgx_par_tasks(n_threads, (size_t)P, [&](int, size_t p) {
+        for (size_t c = 0; c < nc; ++c) {
+            const hgx_batch &lb = res[c].local;
+            for (const Ent &e : bucket[c][p]) {
+                const hgx_piece &pc = lb.pieces[e.local];
+                remap[c][e.local] = hgx_intern_masks(part[p], pc.lo_word, pc.n_words, &lb.masks[pc.mask_off]);
+            }
+        }
+    });
+    std::vector<uint32_t> pbase(P + 1, 0), mbase(P + 1, 0);
+    for (int p = 0; p < P; ++p) {
+        pbase[p + 1] = pbase[p] + (uint32_t)part[p].pieces.size();
+        mbase[p + 1] = mbase[p] + (uint32_t)part[p].masks.size();
+    }
+    B.pieces.resize(pbase[P]);
+    B.masks.resize(mbase[P]);
+    hgx_par_tasks(n_threads, (size_t)P, [&](int, size_t p) {
+        for (size_t k = 0; k < part[p].pieces.size(); ++k) {
+            hgx_piece pc = part[p].pieces[k];
+            pc.mask_off += mbase[p];
+            B.pieces[pbase[p] + k] = pc;
+        }
+        if (!part[p].masks.empty()) memcpy(&B.masks[mbase[p]], part[p].masks.data(), part[p].masks.size() * 4);
+    });
+    std::vector<size_t> roff(nc + 1, 0), poff(nc + 1, 0);
+    for (size_t c = 0; c < nc; ++c) {
+        roff[c + 1] = roff[c] + res[c].local.pair_ref.size();
+        poff[c + 1] = poff[c] + res[c].local.pair_off.size() - 1;
+        B.n_reads += res[c].local.n_reads;
+    }
+    B.pair_ref.resize(roff[nc]);
+    B.pair_off.resize(poff[nc] + 1);
+    B.pair_off[0] = 0;
+    hgx_par_tasks(n_threads, nc, [&](int, size_t c) {
+        const hgx_batch &lb = res[c].local;
+        // which partition a local piece went to: recomputed from the buckets (remap holds the partition-local id)
+        std::vector<uint32_t> gid(lb.pieces.size());
+        for (int p = 0; p < P; ++p)
+            for (const Ent &e : bucket[c][p]) gid[e.local] = pbase[p] + remap[c][e.local];
+        uint32_t *dst = &B.pair_ref[roff[c]];
+        for (size_t k = 0; k < lb.pair_ref.size(); ++k) {
+            const uint32_t ref = lb.pair_ref[k];
+            dst[k] = (ref & 0x80000000u) | gid[ref & 0x7fffffffu];
+        }
+        for (size_t k = 1; k < lb.pair_off.size(); ++k) B.pair_off[poff[c] + k] = (int32_t)(roff[c] + lb.pair_off[k]);
+    });
+    for (auto &r : res)
+        for (auto &t : r.local.trace) B.trace.push_back(std::move(t));
+}
+
+template <class F>
+void parallel_for(int n_threads, size_t n, F fn) {   // fn(thread, begin, end), on the persistent worker pool
+    hgx_par_ranges(n_threads, n, fn);
 }
 
 }   // namespace
 
-// `owned` != nullptr: a writable buffer of n_bytes + 1 bytes that the parser may modify in place (no private copy)
-static int parse_text(hgx_batch **out, const hgx_locus *Lc, const char *sam, char *owned, size_t n_bytes, const hgx_parse_opts *opts);
+static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts);
 
+// SAM text (name-grouped) -> private writable copy + line table -> parse_lines
 extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts) {
-    return parse_text(out, Lc, sam, nullptr, n_bytes, opts);
+    HARGCHK(out && Lc && (sam || n_bytes == 0) && opts);
+    try {
+        int n_threads = opts->n_threads > 0 ? opts->n_threads : (int)std::thread::hardware_concurrency();
+        n_threads = std::max(1, std::min(n_threads, 512));
+        struct PoolFree { void operator()(char *p) const { hgx_host_free(p); } };
+        std::unique_ptr<char, PoolFree> text((char *)hgx_host_alloc(n_bytes + 1));      // tokens are NUL-terminated in place
+        char *base = text.get(), *end = base + n_bytes;
+        const int nt = n_bytes > (8u << 20) ? n_threads : 1;
+        std::vector<std::vector<hgx_line>> part(nt);
+        parallel_for(nt, n_bytes, [&](int, size_t b0, size_t e0) { memcpy(base + b0, sam + b0, e0 - b0); });
+        *end = '\n';
+        parallel_for(nt, n_bytes, [&](int t, size_t b0, size_t e0) {
+            char *p = base + b0;                    // this worker owns the lines that START in [b0, e0)
+            if (b0 > 0) {
+                char *q = (char *)memchr(p - 1, '\n', end - (p - 1));
+                p = q ? q + 1 : end;
+            }
+            part[t].reserve((e0 - b0) / 300 + 16);
+            while (p < base + e0 && p < end) {
+                char *e = (char *)memchr(p, '\n', end - p);
+                if (!e) e = end;
+                if (e > p && *p != '@') part[t].push_back(hgx_line{p, (uint32_t)(e - p), 0, 0});
+                p = e + 1;
+            }
+        });
+        std::vector<size_t> off(nt + 1, 0);
+        for (int t = 0; t < nt; ++t) off[t + 1] = off[t] + part[t].size();
+        std::vector<hgx_line> lines(off[nt]);
+        parallel_for(nt, (size_t)nt, [&](int, size_t b, size_t e) {
+            for (size_t t = b; t < e; ++t)
+                if (!part[t].empty()) memcpy(&lines[off[t]], part[t].data(), part[t].size() * sizeof(hgx_line));
+        });
+        return parse_lines(out, Lc, lines.data(), lines.size(), opts);
+    } catch (const std::exception &e) {
+        hgx_set_error("%s", e.what());
+        return HGX_EINVAL;
+    }
 }
-
-extern "C" int hgx_read_alignments(const char *path, const char *regions, int32_t n_threads, char **text_out, size_t *n_bytes_out);
-extern "C" int hgx_free_text(char *text);
 
 extern "C" int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *Lc, const char *path, const char *regions,
                                         const hgx_parse_opts *opts) {
     HARGCHK(out && Lc && path && opts);
-    char *text = nullptr;
-    size_t n = 0;
     const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
-    int rc = hgx_read_alignments(path, regions, opts->n_threads, &text, &n);
-    if (rc) return rc;
-    const double t1 = now();
-    rc = parse_text(out, Lc, nullptr, text, n, opts);        // tokenises the reader's buffer in place
-    const double t2 = now();
-    hgx_free_text(text);
-    if (prof) fprintf(stderr, "[hgx_parse_alignment_file] read %.1f ms, parse %.1f ms, free %.1f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3,
-                      (now() - t2) * 1e3);
-    return rc;
+    try {
+        const double t0 = now();
+        hgx_align_lines al;                     // the reader's buffers are tokenised in place (no copy, no trip through the caller)
+        int rc = hgx_read_alignment_lines(path, regions, opts->n_threads, al);
+        if (rc) return rc;
+        const double t1 = now();
+        rc = parse_lines(out, Lc, al.lines.data(), al.lines.size(), opts);
+        if (prof) fprintf(stderr, "[hgx_parse_alignment_file] read %.1f ms, parse %.1f ms\n", (t1 - t0) * 1e3, (now() - t1) * 1e3);
+        return rc;
+    } catch (const std::exception &e) {
+        hgx_set_error("hgx_parse_alignment_file: %s", e.what());
+        return HGX_ENOMEM;
+    }
 }
 
-static int parse_text(hgx_batch **out, const hgx_locus *Lc, const char *sam, char *owned, size_t n_bytes, const hgx_parse_opts *opts) {
-    HARGCHK(out && Lc && (sam || owned || n_bytes == 0) && opts);
+// lines: name-grouped records; lines[i].p[lines[i].len] is writable (it becomes the record's terminator)
+static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts) {
+    HARGCHK(out && Lc && (lines || n == 0) && opts);
     hgx_locus &L = *const_cast<hgx_locus *>(Lc);
     hgx_batch *B = new hgx_batch();
     try {
@@ -1167,49 +1275,19 @@ static int parse_text(hgx_batch **out, const hgx_locus *Lc, const char *sam, cha
             t_prev = t;
         };
         hgx_build_alternatives(L);
+        const AltTables alts(L);
         lap("alternatives");
         const int n_ref = (int)L.backbone.size();
         int n_threads = opts->n_threads > 0 ? opts->n_threads : (int)std::thread::hardware_concurrency();
-        n_threads = std::max(1, std::min(n_threads, 64));
+        n_threads = std::max(1, std::min(n_threads, 512));
         if (opts->keep_trace) n_threads = 1;                // traces (and novel-variant numbering) follow stream order
-        // private, writable copy of the text (tokens are NUL-terminated in place) + line table, both in parallel
-        struct PoolFree { void operator()(char *p) const { hgx_host_free(p); } };
-        std::unique_ptr<char, PoolFree> text_mem(owned ? nullptr : (char *)hgx_host_alloc(n_bytes + 1));   // filled by the copy below
-        struct { char *p; size_t n; char *data() { return p; } size_t size() const { return n; } } text{owned ? owned : text_mem.get(), n_bytes + 1};
-        text.p[n_bytes] = '\n';
-        std::vector<std::pair<char *, char *>> lines;
-        {
-            const int nt = n_bytes > (8u << 20) ? n_threads : 1;
-            std::vector<std::vector<std::pair<char *, char *>>> part(nt);
-            if (!owned)
-                parallel_for(nt, n_bytes + 1, [&](int t, size_t b0, size_t e0) {
-                    if (e0 > b0) memcpy(text.data() + b0, b0 < n_bytes ? sam + b0 : "\n", std::min(e0, n_bytes) - b0);
-                });
-            parallel_for(nt, n_bytes + 1, [&](int t, size_t b0, size_t e0) {
-                // this thread owns the lines that START in [b0, e0)
-                char *base = text.data(), *end = text.data() + text.size();
-                char *p = base + b0;
-                if (b0 > 0) {                       // skip the tail of a line owned by the previous range
-                    char *q = (char *)memchr(p - 1, '\n', end - (p - 1));
-                    p = q ? q + 1 : end;
-                }
-                while (p < base + e0 && p < end) {
-                    char *e = (char *)memchr(p, '\n', end - p);
-                    if (!e) e = end;
-                    if (e > p && *p != '@') part[t].push_back({p, e});
-                    p = e + 1;
-                }
-            });
-            size_t tot = 0;
-            for (auto &v : part) tot += v.size();
-            lines.reserve(tot);
-            for (auto &v : part) lines.insert(lines.end(), v.begin(), v.end());
-        }
-        const size_t n = lines.size();
         if (n < 20000) n_threads = 1;
-        lap("copy + line table");
-        std::vector<Fields> recs(n);
-        std::vector<uint8_t> ok(n, 0);
+        // per-record tables: written by the split below, never read before (no zero fill of ~100 bytes per record)
+        struct PoolFree { void operator()(void *p) const { hgx_host_free(p); } };
+        std::unique_ptr<void, PoolFree> recs_mem(hgx_host_alloc(std::max<size_t>(n, 1) * sizeof(Fields)));
+        std::unique_ptr<void, PoolFree> ok_mem(hgx_host_alloc(std::max<size_t>(n, 1)));
+        Fields *recs = (Fields *)recs_mem.get();
+        uint8_t *ok = (uint8_t *)ok_mem.get();
         // field split + pass 1 (pileup over all records, common:1076-1134), both embarrassingly parallel over lines
         std::vector<std::vector<uint32_t>> tcounts(n_threads);
         std::vector<std::string> terr(n_threads);
@@ -1217,8 +1295,9 @@ static int parse_text(hgx_batch **out, const hgx_locus *Lc, const char *sam, cha
             std::vector<uint32_t> &cnt = tcounts[t];
             cnt.assign((size_t)n_ref * 6, 0u);
             for (size_t i = b; i < e; ++i) {
-                *lines[i].second = 0;
-                ok[i] = split_line(lines[i].first, lines[i].second, recs[i]) ? 1 : 0;
+                char *line = lines[i].p, *lend = line + lines[i].len;
+                *lend = 0;
+                ok[i] = split_line(line, lend, recs[i]) ? 1 : 0;
                 if (!ok[i]) continue;
                 const Fields &f = recs[i];
                 if (f.flag & 0x4) continue;
@@ -1253,9 +1332,14 @@ static int parse_text(hgx_batch **out, const hgx_locus *Lc, const char *sam, cha
         for (auto &e : terr) if (!e.empty()) throw RefError(e);
         B->counts.assign((size_t)n_ref * 6, 0u);
         B->nt_set.assign(n_ref, 0);
-        for (auto &cnt : tcounts)
-            if (!cnt.empty())
-                for (size_t k = 0; k < B->counts.size(); ++k) B->counts[k] += cnt[k];
+        {   // partial pileups summed in worker (= stream) order, columns split among the workers
+            const size_t cells = B->counts.size();
+            parallel_for(n_threads, cells, [&](int, size_t b, size_t e) {
+                for (auto &cnt : tcounts)
+                    if (!cnt.empty())
+                        for (size_t k = b; k < e; ++k) B->counts[k] += cnt[k];
+            });
+        }
         for (int i = 0; i < n_ref; ++i) {
             const uint32_t *c = &B->counts[(size_t)i * 6];
             const uint64_t tot = (uint64_t)c[0] + c[1] + c[2] + c[3] + c[4] + c[5];
@@ -1265,7 +1349,7 @@ static int parse_text(hgx_batch **out, const hgx_locus *Lc, const char *sam, cha
                     if ((double)c[k] >= (double)tot * 0.2 || c[k] >= 7) m |= 1 << k;
             B->nt_set[i] = (uint8_t)m;
         }
-        const long expected = opts->codis_choose_pairs ? pair_interdist(recs, ok, opts->simulation != 0) : -1;
+        const long expected = opts->codis_choose_pairs ? pair_interdist(recs, ok, n, opts->simulation != 0) : -1;
         // pass 2: chunks that start where the read id changes
         const int n_chunks = n_threads == 1 ? 1 : n_threads * 4;
         std::vector<size_t> cut{0};
@@ -1284,22 +1368,9 @@ static int parse_text(hgx_batch **out, const hgx_locus *Lc, const char *sam, cha
         const size_t nc = cut.size() - 1;
         std::vector<ChunkResult> res(nc);
         lap("pileup merge + cuts");
-        {
-            std::atomic<size_t> next{0};
-            auto worker = [&]() {
-                for (;;) {
-                    const size_t c = next.fetch_add(1);
-                    if (c >= nc) break;
-                    process_chunk(L, *opts, recs, ok, cut[c], cut[c + 1], *B, c + 1 == nc, expected, res[c]);
-                }
-            };
-            if (n_threads == 1) worker();
-            else {
-                std::vector<std::thread> th;
-                for (int t = 0; t < n_threads; ++t) th.emplace_back(worker);
-                for (auto &x : th) x.join();
-            }
-        }
+        hgx_par_tasks(n_threads, nc, [&](int, size_t c) {
+            process_chunk(L, *opts, alts, recs, ok, cut[c], cut[c + 1], *B, c + 1 == nc, expected, res[c]);
+        });
         for (auto &r : res)
             if (r.error_code) {
                 hgx_set_error("%s", r.error.c_str());
@@ -1308,22 +1379,9 @@ static int parse_text(hgx_batch **out, const hgx_locus *Lc, const char *sam, cha
                 return code;
             }
         lap("streaming loop");
-        // merge in stream order: re-intern each chunk's distinct pieces, renumber its refs
-        for (auto &r : res) {
-            hgx_batch &lb = r.local;
-            std::vector<uint32_t> remap(lb.pieces.size());
-            for (size_t k = 0; k < lb.pieces.size(); ++k) {
-                const hgx_piece &pc = lb.pieces[k];
-                remap[k] = hgx_intern_masks(*B, pc.lo_word, pc.n_words, &lb.masks[pc.mask_off]);
-            }
-            const int32_t base = (int32_t)B->pair_ref.size();
-            for (uint32_t ref : lb.pair_ref) B->pair_ref.push_back((ref & 0x80000000u) | remap[ref & 0x7fffffffu]);
-            for (size_t k = 1; k < lb.pair_off.size(); ++k) B->pair_off.push_back(base + lb.pair_off[k]);
-            B->n_reads += lb.n_reads;
-            for (auto &t : lb.trace) B->trace.push_back(std::move(t));
-        }
+        merge_chunks(*B, res, n_threads);
         lap("merge");
-        hgx_finalize_batch(*B);
+        hgx_finalize_batch(*B, n_threads);
         lap("finalize");
     } catch (const RefError &e) {
         hgx_set_error("the reference would fail on this input: %s", e.what());

@@ -99,3 +99,36 @@ def test_packed_index_cache_round_trip(tmp_path):
         assert (b1.n_reads, b1.n_pairs, b1.n_pieces) == (b2.n_reads, b2.n_pairs, b2.n_pieces)
         assert np.array_equal(b1.pieces, b2.pieces) and np.array_equal(b1.masks, b2.masks)
         assert np.array_equal(b1.pair_off, b2.pair_off) and np.array_equal(b1.pair_ref, b2.pair_ref)
+
+
+def test_front_end_batch_is_independent_of_the_worker_count(tmp_path):
+    """The piece batch of a read set -- distinct pieces in their canonical order, masks, per-pair refs -- is the same whatever
+    the number of front-end workers (chunks are merged through hash partitions; the table is ordered by content), from SAM
+    text, from a SAM file and from a BAM file; and a name-grouped file is recognised as such (no sort) without changing it."""
+    import numpy as np
+    from hisatgenotype_amd import bamio, locus as hl, synth
+    loc = synth.make_hla_like_locus(n_alleles=300, n_vars=500, seed=77)
+    sample = synth.pick_sample(loc, 5)
+    sam = synth.simulate_sam_fast(loc, sample, 15000, err_rate=0.003, seed=8)           # 30 000 records: the threaded paths
+    pl = hl.PackedLocus.from_synth(loc)
+    ref = pl.parse_sam(sam, n_threads=1)
+
+    def same(b):
+        assert (b.n_reads, b.n_pairs, b.n_pieces, b.n_refs) == (ref.n_reads, ref.n_pairs, ref.n_pieces, ref.n_refs)
+        assert np.array_equal(b.pieces, ref.pieces) and np.array_equal(b.masks, ref.masks)
+        assert np.array_equal(b.pair_off, ref.pair_off) and np.array_equal(b.pair_ref, ref.pair_ref)
+
+    for nt in (2, 3, 8):
+        same(pl.parse_sam(sam, n_threads=nt))
+    path = str(tmp_path / "s.sam")
+    open(path, "w").write("@SQ\tSN:%s\tLN:%d\n" % (loc.ref_allele, len(loc.backbone)) + sam)
+    for nt in (1, 8):
+        same(pl.parse_alignment_file(path, [loc.ref_allele], n_threads=nt))
+        same(pl.parse_alignment_file(path, None, n_threads=nt))
+    lines = [l for l in sam.split("\n") if l]
+    lines.sort(key=lambda l: int(l.split("\t")[3]))                                    # coordinate order: the reader must sort
+    bam = str(tmp_path / "s.bam")
+    bamio.write_bam(bam, "\n".join(lines[:6000]) + "\n", [(loc.ref_allele, len(loc.backbone))])
+    a = pl.parse_alignment_file(bam, [loc.ref_allele], n_threads=1)
+    b = pl.parse_alignment_file(bam, [loc.ref_allele], n_threads=8)
+    assert np.array_equal(a.pieces, b.pieces) and np.array_equal(a.pair_ref, b.pair_ref) and a.n_reads == b.n_reads > 0
