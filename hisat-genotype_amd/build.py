@@ -43,10 +43,12 @@ def build(force=False, verbose=True):
                 and os.path.getmtime(obj) > os.path.getmtime(os.path.join(ROOT, "include", "hgx.h"))):
             objs.append(obj)
             continue
-        cmd = [hipcc, "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
-               "-I", CSRC, "-Wall", "-Wno-unused-result", "-c", src, "-o", obj]
         if src.endswith(".hip"):
-            cmd.insert(1, "--offload-arch=" + ARCH)
+            cmd = [hipcc, "--offload-arch=" + ARCH]
+        else:                                    # host-only translation units: plain C++ (hipcc would also run a device pass)
+            cmd = [os.environ.get("CXX", "g++"), "-pthread"]
+        cmd += ["-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                "-I", CSRC, "-Wall", "-Wno-unused-result", "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

@@ -273,8 +273,18 @@ int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &L, int32_t left, int32_t
 // compatibility kernel exploits; and the order depends on nothing but the set of pieces, so a batch is the same whatever
 // the number of front-end workers that interned them, in whatever order.  Masks are re-packed in the same order.
 void hgx_finalize_batch(hgx_batch &b, int n_threads) {
+    std::vector<uint32_t> new_id;
+    hgx_canonical_piece_order(b, n_threads, new_id);
+    hgx_par_ranges(b.pair_ref.size() > 200000 ? n_threads : 1, b.pair_ref.size(), [&](int, size_t lo, size_t hi) {
+        for (size_t k = lo; k < hi; ++k) b.pair_ref[k] = (b.pair_ref[k] & 0x80000000u) | new_id[b.pair_ref[k] & 0x7fffffffu];
+    });
+}
+
+// the table part of hgx_finalize_batch: pieces + masks re-ordered, new_id[old id] = new id (refs are the caller's business)
+void hgx_canonical_piece_order(hgx_batch &b, int n_threads, std::vector<uint32_t> &new_id) {
     const size_t n = b.pieces.size();
-    std::vector<uint32_t> order(n), new_id(n);
+    std::vector<uint32_t> order(n);
+    new_id.assign(n, 0);
     std::vector<uint64_t> hash(n);
     hgx_par_ranges(n > 20000 ? n_threads : 1, n, [&](int, size_t lo, size_t hi) {
         for (size_t i = lo; i < hi; ++i) {
@@ -303,9 +313,6 @@ void hgx_finalize_batch(hgx_batch &b, int n_threads) {
     nm.resize(at);
     b.pieces.swap(np);
     b.masks.swap(nm);
-    hgx_par_ranges(b.pair_ref.size() > 200000 ? n_threads : 1, b.pair_ref.size(), [&](int, size_t lo, size_t hi) {
-        for (size_t k = lo; k < hi; ++k) b.pair_ref[k] = (b.pair_ref[k] & 0x80000000u) | new_id[b.pair_ref[k] & 0x7fffffffu];
-    });
     b.table.clear();
 }
 

@@ -21,6 +21,8 @@
 #include <atomic>
 #include <chrono>
 #include <memory>
+#include <mutex>
+#include <unordered_map>
 #include <string>
 #include <thread>
 #include <unordered_set>
@@ -44,6 +46,47 @@ struct Novel {
     int type, pos, len;       // HGX_VAR_*
     char base;
     std::string ins;
+};
+
+// Novel variants of one parse (core:404-431), shared by all workers: id = V + k.  Every sequencing error that survives error
+// correction becomes one (a novel single), so the table sees a lookup or an insert for a good part of the distinct reads:
+// 256 shards keyed by position take the locking apart; entries live in fixed segments, so `get` needs no lock (an id is only
+// ever used by a thread that obtained it from find / get_or_add, i.e. after the entry was published under a shard lock).
+struct NovelTable {
+    static constexpr int SHARDS = 256, SEG = 4096, MAX_SEG = 16384;
+    struct Shard { std::mutex mu; std::unordered_map<uint64_t, int> map; };
+    Shard shard[SHARDS];
+    std::atomic<Novel *> seg[MAX_SEG];
+    std::atomic<int> count{0};
+    std::mutex grow;
+    NovelTable() { for (auto &p : seg) p.store(nullptr, std::memory_order_relaxed); }
+    NovelTable(const NovelTable &) = delete;
+    ~NovelTable() { for (auto &p : seg) delete[] p.load(std::memory_order_relaxed); }
+    static uint64_t key(int type, int pos, int k) { return ((uint64_t)type << 60) | ((uint64_t)(uint32_t)pos << 24) | (uint32_t)(k & 0xffffff); }
+    Shard &of(uint64_t k) { return shard[(k >> 24) & (SHARDS - 1)]; }                    // by position
+    const Novel &get(int k) const { return seg[k / SEG].load(std::memory_order_acquire)[k % SEG]; }
+    int find(uint64_t k) {
+        if (count.load(std::memory_order_acquire) == 0) return -1;
+        Shard &s = of(k);
+        std::lock_guard<std::mutex> g(s.mu);
+        auto it = s.map.find(k);
+        return it == s.map.end() ? -1 : it->second;
+    }
+    int get_or_add(uint64_t k, Novel &&nv) {
+        Shard &s = of(k);
+        std::lock_guard<std::mutex> g(s.mu);
+        auto it = s.map.find(k);
+        if (it != s.map.end()) return it->second;
+        const int id = count.fetch_add(1, std::memory_order_acq_rel);
+        if (id / SEG >= MAX_SEG) throw std::runtime_error("too many novel variants");
+        if (!seg[id / SEG].load(std::memory_order_acquire)) {
+            std::lock_guard<std::mutex> gg(grow);
+            if (!seg[id / SEG].load(std::memory_order_acquire)) seg[id / SEG].store(new Novel[SEG], std::memory_order_release);
+        }
+        seg[id / SEG].load(std::memory_order_acquire)[id % SEG] = std::move(nv);
+        s.map.emplace(k, id);
+        return id;
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -242,8 +285,7 @@ struct Parser {
     const hgx_locus &L;
     hgx_parse_opts o;
     hgx_batch &B;
-    std::vector<Novel> novel;
-    std::unordered_map<uint64_t, int> novel_lookup;   // (type,pos,key) -> id
+    NovelTable &NT;                                   // novel variants of this parse (shared by all workers)
     // alternatives with spellings, sorted by anchor: built once per parse (AltTables) and shared, read-only, by all chunks
     typedef AltTables::AltRec AltRec;
     const std::vector<AltRec> &alt_l, &alt_r;
@@ -257,13 +299,13 @@ struct Parser {
     std::vector<Ht> ex_buf, union_buf;
     std::vector<int32_t> ids_buf;
     std::vector<uint32_t> eref_buf, gref_buf;
-    Parser(const hgx_locus &l, const hgx_parse_opts &opts, hgx_batch &b, const hgx_batch &pile, const AltTables &at)
-        : L(l), o(opts), B(b), alt_l(at.alt_l), alt_r(at.alt_r), alt_l_pos(at.alt_l_pos), alt_r_pos(at.alt_r_pos), PILE(pile) {}
+    Parser(const hgx_locus &l, const hgx_parse_opts &opts, hgx_batch &b, const hgx_batch &pile, const AltTables &at, NovelTable &nt)
+        : L(l), o(opts), B(b), NT(nt), alt_l(at.alt_l), alt_r(at.alt_r), alt_l_pos(at.alt_l_pos), alt_r_pos(at.alt_r_pos), PILE(pile) {}
 
     // ---- variant accessors over known + novel ids --------------------------------------------
-    int vtype(int id) const { return id < L.V ? L.type[id] : novel[id - L.V].type; }
-    int vpos(int id) const { return id < L.V ? L.pos[id] : novel[id - L.V].pos; }
-    int vlen(int id) const { return id < L.V ? L.len[id] : novel[id - L.V].len; }
+    int vtype(int id) const { return id < L.V ? L.type[id] : NT.get(id - L.V).type; }
+    int vpos(int id) const { return id < L.V ? L.pos[id] : NT.get(id - L.V).pos; }
+    int vlen(int id) const { return id < L.V ? L.len[id] : NT.get(id - L.V).len; }
     bool is_hv(int id) const { return id >= 0 && id < L.V; }
     std::string vname(int id) const {
         if (id == -1) return "unknown";
@@ -272,7 +314,7 @@ struct Parser {
     }
     int vright(int id) const { return vtype(id) == HGX_VAR_DELETION ? vpos(id) + vlen(id) - 1 : vpos(id); }
 
-    static uint64_t nkey(int type, int pos, int k) { return ((uint64_t)type << 60) | ((uint64_t)(uint32_t)pos << 24) | (uint32_t)(k & 0xffffff); }
+    static uint64_t nkey(int type, int pos, int k) { return NovelTable::key(type, pos, k); }
 
     // first variant at `pos` (known list order, then novel) of the wanted type and size/base (core:949-961, 1005-1017, 1045-1057)
     int lookup(int pos, int type, int key) const {
@@ -280,21 +322,19 @@ struct Parser {
             if (L.type[j] != type) continue;
             if (type == HGX_VAR_SINGLE ? L.base[j] == (char)key : L.len[j] == key) return j;
         }
-        auto it = novel_lookup.find(nkey(type, pos, key));
-        return it == novel_lookup.end() ? -1 : it->second;
+        const int k = NT.find(nkey(type, pos, key));
+        return k < 0 ? -1 : L.V + k;
     }
-    int add_novel(int type, int pos, int key, const std::string &ins) {   // core:404-431
-        if (lookup(pos, type, key) >= 0) throw RefError("assert: novel variant already present");
+    // core:404-431.  The reference asserts that the id is new; with several workers decoding at the same time another one may
+    // have created the same variant since this record's lookup, so this is find-or-create (same id either way).
+    int add_novel(int type, int pos, int key, const std::string &ins) {
         Novel nv;
         nv.type = type; nv.pos = pos; nv.base = 0;
         nv.len = 1;
         if (type == HGX_VAR_SINGLE) nv.base = (char)key;
         else nv.len = key;
         nv.ins = ins;
-        const int id = L.V + (int)novel.size();
-        novel.push_back(nv);
-        novel_lookup.emplace(nkey(type, pos, key), id);
-        return id;
+        return L.V + NT.get_or_add(nkey(type, pos, key), std::move(nv));
     }
 
     // ---- error_correct (core:119-243) over the cmp entries of one M op ------------------------------
@@ -780,56 +820,6 @@ struct Parser {
         }
     }
 
-    // ---- pair flush (core:1238-1291): haplotypes -> piece refs --------------------------------------------
-    // choose_pairs (core:680-716): keep the mate haplotype pairs whose inner distance is closest to the expected one
-    static void choose_pairs(std::vector<Ht> &lh, std::vector<Ht> &rh, long expected) {
-        if (lh.empty() || rh.empty() || std::max(lh.size(), rh.size()) < 2) return;
-        long best = -1;
-        std::vector<Ht> nl, nr;
-        auto add = [](std::vector<Ht> &v, const Ht &h) { if (std::find(v.begin(), v.end(), h) == v.end()) v.push_back(h); };
-        for (const Ht &l : lh)
-            for (const Ht &r : rh) {
-                const long inter = l.right < r.right ? (long)r.left - l.right - 1 : (long)l.left - r.right - 1;
-                const long cur = std::labs(expected - inter);
-                if (best < 0 || cur < best) { best = cur; nl.clear(); nr.clear(); }
-                if (cur == best) { add(nl, l); add(nr, r); }
-            }
-        lh.swap(nl);
-        rh.swap(nr);
-    }
-
-    // pair flush (core:1238-1291): the set union of the mates' haplotypes -> piece refs
-    void flush(const std::vector<Ht> &lh, const std::vector<Ht> &rh) {
-        std::vector<Ht> &hts = union_buf;
-        hts.clear();
-        for (const Ht &h : lh) hts.push_back(h);
-        for (const Ht &h : rh) if (std::find(hts.begin(), hts.end(), h) == hts.end()) hts.push_back(h);
-        std::vector<Ht> &ex = ex_buf;
-        std::vector<int32_t> &ids = ids_buf;
-        std::vector<uint32_t> &exon_refs = eref_buf, &gene_refs = gref_buf;
-        exon_refs.clear();
-        gene_refs.clear();
-        auto intern = [&](const Ht &h) -> uint32_t {
-            if (h.left > h.right) throw RefError("assert left <= right");
-            ids.assign(h.ids.begin(), h.ids.end());
-            for (auto &v : ids) if (v >= L.V) v = -1;
-            const int64_t id = hgx_intern_piece(B, L, h.left, h.right, ids.data(), (int32_t)ids.size());
-            if (id < 0) throw std::runtime_error(hgx_last_error());
-            return (uint32_t)id;
-        };
-        for (const Ht &h : hts) {
-            if (L.base_kind == HGX_BASE_HLA) {
-                ex.clear();
-                exon_pieces(h, ex);
-                for (const Ht &e : ex) exon_refs.push_back(intern(e));
-            }
-            gene_refs.push_back(intern(h) | 0x80000000u);
-        }
-        if (exon_refs.size() > 255 || gene_refs.size() > 255) throw std::runtime_error("more than 255 pieces for one pair and level");
-        B.pair_ref.insert(B.pair_ref.end(), exon_refs.begin(), exon_refs.end());
-        B.pair_ref.insert(B.pair_ref.end(), gene_refs.begin(), gene_refs.end());
-        B.pair_off.push_back((int32_t)B.pair_ref.size());
-    }
 };
 
 struct Fields {
@@ -839,8 +829,47 @@ struct Fields {
     const char *seq; size_t seq_len;
     const char *zs, *md;
     bool has_nm, has_nh, yt_cp;
+    uint8_t kept;                    // outcome of the record filters (core:815-872), see filter_records
     long nm, nh;
+    // the DECODE KEY of a record = (pos, cigar, seq, zs, md): everything its cmp_list / haplotypes depend on
+    uint32_t cigar_len, zs_len, md_len;
+    uint32_t rep;                    // index of the first record with an equal decode key
+    uint32_t n_pile;                 // at rep: members of the group that count into the pileup (common:1076-1090)
+    uint32_t slot;                   // at rep: index of the group's decode result, or NO_SLOT
+    uint64_t key;                    // hash of the decode key
 };
+enum { KEPT_NO = 0, KEPT_YES = 1, KEPT_ERR_TAGS = 2, KEPT_ERR_FLAG = 3 };
+constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
+
+inline uint64_t hash_bytes(const char *p, size_t n, uint64_t h) {
+    while (n >= 8) {
+        uint64_t w;
+        memcpy(&w, p, 8);
+        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 32;
+        p += 8;
+        n -= 8;
+    }
+    uint64_t w = 0;
+    memcpy(&w, p, n);
+    h = (h ^ w ^ ((uint64_t)n << 56)) * 0xD6E8FEB86659FD93ull;
+    return h ^ (h >> 29);
+}
+inline void set_decode_key(Fields &f) {
+    f.cigar_len = (uint32_t)strlen(f.cigar);
+    f.zs_len = f.zs ? (uint32_t)strlen(f.zs) : 0;
+    f.md_len = f.md ? (uint32_t)strlen(f.md) : 0;
+    uint64_t h = hash_bytes(f.seq, f.seq_len, 0x243F6A8885A308D3ull ^ (uint32_t)f.pos);
+    h = hash_bytes(f.cigar, f.cigar_len, h);
+    h = hash_bytes(f.zs ? f.zs : "", f.zs_len, h ^ (f.zs ? 1 : 0));
+    f.key = hash_bytes(f.md ? f.md : "", f.md_len, h ^ (f.md ? 2 : 0));
+}
+inline bool same_decode_key(const Fields &a, const Fields &b) {
+    return a.key == b.key && a.pos == b.pos && a.seq_len == b.seq_len && a.cigar_len == b.cigar_len && a.zs_len == b.zs_len &&
+           a.md_len == b.md_len && (a.zs == nullptr) == (b.zs == nullptr) && (a.md == nullptr) == (b.md == nullptr) &&
+           memcmp(a.seq, b.seq, a.seq_len) == 0 && memcmp(a.cigar, b.cigar, a.cigar_len) == 0 &&
+           (a.zs_len == 0 || memcmp(a.zs, b.zs, a.zs_len) == 0) && (a.md_len == 0 || memcmp(a.md, b.md, a.md_len) == 0);
+}
 
 // split one line on whitespace in place (the buffer is a private copy); returns false for header/empty lines
 static bool split_line(char *line, char *end, Fields &f) {
@@ -873,6 +902,7 @@ static bool split_line(char *line, char *end, Fields &f) {
     f.cigar = cols[5];
     f.seq = cols[9];
     f.seq_len = strlen(cols[9]);
+    set_decode_key(f);
     return true;
 }
 
@@ -949,121 +979,296 @@ inline size_t read_id_len(const Fields &f, bool simulation) {
     return f.qname_len;
 }
 
-struct ChunkResult {
-    hgx_batch local;
+// ---- the streaming loop (core:800-1587), restated around the observation that deep coverage repeats records -------------
+// A record's cmp_list, its ambiguity sets and its haplotypes are a function of its DECODE KEY (pos, cigar, seq, Zs, MD) -- and of
+// tables that are fixed while the loop runs (locus, pileup).  At 1 M reads on a 3.5 kb locus some 70 % of the records repeat an
+// earlier key, so the work is split:
+//   filter_records   the record filters, in stream order inside groups of equal read ids (cheap, parallel over id-aligned chunks)
+//   group_records    records with equal keys -> the first of them (hash partitions, exact key compare)
+//   decode_groups    decode + error correction + cmp_list2 + identify_ambigious_diffs + haplotypes + exon clipping + piece
+//                    interning, ONCE per distinct key that some kept record carries
+//   emit_chunk       the pair protocol over the kept records: set union of the mates' haplotypes -> piece refs
+// Results are identical to decoding every record where it stands (pinned by the golden traces and the batch comparisons).
+struct HtRec {                       // one haplotype of a mate + its add_count arguments as interned pieces
+    Ht ht;
+    uint32_t exon_off, n_exon;       // local piece ids in the owning worker's ref pool
+    uint32_t gene_local;
+    uint32_t worker;
+};
+struct MateOut {                     // decode result of one distinct key
+    uint8_t state = 0;               // 1 = haplotypes follow, 2 = decode() said no (record dropped), 3 = the reference would fail
+    uint32_t worker = 0, first = 0, n = 0;          // HtRec range in the worker's arena
+    int err_code = 0;
+    std::string err, trace;
+};
+struct DecodeWorker {
+    hgx_batch table;                 // pieces interned by this worker (local ids)
+    std::vector<HtRec> arena;
+    std::vector<uint32_t> refs;      // exon-level piece ids of the arena's haplotypes
+};
+struct ChunkOut {
+    std::vector<uint32_t> pair_ref;
+    std::vector<int32_t> pair_off{0};
+    int32_t n_reads = 0;
+    std::vector<TraceRec> trace;
     std::string error;
     int error_code = 0;
 };
 
-// The streaming loop (core:800-1587) over records [i0, i1).  Chunks start at read-id boundaries of the name-grouped
-// stream, so pairs, the duplicate-mate filters and the flush protocol never straddle two chunks.
-void process_chunk(const hgx_locus &L, const hgx_parse_opts &o, const AltTables &alts, const Fields *recs, const uint8_t *ok,
-                   size_t i0, size_t i1, const hgx_batch &pile, bool is_last, long expected_interdist, ChunkResult &out) {
-    hgx_batch &B = out.local;
-    try {
-        Parser P(L, o, B, pile, alts);
+// record filters of core:815-872 over records [i0, i1) (a range that starts and ends at read-id boundaries)
+void filter_records(const hgx_parse_opts &o, Fields *recs, const uint8_t *ok, size_t i0, size_t i1) {
+    const char *grp = nullptr;
+    size_t grp_len = 0;
+    bool g_l = false, g_r = false, g_u = false;
+    for (size_t i = i0; i < i1; ++i) {
+        if (!ok[i]) continue;
+        Fields &f = recs[i];
+        f.kept = KEPT_NO;
         // The stream is name-grouped, so the reference's global left/right/unpaired id sets (core:857-872) reduce to
         // three flags per group of equal read ids.
-        const char *grp = nullptr;
-        size_t grp_len = 0;
-        bool g_l = false, g_r = false, g_u = false;
-        std::vector<Ht> lhts, rhts;   // left / right positive haplotypes of the current pair (united at the flush, core:1250-1251)
-        const char *prev_id = nullptr;
-        size_t prev_len = 0;
-        bool have_prev = false;
-        std::vector<int> mid;
-        std::vector<Cmp> cl, c2;
-        std::vector<Parser::AltSide> lset, rset;
-        std::string read;
+        const size_t idlen = read_id_len(f, o.simulation != 0);
+        if (!grp || grp_len != idlen || memcmp(grp, f.qname, idlen) != 0) {
+            grp = f.qname;
+            grp_len = idlen;
+            g_l = g_r = g_u = false;
+        }
+        if (f.pos - (o.base_locus + 1) < 0) continue;
+        if (f.flag & 0x4) continue;
+        if (!f.has_nm || !f.has_nh) { f.kept = KEPT_ERR_TAGS; continue; }
+        if (f.nm > o.num_editdist) continue;
+        if (f.nh > 1) continue;
+        if (!o.allow_discordant && !(f.flag & 0x2)) continue;
+        if (f.flag & 0x40) {
+            if (g_l) continue;
+            g_l = true;
+        } else if (f.flag & 0x80) {
+            if (g_r) continue;
+            g_r = true;
+        } else {
+            if (!o.allow_discordant) { f.kept = KEPT_ERR_FLAG; continue; }
+            if (g_u) continue;
+            g_u = true;
+        }
+        f.kept = KEPT_YES;
+    }
+}
+
+// rep / n_pile / slot of every record.  Partition p owns the keys with (hash >> 44) % P == p: its worker walks the records of
+// the partition in stream order, so rep is the FIRST record of each key whatever the number of workers.
+void group_records(const hgx_parse_opts &o, Fields *recs, const uint8_t *ok, size_t n, int n_threads, std::vector<uint32_t> &reps) {
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, n / 4096 + 1));
+    const int P = T;
+    std::vector<std::vector<std::vector<uint32_t>>> bucket(T, std::vector<std::vector<uint32_t>>(P));
+    hgx_par_ranges(T, n, [&](int t, size_t b, size_t e) {
+        for (auto &v : bucket[t]) v.reserve((e - b) / P + 16);
+        for (size_t i = b; i < e; ++i)
+            if (ok[i]) bucket[t][(recs[i].key >> 44) % P].push_back((uint32_t)i);
+    });
+    std::vector<std::vector<uint32_t>> part_reps(P);
+    hgx_par_tasks(T, (size_t)P, [&](int, size_t p) {
+        size_t cnt = 0;
+        for (int t = 0; t < T; ++t) cnt += bucket[t][p].size();
+        size_t cap = 64;
+        while (cap < 2 * cnt) cap <<= 1;
+        std::vector<uint32_t> slot(cap, NO_SLOT);
+        const size_t mask = cap - 1;
+        for (int t = 0; t < T; ++t)
+            for (uint32_t i : bucket[t][p]) {
+                Fields &f = recs[i];
+                size_t h = (size_t)f.key & mask;
+                uint32_t r;
+                for (;;) {
+                    r = slot[h];
+                    if (r == NO_SLOT) { slot[h] = i; r = i; f.n_pile = 0; f.slot = NO_SLOT; break; }
+                    if (same_decode_key(recs[r], f)) break;
+                    h = (h + 1) & mask;
+                }
+                f.rep = r;
+                Fields &g = recs[r];
+                // pileup membership (common:1076-1090): aligned, inside the locus, concordant unless discordant pairs count
+                if (!(f.flag & 0x4) && f.pos - (o.base_locus + 1) >= 0 && (o.allow_discordant || (f.flag & 0x2))) g.n_pile++;
+                if (f.kept == KEPT_YES && g.slot == NO_SLOT) { g.slot = 0; part_reps[p].push_back(r); }
+            }
+    });
+    // slots in stream order of their first record (so that a single worker creates novel variants in stream order)
+    size_t tot = 0;
+    for (auto &v : part_reps) tot += v.size();
+    reps.clear();
+    reps.reserve(tot);
+    for (auto &v : part_reps) reps.insert(reps.end(), v.begin(), v.end());
+    std::sort(reps.begin(), reps.end());
+    hgx_par_ranges(T, reps.size(), [&](int, size_t b, size_t e) { for (size_t k = b; k < e; ++k) recs[reps[k]].slot = (uint32_t)k; });
+}
+
+// decode result of record `f` (the first of its key): haplotypes with their pieces, into the worker's arena
+void decode_one(Parser &P, const hgx_locus &L, const hgx_parse_opts &o, const Fields &f, uint32_t widx, DecodeWorker &W, MateOut &out,
+                std::string &read, std::vector<Cmp> &cl, std::vector<Cmp> &c2, std::vector<Parser::AltSide> &lset,
+                std::vector<Parser::AltSide> &rset, std::vector<int> &mid, std::vector<Ht> &ex, std::vector<int32_t> &ids) {
+    try {
+        const int pos = f.pos - (o.base_locus + 1);
+        read.assign(f.seq, f.seq_len);
+        if (!P.decode(pos, f.cigar, read, f.zs, f.md, cl)) { out.state = 2; return; }
+        // cmp_list2 (core:1351-1368)
+        c2.clear();
+        for (const Cmp &c : cl) {
+            if (c.type == T_MATCH) {
+                if (!c2.empty() && c2.back().type == T_MATCH) c2.back().len += c.len;
+                else c2.push_back(c);
+            } else if (c.type == T_MISMATCH && (c.id == -1 || c.id >= L.V)) {
+                if (!c2.empty() && c2.back().type == T_MATCH) c2.back().len += 1;
+                else c2.push_back(Cmp{T_MATCH, c.pos, 1, -2});
+            } else c2.push_back(c);
+        }
+        int cleft, cright;
+        P.ambiguous(c2, cleft, cright, lset, rset);
+        mid.clear();
+        for (int k = cleft; k <= cright; ++k)
+            if (c2[k].type != T_MATCH) mid.push_back(c2[k].id);
+        out.worker = widx;
+        out.first = (uint32_t)W.arena.size();
+        auto intern = [&](const Ht &h) -> uint32_t {
+            if (h.left > h.right) throw RefError("assert left <= right");
+            ids.assign(h.ids.begin(), h.ids.end());
+            for (auto &v : ids) if (v >= L.V) v = -1;
+            const int64_t id = hgx_intern_piece(W.table, L, h.left, h.right, ids.data(), (int32_t)ids.size());
+            if (id < 0) throw std::runtime_error(hgx_last_error());
+            return (uint32_t)id;
+        };
+        for (auto &l : lset)
+            for (auto &r : rset) {
+                Ht h;
+                h.left = l.coord;
+                h.right = r.coord;
+                h.ids = l.ids;
+                h.ids.insert(h.ids.end(), mid.begin(), mid.end());
+                h.ids.insert(h.ids.end(), r.ids.begin(), r.ids.end());
+                bool dup = false;
+                for (uint32_t k = out.first; k < W.arena.size() && !dup; ++k) dup = W.arena[k].ht == h;
+                if (dup) continue;
+                HtRec rec;
+                rec.worker = widx;
+                rec.exon_off = (uint32_t)W.refs.size();
+                if (L.base_kind == HGX_BASE_HLA) {                   // exon pieces of the haplotype (core:1259-1276)
+                    ex.clear();
+                    P.exon_pieces(h, ex);
+                    for (const Ht &e : ex) W.refs.push_back(intern(e));
+                }
+                rec.n_exon = (uint32_t)W.refs.size() - rec.exon_off;
+                rec.gene_local = intern(h);
+                rec.ht = std::move(h);
+                W.arena.push_back(std::move(rec));
+            }
+        out.n = (uint32_t)W.arena.size() - out.first;
+        out.state = 1;
+        if (o.keep_trace) {
+            std::string t;
+            for (size_t k = 0; k < c2.size(); ++k) {
+                if (k) t += ',';
+                t += kTypeName[c2[k].type];
+                t += ':' + std::to_string(c2[k].pos) + ':' + std::to_string(c2[k].len);
+                if (c2[k].type != T_MATCH) t += ':' + P.vname(c2[k].id);
+            }
+            t += '\t' + std::to_string(cleft) + '\t' + std::to_string(cright) + '\t';
+            std::vector<std::string> ls, rs;
+            for (auto &l : lset) ls.push_back(std::to_string(l.coord) + (l.ids.empty() ? "" : "-" + P.join_ids(l.ids)));
+            for (auto &r : rset) rs.push_back((r.ids.empty() ? "" : P.join_ids(r.ids) + "-") + std::to_string(r.coord));
+            std::sort(ls.begin(), ls.end());
+            std::sort(rs.begin(), rs.end());
+            for (size_t k = 0; k < ls.size(); ++k) t += (k ? ";" : "") + ls[k];
+            t += '\t';
+            for (size_t k = 0; k < rs.size(); ++k) t += (k ? ";" : "") + rs[k];
+            out.trace = std::move(t);
+        }
+    } catch (const RefError &e) {
+        out.state = 3;
+        out.err = std::string("the reference would fail on this input: ") + e.what();
+        out.err_code = HGX_EPARSE;
+    } catch (const std::exception &e) {
+        out.state = 3;
+        out.err = e.what();
+        out.err_code = HGX_EINVAL;
+    }
+}
+
+// choose_pairs (core:680-716) over haplotype records: keep the mate pairs whose inner distance is closest to the expected one
+void choose_pairs_rec(std::vector<const HtRec *> &lh, std::vector<const HtRec *> &rh, long expected) {
+    if (lh.empty() || rh.empty() || std::max(lh.size(), rh.size()) < 2) return;
+    long best = -1;
+    std::vector<const HtRec *> nl, nr;
+    auto add = [](std::vector<const HtRec *> &v, const HtRec *h) {
+        for (const HtRec *x : v) if (x->ht == h->ht) return;
+        v.push_back(h);
+    };
+    for (const HtRec *l : lh)
+        for (const HtRec *r : rh) {
+            const long inter = l->ht.right < r->ht.right ? (long)r->ht.left - l->ht.right - 1 : (long)l->ht.left - r->ht.right - 1;
+            const long cur = std::labs(expected - inter);
+            if (best < 0 || cur < best) { best = cur; nl.clear(); nr.clear(); }
+            if (cur == best) { add(nl, l); add(nr, r); }
+        }
+    lh.swap(nl);
+    rh.swap(nr);
+}
+
+// The pair protocol (core:1238-1347, 1545-1587) over records [i0, i1): kept records bring their key's haplotypes; when the
+// read id changes the previous pair is flushed: set union of the two mates' haplotypes (left's first), every haplotype's exon
+// pieces and then every haplotype itself as piece refs.  Chunks start at read-id boundaries, so pairs never straddle two.
+void emit_chunk(const hgx_parse_opts &o, const Fields *recs, const uint8_t *ok, size_t i0, size_t i1, const std::vector<MateOut> &outs,
+                const std::vector<DecodeWorker> &workers, const std::vector<std::vector<uint32_t>> &final_id, bool is_last,
+                long expected_interdist, ChunkOut &out) {
+    std::vector<const HtRec *> lhts, rhts, uni;
+    const char *prev_id = nullptr;
+    size_t prev_len = 0;
+    bool have_prev = false;
+    auto flush = [&]() {
+        uni.assign(lhts.begin(), lhts.end());
+        for (const HtRec *h : rhts) {
+            bool dup = false;
+            for (const HtRec *x : uni) if (x->ht == h->ht) { dup = true; break; }
+            if (!dup) uni.push_back(h);
+        }
+        size_t n_exon = 0;
+        for (const HtRec *h : uni) n_exon += h->n_exon;
+        if (n_exon > 255 || uni.size() > 255) throw std::runtime_error("more than 255 pieces for one pair and level");
+        for (const HtRec *h : uni) {
+            const uint32_t *r = workers[h->worker].refs.data() + h->exon_off;
+            for (uint32_t k = 0; k < h->n_exon; ++k) out.pair_ref.push_back(final_id[h->worker][r[k]]);
+        }
+        for (const HtRec *h : uni) out.pair_ref.push_back(final_id[h->worker][h->gene_local] | 0x80000000u);
+        out.pair_off.push_back((int32_t)out.pair_ref.size());
+    };
+    try {
         for (size_t i = i0; i < i1; ++i) {
             if (!ok[i]) continue;
             const Fields &f = recs[i];
+            if (f.kept == KEPT_NO) continue;
+            if (f.kept == KEPT_ERR_TAGS) throw RefError("TypeError: record without NM/NH tag (quirk Q8)");
+            if (f.kept == KEPT_ERR_FLAG) throw RefError("assert allow_discordant");
+            const MateOut &m = outs[recs[f.rep].slot];
+            if (m.state == 3) { out.error = m.err; out.error_code = m.err_code; return; }
+            if (m.state != 1) continue;
+            out.n_reads++;
             const size_t idlen = read_id_len(f, o.simulation != 0);
-            if (!grp || grp_len != idlen || memcmp(grp, f.qname, idlen) != 0) {
-                grp = f.qname;
-                grp_len = idlen;
-                g_l = g_r = g_u = false;
-            }
-            const int pos = f.pos - (o.base_locus + 1);
-            if (pos < 0) continue;
-            if (f.flag & 0x4) continue;
-            if (!f.has_nm || !f.has_nh) throw RefError("TypeError: record without NM/NH tag (quirk Q8)");
-            if (f.nm > o.num_editdist) continue;
-            if (f.nh > 1) continue;
-            if (!o.allow_discordant && !(f.flag & 0x2)) continue;
-            const bool is_left = (f.flag & 0x40) != 0;
-            if (is_left) {
-                if (g_l) continue;
-                g_l = true;
-            } else if (f.flag & 0x80) {
-                if (g_r) continue;
-                g_r = true;
-            } else {
-                if (!o.allow_discordant) throw RefError("assert allow_discordant");
-                if (g_u) continue;
-                g_u = true;
-            }
-            read.assign(f.seq, f.seq_len);
-            if (!P.decode(pos, f.cigar, read, f.zs, f.md, cl)) continue;
-            B.n_reads++;
             if (!have_prev || prev_len != idlen || memcmp(prev_id, f.qname, idlen) != 0) {
-                if (have_prev) P.flush(lhts, rhts);
+                if (have_prev) flush();
                 lhts.clear();
                 rhts.clear();
             }
-            // cmp_list2 (core:1351-1368)
-            c2.clear();
-            for (const Cmp &c : cl) {
-                if (c.type == T_MATCH) {
-                    if (!c2.empty() && c2.back().type == T_MATCH) c2.back().len += c.len;
-                    else c2.push_back(c);
-                } else if (c.type == T_MISMATCH && (c.id == -1 || c.id >= L.V)) {
-                    if (!c2.empty() && c2.back().type == T_MATCH) c2.back().len += 1;
-                    else c2.push_back(Cmp{T_MATCH, c.pos, 1, -2});
-                } else c2.push_back(c);
+            std::vector<const HtRec *> &dst = (f.flag & 0x40) ? lhts : rhts;
+            const HtRec *a = workers[m.worker].arena.data() + m.first;
+            for (uint32_t k = 0; k < m.n; ++k) {
+                bool dup = false;
+                for (const HtRec *x : dst) if (x->ht == a[k].ht) { dup = true; break; }
+                if (!dup) dst.push_back(a + k);
             }
-            int cleft, cright;
-            P.ambiguous(c2, cleft, cright, lset, rset);
-            mid.clear();
-            for (int k = cleft; k <= cright; ++k)
-                if (c2[k].type != T_MATCH) mid.push_back(c2[k].id);
-            for (auto &l : lset)
-                for (auto &r : rset) {
-                    Ht h;
-                    h.left = l.coord;
-                    h.right = r.coord;
-                    h.ids = l.ids;
-                    h.ids.insert(h.ids.end(), mid.begin(), mid.end());
-                    h.ids.insert(h.ids.end(), r.ids.begin(), r.ids.end());
-                    std::vector<Ht> &dst = is_left ? lhts : rhts;
-                    if (std::find(dst.begin(), dst.end(), h) == dst.end()) dst.push_back(std::move(h));
-                }
-            if (o.keep_trace) {
-                std::string t;
-                for (size_t k = 0; k < c2.size(); ++k) {
-                    if (k) t += ',';
-                    t += kTypeName[c2[k].type];
-                    t += ':' + std::to_string(c2[k].pos) + ':' + std::to_string(c2[k].len);
-                    if (c2[k].type != T_MATCH) t += ':' + P.vname(c2[k].id);
-                }
-                t += '\t' + std::to_string(cleft) + '\t' + std::to_string(cright) + '\t';
-                std::vector<std::string> ls, rs;
-                for (auto &l : lset) ls.push_back(std::to_string(l.coord) + (l.ids.empty() ? "" : "-" + P.join_ids(l.ids)));
-                for (auto &r : rset) rs.push_back((r.ids.empty() ? "" : P.join_ids(r.ids) + "-") + std::to_string(r.coord));
-                std::sort(ls.begin(), ls.end());
-                std::sort(rs.begin(), rs.end());
-                for (size_t k = 0; k < ls.size(); ++k) t += (k ? ";" : "") + ls[k];
-                t += '\t';
-                for (size_t k = 0; k < rs.size(); ++k) t += (k ? ";" : "") + rs[k];
-                B.trace.push_back(TraceRec{t});
-            }
+            if (o.keep_trace) out.trace.push_back(TraceRec{m.trace});
             prev_id = f.qname;
             prev_len = idlen;
             have_prev = true;
         }
         if (have_prev) {
-            if (is_last && o.codis_choose_pairs) Parser::choose_pairs(lhts, rhts, expected_interdist);   // core:1547-1552
-            P.flush(lhts, rhts);
+            if (is_last && o.codis_choose_pairs) choose_pairs_rec(lhts, rhts, expected_interdist);   // core:1547-1552
+            flush();
         }
     } catch (const RefError &e) {
         out.error = std::string("the reference would fail on this input: ") + e.what();
@@ -1107,44 +1312,39 @@ long pair_interdist(const Fields *recs, const uint8_t *ok, size_t n_recs, bool s
     return dists.empty() ? -1 : dists[dists.size() / 2];
 }
 
-// Chunk results -> one batch.  Every chunk interned its pieces into a private table; here the tables are united without a
-// serial pass over them: (1) per chunk, its distinct pieces are bucketed by hash partition; (2) per partition, one worker
-// interns the bucket entries of all chunks (in chunk order) into a partition-private table; (3) partition sizes are
-// prefix-summed into global piece ids; (4) per chunk, refs are renumbered and copied to their place in the united arrays.
-// The ids given here carry no meaning: hgx_finalize_batch orders the table by content, so the batch is the same whatever the
-// number of workers and chunks.
-void merge_chunks(hgx_batch &B, std::vector<ChunkResult> &res, int n_threads) {
-    const size_t nc = res.size();
-    if (nc == 1) {                              // one chunk: its table is the batch's
-        hgx_batch &lb = res[0].local;
-        B.pieces.swap(lb.pieces);
-        B.masks.swap(lb.masks);
-        B.pair_off.swap(lb.pair_off);
-        B.pair_ref.swap(lb.pair_ref);
-        B.n_reads = lb.n_reads;
-        B.trace.swap(lb.trace);
+// Worker piece tables -> the batch's table.  Every decode worker interned its pieces into a private table; here the tables are
+// united without a serial pass over them: (1) per worker, its distinct pieces are bucketed by hash partition; (2) per partition,
+// one task interns the bucket entries of all workers into a partition-private table; (3) partition sizes are prefix-summed into
+// global piece ids.  The ids carry no meaning yet: canonical_piece_order below orders the table by content, so the batch is the
+// same whatever the number of workers.  gid[w][local id] = id in B.
+void merge_tables(hgx_batch &B, std::vector<DecodeWorker> &workers, int n_threads, std::vector<std::vector<uint32_t>> &gid) {
+    const size_t nw = workers.size();
+    gid.assign(nw, {});
+    for (size_t w = 0; w < nw; ++w) gid[w].resize(workers[w].table.pieces.size());
+    if (nw == 1) {
+        B.pieces.swap(workers[0].table.pieces);
+        B.masks.swap(workers[0].table.masks);
+        for (size_t k = 0; k < gid[0].size(); ++k) gid[0][k] = (uint32_t)k;
         return;
     }
     const int P = std::max(1, std::min(n_threads, 64));
-    struct Ent { uint32_t local; uint64_t hash; };
-    std::vector<std::vector<std::vector<Ent>>> bucket(nc, std::vector<std::vector<Ent>>(P));     // [chunk][partition]
-    hgx_par_tasks(n_threads, nc, [&](int, size_t c) {
-        const hgx_batch &lb = res[c].local;
+    struct Ent { uint32_t local; };
+    std::vector<std::vector<std::vector<Ent>>> bucket(nw, std::vector<std::vector<Ent>>(P));     // [worker][partition]
+    hgx_par_tasks(n_threads, nw, [&](int, size_t w) {
+        const hgx_batch &lb = workers[w].table;
         for (size_t k = 0; k < lb.pieces.size(); ++k) {
             const hgx_piece &pc = lb.pieces[k];
             const uint64_t h = PieceTable::hash(pc.lo_word, pc.n_words, &lb.masks[pc.mask_off]);
-            bucket[c][(h >> 40) % P].push_back(Ent{(uint32_t)k, h});
+            bucket[w][(h >> 40) % P].push_back(Ent{(uint32_t)k});
         }
     });
     std::vector<hgx_batch> part(P);                                        // partition-private distinct pieces
-    std::vector<std::vector<uint32_t>> remap(nc);                          // [chunk][local id] -> (partition-local id, patched below)
-    for (size_t c = 0; c < nc; ++c) remap[c].resize(res[c].local.pieces.size());
     hgx_par_tasks(n_threads, (size_t)P, [&](int, size_t p) {
-        for (size_t c = 0; c < nc; ++c) {
-            const hgx_batch &lb = res[c].local;
-            for (const Ent &e : bucket[c][p]) {
+        for (size_t w = 0; w < nw; ++w) {
+            const hgx_batch &lb = workers[w].table;
+            for (const Ent &e : bucket[w][p]) {
                 const hgx_piece &pc = lb.pieces[e.local];
-                remap[c][e.local] = hgx_intern_masks(part[p], pc.lo_word, pc.n_words, &lb.masks[pc.mask_off]);
+                gid[w][e.local] = hgx_intern_masks(part[p], pc.lo_word, pc.n_words, &lb.masks[pc.mask_off]);   // partition-local for now
             }
         }
     });
@@ -1163,30 +1363,10 @@ void merge_chunks(hgx_batch &B, std::vector<ChunkResult> &res, int n_threads) {
         }
         if (!part[p].masks.empty()) memcpy(&B.masks[mbase[p]], part[p].masks.data(), part[p].masks.size() * 4);
     });
-    std::vector<size_t> roff(nc + 1, 0), poff(nc + 1, 0);
-    for (size_t c = 0; c < nc; ++c) {
-        roff[c + 1] = roff[c] + res[c].local.pair_ref.size();
-        poff[c + 1] = poff[c] + res[c].local.pair_off.size() - 1;
-        B.n_reads += res[c].local.n_reads;
-    }
-    B.pair_ref.resize(roff[nc]);
-    B.pair_off.resize(poff[nc] + 1);
-    B.pair_off[0] = 0;
-    hgx_par_tasks(n_threads, nc, [&](int, size_t c) {
-        const hgx_batch &lb = res[c].local;
-        // which partition a local piece went to: recomputed from the buckets (remap holds the partition-local id)
-        std::vector<uint32_t> gid(lb.pieces.size());
+    hgx_par_tasks(n_threads, nw, [&](int, size_t w) {
         for (int p = 0; p < P; ++p)
-            for (const Ent &e : bucket[c][p]) gid[e.local] = pbase[p] + remap[c][e.local];
-        uint32_t *dst = &B.pair_ref[roff[c]];
-        for (size_t k = 0; k < lb.pair_ref.size(); ++k) {
-            const uint32_t ref = lb.pair_ref[k];
-            dst[k] = (ref & 0x80000000u) | gid[ref & 0x7fffffffu];
-        }
-        for (size_t k = 1; k < lb.pair_off.size(); ++k) B.pair_off[poff[c] + k] = (int32_t)(roff[c] + lb.pair_off[k]);
+            for (const Ent &e : bucket[w][p]) gid[w][e.local] += pbase[p];
     });
-    for (auto &r : res)
-        for (auto &t : r.local.trace) B.trace.push_back(std::move(t));
 }
 
 template <class F>
@@ -1288,39 +1468,62 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
         std::unique_ptr<void, PoolFree> ok_mem(hgx_host_alloc(std::max<size_t>(n, 1)));
         Fields *recs = (Fields *)recs_mem.get();
         uint8_t *ok = (uint8_t *)ok_mem.get();
-        // field split + pass 1 (pileup over all records, common:1076-1134), both embarrassingly parallel over lines
+        // field split + decode keys, embarrassingly parallel over lines
+        parallel_for(n_threads, n, [&](int, size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                char *line = lines[i].p, *lend = line + lines[i].len;
+                *lend = 0;
+                ok[i] = split_line(line, lend, recs[i]) ? 1 : 0;
+            }
+        });
+        lap("split");
+        // chunks that start where the read id changes (the record filters and the pair protocol work inside them)
+        const int n_chunks = n_threads == 1 ? 1 : n_threads * 4;
+        std::vector<size_t> cut{0};
+        for (int c = 1; c < n_chunks; ++c) {
+            size_t i = std::max(cut.back(), n * c / n_chunks);
+            while (i < n && i > 0) {
+                if (ok[i] && ok[i - 1]) {
+                    const size_t la = read_id_len(recs[i], opts->simulation != 0), lb = read_id_len(recs[i - 1], opts->simulation != 0);
+                    if (la != lb || memcmp(recs[i].qname, recs[i - 1].qname, la) != 0) break;
+                }
+                ++i;
+            }
+            if (i > cut.back() && i < n) cut.push_back(i);
+        }
+        cut.push_back(n);
+        const size_t nc = cut.size() - 1;
+        hgx_par_tasks(n_threads, nc, [&](int, size_t c) { filter_records(*opts, recs, ok, cut[c], cut[c + 1]); });
+        std::vector<uint32_t> reps;                     // first records of the distinct decode keys that some kept record carries
+        group_records(*opts, recs, ok, n, n_threads, reps);
+        lap("filters + grouping");
+        // pass 1: pileup over all records (common:1076-1134) = over the distinct keys, each weighted by its group's size
         std::vector<std::vector<uint32_t>> tcounts(n_threads);
         std::vector<std::string> terr(n_threads);
         parallel_for(n_threads, n, [&](int t, size_t b, size_t e) {
             std::vector<uint32_t> &cnt = tcounts[t];
             cnt.assign((size_t)n_ref * 6, 0u);
+            static const struct Lut { uint8_t t[256]; Lut() { memset(t, 4, 256); t['A'] = 0; t['C'] = 1; t['G'] = 2; t['T'] = 3; } } slot_of;
             for (size_t i = b; i < e; ++i) {
-                char *line = lines[i].p, *lend = line + lines[i].len;
-                *lend = 0;
-                ok[i] = split_line(line, lend, recs[i]) ? 1 : 0;
-                if (!ok[i]) continue;
+                if (!ok[i] || recs[i].rep != i || recs[i].n_pile == 0) continue;
                 const Fields &f = recs[i];
-                if (f.flag & 0x4) continue;
+                const uint32_t w = f.n_pile;
                 const int pos = f.pos - (opts->base_locus + 1);
-                if (pos < 0) continue;
-                if (!opts->allow_discordant && !(f.flag & 0x2)) continue;
                 int rp = 0, gp = pos;
                 for (const char *p = f.cigar; *p;) {
                     char *q;
                     const long len = strtol(p, &q, 10);
                     if (q == p || !*q) break;
                     const char op = *q;
-                    if (op == 'M' || op == 'D') {
-                        for (long j = 0; j < len; ++j) {
-                            if (gp + j >= n_ref) break;
-                            int slot = 5;
-                            if (op == 'M') {
-                                if ((size_t)(rp + j) >= f.seq_len) { terr[t] = "IndexError: read shorter than CIGAR"; break; }
-                                const char c = f.seq[rp + j];
-                                slot = c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
-                            }
-                            cnt[(size_t)(gp + j) * 6 + slot]++;
-                        }
+                    if (op == 'M') {
+                        const long lim = std::min<long>(len, (long)n_ref - gp);
+                        if (lim > 0 && (size_t)(rp + lim) > f.seq_len) { terr[t] = "IndexError: read shorter than CIGAR"; break; }
+                        uint32_t *c = &cnt[(size_t)gp * 6];
+                        const unsigned char *sq = (const unsigned char *)f.seq + rp;
+                        for (long j = 0; j < lim; ++j) c[j * 6 + slot_of.t[sq[j]]] += w;
+                    } else if (op == 'D') {
+                        const long lim = std::min<long>(len, (long)n_ref - gp);
+                        for (long j = 0; j < lim; ++j) cnt[(size_t)(gp + j) * 6 + 5] += w;
                     }
                     if (op == 'M' || op == 'N' || op == 'D') gp += (int)len;
                     if (op == 'M' || op == 'I' || op == 'S') rp += (int)len;
@@ -1328,11 +1531,10 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
                 }
             }
         });
-        lap("split + pileup");
         for (auto &e : terr) if (!e.empty()) throw RefError(e);
         B->counts.assign((size_t)n_ref * 6, 0u);
         B->nt_set.assign(n_ref, 0);
-        {   // partial pileups summed in worker (= stream) order, columns split among the workers
+        {   // partial pileups added up, columns split among the workers
             const size_t cells = B->counts.size();
             parallel_for(n_threads, cells, [&](int, size_t b, size_t e) {
                 for (auto &cnt : tcounts)
@@ -1349,27 +1551,45 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
                     if ((double)c[k] >= (double)tot * 0.2 || c[k] >= 7) m |= 1 << k;
             B->nt_set[i] = (uint8_t)m;
         }
+        lap("pileup");
         const long expected = opts->codis_choose_pairs ? pair_interdist(recs, ok, n, opts->simulation != 0) : -1;
-        // pass 2: chunks that start where the read id changes
-        const int n_chunks = n_threads == 1 ? 1 : n_threads * 4;
-        std::vector<size_t> cut{0};
-        for (int c = 1; c < n_chunks; ++c) {
-            size_t i = std::max(cut.back(), n * c / n_chunks);
-            while (i < n && i > 0) {
-                if (ok[i] && ok[i - 1]) {
-                    const size_t la = read_id_len(recs[i], opts->simulation != 0), lb = read_id_len(recs[i - 1], opts->simulation != 0);
-                    if (la != lb || memcmp(recs[i].qname, recs[i - 1].qname, la) != 0) break;
-                }
-                ++i;
-            }
-            if (i > cut.back() && i < n) cut.push_back(i);
+        // pass 2a: every distinct key once
+        std::vector<MateOut> outs(reps.size());
+        const int n_dec = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, reps.size() / 256 + 1));
+        std::vector<DecodeWorker> workers(n_dec);
+        NovelTable novel;
+        {
+            const size_t BLOCK = 128;
+            const size_t n_blocks = (reps.size() + BLOCK - 1) / BLOCK;
+            std::atomic<size_t> next{0};
+            hgx_run_workers(n_dec, [&](int w) {
+                DecodeWorker &W = workers[w];
+                Parser P(L, *opts, W.table, *B, alts, novel);
+                std::string read;
+                std::vector<Cmp> cl, c2;
+                std::vector<Parser::AltSide> lset, rset;
+                std::vector<int> mid;
+                std::vector<Ht> ex;
+                std::vector<int32_t> ids;
+                for (size_t blk; (blk = next.fetch_add(1)) < n_blocks;)
+                    for (size_t k = blk * BLOCK; k < std::min(reps.size(), (blk + 1) * BLOCK); ++k)
+                        decode_one(P, L, *opts, recs[reps[k]], (uint32_t)w, W, outs[k], read, cl, c2, lset, rset, mid, ex, ids);
+            });
         }
-        cut.push_back(n);
-        const size_t nc = cut.size() - 1;
-        std::vector<ChunkResult> res(nc);
-        lap("pileup merge + cuts");
+        lap("decode distinct keys");
+        // the workers' piece tables -> one table in canonical order; final_id[w][local id] = id in the batch
+        std::vector<std::vector<uint32_t>> final_id;
+        merge_tables(*B, workers, n_threads, final_id);
+        {
+            std::vector<uint32_t> new_id;
+            hgx_canonical_piece_order(*B, n_threads, new_id);
+            hgx_par_tasks(n_threads, final_id.size(), [&](int, size_t w) { for (auto &v : final_id[w]) v = new_id[v]; });
+        }
+        lap("piece table");
+        // pass 2b: the pair protocol per chunk, then the chunks' refs side by side
+        std::vector<ChunkOut> res(nc);
         hgx_par_tasks(n_threads, nc, [&](int, size_t c) {
-            process_chunk(L, *opts, alts, recs, ok, cut[c], cut[c + 1], *B, c + 1 == nc, expected, res[c]);
+            emit_chunk(*opts, recs, ok, cut[c], cut[c + 1], outs, workers, final_id, c + 1 == nc, expected, res[c]);
         });
         for (auto &r : res)
             if (r.error_code) {
@@ -1378,11 +1598,22 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
                 delete B;
                 return code;
             }
-        lap("streaming loop");
-        merge_chunks(*B, res, n_threads);
-        lap("merge");
-        hgx_finalize_batch(*B, n_threads);
-        lap("finalize");
+        std::vector<size_t> roff(nc + 1, 0), poff(nc + 1, 0);
+        for (size_t c = 0; c < nc; ++c) {
+            roff[c + 1] = roff[c] + res[c].pair_ref.size();
+            poff[c + 1] = poff[c] + res[c].pair_off.size() - 1;
+            B->n_reads += res[c].n_reads;
+        }
+        B->pair_ref.resize(roff[nc]);
+        B->pair_off.resize(poff[nc] + 1);
+        B->pair_off[0] = 0;
+        hgx_par_tasks(n_threads, nc, [&](int, size_t c) {
+            if (!res[c].pair_ref.empty()) memcpy(&B->pair_ref[roff[c]], res[c].pair_ref.data(), res[c].pair_ref.size() * 4);
+            for (size_t k = 1; k < res[c].pair_off.size(); ++k) B->pair_off[poff[c] + k] = (int32_t)(roff[c] + res[c].pair_off[k]);
+        });
+        for (auto &r : res)
+            for (auto &t : r.trace) B->trace.push_back(std::move(t));
+        lap("pair protocol");
     } catch (const RefError &e) {
         hgx_set_error("the reference would fail on this input: %s", e.what());
         delete B;
