@@ -40,6 +40,7 @@ def parse_args():
     ap.add_argument("--err", type=float, default=0.002)
     ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file -> result measurement (SAM text and BAM)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (profiling runs)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="samples typed concurrently per GPU (host threads with their own streams and class-row buffers; "
@@ -142,6 +143,78 @@ def cpu_baseline(loc, sam, n_pairs):
         "python_port_reads_per_s": round(r2["num_reads"] / t_py, 1),
         "python_port_sample": "oracle/pyref.py end to end (front-end included) on the first %d pairs" % n_py,
     }, out
+
+
+def cgroup_cpu_quota():
+    """CPUs' worth of CPU time per period this container may use (cgroup v2 cpu.max / v1 cfs quota), or None."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        return None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return q / per if q > 0 and per > 0 else None
+    except Exception:
+        return None
+
+
+def end_to_end(pl, loc, sam, ref_res, runs=5):
+    """File -> typing result through ONE C call (hgx_type_file): read (pread / BGZF inflate / BAM decode / name grouping),
+    front-end, upload, GPU path, result on the host.  SAM text as an aligner writes it (grouped by read) and BAM as the
+    reference's pipeline stores it (`samtools sort`: by coordinate), both from the page cache.  `runs` back-to-back calls
+    after one warm-up; the median is what a caller sees in steady state (the host side is CPU-TIME bound: see `host`)."""
+    import ctypes as C
+    import tempfile
+    from hisatgenotype_amd import bamio
+    d = tempfile.mkdtemp(prefix="hgx_e2e_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    out = {}
+    L = capi.lib()
+    try:
+        paths = {"sam": os.path.join(d, "reads.sam"), "bam": os.path.join(d, "reads.bam")}
+        data = sam.encode()
+        with open(paths["sam"], "wb") as f:
+            f.write(data)
+        bamio.write_bam_native(paths["bam"], data, [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
+        n_records = data.count(b"\n")
+        del data
+        for kind, path in paths.items():
+            times, res = [], None
+            for rep in range(runs + 1):
+                o = capi.ParseOpts(2, 1, 0, 0, 0, 0, 0, 0)
+                to = htyping.TypeOpts(1, 0, -1, 0, None, None, None, None, None)
+                h = C.c_void_p()
+                t0 = time.perf_counter()
+                capi.check(L.hgx_type_file(C.byref(h), pl.h, pl.index(), path.encode(), pl.ref_allele.encode(), C.byref(o), C.byref(to), None))
+                dt = time.perf_counter() - t0
+                try:
+                    if rep == runs:
+                        res = htyping.LocusResult()
+                        nr, npair = C.c_int32(), C.c_int32()
+                        capi.check(L.hgx_typing_dims(h, C.byref(nr), C.byref(npair), None, None, None, None, None, None))
+                        res.num_reads, res.num_pairs = nr.value, npair.value
+                        htyping._result_from_handle(h, pl, res, False)
+                finally:
+                    L.hgx_typing_destroy(h)
+                if rep:
+                    times.append(dt)
+            same = (res.num_reads == ref_res.num_reads and res.gene_prob == ref_res.gene_prob and
+                    [e["n_iter"] for e in res.em] == [e["n_iter"] for e in ref_res.em])
+            med = sorted(times)[len(times) // 2]
+            out[kind] = {"reads_per_s": round(res.num_reads / med, 1), "ms": round(med * 1e3, 2), "best_ms": round(min(times) * 1e3, 2),
+                         "runs_ms": [round(t * 1e3, 1) for t in times], "file_MB": round(os.path.getsize(path) / 1e6, 1),
+                         "records_in_file": n_records, "result_identical_to_hbm_path": bool(same)}
+    finally:
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+    quota = cgroup_cpu_quota()
+    out["host"] = {"hw_threads": os.cpu_count(), "cgroup_cpu_quota": quota,
+                   "front_end_threads": "2 x quota" if quota else "all hardware threads"}
+    out["note"] = ("hgx_type_file per call: file (page cache) -> typing result on the host, H2D and the GPU path included; "
+                   "%d back-to-back runs after a warm-up, median.  The host front-end is bound by CPU TIME: this container's cgroup "
+                   "grants %s CPUs of it, whatever the number of hardware threads." % (runs, "%.0f" % quota if quota else "all"))
+    return out
 
 
 def main():
@@ -280,6 +353,8 @@ def main():
             },
         }
         if sam_keep is not None:
+            if not args.no_e2e:
+                out["e2e"] = end_to_end(pl, loc, sam_keep, res)
             cb, _ = cpu_baseline(loc, sam_keep, min(args.cpu_pairs, batch.n_pairs))
             out["cpu_baseline"] = cb
         print(json.dumps(out))

@@ -246,3 +246,16 @@ def write_bam(path, sam_text, refs, block_size=0xff00):
             fo.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + cdata +
                      struct.pack("<II", zlib.crc32(raw) & 0xffffffff, len(raw)))
         fo.write(_BGZF_EOF)
+
+
+def write_bam_native(path, sam_text, refs, sort_by_coordinate=False, n_threads=0):
+    """write_bam through libhgx (hgx_write_bam: parallel record encoding and BGZF deflate): seconds instead of minutes for a
+    million records.  `sort_by_coordinate` orders the records like `samtools sort` first."""
+    import ctypes as C
+    import numpy as np
+    from . import capi
+    data = sam_text if isinstance(sam_text, (bytes, bytearray)) else sam_text.encode()
+    names = "\n".join(n for n, _ in refs).encode()
+    lens = np.array([ln for _, ln in refs] or [0], np.int32)
+    capi.check(capi.lib().hgx_write_bam(path.encode(), data, C.c_size_t(len(data)), names, capi.ptr(lens), C.c_int32(len(refs)),
+                                        C.c_int32(int(bool(sort_by_coordinate))), C.c_int32(n_threads)))

@@ -358,7 +358,7 @@ inline int64_t cigar_text_reflen(const char *p, const char *e) {
 // The reader proper: the records of `path` as a line table, stable-sorted by QNAME, over buffers `out` owns.  Every line is
 // followed by one byte the parser may overwrite (its terminator).
 int hgx_read_alignment_lines(const char *path, const char *regions, int n_threads, hgx_align_lines &out) {
-    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = hgx_default_threads();
     n_threads = std::max(1, std::min(n_threads, 512));
     const std::vector<Region> regs = parse_regions(regions);
     const bool filtered = regions != nullptr && regions[0] != 0;      // an empty list after parsing keeps nothing, like an unknown name
@@ -561,7 +561,7 @@ extern "C" int hgx_read_alignments(const char *path, const char *regions, int32_
         hgx_align_lines al;
         const int rc = hgx_read_alignment_lines(path, regions, n_threads, al);
         if (rc) return rc;
-        if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+        if (n_threads <= 0) n_threads = hgx_default_threads();
         n_threads = std::max(1, std::min(n_threads, 512));
         const std::vector<Line> &lines = al.lines;
         size_t total = 0;
@@ -588,4 +588,269 @@ extern "C" int hgx_read_alignments(const char *path, const char *regions, int32_
 extern "C" int hgx_free_text(char *text) {
     hgx_host_free(text);
     return HGX_OK;
+}
+
+// ---- BAM writer -----------------------------------------------------------------------------------------------------
+// SAM text (records; header lines are skipped) -> BAM: records encoded in parallel, BGZF blocks of <= 0xff00 payload bytes
+// deflated in parallel (zlib), one EOF block.  Optionally the records are ordered by (reference, position) first, as
+// `samtools sort` leaves an alignment file -- what the reference's pipeline stores (typing_common.py:1041-1050).  The
+// pure-Python statement of the same format is bamio.write_bam.
+namespace {
+
+inline void put32(std::vector<unsigned char> &o, uint32_t v) { o.push_back(v & 255); o.push_back((v >> 8) & 255); o.push_back((v >> 16) & 255); o.push_back(v >> 24); }
+inline void put16(std::vector<unsigned char> &o, uint32_t v) { o.push_back(v & 255); o.push_back((v >> 8) & 255); }
+
+int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+struct SamRec { const char *p; uint32_t len; int32_t rid; int32_t pos0; };
+
+// one SAM line -> one BAM record (block_size word included) appended to `o`; false if the line is malformed
+bool encode_record(const char *line, size_t len, const std::vector<std::string> &refs, std::vector<unsigned char> &o) {
+    const char *f[64];
+    size_t fl[64];
+    int nf = 0;
+    const char *p = line, *end = line + len;
+    while (p <= end && nf < 64) {
+        const char *q = (const char *)memchr(p, '\t', (size_t)(end - p));
+        if (!q) q = end;
+        f[nf] = p; fl[nf++] = (size_t)(q - p);
+        p = q + 1;
+    }
+    if (nf < 11) return false;
+    auto ref_id = [&](const char *s, size_t n) -> int32_t {
+        for (size_t i = 0; i < refs.size(); ++i) if (refs[i].size() == n && memcmp(refs[i].data(), s, n) == 0) return (int32_t)i;
+        return -1;
+    };
+    const int32_t rid = ref_id(f[2], fl[2]);
+    const int32_t nid = (fl[6] == 1 && f[6][0] == '=') ? rid : ref_id(f[6], fl[6]);
+    const long flag = strtol(f[1], nullptr, 10), pos0 = strtol(f[3], nullptr, 10) - 1, mapq = strtol(f[4], nullptr, 10);
+    const long pnext0 = strtol(f[7], nullptr, 10) - 1, tlen = strtol(f[8], nullptr, 10);
+    std::vector<uint32_t> cig;
+    int64_t reflen = 0;
+    if (!(fl[5] == 1 && f[5][0] == '*')) {
+        static const char ops[] = "MIDNSHP=X";
+        uint64_t n = 0;
+        for (size_t k = 0; k < fl[5]; ++k) {
+            const char c = f[5][k];
+            if (c >= '0' && c <= '9') { n = n * 10 + (uint64_t)(c - '0'); continue; }
+            const char *w = strchr(ops, c);
+            if (!w || !c) return false;
+            const uint32_t op = (uint32_t)(w - ops);
+            cig.push_back((uint32_t)(n << 4) | op);
+            if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += (int64_t)n;
+            n = 0;
+        }
+    }
+    const bool no_seq = fl[9] == 1 && f[9][0] == '*';
+    const size_t l_seq = no_seq ? 0 : fl[9];
+    const size_t at = o.size();
+    put32(o, 0);                                          // block_size, patched below
+    put32(o, (uint32_t)rid);
+    put32(o, (uint32_t)pos0);
+    o.push_back((unsigned char)(fl[0] + 1));
+    o.push_back((unsigned char)mapq);
+    put16(o, (uint32_t)reg2bin(pos0, pos0 + std::max<int64_t>(reflen, 1)));
+    put16(o, (uint32_t)cig.size());
+    put16(o, (uint32_t)flag);
+    put32(o, (uint32_t)l_seq);
+    put32(o, (uint32_t)nid);
+    put32(o, (uint32_t)pnext0);
+    put32(o, (uint32_t)tlen);
+    o.insert(o.end(), f[0], f[0] + fl[0]);
+    o.push_back(0);
+    for (uint32_t c : cig) put32(o, c);
+    if (!no_seq) {
+        static const struct Code { unsigned char t[256]; Code() { memset(t, 15, 256); const char *s = "=ACMGRSVTWYHKDBN"; for (int i = 0; i < 16; ++i) t[(unsigned char)s[i]] = (unsigned char)i; } } code;
+        for (size_t k = 0; k < l_seq; k += 2) {
+            const unsigned hi = code.t[(unsigned char)f[9][k]], lo = k + 1 < l_seq ? code.t[(unsigned char)f[9][k + 1]] : 0;
+            o.push_back((unsigned char)((hi << 4) | lo));
+        }
+        if (fl[10] == 1 && f[10][0] == '*') o.insert(o.end(), l_seq, (unsigned char)0xff);
+        else {
+            if (fl[10] != l_seq) return false;
+            for (size_t k = 0; k < l_seq; ++k) o.push_back((unsigned char)(f[10][k] - 33));
+        }
+    }
+    for (int k = 11; k < nf; ++k) {                       // TAG:TYPE:VALUE
+        if (fl[k] < 5 || f[k][2] != ':' || f[k][4] != ':') return false;
+        const char t = f[k][3];
+        const char *v = f[k] + 5;
+        const size_t vl = fl[k] - 5;
+        o.push_back((unsigned char)f[k][0]);
+        o.push_back((unsigned char)f[k][1]);
+        if (t == 'i') {                                   // the smallest type that holds the value, as samtools chooses
+            const long long x = strtoll(v, nullptr, 10);
+            if (x >= 0 && x <= 255) { o.push_back('C'); o.push_back((unsigned char)x); }
+            else if (x >= -128 && x <= 127) { o.push_back('c'); o.push_back((unsigned char)(int8_t)x); }
+            else if (x >= 0 && x <= 65535) { o.push_back('S'); put16(o, (uint32_t)x); }
+            else if (x >= -32768 && x <= 32767) { o.push_back('s'); put16(o, (uint32_t)(uint16_t)(int16_t)x); }
+            else if (x >= 0 && x <= 4294967295ll) { o.push_back('I'); put32(o, (uint32_t)x); }
+            else if (x >= -2147483648ll && x <= 2147483647ll) { o.push_back('i'); put32(o, (uint32_t)(int32_t)x); }
+            else return false;
+        } else if (t == 'Z' || t == 'H') { o.push_back((unsigned char)t); o.insert(o.end(), v, v + vl); o.push_back(0); }
+        else if (t == 'A') { if (vl != 1) return false; o.push_back('A'); o.push_back((unsigned char)v[0]); }
+        else if (t == 'f') { o.push_back('f'); const float x = strtof(v, nullptr); uint32_t u; memcpy(&u, &x, 4); put32(o, u); }
+        else if (t == 'B') {
+            if (vl < 1) return false;
+            const char st = v[0];
+            o.push_back('B');
+            o.push_back((unsigned char)st);
+            const size_t cnt_at = o.size();
+            put32(o, 0);
+            uint32_t cnt = 0;
+            const char *q = v + 1, *ve = v + vl;
+            while (q < ve) {
+                if (*q != ',') return false;
+                ++q;
+                char *e2;
+                if (st == 'f') { const float x = strtof(q, &e2); uint32_t u; memcpy(&u, &x, 4); put32(o, u); }
+                else {
+                    const long long x = strtoll(q, &e2, 10);
+                    if (st == 'c' || st == 'C') o.push_back((unsigned char)x);
+                    else if (st == 's' || st == 'S') put16(o, (uint32_t)(uint16_t)x);
+                    else if (st == 'i' || st == 'I') put32(o, (uint32_t)x);
+                    else return false;
+                }
+                if (e2 == q) return false;
+                q = e2;
+                ++cnt;
+            }
+            o[cnt_at] = cnt & 255; o[cnt_at + 1] = (cnt >> 8) & 255; o[cnt_at + 2] = (cnt >> 16) & 255; o[cnt_at + 3] = cnt >> 24;
+        } else return false;
+    }
+    const uint32_t bs = (uint32_t)(o.size() - at - 4);
+    o[at] = bs & 255; o[at + 1] = (bs >> 8) & 255; o[at + 2] = (bs >> 16) & 255; o[at + 3] = bs >> 24;
+    return true;
+}
+
+}   // namespace
+
+extern "C" int hgx_write_bam(const char *path, const char *sam, size_t n_bytes, const char *ref_names, const int32_t *ref_lens,
+                             int32_t n_refs, int32_t sort_by_coordinate, int32_t n_threads) {
+    HARGCHK(path && (sam || n_bytes == 0) && n_refs >= 0 && (n_refs == 0 || (ref_names && ref_lens)));
+    try {
+        if (n_threads <= 0) n_threads = hgx_default_threads();
+        std::vector<std::string> refs;
+        {
+            const char *p = ref_names;
+            for (int i = 0; i < n_refs; ++i) {
+                const char *e = strchr(p, '\n');
+                if (!e) e = p + strlen(p);
+                refs.emplace_back(p, e);
+                p = *e ? e + 1 : e;
+            }
+        }
+        std::vector<SamRec> recs;
+        for (const char *p = sam, *end = sam + n_bytes; p < end;) {
+            const char *e = (const char *)memchr(p, '\n', (size_t)(end - p));
+            if (!e) e = end;
+            size_t len = (size_t)(e - p);
+            if (len && p[len - 1] == '\r') --len;
+            if (len && *p != '@') recs.push_back(SamRec{p, (uint32_t)len, 0, 0});
+            p = e + 1;
+        }
+        if (sort_by_coordinate) {
+            par_for(n_threads, recs.size(), [&](int, size_t b, size_t e) {
+                for (size_t i = b; i < e; ++i) {
+                    const char *t1 = (const char *)memchr(recs[i].p, '\t', recs[i].len);
+                    const char *t2 = t1 ? (const char *)memchr(t1 + 1, '\t', recs[i].len - (size_t)(t1 + 1 - recs[i].p)) : nullptr;
+                    const char *t3 = t2 ? (const char *)memchr(t2 + 1, '\t', recs[i].len - (size_t)(t2 + 1 - recs[i].p)) : nullptr;
+                    int32_t rid = 0x7fffffff;                              // unplaced records last, as samtools sort puts them
+                    if (t3)
+                        for (size_t k = 0; k < refs.size(); ++k)
+                            if (refs[k].size() == (size_t)(t3 - t2 - 1) && memcmp(refs[k].data(), t2 + 1, refs[k].size()) == 0) { rid = (int32_t)k; break; }
+                    recs[i].rid = rid;
+                    recs[i].pos0 = t3 ? (int32_t)strtol(t3 + 1, nullptr, 10) - 1 : 0;
+                }
+            });
+            std::stable_sort(recs.begin(), recs.end(), [](const SamRec &a, const SamRec &b) {
+                return a.rid != b.rid ? a.rid < b.rid : a.pos0 < b.pos0;
+            });
+        }
+        // header
+        std::vector<unsigned char> head;
+        head.insert(head.end(), {'B', 'A', 'M', 1});
+        std::string text = sort_by_coordinate ? "@HD\tVN:1.6\tSO:coordinate\n" : "";
+        for (int i = 0; i < n_refs; ++i) text += "@SQ\tSN:" + refs[i] + "\tLN:" + std::to_string(ref_lens[i]) + "\n";
+        put32(head, (uint32_t)text.size());
+        head.insert(head.end(), text.begin(), text.end());
+        put32(head, (uint32_t)n_refs);
+        for (int i = 0; i < n_refs; ++i) {
+            put32(head, (uint32_t)refs[i].size() + 1);
+            head.insert(head.end(), refs[i].begin(), refs[i].end());
+            head.push_back(0);
+            put32(head, (uint32_t)ref_lens[i]);
+        }
+        // records, encoded per worker range
+        const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, recs.size() / 2000 + 1));
+        std::vector<std::vector<unsigned char>> enc(T);
+        std::vector<int> bad(T, 0);
+        par_for(T, recs.size(), [&](int t, size_t b, size_t e) {
+            enc[t].reserve((e - b) * 260);
+            for (size_t i = b; i < e; ++i)
+                if (!encode_record(recs[i].p, recs[i].len, refs, enc[t])) { bad[t] = 1; return; }
+        });
+        for (int v : bad) if (v) { hgx_set_error("malformed SAM record: cannot be written as BAM"); return HGX_EPARSE; }
+        // one byte stream -> BGZF blocks
+        size_t total = head.size();
+        std::vector<size_t> off(T + 1, 0);
+        for (int t = 0; t < T; ++t) { off[t] = total; total += enc[t].size(); }
+        Bytes raw;
+        raw.alloc(total);
+        memcpy(raw.data(), head.data(), head.size());
+        par_for(T, (size_t)T, [&](int, size_t b, size_t e) { for (size_t t = b; t < e; ++t) if (!enc[t].empty()) memcpy(raw.data() + off[t], enc[t].data(), enc[t].size()); });
+        const size_t BLK = 0xff00;
+        const size_t n_blocks = (total + BLK - 1) / BLK;
+        std::vector<std::vector<unsigned char>> comp(n_blocks);
+        std::vector<int> zbad(std::max(1, n_threads), 0);
+        par_for(n_threads, n_blocks, [&](int t, size_t b, size_t e) {
+            for (size_t k = b; k < e; ++k) {
+                const unsigned char *src = raw.data() + k * BLK;
+                const size_t n = std::min(BLK, total - k * BLK);
+                std::vector<unsigned char> &o = comp[k];
+                o.resize(18 + compressBound((uLong)n) + 8);
+                z_stream zs;
+                memset(&zs, 0, sizeof zs);
+                if (deflateInit2(&zs, 1, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { zbad[t] = 1; return; }
+                zs.next_in = const_cast<unsigned char *>(src);
+                zs.avail_in = (uInt)n;
+                zs.next_out = o.data() + 18;
+                zs.avail_out = (uInt)(o.size() - 18);
+                const int rc = deflate(&zs, Z_FINISH);
+                const size_t clen = zs.total_out;
+                deflateEnd(&zs);
+                if (rc != Z_STREAM_END || 18 + clen + 8 > 65536) { zbad[t] = 1; return; }
+                static const unsigned char hdr[16] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0};
+                memcpy(o.data(), hdr, 16);
+                const uint32_t bsize = (uint32_t)(18 + clen + 8 - 1);
+                o[16] = bsize & 255; o[17] = bsize >> 8;
+                const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), src, (uInt)n);
+                unsigned char *tail = o.data() + 18 + clen;
+                tail[0] = crc & 255; tail[1] = (crc >> 8) & 255; tail[2] = (crc >> 16) & 255; tail[3] = crc >> 24;
+                tail[4] = n & 255; tail[5] = (n >> 8) & 255; tail[6] = (n >> 16) & 255; tail[7] = (unsigned char)(n >> 24);
+                o.resize(18 + clen + 8);
+            }
+        });
+        for (int v : zbad) if (v) { hgx_set_error("BGZF deflate failed"); return HGX_EINVAL; }
+        FILE *fo = fopen(path, "wb");
+        if (!fo) { hgx_set_error("cannot create %s", path); return HGX_EINVAL; }
+        bool ok = true;
+        for (auto &c : comp) ok = ok && fwrite(c.data(), 1, c.size(), fo) == c.size();
+        static const unsigned char eof_block[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        ok = ok && fwrite(eof_block, 1, sizeof eof_block, fo) == sizeof eof_block;
+        ok = (fclose(fo) == 0) && ok;
+        if (!ok) { hgx_set_error("short write on %s", path); return HGX_EINVAL; }
+        return HGX_OK;
+    } catch (const std::exception &e) {
+        hgx_set_error("hgx_write_bam: %s", e.what());
+        return HGX_ENOMEM;
+    }
 }

@@ -505,3 +505,34 @@ void hgx_run_workers(int n, const std::function<void(int)> &body) {
     P.cv_done.wait(lk, [&] { return P.running == 0; });
     P.body = nullptr;
 }
+
+// ---- how many host threads a parallel phase should use ---------------------------------------------------------------
+// hardware_concurrency() reports the machine; a container is often confined to far less CPU TIME by a cgroup bandwidth quota
+// (cpu.max / cpu.cfs_quota_us): with a quota of 16 CPUs, 256 runnable threads exhaust a 100 ms period's budget in 6 ms and
+// are then all throttled until the next period -- measured here: every phase got SLOWER beyond 32 threads.  Default = twice
+// the quota (short phases may burst above the long-run rate), at most the hardware threads; HGX_THREADS overrides.
+#include <cstdio>
+#include <cstdlib>
+int hgx_default_threads() {
+    static const int cached = [] {
+        if (const char *e = getenv("HGX_THREADS")) { const int v = atoi(e); if (v > 0) return std::min(v, 512); }
+        int hw = (int)std::thread::hardware_concurrency();
+        if (hw <= 0) hw = 1;
+        double quota_cpus = 0;
+        if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+            char q[64];
+            long period = 0;
+            if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) quota_cpus = atof(q) / (double)period;
+            fclose(f);
+        } else {
+            long quota = -1, period = 0;                                           // cgroup v1
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%ld", &quota) != 1) quota = -1; fclose(g); }
+            if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%ld", &period) != 1) period = 0; fclose(g); }
+            if (quota > 0 && period > 0) quota_cpus = (double)quota / (double)period;
+        }
+        int n = hw;
+        if (quota_cpus > 0) n = std::min(hw, std::max(1, (int)(2.0 * quota_cpus + 0.5)));
+        return std::min(n, 512);
+    }();
+    return cached;
+}

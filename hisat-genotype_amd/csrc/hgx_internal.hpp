@@ -126,6 +126,7 @@ typedef std::basic_string<char, std::char_traits<char>, HostPoolAlloc<char>> PSt
 // Persistent host worker pool (hgx_host.cpp): body(worker) runs on `n` threads (worker 0 = the caller) and the call returns when
 // all are done.  The helpers below cut [0, n_items) into contiguous ranges / hand out task indices dynamically.
 void hgx_run_workers(int n, const std::function<void(int)> &body);
+int hgx_default_threads();          // host threads for a parallel phase: hardware threads, capped by the cgroup CPU quota (x2)
 template <class F>
 inline void hgx_par_ranges(int n_threads, size_t n_items, F fn) {          // fn(thread, begin, end)
     n_threads = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(n_threads, 1), n_items));

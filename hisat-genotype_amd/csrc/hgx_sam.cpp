@@ -855,10 +855,7 @@ inline uint64_t hash_bytes(const char *p, size_t n, uint64_t h) {
     h = (h ^ w ^ ((uint64_t)n << 56)) * 0xD6E8FEB86659FD93ull;
     return h ^ (h >> 29);
 }
-inline void set_decode_key(Fields &f) {
-    f.cigar_len = (uint32_t)strlen(f.cigar);
-    f.zs_len = f.zs ? (uint32_t)strlen(f.zs) : 0;
-    f.md_len = f.md ? (uint32_t)strlen(f.md) : 0;
+inline void set_decode_key(Fields &f) {          // (the lengths of cigar / zs / md were set by split_line)
     uint64_t h = hash_bytes(f.seq, f.seq_len, 0x243F6A8885A308D3ull ^ (uint32_t)f.pos);
     h = hash_bytes(f.cigar, f.cigar_len, h);
     h = hash_bytes(f.zs ? f.zs : "", f.zs_len, h ^ (f.zs ? 1 : 0));
@@ -872,36 +869,76 @@ inline bool same_decode_key(const Fields &a, const Fields &b) {
 }
 
 // split one line on whitespace in place (the buffer is a private copy); returns false for header/empty lines
+inline long parse_long(const char *p) {            // strtol(p, nullptr, 10) for the plain decimal fields of a SAM record
+    bool neg = false;
+    if (*p == '-') { neg = true; ++p; }
+    else if (*p == '+') ++p;
+    long v = 0;
+    while (*p >= '0' && *p <= '9') v = v * 10 + (*p++ - '0');
+    return neg ? -v : v;
+}
+
+inline void note_tag(Fields &f, char *tok, size_t len) {
+    if (len < 5) {                                   // too short to carry a value: tok + 5 may not be dereferenced
+        if (tok[0] == 'Z' && tok[1] == 's') { f.zs = tok + len; f.zs_len = 0; }
+        else if (tok[0] == 'M' && tok[1] == 'D') { f.md = tok + len; f.md_len = 0; }
+        else if (tok[0] == 'N' && tok[1] == 'M') f.has_nm = true;
+        else if (tok[0] == 'N' && tok[1] == 'H') f.has_nh = true;
+        return;
+    }
+    if (tok[0] == 'Z' && tok[1] == 's') { f.zs = tok + 5; f.zs_len = (uint32_t)(len - 5); }
+    else if (tok[0] == 'M' && tok[1] == 'D') { f.md = tok + 5; f.md_len = (uint32_t)(len - 5); }
+    else if (tok[0] == 'N' && tok[1] == 'M') { f.has_nm = true; f.nm = strtol(tok + 5, nullptr, 10); }
+    else if (tok[0] == 'N' && tok[1] == 'H') { f.has_nh = true; f.nh = strtol(tok + 5, nullptr, 10); }
+    else if (tok[0] == 'Y' && tok[1] == 'T') f.yt_cp = len == 7 && tok[5] == 'C' && tok[6] == 'P';
+}
+
+// Split one record in place the way the reference's `line.strip().split()` does (on runs of tab / space / CR).  A record
+// without spaces or CRs -- every record an aligner writes -- takes the tab-only path (memchr, 16+ bytes per step); anything
+// else the byte loop.  Returns false for lines with fewer than eleven fields.
 static bool split_line(char *line, char *end, Fields &f) {
     char *cols[11];
+    size_t lens[11];
     int nc = 0;
-    char *p = line;
     f.zs = f.md = nullptr;
+    f.zs_len = f.md_len = 0;
     f.has_nm = f.has_nh = f.yt_cp = false;
     f.nm = f.nh = 0;
-    while (p < end) {
-        while (p < end && (*p == '\t' || *p == ' ' || *p == '\r')) ++p;
-        if (p >= end) break;
-        char *tok = p;
-        while (p < end && *p != '\t' && *p != ' ' && *p != '\r') ++p;
-        if (p < end) *p++ = 0;
-        if (nc < 11) cols[nc++] = tok;
-        else {
-            if (tok[0] == 'Z' && tok[1] == 's') f.zs = tok + 5;
-            else if (tok[0] == 'M' && tok[1] == 'D') f.md = tok + 5;
-            else if (tok[0] == 'N' && tok[1] == 'M') { f.has_nm = true; f.nm = strtol(tok + 5, nullptr, 10); }
-            else if (tok[0] == 'N' && tok[1] == 'H') { f.has_nh = true; f.nh = strtol(tok + 5, nullptr, 10); }
-            else if (tok[0] == 'Y' && tok[1] == 'T') f.yt_cp = strcmp(tok + 5, "CP") == 0;
+    const size_t n = (size_t)(end - line);
+    if (!memchr(line, ' ', n) && !memchr(line, '\r', n)) {
+        char *p = line;
+        while (p < end) {
+            char *q = (char *)memchr(p, '\t', (size_t)(end - p));
+            if (!q) q = end;
+            if (q > p) {                              // (empty tokens between adjacent tabs vanish, as with split())
+                *q = 0;
+                if (nc < 11) { cols[nc] = p; lens[nc++] = (size_t)(q - p); }
+                else note_tag(f, p, (size_t)(q - p));
+            }
+            p = q + 1;
+        }
+    } else {
+        char *p = line;
+        while (p < end) {
+            while (p < end && (*p == '\t' || *p == ' ' || *p == '\r')) ++p;
+            if (p >= end) break;
+            char *tok = p;
+            while (p < end && *p != '\t' && *p != ' ' && *p != '\r') ++p;
+            const size_t len = (size_t)(p - tok);
+            if (p < end) *p++ = 0;
+            if (nc < 11) { cols[nc] = tok; lens[nc++] = len; }
+            else note_tag(f, tok, len);
         }
     }
     if (nc < 11) return false;
     f.qname = cols[0];
-    f.qname_len = strlen(cols[0]);
+    f.qname_len = lens[0];
     f.flag = (int)strtol(cols[1], nullptr, 10);
     f.pos = (int)strtol(cols[3], nullptr, 10);
     f.cigar = cols[5];
+    f.cigar_len = (uint32_t)lens[5];
     f.seq = cols[9];
-    f.seq_len = strlen(cols[9]);
+    f.seq_len = lens[9];
     set_decode_key(f);
     return true;
 }
@@ -1072,8 +1109,15 @@ void group_records(const hgx_parse_opts &o, Fields *recs, const uint8_t *ok, siz
         while (cap < 2 * cnt) cap <<= 1;
         std::vector<uint32_t> slot(cap, NO_SLOT);
         const size_t mask = cap - 1;
-        for (int t = 0; t < T; ++t)
-            for (uint32_t i : bucket[t][p]) {
+        for (int t = 0; t < T; ++t) {
+            const std::vector<uint32_t> &bk = bucket[t][p];
+            for (size_t bi = 0; bi < bk.size(); ++bi) {
+                const uint32_t i = bk[bi];
+                if (bi + 8 < bk.size()) {                               // the walk is a chain of cache misses: look ahead
+                    const Fields &nx = recs[bk[bi + 8]];
+                    __builtin_prefetch(&nx);
+                    __builtin_prefetch(&slot[(size_t)recs[bk[bi + 4]].key & mask]);
+                }
                 Fields &f = recs[i];
                 size_t h = (size_t)f.key & mask;
                 uint32_t r;
@@ -1089,6 +1133,7 @@ void group_records(const hgx_parse_opts &o, Fields *recs, const uint8_t *ok, siz
                 if (!(f.flag & 0x4) && f.pos - (o.base_locus + 1) >= 0 && (o.allow_discordant || (f.flag & 0x2))) g.n_pile++;
                 if (f.kept == KEPT_YES && g.slot == NO_SLOT) { g.slot = 0; part_reps[p].push_back(r); }
             }
+        }
     });
     // slots in stream order of their first record (so that a single worker creates novel variants in stream order)
     size_t tot = 0;
@@ -1382,7 +1427,7 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
 extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts) {
     HARGCHK(out && Lc && (sam || n_bytes == 0) && opts);
     try {
-        int n_threads = opts->n_threads > 0 ? opts->n_threads : (int)std::thread::hardware_concurrency();
+        int n_threads = opts->n_threads > 0 ? opts->n_threads : hgx_default_threads();
         n_threads = std::max(1, std::min(n_threads, 512));
         struct PoolFree { void operator()(char *p) const { hgx_host_free(p); } };
         std::unique_ptr<char, PoolFree> text((char *)hgx_host_alloc(n_bytes + 1));      // tokens are NUL-terminated in place
@@ -1458,7 +1503,7 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
         const AltTables alts(L);
         lap("alternatives");
         const int n_ref = (int)L.backbone.size();
-        int n_threads = opts->n_threads > 0 ? opts->n_threads : (int)std::thread::hardware_concurrency();
+        int n_threads = opts->n_threads > 0 ? opts->n_threads : hgx_default_threads();
         n_threads = std::max(1, std::min(n_threads, 512));
         if (opts->keep_trace) n_threads = 1;                // traces (and novel-variant numbering) follow stream order
         if (n < 20000) n_threads = 1;

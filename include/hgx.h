@@ -294,7 +294,7 @@ typedef struct hgx_parse_opts {
     int32_t base_locus;         /* subtracted from POS                            core:814 */
     int32_t keep_trace;         /* record per-read intermediates for hgx_batch_trace_text   */
     int32_t codis_choose_pairs; /* base codis && gene == "D18S51": choose_pairs at the final flush (core:1547-1552) */
-    int32_t n_threads;          /* host threads for the front-end; 0 = all hardware threads                   */
+    int32_t n_threads;          /* host threads for the front-end; 0 = hardware threads, capped at 2x the cgroup CPU quota */
 } hgx_parse_opts;
 
 /* SAM text (name-grouped, i.e. the stream after `sort -k1,1 -s`, core:458-468) -> batch.
@@ -315,13 +315,19 @@ int hgx_parse_sam(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t
  * the locus span in front of it (core:438-441): typing() here does the same, so reads of other loci in a multi-locus
  * alignment never reach this locus' decode.
  * *text_out is a library-owned (pooled), NUL-terminated buffer of *n_bytes_out bytes (every record ends
- * in '\n'), ready for hgx_parse_sam; release it with hgx_free_text (not free()).  n_threads <= 0: all host threads (at most 64). */
+ * in '\n'), ready for hgx_parse_sam; release it with hgx_free_text (not free()).  n_threads <= 0: the host's hardware threads, capped at twice the container's cgroup CPU quota if it has one (HGX_THREADS overrides). */
 int hgx_read_alignments(const char *path, const char *regions_or_null, int32_t n_threads, char **text_out, size_t *n_bytes_out);
 int hgx_free_text(char *text);
 /* hgx_read_alignments + hgx_parse_sam in one call: the reader's buffer is tokenised in place (no copy, no trip through the
  * caller) -- the whole host side from an alignment file to the piece batch */
 int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *loc, const char *path, const char *regions_or_null,
                              const hgx_parse_opts *opts);
+/* SAM text (records; '@' lines skipped) -> BAM file: records encoded and BGZF blocks deflated in parallel.  ref_names = the
+ * reference sequence names separated by '\n' (n_refs of them, with ref_lens).  sort_by_coordinate != 0 orders the records by
+ * (reference, position) first, as `samtools sort` leaves the alignment the reference's pipeline stores
+ * (typing_common.py:1041-1050).  Tags: A i f Z H B. */
+int hgx_write_bam(const char *path, const char *sam, size_t n_bytes, const char *ref_names, const int32_t *ref_lens, int32_t n_refs,
+                  int32_t sort_by_coordinate, int32_t n_threads);
 /* per kept record: "cmp_list2 \t cmp_left \t cmp_right \t left alts \t right alts" (keep_trace) */
 int hgx_batch_trace_text(const hgx_batch *b, char *buf, size_t cap, size_t *needed);
 /* pileup nt_set per backbone position as a 4-bit mask A=1,C=2,G=4,T=8 and counts[L][6] (A,C,G,T,N,D) */
