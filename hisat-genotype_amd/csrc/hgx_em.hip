@@ -2440,6 +2440,11 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
     return HGX_OK;
 }
 
+// 1 if the calling thread's last EM (hgx_em / hgx_em_ordered / hgx_em_masked) ran on the single-wavefront path in the reference's
+// own order of floating-point operations (its abundances are then the reference's, bit for bit), 0 otherwise
+static thread_local int g_last_exact = 0;
+extern "C" int hgx_em_last_exact(void) { return g_last_exact; }
+
 extern "C" int hgx_em_set_backend(int backend) {
     ARGCHK(backend >= 0 && backend <= 3);
     g_backend = backend;
@@ -2482,6 +2487,7 @@ extern "C" int hgx_em_ordered(const hgx_classes *cc, int32_t n_alleles, int32_t 
 static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len, double *prob_host,
                    int32_t *first_host, int32_t *n_iter_host, void *stream) {
     ARGCHK(cc && prob_host && n_alleles > 0 && n_alleles <= cc->a_pad);
+    g_last_exact = 0;
     hgx_classes_order_after(cc, (hipStream_t)stream);
     if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = -1;
     hgx_classes *c = const_cast<hgx_classes *>(cc);
@@ -2536,6 +2542,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             for (int a = 0; a < n_alleles; ++a) prob_host[a] = out[a];
             if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = h_first[a];
             if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
+            g_last_exact = b_rank.p != nullptr;
             return HGX_OK;
         }
     }
@@ -2946,6 +2953,7 @@ extern "C" int hgx_em_masked(const hgx_classes *cc, const uint64_t *mask_host, i
                              const int32_t *allele_len, double *prob_host, int32_t *first_class_host, int32_t *n_iter_host,
                              int32_t *n_classes_host, void *stream) {
     ARGCHK(cc && mask_host && prob_host && first_class_host && n_alleles > 0 && n_alleles <= cc->a_pad);
+    g_last_exact = 0;
     hipStream_t st = (hipStream_t)stream;
     hgx_classes_order_after(cc, st);
     for (int a = 0; a < n_alleles; ++a) { prob_host[a] = -1.0; first_class_host[a] = -1; }
@@ -2997,6 +3005,7 @@ extern "C" int hgx_em_masked(const hgx_classes *cc, const uint64_t *mask_host, i
             }
             if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
             if (n_classes_host) *n_classes_host = (int)h_scal[S_NCLS];
+            g_last_exact = exact ? 1 : 0;
             return HGX_OK;
         }
     }

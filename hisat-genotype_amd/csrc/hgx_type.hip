@@ -41,6 +41,7 @@ namespace {
 
 struct EmOut {
     int32_t n_classes = 0, n_iter = 0, remove_low = 0, use_length = 0;
+    bool exact = false;              // abundances are the reference's bit for bit (single-wavefront EM in the reference's order)
     std::vector<int32_t> allele;
     std::vector<double> prob;
 };
@@ -50,7 +51,9 @@ constexpr double TIE_REL_TOL = 1e-11;
 // The reference's `sorted(..., key=prob, reverse=True)` (a STABLE sort: equal abundances keep dict insertion order).  Alleles the
 // data cannot tell apart come out of the reference's EM bit-identical; on the GPU they agree to ~1e-14 only (same arithmetic,
 // another summation order), so abundances within a relative 1e-11 of the run's first count as tied and keep insertion order.
-void stable_desc(std::vector<int32_t> &allele, std::vector<double> &prob) {
+// When the values ARE the reference's (`exact`), the plain stable sort is the reference's order and no tolerance applies.
+void stable_desc(std::vector<int32_t> &allele, std::vector<double> &prob, bool exact) {
+    const double tol = exact ? 0.0 : TIE_REL_TOL;
     const size_t n = allele.size();
     std::vector<size_t> idx(n);
     std::iota(idx.begin(), idx.end(), (size_t)0);
@@ -60,7 +63,7 @@ void stable_desc(std::vector<int32_t> &allele, std::vector<double> &prob) {
     for (size_t i = 0; i < n;) {
         size_t j = i + 1;
         const double top = prob[idx[i]];
-        while (j < n && top - prob[idx[j]] <= TIE_REL_TOL * std::fabs(top)) ++j;
+        while (j < n && top - prob[idx[j]] <= tol * std::fabs(top)) ++j;
         const size_t at = order.size();
         order.insert(order.end(), idx.begin() + i, idx.begin() + j);
         std::sort(order.begin() + at, order.end());                 // the tied run, back in insertion order
@@ -86,7 +89,7 @@ void sorted_result(const std::vector<double> &prob, const std::vector<int32_t> &
     o.allele = present;
     o.prob.resize(present.size());
     for (size_t k = 0; k < present.size(); ++k) o.prob[k] = prob[present[k]];
-    stable_desc(o.allele, o.prob);
+    stable_desc(o.allele, o.prob, o.exact);
 }
 
 // ---- stream pairs ---------------------------------------------------------------------------------------------------
@@ -251,6 +254,7 @@ int run_em(hgx_classes *cl, const hgx_locus *loc, int32_t remove_low, const int3
     if (rc) return rc;
     hgx_classes_dims(cl, &C, nullptr);
     EmOut o;
+    o.exact = hgx_em_last_exact() != 0;
     o.n_classes = C; o.n_iter = n_iter; o.remove_low = remove_low ? 1 : 0; o.use_length = lengths ? 1 : 0;
     sorted_result(prob, first, loc->name_rank.data(), A, o);
     t->em.push_back(std::move(o));
@@ -403,13 +407,14 @@ int type_impl(hgx_typing *t, const hgx_locus *loc, const hgx_index *ix, const hg
             t->t_em += now_s() - t0;
             if (rc) return rc;
             EmOut e2;
+            e2.exact = hgx_em_last_exact() != 0;
             e2.n_classes = ncls2; e2.n_iter = it2; e2.remove_low = 1; e2.use_length = 1;
             sorted_result(prob2, first2, loc->name_rank.data(), A, e2);
             EmOut comb;                                                   // dict order: exon-level survivors, then EM #2's
             for (size_t i = 0; i < e1.allele.size(); ++i)
                 if (!in_exon[e1.allele[i]]) { comb.allele.push_back(e1.allele[i]); comb.prob.push_back(e1.prob[i]); }
             for (size_t i = 0; i < e2.allele.size(); ++i) { comb.allele.push_back(e2.allele[i]); comb.prob.push_back(e2.prob[i] * psum); }
-            stable_desc(comb.allele, comb.prob);
+            stable_desc(comb.allele, comb.prob, e1.exact && e2.exact);      // products p2 * psum in the reference's own order
             t->em.push_back(std::move(e2));
             t->gene_prob.allele = comb.allele;
             t->gene_prob.prob = comb.prob;

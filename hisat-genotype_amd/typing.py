@@ -25,37 +25,23 @@ from .locus import PackedLocus
 TIE_REL_TOL = 1e-11
 
 
-def _stable_desc(lst):
+def _stable_desc(lst, exact=False):
     """The reference's ``sorted(..., key=prob, reverse=True)`` (a STABLE sort: equal abundances keep dict insertion order).
     Alleles the data cannot tell apart come out of the reference's EM bit-identical; here they agree to ~1e-14 only (same
     arithmetic, different summation order on the GPU), so abundances within a relative 1e-11 of each other count as tied and
-    keep their insertion order, as an exact tie does in the reference."""
+    keep their insertion order, as an exact tie does in the reference.  `exact`: the values ARE the reference's (the EM ran
+    on one wavefront in the reference's order of operations, hgx_em_last_exact): plain stable sort, no tolerance."""
+    tol = 0.0 if exact else TIE_REL_TOL
     idx = sorted(range(len(lst)), key=lambda i: -lst[i][1])            # stable on equal values
     out, i = [], 0
     while i < len(idx):
         j = i + 1
         top = lst[idx[i]][1]
-        while j < len(idx) and top - lst[idx[j]][1] <= TIE_REL_TOL * abs(top):
+        while j < len(idx) and top - lst[idx[j]][1] <= tol * abs(top):
             j += 1
         out.extend(lst[k] for k in sorted(idx[i:j]))                       # the tied run, back in insertion order
         i = j
     return out
-
-
-def _sorted_result(prob, order):
-    """[[allele index, prob]] for present alleles in dict order, then the reference's stable
-    descending sort (common:1408-1409)."""
-    lst = [[a, float(prob[a])] for a in order]
-    return _stable_desc(lst)
-
-
-def _em_on_classes(classes, n_alleles, name_rank, remove_low, lengths, stream=None):
-    classes.set_allele_rank(name_rank)      # small problems are then summed in the reference's own order (bit-identical)
-    prob, first, n_iter = classes.em_ordered(n_alleles, remove_low, lengths, stream)
-    present = np.nonzero(prob >= 0.0)[0]
-    # dict insertion order of the survivors (common:1300-1305): first class containing each, then name order
-    order = present[np.lexsort((np.asarray(name_rank)[present], first[present]))].tolist()
-    return _sorted_result(prob, order), n_iter
 
 
 def single_abundance(Gene_cmpt, remove_low_abundance_allele=False, Gene_length={}):
@@ -88,11 +74,12 @@ def single_abundance(Gene_cmpt, remove_low_abundance_allele=False, Gene_length={
             rank[np.array(sorted(range(A), key=lambda i: names[i]), np.int64)] = np.arange(A, dtype=np.int32)
             cl.set_allele_rank(rank)
         prob, _ = cl.em(A, bool(remove_low_abundance_allele), lengths)
+        exact = bool(capi.lib().hgx_em_last_exact())
     finally:
         cl.close()
     # allele index == first-appearance order here, which is the dict order of the reference
     res = [[names[a], float(prob[a])] for a in range(A) if prob[a] >= 0.0]
-    return _stable_desc(res)
+    return _stable_desc(res, exact)
 
 
 class LocusResult:

@@ -217,6 +217,10 @@ int hgx_em_ordered(const hgx_classes *c, int32_t n_alleles, int32_t remove_low, 
  * count*prob/alleles_prob, no contraction) and return bit-identical abundances; without it the result is within 1e-9 as
  * everywhere else.  The array is copied; NULL clears it. */
 int hgx_classes_set_allele_rank(hgx_classes *c, const int32_t *rank_host, int32_t n);
+/* 1 if the calling thread's last hgx_em / hgx_em_ordered / hgx_em_masked call took that path: its abundances are then the
+ * reference's doubles, and ties between them are the reference's ties (callers sort them with a plain stable sort instead
+ * of the tolerance they need for results that agree to ~1e-14 only) */
+int hgx_em_last_exact(void);
 
 /* The exon -> gene hand-off in one call (typing_core.py:1752-1782): Gene_cmpt2 = every class of `c` filtered to the alleles of
  * mask_host (a_pad/64 words), empty ones dropped, equal ones merged with summed counts; then the EM on it (as
