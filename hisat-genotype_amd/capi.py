@@ -42,7 +42,11 @@ class LocusDesc(C.Structure):
 class ParseOpts(C.Structure):
     _fields_ = [("num_editdist", C.c_int32), ("error_correction", C.c_int32), ("allow_discordant", C.c_int32),
                 ("simulation", C.c_int32), ("base_locus", C.c_int32), ("keep_trace", C.c_int32),
-                ("codis_choose_pairs", C.c_int32), ("n_threads", C.c_int32)]
+                ("codis_choose_pairs", C.c_int32), ("n_threads", C.c_int32),
+                ("pileup_exchange", C.c_void_p), ("pileup_ctx", C.c_void_p)]
+
+
+PILEUP_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_int64)
 
 
 # every symbol include/hgx.h declares (checked by tests/test_capi_symbols.py)
@@ -59,7 +63,7 @@ SYMBOLS = [
     "hgx_batch_from_haplotypes", "hgx_parse_sam", "hgx_read_alignments", "hgx_free_text", "hgx_parse_alignment_file", "hgx_batch_trace_text", "hgx_batch_pileup",
     "hgx_dbatch_create", "hgx_dbatch_destroy", "hgx_dbatch_dims", "hgx_gate_create", "hgx_gate_destroy", "hgx_type_dbatch",
     "hgx_type_batch", "hgx_type_file", "hgx_typing_destroy", "hgx_typing_dims", "hgx_typing_counts", "hgx_typing_em",
-    "hgx_typing_gene_prob", "hgx_typing_classes", "hgx_write_bam", "hgx_em_last_exact",
+    "hgx_typing_gene_prob", "hgx_typing_classes", "hgx_write_bam", "hgx_em_last_exact", "hgx_index_device_block", "hgx_index_create_device", "hgx_type_classes",
 ]
 
 _lib = None

@@ -244,9 +244,10 @@ extern "C" int hgx_pool_trim(void) {
 
 extern "C" int32_t hgx_a_pad(int32_t n) { return (n + 511) / 512 * 512; }   // rows of a_pad/64 words: multiple of 8 words
 
-extern "C" int hgx_index_create(hgx_index **out, int32_t n_alleles, int32_t n_vars, const uint32_t *bits,
-                                const uint64_t *exon_mask, const uint64_t *gene_mask) {
-    ARGCHK(out && n_alleles > 0 && n_vars >= 0 && bits && exon_mask && gene_mask);
+// The three device tables of an index live in ONE allocation, [link bits | exon mask | gene mask], so that a rank that did not
+// build the locus can receive them with a single collective straight into place (hgx_index_device_block, 8e).
+static int index_alloc(hgx_index **out, int32_t n_alleles, int32_t n_vars) {
+    ARGCHK(out && n_alleles > 0 && n_vars >= 0);
     ARGCHK(n_vars <= 65535 * 32);
     hgx_index *ix = new hgx_index();
     ix->n_alleles = n_alleles;
@@ -254,19 +255,46 @@ extern "C" int hgx_index_create(hgx_index **out, int32_t n_alleles, int32_t n_va
     ix->n_vars = n_vars;
     ix->n_words = std::max(1, (n_vars + 31) / 32);
     ix->w64 = ix->a_pad / 64;
-    size_t nb = (size_t)ix->n_words * ix->a_pad * sizeof(uint32_t);
-    HIPCHK(hipMalloc((void **)&ix->d_bits, nb));
-    HIPCHK(hipMalloc((void **)&ix->d_exon_mask, ix->w64 * 8));
-    HIPCHK(hipMalloc((void **)&ix->d_gene_mask, ix->w64 * 8));
-    HIPCHK(hipMemcpy(ix->d_bits, bits, nb, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ix->d_exon_mask, exon_mask, ix->w64 * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(ix->d_gene_mask, gene_mask, ix->w64 * 8, hipMemcpyHostToDevice));
+    const size_t nb = (size_t)ix->n_words * ix->a_pad * sizeof(uint32_t);
+    void *block = nullptr;
+    if (hipMalloc(&block, nb + 2 * (size_t)ix->w64 * 8) != hipSuccess) {
+        delete ix;
+        hgx_set_error("device allocation of the locus index failed");
+        return HGX_ENOMEM;
+    }
+    ix->d_bits = (uint32_t *)block;
+    ix->d_exon_mask = (uint64_t *)((char *)block + nb);
+    ix->d_gene_mask = ix->d_exon_mask + ix->w64;
     *out = ix;
     return HGX_OK;
 }
+extern "C" int hgx_index_create(hgx_index **out, int32_t n_alleles, int32_t n_vars, const uint32_t *bits,
+                                const uint64_t *exon_mask, const uint64_t *gene_mask) {
+    ARGCHK(out && bits && exon_mask && gene_mask);
+    *out = nullptr;
+    hgx_index *ix = nullptr;
+    { int rc_ = index_alloc(&ix, n_alleles, n_vars); if (rc_) return rc_; }
+    const size_t nb = (size_t)ix->n_words * ix->a_pad * sizeof(uint32_t);
+    if (hipMemcpy(ix->d_bits, bits, nb, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ix->d_exon_mask, exon_mask, ix->w64 * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ix->d_gene_mask, gene_mask, ix->w64 * 8, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(ix->d_bits);
+        delete ix;
+        hgx_set_error("upload of the locus index failed");
+        return HGX_EHIP;
+    }
+    *out = ix;
+    return HGX_OK;
+}
+// an index of the given shape with UNINITIALISED tables: the receiving side of an index broadcast
+extern "C" int hgx_index_create_device(hgx_index **out, int32_t n_alleles, int32_t n_vars) {
+    ARGCHK(out);
+    *out = nullptr;
+    return index_alloc(out, n_alleles, n_vars);
+}
 extern "C" int hgx_index_destroy(hgx_index *ix) {
     if (!ix) return HGX_OK;
-    (void)hipFree(ix->d_bits); (void)hipFree(ix->d_exon_mask); (void)hipFree(ix->d_gene_mask);
+    (void)hipFree(ix->d_bits);                 // one block: the masks live behind the bit matrix
     delete ix;
     return HGX_OK;
 }
@@ -282,6 +310,12 @@ extern "C" int hgx_index_device_bits(const hgx_index *ix, void **p, size_t *byte
     ARGCHK(ix && p && bytes);
     *p = ix->d_bits;
     *bytes = (size_t)ix->n_words * ix->a_pad * sizeof(uint32_t);
+    return HGX_OK;
+}
+extern "C" int hgx_index_device_block(const hgx_index *ix, void **p, size_t *bytes) {
+    ARGCHK(ix && p && bytes);
+    *p = ix->d_bits;
+    *bytes = (size_t)ix->n_words * ix->a_pad * sizeof(uint32_t) + 2 * (size_t)ix->w64 * 8;
     return HGX_OK;
 }
 

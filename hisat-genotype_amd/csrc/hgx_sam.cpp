@@ -1587,6 +1587,10 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
                         for (size_t k = b; k < e; ++k) B->counts[k] += cnt[k];
             });
         }
+        if (opts->pileup_exchange) {             // this shard's counts -> the sum over all shards of the sample (8e)
+            if (opts->pileup_exchange(opts->pileup_ctx, B->counts.data(), (int64_t)B->counts.size()) != 0)
+                throw std::runtime_error("pileup exchange between the ranks of a sharded locus failed");
+        }
         for (int i = 0; i < n_ref; ++i) {
             const uint32_t *c = &B->counts[(size_t)i * 6];
             const uint64_t tot = (uint64_t)c[0] + c[1] + c[2] + c[3] + c[4] + c[5];

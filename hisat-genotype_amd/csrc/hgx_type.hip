@@ -207,6 +207,8 @@ struct GeneSide {                    // what the gene-level side hands back
     char err[512] = "";
 };
 
+int gene_rank(hgx_classes *gcl, int32_t A, int32_t a_pad, hipStream_t st, GeneSide &g);
+
 // Gene_counts (core:1187-1190) and their print order (core:1650-1651): dict insertion order of Gene_counts = (first pair
 // that counted the allele, Gene_names order), then the reference's stable descending sort on the count.
 int gene_side(const hgx_index *ix, const hgx_dbatch *db, const uint64_t *compat, uint64_t *gene_bits, uint64_t *gene_hash,
@@ -222,14 +224,19 @@ int gene_side(const hgx_index *ix, const hgx_dbatch *db, const uint64_t *compat,
     }
     rc = hgx_dedup_classes(&g.gcl, gene_bits, gene_hash, nullptr, db->n_pairs, a_pad, nullptr, st);
     if (rc) return rc;
+    return gene_rank(g.gcl, A, a_pad, st, g);
+}
+
+int gene_rank(hgx_classes *gcl, int32_t A, int32_t a_pad, hipStream_t st, GeneSide &g) {
+    int rc;
     std::vector<int64_t> cnt((size_t)a_pad);
     std::vector<int32_t> first((size_t)a_pad);
-    rc = hgx_allele_counts_on(g.gcl, cnt.data(), first.data(), st);
+    rc = hgx_allele_counts_on(gcl, cnt.data(), first.data(), st);
     if (rc) return rc;
     int32_t C = 0;
-    hgx_classes_dims(g.gcl, &C, nullptr);
+    hgx_classes_dims(gcl, &C, nullptr);
     std::vector<int64_t> fr((size_t)std::max(C, 1));                     // first pair of every class
-    rc = hgx_classes_to_host(g.gcl, nullptr, nullptr, fr.data());
+    rc = hgx_classes_to_host(gcl, nullptr, nullptr, fr.data());
     if (rc) return rc;
     g.cnt.assign(cnt.begin(), cnt.begin() + A);
     for (int32_t a = 0; a < A; ++a) if (cnt[a] > 0) g.counted.push_back(a);
@@ -258,6 +265,80 @@ int run_em(hgx_classes *cl, const hgx_locus *loc, int32_t remove_low, const int3
     o.n_classes = C; o.n_iter = n_iter; o.remove_low = remove_low ? 1 : 0; o.use_length = lengths ? 1 : 0;
     sorted_result(prob, first, loc->name_rank.data(), A, o);
     t->em.push_back(std::move(o));
+    return HGX_OK;
+}
+
+// EM #1 on the exon-level classes, exon_alleles, hand-off and EM #2 on the gene classes, combination (core:1732-1782).
+// `gene_ready` delivers the gene-level class set (and the counts in `t`) when the exon-level EM is done -- the gene side may
+// still be running beside it until then.
+template <class GeneReady>
+int finish_hla(hgx_typing *t, const hgx_locus *loc, hgx_classes *ecl, const hgx_type_opts *opts, hipStream_t em_stream, hipStream_t stream,
+               GeneReady gene_ready) {
+    const int32_t A = loc->A;
+    const int w64 = loc->a_pad / 64;
+    int rc;
+    rc = run_em(ecl, loc, opts->remove_low, nullptr, em_stream, t);                          // core:1732-1737
+    if (rc) return rc;
+    hgx_classes *gcl = nullptr;
+    rc = gene_ready(&gcl);
+    if (rc) return rc;
+    const EmOut &e1 = t->em[0];
+    // exon_alleles (core:1739-1749): the members of the exon groups of the leading representatives
+    std::vector<uint8_t> in_exon((size_t)A, 0);
+    std::vector<int32_t> group_size((size_t)A, 0);
+    for (int32_t a = 0; a < A; ++a) if (loc->rep_of[a] >= 0) ++group_size[loc->rep_of[a]];
+    double psum = 0.0;
+    bool any = false;
+    for (size_t i = 0; i < e1.allele.size(); ++i) {
+        const int32_t a = e1.allele[i];
+        const double p = e1.prob[i];
+        if (i >= 10 && p < 0.03) break;
+        if (group_size[a] <= 1) continue;
+        psum += p;
+        for (int32_t m = 0; m < A; ++m) if (loc->rep_of[m] == a) { in_exon[m] = 1; any = true; }
+    }
+    t->gene_prob = e1;
+    if (any) {                                                                               // core:1752-1782
+        std::vector<uint64_t> mask((size_t)w64, 0);
+        for (int32_t a = 0; a < A; ++a) if (in_exon[a]) mask[a >> 6] |= 1ull << (a & 63);
+        std::vector<double> prob2((size_t)A);
+        std::vector<int32_t> first2((size_t)A);
+        int32_t it2 = 0, ncls2 = 0;
+        const double t0 = now_s();
+        rc = hgx_classes_set_allele_rank(gcl, loc->name_rank.data(), A);
+        // Gene_cmpt2 (gene classes filtered to exon_alleles, merged) and EM #2 in one call
+        if (!rc) rc = hgx_em_masked(gcl, mask.data(), A, 1, loc->allele_len.data(), prob2.data(), first2.data(), &it2, &ncls2, stream);
+        t->t_em += now_s() - t0;
+        if (rc) return rc;
+        EmOut e2;
+        e2.exact = hgx_em_last_exact() != 0;
+        e2.n_classes = ncls2; e2.n_iter = it2; e2.remove_low = 1; e2.use_length = 1;
+        sorted_result(prob2, first2, loc->name_rank.data(), A, e2);
+        EmOut comb;                                                   // dict order: exon-level survivors, then EM #2's
+        for (size_t i = 0; i < e1.allele.size(); ++i)
+            if (!in_exon[e1.allele[i]]) { comb.allele.push_back(e1.allele[i]); comb.prob.push_back(e1.prob[i]); }
+        for (size_t i = 0; i < e2.allele.size(); ++i) { comb.allele.push_back(e2.allele[i]); comb.prob.push_back(e2.prob[i] * psum); }
+        stable_desc(comb.allele, comb.prob, e1.exact && e2.exact);      // products p2 * psum in the reference's own order
+        t->em.push_back(std::move(e2));
+        t->gene_prob.allele = comb.allele;
+        t->gene_prob.prob = comb.prob;
+    }
+    return HGX_OK;
+}
+
+// non-HLA bases (core:1784-1789): the EM on the gene classes, no pruning, no lengths; a single class is the reference's quirk Q3
+int finish_other(hgx_typing *t, const hgx_locus *loc, hgx_classes *gcl, hipStream_t stream) {
+    int32_t C = 0;
+    hgx_classes_dims(gcl, &C, nullptr);
+    if (C == 1) {
+        hgx_set_error("'dict_keys' object is not subscriptable (reference quirk Q3, typing_core.py:1787)");
+        return HGX_ETYPE;
+    }
+    if (C > 1) {
+        const int rc = run_em(gcl, loc, 0, nullptr, stream, t);
+        if (rc) return rc;
+        t->gene_prob = t->em[0];
+    }
     return HGX_OK;
 }
 
@@ -374,66 +455,14 @@ int type_impl(hgx_typing *t, const hgx_locus *loc, const hgx_index *ix, const hg
         }
         if (rc) return rc;
         gate.release();              // several samples in flight: the bandwidth-bound front of this one is through
-        rc = run_em(ecl, loc, opts->remove_low, nullptr, em_stream, t);                          // core:1732-1737
+        rc = finish_hla(t, loc, ecl, opts, em_stream, stream, [&](hgx_classes **g) { const int r = finish_gene(); *g = gs.gcl; return r; });
         if (rc) return rc;
-        rc = finish_gene();
-        if (rc) return rc;
-        const EmOut &e1 = t->em[0];
-        // exon_alleles (core:1739-1749): the members of the exon groups of the leading representatives
-        std::vector<uint8_t> in_exon((size_t)A, 0);
-        std::vector<int32_t> group_size((size_t)A, 0);
-        for (int32_t a = 0; a < A; ++a) if (loc->rep_of[a] >= 0) ++group_size[loc->rep_of[a]];
-        double psum = 0.0;
-        bool any = false;
-        for (size_t i = 0; i < e1.allele.size(); ++i) {
-            const int32_t a = e1.allele[i];
-            const double p = e1.prob[i];
-            if (i >= 10 && p < 0.03) break;
-            if (group_size[a] <= 1) continue;
-            psum += p;
-            for (int32_t m = 0; m < A; ++m) if (loc->rep_of[m] == a) { in_exon[m] = 1; any = true; }
-        }
-        t->gene_prob = e1;
-        if (any) {                                                                               // core:1752-1782
-            std::vector<uint64_t> mask((size_t)w64, 0);
-            for (int32_t a = 0; a < A; ++a) if (in_exon[a]) mask[a >> 6] |= 1ull << (a & 63);
-            std::vector<double> prob2((size_t)A);
-            std::vector<int32_t> first2((size_t)A);
-            int32_t it2 = 0, ncls2 = 0;
-            const double t0 = now_s();
-            rc = hgx_classes_set_allele_rank(gs.gcl, loc->name_rank.data(), A);
-            // Gene_cmpt2 (gene classes filtered to exon_alleles, merged) and EM #2 in one call
-            if (!rc) rc = hgx_em_masked(gs.gcl, mask.data(), A, 1, loc->allele_len.data(), prob2.data(), first2.data(), &it2, &ncls2, stream);
-            t->t_em += now_s() - t0;
-            if (rc) return rc;
-            EmOut e2;
-            e2.exact = hgx_em_last_exact() != 0;
-            e2.n_classes = ncls2; e2.n_iter = it2; e2.remove_low = 1; e2.use_length = 1;
-            sorted_result(prob2, first2, loc->name_rank.data(), A, e2);
-            EmOut comb;                                                   // dict order: exon-level survivors, then EM #2's
-            for (size_t i = 0; i < e1.allele.size(); ++i)
-                if (!in_exon[e1.allele[i]]) { comb.allele.push_back(e1.allele[i]); comb.prob.push_back(e1.prob[i]); }
-            for (size_t i = 0; i < e2.allele.size(); ++i) { comb.allele.push_back(e2.allele[i]); comb.prob.push_back(e2.prob[i] * psum); }
-            stable_desc(comb.allele, comb.prob, e1.exact && e2.exact);      // products p2 * psum in the reference's own order
-            t->em.push_back(std::move(e2));
-            t->gene_prob.allele = comb.allele;
-            t->gene_prob.prob = comb.prob;
-        }
     } else {
         rc = finish_gene();
         if (rc) return rc;
         gate.release();
-        int32_t C = 0;
-        hgx_classes_dims(gs.gcl, &C, nullptr);
-        if (C == 1) {
-            hgx_set_error("'dict_keys' object is not subscriptable (reference quirk Q3, typing_core.py:1787)");
-            return HGX_ETYPE;
-        }
-        if (C > 1) {
-            rc = run_em(gs.gcl, loc, 0, nullptr, stream, t);
-            if (rc) return rc;
-            t->gene_prob = t->em[0];
-        }
+        rc = finish_other(t, loc, gs.gcl, stream);
+        if (rc) return rc;
     }
     if (opts->keep_classes) { t->gene_cl = gs.gcl; gs.gcl = nullptr; t->exon_cl = ecl; ecl = nullptr; }
     return HGX_OK;
@@ -455,6 +484,31 @@ extern "C" int hgx_type_dbatch(hgx_typing **out, const hgx_locus *loc, const hgx
     int rc = acquire_streams(ss);
     if (!rc) rc = type_impl(t, loc, ix, db, opts, (hipStream_t)stream, ss, gate);
     release_streams(ss);
+    if (rc) { delete t; return rc; }
+    *out = t;
+    return HGX_OK;
+}
+
+extern "C" int hgx_type_classes(hgx_typing **out, const hgx_locus *loc, hgx_classes *exon_cl, hgx_classes *gene_cl, int32_t n_reads,
+                                int32_t n_pairs, const hgx_type_opts *opts, void *stream) {
+    ARGCHK(out && loc && gene_cl && opts);
+    *out = nullptr;
+    const bool hla = loc->base_kind == HGX_BASE_HLA;
+    ARGCHK(!hla || exon_cl);
+    ARGCHK(gene_cl->a_pad == loc->a_pad && (!exon_cl || exon_cl->a_pad == loc->a_pad));
+    ARGCHK((int32_t)loc->name_rank.size() == loc->A && (int32_t)loc->allele_len.size() == loc->A);
+    hgx_typing *t = new hgx_typing();
+    t->n_reads = n_reads; t->n_pairs = n_pairs; t->n_alleles = loc->A;
+    if (n_reads <= 0) { *out = t; return HGX_OK; }
+    hipStream_t st = (hipStream_t)stream;
+    GeneSide gs;
+    int rc = gene_rank(gene_cl, loc->A, loc->a_pad, st, gs);
+    if (!rc) {
+        t->counted = gs.counted;
+        t->cnt = gs.cnt;
+        if (hla) rc = finish_hla(t, loc, exon_cl, opts, st, st, [&](hgx_classes **g) { *g = gene_cl; return HGX_OK; });
+        else rc = finish_other(t, loc, gene_cl, st);
+    }
     if (rc) { delete t; return rc; }
     *out = t;
     return HGX_OK;

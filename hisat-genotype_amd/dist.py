@@ -10,6 +10,7 @@ import numpy as np
 from . import capi
 
 
+
 def shard(items, rank, world, weights=None):
     """Greedy longest-processing-time assignment of independent (sample, locus) tasks to ranks.
     Returns the items of ``rank`` (in input order).  Deterministic on every rank."""
@@ -24,12 +25,29 @@ def shard(items, rank, world, weights=None):
     return [items[i] for i in range(n) if owner[i] == rank]
 
 
-def broadcast_index(pl, src=0, group=None):
-    """Make ``pl``'s device index on every rank hold rank ``src``'s packed tables.
+class _DeviceBlock:
+    """A device allocation of libhgx presented through __cuda_array_interface__ so that torch can alias it (no copy)."""
 
-    Every rank passes a PackedLocus of the same locus (host tables are cheap to rebuild from the
-    reference's text files); the device-resident bit matrix is what gets broadcast, so only ``src``
-    needs to have packed it.  Returns the number of bytes broadcast."""
+    def __init__(self, ptr, n_int32):
+        self.__cuda_array_interface__ = {"shape": (int(n_int32),), "typestr": "<i4", "data": (int(ptr), False), "version": 2}
+
+
+def index_block_tensor(index_handle):
+    """torch int32 tensor aliasing the device tables [link bits | exon mask | gene mask] of an hgx_index."""
+    import torch
+    p, nb = C.c_void_p(), C.c_size_t()
+    capi.check(capi.lib().hgx_index_device_block(index_handle, C.byref(p), C.byref(nb)))
+    return torch.as_tensor(_DeviceBlock(p.value, nb.value // 4), device=torch.device("cuda", torch.cuda.current_device()))
+
+
+def broadcast_index(pl, src=0, group=None):
+    """Make ``pl``'s device index on every rank hold rank ``src``'s packed tables; returns the number of bytes broadcast.
+
+    On GPUs (backend ``nccl`` = RCCL) the collective runs on the index memory itself: rank ``src`` sends the device block of
+    its index, every other rank creates an index of the same shape with uninitialised tables (hgx_index_create_device) and
+    receives INTO its block (torch tensors aliasing the allocations, hgx_index_device_block) -- device to device over xGMI,
+    no host bounce, no second upload.  With ``gloo`` (CPU tests) the packed host tables travel instead and a device index is
+    only created where a GPU exists."""
     import torch
     import torch.distributed as dist
     backend = dist.get_backend(group)
@@ -38,28 +56,41 @@ def broadcast_index(pl, src=0, group=None):
     rank = dist.get_rank(group)
     dims = torch.zeros(4, dtype=torch.int64, device=dev)
     if rank == src:
-        t = pl.tables()
         dims[:] = torch.tensor([pl.n_alleles, pl.a_pad, pl.n_vars, pl.n_words], dtype=torch.int64)
     dist.broadcast(dims, src, group=group)
     n_alleles, a_pad, n_vars, n_words = (int(x) for x in dims.tolist())
     if (n_alleles, a_pad, n_vars, n_words) != (pl.n_alleles, pl.a_pad, pl.n_vars, pl.n_words):
         raise ValueError("rank %d holds a different locus than rank %d" % (rank, src))
+    if on_gpu:
+        if rank == src:
+            h = pl.index()                                  # built here from the packed host tables
+        else:
+            h = C.c_void_p()
+            capi.check(capi.lib().hgx_index_create_device(C.byref(h), C.c_int32(n_alleles), C.c_int32(n_vars)))
+            if pl._index is not None:
+                capi.lib().hgx_index_destroy(pl._index)
+            pl._index = h
+        block = index_block_tensor(h)
+        dist.broadcast(block, src, group=group)
+        torch.cuda.synchronize()
+        return int(block.numel()) * 4
     nb = n_words * a_pad
     w64 = a_pad // 64
     # one flat int32 buffer: link bits, exon mask, gene mask
-    buf = torch.zeros(nb + 4 * w64, dtype=torch.int32, device=dev)
+    buf = torch.zeros(nb + 4 * w64, dtype=torch.int32)
     if rank == src:
+        t = pl.tables()
         flat = np.concatenate([t["link_bits"].reshape(-1).view(np.int32), t["exon_mask"].view(np.int32),
                                t["gene_mask"].view(np.int32)])
         buf.copy_(torch.from_numpy(flat))
     dist.broadcast(buf, src, group=group)
-    host = buf.cpu().numpy()
+    host = buf.numpy()
     bits = np.ascontiguousarray(host[:nb].view(np.uint32))
     em = np.ascontiguousarray(host[nb:nb + 2 * w64].view(np.uint64))
     gm = np.ascontiguousarray(host[nb + 2 * w64:].view(np.uint64))
     rep = pl.tables()["rep_of"]          # host-only table, identical on every rank
     pl._tables = dict(link_bits=bits.reshape(n_words, a_pad), exon_mask=em, gene_mask=gm, rep_of=rep)
-    if on_gpu or capi_has_device():
+    if capi_has_device():
         h = C.c_void_p()
         capi.check(capi.lib().hgx_index_create(C.byref(h), C.c_int32(n_alleles), C.c_int32(n_vars), capi.ptr(bits),
                                                capi.ptr(em), capi.ptr(gm)))
@@ -74,3 +105,211 @@ def capi_has_device():
         return capi.device_count() > 0
     except Exception:
         return False
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# intra-locus read sharding (optional part): one sample's pairs of ONE locus split over several ranks
+# ----------------------------------------------------------------------------------------------------------------------
+def split_name_grouped(sam_text, k, simulation=False):
+    """Cut name-grouped SAM text into `k` consecutive shards at read boundaries (mates stay together), near-equal in bytes.
+    `simulation`: the read id is the QNAME up to its first '|' (typing_core.py:808)."""
+    data = sam_text.encode() if isinstance(sam_text, str) else bytes(sam_text)
+    n = len(data)
+
+    def read_id(ls):
+        name = data[ls:data.find(b"\t", ls)]
+        return name.split(b"|", 1)[0] if simulation else name
+
+    cuts = [0]
+    for i in range(1, k):
+        p = max(cuts[-1], n * i // k)
+        while p < n:
+            e = data.find(b"\n", p)
+            if e < 0:
+                p = n
+                break
+            nxt = e + 1
+            if nxt >= n:
+                p = n
+                break
+            # the line starting at nxt begins a new read iff its name differs from the name of the line containing p
+            ls = data.rfind(b"\n", 0, e) + 1
+            if read_id(ls) != read_id(nxt):
+                p = nxt
+                break
+            p = nxt
+        cuts.append(p)
+    cuts.append(n)
+    return [data[cuts[i]:cuts[i + 1]] for i in range(k)]
+
+
+class TorchComm:
+    """The three exchanges of a sharded locus over torch.distributed (nccl = RCCL on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.on_gpu = dist.get_backend(group) == "nccl"
+
+    def _dev(self):
+        import torch
+        return torch.device("cuda", torch.cuda.current_device()) if self.on_gpu else torch.device("cpu")
+
+    def allreduce_sum(self, arr):
+        """In-place element-wise sum of an integer numpy array over the ranks (counts < 2^31 travel as int64)."""
+        import torch
+        t = torch.from_numpy(arr.astype(np.int64)).to(self._dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        arr[...] = t.cpu().numpy().astype(arr.dtype)
+        return arr
+
+    def all_gather_tables(self, bits, counts):
+        """Every rank's class table (bits [C][w64] uint64, counts [C] int64) -> list in rank order."""
+        import torch
+        dev = self._dev()
+        n = torch.tensor([bits.shape[0]], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(self.world)]
+        self.dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(x.item()) for x in sizes]
+        w64, cap = bits.shape[1], max(max(sizes), 1)
+        pad = np.zeros((cap, w64 + 1), np.int64)                      # [row bits | count], padded to the largest table
+        pad[:bits.shape[0], :w64] = bits.view(np.int64)
+        pad[:bits.shape[0], w64] = counts
+        mine = torch.from_numpy(pad).to(dev)
+        parts = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(parts, mine, group=self.group)
+        out = []
+        for k, p in zip(sizes, parts):
+            a = p.cpu().numpy()
+            out.append((np.ascontiguousarray(a[:k, :w64]).view(np.uint64), np.ascontiguousarray(a[:k, w64])))
+        return out
+
+
+class LocalComm:
+    """`world` shards of one locus typed by `world` threads of ONE process (tests, and a single GPU standing in for several):
+    the same three exchanges through a barrier."""
+
+    class _Shared:
+        def __init__(self, world):
+            import threading
+            self.world, self.barrier, self.slots = world, threading.Barrier(world), [None] * world
+
+    def __init__(self, shared, rank):
+        self.sh, self.rank, self.world, self.on_gpu = shared, rank, shared.world, False
+
+    @staticmethod
+    def make(world):
+        sh = LocalComm._Shared(world)
+        return [LocalComm(sh, r) for r in range(world)]
+
+    def _exchange(self, value):
+        self.sh.slots[self.rank] = value
+        self.sh.barrier.wait()
+        got = list(self.sh.slots)
+        self.sh.barrier.wait()
+        return got
+
+    def allreduce_sum(self, arr):
+        parts = self._exchange(arr.copy())
+        arr[...] = np.sum(np.stack([p.astype(np.int64) for p in parts]), axis=0).astype(arr.dtype)
+        return arr
+
+    def all_gather_tables(self, bits, counts):
+        return self._exchange((bits.copy(), counts.copy()))
+
+
+def merge_class_tables(tables, a_pad, stream=None):
+    """Class tables of the shards (rank order = stream order of their pairs) -> ONE class set: rows concatenated, equal rows
+    merged with summed counts by hgx_dedup_classes, which keeps first-seen order -- the dict the reference would have built
+    over all pairs (typing_core.py:1229-1234)."""
+    from . import engine
+    bits = np.concatenate([b for b, _ in tables]) if tables else np.zeros((0, a_pad // 64), np.uint64)
+    cnt = np.concatenate([c for _, c in tables]) if tables else np.zeros(0, np.int64)
+    if len(cnt) == 0:
+        return engine.Classes.from_host(np.zeros((0, a_pad // 64), np.uint64), np.zeros(0, np.int64), a_pad)
+    rows = capi.DevArray.from_host(np.ascontiguousarray(bits, np.uint64), stream)
+    w = capi.DevArray.from_host(np.ascontiguousarray(cnt, np.int64), stream)
+    merged = engine.Classes.dedup(rows, len(cnt), a_pad, weights=w, stream=stream)
+    capi.sync(stream)
+    return merged
+
+
+def type_locus_sharded(pl, sam_shard, comm, num_editdist=2, error_correction=True, allow_discordant=False,
+                       remove_low_abundance_alleles=True, simulation=False, base_locus=0, stream=None):
+    """Type one sample at one locus with its name-grouped reads split over the ranks of `comm` (shard r = the r-th
+    consecutive stretch of the stream, cut at read boundaries: split_name_grouped).  Three exchanges, no other coupling:
+      1. pileup counts, summed (get_mpileup covers the whole alignment; error correction needs all of it),
+      2. the ranks' exon- and gene-level class tables, gathered and merged in rank order (= first-seen order),
+      3. read / pair counts, summed.
+    Every rank then runs the (small) EMs on the merged tables and returns the same LocusResult as the unsharded path."""
+    from . import engine
+    from .typing import LocusResult, TypeOpts, _result_from_handle
+    if pl.base_fname == "codis" and pl.gene == "D18S51":
+        raise NotImplementedError("choose_pairs of D18S51 needs the median pair distance of the whole sample")
+    batch = pl.parse_sam(sam_shard, num_editdist=num_editdist, error_correction=error_correction,
+                         allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus,
+                         pileup_exchange=comm.allreduce_sum)
+    hla = pl.base_fname == "hla"
+    db = engine.DeviceBatch(batch, stream)
+    bufs = engine.ScoreBuffers(pl, db, exon=hla)
+    tables = []
+    if batch.n_pairs > 0:
+        engine.piece_compat(pl, db, bufs, stream)
+        engine.pair_classes(pl, db, bufs, stream, exon=False)
+        levels = ([("exon", engine.Classes.of_level(pl, db, bufs, 0, stream))] if hla else []) + \
+            [("gene", engine.Classes.dedup(bufs.gene_bits, db.n_pairs, pl.a_pad, hashes=bufs.gene_hash, stream=stream))]
+    else:
+        levels = [(name, None) for name in (("exon", "gene") if hla else ("gene",))]
+    merged = {}
+    for name, cl in levels:
+        if cl is None:
+            bits, cnt = np.zeros((0, pl.w64), np.uint64), np.zeros(0, np.int64)
+        else:
+            bits, cnt, _ = cl.to_host()
+            cl.close()
+        merged[name] = merge_class_tables(comm.all_gather_tables(bits, cnt), pl.a_pad, stream)
+    totals = comm.allreduce_sum(np.array([batch.n_reads, batch.n_pairs], np.int64))
+    res = LocusResult()
+    res.num_reads, res.num_pairs = int(totals[0]), int(totals[1])
+    res.n_pieces, res.n_refs = batch.n_pieces, batch.n_refs
+    try:
+        if res.num_reads > 0:
+            o = TypeOpts(int(bool(remove_low_abundance_alleles)), 0, 0, 0, None, None, None, None, None)
+            h = C.c_void_p()
+            ecl = merged.get("exon")
+            rc = capi.lib().hgx_type_classes(C.byref(h), pl.h, ecl.h if ecl is not None else None, merged["gene"].h,
+                                             C.c_int32(res.num_reads), C.c_int32(res.num_pairs), C.byref(o), stream)
+            if rc == -7:
+                raise TypeError(capi.lib().hgx_last_error().decode(errors="replace"))
+            capi.check(rc)
+            try:
+                _result_from_handle(h, pl, res, False)
+            finally:
+                capi.lib().hgx_typing_destroy(h)
+    finally:
+        for cl in merged.values():
+            cl.close()
+    return res
+
+
+def assign_ranks_to_loci(weights, world):
+    """configs[2]-style jobs (a few big loci on more GPUs than loci): rank groups per locus, sizes proportional to the loci's
+    weights, every locus at least one rank; with fewer ranks than loci the loci are packed instead (shard()).  Returns
+    {locus index: [ranks]}; a locus with several ranks is typed with type_locus_sharded over that group."""
+    n = len(weights)
+    if world <= n:
+        owner = {}
+        for r in range(world):
+            for i in shard(list(range(n)), r, world, weights):
+                owner[i] = [r]
+        return owner
+    share = [1] * n
+    for _ in range(world - n):
+        i = max(range(n), key=lambda i: (weights[i] / share[i], -i))
+        share[i] += 1
+    out, nxt = {}, 0
+    for i in range(n):
+        out[i] = list(range(nxt, nxt + share[i]))
+        nxt += share[i]
+    return out

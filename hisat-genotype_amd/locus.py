@@ -257,12 +257,29 @@ class PackedLocus:
         return Batch(h)
 
     def parse_sam(self, sam_text, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False,
-                  base_locus=0, keep_trace=False, n_threads=0):
+                  base_locus=0, keep_trace=False, n_threads=0, pileup_exchange=None):
+        """`pileup_exchange(counts)`: intra-locus read sharding (dist.type_locus_sharded) -- called once with this shard's
+        pileup counts (numpy uint32 [L*6], a view of the front-end's table) and must turn them into the sum over all shards
+        in place (an all-reduce)."""
         data = sam_text if isinstance(sam_text, (bytes, bytearray)) else sam_text.encode()
         o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus,
                            int(keep_trace), int(self.base_fname == "codis" and self.gene == "D18S51"), int(n_threads))
+        cb, failure = None, []
+        if pileup_exchange is not None:
+            def _cb(_ctx, ptr, n):
+                try:
+                    pileup_exchange(np.ctypeslib.as_array(ptr, shape=(n,)))
+                    return 0
+                except BaseException as e:          # never let an exception cross the C frame
+                    failure.append(e)
+                    return 1
+            cb = capi.PILEUP_EXCHANGE(_cb)
+            o.pileup_exchange = C.cast(cb, C.c_void_p)
         h = C.c_void_p()
-        capi.check(capi.lib().hgx_parse_sam(C.byref(h), self.h, data, C.c_size_t(len(data)), C.byref(o)))
+        rc = capi.lib().hgx_parse_sam(C.byref(h), self.h, data, C.c_size_t(len(data)), C.byref(o))
+        if failure:
+            raise failure[0]
+        capi.check(rc)
         return Batch(h)
 
     def parse_alignment_file(self, path, regions=None, num_editdist=2, error_correction=True, allow_discordant=False,

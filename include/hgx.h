@@ -90,8 +90,15 @@ int hgx_index_create(hgx_index **out,
                      const uint64_t *gene_allele_mask);   /* host [a_pad/64]: scored alleles  */
 int hgx_index_destroy(hgx_index *ix);
 int hgx_index_dims(const hgx_index *ix, int32_t *n_alleles, int32_t *a_pad, int32_t *n_vars, int32_t *n_words);
-/* device address of the word-major bit matrix (for RCCL broadcast of a rank-0 index, 8e) */
+/* device address of the word-major bit matrix */
 int hgx_index_device_bits(const hgx_index *ix, void **dev_bits, size_t *bytes);
+/* Index broadcast (8e): the device tables of an index are ONE allocation, [link bits | exon mask | gene mask].  The rank that
+ * packed the locus passes this block to the collective as the send buffer; every other rank makes an index of the same
+ * shape with hgx_index_create_device (tables uninitialised) and passes ITS block as the receive buffer -- RCCL writes the
+ * tables in place over xGMI, nothing bounces through the host (dist.broadcast_index: torch.distributed.broadcast on a
+ * tensor that aliases the block). */
+int hgx_index_device_block(const hgx_index *ix, void **dev_block, size_t *bytes);
+int hgx_index_create_device(hgx_index **out, int32_t n_alleles, int32_t n_vars);
 
 /* ---- 8a-5 / 8a-6: read-pair x allele compatibility -> class bitsets --------------------
  * Replaces add_count (typing_core.py:626-677) + add_stat (core:1171-1236) for a batch of
@@ -299,6 +306,12 @@ typedef struct hgx_parse_opts {
     int32_t keep_trace;         /* record per-read intermediates for hgx_batch_trace_text   */
     int32_t codis_choose_pairs; /* base codis && gene == "D18S51": choose_pairs at the final flush (core:1547-1552) */
     int32_t n_threads;          /* host threads for the front-end; 0 = hardware threads, capped at 2x the cgroup CPU quota */
+    /* Intra-locus read sharding (8e): when ONE sample's reads of a locus are split over several ranks, error correction still
+     * needs the pileup of ALL reads (get_mpileup runs over the whole alignment, common:1059-1134).  If set, the callback is
+     * invoked once with this shard's counts[L][6] (A,C,G,T,N,D per backbone position) and must return with the element-wise
+     * SUM over all shards in place (an all-reduce; dist.py does it with torch.distributed); non-zero return = failure.      */
+    int (*pileup_exchange)(void *ctx, uint32_t *counts, int64_t n_cells);
+    void *pileup_ctx;
 } hgx_parse_opts;
 
 /* SAM text (name-grouped, i.e. the stream after `sort -k1,1 -s`, core:458-468) -> batch.
@@ -373,6 +386,12 @@ int hgx_type_batch(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, 
 /* alignment file -> typing result: hgx_parse_alignment_file + hgx_type_batch (the whole of typing()'s per-locus work) */
 int hgx_type_file(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, const char *path, const char *regions_or_null,
                   const hgx_parse_opts *parse_opts, const hgx_type_opts *opts, void *stream);
+/* The same from class sets that already exist (intra-locus read sharding, 8e: every rank scores its share of the pairs, the
+ * ranks' class tables are gathered, concatenated in rank order and merged with hgx_dedup_classes(weights = counts), which
+ * keeps first-seen order): Gene_counts + ranking from `gene_classes`, EM #1 on `exon_classes` (NULL for non-HLA bases: EM on
+ * the gene classes), hand-off and EM #2.  n_reads / n_pairs are reported as given. */
+int hgx_type_classes(hgx_typing **out, const hgx_locus *loc, hgx_classes *exon_classes_or_null, hgx_classes *gene_classes,
+                     int32_t n_reads, int32_t n_pairs, const hgx_type_opts *opts, void *stream);
 int hgx_typing_destroy(hgx_typing *t);
 int hgx_typing_dims(const hgx_typing *t, int32_t *n_reads, int32_t *n_pairs, int32_t *n_pieces, int64_t *n_refs,
                     int32_t *n_counted, int32_t *n_em, int32_t *n_gene_prob, double *em_seconds);

@@ -34,6 +34,29 @@ WORKER = textwrap.dedent('''
     assert flat == sorted(tasks), "tasks lost or duplicated"
     loads = [sum({"A": 5, "B": 7, "C": 3}[l] for _, l in part) for part in got]
     assert max(loads) - min(loads) <= 7
+    # intra-locus read sharding: the pileup of a sharded parse (all-reduced inside the front-end) is the whole sample's, and
+    # gathered class tables come back in rank order -- no GPU needed for either
+    sample = synth.pick_sample(loc, 3)
+    sam = synth.simulate_sam_fast(loc, sample, 1200, err_rate=0.004, seed=5)
+    comm = hdist.TorchComm()
+    shard_text = hdist.split_name_grouped(sam, world)[rank]
+    whole = pl.parse_sam(sam)
+    mine_b = pl.parse_sam(shard_text, pileup_exchange=comm.allreduce_sum)
+    L = len(loc.backbone)
+    nt_w, cnt_w = whole.pileup(L)
+    nt_s, cnt_s = mine_b.pileup(L)
+    assert np.array_equal(cnt_w, cnt_s) and np.array_equal(nt_w, nt_s), "sharded pileup differs from the whole sample's"
+    pairs = [None] * world
+    dist.all_gather_object(pairs, (mine_b.n_pairs, mine_b.n_reads))
+    assert sum(p for p, _ in pairs) == whole.n_pairs and sum(r for _, r in pairs) == whole.n_reads
+    bits = np.full((3 + rank, pl.w64), rank + 1, np.uint64)
+    cnt = np.arange(3 + rank, dtype=np.int64) + 10 * rank
+    got_t = comm.all_gather_tables(bits, cnt)
+    assert [b.shape[0] for b, _ in got_t] == [3, 4][:world] and all(int(b[0, 0]) == r + 1 for r, (b, _) in enumerate(got_t))
+    assert [c.tolist() for _, c in got_t] == [[0, 1, 2], [10, 11, 12, 13]][:world]
+    tot = comm.allreduce_sum(np.array([mine_b.n_reads, 7], np.int64))
+    assert tot.tolist() == [whole.n_reads, 7 * world]
+    assert hdist.assign_ranks_to_loci([7000, 8000, 7000], 4) == {0: [0], 1: [1, 2], 2: [3]}
     dist.barrier()
     dist.destroy_process_group()
     print("rank", rank, "ok")

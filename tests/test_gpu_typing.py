@@ -419,3 +419,86 @@ def test_exact_ratio_pruning_ties_follow_the_reference(seed0, k, scale):
         assert abs(p - q) <= 1e-9
     for (a, p), (_, q) in zip(res.em[1]["result"], exp["em"][1]["result"]):
         assert p == q                                         # bit-identical hand-off EM
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_locus_equals_unsharded(world):
+    """8e, intra-locus read sharding: one sample's pairs of one locus split over `world` ranks (here: threads of one process
+    on one GPU, the exchanges through dist.LocalComm) -- pileup all-reduce inside the front-end, class tables gathered and
+    merged in rank order, EMs on the merged tables -- give exactly the unsharded result on every rank: counts, their order,
+    every EM (classes, iterations, alleles, abundances) and the final abundances."""
+    import threading
+    from hisatgenotype_amd import capi, dist as hdist
+    for loc, kw in ((synth.make_hla_like_locus(n_alleles=900, n_vars=700, seed=12, sibling_frac=0.4), dict(err_rate=0.004)),
+                    (synth.make_str_like_locus(gene="TH01", unit="AATG", max_repeats=12, min_repeats=4),
+                     dict(read_len=100, frag_len=(230, 270), err_rate=0.002))):
+        pl = hl.PackedLocus.from_synth(loc)
+        pl.index()
+        sample = synth.pick_sample(loc, 3)
+        sam = synth.simulate_sam_fast(loc, sample, 9000, seed=4, **kw)
+        ref = hgx.type_locus(pl, sam)
+        shards = hdist.split_name_grouped(sam, world)
+        assert b"".join(shards) == sam.encode() and all(shards)
+        comms = hdist.LocalComm.make(world)
+        out, errs = [None] * world, []
+
+        def run(r):
+            try:
+                capi.set_device(capi.current_device())
+                out[r] = hdist.type_locus_sharded(pl, shards[r], comms[r], stream=capi.get_stream(2))
+            except BaseException as e:
+                errs.append(e)
+                comms[r].sh.barrier.abort()
+        ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        assert not errs, errs
+        for res in out:
+            assert (res.num_reads, res.num_pairs) == (ref.num_reads, ref.num_pairs)
+            assert res.counts_sorted == ref.counts_sorted
+            assert res.em == ref.em and res.gene_prob == ref.gene_prob
+
+
+def test_index_broadcast_writes_into_index_memory():
+    """8e: dist.broadcast_index over RCCL (backend nccl, here a world of one rank) sends / receives the device block of the
+    index itself -- a torch tensor aliasing [link bits | exon mask | gene mask] (hgx_index_device_block) -- and an index made
+    by hgx_index_create_device + a device-to-device copy of that block types a sample exactly like the original."""
+    import torch
+    import torch.distributed as dist
+    import ctypes as C
+    from hisatgenotype_amd import capi, dist as hdist
+    loc = synth.make_hla_like_locus(n_alleles=700, n_vars=600, seed=31)
+    pl = hl.PackedLocus.from_synth(loc)
+    sample = synth.pick_sample(loc, 2)
+    sam = synth.simulate_sam_fast(loc, sample, 3000, err_rate=0.002, seed=6)
+    ref = hgx.type_locus(pl, sam)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        nbytes = hdist.broadcast_index(pl, src=0)
+        assert nbytes == (pl.n_words * pl.a_pad + 4 * pl.w64) * 4
+        block = hdist.index_block_tensor(pl.index())
+        t = pl.tables()
+        host = block.cpu().numpy()
+        nb = pl.n_words * pl.a_pad
+        assert np.array_equal(host[:nb].view(np.uint32).reshape(pl.n_words, pl.a_pad), t["link_bits"])
+        assert np.array_equal(host[nb:nb + 2 * pl.w64].view(np.uint64), t["exon_mask"])
+        assert np.array_equal(host[nb + 2 * pl.w64:].view(np.uint64), t["gene_mask"])
+        # the receiving side: an index with uninitialised tables, filled device-to-device through its aliasing tensor
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_index_create_device(C.byref(h), C.c_int32(pl.n_alleles), C.c_int32(pl.n_vars)))
+        hdist.index_block_tensor(h).copy_(block)
+        torch.cuda.synchronize()
+        old, pl._index = pl._index, h
+        try:
+            got = hgx.type_locus(pl, sam)
+        finally:
+            pl._index = old
+            capi.lib().hgx_index_destroy(h)
+        assert got.gene_prob == ref.gene_prob and got.counts_sorted == ref.counts_sorted and got.em == ref.em
+    finally:
+        dist.destroy_process_group()
