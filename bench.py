@@ -42,6 +42,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the file -> result measurement (SAM text and BAM)")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (profiling runs)")
+    ap.add_argument("--workload", choices=["configs1", "class1", "panel64"], default="configs1",
+                    help="configs1 (default; BASELINE.json configs[1]: one HLA-A sample of 1 M reads per GPU), class1 (configs[2]: "
+                         "HLA-A + B + C, 1 M reads each, loci -- and the reads of a locus -- sharded over the GPUs), panel64 "
+                         "(configs[3]: six loci x 64 samples sharded over the GPUs)")
+    ap.add_argument("--panel-pairs", type=int, default=5000, help="panel64: read pairs per (sample, locus) task")
     ap.add_argument("--inflight", type=int, default=1,
                     help="samples typed concurrently per GPU (host threads with their own streams and class-row buffers; "
                          "the EM of one sample is a chain of short launches that leaves the GPU to the scoring of the next)")
@@ -217,6 +222,186 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
     return out
 
 
+CLASS1 = [("A", 7000, 3569, 2500, 101), ("B", 8000, 4081, 2800, 102), ("C", 7000, 4305, 2600, 103)]
+PANEL = [("A", 7000, 3569, 2500), ("B", 8000, 4081, 2800), ("C", 7000, 4305, 2600), ("DRB1", 3000, 3800, 1800),
+         ("DQA1", 500, 3300, 600), ("DQB1", 2000, 3600, 1400)]
+
+
+def _timed(dist, n_steps, body):
+    """barrier + sync, `n_steps` x body(), sync + barrier; returns the MAX over ranks of the elapsed seconds."""
+    capi.sync()
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize()
+        dist.barrier()
+    t0 = time.perf_counter()
+    last = None
+    for _ in range(n_steps):
+        last = body()
+    capi.sync()
+    if dist is not None:
+        import torch
+        torch.cuda.synchronize()
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed, last
+
+
+def run_class1(args, rank, local_rank, world, dist):
+    """BASELINE.json configs[2]: HLA class I (A + B + C), 1 M reads each.  Loci are sharded over the GPUs (rank groups in
+    proportion to the loci's read counts); a locus that owns several ranks has its PAIRS sharded over them (pileup
+    all-reduce at parse time, class tables gathered and merged per step, EMs replicated: dist.type_shard).  A step types all
+    three loci once; value = reads of the three loci / time."""
+    from hisatgenotype_amd import dist as hdist
+    t_setup = time.perf_counter()
+    loci = [synth.make_hla_like_locus(gene=g, n_alleles=a, length=ln, n_vars=v, seed=sd, var_id_base=100000 * i)
+            for i, (g, a, ln, v, sd) in enumerate(CLASS1)]
+    groups = hdist.assign_ranks_to_loci([args.pairs] * len(loci), world)
+    comms = {}
+    if dist is not None:                                        # every rank creates every sub-group, in the same order
+        for i in sorted(groups):
+            if len(groups[i]) > 1:
+                g = dist.new_group(groups[i])
+                if rank in groups[i]:
+                    comms[i] = hdist.TorchComm(g)
+    mine = [i for i in sorted(groups) if rank in groups[i]]
+    work = []
+    for i in mine:
+        loc = loci[i]
+        pl = hl.PackedLocus.from_synth(loc)
+        pl.index()
+        sample = synth.pick_sample(loc, 101 + i)
+        sam = synth.simulate_sam_fast(loc, sample, args.pairs, err_rate=args.err, seed=100 + i)
+        if i in comms:
+            shard_text = hdist.split_name_grouped(sam, len(groups[i]))[groups[i].index(rank)]
+            batch = pl.parse_sam(shard_text, pileup_exchange=comms[i].allreduce_sum)
+        else:
+            batch = pl.parse_sam(sam)
+        del sam
+        work.append((i, pl, batch, engine.DeviceBatch(batch), comms.get(i), sample))
+    t_setup = time.perf_counter() - t_setup
+
+    def body():
+        out = {}
+        for i, pl, batch, db, comm, sample in work:
+            if comm is not None:
+                out[i] = hdist.type_shard(pl, batch, db, comm)
+            else:
+                out[i] = step(pl, batch, db)
+        return out
+    for _ in range(args.warmup):
+        body()
+    elapsed, last = _timed(dist, args.steps, body)
+    reads = sum(r.num_reads for i, r in last.items() if groups[i][0] == rank)        # every locus counted once
+    calls = {loci[i].gene: ([a for a, _ in r.gene_prob[:2]], work[k][5]) for k, (i, r) in enumerate(sorted(last.items()))}
+    if dist is not None:
+        import torch
+        rr = torch.tensor([float(reads)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        reads = float(rr.item())
+        allc = [None] * world
+        dist.all_gather_object(allc, calls)
+        calls = {g: v for part in allc for g, v in part.items()}
+    if rank == 0:
+        print(json.dumps({
+            "metric": "typed reads/sec at HLA class I (A+B+C, ~7-8k alleles each, 2x150bp)", "value": round(reads * args.steps / elapsed, 1),
+            "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64 bitsets, f64 EM", "data": "synthetic",
+            "config": {"workload": "configs[2]: HLA class I A+B+C, %d simulated 2x150bp pairs each, piece batches resident in HBM" % args.pairs,
+                       "rank_groups": {loci[i].gene: groups[i] for i in sorted(groups)},
+                       "calls": {g: {"top2": t, "true": s, "correct": sorted(t) == sorted(s)} for g, (t, s) in calls.items()},
+                       "parallelism": "loci over rank groups; pairs of a locus over the ranks of its group (pileup all-reduce at parse, "
+                                      "class-table all-gather + merge per step over RCCL); no other data-path collective",
+                       "setup_s": round(t_setup, 1)},
+            "roofline": None, "cpu_baseline": None}))
+
+
+def run_panel64(args, rank, local_rank, world, dist):
+    """BASELINE.json configs[3]: the full HLA panel (A, B, C, DRB1, DQA1, DQB1) x 64 synthetic samples = 384 independent
+    (sample, locus) tasks, split over the GPUs by dist.shard (greedy by allele count; no data-path collective).  A step types
+    every task of the rank once from its resident piece batch; value = reads of all tasks / time (max over ranks)."""
+    from hisatgenotype_amd import dist as hdist
+    t_setup = time.perf_counter()
+    loci = [synth.make_hla_like_locus(gene=g, n_alleles=a, length=ln, n_vars=v, seed=500 + i, var_id_base=10000 * i)
+            for i, (g, a, ln, v) in enumerate(PANEL)]
+    tasks = [(s, k) for s in range(64) for k in range(len(loci))]
+    mine = hdist.shard(tasks, rank, world, [len(loci[k].allele_names) for _, k in tasks])
+    packed = {}
+    work = []
+    for s, k in mine:
+        if k not in packed:
+            packed[k] = hl.PackedLocus.from_synth(loci[k])
+            packed[k].index()
+        sample = synth.pick_sample(loci[k], 1000 * s + k)
+        sam = synth.simulate_sam_fast(loci[k], sample, args.panel_pairs, err_rate=args.err, seed=100 * s + k)
+        batch = packed[k].parse_sam(sam)
+        work.append((s, k, batch, engine.DeviceBatch(batch), sample))
+    t_setup = time.perf_counter() - t_setup
+    inflight = max(1, args.inflight)
+
+    def body():
+        import threading
+        out = [None] * len(work)
+        if inflight <= 1:
+            for n, (s, k, batch, db, _) in enumerate(work):
+                out[n] = step(packed[k], batch, db)
+            return out
+        nxt, lock, gate, errs = [0], threading.Lock(), engine.Gate(), []
+
+        def worker(slot):
+            try:
+                capi.set_device(local_rank)
+                capi.set_stream_slot(slot)
+                st = capi.get_stream(2)
+                while True:
+                    with lock:
+                        n = nxt[0]
+                        nxt[0] += 1
+                    if n >= len(work):
+                        return
+                    s, k, batch, db, _ = work[n]
+                    out[n] = step(packed[k], batch, db, None, st, gate)
+            except BaseException as e:
+                errs.append(e)
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(inflight)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
+        return out
+    for _ in range(args.warmup):
+        body()
+    elapsed, last = _timed(dist, args.steps, body)
+    reads = float(sum(r.num_reads for r in last))
+    correct = sum(1 for r, (s, k, _, _, sample) in zip(last, work) if sorted(a for a, _ in r.gene_prob[:2]) == sorted(sample))
+    n_tasks = len(work)
+    if dist is not None:
+        import torch
+        rr = torch.tensor([reads, float(correct), float(n_tasks)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        reads, correct, n_tasks = float(rr[0].item()), int(rr[1].item()), int(rr[2].item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "typed reads/sec over the HLA panel (6 loci x 64 samples, 2x150bp)", "value": round(reads * args.steps / elapsed, 1),
+            "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64 bitsets, f64 EM", "data": "synthetic",
+            "config": {"workload": "configs[3]: 6 loci (500-8000 alleles) x 64 samples = %d tasks of %d pairs, piece batches resident in HBM" % (
+                n_tasks, args.panel_pairs),
+                "tasks_with_both_true_alleles_on_top": correct, "tasks": n_tasks, "samples_in_flight_per_gpu": inflight,
+                "parallelism": "(sample, locus) tasks over GPUs by dist.shard (greedy by allele count), no data-path collective",
+                "setup_s": round(t_setup, 1)},
+            "roofline": None, "cpu_baseline": None}))
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -230,6 +415,12 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     capi.set_device(local_rank)
+    if args.workload != "configs1":
+        (run_class1 if args.workload == "class1" else run_panel64)(args, rank, local_rank, world, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- set-up (untimed): locus, index broadcast, reads, front-end, upload --------------------------------
     t_setup = time.perf_counter()

@@ -235,26 +235,15 @@ def merge_class_tables(tables, a_pad, stream=None):
     return merged
 
 
-def type_locus_sharded(pl, sam_shard, comm, num_editdist=2, error_correction=True, allow_discordant=False,
-                       remove_low_abundance_alleles=True, simulation=False, base_locus=0, stream=None):
-    """Type one sample at one locus with its name-grouped reads split over the ranks of `comm` (shard r = the r-th
-    consecutive stretch of the stream, cut at read boundaries: split_name_grouped).  Three exchanges, no other coupling:
-      1. pileup counts, summed (get_mpileup covers the whole alignment; error correction needs all of it),
-      2. the ranks' exon- and gene-level class tables, gathered and merged in rank order (= first-seen order),
-      3. read / pair counts, summed.
-    Every rank then runs the (small) EMs on the merged tables and returns the same LocusResult as the unsharded path."""
+def type_shard(pl, batch, db, comm, remove_low_abundance_alleles=True, stream=None):
+    """The device side of a sharded locus for a shard whose piece batch is resident (`batch` from a parse that already
+    exchanged the pileup, `db` its engine.DeviceBatch): this rank's class tables, the two exchanges, the EMs on the merged
+    tables.  bench.py --workload class1 times this per step."""
     from . import engine
     from .typing import LocusResult, TypeOpts, _result_from_handle
-    if pl.base_fname == "codis" and pl.gene == "D18S51":
-        raise NotImplementedError("choose_pairs of D18S51 needs the median pair distance of the whole sample")
-    batch = pl.parse_sam(sam_shard, num_editdist=num_editdist, error_correction=error_correction,
-                         allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus,
-                         pileup_exchange=comm.allreduce_sum)
     hla = pl.base_fname == "hla"
-    db = engine.DeviceBatch(batch, stream)
-    bufs = engine.ScoreBuffers(pl, db, exon=hla)
-    tables = []
     if batch.n_pairs > 0:
+        bufs = engine.ScoreBuffers(pl, db, exon=hla)
         engine.piece_compat(pl, db, bufs, stream)
         engine.pair_classes(pl, db, bufs, stream, exon=False)
         levels = ([("exon", engine.Classes.of_level(pl, db, bufs, 0, stream))] if hla else []) + \
@@ -291,6 +280,24 @@ def type_locus_sharded(pl, sam_shard, comm, num_editdist=2, error_correction=Tru
         for cl in merged.values():
             cl.close()
     return res
+
+
+def type_locus_sharded(pl, sam_shard, comm, num_editdist=2, error_correction=True, allow_discordant=False,
+                       remove_low_abundance_alleles=True, simulation=False, base_locus=0, stream=None):
+    """Type one sample at one locus with its name-grouped reads split over the ranks of `comm` (shard r = the r-th
+    consecutive stretch of the stream, cut at read boundaries: split_name_grouped).  Three exchanges, no other coupling:
+      1. pileup counts, summed (get_mpileup covers the whole alignment; error correction needs all of it),
+      2. the ranks' exon- and gene-level class tables, gathered and merged in rank order (= first-seen order),
+      3. read / pair counts, summed.
+    Every rank then runs the (small) EMs on the merged tables and returns the same LocusResult as the unsharded path."""
+    from . import engine
+    if pl.base_fname == "codis" and pl.gene == "D18S51":
+        raise NotImplementedError("choose_pairs of D18S51 needs the median pair distance of the whole sample")
+    batch = pl.parse_sam(sam_shard, num_editdist=num_editdist, error_correction=error_correction,
+                         allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus,
+                         pileup_exchange=comm.allreduce_sum)
+    db = engine.DeviceBatch(batch, stream)
+    return type_shard(pl, batch, db, comm, remove_low_abundance_alleles, stream)
 
 
 def assign_ranks_to_loci(weights, world):

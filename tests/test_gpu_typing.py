@@ -461,44 +461,58 @@ def test_sharded_locus_equals_unsharded(world):
             assert res.em == ref.em and res.gene_prob == ref.gene_prob
 
 
-def test_index_broadcast_writes_into_index_memory():
-    """8e: dist.broadcast_index over RCCL (backend nccl, here a world of one rank) sends / receives the device block of the
-    index itself -- a torch tensor aliasing [link bits | exon mask | gene mask] (hgx_index_device_block) -- and an index made
-    by hgx_index_create_device + a device-to-device copy of that block types a sample exactly like the original."""
-    import torch
-    import torch.distributed as dist
-    import ctypes as C
-    from hisatgenotype_amd import capi, dist as hdist
-    loc = synth.make_hla_like_locus(n_alleles=700, n_vars=600, seed=31)
-    pl = hl.PackedLocus.from_synth(loc)
-    sample = synth.pick_sample(loc, 2)
-    sam = synth.simulate_sam_fast(loc, sample, 3000, err_rate=0.002, seed=6)
-    ref = hgx.type_locus(pl, sam)
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29611")
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        nbytes = hdist.broadcast_index(pl, src=0)
-        assert nbytes == (pl.n_words * pl.a_pad + 4 * pl.w64) * 4
-        block = hdist.index_block_tensor(pl.index())
-        t = pl.tables()
-        host = block.cpu().numpy()
-        nb = pl.n_words * pl.a_pad
-        assert np.array_equal(host[:nb].view(np.uint32).reshape(pl.n_words, pl.a_pad), t["link_bits"])
-        assert np.array_equal(host[nb:nb + 2 * pl.w64].view(np.uint64), t["exon_mask"])
-        assert np.array_equal(host[nb + 2 * pl.w64:].view(np.uint64), t["gene_mask"])
-        # the receiving side: an index with uninitialised tables, filled device-to-device through its aliasing tensor
-        h = C.c_void_p()
-        capi.check(capi.lib().hgx_index_create_device(C.byref(h), C.c_int32(pl.n_alleles), C.c_int32(pl.n_vars)))
-        hdist.index_block_tensor(h).copy_(block)
-        torch.cuda.synchronize()
-        old, pl._index = pl._index, h
-        try:
-            got = hgx.type_locus(pl, sam)
-        finally:
-            pl._index = old
-            capi.lib().hgx_index_destroy(h)
-        assert got.gene_prob == ref.gene_prob and got.counts_sorted == ref.counts_sorted and got.em == ref.em
-    finally:
-        dist.destroy_process_group()
+_BROADCAST_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import ctypes as C
+import numpy as np
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)                       # torch's HIP runtime first: it cannot come up after libhgx's in one process
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29611")
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import hisatgenotype_amd as hgx
+from hisatgenotype_amd import capi, synth, locus as hl, dist as hdist
+capi.set_device(0)
+loc = synth.make_hla_like_locus(n_alleles=700, n_vars=600, seed=31)
+pl = hl.PackedLocus.from_synth(loc)
+sample = synth.pick_sample(loc, 2)
+sam = synth.simulate_sam_fast(loc, sample, 3000, err_rate=0.002, seed=6)
+ref = hgx.type_locus(pl, sam)
+nbytes = hdist.broadcast_index(pl, src=0)
+assert nbytes == (pl.n_words * pl.a_pad + 4 * pl.w64) * 4
+block = hdist.index_block_tensor(pl.index())
+t = pl.tables()
+host = block.cpu().numpy()
+nb = pl.n_words * pl.a_pad
+assert np.array_equal(host[:nb].view(np.uint32).reshape(pl.n_words, pl.a_pad), t["link_bits"])
+assert np.array_equal(host[nb:nb + 2 * pl.w64].view(np.uint64), t["exon_mask"])
+assert np.array_equal(host[nb + 2 * pl.w64:].view(np.uint64), t["gene_mask"])
+# the receiving side: an index with uninitialised tables, filled device-to-device through its aliasing tensor
+h = C.c_void_p()
+capi.check(capi.lib().hgx_index_create_device(C.byref(h), C.c_int32(pl.n_alleles), C.c_int32(pl.n_vars)))
+hdist.index_block_tensor(h).copy_(block)
+torch.cuda.synchronize()
+old, pl._index = pl._index, h
+got = hgx.type_locus(pl, sam)
+pl._index = old
+capi.lib().hgx_index_destroy(h)
+assert got.gene_prob == ref.gene_prob and got.counts_sorted == ref.counts_sorted and got.em == ref.em
+dist.destroy_process_group()
+print("broadcast ok", nbytes)
+"""
+
+
+def test_index_broadcast_writes_into_index_memory(tmp_path):
+    """8e: dist.broadcast_index over RCCL (backend nccl, here a world of one rank, in a fresh process: torch's HIP runtime
+    has to come up before libhgx's) sends / receives the device block of the index itself -- a torch tensor aliasing
+    [link bits | exon mask | gene mask] (hgx_index_device_block) -- and an index made by hgx_index_create_device + a
+    device-to-device copy of that block types a sample exactly like the original."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "bcast.py"
+    script.write_text(_BROADCAST_WORKER % root)
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "broadcast ok" in out.stdout
