@@ -24,10 +24,10 @@ class HgxKeyError(HgxError, KeyError):
 
 
 class Piece(C.Structure):
-    _fields_ = [("mask_off", C.c_uint32), ("lo_word", C.c_uint16), ("n_words", C.c_uint8), ("reserved", C.c_uint8)]
+    _fields_ = [("mask_off", C.c_uint32), ("lo_word", C.c_uint16), ("n_words", C.c_uint16)]
 
 
-PIECE_DTYPE = np.dtype([("mask_off", np.uint32), ("lo_word", np.uint16), ("n_words", np.uint8), ("reserved", np.uint8)])
+PIECE_DTYPE = np.dtype([("mask_off", np.uint32), ("lo_word", np.uint16), ("n_words", np.uint16)])
 
 
 class LocusDesc(C.Structure):

@@ -593,6 +593,62 @@ __device__ __forceinline__ void class_for_level(const uint64_t *__restrict__ com
     emit_class<KW, NP>(plane, w64, mask, out_row, out_hash, lane);
 }
 
+// More than 255 refs at a level (a pair whose mates have hundreds of alternative alignments: long STR alleles): 16-plane counters
+// (counts up to 65535) would not fit the register file for every 64-allele slab of the row at once, so the row is walked slab
+// by slab, twice: pass 0 finds the largest count over the level's alleles (top-down scan per slab, maximum over the slabs),
+// pass 1 recounts and keeps the alleles whose counter equals it bit for bit.  Same class, same hash as the register-resident form.
+__device__ __noinline__ void class_for_level_wide(const uint64_t *__restrict__ compat, int w64, const uint32_t *__restrict__ refs,
+                                                  int r0, int r1, uint32_t level, const uint64_t *__restrict__ mask,
+                                                  uint64_t *__restrict__ out_row, uint64_t *__restrict__ out_hash, int lane) {
+    constexpr int NP = 16;
+    const int kw = (w64 + 63) / 64;
+    uint32_t gmax = 0;
+    uint64_t h = 0;
+    bool nz = false;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int s = 0; s < kw; ++s) {
+            const int w = lane + 64 * s;
+            const bool live = w < w64;
+            uint64_t plane[NP];
+#pragma unroll
+            for (int k = 0; k < NP; ++k) plane[k] = 0;
+            for (int r = r0; r < r1; ++r) {
+                const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane(refs[r]);
+                if ((ref >> 31) != level) continue;
+                uint64_t carry = live ? compat[(size_t)(ref & 0x7fffffffu) * w64 + w] : 0ull;
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const uint64_t t = plane[k] & carry;
+                    plane[k] ^= carry;
+                    carry = t;
+                }
+            }
+            uint64_t cand = live ? mask[w] : 0ull;
+            if (pass == 0) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int k = NP - 1; k >= 0; --k) {
+                    const uint64_t t = cand & plane[k];
+                    if (__any(t != 0)) { cand = t; v |= 1u << k; }
+                }
+                gmax = max(gmax, v);                             // wave-uniform
+            } else {
+#pragma unroll
+                for (int k = 0; k < NP; ++k) cand &= ((gmax >> k) & 1u) ? plane[k] : ~plane[k];
+                if (live) {
+                    if (out_row) out_row[w] = cand;
+                    h += word_hash(cand, w);
+                    nz = nz || cand != 0;
+                }
+            }
+        }
+    if (out_hash) {
+        h = wave_sum_u64(h);
+        const bool any_nz = __any(nz);
+        if (lane == 0) *out_hash = finish_hash(h, any_nz);
+    }
+}
+
 // SEL: rows for a selection of pairs (one representative per distinct ref list, hgx_level_classes) instead of every pair
 template <int KW, bool SEL>
 __global__ __launch_bounds__(256) void k_pair_classes(const uint64_t *__restrict__ compat, int w64,
@@ -623,7 +679,15 @@ __global__ __launch_bounds__(256) void k_pair_classes(const uint64_t *__restrict
     } while (0)
     if (n_refs <= 3) HGX_LEVELS(2);
     else if (n_refs <= 15) HGX_LEVELS(4);
-    else HGX_LEVELS(8);
+    else if (n_refs <= 255) HGX_LEVELS(8);
+    else {
+        if (exon_bits || exon_hash)
+            class_for_level_wide(compat, w64, refs, r0, r1, 0u, exon_mask, exon_bits ? exon_bits + (size_t)out * w64 : nullptr,
+                                 exon_hash ? exon_hash + out : nullptr, lane);
+        if (gene_bits || gene_hash)
+            class_for_level_wide(compat, w64, refs, r0, r1, 1u, gene_mask, gene_bits ? gene_bits + (size_t)out * w64 : nullptr,
+                                 gene_hash ? gene_hash + out : nullptr, lane);
+    }
 #undef HGX_LEVELS
 }
 
@@ -697,9 +761,13 @@ __global__ __launch_bounds__(256) void k_pair_classes_x2(const uint64_t *__restr
     const int n_a = r1a - r0a, n_b = has_b ? r1b - r0b : 0;
     uint64_t *row_a = bits ? bits + (size_t)out_a * w64 : nullptr, *row_b = bits ? bits + (size_t)out_b * w64 : nullptr;
     uint64_t *hash_a = hash ? hash + out_a : nullptr, *hash_b = hash ? hash + out_b : nullptr;
-    if (max(n_a, n_b) > 15) {        // many refs (rare; up to 255 per level): 8-plane counters, one pair after the other
-        class_for_level<KW, 8>(compat, w64, refs, r0a, r1a, level, mask, row_a, hash_a, lane);
-        if (has_b) class_for_level<KW, 8>(compat, w64, refs, r0b, r1b, level, mask, row_b, hash_b, lane);
+    if (max(n_a, n_b) > 15) {        // many refs (rare): 8-plane counters up to 255 refs, the slab-wise 16-plane form beyond; one pair after the other
+        if (n_a > 255) class_for_level_wide(compat, w64, refs, r0a, r1a, level, mask, row_a, hash_a, lane);
+        else class_for_level<KW, 8>(compat, w64, refs, r0a, r1a, level, mask, row_a, hash_a, lane);
+        if (has_b) {
+            if (n_b > 255) class_for_level_wide(compat, w64, refs, r0b, r1b, level, mask, row_b, hash_b, lane);
+            else class_for_level<KW, 8>(compat, w64, refs, r0b, r1b, level, mask, row_b, hash_b, lane);
+        }
         return;
     }
     const uint32_t ref_a = lane < n_a ? refs[r0a + lane] : 0u, ref_b = lane < n_b ? refs[r0b + lane] : 0u;

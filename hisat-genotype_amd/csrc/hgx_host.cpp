@@ -182,7 +182,7 @@ extern "C" int hgx_index_from_locus(hgx_index **out, const hgx_locus *L) {
 // drops below `left` (core:651-670) -- every variant above the start has pos > right and every
 // variant below the stop has right end < left, so the scan bounds never change the set.
 // ---------------------------------------------------------------------------------------------
-uint32_t hgx_intern_masks(hgx_batch &b, uint16_t lo, uint8_t nw, const uint32_t *m) {
+uint32_t hgx_intern_masks(hgx_batch &b, uint16_t lo, uint16_t nw, const uint32_t *m) {
     PieceTable &T = b.table;
     if (T.slot.empty()) T.slot.assign(1024, -1);
     if ((T.used + 1) * 2 > T.slot.size()) {                 // grow + rehash from the piece list
@@ -210,7 +210,6 @@ uint32_t hgx_intern_masks(hgx_batch &b, uint16_t lo, uint8_t nw, const uint32_t 
     pc.mask_off = (uint32_t)b.masks.size();
     pc.lo_word = lo;
     pc.n_words = nw;
-    pc.reserved = 0;
     b.pieces.push_back(pc);
     b.masks.insert(b.masks.end(), m, m + 2 * (size_t)nw);
     T.slot[h] = (int32_t)id;
@@ -243,11 +242,14 @@ int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &L, int32_t left, int32_t
     int lo_w = 0, hi_w = 0;
     if (hi_v >= 0) { lo_w = lo_v >> 5; hi_w = hi_v >> 5; }
     const int nw = hi_w - lo_w + 1;
-    if (nw > 255) {
-        hgx_set_error("piece spans %d variant words (> 255)", nw);
+    if (nw > 65535) {
+        hgx_set_error("piece spans %d variant words (> 65535)", nw);
         return -1;
     }
-    uint32_t buf[512];
+    uint32_t small[128];
+    std::vector<uint32_t> big;
+    uint32_t *buf = small;
+    if (nw > 64) { big.resize(2 * (size_t)nw); buf = big.data(); }
     memset(buf, 0, 8 * (size_t)nw);
     if (i1 > i0) {                                               // linked variants of the index range, word at a time
         for (int w = i0 >> 5; w <= (i1 - 1) >> 5; ++w) {
@@ -265,7 +267,7 @@ int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &L, int32_t left, int32_t
             buf[2 * ((v >> 5) - lo_w) + 1] |= 1u << (v & 31);
         }
     }
-    return hgx_intern_masks(b, (uint16_t)lo_w, (uint8_t)nw, buf);
+    return hgx_intern_masks(b, (uint16_t)lo_w, (uint16_t)nw, buf);
 }
 
 // Order the distinct-piece table by first covered word, then width, then CONTENT (hash of the mask words, the words themselves
@@ -332,8 +334,8 @@ extern "C" int hgx_batch_from_haplotypes(hgx_batch **out, const hgx_locus *L, in
             const int64_t id = hgx_intern_piece(*b, *L, left[q], right[q], ids + id_off[q], id_off[q + 1] - id_off[q]);
             if (id < 0) { delete b; return HGX_EINVAL; }
             const uint32_t lv = level[q] ? 1u : 0u;
-            if (++n_lvl[lv] > 255) {
-                hgx_set_error("more than 255 pieces for one pair and level");
+            if (++n_lvl[lv] > 65535) {
+                hgx_set_error("more than 65535 pieces for one pair and level");
                 delete b;
                 return HGX_EINVAL;
             }

@@ -79,7 +79,7 @@ inline int32_t lower_bound_pos(const std::vector<int32_t> &pos, int32_t key) {
 struct PieceTable {
     std::vector<int32_t> slot;     // piece id or -1
     size_t used = 0;
-    static uint64_t hash(uint16_t lo, uint8_t nw, const uint32_t *m) {
+    static uint64_t hash(uint16_t lo, uint16_t nw, const uint32_t *m) {
         uint64_t h = 1469598103934665603ull ^ lo ^ ((uint64_t)nw << 16);
         for (int i = 0; i < 2 * (int)nw; ++i) { h ^= m[i]; h *= 1099511628211ull; h ^= h >> 29; }
         return h;
@@ -156,7 +156,7 @@ struct hgx_align_lines {
 int hgx_read_alignment_lines(const char *path, const char *regions, int n_threads, hgx_align_lines &out);
 
 // find-or-insert a piece given its word range and (MP,P) mask words
-uint32_t hgx_intern_masks(hgx_batch &b, uint16_t lo, uint8_t nw, const uint32_t *m);
+uint32_t hgx_intern_masks(hgx_batch &b, uint16_t lo, uint16_t nw, const uint32_t *m);
 void hgx_finalize_batch(hgx_batch &b, int n_threads = 1);
 void hgx_canonical_piece_order(hgx_batch &b, int n_threads, std::vector<uint32_t> &new_id);
 // alternatives tables (defined in hgx_sam.cpp)

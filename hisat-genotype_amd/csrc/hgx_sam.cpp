@@ -1274,7 +1274,7 @@ void emit_chunk(const hgx_parse_opts &o, const Fields *recs, const uint8_t *ok, 
         }
         size_t n_exon = 0;
         for (const HtRec *h : uni) n_exon += h->n_exon;
-        if (n_exon > 255 || uni.size() > 255) throw std::runtime_error("more than 255 pieces for one pair and level");
+        if (n_exon > 65535 || uni.size() > 65535) throw std::runtime_error("more than 65535 pieces for one pair and level");
         for (const HtRec *h : uni) {
             const uint32_t *r = workers[h->worker].refs.data() + h->exon_off;
             for (uint32_t k = 0; k < h->n_exon; ++k) out.pair_ref.push_back(final_id[h->worker][r[k]]);

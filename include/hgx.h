@@ -113,14 +113,14 @@ int hgx_index_create_device(hgx_index **out, int32_t n_alleles, int32_t n_vars);
  * (one ref per add_count call, duplicates allowed: they count twice, as in the reference).
  * Per pair and level: count[a] = #refs whose piece is compatible with a; class = {a in the
  * level's allele mask : count[a] == max count} (max including 0: quirk Q4, core:1177-1190);
- * at most 255 refs per pair and level.
+ * at most 65535 refs per pair and level (counters as wide as the pair needs: 2 / 4 / 8 bit planes in registers, 16 for the rare
+ * pair with more than 255 refs -- long STR alleles with many alternative alignments).
  * Outputs (device): class bitsets, one row of a_pad/64 uint64 per pair and level, and a 64-bit
  * content hash per row (all-zero row <=> hash 0xFFFFFFFFFFFFFFFF) for hgx_dedup_classes.      */
 typedef struct hgx_piece {
     uint32_t mask_off;   /* index into masks[] (in uint32 units)          */
     uint16_t lo_word;    /* first 32-variant word covered                 */
-    uint8_t  n_words;    /* number of words covered (>= 1)                */
-    uint8_t  reserved;
+    uint16_t n_words;    /* number of words covered (>= 1)                */
 } hgx_piece;
 
 /* stage 1: compat_dev[piece][a_pad/64] = bitset of alleles compatible with each distinct piece.  Any piece order

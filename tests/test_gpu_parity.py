@@ -683,3 +683,58 @@ def test_level_classes_falls_back_to_per_pair_rows_on_a_list_key_collision(orc, 
     fx, loc, t, pl, batch, _ = _setup(orc, "hla_errors_filters")
     monkeypatch.setenv("HGX_TEST_GROUP_COLLISION", "1")
     _level_equals_per_pair(pl, batch, collided=True)
+
+
+def test_pairs_with_hundreds_of_refs_and_very_wide_pieces(orc):
+    """No 255 ceilings (the reference has none, typing_core.py:1250-1270): pairs with 16 / 255 / 256 / 700 /
+    1500 add_count calls per level (the slab-wise 16-plane counters beyond 255, on their own and beside a short pair in the
+    two-pairs-per-wavefront kernel, in the two-level kernel and in the single-level one) and pieces spanning more than 255
+    variant words, bit-exact against the C oracle -- class rows of both levels and, through them, the row hashes' dedup."""
+    from hisatgenotype_amd import synth
+    loc = synth.make_hla_like_locus(n_alleles=2500, n_vars=9000, length=30000, seed=78, unlinked_vars=6)
+    t = tables.oracle_tables(loc)
+    pl = hl.PackedLocus.from_synth(loc)
+    rng = np.random.RandomState(5)
+    names = [n for n in loc.allele_names[1:] if n in loc.allele_vars]
+    pair_off, level, left, right, id_off, ids = [0], [], [], [], [0], []
+
+    def piece(lv, wide=False):
+        l = rng.randint(0, len(loc.backbone) - 200)
+        r = l + rng.randint(1, 150)
+        if wide:
+            l, r = rng.randint(0, 300), len(loc.backbone) - 1 - rng.randint(0, 300)      # nearly the whole locus: > 255 words
+        a = names[rng.randint(len(names))]
+        vs = [v for v in loc.allele_vars[a] if l <= loc.var_pos[v] <= r]
+        if rng.rand() < 0.3 and vs:
+            vs = vs[:-1]
+        level.append(lv); left.append(l); right.append(r)
+        ids.extend(vs)
+        id_off.append(len(ids))
+
+    for n_refs in (2, 700, 1, 16, 255, 256, 3, 1500, 300, 2):
+        for k in range(n_refs):
+            for lv in (0, 1):
+                piece(lv, wide=(k % 97 == 5))
+        pair_off.append(len(level))
+    arrs = (np.array(pair_off, np.int32), np.array(level, np.uint8), np.array(left, np.int32), np.array(right, np.int32),
+            np.array(id_off, np.int32), np.array(ids, np.int32))
+    L = orc.make_locus(t)
+    eb, gb, gc, fp = orc.score_pairs(L, t["exon_keys"], t["gene_keys"], *arrs)
+    batch = pl.batch_from_haplotypes(*arrs)
+    assert int(batch.pieces["n_words"].max()) > 255
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    w = (t["n_alleles"] + 63) // 64
+    engine.score_pairs(pl, db, bufs)                                   # both levels in one launch (one pair per wavefront)
+    assert np.array_equal(bufs.gene_bits.to_host()[:, :w], gb) and np.array_equal(bufs.exon_bits.to_host()[:, :w], eb)
+    h2 = bufs.gene_hash.to_host()
+    bufs.gene_bits.zero()
+    engine.pair_classes(pl, db, bufs, exon=False)                      # one level: two pairs per wavefront
+    assert np.array_equal(bufs.gene_bits.to_host()[:, :w], gb) and np.array_equal(bufs.gene_hash.to_host(), h2)
+    bufs.exon_bits.zero()
+    engine.pair_classes(pl, db, bufs, gene=False)
+    assert np.array_equal(bufs.exon_bits.to_host()[:, :w], eb)
+    cl = engine.Classes.of_level(pl, db, bufs, 1)                      # grouped by ref list
+    ub, uc, fr = orc.dedup(gb)
+    hb, hc, _ = cl.to_host()
+    assert np.array_equal(hb[:, :w], ub) and np.array_equal(hc, uc)
