@@ -66,7 +66,7 @@ def _decode_tags(buf, p, end):
             fmt = {"c": "b", "C": "B", "s": "h", "S": "H", "i": "i", "I": "I", "f": "f"}[st]
             vals = struct.unpack_from("<%d%s" % (cnt, fmt), buf, p + 5)
             p += 5 + cnt * struct.calcsize(fmt)
-            out.append("%s:B:%s,%s" % (tag, st, ",".join(("%g" % v) if st == "f" else str(v) for v in vals)))
+            out.append("%s:B:%s%s" % (tag, st, "".join("," + (("%g" % v) if st == "f" else str(v)) for v in vals)))
         else:
             raise ValueError("unknown BAM tag type %r" % t)
     return out
@@ -155,6 +155,18 @@ def read_bam(path, regions=None):
         qual = "*" if (l_seq == 0 or qb[0] == 0xff) else "".join(chr(b + 33) for b in qb)
         q += l_seq
         tags = _decode_tags(raw, q, rec_end)
+        # long CIGARs (spec 4.2.2): placeholder <l_seq>S<span>N in the CIGAR field, the operations in a CG:B:I tag -- read the
+        # way htslib reads them (the tag becomes the CIGAR and leaves the tag list)
+        if n_cig and ref_id >= 0 and pos >= 0 and cig[0] == "%dS" % l_seq:
+            for k, tg in enumerate(tags):
+                if tg.startswith("CG:B:") and tg[5] in "Ii":
+                    vals = [int(x) for x in tg[7:].split(",")] if len(tg) > 7 else []
+                    if len(vals) >= n_cig:
+                        cig = ["%d%s" % (v >> 4, _CIGAR_OPS[v & 15]) for v in vals]
+                        del tags[k]
+                    break
+                if tg.startswith("CG:"):
+                    break
         p = rec_end
         rname = refs[ref_id] if ref_id >= 0 else "*"
         hits = None

@@ -120,6 +120,52 @@ void put_int(PString &s, long long v) {
     s.append(buf, (size_t)n);
 }
 
+// The real CIGAR of a record whose operation count does not fit 16 bits (SAM/BAM spec 4.2.2): the CIGAR field holds the
+// placeholder <l_seq>S<ref span>N and the operations live in a CG:B:I tag.  As htslib does on reading (bam_tag2cigar: mapped
+// record, first op = S over the whole read, CG of type B with 32-bit items, at least as many items as placeholder ops), the tag
+// is taken for the CIGAR and dropped from the tag list.  Returns the tag's [begin, end) within the record and its items, or false.
+bool find_real_cigar(const unsigned char *r, size_t len, size_t tags_at, int32_t ref_id, int32_t pos, uint32_t n_cig,
+                     const unsigned char *cig, int32_t l_seq, size_t &tag_b, size_t &tag_e, const unsigned char *&items, uint32_t &n_items) {
+    if (n_cig == 0 || ref_id < 0 || pos < 0) return false;
+    const uint32_t c0 = rd32(cig);
+    if ((c0 & 15) != 4 || (int64_t)(c0 >> 4) != (int64_t)l_seq) return false;
+    size_t q = tags_at;
+    while (q + 3 <= len) {
+        const size_t b = q;
+        const char t0 = (char)r[q], t1 = (char)r[q + 1], t = (char)r[q + 2];
+        q += 3;
+        size_t sz = 0;
+        switch (t) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': {
+                const void *e = memchr(r + q, 0, len - q);
+                if (!e) return false;
+                sz = (size_t)((const unsigned char *)e - (r + q)) + 1;
+            } break;
+            case 'B': {
+                if (q + 5 > len) return false;
+                const char st = (char)r[q];
+                const uint32_t cnt = rd32(r + q + 1);
+                const size_t w = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0;
+                if (!w) return false;
+                sz = 5 + w * (size_t)cnt;
+                if (t0 == 'C' && t1 == 'G') {
+                    if ((st != 'I' && st != 'i') || cnt < n_cig || cnt >= (1u << 29) || q + sz > len) return false;
+                    tag_b = b; tag_e = q + sz; items = r + q + 5; n_items = cnt;
+                    return true;
+                }
+            } break;
+            default: return false;
+        }
+        if (t0 == 'C' && t1 == 'G') return false;              // a CG tag of another type is an ordinary tag
+        if (q + sz > len) return false;
+        q += sz;
+    }
+    return false;
+}
+
 // one BAM record (after its block_size word) -> SAM text line (no newline)
 bool bam_record_text(const unsigned char *r, size_t len, const std::vector<std::string> &refs, PString &s) {
     static const char CIG[] = "MIDNSHP=X", SEQ[] = "=ACMGRSVTWYHKDBN";
@@ -138,11 +184,24 @@ bool bam_record_text(const unsigned char *r, size_t len, const std::vector<std::
     s.push_back('\t'); put_int(s, (long long)pos + 1);
     s.push_back('\t'); put_int(s, mapq);
     s.push_back('\t');
-    if (n_cig == 0) s.push_back('*');
-    for (unsigned k = 0; k < n_cig; ++k) {
-        const uint32_t v = rd32(r + q + 4 * k);
-        put_int(s, v >> 4);
-        s.push_back((v & 15) < 9 ? CIG[v & 15] : '?');
+    size_t cg_b = 0, cg_e = 0;
+    const unsigned char *cg_items = nullptr;
+    uint32_t cg_n = 0;
+    const size_t tags_at = q + 4ull * n_cig + (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
+    const bool long_cigar = find_real_cigar(r, len, tags_at, ref_id, pos, n_cig, r + q, l_seq, cg_b, cg_e, cg_items, cg_n);
+    if (long_cigar) {
+        for (uint32_t k = 0; k < cg_n; ++k) {
+            const uint32_t v = rd32(cg_items + 4 * k);
+            put_int(s, v >> 4);
+            s.push_back((v & 15) < 9 ? CIG[v & 15] : '?');
+        }
+    } else {
+        if (n_cig == 0) s.push_back('*');
+        for (unsigned k = 0; k < n_cig; ++k) {
+            const uint32_t v = rd32(r + q + 4 * k);
+            put_int(s, v >> 4);
+            s.push_back((v & 15) < 9 ? CIG[v & 15] : '?');
+        }
     }
     q += 4ull * n_cig;
     s.push_back('\t');
@@ -176,6 +235,7 @@ bool bam_record_text(const unsigned char *r, size_t len, const std::vector<std::
     }
     q += (size_t)l_seq;
     while (q + 3 <= len) {          // tags
+        if (long_cigar && q == cg_b) { q = cg_e; continue; }      // the CG tag became the CIGAR
         s.push_back('\t');
         s.append((const char *)r + q, 2);
         const char t = (char)r[q + 2];

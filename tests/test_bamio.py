@@ -318,3 +318,45 @@ def test_native_bam_writer_round_trip(tmp_path):
     bamio.write_bam(a, fx["sam"], [(loc.ref_allele, len(loc.backbone))])
     bamio.write_bam_native(b, fx["sam"], [(loc.ref_allele, len(loc.backbone))], n_threads=4)
     assert bamio.read_bam(a) == bamio.read_bam(b)
+
+
+def test_readers_on_a_hand_assembled_bam(tmp_path):
+    """The BAM readers against bytes this package did not write (tests/golden/bam_handmade.json: assembled with struct.pack
+    straight from the SAM/BAM specification): several BGZF members whose boundaries fall inside records, a stored member, an
+    empty member mid-file and the EOF marker, three references, every tag type and B-array item type, unmapped and unplaced
+    reads, '*' SEQ / QUAL, missing qualities, a CG-tag long CIGAR.  The decoded text must equal, LITERALLY, the lines
+    `samtools view` prints for such records -- through the Python reader and the native one, unsorted, name-grouped, with
+    regions, and a truncated copy must be refused."""
+    import json
+    import pytest
+    from hisatgenotype_amd import capi
+    from hisatgenotype_amd.typing import read_alignment_text
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bam_handmade.json")))
+    path = str(tmp_path / "hand.bam")
+    data = bytes.fromhex(fx["hex"])
+    open(path, "wb").write(data)
+    exp = fx["expected"]
+    assert bamio.read_bam(path) == exp                                           # file order, literal text
+    by_name = sorted(range(len(exp)), key=lambda i: exp[i].split("\t")[0].encode())   # stable: sort -k1,1 -s
+    want = "".join(exp[i] + "\n" for i in by_name).encode()
+    for nt in (1, 4):
+        assert read_alignment_text(path, n_threads=nt, native=True) == want
+    assert read_alignment_text(path, native=False) == want
+    names = lambda regions: [l.split(b"\t")[0].decode() for l in read_alignment_text(path, regions).split(b"\n") if l]
+    assert names(["HLA:A*BACKBONE"]) == ["longcigar", "other", "pair1", "pair1"]
+    assert names(["HLA:A*BACKBONE:506-506"]) == ["longcigar"]                    # inside the long CIGAR's real span (501..523)
+    assert names(["HLA:A*BACKBONE:524-600"]) == []
+    assert names(["chr6:1001-1001"]) == ["mateless", "mateless"]                 # the unmapped mate counts as one base
+    assert names(["contig_3:100-120"]) == ["noqual"]                             # inside its 100N skip
+    assert names(["contig_3", "chr6:29941260-29941260"]) == ["noqual", "noseq", "tags"]
+    for native in (True, False):
+        assert read_alignment_text(path, ["HLA:A*BACKBONE:506-506"], native=native).decode().split("\t")[5] == "3M1I2M1D4M10N2M3S"
+    # every member boundary really falls where the generator says (and inflating member by member gives the stream back)
+    offs = fx["member_offsets"]
+    assert data[offs[3]:offs[4]][-4:] == b"\0\0\0\0" and len(offs) == 7          # the empty member: ISIZE 0
+    cut = str(tmp_path / "cut.bam")
+    open(cut, "wb").write(data[:offs[5] - 9])
+    with pytest.raises(capi.HgxError):
+        read_alignment_text(cut)
+    with pytest.raises(Exception):
+        bamio.read_bam(cut)
