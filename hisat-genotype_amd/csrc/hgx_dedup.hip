@@ -804,6 +804,11 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
 
 extern "C" int hgx_classes_destroy(hgx_classes *c) {
     if (!c) return HGX_OK;
+    // Kernels of the stream that filled this set may still be queued (error paths, a set dropped before its results were
+    // fetched): its blocks must not reach another stream through the pool before they are done.  A no-op on the happy paths,
+    // where the caller has synchronised to read the results.
+    if (c->ready) (void)hipEventSynchronize(c->ready);
+    else if (c->made_on) (void)hipStreamSynchronize(c->made_on);
     hgx_pool_free(c->d_bits); hgx_pool_free(c->d_count); hgx_pool_free(c->d_first_row); hgx_pool_free(c->d_bitsT);
     hgx_pool_free(c->d_prow); hgx_pool_free(c->d_pcol);
     hgx_pool_free(c->d_act); hgx_pool_free(c->d_bitsC); hgx_pool_free(c->d_bitsTC);

@@ -179,9 +179,10 @@ extern "C" int hgx_event_elapsed_ms(void *a, void *b, float *ms) {
 namespace {
 struct Pool {
     std::mutex mu;
-    std::multimap<size_t, void *> free_blocks;
-    std::unordered_map<void *, size_t> size_of;
+    std::multimap<std::pair<int, size_t>, void *> free_blocks;      // (device, size) -> block: a block never changes device
+    std::unordered_map<void *, std::pair<int, size_t>> size_of;
 };
+int cur_device() { int d = 0; (void)hipGetDevice(&d); return d; }
 Pool &pool() { static Pool p; return p; }
 size_t round_size(size_t n) {
     size_t r = 256;
@@ -197,9 +198,10 @@ size_t round_size(size_t n) {
 void *hgx_pool_alloc(size_t bytes) {
     Pool &P = pool();
     const size_t sz = round_size(bytes ? bytes : 8);
+    const int dev = cur_device();
     {
         std::lock_guard<std::mutex> g(P.mu);
-        auto it = P.free_blocks.find(sz);
+        auto it = P.free_blocks.find({dev, sz});
         if (it != P.free_blocks.end()) {
             void *p = it->second;
             P.free_blocks.erase(it);
@@ -208,16 +210,18 @@ void *hgx_pool_alloc(size_t bytes) {
     }
     void *p = nullptr;
     if (hipMalloc(&p, sz) != hipSuccess) {
-        // give cached blocks back and retry once
+        // give this device's cached blocks back and retry once
         {
             std::lock_guard<std::mutex> g(P.mu);
-            for (auto &kv : P.free_blocks) { P.size_of.erase(kv.second); (void)hipFree(kv.second); }
-            P.free_blocks.clear();
+            for (auto it = P.free_blocks.begin(); it != P.free_blocks.end();) {
+                if (it->first.first == dev) { P.size_of.erase(it->second); (void)hipFree(it->second); it = P.free_blocks.erase(it); }
+                else ++it;
+            }
         }
         if (hipMalloc(&p, sz) != hipSuccess) return nullptr;
     }
     std::lock_guard<std::mutex> g(P.mu);
-    P.size_of[p] = sz;
+    P.size_of[p] = {dev, sz};
     return p;
 }
 void hgx_pool_free(void *p) {
@@ -233,6 +237,7 @@ extern "C" int hgx_pool_trim(void) {
     hgx_host_pool_trim();
     Pool &P = pool();
     std::lock_guard<std::mutex> g(P.mu);
+    // (a hipFree from another device's context is legal: the runtime knows the owner of the pointer)
     for (auto &kv : P.free_blocks) { P.size_of.erase(kv.second); (void)hipFree(kv.second); }
     P.free_blocks.clear();
     return HGX_OK;

@@ -3,23 +3,24 @@
 and rebuild profiles/traffic.json.  Usage: tools/install_profiles.py gpurun_out/<dir>"""
 import collections, csv, json, os, shutil, sys
 src = sys.argv[1]
+R = sys.argv[2] if len(sys.argv) > 2 else "r02"            # round prefix of the files in profiles/
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 for f in os.listdir(dst):
-    if f.startswith("r01_final"):
+    if f.startswith(R + "_final"):
         os.remove(os.path.join(dst, f))
-shutil.copy(f"{src}/stats/r01_kernel_stats.csv", f"{dst}/r01_final_kernel_stats.csv")
-shutil.copy(f"{src}/bench_default.json", f"{dst}/r01_final_bench.json")
-shutil.copy(f"{src}/bench_inflight2.json", f"{dst}/r01_final_bench_inflight2.json")
-shutil.copy(f"{src}/bench_under_rocprof.json", f"{dst}/r01_final_bench_under_rocprofv3.json")
+shutil.copy(f"{src}/stats/{R}_kernel_stats.csv", f"{dst}/{R}_final_kernel_stats.csv")
+shutil.copy(f"{src}/bench_default.json", f"{dst}/{R}_final_bench.json")
+shutil.copy(f"{src}/bench_inflight2.json", f"{dst}/{R}_final_bench_inflight2.json")
+shutil.copy(f"{src}/bench_under_rocprof.json", f"{dst}/{R}_final_bench_under_rocprofv3.json")
 summ = {}
 for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    rows = list(csv.DictReader(open(f"{src}/{name}/r01_counter_collection.csv")))
+    rows = list(csv.DictReader(open(f"{src}/{name}/{R}_counter_collection.csv")))
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
     for r in rows:
         a = agg[r["Kernel_Name"]]
         v = float(r["Counter_Value"])
         a[0] += 1; a[1] += v; a[2] = max(a[2], v)
-    with open(f"{dst}/r01_final_pmc_{ctr}.csv", "w") as f:
+    with open(f"{dst}/{R}_final_pmc_{ctr}.csv", "w") as f:
         w = csv.writer(f)
         w.writerow(["Kernel_Name", "Dispatches", "Counter", ctr + "_avg_KB", ctr + "_max_KB", ctr + "_total_KB"])
         for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
@@ -47,7 +48,7 @@ print({k: (v["avg_ms"], v["total_ms_per_step"], v["GBps"]) for k, v in d["roofli
 u = json.load(open(f"{src}/bench_under_rocprof.json"))
 n_steps = u["steps"] + u["warmup"]                      # the profiled run's steps (warm-up included: the profiler sees all)
 tot = 0
-for r in csv.DictReader(open(f"{dst}/r01_final_kernel_stats.csv")):
+for r in csv.DictReader(open(f"{dst}/{R}_final_kernel_stats.csv")):
     tot += int(r["TotalDurationNs"])
     n = r["Name"].split("(")[0][-48:]
     if int(r["TotalDurationNs"]) > 0.05e6 * n_steps:
