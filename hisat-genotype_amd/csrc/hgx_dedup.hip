@@ -1,14 +1,12 @@
 // hgx_dedup.hip -- class dedup (8a-7), bit-matrix transpose and Gene_counts for libhgx (gfx950).
-#include <hipcub/hipcub.hpp>
-
 #include <algorithm>
 #include <vector>
 
 #include "hgx_common.hpp"
 
 // ------------------------------------------------------------------------------------------------
-// 8a-7 class dedup: hash (optional AND mask) -> radix sort -> run heads -> exact verify ->
-// first-seen order -> gather.
+// 8a-7 class dedup: hash (optional AND mask) -> hash table insert -> first rows numbered by a single-pass scan ->
+// exact verify -> gather (every kernel here is this library's own: no CUB / rocPRIM on the path).
 // ------------------------------------------------------------------------------------------------
 
 // one wavefront per row: hash of (row & mask)
@@ -30,120 +28,97 @@ __global__ __launch_bounds__(256) void k_hash_rows(const uint64_t *__restrict__ 
     if (lane == 0) hash[row] = finish_hash(h, any_nz);
 }
 
-__global__ void k_pack_meta(const uint32_t *last_cls, const uint32_t *last_head, uint32_t *meta) {
-    meta[2] = *last_cls;
-    meta[3] = *last_head;
-}
-
-__global__ void k_iota(uint32_t *v, long n) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = (uint32_t)i;
-}
-
-// head[i] = 1 if sorted key i starts a run of a non-empty key
-// (empty rows carry the largest key and sort last: *n_valid = number of non-empty rows)
-__global__ void k_heads(const uint64_t *__restrict__ key, long n, uint32_t *__restrict__ head, uint32_t *__restrict__ n_valid) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t k = key[i];
-    head[i] = (k != HGX_EMPTY_KEY && (i == 0 || key[i - 1] != k)) ? 1u : 0u;
-    if (k != HGX_EMPTY_KEY && (i == n - 1 || key[i + 1] == HGX_EMPTY_KEY)) *n_valid = (uint32_t)(i + 1);
-}
-
-// for every run head: remember where the run starts and which original row is its first member
-__global__ void k_run_starts(const uint32_t *__restrict__ head, const uint32_t *__restrict__ cls, const uint32_t *__restrict__ idx,
-                             long n, uint32_t *__restrict__ run_start, uint32_t *__restrict__ run_first) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !head[i]) return;
-    run_start[cls[i]] = (uint32_t)i;
-    run_first[cls[i]] = idx[i];   // stable sort => smallest original row of the run
-}
-
-// run weight = sum of member weights (prefix sums) ; unit weights => run length
-__global__ void k_run_counts(const uint32_t *__restrict__ run_start, int n_runs, long n_valid, const int64_t *__restrict__ wsum,
-                             int64_t *__restrict__ run_count) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_runs) return;
-    const long b = run_start[r];
-    const long e = (r + 1 < n_runs) ? (long)run_start[r + 1] : n_valid;
-    if (wsum) run_count[r] = wsum[e - 1] - (b ? wsum[b - 1] : 0);
-    else run_count[r] = e - b;
-}
-
-__global__ void k_gather_weights(const int64_t *__restrict__ w, const uint32_t *__restrict__ idx, long n, int64_t *__restrict__ out) {
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = w[idx[i]];
-}
-
-// exact check: every member row equals its run's first row (under the mask)
-__global__ __launch_bounds__(256) void k_verify(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
-                                                const uint32_t *__restrict__ idx, const uint32_t *__restrict__ cls,
-                                                const uint32_t *__restrict__ head, const uint32_t *__restrict__ run_first,
-                                                long n_valid, int *__restrict__ bad) {
-    const int lane = threadIdx.x & 63;
-    const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (i >= n_valid || head[i]) return;
-    const uint64_t *a = rows + (size_t)idx[i] * w64;
-    const uint64_t *b = rows + (size_t)run_first[cls[i] - 1] * w64;   // non-head: exclusive scan counts its own head
-    bool diff = false;
-    for (int w = lane; w < w64; w += 64) {
-        uint64_t x = a[w], y = b[w];
-        if (mask) { x &= mask[w]; y &= mask[w]; }
-        diff = diff || x != y;
+// ------------------------------------------------------------------------------------------------
+// Exclusive prefix sum of n uint32 values in ONE launch (chained scan with decoupled look-back).  A workgroup takes the next
+// tile in START order (ticket), so every tile it waits for belongs to a workgroup that is already running: no deadlock
+// whatever the dispatch order.  Tile state = one 64-bit word (status in the top two bits: 1 = the tile's own sum, 2 = the
+// inclusive prefix up to and including the tile), published and polled with device-scope atomics -- one word, so no fence.
+// `scratch` = [tiles] state words + 1 ticket word, zeroed before the launch; *total_out = sum of all values.
+// ------------------------------------------------------------------------------------------------
+#define SCAN_T 1024
+#define SCAN_TILE (4 * SCAN_T)
+__global__ __launch_bounds__(SCAN_T) void k_scan_u32(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, long n,
+                                                     unsigned long long *__restrict__ state, uint32_t *__restrict__ ticket,
+                                                     uint32_t *__restrict__ total_out) {
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_wave[SCAN_T / 64];
+    __shared__ unsigned long long s_prefix;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const long i0 = (long)tile * SCAN_TILE + 4 * tid;
+    uint32_t v[4];
+    if (i0 + 3 < n) {
+        const uint4 q = *(const uint4 *)(in + i0);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = i0 + k < n ? in[i0 + k] : 0u;
     }
-    if (__any(diff) && lane == 0) atomicOr(bad, 1);
-}
-
-// streaming form of the exact check: rows are visited in their ORIGINAL order (sequential 16-byte-per-lane reads of the
-// big array), each against the first row of its run (a few thousand distinct rows: cache resident)
-__global__ void k_head_of(const uint32_t *__restrict__ idx, const uint32_t *__restrict__ cls, const uint32_t *__restrict__ head,
-                          const uint32_t *__restrict__ run_first, long n_valid, long n, uint32_t *__restrict__ head_of) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t row = idx[i];
-    head_of[row] = (i < n_valid && !head[i]) ? run_first[cls[i] - 1] : row;
-}
-__global__ __launch_bounds__(256) void k_verify_stream(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
-                                                       const uint32_t *__restrict__ head_of, long n, int *__restrict__ bad) {
-    const int lane = threadIdx.x & 63;
-    const long r = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (r >= n) return;
-    const uint32_t h = head_of[r];
-    if (h == (uint32_t)r) return;
-    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
-    const u64x2 *a = (const u64x2 *)(rows + (size_t)r * w64);
-    const u64x2 *b = (const u64x2 *)(rows + (size_t)h * w64);
-    const u64x2 *m = (const u64x2 *)mask;
-    bool diff = false;
-    for (int w = lane; w < w64 / 2; w += 64) {
-        u64x2 x = a[w], y = b[w];
-        if (mask) { x &= m[w]; y &= m[w]; }
-        diff = diff || x.x != y.x || x.y != y.y;
+    const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = mine;                                   // inclusive scan of the threads' sums inside the wavefront
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
     }
-    if (__any(diff) && lane == 0) atomicOr(bad, 1);
-}
-
-// out[c] = rows[first_row[c]] & mask
-__global__ __launch_bounds__(256) void k_gather_rows(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
-                                                     const uint32_t *__restrict__ first_sorted, const uint32_t *__restrict__ run_sorted,
-                                                     const int64_t *__restrict__ run_count, int n_classes,
-                                                     uint64_t *__restrict__ out_bits, int64_t *__restrict__ out_count,
-                                                     int64_t *__restrict__ out_first) {
-    const int lane = threadIdx.x & 63;
-    const long c = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (c >= n_classes) return;
-    const uint64_t *src = rows + (size_t)first_sorted[c] * w64;
-    for (int w = lane; w < w64; w += 64) {
-        uint64_t x = src[w];
-        if (mask) x &= mask[w];
-        out_bits[(size_t)c * w64 + w] = x;
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    if (wv == 0) {
+        uint32_t w = lane < SCAN_T / 64 ? s_wave[lane] : 0u, wi = w;
+#pragma unroll
+        for (int d = 1; d < SCAN_T / 64; d <<= 1) {
+            const uint32_t up = __shfl_up(wi, d, 64);
+            if (lane >= d) wi += up;
+        }
+        if (lane < SCAN_T / 64) s_wave[lane] = wi - w;      // exclusive offsets of the wavefronts
+        if (lane == SCAN_T / 64 - 1) {
+            const unsigned long long total = wi;
+            unsigned long long before = 0;
+            if (tile == 0) {
+                __hip_atomic_store(&state[0], (2ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(&state[tile], (1ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (long j = (long)tile - 1;; --j) {
+                    unsigned long long st;
+                    do st = __hip_atomic_load(&state[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); while ((st >> 62) == 0);
+                    before += st & ((1ull << 62) - 1);
+                    if ((st >> 62) == 2) break;
+                }
+                __hip_atomic_store(&state[tile], (2ull << 62) | (before + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_prefix = before;
+            if ((long)(tile + 1) * SCAN_TILE >= n && total_out) *total_out = (uint32_t)(before + total);
+        }
     }
-    if (lane == 0) {
-        out_count[c] = run_count[run_sorted[c]];
-        out_first[c] = first_sorted[c];
+    __syncthreads();
+    uint32_t run = (uint32_t)s_prefix + s_wave[wv] + (incl - mine);
+    if (i0 + 3 < n) {
+        uint4 o;
+        o.x = run; run += v[0];
+        o.y = run; run += v[1];
+        o.z = run; run += v[2];
+        o.w = run;
+        *(uint4 *)(out + i0) = o;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < n) out[i0 + k] = run;
+            run += v[k];
+        }
     }
 }
-
+static size_t scan_scratch_bytes(long n) { return ((size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 2) * 8; }
+// out = exclusive prefix sums of in[0..n), *total_dev = their total; scratch from scan_scratch_bytes(n)
+static int scan_u32(const uint32_t *in, uint32_t *out, long n, void *scratch, uint32_t *total_dev, hipStream_t st) {
+    const long tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+    HIPCHK(hipMemsetAsync(scratch, 0, scan_scratch_bytes(n), st));
+    hipLaunchKernelGGL(k_scan_u32, dim3((unsigned)tiles), dim3(SCAN_T), 0, st, in, out, n, (unsigned long long *)scratch,
+                       (uint32_t *)((unsigned long long *)scratch + tiles), total_dev);
+    HIPCHK(hipGetLastError());
+    return HGX_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Hash-table form of the dedup (default).  Sorting 500 k 64-bit keys costs ~25 short library launches; the dict
@@ -351,7 +326,6 @@ __global__ __launch_bounds__(256) void k_ht_gather_slots(const uint64_t *__restr
         dst[w] = x;
     }
 }
-__global__ void k_ht_meta(const uint32_t *last_rank, const uint32_t *last_flag, uint32_t *meta) { meta[1] = *last_rank + *last_flag; }
 
 static hgx_classes *new_classes(int32_t a_pad);
 // small_blocks: insert with 256-row workgroups instead of 1024-row ones.  Alone the large ones win (4x fewer global atomics
@@ -365,17 +339,12 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     ALLOC(b_keys, (size_t)T * 8); ALLOC(b_first, (size_t)T * 4); ALLOC(b_cnt, (size_t)T * 8);
     ALLOC(b_slot, (size_t)n * 4); ALLOC(b_flag, (size_t)n * 4); ALLOC(b_rank, (size_t)n * 4); ALLOC(b_meta, 16);
     ALLOC(b_bad, (size_t)n * 4);
-    size_t tmp_bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
-    ALLOC(b_tmp, tmp_bytes);
-    // first rows of the classes -> flags -> class ids in first-seen order, class count in meta[1]
+    ALLOC(b_tmp, scan_scratch_bytes(n));
+    // first rows of the classes -> flags -> class ids in first-seen order (single-pass scan), class count in meta[1]
     auto number_classes = [&]() -> int {
         hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,
                            b_flag.as<uint32_t>());
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
-        hipLaunchKernelGGL(k_ht_meta, dim3(1), dim3(1), 0, st, b_rank.as<uint32_t>() + (n - 1), b_flag.as<uint32_t>() + (n - 1),
-                           b_meta.as<uint32_t>());
-        return HGX_OK;
+        return scan_u32(b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n, b_tmp.p, b_meta.as<uint32_t>() + 1, st);
     };
     uint32_t meta[4] = {0, 0, 0, 0};           // {some key collided, number of classes, number of collided rows, -}
     // rows that share a key with a different row: re-keyed and re-checked (see k_fix_reinsert); classes renumbered; meta refreshed
@@ -492,94 +461,14 @@ static int dedup_classes_impl(hgx_classes **out, const uint64_t *rows, const uin
     if (n_rows == 0) return HGX_OK;
     ARGCHK(rows);
     const long n = n_rows;
-    DevBuf b_hash, b_key, b_idx0, b_idx, b_head, b_cls, b_tmp, b_bad;
+    DevBuf b_hash;
     const uint64_t *keys_in = row_hash;
     if (!row_hash || and_mask) {   // hashes of masked rows must be recomputed
         ALLOC(b_hash, n * 8);
         hipLaunchKernelGGL(k_hash_rows, dim3(nblk(n, 4)), dim3(256), 0, st, rows, n, w64, and_mask, b_hash.as<uint64_t>());
         keys_in = b_hash.as<uint64_t>();
     }
-    const bool sort_path = getenv("HGX_DEDUP_SORT") != nullptr;      // the radix-sort form, kept for comparison
-    if (!sort_path) return dedup_hash_table(cl, rows, keys_in, row_weight, n, w64, and_mask, st);
-    ALLOC(b_key, n * 8); ALLOC(b_idx0, n * 4); ALLOC(b_idx, n * 4); ALLOC(b_head, n * 4); ALLOC(b_cls, n * 4); ALLOC(b_bad, 16);
-    hipLaunchKernelGGL(k_iota, dim3(nblk(n, 256)), dim3(256), 0, st, b_idx0.as<uint32_t>(), n);
-    size_t tmp_bytes = 0, t2 = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys_in, b_key.as<uint64_t>(), b_idx0.as<uint32_t>(),
-                                              b_idx.as<uint32_t>(), (int)n, 0, 64, st));
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, b_head.as<uint32_t>(), b_cls.as<uint32_t>(), (int)n, st));
-    tmp_bytes = std::max(tmp_bytes, t2);
-    HIPCHK(hipcub::DeviceScan::InclusiveSum(nullptr, t2, (int64_t *)nullptr, (int64_t *)nullptr, (int)n, st));
-    tmp_bytes = std::max(tmp_bytes, t2);
-    ALLOC(b_tmp, tmp_bytes);
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, tmp_bytes, keys_in, b_key.as<uint64_t>(), b_idx0.as<uint32_t>(),
-                                              b_idx.as<uint32_t>(), (int)n, 0, 64, st));
-    HIPCHK(hipMemsetAsync(b_bad.p, 0, 16, st));   // [0] collision flag, [1] n_valid, [2] last scan value, [3] last head
-    hipLaunchKernelGGL(k_heads, dim3(nblk(n, 256)), dim3(256), 0, st, b_key.as<uint64_t>(), n, b_head.as<uint32_t>(),
-                       b_bad.as<uint32_t>() + 1);
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_head.as<uint32_t>(), b_cls.as<uint32_t>(), (int)n, st));
-    // one small D2H: [flag, n_valid, last exclusive-scan value, last head flag]
-    hipLaunchKernelGGL(k_pack_meta, dim3(1), dim3(1), 0, st, b_cls.as<uint32_t>() + (n - 1), b_head.as<uint32_t>() + (n - 1),
-                       b_bad.as<uint32_t>());
-    uint32_t meta[4] = {0, 0, 0, 0};
-    { int rc_ = hgx_d2h(meta, b_bad.p, 16, st); if (rc_) return rc_; }
-    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-    const uint32_t last_cls = meta[2], last_head = meta[3], nv32 = meta[1];
-    const int n_runs = (int)(last_cls + last_head);
-    if (n_runs == 0) return HGX_OK;
-    const long n_valid = nv32;
-    DevBuf b_rs, b_rf, b_rc, b_ws, b_w;
-    ALLOC(b_rs, (size_t)n_runs * 4); ALLOC(b_rf, (size_t)n_runs * 4); ALLOC(b_rc, (size_t)n_runs * 8);
-    hipLaunchKernelGGL(k_run_starts, dim3(nblk(n, 256)), dim3(256), 0, st, b_head.as<uint32_t>(), b_cls.as<uint32_t>(),
-                       b_idx.as<uint32_t>(), n, b_rs.as<uint32_t>(), b_rf.as<uint32_t>());
-    const int64_t *wsum = nullptr;
-    if (row_weight) {
-        ALLOC(b_w, n * 8); ALLOC(b_ws, n * 8);
-        hipLaunchKernelGGL(k_gather_weights, dim3(nblk(n, 256)), dim3(256), 0, st, row_weight, b_idx.as<uint32_t>(), n, b_w.as<int64_t>());
-        HIPCHK(hipcub::DeviceScan::InclusiveSum(b_tmp.p, tmp_bytes, b_w.as<int64_t>(), b_ws.as<int64_t>(), (int)n, st));
-        wsum = b_ws.as<int64_t>();
-    }
-    hipLaunchKernelGGL(k_run_counts, dim3(nblk(n_runs, 256)), dim3(256), 0, st, b_rs.as<uint32_t>(), n_runs, n_valid, wsum,
-                       b_rc.as<int64_t>());
-    const bool sorted_verify = getenv("HGX_VERIFY_SORTED") != nullptr;      // the hash-order walk, for comparison
-    DevBuf b_ho;
-    if (sorted_verify) {
-        hipLaunchKernelGGL(k_verify, dim3(nblk(n_valid, 4)), dim3(256), 0, st, rows, w64, and_mask, b_idx.as<uint32_t>(),
-                           b_cls.as<uint32_t>(), b_head.as<uint32_t>(), b_rf.as<uint32_t>(), n_valid, b_bad.as<int>());
-    } else {
-        ALLOC(b_ho, (size_t)n * 4);
-        hipLaunchKernelGGL(k_head_of, dim3(nblk(n, 256)), dim3(256), 0, st, b_idx.as<uint32_t>(), b_cls.as<uint32_t>(),
-                           b_head.as<uint32_t>(), b_rf.as<uint32_t>(), n_valid, n, b_ho.as<uint32_t>());
-        hipLaunchKernelGGL(k_verify_stream, dim3(nblk(n, 4)), dim3(256), 0, st, rows, w64, and_mask, b_ho.as<uint32_t>(), n,
-                           b_bad.as<int>());
-    }
-    // first-seen order: sort runs by their first row
-    DevBuf b_fs, b_rid0, b_rid, b_tmp2;
-    ALLOC(b_fs, (size_t)n_runs * 4); ALLOC(b_rid0, (size_t)n_runs * 4); ALLOC(b_rid, (size_t)n_runs * 4);
-    hipLaunchKernelGGL(k_iota, dim3(nblk(n_runs, 256)), dim3(256), 0, st, b_rid0.as<uint32_t>(), (long)n_runs);
-    size_t tb2 = 0;
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb2, b_rf.as<uint32_t>(), b_fs.as<uint32_t>(), b_rid0.as<uint32_t>(),
-                                              b_rid.as<uint32_t>(), n_runs, 0, 32, st));
-    ALLOC(b_tmp2, tb2);
-    HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp2.p, tb2, b_rf.as<uint32_t>(), b_fs.as<uint32_t>(), b_rid0.as<uint32_t>(),
-                                              b_rid.as<uint32_t>(), n_runs, 0, 32, st));
-    cl->d_bits = (decltype(cl->d_bits))hgx_pool_alloc((size_t)n_runs * w64 * 8);
-    if (!cl->d_bits) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
-    cl->d_count = (decltype(cl->d_count))hgx_pool_alloc((size_t)n_runs * 8);
-    if (!cl->d_count) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
-    cl->d_first_row = (decltype(cl->d_first_row))hgx_pool_alloc((size_t)n_runs * 8);
-    if (!cl->d_first_row) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
-    hipLaunchKernelGGL(k_gather_rows, dim3(nblk(n_runs, 4)), dim3(256), 0, st, rows, w64, and_mask, b_fs.as<uint32_t>(),
-                       b_rid.as<uint32_t>(), b_rc.as<int64_t>(), n_runs, cl->d_bits, cl->d_count, cl->d_first_row);
-    int bad = 0;
-    { int rc_ = hgx_d2h(&bad, b_bad.p, 4, st); if (rc_) return rc_; }
-    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-    HIPCHK(hipGetLastError());
-    cl->n_classes = n_runs;
-    if (bad) {
-        hgx_set_error("64-bit class hash collision detected by the exact verify pass");
-        return HGX_ECOLLISION;
-    }
-    return HGX_OK;
+    return dedup_hash_table(cl, rows, keys_in, row_weight, n, w64, and_mask, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -696,9 +585,7 @@ static int group_pairs_impl(hgx_groups **out, const int32_t *pair_off, const uin
     ALLOC(b_key, (size_t)n * 8);
     ALLOC(b_keys, (size_t)T * 8); ALLOC(b_first, (size_t)T * 4); ALLOC(b_cnt, (size_t)T * 8);
     ALLOC(b_slot, (size_t)n * 4); ALLOC(b_flag, (size_t)n * 4); ALLOC(b_rank, (size_t)n * 4); ALLOC(b_meta, 16);
-    size_t tmp_bytes = 0;
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
-    ALLOC(b_tmp, tmp_bytes);
+    ALLOC(b_tmp, scan_scratch_bytes(n));
     hipLaunchKernelGGL(k_sig_keys, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level, b_key.as<uint64_t>());
     hipLaunchKernelGGL(k_ht_init, dim3(nblk(std::max(T, n), 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(),
                        b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), T, b_flag.as<uint32_t>(), n, b_meta.as<uint32_t>());
@@ -707,9 +594,7 @@ static int group_pairs_impl(hgx_groups **out, const int32_t *pair_off, const uin
                        b_slot.as<uint32_t>());
     hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,
                        b_flag.as<uint32_t>());
-    HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, tmp_bytes, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n, st));
-    hipLaunchKernelGGL(k_ht_meta, dim3(1), dim3(1), 0, st, b_rank.as<uint32_t>() + (n - 1), b_flag.as<uint32_t>() + (n - 1),
-                       b_meta.as<uint32_t>());
+    { int rc_ = scan_u32(b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n, b_tmp.p, b_meta.as<uint32_t>() + 1, st); if (rc_) return rc_; }
     hipLaunchKernelGGL(k_sig_verify, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level,
                        b_slot.as<uint32_t>(), b_first.as<uint32_t>(), b_meta.as<int>());
     // group id (first-seen order) -> first pair, group size; sized for the worst case: no host-side group count needed yet

@@ -204,35 +204,6 @@ def test_piece_compat_any_piece_order(orc, name):
     assert np.array_equal(out[0], out[2])
 
 
-@pytest.mark.parametrize("name", ["hla_7000", "hla_errors_filters", "codis_d18s51"])
-def test_dedup_sort_path_equals_hash_table_path(orc, name):
-    """The radix-sort dedup (kept for comparison) and the hash-table dedup give the same classes, counts and order,
-    with and without weights / AND mask."""
-    import os
-    fx, loc, t, pl, batch, _ = _setup(orc, name)
-    db = engine.DeviceBatch(batch)
-    bufs = engine.ScoreBuffers(pl, db)
-    engine.score_pairs(pl, db, bufs)
-    rng = np.random.RandomState(5)
-    weights = engine.DevArray.from_host(rng.randint(1, 9, batch.n_pairs).astype(np.int64))
-    mask = np.zeros(pl.w64, np.uint64)
-    mask[: max(1, pl.w64 // 3)] = np.uint64(0xFFFFFFFFFFFFFFFF)
-    d_mask = engine.DevArray.from_host(mask)
-    for kw in ({"hashes": bufs.gene_hash}, {"weights": weights}, {"and_mask": d_mask, "weights": weights}):
-        res = []
-        for sort in (False, True):
-            if sort:
-                os.environ["HGX_DEDUP_SORT"] = "1"
-            try:
-                cl = engine.Classes.dedup(bufs.gene_bits, batch.n_pairs, pl.a_pad, **kw)
-            finally:
-                os.environ.pop("HGX_DEDUP_SORT", None)
-            res.append(cl.to_host())
-            cl.close()
-        for x, y in zip(res[0], res[1]):
-            assert np.array_equal(x, y)
-
-
 @pytest.mark.parametrize("name", ["hla_7000", "hla_mid_real", "codis_like"])
 def test_em_ordered_and_first_classes_match_counts_pass(orc, name):
     """hgx_em_ordered's first-class output (the tie order of the result list) and hgx_first_classes agree with the full
@@ -325,9 +296,7 @@ def test_forged_hash_collision_is_detected(orc, n_rows):
     rows = base[pick].copy()
     keys = (pick.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
     d_rows = engine.DevArray.from_host(rows)
-    for sort in (False, True):
-        if sort:
-            os.environ["HGX_DEDUP_SORT"] = "1"
+    for _ in (0,):
         try:
             cl = engine.Classes.dedup(d_rows, n_rows, a_pad, hashes=engine.DevArray.from_host(keys))
             assert cl.n_classes == len(set(pick.tolist()))
@@ -336,13 +305,7 @@ def test_forged_hash_collision_is_detected(orc, n_rows):
             forged = rows.copy()
             forged[victim, 3] ^= np.uint64(1) << np.uint64(17)
             d_forged = engine.DevArray.from_host(forged)
-            if sort:
-                with pytest.raises(capi.HgxError) as ei:
-                    engine.Classes.dedup(d_forged, n_rows, a_pad, hashes=engine.DevArray.from_host(keys))
-                assert ei.value.code == -5                    # HGX_ECOLLISION
-                continue
             got = engine.Classes.dedup(d_forged, n_rows, a_pad, hashes=engine.DevArray.from_host(keys))
-            os.environ.pop("HGX_DEDUP_SORT", None)
             want = engine.Classes.dedup(d_forged, n_rows, a_pad)           # keys computed from the rows
             assert got.n_classes == want.n_classes == len(set(pick.tolist())) + 1
             for x, y in zip(got.to_host(), want.to_host()):
@@ -359,7 +322,7 @@ def test_forged_hash_collision_is_detected(orc, n_rows):
             for x, y in zip(got.to_host(), want.to_host()):
                 assert np.array_equal(x, y)
         finally:
-            os.environ.pop("HGX_DEDUP_SORT", None)
+            pass
 
 
 @pytest.mark.parametrize("name", ["hla_7000", "hla_mid_real", "hla_errors_filters"])
