@@ -417,7 +417,7 @@ inline int64_t cigar_text_reflen(const char *p, const char *e) {
 
 // The reader proper: the records of `path` as a line table, stable-sorted by QNAME, over buffers `out` owns.  Every line is
 // followed by one byte the parser may overwrite (its terminator).
-int hgx_read_alignment_lines(const char *path, const char *regions, int n_threads, hgx_align_lines &out) {
+int hgx_read_alignment_lines(const char *path, const char *regions, int n_threads, hgx_align_lines &out, bool keep_binary) {
     if (n_threads <= 0) n_threads = hgx_default_threads();
     n_threads = std::max(1, std::min(n_threads, 512));
     const std::vector<Region> regs = parse_regions(regions);
@@ -476,24 +476,110 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             refs.emplace_back((const char *)&raw[p + 4], l_name - 1);
             p += 4 + l_name + 4;
         }
-        std::vector<std::vector<std::pair<size_t, uint32_t>>> per_region(n_reg);   // (offset after block_size, length)
-        while (p < n) {
-            if (p + 4 > n) { hgx_set_error("truncated BAM record at offset %zu", p); return HGX_EPARSE; }
-            // the walk is a pointer chase through memory other cores just wrote (one cache miss per record, ~120 ns each):
-            // touching the lines a few KB ahead turns it into a streaming read
-            if (p + 8192 < n) {
-                __builtin_prefetch(&raw[p + 4096]);
-                __builtin_prefetch(&raw[p + 4096 + 64]);
-                __builtin_prefetch(&raw[p + 4096 + 128]);
-                __builtin_prefetch(&raw[p + 4096 + 192]);
+        // ---- record chain ------------------------------------------------------------------------------------------
+        // The records form a chain (each block_size leads to the next) that one thread walks at ~15 ns per record.  For big
+        // files the inflated stream is cut into ranges instead: every worker but the first GUESSES a record start in its
+        // range (a header that is plausible and leads to three more plausible headers) and walks from there past the end of
+        // its range.  The guesses are then CHECKED: worker t's walk must end exactly where worker t+1's begins; the first
+        // mismatch falls back to the plain walk from that point on.  The record list is therefore exact, not heuristic.
+        auto plausible = [&](size_t o) -> bool {
+            if (o + 36 > n) return false;
+            const uint32_t bs = rd32(&raw[o]);
+            if (bs < 32 || o + 4 + (size_t)bs > n) return false;
+            const unsigned char *r = &raw[o + 4];
+            const int32_t rid = rdi32(r), pos = rdi32(r + 4), nrid = rdi32(r + 20), npos = rdi32(r + 24), l_seq = rdi32(r + 16);
+            const uint32_t l_rn = r[8], n_cig = rd16(r + 12);
+            if (rid < -1 || rid >= (int32_t)refs.size() || nrid < -1 || nrid >= (int32_t)refs.size()) return false;
+            if (pos < -1 || npos < -1 || l_seq < 0 || l_rn == 0) return false;
+            if (32 + (size_t)l_rn + 4 * (size_t)n_cig + (size_t)(l_seq + 1) / 2 + (size_t)l_seq > bs) return false;
+            if (r[32 + l_rn - 1] != 0) return false;
+            for (uint32_t k = 0; k + 1 < l_rn; ++k) if (r[32 + k] < 33 || r[32 + k] > 126) return false;
+            return true;
+        };
+        std::vector<std::pair<size_t, uint32_t>> chain;          // every record: (offset after block_size, length)
+        const size_t body0 = p;
+        const char *chain_min = getenv("HGX_BAM_CHAIN_MIN");              // bytes of records from which the chain is walked in ranges (tests)
+        const size_t chain_min_bytes = chain_min ? (size_t)strtoull(chain_min, nullptr, 10) : (32u << 20);
+        const int W = (n - body0 > chain_min_bytes) ? std::max(1, std::min(n_threads, 64)) : 1;
+        bool chain_error = false;
+        size_t err_at = 0;
+        auto walk = [&](size_t from, size_t until, std::vector<std::pair<size_t, uint32_t>> &dst, size_t &stop) -> bool {
+            size_t q = from;
+            while (q < until && q < n) {
+                if (q + 8192 < n) {       // a pointer chase through memory other cores just wrote: touch the lines ahead
+                    __builtin_prefetch(&raw[q + 4096]);
+                    __builtin_prefetch(&raw[q + 4096 + 64]);
+                    __builtin_prefetch(&raw[q + 4096 + 128]);
+                    __builtin_prefetch(&raw[q + 4096 + 192]);
+                }
+                if (q + 4 > n) { stop = q; return false; }
+                const uint32_t bs = rd32(&raw[q]);
+                if (bs < 32 || q + 4 + (size_t)bs > n) { stop = q; return false; }
+                dst.push_back({q + 4, bs});
+                q += 4 + (size_t)bs;
             }
-            const uint32_t bs = rd32(&raw[p]);
-            if (bs < 32 || p + 4 + bs > n) { hgx_set_error("truncated BAM record at offset %zu", p); return HGX_EPARSE; }
-            if (!filtered) per_region[0].push_back({p + 4, bs});
-            else {
-                const unsigned char *r = &raw[p + 4];
-                const int32_t rid = rdi32(r), pos = rdi32(r + 4);
-                if (rid >= 0 && (size_t)rid < refs.size()) {
+            stop = q;
+            return true;
+        };
+        if (W == 1) {
+            size_t stop = 0;
+            if (!walk(body0, n, chain, stop)) { chain_error = true; err_at = stop; }
+        } else {
+            std::vector<std::vector<std::pair<size_t, uint32_t>>> part(W);
+            std::vector<size_t> first(W, 0), stop(W, 0);
+            std::vector<int> okw(W, 0);
+            par_for(W, (size_t)W, [&](int, size_t tb, size_t te) {
+                for (size_t t = tb; t < te; ++t) {
+                    const size_t lo = body0 + (n - body0) * t / W, hi = body0 + (n - body0) * (t + 1) / W;
+                    size_t o = lo;
+                    if (t > 0) {
+                        bool found = false;
+                        for (; o < hi; ++o) {
+                            if (!plausible(o)) continue;
+                            size_t q = o;
+                            int good = 0;
+                            while (good < 4 && q < n && plausible(q)) { q += 4 + (size_t)rd32(&raw[q]); ++good; }
+                            if (good == 4 || q == n) { found = true; break; }
+                        }
+                        if (!found) { okw[t] = 0; first[t] = hi; stop[t] = hi; continue; }
+                    }
+                    first[t] = o;
+                    part[t].reserve((hi - lo) / 200 + 16);
+                    okw[t] = walk(o, hi, part[t], stop[t]) ? 1 : 0;
+                }
+            });
+            // stitch: accept worker t's records iff the chain so far ends exactly at its first record
+            size_t at = body0;
+            for (int t = 0; t < W && !chain_error; ++t) {
+                if (at == first[t] && okw[t]) {
+                    chain.insert(chain.end(), part[t].begin(), part[t].end());
+                    at = stop[t];
+                } else if (at < (t + 1 < W ? first[t + 1] : n) || !okw[t]) {
+                    // the guess was wrong (or the range held no record start): walk on plainly up to the next range's first record
+                    const size_t until = t + 1 < W ? body0 + (n - body0) * (t + 1) / W : n;
+                    size_t st2 = 0;
+                    if (!walk(at, until, chain, st2)) { chain_error = true; err_at = st2; }
+                    at = st2;
+                }
+            }
+            if (!chain_error && at != n) {
+                size_t st2 = 0;
+                if (!walk(at, n, chain, st2)) { chain_error = true; err_at = st2; }
+            }
+        }
+        if (chain_error) { hgx_set_error("truncated BAM record at offset %zu", err_at); return HGX_EPARSE; }
+        // ---- region filter (parallel over the chain) -----------------------------------------------------------------
+        std::vector<std::pair<size_t, uint32_t>> recs;
+        if (!filtered) recs.swap(chain);
+        else {
+            const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, chain.size() / 4096 + 1));
+            std::vector<std::vector<std::vector<std::pair<size_t, uint32_t>>>> hit(T, std::vector<std::vector<std::pair<size_t, uint32_t>>>(n_reg));
+            par_for(T, chain.size(), [&](int t, size_t b, size_t e) {
+                for (size_t i = b; i < e; ++i) {
+                    const unsigned char *r = &raw[chain[i].first];
+                    const uint32_t bs = chain[i].second;
+                    const int32_t rid = rdi32(r), pos = rdi32(r + 4);
+                    if (rid < 0 || (size_t)rid >= refs.size()) continue;
                     // reference span from the CIGAR (bam_endpos: an unmapped or zero-length record counts as one base)
                     const uint32_t l_rn = r[8], n_cig = rd16(r + 12), flag = rd16(r + 14);
                     int64_t reflen = 0;
@@ -507,15 +593,36 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
                     const int64_t end0 = (int64_t)pos + (reflen > 0 ? reflen : 1) - 1;
                     const std::string &nm = refs[rid];
                     for (size_t g = 0; g < regs.size(); ++g)
-                        if (region_hit(regs[g], nm.data(), nm.size(), pos, end0)) per_region[g].push_back({p + 4, bs});
+                        if (region_hit(regs[g], nm.data(), nm.size(), pos, end0)) hit[t][g].push_back(chain[i]);
                 }
-            }
-            p += 4 + (size_t)bs;
+            });
+            for (size_t g = 0; g < n_reg; ++g)                      // region after region, file order inside
+                for (int t = 0; t < T; ++t) recs.insert(recs.end(), hit[t][g].begin(), hit[t][g].end());
         }
-        std::vector<std::pair<size_t, uint32_t>> recs;
-        if (per_region.size() == 1) recs.swap(per_region[0]);
-        else for (auto &v : per_region) recs.insert(recs.end(), v.begin(), v.end());      // region after region, file order inside
         lap("  BAM record walk");
+        if (keep_binary) {
+            // the parser reads the records as they are (hgx_sam.cpp: split_bam): only the sort keys are made here
+            out.binary = true;
+            out.ref_names = refs;
+            lines.resize(recs.size());
+            std::vector<int> badrec(std::max(1, n_threads), 0);
+            par_for(n_threads, recs.size(), [&](int t, size_t b, size_t e) {
+                for (size_t i = b; i < e; ++i) {
+                    unsigned char *r = &raw[recs[i].first];
+                    const uint32_t bs = recs[i].second, l_rn = r[8];
+                    if (l_rn == 0 || 32 + (size_t)l_rn > bs || r[32 + l_rn - 1] != 0) { badrec[t] = 1; return; }
+                    Line &l = lines[i];
+                    l.p = (char *)r + 32;
+                    l.len = bs;
+                    l.klen = l_rn - 1;
+                    uint64_t key = 0;
+                    for (uint32_t k = 0; k < 8; ++k) key = (key << 8) | (k < l.klen ? r[32 + k] : 0);
+                    l.key = key;
+                }
+            });
+            for (int v : badrec) if (v) { hgx_set_error("malformed BAM record"); return HGX_EPARSE; }
+            lap("  BAM sort keys");
+        } else {
         const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, recs.size() / 2000 + 1));
         out.chunks.clear();
         out.chunks.resize(T);
@@ -541,6 +648,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         for (int v : bad) if (v) { hgx_set_error(v == 2 ? "BAM chunk too large" : "malformed BAM record"); return HGX_EPARSE; }
         raw.release();                                    // the records now live as text in out.chunks
         lap("  BAM -> text");
+        }
     } else {
         // SAM text: records = non-empty lines that do not start with '@'.  Byte ranges are split among the workers; a worker
         // owns the lines that START in its range; per worker and region a list, concatenated region-major (file order inside).

@@ -145,15 +145,19 @@ inline void hgx_par_tasks(int n_threads, size_t n_tasks, F fn) {           // fn
 // buffers this object owns.  p[len] is a byte the parser may overwrite (the line's terminator).
 struct hgx_line { char *p; uint32_t len, klen; uint64_t key; };     // klen = QNAME length, key = its first 8 bytes, big endian
 struct hgx_align_lines {
-    char *raw = nullptr;                   // SAM text as read (pooled block), or null
-    std::vector<PString> chunks;           // text decoded from BAM records
+    char *raw = nullptr;                   // SAM text as read, or the inflated BAM stream (pooled block), or null
+    std::vector<PString> chunks;           // text decoded from BAM records (hgx_read_alignments only)
     std::vector<hgx_line> lines;
+    // BAM records handed over in binary (hgx_parse_alignment_file): lines[i].p = the record's read name (record start + 32,
+    // NUL-terminated), lines[i].len = its block_size; ref_names = the header's reference sequences
+    bool binary = false;
+    std::vector<std::string> ref_names;
     hgx_align_lines() = default;
     hgx_align_lines(const hgx_align_lines &) = delete;
     hgx_align_lines &operator=(const hgx_align_lines &) = delete;
     ~hgx_align_lines() { hgx_host_free(raw); }
 };
-int hgx_read_alignment_lines(const char *path, const char *regions, int n_threads, hgx_align_lines &out);
+int hgx_read_alignment_lines(const char *path, const char *regions, int n_threads, hgx_align_lines &out, bool keep_binary = false);
 
 // find-or-insert a piece given its word range and (MP,P) mask words
 uint32_t hgx_intern_masks(hgx_batch &b, uint16_t lo, uint16_t nw, const uint32_t *m);

@@ -943,6 +943,153 @@ static bool split_line(char *line, char *end, Fields &f) {
     return true;
 }
 
+// ---- BAM records straight into Fields (no text round trip) --------------------------------------------------------------
+// Character data the binary record does not hold as text (SEQ is 4-bit packed, CIGAR is binary) is spelled into a per-worker
+// arena of fixed blocks (pointers stay valid); QNAME and the Z tags (Zs, MD, YT) are used in place.
+struct CharArena {
+    static constexpr size_t BLOCK = 4u << 20;
+    std::vector<char *> blocks;
+    size_t used = BLOCK;
+    CharArena() = default;
+    CharArena(const CharArena &) = delete;
+    CharArena(CharArena &&o) noexcept : blocks(std::move(o.blocks)), used(o.used) { o.blocks.clear(); o.used = BLOCK; }
+    ~CharArena() { for (char *b : blocks) hgx_host_free(b); }
+    char *take(size_t n) {
+        if (n > BLOCK) { blocks.insert(blocks.begin(), (char *)hgx_host_alloc(n)); return blocks.front(); }    // (never the current block)
+        if (used + n > BLOCK) { blocks.push_back((char *)hgx_host_alloc(BLOCK)); used = 0; }
+        char *p = blocks.back() + used;
+        used += n;
+        return p;
+    }
+};
+
+inline uint32_t ld32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint32_t ld16(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+
+// The value of an integer-looking tag the way the text path reads it (strtol on the printed value): ints as they are, a float
+// through its "%g" spelling, Z / A from their characters.
+inline bool bam_tag_long(char t, const unsigned char *v, size_t avail, long &out) {
+    switch (t) {
+        case 'c': if (avail < 1) return false; out = (int8_t)v[0]; return true;
+        case 'C': if (avail < 1) return false; out = v[0]; return true;
+        case 's': if (avail < 2) return false; out = (int16_t)ld16(v); return true;
+        case 'S': if (avail < 2) return false; out = (long)ld16(v); return true;
+        case 'i': if (avail < 4) return false; out = (int32_t)ld32(v); return true;
+        case 'I': if (avail < 4) return false; out = (long)ld32(v); return true;
+        case 'f': { if (avail < 4) return false; float f; const uint32_t u = ld32(v); memcpy(&f, &u, 4); char b[40]; snprintf(b, sizeof b, "%g", f); out = strtol(b, nullptr, 10); return true; }
+        case 'A': { if (avail < 1) return false; const char b[2] = {(char)v[0], 0}; out = strtol(b, nullptr, 10); return true; }
+        case 'Z': case 'H': out = strtol((const char *)v, nullptr, 10); return true;
+        default: return false;
+    }
+}
+
+// one BAM record (r = start of the record after its block_size word, len = block_size) -> Fields; false = malformed
+static bool split_bam(const unsigned char *r, size_t len, Fields &f, CharArena &arena) {
+    static const char CIG[] = "MIDNSHP=X", SEQ[] = "=ACMGRSVTWYHKDBN";
+    if (len < 32) return false;
+    const int32_t ref_id = (int32_t)ld32(r), pos0 = (int32_t)ld32(r + 4);
+    const uint32_t l_rn = r[8], n_cig = ld16(r + 12), flag = ld16(r + 14);
+    const int32_t l_seq = (int32_t)ld32(r + 16);
+    if (l_rn == 0 || l_seq < 0) return false;
+    size_t q = 32 + (size_t)l_rn;
+    const size_t cig_at = q;
+    q += 4ull * n_cig;
+    const size_t seq_at = q;
+    q += (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
+    if (q > len || r[32 + l_rn - 1] != 0) return false;
+    f.zs = f.md = nullptr;
+    f.zs_len = f.md_len = 0;
+    f.has_nm = f.has_nh = f.yt_cp = false;
+    f.nm = f.nh = 0;
+    f.qname = (const char *)r + 32;
+    f.qname_len = l_rn - 1;
+    f.flag = (int)flag;
+    f.pos = pos0 + 1;
+    // tags (and the CG real-CIGAR rule: see hgx_bam.cpp find_real_cigar)
+    const unsigned char *cg_items = nullptr;
+    uint32_t cg_n = 0;
+    while (q + 3 <= len) {
+        const char t0 = (char)r[q], t1 = (char)r[q + 1], t = (char)r[q + 2];
+        q += 3;
+        size_t sz = 0;
+        switch (t) {
+            case 'A': case 'c': case 'C': sz = 1; break;
+            case 's': case 'S': sz = 2; break;
+            case 'i': case 'I': case 'f': sz = 4; break;
+            case 'Z': case 'H': {
+                const void *e = memchr(r + q, 0, len - q);
+                if (!e) return false;
+                sz = (size_t)((const unsigned char *)e - (r + q)) + 1;
+            } break;
+            case 'B': {
+                if (q + 5 > len) return false;
+                const char st = (char)r[q];
+                const uint32_t cnt = ld32(r + q + 1);
+                const size_t w = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0;
+                if (!w) return false;
+                sz = 5 + w * (size_t)cnt;
+                if (t0 == 'C' && t1 == 'G' && (st == 'I' || st == 'i') && cnt >= n_cig && cnt < (1u << 29) && q + sz <= len && !cg_items) {
+                    cg_items = r + q + 5;
+                    cg_n = cnt;
+                }
+            } break;
+            default: return false;
+        }
+        if (q + sz > len) return false;
+        const unsigned char *v = r + q;
+        const bool text = t == 'Z' || t == 'H';
+        if (t0 == 'Z' && t1 == 's') { if (text) { f.zs = (const char *)v; f.zs_len = (uint32_t)(sz - 1); } else { f.zs = ""; f.zs_len = 0; } }
+        else if (t0 == 'M' && t1 == 'D') { if (text) { f.md = (const char *)v; f.md_len = (uint32_t)(sz - 1); } else { f.md = ""; f.md_len = 0; } }
+        else if (t0 == 'N' && t1 == 'M') { f.has_nm = true; long x = 0; if (bam_tag_long(t, v, sz, x)) f.nm = x; else f.nm = 0; }
+        else if (t0 == 'N' && t1 == 'H') { f.has_nh = true; long x = 0; if (bam_tag_long(t, v, sz, x)) f.nh = x; else f.nh = 0; }
+        else if (t0 == 'Y' && t1 == 'T') f.yt_cp = text && sz == 3 && v[0] == 'C' && v[1] == 'P';
+        q += sz;
+    }
+    // CIGAR text
+    const unsigned char *cig = r + cig_at;
+    uint32_t nc = n_cig;
+    if (cg_items && n_cig > 0 && ref_id >= 0 && pos0 >= 0 && (ld32(cig) & 15) == 4 && (int64_t)(ld32(cig) >> 4) == (int64_t)l_seq) {
+        cig = cg_items;
+        nc = cg_n;
+    }
+    char *ct = arena.take(nc ? 11 * (size_t)nc + 1 : 2);
+    char *w = ct;
+    if (nc == 0) *w++ = '*';
+    for (uint32_t k = 0; k < nc; ++k) {
+        const uint32_t v = ld32(cig + 4 * k);
+        uint32_t n = v >> 4;
+        char d[12];
+        int nd = 0;
+        do { d[nd++] = (char)('0' + n % 10); n /= 10; } while (n);
+        while (nd) *w++ = d[--nd];
+        *w++ = (v & 15) < 9 ? CIG[v & 15] : '?';
+    }
+    *w = 0;
+    f.cigar = ct;
+    f.cigar_len = (uint32_t)(w - ct);
+    // SEQ text
+    if (l_seq == 0) {
+        char *st = arena.take(2);
+        st[0] = '*'; st[1] = 0;
+        f.seq = st;
+        f.seq_len = 1;
+    } else {
+        char *st = arena.take((size_t)l_seq + 1);
+        const unsigned char *sp = r + seq_at;
+        for (int32_t i = 0; i + 1 < l_seq; i += 2) {
+            const unsigned b = sp[i / 2];
+            st[i] = SEQ[b >> 4];
+            st[i + 1] = SEQ[b & 15];
+        }
+        if (l_seq & 1) st[l_seq - 1] = SEQ[sp[l_seq / 2] >> 4];
+        st[l_seq] = 0;
+        f.seq = st;
+        f.seq_len = (size_t)l_seq;
+    }
+    set_decode_key(f);
+    return true;
+}
+
 }   // namespace
 
 int hgx_build_alternatives(hgx_locus &L) {
@@ -1421,7 +1568,7 @@ void parallel_for(int n_threads, size_t n, F fn) {   // fn(thread, begin, end), 
 
 }   // namespace
 
-static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts);
+static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts, bool binary = false);
 
 // SAM text (name-grouped) -> private writable copy + line table -> parse_lines
 extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts) {
@@ -1472,10 +1619,10 @@ extern "C" int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *Lc, co
     try {
         const double t0 = now();
         hgx_align_lines al;                     // the reader's buffers are tokenised in place (no copy, no trip through the caller)
-        int rc = hgx_read_alignment_lines(path, regions, opts->n_threads, al);
+        int rc = hgx_read_alignment_lines(path, regions, opts->n_threads, al, /*keep_binary=*/true);
         if (rc) return rc;
         const double t1 = now();
-        rc = parse_lines(out, Lc, al.lines.data(), al.lines.size(), opts);
+        rc = parse_lines(out, Lc, al.lines.data(), al.lines.size(), opts, al.binary);
         if (prof) fprintf(stderr, "[hgx_parse_alignment_file] read %.1f ms, parse %.1f ms\n", (t1 - t0) * 1e3, (now() - t1) * 1e3);
         return rc;
     } catch (const std::exception &e) {
@@ -1484,8 +1631,9 @@ extern "C" int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *Lc, co
     }
 }
 
-// lines: name-grouped records; lines[i].p[lines[i].len] is writable (it becomes the record's terminator)
-static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts) {
+// lines: name-grouped records.  Text: lines[i].p[lines[i].len] is writable (it becomes the record's terminator).  Binary (BAM
+// records as read): lines[i].p = the record's QNAME (32 bytes into the record), lines[i].len = its block_size.
+static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts, bool binary) {
     HARGCHK(out && Lc && (lines || n == 0) && opts);
     hgx_locus &L = *const_cast<hgx_locus *>(Lc);
     hgx_batch *B = new hgx_batch();
@@ -1514,13 +1662,21 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
         Fields *recs = (Fields *)recs_mem.get();
         uint8_t *ok = (uint8_t *)ok_mem.get();
         // field split + decode keys, embarrassingly parallel over lines
-        parallel_for(n_threads, n, [&](int, size_t b, size_t e) {
+        std::vector<CharArena> arenas(binary ? n_threads : 0);
+        std::vector<int> bad_rec(n_threads, 0);
+        parallel_for(n_threads, n, [&](int t, size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
+                if (binary) {
+                    ok[i] = 1;
+                    if (!split_bam((const unsigned char *)lines[i].p - 32, lines[i].len, recs[i], arenas[t])) { bad_rec[t] = 1; return; }
+                    continue;
+                }
                 char *line = lines[i].p, *lend = line + lines[i].len;
                 *lend = 0;
                 ok[i] = split_line(line, lend, recs[i]) ? 1 : 0;
             }
         });
+        for (int v : bad_rec) if (v) { hgx_set_error("malformed BAM record"); delete B; return HGX_EPARSE; }
         lap("split");
         // chunks that start where the read id changes (the record filters and the pair protocol work inside them)
         const int n_chunks = n_threads == 1 ? 1 : n_threads * 4;

@@ -360,3 +360,46 @@ def test_readers_on_a_hand_assembled_bam(tmp_path):
         read_alignment_text(cut)
     with pytest.raises(Exception):
         bamio.read_bam(cut)
+
+
+def test_bam_record_chain_walked_in_ranges_is_exact(tmp_path, monkeypatch):
+    """Big BAM files have their record chain discovered in parallel: every worker but the first guesses a record start in its
+    byte range and the guesses are checked against the chain (hgx_bam.cpp).  (1) With the range walk forced on a fixture, the
+    record stream is the same as with one thread.  (2) A decoy: a record whose B:C tag holds a run of bytes that look like a
+    chain of valid records, placed over the range boundary -- the worker there synchronises on the decoy, the check notices,
+    and the result is still exactly the real records."""
+    import struct
+    from hisatgenotype_amd.typing import read_alignment_text
+    monkeypatch.setenv("HGX_BAM_CHAIN_MIN", "0")
+    fx = gu.load("hla_mid_real")
+    loc = fx["_locus"]
+    path = str(tmp_path / "mid.bam")
+    bamio.write_bam_native(path, fx["sam"], [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
+    one = read_alignment_text(path, n_threads=1)
+    for nt in (2, 3, 7, 16):
+        assert read_alignment_text(path, n_threads=nt) == one
+        assert read_alignment_text(path, [loc.ref_allele + ":1000-1400"], n_threads=nt) == read_alignment_text(path, [loc.ref_allele + ":1000-1400"], n_threads=1)
+    assert one == read_alignment_text(path, native=False)
+
+    def rec(qname, pos0, tags=b""):
+        body = struct.pack("<iiBBHHHiiii", 0, pos0, len(qname) + 1, 60, 4681, 1, 0, 4, -1, -1, 0) + qname.encode() + b"\0"
+        body += struct.pack("<I", (4 << 4) | 0) + bytes([0x12, 0x48]) + bytes([30, 30, 30, 30]) + tags
+        return struct.pack("<i", len(body)) + body
+    fake = rec("decoy", 7)                                    # a perfectly plausible record ... as payload bytes of a tag
+    decoy_tag = b"XBBC" + struct.pack("<I", 120 * len(fake)) + fake * 120
+    recs = [rec("a%d" % k, 10 + k) for k in range(3)] + [rec("big", 50, decoy_tag)] + [rec("z%d" % k, 90 + k) for k in range(3)]
+    head = b"BAM\x01" + struct.pack("<i", 0) + struct.pack("<i", 1) + struct.pack("<i", 5) + b"chr1\0" + struct.pack("<i", 1000)
+    stream = head + b"".join(recs)
+    out = b""
+    for o in range(0, len(stream), 3000):                     # several BGZF members
+        raw = stream[o:o + 3000]
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        d = c.compress(raw) + c.flush()
+        out += (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", len(d) + 25) + d +
+                struct.pack("<II", zlib.crc32(raw) & 0xffffffff, len(raw)))
+    dpath = str(tmp_path / "decoy.bam")
+    open(dpath, "wb").write(out + bamio._BGZF_EOF)
+    want = read_alignment_text(dpath, native=False)
+    assert want.count(b"\n") == 7 and b"decoy\t" not in want
+    for nt in (1, 2, 3, 4):
+        assert read_alignment_text(dpath, n_threads=nt) == want

@@ -1,0 +1,33 @@
+"""BAM (coordinate-sorted) -> typing result through hgx_type_file: phase profile on this host."""
+import ctypes as C, os, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import hisatgenotype_amd  # noqa
+from hisatgenotype_amd import capi, synth, bamio, locus as hl
+ht = sys.modules["hisatgenotype_amd.typing"]
+n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
+loc = synth.make_hla_like_locus(n_alleles=7000, n_vars=2500, seed=101)
+pl = hl.PackedLocus.from_synth(loc)
+pl.index()
+sample = synth.pick_sample(loc, 101)
+sam = synth.simulate_sam_fast(loc, sample, n_pairs, err_rate=0.002, seed=100)
+d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+path = os.path.join(d, "x.bam")
+t0 = time.time()
+bamio.write_bam_native(path, sam, [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
+print("native BAM writer: %.2f s, %.1f MB" % (time.time() - t0, os.path.getsize(path) / 1e6))
+n_reads = sam.count("\n")
+del sam
+L = capi.lib()
+for rep in range(4):
+    if rep == 3:
+        os.environ["HGX_PARSE_PROFILE"] = "1"
+    o = capi.ParseOpts(2, 1, 0, 0, 0, 0, 0, 0)
+    to = ht.TypeOpts(1, 0, -1, 0, None, None, None, None, None)
+    h = C.c_void_p()
+    t0 = time.perf_counter()
+    capi.check(L.hgx_type_file(C.byref(h), pl.h, pl.index(), path.encode(), pl.ref_allele.encode(), C.byref(o), C.byref(to), None))
+    dt = time.perf_counter() - t0
+    L.hgx_typing_destroy(h)
+    print("run %d: %.1f ms = %.2f M reads/s" % (rep, dt * 1e3, n_reads / dt / 1e6), flush=True)
+    time.sleep(0.3)
+os.remove(path)
