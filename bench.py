@@ -479,7 +479,9 @@ def main():
         #  k_piece_compat: n_words x a_pad x 4 index bytes read + one compat row written per distinct piece
         row = pl.a_pad // 8
         n_gene_refs = db.n_gene_refs
-        pc_bytes = n_gene_refs * row + 4 * batch.n_refs + 4 * (batch.n_pairs + 1) + batch.n_pairs * (row + 8)
+        # fused gene-level launch (hgx_pair_classes_dedup): the pairs' gene-level compat rows read, one representative row read
+        # per pair for the exact compare (in place of the row + hash the unfused form wrote), refs / offsets, slot index written
+        pc_bytes = n_gene_refs * row + 4 * batch.n_refs + 4 * (batch.n_pairs + 1) + batch.n_pairs * (row + 4)
         cp_bytes = db.sum_piece_words * pl.a_pad * 4 + batch.n_pieces * (row + 8) + db.sum_piece_words * 8
         pc_ms = sum(e[2].elapsed_ms(e[3]) for e in ev) / len(ev)
         cp_ms = sum(e[0].elapsed_ms(e[1]) for e in ev) / len(ev)

@@ -89,6 +89,15 @@ int hgx_pair_classes_sel(const hgx_index *ix, const uint64_t *compat, const int3
                          const int64_t *sel, int32_t n_pairs, uint64_t *eb, uint64_t *gb, uint64_t *eh,
                          uint64_t *gh, hipStream_t st);
 
+// fused gene-level form (hgx_device.hip): rows are claimed / verified against their class' representative by the wavefront
+// that computed them; hgx_dedup.hip (hgx_pair_classes_dedup) owns the table and turns it into a class set
+int hgx_pair_classes_fused_launch(const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off, const uint32_t *refs,
+                                  int32_t n_pairs, int32_t level, unsigned long long *keys, uint32_t tmask, uint32_t *rep,
+                                  uint32_t *slot_of, int *bad, uint64_t *rows, hipStream_t st);
+
+int hgx_pair_classes_dedup_ev(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off, const uint32_t *refs,
+                              int32_t n_pairs, int32_t level, uint64_t *rows_scratch, void *stream, void *ev_begin, void *ev_end);
+
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------

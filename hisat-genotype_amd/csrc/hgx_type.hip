@@ -216,6 +216,14 @@ int gene_side(const hgx_index *ix, const hgx_dbatch *db, const uint64_t *compat,
     int32_t A = 0, a_pad = 0;
     int rc = hgx_index_dims(ix, &A, &a_pad, nullptr, nullptr);
     if (rc) return rc;
+    if (!rows_ready && !getenv("HGX_NO_FUSED")) {
+        // rows claimed / verified against their class' representative by the wavefront that computes them: no row per pair in
+        // memory, no insert pass, no verify pass (hgx_pair_classes_dedup); a key collision falls through to the two-call form
+        rc = hgx_pair_classes_dedup_ev(&g.gcl, ix, compat, db->d_pair_off, db->d_pair_ref, db->n_pairs, HGX_LEVEL_GENE, gene_bits, st,
+                                       opts->ev_pairs_begin, opts->ev_pairs_end);
+        if (rc == HGX_OK) return gene_rank(g.gcl, A, a_pad, st, g);
+        if (rc != HGX_ECOLLISION) return rc;
+    }
     if (!rows_ready) {
         if (opts->ev_pairs_begin) HIPCHK(hipEventRecord((hipEvent_t)opts->ev_pairs_begin, st));
         rc = hgx_pair_classes(ix, compat, db->d_pair_off, db->d_pair_ref, db->n_pairs, nullptr, gene_bits, nullptr, gene_hash, st);

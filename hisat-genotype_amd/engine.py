@@ -171,6 +171,16 @@ class Classes:
         return Classes(h)
 
     @staticmethod
+    def of_pairs_fused(locus, dbatch, bufs, level, stream=None):
+        """Classes of one level from per-pair rows that never reach memory (hgx_pair_classes_dedup, after piece_compat)."""
+        rows = bufs.exon_bits if level == 0 else bufs.gene_bits
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_pair_classes_dedup(C.byref(h), locus.index(), capi.ptr(bufs.compat), capi.ptr(dbatch.pair_off),
+                                                      capi.ptr(dbatch.pair_ref), C.c_int32(dbatch.n_pairs), C.c_int32(level),
+                                                      capi.ptr(rows), stream))
+        return Classes(h)
+
+    @staticmethod
     def from_host(bits, counts, a_pad):
         bits = np.ascontiguousarray(bits, np.uint64)
         counts = np.ascontiguousarray(counts, np.int64)

@@ -194,6 +194,15 @@ int hgx_level_classes_grouped(hgx_classes **out, const hgx_index *ix, const uint
                               const int32_t *pair_off_dev, const uint32_t *pair_ref_dev, hgx_groups *groups,
                               uint64_t *rows_scratch_dev, uint64_t *hash_scratch_dev, void *stream);
 
+/* hgx_pair_classes + hgx_dedup_classes for ONE level without a class row per pair in memory: the wavefront that computes a
+ * pair's row (in registers) claims the row's slot in the class table itself -- the first row of a class is stored and published
+ * as the class' representative, every later one is compared with it word for word (the exact check) and never stored.
+ * rows_scratch_dev: [n_pairs][a_pad/64] (only representatives are written).  Same class set, counts, first pairs and order as
+ * the two-call form; a 64-bit key shared by DIFFERENT rows (never seen on real data) returns HGX_ECOLLISION and the caller uses
+ * the two-call form, which resolves collisions. */
+int hgx_pair_classes_dedup(hgx_classes **out, const hgx_index *ix, const uint64_t *compat_dev, const int32_t *pair_off_dev,
+                           const uint32_t *pair_ref_dev, int32_t n_pairs, int32_t level, uint64_t *rows_scratch_dev, void *stream);
+
 /* Gene_counts (typing_core.py:1187-1190, 1650-1651): per allele the number of pairs whose
  * class contains it, and the index of the first class (in first-seen order) containing it
  * (-1 if none) -- that is the dict insertion order used to break count ties.             */
