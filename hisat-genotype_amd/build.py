@@ -23,13 +23,25 @@ def _sources():
     return out
 
 
+def _headers():
+    return [os.path.join(ROOT, "include", "hgx.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+
+
+def _object_fresh(src, newest_header):
+    """An object is reused only if it is newer than its source AND every header (struct layouts are shared between units)."""
+    obj = src.rsplit(".", 1)[0] + ".o"
+    return os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src) and os.path.getmtime(obj) > newest_header
+
+
 def needs_build():
     if not os.path.exists(LIB):
         return True
+    newest_header = max(os.path.getmtime(h) for h in _headers())
     t = os.path.getmtime(LIB)
-    deps = _sources() + [os.path.join(ROOT, "include", "hgx.h")]
-    deps += [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
-    return any(os.path.getmtime(d) > t for d in deps)
+    for src in _sources():
+        if not _object_fresh(src, newest_header) or os.path.getmtime(src.rsplit(".", 1)[0] + ".o") > t:
+            return True
+    return False
 
 
 def build(force=False, verbose=True):
@@ -37,10 +49,10 @@ def build(force=False, verbose=True):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
+    newest_header = max(os.path.getmtime(h) for h in _headers())
     for src in _sources():
         obj = src.rsplit(".", 1)[0] + ".o"
-        if (not force and os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src)
-                and os.path.getmtime(obj) > os.path.getmtime(os.path.join(ROOT, "include", "hgx.h"))):
+        if not force and _object_fresh(src, newest_header):
             objs.append(obj)
             continue
         if src.endswith(".hip"):

@@ -546,8 +546,8 @@ __device__ __forceinline__ uint32_t fused_find_slot(const FusedArgs &fa, uint64_
     if (lane == 0) {
         uint32_t h = (uint32_t)key & fa.tmask;
         for (;;) {
-            const unsigned long long k = __hip_atomic_load(&fa.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k == key) break;
+            const unsigned long long k = fa.keys[h];            // plain (cached) load: a slot's key never changes once set, so a
+            if (k == key) break;                                 // stale EMPTY only costs the CAS below, which decides
             if (k == HGX_EMPTY_KEY) {
                 const unsigned long long old = atomicCAS(&fa.keys[h], (unsigned long long)HGX_EMPTY_KEY, (unsigned long long)key);
                 if (old == HGX_EMPTY_KEY) { w = 1; break; }

@@ -146,6 +146,15 @@ extern "C" int hgx_locus_create(hgx_locus **out, const hgx_locus_desc *d) {
         L->gene_mask[a >> 6] |= 1ull << (a & 63);
         if (L->rep_of[a] == a) L->exon_mask[a >> 6] |= 1ull << (a & 63);
     }
+    // exon groups as member lists (allele_rep_groups, core:86-115): the hand-off walks the groups of the leading representatives
+    L->grp_off.assign(A + 1, 0);
+    for (int a = 0; a < A; ++a) if (L->rep_of[a] >= 0) L->grp_off[L->rep_of[a] + 1]++;
+    for (int a = 0; a < A; ++a) L->grp_off[a + 1] += L->grp_off[a];
+    L->grp_member.assign(L->grp_off[A], 0);
+    {
+        std::vector<int32_t> at(L->grp_off.begin(), L->grp_off.end() - 1);
+        for (int a = 0; a < A; ++a) if (L->rep_of[a] >= 0) L->grp_member[at[L->rep_of[a]]++] = a;
+    }
     *out = L;
     return HGX_OK;
 }

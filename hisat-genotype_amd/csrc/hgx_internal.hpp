@@ -50,6 +50,7 @@ struct hgx_locus {
     std::vector<uint8_t> exonic;
     std::vector<int32_t> av_off, av_var;         // allele -> variants in gene_var_list order (core:476-487)
     std::vector<int32_t> rep_of;                 // allele -> representative allele or -1 (core:86-115)
+    std::vector<int32_t> grp_off, grp_member;    // CSR over representatives: members of allele a's exon group (empty unless a is a representative)
     std::vector<uint64_t> exon_mask, gene_mask;
     std::vector<uint32_t> link_bits;             // [n_words][a_pad]
     std::vector<uint32_t> linked_bits;           // [n_words] variants present in Links

@@ -216,9 +216,10 @@ int gene_side(const hgx_index *ix, const hgx_dbatch *db, const uint64_t *compat,
     int32_t A = 0, a_pad = 0;
     int rc = hgx_index_dims(ix, &A, &a_pad, nullptr, nullptr);
     if (rc) return rc;
-    if (!rows_ready && !getenv("HGX_NO_FUSED")) {
-        // rows claimed / verified against their class' representative by the wavefront that computes them: no row per pair in
-        // memory, no insert pass, no verify pass (hgx_pair_classes_dedup); a key collision falls through to the two-call form
+    if (!rows_ready && getenv("HGX_FUSED")) {
+        // OPT-IN (measured slower): rows claimed / verified against their class' representative by the wavefront
+        // that computes them -- no row per pair in memory, no insert pass, no verify pass (hgx_pair_classes_dedup); a key
+        // collision falls through to the two-call form
         rc = hgx_pair_classes_dedup_ev(&g.gcl, ix, compat, db->d_pair_off, db->d_pair_ref, db->n_pairs, HGX_LEVEL_GENE, gene_bits, st,
                                        opts->ev_pairs_begin, opts->ev_pairs_end);
         if (rc == HGX_OK) return gene_rank(g.gcl, A, a_pad, st, g);
@@ -285,25 +286,28 @@ int finish_hla(hgx_typing *t, const hgx_locus *loc, hgx_classes *ecl, const hgx_
     const int32_t A = loc->A;
     const int w64 = loc->a_pad / 64;
     int rc;
+    const bool prof = getenv("HGX_TYPE_PROFILE") != nullptr;
+    const double tp0 = now_s();
     rc = run_em(ecl, loc, opts->remove_low, nullptr, em_stream, t);                          // core:1732-1737
     if (rc) return rc;
+    const double tp1 = now_s();
     hgx_classes *gcl = nullptr;
     rc = gene_ready(&gcl);
     if (rc) return rc;
+    const double tp2 = now_s();
     const EmOut &e1 = t->em[0];
     // exon_alleles (core:1739-1749): the members of the exon groups of the leading representatives
     std::vector<uint8_t> in_exon((size_t)A, 0);
-    std::vector<int32_t> group_size((size_t)A, 0);
-    for (int32_t a = 0; a < A; ++a) if (loc->rep_of[a] >= 0) ++group_size[loc->rep_of[a]];
     double psum = 0.0;
     bool any = false;
     for (size_t i = 0; i < e1.allele.size(); ++i) {
         const int32_t a = e1.allele[i];
         const double p = e1.prob[i];
         if (i >= 10 && p < 0.03) break;
-        if (group_size[a] <= 1) continue;
+        const int32_t g0 = loc->grp_off[a], g1 = loc->grp_off[a + 1];       // members of a's exon group (precomputed per locus)
+        if (g1 - g0 <= 1) continue;
         psum += p;
-        for (int32_t m = 0; m < A; ++m) if (loc->rep_of[m] == a) { in_exon[m] = 1; any = true; }
+        for (int32_t k = g0; k < g1; ++k) { in_exon[loc->grp_member[k]] = 1; any = true; }
     }
     t->gene_prob = e1;
     if (any) {                                                                               // core:1752-1782
@@ -318,6 +322,8 @@ int finish_hla(hgx_typing *t, const hgx_locus *loc, hgx_classes *ecl, const hgx_
         if (!rc) rc = hgx_em_masked(gcl, mask.data(), A, 1, loc->allele_len.data(), prob2.data(), first2.data(), &it2, &ncls2, stream);
         t->t_em += now_s() - t0;
         if (rc) return rc;
+        if (prof) fprintf(stderr, "[finish_hla] EM#1 %.1f us | wait gene %.1f | exon_alleles+mask %.1f | EM#2 call %.1f\n", (tp1 - tp0) * 1e6,
+                          (tp2 - tp1) * 1e6, (t0 - tp2) * 1e6, (now_s() - t0) * 1e6);
         EmOut e2;
         e2.exact = hgx_em_last_exact() != 0;
         e2.n_classes = ncls2; e2.n_iter = it2; e2.remove_low = 1; e2.use_length = 1;
