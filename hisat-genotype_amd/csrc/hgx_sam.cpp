@@ -985,7 +985,7 @@ inline bool bam_tag_long(char t, const unsigned char *v, size_t avail, long &out
 
 // one BAM record (r = start of the record after its block_size word, len = block_size) -> Fields; false = malformed
 static bool split_bam(const unsigned char *r, size_t len, Fields &f, CharArena &arena) {
-    static const char CIG[] = "MIDNSHP=X", SEQ[] = "=ACMGRSVTWYHKDBN";
+    static const char CIG[] = "MIDNSHP=X";
     if (len < 32) return false;
     const int32_t ref_id = (int32_t)ld32(r), pos0 = (int32_t)ld32(r + 4);
     const uint32_t l_rn = r[8], n_cig = ld16(r + 12), flag = ld16(r + 14);
@@ -1074,14 +1074,13 @@ static bool split_bam(const unsigned char *r, size_t len, Fields &f, CharArena &
         f.seq = st;
         f.seq_len = 1;
     } else {
-        char *st = arena.take((size_t)l_seq + 1);
+        char *st = arena.take((size_t)l_seq + 2);
         const unsigned char *sp = r + seq_at;
-        for (int32_t i = 0; i + 1 < l_seq; i += 2) {
-            const unsigned b = sp[i / 2];
-            st[i] = SEQ[b >> 4];
-            st[i + 1] = SEQ[b & 15];
+        static const struct Pair { uint16_t t[256]; Pair() { for (int b = 0; b < 256; ++b) t[b] = (uint16_t)((unsigned char)"=ACMGRSVTWYHKDBN"[b >> 4] | ((unsigned char)"=ACMGRSVTWYHKDBN"[b & 15] << 8)); } } two;
+        for (int32_t i = 0; i < l_seq; i += 2) {            // one table look-up per packed byte = two bases (little endian store)
+            const uint16_t v = two.t[sp[i >> 1]];
+            memcpy(st + i, &v, 2);
         }
-        if (l_seq & 1) st[l_seq - 1] = SEQ[sp[l_seq / 2] >> 4];
         st[l_seq] = 0;
         f.seq = st;
         f.seq_len = (size_t)l_seq;
