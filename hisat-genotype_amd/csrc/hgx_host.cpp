@@ -303,13 +303,29 @@ void hgx_canonical_piece_order(hgx_batch &b, int n_threads, std::vector<uint32_t
             hash[i] = PieceTable::hash(b.pieces[i].lo_word, b.pieces[i].n_words, &b.masks[b.pieces[i].mask_off]);
         }
     });
-    std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    auto less = [&](uint32_t x, uint32_t y) {
         const hgx_piece &px = b.pieces[x], &py = b.pieces[y];
         if (px.lo_word != py.lo_word) return px.lo_word < py.lo_word;
         if (px.n_words != py.n_words) return px.n_words < py.n_words;
         if (hash[x] != hash[y]) return hash[x] < hash[y];
         return memcmp(&b.masks[px.mask_off], &b.masks[py.mask_off], 8 * (size_t)px.n_words) < 0;
-    });
+    };
+    if (n < 20000 || n_threads <= 1) std::sort(order.begin(), order.end(), less);
+    else {
+        // bucket by first word (a counting pass), then the buckets are sorted side by side
+        uint32_t max_lo = 0;
+        for (size_t i = 0; i < n; ++i) max_lo = std::max<uint32_t>(max_lo, b.pieces[i].lo_word);
+        std::vector<size_t> start((size_t)max_lo + 2, 0);
+        for (size_t i = 0; i < n; ++i) start[(size_t)b.pieces[i].lo_word + 1]++;
+        for (size_t k = 0; k + 1 < start.size(); ++k) start[k + 1] += start[k];
+        {
+            std::vector<size_t> at(start.begin(), start.end() - 1);
+            for (size_t i = 0; i < n; ++i) order[at[b.pieces[i].lo_word]++] = (uint32_t)i;
+        }
+        hgx_par_tasks(n_threads, (size_t)max_lo + 1, [&](int, size_t k) {
+            std::sort(order.begin() + start[k], order.begin() + start[k + 1], less);
+        });
+    }
     std::vector<hgx_piece> np(n);
     std::vector<uint32_t> nm(b.masks.size());
     size_t at = 0;

@@ -1247,7 +1247,6 @@ void group_records(const hgx_parse_opts &o, Fields *recs, const uint8_t *ok, siz
         for (size_t i = b; i < e; ++i)
             if (ok[i]) bucket[t][(recs[i].key >> 44) % P].push_back((uint32_t)i);
     });
-    std::vector<std::vector<uint32_t>> part_reps(P);
     hgx_par_tasks(T, (size_t)P, [&](int, size_t p) {
         size_t cnt = 0;
         for (int t = 0; t < T; ++t) cnt += bucket[t][p].size();
@@ -1277,18 +1276,25 @@ void group_records(const hgx_parse_opts &o, Fields *recs, const uint8_t *ok, siz
                 Fields &g = recs[r];
                 // pileup membership (common:1076-1090): aligned, inside the locus, concordant unless discordant pairs count
                 if (!(f.flag & 0x4) && f.pos - (o.base_locus + 1) >= 0 && (o.allow_discordant || (f.flag & 0x2))) g.n_pile++;
-                if (f.kept == KEPT_YES && g.slot == NO_SLOT) { g.slot = 0; part_reps[p].push_back(r); }
+                if (f.kept == KEPT_YES) g.slot = 0;                     // some kept record carries this key: it will be decoded
             }
         }
     });
-    // slots in stream order of their first record (so that a single worker creates novel variants in stream order)
-    size_t tot = 0;
-    for (auto &v : part_reps) tot += v.size();
-    reps.clear();
-    reps.reserve(tot);
-    for (auto &v : part_reps) reps.insert(reps.end(), v.begin(), v.end());
-    std::sort(reps.begin(), reps.end());
-    hgx_par_ranges(T, reps.size(), [&](int, size_t b, size_t e) { for (size_t k = b; k < e; ++k) recs[reps[k]].slot = (uint32_t)k; });
+    // slots = the keys to decode, numbered in stream order of their first record (so that a single worker creates novel variants
+    // in stream order): a flag per record, counted per range, prefix-summed -- no serial sort of a quarter of a million indices
+    std::vector<size_t> cnt_t(T + 1, 0);
+    hgx_par_ranges(T, n, [&](int t, size_t b, size_t e) {
+        size_t c = 0;
+        for (size_t i = b; i < e; ++i) c += ok[i] && recs[i].rep == i && recs[i].slot == 0;
+        cnt_t[t + 1] = c;
+    });
+    for (int t = 0; t < T; ++t) cnt_t[t + 1] += cnt_t[t];
+    reps.assign(cnt_t[T], 0);
+    hgx_par_ranges(T, n, [&](int t, size_t b, size_t e) {
+        size_t k = cnt_t[t];
+        for (size_t i = b; i < e; ++i)
+            if (ok[i] && recs[i].rep == i && recs[i].slot == 0) { recs[i].slot = (uint32_t)k; reps[k++] = (uint32_t)i; }
+    });
 }
 
 // decode result of record `f` (the first of its key): haplotypes with their pieces, into the worker's arena
