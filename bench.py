@@ -140,8 +140,19 @@ def cpu_baseline(loc, sam, n_pairs):
     t0 = time.perf_counter()
     r2 = rl2.run("\n".join(lines[:2 * n_py]) + "\n")
     t_py = time.perf_counter() - t0
+    recorded = None
+    try:                                   # the REAL reference's wall time on configs[0], recorded in the build container with its outputs
+        import gzip
+        with gzip.open(os.path.join(ROOT, "tests", "golden", "hla_7000_10k.json.gz"), "rb") as f:
+            rt = json.loads(f.read().decode())["reference_timing"]
+        recorded = {"reads_per_s": rt["records_per_s"], "seconds": rt["seconds"], "records": rt["sam_records"], "cpu": rt["cpu"],
+                    "cores": rt["cores_used"], "where": "build container, not this box (the reference is Python and cannot travel); "
+                                                        "first 5 000 pairs of this bench's read set; BASELINE.md section 4"}
+    except Exception:
+        pass
     return {
         "value": round(fe["num_reads"] / secs, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+        "reference_recorded": recorded,
         "sample": "first %d pairs (%d reads) of the same synthetic HLA-A read set; C oracle scoring %.2fs + dedup %.2fs + EM %.2fs "
                   "(%d outer iterations); front-end excluded on both sides" % (
                       n_pairs, fe["num_reads"], out["t_score"], out["t_dedup"], out["t_em"], out["n_iter"]),
