@@ -367,6 +367,16 @@ def hla_7000_10k():
 
 
 @scenario
+def codis_10k():
+    """BASELINE.json configs[4] shape through the reference's own CPU path, timed: one CODIS STR locus (D8S1179-like ladder),
+    10 k simulated 2x100 bp reads.  Lean fixture (SAM, EM call with its class dict, report) + the reference's wall time."""
+    loc = synth.make_str_like_locus(gene="D8S1179", unit="TCTA", max_repeats=19, min_repeats=7, flank=200, seed=908)
+    sample = ["D8S1179*10", "D8S1179*14"]
+    sam = synth.simulate_sam_fast(loc, sample, 5000, read_len=100, frag_len=(230, 270), err_rate=0.002, seed=48)
+    return dict(locus=loc, sample=sample, sam=sam, simulation=False, lean=True, read_len=100, frag_len=250)
+
+
+@scenario
 def codis_like():
     loc = synth.make_str_like_locus()
     sample = ["D8S1179*10", "D8S1179*13"]

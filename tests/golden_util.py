@@ -12,7 +12,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 ALL = ["hla_small_pair", "hla_small_single", "hla_errors_filters", "hla_mid_real", "hla_keep_low",
        "hla_single_end", "hla_novel_sample", "hla_insertions", "hla_7000", "codis_like", "codis_d18s51"]
 SMALL = [n for n in ALL if n != "hla_7000"]
-LEAN = ["hla_7000_10k"]      # BASELINE configs[0] at full size: SAM, EM calls (with their class dicts) and report only
+LEAN = ["hla_7000_10k", "codis_10k"]      # BASELINE configs[0] at full size: SAM, EM calls (with their class dicts) and report only
 
 
 @functools.lru_cache(maxsize=None)

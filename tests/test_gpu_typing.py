@@ -75,6 +75,25 @@ def test_config0_ten_thousand_reads_matches_reference():
     assert len([l for l in lines if "(count:" in l]) > 1000
 
 
+def test_codis_ten_thousand_reads_matches_reference():
+    """BASELINE configs[4]'s shape against the REAL reference (fixture `codis_10k`: one CODIS STR ladder, 10 k reads, recorded
+    with the reference's wall time): same class dict into the EM, bit-identical abundances (13 alleles: one wavefront in the
+    reference's order), same iteration count and the same report lines."""
+    fx = gu.load("codis_10k")
+    o = fx["options"]
+    pl = hl.PackedLocus.from_synth(fx["_locus"])
+    res = hgx.type_locus(pl, fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
+                         allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
+                         simulation=o["simulation"], keep_classes=True)
+    assert len(res.em) == len(fx["em"])
+    for got, exp in zip(res.em, fx["em"]):
+        assert got["n_classes"] == len(exp["cmpt"])
+        _check_em(got, exp["result"], exp["n_iter"], exact=True)
+    lines, _ = hgx.report_lines(res, False, (), True)
+    keep = lambda ls: [l for l in ls if "aligned" in l or "ranked" in l or "(count:" in l]
+    assert keep(lines) == keep(fx["report"].split("\n"))
+
+
 @pytest.mark.parametrize("name", ["hla_small_pair", "hla_mid_real", "codis_like"])
 def test_single_abundance_dropin(name):
     """hgx.single_abundance takes the reference's dict-of-strings and returns its list-of-lists."""

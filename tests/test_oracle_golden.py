@@ -136,3 +136,28 @@ def test_oracle_chain_on_the_10k_read_reference_run():
             exp.append((f[1], int(f[3].rstrip(")"))))
     assert [(names[a], int(gc[a])) for a in order] == exp and len(exp) > 1000
     assert fx["reference_timing"]["sam_records"] == 10000 and fx["reference_timing"]["seconds"] > 10
+
+
+def test_oracle_chain_on_the_codis_10k_reference_run():
+    """BASELINE configs[4]'s shape through the real reference (fixture `codis_10k`: one CODIS STR ladder, 10 k reads, timed): the
+    same oracle chain reproduces the reference's counts, its single EM call bit for bit, and the (allele, count) report lines."""
+    import oracle_util as ou
+    fx = gu.load("codis_10k")
+    loc = fx["_locus"]
+    out = ou.oracle_type(loc.to_json(), fx["sam"])
+    head = [l for l in fx["report"].split("\n") if "aligned" in l][0]
+    assert head.strip() == "%d reads and %d pairs are aligned" % (out["num_reads"], out["num_pairs"])
+    names = [n for n in loc.allele_names if "BACKBONE" not in n]
+    assert [(c, it) for c, it, _ in out["em"]] == [(len(e["cmpt"]), e["n_iter"]) for e in fx["em"]]
+    for (c, it, res), e in zip(out["em"], fx["em"]):
+        assert [[a, repr(float(p))] for a, p in res] == e["result"]
+    gc, fp = out["gene_counts"], out["first_pair"]
+    order = sorted([a for a in range(len(names)) if gc[a] > 0], key=lambda a: (fp[a], a))
+    order = sorted(order, key=lambda a: -gc[a])
+    exp = []
+    for l in fx["report"].split("\n"):
+        if "(count:" in l:
+            f = l.strip().split()
+            exp.append((f[1], int(f[3].rstrip(")"))))
+    assert [(names[a], int(gc[a])) for a in order] == exp and len(exp) == 13
+    assert fx["reference_timing"]["sam_records"] == 10000
