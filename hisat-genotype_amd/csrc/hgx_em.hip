@@ -15,7 +15,9 @@
 // The host enqueues iterations in batches without waiting: every kernel starts by reading a device-side
 // `done` word, so iterations queued past convergence fall through in a few microseconds.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 #include <hip/hip_ext.h>
@@ -1571,6 +1573,19 @@ __device__ __forceinline__ double lut_row(const double *T, const uint64_t (&w)[8
     }
     return acc;
 }
+// lut_row for matrix words that live in registers across many passes (k_em_grid): the words are passed through an empty
+// asm so that the compiler cannot hoist the 64 table addresses of a row out of the iteration loop (it did: 128 loop-invariant
+// VGPRs, spilled to scratch and re-loaded before every lookup)
+__device__ __forceinline__ double lut_row_resident(const double *T, const uint64_t (&w)[8]) {
+    uint64_t v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t lo = (uint32_t)w[i], hi = (uint32_t)(w[i] >> 32);
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        v[i] = (uint64_t)hi << 32 | lo;
+    }
+    return lut_row(T, v);
+}
 template <int MODE>
 __global__ __launch_bounds__(BLOCK) void k_lutmatvec(const uint64_t *__restrict__ M, int N, int Npad, int n_k,
                                                      const double *__restrict__ vec, const uint8_t *__restrict__ vec_pres,
@@ -2160,6 +2175,368 @@ __global__ void k_pk_unpack(const double *__restrict__ packed, int n, double *__
     p[i] = v >= 0.0 ? v : 0.0;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Resident-block EM (k_em_grid; opt-in with HGX_EM_GRID=1 -- measured, see the end of this comment).
+// The per-pass kernels above re-read the class matrix (L2 / Infinity Cache) 66 times per EM and pay a kernel boundary,
+// a launch ramp and five dependent memory round trips per pass.  Here the matrix is read ONCE: workgroup (i, j) of an
+// R x K grid keeps its block -- classes [1024 i, 1024 i + 1024) x alleles [512 j, 512 j + 512) -- in VGPRs in both
+// orientations (8 + 8 words per thread) for all iterations of the launch, and only vectors move:
+//   hop A (row group i: the K workgroups of a class chunk)   slab partials of s_c              [K][Cp]  -> w_c
+//   hop B (column group j: the R workgroups of an allele slab) partials of t_a per 512 classes [2R][A]  -> q_a of the slab
+//   hop C (row group i)                                        the slab's q_a                  [R][A]   -> the whole vector
+// Every hop is point to point inside a group of <= 64 workgroups: payload with device-scope (write-through) stores, the
+// storing waves' vmcnt(0), a workgroup barrier, ONE flag store per workgroup (the application's number); the consumer's
+// first wave polls its peers' flags (one lane per peer), joins a workgroup barrier, then everybody loads the payload with
+// device-scope loads (MI355X_MICROARCH.md, hand-off row 1).  No grid-wide barrier, no atomics.  Payload buffers are
+// double-buffered by application parity: a workgroup can be at most one application ahead of a peer of either group.
+// Arithmetic, element-to-thread maps and summation orders are those of k_lutmatvec / k_lut_rows_fused / k_em_init_norm
+// (slab partials added in slab order, vector reductions over element tid + 1024 k in register k): the estimate after
+// every iteration is BIT-IDENTICAL to the per-pass path's (tests/test_gpu_parity.py::test_em_grid_equals_per_pass).
+// Spins are bounded: a workgroup that never becomes resident turns into an abort flag and the host falls back.
+// Measured on MI355X (HGX_GRID_STAMPS=1 prints thread 0's wall_clock64() at the phase boundaries; C = 16 098, A' = 4 549,
+// 16 x 9 workgroups, alone on the chip): 26.9 us per application of the map = tables + lookups 4.0 (rows) and 8.6 (cols: two
+// tables in turn, half of the threads each), hop A 3.4 (publish 0.5, wait 1.0, nine partials per class 1.9), hop B 6.0
+// (0.6 / 1.5-3.3 / 2.4: 32 partials per allele), hop C + gather + vector step 6.3 -- against ~30 us for the two launches of
+// the per-pass path: the EM call takes 0.995 ms instead of 1.029 ms alone, but inside the typing step, beside the gene side's
+// bandwidth-bound kernels, the hand-offs slow down (the step: 2.27 ms against 2.11 ms).  Three all-to-all hand-offs per
+// application cost what two kernel boundaries with their prologues cost; keeping the matrix in registers does not pay because
+// the passes were never bound by reading it.  Kept as the measurement, and as the bit-exact cross-check of the per-pass path.
+// ------------------------------------------------------------------------------------------------------------
+struct GkArgs {
+    const uint64_t *Mr, *Mc;          // word-transposed matrices [w64c][Cp], [c64][A]
+    int C, Cp, A;                     // classes, padded classes (multiple of 512), compact padded alleles (multiple of 512)
+    int R, K;                         // class chunks of 1024, allele slabs of 512
+    const int64_t *count;
+    const double *len;
+    double *p;                        // estimate in / out
+    uint8_t *pr;
+    double *part_r, *part_c, *Y;      // [2][K][Cp], [2][Cp/512][A], [2][R][A]
+    unsigned *flags;                  // [3][R*K] words, 128 bytes apart, zero at launch
+    double *scal;
+    int *abort_flag;
+    int remove_low, n_iters, do_init;
+    unsigned long long *stamps;       // HGX_GRID_STAMPS=1: wall_clock64() of thread 0 at the phase boundaries, [R*K][GK_STAMPS]
+};
+constexpr int GK_STAMPS = 128;
+constexpr long GK_SPIN_LIMIT = 1500000;     // bounded spin (~0.5 s): an error code, never a hung GPU
+constexpr int GK_FLAG_STRIDE = 32;
+constexpr size_t GK_LDS = (size_t)(LUT_G * 256 + BLOCK) * 8;
+
+template <int EK>
+__global__ __launch_bounds__(BLOCK) void k_em_grid(GkArgs a) {
+    extern __shared__ double lds[];
+    double *T = lds;                        // [LUT_G][256]
+    double *xs = lds + LUT_G * 256;         // [BLOCK]
+    __shared__ double shf[3][NWAVE];
+    __shared__ double shm[NWAVE];
+    __shared__ int s_abort;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int K = a.K, R = a.R, G = R * K;
+    const int i = b / K, j = b - i * K;
+    const int n = i * BLOCK + tid;                              // my class (rows orientation)
+    const int half = tid >> 9;
+    const int e = j * LUT_SLAB + (tid & (LUT_SLAB - 1));        // my allele (cols orientation; vector steps: tid < 512)
+    const int nsc = a.Cp / LUT_SLAB;                            // 512-class slabs of the cols pass
+    const int cslab = 2 * i + half;
+    const bool cs_valid = cslab < nsc;
+    const bool slab_thread = tid < LUT_SLAB;
+    // ---- the block, once -------------------------------------------------------------------------------------
+    uint64_t wr[8], wc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wr[k] = n < a.Cp ? a.Mr[(size_t)(j * 8 + k) * a.Cp + n] : 0ull;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wc[k] = cs_valid ? a.Mc[(size_t)(cslab * 8 + k) * a.A + e] : 0ull;
+    const double cnt = n < a.C ? (double)a.count[n] : 0.0;
+    const double len_e = a.len ? a.len[e] : 1.0;
+    int iter = (int)a.scal[S_ITER];
+    if (a.scal[S_DONE] != 0.0) return;
+    unsigned epoch = 0;
+    double n_maps = 0.0;
+    int n_stamp = 0;
+    auto stamp = [&]() {
+        if (a.stamps && tid == 0 && n_stamp < GK_STAMPS) a.stamps[(size_t)b * GK_STAMPS + n_stamp++] = wall_clock64();
+    };
+    stamp();
+
+    auto publish = [&](int which) {
+        pk_flush();
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(&a.flags[((size_t)which * G + b) * GK_FLAG_STRIDE], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // true = abandon the launch
+    auto wait = [&](int which, bool row_group) -> bool {
+        if (tid < 64) {
+            const int np = row_group ? K : R;
+            const int peer = tid < np ? (row_group ? i * K + tid : tid * K + j) : b;
+            const unsigned *f = &a.flags[((size_t)which * G + peer) * GK_FLAG_STRIDE];
+            long spins = 0;
+            int ab = 0;
+            for (;;) {
+                const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool behind = tid < np && (int)(v - epoch) < 0;
+                if (__ballot(behind) == 0ull) break;
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > GK_SPIN_LIMIT) {
+                    if (tid == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ab = 1;
+                    break;
+                }
+                if ((spins & 63) == 0 && __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
+            }
+            if (tid == 0) s_abort = ab;
+        }
+        __syncthreads();
+        return s_abort != 0;
+    };
+
+    // One application of the EM map.  xv: my slab element of the vector the rows pass consumes (tid < 512), e_q / e_pres:
+    // the same element as the cols pass epilogue sees it (k_lutmatvec<COLS>: q_in, pres_in), tot: its S_TOT_A.
+    // Out: the whole result vector (element tid + 1024 k in vq[k], presence bit k of fq) and my slab element (eo, go).
+    auto apply = [&](double xv, double e_q, bool e_pres, double tot, bool init, double &eo, bool &go) -> bool {
+        ++epoch;
+        n_maps += 1.0;
+        const int par = (int)(epoch & 1u);
+        stamp();                                                   // 0: application starts
+        // rows pass over my block
+        if (slab_thread) xs[tid] = xv;
+        __syncthreads();
+        lut_build(xs, T, tid);
+        __syncthreads();
+        const double acc = lut_row_resident(T, wr);
+        double *part_r = a.part_r + (size_t)par * K * a.Cp;
+        if (n < a.Cp) pk_st(&part_r[(size_t)j * a.Cp + n], acc);
+        stamp();                                                   // 1: rows pass done
+        publish(0);
+        stamp();                                                   // 2: published
+        if (wait(0, true)) return true;
+        stamp();                                                   // 3: row group arrived
+        double w = 0.0;
+        if (n < a.C) {
+            double sp = 0.0;
+            for (int k0 = 0; k0 < K; k0 += 8) {       // eight loads in flight, added in slab order
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = k0 + k < K ? pk_ld(&part_r[(size_t)(k0 + k) * a.Cp + n]) : 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sp += v[k];
+            }
+            w = sp > 0.0 ? cnt / sp : 0.0;
+        }
+        xs[tid] = w;
+        stamp();                                                   // 4: w_c
+        // cols pass: my chunk's two 512-class slabs, one table at a time
+        double accc = 0.0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            __syncthreads();
+            if (2 * i + h < nsc) {
+                lut_build(xs + h * LUT_SLAB, T, tid);
+                __syncthreads();
+                if (half == h) accc = lut_row_resident(T, wc);
+            }
+        }
+        double *part_c = a.part_c + (size_t)par * nsc * a.A;
+        if (cs_valid) pk_st(&part_c[(size_t)cslab * a.A + e], accc);
+        stamp();                                                   // 5: cols pass done
+        publish(1);
+        stamp();                                                   // 6: published
+        if (wait(1, false)) return true;
+        stamp();                                                   // 7: column group arrived
+        double *Yp = a.Y + ((size_t)par * R + i) * a.A;
+        if (slab_thread) {
+            double t = 0.0;
+            for (int s0 = 0; s0 < nsc; s0 += 16) {          // sixteen loads in flight, added in slab order
+                double v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = s0 + k < nsc ? pk_ld(&part_c[(size_t)(s0 + k) * a.A + e]) : 0.0;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) t += v[k];
+            }
+            const bool in = init || e_pres;
+            double v = 0.0;
+            if (in && t > 0.0) {
+                v = init ? t : (e_q / tot) * t;
+                if (a.len) v = v / len_e;
+            }
+            eo = v;
+            go = in && t > 0.0;
+            pk_st(&Yp[e], go ? v : -1.0);
+        }
+        stamp();                                                   // 8: slab reduced
+        publish(2);
+        stamp();                                                   // 9: published
+        const bool ab = wait(2, true);
+        stamp();                                                   // 10: row group arrived
+        return ab;
+    };
+    // the whole result vector of application `ep` (the last one or the one before it: both parities are intact until this
+    // workgroup publishes again): element tid + 1024 k in vq[k], presence bit k of fq
+    auto gather = [&](unsigned ep, double (&vq)[EK], unsigned &fq) {
+        const double *Yp = a.Y + ((size_t)(ep & 1u) * R + i) * a.A;
+        double y[EK];
+#pragma unroll
+        for (int k = 0; k < EK; ++k) { const int al = tid + BLOCK * k; y[k] = al < a.A ? pk_ld(&Yp[al]) : -1.0; }
+        fq = 0u;
+#pragma unroll
+        for (int k = 0; k < EK; ++k) {
+            vq[k] = y[k] >= 0.0 ? y[k] : 0.0;
+            if (y[k] >= 0.0) fq |= 1u << k;
+        }
+    };
+
+    // only the estimate stays in registers across the applications; q1 / q2 / q3 are gathered when a vector step needs them
+    double vp[EK];
+    unsigned f0 = 0u;
+    double e0 = 0.0, e1 = 0.0, eb = 0.0;
+    bool g0 = false, g1 = false, gb = false;
+    if (a.do_init) {
+        // initial mass sum_c n_c / |S_c| (common:1299-1309), normalised as k_em_init_norm does
+        if (apply(1.0, 0.0, true, 1.0, true, e0, g0)) return;
+        gather(epoch, vp, f0);
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < EK; ++k) if (f0 >> k & 1u) s += vp[k];
+        const double tot = block_sum(s, shm);
+#pragma unroll
+        for (int k = 0; k < EK; ++k) vp[k] = (f0 >> k & 1u) ? vp[k] / tot : 0.0;
+        e0 = g0 ? e0 / tot : 0.0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < EK; ++k) {
+            const int al = tid + BLOCK * k;
+            const bool in = al < a.A;
+            vp[k] = in ? a.p[al] : 0.0;
+            if (in && a.pr[al]) f0 |= 1u << k;
+        }
+        if (slab_thread) { e0 = a.p[e]; g0 = a.pr[e] != 0; }
+    }
+    double st_flag = 0.0, st_diff = a.scal[S_DIFF], st_npres = a.scal[S_NPRES], st_key = 0.0, st_done = 0.0;
+    for (int it = 0; it < a.n_iters; ++it) {
+        // ---- q1 = T(p) (p used raw), q2 = T(q1 / sum q1) ----
+        if (apply(g0 ? e0 : 0.0, e0, g0, 1.0, false, e1, g1)) return;
+        double totn;
+        {
+            double vq[EK];
+            unsigned fq;
+            gather(epoch, vq, fq);
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < EK; ++k) if (fq >> k & 1u) s += vq[k];
+            totn = block_sum(s, shm);
+        }
+        if (apply((g1 ? e1 : 0.0) / totn, e1, g1, totn, false, eb, gb)) return;
+        double v1[EK], vb[EK];
+        unsigned f1, fb;
+        gather(epoch - 1u, v1, f1);
+        gather(epoch, vb, fb);
+        // ---- SQUAREM (common:1361-1380), arithmetic of k_em_squarem / k_lut_rows_fused<0> ----
+        double red[2] = {0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < EK; ++k) { if (f1 >> k & 1u) red[0] += v1[k]; if (fb >> k & 1u) red[1] += vb[k]; }
+        block_sum_n<2>(red, shf);
+        const double tot1 = red[0], tot2 = red[1];
+        double acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < EK; ++k) {
+            if (!(f0 >> k & 1u)) continue;
+            if (!(f1 >> k & 1u) || !(fb >> k & 1u)) { acc[2] = 1.0; continue; }
+            const double p1 = v1[k] / tot1, p2 = vb[k] / tot2;
+            const double r = p1 - vp[k];
+            const double v = p2 - p1 - r;
+            acc[0] += r * r;
+            acc[1] += v * v;
+        }
+        block_sum_n<3>(acc, shf);
+        const double tsr = acc[0], tsv = acc[1], tkey = acc[2];
+        const bool ext = tsv > 0.0 && tkey == 0.0;
+        st_flag = ext ? 1.0 : 0.0;
+        if (tkey != 0.0) { st_key = 1.0; st_done = 1.0; break; }
+        if (ext) {
+            const double g = -sqrt(tsr / tsv);
+            double val = eb;
+            bool present = gb;
+            if (g0) {
+                const double p1 = e1 / tot1, p2 = eb / tot2;
+                const double r = p1 - e0;
+                const double v = p2 - p1 - r;
+                val = fmax(0.0, e0 - 2 * g * r + g * g * v);
+                present = true;
+            }
+            if (apply(present ? val : 0.0, val, present, 1.0, false, eb, gb)) return;       // q3 = T(q2')
+            gather(epoch, vb, fb);
+        }
+        // ---- prob_diff (common:1272-1279), pruning (common:1338-1346), stopping rule (common:1351): k_em_advance ----
+        // the candidate is q3 if the extrapolation happened, else q1: from here on it is (vb, fb) / (eb, gb) either way
+        if (!ext) {
+#pragma unroll
+            for (int k = 0; k < EK; ++k) vb[k] = v1[k];
+            fb = f1; eb = e1; gb = g1;
+        }
+        double s1[1] = {0.0};
+#pragma unroll
+        for (int k = 0; k < EK; ++k) if (fb >> k & 1u) s1[0] += vb[k];
+        block_sum_n<1>(s1, shf);
+        const double tot = s1[0];
+        double d[1] = {0.0}, mx = 0.0;
+#pragma unroll
+        for (int k = 0; k < EK; ++k) {
+            const bool an = fb >> k & 1u;
+            const double pn = an ? vb[k] / tot : 0.0;
+            if (f0 >> k & 1u) d[0] += an ? fabs(vp[k] - pn) : vp[k];
+            if (an) mx = fmax(mx, pn);
+        }
+        const double tm = block_max(mx, shm);
+        block_sum_n<1>(d, shf);
+        const double td = d[0];
+        const bool prune = a.remove_low && iter >= 10;
+        double kept[1] = {0.0};
+        unsigned f_new = 0u;
+#pragma unroll
+        for (int k = 0; k < EK; ++k) {
+            const bool an = fb >> k & 1u;
+            const double pn = an ? vb[k] / tot : 0.0;
+            bool keep = an;
+            if (prune && keep) keep = pn >= tm / 10.0;
+            if (keep) { kept[0] += 1.0; f_new |= 1u << k; }
+            vp[k] = keep ? pn : 0.0;
+        }
+        f0 = f_new;
+        block_sum_n<1>(kept, shf);
+        {
+            const bool an = gb;
+            const double pn = an ? eb / tot : 0.0;
+            bool keep = an;
+            if (prune && keep) keep = pn >= tm / 10.0;
+            e0 = keep ? pn : 0.0;
+            g0 = keep;
+        }
+        st_npres = kept[0];
+        st_diff = td;
+        iter += 1;
+        if (!(td > 0.0001) || iter >= 1000) { st_done = 1.0; break; }
+    }
+    // ---- the state the following launches (tail, finish, another batch) read -----------------------------------
+    if (b == 0) {
+#pragma unroll
+        for (int k = 0; k < EK; ++k) {
+            const int al = tid + BLOCK * k;
+            if (al < a.A) { a.p[al] = vp[k]; a.pr[al] = (f0 >> k & 1u) ? 1 : 0; }
+        }
+        if (tid == 0) {
+            a.scal[S_ITER] = (double)iter;
+            a.scal[S_FLAG] = st_flag;
+            a.scal[S_DIFF] = st_diff;
+            a.scal[S_NPRES] = st_npres;
+            a.scal[S_TOT_A] = 1.0;
+            a.scal[S_NROWS] += n_maps;
+            a.scal[S_NCOLS] += n_maps;
+            if (st_key != 0.0) a.scal[S_KEYERR] = 1.0;
+            if (st_done != 0.0) a.scal[S_DONE] = 1.0;
+        }
+    }
+}
+
 // u64-element transpose: out[c][r] = in[r][c]  (in [n_rows][n_cols])
 __global__ __launch_bounds__(256) void k_word_transpose(const uint64_t *__restrict__ in, int n_rows, int n_cols,
                                                         uint64_t *__restrict__ out) {
@@ -2280,7 +2657,7 @@ __global__ void k_counts_out(const double *__restrict__ sum, const double *__res
 // Per-kernel timing for bench.py's roofline object.  When enabled (hgx_em_set_timing) every bit-mat-vec launch of
 // hgx_em is bracketed by HIP events on its stream; totals accumulate per kernel instantiation until reset.
 struct PassStats { double ms = 0; int64_t launches = 0, executed = 0, bytes = 0; };
-thread_local PassStats g_stats[4];   // [0] <8,ROWS> [1] <16,ROWS> [2] <8,COLS> [3] <16,COLS>
+thread_local PassStats g_stats[5];   // [0] <8,ROWS> [1] <16,ROWS> [2] <8,COLS> [3] <16,COLS> [4] k_em_grid (executed = applications)
 thread_local int g_timing = 0;
 struct Timed { hipEvent_t a, b; int slot; };
 thread_local std::vector<hipEvent_t> g_event_pool;     // recycled HIP events (creating one per launch is not free)
@@ -2443,6 +2820,7 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
 // 1 if the calling thread's last EM (hgx_em / hgx_em_ordered / hgx_em_masked) ran on the single-wavefront path in the reference's
 // own order of floating-point operations (its abundances are then the reference's, bit for bit), 0 otherwise
 static thread_local int g_last_exact = 0;
+static thread_local bool g_no_grid = false;      // set while an EM is re-run after a resident-block launch was abandoned
 extern "C" int hgx_em_last_exact(void) { return g_last_exact; }
 
 extern "C" int hgx_em_set_backend(int backend) {
@@ -2457,9 +2835,9 @@ extern "C" int hgx_em_set_timing(int on) {
     g_timing = on;
     return HGX_OK;
 }
-// slot: 0 <8,ROWS>, 1 <16,ROWS>, 2 <8,COLS>, 3 <16,COLS>
+// slot: 0 <8,ROWS>, 1 <16,ROWS>, 2 <8,COLS>, 3 <16,COLS>, 4 k_em_grid (whole launches; executed = applications of the EM map)
 extern "C" int hgx_em_get_timing(int slot, double *ms_total, int64_t *launches, int64_t *executed, int64_t *bytes_total) {
-    ARGCHK(slot >= 0 && slot < 4);
+    ARGCHK(slot >= 0 && slot < 5);
     if (ms_total) *ms_total = g_stats[slot].ms;
     if (launches) *launches = g_stats[slot].launches;
     if (executed) *executed = g_stats[slot].executed;
@@ -2775,6 +3153,48 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             return HGX_OK;
         }
     }
+    // ---- resident-block path (k_em_grid): the block grid must be co-resident, one workgroup per CU ----------------
+    static std::mutex grid_mu;                 // two resident grids at once could each hold half the CUs and wait forever
+    std::unique_lock<std::mutex> grid_lock(grid_mu, std::defer_lock);
+    GkArgs ga{};
+    DevBuf b_gpr, b_gpc, b_gy, b_gfl, b_gst;
+    bool grid = false;
+    if (rows.M && rows.defer_combine && A <= EPT * BLOCK && !g_no_grid && getenv("HGX_EM_GRID")) {
+        static int n_cu = 0, occ5 = 0, occ8 = 0;
+        if (!n_cu) {
+            int dev = 0;
+            HIPCHK(hipGetDevice(&dev));
+            hipDeviceProp_t prop;
+            HIPCHK(hipGetDeviceProperties(&prop, dev));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_grid<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GK_LDS));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_grid<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GK_LDS));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ5, k_em_grid<5>, BLOCK, GK_LDS));
+            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ8, k_em_grid<8>, BLOCK, GK_LDS));
+            n_cu = prop.multiProcessorCount;
+        }
+        const int Cp = c->c64 * 64;
+        ga.R = (Cp + BLOCK - 1) / BLOCK;
+        ga.K = A / LUT_SLAB;
+        const int occ = A <= 5 * BLOCK ? occ5 : occ8;
+        // a margin of CUs stays free for the other stream's kernels (and for a CU the runtime may have taken away)
+        if (occ >= 1 && ga.R <= 64 && ga.K <= 64 && ga.R * ga.K <= n_cu - 16 && grid_lock.try_lock()) {
+            const int G = ga.R * ga.K;
+            ALLOC(b_gpr, (size_t)2 * ga.K * Cp * 8); ALLOC(b_gpc, (size_t)2 * (Cp / LUT_SLAB) * A * 8); ALLOC(b_gy, (size_t)2 * ga.R * A * 8);
+            ALLOC(b_gfl, ((size_t)3 * G * GK_FLAG_STRIDE + 32) * 4);
+            ga.Mr = rows.M; ga.Mc = cols.M; ga.C = C; ga.Cp = Cp; ga.A = A;
+            ga.count = c->d_count; ga.len = d_len;
+            ga.part_r = b_gpr.as<double>(); ga.part_c = b_gpc.as<double>(); ga.Y = b_gy.as<double>();
+            ga.flags = b_gfl.as<unsigned>(); ga.abort_flag = (int *)(b_gfl.as<unsigned>() + (size_t)3 * G * GK_FLAG_STRIDE);
+            ga.remove_low = remove_low ? 1 : 0;
+            if (getenv("HGX_GRID_STAMPS")) {
+                ALLOC(b_gst, (size_t)G * GK_STAMPS * 8);
+                HIPCHK(hipMemsetAsync(b_gst.p, 0, (size_t)G * GK_STAMPS * 8, st));
+                ga.stamps = b_gst.as<unsigned long long>();
+            }
+            grid = true;
+        }
+    }
+    int grid_launches = 0;
     std::vector<Timed> timed;
     const int slot_rows = A <= 8 * BLOCK ? 0 : 1, slot_cols = C <= 8 * BLOCK ? 2 : 3;
     // timing: g_timing == 1 samples every 4th ungated rows pass of a call and the cols pass that follows it; g_timing == 2
@@ -2812,11 +3232,14 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         if (r) return r;
         return cols_pass(vec, pres_v, x_mode, q_out, pres_out, gate, stamping);
     };
-    // initial mass sum_c n_c / |S_c|, normalised (common:1299-1309)
-    rc = next_prob(p, pr, 2, p, pr, 0);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_em_init_norm, dim3(1), dim3(BLOCK), 0, st, p, pr, A);
+    // initial mass sum_c n_c / |S_c|, normalised (common:1299-1309); the resident-block kernel does it in its first launch
+    if (!grid) {
+        rc = next_prob(p, pr, 2, p, pr, 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_em_init_norm, dim3(1), dim3(BLOCK), 0, st, p, pr, A);
+    }
     double h_scal[S_N];
+    int h_abort = 0;
     std::vector<double> out(A);
     bool results_fetched = false;         // the speculative tail's results came back with its status word
     const int batch = 4;
@@ -2859,8 +3282,27 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             nb = std::min(batch, 11 - launched_iters);
             if (launched_iters == batch && h_scal[S_DIFF] > 0.001) nb = 11 - launched_iters;
         }
+        if (grid && use_tail && remove_low && launched_iters < 11) nb = 11 - launched_iters;    // no host sync inside: up to the first pruning
         launched_iters += nb;
-        for (int b = 0; b < nb; ++b) {
+        if (grid) {
+            const int G = ga.R * ga.K;
+            ga.p = p; ga.pr = pr; ga.scal = scal;
+            ga.n_iters = nb;
+            ga.do_init = grid_launches == 0 ? 1 : 0;
+            ++grid_launches;
+            HIPCHK(hipMemsetAsync(b_gfl.p, 0, ((size_t)3 * G * GK_FLAG_STRIDE + 32) * 4, st));
+            Timed t{nullptr, nullptr, 4};
+            if (g_timing) { t.a = pool_event(); t.b = pool_event(); timed.push_back(t); }
+            if (A <= 5 * BLOCK) {
+                if (t.a) hipExtLaunchKernelGGL(k_em_grid<5>, dim3(G), dim3(BLOCK), GK_LDS, st, t.a, t.b, 0, ga);
+                else hipLaunchKernelGGL(k_em_grid<5>, dim3(G), dim3(BLOCK), GK_LDS, st, ga);
+            } else {
+                if (t.a) hipExtLaunchKernelGGL(k_em_grid<8>, dim3(G), dim3(BLOCK), GK_LDS, st, t.a, t.b, 0, ga);
+                else hipLaunchKernelGGL(k_em_grid<8>, dim3(G), dim3(BLOCK), GK_LDS, st, ga);
+            }
+            HIPCHK(hipGetLastError());
+        }
+        for (int b = 0; b < (grid ? 0 : nb); ++b) {
             if (fuse) {
                 // six launches per iteration: SQUAREM and the advance step ride in the prologue of the rows pass that follows
                 if (b == 0) {
@@ -2895,7 +3337,56 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
         }
         { int rc_ = hgx_d2h(h_scal, scal, S_N * 8, st); if (rc_) return rc_; }
+        if (grid) { int rc_ = hgx_d2h(&h_abort, ga.abort_flag, 4, st); if (rc_) return rc_; }
         { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+        if (grid && ga.stamps && grid_launches == 1) {
+            // phase profile of the first launch: per workgroup, 11 stamps per application (see apply); printed as the mean over
+            // applications 2.. of the time between consecutive stamps, for the first, a middle and the last workgroup, and the
+            // maximum over all workgroups
+            const int G = ga.R * ga.K;
+            std::vector<unsigned long long> hs((size_t)G * GK_STAMPS);
+            (void)hipMemcpy(hs.data(), ga.stamps, hs.size() * 8, hipMemcpyDeviceToHost);
+            static const char *nm[11] = {"lut+rows", "publish A", "wait A", "sum A -> w", "cols (2 tables)", "publish B", "wait B",
+                                         "reduce B -> q", "publish C", "wait C", "gather + vector step"};
+            const int apps = (GK_STAMPS - 1) / 11;
+            fprintf(stderr, "[k_em_grid] %d x %d workgroups; us per phase (wg 0 | wg %d | wg %d | max over wgs), applications 2..%d\n",
+                    ga.R, ga.K, G / 2, G - 1, apps);
+            double tot[4] = {0, 0, 0, 0};
+            for (int ph = 0; ph < 11; ++ph) {
+                double v[4] = {0, 0, 0, 0};
+                for (int g = 0; g < G; ++g) {
+                    double sum = 0;
+                    int cnt = 0;
+                    for (int ap = 1; ap < apps; ++ap) {
+                        const unsigned long long t0 = hs[(size_t)g * GK_STAMPS + 1 + ap * 11 + ph];
+                        const unsigned long long t1 = ph < 10 ? hs[(size_t)g * GK_STAMPS + 1 + ap * 11 + ph + 1]
+                                                              : (ap + 1 < apps ? hs[(size_t)g * GK_STAMPS + 1 + (ap + 1) * 11] : 0);
+                        if (!t0 || !t1) continue;
+                        sum += (double)(t1 - t0) * 0.01;
+                        ++cnt;
+                    }
+                    const double m = cnt ? sum / cnt : 0.0;
+                    if (g == 0) v[0] = m;
+                    if (g == G / 2) v[1] = m;
+                    if (g == G - 1) v[2] = m;
+                    v[3] = std::max(v[3], m);
+                }
+                for (int k = 0; k < 4; ++k) tot[k] += v[k];
+                fprintf(stderr, "  %-22s %6.2f %6.2f %6.2f %6.2f\n", nm[ph], v[0], v[1], v[2], v[3]);
+            }
+            fprintf(stderr, "  %-22s %6.2f %6.2f %6.2f %6.2f\n", "application", tot[0], tot[1], tot[2], tot[3]);
+            unsigned long long first = ~0ull, last_start = 0;
+            for (int g = 0; g < G; ++g) { first = std::min(first, hs[(size_t)g * GK_STAMPS]); last_start = std::max(last_start, hs[(size_t)g * GK_STAMPS]); }
+            fprintf(stderr, "  first workgroup -> last workgroup started: %.2f us\n", (double)(last_start - first) * 0.01);
+        }
+        if (grid && h_abort) {
+            // a workgroup of the block grid never became resident (bounded spin): run this EM again, one launch per pass
+            grid_lock.unlock();
+            g_no_grid = true;
+            const int r = em_impl(cc, n_alleles, remove_low, allele_len, prob_host, first_host, n_iter_host, stream);
+            g_no_grid = false;
+            return r;
+        }
         if (spec_tail) {
             if (h_scal[S_TAIL] == 1.0) { tail_done = true; results_fetched = true; break; }
             if (h_scal[S_TAIL] == -1.0) tail_failed_at = h_scal[S_NPRES];
@@ -2925,9 +3416,14 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             g_event_pool.push_back(t.b);
         }
         // bytes describe the TIMED launches (all ungated: they did the full pass); executed = every pass of the call
-        for (auto &t : timed) g_stats[t.slot].bytes += t.slot == slot_rows ? rows_bytes : cols_bytes;
-        g_stats[slot_rows].executed += (int64_t)h_scal[S_NROWS];
-        g_stats[slot_cols].executed += (int64_t)h_scal[S_NCOLS];
+        if (grid) {       // SURVEY 8d's bytes of one application (both mat-vecs) x the applications the launches ran
+            g_stats[4].executed += (int64_t)h_scal[S_NROWS];
+            g_stats[4].bytes += (int64_t)h_scal[S_NROWS] * (rows_bytes + cols_bytes);
+        } else {
+            for (auto &t : timed) g_stats[t.slot].bytes += t.slot == slot_rows ? rows_bytes : cols_bytes;
+            g_stats[slot_rows].executed += (int64_t)h_scal[S_NROWS];
+            g_stats[slot_cols].executed += (int64_t)h_scal[S_NCOLS];
+        }
     }
     if (h_scal[S_KEYERR] != 0.0) {
         hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");

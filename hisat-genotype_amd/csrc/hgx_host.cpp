@@ -465,7 +465,57 @@ void hgx_host_pool_trim() {
 #include <atomic>
 #include <condition_variable>
 #include <thread>
+#include <pthread.h>
+#include <sched.h>
 namespace {
+// One hardware thread per core of the NUMA node the calling thread runs on (restricted to the process's affinity mask), or
+// an empty set.  The pool's workers are kept there: the text, the line table and the locus tables were first touched by the
+// caller, and two workers on one core's SMT siblings share its pipes.  HGX_PIN=0 leaves the workers unpinned.
+bool numa_node_cpus(cpu_set_t *out) {
+    CPU_ZERO(out);
+    if (const char *e = getenv("HGX_PIN")) if (atoi(e) == 0) return false;
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return false;
+    cpu_set_t allowed;
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return false;
+    for (int node = 0; node < 64; ++node) {
+        char path[96];
+        snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+        FILE *f = fopen(path, "r");
+        if (!f) { if (node == 0) return false; break; }
+        char buf[4096];
+        const bool ok = fgets(buf, sizeof(buf), f) != nullptr;
+        fclose(f);
+        if (!ok) continue;
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        bool mine = false;
+        for (char *q = buf; *q;) {                                   // "0-63,128-191"
+            char *end;
+            const long lo = strtol(q, &end, 10);
+            if (end == q) break;
+            long hi = lo;
+            q = end;
+            if (*q == '-') { hi = strtol(q + 1, &end, 10); q = end; }
+            for (long c = lo; c <= hi && c < CPU_SETSIZE; ++c) { CPU_SET((int)c, &set); if (c == cpu) mine = true; }
+            while (*q == ',' || *q == '\n' || *q == ' ') ++q;
+        }
+        if (!mine) continue;
+        // one hardware thread per core (the lowest-numbered sibling): two workers sharing a core's pipes gain little
+        int n = 0;
+        for (int c = 0; c < CPU_SETSIZE; ++c) {
+            if (!CPU_ISSET(c, &set) || !CPU_ISSET(c, &allowed)) continue;
+            snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+            long first = c;
+            if (FILE *g = fopen(path, "r")) { if (fscanf(g, "%ld", &first) != 1) first = c; fclose(g); }
+            if (first != c && CPU_ISSET((int)first, &allowed)) continue;
+            CPU_SET(c, out);
+            ++n;
+        }
+        return n >= 2;
+    }
+    return false;
+}
 struct WorkerPool {
     std::mutex owner;                      // one parallel phase at a time
     std::mutex mu;
@@ -476,6 +526,8 @@ struct WorkerPool {
     int want = 0;                          // workers 0 .. want-1 take part in the current phase (as ids 1 .. want)
     int running = 0;
     bool stopping = false;
+    bool pin_known = false, pin = false;   // workers stay on the NUMA node the first caller ran on
+    cpu_set_t pin_set;
 
     void loop(int id) {
         uint64_t seen = 0;
@@ -517,9 +569,11 @@ void hgx_run_workers(int n, const std::function<void(int)> &body) {
     }
     {
         std::lock_guard<std::mutex> g(P.mu);
+        if (!P.pin_known) { P.pin = numa_node_cpus(&P.pin_set); P.pin_known = true; }
         while ((int)P.workers.size() < n - 1) {
             const int id = (int)P.workers.size();
             P.workers.emplace_back([&P, id] { P.loop(id); });
+            if (P.pin) (void)pthread_setaffinity_np(P.workers.back().native_handle(), sizeof(P.pin_set), &P.pin_set);
         }
         P.body = &body;
         P.want = n - 1;

@@ -285,7 +285,8 @@ def em_get_timing():
     out = {}
     # slots 0/1 = rows pass (vector <= 8192 / larger), 2/3 = cols pass; the default (table-lookup) backend runs both sizes
     # with the same kernel, k_lutmatvec<0> / k_lutmatvec<1> in rocprofv3's naming
-    for name, slots in (("k_lutmatvec<0>", (0, 1)), ("k_lutmatvec<1>", (2, 3))):
+    # slot 4 = the resident-block EM (k_em_grid): whole launches; executed = applications of the EM map they ran
+    for name, slots in (("k_lutmatvec<0>", (0, 1)), ("k_lutmatvec<1>", (2, 3)), ("k_em_grid", (4,))):
         tot = [0.0, 0, 0, 0]
         for slot in slots:
             ms, n, ex, by = C.c_double(0), C.c_int64(0), C.c_int64(0), C.c_int64(0)

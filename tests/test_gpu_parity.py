@@ -534,6 +534,51 @@ def test_em_backends_agree(orc, name):
         engine.em_set_backend(0)
 
 
+def test_em_grid_equals_per_pass():
+    """The resident-block EM (k_em_grid, opt-in: matrix blocks in registers for the whole launch, point-to-point flagged hand-offs between
+    the workgroups of a class chunk / an allele slab) keeps the summation orders of the one-launch-per-pass kernels: abundances
+    BIT-identical, same iteration counts, over block grids from 1 x 1 to 17 x 14, ragged last chunks and slabs, with and
+    without pruning and allele lengths; a grid that does not fit the chip falls back to the per-pass path."""
+    import os
+    rng = np.random.RandomState(77)
+    shapes = [(70, 300, 512), (1100, 700, 1024), (2500, 1500, 1536), (3000, 7000, 7168), (9000, 2600, 3072), (17000, 7000, 7168),
+              (16098, 4549, 7168), (21000, 7000, 7168)]
+    ran_grid = 0
+    for C_, A, a_pad in shapes:
+        w = a_pad // 64
+        rows = np.zeros((C_, w), np.uint64)
+        # classes the way typing produces them: a few allele "families", every class a family minus/plus some alleles
+        fam = rng.rand(12, A) < rng.choice([0.02, 0.2, 0.7], size=12)[:, None]
+        pick = rng.randint(0, 12, C_)
+        flip = rng.rand(C_, A) < 0.01
+        m = fam[pick] ^ flip
+        m[np.arange(C_), rng.randint(0, A, C_)] = True
+        rows[:, :] = np.packbits(np.pad(m, ((0, 0), (0, a_pad - A))), axis=1, bitorder="little").view(np.uint64).reshape(C_, w)
+        counts = rng.randint(1, 400, C_).astype(np.int64)
+        lens = rng.randint(2000, 3500, a_pad).astype(np.int32)
+        cl = engine.Classes.from_host(rows, counts, a_pad)
+        for low, use_len in ((True, False), (False, True), (True, True)):
+            ln = lens if use_len else None
+            p_ref, it_ref = cl.em(A, low, ln)
+            engine.em_set_timing(0)
+            engine.em_set_timing(1)
+            os.environ["HGX_EM_GRID"] = "1"
+            try:
+                p, it = cl.em(A, low, ln)
+            finally:
+                os.environ.pop("HGX_EM_GRID", None)
+            launches = engine.em_get_timing()["k_em_grid"][1]
+            engine.em_set_timing(0)
+            ran_grid += launches > 0
+            assert it == it_ref, (C_, A, low, use_len, it, it_ref)
+            assert np.array_equal(p, p_ref), (C_, A, low, use_len, float(np.max(np.abs(p - p_ref))))
+            if C_ > 64 and C_ <= 17000:
+                assert launches > 0, (C_, A)
+            if C_ == 21000:
+                assert launches == 0
+    assert ran_grid >= 15
+
+
 def _level_equals_per_pair(pl, batch, collided=False):
     db = engine.DeviceBatch(batch)
     bufs = engine.ScoreBuffers(pl, db)
