@@ -326,8 +326,8 @@ void hgx_canonical_piece_order(hgx_batch &b, int n_threads, std::vector<uint32_t
             std::sort(order.begin() + start[k], order.begin() + start[k + 1], less);
         });
     }
-    std::vector<hgx_piece> np(n);
-    std::vector<uint32_t> nm(b.masks.size());
+    PVec<hgx_piece> np(n);
+    PVec<uint32_t> nm(b.masks.size());
     size_t at = 0;
     for (size_t k = 0; k < n; ++k) {
         const hgx_piece &src = b.pieces[order[k]];

@@ -92,20 +92,6 @@ struct TraceRec {
     std::string text;
 };
 
-struct hgx_batch {
-    std::vector<hgx_piece> pieces;
-    std::vector<uint32_t> masks;
-    std::vector<int32_t> pair_off{0};
-    std::vector<uint32_t> pair_ref;
-    int32_t n_reads = 0;
-    PieceTable table;
-    std::vector<TraceRec> trace;
-    std::vector<uint8_t> nt_set;        // [L] 4-bit masks
-    std::vector<uint32_t> counts;       // [L][6]
-};
-
-// piece "left-ids-right" -> index of the distinct piece in the batch (creates it if new). < 0 on error.
-int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &loc, int32_t left, int32_t right, const int32_t *ids, int32_t n_ids);
 // Host block pool (hgx_host.cpp): the ingestion path allocates and drops several buffers of hundreds of MB per sample; handing
 // them back to the kernel (munmap) and faulting fresh pages in costs more than the work done on them.  Blocks >= 1 MB are kept
 // and reused (best fit within 2x); hgx_pool_trim() releases them.
@@ -123,6 +109,24 @@ struct HostPoolAlloc {
     template <class U> bool operator!=(const HostPoolAlloc<U> &) const { return false; }
 };
 typedef std::basic_string<char, std::char_traits<char>, HostPoolAlloc<char>> PString;
+// vectors of a batch: MBs each, handed back with every sample.  With 30+ threads in the process an munmap is a round of TLB
+// shoot-down interrupts: destroying one batch took 5-6 ms of a 65 ms file -> result call before its arrays came from the pool.
+template <class T> using PVec = std::vector<T, HostPoolAlloc<T>>;
+
+struct hgx_batch {
+    PVec<hgx_piece> pieces;
+    PVec<uint32_t> masks;
+    PVec<int32_t> pair_off{0};
+    PVec<uint32_t> pair_ref;
+    int32_t n_reads = 0;
+    PieceTable table;
+    std::vector<TraceRec> trace;
+    std::vector<uint8_t> nt_set;        // [L] 4-bit masks
+    std::vector<uint32_t> counts;       // [L][6]
+};
+
+// piece "left-ids-right" -> index of the distinct piece in the batch (creates it if new). < 0 on error.
+int64_t hgx_intern_piece(hgx_batch &b, const hgx_locus &loc, int32_t left, int32_t right, const int32_t *ids, int32_t n_ids);
 
 // Persistent host worker pool (hgx_host.cpp): body(worker) runs on `n` threads (worker 0 = the caller) and the call returns when
 // all are done.  The helpers below cut [0, n_items) into contiguous ranges / hand out task indices dynamically.

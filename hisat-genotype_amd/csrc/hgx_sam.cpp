@@ -1190,8 +1190,8 @@ struct DecodeWorker {
     std::vector<uint32_t> refs;      // exon-level piece ids of the arena's haplotypes
 };
 struct ChunkOut {
-    std::vector<uint32_t> pair_ref;
-    std::vector<int32_t> pair_off{0};
+    PVec<uint32_t> pair_ref;
+    PVec<int32_t> pair_off{0};
     int32_t n_reads = 0;
     std::vector<TraceRec> trace;
     std::string error;
@@ -1298,13 +1298,27 @@ void group_records(const hgx_parse_opts &o, Fields *recs, const uint8_t *ok, siz
 }
 
 // decode result of record `f` (the first of its key): haplotypes with their pieces, into the worker's arena
+// HGX_DECODE_PROF (compile-time): cycle counters of decode_one's stages, printed by parse_lines under HGX_PARSE_PROFILE
+#ifdef HGX_DECODE_PROF
+#include <x86intrin.h>
+static thread_local unsigned long long g_dprof[4];
+#define PROF_T(v) const unsigned long long v = __rdtsc()
+#define PROF_ADD(k, v) g_dprof[k] += __rdtsc() - v
+#else
+#define PROF_T(v)
+#define PROF_ADD(k, v)
+#endif
 void decode_one(Parser &P, const hgx_locus &L, const hgx_parse_opts &o, const Fields &f, uint32_t widx, DecodeWorker &W, MateOut &out,
                 std::string &read, std::vector<Cmp> &cl, std::vector<Cmp> &c2, std::vector<Parser::AltSide> &lset,
                 std::vector<Parser::AltSide> &rset, std::vector<int> &mid, std::vector<Ht> &ex, std::vector<int32_t> &ids) {
     try {
         const int pos = f.pos - (o.base_locus + 1);
+        PROF_T(t0);
         read.assign(f.seq, f.seq_len);
-        if (!P.decode(pos, f.cigar, read, f.zs, f.md, cl)) { out.state = 2; return; }
+        const bool kept = P.decode(pos, f.cigar, read, f.zs, f.md, cl);
+        PROF_ADD(0, t0);
+        if (!kept) { out.state = 2; return; }
+        PROF_T(t1);
         // cmp_list2 (core:1351-1368)
         c2.clear();
         for (const Cmp &c : cl) {
@@ -1316,8 +1330,12 @@ void decode_one(Parser &P, const hgx_locus &L, const hgx_parse_opts &o, const Fi
                 else c2.push_back(Cmp{T_MATCH, c.pos, 1, -2});
             } else c2.push_back(c);
         }
+        PROF_ADD(1, t1);
+        PROF_T(t2);
         int cleft, cright;
         P.ambiguous(c2, cleft, cright, lset, rset);
+        PROF_ADD(2, t2);
+        PROF_T(t3);
         mid.clear();
         for (int k = cleft; k <= cright; ++k)
             if (c2[k].type != T_MATCH) mid.push_back(c2[k].id);
@@ -1357,6 +1375,7 @@ void decode_one(Parser &P, const hgx_locus &L, const hgx_parse_opts &o, const Fi
             }
         out.n = (uint32_t)W.arena.size() - out.first;
         out.state = 1;
+        PROF_ADD(3, t3);
         if (o.keep_trace) {
             std::string t;
             for (size_t k = 0; k < c2.size(); ++k) {
@@ -1784,6 +1803,11 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
                 for (size_t blk; (blk = next.fetch_add(1)) < n_blocks;)
                     for (size_t k = blk * BLOCK; k < std::min(reps.size(), (blk + 1) * BLOCK); ++k)
                         decode_one(P, L, *opts, recs[reps[k]], (uint32_t)w, W, outs[k], read, cl, c2, lset, rset, mid, ex, ids);
+#ifdef HGX_DECODE_PROF
+                if (prof && w == 0)
+                    fprintf(stderr, "[decode_one, worker 0] Mcycles: decode %.1f | cmp_list2 %.1f | ambiguous %.1f | haplotypes + intern %.1f\n",
+                            g_dprof[0] / 1e6, g_dprof[1] / 1e6, g_dprof[2] / 1e6, g_dprof[3] / 1e6);
+#endif
             });
         }
         lap("decode distinct keys");
@@ -1824,6 +1848,16 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
         for (auto &r : res)
             for (auto &t : r.trace) B->trace.push_back(std::move(t));
         lap("pair protocol");
+        // tear-down side by side: the workers' arenas hold a heap block per haplotype (hundreds of thousands of frees), the
+        // chunk results MBs each -- serially, at scope exit, that was ~5 ms of the call
+        hgx_par_tasks(n_threads, workers.size() + res.size(), [&](int, size_t k) {
+            if (k < workers.size()) { DecodeWorker dead; std::swap(dead, workers[k]); }
+            else { ChunkOut dead; std::swap(dead, res[k - workers.size()]); }
+        });
+        hgx_par_ranges(outs.size() > 50000 ? n_threads : 1, outs.size(), [&](int, size_t lo, size_t hi) {
+            for (size_t k = lo; k < hi; ++k) { std::string a, b; a.swap(outs[k].err); b.swap(outs[k].trace); }
+        });
+        lap("tear-down");
     } catch (const RefError &e) {
         hgx_set_error("the reference would fail on this input: %s", e.what());
         delete B;

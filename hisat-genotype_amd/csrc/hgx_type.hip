@@ -545,10 +545,16 @@ extern "C" int hgx_type_file(hgx_typing **out, const hgx_locus *loc, const hgx_i
     ARGCHK(out && loc && ix && path && popts && opts);
     *out = nullptr;
     hgx_batch *b = nullptr;
+    const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
+    const double t0 = now_s();
     int rc = hgx_parse_alignment_file(&b, loc, path, regions, popts);
     if (rc) return rc;
+    const double t1 = now_s();
     rc = hgx_type_batch(out, loc, ix, b, opts, stream);
+    const double t2 = now_s();
     hgx_batch_destroy(b);
+    if (prof) fprintf(stderr, "[hgx_type_file] front end %.1f ms (incl. releasing the reader's buffers), upload + GPU + result %.1f ms, batch destroy %.1f ms\n",
+                      (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
     return rc;
 }
 

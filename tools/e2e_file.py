@@ -1,6 +1,6 @@
 """File -> typing result through ONE C call (hgx_type_file): phase profile and thread scaling on this host.
 usage: python tools/e2e_file.py [pairs] [threads ...]"""
-import ctypes as C, os, sys, tempfile, time
+import ctypes as C, os, resource, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hisatgenotype_amd  # noqa
 from hisatgenotype_amd import capi, synth, locus as hl
@@ -25,10 +25,15 @@ for nt in threads:
         o = capi.ParseOpts(2, 1, 0, 0, 0, 0, 0, nt)
         to = ht.TypeOpts(1, 0, -1, 0, None, None, None, None, None)
         h = C.c_void_p()
+        r0 = resource.getrusage(resource.RUSAGE_SELF)
         t0 = time.perf_counter()
         capi.check(L.hgx_type_file(C.byref(h), pl.h, pl.index(), path.encode(), pl.ref_allele.encode(), C.byref(o), C.byref(to), None))
         dt = time.perf_counter() - t0
+        r1 = resource.getrusage(resource.RUSAGE_SELF)
+        cpu = (r1.ru_utime - r0.ru_utime, r1.ru_stime - r0.ru_stime)
         L.hgx_typing_destroy(h)
         os.environ.pop("HGX_PARSE_PROFILE", None)
-    print("threads %3d: %.1f ms end to end = %.2f M reads/s" % (nt, dt * 1e3, n_reads / dt / 1e6), flush=True)
+    print("threads %3d: %.1f ms end to end = %.2f M reads/s; CPU time of the call %.0f ms user + %.0f ms system" % (
+        nt, dt * 1e3, n_reads / dt / 1e6, cpu[0] * 1e3, cpu[1] * 1e3), flush=True)
+    time.sleep(0.5)
 os.remove(path)
