@@ -1791,7 +1791,9 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
             const size_t BLOCK = 128;
             const size_t n_blocks = (reps.size() + BLOCK - 1) / BLOCK;
             std::atomic<size_t> next{0};
+            std::vector<double> busy(n_dec, 0.0);
             hgx_run_workers(n_dec, [&](int w) {
+                const double tb = prof ? now() : 0.0;
                 DecodeWorker &W = workers[w];
                 Parser P(L, *opts, W.table, *B, alts, novel);
                 std::string read;
@@ -1803,12 +1805,18 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
                 for (size_t blk; (blk = next.fetch_add(1)) < n_blocks;)
                     for (size_t k = blk * BLOCK; k < std::min(reps.size(), (blk + 1) * BLOCK); ++k)
                         decode_one(P, L, *opts, recs[reps[k]], (uint32_t)w, W, outs[k], read, cl, c2, lset, rset, mid, ex, ids);
+                if (prof) busy[w] = now() - tb;
 #ifdef HGX_DECODE_PROF
                 if (prof && w == 0)
                     fprintf(stderr, "[decode_one, worker 0] Mcycles: decode %.1f | cmp_list2 %.1f | ambiguous %.1f | haplotypes + intern %.1f\n",
                             g_dprof[0] / 1e6, g_dprof[1] / 1e6, g_dprof[2] / 1e6, g_dprof[3] / 1e6);
 #endif
             });
+            if (prof) {
+                double lo = 1e30, hi = 0, sum = 0;
+                for (double v : busy) { lo = std::min(lo, v); hi = std::max(hi, v); sum += v; }
+                fprintf(stderr, "[hgx_parse_sam]   decode workers: %d, busy %.1f .. %.1f ms each, %.0f ms in all\n", n_dec, lo * 1e3, hi * 1e3, sum * 1e3);
+            }
         }
         lap("decode distinct keys");
         // the workers' piece tables -> one table in canonical order; final_id[w][local id] = id in the batch

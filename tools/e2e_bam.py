@@ -29,5 +29,5 @@ for rep in range(4):
     dt = time.perf_counter() - t0
     L.hgx_typing_destroy(h)
     print("run %d: %.1f ms = %.2f M reads/s" % (rep, dt * 1e3, n_reads / dt / 1e6), flush=True)
-    time.sleep(0.3)
+    time.sleep(0.4)
 os.remove(path)
