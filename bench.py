@@ -192,9 +192,9 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
     """File -> typing result through ONE C call (hgx_type_file): read (pread / BGZF inflate / BAM decode / name grouping),
     front-end, upload, GPU path, result on the host.  SAM text as an aligner writes it (grouped by read) and BAM as the
     reference's pipeline stores it (`samtools sort`: by coordinate), both from the page cache.  Two regimes after one warm-up
-    call: `runs` calls back to back (steady state of a sample stream: the host side is CPU-TIME bound, a container's CPU quota
-    throttles it -- `throttled_ms` is what the cgroup reports for those calls) and `runs` calls 0.3 s apart (one sample at a
-    time: the call's own latency, quota untouched).  `reads_per_s` / `ms` are the BACK-TO-BACK median, the conservative one."""
+    call: `runs` calls 0.3 s apart (one sample at a time: the call's own latency -- `reads_per_s` / `ms`, the median) and `runs`
+    calls back to back (`back_to_back`: a sample stream; the host side is CPU-TIME bound there and a container's CPU quota
+    throttles it -- `throttled_ms` is the time the cgroup reports the process frozen during those calls)."""
     import ctypes as C
     import resource
     import tempfile
@@ -249,13 +249,13 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
             med = sorted(times)[len(times) // 2]
             med_s = sorted(spaced)[len(spaced) // 2]
             cpu_s = (ru1.ru_utime + ru1.ru_stime - ru0.ru_utime - ru0.ru_stime) / runs
-            out[kind] = {"reads_per_s": round(res.num_reads / med, 1), "ms": round(med * 1e3, 2), "best_ms": round(min(times) * 1e3, 2),
-                         "runs_ms": [round(t * 1e3, 1) for t in times],
-                         "throttled_ms": None if th0 is None else round((th1 - th0) / 1e3, 1),
+            out[kind] = {"reads_per_s": round(res.num_reads / med_s, 1), "ms": round(med_s * 1e3, 2), "best_ms": round(min(spaced) * 1e3, 2),
+                         "runs_ms": [round(t * 1e3, 1) for t in spaced],
+                         "throttled_ms": None if th1 is None else round((th2 - th1) / 1e3, 1),
                          "cpu_seconds_per_call": round(cpu_s, 3),
-                         "one_at_a_time": {"reads_per_s": round(res.num_reads / med_s, 1), "ms": round(med_s * 1e3, 2),
-                                           "runs_ms": [round(t * 1e3, 1) for t in spaced],
-                                           "throttled_ms": None if th1 is None else round((th2 - th1) / 1e3, 1)},
+                         "back_to_back": {"reads_per_s": round(res.num_reads / med, 1), "ms": round(med * 1e3, 2),
+                                          "runs_ms": [round(t * 1e3, 1) for t in times],
+                                          "throttled_ms": None if th0 is None else round((th1 - th0) / 1e3, 1)},
                          "file_MB": round(os.path.getsize(path) / 1e6, 1),
                          "records_in_file": n_records, "result_identical_to_hbm_path": bool(same)}
     finally:
@@ -263,11 +263,11 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
         shutil.rmtree(d, ignore_errors=True)
     quota = cgroup_cpu_quota()
     out["host"] = {"hw_threads": os.cpu_count(), "cgroup_cpu_quota": quota,
-                   "front_end_threads": "2 x quota" if quota else "all hardware threads"}
+                   "front_end_threads": "2.5 x quota" if quota else "all hardware threads"}
     out["note"] = ("hgx_type_file per call: file (page cache) -> typing result on the host, H2D and the GPU path included; "
-                   "reads_per_s / ms = median of %d BACK-TO-BACK calls after a warm-up (a sample stream: bound by the CPU seconds "
-                   "the container's cgroup grants -- %s CPUs, whatever the number of hardware threads; throttled_ms = time the "
-                   "cgroup froze the process during those calls); one_at_a_time = the same call 0.3 s apart (its own latency)."
+                   "reads_per_s / ms = median of %d calls 0.3 s apart after a warm-up (the call's own latency); back_to_back = the "
+                   "same calls without a pause (a sample stream: bound by the CPU seconds the container's cgroup grants -- %s CPUs, "
+                   "whatever the number of hardware threads; throttled_ms = time the cgroup froze the process during those calls)."
                    % (runs, "%.0f" % quota if quota else "all"))
     return out
 
