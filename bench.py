@@ -263,7 +263,7 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
         shutil.rmtree(d, ignore_errors=True)
     quota = cgroup_cpu_quota()
     out["host"] = {"hw_threads": os.cpu_count(), "cgroup_cpu_quota": quota,
-                   "front_end_threads": "2.5 x quota" if quota else "all hardware threads"}
+                   "front_end_threads": "2 x quota" if quota else "all hardware threads"}
     out["note"] = ("hgx_type_file per call: file (page cache) -> typing result on the host, H2D and the GPU path included; "
                    "reads_per_s / ms = median of %d calls 0.3 s apart after a warm-up (the call's own latency); back_to_back = the "
                    "same calls without a pause (a sample stream: bound by the CPU seconds the container's cgroup grants -- %s CPUs, "

@@ -590,9 +590,11 @@ void hgx_run_workers(int n, const std::function<void(int)> &body) {
 // ---- how many host threads a parallel phase should use ---------------------------------------------------------------
 // hardware_concurrency() reports the machine; a container is often confined to far less CPU TIME by a cgroup bandwidth quota
 // (cpu.max / cpu.cfs_quota_us): with a quota of 16 CPUs, 256 runnable threads exhaust a 100 ms period's budget in 6 ms and
-// are then all throttled until the next period -- measured here: every phase got SLOWER beyond 32 threads.  Default = 2.5 x
-// the quota (a call of ~40 ms may burst above the long-run rate: one box, six calls each, 0.4 s apart: 32 threads 45-57 ms,
-// 40 threads 40-45 ms, 48 threads 38-50 ms), at most the hardware threads; HGX_THREADS overrides.
+// are then all throttled until the next period -- measured here: every phase got SLOWER beyond 32 threads.  Default = twice
+// the quota: a call may burst above the long-run rate, but not past one period's budget -- with 2.5 x (40 threads) the SAM call
+// got faster (one box, six calls each, 0.4 s apart: 45-57 ms at 32 threads, 40-45 ms at 40) and the BAM call, whose 1.5 CPU-seconds
+// became 1.8 with the extra threads, crossed the 1.6 CPU-seconds a period grants and was frozen inside every call (88 -> 119 ms);
+// at most the hardware threads; HGX_THREADS overrides.
 #include <cstdio>
 #include <cstdlib>
 int hgx_default_threads() {
@@ -613,7 +615,7 @@ int hgx_default_threads() {
             if (quota > 0 && period > 0) quota_cpus = (double)quota / (double)period;
         }
         int n = hw;
-        if (quota_cpus > 0) n = std::min(hw, std::max(1, (int)(2.5 * quota_cpus + 0.5)));
+        if (quota_cpus > 0) n = std::min(hw, std::max(1, (int)(2.0 * quota_cpus + 0.5)));
         return std::min(n, 512);
     }();
     return cached;
