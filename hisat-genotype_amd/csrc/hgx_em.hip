@@ -1258,6 +1258,356 @@ __global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Mid-size EM in the REFERENCE'S OWN ORDER (k_em_ref): <= MR_C classes over <= MR_A distinct alleles in ONE workgroup.
+// Same contract as ref_em_run (bit-identical abundances, same pruning and stopping decisions) for problems that do not fit one
+// wavefront: thread j = the j-th allele in name order (= class-key order), classes in dict order.  Per application of the map
+//   rows   thread c walks the members of class c in key order:            alleles_prob += prob[a]            (sequential)
+//   cols   thread j walks the classes containing allele j in dict order:  next[a] += count * prob[a] / alleles_prob
+//          (the quotients of up to four classes are formed side by side, then added in order)
+//   dict insertion order of `next` = (first walked class containing the allele, key order) -- re-derived (an LDS bitonic sort)
+//          only when the membership or the set of walked classes changed
+//   sums over a dict (normalisation totals, SQUAREM sums, prob_diff) = ONE lane adding in insertion order: that is what
+//          `sum(d.values())` does, and no faster order gives the same bits
+// The class matrix is re-laid once per call in the compact name-ordered allele space, both orientations (Rm, Km: L2-resident
+// scratch).  Cost: ~10-40 us per SQUAREM iteration against ~100 us for the six launches of the table-lookup path at these sizes,
+// and the result is the reference's bit for bit.  Follows oracle/hgx_oracle.c orc_single_abundance line by line.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int MR_A = 1024, MR_C = 2048;
+constexpr int MR_AW = MR_A / 64, MR_CW = MR_C / 64;
+struct MrLds {
+    double dv[3][MR_A];                 // dict values
+    double tmp[2][MR_A];                // operands of the sequential sums
+    double s[MR_C], n[MR_C];            // alleles_prob and count per class
+    double len[MR_A];
+    unsigned long long valid[MR_CW];    // classes walked by the current application (alleles_prob > 0)
+    unsigned long long sig_in[MR_AW], sig_valid[MR_CW];     // membership / walked classes of the cached insertion order
+    unsigned long long in_now[MR_AW];
+    uint32_t keys[MR_A];
+    int sorted[MR_A];                   // allele id of thread j
+    uint16_t seq[4][MR_A];              // insertion orders (allele threads in dict order)
+    int npos[4];
+    uint8_t din[3][MR_A];               // dict membership
+    double red[NWAVE];
+    double bc[2];                       // broadcast slots of the sequential sums
+    int cache_ord, flag;
+};
+
+#pragma clang fp contract(off)
+// sum of val[j] over the members of the dict (membership `in`) in insertion order `seq`: one lane, eight loads in flight
+__device__ __forceinline__ double mr_seq_sum(const uint16_t *seq, int np, const double *val, const uint8_t *in) {
+    double t = 0.0;
+    int r = 0;
+    for (; r + 8 <= np; r += 8) {
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int j = seq[r + k]; x[k] = in[j] ? val[j] : 0.0; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t = ((t) + (x[k]));          // + 0.0 for a pruned member: exact
+    }
+    for (; r < np; ++r) { const int j = seq[r]; if (in[j]) t = ((t) + (val[j])); }
+    return t;
+}
+__device__ __forceinline__ void mr_seq_sum2(const uint16_t *seq, int np, const double *va, const double *vb, const uint8_t *in,
+                                            double &ta, double &tb) {
+    ta = 0.0; tb = 0.0;
+    int r = 0;
+    for (; r + 4 <= np; r += 4) {
+        double x[4], y[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int j = seq[r + k]; const bool m = in[j] != 0; x[k] = m ? va[j] : 0.0; y[k] = m ? vb[j] : 0.0; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ta = ((ta) + (x[k])); tb = ((tb) + (y[k])); }
+    }
+    for (; r < np; ++r) { const int j = seq[r]; if (in[j]) { ta = ((ta) + (va[j])); tb = ((tb) + (vb[j])); } }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B, int C, int n_words, int a_pad,
+                                                  const int64_t *__restrict__ count, const double *__restrict__ len,
+                                                  const int32_t *__restrict__ rank, int remove_low, uint64_t *__restrict__ Rm,
+                                                  uint64_t *__restrict__ Km, double *__restrict__ out, double *__restrict__ scal,
+                                                  int32_t *__restrict__ first_out) {
+    extern __shared__ double lds_raw[];
+    MrLds &S = *reinterpret_cast<MrLds *>(lds_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int Cw = (C + 63) / 64;
+    // ---- which alleles occur at all; their name order ---------------------------------------------------------
+    unsigned long long *orw2 = reinterpret_cast<unsigned long long *>(S.tmp[0]);        // (scratch until the EM starts)
+    for (int w = tid; w < n_words; w += BLOCK) orw2[w] = 0ull;
+    __syncthreads();
+    {
+        const int w = tid & 127, slice = tid >> 7;      // 8 slices of the classes per word
+        unsigned long long acc = 0ull;
+        if (w < n_words) for (int c = slice; c < C; c += 8) acc |= B[(size_t)c * n_words + w];
+        if (acc) atomicOr(&orw2[w], acc);
+    }
+    __syncthreads();
+    int *base_of = reinterpret_cast<int *>(S.tmp[1]);   // exclusive prefix of the words' bit counts
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < n_words; ++w) { base_of[w] = t; t += __popcll(orw2[w]); }
+        S.flag = t;
+    }
+    __syncthreads();
+    const int A1 = S.flag;
+    if (A1 > MR_A || A1 == 0) {
+        if (tid == 0) { scal[S_FALLBACK] = 1.0; scal[S_DONE] = 1.0; }
+        return;
+    }
+    const int A1w = (A1 + 63) / 64;
+    for (int w = tid; w < n_words; w += BLOCK) {
+        int id = base_of[w];
+        for (unsigned long long m = orw2[w]; m; m &= m - 1) S.sorted[id++] = 64 * w + __builtin_ctzll(m);
+    }
+    __syncthreads();
+    // name order: bitonic sort of (rank, allele id) over MR_A slots (rank < 2^21 alleles, id < 8192 = 2^13)
+    {
+        unsigned long long *sk = reinterpret_cast<unsigned long long *>(S.tmp[0]);       // orw2 is dead from here on
+        const int g0 = tid < A1 ? S.sorted[tid] : 0;
+        __syncthreads();
+        sk[tid] = tid < A1 ? ((unsigned long long)(uint32_t)rank[g0] << 32 | (uint32_t)g0) : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= MR_A; k <<= 1)
+            for (int j2 = k >> 1; j2 > 0; j2 >>= 1) {
+                const int p = tid ^ j2;
+                if (p > tid) {
+                    const unsigned long long a = sk[tid], b = sk[p];
+                    const bool up = (tid & k) == 0;
+                    if ((a > b) == up) { sk[tid] = b; sk[p] = a; }
+                }
+                __syncthreads();
+            }
+        const int g1 = (int)(uint32_t)sk[tid];
+        __syncthreads();
+        S.sorted[tid] = tid < A1 ? g1 : 0;
+    }
+    __syncthreads();
+    const int g = S.sorted[tid];
+    const bool alive = tid < A1;
+    // ---- the class matrix in the compact, name-ordered allele space: Rm [C][A1w] (members of a class), Km [A1][Cw] --------
+    for (int item = wave; item < C * A1w; item += NWAVE) {
+        const int c = item / A1w, w = item - c * A1w;
+        const int j = 64 * w + lane;
+        const int gj = j < A1 ? S.sorted[j] : 0;
+        const bool bit = j < A1 && ((B[(size_t)c * n_words + (gj >> 6)] >> (gj & 63)) & 1ull);
+        const unsigned long long word = __ballot(bit);
+        if (lane == 0) Rm[(size_t)c * A1w + w] = word;
+    }
+    for (int item = wave; item < A1 * Cw; item += NWAVE) {
+        const int j = item / Cw, w = item - j * Cw;
+        const int c = 64 * w + lane;
+        const int gj = S.sorted[j];
+        const bool bit = c < C && ((B[(size_t)c * n_words + (gj >> 6)] >> (gj & 63)) & 1ull);
+        const unsigned long long word = __ballot(bit);
+        if (lane == 0) Km[(size_t)j * Cw + w] = word;
+    }
+    for (int c = tid; c < MR_C; c += BLOCK) S.n[c] = c < C ? (double)count[c] : 0.0;
+    const bool use_len = len != nullptr;
+    S.len[tid] = (use_len && alive) ? len[g] : 1.0;
+    for (int a = tid; a < a_pad; a += BLOCK) out[a] = -1.0;
+    __threadfence_block();
+    __syncthreads();                                     // Rm / Km were written by this workgroup: visible after the barrier
+    const uint64_t *Kme = Km + (size_t)(alive ? tid : 0) * Cw;
+    if (first_out && alive) {
+        int fc = -1;
+        for (int w = 0; w < Cw && fc < 0; ++w) { const uint64_t m = Kme[w]; if (m) fc = 64 * w + __builtin_ctzll(m); }
+        first_out[g] = fc;
+    }
+    const double my_len = S.len[tid];
+
+    // ---- helpers ---------------------------------------------------------------------------------------------------
+    auto block_max_exact = [&](double v) -> double {
+        v = wave_max_f64(v);
+        __syncthreads();
+        if (lane == 0) S.red[wave] = v;
+        __syncthreads();
+        double t = S.red[0];
+#pragma unroll
+        for (int i = 1; i < NWAVE; ++i) t = fmax(t, S.red[i]);
+        return t;
+    };
+    // insertion order of dict d when it is filled class by class over the classes of `walk` (NULL = all): (first class, key order)
+    auto derive_order = [&](int d, const unsigned long long *walk, int buf) {
+        uint32_t key = 0xFFFFFFFFu;
+        if (alive && S.din[d][tid]) {
+            int fc = MR_C;
+            for (int w = 0; w < Cw && fc == MR_C; ++w) { const uint64_t m = Kme[w] & (walk ? walk[w] : ~0ull); if (m) fc = 64 * w + __builtin_ctzll(m); }
+            key = (uint32_t)fc << 10 | (uint32_t)tid;
+        }
+        S.keys[tid] = key;
+        __syncthreads();
+        for (int k = 2; k <= MR_A; k <<= 1)
+            for (int j2 = k >> 1; j2 > 0; j2 >>= 1) {
+                const int p = tid ^ j2;
+                if (p > tid) {
+                    const uint32_t a = S.keys[tid], b = S.keys[p];
+                    const bool up = (tid & k) == 0;
+                    if ((a > b) == up) { S.keys[tid] = b; S.keys[p] = a; }
+                }
+                __syncthreads();
+            }
+        const uint32_t kk = S.keys[tid];
+        S.seq[buf][tid] = (uint16_t)(kk & 1023u);
+        const int cnt = __syncthreads_count(kk != 0xFFFFFFFFu);
+        if (tid == 0) S.npos[buf] = cnt;
+        __syncthreads();
+    };
+    auto normalize = [&](int d, int ord) {                 // common:1285-1297
+        const double mine = use_len ? ((S.dv[d][tid]) / (my_len)) : S.dv[d][tid];
+        S.tmp[0][tid] = mine;
+        __syncthreads();
+        if (tid == 0) S.bc[0] = mr_seq_sum(S.seq[ord], S.npos[ord], S.tmp[0], S.din[d]);
+        __syncthreads();
+        const double total = S.bc[0];
+        if (alive && S.din[d][tid]) S.dv[d][tid] = ((mine) / (total));
+        __syncthreads();
+    };
+    int ord_of[3] = {0, 0, 0};
+    // Gene_prob_next (common:1311-1336): dict P -> dict N (N != P)
+    auto next_prob = [&](int P, int N, int live_a, int live_b) {
+        for (int c = tid; c < C; c += BLOCK) {             // rows: alleles_prob of class c, members in key order
+            double sc = 0.0;
+            const uint64_t *row = Rm + (size_t)c * A1w;
+            for (int w = 0; w < A1w; ++w)
+                for (uint64_t m = row[w]; m; m &= m - 1) {
+                    const int j = 64 * w + __builtin_ctzll(m);
+                    if (S.din[P][j]) sc = ((sc) + (S.dv[P][j]));
+                }
+            S.s[c] = sc;
+        }
+        __syncthreads();
+        for (int w = wave; w < Cw; w += NWAVE) {
+            const int c = 64 * w + lane;
+            const unsigned long long bm = __ballot(c < C && S.s[c] > 0.0);     // classes with alleles_prob <= 0 are skipped
+            if (lane == 0) S.valid[w] = bm;
+        }
+        __syncthreads();
+        double acc = 0.0;
+        bool any = false;
+        const bool pin = alive && S.din[P][tid];
+        if (pin) {                                         // cols: += count * prob / alleles_prob over the walked classes, dict order
+            const double vj = S.dv[P][tid];
+            for (int w = 0; w < Cw; ++w) {
+                uint64_t m = Kme[w] & S.valid[w];
+                any = any || m != 0ull;
+                while (m) {
+                    int cc[4];
+                    double q[4];
+                    int nq = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (m) { cc[k] = 64 * w + __builtin_ctzll(m); m &= m - 1; nq = k + 1; } else cc[k] = cc[0];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q[k] = ((((S.n[cc[k]]) * (vj))) / (S.s[cc[k]]));
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k < nq) acc = ((acc) + (q[k]));
+                }
+            }
+        }
+        const bool nin = pin && any;
+        S.dv[N][tid] = nin ? acc : 0.0;
+        S.din[N][tid] = nin ? 1 : 0;
+        // insertion order: unchanged unless the membership or the walked classes changed since it was last derived
+        const unsigned long long inb = __ballot(nin);
+        if (lane == 0) S.in_now[wave] = inb;
+        __syncthreads();
+        bool differ = S.cache_ord < 0;
+        if (tid < MR_AW) differ = differ || S.in_now[tid] != S.sig_in[tid];
+        if (tid < Cw) differ = differ || S.valid[tid] != S.sig_valid[tid];
+        const int changed = __syncthreads_or(differ);
+        int ord;
+        if (!changed) ord = S.cache_ord;
+        else {
+            ord = 0;
+            while (ord == live_a || ord == live_b) ++ord;  // a buffer no live dict refers to (4 buffers, <= 2 live besides N)
+            derive_order(N, S.valid, ord);
+            if (tid < MR_AW) S.sig_in[tid] = S.in_now[tid];
+            if (tid < MR_CW) S.sig_valid[tid] = tid < Cw ? S.valid[tid] : 0ull;
+            if (tid == 0) S.cache_ord = ord;
+            __syncthreads();
+        }
+        ord_of[N] = ord;
+        normalize(N, ord);
+    };
+    auto select_alleles = [&](int d) {                     // common:1338-1346
+        const bool in = alive && S.din[d][tid];
+        const double mx = block_max_exact(in ? S.dv[d][tid] : 0.0);
+        if (in && !(S.dv[d][tid] >= ((mx) / (10.0)))) { S.din[d][tid] = 0; S.dv[d][tid] = 0.0; }
+        __syncthreads();
+    };
+
+    // ---- initial estimate (common:1300-1309): prob[a] += count / |class| over the classes in dict order ---------------
+    if (tid == 0) S.cache_ord = -1;
+    for (int c = tid; c < C; c += BLOCK) {                 // |class| into s[]
+        int nal = 0;
+        for (int w = 0; w < A1w; ++w) nal += __popcll(Rm[(size_t)c * A1w + w]);
+        S.s[c] = (double)nal;
+    }
+    __syncthreads();
+    int prob = 0, next = 1, next2 = 2;
+    {
+        double acc = 0.0;
+        bool any = false;
+        if (alive)
+            for (int w = 0; w < Cw; ++w)
+                for (uint64_t m = Kme[w]; m; m &= m - 1) {
+                    const int c = 64 * w + __builtin_ctzll(m);
+                    acc = ((acc) + (((S.n[c]) / (S.s[c]))));
+                    any = true;
+                }
+        S.dv[prob][tid] = acc;
+        S.din[prob][tid] = (alive && any) ? 1 : 0;
+        __syncthreads();
+        derive_order(prob, nullptr, 3);
+        ord_of[prob] = 3;
+        normalize(prob, 3);
+    }
+    double diff = 1.0;
+    int iter = 0;
+    bool keyerr = false;
+    while (diff > 0.0001 && iter < 1000) {                 // common:1351
+        next_prob(prob, next, ord_of[prob], -1);
+        next_prob(next, next2, ord_of[prob], ord_of[next]);
+        const bool pin = alive && S.din[prob][tid];
+        if (__syncthreads_or(pin && (!S.din[next][tid] || !S.din[next2][tid]))) { keyerr = true; break; }      // the reference's KeyError (Q6)
+        const double pv0 = S.dv[prob][tid];
+        const double p_r = ((S.dv[next][tid]) - (pv0));
+        const double p_v = ((((S.dv[next2][tid]) - (S.dv[next][tid]))) - (p_r));
+        S.tmp[0][tid] = ((p_r) * (p_r));
+        S.tmp[1][tid] = ((p_v) * (p_v));
+        __syncthreads();
+        if (tid == 0) mr_seq_sum2(S.seq[ord_of[prob]], S.npos[ord_of[prob]], S.tmp[0], S.tmp[1], S.din[prob], S.bc[0], S.bc[1]);
+        __syncthreads();
+        const double ssr = S.bc[0], ssv = S.bc[1];
+        __syncthreads();
+        if (ssv > 0.0) {                                   // common:1370-1383
+            const double gamma = -sqrt(((ssr) / (ssv)));
+            if (pin) {
+                const double x = ((((pv0) - (((((2.0) * (gamma))) * (p_r))))) + (((((gamma) * (gamma))) * (p_v))));
+                S.dv[next2][tid] = 0.0 > x ? 0.0 : x;
+            }
+            __syncthreads();
+            next_prob(next2, next, ord_of[prob], ord_of[next2]);
+        }
+        S.tmp[0][tid] = (alive && S.din[next][tid]) ? fabs(((pv0) - (S.dv[next][tid]))) : pv0;      // prob_diff, common:1272-1279
+        __syncthreads();
+        if (tid == 0) S.bc[0] = mr_seq_sum(S.seq[ord_of[prob]], S.npos[ord_of[prob]], S.tmp[0], S.din[prob]);
+        __syncthreads();
+        diff = S.bc[0];
+        __syncthreads();
+        { const int t = prob; prob = next; next = t; }     // prob = next (common:1387)
+        if (iter >= 10 && remove_low) select_alleles(prob);
+        iter += 1;
+    }
+    if (!keyerr) {
+        if (remove_low) select_alleles(prob);              // common:1402-1407
+        normalize(prob, ord_of[prob]);
+        if (alive && S.din[prob][tid]) out[g] = S.dv[prob][tid];
+    }
+    if (tid == 0) { scal[S_ITER] = (double)iter; scal[S_KEYERR] = keyerr ? 1.0 : 0.0; scal[S_DONE] = 1.0; }
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------------------------------------------------
 // Compact tail of a big EM.  Once pruning (common:1338-1346) has left <= 64 alleles in the estimate -- alleles never
 // come back -- every class collapses to a 64-bit mask over the survivors, classes with equal masks merge (their counts
 // add exactly) and, if <= 64 distinct masks remain, the rest of the EM runs on ONE wavefront (wave_em_run) in this
@@ -2921,6 +3271,55 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = h_first[a];
             if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
             g_last_exact = b_rank.p != nullptr;
+            return HGX_OK;
+        }
+    }
+    if (C <= MR_C && c->w64 <= 128 && c->h_rank && !getenv("HGX_EM_NO_EXACT") && !getenv("HGX_EM_NO_MID")) {
+        // mid-size problems in the reference's own order of operations (k_em_ref): one workgroup, one launch, bit-identical
+        // abundances; falls through if more than MR_A distinct alleles occur
+        DevBuf b_len, b_scal, b_out, b_first, b_rank, b_rm, b_km;
+        ALLOC(b_scal, S_N * 8); ALLOC(b_out, A * 8); ALLOC(b_rank, (size_t)A * 4);
+        ALLOC(b_rm, (size_t)std::max(C, 1) * MR_AW * 8); ALLOC(b_km, (size_t)MR_A * ((C + 63) / 64) * 8);
+        double *d_len = nullptr;
+        if (allele_len) {
+            std::vector<double> l(A, 1.0);
+            for (int a = 0; a < n_alleles; ++a) l[a] = (double)allele_len[a];
+            ALLOC(b_len, A * 8);
+            { int rc_ = hgx_h2d(b_len.p, l.data(), A * 8, st); if (rc_) return rc_; }
+            d_len = b_len.as<double>();
+        }
+        { int rc_ = hgx_h2d(b_rank.p, c->h_rank, (size_t)A * 4, st); if (rc_) return rc_; }
+        HIPCHK(hipMemsetAsync(b_scal.p, 0, S_N * 8, st));
+        std::vector<int32_t> h_first;
+        if (first_host) {
+            ALLOC(b_first, (size_t)A * 4);
+            HIPCHK(hipMemsetAsync(b_first.p, 0xFF, (size_t)A * 4, st));
+            h_first.resize(A);
+        }
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_ref), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MrLds)));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_em_ref, dim3(1), dim3(BLOCK), sizeof(MrLds), st, c->d_bits, C, c->w64, A, c->d_count, d_len, b_rank.as<int32_t>(),
+                           remove_low ? 1 : 0, b_rm.as<uint64_t>(), b_km.as<uint64_t>(), b_out.as<double>(), b_scal.as<double>(),
+                           first_host ? b_first.as<int32_t>() : nullptr);
+        HIPCHK(hipGetLastError());
+        std::vector<double> out(A);
+        double h_scal[S_N];
+        if (first_host) { int rc_ = hgx_d2h(h_first.data(), b_first.p, (size_t)A * 4, st); if (rc_) return rc_; }
+        { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
+        { int rc_ = hgx_d2h(h_scal, b_scal.p, S_N * 8, st); if (rc_) return rc_; }
+        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+        if (h_scal[S_FALLBACK] == 0.0) {
+            if (h_scal[S_KEYERR] != 0.0) {
+                hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
+                return HGX_EKEY;
+            }
+            for (int a = 0; a < n_alleles; ++a) prob_host[a] = out[a];
+            if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = h_first[a];
+            if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
+            g_last_exact = 1;
             return HGX_OK;
         }
     }

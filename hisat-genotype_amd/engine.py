@@ -275,6 +275,11 @@ def em_order(first_class, name_rank, present):
     return idx[np.lexsort((nr, fc))].tolist()
 
 
+def em_last_exact():
+    """True if the last EM on this thread ran in the reference's own order of operations (bit-identical abundances)."""
+    return bool(capi.lib().hgx_em_last_exact())
+
+
 def em_set_timing(on):
     """0 / False = off (totals kept), 1 / True = sampled passes, 2 = every plain mat-vec pass."""
     capi.check(capi.lib().hgx_em_set_timing(C.c_int(int(on))))

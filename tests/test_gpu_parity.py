@@ -451,6 +451,61 @@ def test_em_single_wavefront_path_matches_oracle_and_other_paths(orc):
             assert np.max(np.abs(p_w - p_s)) <= 1e-9
 
 
+def test_em_mid_size_in_reference_order_is_bit_identical(orc):
+    """65 ... 2048 classes over up to 1024 distinct alleles run in ONE workgroup in the reference's own order of operations
+    (k_em_ref): abundances `==` the C oracle's (which the golden vectors pin to the real reference), same iteration counts,
+    with pruning, with allele lengths, with alleles scattered over a wide index range and an arbitrary name order; more than
+    1024 distinct alleles fall through to the table-lookup path and still agree to 1e-9."""
+    import os
+    rng = np.random.RandomState(2024)
+    cases = [(300, 90, 120, 0.10), (700, 400, 600, 0.03), (7000, 1024, 2048, 0.01), (1200, 1000, 300, 0.2), (5000, 200, 1500, 0.3),
+             (2000, 1100, 500, 0.05)]
+    ran_exact = 0
+    for A, n_used, C_, dens in cases:
+        a_pad = engine.capi.a_pad(A)
+        w64 = a_pad // 64
+        used = np.sort(rng.choice(A, n_used, replace=False))
+        fam = rng.rand(6, n_used) < dens * rng.choice([0.5, 1.0, 3.0], size=6)[:, None]
+        classes, rows = [], np.zeros((C_, w64), np.uint64)
+        name_rank = rng.permutation(A).astype(np.int32)           # name order != index order
+        for c in range(C_):
+            m = fam[rng.randint(6)] ^ (rng.rand(n_used) < 0.02)
+            m[rng.randint(n_used)] = True
+            mem = used[m]
+            mem = mem[np.argsort(name_rank[mem])]                # class key = alleles in name order
+            classes.append([int(a) for a in mem])
+            for a in mem:
+                rows[c, a >> 6] |= np.uint64(1) << np.uint64(a & 63)
+        counts = rng.randint(1, 300, C_).astype(np.int64)
+        lengths = rng.randint(200, 3500, A).astype(np.int32)
+        cl = engine.Classes.from_host(rows, counts, a_pad)
+        cl.set_allele_rank(name_rank)
+        for low, ln in ((True, None), (False, lengths), (True, lengths)):
+            try:
+                oa, op, oit = orc.single_abundance(A, classes, counts, low, ln)
+            except KeyError:
+                continue
+            p, it = cl.em(A, low, ln)
+            exp = np.full(A, -1.0)
+            exp[oa] = op
+            assert it == oit, (A, n_used, C_, low, it, oit)
+            assert np.array_equal(p < 0, exp < 0)
+            if n_used <= 1024:
+                assert engine.em_last_exact()
+                assert np.array_equal(p, exp), (A, n_used, C_, low, float(np.max(np.abs(p - exp))))
+                ran_exact += 1
+                os.environ["HGX_EM_NO_MID"] = "1"              # the table-lookup path on the same problem: close, not identical
+                try:
+                    p2, it2 = cl.em(A, low, ln)
+                finally:
+                    del os.environ["HGX_EM_NO_MID"]
+                assert it2 == it and np.max(np.abs(p2 - p)) <= 1e-9
+            else:
+                assert not engine.em_last_exact()
+                assert np.max(np.abs(p - exp)) <= 1e-9
+    assert ran_exact >= 12
+
+
 def test_em_compact_tail_equals_full_iterations(orc):
     """After pruning leaves <= 64 alleles the EM finishes on one wavefront over merged 64-bit class masks (k_em_tail).
     Same iteration count and abundances as iterating over the whole matrix, and as the C oracle."""
