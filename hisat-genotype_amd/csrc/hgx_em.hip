@@ -1269,8 +1269,13 @@ __global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, 
 //   sums over a dict (normalisation totals, SQUAREM sums, prob_diff) = ONE lane adding in insertion order: that is what
 //          `sum(d.values())` does, and no faster order gives the same bits
 // The class matrix is re-laid once per call in the compact name-ordered allele space, both orientations (Rm, Km: L2-resident
-// scratch).  Cost: ~10-40 us per SQUAREM iteration against ~100 us for the six launches of the table-lookup path at these sizes,
-// and the result is the reference's bit for bit.  Follows oracle/hgx_oracle.c orc_single_abundance line by line.
+// scratch).  The price of the reference's order is ONE CU: measured (tools/em_mid_timing.py, HGX_MID_STAMPS=1) 0.10 ms per
+// SQUAREM iteration at 200 classes x 300 alleles (9 k class-member pairs), 0.32 ms at 600 x 600 (54 k pairs), 0.65 ms at
+// 1000 x 1000 (150 k), against 0.04-0.07 ms for the table-lookup path's six launches on all CUs -- every pair is a
+// double-precision division per application and four wavefronts share a SIMD.  Taken for problems of up to HGX_EM_MID_NNZ
+// (default 65 536) pairs: small read sets, where abundances are small rationals and a pruning or stopping decision can sit exactly
+// on a rounding (the fuzz cases of DESIGN.md section 4), at a cost of a few ms.  Follows oracle/hgx_oracle.c orc_single_abundance
+// line by line.
 // ------------------------------------------------------------------------------------------------------------
 constexpr int MR_A = 1024, MR_C = 2048;
 constexpr int MR_AW = MR_A / 64, MR_CW = MR_C / 64;
@@ -1293,52 +1298,83 @@ struct MrLds {
 };
 
 #pragma clang fp contract(off)
-// sum of val[j] over the members of the dict (membership `in`) in insertion order `seq`: one lane, eight loads in flight
+// sum of val[j] over the members of the dict (membership `in`) in insertion order `seq`, computed by ONE WAVEFRONT: the lanes
+// fetch 64 consecutive operands side by side (two dependent LDS reads each), then the additions run in order over the lanes'
+// registers (v_readlane) -- a sequential sum at ~10 cycles per element instead of two LDS latencies.  Every lane returns the sum.
 __device__ __forceinline__ double mr_seq_sum(const uint16_t *seq, int np, const double *val, const uint8_t *in) {
+    const int lane = threadIdx.x & 63;
     double t = 0.0;
-    int r = 0;
-    for (; r + 8 <= np; r += 8) {
-        double x[8];
+    for (int r0 = 0; r0 < np; r0 += 64) {
+        const int r = r0 + lane;
+        const int j = r < np ? seq[r] : 0;
+        const double x = (r < np && in[j]) ? val[j] : 0.0;            // + 0.0 for a pruned member or past the end: exact
+        const int n = min(64, np - r0);
+        if (n == 64) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { const int j = seq[r + k]; x[k] = in[j] ? val[j] : 0.0; }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t = ((t) + (x[k]));          // + 0.0 for a pruned member: exact
+            for (int k = 0; k < 64; ++k) t = ((t) + (lane_f64(x, k)));
+        } else {
+            for (int k = 0; k < n; ++k) t = ((t) + (lane_f64(x, k)));
+        }
     }
-    for (; r < np; ++r) { const int j = seq[r]; if (in[j]) t = ((t) + (val[j])); }
     return t;
 }
 __device__ __forceinline__ void mr_seq_sum2(const uint16_t *seq, int np, const double *va, const double *vb, const uint8_t *in,
                                             double &ta, double &tb) {
+    const int lane = threadIdx.x & 63;
     ta = 0.0; tb = 0.0;
-    int r = 0;
-    for (; r + 4 <= np; r += 4) {
-        double x[4], y[4];
+    for (int r0 = 0; r0 < np; r0 += 64) {
+        const int r = r0 + lane;
+        const int j = r < np ? seq[r] : 0;
+        const bool m = r < np && in[j];
+        const double x = m ? va[j] : 0.0, y = m ? vb[j] : 0.0;
+        const int n = min(64, np - r0);
+        if (n == 64) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { const int j = seq[r + k]; const bool m = in[j] != 0; x[k] = m ? va[j] : 0.0; y[k] = m ? vb[j] : 0.0; }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { ta = ((ta) + (x[k])); tb = ((tb) + (y[k])); }
+            for (int k = 0; k < 64; ++k) { ta = ((ta) + (lane_f64(x, k))); tb = ((tb) + (lane_f64(y, k))); }
+        } else {
+            for (int k = 0; k < n; ++k) { ta = ((ta) + (lane_f64(x, k))); tb = ((tb) + (lane_f64(y, k))); }
+        }
     }
-    for (; r < np; ++r) { const int j = seq[r]; if (in[j]) { ta = ((ta) + (va[j])); tb = ((tb) + (vb[j])); } }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B, int C, int n_words, int a_pad,
                                                   const int64_t *__restrict__ count, const double *__restrict__ len,
                                                   const int32_t *__restrict__ rank, int remove_low, uint64_t *__restrict__ Rm,
                                                   uint64_t *__restrict__ Km, double *__restrict__ out, double *__restrict__ scal,
-                                                  int32_t *__restrict__ first_out) {
+                                                  int32_t *__restrict__ first_out, int max_nnz, unsigned long long *__restrict__ dbg) {
     extern __shared__ double lds_raw[];
     MrLds &S = *reinterpret_cast<MrLds *>(lds_raw);
+    // HGX_MID_STAMPS=1: thread 0's wall_clock64() ticks (10 ns) per stage: [0] set-up, [1] rows, [2] cols, [3] order derivations,
+    // [4] normalisations, [5] SQUAREM / prob_diff sums, [6] number of order derivations
+    unsigned long long acc_t[7] = {0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_mark = dbg ? wall_clock64() : 0;
+    auto lap = [&](int k) { if (dbg) { const unsigned long long t = wall_clock64(); acc_t[k] += t - t_mark; t_mark = t; } };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int Cw = (C + 63) / 64;
     // ---- which alleles occur at all; their name order ---------------------------------------------------------
     unsigned long long *orw2 = reinterpret_cast<unsigned long long *>(S.tmp[0]);        // (scratch until the EM starts)
     for (int w = tid; w < n_words; w += BLOCK) orw2[w] = 0ull;
     __syncthreads();
+    int nz = 0;
     {
         const int w = tid & 127, slice = tid >> 7;      // 8 slices of the classes per word
         unsigned long long acc = 0ull;
-        if (w < n_words) for (int c = slice; c < C; c += 8) acc |= B[(size_t)c * n_words + w];
+        if (w < n_words)
+            for (int c = slice; c < C; c += 8) { const unsigned long long x = B[(size_t)c * n_words + w]; acc |= x; nz += __popcll(x); }
         if (acc) atomicOr(&orw2[w], acc);
+    }
+    {
+        // The whole EM runs on ONE CU: every (class, member) pair costs a double-precision division per application of the map.
+        // Beyond `max_nnz` pairs the table-lookup path (all CUs, rounding-level differences) takes the problem instead.
+        nz = (int)wave_sum_u64((uint64_t)nz);
+        if (lane == 0) S.red[wave] = (double)nz;
+        __syncthreads();
+        double tot = 0.0;
+        for (int i = 0; i < NWAVE; ++i) tot += S.red[i];
+        if (tot > (double)max_nnz) {
+            if (tid == 0) { scal[S_FALLBACK] = 1.0; scal[S_DONE] = 1.0; }
+            return;
+        }
     }
     __syncthreads();
     int *base_of = reinterpret_cast<int *>(S.tmp[1]);   // exclusive prefix of the words' bit counts
@@ -1384,21 +1420,31 @@ __global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B
     const int g = S.sorted[tid];
     const bool alive = tid < A1;
     // ---- the class matrix in the compact, name-ordered allele space: Rm [C][A1w] (members of a class), Km [A1][Cw] --------
-    for (int item = wave; item < C * A1w; item += NWAVE) {
-        const int c = item / A1w, w = item - c * A1w;
-        const int j = 64 * w + lane;
-        const int gj = j < A1 ? S.sorted[j] : 0;
-        const bool bit = j < A1 && ((B[(size_t)c * n_words + (gj >> 6)] >> (gj & 63)) & 1ull);
-        const unsigned long long word = __ballot(bit);
-        if (lane == 0) Rm[(size_t)c * A1w + w] = word;
+    // Rm: a wavefront takes a class, holds its row in registers (<= 128 words: two per lane) and every lane picks the bit of
+    // "its" allele out of the word that another lane holds (no gather from memory); Km = 64 x 64 bit transposes of Rm tiles
+    for (int c = wave; c < C; c += NWAVE) {
+        const uint64_t r0 = lane < n_words ? B[(size_t)c * n_words + lane] : 0ull;
+        const uint64_t r1 = lane + 64 < n_words ? B[(size_t)c * n_words + 64 + lane] : 0ull;
+        for (int w = 0; w < A1w; ++w) {
+            const int j = 64 * w + lane;
+            const int gj = j < A1 ? S.sorted[j] : 0;
+            const int wi = gj >> 6;
+            const uint64_t lo = __shfl(r0, wi & 63, 64);
+            const uint64_t hi = n_words > 64 ? __shfl(r1, wi & 63, 64) : 0ull;
+            const bool bit = j < A1 && (((wi < 64 ? lo : hi) >> (gj & 63)) & 1ull);
+            const unsigned long long word = __ballot(bit);
+            if (lane == 0) Rm[(size_t)c * A1w + w] = word;
+        }
     }
-    for (int item = wave; item < A1 * Cw; item += NWAVE) {
-        const int j = item / Cw, w = item - j * Cw;
-        const int c = 64 * w + lane;
-        const int gj = S.sorted[j];
-        const bool bit = c < C && ((B[(size_t)c * n_words + (gj >> 6)] >> (gj & 63)) & 1ull);
-        const unsigned long long word = __ballot(bit);
-        if (lane == 0) Km[(size_t)j * Cw + w] = word;
+    __threadfence_block();
+    __syncthreads();
+    for (int item = wave; item < Cw * A1w; item += NWAVE) {
+        const int cb = item / A1w, w = item - cb * A1w;
+        const int c = 64 * cb + lane;
+        const uint64_t x = c < C ? Rm[(size_t)c * A1w + w] : 0ull;      // lane = class, bits = alleles 64 w ..
+        const uint64_t y = wave_transpose64(x);                         // lane = allele 64 w + lane, bits = classes 64 cb ..
+        const int j = 64 * w + lane;
+        if (j < A1) Km[(size_t)j * Cw + cb] = y;
     }
     for (int c = tid; c < MR_C; c += BLOCK) S.n[c] = c < C ? (double)count[c] : 0.0;
     const bool use_len = len != nullptr;
@@ -1413,6 +1459,7 @@ __global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B
         first_out[g] = fc;
     }
     const double my_len = S.len[tid];
+    lap(0);
 
     // ---- helpers ---------------------------------------------------------------------------------------------------
     auto block_max_exact = [&](double v) -> double {
@@ -1455,7 +1502,7 @@ __global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B
         const double mine = use_len ? ((S.dv[d][tid]) / (my_len)) : S.dv[d][tid];
         S.tmp[0][tid] = mine;
         __syncthreads();
-        if (tid == 0) S.bc[0] = mr_seq_sum(S.seq[ord], S.npos[ord], S.tmp[0], S.din[d]);
+        if (wave == 0) { const double t = mr_seq_sum(S.seq[ord], S.npos[ord], S.tmp[0], S.din[d]); if (lane == 0) S.bc[0] = t; }
         __syncthreads();
         const double total = S.bc[0];
         if (alive && S.din[d][tid]) S.dv[d][tid] = ((mine) / (total));
@@ -1465,13 +1512,31 @@ __global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B
     // Gene_prob_next (common:1311-1336): dict P -> dict N (N != P)
     auto next_prob = [&](int P, int N, int live_a, int live_b) {
         for (int c = tid; c < C; c += BLOCK) {             // rows: alleles_prob of class c, members in key order
+            // a non-member's value is +0.0 in every dict (next_prob, select_alleles), and x + 0.0 == x: no membership test, and
+            // the operands of four members are fetched side by side before they are added in key order
             double sc = 0.0;
             const uint64_t *row = Rm + (size_t)c * A1w;
-            for (int w = 0; w < A1w; ++w)
-                for (uint64_t m = row[w]; m; m &= m - 1) {
-                    const int j = 64 * w + __builtin_ctzll(m);
-                    if (S.din[P][j]) sc = ((sc) + (S.dv[P][j]));
+            const double *pv = S.dv[P];
+            for (int w0 = 0; w0 < A1w; w0 += 8) {
+              uint64_t rw[8];                            // eight words of the row in flight (the scratch matrix lives in L2)
+#pragma unroll
+              for (int k = 0; k < 8; ++k) rw[k] = w0 + k < A1w ? row[w0 + k] : 0ull;
+#pragma unroll
+              for (int k8 = 0; k8 < 8; ++k8) {
+                const int w = w0 + k8;
+                uint64_t m = rw[k8];
+                while (m) {
+                    double x[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        x[k] = m ? pv[64 * w + __builtin_ctzll(m)] : 0.0;
+                        m &= m - 1;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sc = ((sc) + (x[k]));
                 }
+              }
+            }
             S.s[c] = sc;
         }
         __syncthreads();
@@ -1481,26 +1546,34 @@ __global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B
             if (lane == 0) S.valid[w] = bm;
         }
         __syncthreads();
+        lap(1);
         double acc = 0.0;
         bool any = false;
         const bool pin = alive && S.din[P][tid];
         if (pin) {                                         // cols: += count * prob / alleles_prob over the walked classes, dict order
             const double vj = S.dv[P][tid];
-            for (int w = 0; w < Cw; ++w) {
-                uint64_t m = Kme[w] & S.valid[w];
+            for (int w0 = 0; w0 < Cw; w0 += 8) {
+              uint64_t kw[8];
+#pragma unroll
+              for (int k = 0; k < 8; ++k) kw[k] = w0 + k < Cw ? Kme[w0 + k] : 0ull;
+#pragma unroll
+              for (int k8 = 0; k8 < 8; ++k8) {
+                const int w = w0 + k8;
+                uint64_t m = w < Cw ? kw[k8] & S.valid[w] : 0ull;
                 any = any || m != 0ull;
                 while (m) {
-                    int cc[4];
-                    double q[4];
+                    int cc[8];
+                    double q[8];
                     int nq = 0;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
+                    for (int k = 0; k < 8; ++k)
                         if (m) { cc[k] = 64 * w + __builtin_ctzll(m); m &= m - 1; nq = k + 1; } else cc[k] = cc[0];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) q[k] = ((((S.n[cc[k]]) * (vj))) / (S.s[cc[k]]));
+                    for (int k = 0; k < 8; ++k) q[k] = ((((S.n[cc[k]]) * (vj))) / (S.s[cc[k]]));
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if (k < nq) acc = ((acc) + (q[k]));
+                    for (int k = 0; k < 8; ++k) if (k < nq) acc = ((acc) + (q[k]));
                 }
+              }
             }
         }
         const bool nin = pin && any;
@@ -1510,6 +1583,7 @@ __global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B
         const unsigned long long inb = __ballot(nin);
         if (lane == 0) S.in_now[wave] = inb;
         __syncthreads();
+        lap(2);
         bool differ = S.cache_ord < 0;
         if (tid < MR_AW) differ = differ || S.in_now[tid] != S.sig_in[tid];
         if (tid < Cw) differ = differ || S.valid[tid] != S.sig_valid[tid];
@@ -1524,9 +1598,12 @@ __global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B
             if (tid < MR_CW) S.sig_valid[tid] = tid < Cw ? S.valid[tid] : 0ull;
             if (tid == 0) S.cache_ord = ord;
             __syncthreads();
+            acc_t[6] += 1;
         }
+        lap(3);
         ord_of[N] = ord;
         normalize(N, ord);
+        lap(4);
     };
     auto select_alleles = [&](int d) {                     // common:1338-1346
         const bool in = alive && S.din[d][tid];
@@ -1575,7 +1652,11 @@ __global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B
         S.tmp[0][tid] = ((p_r) * (p_r));
         S.tmp[1][tid] = ((p_v) * (p_v));
         __syncthreads();
-        if (tid == 0) mr_seq_sum2(S.seq[ord_of[prob]], S.npos[ord_of[prob]], S.tmp[0], S.tmp[1], S.din[prob], S.bc[0], S.bc[1]);
+        if (wave == 0) {
+            double ta, tb;
+            mr_seq_sum2(S.seq[ord_of[prob]], S.npos[ord_of[prob]], S.tmp[0], S.tmp[1], S.din[prob], ta, tb);
+            if (lane == 0) { S.bc[0] = ta; S.bc[1] = tb; }
+        }
         __syncthreads();
         const double ssr = S.bc[0], ssv = S.bc[1];
         __syncthreads();
@@ -1590,13 +1671,14 @@ __global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B
         }
         S.tmp[0][tid] = (alive && S.din[next][tid]) ? fabs(((pv0) - (S.dv[next][tid]))) : pv0;      // prob_diff, common:1272-1279
         __syncthreads();
-        if (tid == 0) S.bc[0] = mr_seq_sum(S.seq[ord_of[prob]], S.npos[ord_of[prob]], S.tmp[0], S.din[prob]);
+        if (wave == 0) { const double t = mr_seq_sum(S.seq[ord_of[prob]], S.npos[ord_of[prob]], S.tmp[0], S.din[prob]); if (lane == 0) S.bc[0] = t; }
         __syncthreads();
         diff = S.bc[0];
         __syncthreads();
         { const int t = prob; prob = next; next = t; }     // prob = next (common:1387)
         if (iter >= 10 && remove_low) select_alleles(prob);
         iter += 1;
+        lap(5);
     }
     if (!keyerr) {
         if (remove_low) select_alleles(prob);              // common:1402-1407
@@ -1604,6 +1686,7 @@ __global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B
         if (alive && S.din[prob][tid]) out[g] = S.dv[prob][tid];
     }
     if (tid == 0) { scal[S_ITER] = (double)iter; scal[S_KEYERR] = keyerr ? 1.0 : 0.0; scal[S_DONE] = 1.0; }
+    if (dbg && tid == 0) for (int k = 0; k < 7; ++k) dbg[k] = acc_t[k];
 }
 #pragma clang fp contract(fast)
 
@@ -3301,10 +3384,21 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_ref), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MrLds)));
             attr_set = true;
         }
+        DevBuf b_dbg;
+        const int max_nnz = getenv("HGX_EM_MID_NNZ") ? atoi(getenv("HGX_EM_MID_NNZ")) : 65536;
+        const bool stamps = getenv("HGX_MID_STAMPS") != nullptr;
+        if (stamps) ALLOC(b_dbg, 64);
         hipLaunchKernelGGL(k_em_ref, dim3(1), dim3(BLOCK), sizeof(MrLds), st, c->d_bits, C, c->w64, A, c->d_count, d_len, b_rank.as<int32_t>(),
                            remove_low ? 1 : 0, b_rm.as<uint64_t>(), b_km.as<uint64_t>(), b_out.as<double>(), b_scal.as<double>(),
-                           first_host ? b_first.as<int32_t>() : nullptr);
+                           first_host ? b_first.as<int32_t>() : nullptr, max_nnz, stamps ? b_dbg.as<unsigned long long>() : nullptr);
         HIPCHK(hipGetLastError());
+        if (stamps) {
+            unsigned long long h[8] = {0};
+            (void)hipStreamSynchronize(st);
+            (void)hipMemcpy(h, b_dbg.p, 56, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[k_em_ref] C %d: set-up %.1f us | rows %.1f | cols %.1f | orders %.1f (%llu derived) | normalise %.1f | sums %.1f\n", C,
+                    h[0] * 0.01, h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[6], h[4] * 0.01, h[5] * 0.01);
+        }
         std::vector<double> out(A);
         double h_scal[S_N];
         if (first_host) { int rc_ = hgx_d2h(h_first.data(), b_first.p, (size_t)A * 4, st); if (rc_) return rc_; }

@@ -455,9 +455,11 @@ def test_em_mid_size_in_reference_order_is_bit_identical(orc):
     """65 ... 2048 classes over up to 1024 distinct alleles run in ONE workgroup in the reference's own order of operations
     (k_em_ref): abundances `==` the C oracle's (which the golden vectors pin to the real reference), same iteration counts,
     with pruning, with allele lengths, with alleles scattered over a wide index range and an arbitrary name order; more than
-    1024 distinct alleles fall through to the table-lookup path and still agree to 1e-9."""
+    1024 distinct alleles -- or, by default, more than 65 536 class-member pairs (the kernel owns one CU) -- fall through to
+    the table-lookup path and still agree to 1e-9."""
     import os
     rng = np.random.RandomState(2024)
+    os.environ["HGX_EM_MID_NNZ"] = "100000000"                  # the size gate is lifted for this test (re-armed at the end)
     cases = [(300, 90, 120, 0.10), (700, 400, 600, 0.03), (7000, 1024, 2048, 0.01), (1200, 1000, 300, 0.2), (5000, 200, 1500, 0.3),
              (2000, 1100, 500, 0.05)]
     ran_exact = 0
@@ -504,6 +506,9 @@ def test_em_mid_size_in_reference_order_is_bit_identical(orc):
                 assert not engine.em_last_exact()
                 assert np.max(np.abs(p - exp)) <= 1e-9
     assert ran_exact >= 12
+    del os.environ["HGX_EM_MID_NNZ"]
+    p, it = cl.em(A, True, None)                               # the last problem (> 1024 alleles) and a gated big one: not exact
+    assert not engine.em_last_exact()
 
 
 def test_em_compact_tail_equals_full_iterations(orc):
