@@ -15,6 +15,7 @@
 // The host enqueues iterations in batches without waiting: every kernel starts by reading a device-side
 // `done` word, so iterations queued past convergence fall through in a few microseconds.
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <mutex>
@@ -3647,12 +3648,22 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         }
     }
     // ---- resident-block path (k_em_grid): the block grid must be co-resident, one workgroup per CU ----------------
-    static std::mutex grid_mu;                 // two resident grids at once could each hold half the CUs and wait forever
-    std::unique_lock<std::mutex> grid_lock(grid_mu, std::defer_lock);
+    // two resident grids that together need more CUs than the chip has could each hold a part and wait forever: grids reserve
+    // their CUs from a process-wide budget and one that does not fit runs per pass instead
+    static std::atomic<int> grid_cus{0};
+    struct GridHold {
+        int g = 0;
+        void release() { if (g) grid_cus.fetch_sub(g); g = 0; }
+        ~GridHold() { release(); }
+    } grid_hold;
     GkArgs ga{};
     DevBuf b_gpr, b_gpc, b_gy, b_gfl, b_gst;
     bool grid = false;
-    if (rows.M && rows.defer_combine && A <= EPT * BLOCK && !g_no_grid && getenv("HGX_EM_GRID")) {
+    // opt-in (HGX_EM_GRID=1), or for small block grids only (HGX_EM_GRID_MAX workgroups: many small tasks in flight are bound by
+    // the launch rate, and one launch replaces ~66)
+    static const int grid_small = getenv("HGX_EM_GRID_MAX") ? atoi(getenv("HGX_EM_GRID_MAX")) : 0;
+    const int grid_g = ((c->c64 * 64 + BLOCK - 1) / BLOCK) * (A / LUT_SLAB);
+    if (rows.M && rows.defer_combine && A <= EPT * BLOCK && !g_no_grid && (getenv("HGX_EM_GRID") || grid_g <= grid_small)) {
         static int n_cu = 0, occ5 = 0, occ8 = 0;
         if (!n_cu) {
             int dev = 0;
@@ -3670,7 +3681,13 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         ga.K = A / LUT_SLAB;
         const int occ = A <= 5 * BLOCK ? occ5 : occ8;
         // a margin of CUs stays free for the other stream's kernels (and for a CU the runtime may have taken away)
-        if (occ >= 1 && ga.R <= 64 && ga.K <= 64 && ga.R * ga.K <= n_cu - 16 && grid_lock.try_lock()) {
+        bool reserved = false;
+        if (occ >= 1 && ga.R <= 64 && ga.K <= 64 && ga.R * ga.K <= n_cu - 16) {
+            const int want = ga.R * ga.K;
+            if (grid_cus.fetch_add(want) + want <= n_cu - 16) { grid_hold.g = want; reserved = true; }
+            else grid_cus.fetch_sub(want);
+        }
+        if (reserved) {
             const int G = ga.R * ga.K;
             ALLOC(b_gpr, (size_t)2 * ga.K * Cp * 8); ALLOC(b_gpc, (size_t)2 * (Cp / LUT_SLAB) * A * 8); ALLOC(b_gy, (size_t)2 * ga.R * A * 8);
             ALLOC(b_gfl, ((size_t)3 * G * GK_FLAG_STRIDE + 32) * 4);
@@ -3874,7 +3891,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         }
         if (grid && h_abort) {
             // a workgroup of the block grid never became resident (bounded spin): run this EM again, one launch per pass
-            grid_lock.unlock();
+            grid_hold.release();
             g_no_grid = true;
             const int r = em_impl(cc, n_alleles, remove_low, allele_len, prob_host, first_host, n_iter_host, stream);
             g_no_grid = false;
