@@ -1718,10 +1718,12 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
         }
         cut.push_back(n);
         const size_t nc = cut.size() - 1;
+        lap("  chunk cuts");
         hgx_par_tasks(n_threads, nc, [&](int, size_t c) { filter_records(*opts, recs, ok, cut[c], cut[c + 1]); });
+        lap("  record filters");
         std::vector<uint32_t> reps;                     // first records of the distinct decode keys that some kept record carries
         group_records(*opts, recs, ok, n, n_threads, reps);
-        lap("filters + grouping");
+        lap("  key grouping");
         // pass 1: pileup over all records (common:1076-1134) = over the distinct keys, each weighted by its group's size
         std::vector<std::vector<uint32_t>> tcounts(n_threads);
         std::vector<std::string> terr(n_threads);
