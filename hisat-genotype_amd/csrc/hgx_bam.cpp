@@ -16,6 +16,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -293,6 +294,8 @@ bool bam_record_text(const unsigned char *r, size_t len, const std::vector<std::
 }
 
 typedef hgx_line Line;           // {p, len, klen = QNAME length, key = its first 8 bytes, big endian}
+struct BRec { size_t first; uint32_t second; };      // a BAM record in the inflated stream: (offset after block_size, length)
+typedef RawVec<BRec> BRecVec;                        // (no zero fill on resize: every element is written right after)
 
 inline bool line_less(const Line &a, const Line &b) {
     if (a.key != b.key) return a.key < b.key;
@@ -310,30 +313,48 @@ void make_line(const char *p, size_t len, Line &l) {
     l.key = key;
 }
 
-// stable sort by QNAME: sorted chunks, then rounds of pairwise stable merges
-void sort_lines(std::vector<Line> &v, int n_threads) {
+// stable sort by QNAME: a sample sort.  Splitters from an evenly spaced sample, every element's bucket found by binary search
+// (ranges of the input counted side by side, then scattered to their places in range order: the scatter is stable), buckets sorted
+// side by side.  (Sorted chunks + rounds of pairwise merges ended in ONE thread merging the whole table: 9.7 ms for 1 M records.)
+typedef RawVec<Line> LineVec;
+void sort_lines(LineVec &v, int n_threads) {
     const size_t n = v.size();
-    int T = 1;
-    while (T * 2 <= n_threads && n / (size_t)(T * 2) >= 50000) T *= 2;
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(n_threads, 1), n / 20000));
     if (T == 1) { std::stable_sort(v.begin(), v.end(), line_less); return; }
-    std::vector<size_t> cut(T + 1);
-    for (int t = 0; t <= T; ++t) cut[t] = n * t / T;
-    par_for(T, (size_t)T, [&](int, size_t b, size_t e) {
-        for (size_t t = b; t < e; ++t) std::stable_sort(v.begin() + cut[t], v.begin() + cut[t + 1], line_less);
+    const int B = T;                                                   // buckets
+    std::vector<Line> sample;
+    const size_t S = (size_t)B * 64;
+    for (size_t k = 0; k < S; ++k) sample.push_back(v[n * k / S]);
+    std::stable_sort(sample.begin(), sample.end(), line_less);
+    std::vector<Line> split;                                           // B - 1 splitters; bucket b = elements in (split[b-1], split[b]]
+    for (int b = 1; b < B; ++b) split.push_back(sample[S * b / B]);
+    std::vector<uint16_t> bucket_of(n);
+    std::vector<std::vector<size_t>> cnt(T, std::vector<size_t>(B, 0));
+    par_for(T, n, [&](int t, size_t lo, size_t hi) {
+        std::vector<size_t> &c = cnt[t];
+        for (size_t i = lo; i < hi; ++i) {
+            const int b = (int)(std::lower_bound(split.begin(), split.end(), v[i], line_less) - split.begin());    // equal names: one bucket
+            bucket_of[i] = (uint16_t)b;
+            c[b]++;
+        }
     });
-    std::vector<Line> tmp(n);
-    std::vector<Line> *src = &v, *dst = &tmp;
-    for (int width = 1; width < T; width *= 2) {
-        const int pairs = T / (2 * width);
-        par_for(pairs, (size_t)pairs, [&](int, size_t b, size_t e) {
-            for (size_t k = b; k < e; ++k) {
-                const size_t lo = cut[2 * k * width], mid = cut[(2 * k + 1) * width], hi = cut[(2 * k + 2) * width];
-                std::merge(src->begin() + lo, src->begin() + mid, src->begin() + mid, src->begin() + hi, dst->begin() + lo, line_less);
-            }
-        });
-        std::swap(src, dst);
+    std::vector<size_t> start(B + 1, 0);
+    for (int b = 0; b < B; ++b) {
+        size_t tot = 0;
+        for (int t = 0; t < T; ++t) { const size_t c = cnt[t][b]; cnt[t][b] = start[b] + tot; tot += c; }
+        start[b + 1] = start[b] + tot;
     }
-    if (src != &v) v.swap(*src);
+    LineVec tmp(n);
+    par_for(T, n, [&](int t, size_t lo, size_t hi) {
+        std::vector<size_t> &at = cnt[t];
+        for (size_t i = lo; i < hi; ++i) tmp[at[bucket_of[i]]++] = v[i];
+    });
+    std::atomic<size_t> next{0};
+    par_for(T, (size_t)T, [&](int, size_t, size_t) {
+        for (size_t b; (b = next.fetch_add(1)) < (size_t)B;)
+            std::stable_sort(tmp.begin() + start[b], tmp.begin() + start[b + 1], line_less);
+    });
+    v.swap(tmp);
 }
 
 // ---- regions (samtools view syntax) ---------------------------------------------------------------------------------
@@ -459,7 +480,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         data.release();
     } else raw.swap(data);
     lap("inflate");
-    std::vector<Line> &lines = out.lines;
+    LineVec &lines = out.lines;
     lines.clear();
     if (raw.size() >= 4 && memcmp(raw.data(), "BAM\1", 4) == 0) {
         const size_t n = raw.size();
@@ -496,14 +517,14 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             for (uint32_t k = 0; k + 1 < l_rn; ++k) if (r[32 + k] < 33 || r[32 + k] > 126) return false;
             return true;
         };
-        std::vector<std::pair<size_t, uint32_t>> chain;          // every record: (offset after block_size, length)
+        BRecVec chain;          // every record: (offset after block_size, length)
         const size_t body0 = p;
         const char *chain_min = getenv("HGX_BAM_CHAIN_MIN");              // bytes of records from which the chain is walked in ranges (tests)
         const size_t chain_min_bytes = chain_min ? (size_t)strtoull(chain_min, nullptr, 10) : (32u << 20);
         const int W = (n - body0 > chain_min_bytes) ? std::max(1, std::min(n_threads, 64)) : 1;
         bool chain_error = false;
         size_t err_at = 0;
-        auto walk = [&](size_t from, size_t until, std::vector<std::pair<size_t, uint32_t>> &dst, size_t &stop) -> bool {
+        auto walk = [&](size_t from, size_t until, BRecVec &dst, size_t &stop) -> bool {
             size_t q = from;
             while (q < until && q < n) {
                 if (q + 8192 < n) {       // a pointer chase through memory other cores just wrote: touch the lines ahead
@@ -525,7 +546,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             size_t stop = 0;
             if (!walk(body0, n, chain, stop)) { chain_error = true; err_at = stop; }
         } else {
-            std::vector<std::vector<std::pair<size_t, uint32_t>>> part(W);
+            std::vector<BRecVec> part(W);
             std::vector<size_t> first(W, 0), stop(W, 0);
             std::vector<int> okw(W, 0);
             par_for(W, (size_t)W, [&](int, size_t tb, size_t te) {
@@ -548,9 +569,22 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
                     okw[t] = walk(o, hi, part[t], stop[t]) ? 1 : 0;
                 }
             });
-            // stitch: accept worker t's records iff the chain so far ends exactly at its first record
-            size_t at = body0;
-            for (int t = 0; t < W && !chain_error; ++t) {
+            // stitch: accept worker t's records iff the chain so far ends exactly at its first record.  The usual case -- every
+            // guess was right -- is recognised first and copied side by side (a serial insert of 16 MB was 3-4 ms)
+            bool all_good = first[0] == body0 && okw[0];
+            for (int t = 1; t < W && all_good; ++t) all_good = okw[t] && first[t] == stop[t - 1];
+            all_good = all_good && stop[W - 1] == n;
+            if (all_good) {
+                std::vector<size_t> off(W + 1, 0);
+                for (int t = 0; t < W; ++t) off[t + 1] = off[t] + part[t].size();
+                chain.resize(off[W]);
+                par_for(W, (size_t)W, [&](int, size_t tb, size_t te) {
+                    for (size_t t = tb; t < te; ++t)
+                        if (!part[t].empty()) memcpy(&chain[off[t]], part[t].data(), part[t].size() * sizeof(chain[0]));
+                });
+            }
+            size_t at = all_good ? n : body0;
+            for (int t = 0; t < W && !chain_error && !all_good; ++t) {
                 if (at == first[t] && okw[t]) {
                     chain.insert(chain.end(), part[t].begin(), part[t].end());
                     at = stop[t];
@@ -569,11 +603,11 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         }
         if (chain_error) { hgx_set_error("truncated BAM record at offset %zu", err_at); return HGX_EPARSE; }
         // ---- region filter (parallel over the chain) -----------------------------------------------------------------
-        std::vector<std::pair<size_t, uint32_t>> recs;
+        BRecVec recs;
         if (!filtered) recs.swap(chain);
         else {
             const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, chain.size() / 4096 + 1));
-            std::vector<std::vector<std::vector<std::pair<size_t, uint32_t>>>> hit(T, std::vector<std::vector<std::pair<size_t, uint32_t>>>(n_reg));
+            std::vector<std::vector<BRecVec>> hit(T, std::vector<BRecVec>(n_reg));
             par_for(T, chain.size(), [&](int t, size_t b, size_t e) {
                 for (size_t i = b; i < e; ++i) {
                     const unsigned char *r = &raw[chain[i].first];
@@ -596,8 +630,15 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
                         if (region_hit(regs[g], nm.data(), nm.size(), pos, end0)) hit[t][g].push_back(chain[i]);
                 }
             });
-            for (size_t g = 0; g < n_reg; ++g)                      // region after region, file order inside
-                for (int t = 0; t < T; ++t) recs.insert(recs.end(), hit[t][g].begin(), hit[t][g].end());
+            std::vector<size_t> off((size_t)n_reg * T + 1, 0);   // region after region, file order inside: offsets, then copies side by side
+            for (size_t g = 0; g < n_reg; ++g)
+                for (int t = 0; t < T; ++t) off[g * T + t + 1] = off[g * T + t] + hit[t][g].size();
+            recs.resize(off[(size_t)n_reg * T]);
+            par_for(T, (size_t)T, [&](int, size_t tb, size_t te) {
+                for (size_t t = tb; t < te; ++t)
+                    for (size_t g = 0; g < n_reg; ++g)
+                        if (!hit[t][g].empty()) memcpy(&recs[off[g * T + t]], hit[t][g].data(), hit[t][g].size() * sizeof(recs[0]));
+            });
         }
         lap("  BAM record walk");
         if (keep_binary) {
@@ -731,7 +772,7 @@ extern "C" int hgx_read_alignments(const char *path, const char *regions, int32_
         if (rc) return rc;
         if (n_threads <= 0) n_threads = hgx_default_threads();
         n_threads = std::max(1, std::min(n_threads, 512));
-        const std::vector<Line> &lines = al.lines;
+        const LineVec &lines = al.lines;
         size_t total = 0;
         std::vector<size_t> offs(lines.size() + 1, 0);
         for (size_t i = 0; i < lines.size(); ++i) { offs[i] = total; total += (size_t)lines[i].len + 1; }

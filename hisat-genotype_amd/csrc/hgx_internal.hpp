@@ -112,6 +112,17 @@ typedef std::basic_string<char, std::char_traits<char>, HostPoolAlloc<char>> PSt
 // vectors of a batch: MBs each, handed back with every sample.  With 30+ threads in the process an munmap is a round of TLB
 // shoot-down interrupts: destroying one batch took 5-6 ms of a 65 ms file -> result call before its arrays came from the pool.
 template <class T> using PVec = std::vector<T, HostPoolAlloc<T>>;
+// ... and for tables that are overwritten right after resize(): elements are default-initialised (no zero fill: value-initialising
+// the 24 MB line table of a 1 M-record file was 2-3 ms on one thread)
+template <class T>
+struct HostPoolRawAlloc : HostPoolAlloc<T> {
+    template <class U> struct rebind { typedef HostPoolRawAlloc<U> other; };
+    HostPoolRawAlloc() = default;
+    template <class U> HostPoolRawAlloc(const HostPoolRawAlloc<U> &) {}
+    template <class U> void construct(U *p) { ::new ((void *)p) U; }
+    template <class U, class... Args> void construct(U *p, Args &&...args) { ::new ((void *)p) U(std::forward<Args>(args)...); }
+};
+template <class T> using RawVec = std::vector<T, HostPoolRawAlloc<T>>;
 
 struct hgx_batch {
     PVec<hgx_piece> pieces;
@@ -152,7 +163,7 @@ struct hgx_line { char *p; uint32_t len, klen; uint64_t key; };     // klen = QN
 struct hgx_align_lines {
     char *raw = nullptr;                   // SAM text as read, or the inflated BAM stream (pooled block), or null
     std::vector<PString> chunks;           // text decoded from BAM records (hgx_read_alignments only)
-    std::vector<hgx_line> lines;
+    RawVec<hgx_line> lines;
     // BAM records handed over in binary (hgx_parse_alignment_file): lines[i].p = the record's read name (record start + 32,
     // NUL-terminated), lines[i].len = its block_size; ref_names = the header's reference sequences
     bool binary = false;
