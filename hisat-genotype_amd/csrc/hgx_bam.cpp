@@ -453,6 +453,28 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         fprintf(stderr, "[hgx_read_alignments] %-18s %8.1f ms\n", what, (t - t_prev) * 1e3);
         t_prev = t;
     };
+    // one line of SAM text -> the worker's lists (per region; list 0 when nothing is filtered).  Records = non-empty lines that do
+    // not start with '@'.
+    auto take_line = [&](const char *p, size_t len, std::vector<std::vector<Line>> &mine) {
+        if (len && p[len - 1] == '\r') --len;
+        if (!len || *p == '@') return;
+        if (!filtered) { Line l; make_line(p, len, l); mine[0].push_back(l); return; }
+        const char *f[6];               // FLAG = 2nd field, RNAME = 3rd, POS = 4th (1-based), CIGAR = 6th
+        const char *q = p, *le = p + len;
+        int nf = 0;
+        while (nf < 6 && (q = (const char *)memchr(q, '\t', (size_t)(le - q))) != nullptr) f[nf++] = ++q;
+        if (nf != 6) return;
+        const long flag = strtol(f[0], nullptr, 10);
+        const int64_t pos0 = strtol(f[2], nullptr, 10) - 1;
+        const int64_t reflen = (flag & 4) ? 0 : cigar_text_reflen(f[4], f[5] - 1);
+        const int64_t end0 = pos0 + (reflen > 0 ? reflen : 1) - 1;
+        const size_t rl = (size_t)(f[2] - 1 - f[1]);
+        for (size_t g = 0; g < regs.size(); ++g)
+            if (region_hit(regs[g], f[1], rl, pos0, end0)) { Line l; make_line(p, len, l); mine[g].push_back(l); }
+    };
+    std::vector<std::vector<std::vector<Line>>> text_part;      // [worker][region] line lists of a SAM text
+    int text_nt = 0;
+    bool text_scanned = false;
     Bytes data;
     {
         const int fd = open(path, O_RDONLY);
@@ -462,17 +484,73 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         data.alloc((size_t)sb.st_size + 1);                // not zero-filled: every byte is written by the reads below
         data.n = (size_t)sb.st_size;                       // (+1: room for the terminator of a last line without '\n')
         std::vector<int> bad(n_threads, 0);
-        par_for(data.size() > (8u << 20) ? n_threads : 1, data.size(), [&](int t, size_t b, size_t e) {
-            while (b < e) {
-                const ssize_t got = pread(fd, data.data() + b, e - b, (off_t)b);
-                if (got <= 0) { bad[t] = 1; return; }
-                b += (size_t)got;
-            }
-        });
-        close(fd);
-        for (int v : bad) if (v) { hgx_set_error("short read on %s", path); return HGX_EINVAL; }
+        unsigned char magic[4] = {0, 0, 0, 0};
+        if (sb.st_size >= 4 && pread(fd, magic, 4, 0) != 4) { close(fd); hgx_set_error("short read on %s", path); return HGX_EINVAL; }
+        const bool is_text = !(magic[0] == 0x1f && magic[1] == 0x8b) && memcmp(magic, "BAM\1", 4) != 0;
+        if (is_text && data.size() > (8u << 20)) {
+            // Big SAM text: every worker reads its byte range in 1 MB pieces and scans each piece for lines while it is still in
+            // its cache (the separate scan of the whole text was a second trip through 400 MB of DRAM).  A worker owns the lines
+            // that START in its range; the one that runs over the end of the range is finished after all ranges are in.
+            text_nt = n_threads;
+            text_part.assign(text_nt, std::vector<std::vector<Line>>(n_reg));
+            std::vector<size_t> tail((size_t)text_nt, (size_t)-1);
+            char *base = (char *)data.data();
+            const size_t total = data.size();
+            par_for(text_nt, total, [&](int t, size_t b0, size_t e0) {
+                std::vector<std::vector<Line>> &mine = text_part[t];
+                if (!filtered) mine[0].reserve((e0 - b0) / 300 + 16);
+                unsigned char prev = '\n';
+                if (b0 > 0 && pread(fd, &prev, 1, (off_t)(b0 - 1)) != 1) { bad[t] = 1; return; }
+                bool skipping = prev != '\n';                // the head of my range is the tail of a line owned by the previous range
+                size_t have = b0;
+                const char *p = base + b0;
+                while (have < e0) {
+                    const size_t want = std::min<size_t>(e0 - have, 1u << 20);
+                    size_t got_all = 0;
+                    while (got_all < want) {
+                        const ssize_t got = pread(fd, base + have + got_all, want - got_all, (off_t)(have + got_all));
+                        if (got <= 0) { bad[t] = 1; return; }
+                        got_all += (size_t)got;
+                    }
+                    have += want;
+                    const char *lim = base + have;
+                    if (skipping) {
+                        const char *q = (const char *)memchr(p, '\n', (size_t)(lim - p));
+                        if (!q) { p = lim; continue; }
+                        p = q + 1;
+                        skipping = false;
+                    }
+                    while (p < base + e0) {
+                        const char *e = (const char *)memchr(p, '\n', (size_t)(lim - p));
+                        if (!e) break;
+                        take_line(p, (size_t)(e - p), mine);
+                        p = e + 1;
+                    }
+                }
+                if (!skipping && p < base + e0) tail[t] = (size_t)(p - base);
+            });
+            close(fd);
+            for (int v : bad) if (v) { hgx_set_error("short read on %s", path); return HGX_EINVAL; }
+            for (int t = 0; t < text_nt; ++t)
+                if (tail[t] != (size_t)-1) {
+                    const char *p = base + tail[t], *end = base + total;
+                    const char *e = (const char *)memchr(p, '\n', (size_t)(end - p));
+                    take_line(p, (size_t)((e ? e : end) - p), text_part[t]);
+                }
+            text_scanned = true;
+        } else {
+            par_for(data.size() > (8u << 20) ? n_threads : 1, data.size(), [&](int t, size_t b, size_t e) {
+                while (b < e) {
+                    const ssize_t got = pread(fd, data.data() + b, e - b, (off_t)b);
+                    if (got <= 0) { bad[t] = 1; return; }
+                    b += (size_t)got;
+                }
+            });
+            close(fd);
+            for (int v : bad) if (v) { hgx_set_error("short read on %s", path); return HGX_EINVAL; }
+        }
     }
-    lap("read file");
+    lap(text_scanned ? "read file + lines" : "read file");
     Bytes raw;
     if (data.size() >= 2 && data[0] == 0x1f && data[1] == 0x8b) {
         const int rc = bgzf_inflate(data, n_threads, raw);
@@ -691,45 +769,29 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         lap("  BAM -> text");
         }
     } else {
-        // SAM text: records = non-empty lines that do not start with '@'.  Byte ranges are split among the workers; a worker
-        // owns the lines that START in its range; per worker and region a list, concatenated region-major (file order inside).
+        // SAM text: byte ranges are split among the workers; a worker owns the lines that START in its range; per worker and
+        // region a list, concatenated region-major (file order inside).  (A big file was scanned while it was read, above.)
         const char *base = (const char *)raw.data(), *end = base + raw.size();
-        const int nt = raw.size() > (4u << 20) ? n_threads : 1;
-        std::vector<std::vector<std::vector<Line>>> part(nt, std::vector<std::vector<Line>>(n_reg));
-        par_for(nt, raw.size(), [&](int t, size_t b0, size_t e0) {
-            const char *p = base + b0;
-            if (b0 > 0) {                       // skip the tail of a line owned by the previous range
-                const char *q = (const char *)memchr(p - 1, '\n', (size_t)(end - (p - 1)));
-                p = q ? q + 1 : end;
-            }
-            std::vector<std::vector<Line>> &mine = part[t];
-            if (!filtered) mine[0].reserve((e0 - b0) / 300 + 16);
-            while (p < base + e0 && p < end) {
-                const char *e = (const char *)memchr(p, '\n', (size_t)(end - p));
-                if (!e) e = end;
-                size_t len = (size_t)(e - p);
-                if (len && p[len - 1] == '\r') --len;
-                if (len && *p != '@') {
-                    if (!filtered) { Line l; make_line(p, len, l); mine[0].push_back(l); }
-                    else {           // FLAG = 2nd field, RNAME = 3rd, POS = 4th (1-based), CIGAR = 6th
-                        const char *f[6];
-                        const char *q = p, *le = p + len;
-                        int nf = 0;
-                        while (nf < 6 && (q = (const char *)memchr(q, '\t', (size_t)(le - q))) != nullptr) f[nf++] = ++q;
-                        if (nf == 6) {
-                            const long flag = strtol(f[0], nullptr, 10);
-                            const int64_t pos0 = strtol(f[2], nullptr, 10) - 1;
-                            const int64_t reflen = (flag & 4) ? 0 : cigar_text_reflen(f[4], f[5] - 1);
-                            const int64_t end0 = pos0 + (reflen > 0 ? reflen : 1) - 1;
-                            const size_t rl = (size_t)(f[2] - 1 - f[1]);
-                            for (size_t g = 0; g < regs.size(); ++g)
-                                if (region_hit(regs[g], f[1], rl, pos0, end0)) { Line l; make_line(p, len, l); mine[g].push_back(l); }
-                        }
-                    }
+        const int nt = text_scanned ? text_nt : (raw.size() > (4u << 20) ? n_threads : 1);
+        std::vector<std::vector<std::vector<Line>>> &part = text_part;
+        if (!text_scanned) {
+            part.assign(nt, std::vector<std::vector<Line>>(n_reg));
+            par_for(nt, raw.size(), [&](int t, size_t b0, size_t e0) {
+                const char *p = base + b0;
+                if (b0 > 0) {                       // skip the tail of a line owned by the previous range
+                    const char *q = (const char *)memchr(p - 1, '\n', (size_t)(end - (p - 1)));
+                    p = q ? q + 1 : end;
                 }
-                p = e + 1;
-            }
-        });
+                std::vector<std::vector<Line>> &mine = part[t];
+                if (!filtered) mine[0].reserve((e0 - b0) / 300 + 16);
+                while (p < base + e0 && p < end) {
+                    const char *e = (const char *)memchr(p, '\n', (size_t)(end - p));
+                    if (!e) e = end;
+                    take_line(p, (size_t)(e - p), mine);
+                    p = e + 1;
+                }
+            });
+        }
         // offsets of every (region, worker) list in the final table, then a parallel copy
         std::vector<size_t> off((size_t)nt * n_reg + 1, 0);
         size_t tot = 0;

@@ -4,6 +4,8 @@ import os
 import struct
 import zlib
 
+import numpy as np
+
 import golden_util as gu
 from hisatgenotype_amd import bamio
 
@@ -403,3 +405,26 @@ def test_bam_record_chain_walked_in_ranges_is_exact(tmp_path, monkeypatch):
     assert want.count(b"\n") == 7 and b"decoy\t" not in want
     for nt in (1, 2, 3, 4):
         assert read_alignment_text(dpath, n_threads=nt) == want
+
+
+def test_big_sam_text_is_scanned_while_it_is_read(tmp_path):
+    """A SAM file above 8 MB is read in 1 MB pieces per worker and scanned for lines piece by piece (hgx_bam.cpp); the line that runs
+    over the end of a worker's byte range is finished afterwards.  Header lines, CRLF line ends, no final newline, a region
+    list and 1 ... 32 workers: always the batch of the plain text path."""
+    from hisatgenotype_amd import synth, locus as hl
+    loc = synth.make_hla_like_locus(n_alleles=300, n_vars=200, seed=9)
+    pl = hl.PackedLocus.from_synth(loc)
+    sam = synth.simulate_sam_fast(loc, synth.pick_sample(loc, 9), 14000, err_rate=0.003, seed=5)
+    lines = ["@HD\tVN:1.0", "@SQ\tSN:x\tLN:10"] + [l + ("\r" if i % 7 == 0 else "") for i, l in enumerate(sam.split("\n")) if l]
+    txt = "\n".join(lines)                                     # no final newline
+    assert len(txt) > (8 << 20)
+    path = str(tmp_path / "big.sam")
+    with open(path, "w") as f:
+        f.write(txt)
+    ref = pl.parse_sam(sam, n_threads=4)
+    for nt in (1, 2, 3, 5, 8, 13, 32):
+        for regions in (None, [loc.ref_allele]):
+            b = pl.parse_alignment_file(path, regions, n_threads=nt)
+            assert (b.n_pairs, b.n_reads) == (ref.n_pairs, ref.n_reads), (nt, regions)
+            assert np.array_equal(np.asarray(b.pair_ref), np.asarray(ref.pair_ref))
+            assert np.array_equal(np.asarray(b.masks), np.asarray(ref.masks))
