@@ -65,7 +65,7 @@ def build(force=False, verbose=True):
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-lz"]
+    cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", LIB] + objs + ["-lz", "-ldl"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)

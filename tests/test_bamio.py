@@ -428,3 +428,31 @@ def test_big_sam_text_is_scanned_while_it_is_read(tmp_path):
             assert (b.n_pairs, b.n_reads) == (ref.n_pairs, ref.n_reads), (nt, regions)
             assert np.array_equal(np.asarray(b.pair_ref), np.asarray(ref.pair_ref))
             assert np.array_equal(np.asarray(b.masks), np.asarray(ref.masks))
+
+
+def test_bgzf_inflate_with_libdeflate_and_with_zlib(tmp_path, monkeypatch):
+    """The BGZF blocks are inflated by libdeflate when the system has it (dlopen) and by zlib otherwise (HGX_NO_LIBDEFLATE=1 forces
+    it): same records either way, and a block with a damaged payload is refused by both (CRC-32 / ISIZE check)."""
+    import pytest
+    import sys
+    from hisatgenotype_amd import capi
+    read = sys.modules["hisatgenotype_amd.typing"].read_alignment_text
+    fx = gu.load("hla_small_pair")
+    data = fx["sam"].encode()
+    path = str(tmp_path / "x.bam")
+    bamio.write_bam_native(path, data, [(fx["_locus"].ref_allele, len(fx["_locus"].backbone))], sort_by_coordinate=True)
+    texts = []
+    for force_zlib in (False, True):
+        if force_zlib:
+            monkeypatch.setenv("HGX_NO_LIBDEFLATE", "1")
+        texts.append(read(path))
+    assert texts[0] == texts[1] and texts[0].count(b"\n") == data.count(b"\n")
+    raw = bytearray(open(path, "rb").read())
+    raw[40] ^= 0x55                                             # inside the first block's compressed payload
+    bad = str(tmp_path / "bad.bam")
+    open(bad, "wb").write(bytes(raw))
+    for force_zlib in (True, False):
+        if not force_zlib:
+            monkeypatch.delenv("HGX_NO_LIBDEFLATE")
+        with pytest.raises(capi.HgxError):
+            read(bad)

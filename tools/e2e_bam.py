@@ -1,10 +1,11 @@
 """BAM (coordinate-sorted) -> typing result through hgx_type_file: phase profile on this host."""
-import ctypes as C, os, sys, tempfile, time
+import ctypes as C, os, resource, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hisatgenotype_amd  # noqa
 from hisatgenotype_amd import capi, synth, bamio, locus as hl
 ht = sys.modules["hisatgenotype_amd.typing"]
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
+nt = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 loc = synth.make_hla_like_locus(n_alleles=7000, n_vars=2500, seed=101)
 pl = hl.PackedLocus.from_synth(loc)
 pl.index()
@@ -21,13 +22,16 @@ L = capi.lib()
 for rep in range(4):
     if rep == 3:
         os.environ["HGX_PARSE_PROFILE"] = "1"
-    o = capi.ParseOpts(2, 1, 0, 0, 0, 0, 0, 0)
+    o = capi.ParseOpts(2, 1, 0, 0, 0, 0, 0, nt)
+    r0 = resource.getrusage(resource.RUSAGE_SELF)
     to = ht.TypeOpts(1, 0, -1, 0, None, None, None, None, None)
     h = C.c_void_p()
     t0 = time.perf_counter()
     capi.check(L.hgx_type_file(C.byref(h), pl.h, pl.index(), path.encode(), pl.ref_allele.encode(), C.byref(o), C.byref(to), None))
     dt = time.perf_counter() - t0
     L.hgx_typing_destroy(h)
-    print("run %d: %.1f ms = %.2f M reads/s" % (rep, dt * 1e3, n_reads / dt / 1e6), flush=True)
+    r1 = resource.getrusage(resource.RUSAGE_SELF)
+    print("run %d: %.1f ms = %.2f M reads/s; CPU %.0f ms" % (rep, dt * 1e3, n_reads / dt / 1e6,
+                                                             (r1.ru_utime + r1.ru_stime - r0.ru_utime - r0.ru_stime) * 1e3), flush=True)
     time.sleep(0.4)
 os.remove(path)
