@@ -4,6 +4,8 @@
 #include <cstring>
 #include <map>
 
+#include <sys/mman.h>
+
 #include "hgx_internal.hpp"
 
 extern "C" int hgx_locus_create(hgx_locus **out, const hgx_locus_desc *d) {
@@ -427,8 +429,17 @@ void *hgx_host_alloc(size_t bytes) {
             return (char *)b + sizeof(BlockHeader);
         }
     }
-    const size_t cap = need >= HOST_POOL_MIN ? need + need / 16 : need;      // a little slack so that similar sizes fit later
-    BlockHeader *h = (BlockHeader *)malloc(cap);
+    size_t cap = need >= HOST_POOL_MIN ? need + need / 16 : need;      // a little slack so that similar sizes fit later
+    BlockHeader *h = nullptr;
+    // big blocks on transparent huge pages where the kernel hands them out on request (THP "madvise" mode): the inflated BAM stream
+    // and the record tables are walked in name order, i.e. at random, and a 2 MB page covers what 512 TLB entries would
+    static const bool thp = [] { const char *e = getenv("HGX_THP"); return !(e && atoi(e) == 0); }();
+    if (thp && cap >= (4u << 20)) {
+        cap = (cap + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        h = (BlockHeader *)aligned_alloc(2u << 20, cap);
+        if (h) (void)madvise(h, cap, MADV_HUGEPAGE);
+    }
+    if (!h) h = (BlockHeader *)malloc(cap);
     if (!h) throw std::bad_alloc();
     h->cap = cap;
     h->magic = HOST_MAGIC;
