@@ -431,9 +431,12 @@ void *hgx_host_alloc(size_t bytes) {
     }
     size_t cap = need >= HOST_POOL_MIN ? need + need / 16 : need;      // a little slack so that similar sizes fit later
     BlockHeader *h = nullptr;
-    // big blocks on transparent huge pages where the kernel hands them out on request (THP "madvise" mode): the inflated BAM stream
-    // and the record tables are walked in name order, i.e. at random, and a 2 MB page covers what 512 TLB entries would
-    static const bool thp = [] { const char *e = getenv("HGX_THP"); return !(e && atoi(e) == 0); }();
+    // HGX_THP=1: big blocks on transparent huge pages where the kernel hands them out on request (THP "madvise" mode).  Measured
+    // both ways: alone (tools/e2e_file.py, e2e_bam.py) the call's system time drops from 40-300 ms to 0-25 ms and slow outliers
+    // get rarer; inside bench.py (a process that also holds the 400 MB text and the GPU runtime's memory) the five spaced SAM
+    // calls went from 50.1-51.8 ms to 41.7-86.8 ms -- a huge page that has to be compacted for at fault time stalls the call.
+    // Off by default.
+    static const bool thp = [] { const char *e = getenv("HGX_THP"); return e && atoi(e) != 0; }();
     if (thp && cap >= (4u << 20)) {
         cap = (cap + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
         h = (BlockHeader *)aligned_alloc(2u << 20, cap);
