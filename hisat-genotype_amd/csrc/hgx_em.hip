@@ -4023,6 +4023,12 @@ extern "C" int hgx_em_masked(const hgx_classes *cc, const uint64_t *mask_host, i
     int rc = hgx_dedup_classes(&sub, cc->d_bits, nullptr, cc->d_count, C, cc->a_pad, b_mask.as<uint64_t>(), stream);
     if (rc == HGX_OK) {
         if (n_classes_host) *n_classes_host = sub->n_classes;
+        // the filtered set inherits the alleles' name order: a hand-off with more than 64 alleles then still runs in the
+        // reference's order when it fits k_em_ref (the fuzz found an iteration count off by one exactly here)
+        if (cc->h_rank && !sub->h_rank) {
+            sub->h_rank = new int32_t[sub->a_pad];
+            for (int a = 0; a < sub->a_pad; ++a) sub->h_rank[a] = a < cc->a_pad ? cc->h_rank[a] : 0x7fffffff;
+        }
         rc = hgx_em_ordered(sub, n_alleles, remove_low, allele_len, prob_host, first_class_host, n_iter_host, stream);
     }
     hgx_classes_destroy(sub);
