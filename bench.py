@@ -18,6 +18,53 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+
+def _launch_ranks_if_needed():
+    """`python bench.py --gpus N` without a launcher: start N ranks (one per GPU) of this same script under
+    torch.distributed.run as a CHILD process and exit with its code.  Runs before anything in this process has loaded
+    libhgx or touched the GPU (a process that has initialised the GPU must not be replaced or forked into ranks).
+    Under a launcher (WORLD_SIZE set) the world size must be the --gpus the caller asked for."""
+    import subprocess
+    n, backend, dry = 1, "nccl", False
+    argv = sys.argv[1:]
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+        elif a == "--backend" and i + 1 < len(argv):
+            backend = argv[i + 1]
+        elif a.startswith("--backend="):
+            backend = a.split("=", 1)[1]
+        elif a == "--dry-run":
+            dry = True
+    if n < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    ws = os.environ.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != n:
+            sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (n, ws))
+        return
+    if n == 1:
+        return
+    if backend == "nccl" and not dry:
+        import torch                      # device_count() does not initialise the GPU on this image
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.exit("bench.py: --gpus %d requested but this node has %d visible GPU(s); refusing to report n_gpus=1" % (n, have))
+    import socket
+    with socket.socket() as sk:           # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+if __name__ == "__main__":
+    _launch_ranks_if_needed()
+
 import numpy as np  # noqa: E402
 
 import hisatgenotype_amd as hgx  # noqa: E402
@@ -48,6 +95,9 @@ def parse_args():
                          "HLA-A + B + C, 1 M reads each, loci -- and the reads of a locus -- sharded over the GPUs), panel64 "
                          "(configs[3]: six loci x 64 samples sharded over the GPUs)")
     ap.add_argument("--panel-pairs", type=int, default=5000, help="panel64: read pairs per (sample, locus) task")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for --dry-run on CPU)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous only: every rank joins the process group and rank 0 prints the world it saw (no GPU work)")
     ap.add_argument("--inflight", type=int, default=1,
                     help="samples typed concurrently per GPU (host threads with their own streams and class-row buffers; "
                          "the EM of one sample is a chain of short launches that leaves the GPU to the scoring of the next)")
@@ -459,11 +509,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     use_dist = world > 1 or bool(os.environ.get("HGX_FORCE_DIST"))     # the latter exercises the RCCL path on one GPU
+    if args.dry_run:
+        # launcher check: the ranks meet, agree on the world size, and rank 0 reports what it saw
+        seen = world
+        if use_dist:
+            import torch
+            import torch.distributed as dist
+            dist.init_process_group(args.backend)
+            t = torch.ones(1, dtype=torch.int64)
+            if args.backend == "nccl":
+                torch.cuda.set_device(local_rank)
+                t = t.cuda()
+            dist.all_reduce(t)
+            seen = int(t.item())
+            assert dist.get_world_size() == world
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": seen, "world_size": world, "backend": args.backend, "gpus_arg": args.gpus}))
+        return
+    if args.gpus != world:
+        sys.exit("bench.py: --gpus %d but %d rank(s) are running" % (args.gpus, world))
     if use_dist:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        assert dist.get_world_size() == world
     capi.set_device(local_rank)
     if args.workload != "configs1":
         (run_class1 if args.workload == "class1" else run_panel64)(args, rank, local_rank, world, dist)

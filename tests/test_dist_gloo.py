@@ -72,3 +72,26 @@ def test_broadcast_and_shard_world2(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert out.stdout.count("ok") == 2
+
+
+def test_bench_gpus_flag_launches_that_many_ranks():
+    """`python bench.py --gpus 2` (no launcher) starts two ranks itself -- as a child process, before anything touches the
+    GPU -- and rank 0 reports the world it saw; with the RCCL backend and fewer GPUs than asked for it fails loudly instead
+    of printing n_gpus = 1 (Missing #2)."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--dry-run"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["world_size"] == 2 and rec["gpus_arg"] == 2
+    # no GPU here: asking for two of them over RCCL must fail, not fall back to one
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode != 0 and "refusing" in (out.stderr + out.stdout)
+    # under a launcher whose world size disagrees with --gpus
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"],
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
