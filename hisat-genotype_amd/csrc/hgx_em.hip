@@ -24,6 +24,7 @@
 #include <hip/hip_ext.h>
 
 #include "hgx_common.hpp"
+#include "hgx_emx.hpp"
 
 namespace {
 
@@ -3357,6 +3358,35 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             g_last_exact = b_rank.p != nullptr;
             return HGX_OK;
         }
+    }
+    if (C <= HGX_EMX_MAX_CLASSES && c->w64 <= 128 && c->h_rank && !getenv("HGX_EM_NO_EXACT") && !getenv("HGX_EM_NO_EMX")) {
+        // problems of up to 4096 classes over up to 8192 distinct alleles in the reference's own order of operations
+        // (k_emx, hgx_emx.hip: one workgroup, one launch, bit-identical abundances); falls through if it does not take the problem
+        DevBuf b_rank, b_len;
+        ALLOC(b_rank, (size_t)A * 4);
+        { int rc_ = hgx_h2d(b_rank.p, c->h_rank, (size_t)A * 4, st); if (rc_) return rc_; }
+        if (allele_len) {
+            std::vector<double> l(A, 1.0);
+            for (int a = 0; a < n_alleles; ++a) l[a] = (double)allele_len[a];
+            ALLOC(b_len, (size_t)A * 8);
+            { int rc_ = hgx_h2d(b_len.p, l.data(), (size_t)A * 8, st); if (rc_) return rc_; }
+        }
+        hgx_emx_job job{};
+        job.bits = c->d_bits; job.count = c->d_count; job.rank = b_rank.as<int32_t>(); job.len = allele_len ? b_len.as<double>() : nullptr;
+        job.C = C; job.w64 = c->w64; job.a_pad = A; job.remove_low = remove_low ? 1 : 0;
+        job.prob = prob_host; job.first = first_host; job.n_out = n_alleles;
+        { int rc_ = hgx_emx_run(&job, 1, st); if (rc_) return rc_; }
+        if (job.status == 2) {
+            hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
+            return HGX_EKEY;
+        }
+        if (job.status == 0) {
+            if (n_iter_host) *n_iter_host = job.n_iter;
+            g_last_exact = 1;
+            return HGX_OK;
+        }
+        for (int a = 0; a < n_alleles; ++a) prob_host[a] = 0.0;
+        if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = -1;
     }
     if (C <= MR_C && c->w64 <= 128 && c->h_rank && !getenv("HGX_EM_NO_EXACT") && !getenv("HGX_EM_NO_MID")) {
         // mid-size problems in the reference's own order of operations (k_em_ref): one workgroup, one launch, bit-identical

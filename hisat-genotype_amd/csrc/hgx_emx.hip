@@ -1,0 +1,697 @@
+// hgx_emx.hip -- 8a-8 for MANY problems at once: single_abundance (typing_common.py:1282-1410) in the REFERENCE'S OWN ORDER of
+// floating-point operations, one workgroup per problem, any number of problems per launch (gfx950).
+//
+// Contract (as ref_em_run / k_em_ref in hgx_em.hip, which this generalises to thousands of classes over thousands of alleles
+// and to a task dimension): every sum is sequential in the order typing_common.py walks its dicts -- alleles of a class in key
+// (name) order, classes in dict order, dict values in insertion order --, every term is formed as the reference forms it
+// (`float(count) * Gene_prob[allele] / alleles_prob`), nothing is contracted.  The abundances, the pruning decisions
+// (`prob >= max / 10`) and the stopping decision (`diff > 0.0001`) are therefore the reference's, bit for bit; follows
+// oracle/hgx_oracle.c orc_single_abundance line by line.
+//
+// How the order is kept while 1024 threads work:
+//   rows   alleles_prob of 64 classes at a time: lane = class, the walk over the alleles j (name order) is the loop; the 64-bit
+//          word "which of my 64 classes contain allele j" and p_j are wave-uniform and arrive through the scalar cache
+//          (s_load_dwordx16: eight j per load); the add is acc = fma(b, p_j, acc) with b = 1.0 / 0.0 picked per lane by the mask
+//          word (ONE v_cndmask for the high half of b; fma(1, x, acc) == acc + x and fma(0, x, acc) == acc exactly, x finite)
+//   cols   next[a] of 64 alleles at a time: lane = allele, the walk over the classes c (dict order) is the loop; count_c,
+//          alleles_prob_c and a refined reciprocal are wave-uniform scalars; the quotient (count * prob) / alleles_prob is formed
+//          for all lanes with the last three instructions of the compiler's own correctly rounded division (q0 = x * r,
+//          e = fma(-s, q0, x), q = fma(e, r, q0): the part that depends on the numerator; the reciprocal refinement, which only
+//          depends on alleles_prob, is done once per class) whenever neither operand is so large or small that the division
+//          would rescale -- otherwise by the plain `/` --, and added under the mask as above
+//   sums over a dict (normalisation totals, the two SQUAREM sums, prob_diff): the operands are first stored in insertion
+//          order, then ONE wavefront adds them eight per scalar load: that is what `sum(d.values())` does, no faster order
+//          gives the same bits
+//   the insertion order of a dict = (first WALKED class containing the allele, key order): re-derived (bitonic sort in LDS)
+//          only when the membership or the set of walked classes changed.
+// The class matrix is re-laid once per problem in the compact name-ordered allele space, in the two word orders the passes
+// stream: Mk[allele tile][class] and Mr[class tile][allele].
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "hgx_common.hpp"
+#include "hgx_emx.hpp"
+
+namespace {
+
+constexpr int XB = 1024, XNW = XB / 64;
+constexpr int XA = HGX_EMX_MAX_ALLELES, XC = HGX_EMX_MAX_CLASSES;
+constexpr int XAW = XA / 64, XCW = XC / 64;
+
+enum { XS_ITER = 0, XS_STATUS = 1, XS_A1 = 2, XS_ORDERS = 3, XS_RES_OFF = 4, XS_RES_N = 5, XS_N = 8 };
+
+struct EmxRes { int32_t allele, first; double prob; };       // one allele of a returned dict
+
+struct EmxTask {
+    const uint64_t *B;
+    const int64_t *count;
+    const int32_t *rank;
+    const double *len;
+    int32_t C, w64, a_pad, remove_low;
+    // scratch
+    uint64_t *Mk;       // [A1w][Cp]   word (aw, c): which alleles of tile aw are in class c
+    uint64_t *Mr;       // [Cw][A1s]   word (cw, j): which classes of tile cw contain allele j
+    double *dv;         // [3][A1s]    dict values
+    uint16_t *pos;      // [4][A1s]    insertion position of compact allele j in order buffer k (0xFFFF: not in it)
+    double *tmpv;       // [A1s]
+    double *vlen;       // [A1s]
+    double *cls;        // [5][Cp]     count, count / |class|, and per application: count (0 if skipped), alleles_prob, reciprocal
+    uint8_t *din;       // [3][A1s]    dict membership
+    int32_t *sorted;    // [A1s]       allele index of compact allele j
+    int32_t *first_c;   // [A1s]       first class (dict order) containing compact allele j
+    double *scal;       // [XS_N]
+    EmxRes *res;        // result records of ALL jobs of the launch: a job reserves its run with one atomic add on *cursor
+    unsigned long long *cursor;
+    unsigned long long *stamps;   // [16] or NULL (HGX_EMX_STAMPS=1)
+};
+
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+
+// Wave-uniform 64-byte loads through the scalar cache.  Issue and wait sit in ONE asm statement: the compiler never sees a
+// register that is still being written (with the pressure of this kernel it spills scalar registers, and a spill between an
+// issued load and its wait would save the old contents).  The latency is covered by the other wavefronts of the SIMD.
+__device__ __forceinline__ void sload2(const void *pa, const void *pb, u32x16 &a, u32x16 &b) {
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b) : "s"(pa), "s"(pb) : "memory");
+}
+__device__ __forceinline__ void sload4(const void *pa, const void *pb, const void *pc, const void *pd, u32x16 &a, u32x16 &b,
+                                       u32x16 &c, u32x16 &d) {
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %5, 0x0\n\ts_load_dwordx16 %2, %6, 0x0\n\t"
+                 "s_load_dwordx16 %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(a), "=&s"(b), "=&s"(c), "=&s"(d) : "s"(pa), "s"(pb), "s"(pc), "s"(pd) : "memory");
+}
+__device__ __forceinline__ double dbl_of(const u32x16 &v, int k) {
+    return __hiloint2double((int)v[2 * k + 1], (int)v[2 * k]);
+}
+__device__ __forceinline__ uint64_t u64_of(const u32x16 &v, int k) { return ((uint64_t)v[2 * k + 1] << 32) | v[2 * k]; }
+
+// Everything this workgroup stored to global memory becomes readable through the scalar cache (and by its other waves):
+// stores drained, workgroup barrier, scalar cache invalidated (it may hold the previous contents of the same lines).
+__device__ __forceinline__ void phase_sync() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __builtin_amdgcn_s_dcache_inv();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+struct XLds {
+    double tmpo[2][XA];                        // operands of a sequential sum in insertion order ([1] doubles as sort scratch and,
+                                               // during the set-up, as the name-ordered allele list; [0] as row buffers there)
+    unsigned long long validw[XCW], sig_valid[XCW];
+    unsigned long long in_now[XAW], sig_in[XAW];
+    unsigned long long orw[128], rbm[128];
+    int rpre[128];
+    double red[XNW];
+    double bc[4];
+    int npos[4];
+    int cache_ord, need_slow, A1, res_base;
+};
+
+#pragma clang fp contract(off)
+
+// acc + (bit of my lane in `mask` ? x : 0), as ONE select and ONE fma: b = 1.0 or 0.0 (their low halves are both zero),
+// fma(b, x, acc) rounds x + acc once (b = 1) or returns acc (b = 0, x finite).
+__device__ __forceinline__ double sel_add(double acc, uint64_t mask, double x) {
+    const int hi = __builtin_amdgcn_inverse_ballot_w64(mask) ? 0x3FF00000 : 0;
+    return __builtin_fma(__hiloint2double(hi, 0), x, acc);
+}
+
+// sum of arr[0..n8) (LDS; n8 a multiple of 8, the tail padded with +0.0) added one by one in index order by the calling
+// wavefront (every lane reads the same address: a broadcast, and every lane returns the sum)
+__device__ __forceinline__ double seq_sum(const double *arr, int n8) {
+    double t = 0.0;
+    for (int r0 = 0; r0 < n8; r0 += 8) {
+        double x[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = arr[r0 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t = ((t) + (x[k]));
+    }
+    return t;
+}
+__device__ __forceinline__ void seq_sum2(const double *a, const double *b, int n8, double &ta, double &tb) {
+    ta = 0.0; tb = 0.0;
+    for (int r0 = 0; r0 < n8; r0 += 8) {
+        double x[8], y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { x[k] = a[r0 + k]; y[k] = b[r0 + k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { ta = ((ta) + (x[k])); tb = ((tb) + (y[k])); }
+    }
+}
+
+__global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
+    extern __shared__ double xlds_raw[];
+    XLds &S = *reinterpret_cast<XLds *>(xlds_raw);
+    const EmxTask T = tasks[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = T.C, w64 = T.w64;
+    const int Cp = (C + 63) & ~63, Cw = Cp >> 6, A1s = T.a_pad;
+    unsigned long long t_mark = T.stamps ? wall_clock64() : 0, acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto lap = [&](int k) { if (T.stamps) { const unsigned long long t = wall_clock64(); acc_t[k] += t - t_mark; t_mark = t; } };
+    if (C <= 0 || C > XC || w64 > 128 || A1s > XA) {
+        if (tid == 0) { T.scal[XS_STATUS] = 1.0; T.scal[XS_ITER] = 0.0; }
+        return;
+    }
+    // ---- which alleles occur at all, and their place in name order ----------------------------------------------------
+    for (int w = tid; w < 128; w += XB) { S.orw[w] = 0ull; S.rbm[w] = 0ull; }
+    __syncthreads();
+    {
+        const int w = tid & 127, slice = tid >> 7;
+        unsigned long long acc = 0ull;
+        if (w < w64)
+            for (int c = slice; c < C; c += 8) acc |= T.B[(size_t)c * w64 + w];
+        if (acc) atomicOr(&S.orw[w], acc);
+    }
+    __syncthreads();
+    for (int a = tid; a < 64 * w64; a += XB)
+        if ((S.orw[a >> 6] >> (a & 63)) & 1ull) {
+            const int r = T.rank[a];
+            atomicOr(&S.rbm[(r >> 6) & 127], 1ull << (r & 63));
+        }
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int w = 0; w < 128; ++w) { S.rpre[w] = t; t += __popcll(S.rbm[w]); }
+        S.A1 = t;
+    }
+    __syncthreads();
+    const int A1 = S.A1;
+    if (A1 > XA || A1 <= 0) {
+        if (tid == 0) { T.scal[XS_STATUS] = 1.0; T.scal[XS_ITER] = 0.0; }
+        return;
+    }
+    const int A1w = (A1 + 63) >> 6;
+    int *srt = reinterpret_cast<int *>(&S.tmpo[1][0]);  // (free until the first order derivation)
+    for (int a = tid; a < 64 * w64; a += XB)
+        if ((S.orw[a >> 6] >> (a & 63)) & 1ull) {
+            const int r = T.rank[a], w = (r >> 6) & 127;
+            const int j = S.rpre[w] + __popcll(S.rbm[w] & ((1ull << (r & 63)) - 1ull));
+            srt[j] = a;
+            T.sorted[j] = a;
+        }
+    __syncthreads();
+    // ---- Mk: one wavefront per class picks, for every compact allele, its bit out of the row (held in LDS) ------------------
+    double *cnt_c = T.cls, *t0_c = T.cls + Cp, *n_c = T.cls + 2 * (size_t)Cp, *s_c = T.cls + 3 * (size_t)Cp, *r_c = T.cls + 4 * (size_t)Cp;
+    {
+        unsigned long long *rowbuf = reinterpret_cast<unsigned long long *>(&S.tmpo[0][0]) + (size_t)wave * 128;
+        for (int c = wave; c < Cp; c += XNW) {
+            if (c < C) {
+                rowbuf[lane] = lane < w64 ? T.B[(size_t)c * w64 + lane] : 0ull;
+                rowbuf[64 + lane] = lane + 64 < w64 ? T.B[(size_t)c * w64 + 64 + lane] : 0ull;
+            }
+            __builtin_amdgcn_wave_barrier();
+            int size = 0;
+            unsigned long long keep0 = 0ull, keep1 = 0ull;
+            for (int aw = 0; aw < A1w; ++aw) {
+                const int j = 64 * aw + lane;
+                const int g = j < A1 ? srt[j] : 0;
+                const bool bit = c < C && j < A1 && ((rowbuf[g >> 6] >> (g & 63)) & 1ull);
+                const unsigned long long m = __ballot(bit);
+                size += __popcll(m);
+                if (lane == (aw & 63)) { if (aw < 64) keep0 = m; else keep1 = m; }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < A1w) T.Mk[(size_t)lane * Cp + c] = keep0;
+            if (lane + 64 < A1w) T.Mk[(size_t)(lane + 64) * Cp + c] = keep1;
+            if (lane == 0) {
+                const double n = c < C ? (double)T.count[c] : 0.0;
+                cnt_c[c] = n;
+                t0_c[c] = size > 0 ? ((n) / ((double)size)) : 0.0;      // float(count) / len(alleles), common:1304
+            }
+        }
+    }
+    for (int j = tid; j < A1s; j += XB) T.vlen[j] = (T.len && j < A1) ? T.len[srt[j]] : 1.0;
+    phase_sync();
+    // ---- Mr: 64 x 64 bit transposes of Mk tiles ------------------------------------------------------------------
+    for (int item = wave; item < Cw * A1w; item += XNW) {
+        const int cw = item / A1w, aw = item - cw * A1w;
+        const uint64_t x = T.Mk[(size_t)aw * Cp + 64 * cw + lane];
+        T.Mr[(size_t)cw * A1s + 64 * aw + lane] = wave_transpose64(x);
+    }
+    const bool use_len = T.len != nullptr;
+    const int remove_low = T.remove_low;
+    if (tid == 0) { S.cache_ord = -1; S.need_slow = 0; }
+    uint16_t *posb[4] = {T.pos, T.pos + A1s, T.pos + 2 * (size_t)A1s, T.pos + 3 * (size_t)A1s};
+    uint32_t *skeys = reinterpret_cast<uint32_t *>(&S.tmpo[1][0]);
+    phase_sync();
+    for (int j = tid; j < A1; j += XB) {
+        int fc = -1;
+        for (int cw = 0; cw < Cw && fc < 0; ++cw) { const uint64_t m = T.Mr[(size_t)cw * A1s + j]; if (m) fc = 64 * cw + __builtin_ctzll(m); }
+        T.first_c[j] = fc;
+    }
+    lap(0);
+
+    double *dv[3] = {T.dv, T.dv + A1s, T.dv + 2 * (size_t)A1s};
+    uint8_t *din[3] = {T.din, T.din + A1s, T.din + 2 * (size_t)A1s};
+    double *tmpo0 = &S.tmpo[0][0], *tmpo1 = &S.tmpo[1][0];
+    const int A1p8 = (A1 + 7) & ~7;
+    int n_orders = 0;
+
+    // ---- helpers ---------------------------------------------------------------------------------------------------
+    auto block_max_exact = [&](double v) -> double {
+        v = wave_max_nonneg_f64(v);
+        __syncthreads();
+        if (lane == 0) S.red[wave] = v;
+        __syncthreads();
+        double t = S.red[0];
+#pragma unroll
+        for (int i = 1; i < XNW; ++i) t = fmax(t, S.red[i]);
+        return t;
+    };
+    // insertion order of dict d when it is filled class by class over the classes of `walk` (NULL = all): (first class, key order)
+    auto derive_order = [&](int d, const unsigned long long *walk, int buf) {
+        int N = 1024;
+        while (N < A1) N <<= 1;
+        for (int j = tid; j < N; j += XB) {
+            uint32_t key = 0xFFFFFFFFu;
+            if (j < A1 && din[d][j]) {
+                int fc = -1;
+                for (int cw = 0; cw < Cw && fc < 0; ++cw) {
+                    const uint64_t m = T.Mr[(size_t)cw * A1s + j] & (walk ? walk[cw] : ~0ull);
+                    if (m) fc = 64 * cw + __builtin_ctzll(m);
+                }
+                if (fc >= 0) key = (uint32_t)fc << 13 | (uint32_t)j;
+            }
+            skeys[j] = key;
+        }
+        __syncthreads();
+        for (int k = 2; k <= N; k <<= 1)
+            for (int j2 = k >> 1; j2 > 0; j2 >>= 1) {
+                for (int idx = tid; idx < N / 2; idx += XB) {
+                    const int i = ((idx & ~(j2 - 1)) << 1) | (idx & (j2 - 1)), p = i | j2;
+                    const uint32_t a = skeys[i], b = skeys[p];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { skeys[i] = b; skeys[p] = a; }
+                }
+                __syncthreads();
+            }
+        for (int j = tid; j < A1s; j += XB) posb[buf][j] = 0xFFFFu;
+        if (tid == 0) S.npos[buf] = 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int r = tid; r < N; r += XB) {
+            const uint32_t kk = skeys[r];
+            if (kk != 0xFFFFFFFFu) {
+                posb[buf][kk & 8191u] = (uint16_t)r;
+                if (r + 1 == N || skeys[r + 1] == 0xFFFFFFFFu) S.npos[buf] = r + 1;      // the keys are sorted: members first
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        n_orders += 1;
+    };
+    // operands of a sequential sum over dict d in the order of buffer `ord`: dst[pos] = member ? val : +0.0, tail padded
+    auto store_ordered = [&](double *dst, int ord, int j, bool member, double val) {
+        const uint32_t p = posb[ord][j];
+        if (p != 0xFFFFu) dst[p] = member ? val : 0.0;
+    };
+    auto pad_ordered = [&](double *dst, int ord) {
+        const int np = S.npos[ord];
+        if (tid < 8 && np + tid < ((np + 7) & ~7)) dst[np + tid] = 0.0;
+    };
+    auto normalize = [&](int d, int ord) {                 // common:1285-1297
+        for (int j = tid; j < A1; j += XB) {
+            const double mine = use_len ? ((dv[d][j]) / (T.vlen[j])) : dv[d][j];
+            T.tmpv[j] = mine;
+            store_ordered(tmpo0, ord, j, din[d][j] != 0, mine);
+        }
+        pad_ordered(tmpo0, ord);
+        __syncthreads();
+        if (wave == 0) { const double t = seq_sum(tmpo0, (S.npos[ord] + 7) & ~7); if (lane == 0) S.bc[0] = t; }
+        __syncthreads();
+        const double total = S.bc[0];
+        for (int j = tid; j < A1; j += XB)
+            if (din[d][j]) dv[d][j] = ((T.tmpv[j]) / (total));
+        __syncthreads();
+    };
+    int ord_of[3] = {0, 0, 0};
+    // Gene_prob_next (common:1311-1336): dict P -> dict N (N != P)
+    auto next_prob = [&](int P, int N, int live_a, int live_b) {
+        if (tid == 0) S.need_slow = 0;
+        phase_sync();                                      // dv[P] as written by this workgroup is what the scalar loads see
+        // rows: alleles_prob of the classes of tile cw, alleles in key order.  A non-member's value is +0.0 in every dict
+        // (next_prob, select_alleles) and x + 0.0 == x: no membership test.
+        for (int cw = wave; cw < Cw; cw += XNW) {
+            double acc = 0.0;
+            const uint64_t *mrow = T.Mr + (size_t)cw * A1s;
+            for (int j0 = 0; j0 < A1p8; j0 += 8) {
+                u32x16 mw, pv;
+                sload2(mrow + j0, dv[P] + j0, mw, pv);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc = sel_add(acc, u64_of(mw, k), dbl_of(pv, k));
+            }
+            const int c = 64 * cw + lane;
+            const bool valid = c < C && acc > 0.0;        // classes with alleles_prob <= 0 are skipped (common:1321)
+            // what the compiler's division computes from the denominator alone (no rescaling inside [2^-200, 2^200])
+            double r2 = 1.0;
+            bool slow = false;
+            if (valid) {
+                slow = !(acc >= 0x1p-200 && acc <= 0x1p200);
+                const double r0 = __builtin_amdgcn_rcp(acc);
+                const double e0 = __builtin_fma(-acc, r0, 1.0);
+                const double r1 = __builtin_fma(r0, e0, r0);
+                const double e1 = __builtin_fma(-acc, r1, 1.0);
+                r2 = __builtin_fma(r1, e1, r1);
+            }
+            n_c[c] = valid ? cnt_c[c] : 0.0;
+            s_c[c] = valid ? acc : 1.0;
+            r_c[c] = r2;
+            const unsigned long long bm = __ballot(valid);
+            if (lane == 0) S.validw[cw] = bm;
+            if (__any(slow) && lane == 0) atomicOr(&S.need_slow, 1);
+        }
+        phase_sync();
+        lap(1);
+        // cols: next[a] += count * prob / alleles_prob over the walked classes in dict order (a skipped class adds +0.0)
+        const bool block_slow = S.need_slow != 0;
+        for (int aw = wave; aw < A1w; aw += XNW) {
+            const int j = 64 * aw + lane;
+            const bool alive = j < A1;
+            const bool pin = alive && din[P][j] != 0;
+            const double p = pin ? dv[P][j] : 0.0;
+            const bool lane_fast = p == 0.0 || (p >= 0x1p-600 && p <= 0x1p600);
+            const bool tile_slow = block_slow || __any(!lane_fast);
+            double acc = 0.0;
+            const uint64_t *mcol = T.Mk + (size_t)aw * Cp;
+            if (!tile_slow) {
+                for (int c0 = 0; c0 < Cp; c0 += 8) {
+                    u32x16 mw, vn, vs, vr;
+                    sload4(mcol + c0, n_c + c0, s_c + c0, r_c + c0, mw, vn, vs, vr);
+                    double q[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const double s = dbl_of(vs, k), r = dbl_of(vr, k);
+                        const double x = ((dbl_of(vn, k)) * (p));
+                        const double q0 = ((x) * (r));
+                        const double e = __builtin_fma(-s, q0, x);
+                        q[k] = __builtin_fma(e, r, q0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc = sel_add(acc, u64_of(mw, k), q[k]);
+                }
+            } else {
+                for (int c0 = 0; c0 < Cp; c0 += 8) {
+                    u32x16 mw, vn, vs, vr;
+                    sload4(mcol + c0, n_c + c0, s_c + c0, r_c + c0, mw, vn, vs, vr);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const double q = ((((dbl_of(vn, k)) * (p))) / (dbl_of(vs, k)));
+                        acc = sel_add(acc, u64_of(mw, k), q);
+                    }
+                }
+            }
+            bool seen = false;                             // some walked class contains the allele: it enters the next dict
+            if (alive)
+                for (int cw = 0; cw < Cw; ++cw) seen = seen || (T.Mr[(size_t)cw * A1s + j] & S.validw[cw]) != 0ull;
+            const bool nin = pin && seen;
+            if (alive) { dv[N][j] = nin ? acc : 0.0; din[N][j] = nin ? 1 : 0; }
+            const unsigned long long inb = __ballot(nin);
+            if (lane == 0) S.in_now[aw] = inb;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        lap(2);
+        // insertion order: unchanged unless the membership or the walked classes changed since it was last derived
+        bool differ = S.cache_ord < 0;
+        if (tid < A1w) differ = differ || S.in_now[tid] != S.sig_in[tid];
+        if (tid < Cw) differ = differ || S.validw[tid] != S.sig_valid[tid];
+        const int changed = __syncthreads_or(differ);
+        int ord;
+        if (!changed) ord = S.cache_ord;
+        else {
+            ord = 0;
+            while (ord == live_a || ord == live_b) ++ord;  // a buffer no live dict refers to (4 buffers, <= 2 live besides N)
+            derive_order(N, S.validw, ord);
+            if (tid < A1w) S.sig_in[tid] = S.in_now[tid];
+            if (tid < Cw) S.sig_valid[tid] = S.validw[tid];
+            if (tid == 0) S.cache_ord = ord;
+            __syncthreads();
+        }
+        lap(3);
+        ord_of[N] = ord;
+        normalize(N, ord);
+        lap(4);
+    };
+    auto select_alleles = [&](int d) {                     // common:1338-1346
+        double mx = 0.0;
+        for (int j = tid; j < A1; j += XB) if (din[d][j]) mx = fmax(mx, dv[d][j]);
+        mx = block_max_exact(mx);
+        for (int j = tid; j < A1; j += XB)
+            if (din[d][j] && !(dv[d][j] >= ((mx) / (10.0)))) { din[d][j] = 0; dv[d][j] = 0.0; }
+        __syncthreads();
+    };
+
+    // ---- initial estimate (common:1300-1309): prob[a] += count / |class| over the classes in dict order ---------------
+    int prob = 0, next = 1, next2 = 2;
+    for (int j = tid; j < A1s; j += XB)
+        for (int d = 0; d < 3; ++d) { dv[d][j] = 0.0; din[d][j] = 0; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int aw = wave; aw < A1w; aw += XNW) {
+        const int j = 64 * aw + lane;
+        double acc = 0.0;
+        const uint64_t *mcol = T.Mk + (size_t)aw * Cp;
+        for (int c0 = 0; c0 < Cp; c0 += 8) {
+            u32x16 mw, vt;
+            sload2(mcol + c0, t0_c + c0, mw, vt);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc = sel_add(acc, u64_of(mw, k), dbl_of(vt, k));
+        }
+        if (j < A1) { dv[prob][j] = acc; din[prob][j] = 1; }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    derive_order(prob, nullptr, 3);
+    ord_of[prob] = 3;
+    normalize(prob, 3);
+    lap(5);
+    double diff = 1.0;
+    int iter = 0;
+    bool keyerr = false;
+    while (diff > 0.0001 && iter < 1000) {                 // common:1351
+        next_prob(prob, next, ord_of[prob], -1);
+        next_prob(next, next2, ord_of[prob], ord_of[next]);
+        bool bad = false;
+        for (int j = tid; j < A1; j += XB) bad = bad || (din[prob][j] && (!din[next][j] || !din[next2][j]));
+        if (__syncthreads_or(bad)) { keyerr = true; break; }      // the reference's KeyError (Q6)
+        const int op = ord_of[prob];
+        for (int j = tid; j < A1; j += XB) {
+            const bool pin = din[prob][j] != 0;
+            const double pv0 = dv[prob][j];
+            const double p_r = ((dv[next][j]) - (pv0));
+            const double p_v = ((((dv[next2][j]) - (dv[next][j]))) - (p_r));
+            store_ordered(tmpo0, op, j, pin, ((p_r) * (p_r)));
+            store_ordered(tmpo1, op, j, pin, ((p_v) * (p_v)));
+        }
+        pad_ordered(tmpo0, op);
+        pad_ordered(tmpo1, op);
+        __syncthreads();
+        if (wave == 0) {
+            double ta, tb;
+            seq_sum2(tmpo0, tmpo1, (S.npos[op] + 7) & ~7, ta, tb);
+            if (lane == 0) { S.bc[0] = ta; S.bc[1] = tb; }
+        }
+        __syncthreads();
+        const double ssr = S.bc[0], ssv = S.bc[1];
+        __syncthreads();
+        if (ssv > 0.0) {                                   // common:1370-1383
+            const double gamma = -sqrt(((ssr) / (ssv)));
+            for (int j = tid; j < A1; j += XB)
+                if (din[prob][j]) {
+                    const double pv0 = dv[prob][j];
+                    const double p_r = ((dv[next][j]) - (pv0));
+                    const double p_v = ((((dv[next2][j]) - (dv[next][j]))) - (p_r));
+                    const double x = ((((pv0) - (((((2.0) * (gamma))) * (p_r))))) + (((((gamma) * (gamma))) * (p_v))));
+                    dv[next2][j] = 0.0 > x ? 0.0 : x;
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            next_prob(next2, next, ord_of[prob], ord_of[next2]);
+        }
+        for (int j = tid; j < A1; j += XB) {               // prob_diff, common:1272-1279
+            const bool pin = din[prob][j] != 0;
+            const double pv0 = dv[prob][j];
+            store_ordered(tmpo0, op, j, pin, din[next][j] ? fabs(((pv0) - (dv[next][j]))) : pv0);
+        }
+        pad_ordered(tmpo0, op);
+        __syncthreads();
+        if (wave == 0) { const double t = seq_sum(tmpo0, (S.npos[op] + 7) & ~7); if (lane == 0) S.bc[0] = t; }
+        __syncthreads();
+        diff = S.bc[0];
+        __syncthreads();
+        { const int t = prob; prob = next; next = t; }     // prob = next (common:1387)
+        if (iter >= 10 && remove_low) select_alleles(prob);
+        iter += 1;
+        lap(6);
+    }
+    if (!keyerr) {
+        if (remove_low) select_alleles(prob);              // common:1402-1407
+        normalize(prob, ord_of[prob]);
+    }
+    // the returned dict as records (allele, first class, abundance): members counted per tile, one atomic add reserves the run
+    int res_n = 0;
+    if (!keyerr) {
+        for (int aw = wave; aw < A1w; aw += XNW) {
+            const int j = 64 * aw + lane;
+            const unsigned long long m = __ballot(j < A1 && din[prob][j] != 0);
+            if (lane == 0) S.in_now[aw] = m;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int aw = 0; aw < A1w; ++aw) { S.rpre[aw] = t; t += __popcll(S.in_now[aw]); }
+            S.npos[0] = t;
+            S.res_base = (int)atomicAdd(T.cursor, (unsigned long long)t);
+        }
+        __syncthreads();
+        res_n = S.npos[0];
+        for (int j = tid; j < A1; j += XB)
+            if (din[prob][j]) {
+                const int aw = j >> 6;
+                const int idx = S.res_base + S.rpre[aw] + __popcll(S.in_now[aw] & ((1ull << (j & 63)) - 1ull));
+                EmxRes r;
+                r.allele = T.sorted[j]; r.first = T.first_c[j]; r.prob = dv[prob][j];
+                T.res[idx] = r;
+            }
+    }
+    if (tid == 0) {
+        T.scal[XS_ITER] = (double)iter;
+        T.scal[XS_STATUS] = keyerr ? 2.0 : 0.0;
+        T.scal[XS_A1] = (double)A1;
+        T.scal[XS_ORDERS] = (double)n_orders;
+        T.scal[XS_RES_OFF] = (double)S.res_base;
+        T.scal[XS_RES_N] = (double)res_n;
+    }
+    if (T.stamps && tid == 0) for (int k = 0; k < 8; ++k) T.stamps[k] = acc_t[k];
+}
+#pragma clang fp contract(fast)
+
+inline size_t up64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+}   // namespace
+
+int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
+    ARGCHK(jobs && n_jobs >= 0);
+    if (n_jobs == 0) return HGX_OK;
+    static bool attr_set[64] = {};
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
+        attr_set[dev] = true;
+    }
+    const bool stamps = getenv("HGX_EMX_STAMPS") != nullptr;
+    // scratch of every job out of ONE block; jobs beyond the kernel's limits get status 1 without a descriptor
+    struct Lay { size_t Mk, Mr, dv, pos, tmpv, vlen, cls, din, sorted, first, stamps, end; };
+    std::vector<Lay> lays;
+    std::vector<int> job_of;
+    std::vector<size_t> base;
+    size_t total = 0, res_cap = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        hgx_emx_job &J = jobs[i];
+        J.n_iter = 0;
+        J.status = 1;
+        if (J.C <= 0 || J.C > HGX_EMX_MAX_CLASSES || J.w64 > 128 || J.a_pad > HGX_EMX_MAX_ALLELES || J.a_pad != 64 * J.w64) continue;
+        ARGCHK(J.bits && J.count && J.rank && J.prob && J.n_out <= J.a_pad);
+        const size_t Cp = ((size_t)J.C + 63) & ~(size_t)63, A1s = (size_t)J.a_pad, A1w = A1s / 64, Cw = Cp / 64;
+        Lay L;
+        size_t o = 0;
+        L.Mk = o; o += up64(A1w * Cp * 8);
+        L.Mr = o; o += up64(Cw * A1s * 8);
+        L.dv = o; o += up64(3 * A1s * 8);
+        L.pos = o; o += up64(4 * A1s * 2);
+        L.tmpv = o; o += up64(A1s * 8);
+        L.vlen = o; o += up64(A1s * 8);
+        L.cls = o; o += up64(5 * Cp * 8);
+        L.din = o; o += up64(3 * A1s);
+        L.sorted = o; o += up64(A1s * 4);
+        L.first = o; o += up64(A1s * 4);
+        L.stamps = o; o += up64(16 * 8);
+        L.end = o;
+        lays.push_back(L);
+        base.push_back(total);
+        total += o;
+        res_cap += A1s;
+        job_of.push_back(i);
+    }
+    const int n = (int)job_of.size();
+    if (n == 0) return HGX_OK;
+    // results: [cursor + padding | scal of every job | records], fetched together
+    const size_t head = 64 + (size_t)n * XS_N * 8;
+    DevBuf b_scr, b_tasks, b_res;
+    ALLOC(b_scr, total);
+    ALLOC(b_tasks, (size_t)n * sizeof(EmxTask));
+    ALLOC(b_res, head + res_cap * sizeof(EmxRes));
+    char *scr = b_scr.as<char>(), *resb = b_res.as<char>();
+    HIPCHK(hipMemsetAsync(resb, 0, 64, st));
+    std::vector<EmxTask> tasks((size_t)n);
+    for (int t = 0; t < n; ++t) {
+        const hgx_emx_job &J = jobs[job_of[t]];
+        const Lay &L = lays[t];
+        char *b = scr + base[t];
+        EmxTask &T = tasks[t];
+        T.B = J.bits; T.count = J.count; T.rank = J.rank; T.len = J.len;
+        T.C = J.C; T.w64 = J.w64; T.a_pad = J.a_pad; T.remove_low = J.remove_low ? 1 : 0;
+        T.Mk = (uint64_t *)(b + L.Mk); T.Mr = (uint64_t *)(b + L.Mr); T.dv = (double *)(b + L.dv); T.pos = (uint16_t *)(b + L.pos);
+        T.tmpv = (double *)(b + L.tmpv); T.vlen = (double *)(b + L.vlen); T.cls = (double *)(b + L.cls); T.din = (uint8_t *)(b + L.din);
+        T.sorted = (int32_t *)(b + L.sorted); T.first_c = (int32_t *)(b + L.first);
+        T.scal = (double *)(resb + 64 + (size_t)t * XS_N * 8);
+        T.res = (EmxRes *)(resb + head);
+        T.cursor = (unsigned long long *)resb;
+        T.stamps = stamps ? (unsigned long long *)(b + L.stamps) : nullptr;
+    }
+    for (size_t off = 0; off < tasks.size() * sizeof(EmxTask);) {      // descriptors through the pinned staging buffer
+        const size_t chunk = std::min<size_t>(tasks.size() * sizeof(EmxTask) - off, 128u << 10);
+        { int rc_ = hgx_h2d(b_tasks.as<char>() + off, (const char *)tasks.data() + off, chunk, st); if (rc_) return rc_; }
+        off += chunk;
+    }
+    hipLaunchKernelGGL(k_emx, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
+    HIPCHK(hipGetLastError());
+    // one round trip brings the state words and the first records; a second one the rest of a long result
+    const size_t first_recs = std::min<size_t>(res_cap, ((200u << 10) - head % (200u << 10)) / sizeof(EmxRes) + 0);
+    const size_t first_bytes = std::min<size_t>(head + first_recs * sizeof(EmxRes), head + res_cap * sizeof(EmxRes));
+    std::vector<char> h((size_t)head + res_cap * sizeof(EmxRes));
+    for (size_t off = 0; off < first_bytes;) {
+        const size_t chunk = std::min<size_t>(first_bytes - off, 128u << 10);
+        { int rc_ = hgx_d2h(h.data() + off, resb + off, chunk, st); if (rc_) return rc_; }
+        off += chunk;
+    }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+    const unsigned long long n_rec = *(const unsigned long long *)h.data();
+    if (n_rec > res_cap) { hgx_set_error("EM result records overflow (%llu > %zu)", n_rec, res_cap); return HGX_EHIP; }
+    if (head + n_rec * sizeof(EmxRes) > first_bytes) {
+        HIPCHK(hipMemcpyAsync(h.data() + first_bytes, resb + first_bytes, head + n_rec * sizeof(EmxRes) - first_bytes, hipMemcpyDeviceToHost, st));
+        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+    }
+    const EmxRes *recs = (const EmxRes *)(h.data() + head);
+    for (int t = 0; t < n; ++t) {
+        hgx_emx_job &J = jobs[job_of[t]];
+        const double *sc = (const double *)(h.data() + 64 + (size_t)t * XS_N * 8);
+        J.status = (int32_t)sc[XS_STATUS];
+        J.n_iter = (int32_t)sc[XS_ITER];
+        if (J.status == 1) continue;
+        for (int a = 0; a < J.n_out; ++a) J.prob[a] = -1.0;
+        if (J.first) for (int a = 0; a < J.n_out; ++a) J.first[a] = -1;
+        if (J.status != 0) continue;
+        const size_t off = (size_t)sc[XS_RES_OFF], cnt = (size_t)sc[XS_RES_N];
+        for (size_t k = 0; k < cnt; ++k) {
+            const EmxRes &r = recs[off + k];
+            if (r.allele >= 0 && r.allele < J.n_out) { J.prob[r.allele] = r.prob; if (J.first) J.first[r.allele] = r.first; }
+        }
+    }
+    if (stamps) {
+        for (int t = 0; t < std::min(n, 8); ++t) {
+            unsigned long long hs[8];
+            (void)hipMemcpy(hs, scr + base[t] + lays[t].stamps, 64, hipMemcpyDeviceToHost);
+            const double *sc = (const double *)(h.data() + 64 + (size_t)t * XS_N * 8);
+            fprintf(stderr, "[k_emx] job %d C %d A1 %d iters %d orders %d: set-up %.1f us | rows %.1f | cols %.1f | order %.1f | normalise %.1f | "
+                            "init %.1f | vector steps %.1f\n", job_of[t], jobs[job_of[t]].C, (int)sc[XS_A1], (int)sc[XS_ITER], (int)sc[XS_ORDERS],
+                    hs[0] * 0.01, hs[1] * 0.01, hs[2] * 0.01, hs[3] * 0.01, hs[4] * 0.01, hs[5] * 0.01, hs[6] * 0.01);
+        }
+    }
+    return HGX_OK;
+}

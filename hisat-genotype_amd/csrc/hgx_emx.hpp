@@ -1,0 +1,31 @@
+// hgx_emx.hpp -- the batched EM in the reference's own order of floating-point operations (hgx_emx.hip), shared with the
+// translation units that call it (hgx_em.hip: hgx_em / hgx_em_ordered for one class set; hgx_many.hip: hgx_type_many).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+// One EM problem: `C` classes (rows of `w64` words over the locus' allele indices, dict order), their counts, the alleles' name
+// order (rank[a] = place of allele a among the sorted names = its place inside a class key) and optionally the allele
+// lengths (double per allele index).  All pointers are DEVICE memory that stays valid until the call returns.
+struct hgx_emx_job {
+    const uint64_t *bits;       // [C][w64]
+    const int64_t *count;       // [C]
+    const int32_t *rank;        // [a_pad]
+    const double *len;          // [a_pad] or NULL
+    int32_t C, w64, a_pad, remove_low;
+    // results (HOST memory, filled by hgx_emx_run)
+    double *prob;               // [n_out] abundance, or -1.0 for an allele that is not in the returned dict
+    int32_t *first;             // [n_out] or NULL: first class (dict order) containing the allele, -1 elsewhere
+    int32_t n_out;              // alleles reported (<= a_pad)
+    int32_t n_iter;             // outer iterations
+    int32_t status;             // 0 = done, 1 = not taken (too many classes / distinct alleles: the caller uses another path),
+                                // 2 = the reference would raise KeyError (quirk Q6)
+};
+
+// limits of the kernel (a job beyond them comes back with status 1)
+constexpr int HGX_EMX_MAX_CLASSES = 4096;
+constexpr int HGX_EMX_MAX_ALLELES = 8192;
+
+// Runs all jobs in ONE launch (one workgroup per job) on `st` and returns when the results are on the host.
+int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st);

@@ -1,0 +1,100 @@
+"""GPU parity of the batched reference-order EM (k_emx, csrc/hgx_emx.hip) against the C oracle, which the golden vectors pin
+to the real reference (tests/test_oracle_golden.py): abundances must be EQUAL as doubles, not close."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from hisatgenotype_amd import engine, locus as hl
+import hisatgenotype_amd as hgx
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_problem(rng, A, n_used, C_, dens, n_fam=6):
+    a_pad = engine.capi.a_pad(A)
+    w64 = a_pad // 64
+    used = np.sort(rng.choice(A, n_used, replace=False))
+    fam = rng.rand(n_fam, n_used) < dens * rng.choice([0.5, 1.0, 3.0], size=n_fam)[:, None]
+    fam[0] = True                                             # a class family that holds (nearly) every allele
+    name_rank = rng.permutation(A).astype(np.int32)           # name order != index order
+    classes, rows = [], np.zeros((C_, w64), np.uint64)
+    seen = set()
+    for c in range(C_):
+        while True:
+            m = fam[rng.randint(n_fam)] ^ (rng.rand(n_used) < 0.02)
+            m[rng.randint(n_used)] = True
+            key = m.tobytes()
+            if key not in seen:
+                seen.add(key)
+                break
+        mem = used[m]
+        mem = mem[np.argsort(name_rank[mem])]                 # class key = alleles in name order
+        classes.append([int(a) for a in mem])
+        np.bitwise_or.at(rows[c], mem >> 6, np.uint64(1) << (mem & 63).astype(np.uint64))
+    counts = rng.randint(1, 300, C_).astype(np.int64)
+    lengths = rng.randint(200, 3500, A).astype(np.int32)
+    return a_pad, name_rank, classes, rows, counts, lengths
+
+
+CASES = [(300, 90, 120, 0.10), (700, 400, 600, 0.03), (7000, 1024, 2048, 0.01), (5000, 200, 1500, 0.3),
+         (2000, 1100, 500, 0.05), (7000, 4549, 1600, 0.25), (8000, 5199, 1200, 0.2), (3000, 1949, 1340, 0.27),
+         (8192, 8192, 700, 0.1), (4000, 3000, 4096, 0.02)]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "A%d_used%d_C%d" % c[:3])
+def test_emx_equals_oracle_bit_for_bit(orc, case):
+    """Up to 4096 classes over up to 8192 distinct alleles -- the sizes of BASELINE configs[0] and of the panel's tasks --
+    in the reference's own order of operations: `==` on every abundance, same iteration counts, with pruning, with allele
+    lengths, alleles scattered over a wide index range, arbitrary name order."""
+    A, n_used, C_, dens = case
+    rng = np.random.RandomState(1000 + A + C_)
+    a_pad, name_rank, classes, rows, counts, lengths = _random_problem(rng, A, n_used, C_, dens)
+    cl = engine.Classes.from_host(rows, counts, a_pad)
+    cl.set_allele_rank(name_rank)
+    ran = 0
+    for low, ln in ((True, None), (False, lengths), (True, lengths)):
+        try:
+            oa, op, oit = orc.single_abundance(A, classes, counts, low, ln)
+        except KeyError:
+            continue
+        p, it = cl.em(A, low, ln)
+        assert engine.em_last_exact()
+        exp = np.full(A, -1.0)
+        exp[oa] = op
+        assert it == oit, (case, low, it, oit)
+        assert np.array_equal(p < 0, exp < 0)
+        assert np.array_equal(p, exp), (case, low, float(np.max(np.abs(p - exp))))
+        ran += 1
+    assert ran >= 2
+
+
+def test_emx_first_classes_and_order(orc):
+    """hgx_em_ordered on the same path: first class (dict order) of every allele of the result."""
+    rng = np.random.RandomState(77)
+    A, n_used, C_, dens = 2500, 1500, 900, 0.15
+    a_pad, name_rank, classes, rows, counts, lengths = _random_problem(rng, A, n_used, C_, dens)
+    cl = engine.Classes.from_host(rows, counts, a_pad)
+    cl.set_allele_rank(name_rank)
+    p, first, it = cl.em_ordered(A, False, None)
+    assert engine.em_last_exact()
+    want = np.full(A, -1, np.int64)
+    for c in range(C_ - 1, -1, -1):
+        want[classes[c]] = c
+    assert np.array_equal(first[p >= 0], want[p >= 0]) and (first[p < 0] == -1).all()
+
+
+def test_config0_em1_is_the_reference_bit_for_bit():
+    """EM #1 of BASELINE configs[0] (fixture hla_7000_10k: 1 730 exon-level classes over ~4 500 alleles, recorded from the real
+    reference): every abundance of the result list `==` the reference's float, same order."""
+    fx = gu.load("hla_7000_10k")
+    o = fx["options"]
+    pl = hl.PackedLocus.from_synth(fx["_locus"])
+    res = hgx.type_locus(pl, fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
+                         allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
+                         simulation=o["simulation"])
+    for got, exp in zip(res.em, fx["em"]):
+        assert got["n_iter"] == exp["n_iter"]
+        assert [a for a, _ in got["result"]] == [a for a, _ in exp["result"]]
+        assert [p for _, p in got["result"]] == [float(q) for _, q in exp["result"]]
