@@ -89,6 +89,16 @@ int hgx_pair_classes_sel(const hgx_index *ix, const uint64_t *compat, const int3
                          const int64_t *sel, int32_t n_pairs, uint64_t *eb, uint64_t *gb, uint64_t *eh,
                          uint64_t *gh, hipStream_t st);
 
+// segment-aware forms for many tasks in one launch chain (hgx_dedup.hip; used by hgx_type_many): pair_seg / row_seg = task of a pair / row
+struct hgx_groups;
+int hgx_group_pairs_seg(hgx_groups **out, const int32_t *pair_off, const uint32_t *refs, int32_t n_pairs, int32_t level,
+                        const uint32_t *pair_seg, void *stream);
+int hgx_level_classes_grouped_seg(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
+                                  const uint32_t *refs, hgx_groups *g, uint64_t *rows_scratch, uint64_t *hash_scratch,
+                                  const uint32_t *pair_seg, void *stream);
+int hgx_dedup_classes_seg(hgx_classes **out, const uint64_t *rows, const uint64_t *row_hash, int64_t n_rows, int32_t a_pad,
+                          const uint32_t *row_seg, void *stream);
+
 // fused gene-level form (hgx_device.hip): rows are claimed / verified against their class' representative by the wavefront
 // that computed them; hgx_dedup.hip (hgx_pair_classes_dedup) owns the table and turns it into a class set
 int hgx_pair_classes_fused_launch(const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off, const uint32_t *refs,

@@ -206,7 +206,9 @@ __global__ void k_ht_finalize(const unsigned long long *__restrict__ keys, const
 __global__ __launch_bounds__(256) void k_verify_ht(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
                                                    const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ first, long n,
                                                    int *__restrict__ bad, uint32_t *__restrict__ bad_rows = nullptr,
-                                                   uint32_t *__restrict__ n_bad = nullptr) {
+                                                   uint32_t *__restrict__ n_bad = nullptr, const uint32_t *__restrict__ seg = nullptr) {
+    // seg (many tasks in one dedup): rows of different segments never share a class -- their keys are salted with the segment,
+    // and a row whose slot was founded by another segment's row (a 64-bit key collision) counts as different here
     constexpr int R = 4;
     const int lane = threadIdx.x & 63;
     const long r0 = (((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * R;
@@ -219,6 +221,11 @@ __global__ __launch_bounds__(256) void k_verify_ht(const uint64_t *__restrict__ 
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     const u64x2 *m = (const u64x2 *)mask;
     bool diff = false;
+    if (seg) {
+#pragma unroll
+        for (int k = 0; k < R; ++k)
+            if (sl[k] != HT_NONE && h[k] != (uint32_t)(r0 + k)) diff = diff || seg[r0 + k] != seg[h[k]];
+    }
     for (int w = lane; w < w64 / 2; w += 64) {
         u64x2 x[R], y[R];
 #pragma unroll
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256) void k_verify_ht(const uint64_t *__restrict__ 
     if (!bad_rows) return;
     for (int k = 0; k < R; ++k) {
         if (sl[k] == HT_NONE || h[k] == (uint32_t)(r0 + k)) continue;
-        bool d = false;
+        bool d = seg && seg[r0 + k] != seg[h[k]];
         for (int w = lane; w < w64; w += 64) {
             uint64_t x = rows[(size_t)(r0 + k) * w64 + w], y = rows[(size_t)h[k] * w64 + w];
             if (mask) { x &= mask[w]; y &= mask[w]; }
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256) void k_fix_reinsert(const uint64_t *__restrict
                                                       const int64_t *__restrict__ weight, int round,
                                                       unsigned long long *__restrict__ keys, uint32_t *__restrict__ first,
                                                       unsigned long long *__restrict__ cnt, uint32_t tmask,
-                                                      uint32_t *__restrict__ slot_of) {
+                                                      uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ seg = nullptr) {
     // one wavefront per row: the new key is a (salted) hash of the row's CONTENT -- rows that shared a key part ways at once
     const int lane = threadIdx.x & 63;
     const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(256) void k_fix_reinsert(const uint64_t *__restrict
     h = wave_sum_u64(h);
     if (lane != 0) return;
     uint64_t key = mix64(h + 0x9e3779b97f4a7c15ull * (uint64_t)round);
+    if (seg) key = mix64(key ^ (0xd6e8feb86659fd93ull * (uint64_t)(seg[i] + 1u)));
     if (key == HGX_EMPTY_KEY) key = HGX_EMPTY_KEY - 1;
     const unsigned long long w = (unsigned long long)(weight ? weight[i] : 1);
     atomicAdd(&cnt[slot_of[i]], 0ull - w);
@@ -284,13 +292,14 @@ __global__ __launch_bounds__(256) void k_fix_reinsert(const uint64_t *__restrict
 __global__ __launch_bounds__(256) void k_fix_verify(const uint64_t *__restrict__ rows, int w64, const uint64_t *__restrict__ mask,
                                                     const uint32_t *__restrict__ bad_rows, uint32_t n_bad,
                                                     const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ first,
-                                                    uint32_t *__restrict__ still_bad, uint32_t *__restrict__ n_still) {
+                                                    uint32_t *__restrict__ still_bad, uint32_t *__restrict__ n_still,
+                                                    const uint32_t *__restrict__ seg = nullptr) {
     const int lane = threadIdx.x & 63;
     const uint32_t t = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (t >= n_bad) return;
     const uint32_t i = bad_rows[t], f = first[slot_of[i]];
     if (f == i) return;
-    bool diff = false;
+    bool diff = seg && seg[i] != seg[f];
     for (int w = lane; w < w64; w += 64) {
         uint64_t x = rows[(size_t)i * w64 + w], y = rows[(size_t)f * w64 + w];
         if (mask) { x &= mask[w]; y &= mask[w]; }
@@ -327,15 +336,34 @@ __global__ __launch_bounds__(256) void k_ht_gather_slots(const uint64_t *__restr
     }
 }
 
+// keys of a dedup over MANY tasks' rows: a row's key is salted with its segment, so equal rows of different segments found
+// different classes (the exact check, k_verify_ht, compares segments too)
+__global__ void k_salt_keys(const uint64_t *__restrict__ in, const uint32_t *__restrict__ seg, long n, uint64_t *__restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = in[i];
+    if (k != HGX_EMPTY_KEY) {
+        k = mix64(k ^ (0xd6e8feb86659fd93ull * (uint64_t)(seg[i] + 1u)));
+        if (k == HGX_EMPTY_KEY) k = HGX_EMPTY_KEY - 1;
+    }
+    out[i] = k;
+}
+
 static hgx_classes *new_classes(int32_t a_pad);
 // small_blocks: insert with 256-row workgroups instead of 1024-row ones.  Alone the large ones win (4x fewer global atomics
 // on the hot classes); beside a kernel that fills the chip (hgx_level_classes runs next to the gene level's per-pair rows)
 // a 16-wave workgroup with 48 KB of LDS waits for a whole CU's worth of slots and the insert takes 3-4x longer.
 static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_t *keys_in, const int64_t *row_weight, long n,
-                            int w64, const uint64_t *and_mask, hipStream_t st, bool small_blocks = false) {
+                            int w64, const uint64_t *and_mask, hipStream_t st, bool small_blocks = false,
+                            const uint32_t *seg = nullptr) {
     long T = 1024;
     while (T < 2 * n) T <<= 1;
-    DevBuf b_keys, b_first, b_cnt, b_slot, b_flag, b_rank, b_tmp, b_meta, b_bad;
+    DevBuf b_keys, b_first, b_cnt, b_slot, b_flag, b_rank, b_tmp, b_meta, b_bad, b_salted;
+    if (seg) {
+        ALLOC(b_salted, (size_t)n * 8);
+        hipLaunchKernelGGL(k_salt_keys, dim3(nblk(n, 256)), dim3(256), 0, st, keys_in, seg, n, b_salted.as<uint64_t>());
+        keys_in = b_salted.as<uint64_t>();
+    }
     ALLOC(b_keys, (size_t)T * 8); ALLOC(b_first, (size_t)T * 4); ALLOC(b_cnt, (size_t)T * 8);
     ALLOC(b_slot, (size_t)n * 4); ALLOC(b_flag, (size_t)n * 4); ALLOC(b_rank, (size_t)n * 4); ALLOC(b_meta, 16);
     ALLOC(b_bad, (size_t)n * 4);
@@ -357,9 +385,9 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
             HIPCHK(hipMemsetAsync(b_meta.as<uint32_t>() + 2, 0, 4, st));
             hipLaunchKernelGGL(k_fix_reinsert, dim3(nblk(nb, 4)), dim3(256), 0, st, rows, w64, and_mask, cur, nb, row_weight, round,
                                b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1),
-                               b_slot.as<uint32_t>());
+                               b_slot.as<uint32_t>(), seg);
             hipLaunchKernelGGL(k_fix_verify, dim3(nblk(nb, 4)), dim3(256), 0, st, rows, w64, and_mask, cur, nb, b_slot.as<uint32_t>(),
-                               b_first.as<uint32_t>(), nxt, b_meta.as<uint32_t>() + 2);
+                               b_first.as<uint32_t>(), nxt, b_meta.as<uint32_t>() + 2, seg);
             HIPCHK(hipGetLastError());
             { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
             { int rc_ = hgx_sync(st); if (rc_) return rc_; }
@@ -389,7 +417,7 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     { int rc_ = number_classes(); if (rc_) return rc_; }
     // the exact check does not need the class count: queue it before the D2H that sizes the output
     hipLaunchKernelGGL(k_verify_ht, dim3(nblk((n + 3) / 4, 4)), dim3(256), 0, st, rows, w64, and_mask, b_slot.as<uint32_t>(),
-                       b_first.as<uint32_t>(), n, b_meta.as<int>(), b_bad.as<uint32_t>(), b_meta.as<uint32_t>() + 2);
+                       b_first.as<uint32_t>(), n, b_meta.as<int>(), b_bad.as<uint32_t>(), b_meta.as<uint32_t>() + 2, seg);
     // Small inputs (the hand-off dedup: a few thousand gene classes) size the output for the worst case and finish in
     // ONE host round trip; large ones first learn the class count (the worst case would be the whole input again).
     const bool one_trip = n <= 65536;
@@ -434,6 +462,7 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
         if (hipEventCreateWithFlags(&cl->ready, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(cl->ready, st);
         DevBuf *keep[] = {&b_keys, &b_first, &b_cnt, &b_slot, &b_flag, &b_rank, &b_tmp, &b_meta};
         for (int i = 0; i < 8; ++i) { cl->d_keep[i] = keep[i]->p; keep[i]->p = nullptr; }
+        // (b_salted and b_bad were last read by kernels that completed before the round trip above)
     }
     const int n_runs = (int)meta[1];
     cl->n_classes = n_runs;
@@ -451,7 +480,7 @@ template <class T, class Destroy> static int fail_clean(int rc, T **out, hipStre
 }
 
 static int dedup_classes_impl(hgx_classes **out, const uint64_t *rows, const uint64_t *row_hash, const int64_t *row_weight,
-                              int64_t n_rows, int32_t a_pad, const uint64_t *and_mask, void *stream) {
+                              int64_t n_rows, int32_t a_pad, const uint64_t *and_mask, void *stream, const uint32_t *seg = nullptr) {
     ARGCHK(out && n_rows >= 0 && a_pad > 0 && a_pad % 512 == 0);
     ARGCHK(n_rows < (1ll << 31));
     hipStream_t st = (hipStream_t)stream;
@@ -468,7 +497,7 @@ static int dedup_classes_impl(hgx_classes **out, const uint64_t *rows, const uin
         hipLaunchKernelGGL(k_hash_rows, dim3(nblk(n, 4)), dim3(256), 0, st, rows, n, w64, and_mask, b_hash.as<uint64_t>());
         keys_in = b_hash.as<uint64_t>();
     }
-    return dedup_hash_table(cl, rows, keys_in, row_weight, n, w64, and_mask, st);
+    return dedup_hash_table(cl, rows, keys_in, row_weight, n, w64, and_mask, st, false, seg);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -481,7 +510,7 @@ static int dedup_classes_impl(hgx_classes **out, const uint64_t *rows, const uin
 // 896-byte-per-pair row traffic divided by the repeat factor.
 // ------------------------------------------------------------------------------------------------
 __global__ void k_sig_keys(const int32_t *__restrict__ pair_off, const uint32_t *__restrict__ refs, int n_pairs, uint32_t level,
-                           uint64_t *__restrict__ key) {
+                           uint64_t *__restrict__ key, const uint32_t *__restrict__ seg = nullptr) {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     uint64_t h = 0x243f6a8885a308d3ull;
@@ -493,15 +522,18 @@ __global__ void k_sig_keys(const int32_t *__restrict__ pair_off, const uint32_t 
         ++cnt;                                                                         // permuted list merely stays a separate group
     }
     h = mix64(h ^ cnt);
+    if (seg) h = mix64(h ^ (0xd6e8feb86659fd93ull * (uint64_t)(seg[p] + 1u)));      // pairs of different tasks never share a group
     key[p] = h == HGX_EMPTY_KEY ? HGX_EMPTY_KEY - 1 : h;       // never the "dropped row" key: a pair without refs has a class (Q4)
 }
 // exact check of the grouping: every pair's ref list equals the list of its group's first pair
 __global__ void k_sig_verify(const int32_t *__restrict__ pair_off, const uint32_t *__restrict__ refs, int n_pairs, uint32_t level,
-                             const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ first, int *__restrict__ bad) {
+                             const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ first, int *__restrict__ bad,
+                             const uint32_t *__restrict__ seg = nullptr) {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= n_pairs) return;
     const uint32_t f = first[slot_of[p]];
     if (f == (uint32_t)p) return;
+    if (seg && seg[p] != seg[f]) { atomicOr(bad, 1); return; }
     int a = pair_off[p], b = pair_off[f];
     const int a1 = pair_off[p + 1], b1 = pair_off[f + 1];
     bool same = true;
@@ -567,7 +599,7 @@ extern "C" int hgx_groups_dims(hgx_groups *g, int64_t *n_groups, int32_t *n_pair
 }
 
 static int group_pairs_impl(hgx_groups **out, const int32_t *pair_off, const uint32_t *refs, int32_t n_pairs, int32_t level,
-                            void *stream) {
+                            void *stream, const uint32_t *seg = nullptr) {
     ARGCHK(out && n_pairs >= 0 && (level == 0 || level == 1));
     hipStream_t st = (hipStream_t)stream;
     hgx_groups *g = new hgx_groups();
@@ -586,7 +618,7 @@ static int group_pairs_impl(hgx_groups **out, const int32_t *pair_off, const uin
     ALLOC(b_keys, (size_t)T * 8); ALLOC(b_first, (size_t)T * 4); ALLOC(b_cnt, (size_t)T * 8);
     ALLOC(b_slot, (size_t)n * 4); ALLOC(b_flag, (size_t)n * 4); ALLOC(b_rank, (size_t)n * 4); ALLOC(b_meta, 16);
     ALLOC(b_tmp, scan_scratch_bytes(n));
-    hipLaunchKernelGGL(k_sig_keys, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level, b_key.as<uint64_t>());
+    hipLaunchKernelGGL(k_sig_keys, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level, b_key.as<uint64_t>(), seg);
     hipLaunchKernelGGL(k_ht_init, dim3(nblk(std::max(T, n), 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(),
                        b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), T, b_flag.as<uint32_t>(), n, b_meta.as<uint32_t>());
     hipLaunchKernelGGL(k_ht_insert<256>, dim3(nblk(n, 256)), dim3(256), 0, st, b_key.as<uint64_t>(), (const int64_t *)nullptr, n,
@@ -596,7 +628,7 @@ static int group_pairs_impl(hgx_groups **out, const int32_t *pair_off, const uin
                        b_flag.as<uint32_t>());
     { int rc_ = scan_u32(b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n, b_tmp.p, b_meta.as<uint32_t>() + 1, st); if (rc_) return rc_; }
     hipLaunchKernelGGL(k_sig_verify, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level,
-                       b_slot.as<uint32_t>(), b_first.as<uint32_t>(), b_meta.as<int>());
+                       b_slot.as<uint32_t>(), b_first.as<uint32_t>(), b_meta.as<int>(), seg);
     // group id (first-seen order) -> first pair, group size; sized for the worst case: no host-side group count needed yet
     hipLaunchKernelGGL(k_ht_finalize, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(),
                        b_cnt.as<unsigned long long>(), T, b_rank.as<uint32_t>(), g->d_first, g->d_count);
@@ -614,11 +646,22 @@ extern "C" int hgx_group_pairs(hgx_groups **out, const int32_t *pair_off, const 
     if (out) *out = nullptr;
     return fail_clean(group_pairs_impl(out, pair_off, refs, n_pairs, level, stream), out, (hipStream_t)stream, hgx_groups_destroy);
 }
+// the pairs of MANY tasks at once (hgx_type_many): pair_seg[p] = task of pair p; a group never spans two tasks
+int hgx_group_pairs_seg(hgx_groups **out, const int32_t *pair_off, const uint32_t *refs, int32_t n_pairs, int32_t level,
+                        const uint32_t *pair_seg, void *stream) {
+    if (out) *out = nullptr;
+    return fail_clean(group_pairs_impl(out, pair_off, refs, n_pairs, level, stream, pair_seg), out, (hipStream_t)stream, hgx_groups_destroy);
+}
 
 // stage 2: one row per group, then the row dedup weighted by the group sizes (st must be ordered behind hgx_piece_compat)
+__global__ void k_seg_of_first(const int64_t *__restrict__ first, long n, const uint32_t *__restrict__ seg, uint32_t *__restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = seg[first[i]];
+}
+
 static int level_classes_grouped_impl(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
                                       const uint32_t *refs, hgx_groups *g, uint64_t *rows_scratch, uint64_t *hash_scratch,
-                                      void *stream) {
+                                      void *stream, const uint32_t *pair_seg = nullptr) {
     ARGCHK(out && ix && g);
     { int rc_ = groups_finish(g); if (rc_) return rc_; }
     hipStream_t st = (hipStream_t)stream;
@@ -638,8 +681,16 @@ static int level_classes_grouped_impl(hgx_classes **out, const hgx_index *ix, co
                                   level == 0 ? rows : nullptr, level == 1 ? rows : nullptr, level == 0 ? hash : nullptr,
                                   level == 1 ? hash : nullptr, st);
     if (rc) return rc;
-    rc = dedup_hash_table(cl, rows, hash, plain ? nullptr : g->d_count, n_rows, w64, nullptr, st, true);
+    DevBuf b_rseg;                      // segment of every row: that of the group's first pair (the pairs themselves in the plain form)
+    const uint32_t *row_seg = pair_seg;
+    if (pair_seg && !plain) {
+        ALLOC(b_rseg, (size_t)n_rows * 4);
+        hipLaunchKernelGGL(k_seg_of_first, dim3(nblk(n_rows, 256)), dim3(256), 0, st, g->d_first, n_rows, pair_seg, b_rseg.as<uint32_t>());
+        row_seg = b_rseg.as<uint32_t>();
+    }
+    rc = dedup_hash_table(cl, rows, hash, plain ? nullptr : g->d_count, n_rows, w64, nullptr, st, true, row_seg);
     if (rc) return rc;
+    // (the row segments are read by k_verify_ht / the collision rounds only: all complete at the round trips inside the dedup)
     if (!plain && cl->n_classes > 0)
         hipLaunchKernelGGL(k_remap_first, dim3(nblk(cl->n_classes, 256)), dim3(256), 0, st, cl->d_first_row, cl->n_classes, g->d_first);
     HIPCHK(hipGetLastError());
@@ -662,6 +713,14 @@ extern "C" int hgx_level_classes_grouped(hgx_classes **out, const hgx_index *ix,
                       (hipStream_t)stream, hgx_classes_destroy);
 }
 
+int hgx_level_classes_grouped_seg(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
+                                  const uint32_t *refs, hgx_groups *g, uint64_t *rows_scratch, uint64_t *hash_scratch,
+                                  const uint32_t *pair_seg, void *stream) {
+    if (out) *out = nullptr;
+    return fail_clean(level_classes_grouped_impl(out, ix, compat, pair_off, refs, g, rows_scratch, hash_scratch, stream, pair_seg), out,
+                      (hipStream_t)stream, hgx_classes_destroy);
+}
+
 extern "C" int hgx_level_classes(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
                                  const uint32_t *refs, int32_t n_pairs, int32_t level, uint64_t *rows_scratch,
                                  uint64_t *hash_scratch, void *stream) {
@@ -680,6 +739,12 @@ extern "C" int hgx_level_classes(hgx_classes **out, const hgx_index *ix, const u
 }
 
 extern "C" int hgx_classes_destroy(hgx_classes *c);
+int hgx_dedup_classes_seg(hgx_classes **out, const uint64_t *rows, const uint64_t *row_hash, int64_t n_rows, int32_t a_pad,
+                          const uint32_t *row_seg, void *stream) {
+    if (out) *out = nullptr;
+    return fail_clean(dedup_classes_impl(out, rows, row_hash, nullptr, n_rows, a_pad, nullptr, stream, row_seg), out, (hipStream_t)stream,
+                      hgx_classes_destroy);
+}
 extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const uint64_t *row_hash, const int64_t *row_weight,
                                  int64_t n_rows, int32_t a_pad, const uint64_t *and_mask, void *stream) {
     if (out) *out = nullptr;

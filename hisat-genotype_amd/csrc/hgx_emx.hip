@@ -40,7 +40,7 @@ constexpr int XB = 1024, XNW = XB / 64;
 constexpr int XA = HGX_EMX_MAX_ALLELES, XC = HGX_EMX_MAX_CLASSES;
 constexpr int XAW = XA / 64, XCW = XC / 64;
 
-enum { XS_ITER = 0, XS_STATUS = 1, XS_A1 = 2, XS_ORDERS = 3, XS_RES_OFF = 4, XS_RES_N = 5, XS_N = 8 };
+enum { XS_ITER = 0, XS_STATUS = 1, XS_A1 = 2, XS_ORDERS = 3, XS_RES_OFF = 4, XS_RES_N = 5, XS_NCLS = 6, XS_N = 8 };
 
 struct EmxRes { int32_t allele, first; double prob; };       // one allele of a returned dict
 
@@ -49,7 +49,9 @@ struct EmxTask {
     const int64_t *count;
     const int32_t *rank;
     const double *len;
+    const uint64_t *mask;   // [w64] or NULL: the hand-off (core:1752-1766) -- rows AND mask, empty ones dropped, equal ones merged
     int32_t C, w64, a_pad, remove_low;
+    int32_t c_alloc;        // classes the class-indexed scratch is sized for (= C; the hand-off: the merged classes it may produce)
     // scratch
     uint64_t *Mk;       // [A1w][Cp]   word (aw, c): which alleles of tile aw are in class c
     uint64_t *Mr;       // [Cw][A1s]   word (cw, j): which classes of tile cw contain allele j
@@ -148,14 +150,13 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     const EmxTask T = tasks[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int C = T.C, w64 = T.w64;
-    const int Cp = (C + 63) & ~63, Cw = Cp >> 6, A1s = T.a_pad;
+    const int w64 = T.w64, A1s = T.a_pad;
+    const int CpA = (T.c_alloc + 63) & ~63;             // stride of the class-indexed scratch arrays
+    int C = T.C;                                        // (the hand-off mode continues with the merged classes)
     unsigned long long t_mark = T.stamps ? wall_clock64() : 0, acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     auto lap = [&](int k) { if (T.stamps) { const unsigned long long t = wall_clock64(); acc_t[k] += t - t_mark; t_mark = t; } };
-    if (C <= 0 || C > XC || w64 > 128 || A1s > XA) {
-        if (tid == 0) { T.scal[XS_STATUS] = 1.0; T.scal[XS_ITER] = 0.0; }
-        return;
-    }
+    auto give_up = [&](double status) { if (tid == 0) { T.scal[XS_STATUS] = status; T.scal[XS_ITER] = 0.0; T.scal[XS_RES_N] = 0.0; } };
+    if (C <= 0 || (!T.mask && C > XC) || w64 > 128 || A1s > XA) { give_up(1.0); return; }
     // ---- which alleles occur at all, and their place in name order ----------------------------------------------------
     for (int w = tid; w < 128; w += XB) { S.orw[w] = 0ull; S.rbm[w] = 0ull; }
     __syncthreads();
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
         unsigned long long acc = 0ull;
         if (w < w64)
             for (int c = slice; c < C; c += 8) acc |= T.B[(size_t)c * w64 + w];
+        if (acc && T.mask) acc &= T.mask[w];
         if (acc) atomicOr(&S.orw[w], acc);
     }
     __syncthreads();
@@ -180,8 +182,9 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     }
     __syncthreads();
     const int A1 = S.A1;
-    if (A1 > XA || A1 <= 0) {
-        if (tid == 0) { T.scal[XS_STATUS] = 1.0; T.scal[XS_ITER] = 0.0; }
+    if (A1 > XA || (T.mask && A1 > 64)) { give_up(1.0); return; }
+    if (A1 <= 0) {                                      // (hand-off: no class left) an empty result
+        if (tid == 0) { T.scal[XS_STATUS] = 0.0; T.scal[XS_ITER] = 0.0; T.scal[XS_RES_N] = 0.0; T.scal[XS_NCLS] = 0.0; T.scal[XS_A1] = 0.0; }
         return;
     }
     const int A1w = (A1 + 63) >> 6;
@@ -195,10 +198,10 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
         }
     __syncthreads();
     // ---- Mk: one wavefront per class picks, for every compact allele, its bit out of the row (held in LDS) ------------------
-    double *cnt_c = T.cls, *t0_c = T.cls + Cp, *n_c = T.cls + 2 * (size_t)Cp, *s_c = T.cls + 3 * (size_t)Cp, *r_c = T.cls + 4 * (size_t)Cp;
-    {
-        unsigned long long *rowbuf = reinterpret_cast<unsigned long long *>(&S.tmpo[0][0]) + (size_t)wave * 128;
-        for (int c = wave; c < Cp; c += XNW) {
+    double *cnt_c = T.cls, *t0_c = T.cls + CpA, *n_c = T.cls + 2 * (size_t)CpA, *s_c = T.cls + 3 * (size_t)CpA, *r_c = T.cls + 4 * (size_t)CpA;
+    unsigned long long *rowbuf = reinterpret_cast<unsigned long long *>(&S.tmpo[0][0]) + (size_t)wave * 128;
+    if (!T.mask) {
+        for (int c = wave; c < CpA; c += XNW) {
             if (c < C) {
                 rowbuf[lane] = lane < w64 ? T.B[(size_t)c * w64 + lane] : 0ull;
                 rowbuf[64 + lane] = lane + 64 < w64 ? T.B[(size_t)c * w64 + 64 + lane] : 0ull;
@@ -215,21 +218,74 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
                 if (lane == (aw & 63)) { if (aw < 64) keep0 = m; else keep1 = m; }
             }
             __builtin_amdgcn_wave_barrier();
-            if (lane < A1w) T.Mk[(size_t)lane * Cp + c] = keep0;
-            if (lane + 64 < A1w) T.Mk[(size_t)(lane + 64) * Cp + c] = keep1;
+            if (lane < A1w) T.Mk[(size_t)lane * CpA + c] = keep0;
+            if (lane + 64 < A1w) T.Mk[(size_t)(lane + 64) * CpA + c] = keep1;
             if (lane == 0) {
                 const double n = c < C ? (double)T.count[c] : 0.0;
                 cnt_c[c] = n;
                 t0_c[c] = size > 0 ? ((n) / ((double)size)) : 0.0;      // float(count) / len(alleles), common:1304
             }
         }
+    } else {
+        // Gene_cmpt2 (core:1752-1766): every class filtered to the kept alleles (<= 64: one word over the compact alleles), the
+        // empty ones dropped, equal ones merged with their counts added -- an LDS table keyed by the word -- in the order of
+        // their first class (= the insertion order of the reference's dict)
+        constexpr int MT = 4096;
+        unsigned long long *mkey = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(&S.tmpo[0][0]) + (16 << 10));
+        unsigned int *mfirst = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(&S.tmpo[0][0]) + (48 << 10));
+        unsigned long long *mcnt = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(&S.tmpo[0][0]) + (66 << 10));
+        unsigned int *mlist = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(&S.tmpo[0][0]) + (100 << 10));
+        for (int i = tid; i < MT; i += XB) { mkey[i] = 0ull; mcnt[i] = 0ull; mfirst[i] = 0xFFFFFFFFu; }
+        if (tid == 0) { S.npos[0] = 0; S.npos[1] = 0; }
+        __syncthreads();
+        for (int c = wave; c < C; c += XNW) {
+            rowbuf[lane] = lane < w64 ? T.B[(size_t)c * w64 + lane] & T.mask[lane] : 0ull;
+            rowbuf[64 + lane] = lane + 64 < w64 ? T.B[(size_t)c * w64 + 64 + lane] & T.mask[64 + lane] : 0ull;
+            __builtin_amdgcn_wave_barrier();
+            const int g = lane < A1 ? srt[lane] : 0;
+            const unsigned long long m = __ballot(lane < A1 && ((rowbuf[g >> 6] >> (g & 63)) & 1ull));
+            __builtin_amdgcn_wave_barrier();
+            if (m != 0ull && lane == 0) {
+                unsigned int h = (unsigned int)(mix64(m) >> 40) & (MT - 1);
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&mkey[h], 0ull, m);
+                    if (old == 0ull) atomicAdd(&S.npos[0], 1);
+                    if (old == 0ull || old == m) break;
+                    h = (h + 1) & (MT - 1);
+                    if (S.npos[0] > MT / 2) break;
+                }
+                if (S.npos[0] <= MT / 2) { atomicAdd(&mcnt[h], (unsigned long long)T.count[c]); atomicMin(&mfirst[h], (unsigned int)c); }
+            }
+        }
+        __syncthreads();
+        const int C1 = S.npos[0];
+        if (C1 > MT / 2 || C1 > T.c_alloc) { give_up(1.0); return; }
+        for (int i = tid; i < MT; i += XB)
+            if (mkey[i] != 0ull) mlist[atomicAdd(&S.npos[1], 1)] = (unsigned int)i;
+        __syncthreads();
+        const int C1p = (C1 + 63) & ~63;
+        for (int e = tid; e < C1p; e += XB) {
+            if (e < C1) {
+                const unsigned int slot = mlist[e], f = mfirst[slot];
+                int rk = 0;
+                for (int o = 0; o < C1; ++o) rk += mfirst[mlist[o]] < f;       // first classes are distinct: a permutation
+                const unsigned long long m = mkey[slot];
+                const double n = (double)(long long)mcnt[slot];
+                T.Mk[rk] = m;
+                cnt_c[rk] = n;
+                t0_c[rk] = ((n) / ((double)__popcll(m)));
+            } else { T.Mk[e] = 0ull; cnt_c[e] = 0.0; t0_c[e] = 0.0; }
+        }
+        C = C1;
+        __syncthreads();
     }
+    const int Cp = (C + 63) & ~63, Cw = Cp >> 6;
     for (int j = tid; j < A1s; j += XB) T.vlen[j] = (T.len && j < A1) ? T.len[srt[j]] : 1.0;
     phase_sync();
     // ---- Mr: 64 x 64 bit transposes of Mk tiles ------------------------------------------------------------------
     for (int item = wave; item < Cw * A1w; item += XNW) {
         const int cw = item / A1w, aw = item - cw * A1w;
-        const uint64_t x = T.Mk[(size_t)aw * Cp + 64 * cw + lane];
+        const uint64_t x = T.Mk[(size_t)aw * CpA + 64 * cw + lane];
         T.Mr[(size_t)cw * A1s + 64 * aw + lane] = wave_transpose64(x);
     }
     const bool use_len = T.len != nullptr;
@@ -376,7 +432,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
             const bool lane_fast = p == 0.0 || (p >= 0x1p-600 && p <= 0x1p600);
             const bool tile_slow = block_slow || __any(!lane_fast);
             double acc = 0.0;
-            const uint64_t *mcol = T.Mk + (size_t)aw * Cp;
+            const uint64_t *mcol = T.Mk + (size_t)aw * CpA;
             if (!tile_slow) {
                 for (int c0 = 0; c0 < Cp; c0 += 8) {
                     u32x16 mw, vn, vs, vr;
@@ -454,7 +510,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     for (int aw = wave; aw < A1w; aw += XNW) {
         const int j = 64 * aw + lane;
         double acc = 0.0;
-        const uint64_t *mcol = T.Mk + (size_t)aw * Cp;
+        const uint64_t *mcol = T.Mk + (size_t)aw * CpA;
         for (int c0 = 0; c0 < Cp; c0 += 8) {
             u32x16 mw, vt;
             sload2(mcol + c0, t0_c + c0, mw, vt);
@@ -563,6 +619,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
         T.scal[XS_STATUS] = keyerr ? 2.0 : 0.0;
         T.scal[XS_A1] = (double)A1;
         T.scal[XS_ORDERS] = (double)n_orders;
+        T.scal[XS_NCLS] = (double)C;
         T.scal[XS_RES_OFF] = (double)S.res_base;
         T.scal[XS_RES_N] = (double)res_n;
     }
@@ -594,10 +651,12 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
     for (int i = 0; i < n_jobs; ++i) {
         hgx_emx_job &J = jobs[i];
         J.n_iter = 0;
+        J.n_classes = 0;
         J.status = 1;
-        if (J.C <= 0 || J.C > HGX_EMX_MAX_CLASSES || J.w64 > 128 || J.a_pad > HGX_EMX_MAX_ALLELES || J.a_pad != 64 * J.w64) continue;
+        if (J.C <= 0 || (!J.mask && J.C > HGX_EMX_MAX_CLASSES) || J.w64 > 128 || J.a_pad > HGX_EMX_MAX_ALLELES || J.a_pad != 64 * J.w64) continue;
         ARGCHK(J.bits && J.count && J.rank && J.prob && J.n_out <= J.a_pad);
-        const size_t Cp = ((size_t)J.C + 63) & ~(size_t)63, A1s = (size_t)J.a_pad, A1w = A1s / 64, Cw = Cp / 64;
+        const size_t c_alloc = J.mask ? std::min<size_t>((size_t)J.C, 2048) : (size_t)J.C;
+        const size_t Cp = (c_alloc + 63) & ~(size_t)63, A1s = (size_t)J.a_pad, A1w = J.mask ? 1 : A1s / 64, Cw = Cp / 64;
         Lay L;
         size_t o = 0;
         L.Mk = o; o += up64(A1w * Cp * 8);
@@ -634,8 +693,9 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
         const Lay &L = lays[t];
         char *b = scr + base[t];
         EmxTask &T = tasks[t];
-        T.B = J.bits; T.count = J.count; T.rank = J.rank; T.len = J.len;
+        T.B = J.bits; T.count = J.count; T.rank = J.rank; T.len = J.len; T.mask = J.mask;
         T.C = J.C; T.w64 = J.w64; T.a_pad = J.a_pad; T.remove_low = J.remove_low ? 1 : 0;
+        T.c_alloc = J.mask ? std::min(J.C, 2048) : J.C;
         T.Mk = (uint64_t *)(b + L.Mk); T.Mr = (uint64_t *)(b + L.Mr); T.dv = (double *)(b + L.dv); T.pos = (uint16_t *)(b + L.pos);
         T.tmpv = (double *)(b + L.tmpv); T.vlen = (double *)(b + L.vlen); T.cls = (double *)(b + L.cls); T.din = (uint8_t *)(b + L.din);
         T.sorted = (int32_t *)(b + L.sorted); T.first_c = (int32_t *)(b + L.first);
@@ -673,6 +733,7 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
         const double *sc = (const double *)(h.data() + 64 + (size_t)t * XS_N * 8);
         J.status = (int32_t)sc[XS_STATUS];
         J.n_iter = (int32_t)sc[XS_ITER];
+        J.n_classes = (int32_t)sc[XS_NCLS];
         if (J.status == 1) continue;
         for (int a = 0; a < J.n_out; ++a) J.prob[a] = -1.0;
         if (J.first) for (int a = 0; a < J.n_out; ++a) J.first[a] = -1;

@@ -13,12 +13,17 @@ struct hgx_emx_job {
     const int64_t *count;       // [C]
     const int32_t *rank;        // [a_pad]
     const double *len;          // [a_pad] or NULL
+    const uint64_t *mask;       // [w64] or NULL.  With a mask the job is the exon -> gene hand-off (typing_core.py:1752-1766): every
+                                // class is filtered to the alleles of the mask (at most 64 may occur, else status 1), empty ones are
+                                // dropped, equal ones merged with their counts added, in the order of their first class; the EM
+                                // runs on that set and `first` / n_classes refer to it
     int32_t C, w64, a_pad, remove_low;
     // results (HOST memory, filled by hgx_emx_run)
     double *prob;               // [n_out] abundance, or -1.0 for an allele that is not in the returned dict
     int32_t *first;             // [n_out] or NULL: first class (dict order) containing the allele, -1 elsewhere
     int32_t n_out;              // alleles reported (<= a_pad)
     int32_t n_iter;             // outer iterations
+    int32_t n_classes;          // classes the EM ran on (= C without a mask)
     int32_t status;             // 0 = done, 1 = not taken (too many classes / distinct alleles: the caller uses another path),
                                 // 2 = the reference would raise KeyError (quirk Q6)
 };

@@ -375,6 +375,45 @@ extern "C" int hgx_batch_from_haplotypes(hgx_batch **out, const hgx_locus *L, in
     return HGX_OK;
 }
 
+// The batches of MANY tasks of one locus as ONE batch (hgx_many_create): distinct pieces interned across the tasks (samples of
+// a locus repeat each other's pieces), pairs concatenated task after task, refs renumbered; pair_base[t] = first pair of task t
+// (n + 1 entries).  The piece table is re-ordered canonically, as every batch is.
+int hgx_batch_merge(hgx_batch **out, const hgx_batch *const *batches, int32_t n, int32_t *pair_base) {
+    HARGCHK(out && n >= 0 && (n == 0 || batches) && pair_base);
+    hgx_batch *m = new hgx_batch();
+    size_t n_pairs = 0, n_refs = 0, n_pieces = 0;
+    for (int t = 0; t < n; ++t) {
+        HARGCHK(batches[t]);
+        n_pairs += batches[t]->pair_off.size() - 1;
+        n_refs += batches[t]->pair_ref.size();
+        n_pieces += batches[t]->pieces.size();
+    }
+    if (n_pairs >= (1ull << 31) || n_refs >= (1ull << 31)) { delete m; hgx_set_error("too many pairs / piece refs for one merged batch"); return HGX_EINVAL; }
+    m->pair_off.clear();
+    m->pair_off.reserve(n_pairs + 1);
+    m->pair_off.push_back(0);
+    m->pair_ref.reserve(n_refs);
+    m->pieces.reserve(std::min<size_t>(n_pieces, 1u << 20));
+    std::vector<uint32_t> map;
+    for (int t = 0; t < n; ++t) {
+        const hgx_batch &b = *batches[t];
+        pair_base[t] = (int32_t)(m->pair_off.size() - 1);
+        map.resize(b.pieces.size());
+        for (size_t i = 0; i < b.pieces.size(); ++i) {
+            const hgx_piece &pc = b.pieces[i];
+            map[i] = hgx_intern_masks(*m, pc.lo_word, pc.n_words, &b.masks[pc.mask_off]);
+        }
+        const int32_t ref_base = (int32_t)m->pair_ref.size();
+        for (uint32_t r : b.pair_ref) m->pair_ref.push_back((r & 0x80000000u) | map[r & 0x7fffffffu]);
+        for (size_t p = 1; p < b.pair_off.size(); ++p) m->pair_off.push_back(ref_base + b.pair_off[p]);
+        m->n_reads += b.n_reads;
+    }
+    pair_base[n] = (int32_t)(m->pair_off.size() - 1);
+    hgx_finalize_batch(*m, hgx_default_threads());
+    *out = m;
+    return HGX_OK;
+}
+
 extern "C" int hgx_batch_destroy(hgx_batch *b) { delete b; return HGX_OK; }
 
 extern "C" int hgx_batch_dims(const hgx_batch *b, int32_t *n_pieces, int64_t *n_mask_u32, int32_t *n_pairs, int64_t *n_refs,

@@ -179,5 +179,6 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
 uint32_t hgx_intern_masks(hgx_batch &b, uint16_t lo, uint16_t nw, const uint32_t *m);
 void hgx_finalize_batch(hgx_batch &b, int n_threads = 1);
 void hgx_canonical_piece_order(hgx_batch &b, int n_threads, std::vector<uint32_t> &new_id);
+int hgx_batch_merge(hgx_batch **out, const hgx_batch *const *batches, int32_t n, int32_t *pair_base);
 // alternatives tables (defined in hgx_sam.cpp)
 int hgx_build_alternatives(hgx_locus &loc);

@@ -52,6 +52,32 @@ class DeviceBatch:
             pass
 
 
+class ManyBatch:
+    """The piece batches of many tasks of ONE locus merged and resident in HBM (hgx_many): what hgx_type_many types at once."""
+
+    def __init__(self, locus, batches, stream=None):
+        self.h = C.c_void_p()
+        self.n_tasks = len(batches)
+        arr = (C.c_void_p * max(len(batches), 1))(*[b.h for b in batches])
+        capi.check(capi.lib().hgx_many_create(C.byref(self.h), locus.h, arr, C.c_int32(len(batches)), stream))
+        nt, npc, npr, nrf, nrd = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
+        capi.check(capi.lib().hgx_many_dims(self.h, C.byref(nt), C.byref(npc), C.byref(npr), C.byref(nrf), C.byref(nrd)))
+        self.n_pieces, self.n_pairs, self.n_refs, self.n_reads = npc.value, npr.value, nrf.value, nrd.value
+        self.task_reads = [b.n_reads for b in batches]
+        self.task_pairs = [b.n_pairs for b in batches]
+
+    def close(self):
+        if self.h:
+            capi.lib().hgx_many_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Gate:
     """hgx_gate: shared by the samples in flight on one GPU; hgx_type_* holds it from entry until the sample's exon-level
     classes exist, so that one bandwidth-bound front runs at a time, beside the other samples' EM phases."""

@@ -186,6 +186,41 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
         L.hgx_typing_destroy(h)
 
 
+def type_many(pl, many, remove_low=True, stream=None, return_errors=False):
+    """Every task of a merged batch (engine.ManyBatch: many samples of ONE locus) in one call into libhgx (hgx_type_many): one
+    launch chain for all tasks instead of one per task -- the many-samples form of the per-locus body of typing()
+    (typing_core.py:370, /root/reference/hisatgenotype:613-665).  Returns one LocusResult per task, each identical to
+    _type_batch on that task alone.  Where the reference would raise on a task (quirk Q3 / Q6) the call raises, unless
+    `return_errors`: then that task's entry is the exception instance."""
+    L = capi.lib()
+    n = many.n_tasks
+    o = TypeOpts(int(bool(remove_low)), 0, 0, 0, None, None, None, None, None)
+    hs = (C.c_void_p * max(n, 1))()
+    rcs = (C.c_int32 * max(n, 1))()
+    capi.check(L.hgx_type_many(hs, rcs, pl.h, pl.index(), many.h, C.byref(o), stream))
+    out = []
+    try:
+        for t in range(n):
+            if rcs[t] != 0:
+                err = TypeError("'dict_keys' object is not subscriptable (reference quirk Q3, typing_core.py:1787)") if rcs[t] == -7 else \
+                    capi.HgxKeyError(rcs[t], "EM: allele missing from the next estimate (common:1365-1369)") if rcs[t] == -4 else \
+                    capi.HgxError(rcs[t], "task %d failed" % t)
+                if not return_errors:
+                    raise err
+                out.append(err)
+                continue
+            res = LocusResult()
+            res.num_reads, res.num_pairs = many.task_reads[t], many.task_pairs[t]
+            if res.num_reads > 0:
+                _result_from_handle(C.c_void_p(hs[t]), pl, res, False)
+            out.append(res)
+    finally:
+        for t in range(n):
+            if hs[t]:
+                L.hgx_typing_destroy(C.c_void_p(hs[t]))
+    return out
+
+
 def report_lines(res, simulation=False, true_alleles=(), output_allele_counts=False, best_alleles=False):
     """Report body (core:1593, 1650-1677, 2076-2121)."""
     out = ["\t\t\t%d reads and %d pairs are aligned" % (res.num_reads, res.num_pairs)]

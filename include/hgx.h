@@ -414,6 +414,23 @@ int hgx_typing_gene_prob(const hgx_typing *t, int32_t *allele, double *prob);
 /* with keep_classes: the class sets behind the result (owned by `t`; NULL if that level was not built) */
 int hgx_typing_classes(const hgx_typing *t, int32_t level, const hgx_classes **out);
 
+/* ---- many tasks of ONE locus behind one launch chain ------------------------------------------------------------------
+ * The reference's unit of scale is many samples x loci: one genotyping_locus per sample through a process pool
+ * (/root/reference/hisatgenotype:613-665) and the locus loop inside typing() (typing_core.py:370).  hgx_type_many types every
+ * (sample, locus) task of a locus at once: the tasks' piece batches are merged (hgx_many_create: pairs task after task,
+ * distinct pieces interned across tasks), scored and de-duplicated by the kernels of the one-task path with the dedup keeping
+ * tasks apart, and Gene_counts, EM #1, the hand-off and EM #2 run with a task dimension -- the launch count no longer grows with
+ * the number of tasks.  out[t] = the result of task t (hgx_typing_* accessors; destroy each with hgx_typing_destroy), identical
+ * to hgx_type_batch on task t's batch alone.  rc_out (may be NULL): per-task status -- HGX_ETYPE / HGX_EKEY where the reference
+ * would raise on THAT task (out[t] = NULL then); with rc_out NULL such a task fails the whole call.  hgx_type_opts: remove_low
+ * is honoured; class sets are not kept per task. */
+typedef struct hgx_many hgx_many;
+int hgx_many_create(hgx_many **out, const hgx_locus *loc, const hgx_batch *const *batches, int32_t n_tasks, void *stream);
+int hgx_many_destroy(hgx_many *m);
+int hgx_many_dims(const hgx_many *m, int32_t *n_tasks, int32_t *n_distinct_pieces, int32_t *n_pairs, int64_t *n_refs, int64_t *n_reads);
+int hgx_type_many(hgx_typing **out /* [n_tasks] */, int32_t *rc_out /* [n_tasks] or NULL */, const hgx_locus *loc, const hgx_index *ix,
+                  hgx_many *m, const hgx_type_opts *opts, void *stream);
+
 /* Kernel timing for roofline reports.  hgx_em_set_timing(1) makes hgx_em time a sample of its table-lookup mat-vec launches
  * (every 4th ungated rows pass and the cols pass after it), hgx_em_set_timing(2) every plain rows / cols pass, with events
  * attached to the dispatch itself (hipExtLaunchKernelGGL: kernel begin / end, as rocprofv3 measures).  Switching timing on

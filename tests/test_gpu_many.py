@@ -1,0 +1,77 @@
+"""hgx_type_many (many samples of one locus behind one launch chain) against the one-task path: every field of every task's
+result must be EQUAL -- counts and their order, class counts, iteration counts, and the EM abundances as doubles."""
+import numpy as np
+import pytest
+
+import hisatgenotype_amd as hgx
+from hisatgenotype_amd import engine, locus as hl, synth
+import sys
+htyping = sys.modules["hisatgenotype_amd.typing"]
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    assert a.num_reads == b.num_reads and a.num_pairs == b.num_pairs
+    if a.num_reads == 0:
+        return
+    assert np.array_equal(a.counts_order, b.counts_order)
+    assert np.array_equal(a.counts, b.counts)
+    assert len(a.em) == len(b.em)
+    for x, y in zip(a.em, b.em):
+        assert x["n_classes"] == y["n_classes"] and x["n_iter"] == y["n_iter"]
+        assert x["remove_low"] == y["remove_low"] and x["use_length"] == y["use_length"]
+        assert x["result"] == y["result"], (x["result"][:3], y["result"][:3])
+    assert a.gene_prob == b.gene_prob
+
+
+def _one(pl, batch, remove_low=True):
+    res = htyping.LocusResult()
+    res.num_reads, res.num_pairs = batch.n_reads, batch.n_pairs
+    if batch.n_reads <= 0:
+        return res
+    return htyping._type_batch(pl, batch, res, remove_low)
+
+
+@pytest.mark.parametrize("n_alleles,n_vars,pairs", [(300, 500, [400, 900, 0, 1500, 37, 600]), (2500, 1500, [1200, 2500, 800]),
+                                                     (7000, 2500, [3000, 1000])])
+def test_many_equals_one_by_one_hla(n_alleles, n_vars, pairs):
+    loc = synth.make_hla_like_locus(n_alleles=n_alleles, n_vars=n_vars, seed=31 + n_alleles)
+    pl = hl.PackedLocus.from_synth(loc)
+    batches = []
+    for s, n in enumerate(pairs):
+        sample = synth.pick_sample(loc, 50 + s)
+        sam = synth.simulate_sam_fast(loc, sample, n, err_rate=0.003, seed=7 * s + 1) if n else ""
+        batches.append(pl.parse_sam(sam))
+    many = engine.ManyBatch(pl, batches)
+    assert many.n_pairs == sum(b.n_pairs for b in batches) and many.n_pieces <= sum(b.n_pieces for b in batches)
+    for low in (True, False):
+        got = htyping.type_many(pl, many, remove_low=low)
+        assert len(got) == len(batches)
+        for g, b in zip(got, batches):
+            _same(g, _one(pl, b, low))
+    # the same call again on the same resident batch (buffers recycled, scratch reused): identical
+    again = htyping.type_many(pl, many)
+    for g, h in zip(again, htyping.type_many(pl, many)):
+        _same(g, h)
+
+
+def test_many_equals_one_by_one_str_locus():
+    """CODIS-like STR loci (gene level only, EM without pruning; a task with ONE class is the reference's quirk Q3)."""
+    loc = synth.make_str_like_locus(gene="TH01", unit="AATG", max_repeats=12, min_repeats=4, seed=5)
+    pl = hl.PackedLocus.from_synth(loc)
+    batches = []
+    for s, n in enumerate([300, 50, 700, 2]):
+        names = [a for a in loc.allele_names if "BACKBONE" not in a]
+        sample = [names[2 + s], names[-2 - s]] if n > 2 else [names[1]]
+        sam = synth.simulate_sam_fast(loc, sample, n, read_len=100, frag_len=(200, 300), err_rate=0.002, seed=3 * s + 2)
+        batches.append(pl.parse_sam(sam))
+    many = engine.ManyBatch(pl, batches)
+    got = htyping.type_many(pl, many, return_errors=True)
+    for g, b in zip(got, batches):
+        try:
+            want = _one(pl, b)
+        except TypeError:
+            assert isinstance(g, TypeError)
+            continue
+        _same(g, want)
