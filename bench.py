@@ -98,6 +98,10 @@ def parse_args():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for --dry-run on CPU)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank joins the process group and rank 0 prints the world it saw (no GPU work)")
+    ap.add_argument("--em-exact", action="store_true",
+                    help="panel64: EM #1 in the reference's own order of floating-point operations (hgx_type_opts.em_fast = 0, the "
+                         "library's default: bit-identical abundances) instead of the table-lookup arithmetic the throughput run uses")
+    ap.add_argument("--one-by-one", action="store_true", help="panel64: one launch chain per task (round 2's form) instead of hgx_type_many")
     ap.add_argument("--inflight", type=int, default=1,
                     help="samples typed concurrently per GPU (host threads with their own streams and class-row buffers; "
                          "the EM of one sample is a chain of short launches that leaves the GPU to the scoring of the next)")
@@ -442,12 +446,25 @@ def run_panel64(args, rank, local_rank, world, dist):
         sam = synth.simulate_sam_fast(loci[k], sample, args.panel_pairs, err_rate=args.err, seed=100 * s + k)
         batch = packed[k].parse_sam(sam)
         work.append((s, k, batch, engine.DeviceBatch(batch), sample))
+    # the rank's tasks of a locus, merged and resident in HBM: ONE launch chain per locus (hgx_type_many)
+    manies = {}
+    if not args.one_by_one:
+        for k in sorted(packed):
+            idx = [n for n, w in enumerate(work) if w[1] == k]
+            manies[k] = (idx, engine.ManyBatch(packed[k], [work[n][2] for n in idx]))
     t_setup = time.perf_counter() - t_setup
     inflight = max(1, args.inflight)
 
     def body():
         import threading
         out = [None] * len(work)
+        if manies:
+            ks = sorted(manies)
+            rows = htyping.type_many_loci([packed[k] for k in ks], [manies[k][1] for k in ks], light=True, em_fast=not args.em_exact)
+            for k, row in zip(ks, rows):
+                for n, r in zip(manies[k][0], row):
+                    out[n] = r
+            return out
         if inflight <= 1:
             for n, (s, k, batch, db, _) in enumerate(work):
                 out[n] = step(packed[k], batch, db)
@@ -480,8 +497,12 @@ def run_panel64(args, rank, local_rank, world, dist):
     for _ in range(args.warmup):
         body()
     elapsed, last = _timed(dist, args.steps, body)
-    reads = float(sum(r.num_reads for r in last))
-    correct = sum(1 for r, (s, k, _, _, sample) in zip(last, work) if sorted(a for a, _ in r.gene_prob[:2]) == sorted(sample))
+    if manies:
+        reads = float(sum(r[0] for r in last))
+        correct = sum(1 for r, (s, k, _, _, sample) in zip(last, work) if sorted(r[1]) == sorted(sample))
+    else:
+        reads = float(sum(r.num_reads for r in last))
+        correct = sum(1 for r, (s, k, _, _, sample) in zip(last, work) if sorted(a for a, _ in r.gene_prob[:2]) == sorted(sample))
     n_tasks = len(work)
     if dist is not None:
         import torch
@@ -497,6 +518,8 @@ def run_panel64(args, rank, local_rank, world, dist):
             "config": {"workload": "configs[3]: 6 loci (500-8000 alleles) x 64 samples = %d tasks of %d pairs, piece batches resident in HBM" % (
                 n_tasks, args.panel_pairs),
                 "tasks_with_both_true_alleles_on_top": correct, "tasks": n_tasks, "samples_in_flight_per_gpu": inflight,
+                "form": "one launch chain per task" if args.one_by_one else "hgx_type_many_loci: one launch chain per locus (all its samples together), the EMs of all loci in one launch",
+                "em_arithmetic": ("reference order (bit-identical)" if args.em_exact else "table lookups (within 1e-9; hgx_type_opts.em_fast)") if not args.one_by_one else "default",
                 "parallelism": "(sample, locus) tasks over GPUs by dist.shard (greedy by allele count), no data-path collective",
                 "setup_s": round(t_setup, 1)},
             "roofline": None, "cpu_baseline": None}))

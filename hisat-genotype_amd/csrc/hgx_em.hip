@@ -3255,6 +3255,8 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
 // 1 if the calling thread's last EM (hgx_em / hgx_em_ordered / hgx_em_masked) ran on the single-wavefront path in the reference's
 // own order of floating-point operations (its abundances are then the reference's, bit for bit), 0 otherwise
 static thread_local int g_last_exact = 0;
+static thread_local int g_em_fast = 0;           // hgx_em_set_fast: table-lookup arithmetic on the one-workgroup path (k_emx)
+extern "C" int hgx_em_set_fast(int on) { const int old = g_em_fast; g_em_fast = on ? 1 : 0; return old; }
 static thread_local bool g_no_grid = false;      // set while an EM is re-run after a resident-block launch was abandoned
 extern "C" int hgx_em_last_exact(void) { return g_last_exact; }
 
@@ -3374,6 +3376,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         hgx_emx_job job{};
         job.bits = c->d_bits; job.count = c->d_count; job.rank = b_rank.as<int32_t>(); job.len = allele_len ? b_len.as<double>() : nullptr;
         job.C = C; job.w64 = c->w64; job.a_pad = A; job.remove_low = remove_low ? 1 : 0;
+        job.fast = g_em_fast;
         job.prob = prob_host; job.first = first_host; job.n_out = n_alleles;
         { int rc_ = hgx_emx_run(&job, 1, st); if (rc_) return rc_; }
         if (job.status == 2) {
@@ -3382,7 +3385,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         }
         if (job.status == 0) {
             if (n_iter_host) *n_iter_host = job.n_iter;
-            g_last_exact = 1;
+            g_last_exact = job.fast ? 0 : 1;
             return HGX_OK;
         }
         for (int a = 0; a < n_alleles; ++a) prob_host[a] = 0.0;

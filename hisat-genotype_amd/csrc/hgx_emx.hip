@@ -52,6 +52,7 @@ struct EmxTask {
     const uint64_t *mask;   // [w64] or NULL: the hand-off (core:1752-1766) -- rows AND mask, empty ones dropped, equal ones merged
     int32_t C, w64, a_pad, remove_low;
     int32_t c_alloc;        // classes the class-indexed scratch is sized for (= C; the hand-off: the merged classes it may produce)
+    int32_t fast;           // 1: table-lookup arithmetic (any summation order; within rounding of the reference), see fast_* below
     // scratch
     uint64_t *Mk;       // [A1w][Cp]   word (aw, c): which alleles of tile aw are in class c
     uint64_t *Mr;       // [Cw][A1s]   word (cw, j): which classes of tile cw contain allele j
@@ -109,6 +110,7 @@ struct XLds {
     double bc[4];
     int npos[4];
     int cache_ord, need_slow, A1, res_base;
+    double xs[512];                            // (fast mode) the slab of the vector a lookup table is built from
 };
 
 #pragma clang fp contract(off)
@@ -144,10 +146,48 @@ __device__ __forceinline__ void seq_sum2(const double *a, const double *b, int n
     }
 }
 
+#pragma clang fp contract(fast)
+// ---- fast mode: "four Russians" over a 0/1 matrix (as k_lutmatvec, hgx_em.hip, on ONE workgroup) ---------------------------------
+// 256 subset sums of each of the 64 groups of 8 consecutive elements of xs[512]: one lookup then stands for 8 matrix bits
+__device__ __forceinline__ void xlut_build(const double *xs, double *Tb, int tid) {
+    const int g = tid >> 4, lo = tid & 15;
+    const double x0 = xs[8 * g], x1 = xs[8 * g + 1], x2 = xs[8 * g + 2], x3 = xs[8 * g + 3];
+    const double x4 = xs[8 * g + 4], x5 = xs[8 * g + 5], x6 = xs[8 * g + 6], x7 = xs[8 * g + 7];
+    const double L = (((lo & 1 ? x0 : 0.0) + (lo & 2 ? x1 : 0.0)) + (lo & 4 ? x2 : 0.0)) + (lo & 8 ? x3 : 0.0);
+    double *Tg = Tb + g * 256 + lo;
+#pragma unroll
+    for (int hi = 0; hi < 16; ++hi) {
+        const double H = (((hi & 1 ? x4 : 0.0) + (hi & 2 ? x5 : 0.0)) + (hi & 4 ? x6 : 0.0)) + (hi & 8 ? x7 : 0.0);
+        Tg[hi * 16] = L + H;
+    }
+}
+__device__ __forceinline__ double xlut_row(const double *Tb, const uint64_t (&w)[8]) {
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (__ballot(w[i] != 0ull) == 0ull) continue;
+        const uint32_t wl = (uint32_t)w[i], wh = (uint32_t)(w[i] >> 32);
+        const double *Ti = Tb + i * 8 * 256;
+        acc += Ti[0 * 256 + (wl & 255u)];
+        acc += Ti[1 * 256 + ((wl >> 8) & 255u)];
+        acc += Ti[2 * 256 + ((wl >> 16) & 255u)];
+        acc += Ti[3 * 256 + (wl >> 24)];
+        acc += Ti[4 * 256 + (wh & 255u)];
+        acc += Ti[5 * 256 + ((wh >> 8) & 255u)];
+        acc += Ti[6 * 256 + ((wh >> 16) & 255u)];
+        acc += Ti[7 * 256 + (wh >> 24)];
+        asm volatile("" : "+v"(acc));                      // (eight lookups in flight at a time, not sixty-four)
+    }
+    return acc;
+}
+
+#pragma clang fp contract(off)
+template <bool FAST>
 __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     extern __shared__ double xlds_raw[];
     XLds &S = *reinterpret_cast<XLds *>(xlds_raw);
     const EmxTask T = tasks[blockIdx.x];
+    if ((T.fast != 0) != FAST) return;                    // (the launch of the other arithmetic takes this job)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int w64 = T.w64, A1s = T.a_pad;
@@ -501,12 +541,175 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
         __syncthreads();
     };
 
-    // ---- initial estimate (common:1300-1309): prob[a] += count / |class| over the classes in dict order ---------------
     int prob = 0, next = 1, next2 = 2;
     for (int j = tid; j < A1s; j += XB)
         for (int d = 0; d < 3; ++d) { dv[d][j] = 0.0; din[d][j] = 0; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    double diff = 1.0;
+    int iter = 0;
+    bool keyerr = false;
+    if constexpr (FAST) {
+        // ---- the same EM with table-lookup mat-vecs and tree reductions (any summation order): T(p)_a = p_a * sum_c n_c / s_c ----
+        double *Tb = &S.tmpo[0][0];                        // [64][256]
+        auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
+        auto block_sum = [&](double v) -> double {
+            v = wave_sum_f64(v);
+            __syncthreads();
+            if (lane == 0) S.red[wave] = v;
+            __syncthreads();
+            double t = 0.0;
+#pragma unroll
+            for (int i = 0; i < XNW; ++i) t = t + S.red[i];
+            return t;
+        };
+        // y_j = sum over the classes of x_c [class contains j], for every compact allele j; lane = allele, 512 classes per table
+        auto cols_lut = [&](const double *x, double (&acc)[8]) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc[k] = 0.0;
+            for (int sl = 0; sl * 512 < Cp; ++sl) {
+                __syncthreads();
+                if (tid < 512) { const int c = 512 * sl + tid; S.xs[tid] = c < Cp ? x[c] : 0.0; }
+                __syncthreads();
+                xlut_build(S.xs, Tb, tid);
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int j = tid + XB * k;
+                    asm volatile("" : "+v"(j));            // (addresses formed here, not kept in 128 registers across the slabs)
+                    if (j < 64 * A1w) {
+                        uint64_t w[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { const int cw = 8 * sl + i; w[i] = cw < Cw ? T.Mr[(size_t)cw * A1s + j] : 0ull; }
+                        acc[k] += xlut_row(Tb, w);
+                    }
+                    asm volatile("" ::: "memory");         // (one allele's eight words at a time: keeps the eight accumulators in registers)
+                }
+            }
+        };
+        // Gene_prob_next (common:1311-1336) from dict P into dict N, normalised
+        auto next_fast = [&](int P, int N) {
+            double sacc[4] = {0.0, 0.0, 0.0, 0.0};         // rows: alleles_prob of class tid + 1024 k; 512 alleles per table
+            for (int sl = 0; sl * 512 < A1; ++sl) {
+                __syncthreads();
+                if (tid < 512) { const int j = 512 * sl + tid; S.xs[tid] = j < A1 ? dv[P][j] : 0.0; }    // (a non-member holds 0)
+                __syncthreads();
+                xlut_build(S.xs, Tb, tid);
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int c = tid + XB * k;
+                    asm volatile("" : "+v"(c));
+                    if (c < Cp) {
+                        uint64_t w[8];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) { const int aw = 8 * sl + i; w[i] = aw < A1w ? T.Mk[(size_t)aw * CpA + c] : 0ull; }
+                        sacc[k] += xlut_row(Tb, w);
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = tid + XB * k;
+                if (c < Cp) n_c[c] = (c < C && sacc[k] > 0.0) ? cnt_c[c] / sacc[k] : 0.0;       // classes with alleles_prob <= 0 are skipped
+            }
+            drain();
+            lap(1);
+            double acc[8];
+            cols_lut(n_c, acc);
+            double part = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = tid + XB * k;
+                if (j < A1) {
+                    const bool nin = din[P][j] != 0 && acc[k] > 0.0;
+                    double v = nin ? dv[P][j] * acc[k] : 0.0;
+                    if (use_len) v = v / T.vlen[j];
+                    dv[N][j] = v;
+                    din[N][j] = nin ? 1 : 0;
+                    part += v;
+                }
+            }
+            const double total = block_sum(part);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = tid + XB * k;
+                if (j < A1 && din[N][j]) dv[N][j] = dv[N][j] / total;
+            }
+            drain();
+            lap(2);
+        };
+        auto select_fast = [&](int d) {
+            double mx = 0.0;
+            for (int j = tid; j < A1; j += XB) if (din[d][j]) mx = fmax(mx, dv[d][j]);
+            mx = block_max_exact(mx);
+            for (int j = tid; j < A1; j += XB)
+                if (din[d][j] && !(dv[d][j] >= mx / 10.0)) { din[d][j] = 0; dv[d][j] = 0.0; }
+            drain();
+        };
+        {   // initial estimate (common:1300-1309)
+            double acc[8], part = 0.0;
+            cols_lut(t0_c, acc);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int j = tid + XB * k;
+                if (j < A1) { const double v = use_len ? acc[k] / T.vlen[j] : acc[k]; dv[prob][j] = v; din[prob][j] = 1; part += v; }
+            }
+            const double total = block_sum(part);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int j = tid + XB * k; if (j < A1) dv[prob][j] = dv[prob][j] / total; }
+            drain();
+            lap(5);
+        }
+        while (diff > 0.0001 && iter < 1000) {             // common:1351
+            next_fast(prob, next);
+            next_fast(next, next2);
+            bool bad = false;
+            double sr = 0.0, sv = 0.0;
+            for (int j = tid; j < A1; j += XB) {
+                if (!din[prob][j]) continue;
+                bad = bad || !din[next][j] || !din[next2][j];
+                const double p_r = dv[next][j] - dv[prob][j];
+                const double p_v = (dv[next2][j] - dv[next][j]) - p_r;
+                sr += p_r * p_r;
+                sv += p_v * p_v;
+            }
+            if (__syncthreads_or(bad)) { keyerr = true; break; }      // the reference's KeyError (Q6)
+            const double ssr = block_sum(sr), ssv = block_sum(sv);
+            if (ssv > 0.0) {                               // common:1370-1383
+                const double gamma = -sqrt(ssr / ssv);
+                for (int j = tid; j < A1; j += XB)
+                    if (din[prob][j]) {
+                        const double pv0 = dv[prob][j];
+                        const double p_r = dv[next][j] - pv0;
+                        const double p_v = (dv[next2][j] - dv[next][j]) - p_r;
+                        const double x = (pv0 - (2.0 * gamma) * p_r) + (gamma * gamma) * p_v;
+                        dv[next2][j] = 0.0 > x ? 0.0 : x;
+                    }
+                drain();
+                next_fast(next2, next);
+            }
+            double dd = 0.0;
+            for (int j = tid; j < A1; j += XB)
+                if (din[prob][j]) dd += din[next][j] ? fabs(dv[prob][j] - dv[next][j]) : dv[prob][j];
+            diff = block_sum(dd);
+            { const int t = prob; prob = next; next = t; }
+            if (iter >= 10 && remove_low) select_fast(prob);
+            iter += 1;
+            lap(6);
+        }
+        if (!keyerr) {
+            if (remove_low) select_fast(prob);
+            double part = 0.0;
+            for (int j = tid; j < A1; j += XB) if (din[prob][j]) part += use_len ? dv[prob][j] / T.vlen[j] : dv[prob][j];
+            const double total = block_sum(part);
+            for (int j = tid; j < A1; j += XB)
+                if (din[prob][j]) dv[prob][j] = use_len ? dv[prob][j] / T.vlen[j] / total : dv[prob][j] / total;
+            drain();
+        }
+    } else {
+    // ---- initial estimate (common:1300-1309): prob[a] += count / |class| over the classes in dict order ---------------
     for (int aw = wave; aw < A1w; aw += XNW) {
         const int j = 64 * aw + lane;
         double acc = 0.0;
@@ -525,9 +728,6 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     ord_of[prob] = 3;
     normalize(prob, 3);
     lap(5);
-    double diff = 1.0;
-    int iter = 0;
-    bool keyerr = false;
     while (diff > 0.0001 && iter < 1000) {                 // common:1351
         next_prob(prob, next, ord_of[prob], -1);
         next_prob(next, next2, ord_of[prob], ord_of[next]);
@@ -588,6 +788,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
         if (remove_low) select_alleles(prob);              // common:1402-1407
         normalize(prob, ord_of[prob]);
     }
+    }   // (exact mode)
     // the returned dict as records (allele, first class, abundance): members counted per tile, one atomic add reserves the run
     int res_n = 0;
     if (!keyerr) {
@@ -638,7 +839,8 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     if (dev >= 0 && dev < 64 && !attr_set[dev]) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
         attr_set[dev] = true;
     }
     const bool stamps = getenv("HGX_EMX_STAMPS") != nullptr;
@@ -679,6 +881,20 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
     }
     const int n = (int)job_of.size();
     if (n == 0) return HGX_OK;
+    {
+        // longest first: workgroups are dispatched in block order, and the launch ends when the last one does
+        std::vector<int> ord((size_t)n);
+        for (int t = 0; t < n; ++t) ord[t] = t;
+        std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) {
+            const hgx_emx_job &a = jobs[job_of[x]], &b = jobs[job_of[y]];
+            return (int64_t)(a.mask ? 1 : a.C) * a.a_pad > (int64_t)(b.mask ? 1 : b.C) * b.a_pad;
+        });
+        std::vector<Lay> l2((size_t)n);
+        std::vector<int> j2((size_t)n);
+        std::vector<size_t> b2((size_t)n);
+        for (int t = 0; t < n; ++t) { l2[t] = lays[ord[t]]; j2[t] = job_of[ord[t]]; b2[t] = base[ord[t]]; }
+        lays.swap(l2); job_of.swap(j2); base.swap(b2);
+    }
     // results: [cursor + padding | scal of every job | records], fetched together
     const size_t head = 64 + (size_t)n * XS_N * 8;
     DevBuf b_scr, b_tasks, b_res;
@@ -696,6 +912,7 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
         T.B = J.bits; T.count = J.count; T.rank = J.rank; T.len = J.len; T.mask = J.mask;
         T.C = J.C; T.w64 = J.w64; T.a_pad = J.a_pad; T.remove_low = J.remove_low ? 1 : 0;
         T.c_alloc = J.mask ? std::min(J.C, 2048) : J.C;
+        T.fast = J.fast ? 1 : 0;
         T.Mk = (uint64_t *)(b + L.Mk); T.Mr = (uint64_t *)(b + L.Mr); T.dv = (double *)(b + L.dv); T.pos = (uint16_t *)(b + L.pos);
         T.tmpv = (double *)(b + L.tmpv); T.vlen = (double *)(b + L.vlen); T.cls = (double *)(b + L.cls); T.din = (uint8_t *)(b + L.din);
         T.sorted = (int32_t *)(b + L.sorted); T.first_c = (int32_t *)(b + L.first);
@@ -709,7 +926,10 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
         { int rc_ = hgx_h2d(b_tasks.as<char>() + off, (const char *)tasks.data() + off, chunk, st); if (rc_) return rc_; }
         off += chunk;
     }
-    hipLaunchKernelGGL(k_emx, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
+    bool any_fast = false, any_exact = false;
+    for (const EmxTask &T : tasks) { any_fast = any_fast || T.fast; any_exact = any_exact || !T.fast; }
+    if (any_exact) hipLaunchKernelGGL(k_emx<false>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
+    if (any_fast) hipLaunchKernelGGL(k_emx<true>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
     HIPCHK(hipGetLastError());
     // one round trip brings the state words and the first records; a second one the rest of a long result
     const size_t first_recs = std::min<size_t>(res_cap, ((200u << 10) - head % (200u << 10)) / sizeof(EmxRes) + 0);

@@ -18,6 +18,9 @@ struct hgx_emx_job {
                                 // dropped, equal ones merged with their counts added, in the order of their first class; the EM
                                 // runs on that set and `first` / n_classes refer to it
     int32_t C, w64, a_pad, remove_low;
+    int32_t fast;               // 0: the reference's own order of operations (bit-identical abundances); 1: table-lookup mat-vecs and
+                                // tree reductions on the same workgroup -- ~5x faster, abundances within rounding (~1e-12) of the
+                                // reference's, same stopping and pruning rules
     // results (HOST memory, filled by hgx_emx_run)
     double *prob;               // [n_out] abundance, or -1.0 for an allele that is not in the returned dict
     int32_t *first;             // [n_out] or NULL: first class (dict order) containing the allele, -1 elsewhere

@@ -27,6 +27,8 @@
 #include "hgx_emx.hpp"
 #include "hgx_internal.hpp"
 
+extern "C" int hgx_em_set_fast(int on);
+
 struct hgx_dbatch {
     int32_t n_pieces = 0, n_pairs = 0, n_reads = 0;
     int64_t n_refs = 0, n_mask_u32 = 0, sum_piece_words = 0, n_gene_refs = 0;
@@ -130,6 +132,12 @@ struct GateHold {                    // a held gate that is released exactly onc
 };
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+struct EmFastScope {                 // hgx_type_opts.em_fast for the EMs of this call (this thread)
+    int old;
+    explicit EmFastScope(int on) : old(hgx_em_set_fast(on)) {}
+    ~EmFastScope() { hgx_em_set_fast(old); }
+};
 
 }   // namespace
 
@@ -507,6 +515,7 @@ extern "C" int hgx_type_dbatch(hgx_typing **out, const hgx_locus *loc, const hgx
     t->n_reads = db->n_reads; t->n_pairs = db->n_pairs; t->n_pieces = db->n_pieces; t->n_refs = db->n_refs; t->n_alleles = loc->A;
     if (db->n_reads <= 0) { *out = t; return HGX_OK; }                                           // core:1589-1590
     GateHold gate(opts->gate);
+    EmFastScope em_mode(opts->em_fast);
     StreamSet ss;
     int rc = acquire_streams(ss);
     if (!rc) rc = type_impl(t, loc, ix, db, opts, (hipStream_t)stream, ss, gate);
@@ -528,6 +537,7 @@ extern "C" int hgx_type_classes(hgx_typing **out, const hgx_locus *loc, hgx_clas
     t->n_reads = n_reads; t->n_pairs = n_pairs; t->n_alleles = loc->A;
     if (n_reads <= 0) { *out = t; return HGX_OK; }
     hipStream_t st = (hipStream_t)stream;
+    EmFastScope em_mode(opts->em_fast);
     GeneSide gs;
     int rc = gene_rank(gene_cl, loc->A, loc->a_pad, st, gs);
     if (!rc) {
@@ -743,242 +753,331 @@ int class_offsets(const hgx_classes *cl, const hgx_many *m, int32_t *scratch_dev
 }
 
 void em_out_from(const hgx_emx_job &J, const std::vector<double> &prob, const std::vector<int32_t> &first, const hgx_locus *loc, int32_t use_length, EmOut &o) {
-    o.exact = true;
+    o.exact = J.fast == 0;
     o.n_classes = J.n_classes; o.n_iter = J.n_iter; o.remove_low = J.remove_low ? 1 : 0; o.use_length = use_length;
     sorted_result(prob, first, loc->name_rank.data(), loc->A, o);
 }
 
 }   // namespace
 
-extern "C" int hgx_type_many(hgx_typing **out, int32_t *rc_out, const hgx_locus *loc, const hgx_index *ix, hgx_many *m,
-                             const hgx_type_opts *opts, void *stream) {
-    ARGCHK(out && loc && ix && m && opts);
-    const int n = m->n_tasks;
-    for (int t = 0; t < n; ++t) { out[t] = nullptr; if (rc_out) rc_out[t] = HGX_OK; }
-    if (n == 0) return HGX_OK;
-    int32_t A = 0, a_pad = 0;
-    int rc = hgx_index_dims(ix, &A, &a_pad, nullptr, nullptr);
-    if (rc) return rc;
-    ARGCHK(A == loc->A && a_pad == loc->a_pad && A == m->A && a_pad == m->a_pad);
-    const int w64 = a_pad / 64;
-    const bool hla = loc->base_kind == HGX_BASE_HLA;
-    hipStream_t st = (hipStream_t)stream;
-    const hgx_dbatch *db = m->db;
-    const int32_t n_pairs = db->n_pairs;
-    const bool prof = getenv("HGX_TYPE_PROFILE") != nullptr;
-    double tp[8];
-    tp[0] = now_s();
+namespace {
 
-    std::vector<hgx_typing *> res((size_t)n, nullptr);
-    struct Cleanup { std::vector<hgx_typing *> &r; bool armed = true; ~Cleanup() { if (armed) for (auto *t : r) delete t; } } cleanup{res};
-    for (int t = 0; t < n; ++t) {
-        hgx_typing *ty = new hgx_typing();
-        ty->n_reads = m->n_reads[t]; ty->n_pairs = m->pair_base[t + 1] - m->pair_base[t]; ty->n_pieces = m->n_pieces[t];
-        ty->n_refs = m->n_refs[t]; ty->n_alleles = A;
-        res[t] = ty;
+// One locus' share of a hgx_type_many / hgx_type_many_loci call.  The phases of all loci are interleaved by the caller so that
+// the EM jobs of EVERY locus go out in one launch (one workgroup per task: the launch is as wide as the panel, not as one locus).
+struct ManyRun {
+    const hgx_locus *loc = nullptr;
+    const hgx_index *ix = nullptr;
+    hgx_many *m = nullptr;
+    const hgx_type_opts *opts = nullptr;
+    hipStream_t st = nullptr;
+    int32_t *rc_out = nullptr;
+    int n = 0, A = 0, a_pad = 0, w64 = 0;
+    bool hla = false, active = false;
+    std::vector<hgx_typing *> res;
+    DevBuf b_compat, b_gbits, b_ghash, b_ebits, b_ehash, b_pt, b_goff, b_cnt, b_fp, b_masks;
+    hgx_classes *ecl = nullptr, *gcl = nullptr;
+    hgx_groups *groups = nullptr;
+    std::vector<int32_t> e_off, g_off;
+    std::unique_lock<std::mutex> pin_lock;
+    int64_t *h_cnt = nullptr;
+    int32_t *h_fp = nullptr;
+    std::vector<std::vector<double>> prob1, prob2;
+    std::vector<std::vector<int32_t>> first1, first2;
+    std::vector<std::vector<uint8_t>> in_exon;
+    std::vector<double> psum;
+    std::vector<uint64_t> masks;
+    size_t job_lo = 0, job_hi = 0, job2_lo = 0, job2_hi = 0;     // this locus' ranges in the callers' job lists
+    std::vector<int> job_task, job2_task;
+
+    ~ManyRun() {
+        if (st || active) (void)hipStreamSynchronize(st);
+        hgx_groups_destroy(groups);
+        hgx_classes_destroy(ecl);
+        hgx_classes_destroy(gcl);
+        for (auto *t : res) delete t;
     }
-    auto fail_task = [&](int t, int code) -> int {        // per-task error: reported through rc_out, or the whole call fails
+    int fail_task(int t, int code) {                       // per-task error: reported through rc_out, or the whole call fails
         if (!rc_out) return code;
         rc_out[t] = code;
         delete res[t];
         res[t] = nullptr;
         return HGX_OK;
-    };
-    auto hand_out = [&]() { for (int t = 0; t < n; ++t) out[t] = res[t]; cleanup.armed = false; return HGX_OK; };
-    if (n_pairs == 0) return hand_out();                   // core:1589-1590: loci without reads are skipped
-
-    // ---- scoring + dedup of ALL tasks' pairs: the same kernels as one task ---------------------------------------------
-    DevBuf b_compat, b_gbits, b_ghash, b_ebits, b_ehash, b_pt;
-    hgx_classes *ecl = nullptr, *gcl = nullptr;
-    hgx_groups *groups = nullptr;
-    struct Handles { hgx_classes *&e, *&g; hgx_groups *&gr; hipStream_t st; ~Handles() { (void)hipStreamSynchronize(st); hgx_groups_destroy(gr); hgx_classes_destroy(e); hgx_classes_destroy(g); } } handles{ecl, gcl, groups, st};
-    ALLOC(b_compat, (size_t)std::max(db->n_pieces, 1) * w64 * 8);
-    ALLOC(b_gbits, (size_t)n_pairs * w64 * 8);
-    ALLOC(b_ghash, (size_t)n_pairs * 8);
-    ALLOC(b_pt, (size_t)(2 * n + 2) * 4);
-    uint64_t *compat = b_compat.as<uint64_t>();
-    rc = hgx_piece_compat(ix, db->d_pieces, db->d_masks, db->n_pieces, compat, st);
-    if (rc) return rc;
-    if (hla) {
-        rc = hgx_group_pairs_seg(&groups, db->d_pair_off, db->d_pair_ref, n_pairs, HGX_LEVEL_EXON, m->d_pair_seg, st);
-        if (rc) return rc;
-        int64_t ng = 0;
-        rc = hgx_groups_dims(groups, &ng, nullptr);
-        if (rc) return rc;
-        const size_t n_rows = ng > 0 ? (size_t)ng : (size_t)n_pairs;
-        ALLOC(b_ebits, n_rows * w64 * 8);
-        ALLOC(b_ehash, n_rows * 8);
-        rc = hgx_level_classes_grouped_seg(&ecl, ix, compat, db->d_pair_off, db->d_pair_ref, groups, b_ebits.as<uint64_t>(), b_ehash.as<uint64_t>(),
-                                           m->d_pair_seg, st);
-        if (rc) return rc;
     }
-    rc = hgx_pair_classes(ix, compat, db->d_pair_off, db->d_pair_ref, n_pairs, nullptr, b_gbits.as<uint64_t>(), nullptr, b_ghash.as<uint64_t>(), st);
-    if (rc) return rc;
-    rc = hgx_dedup_classes_seg(&gcl, b_gbits.as<uint64_t>(), b_ghash.as<uint64_t>(), n_pairs, a_pad, m->d_pair_seg, st);
-    if (rc) return rc;
-    tp[1] = now_s();
+    const hgx_classes *cl1() const { return hla ? ecl : gcl; }
+    const std::vector<int32_t> &off1() const { return hla ? e_off : g_off; }
 
-    // ---- per-task class ranges; Gene_counts of every task ------------------------------------------------------------------
-    std::vector<int32_t> e_off, g_off;
-    if (hla) { rc = class_offsets(ecl, m, b_pt.as<int32_t>(), e_off, st); if (rc) return rc; }
-    rc = class_offsets(gcl, m, b_pt.as<int32_t>(), g_off, st);
-    if (rc) return rc;
-    DevBuf b_goff, b_cnt, b_fp;
-    ALLOC(b_goff, (size_t)(n + 1) * 4);
-    ALLOC(b_cnt, (size_t)n * a_pad * 8);
-    ALLOC(b_fp, (size_t)n * a_pad * 4);
-    { int rc_ = hgx_h2d(b_goff.p, g_off.data(), (size_t)(n + 1) * 4, st); if (rc_) return rc_; }
-    rc = hgx_many_counts(gcl, b_goff.as<int32_t>(), m->d_pair_base, n, b_cnt.as<int64_t>(), b_fp.as<int32_t>(), st);
-    if (rc) return rc;
-    std::lock_guard<std::mutex> pin_lock(m->mu);
-    const size_t need = (size_t)n * a_pad * 12;
-    if (m->h_pinned_bytes < need) {
-        if (m->h_pinned) (void)hipHostFree(m->h_pinned);
-        m->h_pinned = nullptr; m->h_pinned_bytes = 0;
-        HIPCHK(hipHostMalloc(&m->h_pinned, need, hipHostMallocDefault));
-        m->h_pinned_bytes = need;
-    }
-    int64_t *h_cnt = (int64_t *)m->h_pinned;
-    int32_t *h_fp = (int32_t *)((char *)m->h_pinned + (size_t)n * a_pad * 8);
-    HIPCHK(hipMemcpyAsync(h_cnt, b_cnt.p, (size_t)n * a_pad * 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(h_fp, b_fp.p, (size_t)n * a_pad * 4, hipMemcpyDeviceToHost, st));
-
-    // ---- EM #1 of every task in one launch (HLA: exon classes; other bases: gene classes, no pruning) -------------------------
-    const hgx_classes *cl1 = hla ? ecl : gcl;
-    const std::vector<int32_t> &off1 = hla ? e_off : g_off;
-    std::vector<std::vector<double>> prob1((size_t)n);
-    std::vector<std::vector<int32_t>> first1((size_t)n);
-    std::vector<hgx_emx_job> jobs;
-    std::vector<int> job_task;
-    for (int t = 0; t < n; ++t) {
-        const int32_t C = off1[t + 1] - off1[t];
-        if (res[t]->n_reads <= 0 || C == 0) continue;
-        if (!hla && C == 1) {                               // core:1784-1787, quirk Q3
-            hgx_set_error("'dict_keys' object is not subscriptable (reference quirk Q3, typing_core.py:1787)");
-            rc = fail_task(t, HGX_ETYPE);
-            if (rc) return rc;
-            continue;
+    int init(hgx_typing **out, int32_t *rc, const hgx_locus *loc_, const hgx_index *ix_, hgx_many *m_, const hgx_type_opts *o, hipStream_t s) {
+        ARGCHK(out && loc_ && ix_ && m_ && o);
+        loc = loc_; ix = ix_; m = m_; opts = o; st = s; rc_out = rc;
+        n = m->n_tasks;
+        for (int t = 0; t < n; ++t) { out[t] = nullptr; if (rc_out) rc_out[t] = HGX_OK; }
+        int rc_ = hgx_index_dims(ix, &A, &a_pad, nullptr, nullptr);
+        if (rc_) return rc_;
+        ARGCHK(A == loc->A && a_pad == loc->a_pad && A == m->A && a_pad == m->a_pad);
+        w64 = a_pad / 64;
+        hla = loc->base_kind == HGX_BASE_HLA;
+        res.assign((size_t)n, nullptr);
+        for (int t = 0; t < n; ++t) {
+            hgx_typing *ty = new hgx_typing();
+            ty->n_reads = m->n_reads[t]; ty->n_pairs = m->pair_base[t + 1] - m->pair_base[t]; ty->n_pieces = m->n_pieces[t];
+            ty->n_refs = m->n_refs[t]; ty->n_alleles = A;
+            res[t] = ty;
         }
-        prob1[t].assign((size_t)A, -1.0);
-        first1[t].assign((size_t)A, -1);
-        hgx_emx_job J{};
-        J.bits = cl1->d_bits + (size_t)off1[t] * w64; J.count = cl1->d_count + off1[t]; J.rank = m->d_rank; J.len = nullptr; J.mask = nullptr;
-        J.C = C; J.w64 = w64; J.a_pad = a_pad; J.remove_low = hla ? (opts->remove_low ? 1 : 0) : 0;
-        J.prob = prob1[t].data(); J.first = first1[t].data(); J.n_out = A;
-        jobs.push_back(J);
-        job_task.push_back(t);
+        active = n > 0 && m->db->n_pairs > 0;              // core:1589-1590: loci without reads are skipped
+        return HGX_OK;
     }
+
+    // scoring + dedup of ALL tasks' pairs (the kernels of the one-task path), per-task class ranges, Gene_counts of every task
+    int score() {
+        if (!active) return HGX_OK;
+        const hgx_dbatch *db = m->db;
+        const int32_t n_pairs = db->n_pairs;
+        ALLOC(b_compat, (size_t)std::max(db->n_pieces, 1) * w64 * 8);
+        ALLOC(b_gbits, (size_t)n_pairs * w64 * 8);
+        ALLOC(b_ghash, (size_t)n_pairs * 8);
+        ALLOC(b_pt, (size_t)(2 * n + 2) * 4);
+        uint64_t *compat = b_compat.as<uint64_t>();
+        int rc = hgx_piece_compat(ix, db->d_pieces, db->d_masks, db->n_pieces, compat, st);
+        if (rc) return rc;
+        if (hla) {
+            rc = hgx_group_pairs_seg(&groups, db->d_pair_off, db->d_pair_ref, n_pairs, HGX_LEVEL_EXON, m->d_pair_seg, st);
+            if (rc) return rc;
+            int64_t ng = 0;
+            rc = hgx_groups_dims(groups, &ng, nullptr);
+            if (rc) return rc;
+            const size_t n_rows = ng > 0 ? (size_t)ng : (size_t)n_pairs;
+            ALLOC(b_ebits, n_rows * w64 * 8);
+            ALLOC(b_ehash, n_rows * 8);
+            rc = hgx_level_classes_grouped_seg(&ecl, ix, compat, db->d_pair_off, db->d_pair_ref, groups, b_ebits.as<uint64_t>(),
+                                               b_ehash.as<uint64_t>(), m->d_pair_seg, st);
+            if (rc) return rc;
+        }
+        rc = hgx_pair_classes(ix, compat, db->d_pair_off, db->d_pair_ref, n_pairs, nullptr, b_gbits.as<uint64_t>(), nullptr,
+                              b_ghash.as<uint64_t>(), st);
+        if (rc) return rc;
+        rc = hgx_dedup_classes_seg(&gcl, b_gbits.as<uint64_t>(), b_ghash.as<uint64_t>(), n_pairs, a_pad, m->d_pair_seg, st);
+        if (rc) return rc;
+        if (hla) { rc = class_offsets(ecl, m, b_pt.as<int32_t>(), e_off, st); if (rc) return rc; }
+        rc = class_offsets(gcl, m, b_pt.as<int32_t>(), g_off, st);
+        if (rc) return rc;
+        ALLOC(b_goff, (size_t)(n + 1) * 4);
+        ALLOC(b_cnt, (size_t)n * a_pad * 8);
+        ALLOC(b_fp, (size_t)n * a_pad * 4);
+        { int rc_ = hgx_h2d(b_goff.p, g_off.data(), (size_t)(n + 1) * 4, st); if (rc_) return rc_; }
+        rc = hgx_many_counts(gcl, b_goff.as<int32_t>(), m->d_pair_base, n, b_cnt.as<int64_t>(), b_fp.as<int32_t>(), st);
+        if (rc) return rc;
+        pin_lock = std::unique_lock<std::mutex>(m->mu);
+        const size_t need = (size_t)n * a_pad * 12;
+        if (m->h_pinned_bytes < need) {
+            if (m->h_pinned) (void)hipHostFree(m->h_pinned);
+            m->h_pinned = nullptr; m->h_pinned_bytes = 0;
+            HIPCHK(hipHostMalloc(&m->h_pinned, need, hipHostMallocDefault));
+            m->h_pinned_bytes = need;
+        }
+        h_cnt = (int64_t *)m->h_pinned;
+        h_fp = (int32_t *)((char *)m->h_pinned + (size_t)n * a_pad * 8);
+        HIPCHK(hipMemcpyAsync(h_cnt, b_cnt.p, (size_t)n * a_pad * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_fp, b_fp.p, (size_t)n * a_pad * 4, hipMemcpyDeviceToHost, st));
+        return HGX_OK;
+    }
+
+    // EM #1 of every task (HLA: exon classes; other bases: gene classes, no pruning): jobs appended to the callers' list
+    int em1_jobs(std::vector<hgx_emx_job> &jobs) {
+        job_lo = jobs.size();
+        prob1.assign((size_t)n, {}); first1.assign((size_t)n, {});
+        if (active)
+            for (int t = 0; t < n; ++t) {
+                const int32_t C = off1()[t + 1] - off1()[t];
+                if (!res[t] || res[t]->n_reads <= 0 || C == 0) continue;
+                if (!hla && C == 1) {                           // core:1784-1787, quirk Q3
+                    hgx_set_error("'dict_keys' object is not subscriptable (reference quirk Q3, typing_core.py:1787)");
+                    const int rc = fail_task(t, HGX_ETYPE);
+                    if (rc) return rc;
+                    continue;
+                }
+                prob1[t].assign((size_t)A, -1.0);
+                first1[t].assign((size_t)A, -1);
+                hgx_emx_job J{};
+                J.bits = cl1()->d_bits + (size_t)off1()[t] * w64; J.count = cl1()->d_count + off1()[t]; J.rank = m->d_rank;
+                J.C = C; J.w64 = w64; J.a_pad = a_pad; J.remove_low = hla ? (opts->remove_low ? 1 : 0) : 0;
+                J.fast = opts->em_fast ? 1 : 0;
+                J.prob = prob1[t].data(); J.first = first1[t].data(); J.n_out = A;
+                jobs.push_back(J);
+                job_task.push_back(t);
+            }
+        job_hi = jobs.size();
+        return HGX_OK;
+    }
+
+    // EM #1's results -> the tasks; Gene_counts ranking (core:1650-1651); exon_alleles and the hand-off jobs (core:1739-1766)
+    int after_em1(const std::vector<hgx_emx_job> &jobs, std::vector<hgx_emx_job> &jobs2) {
+        job2_lo = job2_hi = jobs2.size();
+        if (!active) return HGX_OK;
+        int rc = HGX_OK;
+        for (size_t k = job_lo; k < job_hi; ++k) {
+            const int t = job_task[k - job_lo];
+            hgx_typing *ty = res[t];
+            if (!ty) continue;
+            const hgx_emx_job &J = jobs[k];
+            if (J.status == 2) {
+                hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
+                rc = fail_task(t, HGX_EKEY);
+                if (rc) return rc;
+                continue;
+            }
+            if (J.status == 1) {                                // beyond the batched kernel's limits: this task's EM through the one-task path
+                ClassesView v(cl1(), off1()[t], J.C);
+                rc = run_em(&v.c, loc, J.remove_low, nullptr, st, ty);
+                if (rc) { rc = fail_task(t, rc); if (rc) return rc; }
+                continue;
+            }
+            EmOut o;
+            em_out_from(J, prob1[t], first1[t], loc, 0, o);
+            ty->em.push_back(std::move(o));
+        }
+        hgx_par_tasks(std::min(hgx_default_threads(), 16), (size_t)n, [&](int, size_t t) {
+            hgx_typing *ty = res[t];
+            if (!ty || ty->n_reads <= 0) return;
+            const int64_t *cnt = h_cnt + t * (size_t)a_pad;
+            const int32_t *fp = h_fp + t * (size_t)a_pad;
+            ty->cnt.assign(cnt, cnt + A);
+            for (int32_t a = 0; a < A; ++a) if (cnt[a] > 0) ty->counted.push_back(a);
+            std::sort(ty->counted.begin(), ty->counted.end(), [&](int32_t a, int32_t b) {
+                if (cnt[a] != cnt[b]) return cnt[a] > cnt[b];
+                if (fp[a] != fp[b]) return fp[a] < fp[b];
+                return a < b;
+            });
+        });
+        if (pin_lock.owns_lock()) pin_lock.unlock();
+        if (!hla) {
+            for (int t = 0; t < n; ++t) if (res[t] && !res[t]->em.empty()) res[t]->gene_prob = res[t]->em[0];
+            return HGX_OK;
+        }
+        in_exon.assign((size_t)n, {}); psum.assign((size_t)n, 0.0);
+        masks.assign((size_t)n * w64, 0);
+        prob2.assign((size_t)n, {}); first2.assign((size_t)n, {});
+        ALLOC(b_masks, masks.size() * 8);
+        for (int t = 0; t < n; ++t) {
+            hgx_typing *ty = res[t];
+            if (!ty || ty->em.empty()) continue;
+            ty->gene_prob = ty->em[0];
+            if (!exon_alleles_of(ty->em[0], loc, in_exon[t], psum[t])) continue;
+            uint64_t *mk = &masks[(size_t)t * w64];
+            for (int32_t a = 0; a < A; ++a) if (in_exon[t][a]) mk[a >> 6] |= 1ull << (a & 63);
+            prob2[t].assign((size_t)A, -1.0);
+            first2[t].assign((size_t)A, -1);
+            hgx_emx_job J{};
+            J.bits = gcl->d_bits + (size_t)g_off[t] * w64; J.count = gcl->d_count + g_off[t]; J.rank = m->d_rank; J.len = m->d_len;
+            J.mask = b_masks.as<uint64_t>() + (size_t)t * w64;
+            J.C = g_off[t + 1] - g_off[t]; J.w64 = w64; J.a_pad = a_pad; J.remove_low = 1;
+            J.prob = prob2[t].data(); J.first = first2[t].data(); J.n_out = A;
+            jobs2.push_back(J);
+            job2_task.push_back(t);
+        }
+        job2_hi = jobs2.size();
+        if (job2_hi > job2_lo) HIPCHK(hipMemcpyAsync(b_masks.p, masks.data(), masks.size() * 8, hipMemcpyHostToDevice, st));
+        return HGX_OK;
+    }
+
+    // EM #2's results, the combination of the two levels (core:1771-1782); hands the results out
+    int finish(const std::vector<hgx_emx_job> &jobs2, hgx_typing **out) {
+        int rc = HGX_OK;
+        for (size_t k = job2_lo; k < job2_hi; ++k) {
+            const int t = job2_task[k - job2_lo];
+            hgx_typing *ty = res[t];
+            const hgx_emx_job &J = jobs2[k];
+            if (J.status == 2) {
+                hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
+                rc = fail_task(t, HGX_EKEY);
+                if (rc) return rc;
+                continue;
+            }
+            EmOut e2;
+            if (J.status == 1) {                                // more than 64 alleles pass the filter (or too many merged classes)
+                ClassesView v(gcl, g_off[t], J.C);
+                int32_t it2 = 0, ncls2 = 0;
+                rc = hgx_classes_set_allele_rank(&v.c, loc->name_rank.data(), A);
+                if (!rc) rc = hgx_em_masked(&v.c, &masks[(size_t)t * w64], A, 1, loc->allele_len.data(), prob2[t].data(), first2[t].data(), &it2,
+                                            &ncls2, st);
+                if (rc) { rc = fail_task(t, rc); if (rc) return rc; continue; }
+                e2.exact = hgx_em_last_exact() != 0;
+                e2.n_classes = ncls2; e2.n_iter = it2; e2.remove_low = 1; e2.use_length = 1;
+                sorted_result(prob2[t], first2[t], loc->name_rank.data(), A, e2);
+            } else {
+                em_out_from(J, prob2[t], first2[t], loc, 1, e2);
+            }
+            combine_levels(ty, std::move(e2), in_exon[t], psum[t]);
+        }
+        for (int t = 0; t < n; ++t) out[t] = res[t];
+        res.clear();
+        return HGX_OK;
+    }
+};
+
+// the loci's phases, interleaved: scoring of every locus, ONE launch for every EM #1, ranking + hand-off set-up, ONE launch for
+// every EM #2.  The EM jobs go out longest first (the launch's makespan is the longest task's time plus what queues behind it).
+int run_many(std::vector<ManyRun> &runs, hgx_typing ***out, hipStream_t st) {
+    const bool prof = getenv("HGX_TYPE_PROFILE") != nullptr;
+    double tp[6];
+    tp[0] = now_s();
+    int rc = HGX_OK;
+    for (auto &r : runs) { rc = r.score(); if (rc) return rc; }
+    tp[1] = now_s();
+    std::vector<hgx_emx_job> jobs, jobs2;
+    for (auto &r : runs) { rc = r.em1_jobs(jobs); if (rc) return rc; }
     const double t_em0 = now_s();
-    rc = hgx_emx_run(jobs.data(), (int)jobs.size(), st);       // (returns with the stream drained: the Gene_counts are on the host too)
+    rc = hgx_emx_run(jobs.data(), (int)jobs.size(), st);           // (returns with the stream drained: the Gene_counts are on the host too)
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(st));
     tp[2] = now_s();
-    for (size_t k = 0; k < jobs.size(); ++k) {
-        const int t = job_task[k];
-        hgx_typing *ty = res[t];
-        if (!ty) continue;
-        const hgx_emx_job &J = jobs[k];
-        if (J.status == 2) {
-            hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
-            rc = fail_task(t, HGX_EKEY);
-            if (rc) return rc;
-            continue;
-        }
-        if (J.status == 1) {                                // beyond the batched kernel's limits: this task's EM through the one-task path
-            ClassesView v(cl1, off1[t], J.C);
-            rc = run_em(&v.c, loc, J.remove_low, nullptr, st, ty);
-            if (rc) { rc = fail_task(t, rc); if (rc) return rc; }
-            continue;
-        }
-        EmOut o;
-        em_out_from(J, prob1[t], first1[t], loc, 0, o);
-        ty->em.push_back(std::move(o));
-    }
-    // ---- Gene_counts ranking (core:1650-1651) on the host workers --------------------------------------------------------------
-    hgx_par_tasks(std::min(hgx_default_threads(), 16), (size_t)n, [&](int, size_t t) {
-        hgx_typing *ty = res[t];
-        if (!ty || ty->n_reads <= 0) return;
-        const int64_t *cnt = h_cnt + t * (size_t)a_pad;
-        const int32_t *fp = h_fp + t * (size_t)a_pad;
-        ty->cnt.assign(cnt, cnt + A);
-        for (int32_t a = 0; a < A; ++a) if (cnt[a] > 0) ty->counted.push_back(a);
-        std::sort(ty->counted.begin(), ty->counted.end(), [&](int32_t a, int32_t b) {
-            if (cnt[a] != cnt[b]) return cnt[a] > cnt[b];
-            if (fp[a] != fp[b]) return fp[a] < fp[b];
-            return a < b;
-        });
-    });
+    for (auto &r : runs) { rc = r.after_em1(jobs, jobs2); if (rc) return rc; }
     tp[3] = now_s();
-    if (!hla) {
-        for (int t = 0; t < n; ++t) if (res[t] && !res[t]->em.empty()) { res[t]->gene_prob = res[t]->em[0]; res[t]->t_em = (tp[2] - t_em0) / std::max<size_t>(jobs.size(), 1); }
-        if (opts->keep_classes) {}                          // (class sets of a merged batch are not handed out per task)
-        return hand_out();
-    }
-    // ---- the hand-off (core:1739-1782): exon_alleles per task, Gene_cmpt2 + EM #2 of every task in one launch ---------------
-    std::vector<std::vector<uint8_t>> in_exon((size_t)n);
-    std::vector<double> psum((size_t)n, 0.0);
-    std::vector<uint64_t> masks((size_t)n * w64, 0);
-    std::vector<std::vector<double>> prob2((size_t)n);
-    std::vector<std::vector<int32_t>> first2((size_t)n);
-    std::vector<hgx_emx_job> jobs2;
-    std::vector<int> job2_task;
-    DevBuf b_masks;
-    ALLOC(b_masks, masks.size() * 8);
-    for (int t = 0; t < n; ++t) {
-        hgx_typing *ty = res[t];
-        if (!ty || ty->em.empty()) continue;
-        ty->gene_prob = ty->em[0];
-        if (!exon_alleles_of(ty->em[0], loc, in_exon[t], psum[t])) continue;
-        uint64_t *mk = &masks[(size_t)t * w64];
-        for (int32_t a = 0; a < A; ++a) if (in_exon[t][a]) mk[a >> 6] |= 1ull << (a & 63);
-        const int32_t C = g_off[t + 1] - g_off[t];
-        prob2[t].assign((size_t)A, -1.0);
-        first2[t].assign((size_t)A, -1);
-        hgx_emx_job J{};
-        J.bits = gcl->d_bits + (size_t)g_off[t] * w64; J.count = gcl->d_count + g_off[t]; J.rank = m->d_rank; J.len = m->d_len;
-        J.mask = b_masks.as<uint64_t>() + (size_t)t * w64;
-        J.C = C; J.w64 = w64; J.a_pad = a_pad; J.remove_low = 1;
-        J.prob = prob2[t].data(); J.first = first2[t].data(); J.n_out = A;
-        jobs2.push_back(J);
-        job2_task.push_back(t);
-    }
     if (!jobs2.empty()) {
-        HIPCHK(hipMemcpyAsync(b_masks.p, masks.data(), masks.size() * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipStreamSynchronize(st));                          // (the masks were copied from pageable memory)
         rc = hgx_emx_run(jobs2.data(), (int)jobs2.size(), st);
         if (rc) return rc;
     }
     tp[4] = now_s();
-    for (size_t k = 0; k < jobs2.size(); ++k) {
-        const int t = job2_task[k];
-        hgx_typing *ty = res[t];
-        const hgx_emx_job &J = jobs2[k];
-        if (J.status == 2) {
-            hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
-            rc = fail_task(t, HGX_EKEY);
-            if (rc) return rc;
-            continue;
-        }
-        EmOut e2;
-        if (J.status == 1) {                                // more than 64 alleles pass the filter (or too many merged classes)
-            ClassesView v(gcl, g_off[t], J.C);
-            int32_t it2 = 0, ncls2 = 0;
-            rc = hgx_classes_set_allele_rank(&v.c, loc->name_rank.data(), A);
-            if (!rc) rc = hgx_em_masked(&v.c, &masks[(size_t)t * w64], A, 1, loc->allele_len.data(), prob2[t].data(), first2[t].data(), &it2, &ncls2, st);
-            if (rc) { rc = fail_task(t, rc); if (rc) return rc; continue; }
-            e2.exact = hgx_em_last_exact() != 0;
-            e2.n_classes = ncls2; e2.n_iter = it2; e2.remove_low = 1; e2.use_length = 1;
-            sorted_result(prob2[t], first2[t], loc->name_rank.data(), A, e2);
-        } else {
-            em_out_from(J, prob2[t], first2[t], loc, 1, e2);
-        }
-        combine_levels(ty, std::move(e2), in_exon[t], psum[t]);
-    }
     const double em_share = ((tp[2] - t_em0) + (tp[4] - tp[3])) / std::max<size_t>(jobs.size(), 1);
-    for (int t = 0; t < n; ++t) if (res[t]) res[t]->t_em = em_share;
+    size_t n_tasks = 0;
+    for (size_t i = 0; i < runs.size(); ++i) {
+        for (auto *t : runs[i].res) if (t) t->t_em = em_share;
+        n_tasks += runs[i].n;
+        rc = runs[i].finish(jobs2, out[i]);
+        if (rc) return rc;
+    }
     if (prof)
-        fprintf(stderr, "[hgx_type_many] %d tasks, %d pairs, %d pieces: scoring + dedup %.2f ms | offsets + counts + EM #1 %.2f | ranking %.2f | "
-                        "hand-off + EM #2 %.2f | results %.2f\n", n, n_pairs, db->n_pieces, (tp[1] - tp[0]) * 1e3, (tp[2] - tp[1]) * 1e3,
-                (tp[3] - tp[2]) * 1e3, (tp[4] - tp[3]) * 1e3, (now_s() - tp[4]) * 1e3);
-    return hand_out();
+        fprintf(stderr, "[hgx_type_many] %zu loci, %zu tasks: scoring + dedup + counts %.2f ms | EM #1 (%zu jobs) %.2f | ranking + hand-off set-up %.2f | "
+                        "EM #2 (%zu jobs) %.2f | results %.2f\n", runs.size(), n_tasks, (tp[1] - tp[0]) * 1e3, jobs.size(), (tp[2] - tp[1]) * 1e3,
+                (tp[3] - tp[2]) * 1e3, jobs2.size(), (tp[4] - tp[3]) * 1e3, (now_s() - tp[4]) * 1e3);
+    return HGX_OK;
+}
+
+}   // namespace
+
+extern "C" int hgx_type_many(hgx_typing **out, int32_t *rc_out, const hgx_locus *loc, const hgx_index *ix, hgx_many *m,
+                             const hgx_type_opts *opts, void *stream) {
+    ARGCHK(opts);
+    EmFastScope em_mode(opts->em_fast);        // (tasks that fall back to the one-task EM follow the same setting)
+    std::vector<ManyRun> runs(1);
+    int rc = runs[0].init(out, rc_out, loc, ix, m, opts, (hipStream_t)stream);
+    if (rc) return rc;
+    hgx_typing **outs[1] = {out};
+    rc = run_many(runs, outs, (hipStream_t)stream);
+    if (rc) for (int t = 0; t < m->n_tasks; ++t) { if (out[t]) { delete out[t]; out[t] = nullptr; } }
+    return rc;
+}
+
+extern "C" int hgx_type_many_loci(int32_t n_loci, hgx_typing ***out, int32_t **rc_out, const hgx_locus *const *loci, const hgx_index *const *ixs,
+                                  hgx_many *const *manies, const hgx_type_opts *opts, void *stream) {
+    ARGCHK(n_loci >= 0 && (n_loci == 0 || (out && loci && ixs && manies)) && opts);
+    EmFastScope em_mode(opts->em_fast);
+    std::vector<ManyRun> runs((size_t)n_loci);
+    int rc = HGX_OK;
+    for (int i = 0; i < n_loci && !rc; ++i) rc = runs[i].init(out[i], rc_out ? rc_out[i] : nullptr, loci[i], ixs[i], manies[i], opts, (hipStream_t)stream);
+    if (!rc) rc = run_many(runs, out, (hipStream_t)stream);
+    if (rc)
+        for (int i = 0; i < n_loci; ++i)
+            for (int t = 0; t < manies[i]->n_tasks; ++t) { if (out[i][t]) { delete out[i][t]; out[i][t] = nullptr; } }
+    return rc;
 }

@@ -120,12 +120,14 @@ def genotyping_locus(base_fname, locus_list, genotype_genome, ix_dir, only_locus
     return test_passed
 
 
-def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, ix_dir=None, inflight=1, **typing_opts):
+def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, ix_dir=None, inflight=1, many=False, **typing_opts):
     """Type independent (sample_id, gene, sam_text_or_path) tasks; rank `rank` of `world` handles its share
     (deterministic greedy split, no communication).  `index` is the dict from indexio.load_index; with `ix_dir` the
     packed loci come through the binary cache next to the index files (indexio.packed_locus).  `inflight` > 1 types that many
     tasks concurrently on this rank's GPU (host threads with their own streams): the EM of one sample is a chain of short
     launches that leaves the GPU to the front-end work and scoring of the next (bench.py --inflight).
+    `many`: the rank's tasks of one locus are typed TOGETHER (hgx_type_many: one launch chain per locus instead of one per
+    task -- the many-samples form, /root/reference/hisatgenotype:613-665); results are identical to the one-by-one form.
     Returns {(sample_id, gene): LocusResult} for this rank's tasks."""
     import threading
     from . import capi
@@ -157,6 +159,30 @@ def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, ix_dir=No
         opts.setdefault("regions", [packed[gene].ref_allele])
         return (sample_id, gene), type_locus(packed[gene], None, alignment_file=sam, stream=stream, gate=heavy, **opts)
 
+    if many:
+        from .typing import type_many
+        by_gene = {}
+        for task in mine:
+            by_gene.setdefault(task[1], []).append(task)
+        parse_keys = ("num_editdist", "error_correction", "allow_discordant", "simulation", "base_locus")
+        popts = {k: v for k, v in typing_opts.items() if k in parse_keys}
+        for gene, group in by_gene.items():
+            pl = packed[gene]
+            batches = []
+            for _, _, sam in group:
+                if isinstance(sam, (bytes, bytearray)) or "\t" in sam:
+                    batches.append(pl.parse_sam(sam, **popts))
+                else:
+                    batches.append(pl.parse_alignment_file(sam, typing_opts.get("regions", [pl.ref_allele]), **popts))
+            mb = engine.ManyBatch(pl, batches)
+            try:
+                res = type_many(pl, mb, remove_low=typing_opts.get("remove_low_abundance_alleles", True))
+            finally:
+                mb.close()
+            for (sample_id, _, _), r, b in zip(group, res, batches):
+                r.n_pieces, r.n_refs = b.n_pieces, b.n_refs
+                out[(sample_id, gene)] = r
+        return out
     if inflight <= 1 or len(mine) <= 1:
         for task in mine:
             k, v = one(task, None)

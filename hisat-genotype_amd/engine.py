@@ -52,6 +52,12 @@ class DeviceBatch:
             pass
 
 
+def em_set_fast(on):
+    """Arithmetic of Classes.em / em_ordered on this thread for problems the one-workgroup kernel takes: False = the reference's own
+    order of operations (default, bit-identical), True = table lookups (~5x faster, within rounding).  Returns the old setting."""
+    return bool(capi.lib().hgx_em_set_fast(C.c_int32(1 if on else 0)))
+
+
 class ManyBatch:
     """The piece batches of many tasks of ONE locus merged and resident in HBM (hgx_many): what hgx_type_many types at once."""
 

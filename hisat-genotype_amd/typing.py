@@ -127,7 +127,7 @@ class TypeOpts(C.Structure):
     """hgx_type_opts (include/hgx.h)."""
     _fields_ = [("remove_low", C.c_int32), ("keep_classes", C.c_int32), ("overlap", C.c_int32), ("per_pair_exon", C.c_int32),
                 ("gate", C.c_void_p), ("ev_compat_begin", C.c_void_p), ("ev_compat_end", C.c_void_p),
-                ("ev_pairs_begin", C.c_void_p), ("ev_pairs_end", C.c_void_p)]
+                ("ev_pairs_begin", C.c_void_p), ("ev_pairs_end", C.c_void_p), ("em_fast", C.c_int32)]
 
 
 def _result_from_handle(h, pl, res, keep_classes):
@@ -162,7 +162,8 @@ def _result_from_handle(h, pl, res, keep_classes):
     return res
 
 
-def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dbatch=None, overlap=None, gate=None, events=None):
+def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dbatch=None, overlap=None, gate=None, events=None,
+                em_fast=False):
     """The per-locus body of typing() for one piece batch: ONE call into libhgx (hgx_type_dbatch / hgx_type_batch, which
     orchestrate scoring, grouping, dedup, Gene_counts, both EMs and the hand-off on the GPU; typing_core.py:1589-1789).
     `dbatch`: the batch already resident in HBM (engine.DeviceBatch; bench.py types it repeatedly); `overlap`: None = the
@@ -170,7 +171,8 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
     samples in flight on one GPU take turns with their bandwidth-bound front; `events` = (compat begin, compat end, pairs
     begin, pairs end) capi.Event objects recorded around hgx_piece_compat and the gene-level hgx_pair_classes launch."""
     o = TypeOpts(int(bool(remove_low)), int(bool(keep_classes)), -1 if overlap is None else int(bool(overlap)), 0,
-                 gate.h if gate is not None else None, *[(e.h if e is not None else None) for e in (events or (None,) * 4)])
+                 gate.h if gate is not None else None, *[(e.h if e is not None else None) for e in (events or (None,) * 4)],
+                 int(bool(em_fast)))
     h = C.c_void_p()
     L = capi.lib()
     if dbatch is not None:
@@ -186,7 +188,7 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
         L.hgx_typing_destroy(h)
 
 
-def type_many(pl, many, remove_low=True, stream=None, return_errors=False):
+def type_many(pl, many, remove_low=True, stream=None, return_errors=False, em_fast=False):
     """Every task of a merged batch (engine.ManyBatch: many samples of ONE locus) in one call into libhgx (hgx_type_many): one
     launch chain for all tasks instead of one per task -- the many-samples form of the per-locus body of typing()
     (typing_core.py:370, /root/reference/hisatgenotype:613-665).  Returns one LocusResult per task, each identical to
@@ -194,7 +196,7 @@ def type_many(pl, many, remove_low=True, stream=None, return_errors=False):
     `return_errors`: then that task's entry is the exception instance."""
     L = capi.lib()
     n = many.n_tasks
-    o = TypeOpts(int(bool(remove_low)), 0, 0, 0, None, None, None, None, None)
+    o = TypeOpts(int(bool(remove_low)), 0, 0, 0, None, None, None, None, None, int(bool(em_fast)))
     hs = (C.c_void_p * max(n, 1))()
     rcs = (C.c_int32 * max(n, 1))()
     capi.check(L.hgx_type_many(hs, rcs, pl.h, pl.index(), many.h, C.byref(o), stream))
@@ -218,6 +220,51 @@ def type_many(pl, many, remove_low=True, stream=None, return_errors=False):
         for t in range(n):
             if hs[t]:
                 L.hgx_typing_destroy(C.c_void_p(hs[t]))
+    return out
+
+
+def type_many_loci(pls, manies, remove_low=True, stream=None, light=False, em_fast=False):
+    """A whole panel in one call (hgx_type_many_loci): `manies[i]` = the merged batch of locus `pls[i]`'s samples.  The loci are
+    scored one after the other; the EMs of all their tasks go out in ONE launch.  Returns a list (per locus) of lists (per task)
+    of LocusResult -- or, with `light`, of (num_reads, [top-2 allele names], EM iterations): what a throughput run looks at."""
+    L = capi.lib()
+    nl = len(pls)
+    o = TypeOpts(int(bool(remove_low)), 0, 0, 0, None, None, None, None, None, int(bool(em_fast)))
+    hs = [(C.c_void_p * max(m.n_tasks, 1))() for m in manies]
+    rcs = [(C.c_int32 * max(m.n_tasks, 1))() for m in manies]
+    out_pp = (C.POINTER(C.c_void_p) * max(nl, 1))(*[C.cast(h, C.POINTER(C.c_void_p)) for h in hs])
+    rc_pp = (C.POINTER(C.c_int32) * max(nl, 1))(*[C.cast(r, C.POINTER(C.c_int32)) for r in rcs])
+    loc_p = (C.c_void_p * max(nl, 1))(*[pl.h for pl in pls])
+    ix_p = (C.c_void_p * max(nl, 1))(*[pl.index() for pl in pls])
+    many_p = (C.c_void_p * max(nl, 1))(*[m.h for m in manies])
+    capi.check(L.hgx_type_many_loci(C.c_int32(nl), out_pp, rc_pp, loc_p, ix_p, many_p, C.byref(o), stream))
+    out = []
+    try:
+        for i, (pl, many) in enumerate(zip(pls, manies)):
+            row = []
+            for t in range(many.n_tasks):
+                if rcs[i][t] != 0:
+                    raise capi.HgxError(rcs[i][t], "task %d of locus %d failed (the reference would raise here)" % (t, i))
+                h = C.c_void_p(hs[i][t])
+                if light:
+                    n_gp, n_em = C.c_int32(), C.c_int32()
+                    capi.check(L.hgx_typing_dims(h, None, None, None, None, None, C.byref(n_em), C.byref(n_gp), None))
+                    al, pr = np.zeros(max(n_gp.value, 1), np.int32), np.zeros(max(n_gp.value, 1), np.float64)
+                    if n_gp.value:
+                        capi.check(L.hgx_typing_gene_prob(h, capi.ptr(al), capi.ptr(pr)))
+                    row.append((many.task_reads[t], [pl.names[a] for a in al[:min(2, n_gp.value)].tolist()], n_em.value))
+                    continue
+                res = LocusResult()
+                res.num_reads, res.num_pairs = many.task_reads[t], many.task_pairs[t]
+                if res.num_reads > 0:
+                    _result_from_handle(h, pl, res, False)
+                row.append(res)
+            out.append(row)
+    finally:
+        for i, many in enumerate(manies):
+            for t in range(many.n_tasks):
+                if hs[i][t]:
+                    L.hgx_typing_destroy(C.c_void_p(hs[i][t]))
     return out
 
 

@@ -237,6 +237,9 @@ int hgx_classes_set_allele_rank(hgx_classes *c, const int32_t *rank_host, int32_
  * reference's doubles, and ties between them are the reference's ties (callers sort them with a plain stable sort instead
  * of the tolerance they need for results that agree to ~1e-14 only) */
 int hgx_em_last_exact(void);
+/* arithmetic of hgx_em / hgx_em_ordered on this thread for problems the one-workgroup kernel takes (see hgx_type_opts.em_fast):
+ * 0 = the reference's order (default), 1 = table lookups.  Returns the previous setting. */
+int hgx_em_set_fast(int on);
 
 /* The exon -> gene hand-off in one call (typing_core.py:1752-1782): Gene_cmpt2 = every class of `c` filtered to the alleles of
  * mask_host (a_pad/64 words), empty ones dropped, equal ones merged with summed counts; then the EM on it (as
@@ -379,6 +382,10 @@ typedef struct hgx_type_opts {
                                  classes exist, so that ONE bandwidth-bound front runs at a time, beside the others' EM phases */
     void *ev_compat_begin, *ev_compat_end;   /* optional hipEvent_t recorded around hgx_piece_compat                      */
     void *ev_pairs_begin, *ev_pairs_end;     /* ... and around the gene-level hgx_pair_classes launch (bench.py)           */
+    int32_t em_fast;          /* EM #1 of problems of up to 4096 classes x 8192 alleles: 0 (default) = the reference's own order of
+                                 floating-point operations (bit-identical abundances, hgx_emx.hip); 1 = table-lookup arithmetic on
+                                 the same one-workgroup kernel: ~5x faster, abundances within rounding (~1e-12; bar 1e-5), same
+                                 stopping and pruning rules.  Larger problems always take the multi-launch table-lookup path. */
 } hgx_type_opts;
 
 int hgx_dbatch_create(hgx_dbatch **out, const hgx_batch *b, void *stream);     /* upload; returns when the copy is complete */
@@ -430,6 +437,11 @@ int hgx_many_destroy(hgx_many *m);
 int hgx_many_dims(const hgx_many *m, int32_t *n_tasks, int32_t *n_distinct_pieces, int32_t *n_pairs, int64_t *n_refs, int64_t *n_reads);
 int hgx_type_many(hgx_typing **out /* [n_tasks] */, int32_t *rc_out /* [n_tasks] or NULL */, const hgx_locus *loc, const hgx_index *ix,
                   hgx_many *m, const hgx_type_opts *opts, void *stream);
+/* Several loci at once (a whole panel): out[i] / rc_out[i] are locus i's arrays as in hgx_type_many.  The loci are scored one
+ * after the other, but the EMs of ALL their tasks go out in one launch (one workgroup per task), so the launch is as wide as
+ * the panel and its time is the longest task's, not the sum over the loci. */
+int hgx_type_many_loci(int32_t n_loci, hgx_typing ***out, int32_t **rc_out_or_null, const hgx_locus *const *loci,
+                       const hgx_index *const *ixs, hgx_many *const *manies, const hgx_type_opts *opts, void *stream);
 
 /* Kernel timing for roofline reports.  hgx_em_set_timing(1) makes hgx_em time a sample of its table-lookup mat-vec launches
  * (every 4th ungated rows pass and the cols pass after it), hgx_em_set_timing(2) every plain rows / cols pass, with events

@@ -146,6 +146,13 @@ def test_config3_full_panel_64_samples(tmp_path):
         assert set(got) == set(truth)
         conc = hgx.run_panel(tasks, ix, "hla", inflight=3, weights=weights, ix_dir=ix_dir)
         assert set(conc) == set(got)
+        # ... and with all the tasks of a locus behind ONE launch chain (hgx_type_many): `==` on every field of all 384 results
+        batched = hgx.run_panel(tasks, ix, "hla", many=True, weights=weights, ix_dir=ix_dir)
+        assert set(batched) == set(got)
+        for key, res in got.items():
+            b = batched[key]
+            assert b.num_reads == res.num_reads and b.num_pairs == res.num_pairs
+            assert b.gene_prob == res.gene_prob and b.em == res.em and b.counts_sorted == res.counts_sorted, key
         for key, res in got.items():
             assert 0.99 * PAIRS_PER_TASK <= res.num_pairs <= PAIRS_PER_TASK and res.num_reads > 1.9 * PAIRS_PER_TASK
             assert max(c for _, c in res.counts_sorted[:1]) <= res.num_pairs

@@ -98,3 +98,32 @@ def test_config0_em1_is_the_reference_bit_for_bit():
         assert got["n_iter"] == exp["n_iter"]
         assert [a for a, _ in got["result"]] == [a for a, _ in exp["result"]]
         assert [p for _, p in got["result"]] == [float(q) for _, q in exp["result"]]
+
+
+@pytest.mark.parametrize("case", CASES[:8], ids=lambda c: "A%d_used%d_C%d" % c[:3])
+def test_emx_fast_mode_is_within_rounding(orc, case):
+    """hgx_type_opts.em_fast / hgx_em_set_fast: table-lookup mat-vecs and tree reductions on the same one-workgroup kernel --
+    same iteration counts, same survivors, abundances within 1e-9 of the oracle's (bar: 1e-5); not flagged exact."""
+    A, n_used, C_, dens = case
+    rng = np.random.RandomState(1000 + A + C_)
+    a_pad, name_rank, classes, rows, counts, lengths = _random_problem(rng, A, n_used, C_, dens)
+    cl = engine.Classes.from_host(rows, counts, a_pad)
+    cl.set_allele_rank(name_rank)
+    old = engine.em_set_fast(True)
+    try:
+        for low, ln in ((True, None), (False, lengths), (True, lengths)):
+            try:
+                oa, op, oit = orc.single_abundance(A, classes, counts, low, ln)
+            except KeyError:
+                continue
+            p, it = cl.em(A, low, ln)
+            assert not engine.em_last_exact()
+            exp = np.full(A, -1.0)
+            exp[oa] = op
+            assert it == oit, (case, low, it, oit)
+            assert np.array_equal(p < 0, exp < 0)
+            assert np.max(np.abs(p - exp)) <= 1e-9
+            p2, first, it2 = cl.em_ordered(A, low, ln)
+            assert it2 == it and np.array_equal(p2, p)                 # deterministic
+    finally:
+        engine.em_set_fast(old)

@@ -25,12 +25,12 @@ def _same(a, b):
     assert a.gene_prob == b.gene_prob
 
 
-def _one(pl, batch, remove_low=True):
+def _one(pl, batch, remove_low=True, em_fast=False):
     res = htyping.LocusResult()
     res.num_reads, res.num_pairs = batch.n_reads, batch.n_pairs
     if batch.n_reads <= 0:
         return res
-    return htyping._type_batch(pl, batch, res, remove_low)
+    return htyping._type_batch(pl, batch, res, remove_low, em_fast=em_fast)
 
 
 @pytest.mark.parametrize("n_alleles,n_vars,pairs", [(300, 500, [400, 900, 0, 1500, 37, 600]), (2500, 1500, [1200, 2500, 800]),
@@ -50,6 +50,10 @@ def test_many_equals_one_by_one_hla(n_alleles, n_vars, pairs):
         assert len(got) == len(batches)
         for g, b in zip(got, batches):
             _same(g, _one(pl, b, low))
+    # throughput arithmetic (hgx_type_opts.em_fast): still task for task what the one-task path gives with the same option
+    got = htyping.type_many(pl, many, em_fast=True)
+    for g, b in zip(got, batches):
+        _same(g, _one(pl, b, True, em_fast=True))
     # the same call again on the same resident batch (buffers recycled, scratch reused): identical
     again = htyping.type_many(pl, many)
     for g, h in zip(again, htyping.type_many(pl, many)):
