@@ -829,6 +829,8 @@ struct Fields {
     const char *seq; size_t seq_len;
     const char *zs, *md;
     bool has_nm, has_nh, yt_cp;
+    uint8_t bad_tag;                 // an NM / NH tag whose value int() would reject (core:838-841): raises once the record gets that far
+    const char *bad_tok;             // ... the offending text
     uint8_t kept;                    // outcome of the record filters (core:815-872), see filter_records
     long nm, nh;
     // the DECODE KEY of a record = (pos, cigar, seq, zs, md): everything its cmp_list / haplotypes depend on
@@ -838,7 +840,7 @@ struct Fields {
     uint32_t slot;                   // at rep: index of the group's decode result, or NO_SLOT
     uint64_t key;                    // hash of the decode key
 };
-enum { KEPT_NO = 0, KEPT_YES = 1, KEPT_ERR_TAGS = 2, KEPT_ERR_FLAG = 3 };
+enum { KEPT_NO = 0, KEPT_YES = 1, KEPT_ERR_TAGS = 2, KEPT_ERR_FLAG = 3, KEPT_ERR_TAGVAL = 4 };
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 
 inline uint64_t hash_bytes(const char *p, size_t n, uint64_t h) {
@@ -878,25 +880,48 @@ inline long parse_long(const char *p) {            // strtol(p, nullptr, 10) for
     return neg ? -v : v;
 }
 
+// would Python's int(text) accept it?  optional surrounding blanks cannot occur inside a token; sign, digits, single underscores
+// between digits (typing_core.py:811-812, 838-841 call int() on FLAG, POS and the NM / NH values)
+inline bool py_int_ok(const char *t, size_t n) {
+    size_t i = 0;
+    if (i < n && (t[i] == '+' || t[i] == '-')) ++i;
+    if (i >= n || t[i] < '0' || t[i] > '9') return false;
+    for (; i < n; ++i) {
+        if (t[i] >= '0' && t[i] <= '9') continue;
+        if (t[i] == '_' && i + 1 < n && t[i + 1] >= '0' && t[i + 1] <= '9' && t[i - 1] != '_') continue;
+        return false;
+    }
+    return true;
+}
+
 inline void note_tag(Fields &f, char *tok, size_t len) {
     if (len < 5) {                                   // too short to carry a value: tok + 5 may not be dereferenced
         if (tok[0] == 'Z' && tok[1] == 's') { f.zs = tok + len; f.zs_len = 0; }
         else if (tok[0] == 'M' && tok[1] == 'D') { f.md = tok + len; f.md_len = 0; }
-        else if (tok[0] == 'N' && tok[1] == 'M') f.has_nm = true;
-        else if (tok[0] == 'N' && tok[1] == 'H') f.has_nh = true;
+        else if (tok[0] == 'N' && (tok[1] == 'M' || tok[1] == 'H')) {      // int(col[5:]) of an empty string raises
+            if (tok[1] == 'M') f.has_nm = true; else f.has_nh = true;
+            if (!f.bad_tag) { f.bad_tag = 1; f.bad_tok = tok + len; }
+        }
         return;
     }
     if (tok[0] == 'Z' && tok[1] == 's') { f.zs = tok + 5; f.zs_len = (uint32_t)(len - 5); }
     else if (tok[0] == 'M' && tok[1] == 'D') { f.md = tok + 5; f.md_len = (uint32_t)(len - 5); }
-    else if (tok[0] == 'N' && tok[1] == 'M') { f.has_nm = true; f.nm = strtol(tok + 5, nullptr, 10); }
-    else if (tok[0] == 'N' && tok[1] == 'H') { f.has_nh = true; f.nh = strtol(tok + 5, nullptr, 10); }
+    else if (tok[0] == 'N' && tok[1] == 'M') {
+        f.has_nm = true; f.nm = strtol(tok + 5, nullptr, 10);
+        if (!f.bad_tag && !py_int_ok(tok + 5, len - 5)) { f.bad_tag = 1; f.bad_tok = tok + 5; }
+    } else if (tok[0] == 'N' && tok[1] == 'H') {
+        f.has_nh = true; f.nh = strtol(tok + 5, nullptr, 10);
+        if (!f.bad_tag && !py_int_ok(tok + 5, len - 5)) { f.bad_tag = 1; f.bad_tok = tok + 5; }
+    }
     else if (tok[0] == 'Y' && tok[1] == 'T') f.yt_cp = len == 7 && tok[5] == 'C' && tok[6] == 'P';
 }
 
 // Split one record in place the way the reference's `line.strip().split()` does (on runs of tab / space / CR).  A record
 // without spaces or CRs -- every record an aligner writes -- takes the tab-only path (memchr, 16+ bytes per step); anything
-// else the byte loop.  Returns false for lines with fewer than eleven fields.
-static bool split_line(char *line, char *end, Fields &f) {
+// else the byte loop.  Returns 0 for a record, else what the reference's loop dies of on this line (typing_core.py:803-814):
+// 1 = fewer than six fields (the unpacking of cols[:6]: ValueError), 2 = fewer than eleven (cols[9] / cols[10]: IndexError),
+// 3 / 4 = FLAG / POS that int() rejects (ValueError); *bad_n / *bad_tok say how many fields / which text.
+static int split_line(char *line, char *end, Fields &f, int *bad_n, const char **bad_tok) {
     char *cols[11];
     size_t lens[11];
     int nc = 0;
@@ -904,6 +929,8 @@ static bool split_line(char *line, char *end, Fields &f) {
     f.zs_len = f.md_len = 0;
     f.has_nm = f.has_nh = f.yt_cp = false;
     f.nm = f.nh = 0;
+    f.bad_tag = 0;
+    f.bad_tok = nullptr;
     const size_t n = (size_t)(end - line);
     if (!memchr(line, ' ', n) && !memchr(line, '\r', n)) {
         char *p = line;
@@ -930,7 +957,9 @@ static bool split_line(char *line, char *end, Fields &f) {
             else note_tag(f, tok, len);
         }
     }
-    if (nc < 11) return false;
+    if (nc < 11) { *bad_n = nc; return nc < 6 ? 1 : 2; }
+    if (!py_int_ok(cols[1], lens[1])) { *bad_tok = cols[1]; return 3; }
+    if (!py_int_ok(cols[3], lens[3])) { *bad_tok = cols[3]; return 4; }
     f.qname = cols[0];
     f.qname_len = lens[0];
     f.flag = (int)strtol(cols[1], nullptr, 10);
@@ -940,7 +969,7 @@ static bool split_line(char *line, char *end, Fields &f) {
     f.seq = cols[9];
     f.seq_len = lens[9];
     set_decode_key(f);
-    return true;
+    return 0;
 }
 
 // ---- BAM records straight into Fields (no text round trip) --------------------------------------------------------------
@@ -1000,6 +1029,8 @@ static bool split_bam(const unsigned char *r, size_t len, Fields &f, CharArena &
     f.zs = f.md = nullptr;
     f.zs_len = f.md_len = 0;
     f.has_nm = f.has_nh = f.yt_cp = false;
+    f.bad_tag = 0;
+    f.bad_tok = nullptr;
     f.nm = f.nh = 0;
     f.qname = (const char *)r + 32;
     f.qname_len = l_rn - 1;
@@ -1217,6 +1248,7 @@ void filter_records(const hgx_parse_opts &o, Fields *recs, const uint8_t *ok, si
         }
         if (f.pos - (o.base_locus + 1) < 0) continue;
         if (f.flag & 0x4) continue;
+        if (f.bad_tag) { f.kept = KEPT_ERR_TAGVAL; continue; }              // int(col[5:]) raises while the tags are read (core:838-841)
         if (!f.has_nm || !f.has_nh) { f.kept = KEPT_ERR_TAGS; continue; }
         if (f.nm > o.num_editdist) continue;
         if (f.nh > 1) continue;
@@ -1459,6 +1491,8 @@ void emit_chunk(const hgx_parse_opts &o, const Fields *recs, const uint8_t *ok, 
             const Fields &f = recs[i];
             if (f.kept == KEPT_NO) continue;
             if (f.kept == KEPT_ERR_TAGS) throw RefError("TypeError: record without NM/NH tag (quirk Q8)");
+            if (f.kept == KEPT_ERR_TAGVAL)
+                throw RefError(std::string("ValueError: invalid literal for int() with base 10: '") + std::string(f.bad_tok ? f.bad_tok : "").substr(0, 60) + "'");
             if (f.kept == KEPT_ERR_FLAG) throw RefError("assert allow_discordant");
             const MateOut &m = outs[recs[f.rep].slot];
             if (m.state == 3) { out.error = m.err; out.error_code = m.err_code; return; }
@@ -1688,6 +1722,8 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
         // field split + decode keys, embarrassingly parallel over lines
         std::vector<CharArena> arenas(binary ? n_threads : 0);
         std::vector<int> bad_rec(n_threads, 0);
+        struct BadLine { size_t index = 0; int code = 0, n = 0; std::string tok; };
+        std::vector<BadLine> bad_line(n_threads);
         parallel_for(n_threads, n, [&](int t, size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {
                 if (binary) {
@@ -1702,10 +1738,30 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
                 }
                 char *line = lines[i].p, *lend = line + lines[i].len;
                 *lend = 0;
-                ok[i] = split_line(line, lend, recs[i]) ? 1 : 0;
+                int bad_n = 0;
+                const char *bad_tok = nullptr;
+                const int bad = split_line(line, lend, recs[i], &bad_n, &bad_tok);
+                ok[i] = bad ? 0 : 1;
+                if (bad && (bad_line[t].code == 0 || i < bad_line[t].index)) {
+                    bad_line[t].index = i; bad_line[t].code = bad; bad_line[t].n = bad_n;
+                    bad_line[t].tok = bad_tok ? std::string(bad_tok).substr(0, 60) : std::string();
+                }
             }
         });
         for (int v : bad_rec) if (v) { hgx_set_error("malformed BAM record"); delete B; return HGX_EPARSE; }
+        {   // a line the reference's record loop cannot take apart kills it right there (typing_core.py:803-814): the first such line
+            const BadLine *first = nullptr;
+            for (const BadLine &b : bad_line) if (b.code && (!first || b.index < first->index)) first = &b;
+            if (first) {
+                char msg[200];
+                if (first->code == 1) snprintf(msg, sizeof(msg), "ValueError: not enough values to unpack (expected 6, got %d)", first->n);
+                else if (first->code == 2) snprintf(msg, sizeof(msg), "IndexError: list index out of range");
+                else snprintf(msg, sizeof(msg), "ValueError: invalid literal for int() with base 10: '%s'", first->tok.c_str());
+                hgx_set_error("the reference would fail on this input: %s (record %zu)", msg, first->index + 1);
+                delete B;
+                return HGX_EPARSE;
+            }
+        }
         lap("split");
         // chunks that start where the read id changes (the record filters and the pair protocol work inside them)
         const int n_chunks = n_threads == 1 ? 1 : n_threads * 4;

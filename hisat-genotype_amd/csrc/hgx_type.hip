@@ -14,12 +14,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <numeric>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -144,8 +146,29 @@ struct EmFastScope {                 // hgx_type_opts.em_fast for the EMs of thi
 struct hgx_typing {
     int32_t n_reads = 0, n_pairs = 0, n_pieces = 0, n_alleles = 0;
     int64_t n_refs = 0;
-    std::vector<int32_t> counted;        // alleles with a non-zero Gene_count, in the reference's print order
+    mutable std::vector<int32_t> counted;        // alleles with a non-zero Gene_count, in the reference's print order
     std::vector<int64_t> cnt;            // Gene_counts per allele index [n_alleles]
+    // hgx_type_many leaves the ranking (core:1650-1651: a sort of every counted allele) to the first caller that asks for it
+    mutable std::vector<int32_t> first_pair;     // per allele: first pair of the first class containing it (the tie order)
+    mutable bool ranked = true;
+    mutable std::mutex rank_mu;
+    void ensure_ranked() const {
+        std::lock_guard<std::mutex> g(rank_mu);
+        if (ranked) return;
+        const int32_t A = (int32_t)cnt.size();
+        counted.clear();
+        for (int32_t a = 0; a < A; ++a) if (cnt[a] > 0) counted.push_back(a);
+        const int64_t *c = cnt.data();
+        const int32_t *fp = first_pair.data();
+        std::sort(counted.begin(), counted.end(), [&](int32_t a, int32_t b) {
+            if (c[a] != c[b]) return c[a] > c[b];
+            if (fp[a] != fp[b]) return fp[a] < fp[b];
+            return a < b;
+        });
+        first_pair.clear();
+        first_pair.shrink_to_fit();
+        ranked = true;
+    }
     std::vector<EmOut> em;
     EmOut gene_prob;                     // final Gene_prob (allele, prob), sorted
     hgx_classes *exon_cl = nullptr, *gene_cl = nullptr;      // kept alive with keep_classes
@@ -588,7 +611,7 @@ extern "C" int hgx_typing_dims(const hgx_typing *t, int32_t *n_reads, int32_t *n
     if (n_pairs) *n_pairs = t->n_pairs;
     if (n_pieces) *n_pieces = t->n_pieces;
     if (n_refs) *n_refs = t->n_refs;
-    if (n_counted) *n_counted = (int32_t)t->counted.size();
+    if (n_counted) { t->ensure_ranked(); *n_counted = (int32_t)t->counted.size(); }
     if (n_em) *n_em = (int32_t)t->em.size();
     if (n_gene_prob) *n_gene_prob = (int32_t)t->gene_prob.allele.size();
     if (em_seconds) *em_seconds = t->t_em;
@@ -597,6 +620,7 @@ extern "C" int hgx_typing_dims(const hgx_typing *t, int32_t *n_reads, int32_t *n
 
 extern "C" int hgx_typing_counts(const hgx_typing *t, int32_t *ranked_allele, int64_t *count_per_allele) {
     ARGCHK(t);
+    if (ranked_allele) t->ensure_ranked();
     if (ranked_allele && !t->counted.empty()) memcpy(ranked_allele, t->counted.data(), t->counted.size() * 4);
     if (count_per_allele && !t->cnt.empty()) memcpy(count_per_allele, t->cnt.data(), t->cnt.size() * 8);
     return HGX_OK;
@@ -656,7 +680,7 @@ struct hgx_many {
     double *d_len = nullptr;                         // [a_pad] allele lengths
     void *h_pinned = nullptr;                        // staging of the tasks' Gene_counts
     size_t h_pinned_bytes = 0;
-    std::mutex mu;                                   // (the staging block serves one call at a time)
+    std::atomic<int> in_use{0};                      // the staging block serves one call at a time
 };
 
 extern "C" int hgx_many_destroy(hgx_many *m) {
@@ -778,7 +802,7 @@ struct ManyRun {
     hgx_classes *ecl = nullptr, *gcl = nullptr;
     hgx_groups *groups = nullptr;
     std::vector<int32_t> e_off, g_off;
-    std::unique_lock<std::mutex> pin_lock;
+    bool holds_many = false;
     int64_t *h_cnt = nullptr;
     int32_t *h_fp = nullptr;
     std::vector<std::vector<double>> prob1, prob2;
@@ -791,6 +815,7 @@ struct ManyRun {
 
     ~ManyRun() {
         if (st || active) (void)hipStreamSynchronize(st);
+        if (holds_many) m->in_use.store(0);
         hgx_groups_destroy(groups);
         hgx_classes_destroy(ecl);
         hgx_classes_destroy(gcl);
@@ -866,7 +891,8 @@ struct ManyRun {
         { int rc_ = hgx_h2d(b_goff.p, g_off.data(), (size_t)(n + 1) * 4, st); if (rc_) return rc_; }
         rc = hgx_many_counts(gcl, b_goff.as<int32_t>(), m->d_pair_base, n, b_cnt.as<int64_t>(), b_fp.as<int32_t>(), st);
         if (rc) return rc;
-        pin_lock = std::unique_lock<std::mutex>(m->mu);
+        if (m->in_use.exchange(1) != 0) { hgx_set_error("hgx_many: one hgx_type_many call at a time per merged batch"); return HGX_EINVAL; }
+        holds_many = true;
         const size_t need = (size_t)n * a_pad * 12;
         if (m->h_pinned_bytes < need) {
             if (m->h_pinned) (void)hipHostFree(m->h_pinned);
@@ -941,14 +967,10 @@ struct ManyRun {
             const int64_t *cnt = h_cnt + t * (size_t)a_pad;
             const int32_t *fp = h_fp + t * (size_t)a_pad;
             ty->cnt.assign(cnt, cnt + A);
-            for (int32_t a = 0; a < A; ++a) if (cnt[a] > 0) ty->counted.push_back(a);
-            std::sort(ty->counted.begin(), ty->counted.end(), [&](int32_t a, int32_t b) {
-                if (cnt[a] != cnt[b]) return cnt[a] > cnt[b];
-                if (fp[a] != fp[b]) return fp[a] < fp[b];
-                return a < b;
-            });
+            ty->first_pair.assign(fp, fp + A);
+            ty->ranked = false;                                 // sorted when somebody asks for the ranking (ensure_ranked)
         });
-        if (pin_lock.owns_lock()) pin_lock.unlock();
+        if (holds_many) { m->in_use.store(0); holds_many = false; }
         if (!hla) {
             for (int t = 0; t < n; ++t) if (res[t] && !res[t]->em.empty()) res[t]->gene_prob = res[t]->em[0];
             return HGX_OK;
@@ -1021,7 +1043,34 @@ int run_many(std::vector<ManyRun> &runs, hgx_typing ***out, hipStream_t st) {
     double tp[6];
     tp[0] = now_s();
     int rc = HGX_OK;
-    for (auto &r : runs) { rc = r.score(); if (rc) return rc; }
+    if (runs.size() <= 1) {
+        for (auto &r : runs) { rc = r.score(); if (rc) return rc; }
+    } else {
+        // the loci's scoring chains (a dozen host round trips each) side by side: one host thread and stream per locus
+        int dev = 0;
+        HIPCHK(hipGetDevice(&dev));
+        std::vector<StreamSet> sets(runs.size());
+        std::vector<int> rcs(runs.size(), HGX_OK);
+        std::vector<std::string> errs(runs.size());
+        for (size_t i = 0; i < runs.size(); ++i) { rc = acquire_streams(sets[i]); if (rc) return rc; }
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<std::thread> th;
+        for (size_t i = 0; i < runs.size(); ++i)
+            th.emplace_back([&, i, dev] {
+                if (hipSetDevice(dev) != hipSuccess) { rcs[i] = HGX_EHIP; errs[i] = "hipSetDevice failed on a scoring thread"; return; }
+                ManyRun &r = runs[i];
+                const hipStream_t main_st = r.st;
+                r.st = sets[i].em;
+                rcs[i] = r.score();
+                if (rcs[i] == HGX_OK && hgx_sync(r.st) != HGX_OK) rcs[i] = HGX_EHIP;
+                if (rcs[i]) errs[i] = hgx_last_error();
+                r.st = main_st;
+            });
+        for (auto &t : th) t.join();
+        for (size_t i = 0; i < runs.size(); ++i) release_streams(sets[i]);
+        for (size_t i = 0; i < runs.size(); ++i)
+            if (rcs[i]) { hgx_set_error("%s", errs[i].c_str()); return rcs[i]; }
+    }
     tp[1] = now_s();
     std::vector<hgx_emx_job> jobs, jobs2;
     for (auto &r : runs) { rc = r.em1_jobs(jobs); if (rc) return rc; }

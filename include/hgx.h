@@ -430,7 +430,7 @@ int hgx_typing_classes(const hgx_typing *t, int32_t level, const hgx_classes **o
  * the number of tasks.  out[t] = the result of task t (hgx_typing_* accessors; destroy each with hgx_typing_destroy), identical
  * to hgx_type_batch on task t's batch alone.  rc_out (may be NULL): per-task status -- HGX_ETYPE / HGX_EKEY where the reference
  * would raise on THAT task (out[t] = NULL then); with rc_out NULL such a task fails the whole call.  hgx_type_opts: remove_low
- * is honoured; class sets are not kept per task. */
+ * and em_fast are honoured; class sets are not kept per task.  One call at a time per hgx_many (its staging memory is reused). */
 typedef struct hgx_many hgx_many;
 int hgx_many_create(hgx_many **out, const hgx_locus *loc, const hgx_batch *const *batches, int32_t n_tasks, void *stream);
 int hgx_many_destroy(hgx_many *m);

@@ -92,3 +92,33 @@ def test_empty_input():
     pl = hl.PackedLocus.from_synth(fx["_locus"])
     b = pl.parse_sam("")
     assert b.n_pairs == 0 and b.n_reads == 0 and b.n_pieces == 0
+
+
+def test_malformed_records_fail_as_the_reference_does():
+    """tests/golden/malformed_records.json (made by driving the REAL reference, make_malformed_golden.py): a record the reference's
+    loop cannot take apart -- too few fields, FLAG / POS / NM that int() rejects, a SEQ shorter than its CIGAR -- kills the
+    reference with ValueError / IndexError / TypeError; the front-end refuses the input with the same exception named in its
+    message instead of dropping the record.  One documented difference: a BLANK line is no record here (the
+    reader drops blank and header lines, as `samtools view` never prints one) where the reference, fed one, dies of it."""
+    import json
+    import os
+    from hisatgenotype_amd import capi
+    fx = gu.load("hla_small_pair")
+    pl = hl.PackedLocus.from_synth(fx["_locus"])
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "malformed_records.json")))["cases"]
+    assert len(cases) >= 12
+    for c in cases:
+        want = c["reference_exception"]
+        if c["name"] == "blank_line":
+            assert want == "ValueError"
+            pl.parse_sam(c["sam"], simulation=True)
+            continue
+        if not want:
+            assert pl.parse_sam(c["sam"], simulation=True).n_reads > 0
+            continue
+        with pytest.raises(capi.HgxError) as e:
+            pl.parse_sam(c["sam"], simulation=True)
+        msg = str(e.value)
+        assert "the reference would fail on this input" in msg and want in msg, (c["name"], want, msg)
+        if want == "ValueError":                       # the message the reference printed, word for word
+            assert c["reference_message"].split(": ", 1)[1] in msg, (c["name"], msg)
