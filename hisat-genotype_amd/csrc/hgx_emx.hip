@@ -42,7 +42,7 @@ constexpr int XAW = XA / 64, XCW = XC / 64;
 
 enum { XS_ITER = 0, XS_STATUS = 1, XS_A1 = 2, XS_ORDERS = 3, XS_RES_OFF = 4, XS_RES_N = 5, XS_NCLS = 6, XS_N = 8 };
 
-struct EmxRes { int32_t allele, first; double prob; };       // one allele of a returned dict
+typedef hgx_emx_rec EmxRes;                                  // one allele of a returned dict
 
 struct EmxTask {
     const uint64_t *B;
@@ -54,6 +54,7 @@ struct EmxTask {
     int32_t c_alloc;        // classes the class-indexed scratch is sized for (= C; the hand-off: the merged classes it may produce)
     int32_t fast;           // 1: table-lookup arithmetic (any summation order; within rounding of the reference), see fast_* below
     // scratch
+    uint64_t *Rm;       // [Cp][w64]   set-up only: the class rows in the compact name-ordered allele space, class-major
     uint64_t *Mk;       // [A1w][Cp]   word (aw, c): which alleles of tile aw are in class c
     uint64_t *Mr;       // [Cw][A1s]   word (cw, j): which classes of tile cw contain allele j
     double *dv;         // [3][A1s]    dict values
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     const int w64 = T.w64, A1s = T.a_pad;
     const int CpA = (T.c_alloc + 63) & ~63;             // stride of the class-indexed scratch arrays
     int C = T.C;                                        // (the hand-off mode continues with the merged classes)
-    unsigned long long t_mark = T.stamps ? wall_clock64() : 0, acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_mark = T.stamps ? wall_clock64() : 0, acc_t[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto lap = [&](int k) { if (T.stamps) { const unsigned long long t = wall_clock64(); acc_t[k] += t - t_mark; t_mark = t; } };
     auto give_up = [&](double status) { if (tid == 0) { T.scal[XS_STATUS] = status; T.scal[XS_ITER] = 0.0; T.scal[XS_RES_N] = 0.0; } };
     if (C <= 0 || (!T.mask && C > XC) || w64 > 128 || A1s > XA) { give_up(1.0); return; }
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     }
     __syncthreads();
     const int A1 = S.A1;
+    lap(7);
     if (A1 > XA || (T.mask && A1 > 64)) { give_up(1.0); return; }
     if (A1 <= 0) {                                      // (hand-off: no class left) an empty result
         if (tid == 0) { T.scal[XS_STATUS] = 0.0; T.scal[XS_ITER] = 0.0; T.scal[XS_RES_N] = 0.0; T.scal[XS_NCLS] = 0.0; T.scal[XS_A1] = 0.0; }
@@ -249,17 +251,27 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
             __builtin_amdgcn_wave_barrier();
             int size = 0;
             unsigned long long keep0 = 0ull, keep1 = 0ull;
-            for (int aw = 0; aw < A1w; ++aw) {
-                const int j = 64 * aw + lane;
-                const int g = j < A1 ? srt[j] : 0;
-                const bool bit = c < C && j < A1 && ((rowbuf[g >> 6] >> (g & 63)) & 1ull);
-                const unsigned long long m = __ballot(bit);
-                size += __popcll(m);
-                if (lane == (aw & 63)) { if (aw < 64) keep0 = m; else keep1 = m; }
+            for (int aw0 = 0; aw0 < A1w; aw0 += 4) {       // four tiles at a time: the two dependent LDS reads of each are in flight together
+                int g[4];
+                unsigned long long word[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int j = 64 * (aw0 + u) + lane; g[u] = j < A1 ? srt[j] : 0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) word[u] = rowbuf[g[u] >> 6];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int aw = aw0 + u, j = 64 * aw + lane;
+                    const bool bit = c < C && j < A1 && ((word[u] >> (g[u] & 63)) & 1ull);
+                    const unsigned long long m = __ballot(bit);
+                    size += __popcll(m);
+                    if (lane == (aw & 63)) { if (aw < 64) keep0 = m; else keep1 = m; }
+                }
             }
             __builtin_amdgcn_wave_barrier();
-            if (lane < A1w) T.Mk[(size_t)lane * CpA + c] = keep0;
-            if (lane + 64 < A1w) T.Mk[(size_t)(lane + 64) * CpA + c] = keep1;
+            // (class-major first: one contiguous run of words per class; a store per word straight into Mk[aw][c] would be
+            // A1w scattered 8-byte writes per class)
+            if (lane < A1w) T.Rm[(size_t)c * w64 + lane] = keep0;
+            if (lane + 64 < A1w) T.Rm[(size_t)c * w64 + 64 + lane] = keep1;
             if (lane == 0) {
                 const double n = c < C ? (double)T.count[c] : 0.0;
                 cnt_c[c] = n;
@@ -320,14 +332,34 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
         __syncthreads();
     }
     const int Cp = (C + 63) & ~63, Cw = Cp >> 6;
+    lap(8);
     for (int j = tid; j < A1s; j += XB) T.vlen[j] = (T.len && j < A1) ? T.len[srt[j]] : 1.0;
     phase_sync();
-    // ---- Mr: 64 x 64 bit transposes of Mk tiles ------------------------------------------------------------------
-    for (int item = wave; item < Cw * A1w; item += XNW) {
-        const int cw = item / A1w, aw = item - cw * A1w;
-        const uint64_t x = T.Mk[(size_t)aw * CpA + 64 * cw + lane];
-        T.Mr[(size_t)cw * A1s + 64 * aw + lane] = wave_transpose64(x);
+    // ---- Mk (word (aw, c), coalesced over c) and Mr (64 x 64 bit transposes, coalesced over the alleles) from the class-major rows
+    if (!T.mask) {
+        for (int item = wave; item < Cw * ((A1w + 7) / 8); item += XNW) {       // (class tile, eight allele tiles): 8 loads in flight
+            const int cw = item % Cw, a8 = item / Cw;
+            const int c = 64 * cw + lane;
+            uint64_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = 8 * a8 + u < A1w ? T.Rm[(size_t)c * w64 + 8 * a8 + u] : 0ull;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int aw = 8 * a8 + u;
+                if (aw < A1w) {
+                    T.Mk[(size_t)aw * CpA + c] = x[u];
+                    T.Mr[(size_t)cw * A1s + 64 * aw + lane] = wave_transpose64(x[u]);
+                }
+            }
+        }
+    } else {
+        for (int item = wave; item < Cw * A1w; item += XNW) {
+            const int cw = item / A1w, aw = item - cw * A1w;
+            const uint64_t x = T.Mk[(size_t)aw * CpA + 64 * cw + lane];
+            T.Mr[(size_t)cw * A1s + 64 * aw + lane] = wave_transpose64(x);
+        }
     }
+    lap(9);
     const bool use_len = T.len != nullptr;
     const int remove_low = T.remove_low;
     if (tid == 0) { S.cache_ord = -1; S.need_slow = 0; }
@@ -824,7 +856,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
         T.scal[XS_RES_OFF] = (double)S.res_base;
         T.scal[XS_RES_N] = (double)res_n;
     }
-    if (T.stamps && tid == 0) for (int k = 0; k < 8; ++k) T.stamps[k] = acc_t[k];
+    if (T.stamps && tid == 0) for (int k = 0; k < 12; ++k) T.stamps[k] = acc_t[k];
 }
 #pragma clang fp contract(fast)
 
@@ -832,7 +864,7 @@ inline size_t up64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 }   // namespace
 
-int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
+int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs_out) {
     ARGCHK(jobs && n_jobs >= 0);
     if (n_jobs == 0) return HGX_OK;
     static bool attr_set[64] = {};
@@ -845,7 +877,7 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
     }
     const bool stamps = getenv("HGX_EMX_STAMPS") != nullptr;
     // scratch of every job out of ONE block; jobs beyond the kernel's limits get status 1 without a descriptor
-    struct Lay { size_t Mk, Mr, dv, pos, tmpv, vlen, cls, din, sorted, first, stamps, end; };
+    struct Lay { size_t Rm, Mk, Mr, dv, pos, tmpv, vlen, cls, din, sorted, first, stamps, end; };
     std::vector<Lay> lays;
     std::vector<int> job_of;
     std::vector<size_t> base;
@@ -856,11 +888,12 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
         J.n_classes = 0;
         J.status = 1;
         if (J.C <= 0 || (!J.mask && J.C > HGX_EMX_MAX_CLASSES) || J.w64 > 128 || J.a_pad > HGX_EMX_MAX_ALLELES || J.a_pad != 64 * J.w64) continue;
-        ARGCHK(J.bits && J.count && J.rank && J.prob && J.n_out <= J.a_pad);
+        ARGCHK(J.bits && J.count && J.rank && (J.prob || recs_out) && J.n_out <= J.a_pad);
         const size_t c_alloc = J.mask ? std::min<size_t>((size_t)J.C, 2048) : (size_t)J.C;
         const size_t Cp = (c_alloc + 63) & ~(size_t)63, A1s = (size_t)J.a_pad, A1w = J.mask ? 1 : A1s / 64, Cw = Cp / 64;
         Lay L;
         size_t o = 0;
+        L.Rm = o; o += up64(J.mask ? 64 : Cp * A1s / 64 * 8);
         L.Mk = o; o += up64(A1w * Cp * 8);
         L.Mr = o; o += up64(Cw * A1s * 8);
         L.dv = o; o += up64(3 * A1s * 8);
@@ -913,7 +946,7 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
         T.C = J.C; T.w64 = J.w64; T.a_pad = J.a_pad; T.remove_low = J.remove_low ? 1 : 0;
         T.c_alloc = J.mask ? std::min(J.C, 2048) : J.C;
         T.fast = J.fast ? 1 : 0;
-        T.Mk = (uint64_t *)(b + L.Mk); T.Mr = (uint64_t *)(b + L.Mr); T.dv = (double *)(b + L.dv); T.pos = (uint16_t *)(b + L.pos);
+        T.Rm = (uint64_t *)(b + L.Rm); T.Mk = (uint64_t *)(b + L.Mk); T.Mr = (uint64_t *)(b + L.Mr); T.dv = (double *)(b + L.dv); T.pos = (uint16_t *)(b + L.pos);
         T.tmpv = (double *)(b + L.tmpv); T.vlen = (double *)(b + L.vlen); T.cls = (double *)(b + L.cls); T.din = (uint8_t *)(b + L.din);
         T.sorted = (int32_t *)(b + L.sorted); T.first_c = (int32_t *)(b + L.first);
         T.scal = (double *)(resb + 64 + (size_t)t * XS_N * 8);
@@ -948,6 +981,7 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
         { int rc_ = hgx_sync(st); if (rc_) return rc_; }
     }
     const EmxRes *recs = (const EmxRes *)(h.data() + head);
+    if (recs_out) recs_out->assign(recs, recs + n_rec);
     for (int t = 0; t < n; ++t) {
         hgx_emx_job &J = jobs[job_of[t]];
         const double *sc = (const double *)(h.data() + 64 + (size_t)t * XS_N * 8);
@@ -955,6 +989,11 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
         J.n_iter = (int32_t)sc[XS_ITER];
         J.n_classes = (int32_t)sc[XS_NCLS];
         if (J.status == 1) continue;
+        if (recs_out) {
+            J.rec_off = J.status == 0 ? (size_t)sc[XS_RES_OFF] : 0;
+            J.n_rec = J.status == 0 ? (int32_t)sc[XS_RES_N] : 0;
+            continue;
+        }
         for (int a = 0; a < J.n_out; ++a) J.prob[a] = -1.0;
         if (J.first) for (int a = 0; a < J.n_out; ++a) J.first[a] = -1;
         if (J.status != 0) continue;
@@ -966,12 +1005,13 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st) {
     }
     if (stamps) {
         for (int t = 0; t < std::min(n, 8); ++t) {
-            unsigned long long hs[8];
-            (void)hipMemcpy(hs, scr + base[t] + lays[t].stamps, 64, hipMemcpyDeviceToHost);
+            unsigned long long hs[12];
+            (void)hipMemcpy(hs, scr + base[t] + lays[t].stamps, 96, hipMemcpyDeviceToHost);
             const double *sc = (const double *)(h.data() + 64 + (size_t)t * XS_N * 8);
             fprintf(stderr, "[k_emx] job %d C %d A1 %d iters %d orders %d: set-up %.1f us | rows %.1f | cols %.1f | order %.1f | normalise %.1f | "
-                            "init %.1f | vector steps %.1f\n", job_of[t], jobs[job_of[t]].C, (int)sc[XS_A1], (int)sc[XS_ITER], (int)sc[XS_ORDERS],
-                    hs[0] * 0.01, hs[1] * 0.01, hs[2] * 0.01, hs[3] * 0.01, hs[4] * 0.01, hs[5] * 0.01, hs[6] * 0.01);
+                            "init %.1f | vector steps %.1f || set-up: active alleles %.1f, class rows %.1f, Mk + Mr %.1f, rest %.1f\n", job_of[t], jobs[job_of[t]].C, (int)sc[XS_A1], (int)sc[XS_ITER], (int)sc[XS_ORDERS],
+                    (hs[0] + hs[7] + hs[8] + hs[9]) * 0.01, hs[1] * 0.01, hs[2] * 0.01, hs[3] * 0.01, hs[4] * 0.01, hs[5] * 0.01, hs[6] * 0.01, hs[7] * 0.01,
+                    hs[8] * 0.01, hs[9] * 0.01, hs[0] * 0.01);
         }
     }
     return HGX_OK;

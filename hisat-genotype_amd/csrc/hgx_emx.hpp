@@ -5,6 +5,11 @@
 
 #include <cstdint>
 
+#include <vector>
+
+// one allele of a returned dict (what the kernel writes; hgx_emx_run hands these out as they are when asked to)
+struct hgx_emx_rec { int32_t allele, first; double prob; };
+
 // One EM problem: `C` classes (rows of `w64` words over the locus' allele indices, dict order), their counts, the alleles' name
 // order (rank[a] = place of allele a among the sorted names = its place inside a class key) and optionally the allele
 // lengths (double per allele index).  All pointers are DEVICE memory that stays valid until the call returns.
@@ -22,9 +27,11 @@ struct hgx_emx_job {
                                 // tree reductions on the same workgroup -- ~5x faster, abundances within rounding (~1e-12) of the
                                 // reference's, same stopping and pruning rules
     // results (HOST memory, filled by hgx_emx_run)
-    double *prob;               // [n_out] abundance, or -1.0 for an allele that is not in the returned dict
+    double *prob;               // [n_out] abundance, or -1.0 for an allele that is not in the returned dict (NULL with `recs`, below)
     int32_t *first;             // [n_out] or NULL: first class (dict order) containing the allele, -1 elsewhere
     int32_t n_out;              // alleles reported (<= a_pad)
+    size_t rec_off;             // with `recs`: the job's records are recs[rec_off .. rec_off + n_rec)
+    int32_t n_rec;
     int32_t n_iter;             // outer iterations
     int32_t n_classes;          // classes the EM ran on (= C without a mask)
     int32_t status;             // 0 = done, 1 = not taken (too many classes / distinct alleles: the caller uses another path),
@@ -36,4 +43,6 @@ constexpr int HGX_EMX_MAX_CLASSES = 4096;
 constexpr int HGX_EMX_MAX_ALLELES = 8192;
 
 // Runs all jobs in ONE launch (one workgroup per job) on `st` and returns when the results are on the host.
-int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st);
+// `recs` != NULL: the returned dicts come back as records (the alleles IN the dict only; a job's records are in compact
+// name order) instead of dense per-allele arrays -- many small results cost nothing to clear and scan.
+int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs = nullptr);

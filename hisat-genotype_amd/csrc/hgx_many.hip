@@ -11,17 +11,20 @@
 
 #include "hgx_common.hpp"
 
-// classes per task: the task of a class is the task of its first pair
+// First class of every task.  The class table of a merged batch is in first-seen order over pairs that come task after task, so
+// a task's classes are one run: start[t] = index of the first class whose first pair belongs to task t (-1 if it has none).
 __global__ void k_class_tasks(const int64_t *__restrict__ first_row, int n_classes, const uint32_t *__restrict__ pair_seg,
-                              int32_t *__restrict__ per_task) {
+                              int32_t *__restrict__ start) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < n_classes) atomicAdd(&per_task[pair_seg[first_row[c]]], 1);
+    if (c >= n_classes) return;
+    const uint32_t t = pair_seg[first_row[c]];
+    if (c == 0 || pair_seg[first_row[c - 1]] != t) start[t] = c;
 }
 
-int hgx_many_class_tasks(const hgx_classes *cl, const uint32_t *pair_seg, int32_t n_tasks, int32_t *per_task_dev, hipStream_t st) {
-    HIPCHK(hipMemsetAsync(per_task_dev, 0, (size_t)n_tasks * 4, st));
+int hgx_many_class_tasks(const hgx_classes *cl, const uint32_t *pair_seg, int32_t n_tasks, int32_t *start_dev, hipStream_t st) {
+    HIPCHK(hipMemsetAsync(start_dev, 0xFF, (size_t)n_tasks * 4, st));
     if (cl->n_classes > 0)
-        hipLaunchKernelGGL(k_class_tasks, dim3(nblk(cl->n_classes, 256)), dim3(256), 0, st, cl->d_first_row, cl->n_classes, pair_seg, per_task_dev);
+        hipLaunchKernelGGL(k_class_tasks, dim3(nblk(cl->n_classes, 256)), dim3(256), 0, st, cl->d_first_row, cl->n_classes, pair_seg, start_dev);
     HIPCHK(hipGetLastError());
     return HGX_OK;
 }

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -768,18 +769,36 @@ int class_offsets(const hgx_classes *cl, const hgx_many *m, int32_t *scratch_dev
     if (!cl || cl->n_classes == 0) return HGX_OK;
     int rc = hgx_many_class_tasks(cl, m->d_pair_seg, n, scratch_dev, st);
     if (rc) return rc;
-    std::vector<int32_t> per((size_t)n);
-    HIPCHK(hipMemcpyAsync(per.data(), scratch_dev, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    for (int t = 0; t < n; ++t) off[t + 1] = off[t] + per[t];
-    if (off[n] != cl->n_classes) { hgx_set_error("class table of the merged batch does not partition into tasks (%d of %d)", off[n], cl->n_classes); return HGX_EHIP; }
+    std::vector<int32_t> start((size_t)n);
+    { int rc_ = hgx_d2h(start.data(), scratch_dev, (size_t)n * 4, st); if (rc_) return rc_; }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+    // runs of classes, task after task: a task without classes starts where the next one does
+    off[n] = cl->n_classes;
+    int32_t last = -1;
+    for (int t = n - 1; t >= 0; --t) {
+        off[t] = start[t] >= 0 ? start[t] : off[t + 1];
+        if (start[t] >= 0) { if (last >= 0 && start[t] > last) { hgx_set_error("class table of the merged batch is not ordered by task"); return HGX_EHIP; } last = start[t]; }
+    }
+    if (off[0] != 0) { hgx_set_error("class table of the merged batch does not start with the first task's classes"); return HGX_EHIP; }
     return HGX_OK;
 }
 
-void em_out_from(const hgx_emx_job &J, const std::vector<double> &prob, const std::vector<int32_t> &first, const hgx_locus *loc, int32_t use_length, EmOut &o) {
+// the result list of a batched EM from its records: dict insertion order (first class, then name order), then the reference's
+// stable descending sort -- what sorted_result does from dense arrays
+void em_out_from(const hgx_emx_job &J, const std::vector<hgx_emx_rec> &recs, const hgx_locus *loc, int32_t use_length, EmOut &o) {
     o.exact = J.fast == 0;
     o.n_classes = J.n_classes; o.n_iter = J.n_iter; o.remove_low = J.remove_low ? 1 : 0; o.use_length = use_length;
-    sorted_result(prob, first, loc->name_rank.data(), loc->A, o);
+    std::vector<hgx_emx_rec> r(recs.begin() + J.rec_off, recs.begin() + J.rec_off + J.n_rec);
+    const int32_t *name_rank = loc->name_rank.data();
+    std::sort(r.begin(), r.end(), [&](const hgx_emx_rec &x, const hgx_emx_rec &y) {
+        if (x.first != y.first) return x.first < y.first;
+        if (name_rank[x.allele] != name_rank[y.allele]) return name_rank[x.allele] < name_rank[y.allele];
+        return x.allele < y.allele;
+    });
+    o.allele.resize(r.size());
+    o.prob.resize(r.size());
+    for (size_t k = 0; k < r.size(); ++k) { o.allele[k] = r[k].allele; o.prob[k] = r[k].prob; }
+    stable_desc(o.allele, o.prob, o.exact);
 }
 
 }   // namespace
@@ -805,8 +824,6 @@ struct ManyRun {
     bool holds_many = false;
     int64_t *h_cnt = nullptr;
     int32_t *h_fp = nullptr;
-    std::vector<std::vector<double>> prob1, prob2;
-    std::vector<std::vector<int32_t>> first1, first2;
     std::vector<std::vector<uint8_t>> in_exon;
     std::vector<double> psum;
     std::vector<uint64_t> masks;
@@ -910,7 +927,6 @@ struct ManyRun {
     // EM #1 of every task (HLA: exon classes; other bases: gene classes, no pruning): jobs appended to the callers' list
     int em1_jobs(std::vector<hgx_emx_job> &jobs) {
         job_lo = jobs.size();
-        prob1.assign((size_t)n, {}); first1.assign((size_t)n, {});
         if (active)
             for (int t = 0; t < n; ++t) {
                 const int32_t C = off1()[t + 1] - off1()[t];
@@ -921,13 +937,11 @@ struct ManyRun {
                     if (rc) return rc;
                     continue;
                 }
-                prob1[t].assign((size_t)A, -1.0);
-                first1[t].assign((size_t)A, -1);
                 hgx_emx_job J{};
                 J.bits = cl1()->d_bits + (size_t)off1()[t] * w64; J.count = cl1()->d_count + off1()[t]; J.rank = m->d_rank;
                 J.C = C; J.w64 = w64; J.a_pad = a_pad; J.remove_low = hla ? (opts->remove_low ? 1 : 0) : 0;
                 J.fast = opts->em_fast ? 1 : 0;
-                J.prob = prob1[t].data(); J.first = first1[t].data(); J.n_out = A;
+                J.prob = nullptr; J.first = nullptr; J.n_out = A;
                 jobs.push_back(J);
                 job_task.push_back(t);
             }
@@ -935,8 +949,26 @@ struct ManyRun {
         return HGX_OK;
     }
 
-    // EM #1's results -> the tasks; Gene_counts ranking (core:1650-1651); exon_alleles and the hand-off jobs (core:1739-1766)
-    int after_em1(const std::vector<hgx_emx_job> &jobs, std::vector<hgx_emx_job> &jobs2) {
+    // Gene_counts of every task from the staging block into the results (the scoring stream must be drained); the ranking itself
+    // (core:1650-1651, a sort of every counted allele) is left to the first caller that asks for it (hgx_typing::ensure_ranked)
+    bool counts_taken = false;
+    void take_counts() {
+        counts_taken = true;
+        if (!active) return;
+        for (int t = 0; t < n; ++t) {
+            hgx_typing *ty = res[t];
+            if (!ty || ty->n_reads <= 0) continue;
+            const int64_t *cnt = h_cnt + t * (size_t)a_pad;
+            const int32_t *fp = h_fp + t * (size_t)a_pad;
+            ty->cnt.assign(cnt, cnt + A);
+            ty->first_pair.assign(fp, fp + A);
+            ty->ranked = false;
+        }
+        if (holds_many) { m->in_use.store(0); holds_many = false; }
+    }
+
+    // EM #1's results -> the tasks; exon_alleles and the hand-off jobs (core:1739-1766)
+    int after_em1(const std::vector<hgx_emx_job> &jobs, const std::vector<hgx_emx_rec> &recs, std::vector<hgx_emx_job> &jobs2) {
         job2_lo = job2_hi = jobs2.size();
         if (!active) return HGX_OK;
         int rc = HGX_OK;
@@ -958,26 +990,16 @@ struct ManyRun {
                 continue;
             }
             EmOut o;
-            em_out_from(J, prob1[t], first1[t], loc, 0, o);
+            em_out_from(J, recs, loc, 0, o);
             ty->em.push_back(std::move(o));
         }
-        hgx_par_tasks(std::min(hgx_default_threads(), 16), (size_t)n, [&](int, size_t t) {
-            hgx_typing *ty = res[t];
-            if (!ty || ty->n_reads <= 0) return;
-            const int64_t *cnt = h_cnt + t * (size_t)a_pad;
-            const int32_t *fp = h_fp + t * (size_t)a_pad;
-            ty->cnt.assign(cnt, cnt + A);
-            ty->first_pair.assign(fp, fp + A);
-            ty->ranked = false;                                 // sorted when somebody asks for the ranking (ensure_ranked)
-        });
-        if (holds_many) { m->in_use.store(0); holds_many = false; }
+        if (!counts_taken) take_counts();
         if (!hla) {
             for (int t = 0; t < n; ++t) if (res[t] && !res[t]->em.empty()) res[t]->gene_prob = res[t]->em[0];
             return HGX_OK;
         }
         in_exon.assign((size_t)n, {}); psum.assign((size_t)n, 0.0);
         masks.assign((size_t)n * w64, 0);
-        prob2.assign((size_t)n, {}); first2.assign((size_t)n, {});
         ALLOC(b_masks, masks.size() * 8);
         for (int t = 0; t < n; ++t) {
             hgx_typing *ty = res[t];
@@ -986,13 +1008,11 @@ struct ManyRun {
             if (!exon_alleles_of(ty->em[0], loc, in_exon[t], psum[t])) continue;
             uint64_t *mk = &masks[(size_t)t * w64];
             for (int32_t a = 0; a < A; ++a) if (in_exon[t][a]) mk[a >> 6] |= 1ull << (a & 63);
-            prob2[t].assign((size_t)A, -1.0);
-            first2[t].assign((size_t)A, -1);
             hgx_emx_job J{};
             J.bits = gcl->d_bits + (size_t)g_off[t] * w64; J.count = gcl->d_count + g_off[t]; J.rank = m->d_rank; J.len = m->d_len;
             J.mask = b_masks.as<uint64_t>() + (size_t)t * w64;
             J.C = g_off[t + 1] - g_off[t]; J.w64 = w64; J.a_pad = a_pad; J.remove_low = 1;
-            J.prob = prob2[t].data(); J.first = first2[t].data(); J.n_out = A;
+            J.prob = nullptr; J.first = nullptr; J.n_out = A;
             jobs2.push_back(J);
             job2_task.push_back(t);
         }
@@ -1002,7 +1022,7 @@ struct ManyRun {
     }
 
     // EM #2's results, the combination of the two levels (core:1771-1782); hands the results out
-    int finish(const std::vector<hgx_emx_job> &jobs2, hgx_typing **out) {
+    int finish(const std::vector<hgx_emx_job> &jobs2, const std::vector<hgx_emx_rec> &recs2, hgx_typing **out) {
         int rc = HGX_OK;
         for (size_t k = job2_lo; k < job2_hi; ++k) {
             const int t = job2_task[k - job2_lo];
@@ -1018,15 +1038,16 @@ struct ManyRun {
             if (J.status == 1) {                                // more than 64 alleles pass the filter (or too many merged classes)
                 ClassesView v(gcl, g_off[t], J.C);
                 int32_t it2 = 0, ncls2 = 0;
+                std::vector<double> p2((size_t)A);
+                std::vector<int32_t> f2((size_t)A);
                 rc = hgx_classes_set_allele_rank(&v.c, loc->name_rank.data(), A);
-                if (!rc) rc = hgx_em_masked(&v.c, &masks[(size_t)t * w64], A, 1, loc->allele_len.data(), prob2[t].data(), first2[t].data(), &it2,
-                                            &ncls2, st);
+                if (!rc) rc = hgx_em_masked(&v.c, &masks[(size_t)t * w64], A, 1, loc->allele_len.data(), p2.data(), f2.data(), &it2, &ncls2, st);
                 if (rc) { rc = fail_task(t, rc); if (rc) return rc; continue; }
                 e2.exact = hgx_em_last_exact() != 0;
                 e2.n_classes = ncls2; e2.n_iter = it2; e2.remove_low = 1; e2.use_length = 1;
-                sorted_result(prob2[t], first2[t], loc->name_rank.data(), A, e2);
+                sorted_result(p2, f2, loc->name_rank.data(), A, e2);
             } else {
-                em_out_from(J, prob2[t], first2[t], loc, 1, e2);
+                em_out_from(J, recs2, loc, 1, e2);
             }
             combine_levels(ty, std::move(e2), in_exon[t], psum[t]);
         }
@@ -1038,6 +1059,9 @@ struct ManyRun {
 
 // the loci's phases, interleaved: scoring of every locus, ONE launch for every EM #1, ranking + hand-off set-up, ONE launch for
 // every EM #2.  The EM jobs go out longest first (the launch's makespan is the longest task's time plus what queues behind it).
+// The phases of all loci: scoring side by side (one host thread and stream per locus: a dozen round trips each), ONE launch for
+// the EM #1 of every task of every locus (longest first) while the host copies the Gene_counts into the results, the hand-off
+// set-up, ONE launch for every EM #2.
 int run_many(std::vector<ManyRun> &runs, hgx_typing ***out, hipStream_t st) {
     const bool prof = getenv("HGX_TYPE_PROFILE") != nullptr;
     double tp[6];
@@ -1045,8 +1069,8 @@ int run_many(std::vector<ManyRun> &runs, hgx_typing ***out, hipStream_t st) {
     int rc = HGX_OK;
     if (runs.size() <= 1) {
         for (auto &r : runs) { rc = r.score(); if (rc) return rc; }
+        HIPCHK(hipStreamSynchronize(st));
     } else {
-        // the loci's scoring chains (a dozen host round trips each) side by side: one host thread and stream per locus
         int dev = 0;
         HIPCHK(hipGetDevice(&dev));
         std::vector<StreamSet> sets(runs.size());
@@ -1073,30 +1097,31 @@ int run_many(std::vector<ManyRun> &runs, hgx_typing ***out, hipStream_t st) {
     }
     tp[1] = now_s();
     std::vector<hgx_emx_job> jobs, jobs2;
+    std::vector<hgx_emx_rec> recs, recs2;
     for (auto &r : runs) { rc = r.em1_jobs(jobs); if (rc) return rc; }
-    const double t_em0 = now_s();
-    rc = hgx_emx_run(jobs.data(), (int)jobs.size(), st);           // (returns with the stream drained: the Gene_counts are on the host too)
+    std::thread copier([&] { for (auto &r : runs) r.take_counts(); });       // (host work behind the EM launch)
+    rc = hgx_emx_run(jobs.data(), (int)jobs.size(), st, &recs);
+    copier.join();
     if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(st));
     tp[2] = now_s();
-    for (auto &r : runs) { rc = r.after_em1(jobs, jobs2); if (rc) return rc; }
+    for (auto &r : runs) { rc = r.after_em1(jobs, recs, jobs2); if (rc) return rc; }
     tp[3] = now_s();
     if (!jobs2.empty()) {
         HIPCHK(hipStreamSynchronize(st));                          // (the masks were copied from pageable memory)
-        rc = hgx_emx_run(jobs2.data(), (int)jobs2.size(), st);
+        rc = hgx_emx_run(jobs2.data(), (int)jobs2.size(), st, &recs2);
         if (rc) return rc;
     }
     tp[4] = now_s();
-    const double em_share = ((tp[2] - t_em0) + (tp[4] - tp[3])) / std::max<size_t>(jobs.size(), 1);
+    const double em_share = ((tp[2] - tp[1]) + (tp[4] - tp[3])) / std::max<size_t>(jobs.size(), 1);
     size_t n_tasks = 0;
     for (size_t i = 0; i < runs.size(); ++i) {
         for (auto *t : runs[i].res) if (t) t->t_em = em_share;
         n_tasks += runs[i].n;
-        rc = runs[i].finish(jobs2, out[i]);
+        rc = runs[i].finish(jobs2, recs2, out[i]);
         if (rc) return rc;
     }
     if (prof)
-        fprintf(stderr, "[hgx_type_many] %zu loci, %zu tasks: scoring + dedup + counts %.2f ms | EM #1 (%zu jobs) %.2f | ranking + hand-off set-up %.2f | "
+        fprintf(stderr, "[hgx_type_many] %zu loci, %zu tasks: scoring + dedup + counts %.2f ms | EM #1 (%zu jobs) %.2f | hand-off set-up %.2f | "
                         "EM #2 (%zu jobs) %.2f | results %.2f\n", runs.size(), n_tasks, (tp[1] - tp[0]) * 1e3, jobs.size(), (tp[2] - tp[1]) * 1e3,
                 (tp[3] - tp[2]) * 1e3, jobs2.size(), (tp[4] - tp[3]) * 1e3, (now_s() - tp[4]) * 1e3);
     return HGX_OK;
@@ -1129,4 +1154,21 @@ extern "C" int hgx_type_many_loci(int32_t n_loci, hgx_typing ***out, int32_t **r
         for (int i = 0; i < n_loci; ++i)
             for (int t = 0; t < manies[i]->n_tasks; ++t) { if (out[i][t]) { delete out[i][t]; out[i][t] = nullptr; } }
     return rc;
+}
+
+// The calls of many results at once (what a throughput run looks at): per result the reads, the single_abundance calls made and
+// the first `k` alleles of the final Gene_prob with their abundances (-1 / 0.0 beyond the end of a shorter list).
+extern "C" int hgx_typing_top(const hgx_typing *const *ts, int32_t n, int32_t k, int32_t *n_reads, int32_t *n_em, int32_t *allele, double *prob) {
+    ARGCHK(n >= 0 && k >= 0 && (n == 0 || ts));
+    for (int32_t i = 0; i < n; ++i) {
+        const hgx_typing *t = ts[i];
+        if (n_reads) n_reads[i] = t ? t->n_reads : 0;
+        if (n_em) n_em[i] = t ? (int32_t)t->em.size() : 0;
+        for (int32_t j = 0; j < k; ++j) {
+            const bool have = t && (size_t)j < t->gene_prob.allele.size();
+            if (allele) allele[(size_t)i * k + j] = have ? t->gene_prob.allele[j] : -1;
+            if (prob) prob[(size_t)i * k + j] = have ? t->gene_prob.prob[j] : 0.0;
+        }
+    }
+    return HGX_OK;
 }

@@ -245,15 +245,16 @@ def type_many_loci(pls, manies, remove_low=True, stream=None, light=False, em_fa
             for t in range(many.n_tasks):
                 if rcs[i][t] != 0:
                     raise capi.HgxError(rcs[i][t], "task %d of locus %d failed (the reference would raise here)" % (t, i))
+            if light:                                        # one call for the locus' tasks (hgx_typing_top)
+                n = many.n_tasks
+                nr, ne = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+                al, pr = np.zeros((max(n, 1), 2), np.int32), np.zeros((max(n, 1), 2), np.float64)
+                capi.check(L.hgx_typing_top(hs[i], C.c_int32(n), C.c_int32(2), capi.ptr(nr), capi.ptr(ne), capi.ptr(al), capi.ptr(pr)))
+                names = pl.names
+                out.append([(int(nr[t]), [names[a] for a in al[t].tolist() if a >= 0], int(ne[t])) for t in range(n)])
+                continue
+            for t in range(many.n_tasks):
                 h = C.c_void_p(hs[i][t])
-                if light:
-                    n_gp, n_em = C.c_int32(), C.c_int32()
-                    capi.check(L.hgx_typing_dims(h, None, None, None, None, None, C.byref(n_em), C.byref(n_gp), None))
-                    al, pr = np.zeros(max(n_gp.value, 1), np.int32), np.zeros(max(n_gp.value, 1), np.float64)
-                    if n_gp.value:
-                        capi.check(L.hgx_typing_gene_prob(h, capi.ptr(al), capi.ptr(pr)))
-                    row.append((many.task_reads[t], [pl.names[a] for a in al[:min(2, n_gp.value)].tolist()], n_em.value))
-                    continue
                 res = LocusResult()
                 res.num_reads, res.num_pairs = many.task_reads[t], many.task_pairs[t]
                 if res.num_reads > 0:

@@ -418,6 +418,10 @@ int hgx_typing_em(const hgx_typing *t, int32_t k, int32_t *n_classes, int32_t *n
                   int32_t *n_result, int32_t *allele, double *prob);
 /* final Gene_prob (core:1732-1789): n_gene_prob entries */
 int hgx_typing_gene_prob(const hgx_typing *t, int32_t *allele, double *prob);
+/* the calls of MANY results in one call: per result its reads, the number of single_abundance calls and the first k entries of
+ * the final Gene_prob (allele -1 / abundance 0.0 beyond the end of a shorter list); a NULL result reads as empty */
+int hgx_typing_top(const hgx_typing *const *ts, int32_t n, int32_t k, int32_t *n_reads, int32_t *n_em, int32_t *allele /* [n][k] */,
+                   double *prob /* [n][k] */);
 /* with keep_classes: the class sets behind the result (owned by `t`; NULL if that level was not built) */
 int hgx_typing_classes(const hgx_typing *t, int32_t level, const hgx_classes **out);
 

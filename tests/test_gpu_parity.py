@@ -452,14 +452,13 @@ def test_em_single_wavefront_path_matches_oracle_and_other_paths(orc):
 
 
 def test_em_mid_size_in_reference_order_is_bit_identical(orc):
-    """65 ... 2048 classes over up to 1024 distinct alleles run in ONE workgroup in the reference's own order of operations
-    (k_em_ref): abundances `==` the C oracle's (which the golden vectors pin to the real reference), same iteration counts,
-    with pruning, with allele lengths, with alleles scattered over a wide index range and an arbitrary name order; more than
-    1024 distinct alleles -- or, by default, more than 65 536 class-member pairs (the kernel owns one CU) -- fall through to
-    the table-lookup path and still agree to 1e-9."""
+    """65 ... 2048 classes over hundreds to thousands of distinct alleles in the reference's own order of operations (k_emx,
+    hgx_emx.hip, since round 3: up to 4096 classes x 8192 alleles; k_em_ref, round 2's one-workgroup kernel for <= 1024 alleles,
+    is still reachable with HGX_EM_NO_EMX=1): abundances `==` the C oracle's (which the golden vectors pin to the real
+    reference), same iteration counts, with pruning, with allele lengths, with alleles scattered over a wide index range and an
+    arbitrary name order.  The table-lookup path on the same problems (both switched off) agrees to 1e-9."""
     import os
     rng = np.random.RandomState(2024)
-    os.environ["HGX_EM_MID_NNZ"] = "100000000"                  # the size gate is lifted for this test (re-armed at the end)
     cases = [(300, 90, 120, 0.10), (700, 400, 600, 0.03), (7000, 1024, 2048, 0.01), (1200, 1000, 300, 0.2), (5000, 200, 1500, 0.3),
              (2000, 1100, 500, 0.05)]
     ran_exact = 0
@@ -492,23 +491,26 @@ def test_em_mid_size_in_reference_order_is_bit_identical(orc):
             exp[oa] = op
             assert it == oit, (A, n_used, C_, low, it, oit)
             assert np.array_equal(p < 0, exp < 0)
-            if n_used <= 1024:
-                assert engine.em_last_exact()
-                assert np.array_equal(p, exp), (A, n_used, C_, low, float(np.max(np.abs(p - exp))))
-                ran_exact += 1
-                os.environ["HGX_EM_NO_MID"] = "1"              # the table-lookup path on the same problem: close, not identical
+            assert engine.em_last_exact()
+            assert np.array_equal(p, exp), (A, n_used, C_, low, float(np.max(np.abs(p - exp))))
+            ran_exact += 1
+            if n_used <= 1024:                                 # round 2's kernel on the same problem: the same doubles
+                os.environ["HGX_EM_NO_EMX"] = "1"
+                os.environ["HGX_EM_MID_NNZ"] = "100000000"
                 try:
-                    p2, it2 = cl.em(A, low, ln)
+                    p1, it1 = cl.em(A, low, ln)
+                    assert engine.em_last_exact() and it1 == it and np.array_equal(p1, p)
                 finally:
-                    del os.environ["HGX_EM_NO_MID"]
-                assert it2 == it and np.max(np.abs(p2 - p)) <= 1e-9
-            else:
+                    del os.environ["HGX_EM_NO_EMX"], os.environ["HGX_EM_MID_NNZ"]
+            os.environ["HGX_EM_NO_EMX"] = "1"                  # the table-lookup path: close, not identical
+            os.environ["HGX_EM_NO_MID"] = "1"
+            try:
+                p2, it2 = cl.em(A, low, ln)
                 assert not engine.em_last_exact()
-                assert np.max(np.abs(p - exp)) <= 1e-9
-    assert ran_exact >= 12
-    del os.environ["HGX_EM_MID_NNZ"]
-    p, it = cl.em(A, True, None)                               # the last problem (> 1024 alleles) and a gated big one: not exact
-    assert not engine.em_last_exact()
+            finally:
+                del os.environ["HGX_EM_NO_EMX"], os.environ["HGX_EM_NO_MID"]
+            assert it2 == it and np.max(np.abs(p2 - p)) <= 1e-9
+    assert ran_exact >= 15
 
 
 def test_em_compact_tail_equals_full_iterations(orc):
