@@ -98,6 +98,8 @@ def parse_args():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for --dry-run on CPU)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank joins the process group and rank 0 prints the world it saw (no GPU work)")
+    ap.add_argument("--no-workloads", action="store_true", help="default workload only: skip the class1 / panel64 runs that follow it")
+    ap.add_argument("--wl-steps", type=int, default=10, help="timed steps of the class1 / panel64 runs that follow the default workload")
     ap.add_argument("--em-exact", action="store_true",
                     help="panel64: EM #1 in the reference's own order of floating-point operations (hgx_type_opts.em_fast = 0, the "
                          "library's default: bit-identical abundances) instead of the table-lookup arithmetic the throughput run uses")
@@ -214,6 +216,52 @@ def cpu_baseline(loc, sam, n_pairs):
         "python_port_reads_per_s": round(r2["num_reads"] / t_py, 1),
         "python_port_sample": "oracle/pyref.py end to end (front-end included) on the first %d pairs" % n_py,
     }, out
+
+
+def cpu_baseline_tasks(tasks, what):
+    """The C oracle (1 core) on a bounded sample of a multi-task workload: `tasks` = [(synth locus, SAM text)]; scoring + dedup
+    + EM summed over the tasks (front-end excluded on both sides, as in the headline's baseline)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import orclib
+    import orc_pipeline
+    import pyref
+    import tables
+    orc = orclib.load()
+    reads, secs, iters, t_em = 0, 0.0, 0, 0.0
+    for loc, sam in tasks:
+        rl = pyref.RefLocus(loc)
+        rl.score = False
+        fe = rl.run(sam)
+        t = tables.oracle_tables(loc)
+        arrs = tables.pieces_from_pairs(fe["pairs"], t["var_index"])
+        lengths = np.array([loc.allele_length(n) for n in t["names"]], dtype=np.int32)
+        out = orc_pipeline.run(orc, t, arrs, loc.base_fname == "hla", lengths)
+        reads += fe["num_reads"]
+        secs += out["t_score"] + out["t_dedup"] + out["t_em"]
+        iters += out["n_iter"]
+        t_em += out["t_em"]
+    return {"value": round(reads / max(secs, 1e-9), 1), "unit": "reads/s", "cores": 1, "kind": "port",
+            "sample": "%s: %d reads, C oracle scoring + dedup + EM %.2f s (%d outer EM iterations); front-end excluded on both sides" % (
+                what, reads, secs, iters),
+            "em_iters_per_s": round(iters / max(t_em, 1e-9), 2)}
+
+
+def em_roofline(em_timing, n_timed_steps):
+    """roofline object of a workload whose EM passes were timed with dispatch-attached events (engine.em_set_timing(2))."""
+    kernels = {}
+    for name, (ms, n, ex, by) in em_timing.items():
+        if n:
+            kernels[name] = {"timed_launches": n, "timed_steps": n_timed_steps, "alg_bytes_per_launch": int(by // n), "avg_ms": round(ms / n, 5),
+                             "total_ms_per_step": round(ms / n_timed_steps, 4), "GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else 0.0}
+    if not kernels:
+        return None
+    dom = max(kernels, key=lambda k: kernels[k]["total_ms_per_step"])
+    k = kernels[dom]
+    return {"bound": "hbm", "kernel": dom, "achieved": k["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(k["GBps"] / HBM_PEAK_GBS, 4),
+            "traffic": None, "alg_bytes_per_launch": k["alg_bytes_per_launch"], "avg_launch_ms": k["avg_ms"],
+            "note": "EM mat-vec pass with the largest aggregate time per step (every plain rows / cols pass of the last %d steps timed with "
+                    "dispatch-attached HIP events); algorithmic bytes per pass = the compact class bit matrix once + its dense vectors" % n_timed_steps,
+            "kernels": kernels}
 
 
 def cgroup_cpu_quota():
@@ -400,7 +448,17 @@ def run_class1(args, rank, local_rank, world, dist):
         return out
     for _ in range(args.warmup):
         body()
-    elapsed, last = _timed(dist, args.steps, body)
+    state = {"k": 0}
+    timing = not args.no_kernel_timing and not comms
+    n_timed = min(N_TIMED_STEPS, args.steps)
+
+    def timed_body():
+        engine.em_set_timing(2 if (timing and state["k"] >= args.steps - n_timed) else 0)
+        state["k"] += 1
+        return body()
+    elapsed, last = _timed(dist, args.steps, timed_body)
+    em_timing = engine.em_get_timing() if timing else {}
+    engine.em_set_timing(0)
     reads = sum(r.num_reads for i, r in last.items() if groups[i][0] == rank)        # every locus counted once
     calls = {loci[i].gene: ([a for a, _ in r.gene_prob[:2]], work[k][5]) for k, (i, r) in enumerate(sorted(last.items()))}
     if dist is not None:
@@ -411,8 +469,13 @@ def run_class1(args, rank, local_rank, world, dist):
         allc = [None] * world
         dist.all_gather_object(allc, calls)
         calls = {g: v for part in allc for g, v in part.items()}
+    cb = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n_cpu = 1500
+        cb = cpu_baseline_tasks([(loci[i], synth.simulate_sam_fast(loci[i], work[k][5], n_cpu, err_rate=args.err, seed=100 + i))
+                                 for k, (i, *_rest) in enumerate(work)], "%d pairs of each of the three loci (same generator and seeds)" % n_cpu)
     if rank == 0:
-        print(json.dumps({
+        return ({
             "metric": "typed reads/sec at HLA class I (A+B+C, ~7-8k alleles each, 2x150bp)", "value": round(reads * args.steps / elapsed, 1),
             "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -423,7 +486,8 @@ def run_class1(args, rank, local_rank, world, dist):
                        "parallelism": "loci over rank groups; pairs of a locus over the ranks of its group (pileup all-reduce at parse, "
                                       "class-table all-gather + merge per step over RCCL); no other data-path collective",
                        "setup_s": round(t_setup, 1)},
-            "roofline": None, "cpu_baseline": None}))
+            "roofline": em_roofline(em_timing, n_timed) if timing else None, "cpu_baseline": cb})
+    return None
 
 
 def run_panel64(args, rank, local_rank, world, dist):
@@ -496,7 +560,14 @@ def run_panel64(args, rank, local_rank, world, dist):
         return out
     for _ in range(args.warmup):
         body()
+    timing = bool(manies) and not args.no_kernel_timing
+    if timing:
+        engine.emx_set_timing(True)
     elapsed, last = _timed(dist, args.steps, body)
+    emx = None
+    if timing:
+        engine.emx_set_timing(False)
+        emx = {"table lookups" if f else "reference order": engine.emx_get_timing(f) for f in (1, 0)}
     if manies:
         reads = float(sum(r[0] for r in last))
         correct = sum(1 for r, (s, k, _, _, sample) in zip(last, work) if sorted(r[1]) == sorted(sample))
@@ -509,8 +580,31 @@ def run_panel64(args, rank, local_rank, world, dist):
         rr = torch.tensor([reads, float(correct), float(n_tasks)], dtype=torch.float64, device="cuda")
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         reads, correct, n_tasks = float(rr[0].item()), int(rr[1].item()), int(rr[2].item())
+    roof = None
+    if emx:
+        kernels = {}
+        for name, (ms, nl, nj, na, nb) in emx.items():
+            if nl:
+                kernels["k_emx (%s)" % name] = {
+                    "launches": nl, "jobs_per_launch": nj // nl, "em_map_applications_per_launch": na // nl, "alg_bytes_per_launch": int(nb // nl),
+                    "avg_ms": round(ms / nl, 4), "total_ms_per_step": round(ms / args.steps, 4), "GBps": round(nb / (ms * 1e-3) / 1e9, 1),
+                    "bound": "hbm", "peak_GBps": HBM_PEAK_GBS, "frac": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if kernels:
+            dom = max(kernels, key=lambda k: kernels[k]["total_ms_per_step"])
+            roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["frac"],
+                    "traffic": None, "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"], "avg_launch_ms": kernels[dom]["avg_ms"],
+                    "note": "the one-workgroup-per-task EM kernel (EM #1 of all tasks in one launch; EM #2 in another): HIP events around every "
+                            "launch of the timed region; algorithmic bytes per launch = sum over its jobs of applications x (C * A' / 8 + 16 A' + "
+                            "16 C) (SURVEY.md 8d).  The kernel is bound by LDS table lookups and FP64 issue on ONE CU per task, not by HBM: the "
+                            "fraction says how far a task-parallel EM sits from streaming its matrices",
+                    "kernels": kernels}
+    cb = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        n_cpu = 1000
+        cb = cpu_baseline_tasks([(loci[k], synth.simulate_sam_fast(loci[k], synth.pick_sample(loci[k], k), n_cpu, err_rate=args.err, seed=k))
+                                 for k in range(len(loci))], "sample 0's six tasks at %d pairs each (same generator and seeds)" % n_cpu)
     if rank == 0:
-        print(json.dumps({
+        return ({
             "metric": "typed reads/sec over the HLA panel (6 loci x 64 samples, 2x150bp)", "value": round(reads * args.steps / elapsed, 1),
             "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -522,7 +616,8 @@ def run_panel64(args, rank, local_rank, world, dist):
                 "em_arithmetic": ("reference order (bit-identical)" if args.em_exact else "table lookups (within 1e-9; hgx_type_opts.em_fast)") if not args.one_by_one else "default",
                 "parallelism": "(sample, locus) tasks over GPUs by dist.shard (greedy by allele count), no data-path collective",
                 "setup_s": round(t_setup, 1)},
-            "roofline": None, "cpu_baseline": None}))
+            "roofline": roof, "cpu_baseline": cb})
+    return None
 
 
 def main():
@@ -561,7 +656,9 @@ def main():
         assert dist.get_world_size() == world
     capi.set_device(local_rank)
     if args.workload != "configs1":
-        (run_class1 if args.workload == "class1" else run_panel64)(args, rank, local_rank, world, dist)
+        line = (run_class1 if args.workload == "class1" else run_panel64)(args, rank, local_rank, world, dist)
+        if rank == 0:
+            print(json.dumps(line))
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
@@ -702,6 +799,22 @@ def main():
                 out["e2e"] = end_to_end(pl, loc, sam_keep, res)
             cb, _ = cpu_baseline(loc, sam_keep, min(args.cpu_pairs, batch.n_pairs))
             out["cpu_baseline"] = cb
+    # ---- the other BASELINE.json workloads, driver-timed in the same run: configs[2] (class1) and configs[3] (panel64) --------
+    if not args.no_workloads:
+        del batch, db
+        import copy
+        wl = {}
+        for name, fn, steps, warm in (("class1", run_class1, args.wl_steps, 2), ("panel64", run_panel64, args.wl_steps, 2)):
+            a2 = copy.copy(args)
+            a2.steps, a2.warmup, a2.workload = steps, warm, name
+            t0 = time.perf_counter()
+            line = fn(a2, rank, local_rank, world, dist)
+            if rank == 0:
+                line["wall_s_incl_setup"] = round(time.perf_counter() - t0, 1)
+                wl[name] = line
+        if rank == 0:
+            out["workloads"] = wl
+    if rank == 0:
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

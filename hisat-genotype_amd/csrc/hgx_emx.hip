@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "hgx_common.hpp"
@@ -40,7 +41,7 @@ constexpr int XB = 1024, XNW = XB / 64;
 constexpr int XA = HGX_EMX_MAX_ALLELES, XC = HGX_EMX_MAX_CLASSES;
 constexpr int XAW = XA / 64, XCW = XC / 64;
 
-enum { XS_ITER = 0, XS_STATUS = 1, XS_A1 = 2, XS_ORDERS = 3, XS_RES_OFF = 4, XS_RES_N = 5, XS_NCLS = 6, XS_N = 8 };
+enum { XS_ITER = 0, XS_STATUS = 1, XS_A1 = 2, XS_ORDERS = 3, XS_RES_OFF = 4, XS_RES_N = 5, XS_NCLS = 6, XS_APPS = 7, XS_N = 8 };
 
 typedef hgx_emx_rec EmxRes;                                  // one allele of a returned dict
 
@@ -377,7 +378,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     uint8_t *din[3] = {T.din, T.din + A1s, T.din + 2 * (size_t)A1s};
     double *tmpo0 = &S.tmpo[0][0], *tmpo1 = &S.tmpo[1][0];
     const int A1p8 = (A1 + 7) & ~7;
-    int n_orders = 0;
+    int n_orders = 0, n_apps = 0;                       // (applications of the EM map: what the byte model of a launch is counted in)
 
     // ---- helpers ---------------------------------------------------------------------------------------------------
     auto block_max_exact = [&](double v) -> double {
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     int ord_of[3] = {0, 0, 0};
     // Gene_prob_next (common:1311-1336): dict P -> dict N (N != P)
     auto next_prob = [&](int P, int N, int live_a, int live_b) {
+        n_apps += 1;
         if (tid == 0) S.need_slow = 0;
         phase_sync();                                      // dv[P] as written by this workgroup is what the scalar loads see
         // rows: alleles_prob of the classes of tile cw, alleles in key order.  A non-member's value is +0.0 in every dict
@@ -621,6 +623,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
         };
         // Gene_prob_next (common:1311-1336) from dict P into dict N, normalised
         auto next_fast = [&](int P, int N) {
+            n_apps += 1;
             double sacc[4] = {0.0, 0.0, 0.0, 0.0};         // rows: alleles_prob of class tid + 1024 k; 512 alleles per table
             for (int sl = 0; sl * 512 < A1; ++sl) {
                 __syncthreads();
@@ -853,6 +856,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
         T.scal[XS_A1] = (double)A1;
         T.scal[XS_ORDERS] = (double)n_orders;
         T.scal[XS_NCLS] = (double)C;
+        T.scal[XS_APPS] = (double)n_apps;
         T.scal[XS_RES_OFF] = (double)S.res_base;
         T.scal[XS_RES_N] = (double)res_n;
     }
@@ -862,7 +866,33 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
 
 inline size_t up64(size_t n) { return (n + 63) & ~(size_t)63; }
 
+// kernel timing for roofline reports (bench.py): HIP events around the k_emx launches of the calls made while it is on
+struct EmxStats { double ms = 0.0; long long launches = 0, apps = 0, bytes = 0, jobs = 0; };
+std::mutex g_emx_mu;
+bool g_emx_timing = false;
+EmxStats g_emx_stats[2];           // [0] reference order, [1] table lookups
+
 }   // namespace
+
+extern "C" int hgx_emx_set_timing(int on) {
+    std::lock_guard<std::mutex> g(g_emx_mu);
+    if (on && !g_emx_timing) { g_emx_stats[0] = EmxStats(); g_emx_stats[1] = EmxStats(); }
+    g_emx_timing = on != 0;
+    return HGX_OK;
+}
+// totals since timing was switched on, for the launches in the reference's order (fast = 0) or with table lookups (fast = 1):
+// kernel milliseconds, launches, jobs, applications of the EM map, and the algorithmic bytes of those applications
+// (per application C * A' / 8 + 16 A' + 16 C with A' = the distinct alleles of the job's classes)
+extern "C" int hgx_emx_get_timing(int fast, double *ms, long long *launches, long long *jobs, long long *apps, long long *bytes) {
+    std::lock_guard<std::mutex> g(g_emx_mu);
+    const EmxStats &s = g_emx_stats[fast ? 1 : 0];
+    if (ms) *ms = s.ms;
+    if (launches) *launches = s.launches;
+    if (jobs) *jobs = s.jobs;
+    if (apps) *apps = s.apps;
+    if (bytes) *bytes = s.bytes;
+    return HGX_OK;
+}
 
 int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs_out) {
     ARGCHK(jobs && n_jobs >= 0);
@@ -961,8 +991,20 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_e
     }
     bool any_fast = false, any_exact = false;
     for (const EmxTask &T : tasks) { any_fast = any_fast || T.fast; any_exact = any_exact || !T.fast; }
-    if (any_exact) hipLaunchKernelGGL(k_emx<false>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
-    if (any_fast) hipLaunchKernelGGL(k_emx<true>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
+    bool timing;
+    { std::lock_guard<std::mutex> g(g_emx_mu); timing = g_emx_timing; }
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (timing) for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    if (any_exact) {
+        if (timing) HIPCHK(hipEventRecord(ev[0], st));
+        hipLaunchKernelGGL(k_emx<false>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
+        if (timing) HIPCHK(hipEventRecord(ev[1], st));
+    }
+    if (any_fast) {
+        if (timing) HIPCHK(hipEventRecord(ev[2], st));
+        hipLaunchKernelGGL(k_emx<true>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
+        if (timing) HIPCHK(hipEventRecord(ev[3], st));
+    }
     HIPCHK(hipGetLastError());
     // one round trip brings the state words and the first records; a second one the rest of a long result
     const size_t first_recs = std::min<size_t>(res_cap, ((200u << 10) - head % (200u << 10)) / sizeof(EmxRes) + 0);
@@ -982,6 +1024,26 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_e
     }
     const EmxRes *recs = (const EmxRes *)(h.data() + head);
     if (recs_out) recs_out->assign(recs, recs + n_rec);
+    if (timing) {
+        std::lock_guard<std::mutex> g(g_emx_mu);
+        for (int f = 0; f < 2; ++f) {
+            if (!(f ? any_fast : any_exact)) continue;
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[2 * f], ev[2 * f + 1]);
+            g_emx_stats[f].ms += ms;
+            g_emx_stats[f].launches += 1;
+        }
+        for (int t = 0; t < n; ++t) {
+            const double *sc = (const double *)(h.data() + 64 + (size_t)t * XS_N * 8);
+            if ((int)sc[XS_STATUS] == 1) continue;
+            EmxStats &s = g_emx_stats[tasks[t].fast ? 1 : 0];
+            const long long C = (long long)sc[XS_NCLS], A1 = (long long)sc[XS_A1], apps = (long long)sc[XS_APPS];
+            s.jobs += 1;
+            s.apps += apps;
+            s.bytes += apps * (C * A1 / 8 + 16 * A1 + 16 * C);
+        }
+        for (auto &e : ev) (void)hipEventDestroy(e);
+    }
     for (int t = 0; t < n; ++t) {
         hgx_emx_job &J = jobs[job_of[t]];
         const double *sc = (const double *)(h.data() + 64 + (size_t)t * XS_N * 8);

@@ -52,6 +52,17 @@ class DeviceBatch:
             pass
 
 
+def emx_set_timing(on):
+    capi.check(capi.lib().hgx_emx_set_timing(C.c_int(1 if on else 0)))
+
+
+def emx_get_timing(fast):
+    """(kernel ms, launches, jobs, applications of the EM map, algorithmic bytes) of the k_emx launches timed so far."""
+    ms, nl, nj, na, nb = C.c_double(0), C.c_longlong(0), C.c_longlong(0), C.c_longlong(0), C.c_longlong(0)
+    capi.check(capi.lib().hgx_emx_get_timing(C.c_int(1 if fast else 0), C.byref(ms), C.byref(nl), C.byref(nj), C.byref(na), C.byref(nb)))
+    return ms.value, nl.value, nj.value, na.value, nb.value
+
+
 def em_set_fast(on):
     """Arithmetic of Classes.em / em_ordered on this thread for problems the one-workgroup kernel takes: False = the reference's own
     order of operations (default, bit-identical), True = table lookups (~5x faster, within rounding).  Returns the old setting."""

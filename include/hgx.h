@@ -460,6 +460,11 @@ int hgx_em_set_backend(int backend);
  * B[c][a] x[c]) with backend 1 or 2; x and y are host arrays of a_pad / n_classes doubles                        */
 int hgx_debug_matvec(const hgx_classes *c, int which, int backend, const double *x_host, double *y_host);
 int hgx_em_set_timing(int on);
+/* the one-workgroup EM kernel (k_emx: hgx_em / hgx_type_* on problems of up to 4096 classes, every EM of hgx_type_many): HIP
+ * events around its launches while timing is on; totals per arithmetic (fast = 0: the reference's order, 1: table lookups):
+ * kernel ms, launches, jobs, applications of the EM map, algorithmic bytes (per application C * A' / 8 + 16 A' + 16 C). */
+int hgx_emx_set_timing(int on);
+int hgx_emx_get_timing(int fast, double *ms_total, long long *launches, long long *jobs, long long *applications, long long *bytes_total);
 int hgx_em_get_timing(int slot, double *ms_total, int64_t *launches, int64_t *executed, int64_t *bytes_total);
 
 #ifdef __cplusplus
