@@ -188,6 +188,38 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
         L.hgx_typing_destroy(h)
 
 
+def type_file(pl, alignment_fname, regions=None, num_editdist=2, error_correction=True, allow_discordant=False,
+              remove_low_abundance_alleles=True, simulation=False, base_locus=0, stream=None, em_fast=False):
+    """Alignment file (SAM text or BAM, any order) -> typing result in ONE call into libhgx (hgx_type_file): read / inflate /
+    decode, region filter, name grouping, front-end, upload, device path, result -- the whole per-locus work of typing()
+    (typing_core.py:436-468 + 800-1789).  `regions`: samtools region strings (list or newline-separated); None = the locus'
+    backbone, as the reference's `samtools view F ref_allele` (core:443-444)."""
+    if regions is None:
+        regions = [pl.ref_allele]
+    if not isinstance(regions, (str, bytes)):
+        regions = "\n".join(regions)
+    reg = regions.encode() if isinstance(regions, str) else regions
+    po = capi.ParseOpts(int(num_editdist), int(bool(error_correction)), int(bool(allow_discordant)), int(bool(simulation)), int(base_locus),
+                        0, int(pl.base_fname == "codis" and pl.gene == "D18S51"), 0)
+    to = TypeOpts(int(bool(remove_low_abundance_alleles)), 0, -1, 0, None, None, None, None, None, int(bool(em_fast)))
+    h = C.c_void_p()
+    L = capi.lib()
+    rc = L.hgx_type_file(C.byref(h), pl.h, pl.index(), alignment_fname.encode(), reg or None, C.byref(po), C.byref(to), stream)
+    if rc == -7:
+        raise TypeError(L.hgx_last_error().decode(errors="replace"))
+    capi.check(rc)
+    try:
+        res = LocusResult()
+        nr, npair, npc, nrf = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        capi.check(L.hgx_typing_dims(h, C.byref(nr), C.byref(npair), C.byref(npc), C.byref(nrf), None, None, None, None))
+        res.num_reads, res.num_pairs, res.n_pieces, res.n_refs = nr.value, npair.value, npc.value, nrf.value
+        if res.num_reads > 0:
+            _result_from_handle(h, pl, res, False)
+        return res
+    finally:
+        L.hgx_typing_destroy(h)
+
+
 def type_many(pl, many, remove_low=True, stream=None, return_errors=False, em_fast=False):
     """Every task of a merged batch (engine.ManyBatch: many samples of ONE locus) in one call into libhgx (hgx_type_many): one
     launch chain for all tasks instead of one per task -- the many-samples form of the per-locus body of typing()

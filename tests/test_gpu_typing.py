@@ -559,3 +559,99 @@ def test_index_broadcast_writes_into_index_memory(tmp_path):
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "broadcast ok" in out.stdout
+
+
+@pytest.mark.parametrize("name", gu.ALL)
+def test_type_file_sam_bam_sorted_bam_with_regions(name, tmp_path):
+    """hgx_type_file -- the entry bench.py's file -> result leg times -- on every fixture, from (a) the SAM text as the aligner
+    writes it, (b) a BAM of the same records, (c) a coordinate-sorted BAM that also holds reads of ANOTHER reference sequence,
+    with the locus' backbone as the region (what the reference's `samtools view F ref_allele | sort -k1,1 -s` sees): the
+    reference's report lines in all three cases (VERDICT r2 #10)."""
+    from hisatgenotype_amd import bamio
+    fx = gu.load(name)
+    if fx.get("error"):
+        pytest.skip("the reference raises on this fixture")
+    o = fx["options"]
+    loc = fx["_locus"]
+    pl = hl.PackedLocus.from_synth(loc)
+    lines = [l for l in fx["sam"].split("\n") if l]
+    sam = tmp_path / "reads.sam"
+    sam.write_text("@HD\tVN:1.0\tSO:unsorted\n" + "\n".join(lines) + "\n")
+    bam = tmp_path / "reads.bam"
+    refs = [(loc.ref_allele, len(loc.backbone)), ("other*BACKBONE", 5000)]
+    bamio.write_bam_native(str(bam), "\n".join(lines) + "\n", refs)
+    # decoys on the other sequence (same read names as real reads, so a reader that ignored the region would pair them up)
+    decoys = []
+    for l in lines[:40]:
+        c = l.split("\t")
+        c[2] = "other*BACKBONE"
+        decoys.append("\t".join(c))
+    sbam = tmp_path / "sorted.bam"
+    bamio.write_bam_native(str(sbam), "\n".join(lines + decoys) + "\n", refs, sort_by_coordinate=True)
+    kw = dict(num_editdist=o["num_editdist"], error_correction=o["error_correction"], allow_discordant=o["allow_discordant"],
+              remove_low_abundance_alleles=o["remove_low"], simulation=o["simulation"])
+    keep = lambda ls: [l for l in ls if "aligned" in l or "ranked" in l or "(count:" in l]
+    want = keep(fx["report"].split("\n"))
+    ref = hgx.type_locus(pl, fx["sam"], **kw)
+    for path in (sam, bam, sbam):
+        res = hgx.type_file(pl, str(path), **kw)
+        assert res.num_reads == ref.num_reads and res.num_pairs == ref.num_pairs, path.name
+        assert res.gene_prob == ref.gene_prob and res.em == ref.em and res.counts_sorted == ref.counts_sorted, path.name
+        got, _ = hgx.report_lines(res, o["simulation"], o["sample"] if o["simulation"] else (), True)
+        assert keep(got) == want, path.name
+
+
+def _type_sharded(pl, sam, world):
+    """One sample's pairs of a locus split over `world` threads-as-ranks on one GPU (dist.LocalComm); returns rank 0's result."""
+    import threading
+    from hisatgenotype_amd import capi, dist as hdist
+    pl.index()
+    shards = hdist.split_name_grouped(sam, world)
+    comms = hdist.LocalComm.make(world)
+    out, errs = [None] * world, []
+
+    def run(r):
+        try:
+            capi.set_device(capi.current_device())
+            out[r] = hdist.type_locus_sharded(pl, shards[r], comms[r], stream=capi.get_stream(2))
+        except BaseException as e:
+            errs.append(e)
+            comms[r].sh.barrier.abort()
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for r in out[1:]:
+        assert r.gene_prob == out[0].gene_prob and r.counts_sorted == out[0].counts_sorted
+    return out[0]
+
+
+def test_class1_at_stated_size_properties_and_sharding():
+    """BASELINE configs[2] at its stated size -- HLA class I A / B / C with 7 000 / 8 000 / 7 000 alleles, 500 k pairs (1 M reads)
+    each: size-independent properties per locus (both true alleles on top, pairs conserved, abundances sum to one, a second run
+    identical) and, for the largest locus, the sharded form (two threads as ranks, pileup exchange + class-table merge) equal to
+    the unsharded one (VERDICT r2 #7)."""
+    from hisatgenotype_amd import dist as hdist
+    cfg = [("A", 7000, 3569, 2500, 101), ("B", 8000, 4081, 2800, 102), ("C", 7000, 4305, 2600, 103)]
+    n_pairs = 500000
+    for i, (g, a, ln, v, sd) in enumerate(cfg):
+        loc = synth.make_hla_like_locus(gene=g, n_alleles=a, length=ln, n_vars=v, seed=sd, var_id_base=100000 * i)
+        pl = hl.PackedLocus.from_synth(loc)
+        sample = synth.pick_sample(loc, 101 + i)
+        sam = synth.simulate_sam_fast(loc, sample, n_pairs, err_rate=0.002, seed=100 + i)
+        res = hgx.type_locus(pl, sam)
+        assert 0.99 * n_pairs <= res.num_pairs <= n_pairs and res.num_reads > 1.9 * n_pairs
+        assert sorted(x for x, _ in res.gene_prob[:2]) == sorted(sample)
+        assert abs(sum(p for _, p in res.gene_prob) - 1.0) < 1e-9
+        assert res.counts_sorted[0][1] <= res.num_pairs
+        again = hgx.type_locus(pl, sam)
+        assert again.gene_prob == res.gene_prob and again.em == res.em
+        if g == "B":
+            sharded = _type_sharded(pl, sam, 2)
+            assert sharded.num_reads == res.num_reads and sharded.num_pairs == res.num_pairs
+            assert sharded.counts_sorted == res.counts_sorted
+            assert [a for a, _ in sharded.gene_prob] == [a for a, _ in res.gene_prob]
+            assert max(abs(p - q) for (_, p), (_, q) in zip(sharded.gene_prob, res.gene_prob)) <= 1e-9
+        del sam
