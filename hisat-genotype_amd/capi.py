@@ -43,10 +43,12 @@ class ParseOpts(C.Structure):
     _fields_ = [("num_editdist", C.c_int32), ("error_correction", C.c_int32), ("allow_discordant", C.c_int32),
                 ("simulation", C.c_int32), ("base_locus", C.c_int32), ("keep_trace", C.c_int32),
                 ("codis_choose_pairs", C.c_int32), ("n_threads", C.c_int32),
-                ("pileup_exchange", C.c_void_p), ("pileup_ctx", C.c_void_p)]
+                ("pileup_exchange", C.c_void_p), ("pileup_ctx", C.c_void_p),
+                ("interdist_exchange", C.c_void_p), ("interdist_ctx", C.c_void_p)]
 
 
 PILEUP_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_int64)
+INTERDIST_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64)
 
 
 # every symbol include/hgx.h declares (checked by tests/test_capi_symbols.py)
@@ -65,6 +67,7 @@ SYMBOLS = [
     "hgx_type_batch", "hgx_type_file", "hgx_typing_destroy", "hgx_typing_dims", "hgx_typing_counts", "hgx_typing_em",
     "hgx_typing_gene_prob", "hgx_typing_classes", "hgx_write_bam", "hgx_em_last_exact", "hgx_index_device_block", "hgx_index_create_device", "hgx_type_classes", "hgx_pair_classes_dedup",
     "hgx_many_create", "hgx_many_destroy", "hgx_many_dims", "hgx_type_many", "hgx_type_many_loci", "hgx_em_set_fast", "hgx_typing_top", "hgx_emx_set_timing", "hgx_emx_get_timing",
+    "hgx_index_broadcast", "hgx_allreduce_sum_u32", "hgx_allreduce_sum_i64", "hgx_classes_allgather",
 ]
 
 _lib = None

@@ -1,0 +1,135 @@
+// hgx_rccl.hip -- 8e: the three exchanges of a sharded locus and the index broadcast as C-ABI entry points on DEVICE buffers,
+// for callers that hold an RCCL communicator (ncclComm_t).  SURVEY.md 8(b) lists hgx_index_broadcast(handle, root, rccl_comm);
+// the reference has no such layer (its concurrency is one process per sample, /root/reference/hisatgenotype:613-665).
+// librccl is loaded on first use (dlopen): libhgx itself does not link against it.
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "hgx_common.hpp"
+
+namespace {
+
+typedef int ncclResult_t;
+typedef void *ncclComm_t;
+enum { NCCL_UINT8 = 1, NCCL_INT32 = 2, NCCL_UINT32 = 3, NCCL_INT64 = 4, NCCL_SUM = 0 };   // rccl.h: ncclDataType_t / ncclRedOp_t
+
+struct Rccl {
+    void *lib = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+int rccl_load() {
+    std::call_once(g_rccl_once, [] {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (g_rccl.lib) break;
+        }
+        if (!g_rccl.lib) return;
+        auto sym = [&](const char *n) { return dlsym(g_rccl.lib, n); };
+        g_rccl.Broadcast = (decltype(g_rccl.Broadcast))sym("ncclBroadcast");
+        g_rccl.AllReduce = (decltype(g_rccl.AllReduce))sym("ncclAllReduce");
+        g_rccl.AllGather = (decltype(g_rccl.AllGather))sym("ncclAllGather");
+        g_rccl.CommCount = (decltype(g_rccl.CommCount))sym("ncclCommCount");
+        g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))sym("ncclCommUserRank");
+        g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
+        g_rccl.ok = g_rccl.Broadcast && g_rccl.AllReduce && g_rccl.AllGather && g_rccl.CommCount && g_rccl.CommUserRank;
+    });
+    if (!g_rccl.ok) { hgx_set_error("librccl could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing"); return HGX_EHIP; }
+    return HGX_OK;
+}
+#define RCCLCHK(expr)                                                                                                   \
+    do {                                                                                                                \
+        const ncclResult_t r_ = (expr);                                                                                 \
+        if (r_ != 0) {                                                                                                  \
+            hgx_set_error("%s failed: %s", #expr, g_rccl.GetErrorString ? g_rccl.GetErrorString(r_) : "rccl error");     \
+            return HGX_EHIP;                                                                                            \
+        }                                                                                                               \
+    } while (0)
+
+}   // namespace
+
+extern "C" int hgx_index_device_block(const hgx_index *ix, void **dev_block, size_t *bytes);
+
+extern "C" int hgx_index_broadcast(hgx_index *ix, int32_t root, void *comm, void *stream) {
+    ARGCHK(ix && comm && root >= 0);
+    { int rc_ = rccl_load(); if (rc_) return rc_; }
+    void *block = nullptr;
+    size_t bytes = 0;
+    { int rc_ = hgx_index_device_block(ix, &block, &bytes); if (rc_) return rc_; }
+    RCCLCHK(g_rccl.Broadcast(block, block, bytes, NCCL_UINT8, root, (ncclComm_t)comm, (hipStream_t)stream));
+    return HGX_OK;
+}
+
+extern "C" int hgx_allreduce_sum_u32(uint32_t *buf, size_t n, void *comm, void *stream) {
+    ARGCHK(buf && comm);
+    { int rc_ = rccl_load(); if (rc_) return rc_; }
+    RCCLCHK(g_rccl.AllReduce(buf, buf, n, NCCL_UINT32, NCCL_SUM, (ncclComm_t)comm, (hipStream_t)stream));
+    return HGX_OK;
+}
+extern "C" int hgx_allreduce_sum_i64(int64_t *buf, size_t n, void *comm, void *stream) {
+    ARGCHK(buf && comm);
+    { int rc_ = rccl_load(); if (rc_) return rc_; }
+    RCCLCHK(g_rccl.AllReduce(buf, buf, n, NCCL_INT64, NCCL_SUM, (ncclComm_t)comm, (hipStream_t)stream));
+    return HGX_OK;
+}
+
+// rows [bits | count] of every rank, padded to the largest table, gathered; then unpacked in rank order and merged
+extern "C" int hgx_classes_allgather(hgx_classes **out, const hgx_classes *mine, int32_t a_pad, void *comm, void *stream) {
+    ARGCHK(out && comm && a_pad > 0 && a_pad % 512 == 0 && (!mine || mine->a_pad == a_pad));
+    *out = nullptr;
+    { int rc_ = rccl_load(); if (rc_) return rc_; }
+    hipStream_t st = (hipStream_t)stream;
+    int world = 0, rank = 0;
+    RCCLCHK(g_rccl.CommCount((ncclComm_t)comm, &world));
+    RCCLCHK(g_rccl.CommUserRank((ncclComm_t)comm, &rank));
+    const int w64 = a_pad / 64;
+    const int32_t my_c = mine ? mine->n_classes : 0;
+    if (mine) hgx_classes_order_after(mine, st);
+    DevBuf b_sizes;
+    ALLOC(b_sizes, (size_t)(world + 1) * 4);
+    int32_t *d_sizes = b_sizes.as<int32_t>();
+    { int rc_ = hgx_h2d(d_sizes + world, &my_c, 4, st); if (rc_) return rc_; }
+    RCCLCHK(g_rccl.AllGather(d_sizes + world, d_sizes, 1, NCCL_INT32, (ncclComm_t)comm, st));
+    std::vector<int32_t> sizes((size_t)world);
+    { int rc_ = hgx_d2h(sizes.data(), d_sizes, (size_t)world * 4, st); if (rc_) return rc_; }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+    int64_t total = 0;
+    int32_t cap = 1;
+    for (int32_t c : sizes) { total += c; cap = std::max(cap, c); }
+    const size_t pitch = (size_t)(w64 + 1) * 8;
+    DevBuf b_send, b_recv, b_rows, b_w;
+    ALLOC(b_send, (size_t)cap * pitch);
+    ALLOC(b_recv, (size_t)world * cap * pitch);
+    HIPCHK(hipMemsetAsync(b_send.p, 0, (size_t)cap * pitch, st));
+    if (my_c > 0) {
+        HIPCHK(hipMemcpy2DAsync(b_send.p, pitch, mine->d_bits, (size_t)w64 * 8, (size_t)w64 * 8, (size_t)my_c, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpy2DAsync((char *)b_send.p + (size_t)w64 * 8, pitch, mine->d_count, 8, 8, (size_t)my_c, hipMemcpyDeviceToDevice, st));
+    }
+    RCCLCHK(g_rccl.AllGather(b_send.p, b_recv.p, (size_t)cap * (w64 + 1), NCCL_INT64, (ncclComm_t)comm, st));
+    ALLOC(b_rows, (size_t)std::max<int64_t>(total, 1) * w64 * 8);
+    ALLOC(b_w, (size_t)std::max<int64_t>(total, 1) * 8);
+    int64_t at = 0;
+    for (int r = 0; r < world; ++r) {
+        if (sizes[r] <= 0) continue;
+        const char *src = (const char *)b_recv.p + (size_t)r * cap * pitch;
+        HIPCHK(hipMemcpy2DAsync((char *)b_rows.p + (size_t)at * w64 * 8, (size_t)w64 * 8, src, pitch, (size_t)w64 * 8, (size_t)sizes[r],
+                                hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpy2DAsync((char *)b_w.p + (size_t)at * 8, 8, src + (size_t)w64 * 8, pitch, 8, (size_t)sizes[r], hipMemcpyDeviceToDevice, st));
+        at += sizes[r];
+    }
+    int rc = hgx_dedup_classes(out, b_rows.as<uint64_t>(), nullptr, b_w.as<int64_t>(), total, a_pad, nullptr, stream);
+    if (rc) return rc;
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }          // (the row / weight buffers are read by kernels the dedup queued)
+    return HGX_OK;
+}

@@ -1530,7 +1530,7 @@ void emit_chunk(const hgx_parse_opts &o, const Fields *recs, const uint8_t *ok, 
 }
 
 // get_pair_interdist (common:1187-1265): median inner distance of unique concordant pairs (CODIS D18S51 only)
-long pair_interdist(const Fields *recs, const uint8_t *ok, size_t n_recs, bool simulation) {
+long pair_interdist(const Fields *recs, const uint8_t *ok, size_t n_recs, bool simulation, const hgx_parse_opts *opts = nullptr) {
     std::vector<long> dists;
     std::string prev;
     bool hp = false;
@@ -1557,6 +1557,29 @@ long pair_interdist(const Fields *recs, const uint8_t *ok, size_t n_recs, bool s
         rd.push_back({(long)f.pos, right - 1});
         prev = id;
         hp = true;
+    }
+    if (opts && opts->interdist_exchange) {
+        // reads of the sample on several ranks: the median of ALL distances from the summed histogram (element int(len / 2) of the
+        // sorted list, common:1258-1262)
+        std::vector<int64_t> hist((size_t)HGX_INTERDIST_BINS, 0);
+        for (long d : dists) {
+            const long b = d < -(long)HGX_INTERDIST_HALF ? 0 : (d > (long)HGX_INTERDIST_HALF - 1 ? HGX_INTERDIST_BINS - 1 : 1 + d + HGX_INTERDIST_HALF);
+            hist[(size_t)b] += 1;
+        }
+        if (opts->interdist_exchange(opts->interdist_ctx, hist.data(), (int64_t)hist.size()) != 0)
+            throw std::runtime_error("inter-distance exchange between the ranks of a sharded locus failed");
+        int64_t total = 0;
+        for (int64_t c : hist) total += c;
+        if (total == 0) return -1;
+        int64_t k = total / 2, seen = 0;
+        for (size_t b = 0; b < hist.size(); ++b) {
+            seen += hist[b];
+            if (seen > k) {
+                if (b == 0 || b + 1 == hist.size()) throw std::runtime_error("median pair distance outside the exchanged histogram's range");
+                return (long)b - 1 - (long)HGX_INTERDIST_HALF;
+            }
+        }
+        return -1;
     }
     std::sort(dists.begin(), dists.end());
     return dists.empty() ? -1 : dists[dists.size() / 2];
@@ -1844,7 +1867,8 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
             B->nt_set[i] = (uint8_t)m;
         }
         lap("pileup");
-        const long expected = opts->codis_choose_pairs ? pair_interdist(recs, ok, n, opts->simulation != 0) : -1;
+        // (a shard that does not hold the stream's last pair skips choose_pairs but still takes part in the exchange)
+        const long expected = (opts->codis_choose_pairs || opts->interdist_exchange) ? pair_interdist(recs, ok, n, opts->simulation != 0, opts) : -1;
         // pass 2a: every distinct key once
         std::vector<MateOut> outs(reps.size());
         const int n_dec = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, reps.size() / 256 + 1));

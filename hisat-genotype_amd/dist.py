@@ -115,6 +115,9 @@ def split_name_grouped(sam_text, k, simulation=False):
     `simulation`: the read id is the QNAME up to its first '|' (typing_core.py:808)."""
     data = sam_text.encode() if isinstance(sam_text, str) else bytes(sam_text)
     n = len(data)
+    # The shards are typed in rank order and their class tables concatenated in rank order: that reproduces the unsharded
+    # first-seen order for ANY name-grouped stream (sorted or not), because every shard keeps its records in stream order
+    # (the front-end does not re-sort a grouped stream: hgx_sam.cpp recognises it and leaves it alone).
 
     def read_id(ls):
         name = data[ls:data.find(b"\t", ls)]
@@ -186,6 +189,90 @@ class TorchComm:
         return out
 
 
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+class RcclComm:
+    """An RCCL communicator held by this library's caller (ncclCommInitRank through ctypes) and the exchanges of a sharded locus
+    on DEVICE buffers through the C-ABI (hgx_allreduce_sum_*, hgx_classes_allgather, hgx_index_broadcast): no
+    `.cpu().numpy()` per step.  The 128-byte unique id of rank 0 reaches the other ranks through `share` -- e.g.
+    torch.distributed.broadcast_object_list (any backend), a file, MPI."""
+
+    _lib = None
+
+    @classmethod
+    def rccl(cls):
+        if cls._lib is None:
+            for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
+                try:
+                    cls._lib = C.CDLL(name, mode=C.RTLD_GLOBAL)
+                    break
+                except OSError:
+                    continue
+            if cls._lib is None:
+                raise ImportError("librccl.so not found")
+        return cls._lib
+
+    def __init__(self, rank, world, share):
+        """`share(obj)`: returns rank 0's `obj` on every rank (identity for world 1)."""
+        import os
+        # ranks of ONE node: the bootstrap sockets go over the loopback interface (a container's hostname may not resolve);
+        # a multi-node caller sets NCCL_SOCKET_IFNAME itself
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        R = self.rccl()
+        uid = _NcclUniqueId()
+        if rank == 0:
+            rc = R.ncclGetUniqueId(C.byref(uid))
+            if rc:
+                raise RuntimeError("ncclGetUniqueId failed: %d" % rc)
+        if world > 1:                                   # (string_at: a c_char array read as bytes would stop at the first NUL)
+            raw = share(C.string_at(C.byref(uid), 128))
+            assert len(raw) == 128
+            C.memmove(C.byref(uid), raw, 128)
+        self.h = C.c_void_p()
+        R.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+        rc = R.ncclCommInitRank(C.byref(self.h), C.c_int(world), uid, C.c_int(rank))
+        if rc:
+            raise RuntimeError("ncclCommInitRank failed: %d" % rc)
+        self.rank, self.world, self.on_gpu = rank, world, True
+
+    @classmethod
+    def from_torch(cls, group=None):
+        """One communicator per rank of a torch.distributed group (the id travels with broadcast_object_list)."""
+        import torch.distributed as dist
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+
+        def share(obj):
+            box = [obj]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            return box[0]
+        return cls(rank, world, share)
+
+    def close(self):
+        if self.h:
+            self.rccl().ncclCommDestroy(self.h)
+            self.h = None
+
+    def broadcast_index(self, pl, src=0, stream=None):
+        capi.check(capi.lib().hgx_index_broadcast(pl.index(), C.c_int32(src), self.h, stream))
+        capi.sync(stream)
+
+    def allreduce_sum(self, arr, stream=None):
+        """In-place element-wise sum of an integer numpy array over the ranks (the front-end's pileup / histogram live on the host)."""
+        d = capi.DevArray.from_host(np.ascontiguousarray(arr.astype(np.int64)).ravel(), stream)
+        capi.check(capi.lib().hgx_allreduce_sum_i64(capi.ptr(d), C.c_size_t(arr.size), self.h, stream))
+        arr[...] = d.to_host(stream).reshape(arr.shape).astype(arr.dtype)
+        return arr
+
+    def merge_classes(self, cl, a_pad, stream=None):
+        """This rank's class set of one level (or None) -> the merged class set of the whole sample, on every rank."""
+        from . import engine
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_classes_allgather(C.byref(h), cl.h if cl is not None else None, C.c_int32(a_pad), self.h, stream))
+        return engine.Classes(h)
+
+
 class LocalComm:
     """`world` shards of one locus typed by `world` threads of ONE process (tests, and a single GPU standing in for several):
     the same three exchanges through a barrier."""
@@ -252,6 +339,11 @@ def type_shard(pl, batch, db, comm, remove_low_abundance_alleles=True, stream=No
         levels = [(name, None) for name in (("exon", "gene") if hla else ("gene",))]
     merged = {}
     for name, cl in levels:
+        if hasattr(comm, "merge_classes"):                  # device to device over RCCL (hgx_classes_allgather)
+            merged[name] = comm.merge_classes(cl, pl.a_pad, stream)
+            if cl is not None:
+                cl.close()
+            continue
         if cl is None:
             bits, cnt = np.zeros((0, pl.w64), np.uint64), np.zeros(0, np.int64)
         else:
@@ -291,13 +383,53 @@ def type_locus_sharded(pl, sam_shard, comm, num_editdist=2, error_correction=Tru
       3. read / pair counts, summed.
     Every rank then runs the (small) EMs on the merged tables and returns the same LocusResult as the unsharded path."""
     from . import engine
-    if pl.base_fname == "codis" and pl.gene == "D18S51":
-        raise NotImplementedError("choose_pairs of D18S51 needs the median pair distance of the whole sample")
-    batch = pl.parse_sam(sam_shard, num_editdist=num_editdist, error_correction=error_correction,
-                         allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus,
-                         pileup_exchange=comm.allreduce_sum)
+    # A rank whose front-end fails must not leave its peers waiting in an exchange.  Every exchange of the parse carries one
+    # extra element, the failure flag (sum > 0 = some rank failed: every rank raises out of that exchange and skips the later
+    # ones); a rank that fails LOCALLY before an exchange its peers will enter contributes the flag to that one exchange; and
+    # after the parse -- whatever happened -- every rank takes part in one status exchange, so that a failure behind the last
+    # exchange of the parse reaches the peers before they enter the class-table gather.
+    state = {"local": None, "remote": False, "n": 0}
+
+    def exchange(arr):
+        state["n"] += 1
+        ext = np.zeros(arr.size + 1, np.int64)
+        ext[:arr.size] = arr.astype(np.int64).ravel()
+        comm.allreduce_sum(ext)
+        if ext[-1] != 0:
+            state["remote"] = True
+            raise RuntimeError("another rank of this locus failed in its front-end")
+        arr[...] = ext[:arr.size].reshape(arr.shape).astype(arr.dtype)
+        return arr
+    d18 = pl.base_fname == "codis" and pl.gene == "D18S51"
+    n_exchanges = 2 if d18 else 1
+    batch = None
+    try:
+        batch = pl.parse_sam(sam_shard, num_editdist=num_editdist, error_correction=error_correction,
+                             allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus,
+                             pileup_exchange=exchange, interdist_exchange=exchange if d18 else None,
+                             last_shard=comm.rank == comm.world - 1)
+    except BaseException as e:
+        state["local"] = e
+        if not state["remote"] and state["n"] < n_exchanges:      # the peers are in (or heading for) the next exchange: flag it
+            state["n"] += 1
+            comm.allreduce_sum(_flag_only(pl, state["n"]))
+    status = np.array([0 if state["local"] is None else 1], np.int64)
+    comm.allreduce_sum(status)
+    if state["local"] is not None:
+        raise state["local"]
+    if status[0] != 0:
+        raise RuntimeError("another rank of this locus failed in its front-end")
     db = engine.DeviceBatch(batch, stream)
     return type_shard(pl, batch, db, comm, remove_low_abundance_alleles, stream)
+
+
+def _flag_only(pl, k):
+    """The array a FAILED rank contributes to the k-th exchange of a sharded parse: zeros of the shape its peers send, with the
+    failure flag set (exchange 1 = pileup counts [L][6], exchange 2 = the D18S51 inter-distance histogram)."""
+    n = len(pl.ref_seq) * 6 if k == 1 else 2 * 65536 + 2
+    ext = np.zeros(n + 1, np.int64)
+    ext[-1] = 1
+    return ext
 
 
 def assign_ranks_to_loci(weights, world):

@@ -257,13 +257,15 @@ class PackedLocus:
         return Batch(h)
 
     def parse_sam(self, sam_text, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False,
-                  base_locus=0, keep_trace=False, n_threads=0, pileup_exchange=None):
+                  base_locus=0, keep_trace=False, n_threads=0, pileup_exchange=None, interdist_exchange=None, last_shard=True):
         """`pileup_exchange(counts)`: intra-locus read sharding (dist.type_locus_sharded) -- called once with this shard's
         pileup counts (numpy uint32 [L*6], a view of the front-end's table) and must turn them into the sum over all shards
-        in place (an all-reduce)."""
+        in place (an all-reduce).  `interdist_exchange(hist)`: the same for the inter-distance histogram of a sharded CODIS
+        D18S51 sample (int64 [HGX_INTERDIST_BINS]); `last_shard`: this shard ends with the stream's last pair -- the only one
+        choose_pairs is applied to (typing_core.py:1547-1552)."""
         data = sam_text if isinstance(sam_text, (bytes, bytearray)) else sam_text.encode()
         o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus,
-                           int(keep_trace), int(self.base_fname == "codis" and self.gene == "D18S51"), int(n_threads))
+                           int(keep_trace), int(self.base_fname == "codis" and self.gene == "D18S51" and last_shard), int(n_threads))
         cb, failure = None, []
         if pileup_exchange is not None:
             def _cb(_ctx, ptr, n):
@@ -275,6 +277,17 @@ class PackedLocus:
                     return 1
             cb = capi.PILEUP_EXCHANGE(_cb)
             o.pileup_exchange = C.cast(cb, C.c_void_p)
+        cb2 = None
+        if interdist_exchange is not None:
+            def _cb2(_ctx, ptr, n):
+                try:
+                    interdist_exchange(np.ctypeslib.as_array(ptr, shape=(n,)))
+                    return 0
+                except BaseException as e:
+                    failure.append(e)
+                    return 1
+            cb2 = capi.INTERDIST_EXCHANGE(_cb2)
+            o.interdist_exchange = C.cast(cb2, C.c_void_p)
         h = C.c_void_p()
         rc = capi.lib().hgx_parse_sam(C.byref(h), self.h, data, C.c_size_t(len(data)), C.byref(o))
         if failure:

@@ -100,6 +100,21 @@ int hgx_index_device_bits(const hgx_index *ix, void **dev_bits, size_t *bytes);
 int hgx_index_device_block(const hgx_index *ix, void **dev_block, size_t *bytes);
 int hgx_index_create_device(hgx_index **out, int32_t n_alleles, int32_t n_vars);
 
+/* ---- 8e: collectives on device buffers, for callers that hold an RCCL communicator -----------------------------------
+ * `rccl_comm` is an ncclComm_t (librccl is loaded on first use: the library itself does not link against it); everything
+ * runs on `stream`, nothing bounces through the host but a rank-count-sized table of sizes.
+ *   hgx_index_broadcast   the index' device block [link bits | exon mask | gene mask] from rank `root` to every rank, in place
+ *                         (receivers: an index of the same shape from hgx_index_create_device)
+ *   hgx_allreduce_sum_*   element-wise sum of a device buffer over the ranks, in place (pileup counts: u32; totals / inter-
+ *                         distance histogram: i64)
+ *   hgx_classes_allgather the ranks' class tables of ONE level (mine may be NULL = no classes on this rank) gathered in rank
+ *                         order -- which is stream order of their pairs, so first-seen order survives -- and merged
+ *                         (hgx_dedup_classes with the counts as weights): every rank gets the class set of the whole sample */
+int hgx_index_broadcast(hgx_index *ix, int32_t root, void *rccl_comm, void *stream);
+int hgx_allreduce_sum_u32(uint32_t *dev_buf, size_t n, void *rccl_comm, void *stream);
+int hgx_allreduce_sum_i64(int64_t *dev_buf, size_t n, void *rccl_comm, void *stream);
+/* (hgx_classes_allgather is declared with the class-set functions below) */
+
 /* ---- 8a-5 / 8a-6: read-pair x allele compatibility -> class bitsets --------------------
  * Replaces add_count (typing_core.py:626-677) + add_stat (core:1171-1236) for a batch of
  * pairs.  A *piece* is the argument of one add_count call with the haplotype string
@@ -169,6 +184,8 @@ int hgx_classes_device(const hgx_classes *c, void **bits_dev, void **count_dev /
 int hgx_classes_to_host(const hgx_classes *c, uint64_t *bits_host, int64_t *count_host, int64_t *first_row_host);
 int hgx_classes_from_host(hgx_classes **out, const uint64_t *bits_host, const int64_t *count_host,
                           int32_t n_classes, int32_t a_pad);
+/* 8e (see the collectives next to hgx_index_broadcast): every rank's class table of one level, gathered in rank order and merged */
+int hgx_classes_allgather(hgx_classes **out, const hgx_classes *mine_or_null, int32_t a_pad, void *rccl_comm, void *stream);
 
 /* 8a-5/6 stage 2 and 8a-7 in one call for ONE level (0 = exon, 1 = gene): the classes of all pairs in first-seen order with
  * their pair counts and first pairs -- the same result as hgx_pair_classes + hgx_dedup_classes on that level's rows
@@ -324,7 +341,16 @@ typedef struct hgx_parse_opts {
      * SUM over all shards in place (an all-reduce; dist.py does it with torch.distributed); non-zero return = failure.      */
     int (*pileup_exchange)(void *ctx, uint32_t *counts, int64_t n_cells);
     void *pileup_ctx;
+    /* The same for CODIS D18S51 (codis_choose_pairs): choose_pairs needs the MEDIAN inner distance of the whole sample's unique
+     * concordant pairs (get_pair_interdist, typing_common.py:1187-1265).  If set, the callback is invoked once with this
+     * shard's histogram of the distances -- HGX_INTERDIST_BINS int64 counters: bin 0 = below -HGX_INTERDIST_HALF, bin 1 + d +
+     * HGX_INTERDIST_HALF = distance d, the last bin = above -- and must return with the element-wise sum over all shards in
+     * place; the median is then read from the summed histogram (exact; outside the range the parse fails).                  */
+    int (*interdist_exchange)(void *ctx, int64_t *hist, int64_t n_bins);
+    void *interdist_ctx;
 } hgx_parse_opts;
+#define HGX_INTERDIST_HALF 65536
+#define HGX_INTERDIST_BINS (2 * HGX_INTERDIST_HALF + 2)
 
 /* SAM text (name-grouped, i.e. the stream after `sort -k1,1 -s`, core:458-468) -> batch.
  * Replaces typing_core.py:800-1406 + get_mpileup (common:1059-1134).                        */
