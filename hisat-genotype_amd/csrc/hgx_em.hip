@@ -18,6 +18,7 @@
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -3255,7 +3256,16 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
 // 1 if the calling thread's last EM (hgx_em / hgx_em_ordered / hgx_em_masked) ran on the single-wavefront path in the reference's
 // own order of floating-point operations (its abundances are then the reference's, bit for bit), 0 otherwise
 static thread_local int g_last_exact = 0;
+static thread_local std::vector<int32_t> g_last_order;     // per allele: position in the returned dict's insertion order (hgx_em_last_order)
 static thread_local int g_em_fast = 0;           // hgx_em_set_fast: table-lookup arithmetic on the one-workgroup path (k_emx)
+// Insertion order of the dict the calling thread's last hgx_em / hgx_em_ordered returned, when that EM ran in the reference's own
+// order on the one-workgroup kernel (hgx_em_last_exact() == 1 and the problem had more than 64 classes or alleles): order_host[a] =
+// position of allele a (-1 if not in the dict).  Returns 1 if available, else 0 (callers then use (first class, name order)).
+extern "C" int hgx_em_last_order(int32_t *order_host, int32_t n) {
+    if (g_last_order.empty() || !order_host || n > (int32_t)g_last_order.size()) return 0;
+    memcpy(order_host, g_last_order.data(), (size_t)n * 4);
+    return 1;
+}
 extern "C" int hgx_em_set_fast(int on) { const int old = g_em_fast; g_em_fast = on ? 1 : 0; return old; }
 static thread_local bool g_no_grid = false;      // set while an EM is re-run after a resident-block launch was abandoned
 extern "C" int hgx_em_last_exact(void) { return g_last_exact; }
@@ -3303,6 +3313,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
                    int32_t *first_host, int32_t *n_iter_host, void *stream) {
     ARGCHK(cc && prob_host && n_alleles > 0 && n_alleles <= cc->a_pad);
     g_last_exact = 0;
+    g_last_order.clear();
     hgx_classes_order_after(cc, (hipStream_t)stream);
     if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = -1;
     hgx_classes *c = const_cast<hgx_classes *>(cc);
@@ -3377,7 +3388,8 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         job.bits = c->d_bits; job.count = c->d_count; job.rank = b_rank.as<int32_t>(); job.len = allele_len ? b_len.as<double>() : nullptr;
         job.C = C; job.w64 = c->w64; job.a_pad = A; job.remove_low = remove_low ? 1 : 0;
         job.fast = g_em_fast;
-        job.prob = prob_host; job.first = first_host; job.n_out = n_alleles;
+        std::vector<int32_t> order((size_t)n_alleles, -1);
+        job.prob = prob_host; job.first = first_host; job.order = order.data(); job.n_out = n_alleles;
         { int rc_ = hgx_emx_run(&job, 1, st); if (rc_) return rc_; }
         if (job.status == 2) {
             hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
@@ -3386,6 +3398,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         if (job.status == 0) {
             if (n_iter_host) *n_iter_host = job.n_iter;
             g_last_exact = job.fast ? 0 : 1;
+            if (!job.fast) g_last_order.swap(order);
             return HGX_OK;
         }
         for (int a = 0; a < n_alleles; ++a) prob_host[a] = 0.0;

@@ -847,6 +847,8 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
                 const int idx = S.res_base + S.rpre[aw] + __popcll(S.in_now[aw] & ((1ull << (j & 63)) - 1ull));
                 EmxRes r;
                 r.allele = T.sorted[j]; r.first = T.first_c[j]; r.prob = dv[prob][j];
+                r.order = FAST ? -1 : (int)posb[ord_of[prob]][j];
+                r.pad_ = 0;
                 T.res[idx] = r;
             }
     }
@@ -1058,11 +1060,16 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_e
         }
         for (int a = 0; a < J.n_out; ++a) J.prob[a] = -1.0;
         if (J.first) for (int a = 0; a < J.n_out; ++a) J.first[a] = -1;
+        if (J.order) for (int a = 0; a < J.n_out; ++a) J.order[a] = -1;
         if (J.status != 0) continue;
         const size_t off = (size_t)sc[XS_RES_OFF], cnt = (size_t)sc[XS_RES_N];
         for (size_t k = 0; k < cnt; ++k) {
             const EmxRes &r = recs[off + k];
-            if (r.allele >= 0 && r.allele < J.n_out) { J.prob[r.allele] = r.prob; if (J.first) J.first[r.allele] = r.first; }
+            if (r.allele >= 0 && r.allele < J.n_out) {
+                J.prob[r.allele] = r.prob;
+                if (J.first) J.first[r.allele] = r.first;
+                if (J.order) J.order[r.allele] = r.order;
+            }
         }
     }
     if (stamps) {

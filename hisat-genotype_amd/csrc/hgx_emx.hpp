@@ -8,7 +8,11 @@
 #include <vector>
 
 // one allele of a returned dict (what the kernel writes; hgx_emx_run hands these out as they are when asked to)
-struct hgx_emx_rec { int32_t allele, first; double prob; };
+// `order`: the allele's position in the insertion order of the RETURNED dict (the last Gene_prob_next: first WALKED class containing
+// the allele, then key order -- classes whose alleles_prob is 0 are skipped, typing_common.py:1321, so this can differ from the
+// first class over all classes); -1 from the table-lookup arithmetic, which does not track dict orders.  The reference's final
+// stable sort breaks abundance ties in this order.
+struct hgx_emx_rec { int32_t allele, first; double prob; int32_t order, pad_; };
 
 // One EM problem: `C` classes (rows of `w64` words over the locus' allele indices, dict order), their counts, the alleles' name
 // order (rank[a] = place of allele a among the sorted names = its place inside a class key) and optionally the allele
@@ -29,6 +33,7 @@ struct hgx_emx_job {
     // results (HOST memory, filled by hgx_emx_run)
     double *prob;               // [n_out] abundance, or -1.0 for an allele that is not in the returned dict (NULL with `recs`, below)
     int32_t *first;             // [n_out] or NULL: first class (dict order) containing the allele, -1 elsewhere
+    int32_t *order;             // [n_out] or NULL: hgx_emx_rec::order per allele, -1 elsewhere
     int32_t n_out;              // alleles reported (<= a_pad)
     size_t rec_off;             // with `recs`: the job's records are recs[rec_off .. rec_off + n_rec)
     int32_t n_rec;

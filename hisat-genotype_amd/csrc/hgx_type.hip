@@ -31,6 +31,7 @@
 #include "hgx_internal.hpp"
 
 extern "C" int hgx_em_set_fast(int on);
+extern "C" int hgx_em_last_order(int32_t *order_host, int32_t n);
 
 struct hgx_dbatch {
     int32_t n_pieces = 0, n_pairs = 0, n_reads = 0;
@@ -305,6 +306,11 @@ int run_em(hgx_classes *cl, const hgx_locus *loc, int32_t remove_low, const int3
     EmOut o;
     o.exact = hgx_em_last_exact() != 0;
     o.n_classes = C; o.n_iter = n_iter; o.remove_low = remove_low ? 1 : 0; o.use_length = lengths ? 1 : 0;
+    std::vector<int32_t> order((size_t)A);
+    if (o.exact && hgx_em_last_order(order.data(), A)) {
+        // the returned dict's own insertion order (its positions are distinct): the sort key instead of (first class, name order)
+        for (int32_t a = 0; a < A; ++a) first[a] = prob[a] >= 0.0 ? order[a] : -1;
+    }
     sorted_result(prob, first, loc->name_rank.data(), A, o);
     t->em.push_back(std::move(o));
     return HGX_OK;
@@ -785,12 +791,13 @@ int class_offsets(const hgx_classes *cl, const hgx_many *m, int32_t *scratch_dev
 
 // the result list of a batched EM from its records: dict insertion order (first class, then name order), then the reference's
 // stable descending sort -- what sorted_result does from dense arrays
-void em_out_from(const hgx_emx_job &J, const std::vector<hgx_emx_rec> &recs, const hgx_locus *loc, int32_t use_length, EmOut &o) {
+void em_out_from(const hgx_emx_job &J, const std::vector<hgx_emx_rec> &recs, const hgx_locus *loc, int32_t use_length, EmOut &o, bool by_dict_order) {
     o.exact = J.fast == 0;
     o.n_classes = J.n_classes; o.n_iter = J.n_iter; o.remove_low = J.remove_low ? 1 : 0; o.use_length = use_length;
     std::vector<hgx_emx_rec> r(recs.begin() + J.rec_off, recs.begin() + J.rec_off + J.n_rec);
     const int32_t *name_rank = loc->name_rank.data();
     std::sort(r.begin(), r.end(), [&](const hgx_emx_rec &x, const hgx_emx_rec &y) {
+        if (by_dict_order && o.exact) return x.order < y.order;          // the returned dict's insertion order (distinct positions)
         if (x.first != y.first) return x.first < y.first;
         if (name_rank[x.allele] != name_rank[y.allele]) return name_rank[x.allele] < name_rank[y.allele];
         return x.allele < y.allele;
@@ -990,7 +997,7 @@ struct ManyRun {
                 continue;
             }
             EmOut o;
-            em_out_from(J, recs, loc, 0, o);
+            em_out_from(J, recs, loc, 0, o, true);
             ty->em.push_back(std::move(o));
         }
         if (!counts_taken) take_counts();
@@ -1047,7 +1054,7 @@ struct ManyRun {
                 e2.n_classes = ncls2; e2.n_iter = it2; e2.remove_low = 1; e2.use_length = 1;
                 sorted_result(p2, f2, loc->name_rank.data(), A, e2);
             } else {
-                em_out_from(J, recs2, loc, 1, e2);
+                em_out_from(J, recs2, loc, 1, e2, false);      // (as the one-task path's hand-off kernel orders its result)
             }
             combine_levels(ty, std::move(e2), in_exon[t], psum[t]);
         }

@@ -52,6 +52,14 @@ class DeviceBatch:
             pass
 
 
+def em_last_order(n_alleles):
+    """Insertion order of the dict the last em() / em_ordered() of this thread returned (position per allele, -1 outside), or None
+    when that EM did not run on the reference-order kernel (hgx_em_last_order)."""
+    order = np.zeros(max(n_alleles, 1), np.int32)
+    ok = capi.lib().hgx_em_last_order(capi.ptr(order), C.c_int32(n_alleles))
+    return order[:n_alleles] if ok else None
+
+
 def emx_set_timing(on):
     capi.check(capi.lib().hgx_emx_set_timing(C.c_int(1 if on else 0)))
 

@@ -75,10 +75,15 @@ def single_abundance(Gene_cmpt, remove_low_abundance_allele=False, Gene_length={
             cl.set_allele_rank(rank)
         prob, _ = cl.em(A, bool(remove_low_abundance_allele), lengths)
         exact = bool(capi.lib().hgx_em_last_exact())
+        order = engine.em_last_order(A) if exact else None
     finally:
         cl.close()
-    # allele index == first-appearance order here, which is the dict order of the reference
-    res = [[names[a], float(prob[a])] for a in range(A) if prob[a] >= 0.0]
+    # allele index == first-appearance order here, which is the dict order of the reference -- unless the EM skipped classes
+    # whose alleles_prob was 0 (common:1321): the kernel then reports the returned dict's own insertion order
+    idx = [a for a in range(A) if prob[a] >= 0.0]
+    if order is not None:
+        idx.sort(key=lambda a: int(order[a]))
+    res = [[names[a], float(prob[a])] for a in idx]
     return _stable_desc(res, exact)
 
 

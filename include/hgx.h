@@ -254,6 +254,12 @@ int hgx_classes_set_allele_rank(hgx_classes *c, const int32_t *rank_host, int32_
  * reference's doubles, and ties between them are the reference's ties (callers sort them with a plain stable sort instead
  * of the tolerance they need for results that agree to ~1e-14 only) */
 int hgx_em_last_exact(void);
+/* The insertion order of the dict the calling thread's last hgx_em / hgx_em_ordered returned -- the tie order of the reference's
+ * final stable sort.  It is (first WALKED class containing the allele, name order) in the LAST Gene_prob_next: classes whose
+ * alleles_prob is 0 are skipped (typing_common.py:1321), so it can differ from (first class over all classes, name order), which
+ * is what first_class_host gives.  Available (return 1) after an EM of more than 64 classes or alleles that ran in the reference's
+ * own order (hgx_em_last_exact); order_host[a] = position, -1 for alleles outside the dict.  Returns 0 otherwise. */
+int hgx_em_last_order(int32_t *order_host, int32_t n_alleles);
 /* arithmetic of hgx_em / hgx_em_ordered on this thread for problems the one-workgroup kernel takes (see hgx_type_opts.em_fast):
  * 0 = the reference's order (default), 1 = table lookups.  Returns the previous setting. */
 int hgx_em_set_fast(int on);
