@@ -591,8 +591,13 @@ def run_panel64(args, rank, local_rank, world, dist):
                     "bound": "hbm", "peak_GBps": HBM_PEAK_GBS, "frac": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
         if kernels:
             dom = max(kernels, key=lambda k: kernels[k]["total_ms_per_step"])
+            traffic = None
+            try:                                                   # PMC passes of the panel64 command (profiles/README.md)
+                traffic = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))["hbm_bytes_per_launch"].get(dom)
+            except Exception:
+                traffic = None
             roof = {"bound": "hbm", "kernel": dom, "achieved": kernels[dom]["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["frac"],
-                    "traffic": None, "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"], "avg_launch_ms": kernels[dom]["avg_ms"],
+                    "traffic": traffic, "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"], "avg_launch_ms": kernels[dom]["avg_ms"],
                     "note": "the one-workgroup-per-task EM kernel (EM #1 of all tasks in one launch; EM #2 in another): HIP events around every "
                             "launch of the timed region; algorithmic bytes per launch = sum over its jobs of applications x (C * A' / 8 + 16 A' + "
                             "16 C) (SURVEY.md 8d).  The kernel is bound by LDS table lookups and FP64 issue on ONE CU per task, not by HBM: the "

@@ -72,5 +72,36 @@ def build(force=False, verbose=True):
     return LIB
 
 
+LAB_DIR = os.path.join(CSRC, "lab")
+LAB_LIB = os.path.join(LAB_DIR, "libhgx_lab.so")
+
+
+def build_lab(force=False, verbose=True):
+    """libhgx_lab.so: the product objects with hgx_em.hip recompiled under -DHGX_LAB (the only unit that has lab code: the int8-MFMA,
+    persistent and resident-grid EM back-ends in csrc/lab/*.inc).  Lab tools and tests/test_gpu_lab.py bind it (capi.use_lab());
+    nothing in the product path does."""
+    build(force=force, verbose=verbose)
+    src = os.path.join(CSRC, "hgx_em.hip")
+    obj = os.path.join(LAB_DIR, "hgx_em_lab.o")
+    deps = _headers() + [src] + [os.path.join(LAB_DIR, f) for f in os.listdir(LAB_DIR) if f.endswith(".inc")]
+    newest = max(os.path.getmtime(d) for d in deps)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-DHGX_LAB", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+               "-I", CSRC, "-Wall", "-Wno-unused-result", "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    if force or not os.path.exists(LAB_LIB) or os.path.getmtime(LAB_LIB) < max(os.path.getmtime(obj), os.path.getmtime(LIB)):
+        objs = [s_.rsplit(".", 1)[0] + ".o" for s_ in _sources() if os.path.basename(s_) != "hgx_em.hip"] + [obj]
+        cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", LAB_LIB] + objs + ["-lz", "-ldl"]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return LAB_LIB
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv)
+    if "--lab" in sys.argv:
+        build_lab(force="--force" in sys.argv)

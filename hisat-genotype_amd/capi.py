@@ -8,6 +8,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libhgx.so")
+LAB_PATH = os.path.join(HERE, "csrc", "lab", "libhgx_lab.so")     # same sources with -DHGX_LAB (build.build_lab): lab tools / tests only
 
 VAR_INSERTION, VAR_SINGLE, VAR_DELETION = 0, 1, 2
 BASE_KIND = {"hla": 0, "codis": 1, "genome": 2}
@@ -59,7 +60,7 @@ SYMBOLS = [
     "hgx_index_destroy", "hgx_index_dims", "hgx_index_device_bits", "hgx_piece_compat", "hgx_pair_classes",
     "hgx_score_pairs", "hgx_level_classes", "hgx_group_pairs", "hgx_groups_dims", "hgx_groups_destroy",
     "hgx_level_classes_grouped", "hgx_classes_set_allele_rank", "hgx_dedup_classes", "hgx_classes_destroy", "hgx_classes_dims", "hgx_classes_device",
-    "hgx_classes_to_host", "hgx_classes_from_host", "hgx_allele_counts", "hgx_allele_counts_on", "hgx_first_classes", "hgx_em", "hgx_em_ordered", "hgx_em_masked", "hgx_em_set_backend", "hgx_debug_matvec", "hgx_em_set_timing", "hgx_em_get_timing", "hgx_locus_create",
+    "hgx_classes_to_host", "hgx_classes_from_host", "hgx_allele_counts", "hgx_allele_counts_on", "hgx_first_classes", "hgx_em", "hgx_em_ordered", "hgx_em_masked", "hgx_em_set_backend", "hgx_test_switch_set", "hgx_debug_matvec", "hgx_em_set_timing", "hgx_em_get_timing", "hgx_locus_create",
     "hgx_locus_destroy", "hgx_locus_dims", "hgx_locus_tables", "hgx_index_from_locus",
     "hgx_locus_alternatives_text", "hgx_batch_destroy", "hgx_batch_dims", "hgx_batch_arrays",
     "hgx_batch_from_haplotypes", "hgx_parse_sam", "hgx_read_alignments", "hgx_free_text", "hgx_parse_alignment_file", "hgx_batch_trace_text", "hgx_batch_pileup",
@@ -83,6 +84,14 @@ def lib():
         _lib.hgx_last_error.restype = C.c_char_p
         _lib.hgx_a_pad.restype = C.c_int32
     return _lib
+
+
+def use_lab():
+    """Bind the lab build (opt-in EM back-ends of rounds 1-2) instead of the product library; before the first call only."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("libhgx.so is already loaded in this process")
+    LIB_PATH = LAB_PATH
 
 
 def check(rc):

@@ -636,7 +636,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         };
         BRecVec chain;          // every record: (offset after block_size, length)
         const size_t body0 = p;
-        const char *chain_min = getenv("HGX_BAM_CHAIN_MIN");              // bytes of records from which the chain is walked in ranges (tests)
+        const char *chain_min = hgx_test_switch("bam_chain_min");              // bytes of records from which the chain is walked in ranges (tests)
         const size_t chain_min_bytes = chain_min ? (size_t)strtoull(chain_min, nullptr, 10) : (32u << 20);
         const int W = (n - body0 > chain_min_bytes) ? std::max(1, std::min(n_threads, 64)) : 1;
         bool chain_error = false;

@@ -4,10 +4,13 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 
 #include "hgx.h"
 
 extern "C" void hgx_set_error(const char *fmt, ...);
+// test hook (hgx.h: hgx_test_switch_set): value of a path-forcing switch, NULL when it is not set (one relaxed load then)
+extern "C" const char *hgx_test_switch(const char *name);
 
 #define HIPCHK(expr)                                                                   \
     do {                                                                               \
@@ -81,6 +84,21 @@ struct DevBuf {
 static inline void hgx_classes_order_after(const hgx_classes *c, hipStream_t st) {
     if (c && c->ready && st != c->made_on) (void)hipStreamWaitEvent(st, c->ready, 0);
 }
+
+// `body` (hipFuncSetAttribute calls: per-DEVICE state) runs once per device at this call site, under a lock: a second device, or a
+// second host thread arriving during the first call, never launches without the attribute
+#define HGX_ONCE_PER_DEVICE(body)                                            \
+    do {                                                                     \
+        static std::mutex once_mu_;                                          \
+        static uint64_t once_done_ = 0;                                      \
+        int once_dev_ = 0;                                                   \
+        HIPCHK(hipGetDevice(&once_dev_));                                    \
+        std::lock_guard<std::mutex> once_g_(once_mu_);                       \
+        if (!((once_done_ >> (once_dev_ & 63)) & 1ull)) {                    \
+            body;                                                            \
+            once_done_ |= 1ull << (once_dev_ & 63);                          \
+        }                                                                    \
+    } while (0)
 
 static inline unsigned nblk(long n, int per) { return (unsigned)((n + per - 1) / per); }
 

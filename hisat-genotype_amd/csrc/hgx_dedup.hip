@@ -579,7 +579,7 @@ static int groups_finish(hgx_groups *g) {
     g->finished = true;
     if (rc) return rc;
     g->n_groups = g->meta[0] ? 0 : (int64_t)g->meta[1];
-    if (getenv("HGX_TEST_GROUP_COLLISION")) g->n_groups = 0;      // test aid: take the per-pair fallback of a list-key collision
+    if (hgx_test_switch("test_group_collision")) g->n_groups = 0;      // test aid: take the per-pair fallback of a list-key collision
     return HGX_OK;
 }
 

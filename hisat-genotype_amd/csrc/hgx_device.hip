@@ -496,7 +496,7 @@ extern "C" int hgx_piece_compat(const hgx_index *ix, const hgx_piece *pieces, co
     ARGCHK(ix && n_pieces >= 0);
     if (n_pieces == 0) return HGX_OK;
     ARGCHK(pieces && masks && compat);
-    const bool untiled = getenv("HGX_PIECE_UNTILED") != nullptr;     // the L2-served kernel, kept for comparison
+    const bool untiled = hgx_test_switch("piece_untiled") != nullptr;     // the L2-served kernel, kept for comparison
     if (untiled) {
         const int chunks = (ix->w64 + PC_GROUPS - 1) / PC_GROUPS;
         const long waves = (long)n_pieces * chunks;
@@ -561,9 +561,17 @@ __device__ __forceinline__ uint32_t fused_find_slot(const FusedArgs &fa, uint64_
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
 }
 __device__ __forceinline__ uint32_t fused_wait_rep(const FusedArgs &fa, uint32_t slot, int lane) {
+    // bounded: a representative that never shows up (a lost publish) becomes the caller's HGX_ECOLLISION fallback (*bad), never a
+    // hung queue; the winner published its own pair index, so comparing with row 0 is harmless once *bad is set
     uint32_t r = 0;
     if (lane == 0) {
-        do r = __hip_atomic_load(&fa.rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); while (r == 0xFFFFFFFFu);
+        unsigned spins = 0;
+        do {
+            r = __hip_atomic_load(&fa.rep[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (r != 0xFFFFFFFFu) break;
+            __builtin_amdgcn_s_sleep(2);
+        } while (++spins < (1u << 22));
+        if (r == 0xFFFFFFFFu) { atomicOr(fa.bad, 1); r = 0; }
     }
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
 }
@@ -955,7 +963,7 @@ int hgx_pair_classes_sel(const hgx_index *ix, const uint64_t *compat, const int3
     const long blocks = ((long)n_pairs + 3) / 4;
     const int kw = (ix->w64 + 63) / 64;
     const bool exon = eb || eh, gene = gb || gh;
-    if (exon != gene && kw <= 8 && !getenv("HGX_PAIR_X1")) {       // one level: two pairs per wavefront
+    if (exon != gene && kw <= 8 && !hgx_test_switch("pair_x1")) {       // one level: two pairs per wavefront
         const long blocks2 = ((long)n_pairs + 7) / 8;
         const uint32_t level = gene ? 1u : 0u;
         const uint64_t *mask = gene ? ix->d_gene_mask : ix->d_exon_mask;

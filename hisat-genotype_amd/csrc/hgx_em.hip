@@ -496,247 +496,10 @@ __global__ __launch_bounds__(BLOCK) void k_em_finish(const double *__restrict__ 
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// MFMA form of the bit mat-vec (rocprof: the EXEC-masked VALU kernel above is issue bound -- one vector instruction per
-// 64 matrix bits and a 10-step cross-lane reduction per 8 rows -- and is the largest aggregate kernel of the step).
-// y = B x is evaluated EXACTLY in integers on the matrix cores:
-//   * x (>= 0) is turned into 119-bit fixed point relative to 2^ceil(log2 max x), as sixteen planes of balanced
-//     base-256 digits X_n[k] in [-128, 127] (the int8 operands are signed);
-//   * the 0/1 matrix is expanded on the fly to int8 (16 bits -> 16 bytes per lane and MFMA);
-//   * v_mfma_i32_16x16x64_i8 accumulates  D[row][n] = sum_k B[row][k] * X_n[k]  in int32 (exact: K * 255 < 2^31);
-//   * y[row] = sum_n D[row][n] * 2^(8n) * 2^(e - 128), rounded once to FP64.
-// Operand maps (probed with tools/mfma_layout_test.hip): lane l holds A[row = l&15][k = 16*(l>>4)+j] and
-// B[k = 16*(l>>4)+j][col = l&15] in byte j of its 128-bit operand; D[row = 4*(l>>4)+reg][col = l&15].
-// The matrix is pre-permuted once per class set (k_permute_mfma) so that a wave fetches the 16-bit slices of four
-// K-steps as ONE coalesced 8-byte-per-lane load; the byte planes live in LDS (stride chosen conflict free for
-// ds_read_b128).  A workgroup = 4 waves = 64 matrix rows; K is walked in chunks of 8192 elements.
-// ------------------------------------------------------------------------------------------------------------
-typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr int MF_BLOCK = 256;
-constexpr int MF_WAVES = MF_BLOCK / 64;
-constexpr int MF_KC = 4096;                 // elements per LDS chunk (66 KB of planes: two workgroups per CU)
-constexpr int MF_STRIDE = MF_KC + 32;       // plane stride in bytes: (stride / 16) % 16 == 2 -> no bank conflicts
-constexpr int MF_NP = 16;                   // byte planes (128-bit fixed point)
+#ifdef HGX_LAB
+#include "lab/hgx_em_mfma.inc"            // int8-MFMA form of the bit mat-vec (backend 2): lab build only
+#endif
 
-// P[(tile * n_super + u) * 64 + lane] = the four 16-bit slices (K-steps 4u .. 4u+3) lane (row = lane&15, h = lane>>4)
-// feeds to the MFMA: slice q = bits [16h, 16h+16) of word 4u+q of row 16*tile + row.
-__global__ __launch_bounds__(256) void k_permute_mfma(const uint64_t *__restrict__ B, int n_rows, int n_words, int n_super,
-                                                      long total, uint64_t *__restrict__ P) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int lane = (int)(i & 63);
-    const long tu = i >> 6;
-    const int u = (int)(tu % n_super);
-    const long tile = tu / n_super;
-    const long row = tile * 16 + (lane & 15);
-    const int h = lane >> 4;
-    uint64_t v = 0;
-    if (row < n_rows) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int w = 4 * u + q;
-            const uint64_t word = w < n_words ? B[(size_t)row * n_words + w] : 0ull;
-            v |= ((word >> (16 * h)) & 0xFFFFull) << (16 * q);
-        }
-    }
-    P[i] = v;
-}
-
-// 16 bits -> 16 bytes of 0/1 (4 dwords): nibble * 0x00204081 spreads its four bits to bit 0 of each byte
-__device__ __forceinline__ v4i expand16(uint32_t bits) {
-    v4i r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = (int)((((bits >> (4 * i)) & 0xFu) * 0x00204081u) & 0x01010101u);
-    return r;
-}
-
-// byte transpose of a 4x4 byte block: in: a,b,c,d (one dword per element), out[j] = byte j of (a,b,c,d)
-__device__ __forceinline__ void transpose4(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t (&out)[4]) {
-    const uint32_t ab_lo = __builtin_amdgcn_perm(b, a, 0x05010400u);   // a0 b0 a1 b1
-    const uint32_t ab_hi = __builtin_amdgcn_perm(b, a, 0x07030602u);   // a2 b2 a3 b3
-    const uint32_t cd_lo = __builtin_amdgcn_perm(d, c, 0x05010400u);
-    const uint32_t cd_hi = __builtin_amdgcn_perm(d, c, 0x07030602u);
-    out[0] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x05040100u);          // a0 b0 c0 d0
-    out[1] = __builtin_amdgcn_perm(cd_lo, ab_lo, 0x07060302u);          // a1 b1 c1 d1
-    out[2] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x05040100u);
-    out[3] = __builtin_amdgcn_perm(cd_hi, ab_hi, 0x07060302u);
-}
-
-// x >= 0 as fixed point X = floor(x * 2^(1141 - exm)) < 2^119 (`exm` = biased exponent of the maximum), written in
-// BALANCED base-256 digits d_n in [-128, 127] (X = sum d_n 256^n) because the int8 MFMA operands are signed:
-// add 0x80 to every byte with carry propagation, then flip each byte's top bit.
-__device__ __forceinline__ void to_fixed128(double x, int exm, uint32_t (&d)[4]) {
-    const uint64_t bits = (uint64_t)__double_as_longlong(x);
-    const int ex = (int)((bits >> 52) & 0x7FF);
-    uint64_t lo = 0, hi = 0;
-    if (ex != 0) {                                   // zero / subnormal inputs contribute nothing
-        const uint64_t m = (bits & 0xFFFFFFFFFFFFFull) | (1ull << 52);
-        const int sh = ex - exm + 66;                // x == max -> top bit at position 118
-        if (sh >= 64) hi = m << (sh - 64);
-        else if (sh > 0) { lo = m << sh; hi = m >> (64 - sh); }
-        else if (sh > -53) lo = m >> (-sh);
-    }
-    const uint64_t c = 0x8080808080808080ull;
-    const uint64_t lo2 = lo + c;
-    const uint64_t hi2 = hi + c + (lo2 < lo ? 1ull : 0ull);
-    lo = lo2 ^ c;
-    hi = hi2 ^ c;
-    d[0] = (uint32_t)lo; d[1] = (uint32_t)(lo >> 32); d[2] = (uint32_t)hi; d[3] = (uint32_t)(hi >> 32);
-}
-
-template <int MODE>
-__global__ __launch_bounds__(MF_BLOCK) void k_mfma_matvec(const uint64_t *__restrict__ P, int n_rows, int n_super, int n_k,
-                                                          const double *__restrict__ vec, const uint8_t *__restrict__ vec_pres,
-                                                          int x_mode /* rows: 0 raw, 1 normalise, 2 ones */,
-                                                          const int64_t *__restrict__ count, const double *__restrict__ q_in,
-                                                          const uint8_t *__restrict__ pres_in, const double *__restrict__ len,
-                                                          double *__restrict__ y, uint8_t *__restrict__ pres_out,
-                                                          double *__restrict__ scal, int gate) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t planes[];      // [MF_NP][MF_STRIDE]
-    __shared__ double sh[2][NWAVE];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = lane & 15, h = lane >> 4;
-    const long tile = (long)blockIdx.x * MF_WAVES + wv;
-    const int row_base = (int)(tile * 16) + 4 * h;             // rows row_base .. +3 end up in this lane (if n == 0)
-    double st_done = scal[S_DONE], st_flag = scal[S_FLAG], tot = 1.0;
-    if (MODE == MODE_COLS) tot = scal[S_TOT_A];
-    double e_a[4] = {0, 0, 0, 0}, e_len[4] = {1, 1, 1, 1};
-    bool e_pres[4] = {true, true, true, true};
-    if (n == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row_base + r;
-            if (row < n_rows) {
-                if (MODE == MODE_ROWS) e_a[r] = (double)count[row];
-                else {
-                    if (x_mode != 2) { e_a[r] = q_in[row]; e_pres[r] = pres_in[row] != 0; }
-                    if (len) e_len[r] = len[row];
-                }
-            }
-        }
-    }
-    if (st_done != 0.0) return;
-    if (gate && st_flag == 0.0) return;
-    // ---- pass over the vector: maximum (fixed-point scale) and, for the normalising rows pass, the total ----------
-    auto value = [&](int e) -> double {
-        if (e >= n_k) return 0.0;
-        if (MODE == MODE_ROWS) return x_mode == 2 ? 1.0 : (vec_pres[e] ? vec[e] : 0.0);
-        return vec[e];
-    };
-    double mx = 0.0, sm = 0.0;
-    for (int e = tid; e < n_k; e += MF_BLOCK) {
-        const double v = value(e);
-        mx = fmax(mx, v);
-        sm += v;
-    }
-    {
-        // block max and sum (fixed order)
-        mx = wave_max_nonneg_f64(mx);
-        sm = wave_sum_f64(sm);
-        __syncthreads();
-        if (lane == 0) { sh[0][wv] = mx; sh[1][wv] = sm; }
-        __syncthreads();
-        mx = sh[0][0]; sm = 0.0;
-#pragma unroll
-        for (int i = 0; i < MF_WAVES; ++i) { mx = fmax(mx, sh[0][i]); sm += sh[1][i]; }
-    }
-    if (MODE == MODE_ROWS && x_mode == 1) tot = sm;
-    if (MODE == MODE_ROWS && blockIdx.x == 0 && tid == 0) { scal[S_TOT_A] = tot; scal[S_NROWS] += 1.0; }
-    if (MODE == MODE_COLS && blockIdx.x == 0 && tid == 0) scal[S_NCOLS] += 1.0;
-    const int exm = (int)(((uint64_t)__double_as_longlong(mx) >> 52) & 0x7FF);     // 0 if the vector is all zero
-    // four independent accumulators (one per K-step of a slice group): no MFMA waits for the previous one
-    v4i acc4[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) acc4[q] = v4i{0, 0, 0, 0};
-    const uint64_t *Pt = P + (size_t)tile * n_super * 64 + lane;
-    const bool tile_ok = tile * 16 < n_rows;
-    for (int c0 = 0; c0 < n_k; c0 += MF_KC) {
-        // ---- byte planes of this chunk: a thread converts 4 consecutive elements and writes one dword per plane --------
-        for (int g = tid; g < MF_KC / 4; g += MF_BLOCK) {
-            uint32_t d[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) to_fixed128(value(c0 + 4 * g + i), exm, d[i]);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint32_t t[4];
-                transpose4(d[0][j], d[1][j], d[2][j], d[3][j], t);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) *reinterpret_cast<uint32_t *>(planes + (size_t)(4 * j + b) * MF_STRIDE + 4 * g) = t[b];
-            }
-        }
-        __syncthreads();
-        if (tile_ok) {
-            const int u0 = c0 / 256;
-            const int u1 = min(n_super, (c0 + MF_KC) / 256);
-            const uint8_t *bp = planes + (size_t)n * MF_STRIDE + 16 * h;
-            // software pipeline: slice group and plane fragments of the NEXT group are fetched while this one multiplies
-            uint64_t cur = 0ull;
-            v4i bf[4];
-            if (u0 < u1) {
-                cur = Pt[(size_t)u0 * 64];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bf[q] = *reinterpret_cast<const v4i *>(bp + 64 * q);
-            }
-            for (int u = u0; u < u1; ++u) {
-                uint64_t nxt = 0ull;
-                v4i nb[4];
-                if (u + 1 < u1) {
-                    nxt = Pt[(size_t)(u + 1) * 64];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) nb[q] = *reinterpret_cast<const v4i *>(bp + 64 * (4 * (u + 1 - u0) + q));
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) nb[q] = v4i{0, 0, 0, 0};
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const v4i a = expand16((uint32_t)(cur >> (16 * q)) & 0xFFFFu);
-                    acc4[q] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bf[q], acc4[q], 0, 0, 0);
-                }
-                cur = nxt;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) bf[q] = nb[q];
-            }
-        }
-        __syncthreads();            // planes are rebuilt for the next chunk
-    }
-    v4i acc;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = acc4[0][r] + acc4[1][r] + acc4[2][r] + acc4[3][r];
-    // ---- combine the planes: lane (n, h) holds D[4h + r][n]; y[row] = 2^(exm-1141) * sum_n D * 2^(8n) -----------------
-    double t[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        double v = exm ? ldexp((double)acc[r], 8 * n + exm - 1141) : 0.0;
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        t[r] = v;
-    }
-    if (n == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = row_base + r;
-            if (row >= n_rows) continue;
-            if (MODE == MODE_ROWS) {
-                const double s = (x_mode == 1) ? t[r] / tot : t[r];
-                y[row] = s > 0.0 ? e_a[r] / s : 0.0;
-            } else {
-                const bool init = x_mode == 2;
-                const bool in = init || e_pres[r];
-                double v = 0.0;
-                if (in && t[r] > 0.0) {
-                    v = init ? t[r] : (e_a[r] / tot) * t[r];
-                    if (len) v = v / e_len[r];
-                }
-                y[row] = v;
-                pres_out[row] = (in && t[r] > 0.0) ? 1 : 0;
-            }
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------------------
 // Whole EM in ONE workgroup for small problems (C <= SMALL_C classes, a_pad <= 8192): the exon->gene hand-off EM and
@@ -2012,7 +1775,7 @@ __device__ __forceinline__ double lut_row(const double *T, const uint64_t (&w)[8
 // lut_row for matrix words that live in registers across many passes (k_em_grid): the words are passed through an empty
 // asm so that the compiler cannot hoist the 64 table addresses of a row out of the iteration loop (it did: 128 loop-invariant
 // VGPRs, spilled to scratch and re-loaded before every lookup)
-__device__ __forceinline__ double lut_row_resident(const double *T, const uint64_t (&w)[8]) {
+[[maybe_unused]] __device__ __forceinline__ double lut_row_resident(const double *T, const uint64_t (&w)[8]) {
     uint64_t v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -2315,329 +2078,11 @@ __global__ __launch_bounds__(BLOCK) void k_lut_rows_fused(const uint64_t *__rest
     if (n < Npad) part[(size_t)slab * Npad + n] = acc2;      // the cols pass adds the slabs
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Persistent EM (opt-in, HGX_EM_PERSIST=1; see the measurement note in hgx_em).  With the table-lookup mat-vec a whole
-// SQUAREM iteration is ~50 us of work spread over eight launches.  k_em_persist keeps one workgroup per CU resident and runs
-// `n_iters` complete iterations (and optionally the initial estimate) in ONE launch:
-//   * the six mat-vec passes of an iteration are the same (slab, chunk) work items as k_lutmatvec, dealt round-robin
-//     to the resident workgroups; the last workgroup of a row chunk still adds the slab partials;
-//   * passes are separated by a device-wide barrier: one device-scope atomic per workgroup and a bounded spin
-//     (abort flag instead of a hang if the grid is ever not co-resident);
-//   * the vector steps (normalisation totals, SQUAREM extrapolation, prob_diff, pruning) are done by the workgroups
-//     that own an allele chunk, through per-chunk partial sums in memory, added in chunk order by everyone;
-//   * every value that crosses workgroups is written and read with device-scope (L2-bypassing) accesses;
-//     "allele not in the dict" is encoded as -1 in the vectors, so there are no separate presence arrays.
-// ------------------------------------------------------------------------------------------------------------
-struct PkArgs {
-    const uint64_t *Mr, *Mc;          // word-transposed matrices [w64c][Cp], [c64][A]
-    int C, Cp, A;                     // classes, padded classes, compact padded alleles
-    int nsr, ncr, nsc, ncc;           // slabs / row chunks of the rows pass and of the cols pass
-    const int64_t *count;
-    const double *len;
-    double *p, *q1, *q2, *q3, *wc, *part, *ctot, *red, *scal;
-    unsigned *chunk_cnt, *bar;
-    int *abort_flag;
-    int remove_low, n_iters, do_init;
-};
+#ifdef HGX_LAB
+#include "lab/hgx_em_persist.inc"         // whole iterations per launch behind device-wide barriers (HGX_EM_PERSIST): lab build only
+#endif
 
-__device__ __forceinline__ double pk_ld(const double *p) {
-    return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void pk_st(double *p, double v) {
-    __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// own stores complete (they are write-through device-scope stores) before anything that follows
-__device__ __forceinline__ void pk_flush() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-constexpr long PK_SPIN_LIMIT = 400000;      // ~0.5 s: a lost workgroup becomes an error code, never a hung GPU
-
-// returns true if the launch must be abandoned
-__device__ __forceinline__ bool pk_barrier(const PkArgs &a, unsigned &target, int *s_abort) {
-    pk_flush();
-    __syncthreads();
-    target += gridDim.x;
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(a.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        long spins = 0;
-        int ab = 0;
-        while ((int)(__hip_atomic_load(a.bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-            __builtin_amdgcn_s_sleep(4);
-            ++spins;
-            if (spins > PK_SPIN_LIMIT) { __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ab = 1; break; }
-            if ((spins & 255) == 0 && __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
-        }
-        *s_abort = ab;
-    }
-    __syncthreads();
-    return *s_abort != 0;
-}
-
-// slab partials of one row, added in slab order (eight loads in flight)
-__device__ __forceinline__ double pk_sum_part(const double *part, int n_slabs, size_t stride, int n) {
-    double t = 0.0;
-    for (int s0 = 0; s0 < n_slabs; s0 += 8) {
-        double v[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = s0 + k < n_slabs ? pk_ld(&part[(size_t)(s0 + k) * stride + n]) : 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t += v[k];
-    }
-    return t;
-}
-
-__global__ __launch_bounds__(BLOCK) void k_em_persist(PkArgs a) {
-    extern __shared__ double lds[];
-    double *T = lds;
-    double *xs = lds + LUT_G * 256;
-    __shared__ double sh[3][NWAVE];
-    __shared__ double shm[NWAVE];
-    __shared__ int is_last, s_abort;
-    const int tid = threadIdx.x, b = blockIdx.x, G = gridDim.x;
-    unsigned target = 0;
-    double n_maps = 0.0;
-
-    // this workgroup's ticket for a row chunk: true for the last of the chunk's n_slabs workgroups
-    auto last_of_chunk = [&](int chunk, int n_slabs) -> bool {
-        pk_flush();
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned old = __hip_atomic_fetch_add(&a.chunk_cnt[chunk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            is_last = old == (unsigned)(n_slabs - 1);
-            if (is_last) __hip_atomic_store(&a.chunk_cnt[chunk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        return is_last != 0;
-    };
-    // w_c = n_c / sum_{j in c} x_j   with x = src / scale (absent alleles contribute 0), or all ones (init)
-    auto rows_pass = [&](const double *src, double scale, bool init) {
-        for (int item = b; item < a.nsr * a.ncr; item += G) {
-            const int chunk = item / a.nsr, slab = item % a.nsr;
-            const int n = chunk * BLOCK + tid;
-            uint64_t w[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = n < a.Cp ? a.Mr[(size_t)(slab * 8 + i) * a.Cp + n] : 0ull;
-            double xv = 0.0;
-            if (tid < LUT_SLAB) {
-                const int e = slab * LUT_SLAB + tid;
-                if (e < a.A) {
-                    if (init) xv = 1.0;
-                    else { const double v = pk_ld(src + e); xv = v >= 0.0 ? v / scale : 0.0; }
-                }
-            }
-            __syncthreads();                       // the previous item's lookups are done with T
-            if (tid < LUT_SLAB) xs[tid] = xv;
-            __syncthreads();
-            lut_build(xs, T, tid);
-            __syncthreads();
-            const double acc = lut_row(T, w);
-            if (n < a.Cp) pk_st(&a.part[(size_t)slab * a.Cp + n], acc);
-            if (last_of_chunk(chunk, a.nsr) && n < a.C) {
-                const double t = pk_sum_part(a.part, a.nsr, a.Cp, n);
-                pk_st(&a.wc[n], t > 0.0 ? (double)a.count[n] / t : 0.0);
-            }
-        }
-    };
-    // out_j = x_j * sum_{c containing j} w_c / len_j for alleles in the dict (x = in / in_scale), -1 otherwise
-    auto cols_pass = [&](const double *in, double in_scale, double *out, int slot, bool init) {
-        for (int item = b; item < a.nsc * a.ncc; item += G) {
-            const int chunk = item / a.nsc, slab = item % a.nsc;
-            const int j = chunk * BLOCK + tid;
-            uint64_t w[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) w[i] = j < a.A ? a.Mc[(size_t)(slab * 8 + i) * a.A + j] : 0ull;
-            double xv = 0.0;
-            if (tid < LUT_SLAB) {
-                const int e = slab * LUT_SLAB + tid;
-                if (e < a.C) xv = pk_ld(a.wc + e);
-            }
-            __syncthreads();
-            if (tid < LUT_SLAB) xs[tid] = xv;
-            __syncthreads();
-            lut_build(xs, T, tid);
-            __syncthreads();
-            const double acc = lut_row(T, w);
-            if (j < a.A) pk_st(&a.part[(size_t)slab * a.A + j], acc);
-            if (last_of_chunk(chunk, a.nsc)) {
-                double v = -1.0;
-                if (j < a.A) {
-                    const double t = pk_sum_part(a.part, a.nsc, a.A, j);
-                    const double xin = init ? 0.0 : pk_ld(in + j);
-                    if ((init || xin >= 0.0) && t > 0.0) {
-                        v = init ? t : (xin / in_scale) * t;
-                        if (a.len) v = v / a.len[j];
-                    }
-                    pk_st(out + j, v);
-                }
-                double s[1] = {v >= 0.0 ? v : 0.0};
-                block_sum_n<1>(s, sh);
-                if (tid == 0) pk_st(&a.ctot[slot * a.ncc + chunk], s[0]);
-            }
-        }
-        n_maps += 1.0;
-    };
-    auto total = [&](int slot) {
-        double t = 0.0;
-        for (int ch = 0; ch < a.ncc; ++ch) t += pk_ld(&a.ctot[slot * a.ncc + ch]);
-        return t;
-    };
-#define PK_BARRIER() do { if (pk_barrier(a, target, &s_abort)) return; } while (0)
-
-    const int j = b * BLOCK + tid;                   // my allele in the vector steps (workgroups b < ncc)
-    const bool vec_wg = b < a.ncc;
-    int iter = (int)a.scal[S_ITER];
-    if (a.do_init) {                                  // initial estimate (common:1299-1309)
-        rows_pass(nullptr, 1.0, true);
-        PK_BARRIER();
-        cols_pass(nullptr, 1.0, a.p, 0, true);
-        PK_BARRIER();
-        const double tot0 = total(0);
-        if (vec_wg && j < a.A) {
-            const double v = pk_ld(a.p + j);
-            pk_st(a.p + j, v >= 0.0 ? v / tot0 : -1.0);
-        }
-        PK_BARRIER();
-    }
-    bool done = false;
-    double td = 0.0, flag_d = 0.0;
-    for (int it = 0; it < a.n_iters && !done; ++it) {
-        rows_pass(a.p, 1.0, false);
-        PK_BARRIER();
-        cols_pass(a.p, 1.0, a.q1, 0, false);
-        PK_BARRIER();
-        const double tot1 = total(0);
-        rows_pass(a.q1, tot1, false);
-        PK_BARRIER();
-        cols_pass(a.q1, tot1, a.q2, 1, false);
-        PK_BARRIER();
-        const double tot2 = total(1);
-        // SQUAREM (common:1361-1380)
-        double x0 = -1.0, r = 0.0, v = 0.0;
-        if (vec_wg) {
-            double acc[3] = {0.0, 0.0, 0.0};
-            if (j < a.A) {
-                x0 = pk_ld(a.p + j);
-                if (x0 >= 0.0) {
-                    const double x1 = pk_ld(a.q1 + j), x2 = pk_ld(a.q2 + j);
-                    if (x1 < 0.0 || x2 < 0.0) acc[2] = 1.0;
-                    else {
-                        const double p1 = x1 / tot1, p2 = x2 / tot2;
-                        r = p1 - x0;
-                        v = p2 - p1 - r;
-                        acc[0] = r * r;
-                        acc[1] = v * v;
-                    }
-                }
-            }
-            block_sum_n<3>(acc, sh);
-            if (tid == 0) { pk_st(&a.red[b * 4 + 0], acc[0]); pk_st(&a.red[b * 4 + 1], acc[1]); pk_st(&a.red[b * 4 + 2], acc[2]); }
-        }
-        PK_BARRIER();
-        double sr = 0.0, sv = 0.0, key = 0.0;
-        for (int ch = 0; ch < a.ncc; ++ch) { sr += pk_ld(&a.red[ch * 4 + 0]); sv += pk_ld(&a.red[ch * 4 + 1]); key += pk_ld(&a.red[ch * 4 + 2]); }
-        if (key != 0.0) {                             // the reference raises KeyError here (quirk Q6)
-            if (b == 0 && tid == 0) { a.scal[S_KEYERR] = 1.0; a.scal[S_DONE] = 1.0; a.scal[S_ITER] = (double)iter; }
-            return;
-        }
-        const bool ext = sv > 0.0;
-        double tot3 = 1.0;
-        if (ext) {
-            const double g = -sqrt(sr / sv);
-            if (vec_wg && j < a.A && x0 >= 0.0) pk_st(a.q2 + j, fmax(0.0, x0 - 2 * g * r + g * g * v));
-            PK_BARRIER();
-            rows_pass(a.q2, 1.0, false);
-            PK_BARRIER();
-            cols_pass(a.q2, 1.0, a.q3, 2, false);
-            PK_BARRIER();
-            tot3 = total(2);
-        }
-        // prob_diff (common:1272-1279), pruning (common:1338-1346), stopping rule (common:1351)
-        const double *qn = ext ? a.q3 : a.q1;
-        const double totn = ext ? tot3 : tot1;
-        double pn = 0.0;
-        bool an = false;
-        if (vec_wg) {
-            double d[1] = {0.0}, mx = 0.0;
-            if (j < a.A) {
-                const double xn = pk_ld(qn + j);
-                an = xn >= 0.0;
-                pn = an ? xn / totn : 0.0;
-                if (x0 >= 0.0) d[0] = an ? fabs(x0 - pn) : x0;
-                if (an) mx = pn;
-            }
-            const double tm_wg = block_max(mx, shm);
-            block_sum_n<1>(d, sh);
-            if (tid == 0) { pk_st(&a.red[b * 4 + 0], d[0]); pk_st(&a.red[b * 4 + 1], tm_wg); }
-        }
-        PK_BARRIER();
-        td = 0.0;
-        double tm = 0.0;
-        for (int ch = 0; ch < a.ncc; ++ch) { td += pk_ld(&a.red[ch * 4 + 0]); tm = fmax(tm, pk_ld(&a.red[ch * 4 + 1])); }
-        const bool prune = a.remove_low && iter >= 10;
-        if (vec_wg) {
-            bool keep = an;
-            if (prune && keep) keep = pn >= tm / 10.0;
-            if (j < a.A) pk_st(a.p + j, keep ? pn : -1.0);
-            double kept[1] = {keep ? 1.0 : 0.0};
-            block_sum_n<1>(kept, sh);
-            if (tid == 0) pk_st(&a.red[b * 4 + 3], kept[0]);
-        }
-        iter += 1;
-        flag_d = ext ? 1.0 : 0.0;
-        done = !(td > 0.0001) || iter >= 1000;
-        PK_BARRIER();
-    }
-    if (b == 0 && tid == 0) {
-        double kept = 0.0;
-        for (int ch = 0; ch < a.ncc; ++ch) kept += pk_ld(&a.red[ch * 4 + 3]);
-        a.scal[S_NPRES] = kept;
-        a.scal[S_DIFF] = td;
-        a.scal[S_FLAG] = flag_d;
-        a.scal[S_ITER] = (double)iter;
-        a.scal[S_DONE] = done ? 1.0 : 0.0;
-        a.scal[S_NROWS] += n_maps;
-        a.scal[S_NCOLS] += n_maps;
-    }
-#undef PK_BARRIER
-}
-
-// (p with -1 for absent) <-> (p, presence bytes) for the kernels that finish or take over the EM
-__global__ void k_pk_unpack(const double *__restrict__ packed, int n, double *__restrict__ p, uint8_t *__restrict__ pres) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const double v = packed[i];
-    pres[i] = v >= 0.0 ? 1 : 0;
-    p[i] = v >= 0.0 ? v : 0.0;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Resident-block EM (k_em_grid; opt-in with HGX_EM_GRID=1 -- measured, see the end of this comment).
-// The per-pass kernels above re-read the class matrix (L2 / Infinity Cache) 66 times per EM and pay a kernel boundary,
-// a launch ramp and five dependent memory round trips per pass.  Here the matrix is read ONCE: workgroup (i, j) of an
-// R x K grid keeps its block -- classes [1024 i, 1024 i + 1024) x alleles [512 j, 512 j + 512) -- in VGPRs in both
-// orientations (8 + 8 words per thread) for all iterations of the launch, and only vectors move:
-//   hop A (row group i: the K workgroups of a class chunk)   slab partials of s_c              [K][Cp]  -> w_c
-//   hop B (column group j: the R workgroups of an allele slab) partials of t_a per 512 classes [2R][A]  -> q_a of the slab
-//   hop C (row group i)                                        the slab's q_a                  [R][A]   -> the whole vector
-// Every hop is point to point inside a group of <= 64 workgroups: payload with device-scope (write-through) stores, the
-// storing waves' vmcnt(0), a workgroup barrier, ONE flag store per workgroup (the application's number); the consumer's
-// first wave polls its peers' flags (one lane per peer), joins a workgroup barrier, then everybody loads the payload with
-// device-scope loads (MI355X_MICROARCH.md, hand-off row 1).  No grid-wide barrier, no atomics.  Payload buffers are
-// double-buffered by application parity: a workgroup can be at most one application ahead of a peer of either group.
-// Arithmetic, element-to-thread maps and summation orders are those of k_lutmatvec / k_lut_rows_fused / k_em_init_norm
-// (slab partials added in slab order, vector reductions over element tid + 1024 k in register k): the estimate after
-// every iteration is BIT-IDENTICAL to the per-pass path's (tests/test_gpu_parity.py::test_em_grid_equals_per_pass).
-// Spins are bounded: a workgroup that never becomes resident turns into an abort flag and the host falls back.
-// Measured on MI355X (HGX_GRID_STAMPS=1 prints thread 0's wall_clock64() at the phase boundaries; C = 16 098, A' = 4 549,
-// 16 x 9 workgroups, alone on the chip): 26.9 us per application of the map = tables + lookups 4.0 (rows) and 8.6 (cols: two
-// tables in turn, half of the threads each), hop A 3.4 (publish 0.5, wait 1.0, nine partials per class 1.9), hop B 6.0
-// (0.6 / 1.5-3.3 / 2.4: 32 partials per allele), hop C + gather + vector step 6.3 -- against ~30 us for the two launches of
-// the per-pass path: the EM call takes 0.995 ms instead of 1.029 ms alone, but inside the typing step, beside the gene side's
-// bandwidth-bound kernels, the hand-offs slow down (the step: 2.27 ms against 2.11 ms).  Three all-to-all hand-offs per
-// application cost what two kernel boundaries with their prologues cost; keeping the matrix in registers does not pay because
-// the passes were never bound by reading it.  Kept as the measurement, and as the bit-exact cross-check of the per-pass path.
-// ------------------------------------------------------------------------------------------------------------
+// arguments of the resident-block EM (k_em_grid, lab build): the host code that prepares them is shared
 struct GkArgs {
     const uint64_t *Mr, *Mc;          // word-transposed matrices [w64c][Cp], [c64][A]
     int C, Cp, A;                     // classes, padded classes (multiple of 512), compact padded alleles (multiple of 512)
@@ -2654,324 +2099,12 @@ struct GkArgs {
     unsigned long long *stamps;       // HGX_GRID_STAMPS=1: wall_clock64() of thread 0 at the phase boundaries, [R*K][GK_STAMPS]
 };
 constexpr int GK_STAMPS = 128;
-constexpr long GK_SPIN_LIMIT = 1500000;     // bounded spin (~0.5 s): an error code, never a hung GPU
+[[maybe_unused]] constexpr long GK_SPIN_LIMIT = 1500000;     // bounded spin (~0.5 s): an error code, never a hung GPU
 constexpr int GK_FLAG_STRIDE = 32;
-constexpr size_t GK_LDS = (size_t)(LUT_G * 256 + BLOCK) * 8;
-
-template <int EK>
-__global__ __launch_bounds__(BLOCK) void k_em_grid(GkArgs a) {
-    extern __shared__ double lds[];
-    double *T = lds;                        // [LUT_G][256]
-    double *xs = lds + LUT_G * 256;         // [BLOCK]
-    __shared__ double shf[3][NWAVE];
-    __shared__ double shm[NWAVE];
-    __shared__ int s_abort;
-    const int tid = threadIdx.x, b = blockIdx.x;
-    const int K = a.K, R = a.R, G = R * K;
-    const int i = b / K, j = b - i * K;
-    const int n = i * BLOCK + tid;                              // my class (rows orientation)
-    const int half = tid >> 9;
-    const int e = j * LUT_SLAB + (tid & (LUT_SLAB - 1));        // my allele (cols orientation; vector steps: tid < 512)
-    const int nsc = a.Cp / LUT_SLAB;                            // 512-class slabs of the cols pass
-    const int cslab = 2 * i + half;
-    const bool cs_valid = cslab < nsc;
-    const bool slab_thread = tid < LUT_SLAB;
-    // ---- the block, once -------------------------------------------------------------------------------------
-    uint64_t wr[8], wc[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) wr[k] = n < a.Cp ? a.Mr[(size_t)(j * 8 + k) * a.Cp + n] : 0ull;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) wc[k] = cs_valid ? a.Mc[(size_t)(cslab * 8 + k) * a.A + e] : 0ull;
-    const double cnt = n < a.C ? (double)a.count[n] : 0.0;
-    const double len_e = a.len ? a.len[e] : 1.0;
-    int iter = (int)a.scal[S_ITER];
-    if (a.scal[S_DONE] != 0.0) return;
-    unsigned epoch = 0;
-    double n_maps = 0.0;
-    int n_stamp = 0;
-    auto stamp = [&]() {
-        if (a.stamps && tid == 0 && n_stamp < GK_STAMPS) a.stamps[(size_t)b * GK_STAMPS + n_stamp++] = wall_clock64();
-    };
-    stamp();
-
-    auto publish = [&](int which) {
-        pk_flush();
-        __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(&a.flags[((size_t)which * G + b) * GK_FLAG_STRIDE], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    // true = abandon the launch
-    auto wait = [&](int which, bool row_group) -> bool {
-        if (tid < 64) {
-            const int np = row_group ? K : R;
-            const int peer = tid < np ? (row_group ? i * K + tid : tid * K + j) : b;
-            const unsigned *f = &a.flags[((size_t)which * G + peer) * GK_FLAG_STRIDE];
-            long spins = 0;
-            int ab = 0;
-            for (;;) {
-                const unsigned v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const bool behind = tid < np && (int)(v - epoch) < 0;
-                if (__ballot(behind) == 0ull) break;
-                __builtin_amdgcn_s_sleep(1);
-                if (++spins > GK_SPIN_LIMIT) {
-                    if (tid == 0) __hip_atomic_store(a.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ab = 1;
-                    break;
-                }
-                if ((spins & 63) == 0 && __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ab = 1; break; }
-            }
-            if (tid == 0) s_abort = ab;
-        }
-        __syncthreads();
-        return s_abort != 0;
-    };
-
-    // One application of the EM map.  xv: my slab element of the vector the rows pass consumes (tid < 512), e_q / e_pres:
-    // the same element as the cols pass epilogue sees it (k_lutmatvec<COLS>: q_in, pres_in), tot: its S_TOT_A.
-    // Out: the whole result vector (element tid + 1024 k in vq[k], presence bit k of fq) and my slab element (eo, go).
-    auto apply = [&](double xv, double e_q, bool e_pres, double tot, bool init, double &eo, bool &go) -> bool {
-        ++epoch;
-        n_maps += 1.0;
-        const int par = (int)(epoch & 1u);
-        stamp();                                                   // 0: application starts
-        // rows pass over my block
-        if (slab_thread) xs[tid] = xv;
-        __syncthreads();
-        lut_build(xs, T, tid);
-        __syncthreads();
-        const double acc = lut_row_resident(T, wr);
-        double *part_r = a.part_r + (size_t)par * K * a.Cp;
-        if (n < a.Cp) pk_st(&part_r[(size_t)j * a.Cp + n], acc);
-        stamp();                                                   // 1: rows pass done
-        publish(0);
-        stamp();                                                   // 2: published
-        if (wait(0, true)) return true;
-        stamp();                                                   // 3: row group arrived
-        double w = 0.0;
-        if (n < a.C) {
-            double sp = 0.0;
-            for (int k0 = 0; k0 < K; k0 += 8) {       // eight loads in flight, added in slab order
-                double v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) v[k] = k0 + k < K ? pk_ld(&part_r[(size_t)(k0 + k) * a.Cp + n]) : 0.0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) sp += v[k];
-            }
-            w = sp > 0.0 ? cnt / sp : 0.0;
-        }
-        xs[tid] = w;
-        stamp();                                                   // 4: w_c
-        // cols pass: my chunk's two 512-class slabs, one table at a time
-        double accc = 0.0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            __syncthreads();
-            if (2 * i + h < nsc) {
-                lut_build(xs + h * LUT_SLAB, T, tid);
-                __syncthreads();
-                if (half == h) accc = lut_row_resident(T, wc);
-            }
-        }
-        double *part_c = a.part_c + (size_t)par * nsc * a.A;
-        if (cs_valid) pk_st(&part_c[(size_t)cslab * a.A + e], accc);
-        stamp();                                                   // 5: cols pass done
-        publish(1);
-        stamp();                                                   // 6: published
-        if (wait(1, false)) return true;
-        stamp();                                                   // 7: column group arrived
-        double *Yp = a.Y + ((size_t)par * R + i) * a.A;
-        if (slab_thread) {
-            double t = 0.0;
-            for (int s0 = 0; s0 < nsc; s0 += 16) {          // sixteen loads in flight, added in slab order
-                double v[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) v[k] = s0 + k < nsc ? pk_ld(&part_c[(size_t)(s0 + k) * a.A + e]) : 0.0;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) t += v[k];
-            }
-            const bool in = init || e_pres;
-            double v = 0.0;
-            if (in && t > 0.0) {
-                v = init ? t : (e_q / tot) * t;
-                if (a.len) v = v / len_e;
-            }
-            eo = v;
-            go = in && t > 0.0;
-            pk_st(&Yp[e], go ? v : -1.0);
-        }
-        stamp();                                                   // 8: slab reduced
-        publish(2);
-        stamp();                                                   // 9: published
-        const bool ab = wait(2, true);
-        stamp();                                                   // 10: row group arrived
-        return ab;
-    };
-    // the whole result vector of application `ep` (the last one or the one before it: both parities are intact until this
-    // workgroup publishes again): element tid + 1024 k in vq[k], presence bit k of fq
-    auto gather = [&](unsigned ep, double (&vq)[EK], unsigned &fq) {
-        const double *Yp = a.Y + ((size_t)(ep & 1u) * R + i) * a.A;
-        double y[EK];
-#pragma unroll
-        for (int k = 0; k < EK; ++k) { const int al = tid + BLOCK * k; y[k] = al < a.A ? pk_ld(&Yp[al]) : -1.0; }
-        fq = 0u;
-#pragma unroll
-        for (int k = 0; k < EK; ++k) {
-            vq[k] = y[k] >= 0.0 ? y[k] : 0.0;
-            if (y[k] >= 0.0) fq |= 1u << k;
-        }
-    };
-
-    // only the estimate stays in registers across the applications; q1 / q2 / q3 are gathered when a vector step needs them
-    double vp[EK];
-    unsigned f0 = 0u;
-    double e0 = 0.0, e1 = 0.0, eb = 0.0;
-    bool g0 = false, g1 = false, gb = false;
-    if (a.do_init) {
-        // initial mass sum_c n_c / |S_c| (common:1299-1309), normalised as k_em_init_norm does
-        if (apply(1.0, 0.0, true, 1.0, true, e0, g0)) return;
-        gather(epoch, vp, f0);
-        double s = 0.0;
-#pragma unroll
-        for (int k = 0; k < EK; ++k) if (f0 >> k & 1u) s += vp[k];
-        const double tot = block_sum(s, shm);
-#pragma unroll
-        for (int k = 0; k < EK; ++k) vp[k] = (f0 >> k & 1u) ? vp[k] / tot : 0.0;
-        e0 = g0 ? e0 / tot : 0.0;
-    } else {
-#pragma unroll
-        for (int k = 0; k < EK; ++k) {
-            const int al = tid + BLOCK * k;
-            const bool in = al < a.A;
-            vp[k] = in ? a.p[al] : 0.0;
-            if (in && a.pr[al]) f0 |= 1u << k;
-        }
-        if (slab_thread) { e0 = a.p[e]; g0 = a.pr[e] != 0; }
-    }
-    double st_flag = 0.0, st_diff = a.scal[S_DIFF], st_npres = a.scal[S_NPRES], st_key = 0.0, st_done = 0.0;
-    for (int it = 0; it < a.n_iters; ++it) {
-        // ---- q1 = T(p) (p used raw), q2 = T(q1 / sum q1) ----
-        if (apply(g0 ? e0 : 0.0, e0, g0, 1.0, false, e1, g1)) return;
-        double totn;
-        {
-            double vq[EK];
-            unsigned fq;
-            gather(epoch, vq, fq);
-            double s = 0.0;
-#pragma unroll
-            for (int k = 0; k < EK; ++k) if (fq >> k & 1u) s += vq[k];
-            totn = block_sum(s, shm);
-        }
-        if (apply((g1 ? e1 : 0.0) / totn, e1, g1, totn, false, eb, gb)) return;
-        double v1[EK], vb[EK];
-        unsigned f1, fb;
-        gather(epoch - 1u, v1, f1);
-        gather(epoch, vb, fb);
-        // ---- SQUAREM (common:1361-1380), arithmetic of k_em_squarem / k_lut_rows_fused<0> ----
-        double red[2] = {0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < EK; ++k) { if (f1 >> k & 1u) red[0] += v1[k]; if (fb >> k & 1u) red[1] += vb[k]; }
-        block_sum_n<2>(red, shf);
-        const double tot1 = red[0], tot2 = red[1];
-        double acc[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < EK; ++k) {
-            if (!(f0 >> k & 1u)) continue;
-            if (!(f1 >> k & 1u) || !(fb >> k & 1u)) { acc[2] = 1.0; continue; }
-            const double p1 = v1[k] / tot1, p2 = vb[k] / tot2;
-            const double r = p1 - vp[k];
-            const double v = p2 - p1 - r;
-            acc[0] += r * r;
-            acc[1] += v * v;
-        }
-        block_sum_n<3>(acc, shf);
-        const double tsr = acc[0], tsv = acc[1], tkey = acc[2];
-        const bool ext = tsv > 0.0 && tkey == 0.0;
-        st_flag = ext ? 1.0 : 0.0;
-        if (tkey != 0.0) { st_key = 1.0; st_done = 1.0; break; }
-        if (ext) {
-            const double g = -sqrt(tsr / tsv);
-            double val = eb;
-            bool present = gb;
-            if (g0) {
-                const double p1 = e1 / tot1, p2 = eb / tot2;
-                const double r = p1 - e0;
-                const double v = p2 - p1 - r;
-                val = fmax(0.0, e0 - 2 * g * r + g * g * v);
-                present = true;
-            }
-            if (apply(present ? val : 0.0, val, present, 1.0, false, eb, gb)) return;       // q3 = T(q2')
-            gather(epoch, vb, fb);
-        }
-        // ---- prob_diff (common:1272-1279), pruning (common:1338-1346), stopping rule (common:1351): k_em_advance ----
-        // the candidate is q3 if the extrapolation happened, else q1: from here on it is (vb, fb) / (eb, gb) either way
-        if (!ext) {
-#pragma unroll
-            for (int k = 0; k < EK; ++k) vb[k] = v1[k];
-            fb = f1; eb = e1; gb = g1;
-        }
-        double s1[1] = {0.0};
-#pragma unroll
-        for (int k = 0; k < EK; ++k) if (fb >> k & 1u) s1[0] += vb[k];
-        block_sum_n<1>(s1, shf);
-        const double tot = s1[0];
-        double d[1] = {0.0}, mx = 0.0;
-#pragma unroll
-        for (int k = 0; k < EK; ++k) {
-            const bool an = fb >> k & 1u;
-            const double pn = an ? vb[k] / tot : 0.0;
-            if (f0 >> k & 1u) d[0] += an ? fabs(vp[k] - pn) : vp[k];
-            if (an) mx = fmax(mx, pn);
-        }
-        const double tm = block_max(mx, shm);
-        block_sum_n<1>(d, shf);
-        const double td = d[0];
-        const bool prune = a.remove_low && iter >= 10;
-        double kept[1] = {0.0};
-        unsigned f_new = 0u;
-#pragma unroll
-        for (int k = 0; k < EK; ++k) {
-            const bool an = fb >> k & 1u;
-            const double pn = an ? vb[k] / tot : 0.0;
-            bool keep = an;
-            if (prune && keep) keep = pn >= tm / 10.0;
-            if (keep) { kept[0] += 1.0; f_new |= 1u << k; }
-            vp[k] = keep ? pn : 0.0;
-        }
-        f0 = f_new;
-        block_sum_n<1>(kept, shf);
-        {
-            const bool an = gb;
-            const double pn = an ? eb / tot : 0.0;
-            bool keep = an;
-            if (prune && keep) keep = pn >= tm / 10.0;
-            e0 = keep ? pn : 0.0;
-            g0 = keep;
-        }
-        st_npres = kept[0];
-        st_diff = td;
-        iter += 1;
-        if (!(td > 0.0001) || iter >= 1000) { st_done = 1.0; break; }
-    }
-    // ---- the state the following launches (tail, finish, another batch) read -----------------------------------
-    if (b == 0) {
-#pragma unroll
-        for (int k = 0; k < EK; ++k) {
-            const int al = tid + BLOCK * k;
-            if (al < a.A) { a.p[al] = vp[k]; a.pr[al] = (f0 >> k & 1u) ? 1 : 0; }
-        }
-        if (tid == 0) {
-            a.scal[S_ITER] = (double)iter;
-            a.scal[S_FLAG] = st_flag;
-            a.scal[S_DIFF] = st_diff;
-            a.scal[S_NPRES] = st_npres;
-            a.scal[S_TOT_A] = 1.0;
-            a.scal[S_NROWS] += n_maps;
-            a.scal[S_NCOLS] += n_maps;
-            if (st_key != 0.0) a.scal[S_KEYERR] = 1.0;
-            if (st_done != 0.0) a.scal[S_DONE] = 1.0;
-        }
-    }
-}
+[[maybe_unused]] constexpr size_t GK_LDS = (size_t)(LUT_G * 256 + BLOCK) * 8;
+#ifdef HGX_LAB
+#include "lab/hgx_em_grid.inc"            // the class matrix resident in registers, point-to-point hand-offs (HGX_EM_GRID): lab build only
+#endif
 
 // u64-element transpose: out[c][r] = in[r][c]  (in [n_rows][n_cols])
 __global__ __launch_bounds__(256) void k_word_transpose(const uint64_t *__restrict__ in, int n_rows, int n_cols,
@@ -3019,21 +2152,23 @@ template <int MODE>
 int launch_mfma(const MatVec &m, hipStream_t st, const double *vec, const uint8_t *vec_pres, int x_mode, const int64_t *count,
                 const double *q_in, const uint8_t *pres_in, const double *len, double *y, uint8_t *pres_out, double *scal,
                 int gate) {
-    static bool attr_set = false;
+#ifdef HGX_LAB
     const size_t lds = (size_t)MF_NP * MF_STRIDE;
-    if (!attr_set) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma_matvec<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
-        attr_set = true;
-    }
+    HGX_ONCE_PER_DEVICE({
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma_matvec<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    });
     const int grid = (m.n_rows + 16 * MF_WAVES - 1) / (16 * MF_WAVES);
     hipLaunchKernelGGL((k_mfma_matvec<MODE>), dim3(grid), dim3(MF_BLOCK), lds, st, m.P, m.n_rows, m.n_super, m.n_k, vec, vec_pres,
                        x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate);
     return HGX_OK;
+#else
+    hgx_set_error("this EM back-end is lab code: build libhgx_lab.so (hisat-genotype_amd/build.py build_lab) -- libhgx.so ships the table-lookup and reference-order paths only");
+    return HGX_EINVAL;
+#endif
 }
 
 inline int rows_per_block(int n_rows) {
-    static const int forced = getenv("HGX_RPB") ? atoi(getenv("HGX_RPB")) : 0;     // tuning aid
+    const int forced = hgx_test_switch("rpb") ? atoi(hgx_test_switch("rpb")) : 0;     // tuning aid
     if (forced >= RB && forced <= MAX_RPB && forced % RB == 0) return forced;
     int rpb = ((n_rows + 511) / 512 + RB - 1) / RB * RB;
     return std::max(RB, std::min(MAX_RPB, rpb));
@@ -3051,12 +2186,10 @@ int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint
         if (use_mfma(m))
             return launch_mfma<MODE>(m, st, vec, vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate);
         if (m.M) {
-            static bool attr_set = false;
-            if (!attr_set) {
+            HGX_ONCE_PER_DEVICE({
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lutmatvec<MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)LUT_LDS));
-                attr_set = true;
-            }
+            });
             if (g_ev_start) {
                 hipExtLaunchKernelGGL((k_lutmatvec<MODE>), dim3(m.n_words / 8, (m.n_rows + BLOCK - 1) / BLOCK), dim3(BLOCK), LUT_LDS, st,
                                       g_ev_start, g_ev_stop, 0, m.M, m.n_rows, m.n_pad, m.n_k, vec, vec_pres, x_mode, count, q_in, pres_in,
@@ -3272,6 +2405,9 @@ extern "C" int hgx_em_last_exact(void) { return g_last_exact; }
 
 extern "C" int hgx_em_set_backend(int backend) {
     ARGCHK(backend >= 0 && backend <= 3);
+#ifndef HGX_LAB
+    if (backend == 2) { hgx_set_error("this EM back-end is lab code: build libhgx_lab.so (hisat-genotype_amd/build.py build_lab) -- libhgx.so ships the table-lookup and reference-order paths only"); return HGX_EINVAL; }
+#endif
     g_backend = backend;
     return HGX_OK;
 }
@@ -3325,7 +2461,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         for (int a = 0; a < n_alleles; ++a) prob_host[a] = -1.0;
         return HGX_OK;
     }
-    if (C <= 64 && c->w64 <= 128 && !getenv("HGX_EM_NO_SMALL") && !getenv("HGX_EM_NO_WAVE")) {
+    if (C <= 64 && c->w64 <= 128 && !hgx_test_switch("em_no_small") && !hgx_test_switch("em_no_wave")) {
         // single-wavefront path (<= 64 classes over <= 64 distinct alleles); falls through if more alleles occur
         DevBuf b_len, b_scal, b_out;
         ALLOC(b_scal, S_N * 8); ALLOC(b_out, A * 8);
@@ -3346,7 +2482,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             h_first.resize(A);
         }
         DevBuf b_rank;
-        if (c->h_rank && !getenv("HGX_EM_NO_EXACT")) {
+        if (c->h_rank && !hgx_test_switch("em_no_exact")) {
             ALLOC(b_rank, (size_t)A * 4);
             { int rc_ = hgx_h2d(b_rank.p, c->h_rank, (size_t)A * 4, st); if (rc_) return rc_; }
         }
@@ -3372,7 +2508,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             return HGX_OK;
         }
     }
-    if (C <= HGX_EMX_MAX_CLASSES && c->w64 <= 128 && c->h_rank && !getenv("HGX_EM_NO_EXACT") && !getenv("HGX_EM_NO_EMX")) {
+    if (C <= HGX_EMX_MAX_CLASSES && c->w64 <= 128 && c->h_rank && !hgx_test_switch("em_no_exact") && !hgx_test_switch("em_no_emx")) {
         // problems of up to 4096 classes over up to 8192 distinct alleles in the reference's own order of operations
         // (k_emx, hgx_emx.hip: one workgroup, one launch, bit-identical abundances); falls through if it does not take the problem
         DevBuf b_rank, b_len;
@@ -3404,7 +2540,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         for (int a = 0; a < n_alleles; ++a) prob_host[a] = 0.0;
         if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = -1;
     }
-    if (C <= MR_C && c->w64 <= 128 && c->h_rank && !getenv("HGX_EM_NO_EXACT") && !getenv("HGX_EM_NO_MID")) {
+    if (C <= MR_C && c->w64 <= 128 && c->h_rank && !hgx_test_switch("em_no_exact") && !hgx_test_switch("em_no_mid")) {
         // mid-size problems in the reference's own order of operations (k_em_ref): one workgroup, one launch, bit-identical
         // abundances; falls through if more than MR_A distinct alleles occur
         DevBuf b_len, b_scal, b_out, b_first, b_rank, b_rm, b_km;
@@ -3426,14 +2562,12 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             HIPCHK(hipMemsetAsync(b_first.p, 0xFF, (size_t)A * 4, st));
             h_first.resize(A);
         }
-        static bool attr_set = false;
-        if (!attr_set) {
+        HGX_ONCE_PER_DEVICE({
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_ref), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MrLds)));
-            attr_set = true;
-        }
+        });
         DevBuf b_dbg;
-        const int max_nnz = getenv("HGX_EM_MID_NNZ") ? atoi(getenv("HGX_EM_MID_NNZ")) : 65536;
-        const bool stamps = getenv("HGX_MID_STAMPS") != nullptr;
+        const int max_nnz = hgx_test_switch("em_mid_nnz") ? atoi(hgx_test_switch("em_mid_nnz")) : 65536;
+        const bool stamps = hgx_test_switch("mid_stamps") != nullptr;
         if (stamps) ALLOC(b_dbg, 64);
         hipLaunchKernelGGL(k_em_ref, dim3(1), dim3(BLOCK), sizeof(MrLds), st, c->d_bits, C, c->w64, A, c->d_count, d_len, b_rank.as<int32_t>(),
                            remove_low ? 1 : 0, b_rm.as<uint64_t>(), b_km.as<uint64_t>(), b_out.as<double>(), b_scal.as<double>(),
@@ -3476,7 +2610,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         for (size_t i = 0; i < al.size(); ++i) first_host[al[i]] = f[i];
         return HGX_OK;
     };
-    if (C <= SMALL_C && A <= EPT * BLOCK && !getenv("HGX_EM_NO_SMALL")) {
+    if (C <= SMALL_C && A <= EPT * BLOCK && !hgx_test_switch("em_no_small")) {
         // single-workgroup path: one launch, one sync
         DevBuf b_len, b_scal, b_out;
         ALLOC(b_scal, S_N * 8); ALLOC(b_out, A * 8);
@@ -3489,12 +2623,10 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             d_len = b_len.as<double>();
         }
         const size_t lds = (size_t)C * c->w64 * 8;
-        static bool attr_set = false;
-        if (!attr_set) {
+        HGX_ONCE_PER_DEVICE({
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_small), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        SMALL_C * (EPT * BLOCK / 64) * 8));
-            attr_set = true;
-        }
+        });
         hipLaunchKernelGGL(k_em_small, dim3(1), dim3(BLOCK), lds, st, c->d_bits, C, c->w64, A, c->d_count, d_len, remove_low ? 1 : 0,
                            b_out.as<double>(), b_scal.as<double>());
         HIPCHK(hipGetLastError());
@@ -3543,6 +2675,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     }
     MatVec rows{c->d_bitsC, C, w64c, A};
     MatVec cols{c->d_bitsTC, A, c->c64, C};
+#ifdef HGX_LAB
     if (g_backend == 2 && A >= 512 && C >= 64) {
         // MFMA operand order of both matrices, built once per class set
         auto permute = [&](const uint64_t *Bm, int n_rows, int n_words, uint64_t **dst) -> int {
@@ -3562,6 +2695,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         rows.P = c->d_prow; rows.n_super = w64c / 4;
         cols.P = c->d_pcol; cols.n_super = c->c64 / 4;
     }
+#endif
 
     DevBuf b_part, b_part_c, b_cnt;
     if (g_backend == 0 || g_backend == 3) {
@@ -3580,13 +2714,14 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         HIPCHK(hipMemsetAsync(b_cnt.p, 0, n_cnt * 4, st));
         rows.M = c->d_wrow; rows.n_pad = Cp; rows.part = b_part.as<double>(); rows.counters = b_cnt.as<unsigned>();
         cols.M = c->d_wcol; cols.n_pad = A; cols.part = b_part_c.as<double>(); cols.counters = b_cnt.as<unsigned>();
-        if (!getenv("HGX_EM_PERSIST") && !getenv("HGX_EM_NO_DEFER")) {
+        if (!hgx_test_switch("em_persist") && !hgx_test_switch("em_no_defer")) {
             // the rows pass stops at its slab partials; the cols pass turns them into w_c in its prologue
             rows.defer_combine = 1;
             cols.src_part = rows.part; cols.src_slabs = w64c / 8; cols.src_pad = Cp; cols.src_count = c->d_count;
         }
     }
-    if (rows.M && getenv("HGX_EM_PERSIST")) {
+#ifdef HGX_LAB
+    if (rows.M && hgx_test_switch("em_persist")) {
         // ---- persistent path: whole iterations per launch (k_em_persist).  Opt-in: measured on MI355X it is not faster
         // than one launch per pass (a device-wide barrier across the 8 XCDs costs about what a kernel boundary costs,
         // ~5-8 us, and an iteration needs 10 of them plus 6 chunk tickets): 124 us vs 125 us per iteration. ----------
@@ -3621,7 +2756,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             int h_sync[4] = {0, 0, 0, 0};
             bool first = true, tail_done = false;
             double tail_failed_at = 1e300;
-            const bool use_tail = !getenv("HGX_EM_NO_TAIL");
+            const bool use_tail = !hgx_test_switch("em_no_tail");
             std::vector<Timed> timed;
             double *pu = nullptr;
             DevBuf b_pu;
@@ -3693,6 +2828,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             return HGX_OK;
         }
     }
+#endif
     // ---- resident-block path (k_em_grid): the block grid must be co-resident, one workgroup per CU ----------------
     // two resident grids that together need more CUs than the chip has could each hold a part and wait forever: grids reserve
     // their CUs from a process-wide budget and one that does not fit runs per pass instead
@@ -3707,9 +2843,10 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     bool grid = false;
     // opt-in (HGX_EM_GRID=1), or for small block grids only (HGX_EM_GRID_MAX workgroups: many small tasks in flight are bound by
     // the launch rate, and one launch replaces ~66)
-    static const int grid_small = getenv("HGX_EM_GRID_MAX") ? atoi(getenv("HGX_EM_GRID_MAX")) : 0;
+#ifdef HGX_LAB
+    const int grid_small = hgx_test_switch("em_grid_max") ? atoi(hgx_test_switch("em_grid_max")) : 0;
     const int grid_g = ((c->c64 * 64 + BLOCK - 1) / BLOCK) * (A / LUT_SLAB);
-    if (rows.M && rows.defer_combine && A <= EPT * BLOCK && !g_no_grid && (getenv("HGX_EM_GRID") || grid_g <= grid_small)) {
+    if (rows.M && rows.defer_combine && A <= EPT * BLOCK && !g_no_grid && (hgx_test_switch("em_grid") || grid_g <= grid_small)) {
         static int n_cu = 0, occ5 = 0, occ8 = 0;
         if (!n_cu) {
             int dev = 0;
@@ -3742,7 +2879,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             ga.part_r = b_gpr.as<double>(); ga.part_c = b_gpc.as<double>(); ga.Y = b_gy.as<double>();
             ga.flags = b_gfl.as<unsigned>(); ga.abort_flag = (int *)(b_gfl.as<unsigned>() + (size_t)3 * G * GK_FLAG_STRIDE);
             ga.remove_low = remove_low ? 1 : 0;
-            if (getenv("HGX_GRID_STAMPS")) {
+            if (hgx_test_switch("grid_stamps")) {
                 ALLOC(b_gst, (size_t)G * GK_STAMPS * 8);
                 HIPCHK(hipMemsetAsync(b_gst.p, 0, (size_t)G * GK_STAMPS * 8, st));
                 ga.stamps = b_gst.as<unsigned long long>();
@@ -3750,6 +2887,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             grid = true;
         }
     }
+#endif
     int grid_launches = 0;
     std::vector<Timed> timed;
     const int slot_rows = A <= 8 * BLOCK ? 0 : 1, slot_cols = C <= 8 * BLOCK ? 2 : 3;
@@ -3802,9 +2940,9 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     int launched_iters = 0;
     double tail_failed_at = 1e300;
     bool tail_done = false;
-    const bool use_tail = !getenv("HGX_EM_NO_TAIL");
+    const bool use_tail = !hgx_test_switch("em_no_tail");
     // ---- fused vector steps (k_lut_rows_fused): ping-pong estimate, extrapolated vector and state words -----------
-    const bool fuse = rows.defer_combine && A <= EPT * BLOCK && !getenv("HGX_EM_NO_FUSE");
+    const bool fuse = rows.defer_combine && A <= EPT * BLOCK && !hgx_test_switch("em_no_fuse");
     DevBuf b_palt, b_pralt, b_q2x, b_prx, b_scal2;
     double *p_alt = nullptr, *q2x = nullptr, *scal_alt = nullptr;
     uint8_t *pr_alt = nullptr, *prx = nullptr;
@@ -3812,14 +2950,12 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         ALLOC(b_palt, A * 8); ALLOC(b_pralt, A); ALLOC(b_q2x, A * 8); ALLOC(b_prx, A); ALLOC(b_scal2, S_N * 8);
         p_alt = b_palt.as<double>(); pr_alt = b_pralt.as<uint8_t>(); q2x = b_q2x.as<double>(); prx = b_prx.as<uint8_t>();
         scal_alt = b_scal2.as<double>();
-        static bool attr_set = false;
-        if (!attr_set) {
+        HGX_ONCE_PER_DEVICE({
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut_rows_fused<0>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)LUT_LDS));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut_rows_fused<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)LUT_LDS));
-            attr_set = true;
-        }
+        });
     }
     auto rows_fused = [&](int fm, const double *qb, const uint8_t *prb, double *out_v, uint8_t *out_p) -> int {
         FuseArgs fz{q1, qb, pr1, prb, out_v, out_p, scal, scal_alt, remove_low ? 1 : 0};
@@ -3849,6 +2985,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             HIPCHK(hipMemsetAsync(b_gfl.p, 0, ((size_t)3 * G * GK_FLAG_STRIDE + 32) * 4, st));
             Timed t{nullptr, nullptr, 4};
             if (g_timing) { t.a = pool_event(); t.b = pool_event(); timed.push_back(t); }
+#ifdef HGX_LAB
             if (A <= 5 * BLOCK) {
                 if (t.a) hipExtLaunchKernelGGL(k_em_grid<5>, dim3(G), dim3(BLOCK), GK_LDS, st, t.a, t.b, 0, ga);
                 else hipLaunchKernelGGL(k_em_grid<5>, dim3(G), dim3(BLOCK), GK_LDS, st, ga);
@@ -3856,6 +2993,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
                 if (t.a) hipExtLaunchKernelGGL(k_em_grid<8>, dim3(G), dim3(BLOCK), GK_LDS, st, t.a, t.b, 0, ga);
                 else hipLaunchKernelGGL(k_em_grid<8>, dim3(G), dim3(BLOCK), GK_LDS, st, ga);
             }
+#endif
             HIPCHK(hipGetLastError());
         }
         for (int b = 0; b < (grid ? 0 : nb); ++b) {
@@ -4020,11 +3158,11 @@ extern "C" int hgx_em_masked(const hgx_classes *cc, const uint64_t *mask_host, i
             if (a < n_alleles) al.push_back(a);
         }
     if (al.empty()) return HGX_OK;
-    if (al.size() <= 64 && !getenv("HGX_EM_NO_MASKED")) {
+    if (al.size() <= 64 && !hgx_test_switch("em_no_masked")) {
         const int A1 = (int)al.size();
         // with the alleles' name order at hand the kept alleles go up in that order (= their order inside a class key), and the
         // single-wavefront EM follows the reference's summation order exactly
-        const bool exact = cc->h_rank != nullptr && !getenv("HGX_EM_NO_EXACT");
+        const bool exact = cc->h_rank != nullptr && !hgx_test_switch("em_no_exact");
         if (exact) std::sort(al.begin(), al.end(), [&](int32_t x, int32_t y) { return cc->h_rank[x] < cc->h_rank[y]; });
         // one staging struct each way: [al | len] up, [scal | ticket | out | first] down (one copy + one memset + one copy)
         struct Up { int32_t al[64]; double len[64]; } up;
@@ -4283,7 +3421,7 @@ extern "C" int hgx_allele_counts_on(const hgx_classes *cc, int64_t *count_host, 
         for (int a = 0; a < A; ++a) { count_host[a] = 0; first_host[a] = -1; }
         return HGX_OK;
     }
-    if (!getenv("HGX_COUNTS_MATVEC")) {
+    if (!hgx_test_switch("counts_matvec")) {
         const int C = c->n_classes;
         DevBuf b_cnt, b_first, b_big, b_cp, b_fp;
         ALLOC(b_cnt, (size_t)A * 8); ALLOC(b_first, (size_t)A * 4); ALLOC(b_big, 16);
@@ -4345,6 +3483,7 @@ extern "C" int hgx_debug_matvec(const hgx_classes *cc, int which, int backend, c
     HIPCHK(hipMemcpy(b_scal.as<double>() + S_TOT_A, &one, 8, hipMemcpyHostToDevice));
     MatVec m = which == 0 ? MatVec{c->d_bits, C, c->w64, A} : MatVec{c->d_bitsT, A, c->c64, C};
     DevBuf b_P;
+#ifdef HGX_LAB
     if (backend == 2) {
         const int n_super = m.n_words / 4;
         const long tiles = (m.n_rows + 15) / 16;
@@ -4356,6 +3495,9 @@ extern "C" int hgx_debug_matvec(const hgx_classes *cc, int which, int backend, c
         m.P = b_P.as<uint64_t>();
         m.n_super = n_super;
     }
+#else
+    if (backend == 2) { hgx_set_error("hgx_dbg_matvec: back-end 2 is lab code (libhgx_lab.so)"); return HGX_EINVAL; }
+#endif
     DevBuf b_M, b_part, b_cnt;
     if (backend == 3) {
         ALLOC(b_M, (size_t)m.n_words * m.n_rows * 8);
@@ -4368,7 +3510,7 @@ extern "C" int hgx_debug_matvec(const hgx_classes *cc, int which, int backend, c
     }
     const int saved = g_backend;
     g_backend = backend;
-    const int reps = getenv("HGX_DBG_REPS") ? atoi(getenv("HGX_DBG_REPS")) : 1;
+    const int reps = hgx_test_switch("dbg_reps") ? atoi(hgx_test_switch("dbg_reps")) : 1;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, nullptr);

@@ -899,15 +899,11 @@ extern "C" int hgx_emx_get_timing(int fast, double *ms, long long *launches, lon
 int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs_out) {
     ARGCHK(jobs && n_jobs >= 0);
     if (n_jobs == 0) return HGX_OK;
-    static bool attr_set[64] = {};
-    int dev = 0;
-    HIPCHK(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    HGX_ONCE_PER_DEVICE({
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
-        attr_set[dev] = true;
-    }
-    const bool stamps = getenv("HGX_EMX_STAMPS") != nullptr;
+    });
+    const bool stamps = hgx_test_switch("emx_stamps") != nullptr;
     // scratch of every job out of ONE block; jobs beyond the kernel's limits get status 1 without a descriptor
     struct Lay { size_t Rm, Mk, Mr, dv, pos, tmpv, vlen, cls, din, sorted, first, stamps, end; };
     std::vector<Lay> lays;

@@ -1,6 +1,9 @@
 // hgx_host.cpp -- host side of libhgx: locus tables (8a-0) and haplotype -> piece-mask reduction
 // (the host half of add_count, typing_core.py:626-677).  Plain C++; no device code here.
 #include <algorithm>
+#include <atomic>
+#include <mutex>
+#include <string>
 #include <cstring>
 #include <map>
 
@@ -437,6 +440,30 @@ extern "C" int hgx_batch_arrays(const hgx_batch *b, const hgx_piece **pieces, co
     return HGX_OK;
 }
 
+
+// ---- test hooks (hgx.h: hgx_test_switch_set) --------------------------------------------------------------------
+// Path-forcing switches of the test-suite and the lab tools (a kernel kept for comparison, a size threshold moved so that a
+// small case reaches the large-problem path).  They live in the process, not in the environment: a product run cannot pick one up
+// by accident, and the query is one relaxed load while none is set.
+namespace {
+std::mutex g_sw_mu;
+std::map<std::string, std::string> g_sw;          // values are never erased while set: c_str() stays valid for the caller
+std::atomic<int> g_sw_n{0};
+}
+extern "C" const char *hgx_test_switch(const char *name) {
+    if (g_sw_n.load(std::memory_order_relaxed) == 0) return nullptr;
+    std::lock_guard<std::mutex> g(g_sw_mu);
+    auto it = g_sw.find(name);
+    return it == g_sw.end() ? nullptr : it->second.c_str();
+}
+extern "C" int hgx_test_switch_set(const char *name, const char *value) {
+    std::lock_guard<std::mutex> g(g_sw_mu);
+    if (!name) g_sw.clear();
+    else if (!value) g_sw.erase(name);
+    else g_sw[name] = value;
+    g_sw_n.store((int)g_sw.size(), std::memory_order_relaxed);
+    return HGX_OK;
+}
 
 // ---- host block pool (declared in hgx_internal.hpp) ------------------------------------------------------------
 #include <map>

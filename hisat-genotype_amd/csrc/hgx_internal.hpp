@@ -12,6 +12,7 @@
 #include "hgx.h"
 
 extern "C" void hgx_set_error(const char *fmt, ...);
+extern "C" const char *hgx_test_switch(const char *name);
 
 #define HARGCHK(cond)                                                                  \
     do {                                                                               \

@@ -250,7 +250,7 @@ int gene_side(const hgx_index *ix, const hgx_dbatch *db, const uint64_t *compat,
     int32_t A = 0, a_pad = 0;
     int rc = hgx_index_dims(ix, &A, &a_pad, nullptr, nullptr);
     if (rc) return rc;
-    if (!rows_ready && getenv("HGX_FUSED")) {
+    if (!rows_ready && hgx_test_switch("fused")) {
         // OPT-IN (measured slower): rows claimed / verified against their class' representative by the wavefront
         // that computes them -- no row per pair in memory, no insert pass, no verify pass (hgx_pair_classes_dedup); a key
         // collision falls through to the two-call form
@@ -417,7 +417,7 @@ int type_impl(hgx_typing *t, const hgx_locus *loc, const hgx_index *ix, const hg
     const int w64 = a_pad / 64;
     const bool hla = loc->base_kind == HGX_BASE_HLA;
     const int32_t n_pairs = db->n_pairs;
-    const bool by_list = hla && !opts->per_pair_exon && !getenv("HGX_NO_SIG");
+    const bool by_list = hla && !opts->per_pair_exon && !hgx_test_switch("no_sig");
     bool overlap = opts->overlap < 0 ? stream == nullptr : opts->overlap != 0;
     overlap = overlap && hla && n_pairs >= 4096;
 

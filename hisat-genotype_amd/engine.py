@@ -352,7 +352,30 @@ def em_get_timing():
     return out
 
 
+def test_switch(name, value="1"):
+    """Test hook (hgx.h hgx_test_switch_set): set (value a string) or clear (value None) a named path-forcing switch;
+    name None clears all.  The library reads no path-selecting environment variable."""
+    capi.check(capi.lib().hgx_test_switch_set(None if name is None else name.encode(),
+                                              None if value is None else str(value).encode()))
+
+
+class test_switches:
+    """with engine.test_switches(em_no_small=1): ...  -- switches set inside the block, cleared after it"""
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            test_switch(k, v)
+        return self
+
+    def __exit__(self, *exc):
+        for k in self.kw:
+            test_switch(k, None)
+        return False
+
+
 def em_set_backend(backend):
-    """0 = auto (table lookup), 1 = EXEC-masked FP64 VALU mat-vec, 2 = int8 MFMA mat-vec (128-bit fixed point),
-    3 = table-lookup mat-vec (256 subset sums per 8 columns in LDS)."""
+    """0 = auto (table lookup), 1 = EXEC-masked FP64 VALU mat-vec, 3 = table-lookup mat-vec (256 subset sums per 8 columns in
+    LDS); 2 = int8 MFMA mat-vec (128-bit fixed point), lab build only (capi.use_lab())."""
     capi.check(capi.lib().hgx_em_set_backend(C.c_int(backend)))

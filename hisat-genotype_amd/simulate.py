@@ -295,8 +295,24 @@ def truth_align(read_fname, out_fname, Genes, Vars, refGenes):
             tags = ["NM:i:%d" % nm, "MD:Z:%s" % md] + (["Zs:Z:%s" % zs] if zs else []) + ["NH:i:1", "YT:Z:%s" % ("CP" if paired else "UU")]
             lines.append("\t".join([qname, str(flag), refGenes[gene], str(pos0 + 1), "60", cigar, "=" if paired else "*",
                                     str(mate_pos + 1) if paired else "0", "0", seq, "I" * len(seq)] + tags))
-    with open(out_fname, "w") as f:
-        f.write("\n".join(lines) + "\n")
+    _store_as_the_reference_does(out_fname, "\n".join(lines) + "\n")
+
+
+def _store_as_the_reference_does(out_fname, sam_text):
+    """The reference pipes the aligner through `samtools view -bS - | samtools sort` (typing_common.py:1038-1051): the
+    alignment file it later reads (`samtools view F | sort -k1,1 -s`, typing_core.py:458-468) is a COORDINATE-sorted BAM, so the
+    records of one read name -- mates, secondary hits -- reach the decode loop in coordinate order, not in the aligner's
+    (ADVICE r2).  Same here: the SAM text becomes a coordinate-sorted BAM (libhgx's writer; no samtools)."""
+    from . import bamio
+    refs = []
+    for line in sam_text.split("\n"):
+        if not line.startswith("@"):
+            break
+        if line.startswith("@SQ"):
+            f = dict(t.split(":", 1) for t in line.split("\t")[1:] if ":" in t)
+            refs.append((f["SN"], int(f["LN"])))
+    body = "\n".join(l for l in sam_text.split("\n") if l and not l.startswith("@")) + "\n"
+    bamio.write_bam_native(out_fname, body, refs, sort_by_coordinate=True)
 
 
 def align_reads(aligner, simulation, index_name, index_type, base_fname, read_fname, fastq, threads, out_fname, verbose,
@@ -323,8 +339,11 @@ def align_reads(aligner, simulation, index_name, index_type, base_fname, read_fn
         cmd += ["-U", read_fname[0]] if len(read_fname) == 1 else ["-1", read_fname[0], "-2", read_fname[1]]
         if verbose >= 1:
             print(" ".join(cmd), file=sys.stderr)
-        with open(out_fname, "w") as out, open(os.devnull, "w") as null:
+        with open(out_fname + ".sam", "w") as out, open(os.devnull, "w") as null:
             subprocess.check_call(cmd, stdout=out, stderr=null)
+        with open(out_fname + ".sam") as f:
+            _store_as_the_reference_does(out_fname, f.read())
+        os.remove(out_fname + ".sam")
         return
     if simulation and truth is not None:
         truth_align(read_fname, out_fname, *truth)

@@ -485,8 +485,15 @@ int hgx_type_many_loci(int32_t n_loci, hgx_typing ***out, int32_t **rc_out_or_nu
  * restarts the per-thread totals; 0 switches it off and keeps them.  Slots 0/1 = rows pass (vector of <= 8192 / more elements),
  * 2/3 = cols pass (k_lutmatvec<0> / <1> with the default backend).  `executed` counts the plain passes that ran while timing was
  * on (device-side counter) and bytes_total the algorithmic bytes of the timed ones (bit matrix once + dense vectors).       */
-/* mat-vec backend of hgx_em: 0 = auto (table lookup), 1 = EXEC-masked FP64 VALU kernel, 2 = int8 MFMA kernel,
- * 3 = table-lookup kernel (256 subset sums per 8 matrix columns in LDS; one lookup per 8 matrix bits) */
+/* Test hook.  The library reads no path-selecting environment variable: the test-suite forces an alternative path (a kernel kept
+ * for comparison, a threshold moved so a small case reaches the large-problem code) with named in-process switches.  name = NULL
+ * clears all, value = NULL clears one.  The names are listed in DESIGN.md ("switches"); none changes results beyond what the
+ * test that uses it states.  Environment variables the library does read: HGX_THREADS, HGX_PIN, HGX_THP, HGX_NO_LIBDEFLATE
+ * (host tuning) and HGX_PARSE_PROFILE, HGX_TYPE_PROFILE (timing prints on stderr).                                            */
+int hgx_test_switch_set(const char *name, const char *value);
+/* mat-vec backend of hgx_em: 0 = auto (table lookup), 1 = EXEC-masked FP64 VALU kernel, 3 = table-lookup kernel (256 subset
+ * sums per 8 matrix columns in LDS; one lookup per 8 matrix bits); 2 = int8 MFMA kernel, in the lab build only (libhgx_lab.so,
+ * -DHGX_LAB: the MFMA, persistent and resident-grid EM back-ends measured in rounds 1-2 and kept out of the product library) */
 int hgx_em_set_backend(int backend);
 /* test aid: one rows pass (which = 0: y[c] = count[c] / sum_a B[c][a] x[a]) or cols pass (which = 1: y[a] = sum_c
  * B[c][a] x[c]) with backend 1 or 2; x and y are host arrays of a_pad / n_classes doubles                        */

@@ -19,3 +19,12 @@ def pytest_configure(config):
 def orc():
     import orclib
     return orclib.load()
+
+
+@pytest.fixture(autouse=True)
+def _clear_test_switches():
+    """Path-forcing switches (engine.test_switch) never outlive the test that set them."""
+    yield
+    from hisatgenotype_amd import capi
+    if capi._lib is not None:
+        capi._lib.hgx_test_switch_set(None, None)

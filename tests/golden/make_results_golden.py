@@ -68,6 +68,10 @@ def main():
     cases = dict(HAND)
     for name in ("hla_mid_real", "hla_small_pair", "hla_7000", "codis_like"):
         cases["fixture_" + name] = gu.load(name)["report"]
+    # the 13 reports the reference itself holds as expected outputs of its integration runs (devel/hg_test1..5: data, not source)
+    import glob
+    for path in sorted(glob.glob(os.path.join(REF, "devel", "hg_test*", "*.report"))):
+        cases["devel_%s_%s" % (os.path.basename(os.path.dirname(path)), os.path.basename(path).split(".")[1])] = open(path).read()
     out = {}
     for name, text in cases.items():
         d = tempfile.mkdtemp()

@@ -1,0 +1,107 @@
+"""Lab build only (libhgx_lab.so, -DHGX_LAB): the opt-in EM back-ends of rounds 1-2 -- int8-MFMA mat-vec, persistent kernel,
+resident-grid kernel (csrc/lab/*.inc) -- against the product's default path.  Not collected by the suite itself (the product
+library is what the suite's process has loaded): tests/test_gpu_lab.py runs this file with pytest in a child process."""
+import numpy as np
+import pytest
+
+import golden_util as gu
+import tables
+from hisatgenotype_amd import capi, engine, locus as hl
+
+capi.use_lab()
+
+
+def _setup(name):
+    fx = gu.load(name)
+    loc = fx["_locus"]
+    return fx, tables.oracle_tables(loc), hl.PackedLocus.from_synth(loc)
+
+
+@pytest.mark.parametrize("name", ["hla_7000", "hla_mid_real"])
+def test_em_backends_agree(name):
+    """The int8-MFMA mat-vec (exact integer accumulation of 128-bit fixed-point planes) and the table-lookup mat-vec
+    (256 subset sums per group of 8 columns, one LDS lookup per 8 matrix bits) against the EXEC-masked FP64 VALU mat-vec:
+    same iteration counts, abundances equal to rounding, on the reference's recorded EM inputs and on a big random one."""
+    fx, t, pl = _setup(name)
+    A = t["n_alleles"]
+    w = (A + 63) // 64
+    cases = []
+    for em in fx["em"]:
+        rows = np.zeros((len(em["cmpt"]), pl.w64), np.uint64)
+        for k, (cid, n) in enumerate(em["cmpt"]):
+            rows[k, :w] = gu.class_bits(fx, cid, A)
+        cases.append((rows, np.array([n for _, n in em["cmpt"]], np.int64), em["remove_low"], em["use_length"]))
+    rng = np.random.RandomState(9)
+    big = np.zeros((3000, pl.w64), np.uint64)
+    dens = rng.choice([0.002, 0.05, 0.6], size=3000)
+    for k in range(3000):
+        m = rng.rand(A) < dens[k]
+        m[rng.randint(A)] = True
+        big[k, :w] = np.packbits(np.pad(m, (0, 64 * w - A)), bitorder="little").view(np.uint64)
+    cases.append((big, rng.randint(1, 500, 3000).astype(np.int64), True, False))
+    cases.append((big, rng.randint(1, 500, 3000).astype(np.int64), False, True))
+    try:
+        for rows, counts, low, use_len in cases:
+            cl = engine.Classes.from_host(rows, counts, pl.a_pad)
+            ln = pl.allele_len if use_len else None
+            engine.em_set_backend(1)
+            p1, it1 = cl.em(A, low, ln)
+            import os
+            for backend, persist in ((2, False), (3, False), (3, True)):   # int8 MFMA; table lookup: one launch per pass / persistent kernel
+                engine.em_set_backend(backend)
+                if persist:
+                    engine.test_switch("em_persist", "1")
+                try:
+                    p2, it2 = cl.em(A, low, ln)
+                finally:
+                    engine.test_switch("em_persist", None)
+                assert it1 == it2, (backend, persist, it1, it2)
+                assert np.array_equal(p1 < 0, p2 < 0)
+                assert np.max(np.abs(p1 - p2)) <= 1e-11, (backend, persist, np.max(np.abs(p1 - p2)))
+    finally:
+        engine.em_set_backend(0)
+
+
+def test_em_grid_equals_per_pass():
+    """The resident-block EM (k_em_grid, opt-in: matrix blocks in registers for the whole launch, point-to-point flagged hand-offs between
+    the workgroups of a class chunk / an allele slab) keeps the summation orders of the one-launch-per-pass kernels: abundances
+    BIT-identical, same iteration counts, over block grids from 1 x 1 to 17 x 14, ragged last chunks and slabs, with and
+    without pruning and allele lengths; a grid that does not fit the chip falls back to the per-pass path."""
+    import os
+    rng = np.random.RandomState(77)
+    shapes = [(70, 300, 512), (1100, 700, 1024), (2500, 1500, 1536), (3000, 7000, 7168), (9000, 2600, 3072), (17000, 7000, 7168),
+              (16098, 4549, 7168), (21000, 7000, 7168)]
+    ran_grid = 0
+    for C_, A, a_pad in shapes:
+        w = a_pad // 64
+        rows = np.zeros((C_, w), np.uint64)
+        # classes the way typing produces them: a few allele "families", every class a family minus/plus some alleles
+        fam = rng.rand(12, A) < rng.choice([0.02, 0.2, 0.7], size=12)[:, None]
+        pick = rng.randint(0, 12, C_)
+        flip = rng.rand(C_, A) < 0.01
+        m = fam[pick] ^ flip
+        m[np.arange(C_), rng.randint(0, A, C_)] = True
+        rows[:, :] = np.packbits(np.pad(m, ((0, 0), (0, a_pad - A))), axis=1, bitorder="little").view(np.uint64).reshape(C_, w)
+        counts = rng.randint(1, 400, C_).astype(np.int64)
+        lens = rng.randint(2000, 3500, a_pad).astype(np.int32)
+        cl = engine.Classes.from_host(rows, counts, a_pad)
+        for low, use_len in ((True, False), (False, True), (True, True)):
+            ln = lens if use_len else None
+            p_ref, it_ref = cl.em(A, low, ln)
+            engine.em_set_timing(0)
+            engine.em_set_timing(1)
+            engine.test_switch("em_grid", "1")
+            try:
+                p, it = cl.em(A, low, ln)
+            finally:
+                engine.test_switch("em_grid", None)
+            launches = engine.em_get_timing()["k_em_grid"][1]
+            engine.em_set_timing(0)
+            ran_grid += launches > 0
+            assert it == it_ref, (C_, A, low, use_len, it, it_ref)
+            assert np.array_equal(p, p_ref), (C_, A, low, use_len, float(np.max(np.abs(p - p_ref))))
+            if C_ > 64 and C_ <= 9000:                      # (the biggest grids need 224 / 238 of the chip's CUs: taken when they fit)
+                assert launches > 0, (C_, A)
+            if C_ == 21000:
+                assert launches == 0
+    assert ran_grid >= 9

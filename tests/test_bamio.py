@@ -372,7 +372,8 @@ def test_bam_record_chain_walked_in_ranges_is_exact(tmp_path, monkeypatch):
     and the result is still exactly the real records."""
     import struct
     from hisatgenotype_amd.typing import read_alignment_text
-    monkeypatch.setenv("HGX_BAM_CHAIN_MIN", "0")
+    from hisatgenotype_amd import engine
+    engine.test_switch("bam_chain_min", "0")
     fx = gu.load("hla_mid_real")
     loc = fx["_locus"]
     path = str(tmp_path / "mid.bam")

@@ -194,11 +194,11 @@ def test_piece_compat_any_piece_order(orc, name):
         d_p = engine.DevArray.from_host(np.ascontiguousarray(pieces))
         a = engine.DevArray((batch.n_pieces, pl.w64), np.uint64)
         if untiled:
-            os.environ["HGX_PIECE_UNTILED"] = "1"          # the kernel that reads the index rows straight from L2
+            engine.test_switch("piece_untiled", "1")          # the kernel that reads the index rows straight from L2
         try:
             capi.check(L.hgx_piece_compat(pl.index(), capi.ptr(d_p), capi.ptr(d_masks), C.c_int32(batch.n_pieces), capi.ptr(a), None))
         finally:
-            os.environ.pop("HGX_PIECE_UNTILED", None)
+            engine.test_switch("piece_untiled", None)
         out.append(a.to_host())
     assert np.array_equal(out[0][perm], out[1])
     assert np.array_equal(out[0], out[2])
@@ -219,14 +219,15 @@ def test_em_ordered_and_first_classes_match_counts_pass(orc, name):
     _, first_full = cl.allele_counts()
     some = np.random.RandomState(2).choice(A, min(A, 40), replace=False).astype(np.int32)
     assert np.array_equal(cl.first_classes(some), first_full[some])
-    for env in ({}, {"HGX_EM_NO_WAVE": "1"}, {"HGX_EM_NO_SMALL": "1"}):
-        os.environ.update(env)
+    for env in ({}, {"em_no_wave": "1"}, {"em_no_small": "1"}):
+        for k, v in env.items():
+            engine.test_switch(k, v)
         try:
             prob, first, it = cl.em_ordered(A, True, None)
             prob2, it2 = cl.em(A, True, None)
         finally:
             for k in env:
-                os.environ.pop(k, None)
+                engine.test_switch(k, None)
         assert it == it2 and np.array_equal(prob, prob2)
         present = prob >= 0
         assert present.any()
@@ -347,13 +348,14 @@ def test_em_masked_equals_dedup_then_em(orc, name):
         d_mask = engine.DevArray.from_host(mask)
         sub = engine.Classes.dedup(engine._RawDev(gb), gcl.n_classes, pl.a_pad, weights=engine._RawDev(gc), and_mask=d_mask)
         p_ref, f_ref, it_ref = sub.em_ordered(A, True, pl.allele_len)
-        for env in ({}, {"HGX_EM_NO_MASKED": "1"}):
-            os.environ.update(env)
+        for env in ({}, {"em_no_masked": "1"}):
+            for k, v in env.items():
+                engine.test_switch(k, v)
             try:
                 p, f, it, nc = gcl.em_masked(mask, A, True, pl.allele_len)
             finally:
                 for k in env:
-                    os.environ.pop(k, None)
+                    engine.test_switch(k, None)
             assert it == it_ref and nc == sub.n_classes, (n_keep, env, it, it_ref, nc, sub.n_classes)
             assert np.array_equal(p < 0, p_ref < 0)
             assert np.max(np.abs(p - p_ref)) <= 1e-12
@@ -396,11 +398,11 @@ def test_em_single_workgroup_path_equals_multi_launch_path(orc):
     cl = engine.Classes.from_host(rows, uc[:40], pl.a_pad)
     for low, ln in ((False, None), (True, pl.allele_len), (True, None)):
         p_small, it_small = cl.em(A, low, ln)
-        os.environ["HGX_EM_NO_SMALL"] = "1"
+        engine.test_switch("em_no_small", "1")
         try:
             p_big, it_big = cl.em(A, low, ln)
         finally:
-            del os.environ["HGX_EM_NO_SMALL"]
+            engine.test_switch("em_no_small", None)
         assert it_small == it_big
         assert np.array_equal(p_small < 0, p_big < 0)
         assert np.max(np.abs(p_small - p_big)) <= 1e-12
@@ -438,11 +440,11 @@ def test_em_single_wavefront_path_matches_oracle_and_other_paths(orc):
             except KeyError:
                 continue
             p_w, it_w = cl.em(A, low, ln)
-            os.environ["HGX_EM_NO_WAVE"] = "1"
+            engine.test_switch("em_no_wave", "1")
             try:
                 p_s, it_s = cl.em(A, low, ln)
             finally:
-                del os.environ["HGX_EM_NO_WAVE"]
+                engine.test_switch("em_no_wave", None)
             assert it_w == oit == it_s, (trial, it_w, oit, it_s)
             exp = np.full(A, -1.0)
             exp[oa] = op
@@ -454,7 +456,7 @@ def test_em_single_wavefront_path_matches_oracle_and_other_paths(orc):
 def test_em_mid_size_in_reference_order_is_bit_identical(orc):
     """65 ... 2048 classes over hundreds to thousands of distinct alleles in the reference's own order of operations (k_emx,
     hgx_emx.hip, since round 3: up to 4096 classes x 8192 alleles; k_em_ref, round 2's one-workgroup kernel for <= 1024 alleles,
-    is still reachable with HGX_EM_NO_EMX=1): abundances `==` the C oracle's (which the golden vectors pin to the real
+    is still reachable with the test switch em_no_emx): abundances `==` the C oracle's (which the golden vectors pin to the real
     reference), same iteration counts, with pruning, with allele lengths, with alleles scattered over a wide index range and an
     arbitrary name order.  The table-lookup path on the same problems (both switched off) agrees to 1e-9."""
     import os
@@ -495,20 +497,20 @@ def test_em_mid_size_in_reference_order_is_bit_identical(orc):
             assert np.array_equal(p, exp), (A, n_used, C_, low, float(np.max(np.abs(p - exp))))
             ran_exact += 1
             if n_used <= 1024:                                 # round 2's kernel on the same problem: the same doubles
-                os.environ["HGX_EM_NO_EMX"] = "1"
-                os.environ["HGX_EM_MID_NNZ"] = "100000000"
+                engine.test_switch("em_no_emx", "1")
+                engine.test_switch("em_mid_nnz", "100000000")
                 try:
                     p1, it1 = cl.em(A, low, ln)
                     assert engine.em_last_exact() and it1 == it and np.array_equal(p1, p)
                 finally:
-                    del os.environ["HGX_EM_NO_EMX"], os.environ["HGX_EM_MID_NNZ"]
-            os.environ["HGX_EM_NO_EMX"] = "1"                  # the table-lookup path: close, not identical
-            os.environ["HGX_EM_NO_MID"] = "1"
+                    engine.test_switch("em_no_emx", None); engine.test_switch("em_mid_nnz", None)
+            engine.test_switch("em_no_emx", "1")                  # the table-lookup path: close, not identical
+            engine.test_switch("em_no_mid", "1")
             try:
                 p2, it2 = cl.em(A, low, ln)
                 assert not engine.em_last_exact()
             finally:
-                del os.environ["HGX_EM_NO_EMX"], os.environ["HGX_EM_NO_MID"]
+                engine.test_switch("em_no_emx", None); engine.test_switch("em_no_mid", None)
             assert it2 == it and np.max(np.abs(p2 - p)) <= 1e-9
     assert ran_exact >= 15
 
@@ -538,107 +540,17 @@ def test_em_compact_tail_equals_full_iterations(orc):
         for low, ln in ((True, None), (True, lengths)):
             oa, op, oit = orc.single_abundance(A, classes, counts, low, ln)
             p_t, it_t = cl.em(A, low, ln)
-            os.environ["HGX_EM_NO_TAIL"] = "1"
+            engine.test_switch("em_no_tail", "1")
             try:
                 p_f, it_f = cl.em(A, low, ln)
             finally:
-                del os.environ["HGX_EM_NO_TAIL"]
+                engine.test_switch("em_no_tail", None)
             assert it_t == it_f == oit, (A, C_, it_t, it_f, oit)
             assert oit > 11                                   # the tail really took over
             exp = np.full(A, -1.0)
             exp[oa] = op
             assert np.array_equal(p_t < 0, exp < 0) and np.array_equal(p_f < 0, exp < 0)
             assert np.max(np.abs(p_t - exp)) <= 1e-9 and np.max(np.abs(p_t - p_f)) <= 1e-9
-
-
-@pytest.mark.parametrize("name", ["hla_7000", "hla_mid_real"])
-def test_em_backends_agree(orc, name):
-    """The int8-MFMA mat-vec (exact integer accumulation of 128-bit fixed-point planes) and the table-lookup mat-vec
-    (256 subset sums per group of 8 columns, one LDS lookup per 8 matrix bits) against the EXEC-masked FP64 VALU mat-vec:
-    same iteration counts, abundances equal to rounding, on the reference's recorded EM inputs and on a big random one."""
-    fx, loc, t, pl, batch, (eb, gb, gc, fp) = _setup(orc, name)
-    A = t["n_alleles"]
-    w = (A + 63) // 64
-    cases = []
-    for em in fx["em"]:
-        rows = np.zeros((len(em["cmpt"]), pl.w64), np.uint64)
-        for k, (cid, n) in enumerate(em["cmpt"]):
-            rows[k, :w] = gu.class_bits(fx, cid, A)
-        cases.append((rows, np.array([n for _, n in em["cmpt"]], np.int64), em["remove_low"], em["use_length"]))
-    rng = np.random.RandomState(9)
-    big = np.zeros((3000, pl.w64), np.uint64)
-    dens = rng.choice([0.002, 0.05, 0.6], size=3000)
-    for k in range(3000):
-        m = rng.rand(A) < dens[k]
-        m[rng.randint(A)] = True
-        big[k, :w] = np.packbits(np.pad(m, (0, 64 * w - A)), bitorder="little").view(np.uint64)
-    cases.append((big, rng.randint(1, 500, 3000).astype(np.int64), True, False))
-    cases.append((big, rng.randint(1, 500, 3000).astype(np.int64), False, True))
-    try:
-        for rows, counts, low, use_len in cases:
-            cl = engine.Classes.from_host(rows, counts, pl.a_pad)
-            ln = pl.allele_len if use_len else None
-            engine.em_set_backend(1)
-            p1, it1 = cl.em(A, low, ln)
-            import os
-            for backend, persist in ((2, False), (3, False), (3, True)):   # int8 MFMA; table lookup: one launch per pass / persistent kernel
-                engine.em_set_backend(backend)
-                if persist:
-                    os.environ["HGX_EM_PERSIST"] = "1"
-                try:
-                    p2, it2 = cl.em(A, low, ln)
-                finally:
-                    os.environ.pop("HGX_EM_PERSIST", None)
-                assert it1 == it2, (backend, persist, it1, it2)
-                assert np.array_equal(p1 < 0, p2 < 0)
-                assert np.max(np.abs(p1 - p2)) <= 1e-11, (backend, persist, np.max(np.abs(p1 - p2)))
-    finally:
-        engine.em_set_backend(0)
-
-
-def test_em_grid_equals_per_pass():
-    """The resident-block EM (k_em_grid, opt-in: matrix blocks in registers for the whole launch, point-to-point flagged hand-offs between
-    the workgroups of a class chunk / an allele slab) keeps the summation orders of the one-launch-per-pass kernels: abundances
-    BIT-identical, same iteration counts, over block grids from 1 x 1 to 17 x 14, ragged last chunks and slabs, with and
-    without pruning and allele lengths; a grid that does not fit the chip falls back to the per-pass path."""
-    import os
-    rng = np.random.RandomState(77)
-    shapes = [(70, 300, 512), (1100, 700, 1024), (2500, 1500, 1536), (3000, 7000, 7168), (9000, 2600, 3072), (17000, 7000, 7168),
-              (16098, 4549, 7168), (21000, 7000, 7168)]
-    ran_grid = 0
-    for C_, A, a_pad in shapes:
-        w = a_pad // 64
-        rows = np.zeros((C_, w), np.uint64)
-        # classes the way typing produces them: a few allele "families", every class a family minus/plus some alleles
-        fam = rng.rand(12, A) < rng.choice([0.02, 0.2, 0.7], size=12)[:, None]
-        pick = rng.randint(0, 12, C_)
-        flip = rng.rand(C_, A) < 0.01
-        m = fam[pick] ^ flip
-        m[np.arange(C_), rng.randint(0, A, C_)] = True
-        rows[:, :] = np.packbits(np.pad(m, ((0, 0), (0, a_pad - A))), axis=1, bitorder="little").view(np.uint64).reshape(C_, w)
-        counts = rng.randint(1, 400, C_).astype(np.int64)
-        lens = rng.randint(2000, 3500, a_pad).astype(np.int32)
-        cl = engine.Classes.from_host(rows, counts, a_pad)
-        for low, use_len in ((True, False), (False, True), (True, True)):
-            ln = lens if use_len else None
-            p_ref, it_ref = cl.em(A, low, ln)
-            engine.em_set_timing(0)
-            engine.em_set_timing(1)
-            os.environ["HGX_EM_GRID"] = "1"
-            try:
-                p, it = cl.em(A, low, ln)
-            finally:
-                os.environ.pop("HGX_EM_GRID", None)
-            launches = engine.em_get_timing()["k_em_grid"][1]
-            engine.em_set_timing(0)
-            ran_grid += launches > 0
-            assert it == it_ref, (C_, A, low, use_len, it, it_ref)
-            assert np.array_equal(p, p_ref), (C_, A, low, use_len, float(np.max(np.abs(p - p_ref))))
-            if C_ > 64 and C_ <= 9000:                      # (the biggest grids need 224 / 238 of the chip's CUs: taken when they fit)
-                assert launches > 0, (C_, A)
-            if C_ == 21000:
-                assert launches == 0
-    assert ran_grid >= 9
 
 
 def _level_equals_per_pair(pl, batch, collided=False):
@@ -736,9 +648,9 @@ def test_allele_counts_direct_equals_matvec_form(orc, monkeypatch):
         sets.append(engine.Classes.from_host(bits, cnt, pl.a_pad))
     for cl in sets:
         got_c, got_f = cl.allele_counts()
-        monkeypatch.setenv("HGX_COUNTS_MATVEC", "1")
+        engine.test_switch("counts_matvec", "1")
         exp_c, exp_f = cl.allele_counts()
-        monkeypatch.delenv("HGX_COUNTS_MATVEC")
+        engine.test_switch("counts_matvec", None)
         assert np.array_equal(got_c, exp_c) and np.array_equal(got_f, exp_f)
         b, c, _ = cl.to_host()
         a = int(np.flatnonzero(got_c)[0]) if got_c.any() else 0
@@ -751,7 +663,7 @@ def test_level_classes_falls_back_to_per_pair_rows_on_a_list_key_collision(orc, 
     """Two different ref lists with one 64-bit list key (never seen; forced here) make hgx_level_classes take the per-pair form:
     same classes, counts, order and first pairs."""
     fx, loc, t, pl, batch, _ = _setup(orc, "hla_errors_filters")
-    monkeypatch.setenv("HGX_TEST_GROUP_COLLISION", "1")
+    engine.test_switch("test_group_collision", "1")
     _level_equals_per_pair(pl, batch, collided=True)
 
 

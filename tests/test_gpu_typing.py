@@ -381,7 +381,7 @@ def test_concurrent_samples_give_identical_results():
 @pytest.mark.parametrize("name", ["hla_small_pair", "hla_mid_real", "hla_errors_filters", "hla_7000"])
 def test_grouped_exon_path_equals_per_pair_path(name, monkeypatch):
     """type_locus through hgx_level_classes (pairs grouped by exon-level ref list, the default) and through the per-pair rows +
-    dedup (HGX_NO_SIG=1) give the same classes, counts, EM results and report."""
+    dedup (test switch no_sig) give the same classes, counts, EM results and report."""
     fx = gu.load(name)
     o = fx["options"]
     pl = hl.PackedLocus.from_synth(fx["_locus"])
@@ -391,7 +391,7 @@ def test_grouped_exon_path_equals_per_pair_path(name, monkeypatch):
                               allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
                               simulation=o["simulation"], keep_classes=True)
     a = run()
-    monkeypatch.setenv("HGX_NO_SIG", "1")
+    engine.test_switch("no_sig", "1")
     b = run()
     assert a.em == b.em and a.gene_prob == b.gene_prob
     for x, y in zip(a.exon_classes, b.exon_classes):
@@ -409,7 +409,7 @@ def test_grouped_exon_path_equals_per_pair_path_at_size(monkeypatch):
     sam = synth.simulate_sam_fast(loc, sample, 200000, err_rate=0.002, seed=7)
     pl = hl.PackedLocus.from_synth(loc)
     a = hgx.type_locus(pl, sam)
-    monkeypatch.setenv("HGX_NO_SIG", "1")
+    engine.test_switch("no_sig", "1")
     b = hgx.type_locus(pl, sam)
     assert a.em == b.em and a.gene_prob == b.gene_prob
     assert np.array_equal(a.counts, b.counts) and np.array_equal(a.counts_order, b.counts_order)

@@ -20,16 +20,13 @@ for A, n_used, C_, dens in ((700, 300, 200, 0.1), (700, 600, 600, 0.1), (2000, 1
     cl.set_allele_rank(np.arange(A, dtype=np.int32))
     out = []
     for env in (None, "1"):
-        if env:
-            os.environ["HGX_EM_NO_MID"] = env
-        else:
-            os.environ.pop("HGX_EM_NO_MID", None)
+        engine.test_switch("em_no_mid", env)
         for _ in range(3):
             p, it = cl.em(A, True, None)
         t0 = time.perf_counter()
         for _ in range(20):
             p, it = cl.em(A, True, None)
         out.append(((time.perf_counter() - t0) / 20 * 1e3, it))
-    os.environ.pop("HGX_EM_NO_MID", None)
+    engine.test_switch("em_no_mid", None)
     print("C=%5d alleles=%5d density~%.2f: reference order %.3f ms (%d iterations) | table lookup %.3f ms (%d iterations)" % (
         C_, n_used, dens, out[0][0], out[0][1], out[1][0], out[1][1]))

@@ -1,4 +1,4 @@
-"""Phase profile of k_emx (HGX_EMX_STAMPS=1) on panel-sized random problems, and wall time per call."""
+"""Phase profile of k_emx (test switch emx_stamps) on panel-sized random problems, and wall time per call."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -6,7 +6,7 @@ import numpy as np
 import hisatgenotype_amd
 from hisatgenotype_amd import engine
 from test_gpu_emx import _random_problem
-os.environ["HGX_EMX_STAMPS"] = "1"
+engine.test_switch("emx_stamps", "1")
 for case in [(7000, 4549, 1600, 0.25), (3000, 1949, 1340, 0.27), (500, 323, 704, 0.3), (2000, 1100, 500, 0.05)]:
     A, n_used, C_, dens = case
     rng = np.random.RandomState(5)
@@ -18,10 +18,10 @@ for case in [(7000, 4549, 1600, 0.25), (3000, 1949, 1340, 0.27), (500, 323, 704,
         p, it = cl.em(A, True, None)
         dt = time.perf_counter() - t0
     print(case, "iters", it, "exact", engine.em_last_exact(), "call %.2f ms" % (dt * 1e3), flush=True)
-    os.environ["HGX_EM_NO_EMX"] = "1"; os.environ["HGX_EM_NO_MID"] = "1"
+    engine.test_switch("em_no_emx", "1"); engine.test_switch("em_no_mid", "1")
     for rep in range(2):
         t0 = time.perf_counter()
         p2, it2 = cl.em(A, True, None)
         dt = time.perf_counter() - t0
-    del os.environ["HGX_EM_NO_EMX"]; del os.environ["HGX_EM_NO_MID"]
+    engine.test_switch("em_no_emx", None); engine.test_switch("em_no_mid", None)
     print("   table-lookup path: iters", it2, "call %.2f ms" % (dt * 1e3), "max |diff| %.3g" % float(np.max(np.abs(p - p2))), flush=True)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round 3 profile set on the GPU box: tools/run_profiles_r03.sh <name>  ->  gpurun_out/<name>/ (then tools/install_profiles_r03.py).
+# rocprofv3 gets the program itself after `--`; counters are collected in their own passes (no trace options beside --pmc).
+set -u
+D=gpurun_out/$1
+mkdir -p $D
+R=$(pwd)
+cd /tmp && export TMPDIR=/tmp && cd $R
+python3 bench.py > $D/bench_default.json 2> $D/bench_default.err
+python3 bench.py --workload panel64 --em-exact --no-cpu-baseline --steps 6 --warmup 2 > $D/bench_panel64_em_exact.json 2>> $D/bench_default.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats -o r03 -- python3 bench.py --no-cpu-baseline --no-e2e --no-workloads > $D/bench_under_rocprof.json 2> $D/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats_panel -o r03p -- python3 bench.py --workload panel64 --no-cpu-baseline --steps 8 --warmup 2 > $D/panel_under_rocprof.json 2> $D/stats_panel.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -o r03 -- python3 bench.py --no-cpu-baseline --no-e2e --no-workloads --steps 3 --warmup 1 > /dev/null 2> $D/pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -o r03 -- python3 bench.py --no-cpu-baseline --no-e2e --no-workloads --steps 3 --warmup 1 > /dev/null 2> $D/pmc_write.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch_panel -o r03p -- python3 bench.py --workload panel64 --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $D/pmc_fetch_panel.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write_panel -o r03p -- python3 bench.py --workload panel64 --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $D/pmc_write_panel.err
+rm -f $D/stats*/*kernel_trace.csv $D/stats*/*agent_info.csv $D/pmc_*/*agent_info.csv
+ls -la $D $D/stats $D/stats_panel $D/pmc_fetch $D/pmc_fetch_panel | head -60
+head -c 400 $D/bench_default.json

@@ -11,7 +11,7 @@ counts = rng.randint(1, 500, Cn).astype(np.int64)
 cl = engine.Classes.from_host(bits, counts, ap)
 x = np.zeros(ap); x[:A] = rng.rand(A)
 xc = rng.rand(Cn)
-os.environ["HGX_DBG_REPS"] = "50"
+engine.test_switch("dbg_reps", "50")
 for backend in [int(b) for b in os.environ.get('BACKENDS', '1,3').split(',')]:
     for which, xx, ny in ((0, x, Cn), (1, xc, ap)):
         y = np.zeros(ny)
