@@ -1007,7 +1007,9 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_e
     // one round trip brings the state words and the first records; a second one the rest of a long result
     const size_t first_recs = std::min<size_t>(res_cap, ((200u << 10) - head % (200u << 10)) / sizeof(EmxRes) + 0);
     const size_t first_bytes = std::min<size_t>(head + first_recs * sizeof(EmxRes), head + res_cap * sizeof(EmxRes));
-    std::vector<char> h((size_t)head + res_cap * sizeof(EmxRes));
+    // (the host copy is sized by what came back, never by res_cap: tens of MB of fresh pages per call -- above malloc's mmap
+    // threshold -- cost more than the EM #2 launch itself)
+    std::vector<char> h(first_bytes);
     for (size_t off = 0; off < first_bytes;) {
         const size_t chunk = std::min<size_t>(first_bytes - off, 128u << 10);
         { int rc_ = hgx_d2h(h.data() + off, resb + off, chunk, st); if (rc_) return rc_; }
@@ -1016,8 +1018,14 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_e
     { int rc_ = hgx_sync(st); if (rc_) return rc_; }
     const unsigned long long n_rec = *(const unsigned long long *)h.data();
     if (n_rec > res_cap) { hgx_set_error("EM result records overflow (%llu > %zu)", n_rec, res_cap); return HGX_EHIP; }
-    if (head + n_rec * sizeof(EmxRes) > first_bytes) {
-        HIPCHK(hipMemcpyAsync(h.data() + first_bytes, resb + first_bytes, head + n_rec * sizeof(EmxRes) - first_bytes, hipMemcpyDeviceToHost, st));
+    const size_t all_bytes = head + (size_t)n_rec * sizeof(EmxRes);
+    if (all_bytes > first_bytes) {
+        h.resize(all_bytes);
+        for (size_t off = first_bytes; off < all_bytes;) {
+            const size_t chunk = std::min<size_t>(all_bytes - off, 128u << 10);
+            { int rc_ = hgx_d2h(h.data() + off, resb + off, chunk, st); if (rc_) return rc_; }
+            off += chunk;
+        }
         { int rc_ = hgx_sync(st); if (rc_) return rc_; }
     }
     const EmxRes *recs = (const EmxRes *)(h.data() + head);

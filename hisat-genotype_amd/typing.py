@@ -15,6 +15,7 @@ Nothing here computes the hot path on the CPU: all of it goes through libhgx (HI
 import ctypes as C
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -274,7 +275,10 @@ def type_many_loci(pls, manies, remove_low=True, stream=None, light=False, em_fa
     loc_p = (C.c_void_p * max(nl, 1))(*[pl.h for pl in pls])
     ix_p = (C.c_void_p * max(nl, 1))(*[pl.index() for pl in pls])
     many_p = (C.c_void_p * max(nl, 1))(*[m.h for m in manies])
+    prof = "HGX_TYPE_PROFILE" in os.environ
+    t0 = time.perf_counter()
     capi.check(L.hgx_type_many_loci(C.c_int32(nl), out_pp, rc_pp, loc_p, ix_p, many_p, C.byref(o), stream))
+    t1 = time.perf_counter()
     out = []
     try:
         for i, (pl, many) in enumerate(zip(pls, manies)):
@@ -299,10 +303,14 @@ def type_many_loci(pls, manies, remove_low=True, stream=None, light=False, em_fa
                 row.append(res)
             out.append(row)
     finally:
+        t2 = time.perf_counter()
         for i, many in enumerate(manies):
             for t in range(many.n_tasks):
                 if hs[i][t]:
                     L.hgx_typing_destroy(C.c_void_p(hs[i][t]))
+        if prof:
+            print("[type_many_loci] call %.2f ms | results %.2f | destroy %.2f" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (time.perf_counter() - t2) * 1e3),
+                  file=sys.stderr)
     return out
 
 

@@ -473,9 +473,9 @@ int hgx_many_destroy(hgx_many *m);
 int hgx_many_dims(const hgx_many *m, int32_t *n_tasks, int32_t *n_distinct_pieces, int32_t *n_pairs, int64_t *n_refs, int64_t *n_reads);
 int hgx_type_many(hgx_typing **out /* [n_tasks] */, int32_t *rc_out /* [n_tasks] or NULL */, const hgx_locus *loc, const hgx_index *ix,
                   hgx_many *m, const hgx_type_opts *opts, void *stream);
-/* Several loci at once (a whole panel): out[i] / rc_out[i] are locus i's arrays as in hgx_type_many.  The loci are scored one
- * after the other, but the EMs of ALL their tasks go out in one launch (one workgroup per task), so the launch is as wide as
- * the panel and its time is the longest task's, not the sum over the loci. */
+/* Several loci at once (a whole panel): out[i] / rc_out[i] are locus i's arrays as in hgx_type_many.  The loci are scored side by
+ * side (one host thread and stream pair per locus), and the EMs of ALL their tasks go out in one launch (one workgroup per task,
+ * longest problem first), so the launch is as wide as the panel and ends with its longest problem.                              */
 int hgx_type_many_loci(int32_t n_loci, hgx_typing ***out, int32_t **rc_out_or_null, const hgx_locus *const *loci,
                        const hgx_index *const *ixs, hgx_many *const *manies, const hgx_type_opts *opts, void *stream);
 
@@ -488,8 +488,8 @@ int hgx_type_many_loci(int32_t n_loci, hgx_typing ***out, int32_t **rc_out_or_nu
 /* Test hook.  The library reads no path-selecting environment variable: the test-suite forces an alternative path (a kernel kept
  * for comparison, a threshold moved so a small case reaches the large-problem code) with named in-process switches.  name = NULL
  * clears all, value = NULL clears one.  The names are listed in DESIGN.md ("switches"); none changes results beyond what the
- * test that uses it states.  Environment variables the library does read: HGX_THREADS, HGX_PIN, HGX_THP, HGX_NO_LIBDEFLATE
- * (host tuning) and HGX_PARSE_PROFILE, HGX_TYPE_PROFILE (timing prints on stderr).                                            */
+ * test that uses it states.  Environment variables the library does read: HGX_THREADS, HGX_PIN, HGX_THP, HGX_NO_LIBDEFLATE,
+ * HGX_MALLOC_TUNE (host tuning) and HGX_PARSE_PROFILE, HGX_TYPE_PROFILE (timing prints on stderr).                                            */
 int hgx_test_switch_set(const char *name, const char *value);
 /* mat-vec backend of hgx_em: 0 = auto (table lookup), 1 = EXEC-masked FP64 VALU kernel, 3 = table-lookup kernel (256 subset
  * sums per 8 matrix columns in LDS; one lookup per 8 matrix bits); 2 = int8 MFMA kernel, in the lab build only (libhgx_lab.so,

@@ -59,7 +59,24 @@ for stats, u in ((f"{dst}/{R}_final_kernel_stats.csv", f"{src}/bench_under_rocpr
     tot = 0
     for r in csv.DictReader(open(stats)):
         tot += int(r["TotalDurationNs"])
-        n = r["Name"].split("(")[0][-48:]
+        n = r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-48:]
         if int(r["TotalDurationNs"]) > 0.05e6 * n_steps:
             print("%-50s calls %5s avg %9.1f us total/step %7.3f ms" % (n, r["Calls"], float(r["AverageNs"]) / 1e3, int(r["TotalDurationNs"]) / 1e6 / n_steps))
     print("kernel time per step %.3f ms over %d steps" % (tot / 1e6 / n_steps, n_steps))
+# the one-step timeline and the wave / busy counters
+if os.path.exists(f"{src}/step_timeline.txt") and os.path.getsize(f"{src}/step_timeline.txt") > 0:
+    shutil.copy(f"{src}/step_timeline.txt", f"{dst}/{R}_final_step_timeline.txt")
+for name, stem in (("pmc_waves", "r03"), ("pmc_busy", "r03")):
+    path = f"{src}/{name}/{stem}_counter_collection.csv"
+    if not os.path.exists(path):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    for r in csv.DictReader(open(path)):
+        a = agg[r["Kernel_Name"]][r["Counter_Name"]]
+        a[0] += 1; a[1] += float(r["Counter_Value"])
+    with open(f"{dst}/{R}_final_{name}.csv", "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Counter", "Dispatches", "avg", "total"])
+        for k, d in sorted(agg.items(), key=lambda kv: -sum(v[1] for v in kv[1].values())):
+            for c, a in sorted(d.items()):
+                w.writerow([k, c, a[0], round(a[1] / a[0], 1), round(a[1], 1)])

@@ -14,6 +14,12 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch -o r03 -- python3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write -o r03 -- python3 bench.py --no-cpu-baseline --no-e2e --no-workloads --steps 3 --warmup 1 > /dev/null 2> $D/pmc_write.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $D/pmc_fetch_panel -o r03p -- python3 bench.py --workload panel64 --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $D/pmc_fetch_panel.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $D/pmc_write_panel -o r03p -- python3 bench.py --workload panel64 --no-cpu-baseline --steps 2 --warmup 1 > /dev/null 2> $D/pmc_write_panel.err
+# one step as a timeline: kernel trace of a 1-step run (tools/step_timeline.py turns the CSV into profiles/r03_step_timeline.txt)
+rocprofv3 --kernel-trace --output-format csv -d $D/trace_step -o r03s -- python3 bench.py --no-cpu-baseline --no-e2e --no-workloads --steps 1 --warmup 3 > /dev/null 2> $D/trace_step.err
+python3 tools/step_timeline.py $D/trace_step/r03s_kernel_trace.csv > $D/step_timeline.txt 2>> $D/trace_step.err
+rocprofv3 --pmc SQ_WAVES --output-format csv -d $D/pmc_waves -o r03 -- python3 bench.py --no-cpu-baseline --no-e2e --no-workloads --steps 2 --warmup 1 > /dev/null 2> $D/pmc_waves.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $D/pmc_busy -o r03 -- python3 bench.py --no-cpu-baseline --no-e2e --no-workloads --steps 2 --warmup 1 > /dev/null 2> $D/pmc_busy.err
+rm -f $D/trace_step/*agent_info.csv
 rm -f $D/stats*/*kernel_trace.csv $D/stats*/*agent_info.csv $D/pmc_*/*agent_info.csv
 ls -la $D $D/stats $D/stats_panel $D/pmc_fetch $D/pmc_fetch_panel | head -60
 head -c 400 $D/bench_default.json
