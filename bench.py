@@ -99,6 +99,8 @@ def parse_args():
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank joins the process group and rank 0 prints the world it saw (no GPU work)")
     ap.add_argument("--no-workloads", action="store_true", help="default workload only: skip the class1 / panel64 runs that follow it")
+    ap.add_argument("--workloads", action="store_true", help="run class1 / panel64 behind the default workload also with more than one rank "
+                                                               "(by default they are N = 1 legs, like cpu_baseline and e2e: the scaling run is about `value`)")
     ap.add_argument("--wl-steps", type=int, default=10, help="timed steps of the class1 / panel64 runs that follow the default workload")
     ap.add_argument("--em-exact", action="store_true",
                     help="panel64: EM #1 in the reference's own order of floating-point operations (hgx_type_opts.em_fast = 0, the "
@@ -620,6 +622,8 @@ def run_panel64(args, rank, local_rank, world, dist):
                 "form": "one launch chain per task" if args.one_by_one else "hgx_type_many_loci: one launch chain per locus (all its samples together), the EMs of all loci in one launch",
                 "em_arithmetic": ("reference order (bit-identical)" if args.em_exact else "table lookups (within 1e-9; hgx_type_opts.em_fast)") if not args.one_by_one else "default",
                 "parallelism": "(sample, locus) tasks over GPUs by dist.shard (greedy by allele count), no data-path collective",
+                "merged_batches": {packed[k].gene: {"alleles": packed[k].n_alleles, "tasks": m.n_tasks, "pairs": m.n_pairs, "piece_refs": m.n_refs,
+                                                    "distinct_pieces": m.n_pieces} for k, (_, m) in sorted(manies.items())},
                 "setup_s": round(t_setup, 1)},
             "roofline": roof, "cpu_baseline": cb})
     return None
@@ -805,7 +809,7 @@ def main():
             cb, _ = cpu_baseline(loc, sam_keep, min(args.cpu_pairs, batch.n_pairs))
             out["cpu_baseline"] = cb
     # ---- the other BASELINE.json workloads, driver-timed in the same run: configs[2] (class1) and configs[3] (panel64) --------
-    if not args.no_workloads:
+    if not args.no_workloads and (world == 1 or args.workloads):
         del batch, db
         import copy
         wl = {}
