@@ -2458,7 +2458,10 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     const int C = c->n_classes;
     if (n_iter_host) *n_iter_host = 0;
     if (C == 0) {
+        // single_abundance({}): `diff` starts at 1.0, so the loop makes ONE pass over the empty dict before it stops
+        // (typing_common.py:1351-1404) -- an empty result after 1 iteration (tools/fuzz_many.py: a hand-off that leaves no class)
         for (int a = 0; a < n_alleles; ++a) prob_host[a] = -1.0;
+        if (n_iter_host) *n_iter_host = 1;
         return HGX_OK;
     }
     if (C <= 64 && c->w64 <= 128 && !hgx_test_switch("em_no_small") && !hgx_test_switch("em_no_wave")) {
@@ -3147,7 +3150,7 @@ extern "C" int hgx_em_masked(const hgx_classes *cc, const uint64_t *mask_host, i
     hipStream_t st = (hipStream_t)stream;
     hgx_classes_order_after(cc, st);
     for (int a = 0; a < n_alleles; ++a) { prob_host[a] = -1.0; first_class_host[a] = -1; }
-    if (n_iter_host) *n_iter_host = 0;
+    if (n_iter_host) *n_iter_host = 1;          // (an empty Gene_cmpt2 still costs the reference one pass of its loop: see em_impl)
     if (n_classes_host) *n_classes_host = 0;
     const int C = cc->n_classes;
     if (C == 0) return HGX_OK;

@@ -263,7 +263,7 @@ def type_many(pl, many, remove_low=True, stream=None, return_errors=False, em_fa
 
 def type_many_loci(pls, manies, remove_low=True, stream=None, light=False, em_fast=False):
     """A whole panel in one call (hgx_type_many_loci): `manies[i]` = the merged batch of locus `pls[i]`'s samples.  The loci are
-    scored one after the other; the EMs of all their tasks go out in ONE launch.  Returns a list (per locus) of lists (per task)
+    scored side by side (a host thread and stream pair per locus); the EMs of all their tasks go out in ONE launch.  Returns a list (per locus) of lists (per task)
     of LocusResult -- or, with `light`, of (num_reads, [top-2 allele names], EM iterations): what a throughput run looks at."""
     L = capi.lib()
     nl = len(pls)

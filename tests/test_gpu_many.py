@@ -79,3 +79,52 @@ def test_many_equals_one_by_one_str_locus():
             assert isinstance(g, TypeError)
             continue
         _same(g, want)
+
+
+def _fuzz_tool():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("fuzz_many", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_many.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("seed", [800012, 800028, 800044, 800020, 800058, 800101])
+def test_many_fuzz_cases_with_tiny_tasks(seed):
+    """Cases tools/fuzz_many.py found: a task of ONE pair whose hand-off leaves no class (the reference's loop over the empty dict
+    still makes one pass: n_iter 1, empty result) typed beside ordinary tasks; and a CODIS task on which the reference raises
+    (quirk Q3) that must fail alone.  Compared with the one-task path AND with oracle/pyref.py, `==`."""
+    import pyref
+    fm = _fuzz_tool()
+    loc, sams = fm.make_case(seed)
+    pl = hl.PackedLocus.from_synth(loc)
+    batches = [pl.parse_sam(s) for s in sams]
+    many = engine.ManyBatch(pl, batches)
+    got = htyping.type_many(pl, many, return_errors=True)
+    for t, sam in enumerate(sams):
+        try:
+            one = htyping.type_locus(pl, sam) if sam else None
+        except Exception as e:
+            one = e
+        try:
+            exp = pyref.RefLocus(loc).run(sam) if sam else {"num_reads": 0}
+        except Exception as e:
+            exp = e
+        s_many = fm.summary(got[t])
+        assert fm.first_difference(s_many, (0, 0) if one is None else fm.summary(one)) is None, (seed, t)
+        assert fm.first_difference(s_many, fm.summary(exp)) is None, (seed, t)
+    many.close()
+
+
+def test_many_with_only_empty_tasks():
+    """No task has a class: no EM job at all (the launch is skipped, not an argument error)."""
+    loc = synth.make_hla_like_locus(n_alleles=120, n_vars=200, seed=11)
+    pl = hl.PackedLocus.from_synth(loc)
+    batches = [pl.parse_sam(""), pl.parse_sam("")]
+    many = engine.ManyBatch(pl, batches)
+    got = htyping.type_many(pl, many)
+    assert [g.num_reads for g in got] == [0, 0]
+    rows = htyping.type_many_loci([pl], [many], light=True)
+    assert [r[0] for r in rows[0]] == [0, 0]
+    many.close()

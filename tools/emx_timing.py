@@ -18,6 +18,13 @@ for case in [(7000, 4549, 1600, 0.25), (3000, 1949, 1340, 0.27), (500, 323, 704,
         p, it = cl.em(A, True, None)
         dt = time.perf_counter() - t0
     print(case, "iters", it, "exact", engine.em_last_exact(), "call %.2f ms" % (dt * 1e3), flush=True)
+    engine.em_set_fast(True)                                        # the same kernel skeleton with table lookups (hgx_type_opts.em_fast)
+    for rep in range(2):
+        t0 = time.perf_counter()
+        pf, itf = cl.em(A, True, None)
+        dt = time.perf_counter() - t0
+    engine.em_set_fast(False)
+    print("   fast mode: iters", itf, "call %.2f ms" % (dt * 1e3), "max |diff| %.3g" % float(np.max(np.abs(p - pf))), flush=True)
     engine.test_switch("em_no_emx", "1"); engine.test_switch("em_no_mid", "1")
     for rep in range(2):
         t0 = time.perf_counter()
