@@ -104,7 +104,9 @@ def parse_args():
     ap.add_argument("--wl-steps", type=int, default=10, help="timed steps of the class1 / panel64 runs that follow the default workload")
     ap.add_argument("--em-exact", action="store_true",
                     help="panel64: EM #1 in the reference's own order of floating-point operations (hgx_type_opts.em_fast = 0, the "
-                         "library's default: bit-identical abundances) instead of the table-lookup arithmetic the throughput run uses")
+                         "library's default: bit-identical abundances) instead of the table-lookup arithmetic the throughput run uses; "
+                         "configs1 / class1: em_fast = -1, the reference's order also for the > 4096-class exon-level EM (one CU: "
+                         "the price of bit-identical abundances at that size)")
     ap.add_argument("--one-by-one", action="store_true", help="panel64: one launch chain per task (round 2's form) instead of hgx_type_many")
     ap.add_argument("--inflight", type=int, default=1,
                     help="samples typed concurrently per GPU (host threads with their own streams and class-row buffers; "
@@ -112,12 +114,15 @@ def parse_args():
     return ap.parse_args()
 
 
+EM_MODE = False          # --em-exact: -1 = the reference's order of operations at every size (hgx_type_opts.em_fast = -1)
+
+
 def step(pl, batch, db, ev=None, stream=None, gate=None):
     """One pass of the hot path on `stream` (None = the default stream): ONE call into libhgx (hgx_type_dbatch) over the
     piece batch resident in HBM.  `ev` = (compat begin, compat end, pairs begin, pairs end) events.  Returns the LocusResult."""
     res = htyping.LocusResult()
     res.num_reads, res.num_pairs = batch.n_reads, batch.n_pairs
-    return htyping._type_batch(pl, batch, res, True, dbatch=db, stream=stream, overlap=True, gate=gate, events=ev)
+    return htyping._type_batch(pl, batch, res, True, dbatch=db, stream=stream, overlap=True, gate=gate, events=ev, em_fast=EM_MODE)
 
 
 def run_steps(pl, batch, db, inflight, n_steps, ev_list, timing, local_rank):
@@ -631,6 +636,8 @@ def run_panel64(args, rank, local_rank, world, dist):
 
 def main():
     args = parse_args()
+    global EM_MODE
+    EM_MODE = -1 if args.em_exact else False
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -787,6 +794,8 @@ def main():
                 "exon_classes": res.em[0]["n_classes"] if res.em else 0,
                 "gene_classes_after_handoff": res.em[1]["n_classes"] if len(res.em) > 1 else 0,
                 "em_outer_iterations_per_step": n_em_iter // max(args.steps, 1),
+                "em_arithmetic": "reference order at every size (hgx_type_opts.em_fast = -1: bit-identical abundances; EM #1 on one CU)" if args.em_exact
+                                 else "default: reference order up to 4096 classes (EM #2 here), chip-wide table lookups beyond (EM #1 here, <= 1e-9)",
                 "top2": [a for a, _ in res.gene_prob[:2]], "true_alleles": sample,
                 "parallelism": "samples/loci shard over GPUs with no data-path collective; %d sample(s) in flight per GPU" % inflight,
                 "input": "front-end piece batch resident in HBM (host C++ front-end: %.0f reads/s on %d host threads, not timed)" % (

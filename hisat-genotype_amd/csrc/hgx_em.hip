@@ -2390,7 +2390,8 @@ static int hgx_ensure_compact(hgx_classes *c, hipStream_t st) {
 // own order of floating-point operations (its abundances are then the reference's, bit for bit), 0 otherwise
 static thread_local int g_last_exact = 0;
 static thread_local std::vector<int32_t> g_last_order;     // per allele: position in the returned dict's insertion order (hgx_em_last_order)
-static thread_local int g_em_fast = 0;           // hgx_em_set_fast: table-lookup arithmetic on the one-workgroup path (k_emx)
+static thread_local int g_em_fast = 0;           // hgx_em_set_fast: 1 = table-lookup arithmetic on the one-workgroup path (k_emx), -1 = the
+                                                 // reference's order at every size (k_emx also beyond 4096 classes)
 // Insertion order of the dict the calling thread's last hgx_em / hgx_em_ordered returned, when that EM ran in the reference's own
 // order on the one-workgroup kernel (hgx_em_last_exact() == 1 and the problem had more than 64 classes or alleles): order_host[a] =
 // position of allele a (-1 if not in the dict).  Returns 1 if available, else 0 (callers then use (first class, name order)).
@@ -2399,7 +2400,7 @@ extern "C" int hgx_em_last_order(int32_t *order_host, int32_t n) {
     memcpy(order_host, g_last_order.data(), (size_t)n * 4);
     return 1;
 }
-extern "C" int hgx_em_set_fast(int on) { const int old = g_em_fast; g_em_fast = on ? 1 : 0; return old; }
+extern "C" int hgx_em_set_fast(int on) { const int old = g_em_fast; g_em_fast = on > 0 ? 1 : (on < 0 ? -1 : 0); return old; }
 static thread_local bool g_no_grid = false;      // set while an EM is re-run after a resident-block launch was abandoned
 extern "C" int hgx_em_last_exact(void) { return g_last_exact; }
 
@@ -2511,7 +2512,8 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             return HGX_OK;
         }
     }
-    if (C <= HGX_EMX_MAX_CLASSES && c->w64 <= 128 && c->h_rank && !hgx_test_switch("em_no_exact") && !hgx_test_switch("em_no_emx")) {
+    if (C <= (g_em_fast < 0 ? HGX_EMX_HARD_MAX_CLASSES : HGX_EMX_MAX_CLASSES) && c->w64 <= 128 && c->h_rank && !hgx_test_switch("em_no_exact") &&
+        !hgx_test_switch("em_no_emx")) {
         // problems of up to 4096 classes over up to 8192 distinct alleles in the reference's own order of operations
         // (k_emx, hgx_emx.hip: one workgroup, one launch, bit-identical abundances); falls through if it does not take the problem
         DevBuf b_rank, b_len;
@@ -2526,7 +2528,8 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         hgx_emx_job job{};
         job.bits = c->d_bits; job.count = c->d_count; job.rank = b_rank.as<int32_t>(); job.len = allele_len ? b_len.as<double>() : nullptr;
         job.C = C; job.w64 = c->w64; job.a_pad = A; job.remove_low = remove_low ? 1 : 0;
-        job.fast = g_em_fast;
+        job.fast = g_em_fast > 0 ? 1 : 0;
+        job.any_size = g_em_fast < 0 ? 1 : 0;
         std::vector<int32_t> order((size_t)n_alleles, -1);
         job.prob = prob_host; job.first = first_host; job.order = order.data(); job.n_out = n_alleles;
         { int rc_ = hgx_emx_run(&job, 1, st); if (rc_) return rc_; }

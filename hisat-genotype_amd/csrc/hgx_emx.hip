@@ -38,7 +38,7 @@
 namespace {
 
 constexpr int XB = 1024, XNW = XB / 64;
-constexpr int XA = HGX_EMX_MAX_ALLELES, XC = HGX_EMX_MAX_CLASSES;
+constexpr int XA = HGX_EMX_MAX_ALLELES, XC = HGX_EMX_HARD_MAX_CLASSES;
 constexpr int XAW = XA / 64, XCW = XC / 64;
 
 enum { XS_ITER = 0, XS_STATUS = 1, XS_A1 = 2, XS_ORDERS = 3, XS_RES_OFF = 4, XS_RES_N = 5, XS_NCLS = 6, XS_APPS = 7, XS_N = 8 };
@@ -114,6 +114,8 @@ struct XLds {
     int cache_ord, need_slow, A1, res_base;
     double xs[512];                            // (fast mode) the slab of the vector a lookup table is built from
 };
+
+static_assert(sizeof(XLds) + 256 <= 160 * 1024, "k_emx: one workgroup per CU, all of its LDS");
 
 #pragma clang fp contract(off)
 
@@ -952,7 +954,8 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_e
         J.n_iter = 0;
         J.n_classes = 0;
         J.status = 1;
-        if (J.C <= 0 || (!J.mask && J.C > HGX_EMX_MAX_CLASSES) || J.w64 > 128 || J.a_pad > HGX_EMX_MAX_ALLELES || J.a_pad != 64 * J.w64) continue;
+        const int c_max = (J.any_size && !J.fast) ? HGX_EMX_HARD_MAX_CLASSES : HGX_EMX_MAX_CLASSES;      // (the fast arithmetic holds 4 classes per thread)
+        if (J.C <= 0 || (!J.mask && J.C > c_max) || J.w64 > 128 || J.a_pad > HGX_EMX_MAX_ALLELES || J.a_pad != 64 * J.w64) continue;
         ARGCHK(J.bits && J.count && J.rank && (J.prob || recs_out) && J.n_out <= J.a_pad);
         const size_t c_alloc = J.mask ? std::min<size_t>((size_t)J.C, 2048) : (size_t)J.C;
         const size_t Cp = (c_alloc + 63) & ~(size_t)63, A1s = (size_t)J.a_pad, A1w = J.mask ? 1 : A1s / 64, Cw = Cp / 64;

@@ -27,6 +27,8 @@ struct hgx_emx_job {
                                 // dropped, equal ones merged with their counts added, in the order of their first class; the EM
                                 // runs on that set and `first` / n_classes refer to it
     int32_t C, w64, a_pad, remove_low;
+    int32_t any_size;           // 1 (with fast = 0): take the problem up to HGX_EMX_HARD_MAX_CLASSES classes -- still ONE workgroup, so a
+                                // 16 000-class problem takes ~0.2 s: the validation mode "the reference's order at every size"
     int32_t fast;               // 0: the reference's own order of operations (bit-identical abundances); 1: table-lookup mat-vecs and
                                 // tree reductions on the same workgroup -- ~5x faster, abundances within rounding (~1e-12) of the
                                 // reference's, same stopping and pruning rules
@@ -44,7 +46,8 @@ struct hgx_emx_job {
 };
 
 // limits of the kernel (a job beyond them comes back with status 1)
-constexpr int HGX_EMX_MAX_CLASSES = 4096;
+constexpr int HGX_EMX_MAX_CLASSES = 4096;            // what a caller gets by default (beyond it the chip-wide table-lookup EM is ~100x faster)
+constexpr int HGX_EMX_HARD_MAX_CLASSES = 32768;      // what the kernel can take (hgx_emx_job::any_size)
 constexpr int HGX_EMX_MAX_ALLELES = 8192;
 
 // Runs all jobs in ONE launch (one workgroup per job) on `st` and returns when the results are on the host.

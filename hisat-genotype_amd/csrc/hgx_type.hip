@@ -947,7 +947,8 @@ struct ManyRun {
                 hgx_emx_job J{};
                 J.bits = cl1()->d_bits + (size_t)off1()[t] * w64; J.count = cl1()->d_count + off1()[t]; J.rank = m->d_rank;
                 J.C = C; J.w64 = w64; J.a_pad = a_pad; J.remove_low = hla ? (opts->remove_low ? 1 : 0) : 0;
-                J.fast = opts->em_fast ? 1 : 0;
+                J.fast = opts->em_fast > 0 ? 1 : 0;
+                J.any_size = opts->em_fast < 0 ? 1 : 0;
                 J.prob = nullptr; J.first = nullptr; J.n_out = A;
                 jobs.push_back(J);
                 job_task.push_back(t);

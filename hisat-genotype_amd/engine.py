@@ -74,7 +74,9 @@ def emx_get_timing(fast):
 def em_set_fast(on):
     """Arithmetic of Classes.em / em_ordered on this thread for problems the one-workgroup kernel takes: False = the reference's own
     order of operations (default, bit-identical), True = table lookups (~5x faster, within rounding).  Returns the old setting."""
-    return bool(capi.lib().hgx_em_set_fast(C.c_int32(1 if on else 0)))
+    mode = -1 if (on is not True and on is not False and int(on) < 0) else (1 if on else 0)    # -1: the reference's order at EVERY size
+    old = capi.lib().hgx_em_set_fast(C.c_int32(mode))
+    return -1 if old < 0 else bool(old)
 
 
 class ManyBatch:

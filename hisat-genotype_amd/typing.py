@@ -109,6 +109,12 @@ class LocusResult:
         return [[self._names[a], int(self.counts[a])] for a in self.counts_order]
 
 
+def _em_mode(em_fast):
+    """hgx_type_opts.em_fast: False / 0 = the reference's order where the one-workgroup kernel takes the problem (default), True / 1 =
+    table lookups, -1 = the reference's order at every size (validation mode: slow beyond 4096 classes)."""
+    return -1 if (em_fast is not True and em_fast is not False and int(em_fast) < 0) else int(bool(em_fast))
+
+
 def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discordant=False,
                remove_low_abundance_alleles=True, simulation=False, base_locus=0, keep_classes=False, stream=None,
                alignment_file=None, regions=None, gate=None):
@@ -178,7 +184,7 @@ def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dba
     begin, pairs end) capi.Event objects recorded around hgx_piece_compat and the gene-level hgx_pair_classes launch."""
     o = TypeOpts(int(bool(remove_low)), int(bool(keep_classes)), -1 if overlap is None else int(bool(overlap)), 0,
                  gate.h if gate is not None else None, *[(e.h if e is not None else None) for e in (events or (None,) * 4)],
-                 int(bool(em_fast)))
+                 _em_mode(em_fast))
     h = C.c_void_p()
     L = capi.lib()
     if dbatch is not None:
@@ -207,7 +213,7 @@ def type_file(pl, alignment_fname, regions=None, num_editdist=2, error_correctio
     reg = regions.encode() if isinstance(regions, str) else regions
     po = capi.ParseOpts(int(num_editdist), int(bool(error_correction)), int(bool(allow_discordant)), int(bool(simulation)), int(base_locus),
                         0, int(pl.base_fname == "codis" and pl.gene == "D18S51"), 0)
-    to = TypeOpts(int(bool(remove_low_abundance_alleles)), 0, -1, 0, None, None, None, None, None, int(bool(em_fast)))
+    to = TypeOpts(int(bool(remove_low_abundance_alleles)), 0, -1, 0, None, None, None, None, None, _em_mode(em_fast))
     h = C.c_void_p()
     L = capi.lib()
     rc = L.hgx_type_file(C.byref(h), pl.h, pl.index(), alignment_fname.encode(), reg or None, C.byref(po), C.byref(to), stream)
@@ -234,7 +240,7 @@ def type_many(pl, many, remove_low=True, stream=None, return_errors=False, em_fa
     `return_errors`: then that task's entry is the exception instance."""
     L = capi.lib()
     n = many.n_tasks
-    o = TypeOpts(int(bool(remove_low)), 0, 0, 0, None, None, None, None, None, int(bool(em_fast)))
+    o = TypeOpts(int(bool(remove_low)), 0, 0, 0, None, None, None, None, None, _em_mode(em_fast))
     hs = (C.c_void_p * max(n, 1))()
     rcs = (C.c_int32 * max(n, 1))()
     capi.check(L.hgx_type_many(hs, rcs, pl.h, pl.index(), many.h, C.byref(o), stream))
@@ -267,7 +273,7 @@ def type_many_loci(pls, manies, remove_low=True, stream=None, light=False, em_fa
     of LocusResult -- or, with `light`, of (num_reads, [top-2 allele names], EM iterations): what a throughput run looks at."""
     L = capi.lib()
     nl = len(pls)
-    o = TypeOpts(int(bool(remove_low)), 0, 0, 0, None, None, None, None, None, int(bool(em_fast)))
+    o = TypeOpts(int(bool(remove_low)), 0, 0, 0, None, None, None, None, None, _em_mode(em_fast))
     hs = [(C.c_void_p * max(m.n_tasks, 1))() for m in manies]
     rcs = [(C.c_int32 * max(m.n_tasks, 1))() for m in manies]
     out_pp = (C.POINTER(C.c_void_p) * max(nl, 1))(*[C.cast(h, C.POINTER(C.c_void_p)) for h in hs])
