@@ -30,7 +30,7 @@ struct hgx_emx_job {
     int32_t any_size;           // 1 (with fast = 0): take the problem up to HGX_EMX_HARD_MAX_CLASSES classes -- still ONE workgroup, so a
                                 // 16 000-class problem takes ~0.2 s: the validation mode "the reference's order at every size"
     int32_t fast;               // 0: the reference's own order of operations (bit-identical abundances); 1: table-lookup mat-vecs and
-                                // tree reductions on the same workgroup -- ~5x faster, abundances within rounding (~1e-12) of the
+                                // tree reductions on the same workgroup -- ~5x faster, abundances within 1e-8 (typically 1e-11) of the
                                 // reference's, same stopping and pruning rules
     // results (HOST memory, filled by hgx_emx_run)
     double *prob;               // [n_out] abundance, or -1.0 for an allele that is not in the returned dict (NULL with `recs`, below)

@@ -418,7 +418,7 @@ typedef struct hgx_type_opts {
     void *ev_pairs_begin, *ev_pairs_end;     /* ... and around the gene-level hgx_pair_classes launch (bench.py)           */
     int32_t em_fast;          /* EM #1 of problems of up to 4096 classes x 8192 alleles: 0 (default) = the reference's own order of
                                  floating-point operations (bit-identical abundances, hgx_emx.hip); 1 = table-lookup arithmetic on
-                                 the same one-workgroup kernel: ~5x faster, abundances within rounding (~1e-12; bar 1e-5), same
+                                 the same one-workgroup kernel: ~5x faster, abundances within 1e-8 (typically 1e-11; bar 1e-5), same
                                  stopping and pruning rules.  Larger problems take the chip-wide table-lookup path (<= 1e-9),
                                  unless em_fast = -1: the reference's order at EVERY size (k_emx up to 32768 classes; bit-identical
                                  abundances for any EM, at ~0.2 s for the 16 000-class EM #1 of a 1 M-read sample instead of 1 ms) */
