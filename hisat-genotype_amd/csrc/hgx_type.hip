@@ -471,6 +471,9 @@ int type_impl(hgx_typing *t, const hgx_locus *loc, const hgx_index *ix, const hg
     }
 
     hipStream_t em_stream = stream, gene_stream = stream;
+    const bool prof = getenv("HGX_TYPE_PROFILE") != nullptr;
+    const double tq0 = now_s();
+    double tq1 = tq0;
 
     if (overlap) {
         em_stream = ss.em;
@@ -496,6 +499,7 @@ int type_impl(hgx_typing *t, const hgx_locus *loc, const hgx_index *ix, const hg
             rc = hgx_groups_dims(groups, &ng, nullptr);          // host wait for the grouping alone
             if (rc) return rc;
         }
+        tq1 = now_s();
         HIPCHK(hipStreamWaitEvent(em_stream, ss.fork, 0));
     } else {
         gs.rc = gene_side(ix, db, compat, b_gbits.as<uint64_t>(), b_ghash.as<uint64_t>(), rows_ready, opts, stream, gs);
@@ -519,6 +523,8 @@ int type_impl(hgx_typing *t, const hgx_locus *loc, const hgx_index *ix, const hg
             rc = hgx_dedup_classes(&ecl, b_ebits.as<uint64_t>(), b_ehash.as<uint64_t>(), nullptr, n_pairs, a_pad, nullptr, em_stream);
         }
         if (rc) return rc;
+        if (prof) fprintf(stderr, "[type_impl] queue + wait for the grouping %.1f us | exon-level classes (rows, dedup) %.1f us\n", (tq1 - tq0) * 1e6,
+                          (now_s() - tq1) * 1e6);
         gate.release();              // several samples in flight: the bandwidth-bound front of this one is through
         rc = finish_hla(t, loc, ecl, opts, em_stream, stream, [&](hgx_classes **g) { const int r = finish_gene(); *g = gs.gcl; return r; });
         if (rc) return rc;
