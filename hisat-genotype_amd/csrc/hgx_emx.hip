@@ -70,6 +70,12 @@ struct EmxTask {
     EmxRes *res;        // result records of ALL jobs of the launch: a job reserves its run with one atomic add on *cursor
     unsigned long long *cursor;
     unsigned long long *stamps;   // [16] or NULL (HGX_EMX_STAMPS=1)
+    // cluster mode (k_emx<false, true>: ONE problem on gridDim.x workgroups): [0] barrier count, [1] abort flag, [2] command,
+    // [3] "some class needs the plain division" -- and the words the tile loops hand to the leader
+    int32_t cluster;              // > 0: this job runs as k_emx<false, true> on that many workgroups (the ordinary launch skips it)
+    unsigned int *cl_ctl;
+    unsigned long long *gvalid;   // [XCW]  as XLds::validw, written by the workgroup that walked the class tile
+    unsigned long long *gin;      // [XAW]  as XLds::in_now
 };
 
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
@@ -111,7 +117,7 @@ struct XLds {
     double red[XNW];
     double bc[4];
     int npos[4];
-    int cache_ord, need_slow, A1, res_base;
+    int cache_ord, need_slow, A1, res_base, cl_ok;
     double xs[512];                            // (fast mode) the slab of the vector a lookup table is built from
 };
 
@@ -186,14 +192,52 @@ __device__ __forceinline__ double xlut_row(const double *Tb, const uint64_t (&w)
 }
 
 #pragma clang fp contract(off)
-template <bool FAST>
+// CL (cluster mode, reference-order arithmetic only): ONE problem on gridDim.x workgroups -- for a problem far beyond the default gate
+// (16 000 classes: hgx_emx_job::any_size) the tile loops (class rows, Mk / Mr, initial estimate, rows, cols) are shared out over
+// the workgroups, everything per allele or per dict stays with workgroup 0 (the leader); the others serve commands.  Hand-overs
+// are agent-scope release / acquire fences around a counting barrier in global memory (bounded spins: a cluster that is not
+// co-resident in time gives up and the caller runs the problem on one workgroup).  Same sums in the same orders: same bits.
+template <bool FAST, bool CL = false>
 __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
+    static_assert(!(FAST && CL), "cluster mode is for the reference-order arithmetic");
     extern __shared__ double xlds_raw[];
     XLds &S = *reinterpret_cast<XLds *>(xlds_raw);
-    const EmxTask T = tasks[blockIdx.x];
+    const EmxTask T = tasks[CL ? 0 : blockIdx.x];
     if ((T.fast != 0) != FAST) return;                    // (the launch of the other arithmetic takes this job)
+    if ((T.cluster > 0) != CL) return;                    // (... and the cluster launch a cluster job)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wg = CL ? (int)blockIdx.x : 0, n_wg = CL ? (int)gridDim.x : 1;       // tile loops: start wave * n_wg + wg, stride XNW * n_wg
+    int cl_phase = 0;
+    bool cl_dead = false;
+    auto cluster_sync = [&]() {
+        if constexpr (CL) {
+            cl_phase += 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                bool ok = !cl_dead;
+                if (ok) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    __hip_atomic_fetch_add(&T.cl_ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned target = (unsigned)n_wg * (unsigned)cl_phase;
+                    long spins = 0;
+                    while (__hip_atomic_load(&T.cl_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        if (__hip_atomic_load(&T.cl_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+                        if (++spins > 400000) { __hip_atomic_store(&T.cl_ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+                        __builtin_amdgcn_s_sleep(8);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                S.cl_ok = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (!S.cl_ok) cl_dead = true;
+            __builtin_amdgcn_s_dcache_inv();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    };
     const int w64 = T.w64, A1s = T.a_pad;
     const int CpA = (T.c_alloc + 63) & ~63;             // stride of the class-indexed scratch arrays
     int C = T.C;                                        // (the hand-off mode continues with the merged classes)
@@ -250,7 +294,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
         // four classes per pass: the compact allele list (srt, 4 bytes per allele) is read once for the four, and a row is
         // read as 32-bit words -- the phase is bound by these LDS reads (12 bytes per class and allele before, 5 now)
         const uint32_t *row32 = reinterpret_cast<const uint32_t *>(rowbuf);
-        for (int c0 = 4 * wave; c0 < CpA; c0 += 4 * XNW) {
+        for (int c0 = 4 * (wave * n_wg + wg); c0 < CpA; c0 += 4 * XNW * n_wg) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int c = c0 + u;
@@ -352,15 +396,16 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     }
     const int Cp = (C + 63) & ~63, Cw = Cp >> 6;
     lap(8);
-    for (int j = tid; j < A1s; j += XB) T.vlen[j] = (T.len && j < A1) ? T.len[srt[j]] : 1.0;
+    if (wg == 0) for (int j = tid; j < A1s; j += XB) T.vlen[j] = (T.len && j < A1) ? T.len[srt[j]] : 1.0;
     phase_sync();
+    cluster_sync();                                       // every class row is in place
     // ---- Mk (word (aw, c), coalesced over c) and Mr (64 x 64 bit transposes, coalesced over the alleles) from the class-major rows
     if (!T.mask) {
         // (class tile, eight allele tiles) per item.  The class-major rows are read the way they lie in memory -- 8 classes x 8
         // words = eight 64-byte runs per load instruction; lane = class would be 64 cache lines per load -- and change hands through
         // a 4 KB stage per wavefront in LDS (slot of word u of class k: 8 k + (u ^ (k & 7)))
         unsigned long long *stage = reinterpret_cast<unsigned long long *>(&S.tmpo[0][0]) + (size_t)wave * 512;
-        for (int item = wave; item < Cw * ((A1w + 7) / 8); item += XNW) {
+        for (int item = wave * n_wg + wg; item < Cw * ((A1w + 7) / 8); item += XNW * n_wg) {
             const int cw = item % Cw, a8 = item / Cw;
             const int c = 64 * cw + lane;
             {
@@ -405,7 +450,8 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     uint16_t *posb[4] = {T.pos, T.pos + A1s, T.pos + 2 * (size_t)A1s, T.pos + 3 * (size_t)A1s};
     uint32_t *skeys = reinterpret_cast<uint32_t *>(&S.tmpo[1][0]);
     phase_sync();
-    for (int j = tid; j < A1; j += XB) {
+    cluster_sync();                                       // Mk and Mr are complete
+    if (wg == 0) for (int j = tid; j < A1; j += XB) {
         int fc = -1;
         for (int cw = 0; cw < Cw && fc < 0; ++cw) { const uint64_t m = T.Mr[(size_t)cw * A1s + j]; if (m) fc = 64 * cw + __builtin_ctzll(m); }
         T.first_c[j] = fc;
@@ -497,20 +543,44 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     };
     int ord_of[3] = {0, 0, 0};
     // Gene_prob_next (common:1311-1336): dict P -> dict N (N != P)
-    auto next_prob = [&](int P, int N, int live_a, int live_b) {
-        n_apps += 1;
-        if (tid == 0) S.need_slow = 0;
-        phase_sync();                                      // dv[P] as written by this workgroup is what the scalar loads see
-        // rows: alleles_prob of the classes of tile cw, alleles in key order.  A non-member's value is +0.0 in every dict
-        // (next_prob, select_alleles) and x + 0.0 == x: no membership test.
-        for (int cw = wave; cw < Cw; cw += XNW) {
+    enum : unsigned { CMD_EXIT = 0u, CMD_NEXT = 0x100u, CMD_INIT = 0x200u };
+    // Cluster mode walks its tiles with ONE or two wavefronts per SIMD, so nothing hides the latency of a scalar load per eight
+    // steps (it was 2/3 of a walk).  There the wave-uniform operands of 64 steps are fetched by the lanes (coalesced), parked in a
+    // per-wavefront LDS block and read back as broadcasts -- plain loads that the compiler keeps in flight across the steps -- while
+    // the next block's global loads are under way.  Same operations in the same order as the scalar-cache walks.
+    double *stg = reinterpret_cast<double *>(&S.tmpo[0][0]) + (size_t)wave * 512;          // two buffers of four 64-entry arrays
+    auto uni64 = [&](double v) -> uint64_t {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+    };
+    // rows: alleles_prob of the classes of tile cw, alleles in key order.  A non-member's value is +0.0 in every dict
+    // (next_prob, select_alleles) and x + 0.0 == x: no membership test.
+    auto rows_share = [&](int P) {
+        for (int cw = wave * n_wg + wg; cw < Cw; cw += XNW * n_wg) {
             double acc = 0.0;
             const uint64_t *mrow = T.Mr + (size_t)cw * A1s;
-            for (int j0 = 0; j0 < A1p8; j0 += 8) {
-                u32x16 mw, pv;
-                sload2(mrow + j0, dv[P] + j0, mw, pv);
+            if constexpr (CL) {
+                double m_nx = __longlong_as_double((long long)mrow[lane]), p_nx = dv[P][lane];
+                for (int blk = 0; blk < A1w; ++blk) {
+                    double *b = stg + (blk & 1) * 256;
+                    b[lane] = m_nx; b[64 + lane] = p_nx;
+                    __builtin_amdgcn_wave_barrier();
+                    if (blk + 1 < A1w) { m_nx = __longlong_as_double((long long)mrow[64 * (blk + 1) + lane]); p_nx = dv[P][64 * (blk + 1) + lane]; }
+                    for (int k0 = 0; k0 < 64; k0 += 16) {      // sixteen steps' operands in flight, then the sixteen dependent adds
+                        double mv[16], xv[16];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) acc = sel_add(acc, u64_of(mw, k), dbl_of(pv, k));
+                        for (int u = 0; u < 16; ++u) { mv[u] = b[k0 + u]; xv[u] = b[64 + k0 + u]; }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) acc = sel_add(acc, uni64(mv[u]), xv[u]);
+                    }
+                }
+            } else {
+                for (int j0 = 0; j0 < A1p8; j0 += 8) {
+                    u32x16 mw, pv;
+                    sload2(mrow + j0, dv[P] + j0, mw, pv);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc = sel_add(acc, u64_of(mw, k), dbl_of(pv, k));
+                }
             }
             const int c = 64 * cw + lane;
             const bool valid = c < C && acc > 0.0;        // classes with alleles_prob <= 0 are skipped (common:1321)
@@ -529,14 +599,20 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
             s_c[c] = valid ? acc : 1.0;
             r_c[c] = r2;
             const unsigned long long bm = __ballot(valid);
-            if (lane == 0) S.validw[cw] = bm;
-            if (__any(slow) && lane == 0) atomicOr(&S.need_slow, 1);
+            if constexpr (CL) {
+                if (lane == 0) T.gvalid[cw] = bm;
+                if (__any(slow) && lane == 0) atomicOr(&T.cl_ctl[3], 1u);
+            } else {
+                if (lane == 0) S.validw[cw] = bm;
+                if (__any(slow) && lane == 0) atomicOr(&S.need_slow, 1);
+            }
         }
-        phase_sync();
-        lap(1);
-        // cols: next[a] += count * prob / alleles_prob over the walked classes in dict order (a skipped class adds +0.0)
-        const bool block_slow = S.need_slow != 0;
-        for (int aw = wave; aw < A1w; aw += XNW) {
+    };
+    // cols: next[a] += count * prob / alleles_prob over the walked classes in dict order (a skipped class adds +0.0)
+    auto cols_share = [&](int P, int N) {
+        const unsigned long long *validw = CL ? T.gvalid : S.validw;
+        const bool block_slow = CL ? (T.cl_ctl[3] != 0u) : (S.need_slow != 0);
+        for (int aw = wave * n_wg + wg; aw < A1w; aw += XNW * n_wg) {
             const int j = 64 * aw + lane;
             const bool alive = j < A1;
             const bool pin = alive && din[P][j] != 0;
@@ -545,7 +621,33 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
             const bool tile_slow = block_slow || __any(!lane_fast);
             double acc = 0.0;
             const uint64_t *mcol = T.Mk + (size_t)aw * CpA;
-            if (!tile_slow) {
+            if (CL && !tile_slow) {
+                double m_nx = __longlong_as_double((long long)mcol[lane]), n_nx = n_c[lane], s_nx = s_c[lane], r_nx = r_c[lane];
+                for (int blk = 0; blk < Cw; ++blk) {
+                    double *b = stg + (blk & 1) * 256;
+                    b[lane] = m_nx; b[64 + lane] = n_nx; b[128 + lane] = s_nx; b[192 + lane] = r_nx;
+                    __builtin_amdgcn_wave_barrier();
+                    if (blk + 1 < Cw) {
+                        const int c = 64 * (blk + 1) + lane;
+                        m_nx = __longlong_as_double((long long)mcol[c]); n_nx = n_c[c]; s_nx = s_c[c]; r_nx = r_c[c];
+                    }
+                    for (int k0 = 0; k0 < 64; k0 += 8) {       // eight classes' operands in flight, the quotients, then the dependent adds
+                        double mv[8], nv[8], sv[8], rv[8], q[8];    // (four at a time: 36.2 ms of cols per EM instead of 33.6; a two-set
+                                                                    // software pipeline does not fit the 128 registers of a 1024-thread block)
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) { mv[u] = b[k0 + u]; nv[u] = b[64 + k0 + u]; sv[u] = b[128 + k0 + u]; rv[u] = b[192 + k0 + u]; }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const double x = ((nv[u]) * (p));
+                            const double q0 = ((x) * (rv[u]));
+                            const double e = __builtin_fma(-sv[u], q0, x);
+                            q[u] = __builtin_fma(e, rv[u], q0);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc = sel_add(acc, uni64(mv[u]), q[u]);
+                    }
+                }
+            } else if (!tile_slow) {
                 for (int c0 = 0; c0 < Cp; c0 += 8) {
                     u32x16 mw, vn, vs, vr;
                     sload4(mcol + c0, n_c + c0, s_c + c0, r_c + c0, mw, vn, vs, vr);
@@ -574,14 +676,35 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
             }
             bool seen = false;                             // some walked class contains the allele: it enters the next dict
             if (alive)
-                for (int cw = 0; cw < Cw; ++cw) seen = seen || (T.Mr[(size_t)cw * A1s + j] & S.validw[cw]) != 0ull;
+                for (int cw = 0; cw < Cw; ++cw) seen = seen || (T.Mr[(size_t)cw * A1s + j] & validw[cw]) != 0ull;
             const bool nin = pin && seen;
             if (alive) { dv[N][j] = nin ? acc : 0.0; din[N][j] = nin ? 1 : 0; }
             const unsigned long long inb = __ballot(nin);
-            if (lane == 0) S.in_now[aw] = inb;
+            if constexpr (CL) { if (lane == 0) T.gin[aw] = inb; }
+            else { if (lane == 0) S.in_now[aw] = inb; }
         }
+    };
+    auto next_prob = [&](int P, int N, int live_a, int live_b) {
+        n_apps += 1;
+        if (tid == 0) {
+            S.need_slow = 0;
+            if constexpr (CL) { T.cl_ctl[3] = 0u; T.cl_ctl[2] = CMD_NEXT | (unsigned)P | ((unsigned)N << 2); }
+        }
+        phase_sync();                                      // dv[P] as written by this workgroup is what the scalar loads see
+        cluster_sync();                                    // (cluster: the helpers take the command; dv[P] is complete for them)
+        rows_share(P);
+        phase_sync();
+        cluster_sync();
+        lap(1);
+        cols_share(P, N);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        cluster_sync();
+        if constexpr (CL) {                                // what the tile loops of all workgroups found, into the leader's LDS
+            for (int w = tid; w < Cw; w += XB) S.validw[w] = T.gvalid[w];
+            for (int w = tid; w < A1w; w += XB) S.in_now[w] = T.gin[w];
+            __syncthreads();
+        }
         lap(2);
         // insertion order: unchanged unless the membership or the walked classes changed since it was last derived
         bool differ = S.cache_ord < 0;
@@ -614,8 +737,9 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     };
 
     int prob = 0, next = 1, next2 = 2;
-    for (int j = tid; j < A1s; j += XB)
-        for (int d = 0; d < 3; ++d) { dv[d][j] = 0.0; din[d][j] = 0; }
+    if (wg == 0)
+        for (int j = tid; j < A1s; j += XB)
+            for (int d = 0; d < 3; ++d) { dv[d][j] = 0.0; din[d][j] = 0; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     double diff = 1.0;
@@ -783,25 +907,65 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
         }
     } else {
     // ---- initial estimate (common:1300-1309): prob[a] += count / |class| over the classes in dict order ---------------
-    for (int aw = wave; aw < A1w; aw += XNW) {
-        const int j = 64 * aw + lane;
-        double acc = 0.0;
-        const uint64_t *mcol = T.Mk + (size_t)aw * CpA;
-        for (int c0 = 0; c0 < Cp; c0 += 8) {
-            u32x16 mw, vt;
-            sload2(mcol + c0, t0_c + c0, mw, vt);
+    auto init_share = [&](int d) {
+        for (int aw = wave * n_wg + wg; aw < A1w; aw += XNW * n_wg) {
+            const int j = 64 * aw + lane;
+            double acc = 0.0;
+            const uint64_t *mcol = T.Mk + (size_t)aw * CpA;
+            if constexpr (CL) {
+                double m_nx = __longlong_as_double((long long)mcol[lane]), t_nx = t0_c[lane];
+                for (int blk = 0; blk < Cw; ++blk) {
+                    double *b = stg + (blk & 1) * 256;
+                    b[lane] = m_nx; b[64 + lane] = t_nx;
+                    __builtin_amdgcn_wave_barrier();
+                    if (blk + 1 < Cw) { m_nx = __longlong_as_double((long long)mcol[64 * (blk + 1) + lane]); t_nx = t0_c[64 * (blk + 1) + lane]; }
+                    for (int k0 = 0; k0 < 64; k0 += 16) {      // sixteen steps' operands in flight, then the sixteen dependent adds
+                        double mv[16], xv[16];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) acc = sel_add(acc, u64_of(mw, k), dbl_of(vt, k));
+                        for (int u = 0; u < 16; ++u) { mv[u] = b[k0 + u]; xv[u] = b[64 + k0 + u]; }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) acc = sel_add(acc, uni64(mv[u]), xv[u]);
+                    }
+                }
+            } else {
+                for (int c0 = 0; c0 < Cp; c0 += 8) {
+                    u32x16 mw, vt;
+                    sload2(mcol + c0, t0_c + c0, mw, vt);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) acc = sel_add(acc, u64_of(mw, k), dbl_of(vt, k));
+                }
+            }
+            if (j < A1) { dv[d][j] = acc; din[d][j] = 1; }
         }
-        if (j < A1) { dv[prob][j] = acc; din[prob][j] = 1; }
+    };
+    if constexpr (CL) {
+        if (wg != 0) {                                     // a helper: the tile loops the leader asks for, until it says stop
+            for (;;) {
+                cluster_sync();
+                if (cl_dead) return;
+                const unsigned cmd = (unsigned)__builtin_amdgcn_readfirstlane((int)T.cl_ctl[2]);
+                if (cmd == CMD_EXIT) return;
+                if (cmd & CMD_INIT) { init_share((int)(cmd & 3u)); cluster_sync(); continue; }
+                rows_share((int)(cmd & 3u));
+                phase_sync();
+                cluster_sync();
+                cols_share((int)(cmd & 3u), (int)((cmd >> 2) & 3u));
+                cluster_sync();
+            }
+        }
+        if (tid == 0) T.cl_ctl[2] = CMD_INIT | (unsigned)prob;
+        phase_sync();
+        cluster_sync();
     }
+    init_share(prob);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    cluster_sync();
     derive_order(prob, nullptr, 3);
     ord_of[prob] = 3;
     normalize(prob, 3);
     lap(5);
-    while (diff > 0.0001 && iter < 1000) {                 // common:1351
+    while (diff > 0.0001 && iter < 1000 && !cl_dead) {     // common:1351
         next_prob(prob, next, ord_of[prob], -1);
         next_prob(next, next2, ord_of[prob], ord_of[next]);
         bool bad = false;
@@ -856,6 +1020,11 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
         if (iter >= 10 && remove_low) select_alleles(prob);
         iter += 1;
         lap(6);
+    }
+    if constexpr (CL) {
+        if (tid == 0) T.cl_ctl[2] = CMD_EXIT;
+        cluster_sync();                                    // the helpers leave
+        if (cl_dead) { give_up(1.0); return; }             // (a cluster that was not co-resident in time: the caller uses one workgroup)
     }
     if (!keyerr) {
         if (remove_low) select_alleles(prob);              // common:1402-1407
@@ -934,17 +1103,30 @@ extern "C" int hgx_emx_get_timing(int fast, double *ms, long long *launches, lon
     return HGX_OK;
 }
 
+static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs_out, bool allow_cluster);
 int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs_out) {
+    int rc = emx_run(jobs, n_jobs, st, recs_out, true);
+    // a cluster that was not co-resident in time gave up (status 1 although the problem is within the limits): on one workgroup then
+    if (rc == HGX_OK && n_jobs == 1 && jobs[0].status == 1 && jobs[0].any_size && !jobs[0].fast && !jobs[0].mask &&
+        jobs[0].C > HGX_EMX_MAX_CLASSES && jobs[0].C <= HGX_EMX_HARD_MAX_CLASSES)
+        rc = emx_run(jobs, n_jobs, st, recs_out, false);
+    return rc;
+}
+static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs_out, bool allow_cluster) {
     ARGCHK(n_jobs >= 0);
     if (n_jobs == 0) return HGX_OK;
     ARGCHK(jobs);
     HGX_ONCE_PER_DEVICE({
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
     });
+    // cluster mode: a lone problem far beyond the default gate (the any-size validation mode of hgx_em / hgx_type_*) on several workgroups
+    const bool cluster = allow_cluster && n_jobs == 1 && jobs[0].any_size && !jobs[0].fast && !jobs[0].mask && jobs[0].C > HGX_EMX_MAX_CLASSES &&
+                         !hgx_test_switch("emx_no_cluster");
     const bool stamps = hgx_test_switch("emx_stamps") != nullptr;
     // scratch of every job out of ONE block; jobs beyond the kernel's limits get status 1 without a descriptor
-    struct Lay { size_t Rm, Mk, Mr, dv, pos, tmpv, vlen, cls, din, sorted, first, stamps, end; };
+    struct Lay { size_t Rm, Mk, Mr, dv, pos, tmpv, vlen, cls, din, sorted, first, stamps, cl, end; };
     std::vector<Lay> lays;
     std::vector<int> job_of;
     std::vector<size_t> base;
@@ -973,6 +1155,7 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_e
         L.sorted = o; o += up64(A1s * 4);
         L.first = o; o += up64(A1s * 4);
         L.stamps = o; o += up64(16 * 8);
+        L.cl = o; o += up64(64 + (size_t)(XCW + XAW) * 8);        // cluster control words, gvalid, gin
         L.end = o;
         lays.push_back(L);
         base.push_back(total);
@@ -1021,6 +1204,15 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_e
         T.res = (EmxRes *)(resb + head);
         T.cursor = (unsigned long long *)resb;
         T.stamps = stamps ? (unsigned long long *)(b + L.stamps) : nullptr;
+        T.cluster = 0;
+        T.cl_ctl = (unsigned int *)(b + L.cl);
+        T.gvalid = (unsigned long long *)(b + L.cl + 64);
+        T.gin = T.gvalid + XCW;
+        if (cluster) {
+            const int Cw = (int)(((size_t)J.C + 63) / 64);
+            T.cluster = std::max(2, std::min(64, (Cw + 3) / 4));        // a class tile per SIMD
+            HIPCHK(hipMemsetAsync(b + L.cl, 0, 64 + (size_t)(XCW + XAW) * 8, st));
+        }
     }
     for (size_t off = 0; off < tasks.size() * sizeof(EmxTask);) {      // descriptors through the pinned staging buffer
         const size_t chunk = std::min<size_t>(tasks.size() * sizeof(EmxTask) - off, 128u << 10);
@@ -1035,7 +1227,8 @@ int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_e
     if (timing) for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     if (any_exact) {
         if (timing) HIPCHK(hipEventRecord(ev[0], st));
-        hipLaunchKernelGGL(k_emx<false>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
+        if (cluster) hipLaunchKernelGGL((k_emx<false, true>), dim3((unsigned)tasks[0].cluster), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
+        else hipLaunchKernelGGL(k_emx<false>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
         if (timing) HIPCHK(hipEventRecord(ev[1], st));
     }
     if (any_fast) {

@@ -261,9 +261,9 @@ int hgx_em_last_exact(void);
  * own order (hgx_em_last_exact); order_host[a] = position, -1 for alleles outside the dict.  Returns 0 otherwise. */
 int hgx_em_last_order(int32_t *order_host, int32_t n_alleles);
 /* arithmetic of hgx_em / hgx_em_ordered on this thread for problems the one-workgroup kernel takes (see hgx_type_opts.em_fast):
- * 0 = the reference's order (default), 1 = table lookups, -1 = the reference's order at EVERY size (the one-workgroup kernel also
- * beyond 4096 classes, up to 32768: a validation mode -- one CU, ~0.2 s for 16 000 classes x 4 500 alleles).  Returns the previous
- * setting. */
+ * 0 = the reference's order (default), 1 = table lookups, -1 = the reference's order at EVERY size (k_emx also beyond 4096
+ * classes, up to 32768; a lone problem of that size runs on a cluster of workgroups: ~45 ms for 16 000 classes x 4 500 alleles, where
+ * the default table-lookup path takes 1 ms).  Returns the previous setting. */
 int hgx_em_set_fast(int on);
 
 /* The exon -> gene hand-off in one call (typing_core.py:1752-1782): Gene_cmpt2 = every class of `c` filtered to the alleles of
@@ -420,8 +420,9 @@ typedef struct hgx_type_opts {
                                  floating-point operations (bit-identical abundances, hgx_emx.hip); 1 = table-lookup arithmetic on
                                  the same one-workgroup kernel: ~5x faster, abundances within 1e-8 (typically 1e-11; bar 1e-5), same
                                  stopping and pruning rules.  Larger problems take the chip-wide table-lookup path (<= 1e-9),
-                                 unless em_fast = -1: the reference's order at EVERY size (k_emx up to 32768 classes; bit-identical
-                                 abundances for any EM, at ~0.2 s for the 16 000-class EM #1 of a 1 M-read sample instead of 1 ms) */
+                                 unless em_fast = -1: the reference's order at EVERY size (k_emx up to 32768 classes, in cluster mode for
+                                 a lone large problem; bit-identical abundances for any EM: 33 ms per step for a 1 M-read sample with
+                                 a 16 000-class EM #1 instead of 2.2 ms) */
 } hgx_type_opts;
 
 int hgx_dbatch_create(hgx_dbatch **out, const hgx_batch *b, void *stream);     /* upload; returns when the copy is complete */

@@ -129,13 +129,18 @@ def test_emx_fast_mode_is_within_rounding(orc, case):
         engine.em_set_fast(old)
 
 
+@pytest.mark.parametrize("cluster", [True, False], ids=["cluster", "one_workgroup"])
 @pytest.mark.parametrize("case", [(7000, 2600, 9000, 0.2), (7000, 4549, 16098, 0.3)], ids=lambda c: "A%d_used%d_C%d" % c[:3])
-def test_any_size_mode_is_the_reference_bit_for_bit(orc, case):
-    """em_fast = -1: the reference's own order of operations at EVERY size -- the one-workgroup kernel takes problems beyond its
-    default gate of 4 096 classes (here 9 000, and the 16 098 classes x 4 549 alleles of the exon-level EM of BASELINE
-    configs[1]): `==` the C oracle on every abundance, same iteration count, plain stable sort for ties (no tolerance).  The
-    default mode sends such problems to the chip-wide table-lookup path (<= 1e-9), which this test also checks."""
+def test_any_size_mode_is_the_reference_bit_for_bit(orc, case, cluster):
+    """em_fast = -1: the reference's own order of operations at EVERY size -- the kernel takes problems beyond its default gate of
+    4 096 classes (here 9 000, and the 16 098 classes x 4 549 alleles of the exon-level EM of BASELINE configs[1]): `==` the C
+    oracle on every abundance, same iteration count, plain stable sort for ties (no tolerance).  A lone problem of that size runs
+    in CLUSTER mode (k_emx<false, true>: its tile loops shared out over several workgroups, hand-overs through agent-scope
+    fences): repeated runs must give the same bits; `emx_no_cluster` keeps it on one workgroup.  The default mode sends such
+    problems to the chip-wide table-lookup path (<= 1e-9), which this test also checks."""
     A, n_used, C_, dens = case
+    if not cluster and C_ > 10000:
+        pytest.skip("one workgroup at 16 098 classes takes a few seconds per EM: covered at 9 000")
     rng = np.random.RandomState(77 + C_)
     a_pad, name_rank, classes, rows, counts, lengths = _random_problem(rng, A, n_used, C_, dens)
     cl = engine.Classes.from_host(rows, counts, a_pad)
@@ -144,13 +149,22 @@ def test_any_size_mode_is_the_reference_bit_for_bit(orc, case):
     exp = np.full(A, -1.0)
     exp[oa] = op
     old = engine.em_set_fast(-1)
+    if not cluster:
+        engine.test_switch("emx_no_cluster", "1")
     try:
-        p, it = cl.em(A, True, None)
-        assert engine.em_last_exact()
+        for rep in range(3 if cluster else 1):
+            p, it = cl.em(A, True, None)
+            assert engine.em_last_exact()
+            assert it == oit, (rep, it, oit)
+            assert np.array_equal(p, exp), (rep, float(np.max(np.abs(p - exp))))
+        pl, itl = cl.em(A, False, lengths)                  # no pruning, allele lengths
+        oa2, op2, oit2 = orc.single_abundance(A, classes, counts, False, lengths)
+        exp2 = np.full(A, -1.0)
+        exp2[oa2] = op2
+        assert itl == oit2 and np.array_equal(pl, exp2)
     finally:
         engine.em_set_fast(old)
-    assert it == oit
-    assert np.array_equal(p, exp), float(np.max(np.abs(p - exp)))
+        engine.test_switch("emx_no_cluster", None)
     p2, it2 = cl.em(A, True, None)                       # default: table lookups for this size
     assert not engine.em_last_exact()
     assert it2 == oit and np.array_equal(p2 < 0, exp < 0) and np.max(np.abs(p2 - exp)) <= 1e-9
