@@ -26,6 +26,10 @@
 //          only when the membership or the set of walked classes changed.
 // The class matrix is re-laid once per problem in the compact name-ordered allele space, in the two word orders the passes
 // stream: Mk[allele tile][class] and Mr[class tile][allele].
+//
+// Three instantiations: k_emx<false> (this contract), k_emx<true> (hgx_type_opts.em_fast: the same skeleton with table-lookup
+// mat-vecs and tree reductions, within ~1e-11 of the reference) and k_emx<false, true> (cluster mode: ONE large problem on several
+// workgroups, same contract, same bits -- see the comment at the kernel).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
