@@ -36,7 +36,7 @@ def get(tag, ctr, sub):
             return v
 d = json.load(open(f"{src}/bench_default.json"))
 names = {"k_pair_classes": ("", "k_pair_classes_x2<2, false>"), "k_piece_compat": ("", "k_piece_compat_tiled"), "k_lutmatvec<0>": ("", "k_lutmatvec<0>"),
-         "k_lutmatvec<1>": ("", "k_lutmatvec<1>"), "k_emx (table lookups)": ("_panel", "k_emx<true>"), "k_emx (reference order)": ("_panel", "k_emx<false>")}
+         "k_lutmatvec<1>": ("", "k_lutmatvec<1>"), "k_emx (table lookups)": ("_panel", "k_emx<true"), "k_emx (reference order)": ("_panel", "k_emx<false")}
 raw, hb = {}, {}
 for k, (tag, sub) in names.items():
     f, w = get(tag, "FETCH_SIZE", sub), get(tag, "WRITE_SIZE", sub)
