@@ -610,6 +610,19 @@ def run_panel64(args, rank, local_rank, world, dist):
                             "16 C) (SURVEY.md 8d).  The kernel is bound by LDS table lookups and FP64 issue on ONE CU per task, not by HBM: the "
                             "fraction says how far a task-parallel EM sits from streaming its matrices",
                     "kernels": kernels}
+    # the same panel with the OTHER EM arithmetic, a few steps outside the timed region: the line then carries both the throughput
+    # form (table lookups, <= 1e-8) and the bit-identical form (the library's default, hgx_type_opts.em_fast = 0)
+    other = None
+    if manies and world == 1:
+        ks = sorted(manies)
+        t0 = time.perf_counter()
+        n_other = 3
+        for _ in range(n_other):
+            rows_o = htyping.type_many_loci([packed[k] for k in ks], [manies[k][1] for k in ks], light=True, em_fast=bool(args.em_exact))
+        dt = (time.perf_counter() - t0) / n_other
+        same = sum(1 for k, row in zip(ks, rows_o) for n, r in zip(manies[k][0], row) if sorted(r[1]) == sorted(last[n][1]))
+        other = {"em_arithmetic": "table lookups (hgx_type_opts.em_fast = 1)" if args.em_exact else "reference order (hgx_type_opts.em_fast = 0: bit-identical abundances)",
+                 "ms_per_step": round(dt * 1e3, 3), "value": round(reads / dt, 1), "steps": n_other, "tasks_with_the_same_top2_as_the_timed_form": same}
     cb = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_cpu = 1000
@@ -630,7 +643,7 @@ def run_panel64(args, rank, local_rank, world, dist):
                 "merged_batches": {packed[k].gene: {"alleles": packed[k].n_alleles, "tasks": m.n_tasks, "pairs": m.n_pairs, "piece_refs": m.n_refs,
                                                     "distinct_pieces": m.n_pieces} for k, (_, m) in sorted(manies.items())},
                 "setup_s": round(t_setup, 1)},
-            "roofline": roof, "cpu_baseline": cb})
+            "roofline": roof, "cpu_baseline": cb, "other_em_arithmetic": other})
     return None
 
 
