@@ -445,8 +445,48 @@ def run_class1(args, rank, local_rank, world, dist):
         work.append((i, pl, batch, engine.DeviceBatch(batch), comms.get(i), sample))
     t_setup = time.perf_counter() - t_setup
 
+    # Several whole loci on this rank (always so on one GPU): typed side by side, one host thread and stream set per locus -- the
+    # reference's locus loop (typing_core.py:370) has no dependency between loci, and the EM of one locus is a chain of short launches
+    # that leaves most of the GPU to the scoring of the next.  (--one-by-one: locus after locus.)
+    import threading
+    side_by_side = not comms and len(work) > 1 and not args.one_by_one
+    pool = {"mode": 0, "stop": False, "res": [None] * len(work), "err": [], "timing": {}}
+    if side_by_side:
+        pool["start"], pool["done"] = threading.Barrier(len(work) + 1), threading.Barrier(len(work) + 1)
+        gate = engine.Gate()
+
+        def worker(k):
+            i, pl, batch, db, _, _ = work[k]
+            capi.set_device(local_rank)
+            capi.set_stream_slot(k)
+            st = capi.get_stream(2)
+            mode = 0
+            while True:
+                pool["start"].wait()
+                if pool["stop"]:
+                    break
+                try:
+                    if pool["mode"] != mode:
+                        mode = pool["mode"]
+                        engine.em_set_timing(mode)
+                    pool["res"][k] = step(pl, batch, db, None, st, gate)
+                    capi.sync(st)
+                except BaseException as e:        # re-raised on the main thread
+                    pool["err"].append(e)
+                pool["done"].wait()
+            pool["timing"][k] = engine.em_get_timing()
+        threads = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(len(work))]
+        for t in threads:
+            t.start()
+
     def body():
         out = {}
+        if side_by_side:
+            pool["start"].wait()
+            pool["done"].wait()
+            if pool["err"]:
+                raise pool["err"][0]
+            return {w[0]: pool["res"][k] for k, w in enumerate(work)}
         for i, pl, batch, db, comm, sample in work:
             if comm is not None:
                 out[i] = hdist.type_shard(pl, batch, db, comm)
@@ -460,12 +500,27 @@ def run_class1(args, rank, local_rank, world, dist):
     n_timed = min(N_TIMED_STEPS, args.steps)
 
     def timed_body():
-        engine.em_set_timing(2 if (timing and state["k"] >= args.steps - n_timed) else 0)
+        mode = 2 if (timing and state["k"] >= args.steps - n_timed) else 0
+        pool["mode"] = mode
+        engine.em_set_timing(mode)
         state["k"] += 1
         return body()
     elapsed, last = _timed(dist, args.steps, timed_body)
     em_timing = engine.em_get_timing() if timing else {}
     engine.em_set_timing(0)
+    if side_by_side:
+        pool["stop"] = True
+        pool["start"].wait()
+        for t in threads:
+            t.join()
+        if timing:                                              # the workers' totals (thread-local in libhgx), added up
+            em_timing = {}
+            for tm in pool["timing"].values():
+                for name, v in tm.items():
+                    acc = em_timing.setdefault(name, [0.0, 0, 0, 0])
+                    for q in range(4):
+                        acc[q] += v[q]
+            em_timing = {k: tuple(v) for k, v in em_timing.items()}
     reads = sum(r.num_reads for i, r in last.items() if groups[i][0] == rank)        # every locus counted once
     calls = {loci[i].gene: ([a for a, _ in r.gene_prob[:2]], work[k][5]) for k, (i, r) in enumerate(sorted(last.items()))}
     if dist is not None:
@@ -490,6 +545,7 @@ def run_class1(args, rank, local_rank, world, dist):
             "config": {"workload": "configs[2]: HLA class I A+B+C, %d simulated 2x150bp pairs each, piece batches resident in HBM" % args.pairs,
                        "rank_groups": {loci[i].gene: groups[i] for i in sorted(groups)},
                        "calls": {g: {"top2": t, "true": s, "correct": sorted(t) == sorted(s)} for g, (t, s) in calls.items()},
+                       "form": "the rank's loci side by side (a host thread and stream set per locus)" if side_by_side else "locus after locus",
                        "parallelism": "loci over rank groups; pairs of a locus over the ranks of its group (pileup all-reduce at parse, "
                                       "class-table all-gather + merge per step over RCCL); no other data-path collective",
                        "setup_s": round(t_setup, 1)},
