@@ -34,3 +34,34 @@ def test_invalid_arguments_are_reported_not_crashed():
     lib = capi.lib()
     rc = lib.hgx_locus_create(None, None)
     assert rc == -1 and b"invalid argument" in lib.hgx_last_error()
+
+
+def test_switches_live_in_the_process_not_in_the_environment(monkeypatch):
+    """Path-forcing switches are an in-process test hook (hgx_test_switch_set): set, cleared one by one or all at once; an
+    environment variable of the old name does nothing (the library reads no path-selecting environment variable)."""
+    import ctypes as C
+    from hisatgenotype_amd import capi, engine
+    L = capi.lib()
+    L.hgx_test_switch.restype = C.c_char_p
+    monkeypatch.setenv("HGX_EM_NO_EMX", "1")
+    assert L.hgx_test_switch(b"em_no_emx") is None
+    engine.test_switch("em_no_emx", "1")
+    engine.test_switch("em_mid_nnz", 123)
+    assert L.hgx_test_switch(b"em_no_emx") == b"1" and L.hgx_test_switch(b"em_mid_nnz") == b"123"
+    engine.test_switch("em_no_emx", None)
+    assert L.hgx_test_switch(b"em_no_emx") is None and L.hgx_test_switch(b"em_mid_nnz") == b"123"
+    with engine.test_switches(piece_untiled=1):
+        assert L.hgx_test_switch(b"piece_untiled") == b"1"
+    assert L.hgx_test_switch(b"piece_untiled") is None
+    engine.test_switch(None)
+    assert L.hgx_test_switch(b"em_mid_nnz") is None
+
+
+def test_em_mode_values():
+    """hgx_em_set_fast: 0 the reference's order where the default gate allows, 1 table lookups, -1 the reference's order at every size;
+    the call returns the previous setting (thread-local)."""
+    from hisatgenotype_amd import engine
+    assert engine.em_set_fast(True) is False
+    assert engine.em_set_fast(-1) is True
+    assert engine.em_set_fast(False) == -1
+    assert engine.em_set_fast(False) is False
