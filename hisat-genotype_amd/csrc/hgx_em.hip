@@ -3002,6 +3002,10 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
 #endif
             HIPCHK(hipGetLastError());
         }
+        // test switch em_graph: the batch's launches captured into a hipGraph and launched as one (measurement of what a graph
+        // buys a chain of dependent 15 us kernels; NOTEBOOK.md section 10) -- capture, instantiation and launch are all inside the call
+        const bool as_graph = !grid && !g_timing && hgx_test_switch("em_graph") != nullptr;
+        if (as_graph) HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         for (int b = 0; b < (grid ? 0 : nb); ++b) {
             if (fuse) {
                 // six launches per iteration: SQUAREM and the advance step ride in the prologue of the rows pass that follows
@@ -3026,6 +3030,14 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             if ((rc = next_prob(q2, pr2, 0, q3, pr3, 1))) return rc;      // only if extrapolated
             hipLaunchKernelGGL(k_em_advance, dim3(1), dim3(BLOCK), 0, st, p, pr, q1, pr1, q3, pr3, A, remove_low ? 1 : 0, scal);
         }
+        hipGraphExec_t gexec = nullptr;
+        hipGraph_t gcap = nullptr;
+        if (as_graph) {
+            HIPCHK(hipStreamEndCapture(st, &gcap));
+            HIPCHK(hipGraphInstantiate(&gexec, gcap, nullptr, nullptr, 0));
+            HIPCHK(hipGraphLaunch(gexec, st));
+        }
+        struct GraphDrop { hipGraphExec_t &e; hipGraph_t &g; hipStream_t s; ~GraphDrop() { if (e) { (void)hipStreamSynchronize(s); (void)hipGraphExecDestroy(e); } if (g) (void)hipGraphDestroy(g); } } graph_drop{gexec, gcap, st};
         // Pruning has started (iteration index >= 10): the compact tail kernel goes out speculatively right behind the batch --
         // it checks the survivor count itself -- so that batch result and tail result come back in ONE host round trip.
         const bool spec_tail = use_tail && remove_low && launched_iters >= 11 && tail_failed_at == 1e300;
