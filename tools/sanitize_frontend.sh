@@ -12,7 +12,7 @@ for f in hgx_sam hgx_bam hgx_host; do
     g++ -pthread -O1 -g -fsanitize=address -fno-omit-frame-pointer -std=c++17 -fPIC -I $R/include -I $C -c $C/$f.cpp -o /tmp/${f}_asan.o
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o $C/libhgx.so /tmp/hgx_sam_asan.o /tmp/hgx_bam_asan.o /tmp/hgx_host_asan.o \
-    $C/hgx_device.o $C/hgx_dedup.o $C/hgx_em.o $C/hgx_type.o -lz
+    $(ls $C/*.o | grep -v -e hgx_sam.o -e hgx_bam.o -e hgx_host.o) -lz -ldl
 export LD_PRELOAD=$(gcc -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0:halt_on_error=1
 cd $R
 # (tests of the error paths throw C++ exceptions; under an LD_PRELOADed libasan in a Python process the __cxa_throw interceptor
@@ -32,7 +32,8 @@ d = tempfile.mkdtemp()
 ps, pb = os.path.join(d, "x.sam"), os.path.join(d, "x.bam")
 open(ps, "w").write(sam)
 bamio.write_bam_native(pb, sam, [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
-os.environ["HGX_BAM_CHAIN_MIN"] = "1000000"          # the record chain is walked in ranges
+from hisatgenotype_amd import engine
+engine.test_switch("bam_chain_min", "1000000")      # the record chain is walked in ranges
 b1 = pl.parse_sam(sam, n_threads=8)
 for b in (pl.parse_alignment_file(ps, None, n_threads=8), pl.parse_alignment_file(pb, None, n_threads=8),
           pl.parse_alignment_file(pb, [loc.ref_allele], n_threads=5)):
@@ -47,7 +48,7 @@ for f in hgx_sam hgx_bam hgx_host; do
     g++ -pthread -O1 -g -fsanitize=thread -std=c++17 -fPIC -I $R/include -I $C -c $C/$f.cpp -o /tmp/${f}_tsan.o
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o $C/libhgx.so /tmp/hgx_sam_tsan.o /tmp/hgx_bam_tsan.o /tmp/hgx_host_tsan.o \
-    $C/hgx_device.o $C/hgx_dedup.o $C/hgx_em.o $C/hgx_type.o -lz
+    $(ls $C/*.o | grep -v -e hgx_sam.o -e hgx_bam.o -e hgx_host.o) -lz -ldl
 LD_PRELOAD=$(gcc -print-file-name=libtsan.so) TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0 exitcode=0" python3 - > /tmp/hgx_tsan.log 2>&1 <<'PY'
 import sys, os, tempfile
 sys.path.insert(0, os.getcwd())
