@@ -1110,10 +1110,13 @@ extern "C" int hgx_emx_get_timing(int fast, double *ms, long long *launches, lon
 static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs_out, bool allow_cluster);
 int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs_out) {
     int rc = emx_run(jobs, n_jobs, st, recs_out, true);
-    // a cluster that was not co-resident in time gave up (status 1 although the problem is within the limits): on one workgroup then
-    if (rc == HGX_OK && n_jobs == 1 && jobs[0].status == 1 && jobs[0].any_size && !jobs[0].fast && !jobs[0].mask &&
-        jobs[0].C > HGX_EMX_MAX_CLASSES && jobs[0].C <= HGX_EMX_HARD_MAX_CLASSES)
-        rc = emx_run(jobs, n_jobs, st, recs_out, false);
+    // a cluster that was not co-resident in time gave up (status 1 although the problem is within the limits): the call again with
+    // every problem on one workgroup
+    bool gave_up = false;
+    for (int i = 0; i < n_jobs && rc == HGX_OK; ++i)
+        gave_up = gave_up || (jobs[i].status == 1 && jobs[i].any_size && !jobs[i].fast && !jobs[i].mask && jobs[i].C > HGX_EMX_MAX_CLASSES &&
+                              jobs[i].C <= HGX_EMX_HARD_MAX_CLASSES && jobs[i].w64 <= 128 && jobs[i].a_pad <= HGX_EMX_MAX_ALLELES);
+    if (rc == HGX_OK && gave_up) rc = emx_run(jobs, n_jobs, st, recs_out, false);
     return rc;
 }
 static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs_out, bool allow_cluster) {
@@ -1125,9 +1128,10 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
     });
-    // cluster mode: a lone problem far beyond the default gate (the any-size validation mode of hgx_em / hgx_type_*) on several workgroups
-    const bool cluster = allow_cluster && n_jobs == 1 && jobs[0].any_size && !jobs[0].fast && !jobs[0].mask && jobs[0].C > HGX_EMX_MAX_CLASSES &&
-                         !hgx_test_switch("emx_no_cluster");
+    // cluster mode: a problem far beyond the default gate (the any-size mode of hgx_em / hgx_type_*) gets a launch of its own on several
+    // workgroups; such launches follow each other on the stream (one problem's cluster fills a good part of the chip)
+    const bool clusters = allow_cluster && !hgx_test_switch("emx_no_cluster");
+    auto wants_cluster = [&](const hgx_emx_job &J) { return clusters && J.any_size && !J.fast && !J.mask && J.C > HGX_EMX_MAX_CLASSES; };
     const bool stamps = hgx_test_switch("emx_stamps") != nullptr;
     // scratch of every job out of ONE block; jobs beyond the kernel's limits get status 1 without a descriptor
     struct Lay { size_t Rm, Mk, Mr, dv, pos, tmpv, vlen, cls, din, sorted, first, stamps, cl, end; };
@@ -1212,7 +1216,7 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
         T.cl_ctl = (unsigned int *)(b + L.cl);
         T.gvalid = (unsigned long long *)(b + L.cl + 64);
         T.gin = T.gvalid + XCW;
-        if (cluster) {
+        if (wants_cluster(J)) {
             const int Cw = (int)(((size_t)J.C + 63) / 64);
             T.cluster = std::max(2, std::min(64, (Cw + 3) / 4));        // a class tile per SIMD
             HIPCHK(hipMemsetAsync(b + L.cl, 0, 64 + (size_t)(XCW + XAW) * 8, st));
@@ -1231,8 +1235,12 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
     if (timing) for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     if (any_exact) {
         if (timing) HIPCHK(hipEventRecord(ev[0], st));
-        if (cluster) hipLaunchKernelGGL((k_emx<false, true>), dim3((unsigned)tasks[0].cluster), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
-        else hipLaunchKernelGGL(k_emx<false>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
+        bool any_plain = false;
+        for (const EmxTask &T : tasks) any_plain = any_plain || (!T.fast && T.cluster == 0);
+        if (any_plain) hipLaunchKernelGGL(k_emx<false>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
+        for (int t = 0; t < n; ++t)
+            if (tasks[t].cluster > 0)
+                hipLaunchKernelGGL((k_emx<false, true>), dim3((unsigned)tasks[t].cluster), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>() + t);
         if (timing) HIPCHK(hipEventRecord(ev[1], st));
     }
     if (any_fast) {

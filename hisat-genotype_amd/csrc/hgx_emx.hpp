@@ -28,8 +28,8 @@ struct hgx_emx_job {
                                 // runs on that set and `first` / n_classes refer to it
     int32_t C, w64, a_pad, remove_low;
     int32_t any_size;           // 1 (with fast = 0): take the problem up to HGX_EMX_HARD_MAX_CLASSES classes: "the reference's order at
-                                // every size".  A lone such job runs in cluster mode (several workgroups, ~45 ms at 16 000 classes);
-                                // several in one call run on one workgroup each (~0.3 s)
+                                // every size".  Such a job beyond the default gate gets a cluster launch of its own (several workgroups,
+                                // ~45 ms at 16 000 classes), behind the ordinary launch of the call's other jobs
     int32_t fast;               // 0: the reference's own order of operations (bit-identical abundances); 1: table-lookup mat-vecs and
                                 // tree reductions on the same workgroup -- ~5x faster, abundances within 1e-8 (typically 1e-11) of the
                                 // reference's, same stopping and pruning rules

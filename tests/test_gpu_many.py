@@ -128,3 +128,26 @@ def test_many_with_only_empty_tasks():
     rows = htyping.type_many_loci([pl], [many], light=True)
     assert [r[0] for r in rows[0]] == [0, 0]
     many.close()
+
+
+def test_many_loci_in_the_any_size_mode():
+    """em_fast = -1 through the many-task path with deep samples (more than 4 096 exon-level classes): each such EM gets a cluster
+    launch of its own behind the ordinary launch; results `==` the one-task path in the same mode (itself `==` the C oracle: test_gpu_emx.py)."""
+    pls, manies, batches = [], [], []
+    for k, (A, V) in enumerate([(7000, 2500), (5000, 1800)]):
+        loc = synth.make_hla_like_locus(n_alleles=A, n_vars=V, seed=60 + k, var_id_base=100000 * k)
+        pl = hl.PackedLocus.from_synth(loc)
+        sample = synth.pick_sample(loc, 3 + k)
+        deep = pl.parse_sam(synth.simulate_sam_fast(loc, sample, 60000, err_rate=0.002, seed=19 + k))
+        small = pl.parse_sam(synth.simulate_sam_fast(loc, sample, 700, err_rate=0.002, seed=29 + k))
+        pls.append(pl); batches.append([deep, small]); manies.append(engine.ManyBatch(pl, [deep, small]))
+    rows = htyping.type_many_loci(pls, manies, em_fast=-1)
+    big = 0
+    for pl, bs, row in zip(pls, batches, rows):
+        for b, got in zip(bs, row):
+            want = _one(pl, b, em_fast=-1)
+            big += want.em[0]["n_classes"] > 4096
+            _same(got, want)
+    assert big >= 2
+    for m in manies:
+        m.close()
