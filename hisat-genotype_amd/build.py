@@ -27,10 +27,25 @@ def _headers():
     return [os.path.join(ROOT, "include", "hgx.h")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
 
 
-def _object_fresh(src, newest_header):
-    """An object is reused only if it is newer than its source AND every header (struct layouts are shared between units)."""
+def _deps(path, seen=None):
+    """`path` and every local header it includes, directly or not (#include "..." resolved in csrc/, csrc/lab/ and include/)."""
+    import re
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    with open(path, errors="replace") as f:
+        for m in re.finditer(r'^\s*#\s*include\s*"([^"]+)"', f.read(), re.M):
+            for d in (os.path.dirname(path), CSRC, os.path.join(CSRC, "lab"), os.path.join(ROOT, "include")):
+                _deps(os.path.join(d, m.group(1)), seen)
+    return seen
+
+
+def _object_fresh(src, newest_header=None):
+    """An object is reused only if it is newer than its source AND every header that source includes (struct layouts are shared
+    between units)."""
     obj = src.rsplit(".", 1)[0] + ".o"
-    return os.path.exists(obj) and os.path.getmtime(obj) > os.path.getmtime(src) and os.path.getmtime(obj) > newest_header
+    return os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(d) for d in _deps(src))
 
 
 def needs_build():
@@ -76,24 +91,35 @@ LAB_DIR = os.path.join(CSRC, "lab")
 LAB_LIB = os.path.join(LAB_DIR, "libhgx_lab.so")
 
 
+LAB_UNITS = ["hgx_em.hip", "hgx_front_host.cpp"]      # the units with #ifdef HGX_LAB code
+
+
 def build_lab(force=False, verbose=True):
-    """libhgx_lab.so: the product objects with hgx_em.hip recompiled under -DHGX_LAB (the only unit that has lab code: the int8-MFMA,
-    persistent and resident-grid EM back-ends in csrc/lab/*.inc).  Lab tools and tests/test_gpu_lab.py bind it (capi.use_lab());
-    nothing in the product path does."""
+    """libhgx_lab.so: the product objects with the LAB_UNITS recompiled under -DHGX_LAB -- hgx_em.hip (the int8-MFMA, persistent and
+    resident-grid EM back-ends in csrc/lab/*.inc) and hgx_front_host.cpp (the CPU emulation of the device front end's kernels, which
+    the CPU test-suite compares with the host front end).  Lab tools and tests bind it (capi.use_lab()); nothing in the product
+    path does."""
     build(force=force, verbose=verbose)
-    src = os.path.join(CSRC, "hgx_em.hip")
-    obj = os.path.join(LAB_DIR, "hgx_em_lab.o")
-    deps = _headers() + [src] + [os.path.join(LAB_DIR, f) for f in os.listdir(LAB_DIR) if f.endswith(".inc")]
-    newest = max(os.path.getmtime(d) for d in deps)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
-        cmd = [hipcc, "--offload-arch=" + ARCH, "-DHGX_LAB", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
-               "-I", CSRC, "-Wall", "-Wno-unused-result", "-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-    if force or not os.path.exists(LAB_LIB) or os.path.getmtime(LAB_LIB) < max(os.path.getmtime(obj), os.path.getmtime(LIB)):
-        objs = [s_.rsplit(".", 1)[0] + ".o" for s_ in _sources() if os.path.basename(s_) != "hgx_em.hip"] + [obj]
+    incs = [os.path.join(LAB_DIR, f) for f in os.listdir(LAB_DIR) if f.endswith(".inc")]
+    lab_objs = []
+    for unit in LAB_UNITS:
+        src = os.path.join(CSRC, unit)
+        obj = os.path.join(LAB_DIR, unit.rsplit(".", 1)[0] + "_lab.o")
+        newest = max(os.path.getmtime(d) for d in list(_deps(src)) + incs)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < newest:
+            if unit.endswith(".hip"):
+                cmd = [hipcc, "--offload-arch=" + ARCH]
+            else:
+                cmd = [os.environ.get("CXX", "g++"), "-pthread"]
+            cmd += ["-DHGX_LAB", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+                    "-I", CSRC, "-Wall", "-Wno-unused-result", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            subprocess.check_call(cmd)
+        lab_objs.append(obj)
+    if force or not os.path.exists(LAB_LIB) or os.path.getmtime(LAB_LIB) < max([os.path.getmtime(o) for o in lab_objs] + [os.path.getmtime(LIB)]):
+        objs = [s_.rsplit(".", 1)[0] + ".o" for s_ in _sources() if os.path.basename(s_) not in LAB_UNITS] + lab_objs
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-pthread", "-o", LAB_LIB] + objs + ["-lz", "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)

@@ -1,0 +1,235 @@
+// hgx_front_host.cpp -- host side of the device front end: the flat tables its kernels read (alternatives with the
+// reference's spellings, variant names, exons), and -- in the LAB build only (-DHGX_LAB, libhgx_lab.so) -- an emulation that
+// runs the kernels' per-key / per-pair functions (hgx_front_core.hpp) as loops on the CPU, so that the CPU test-suite can
+// compare that logic with the pinned host front end where no GPU exists.  Nothing in the product library calls the emulation.
+#include <algorithm>
+#include <cstring>
+#include <string>
+
+#include "hgx_internal.hpp"
+
+int hgx_front_tables_build(hgx_locus &L, hgx_front_tables &T) {
+    const int rc = hgx_build_alternatives(L);
+    if (rc) return rc;
+    T = hgx_front_tables();
+    T.usable = true;
+    for (auto &e : L.exons) { T.exons.push_back(e[0]); T.exons.push_back(e[1]); }
+    T.name_off.push_back(0);
+    for (int v = 0; v < L.V; ++v) {
+        const std::string &nm = L.name[v];
+        // the kernels resolve Zs ids through the "hv<n>" table and spell novel ids with an 'n': names must be hv<digits>
+        bool ok = nm.size() > 2 && nm[0] == 'h' && nm[1] == 'v';
+        for (size_t k = 2; k < nm.size() && ok; ++k) ok = nm[k] >= '0' && nm[k] <= '9';
+        if (!ok && T.usable) { T.usable = false; T.why = "variant id '" + nm + "' is not hv<digits>"; }
+        T.name_pool.insert(T.name_pool.end(), nm.begin(), nm.end());
+        T.name_off.push_back((int32_t)T.name_pool.size());
+    }
+    if (L.backbone.size() > 0x1ffff) { T.usable = false; T.why = "backbone longer than the novel-id encoding's 17 position bits"; }
+    for (int dir = 0; dir < 2; ++dir) {                             // the keys first: as integers and as the reference spells them
+        const std::vector<AltEntry> &src = dir == 0 ? L.alts_left : L.alts_right;
+        T.alt_key_off[dir].push_back((int32_t)T.alt_ints.size());
+        T.alt_str_off[dir].push_back((int32_t)T.alt_chars.size());
+        for (const AltEntry &e : src) {
+            T.alt_anchor[dir].push_back(dir == 0 ? e.key.right : e.key.left);
+            T.alt_ints.push_back(e.key.left);
+            T.alt_ints.insert(T.alt_ints.end(), e.key.vars.begin(), e.key.vars.end());
+            T.alt_ints.push_back(e.key.right);
+            T.alt_key_off[dir].push_back((int32_t)T.alt_ints.size());
+            std::string s = std::to_string(e.key.left);             // "529-hv8-hv22-606" (typing_common.py:1421)
+            for (int v : e.key.vars) { s += '-'; s += L.name[v]; }
+            s += '-';
+            s += std::to_string(e.key.right);
+            T.alt_chars.insert(T.alt_chars.end(), s.begin(), s.end());
+            T.alt_str_off[dir].push_back((int32_t)T.alt_chars.size());
+        }
+    }
+    T.alt_ht_off.push_back((int32_t)T.alt_ints.size());             // then the alternatives, back to back
+    for (int dir = 0; dir < 2; ++dir) {
+        const std::vector<AltEntry> &src = dir == 0 ? L.alts_left : L.alts_right;
+        T.alt_list_off[dir].push_back((int32_t)T.alt_ht_off.size() - 1);
+        for (const AltEntry &e : src) {
+            for (const AltHt &a : e.alts) {
+                T.alt_ints.push_back(a.left);
+                T.alt_ints.insert(T.alt_ints.end(), a.vars.begin(), a.vars.end());
+                T.alt_ints.push_back(a.right);
+                T.alt_ht_off.push_back((int32_t)T.alt_ints.size());
+            }
+            T.alt_list_off[dir].push_back((int32_t)T.alt_ht_off.size() - 1);
+        }
+    }
+    return HGX_OK;
+}
+
+FeLocus hgx_front_view(const hgx_locus &L, const hgx_front_tables &T) {
+    FeLocus F;
+    memset(&F, 0, sizeof(F));
+    F.V = L.V;
+    F.n_ref = (int32_t)L.backbone.size();
+    F.base_kind = L.base_kind;
+    F.n_exons = (int32_t)L.exons.size();
+    F.n_hv = (int32_t)L.hv_index.size();
+    F.pos = L.pos.data(); F.right = L.right.data(); F.len = L.len.data(); F.maxright = L.maxright.data();
+    F.type = L.type.data(); F.linked = L.linked.data(); F.base = L.base.data();
+    F.linked_bits = L.linked_bits.data();
+    F.backbone = L.backbone.data();
+    F.exons = T.exons.data();
+    F.hv_index = L.hv_index.data();
+    F.name_off = T.name_off.data();
+    F.name_pool = T.name_pool.data();
+    for (int d = 0; d < 2; ++d) {
+        F.n_alt[d] = (int32_t)T.alt_anchor[d].size();
+        F.alt_anchor[d] = T.alt_anchor[d].data();
+        F.alt_key_off[d] = T.alt_key_off[d].data();
+        F.alt_str_off[d] = T.alt_str_off[d].data();
+        F.alt_list_off[d] = T.alt_list_off[d].data();
+    }
+    F.alt_ht_off = T.alt_ht_off.data();
+    F.alt_ints = T.alt_ints.data();
+    F.alt_chars = T.alt_chars.data();
+    return F;
+}
+
+#ifdef HGX_LAB
+// ---- the device pipeline as loops (lab build only; mirrors hgx_front.hip stage by stage) ---------------------------------------
+// *declined = 0 and *out = the batch, or *declined = the reason and no batch.
+int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &opts, int *declined) {
+    *out = nullptr;
+    *declined = 0;
+    hgx_front_tables T;
+    int rc = hgx_front_tables_build(L, T);
+    if (rc) return rc;
+    if (!T.usable) { *declined = HGX_FE_DECLINE_LOCUS; return HGX_OK; }
+    const FeLocus F = hgx_front_view(L, T);
+    const int n_ref = F.n_ref;
+    hgx_batch *B = new hgx_batch();
+    // k_fe_pileup + k_fe_nt_set
+    B->counts.assign((size_t)n_ref * 6, 0u);
+    B->nt_set.assign(n_ref, 0);
+    for (size_t k = 0; k < in.n_keys; ++k) {
+        if (in.keys[k].n_pile == 0) continue;
+        uint32_t *cnt = B->counts.data();
+        const int r = fe_pileup_key(in.keys[k], in.text, n_ref, 0, 1, [cnt](uint32_t cell, uint32_t w) { cnt[cell] += w; });
+        if (r < 0) { *declined = -r; delete B; return HGX_OK; }
+    }
+    if (opts.pileup_exchange && opts.pileup_exchange(opts.pileup_ctx, B->counts.data(), (int64_t)B->counts.size()) != 0) {
+        hgx_set_error("pileup exchange between the ranks of a sharded locus failed");
+        delete B;
+        return HGX_EINVAL;
+    }
+    for (int i = 0; i < n_ref; ++i) B->nt_set[i] = fe_nt_set(&B->counts[(size_t)i * 6]);
+    // k_fe_decode
+    const size_t S = in.n_slots;
+    std::vector<uint8_t> state(S, 0);
+    std::vector<uint32_t> key_ht_off(S, 0), key_n_ht(S, 0);
+    std::vector<int32_t> ht_pool(std::max<size_t>(S * 48 + 4096, 16));
+    const size_t cand_cap = S * 12 + 4096;
+    std::vector<uint16_t> cand_lo(cand_cap), cand_nw(cand_cap);
+    std::vector<uint64_t> cand_key(cand_cap);
+    std::vector<uint32_t> cand_mask_off(cand_cap), mask_pool(cand_cap * 16);
+    uint32_t cur[3] = {0, 0, 0};
+    FePools pools;
+    pools.ht_pool = ht_pool.data(); pools.ht_cap = (uint32_t)ht_pool.size(); pools.ht_cursor = &cur[0];
+    pools.cand_lo = cand_lo.data(); pools.cand_nw = cand_nw.data(); pools.cand_key = cand_key.data();
+    pools.cand_mask_off = cand_mask_off.data(); pools.cand_cap = (uint32_t)cand_cap; pools.cand_cursor = &cur[1];
+    pools.mask_pool = mask_pool.data(); pools.mask_cap = (uint32_t)mask_pool.size(); pools.mask_cursor = &cur[2];
+    FeParse po{opts.num_editdist, opts.error_correction};
+    FePile pile{B->nt_set.data(), B->counts.data()};
+    for (size_t k = 0; k < in.n_keys; ++k) {
+        const FeKey &K = in.keys[k];
+        if (K.slot == FE_NO_SLOT) continue;
+        const int r = fe_key(F, po, pile, K, in.text, pools, state[K.slot], key_ht_off[K.slot], key_n_ht[K.slot]);
+        if (r < 0) { *declined = -r; delete B; return HGX_OK; }
+    }
+    // candidate pieces -> distinct pieces (sort by key, run heads, word-for-word check) -> canonical order of the heads: first word,
+    // width, PieceTable::hash, bytes (hgx_canonical_piece_order)
+    const uint32_t n_cand = cur[1];
+    std::vector<uint32_t> order(n_cand);
+    for (uint32_t c = 0; c < n_cand; ++c) order[c] = c;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return cand_key[a] < cand_key[b]; });
+    std::vector<uint32_t> head_of(n_cand), heads;
+    for (uint32_t k = 0; k < n_cand; ++k) {
+        const uint32_t c = order[k];
+        if (k > 0 && cand_key[c] == cand_key[order[k - 1]]) {
+            const uint32_t h = heads.back();
+            if (cand_lo[c] != cand_lo[h] || cand_nw[c] != cand_nw[h] ||
+                memcmp(&mask_pool[cand_mask_off[c]], &mask_pool[cand_mask_off[h]], 8 * (size_t)cand_nw[c]) != 0) {
+                *declined = HGX_FE_DECLINE_COLLISION;
+                delete B;
+                return HGX_OK;
+            }
+        } else heads.push_back(c);
+        head_of[c] = (uint32_t)heads.size() - 1;
+    }
+    std::vector<uint32_t> hord(heads.size());
+    std::vector<uint64_t> hhash(heads.size());
+    for (size_t k = 0; k < heads.size(); ++k) {
+        hord[k] = (uint32_t)k;
+        hhash[k] = fe_piece_hash(cand_lo[heads[k]], cand_nw[heads[k]], &mask_pool[cand_mask_off[heads[k]]]);
+    }
+    std::sort(hord.begin(), hord.end(), [&](uint32_t a, uint32_t b) {
+        const uint32_t ca = heads[a], cb = heads[b];
+        if (cand_lo[ca] != cand_lo[cb]) return cand_lo[ca] < cand_lo[cb];
+        if (cand_nw[ca] != cand_nw[cb]) return cand_nw[ca] < cand_nw[cb];
+        if (hhash[a] != hhash[b]) return hhash[a] < hhash[b];
+        return memcmp(&mask_pool[cand_mask_off[ca]], &mask_pool[cand_mask_off[cb]], 8 * (size_t)cand_nw[ca]) < 0;
+    });
+    std::vector<uint32_t> new_id(heads.size());
+    B->pieces.resize(heads.size());
+    for (size_t k = 0; k < hord.size(); ++k) {
+        const uint32_t c = heads[hord[k]];
+        new_id[hord[k]] = (uint32_t)k;
+        hgx_piece pc;
+        pc.mask_off = (uint32_t)B->masks.size();
+        pc.lo_word = cand_lo[c];
+        pc.n_words = cand_nw[c];
+        B->pieces[k] = pc;
+        B->masks.insert(B->masks.end(), &mask_pool[cand_mask_off[c]], &mask_pool[cand_mask_off[c]] + 2 * (size_t)cand_nw[c]);
+    }
+    // k_fe_pairs: count, scan, emit
+    int64_t n_reads = 0;
+    for (size_t i = 0; i < in.n_rec; ++i) {
+        if (!FE_REC_HEAD(in.rec_info[i])) continue;
+        uint32_t uni[FE_MAX_PAIR_HT];
+        int n_uni = 0;
+        const int ns = fe_pair_union(in.rec_info, (uint32_t)i, (uint32_t)in.n_rec, state.data(), key_ht_off.data(), key_n_ht.data(),
+                                     ht_pool.data(), uni, n_uni);
+        if (ns < 0) { *declined = -ns; delete B; return HGX_OK; }
+        if (ns == 0) continue;
+        n_reads += ns;
+        size_t n_exon = 0;
+        for (int x = 0; x < n_uni; ++x) n_exon += (size_t)ht_pool[uni[x] + 3];
+        if (n_exon > 65535 || n_uni > 65535) { *declined = -FE_E_PAIR; delete B; return HGX_OK; }
+        for (int x = 0; x < n_uni; ++x) {
+            const int32_t *rec = &ht_pool[uni[x]];
+            for (int e = 0; e < rec[3]; ++e) B->pair_ref.push_back(new_id[head_of[(uint32_t)rec[4] + e]]);
+        }
+        for (int x = 0; x < n_uni; ++x) {
+            const int32_t *rec = &ht_pool[uni[x]];
+            B->pair_ref.push_back(new_id[head_of[(uint32_t)rec[4] + rec[3]]] | 0x80000000u);
+        }
+        B->pair_off.push_back((int32_t)B->pair_ref.size());
+    }
+    B->n_reads = (int32_t)n_reads;
+    *out = B;
+    return HGX_OK;
+}
+#endif
+
+#ifdef HGX_LAB
+// SAM text -> batch through the emulated device stages (lab library only; tests/test_front_emulation.py).  *declined != 0: the
+// device path would hand this input to the host stages, which then produced the batch.
+extern "C" int hgx_lab_parse_sam_emulated(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts,
+                                          int32_t *declined) {
+    HARGCHK(out && loc && opts && declined);
+    hgx_batch *made = nullptr;
+    hgx_front_hook hook;
+    hook.mem = hgx_front_alloc{[](size_t n) { return hgx_host_alloc(n); }, [](void *p) { hgx_host_free(p); }};
+    hook.run = [&](hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, int *dec) { return hgx_front_emulate(&made, L, in, o, dec); };
+    const int rc = hgx_parse_sam_hook(out, loc, sam, n_bytes, opts, &hook);
+    *declined = hook.declined;
+    if (rc) { delete made; return rc; }
+    if (!hook.declined) *out = made;
+    else delete made;
+    return HGX_OK;
+}
+#endif

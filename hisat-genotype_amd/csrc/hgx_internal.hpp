@@ -183,3 +183,53 @@ void hgx_canonical_piece_order(hgx_batch &b, int n_threads, std::vector<uint32_t
 int hgx_batch_merge(hgx_batch **out, const hgx_batch *const *batches, int32_t n, int32_t *pair_base);
 // alternatives tables (defined in hgx_sam.cpp)
 int hgx_build_alternatives(hgx_locus &loc);
+
+// ---- device front end (hgx_front_core.hpp, hgx_front.hip, hgx_front_host.cpp) ------------------------------------------------
+#include "hgx_front_core.hpp"
+// host copies of the tables an FeLocus points into (the device path uploads them once per locus and device)
+struct hgx_front_tables {
+    std::vector<int32_t> exons, name_off;
+    std::vector<char> name_pool;
+    std::vector<int32_t> alt_anchor[2], alt_key_off[2], alt_str_off[2], alt_list_off[2], alt_ht_off, alt_ints;
+    std::vector<char> alt_chars;
+    bool usable = false;               // false: the locus has something the device path does not take (see hgx_front_tables_build)
+    std::string why;
+};
+int hgx_front_tables_build(hgx_locus &L, hgx_front_tables &T);
+FeLocus hgx_front_view(const hgx_locus &L, const hgx_front_tables &T);       // pointers into L and T (host side)
+
+// What the host stages (split, filters, key grouping) hand to the device stages: the distinct keys that count into the pileup
+// or are decoded, in stream order of their first records, with their text; and the records that passed the filters.
+// The three arrays live in staging memory obtained from `alloc` (pinned for the device path).
+struct hgx_front_alloc { void *(*alloc)(size_t); void (*release)(void *); };
+struct hgx_front_input {
+    hgx_front_alloc mem{nullptr, nullptr};
+    FeKey *keys = nullptr; size_t n_keys = 0;
+    char *text = nullptr; size_t n_text = 0;
+    uint32_t *rec_info = nullptr; size_t n_rec = 0;
+    size_t n_slots = 0;                // distinct keys that are decoded
+    hgx_front_input() = default;
+    hgx_front_input(const hgx_front_input &) = delete;
+    hgx_front_input &operator=(const hgx_front_input &) = delete;
+    ~hgx_front_input() { if (mem.release) { mem.release(keys); mem.release(text); mem.release(rec_info); } }
+};
+// > 0: the device front end declines this input (code = an FE_E_* value negated, or one of the HGX_FE_DECLINE_* below)
+#define HGX_FE_DECLINE_OPTS 1          // keep_trace / choose_pairs / inter-distance exchange: host only
+#define HGX_FE_DECLINE_RECORD 2        // a record the reference would raise on
+#define HGX_FE_DECLINE_LOCUS 3         // tables the device path does not take
+#define HGX_FE_DECLINE_SIZE 4          // more records / keys / text than its 32-bit offsets hold
+#define HGX_FE_DECLINE_COLLISION 5     // two different pieces with one 64-bit hash
+// The host stages call `run` after key grouping; it returns HGX_OK with *declined = 0 when the device stages produced the result
+// (which the hook's owner holds: the parse functions then return *out = NULL), or *declined = the reason -- the host stages
+// then finish the job and `declined` says why.
+struct hgx_front_hook {
+    hgx_front_alloc mem{nullptr, nullptr};
+    std::function<int(hgx_locus &, const hgx_front_input &, const hgx_parse_opts &, int *declined)> run;
+    int declined = 0;
+};
+int hgx_parse_sam_hook(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, hgx_front_hook *hook);
+int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *loc, const char *path, const char *regions, const hgx_parse_opts *opts,
+                                  hgx_front_hook *hook);
+#ifdef HGX_LAB
+int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &opts, int *declined);
+#endif

@@ -1642,6 +1642,98 @@ void merge_tables(hgx_batch &B, std::vector<DecodeWorker> &workers, int n_thread
     });
 }
 
+// The input of the device stages (hgx_front_input): the distinct keys that count into the pileup or are decoded, in stream order
+// of their first records, their text gathered into staging memory (cigar | seq | zs | md per key), and one word per record that
+// passed the filters: decode slot of its key | left mate << 30 | first kept record of its read id << 31.  Returns 0, or the
+// reason (HGX_FE_DECLINE_*) why this input stays on the host.
+int build_front_input(const hgx_parse_opts &o, const Fields *recs, const uint8_t *ok, size_t n, const std::vector<size_t> &cut, int n_threads,
+                      size_t n_slots, hgx_front_input &in) {
+    if (n >= (1ull << 30) || n_slots >= (1ull << 30)) return HGX_FE_DECLINE_SIZE;
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_threads, n / 4096 + 1));
+    std::vector<size_t> kcnt(T + 1, 0), kbytes(T + 1, 0);
+    auto is_key = [&](size_t i) { return ok[i] && recs[i].rep == i && (recs[i].n_pile > 0 || recs[i].slot != NO_SLOT); };
+    auto key_bytes = [&](const Fields &f) { return (size_t)f.cigar_len + f.seq_len + f.zs_len + f.md_len; };
+    std::atomic<int> too_long{0};
+    hgx_par_ranges(T, n, [&](int t, size_t b, size_t e) {
+        size_t c = 0, by = 0;
+        for (size_t i = b; i < e; ++i)
+            if (is_key(i)) {
+                const Fields &f = recs[i];
+                if (f.cigar_len > 65535 || f.zs_len > 65535 || f.md_len > 65535 || f.seq_len > (1u << 24)) too_long.store(1);
+                ++c;
+                by += key_bytes(f);
+            }
+        kcnt[t + 1] = c;
+        kbytes[t + 1] = by;
+    });
+    if (too_long.load()) return HGX_FE_DECLINE_SIZE;
+    for (int t = 0; t < T; ++t) { kcnt[t + 1] += kcnt[t]; kbytes[t + 1] += kbytes[t]; }
+    if (kbytes[T] >= (1ull << 32) - 64) return HGX_FE_DECLINE_SIZE;
+    in.n_keys = kcnt[T];
+    in.n_text = kbytes[T];
+    in.n_slots = n_slots;
+    in.keys = (FeKey *)in.mem.alloc(std::max<size_t>(in.n_keys, 1) * sizeof(FeKey));
+    in.text = (char *)in.mem.alloc(in.n_text + 64);
+    if (!in.keys || !in.text) throw std::bad_alloc();
+    hgx_par_ranges(T, n, [&](int t, size_t b, size_t e) {
+        size_t k = kcnt[t], at = kbytes[t];
+        for (size_t i = b; i < e; ++i) {
+            if (!is_key(i)) continue;
+            const Fields &f = recs[i];
+            FeKey &K = in.keys[k++];
+            K.pos = f.pos - (o.base_locus + 1);
+            K.n_pile = f.n_pile;
+            K.slot = f.slot;
+            K.off = (uint32_t)at;
+            K.seq_len = (uint32_t)f.seq_len;
+            K.cigar_len = (uint16_t)f.cigar_len;
+            K.zs_len = (uint16_t)f.zs_len;
+            K.md_len = (uint16_t)f.md_len;
+            K.flags = (uint16_t)((f.zs ? 1 : 0) | (f.md ? 2 : 0));
+            char *w = in.text + at;
+            memcpy(w, f.cigar, f.cigar_len); w += f.cigar_len;
+            memcpy(w, f.seq, f.seq_len); w += f.seq_len;
+            if (f.zs_len) memcpy(w, f.zs, f.zs_len);
+            w += f.zs_len;
+            if (f.md_len) memcpy(w, f.md, f.md_len);
+            at += key_bytes(f);
+        }
+    });
+    // the records that passed the filters, chunk by chunk (chunks start where the read id changes)
+    const size_t nc = cut.size() - 1;
+    std::vector<size_t> rcnt(nc + 1, 0);
+    std::atomic<int> bad{0};
+    hgx_par_tasks(n_threads, nc, [&](int, size_t c) {
+        size_t k = 0;
+        for (size_t i = cut[c]; i < cut[c + 1]; ++i) {
+            if (!ok[i] || recs[i].kept == KEPT_NO) continue;
+            if (recs[i].kept != KEPT_YES) { bad.store(1); break; }
+            ++k;
+        }
+        rcnt[c + 1] = k;
+    });
+    if (bad.load()) return HGX_FE_DECLINE_RECORD;                 // the reference raises on such a record: the host stages say how
+    for (size_t c = 0; c < nc; ++c) rcnt[c + 1] += rcnt[c];
+    in.n_rec = rcnt[nc];
+    in.rec_info = (uint32_t *)in.mem.alloc(std::max<size_t>(in.n_rec, 1) * 4);
+    if (!in.rec_info) throw std::bad_alloc();
+    hgx_par_tasks(n_threads, nc, [&](int, size_t c) {
+        size_t k = rcnt[c];
+        const Fields *prev = nullptr;
+        size_t prev_len = 0;
+        for (size_t i = cut[c]; i < cut[c + 1]; ++i) {
+            if (!ok[i] || recs[i].kept != KEPT_YES) continue;
+            const Fields &f = recs[i];
+            const size_t idlen = read_id_len(f, o.simulation != 0);
+            const bool head = !prev || prev_len != idlen || memcmp(prev->qname, f.qname, idlen) != 0;
+            in.rec_info[k++] = recs[f.rep].slot | ((f.flag & 0x40) ? 1u << 30 : 0u) | (head ? 1u << 31 : 0u);
+            prev = &f;
+            prev_len = idlen;
+        }
+    });
+    return 0;
+}
+
 template <class F>
 void parallel_for(int n_threads, size_t n, F fn) {   // fn(thread, begin, end), on the persistent worker pool
     hgx_par_ranges(n_threads, n, fn);
@@ -1649,10 +1741,11 @@ void parallel_for(int n_threads, size_t n, F fn) {   // fn(thread, begin, end), 
 
 }   // namespace
 
-static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts, bool binary = false);
+static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts, bool binary = false,
+                       hgx_front_hook *hook = nullptr);
 
 // SAM text (name-grouped) -> private writable copy + line table -> parse_lines
-extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts) {
+int hgx_parse_sam_hook(hgx_batch **out, const hgx_locus *Lc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, hgx_front_hook *hook) {
     HARGCHK(out && Lc && (sam || n_bytes == 0) && opts);
     try {
         int n_threads = opts->n_threads > 0 ? opts->n_threads : hgx_default_threads();
@@ -1685,15 +1778,24 @@ extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *s
             for (size_t t = b; t < e; ++t)
                 if (!part[t].empty()) memcpy(&lines[off[t]], part[t].data(), part[t].size() * sizeof(hgx_line));
         });
-        return parse_lines(out, Lc, lines.data(), lines.size(), opts);
+        return parse_lines(out, Lc, lines.data(), lines.size(), opts, false, hook);
     } catch (const std::exception &e) {
         hgx_set_error("%s", e.what());
         return HGX_EINVAL;
     }
 }
 
+extern "C" int hgx_parse_sam(hgx_batch **out, const hgx_locus *Lc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts) {
+    return hgx_parse_sam_hook(out, Lc, sam, n_bytes, opts, nullptr);
+}
+
 extern "C" int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *Lc, const char *path, const char *regions,
                                         const hgx_parse_opts *opts) {
+    return hgx_parse_alignment_file_hook(out, Lc, path, regions, opts, nullptr);
+}
+
+int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *Lc, const char *path, const char *regions, const hgx_parse_opts *opts,
+                                  hgx_front_hook *hook) {
     HARGCHK(out && Lc && path && opts);
     const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -1703,7 +1805,7 @@ extern "C" int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *Lc, co
         int rc = hgx_read_alignment_lines(path, regions, opts->n_threads, al, /*keep_binary=*/true);
         if (rc) return rc;
         const double t1 = now();
-        rc = parse_lines(out, Lc, al.lines.data(), al.lines.size(), opts, al.binary);
+        rc = parse_lines(out, Lc, al.lines.data(), al.lines.size(), opts, al.binary, hook);
         if (prof) fprintf(stderr, "[hgx_parse_alignment_file] read %.1f ms, parse %.1f ms\n", (t1 - t0) * 1e3, (now() - t1) * 1e3);
         return rc;
     } catch (const std::exception &e) {
@@ -1714,8 +1816,10 @@ extern "C" int hgx_parse_alignment_file(hgx_batch **out, const hgx_locus *Lc, co
 
 // lines: name-grouped records.  Text: lines[i].p[lines[i].len] is writable (it becomes the record's terminator).  Binary (BAM
 // records as read): lines[i].p = the record's QNAME (32 bytes into the record), lines[i].len = its block_size.
-static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts, bool binary) {
+static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts, bool binary,
+                       hgx_front_hook *hook) {
     HARGCHK(out && Lc && (lines || n == 0) && opts);
+    *out = nullptr;
     hgx_locus &L = *const_cast<hgx_locus *>(Lc);
     hgx_batch *B = new hgx_batch();
     try {
@@ -1808,6 +1912,24 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
         std::vector<uint32_t> reps;                     // first records of the distinct decode keys that some kept record carries
         group_records(*opts, recs, ok, n, n_threads, reps);
         lap("  key grouping");
+        if (hook) {
+            // The device front end (hgx_front.hip; the lab build's emulation): everything from here on -- pileup, decode of the distinct
+            // keys, piece table, pair protocol -- as kernels over the keys' text.  It may decline; the host stages below then run.
+            hook->declined = 0;
+            if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange) hook->declined = HGX_FE_DECLINE_OPTS;
+            else {
+                hgx_front_input in;
+                in.mem = hook->mem;
+                hook->declined = build_front_input(*opts, recs, ok, n, cut, n_threads, reps.size(), in);
+                lap("  key table for the device");
+                if (!hook->declined) {
+                    const int rc = hook->run(L, in, *opts, &hook->declined);
+                    lap("device stages");
+                    if (rc) { delete B; return rc; }
+                    if (!hook->declined) { delete B; return HGX_OK; }          // (the hook holds the result)
+                }
+            }
+        }
         // pass 1: pileup over all records (common:1076-1134) = over the distinct keys, each weighted by its group's size
         std::vector<std::vector<uint32_t>> tcounts(n_threads);
         std::vector<std::string> terr(n_threads);

@@ -1,0 +1,93 @@
+"""Lab build only (libhgx_lab.so, -DHGX_LAB): the per-key / per-pair functions of the DEVICE front end (csrc/hgx_front_core.hpp:
+CIGAR x MD x Zs walk, error correction, ambiguity sets, haplotypes, exon pieces, piece masks, pair protocol -- the code the kernels
+of hgx_front.hip run one lane per key) executed as loops on the CPU (hgx_front_host.cpp, hgx_front_emulate) against the pinned host
+front end (hgx_sam.cpp).  Batches must be identical byte for byte.  Not collected by the suite itself: tests/test_front_emulation.py
+runs this file with pytest in a child process (the suite's own process has the product library loaded)."""
+import ctypes as C
+import random
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from hisatgenotype_amd import capi, locus as hl, synth
+
+capi.use_lab()
+
+
+def emulated(pl, sam, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False, n_threads=0):
+    data = sam if isinstance(sam, (bytes, bytearray)) else sam.encode()
+    o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), 0, 0,
+                       int(pl.base_fname == "codis" and pl.gene == "D18S51"), int(n_threads))
+    h, dec = C.c_void_p(), C.c_int32(0)
+    capi.check(capi.lib().hgx_lab_parse_sam_emulated(C.byref(h), pl.h, data, C.c_size_t(len(data)), C.byref(o), C.byref(dec)))
+    return hl.Batch(h), dec.value
+
+
+def same_batch(a, b, length):
+    assert (a.n_reads, a.n_pairs, a.n_pieces, a.n_refs, a.n_mask_u32) == (b.n_reads, b.n_pairs, b.n_pieces, b.n_refs, b.n_mask_u32)
+    assert a.pieces.tobytes() == b.pieces.tobytes()
+    assert a.masks.tobytes() == b.masks.tobytes()
+    assert a.pair_off.tobytes() == b.pair_off.tobytes()
+    assert a.pair_ref.tobytes() == b.pair_ref.tobytes()
+    na, ca = a.pileup(length)
+    nb, cb = b.pileup(length)
+    assert np.array_equal(na, nb) and np.array_equal(ca, cb)
+
+
+@pytest.mark.parametrize("name", gu.ALL + gu.LEAN)
+def test_emulated_device_stages_equal_the_host_front_end_on_every_fixture(name):
+    fx = gu.load(name)
+    o = fx["options"]
+    pl = hl.PackedLocus.from_synth(fx["_locus"])
+    kw = dict(num_editdist=o["num_editdist"], error_correction=o["error_correction"], allow_discordant=o["allow_discordant"],
+              simulation=o["simulation"])
+    host = pl.parse_sam(fx["sam"], **kw)
+    emu, declined = emulated(pl, fx["sam"], **kw)
+    if name == "codis_d18s51":
+        assert declined == 1                      # choose_pairs (typing_core.py:1547-1552) stays on the host
+    else:
+        assert declined == 0, declined
+    same_batch(host, emu, len(fx["_locus"].backbone))
+
+
+def test_emulated_device_stages_on_fuzz_cases():
+    """The cases of tools/fuzz_parity.py (HLA-like loci with deletions / insertions / unlinked variants, STR loci, sequencing
+    errors, soft clips, novel indels, multi-hit and duplicate records, single-end samples) plus deeper samples of the fast generator."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    n_dev = n_all = 0
+    why = {}
+    for k in range(int(os.environ.get("HGX_FRONT_FUZZ", "120"))):
+        loc, sam, single = fuzz_parity.make_case(770000, k, 1 + k % 3)
+        pl = hl.PackedLocus.from_synth(loc)
+        for ec in (True, False):
+            try:
+                host = pl.parse_sam(sam, error_correction=ec, allow_discordant=single)
+            except capi.HgxError:
+                with pytest.raises(capi.HgxError):
+                    emulated(pl, sam, error_correction=ec, allow_discordant=single)
+                continue
+            emu, declined = emulated(pl, sam, error_correction=ec, allow_discordant=single)
+            n_all += 1
+            n_dev += declined == 0
+            why[declined] = why.get(declined, 0) + 1
+            same_batch(host, emu, len(loc.backbone))
+        pl.close()
+    rng = random.Random(20261003)
+    for _ in range(6):
+        loc = synth.make_hla_like_locus(n_alleles=rng.choice([40, 400]), n_vars=rng.choice([150, 900]), seed=rng.randrange(1 << 30),
+                                        deletion_frac=rng.choice([0.07, 0.3]))
+        sam = synth.simulate_sam_fast(loc, synth.pick_sample(loc, rng.randrange(1 << 30)), rng.choice([1200, 15000]),
+                                      err_rate=rng.choice([0.002, 0.01]), seed=rng.randrange(1 << 30))
+        pl = hl.PackedLocus.from_synth(loc)
+        host = pl.parse_sam(sam)
+        emu, declined = emulated(pl, sam)
+        n_all += 1
+        n_dev += declined == 0
+        why[declined] = why.get(declined, 0) + 1
+        same_batch(host, emu, len(loc.backbone))
+    print("device stages took %d of %d inputs; decline codes %s" % (n_dev, n_all, why))
+    assert n_dev >= 0.8 * n_all, (n_dev, n_all, why)
