@@ -66,6 +66,20 @@ struct hgx_classes {
                         nullptr, nullptr, nullptr, nullptr};   // dedup scratch still read by queued kernels
 };
 
+// a piece batch resident in HBM: uploaded from a host batch (hgx_dbatch_create) or built there by the device front end
+// (hgx_front.hip), which also leaves the pileup tables behind
+struct hgx_dbatch {
+    int32_t n_pieces = 0, n_pairs = 0, n_reads = 0;
+    int64_t n_refs = 0, n_mask_u32 = 0, sum_piece_words = 0, n_gene_refs = 0;
+    hgx_piece *d_pieces = nullptr;
+    uint32_t *d_masks = nullptr;
+    int32_t *d_pair_off = nullptr;
+    uint32_t *d_pair_ref = nullptr;
+    int32_t n_ref = 0;                   // pileup tables (device front end only): counts[n_ref][6], nt_set[n_ref]
+    uint32_t *d_counts = nullptr;
+    uint8_t *d_nt_set = nullptr;
+};
+
 struct DevBuf {
     void *p = nullptr;
     ~DevBuf() { if (p) hgx_pool_free(p); }

@@ -1,0 +1,644 @@
+// hgx_front.hip -- the DEVICE front end (gfx950): rows 8a-2 .. 8a-5 of the scope table as kernels.
+//
+// The host stages (hgx_sam.cpp: tokenise, record filters, grouping of the records by decode key) hand over the DISTINCT decode
+// keys with their text (cigar | seq | Zs | MD: ~200 bytes per key, 0.28 keys per read at 1 M reads) and one word per record that
+// passed the filters.  Everything after that runs here, in HBM, and ends as an hgx_dbatch that the scoring kernels read in place:
+//   k_fe_pileup     get_mpileup (typing_common.py:1059-1134): one wavefront per key, lanes over the bases of an M op, counters
+//                   privatised in LDS per workgroup (84 KB for a 3.5 kb locus), flushed with one global atomic per non-zero cell
+//   k_fe_nt_set     the 20 % / >= 7 rule per position (typing_common.py:1124-1134)
+//   k_fe_decode     ONE LANE PER KEY: CIGAR x MD x Zs walk, error correction against the pileup, novel variants, cmp_list2,
+//                   identify_ambigious_diffs, haplotypes, exon clipping and piece masks (hgx_front_core.hpp: typing_core.py:
+//                   899-1164, 119-243, 1351-1406, 718-792, 641-670; typing_common.py:1663-1955); haplotype records, candidate
+//                   pieces and mask words go to pools through atomic cursors
+//   piece table     candidates radix-sorted by a 64-bit content key (hipcub), run heads = distinct pieces (every candidate is
+//                   compared word for word with its run's predecessor), heads ordered by (first word, width, PieceTable::hash,
+//                   bytes) -- the host's canonical order, so the batch is the host's batch byte for byte
+//   k_fe_pair_*     the pair protocol (typing_core.py:1238-1347, 1545-1587): one lane per run of records with one read id, set
+//                   union of the mates' haplotypes, refs counted, scanned, written
+// Whatever the kernels cannot take (a record the reference would raise on, a scratch limit, a full pool) sets a decline code:
+// the call then runs the host stages, which are pinned to the reference and reproduce its failures.  The host front end is the
+// checker of this file (tests/test_gpu_front.py: device batch == host batch on every fixture and on fuzz cases).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <chrono>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "hgx_common.hpp"
+#include "hgx_internal.hpp"
+
+namespace {
+
+// ---- pinned staging blocks (the key table of a 1 M-read sample is ~65 MB: pinning that much per call costs more than the copy) ----
+struct PinnedPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;
+    std::map<void *, size_t> size_of;
+};
+PinnedPool &pinned() { static PinnedPool *p = new PinnedPool(); return *p; }
+void *pinned_alloc(size_t n) {
+    PinnedPool &P = pinned();
+    size_t need = std::max<size_t>(n, 4096);
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.free_blocks.lower_bound(need);
+        if (it != P.free_blocks.end() && it->first <= 4 * need + (1u << 20)) {
+            void *p = it->second;
+            P.free_blocks.erase(it);
+            return p;
+        }
+    }
+    need += need / 8;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(P.mu);
+    P.size_of[p] = need;
+    return p;
+}
+void pinned_release(void *p) {
+    if (!p) return;
+    PinnedPool &P = pinned();
+    std::lock_guard<std::mutex> g(P.mu);
+    auto it = P.size_of.find(p);
+    if (it == P.size_of.end()) return;
+    P.free_blocks.emplace(it->second, p);
+}
+
+// ---- the locus tables on the device (once per locus and device) ---------------------------------------------------------------
+struct DevLocus {
+    hgx_front_tables T;
+    struct PerDev { int dev; void *block; FeLocus view; };
+    std::vector<PerDev> per_dev;
+    std::mutex mu;
+    ~DevLocus() { for (auto &d : per_dev) hgx_pool_free(d.block); }
+};
+void dev_locus_free(void *p) { delete (DevLocus *)p; }
+std::mutex g_locus_mu;
+
+int dev_locus(hgx_locus &L, hipStream_t st, const FeLocus **view, bool *usable) {
+    DevLocus *D;
+    {
+        std::lock_guard<std::mutex> g(g_locus_mu);
+        if (!L.fe_dev) {
+            D = new DevLocus();
+            const int rc = hgx_front_tables_build(L, D->T);
+            if (rc) { delete D; return rc; }
+            L.fe_dev = D;
+            L.fe_dev_free = dev_locus_free;
+        }
+        D = (DevLocus *)L.fe_dev;
+    }
+    *usable = D->T.usable;
+    if (!D->T.usable) return HGX_OK;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(D->mu);
+    for (auto &d : D->per_dev) if (d.dev == dev) { *view = &d.view; return HGX_OK; }
+    // one allocation, every table 256-byte aligned
+    const FeLocus H = hgx_front_view(L, D->T);
+    struct Part { const void *src; size_t bytes; size_t off; };
+    std::vector<Part> parts;
+    size_t total = 0;
+    auto add = [&](const void *src, size_t bytes) { parts.push_back({src, bytes, total}); total += (bytes + 255) & ~(size_t)255; return parts.size() - 1; };
+    const size_t V = (size_t)L.V;
+    const size_t i_pos = add(H.pos, V * 4), i_right = add(H.right, V * 4), i_len = add(H.len, V * 4), i_maxr = add(H.maxright, V * 4);
+    const size_t i_type = add(H.type, V), i_linked = add(H.linked, V), i_base = add(H.base, V);
+    const size_t i_lbits = add(H.linked_bits, L.linked_bits.size() * 4), i_bb = add(H.backbone, L.backbone.size());
+    const size_t i_ex = add(H.exons, D->T.exons.size() * 4), i_hv = add(H.hv_index, L.hv_index.size() * 4);
+    const size_t i_noff = add(H.name_off, D->T.name_off.size() * 4), i_npool = add(H.name_pool, D->T.name_pool.size());
+    size_t i_anchor[2], i_koff[2], i_soff[2], i_loff[2];
+    for (int d = 0; d < 2; ++d) {
+        i_anchor[d] = add(H.alt_anchor[d], D->T.alt_anchor[d].size() * 4);
+        i_koff[d] = add(H.alt_key_off[d], D->T.alt_key_off[d].size() * 4);
+        i_soff[d] = add(H.alt_str_off[d], D->T.alt_str_off[d].size() * 4);
+        i_loff[d] = add(H.alt_list_off[d], D->T.alt_list_off[d].size() * 4);
+    }
+    const size_t i_htoff = add(H.alt_ht_off, D->T.alt_ht_off.size() * 4), i_ints = add(H.alt_ints, D->T.alt_ints.size() * 4);
+    const size_t i_chars = add(H.alt_chars, D->T.alt_chars.size());
+    char *block = (char *)hgx_pool_alloc(std::max<size_t>(total, 256));
+    if (!block) { hgx_set_error("device allocation of the front end's locus tables failed"); return HGX_ENOMEM; }
+    std::vector<char> host(total, 0);
+    for (auto &p : parts) if (p.bytes) memcpy(host.data() + p.off, p.src, p.bytes);
+    if (total) HIPCHK(hipMemcpyAsync(block, host.data(), total, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    FeLocus F = H;
+    auto at = [&](size_t i) { return (const void *)(block + parts[i].off); };
+    F.pos = (const int32_t *)at(i_pos); F.right = (const int32_t *)at(i_right); F.len = (const int32_t *)at(i_len);
+    F.maxright = (const int32_t *)at(i_maxr); F.type = (const uint8_t *)at(i_type); F.linked = (const uint8_t *)at(i_linked);
+    F.base = (const char *)at(i_base); F.linked_bits = (const uint32_t *)at(i_lbits); F.backbone = (const char *)at(i_bb);
+    F.exons = (const int32_t *)at(i_ex); F.hv_index = (const int32_t *)at(i_hv); F.name_off = (const int32_t *)at(i_noff);
+    F.name_pool = (const char *)at(i_npool);
+    for (int d = 0; d < 2; ++d) {
+        F.alt_anchor[d] = (const int32_t *)at(i_anchor[d]); F.alt_key_off[d] = (const int32_t *)at(i_koff[d]);
+        F.alt_str_off[d] = (const int32_t *)at(i_soff[d]); F.alt_list_off[d] = (const int32_t *)at(i_loff[d]);
+    }
+    F.alt_ht_off = (const int32_t *)at(i_htoff); F.alt_ints = (const int32_t *)at(i_ints); F.alt_chars = (const char *)at(i_chars);
+    D->per_dev.push_back({dev, block, F});
+    *view = &D->per_dev.back().view;
+    return HGX_OK;
+}
+
+// ---- control block of one call ----------------------------------------------------------------------------------------------------
+struct FeCtl {
+    uint32_t ht_cursor, cand_cursor, mask_cursor;
+    int32_t decline;                 // first decline code seen (an FE_E_* value, negative), 0 = none
+    uint32_t n_heads, n_masks;
+    unsigned long long n_reads, n_gene_refs, pair_total;      // pair_total = pairs << 40 | refs
+};
+
+__device__ __forceinline__ void fe_decline(FeCtl *ctl, int code) { atomicCAS(&ctl->decline, 0, code); }
+
+// ---- kernels ----------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_fe_pileup(const FeKey *__restrict__ keys, uint32_t n_keys, const char *__restrict__ text, int n_ref,
+                                                    int tile, uint32_t *__restrict__ counts, FeCtl *ctl) {
+    extern __shared__ uint32_t hist[];
+    const int t0 = blockIdx.y * tile, t1 = min(n_ref, t0 + tile);
+    const int cells = (t1 - t0) * 6;
+    for (int c = threadIdx.x; c < cells; c += blockDim.x) hist[c] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    for (uint32_t k = blockIdx.x * wpb + wave; k < n_keys; k += gridDim.x * wpb) {
+        const FeKey K = keys[k];
+        if (K.n_pile == 0 || K.pos >= t1) continue;
+        const int lo = t0 * 6;
+        const int rc = fe_pileup_key(K, text, n_ref, lane, 64, [&](uint32_t cell, uint32_t w) {
+            const int c = (int)cell - lo;
+            if (c >= 0 && c < cells) atomicAdd(&hist[c], w);
+        });
+        if (rc < 0 && lane == 0) fe_decline(ctl, rc);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cells; c += blockDim.x) {
+        const uint32_t v = hist[c];
+        if (v) atomicAdd(&counts[(size_t)t0 * 6 + c], v);
+    }
+}
+
+__global__ void k_fe_nt_set(const uint32_t *__restrict__ counts, int n_ref, uint8_t *__restrict__ nt_set) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_ref) nt_set[i] = fe_nt_set(counts + (size_t)i * 6);
+}
+
+__global__ void __launch_bounds__(256) k_fe_decode(FeLocus L, FeParse o, FePile P, const FeKey *__restrict__ keys, uint32_t n_keys,
+                                                   const char *__restrict__ text, FePools pools, uint8_t *__restrict__ state,
+                                                   uint32_t *__restrict__ key_ht_off, uint32_t *__restrict__ key_n_ht, FeCtl *ctl) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_keys) return;
+    const FeKey K = keys[k];
+    if (K.slot == FE_NO_SLOT) return;
+    uint8_t st = 2;
+    uint32_t off = 0, n = 0;
+    const int rc = fe_key(L, o, P, K, text, pools, st, off, n);
+    if (rc < 0) { fe_decline(ctl, rc); st = 2; n = 0; }
+    state[K.slot] = st;
+    key_ht_off[K.slot] = off;
+    key_n_ht[K.slot] = n;
+}
+
+__global__ void k_fe_iota(uint32_t *a, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = i;
+}
+
+// candidates sorted by content key: flag the first of every run; the others must equal their predecessor word for word
+__global__ void k_fe_heads(const uint64_t *__restrict__ key_s, const uint32_t *__restrict__ idx_s, uint32_t n, const uint16_t *__restrict__ lo,
+                           const uint16_t *__restrict__ nw, const uint32_t *__restrict__ mask_off, const uint32_t *__restrict__ masks,
+                           uint32_t *__restrict__ flag, FeCtl *ctl) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const bool head = k == 0 || key_s[k] != key_s[k - 1];
+    if (!head) {
+        const uint32_t a = idx_s[k], b = idx_s[k - 1];
+        bool same = lo[a] == lo[b] && nw[a] == nw[b];
+        if (same) {
+            const uint32_t *ma = masks + mask_off[a], *mb = masks + mask_off[b];
+            for (int i = 0; i < 2 * (int)nw[a] && same; ++i) same = ma[i] == mb[i];
+        }
+        if (!same) fe_decline(ctl, -HGX_FE_DECLINE_COLLISION);
+    }
+    flag[k] = head ? 1u : 0u;
+}
+__global__ void k_fe_assign_heads(const uint32_t *__restrict__ idx_s, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ rank_ex, uint32_t n,
+                                  uint32_t *__restrict__ head_of, uint32_t *__restrict__ head_cand, FeCtl *ctl) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t h = rank_ex[k] + flag[k] - 1;
+    head_of[idx_s[k]] = h;
+    if (flag[k]) head_cand[h] = idx_s[k];
+    if (k == n - 1) ctl->n_heads = h + 1;
+}
+__global__ void k_fe_head_keys(const uint32_t *__restrict__ head_cand, uint32_t n, const uint16_t *__restrict__ lo, const uint16_t *__restrict__ nw,
+                               const uint32_t *__restrict__ mask_off, const uint32_t *__restrict__ masks, uint64_t *__restrict__ whash,
+                               uint32_t *__restrict__ idx) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n) return;
+    const uint32_t c = head_cand[h];
+    whash[h] = fe_piece_hash(lo[c], nw[c], masks + mask_off[c]);
+    idx[h] = h;
+}
+__global__ void k_fe_lonw(const uint32_t *__restrict__ idx_s, const uint32_t *__restrict__ head_cand, uint32_t n, const uint16_t *__restrict__ lo,
+                          const uint16_t *__restrict__ nw, uint32_t *__restrict__ lonw) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t c = head_cand[idx_s[k]];
+    lonw[k] = ((uint32_t)lo[c] << 16) | nw[c];
+}
+// heads in (first word, width, PieceTable::hash) order: runs that still tie are ordered by their bytes (never seen; exactness)
+__global__ void k_fe_tie_fix(uint32_t *__restrict__ ord, uint32_t n, const uint32_t *__restrict__ head_cand, const uint16_t *__restrict__ lo,
+                             const uint16_t *__restrict__ nw, const uint32_t *__restrict__ mask_off, const uint32_t *__restrict__ masks) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    auto same = [&](uint32_t x, uint32_t y) {
+        const uint32_t a = head_cand[ord[x]], b = head_cand[ord[y]];
+        return lo[a] == lo[b] && nw[a] == nw[b] && fe_piece_hash(lo[a], nw[a], masks + mask_off[a]) == fe_piece_hash(lo[b], nw[b], masks + mask_off[b]);
+    };
+    if (k + 1 >= n || !same(k, k + 1) || (k > 0 && same(k - 1, k))) return;
+    uint32_t e = k + 1;
+    while (e + 1 < n && same(e, e + 1)) ++e;
+    auto less = [&](uint32_t ha, uint32_t hb) {
+        const uint32_t a = head_cand[ha], b = head_cand[hb];
+        const unsigned char *pa = (const unsigned char *)(masks + mask_off[a]), *pb = (const unsigned char *)(masks + mask_off[b]);
+        for (int i = 0; i < 8 * (int)nw[a]; ++i) if (pa[i] != pb[i]) return pa[i] < pb[i];
+        return false;
+    };
+    for (uint32_t i = k + 1; i <= e; ++i) {
+        const uint32_t v = ord[i];
+        uint32_t j = i;
+        while (j > k && less(v, ord[j - 1])) { ord[j] = ord[j - 1]; --j; }
+        ord[j] = v;
+    }
+}
+__global__ void k_fe_piece_sizes(const uint32_t *__restrict__ ord, const uint32_t *__restrict__ head_cand, uint32_t n, const uint16_t *__restrict__ nw,
+                                 uint32_t *__restrict__ nw2) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) nw2[k] = 2u * nw[head_cand[ord[k]]];
+}
+__global__ void k_fe_write_pieces(const uint32_t *__restrict__ ord, const uint32_t *__restrict__ head_cand, uint32_t n, const uint16_t *__restrict__ lo,
+                                  const uint16_t *__restrict__ nw, const uint32_t *__restrict__ mask_off, const uint32_t *__restrict__ masks,
+                                  const uint32_t *__restrict__ moff, hgx_piece *__restrict__ pieces, uint32_t *__restrict__ out_masks,
+                                  uint32_t *__restrict__ new_id, FeCtl *ctl) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t h = ord[k], c = head_cand[h];
+    hgx_piece pc;
+    pc.mask_off = moff[k];
+    pc.lo_word = lo[c];
+    pc.n_words = nw[c];
+    pieces[k] = pc;
+    const uint32_t *src = masks + mask_off[c];
+    for (int i = 0; i < 2 * (int)nw[c]; ++i) out_masks[moff[k] + i] = src[i];
+    new_id[h] = k;
+    if (k == n - 1) ctl->n_masks = moff[k] + 2u * nw[c];
+}
+__global__ void k_fe_cand_piece(const uint32_t *__restrict__ head_of, const uint32_t *__restrict__ new_id, uint32_t n, uint32_t *__restrict__ cand_piece) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n) cand_piece[c] = new_id[head_of[c]];
+}
+
+// pair protocol, pass 1: per run of records with one read id -> (1 << 40 | refs) if it yields a pair
+__global__ void __launch_bounds__(256) k_fe_pair_count(const uint32_t *__restrict__ rec_info, uint32_t n_rec, const uint8_t *__restrict__ state,
+                                                       const uint32_t *__restrict__ key_ht_off, const uint32_t *__restrict__ key_n_ht,
+                                                       const int32_t *__restrict__ ht_pool, unsigned long long *__restrict__ cnt, FeCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0, reads = 0, gene = 0;
+    if (i < n_rec && FE_REC_HEAD(rec_info[i])) {
+        uint32_t uni[FE_MAX_PAIR_HT];
+        int n_uni = 0;
+        const int ns = fe_pair_union(rec_info, i, n_rec, state, key_ht_off, key_n_ht, ht_pool, uni, n_uni);
+        if (ns < 0) fe_decline(ctl, ns);
+        else if (ns > 0) {
+            unsigned long long n_exon = 0;
+            for (int x = 0; x < n_uni; ++x) n_exon += (unsigned long long)ht_pool[uni[x] + 3];
+            if (n_exon > 65535 || n_uni > 65535) fe_decline(ctl, FE_E_PAIR);
+            c = (1ull << 40) | (n_exon + (unsigned long long)n_uni);
+            reads = (unsigned long long)ns;
+            gene = (unsigned long long)n_uni;
+        }
+    }
+    if (i < n_rec) cnt[i] = c;
+    reads = wave_sum_u64(reads);
+    gene = wave_sum_u64(gene);
+    if ((threadIdx.x & 63) == 0 && (reads | gene)) { atomicAdd(&ctl->n_reads, reads); atomicAdd(&ctl->n_gene_refs, gene); }
+}
+__global__ void k_fe_pair_total(const unsigned long long *__restrict__ cnt, const unsigned long long *__restrict__ off, uint32_t n, FeCtl *ctl) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->pair_total = n ? off[n - 1] + cnt[n - 1] : 0ull;
+}
+__global__ void __launch_bounds__(256) k_fe_pair_emit(const uint32_t *__restrict__ rec_info, uint32_t n_rec, const uint8_t *__restrict__ state,
+                                                      const uint32_t *__restrict__ key_ht_off, const uint32_t *__restrict__ key_n_ht,
+                                                      const int32_t *__restrict__ ht_pool, const unsigned long long *__restrict__ cnt,
+                                                      const unsigned long long *__restrict__ off, const uint32_t *__restrict__ cand_piece,
+                                                      int32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_ref, uint32_t n_pairs, uint32_t n_refs) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) pair_off[n_pairs] = (int32_t)n_refs;
+    if (i >= n_rec || cnt[i] == 0) return;
+    uint32_t uni[FE_MAX_PAIR_HT];
+    int n_uni = 0;
+    (void)fe_pair_union(rec_info, i, n_rec, state, key_ht_off, key_n_ht, ht_pool, uni, n_uni);
+    const uint32_t p = (uint32_t)(off[i] >> 40);
+    uint32_t r = (uint32_t)(off[i] & ((1ull << 40) - 1));
+    pair_off[p] = (int32_t)r;
+    for (int x = 0; x < n_uni; ++x) {
+        const int32_t *rec = ht_pool + uni[x];
+        for (int e = 0; e < rec[3]; ++e) pair_ref[r++] = cand_piece[(uint32_t)rec[4] + e];
+    }
+    for (int x = 0; x < n_uni; ++x) {
+        const int32_t *rec = ht_pool + uni[x];
+        pair_ref[r++] = cand_piece[(uint32_t)rec[4] + rec[3]] | 0x80000000u;
+    }
+}
+
+thread_local int g_last_device = 0, g_last_decline = 0;
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- the device stages of one call ------------------------------------------------------------------------------------------------
+int front_run(hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, int *declined) {
+    *out = nullptr;
+    *declined = 0;
+    const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
+    double t_prev = now_ms();
+    auto lap = [&](const char *what) {
+        if (!prof) return;
+        (void)hipStreamSynchronize(st);
+        const double t = now_ms();
+        fprintf(stderr, "[hgx_front]     %-28s %8.2f ms\n", what, t - t_prev);
+        t_prev = t;
+    };
+    const FeLocus *Fp = nullptr;
+    bool usable = false;
+    int rc = dev_locus(L, st, &Fp, &usable);
+    if (rc) return rc;
+    if (!usable) { *declined = HGX_FE_DECLINE_LOCUS; return HGX_OK; }
+    const FeLocus F = *Fp;
+    const int n_ref = F.n_ref;
+    const uint32_t n_keys = (uint32_t)in.n_keys, n_rec = (uint32_t)in.n_rec, S = (uint32_t)in.n_slots;
+    if (in.n_keys >= (1ull << 31) || in.n_rec >= (1ull << 31)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+
+    // every buffer of the call is declared here, the guard after them: on ANY way out the stream is drained first, then the
+    // buffers go back to the pool
+    DevBuf b_keys, b_text, b_rec, b_ctl, b_state, b_koff, b_knht, b_ht, b_clo, b_cnw, b_ckey, b_cmoff, b_mpool;
+    DevBuf b_cnt, b_off, b_tmp, b_tmp2, b_key_s, b_idx, b_idx_s, b_flag, b_rank, b_head_of, b_head_cand;
+    DevBuf b_wh, b_wh_s, b_hidx, b_hidx_s, b_lonw, b_lonw_s, b_ord, b_nw2, b_moff, b_new_id, b_cand_piece;
+    hgx_dbatch *d = new hgx_dbatch();
+    struct Guard { hgx_dbatch *&d; hipStream_t st; ~Guard() { (void)hipStreamSynchronize(st); if (d) hgx_dbatch_destroy(d); } } guard{d, st};
+    ALLOC(b_keys, std::max<size_t>(in.n_keys, 1) * sizeof(FeKey));
+    ALLOC(b_text, in.n_text + 64);
+    ALLOC(b_rec, std::max<size_t>(in.n_rec, 1) * 4);
+    ALLOC(b_ctl, sizeof(FeCtl));
+    if (in.n_keys) HIPCHK(hipMemcpyAsync(b_keys.p, in.keys, in.n_keys * sizeof(FeKey), hipMemcpyHostToDevice, st));
+    if (in.n_text) HIPCHK(hipMemcpyAsync(b_text.p, in.text, in.n_text, hipMemcpyHostToDevice, st));
+    if (in.n_rec) HIPCHK(hipMemcpyAsync(b_rec.p, in.rec_info, in.n_rec * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(b_ctl.p, 0, sizeof(FeCtl), st));
+    FeCtl *ctl = b_ctl.as<FeCtl>();
+    const FeKey *keys = b_keys.as<FeKey>();
+    const char *text = b_text.as<char>();
+    const uint32_t *rec_info = b_rec.as<uint32_t>();
+    lap("upload");
+
+    // pileup
+    d->n_ref = n_ref;
+    d->d_counts = (uint32_t *)hgx_pool_alloc(std::max<size_t>((size_t)n_ref * 6 * 4, 16));
+    d->d_nt_set = (uint8_t *)hgx_pool_alloc(std::max<size_t>(n_ref, 16));
+    if (!d->d_counts || !d->d_nt_set) { hgx_set_error("device allocation of the pileup tables failed"); return HGX_ENOMEM; }
+    HIPCHK(hipMemsetAsync(d->d_counts, 0, (size_t)n_ref * 6 * 4, st));
+    if (n_keys && n_ref > 0) {
+        const int tile = std::min(n_ref, 6000);                       // 6 counters x 4 bytes x 6000 positions = 144 KB of LDS
+        const size_t lds = (size_t)tile * 6 * 4;
+        HGX_ONCE_PER_DEVICE(HIPCHK(hipFuncSetAttribute((const void *)k_fe_pileup, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
+        const unsigned n_tiles = (unsigned)((n_ref + tile - 1) / tile);
+        const unsigned nb = std::max(1u, std::min(256u, (n_keys + 63) / 64));
+        k_fe_pileup<<<dim3(nb, n_tiles), 1024, lds, st>>>(keys, n_keys, text, n_ref, tile, d->d_counts, ctl);
+    }
+    if (o.pileup_exchange && n_ref > 0) {                               // intra-locus read sharding: the sum over all shards (8e)
+        std::vector<uint32_t> h((size_t)n_ref * 6);
+        HIPCHK(hipMemcpyAsync(h.data(), d->d_counts, h.size() * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (o.pileup_exchange(o.pileup_ctx, h.data(), (int64_t)h.size()) != 0) {
+            hgx_set_error("pileup exchange between the ranks of a sharded locus failed");
+            return HGX_EINVAL;
+        }
+        HIPCHK(hipMemcpyAsync(d->d_counts, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    if (n_ref > 0) k_fe_nt_set<<<nblk(n_ref, 256), 256, 0, st>>>(d->d_counts, n_ref, d->d_nt_set);
+    lap("pileup");
+
+    // decode
+    const size_t ht_cap = (size_t)S * 48 + 4096, cand_cap = (size_t)S * 12 + 4096, mask_cap = cand_cap * 16;
+    if (ht_cap >= (1ull << 32) || mask_cap >= (1ull << 32)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+    ALLOC(b_state, std::max<size_t>(S, 16));
+    ALLOC(b_koff, std::max<size_t>(S, 4) * 4);
+    ALLOC(b_knht, std::max<size_t>(S, 4) * 4);
+    ALLOC(b_ht, ht_cap * 4);
+    ALLOC(b_clo, cand_cap * 2);
+    ALLOC(b_cnw, cand_cap * 2);
+    ALLOC(b_ckey, cand_cap * 8);
+    ALLOC(b_cmoff, cand_cap * 4);
+    ALLOC(b_mpool, mask_cap * 4);
+    FePools pools;
+    pools.ht_pool = b_ht.as<int32_t>(); pools.ht_cap = (uint32_t)ht_cap; pools.ht_cursor = &ctl->ht_cursor;
+    pools.cand_lo = b_clo.as<uint16_t>(); pools.cand_nw = b_cnw.as<uint16_t>(); pools.cand_key = b_ckey.as<uint64_t>();
+    pools.cand_mask_off = b_cmoff.as<uint32_t>(); pools.cand_cap = (uint32_t)cand_cap; pools.cand_cursor = &ctl->cand_cursor;
+    pools.mask_pool = b_mpool.as<uint32_t>(); pools.mask_cap = (uint32_t)mask_cap; pools.mask_cursor = &ctl->mask_cursor;
+    const FeParse po{o.num_editdist, o.error_correction};
+    const FePile pile{d->d_nt_set, d->d_counts};
+    if (n_keys) k_fe_decode<<<nblk(n_keys, 256), 256, 0, st>>>(F, po, pile, keys, n_keys, text, pools, b_state.as<uint8_t>(), b_koff.as<uint32_t>(),
+                                                               b_knht.as<uint32_t>(), ctl);
+    // the pair counts need nothing but the decode results
+    ALLOC(b_cnt, std::max<size_t>(n_rec, 1) * 8);
+    ALLOC(b_off, std::max<size_t>(n_rec, 1) * 8);
+    if (n_rec) k_fe_pair_count<<<nblk(n_rec, 256), 256, 0, st>>>(rec_info, n_rec, b_state.as<uint8_t>(), b_koff.as<uint32_t>(), b_knht.as<uint32_t>(),
+                                                                 b_ht.as<int32_t>(), b_cnt.as<unsigned long long>(), ctl);
+    FeCtl h;
+    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    lap("decode + pair counts");
+    if (h.decline) { *declined = -h.decline; return HGX_OK; }
+    const uint32_t n_cand = h.cand_cursor;
+    d->n_reads = (int32_t)h.n_reads;
+    d->n_gene_refs = (int64_t)h.n_gene_refs;
+
+    // temp storage for the scans / sorts (one block, the largest request)
+    size_t tmp_bytes = 0;
+    {
+        size_t b = 0;
+        (void)hipcub::DeviceScan::ExclusiveSum((void *)nullptr, b, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int)std::max<uint32_t>(n_rec, 1), st);
+        tmp_bytes = std::max(tmp_bytes, b);
+        (void)hipcub::DeviceRadixSort::SortPairs((void *)nullptr, b, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+                                           (int)std::max<uint32_t>(n_cand, 1), 0, 64, st);
+        tmp_bytes = std::max(tmp_bytes, b);
+        (void)hipcub::DeviceScan::ExclusiveSum((void *)nullptr, b, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)std::max<uint32_t>(n_cand, 1), st);
+        tmp_bytes = std::max(tmp_bytes, b);
+    }
+    ALLOC(b_tmp, std::max<size_t>(tmp_bytes, 256));
+    if (n_rec) {
+        size_t b = tmp_bytes;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_cnt.as<unsigned long long>(), b_off.as<unsigned long long>(), (int)n_rec, st));
+        k_fe_pair_total<<<1, 64, 0, st>>>(b_cnt.as<unsigned long long>(), b_off.as<unsigned long long>(), n_rec, ctl);
+    }
+    // distinct pieces
+    ALLOC(b_key_s, std::max<size_t>(n_cand, 1) * 8);
+    ALLOC(b_idx, std::max<size_t>(n_cand, 1) * 4);
+    ALLOC(b_idx_s, std::max<size_t>(n_cand, 1) * 4);
+    ALLOC(b_flag, std::max<size_t>(n_cand, 1) * 4);
+    ALLOC(b_rank, std::max<size_t>(n_cand, 1) * 4);
+    ALLOC(b_head_of, std::max<size_t>(n_cand, 1) * 4);
+    ALLOC(b_head_cand, std::max<size_t>(n_cand, 1) * 4);
+    if (n_cand) {
+        k_fe_iota<<<nblk(n_cand, 256), 256, 0, st>>>(b_idx.as<uint32_t>(), n_cand);
+        size_t b = tmp_bytes;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, b_ckey.as<uint64_t>(), b_key_s.as<uint64_t>(), b_idx.as<uint32_t>(), b_idx_s.as<uint32_t>(),
+                                                  (int)n_cand, 0, 64, st));
+        k_fe_heads<<<nblk(n_cand, 256), 256, 0, st>>>(b_key_s.as<uint64_t>(), b_idx_s.as<uint32_t>(), n_cand, pools.cand_lo, pools.cand_nw,
+                                                      pools.cand_mask_off, pools.mask_pool, b_flag.as<uint32_t>(), ctl);
+        b = tmp_bytes;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n_cand, st));
+        k_fe_assign_heads<<<nblk(n_cand, 256), 256, 0, st>>>(b_idx_s.as<uint32_t>(), b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n_cand,
+                                                             b_head_of.as<uint32_t>(), b_head_cand.as<uint32_t>(), ctl);
+    }
+    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    lap("distinct pieces");
+    if (h.decline) { *declined = -h.decline; return HGX_OK; }
+    const uint32_t n_heads = n_cand ? h.n_heads : 0;
+    const uint64_t n_pairs64 = h.pair_total >> 40, n_refs64 = h.pair_total & ((1ull << 40) - 1);
+    if (n_refs64 >= (1ull << 31) || n_pairs64 >= (1ull << 31)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+    const uint32_t n_pairs = (uint32_t)n_pairs64, n_refs = (uint32_t)n_refs64;
+
+    // canonical order of the distinct pieces, the piece table, the refs
+    ALLOC(b_wh, std::max<size_t>(n_heads, 1) * 8);
+    ALLOC(b_wh_s, std::max<size_t>(n_heads, 1) * 8);
+    ALLOC(b_hidx, std::max<size_t>(n_heads, 1) * 4);
+    ALLOC(b_hidx_s, std::max<size_t>(n_heads, 1) * 4);
+    ALLOC(b_lonw, std::max<size_t>(n_heads, 1) * 4);
+    ALLOC(b_lonw_s, std::max<size_t>(n_heads, 1) * 4);
+    ALLOC(b_ord, std::max<size_t>(n_heads, 1) * 4);
+    ALLOC(b_nw2, std::max<size_t>(n_heads, 1) * 4);
+    ALLOC(b_moff, std::max<size_t>(n_heads, 1) * 4);
+    ALLOC(b_new_id, std::max<size_t>(n_heads, 1) * 4);
+    ALLOC(b_cand_piece, std::max<size_t>(n_cand, 1) * 4);
+    d->n_pieces = (int32_t)n_heads;
+    d->n_pairs = (int32_t)n_pairs;
+    d->n_refs = (int64_t)n_refs;
+    d->d_pieces = (hgx_piece *)hgx_pool_alloc(std::max<size_t>((size_t)n_heads * sizeof(hgx_piece), 16));
+    d->d_masks = (uint32_t *)hgx_pool_alloc(std::max<size_t>((size_t)h.mask_cursor * 4, 16));
+    d->d_pair_off = (int32_t *)hgx_pool_alloc(((size_t)n_pairs + 1) * 4);
+    d->d_pair_ref = (uint32_t *)hgx_pool_alloc(std::max<size_t>((size_t)n_refs * 4, 16));
+    if (!d->d_pieces || !d->d_masks || !d->d_pair_off || !d->d_pair_ref) { hgx_set_error("device allocation of the piece batch failed"); return HGX_ENOMEM; }
+    if (n_heads) {
+        k_fe_head_keys<<<nblk(n_heads, 256), 256, 0, st>>>(b_head_cand.as<uint32_t>(), n_heads, pools.cand_lo, pools.cand_nw, pools.cand_mask_off,
+                                                          pools.mask_pool, b_wh.as<uint64_t>(), b_hidx.as<uint32_t>());
+        size_t b = tmp_bytes;                                      // (n_heads <= n_cand: the block is large enough)
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, b_wh.as<uint64_t>(), b_wh_s.as<uint64_t>(), b_hidx.as<uint32_t>(), b_hidx_s.as<uint32_t>(),
+                                                  (int)n_heads, 0, 64, st));
+        k_fe_lonw<<<nblk(n_heads, 256), 256, 0, st>>>(b_hidx_s.as<uint32_t>(), b_head_cand.as<uint32_t>(), n_heads, pools.cand_lo, pools.cand_nw,
+                                                     b_lonw.as<uint32_t>());
+        size_t b2 = 0;
+        (void)hipcub::DeviceRadixSort::SortPairs((void *)nullptr, b2, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_heads, 0, 32, st);
+        void *tmp2 = b_tmp.p;
+        if (b2 > tmp_bytes) { ALLOC(b_tmp2, b2); tmp2 = b_tmp2.p; }
+        else b2 = tmp_bytes;
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(tmp2, b2, b_lonw.as<uint32_t>(), b_lonw_s.as<uint32_t>(), b_hidx_s.as<uint32_t>(), b_ord.as<uint32_t>(),
+                                                  (int)n_heads, 0, 32, st));
+        k_fe_tie_fix<<<nblk(n_heads, 256), 256, 0, st>>>(b_ord.as<uint32_t>(), n_heads, b_head_cand.as<uint32_t>(), pools.cand_lo, pools.cand_nw,
+                                                        pools.cand_mask_off, pools.mask_pool);
+        k_fe_piece_sizes<<<nblk(n_heads, 256), 256, 0, st>>>(b_ord.as<uint32_t>(), b_head_cand.as<uint32_t>(), n_heads, pools.cand_nw, b_nw2.as<uint32_t>());
+        b = tmp_bytes;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_nw2.as<uint32_t>(), b_moff.as<uint32_t>(), (int)n_heads, st));
+        k_fe_write_pieces<<<nblk(n_heads, 256), 256, 0, st>>>(b_ord.as<uint32_t>(), b_head_cand.as<uint32_t>(), n_heads, pools.cand_lo, pools.cand_nw,
+                                                             pools.cand_mask_off, pools.mask_pool, b_moff.as<uint32_t>(), d->d_pieces, d->d_masks,
+                                                             b_new_id.as<uint32_t>(), ctl);
+        k_fe_cand_piece<<<nblk(n_cand, 256), 256, 0, st>>>(b_head_of.as<uint32_t>(), b_new_id.as<uint32_t>(), n_cand, b_cand_piece.as<uint32_t>());
+    }
+    if (n_rec) k_fe_pair_emit<<<nblk(n_rec, 256), 256, 0, st>>>(rec_info, n_rec, b_state.as<uint8_t>(), b_koff.as<uint32_t>(), b_knht.as<uint32_t>(),
+                                                                b_ht.as<int32_t>(), b_cnt.as<unsigned long long>(), b_off.as<unsigned long long>(),
+                                                                b_cand_piece.as<uint32_t>(), d->d_pair_off, d->d_pair_ref, n_pairs, n_refs);
+    else HIPCHK(hipMemsetAsync(d->d_pair_off, 0, 4, st));
+    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    lap("piece table + refs");
+    d->n_mask_u32 = n_heads ? (int64_t)h.n_masks : 0;
+    d->sum_piece_words = d->n_mask_u32 / 2;
+    *out = d;
+    d = nullptr;                       // (the guard keeps its hands off)
+    return HGX_OK;
+}
+
+// host stages with the device stages hooked in; *out is always a device batch on success
+template <class Parse>
+int parse_dev(hgx_dbatch **out, hipStream_t st, Parse parse) {
+    *out = nullptr;
+    hgx_dbatch *made = nullptr;
+    hgx_front_hook hook;
+    hook.mem = hgx_front_alloc{pinned_alloc, pinned_release};
+    const bool force = hgx_test_switch("front_device") != nullptr;
+    bool ran = false;
+    hook.run = [&](hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, int *declined) {
+        ran = true;
+        if (!force && in.n_rec < 20000) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }     // a dozen launches cost more than a small host decode
+        return front_run(L, in, o, st, &made, declined);
+    };
+    hgx_batch *b = nullptr;
+    const bool host_only = hgx_test_switch("front_host") != nullptr;
+    const int rc = parse(&b, host_only ? nullptr : &hook);
+    g_last_decline = host_only ? -1 : hook.declined;
+    g_last_device = (!host_only && ran && !hook.declined && !rc && made) ? 1 : 0;
+    if (rc) { hgx_dbatch_destroy(made); return rc; }
+    if (g_last_device) { *out = made; return HGX_OK; }
+    hgx_dbatch_destroy(made);
+    if (!b) { hgx_set_error("front end produced no batch"); return HGX_EINVAL; }
+    const int rc2 = hgx_dbatch_create(out, b, st);
+    hgx_batch_destroy(b);
+    return rc2;
+}
+
+}   // namespace
+
+extern "C" int hgx_parse_sam_dev(hgx_dbatch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, void *stream) {
+    ARGCHK(out && loc && opts);
+    return parse_dev(out, (hipStream_t)stream, [&](hgx_batch **b, hgx_front_hook *hook) { return hgx_parse_sam_hook(b, loc, sam, n_bytes, opts, hook); });
+}
+
+extern "C" int hgx_parse_alignment_file_dev(hgx_dbatch **out, const hgx_locus *loc, const char *path, const char *regions,
+                                            const hgx_parse_opts *opts, void *stream) {
+    ARGCHK(out && loc && path && opts);
+    return parse_dev(out, (hipStream_t)stream,
+                     [&](hgx_batch **b, hgx_front_hook *hook) { return hgx_parse_alignment_file_hook(b, loc, path, regions, opts, hook); });
+}
+
+extern "C" int hgx_front_last(int32_t *device_stages_ran, int32_t *decline_code) {
+    if (device_stages_ran) *device_stages_ran = g_last_device;
+    if (decline_code) *decline_code = g_last_decline;
+    return HGX_OK;
+}
+
+// a device batch back on the host (tests, tools): pieces, masks, refs -- and the pileup tables where the device front end made them
+extern "C" int hgx_dbatch_to_host(const hgx_dbatch *d, hgx_batch **out) {
+    ARGCHK(d && out);
+    hgx_batch *b = new hgx_batch();
+    b->pieces.resize((size_t)d->n_pieces);
+    b->masks.resize((size_t)d->n_mask_u32);
+    b->pair_off.assign((size_t)d->n_pairs + 1, 0);
+    b->pair_ref.resize((size_t)d->n_refs);
+    b->n_reads = d->n_reads;
+    auto down = [&](void *dst, const void *src, size_t n) -> int {
+        if (n) HIPCHK(hipMemcpy(dst, src, n, hipMemcpyDeviceToHost));
+        return HGX_OK;
+    };
+    int rc = down(b->pieces.data(), d->d_pieces, b->pieces.size() * sizeof(hgx_piece));
+    if (!rc) rc = down(b->masks.data(), d->d_masks, b->masks.size() * 4);
+    if (!rc) rc = down(b->pair_off.data(), d->d_pair_off, b->pair_off.size() * 4);
+    if (!rc) rc = down(b->pair_ref.data(), d->d_pair_ref, b->pair_ref.size() * 4);
+    if (!rc && d->d_counts && d->n_ref > 0) {
+        b->counts.resize((size_t)d->n_ref * 6);
+        b->nt_set.resize((size_t)d->n_ref);
+        rc = down(b->counts.data(), d->d_counts, b->counts.size() * 4);
+        if (!rc) rc = down(b->nt_set.data(), d->d_nt_set, b->nt_set.size());
+    }
+    if (rc) { delete b; return rc; }
+    *out = b;
+    return HGX_OK;
+}

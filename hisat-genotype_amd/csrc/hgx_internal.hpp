@@ -59,6 +59,13 @@ struct hgx_locus {
     // alternatives (common:1424-1657), sorted by anchor position like Alts_left_list / Alts_right_list
     std::vector<AltEntry> alts_left, alts_right;
     bool alts_built = false;
+    // the device front end's tables of this locus (hgx_front.hip), made on first use: owned here, freed through fe_dev_free
+    mutable void *fe_dev = nullptr;
+    mutable void (*fe_dev_free)(void *) = nullptr;
+    hgx_locus() = default;
+    hgx_locus(const hgx_locus &) = delete;
+    hgx_locus &operator=(const hgx_locus &) = delete;
+    ~hgx_locus() { if (fe_dev && fe_dev_free) fe_dev_free(fe_dev); }
 
     bool carries(int32_t allele, int32_t v) const {
         return (link_bits[(size_t)(v >> 5) * a_pad + allele] >> (v & 31)) & 1u;
@@ -218,7 +225,8 @@ struct hgx_front_input {
 #define HGX_FE_DECLINE_RECORD 2        // a record the reference would raise on
 #define HGX_FE_DECLINE_LOCUS 3         // tables the device path does not take
 #define HGX_FE_DECLINE_SIZE 4          // more records / keys / text than its 32-bit offsets hold
-#define HGX_FE_DECLINE_COLLISION 5     // two different pieces with one 64-bit hash
+#define HGX_FE_DECLINE_COLLISION 5     // two different pieces with one 64-bit content key
+#define HGX_FE_DECLINE_SMALL 6         // too few records for a dozen launches to pay
 // The host stages call `run` after key grouping; it returns HGX_OK with *declined = 0 when the device stages produced the result
 // (which the hook's owner holds: the parse functions then return *out = NULL), or *declined = the reason -- the host stages
 // then finish the job and `declined` says why.

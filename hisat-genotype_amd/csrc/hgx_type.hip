@@ -33,15 +33,6 @@
 extern "C" int hgx_em_set_fast(int on);
 extern "C" int hgx_em_last_order(int32_t *order_host, int32_t n);
 
-struct hgx_dbatch {
-    int32_t n_pieces = 0, n_pairs = 0, n_reads = 0;
-    int64_t n_refs = 0, n_mask_u32 = 0, sum_piece_words = 0, n_gene_refs = 0;
-    hgx_piece *d_pieces = nullptr;
-    uint32_t *d_masks = nullptr;
-    int32_t *d_pair_off = nullptr;
-    uint32_t *d_pair_ref = nullptr;
-};
-
 struct hgx_gate { std::mutex mu; };
 
 namespace {
@@ -183,6 +174,7 @@ struct hgx_typing {
 extern "C" int hgx_dbatch_destroy(hgx_dbatch *d) {
     if (!d) return HGX_OK;
     hgx_pool_free(d->d_pieces); hgx_pool_free(d->d_masks); hgx_pool_free(d->d_pair_off); hgx_pool_free(d->d_pair_ref);
+    hgx_pool_free(d->d_counts); hgx_pool_free(d->d_nt_set);
     delete d;
     return HGX_OK;
 }
@@ -603,16 +595,18 @@ extern "C" int hgx_type_file(hgx_typing **out, const hgx_locus *loc, const hgx_i
                              const hgx_parse_opts *popts, const hgx_type_opts *opts, void *stream) {
     ARGCHK(out && loc && ix && path && popts && opts);
     *out = nullptr;
-    hgx_batch *b = nullptr;
+    hgx_dbatch *db = nullptr;
     const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
     const double t0 = now_s();
-    int rc = hgx_parse_alignment_file(&b, loc, path, regions, popts);
+    // host stages (read, tokenise, filters, key grouping) + device stages (pileup, decode, piece table, pair protocol): the batch is
+    // born in HBM; inputs the kernels decline are finished on the host and uploaded (hgx_front.hip)
+    int rc = hgx_parse_alignment_file_dev(&db, loc, path, regions, popts, stream);
     if (rc) return rc;
     const double t1 = now_s();
-    rc = hgx_type_batch(out, loc, ix, b, opts, stream);
+    rc = hgx_type_dbatch(out, loc, ix, db, opts, stream);
     const double t2 = now_s();
-    hgx_batch_destroy(b);
-    if (prof) fprintf(stderr, "[hgx_type_file] front end %.1f ms (incl. releasing the reader's buffers), upload + GPU + result %.1f ms, batch destroy %.1f ms\n",
+    hgx_dbatch_destroy(db);
+    if (prof) fprintf(stderr, "[hgx_type_file] front end %.1f ms (incl. releasing the reader's buffers), GPU path + result %.1f ms, batch destroy %.1f ms\n",
                       (t1 - t0) * 1e3, (t2 - t1) * 1e3, (now_s() - t2) * 1e3);
     return rc;
 }

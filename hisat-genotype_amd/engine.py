@@ -25,8 +25,30 @@ class DeviceBatch:
         self._batch = batch
         self._dev = None
 
+    @classmethod
+    def from_handle(cls, h):
+        """Wrap an hgx_dbatch made by the library (the device front end: hgx_parse_sam_dev / hgx_parse_alignment_file_dev)."""
+        self = cls.__new__(cls)
+        self.h = h
+        npc, npr, nrf, nrd, spw, ngr = C.c_int32(), C.c_int32(), C.c_int64(), C.c_int32(), C.c_int64(), C.c_int64()
+        capi.check(capi.lib().hgx_dbatch_dims(self.h, C.byref(npc), C.byref(npr), C.byref(nrf), C.byref(nrd), C.byref(spw), C.byref(ngr)))
+        self.n_pieces, self.n_pairs, self.n_refs, self.n_reads = npc.value, npr.value, nrf.value, nrd.value
+        self.sum_piece_words, self.n_gene_refs = spw.value, ngr.value
+        self._batch = None
+        self._dev = None
+        return self
+
+    def to_host(self):
+        """The batch as a host Batch (hgx_dbatch_to_host): pieces, masks, refs and -- if the kernels made them -- the pileup tables."""
+        from . import locus
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_dbatch_to_host(self.h, C.byref(h)))
+        return locus.Batch(h)
+
     def _arrays(self):
         """Separate device copies for the callers that drive the stages one by one (tests, tools)."""
+        if self._batch is None:
+            self._batch = self.to_host()
         if self._dev is None:
             b = self._batch
             self._dev = (DevArray.from_host(b.pieces if b.n_pieces else np.zeros(1, capi.PIECE_DTYPE)),
@@ -50,6 +72,13 @@ class DeviceBatch:
             self.close()
         except Exception:
             pass
+
+
+def front_last():
+    """(device stages ran?, decline code) of the calling thread's last hgx_parse_*_dev / hgx_type_file call."""
+    ran, code = C.c_int32(0), C.c_int32(0)
+    capi.check(capi.lib().hgx_front_last(C.byref(ran), C.byref(code)))
+    return bool(ran.value), code.value
 
 
 def em_last_order(n_alleles):
