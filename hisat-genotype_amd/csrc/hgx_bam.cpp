@@ -597,6 +597,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         data.release();
     } else raw.swap(data);
     lap("inflate");
+    if (out.on_raw) out.on_raw((const char *)raw.data(), raw.size());       // (the device front end's upload starts here)
     LineVec &lines = out.lines;
     lines.clear();
     if (raw.size() >= 4 && memcmp(raw.data(), "BAM\1", 4) == 0) {
@@ -858,6 +859,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
     lap(sorted ? "name order check" : "name sort");
     hgx_host_free(out.raw);
     out.raw = (char *)raw.p;                 // the line table points into it (SAM text); BAM text lives in out.chunks
+    out.raw_bytes = raw.n;
     raw.p = nullptr;
     raw.n = 0;
     return HGX_OK;

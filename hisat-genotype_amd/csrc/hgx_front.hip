@@ -146,6 +146,7 @@ struct FeCtl {
     uint32_t ht_cursor, cand_cursor, mask_cursor;
     int32_t decline;                 // first decline code seen (an FE_E_* value, negative), 0 = none
     uint32_t n_heads, n_masks;
+    uint32_t n_keys, n_slots, n_rec, pad_;                    // record stage: distinct keys, decoded keys, records that passed the filters
     unsigned long long n_reads, n_gene_refs, pair_total;      // pair_total = pairs << 40 | refs
 };
 
@@ -350,53 +351,140 @@ __global__ void __launch_bounds__(256) k_fe_pair_emit(const uint32_t *__restrict
     }
 }
 
-thread_local int g_last_device = 0, g_last_decline = 0;
+// ---- the record stage (row 8a-1): fields, filters, key grouping -----------------------------------------------------------------
+struct LineRef { uint32_t off, len; };      // a record of the name-ordered stream: first byte (after block_size for BAM) and length
+
+__global__ void __launch_bounds__(256) k_fe_records(const char *__restrict__ text, const LineRef *__restrict__ lines, uint32_t n, int binary,
+                                                    int simulation, FeRec *__restrict__ recs, FeCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    FeRec r;
+    const int rc = binary ? fe_parse_bam_record(text, lines[i].off, lines[i].len, simulation != 0, r)
+                          : fe_parse_text_record(text, lines[i].off, lines[i].len, simulation != 0, r);
+    if (rc < 0) { fe_decline(ctl, rc); r.bits = 0; r.flag = 4; r.id_len = 0; r.qname_off = 0; r.key = 0; }
+    recs[i] = r;
+}
+__global__ void k_fe_rec_heads(const FeRec *__restrict__ recs, uint32_t n, const char *__restrict__ text, uint8_t *__restrict__ head) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || !fe_same_read_id(recs[i - 1], recs[i], text)) ? 1 : 0;
+}
+// filters + insertion into the key table: slot claimed by the 64-bit key, representative = the FIRST record (atomicMin)
+__global__ void __launch_bounds__(256) k_fe_rec_filter_insert(const FeRec *__restrict__ recs, const uint8_t *__restrict__ head, uint32_t n, FeFilter flt,
+                                                              unsigned long long *__restrict__ tkeys, uint32_t *__restrict__ rep,
+                                                              uint32_t *__restrict__ pile, uint32_t *__restrict__ anyk, uint32_t mask,
+                                                              uint8_t *__restrict__ kept, uint32_t *__restrict__ slot_of, FeCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int k = fe_rec_kept(recs, head, i, flt);
+    if (k < 0) { fe_decline(ctl, k); k = 0; }
+    kept[i] = (uint8_t)k;
+    const bool pm = fe_rec_in_pileup(recs[i], flt);
+    const unsigned long long h = recs[i].key;
+    uint32_t slot = (uint32_t)h & mask;
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        const unsigned long long cur = atomicCAS(&tkeys[slot], ~0ull, h);
+        if (cur == ~0ull || cur == h) break;
+        slot = (slot + 1) & mask;
+    }
+    atomicMin(&rep[slot], i);
+    if (pm) atomicAdd(&pile[slot], 1u);
+    if (k) atomicOr(&anyk[slot], 1u);
+    slot_of[i] = slot;
+}
+// every record against its key's representative, byte for byte; and the flags the numbering is scanned from
+__global__ void __launch_bounds__(256) k_fe_group_flags(const FeRec *__restrict__ recs, uint32_t n, const char *__restrict__ text,
+                                                        const uint32_t *__restrict__ rep, const uint32_t *__restrict__ pile,
+                                                        const uint32_t *__restrict__ anyk, const uint32_t *__restrict__ slot_of,
+                                                        const uint8_t *__restrict__ kept, uint32_t *__restrict__ is_key, uint32_t *__restrict__ is_dec,
+                                                        uint32_t *__restrict__ kept32, uint32_t *__restrict__ prev_in, FeCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = slot_of[i], r = rep[s];
+    if (r != i && !fe_rec_same_key(recs[r], recs[i], text)) fe_decline(ctl, -HGX_FE_DECLINE_COLLISION);
+    const bool key = r == i && (pile[s] > 0 || anyk[s]);
+    is_key[i] = key ? 1u : 0u;
+    is_dec[i] = (key && anyk[s]) ? 1u : 0u;
+    kept32[i] = kept[i];
+    prev_in[i] = kept[i] ? i + 1 : 0u;
+}
+__global__ void __launch_bounds__(256) k_fe_build_keys(const FeRec *__restrict__ recs, uint32_t n, const uint32_t *__restrict__ is_key,
+                                                       const uint32_t *__restrict__ is_dec, const uint32_t *__restrict__ key_idx,
+                                                       const uint32_t *__restrict__ dec_idx, const uint32_t *__restrict__ kept32,
+                                                       const uint32_t *__restrict__ rec_idx, const uint32_t *__restrict__ slot_of,
+                                                       const uint32_t *__restrict__ pile, int base_locus, FeKey *__restrict__ keys,
+                                                       uint32_t *__restrict__ dslot, FeCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (i == n - 1) { ctl->n_keys = key_idx[i] + is_key[i]; ctl->n_slots = dec_idx[i] + is_dec[i]; ctl->n_rec = rec_idx[i] + kept32[i]; }
+    if (!is_key[i]) return;
+    const FeRec f = recs[i];
+    FeKey K;
+    K.pos = f.pos - (base_locus + 1);
+    K.n_pile = pile[slot_of[i]];
+    K.slot = is_dec[i] ? dec_idx[i] : FE_NO_SLOT;
+    K.cigar_off = f.cigar_off; K.seq_off = f.seq_off; K.zs_off = f.zs_off; K.md_off = f.md_off;
+    K.seq_len = f.seq_len; K.cigar_len = f.cigar_len; K.zs_len = f.zs_len; K.md_len = f.md_len;
+    K.flags = (uint16_t)(((f.bits & FE_R_HAS_ZS) ? FE_K_HAS_ZS : 0) | ((f.bits & FE_R_HAS_MD) ? FE_K_HAS_MD : 0) |
+                         ((f.bits & FE_R_BIN) ? (FE_K_BIN_CIGAR | FE_K_PACKED_SEQ) : 0));
+    keys[key_idx[i]] = K;
+    dslot[slot_of[i]] = K.slot;
+}
+__global__ void __launch_bounds__(256) k_fe_build_recinfo(const FeRec *__restrict__ recs, uint32_t n, const char *__restrict__ text,
+                                                          const uint8_t *__restrict__ kept, const uint32_t *__restrict__ rec_idx,
+                                                          const uint32_t *__restrict__ prev_kept, const uint32_t *__restrict__ slot_of,
+                                                          const uint32_t *__restrict__ dslot, uint32_t *__restrict__ rec_info) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !kept[i]) return;
+    const uint32_t pv = prev_kept[i];                     // index + 1 of the previous record that passed the filters, 0 = none
+    const bool hd = pv == 0 || !fe_same_read_id(recs[pv - 1], recs[i], text);
+    rec_info[rec_idx[i]] = dslot[slot_of[i]] | ((recs[i].flag & 0x40) ? 1u << 30 : 0u) | (hd ? 1u << 31 : 0u);
+}
+
+struct MaxU32 { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
+
+thread_local int g_last_device = 0, g_last_decline = 0, g_last_route = 0;
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // ---- the device stages of one call ------------------------------------------------------------------------------------------------
-int front_run(hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, int *declined) {
-    *out = nullptr;
-    *declined = 0;
-    const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
-    double t_prev = now_ms();
-    auto lap = [&](const char *what) {
+struct DevInput {                     // keys, their text and the kept records, resident in HBM; ctl zeroed (or carrying a decline code)
+    const FeKey *keys; uint32_t n_keys;
+    const char *text;
+    const uint32_t *rec_info; uint32_t n_rec;
+    uint32_t n_slots;
+    FeCtl *ctl;
+};
+struct Lap {
+    bool prof; hipStream_t st; double t_prev;
+    explicit Lap(hipStream_t s) : prof(getenv("HGX_PARSE_PROFILE") != nullptr), st(s), t_prev(now_ms()) {}
+    void operator()(const char *what) {
         if (!prof) return;
         (void)hipStreamSynchronize(st);
         const double t = now_ms();
         fprintf(stderr, "[hgx_front]     %-28s %8.2f ms\n", what, t - t_prev);
         t_prev = t;
-    };
-    const FeLocus *Fp = nullptr;
-    bool usable = false;
-    int rc = dev_locus(L, st, &Fp, &usable);
-    if (rc) return rc;
-    if (!usable) { *declined = HGX_FE_DECLINE_LOCUS; return HGX_OK; }
-    const FeLocus F = *Fp;
-    const int n_ref = F.n_ref;
-    const uint32_t n_keys = (uint32_t)in.n_keys, n_rec = (uint32_t)in.n_rec, S = (uint32_t)in.n_slots;
-    if (in.n_keys >= (1ull << 31) || in.n_rec >= (1ull << 31)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+    }
+};
 
+int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, int *declined) {
+    *out = nullptr;
+    *declined = 0;
+    Lap lap(st);
+    int rc = HGX_OK;
+    const int n_ref = F.n_ref;
+    const uint32_t n_keys = di.n_keys, n_rec = di.n_rec, S = di.n_slots;
     // every buffer of the call is declared here, the guard after them: on ANY way out the stream is drained first, then the
     // buffers go back to the pool
-    DevBuf b_keys, b_text, b_rec, b_ctl, b_state, b_koff, b_knht, b_ht, b_clo, b_cnw, b_ckey, b_cmoff, b_mpool;
+    DevBuf b_state, b_koff, b_knht, b_ht, b_clo, b_cnw, b_ckey, b_cmoff, b_mpool;
     DevBuf b_cnt, b_off, b_tmp, b_tmp2, b_key_s, b_idx, b_idx_s, b_flag, b_rank, b_head_of, b_head_cand;
     DevBuf b_wh, b_wh_s, b_hidx, b_hidx_s, b_lonw, b_lonw_s, b_ord, b_nw2, b_moff, b_new_id, b_cand_piece;
     hgx_dbatch *d = new hgx_dbatch();
     struct Guard { hgx_dbatch *&d; hipStream_t st; ~Guard() { (void)hipStreamSynchronize(st); if (d) hgx_dbatch_destroy(d); } } guard{d, st};
-    ALLOC(b_keys, std::max<size_t>(in.n_keys, 1) * sizeof(FeKey));
-    ALLOC(b_text, in.n_text + 64);
-    ALLOC(b_rec, std::max<size_t>(in.n_rec, 1) * 4);
-    ALLOC(b_ctl, sizeof(FeCtl));
-    if (in.n_keys) HIPCHK(hipMemcpyAsync(b_keys.p, in.keys, in.n_keys * sizeof(FeKey), hipMemcpyHostToDevice, st));
-    if (in.n_text) HIPCHK(hipMemcpyAsync(b_text.p, in.text, in.n_text, hipMemcpyHostToDevice, st));
-    if (in.n_rec) HIPCHK(hipMemcpyAsync(b_rec.p, in.rec_info, in.n_rec * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(b_ctl.p, 0, sizeof(FeCtl), st));
-    FeCtl *ctl = b_ctl.as<FeCtl>();
-    const FeKey *keys = b_keys.as<FeKey>();
-    const char *text = b_text.as<char>();
-    const uint32_t *rec_info = b_rec.as<uint32_t>();
-    lap("upload");
+    FeCtl *ctl = di.ctl;
+    const FeKey *keys = di.keys;
+    const char *text = di.text;
+    const uint32_t *rec_info = di.rec_info;
+    (void)rc;
 
     // pileup
     d->n_ref = n_ref;
@@ -567,27 +655,184 @@ int front_run(hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, 
     return HGX_OK;
 }
 
+// the key route: the host stages made the key table; upload it, then the stages above
+int front_run(hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, int *declined) {
+    *out = nullptr;
+    *declined = 0;
+    Lap lap(st);
+    const FeLocus *Fp = nullptr;
+    bool usable = false;
+    int rc = dev_locus(L, st, &Fp, &usable);
+    if (rc) return rc;
+    if (!usable) { *declined = HGX_FE_DECLINE_LOCUS; return HGX_OK; }
+    if (in.n_keys >= (1ull << 31) || in.n_rec >= (1ull << 31)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+    DevBuf b_keys, b_text, b_rec, b_ctl;
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
+    ALLOC(b_keys, std::max<size_t>(in.n_keys, 1) * sizeof(FeKey));
+    ALLOC(b_text, in.n_text + 64);
+    ALLOC(b_rec, std::max<size_t>(in.n_rec, 1) * 4);
+    ALLOC(b_ctl, sizeof(FeCtl));
+    if (in.n_keys) HIPCHK(hipMemcpyAsync(b_keys.p, in.keys, in.n_keys * sizeof(FeKey), hipMemcpyHostToDevice, st));
+    if (in.n_text) HIPCHK(hipMemcpyAsync(b_text.p, in.text, in.n_text, hipMemcpyHostToDevice, st));
+    if (in.n_rec) HIPCHK(hipMemcpyAsync(b_rec.p, in.rec_info, in.n_rec * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(b_ctl.p, 0, sizeof(FeCtl), st));
+    lap("upload");
+    const DevInput di{b_keys.as<FeKey>(), (uint32_t)in.n_keys, b_text.as<char>(), b_rec.as<uint32_t>(), (uint32_t)in.n_rec, (uint32_t)in.n_slots,
+                      b_ctl.as<FeCtl>()};
+    return front_stages(*Fp, di, o, st, out, declined);
+}
+
+// The record route: the text (SAM) or the inflated stream (BAM) is already on its way to `d_text`; the line table follows, and
+// fields, filters and key grouping run as kernels before the stages above.
+int records_run(hgx_locus &L, const char *d_text, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n_lines, bool binary,
+                const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, int *declined) {
+    *out = nullptr;
+    *declined = 0;
+    Lap lap(st);
+    const FeLocus *Fp = nullptr;
+    bool usable = false;
+    int rc = dev_locus(L, st, &Fp, &usable);
+    if (rc) return rc;
+    if (!usable) { *declined = HGX_FE_DECLINE_LOCUS; return HGX_OK; }
+    if (raw_bytes >= (1ull << 32) - 64 || n_lines >= (1ull << 30)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+    const uint32_t n = (uint32_t)n_lines;
+    uint32_t cap = 1024;
+    while (cap < 2 * (uint64_t)n) cap <<= 1;
+    DevBuf b_lines, b_recs, b_head, b_kept, b_slot_of, b_tkeys, b_rep, b_pile, b_anyk, b_dslot, b_is_key, b_is_dec, b_kept32, b_prev_in;
+    DevBuf b_key_idx, b_dec_idx, b_rec_idx, b_prev, b_tmp, b_keys, b_rec, b_ctl;
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
+    // the line table as (offset, length): made in pinned staging by the host's workers, 8 bytes per record
+    LineRef *h_lines = (LineRef *)pinned_alloc(std::max<size_t>(n_lines, 1) * sizeof(LineRef));
+    if (!h_lines) { hgx_set_error("pinned allocation of the line table failed"); return HGX_ENOMEM; }
+    struct Unpin { void *p; ~Unpin() { pinned_release(p); } } unpin{h_lines};
+    const size_t skip = binary ? 32 : 0;
+    hgx_par_ranges(n_lines > 50000 ? hgx_default_threads() : 1, n_lines, [&](int, size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) { h_lines[i].off = (uint32_t)((size_t)(lines[i].p - raw) - skip); h_lines[i].len = lines[i].len; }
+    });
+    ALLOC(b_lines, std::max<size_t>(n_lines, 1) * sizeof(LineRef));
+    ALLOC(b_recs, std::max<size_t>(n_lines, 1) * sizeof(FeRec));
+    ALLOC(b_head, std::max<size_t>(n_lines, 16));
+    ALLOC(b_kept, std::max<size_t>(n_lines, 16));
+    ALLOC(b_slot_of, std::max<size_t>(n_lines, 4) * 4);
+    ALLOC(b_tkeys, (size_t)cap * 8);
+    ALLOC(b_rep, (size_t)cap * 4);
+    ALLOC(b_pile, (size_t)cap * 4);
+    ALLOC(b_anyk, (size_t)cap * 4);
+    ALLOC(b_dslot, (size_t)cap * 4);
+    ALLOC(b_is_key, std::max<size_t>(n_lines, 4) * 4);
+    ALLOC(b_is_dec, std::max<size_t>(n_lines, 4) * 4);
+    ALLOC(b_kept32, std::max<size_t>(n_lines, 4) * 4);
+    ALLOC(b_prev_in, std::max<size_t>(n_lines, 4) * 4);
+    ALLOC(b_key_idx, std::max<size_t>(n_lines, 4) * 4);
+    ALLOC(b_dec_idx, std::max<size_t>(n_lines, 4) * 4);
+    ALLOC(b_rec_idx, std::max<size_t>(n_lines, 4) * 4);
+    ALLOC(b_prev, std::max<size_t>(n_lines, 4) * 4);
+    ALLOC(b_ctl, sizeof(FeCtl));
+    HIPCHK(hipMemsetAsync(b_ctl.p, 0, sizeof(FeCtl), st));
+    HIPCHK(hipMemsetAsync(b_tkeys.p, 0xFF, (size_t)cap * 8, st));
+    HIPCHK(hipMemsetAsync(b_rep.p, 0xFF, (size_t)cap * 4, st));
+    HIPCHK(hipMemsetAsync(b_pile.p, 0, (size_t)cap * 4, st));
+    HIPCHK(hipMemsetAsync(b_anyk.p, 0, (size_t)cap * 4, st));
+    if (n) HIPCHK(hipMemcpyAsync(b_lines.p, h_lines, (size_t)n * sizeof(LineRef), hipMemcpyHostToDevice, st));
+    lap("text + line table on the device");
+    FeCtl *ctl = b_ctl.as<FeCtl>();
+    FeCtl h;
+    memset(&h, 0, sizeof(h));
+    if (n) {
+        const FeFilter flt{o.num_editdist, o.allow_discordant, o.base_locus};
+        FeRec *recs = b_recs.as<FeRec>();
+        k_fe_records<<<nblk(n, 256), 256, 0, st>>>(d_text, b_lines.as<LineRef>(), n, binary ? 1 : 0, o.simulation, recs, ctl);
+        k_fe_rec_heads<<<nblk(n, 256), 256, 0, st>>>(recs, n, d_text, b_head.as<uint8_t>());
+        k_fe_rec_filter_insert<<<nblk(n, 256), 256, 0, st>>>(recs, b_head.as<uint8_t>(), n, flt, b_tkeys.as<unsigned long long>(), b_rep.as<uint32_t>(),
+                                                            b_pile.as<uint32_t>(), b_anyk.as<uint32_t>(), cap - 1, b_kept.as<uint8_t>(),
+                                                            b_slot_of.as<uint32_t>(), ctl);
+        k_fe_group_flags<<<nblk(n, 256), 256, 0, st>>>(recs, n, d_text, b_rep.as<uint32_t>(), b_pile.as<uint32_t>(), b_anyk.as<uint32_t>(),
+                                                      b_slot_of.as<uint32_t>(), b_kept.as<uint8_t>(), b_is_key.as<uint32_t>(), b_is_dec.as<uint32_t>(),
+                                                      b_kept32.as<uint32_t>(), b_prev_in.as<uint32_t>(), ctl);
+        size_t tb = 0, tb2 = 0;
+        (void)hipcub::DeviceScan::ExclusiveSum((void *)nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, st);
+        (void)hipcub::DeviceScan::ExclusiveScan((void *)nullptr, tb2, (uint32_t *)nullptr, (uint32_t *)nullptr, MaxU32(), 0u, (int)n, st);
+        tb = std::max(tb, tb2);
+        ALLOC(b_tmp, std::max<size_t>(tb, 256));
+        size_t b = tb;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_is_key.as<uint32_t>(), b_key_idx.as<uint32_t>(), (int)n, st));
+        b = tb;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_is_dec.as<uint32_t>(), b_dec_idx.as<uint32_t>(), (int)n, st));
+        b = tb;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_kept32.as<uint32_t>(), b_rec_idx.as<uint32_t>(), (int)n, st));
+        b = tb;
+        HIPCHK(hipcub::DeviceScan::ExclusiveScan(b_tmp.p, b, b_prev_in.as<uint32_t>(), b_prev.as<uint32_t>(), MaxU32(), 0u, (int)n, st));
+        // (the key table is sized by the records: a key per record at most)
+        ALLOC(b_keys, (size_t)n * sizeof(FeKey));
+        ALLOC(b_rec, (size_t)n * 4);
+        k_fe_build_keys<<<nblk(n, 256), 256, 0, st>>>(recs, n, b_is_key.as<uint32_t>(), b_is_dec.as<uint32_t>(), b_key_idx.as<uint32_t>(),
+                                                     b_dec_idx.as<uint32_t>(), b_kept32.as<uint32_t>(), b_rec_idx.as<uint32_t>(), b_slot_of.as<uint32_t>(),
+                                                     b_pile.as<uint32_t>(), o.base_locus, b_keys.as<FeKey>(), b_dslot.as<uint32_t>(), ctl);
+        k_fe_build_recinfo<<<nblk(n, 256), 256, 0, st>>>(recs, n, d_text, b_kept.as<uint8_t>(), b_rec_idx.as<uint32_t>(), b_prev.as<uint32_t>(),
+                                                        b_slot_of.as<uint32_t>(), b_dslot.as<uint32_t>(), b_rec.as<uint32_t>());
+        HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    } else {
+        ALLOC(b_keys, sizeof(FeKey));
+        ALLOC(b_rec, 16);
+    }
+    lap("records: fields, filters, keys");
+    if (h.decline) { *declined = -h.decline; return HGX_OK; }
+    const DevInput di{b_keys.as<FeKey>(), h.n_keys, d_text, b_rec.as<uint32_t>(), h.n_rec, h.n_slots, ctl};
+    return front_stages(*Fp, di, o, st, out, declined);
+}
+
 // host stages with the device stages hooked in; *out is always a device batch on success
 template <class Parse>
-int parse_dev(hgx_dbatch **out, hipStream_t st, Parse parse) {
+int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Parse parse) {
     *out = nullptr;
     hgx_dbatch *made = nullptr;
     hgx_front_hook hook;
     hook.mem = hgx_front_alloc{pinned_alloc, pinned_release};
     const bool force = hgx_test_switch("front_device") != nullptr;
-    bool ran = false;
-    hook.run = [&](hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, int *declined) {
-        ran = true;
-        if (!force && in.n_rec < 20000) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }     // a dozen launches cost more than a small host decode
-        return front_run(L, in, o, st, &made, declined);
-    };
-    hgx_batch *b = nullptr;
     const bool host_only = hgx_test_switch("front_host") != nullptr;
+    const bool no_records = hgx_test_switch("front_keys_only") != nullptr;
+    int route = 0;                         // 2 = the record route produced the batch, 1 = the key route, 0 = the host stages
+    hook.run = [&](hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, int *declined) {
+        if (!force && in.n_rec < 20000) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }     // a dozen launches cost more than a small host decode
+        hgx_dbatch_destroy(made);
+        made = nullptr;
+        const int rc = front_run(L, in, o, st, &made, declined);
+        if (!rc && !*declined && made) route = 1;
+        return rc;
+    };
+    // record route: the reader's bytes go up as soon as they are complete (SAM text read / BAM stream inflated), while the host
+    // still walks and name-sorts the records
+    DevBuf b_text;
+    const char *up_raw = nullptr;
+    size_t up_bytes = 0;
+    bool up_failed = false;
+    if (!host_only && !no_records && !(opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange)) {
+        hook.on_raw = [&](const char *raw, size_t n_bytes) {
+            if (n_bytes >= (1ull << 32) - 64) return;
+            if (b_text.alloc(n_bytes + 64)) { up_failed = true; return; }
+            if (n_bytes && hipMemcpyAsync(b_text.p, raw, n_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { up_failed = true; return; }
+            up_raw = raw;
+            up_bytes = n_bytes;
+        };
+        hook.records = [&](hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &o,
+                           int *declined) {
+            if (!force && n < 20000) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }
+            if (up_failed || raw != up_raw || raw_bytes != up_bytes) { *declined = HGX_FE_DECLINE_SIZE; return (int)HGX_OK; }
+            const int rc = records_run(L, b_text.as<char>(), raw, raw_bytes, lines, n, binary, o, st, &made, declined);
+            if (!rc && !*declined && made) route = 2;
+            return rc;
+        };
+    }
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};     // (an upload may still read the reader's buffer)
+    hgx_batch *b = nullptr;
     const int rc = parse(&b, host_only ? nullptr : &hook);
-    g_last_decline = host_only ? -1 : hook.declined;
-    g_last_device = (!host_only && ran && !hook.declined && !rc && made) ? 1 : 0;
-    if (rc) { hgx_dbatch_destroy(made); return rc; }
-    if (g_last_device) { *out = made; return HGX_OK; }
+    (void)hipStreamSynchronize(st);
+    g_last_route = rc ? 0 : route;
+    g_last_decline = host_only ? -1 : (route == 2 ? 0 : route == 1 ? 0 : hook.declined ? hook.declined : hook.declined_records);
+    g_last_device = (!rc && route > 0 && made) ? 1 : 0;
+    if (rc) { hgx_dbatch_destroy(made); hgx_batch_destroy(b); return rc; }
+    if (g_last_device) { hgx_batch_destroy(b); *out = made; return HGX_OK; }
     hgx_dbatch_destroy(made);
     if (!b) { hgx_set_error("front end produced no batch"); return HGX_EINVAL; }
     const int rc2 = hgx_dbatch_create(out, b, st);
@@ -599,18 +844,18 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, Parse parse) {
 
 extern "C" int hgx_parse_sam_dev(hgx_dbatch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, void *stream) {
     ARGCHK(out && loc && opts);
-    return parse_dev(out, (hipStream_t)stream, [&](hgx_batch **b, hgx_front_hook *hook) { return hgx_parse_sam_hook(b, loc, sam, n_bytes, opts, hook); });
+    return parse_dev(out, (hipStream_t)stream, opts, [&](hgx_batch **b, hgx_front_hook *hook) { return hgx_parse_sam_hook(b, loc, sam, n_bytes, opts, hook); });
 }
 
 extern "C" int hgx_parse_alignment_file_dev(hgx_dbatch **out, const hgx_locus *loc, const char *path, const char *regions,
                                             const hgx_parse_opts *opts, void *stream) {
     ARGCHK(out && loc && path && opts);
-    return parse_dev(out, (hipStream_t)stream,
+    return parse_dev(out, (hipStream_t)stream, opts,
                      [&](hgx_batch **b, hgx_front_hook *hook) { return hgx_parse_alignment_file_hook(b, loc, path, regions, opts, hook); });
 }
 
 extern "C" int hgx_front_last(int32_t *device_stages_ran, int32_t *decline_code) {
-    if (device_stages_ran) *device_stages_ran = g_last_device;
+    if (device_stages_ran) *device_stages_ran = g_last_device ? g_last_route : 0;
     if (decline_code) *decline_code = g_last_decline;
     return HGX_OK;
 }

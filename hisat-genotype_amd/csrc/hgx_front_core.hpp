@@ -106,16 +106,74 @@ struct FePile {
     const uint32_t *counts;          // [n_ref][6] A C G T N D
 };
 
-// one distinct decode key as uploaded: text = cigar | seq | zs | md, back to back at text + off
+// one distinct decode key: where its fields lie in `text` (the gathered key text of the key route, the SAM text or the inflated
+// BAM stream of the record route)
+#define FE_K_HAS_ZS 1
+#define FE_K_HAS_MD 2
+#define FE_K_BIN_CIGAR 4             // cigar_off -> n ops of uint32 little endian (len << 4 | op), cigar_len = n
+#define FE_K_PACKED_SEQ 8            // seq_off -> 4-bit bases, two per byte ("=ACMGRSVTWYHKDBN")
 struct FeKey {
     int32_t pos;                     // POS - (base_locus + 1)
     uint32_t n_pile;                 // records of the key that count into the pileup
     uint32_t slot;                   // decode slot or FE_NO_SLOT (pileup only)
-    uint32_t off;
+    uint32_t cigar_off, seq_off, zs_off, md_off;
     uint32_t seq_len;
     uint16_t cigar_len, zs_len, md_len;
-    uint16_t flags;                  // 1 = has Zs, 2 = has MD
+    uint16_t flags;
 };
+
+// read bases of a record, text or BAM-packed
+struct FeSeq {
+    const unsigned char *p;
+    int len;
+    bool packed;
+    FE_HD char at(int i) const {
+        if (!packed) return (char)p[i];
+        const int nib = (i & 1) ? (p[i >> 1] & 15) : (p[i >> 1] >> 4);
+        return "=ACMGRSVTWYHKDBN"[nib];
+    }
+};
+FE_HD inline FeSeq fe_seq_of(const FeKey &K, const char *text) {
+    FeSeq q;
+    q.p = (const unsigned char *)text + K.seq_off;
+    q.len = (int)K.seq_len;
+    q.packed = (K.flags & FE_K_PACKED_SEQ) != 0;
+    return q;
+}
+// CIGAR ops one by one, from text ("76M2D74M") or BAM words.  next(): 1 = an op, 0 = end, -1 = what strtol would not read as
+// plain digits followed by an op character
+struct FeCigar {
+    const unsigned char *p;
+    int n, at;
+    bool bin;
+    FE_HD int next(char &op, int &len) {
+        if (bin) {
+            if (at >= n) return 0;
+            const unsigned char *w = p + 4 * at;
+            const uint32_t v = (uint32_t)w[0] | ((uint32_t)w[1] << 8) | ((uint32_t)w[2] << 16) | ((uint32_t)w[3] << 24);
+            ++at;
+            op = (v & 15) < 9 ? "MIDNSHP=X"[v & 15] : '?';
+            len = (int)(v >> 4);
+            return 1;
+        }
+        if (at >= n) return 0;
+        long v = 0;
+        int nd = 0;
+        while (at < n && p[at] >= '0' && p[at] <= '9') { if (v > 100000000) return -1; v = v * 10 + (p[at++] - '0'); nd++; }
+        if (nd == 0 || at >= n) return -1;
+        op = (char)p[at++];
+        len = (int)v;
+        return 1;
+    }
+};
+FE_HD inline FeCigar fe_cigar_of(const FeKey &K, const char *text) {
+    FeCigar c;
+    c.p = (const unsigned char *)text + K.cigar_off;
+    c.n = K.cigar_len;
+    c.at = 0;
+    c.bin = (K.flags & FE_K_BIN_CIGAR) != 0;
+    return c;
+}
 
 struct FeCmp {
     int32_t type;                    // FE_T_* | read base << 8 (mismatch entries: the base the read shows AFTER error correction)
@@ -154,9 +212,10 @@ FE_HD inline int fe_lookup(const FeLocus &L, int pos, int type, int key) {
 }
 
 // ---- error_correct (typing_core.py:119-243) over cl[start, n): returns the number of corrections, < 0 = decline ------------
-FE_HD inline int fe_error_correct(const FeLocus &L, const FePile &P, const char *seq, int seq_len, int read_pos, FeCmp *cl, int start,
+FE_HD inline int fe_error_correct(const FeLocus &L, const FePile &P, const FeSeq &seq, int read_pos, FeCmp *cl, int start,
                                   int &n_cl, FeCmp *out) {
     const int n_ref = L.n_ref;
+    const int seq_len = seq.len;
     int ncorr = 0, n_out = 0;
     bool stopped = false;
     for (int i = start; i < n_cl; ++i) {
@@ -172,7 +231,7 @@ FE_HD inline int fe_error_correct(const FeLocus &L, const FePile &P, const char 
             int last = 0;
             for (int j = 0; j < c.len; ++j) {
                 if (read_pos + j >= seq_len || c.pos + j >= n_ref) continue;
-                char b = seq[read_pos + j];
+                char b = seq.at(read_pos + j);
                 const int s = P.nt_set[c.pos + j];
                 if (s != 0 && !(s & fe_nt_bit(b))) {
                     b = (s & (s - 1)) ? 'N' : fe_single_nt(s);
@@ -197,7 +256,7 @@ FE_HD inline int fe_error_correct(const FeLocus &L, const FePile &P, const char 
             }
         } else {
             if (read_pos >= seq_len) return FE_FAIL(FE_E_SHORT);
-            char b = seq[read_pos];
+            char b = seq.at(read_pos);
             const int s = P.nt_set[c.pos];
             if (s != 0 && !(s & fe_nt_bit(b))) {
                 b = (s & (s - 1)) ? 'N' : fe_single_nt(s);
@@ -222,8 +281,9 @@ FE_HD inline int fe_error_correct(const FeLocus &L, const FePile &P, const char 
 }
 
 // ---- one record -> cmp_list with novel ids (typing_core.py:876-1164).  1 = kept, 0 = dropped, < 0 = decline --------------
-FE_HD inline int fe_decode(const FeLocus &L, const FeParse &o, const FePile &P, int pos, const char *cigar, int cigar_len, const char *seq,
-                           int seq_len, const char *zs, int zs_len, const char *md, int md_n, FeCmp *cl, int &n_cl, FeCmp *tmp) {
+FE_HD inline int fe_decode(const FeLocus &L, const FeParse &o, const FePile &P, int pos, FeCigar cigar, const FeSeq &seq,
+                           const char *zs, int zs_len, const char *md, int md_n, FeCmp *cl, int &n_cl, FeCmp *tmp) {
+    const int seq_len = seq.len;
     int zs_gap[FE_MAX_ZS], zs_id[FE_MAX_ZS];
     char zs_type[FE_MAX_ZS];
     int n_zs = 0;
@@ -260,17 +320,15 @@ FE_HD inline int fe_decode(const FeLocus &L, const FeParse &o, const FePile &P, 
     char op_c[FE_MAX_OPS];
     int op_n[FE_MAX_OPS];
     int n_ops = 0;
-    {
-        int p = 0;
-        while (p < cigar_len) {
-            long n = 0;
-            int nd = 0;
-            while (p < cigar_len && cigar[p] >= '0' && cigar[p] <= '9') { if (n > 100000000) return FE_FAIL(FE_E_CIGAR); n = n * 10 + (cigar[p++] - '0'); nd++; }
-            if (nd == 0 || p >= cigar_len) return FE_FAIL(FE_E_CIGAR);
-            if (n_ops >= FE_MAX_OPS) return FE_FAIL(FE_E_CAP);
-            op_c[n_ops] = cigar[p++];
-            op_n[n_ops++] = (int)n;
-        }
+    for (;;) {
+        char op;
+        int n;
+        const int r = cigar.next(op, n);
+        if (r == 0) break;
+        if (r < 0) return FE_FAIL(FE_E_CIGAR);
+        if (n_ops >= FE_MAX_OPS) return FE_FAIL(FE_E_CAP);
+        op_c[n_ops] = op;
+        op_n[n_ops++] = n;
     }
     int md_i = 0, md_len = 0;
     int zs_i = 0;
@@ -314,7 +372,7 @@ FE_HD inline int fe_decode(const FeLocus &L, const FeParse &o, const FePile &P, 
                 }
                 first = false;
                 if (rp + md_len >= seq_len) return FE_FAIL(FE_E_SHORT);
-                const char base = seq[rp + md_len];
+                const char base = seq.at(rp + md_len);
                 if (md_i >= md_n || !fe_is_acgt(md[md_i])) return FE_FAIL(FE_E_MD);
                 md_i++;
                 if (md_len > used) FE_PUSH(FE_T_MATCH, gp + used, md_len - used, -2);
@@ -330,7 +388,7 @@ FE_HD inline int fe_decode(const FeLocus &L, const FeParse &o, const FePile &P, 
                 if (md_len == n) { md_len = 0; break; }
             }
             if (o.error_correction) {
-                const int r = fe_error_correct(L, P, seq, seq_len, rp, cl, start, n_cl, tmp);
+                const int r = fe_error_correct(L, P, seq, rp, cl, start, n_cl, tmp);
                 if (r < 0) return r;
                 n_ec += r;
             }
@@ -343,7 +401,7 @@ FE_HD inline int fe_decode(const FeLocus &L, const FeParse &o, const FePile &P, 
             } else id = fe_lookup(L, gp, FE_VAR_INSERTION, n);
             FE_PUSH(FE_T_INSERTION, gp, n, id);
             for (int k = rp; k < rp + n && k < seq_len; ++k)
-                if (seq[k] == 'N') bad = true;
+                if (seq.at(k) == 'N') bad = true;
         } else if (op == 'D') {
             if (md_i < md_n && md[md_i] == '0') md_i++;
             if (md_i >= md_n || md[md_i] != '^') return FE_FAIL(FE_E_MD);
@@ -825,12 +883,11 @@ FE_HD inline int fe_key(const FeLocus &L, const FeParse &o, const FePile &P, con
                         uint8_t &state, uint32_t &ht_off, uint32_t &n_ht_out) {
     FeCmp cl[FE_MAX_CMP], tmp[FE_MAX_CMP];
     int n_cl = 0;
-    const char *cigar = text + K.off, *seq = cigar + K.cigar_len, *zs = seq + K.seq_len, *md = zs + K.zs_len;
     state = 2;
     ht_off = 0;
     n_ht_out = 0;
-    int rc = fe_decode(L, o, P, K.pos, cigar, K.cigar_len, seq, (int)K.seq_len, zs, (K.flags & 1) ? K.zs_len : 0, md,
-                       (K.flags & 2) ? K.md_len : 0, cl, n_cl, tmp);
+    int rc = fe_decode(L, o, P, K.pos, fe_cigar_of(K, text), fe_seq_of(K, text), text + K.zs_off, (K.flags & FE_K_HAS_ZS) ? K.zs_len : 0,
+                       text + K.md_off, (K.flags & FE_K_HAS_MD) ? K.md_len : 0, cl, n_cl, tmp);
     if (rc <= 0) return rc;
     fe_cmp_list2(L, cl, n_cl);
     if (n_cl <= 0) return FE_FAIL(FE_E_ASSERT);
@@ -959,22 +1016,31 @@ FE_HD inline int fe_pair_union(const uint32_t *rec_info, uint32_t i, uint32_t n_
 // the lanes of a wavefront (0 / 1 = one walker does them all).  Returns 0, or < 0 = decline.
 template <class Add>
 FE_HD inline int fe_pileup_key(const FeKey &K, const char *text, int n_ref, int lane, int n_lanes, Add add) {
-    const char *cigar = text + K.off, *seq = cigar + K.cigar_len;
+    const FeSeq seq = fe_seq_of(K, text);
+    FeCigar cg = fe_cigar_of(K, text);
     const uint32_t w = K.n_pile;
-    int rp = 0, gp = K.pos, p = 0;
-    while (p < K.cigar_len) {
-        long len = 0;
-        int nd = 0;
-        const char c0 = cigar[p];
-        if (c0 == '+' || c0 == '-' || c0 == ' ' || (c0 >= 9 && c0 <= 13)) return FE_FAIL(FE_E_CIGAR);      // forms strtol reads: the host's business
-        while (p < K.cigar_len && cigar[p] >= '0' && cigar[p] <= '9') { if (len > 100000000) return FE_FAIL(FE_E_CIGAR); len = len * 10 + (cigar[p++] - '0'); nd++; }
-        if (nd == 0 || p >= K.cigar_len) break;
-        const char op = cigar[p++];
+    int rp = 0, gp = K.pos;
+    if (!cg.bin && cg.n > 0) {
+        const char c0 = (char)cg.p[0];
+        if (c0 == '+' || c0 == '-' || c0 == ' ' || (c0 >= 9 && c0 <= 13)) return FE_FAIL(FE_E_CIGAR);   // forms strtol reads: the host's business
+    }
+    for (;;) {
+        char op;
+        int ilen;
+        const int r = cg.next(op, ilen);
+        if (r <= 0) {
+            if (r < 0 && cg.at < cg.n) {
+                const char c0 = (char)cg.p[cg.at];
+                if (c0 == '+' || c0 == '-' || c0 == ' ' || (c0 >= 9 && c0 <= 13)) return FE_FAIL(FE_E_CIGAR);
+            }
+            break;                                                   // (the host stops at what it cannot read, silently)
+        }
+        const long len = ilen;
         if (op == 'M') {
             long lim = len < (long)n_ref - gp ? len : (long)n_ref - gp;
             if (lim > 0 && (uint64_t)(rp + lim) > (uint64_t)K.seq_len) return FE_FAIL(FE_E_SHORT);
             for (long j = lane; j < lim; j += n_lanes) {
-                const char b = seq[rp + j];
+                const char b = seq.at((int)(rp + j));
                 const int s = b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : 4;
                 add((uint32_t)((gp + j) * 6 + s), w);
             }
@@ -995,4 +1061,279 @@ FE_HD inline uint8_t fe_nt_set(const uint32_t *c) {
         for (int k = 0; k < 4; ++k)
             if ((double)c[k] >= (double)tot * 0.2 || c[k] >= 7) m |= 1 << k;
     return (uint8_t)m;
+}
+
+// =====================================================================================================================================
+// The RECORD stage on the device (row 8a-1): one lane per record of the name-ordered stream -- fields (typing_core.py:800-841),
+// record filters (typing_core.py:815-872) and the grouping of the records by decode key -- so that the host only reads (and, for
+// BAM, inflates and name-sorts) the file.  Restates split_line / note_tag / split_bam / filter_records / group_records of
+// hgx_sam.cpp; every input they treat specially (blanks or CRs inside a line, tags whose value int() rejects, fewer than eleven
+// fields, float / text typed NM tags, a CG tag, ...) declines.
+// =====================================================================================================================================
+#define FE_R_HAS_NM 1
+#define FE_R_HAS_NH 2
+#define FE_R_HAS_ZS 4
+#define FE_R_HAS_MD 8
+#define FE_R_BIN 16                  // BAM record: binary CIGAR, packed SEQ
+struct FeRec {
+    uint32_t qname_off;
+    uint16_t id_len;                 // read id = QNAME, or QNAME up to the first '|' in simulation mode (typing_core.py:808-809)
+    uint16_t bits;
+    int32_t flag, pos;               // FLAG, POS (1-based, as in the file)
+    int32_t nm, nh;                  // saturated to int32
+    uint32_t cigar_off, seq_off, zs_off, md_off, seq_len;
+    uint16_t cigar_len, zs_len, md_len, pad_;
+    uint64_t key;                    // hash of the decode key (pos, cigar, seq, Zs, MD)
+};
+
+FE_HD inline bool fe_py_int_ok(const unsigned char *t, int n) {      // would Python's int(text) take it?  (hgx_sam.cpp py_int_ok)
+    int i = 0;
+    if (i < n && (t[i] == '+' || t[i] == '-')) ++i;
+    if (i >= n || t[i] < '0' || t[i] > '9') return false;
+    for (; i < n; ++i) {
+        if (t[i] >= '0' && t[i] <= '9') continue;
+        if (t[i] == '_' && i + 1 < n && t[i + 1] >= '0' && t[i + 1] <= '9' && t[i - 1] != '_') continue;
+        return false;
+    }
+    return true;
+}
+// strtol(text, 0, 10) of a token that fe_py_int_ok accepted (sign, digits; stops at an underscore), saturated to int32
+FE_HD inline int32_t fe_strtol32(const unsigned char *t, int n) {
+    int i = 0;
+    bool neg = false;
+    if (i < n && (t[i] == '+' || t[i] == '-')) { neg = t[i] == '-'; ++i; }
+    long long v = 0;
+    for (; i < n && t[i] >= '0' && t[i] <= '9'; ++i) { v = v * 10 + (t[i] - '0'); if (v > 0x7fffffffll) v = 0x7fffffffll; }
+    return (int32_t)(neg ? -v : v);
+}
+FE_HD inline uint64_t fe_hash_bytes(const unsigned char *p, int n, uint64_t h) {
+    int i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w = 0;
+        for (int k = 0; k < 8; ++k) w |= (uint64_t)p[i + k] << (8 * k);
+        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 32;
+    }
+    uint64_t w = 0;
+    for (int k = 0; i + k < n; ++k) w |= (uint64_t)p[i + k] << (8 * k);
+    h = (h ^ w ^ ((uint64_t)n << 56)) * 0xD6E8FEB86659FD93ull;
+    return h ^ (h >> 29);
+}
+// hash of a record's decode key; for a packed SEQ the unused low nibble of an odd length's last byte is left out
+FE_HD inline uint64_t fe_rec_key(const FeRec &r, const char *text) {
+    const unsigned char *t = (const unsigned char *)text;
+    uint64_t h = fe_mix64(0x243F6A8885A308D3ull ^ (uint32_t)r.pos ^ ((uint64_t)r.seq_len << 32));
+    if (r.bits & FE_R_BIN) {
+        h = fe_hash_bytes(t + r.cigar_off, 4 * (int)r.cigar_len, h);
+        const int full = (int)(r.seq_len / 2);
+        h = fe_hash_bytes(t + r.seq_off, full, h);
+        if (r.seq_len & 1) h = fe_mix64(h ^ (uint64_t)(t[r.seq_off + full] >> 4));
+    } else {
+        h = fe_hash_bytes(t + r.cigar_off, r.cigar_len, h);
+        h = fe_hash_bytes(t + r.seq_off, (int)r.seq_len, h);
+    }
+    h = fe_hash_bytes(t + r.zs_off, r.zs_len, h ^ ((r.bits & FE_R_HAS_ZS) ? 1 : 0));
+    h = fe_hash_bytes(t + r.md_off, r.md_len, h ^ ((r.bits & FE_R_HAS_MD) ? 2 : 0));
+    h = fe_mix64(h);
+    return h == ~0ull ? 0 : h;                                      // (all ones = the hash table's empty slot)
+}
+FE_HD inline bool fe_bytes_equal(const unsigned char *a, const unsigned char *b, int n) {
+    for (int i = 0; i < n; ++i) if (a[i] != b[i]) return false;
+    return true;
+}
+FE_HD inline bool fe_rec_same_key(const FeRec &a, const FeRec &b, const char *text) {      // same_decode_key of hgx_sam.cpp
+    const unsigned char *t = (const unsigned char *)text;
+    if (a.pos != b.pos || a.seq_len != b.seq_len || a.cigar_len != b.cigar_len || a.zs_len != b.zs_len || a.md_len != b.md_len) return false;
+    if (((a.bits ^ b.bits) & (FE_R_HAS_ZS | FE_R_HAS_MD | FE_R_BIN)) != 0) return false;
+    if (a.bits & FE_R_BIN) {
+        if (!fe_bytes_equal(t + a.cigar_off, t + b.cigar_off, 4 * (int)a.cigar_len)) return false;
+        const int full = (int)(a.seq_len / 2);
+        if (!fe_bytes_equal(t + a.seq_off, t + b.seq_off, full)) return false;
+        if ((a.seq_len & 1) && (t[a.seq_off + full] >> 4) != (t[b.seq_off + full] >> 4)) return false;
+    } else {
+        if (!fe_bytes_equal(t + a.cigar_off, t + b.cigar_off, a.cigar_len)) return false;
+        if (!fe_bytes_equal(t + a.seq_off, t + b.seq_off, (int)a.seq_len)) return false;
+    }
+    return fe_bytes_equal(t + a.zs_off, t + b.zs_off, a.zs_len) && fe_bytes_equal(t + a.md_off, t + b.md_off, a.md_len);
+}
+
+// one line of SAM text (without its line end) -> FeRec.  The tab-only split of split_line; anything else declines.
+FE_HD inline int fe_parse_text_record(const char *text, uint32_t off, uint32_t len, bool simulation, FeRec &r) {
+    const unsigned char *line = (const unsigned char *)text + off;
+    r.bits = 0;
+    r.nm = r.nh = 0;
+    r.zs_off = r.md_off = off;
+    r.zs_len = r.md_len = 0;
+    r.pad_ = 0;
+    uint32_t col_at[11], col_len[11];
+    int nc = 0;
+    uint32_t p = 0;
+    while (p < len) {
+        uint32_t q = p;
+        while (q < len && line[q] != '\t') {
+            if (line[q] == ' ' || line[q] == '\r') return FE_FAIL(FE_E_ASSERT);       // the reference's split() cuts there too: host
+            ++q;
+        }
+        if (q > p) {
+            const uint32_t tl = q - p;
+            if (nc < 11) { col_at[nc] = p; col_len[nc] = tl; nc++; }
+            else {                                                                  // note_tag
+                const unsigned char *tok = line + p;
+                if (tl < 5) {
+                    if (tl >= 2 && tok[0] == 'Z' && tok[1] == 's') { r.bits |= FE_R_HAS_ZS; r.zs_off = off + q; r.zs_len = 0; }
+                    else if (tl >= 2 && tok[0] == 'M' && tok[1] == 'D') { r.bits |= FE_R_HAS_MD; r.md_off = off + q; r.md_len = 0; }
+                    else if (tl >= 2 && tok[0] == 'N' && (tok[1] == 'M' || tok[1] == 'H')) return FE_FAIL(FE_E_ASSERT);   // int('') raises
+                } else if (tok[0] == 'Z' && tok[1] == 's') {
+                    if (tl - 5 > 65535) return FE_FAIL(FE_E_CAP);
+                    r.bits |= FE_R_HAS_ZS; r.zs_off = off + p + 5; r.zs_len = (uint16_t)(tl - 5);
+                } else if (tok[0] == 'M' && tok[1] == 'D') {
+                    if (tl - 5 > 65535) return FE_FAIL(FE_E_CAP);
+                    r.bits |= FE_R_HAS_MD; r.md_off = off + p + 5; r.md_len = (uint16_t)(tl - 5);
+                } else if (tok[0] == 'N' && (tok[1] == 'M' || tok[1] == 'H')) {
+                    if (!fe_py_int_ok(tok + 5, (int)tl - 5)) return FE_FAIL(FE_E_ASSERT);
+                    const int32_t v = fe_strtol32(tok + 5, (int)tl - 5);
+                    if (tok[1] == 'M') { r.bits |= FE_R_HAS_NM; r.nm = v; }
+                    else { r.bits |= FE_R_HAS_NH; r.nh = v; }
+                }
+            }
+        }
+        p = q + 1;
+    }
+    if (nc < 11) return FE_FAIL(FE_E_ASSERT);
+    if (!fe_py_int_ok(line + col_at[1], (int)col_len[1]) || !fe_py_int_ok(line + col_at[3], (int)col_len[3])) return FE_FAIL(FE_E_ASSERT);
+    if (col_len[1] > 9 || col_len[3] > 10 || col_len[5] > 65535 || col_len[0] > 65535 || col_len[9] > (1u << 24)) return FE_FAIL(FE_E_CAP);
+    r.qname_off = off + col_at[0];
+    uint32_t idl = col_len[0];
+    if (simulation)
+        for (uint32_t k = 0; k < col_len[0]; ++k) if (line[col_at[0] + k] == '|') { idl = k; break; }
+    r.id_len = (uint16_t)idl;
+    r.flag = fe_strtol32(line + col_at[1], (int)col_len[1]);
+    r.pos = fe_strtol32(line + col_at[3], (int)col_len[3]);
+    r.cigar_off = off + col_at[5];
+    r.cigar_len = (uint16_t)col_len[5];
+    r.seq_off = off + col_at[9];
+    r.seq_len = col_len[9];
+    r.key = fe_rec_key(r, text);
+    return 0;
+}
+
+// one BAM record (rec_off = the record's first byte after block_size, len = block_size) -> FeRec: split_bam of hgx_sam.cpp
+FE_HD inline uint32_t fe_ld32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+FE_HD inline int fe_parse_bam_record(const char *text, uint32_t rec_off, uint32_t len, bool simulation, FeRec &rec) {
+    const unsigned char *r = (const unsigned char *)text + rec_off;
+    if (len < 32) return FE_FAIL(FE_E_ASSERT);
+    const int32_t pos0 = (int32_t)fe_ld32(r + 4);
+    const uint32_t l_rn = r[8], n_cig = (uint32_t)r[12] | ((uint32_t)r[13] << 8), flag = (uint32_t)r[14] | ((uint32_t)r[15] << 8);
+    const int32_t l_seq = (int32_t)fe_ld32(r + 16);
+    if (l_rn == 0 || l_seq <= 0) return FE_FAIL(FE_E_ASSERT);           // (a record without SEQ spells "*": the host's business)
+    size_t q = 32 + (size_t)l_rn;
+    const size_t cig_at = q;
+    q += 4ull * n_cig;
+    const size_t seq_at = q;
+    q += (size_t)(l_seq + 1) / 2 + (size_t)l_seq;
+    if (q > len || r[32 + l_rn - 1] != 0) return FE_FAIL(FE_E_ASSERT);
+    if (n_cig == 0) return FE_FAIL(FE_E_ASSERT);                          // ("*")
+    rec.bits = FE_R_BIN;
+    rec.nm = rec.nh = 0;
+    rec.zs_off = rec.md_off = rec_off;
+    rec.zs_len = rec.md_len = 0;
+    rec.pad_ = 0;
+    while (q + 3 <= len) {
+        const char t0 = (char)r[q], t1 = (char)r[q + 1], t = (char)r[q + 2];
+        q += 3;
+        size_t sz = 0;
+        if (t == 'A' || t == 'c' || t == 'C') sz = 1;
+        else if (t == 's' || t == 'S') sz = 2;
+        else if (t == 'i' || t == 'I' || t == 'f') sz = 4;
+        else if (t == 'Z' || t == 'H') {
+            size_t e = q;
+            while (e < len && r[e] != 0) ++e;
+            if (e >= len) return FE_FAIL(FE_E_ASSERT);
+            sz = e - q + 1;
+        } else if (t == 'B') {
+            if (q + 5 > len) return FE_FAIL(FE_E_ASSERT);
+            const char st = (char)r[q];
+            const uint32_t cnt = fe_ld32(r + q + 1);
+            const size_t w = (st == 'c' || st == 'C') ? 1 : (st == 's' || st == 'S') ? 2 : (st == 'i' || st == 'I' || st == 'f') ? 4 : 0;
+            if (!w) return FE_FAIL(FE_E_ASSERT);
+            sz = 5 + w * (size_t)cnt;
+            if (t0 == 'C' && t1 == 'G') return FE_FAIL(FE_E_ASSERT);        // the real-CIGAR rule: host
+        } else return FE_FAIL(FE_E_ASSERT);
+        if (q + sz > len) return FE_FAIL(FE_E_ASSERT);
+        const unsigned char *v = r + q;
+        const bool is_text = t == 'Z' || t == 'H';
+        if (t0 == 'Z' && t1 == 's') {
+            rec.bits |= FE_R_HAS_ZS;
+            if (is_text) { if (sz - 1 > 65535) return FE_FAIL(FE_E_CAP); rec.zs_off = rec_off + (uint32_t)q; rec.zs_len = (uint16_t)(sz - 1); }
+            else { rec.zs_off = rec_off; rec.zs_len = 0; }
+        } else if (t0 == 'M' && t1 == 'D') {
+            rec.bits |= FE_R_HAS_MD;
+            if (is_text) { if (sz - 1 > 65535) return FE_FAIL(FE_E_CAP); rec.md_off = rec_off + (uint32_t)q; rec.md_len = (uint16_t)(sz - 1); }
+            else { rec.md_off = rec_off; rec.md_len = 0; }
+        } else if (t0 == 'N' && (t1 == 'M' || t1 == 'H')) {
+            long long x;
+            if (t == 'c') x = (signed char)v[0];
+            else if (t == 'C') x = v[0];
+            else if (t == 's') x = (short)((uint32_t)v[0] | ((uint32_t)v[1] << 8));
+            else if (t == 'S') x = (long long)((uint32_t)v[0] | ((uint32_t)v[1] << 8));
+            else if (t == 'i') x = (int32_t)fe_ld32(v);
+            else if (t == 'I') x = (long long)fe_ld32(v);
+            else return FE_FAIL(FE_E_ASSERT);                              // float / text typed: read through their spelling on the host
+            if (x > 0x7fffffffll) x = 0x7fffffffll;
+            if (t1 == 'M') { rec.bits |= FE_R_HAS_NM; rec.nm = (int32_t)x; }
+            else { rec.bits |= FE_R_HAS_NH; rec.nh = (int32_t)x; }
+        }
+        q += sz;
+    }
+    for (uint32_t k = 0; k < n_cig; ++k) if ((r[cig_at + 4 * k] & 15) >= 9) return FE_FAIL(FE_E_CIGAR);
+    rec.qname_off = rec_off + 32;
+    uint32_t idl = l_rn - 1;
+    if (simulation)
+        for (uint32_t k = 0; k + 1 < l_rn; ++k) if (r[32 + k] == '|') { idl = k; break; }
+    rec.id_len = (uint16_t)idl;
+    rec.flag = (int32_t)flag;
+    rec.pos = pos0 + 1;
+    rec.cigar_off = rec_off + (uint32_t)cig_at;
+    rec.cigar_len = (uint16_t)n_cig;
+    rec.seq_off = rec_off + (uint32_t)seq_at;
+    rec.seq_len = (uint32_t)l_seq;
+    rec.key = fe_rec_key(rec, text);
+    return 0;
+}
+
+FE_HD inline bool fe_same_read_id(const FeRec &a, const FeRec &b, const char *text) {
+    return a.id_len == b.id_len && fe_bytes_equal((const unsigned char *)text + a.qname_off, (const unsigned char *)text + b.qname_off, a.id_len);
+}
+
+// record filters (typing_core.py:815-872; filter_records of hgx_sam.cpp).  `head[i]` = record i opens a group of equal read ids.
+// A record passes up to the mate rule iff it is aligned, inside the locus, has its tags, few enough edits, one hit and is
+// concordant (or discordant pairs count); of the passing records of a group the FIRST left mate, the first right mate and the
+// first unpaired one are kept.  Returns 1 kept, 0 dropped, < 0 where the reference raises (the host says how).
+struct FeFilter { int32_t num_editdist, allow_discordant, base_locus; };
+FE_HD inline int fe_rec_passes(const FeRec &f, const FeFilter &o) {
+    if (f.pos - (o.base_locus + 1) < 0) return 0;
+    if (f.flag & 0x4) return 0;
+    if (!(f.bits & FE_R_HAS_NM) || !(f.bits & FE_R_HAS_NH)) return FE_FAIL(FE_E_ASSERT);     // quirk Q8
+    if (f.nm > o.num_editdist) return 0;
+    if (f.nh > 1) return 0;
+    if (!o.allow_discordant && !(f.flag & 0x2)) return 0;
+    if (!(f.flag & 0x40) && !(f.flag & 0x80) && !o.allow_discordant) return FE_FAIL(FE_E_ASSERT);    // assert allow_discordant
+    return 1;
+}
+FE_HD inline int fe_rec_side(const FeRec &f) { return (f.flag & 0x40) ? 0 : (f.flag & 0x80) ? 1 : 2; }
+FE_HD inline int fe_rec_kept(const FeRec *recs, const uint8_t *head, uint32_t i, const FeFilter &o) {
+    const int p = fe_rec_passes(recs[i], o);
+    if (p <= 0) return p;
+    const int side = fe_rec_side(recs[i]);
+    for (uint32_t j = i; j > 0 && !head[j]; ) {
+        --j;
+        const int pj = fe_rec_passes(recs[j], o);
+        if (pj < 0) return pj;
+        if (pj == 1 && fe_rec_side(recs[j]) == side) return 0;
+        if (head[j]) break;
+    }
+    return 1;
+}
+FE_HD inline bool fe_rec_in_pileup(const FeRec &f, const FeFilter &o) {      // typing_common.py:1076-1090
+    return !(f.flag & 0x4) && f.pos - (o.base_locus + 1) >= 0 && (o.allow_discordant || (f.flag & 0x2));
 }

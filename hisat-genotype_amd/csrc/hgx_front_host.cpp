@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstring>
 #include <string>
+#include <unordered_map>
 
 #include "hgx_internal.hpp"
 
@@ -216,6 +217,86 @@ int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, 
 #endif
 
 #ifdef HGX_LAB
+// ---- the record stage as loops (mirrors k_fe_records .. k_fe_build of hgx_front.hip), then the key stages above -----------------
+int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary,
+                              const hgx_parse_opts &o, int *declined) {
+    *out = nullptr;
+    *declined = 0;
+    if (raw_bytes >= (1ull << 32) - 64 || n >= (1ull << 30)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+    std::vector<FeRec> recs(n);
+    for (size_t i = 0; i < n; ++i) {
+        const uint32_t off = (uint32_t)(lines[i].p - raw) - (binary ? 32u : 0u);
+        const int r = binary ? fe_parse_bam_record(raw, off, lines[i].len, o.simulation != 0, recs[i])
+                             : fe_parse_text_record(raw, off, lines[i].len, o.simulation != 0, recs[i]);
+        if (r < 0) { *declined = -r; return HGX_OK; }
+    }
+    std::vector<uint8_t> head(n, 0), kept(n, 0), pm(n, 0);
+    for (size_t i = 0; i < n; ++i) head[i] = i == 0 || !fe_same_read_id(recs[i - 1], recs[i], raw);
+    const FeFilter flt{o.num_editdist, o.allow_discordant, o.base_locus};
+    for (size_t i = 0; i < n; ++i) {
+        const int k = fe_rec_kept(recs.data(), head.data(), (uint32_t)i, flt);
+        if (k < 0) { *declined = -k; return HGX_OK; }
+        kept[i] = (uint8_t)k;
+        pm[i] = fe_rec_in_pileup(recs[i], flt) ? 1 : 0;
+    }
+    // grouping by decode key: hash table on the 64-bit key, first record of a key = its representative, exact check against it
+    std::unordered_map<uint64_t, uint32_t> slot_of_key;
+    std::vector<uint32_t> rep, n_pile, slot_of(n);
+    std::vector<uint8_t> any_kept;
+    for (size_t i = 0; i < n; ++i) {
+        auto it = slot_of_key.find(recs[i].key);
+        uint32_t s;
+        if (it == slot_of_key.end()) {
+            s = (uint32_t)rep.size();
+            slot_of_key.emplace(recs[i].key, s);
+            rep.push_back((uint32_t)i); n_pile.push_back(0); any_kept.push_back(0);
+        } else {
+            s = it->second;
+            if (!fe_rec_same_key(recs[rep[s]], recs[i], raw)) { *declined = HGX_FE_DECLINE_COLLISION; return HGX_OK; }
+        }
+        slot_of[i] = s;
+        n_pile[s] += pm[i];
+        any_kept[s] |= kept[i];
+    }
+    hgx_front_input in;
+    in.mem = hgx_front_alloc{[](size_t b) { return hgx_host_alloc(b); }, [](void *p) { hgx_host_free(p); }};
+    in.text = const_cast<char *>(raw);
+    in.text_borrowed = true;
+    in.n_text = raw_bytes;
+    std::vector<uint32_t> dslot(rep.size(), FE_NO_SLOT);
+    size_t nk = 0, ns = 0, nr = 0;
+    for (size_t s = 0; s < rep.size(); ++s) if (n_pile[s] > 0 || any_kept[s]) ++nk;
+    for (size_t i = 0; i < n; ++i) nr += kept[i];
+    in.keys = (FeKey *)in.mem.alloc(std::max<size_t>(nk, 1) * sizeof(FeKey));
+    in.rec_info = (uint32_t *)in.mem.alloc(std::max<size_t>(nr, 1) * 4);
+    for (size_t s = 0, k = 0; s < rep.size(); ++s) {                 // (slots are in stream order of their first records here)
+        if (!(n_pile[s] > 0 || any_kept[s])) continue;
+        const FeRec &f = recs[rep[s]];
+        FeKey &K = in.keys[k++];
+        K.pos = f.pos - (o.base_locus + 1);
+        K.n_pile = n_pile[s];
+        K.slot = any_kept[s] ? (uint32_t)ns++ : FE_NO_SLOT;
+        dslot[s] = K.slot;
+        K.cigar_off = f.cigar_off; K.seq_off = f.seq_off; K.zs_off = f.zs_off; K.md_off = f.md_off;
+        K.seq_len = f.seq_len; K.cigar_len = f.cigar_len; K.zs_len = f.zs_len; K.md_len = f.md_len;
+        K.flags = (uint16_t)(((f.bits & FE_R_HAS_ZS) ? FE_K_HAS_ZS : 0) | ((f.bits & FE_R_HAS_MD) ? FE_K_HAS_MD : 0) |
+                             ((f.bits & FE_R_BIN) ? (FE_K_BIN_CIGAR | FE_K_PACKED_SEQ) : 0));
+    }
+    in.n_keys = nk;
+    in.n_slots = ns;
+    size_t prev = (size_t)-1, k = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!kept[i]) continue;
+        const bool hd = prev == (size_t)-1 || !fe_same_read_id(recs[prev], recs[i], raw);
+        in.rec_info[k++] = dslot[slot_of[i]] | ((recs[i].flag & 0x40) ? 1u << 30 : 0u) | (hd ? 1u << 31 : 0u);
+        prev = i;
+    }
+    in.n_rec = nr;
+    return hgx_front_emulate(out, L, in, o, declined);
+}
+#endif
+
+#ifdef HGX_LAB
 // SAM text -> batch through the emulated device stages (lab library only; tests/test_front_emulation.py).  *declined != 0: the
 // device path would hand this input to the host stages, which then produced the batch.
 extern "C" int hgx_lab_parse_sam_emulated(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts,
@@ -229,6 +310,30 @@ extern "C" int hgx_lab_parse_sam_emulated(hgx_batch **out, const hgx_locus *loc,
     *declined = hook.declined;
     if (rc) { delete made; return rc; }
     if (!hook.declined) *out = made;
+    else delete made;
+    return HGX_OK;
+}
+
+// the same with the RECORD stage emulated too (fields, filters, key grouping: the device takes the records themselves);
+// path != NULL: an alignment file (SAM text or BAM) instead of text.  declined[0] = record route, declined[1] = key route.
+extern "C" int hgx_lab_parse_records_emulated(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const char *path,
+                                              const char *regions, const hgx_parse_opts *opts, int32_t *declined) {
+    HARGCHK(out && loc && opts && declined && (sam || path || n_bytes == 0));
+    hgx_batch *made = nullptr;
+    hgx_front_hook hook;
+    hook.mem = hgx_front_alloc{[](size_t n) { return hgx_host_alloc(n); }, [](void *p) { hgx_host_free(p); }};
+    hook.run = [&](hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, int *dec) {
+        delete made; made = nullptr;
+        return hgx_front_emulate(&made, L, in, o, dec);
+    };
+    hook.records = [&](hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &o, int *dec) {
+        return hgx_front_emulate_records(&made, L, raw, raw_bytes, lines, n, binary, o, dec);
+    };
+    const int rc = path ? hgx_parse_alignment_file_hook(out, loc, path, regions, opts, &hook) : hgx_parse_sam_hook(out, loc, sam, n_bytes, opts, &hook);
+    declined[0] = hook.declined_records;
+    declined[1] = hook.declined;
+    if (rc) { delete made; return rc; }
+    if (!*out) *out = made;
     else delete made;
     return HGX_OK;
 }

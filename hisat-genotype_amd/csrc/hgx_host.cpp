@@ -447,20 +447,27 @@ extern "C" int hgx_batch_arrays(const hgx_batch *b, const hgx_piece **pieces, co
 // by accident, and the query is one relaxed load while none is set.
 namespace {
 std::mutex g_sw_mu;
-std::map<std::string, std::string> g_sw;          // values are never erased while set: c_str() stays valid for the caller
+std::map<std::string, const std::string *> g_sw;      // name -> current value
+// values are interned and never freed: a pointer handed out stays valid whatever another thread sets or clears afterwards
+// (test hooks only: a few dozen short strings per process)
+std::map<std::string, std::string *> g_sw_values;
 std::atomic<int> g_sw_n{0};
 }
 extern "C" const char *hgx_test_switch(const char *name) {
     if (g_sw_n.load(std::memory_order_relaxed) == 0) return nullptr;
     std::lock_guard<std::mutex> g(g_sw_mu);
     auto it = g_sw.find(name);
-    return it == g_sw.end() ? nullptr : it->second.c_str();
+    return it == g_sw.end() ? nullptr : it->second->c_str();
 }
 extern "C" int hgx_test_switch_set(const char *name, const char *value) {
     std::lock_guard<std::mutex> g(g_sw_mu);
     if (!name) g_sw.clear();
     else if (!value) g_sw.erase(name);
-    else g_sw[name] = value;
+    else {
+        auto it = g_sw_values.find(value);
+        if (it == g_sw_values.end()) it = g_sw_values.emplace(value, new std::string(value)).first;
+        g_sw[name] = it->second;
+    }
     g_sw_n.store((int)g_sw.size(), std::memory_order_relaxed);
     return HGX_OK;
 }
@@ -501,7 +508,33 @@ constexpr uint64_t HOST_MAGIC = 0x6867785f686f7374ull;
 constexpr size_t HOST_POOL_MIN = 1u << 20;
 }   // namespace
 
+// Blocks from another allocator (the device front end's pinned staging): while a thread holds an hgx_big_alloc_scope, its
+// allocations of at least `min_bytes` come from that allocator, and hgx_host_free hands them back to it (a registry of the live
+// foreign blocks: they carry no header).
+namespace {
+struct Foreign { std::mutex mu; std::map<void *, void (*)(void *)> live; };
+Foreign &foreign() { static Foreign *f = new Foreign(); return *f; }
+thread_local hgx_front_alloc g_big_alloc{nullptr, nullptr};
+thread_local size_t g_big_min = 0;
+std::atomic<long> g_foreign_n{0};
+}
+hgx_big_alloc_scope::hgx_big_alloc_scope(hgx_front_alloc a, size_t min_bytes) : old(g_big_alloc), old_min(g_big_min) { g_big_alloc = a; g_big_min = min_bytes; }
+hgx_big_alloc_scope::~hgx_big_alloc_scope() { g_big_alloc = old; g_big_min = old_min; }
+
 void *hgx_host_alloc(size_t bytes) {
+    if (g_big_alloc.alloc && bytes >= g_big_min) {
+        const hgx_front_alloc a = g_big_alloc;
+        g_big_alloc.alloc = nullptr;                       // (the other allocator may itself be built on this one)
+        void *p = a.alloc(bytes);
+        g_big_alloc = a;
+        if (p) {
+            Foreign &F = foreign();
+            std::lock_guard<std::mutex> g(F.mu);
+            F.live[p] = a.release;
+            g_foreign_n.fetch_add(1);
+            return p;
+        }
+    }
     const size_t need = bytes + sizeof(BlockHeader);
     if (need >= HOST_POOL_MIN) {
         HostPool &P = host_pool();
@@ -535,6 +568,16 @@ void *hgx_host_alloc(size_t bytes) {
 }
 void hgx_host_free(void *p) {
     if (!p) return;
+    if (g_foreign_n.load(std::memory_order_relaxed) > 0) {
+        Foreign &F = foreign();
+        void (*rel)(void *) = nullptr;
+        {
+            std::lock_guard<std::mutex> g(F.mu);
+            auto it = F.live.find(p);
+            if (it != F.live.end()) { rel = it->second; F.live.erase(it); g_foreign_n.fetch_sub(1); }
+        }
+        if (rel) { rel(p); return; }
+    }
     BlockHeader *h = (BlockHeader *)((char *)p - sizeof(BlockHeader));
     if (h->magic != HOST_MAGIC) return;               // not ours: leak rather than corrupt
     if (h->cap >= HOST_POOL_MIN) {

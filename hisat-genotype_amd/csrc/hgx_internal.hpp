@@ -176,6 +176,10 @@ struct hgx_align_lines {
     // NUL-terminated), lines[i].len = its block_size; ref_names = the header's reference sequences
     bool binary = false;
     std::vector<std::string> ref_names;
+    size_t raw_bytes = 0;
+    // called once, as soon as the bytes the line table will point into are complete (SAM text read / BAM stream inflated) and
+    // before the record walk and the name sort: the device front end starts its upload there
+    std::function<void(const char *raw, size_t n_bytes)> on_raw;
     hgx_align_lines() = default;
     hgx_align_lines(const hgx_align_lines &) = delete;
     hgx_align_lines &operator=(const hgx_align_lines &) = delete;
@@ -209,16 +213,24 @@ FeLocus hgx_front_view(const hgx_locus &L, const hgx_front_tables &T);       // 
 // or are decoded, in stream order of their first records, with their text; and the records that passed the filters.
 // The three arrays live in staging memory obtained from `alloc` (pinned for the device path).
 struct hgx_front_alloc { void *(*alloc)(size_t); void (*release)(void *); };
+// while alive, this thread's hgx_host_alloc calls of >= min_bytes come from `a` (hgx_host_free gives such blocks back to it)
+struct hgx_big_alloc_scope {
+    hgx_front_alloc old;
+    size_t old_min;
+    hgx_big_alloc_scope(hgx_front_alloc a, size_t min_bytes);
+    ~hgx_big_alloc_scope();
+};
 struct hgx_front_input {
     hgx_front_alloc mem{nullptr, nullptr};
     FeKey *keys = nullptr; size_t n_keys = 0;
     char *text = nullptr; size_t n_text = 0;
     uint32_t *rec_info = nullptr; size_t n_rec = 0;
     size_t n_slots = 0;                // distinct keys that are decoded
+    bool text_borrowed = false;        // `text` belongs to someone else (the record route reads the file's bytes in place)
     hgx_front_input() = default;
     hgx_front_input(const hgx_front_input &) = delete;
     hgx_front_input &operator=(const hgx_front_input &) = delete;
-    ~hgx_front_input() { if (mem.release) { mem.release(keys); mem.release(text); mem.release(rec_info); } }
+    ~hgx_front_input() { if (mem.release) { mem.release(keys); if (!text_borrowed) mem.release(text); mem.release(rec_info); } }
 };
 // > 0: the device front end declines this input (code = an FE_E_* value negated, or one of the HGX_FE_DECLINE_* below)
 #define HGX_FE_DECLINE_OPTS 1          // keep_trace / choose_pairs / inter-distance exchange: host only
@@ -234,10 +246,20 @@ struct hgx_front_hook {
     hgx_front_alloc mem{nullptr, nullptr};
     std::function<int(hgx_locus &, const hgx_front_input &, const hgx_parse_opts &, int *declined)> run;
     int declined = 0;
+    // The RECORD route, tried first when set: the device takes the records themselves (fields, filters, key grouping as kernels
+    // over the SAM text / the inflated BAM stream it was sent through `on_raw`), the host stages do not run at all.  `lines`: the
+    // name-ordered line table of the reader; raw / raw_bytes: the bytes it points into.  *declined != 0: the host stages run
+    // (and `run` gets its chance after them).
+    std::function<int(hgx_locus &, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &,
+                      int *declined)> records;
+    std::function<void(const char *raw, size_t n_bytes)> on_raw;
+    int declined_records = 0;
 };
 int hgx_parse_sam_hook(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, hgx_front_hook *hook);
 int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *loc, const char *path, const char *regions, const hgx_parse_opts *opts,
                                   hgx_front_hook *hook);
 #ifdef HGX_LAB
 int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &opts, int *declined);
+int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary,
+                              const hgx_parse_opts &opts, int *declined);
 #endif

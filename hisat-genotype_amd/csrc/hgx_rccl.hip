@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "hgx_common.hpp"
@@ -25,6 +26,7 @@ struct Rccl {
     ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    std::string why;              // why loading failed (dlopen's message, captured once)
 };
 Rccl g_rccl;
 std::once_flag g_rccl_once;
@@ -34,6 +36,7 @@ int rccl_load() {
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (g_rccl.lib) break;
+            if (const char *e = dlerror()) g_rccl.why = e;        // captured once, here: dlerror() clears itself when read
         }
         if (!g_rccl.lib) return;
         auto sym = [&](const char *n) { return dlsym(g_rccl.lib, n); };
@@ -44,8 +47,9 @@ int rccl_load() {
         g_rccl.CommUserRank = (decltype(g_rccl.CommUserRank))sym("ncclCommUserRank");
         g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))sym("ncclGetErrorString");
         g_rccl.ok = g_rccl.Broadcast && g_rccl.AllReduce && g_rccl.AllGather && g_rccl.CommCount && g_rccl.CommUserRank;
+        if (!g_rccl.ok) g_rccl.why = "symbols missing";
     });
-    if (!g_rccl.ok) { hgx_set_error("librccl could not be loaded (%s)", dlerror() ? dlerror() : "symbols missing"); return HGX_EHIP; }
+    if (!g_rccl.ok) { hgx_set_error("librccl could not be loaded (%s)", g_rccl.why.empty() ? "not found" : g_rccl.why.c_str()); return HGX_EHIP; }
     return HGX_OK;
 }
 #define RCCLCHK(expr)                                                                                                   \
@@ -109,6 +113,9 @@ extern "C" int hgx_classes_allgather(hgx_classes **out, const hgx_classes *mine,
     for (int32_t c : sizes) { total += c; cap = std::max(cap, c); }
     const size_t pitch = (size_t)(w64 + 1) * 8;
     DevBuf b_send, b_recv, b_rows, b_w;
+    // declared after the buffers = destroyed before them: an error return behind a queued collective / copy drains the stream
+    // before the buffers go back to the pool
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
     ALLOC(b_send, (size_t)cap * pitch);
     ALLOC(b_recv, (size_t)world * cap * pitch);
     HIPCHK(hipMemsetAsync(b_send.p, 0, (size_t)cap * pitch, st));

@@ -1684,12 +1684,15 @@ int build_front_input(const hgx_parse_opts &o, const Fields *recs, const uint8_t
             K.pos = f.pos - (o.base_locus + 1);
             K.n_pile = f.n_pile;
             K.slot = f.slot;
-            K.off = (uint32_t)at;
+            K.cigar_off = (uint32_t)at;
+            K.seq_off = K.cigar_off + f.cigar_len;
+            K.zs_off = K.seq_off + (uint32_t)f.seq_len;
+            K.md_off = K.zs_off + f.zs_len;
             K.seq_len = (uint32_t)f.seq_len;
             K.cigar_len = (uint16_t)f.cigar_len;
             K.zs_len = (uint16_t)f.zs_len;
             K.md_len = (uint16_t)f.md_len;
-            K.flags = (uint16_t)((f.zs ? 1 : 0) | (f.md ? 2 : 0));
+            K.flags = (uint16_t)((f.zs ? FE_K_HAS_ZS : 0) | (f.md ? FE_K_HAS_MD : 0));
             char *w = in.text + at;
             memcpy(w, f.cigar, f.cigar_len); w += f.cigar_len;
             memcpy(w, f.seq, f.seq_len); w += f.seq_len;
@@ -1742,7 +1745,7 @@ void parallel_for(int n_threads, size_t n, F fn) {   // fn(thread, begin, end), 
 }   // namespace
 
 static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts, bool binary = false,
-                       hgx_front_hook *hook = nullptr);
+                       hgx_front_hook *hook = nullptr, const char *raw = nullptr, size_t raw_bytes = 0);
 
 // SAM text (name-grouped) -> private writable copy + line table -> parse_lines
 int hgx_parse_sam_hook(hgx_batch **out, const hgx_locus *Lc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, hgx_front_hook *hook) {
@@ -1751,7 +1754,10 @@ int hgx_parse_sam_hook(hgx_batch **out, const hgx_locus *Lc, const char *sam, si
         int n_threads = opts->n_threads > 0 ? opts->n_threads : hgx_default_threads();
         n_threads = std::max(1, std::min(n_threads, 512));
         struct PoolFree { void operator()(char *p) const { hgx_host_free(p); } };
+        std::unique_ptr<hgx_big_alloc_scope> pinned;                       // the record route uploads the text: staging memory for it
+        if (hook && hook->records && hook->mem.alloc) pinned.reset(new hgx_big_alloc_scope(hook->mem, 1u << 20));
         std::unique_ptr<char, PoolFree> text((char *)hgx_host_alloc(n_bytes + 1));      // tokens are NUL-terminated in place
+        pinned.reset();
         char *base = text.get(), *end = base + n_bytes;
         const int nt = n_bytes > (8u << 20) ? n_threads : 1;
         std::vector<std::vector<hgx_line>> part(nt);
@@ -1778,7 +1784,8 @@ int hgx_parse_sam_hook(hgx_batch **out, const hgx_locus *Lc, const char *sam, si
             for (size_t t = b; t < e; ++t)
                 if (!part[t].empty()) memcpy(&lines[off[t]], part[t].data(), part[t].size() * sizeof(hgx_line));
         });
-        return parse_lines(out, Lc, lines.data(), lines.size(), opts, false, hook);
+        if (hook && hook->on_raw) hook->on_raw(base, n_bytes);
+        return parse_lines(out, Lc, lines.data(), lines.size(), opts, false, hook, base, n_bytes);
     } catch (const std::exception &e) {
         hgx_set_error("%s", e.what());
         return HGX_EINVAL;
@@ -1802,10 +1809,13 @@ int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *Lc, const ch
     try {
         const double t0 = now();
         hgx_align_lines al;                     // the reader's buffers are tokenised in place (no copy, no trip through the caller)
+        std::unique_ptr<hgx_big_alloc_scope> pinned;   // the record route uploads the text / the inflated stream: staging memory for them
+        if (hook && hook->records && hook->mem.alloc) { pinned.reset(new hgx_big_alloc_scope(hook->mem, 32u << 20)); al.on_raw = hook->on_raw; }
         int rc = hgx_read_alignment_lines(path, regions, opts->n_threads, al, /*keep_binary=*/true);
+        pinned.reset();
         if (rc) return rc;
         const double t1 = now();
-        rc = parse_lines(out, Lc, al.lines.data(), al.lines.size(), opts, al.binary, hook);
+        rc = parse_lines(out, Lc, al.lines.data(), al.lines.size(), opts, al.binary, hook, al.raw, al.raw_bytes);
         if (prof) fprintf(stderr, "[hgx_parse_alignment_file] read %.1f ms, parse %.1f ms\n", (t1 - t0) * 1e3, (now() - t1) * 1e3);
         return rc;
     } catch (const std::exception &e) {
@@ -1817,9 +1827,24 @@ int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *Lc, const ch
 // lines: name-grouped records.  Text: lines[i].p[lines[i].len] is writable (it becomes the record's terminator).  Binary (BAM
 // records as read): lines[i].p = the record's QNAME (32 bytes into the record), lines[i].len = its block_size.
 static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts, bool binary,
-                       hgx_front_hook *hook) {
+                       hgx_front_hook *hook, const char *raw, size_t raw_bytes) {
     HARGCHK(out && Lc && (lines || n == 0) && opts);
     *out = nullptr;
+    if (hook && hook->records && raw) {
+        // the record route of the device front end: fields, filters and key grouping as kernels too -- nothing below runs
+        hook->declined_records = 0;
+        if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange) hook->declined_records = HGX_FE_DECLINE_OPTS;
+        else {
+            try {
+                const int rc = hook->records(*const_cast<hgx_locus *>(Lc), raw, raw_bytes, lines, n, binary, *opts, &hook->declined_records);
+                if (rc) return rc;
+            } catch (const std::exception &e) {
+                hgx_set_error("%s", e.what());
+                return HGX_EINVAL;
+            }
+            if (!hook->declined_records) { hook->declined = 0; return HGX_OK; }
+        }
+    }
     hgx_locus &L = *const_cast<hgx_locus *>(Lc);
     hgx_batch *B = new hgx_batch();
     try {

@@ -1153,6 +1153,11 @@ extern "C" int hgx_type_many(hgx_typing **out, int32_t *rc_out, const hgx_locus 
 extern "C" int hgx_type_many_loci(int32_t n_loci, hgx_typing ***out, int32_t **rc_out, const hgx_locus *const *loci, const hgx_index *const *ixs,
                                   hgx_many *const *manies, const hgx_type_opts *opts, void *stream) {
     ARGCHK(n_loci >= 0 && (n_loci == 0 || (out && loci && ixs && manies)) && opts);
+    // every locus is checked and its outputs are cleared BEFORE anything runs: the clean-up below may then visit any of them
+    for (int i = 0; i < n_loci; ++i) {
+        ARGCHK(out[i] && loci[i] && ixs[i] && manies[i]);
+        for (int t = 0; t < manies[i]->n_tasks; ++t) out[i][t] = nullptr;
+    }
     EmFastScope em_mode(opts->em_fast);
     std::vector<ManyRun> runs((size_t)n_loci);
     int rc = HGX_OK;

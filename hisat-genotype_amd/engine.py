@@ -75,10 +75,12 @@ class DeviceBatch:
 
 
 def front_last():
-    """(device stages ran?, decline code) of the calling thread's last hgx_parse_*_dev / hgx_type_file call."""
+    """(route, decline code) of the calling thread's last hgx_parse_*_dev / hgx_type_file call: route 2 = the device took the
+    records themselves (fields, filters, key grouping as kernels), 1 = the host made the key table and the device the rest,
+    0 = the host stages finished the job (decline code says why)."""
     ran, code = C.c_int32(0), C.c_int32(0)
     capi.check(capi.lib().hgx_front_last(C.byref(ran), C.byref(code)))
-    return bool(ran.value), code.value
+    return ran.value, code.value
 
 
 def em_last_order(n_alleles):

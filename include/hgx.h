@@ -439,22 +439,26 @@ int hgx_type_batch(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, 
 /* alignment file -> typing result: hgx_parse_alignment_file + hgx_type_batch (the whole of typing()'s per-locus work) */
 int hgx_type_file(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, const char *path, const char *regions_or_null,
                   const hgx_parse_opts *parse_opts, const hgx_type_opts *opts, void *stream);
-/* ---- the front end on the device (rows 8a-2 .. 8a-5 as kernels, csrc/hgx_front.hip) ----------------------------------------
- * The host keeps tokenising, the record filters of typing_core.py:815-872 and the grouping of the records by decode key; the
- * distinct keys (~0.28 per read at 1 M reads, ~200 bytes each) are uploaded and get_mpileup (typing_common.py:1059-1134), the
- * CIGAR x MD x Zs walk + error_correct (typing_core.py:899-1124, 119-243), identify_ambigious_diffs (typing_common.py:1663-1955),
- * haplotype assembly, get_exon_haplotypes (typing_core.py:1386-1406, 718-792), the piece masks of add_count's span scan
- * (typing_core.py:641-670), the distinct-piece table and the pair protocol (typing_core.py:1238-1347) run as kernels; the batch is
- * born in HBM, byte for byte the batch hgx_parse_sam / hgx_parse_alignment_file build (hgx_dbatch_to_host shows it).  Inputs the
- * kernels do not take -- fewer than 20 000 records, keep_trace, CODIS D18S51's choose_pairs, variant ids that are not hv<n>, a
- * record the reference would raise on, a pair with more alternatives than the kernels' scratch holds -- are finished by the host
- * stages and uploaded: the result is the same batch either way, and hgx_front_last says which way the calling thread's last
- * call went (decline_code: 0 = the kernels ran; see HGX_FE_DECLINE_* / FE_E_* in csrc/hgx_internal.hpp, csrc/hgx_front_core.hpp).
- * hgx_type_file goes through hgx_parse_alignment_file_dev. */
+/* ---- the front end on the device (rows 8a-1 .. 8a-5 as kernels, csrc/hgx_front.hip) ----------------------------------------
+ * RECORD route (tried first): the host only reads the file -- and, for BAM, inflates it, walks the record chain and name-sorts it;
+ * the SAM text / inflated stream goes to the GPU while that happens, and the record fields (typing_core.py:800-841), the record
+ * filters (typing_core.py:815-872) and the grouping of the records by decode key run as kernels, one lane per record.
+ * KEY route (when the record route declines: a line with blanks, a float-typed NM tag, ...): the host tokenises, filters and groups;
+ * the distinct keys (~0.28 per read at 1 M reads, ~200 bytes each) are uploaded.
+ * Either way get_mpileup (typing_common.py:1059-1134), the CIGAR x MD x Zs walk + error_correct (typing_core.py:899-1124,
+ * 119-243), identify_ambigious_diffs (typing_common.py:1663-1955), haplotype assembly, get_exon_haplotypes
+ * (typing_core.py:1386-1406, 718-792), the piece masks of add_count's span scan (typing_core.py:641-670), the distinct-piece
+ * table and the pair protocol (typing_core.py:1238-1347) run as kernels; the batch is born in HBM, byte for byte the batch
+ * hgx_parse_sam / hgx_parse_alignment_file build (hgx_dbatch_to_host shows it).  Inputs the kernels do not take -- fewer than
+ * 20 000 records, keep_trace, CODIS D18S51's choose_pairs, variant ids that are not hv<n>, a record the reference would raise on,
+ * a pair with more alternatives than the kernels' scratch holds -- are finished by the host stages and uploaded: the result is
+ * the same batch either way, and hgx_front_last says which way the calling thread's last call went (route: 2 = record route,
+ * 1 = key route, 0 = host stages; decline_code: see HGX_FE_DECLINE_* / FE_E_* in csrc/hgx_internal.hpp,
+ * csrc/hgx_front_core.hpp).  hgx_type_file goes through hgx_parse_alignment_file_dev. */
 int hgx_parse_sam_dev(hgx_dbatch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, void *stream);
 int hgx_parse_alignment_file_dev(hgx_dbatch **out, const hgx_locus *loc, const char *path, const char *regions_or_null,
                                  const hgx_parse_opts *opts, void *stream);
-int hgx_front_last(int32_t *device_stages_ran, int32_t *decline_code);
+int hgx_front_last(int32_t *route, int32_t *decline_code);
 /* a device batch back on the host (tests, tools): pieces, masks, refs, and the pileup tables if the kernels made them */
 int hgx_dbatch_to_host(const hgx_dbatch *d, hgx_batch **out);
 /* The same from class sets that already exist (intra-locus read sharding, 8e: every rank scores its share of the pairs, the

@@ -24,6 +24,18 @@ def emulated(pl, sam, num_editdist=2, error_correction=True, allow_discordant=Fa
     return hl.Batch(h), dec.value
 
 
+def emulated_records(pl, sam=None, path=None, regions=None, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False):
+    """The record route: fields, filters and key grouping emulated too (hgx_lab_parse_records_emulated); text or a SAM / BAM file."""
+    data = None if sam is None else (sam if isinstance(sam, (bytes, bytearray)) else sam.encode())
+    o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), 0, 0,
+                       int(pl.base_fname == "codis" and pl.gene == "D18S51"), 0)
+    h, dec = C.c_void_p(), (C.c_int32 * 2)(0, 0)
+    capi.check(capi.lib().hgx_lab_parse_records_emulated(C.byref(h), pl.h, data, C.c_size_t(len(data) if data else 0),
+                                                         path.encode() if path else None, regions.encode() if regions else None,
+                                                         C.byref(o), dec))
+    return hl.Batch(h), (dec[0], dec[1])
+
+
 def same_batch(a, b, length):
     assert (a.n_reads, a.n_pairs, a.n_pieces, a.n_refs, a.n_mask_u32) == (b.n_reads, b.n_pairs, b.n_pieces, b.n_refs, b.n_mask_u32)
     assert a.pieces.tobytes() == b.pieces.tobytes()
@@ -51,6 +63,32 @@ def test_emulated_device_stages_equal_the_host_front_end_on_every_fixture(name):
     same_batch(host, emu, len(fx["_locus"].backbone))
 
 
+@pytest.mark.parametrize("name", gu.ALL + gu.LEAN)
+def test_emulated_record_route_equals_the_host_front_end_on_every_fixture(name, tmp_path):
+    """Fields, record filters and key grouping emulated too -- from SAM text, a SAM file, a name-grouped BAM and a coordinate-sorted
+    BAM with regions (the BAM records are read in binary: CIGAR words, packed SEQ)."""
+    from hisatgenotype_amd import bamio
+    fx = gu.load(name)
+    o = fx["options"]
+    loc = fx["_locus"]
+    pl = hl.PackedLocus.from_synth(loc)
+    kw = dict(num_editdist=o["num_editdist"], error_correction=o["error_correction"], allow_discordant=o["allow_discordant"],
+              simulation=o["simulation"])
+    host = pl.parse_sam(fx["sam"], **kw)
+    want = (1, 1) if name == "codis_d18s51" else (0, 0)
+    emu, dec = emulated_records(pl, sam=fx["sam"], **kw)
+    assert dec == want, dec
+    same_batch(host, emu, len(loc.backbone))
+    p_sam, p_bam, p_sorted = str(tmp_path / "r.sam"), str(tmp_path / "r.bam"), str(tmp_path / "s.bam")
+    open(p_sam, "w").write(fx["sam"])
+    bamio.write_bam_native(p_bam, fx["sam"].encode(), [(loc.ref_allele, len(loc.backbone))])
+    bamio.write_bam_native(p_sorted, fx["sam"].encode(), [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
+    for path in (p_sam, p_bam, p_sorted):
+        emu, dec = emulated_records(pl, path=path, regions=loc.ref_allele, **kw)
+        assert dec == want, (path, dec)
+        same_batch(host, emu, len(loc.backbone))
+
+
 def test_emulated_device_stages_on_fuzz_cases():
     """The cases of tools/fuzz_parity.py (HLA-like loci with deletions / insertions / unlinked variants, STR loci, sequencing
     errors, soft clips, novel indels, multi-hit and duplicate records, single-end samples) plus deeper samples of the fast generator."""
@@ -58,8 +96,8 @@ def test_emulated_device_stages_on_fuzz_cases():
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_parity
-    n_dev = n_all = 0
-    why = {}
+    n_dev = n_all = n_rec = 0
+    why, why_rec = {}, {}
     for k in range(int(os.environ.get("HGX_FRONT_FUZZ", "120"))):
         loc, sam, single = fuzz_parity.make_case(770000, k, 1 + k % 3)
         pl = hl.PackedLocus.from_synth(loc)
@@ -75,6 +113,10 @@ def test_emulated_device_stages_on_fuzz_cases():
             n_dev += declined == 0
             why[declined] = why.get(declined, 0) + 1
             same_batch(host, emu, len(loc.backbone))
+            emu, dec = emulated_records(pl, sam=sam, error_correction=ec, allow_discordant=single)
+            n_rec += dec[0] == 0
+            why_rec[dec[0]] = why_rec.get(dec[0], 0) + 1
+            same_batch(host, emu, len(loc.backbone))
         pl.close()
     rng = random.Random(20261003)
     for _ in range(6):
@@ -89,5 +131,5 @@ def test_emulated_device_stages_on_fuzz_cases():
         n_dev += declined == 0
         why[declined] = why.get(declined, 0) + 1
         same_batch(host, emu, len(loc.backbone))
-    print("device stages took %d of %d inputs; decline codes %s" % (n_dev, n_all, why))
+    print("device stages took %d of %d inputs; decline codes %s; record route %d, decline codes %s" % (n_dev, n_all, why, n_rec, why_rec))
     assert n_dev >= 0.8 * n_all, (n_dev, n_all, why)

@@ -37,17 +37,41 @@ def test_device_front_end_equals_the_host_front_end_on_every_fixture(name):
     kw = dict(num_editdist=o["num_editdist"], error_correction=o["error_correction"], allow_discordant=o["allow_discordant"],
               simulation=o["simulation"])
     host = pl.parse_sam(fx["sam"], **kw)
-    with engine.test_switches(front_device=1):             # (the fixtures are smaller than the size gate)
-        dev = pl.parse_sam_dev(fx["sam"], **kw)
-        ran, code = engine.front_last()
-    if name == "codis_d18s51":
-        assert (ran, code) == (False, 1)                   # choose_pairs (typing_core.py:1547-1552) stays on the host
-    else:
-        assert ran and code == 0, code
-    assert (dev.n_reads, dev.n_pairs, dev.n_pieces, dev.n_refs) == (host.n_reads, host.n_pairs, host.n_pieces, host.n_refs)
-    same_batch(host, dev.to_host(), len(fx["_locus"].backbone), pileup=ran)
-    hd = engine.DeviceBatch(host)                          # the byte-model inputs of the bench line agree too
-    assert (dev.sum_piece_words, dev.n_gene_refs) == (hd.sum_piece_words, hd.n_gene_refs)
+    hd = engine.DeviceBatch(host)
+    for switches, want in ((dict(front_device=1), 2), (dict(front_device=1, front_keys_only=1), 1)):
+        with engine.test_switches(**switches):             # (the fixtures are smaller than the size gate)
+            dev = pl.parse_sam_dev(fx["sam"], **kw)
+            route, code = engine.front_last()
+        if name == "codis_d18s51":
+            assert (route, code) == (0, 1)                 # choose_pairs (typing_core.py:1547-1552) stays on the host
+        else:
+            assert (route, code) == (want, 0), (route, code)
+        assert (dev.n_reads, dev.n_pairs, dev.n_pieces, dev.n_refs) == (host.n_reads, host.n_pairs, host.n_pieces, host.n_refs)
+        same_batch(host, dev.to_host(), len(fx["_locus"].backbone), pileup=route > 0)
+        assert (dev.sum_piece_words, dev.n_gene_refs) == (hd.sum_piece_words, hd.n_gene_refs)   # the byte-model inputs of the bench line
+
+
+@pytest.mark.parametrize("name", gu.ALL)
+def test_record_route_on_files(name, tmp_path):
+    """SAM file, name-grouped BAM, coordinate-sorted BAM with regions: the device parses the records (BAM: binary CIGAR, packed SEQ)."""
+    from hisatgenotype_amd import bamio
+    fx = gu.load(name)
+    o = fx["options"]
+    loc = fx["_locus"]
+    pl = hl.PackedLocus.from_synth(loc)
+    kw = dict(num_editdist=o["num_editdist"], error_correction=o["error_correction"], allow_discordant=o["allow_discordant"],
+              simulation=o["simulation"])
+    host = pl.parse_sam(fx["sam"], **kw)
+    p_sam, p_bam, p_sorted = str(tmp_path / "r.sam"), str(tmp_path / "r.bam"), str(tmp_path / "s.bam")
+    open(p_sam, "w").write(fx["sam"])
+    bamio.write_bam_native(p_bam, fx["sam"].encode(), [(loc.ref_allele, len(loc.backbone))])
+    bamio.write_bam_native(p_sorted, fx["sam"].encode(), [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
+    for path in (p_sam, p_bam, p_sorted):
+        with engine.test_switches(front_device=1):
+            dev = pl.parse_alignment_file_dev(path, regions=[loc.ref_allele], **kw)
+            route, code = engine.front_last()
+        assert (route, code) == ((0, 1) if name == "codis_d18s51" else (2, 0)), (path, route, code)
+        same_batch(host, dev.to_host(), len(loc.backbone), pileup=route > 0)
 
 
 def test_size_gate_and_switches():
@@ -55,11 +79,11 @@ def test_size_gate_and_switches():
     pl = hl.PackedLocus.from_synth(fx["_locus"])
     host = pl.parse_sam(fx["sam"], simulation=True)
     dev = pl.parse_sam_dev(fx["sam"], simulation=True)
-    assert engine.front_last() == (False, 6)               # a few hundred records: the host stages finish the job
+    assert engine.front_last() == (0, 6)                   # a few hundred records: the host stages finish the job
     same_batch(host, dev.to_host(), len(fx["_locus"].backbone), pileup=False)
     with engine.test_switches(front_host=1):
         dev = pl.parse_sam_dev(fx["sam"], simulation=True)
-        assert engine.front_last() == (False, -1)
+        assert engine.front_last() == (0, -1)
     same_batch(host, dev.to_host(), len(fx["_locus"].backbone), pileup=False)
 
 
@@ -78,13 +102,14 @@ def test_device_front_end_on_fuzz_cases():
                 with engine.test_switches(front_device=1), pytest.raises(capi.HgxError):
                     pl.parse_sam_dev(sam, error_correction=ec, allow_discordant=single)
                 continue
-            with engine.test_switches(front_device=1):
-                dev = pl.parse_sam_dev(sam, error_correction=ec, allow_discordant=single)
-                ran, code = engine.front_last()
-            n_all += 1
-            n_dev += ran
-            why[code] = why.get(code, 0) + 1
-            same_batch(host, dev.to_host(), len(loc.backbone), pileup=ran)
+            for extra in ({}, {"front_keys_only": 1}):
+                with engine.test_switches(front_device=1, **extra):
+                    dev = pl.parse_sam_dev(sam, error_correction=ec, allow_discordant=single)
+                    ran, code = engine.front_last()
+                n_all += 1
+                n_dev += ran > 0
+                why[(ran, code)] = why.get((ran, code), 0) + 1
+                same_batch(host, dev.to_host(), len(loc.backbone), pileup=ran > 0)
         pl.close()
     print("device stages took %d of %d inputs; decline codes %s" % (n_dev, n_all, why))
     assert n_dev >= 0.8 * n_all, (n_dev, n_all, why)
@@ -102,7 +127,11 @@ def test_device_front_end_on_deep_samples_and_files(tmp_path, n_pairs, err):
     pl = hl.PackedLocus.from_synth(loc)
     host = pl.parse_sam(sam)
     dev = pl.parse_sam_dev(sam)
-    assert engine.front_last() == (True, 0)
+    assert engine.front_last() == (2, 0)
+    same_batch(host, dev.to_host(), len(loc.backbone))
+    with engine.test_switches(front_keys_only=1):
+        dev = pl.parse_sam_dev(sam)
+        assert engine.front_last() == (1, 0)
     same_batch(host, dev.to_host(), len(loc.backbone))
     p_sam = str(tmp_path / "r.sam")
     open(p_sam, "w").write(sam)
@@ -111,14 +140,14 @@ def test_device_front_end_on_deep_samples_and_files(tmp_path, n_pairs, err):
     bamio.write_bam_native(p_sorted, sam.encode(), [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
     for path in (p_sam, p_bam, p_sorted):
         d2 = pl.parse_alignment_file_dev(path, regions=[loc.ref_allele])
-        assert engine.front_last() == (True, 0), path
+        assert engine.front_last() == (2, 0), path
         same_batch(host, d2.to_host(), len(loc.backbone))
     ref = hgx.type_locus(pl, sam)
     for path in (p_sam, p_sorted):
         res = hgx.type_file(pl, path) if hasattr(hgx, "type_file") else None
         if res is None:
             break
-        assert engine.front_last() == (True, 0)
+        assert engine.front_last() == (2, 0)
         assert (res.num_reads, res.num_pairs) == (ref.num_reads, ref.num_pairs)
         assert res.counts_sorted == ref.counts_sorted and res.gene_prob == ref.gene_prob
         assert [e["n_iter"] for e in res.em] == [e["n_iter"] for e in ref.em]
