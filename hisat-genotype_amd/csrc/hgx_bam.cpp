@@ -512,6 +512,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             if (region_hit(regs[g], f[1], rl, pos0, end0)) { Line l; make_line(p, len, l); mine[g].push_back(l); }
     };
     std::vector<std::vector<std::vector<Line>>> text_part;      // [worker][region] line lists of a SAM text
+    bool on_raw_done = false;
     int text_nt = 0;
     bool text_scanned = false;
     Bytes data;
@@ -530,13 +531,19 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             // Big SAM text: every worker reads its byte range in 1 MB pieces and scans each piece for lines while it is still in
             // its cache (the separate scan of the whole text was a second trip through 400 MB of DRAM).  A worker owns the lines
             // that START in its range; the one that runs over the end of the range is finished after all ranges are in.
-            text_nt = n_threads;
+            // With an upload waiting (out.on_raw: the device front end) the file is read in a few phases, and each phase's bytes are
+            // handed over while the next phase is read: the transfer hides behind the read.
+            const int n_phase = (out.on_raw && data.size() > (64u << 20)) ? 4 : 1;
+            text_nt = n_threads * n_phase;
             text_part.assign(text_nt, std::vector<std::vector<Line>>(n_reg));
             std::vector<size_t> tail((size_t)text_nt, (size_t)-1);
             char *base = (char *)data.data();
             const size_t total = data.size();
-            par_for(text_nt, total, [&](int t, size_t b0, size_t e0) {
-                std::vector<std::vector<Line>> &mine = text_part[t];
+            for (int ph = 0; ph < n_phase; ++ph) {
+            const size_t ph_b = total * (size_t)ph / n_phase, ph_e = total * (size_t)(ph + 1) / n_phase;
+            par_for(n_threads, ph_e - ph_b, [&](int t, size_t rb0, size_t re0) {
+                const size_t b0 = ph_b + rb0, e0 = ph_b + re0;
+                std::vector<std::vector<Line>> &mine = text_part[ph * n_threads + t];
                 if (!filtered) mine[0].reserve((e0 - b0) / 300 + 16);
                 unsigned char prev = '\n';
                 if (b0 > 0 && pread(fd, &prev, 1, (off_t)(b0 - 1)) != 1) { bad[t] = 1; return; }
@@ -566,8 +573,13 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
                         p = e + 1;
                     }
                 }
-                if (!skipping && p < base + e0) tail[t] = (size_t)(p - base);
+                if (!skipping && p < base + e0) tail[ph * n_threads + t] = (size_t)(p - base);
             });
+            bool any_bad = false;
+            for (int v : bad) any_bad = any_bad || v;
+            if (any_bad) break;
+            if (out.on_raw) { out.on_raw(base, total, ph_b, ph_e); on_raw_done = true; }
+            }
             close(fd);
             for (int v : bad) if (v) { hgx_set_error("short read on %s", path); return HGX_EINVAL; }
             for (int t = 0; t < text_nt; ++t)
@@ -597,7 +609,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         data.release();
     } else raw.swap(data);
     lap("inflate");
-    if (out.on_raw) out.on_raw((const char *)raw.data(), raw.size());       // (the device front end's upload starts here)
+    if (out.on_raw && !on_raw_done) out.on_raw((const char *)raw.data(), raw.size(), 0, raw.size());       // (the device front end's upload starts here)
     LineVec &lines = out.lines;
     lines.clear();
     if (raw.size() >= 4 && memcmp(raw.data(), "BAM\1", 4) == 0) {
@@ -838,7 +850,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         for (size_t g = 0; g < n_reg; ++g)
             for (int t = 0; t < nt; ++t) { off[g * nt + t] = tot; tot += part[t][g].size(); }
         lines.resize(tot);
-        par_for(nt, (size_t)nt, [&](int, size_t b, size_t e) {
+        par_for(std::min(nt, n_threads), (size_t)nt, [&](int, size_t b, size_t e) {
             for (size_t t = b; t < e; ++t)
                 for (size_t g = 0; g < n_reg; ++g)
                     if (!part[t][g].empty()) memcpy(&lines[off[g * nt + t]], part[t][g].data(), part[t][g].size() * sizeof(Line));

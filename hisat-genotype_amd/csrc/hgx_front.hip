@@ -51,9 +51,14 @@ void *pinned_alloc(size_t n) {
             return p;
         }
     }
+    // ordinary (first-touch, huge-page eligible) memory registered with the runtime: the host's workers fill it at malloc speed --
+    // tools/pinned_probe.hip: 185 GB/s against 130 GB/s into hipHostMalloc memory, and pread() into the latter took twice as long --
+    // and it travels at the same 57 GB/s.  Registering costs ~0.1 ms per MB: blocks are kept for the life of the process.
     need += need / 8;
-    void *p = nullptr;
-    if (hipHostMalloc(&p, need, hipHostMallocDefault) != hipSuccess) return nullptr;
+    need = (need + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+    void *p = aligned_alloc(2u << 20, need);
+    if (!p) return nullptr;
+    if (hipHostRegister(p, need, hipHostRegisterDefault) != hipSuccess) { free(p); return nullptr; }
     std::lock_guard<std::mutex> g(P.mu);
     P.size_of[p] = need;
     return p;
@@ -354,13 +359,13 @@ __global__ void __launch_bounds__(256) k_fe_pair_emit(const uint32_t *__restrict
 // ---- the record stage (row 8a-1): fields, filters, key grouping -----------------------------------------------------------------
 struct LineRef { uint32_t off, len; };      // a record of the name-ordered stream: first byte (after block_size for BAM) and length
 
-__global__ void __launch_bounds__(256) k_fe_records(const char *__restrict__ text, const LineRef *__restrict__ lines, uint32_t n, int binary,
+__global__ void __launch_bounds__(256) k_fe_records(const char *__restrict__ text, size_t text_bytes, const LineRef *__restrict__ lines, uint32_t n, int binary,
                                                     int simulation, FeRec *__restrict__ recs, FeCtl *ctl) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     FeRec r;
     const int rc = binary ? fe_parse_bam_record(text, lines[i].off, lines[i].len, simulation != 0, r)
-                          : fe_parse_text_record(text, lines[i].off, lines[i].len, simulation != 0, r);
+                          : fe_parse_text_record(text, text_bytes, lines[i].off, lines[i].len, simulation != 0, r);
     if (rc < 0) { fe_decline(ctl, rc); r.bits = 0; r.flag = 4; r.id_len = 0; r.qname_off = 0; r.key = 0; }
     recs[i] = r;
 }
@@ -741,7 +746,7 @@ int records_run(hgx_locus &L, const char *d_text, const char *raw, size_t raw_by
     if (n) {
         const FeFilter flt{o.num_editdist, o.allow_discordant, o.base_locus};
         FeRec *recs = b_recs.as<FeRec>();
-        k_fe_records<<<nblk(n, 256), 256, 0, st>>>(d_text, b_lines.as<LineRef>(), n, binary ? 1 : 0, o.simulation, recs, ctl);
+        k_fe_records<<<nblk(n, 256), 256, 0, st>>>(d_text, raw_bytes + 64, b_lines.as<LineRef>(), n, binary ? 1 : 0, o.simulation, recs, ctl);
         k_fe_rec_heads<<<nblk(n, 256), 256, 0, st>>>(recs, n, d_text, b_head.as<uint8_t>());
         k_fe_rec_filter_insert<<<nblk(n, 256), 256, 0, st>>>(recs, b_head.as<uint8_t>(), n, flt, b_tkeys.as<unsigned long long>(), b_rep.as<uint32_t>(),
                                                             b_pile.as<uint32_t>(), b_anyk.as<uint32_t>(), cap - 1, b_kept.as<uint8_t>(),
@@ -808,10 +813,10 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Pars
     size_t up_bytes = 0;
     bool up_failed = false;
     if (!host_only && !no_records && !(opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange)) {
-        hook.on_raw = [&](const char *raw, size_t n_bytes) {
-            if (n_bytes >= (1ull << 32) - 64) return;
-            if (b_text.alloc(n_bytes + 64)) { up_failed = true; return; }
-            if (n_bytes && hipMemcpyAsync(b_text.p, raw, n_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { up_failed = true; return; }
+        hook.on_raw = [&](const char *raw, size_t n_bytes, size_t begin, size_t end) {
+            if (n_bytes >= (1ull << 32) - 64 || up_failed) return;
+            if (!b_text.p && b_text.alloc(n_bytes + 64)) { up_failed = true; return; }
+            if (end > begin && hipMemcpyAsync((char *)b_text.p + begin, raw + begin, end - begin, hipMemcpyHostToDevice, st) != hipSuccess) { up_failed = true; return; }
             up_raw = raw;
             up_bytes = n_bytes;
         };

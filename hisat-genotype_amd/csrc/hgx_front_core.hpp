@@ -1106,12 +1106,12 @@ FE_HD inline int32_t fe_strtol32(const unsigned char *t, int n) {
     for (; i < n && t[i] >= '0' && t[i] <= '9'; ++i) { v = v * 10 + (t[i] - '0'); if (v > 0x7fffffffll) v = 0x7fffffffll; }
     return (int32_t)(neg ? -v : v);
 }
+// (8 bytes per load: the compiler emits one unaligned dwordx2 load on gfx950, one mov on x86; both little endian)
+FE_HD inline uint64_t fe_load8(const unsigned char *p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
 FE_HD inline uint64_t fe_hash_bytes(const unsigned char *p, int n, uint64_t h) {
     int i = 0;
     for (; i + 8 <= n; i += 8) {
-        uint64_t w = 0;
-        for (int k = 0; k < 8; ++k) w |= (uint64_t)p[i + k] << (8 * k);
-        h = (h ^ w) * 0x9E3779B97F4A7C15ull;
+        h = (h ^ fe_load8(p + i)) * 0x9E3779B97F4A7C15ull;
         h ^= h >> 32;
     }
     uint64_t w = 0;
@@ -1138,7 +1138,9 @@ FE_HD inline uint64_t fe_rec_key(const FeRec &r, const char *text) {
     return h == ~0ull ? 0 : h;                                      // (all ones = the hash table's empty slot)
 }
 FE_HD inline bool fe_bytes_equal(const unsigned char *a, const unsigned char *b, int n) {
-    for (int i = 0; i < n; ++i) if (a[i] != b[i]) return false;
+    int i = 0;
+    for (; i + 8 <= n; i += 8) if (fe_load8(a + i) != fe_load8(b + i)) return false;
+    for (; i < n; ++i) if (a[i] != b[i]) return false;
     return true;
 }
 FE_HD inline bool fe_rec_same_key(const FeRec &a, const FeRec &b, const char *text) {      // same_decode_key of hgx_sam.cpp
@@ -1157,8 +1159,10 @@ FE_HD inline bool fe_rec_same_key(const FeRec &a, const FeRec &b, const char *te
     return fe_bytes_equal(t + a.zs_off, t + b.zs_off, a.zs_len) && fe_bytes_equal(t + a.md_off, t + b.md_off, a.md_len);
 }
 
-// one line of SAM text (without its line end) -> FeRec.  The tab-only split of split_line; anything else declines.
-FE_HD inline int fe_parse_text_record(const char *text, uint32_t off, uint32_t len, bool simulation, FeRec &r) {
+// one line of SAM text (without its line end) -> FeRec.  The tab-only split of split_line; anything else declines.  The line is
+// scanned eight bytes at a time (a word without tab, blank or CR -- most of SEQ and QUAL -- is skipped whole); `text_bytes` = size
+// of the buffer, so that no load reaches past it.
+FE_HD inline int fe_parse_text_record(const char *text, size_t text_bytes, uint32_t off, uint32_t len, bool simulation, FeRec &r) {
     const unsigned char *line = (const unsigned char *)text + off;
     r.bits = 0;
     r.nm = r.nh = 0;
@@ -1167,37 +1171,59 @@ FE_HD inline int fe_parse_text_record(const char *text, uint32_t off, uint32_t l
     r.pad_ = 0;
     uint32_t col_at[11], col_len[11];
     int nc = 0;
-    uint32_t p = 0;
-    while (p < len) {
-        uint32_t q = p;
-        while (q < len && line[q] != '\t') {
-            if (line[q] == ' ' || line[q] == '\r') return FE_FAIL(FE_E_ASSERT);       // the reference's split() cuts there too: host
-            ++q;
+    uint32_t p = 0, tok = 0;
+    const uint32_t safe = (size_t)off + len + 8 <= text_bytes ? len : (len >= 8 ? len - 8 : 0);      // words may start below `safe`
+    const uint64_t ones = 0x0101010101010101ull, highs = 0x8080808080808080ull;
+    for (;;) {
+        bool at_end = p >= len;
+        if (!at_end && p < safe) {
+            const uint64_t w = fe_load8(line + p);
+            const uint64_t xt = w ^ (ones * 0x09), xs = w ^ (ones * 0x20), xr = w ^ (ones * 0x0d);
+            const uint64_t hit = (((xt - ones) & ~xt) | ((xs - ones) & ~xs) | ((xr - ones) & ~xr)) & highs;
+            uint32_t clean = 8;                                     // bytes of the word before the first tab / blank / CR
+            if (hit) {
+                uint32_t k = 0;
+                uint64_t m = hit;
+                while (!(m & 0xff)) { m >>= 8; ++k; }
+                clean = k;
+            }
+            if (p + clean > len) clean = len - p;                   // (bytes past the line's end are somebody else's)
+            p += clean;
+            if (clean == 8 || p >= len) { if (p < len) continue; at_end = true; }
         }
-        if (q > p) {
-            const uint32_t tl = q - p;
-            if (nc < 11) { col_at[nc] = p; col_len[nc] = tl; nc++; }
+        unsigned char c = 0;
+        if (!at_end) {
+            c = line[p];
+            if (c == ' ' || c == '\r') return FE_FAIL(FE_E_ASSERT);       // the reference's split() cuts there too: the host's business
+            if (c != '\t') { ++p; continue; }
+        }
+        // a token ends at p (a tab, or the line's end)
+        if (p > tok) {
+            const uint32_t tl = p - tok;
+            if (nc < 11) { col_at[nc] = tok; col_len[nc] = tl; nc++; }
             else {                                                                  // note_tag
-                const unsigned char *tok = line + p;
+                const unsigned char *t = line + tok;
                 if (tl < 5) {
-                    if (tl >= 2 && tok[0] == 'Z' && tok[1] == 's') { r.bits |= FE_R_HAS_ZS; r.zs_off = off + q; r.zs_len = 0; }
-                    else if (tl >= 2 && tok[0] == 'M' && tok[1] == 'D') { r.bits |= FE_R_HAS_MD; r.md_off = off + q; r.md_len = 0; }
-                    else if (tl >= 2 && tok[0] == 'N' && (tok[1] == 'M' || tok[1] == 'H')) return FE_FAIL(FE_E_ASSERT);   // int('') raises
-                } else if (tok[0] == 'Z' && tok[1] == 's') {
+                    if (tl >= 2 && t[0] == 'Z' && t[1] == 's') { r.bits |= FE_R_HAS_ZS; r.zs_off = off + p; r.zs_len = 0; }
+                    else if (tl >= 2 && t[0] == 'M' && t[1] == 'D') { r.bits |= FE_R_HAS_MD; r.md_off = off + p; r.md_len = 0; }
+                    else if (tl >= 2 && t[0] == 'N' && (t[1] == 'M' || t[1] == 'H')) return FE_FAIL(FE_E_ASSERT);   // int('') raises
+                } else if (t[0] == 'Z' && t[1] == 's') {
                     if (tl - 5 > 65535) return FE_FAIL(FE_E_CAP);
-                    r.bits |= FE_R_HAS_ZS; r.zs_off = off + p + 5; r.zs_len = (uint16_t)(tl - 5);
-                } else if (tok[0] == 'M' && tok[1] == 'D') {
+                    r.bits |= FE_R_HAS_ZS; r.zs_off = off + tok + 5; r.zs_len = (uint16_t)(tl - 5);
+                } else if (t[0] == 'M' && t[1] == 'D') {
                     if (tl - 5 > 65535) return FE_FAIL(FE_E_CAP);
-                    r.bits |= FE_R_HAS_MD; r.md_off = off + p + 5; r.md_len = (uint16_t)(tl - 5);
-                } else if (tok[0] == 'N' && (tok[1] == 'M' || tok[1] == 'H')) {
-                    if (!fe_py_int_ok(tok + 5, (int)tl - 5)) return FE_FAIL(FE_E_ASSERT);
-                    const int32_t v = fe_strtol32(tok + 5, (int)tl - 5);
-                    if (tok[1] == 'M') { r.bits |= FE_R_HAS_NM; r.nm = v; }
+                    r.bits |= FE_R_HAS_MD; r.md_off = off + tok + 5; r.md_len = (uint16_t)(tl - 5);
+                } else if (t[0] == 'N' && (t[1] == 'M' || t[1] == 'H')) {
+                    if (!fe_py_int_ok(t + 5, (int)tl - 5)) return FE_FAIL(FE_E_ASSERT);
+                    const int32_t v = fe_strtol32(t + 5, (int)tl - 5);
+                    if (t[1] == 'M') { r.bits |= FE_R_HAS_NM; r.nm = v; }
                     else { r.bits |= FE_R_HAS_NH; r.nh = v; }
                 }
             }
         }
-        p = q + 1;
+        if (at_end) break;
+        ++p;
+        tok = p;
     }
     if (nc < 11) return FE_FAIL(FE_E_ASSERT);
     if (!fe_py_int_ok(line + col_at[1], (int)col_len[1]) || !fe_py_int_ok(line + col_at[3], (int)col_len[3])) return FE_FAIL(FE_E_ASSERT);

@@ -227,7 +227,7 @@ int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, si
     for (size_t i = 0; i < n; ++i) {
         const uint32_t off = (uint32_t)(lines[i].p - raw) - (binary ? 32u : 0u);
         const int r = binary ? fe_parse_bam_record(raw, off, lines[i].len, o.simulation != 0, recs[i])
-                             : fe_parse_text_record(raw, off, lines[i].len, o.simulation != 0, recs[i]);
+                             : fe_parse_text_record(raw, raw_bytes, off, lines[i].len, o.simulation != 0, recs[i]);
         if (r < 0) { *declined = -r; return HGX_OK; }
     }
     std::vector<uint8_t> head(n, 0), kept(n, 0), pm(n, 0);

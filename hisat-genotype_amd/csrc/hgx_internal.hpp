@@ -177,9 +177,10 @@ struct hgx_align_lines {
     bool binary = false;
     std::vector<std::string> ref_names;
     size_t raw_bytes = 0;
-    // called once, as soon as the bytes the line table will point into are complete (SAM text read / BAM stream inflated) and
-    // before the record walk and the name sort: the device front end starts its upload there
-    std::function<void(const char *raw, size_t n_bytes)> on_raw;
+    // called as soon as bytes the line table will point into are complete -- a big SAM text in a few consecutive ranges while it is
+    // read, a BAM stream once, when it is inflated and before the record walk and the name sort: the device front end uploads
+    // [begin, end) of the n_bytes at `raw` there
+    std::function<void(const char *raw, size_t n_bytes, size_t begin, size_t end)> on_raw;
     hgx_align_lines() = default;
     hgx_align_lines(const hgx_align_lines &) = delete;
     hgx_align_lines &operator=(const hgx_align_lines &) = delete;
@@ -252,7 +253,7 @@ struct hgx_front_hook {
     // (and `run` gets its chance after them).
     std::function<int(hgx_locus &, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &,
                       int *declined)> records;
-    std::function<void(const char *raw, size_t n_bytes)> on_raw;
+    std::function<void(const char *raw, size_t n_bytes, size_t begin, size_t end)> on_raw;
     int declined_records = 0;
 };
 int hgx_parse_sam_hook(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, hgx_front_hook *hook);

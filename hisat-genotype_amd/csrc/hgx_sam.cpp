@@ -1784,7 +1784,7 @@ int hgx_parse_sam_hook(hgx_batch **out, const hgx_locus *Lc, const char *sam, si
             for (size_t t = b; t < e; ++t)
                 if (!part[t].empty()) memcpy(&lines[off[t]], part[t].data(), part[t].size() * sizeof(hgx_line));
         });
-        if (hook && hook->on_raw) hook->on_raw(base, n_bytes);
+        if (hook && hook->on_raw) hook->on_raw(base, n_bytes, 0, n_bytes);
         return parse_lines(out, Lc, lines.data(), lines.size(), opts, false, hook, base, n_bytes);
     } catch (const std::exception &e) {
         hgx_set_error("%s", e.what());
