@@ -12,6 +12,7 @@ Prints ONE JSON line on rank 0 (see DESIGN.md section 6 for the byte model behin
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -75,6 +76,7 @@ from hisatgenotype_amd import locus as hl  # noqa: E402
 N_TIMED_STEPS = 2         # steps (the last ones) whose EM mat-vec launches are all timed
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 LDS_READ_B32_PEAK_GBS = 75000.0   # aggregate ds_read_b32 rate with every CU streaming (MI355X_MICROARCH.md, LDS section)
+PCIE_H2D_GBS = 57.5               # host -> device rate of registered host memory on the GPU box (tools/pinned_probe.hip)
 
 
 def parse_args():
@@ -88,7 +90,10 @@ def parse_args():
     ap.add_argument("--err", type=float, default=0.002)
     ap.add_argument("--cpu-pairs", type=int, default=20000, help="pairs of the same workload timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-e2e", action="store_true", help="skip the file -> result measurement (SAM text and BAM)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the file -> result measurements (SAM text and BAM; the N-process leg; the workloads' file legs)")
+    ap.add_argument("--e2e-procs", default="1,2,4,8",
+                    help="file -> result with N processes sharing GPU 0 (one sample stream each): the host-scaling leg of the default run; '' skips it")
+    ap.add_argument("--e2e-child", default=None, help=argparse.SUPPRESS)      # internal: one process of that leg (a JSON job description)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (profiling runs)")
     ap.add_argument("--workload", choices=["configs1", "class1", "panel64"], default="configs1",
                     help="configs1 (default; BASELINE.json configs[1]: one HLA-A sample of 1 M reads per GPU), class1 (configs[2]: "
@@ -358,7 +363,16 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
             med = sorted(times)[len(times) // 2]
             med_s = sorted(spaced)[len(spaced) // 2]
             cpu_s = (ru1.ru_utime + ru1.ru_stime - ru0.ru_utime - ru0.ru_stime) / runs
+            route, code = engine.front_last()
+            sent = engine.front_last_bytes()
             out[kind] = {"reads_per_s": round(res.num_reads / med_s, 1), "ms": round(med_s * 1e3, 2), "best_ms": round(min(spaced) * 1e3, 2),
+                         "front_end": {"route": {2: "record route: fields, filters, key grouping, pileup, decode, piece table, pair protocol as kernels",
+                                                 1: "key route: host tokenises / filters / groups, the rest as kernels",
+                                                 0: "host stages"}[route], "decline_code": code, "bytes_to_device": sent},
+                         "roofline": {"bound": "pcie", "achieved": round(sent / med_s / 1e9, 2), "peak": PCIE_H2D_GBS, "unit": "GB/s",
+                                      "frac": round(sent / med_s / 1e9 / PCIE_H2D_GBS, 4),
+                                      "note": "bytes the call sends to the device (SAM text / inflated BAM stream + line table) / the call's time, against "
+                                              "the measured host-to-device rate of registered memory (tools/pinned_probe.hip: 57.5 GB/s; PCIe Gen5 x16)"},
                          "runs_ms": [round(t * 1e3, 1) for t in spaced],
                          "throttled_ms": None if th1 is None else round((th2 - th1) / 1e3, 1),
                          "cpu_seconds_per_call": round(cpu_s, 3),
@@ -378,6 +392,116 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
                    "same calls without a pause (a sample stream: bound by the CPU seconds the container's cgroup grants -- %s CPUs, "
                    "whatever the number of hardware threads; throttled_ms = time the cgroup froze the process during those calls)."
                    % (runs, "%.0f" % quota if quota else "all"))
+    return out
+
+
+# ---- file -> result with N processes sharing one GPU: how far does the HOST side scale? ----------------------------------------
+# The reference's unit of scale is one process per sample (/root/reference/hisatgenotype:613-665).  N fresh child processes, started
+# BEFORE this process touches the GPU, each type their own copy of the sample file K times back to back against GPU 0 after a
+# warm-up call; they start together (a "go" file) and report their call times, CPU seconds and end time.  samples/s = N * K / (last
+# end - go).
+def _e2e_child(job_json):
+    import ctypes as C
+    import resource
+    job = json.loads(job_json)
+    pl = hl.PackedLocus.load_cache(job["cache"])
+    capi.set_device(0)
+    pl.index()
+    L = capi.lib()
+
+    def one_call():
+        o = capi.ParseOpts(2, 1, 0, 0, 0, 0, 0, 0)
+        to = htyping.TypeOpts(1, 0, -1, 0, None, None, None, None, None)
+        h = C.c_void_p()
+        t0 = time.perf_counter()
+        capi.check(L.hgx_type_file(C.byref(h), pl.h, pl.index(), job["path"].encode(), pl.ref_allele.encode(), C.byref(o), C.byref(to), None))
+        dt = time.perf_counter() - t0
+        nr = C.c_int32()
+        capi.check(L.hgx_typing_dims(h, C.byref(nr), None, None, None, None, None, None, None))
+        L.hgx_typing_destroy(h)
+        return dt, nr.value
+    one_call()
+    one_call()
+    open(os.path.join(job["sync"], "ready_%d" % job["idx"]), "w").close()
+    go = os.path.join(job["sync"], "go")
+    while not os.path.exists(go):
+        time.sleep(0.0005)
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    times, reads = [], 0
+    for _ in range(job["calls"]):
+        dt, nr = one_call()
+        times.append(dt)
+        reads += nr
+    end = time.time()
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    route, code = engine.front_last()
+    print(json.dumps({"idx": job["idx"], "times": times, "reads": reads, "end": end, "route": route, "decline_code": code,
+                      "cpu_s": ru1.ru_utime + ru1.ru_stime - ru0.ru_utime - ru0.ru_stime}))
+
+
+def e2e_scaling(loc, sam, procs, calls=6):
+    """The host-scaling leg (parent side; no GPU call in this process yet).  Returns the `e2e_scaling` object of the JSON line."""
+    import shutil
+    import tempfile
+    from hisatgenotype_amd import bamio
+    d = tempfile.mkdtemp(prefix="hgx_e2e_procs_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    out = {"calls_per_process": calls, "host": {"hw_threads": os.cpu_count(), "cgroup_cpu_quota": cgroup_cpu_quota()}, "bam": {}, "sam": {}}
+    try:
+        pl = hl.PackedLocus.from_synth(loc)                     # (host tables only: no device index is made here)
+        cache = os.path.join(d, "locus.npz")
+        pl.save_cache(cache)
+        data = sam.encode()
+        n_records = data.count(b"\n")
+        paths = {"sam": os.path.join(d, "reads.sam"), "bam": os.path.join(d, "reads.bam")}
+        with open(paths["sam"], "wb") as f:
+            f.write(data)
+        bamio.write_bam_native(paths["bam"], data, [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
+        del data
+        for kind in ("bam", "sam"):
+            for n in procs:
+                sync = tempfile.mkdtemp(prefix="sync_", dir=d)
+                files = []
+                for i in range(n):                              # every process its own file (BAM: a copy; SAM text: one 400 MB file, shared)
+                    if kind == "bam":
+                        fp = os.path.join(sync, "reads_%d.bam" % i)
+                        shutil.copyfile(paths["bam"], fp)
+                    else:
+                        fp = paths["sam"]
+                    files.append(fp)
+                kids = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--e2e-child",
+                                          json.dumps({"cache": cache, "path": files[i], "sync": sync, "idx": i, "calls": calls})],
+                                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for i in range(n)]
+                t_wait = time.time()
+                while sum(os.path.exists(os.path.join(sync, "ready_%d" % i)) for i in range(n)) < n:
+                    if any(k.poll() is not None for k in kids) or time.time() - t_wait > 300:
+                        break
+                    time.sleep(0.005)
+                th0 = cgroup_throttled_usec()
+                go = time.time()
+                open(os.path.join(sync, "go"), "w").close()
+                res = []
+                for k in kids:
+                    so, se = k.communicate(timeout=600)
+                    if k.returncode != 0:
+                        raise RuntimeError("e2e child failed: " + se[-2000:])
+                    res.append(json.loads(so.strip().splitlines()[-1]))
+                th1 = cgroup_throttled_usec()
+                wall = max(r["end"] for r in res) - go
+                all_t = sorted(t for r in res for t in r["times"])
+                out[kind][str(n)] = {"processes": n, "calls": n * calls, "wall_s": round(wall, 4),
+                                     "samples_per_s": round(n * calls / wall, 2), "reads_per_s": round(sum(r["reads"] for r in res) / wall, 1),
+                                     "ms_per_call_median": round(all_t[len(all_t) // 2] * 1e3, 2),
+                                     "cpu_seconds_per_call": round(sum(r["cpu_s"] for r in res) / (n * calls), 3),
+                                     "throttled_ms": None if th0 is None else round((th1 - th0) / 1e3, 1),
+                                     "front_end_route": sorted(set(r["route"] for r in res))}
+                shutil.rmtree(sync, ignore_errors=True)
+        out["records_per_sample"] = n_records
+        out["note"] = ("N processes (started before the parent touched the GPU), each typing its own copy of the sample file %d times back to back "
+                       "through hgx_type_file against GPU 0 after two warm-up calls; samples_per_s = N x %d / (last end - common start).  The GPU "
+                       "work of a call is ~7 ms (device front end + typing): beyond that the sample rate is bound by the CPU seconds the "
+                       "container's cgroup grants (cpu_seconds_per_call x samples_per_s vs the quota)." % (calls, calls))
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
     return out
 
 
@@ -430,12 +554,22 @@ def run_class1(args, rank, local_rank, world, dist):
                     comms[i] = hdist.TorchComm(g)
     mine = [i for i in sorted(groups) if rank in groups[i]]
     work = []
+    want_files = world == 1 and dist is None and not args.no_e2e
+    file_of, file_dir = {}, None
+    if want_files:
+        import tempfile
+        file_dir = tempfile.mkdtemp(prefix="hgx_class1_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     for i in mine:
         loc = loci[i]
         pl = hl.PackedLocus.from_synth(loc)
         pl.index()
         sample = synth.pick_sample(loc, 101 + i)
         sam = synth.simulate_sam_fast(loc, sample, args.pairs, err_rate=args.err, seed=100 + i)
+        if want_files:
+            from hisatgenotype_amd import bamio
+            fp = os.path.join(file_dir, "%s.bam" % loc.gene)
+            bamio.write_bam_native(fp, sam.encode(), [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
+            file_of[i] = fp
         if i in comms:
             shard_text = hdist.split_name_grouped(sam, len(groups[i]))[groups[i].index(rank)]
             batch = pl.parse_sam(shard_text, pileup_exchange=comms[i].allreduce_sum)
@@ -531,6 +665,44 @@ def run_class1(args, rank, local_rank, world, dist):
         allc = [None] * world
         dist.all_gather_object(allc, calls)
         calls = {g: v for part in allc for g, v in part.items()}
+    e2e = None
+    if want_files:
+        # file -> result for the three loci: coordinate-sorted BAM files (as the reference's pipeline stores alignments) through
+        # hgx_type_file, locus after locus and side by side (a host thread per locus); the results must be the resident path's
+        import shutil
+        import threading
+        try:
+            def files_once(parallel):
+                got = {}
+
+                def one(k):
+                    i, pl = work[k][0], work[k][1]
+                    got[i] = hgx.type_file(pl, file_of[i])
+                t0 = time.perf_counter()
+                if parallel:
+                    ths = [threading.Thread(target=one, args=(k,)) for k in range(len(work))]
+                    for t in ths:
+                        t.start()
+                    for t in ths:
+                        t.join()
+                else:
+                    for k in range(len(work)):
+                        one(k)
+                return time.perf_counter() - t0, got
+            files_once(False)
+            seq = sorted(files_once(False)[0] for _ in range(3))
+            par_runs = [files_once(True) for _ in range(3)]
+            par = sorted(t for t, _ in par_runs)
+            got = par_runs[-1][1]
+            same = all(got[i].gene_prob == last[i].gene_prob and got[i].num_reads == last[i].num_reads for i in got)
+            n_r = sum(r.num_reads for r in got.values())
+            e2e = {"input": "three coordinate-sorted BAM files (%.0f MB in all)" % (sum(os.path.getsize(f) for f in file_of.values()) / 1e6),
+                   "locus_after_locus_ms": round(seq[1] * 1e3, 2), "side_by_side_ms": round(par[1] * 1e3, 2),
+                   "reads_per_s": round(n_r / min(seq[1], par[1]), 1), "result_identical_to_hbm_path": bool(same),
+                   "note": "hgx_type_file per locus: read, inflate, record walk and name sort on the host; record fields, filters, key grouping, "
+                           "pileup, decode, piece table, pair protocol and the typing path on the GPU (median of 3 after a warm-up)"}
+        finally:
+            shutil.rmtree(file_dir, ignore_errors=True)
     cb = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_cpu = 1500
@@ -549,7 +721,7 @@ def run_class1(args, rank, local_rank, world, dist):
                        "parallelism": "loci over rank groups; pairs of a locus over the ranks of its group (pileup all-reduce at parse, "
                                       "class-table all-gather + merge per step over RCCL); no other data-path collective",
                        "setup_s": round(t_setup, 1)},
-            "roofline": em_roofline(em_timing, n_timed) if timing else None, "cpu_baseline": cb})
+            "roofline": em_roofline(em_timing, n_timed) if timing else None, "cpu_baseline": cb, "e2e": e2e})
     return None
 
 
@@ -565,12 +737,22 @@ def run_panel64(args, rank, local_rank, world, dist):
     mine = hdist.shard(tasks, rank, world, [len(loci[k].allele_names) for _, k in tasks])
     packed = {}
     work = []
+    want_files = world == 1 and dist is None and not args.no_e2e and not args.one_by_one
+    file_of, file_dir = {}, None
+    if want_files:
+        import tempfile
+        from hisatgenotype_amd import bamio
+        file_dir = tempfile.mkdtemp(prefix="hgx_panel_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     for s, k in mine:
         if k not in packed:
             packed[k] = hl.PackedLocus.from_synth(loci[k])
             packed[k].index()
         sample = synth.pick_sample(loci[k], 1000 * s + k)
         sam = synth.simulate_sam_fast(loci[k], sample, args.panel_pairs, err_rate=args.err, seed=100 * s + k)
+        if want_files:
+            fp = os.path.join(file_dir, "s%02d_%s.bam" % (s, loci[k].gene))
+            bamio.write_bam_native(fp, sam.encode(), [(loci[k].ref_allele, len(loci[k].backbone))], sort_by_coordinate=True)
+            file_of[(s, k)] = fp
         batch = packed[k].parse_sam(sam)
         work.append((s, k, batch, engine.DeviceBatch(batch), sample))
     # the rank's tasks of a locus, merged and resident in HBM: ONE launch chain per locus (hgx_type_many)
@@ -679,6 +861,45 @@ def run_panel64(args, rank, local_rank, world, dist):
         same = sum(1 for k, row in zip(ks, rows_o) for n, r in zip(manies[k][0], row) if sorted(r[1]) == sorted(last[n][1]))
         other = {"em_arithmetic": "table lookups (hgx_type_opts.em_fast = 1)" if args.em_exact else "reference order (hgx_type_opts.em_fast = 0: bit-identical abundances)",
                  "ms_per_step": round(dt * 1e3, 3), "value": round(reads / dt, 1), "steps": n_other, "tasks_with_the_same_top2_as_the_timed_form": same}
+    e2e = None
+    if want_files and manies:
+        # 384 files -> 384 results (the loop of /root/reference/hisatgenotype:613-665 over samples x loci): the files' front ends side
+        # by side on host threads (small files: the host stages; a task is 10 000 records), then hgx_type_many_loci as in the timed step
+        import shutil
+        from concurrent.futures import ThreadPoolExecutor
+        try:
+            nthr = max(4, int(2 * (cgroup_cpu_quota() or (os.cpu_count() or 8))))
+
+            def files_once():
+                t0 = time.perf_counter()
+                ks = sorted(manies)
+                with ThreadPoolExecutor(nthr) as ex:
+                    futs = {k: [ex.submit(packed[k].parse_alignment_file, file_of[(work[n][0], k)], [packed[k].ref_allele], n_threads=1)
+                                for n in manies[k][0]] for k in ks}
+                    got_b = {k: [f.result() for f in futs[k]] for k in ks}
+                t1 = time.perf_counter()
+                mbs = [engine.ManyBatch(packed[k], got_b[k]) for k in ks]
+                t2 = time.perf_counter()
+                rows_f = htyping.type_many_loci([packed[k] for k in ks], mbs, light=True, em_fast=not args.em_exact)
+                t3 = time.perf_counter()
+                for m in mbs:
+                    m.close()
+                return (t3 - t0, t1 - t0, t2 - t1, t3 - t2), {k: row for k, row in zip(ks, rows_f)}
+            files_once()
+            runs = [files_once() for _ in range(3)]
+            runs.sort(key=lambda r: r[0][0])
+            (tot, t_fe, t_merge, t_gpu), rows_f = runs[1]
+            same = sum(1 for k in rows_f for n, r in zip(manies[k][0], rows_f[k]) if sorted(r[1]) == sorted(last[n][1]) and r[0] == last[n][0])
+            e2e = {"input": "%d coordinate-sorted BAM files of %d pairs (%.0f MB in all)" % (len(file_of), args.panel_pairs,
+                                                                                               sum(os.path.getsize(f) for f in file_of.values()) / 1e6),
+                   "ms": round(tot * 1e3, 1), "reads_per_s": round(reads / tot, 1),
+                   "stages_ms": {"front ends of the files (host stages, %d threads)" % nthr: round(t_fe * 1e3, 1),
+                                 "merge + upload (hgx_many_create)": round(t_merge * 1e3, 1), "hgx_type_many_loci": round(t_gpu * 1e3, 1)},
+                   "tasks_with_the_timed_step_s_reads_and_top2": same,
+                   "note": "files -> results for the whole panel (median of 3 after a warm-up).  A task is 10 000 records: below the device "
+                           "front end's size gate, so the files' front ends run on the host, side by side; the GPU part is the timed step"}
+        finally:
+            shutil.rmtree(file_dir, ignore_errors=True)
     cb = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_cpu = 1000
@@ -699,12 +920,15 @@ def run_panel64(args, rank, local_rank, world, dist):
                 "merged_batches": {packed[k].gene: {"alleles": packed[k].n_alleles, "tasks": m.n_tasks, "pairs": m.n_pairs, "piece_refs": m.n_refs,
                                                     "distinct_pieces": m.n_pieces} for k, (_, m) in sorted(manies.items())},
                 "setup_s": round(t_setup, 1)},
-            "roofline": roof, "cpu_baseline": cb, "other_em_arithmetic": other})
+            "roofline": roof, "cpu_baseline": cb, "other_em_arithmetic": other, "e2e": e2e})
     return None
 
 
 def main():
     args = parse_args()
+    if args.e2e_child:
+        _e2e_child(args.e2e_child)
+        return
     global EM_MODE
     EM_MODE = -1 if args.em_exact else False
     rank = int(os.environ.get("RANK", "0"))
@@ -739,6 +963,18 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         assert dist.get_world_size() == world
+    pre = None
+    if (args.workload == "configs1" and world == 1 and not use_dist and not args.no_e2e and not args.no_cpu_baseline and args.e2e_procs.strip()):
+        # the N-process host-scaling leg comes FIRST: its children start before this process has touched the GPU.  The sample
+        # it makes is the one the rest of the run uses.
+        loc0 = synth.make_hla_like_locus(n_alleles=args.alleles, n_vars=args.vars, seed=101)
+        sam0 = synth.simulate_sam_fast(loc0, synth.pick_sample(loc0, 101), args.pairs, err_rate=args.err, seed=100)
+        procs = [int(x) for x in args.e2e_procs.split(",") if x.strip()]
+        try:
+            scaling = e2e_scaling(loc0, sam0, procs)
+        except Exception as e:                                      # (the leg must not cost the run its headline)
+            scaling = {"error": repr(e)[:500]}
+        pre = (loc0, sam0, scaling)
     capi.set_device(local_rank)
     if args.workload != "configs1":
         line = (run_class1 if args.workload == "class1" else run_panel64)(args, rank, local_rank, world, dist)
@@ -751,7 +987,7 @@ def main():
 
     # ---- set-up (untimed): locus, index broadcast, reads, front-end, upload --------------------------------
     t_setup = time.perf_counter()
-    loc = synth.make_hla_like_locus(n_alleles=args.alleles, n_vars=args.vars, seed=101)
+    loc = pre[0] if pre else synth.make_hla_like_locus(n_alleles=args.alleles, n_vars=args.vars, seed=101)
     pl = hl.PackedLocus.from_synth(loc)
     if use_dist:
         from hisatgenotype_amd import dist as hdist
@@ -759,16 +995,33 @@ def main():
     else:
         pl.index()
     sample = synth.pick_sample(loc, 101 + rank)
-    sam = synth.simulate_sam_fast(loc, sample, args.pairs, err_rate=args.err, seed=100 + rank)
+    sam = pre[1] if pre else synth.simulate_sam_fast(loc, sample, args.pairs, err_rate=args.err, seed=100 + rank)
     t0 = time.perf_counter()
-    batch = pl.parse_sam(sam)
+    batch = pl.parse_sam(sam)                               # host front end: the pinned checker of the device front end
     t_parse = time.perf_counter() - t0
-    db = engine.DeviceBatch(batch)
+    # the batch the timed steps read is the one the DEVICE front end builds in HBM (record route); it must be the host's, byte for byte
+    pl.parse_sam_dev(sam).close()                           # (warm-up: staging memory, locus tables)
+    t0 = time.perf_counter()
+    db = pl.parse_sam_dev(sam)
+    t_parse_dev = time.perf_counter() - t0
+    fe_route, fe_code = engine.front_last()
+    hb = db.to_host()
+    fe_same = all(getattr(hb, k).tobytes() == getattr(batch, k).tobytes() for k in ("pieces", "masks", "pair_off", "pair_ref")) and \
+        hb.n_reads == batch.n_reads
+    del hb
     inflight = max(1, args.inflight)
     if rank != 0 or args.no_cpu_baseline or use_dist:
         sam_keep = None
     else:
         sam_keep = sam
+    rank_bam = None
+    if use_dist and not args.no_e2e:
+        # every rank's own sample as a coordinate-sorted BAM file: the file -> result leg of the N-GPU line (below)
+        import tempfile
+        from hisatgenotype_amd import bamio
+        rank_dir = tempfile.mkdtemp(prefix="hgx_rank%d_" % rank, dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        rank_bam = os.path.join(rank_dir, "reads.bam")
+        bamio.write_bam_native(rank_bam, sam.encode(), [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
     del sam
     t_setup = time.perf_counter() - t_setup
 
@@ -796,6 +1049,33 @@ def main():
         total_reads = float(rr.item())
     else:
         total_reads = float(batch.n_reads)
+    e2e_ranks = None
+    if rank_bam is not None:
+        # N ranks, N GPUs, ONE host: every rank types its own BAM file through hgx_type_file, all at the same time
+        import shutil
+        import torch
+        try:
+            hgx.type_file(pl, rank_bam)
+            n_calls = 4
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(n_calls):
+                r_f = hgx.type_file(pl, rank_bam)
+            dt = time.perf_counter() - t0
+            dist.barrier()
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ok = torch.tensor([1.0 if (r_f.gene_prob == res.gene_prob and r_f.num_reads == res.num_reads) else 0.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            e2e_ranks = {"input": "every rank its own coordinate-sorted BAM file, %d calls back to back, all ranks at once" % n_calls,
+                         "ms_per_call": round(float(tt.item()) / n_calls * 1e3, 2),
+                         "reads_per_s_all_ranks": round(total_reads * n_calls / float(tt.item()), 1),
+                         "results_identical_to_hbm_path_on_every_rank": bool(ok.item() > 0.5),
+                         "note": "hgx_type_file: the ranks share the node's host cores (cgroup quota: %s CPUs): this is where file -> result "
+                                 "stops scaling with the GPUs" % cgroup_cpu_quota()}
+        finally:
+            shutil.rmtree(os.path.dirname(rank_bam), ignore_errors=True)
 
     if rank == 0:
         # Per-kernel achieved rates from HIP events recorded inside the timed region (byte models: DESIGN.md section 5).
@@ -867,8 +1147,10 @@ def main():
                                  else "default: reference order up to 4096 classes (EM #2 here), chip-wide table lookups beyond (EM #1 here, <= 1e-9)",
                 "top2": [a for a, _ in res.gene_prob[:2]], "true_alleles": sample,
                 "parallelism": "samples/loci shard over GPUs with no data-path collective; %d sample(s) in flight per GPU" % inflight,
-                "input": "front-end piece batch resident in HBM (host C++ front-end: %.0f reads/s on %d host threads, not timed)" % (
-                    batch.n_reads / t_parse, os.cpu_count() or 1),
+                "input": "piece batch built in HBM by the device front end from the SAM text (route %d, decline code %d: %.1f ms, not timed; "
+                         "identical to the host front end's batch: %s -- the host takes %.1f ms on %d host threads)" % (
+                             fe_route, fe_code, t_parse_dev * 1e3, fe_same, t_parse * 1e3, os.cpu_count() or 1),
+                "device_front_end_batch_identical_to_host": bool(fe_same),
                 "setup_s": round(t_setup, 1),
             },
             "roofline": {
@@ -881,6 +1163,10 @@ def main():
                 "kernels": kernels,
             },
         }
+        if pre is not None:
+            out["e2e_scaling"] = pre[2]
+        if e2e_ranks is not None:
+            out["e2e"] = e2e_ranks
         if sam_keep is not None:
             if not args.no_e2e:
                 out["e2e"] = end_to_end(pl, loc, sam_keep, res)

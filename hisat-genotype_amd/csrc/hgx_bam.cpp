@@ -533,7 +533,8 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             // that START in its range; the one that runs over the end of the range is finished after all ranges are in.
             // With an upload waiting (out.on_raw: the device front end) the file is read in a few phases, and each phase's bytes are
             // handed over while the next phase is read: the transfer hides behind the read.
-            const int n_phase = (out.on_raw && data.size() > (64u << 20)) ? 4 : 1;
+            const char *ph_env = getenv("HGX_READ_PHASES");
+            const int n_phase = (out.on_raw && data.size() > (64u << 20)) ? (ph_env ? std::max(1, atoi(ph_env)) : 4) : 1;
             text_nt = n_threads * n_phase;
             text_part.assign(text_nt, std::vector<std::vector<Line>>(n_reg));
             std::vector<size_t> tail((size_t)text_nt, (size_t)-1);

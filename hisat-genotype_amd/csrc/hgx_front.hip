@@ -448,6 +448,7 @@ __global__ void __launch_bounds__(256) k_fe_build_recinfo(const FeRec *__restric
 struct MaxU32 { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
 
 thread_local int g_last_device = 0, g_last_decline = 0, g_last_route = 0;
+thread_local long long g_last_bytes = 0;      // bytes the last call sent to the device (text / inflated stream / key table)
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -681,6 +682,7 @@ int front_run(hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, 
     if (in.n_text) HIPCHK(hipMemcpyAsync(b_text.p, in.text, in.n_text, hipMemcpyHostToDevice, st));
     if (in.n_rec) HIPCHK(hipMemcpyAsync(b_rec.p, in.rec_info, in.n_rec * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(b_ctl.p, 0, sizeof(FeCtl), st));
+    g_last_bytes += (long long)(in.n_keys * sizeof(FeKey) + in.n_text + in.n_rec * 4);
     lap("upload");
     const DevInput di{b_keys.as<FeKey>(), (uint32_t)in.n_keys, b_text.as<char>(), b_rec.as<uint32_t>(), (uint32_t)in.n_rec, (uint32_t)in.n_slots,
                       b_ctl.as<FeCtl>()};
@@ -739,6 +741,7 @@ int records_run(hgx_locus &L, const char *d_text, const char *raw, size_t raw_by
     HIPCHK(hipMemsetAsync(b_pile.p, 0, (size_t)cap * 4, st));
     HIPCHK(hipMemsetAsync(b_anyk.p, 0, (size_t)cap * 4, st));
     if (n) HIPCHK(hipMemcpyAsync(b_lines.p, h_lines, (size_t)n * sizeof(LineRef), hipMemcpyHostToDevice, st));
+    g_last_bytes += (long long)((size_t)n * sizeof(LineRef));
     lap("text + line table on the device");
     FeCtl *ctl = b_ctl.as<FeCtl>();
     FeCtl h;
@@ -819,6 +822,7 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Pars
             if (end > begin && hipMemcpyAsync((char *)b_text.p + begin, raw + begin, end - begin, hipMemcpyHostToDevice, st) != hipSuccess) { up_failed = true; return; }
             up_raw = raw;
             up_bytes = n_bytes;
+            g_last_bytes += (long long)(end - begin);
         };
         hook.records = [&](hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &o,
                            int *declined) {
@@ -831,6 +835,7 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Pars
     }
     struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};     // (an upload may still read the reader's buffer)
     hgx_batch *b = nullptr;
+    g_last_bytes = 0;
     const int rc = parse(&b, host_only ? nullptr : &hook);
     (void)hipStreamSynchronize(st);
     g_last_route = rc ? 0 : route;
@@ -859,9 +864,10 @@ extern "C" int hgx_parse_alignment_file_dev(hgx_dbatch **out, const hgx_locus *l
                      [&](hgx_batch **b, hgx_front_hook *hook) { return hgx_parse_alignment_file_hook(b, loc, path, regions, opts, hook); });
 }
 
-extern "C" int hgx_front_last(int32_t *device_stages_ran, int32_t *decline_code) {
-    if (device_stages_ran) *device_stages_ran = g_last_device ? g_last_route : 0;
+extern "C" int hgx_front_last(int32_t *route, int32_t *decline_code, int64_t *bytes_to_device) {
+    if (route) *route = g_last_device ? g_last_route : 0;
     if (decline_code) *decline_code = g_last_decline;
+    if (bytes_to_device) *bytes_to_device = g_last_bytes;
     return HGX_OK;
 }
 

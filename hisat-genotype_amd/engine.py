@@ -79,8 +79,15 @@ def front_last():
     records themselves (fields, filters, key grouping as kernels), 1 = the host made the key table and the device the rest,
     0 = the host stages finished the job (decline code says why)."""
     ran, code = C.c_int32(0), C.c_int32(0)
-    capi.check(capi.lib().hgx_front_last(C.byref(ran), C.byref(code)))
+    capi.check(capi.lib().hgx_front_last(C.byref(ran), C.byref(code), None))
     return ran.value, code.value
+
+
+def front_last_bytes():
+    """Bytes that call sent to the device (SAM text / inflated BAM stream + line table, or the key table of the key route)."""
+    n = C.c_int64(0)
+    capi.check(capi.lib().hgx_front_last(None, None, C.byref(n)))
+    return n.value
 
 
 def em_last_order(n_alleles):

@@ -122,17 +122,22 @@ def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discor
     (`sam_text`), or `alignment_file` (SAM / BAM; `regions` = samtools region strings, see read_alignment_text) read inside
     libhgx.  `gate` (engine.Gate): shared by the samples in flight on one GPU, see _type_batch."""
     res = LocusResult()
+    # the front end on the device (hgx_parse_*_dev: record fields, filters, key grouping, pileup, decode, piece table and pair protocol
+    # as kernels; small or unusual inputs are finished by the host stages inside the same call): the batch is born in HBM
     if alignment_file is not None:
-        batch = pl.parse_alignment_file(alignment_file, regions, num_editdist=num_editdist, error_correction=error_correction,
-                                        allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus)
+        dbatch = pl.parse_alignment_file_dev(alignment_file, regions, num_editdist=num_editdist, error_correction=error_correction,
+                                             allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus, stream=stream)
     else:
-        batch = pl.parse_sam(sam_text, num_editdist=num_editdist, error_correction=error_correction,
-                             allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus)
-    res.num_reads, res.num_pairs = batch.n_reads, batch.n_pairs
-    res.n_pieces, res.n_refs = batch.n_pieces, batch.n_refs
-    if batch.n_reads <= 0:                                  # core:1589-1590
-        return res
-    return _type_batch(pl, batch, res, remove_low_abundance_alleles, keep_classes, stream, gate=gate)
+        dbatch = pl.parse_sam_dev(sam_text, num_editdist=num_editdist, error_correction=error_correction,
+                                  allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus, stream=stream)
+    try:
+        res.num_reads, res.num_pairs = dbatch.n_reads, dbatch.n_pairs
+        res.n_pieces, res.n_refs = dbatch.n_pieces, dbatch.n_refs
+        if dbatch.n_reads <= 0:                                 # core:1589-1590
+            return res
+        return _type_batch(pl, None, res, remove_low_abundance_alleles, keep_classes, stream, dbatch=dbatch, gate=gate)
+    finally:
+        dbatch.close()
 
 
 class TypeOpts(C.Structure):

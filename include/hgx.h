@@ -458,7 +458,7 @@ int hgx_type_file(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, c
 int hgx_parse_sam_dev(hgx_dbatch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, void *stream);
 int hgx_parse_alignment_file_dev(hgx_dbatch **out, const hgx_locus *loc, const char *path, const char *regions_or_null,
                                  const hgx_parse_opts *opts, void *stream);
-int hgx_front_last(int32_t *route, int32_t *decline_code);
+int hgx_front_last(int32_t *route, int32_t *decline_code, int64_t *bytes_to_device /* sent by that call: text / stream / key table */);
 /* a device batch back on the host (tests, tools): pieces, masks, refs, and the pileup tables if the kernels made them */
 int hgx_dbatch_to_host(const hgx_dbatch *d, hgx_batch **out);
 /* The same from class sets that already exist (intra-locus read sharding, 8e: every rank scores its share of the pairs, the
