@@ -42,7 +42,16 @@ struct hgx_index {
     int32_t n_alleles, a_pad, n_vars, n_words, w64;
     uint32_t *d_bits;
     uint64_t *d_exon_mask, *d_gene_mask;
+    // per-LOCUS pattern tables of the piece x allele kernel (hgx_device.hip, k_piece_compat_pat), made on first use from d_bits:
+    // the distinct 32-bit values of every variant word over the alleles (~100 of 7 000 at HLA-A) and every allele's value id
+    int pat_state = 0;                   // 0 = not made yet, 1 = ready, 2 = this locus does not fit (a word with too many values)
+    uint16_t *d_pid = nullptr;           // [n_words][a_pad]
+    uint32_t *d_vals = nullptr;          // [n_words][HGX_PAT_D]
+    int32_t *d_nval = nullptr;           // [n_words]
+    int pat_dmax = 0;
+    std::mutex *pat_mu = nullptr;
 };
+#define HGX_PAT_D 512
 
 struct hgx_classes {
     int32_t n_classes, a_pad, w64, c64;

@@ -300,6 +300,8 @@ extern "C" int hgx_index_create_device(hgx_index **out, int32_t n_alleles, int32
 extern "C" int hgx_index_destroy(hgx_index *ix) {
     if (!ix) return HGX_OK;
     (void)hipFree(ix->d_bits);                 // one block: the masks live behind the bit matrix
+    hgx_pool_free(ix->d_pid); hgx_pool_free(ix->d_vals); hgx_pool_free(ix->d_nval);
+    delete ix->pat_mu;
     delete ix;
     return HGX_OK;
 }
@@ -491,13 +493,226 @@ __global__ __launch_bounds__(PT_T) void k_piece_compat_tiled(const uint32_t *__r
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pattern form (round 4; the one hgx_piece_compat launches when the locus fits).  Of the ~7 000 alleles of an HLA locus only
+// ~100 DISTINCT values occur in any one 32-variant word (max 222 at the bench's HLA-A, 367 at B): the word tests of a piece
+// need to be made once per distinct value, not once per allele.  Per LOCUS (made once from the index, ensure_patterns):
+// vals[w][id] = the distinct values of word w, pid[w][a] = the id of allele a's value.  Per window of 8 variant words and group
+// of 64 pieces, a workgroup
+//   phase 1  tests every (window word j, value id) against the 64 pieces' (MP, P) words of j at once: match[j][id] = 64 verdict
+//            bits (a piece that does not cover j passes), ~8 x 100 items of 64 tests -- what 7 alleles cost in the tiled form;
+//   phase 2  every allele ANDs the eight words match[j][pid[j][a]] (eight LDS reads for 64 pieces, where the tiled form makes
+//            64 x 3.85) and a 64 x 64 bit transpose per wavefront (wave_transpose64) turns "lane = allele, bit = piece" into the
+//            compat words "lane = piece, bit = allele", stored 32 bytes per lane.
+// Exact (the same tests on the same words), any piece order is correct; pieces wider than the window or over a word with more
+// than HGX_PAT_D values are tested straight from the index.
+// ------------------------------------------------------------------------------------------------
+#define PP_T 1024
+#define PP_PB 256
+#define PP_W 8
+#define PP_NW 8
+#define PP_G 4                // 64-allele words per wavefront: 4 x 64 x 16 waves = 4096 alleles per workgroup
+__global__ __launch_bounds__(PP_T) void k_piece_compat_pat(const uint32_t *__restrict__ bits, int a_pad, int n_index_words,
+                                                           const uint16_t *__restrict__ pid, const uint32_t *__restrict__ vals,
+                                                           const int32_t *__restrict__ nval, const hgx_piece *__restrict__ pieces,
+                                                           const uint32_t *__restrict__ masks, int n_pieces, uint64_t *__restrict__ compat,
+                                                           int w64) {
+    __shared__ uint32_t smask[PP_PB][2 * PP_NW];
+    __shared__ int s_lo[PP_PB], s_nw[PP_PB];
+    __shared__ int s_end, s_big;
+    __shared__ uint32_t s_vals[PP_W][HGX_PAT_D];
+    __shared__ int s_nval[PP_W], s_voff[PP_W + 1];
+    __shared__ uint2 s_wm[PP_W][64];
+    __shared__ uint64_t s_match[PP_W][HGX_PAT_D];
+    const int tid = threadIdx.x, lane = tid & 63, nthr = blockDim.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int a_base = blockIdx.y * (nthr * PP_G) + wv * (64 * PP_G);          // this wave's first allele
+    const int word0 = a_base >> 6;                                          // ... = its first 64-allele word of a compat row
+    const int p0 = blockIdx.x * PP_PB;
+    const int np = min(PP_PB, n_pieces - p0);
+    for (int t = tid; t < PP_PB * 4; t += nthr) {       // descriptors and masks: t = (piece, quarter of its 16 mask words)
+        const int p = t >> 2, q = t & 3;
+        if (p < np) {
+            const hgx_piece pc = pieces[p0 + p];
+            const int nw2 = 2 * (int)pc.n_words;
+            if (q == 0) { s_lo[p] = pc.lo_word; s_nw[p] = pc.n_words; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = 4 * q + k;
+                smask[p][i] = i < nw2 ? masks[pc.mask_off + i] : 0u;
+            }
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    while (cur < np) {
+        const int win_lo = s_lo[cur];
+        if (tid == 0) { s_end = np; s_big = 0; }
+        __syncthreads();
+        if (tid < PP_W) {
+            const int w = win_lo + tid;
+            const int nv = w < n_index_words ? nval[w] : 0;
+            s_nval[tid] = nv;
+            if (nv > HGX_PAT_D) s_big = 1;
+        }
+        for (int t = cur + tid; t < np; t += nthr) {                 // (a workgroup of a small locus has fewer threads than pieces)
+            const int l = s_lo[t];
+            if (l < win_lo || s_nw[t] > PP_NW || l + s_nw[t] - win_lo > PP_W) { atomicMin(&s_end, t); break; }
+        }
+        __syncthreads();
+        if (s_nw[cur] > PP_NW || s_big) {
+            // a piece wider than the window, or a word with too many values: straight from the index
+            const hgx_piece pc = pieces[p0 + cur];
+            const uint32_t *m = masks + pc.mask_off;
+#pragma unroll
+            for (int g = 0; g < PP_G; ++g) {
+                const int a = a_base + 64 * g + lane;
+                bool ok = true;
+                for (int i = 0; i < (int)pc.n_words; ++i) {
+                    const uint32_t r = a < a_pad ? bits[(size_t)(pc.lo_word + i) * a_pad + a] : 0u;
+                    ok = ok && ((r & m[2 * i]) == m[2 * i + 1]);
+                }
+                const uint64_t b = __ballot(ok);
+                if (lane == 0 && word0 + g < w64) compat[(size_t)(p0 + cur) * w64 + word0 + g] = b;
+            }
+            ++cur;
+            __syncthreads();
+            continue;
+        }
+        const int end = s_end;
+        if (tid == 0) {
+            int o = 0;
+            for (int j = 0; j < PP_W; ++j) { s_voff[j] = o; o += s_nval[j]; }
+            s_voff[PP_W] = o;
+        }
+        for (int j = 0; j < PP_W; ++j) {
+            const int nv = s_nval[j];
+            for (int id = tid; id < nv; id += nthr) s_vals[j][id] = vals[(size_t)(win_lo + j) * HGX_PAT_D + id];
+        }
+        // this thread's alleles' value ids in the window's words, two per register
+        uint32_t pr[PP_G][PP_W / 2];
+#pragma unroll
+        for (int g = 0; g < PP_G; ++g) {
+            const int a = a_base + 64 * g + lane;
+#pragma unroll
+            for (int j = 0; j < PP_W; j += 2) {
+                const int w = win_lo + j;
+                const uint32_t lo16 = (a < a_pad && w < n_index_words) ? pid[(size_t)w * a_pad + a] : 0u;
+                const uint32_t hi16 = (a < a_pad && w + 1 < n_index_words) ? pid[(size_t)(w + 1) * a_pad + a] : 0u;
+                pr[g][j >> 1] = lo16 | (hi16 << 16);
+            }
+        }
+        __syncthreads();
+        const int total = s_voff[PP_W];
+        for (int g0 = cur; g0 < end; g0 += 64) {
+            const int cnt = min(end, g0 + 64) - g0;
+            for (int t = tid; t < PP_W * 64; t += nthr) {          // the group's (MP, P) word of every window word (0, 0 = passes)
+                const int j = t >> 6, k = t & 63;
+                uint2 wm = make_uint2(0u, 0u);
+                if (k < cnt) {
+                    const int off = s_lo[g0 + k] - win_lo, nw = s_nw[g0 + k];
+                    if (j >= off && j < off + nw) wm = make_uint2(smask[g0 + k][2 * (j - off)], smask[g0 + k][2 * (j - off) + 1]);
+                }
+                s_wm[j][k] = wm;
+            }
+            __syncthreads();
+            for (int t = tid; t < total; t += nthr) {              // phase 1: one (word, value) per thread, 64 pieces each
+                int j = 0;
+#pragma unroll
+                for (int q = 1; q < PP_W; ++q) j += t >= s_voff[q] ? 1 : 0;
+                const int id = t - s_voff[j];
+                const uint32_t v = s_vals[j][id];
+                uint32_t mlo = 0, mhi = 0;
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) {
+                    const uint2 a = s_wm[j][k], b = s_wm[j][k + 32];
+                    mlo |= (uint32_t)((v & a.x) == a.y) << k;
+                    mhi |= (uint32_t)((v & b.x) == b.y) << k;
+                }
+                s_match[j][id] = ((uint64_t)mhi << 32) | mlo;
+            }
+            __syncthreads();
+            uint64_t out[PP_G];                                     // phase 2
+#pragma unroll
+            for (int g = 0; g < PP_G; ++g) {
+                uint64_t v = ~0ull;
+#pragma unroll
+                for (int j = 0; j < PP_W; ++j) {
+                    const uint32_t id = (pr[g][j >> 1] >> (16 * (j & 1))) & 0xffffu;
+                    if (s_nval[j] > 0) v &= s_match[j][id];
+                }
+                out[g] = wave_transpose64(v);                       // lane k: piece g0 + k over this wave's g-th 64 alleles
+            }
+            if (lane < cnt) {
+                uint64_t *row = compat + (size_t)(p0 + g0 + lane) * w64 + word0;
+#pragma unroll
+                for (int g = 0; g < PP_G; ++g)
+                    if (word0 + g < w64) row[g] = out[g];
+            }
+        }
+        __syncthreads();
+        cur = end;
+    }
+}
+
+// the pattern tables of an index, made once from its bit matrix (host: sort + unique per word; 72 words x 7 168 alleles at HLA-A)
+static int ensure_patterns(hgx_index *ix, hipStream_t st) {
+    if (ix->pat_state) return HGX_OK;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> g(mu);
+    if (ix->pat_state) return HGX_OK;
+    const size_t nw = (size_t)ix->n_words, ap = (size_t)ix->a_pad;
+    std::vector<uint32_t> hb(nw * ap);
+    HIPCHK(hipMemcpyAsync(hb.data(), ix->d_bits, hb.size() * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<uint16_t> pid(nw * ap);
+    std::vector<uint32_t> vals(nw * HGX_PAT_D, 0u);
+    std::vector<int32_t> nval(nw, 0);
+    std::vector<uint32_t> u;
+    int dmax = 0;
+    bool fits = true;
+    for (size_t w = 0; w < nw; ++w) {
+        u.assign(hb.begin() + w * ap, hb.begin() + (w + 1) * ap);
+        std::sort(u.begin(), u.end());
+        u.erase(std::unique(u.begin(), u.end()), u.end());
+        dmax = std::max(dmax, (int)u.size());
+        nval[w] = (int32_t)u.size();
+        if (u.size() > 65535) { fits = false; break; }
+        if (u.size() <= HGX_PAT_D) std::copy(u.begin(), u.end(), vals.begin() + w * HGX_PAT_D);
+        for (size_t a = 0; a < ap; ++a) pid[w * ap + a] = (uint16_t)(std::lower_bound(u.begin(), u.end(), hb[w * ap + a]) - u.begin());
+    }
+    ix->pat_dmax = dmax;
+    if (!fits) { ix->pat_state = 2; return HGX_OK; }
+    ix->d_pid = (uint16_t *)hgx_pool_alloc(std::max<size_t>(pid.size() * 2, 16));
+    ix->d_vals = (uint32_t *)hgx_pool_alloc(std::max<size_t>(vals.size() * 4, 16));
+    ix->d_nval = (int32_t *)hgx_pool_alloc(std::max<size_t>(nval.size() * 4, 16));
+    if (!ix->d_pid || !ix->d_vals || !ix->d_nval) { hgx_set_error("device allocation of the pattern tables failed"); return HGX_ENOMEM; }
+    HIPCHK(hipMemcpyAsync(ix->d_pid, pid.data(), pid.size() * 2, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ix->d_vals, vals.data(), vals.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ix->d_nval, nval.data(), nval.size() * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipStreamSynchronize(st));
+    ix->pat_state = 1;
+    return HGX_OK;
+}
+
 extern "C" int hgx_piece_compat(const hgx_index *ix, const hgx_piece *pieces, const uint32_t *masks, int32_t n_pieces,
                                 uint64_t *compat, void *stream) {
     ARGCHK(ix && n_pieces >= 0);
     if (n_pieces == 0) return HGX_OK;
     ARGCHK(pieces && masks && compat);
     const bool untiled = hgx_test_switch("piece_untiled") != nullptr;     // the L2-served kernel, kept for comparison
-    if (untiled) {
+    const bool tiled = hgx_test_switch("piece_tiled") != nullptr;         // round 1-3's LDS-tiled kernel, kept for comparison
+    if (!untiled && !tiled) {
+        const int rc_ = ensure_patterns(const_cast<hgx_index *>(ix), (hipStream_t)stream);
+        if (rc_) return rc_;
+    }
+    if (!untiled && !tiled && ix->pat_state == 1) {
+        const int thr = std::min(PP_T, std::max(64, ((ix->a_pad + 64 * PP_G - 1) / (64 * PP_G)) * 64));
+        const int per_wg = thr * PP_G;
+        hipLaunchKernelGGL(k_piece_compat_pat, dim3((n_pieces + PP_PB - 1) / PP_PB, (ix->a_pad + per_wg - 1) / per_wg), dim3(thr), 0,
+                           (hipStream_t)stream, ix->d_bits, ix->a_pad, ix->n_words, ix->d_pid, ix->d_vals, ix->d_nval, pieces, masks, n_pieces,
+                           compat, ix->w64);
+    } else if (untiled) {
         const int chunks = (ix->w64 + PC_GROUPS - 1) / PC_GROUPS;
         const long waves = (long)n_pieces * chunks;
         const long blocks = (waves + 3) / 4;
