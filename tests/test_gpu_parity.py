@@ -786,3 +786,70 @@ def test_fused_pair_classes_dedup_at_size_and_with_zero_rows(orc):
         got = engine.Classes.of_pairs_fused(pl, d2, f2, lv).to_host()
         for x, y in zip(got, want):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("n_alleles,n_vars,dense", [(700, 300, False), (5000, 700, False), (3000, 260, True), (9000, 500, True)])
+def test_piece_compat_kernels_agree_with_the_definition(n_alleles, n_vars, dense):
+    """hgx_piece_compat straight through the C-ABI on a random index: the pattern form (the default: word tests once per DISTINCT
+    value of a variant word), the LDS-tiled form of rounds 1-3 (`piece_tiled`) and the L2-served form (`piece_untiled`) against
+    compat(a) <=> for every word i: (bits[lo + i][a] & MP_i) == P_i in numpy.  `dense`: independent random bits -- every allele
+    has its own value in every word (more than HGX_PAT_D = 512 of them), so the pattern form takes its straight-from-the-index
+    path; otherwise alleles copy a few hundred founders, as real loci do (a few hundred values per word at most)."""
+    import ctypes as C
+    from hisatgenotype_amd import capi
+    rng = np.random.RandomState(n_alleles + n_vars)
+    a_pad = capi.a_pad(n_alleles)
+    n_words = (n_vars + 31) // 32
+    bits = np.zeros((n_words, a_pad), np.uint32)
+    if dense:
+        bits[:, :n_alleles] = rng.randint(0, 1 << 32, size=(n_words, n_alleles), dtype=np.uint64).astype(np.uint32) & \
+            rng.randint(0, 1 << 32, size=(n_words, n_alleles), dtype=np.uint64).astype(np.uint32)
+    else:
+        founders = rng.randint(0, 1 << 32, size=(n_words, 150), dtype=np.uint64).astype(np.uint32) & \
+            rng.randint(0, 1 << 32, size=(n_words, 150), dtype=np.uint64).astype(np.uint32)
+        bits[:, :n_alleles] = founders[:, rng.randint(0, 150, n_alleles)]
+        flip = rng.rand(n_words, n_alleles) < 0.02                       # private variants
+        bits[:, :n_alleles] ^= (flip * (1 << rng.randint(0, 32, size=(n_words, n_alleles)))).astype(np.uint32)
+    if n_vars % 32:
+        bits[-1] &= np.uint32((1 << (n_vars % 32)) - 1)
+    em = np.zeros(a_pad // 64, np.uint64)
+    ix = C.c_void_p()
+    L = capi.lib()
+    capi.check(L.hgx_index_create(C.byref(ix), C.c_int32(n_alleles), C.c_int32(n_vars), capi.ptr(bits), capi.ptr(em), capi.ptr(em)))
+    try:
+        n_pieces = 3000
+        pieces = np.zeros(n_pieces, capi.PIECE_DTYPE)
+        masks = []
+        for p in range(n_pieces):
+            nw = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 12])) if rng.rand() < 0.3 else int(rng.randint(1, 6))
+            nw = min(nw, n_words)
+            lo = int(rng.randint(0, n_words - nw + 1))
+            pieces[p] = (len(masks), lo, nw)
+            a = int(rng.randint(n_alleles))                             # masks cut from a real allele, so that some alleles pass
+            for i in range(nw):
+                mp = int(rng.randint(0, 1 << 32, dtype=np.uint64)) & int(rng.randint(0, 1 << 32, dtype=np.uint64))
+                pw = int(bits[lo + i, a]) & mp
+                if rng.rand() < 0.03:
+                    pw ^= mp & (1 << int(rng.randint(32)))
+                masks += [mp, pw]
+        order = np.lexsort((pieces["n_words"], pieces["lo_word"]))      # the front end's order: by first word, then width
+        pieces = pieces[order]
+        masks = np.array(masks, np.uint32)
+        want = np.zeros((n_pieces, a_pad // 64), np.uint64)
+        for p in range(n_pieces):
+            mo, lo, nw = int(pieces[p]["mask_off"]), int(pieces[p]["lo_word"]), int(pieces[p]["n_words"])
+            ok = np.ones(a_pad, bool)
+            for i in range(nw):
+                ok &= (bits[lo + i] & masks[mo + 2 * i]) == masks[mo + 2 * i + 1]
+            want[p] = np.packbits(ok, bitorder="little").view(np.uint64)
+        d_pieces, d_masks = capi.DevArray.from_host(pieces), capi.DevArray.from_host(masks)
+        for sw in ({}, {"piece_tiled": 1}, {"piece_untiled": 1}):
+            out = capi.DevArray((n_pieces, a_pad // 64), np.uint64)
+            out.zero()
+            with engine.test_switches(**sw):
+                capi.check(L.hgx_piece_compat(ix, capi.ptr(d_pieces), capi.ptr(d_masks), C.c_int32(n_pieces), capi.ptr(out), None))
+            capi.sync()
+            got = out.to_host()
+            assert np.array_equal(got, want), (sw, int((got != want).any(axis=1).sum()))
+    finally:
+        L.hgx_index_destroy(ix)
