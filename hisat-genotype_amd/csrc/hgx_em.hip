@@ -2078,7 +2078,9 @@ __global__ __launch_bounds__(BLOCK) void k_lut_rows_fused(const uint64_t *__rest
     if (n < Npad) part[(size_t)slab * Npad + n] = acc2;      // the cols pass adds the slabs
 }
 
+
 #ifdef HGX_LAB
+#include "lab/hgx_em_lut4.inc"            // narrow-table form of the two passes (measured slower: lab build only)
 #include "lab/hgx_em_persist.inc"         // whole iterations per launch behind device-wide barriers (HGX_EM_PERSIST): lab build only
 #endif
 
@@ -2133,6 +2135,7 @@ struct MatVec {
     double *part = nullptr;         // [n_words / 8][n_pad] slab partials
     unsigned *counters = nullptr;   // [ceil(n_rows / 1024)], zero between launches
     // table-lookup EM only: the rows pass leaves its partials for the cols pass to add (see k_lutmatvec)
+    int narrow = 0;                 // the narrow-table form (k_lut4): a workgroup owns its rows for the whole of K
     int defer_combine = 0;
     const double *src_part = nullptr;
     int src_slabs = 0, src_pad = 0;
@@ -2178,6 +2181,12 @@ inline int rows_per_block(int n_rows) {
 // kernel's begin and end, like rocprofv3 does, instead of bracketing it with separately queued event records)
 thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 
+// rows per workgroup of the narrow-table form: few enough that the launch spreads over most of the chip
+[[maybe_unused]] inline int l4_rows(int n_rows) {
+    if (const char *f = hgx_test_switch("l4_rows")) { const int v = atoi(f); if (v == 16 || v == 32 || v == 64 || v == 128) return v; }
+    return n_rows >= 8192 ? 64 : 32;
+}
+
 template <int MODE>
 int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint8_t *vec_pres, int x_mode,
                   const int64_t *count, const double *q_in, const uint8_t *pres_in, const double *len, double *y,
@@ -2185,6 +2194,27 @@ int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint
     if constexpr (MODE == MODE_ROWS || MODE == MODE_COLS) {
         if (use_mfma(m))
             return launch_mfma<MODE>(m, st, vec, vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate);
+#ifdef HGX_LAB
+        if (m.M && m.narrow) {
+            constexpr int XS = MODE == MODE_ROWS ? 0 : 1;
+            HGX_ONCE_PER_DEVICE({
+                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut4<XS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L4_LDS));
+            });
+            const int R = l4_rows(m.n_rows);
+            const dim3 grid((unsigned)((m.n_rows + R - 1) / R));
+            const FuseArgs fz{};
+            if (g_ev_start) {
+                hipExtLaunchKernelGGL((k_lut4<XS>), grid, dim3(BLOCK), L4_LDS, st, g_ev_start, g_ev_stop, 0, m.M, m.n_rows, m.n_pad, m.n_words, m.n_k, R,
+                                      vec, vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate, (const double *)nullptr,
+                                      (const uint8_t *)nullptr, fz);
+                g_ev_start = g_ev_stop = nullptr;
+            } else {
+                hipLaunchKernelGGL((k_lut4<XS>), grid, dim3(BLOCK), L4_LDS, st, m.M, m.n_rows, m.n_pad, m.n_words, m.n_k, R, vec, vec_pres, x_mode,
+                                   count, q_in, pres_in, len, y, pres_out, scal, gate, (const double *)nullptr, (const uint8_t *)nullptr, fz);
+            }
+            return HGX_OK;
+        }
+#endif
         if (m.M) {
             HGX_ONCE_PER_DEVICE({
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lutmatvec<MODE>),
@@ -2720,7 +2750,11 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         HIPCHK(hipMemsetAsync(b_cnt.p, 0, n_cnt * 4, st));
         rows.M = c->d_wrow; rows.n_pad = Cp; rows.part = b_part.as<double>(); rows.counters = b_cnt.as<unsigned>();
         cols.M = c->d_wcol; cols.n_pad = A; cols.part = b_part_c.as<double>(); cols.counters = b_cnt.as<unsigned>();
-        if (!hgx_test_switch("em_persist") && !hgx_test_switch("em_no_defer")) {
+#ifdef HGX_LAB
+        if (hgx_test_switch("em_lut4") && !hgx_test_switch("em_persist") && !hgx_test_switch("em_grid"))
+            rows.narrow = cols.narrow = 1;      // the narrow-table form (k_lut4, lab): a workgroup owns its rows for the whole of K
+#endif
+        if (!rows.narrow && !hgx_test_switch("em_persist") && !hgx_test_switch("em_no_defer")) {
             // the rows pass stops at its slab partials; the cols pass turns them into w_c in its prologue
             rows.defer_combine = 1;
             cols.src_part = rows.part; cols.src_slabs = w64c / 8; cols.src_pad = Cp; cols.src_count = c->d_count;
@@ -2948,7 +2982,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     bool tail_done = false;
     const bool use_tail = !hgx_test_switch("em_no_tail");
     // ---- fused vector steps (k_lut_rows_fused): ping-pong estimate, extrapolated vector and state words -----------
-    const bool fuse = rows.defer_combine && A <= EPT * BLOCK && !hgx_test_switch("em_no_fuse");
+    const bool fuse = (rows.defer_combine || rows.narrow) && A <= EPT * BLOCK && !hgx_test_switch("em_no_fuse");
     DevBuf b_palt, b_pralt, b_q2x, b_prx, b_scal2;
     double *p_alt = nullptr, *q2x = nullptr, *scal_alt = nullptr;
     uint8_t *pr_alt = nullptr, *prx = nullptr;
@@ -2961,10 +2995,28 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
                                        (int)LUT_LDS));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut_rows_fused<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)LUT_LDS));
+#ifdef HGX_LAB
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut4<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L4_LDS));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut4<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L4_LDS));
+#endif
         });
     }
     auto rows_fused = [&](int fm, const double *qb, const uint8_t *prb, double *out_v, uint8_t *out_p) -> int {
         FuseArgs fz{q1, qb, pr1, prb, out_v, out_p, scal, scal_alt, remove_low ? 1 : 0};
+#ifdef HGX_LAB
+        if (rows.narrow) {
+            const int R = l4_rows(rows.n_rows);
+            const dim3 g4((unsigned)((rows.n_rows + R - 1) / R));
+            if (fm == 0) hipLaunchKernelGGL(k_lut4<2>, g4, dim3(BLOCK), L4_LDS, st, rows.M, rows.n_rows, rows.n_pad, rows.n_words, A, R,
+                                            (const double *)nullptr, (const uint8_t *)nullptr, 0, c->d_count, (const double *)nullptr,
+                                            (const uint8_t *)nullptr, (const double *)nullptr, wc, (uint8_t *)nullptr, (double *)nullptr, 0, p, pr, fz);
+            else hipLaunchKernelGGL(k_lut4<3>, g4, dim3(BLOCK), L4_LDS, st, rows.M, rows.n_rows, rows.n_pad, rows.n_words, A, R,
+                                    (const double *)nullptr, (const uint8_t *)nullptr, 0, c->d_count, (const double *)nullptr,
+                                    (const uint8_t *)nullptr, (const double *)nullptr, wc, (uint8_t *)nullptr, (double *)nullptr, 0, p, pr, fz);
+            std::swap(scal, scal_alt);
+            return HGX_OK;
+        }
+#endif
         const dim3 grid(rows.n_words / 8, (rows.n_rows + BLOCK - 1) / BLOCK);
         if (fm == 0) hipLaunchKernelGGL(k_lut_rows_fused<0>, grid, dim3(BLOCK), LUT_LDS, st, rows.M, rows.n_pad, A, p, pr, fz, rows.part);
         else hipLaunchKernelGGL(k_lut_rows_fused<1>, grid, dim3(BLOCK), LUT_LDS, st, rows.M, rows.n_pad, A, p, pr, fz, rows.part);

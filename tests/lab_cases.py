@@ -105,3 +105,29 @@ def test_em_grid_equals_per_pass():
             if C_ == 21000:
                 assert launches == 0
     assert ran_grid >= 9
+
+
+def test_narrow_table_form_agrees_with_the_product_path():
+    """k_lut4 (round 4, lab: a workgroup owns its rows for the whole of K, 4-bit tables, no cross-workgroup combine -- measured 2.3x
+    SLOWER than the 8-bit slab form, tools/em_forms.py): same iteration counts, abundances within 1e-12, plain and fused steps,
+    one and several slabs in both passes."""
+    rng = np.random.RandomState(5)
+    for C_, A, a_pad in [(5000, 700, 1024), (9000, 2600, 3072), (16098, 4549, 7168), (4200, 6000, 6144)]:
+        w = a_pad // 64
+        fam = rng.rand(12, A) < rng.choice([0.02, 0.2, 0.7], size=12)[:, None]
+        m = fam[rng.randint(0, 12, C_)] ^ (rng.rand(C_, A) < 0.01)
+        m[np.arange(C_), rng.randint(0, A, C_)] = True
+        rows = np.packbits(np.pad(m, ((0, 0), (0, a_pad - A))), axis=1, bitorder="little").view(np.uint64).reshape(C_, w)
+        counts = rng.randint(1, 400, C_).astype(np.int64)
+        lens = rng.randint(2000, 3500, a_pad).astype(np.int32)
+        for low, use_len in ((True, False), (False, True)):
+            ln = lens if use_len else None
+            cl = engine.Classes.from_host(rows, counts, a_pad)
+            p_ref, it_ref = cl.em(A, low, ln)
+            for extra in ({}, {"l4_rows": 32}, {"em_no_fuse": 1}):
+                with engine.test_switches(em_lut4=1, **extra):
+                    cl2 = engine.Classes.from_host(rows, counts, a_pad)
+                    p, it = cl2.em(A, low, ln)
+                assert it == it_ref, (C_, A, low, use_len, extra, it, it_ref)
+                assert np.array_equal(p < 0, p_ref < 0)
+                assert np.max(np.abs(p - p_ref)) <= 1e-12, (C_, A, extra, float(np.max(np.abs(p - p_ref))))
