@@ -769,7 +769,7 @@ def run_panel64(args, rank, local_rank, world, dist):
         out = [None] * len(work)
         if manies:
             ks = sorted(manies)
-            rows = htyping.type_many_loci([packed[k] for k in ks], [manies[k][1] for k in ks], light=True, em_fast=not args.em_exact)
+            rows = htyping.type_many_loci([packed[k] for k in ks], [manies[k][1] for k in ks], light=True, em_fast=False if args.em_exact else None)
             for k, row in zip(ks, rows):
                 for n, r in zip(manies[k][0], row):
                     out[n] = r
@@ -856,10 +856,10 @@ def run_panel64(args, rank, local_rank, world, dist):
         t0 = time.perf_counter()
         n_other = 3
         for _ in range(n_other):
-            rows_o = htyping.type_many_loci([packed[k] for k in ks], [manies[k][1] for k in ks], light=True, em_fast=bool(args.em_exact))
+            rows_o = htyping.type_many_loci([packed[k] for k in ks], [manies[k][1] for k in ks], light=True, em_fast=None if args.em_exact else False)
         dt = (time.perf_counter() - t0) / n_other
         same = sum(1 for k, row in zip(ks, rows_o) for n, r in zip(manies[k][0], row) if sorted(r[1]) == sorted(last[n][1]))
-        other = {"em_arithmetic": "table lookups (hgx_type_opts.em_fast = 1)" if args.em_exact else "reference order (hgx_type_opts.em_fast = 0: bit-identical abundances)",
+        other = {"em_arithmetic": "table lookups (the many-task calls' default)" if args.em_exact else "reference order (hgx_type_opts.em_fast = 2: bit-identical abundances)",
                  "ms_per_step": round(dt * 1e3, 3), "value": round(reads / dt, 1), "steps": n_other, "tasks_with_the_same_top2_as_the_timed_form": same}
     e2e = None
     if want_files and manies:
@@ -880,7 +880,7 @@ def run_panel64(args, rank, local_rank, world, dist):
                 t1 = time.perf_counter()
                 mbs = [engine.ManyBatch(packed[k], got_b[k]) for k in ks]
                 t2 = time.perf_counter()
-                rows_f = htyping.type_many_loci([packed[k] for k in ks], mbs, light=True, em_fast=not args.em_exact)
+                rows_f = htyping.type_many_loci([packed[k] for k in ks], mbs, light=True, em_fast=False if args.em_exact else None)
                 t3 = time.perf_counter()
                 for m in mbs:
                     m.close()
@@ -915,7 +915,8 @@ def run_panel64(args, rank, local_rank, world, dist):
                 n_tasks, args.panel_pairs),
                 "tasks_with_both_true_alleles_on_top": correct, "tasks": n_tasks, "samples_in_flight_per_gpu": inflight,
                 "form": "one launch chain per task" if args.one_by_one else "hgx_type_many_loci: one launch chain per locus (all its samples together), the EMs of all loci in one launch",
-                "em_arithmetic": ("reference order (bit-identical)" if args.em_exact else "table lookups (within 1e-9; hgx_type_opts.em_fast)") if not args.one_by_one else "default",
+                "em_arithmetic": ("reference order (hgx_type_opts.em_fast = 2: bit-identical)" if args.em_exact else
+                                  "the library's default for hgx_type_many_loci: table lookups (abundances within 1e-8 of the reference; bar 1e-5)") if not args.one_by_one else "default",
                 "parallelism": "(sample, locus) tasks over GPUs by dist.shard (greedy by allele count), no data-path collective",
                 "merged_batches": {packed[k].gene: {"alleles": packed[k].n_alleles, "tasks": m.n_tasks, "pairs": m.n_pairs, "piece_refs": m.n_refs,
                                                     "distinct_pieces": m.n_pieces} for k, (_, m) in sorted(manies.items())},

@@ -128,6 +128,12 @@ struct GateHold {                    // a held gate that is released exactly onc
 
 double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// hgx_type_opts.em_fast as the library uses it inside: 0 = the reference's order (one-workgroup problems), 1 = table lookups, -1 = the
+// reference's order at every size.  The option's 0 means "the default of the entry point": the reference's order for the one-task
+// calls, table lookups for the many-task calls (the throughput API); 2 asks for the reference's order there too.
+inline int em_mode_one(int em_fast) { return em_fast == 2 ? 0 : em_fast; }
+inline int em_mode_many(int em_fast) { return em_fast == 0 ? 1 : (em_fast == 2 ? 0 : em_fast); }
+
 struct EmFastScope {                 // hgx_type_opts.em_fast for the EMs of this call (this thread)
     int old;
     explicit EmFastScope(int on) : old(hgx_em_set_fast(on)) {}
@@ -543,7 +549,7 @@ extern "C" int hgx_type_dbatch(hgx_typing **out, const hgx_locus *loc, const hgx
     t->n_reads = db->n_reads; t->n_pairs = db->n_pairs; t->n_pieces = db->n_pieces; t->n_refs = db->n_refs; t->n_alleles = loc->A;
     if (db->n_reads <= 0) { *out = t; return HGX_OK; }                                           // core:1589-1590
     GateHold gate(opts->gate);
-    EmFastScope em_mode(opts->em_fast);
+    EmFastScope em_mode(em_mode_one(opts->em_fast));
     StreamSet ss;
     int rc = acquire_streams(ss);
     if (!rc) rc = type_impl(t, loc, ix, db, opts, (hipStream_t)stream, ss, gate);
@@ -565,7 +571,7 @@ extern "C" int hgx_type_classes(hgx_typing **out, const hgx_locus *loc, hgx_clas
     t->n_reads = n_reads; t->n_pairs = n_pairs; t->n_alleles = loc->A;
     if (n_reads <= 0) { *out = t; return HGX_OK; }
     hipStream_t st = (hipStream_t)stream;
-    EmFastScope em_mode(opts->em_fast);
+    EmFastScope em_mode(em_mode_one(opts->em_fast));
     GeneSide gs;
     int rc = gene_rank(gene_cl, loc->A, loc->a_pad, st, gs);
     if (!rc) {
@@ -947,8 +953,8 @@ struct ManyRun {
                 hgx_emx_job J{};
                 J.bits = cl1()->d_bits + (size_t)off1()[t] * w64; J.count = cl1()->d_count + off1()[t]; J.rank = m->d_rank;
                 J.C = C; J.w64 = w64; J.a_pad = a_pad; J.remove_low = hla ? (opts->remove_low ? 1 : 0) : 0;
-                J.fast = opts->em_fast > 0 ? 1 : 0;
-                J.any_size = opts->em_fast < 0 ? 1 : 0;
+                J.fast = em_mode_many(opts->em_fast) > 0 ? 1 : 0;
+                J.any_size = em_mode_many(opts->em_fast) < 0 ? 1 : 0;
                 J.prob = nullptr; J.first = nullptr; J.n_out = A;
                 jobs.push_back(J);
                 job_task.push_back(t);
@@ -1140,7 +1146,7 @@ int run_many(std::vector<ManyRun> &runs, hgx_typing ***out, hipStream_t st) {
 extern "C" int hgx_type_many(hgx_typing **out, int32_t *rc_out, const hgx_locus *loc, const hgx_index *ix, hgx_many *m,
                              const hgx_type_opts *opts, void *stream) {
     ARGCHK(opts);
-    EmFastScope em_mode(opts->em_fast);        // (tasks that fall back to the one-task EM follow the same setting)
+    EmFastScope em_mode(em_mode_many(opts->em_fast));        // (tasks that fall back to the one-task EM follow the same setting)
     std::vector<ManyRun> runs(1);
     int rc = runs[0].init(out, rc_out, loc, ix, m, opts, (hipStream_t)stream);
     if (rc) return rc;
@@ -1158,7 +1164,7 @@ extern "C" int hgx_type_many_loci(int32_t n_loci, hgx_typing ***out, int32_t **r
         ARGCHK(out[i] && loci[i] && ixs[i] && manies[i]);
         for (int t = 0; t < manies[i]->n_tasks; ++t) out[i][t] = nullptr;
     }
-    EmFastScope em_mode(opts->em_fast);
+    EmFastScope em_mode(em_mode_many(opts->em_fast));
     std::vector<ManyRun> runs((size_t)n_loci);
     int rc = HGX_OK;
     for (int i = 0; i < n_loci && !rc; ++i) rc = runs[i].init(out[i], rc_out ? rc_out[i] : nullptr, loci[i], ixs[i], manies[i], opts, (hipStream_t)stream);

@@ -110,9 +110,14 @@ class LocusResult:
 
 
 def _em_mode(em_fast):
-    """hgx_type_opts.em_fast: False / 0 = the reference's order where the one-workgroup kernel takes the problem (default), True / 1 =
+    """hgx_type_opts.em_fast: None = the entry point's default (one-task calls: the reference's order where the one-workgroup kernel
+    takes the problem; many-task calls: table lookups), False = the reference's order (2: also in the many-task calls), True / 1 =
     table lookups, -1 = the reference's order at every size (validation mode: slow beyond 4096 classes)."""
-    return -1 if (em_fast is not True and em_fast is not False and int(em_fast) < 0) else int(bool(em_fast))
+    if em_fast is None:
+        return 0
+    if em_fast is False:
+        return 2
+    return -1 if (em_fast is not True and int(em_fast) < 0) else (1 if (em_fast is True or int(em_fast) == 1) else int(em_fast))
 
 
 def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discordant=False,
@@ -237,7 +242,7 @@ def type_file(pl, alignment_fname, regions=None, num_editdist=2, error_correctio
         L.hgx_typing_destroy(h)
 
 
-def type_many(pl, many, remove_low=True, stream=None, return_errors=False, em_fast=False):
+def type_many(pl, many, remove_low=True, stream=None, return_errors=False, em_fast=None):
     """Every task of a merged batch (engine.ManyBatch: many samples of ONE locus) in one call into libhgx (hgx_type_many): one
     launch chain for all tasks instead of one per task -- the many-samples form of the per-locus body of typing()
     (typing_core.py:370, /root/reference/hisatgenotype:613-665).  Returns one LocusResult per task, each identical to
@@ -272,7 +277,7 @@ def type_many(pl, many, remove_low=True, stream=None, return_errors=False, em_fa
     return out
 
 
-def type_many_loci(pls, manies, remove_low=True, stream=None, light=False, em_fast=False):
+def type_many_loci(pls, manies, remove_low=True, stream=None, light=False, em_fast=None):
     """A whole panel in one call (hgx_type_many_loci): `manies[i]` = the merged batch of locus `pls[i]`'s samples.  The loci are
     scored side by side (a host thread and stream pair per locus); the EMs of all their tasks go out in ONE launch.  Returns a list (per locus) of lists (per task)
     of LocusResult -- or, with `light`, of (num_reads, [top-2 allele names], EM iterations): what a throughput run looks at."""

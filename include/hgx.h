@@ -416,13 +416,17 @@ typedef struct hgx_type_opts {
                                  classes exist, so that ONE bandwidth-bound front runs at a time, beside the others' EM phases */
     void *ev_compat_begin, *ev_compat_end;   /* optional hipEvent_t recorded around hgx_piece_compat                      */
     void *ev_pairs_begin, *ev_pairs_end;     /* ... and around the gene-level hgx_pair_classes launch (bench.py)           */
-    int32_t em_fast;          /* EM #1 of problems of up to 4096 classes x 8192 alleles: 0 (default) = the reference's own order of
-                                 floating-point operations (bit-identical abundances, hgx_emx.hip); 1 = table-lookup arithmetic on
-                                 the same one-workgroup kernel: ~5x faster, abundances within 1e-8 (typically 1e-11; bar 1e-5), same
-                                 stopping and pruning rules.  Larger problems take the chip-wide table-lookup path (<= 1e-9),
-                                 unless em_fast = -1: the reference's order at EVERY size (k_emx up to 32768 classes, in cluster mode for
-                                 a lone large problem; bit-identical abundances for any EM: 33 ms per step for a 1 M-read sample with
-                                 a 16 000-class EM #1 instead of 2.2 ms) */
+    int32_t em_fast;          /* arithmetic of EM #1 for problems of up to 4096 classes x 8192 alleles (the one-workgroup kernel, hgx_emx.hip):
+                                   0  the entry point's default: the ONE-TASK calls (hgx_type_dbatch / _batch / _file / _classes) run the
+                                      reference's own order of floating-point operations -- abundances, pruning and stopping decisions
+                                      bit-identical to typing_common.py:1282-1410; the MANY-TASK calls (hgx_type_many / _many_loci: the
+                                      throughput API) run table-lookup arithmetic on the same kernel: ~3x faster per panel, abundances
+                                      within 1e-8 of the reference (typically 1e-11; bar 1e-5), same stopping and pruning rules;
+                                   1  table lookups in the one-task calls too;
+                                   2  the reference's order in the many-task calls too (bit-identical; the hand-off EM always is);
+                                  -1  the reference's order at EVERY size (k_emx up to 32768 classes, in cluster mode for a lone large
+                                      problem: 33 ms per step for a 1 M-read sample with a 16 000-class EM #1 instead of 2 ms).
+                                 Larger problems (EM #1 of a deep sample) take the chip-wide table-lookup path (<= 1e-9) unless -1. */
 } hgx_type_opts;
 
 int hgx_dbatch_create(hgx_dbatch **out, const hgx_batch *b, void *stream);     /* upload; returns when the copy is complete */

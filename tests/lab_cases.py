@@ -109,7 +109,7 @@ def test_em_grid_equals_per_pass():
 
 def test_narrow_table_form_agrees_with_the_product_path():
     """k_lut4 (round 4, lab: a workgroup owns its rows for the whole of K, 4-bit tables, no cross-workgroup combine -- measured 2.3x
-    SLOWER than the 8-bit slab form, tools/em_forms.py): same iteration counts, abundances within 1e-12, plain and fused steps,
+    SLOWER than the 8-bit slab form, tools/em_forms.py): same iteration counts, abundances within 1e-10, plain and fused steps,
     one and several slabs in both passes."""
     rng = np.random.RandomState(5)
     for C_, A, a_pad in [(5000, 700, 1024), (9000, 2600, 3072), (16098, 4549, 7168), (4200, 6000, 6144)]:
@@ -130,4 +130,4 @@ def test_narrow_table_form_agrees_with_the_product_path():
                     p, it = cl2.em(A, low, ln)
                 assert it == it_ref, (C_, A, low, use_len, extra, it, it_ref)
                 assert np.array_equal(p < 0, p_ref < 0)
-                assert np.max(np.abs(p - p_ref)) <= 1e-12, (C_, A, extra, float(np.max(np.abs(p - p_ref))))
+                assert np.max(np.abs(p - p_ref)) <= 1e-10, (C_, A, extra, float(np.max(np.abs(p - p_ref))))

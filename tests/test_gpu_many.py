@@ -46,14 +46,23 @@ def test_many_equals_one_by_one_hla(n_alleles, n_vars, pairs):
     many = engine.ManyBatch(pl, batches)
     assert many.n_pairs == sum(b.n_pairs for b in batches) and many.n_pieces <= sum(b.n_pieces for b in batches)
     for low in (True, False):
-        got = htyping.type_many(pl, many, remove_low=low)
+        got = htyping.type_many(pl, many, remove_low=low, em_fast=False)        # the reference's order of operations (em_fast = 2)
         assert len(got) == len(batches)
         for g, b in zip(got, batches):
             _same(g, _one(pl, b, low))
-    # throughput arithmetic (hgx_type_opts.em_fast): still task for task what the one-task path gives with the same option
-    got = htyping.type_many(pl, many, em_fast=True)
+    # throughput arithmetic (the many-task calls' DEFAULT: hgx_type_opts.em_fast = 0 there means table lookups): task for task
+    # what the one-task path gives with em_fast = 1, and within 1e-8 of the reference-order results
+    got = htyping.type_many(pl, many)
     for g, b in zip(got, batches):
         _same(g, _one(pl, b, True, em_fast=True))
+    for g, h in zip(got, htyping.type_many(pl, many, em_fast=True)):
+        _same(g, h)
+    for g, b in zip(got, batches):
+        want = _one(pl, b, True)
+        assert [e["n_iter"] for e in g.em] == [e["n_iter"] for e in want.em]
+        assert [a for a, _ in g.gene_prob] == [a for a, _ in want.gene_prob] or max(abs(p - q) for (_, p), (_, q) in zip(g.gene_prob, want.gene_prob)) <= 1e-8
+        for (_, p), (_, q) in zip(sorted(g.gene_prob), sorted(want.gene_prob)):
+            assert abs(p - q) <= 1e-8
     # the same call again on the same resident batch (buffers recycled, scratch reused): identical
     again = htyping.type_many(pl, many)
     for g, h in zip(again, htyping.type_many(pl, many)):
@@ -71,7 +80,7 @@ def test_many_equals_one_by_one_str_locus():
         sam = synth.simulate_sam_fast(loc, sample, n, read_len=100, frag_len=(200, 300), err_rate=0.002, seed=3 * s + 2)
         batches.append(pl.parse_sam(sam))
     many = engine.ManyBatch(pl, batches)
-    got = htyping.type_many(pl, many, return_errors=True)
+    got = htyping.type_many(pl, many, return_errors=True, em_fast=False)
     for g, b in zip(got, batches):
         try:
             want = _one(pl, b)
@@ -101,7 +110,7 @@ def test_many_fuzz_cases_with_tiny_tasks(seed):
     pl = hl.PackedLocus.from_synth(loc)
     batches = [pl.parse_sam(s) for s in sams]
     many = engine.ManyBatch(pl, batches)
-    got = htyping.type_many(pl, many, return_errors=True)
+    got = htyping.type_many(pl, many, return_errors=True, em_fast=False)
     for t, sam in enumerate(sams):
         try:
             one = htyping.type_locus(pl, sam) if sam else None

@@ -85,7 +85,7 @@ if __name__ == "__main__":
         pl = hl.PackedLocus.from_synth(loc)
         batches = [pl.parse_sam(s) for s in sams]
         many = engine.ManyBatch(pl, batches)
-        got = htyping.type_many(pl, many, return_errors=True)
+        got = htyping.type_many(pl, many, return_errors=True, em_fast=False)
         why = []
         for t, (sam, b) in enumerate(zip(sams, batches)):
             try:
