@@ -328,170 +328,10 @@ extern "C" int hgx_index_device_block(const hgx_index *ix, void **p, size_t *byt
 
 // ------------------------------------------------------------------------------------------------
 // 8a-5 stage 1: piece x allele compatibility.  compat(a) <=> AND_i ((bits[lo+i][a] & MP_i) == P_i)
-// One wavefront per (piece, 16 x 64 alleles): lane = allele, masks are wave-uniform (SGPRs), each
-// word row is a 256-byte coalesced load, the 64 verdicts leave as one __ballot word.  Any piece order is
-// correct; tables sorted by lo_word (as the front-end emits them) get L1 reuse of the index rows.
 // ------------------------------------------------------------------------------------------------
-#define PC_GROUPS 16
-__global__ __launch_bounds__(256) void k_piece_compat(const uint32_t *__restrict__ bits, int a_pad,
-                                                      const hgx_piece *__restrict__ pieces,
-                                                      const uint32_t *__restrict__ masks, int n_pieces,
-                                                      uint64_t *__restrict__ compat, int w64, int chunks) {
-    const int lane = threadIdx.x & 63;
-    const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    // chunk-major: consecutive waves score consecutive pieces (the front-end sorts the table by lo_word) against the
-    // SAME 1024-allele column block, so a CU's L1 keeps serving the few index rows they share
-    const int chunk = (int)(wave / n_pieces);
-    const int piece = (int)(wave % n_pieces);
-    if (chunk >= chunks) return;
-    const hgx_piece pc = pieces[piece];
-    const int lo = __builtin_amdgcn_readfirstlane((int)pc.lo_word);
-    const int nw = __builtin_amdgcn_readfirstlane((int)pc.n_words);
-    const uint32_t *m = masks + __builtin_amdgcn_readfirstlane((int)pc.mask_off);
-    uint64_t mine = 0;
-    const int g_end = min(PC_GROUPS, w64 - chunk * PC_GROUPS);
-    for (int g = 0; g < g_end; ++g) {
-        const int a = (chunk * PC_GROUPS + g) * 64 + lane;
-        const uint32_t *col = bits + (size_t)lo * a_pad + a;
-        bool ok = true;
-        for (int i = 0; i < nw; ++i) {
-            const uint32_t r = col[(size_t)i * a_pad];
-            ok = ok && ((r & m[2 * i]) == m[2 * i + 1]);
-        }
-        const uint64_t b = __ballot(ok);
-        if (lane == g) mine = b;
-    }
-    if (lane < g_end) compat[(size_t)piece * w64 + chunk * PC_GROUPS + lane] = mine;
-}
-
-// ------------------------------------------------------------------------------------------------
-// LDS-tiled form (the one hgx_piece_compat launches).  The kernel above re-reads the index rows of a piece's
-// word range from L2 for every piece (rocprof: ~9 TB/s of L2 traffic, the whole 0.8 ms); here a workgroup
-// = 1024 alleles x 256 consecutive pieces stages what they share once:
-//   * the pieces' descriptors and (MP, P) mask words            -> LDS (broadcast reads in the loop),
-//   * the index rows of the window of <= 8 variant words the pieces cover -> LDS tile[word][allele]
-//     (the front-end sorts pieces by lo_word, so 256 neighbours span one or two words plus their length; 8 words keep the
-//     workgroup at 50 KB of LDS = three workgroups per CU, which matters more than the occasional extra window);
-//   * thread = allele: per piece and word one conflict-free ds_read_b32 + xor + and-or, the 64 verdicts of
-//     a wave leave as a ballot that lane (piece mod 64) keeps; one store per 64 pieces.
-// Pieces that do not fit the current window start a new one (any piece order stays correct).
-// ------------------------------------------------------------------------------------------------
-#define PT_W 8
-#define PT_PB 256
-#define PT_NW 8
-#define PT_T 512              // threads per workgroup: every thread scores TWO alleles (tid and tid + 512) per piece, so the
-                              // broadcast mask reads, descriptor broadcasts and loop control are paid once per 128 alleles
-__global__ __launch_bounds__(PT_T) void k_piece_compat_tiled(const uint32_t *__restrict__ bits, int a_pad, int n_index_words,
-                                                             const hgx_piece *__restrict__ pieces,
-                                                             const uint32_t *__restrict__ masks, int n_pieces,
-                                                             uint64_t *__restrict__ compat, int w64) {
-    __shared__ uint32_t tile[PT_W][1024];
-    __shared__ uint32_t smask[PT_PB][2 * PT_NW];
-    __shared__ int s_lo[PT_PB], s_nw[PT_PB];
-    __shared__ int s_end;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int chunk = blockIdx.y;
-    const int p0 = blockIdx.x * PT_PB;
-    const int np = min(PT_PB, n_pieces - p0);
-    for (int t = tid; t < PT_PB * 4; t += PT_T) {   // stage descriptors and masks: t = (piece, quarter of its 16 mask words)
-        const int p = t >> 2, q = t & 3;
-        if (p < np) {
-            const hgx_piece pc = pieces[p0 + p];
-            const int nw2 = 2 * (int)pc.n_words;
-            if (q == 0) { s_lo[p] = pc.lo_word; s_nw[p] = pc.n_words; }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int i = 4 * q + k;
-                smask[p][i] = i < nw2 ? masks[pc.mask_off + i] : 0u;
-            }
-        }
-    }
-    __syncthreads();
-    const int a0 = chunk * 1024 + tid, a1 = a0 + PT_T;
-    const int wslot0 = chunk * 16 + wv, wslot1 = wslot0 + PT_T / 64;   // this wave's two 64-allele words of the compat row
-    int cur = 0;
-    while (cur < np) {
-        if (s_nw[cur] > PT_NW) {
-            // a piece wider than the staging area (long deletions / dense variant runs): straight from the index
-            const hgx_piece pc = pieces[p0 + cur];
-            const uint32_t *m = masks + pc.mask_off;
-            bool ok0 = true, ok1 = true;
-            for (int i = 0; i < (int)pc.n_words; ++i) {
-                const uint32_t r0 = a0 < a_pad ? bits[(size_t)(pc.lo_word + i) * a_pad + a0] : 0u;
-                const uint32_t r1 = a1 < a_pad ? bits[(size_t)(pc.lo_word + i) * a_pad + a1] : 0u;
-                ok0 = ok0 && ((r0 & m[2 * i]) == m[2 * i + 1]);
-                ok1 = ok1 && ((r1 & m[2 * i]) == m[2 * i + 1]);
-            }
-            const uint64_t b0 = __ballot(ok0), b1 = __ballot(ok1);
-            if (lane == 0 && wslot0 < w64) compat[(size_t)(p0 + cur) * w64 + wslot0] = b0;
-            if (lane == 0 && wslot1 < w64) compat[(size_t)(p0 + cur) * w64 + wslot1] = b1;
-            ++cur;
-            continue;
-        }
-        const int win_lo = s_lo[cur];
-        if (tid == 0) s_end = np;
-        __syncthreads();
-        if (tid >= cur && tid < np) {
-            const int l = s_lo[tid];
-            if (l < win_lo || s_nw[tid] > PT_NW || l + s_nw[tid] - win_lo > PT_W) atomicMin(&s_end, tid);
-        }
-#pragma unroll
-        for (int i = 0; i < PT_W; ++i) {
-            const int w = win_lo + i;
-            tile[i][tid] = (w < n_index_words && a0 < a_pad) ? bits[(size_t)w * a_pad + a0] : 0u;
-            tile[i][tid + PT_T] = (w < n_index_words && a1 < a_pad) ? bits[(size_t)w * a_pad + a1] : 0u;
-        }
-        __syncthreads();
-        const int end = s_end;
-        for (int g0 = cur; g0 < end; g0 += 64) {
-            const int cnt = min(end, g0 + 64) - g0;
-            // the group's descriptors, one piece per lane: no LDS round trip for them inside the piece loop
-            const int d_off = lane < cnt ? s_lo[g0 + lane] - win_lo : 0;
-            const int d_nw = lane < cnt ? s_nw[g0 + lane] : 1;
-            uint32_t m0lo = 0, m0hi = 0, m1lo = 0, m1hi = 0;
-            for (int k = 0; k < cnt; ++k) {
-                const int off = __builtin_amdgcn_readlane(d_off, k);
-                const int nw = __builtin_amdgcn_readlane(d_nw, k);
-                const uint32_t *trow = &tile[off][tid];
-                const uint2 *mk = (const uint2 *)&smask[g0 + k][0];
-                uint32_t bad0, bad1;
-                // straight-line per width: all LDS reads of the piece are issued together, then one wait
-                switch (nw) {
-#define PT_CASE(N)                                                                                                     \
-    case N: {                                                                                                          \
-        uint32_t r0[N], r1[N];                                                                                         \
-        uint2 m[N];                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < N; ++i) { r0[i] = trow[i * 1024]; r1[i] = trow[i * 1024 + PT_T]; m[i] = mk[i]; } \
-        bad0 = 0; bad1 = 0;                                                                                            \
-        _Pragma("unroll") for (int i = 0; i < N; ++i) { bad0 |= (r0[i] ^ m[i].y) & m[i].x; bad1 |= (r1[i] ^ m[i].y) & m[i].x; } \
-    } break;
-                    PT_CASE(1) PT_CASE(2) PT_CASE(3) PT_CASE(4) PT_CASE(5) PT_CASE(6) PT_CASE(7)
-                    default: PT_CASE(8)
-#undef PT_CASE
-                }
-                const uint64_t b0 = __ballot(bad0 == 0), b1 = __ballot(bad1 == 0);
-                // lane k keeps the verdict words of piece k: EXEC = 1 << k around four moves (no compare + selects)
-                {
-                    uint64_t saved;
-                    asm volatile("s_mov_b64 %[sv], exec\n\ts_lshl_b64 exec, 1, %[k]\n\tv_mov_b32 %[a], %[sa]\n\tv_mov_b32 %[b], %[sb]\n\t"
-                                 "v_mov_b32 %[c], %[sc]\n\tv_mov_b32 %[d], %[sd]\n\ts_mov_b64 exec, %[sv]"
-                                 : [a] "+v"(m0lo), [b] "+v"(m0hi), [c] "+v"(m1lo), [d] "+v"(m1hi), [sv] "=&s"(saved)
-                                 : [sa] "s"((uint32_t)b0), [sb] "s"((uint32_t)(b0 >> 32)), [sc] "s"((uint32_t)b1),
-                                   [sd] "s"((uint32_t)(b1 >> 32)), [k] "s"(k)
-                                 : "scc");
-                }
-            }
-            if (lane < cnt) {
-                uint64_t *row = compat + (size_t)(p0 + g0 + lane) * w64;
-                if (wslot0 < w64) row[wslot0] = ((uint64_t)m0hi << 32) | m0lo;
-                if (wslot1 < w64) row[wslot1] = ((uint64_t)m1hi << 32) | m1lo;
-            }
-        }
-        __syncthreads();
-        cur = end;
-    }
-}
+#ifdef HGX_LAB
+#include "lab/hgx_compat_lab.inc"         // rounds 1-3: the L2-served and the LDS-tiled kernels (comparison forms)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Pattern form (round 4; the one hgx_piece_compat launches when the locus fits).  Of the ~7 000 alleles of an HLA locus only
@@ -700,27 +540,36 @@ extern "C" int hgx_piece_compat(const hgx_index *ix, const hgx_piece *pieces, co
     ARGCHK(ix && n_pieces >= 0);
     if (n_pieces == 0) return HGX_OK;
     ARGCHK(pieces && masks && compat);
-    const bool untiled = hgx_test_switch("piece_untiled") != nullptr;     // the L2-served kernel, kept for comparison
-    const bool tiled = hgx_test_switch("piece_tiled") != nullptr;         // round 1-3's LDS-tiled kernel, kept for comparison
-    if (!untiled && !tiled) {
-        const int rc_ = ensure_patterns(const_cast<hgx_index *>(ix), (hipStream_t)stream);
-        if (rc_) return rc_;
-    }
-    if (!untiled && !tiled && ix->pat_state == 1) {
-        const int thr = std::min(PP_T, std::max(64, ((ix->a_pad + 64 * PP_G - 1) / (64 * PP_G)) * 64));
-        const int per_wg = thr * PP_G;
-        hipLaunchKernelGGL(k_piece_compat_pat, dim3((n_pieces + PP_PB - 1) / PP_PB, (ix->a_pad + per_wg - 1) / per_wg), dim3(thr), 0,
-                           (hipStream_t)stream, ix->d_bits, ix->a_pad, ix->n_words, ix->d_pid, ix->d_vals, ix->d_nval, pieces, masks, n_pieces,
-                           compat, ix->w64);
-    } else if (untiled) {
+#ifdef HGX_LAB
+    const bool untiled = hgx_test_switch("piece_untiled") != nullptr;     // the L2-served kernel of round 1
+    const bool tiled = hgx_test_switch("piece_tiled") != nullptr;         // the LDS-tiled kernel of rounds 1-3
+    if (untiled) {
         const int chunks = (ix->w64 + PC_GROUPS - 1) / PC_GROUPS;
         const long waves = (long)n_pieces * chunks;
         const long blocks = (waves + 3) / 4;
         hipLaunchKernelGGL(k_piece_compat, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ix->d_bits, ix->a_pad,
                            pieces, masks, n_pieces, compat, ix->w64, chunks);
-    } else {
+        HIPCHK(hipGetLastError());
+        return HGX_OK;
+    }
+    if (tiled) {
         hipLaunchKernelGGL(k_piece_compat_tiled, dim3((n_pieces + PT_PB - 1) / PT_PB, (ix->a_pad + 1023) / 1024), dim3(PT_T), 0,
                            (hipStream_t)stream, ix->d_bits, ix->a_pad, ix->n_words, pieces, masks, n_pieces, compat, ix->w64);
+        HIPCHK(hipGetLastError());
+        return HGX_OK;
+    }
+#endif
+    {
+        const int rc_ = ensure_patterns(const_cast<hgx_index *>(ix), (hipStream_t)stream);
+        if (rc_) return rc_;
+    }
+    if (ix->pat_state != 1) { hgx_set_error("the locus does not fit the pattern tables of the piece x allele kernel (more than 65535 distinct values in a variant word)"); return HGX_EINVAL; }
+    {
+        const int thr = std::min(PP_T, std::max(64, ((ix->a_pad + 64 * PP_G - 1) / (64 * PP_G)) * 64));
+        const int per_wg = thr * PP_G;
+        hipLaunchKernelGGL(k_piece_compat_pat, dim3((n_pieces + PP_PB - 1) / PP_PB, (ix->a_pad + per_wg - 1) / per_wg), dim3(thr), 0,
+                           (hipStream_t)stream, ix->d_bits, ix->a_pad, ix->n_words, ix->d_pid, ix->d_vals, ix->d_nval, pieces, masks, n_pieces,
+                           compat, ix->w64);
     }
     HIPCHK(hipGetLastError());
     return HGX_OK;

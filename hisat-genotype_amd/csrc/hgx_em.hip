@@ -501,209 +501,9 @@ __global__ __launch_bounds__(BLOCK) void k_em_finish(const double *__restrict__ 
 #endif
 
 
-// ------------------------------------------------------------------------------------------------------------
-// Whole EM in ONE workgroup for small problems (C <= SMALL_C classes, a_pad <= 8192): the exon->gene hand-off EM and
-// STR loci have a few dozen classes, where eight launches per iteration cost far more than the arithmetic.
-// Same step sequence and summation structure as the multi-launch path; vectors live in registers (thread = the
-// elements 64*(8*wave + k) + lane), the class matrix is read row-major for both halves of the map.
-// ------------------------------------------------------------------------------------------------------------
-constexpr int SMALL_C = 64;
-
-struct SmallVec {
-    double v[EPT];
-    uint32_t pres;      // bit k: element k present
-};
-
-__device__ __forceinline__ double sv_total(const SmallVec &a, double (*sh)[NWAVE]) {
-    double s[1] = {0.0};
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) if ((a.pres >> k) & 1u) s[0] += a.v[k];
-    block_sum_n<1>(s, sh);
-    return s[0];
-}
-
-// out = T(in): in is used as in.v[k] / scale.  Rows half through LDS partials, columns half thread-local.
-__device__ __forceinline__ void small_map(const uint64_t *__restrict__ B, int C, int n_words, const int64_t *__restrict__ count,
-                                          const double *__restrict__ len_reg, bool use_len, const SmallVec &in, double scale,
-                                          bool init, SmallVec &out, double (*part)[NWAVE], double *wc, int wv, int lane,
-                                          int wbase, uint32_t valid) {
-    // `valid` bit k: this thread really owns element k (waves past the matrix width read clamped words: their x is 0)
-    double x[EPT];
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-        const bool ok = (valid >> k) & 1u;
-        x[k] = !ok ? 0.0 : (init ? 1.0 : (((in.pres >> k) & 1u) ? in.v[k] / scale : 0.0));
-    }
-    auto row_word = [&](uint64_t mine, int k) -> uint64_t {      // word k of this wave's 8-word slice, as a scalar
-        return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(mine >> 32), k) << 32) |
-               (uint32_t)__builtin_amdgcn_readlane((int)mine, k);
-    };
-    for (int c0 = 0; c0 < C; c0 += RB) {                            // eight classes per cross-lane reduction
-        double acc[RB];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            acc[r] = 0.0;
-            const int c = min(c0 + r, C - 1);
-            const uint64_t mine = B[(size_t)c * n_words + wbase + (lane & 7)];     // B is the LDS copy of the class matrix
-#pragma unroll
-            for (int k = 0; k < 8; ++k) masked_add(acc[r], x[k], row_word(mine, k));
-        }
-        const double s8 = reduce8<false>(acc, lane);
-        if ((lane & 7) == 0) {
-            const int r = c0 + ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
-            if (r < C) part[r][wv] = s8;
-        }
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < C) {
-        double t = 0.0;
-#pragma unroll
-        for (int i = 0; i < NWAVE; ++i) t += part[threadIdx.x][i];
-        wc[threadIdx.x] = t > 0.0 ? (double)count[threadIdx.x] / t : 0.0;
-    }
-    __syncthreads();
-    double acc[EPT];
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) acc[k] = 0.0;
-    for (int c = 0; c < C; ++c) {
-        const uint64_t mine = B[(size_t)c * n_words + wbase + (lane & 7)];
-        const double wv_c = wc[c];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) masked_add(acc[k], wv_c, row_word(mine, k));
-    }
-    out.pres = 0;
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-        const bool in_k = ((valid >> k) & 1u) && (init || ((in.pres >> k) & 1u));
-        double v = 0.0;
-        if (in_k && acc[k] > 0.0) {
-            v = init ? acc[k] : (in.v[k] / scale) * acc[k];
-            if (use_len) v = v / len_reg[k];
-            out.pres |= 1u << k;
-        }
-        out.v[k] = v;
-    }
-    __syncthreads();          // part / wc are reused by the next application
-}
-
-__global__ __launch_bounds__(BLOCK) void k_em_small(const uint64_t *__restrict__ Bg, int C, int n_words, int a_pad,
-                                                    const int64_t *__restrict__ count, const double *__restrict__ len,
-                                                    int remove_low, double *__restrict__ out, double *__restrict__ scal) {
-    // the class matrix (<= 64 x 128 words) is copied into LDS once: every map application walks all of it twice, and from
-    // one workgroup each global round trip would be fully exposed
-    extern __shared__ __attribute__((aligned(16))) uint64_t Bl[];
-    for (int i = threadIdx.x; i < C * n_words; i += BLOCK) Bl[i] = Bg[i];
-    __syncthreads();
-    const uint64_t *B = Bl;
-    __shared__ double sh[3][NWAVE];
-    __shared__ double shm[NWAVE];
-    __shared__ double part[SMALL_C][NWAVE];
-    __shared__ double wc[SMALL_C];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wbase = min(8 * wv, n_words - 8);
-    const bool own = 8 * wv + 8 <= n_words;                 // waves beyond the matrix width own no elements
-    double len_reg[EPT];
-    int elem[EPT];
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-        elem[k] = 64 * (8 * wv + k) + lane;
-        len_reg[k] = (len && own && elem[k] < a_pad) ? len[elem[k]] : 1.0;
-    }
-    const bool use_len = len != nullptr;
-    uint32_t valid = 0;
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) if (own && elem[k] < a_pad) valid |= 1u << k;
-    SmallVec p, q1, q2, q3, none;
-    none.pres = 0;
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) none.v[k] = 0.0;
-    small_map(B, C, n_words, count, len_reg, use_len, none, 1.0, true, p, part, wc, wv, lane, wbase, valid);   // common:1299-1305
-    double tot = sv_total(p, sh);
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) p.v[k] = ((p.pres >> k) & 1u) ? p.v[k] / tot : 0.0;
-    int iter = 0;
-    double diff = 1.0;
-    bool keyerr = false;
-    while (diff > 0.0001 && iter < 1000) {
-        small_map(B, C, n_words, count, len_reg, use_len, p, 1.0, false, q1, part, wc, wv, lane, wbase, valid);
-        const double tot1 = sv_total(q1, sh);
-        small_map(B, C, n_words, count, len_reg, use_len, q1, tot1, false, q2, part, wc, wv, lane, wbase, valid);
-        const double tot2 = sv_total(q2, sh);
-        double acc[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            if (!((p.pres >> k) & 1u)) continue;
-            if (!((q1.pres >> k) & 1u) || !((q2.pres >> k) & 1u)) { acc[2] = 1.0; continue; }
-            const double p1 = q1.v[k] / tot1, p2 = q2.v[k] / tot2;
-            const double r = p1 - p.v[k];
-            const double v = p2 - p1 - r;
-            acc[0] += r * r;
-            acc[1] += v * v;
-        }
-        block_sum_n<3>(acc, sh);
-        if (acc[2] != 0.0) { keyerr = true; break; }
-        const SmallVec *pn = &q1;
-        double totn = tot1;
-        if (acc[1] > 0.0) {
-            const double g = -sqrt(acc[0] / acc[1]);
-#pragma unroll
-            for (int k = 0; k < EPT; ++k) {
-                if (!((p.pres >> k) & 1u)) continue;
-                const double p1 = q1.v[k] / tot1, p2 = q2.v[k] / tot2;
-                const double r = p1 - p.v[k];
-                const double v = p2 - p1 - r;
-                q2.v[k] = fmax(0.0, p.v[k] - 2 * g * r + g * g * v);
-                q2.pres |= 1u << k;
-            }
-            small_map(B, C, n_words, count, len_reg, use_len, q2, 1.0, false, q3, part, wc, wv, lane, wbase, valid);
-            pn = &q3;
-            totn = sv_total(q3, sh);
-        }
-        double d[1] = {0.0}, mx = 0.0;
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            const bool an = (pn->pres >> k) & 1u;
-            const double x = an ? pn->v[k] / totn : 0.0;
-            if ((p.pres >> k) & 1u) d[0] += an ? fabs(p.v[k] - x) : p.v[k];
-            if (an) mx = fmax(mx, x);
-        }
-        const double tm = block_max(mx, shm);
-        block_sum_n<1>(d, sh);
-        diff = d[0];
-        const bool prune = remove_low && iter >= 10;
-        uint32_t np = 0;
-#pragma unroll
-        for (int k = 0; k < EPT; ++k) {
-            const bool an = (pn->pres >> k) & 1u;
-            const double x = an ? pn->v[k] / totn : 0.0;
-            bool keep = an;
-            if (prune && keep) keep = x >= tm / 10.0;
-            p.v[k] = keep ? x : 0.0;
-            if (keep) np |= 1u << k;
-        }
-        p.pres = np;
-        iter += 1;
-    }
-    // final select_alleles + normalise (common:1402-1407)
-    double mx = 0.0;
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) if ((p.pres >> k) & 1u) mx = fmax(mx, p.v[k]);
-    const double tm = block_max(mx, shm);
-    double s[1] = {0.0};
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-        const bool keep = ((p.pres >> k) & 1u) && (!remove_low || p.v[k] >= tm / 10.0);
-        if (keep) s[0] += use_len ? p.v[k] / len_reg[k] : p.v[k];
-    }
-    block_sum_n<1>(s, sh);
-#pragma unroll
-    for (int k = 0; k < EPT; ++k) {
-        const bool keep = ((p.pres >> k) & 1u) && (!remove_low || p.v[k] >= tm / 10.0);
-        if ((valid >> k) & 1u) out[elem[k]] = keep ? (use_len ? p.v[k] / len_reg[k] / s[0] : p.v[k] / s[0]) : -1.0;
-    }
-    if (tid == 0) { scal[S_ITER] = (double)iter; scal[S_KEYERR] = keyerr ? 1.0 : 0.0; scal[S_DONE] = 1.0; }
-}
+#ifdef HGX_LAB
+#include "lab/hgx_em_small.inc"          // one-workgroup EM for <= 64 classes over many alleles (superseded by k_emx)
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // Whole EM in ONE WAVEFRONT when at most 64 classes involve at most 64 distinct alleles (the exon->gene hand-off EM,
@@ -1023,438 +823,9 @@ __global__ __launch_bounds__(64) void k_em_wave(const uint64_t *__restrict__ B, 
     wave_em_run(E, p, pr, 0, remove_low, use_len, g, out, scal);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Mid-size EM in the REFERENCE'S OWN ORDER (k_em_ref): <= MR_C classes over <= MR_A distinct alleles in ONE workgroup.
-// Same contract as ref_em_run (bit-identical abundances, same pruning and stopping decisions) for problems that do not fit one
-// wavefront: thread j = the j-th allele in name order (= class-key order), classes in dict order.  Per application of the map
-//   rows   thread c walks the members of class c in key order:            alleles_prob += prob[a]            (sequential)
-//   cols   thread j walks the classes containing allele j in dict order:  next[a] += count * prob[a] / alleles_prob
-//          (the quotients of up to four classes are formed side by side, then added in order)
-//   dict insertion order of `next` = (first walked class containing the allele, key order) -- re-derived (an LDS bitonic sort)
-//          only when the membership or the set of walked classes changed
-//   sums over a dict (normalisation totals, SQUAREM sums, prob_diff) = ONE lane adding in insertion order: that is what
-//          `sum(d.values())` does, and no faster order gives the same bits
-// The class matrix is re-laid once per call in the compact name-ordered allele space, both orientations (Rm, Km: L2-resident
-// scratch).  The price of the reference's order is ONE CU: measured (tools/em_mid_timing.py, HGX_MID_STAMPS=1) 0.10 ms per
-// SQUAREM iteration at 200 classes x 300 alleles (9 k class-member pairs), 0.32 ms at 600 x 600 (54 k pairs), 0.65 ms at
-// 1000 x 1000 (150 k), against 0.04-0.07 ms for the table-lookup path's six launches on all CUs -- every pair is a
-// double-precision division per application and four wavefronts share a SIMD.  Taken for problems of up to HGX_EM_MID_NNZ
-// (default 65 536) pairs: small read sets, where abundances are small rationals and a pruning or stopping decision can sit exactly
-// on a rounding (the fuzz cases of DESIGN.md section 4), at a cost of a few ms.  Follows oracle/hgx_oracle.c orc_single_abundance
-// line by line.
-// ------------------------------------------------------------------------------------------------------------
-constexpr int MR_A = 1024, MR_C = 2048;
-constexpr int MR_AW = MR_A / 64, MR_CW = MR_C / 64;
-struct MrLds {
-    double dv[3][MR_A];                 // dict values
-    double tmp[2][MR_A];                // operands of the sequential sums
-    double s[MR_C], n[MR_C];            // alleles_prob and count per class
-    double len[MR_A];
-    unsigned long long valid[MR_CW];    // classes walked by the current application (alleles_prob > 0)
-    unsigned long long sig_in[MR_AW], sig_valid[MR_CW];     // membership / walked classes of the cached insertion order
-    unsigned long long in_now[MR_AW];
-    uint32_t keys[MR_A];
-    int sorted[MR_A];                   // allele id of thread j
-    uint16_t seq[4][MR_A];              // insertion orders (allele threads in dict order)
-    int npos[4];
-    uint8_t din[3][MR_A];               // dict membership
-    double red[NWAVE];
-    double bc[2];                       // broadcast slots of the sequential sums
-    int cache_ord, flag;
-};
-
-#pragma clang fp contract(off)
-// sum of val[j] over the members of the dict (membership `in`) in insertion order `seq`, computed by ONE WAVEFRONT: the lanes
-// fetch 64 consecutive operands side by side (two dependent LDS reads each), then the additions run in order over the lanes'
-// registers (v_readlane) -- a sequential sum at ~10 cycles per element instead of two LDS latencies.  Every lane returns the sum.
-__device__ __forceinline__ double mr_seq_sum(const uint16_t *seq, int np, const double *val, const uint8_t *in) {
-    const int lane = threadIdx.x & 63;
-    double t = 0.0;
-    for (int r0 = 0; r0 < np; r0 += 64) {
-        const int r = r0 + lane;
-        const int j = r < np ? seq[r] : 0;
-        const double x = (r < np && in[j]) ? val[j] : 0.0;            // + 0.0 for a pruned member or past the end: exact
-        const int n = min(64, np - r0);
-        if (n == 64) {
-#pragma unroll
-            for (int k = 0; k < 64; ++k) t = ((t) + (lane_f64(x, k)));
-        } else {
-            for (int k = 0; k < n; ++k) t = ((t) + (lane_f64(x, k)));
-        }
-    }
-    return t;
-}
-__device__ __forceinline__ void mr_seq_sum2(const uint16_t *seq, int np, const double *va, const double *vb, const uint8_t *in,
-                                            double &ta, double &tb) {
-    const int lane = threadIdx.x & 63;
-    ta = 0.0; tb = 0.0;
-    for (int r0 = 0; r0 < np; r0 += 64) {
-        const int r = r0 + lane;
-        const int j = r < np ? seq[r] : 0;
-        const bool m = r < np && in[j];
-        const double x = m ? va[j] : 0.0, y = m ? vb[j] : 0.0;
-        const int n = min(64, np - r0);
-        if (n == 64) {
-#pragma unroll
-            for (int k = 0; k < 64; ++k) { ta = ((ta) + (lane_f64(x, k))); tb = ((tb) + (lane_f64(y, k))); }
-        } else {
-            for (int k = 0; k < n; ++k) { ta = ((ta) + (lane_f64(x, k))); tb = ((tb) + (lane_f64(y, k))); }
-        }
-    }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_em_ref(const uint64_t *__restrict__ B, int C, int n_words, int a_pad,
-                                                  const int64_t *__restrict__ count, const double *__restrict__ len,
-                                                  const int32_t *__restrict__ rank, int remove_low, uint64_t *__restrict__ Rm,
-                                                  uint64_t *__restrict__ Km, double *__restrict__ out, double *__restrict__ scal,
-                                                  int32_t *__restrict__ first_out, int max_nnz, unsigned long long *__restrict__ dbg) {
-    extern __shared__ double lds_raw[];
-    MrLds &S = *reinterpret_cast<MrLds *>(lds_raw);
-    // HGX_MID_STAMPS=1: thread 0's wall_clock64() ticks (10 ns) per stage: [0] set-up, [1] rows, [2] cols, [3] order derivations,
-    // [4] normalisations, [5] SQUAREM / prob_diff sums, [6] number of order derivations
-    unsigned long long acc_t[7] = {0, 0, 0, 0, 0, 0, 0};
-    unsigned long long t_mark = dbg ? wall_clock64() : 0;
-    auto lap = [&](int k) { if (dbg) { const unsigned long long t = wall_clock64(); acc_t[k] += t - t_mark; t_mark = t; } };
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int Cw = (C + 63) / 64;
-    // ---- which alleles occur at all; their name order ---------------------------------------------------------
-    unsigned long long *orw2 = reinterpret_cast<unsigned long long *>(S.tmp[0]);        // (scratch until the EM starts)
-    for (int w = tid; w < n_words; w += BLOCK) orw2[w] = 0ull;
-    __syncthreads();
-    int nz = 0;
-    {
-        const int w = tid & 127, slice = tid >> 7;      // 8 slices of the classes per word
-        unsigned long long acc = 0ull;
-        if (w < n_words)
-            for (int c = slice; c < C; c += 8) { const unsigned long long x = B[(size_t)c * n_words + w]; acc |= x; nz += __popcll(x); }
-        if (acc) atomicOr(&orw2[w], acc);
-    }
-    {
-        // The whole EM runs on ONE CU: every (class, member) pair costs a double-precision division per application of the map.
-        // Beyond `max_nnz` pairs the table-lookup path (all CUs, rounding-level differences) takes the problem instead.
-        nz = (int)wave_sum_u64((uint64_t)nz);
-        if (lane == 0) S.red[wave] = (double)nz;
-        __syncthreads();
-        double tot = 0.0;
-        for (int i = 0; i < NWAVE; ++i) tot += S.red[i];
-        if (tot > (double)max_nnz) {
-            if (tid == 0) { scal[S_FALLBACK] = 1.0; scal[S_DONE] = 1.0; }
-            return;
-        }
-    }
-    __syncthreads();
-    int *base_of = reinterpret_cast<int *>(S.tmp[1]);   // exclusive prefix of the words' bit counts
-    if (tid == 0) {
-        int t = 0;
-        for (int w = 0; w < n_words; ++w) { base_of[w] = t; t += __popcll(orw2[w]); }
-        S.flag = t;
-    }
-    __syncthreads();
-    const int A1 = S.flag;
-    if (A1 > MR_A || A1 == 0) {
-        if (tid == 0) { scal[S_FALLBACK] = 1.0; scal[S_DONE] = 1.0; }
-        return;
-    }
-    const int A1w = (A1 + 63) / 64;
-    for (int w = tid; w < n_words; w += BLOCK) {
-        int id = base_of[w];
-        for (unsigned long long m = orw2[w]; m; m &= m - 1) S.sorted[id++] = 64 * w + __builtin_ctzll(m);
-    }
-    __syncthreads();
-    // name order: bitonic sort of (rank, allele id) over MR_A slots (rank < 2^21 alleles, id < 8192 = 2^13)
-    {
-        unsigned long long *sk = reinterpret_cast<unsigned long long *>(S.tmp[0]);       // orw2 is dead from here on
-        const int g0 = tid < A1 ? S.sorted[tid] : 0;
-        __syncthreads();
-        sk[tid] = tid < A1 ? ((unsigned long long)(uint32_t)rank[g0] << 32 | (uint32_t)g0) : ~0ull;
-        __syncthreads();
-        for (int k = 2; k <= MR_A; k <<= 1)
-            for (int j2 = k >> 1; j2 > 0; j2 >>= 1) {
-                const int p = tid ^ j2;
-                if (p > tid) {
-                    const unsigned long long a = sk[tid], b = sk[p];
-                    const bool up = (tid & k) == 0;
-                    if ((a > b) == up) { sk[tid] = b; sk[p] = a; }
-                }
-                __syncthreads();
-            }
-        const int g1 = (int)(uint32_t)sk[tid];
-        __syncthreads();
-        S.sorted[tid] = tid < A1 ? g1 : 0;
-    }
-    __syncthreads();
-    const int g = S.sorted[tid];
-    const bool alive = tid < A1;
-    // ---- the class matrix in the compact, name-ordered allele space: Rm [C][A1w] (members of a class), Km [A1][Cw] --------
-    // Rm: a wavefront takes a class, holds its row in registers (<= 128 words: two per lane) and every lane picks the bit of
-    // "its" allele out of the word that another lane holds (no gather from memory); Km = 64 x 64 bit transposes of Rm tiles
-    for (int c = wave; c < C; c += NWAVE) {
-        const uint64_t r0 = lane < n_words ? B[(size_t)c * n_words + lane] : 0ull;
-        const uint64_t r1 = lane + 64 < n_words ? B[(size_t)c * n_words + 64 + lane] : 0ull;
-        for (int w = 0; w < A1w; ++w) {
-            const int j = 64 * w + lane;
-            const int gj = j < A1 ? S.sorted[j] : 0;
-            const int wi = gj >> 6;
-            const uint64_t lo = __shfl(r0, wi & 63, 64);
-            const uint64_t hi = n_words > 64 ? __shfl(r1, wi & 63, 64) : 0ull;
-            const bool bit = j < A1 && (((wi < 64 ? lo : hi) >> (gj & 63)) & 1ull);
-            const unsigned long long word = __ballot(bit);
-            if (lane == 0) Rm[(size_t)c * A1w + w] = word;
-        }
-    }
-    __threadfence_block();
-    __syncthreads();
-    for (int item = wave; item < Cw * A1w; item += NWAVE) {
-        const int cb = item / A1w, w = item - cb * A1w;
-        const int c = 64 * cb + lane;
-        const uint64_t x = c < C ? Rm[(size_t)c * A1w + w] : 0ull;      // lane = class, bits = alleles 64 w ..
-        const uint64_t y = wave_transpose64(x);                         // lane = allele 64 w + lane, bits = classes 64 cb ..
-        const int j = 64 * w + lane;
-        if (j < A1) Km[(size_t)j * Cw + cb] = y;
-    }
-    for (int c = tid; c < MR_C; c += BLOCK) S.n[c] = c < C ? (double)count[c] : 0.0;
-    const bool use_len = len != nullptr;
-    S.len[tid] = (use_len && alive) ? len[g] : 1.0;
-    for (int a = tid; a < a_pad; a += BLOCK) out[a] = -1.0;
-    __threadfence_block();
-    __syncthreads();                                     // Rm / Km were written by this workgroup: visible after the barrier
-    const uint64_t *Kme = Km + (size_t)(alive ? tid : 0) * Cw;
-    if (first_out && alive) {
-        int fc = -1;
-        for (int w = 0; w < Cw && fc < 0; ++w) { const uint64_t m = Kme[w]; if (m) fc = 64 * w + __builtin_ctzll(m); }
-        first_out[g] = fc;
-    }
-    const double my_len = S.len[tid];
-    lap(0);
-
-    // ---- helpers ---------------------------------------------------------------------------------------------------
-    auto block_max_exact = [&](double v) -> double {
-        v = wave_max_f64(v);
-        __syncthreads();
-        if (lane == 0) S.red[wave] = v;
-        __syncthreads();
-        double t = S.red[0];
-#pragma unroll
-        for (int i = 1; i < NWAVE; ++i) t = fmax(t, S.red[i]);
-        return t;
-    };
-    // insertion order of dict d when it is filled class by class over the classes of `walk` (NULL = all): (first class, key order)
-    auto derive_order = [&](int d, const unsigned long long *walk, int buf) {
-        uint32_t key = 0xFFFFFFFFu;
-        if (alive && S.din[d][tid]) {
-            int fc = MR_C;
-            for (int w = 0; w < Cw && fc == MR_C; ++w) { const uint64_t m = Kme[w] & (walk ? walk[w] : ~0ull); if (m) fc = 64 * w + __builtin_ctzll(m); }
-            key = (uint32_t)fc << 10 | (uint32_t)tid;
-        }
-        S.keys[tid] = key;
-        __syncthreads();
-        for (int k = 2; k <= MR_A; k <<= 1)
-            for (int j2 = k >> 1; j2 > 0; j2 >>= 1) {
-                const int p = tid ^ j2;
-                if (p > tid) {
-                    const uint32_t a = S.keys[tid], b = S.keys[p];
-                    const bool up = (tid & k) == 0;
-                    if ((a > b) == up) { S.keys[tid] = b; S.keys[p] = a; }
-                }
-                __syncthreads();
-            }
-        const uint32_t kk = S.keys[tid];
-        S.seq[buf][tid] = (uint16_t)(kk & 1023u);
-        const int cnt = __syncthreads_count(kk != 0xFFFFFFFFu);
-        if (tid == 0) S.npos[buf] = cnt;
-        __syncthreads();
-    };
-    auto normalize = [&](int d, int ord) {                 // common:1285-1297
-        const double mine = use_len ? ((S.dv[d][tid]) / (my_len)) : S.dv[d][tid];
-        S.tmp[0][tid] = mine;
-        __syncthreads();
-        if (wave == 0) { const double t = mr_seq_sum(S.seq[ord], S.npos[ord], S.tmp[0], S.din[d]); if (lane == 0) S.bc[0] = t; }
-        __syncthreads();
-        const double total = S.bc[0];
-        if (alive && S.din[d][tid]) S.dv[d][tid] = ((mine) / (total));
-        __syncthreads();
-    };
-    int ord_of[3] = {0, 0, 0};
-    // Gene_prob_next (common:1311-1336): dict P -> dict N (N != P)
-    auto next_prob = [&](int P, int N, int live_a, int live_b) {
-        for (int c = tid; c < C; c += BLOCK) {             // rows: alleles_prob of class c, members in key order
-            // a non-member's value is +0.0 in every dict (next_prob, select_alleles), and x + 0.0 == x: no membership test, and
-            // the operands of four members are fetched side by side before they are added in key order
-            double sc = 0.0;
-            const uint64_t *row = Rm + (size_t)c * A1w;
-            const double *pv = S.dv[P];
-            for (int w0 = 0; w0 < A1w; w0 += 8) {
-              uint64_t rw[8];                            // eight words of the row in flight (the scratch matrix lives in L2)
-#pragma unroll
-              for (int k = 0; k < 8; ++k) rw[k] = w0 + k < A1w ? row[w0 + k] : 0ull;
-#pragma unroll
-              for (int k8 = 0; k8 < 8; ++k8) {
-                const int w = w0 + k8;
-                uint64_t m = rw[k8];
-                while (m) {
-                    double x[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        x[k] = m ? pv[64 * w + __builtin_ctzll(m)] : 0.0;
-                        m &= m - 1;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) sc = ((sc) + (x[k]));
-                }
-              }
-            }
-            S.s[c] = sc;
-        }
-        __syncthreads();
-        for (int w = wave; w < Cw; w += NWAVE) {
-            const int c = 64 * w + lane;
-            const unsigned long long bm = __ballot(c < C && S.s[c] > 0.0);     // classes with alleles_prob <= 0 are skipped
-            if (lane == 0) S.valid[w] = bm;
-        }
-        __syncthreads();
-        lap(1);
-        double acc = 0.0;
-        bool any = false;
-        const bool pin = alive && S.din[P][tid];
-        if (pin) {                                         // cols: += count * prob / alleles_prob over the walked classes, dict order
-            const double vj = S.dv[P][tid];
-            for (int w0 = 0; w0 < Cw; w0 += 8) {
-              uint64_t kw[8];
-#pragma unroll
-              for (int k = 0; k < 8; ++k) kw[k] = w0 + k < Cw ? Kme[w0 + k] : 0ull;
-#pragma unroll
-              for (int k8 = 0; k8 < 8; ++k8) {
-                const int w = w0 + k8;
-                uint64_t m = w < Cw ? kw[k8] & S.valid[w] : 0ull;
-                any = any || m != 0ull;
-                while (m) {
-                    int cc[8];
-                    double q[8];
-                    int nq = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if (m) { cc[k] = 64 * w + __builtin_ctzll(m); m &= m - 1; nq = k + 1; } else cc[k] = cc[0];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) q[k] = ((((S.n[cc[k]]) * (vj))) / (S.s[cc[k]]));
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) if (k < nq) acc = ((acc) + (q[k]));
-                }
-              }
-            }
-        }
-        const bool nin = pin && any;
-        S.dv[N][tid] = nin ? acc : 0.0;
-        S.din[N][tid] = nin ? 1 : 0;
-        // insertion order: unchanged unless the membership or the walked classes changed since it was last derived
-        const unsigned long long inb = __ballot(nin);
-        if (lane == 0) S.in_now[wave] = inb;
-        __syncthreads();
-        lap(2);
-        bool differ = S.cache_ord < 0;
-        if (tid < MR_AW) differ = differ || S.in_now[tid] != S.sig_in[tid];
-        if (tid < Cw) differ = differ || S.valid[tid] != S.sig_valid[tid];
-        const int changed = __syncthreads_or(differ);
-        int ord;
-        if (!changed) ord = S.cache_ord;
-        else {
-            ord = 0;
-            while (ord == live_a || ord == live_b) ++ord;  // a buffer no live dict refers to (4 buffers, <= 2 live besides N)
-            derive_order(N, S.valid, ord);
-            if (tid < MR_AW) S.sig_in[tid] = S.in_now[tid];
-            if (tid < MR_CW) S.sig_valid[tid] = tid < Cw ? S.valid[tid] : 0ull;
-            if (tid == 0) S.cache_ord = ord;
-            __syncthreads();
-            acc_t[6] += 1;
-        }
-        lap(3);
-        ord_of[N] = ord;
-        normalize(N, ord);
-        lap(4);
-    };
-    auto select_alleles = [&](int d) {                     // common:1338-1346
-        const bool in = alive && S.din[d][tid];
-        const double mx = block_max_exact(in ? S.dv[d][tid] : 0.0);
-        if (in && !(S.dv[d][tid] >= ((mx) / (10.0)))) { S.din[d][tid] = 0; S.dv[d][tid] = 0.0; }
-        __syncthreads();
-    };
-
-    // ---- initial estimate (common:1300-1309): prob[a] += count / |class| over the classes in dict order ---------------
-    if (tid == 0) S.cache_ord = -1;
-    for (int c = tid; c < C; c += BLOCK) {                 // |class| into s[]
-        int nal = 0;
-        for (int w = 0; w < A1w; ++w) nal += __popcll(Rm[(size_t)c * A1w + w]);
-        S.s[c] = (double)nal;
-    }
-    __syncthreads();
-    int prob = 0, next = 1, next2 = 2;
-    {
-        double acc = 0.0;
-        bool any = false;
-        if (alive)
-            for (int w = 0; w < Cw; ++w)
-                for (uint64_t m = Kme[w]; m; m &= m - 1) {
-                    const int c = 64 * w + __builtin_ctzll(m);
-                    acc = ((acc) + (((S.n[c]) / (S.s[c]))));
-                    any = true;
-                }
-        S.dv[prob][tid] = acc;
-        S.din[prob][tid] = (alive && any) ? 1 : 0;
-        __syncthreads();
-        derive_order(prob, nullptr, 3);
-        ord_of[prob] = 3;
-        normalize(prob, 3);
-    }
-    double diff = 1.0;
-    int iter = 0;
-    bool keyerr = false;
-    while (diff > 0.0001 && iter < 1000) {                 // common:1351
-        next_prob(prob, next, ord_of[prob], -1);
-        next_prob(next, next2, ord_of[prob], ord_of[next]);
-        const bool pin = alive && S.din[prob][tid];
-        if (__syncthreads_or(pin && (!S.din[next][tid] || !S.din[next2][tid]))) { keyerr = true; break; }      // the reference's KeyError (Q6)
-        const double pv0 = S.dv[prob][tid];
-        const double p_r = ((S.dv[next][tid]) - (pv0));
-        const double p_v = ((((S.dv[next2][tid]) - (S.dv[next][tid]))) - (p_r));
-        S.tmp[0][tid] = ((p_r) * (p_r));
-        S.tmp[1][tid] = ((p_v) * (p_v));
-        __syncthreads();
-        if (wave == 0) {
-            double ta, tb;
-            mr_seq_sum2(S.seq[ord_of[prob]], S.npos[ord_of[prob]], S.tmp[0], S.tmp[1], S.din[prob], ta, tb);
-            if (lane == 0) { S.bc[0] = ta; S.bc[1] = tb; }
-        }
-        __syncthreads();
-        const double ssr = S.bc[0], ssv = S.bc[1];
-        __syncthreads();
-        if (ssv > 0.0) {                                   // common:1370-1383
-            const double gamma = -sqrt(((ssr) / (ssv)));
-            if (pin) {
-                const double x = ((((pv0) - (((((2.0) * (gamma))) * (p_r))))) + (((((gamma) * (gamma))) * (p_v))));
-                S.dv[next2][tid] = 0.0 > x ? 0.0 : x;
-            }
-            __syncthreads();
-            next_prob(next2, next, ord_of[prob], ord_of[next2]);
-        }
-        S.tmp[0][tid] = (alive && S.din[next][tid]) ? fabs(((pv0) - (S.dv[next][tid]))) : pv0;      // prob_diff, common:1272-1279
-        __syncthreads();
-        if (wave == 0) { const double t = mr_seq_sum(S.seq[ord_of[prob]], S.npos[ord_of[prob]], S.tmp[0], S.din[prob]); if (lane == 0) S.bc[0] = t; }
-        __syncthreads();
-        diff = S.bc[0];
-        __syncthreads();
-        { const int t = prob; prob = next; next = t; }     // prob = next (common:1387)
-        if (iter >= 10 && remove_low) select_alleles(prob);
-        iter += 1;
-        lap(5);
-    }
-    if (!keyerr) {
-        if (remove_low) select_alleles(prob);              // common:1402-1407
-        normalize(prob, ord_of[prob]);
-        if (alive && S.din[prob][tid]) out[g] = S.dv[prob][tid];
-    }
-    if (tid == 0) { scal[S_ITER] = (double)iter; scal[S_KEYERR] = keyerr ? 1.0 : 0.0; scal[S_DONE] = 1.0; }
-    if (dbg && tid == 0) for (int k = 0; k < 7; ++k) dbg[k] = acc_t[k];
-}
-#pragma clang fp contract(fast)
+#ifdef HGX_LAB
+#include "lab/hgx_em_ref.inc"            // round 2's mid-size reference-order EM (superseded by k_emx)
+#endif
 
 // ------------------------------------------------------------------------------------------------------------
 // Compact tail of a big EM.  Once pruning (common:1338-1346) has left <= 64 alleles in the estimate -- alleles never
@@ -2437,7 +1808,7 @@ extern "C" int hgx_em_last_exact(void) { return g_last_exact; }
 extern "C" int hgx_em_set_backend(int backend) {
     ARGCHK(backend >= 0 && backend <= 3);
 #ifndef HGX_LAB
-    if (backend == 2) { hgx_set_error("this EM back-end is lab code: build libhgx_lab.so (hisat-genotype_amd/build.py build_lab) -- libhgx.so ships the table-lookup and reference-order paths only"); return HGX_EINVAL; }
+    if (backend == 1 || backend == 2) { hgx_set_error("this EM back-end is lab code: build libhgx_lab.so (hisat-genotype_amd/build.py build_lab) -- libhgx.so ships the table-lookup and reference-order paths only"); return HGX_EINVAL; }
 #endif
     g_backend = backend;
     return HGX_OK;
@@ -2576,6 +1947,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         for (int a = 0; a < n_alleles; ++a) prob_host[a] = 0.0;
         if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = -1;
     }
+#ifdef HGX_LAB
     if (C <= MR_C && c->w64 <= 128 && c->h_rank && !hgx_test_switch("em_no_exact") && !hgx_test_switch("em_no_mid")) {
         // mid-size problems in the reference's own order of operations (k_em_ref): one workgroup, one launch, bit-identical
         // abundances; falls through if more than MR_A distinct alleles occur
@@ -2634,8 +2006,9 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             return HGX_OK;
         }
     }
+#endif
     // helper for the paths that do not carry the first-class information: look it up for the survivors afterwards
-    auto first_for_present = [&]() -> int {
+    [[maybe_unused]] auto first_for_present = [&]() -> int {
         if (!first_host) return HGX_OK;
         std::vector<int32_t> al;
         for (int a = 0; a < n_alleles; ++a) if (prob_host[a] >= 0.0) al.push_back(a);
@@ -2646,6 +2019,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         for (size_t i = 0; i < al.size(); ++i) first_host[al[i]] = f[i];
         return HGX_OK;
     };
+#ifdef HGX_LAB
     if (C <= SMALL_C && A <= EPT * BLOCK && !hgx_test_switch("em_no_small")) {
         // single-workgroup path: one launch, one sync
         DevBuf b_len, b_scal, b_out;
@@ -2679,6 +2053,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
         return first_for_present();
     }
+#endif
     int rc = hgx_ensure_compact(c, st);
     if (rc) return rc;
     // from here on every vector lives in the compact allele space: element j is allele c->h_act[j]
@@ -3534,6 +2909,11 @@ extern "C" int hgx_allele_counts_on(const hgx_classes *cc, int64_t *count_host, 
 //   which = 0: y[c] = count[c] / sum_a B[c][a] x[a]   (x: a_pad doubles)      -> n_classes doubles
 //   which = 1: y[a] = sum_c B[c][a] x[c]              (x: n_classes doubles)  -> a_pad doubles
 extern "C" int hgx_debug_matvec(const hgx_classes *cc, int which, int backend, const double *x_host, double *y_host) {
+#ifndef HGX_LAB
+    (void)cc; (void)which; (void)backend; (void)x_host; (void)y_host;
+    hgx_set_error("hgx_debug_matvec drives the lab back-ends of the bit mat-vec: build libhgx_lab.so (hisat-genotype_amd/build.py build_lab)");
+    return HGX_EINVAL;
+#else
     ARGCHK(cc && x_host && y_host && (which == 0 || which == 1) && backend >= 1 && backend <= 3);
     hgx_classes *c = const_cast<hgx_classes *>(cc);
     const int A = c->a_pad, C = c->n_classes;
@@ -3601,4 +2981,5 @@ extern "C" int hgx_debug_matvec(const hgx_classes *cc, int which, int backend, c
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy(y_host, b_y.p, (size_t)ny * 8, hipMemcpyDeviceToHost));
     return HGX_OK;
+#endif
 }

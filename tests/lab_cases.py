@@ -131,3 +131,56 @@ def test_narrow_table_form_agrees_with_the_product_path():
                 assert it == it_ref, (C_, A, low, use_len, extra, it, it_ref)
                 assert np.array_equal(p < 0, p_ref < 0)
                 assert np.max(np.abs(p - p_ref)) <= 1e-10, (C_, A, extra, float(np.max(np.abs(p - p_ref))))
+
+
+@pytest.mark.parametrize("n_alleles,n_vars,dense", [(700, 300, False), (5000, 700, False), (3000, 260, True)])
+def test_piece_compat_comparison_kernels(n_alleles, n_vars, dense):
+    """The L2-served kernel of round 1 and the LDS-tiled kernel of rounds 1-3 (lab code since round 4) against the definition and the
+    pattern form: the body of tests/test_gpu_parity.py::test_piece_compat_kernels_agree_with_the_definition with all three forms."""
+    import test_gpu_parity as tp
+    tp.COMPAT_FORMS = [{}, {"piece_tiled": 1}, {"piece_untiled": 1}]
+    try:
+        tp.test_piece_compat_kernels_agree_with_the_definition(n_alleles, n_vars, dense)
+    finally:
+        tp.COMPAT_FORMS = [{}]
+
+
+def test_round2_mid_size_em_is_the_reference_bit_for_bit(orc):
+    """k_em_ref (round 2's mid-size EM in the reference's order; lab code since round 4: k_emx took its place) and k_em_small on the
+    problems the product's k_emx takes: the same doubles as the C oracle / within 1e-9 for the tolerance kernel."""
+    rng = np.random.RandomState(2)
+    ran = 0
+    for A, n_used, C_, dens in [(700, 300, 400, 0.05), (2000, 900, 1500, 0.02), (1500, 1000, 60, 0.3)]:
+        a_pad = capi.a_pad(A)
+        w64 = a_pad // 64
+        used = np.sort(rng.choice(A, n_used, replace=False))
+        fam = rng.rand(6, n_used) < dens * rng.choice([0.5, 1.0, 3.0], size=6)[:, None]
+        classes, rows = [], np.zeros((C_, w64), np.uint64)
+        name_rank = rng.permutation(A).astype(np.int32)
+        for c in range(C_):
+            m = fam[rng.randint(6)] ^ (rng.rand(n_used) < 0.02)
+            m[rng.randint(n_used)] = True
+            mem = used[m]
+            mem = mem[np.argsort(name_rank[mem])]
+            classes.append([int(a) for a in mem])
+            for a in mem:
+                rows[c, a >> 6] |= np.uint64(1) << np.uint64(a & 63)
+        counts = rng.randint(1, 300, C_).astype(np.int64)
+        cl = engine.Classes.from_host(rows, counts, a_pad)
+        cl.set_allele_rank(name_rank)
+        for low in (True, False):
+            try:
+                oa, op, oit = orc.single_abundance(A, classes, counts, low, None)
+            except KeyError:
+                continue
+            exp = np.full(A, -1.0)
+            exp[oa] = op
+            with engine.test_switches(em_no_emx=1, em_mid_nnz=100000000):
+                p1, it1 = cl.em(A, low, None)
+                assert engine.em_last_exact() and it1 == oit and np.array_equal(p1, exp)
+            if C_ <= 64:
+                with engine.test_switches(em_no_emx=1, em_no_mid=1, em_no_wave=1):
+                    p2, it2 = cl.em(A, low, None)
+                assert it2 == oit and np.max(np.abs(p2 - exp)) <= 1e-9
+            ran += 1
+    assert ran >= 4

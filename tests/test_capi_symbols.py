@@ -50,9 +50,9 @@ def test_switches_live_in_the_process_not_in_the_environment(monkeypatch):
     assert L.hgx_test_switch(b"em_no_emx") == b"1" and L.hgx_test_switch(b"em_mid_nnz") == b"123"
     engine.test_switch("em_no_emx", None)
     assert L.hgx_test_switch(b"em_no_emx") is None and L.hgx_test_switch(b"em_mid_nnz") == b"123"
-    with engine.test_switches(piece_untiled=1):
-        assert L.hgx_test_switch(b"piece_untiled") == b"1"
-    assert L.hgx_test_switch(b"piece_untiled") is None
+    with engine.test_switches(front_host=1):
+        assert L.hgx_test_switch(b"front_host") == b"1"
+    assert L.hgx_test_switch(b"front_host") is None
     engine.test_switch(None)
     assert L.hgx_test_switch(b"em_mid_nnz") is None
 

@@ -3,6 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import hisatgenotype_amd
 from hisatgenotype_amd import capi, engine
+capi.use_lab()            # (drives comparison kernels that live in the lab build since round 4)
 rng = np.random.RandomState(1)
 A, Cn = 7000, 900
 ap = capi.a_pad(A); w64 = ap // 64

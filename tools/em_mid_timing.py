@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import hisatgenotype_amd  # noqa
 from hisatgenotype_amd import engine, capi
+capi.use_lab()            # (drives comparison kernels that live in the lab build since round 4)
 rng = np.random.RandomState(5)
 for A, n_used, C_, dens in ((700, 300, 200, 0.1), (700, 600, 600, 0.1), (2000, 1000, 1000, 0.1), (7000, 1024, 2048, 0.05), (7000, 1024, 2048, 0.3)):
     a_pad = capi.a_pad(A)

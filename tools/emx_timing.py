@@ -5,6 +5,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import hisatgenotype_amd
 from hisatgenotype_amd import engine
+from hisatgenotype_amd import capi
+capi.use_lab()            # (drives comparison kernels that live in the lab build since round 4)
 from test_gpu_emx import _random_problem
 engine.test_switch("emx_stamps", "1")
 for case in [(7000, 4549, 1600, 0.25), (3000, 1949, 1340, 0.27), (500, 323, 704, 0.3), (2000, 1100, 500, 0.05)]:
