@@ -31,6 +31,8 @@
 // mat-vecs and tree reductions, within ~1e-11 of the reference) and k_emx<false, true> (cluster mode: ONE large problem on several
 // workgroups, same contract, same bits -- see the comment at the kernel).
 #include <algorithm>
+#include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -77,6 +79,8 @@ struct EmxTask {
     // cluster mode (k_emx<false, true>: ONE problem on gridDim.x workgroups): [0] barrier count, [1] abort flag, [2] command,
     // [3] "some class needs the plain division" -- and the words the tile loops hand to the leader
     int32_t cluster;              // > 0: this job runs as k_emx<false, true> on that many workgroups (the ordinary launch skips it)
+    int32_t cl_first;             // ... blocks [cl_first, cl_first + cluster) of the cluster launch (several clusters side by side)
+    int32_t cl_spins;             // polls a cluster barrier waits before the cluster gives up (test switch emx_cluster_spins)
     unsigned int *cl_ctl;
     unsigned long long *gvalid;   // [XCW]  as XLds::validw, written by the workgroup that walked the class tile
     unsigned long long *gin;      // [XAW]  as XLds::in_now
@@ -202,16 +206,21 @@ __device__ __forceinline__ double xlut_row(const double *Tb, const uint64_t (&w)
 // are agent-scope release / acquire fences around a counting barrier in global memory (bounded spins: a cluster that is not
 // co-resident in time gives up and the caller runs the problem on one workgroup).  Same sums in the same orders: same bits.
 template <bool FAST, bool CL = false>
-__global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
+__global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, int n_tasks) {
     static_assert(!(FAST && CL), "cluster mode is for the reference-order arithmetic");
     extern __shared__ double xlds_raw[];
     XLds &S = *reinterpret_cast<XLds *>(xlds_raw);
-    const EmxTask T = tasks[CL ? 0 : blockIdx.x];
+    int t_idx = CL ? 0 : (int)blockIdx.x;
+    if constexpr (CL) {                                   // several clusters side by side: mine is the one whose block range holds me
+        for (int k = 0; k < n_tasks; ++k)
+            if (tasks[k].cluster > 0 && (int)blockIdx.x >= tasks[k].cl_first && (int)blockIdx.x < tasks[k].cl_first + tasks[k].cluster) t_idx = k;
+    }
+    const EmxTask T = tasks[t_idx];
     if ((T.fast != 0) != FAST) return;                    // (the launch of the other arithmetic takes this job)
     if ((T.cluster > 0) != CL) return;                    // (... and the cluster launch a cluster job)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wg = CL ? (int)blockIdx.x : 0, n_wg = CL ? (int)gridDim.x : 1;       // tile loops: start wave * n_wg + wg, stride XNW * n_wg
+    const int wg = CL ? (int)blockIdx.x - T.cl_first : 0, n_wg = CL ? T.cluster : 1;       // tile loops: start wave * n_wg + wg, stride XNW * n_wg
     int cl_phase = 0;
     bool cl_dead = false;
     auto cluster_sync = [&]() {
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
                     long spins = 0;
                     while (__hip_atomic_load(&T.cl_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
                         if (__hip_atomic_load(&T.cl_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
-                        if (++spins > 400000) { __hip_atomic_store(&T.cl_ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+                        if (++spins > (long)T.cl_spins) { __hip_atomic_store(&T.cl_ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
                         __builtin_amdgcn_s_sleep(8);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1028,7 +1037,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks) {
     if constexpr (CL) {
         if (tid == 0) T.cl_ctl[2] = CMD_EXIT;
         cluster_sync();                                    // the helpers leave
-        if (cl_dead) { give_up(1.0); return; }             // (a cluster that was not co-resident in time: the caller uses one workgroup)
+        if (cl_dead) { give_up(3.0); return; }             // (a cluster that was not co-resident in time: status 3, the caller re-runs the job on one workgroup)
     }
     if (!keyerr) {
         if (remove_low) select_alleles(prob);              // common:1402-1407
@@ -1108,16 +1117,37 @@ extern "C" int hgx_emx_get_timing(int fast, double *ms, long long *launches, lon
 }
 
 static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs_out, bool allow_cluster);
+// cluster launches and give-ups since the library was loaded (hgx_emx_cluster_stats; printed under HGX_TYPE_PROFILE)
+static std::atomic<long long> g_cluster_jobs{0}, g_cluster_fallbacks{0};
+extern "C" int hgx_emx_cluster_stats(long long *cluster_jobs, long long *fallbacks) {
+    if (cluster_jobs) *cluster_jobs = g_cluster_jobs.load();
+    if (fallbacks) *fallbacks = g_cluster_fallbacks.load();
+    return HGX_OK;
+}
 int hgx_emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs_out) {
     int rc = emx_run(jobs, n_jobs, st, recs_out, true);
-    // a cluster that was not co-resident in time gave up (status 1 although the problem is within the limits): the call again with
-    // every problem on one workgroup
-    bool gave_up = false;
-    for (int i = 0; i < n_jobs && rc == HGX_OK; ++i)
-        gave_up = gave_up || (jobs[i].status == 1 && jobs[i].any_size && !jobs[i].fast && !jobs[i].mask && jobs[i].C > HGX_EMX_MAX_CLASSES &&
-                              jobs[i].C <= HGX_EMX_HARD_MAX_CLASSES && jobs[i].w64 <= 128 && jobs[i].a_pad <= HGX_EMX_MAX_ALLELES);
-    if (rc == HGX_OK && gave_up) rc = emx_run(jobs, n_jobs, st, recs_out, false);
-    return rc;
+    if (rc) return rc;
+    // A cluster that was not co-resident in time gave up (status 3): THOSE jobs again, each on one workgroup -- the same sums in
+    // the same orders, ~7x slower; the others keep their results.  Counted and, under HGX_TYPE_PROFILE, said.
+    std::vector<int> again;
+    for (int i = 0; i < n_jobs; ++i) if (jobs[i].status == 3) again.push_back(i);
+    if (again.empty()) return HGX_OK;
+    g_cluster_fallbacks.fetch_add((long long)again.size());
+    if (getenv("HGX_TYPE_PROFILE"))
+        fprintf(stderr, "[hgx_emx_run] %zu cluster problem(s) were not co-resident in time: re-run on one workgroup each\n", again.size());
+    std::vector<hgx_emx_job> sub;
+    for (int i : again) sub.push_back(jobs[i]);
+    std::vector<hgx_emx_rec> recs2;
+    rc = emx_run(sub.data(), (int)sub.size(), st, recs_out ? &recs2 : nullptr, false);
+    if (rc) return rc;
+    const size_t shift = recs_out ? recs_out->size() : 0;
+    if (recs_out) recs_out->insert(recs_out->end(), recs2.begin(), recs2.end());
+    for (size_t k = 0; k < again.size(); ++k) {
+        hgx_emx_job &J = jobs[again[k]];
+        J.status = sub[k].status; J.n_iter = sub[k].n_iter; J.n_classes = sub[k].n_classes;
+        J.rec_off = sub[k].rec_off + shift; J.n_rec = sub[k].n_rec;
+    }
+    return HGX_OK;
 }
 static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hgx_emx_rec> *recs_out, bool allow_cluster) {
     ARGCHK(n_jobs >= 0);
@@ -1213,13 +1243,41 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
         T.cursor = (unsigned long long *)resb;
         T.stamps = stamps ? (unsigned long long *)(b + L.stamps) : nullptr;
         T.cluster = 0;
+        T.cl_first = 0;
+        T.cl_spins = 400000;
         T.cl_ctl = (unsigned int *)(b + L.cl);
         T.gvalid = (unsigned long long *)(b + L.cl + 64);
         T.gin = T.gvalid + XCW;
-        if (wants_cluster(J)) {
+    }
+    // Cluster problems run SIDE BY SIDE in one launch: a workgroup of k_emx needs a whole CU (150 KB of LDS), so the clusters of a
+    // launch share the chip's CUs -- 64 workgroups for a lone problem (a class tile per SIMD), fewer each when there are several;
+    // more cluster problems than a launch can seat go out in further launches.
+    std::vector<std::vector<int>> cl_launches;
+    {
+        int n_cl = 0;
+        for (int t = 0; t < n; ++t) n_cl += wants_cluster(jobs[job_of[t]]) ? 1 : 0;
+        static const int n_cu = [] {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }();
+        const int seats = std::max(8, n_cu - 16);                       // (leave room for whatever else is resident)
+        const char *spin_sw = hgx_test_switch("emx_cluster_spins");
+        int first = 0;
+        for (int t = 0; t < n; ++t) {
+            const hgx_emx_job &J = jobs[job_of[t]];
+            if (!wants_cluster(J)) continue;
             const int Cw = (int)(((size_t)J.C + 63) / 64);
-            T.cluster = std::max(2, std::min(64, (Cw + 3) / 4));        // a class tile per SIMD
-            HIPCHK(hipMemsetAsync(b + L.cl, 0, 64 + (size_t)(XCW + XAW) * 8, st));
+            const int per = std::max(2, std::min(64, seats / std::max(1, std::min(n_cl, seats / 2))));
+            int want = std::max(2, std::min(per, (Cw + 3) / 4));
+            if (cl_launches.empty() || first + want > seats) { cl_launches.push_back({}); first = 0; }
+            tasks[t].cluster = want;
+            tasks[t].cl_first = first;
+            if (spin_sw) tasks[t].cl_spins = std::max(1, atoi(spin_sw));
+            first += want;
+            cl_launches.back().push_back(t);
+            HIPCHK(hipMemsetAsync(scr + base[t] + lays[t].cl, 0, 64 + (size_t)(XCW + XAW) * 8, st));
+            g_cluster_jobs.fetch_add(1);
         }
     }
     for (size_t off = 0; off < tasks.size() * sizeof(EmxTask);) {      // descriptors through the pinned staging buffer
@@ -1237,15 +1295,18 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
         if (timing) HIPCHK(hipEventRecord(ev[0], st));
         bool any_plain = false;
         for (const EmxTask &T : tasks) any_plain = any_plain || (!T.fast && T.cluster == 0);
-        if (any_plain) hipLaunchKernelGGL(k_emx<false>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
-        for (int t = 0; t < n; ++t)
-            if (tasks[t].cluster > 0)
-                hipLaunchKernelGGL((k_emx<false, true>), dim3((unsigned)tasks[t].cluster), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>() + t);
+        if (any_plain) hipLaunchKernelGGL(k_emx<false>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>(), n);
+        for (const std::vector<int> &grp : cl_launches) {
+            // (a launch's clusters are consecutive in the task table: the kernel scans tasks[first .. last] for its block range)
+            const int lo = grp.front(), hi = grp.back();
+            const int blocks = tasks[hi].cl_first + tasks[hi].cluster;
+            hipLaunchKernelGGL((k_emx<false, true>), dim3((unsigned)blocks), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>() + lo, hi - lo + 1);
+        }
         if (timing) HIPCHK(hipEventRecord(ev[1], st));
     }
     if (any_fast) {
         if (timing) HIPCHK(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k_emx<true>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>());
+        hipLaunchKernelGGL(k_emx<true>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>(), n);
         if (timing) HIPCHK(hipEventRecord(ev[3], st));
     }
     HIPCHK(hipGetLastError());

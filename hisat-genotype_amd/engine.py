@@ -109,6 +109,13 @@ def emx_get_timing(fast):
     return ms.value, nl.value, nj.value, na.value, nb.value
 
 
+def emx_cluster_stats():
+    """(problems launched on a cluster of workgroups, those whose cluster gave up and were re-run on one workgroup) since the library was loaded."""
+    a, b = C.c_longlong(0), C.c_longlong(0)
+    capi.check(capi.lib().hgx_emx_cluster_stats(C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
 def em_set_fast(on):
     """Arithmetic of Classes.em / em_ordered on this thread for problems the one-workgroup kernel takes: False = the reference's own
     order of operations (default, bit-identical), True = table lookups (~5x faster, within rounding).  Returns the old setting."""

@@ -535,6 +535,11 @@ int hgx_em_set_timing(int on);
  * kernel ms, launches, jobs, applications of the EM map, algorithmic bytes (per application C * A' / 8 + 16 A' + 16 C). */
 int hgx_emx_set_timing(int on);
 int hgx_emx_get_timing(int fast, double *ms_total, long long *launches, long long *jobs, long long *applications, long long *bytes_total);
+/* em_fast = -1 runs a problem beyond 4096 classes on a CLUSTER of workgroups (several such problems of a call side by side, sharing
+ * the chip's CUs).  A cluster whose workgroups are not co-resident in time (the chip is full of other work) gives up and the problem
+ * is re-run on one workgroup -- same sums in the same orders, same bits, ~7x slower.  Counts since the library was loaded: problems
+ * launched on a cluster, and those that fell back (also said on stderr under HGX_TYPE_PROFILE). */
+int hgx_emx_cluster_stats(long long *cluster_problems, long long *fallbacks);
 int hgx_em_get_timing(int slot, double *ms_total, int64_t *launches, int64_t *executed, int64_t *bytes_total);
 
 #ifdef __cplusplus

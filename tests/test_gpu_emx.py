@@ -168,3 +168,71 @@ def test_any_size_mode_is_the_reference_bit_for_bit(orc, case, cluster):
     p2, it2 = cl.em(A, True, None)                       # default: table lookups for this size
     assert not engine.em_last_exact()
     assert it2 == oit and np.array_equal(p2 < 0, exp < 0) and np.max(np.abs(p2 - exp)) <= 1e-9
+
+
+def test_cluster_fallback_is_counted_and_still_the_reference(orc):
+    """A cluster whose workgroups are not co-resident in time gives up and the problem is re-run on one workgroup: the result is still
+    `==` the C oracle and hgx_emx_cluster_stats counts the fallback.  Provoked two ways: (1) deterministically, with the barrier's spin
+    budget cut to a few polls (test switch emx_cluster_spins); (2) the way it happens in production -- a second thread keeps the chip
+    full of other work (hgx_piece_compat launches on its own stream) while clusters run: whatever the race gives, the results are
+    the reference's and the counters add up."""
+    import ctypes as C
+    import threading
+    from hisatgenotype_amd import capi
+    rng = np.random.RandomState(4711)
+    A, n_used, C_, dens = 7000, 2000, 6000, 0.2
+    a_pad, name_rank, classes, rows, counts, lengths = _random_problem(rng, A, n_used, C_, dens)
+    cl = engine.Classes.from_host(rows, counts, a_pad)
+    cl.set_allele_rank(name_rank)
+    oa, op, oit = orc.single_abundance(A, classes, counts, True, None)
+    exp = np.full(A, -1.0)
+    exp[oa] = op
+    old = engine.em_set_fast(-1)
+    try:
+        j0, f0 = engine.emx_cluster_stats()
+        p, it = cl.em(A, True, None)
+        j1, f1 = engine.emx_cluster_stats()
+        assert (j1 - j0, f1 - f0) == (1, 0) and it == oit and np.array_equal(p, exp)
+        with engine.test_switches(emx_cluster_spins=3):       # (1) the cluster cannot possibly meet in three polls
+            p, it = cl.em(A, True, None)
+        j2, f2 = engine.emx_cluster_stats()
+        assert (j2 - j1, f2 - f1) == (1, 1), (j2 - j1, f2 - f1)
+        assert engine.em_last_exact() and it == oit and np.array_equal(p, exp)
+        # (2) a busy chip beside the clusters
+        L = capi.lib()
+        n_words, n_pieces = 40, 60000
+        bits = rng.randint(0, 1 << 32, size=(n_words, a_pad), dtype=np.uint64).astype(np.uint32)
+        em = np.zeros(a_pad // 64, np.uint64)
+        ix = C.c_void_p()
+        capi.check(L.hgx_index_create(C.byref(ix), C.c_int32(A), C.c_int32(n_words * 32), capi.ptr(bits), capi.ptr(em), capi.ptr(em)))
+        pieces = np.zeros(n_pieces, capi.PIECE_DTYPE)
+        pieces["lo_word"] = np.sort(rng.randint(0, n_words - 4, n_pieces))
+        pieces["n_words"] = 4
+        pieces["mask_off"] = 8 * np.arange(n_pieces)
+        masks = rng.randint(0, 1 << 32, size=8 * n_pieces, dtype=np.uint64).astype(np.uint32)
+        d_p, d_m = capi.DevArray.from_host(pieces), capi.DevArray.from_host(masks)
+        out = capi.DevArray((n_pieces, a_pad // 64), np.uint64)
+        stop = threading.Event()
+
+        def hog():
+            capi.set_device(capi.current_device())
+            st = capi.get_stream(1)
+            while not stop.is_set():
+                for _ in range(8):
+                    capi.check(L.hgx_piece_compat(ix, capi.ptr(d_p), capi.ptr(d_m), C.c_int32(n_pieces), capi.ptr(out), st))
+                capi.sync(st)
+        th = threading.Thread(target=hog)
+        th.start()
+        try:
+            for _ in range(4):
+                p, it = cl.em(A, True, None)
+                assert engine.em_last_exact() and it == oit and np.array_equal(p, exp)
+        finally:
+            stop.set()
+            th.join()
+            L.hgx_index_destroy(ix)
+        j3, f3 = engine.emx_cluster_stats()
+        assert j3 - j2 == 4 and 0 <= f3 - f2 <= 4
+        print("cluster problems beside a busy chip: %d, fell back: %d" % (j3 - j2, f3 - f2))
+    finally:
+        engine.em_set_fast(old)
