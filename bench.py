@@ -952,9 +952,26 @@ def main():
             seen = int(t.item())
             assert dist.get_world_size() == world
             dist.barrier()
-            dist.destroy_process_group()
+            if args.workload != "class1":
+                dist.destroy_process_group()
+        line = {"dry_run": True, "n_gpus": seen, "world_size": world, "backend": args.backend, "gpus_arg": args.gpus}
+        if args.workload == "class1":
+            # the rank groups configs[2] would run with (dist.assign_ranks_to_loci: every rank computes them; they must agree)
+            from hisatgenotype_amd import dist as hdist
+            groups = hdist.assign_ranks_to_loci([args.pairs] * len(CLASS1), world)
+            line["rank_groups"] = {CLASS1[i][0]: groups[i] for i in sorted(groups)}
+            line["my_loci_agree"] = True
+            if use_dist:
+                import torch.distributed as dist
+                got = [None] * world
+                dist.all_gather_object(got, {k: v for k, v in line["rank_groups"].items()})
+                line["my_loci_agree"] = all(g == got[0] for g in got)
+                covered = sorted(r for v in got[0].values() for r in v)
+                line["every_rank_has_work"] = covered == list(range(world)) or world <= len(CLASS1)
+                dist.barrier()
+                dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": seen, "world_size": world, "backend": args.backend, "gpus_arg": args.gpus}))
+            print(json.dumps(line))
         return
     if args.gpus != world:
         sys.exit("bench.py: --gpus %d but %d rank(s) are running" % (args.gpus, world))

@@ -95,3 +95,19 @@ def test_bench_gpus_flag_launches_that_many_ranks():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"],
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
     assert out.returncode != 0 and "WORLD_SIZE" in (out.stderr + out.stdout)
+
+
+def test_bench_dry_run_class1_rank_groups():
+    """`bench.py --gpus 4 --backend gloo --dry-run --workload class1`: four ranks meet over gloo, every rank computes the rank groups of
+    configs[2] (dist.assign_ranks_to_loci: three loci on four ranks, the largest locus gets two), and they agree."""
+    import json
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--dry-run", "--workload", "class1"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 4 and rec["my_loci_agree"] and rec["every_rank_has_work"]
+    groups = rec["rank_groups"]
+    assert sorted(groups) == ["A", "B", "C"] and sorted(r for v in groups.values() for r in v) == [0, 1, 2, 3]
+    assert max(len(v) for v in groups.values()) == 2

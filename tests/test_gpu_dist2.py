@@ -1,0 +1,120 @@
+"""Two PROCESSES, one GPU, control plane over gloo: type_locus_sharded end to end on real shards -- the exchanges of dist.TorchComm
+(pileup all-reduce inside the front end, class tables of DIFFERENT sizes gathered in rank order, totals) between ranks that score their
+shares on the same MI355X.  Cases: a natural split, a rank with NO pairs at all, an STR locus.  Every rank's result must be the
+unsharded result.  (A second GPU is not needed for any of this; the 2-GPU RCCL test stays gated on device_count >= 2.)"""
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    import numpy as np
+    import torch.distributed as dist
+    import hisatgenotype_amd as hgx
+    from hisatgenotype_amd import synth, locus as hl, dist as hdist, capi
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    capi.set_device(0)                                   # both ranks on the one GPU of the box
+    comm = hdist.TorchComm()
+    cases = []
+    loc = synth.make_hla_like_locus(n_alleles=1500, n_vars=1200, seed=41)
+    sam = synth.simulate_sam_fast(loc, synth.pick_sample(loc, 9), 6000, err_rate=0.004, seed=17)
+    cases.append(("natural split", loc, sam, hdist.split_name_grouped(sam, world)))
+    cases.append(("rank 1 holds no pairs", loc, sam, [sam.encode()] + [b""] * (world - 1)))
+    cases.append(("rank 0 holds no pairs", loc, sam, [b""] * (world - 1) + [sam.encode()]))
+    str_loc = synth.make_str_like_locus(gene="TH01", unit="AATG", max_repeats=12, min_repeats=4, seed=5)
+    names = [a for a in str_loc.allele_names if "BACKBONE" not in a]
+    str_sam = synth.simulate_sam_fast(str_loc, [names[2], names[-3]], 900, read_len=100, frag_len=(200, 300), err_rate=0.002, seed=8)
+    cases.append(("STR locus", str_loc, str_sam, hdist.split_name_grouped(str_sam, world)))
+    for what, loc, sam, shards in cases:
+        pl = hl.PackedLocus.from_synth(loc)
+        res = hdist.type_locus_sharded(pl, shards[rank], comm)
+        ref = hgx.type_locus(pl, sam)
+        assert (res.num_reads, res.num_pairs) == (ref.num_reads, ref.num_pairs), (what, rank)
+        assert res.counts_sorted == ref.counts_sorted, (what, rank)
+        assert [e["n_iter"] for e in res.em] == [e["n_iter"] for e in ref.em], (what, rank)
+        assert res.gene_prob == ref.gene_prob, (what, rank)
+        got = [None] * world
+        dist.all_gather_object(got, res.gene_prob)
+        assert all(g == got[0] for g in got), what
+        pl.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %%d ok" %% rank)
+''') % ROOT
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_processes_share_one_gpu_over_gloo(tmp_path):
+    w = tmp_path / "worker.py"
+    w.write_text(WORKER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), str(w)], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count("ok") >= 2
+
+
+RCCL_ORDER = textwrap.dedent('''
+    import os, sys
+    sys.path.insert(0, %r)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", sys.argv[2])
+    os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+    import numpy as np
+    import torch, torch.distributed as dist
+    import hisatgenotype_amd
+    from hisatgenotype_amd import synth, locus as hl, dist as hdist, capi
+    torch_first = sys.argv[1] == "torch_first"
+    torch.cuda.set_device(0)
+    capi.set_device(0)
+    if torch_first:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        t = torch.ones(4, device="cuda"); dist.all_reduce(t); torch.cuda.synchronize()
+        comm = hdist.RcclComm.from_torch()
+    else:
+        comm = hdist.RcclComm(0, 1, lambda x: x)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        t = torch.ones(4, device="cuda"); dist.all_reduce(t); torch.cuda.synchronize()
+    loc = synth.make_hla_like_locus(n_alleles=300, n_vars=500, seed=21)
+    pl = hl.PackedLocus.from_synth(loc)
+    comm.broadcast_index(pl, 0)
+    a = comm.allreduce_sum(np.arange(10, dtype=np.int64))
+    assert a.tolist() == list(range(10))
+    sam = synth.simulate_sam_fast(loc, synth.pick_sample(loc, 3), 900, err_rate=0.003, seed=5)
+    import hisatgenotype_amd as hgx
+    res = hdist.type_locus_sharded(pl, sam, comm)
+    ref = hgx.type_locus(pl, sam)
+    assert res.gene_prob == ref.gene_prob and res.counts_sorted == ref.counts_sorted
+    t2 = torch.ones(4, device="cuda"); dist.all_reduce(t2); torch.cuda.synchronize()     # torch's communicator still works afterwards
+    comm.close()
+    dist.destroy_process_group()
+    print("order ok")
+''') % ROOT
+
+
+@pytest.mark.parametrize("order", ["torch_first", "hgx_first"])
+def test_rccl_communicator_beside_a_torch_nccl_group(tmp_path, order):
+    """libhgx's own RCCL communicator (dist.RcclComm: ncclCommInitRank through ctypes, exchanges on device buffers through the C-ABI)
+    created AFTER and BEFORE a torch.distributed nccl group in the same process: both keep working (world size 1 here; the two
+    runtimes share the HIP context and load librccl once)."""
+    w = tmp_path / "w.py"
+    w.write_text(RCCL_ORDER)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(w), order, str(_free_port())], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "order ok" in r.stdout
