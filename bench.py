@@ -863,41 +863,64 @@ def run_panel64(args, rank, local_rank, world, dist):
                  "ms_per_step": round(dt * 1e3, 3), "value": round(reads / dt, 1), "steps": n_other, "tasks_with_the_same_top2_as_the_timed_form": same}
     e2e = None
     if want_files and manies:
-        # 384 files -> 384 results (the loop of /root/reference/hisatgenotype:613-665 over samples x loci): the files' front ends side
-        # by side on host threads (small files: the host stages; a task is 10 000 records), then hgx_type_many_loci as in the timed step
+        # 384 files -> 384 results (the loop of /root/reference/hisatgenotype:613-665 over samples x loci): per locus ONE pass of the
+        # device front end over its 64 samples' files (hgx_many_create_files: the files read side by side on host threads, every
+        # record carries its task), the loci side by side; then hgx_type_many_loci as in the timed step.  Beside it, once, round
+        # 3's form: the host front end per file, then hgx_many_create's merge + upload.
         import shutil
         from concurrent.futures import ThreadPoolExecutor
         try:
             nthr = max(4, int(2 * (cgroup_cpu_quota() or (os.cpu_count() or 8))))
+            ks = sorted(manies)
+            paths_of = {k: [file_of[(work[n][0], k)] for n in manies[k][0]] for k in ks}
 
-            def files_once():
+            def files_once(device=True):
                 t0 = time.perf_counter()
-                ks = sorted(manies)
-                with ThreadPoolExecutor(nthr) as ex:
-                    futs = {k: [ex.submit(packed[k].parse_alignment_file, file_of[(work[n][0], k)], [packed[k].ref_allele], n_threads=1)
-                                for n in manies[k][0]] for k in ks}
-                    got_b = {k: [f.result() for f in futs[k]] for k in ks}
-                t1 = time.perf_counter()
-                mbs = [engine.ManyBatch(packed[k], got_b[k]) for k in ks]
-                t2 = time.perf_counter()
+                routes = None
+                if device:
+                    def one(k):
+                        m = engine.ManyBatch.from_files(packed[k], paths_of[k], regions=[packed[k].ref_allele] * len(paths_of[k]),
+                                                        n_threads=max(2, nthr // 3))
+                        return m, engine.front_last(), engine.front_last_bytes()
+                    with ThreadPoolExecutor(len(ks)) as ex:
+                        got = list(ex.map(one, ks))
+                    mbs = [g[0] for g in got]
+                    routes = [(g[1], g[2]) for g in got]
+                    t1 = t2 = time.perf_counter()
+                else:
+                    with ThreadPoolExecutor(nthr) as ex:
+                        futs = {k: [ex.submit(packed[k].parse_alignment_file, fp, [packed[k].ref_allele], n_threads=1) for fp in paths_of[k]] for k in ks}
+                        got_b = {k: [f.result() for f in futs[k]] for k in ks}
+                    t1 = time.perf_counter()
+                    mbs = [engine.ManyBatch(packed[k], got_b[k]) for k in ks]
+                    t2 = time.perf_counter()
                 rows_f = htyping.type_many_loci([packed[k] for k in ks], mbs, light=True, em_fast=False if args.em_exact else None)
                 t3 = time.perf_counter()
+                dims = [(m.n_pieces, m.n_pairs, m.n_refs, m.n_reads, tuple(m.task_reads), tuple(m.task_pieces)) for m in mbs]
                 for m in mbs:
                     m.close()
-                return (t3 - t0, t1 - t0, t2 - t1, t3 - t2), {k: row for k, row in zip(ks, rows_f)}
+                return (t3 - t0, t1 - t0, t2 - t1, t3 - t2), {k: row for k, row in zip(ks, rows_f)}, routes, dims
             files_once()
             runs = [files_once() for _ in range(3)]
             runs.sort(key=lambda r: r[0][0])
-            (tot, t_fe, t_merge, t_gpu), rows_f = runs[1]
+            (tot, t_fe, _, t_gpu), rows_f, routes, dims = runs[1]
+            files_once(False)
+            (tot_h, t_fe_h, t_merge_h, t_gpu_h), rows_h, _, dims_h = files_once(False)
             same = sum(1 for k in rows_f for n, r in zip(manies[k][0], rows_f[k]) if sorted(r[1]) == sorted(last[n][1]) and r[0] == last[n][0])
             e2e = {"input": "%d coordinate-sorted BAM files of %d pairs (%.0f MB in all)" % (len(file_of), args.panel_pairs,
                                                                                                sum(os.path.getsize(f) for f in file_of.values()) / 1e6),
                    "ms": round(tot * 1e3, 1), "reads_per_s": round(reads / tot, 1),
-                   "stages_ms": {"front ends of the files (host stages, %d threads)" % nthr: round(t_fe * 1e3, 1),
-                                 "merge + upload (hgx_many_create)": round(t_merge * 1e3, 1), "hgx_type_many_loci": round(t_gpu * 1e3, 1)},
+                   "stages_ms": {"hgx_many_create_files, %d loci side by side (read + inflate + walk on the host, records -> merged batch on the device)" % len(ks):
+                                 round(t_fe * 1e3, 1), "hgx_type_many_loci": round(t_gpu * 1e3, 1)},
+                   "front_end": {"route_and_decline_code_per_locus": [list(r[0]) for r in routes], "bytes_to_device": sum(r[1] for r in routes)},
                    "tasks_with_the_timed_step_s_reads_and_top2": same,
-                   "note": "files -> results for the whole panel (median of 3 after a warm-up).  A task is 10 000 records: below the device "
-                           "front end's size gate, so the files' front ends run on the host, side by side; the GPU part is the timed step"}
+                   "merged_batches_identical_to_the_host_front_ends": dims == dims_h and all(rows_f[k] == rows_h[k] for k in rows_f),
+                   "host_front_ends_instead": {"ms": round(tot_h * 1e3, 1),
+                                               "stages_ms": {"front ends of the files (host stages, %d threads)" % nthr: round(t_fe_h * 1e3, 1),
+                                                             "merge + upload (hgx_many_create)": round(t_merge_h * 1e3, 1),
+                                                             "hgx_type_many_loci": round(t_gpu_h * 1e3, 1)}},
+                   "note": "files -> results for the whole panel (median of 3 after a warm-up): the samples of a locus go through ONE pass "
+                           "of the device front end (a task alone, 10 000 records, is below its size gate; 64 together are not)"}
         finally:
             shutil.rmtree(file_dir, ignore_errors=True)
     cb = None

@@ -183,6 +183,20 @@ __global__ void __launch_bounds__(1024) k_fe_pileup(const FeKey *__restrict__ ke
     }
 }
 
+// the samples of a many-task batch have a pileup each (counts[task][n_ref][6]): one wavefront per key, global atomics (a
+// task's keys are few thousand: no counter is hot)
+__global__ void __launch_bounds__(256) k_fe_pileup_many(const FeKey *__restrict__ keys, uint32_t n_keys, const char *__restrict__ text, int n_ref,
+                                                        uint32_t *__restrict__ counts, FeCtl *ctl) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (k >= n_keys) return;
+    const FeKey K = keys[k];
+    if (K.n_pile == 0) return;
+    uint32_t *mine = counts + (size_t)K.task * n_ref * 6;
+    const int rc = fe_pileup_key(K, text, n_ref, lane, 64, [&](uint32_t cell, uint32_t w) { atomicAdd(&mine[cell], w); });
+    if (rc < 0 && lane == 0) fe_decline(ctl, rc);
+}
+
 __global__ void k_fe_nt_set(const uint32_t *__restrict__ counts, int n_ref, uint8_t *__restrict__ nt_set) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_ref) nt_set[i] = fe_nt_set(counts + (size_t)i * 6);
@@ -190,14 +204,19 @@ __global__ void k_fe_nt_set(const uint32_t *__restrict__ counts, int n_ref, uint
 
 __global__ void __launch_bounds__(256) k_fe_decode(FeLocus L, FeParse o, FePile P, const FeKey *__restrict__ keys, uint32_t n_keys,
                                                    const char *__restrict__ text, FePools pools, uint8_t *__restrict__ state,
-                                                   uint32_t *__restrict__ key_ht_off, uint32_t *__restrict__ key_n_ht, FeCtl *ctl) {
+                                                   uint32_t *__restrict__ key_ht_off, uint32_t *__restrict__ key_n_ht,
+                                                   uint16_t *__restrict__ slot_task, FeCtl *ctl) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_keys) return;
     const FeKey K = keys[k];
     if (K.slot == FE_NO_SLOT) return;
     uint8_t st = 2;
     uint32_t off = 0, n = 0;
-    const int rc = fe_key(L, o, P, K, text, pools, st, off, n);
+    FePile Pk = P;                                         // (a many-task batch: the pileup of the key's own sample)
+    Pk.nt_set += (size_t)K.task * L.n_ref;
+    Pk.counts += (size_t)K.task * L.n_ref * 6;
+    if (slot_task) slot_task[K.slot] = (uint16_t)K.task;
+    const int rc = fe_key(L, o, Pk, K, text, pools, st, off, n);
     if (rc < 0) { fe_decline(ctl, rc); st = 2; n = 0; }
     state[K.slot] = st;
     key_ht_off[K.slot] = off;
@@ -304,10 +323,42 @@ __global__ void k_fe_cand_piece(const uint32_t *__restrict__ head_of, const uint
     if (c < n) cand_piece[c] = new_id[head_of[c]];
 }
 
+// a many-task batch: the distinct pieces each task's decoded keys produced (= the piece count of the task's own batch), as a
+// bit per (task, piece), then a population count per task
+__global__ void __launch_bounds__(256) k_fe_task_piece_bits(const uint8_t *__restrict__ state, const uint32_t *__restrict__ key_ht_off,
+                                                            const uint32_t *__restrict__ key_n_ht, const int32_t *__restrict__ ht_pool,
+                                                            const uint32_t *__restrict__ cand_piece, const uint16_t *__restrict__ slot_task, uint32_t n_slots,
+                                                            uint32_t words_per_task, uint32_t *__restrict__ bits) {
+    const uint32_t sl = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sl >= n_slots || state[sl] != 1) return;
+    uint32_t *mine = bits + (size_t)slot_task[sl] * words_per_task;
+    uint32_t at = key_ht_off[sl];
+    for (uint32_t x = 0, n = key_n_ht[sl]; x < n; ++x) {
+        const int32_t *rec = ht_pool + at;
+        for (int e = 0; e <= rec[3]; ++e) {
+            const uint32_t pc = cand_piece[(uint32_t)rec[4] + e];
+            atomicOr(&mine[pc >> 5], 1u << (pc & 31));
+        }
+        at += FE_HT_HDR + (uint32_t)rec[2];
+    }
+}
+__global__ void __launch_bounds__(256) k_fe_task_piece_count(const uint32_t *__restrict__ bits, uint32_t words_per_task, uint32_t *__restrict__ task_pieces) {
+    __shared__ uint32_t part[4];
+    const uint32_t *mine = bits + (size_t)blockIdx.x * words_per_task;
+    uint32_t c = 0;
+    for (uint32_t w = threadIdx.x; w < words_per_task; w += blockDim.x) c += (uint32_t)__popc(mine[w]);
+    c = (uint32_t)wave_sum_u64(c);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) task_pieces[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+
 // pair protocol, pass 1: per run of records with one read id -> (1 << 40 | refs) if it yields a pair
 __global__ void __launch_bounds__(256) k_fe_pair_count(const uint32_t *__restrict__ rec_info, uint32_t n_rec, const uint8_t *__restrict__ state,
                                                        const uint32_t *__restrict__ key_ht_off, const uint32_t *__restrict__ key_n_ht,
-                                                       const int32_t *__restrict__ ht_pool, unsigned long long *__restrict__ cnt, FeCtl *ctl) {
+                                                       const int32_t *__restrict__ ht_pool, unsigned long long *__restrict__ cnt, FeCtl *ctl,
+                                                       const uint16_t *__restrict__ slot_task, uint32_t *__restrict__ task_reads,
+                                                       uint32_t *__restrict__ task_pairs, unsigned long long *__restrict__ task_refs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long c = 0, reads = 0, gene = 0;
     if (i < n_rec && FE_REC_HEAD(rec_info[i])) {
@@ -322,6 +373,12 @@ __global__ void __launch_bounds__(256) k_fe_pair_count(const uint32_t *__restric
             c = (1ull << 40) | (n_exon + (unsigned long long)n_uni);
             reads = (unsigned long long)ns;
             gene = (unsigned long long)n_uni;
+            if (task_reads) {                               // a many-task batch: the totals of the pair's sample
+                const uint32_t t = slot_task[FE_REC_SLOT(rec_info[i])];
+                atomicAdd(&task_reads[t], (uint32_t)ns);
+                atomicAdd(&task_pairs[t], 1u);
+                atomicAdd(&task_refs[t], n_exon + (unsigned long long)n_uni);
+            }
         }
     }
     if (i < n_rec) cnt[i] = c;
@@ -357,16 +414,16 @@ __global__ void __launch_bounds__(256) k_fe_pair_emit(const uint32_t *__restrict
 }
 
 // ---- the record stage (row 8a-1): fields, filters, key grouping -----------------------------------------------------------------
-struct LineRef { uint32_t off, len; };      // a record of the name-ordered stream: first byte (after block_size for BAM) and length
+typedef FeLine LineRef;
 
 __global__ void __launch_bounds__(256) k_fe_records(const char *__restrict__ text, size_t text_bytes, const LineRef *__restrict__ lines, uint32_t n, int binary,
                                                     int simulation, FeRec *__restrict__ recs, FeCtl *ctl) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     FeRec r;
-    const int rc = binary ? fe_parse_bam_record(text, lines[i].off, lines[i].len, simulation != 0, r)
-                          : fe_parse_text_record(text, text_bytes, lines[i].off, lines[i].len, simulation != 0, r);
-    if (rc < 0) { fe_decline(ctl, rc); r.bits = 0; r.flag = 4; r.id_len = 0; r.qname_off = 0; r.key = 0; }
+    const int rc = binary ? fe_parse_bam_record(text, lines[i].off, lines[i].len, simulation != 0, lines[i].task, r)
+                          : fe_parse_text_record(text, text_bytes, lines[i].off, lines[i].len, simulation != 0, lines[i].task, r);
+    if (rc < 0) { fe_decline(ctl, rc); r.bits = 0; r.flag = 4; r.id_len = 0; r.qname_off = 0; r.key = 0; r.task = (uint16_t)lines[i].task; }
     recs[i] = r;
 }
 __global__ void k_fe_rec_heads(const FeRec *__restrict__ recs, uint32_t n, const char *__restrict__ text, uint8_t *__restrict__ head) {
@@ -431,6 +488,7 @@ __global__ void __launch_bounds__(256) k_fe_build_keys(const FeRec *__restrict__
     K.seq_len = f.seq_len; K.cigar_len = f.cigar_len; K.zs_len = f.zs_len; K.md_len = f.md_len;
     K.flags = (uint16_t)(((f.bits & FE_R_HAS_ZS) ? FE_K_HAS_ZS : 0) | ((f.bits & FE_R_HAS_MD) ? FE_K_HAS_MD : 0) |
                          ((f.bits & FE_R_BIN) ? (FE_K_BIN_CIGAR | FE_K_PACKED_SEQ) : 0));
+    K.task = f.task;
     keys[key_idx[i]] = K;
     dslot[slot_of[i]] = K.slot;
 }
@@ -459,6 +517,11 @@ struct DevInput {                     // keys, their text and the kept records, 
     const uint32_t *rec_info; uint32_t n_rec;
     uint32_t n_slots;
     FeCtl *ctl;
+    // a many-task batch (the samples of one locus in one pass): a pileup per task, and per task the reads, pairs and refs it
+    // contributed (device arrays, zeroed by the caller; NULL for one task)
+    int n_tasks = 1;
+    uint32_t *task_reads = nullptr, *task_pairs = nullptr, *task_pieces = nullptr;
+    unsigned long long *task_refs = nullptr;
 };
 struct Lap {
     bool prof; hipStream_t st; double t_prev;
@@ -481,9 +544,9 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     const uint32_t n_keys = di.n_keys, n_rec = di.n_rec, S = di.n_slots;
     // every buffer of the call is declared here, the guard after them: on ANY way out the stream is drained first, then the
     // buffers go back to the pool
-    DevBuf b_state, b_koff, b_knht, b_ht, b_clo, b_cnw, b_ckey, b_cmoff, b_mpool;
+    DevBuf b_state, b_koff, b_knht, b_ht, b_clo, b_cnw, b_ckey, b_cmoff, b_mpool, b_slot_task;
     DevBuf b_cnt, b_off, b_tmp, b_tmp2, b_key_s, b_idx, b_idx_s, b_flag, b_rank, b_head_of, b_head_cand;
-    DevBuf b_wh, b_wh_s, b_hidx, b_hidx_s, b_lonw, b_lonw_s, b_ord, b_nw2, b_moff, b_new_id, b_cand_piece;
+    DevBuf b_wh, b_wh_s, b_hidx, b_hidx_s, b_lonw, b_lonw_s, b_ord, b_nw2, b_moff, b_new_id, b_cand_piece, b_tbits;
     hgx_dbatch *d = new hgx_dbatch();
     struct Guard { hgx_dbatch *&d; hipStream_t st; ~Guard() { (void)hipStreamSynchronize(st); if (d) hgx_dbatch_destroy(d); } } guard{d, st};
     FeCtl *ctl = di.ctl;
@@ -493,12 +556,18 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     (void)rc;
 
     // pileup
+    const int n_tasks = std::max(1, di.n_tasks);
+    if (n_tasks > 1 && o.pileup_exchange) { *declined = HGX_FE_DECLINE_OPTS; return HGX_OK; }
+    if (n_tasks > 65535) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
     d->n_ref = n_ref;
-    d->d_counts = (uint32_t *)hgx_pool_alloc(std::max<size_t>((size_t)n_ref * 6 * 4, 16));
-    d->d_nt_set = (uint8_t *)hgx_pool_alloc(std::max<size_t>(n_ref, 16));
+    const size_t n_cells = (size_t)n_tasks * n_ref * 6;
+    d->d_counts = (uint32_t *)hgx_pool_alloc(std::max<size_t>(n_cells * 4, 16));
+    d->d_nt_set = (uint8_t *)hgx_pool_alloc(std::max<size_t>((size_t)n_tasks * n_ref, 16));
     if (!d->d_counts || !d->d_nt_set) { hgx_set_error("device allocation of the pileup tables failed"); return HGX_ENOMEM; }
-    HIPCHK(hipMemsetAsync(d->d_counts, 0, (size_t)n_ref * 6 * 4, st));
-    if (n_keys && n_ref > 0) {
+    HIPCHK(hipMemsetAsync(d->d_counts, 0, n_cells * 4, st));
+    if (n_keys && n_ref > 0 && n_tasks > 1) {
+        k_fe_pileup_many<<<nblk((long)n_keys * 64, 256), 256, 0, st>>>(keys, n_keys, text, n_ref, d->d_counts, ctl);
+    } else if (n_keys && n_ref > 0) {
         const int tile = std::min(n_ref, 6000);                       // 6 counters x 4 bytes x 6000 positions = 144 KB of LDS
         const size_t lds = (size_t)tile * 6 * 4;
         HGX_ONCE_PER_DEVICE(HIPCHK(hipFuncSetAttribute((const void *)k_fe_pileup, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
@@ -517,7 +586,7 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
         HIPCHK(hipMemcpyAsync(d->d_counts, h.data(), h.size() * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipStreamSynchronize(st));
     }
-    if (n_ref > 0) k_fe_nt_set<<<nblk(n_ref, 256), 256, 0, st>>>(d->d_counts, n_ref, d->d_nt_set);
+    if (n_ref > 0) k_fe_nt_set<<<nblk((long)n_tasks * n_ref, 256), 256, 0, st>>>(d->d_counts, n_tasks * n_ref, d->d_nt_set);
     lap("pileup");
 
     // decode
@@ -532,6 +601,7 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     ALLOC(b_ckey, cand_cap * 8);
     ALLOC(b_cmoff, cand_cap * 4);
     ALLOC(b_mpool, mask_cap * 4);
+    if (n_tasks > 1) ALLOC(b_slot_task, std::max<size_t>(S, 8) * 2);
     FePools pools;
     pools.ht_pool = b_ht.as<int32_t>(); pools.ht_cap = (uint32_t)ht_cap; pools.ht_cursor = &ctl->ht_cursor;
     pools.cand_lo = b_clo.as<uint16_t>(); pools.cand_nw = b_cnw.as<uint16_t>(); pools.cand_key = b_ckey.as<uint64_t>();
@@ -540,12 +610,14 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     const FeParse po{o.num_editdist, o.error_correction};
     const FePile pile{d->d_nt_set, d->d_counts};
     if (n_keys) k_fe_decode<<<nblk(n_keys, 256), 256, 0, st>>>(F, po, pile, keys, n_keys, text, pools, b_state.as<uint8_t>(), b_koff.as<uint32_t>(),
-                                                               b_knht.as<uint32_t>(), ctl);
+                                                               b_knht.as<uint32_t>(), n_tasks > 1 ? b_slot_task.as<uint16_t>() : (uint16_t *)nullptr, ctl);
     // the pair counts need nothing but the decode results
     ALLOC(b_cnt, std::max<size_t>(n_rec, 1) * 8);
     ALLOC(b_off, std::max<size_t>(n_rec, 1) * 8);
     if (n_rec) k_fe_pair_count<<<nblk(n_rec, 256), 256, 0, st>>>(rec_info, n_rec, b_state.as<uint8_t>(), b_koff.as<uint32_t>(), b_knht.as<uint32_t>(),
-                                                                 b_ht.as<int32_t>(), b_cnt.as<unsigned long long>(), ctl);
+                                                                 b_ht.as<int32_t>(), b_cnt.as<unsigned long long>(), ctl,
+                                                                 n_tasks > 1 ? b_slot_task.as<uint16_t>() : (const uint16_t *)nullptr,
+                                                                 n_tasks > 1 ? di.task_reads : (uint32_t *)nullptr, di.task_pairs, di.task_refs);
     FeCtl h;
     HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -646,6 +718,14 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
                                                              pools.cand_mask_off, pools.mask_pool, b_moff.as<uint32_t>(), d->d_pieces, d->d_masks,
                                                              b_new_id.as<uint32_t>(), ctl);
         k_fe_cand_piece<<<nblk(n_cand, 256), 256, 0, st>>>(b_head_of.as<uint32_t>(), b_new_id.as<uint32_t>(), n_cand, b_cand_piece.as<uint32_t>());
+        if (n_tasks > 1 && di.task_pieces && S) {
+            const uint32_t wpt = (n_heads + 31) / 32;
+            ALLOC(b_tbits, (size_t)n_tasks * wpt * 4);
+            HIPCHK(hipMemsetAsync(b_tbits.p, 0, (size_t)n_tasks * wpt * 4, st));
+            k_fe_task_piece_bits<<<nblk(S, 256), 256, 0, st>>>(b_state.as<uint8_t>(), b_koff.as<uint32_t>(), b_knht.as<uint32_t>(), b_ht.as<int32_t>(),
+                                                               b_cand_piece.as<uint32_t>(), b_slot_task.as<uint16_t>(), S, wpt, b_tbits.as<uint32_t>());
+            k_fe_task_piece_count<<<n_tasks, 256, 0, st>>>(b_tbits.as<uint32_t>(), wpt, di.task_pieces);
+        }
     }
     if (n_rec) k_fe_pair_emit<<<nblk(n_rec, 256), 256, 0, st>>>(rec_info, n_rec, b_state.as<uint8_t>(), b_koff.as<uint32_t>(), b_knht.as<uint32_t>(),
                                                                 b_ht.as<int32_t>(), b_cnt.as<unsigned long long>(), b_off.as<unsigned long long>(),
@@ -691,8 +771,23 @@ int front_run(hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, 
 
 // The record route: the text (SAM) or the inflated stream (BAM) is already on its way to `d_text`; the line table follows, and
 // fields, filters and key grouping run as kernels before the stages above.
-int records_run(hgx_locus &L, const char *d_text, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n_lines, bool binary,
-                const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, int *declined) {
+typedef hgx_front_totals ManyTotals;       // what a many-task pass reports per task (host side)
+
+// the line table of a stream as (offset, length, task), in pinned staging (made by the host's workers)
+LineRef *line_refs(const char *raw, const hgx_line *lines, size_t n_lines, bool binary, uint32_t base, uint32_t task, LineRef *dst) {
+    const size_t skip = binary ? 32 : 0;
+    hgx_par_ranges(n_lines > 50000 ? hgx_default_threads() : 1, n_lines, [&](int, size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            dst[i].off = base + (uint32_t)((size_t)(lines[i].p - raw) - skip);
+            dst[i].len = lines[i].len;
+            dst[i].task = task;
+        }
+    });
+    return dst;
+}
+
+int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRef *h_lines, size_t n_lines, bool binary, int n_tasks,
+                const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, ManyTotals *many, int *declined) {
     *out = nullptr;
     *declined = 0;
     Lap lap(st);
@@ -706,16 +801,8 @@ int records_run(hgx_locus &L, const char *d_text, const char *raw, size_t raw_by
     uint32_t cap = 1024;
     while (cap < 2 * (uint64_t)n) cap <<= 1;
     DevBuf b_lines, b_recs, b_head, b_kept, b_slot_of, b_tkeys, b_rep, b_pile, b_anyk, b_dslot, b_is_key, b_is_dec, b_kept32, b_prev_in;
-    DevBuf b_key_idx, b_dec_idx, b_rec_idx, b_prev, b_tmp, b_keys, b_rec, b_ctl;
+    DevBuf b_key_idx, b_dec_idx, b_rec_idx, b_prev, b_tmp, b_keys, b_rec, b_ctl, b_treads, b_tpairs, b_trefs, b_tpieces;
     struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
-    // the line table as (offset, length): made in pinned staging by the host's workers, 8 bytes per record
-    LineRef *h_lines = (LineRef *)pinned_alloc(std::max<size_t>(n_lines, 1) * sizeof(LineRef));
-    if (!h_lines) { hgx_set_error("pinned allocation of the line table failed"); return HGX_ENOMEM; }
-    struct Unpin { void *p; ~Unpin() { pinned_release(p); } } unpin{h_lines};
-    const size_t skip = binary ? 32 : 0;
-    hgx_par_ranges(n_lines > 50000 ? hgx_default_threads() : 1, n_lines, [&](int, size_t b, size_t e) {
-        for (size_t i = b; i < e; ++i) { h_lines[i].off = (uint32_t)((size_t)(lines[i].p - raw) - skip); h_lines[i].len = lines[i].len; }
-    });
     ALLOC(b_lines, std::max<size_t>(n_lines, 1) * sizeof(LineRef));
     ALLOC(b_recs, std::max<size_t>(n_lines, 1) * sizeof(FeRec));
     ALLOC(b_head, std::max<size_t>(n_lines, 16));
@@ -786,8 +873,33 @@ int records_run(hgx_locus &L, const char *d_text, const char *raw, size_t raw_by
     }
     lap("records: fields, filters, keys");
     if (h.decline) { *declined = -h.decline; return HGX_OK; }
-    const DevInput di{b_keys.as<FeKey>(), h.n_keys, d_text, b_rec.as<uint32_t>(), h.n_rec, h.n_slots, ctl};
-    return front_stages(*Fp, di, o, st, out, declined);
+    DevInput di{b_keys.as<FeKey>(), h.n_keys, d_text, b_rec.as<uint32_t>(), h.n_rec, h.n_slots, ctl};
+    di.n_tasks = std::max(1, n_tasks);
+    if (di.n_tasks > 1) {
+        ALLOC(b_treads, (size_t)di.n_tasks * 4); ALLOC(b_tpairs, (size_t)di.n_tasks * 4); ALLOC(b_trefs, (size_t)di.n_tasks * 8);
+        ALLOC(b_tpieces, (size_t)di.n_tasks * 4);
+        HIPCHK(hipMemsetAsync(b_tpieces.p, 0, (size_t)di.n_tasks * 4, st));
+        di.task_pieces = b_tpieces.as<uint32_t>();
+        HIPCHK(hipMemsetAsync(b_treads.p, 0, (size_t)di.n_tasks * 4, st));
+        HIPCHK(hipMemsetAsync(b_tpairs.p, 0, (size_t)di.n_tasks * 4, st));
+        HIPCHK(hipMemsetAsync(b_trefs.p, 0, (size_t)di.n_tasks * 8, st));
+        di.task_reads = b_treads.as<uint32_t>(); di.task_pairs = b_tpairs.as<uint32_t>(); di.task_refs = b_trefs.as<unsigned long long>();
+    }
+    rc = front_stages(*Fp, di, o, st, out, declined);
+    if (rc || *declined || !many) return rc;
+    many->reads.assign((size_t)di.n_tasks, 0); many->pairs.assign((size_t)di.n_tasks, 0); many->refs.assign((size_t)di.n_tasks, 0);
+    many->pieces.assign((size_t)di.n_tasks, 0);
+    if (di.n_tasks > 1) {
+        HIPCHK(hipMemcpyAsync(many->pieces.data(), b_tpieces.p, (size_t)di.n_tasks * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(many->reads.data(), b_treads.p, (size_t)di.n_tasks * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(many->pairs.data(), b_tpairs.p, (size_t)di.n_tasks * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(many->refs.data(), b_trefs.p, (size_t)di.n_tasks * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    } else if (*out) {
+        many->reads[0] = (uint32_t)(*out)->n_reads; many->pairs[0] = (uint32_t)(*out)->n_pairs; many->refs[0] = (uint64_t)(*out)->n_refs;
+        many->pieces[0] = (uint32_t)(*out)->n_pieces;
+    }
+    return HGX_OK;
 }
 
 // host stages with the device stages hooked in; *out is always a device batch on success
@@ -828,7 +940,11 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Pars
                            int *declined) {
             if (!force && n < 20000) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }
             if (up_failed || raw != up_raw || raw_bytes != up_bytes) { *declined = HGX_FE_DECLINE_SIZE; return (int)HGX_OK; }
-            const int rc = records_run(L, b_text.as<char>(), raw, raw_bytes, lines, n, binary, o, st, &made, declined);
+            LineRef *h_lines = (LineRef *)pinned_alloc(std::max<size_t>(n, 1) * sizeof(LineRef));
+            if (!h_lines) { hgx_set_error("pinned allocation of the line table failed"); return (int)HGX_ENOMEM; }
+            struct Unpin { void *p; ~Unpin() { pinned_release(p); } } unpin{h_lines};
+            line_refs(raw, lines, n, binary, 0u, 0u, h_lines);
+            const int rc = records_run(L, b_text.as<char>(), raw_bytes, h_lines, n, binary, 1, o, st, &made, nullptr, declined);
             if (!rc && !*declined && made) route = 2;
             return rc;
         };
@@ -862,6 +978,52 @@ extern "C" int hgx_parse_alignment_file_dev(hgx_dbatch **out, const hgx_locus *l
     ARGCHK(out && loc && path && opts);
     return parse_dev(out, (hipStream_t)stream, opts,
                      [&](hgx_batch **b, hgx_front_hook *hook) { return hgx_parse_alignment_file_hook(b, loc, path, regions, opts, hook); });
+}
+
+// MANY tasks of one locus (the samples of a panel) in ONE pass of the record route: the tasks' files are read side by side on the
+// host's threads, their bytes land in one device buffer, and every record carries its task -- keys, read ids and pairs never
+// cross tasks, each task has its own pileup, the piece table is shared (what hgx_batch_merge makes of the tasks' own batches).
+// *declined != 0: nothing was made (the caller runs the host front end per task and merges).
+int hgx_front_many_dev(hgx_dbatch **out, hgx_front_totals *tot, const hgx_locus *loc, const char *const *paths, const char *const *regions,
+                       const char *const *sams, const size_t *sam_bytes, int n_tasks, const hgx_parse_opts *opts, void *stream, int *declined) {
+    ARGCHK(out && tot && loc && opts && declined && n_tasks >= 0);
+    *out = nullptr;
+    *declined = 0;
+    hipStream_t st = (hipStream_t)stream;
+    g_last_bytes = 0; g_last_route = 0; g_last_device = 0; g_last_decline = 0;
+    auto decline = [&](int code) { *declined = code; g_last_decline = code; return (int)HGX_OK; };
+    if (hgx_test_switch("front_host")) { *declined = -1; g_last_decline = -1; return HGX_OK; }
+    if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange || opts->pileup_exchange) return decline(HGX_FE_DECLINE_OPTS);
+    if (n_tasks < 1 || n_tasks > 65535) return decline(HGX_FE_DECLINE_SIZE);
+    hgx_many_streams ms;
+    const hgx_front_alloc mem{pinned_alloc, pinned_release};
+    int rc = hgx_many_read(ms, paths, regions, sams, sam_bytes, n_tasks, opts->n_threads, &mem);
+    if (rc) return rc;
+    if (ms.mixed) return decline(HGX_FE_DECLINE_OPTS);                   // SAM text and BAM records in one batch: per task on the host
+    const size_t total = ms.base[(size_t)n_tasks], n_lines = ms.line_base[(size_t)n_tasks];
+    if (!hgx_test_switch("front_device") && n_lines < 20000) return decline(HGX_FE_DECLINE_SMALL);
+    if (total >= (1ull << 32) - 64 || n_lines >= (1ull << 30)) return decline(HGX_FE_DECLINE_SIZE);
+    DevBuf b_text;
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};       // (uploads read the readers' buffers)
+    ALLOC(b_text, total + 64);
+    for (int t = 0; t < n_tasks; ++t) {
+        if (!ms.raw_bytes[t]) continue;
+        HIPCHK(hipMemcpyAsync((char *)b_text.p + ms.base[t], ms.raw[t], ms.raw_bytes[t], hipMemcpyHostToDevice, st));
+        g_last_bytes += (long long)ms.raw_bytes[t];
+    }
+    LineRef *h_lines = (LineRef *)pinned_alloc(std::max<size_t>(n_lines, 1) * sizeof(LineRef));
+    if (!h_lines) { hgx_set_error("pinned allocation of the line table failed"); return HGX_ENOMEM; }
+    struct Unpin { void *p; ~Unpin() { pinned_release(p); } } unpin{h_lines};
+    hgx_many_lines(ms, h_lines, opts->n_threads);
+    hgx_dbatch *made = nullptr;
+    int dec = 0;
+    rc = records_run(*const_cast<hgx_locus *>(loc), b_text.as<char>(), total, h_lines, n_lines, ms.binary, n_tasks, *opts, st, &made, tot, &dec);
+    (void)hipStreamSynchronize(st);
+    if (rc) { hgx_dbatch_destroy(made); return rc; }
+    if (dec || !made) { hgx_dbatch_destroy(made); return decline(dec ? dec : HGX_FE_DECLINE_SIZE); }
+    g_last_route = 2; g_last_device = 1;
+    *out = made;
+    return HGX_OK;
 }
 
 extern "C" int hgx_front_last(int32_t *route, int32_t *decline_code, int64_t *bytes_to_device) {

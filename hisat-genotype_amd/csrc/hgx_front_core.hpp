@@ -120,6 +120,7 @@ struct FeKey {
     uint32_t seq_len;
     uint16_t cigar_len, zs_len, md_len;
     uint16_t flags;
+    uint32_t task;                   // many-task batches (the samples of one locus in one pass): whose pileup corrects this key
 };
 
 // read bases of a record, text or BAM-packed
@@ -1082,8 +1083,9 @@ struct FeRec {
     int32_t flag, pos;               // FLAG, POS (1-based, as in the file)
     int32_t nm, nh;                  // saturated to int32
     uint32_t cigar_off, seq_off, zs_off, md_off, seq_len;
-    uint16_t cigar_len, zs_len, md_len, pad_;
-    uint64_t key;                    // hash of the decode key (pos, cigar, seq, Zs, MD)
+    uint16_t cigar_len, zs_len, md_len;
+    uint16_t task;                   // sample of a many-task batch (0 otherwise): keys, read ids and pairs never cross tasks
+    uint64_t key;                    // hash of the decode key (task, pos, cigar, seq, Zs, MD)
 };
 
 FE_HD inline bool fe_py_int_ok(const unsigned char *t, int n) {      // would Python's int(text) take it?  (hgx_sam.cpp py_int_ok)
@@ -1123,6 +1125,7 @@ FE_HD inline uint64_t fe_hash_bytes(const unsigned char *p, int n, uint64_t h) {
 FE_HD inline uint64_t fe_rec_key(const FeRec &r, const char *text) {
     const unsigned char *t = (const unsigned char *)text;
     uint64_t h = fe_mix64(0x243F6A8885A308D3ull ^ (uint32_t)r.pos ^ ((uint64_t)r.seq_len << 32));
+    h = fe_mix64(h + 0x9e3779b97f4a7c15ull * (uint64_t)(r.task + 1));
     if (r.bits & FE_R_BIN) {
         h = fe_hash_bytes(t + r.cigar_off, 4 * (int)r.cigar_len, h);
         const int full = (int)(r.seq_len / 2);
@@ -1145,7 +1148,7 @@ FE_HD inline bool fe_bytes_equal(const unsigned char *a, const unsigned char *b,
 }
 FE_HD inline bool fe_rec_same_key(const FeRec &a, const FeRec &b, const char *text) {      // same_decode_key of hgx_sam.cpp
     const unsigned char *t = (const unsigned char *)text;
-    if (a.pos != b.pos || a.seq_len != b.seq_len || a.cigar_len != b.cigar_len || a.zs_len != b.zs_len || a.md_len != b.md_len) return false;
+    if (a.task != b.task || a.pos != b.pos || a.seq_len != b.seq_len || a.cigar_len != b.cigar_len || a.zs_len != b.zs_len || a.md_len != b.md_len) return false;
     if (((a.bits ^ b.bits) & (FE_R_HAS_ZS | FE_R_HAS_MD | FE_R_BIN)) != 0) return false;
     if (a.bits & FE_R_BIN) {
         if (!fe_bytes_equal(t + a.cigar_off, t + b.cigar_off, 4 * (int)a.cigar_len)) return false;
@@ -1159,16 +1162,19 @@ FE_HD inline bool fe_rec_same_key(const FeRec &a, const FeRec &b, const char *te
     return fe_bytes_equal(t + a.zs_off, t + b.zs_off, a.zs_len) && fe_bytes_equal(t + a.md_off, t + b.md_off, a.md_len);
 }
 
+// a record of the name-ordered stream handed to the record stage: first byte (after block_size for BAM), length, sample
+struct FeLine { uint32_t off, len, task; };
+
 // one line of SAM text (without its line end) -> FeRec.  The tab-only split of split_line; anything else declines.  The line is
 // scanned eight bytes at a time (a word without tab, blank or CR -- most of SEQ and QUAL -- is skipped whole); `text_bytes` = size
 // of the buffer, so that no load reaches past it.
-FE_HD inline int fe_parse_text_record(const char *text, size_t text_bytes, uint32_t off, uint32_t len, bool simulation, FeRec &r) {
+FE_HD inline int fe_parse_text_record(const char *text, size_t text_bytes, uint32_t off, uint32_t len, bool simulation, uint32_t task, FeRec &r) {
     const unsigned char *line = (const unsigned char *)text + off;
     r.bits = 0;
+    r.task = (uint16_t)task;
     r.nm = r.nh = 0;
     r.zs_off = r.md_off = off;
     r.zs_len = r.md_len = 0;
-    r.pad_ = 0;
     uint32_t col_at[11], col_len[11];
     int nc = 0;
     uint32_t p = 0, tok = 0;
@@ -1245,7 +1251,7 @@ FE_HD inline int fe_parse_text_record(const char *text, size_t text_bytes, uint3
 
 // one BAM record (rec_off = the record's first byte after block_size, len = block_size) -> FeRec: split_bam of hgx_sam.cpp
 FE_HD inline uint32_t fe_ld32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
-FE_HD inline int fe_parse_bam_record(const char *text, uint32_t rec_off, uint32_t len, bool simulation, FeRec &rec) {
+FE_HD inline int fe_parse_bam_record(const char *text, uint32_t rec_off, uint32_t len, bool simulation, uint32_t task, FeRec &rec) {
     const unsigned char *r = (const unsigned char *)text + rec_off;
     if (len < 32) return FE_FAIL(FE_E_ASSERT);
     const int32_t pos0 = (int32_t)fe_ld32(r + 4);
@@ -1260,10 +1266,10 @@ FE_HD inline int fe_parse_bam_record(const char *text, uint32_t rec_off, uint32_
     if (q > len || r[32 + l_rn - 1] != 0) return FE_FAIL(FE_E_ASSERT);
     if (n_cig == 0) return FE_FAIL(FE_E_ASSERT);                          // ("*")
     rec.bits = FE_R_BIN;
+    rec.task = (uint16_t)task;
     rec.nm = rec.nh = 0;
     rec.zs_off = rec.md_off = rec_off;
     rec.zs_len = rec.md_len = 0;
-    rec.pad_ = 0;
     while (q + 3 <= len) {
         const char t0 = (char)r[q], t1 = (char)r[q + 1], t = (char)r[q + 2];
         q += 3;
@@ -1328,7 +1334,8 @@ FE_HD inline int fe_parse_bam_record(const char *text, uint32_t rec_off, uint32_
 }
 
 FE_HD inline bool fe_same_read_id(const FeRec &a, const FeRec &b, const char *text) {
-    return a.id_len == b.id_len && fe_bytes_equal((const unsigned char *)text + a.qname_off, (const unsigned char *)text + b.qname_off, a.id_len);
+    return a.task == b.task && a.id_len == b.id_len &&
+           fe_bytes_equal((const unsigned char *)text + a.qname_off, (const unsigned char *)text + b.qname_off, a.id_len);
 }
 
 // record filters (typing_core.py:815-872; filter_records of hgx_sam.cpp).  `head[i]` = record i opens a group of equal read ids.

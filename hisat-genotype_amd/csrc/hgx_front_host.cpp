@@ -93,7 +93,8 @@ FeLocus hgx_front_view(const hgx_locus &L, const hgx_front_tables &T) {
 #ifdef HGX_LAB
 // ---- the device pipeline as loops (lab build only; mirrors hgx_front.hip stage by stage) ---------------------------------------
 // *declined = 0 and *out = the batch, or *declined = the reason and no batch.
-int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &opts, int *declined) {
+int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &opts, int *declined, int n_tasks,
+                      hgx_front_totals *many) {
     *out = nullptr;
     *declined = 0;
     hgx_front_tables T;
@@ -102,13 +103,17 @@ int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, 
     if (!T.usable) { *declined = HGX_FE_DECLINE_LOCUS; return HGX_OK; }
     const FeLocus F = hgx_front_view(L, T);
     const int n_ref = F.n_ref;
+    n_tasks = std::max(1, n_tasks);
+    if (n_tasks > 1 && opts.pileup_exchange) { *declined = HGX_FE_DECLINE_OPTS; return HGX_OK; }
+    if (n_tasks > 65535) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
     hgx_batch *B = new hgx_batch();
-    // k_fe_pileup + k_fe_nt_set
-    B->counts.assign((size_t)n_ref * 6, 0u);
-    B->nt_set.assign(n_ref, 0);
+    // k_fe_pileup (k_fe_pileup_many: a pileup per task) + k_fe_nt_set
+    B->counts.assign((size_t)n_tasks * n_ref * 6, 0u);
+    B->nt_set.assign((size_t)n_tasks * n_ref, 0);
     for (size_t k = 0; k < in.n_keys; ++k) {
         if (in.keys[k].n_pile == 0) continue;
-        uint32_t *cnt = B->counts.data();
+        if ((int)in.keys[k].task >= n_tasks) { hgx_set_error("key of task %u in a batch of %d tasks", in.keys[k].task, n_tasks); delete B; return HGX_EINVAL; }
+        uint32_t *cnt = B->counts.data() + (size_t)in.keys[k].task * n_ref * 6;
         const int r = fe_pileup_key(in.keys[k], in.text, n_ref, 0, 1, [cnt](uint32_t cell, uint32_t w) { cnt[cell] += w; });
         if (r < 0) { *declined = -r; delete B; return HGX_OK; }
     }
@@ -117,10 +122,11 @@ int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, 
         delete B;
         return HGX_EINVAL;
     }
-    for (int i = 0; i < n_ref; ++i) B->nt_set[i] = fe_nt_set(&B->counts[(size_t)i * 6]);
+    for (size_t i = 0; i < (size_t)n_tasks * n_ref; ++i) B->nt_set[i] = fe_nt_set(&B->counts[i * 6]);
     // k_fe_decode
     const size_t S = in.n_slots;
     std::vector<uint8_t> state(S, 0);
+    std::vector<uint16_t> slot_task(S, 0);
     std::vector<uint32_t> key_ht_off(S, 0), key_n_ht(S, 0);
     std::vector<int32_t> ht_pool(std::max<size_t>(S * 48 + 4096, 16));
     const size_t cand_cap = S * 12 + 4096;
@@ -134,10 +140,11 @@ int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, 
     pools.cand_mask_off = cand_mask_off.data(); pools.cand_cap = (uint32_t)cand_cap; pools.cand_cursor = &cur[1];
     pools.mask_pool = mask_pool.data(); pools.mask_cap = (uint32_t)mask_pool.size(); pools.mask_cursor = &cur[2];
     FeParse po{opts.num_editdist, opts.error_correction};
-    FePile pile{B->nt_set.data(), B->counts.data()};
     for (size_t k = 0; k < in.n_keys; ++k) {
         const FeKey &K = in.keys[k];
         if (K.slot == FE_NO_SLOT) continue;
+        const FePile pile{B->nt_set.data() + (size_t)K.task * n_ref, B->counts.data() + (size_t)K.task * n_ref * 6};   // the key's own sample
+        slot_task[K.slot] = (uint16_t)K.task;
         const int r = fe_key(F, po, pile, K, in.text, pools, state[K.slot], key_ht_off[K.slot], key_n_ht[K.slot]);
         if (r < 0) { *declined = -r; delete B; return HGX_OK; }
     }
@@ -186,6 +193,24 @@ int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, 
         B->pieces[k] = pc;
         B->masks.insert(B->masks.end(), &mask_pool[cand_mask_off[c]], &mask_pool[cand_mask_off[c]] + 2 * (size_t)cand_nw[c]);
     }
+    // k_fe_task_pieces: the distinct pieces each task's decoded keys produced (what the task's own batch would hold)
+    if (many) {
+        many->reads.assign((size_t)n_tasks, 0); many->pairs.assign((size_t)n_tasks, 0); many->refs.assign((size_t)n_tasks, 0);
+        many->pieces.assign((size_t)n_tasks, 0);
+        std::vector<std::vector<uint8_t>> seen((size_t)n_tasks, std::vector<uint8_t>(heads.size(), 0));
+        for (size_t sl = 0; sl < S; ++sl) {
+            if (state[sl] != 1) continue;
+            uint32_t at = key_ht_off[sl];
+            for (uint32_t x = 0; x < key_n_ht[sl]; ++x) {
+                const int32_t *rec = &ht_pool[at];
+                for (int e = 0; e <= rec[3]; ++e) {
+                    uint8_t &b = seen[slot_task[sl]][new_id[head_of[(uint32_t)rec[4] + e]]];
+                    if (!b) { b = 1; many->pieces[slot_task[sl]]++; }
+                }
+                at += FE_HT_HDR + (uint32_t)rec[2];
+            }
+        }
+    }
     // k_fe_pairs: count, scan, emit
     int64_t n_reads = 0;
     for (size_t i = 0; i < in.n_rec; ++i) {
@@ -200,6 +225,10 @@ int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, 
         size_t n_exon = 0;
         for (int x = 0; x < n_uni; ++x) n_exon += (size_t)ht_pool[uni[x] + 3];
         if (n_exon > 65535 || n_uni > 65535) { *declined = -FE_E_PAIR; delete B; return HGX_OK; }
+        if (many) {
+            const uint32_t t = slot_task[FE_REC_SLOT(in.rec_info[i])];
+            many->reads[t] += (uint32_t)ns; many->pairs[t] += 1; many->refs[t] += n_exon + (size_t)n_uni;
+        }
         for (int x = 0; x < n_uni; ++x) {
             const int32_t *rec = &ht_pool[uni[x]];
             for (int e = 0; e < rec[3]; ++e) B->pair_ref.push_back(new_id[head_of[(uint32_t)rec[4] + e]]);
@@ -218,16 +247,15 @@ int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, 
 
 #ifdef HGX_LAB
 // ---- the record stage as loops (mirrors k_fe_records .. k_fe_build of hgx_front.hip), then the key stages above -----------------
-int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary,
-                              const hgx_parse_opts &o, int *declined) {
+int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, size_t raw_bytes, const FeLine *lines, size_t n, bool binary,
+                              const hgx_parse_opts &o, int *declined, int n_tasks, hgx_front_totals *many) {
     *out = nullptr;
     *declined = 0;
     if (raw_bytes >= (1ull << 32) - 64 || n >= (1ull << 30)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
     std::vector<FeRec> recs(n);
     for (size_t i = 0; i < n; ++i) {
-        const uint32_t off = (uint32_t)(lines[i].p - raw) - (binary ? 32u : 0u);
-        const int r = binary ? fe_parse_bam_record(raw, off, lines[i].len, o.simulation != 0, recs[i])
-                             : fe_parse_text_record(raw, raw_bytes, off, lines[i].len, o.simulation != 0, recs[i]);
+        const int r = binary ? fe_parse_bam_record(raw, lines[i].off, lines[i].len, o.simulation != 0, lines[i].task, recs[i])
+                             : fe_parse_text_record(raw, raw_bytes, lines[i].off, lines[i].len, o.simulation != 0, lines[i].task, recs[i]);
         if (r < 0) { *declined = -r; return HGX_OK; }
     }
     std::vector<uint8_t> head(n, 0), kept(n, 0), pm(n, 0);
@@ -281,6 +309,7 @@ int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, si
         K.seq_len = f.seq_len; K.cigar_len = f.cigar_len; K.zs_len = f.zs_len; K.md_len = f.md_len;
         K.flags = (uint16_t)(((f.bits & FE_R_HAS_ZS) ? FE_K_HAS_ZS : 0) | ((f.bits & FE_R_HAS_MD) ? FE_K_HAS_MD : 0) |
                              ((f.bits & FE_R_BIN) ? (FE_K_BIN_CIGAR | FE_K_PACKED_SEQ) : 0));
+        K.task = f.task;
     }
     in.n_keys = nk;
     in.n_slots = ns;
@@ -292,7 +321,7 @@ int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, si
         prev = i;
     }
     in.n_rec = nr;
-    return hgx_front_emulate(out, L, in, o, declined);
+    return hgx_front_emulate(out, L, in, o, declined, n_tasks, many);
 }
 #endif
 
@@ -327,7 +356,9 @@ extern "C" int hgx_lab_parse_records_emulated(hgx_batch **out, const hgx_locus *
         return hgx_front_emulate(&made, L, in, o, dec);
     };
     hook.records = [&](hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &o, int *dec) {
-        return hgx_front_emulate_records(&made, L, raw, raw_bytes, lines, n, binary, o, dec);
+        std::vector<FeLine> refs(n);
+        for (size_t i = 0; i < n; ++i) refs[i] = FeLine{(uint32_t)((size_t)(lines[i].p - raw) - (binary ? 32u : 0u)), lines[i].len, 0u};
+        return hgx_front_emulate_records(&made, L, raw, raw_bytes, refs.data(), n, binary, o, dec);
     };
     const int rc = path ? hgx_parse_alignment_file_hook(out, loc, path, regions, opts, &hook) : hgx_parse_sam_hook(out, loc, sam, n_bytes, opts, &hook);
     declined[0] = hook.declined_records;
@@ -336,5 +367,47 @@ extern "C" int hgx_lab_parse_records_emulated(hgx_batch **out, const hgx_locus *
     if (!*out) *out = made;
     else delete made;
     return HGX_OK;
+}
+// MANY tasks of one locus through the emulated record route (hgx_front_many_dev's stages as loops): the tasks' streams are
+// concatenated at their 64-byte aligned bases (the gaps filled with a byte no record holds), every line carries its task.
+// out = the merged batch; pair_base [n_tasks + 1], n_reads / n_pieces / n_refs [n_tasks].
+extern "C" int hgx_lab_many_emulated(hgx_batch **out, const hgx_locus *loc, const char *const *paths, const char *const *regions,
+                                     const char *const *sams, const size_t *sam_bytes, int32_t n_tasks, const hgx_parse_opts *opts,
+                                     int32_t *pair_base, int32_t *n_reads, int32_t *n_pieces, int64_t *n_refs, int32_t *declined) {
+    HARGCHK(out && loc && opts && declined && n_tasks >= 1 && (paths || (sams && sam_bytes)));
+    *out = nullptr;
+    *declined = 0;
+    if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange || opts->pileup_exchange) { *declined = HGX_FE_DECLINE_OPTS; return HGX_OK; }
+    hgx_many_streams ms;
+    int rc = hgx_many_read(ms, paths, regions, sams, sam_bytes, n_tasks, opts->n_threads, nullptr);
+    if (rc) return rc;
+    if (ms.mixed) { *declined = HGX_FE_DECLINE_OPTS; return HGX_OK; }
+    const size_t total = ms.base[(size_t)n_tasks], n_lines = ms.line_base[(size_t)n_tasks];
+    std::vector<char> text(total + 64, (char)0xAA);
+    for (int t = 0; t < n_tasks; ++t) if (ms.raw_bytes[t]) memcpy(&text[ms.base[t]], ms.raw[t], ms.raw_bytes[t]);
+    std::vector<FeLine> lines(std::max<size_t>(n_lines, 1));
+    hgx_many_lines(ms, lines.data(), opts->n_threads);
+    hgx_front_totals tot;
+    int dec = 0;
+    hgx_batch *made = nullptr;
+    rc = hgx_front_emulate_records(&made, *const_cast<hgx_locus *>(loc), text.data(), total, lines.data(), n_lines, ms.binary, *opts, &dec, n_tasks, &tot);
+    if (rc) { delete made; return rc; }
+    if (dec) { delete made; *declined = dec; return HGX_OK; }
+    int32_t base = 0;
+    for (int t = 0; t < n_tasks; ++t) {
+        if (pair_base) pair_base[t] = base;
+        base += (int32_t)tot.pairs[t];
+        if (n_reads) n_reads[t] = (int32_t)tot.reads[t];
+        if (n_pieces) n_pieces[t] = (int32_t)tot.pieces[t];
+        if (n_refs) n_refs[t] = (int64_t)tot.refs[t];
+    }
+    if (pair_base) pair_base[n_tasks] = base;
+    *out = made;
+    return HGX_OK;
+}
+
+// hgx_batch_merge for the CPU tests (the product reaches it through hgx_many_create, which needs a device)
+extern "C" int hgx_lab_batch_merge(hgx_batch **out, const hgx_batch *const *batches, int32_t n, int32_t *pair_base) {
+    return hgx_batch_merge(out, batches, n, pair_base);
 }
 #endif

@@ -5,6 +5,7 @@
 #include <atomic>
 #include <cstdint>
 #include <functional>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -259,8 +260,30 @@ struct hgx_front_hook {
 int hgx_parse_sam_hook(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, hgx_front_hook *hook);
 int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *loc, const char *path, const char *regions, const hgx_parse_opts *opts,
                                   hgx_front_hook *hook);
+// ---- the record streams of MANY tasks of one locus as one stream (hgx_many_create_files / _sams: one device pass for all) ------
+// what a many-task pass reports per task
+struct hgx_front_totals { std::vector<uint32_t> reads, pairs, pieces; std::vector<uint64_t> refs; };
+struct hgx_many_streams {
+    int n_tasks = 0;
+    std::unique_ptr<hgx_align_lines[]> al;       // per task: the reader's line table (and its bytes, when it read a file)
+    std::vector<const char *> raw;               // per task: the bytes the lines point into (a file's, or the caller's SAM text)
+    std::vector<size_t> raw_bytes;
+    std::vector<size_t> base, line_base;         // [n_tasks + 1]: where a task's bytes / lines start in the concatenation (bytes 64-aligned)
+    bool binary = false;                         // BAM records (all tasks alike: a mix is refused with `mixed`)
+    bool mixed = false;
+};
+// reads (paths[t], regions[t] or regions NULL) or walks (sams[t], sam_bytes[t]) every task's stream, tasks side by side on the
+// host's threads; big reader blocks come from `mem` (pinned staging) when given
+int hgx_many_read(hgx_many_streams &ms, const char *const *paths, const char *const *regions, const char *const *sams, const size_t *sam_bytes,
+                  int n_tasks, int n_threads, const hgx_front_alloc *mem);
+void hgx_many_lines(const hgx_many_streams &ms, FeLine *dst, int n_threads);     // the concatenated line table: (offset, length, task)
+struct hgx_dbatch;
+// the device pass over them (hgx_front.hip): *declined != 0 -> nothing made, the caller goes task by task through the host stages
+int hgx_front_many_dev(hgx_dbatch **out, hgx_front_totals *tot, const hgx_locus *loc, const char *const *paths, const char *const *regions,
+                       const char *const *sams, const size_t *sam_bytes, int n_tasks, const hgx_parse_opts *opts, void *stream, int *declined);
 #ifdef HGX_LAB
-int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &opts, int *declined);
-int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary,
-                              const hgx_parse_opts &opts, int *declined);
+int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &opts, int *declined, int n_tasks = 1,
+                      hgx_front_totals *many = nullptr);
+int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, size_t raw_bytes, const FeLine *lines, size_t n, bool binary,
+                              const hgx_parse_opts &opts, int *declined, int n_tasks = 1, hgx_front_totals *many = nullptr);
 #endif

@@ -1693,6 +1693,7 @@ int build_front_input(const hgx_parse_opts &o, const Fields *recs, const uint8_t
             K.zs_len = (uint16_t)f.zs_len;
             K.md_len = (uint16_t)f.md_len;
             K.flags = (uint16_t)((f.zs ? FE_K_HAS_ZS : 0) | (f.md ? FE_K_HAS_MD : 0));
+            K.task = 0;
             char *w = in.text + at;
             memcpy(w, f.cigar, f.cigar_len); w += f.cigar_len;
             memcpy(w, f.seq, f.seq_len); w += f.seq_len;
@@ -1822,6 +1823,81 @@ int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *Lc, const ch
         hgx_set_error("hgx_parse_alignment_file: %s", e.what());
         return HGX_ENOMEM;
     }
+}
+
+// ---- many tasks of one locus, read side by side (hgx_internal.hpp: hgx_many_streams) --------------------------------------------
+int hgx_many_read(hgx_many_streams &ms, const char *const *paths, const char *const *regions, const char *const *sams, const size_t *sam_bytes,
+                  int n_tasks, int n_threads, const hgx_front_alloc *mem) {
+    HARGCHK(n_tasks >= 0 && (n_tasks == 0 || paths || (sams && sam_bytes)));
+    ms.n_tasks = n_tasks;
+    ms.al.reset(new hgx_align_lines[(size_t)std::max(n_tasks, 1)]);
+    ms.raw.assign((size_t)n_tasks, nullptr);
+    ms.raw_bytes.assign((size_t)n_tasks, 0);
+    ms.base.assign((size_t)n_tasks + 1, 0);
+    ms.line_base.assign((size_t)n_tasks + 1, 0);
+    if (n_threads <= 0) n_threads = hgx_default_threads();
+    n_threads = std::max(1, std::min(n_threads, 512));
+    std::vector<int> rcs((size_t)n_tasks, HGX_OK);
+    std::vector<std::string> errs((size_t)n_tasks);
+    // few tasks: the threads go to the readers' own phases (inflate, walk, sort); many: one thread per task
+    const int inner = n_tasks > 0 ? std::max(1, n_threads / n_tasks) : 1;
+    hgx_par_tasks(std::min(n_threads, std::max(n_tasks, 1)), (size_t)n_tasks, [&](int, size_t t) {
+        try {
+            hgx_align_lines &al = ms.al[t];
+            if (paths) {
+                if (!paths[t]) { rcs[t] = HGX_EINVAL; errs[t] = "task without a path"; return; }
+                std::unique_ptr<hgx_big_alloc_scope> pinned;
+                if (mem && mem->alloc) pinned.reset(new hgx_big_alloc_scope(*mem, 1u << 20));
+                rcs[t] = hgx_read_alignment_lines(paths[t], regions ? regions[t] : nullptr, inner, al, /*keep_binary=*/true);
+                pinned.reset();
+                if (rcs[t]) { errs[t] = hgx_last_error(); return; }
+                ms.raw[t] = al.raw;
+                ms.raw_bytes[t] = al.raw_bytes;
+            } else {
+                const char *base = sams[t], *end = base + sam_bytes[t];
+                if (!base && sam_bytes[t]) { rcs[t] = HGX_EINVAL; errs[t] = "task without text"; return; }
+                for (const char *p = base; p < end;) {
+                    const char *e = (const char *)memchr(p, '\n', (size_t)(end - p));
+                    if (!e) e = end;
+                    if (e > p && *p != '@') al.lines.push_back(hgx_line{const_cast<char *>(p), (uint32_t)(e - p), 0, 0});
+                    p = e + 1;
+                }
+                ms.raw[t] = base;
+                ms.raw_bytes[t] = sam_bytes[t];
+            }
+        } catch (const std::exception &e) {
+            rcs[t] = HGX_ENOMEM;
+            errs[t] = e.what();
+        }
+    });
+    for (int t = 0; t < n_tasks; ++t)
+        if (rcs[t]) { hgx_set_error("task %d: %s", t, errs[t].c_str()); return rcs[t]; }
+    bool any = false;
+    for (int t = 0; t < n_tasks; ++t) {
+        if (ms.al[t].lines.size() > 0) {
+            if (any && ms.al[t].binary != ms.binary) ms.mixed = true;
+            if (!any) ms.binary = ms.al[t].binary;
+            any = true;
+        }
+        ms.base[t + 1] = (ms.base[t] + ms.raw_bytes[t] + 63) & ~(size_t)63;
+        ms.line_base[t + 1] = ms.line_base[t] + ms.al[t].lines.size();
+    }
+    return HGX_OK;
+}
+
+void hgx_many_lines(const hgx_many_streams &ms, FeLine *dst, int n_threads) {
+    if (n_threads <= 0) n_threads = hgx_default_threads();
+    const size_t skip = ms.binary ? 32 : 0;
+    hgx_par_tasks(std::max(1, std::min(n_threads, std::max(ms.n_tasks, 1))), (size_t)ms.n_tasks, [&](int, size_t t) {
+        const hgx_align_lines &al = ms.al[t];
+        FeLine *d = dst + ms.line_base[t];
+        const hgx_line *ln = al.lines.data();
+        for (size_t i = 0, n = al.lines.size(); i < n; ++i) {
+            d[i].off = (uint32_t)(ms.base[t] + (size_t)(ln[i].p - ms.raw[t]) - skip);
+            d[i].len = ln[i].len;
+            d[i].task = (uint32_t)t;
+        }
+    });
 }
 
 // lines: name-grouped records.  Text: lines[i].p[lines[i].len] is writable (it becomes the record's terminator).  Binary (BAM

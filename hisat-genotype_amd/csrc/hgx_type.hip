@@ -705,6 +705,29 @@ extern "C" int hgx_many_destroy(hgx_many *m) {
     return HGX_OK;
 }
 
+namespace {
+// the tables a many-task batch needs besides the merged batch itself: task of every pair, the alleles' name order and lengths
+int many_finish(hgx_many *m, const hgx_locus *loc, hipStream_t st) {
+    const int32_t n_tasks = m->n_tasks, n_pairs = m->db->n_pairs;
+    m->d_pair_seg = (uint32_t *)hgx_pool_alloc((size_t)std::max(n_pairs, 1) * 4);
+    m->d_pair_base = (int32_t *)hgx_pool_alloc((size_t)(n_tasks + 1) * 4);
+    m->d_rank = (int32_t *)hgx_pool_alloc((size_t)loc->a_pad * 4);
+    m->d_len = (double *)hgx_pool_alloc((size_t)loc->a_pad * 8);
+    if (!m->d_pair_seg || !m->d_pair_base || !m->d_rank || !m->d_len) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
+    std::vector<int32_t> rank((size_t)loc->a_pad, 0);
+    std::vector<double> len((size_t)loc->a_pad, 1.0);
+    for (int32_t a = 0; a < loc->A; ++a) { rank[a] = loc->name_rank[a]; len[a] = (double)loc->allele_len[a]; }
+    for (int32_t a = loc->A; a < loc->a_pad; ++a) rank[a] = a;       // (never read: padding alleles occur in no class)
+    bool ok = hipMemcpyAsync(m->d_pair_base, m->pair_base.data(), (size_t)(n_tasks + 1) * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(m->d_rank, rank.data(), rank.size() * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && hipMemcpyAsync(m->d_len, len.data(), len.size() * 8, hipMemcpyHostToDevice, st) == hipSuccess;
+    ok = ok && hgx_many_fill_seg(m->d_pair_base, n_tasks, m->d_pair_seg, st) == HGX_OK;
+    ok = ok && hipStreamSynchronize(st) == hipSuccess;
+    if (!ok) { hgx_set_error("upload of the merged batch tables failed"); return HGX_EHIP; }
+    return HGX_OK;
+}
+}   // namespace
+
 extern "C" int hgx_many_create(hgx_many **out, const hgx_locus *loc, const hgx_batch *const *batches, int32_t n_tasks, void *stream) {
     ARGCHK(out && loc && n_tasks >= 0 && (n_tasks == 0 || batches));
     *out = nullptr;
@@ -723,24 +746,93 @@ extern "C" int hgx_many_create(hgx_many **out, const hgx_locus *loc, const hgx_b
     int rc = hgx_batch_merge(&merged, batches, n_tasks, m->pair_base.data());
     if (!rc) rc = hgx_dbatch_create(&m->db, merged, stream);
     hgx_batch_destroy(merged);
+    if (!rc) rc = many_finish(m, loc, st);
     if (rc) { hgx_many_destroy(m); return rc; }
-    const int32_t n_pairs = m->db->n_pairs;
-    m->d_pair_seg = (uint32_t *)hgx_pool_alloc((size_t)std::max(n_pairs, 1) * 4);
-    m->d_pair_base = (int32_t *)hgx_pool_alloc((size_t)(n_tasks + 1) * 4);
-    m->d_rank = (int32_t *)hgx_pool_alloc((size_t)loc->a_pad * 4);
-    m->d_len = (double *)hgx_pool_alloc((size_t)loc->a_pad * 8);
-    if (!m->d_pair_seg || !m->d_pair_base || !m->d_rank || !m->d_len) { hgx_many_destroy(m); hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
-    std::vector<int32_t> rank((size_t)loc->a_pad, 0);
-    std::vector<double> len((size_t)loc->a_pad, 1.0);
-    for (int32_t a = 0; a < loc->A; ++a) { rank[a] = loc->name_rank[a]; len[a] = (double)loc->allele_len[a]; }
-    for (int32_t a = loc->A; a < loc->a_pad; ++a) rank[a] = a;       // (never read: padding alleles occur in no class)
-    bool ok = hipMemcpyAsync(m->d_pair_base, m->pair_base.data(), (size_t)(n_tasks + 1) * 4, hipMemcpyHostToDevice, st) == hipSuccess;
-    ok = ok && hipMemcpyAsync(m->d_rank, rank.data(), rank.size() * 4, hipMemcpyHostToDevice, st) == hipSuccess;
-    ok = ok && hipMemcpyAsync(m->d_len, len.data(), len.size() * 8, hipMemcpyHostToDevice, st) == hipSuccess;
-    ok = ok && hgx_many_fill_seg(m->d_pair_base, n_tasks, m->d_pair_seg, st) == HGX_OK;
-    ok = ok && hipStreamSynchronize(st) == hipSuccess;
-    if (!ok) { hgx_many_destroy(m); hgx_set_error("upload of the merged batch tables failed"); return HGX_EHIP; }
     *out = m;
+    return HGX_OK;
+}
+
+namespace {
+// alignment streams -> many-task batch: one pass of the device front end over all tasks, or -- where it declines (a record the
+// reference would raise on, options it leaves to the host, too little work) -- the host front end task by task, then the merge
+int many_from_streams(hgx_many **out, const hgx_locus *loc, const char *const *paths, const char *const *regions, const char *const *sams,
+                      const size_t *sam_bytes, int32_t n_tasks, const hgx_parse_opts *opts, void *stream) {
+    *out = nullptr;
+    ARGCHK((int32_t)loc->name_rank.size() == loc->A && (int32_t)loc->allele_len.size() == loc->A);
+    hipStream_t st = (hipStream_t)stream;
+    hgx_dbatch *db = nullptr;
+    hgx_front_totals tot;
+    int declined = 0;
+    int rc = n_tasks > 0 ? hgx_front_many_dev(&db, &tot, loc, paths, regions, sams, sam_bytes, n_tasks, opts, stream, &declined) : HGX_OK;
+    if (rc) return rc;
+    if (n_tasks > 0 && !declined && db) {
+        hgx_many *m = new hgx_many();
+        m->n_tasks = n_tasks; m->A = loc->A; m->a_pad = loc->a_pad;
+        m->db = db;
+        m->pair_base.assign((size_t)n_tasks + 1, 0);
+        for (int t = 0; t < n_tasks; ++t) {
+            m->pair_base[(size_t)t + 1] = m->pair_base[t] + (int32_t)tot.pairs[t];
+            m->n_reads.push_back((int32_t)tot.reads[t]);
+            m->n_pieces.push_back((int32_t)tot.pieces[t]);
+            m->n_refs.push_back((int64_t)tot.refs[t]);
+        }
+        if (m->pair_base[(size_t)n_tasks] != db->n_pairs) {
+            hgx_many_destroy(m);
+            hgx_set_error("device front end: the tasks' pair counts do not add up to the batch");
+            return HGX_EHIP;
+        }
+        rc = many_finish(m, loc, st);
+        if (rc) { hgx_many_destroy(m); return rc; }
+        *out = m;
+        return HGX_OK;
+    }
+    // host front end, tasks side by side
+    std::vector<hgx_batch *> bs((size_t)n_tasks, nullptr);
+    std::vector<int> rcs((size_t)n_tasks, HGX_OK);
+    std::vector<std::string> errs((size_t)n_tasks);
+    const int n_threads = opts->n_threads > 0 ? opts->n_threads : hgx_default_threads();
+    hgx_parse_opts po = *opts;
+    po.n_threads = n_tasks > 0 ? std::max(1, n_threads / n_tasks) : 1;
+    hgx_par_tasks(std::max(1, std::min(n_threads, n_tasks)), (size_t)n_tasks, [&](int, size_t t) {
+        rcs[t] = paths ? hgx_parse_alignment_file(&bs[t], loc, paths[t], regions ? regions[t] : nullptr, &po)
+                       : hgx_parse_sam(&bs[t], loc, sams[t], sam_bytes[t], &po);
+        if (rcs[t]) errs[t] = hgx_last_error();
+    });
+    rc = HGX_OK;
+    for (int t = 0; t < n_tasks && !rc; ++t)
+        if (rcs[t]) { hgx_set_error("task %d: %s", t, errs[t].c_str()); rc = rcs[t]; }
+    if (!rc) rc = hgx_many_create(out, loc, bs.data(), n_tasks, stream);
+    for (hgx_batch *b : bs) hgx_batch_destroy(b);
+    return rc;
+}
+}   // namespace
+
+extern "C" int hgx_many_create_files(hgx_many **out, const hgx_locus *loc, const char *const *paths, const char *const *regions, int32_t n_tasks,
+                                     const hgx_parse_opts *opts, void *stream) {
+    ARGCHK(out && loc && opts && n_tasks >= 0 && (n_tasks == 0 || paths));
+    for (int t = 0; t < n_tasks; ++t) ARGCHK(paths[t]);
+    return many_from_streams(out, loc, paths, regions, nullptr, nullptr, n_tasks, opts, stream);
+}
+
+extern "C" int hgx_many_create_sams(hgx_many **out, const hgx_locus *loc, const char *const *sams, const size_t *n_bytes, int32_t n_tasks,
+                                    const hgx_parse_opts *opts, void *stream) {
+    ARGCHK(out && loc && opts && n_tasks >= 0 && (n_tasks == 0 || (sams && n_bytes)));
+    for (int t = 0; t < n_tasks; ++t) ARGCHK(sams[t] || n_bytes[t] == 0);
+    return many_from_streams(out, loc, nullptr, nullptr, sams, n_bytes, n_tasks, opts, stream);
+}
+
+// the merged batch of a many-task batch (tests, tools: hgx_dbatch_to_host on it) and its per-task extents; arrays of n_tasks (+ 1
+// for pair_base) entries or NULL
+extern "C" int hgx_many_tasks(const hgx_many *m, const hgx_dbatch **db, int32_t *pair_base, int32_t *n_reads, int32_t *n_pieces, int64_t *n_refs) {
+    ARGCHK(m);
+    if (db) *db = m->db;
+    for (int t = 0; t < m->n_tasks; ++t) {
+        if (pair_base) pair_base[t] = m->pair_base[t];
+        if (n_reads) n_reads[t] = m->n_reads[t];
+        if (n_pieces) n_pieces[t] = m->n_pieces[t];
+        if (n_refs) n_refs[t] = m->n_refs[t];
+    }
+    if (pair_base) pair_base[m->n_tasks] = m->pair_base[(size_t)m->n_tasks];
     return HGX_OK;
 }
 

@@ -124,19 +124,72 @@ def em_set_fast(on):
     return -1 if old < 0 else bool(old)
 
 
+def _parse_opts(locus, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False, base_locus=0, n_threads=0):
+    return capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus, 0,
+                          int(locus.base_fname == "codis" and locus.gene == "D18S51"), int(n_threads))
+
+
 class ManyBatch:
     """The piece batches of many tasks of ONE locus merged and resident in HBM (hgx_many): what hgx_type_many types at once."""
 
     def __init__(self, locus, batches, stream=None):
         self.h = C.c_void_p()
-        self.n_tasks = len(batches)
         arr = (C.c_void_p * max(len(batches), 1))(*[b.h for b in batches])
         capi.check(capi.lib().hgx_many_create(C.byref(self.h), locus.h, arr, C.c_int32(len(batches)), stream))
+        self._dims()
+
+    def _dims(self):
         nt, npc, npr, nrf, nrd = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_int64()
         capi.check(capi.lib().hgx_many_dims(self.h, C.byref(nt), C.byref(npc), C.byref(npr), C.byref(nrf), C.byref(nrd)))
-        self.n_pieces, self.n_pairs, self.n_refs, self.n_reads = npc.value, npr.value, nrf.value, nrd.value
-        self.task_reads = [b.n_reads for b in batches]
-        self.task_pairs = [b.n_pairs for b in batches]
+        self.n_tasks, self.n_pieces, self.n_pairs, self.n_refs, self.n_reads = nt.value, npc.value, npr.value, nrf.value, nrd.value
+        n = self.n_tasks
+        base, reads = (C.c_int32 * (n + 1))(), (C.c_int32 * max(n, 1))()
+        pieces, refs = (C.c_int32 * max(n, 1))(), (C.c_int64 * max(n, 1))()
+        capi.check(capi.lib().hgx_many_tasks(self.h, None, base, reads, pieces, refs))
+        self.pair_base = list(base)
+        self.task_reads = list(reads)[:n]
+        self.task_pairs = [base[t + 1] - base[t] for t in range(n)]
+        self.task_pieces = list(pieces)[:n]
+        self.task_refs = list(refs)[:n]
+
+    @classmethod
+    def from_files(cls, locus, paths, regions=None, stream=None, **opts):
+        """hgx_many_create_files: the samples' alignment files (SAM text or BAM) of one locus -> merged batch, in one pass of the
+        device front end (or, where it declines, through the host front end per task: `engine.front_last()` says which)."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        n = len(paths)
+        p_arr = (C.c_char_p * max(n, 1))(*[str(p).encode() for p in paths])
+        r_arr = None
+        if regions is not None:
+            r_arr = (C.c_char_p * max(n, 1))(*[(r.encode() if r else None) for r in regions])
+        o = _parse_opts(locus, **opts)
+        capi.check(capi.lib().hgx_many_create_files(C.byref(self.h), locus.h, p_arr, r_arr, C.c_int32(n), C.byref(o), stream))
+        self._dims()
+        return self
+
+    @classmethod
+    def from_sams(cls, locus, sams, stream=None, **opts):
+        """hgx_many_create_sams: name-grouped SAM texts (bytes) in memory, one per task."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        n = len(sams)
+        keep = [s if isinstance(s, bytes) else s.encode() for s in sams]
+        s_arr = (C.c_char_p * max(n, 1))(*keep)
+        n_arr = (C.c_size_t * max(n, 1))(*[len(s) for s in keep])
+        o = _parse_opts(locus, **opts)
+        capi.check(capi.lib().hgx_many_create_sams(C.byref(self.h), locus.h, s_arr, n_arr, C.c_int32(n), C.byref(o), stream))
+        self._dims()
+        return self
+
+    def merged(self):
+        """The merged device batch as a host Batch-like object (tests, tools): pieces, masks, pair_off, pair_ref."""
+        db = C.c_void_p()
+        capi.check(capi.lib().hgx_many_tasks(self.h, C.byref(db), None, None, None, None))
+        from . import locus
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_dbatch_to_host(db, C.byref(h)))
+        return locus.Batch(h)
 
     def close(self):
         if self.h:

@@ -500,6 +500,20 @@ int hgx_typing_classes(const hgx_typing *t, int32_t level, const hgx_classes **o
  * and em_fast are honoured; class sets are not kept per task.  One call at a time per hgx_many (its staging memory is reused). */
 typedef struct hgx_many hgx_many;
 int hgx_many_create(hgx_many **out, const hgx_locus *loc, const hgx_batch *const *batches, int32_t n_tasks, void *stream);
+/* The same batch straight from the tasks' alignment streams -- files (SAM text or BAM; regions[t] as in
+ * hgx_parse_alignment_file, `regions` may be NULL) or name-grouped SAM texts in memory: the samples of a panel at one locus in
+ * ONE pass of the device front end (the tasks' files are read side by side on the host's threads, their bytes land in one device
+ * buffer, every record carries its task: keys, read ids and pairs never cross tasks, each task has its own pileup for the error
+ * correction, the piece table is shared).  The batch is the one hgx_many_create makes of hgx_parse_alignment_file's per-task
+ * batches, array for array; where the device front end declines (hgx_front_last) exactly that is done instead.
+ * The reference's call site: one hisatgenotype_locus process per sample through the pool (/root/reference/hisatgenotype:613-665),
+ * each reading its own alignment file (typing_core.py:826-897).                                                               */
+int hgx_many_create_files(hgx_many **out, const hgx_locus *loc, const char *const *paths, const char *const *regions /* or NULL */,
+                          int32_t n_tasks, const hgx_parse_opts *opts, void *stream);
+int hgx_many_create_sams(hgx_many **out, const hgx_locus *loc, const char *const *sams, const size_t *n_bytes, int32_t n_tasks,
+                         const hgx_parse_opts *opts, void *stream);
+/* the merged device batch of `m` (owned by it) and the tasks' extents: pair_base [n_tasks + 1], the others [n_tasks]; any may be NULL */
+int hgx_many_tasks(const hgx_many *m, const hgx_dbatch **db, int32_t *pair_base, int32_t *n_reads, int32_t *n_pieces, int64_t *n_refs);
 int hgx_many_destroy(hgx_many *m);
 int hgx_many_dims(const hgx_many *m, int32_t *n_tasks, int32_t *n_distinct_pieces, int32_t *n_pairs, int64_t *n_refs, int64_t *n_reads);
 int hgx_type_many(hgx_typing **out /* [n_tasks] */, int32_t *rc_out /* [n_tasks] or NULL */, const hgx_locus *loc, const hgx_index *ix,

@@ -133,3 +133,131 @@ def test_emulated_device_stages_on_fuzz_cases():
         same_batch(host, emu, len(loc.backbone))
     print("device stages took %d of %d inputs; decline codes %s; record route %d, decline codes %s" % (n_dev, n_all, why, n_rec, why_rec))
     assert n_dev >= 0.8 * n_all, (n_dev, n_all, why)
+
+
+# ---- MANY tasks of one locus in one pass (hgx_many_create_files / _sams): emulated stages against hgx_batch_merge of the host's batches ----
+def many_emulated(pl, sams=None, paths=None, regions=None, **kw):
+    n = len(sams if sams is not None else paths)
+    o = capi.ParseOpts(kw.get("num_editdist", 2), int(kw.get("error_correction", True)), int(kw.get("allow_discordant", False)),
+                       int(kw.get("simulation", False)), 0, 0, int(pl.base_fname == "codis" and pl.gene == "D18S51"), 0)
+    h, dec = C.c_void_p(), C.c_int32(0)
+    base, reads, pieces, refs = (C.c_int32 * (n + 1))(), (C.c_int32 * n)(), (C.c_int32 * n)(), (C.c_int64 * n)()
+    p_arr = r_arr = s_arr = n_arr = None
+    if paths is not None:
+        p_arr = (C.c_char_p * n)(*[p.encode() for p in paths])
+        if regions is not None:
+            r_arr = (C.c_char_p * n)(*[r.encode() if r else None for r in regions])
+    else:
+        keep = [s if isinstance(s, bytes) else s.encode() for s in sams]
+        s_arr = (C.c_char_p * n)(*keep)
+        n_arr = (C.c_size_t * n)(*[len(s) for s in keep])
+    capi.check(capi.lib().hgx_lab_many_emulated(C.byref(h), pl.h, p_arr, r_arr, s_arr, n_arr, C.c_int32(n), C.byref(o), base, reads, pieces,
+                                                refs, C.byref(dec)))
+    if dec.value:
+        return None, dec.value, None
+    return hl.Batch(h), 0, (list(base), list(reads), list(pieces), list(refs))
+
+
+def host_merged(pl, sams, **kw):
+    bs = [pl.parse_sam(s, **kw) for s in sams]
+    n = len(bs)
+    arr = (C.c_void_p * n)(*[b.h for b in bs])
+    base = (C.c_int32 * (n + 1))()
+    h = C.c_void_p()
+    capi.check(capi.lib().hgx_lab_batch_merge(C.byref(h), arr, C.c_int32(n), base))
+    return hl.Batch(h), (list(base), [b.n_reads for b in bs], [b.n_pieces for b in bs], [b.n_refs for b in bs]), bs
+
+
+def same_merged(a, b):
+    assert (a.n_reads, a.n_pairs, a.n_pieces, a.n_refs, a.n_mask_u32) == (b.n_reads, b.n_pairs, b.n_pieces, b.n_refs, b.n_mask_u32)
+    assert a.pieces.tobytes() == b.pieces.tobytes()
+    assert a.masks.tobytes() == b.masks.tobytes()
+    assert a.pair_off.tobytes() == b.pair_off.tobytes()
+    assert a.pair_ref.tobytes() == b.pair_ref.tobytes()
+
+
+def _samples(loc, n, pairs, seed, **kw):
+    rng = random.Random(seed)
+    return [synth.simulate_sam_fast(loc, synth.pick_sample(loc, rng.randrange(1 << 30)), pairs + 37 * t, err_rate=kw.get("err_rate", 0.004),
+                                    seed=rng.randrange(1 << 30)) for t in range(n)]
+
+
+def test_many_tasks_in_one_emulated_pass_equal_the_merge_of_the_hosts_batches(tmp_path):
+    """Samples of one locus with DIFFERENT alleles (so the same read text decodes differently under each sample's own pileup), an
+    empty task among them, the same sample twice (equal records in two tasks stay two keys); texts in memory, SAM files and BAMs."""
+    from hisatgenotype_amd import bamio
+    loc = synth.make_hla_like_locus(n_alleles=120, n_vars=400, seed=5, deletion_frac=0.15)
+    pl = hl.PackedLocus.from_synth(loc)
+    sams = _samples(loc, 5, 700, 11, err_rate=0.01)
+    sams = sams[:2] + [""] + sams[2:] + [sams[0]]
+    want, wt, _ = host_merged(pl, sams)
+    got, dec, gt = many_emulated(pl, sams=sams)
+    assert dec == 0, dec
+    same_merged(want, got)
+    assert gt == wt, (gt, wt)
+    p_sam, p_bam = [], []
+    for t, s in enumerate(sams):
+        p_sam.append(str(tmp_path / ("t%d.sam" % t)))
+        open(p_sam[-1], "w").write(s)
+        p_bam.append(str(tmp_path / ("t%d.bam" % t)))
+        bamio.write_bam_native(p_bam[-1], s.encode(), [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=(t % 2 == 1))
+    for paths in (p_sam, p_bam):
+        got, dec, gt = many_emulated(pl, paths=paths, regions=[loc.ref_allele] * len(paths))
+        assert dec == 0, dec
+        same_merged(want, got)
+        assert gt == wt
+    # SAM text and BAM records in one batch: declined (the host goes task by task)
+    got, dec, _ = many_emulated(pl, paths=[p_sam[0], p_bam[1]])
+    assert got is None and dec == 1
+
+
+def test_many_task_emulation_on_fixtures_and_fuzz_cases():
+    """Every golden fixture three times over as the tasks of one batch, and fuzz loci with several samples each."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_parity
+    for name in gu.ALL + gu.LEAN:
+        if name == "codis_d18s51":
+            continue
+        fx = gu.load(name)
+        o = fx["options"]
+        pl = hl.PackedLocus.from_synth(fx["_locus"])
+        kw = dict(num_editdist=o["num_editdist"], error_correction=o["error_correction"], allow_discordant=o["allow_discordant"],
+                  simulation=o["simulation"])
+        lines = fx["sam"].splitlines(keepends=True)
+        half = "".join(lines[: len(lines) // 2])
+        # (a read's records stay together: cut at a read-id boundary)
+        cut = len(lines) // 2
+        while 0 < cut < len(lines) and lines[cut].split("\t")[0] == lines[cut - 1].split("\t")[0]:
+            cut += 1
+        half = "".join(lines[:cut])
+        sams = [fx["sam"], half, fx["sam"]]
+        want, wt, _ = host_merged(pl, sams, **kw)
+        got, dec, gt = many_emulated(pl, sams=sams, **kw)
+        assert dec == 0, (name, dec)
+        same_merged(want, got)
+        assert gt == wt, name
+    n_dev = n_all = 0
+    for k in range(int(os.environ.get("HGX_FRONT_FUZZ", "120")) // 3):
+        rng = random.Random(880000 + k)
+        loc, sam0, single = fuzz_parity.make_case(880000, k, 1 + k % 3)
+        sams = [sam0]
+        for j in range(1 + k % 3):
+            _, s, _ = fuzz_parity.make_case(880000, k, 1 + (k + j + 1) % 3)
+            sams.append(s)
+        pl = hl.PackedLocus.from_synth(loc)
+        try:
+            want, wt, _ = host_merged(pl, sams, allow_discordant=single)
+        except capi.HgxError:
+            continue
+        got, dec, gt = many_emulated(pl, sams=sams, allow_discordant=single)
+        n_all += 1
+        if dec:
+            continue
+        n_dev += 1
+        same_merged(want, got)
+        assert gt == wt
+        pl.close()
+    print("many-task emulation took %d of %d fuzz batches" % (n_dev, n_all))
+    assert n_dev >= 0.7 * n_all, (n_dev, n_all)
