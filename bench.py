@@ -879,8 +879,9 @@ def run_panel64(args, rank, local_rank, world, dist):
                 routes = None
                 if device:
                     def one(k):
+                        capi.set_stream_slot(("panel files", k))              # a stream per locus: its uploads and kernels beside the others'
                         m = engine.ManyBatch.from_files(packed[k], paths_of[k], regions=[packed[k].ref_allele] * len(paths_of[k]),
-                                                        n_threads=max(2, nthr // 3))
+                                                        n_threads=max(2, nthr // 3), stream=capi.get_stream(1))
                         return m, engine.front_last(), engine.front_last_bytes()
                     with ThreadPoolExecutor(len(ks)) as ex:
                         got = list(ex.map(one, ks))

@@ -21,11 +21,14 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <vector>
+
+#include <sys/stat.h>
 
 #include "hgx_common.hpp"
 #include "hgx_internal.hpp"
@@ -158,15 +161,27 @@ struct FeCtl {
 __device__ __forceinline__ void fe_decline(FeCtl *ctl, int code) { atomicCAS(&ctl->decline, 0, code); }
 
 // ---- kernels ----------------------------------------------------------------------------------------------------------------------
+// grid (blocks per task, tiles of the backbone, tasks).  The keys are in stream order of their first records, so a task's keys
+// are one run of the table: its ends are found by bisection on FeKey::task (one task: the whole table).
 __global__ void __launch_bounds__(1024) k_fe_pileup(const FeKey *__restrict__ keys, uint32_t n_keys, const char *__restrict__ text, int n_ref,
                                                     int tile, uint32_t *__restrict__ counts, FeCtl *ctl) {
     extern __shared__ uint32_t hist[];
     const int t0 = blockIdx.y * tile, t1 = min(n_ref, t0 + tile);
     const int cells = (t1 - t0) * 6;
     for (int c = threadIdx.x; c < cells; c += blockDim.x) hist[c] = 0;
+    uint32_t k_lo = 0, k_hi = n_keys;
+    const uint32_t task = blockIdx.z;
+    if (gridDim.z > 1) {
+        uint32_t lo = 0, hi = n_keys;                      // first key with task >= `task`
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid].task < task) lo = mid + 1; else hi = mid; }
+        k_lo = lo;
+        hi = n_keys;                                       // first key with task > `task`
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid].task <= task) lo = mid + 1; else hi = mid; }
+        k_hi = lo;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    for (uint32_t k = blockIdx.x * wpb + wave; k < n_keys; k += gridDim.x * wpb) {
+    for (uint32_t k = k_lo + blockIdx.x * wpb + wave; k < k_hi; k += gridDim.x * wpb) {
         const FeKey K = keys[k];
         if (K.n_pile == 0 || K.pos >= t1) continue;
         const int lo = t0 * 6;
@@ -177,24 +192,11 @@ __global__ void __launch_bounds__(1024) k_fe_pileup(const FeKey *__restrict__ ke
         if (rc < 0 && lane == 0) fe_decline(ctl, rc);
     }
     __syncthreads();
+    uint32_t *mine = counts + (size_t)task * n_ref * 6;
     for (int c = threadIdx.x; c < cells; c += blockDim.x) {
         const uint32_t v = hist[c];
-        if (v) atomicAdd(&counts[(size_t)t0 * 6 + c], v);
+        if (v) atomicAdd(&mine[(size_t)t0 * 6 + c], v);
     }
-}
-
-// the samples of a many-task batch have a pileup each (counts[task][n_ref][6]): one wavefront per key, global atomics (a
-// task's keys are few thousand: no counter is hot)
-__global__ void __launch_bounds__(256) k_fe_pileup_many(const FeKey *__restrict__ keys, uint32_t n_keys, const char *__restrict__ text, int n_ref,
-                                                        uint32_t *__restrict__ counts, FeCtl *ctl) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t k = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (k >= n_keys) return;
-    const FeKey K = keys[k];
-    if (K.n_pile == 0) return;
-    uint32_t *mine = counts + (size_t)K.task * n_ref * 6;
-    const int rc = fe_pileup_key(K, text, n_ref, lane, 64, [&](uint32_t cell, uint32_t w) { atomicAdd(&mine[cell], w); });
-    if (rc < 0 && lane == 0) fe_decline(ctl, rc);
 }
 
 __global__ void k_fe_nt_set(const uint32_t *__restrict__ counts, int n_ref, uint8_t *__restrict__ nt_set) {
@@ -361,6 +363,7 @@ __global__ void __launch_bounds__(256) k_fe_pair_count(const uint32_t *__restric
                                                        uint32_t *__restrict__ task_pairs, unsigned long long *__restrict__ task_refs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long c = 0, reads = 0, gene = 0;
+    uint32_t my_task = 0xffffffffu;
     if (i < n_rec && FE_REC_HEAD(rec_info[i])) {
         uint32_t uni[FE_MAX_PAIR_HT];
         int n_uni = 0;
@@ -373,11 +376,22 @@ __global__ void __launch_bounds__(256) k_fe_pair_count(const uint32_t *__restric
             c = (1ull << 40) | (n_exon + (unsigned long long)n_uni);
             reads = (unsigned long long)ns;
             gene = (unsigned long long)n_uni;
-            if (task_reads) {                               // a many-task batch: the totals of the pair's sample
-                const uint32_t t = slot_task[FE_REC_SLOT(rec_info[i])];
-                atomicAdd(&task_reads[t], (uint32_t)ns);
-                atomicAdd(&task_pairs[t], 1u);
-                atomicAdd(&task_refs[t], n_exon + (unsigned long long)n_uni);
+            if (task_reads) my_task = slot_task[FE_REC_SLOT(rec_info[i])];
+        }
+    }
+    if (task_reads) {
+        // a many-task batch: the totals of the pair's sample.  The records come task after task, so a wavefront nearly always
+        // holds one task: one set of atomics per wavefront then (per lane, the 64 samples' counters are a hot spot)
+        const unsigned long long have = __ballot(my_task != 0xffffffffu);
+        if (have) {
+            const uint32_t t0 = (uint32_t)__shfl((int)my_task, __ffsll((long long)have) - 1);
+            if (__all(my_task == 0xffffffffu || my_task == t0)) {
+                const unsigned long long r = wave_sum_u64(reads), p = wave_sum_u64(c >> 40), f = wave_sum_u64(c & ((1ull << 40) - 1));
+                if ((threadIdx.x & 63) == 0) { atomicAdd(&task_reads[t0], (uint32_t)r); atomicAdd(&task_pairs[t0], (uint32_t)p); atomicAdd(&task_refs[t0], f); }
+            } else if (my_task != 0xffffffffu) {
+                atomicAdd(&task_reads[my_task], (uint32_t)reads);
+                atomicAdd(&task_pairs[my_task], 1u);
+                atomicAdd(&task_refs[my_task], c & ((1ull << 40) - 1));
             }
         }
     }
@@ -565,15 +579,15 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     d->d_nt_set = (uint8_t *)hgx_pool_alloc(std::max<size_t>((size_t)n_tasks * n_ref, 16));
     if (!d->d_counts || !d->d_nt_set) { hgx_set_error("device allocation of the pileup tables failed"); return HGX_ENOMEM; }
     HIPCHK(hipMemsetAsync(d->d_counts, 0, n_cells * 4, st));
-    if (n_keys && n_ref > 0 && n_tasks > 1) {
-        k_fe_pileup_many<<<nblk((long)n_keys * 64, 256), 256, 0, st>>>(keys, n_keys, text, n_ref, d->d_counts, ctl);
-    } else if (n_keys && n_ref > 0) {
+    if (n_keys && n_ref > 0) {
         const int tile = std::min(n_ref, 6000);                       // 6 counters x 4 bytes x 6000 positions = 144 KB of LDS
         const size_t lds = (size_t)tile * 6 * 4;
         HGX_ONCE_PER_DEVICE(HIPCHK(hipFuncSetAttribute((const void *)k_fe_pileup, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)));
         const unsigned n_tiles = (unsigned)((n_ref + tile - 1) / tile);
-        const unsigned nb = std::max(1u, std::min(256u, (n_keys + 63) / 64));
-        k_fe_pileup<<<dim3(nb, n_tiles), 1024, lds, st>>>(keys, n_keys, text, n_ref, tile, d->d_counts, ctl);
+        // one task: up to 256 blocks share the keys; many: a task's few thousand keys go to 1-4 blocks (256 CUs / tasks)
+        const unsigned per_task = (unsigned)std::max(1, std::min(4, 256 / n_tasks));
+        const unsigned nb = n_tasks > 1 ? per_task : std::max(1u, std::min(256u, (n_keys + 63) / 64));
+        k_fe_pileup<<<dim3(nb, n_tiles, (unsigned)n_tasks), 1024, lds, st>>>(keys, n_keys, text, n_ref, tile, d->d_counts, ctl);
     }
     if (o.pileup_exchange && n_ref > 0) {                               // intra-locus read sharding: the sum over all shards (8e)
         std::vector<uint32_t> h((size_t)n_ref * 6);
@@ -997,28 +1011,76 @@ int hgx_front_many_dev(hgx_dbatch **out, hgx_front_totals *tot, const hgx_locus 
     if (n_tasks < 1 || n_tasks > 65535) return decline(HGX_FE_DECLINE_SIZE);
     hgx_many_streams ms;
     const hgx_front_alloc mem{pinned_alloc, pinned_release};
-    int rc = hgx_many_read(ms, paths, regions, sams, sam_bytes, n_tasks, opts->n_threads, &mem);
-    if (rc) return rc;
-    if (ms.mixed) return decline(HGX_FE_DECLINE_OPTS);                   // SAM text and BAM records in one batch: per task on the host
-    const size_t total = ms.base[(size_t)n_tasks], n_lines = ms.line_base[(size_t)n_tasks];
-    if (!hgx_test_switch("front_device") && n_lines < 20000) return decline(HGX_FE_DECLINE_SMALL);
-    if (total >= (1ull << 32) - 64 || n_lines >= (1ull << 30)) return decline(HGX_FE_DECLINE_SIZE);
+    const bool prof = getenv("HGX_PARSE_PROFILE") != nullptr;
+    double t_prev = now_ms();
+    auto lap = [&](const char *what) {
+        if (!prof) return;
+        const double t = now_ms();
+        fprintf(stderr, "[hgx_front_many] %-28s %8.2f ms\n", what, t - t_prev);
+        t_prev = t;
+    };
+    // The device text buffer is reserved before the sizes are known (files: 16x their bytes on disk -- BGZF rarely inflates that
+    // far -- at most what 32-bit offsets hold), and every reader thread takes the next free range for its task and starts the
+    // upload the moment its bytes are complete: the transfers run under the other tasks' inflate / walk / sort.  A task that no
+    // longer fits only takes its range: everything is sent again, to a buffer of the right size, after the reads.
+    size_t cap = 0;
+    for (int t = 0; t < n_tasks; ++t) {
+        if (paths) {
+            struct stat sb;
+            cap += (paths[t] && stat(paths[t], &sb) == 0 ? (size_t)sb.st_size * 16 : 0) + (64u << 10);
+        } else cap += (sam_bytes[t] + 63) & ~(size_t)63;
+    }
+    cap = std::min<size_t>(cap, (1ull << 32) - 128);
     DevBuf b_text;
     struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};       // (uploads read the readers' buffers)
-    ALLOC(b_text, total + 64);
-    for (int t = 0; t < n_tasks; ++t) {
-        if (!ms.raw_bytes[t]) continue;
-        HIPCHK(hipMemcpyAsync((char *)b_text.p + ms.base[t], ms.raw[t], ms.raw_bytes[t], hipMemcpyHostToDevice, st));
-        g_last_bytes += (long long)ms.raw_bytes[t];
+    ALLOC(b_text, cap + 64);
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    std::atomic<size_t> cursor{0};
+    std::atomic<long long> sent{0};
+    std::atomic<bool> late{false};
+    auto on_task = [&](int t) -> int {
+        const size_t n = (ms.raw_bytes[t] + 63) & ~(size_t)63;
+        const size_t off = cursor.fetch_add(n);
+        ms.base[t] = off;
+        if (off + n > cap) { late = true; return HGX_OK; }
+        if (!ms.raw_bytes[t]) return HGX_OK;
+        HIPCHK(hipSetDevice(dev));                                         // (a reader thread of the host pool)
+        HIPCHK(hipMemcpyAsync((char *)b_text.p + off, ms.raw[t], ms.raw_bytes[t], hipMemcpyHostToDevice, st));
+        sent += (long long)ms.raw_bytes[t];
+        return HGX_OK;
+    };
+    int rc = hgx_many_read(ms, paths, regions, sams, sam_bytes, n_tasks, opts->n_threads, &mem, on_task);
+    if (rc) return rc;
+    lap("read (+ uploads issued)");
+    const size_t total = cursor.load(), n_lines = ms.line_base[(size_t)n_tasks];
+    ms.base[(size_t)n_tasks] = total;
+    if (ms.mixed) return decline(HGX_FE_DECLINE_OPTS);                   // SAM text and BAM records in one batch: per task on the host
+    if (!hgx_test_switch("front_device") && n_lines < 20000) return decline(HGX_FE_DECLINE_SMALL);
+    if (total >= (1ull << 32) - 64 || n_lines >= (1ull << 30)) return decline(HGX_FE_DECLINE_SIZE);
+    if (late.load() || hgx_test_switch("front_late_upload")) {
+        HIPCHK(hipStreamSynchronize(st));
+        hgx_pool_free(b_text.p);
+        b_text.p = nullptr;
+        ALLOC(b_text, total + 64);
+        for (int t = 0; t < n_tasks; ++t) {
+            if (!ms.raw_bytes[t]) continue;
+            HIPCHK(hipMemcpyAsync((char *)b_text.p + ms.base[t], ms.raw[t], ms.raw_bytes[t], hipMemcpyHostToDevice, st));
+            sent += (long long)ms.raw_bytes[t];
+        }
     }
+    g_last_bytes += sent.load();
     LineRef *h_lines = (LineRef *)pinned_alloc(std::max<size_t>(n_lines, 1) * sizeof(LineRef));
     if (!h_lines) { hgx_set_error("pinned allocation of the line table failed"); return HGX_ENOMEM; }
     struct Unpin { void *p; ~Unpin() { pinned_release(p); } } unpin{h_lines};
     hgx_many_lines(ms, h_lines, opts->n_threads);
+    lap("line table");
+    if (prof) { (void)hipStreamSynchronize(st); lap("uploads done"); }
     hgx_dbatch *made = nullptr;
     int dec = 0;
     rc = records_run(*const_cast<hgx_locus *>(loc), b_text.as<char>(), total, h_lines, n_lines, ms.binary, n_tasks, *opts, st, &made, tot, &dec);
     (void)hipStreamSynchronize(st);
+    lap("device stages");
     if (rc) { hgx_dbatch_destroy(made); return rc; }
     if (dec || !made) { hgx_dbatch_destroy(made); return decline(dec ? dec : HGX_FE_DECLINE_SIZE); }
     g_last_route = 2; g_last_device = 1;

@@ -274,8 +274,11 @@ struct hgx_many_streams {
 };
 // reads (paths[t], regions[t] or regions NULL) or walks (sams[t], sam_bytes[t]) every task's stream, tasks side by side on the
 // host's threads; big reader blocks come from `mem` (pinned staging) when given
+// when given; on_task(t), when given, runs on the task's reader thread as soon as raw[t] / raw_bytes[t] are known and sets
+// base[t] itself (the device front end reserves a range of its text buffer there and starts the upload); otherwise the tasks'
+// bytes are laid out one after the other
 int hgx_many_read(hgx_many_streams &ms, const char *const *paths, const char *const *regions, const char *const *sams, const size_t *sam_bytes,
-                  int n_tasks, int n_threads, const hgx_front_alloc *mem);
+                  int n_tasks, int n_threads, const hgx_front_alloc *mem, const std::function<int(int task)> &on_task = nullptr);
 void hgx_many_lines(const hgx_many_streams &ms, FeLine *dst, int n_threads);     // the concatenated line table: (offset, length, task)
 struct hgx_dbatch;
 // the device pass over them (hgx_front.hip): *declined != 0 -> nothing made, the caller goes task by task through the host stages

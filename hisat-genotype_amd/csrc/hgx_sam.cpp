@@ -1827,7 +1827,7 @@ int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *Lc, const ch
 
 // ---- many tasks of one locus, read side by side (hgx_internal.hpp: hgx_many_streams) --------------------------------------------
 int hgx_many_read(hgx_many_streams &ms, const char *const *paths, const char *const *regions, const char *const *sams, const size_t *sam_bytes,
-                  int n_tasks, int n_threads, const hgx_front_alloc *mem) {
+                  int n_tasks, int n_threads, const hgx_front_alloc *mem, const std::function<int(int task)> &on_task) {
     HARGCHK(n_tasks >= 0 && (n_tasks == 0 || paths || (sams && sam_bytes)));
     ms.n_tasks = n_tasks;
     ms.al.reset(new hgx_align_lines[(size_t)std::max(n_tasks, 1)]);
@@ -1865,6 +1865,10 @@ int hgx_many_read(hgx_many_streams &ms, const char *const *paths, const char *co
                 ms.raw[t] = base;
                 ms.raw_bytes[t] = sam_bytes[t];
             }
+            if (on_task) {
+                rcs[t] = on_task((int)t);
+                if (rcs[t]) errs[t] = hgx_last_error();
+            }
         } catch (const std::exception &e) {
             rcs[t] = HGX_ENOMEM;
             errs[t] = e.what();
@@ -1879,7 +1883,7 @@ int hgx_many_read(hgx_many_streams &ms, const char *const *paths, const char *co
             if (!any) ms.binary = ms.al[t].binary;
             any = true;
         }
-        ms.base[t + 1] = (ms.base[t] + ms.raw_bytes[t] + 63) & ~(size_t)63;
+        if (!on_task) ms.base[t + 1] = (ms.base[t] + ms.raw_bytes[t] + 63) & ~(size_t)63;
         ms.line_base[t + 1] = ms.line_base[t] + ms.al[t].lines.size();
     }
     return HGX_OK;

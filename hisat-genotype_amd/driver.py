@@ -170,19 +170,31 @@ def run_panel(tasks, index, base_fname, rank=0, world=1, weights=None, ix_dir=No
         popts = {k: v for k, v in typing_opts.items() if k in parse_keys}
         for gene, group in by_gene.items():
             pl = packed[gene]
-            batches = []
-            for _, _, sam in group:
-                if isinstance(sam, (bytes, bytearray)) or "\t" in sam:
-                    batches.append(pl.parse_sam(sam, **popts))
+            is_text = [isinstance(sam, (bytes, bytearray)) or "\t" in sam for _, _, sam in group]
+            if all(is_text) or not any(is_text):
+                # the samples of the locus through ONE pass of the device front end (hgx_many_create_sams / _files; where it
+                # declines, the library runs the host front end per task and merges: the same batch either way)
+                if all(is_text):
+                    mb = engine.ManyBatch.from_sams(pl, [sam for _, _, sam in group], **popts)
                 else:
-                    batches.append(pl.parse_alignment_file(sam, typing_opts.get("regions", [pl.ref_allele]), **popts))
-            mb = engine.ManyBatch(pl, batches)
+                    regions = typing_opts.get("regions", [pl.ref_allele])
+                    regions = regions if isinstance(regions, str) else "\n".join(regions)
+                    mb = engine.ManyBatch.from_files(pl, [sam for _, _, sam in group], regions=[regions] * len(group), **popts)
+            else:
+                batches = []
+                for (_, _, sam), text in zip(group, is_text):
+                    if text:
+                        batches.append(pl.parse_sam(sam, **popts))
+                    else:
+                        batches.append(pl.parse_alignment_file(sam, typing_opts.get("regions", [pl.ref_allele]), **popts))
+                mb = engine.ManyBatch(pl, batches)
             try:
                 res = type_many(pl, mb, remove_low=typing_opts.get("remove_low_abundance_alleles", True), em_fast=em_fast)
+                pieces, refs = mb.task_pieces, mb.task_refs
             finally:
                 mb.close()
-            for (sample_id, _, _), r, b in zip(group, res, batches):
-                r.n_pieces, r.n_refs = b.n_pieces, b.n_refs
+            for t, ((sample_id, _, _), r) in enumerate(zip(group, res)):
+                r.n_pieces, r.n_refs = pieces[t], refs[t]
                 out[(sample_id, gene)] = r
         return out
     if inflight <= 1 or len(mine) <= 1:

@@ -74,6 +74,14 @@ def test_many_samples_in_one_device_pass(tmp_path):
             dev = engine.ManyBatch.from_files(pl, paths, regions=[loc.ref_allele] * len(paths))
             assert engine.front_last() == (2, 0)
         same_many(dev, host)
+    with engine.test_switches(front_device=1, front_late_upload=1):                   # the buffer estimate was too small: sent again after the reads
+        dev = engine.ManyBatch.from_files(pl, p_bam, regions=[loc.ref_allele] * len(p_bam))
+        assert engine.front_last() == (2, 0)
+    same_many(dev, host)
+    with engine.test_switches(front_device=1):                                        # on a stream of the caller's
+        dev = engine.ManyBatch.from_files(pl, p_bam, regions=[loc.ref_allele] * len(p_bam), stream=capi.get_stream(1))
+        assert engine.front_last() == (2, 0)
+    same_many(dev, host)
     # where the device front end declines, the host front end runs task by task: the same batch again
     for switches, want in ((dict(front_host=1), (0, -1)), (dict(), (0, 6))):          # (6: fewer records than the size gate)
         with engine.test_switches(**switches):
