@@ -91,7 +91,7 @@ LAB_DIR = os.path.join(CSRC, "lab")
 LAB_LIB = os.path.join(LAB_DIR, "libhgx_lab.so")
 
 
-LAB_UNITS = ["hgx_em.hip", "hgx_device.hip", "hgx_front_host.cpp"]      # the units with #ifdef HGX_LAB code
+LAB_UNITS = ["hgx_em.hip", "hgx_device.hip", "hgx_dedup.hip", "hgx_type.hip", "hgx_emx.hip", "hgx_front_host.cpp"]      # the units with #ifdef HGX_LAB code
 
 
 def build_lab(force=False, verbose=True):

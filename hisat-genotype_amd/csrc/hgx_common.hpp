@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstring>
 #include <cstdio>
 #include <mutex>
 
@@ -11,6 +12,25 @@
 extern "C" void hgx_set_error(const char *fmt, ...);
 // test hook (hgx.h: hgx_test_switch_set): value of a path-forcing switch, NULL when it is not set (one relaxed load then)
 extern "C" const char *hgx_test_switch(const char *name);
+// a switch whose value is a comma-separated list ("em_skip" = "emx,tail"): is `token` in it?
+static inline bool hgx_switch_has(const char *name, const char *token) {
+    const char *v = hgx_test_switch(name);
+    if (!v) return false;
+    const size_t n = strlen(token);
+    for (const char *p = v;;) {
+        const char *e = strchr(p, ',');
+        const size_t len = e ? (size_t)(e - p) : strlen(p);
+        if (len == n && memcmp(p, token, n) == 0) return true;
+        if (!e) return false;
+        p = e + 1;
+    }
+}
+// switches of comparison / measurement forms that only the lab library (-DHGX_LAB) carries
+#ifdef HGX_LAB
+#define HGX_LAB_SWITCH(name) hgx_test_switch(name)
+#else
+#define HGX_LAB_SWITCH(name) ((const char *)nullptr)
+#endif
 
 #define HIPCHK(expr)                                                                   \
     do {                                                                               \

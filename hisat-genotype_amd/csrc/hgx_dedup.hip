@@ -752,131 +752,16 @@ extern "C" int hgx_dedup_classes(hgx_classes **out, const uint64_t *rows, const 
                       hgx_classes_destroy);
 }
 
-// ------------------------------------------------------------------------------------------------
-// hgx_pair_classes_dedup: per-pair class rows of ONE level and their dedup in one go, without a row per pair in memory.
-// k_pair_classes_fused (hgx_device.hip) claims / verifies every row against its class' representative while the row is in
-// registers and leaves: keys[] (the table), rep[slot] (pair whose row was stored), slot_of[pair].  Here: counts and first
-// pairs per slot (k_slot_count: LDS pre-merge, as k_ht_insert does for hashes), class ids in first-seen order (mark + scan),
-// class rows gathered from the representatives.  Same class set as hgx_pair_classes + hgx_dedup_classes.  A key collision
-// (row != its slot's representative) is not resolved here: the caller falls back to that pair of calls.
-// ------------------------------------------------------------------------------------------------
-template <int BS>
-__global__ __launch_bounds__(BS) void k_slot_count(const uint32_t *__restrict__ slot_of, long n, uint32_t *__restrict__ first,
-                                                   unsigned long long *__restrict__ cnt) {
-    constexpr int SLOTS = 2 * BS;
-    __shared__ uint32_t lslot[SLOTS], lmin[SLOTS], lcnt[SLOTS];
-    const int tid = threadIdx.x;
-    for (int s = tid; s < SLOTS; s += BS) { lslot[s] = HT_NONE; lcnt[s] = 0; lmin[s] = HT_NONE; }
-    __syncthreads();
-    const long i = (long)blockIdx.x * BS + tid;
-    const uint32_t g = i < n ? slot_of[i] : HT_NONE;
-    if (g != HT_NONE) {
-        uint32_t ls = (g * 2654435761u >> 7) & (SLOTS - 1);
-        for (;;) {
-            const uint32_t old = atomicCAS(&lslot[ls], HT_NONE, g);
-            if (old == HT_NONE || old == g) break;
-            ls = (ls + 1) & (SLOTS - 1);
-        }
-        atomicMin(&lmin[ls], (uint32_t)i);
-        atomicAdd(&lcnt[ls], 1u);
-    }
-    __syncthreads();
-    for (int s = tid; s < SLOTS; s += BS)
-        if (lslot[s] != HT_NONE) {
-            atomicMin(&first[lslot[s]], lmin[s]);
-            atomicAdd(&cnt[lslot[s]], (unsigned long long)lcnt[s]);
-        }
-}
-__global__ void k_fused_init(unsigned long long *__restrict__ keys, uint32_t *__restrict__ first, unsigned long long *__restrict__ cnt,
-                             uint32_t *__restrict__ rep, long T, uint32_t *__restrict__ flag, long n, uint32_t *__restrict__ meta) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < T) { keys[i] = HGX_EMPTY_KEY; first[i] = HT_NONE; cnt[i] = 0; rep[i] = HT_NONE; }
-    if (i < n) flag[i] = 0;
-    if (i < 4) meta[i] = 0;
-}
-// class id -> first pair, count, and the pair whose row represents the class
-__global__ void k_fused_finalize(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ first,
-                                 const unsigned long long *__restrict__ cnt, const uint32_t *__restrict__ rep, long T,
-                                 const uint32_t *__restrict__ rank, int64_t *__restrict__ out_first, int64_t *__restrict__ out_count,
-                                 int64_t *__restrict__ out_rep) {
-    const long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= T || keys[s] == HGX_EMPTY_KEY) return;
-    const uint32_t c = rank[first[s]];
-    out_first[c] = (int64_t)first[s];
-    out_count[c] = (int64_t)cnt[s];
-    out_rep[c] = (int64_t)rep[s];
-}
-
-static int pair_classes_dedup_impl(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
-                                   const uint32_t *refs, int32_t n_pairs, int32_t level, uint64_t *rows_scratch, void *stream,
-                                   void *ev_begin, void *ev_end) {
-    ARGCHK(out && ix && n_pairs >= 0 && (level == 0 || level == 1) && rows_scratch);
-    hipStream_t st = (hipStream_t)stream;
-    const int w64 = ix->w64;
-    hgx_classes *cl = new_classes(ix->a_pad);
-    *out = cl;
-    if (n_pairs == 0) return HGX_OK;
-    const long n = n_pairs;
-    long T = 1024;
-    while (T < 2 * n) T <<= 1;
-    DevBuf b_keys, b_first, b_cnt, b_rep, b_slot, b_flag, b_rank, b_tmp, b_meta, b_orep;
-    ALLOC(b_keys, (size_t)T * 8); ALLOC(b_first, (size_t)T * 4); ALLOC(b_cnt, (size_t)T * 8); ALLOC(b_rep, (size_t)T * 4);
-    ALLOC(b_slot, (size_t)n * 4); ALLOC(b_flag, (size_t)n * 4); ALLOC(b_rank, (size_t)n * 4); ALLOC(b_meta, 16);
-    ALLOC(b_tmp, scan_scratch_bytes(n));
-    hipLaunchKernelGGL(k_fused_init, dim3(nblk(std::max(T, n), 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(),
-                       b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), b_rep.as<uint32_t>(), T, b_flag.as<uint32_t>(), n,
-                       b_meta.as<uint32_t>());
-    if (ev_begin) HIPCHK(hipEventRecord((hipEvent_t)ev_begin, st));
-    { int rc_ = hgx_pair_classes_fused_launch(ix, compat, pair_off, refs, n_pairs, level, b_keys.as<unsigned long long>(), (uint32_t)(T - 1),
-                                              b_rep.as<uint32_t>(), b_slot.as<uint32_t>(), b_meta.as<int>(), rows_scratch, st); if (rc_) return rc_; }
-    if (ev_end) HIPCHK(hipEventRecord((hipEvent_t)ev_end, st));
-    hipLaunchKernelGGL(k_slot_count<1024>, dim3(nblk(n, 1024)), dim3(1024), 0, st, b_slot.as<uint32_t>(), n, b_first.as<uint32_t>(),
-                       b_cnt.as<unsigned long long>());
-    hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,
-                       b_flag.as<uint32_t>());
-    { int rc_ = scan_u32(b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n, b_tmp.p, b_meta.as<uint32_t>() + 1, st); if (rc_) return rc_; }
-    uint32_t meta[4] = {0, 0, 0, 0};           // {some row differed from its representative, number of classes, -, -}
-    { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
-    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-    HIPCHK(hipGetLastError());
-    if (meta[0]) {
-        hgx_set_error("64-bit class key shared by different rows (fused form): use the unfused path");
-        return HGX_ECOLLISION;
-    }
-    const int n_classes = (int)meta[1];
-    if (n_classes == 0) return HGX_OK;
-    cl->d_bits = (decltype(cl->d_bits))hgx_pool_alloc((size_t)n_classes * w64 * 8);
-    cl->d_count = (decltype(cl->d_count))hgx_pool_alloc((size_t)n_classes * 8);
-    cl->d_first_row = (decltype(cl->d_first_row))hgx_pool_alloc((size_t)n_classes * 8);
-    ALLOC(b_orep, (size_t)n_classes * 8);
-    if (!cl->d_bits || !cl->d_count || !cl->d_first_row) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
-    hipLaunchKernelGGL(k_fused_finalize, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(),
-                       b_cnt.as<unsigned long long>(), b_rep.as<uint32_t>(), T, b_rank.as<uint32_t>(), cl->d_first_row, cl->d_count,
-                       b_orep.as<int64_t>());
-    hipLaunchKernelGGL(k_ht_gather, dim3(nblk(n_classes, 4)), dim3(256), 0, st, rows_scratch, w64, (const uint64_t *)nullptr,
-                       b_orep.as<int64_t>(), n_classes, cl->d_bits);
-    HIPCHK(hipGetLastError());
-    // the finalize / gather kernels are queued; the scratch they read stays with the class set (freed with it), so the caller's
-    // next launches follow without another host sync
-    cl->made_on = st;
-    if (hipEventCreateWithFlags(&cl->ready, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(cl->ready, st);
-    DevBuf *keep[] = {&b_keys, &b_first, &b_cnt, &b_rep, &b_slot, &b_flag, &b_rank, &b_tmp, &b_meta, &b_orep};
-    for (int i = 0; i < 10; ++i) { cl->d_keep[i] = keep[i]->p; keep[i]->p = nullptr; }
-    cl->n_classes = n_classes;
-    return HGX_OK;
-}
-
-extern "C" int hgx_pair_classes_dedup(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off,
-                                      const uint32_t *refs, int32_t n_pairs, int32_t level, uint64_t *rows_scratch, void *stream) {
-    return hgx_pair_classes_dedup_ev(out, ix, compat, pair_off, refs, n_pairs, level, rows_scratch, stream, nullptr, nullptr);
-}
-// the same with events recorded around the fused launch itself (bench.py's per-kernel timing through hgx_type_opts)
-int hgx_pair_classes_dedup_ev(hgx_classes **out, const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off, const uint32_t *refs,
-                              int32_t n_pairs, int32_t level, uint64_t *rows_scratch, void *stream, void *ev_begin, void *ev_end) {
+#ifdef HGX_LAB
+#include "lab/hgx_fused_dedup_lab.inc"        // hgx_pair_classes_dedup: round 2's fused gene-level form (measured slower), lab build only
+#else
+extern "C" int hgx_pair_classes_dedup(hgx_classes **out, const hgx_index *, const uint64_t *, const int32_t *, const uint32_t *, int32_t, int32_t,
+                                      uint64_t *, void *) {
     if (out) *out = nullptr;
-    return fail_clean(pair_classes_dedup_impl(out, ix, compat, pair_off, refs, n_pairs, level, rows_scratch, stream, ev_begin, ev_end), out,
-                      (hipStream_t)stream, hgx_classes_destroy);
+    hgx_set_error("hgx_pair_classes_dedup is lab code (measured slower than hgx_pair_classes + hgx_dedup_classes): build libhgx_lab.so");
+    return HGX_EINVAL;
 }
+#endif
 
 extern "C" int hgx_classes_destroy(hgx_classes *c) {
     if (!c) return HGX_OK;

@@ -583,97 +583,11 @@ extern "C" int hgx_piece_compat(const hgx_index *ix, const hgx_piece *pieces, co
 // which leaves exactly {a : count[a] == max count} -- add_stat's class (core:1177-1190) -- without
 // ever materialising a count.
 // ------------------------------------------------------------------------------------------------
-// ---- fused dedup (gene level of the typing path): the class row never goes to memory unless it is the FIRST of its class --------
-// The wavefront that computed a row (it sits in registers) also claims the row's slot in the class hash table:
-//   * key found / CAS lost  -> the slot has a representative row: wait until its owner has published it, load it and compare
-//     it with the registers (the exact check that k_verify_ht did by re-reading 448 MB of rows);
-//   * CAS won               -> this row is the representative: store it (at its own pair index) and publish the index.
-// Cross-CU visibility follows MI355X_MICROARCH.md ("{8-B agent atomics both sides}"): the representative is stored with
-// 8-byte agent-scope stores, the storing wave waits for them (vmcnt(0)), THEN one lane publishes rep[slot]; a checker polls
-// rep[slot] with agent-scope loads and reads the row with agent-scope loads only.  Counts and first pairs are added up from
-// slot_of[] by k_slot_count afterwards (hot classes merge in LDS there; per-pair global atomics on a hot slot would serialise).
-// A row that differs from its slot's representative (a 64-bit key collision: never seen on real data) sets *bad and the
-// caller falls back to the unfused path, which resolves collisions.
-struct FusedArgs {
-    unsigned long long *keys;     // [T] class keys, HGX_EMPTY_KEY = free
-    uint32_t tmask;               // T - 1
-    uint32_t *rep;                // [T] pair index whose row represents the slot (0xFFFFFFFF until published)
-    uint32_t *slot_of;            // [n_pairs]
-    int *bad;
-    uint64_t *rows;               // [n_pairs][w64]: only representatives are written
-};
-
-// lane 0 finds or claims the slot of `key`; returns (slot, won) wave-uniform
-__device__ __forceinline__ uint32_t fused_find_slot(const FusedArgs &fa, uint64_t key, int lane, int &won) {
-    uint32_t slot = 0;
-    int w = 0;
-    if (lane == 0) {
-        uint32_t h = (uint32_t)key & fa.tmask;
-        for (;;) {
-            const unsigned long long k = fa.keys[h];            // plain (cached) load: a slot's key never changes once set, so a
-            if (k == key) break;                                 // stale EMPTY only costs the CAS below, which decides
-            if (k == HGX_EMPTY_KEY) {
-                const unsigned long long old = atomicCAS(&fa.keys[h], (unsigned long long)HGX_EMPTY_KEY, (unsigned long long)key);
-                if (old == HGX_EMPTY_KEY) { w = 1; break; }
-                if (old == key) break;
-            }
-            h = (h + 1) & fa.tmask;
-        }
-        slot = h;
-    }
-    won = __builtin_amdgcn_readfirstlane(w);
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-}
-__device__ __forceinline__ uint32_t fused_wait_rep(const FusedArgs &fa, uint32_t slot, int lane) {
-    // bounded: a representative that never shows up (a lost publish) becomes the caller's HGX_ECOLLISION fallback (*bad), never a
-    // hung queue; the winner published its own pair index, so comparing with row 0 is harmless once *bad is set
-    uint32_t r = 0;
-    if (lane == 0) {
-        unsigned spins = 0;
-        do {
-            r = __hip_atomic_load(&fa.rep[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            if (r != 0xFFFFFFFFu) break;
-            __builtin_amdgcn_s_sleep(2);
-        } while (++spins < (1u << 22));
-        if (r == 0xFFFFFFFFu) { atomicOr(fa.bad, 1); r = 0; }
-    }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
-}
-
-template <int KW>
-__device__ __forceinline__ void fused_claim(const uint64_t (&cand)[KW], int w64, uint64_t key, long pair, const FusedArgs &fa, int lane) {
-    if (key == HGX_EMPTY_KEY) {                       // an all-zero row: dropped by the dedup
-        if (lane == 0) fa.slot_of[pair] = 0xFFFFFFFFu;
-        return;
-    }
-    int won;
-    const uint32_t slot = fused_find_slot(fa, key, lane, won);
-    if (lane == 0) fa.slot_of[pair] = slot;
-    if (won) {
-#pragma unroll
-        for (int s = 0; s < KW; ++s) {
-            const int w = lane + 64 * s;
-            if (w < w64)
-                __hip_atomic_store((unsigned long long *)&fa.rows[(size_t)pair * w64 + w], (unsigned long long)cand[s], __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(&fa.rep[slot], (uint32_t)pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    const uint32_t r = fused_wait_rep(fa, slot, lane);
-    bool diff = false;
-#pragma unroll
-    for (int s = 0; s < KW; ++s) {
-        const int w = lane + 64 * s;
-        if (w < w64) {
-            const unsigned long long x = __hip_atomic_load((unsigned long long *)&fa.rows[(size_t)r * w64 + w], __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_AGENT);
-            diff = diff || x != (unsigned long long)cand[s];
-        }
-    }
-    if (__any(diff) && lane == 0) atomicOr(fa.bad, 1);
-}
+#ifdef HGX_LAB
+#include "lab/hgx_fused_lab.inc"        // round 2's fused gene-level form (FusedArgs, fused_claim): lab build only
+#else
+struct FusedArgs;                        // (the hooks below compile away)
+#endif
 
 // NP = number of counter planes: 2 when the pair has <= 3 refs (nearly every pair), 4 up to 15, 8 up to 255
 // arg-max set of the bit-sliced counters under the level mask, its row hash, and the stores
@@ -705,11 +619,13 @@ __device__ __forceinline__ void emit_class(const uint64_t (&plane)[NP][KW], int 
             nz = nz || cand[s] != 0;
         }
     }
+#ifdef HGX_LAB
     if (FUSE) {
         h = wave_sum_u64(h);
         fused_claim<KW>(cand, w64, finish_hash(h, __any(nz)), pair, *fa, lane);
         return;
     }
+#endif
     if (out_hash) {
         h = wave_sum_u64(h);
         const bool any_nz = __any(nz);
@@ -770,7 +686,9 @@ __device__ __noinline__ void class_for_level_wide(const uint64_t *__restrict__ c
                                                   uint64_t *__restrict__ out_row, uint64_t *__restrict__ out_hash, int lane,
                                                   const FusedArgs *fa = nullptr, long pair = 0) {
     constexpr int NP = 16;
+#ifdef HGX_LAB
     if (fa) out_row = fa->rows + (size_t)pair * w64;      // (fused: every such row is stored -- the path is rare -- and compared from memory)
+#endif
     const int kw = (w64 + 63) / 64;
     uint32_t gmax = 0;
     uint64_t h = 0;
@@ -806,13 +724,17 @@ __device__ __noinline__ void class_for_level_wide(const uint64_t *__restrict__ c
 #pragma unroll
                 for (int k = 0; k < NP; ++k) cand &= ((gmax >> k) & 1u) ? plane[k] : ~plane[k];
                 if (live) {
+#ifdef HGX_LAB
                     if (fa) __hip_atomic_store((unsigned long long *)&out_row[w], (unsigned long long)cand, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else if (out_row) out_row[w] = cand;
+                    else
+#endif
+                    if (out_row) out_row[w] = cand;
                     h += word_hash(cand, w);
                     nz = nz || cand != 0;
                 }
             }
         }
+#ifdef HGX_LAB
     if (fa) {
         h = wave_sum_u64(h);
         const uint64_t key = finish_hash(h, __any(nz));
@@ -830,6 +752,7 @@ __device__ __noinline__ void class_for_level_wide(const uint64_t *__restrict__ c
         if (__any(diff) && lane == 0) atomicOr(fa->bad, 1);
         return;
     }
+#endif
     if (out_hash) {
         h = wave_sum_u64(h);
         const bool any_nz = __any(nz);
@@ -966,56 +889,9 @@ __global__ __launch_bounds__(256) void k_pair_classes_x2(const uint64_t *__restr
     else two_classes<KW, 4>(compat, w64, ref_a, ref_b, todo_a, todo_b, mask, row_a, row_b, hash_a, hash_b, has_b, lane);
 }
 
-// The fused form of the single-level launch (see FusedArgs): every pair in order, no row / hash outputs.
-template <int KW>
-__global__ __launch_bounds__(256) void k_pair_classes_fused(const uint64_t *__restrict__ compat, int w64,
-                                                            const int32_t *__restrict__ pair_off, const uint32_t *__restrict__ refs,
-                                                            int n_pairs, uint32_t level, const uint64_t *__restrict__ mask, FusedArgs fa) {
-    const int lane = threadIdx.x & 63;
-    const long pair_a = (((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 2, pair_b = pair_a + 1;
-    if (pair_a >= n_pairs) return;
-    const bool has_b = pair_b < n_pairs;
-    const long pb = has_b ? pair_b : pair_a;
-    const int r0a = __builtin_amdgcn_readfirstlane(pair_off[pair_a]), r1a = __builtin_amdgcn_readfirstlane(pair_off[pair_a + 1]);
-    const int r0b = __builtin_amdgcn_readfirstlane(pair_off[pb]), r1b = __builtin_amdgcn_readfirstlane(pair_off[pb + 1]);
-    const int n_a = r1a - r0a, n_b = has_b ? r1b - r0b : 0;
-    if (max(n_a, n_b) > 15) {
-        if (n_a > 255) class_for_level_wide(compat, w64, refs, r0a, r1a, level, mask, nullptr, nullptr, lane, &fa, pair_a);
-        else class_for_level<KW, 8, true>(compat, w64, refs, r0a, r1a, level, mask, nullptr, nullptr, lane, &fa, pair_a);
-        if (has_b) {
-            if (n_b > 255) class_for_level_wide(compat, w64, refs, r0b, r1b, level, mask, nullptr, nullptr, lane, &fa, pair_b);
-            else class_for_level<KW, 8, true>(compat, w64, refs, r0b, r1b, level, mask, nullptr, nullptr, lane, &fa, pair_b);
-        }
-        return;
-    }
-    const uint32_t ref_a = lane < n_a ? refs[r0a + lane] : 0u, ref_b = lane < n_b ? refs[r0b + lane] : 0u;
-    const uint64_t todo_a = __ballot(lane < n_a && (ref_a >> 31) == level), todo_b = __ballot(lane < n_b && (ref_b >> 31) == level);
-    if (max(n_a, n_b) <= 3)
-        two_classes<KW, 2, true>(compat, w64, ref_a, ref_b, todo_a, todo_b, mask, nullptr, nullptr, nullptr, nullptr, has_b, lane, &fa, pair_a, pair_b);
-    else
-        two_classes<KW, 4, true>(compat, w64, ref_a, ref_b, todo_a, todo_b, mask, nullptr, nullptr, nullptr, nullptr, has_b, lane, &fa, pair_a, pair_b);
-}
-
-// launch of the fused form for one level (hgx_dedup.hip owns the table and what follows); false = not supported for this shape
-int hgx_pair_classes_fused_launch(const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off, const uint32_t *refs,
-                                  int32_t n_pairs, int32_t level, unsigned long long *keys, uint32_t tmask, uint32_t *rep,
-                                  uint32_t *slot_of, int *bad, uint64_t *rows, hipStream_t st) {
-    ARGCHK(ix && n_pairs > 0 && compat && pair_off && refs && keys && rep && slot_of && bad && rows);
-    const int kw = (ix->w64 + 63) / 64;
-    if (kw > 8) { hgx_set_error("more than 32768 alleles per locus are not supported (a_pad=%d)", ix->a_pad); return HGX_EINVAL; }
-    const long blocks2 = ((long)n_pairs + 7) / 8;
-    const uint64_t *mask = level ? ix->d_gene_mask : ix->d_exon_mask;
-    FusedArgs fa{keys, tmask, rep, slot_of, bad, rows};
-#define LAUNCH_F(KW_) hipLaunchKernelGGL((k_pair_classes_fused<KW_>), dim3((unsigned)blocks2), dim3(256), 0, st, compat, ix->w64, pair_off, refs, \
-                                         n_pairs, (uint32_t)level, mask, fa)
-    if (kw <= 1) LAUNCH_F(1);
-    else if (kw <= 2) LAUNCH_F(2);
-    else if (kw <= 4) LAUNCH_F(4);
-    else LAUNCH_F(8);
-#undef LAUNCH_F
-    HIPCHK(hipGetLastError());
-    return HGX_OK;
-}
+#ifdef HGX_LAB
+#include "lab/hgx_fused_kernel_lab.inc"        // k_pair_classes_fused + hgx_pair_classes_fused_launch: lab build only
+#endif
 
 // sel: see k_pair_classes (NULL = every pair in order)
 int hgx_pair_classes_sel(const hgx_index *ix, const uint64_t *compat, const int32_t *pair_off, const uint32_t *refs,
@@ -1027,7 +903,7 @@ int hgx_pair_classes_sel(const hgx_index *ix, const uint64_t *compat, const int3
     const long blocks = ((long)n_pairs + 3) / 4;
     const int kw = (ix->w64 + 63) / 64;
     const bool exon = eb || eh, gene = gb || gh;
-    if (exon != gene && kw <= 8 && !hgx_test_switch("pair_x1")) {       // one level: two pairs per wavefront
+    if (exon != gene && kw <= 8 && !HGX_LAB_SWITCH("pair_x1")) {       // one level: two pairs per wavefront
         const long blocks2 = ((long)n_pairs + 7) / 8;
         const uint32_t level = gene ? 1u : 0u;
         const uint64_t *mask = gene ? ix->d_gene_mask : ix->d_exon_mask;

@@ -46,7 +46,6 @@ enum {
 
 constexpr int BLOCK = 1024;
 constexpr int NWAVE = BLOCK / 64;
-constexpr int RB = 8;            // rows reduced together
 
 __device__ __forceinline__ double block_sum(double v, double *sh) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -73,231 +72,6 @@ __device__ __forceinline__ double block_max(double v, double *sh) {
 
 enum { MODE_ROWS = 0, MODE_COLS = 1, MODE_SUM = 2, MODE_MIN = 3 };
 
-typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
-
-// 64-byte scalar load issued by hand so that it can stay in flight across the masked adds of the previous rows
-__device__ __forceinline__ u32x16 sload16(const void *p) {
-    u32x16 r;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(r) : "s"(p) : "memory");
-    return r;
-}
-template <int N>
-__device__ __forceinline__ void swait(u32x16 (&v)[N]) {
-    if constexpr (N == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v[0]));
-    else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v[0]), "+s"(v[1]));
-}
-
-// acc (op)= x on the lanes whose bit is set in the wave-uniform 64-bit `word`: the word goes straight into
-// EXEC, so one matrix word costs ONE vector instruction (plus two scalar ones) instead of shift/and/select.
-__device__ __forceinline__ void masked_add(double &acc, double x, uint64_t word) {
-    uint64_t saved;
-    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tv_add_f64 %[a], %[a], %[x]\n\ts_mov_b64 exec, %[sv]"
-                 : [a] "+v"(acc), [sv] "=&s"(saved)
-                 : [x] "v"(x), [m] "s"(word)
-                 : "scc");
-}
-__device__ __forceinline__ void masked_min(double &acc, double x, uint64_t word) {
-    uint64_t saved;
-    asm volatile("s_and_saveexec_b64 %[sv], %[m]\n\tv_min_f64 %[a], %[a], %[x]\n\ts_mov_b64 exec, %[sv]"
-                 : [a] "+v"(acc), [sv] "=&s"(saved)
-                 : [x] "v"(x), [m] "s"(word)
-                 : "scc");
-}
-
-template <bool MIN>
-__device__ __forceinline__ double comb(double a, double b) { return MIN ? fmin(a, b) : a + b; }
-
-// reduce RB=8 per-lane partials over the 64 lanes of a wave; afterwards every lane holds the result of
-// row ((lane>>3)&1)*4 + ((lane>>4)&1)*2 + ((lane>>5)&1)
-template <bool MIN>
-__device__ __forceinline__ double reduce8(const double (&v)[RB], int lane) {
-    double u[4], t[2], s;
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double mine = b5 ? v[2 * i + 1] : v[2 * i];
-        const double other = b5 ? v[2 * i] : v[2 * i + 1];
-        u[i] = comb<MIN>(mine, __shfl_xor(other, 32, 64));
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const double mine = b4 ? u[2 * i + 1] : u[2 * i];
-        const double other = b4 ? u[2 * i] : u[2 * i + 1];
-        t[i] = comb<MIN>(mine, __shfl_xor(other, 16, 64));
-    }
-    {
-        const double mine = b3 ? t[1] : t[0];
-        const double other = b3 ? t[0] : t[1];
-        s = comb<MIN>(mine, __shfl_xor(other, 8, 64));
-    }
-    s = comb<MIN>(s, __shfl_xor(s, 4, 64));
-    s = comb<MIN>(s, __shfl_xor(s, 2, 64));
-    s = comb<MIN>(s, __shfl_xor(s, 1, 64));
-    return s;
-}
-
-constexpr int MAX_RPB = 64;      // matrix rows per workgroup
-
-// y = f(B x) for a bit matrix B [n_rows][n_words * 64 bits] (n_words = row stride, a multiple of 8, zero padded)
-// and a dense vector x [n_k].
-// A workgroup owns rows_per_block consecutive rows and walks the K dimension in chunks of KPT*1024 elements;
-// inside a chunk x lives in registers and matrix words are wave-uniform scalar loads.
-//   MODE_ROWS: x = vec (raw) or vec / sum(vec) (normalise) or all-ones (init);  y[c] = s > 0 ? count[c] / s : 0
-//   MODE_COLS: x = w;  t = B x;  q_out[a] = pres_in[a] ? p_a * t / len[a] : 0 with p_a = q_in[a] / *tot
-//              (init: q_out = t / len),  pres_out[a] = pres_in[a] && t > 0
-//   MODE_SUM : x = (double)count (exact below 2^53), y = B x            -> Gene_counts
-//   MODE_MIN : x = element index, y = min over set bits (+inf if none)  -> first class containing the allele
-template <int KPT, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_bitmatvec(const uint64_t *__restrict__ B, int n_rows, int n_words, int n_k,
-                                                     int rows_per_block, const double *__restrict__ vec,
-                                                     const uint8_t *__restrict__ vec_pres,
-                                                     int x_mode /* rows: 0 raw, 1 normalise, 2 ones */,
-                                                     const int64_t *__restrict__ count, const double *__restrict__ q_in,
-                                                     const uint8_t *__restrict__ pres_in, const double *__restrict__ len,
-                                                     double *__restrict__ y, uint8_t *__restrict__ pres_out,
-                                                     double *__restrict__ scal, int gate /* 0 always, 1 needs S_FLAG */) {
-    constexpr bool MIN = MODE == MODE_MIN;
-    constexpr bool EM = MODE == MODE_ROWS || MODE == MODE_COLS;
-    __shared__ double sh[NWAVE];
-    __shared__ double part[MAX_RPB][NWAVE];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int row0 = blockIdx.x * rows_per_block;
-    const int nrow = min(rows_per_block, n_rows - row0);
-    // Everything the kernel will need from memory besides the matrix is requested up front, before the convergence
-    // gate is even known: the state words, this thread's epilogue operands and its vector elements.  These launches
-    // are short, so dependent round trips to memory are what they cost.
-    double st_done = 0.0, st_flag = 1.0, tot = 1.0;
-    if (EM) { st_done = scal[S_DONE]; st_flag = scal[S_FLAG]; }
-    if (MODE == MODE_COLS) tot = scal[S_TOT_A];
-    double e_count = 0.0, e_q = 0.0, e_len = 1.0;
-    bool e_pres = true;
-    if (tid < nrow) {
-        const int row = row0 + tid;
-        if (MODE == MODE_ROWS) e_count = (double)count[row];
-        if (MODE == MODE_COLS) {
-            if (x_mode != 2) { e_q = q_in[row]; e_pres = pres_in[row] != 0; }
-            if (len) e_len = len[row];
-        }
-    }
-    double x[KPT];
-    auto load_x = [&](int k0) {
-#pragma unroll
-        for (int k = 0; k < KPT; ++k) {
-            const int e = k0 + 64 * (KPT * wv + k) + lane;
-            double v = MIN ? __builtin_inf() : 0.0;
-            if (e < n_k) {
-                if (MODE == MODE_ROWS) v = (x_mode == 2) ? 1.0 : (vec_pres[e] ? vec[e] : 0.0);
-                else if (MODE == MODE_COLS) v = vec[e];
-                else if (MODE == MODE_SUM) v = (double)count[e];
-                else v = (double)e;
-            }
-            x[k] = v;
-        }
-    };
-    load_x(0);
-    if (nrow <= 0) return;
-    if (EM) {
-        if (st_done != 0.0) return;
-        if (gate && st_flag == 0.0) return;
-    }
-    if (MODE == MODE_COLS && x_mode != 2) {
-        // rows (alleles) that are not present produce 0 whatever the matrix says: a block without a present row is done
-        if (!__syncthreads_or(tid < nrow && e_pres)) {
-            if (tid < nrow) { y[row0 + tid] = 0.0; pres_out[row0 + tid] = 0; }
-            if (blockIdx.x == 0 && tid == 0) scal[S_NCOLS] += 1.0;
-            return;
-        }
-    }
-    // every (row, wave) slot of `part` is owned by one lane of that wave: no cross-wave traffic before the final barrier
-    for (int i = tid; i < MAX_RPB * NWAVE; i += BLOCK) (&part[0][0])[i] = MIN ? __builtin_inf() : 0.0;
-    if (MODE == MODE_ROWS && x_mode == 1) {
-        double s = 0.0;
-        for (int e = tid; e < n_k; e += BLOCK) if (vec_pres[e]) s += vec[e];
-        tot = block_sum(s, sh);
-    }
-    if (MODE == MODE_ROWS && blockIdx.x == 0 && tid == 0) { scal[S_TOT_A] = tot; scal[S_NROWS] += 1.0; }
-    if (MODE == MODE_COLS && blockIdx.x == 0 && tid == 0) scal[S_NCOLS] += 1.0;
-    __syncthreads();
-    // Wave w owns KPT consecutive 64-bit words of every row chunk (elements 64*(KPT*w + k) + lane), fetched with
-    // one 64-byte scalar load per 8 words.  No validity tests in the hot loop: addresses are clamped into the
-    // (8-word padded, zero filled) row and out-of-range elements carry x = 0 (+inf for MIN), so whatever bits a
-    // clamped load returns contribute nothing.
-    for (int k0 = 0; k0 < n_k; k0 += KPT * BLOCK) {
-        if (k0 > 0) load_x(k0);
-        if (MODE == MODE_ROWS && x_mode == 1) {
-#pragma unroll
-            for (int k = 0; k < KPT; ++k) x[k] = x[k] / tot;
-        }
-        const int wbase = min((k0 >> 6) + KPT * wv, n_words - KPT);
-        // Row words arrive through the scalar cache (64 bytes per s_load_dwordx16).  SMEM returns out of order, so the
-        // only safe wait is lgkmcnt(0); to keep the loads off the critical path the batch of 8 rows is walked in halves:
-        // while one half is being applied (EXEC-masked adds) the next half's loads are already in flight.
-        constexpr int RH = KPT == 8 ? 2 : 1;               // rows per half: 32 SGPRs of matrix words in each buffer
-        constexpr int L16 = KPT / 8;                        // 64-byte loads per row
-        for (int rb = 0; rb < nrow; rb += RB) {
-            double acc[RB];
-#pragma unroll
-            for (int r = 0; r < RB; ++r) acc[r] = MIN ? __builtin_inf() : 0.0;
-            u32x16 buf[2][RH * L16];
-            auto issue = [&](int half, u32x16 (&dst)[RH * L16]) {
-#pragma unroll
-                for (int i = 0; i < RH; ++i) {
-                    const uint64_t *brow = B + (size_t)min(row0 + rb + half * RH + i, n_rows - 1) * n_words + wbase;
-#pragma unroll
-                    for (int h = 0; h < L16; ++h) dst[i * L16 + h] = sload16(brow + 8 * h);
-                }
-            };
-            issue(0, buf[0]);
-#pragma unroll
-            for (int half = 0; half < RB / RH; ++half) {
-                u32x16(&cur)[RH * L16] = buf[half & 1];
-                swait(cur);
-                if (half + 1 < RB / RH) issue(half + 1, buf[(half + 1) & 1]);
-#pragma unroll
-                for (int i = 0; i < RH; ++i) {
-                    const int r = half * RH + i;
-#pragma unroll
-                    for (int h = 0; h < L16; ++h)
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const uint64_t word = ((uint64_t)cur[i * L16 + h][2 * k + 1] << 32) | cur[i * L16 + h][2 * k];
-                            if (MIN) masked_min(acc[r], x[8 * h + k], word);
-                            else masked_add(acc[r], x[8 * h + k], word);
-                        }
-                }
-            }
-            const double s = reduce8<MIN>(acc, lane);
-            if ((lane & 7) == 0) {
-                const int r = rb + ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
-                part[r][wv] = comb<MIN>(part[r][wv], s);
-            }
-        }
-    }
-    __syncthreads();
-    if (tid < nrow) {
-        double t = part[tid][0];
-#pragma unroll
-        for (int i = 1; i < NWAVE; ++i) t = comb<MIN>(t, part[tid][i]);
-        const int row = row0 + tid;
-        if (MODE == MODE_ROWS) {
-            y[row] = t > 0.0 ? e_count / t : 0.0;
-        } else if (MODE == MODE_COLS) {
-            const bool init = x_mode == 2;
-            const bool in = init || e_pres;
-            double v = 0.0;
-            if (in && t > 0.0) {
-                v = init ? t : (e_q / tot) * t;
-                if (len) v = v / e_len;
-            }
-            y[row] = v;
-            pres_out[row] = (in && t > 0.0) ? 1 : 0;
-        } else {
-            y[row] = t;
-        }
-    }
-}
-
 // N block-wide sums with a single barrier pair (fixed summation order: identical in every launch)
 template <int N>
 __device__ __forceinline__ void block_sum_n(double (&v)[N], double (*sh)[NWAVE]) {
@@ -317,6 +91,10 @@ __device__ __forceinline__ void block_sum_n(double (&v)[N], double (*sh)[NWAVE])
         v[n] = t;
     }
 }
+
+#ifdef HGX_LAB
+#include "lab/hgx_em_bitmatvec.inc"        // round 1's VALU bit mat-vec (backend 1) and its helpers: lab build only
+#endif
 
 constexpr int EPT = 8;     // vector elements per thread kept in registers by the single-workgroup kernels (a_pad <= 8192)
 
@@ -1541,22 +1319,9 @@ int launch_mfma(const MatVec &m, hipStream_t st, const double *vec, const uint8_
 #endif
 }
 
-inline int rows_per_block(int n_rows) {
-    const int forced = hgx_test_switch("rpb") ? atoi(hgx_test_switch("rpb")) : 0;     // tuning aid
-    if (forced >= RB && forced <= MAX_RPB && forced % RB == 0) return forced;
-    int rpb = ((n_rows + 511) / 512 + RB - 1) / RB * RB;
-    return std::max(RB, std::min(MAX_RPB, rpb));
-}
-
 // events that the next table-lookup launch attaches to its own dispatch (hipExtLaunchKernelGGL: the runtime timestamps the
 // kernel's begin and end, like rocprofv3 does, instead of bracketing it with separately queued event records)
 thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-
-// rows per workgroup of the narrow-table form: few enough that the launch spreads over most of the chip
-[[maybe_unused]] inline int l4_rows(int n_rows) {
-    if (const char *f = hgx_test_switch("l4_rows")) { const int v = atoi(f); if (v == 16 || v == 32 || v == 64 || v == 128) return v; }
-    return n_rows >= 8192 ? 64 : 32;
-}
 
 template <int MODE>
 int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint8_t *vec_pres, int x_mode,
@@ -1566,25 +1331,7 @@ int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint
         if (use_mfma(m))
             return launch_mfma<MODE>(m, st, vec, vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate);
 #ifdef HGX_LAB
-        if (m.M && m.narrow) {
-            constexpr int XS = MODE == MODE_ROWS ? 0 : 1;
-            HGX_ONCE_PER_DEVICE({
-                HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut4<XS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L4_LDS));
-            });
-            const int R = l4_rows(m.n_rows);
-            const dim3 grid((unsigned)((m.n_rows + R - 1) / R));
-            const FuseArgs fz{};
-            if (g_ev_start) {
-                hipExtLaunchKernelGGL((k_lut4<XS>), grid, dim3(BLOCK), L4_LDS, st, g_ev_start, g_ev_stop, 0, m.M, m.n_rows, m.n_pad, m.n_words, m.n_k, R,
-                                      vec, vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate, (const double *)nullptr,
-                                      (const uint8_t *)nullptr, fz);
-                g_ev_start = g_ev_stop = nullptr;
-            } else {
-                hipLaunchKernelGGL((k_lut4<XS>), grid, dim3(BLOCK), L4_LDS, st, m.M, m.n_rows, m.n_pad, m.n_words, m.n_k, R, vec, vec_pres, x_mode,
-                                   count, q_in, pres_in, len, y, pres_out, scal, gate, (const double *)nullptr, (const uint8_t *)nullptr, fz);
-            }
-            return HGX_OK;
-        }
+#include "lab/hgx_launch_lut4.inc"        // the narrow-table form of a pass (k_lut4)
 #endif
         if (m.M) {
             HGX_ONCE_PER_DEVICE({
@@ -1605,6 +1352,7 @@ int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint
             return HGX_OK;
         }
     }
+#ifdef HGX_LAB
     const int rpb = rows_per_block(m.n_rows);
     const int grid = (m.n_rows + rpb - 1) / rpb;
     if (m.n_k <= 8 * BLOCK)
@@ -1614,14 +1362,10 @@ int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint
         hipLaunchKernelGGL((k_bitmatvec<16, MODE>), dim3(grid), dim3(BLOCK), 0, st, m.B, m.n_rows, m.n_words, m.n_k, rpb, vec,
                            vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate);
     return HGX_OK;
-}
-
-__global__ void k_counts_out(const double *__restrict__ sum, const double *__restrict__ first, int n, int64_t *__restrict__ out_count,
-                             int32_t *__restrict__ out_first) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= n) return;
-    out_count[a] = (int64_t)sum[a];
-    out_first[a] = first[a] < 1e300 ? (int32_t)first[a] : -1;
+#else
+    hgx_set_error("bit mat-vec without table-lookup operands: the VALU back-end is lab code (libhgx_lab.so)");
+    return HGX_EINVAL;
+#endif
 }
 
 // Per-kernel timing for bench.py's roofline object.  When enabled (hgx_em_set_timing) every bit-mat-vec launch of
@@ -1866,7 +1610,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         if (n_iter_host) *n_iter_host = 1;
         return HGX_OK;
     }
-    if (C <= 64 && c->w64 <= 128 && !hgx_test_switch("em_no_small") && !hgx_test_switch("em_no_wave")) {
+    if (C <= 64 && c->w64 <= 128 && !hgx_switch_has("em_skip", "wave")) {
         // single-wavefront path (<= 64 classes over <= 64 distinct alleles); falls through if more alleles occur
         DevBuf b_len, b_scal, b_out;
         ALLOC(b_scal, S_N * 8); ALLOC(b_out, A * 8);
@@ -1887,7 +1631,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             h_first.resize(A);
         }
         DevBuf b_rank;
-        if (c->h_rank && !hgx_test_switch("em_no_exact")) {
+        if (c->h_rank && !hgx_switch_has("em_skip", "exact")) {
             ALLOC(b_rank, (size_t)A * 4);
             { int rc_ = hgx_h2d(b_rank.p, c->h_rank, (size_t)A * 4, st); if (rc_) return rc_; }
         }
@@ -1913,8 +1657,8 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             return HGX_OK;
         }
     }
-    if (C <= (g_em_fast < 0 ? HGX_EMX_HARD_MAX_CLASSES : HGX_EMX_MAX_CLASSES) && c->w64 <= 128 && c->h_rank && !hgx_test_switch("em_no_exact") &&
-        !hgx_test_switch("em_no_emx")) {
+    if (C <= (g_em_fast < 0 ? HGX_EMX_HARD_MAX_CLASSES : HGX_EMX_MAX_CLASSES) && c->w64 <= 128 && c->h_rank && !hgx_switch_has("em_skip", "exact") &&
+        !hgx_switch_has("em_skip", "emx")) {
         // problems of up to 4096 classes over up to 8192 distinct alleles in the reference's own order of operations
         // (k_emx, hgx_emx.hip: one workgroup, one launch, bit-identical abundances); falls through if it does not take the problem
         DevBuf b_rank, b_len;
@@ -1948,64 +1692,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = -1;
     }
 #ifdef HGX_LAB
-    if (C <= MR_C && c->w64 <= 128 && c->h_rank && !hgx_test_switch("em_no_exact") && !hgx_test_switch("em_no_mid")) {
-        // mid-size problems in the reference's own order of operations (k_em_ref): one workgroup, one launch, bit-identical
-        // abundances; falls through if more than MR_A distinct alleles occur
-        DevBuf b_len, b_scal, b_out, b_first, b_rank, b_rm, b_km;
-        ALLOC(b_scal, S_N * 8); ALLOC(b_out, A * 8); ALLOC(b_rank, (size_t)A * 4);
-        ALLOC(b_rm, (size_t)std::max(C, 1) * MR_AW * 8); ALLOC(b_km, (size_t)MR_A * ((C + 63) / 64) * 8);
-        double *d_len = nullptr;
-        if (allele_len) {
-            std::vector<double> l(A, 1.0);
-            for (int a = 0; a < n_alleles; ++a) l[a] = (double)allele_len[a];
-            ALLOC(b_len, A * 8);
-            { int rc_ = hgx_h2d(b_len.p, l.data(), A * 8, st); if (rc_) return rc_; }
-            d_len = b_len.as<double>();
-        }
-        { int rc_ = hgx_h2d(b_rank.p, c->h_rank, (size_t)A * 4, st); if (rc_) return rc_; }
-        HIPCHK(hipMemsetAsync(b_scal.p, 0, S_N * 8, st));
-        std::vector<int32_t> h_first;
-        if (first_host) {
-            ALLOC(b_first, (size_t)A * 4);
-            HIPCHK(hipMemsetAsync(b_first.p, 0xFF, (size_t)A * 4, st));
-            h_first.resize(A);
-        }
-        HGX_ONCE_PER_DEVICE({
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_ref), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MrLds)));
-        });
-        DevBuf b_dbg;
-        const int max_nnz = hgx_test_switch("em_mid_nnz") ? atoi(hgx_test_switch("em_mid_nnz")) : 65536;
-        const bool stamps = hgx_test_switch("mid_stamps") != nullptr;
-        if (stamps) ALLOC(b_dbg, 64);
-        hipLaunchKernelGGL(k_em_ref, dim3(1), dim3(BLOCK), sizeof(MrLds), st, c->d_bits, C, c->w64, A, c->d_count, d_len, b_rank.as<int32_t>(),
-                           remove_low ? 1 : 0, b_rm.as<uint64_t>(), b_km.as<uint64_t>(), b_out.as<double>(), b_scal.as<double>(),
-                           first_host ? b_first.as<int32_t>() : nullptr, max_nnz, stamps ? b_dbg.as<unsigned long long>() : nullptr);
-        HIPCHK(hipGetLastError());
-        if (stamps) {
-            unsigned long long h[8] = {0};
-            (void)hipStreamSynchronize(st);
-            (void)hipMemcpy(h, b_dbg.p, 56, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[k_em_ref] C %d: set-up %.1f us | rows %.1f | cols %.1f | orders %.1f (%llu derived) | normalise %.1f | sums %.1f\n", C,
-                    h[0] * 0.01, h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[6], h[4] * 0.01, h[5] * 0.01);
-        }
-        std::vector<double> out(A);
-        double h_scal[S_N];
-        if (first_host) { int rc_ = hgx_d2h(h_first.data(), b_first.p, (size_t)A * 4, st); if (rc_) return rc_; }
-        { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
-        { int rc_ = hgx_d2h(h_scal, b_scal.p, S_N * 8, st); if (rc_) return rc_; }
-        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-        if (h_scal[S_FALLBACK] == 0.0) {
-            if (h_scal[S_KEYERR] != 0.0) {
-                hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
-                return HGX_EKEY;
-            }
-            for (int a = 0; a < n_alleles; ++a) prob_host[a] = out[a];
-            if (first_host) for (int a = 0; a < n_alleles; ++a) first_host[a] = h_first[a];
-            if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
-            g_last_exact = 1;
-            return HGX_OK;
-        }
-    }
+#include "lab/hgx_em_impl_mid.inc"        // round 2's mid-size reference-order EM (k_em_ref)
 #endif
     // helper for the paths that do not carry the first-class information: look it up for the survivors afterwards
     [[maybe_unused]] auto first_for_present = [&]() -> int {
@@ -2020,39 +1707,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         return HGX_OK;
     };
 #ifdef HGX_LAB
-    if (C <= SMALL_C && A <= EPT * BLOCK && !hgx_test_switch("em_no_small")) {
-        // single-workgroup path: one launch, one sync
-        DevBuf b_len, b_scal, b_out;
-        ALLOC(b_scal, S_N * 8); ALLOC(b_out, A * 8);
-        double *d_len = nullptr;
-        if (allele_len) {
-            std::vector<double> l(A, 1.0);
-            for (int a = 0; a < n_alleles; ++a) l[a] = (double)allele_len[a];
-            ALLOC(b_len, A * 8);
-            { int rc_ = hgx_h2d(b_len.p, l.data(), A * 8, st); if (rc_) return rc_; }
-            d_len = b_len.as<double>();
-        }
-        const size_t lds = (size_t)C * c->w64 * 8;
-        HGX_ONCE_PER_DEVICE({
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_small), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       SMALL_C * (EPT * BLOCK / 64) * 8));
-        });
-        hipLaunchKernelGGL(k_em_small, dim3(1), dim3(BLOCK), lds, st, c->d_bits, C, c->w64, A, c->d_count, d_len, remove_low ? 1 : 0,
-                           b_out.as<double>(), b_scal.as<double>());
-        HIPCHK(hipGetLastError());
-        std::vector<double> out(A);
-        double h_scal[S_N];
-        { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
-        { int rc_ = hgx_d2h(h_scal, b_scal.p, S_N * 8, st); if (rc_) return rc_; }
-        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-        if (h_scal[S_KEYERR] != 0.0) {
-            hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
-            return HGX_EKEY;
-        }
-        for (int a = 0; a < n_alleles; ++a) prob_host[a] = out[a];
-        if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
-        return first_for_present();
-    }
+#include "lab/hgx_em_impl_small.inc"        // round 1's one-workgroup EM (k_em_small)
 #endif
     int rc = hgx_ensure_compact(c, st);
     if (rc) return rc;
@@ -2087,25 +1742,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     MatVec rows{c->d_bitsC, C, w64c, A};
     MatVec cols{c->d_bitsTC, A, c->c64, C};
 #ifdef HGX_LAB
-    if (g_backend == 2 && A >= 512 && C >= 64) {
-        // MFMA operand order of both matrices, built once per class set
-        auto permute = [&](const uint64_t *Bm, int n_rows, int n_words, uint64_t **dst) -> int {
-            const int n_super = n_words / 4;
-            const long tiles = (n_rows + 15) / 16;
-            const long tiles_pad = (tiles + MF_WAVES - 1) / MF_WAVES * MF_WAVES;     // whole workgroups
-            const long total = tiles_pad * n_super * 64;
-            if (!*dst) {
-                *dst = (uint64_t *)hgx_pool_alloc((size_t)total * 8);
-                if (!*dst) { hgx_set_error("device allocation failed"); return HGX_ENOMEM; }
-                hipLaunchKernelGGL(k_permute_mfma, dim3(nblk(total, 256)), dim3(256), 0, st, Bm, n_rows, n_words, n_super, total, *dst);
-            }
-            return HGX_OK;
-        };
-        if ((rc = permute(c->d_bitsC, C, w64c, &c->d_prow))) return rc;
-        if ((rc = permute(c->d_bitsTC, A, c->c64, &c->d_pcol))) return rc;
-        rows.P = c->d_prow; rows.n_super = w64c / 4;
-        cols.P = c->d_pcol; cols.n_super = c->c64 / 4;
-    }
+#include "lab/hgx_em_impl_mfma_setup.inc"        // MFMA operand order of both matrices (back-end 2)
 #endif
 
     DevBuf b_part, b_part_c, b_cnt;
@@ -2126,123 +1763,17 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         rows.M = c->d_wrow; rows.n_pad = Cp; rows.part = b_part.as<double>(); rows.counters = b_cnt.as<unsigned>();
         cols.M = c->d_wcol; cols.n_pad = A; cols.part = b_part_c.as<double>(); cols.counters = b_cnt.as<unsigned>();
 #ifdef HGX_LAB
-        if (hgx_test_switch("em_lut4") && !hgx_test_switch("em_persist") && !hgx_test_switch("em_grid"))
+        if (hgx_test_switch("em_lut4") && !HGX_LAB_SWITCH("em_persist") && !hgx_test_switch("em_grid"))
             rows.narrow = cols.narrow = 1;      // the narrow-table form (k_lut4, lab): a workgroup owns its rows for the whole of K
 #endif
-        if (!rows.narrow && !hgx_test_switch("em_persist") && !hgx_test_switch("em_no_defer")) {
+        if (!rows.narrow && !HGX_LAB_SWITCH("em_persist") && !hgx_switch_has("em_skip", "defer")) {
             // the rows pass stops at its slab partials; the cols pass turns them into w_c in its prologue
             rows.defer_combine = 1;
             cols.src_part = rows.part; cols.src_slabs = w64c / 8; cols.src_pad = Cp; cols.src_count = c->d_count;
         }
     }
 #ifdef HGX_LAB
-    if (rows.M && hgx_test_switch("em_persist")) {
-        // ---- persistent path: whole iterations per launch (k_em_persist).  Opt-in: measured on MI355X it is not faster
-        // than one launch per pass (a device-wide barrier across the 8 XCDs costs about what a kernel boundary costs,
-        // ~5-8 us, and an iteration needs 10 of them plus 6 chunk tickets): 124 us vs 125 us per iteration. ----------
-        static int n_cu = 0, occ = 0;
-        if (!n_cu) {
-            int dev = 0;
-            HIPCHK(hipGetDevice(&dev));
-            hipDeviceProp_t prop;
-            HIPCHK(hipGetDeviceProperties(&prop, dev));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_persist), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)LUT_LDS));
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_em_persist, BLOCK, LUT_LDS));
-            n_cu = prop.multiProcessorCount;
-        }
-        PkArgs a;
-        a.Mr = rows.M; a.Mc = cols.M; a.C = C; a.Cp = c->c64 * 64; a.A = A;
-        a.nsr = w64c / 8; a.ncr = (C + BLOCK - 1) / BLOCK; a.nsc = c->c64 / 8; a.ncc = (A + BLOCK - 1) / BLOCK;
-        const int items = std::max(a.nsr * a.ncr, a.nsc * a.ncc);
-        const int G = std::min(items, std::max(1, occ) * n_cu);
-        if (occ >= 1 && G >= a.ncc) {
-            DevBuf b_aux, b_sync;
-            ALLOC(b_aux, (size_t)(7 * a.ncc) * 8); ALLOC(b_sync, 16);
-            HIPCHK(hipMemsetAsync(b_sync.p, 0, 16, st));
-            a.count = c->d_count; a.len = d_len;
-            a.p = p; a.q1 = q1; a.q2 = q2; a.q3 = q3; a.wc = wc; a.part = rows.part;
-            a.ctot = b_aux.as<double>(); a.red = b_aux.as<double>() + 3 * a.ncc; a.scal = scal;
-            a.chunk_cnt = rows.counters; a.bar = b_sync.as<unsigned>(); a.abort_flag = (int *)(b_sync.as<unsigned>() + 1);
-            a.remove_low = remove_low ? 1 : 0;
-            const int64_t pair_bytes = ((int64_t)C * w64c * 8 + (int64_t)A * 8 + (int64_t)C * 16) +
-                                       ((int64_t)A * c->c64 * 8 + (int64_t)C * 8 + (int64_t)A * 24);
-            double h_scal[S_N];
-            int h_sync[4] = {0, 0, 0, 0};
-            bool first = true, tail_done = false;
-            double tail_failed_at = 1e300;
-            const bool use_tail = !hgx_test_switch("em_no_tail");
-            std::vector<Timed> timed;
-            double *pu = nullptr;
-            DevBuf b_pu;
-            ALLOC(b_pu, A * 8);
-            pu = b_pu.as<double>();
-            for (;;) {
-                a.do_init = first ? 1 : 0;
-                a.n_iters = (first && use_tail && remove_low) ? 11 : 4;     // pruning starts at iteration 10: look at the survivors
-                first = false;
-                if (g_timing) {
-                    Timed t;
-                    t.a = pool_event(); t.b = pool_event(); t.slot = 0;
-                    (void)hipEventRecord(t.a, st);
-                    timed.push_back(t);
-                }
-                HIPCHK(hipMemsetAsync(b_sync.p, 0, 4, st));          // the barrier counter starts at 0 in every launch
-                hipLaunchKernelGGL(k_em_persist, dim3(G), dim3(BLOCK), LUT_LDS, st, a);
-                if (g_timing) (void)hipEventRecord(timed.back().b, st);
-                HIPCHK(hipGetLastError());
-                { int rc_ = hgx_d2h(h_scal, scal, S_N * 8, st); if (rc_) return rc_; }
-                { int rc_ = hgx_d2h(h_sync, b_sync.p, 16, st); if (rc_) return rc_; }
-                { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-                if (h_sync[1] != 0) {
-                    hgx_set_error("persistent EM: device-wide barrier timed out (grid of %d workgroups not co-resident?)", G);
-                    return HGX_EHIP;
-                }
-                if (h_scal[S_DONE] != 0.0) break;
-                if (use_tail && h_scal[S_NPRES] <= 64.0 && h_scal[S_NPRES] < tail_failed_at) {
-                    hipLaunchKernelGGL(k_pk_unpack, dim3(nblk(A, 256)), dim3(256), 0, st, p, A, pu, pr);
-                    hipLaunchKernelGGL(k_em_tail, dim3(1), dim3(BLOCK), 0, st, c->d_bitsTC, C, c->c64, A, c->d_count, pu, pr, d_len,
-                                       remove_low ? 1 : 0, b_out.as<double>(), scal);
-                    const double maps_ran = h_scal[S_NROWS];
-                    { int rc_ = hgx_d2h(h_scal, scal, S_N * 8, st); if (rc_) return rc_; }
-                    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-                    h_scal[S_NROWS] = maps_ran;
-                    if (h_scal[S_TAIL] == 1.0) { tail_done = true; break; }
-                    tail_failed_at = h_scal[S_NPRES];
-                }
-            }
-            if (g_timing) {
-                for (auto &t : timed) {
-                    float ms = 0.f;
-                    (void)hipEventElapsedTime(&ms, t.a, t.b);
-                    g_stats[0].ms += ms;
-                    g_stats[0].launches += 1;
-                    g_event_pool.push_back(t.a);
-                    g_event_pool.push_back(t.b);
-                }
-                g_stats[0].executed += (int64_t)h_scal[S_NROWS];
-                g_stats[0].bytes += (int64_t)h_scal[S_NROWS] * pair_bytes;
-            }
-            if (h_scal[S_KEYERR] != 0.0) {
-                hgx_set_error("EM: allele missing from the next estimate (the reference raises KeyError here, common:1365-1369)");
-                return HGX_EKEY;
-            }
-            if (!tail_done) {
-                hipLaunchKernelGGL(k_pk_unpack, dim3(nblk(A, 256)), dim3(256), 0, st, p, A, pu, pr);
-                hipLaunchKernelGGL(k_em_finish, dim3(1), dim3(BLOCK), 0, st, pu, pr, d_len, A, remove_low ? 1 : 0, b_out.as<double>());
-            }
-            HIPCHK(hipGetLastError());
-            std::vector<double> out(A);
-            if (first_host) { int rc_ = hgx_d2h(h_fc.data(), b_fc.p, (size_t)A * 4, st); if (rc_) return rc_; }
-            { int rc_ = hgx_d2h(out.data(), b_out.p, A * 8, st); if (rc_) return rc_; }
-            { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-            for (int al = 0; al < n_alleles; ++al) prob_host[al] = -1.0;
-            for (int jj = 0; jj < c->n_act; ++jj) if (c->h_act[jj] < n_alleles) prob_host[c->h_act[jj]] = out[jj];
-            if (first_host) for (int jj = 0; jj < c->n_act; ++jj) if (c->h_act[jj] < n_alleles) first_host[c->h_act[jj]] = h_fc[jj];
-            if (n_iter_host) *n_iter_host = (int)h_scal[S_ITER];
-            return HGX_OK;
-        }
-    }
+#include "lab/hgx_em_impl_persist.inc"        // the persistent whole-iteration EM (k_em_persist)
 #endif
     // ---- resident-block path (k_em_grid): the block grid must be co-resident, one workgroup per CU ----------------
     // two resident grids that together need more CUs than the chip has could each hold a part and wait forever: grids reserve
@@ -2259,49 +1790,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     // opt-in (HGX_EM_GRID=1), or for small block grids only (HGX_EM_GRID_MAX workgroups: many small tasks in flight are bound by
     // the launch rate, and one launch replaces ~66)
 #ifdef HGX_LAB
-    const int grid_small = hgx_test_switch("em_grid_max") ? atoi(hgx_test_switch("em_grid_max")) : 0;
-    const int grid_g = ((c->c64 * 64 + BLOCK - 1) / BLOCK) * (A / LUT_SLAB);
-    if (rows.M && rows.defer_combine && A <= EPT * BLOCK && !g_no_grid && (hgx_test_switch("em_grid") || grid_g <= grid_small)) {
-        static int n_cu = 0, occ5 = 0, occ8 = 0;
-        if (!n_cu) {
-            int dev = 0;
-            HIPCHK(hipGetDevice(&dev));
-            hipDeviceProp_t prop;
-            HIPCHK(hipGetDeviceProperties(&prop, dev));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_grid<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GK_LDS));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_em_grid<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)GK_LDS));
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ5, k_em_grid<5>, BLOCK, GK_LDS));
-            HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ8, k_em_grid<8>, BLOCK, GK_LDS));
-            n_cu = prop.multiProcessorCount;
-        }
-        const int Cp = c->c64 * 64;
-        ga.R = (Cp + BLOCK - 1) / BLOCK;
-        ga.K = A / LUT_SLAB;
-        const int occ = A <= 5 * BLOCK ? occ5 : occ8;
-        // a margin of CUs stays free for the other stream's kernels (and for a CU the runtime may have taken away)
-        bool reserved = false;
-        if (occ >= 1 && ga.R <= 64 && ga.K <= 64 && ga.R * ga.K <= n_cu - 16) {
-            const int want = ga.R * ga.K;
-            if (grid_cus.fetch_add(want) + want <= n_cu - 16) { grid_hold.g = want; reserved = true; }
-            else grid_cus.fetch_sub(want);
-        }
-        if (reserved) {
-            const int G = ga.R * ga.K;
-            ALLOC(b_gpr, (size_t)2 * ga.K * Cp * 8); ALLOC(b_gpc, (size_t)2 * (Cp / LUT_SLAB) * A * 8); ALLOC(b_gy, (size_t)2 * ga.R * A * 8);
-            ALLOC(b_gfl, ((size_t)3 * G * GK_FLAG_STRIDE + 32) * 4);
-            ga.Mr = rows.M; ga.Mc = cols.M; ga.C = C; ga.Cp = Cp; ga.A = A;
-            ga.count = c->d_count; ga.len = d_len;
-            ga.part_r = b_gpr.as<double>(); ga.part_c = b_gpc.as<double>(); ga.Y = b_gy.as<double>();
-            ga.flags = b_gfl.as<unsigned>(); ga.abort_flag = (int *)(b_gfl.as<unsigned>() + (size_t)3 * G * GK_FLAG_STRIDE);
-            ga.remove_low = remove_low ? 1 : 0;
-            if (hgx_test_switch("grid_stamps")) {
-                ALLOC(b_gst, (size_t)G * GK_STAMPS * 8);
-                HIPCHK(hipMemsetAsync(b_gst.p, 0, (size_t)G * GK_STAMPS * 8, st));
-                ga.stamps = b_gst.as<unsigned long long>();
-            }
-            grid = true;
-        }
-    }
+#include "lab/hgx_em_impl_grid.inc"        // the resident-block EM (k_em_grid) taking over a small enough problem
 #endif
     int grid_launches = 0;
     std::vector<Timed> timed;
@@ -2355,9 +1844,9 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
     int launched_iters = 0;
     double tail_failed_at = 1e300;
     bool tail_done = false;
-    const bool use_tail = !hgx_test_switch("em_no_tail");
+    const bool use_tail = !hgx_switch_has("em_skip", "tail");
     // ---- fused vector steps (k_lut_rows_fused): ping-pong estimate, extrapolated vector and state words -----------
-    const bool fuse = (rows.defer_combine || rows.narrow) && A <= EPT * BLOCK && !hgx_test_switch("em_no_fuse");
+    const bool fuse = (rows.defer_combine || rows.narrow) && A <= EPT * BLOCK && !hgx_switch_has("em_skip", "fuse");
     DevBuf b_palt, b_pralt, b_q2x, b_prx, b_scal2;
     double *p_alt = nullptr, *q2x = nullptr, *scal_alt = nullptr;
     uint8_t *pr_alt = nullptr, *prx = nullptr;
@@ -2407,6 +1896,12 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             nb = std::min(batch, 11 - launched_iters);
             if (launched_iters == batch && h_scal[S_DIFF] > 0.001) nb = 11 - launched_iters;
         }
+        {   // EXPERIMENT (measurement of the host syncs' cost): HGX_EM_BATCH1 = iterations before the first sync, HGX_EM_BATCH = after
+            static const int b1 = getenv("HGX_EM_BATCH1") ? atoi(getenv("HGX_EM_BATCH1")) : 0;
+            static const int bn = getenv("HGX_EM_BATCH") ? atoi(getenv("HGX_EM_BATCH")) : 0;
+            if (b1 > 0 && launched_iters == 0) nb = b1;
+            else if (bn > 0 && launched_iters > 0) nb = (use_tail && remove_low && launched_iters < 11) ? std::max(1, std::min(bn, 11 - launched_iters)) : bn;
+        }
         if (grid && use_tail && remove_low && launched_iters < 11) nb = 11 - launched_iters;    // no host sync inside: up to the first pruning
         launched_iters += nb;
         if (grid) {
@@ -2431,7 +1926,7 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
         }
         // test switch em_graph: the batch's launches captured into a hipGraph and launched as one (measurement of what a graph
         // buys a chain of dependent 15 us kernels; NOTEBOOK.md section 10) -- capture, instantiation and launch are all inside the call
-        const bool as_graph = !grid && !g_timing && hgx_test_switch("em_graph") != nullptr;
+        const bool as_graph = !grid && !g_timing && HGX_LAB_SWITCH("em_graph") != nullptr;
         if (as_graph) HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         for (int b = 0; b < (grid ? 0 : nb); ++b) {
             if (fuse) {
@@ -2603,11 +2098,11 @@ extern "C" int hgx_em_masked(const hgx_classes *cc, const uint64_t *mask_host, i
             if (a < n_alleles) al.push_back(a);
         }
     if (al.empty()) return HGX_OK;
-    if (al.size() <= 64 && !hgx_test_switch("em_no_masked")) {
+    if (al.size() <= 64 && !hgx_switch_has("em_skip", "masked")) {
         const int A1 = (int)al.size();
         // with the alleles' name order at hand the kept alleles go up in that order (= their order inside a class key), and the
         // single-wavefront EM follows the reference's summation order exactly
-        const bool exact = cc->h_rank != nullptr && !hgx_test_switch("em_no_exact");
+        const bool exact = cc->h_rank != nullptr && !hgx_switch_has("em_skip", "exact");
         if (exact) std::sort(al.begin(), al.end(), [&](int32_t x, int32_t y) { return cc->h_rank[x] < cc->h_rank[y]; });
         // one staging struct each way: [al | len] up, [scal | ticket | out | first] down (one copy + one memset + one copy)
         struct Up { int32_t al[64]; double len[64]; } up;
@@ -2676,235 +2171,6 @@ extern "C" int hgx_classes_set_allele_rank(hgx_classes *c, const int32_t *rank_h
     return HGX_OK;
 }
 
-// first class containing each compact allele = first set bit of its row in the transposed matrix (one wavefront per row)
-__global__ __launch_bounds__(256) void k_first_set_rows(const uint64_t *__restrict__ BT, int n_rows, int c64, int32_t *__restrict__ first) {
-    const int lane = threadIdx.x & 63;
-    const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (row >= n_rows) return;
-    int best = 0x7fffffff;
-    for (int w0 = 0; w0 < c64; w0 += 64) {
-        const int w = w0 + lane;
-        const uint64_t x = w < c64 ? BT[(size_t)row * c64 + w] : 0ull;
-        const uint64_t hit = __ballot(x != 0ull);
-        if (hit) {
-            const int l = __builtin_ctzll(hit);
-            const uint64_t xl = lane_u64(x, l);
-            best = 64 * (w0 + l) + __builtin_ctzll(xl);
-            break;
-        }
-    }
-    if (lane == 0) first[row] = best == 0x7fffffff ? -1 : best;
-}
-
-// first class containing an allele, for a handful of alleles: one workgroup per allele walks the allele's bit column
-__global__ __launch_bounds__(256) void k_first_classes(const uint64_t *__restrict__ B, int n_classes, int w64,
-                                                       const int32_t *__restrict__ alleles, int32_t *__restrict__ first) {
-    __shared__ int best;
-    const int a = alleles[blockIdx.x];
-    if (threadIdx.x == 0) best = n_classes;
-    __syncthreads();
-    const int word = a >> 6;
-    const uint64_t bit = 1ull << (a & 63);
-    for (int c0 = 0; c0 < n_classes; c0 += 256) {
-        const int c = c0 + threadIdx.x;
-        const bool hit = c < n_classes && (B[(size_t)c * w64 + word] & bit);
-        if (__syncthreads_or(hit)) {
-            if (hit) atomicMin(&best, c);
-            __syncthreads();
-            break;
-        }
-    }
-    if (threadIdx.x == 0) first[blockIdx.x] = best < n_classes ? best : -1;
-}
-
-extern "C" int hgx_first_classes(const hgx_classes *c, const int32_t *alleles_host, int32_t n, int32_t *first_host, void *stream) {
-    ARGCHK(c && n >= 0);
-    if (n == 0) return HGX_OK;
-    hgx_classes_order_after(c, (hipStream_t)stream);
-    ARGCHK(alleles_host && first_host);
-    for (int i = 0; i < n; ++i) ARGCHK(alleles_host[i] >= 0 && alleles_host[i] < c->a_pad);
-    if (c->n_classes == 0) { for (int i = 0; i < n; ++i) first_host[i] = -1; return HGX_OK; }
-    hipStream_t st = (hipStream_t)stream;
-    DevBuf b_a, b_f;
-    ALLOC(b_a, (size_t)n * 4); ALLOC(b_f, (size_t)n * 4);
-    { int rc_ = hgx_h2d(b_a.p, alleles_host, (size_t)n * 4, st); if (rc_) return rc_; }
-    hipLaunchKernelGGL(k_first_classes, dim3(n), dim3(256), 0, st, c->d_bits, c->n_classes, c->w64, b_a.as<int32_t>(), b_f.as<int32_t>());
-    HIPCHK(hipGetLastError());
-    { int rc_ = hgx_d2h(first_host, b_f.p, (size_t)n * 4, st); if (rc_) return rc_; }
-    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-    return HGX_OK;
-}
-
-// Gene_counts (typing_core.py:1187-1190): per allele the summed count of the classes containing it, and the first
-// such class (dict insertion order for ties).
-// Direct form, straight from the row-major class matrix (no transposed copy, no FP64 mat-vec passes): a lane owns one 32-bit
-// half of an allele word and a wavefront walks a range of classes -- a 256-byte coalesced load per class, the class count
-// wave-uniform -- keeping 32 integer column sums in registers (one v_bfe + one v_mad_u32_u24 per bit and class; 64-bit
-// multiply-adds made the kernel 114 us instead of the mat-vec form's 190).  First
-// classes: classes are visited in ascending order, so a bit that a lane sees for the first time records the class index
-// (kept in LDS, touched only when some lane of the wave has a new bit).  The four waves of a workgroup take consecutive class
-// ranges of the same words and are added / min-ed in LDS; the workgroup's partial columns go to memory with plain coalesced
-// stores and a second small kernel adds the <= 64 partials per allele (a global atomic per column and workgroup instead --
-// 1 M atomics on 7 168 hot addresses -- was most of a 101 us launch).  Integers: exact.  Needs every class count < 2^24 and
-// their sum < 2^32 (checked on the device; otherwise the mat-vec form below runs).
-constexpr int AC_WAVES = 4;
-__global__ __launch_bounds__(64 * AC_WAVES) void k_allele_counts_direct(const uint64_t *__restrict__ bits, int C, int w64,
-                                                                         const int64_t *__restrict__ count, int per_wave,
-                                                                         unsigned long long *__restrict__ cnt_part,
-                                                                         int *__restrict__ first_part, int A) {
-    __shared__ int s_first[AC_WAVES][32][64];                 // [wave][bit][lane]
-    __shared__ uint32_t s_cnt[AC_WAVES][32][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int n_half = 2 * w64;
-    const int hw = blockIdx.x * 64 + lane;                    // my 32-bit half-word of the allele row
-    const bool live = hw < n_half;
-    const int c0 = (blockIdx.y * AC_WAVES + wv) * per_wave, c1 = min(C, c0 + per_wave);
-    const uint32_t *rows = (const uint32_t *)bits;
-    uint32_t acc[32];
-#pragma unroll
-    for (int b = 0; b < 32; ++b) { acc[b] = 0u; s_first[wv][b][lane] = 0x7fffffff; }
-    uint32_t seen = 0u;
-    constexpr int U = 8;                                       // class rows in flight per wave (one wave per SIMD: no other latency hiding)
-    uint32_t xn[U], nn[U];                                      // the next batch: requested before the current one is worked through
-    auto fetch = [&](int cb) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int c = cb + u;
-            xn[u] = (live && c < c1) ? rows[(size_t)c * n_half + hw] : 0u;
-            nn[u] = c < c1 ? (uint32_t)count[c] : 0u;
-        }
-    };
-    fetch(c0);
-    for (int cb = c0; cb < c1; cb += U) {
-        uint32_t xs[U], ns[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) { xs[u] = xn[u]; ns[u] = nn[u]; }
-        fetch(cb + U);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const uint32_t x = xs[u];
-            const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)ns[u]);
-#pragma unroll
-            for (int b = 0; b < 32; ++b) acc[b] = __umul24((x >> b) & 1u, n) + acc[b];      // v_bfe_u32 + v_mad_u32_u24
-            uint32_t fresh = x & ~seen;
-            if (__any(fresh != 0u)) {
-                seen |= x;
-                while (fresh) {
-                    const int b = __builtin_ctz(fresh);
-                    s_first[wv][b][lane] = cb + u;
-                    fresh &= fresh - 1;
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < 32; ++b) s_cnt[wv][b][lane] = acc[b];
-    __syncthreads();
-    // thread (wv, lane) finishes bits 8 wv .. 8 wv + 7 of every lane's half-word: add / min over the four waves
-    if (live) {
-#pragma unroll
-        for (int k = 0; k < 32 / AC_WAVES; ++k) {
-            const int b = wv * (32 / AC_WAVES) + k;
-            unsigned long long t = 0ull;
-            int f = 0x7fffffff;
-#pragma unroll
-            for (int q = 0; q < AC_WAVES; ++q) { t += (unsigned long long)s_cnt[q][b][lane]; f = min(f, s_first[q][b][lane]); }
-            const int a = hw * 32 + b;
-            cnt_part[(size_t)blockIdx.y * A + a] = t;
-            first_part[(size_t)blockIdx.y * A + a] = f;
-        }
-    }
-}
-__global__ void k_allele_counts_reduce(const unsigned long long *__restrict__ cnt_part, const int *__restrict__ first_part, int groups,
-                                       int A, int64_t *__restrict__ cnt, int *__restrict__ first) {
-    const int a = blockIdx.x * blockDim.x + threadIdx.x;
-    if (a >= A) return;
-    unsigned long long t = 0ull;
-    int f = 0x7fffffff;
-    for (int g0 = 0; g0 < groups; g0 += 8) {                  // eight partials in flight
-        unsigned long long tv[8];
-        int fv[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const bool in = g0 + k < groups;
-            tv[k] = in ? cnt_part[(size_t)(g0 + k) * A + a] : 0ull;
-            fv[k] = in ? first_part[(size_t)(g0 + k) * A + a] : 0x7fffffff;
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { t += tv[k]; f = min(f, fv[k]); }
-    }
-    cnt[a] = (int64_t)t;
-    first[a] = f == 0x7fffffff ? -1 : f;
-}
-__global__ void k_allele_counts_check(const int64_t *__restrict__ count, int C, unsigned long long *__restrict__ chk) {
-    // chk[0] = some count outside [0, 2^24), chk[1] = sum of the counts; 16 classes per thread: a few dozen atomics in all
-    unsigned long long s = 0ull;
-    bool bad = false;
-    for (int k = 0; k < 16; ++k) {
-        const long c = ((long)blockIdx.x * 16 + k) * blockDim.x + threadIdx.x;
-        const long long n = c < C ? count[c] : 0;
-        bad = bad || n < 0 || n >= (1ll << 24);
-        s += (unsigned long long)(n < 0 ? 0 : n);
-    }
-    if (bad) chk[0] = 1ull;
-    s = wave_sum_u64(s);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&chk[1], s);
-}
-
-// The mat-vec form (two passes of the bit mat-vec over the transposed class matrix), for class counts beyond 32 bits.
-extern "C" int hgx_allele_counts_on(const hgx_classes *cc, int64_t *count_host, int32_t *first_host, void *stream);
-extern "C" int hgx_allele_counts(const hgx_classes *cc, int64_t *count_host, int32_t *first_host) {
-    return hgx_allele_counts_on(cc, count_host, first_host, nullptr);
-}
-extern "C" int hgx_allele_counts_on(const hgx_classes *cc, int64_t *count_host, int32_t *first_host, void *stream) {
-    ARGCHK(cc && count_host && first_host);
-    hipStream_t st = (hipStream_t)stream;
-    hgx_classes_order_after(cc, st);
-    hgx_classes *c = const_cast<hgx_classes *>(cc);
-    const int A = c->a_pad;
-    if (c->n_classes == 0) {
-        for (int a = 0; a < A; ++a) { count_host[a] = 0; first_host[a] = -1; }
-        return HGX_OK;
-    }
-    if (!hgx_test_switch("counts_matvec")) {
-        const int C = c->n_classes;
-        DevBuf b_cnt, b_first, b_big, b_cp, b_fp;
-        ALLOC(b_cnt, (size_t)A * 8); ALLOC(b_first, (size_t)A * 4); ALLOC(b_big, 16);
-        HIPCHK(hipMemsetAsync(b_big.p, 0, 16, st));
-        hipLaunchKernelGGL(k_allele_counts_check, dim3(nblk(C, 256 * 16)), dim3(256), 0, st, c->d_count, C, b_big.as<unsigned long long>());
-        // ~1024 wavefronts: 64 half-words each, four consecutive class ranges per workgroup
-        const int spans = (2 * c->w64 + 63) / 64;
-        const int groups = std::max(1, std::min(256 / std::max(spans, 1), (C + 64 * AC_WAVES - 1) / (64 * AC_WAVES)));
-        const int per_wave = (C + groups * AC_WAVES - 1) / (groups * AC_WAVES);
-        ALLOC(b_cp, (size_t)groups * A * 8); ALLOC(b_fp, (size_t)groups * A * 4);
-        hipLaunchKernelGGL(k_allele_counts_direct, dim3(spans, groups), dim3(64 * AC_WAVES), 0, st, c->d_bits, C, c->w64, c->d_count,
-                           per_wave, b_cp.as<unsigned long long>(), b_fp.as<int>(), A);
-        hipLaunchKernelGGL(k_allele_counts_reduce, dim3(nblk(A, 64)), dim3(64), 0, st, b_cp.as<unsigned long long>(), b_fp.as<int>(),
-                           groups, A, b_cnt.as<int64_t>(), b_first.as<int>());
-        HIPCHK(hipGetLastError());
-        unsigned long long big[2] = {0, 0};
-        { int rc_ = hgx_d2h(count_host, b_cnt.p, (size_t)A * 8, st); if (rc_) return rc_; }
-        { int rc_ = hgx_d2h(first_host, b_first.p, (size_t)A * 4, st); if (rc_) return rc_; }
-        { int rc_ = hgx_d2h(big, b_big.p, 16, st); if (rc_) return rc_; }
-        { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-        if (!big[0] && big[1] < (1ull << 32)) return HGX_OK;
-    }
-    int rc = hgx_ensure_transposed(c, st);
-    if (rc) return rc;
-    DevBuf b_s, b_f, b_c, b_i;
-    ALLOC(b_s, (size_t)A * 8); ALLOC(b_f, (size_t)A * 8); ALLOC(b_c, (size_t)A * 8); ALLOC(b_i, (size_t)A * 4);
-    const MatVec cols{c->d_bitsT, A, c->c64, c->n_classes};
-    launch_matvec<MODE_SUM>(cols, st, nullptr, nullptr, 0, c->d_count, nullptr, nullptr, nullptr, b_s.as<double>(), nullptr, nullptr, 0);
-    launch_matvec<MODE_MIN>(cols, st, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, b_f.as<double>(), nullptr, nullptr, 0);
-    hipLaunchKernelGGL(k_counts_out, dim3(nblk(A, 256)), dim3(256), 0, st, b_s.as<double>(), b_f.as<double>(), A,
-                       b_c.as<int64_t>(), b_i.as<int32_t>());
-    HIPCHK(hipGetLastError());
-    { int rc_ = hgx_d2h(count_host, b_c.p, (size_t)A * 8, st); if (rc_) return rc_; }
-    { int rc_ = hgx_d2h(first_host, b_i.p, (size_t)A * 4, st); if (rc_) return rc_; }
-    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-    return HGX_OK;
-}
-
 // Test aid: one rows pass (s_c -> w_c = n_c / s_c) or cols pass (t_a) of the EM map with a chosen backend.
 //   which = 0: y[c] = count[c] / sum_a B[c][a] x[a]   (x: a_pad doubles)      -> n_classes doubles
 //   which = 1: y[a] = sum_c B[c][a] x[c]              (x: n_classes doubles)  -> a_pad doubles
@@ -2914,72 +2180,6 @@ extern "C" int hgx_debug_matvec(const hgx_classes *cc, int which, int backend, c
     hgx_set_error("hgx_debug_matvec drives the lab back-ends of the bit mat-vec: build libhgx_lab.so (hisat-genotype_amd/build.py build_lab)");
     return HGX_EINVAL;
 #else
-    ARGCHK(cc && x_host && y_host && (which == 0 || which == 1) && backend >= 1 && backend <= 3);
-    hgx_classes *c = const_cast<hgx_classes *>(cc);
-    const int A = c->a_pad, C = c->n_classes;
-    ARGCHK(C > 0);
-    int rc = hgx_ensure_transposed(c, nullptr);
-    if (rc) return rc;
-    const int nx = which == 0 ? A : C, ny = which == 0 ? C : A;
-    DevBuf b_x, b_y, b_pr, b_pr2, b_scal, b_q;
-    ALLOC(b_x, (size_t)nx * 8); ALLOC(b_y, (size_t)ny * 8); ALLOC(b_pr, (size_t)std::max(nx, ny)); ALLOC(b_pr2, (size_t)std::max(nx, ny));
-    ALLOC(b_scal, S_N * 8); ALLOC(b_q, (size_t)ny * 8);
-    HIPCHK(hipMemcpy(b_x.p, x_host, (size_t)nx * 8, hipMemcpyHostToDevice));
-    HIPCHK(hipMemset(b_pr.p, 1, (size_t)std::max(nx, ny)));
-    HIPCHK(hipMemset(b_scal.p, 0, S_N * 8));
-    std::vector<double> ones(ny, 1.0);
-    HIPCHK(hipMemcpy(b_q.p, ones.data(), (size_t)ny * 8, hipMemcpyHostToDevice));
-    double one = 1.0;
-    HIPCHK(hipMemcpy(b_scal.as<double>() + S_TOT_A, &one, 8, hipMemcpyHostToDevice));
-    MatVec m = which == 0 ? MatVec{c->d_bits, C, c->w64, A} : MatVec{c->d_bitsT, A, c->c64, C};
-    DevBuf b_P;
-#ifdef HGX_LAB
-    if (backend == 2) {
-        const int n_super = m.n_words / 4;
-        const long tiles = (m.n_rows + 15) / 16;
-        const long tiles_pad = (tiles + MF_WAVES - 1) / MF_WAVES * MF_WAVES;
-        const long total = tiles_pad * n_super * 64;
-        ALLOC(b_P, (size_t)total * 8);
-        hipLaunchKernelGGL(k_permute_mfma, dim3(nblk(total, 256)), dim3(256), 0, nullptr, m.B, m.n_rows, m.n_words, n_super, total,
-                           b_P.as<uint64_t>());
-        m.P = b_P.as<uint64_t>();
-        m.n_super = n_super;
-    }
-#else
-    if (backend == 2) { hgx_set_error("hgx_dbg_matvec: back-end 2 is lab code (libhgx_lab.so)"); return HGX_EINVAL; }
-#endif
-    DevBuf b_M, b_part, b_cnt;
-    if (backend == 3) {
-        ALLOC(b_M, (size_t)m.n_words * m.n_rows * 8);
-        hipLaunchKernelGGL(k_word_transpose, dim3((m.n_words + 31) / 32, (m.n_rows + 31) / 32), dim3(256), 0, nullptr, m.B, m.n_rows,
-                           m.n_words, b_M.as<uint64_t>());
-        ALLOC(b_part, (size_t)(m.n_words / 8) * m.n_rows * 8);
-        ALLOC(b_cnt, (size_t)((m.n_rows + BLOCK - 1) / BLOCK) * 4);
-        HIPCHK(hipMemset(b_cnt.p, 0, (size_t)((m.n_rows + BLOCK - 1) / BLOCK) * 4));
-        m.M = b_M.as<uint64_t>(); m.n_pad = m.n_rows; m.part = b_part.as<double>(); m.counters = b_cnt.as<unsigned>();
-    }
-    const int saved = g_backend;
-    g_backend = backend;
-    const int reps = hgx_test_switch("dbg_reps") ? atoi(hgx_test_switch("dbg_reps")) : 1;
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, nullptr);
-    for (int rep = 0; rep < reps; ++rep)
-    if (which == 0)
-        rc = launch_matvec<MODE_ROWS>(m, nullptr, b_x.as<double>(), b_pr.as<uint8_t>(), 0, c->d_count, nullptr, nullptr, nullptr,
-                                      b_y.as<double>(), nullptr, b_scal.as<double>(), 0);
-    else   // q_in = 1, tot = 1, present everywhere: y = t
-        rc = launch_matvec<MODE_COLS>(m, nullptr, b_x.as<double>(), nullptr, 0, nullptr, b_q.as<double>(), b_pr.as<uint8_t>(), nullptr,
-                                      b_y.as<double>(), b_pr2.as<uint8_t>(), b_scal.as<double>(), 0);
-    g_backend = saved;
-    (void)hipEventRecord(e1, nullptr);
-    (void)hipEventSynchronize(e1);
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    if (reps > 1) fprintf(stderr, "[hgx_debug_matvec] which=%d backend=%d: %.2f us per launch\n", which, backend, ms * 1e3 / reps);
-    if (rc) return rc;
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpy(y_host, b_y.p, (size_t)ny * 8, hipMemcpyDeviceToHost));
-    return HGX_OK;
+#include "lab/hgx_em_debug_matvec.inc"
 #endif
 }

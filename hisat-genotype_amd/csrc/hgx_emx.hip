@@ -1162,7 +1162,7 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
     // workgroups; such launches follow each other on the stream (one problem's cluster fills a good part of the chip)
     const bool clusters = allow_cluster && !hgx_test_switch("emx_no_cluster");
     auto wants_cluster = [&](const hgx_emx_job &J) { return clusters && J.any_size && !J.fast && !J.mask && J.C > HGX_EMX_MAX_CLASSES; };
-    const bool stamps = hgx_test_switch("emx_stamps") != nullptr;
+    const bool stamps = HGX_LAB_SWITCH("emx_stamps") != nullptr;
     // scratch of every job out of ONE block; jobs beyond the kernel's limits get status 1 without a descriptor
     struct Lay { size_t Rm, Mk, Mr, dv, pos, tmpv, vlen, cls, din, sorted, first, stamps, cl, end; };
     std::vector<Lay> lays;

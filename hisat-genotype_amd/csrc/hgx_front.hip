@@ -923,9 +923,9 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Pars
     hgx_dbatch *made = nullptr;
     hgx_front_hook hook;
     hook.mem = hgx_front_alloc{pinned_alloc, pinned_release};
-    const bool force = hgx_test_switch("front_device") != nullptr;
-    const bool host_only = hgx_test_switch("front_host") != nullptr;
-    const bool no_records = hgx_test_switch("front_keys_only") != nullptr;
+    const bool force = hgx_switch_has("front", "device");
+    const bool host_only = hgx_switch_has("front", "host");
+    const bool no_records = hgx_switch_has("front", "keys");
     int route = 0;                         // 2 = the record route produced the batch, 1 = the key route, 0 = the host stages
     hook.run = [&](hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, int *declined) {
         if (!force && in.n_rec < 20000) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }     // a dozen launches cost more than a small host decode
@@ -1006,7 +1006,7 @@ int hgx_front_many_dev(hgx_dbatch **out, hgx_front_totals *tot, const hgx_locus 
     hipStream_t st = (hipStream_t)stream;
     g_last_bytes = 0; g_last_route = 0; g_last_device = 0; g_last_decline = 0;
     auto decline = [&](int code) { *declined = code; g_last_decline = code; return (int)HGX_OK; };
-    if (hgx_test_switch("front_host")) { *declined = -1; g_last_decline = -1; return HGX_OK; }
+    if (hgx_switch_has("front", "host")) { *declined = -1; g_last_decline = -1; return HGX_OK; }
     if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange || opts->pileup_exchange) return decline(HGX_FE_DECLINE_OPTS);
     if (n_tasks < 1 || n_tasks > 65535) return decline(HGX_FE_DECLINE_SIZE);
     hgx_many_streams ms;
@@ -1056,9 +1056,9 @@ int hgx_front_many_dev(hgx_dbatch **out, hgx_front_totals *tot, const hgx_locus 
     const size_t total = cursor.load(), n_lines = ms.line_base[(size_t)n_tasks];
     ms.base[(size_t)n_tasks] = total;
     if (ms.mixed) return decline(HGX_FE_DECLINE_OPTS);                   // SAM text and BAM records in one batch: per task on the host
-    if (!hgx_test_switch("front_device") && n_lines < 20000) return decline(HGX_FE_DECLINE_SMALL);
+    if (!hgx_switch_has("front", "device") && n_lines < 20000) return decline(HGX_FE_DECLINE_SMALL);
     if (total >= (1ull << 32) - 64 || n_lines >= (1ull << 30)) return decline(HGX_FE_DECLINE_SIZE);
-    if (late.load() || hgx_test_switch("front_late_upload")) {
+    if (late.load() || hgx_switch_has("front", "late")) {
         HIPCHK(hipStreamSynchronize(st));
         hgx_pool_free(b_text.p);
         b_text.p = nullptr;

@@ -248,6 +248,7 @@ int gene_side(const hgx_index *ix, const hgx_dbatch *db, const uint64_t *compat,
     int32_t A = 0, a_pad = 0;
     int rc = hgx_index_dims(ix, &A, &a_pad, nullptr, nullptr);
     if (rc) return rc;
+#ifdef HGX_LAB
     if (!rows_ready && hgx_test_switch("fused")) {
         // OPT-IN (measured slower): rows claimed / verified against their class' representative by the wavefront
         // that computes them -- no row per pair in memory, no insert pass, no verify pass (hgx_pair_classes_dedup); a key
@@ -257,6 +258,7 @@ int gene_side(const hgx_index *ix, const hgx_dbatch *db, const uint64_t *compat,
         if (rc == HGX_OK) return gene_rank(g.gcl, A, a_pad, st, g);
         if (rc != HGX_ECOLLISION) return rc;
     }
+#endif
     if (!rows_ready) {
         if (opts->ev_pairs_begin) HIPCHK(hipEventRecord((hipEvent_t)opts->ev_pairs_begin, st));
         rc = hgx_pair_classes(ix, compat, db->d_pair_off, db->d_pair_ref, db->n_pairs, nullptr, gene_bits, nullptr, gene_hash, st);
@@ -415,7 +417,7 @@ int type_impl(hgx_typing *t, const hgx_locus *loc, const hgx_index *ix, const hg
     const int w64 = a_pad / 64;
     const bool hla = loc->base_kind == HGX_BASE_HLA;
     const int32_t n_pairs = db->n_pairs;
-    const bool by_list = hla && !opts->per_pair_exon && !hgx_test_switch("no_sig");
+    const bool by_list = hla && !opts->per_pair_exon;
     bool overlap = opts->overlap < 0 ? stream == nullptr : opts->overlap != 0;
     overlap = overlap && hla && n_pairs >= 4096;
 

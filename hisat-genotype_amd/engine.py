@@ -460,7 +460,7 @@ def test_switch(name, value="1"):
 
 
 class test_switches:
-    """with engine.test_switches(em_no_small=1): ...  -- switches set inside the block, cleared after it"""
+    """with engine.test_switches(em_skip="wave"): ...  -- switches set inside the block, cleared after it"""
     def __init__(self, **kw):
         self.kw = kw
 

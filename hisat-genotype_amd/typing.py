@@ -122,7 +122,7 @@ def _em_mode(em_fast):
 
 def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discordant=False,
                remove_low_abundance_alleles=True, simulation=False, base_locus=0, keep_classes=False, stream=None,
-               alignment_file=None, regions=None, gate=None):
+               alignment_file=None, regions=None, gate=None, per_pair_exon=False):
     """Per-locus typing: the reference's loop body with the O(alleles) work on the GPU.  Input: name-grouped SAM text
     (`sam_text`), or `alignment_file` (SAM / BAM; `regions` = samtools region strings, see read_alignment_text) read inside
     libhgx.  `gate` (engine.Gate): shared by the samples in flight on one GPU, see _type_batch."""
@@ -140,7 +140,7 @@ def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discor
         res.n_pieces, res.n_refs = dbatch.n_pieces, dbatch.n_refs
         if dbatch.n_reads <= 0:                                 # core:1589-1590
             return res
-        return _type_batch(pl, None, res, remove_low_abundance_alleles, keep_classes, stream, dbatch=dbatch, gate=gate)
+        return _type_batch(pl, None, res, remove_low_abundance_alleles, keep_classes, stream, dbatch=dbatch, gate=gate, per_pair_exon=per_pair_exon)
     finally:
         dbatch.close()
 
@@ -185,14 +185,14 @@ def _result_from_handle(h, pl, res, keep_classes):
 
 
 def _type_batch(pl, batch, res, remove_low, keep_classes=False, stream=None, dbatch=None, overlap=None, gate=None, events=None,
-                em_fast=False):
+                em_fast=False, per_pair_exon=False):
     """The per-locus body of typing() for one piece batch: ONE call into libhgx (hgx_type_dbatch / hgx_type_batch, which
     orchestrate scoring, grouping, dedup, Gene_counts, both EMs and the hand-off on the GPU; typing_core.py:1589-1789).
     `dbatch`: the batch already resident in HBM (engine.DeviceBatch; bench.py types it repeatedly); `overlap`: None = the
     library's default (gene side beside the exon-level EM when `stream` is None), else forced; `gate` (engine.Gate): several
     samples in flight on one GPU take turns with their bandwidth-bound front; `events` = (compat begin, compat end, pairs
     begin, pairs end) capi.Event objects recorded around hgx_piece_compat and the gene-level hgx_pair_classes launch."""
-    o = TypeOpts(int(bool(remove_low)), int(bool(keep_classes)), -1 if overlap is None else int(bool(overlap)), 0,
+    o = TypeOpts(int(bool(remove_low)), int(bool(keep_classes)), -1 if overlap is None else int(bool(overlap)), int(bool(per_pair_exon)),
                  gate.h if gate is not None else None, *[(e.h if e is not None else None) for e in (events or (None,) * 4)],
                  _em_mode(em_fast))
     h = C.c_void_p()

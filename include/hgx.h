@@ -216,7 +216,8 @@ int hgx_level_classes_grouped(hgx_classes **out, const hgx_index *ix, const uint
  * as the class' representative, every later one is compared with it word for word (the exact check) and never stored.
  * rows_scratch_dev: [n_pairs][a_pad/64] (only representatives are written).  Same class set, counts, first pairs and order as
  * the two-call form; a 64-bit key shared by DIFFERENT rows (never seen on real data) returns HGX_ECOLLISION and the caller uses
- * the two-call form, which resolves collisions. */
+ * the two-call form, which resolves collisions.  LAB LIBRARY ONLY (libhgx_lab.so: measured slower than the two-call form, kept for
+ * comparison): libhgx.so exports the symbol and returns HGX_EINVAL. */
 int hgx_pair_classes_dedup(hgx_classes **out, const hgx_index *ix, const uint64_t *compat_dev, const int32_t *pair_off_dev,
                            const uint32_t *pair_ref_dev, int32_t n_pairs, int32_t level, uint64_t *rows_scratch_dev, void *stream);
 

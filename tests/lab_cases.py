@@ -124,7 +124,7 @@ def test_narrow_table_form_agrees_with_the_product_path():
             ln = lens if use_len else None
             cl = engine.Classes.from_host(rows, counts, a_pad)
             p_ref, it_ref = cl.em(A, low, ln)
-            for extra in ({}, {"l4_rows": 32}, {"em_no_fuse": 1}):
+            for extra in ({}, {"l4_rows": 32}, {"em_skip": "fuse"}):
                 with engine.test_switches(em_lut4=1, **extra):
                     cl2 = engine.Classes.from_host(rows, counts, a_pad)
                     p, it = cl2.em(A, low, ln)
@@ -175,12 +175,84 @@ def test_round2_mid_size_em_is_the_reference_bit_for_bit(orc):
                 continue
             exp = np.full(A, -1.0)
             exp[oa] = op
-            with engine.test_switches(em_no_emx=1, em_mid_nnz=100000000):
+            with engine.test_switches(em_skip="emx", em_mid_nnz=100000000):
                 p1, it1 = cl.em(A, low, None)
                 assert engine.em_last_exact() and it1 == oit and np.array_equal(p1, exp)
             if C_ <= 64:
-                with engine.test_switches(em_no_emx=1, em_no_mid=1, em_no_wave=1):
+                with engine.test_switches(em_skip="emx,wave", em_no_mid=1):
                     p2, it2 = cl.em(A, low, None)
                 assert it2 == oit and np.max(np.abs(p2 - exp)) <= 1e-9
             ran += 1
     assert ran >= 4
+
+
+# ---- round 2's fused gene-level form (hgx_pair_classes_dedup: csrc/lab/hgx_fused_*.inc) ---------------------------------------------
+@pytest.mark.parametrize("name", ["hla_small_pair", "hla_mid_real", "hla_errors_filters", "hla_novel_sample", "hla_7000", "codis_like"])
+def test_fused_pair_classes_dedup_equals_two_call_form(name):
+    """hgx_pair_classes_dedup (rows claimed / verified in registers, only representatives stored) == hgx_pair_classes +
+    hgx_dedup_classes: bit rows, counts, first pairs, order -- on both levels."""
+    fx = gu.load(name)
+    loc = fx["_locus"]
+    pl = hl.PackedLocus.from_synth(loc)
+    o = fx["options"]
+    batch = pl.parse_sam(fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"], allow_discordant=o["allow_discordant"],
+                         simulation=o["simulation"])
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    hla = loc.base_fname == "hla"
+    for level in ((0, 1) if hla else (1,)):
+        rows, hashes = (bufs.exon_bits, bufs.exon_hash) if level == 0 else (bufs.gene_bits, bufs.gene_hash)
+        want = engine.Classes.dedup(rows, batch.n_pairs, pl.a_pad, hashes=hashes).to_host()
+        rows.zero()
+        got = engine.Classes.of_pairs_fused(pl, db, bufs, level).to_host()
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y)
+
+
+def test_fused_pair_classes_dedup_at_size_and_with_zero_rows():
+    """200 k pairs of the bench locus (hot classes: a fifth of the pairs share one class; > 65 536 rows), pairs without refs
+    at the level (all-zero rows are dropped) and pairs with hundreds of refs (the slab-wise path) through the fused form."""
+    from hisatgenotype_amd import synth
+    loc = synth.make_hla_like_locus(n_alleles=7000, n_vars=2500, seed=101)
+    sample = synth.pick_sample(loc, 103)
+    sam = synth.simulate_sam_fast(loc, sample, 200000, err_rate=0.002, seed=7)
+    pl = hl.PackedLocus.from_synth(loc)
+    batch = pl.parse_sam(sam)
+    db = engine.DeviceBatch(batch)
+    bufs = engine.ScoreBuffers(pl, db)
+    engine.score_pairs(pl, db, bufs)
+    want = engine.Classes.dedup(bufs.gene_bits, batch.n_pairs, pl.a_pad, hashes=bufs.gene_hash).to_host()
+    bufs.gene_bits.zero()
+    for _ in range(3):                                   # repeated: stale representatives of an earlier run must not matter
+        got = engine.Classes.of_pairs_fused(pl, db, bufs, 1).to_host()
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y)
+    assert want[1].sum() == batch.n_pairs and want[1].max() > batch.n_pairs // 10
+    # small hand-made batch: pairs with no refs at the exon level, duplicates, and a 400-ref pair
+    t = tables.oracle_tables(loc)
+    rng = np.random.RandomState(9)
+    names = [n for n in loc.allele_names[1:] if n in loc.allele_vars]
+    pair_off, level, left, right, id_off, ids = [0], [], [], [], [0], []
+    def piece(lv):
+        l = int(rng.randint(0, len(loc.backbone) - 200)); r = l + int(rng.randint(1, 150))
+        a = names[rng.randint(len(names))]
+        vs = [v for v in loc.allele_vars[a] if l <= loc.var_pos[v] <= r]
+        level.append(lv); left.append(l); right.append(r); ids.extend(vs); id_off.append(len(ids))
+    for n_refs, lvls in ((2, (1,)), (0, ()), (3, (0, 1)), (400, (0, 1)), (1, (1,)), (2, (0, 1))):
+        for _ in range(n_refs):
+            for lv in lvls:
+                piece(lv)
+        pair_off.append(len(level))
+    arrs = (np.array(pair_off, np.int32), np.array(level, np.uint8), np.array(left, np.int32), np.array(right, np.int32),
+            np.array(id_off, np.int32), np.array(ids or [0], np.int32))
+    b2 = pl.batch_from_haplotypes(*arrs)
+    d2 = engine.DeviceBatch(b2)
+    f2 = engine.ScoreBuffers(pl, d2)
+    engine.score_pairs(pl, d2, f2)
+    for lv, rows, hs in ((0, f2.exon_bits, f2.exon_hash), (1, f2.gene_bits, f2.gene_hash)):
+        want = engine.Classes.dedup(rows, b2.n_pairs, pl.a_pad, hashes=hs).to_host()
+        rows.zero()
+        got = engine.Classes.of_pairs_fused(pl, d2, f2, lv).to_host()
+        for x, y in zip(got, want):
+            assert np.array_equal(x, y)

@@ -44,15 +44,15 @@ def test_switches_live_in_the_process_not_in_the_environment(monkeypatch):
     L = capi.lib()
     L.hgx_test_switch.restype = C.c_char_p
     monkeypatch.setenv("HGX_EM_NO_EMX", "1")
-    assert L.hgx_test_switch(b"em_no_emx") is None
-    engine.test_switch("em_no_emx", "1")
+    assert L.hgx_test_switch(b"em_skip") is None
+    engine.test_switch("em_skip", "emx")
     engine.test_switch("em_mid_nnz", 123)
-    assert L.hgx_test_switch(b"em_no_emx") == b"1" and L.hgx_test_switch(b"em_mid_nnz") == b"123"
-    engine.test_switch("em_no_emx", None)
-    assert L.hgx_test_switch(b"em_no_emx") is None and L.hgx_test_switch(b"em_mid_nnz") == b"123"
-    with engine.test_switches(front_host=1):
-        assert L.hgx_test_switch(b"front_host") == b"1"
-    assert L.hgx_test_switch(b"front_host") is None
+    assert L.hgx_test_switch(b"em_skip") == b"emx" and L.hgx_test_switch(b"em_mid_nnz") == b"123"
+    engine.test_switch("em_skip", None)
+    assert L.hgx_test_switch(b"em_skip") is None and L.hgx_test_switch(b"em_mid_nnz") == b"123"
+    with engine.test_switches(front="host"):
+        assert L.hgx_test_switch(b"front") == b"host"
+    assert L.hgx_test_switch(b"front") is None
     engine.test_switch(None)
     assert L.hgx_test_switch(b"em_mid_nnz") is None
 

@@ -38,7 +38,7 @@ def test_device_front_end_equals_the_host_front_end_on_every_fixture(name):
               simulation=o["simulation"])
     host = pl.parse_sam(fx["sam"], **kw)
     hd = engine.DeviceBatch(host)
-    for switches, want in ((dict(front_device=1), 2), (dict(front_device=1, front_keys_only=1), 1)):
+    for switches, want in ((dict(front="device"), 2), (dict(front="device,keys"), 1)):
         with engine.test_switches(**switches):             # (the fixtures are smaller than the size gate)
             dev = pl.parse_sam_dev(fx["sam"], **kw)
             route, code = engine.front_last()
@@ -67,7 +67,7 @@ def test_record_route_on_files(name, tmp_path):
     bamio.write_bam_native(p_bam, fx["sam"].encode(), [(loc.ref_allele, len(loc.backbone))])
     bamio.write_bam_native(p_sorted, fx["sam"].encode(), [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
     for path in (p_sam, p_bam, p_sorted):
-        with engine.test_switches(front_device=1):
+        with engine.test_switches(front="device"):
             dev = pl.parse_alignment_file_dev(path, regions=[loc.ref_allele], **kw)
             route, code = engine.front_last()
         assert (route, code) == ((0, 1) if name == "codis_d18s51" else (2, 0)), (path, route, code)
@@ -81,7 +81,7 @@ def test_size_gate_and_switches():
     dev = pl.parse_sam_dev(fx["sam"], simulation=True)
     assert engine.front_last() == (0, 6)                   # a few hundred records: the host stages finish the job
     same_batch(host, dev.to_host(), len(fx["_locus"].backbone), pileup=False)
-    with engine.test_switches(front_host=1):
+    with engine.test_switches(front="host"):
         dev = pl.parse_sam_dev(fx["sam"], simulation=True)
         assert engine.front_last() == (0, -1)
     same_batch(host, dev.to_host(), len(fx["_locus"].backbone), pileup=False)
@@ -99,11 +99,11 @@ def test_device_front_end_on_fuzz_cases():
             try:
                 host = pl.parse_sam(sam, error_correction=ec, allow_discordant=single)
             except capi.HgxError:
-                with engine.test_switches(front_device=1), pytest.raises(capi.HgxError):
+                with engine.test_switches(front="device"), pytest.raises(capi.HgxError):
                     pl.parse_sam_dev(sam, error_correction=ec, allow_discordant=single)
                 continue
-            for extra in ({}, {"front_keys_only": 1}):
-                with engine.test_switches(front_device=1, **extra):
+            for extra in ("device", "device,keys"):
+                with engine.test_switches(front=extra):
                     dev = pl.parse_sam_dev(sam, error_correction=ec, allow_discordant=single)
                     ran, code = engine.front_last()
                 n_all += 1
@@ -129,7 +129,7 @@ def test_device_front_end_on_deep_samples_and_files(tmp_path, n_pairs, err):
     dev = pl.parse_sam_dev(sam)
     assert engine.front_last() == (2, 0)
     same_batch(host, dev.to_host(), len(loc.backbone))
-    with engine.test_switches(front_keys_only=1):
+    with engine.test_switches(front="keys"):
         dev = pl.parse_sam_dev(sam)
         assert engine.front_last() == (1, 0)
     same_batch(host, dev.to_host(), len(loc.backbone))

@@ -24,3 +24,12 @@ def test_product_library_has_no_lab_backend():
     with pytest.raises(capi.HgxError):
         engine.em_set_backend(2)
     engine.em_set_backend(0)
+
+
+def test_product_library_has_no_fused_gene_level_form():
+    """hgx_pair_classes_dedup (round 2's fused gene-level form, measured slower) lives in the lab library; libhgx.so says so."""
+    import ctypes as C
+    from hisatgenotype_amd import capi
+    h = C.c_void_p()
+    rc = capi.lib().hgx_pair_classes_dedup(C.byref(h), None, None, None, None, C.c_int32(0), C.c_int32(1), None, None)
+    assert rc != 0 and b"lab" in capi.lib().hgx_last_error()

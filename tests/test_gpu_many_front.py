@@ -58,7 +58,7 @@ def test_many_samples_in_one_device_pass(tmp_path):
     sams = _samples(loc, 5, 900, 21, err=0.01)
     sams = sams[:2] + [""] + sams[2:] + [sams[0]]
     host = engine.ManyBatch(pl, [pl.parse_sam(s) for s in sams])
-    with engine.test_switches(front_device=1):
+    with engine.test_switches(front="device"):
         dev = engine.ManyBatch.from_sams(pl, sams)
         assert engine.front_last() == (2, 0)
     same_many(dev, host)
@@ -70,25 +70,25 @@ def test_many_samples_in_one_device_pass(tmp_path):
         p_bam.append(str(tmp_path / ("t%d.bam" % t)))
         bamio.write_bam_native(p_bam[-1], s.encode(), [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=(t % 2 == 1))
     for paths in (p_sam, p_bam):
-        with engine.test_switches(front_device=1):
+        with engine.test_switches(front="device"):
             dev = engine.ManyBatch.from_files(pl, paths, regions=[loc.ref_allele] * len(paths))
             assert engine.front_last() == (2, 0)
         same_many(dev, host)
-    with engine.test_switches(front_device=1, front_late_upload=1):                   # the buffer estimate was too small: sent again after the reads
+    with engine.test_switches(front="device,late"):                   # the buffer estimate was too small: sent again after the reads
         dev = engine.ManyBatch.from_files(pl, p_bam, regions=[loc.ref_allele] * len(p_bam))
         assert engine.front_last() == (2, 0)
     same_many(dev, host)
-    with engine.test_switches(front_device=1):                                        # on a stream of the caller's
+    with engine.test_switches(front="device"):                                        # on a stream of the caller's
         dev = engine.ManyBatch.from_files(pl, p_bam, regions=[loc.ref_allele] * len(p_bam), stream=capi.get_stream(1))
         assert engine.front_last() == (2, 0)
     same_many(dev, host)
     # where the device front end declines, the host front end runs task by task: the same batch again
-    for switches, want in ((dict(front_host=1), (0, -1)), (dict(), (0, 6))):          # (6: fewer records than the size gate)
+    for switches, want in ((dict(front="host"), (0, -1)), (dict(), (0, 6))):          # (6: fewer records than the size gate)
         with engine.test_switches(**switches):
             dev = engine.ManyBatch.from_files(pl, p_bam, regions=[loc.ref_allele] * len(p_bam))
             assert engine.front_last() == want, engine.front_last()
         same_many(dev, host)
-    with engine.test_switches(front_device=1):
+    with engine.test_switches(front="device"):
         dev = engine.ManyBatch.from_files(pl, [p_sam[0], p_bam[1]])                  # SAM text and BAM records in one batch
         assert engine.front_last() == (0, 1)
     same_many(dev, engine.ManyBatch(pl, [pl.parse_sam(sams[0]), pl.parse_sam(sams[1])]))
@@ -109,7 +109,7 @@ def test_many_front_on_fixtures(name):
         cut += 1
     sams = [fx["sam"], "".join(lines[:cut]), fx["sam"]]
     host = engine.ManyBatch(pl, [pl.parse_sam(s, **kw) for s in sams])
-    with engine.test_switches(front_device=1):
+    with engine.test_switches(front="device"):
         dev = engine.ManyBatch.from_sams(pl, sams, **kw)
         assert engine.front_last() == (2, 0), engine.front_last()
     same_many(dev, host)
@@ -143,10 +143,10 @@ def test_many_front_on_fuzz_cases():
             host = engine.ManyBatch(pl, [pl.parse_sam(s, allow_discordant=single) for s in sams])
         except capi.HgxError:
             with pytest.raises(capi.HgxError):
-                with engine.test_switches(front_device=1):
+                with engine.test_switches(front="device"):
                     engine.ManyBatch.from_sams(pl, sams, allow_discordant=single)
             continue
-        with engine.test_switches(front_device=1):
+        with engine.test_switches(front="device"):
             dev = engine.ManyBatch.from_sams(pl, sams, allow_discordant=single)
             route, _ = engine.front_last()
         n_all += 1

@@ -381,18 +381,17 @@ def test_concurrent_samples_give_identical_results():
 @pytest.mark.parametrize("name", ["hla_small_pair", "hla_mid_real", "hla_errors_filters", "hla_7000"])
 def test_grouped_exon_path_equals_per_pair_path(name, monkeypatch):
     """type_locus through hgx_level_classes (pairs grouped by exon-level ref list, the default) and through the per-pair rows +
-    dedup (test switch no_sig) give the same classes, counts, EM results and report."""
+    dedup (hgx_type_opts.per_pair_exon) give the same classes, counts, EM results and report."""
     fx = gu.load(name)
     o = fx["options"]
     pl = hl.PackedLocus.from_synth(fx["_locus"])
 
-    def run():
+    def run(per_pair):
         return hgx.type_locus(pl, fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
                               allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
-                              simulation=o["simulation"], keep_classes=True)
-    a = run()
-    engine.test_switch("no_sig", "1")
-    b = run()
+                              simulation=o["simulation"], keep_classes=True, per_pair_exon=per_pair)
+    a = run(False)
+    b = run(True)
     assert a.em == b.em and a.gene_prob == b.gene_prob
     for x, y in zip(a.exon_classes, b.exon_classes):
         assert np.array_equal(x, y)
@@ -409,8 +408,7 @@ def test_grouped_exon_path_equals_per_pair_path_at_size(monkeypatch):
     sam = synth.simulate_sam_fast(loc, sample, 200000, err_rate=0.002, seed=7)
     pl = hl.PackedLocus.from_synth(loc)
     a = hgx.type_locus(pl, sam)
-    engine.test_switch("no_sig", "1")
-    b = hgx.type_locus(pl, sam)
+    b = hgx.type_locus(pl, sam, per_pair_exon=True)
     assert a.em == b.em and a.gene_prob == b.gene_prob
     assert np.array_equal(a.counts, b.counts) and np.array_equal(a.counts_order, b.counts_order)
 

@@ -27,10 +27,10 @@ for case in [(7000, 4549, 1600, 0.25), (3000, 1949, 1340, 0.27), (500, 323, 704,
         dt = time.perf_counter() - t0
     engine.em_set_fast(False)
     print("   fast mode: iters", itf, "call %.2f ms" % (dt * 1e3), "max |diff| %.3g" % float(np.max(np.abs(p - pf))), flush=True)
-    engine.test_switch("em_no_emx", "1"); engine.test_switch("em_no_mid", "1")
+    engine.test_switch("em_skip", "emx"); engine.test_switch("em_no_mid", "1")
     for rep in range(2):
         t0 = time.perf_counter()
         p2, it2 = cl.em(A, True, None)
         dt = time.perf_counter() - t0
-    engine.test_switch("em_no_emx", None); engine.test_switch("em_no_mid", None)
+    engine.test_switch("em_skip", None); engine.test_switch("em_no_mid", None)
     print("   table-lookup path: iters", it2, "call %.2f ms" % (dt * 1e3), "max |diff| %.3g" % float(np.max(np.abs(p - p2))), flush=True)

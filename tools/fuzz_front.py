@@ -22,17 +22,17 @@ for k in range(n_cases):
         try:
             host = pl.parse_sam(sam, error_correction=ec, allow_discordant=single)
         except capi.HgxError as e:
-            for extra in ({}, {"front_keys_only": 1}):
+            for extra in ("device", "device,keys"):
                 try:
-                    with engine.test_switches(front_device=1, **extra):
+                    with engine.test_switches(front=extra):
                         pl.parse_sam_dev(sam, error_correction=ec, allow_discordant=single)
                     print("case %d seed %d: host raised %r, device did not" % (k, seed0 + k, e)); bad += 1
                 except capi.HgxError:
                     pass
             continue
         L = len(loc.backbone)
-        for extra in ({}, {"front_keys_only": 1}):
-            with engine.test_switches(front_device=1, **extra):
+        for extra in ("device", "device,keys"):
+            with engine.test_switches(front=extra):
                 dev = pl.parse_sam_dev(sam, error_correction=ec, allow_discordant=single)
                 route, code = engine.front_last()
             routes[(route, code)] = routes.get((route, code), 0) + 1
