@@ -1896,12 +1896,6 @@ static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low,
             nb = std::min(batch, 11 - launched_iters);
             if (launched_iters == batch && h_scal[S_DIFF] > 0.001) nb = 11 - launched_iters;
         }
-        {   // EXPERIMENT (measurement of the host syncs' cost): HGX_EM_BATCH1 = iterations before the first sync, HGX_EM_BATCH = after
-            static const int b1 = getenv("HGX_EM_BATCH1") ? atoi(getenv("HGX_EM_BATCH1")) : 0;
-            static const int bn = getenv("HGX_EM_BATCH") ? atoi(getenv("HGX_EM_BATCH")) : 0;
-            if (b1 > 0 && launched_iters == 0) nb = b1;
-            else if (bn > 0 && launched_iters > 0) nb = (use_tail && remove_low && launched_iters < 11) ? std::max(1, std::min(bn, 11 - launched_iters)) : bn;
-        }
         if (grid && use_tail && remove_low && launched_iters < 11) nb = 11 - launched_iters;    // no host sync inside: up to the first pruning
         launched_iters += nb;
         if (grid) {
