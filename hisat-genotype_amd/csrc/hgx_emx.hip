@@ -115,6 +115,15 @@ __device__ __forceinline__ void phase_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// agent-scope 8- / 4-byte accesses (global_load / global_store ... sc1): what a table-lookup cluster hands over goes through these on
+// both sides, so its hand-overs need no cache write-back or invalidate (MI355X_MICROARCH.md, "8-B agent atomics both sides")
+typedef __attribute__((address_space(1))) double gdouble_t;
+typedef __attribute__((address_space(1))) unsigned int guint_t;
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load((const gdouble_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store((gdouble_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned int ld_agent(const unsigned int *p) { return __hip_atomic_load((const guint_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(unsigned int *p, unsigned int v) { __hip_atomic_store((guint_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 struct XLds {
     double tmpo[2][XA];                        // operands of a sequential sum in insertion order ([1] doubles as sort scratch and,
                                                // during the set-up, as the name-ordered allele list; [0] as row buffers there)
@@ -207,11 +216,14 @@ __device__ __forceinline__ double xlut_row(const double *Tb, const uint64_t (&w)
 // co-resident in time gives up and the caller runs the problem on one workgroup).  Same sums in the same orders: same bits.
 template <bool FAST, bool CL = false>
 __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, int n_tasks) {
-    static_assert(!(FAST && CL), "cluster mode is for the reference-order arithmetic");
     extern __shared__ double xlds_raw[];
     XLds &S = *reinterpret_cast<XLds *>(xlds_raw);
     int t_idx = CL ? 0 : (int)blockIdx.x;
-    if constexpr (CL) {                                   // several clusters side by side: mine is the one whose block range holds me
+    if constexpr (CL && FAST) {                           // every task of the launch has a block range, in task order: bisection
+        int lo = 0, hi = n_tasks - 1;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tasks[mid].cl_first <= (int)blockIdx.x) lo = mid; else hi = mid - 1; }
+        t_idx = lo;
+    } else if constexpr (CL) {                            // several clusters side by side: mine is the one whose block range holds me
         for (int k = 0; k < n_tasks; ++k)
             if (tasks[k].cluster > 0 && (int)blockIdx.x >= tasks[k].cl_first && (int)blockIdx.x < tasks[k].cl_first + tasks[k].cluster) t_idx = k;
     }
@@ -225,6 +237,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
     bool cl_dead = false;
     auto cluster_sync = [&]() {
         if constexpr (CL) {
+            if (n_wg == 1) return;                         // (a table-lookup launch seats most problems on one workgroup)
             cl_phase += 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -249,6 +262,32 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
             __builtin_amdgcn_s_dcache_inv();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __syncthreads();
+        }
+    };
+    // hand-over of a table-lookup cluster: the bytes travel as agent-scope stores and loads (st_agent / ld_agent), so the barrier is
+    // only the counter -- stores drained, one lane adds and polls, the workgroup's barrier releases the other wavefronts
+    auto cluster_sync_light = [&]() {
+        if constexpr (CL) {
+            if (n_wg == 1) return;
+            cl_phase += 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                bool ok = !cl_dead;
+                if (ok) {
+                    __hip_atomic_fetch_add(&T.cl_ctl[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned target = (unsigned)n_wg * (unsigned)cl_phase;
+                    long spins = 0;
+                    while (__hip_atomic_load(&T.cl_ctl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                        if (__hip_atomic_load(&T.cl_ctl[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+                        if (++spins > (long)T.cl_spins) { __hip_atomic_store(&T.cl_ctl[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok = false; break; }
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                S.cl_ok = ok ? 1 : 0;
+            }
+            __syncthreads();
+            if (!S.cl_ok) cl_dead = true;
         }
     };
     const int w64 = T.w64, A1s = T.a_pad;
@@ -471,8 +510,11 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
     }
     lap(0);
 
-    double *dv[3] = {T.dv, T.dv + A1s, T.dv + 2 * (size_t)A1s};
-    uint8_t *din[3] = {T.din, T.din + A1s, T.din + 2 * (size_t)A1s};
+    // (table-lookup cluster: every workgroup keeps the three dicts for itself -- the vector steps are done by all of them alike, only
+    // the two matrix passes are shared out -- so nothing but n_c and the raw result of a cols pass ever changes hands)
+    const size_t dict_of_wg = (FAST && CL) ? (size_t)wg * 3 * (size_t)A1s : 0;
+    double *dv[3] = {T.dv + dict_of_wg, T.dv + dict_of_wg + A1s, T.dv + dict_of_wg + 2 * (size_t)A1s};
+    uint8_t *din[3] = {T.din + dict_of_wg, T.din + dict_of_wg + A1s, T.din + dict_of_wg + 2 * (size_t)A1s};
     double *tmpo0 = &S.tmpo[0][0], *tmpo1 = &S.tmpo[1][0];
     const int A1p8 = (A1 + 7) & ~7;
     int n_orders = 0, n_apps = 0;                       // (applications of the EM map: what the byte model of a launch is counted in)
@@ -750,7 +792,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
     };
 
     int prob = 0, next = 1, next2 = 2;
-    if (wg == 0)
+    if (wg == 0 || (FAST && CL))
         for (int j = tid; j < A1s; j += XB)
             for (int d = 0; d < 3; ++d) { dv[d][j] = 0.0; din[d][j] = 0; }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -762,6 +804,19 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
         // ---- the same EM with table-lookup mat-vecs and tree reductions (any summation order): T(p)_a = p_a * sum_c n_c / s_c ----
         double *Tb = &S.tmpo[0][0];                        // [64][256]
         auto drain = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); };
+        // cluster (k_emx<true, true>): the lookups of a pass are shared out by WAVEFRONT (wave w of every 1 024-row tile belongs to
+        // workgroup w % n_wg: the passes are bound by VALU issue, so half the wavefronts take half the time); the tables are
+        // built by every workgroup.  A rows pass hands over n_c, a cols pass its raw sums and membership flags (vraw / vin);
+        // everything else every workgroup does for itself, on its own dicts, bit for bit what one workgroup does.
+        // whole 1 024-row tiles where a pass has at least one per workgroup (a tile's time does not depend on how many of its
+        // wavefronts look up), else the wavefronts of the tiles
+        const int tiles_c = (Cp + XB - 1) / XB, tiles_a = (64 * A1w + XB - 1) / XB;
+        auto mine_of = [&](int k, int n_tiles) -> bool {
+            if constexpr (!CL) return true;
+            return n_tiles >= n_wg ? (k % n_wg) == wg : (wave % n_wg) == wg;
+        };
+        double *vraw = T.tmpv;
+        unsigned int *vin = reinterpret_cast<unsigned int *>(T.pos);
         auto block_sum = [&](double v) __attribute__((always_inline)) -> double {
             v = wave_sum_f64(v);
             __syncthreads();
@@ -773,12 +828,16 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
             return t;
         };
         // y_j = sum over the classes of x_c [class contains j], for every compact allele j; lane = allele, 512 classes per table
-        auto cols_lut = [&](const double *x, double (&acc)[8]) __attribute__((always_inline)) {
+        // y_j = sum over the classes of x_c [class contains j], for every compact allele j; lane = allele, 512 classes per table.
+        // (A (slab, tile) unit is 64 lookups per lane = 512 KB of LDS reads per workgroup: ~1.7 us at the CU's 128 B per clock, and
+        // the units measure 2.0-2.3 us -- the passes sit on the LDS pipe; requesting the next unit's matrix words ahead of the
+        // lookups changed nothing but the spill count: NOTEBOOK.md section 11.)
+        auto cols_lut = [&](const double *x, bool handed, double (&acc)[8]) __attribute__((always_inline)) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) acc[k] = 0.0;
             for (int sl = 0; sl * 512 < Cp; ++sl) {
                 __syncthreads();
-                if (tid < 512) { const int c = 512 * sl + tid; S.xs[tid] = c < Cp ? x[c] : 0.0; }
+                if (tid < 512) { const int c = 512 * sl + tid; S.xs[tid] = c < Cp ? ((CL && handed) ? ld_agent(&x[c]) : x[c]) : 0.0; }
                 __syncthreads();
                 xlut_build(S.xs, Tb, tid);
                 __syncthreads();
@@ -786,7 +845,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
                 for (int k = 0; k < 8; ++k) {
                     int j = tid + XB * k;
                     asm volatile("" : "+v"(j));            // (addresses formed here, not kept in 128 registers across the slabs)
-                    if (j < 64 * A1w) {
+                    if (j < 64 * A1w && mine_of(k, tiles_a)) {
                         uint64_t w[8];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) { const int cw = 8 * sl + i; w[i] = cw < Cw ? T.Mr[(size_t)cw * A1s + j] : 0ull; }
@@ -810,7 +869,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
                 for (int k = 0; k < 4; ++k) {
                     int c = tid + XB * k;
                     asm volatile("" : "+v"(c));
-                    if (c < Cp) {
+                    if (c < Cp && mine_of(k, tiles_c)) {
                         uint64_t w[8];
 #pragma unroll
                         for (int i = 0; i < 8; ++i) { const int aw = 8 * sl + i; w[i] = aw < A1w ? T.Mk[(size_t)aw * CpA + c] : 0ull; }
@@ -822,13 +881,37 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int c = tid + XB * k;
-                if (c < Cp) n_c[c] = (c < C && sacc[k] > 0.0) ? cnt_c[c] / sacc[k] : 0.0;       // classes with alleles_prob <= 0 are skipped
+                if (c < Cp && mine_of(k, tiles_c)) {          // classes with alleles_prob <= 0 are skipped
+                    const double v = (c < C && sacc[k] > 0.0) ? cnt_c[c] / sacc[k] : 0.0;
+                    if constexpr (CL) st_agent(&n_c[c], v); else n_c[c] = v;
+                }
             }
             drain();
+            cluster_sync_light();                          // (cluster: n_c is complete)
             lap(1);
             double acc[8];
-            cols_lut(n_c, acc);
+            cols_lut(n_c, true, acc);
             double part = 0.0;
+            if constexpr (CL) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int j = tid + XB * k;
+                    if (j < A1 && mine_of(k, tiles_a)) {
+                        const bool nin = din[P][j] != 0 && acc[k] > 0.0;
+                        double v = nin ? dv[P][j] * acc[k] : 0.0;
+                        if (use_len) v = v / T.vlen[j];
+                        st_agent(&vraw[j], v);
+                        st_agent(&vin[j], nin ? 1u : 0u);
+                    }
+                }
+                drain();
+                cluster_sync_light();                      // (every allele's raw value is there)
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int j = tid + XB * k;
+                    if (j < A1) { const double v = ld_agent(&vraw[j]); dv[N][j] = v; din[N][j] = (uint8_t)ld_agent(&vin[j]); part += v; }
+                }
+            } else {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int j = tid + XB * k;
@@ -840,6 +923,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
                     din[N][j] = nin ? 1 : 0;
                     part += v;
                 }
+            }
             }
             const double total = block_sum(part);
 #pragma unroll
@@ -860,11 +944,20 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
         };
         {   // initial estimate (common:1300-1309)
             double acc[8], part = 0.0;
-            cols_lut(t0_c, acc);
+            cols_lut(t0_c, false, acc);
+            if constexpr (CL) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int j = tid + XB * k;
+                    if (j < A1 && mine_of(k, tiles_a)) st_agent(&vraw[j], use_len ? acc[k] / T.vlen[j] : acc[k]);
+                }
+                drain();
+                cluster_sync_light();
+            }
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 const int j = tid + XB * k;
-                if (j < A1) { const double v = use_len ? acc[k] / T.vlen[j] : acc[k]; dv[prob][j] = v; din[prob][j] = 1; part += v; }
+                if (j < A1) { const double v = CL ? ld_agent(&vraw[j]) : (use_len ? acc[k] / T.vlen[j] : acc[k]); dv[prob][j] = v; din[prob][j] = 1; part += v; }
             }
             const double total = block_sum(part);
 #pragma unroll
@@ -872,7 +965,7 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
             drain();
             lap(5);
         }
-        while (diff > 0.0001 && iter < 1000) {             // common:1351
+        while (diff > 0.0001 && iter < 1000 && !cl_dead) { // common:1351
             next_fast(prob, next);
             next_fast(next, next2);
             bool bad = false;
@@ -908,6 +1001,10 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
             if (iter >= 10 && remove_low) select_fast(prob);
             iter += 1;
             lap(6);
+        }
+        if constexpr (CL) {
+            if (cl_dead) { if (wg == 0) give_up(3.0); return; }     // (not co-resident in time: status 3, the caller re-runs the job on one workgroup)
+            if (wg != 0) return;                           // (the result is the leader's to report)
         }
         if (!keyerr) {
             if (remove_low) select_fast(prob);
@@ -1157,11 +1254,34 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_emx<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(XLds)));
     });
     // cluster mode: a problem far beyond the default gate (the any-size mode of hgx_em / hgx_type_*) gets a launch of its own on several
     // workgroups; such launches follow each other on the stream (one problem's cluster fills a good part of the chip)
     const bool clusters = allow_cluster && !hgx_test_switch("emx_no_cluster");
     auto wants_cluster = [&](const hgx_emx_job &J) { return clusters && J.any_size && !J.fast && !J.mask && J.C > HGX_EMX_MAX_CLASSES; };
+    // table-lookup problems: while a launch leaves CUs idle (a single sample, a few samples), its big problems run on two or four
+    // workgroups each (k_emx<true, true>: the tiles of the two matrix passes shared out, hand-overs through agent-scope loads
+    // and stores; 3.45 -> 2.48 -> 2.29 ms for a 1 456-class x 4 500-allele problem).  A full panel keeps one workgroup per
+    // problem: its launch is as long as its longest problem either way (6.28 -> 6.07 ms with pairs), and an oversubscribed chip
+    // is where a pair may have to wait for a seat.  test switch emx_fast_wg = N: N workgroups for EVERY table-lookup problem.
+    const char *fwg_sw = hgx_test_switch("emx_fast_wg");
+    static const int n_cu_f = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        return (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }();
+    int n_big_fast = 0, n_fast = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        n_fast += jobs[i].fast ? 1 : 0;
+        n_big_fast += (jobs[i].fast && !jobs[i].mask && (int64_t)jobs[i].C * jobs[i].a_pad >= (int64_t)768 * 4096) ? 1 : 0;
+    }
+    const int wg_for_big = (n_fast + 3 * n_big_fast <= n_cu_f / 2) ? 4 : (n_fast + n_big_fast <= n_cu_f / 2) ? 2 : 1;
+    auto fast_wg = [&](const hgx_emx_job &J) -> int {
+        if (!clusters || !J.fast || J.mask) return 1;
+        if (fwg_sw) return std::max(1, std::min(8, atoi(fwg_sw)));
+        return (int64_t)J.C * J.a_pad >= (int64_t)768 * 4096 ? wg_for_big : 1;
+    };
     const bool stamps = HGX_LAB_SWITCH("emx_stamps") != nullptr;
     // scratch of every job out of ONE block; jobs beyond the kernel's limits get status 1 without a descriptor
     struct Lay { size_t Rm, Mk, Mr, dv, pos, tmpv, vlen, cls, din, sorted, first, stamps, cl, end; };
@@ -1184,12 +1304,13 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
         L.Rm = o; o += up64(J.mask ? 64 : Cp * A1s / 64 * 8);
         L.Mk = o; o += up64(A1w * Cp * 8);
         L.Mr = o; o += up64(Cw * A1s * 8);
-        L.dv = o; o += up64(3 * A1s * 8);
+        const size_t n_dict = (size_t)fast_wg(J);             // (a table-lookup cluster: the dicts once per workgroup)
+        L.dv = o; o += up64(n_dict * 3 * A1s * 8);
         L.pos = o; o += up64(4 * A1s * 2);
         L.tmpv = o; o += up64(A1s * 8);
         L.vlen = o; o += up64(A1s * 8);
         L.cls = o; o += up64(5 * Cp * 8);
-        L.din = o; o += up64(3 * A1s);
+        L.din = o; o += up64(n_dict * 3 * A1s);
         L.sorted = o; o += up64(A1s * 4);
         L.first = o; o += up64(A1s * 4);
         L.stamps = o; o += up64(16 * 8);
@@ -1280,6 +1401,36 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
             g_cluster_jobs.fetch_add(1);
         }
     }
+    // the table-lookup launch with clusters: its tasks in launch order, every one with a block range (most of them one block)
+    std::vector<EmxTask> ftasks;
+    DevBuf b_ftasks, b_fctl;
+    int fast_blocks = 0;
+    {
+        bool any_pair = false;
+        for (int t = 0; t < n; ++t) any_pair = any_pair || fast_wg(jobs[job_of[t]]) > 1;
+        if (any_pair) {
+            const char *spin_sw = hgx_test_switch("emx_cluster_spins");
+            for (int t = 0; t < n; ++t) {
+                if (!tasks[t].fast) continue;
+                EmxTask T = tasks[t];
+                T.cluster = fast_wg(jobs[job_of[t]]);
+                T.cl_first = fast_blocks;
+                if (spin_sw) T.cl_spins = std::max(1, atoi(spin_sw));
+                fast_blocks += T.cluster;
+                if (T.cluster > 1) g_cluster_jobs.fetch_add(1);
+                ftasks.push_back(T);
+            }
+            ALLOC(b_fctl, ftasks.size() * 64);                          // barrier count + abort flag per task, on a line of its own
+            HIPCHK(hipMemsetAsync(b_fctl.p, 0, ftasks.size() * 64, st));
+            for (size_t k = 0; k < ftasks.size(); ++k) ftasks[k].cl_ctl = (unsigned int *)(b_fctl.as<char>() + 64 * k);
+            ALLOC(b_ftasks, ftasks.size() * sizeof(EmxTask));
+            for (size_t off = 0; off < ftasks.size() * sizeof(EmxTask);) {
+                const size_t chunk = std::min<size_t>(ftasks.size() * sizeof(EmxTask) - off, 128u << 10);
+                { int rc_ = hgx_h2d(b_ftasks.as<char>() + off, (const char *)ftasks.data() + off, chunk, st); if (rc_) return rc_; }
+                off += chunk;
+            }
+        }
+    }
     for (size_t off = 0; off < tasks.size() * sizeof(EmxTask);) {      // descriptors through the pinned staging buffer
         const size_t chunk = std::min<size_t>(tasks.size() * sizeof(EmxTask) - off, 128u << 10);
         { int rc_ = hgx_h2d(b_tasks.as<char>() + off, (const char *)tasks.data() + off, chunk, st); if (rc_) return rc_; }
@@ -1306,7 +1457,10 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
     }
     if (any_fast) {
         if (timing) HIPCHK(hipEventRecord(ev[2], st));
-        hipLaunchKernelGGL(k_emx<true>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>(), n);
+        if (!ftasks.empty())
+            hipLaunchKernelGGL((k_emx<true, true>), dim3((unsigned)fast_blocks), dim3(XB), sizeof(XLds), st, b_ftasks.as<EmxTask>(), (int)ftasks.size());
+        else
+            hipLaunchKernelGGL(k_emx<true>, dim3((unsigned)n), dim3(XB), sizeof(XLds), st, b_tasks.as<EmxTask>(), n);
         if (timing) HIPCHK(hipEventRecord(ev[3], st));
     }
     HIPCHK(hipGetLastError());

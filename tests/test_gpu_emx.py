@@ -129,6 +129,49 @@ def test_emx_fast_mode_is_within_rounding(orc, case):
         engine.em_set_fast(old)
 
 
+@pytest.mark.parametrize("case", [(7000, 4549, 1600, 0.25), (7000, 3000, 900, 0.3), (3000, 1949, 2500, 0.2), (500, 323, 704, 0.3), (8000, 6100, 4000, 0.1)],
+                         ids=lambda c: "A%d_used%d_C%d" % c[:3])
+def test_table_lookup_cluster_equals_one_workgroup(case):
+    """k_emx<true, true>: a table-lookup problem on 2 / 3 / 4 workgroups (tiles -- or, where a pass has fewer tiles than workgroups,
+    wavefronts -- of the two matrix passes shared out, hand-overs through agent-scope loads and stores) gives the doubles one
+    workgroup gives, bit for bit: every workgroup does the vector steps itself on its own dicts, in the same order of operations."""
+    A, n_used, C_, dens = case
+    rng = np.random.RandomState(77 + A + C_)
+    a_pad, name_rank, classes, rows, counts, lengths = _random_problem(rng, A, n_used, C_, dens)
+    cl = engine.Classes.from_host(rows, counts, a_pad)
+    cl.set_allele_rank(name_rank)
+    old = engine.em_set_fast(True)
+    try:
+        for low, ln in ((True, None), (False, lengths)):
+            with engine.test_switches(emx_fast_wg=1):
+                try:
+                    want, it_want = cl.em(A, low, ln)
+                except capi_err():
+                    continue
+            j0, f0 = engine.emx_cluster_stats()
+            for wgs in (2, 3, 4):
+                with engine.test_switches(emx_fast_wg=wgs):
+                    got, it = cl.em(A, low, ln)
+                assert it == it_want and np.array_equal(got, want), (case, low, wgs)
+            j1, f1 = engine.emx_cluster_stats()
+            assert (j1 - j0, f1 - f0) == (3, 0)
+            # a pair that cannot meet in a few polls gives up; the problem is re-run on one workgroup and counted
+            with engine.test_switches(emx_fast_wg=2, emx_cluster_spins=1):
+                got, it = cl.em(A, low, ln)
+            j2, f2 = engine.emx_cluster_stats()
+            assert it == it_want and np.array_equal(got, want)
+            assert j2 - j1 == 1 and f2 - f1 in (0, 1)          # (one poll may just be enough when both workgroups arrive together)
+            got, it = cl.em(A, low, ln)                        # the default: a lone big problem gets four workgroups, a small one stays alone
+            assert it == it_want and np.array_equal(got, want)
+    finally:
+        engine.em_set_fast(old)
+
+
+def capi_err():
+    from hisatgenotype_amd import capi
+    return capi.HgxError
+
+
 @pytest.mark.parametrize("cluster", [True, False], ids=["cluster", "one_workgroup"])
 @pytest.mark.parametrize("case", [(7000, 2600, 9000, 0.2), (7000, 4549, 16098, 0.3)], ids=lambda c: "A%d_used%d_C%d" % c[:3])
 def test_any_size_mode_is_the_reference_bit_for_bit(orc, case, cluster):
