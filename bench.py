@@ -845,8 +845,11 @@ def run_panel64(args, rank, local_rank, world, dist):
                     "traffic": traffic, "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"], "avg_launch_ms": kernels[dom]["avg_ms"],
                     "note": "the one-workgroup-per-task EM kernel (EM #1 of all tasks in one launch; EM #2 in another): HIP events around every "
                             "launch of the timed region; algorithmic bytes per launch = sum over its jobs of applications x (C * A' / 8 + 16 A' + "
-                            "16 C) (SURVEY.md 8d).  The kernel is bound by LDS table lookups and FP64 issue on ONE CU per task, not by HBM: the "
-                            "fraction says how far a task-parallel EM sits from streaming its matrices",
+                            "16 C) (SURVEY.md 8d).  The kernel is bound by the LDS pipe of ONE CU per task, not by HBM: a pass makes one 8-byte table "
+                            "lookup per 8 matrix bits, i.e. 2 C A' bytes of LDS reads per application -- alone on a CU a 1 600 x 4 549 problem "
+                            "reads 14.6 MB per application in 89 us = 164 GB/s = 0.56 of a CU's 293 GB/s (tools/emx_timing.py) -- and the launch "
+                            "ends with its longest problem (3-13 EM iterations per task).  The HBM fraction says how far a task-parallel EM sits "
+                            "from streaming its matrices",
                     "kernels": kernels}
     # the same panel with the OTHER EM arithmetic, a few steps outside the timed region: the line then carries both the throughput
     # form (table lookups, <= 1e-8) and the bit-identical form (the library's default, hgx_type_opts.em_fast = 0)
