@@ -91,7 +91,9 @@ const FastInflate *fast_inflate() {
 }
 
 // inflate every BGZF block of `data` into one buffer
-int bgzf_inflate(const Bytes &data, int n_threads, Bytes &out) {
+// `on_part` (may be empty): called with [begin, end) of the output as soon as those bytes are complete -- the blocks are inflated
+// in a few groups, and a group's bytes travel (the device front end's upload) while the next group is inflated
+int bgzf_inflate(const Bytes &data, int n_threads, Bytes &out, const std::function<void(size_t, size_t)> &on_part = nullptr) {
     std::vector<Block> blocks;
     size_t off = 0, total = 0;
     const size_t n = data.size();
@@ -125,9 +127,12 @@ int bgzf_inflate(const Bytes &data, int n_threads, Bytes &out) {
     out.n = total;
     std::vector<int> bad(std::max(1, n_threads), 0);
     const FastInflate *fi = fast_inflate();
-    par_for(n_threads, blocks.size(), [&](int t, size_t b0, size_t b1) {
+    const size_t n_groups = (on_part && total > (64u << 20)) ? 4 : 1;
+    for (size_t g = 0; g < n_groups; ++g) {
+    const size_t g0 = blocks.size() * g / n_groups, g1 = blocks.size() * (g + 1) / n_groups;
+    par_for(n_threads, g1 - g0, [&](int t, size_t b0, size_t b1) {
         void *dec = fi ? fi->alloc() : nullptr;
-        for (size_t i = b0; i < b1; ++i) {
+        for (size_t i = g0 + b0; i < g0 + b1; ++i) {
             const Block &b = blocks[i];
             if (b.out_len == 0) continue;
             if (dec) {
@@ -151,6 +156,8 @@ int bgzf_inflate(const Bytes &data, int n_threads, Bytes &out) {
         if (dec) fi->release(dec);
     });
     for (int v : bad) if (v) { hgx_set_error("corrupt BGZF block (inflate / CRC32 / ISIZE mismatch)"); return HGX_EPARSE; }
+    if (on_part && g1 > g0) on_part(blocks[g0].out_off, g1 < blocks.size() ? blocks[g1].out_off : total);
+    }
     return HGX_OK;
 }
 
@@ -605,7 +612,12 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
     lap(text_scanned ? "read file + lines" : "read file");
     Bytes raw;
     if (data.size() >= 2 && data[0] == 0x1f && data[1] == 0x8b) {
-        const int rc = bgzf_inflate(data, n_threads, raw);
+        std::function<void(size_t, size_t)> part;
+        if (out.on_raw) {
+            part = [&](size_t b, size_t e) { out.on_raw((const char *)raw.data(), raw.size(), b, e); };
+            on_raw_done = true;
+        }
+        const int rc = bgzf_inflate(data, n_threads, raw, part);
         if (rc) return rc;
         data.release();
     } else raw.swap(data);
@@ -627,6 +639,33 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             if (l_name == 0 || p + 4 + l_name + 4 > n) { hgx_set_error("truncated BAM reference list"); return HGX_EPARSE; }
             refs.emplace_back((const char *)&raw[p + 4], l_name - 1);
             p += 4 + l_name + 4;
+        }
+        if (keep_binary && out.defer_walk && regs.size() <= 1 && (!filtered || regs.size() == 1) && n - p >= out.defer_min_bytes &&
+            n < (1ull << 32) - 64 && refs.size() < 65536) {
+            // the caller walks, filters and sorts the records itself (the device front end): hand the stream over as it is
+            hgx_bam_deferred &d = out.deferred;
+            d.on = true;
+            d.body0 = p;
+            d.filtered = filtered;
+            d.ref_action.assign(refs.size(), filtered ? 0 : 1);
+            if (filtered) {
+                const Region &r = regs[0];
+                d.left0 = r.left0; d.right0 = r.right0;
+                for (size_t i = 0; i < refs.size(); ++i) {
+                    if (refs[i].size() == r.whole.size() && memcmp(refs[i].data(), r.whole.data(), r.whole.size()) == 0) d.ref_action[i] = 1;
+                    else if (!r.name.empty() && refs[i].size() == r.name.size() && memcmp(refs[i].data(), r.name.data(), r.name.size()) == 0) d.ref_action[i] = 2;
+                }
+            }
+            out.binary = true;
+            out.ref_names = refs;
+            lines.clear();
+            hgx_host_free(out.raw);
+            out.raw = (char *)raw.p;
+            out.raw_bytes = raw.n;
+            raw.p = nullptr;
+            raw.n = 0;
+            lap("  (records left to the device)");
+            return HGX_OK;
         }
         // ---- record chain ------------------------------------------------------------------------------------------
         // The records form a chain (each block_size leads to the next) that one thread walks at ~15 ns per record.  For big

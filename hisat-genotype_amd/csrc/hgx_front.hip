@@ -517,6 +517,156 @@ __global__ void __launch_bounds__(256) k_fe_build_recinfo(const FeRec *__restric
     rec_info[rec_idx[i]] = dslot[slot_of[i]] | ((recs[i].flag & 0x40) ? 1u << 30 : 0u) | (hd ? 1u << 31 : 0u);
 }
 
+// ---- BAM records straight from the inflated stream (round 4): chain walk, region filter, name sort as kernels -----------------
+// What hgx_bam.cpp does on the host's threads when the records are not left to the device: the records of a BAM form a chain (each
+// block_size leads to the next), so the stream is cut into ranges; every range but the first GUESSES a record start (a header that
+// is plausible and leads to three more plausible headers) and walks from there past its end; the guesses are then CHECKED -- a
+// range's walk must end exactly where the next one's begins -- and anything that does not link up declines the call.
+struct BamCtl { int32_t decline; uint32_t n_rec, n_kept, max_klen, unsorted; };
+__device__ __forceinline__ void bam_decline(BamCtl *c, int code) { atomicCAS(&c->decline, 0, code); }
+__device__ __forceinline__ uint32_t bam_u32(const unsigned char *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ int32_t bam_i32(const unsigned char *p) { int32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint32_t bam_u16(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ bool bam_plausible(const unsigned char *raw, size_t n, size_t o, int n_ref) {
+    if (o + 36 > n) return false;
+    const uint32_t bs = bam_u32(raw + o);
+    if (bs < 32 || o + 4 + (size_t)bs > n) return false;
+    const unsigned char *r = raw + o + 4;
+    const int32_t rid = bam_i32(r), pos = bam_i32(r + 4), nrid = bam_i32(r + 20), npos = bam_i32(r + 24), l_seq = bam_i32(r + 16);
+    const uint32_t l_rn = r[8], n_cig = bam_u16(r + 12);
+    if (rid < -1 || rid >= n_ref || nrid < -1 || nrid >= n_ref) return false;
+    if (pos < -1 || npos < -1 || l_seq < 0 || l_rn == 0) return false;
+    if (32 + (size_t)l_rn + 4 * (size_t)n_cig + (size_t)(l_seq + 1) / 2 + (size_t)l_seq > bs) return false;
+    if (r[32 + l_rn - 1] != 0) return false;
+    for (uint32_t k = 0; k + 1 < l_rn; ++k) if (r[32 + k] < 33 || r[32 + k] > 126) return false;
+    return true;
+}
+struct BamRange { uint32_t first, stop, count, state; };     // state: 1 = walked, 2 = no record start in the range, 0 = a broken record
+// PASS 0: find the range's first record and count; PASS 1: the same walk again, writing (offset after block_size, length)
+template <int PASS>
+__global__ void __launch_bounds__(64) k_bam_walk(const unsigned char *__restrict__ raw, size_t n, size_t body0, int n_ref, int W, BamRange *__restrict__ rng,
+                                                 const uint32_t *__restrict__ base, uint32_t *__restrict__ rec_off, uint32_t *__restrict__ rec_len) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W) return;
+    const size_t lo = body0 + (n - body0) * (size_t)t / (size_t)W, hi = body0 + (n - body0) * (size_t)(t + 1) / (size_t)W;
+    size_t o = lo;
+    if (PASS == 0) {
+        if (t > 0) {
+            bool found = false;
+            for (; o < hi; ++o) {
+                if (!bam_plausible(raw, n, o, n_ref)) continue;
+                size_t q = o;
+                int good = 0;
+                while (good < 4 && q < n && bam_plausible(raw, n, q, n_ref)) { q += 4 + (size_t)bam_u32(raw + q); ++good; }
+                if (good == 4 || q == n) { found = true; break; }
+            }
+            if (!found) { rng[t] = BamRange{(uint32_t)hi, (uint32_t)hi, 0u, 2u}; return; }
+        }
+    } else {
+        if (rng[t].state != 1u) return;
+        o = rng[t].first;
+    }
+    size_t q = o;
+    uint32_t cnt = 0;
+    bool ok = true;
+    uint32_t at = PASS == 1 ? base[t] : 0u;
+    while (q < hi && q < n) {
+        if (q + 4 > n) { ok = false; break; }
+        const uint32_t bs = bam_u32(raw + q);
+        if (bs < 32 || q + 4 + (size_t)bs > n) { ok = false; break; }
+        if (PASS == 1) { rec_off[at] = (uint32_t)(q + 4); rec_len[at] = bs; ++at; }
+        ++cnt;
+        q += 4 + (size_t)bs;
+    }
+    if (PASS == 0) rng[t] = BamRange{(uint32_t)o, (uint32_t)q, cnt, ok ? 1u : 0u};
+}
+// the ranges must link up: every walked range begins where the walked range before it stopped (ranges without a record start --
+// a record longer than a range -- are passed over), the first at the first record, the last ends with the stream
+__global__ void __launch_bounds__(256) k_bam_link(const BamRange *__restrict__ rng, int W, size_t n, size_t body0, uint32_t *__restrict__ cnt, BamCtl *ctl) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= W) return;
+    const BamRange r = rng[t];
+    cnt[t] = r.state == 1u ? r.count : 0u;
+    if (r.state == 2u) return;
+    if (r.state != 1u) { bam_decline(ctl, HGX_FE_DECLINE_RECORD); return; }
+    int p = t - 1;
+    while (p >= 0 && rng[p].state == 2u) --p;
+    const size_t expect = p < 0 ? body0 : (size_t)rng[p].stop;
+    if ((size_t)r.first != expect) { bam_decline(ctl, HGX_FE_DECLINE_RECORD); return; }
+    int q = t + 1;
+    while (q < W && rng[q].state == 2u) ++q;
+    if (q == W && (size_t)r.stop != n) bam_decline(ctl, HGX_FE_DECLINE_RECORD);
+}
+__global__ void k_bam_total(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ base, int W, BamCtl *ctl) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->n_rec = base[W - 1] + cnt[W - 1];
+}
+// region filter (hgx_bam.cpp: reference span from the CIGAR, overlap with the one region) + the checks the host makes on a record
+__global__ void __launch_bounds__(256) k_bam_filter(const unsigned char *__restrict__ raw, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ rec_len,
+                                                    uint32_t n_rec, const uint8_t *__restrict__ ref_action, int n_ref, int filtered, long long left0,
+                                                    long long right0, uint32_t *__restrict__ keep, BamCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    const unsigned char *r = raw + rec_off[i];
+    const uint32_t bs = rec_len[i], l_rn = r[8];
+    uint32_t k = 1;
+    if (filtered) {
+        const int32_t rid = bam_i32(r), pos = bam_i32(r + 4);
+        if (rid < 0 || rid >= n_ref) k = 0;
+        else {
+            const uint32_t n_cig = bam_u16(r + 12), flag = bam_u16(r + 14);
+            long long reflen = 0;
+            if (!(flag & 4) && 32 + (size_t)l_rn + 4 * (size_t)n_cig <= bs) {
+                const unsigned char *c = r + 32 + l_rn;
+                for (uint32_t x = 0; x < n_cig; ++x) {
+                    const uint32_t v = bam_u32(c + 4 * x), op = v & 15;
+                    if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) reflen += v >> 4;
+                }
+            }
+            const long long end0 = (long long)pos + (reflen > 0 ? reflen : 1) - 1;
+            const uint8_t act = ref_action[rid];
+            k = act == 1 ? 1u : (act == 2 ? ((end0 >= left0 && (long long)pos <= right0) ? 1u : 0u) : 0u);
+        }
+    }
+    if (k && (l_rn == 0 || 32 + (size_t)l_rn > bs || r[32 + l_rn - 1] != 0)) { bam_decline(ctl, HGX_FE_DECLINE_RECORD); k = 0; }   // "malformed BAM record": the host's to report
+    keep[i] = k;
+    if (k) atomicMax(&ctl->max_klen, l_rn - 1);
+}
+__global__ void k_bam_compact(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, uint32_t n_rec, uint32_t *__restrict__ idx, BamCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rec) return;
+    if (keep[i]) idx[pos[i]] = i;
+    if (i == n_rec - 1) ctl->n_kept = pos[i] + keep[i];
+}
+// QNAME order as hgx_bam.cpp's line_less: bytes, a name that is a prefix of another first
+__device__ __forceinline__ int bam_name_cmp(const unsigned char *a, uint32_t la, const unsigned char *b, uint32_t lb) {
+    const uint32_t m = la < lb ? la : lb;
+    for (uint32_t k = 0; k < m; ++k) if (a[k] != b[k]) return a[k] < b[k] ? -1 : 1;
+    return la < lb ? -1 : (la > lb ? 1 : 0);
+}
+__global__ void __launch_bounds__(256) k_bam_sorted(const unsigned char *__restrict__ raw, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ idx,
+                                                    uint32_t n, BamCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 || i >= n) return;
+    const unsigned char *a = raw + rec_off[idx[i - 1]], *b = raw + rec_off[idx[i]];
+    if (bam_name_cmp(b + 32, (uint32_t)b[8] - 1, a + 32, (uint32_t)a[8] - 1) < 0) ctl->unsorted = 1;
+}
+// bytes [8 c, 8 c + 8) of every name, big endian, zero beyond its end: LSD radix passes over these give the byte order above
+__global__ void __launch_bounds__(256) k_bam_name_key(const unsigned char *__restrict__ raw, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ idx,
+                                                      uint32_t n, uint32_t chunk, unsigned long long *__restrict__ key) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char *r = raw + rec_off[idx[i]];
+    const uint32_t klen = (uint32_t)r[8] - 1;
+    unsigned long long v = 0;
+    for (uint32_t k = 0; k < 8; ++k) { const uint32_t at = 8 * chunk + k; v = (v << 8) | (at < klen ? r[32 + at] : 0u); }
+    key[i] = v;
+}
+__global__ void k_bam_lines(const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ rec_len, const uint32_t *__restrict__ idx, uint32_t n,
+                            FeLine *__restrict__ lines) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t r = idx[i]; lines[i] = FeLine{rec_off[r], rec_len[r], 0u}; }
+}
+
 struct MaxU32 { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
 
 thread_local int g_last_device = 0, g_last_decline = 0, g_last_route = 0;
@@ -800,8 +950,88 @@ LineRef *line_refs(const char *raw, const hgx_line *lines, size_t n_lines, bool 
     return dst;
 }
 
+// the line table of an unwalked BAM stream (resident at d_text), made on the device: (offset, length) of the records the region
+// keeps, in QNAME order (stable: file order among equal names) -- what hgx_bam.cpp's walk + filter + sort_lines give
+int bam_lines_dev(const char *d_text, size_t raw_bytes, const hgx_bam_deferred &def, hipStream_t st, DevBuf &b_lines, uint32_t *n_lines, int *declined) {
+    *declined = 0;
+    *n_lines = 0;
+    Lap lap(st);
+    const unsigned char *raw = (const unsigned char *)d_text;
+    const size_t n = raw_bytes, body0 = def.body0;
+    const int n_ref = (int)def.ref_action.size();
+    if (body0 > n || n >= (1ull << 32) - 64) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+    const int W = (int)std::max<size_t>(1, std::min<size_t>(8192, (n - body0) / 16384 + 1));
+    DevBuf b_rng, b_base, b_cnt, b_tmpw, b_ctl, b_act, b_off, b_len, b_keep, b_pos, b_idx, b_idx2, b_key, b_key2, b_tmp;
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
+    ALLOC(b_rng, (size_t)W * sizeof(BamRange));
+    ALLOC(b_base, (size_t)W * 4);
+    ALLOC(b_cnt, (size_t)W * 4);
+    ALLOC(b_ctl, sizeof(BamCtl));
+    ALLOC(b_act, std::max<size_t>((size_t)n_ref, 16));
+    HIPCHK(hipMemsetAsync(b_ctl.p, 0, sizeof(BamCtl), st));
+    if (n_ref) HIPCHK(hipMemcpyAsync(b_act.p, def.ref_action.data(), (size_t)n_ref, hipMemcpyHostToDevice, st));
+    BamCtl *ctl = b_ctl.as<BamCtl>();
+    k_bam_walk<0><<<nblk(W, 64), 64, 0, st>>>(raw, n, body0, n_ref, W, b_rng.as<BamRange>(), nullptr, nullptr, nullptr);
+    k_bam_link<<<nblk(W, 256), 256, 0, st>>>(b_rng.as<BamRange>(), W, n, body0, b_cnt.as<uint32_t>(), ctl);
+    {
+        size_t tbw = 0;
+        (void)hipcub::DeviceScan::ExclusiveSum((void *)nullptr, tbw, (uint32_t *)nullptr, (uint32_t *)nullptr, W, st);
+        ALLOC(b_tmpw, std::max<size_t>(tbw, 256));
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmpw.p, tbw, b_cnt.as<uint32_t>(), b_base.as<uint32_t>(), W, st));
+    }
+    k_bam_total<<<1, 64, 0, st>>>(b_cnt.as<uint32_t>(), b_base.as<uint32_t>(), W, ctl);
+    BamCtl h;
+    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    lap("BAM record walk (ranges)");
+    if (h.decline) { *declined = h.decline; return HGX_OK; }
+    const uint32_t n_rec = h.n_rec;
+    if (n_rec >= (1u << 30)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+    ALLOC(b_lines, std::max<size_t>(n_rec, 1) * sizeof(LineRef));
+    if (n_rec == 0) return HGX_OK;
+    ALLOC(b_off, (size_t)n_rec * 4); ALLOC(b_len, (size_t)n_rec * 4); ALLOC(b_keep, (size_t)n_rec * 4); ALLOC(b_pos, (size_t)n_rec * 4);
+    ALLOC(b_idx, (size_t)n_rec * 4); ALLOC(b_idx2, (size_t)n_rec * 4); ALLOC(b_key, (size_t)n_rec * 8); ALLOC(b_key2, (size_t)n_rec * 8);
+    size_t tb = 0, tb2 = 0;
+    (void)hipcub::DeviceScan::ExclusiveSum((void *)nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_rec, st);
+    (void)hipcub::DeviceRadixSort::SortPairs((void *)nullptr, tb2, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr,
+                                             (uint32_t *)nullptr, (int)n_rec, 0, 64, st);
+    const size_t tmp_bytes = std::max(tb, tb2);
+    ALLOC(b_tmp, std::max<size_t>(tmp_bytes, 256));
+    k_bam_walk<1><<<nblk(W, 64), 64, 0, st>>>(raw, n, body0, n_ref, W, b_rng.as<BamRange>(), b_base.as<uint32_t>(), b_off.as<uint32_t>(), b_len.as<uint32_t>());
+    k_bam_filter<<<nblk(n_rec, 256), 256, 0, st>>>(raw, b_off.as<uint32_t>(), b_len.as<uint32_t>(), n_rec, b_act.as<uint8_t>(), n_ref, def.filtered ? 1 : 0,
+                                                   (long long)def.left0, (long long)def.right0, b_keep.as<uint32_t>(), ctl);
+    { size_t b = tmp_bytes; HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_keep.as<uint32_t>(), b_pos.as<uint32_t>(), (int)n_rec, st)); }
+    k_bam_compact<<<nblk(n_rec, 256), 256, 0, st>>>(b_keep.as<uint32_t>(), b_pos.as<uint32_t>(), n_rec, b_idx.as<uint32_t>(), ctl);
+    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    lap("BAM records + region filter");
+    if (h.decline) { *declined = h.decline; return HGX_OK; }
+    const uint32_t n_kept = h.n_kept;
+    uint32_t *idx = b_idx.as<uint32_t>(), *idx_alt = b_idx2.as<uint32_t>();
+    if (n_kept > 1) {
+        // an aligner writes its records grouped by read already: a stable sort would not move anything
+        k_bam_sorted<<<nblk(n_kept, 256), 256, 0, st>>>(raw, b_off.as<uint32_t>(), idx, n_kept, ctl);
+        HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h.unsorted) {
+            unsigned long long *key = b_key.as<unsigned long long>(), *key_alt = b_key2.as<unsigned long long>();
+            for (int chunk = (int)(h.max_klen + 7) / 8 - 1; chunk >= 0; --chunk) {      // least significant eight bytes first; every pass stable
+                k_bam_name_key<<<nblk(n_kept, 256), 256, 0, st>>>(raw, b_off.as<uint32_t>(), idx, n_kept, (uint32_t)chunk, key);
+                size_t b = tmp_bytes;
+                HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, key, key_alt, idx, idx_alt, (int)n_kept, 0, 64, st));
+                std::swap(idx, idx_alt);
+            }
+        }
+        lap(h.unsorted ? "BAM name sort" : "BAM name order check");
+    }
+    if (n_kept) k_bam_lines<<<nblk(n_kept, 256), 256, 0, st>>>(b_off.as<uint32_t>(), b_len.as<uint32_t>(), idx, n_kept, b_lines.as<LineRef>());
+    HIPCHK(hipGetLastError());
+    *n_lines = n_kept;
+    return HGX_OK;
+}
+
 int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRef *h_lines, size_t n_lines, bool binary, int n_tasks,
-                const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, ManyTotals *many, int *declined) {
+                const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, ManyTotals *many, int *declined, const LineRef *d_lines = nullptr) {
     *out = nullptr;
     *declined = 0;
     Lap lap(st);
@@ -817,7 +1047,7 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
     DevBuf b_lines, b_recs, b_head, b_kept, b_slot_of, b_tkeys, b_rep, b_pile, b_anyk, b_dslot, b_is_key, b_is_dec, b_kept32, b_prev_in;
     DevBuf b_key_idx, b_dec_idx, b_rec_idx, b_prev, b_tmp, b_keys, b_rec, b_ctl, b_treads, b_tpairs, b_trefs, b_tpieces;
     struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
-    ALLOC(b_lines, std::max<size_t>(n_lines, 1) * sizeof(LineRef));
+    if (!d_lines) ALLOC(b_lines, std::max<size_t>(n_lines, 1) * sizeof(LineRef));
     ALLOC(b_recs, std::max<size_t>(n_lines, 1) * sizeof(FeRec));
     ALLOC(b_head, std::max<size_t>(n_lines, 16));
     ALLOC(b_kept, std::max<size_t>(n_lines, 16));
@@ -841,8 +1071,11 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
     HIPCHK(hipMemsetAsync(b_rep.p, 0xFF, (size_t)cap * 4, st));
     HIPCHK(hipMemsetAsync(b_pile.p, 0, (size_t)cap * 4, st));
     HIPCHK(hipMemsetAsync(b_anyk.p, 0, (size_t)cap * 4, st));
-    if (n) HIPCHK(hipMemcpyAsync(b_lines.p, h_lines, (size_t)n * sizeof(LineRef), hipMemcpyHostToDevice, st));
-    g_last_bytes += (long long)((size_t)n * sizeof(LineRef));
+    if (n && !d_lines) {
+        HIPCHK(hipMemcpyAsync(b_lines.p, h_lines, (size_t)n * sizeof(LineRef), hipMemcpyHostToDevice, st));
+        g_last_bytes += (long long)((size_t)n * sizeof(LineRef));
+    }
+    const LineRef *lines_dev = d_lines ? d_lines : b_lines.as<LineRef>();
     lap("text + line table on the device");
     FeCtl *ctl = b_ctl.as<FeCtl>();
     FeCtl h;
@@ -850,7 +1083,7 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
     if (n) {
         const FeFilter flt{o.num_editdist, o.allow_discordant, o.base_locus};
         FeRec *recs = b_recs.as<FeRec>();
-        k_fe_records<<<nblk(n, 256), 256, 0, st>>>(d_text, raw_bytes + 64, b_lines.as<LineRef>(), n, binary ? 1 : 0, o.simulation, recs, ctl);
+        k_fe_records<<<nblk(n, 256), 256, 0, st>>>(d_text, raw_bytes + 64, lines_dev, n, binary ? 1 : 0, o.simulation, recs, ctl);
         k_fe_rec_heads<<<nblk(n, 256), 256, 0, st>>>(recs, n, d_text, b_head.as<uint8_t>());
         k_fe_rec_filter_insert<<<nblk(n, 256), 256, 0, st>>>(recs, b_head.as<uint8_t>(), n, flt, b_tkeys.as<unsigned long long>(), b_rep.as<uint32_t>(),
                                                             b_pile.as<uint32_t>(), b_anyk.as<uint32_t>(), cap - 1, b_kept.as<uint8_t>(),
@@ -950,10 +1183,23 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Pars
             up_bytes = n_bytes;
             g_last_bytes += (long long)(end - begin);
         };
+        // a BAM's records are walked, filtered and name-sorted on the device too when the stream is big enough to be worth the launches
+        hook.defer_walk = true;
+        hook.defer_min_bytes = force ? 0 : (8u << 20);
         hook.records = [&](hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &o,
-                           int *declined) {
-            if (!force && n < 20000) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }
+                           int *declined, const hgx_bam_deferred *def) {
+            if (!def && !force && n < 20000) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }
             if (up_failed || raw != up_raw || raw_bytes != up_bytes) { *declined = HGX_FE_DECLINE_SIZE; return (int)HGX_OK; }
+            if (def) {
+                DevBuf b_dl;
+                uint32_t n_dl = 0;
+                struct DrainL { hipStream_t s; ~DrainL() { (void)hipStreamSynchronize(s); } } drain_l{st};
+                int rc = bam_lines_dev(b_text.as<char>(), raw_bytes, *def, st, b_dl, &n_dl, declined);
+                if (rc || *declined) return rc;
+                rc = records_run(L, b_text.as<char>(), raw_bytes, nullptr, n_dl, true, 1, o, st, &made, nullptr, declined, b_dl.as<LineRef>());
+                if (!rc && !*declined && made) route = 2;
+                return rc;
+            }
             LineRef *h_lines = (LineRef *)pinned_alloc(std::max<size_t>(n, 1) * sizeof(LineRef));
             if (!h_lines) { hgx_set_error("pinned allocation of the line table failed"); return (int)HGX_ENOMEM; }
             struct Unpin { void *p; ~Unpin() { pinned_release(p); } } unpin{h_lines};

@@ -355,7 +355,8 @@ extern "C" int hgx_lab_parse_records_emulated(hgx_batch **out, const hgx_locus *
         delete made; made = nullptr;
         return hgx_front_emulate(&made, L, in, o, dec);
     };
-    hook.records = [&](hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &o, int *dec) {
+    hook.records = [&](hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &o, int *dec,
+                       const hgx_bam_deferred *) {
         std::vector<FeLine> refs(n);
         for (size_t i = 0; i < n; ++i) refs[i] = FeLine{(uint32_t)((size_t)(lines[i].p - raw) - (binary ? 32u : 0u)), lines[i].len, 0u};
         return hgx_front_emulate_records(&made, L, raw, raw_bytes, refs.data(), n, binary, o, dec);

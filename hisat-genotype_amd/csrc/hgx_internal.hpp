@@ -169,6 +169,15 @@ inline void hgx_par_tasks(int n_threads, size_t n_tasks, F fn) {           // fn
 // The alignment reader's internal result (hgx_bam.cpp -> hgx_sam.cpp): the records as a line table, stable-sorted by QNAME, over
 // buffers this object owns.  p[len] is a byte the parser may overwrite (the line's terminator).
 struct hgx_line { char *p; uint32_t len, klen; uint64_t key; };     // klen = QNAME length, key = its first 8 bytes, big endian
+// a BAM whose record walk, region filter and name sort are left to the device front end (hgx_front.hip: k_bam_*): the reader stops
+// after the inflate and the header
+struct hgx_bam_deferred {
+    bool on = false;
+    size_t body0 = 0;                    // offset of the first record's block_size in the inflated stream
+    bool filtered = false;               // ONE region was given: per reference what it keeps
+    std::vector<uint8_t> ref_action;     // [n_ref] 0 = drop, 1 = keep, 2 = keep where [pos0, end0] overlaps [left0, right0]
+    int64_t left0 = 0, right0 = 0;
+};
 struct hgx_align_lines {
     char *raw = nullptr;                   // SAM text as read, or the inflated BAM stream (pooled block), or null
     std::vector<PString> chunks;           // text decoded from BAM records (hgx_read_alignments only)
@@ -182,6 +191,11 @@ struct hgx_align_lines {
     // read, a BAM stream once, when it is inflated and before the record walk and the name sort: the device front end uploads
     // [begin, end) of the n_bytes at `raw` there
     std::function<void(const char *raw, size_t n_bytes, size_t begin, size_t end)> on_raw;
+    // in: the caller can walk / filter / sort BAM records itself (the device front end) when the inflated stream has at least
+    // defer_min_bytes and at most one region was asked for; out: `deferred.on` -- `lines` is empty then
+    bool defer_walk = false;
+    size_t defer_min_bytes = 0;
+    hgx_bam_deferred deferred;
     hgx_align_lines() = default;
     hgx_align_lines(const hgx_align_lines &) = delete;
     hgx_align_lines &operator=(const hgx_align_lines &) = delete;
@@ -252,8 +266,11 @@ struct hgx_front_hook {
     // over the SAM text / the inflated BAM stream it was sent through `on_raw`), the host stages do not run at all.  `lines`: the
     // name-ordered line table of the reader; raw / raw_bytes: the bytes it points into.  *declined != 0: the host stages run
     // (and `run` gets its chance after them).
+    // `def` != NULL: a BAM stream whose records have not been walked (lines == NULL, n == 0): the device does that too.
     std::function<int(hgx_locus &, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &,
-                      int *declined)> records;
+                      int *declined, const hgx_bam_deferred *def)> records;
+    bool defer_walk = false;           // the hook's owner takes unwalked BAM streams
+    size_t defer_min_bytes = 0;
     std::function<void(const char *raw, size_t n_bytes, size_t begin, size_t end)> on_raw;
     int declined_records = 0;
 };

@@ -1746,7 +1746,7 @@ void parallel_for(int n_threads, size_t n, F fn) {   // fn(thread, begin, end), 
 }   // namespace
 
 static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts, bool binary = false,
-                       hgx_front_hook *hook = nullptr, const char *raw = nullptr, size_t raw_bytes = 0);
+                       hgx_front_hook *hook = nullptr, const char *raw = nullptr, size_t raw_bytes = 0, const hgx_bam_deferred *def = nullptr);
 
 // SAM text (name-grouped) -> private writable copy + line table -> parse_lines
 int hgx_parse_sam_hook(hgx_batch **out, const hgx_locus *Lc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, hgx_front_hook *hook) {
@@ -1811,11 +1811,34 @@ int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *Lc, const ch
         const double t0 = now();
         hgx_align_lines al;                     // the reader's buffers are tokenised in place (no copy, no trip through the caller)
         std::unique_ptr<hgx_big_alloc_scope> pinned;   // the record route uploads the text / the inflated stream: staging memory for them
-        if (hook && hook->records && hook->mem.alloc) { pinned.reset(new hgx_big_alloc_scope(hook->mem, 32u << 20)); al.on_raw = hook->on_raw; }
+        if (hook && hook->records && hook->mem.alloc) {
+            pinned.reset(new hgx_big_alloc_scope(hook->mem, 32u << 20));
+            al.on_raw = hook->on_raw;
+            al.defer_walk = hook->defer_walk && !(opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange);
+            al.defer_min_bytes = hook->defer_min_bytes;
+        }
         int rc = hgx_read_alignment_lines(path, regions, opts->n_threads, al, /*keep_binary=*/true);
         pinned.reset();
         if (rc) return rc;
         const double t1 = now();
+        if (al.deferred.on) {
+            // a BAM stream whose records the device walks, filters and sorts itself; should it decline, the file is read again
+            // the ordinary way (a rare path: a record the kernels do not take, a chain that does not link up)
+            rc = parse_lines(out, Lc, nullptr, 0, opts, true, hook, al.raw, al.raw_bytes, &al.deferred);
+            if (rc || !hook->declined_records) {
+                if (prof) fprintf(stderr, "[hgx_parse_alignment_file] read %.1f ms, parse %.1f ms (records walked on the device)\n", (t1 - t0) * 1e3, (now() - t1) * 1e3);
+                return rc;
+            }
+            hgx_batch_destroy(*out);
+            *out = nullptr;
+            hgx_align_lines al2;
+            pinned.reset(new hgx_big_alloc_scope(hook->mem, 32u << 20));
+            al2.on_raw = hook->on_raw;
+            rc = hgx_read_alignment_lines(path, regions, opts->n_threads, al2, /*keep_binary=*/true);
+            pinned.reset();
+            if (rc) return rc;
+            return parse_lines(out, Lc, al2.lines.data(), al2.lines.size(), opts, al2.binary, hook, al2.raw, al2.raw_bytes);
+        }
         rc = parse_lines(out, Lc, al.lines.data(), al.lines.size(), opts, al.binary, hook, al.raw, al.raw_bytes);
         if (prof) fprintf(stderr, "[hgx_parse_alignment_file] read %.1f ms, parse %.1f ms\n", (t1 - t0) * 1e3, (now() - t1) * 1e3);
         return rc;
@@ -1907,8 +1930,8 @@ void hgx_many_lines(const hgx_many_streams &ms, FeLine *dst, int n_threads) {
 // lines: name-grouped records.  Text: lines[i].p[lines[i].len] is writable (it becomes the record's terminator).  Binary (BAM
 // records as read): lines[i].p = the record's QNAME (32 bytes into the record), lines[i].len = its block_size.
 static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts, bool binary,
-                       hgx_front_hook *hook, const char *raw, size_t raw_bytes) {
-    HARGCHK(out && Lc && (lines || n == 0) && opts);
+                       hgx_front_hook *hook, const char *raw, size_t raw_bytes, const hgx_bam_deferred *def) {
+    HARGCHK(out && Lc && (lines || n == 0) && opts && (!def || (hook && hook->records && raw)));
     *out = nullptr;
     if (hook && hook->records && raw) {
         // the record route of the device front end: fields, filters and key grouping as kernels too -- nothing below runs
@@ -1916,7 +1939,7 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
         if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange) hook->declined_records = HGX_FE_DECLINE_OPTS;
         else {
             try {
-                const int rc = hook->records(*const_cast<hgx_locus *>(Lc), raw, raw_bytes, lines, n, binary, *opts, &hook->declined_records);
+                const int rc = hook->records(*const_cast<hgx_locus *>(Lc), raw, raw_bytes, lines, n, binary, *opts, &hook->declined_records, def);
                 if (rc) return rc;
             } catch (const std::exception &e) {
                 hgx_set_error("%s", e.what());
@@ -1925,6 +1948,7 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
             if (!hook->declined_records) { hook->declined = 0; return HGX_OK; }
         }
     }
+    if (def) return HGX_OK;                           // (declined: the caller reads the file again, with its records walked)
     hgx_locus &L = *const_cast<hgx_locus *>(Lc);
     hgx_batch *B = new hgx_batch();
     try {
