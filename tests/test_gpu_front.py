@@ -151,3 +151,76 @@ def test_device_front_end_on_deep_samples_and_files(tmp_path, n_pairs, err):
         assert (res.num_reads, res.num_pairs) == (ref.num_reads, ref.num_pairs)
         assert res.counts_sorted == ref.counts_sorted and res.gene_prob == ref.gene_prob
         assert [e["n_iter"] for e in res.em] == [e["n_iter"] for e in ref.em]
+
+
+def test_bam_records_walked_filtered_and_sorted_on_the_device(tmp_path):
+    """hgx_bam.cpp leaves a BAM's record walk, region filter and name sort to the device (k_bam_*): same batch as the host reader's
+    own walk / filter / stable name sort on -- a coordinate-sorted BAM with reads on a decoy reference, with a span region (overlap
+    rule from the CIGAR), without regions, with read names that are prefixes of each other and longer than one 8-byte sort chunk,
+    with a 40 kb record (longer than a walk range: the range without a record start is passed over), and a name-grouped BAM
+    (already in order: no sort).  A truncated stream is refused as the host refuses it."""
+    from hisatgenotype_amd import bamio
+    loc = synth.make_hla_like_locus(n_alleles=300, n_vars=500, seed=12)
+    pl = hl.PackedLocus.from_synth(loc)
+    sam = synth.simulate_sam_fast(loc, synth.pick_sample(loc, 2), 6000, err_rate=0.004, seed=9)
+    rng = random.Random(5)
+    lines = sam.splitlines()
+    out, k = [], 0
+    while k < len(lines):
+        name = lines[k].split("\t", 1)[0]
+        j = k
+        while j < len(lines) and lines[j].split("\t", 1)[0] == name:
+            j += 1
+        # awkward names: "q7" / "q70" / "q700..." (one a prefix of the other), some 30+ characters long with a common 24-character prefix
+        n = int(name[1:])
+        new = ("q%d" % n) if n % 3 == 0 else ("a_common_prefix_of_24_chr" + "x" * (n % 5) + "%d" % n if n % 3 == 1 else name)
+        for l in lines[k:j]:
+            out.append(new + "\t" + l.split("\t", 1)[1])
+        k = j
+    # decoy records on another reference, and one record far longer than a walk range (soft-clipped: it is filtered out later by its edit distance fields)
+    for d in range(200):
+        out.append("decoy%04d\t0\tDECOY\t%d\t60\t50M\t*\t0\t0\t%s\t%s\tNM:i:0\tMD:Z:50\tNH:i:1" % (d, 1 + 7 * d, "A" * 50, "I" * 50))
+    long_seq = "".join(rng.choice("ACGT") for _ in range(40000))
+    out.append("zlong\t0\tDECOY\t5\t60\t40000M\t*\t0\t0\t%s\t%s\tNM:i:0\tMD:Z:40000\tNH:i:1" % (long_seq, "I" * 40000))
+    rng.shuffle(out)                          # (write_bam_native sorts by coordinate; the name order is the reader's to restore)
+    text = "\n".join(out) + "\n"
+    refs = [(loc.ref_allele, len(loc.backbone)), ("DECOY", 50000)]
+    p_sorted, p_grouped = str(tmp_path / "s.bam"), str(tmp_path / "g.bam")
+    bamio.write_bam_native(p_sorted, text.encode(), refs, sort_by_coordinate=True)
+    grouped = "\n".join(sorted(out, key=lambda l: l.split("\t", 1)[0].encode())) + "\n"
+    bamio.write_bam_native(p_grouped, grouped.encode(), refs)
+    span = "%s:%d-%d" % (loc.ref_allele, 400, len(loc.backbone) - 700)
+    for path in (p_sorted, p_grouped):
+        for regions in ([loc.ref_allele], [span], None):
+            host = pl.parse_alignment_file(path, regions)
+            with engine.test_switches(front="device"):
+                dev = pl.parse_alignment_file_dev(path, regions=regions)
+                route, code = engine.front_last()
+            assert (route, code) == (2, 0), (path, regions, route, code)
+            assert host.n_reads > 5000
+            same_batch(host, dev.to_host(), len(loc.backbone))
+    # two regions: the reader keeps the walk (a record may belong to both); same batch through the host's line table
+    two = [loc.ref_allele, "DECOY:1-100"]
+    host = pl.parse_alignment_file(p_sorted, two)
+    with engine.test_switches(front="device"):
+        dev = pl.parse_alignment_file_dev(p_sorted, regions=two)
+        assert engine.front_last() == (2, 0)
+    same_batch(host, dev.to_host(), len(loc.backbone))
+    # a stream cut inside a record: refused by both
+    import struct
+    import zlib
+    raw = b"".join(bamio._bgzf_blocks(open(p_sorted, "rb").read()))
+    cut = raw[: len(raw) - 37]
+    p_cut = str(tmp_path / "cut.bam")
+    with open(p_cut, "wb") as fo:
+        for i in range(0, len(cut), 0xff00):
+            blk = cut[i:i + 0xff00]
+            comp = zlib.compressobj(1, zlib.DEFLATED, -15)
+            cdata = comp.compress(blk) + comp.flush()
+            fo.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cdata) + 25) + cdata +
+                     struct.pack("<II", zlib.crc32(blk) & 0xffffffff, len(blk)))
+        fo.write(bamio._BGZF_EOF)
+    with pytest.raises(capi.HgxError):
+        pl.parse_alignment_file(p_cut, None)
+    with engine.test_switches(front="device"), pytest.raises(capi.HgxError):
+        pl.parse_alignment_file_dev(p_cut, regions=None)
