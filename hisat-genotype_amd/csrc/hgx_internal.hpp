@@ -169,6 +169,9 @@ inline void hgx_par_tasks(int n_threads, size_t n_tasks, F fn) {           // fn
 // The alignment reader's internal result (hgx_bam.cpp -> hgx_sam.cpp): the records as a line table, stable-sorted by QNAME, over
 // buffers this object owns.  p[len] is a byte the parser may overwrite (the line's terminator).
 struct hgx_line { char *p; uint32_t len, klen; uint64_t key; };     // klen = QNAME length, key = its first 8 bytes, big endian
+// BGZF container (hgx_inflate.hip: inflate on the device, one wavefront per block)
+struct hgx_bgzf_block { size_t in_off, in_len, out_off, out_len; uint32_t crc; };
+int hgx_bgzf_scan(const unsigned char *data, size_t n, std::vector<hgx_bgzf_block> &blocks, size_t *total_out);
 // a BAM whose record walk, region filter and name sort are left to the device front end (hgx_front.hip: k_bam_*): the reader stops
 // after the inflate and the header
 struct hgx_bam_deferred {

@@ -525,6 +525,13 @@ int hgx_type_many(hgx_typing **out /* [n_tasks] */, int32_t *rc_out /* [n_tasks]
 int hgx_type_many_loci(int32_t n_loci, hgx_typing ***out, int32_t **rc_out_or_null, const hgx_locus *const *loci,
                        const hgx_index *const *ixs, hgx_many *const *manies, const hgx_type_opts *opts, void *stream);
 
+/* BGZF inflate on the device (SAM/BAM specification section 4.1; row 8f-3): a whole BGZF file in host memory -> its payload in host
+ * memory.  One wavefront per BGZF block decodes the block's DEFLATE stream (stored / fixed / dynamic Huffman) and checks CRC-32
+ * and ISIZE; *bad_blocks = blocks that did not pass (the payload is not to be used then).  *n_out = payload bytes (also when
+ * out_cap is too small: HGX_EINVAL).  What hgx_parse_alignment_file_dev / hgx_type_file do with a BAM goes through the same
+ * kernel, the payload staying in HBM.  Replaces the reference's `samtools view` decompression (typing_core.py:436-468).          */
+int hgx_bgzf_inflate(const void *bgzf, size_t n_bytes, void *out, size_t out_cap, size_t *n_out, int32_t *bad_blocks, void *stream);
+
 /* Kernel timing for roofline reports.  hgx_em_set_timing(1) makes hgx_em time a sample of its table-lookup mat-vec launches
  * (every 4th ungated rows pass and the cols pass after it), hgx_em_set_timing(2) every plain rows / cols pass, with events
  * attached to the dispatch itself (hipExtLaunchKernelGGL: kernel begin / end, as rocprofv3 measures).  Switching timing on
