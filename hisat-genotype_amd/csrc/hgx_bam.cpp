@@ -480,6 +480,43 @@ inline int64_t cigar_text_reflen(const char *p, const char *e) {
     return tot;
 }
 
+// BAM header: 1 = complete (refs, *body0 = offset of the first record), 0 = more bytes needed, -1 = not a BAM / malformed
+int parse_bam_header(const unsigned char *raw, size_t n, std::vector<std::string> &refs, size_t *body0) {
+    refs.clear();
+    if (n < 4) return 0;
+    if (memcmp(raw, "BAM\1", 4) != 0) return -1;
+    if (n < 12) return 0;
+    size_t p = 8 + (size_t)rd32(&raw[4]);
+    if (p + 4 > n) return 0;
+    const uint32_t n_ref = rd32(&raw[p]);
+    p += 4;
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (p + 4 > n) return 0;
+        const uint32_t l_name = rd32(&raw[p]);
+        if (l_name == 0) return -1;
+        if (p + 4 + l_name + 4 > n) return 0;
+        refs.emplace_back((const char *)&raw[p + 4], l_name - 1);
+        p += 4 + l_name + 4;
+    }
+    *body0 = p;
+    return 1;
+}
+
+// one BGZF block on this thread (zlib): false = corrupt
+bool inflate_one(const unsigned char *data, const hgx_bgzf_block &b, unsigned char *dst) {
+    if (b.out_len == 0) return true;
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) return false;
+    zs.next_in = const_cast<unsigned char *>(data + b.in_off);
+    zs.avail_in = (uInt)b.in_len;
+    zs.next_out = dst;
+    zs.avail_out = (uInt)b.out_len;
+    const int rc = inflate(&zs, Z_FINISH);
+    inflateEnd(&zs);
+    return rc == Z_STREAM_END && zs.total_out == b.out_len && (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, (uInt)b.out_len) == b.crc;
+}
+
 }   // namespace
 
 // The reader proper: the records of `path` as a line table, stable-sorted by QNAME, over buffers `out` owns.  Every line is
@@ -611,6 +648,52 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
     }
     lap(text_scanned ? "read file + lines" : "read file");
     Bytes raw;
+    if (data.size() >= 2 && data[0] == 0x1f && data[1] == 0x8b && keep_binary && out.defer_walk && out.inflate_dev && regs.size() <= 1 &&
+        (!filtered || regs.size() == 1)) {
+        // The caller inflates, walks, filters and sorts on the device: the host hops through the container, inflates the block(s) that
+        // hold the BAM header to learn the references and where the records begin, and hands the deflated bytes over.  Whatever
+        // does not fit (not a BAM, a malformed container or header, a small stream, a block the kernel does not take) goes the
+        // ordinary way below, which also words the errors.
+        std::vector<hgx_bgzf_block> blocks;
+        size_t total = 0;
+        if (hgx_bgzf_scan(data.data(), data.size(), blocks, &total) == HGX_OK && total < (1ull << 32) - 64) {
+            std::vector<unsigned char> head;
+            std::vector<std::string> refs;
+            size_t body0 = 0;
+            int st_h = 0;
+            for (size_t k = 0; k < blocks.size() && st_h == 0 && head.size() < (64u << 20); ++k) {
+                const size_t at = head.size();
+                head.resize(at + blocks[k].out_len);
+                if (!inflate_one(data.data(), blocks[k], head.data() + at)) { st_h = -1; break; }
+                st_h = parse_bam_header(head.data(), head.size(), refs, &body0);
+            }
+            if (st_h == 1 && total >= body0 && total - body0 >= out.defer_min_bytes && refs.size() < 65536 &&
+                out.inflate_dev(data.data(), data.size(), blocks, total) == 0) {
+                hgx_bam_deferred &d = out.deferred;
+                d.on = true;
+                d.on_device = true;
+                d.body0 = body0;
+                d.filtered = filtered;
+                d.ref_action.assign(refs.size(), filtered ? 0 : 1);
+                if (filtered) {
+                    const Region &r = regs[0];
+                    d.left0 = r.left0; d.right0 = r.right0;
+                    for (size_t i = 0; i < refs.size(); ++i) {
+                        if (refs[i].size() == r.whole.size() && memcmp(refs[i].data(), r.whole.data(), r.whole.size()) == 0) d.ref_action[i] = 1;
+                        else if (!r.name.empty() && refs[i].size() == r.name.size() && memcmp(refs[i].data(), r.name.data(), r.name.size()) == 0) d.ref_action[i] = 2;
+                    }
+                }
+                out.binary = true;
+                out.ref_names = refs;
+                out.lines.clear();
+                hgx_host_free(out.raw);
+                out.raw = nullptr;
+                out.raw_bytes = total;
+                lap("container + header (inflate, records: the device)");
+                return HGX_OK;
+            }
+        }
+    }
     if (data.size() >= 2 && data[0] == 0x1f && data[1] == 0x8b) {
         std::function<void(size_t, size_t)> part;
         if (out.on_raw) {

@@ -33,6 +33,8 @@
 #include "hgx_common.hpp"
 #include "hgx_internal.hpp"
 
+int hgx_bgzf_inflate_dev(const unsigned char *d_in, const hgx_bgzf_block *blocks, size_t n_blocks, unsigned char *d_out, hipStream_t st, int *bad);
+
 namespace {
 
 // ---- pinned staging blocks (the key table of a 1 M-read sample is ~65 MB: pinning that much per call costs more than the copy) ----
@@ -1184,12 +1186,29 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Pars
             g_last_bytes += (long long)(end - begin);
         };
         // a BAM's records are walked, filtered and name-sorted on the device too when the stream is big enough to be worth the launches
+        // -- and its BGZF blocks inflated there (hgx_inflate.hip): the deflated file goes up instead of the inflated stream
         hook.defer_walk = true;
         hook.defer_min_bytes = force ? 0 : (8u << 20);
+        if (!hgx_switch_has("front", "host_inflate"))
+            hook.inflate_dev = [&](const unsigned char *data, size_t n, const std::vector<hgx_bgzf_block> &blocks, size_t total) -> int {
+                if (up_failed || total >= (1ull << 32) - 64) return 1;
+                DevBuf b_comp;
+                if (b_comp.alloc(n + 2048)) return 1;
+                if (!b_text.p && b_text.alloc(total + 64)) return 1;
+                struct DrainC { hipStream_t s; ~DrainC() { (void)hipStreamSynchronize(s); } } drain_c{st};
+                if (hipMemcpyAsync(b_comp.p, data, n, hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+                if (hipMemsetAsync((char *)b_comp.p + n, 0, 2048, st) != hipSuccess) return 1;
+                int bad = 0;
+                if (hgx_bgzf_inflate_dev(b_comp.as<unsigned char>(), blocks.data(), blocks.size(), b_text.as<unsigned char>(), st, &bad) != HGX_OK || bad) return 1;
+                up_raw = nullptr;
+                up_bytes = total;
+                g_last_bytes += (long long)n;
+                return 0;
+            };
         hook.records = [&](hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &o,
                            int *declined, const hgx_bam_deferred *def) {
             if (!def && !force && n < 20000) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }
-            if (up_failed || raw != up_raw || raw_bytes != up_bytes) { *declined = HGX_FE_DECLINE_SIZE; return (int)HGX_OK; }
+            if (up_failed || raw != up_raw || raw_bytes != up_bytes || !b_text.p) { *declined = HGX_FE_DECLINE_SIZE; return (int)HGX_OK; }
             if (def) {
                 DevBuf b_dl;
                 uint32_t n_dl = 0;

@@ -9,9 +9,12 @@
 //            a v_readlane: no memory latency inside the symbol loop;
 //   symbols  a 10-bit (literal/length) and an 8-bit (distance) table of {symbol, code length} in LDS, built per DEFLATE block by
 //            the lanes; longer codes by the canonical first-code walk (counts per length, symbols sorted by (length, symbol));
-//   output   a 32 KB ring in LDS (DEFLATE's window): a literal is one byte store, a match is copied by the lanes from the ring
-//            (source index modulo the distance: every source byte lies before the match); 16 KB at a time leaves for memory,
-//            and each lane takes the CRC-32 of its 256-byte piece on the way, the pieces joined with the "256 zero bytes"
+//   output   an 8 KB ring in LDS holds the NEAR part of DEFLATE's 32 KB window: a literal is one byte store, a match up to ~7.9 KB
+//            back is copied by the lanes inside the ring (source index modulo the distance: every source byte lies before the
+//            match); a match farther back reads what has already left for memory (L1-bypassing loads behind a wait for the
+//            wavefront's own stores).  A small ring is what buys occupancy: 13 KB of LDS per wavefront seats three per SIMD, and
+//            with sequential symbol decoding the number of wavefronts in flight IS the throughput.  2 KB at a time leave for
+//            memory, each lane taking the CRC-32 of its 32-byte piece on the way, the pieces joined with the "32 zero bytes"
 //            operator of the CRC (crc32_combine's algebra, the matrix precomputed on the host).
 // A block's verdict (0 = inflated, CRC-32 and ISIZE right) is written per block: anything else makes the caller fall back to the
 // host reader, which reproduces the failure with its own message.
@@ -26,8 +29,9 @@
 
 namespace {
 
-constexpr int RING = 32768, RMASK = RING - 1, FLUSH = 16384;
+constexpr int RING = 8192, RMASK = RING - 1, FLUSH = 2048, PIECE = FLUSH / 64;      // (see the header: the ring holds the near window only)
 constexpr int LIT_P = 10, DIST_P = 8;
+constexpr bool REG_TABLES = false;      // primary tables through v_readlane from registers instead of LDS (measured: see NOTEBOOK.md section 11)
 
 struct HuffLds {
     uint16_t pt[1 << LIT_P];             // primary table: symbol << 4 | code length (0 = longer than the table's bits, or no such code)
@@ -55,7 +59,7 @@ __constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct BlockDesc { uint32_t in_off, in_len, out_off, out_len, crc; };
-struct CrcOp { uint32_t col[32]; };          // crc -> crc advanced by 256 zero bytes
+struct CrcOp { uint32_t col[32]; };          // crc -> crc advanced by PIECE zero bytes
 
 enum { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_CODE = 3, INF_BAD_DIST = 4, INF_OVERRUN = 5, INF_BAD_SIZE = 6, INF_BAD_CRC = 7,
        INF_BAD_LENGTHS = 8, INF_INPUT_END = 9 };
@@ -149,10 +153,30 @@ __device__ bool huff_build(T &H, const unsigned char *lens, uint16_t *code, int 
     __builtin_amdgcn_wave_barrier();
     return true;
 }
+// The primary table lives in REGISTERS for the symbol loop: entry i is half (i & 1) of dword i >> 1, which lane (i >> 1) & 63 holds
+// in register i >> 7 -- a lookup is a handful of v_readlane (the index is wave-uniform) instead of an LDS round trip, and with one
+// wavefront per SIMD (the 32 KB ring allows four per CU) that latency is the symbol rate.
+template <int NR>
+__device__ __forceinline__ void tab_load(uint32_t (&t)[NR], const uint16_t *pt, int lane) {
+#pragma unroll
+    for (int k = 0; k < NR; ++k) t[k] = reinterpret_cast<const uint32_t *>(pt)[k * 64 + lane];
+}
+template <int NR>
+__device__ __forceinline__ uint32_t tab_get(const uint32_t (&t)[NR], uint32_t i) {
+    const int ln = (int)((i >> 1) & 63u);
+    const uint32_t r = i >> 7;
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) {
+        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)t[k], ln);
+        v = r == (uint32_t)k ? x : v;
+    }
+    return (i & 1u) ? v >> 16 : v & 0xFFFFu;
+}
 // one symbol: the primary table, or the walk over the longer lengths; -1 = no such code.  (At least 15 bits are in the buffer.)
-template <class T, int P>
-__device__ __forceinline__ int huff_decode(const T &H, Bits &b) {
-    const uint16_t e = H.pt[bits_peek(b, P)];
+template <class T, int P, int NR>
+__device__ __forceinline__ int huff_decode(const T &H, const uint32_t (&t)[NR], Bits &b) {
+    const uint32_t e = REG_TABLES ? tab_get<NR>(t, bits_peek(b, P)) : (uint32_t)__builtin_amdgcn_readfirstlane((int)H.pt[bits_peek(b, P)]);
     if (e & 15) { bits_drop(b, e & 15); return e >> 4; }
     const uint32_t rev15 = __brev(bits_peek(b, 15)) >> 17;           // the next 15 bits, first bit most significant
     for (int L = P + 1; L <= 15; ++L) {
@@ -172,7 +196,7 @@ __device__ __forceinline__ uint32_t crc_bytes(const unsigned char *ring, uint32_
     }
     return ~c;
 }
-__device__ __forceinline__ uint32_t crc_advance256(const CrcOp &op, uint32_t v) {
+__device__ __forceinline__ uint32_t crc_advance_piece(const CrcOp &op, uint32_t v) {
     uint32_t r = 0;
 #pragma unroll
     for (int i = 0; i < 32; ++i) r ^= op.col[i] & (0u - ((v >> i) & 1u));
@@ -192,17 +216,17 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
     int err = INF_OK;
     auto flush = [&](uint32_t n) {             // the n oldest pending bytes leave the ring (n = FLUSH, or the rest at the end)
         for (uint32_t i = lane; i < n; i += 64) dst[fpos + i] = S.ring[(fpos + i) & RMASK];
-        // CRC-32: a 256-byte piece per lane, joined in order
-        const uint32_t n_piece = (n + 255) / 256;
+        // CRC-32: a PIECE-byte piece per lane, joined in order
+        const uint32_t n_piece = (n + PIECE - 1) / PIECE;
         if ((uint32_t)lane < n_piece) {
-            const uint32_t p0 = fpos + 256u * lane;
-            const int len = (int)min(256u, n - 256u * lane);
+            const uint32_t p0 = fpos + (uint32_t)PIECE * lane;
+            const int len = (int)min((uint32_t)PIECE, n - (uint32_t)PIECE * lane);
             S.crc_piece[lane] = crc_bytes(S.ring, p0, len);
         }
         __builtin_amdgcn_wave_barrier();
         for (uint32_t p = 0; p < n_piece; ++p) {
-            const uint32_t len = min(256u, n - 256u * p);
-            if (len == 256u) crc = crc_advance256(op, crc);
+            const uint32_t len = min((uint32_t)PIECE, n - (uint32_t)PIECE * p);
+            if (len == (uint32_t)PIECE) crc = crc_advance_piece(op, crc);
             else for (uint32_t k = 0; k < 8 * len; ++k) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
             crc ^= S.crc_piece[p];
         }
@@ -212,6 +236,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
     if (B.out_len > 0) {
         Bits b;
         bits_init(b, in + B.in_off, B.in_len, lane);
+        uint32_t tl[8], td[2];
         bool last = false;
         while (!last && !err) {
             bits_refill(b, lane);
@@ -256,11 +281,12 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                 __builtin_amdgcn_wave_barrier();
                 // the code-length code goes through the distance slot (19 symbols, at most 7 bits)
                 if (!huff_build<DistLds, DIST_P>(S.dist, S.lens, S.code, 19, lane, false)) { err = INF_BAD_LENGTHS; break; }
+                tab_load<2>(td, S.dist.pt, lane);
                 int at = 0, prev = 0;
                 const int total = n_lit + n_dist;
                 while (at < total && !err) {
                     bits_refill(b, lane);
-                    const int sym = huff_decode<DistLds, DIST_P>(S.dist, b);
+                    const int sym = huff_decode<DistLds, DIST_P, 2>(S.dist, td, b);
                     if (sym < 0) { err = INF_BAD_CODE; break; }
                     int rep = 1, val = sym;
                     if (sym == 16) { if (at == 0) { err = INF_BAD_LENGTHS; break; } rep = 3 + (int)bits_take(b, 2); val = prev; }
@@ -283,30 +309,58 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                 if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 32 + n_lit, S.code, n_dist, lane, true)) { err = INF_BAD_LENGTHS; break; }
             }
             // ---- the symbols of the block -------------------------------------------------------------------------------
+            tab_load<8>(tl, S.lit.pt, lane);
+            tab_load<2>(td, S.dist.pt, lane);
+            // (literals are gathered eight at a time: one byte store by eight lanes instead of eight stores by one)
+            uint64_t lit_acc = 0;
+            uint32_t lit_n = 0;
+            auto lit_out = [&]() {
+                if (lit_n) {
+                    if ((uint32_t)lane < lit_n) S.ring[(wpos + lane) & RMASK] = (unsigned char)(lit_acc >> (8 * lane));
+                    wpos += lit_n;
+                    lit_n = 0;
+                    lit_acc = 0;
+                }
+            };
             for (;;) {
                 bits_refill(b, lane);
-                const int sym = huff_decode<HuffLds, LIT_P>(S.lit, b);
+                const int sym = huff_decode<HuffLds, LIT_P, 8>(S.lit, tl, b);
                 if (sym < 0) { err = INF_BAD_CODE; break; }
                 if (sym < 256) {
-                    if (wpos >= B.out_len) { err = INF_OVERRUN; break; }
-                    if (lane == 0) S.ring[wpos & RMASK] = (unsigned char)sym;
-                    wpos += 1;
-                } else if (sym == 256) break;
-                else {
+                    lit_acc |= (uint64_t)(uint32_t)sym << (8 * lit_n);
+                    lit_n += 1;
+                    if (lit_n < 8) continue;
+                    if (wpos + lit_n > B.out_len) { err = INF_OVERRUN; break; }
+                    lit_out();
+                } else if (sym == 256) {
+                    if (wpos + lit_n > B.out_len) { err = INF_OVERRUN; break; }
+                    lit_out();
+                    break;
+                } else {
+                    if (wpos + lit_n > B.out_len) { err = INF_OVERRUN; break; }
+                    lit_out();
                     const int li = sym - 257;
                     if (li >= 29) { err = INF_BAD_CODE; break; }
                     const uint32_t len = c_len_base[li] + bits_take(b, c_len_extra[li]);
                     bits_refill(b, lane);
-                    const int ds = huff_decode<DistLds, DIST_P>(S.dist, b);
+                    const int ds = huff_decode<DistLds, DIST_P, 2>(S.dist, td, b);
                     if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
                     const uint32_t dist = c_dist_base[ds] + bits_take(b, c_dist_extra[ds]);
                     if (dist > wpos) { err = INF_BAD_DIST; break; }
                     if (wpos + len > B.out_len) { err = INF_OVERRUN; break; }
                     __builtin_amdgcn_wave_barrier();
                     // every source byte lies before the match: byte i comes from (i mod dist) bytes into the last `dist` bytes
-                    for (uint32_t i = lane; i < len; i += 64) {
-                        const uint32_t k = dist >= len ? i : i % dist;
-                        S.ring[(wpos + i) & RMASK] = S.ring[(wpos - dist + k) & RMASK];
+                    if (dist <= (uint32_t)(RING - 258)) {
+                        for (uint32_t i = lane; i < len; i += 64) {
+                            const uint32_t k = dist >= len ? i : i % dist;
+                            S.ring[(wpos + i) & RMASK] = S.ring[(wpos - dist + k) & RMASK];
+                        }
+                    } else {
+                        // beyond the ring: those bytes left for memory at least RING - FLUSH - 516 bytes ago (what is still pending
+                        // is closer than that); the wavefront's own stores are waited for, the loads bypass its L1
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        for (uint32_t i = lane; i < len; i += 64)
+                            S.ring[(wpos + i) & RMASK] = __builtin_nontemporal_load(dst + (wpos - dist + i));      // (dist > len here)
                     }
                     __builtin_amdgcn_wave_barrier();
                     wpos += len;
@@ -332,7 +386,7 @@ CrcOp make_crc_op() {
     CrcOp op;
     for (int i = 0; i < 32; ++i) {
         uint32_t c = 1u << i;
-        for (int k = 0; k < 8 * 256; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+        for (int k = 0; k < 8 * PIECE; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
         op.col[i] = c;
     }
     return op;

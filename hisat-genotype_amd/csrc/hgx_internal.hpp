@@ -176,6 +176,7 @@ int hgx_bgzf_scan(const unsigned char *data, size_t n, std::vector<hgx_bgzf_bloc
 // after the inflate and the header
 struct hgx_bam_deferred {
     bool on = false;
+    bool on_device = false;              // the inflated stream exists only in the caller's device buffer (it inflated the blocks itself)
     size_t body0 = 0;                    // offset of the first record's block_size in the inflated stream
     bool filtered = false;               // ONE region was given: per reference what it keeps
     std::vector<uint8_t> ref_action;     // [n_ref] 0 = drop, 1 = keep, 2 = keep where [pos0, end0] overlaps [left0, right0]
@@ -199,6 +200,10 @@ struct hgx_align_lines {
     bool defer_walk = false;
     size_t defer_min_bytes = 0;
     hgx_bam_deferred deferred;
+    // in: with defer_walk -- the caller can also inflate the BGZF blocks itself (hgx_inflate.hip): called with the file's bytes and
+    // block table once the BAM header (inflated on the host) says the stream qualifies; returns 0 when the payload now lies in
+    // the caller's device buffer (deferred.on_device: `raw` stays NULL, raw_bytes = the payload's size), else the host inflates
+    std::function<int(const unsigned char *data, size_t n, const std::vector<hgx_bgzf_block> &blocks, size_t total)> inflate_dev;
     hgx_align_lines() = default;
     hgx_align_lines(const hgx_align_lines &) = delete;
     hgx_align_lines &operator=(const hgx_align_lines &) = delete;
@@ -274,6 +279,7 @@ struct hgx_front_hook {
                       int *declined, const hgx_bam_deferred *def)> records;
     bool defer_walk = false;           // the hook's owner takes unwalked BAM streams
     size_t defer_min_bytes = 0;
+    std::function<int(const unsigned char *data, size_t n, const std::vector<hgx_bgzf_block> &blocks, size_t total)> inflate_dev;   // ... and deflated ones
     std::function<void(const char *raw, size_t n_bytes, size_t begin, size_t end)> on_raw;
     int declined_records = 0;
 };

@@ -1812,10 +1812,11 @@ int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *Lc, const ch
         hgx_align_lines al;                     // the reader's buffers are tokenised in place (no copy, no trip through the caller)
         std::unique_ptr<hgx_big_alloc_scope> pinned;   // the record route uploads the text / the inflated stream: staging memory for them
         if (hook && hook->records && hook->mem.alloc) {
-            pinned.reset(new hgx_big_alloc_scope(hook->mem, 32u << 20));
+            pinned.reset(new hgx_big_alloc_scope(hook->mem, 4u << 20));
             al.on_raw = hook->on_raw;
             al.defer_walk = hook->defer_walk && !(opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange);
             al.defer_min_bytes = hook->defer_min_bytes;
+            if (al.defer_walk) al.inflate_dev = hook->inflate_dev;
         }
         int rc = hgx_read_alignment_lines(path, regions, opts->n_threads, al, /*keep_binary=*/true);
         pinned.reset();
@@ -1931,9 +1932,9 @@ void hgx_many_lines(const hgx_many_streams &ms, FeLine *dst, int n_threads) {
 // records as read): lines[i].p = the record's QNAME (32 bytes into the record), lines[i].len = its block_size.
 static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, size_t n, const hgx_parse_opts *opts, bool binary,
                        hgx_front_hook *hook, const char *raw, size_t raw_bytes, const hgx_bam_deferred *def) {
-    HARGCHK(out && Lc && (lines || n == 0) && opts && (!def || (hook && hook->records && raw)));
+    HARGCHK(out && Lc && (lines || n == 0) && opts && (!def || (hook && hook->records && (raw || def->on_device))));
     *out = nullptr;
-    if (hook && hook->records && raw) {
+    if (hook && hook->records && (raw || (def && def->on_device))) {
         // the record route of the device front end: fields, filters and key grouping as kernels too -- nothing below runs
         hook->declined_records = 0;
         if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange) hook->declined_records = HGX_FE_DECLINE_OPTS;
