@@ -366,13 +366,17 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
             route, code = engine.front_last()
             sent = engine.front_last_bytes()
             out[kind] = {"reads_per_s": round(res.num_reads / med_s, 1), "ms": round(med_s * 1e3, 2), "best_ms": round(min(spaced) * 1e3, 2),
-                         "front_end": {"route": {2: "record route: fields, filters, key grouping, pileup, decode, piece table, pair protocol as kernels",
+                         "front_end": {"route": {2: "record route: " + ("BGZF inflate, record walk, region filter, name sort, " if kind == "bam" else "") +
+                                                    "fields, filters, key grouping, pileup, decode, piece table, pair protocol as kernels",
                                                  1: "key route: host tokenises / filters / groups, the rest as kernels",
                                                  0: "host stages"}[route], "decline_code": code, "bytes_to_device": sent},
                          "roofline": {"bound": "pcie", "achieved": round(sent / med_s / 1e9, 2), "peak": PCIE_H2D_GBS, "unit": "GB/s",
                                       "frac": round(sent / med_s / 1e9 / PCIE_H2D_GBS, 4),
-                                      "note": "bytes the call sends to the device (SAM text / inflated BAM stream + line table) / the call's time, against "
-                                              "the measured host-to-device rate of registered memory (tools/pinned_probe.hip: 57.5 GB/s; PCIe Gen5 x16)"},
+                                      "note": ("bytes the call sends to the device (the SAM text + its line table) / the call's time, against the measured "
+                                               "host-to-device rate of registered memory (tools/pinned_probe.hip: 57.5 GB/s; PCIe Gen5 x16)") if kind == "sam" else
+                                              ("a BAM travels DEFLATED (the file's bytes + a block table): the link is idle; the call is bound by "
+                                               "k_bgzf_inflate -- sequential symbol decoding, one wavefront per BGZF block, ~55-60 GB/s of payload -- and "
+                                               "the record kernels behind it (DESIGN.md section 5.6)")},
                          "runs_ms": [round(t * 1e3, 1) for t in spaced],
                          "throttled_ms": None if th1 is None else round((th2 - th1) / 1e3, 1),
                          "cpu_seconds_per_call": round(cpu_s, 3),

@@ -1000,6 +1000,71 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
     return HGX_OK;
 }
 
+// many tasks' BAM files, read side by side and left deflated (hgx_internal.hpp: hgx_bgzf_task)
+int hgx_bgzf_tasks_read(std::vector<hgx_bgzf_task> &tasks, const char *const *paths, const char *const *regions, int n_tasks, int n_threads,
+                        const hgx_front_alloc *mem, const std::function<void(int)> &on_task) {
+    HARGCHK(paths && n_tasks >= 0);
+    tasks.clear();
+    tasks.resize((size_t)n_tasks);
+    if (n_threads <= 0) n_threads = hgx_default_threads();
+    n_threads = std::max(1, std::min(n_threads, 512));
+    hgx_par_tasks(std::min(n_threads, std::max(n_tasks, 1)), (size_t)n_tasks, [&](int, size_t t) {
+        hgx_bgzf_task &T = tasks[t];
+        try {
+            if (!paths[t]) return;
+            const int fd = open(paths[t], O_RDONLY);
+            if (fd < 0) return;
+            struct stat sb;
+            if (fstat(fd, &sb) != 0 || sb.st_size < 28) { close(fd); return; }
+            {
+                std::unique_ptr<hgx_big_alloc_scope> pinned;
+                if (mem && mem->alloc) pinned.reset(new hgx_big_alloc_scope(*mem, 64u << 10));
+                T.data = (unsigned char *)hgx_host_alloc((size_t)sb.st_size + 1);
+            }
+            T.n = (size_t)sb.st_size;
+            size_t got_all = 0;
+            while (got_all < T.n) {
+                const ssize_t got = pread(fd, T.data + got_all, T.n - got_all, (off_t)got_all);
+                if (got <= 0) break;
+                got_all += (size_t)got;
+            }
+            close(fd);
+            if (got_all != T.n || T.data[0] != 0x1f || T.data[1] != 0x8b) return;
+            const std::vector<Region> regs = parse_regions(regions ? regions[t] : nullptr);
+            const bool filtered = regions && regions[t] && regions[t][0] != 0;
+            if (regs.size() > 1 || (filtered && regs.size() != 1)) return;
+            if (hgx_bgzf_scan(T.data, T.n, T.blocks, &T.total) != HGX_OK || T.total >= (1ull << 32) - 64) return;
+            std::vector<unsigned char> head;
+            std::vector<std::string> refs;
+            size_t body0 = 0;
+            int st_h = 0;
+            for (size_t k = 0; k < T.blocks.size() && st_h == 0 && head.size() < (64u << 20); ++k) {
+                const size_t at = head.size();
+                head.resize(at + T.blocks[k].out_len);
+                if (!inflate_one(T.data, T.blocks[k], head.data() + at)) { st_h = -1; break; }
+                st_h = parse_bam_header(head.data(), head.size(), refs, &body0);
+            }
+            if (st_h != 1 || body0 > T.total || refs.size() >= 65536) return;
+            hgx_bam_deferred &d = T.def;
+            d.on = true; d.on_device = true; d.body0 = body0; d.filtered = filtered;
+            d.ref_action.assign(refs.size(), filtered ? 0 : 1);
+            if (filtered) {
+                const Region &r = regs[0];
+                d.left0 = r.left0; d.right0 = r.right0;
+                for (size_t i = 0; i < refs.size(); ++i) {
+                    if (refs[i].size() == r.whole.size() && memcmp(refs[i].data(), r.whole.data(), r.whole.size()) == 0) d.ref_action[i] = 1;
+                    else if (!r.name.empty() && refs[i].size() == r.name.size() && memcmp(refs[i].data(), r.name.data(), r.name.size()) == 0) d.ref_action[i] = 2;
+                }
+            }
+            T.ok = true;
+            if (on_task) on_task((int)t);
+        } catch (const std::exception &) {
+            T.ok = false;
+        }
+    });
+    return HGX_OK;
+}
+
 extern "C" int hgx_read_alignments(const char *path, const char *regions, int32_t n_threads, char **text_out, size_t *n_bytes_out) {
     HARGCHK(path && text_out && n_bytes_out);
     *text_out = nullptr;

@@ -543,23 +543,43 @@ __device__ bool bam_plausible(const unsigned char *raw, size_t n, size_t o, int 
     for (uint32_t k = 0; k + 1 < l_rn; ++k) if (r[32 + k] < 33 || r[32 + k] > 126) return false;
     return true;
 }
-struct BamRange { uint32_t first, stop, count, state; };     // state: 1 = walked, 2 = no record start in the range, 0 = a broken record
-// PASS 0: find the range's first record and count; PASS 1: the same walk again, writing (offset after block_size, length)
+struct BamRange { uint32_t first, stop, count, state; };     // (offsets inside the task's stream) state: 1 = walked, 2 = no record start in the range, 0 = a broken record
+// a task's stream inside the device text (one task: the whole text), its header's verdicts and its share of the walk ranges
+struct BamSeg {
+    uint32_t base, n, body0;           // where the stream starts in the text, its bytes, its first record
+    int32_t n_ref;
+    uint32_t act_off;                  // its references' actions in the action table (0 drop, 1 keep, 2 keep where the span overlaps)
+    uint32_t filtered;
+    long long left0, right0;
+    uint32_t first_range, n_ranges;
+};
+__device__ __forceinline__ int bam_seg_of(const BamSeg *__restrict__ segs, int n_seg, uint32_t range) {
+    int lo = 0, hi = n_seg - 1;
+    while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (segs[mid].first_range <= range) lo = mid; else hi = mid - 1; }
+    return lo;
+}
+// PASS 0: find the range's first record and count; PASS 1: the same walk again, writing (offset after block_size, length, task)
 template <int PASS>
-__global__ void __launch_bounds__(64) k_bam_walk(const unsigned char *__restrict__ raw, size_t n, size_t body0, int n_ref, int W, BamRange *__restrict__ rng,
-                                                 const uint32_t *__restrict__ base, uint32_t *__restrict__ rec_off, uint32_t *__restrict__ rec_len) {
+__global__ void __launch_bounds__(64) k_bam_walk(const unsigned char *__restrict__ text, const BamSeg *__restrict__ segs, int n_seg, int W,
+                                                 BamRange *__restrict__ rng, const uint32_t *__restrict__ base, uint32_t *__restrict__ rec_off,
+                                                 uint32_t *__restrict__ rec_len, uint16_t *__restrict__ rec_task) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= W) return;
-    const size_t lo = body0 + (n - body0) * (size_t)t / (size_t)W, hi = body0 + (n - body0) * (size_t)(t + 1) / (size_t)W;
+    const int sg = bam_seg_of(segs, n_seg, (uint32_t)t);
+    const BamSeg G = segs[sg];
+    const unsigned char *raw = text + G.base;
+    const size_t n = G.n, body0 = G.body0;
+    const size_t k = (size_t)t - G.first_range, Wg = G.n_ranges;
+    const size_t lo = body0 + (n - body0) * k / Wg, hi = body0 + (n - body0) * (k + 1) / Wg;
     size_t o = lo;
     if (PASS == 0) {
-        if (t > 0) {
+        if (k > 0) {
             bool found = false;
             for (; o < hi; ++o) {
-                if (!bam_plausible(raw, n, o, n_ref)) continue;
+                if (!bam_plausible(raw, n, o, G.n_ref)) continue;
                 size_t q = o;
                 int good = 0;
-                while (good < 4 && q < n && bam_plausible(raw, n, q, n_ref)) { q += 4 + (size_t)bam_u32(raw + q); ++good; }
+                while (good < 4 && q < n && bam_plausible(raw, n, q, G.n_ref)) { q += 4 + (size_t)bam_u32(raw + q); ++good; }
                 if (good == 4 || q == n) { found = true; break; }
             }
             if (!found) { rng[t] = BamRange{(uint32_t)hi, (uint32_t)hi, 0u, 2u}; return; }
@@ -576,44 +596,48 @@ __global__ void __launch_bounds__(64) k_bam_walk(const unsigned char *__restrict
         if (q + 4 > n) { ok = false; break; }
         const uint32_t bs = bam_u32(raw + q);
         if (bs < 32 || q + 4 + (size_t)bs > n) { ok = false; break; }
-        if (PASS == 1) { rec_off[at] = (uint32_t)(q + 4); rec_len[at] = bs; ++at; }
+        if (PASS == 1) { rec_off[at] = (uint32_t)(G.base + q + 4); rec_len[at] = bs; rec_task[at] = (uint16_t)sg; ++at; }
         ++cnt;
         q += 4 + (size_t)bs;
     }
     if (PASS == 0) rng[t] = BamRange{(uint32_t)o, (uint32_t)q, cnt, ok ? 1u : 0u};
 }
-// the ranges must link up: every walked range begins where the walked range before it stopped (ranges without a record start --
-// a record longer than a range -- are passed over), the first at the first record, the last ends with the stream
-__global__ void __launch_bounds__(256) k_bam_link(const BamRange *__restrict__ rng, int W, size_t n, size_t body0, uint32_t *__restrict__ cnt, BamCtl *ctl) {
+// the ranges of a task must link up: every walked range begins where the walked range before it stopped (ranges without a record
+// start -- a record longer than a range -- are passed over), the first at the first record, the last ends with the stream
+__global__ void __launch_bounds__(256) k_bam_link(const BamRange *__restrict__ rng, const BamSeg *__restrict__ segs, int n_seg, int W,
+                                                  uint32_t *__restrict__ cnt, BamCtl *ctl) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= W) return;
     const BamRange r = rng[t];
     cnt[t] = r.state == 1u ? r.count : 0u;
     if (r.state == 2u) return;
     if (r.state != 1u) { bam_decline(ctl, HGX_FE_DECLINE_RECORD); return; }
+    const BamSeg G = segs[bam_seg_of(segs, n_seg, (uint32_t)t)];
+    const int r0 = (int)G.first_range, r1 = r0 + (int)G.n_ranges;
     int p = t - 1;
-    while (p >= 0 && rng[p].state == 2u) --p;
-    const size_t expect = p < 0 ? body0 : (size_t)rng[p].stop;
-    if ((size_t)r.first != expect) { bam_decline(ctl, HGX_FE_DECLINE_RECORD); return; }
+    while (p >= r0 && rng[p].state == 2u) --p;
+    const uint32_t expect = p < r0 ? G.body0 : rng[p].stop;
+    if (r.first != expect) { bam_decline(ctl, HGX_FE_DECLINE_RECORD); return; }
     int q = t + 1;
-    while (q < W && rng[q].state == 2u) ++q;
-    if (q == W && (size_t)r.stop != n) bam_decline(ctl, HGX_FE_DECLINE_RECORD);
+    while (q < r1 && rng[q].state == 2u) ++q;
+    if (q == r1 && r.stop != G.n) bam_decline(ctl, HGX_FE_DECLINE_RECORD);
 }
 __global__ void k_bam_total(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ base, int W, BamCtl *ctl) {
     if (blockIdx.x == 0 && threadIdx.x == 0) ctl->n_rec = base[W - 1] + cnt[W - 1];
 }
 // region filter (hgx_bam.cpp: reference span from the CIGAR, overlap with the one region) + the checks the host makes on a record
-__global__ void __launch_bounds__(256) k_bam_filter(const unsigned char *__restrict__ raw, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ rec_len,
-                                                    uint32_t n_rec, const uint8_t *__restrict__ ref_action, int n_ref, int filtered, long long left0,
-                                                    long long right0, uint32_t *__restrict__ keep, BamCtl *ctl) {
+__global__ void __launch_bounds__(256) k_bam_filter(const unsigned char *__restrict__ text, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ rec_len,
+                                                    const uint16_t *__restrict__ rec_task, uint32_t n_rec, const BamSeg *__restrict__ segs,
+                                                    const uint8_t *__restrict__ ref_action, uint32_t *__restrict__ keep, BamCtl *ctl) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_rec) return;
-    const unsigned char *r = raw + rec_off[i];
+    const unsigned char *r = text + rec_off[i];
     const uint32_t bs = rec_len[i], l_rn = r[8];
+    const BamSeg G = segs[rec_task[i]];
     uint32_t k = 1;
-    if (filtered) {
+    if (G.filtered) {
         const int32_t rid = bam_i32(r), pos = bam_i32(r + 4);
-        if (rid < 0 || rid >= n_ref) k = 0;
+        if (rid < 0 || rid >= G.n_ref) k = 0;
         else {
             const uint32_t n_cig = bam_u16(r + 12), flag = bam_u16(r + 14);
             long long reflen = 0;
@@ -625,8 +649,8 @@ __global__ void __launch_bounds__(256) k_bam_filter(const unsigned char *__restr
                 }
             }
             const long long end0 = (long long)pos + (reflen > 0 ? reflen : 1) - 1;
-            const uint8_t act = ref_action[rid];
-            k = act == 1 ? 1u : (act == 2 ? ((end0 >= left0 && (long long)pos <= right0) ? 1u : 0u) : 0u);
+            const uint8_t act = ref_action[G.act_off + (uint32_t)rid];
+            k = act == 1 ? 1u : (act == 2 ? ((end0 >= G.left0 && (long long)pos <= G.right0) ? 1u : 0u) : 0u);
         }
     }
     if (k && (l_rn == 0 || 32 + (size_t)l_rn > bs || r[32 + l_rn - 1] != 0)) { bam_decline(ctl, HGX_FE_DECLINE_RECORD); k = 0; }   // "malformed BAM record": the host's to report
@@ -645,28 +669,33 @@ __device__ __forceinline__ int bam_name_cmp(const unsigned char *a, uint32_t la,
     for (uint32_t k = 0; k < m; ++k) if (a[k] != b[k]) return a[k] < b[k] ? -1 : 1;
     return la < lb ? -1 : (la > lb ? 1 : 0);
 }
-__global__ void __launch_bounds__(256) k_bam_sorted(const unsigned char *__restrict__ raw, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ idx,
-                                                    uint32_t n, BamCtl *ctl) {
+__global__ void __launch_bounds__(256) k_bam_sorted(const unsigned char *__restrict__ text, const uint32_t *__restrict__ rec_off, const uint16_t *__restrict__ rec_task,
+                                                    const uint32_t *__restrict__ idx, uint32_t n, BamCtl *ctl) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 || i >= n) return;
-    const unsigned char *a = raw + rec_off[idx[i - 1]], *b = raw + rec_off[idx[i]];
+    if (rec_task[idx[i - 1]] != rec_task[idx[i]]) return;                  // (records are in task order before the sort: only names inside a task matter)
+    const unsigned char *a = text + rec_off[idx[i - 1]], *b = text + rec_off[idx[i]];
     if (bam_name_cmp(b + 32, (uint32_t)b[8] - 1, a + 32, (uint32_t)a[8] - 1) < 0) ctl->unsorted = 1;
 }
 // bytes [8 c, 8 c + 8) of every name, big endian, zero beyond its end: LSD radix passes over these give the byte order above
-__global__ void __launch_bounds__(256) k_bam_name_key(const unsigned char *__restrict__ raw, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ idx,
+__global__ void __launch_bounds__(256) k_bam_name_key(const unsigned char *__restrict__ text, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ idx,
                                                       uint32_t n, uint32_t chunk, unsigned long long *__restrict__ key) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const unsigned char *r = raw + rec_off[idx[i]];
+    const unsigned char *r = text + rec_off[idx[i]];
     const uint32_t klen = (uint32_t)r[8] - 1;
     unsigned long long v = 0;
     for (uint32_t k = 0; k < 8; ++k) { const uint32_t at = 8 * chunk + k; v = (v << 8) | (at < klen ? r[32 + at] : 0u); }
     key[i] = v;
 }
-__global__ void k_bam_lines(const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ rec_len, const uint32_t *__restrict__ idx, uint32_t n,
-                            FeLine *__restrict__ lines) {
+__global__ void k_bam_task_key(const uint16_t *__restrict__ rec_task, const uint32_t *__restrict__ idx, uint32_t n, unsigned long long *__restrict__ key) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const uint32_t r = idx[i]; lines[i] = FeLine{rec_off[r], rec_len[r], 0u}; }
+    if (i < n) key[i] = rec_task[idx[i]];
+}
+__global__ void k_bam_lines(const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ rec_len, const uint16_t *__restrict__ rec_task,
+                            const uint32_t *__restrict__ idx, uint32_t n, FeLine *__restrict__ lines) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t r = idx[i]; lines[i] = FeLine{rec_off[r], rec_len[r], (uint32_t)rec_task[r]}; }
 }
 
 struct MaxU32 { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
@@ -952,29 +981,56 @@ LineRef *line_refs(const char *raw, const hgx_line *lines, size_t n_lines, bool 
     return dst;
 }
 
-// the line table of an unwalked BAM stream (resident at d_text), made on the device: (offset, length) of the records the region
-// keeps, in QNAME order (stable: file order among equal names) -- what hgx_bam.cpp's walk + filter + sort_lines give
-int bam_lines_dev(const char *d_text, size_t raw_bytes, const hgx_bam_deferred &def, hipStream_t st, DevBuf &b_lines, uint32_t *n_lines, int *declined) {
+// the line table of unwalked BAM streams (resident at d_text: one per task, at `bases`), made on the device: (offset, length, task) of
+// the records the tasks' regions keep, task after task, in QNAME order inside a task (stable: file order among equal names) -- what
+// hgx_bam.cpp's walk + filter + sort_lines give per file
+int bam_lines_dev(const char *d_text, const std::vector<const hgx_bam_deferred *> &defs, const std::vector<size_t> &bases, const std::vector<size_t> &sizes,
+                  hipStream_t st, DevBuf &b_lines, uint32_t *n_lines, int *declined) {
     *declined = 0;
     *n_lines = 0;
     Lap lap(st);
-    const unsigned char *raw = (const unsigned char *)d_text;
-    const size_t n = raw_bytes, body0 = def.body0;
-    const int n_ref = (int)def.ref_action.size();
-    if (body0 > n || n >= (1ull << 32) - 64) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
-    const int W = (int)std::max<size_t>(1, std::min<size_t>(8192, (n - body0) / 16384 + 1));
-    DevBuf b_rng, b_base, b_cnt, b_tmpw, b_ctl, b_act, b_off, b_len, b_keep, b_pos, b_idx, b_idx2, b_key, b_key2, b_tmp;
+    const unsigned char *text = (const unsigned char *)d_text;
+    const int n_seg = (int)defs.size();
+    if (n_seg < 1 || n_seg > 65535) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+    std::vector<BamSeg> segs((size_t)n_seg);
+    std::vector<uint8_t> acts;
+    size_t total_body = 0;
+    for (int t = 0; t < n_seg; ++t) {
+        if (defs[t]->body0 > sizes[t] || bases[t] + sizes[t] >= (1ull << 32) - 64) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+        total_body += sizes[t] - defs[t]->body0;
+    }
+    // ranges: ~16 KB of records each, at most 8192 for a lone stream, shared out by size among many
+    const size_t W_all = std::max<size_t>((size_t)n_seg, std::min<size_t>(8192 + (size_t)n_seg, total_body / 16384 + 1));
+    uint32_t w_at = 0;
+    for (int t = 0; t < n_seg; ++t) {
+        const hgx_bam_deferred &d = *defs[t];
+        BamSeg &G = segs[t];
+        G.base = (uint32_t)bases[t]; G.n = (uint32_t)sizes[t]; G.body0 = (uint32_t)d.body0;
+        G.n_ref = (int32_t)d.ref_action.size();
+        G.act_off = (uint32_t)acts.size();
+        acts.insert(acts.end(), d.ref_action.begin(), d.ref_action.end());
+        G.filtered = d.filtered ? 1u : 0u; G.left0 = (long long)d.left0; G.right0 = (long long)d.right0;
+        const size_t body = sizes[t] - d.body0;
+        G.first_range = w_at;
+        G.n_ranges = (uint32_t)std::max<size_t>(1, total_body ? (W_all * body + total_body - 1) / total_body : 1);
+        w_at += G.n_ranges;
+    }
+    const int W = (int)w_at;
+    DevBuf b_seg, b_rng, b_base, b_cnt, b_tmpw, b_ctl, b_act, b_off, b_len, b_task, b_keep, b_pos, b_idx, b_idx2, b_key, b_key2, b_tmp;
     struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
+    ALLOC(b_seg, (size_t)n_seg * sizeof(BamSeg));
     ALLOC(b_rng, (size_t)W * sizeof(BamRange));
     ALLOC(b_base, (size_t)W * 4);
     ALLOC(b_cnt, (size_t)W * 4);
     ALLOC(b_ctl, sizeof(BamCtl));
-    ALLOC(b_act, std::max<size_t>((size_t)n_ref, 16));
+    ALLOC(b_act, std::max<size_t>(acts.size(), 16));
     HIPCHK(hipMemsetAsync(b_ctl.p, 0, sizeof(BamCtl), st));
-    if (n_ref) HIPCHK(hipMemcpyAsync(b_act.p, def.ref_action.data(), (size_t)n_ref, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b_seg.p, segs.data(), (size_t)n_seg * sizeof(BamSeg), hipMemcpyHostToDevice, st));
+    if (!acts.empty()) HIPCHK(hipMemcpyAsync(b_act.p, acts.data(), acts.size(), hipMemcpyHostToDevice, st));
     BamCtl *ctl = b_ctl.as<BamCtl>();
-    k_bam_walk<0><<<nblk(W, 64), 64, 0, st>>>(raw, n, body0, n_ref, W, b_rng.as<BamRange>(), nullptr, nullptr, nullptr);
-    k_bam_link<<<nblk(W, 256), 256, 0, st>>>(b_rng.as<BamRange>(), W, n, body0, b_cnt.as<uint32_t>(), ctl);
+    const BamSeg *d_seg = b_seg.as<BamSeg>();
+    k_bam_walk<0><<<nblk(W, 64), 64, 0, st>>>(text, d_seg, n_seg, W, b_rng.as<BamRange>(), nullptr, nullptr, nullptr, nullptr);
+    k_bam_link<<<nblk(W, 256), 256, 0, st>>>(b_rng.as<BamRange>(), d_seg, n_seg, W, b_cnt.as<uint32_t>(), ctl);
     {
         size_t tbw = 0;
         (void)hipcub::DeviceScan::ExclusiveSum((void *)nullptr, tbw, (uint32_t *)nullptr, (uint32_t *)nullptr, W, st);
@@ -991,7 +1047,7 @@ int bam_lines_dev(const char *d_text, size_t raw_bytes, const hgx_bam_deferred &
     if (n_rec >= (1u << 30)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
     ALLOC(b_lines, std::max<size_t>(n_rec, 1) * sizeof(LineRef));
     if (n_rec == 0) return HGX_OK;
-    ALLOC(b_off, (size_t)n_rec * 4); ALLOC(b_len, (size_t)n_rec * 4); ALLOC(b_keep, (size_t)n_rec * 4); ALLOC(b_pos, (size_t)n_rec * 4);
+    ALLOC(b_off, (size_t)n_rec * 4); ALLOC(b_len, (size_t)n_rec * 4); ALLOC(b_task, (size_t)n_rec * 2 + 16); ALLOC(b_keep, (size_t)n_rec * 4); ALLOC(b_pos, (size_t)n_rec * 4);
     ALLOC(b_idx, (size_t)n_rec * 4); ALLOC(b_idx2, (size_t)n_rec * 4); ALLOC(b_key, (size_t)n_rec * 8); ALLOC(b_key2, (size_t)n_rec * 8);
     size_t tb = 0, tb2 = 0;
     (void)hipcub::DeviceScan::ExclusiveSum((void *)nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_rec, st);
@@ -999,9 +1055,10 @@ int bam_lines_dev(const char *d_text, size_t raw_bytes, const hgx_bam_deferred &
                                              (uint32_t *)nullptr, (int)n_rec, 0, 64, st);
     const size_t tmp_bytes = std::max(tb, tb2);
     ALLOC(b_tmp, std::max<size_t>(tmp_bytes, 256));
-    k_bam_walk<1><<<nblk(W, 64), 64, 0, st>>>(raw, n, body0, n_ref, W, b_rng.as<BamRange>(), b_base.as<uint32_t>(), b_off.as<uint32_t>(), b_len.as<uint32_t>());
-    k_bam_filter<<<nblk(n_rec, 256), 256, 0, st>>>(raw, b_off.as<uint32_t>(), b_len.as<uint32_t>(), n_rec, b_act.as<uint8_t>(), n_ref, def.filtered ? 1 : 0,
-                                                   (long long)def.left0, (long long)def.right0, b_keep.as<uint32_t>(), ctl);
+    k_bam_walk<1><<<nblk(W, 64), 64, 0, st>>>(text, d_seg, n_seg, W, b_rng.as<BamRange>(), b_base.as<uint32_t>(), b_off.as<uint32_t>(), b_len.as<uint32_t>(),
+                                             b_task.as<uint16_t>());
+    k_bam_filter<<<nblk(n_rec, 256), 256, 0, st>>>(text, b_off.as<uint32_t>(), b_len.as<uint32_t>(), b_task.as<uint16_t>(), n_rec, d_seg, b_act.as<uint8_t>(),
+                                                   b_keep.as<uint32_t>(), ctl);
     { size_t b = tmp_bytes; HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_keep.as<uint32_t>(), b_pos.as<uint32_t>(), (int)n_rec, st)); }
     k_bam_compact<<<nblk(n_rec, 256), 256, 0, st>>>(b_keep.as<uint32_t>(), b_pos.as<uint32_t>(), n_rec, b_idx.as<uint32_t>(), ctl);
     HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
@@ -1012,21 +1069,27 @@ int bam_lines_dev(const char *d_text, size_t raw_bytes, const hgx_bam_deferred &
     uint32_t *idx = b_idx.as<uint32_t>(), *idx_alt = b_idx2.as<uint32_t>();
     if (n_kept > 1) {
         // an aligner writes its records grouped by read already: a stable sort would not move anything
-        k_bam_sorted<<<nblk(n_kept, 256), 256, 0, st>>>(raw, b_off.as<uint32_t>(), idx, n_kept, ctl);
+        k_bam_sorted<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_off.as<uint32_t>(), b_task.as<uint16_t>(), idx, n_kept, ctl);
         HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (h.unsorted) {
             unsigned long long *key = b_key.as<unsigned long long>(), *key_alt = b_key2.as<unsigned long long>();
             for (int chunk = (int)(h.max_klen + 7) / 8 - 1; chunk >= 0; --chunk) {      // least significant eight bytes first; every pass stable
-                k_bam_name_key<<<nblk(n_kept, 256), 256, 0, st>>>(raw, b_off.as<uint32_t>(), idx, n_kept, (uint32_t)chunk, key);
+                k_bam_name_key<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_off.as<uint32_t>(), idx, n_kept, (uint32_t)chunk, key);
                 size_t b = tmp_bytes;
                 HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, key, key_alt, idx, idx_alt, (int)n_kept, 0, 64, st));
+                std::swap(idx, idx_alt);
+            }
+            if (n_seg > 1) {                                                           // ... and the tasks apart again, names in order inside
+                k_bam_task_key<<<nblk(n_kept, 256), 256, 0, st>>>(b_task.as<uint16_t>(), idx, n_kept, key);
+                size_t b = tmp_bytes;
+                HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, key, key_alt, idx, idx_alt, (int)n_kept, 0, 16, st));
                 std::swap(idx, idx_alt);
             }
         }
         lap(h.unsorted ? "BAM name sort" : "BAM name order check");
     }
-    if (n_kept) k_bam_lines<<<nblk(n_kept, 256), 256, 0, st>>>(b_off.as<uint32_t>(), b_len.as<uint32_t>(), idx, n_kept, b_lines.as<LineRef>());
+    if (n_kept) k_bam_lines<<<nblk(n_kept, 256), 256, 0, st>>>(b_off.as<uint32_t>(), b_len.as<uint32_t>(), b_task.as<uint16_t>(), idx, n_kept, b_lines.as<LineRef>());
     HIPCHK(hipGetLastError());
     *n_lines = n_kept;
     return HGX_OK;
@@ -1213,7 +1276,7 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Pars
                 DevBuf b_dl;
                 uint32_t n_dl = 0;
                 struct DrainL { hipStream_t s; ~DrainL() { (void)hipStreamSynchronize(s); } } drain_l{st};
-                int rc = bam_lines_dev(b_text.as<char>(), raw_bytes, *def, st, b_dl, &n_dl, declined);
+                int rc = bam_lines_dev(b_text.as<char>(), {def}, {(size_t)0}, {raw_bytes}, st, b_dl, &n_dl, declined);
                 if (rc || *declined) return rc;
                 rc = records_run(L, b_text.as<char>(), raw_bytes, nullptr, n_dl, true, 1, o, st, &made, nullptr, declined, b_dl.as<LineRef>());
                 if (!rc && !*declined && made) route = 2;
@@ -1284,6 +1347,83 @@ int hgx_front_many_dev(hgx_dbatch **out, hgx_front_totals *tot, const hgx_locus 
         fprintf(stderr, "[hgx_front_many] %-28s %8.2f ms\n", what, t - t_prev);
         t_prev = t;
     };
+    // BAM files: left deflated -- the files' bytes go up as they are read, ONE launch inflates the BGZF blocks of all tasks, the
+    // records are walked / filtered / name-sorted per task on the device (k_bgzf_inflate, k_bam_*); the host reads, hops through
+    // the containers and inflates the header blocks.  Anything that does not fit goes the way below.
+    if (paths && !hgx_switch_has("front", "host_inflate")) {
+        std::vector<size_t> cbase((size_t)n_tasks + 1, 0), csize((size_t)n_tasks, 0);
+        bool stat_ok = true;
+        for (int t = 0; t < n_tasks; ++t) {
+            struct stat sb;
+            if (!paths[t] || stat(paths[t], &sb) != 0) { stat_ok = false; break; }
+            csize[t] = (size_t)sb.st_size;
+            cbase[(size_t)t + 1] = (cbase[t] + csize[t] + 63) & ~(size_t)63;
+        }
+        const size_t ctotal = cbase[(size_t)n_tasks];
+        if (stat_ok && ctotal < (1ull << 32) - 4096) {
+            DevBuf b_comp, b_text2, b_dl;
+            struct DrainB { hipStream_t s; ~DrainB() { (void)hipStreamSynchronize(s); } } drain_b{st};
+            ALLOC(b_comp, ctotal + 4096);
+            int dev = 0;
+            HIPCHK(hipGetDevice(&dev));
+            std::vector<hgx_bgzf_task> bt;
+            std::atomic<bool> up_bad{false};
+            auto on_bt = [&](int t) {
+                if (bt[t].n != csize[t] || hipSetDevice(dev) != hipSuccess ||
+                    hipMemcpyAsync((char *)b_comp.p + cbase[t], bt[t].data, bt[t].n, hipMemcpyHostToDevice, st) != hipSuccess) up_bad = true;
+            };
+            struct FreeTasks { std::vector<hgx_bgzf_task> &v; hipStream_t s; ~FreeTasks() { (void)hipStreamSynchronize(s); for (auto &x : v) hgx_host_free(x.data); } } free_tasks{bt, st};
+            int rcb = hgx_bgzf_tasks_read(bt, paths, regions, n_tasks, opts->n_threads, &mem, on_bt);
+            if (rcb) return rcb;
+            lap("read (deflated; uploads issued)");
+            bool all_ok = !up_bad.load();
+            for (int t = 0; t < n_tasks && all_ok; ++t) all_ok = bt[t].ok;
+            std::vector<size_t> pbase((size_t)n_tasks + 1, 0), psize((size_t)n_tasks, 0);
+            size_t n_blocks = 0;
+            for (int t = 0; t < n_tasks && all_ok; ++t) {
+                psize[t] = bt[t].total;
+                pbase[(size_t)t + 1] = (pbase[t] + bt[t].total + 63) & ~(size_t)63;
+                n_blocks += bt[t].blocks.size();
+            }
+            const size_t ptotal = pbase[(size_t)n_tasks];
+            if (all_ok && ptotal < (1ull << 32) - 64 && (hgx_switch_has("front", "device") || ptotal >= (8u << 20))) {
+                std::vector<hgx_bgzf_block> all;
+                all.reserve(n_blocks);
+                for (int t = 0; t < n_tasks; ++t)
+                    for (hgx_bgzf_block b : bt[t].blocks) { b.in_off += cbase[t]; b.out_off += pbase[t]; all.push_back(b); }
+                ALLOC(b_text2, ptotal + 64);
+                HIPCHK(hipMemsetAsync((char *)b_comp.p + ctotal, 0, 4096, st));
+                int bad = 0;
+                rcb = hgx_bgzf_inflate_dev(b_comp.as<unsigned char>(), all.data(), all.size(), b_text2.as<unsigned char>(), st, &bad);
+                if (rcb) return rcb;
+                lap("BGZF inflate (device)");
+                if (!bad) {
+                    std::vector<const hgx_bam_deferred *> defs((size_t)n_tasks);
+                    for (int t = 0; t < n_tasks; ++t) defs[t] = &bt[t].def;
+                    pbase.resize((size_t)n_tasks);
+                    uint32_t n_dl = 0;
+                    int dec = 0;
+                    rcb = bam_lines_dev(b_text2.as<char>(), defs, pbase, psize, st, b_dl, &n_dl, &dec);
+                    if (rcb) return rcb;
+                    if (!dec) {
+                        hgx_dbatch *made = nullptr;
+                        rcb = records_run(*const_cast<hgx_locus *>(loc), b_text2.as<char>(), ptotal, nullptr, n_dl, true, n_tasks, *opts, st, &made, tot, &dec,
+                                          b_dl.as<LineRef>());
+                        (void)hipStreamSynchronize(st);
+                        lap("device stages");
+                        if (rcb) { hgx_dbatch_destroy(made); return rcb; }
+                        if (!dec && made) {
+                            g_last_bytes += (long long)ctotal;
+                            g_last_route = 2; g_last_device = 1;
+                            *out = made;
+                            return HGX_OK;
+                        }
+                        hgx_dbatch_destroy(made);
+                    }
+                }
+            }
+        }
+    }
     // The device text buffer is reserved before the sizes are known (files: 16x their bytes on disk -- BGZF rarely inflates that
     // far -- at most what 32-bit offsets hold), and every reader thread takes the next free range for its task and starts the
     // upload the moment its bytes are complete: the transfers run under the other tasks' inflate / walk / sort.  A task that no

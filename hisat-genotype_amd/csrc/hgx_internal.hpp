@@ -286,6 +286,19 @@ struct hgx_front_hook {
 int hgx_parse_sam_hook(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, hgx_front_hook *hook);
 int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *loc, const char *path, const char *regions, const hgx_parse_opts *opts,
                                   hgx_front_hook *hook);
+// the BGZF-compressed BAM files of many tasks, read but not inflated (the device front end inflates, walks, filters and sorts):
+// data = the file's bytes (hgx_host_alloc: the caller frees), ok = a BAM whose header (inflated here) was understood and whose region
+// list has at most one entry; on_task(t) runs on the reader's thread when task t's bytes are in memory
+struct hgx_bgzf_task {
+    unsigned char *data = nullptr;
+    size_t n = 0;
+    std::vector<hgx_bgzf_block> blocks;
+    size_t total = 0;
+    hgx_bam_deferred def;
+    bool ok = false;
+};
+int hgx_bgzf_tasks_read(std::vector<hgx_bgzf_task> &tasks, const char *const *paths, const char *const *regions, int n_tasks, int n_threads,
+                        const hgx_front_alloc *mem, const std::function<void(int)> &on_task);
 // ---- the record streams of MANY tasks of one locus as one stream (hgx_many_create_files / _sams: one device pass for all) ------
 // what a many-task pass reports per task
 struct hgx_front_totals { std::vector<uint32_t> reads, pairs, pieces; std::vector<uint64_t> refs; };

@@ -193,12 +193,16 @@ def test_bam_records_walked_filtered_and_sorted_on_the_device(tmp_path):
     for path in (p_sorted, p_grouped):
         for regions in ([loc.ref_allele], [span], None):
             host = pl.parse_alignment_file(path, regions)
-            with engine.test_switches(front="device"):
-                dev = pl.parse_alignment_file_dev(path, regions=regions)
-                route, code = engine.front_last()
-            assert (route, code) == (2, 0), (path, regions, route, code)
             assert host.n_reads > 5000
-            same_batch(host, dev.to_host(), len(loc.backbone))
+            sent = {}
+            for sw in ("device", "device,host_inflate"):          # BGZF blocks inflated by the device / by the host's threads
+                with engine.test_switches(front=sw):
+                    dev = pl.parse_alignment_file_dev(path, regions=regions)
+                    route, code = engine.front_last()
+                    sent[sw] = engine.front_last_bytes()
+                assert (route, code) == (2, 0), (path, regions, sw, route, code)
+                same_batch(host, dev.to_host(), len(loc.backbone))
+            assert sent["device"] < sent["device,host_inflate"] / 2       # (the deflated file went up, not its payload)
     # two regions: the reader keeps the walk (a record may belong to both); same batch through the host's line table
     two = [loc.ref_allele, "DECOY:1-100"]
     host = pl.parse_alignment_file(p_sorted, two)
@@ -224,3 +228,12 @@ def test_bam_records_walked_filtered_and_sorted_on_the_device(tmp_path):
         pl.parse_alignment_file(p_cut, None)
     with engine.test_switches(front="device"), pytest.raises(capi.HgxError):
         pl.parse_alignment_file_dev(p_cut, regions=None)
+    # a block with a damaged payload: the device's inflate reports it, the call falls back to the host reader, which refuses the file
+    blob = bytearray(open(p_sorted, "rb").read())
+    blob[len(blob) // 2] ^= 0x10
+    p_bad = str(tmp_path / "bad.bam")
+    open(p_bad, "wb").write(bytes(blob))
+    with pytest.raises(capi.HgxError):
+        pl.parse_alignment_file(p_bad, None)
+    with engine.test_switches(front="device"), pytest.raises(capi.HgxError):
+        pl.parse_alignment_file_dev(p_bad, regions=None)
