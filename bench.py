@@ -703,8 +703,9 @@ def run_class1(args, rank, local_rank, world, dist):
             e2e = {"input": "three coordinate-sorted BAM files (%.0f MB in all)" % (sum(os.path.getsize(f) for f in file_of.values()) / 1e6),
                    "locus_after_locus_ms": round(seq[1] * 1e3, 2), "side_by_side_ms": round(par[1] * 1e3, 2),
                    "reads_per_s": round(n_r / min(seq[1], par[1]), 1), "result_identical_to_hbm_path": bool(same),
-                   "note": "hgx_type_file per locus: read, inflate, record walk and name sort on the host; record fields, filters, key grouping, "
-                           "pileup, decode, piece table, pair protocol and the typing path on the GPU (median of 3 after a warm-up)"}
+                   "note": "hgx_type_file per locus: the host reads the file and hops through its BGZF container; inflate, record walk, region "
+                           "filter, name sort, record fields, filters, key grouping, pileup, decode, piece table, pair protocol and the typing "
+                           "path on the GPU (median of 3 after a warm-up)"}
         finally:
             shutil.rmtree(file_dir, ignore_errors=True)
     cb = None
@@ -918,7 +919,7 @@ def run_panel64(args, rank, local_rank, world, dist):
             e2e = {"input": "%d coordinate-sorted BAM files of %d pairs (%.0f MB in all)" % (len(file_of), args.panel_pairs,
                                                                                                sum(os.path.getsize(f) for f in file_of.values()) / 1e6),
                    "ms": round(tot * 1e3, 1), "reads_per_s": round(reads / tot, 1),
-                   "stages_ms": {"hgx_many_create_files, %d loci side by side (read + inflate + walk on the host, records -> merged batch on the device)" % len(ks):
+                   "stages_ms": {"hgx_many_create_files, %d loci side by side (the host reads the files; BGZF inflate, record walk / filter / name sort, records -> merged batch on the device)" % len(ks):
                                  round(t_fe * 1e3, 1), "hgx_type_many_loci": round(t_gpu * 1e3, 1)},
                    "front_end": {"route_and_decline_code_per_locus": [list(r[0]) for r in routes], "bytes_to_device": sum(r[1] for r in routes)},
                    "tasks_with_the_timed_step_s_reads_and_top2": same,

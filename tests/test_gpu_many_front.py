@@ -69,11 +69,15 @@ def test_many_samples_in_one_device_pass(tmp_path):
         open(p_sam[-1], "w").write(s)
         p_bam.append(str(tmp_path / ("t%d.bam" % t)))
         bamio.write_bam_native(p_bam[-1], s.encode(), [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=(t % 2 == 1))
-    for paths in (p_sam, p_bam):
-        with engine.test_switches(front="device"):
+    sent = {}
+    for paths, sw in ((p_sam, "device"), (p_bam, "device"), (p_bam, "device,host_inflate")):
+        # (BAM: the files travel deflated and one launch inflates every task's BGZF blocks -- or the host's threads inflate)
+        with engine.test_switches(front=sw):
             dev = engine.ManyBatch.from_files(pl, paths, regions=[loc.ref_allele] * len(paths))
             assert engine.front_last() == (2, 0)
+            sent[(paths is p_bam, sw)] = engine.front_last_bytes()
         same_many(dev, host)
+    assert sent[(True, "device")] < sent[(True, "device,host_inflate")] / 2
     with engine.test_switches(front="device,late"):                   # the buffer estimate was too small: sent again after the reads
         dev = engine.ManyBatch.from_files(pl, p_bam, regions=[loc.ref_allele] * len(p_bam))
         assert engine.front_last() == (2, 0)

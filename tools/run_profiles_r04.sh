@@ -27,3 +27,7 @@ head -c 400 $D/bench_default.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats_fe_sam -o r04fe -- python3 tools/e2e_file.py 500000 0 > $D/fe_sam.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats_fe_bam -o r04fe -- python3 tools/e2e_bam.py 500000 > $D/fe_bam.log 2>&1
 rm -f $D/stats_fe_*/*kernel_trace.csv $D/stats_fe_*/*agent_info.csv
+# the stages of the calls as the library prints them (HGX_PARSE_PROFILE), untraced
+HGX_PARSE_PROFILE=1 python3 tools/e2e_file.py 500000 0 > $D/fe_sam_stages.log 2>&1
+HGX_PARSE_PROFILE=1 python3 tools/e2e_bam.py 500000 > $D/fe_bam_stages.log 2>&1
+HGX_PARSE_PROFILE=1 python3 tools/prof_many_front.py > $D/fe_many_stages.log 2>&1
