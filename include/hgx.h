@@ -459,7 +459,12 @@ int hgx_type_file(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, c
  * a pair with more alternatives than the kernels' scratch holds -- are finished by the host stages and uploaded: the result is
  * the same batch either way, and hgx_front_last says which way the calling thread's last call went (route: 2 = record route,
  * 1 = key route, 0 = host stages; decline_code: see HGX_FE_DECLINE_* / FE_E_* in csrc/hgx_internal.hpp,
- * csrc/hgx_front_core.hpp).  hgx_type_file goes through hgx_parse_alignment_file_dev. */
+ * csrc/hgx_front_core.hpp).  hgx_type_file goes through hgx_parse_alignment_file_dev.
+ * A BAM file (with at most one region) does not even get inflated on the host: the host reads it, hops through the BGZF container
+ * and inflates the block(s) holding the BAM header; the deflated bytes go up, and BGZF inflate (csrc/hgx_inflate.hip), the record
+ * chain walk, the region filter (samtools' overlap rule, typing_core.py:438-444) and the stable sort by read name
+ * (`sort -k 1,1 -s`, typing_core.py:436-468) run as kernels in front of the record route.  A block that fails CRC-32 / ISIZE, a
+ * chain that does not link up or a malformed record sends the call to the host reader, which words the error. */
 int hgx_parse_sam_dev(hgx_dbatch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, void *stream);
 int hgx_parse_alignment_file_dev(hgx_dbatch **out, const hgx_locus *loc, const char *path, const char *regions_or_null,
                                  const hgx_parse_opts *opts, void *stream);
