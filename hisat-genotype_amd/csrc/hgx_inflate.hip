@@ -59,7 +59,7 @@ __constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct BlockDesc { uint32_t in_off, in_len, out_off, out_len, crc; };
-struct CrcOp { uint32_t col[32]; };          // crc -> crc advanced by PIECE zero bytes
+struct CrcOp { uint32_t col[7][32]; };       // level k: crc -> crc advanced by PIECE << k zero bytes (k = 6: a whole FLUSH)
 
 enum { INF_OK = 0, INF_BAD_BLOCK_TYPE = 1, INF_BAD_STORED = 2, INF_BAD_CODE = 3, INF_BAD_DIST = 4, INF_OVERRUN = 5, INF_BAD_SIZE = 6, INF_BAD_CRC = 7,
        INF_BAD_LENGTHS = 8, INF_INPUT_END = 9 };
@@ -110,7 +110,7 @@ __device__ __forceinline__ uint32_t bits_take(Bits &b, int n) { const uint32_t v
 
 // canonical Huffman tables from code lengths lens[0..n): false = over-subscribed (or, for `strict`, incomplete) set of lengths
 template <class T, int P>
-__device__ bool huff_build(T &H, const unsigned char *lens, uint16_t *code, int n, int lane, bool allow_incomplete) {
+__device__ bool huff_build(T &H, const unsigned char *lens, uint16_t *code, int n, int lane, bool allow_incomplete, bool mark_literals = false) {
     for (int i = lane; i < (1 << P); i += 64) H.pt[i] = 0;
     if (lane < 16) H.count[lane] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -147,7 +147,7 @@ __device__ bool huff_build(T &H, const unsigned char *lens, uint16_t *code, int 
         const int L = lens[s];
         if (L == 0 || L > P) continue;
         const uint32_t rev = __brev((uint32_t)code[s]) >> (32 - L);
-        const uint16_t e = (uint16_t)((s << 4) | L);
+        const uint16_t e = (uint16_t)((s << 4) | L | ((mark_literals && s < 256) ? 0x8000 : 0));      // (literal/length table: bit 15 = a literal)
         for (uint32_t k = rev; k < (1u << P); k += 1u << L) H.pt[k] = e;
     }
     __builtin_amdgcn_wave_barrier();
@@ -196,10 +196,10 @@ __device__ __forceinline__ uint32_t crc_bytes(const unsigned char *ring, uint32_
     }
     return ~c;
 }
-__device__ __forceinline__ uint32_t crc_advance_piece(const CrcOp &op, uint32_t v) {
+__device__ __forceinline__ uint32_t crc_advance(const CrcOp &op, int level, uint32_t v) {
     uint32_t r = 0;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) r ^= op.col[i] & (0u - ((v >> i) & 1u));
+    for (int i = 0; i < 32; ++i) r ^= op.col[level][i] & (0u - ((v >> i) & 1u));
     return r;
 }
 
@@ -216,21 +216,33 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
     int err = INF_OK;
     auto flush = [&](uint32_t n) {             // the n oldest pending bytes leave the ring (n = FLUSH, or the rest at the end)
         for (uint32_t i = lane; i < n; i += 64) dst[fpos + i] = S.ring[(fpos + i) & RMASK];
-        // CRC-32: a PIECE-byte piece per lane, joined in order
+        // CRC-32: a PIECE-byte piece per lane; a full FLUSH is joined pairwise in six rounds (piece 2j advanced by the length of
+        // piece 2j + 1 and xor-ed with it, lengths doubling), the last, partial one piece by piece
         const uint32_t n_piece = (n + PIECE - 1) / PIECE;
+        uint32_t mine = 0;
         if ((uint32_t)lane < n_piece) {
             const uint32_t p0 = fpos + (uint32_t)PIECE * lane;
             const int len = (int)min((uint32_t)PIECE, n - (uint32_t)PIECE * lane);
-            S.crc_piece[lane] = crc_bytes(S.ring, p0, len);
+            mine = crc_bytes(S.ring, p0, len);
         }
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t p = 0; p < n_piece; ++p) {
-            const uint32_t len = min((uint32_t)PIECE, n - (uint32_t)PIECE * p);
-            if (len == (uint32_t)PIECE) crc = crc_advance_piece(op, crc);
-            else for (uint32_t k = 0; k < 8 * len; ++k) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
-            crc ^= S.crc_piece[p];
+        if (n == (uint32_t)FLUSH) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const uint32_t other = (uint32_t)__shfl_down((int)mine, 1 << k, 64);
+                mine = crc_advance(op, k, mine) ^ other;           // (meaningful on the lanes that are multiples of 2 << k; lane 0 in the end)
+            }
+            crc = crc_advance(op, 6, crc) ^ (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+        } else {
+            S.crc_piece[lane] = mine;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t p = 0; p < n_piece; ++p) {
+                const uint32_t len = min((uint32_t)PIECE, n - (uint32_t)PIECE * p);
+                if (len == (uint32_t)PIECE) crc = crc_advance(op, 0, crc);
+                else for (uint32_t k = 0; k < 8 * len; ++k) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+                crc ^= S.crc_piece[p];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
         fpos += n;
     };
     if (B.out_len > 0) {
@@ -264,7 +276,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                 if (lane < 32) S.lens[288 + lane] = 5;
                 n_lit = 288; n_dist = 30;
                 __builtin_amdgcn_wave_barrier();
-                if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens, S.code, 288, lane, false)) { err = INF_BAD_LENGTHS; break; }
+                if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens, S.code, 288, lane, false, true)) { err = INF_BAD_LENGTHS; break; }
                 if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 288, S.code, 32, lane, true)) { err = INF_BAD_LENGTHS; break; }   // (32 five-bit codes, two of them never sent)
             } else {                                                // dynamic codes (3.2.7)
                 n_lit = (int)bits_take(b, 5) + 257;
@@ -302,9 +314,9 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                 if (err) break;
                 __builtin_amdgcn_wave_barrier();
                 if (S.lens[32 + 256] == 0) { err = INF_BAD_LENGTHS; break; }              // no end-of-block code
-                if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, S.code, n_lit, lane, false)) {
+                if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, S.code, n_lit, lane, false, true)) {
                     // (an incomplete literal/length code is legal only when it has a single code: zlib accepts that; so do we)
-                    if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, S.code, n_lit, lane, true)) { err = INF_BAD_LENGTHS; break; }
+                    if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, S.code, n_lit, lane, true, true)) { err = INF_BAD_LENGTHS; break; }
                 }
                 if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 32 + n_lit, S.code, n_dist, lane, true)) { err = INF_BAD_LENGTHS; break; }
             }
@@ -323,8 +335,34 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                 }
             };
             for (;;) {
-                bits_refill(b, lane);
-                const int sym = huff_decode<HuffLds, LIT_P, 8>(S.lit, tl, b);
+                // runs of literals: the shortest path through the table there is -- peek, look up, drop, gather
+                uint32_t e;
+                for (;;) {
+                    bits_refill(b, lane);
+                    e = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.lit.pt[bits_peek(b, LIT_P)]);
+                    if (!(e & 0x8000u)) break;
+                    bits_drop(b, (int)(e & 15u));
+                    lit_acc |= (uint64_t)((e >> 4) & 255u) << (8 * lit_n);
+                    lit_n += 1;
+                    if (lit_n == 8) {
+                        if (wpos + lit_n > B.out_len) { err = INF_OVERRUN; break; }
+                        lit_out();
+                        if (wpos - fpos >= (uint32_t)FLUSH) { __builtin_amdgcn_wave_barrier(); flush(FLUSH); }
+                    }
+                }
+                if (err) break;
+                int sym;
+                if (e & 15u) { bits_drop(b, (int)(e & 15u)); sym = (int)(e >> 4); }
+                else {                                              // a code longer than the table's bits (or none at all)
+                    sym = -1;
+                    const uint32_t rev15 = __brev(bits_peek(b, 15)) >> 17;
+                    for (int L = LIT_P + 1; L <= 15; ++L) {
+                        const uint32_t c = rev15 >> (15 - L);
+                        const uint32_t d = c - S.lit.first[L];
+                        if (d < S.lit.count[L]) { bits_drop(b, L); sym = S.lit.sorted[S.lit.offs[L] + d]; break; }
+                    }
+                    sym = __builtin_amdgcn_readfirstlane(sym);
+                }
                 if (sym < 0) { err = INF_BAD_CODE; break; }
                 if (sym < 256) {
                     lit_acc |= (uint64_t)(uint32_t)sym << (8 * lit_n);
@@ -384,11 +422,12 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
 
 CrcOp make_crc_op() {
     CrcOp op;
-    for (int i = 0; i < 32; ++i) {
-        uint32_t c = 1u << i;
-        for (int k = 0; k < 8 * PIECE; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
-        op.col[i] = c;
-    }
+    for (int lv = 0; lv < 7; ++lv)
+        for (int i = 0; i < 32; ++i) {
+            uint32_t c = 1u << i;
+            for (int k = 0; k < 8 * (PIECE << lv); ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+            op.col[lv][i] = c;
+        }
     return op;
 }
 
