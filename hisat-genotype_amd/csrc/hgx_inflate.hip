@@ -31,7 +31,6 @@ namespace {
 
 constexpr int RING = 8192, RMASK = RING - 1, FLUSH = 2048, PIECE = FLUSH / 64;      // (see the header: the ring holds the near window only)
 constexpr int LIT_P = 10, DIST_P = 8;
-constexpr bool REG_TABLES = false;      // primary tables through v_readlane from registers instead of LDS (measured: see NOTEBOOK.md section 11)
 
 struct HuffLds {
     uint16_t pt[1 << LIT_P];             // primary table: symbol << 4 | code length (0 = longer than the table's bits, or no such code)
@@ -153,30 +152,10 @@ __device__ bool huff_build(T &H, const unsigned char *lens, uint16_t *code, int 
     __builtin_amdgcn_wave_barrier();
     return true;
 }
-// The primary table lives in REGISTERS for the symbol loop: entry i is half (i & 1) of dword i >> 1, which lane (i >> 1) & 63 holds
-// in register i >> 7 -- a lookup is a handful of v_readlane (the index is wave-uniform) instead of an LDS round trip, and with one
-// wavefront per SIMD (the 32 KB ring allows four per CU) that latency is the symbol rate.
-template <int NR>
-__device__ __forceinline__ void tab_load(uint32_t (&t)[NR], const uint16_t *pt, int lane) {
-#pragma unroll
-    for (int k = 0; k < NR; ++k) t[k] = reinterpret_cast<const uint32_t *>(pt)[k * 64 + lane];
-}
-template <int NR>
-__device__ __forceinline__ uint32_t tab_get(const uint32_t (&t)[NR], uint32_t i) {
-    const int ln = (int)((i >> 1) & 63u);
-    const uint32_t r = i >> 7;
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < NR; ++k) {
-        const uint32_t x = (uint32_t)__builtin_amdgcn_readlane((int)t[k], ln);
-        v = r == (uint32_t)k ? x : v;
-    }
-    return (i & 1u) ? v >> 16 : v & 0xFFFFu;
-}
 // one symbol: the primary table, or the walk over the longer lengths; -1 = no such code.  (At least 15 bits are in the buffer.)
-template <class T, int P, int NR>
-__device__ __forceinline__ int huff_decode(const T &H, const uint32_t (&t)[NR], Bits &b) {
-    const uint32_t e = REG_TABLES ? tab_get<NR>(t, bits_peek(b, P)) : (uint32_t)__builtin_amdgcn_readfirstlane((int)H.pt[bits_peek(b, P)]);
+template <class T, int P>
+__device__ __forceinline__ int huff_decode(const T &H, Bits &b) {
+    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)H.pt[bits_peek(b, P)]);
     if (e & 15) { bits_drop(b, e & 15); return e >> 4; }
     const uint32_t rev15 = __brev(bits_peek(b, 15)) >> 17;           // the next 15 bits, first bit most significant
     for (int L = P + 1; L <= 15; ++L) {
@@ -248,7 +227,6 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
     if (B.out_len > 0) {
         Bits b;
         bits_init(b, in + B.in_off, B.in_len, lane);
-        uint32_t tl[8], td[2];
         bool last = false;
         while (!last && !err) {
             bits_refill(b, lane);
@@ -293,12 +271,11 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                 __builtin_amdgcn_wave_barrier();
                 // the code-length code goes through the distance slot (19 symbols, at most 7 bits)
                 if (!huff_build<DistLds, DIST_P>(S.dist, S.lens, S.code, 19, lane, false)) { err = INF_BAD_LENGTHS; break; }
-                tab_load<2>(td, S.dist.pt, lane);
                 int at = 0, prev = 0;
                 const int total = n_lit + n_dist;
                 while (at < total && !err) {
                     bits_refill(b, lane);
-                    const int sym = huff_decode<DistLds, DIST_P, 2>(S.dist, td, b);
+                    const int sym = huff_decode<DistLds, DIST_P>(S.dist, b);
                     if (sym < 0) { err = INF_BAD_CODE; break; }
                     int rep = 1, val = sym;
                     if (sym == 16) { if (at == 0) { err = INF_BAD_LENGTHS; break; } rep = 3 + (int)bits_take(b, 2); val = prev; }
@@ -321,8 +298,6 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                 if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 32 + n_lit, S.code, n_dist, lane, true)) { err = INF_BAD_LENGTHS; break; }
             }
             // ---- the symbols of the block -------------------------------------------------------------------------------
-            tab_load<8>(tl, S.lit.pt, lane);
-            tab_load<2>(td, S.dist.pt, lane);
             // (literals are gathered eight at a time: one byte store by eight lanes instead of eight stores by one)
             uint64_t lit_acc = 0;
             uint32_t lit_n = 0;
@@ -381,7 +356,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                     if (li >= 29) { err = INF_BAD_CODE; break; }
                     const uint32_t len = c_len_base[li] + bits_take(b, c_len_extra[li]);
                     bits_refill(b, lane);
-                    const int ds = huff_decode<DistLds, DIST_P, 2>(S.dist, td, b);
+                    const int ds = huff_decode<DistLds, DIST_P>(S.dist, b);
                     if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
                     const uint32_t dist = c_dist_base[ds] + bits_take(b, c_dist_extra[ds]);
                     if (dist > wpos) { err = INF_BAD_DIST; break; }
