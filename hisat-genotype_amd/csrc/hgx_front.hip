@@ -42,6 +42,10 @@ struct PinnedPool {
     std::mutex mu;
     std::multimap<size_t, void *> free_blocks;
     std::map<void *, size_t> size_of;
+    size_t idle_bytes = 0;                 // bytes of the blocks waiting in free_blocks
+    // idle blocks beyond this are unregistered and freed instead of kept (a long-lived process that sees inputs of many sizes
+    // must not accumulate pinned memory without bound); HGX_PINNED_IDLE_MB overrides the 4 GB default
+    size_t idle_cap = [] { const char *e = getenv("HGX_PINNED_IDLE_MB"); return e ? (size_t)strtoull(e, nullptr, 10) << 20 : (size_t)4 << 30; }();
 };
 PinnedPool &pinned() { static PinnedPool *p = new PinnedPool(); return *p; }
 void *pinned_alloc(size_t n) {
@@ -52,6 +56,7 @@ void *pinned_alloc(size_t n) {
         auto it = P.free_blocks.lower_bound(need);
         if (it != P.free_blocks.end() && it->first <= 4 * need + (1u << 20)) {
             void *p = it->second;
+            P.idle_bytes -= it->first;
             P.free_blocks.erase(it);
             return p;
         }
@@ -74,6 +79,13 @@ void pinned_release(void *p) {
     std::lock_guard<std::mutex> g(P.mu);
     auto it = P.size_of.find(p);
     if (it == P.size_of.end()) return;
+    if (P.idle_bytes + it->second > P.idle_cap) {          // enough idle staging already: give this one back to the system
+        P.size_of.erase(it);
+        (void)hipHostUnregister(p);
+        free(p);
+        return;
+    }
+    P.idle_bytes += it->second;
     P.free_blocks.emplace(it->second, p);
 }
 

@@ -547,7 +547,7 @@ int hgx_bgzf_inflate(const void *bgzf, size_t n_bytes, void *out, size_t out_cap
  * for comparison, a threshold moved so a small case reaches the large-problem code) with named in-process switches.  name = NULL
  * clears all, value = NULL clears one.  The names are listed in DESIGN.md ("switches"); none changes results beyond what the
  * test that uses it states.  Environment variables the library does read: HGX_THREADS, HGX_PIN, HGX_THP, HGX_NO_LIBDEFLATE,
- * HGX_MALLOC_TUNE (host tuning) and HGX_PARSE_PROFILE, HGX_TYPE_PROFILE (timing prints on stderr).                                            */
+ * HGX_MALLOC_TUNE, HGX_READ_PHASES, HGX_PINNED_IDLE_MB (host tuning) and HGX_PARSE_PROFILE, HGX_TYPE_PROFILE (timing prints on stderr).                                            */
 int hgx_test_switch_set(const char *name, const char *value);
 /* mat-vec backend of hgx_em: 0 = auto (table lookup), 1 = EXEC-masked FP64 VALU kernel, 3 = table-lookup kernel (256 subset
  * sums per 8 matrix columns in LDS; one lookup per 8 matrix bits); 2 = int8 MFMA kernel, in the lab build only (libhgx_lab.so,
