@@ -221,9 +221,10 @@ __global__ void k_fe_nt_set(const uint32_t *__restrict__ counts, int n_ref, uint
 __global__ void __launch_bounds__(256) k_fe_decode(FeLocus L, FeParse o, FePile P, const FeKey *__restrict__ keys, uint32_t n_keys,
                                                    const char *__restrict__ text, FePools pools, uint8_t *__restrict__ state,
                                                    uint32_t *__restrict__ key_ht_off, uint32_t *__restrict__ key_n_ht,
-                                                   uint16_t *__restrict__ slot_task, FeCtl *ctl) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n_keys) return;
+                                                   uint16_t *__restrict__ slot_task, const uint32_t *__restrict__ order, FeCtl *ctl) {
+    const uint32_t k0 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k0 >= n_keys) return;
+    const uint32_t k = order ? order[k0] : k0;             // (keys in backbone order: the lanes of a wavefront meet the same variants)
     const FeKey K = keys[k];
     if (K.slot == FE_NO_SLOT) return;
     uint8_t st = 2;
@@ -239,6 +240,10 @@ __global__ void __launch_bounds__(256) k_fe_decode(FeLocus L, FeParse o, FePile 
     key_n_ht[K.slot] = n;
 }
 
+__global__ void k_fe_key_pos(const FeKey *__restrict__ keys, uint32_t n, uint32_t *__restrict__ pos, uint32_t *__restrict__ idx) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { pos[i] = ((uint32_t)keys[i].task << 20) ^ (uint32_t)(keys[i].pos + 4096); idx[i] = i; }      // (task, position)
+}
 __global__ void k_fe_iota(uint32_t *a, uint32_t n) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] = i;
@@ -751,7 +756,7 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     const uint32_t n_keys = di.n_keys, n_rec = di.n_rec, S = di.n_slots;
     // every buffer of the call is declared here, the guard after them: on ANY way out the stream is drained first, then the
     // buffers go back to the pool
-    DevBuf b_state, b_koff, b_knht, b_ht, b_clo, b_cnw, b_ckey, b_cmoff, b_mpool, b_slot_task;
+    DevBuf b_state, b_koff, b_knht, b_ht, b_clo, b_cnw, b_ckey, b_cmoff, b_mpool, b_slot_task, b_kpos, b_kpos2, b_kord, b_kord2, b_ktmp;
     DevBuf b_cnt, b_off, b_tmp, b_tmp2, b_key_s, b_idx, b_idx_s, b_flag, b_rank, b_head_of, b_head_cand;
     DevBuf b_wh, b_wh_s, b_hidx, b_hidx_s, b_lonw, b_lonw_s, b_ord, b_nw2, b_moff, b_new_id, b_cand_piece, b_tbits;
     hgx_dbatch *d = new hgx_dbatch();
@@ -816,8 +821,23 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     pools.mask_pool = b_mpool.as<uint32_t>(); pools.mask_cap = (uint32_t)mask_cap; pools.mask_cursor = &ctl->mask_cursor;
     const FeParse po{o.num_editdist, o.error_correction};
     const FePile pile{d->d_nt_set, d->d_counts};
-    if (n_keys) k_fe_decode<<<nblk(n_keys, 256), 256, 0, st>>>(F, po, pile, keys, n_keys, text, pools, b_state.as<uint8_t>(), b_koff.as<uint32_t>(),
-                                                               b_knht.as<uint32_t>(), n_tasks > 1 ? b_slot_task.as<uint16_t>() : (uint16_t *)nullptr, ctl);
+    if (n_keys) {
+        // decode in backbone order of the keys: neighbours in a wavefront then walk the same stretch of the variant list and take the
+        // same branches (the result does not depend on who decodes what: pools are filled through cursors, the piece table is
+        // ordered by content)
+        const uint32_t *order = nullptr;
+        if (n_keys >= 4096) {
+            ALLOC(b_kpos, (size_t)n_keys * 4); ALLOC(b_kpos2, (size_t)n_keys * 4); ALLOC(b_kord, (size_t)n_keys * 4); ALLOC(b_kord2, (size_t)n_keys * 4);
+            k_fe_key_pos<<<nblk(n_keys, 256), 256, 0, st>>>(keys, n_keys, b_kpos.as<uint32_t>(), b_kord.as<uint32_t>());
+            size_t tb = 0;
+            (void)hipcub::DeviceRadixSort::SortPairs((void *)nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_keys, 0, 32, st);
+            ALLOC(b_ktmp, std::max<size_t>(tb, 256));
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_ktmp.p, tb, b_kpos.as<uint32_t>(), b_kpos2.as<uint32_t>(), b_kord.as<uint32_t>(), b_kord2.as<uint32_t>(), (int)n_keys, 0, 32, st));
+            order = b_kord2.as<uint32_t>();
+        }
+        k_fe_decode<<<nblk(n_keys, 256), 256, 0, st>>>(F, po, pile, keys, n_keys, text, pools, b_state.as<uint8_t>(), b_koff.as<uint32_t>(),
+                                                       b_knht.as<uint32_t>(), n_tasks > 1 ? b_slot_task.as<uint16_t>() : (uint16_t *)nullptr, order, ctl);
+    }
     // the pair counts need nothing but the decode results
     ALLOC(b_cnt, std::max<size_t>(n_rec, 1) * 8);
     ALLOC(b_off, std::max<size_t>(n_rec, 1) * 8);
