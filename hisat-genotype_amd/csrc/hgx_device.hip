@@ -348,10 +348,12 @@ extern "C" int hgx_index_device_block(const hgx_index *ix, void **p, size_t *byt
 // than HGX_PAT_D values are tested straight from the index.
 // ------------------------------------------------------------------------------------------------
 #define PP_T 1024
-#define PP_PB 256
 #define PP_W 8
 #define PP_NW 8
-#define PP_G 4                // 64-allele words per wavefront: 4 x 64 x 16 waves = 4096 alleles per workgroup
+#define PP_G 8                // 64-allele words per wavefront: 8 x 64 x 16 waves = 8192 alleles per workgroup -- a whole locus: the tests of a
+                              // (word, value) are then made once per 256 pieces, and the 1 M-read sample's 249 workgroups are one per CU
+                              // (measured: PB x G = 256 x 4 0.136 ms, 512 x 4 0.077, 256 x 8 0.072, 384 x 8 0.107, 512 x 8 0.132, 1024 x 8 0.239)
+template <int PP_PB>            // pieces per workgroup (hgx_piece_compat launches 256)
 __global__ __launch_bounds__(PP_T) void k_piece_compat_pat(const uint32_t *__restrict__ bits, int a_pad, int n_index_words,
                                                            const uint16_t *__restrict__ pid, const uint32_t *__restrict__ vals,
                                                            const int32_t *__restrict__ nval, const hgx_piece *__restrict__ pieces,
@@ -567,9 +569,10 @@ extern "C" int hgx_piece_compat(const hgx_index *ix, const hgx_piece *pieces, co
     {
         const int thr = std::min(PP_T, std::max(64, ((ix->a_pad + 64 * PP_G - 1) / (64 * PP_G)) * 64));
         const int per_wg = thr * PP_G;
-        hipLaunchKernelGGL(k_piece_compat_pat, dim3((n_pieces + PP_PB - 1) / PP_PB, (ix->a_pad + per_wg - 1) / per_wg), dim3(thr), 0,
-                           (hipStream_t)stream, ix->d_bits, ix->a_pad, ix->n_words, ix->d_pid, ix->d_vals, ix->d_nval, pieces, masks, n_pieces,
-                           compat, ix->w64);
+        // (pieces per workgroup: 256.  More -- 512, 1024 -- amortise the tests of a (word, value) over more pieces but are slower at every
+        // size tried: 63 000 pieces 0.071 / 0.109 / 0.196 ms, 177 000 pieces 0.188 / 0.208 / 0.205 ms: tools/compat_probe.py)
+        hipLaunchKernelGGL(k_piece_compat_pat<256>, dim3((n_pieces + 255) / 256, (ix->a_pad + per_wg - 1) / per_wg), dim3(thr), 0, (hipStream_t)stream,
+                           ix->d_bits, ix->a_pad, ix->n_words, ix->d_pid, ix->d_vals, ix->d_nval, pieces, masks, n_pieces, compat, ix->w64);
     }
     HIPCHK(hipGetLastError());
     return HGX_OK;
