@@ -160,3 +160,34 @@ def test_many_loci_in_the_any_size_mode():
     assert big >= 2
     for m in manies:
         m.close()
+
+
+def test_gene_level_beside_em1_equals_gene_level_before_it():
+    """The many-task calls score the gene level of an HLA locus and copy the Gene_counts while the launch of EM #1 runs
+    (hgx_type.hip run_many); the test switch many=rest_first scores everything before the launch, as rounds 3-4 did: every field
+    of every task equal, for an HLA locus and a locus of another base side by side (the latter has no second half)."""
+    pls, manies = [], []
+    loc = synth.make_hla_like_locus(n_alleles=2500, n_vars=1500, seed=77)
+    pl = hl.PackedLocus.from_synth(loc)
+    bs = [pl.parse_sam(synth.simulate_sam_fast(loc, synth.pick_sample(loc, 9 + s), n, err_rate=0.003, seed=5 * s + 2) if n else "")
+          for s, n in enumerate([1500, 0, 700, 2600, 90])]
+    pls.append(pl); manies.append(engine.ManyBatch(pl, bs))
+    sloc = synth.make_str_like_locus(gene="TH01", unit="AATG", max_repeats=12, min_repeats=4, seed=5)
+    spl = hl.PackedLocus.from_synth(sloc)
+    names = [a for a in sloc.allele_names if "BACKBONE" not in a]
+    sbs = [spl.parse_sam(synth.simulate_sam_fast(sloc, [names[2 + s], names[-2 - s]], 300 + 100 * s, read_len=100, frag_len=(200, 300), err_rate=0.002, seed=3 * s + 2))
+           for s in range(3)]
+    pls.append(spl); manies.append(engine.ManyBatch(spl, sbs))
+    for kw in (dict(), dict(em_fast=False)):
+        rows = htyping.type_many_loci(pls, manies, **kw)
+        with engine.test_switches(many="rest_first"):
+            rows0 = htyping.type_many_loci(pls, manies, **kw)
+        for row, row0 in zip(rows, rows0):
+            assert len(row) == len(row0)
+            for g, h in zip(row, row0):
+                _same(g, h)
+        one = htyping.type_many(pls[0], manies[0], **kw)                   # (the one-locus entry point goes the same way)
+        for g, h in zip(one, rows[0]):
+            _same(g, h)
+    for m in manies:
+        m.close()
