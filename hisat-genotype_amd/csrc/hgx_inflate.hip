@@ -29,7 +29,11 @@
 
 namespace {
 
-constexpr int RING = 8192, RMASK = RING - 1, FLUSH = 2048, PIECE = FLUSH / 64;      // (see the header: the ring holds the near window only)
+#ifndef HGX_INF_RING
+#define HGX_INF_RING 8192
+#define HGX_INF_FLUSH 2048
+#endif
+constexpr int RING = HGX_INF_RING, RMASK = RING - 1, FLUSH = HGX_INF_FLUSH, PIECE = FLUSH / 64;      // (see the header: the ring holds the near window only)
 constexpr int LIT_P = 10, DIST_P = 8;
 
 struct HuffLds {
@@ -47,14 +51,9 @@ struct InfLds {
     HuffLds lit;
     DistLds dist;
     unsigned char lens[384];             // [0, 19): the code-length code; [32, 32 + n_lit + n_dist): the two codes' lengths
-    uint16_t code[320];
     uint32_t crc_piece[64];
 };
 
-__constant__ uint16_t c_len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-__constant__ uint8_t c_len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-__constant__ uint16_t c_dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-__constant__ uint8_t c_dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 __constant__ uint8_t c_cl_order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 struct BlockDesc { uint32_t in_off, in_len, out_off, out_len, crc; };
@@ -107,47 +106,63 @@ __device__ __forceinline__ uint32_t bits_peek(const Bits &b, int n) { return (ui
 __device__ __forceinline__ void bits_drop(Bits &b, int n) { b.buf >>= n; b.cnt -= n; }
 __device__ __forceinline__ uint32_t bits_take(Bits &b, int n) { const uint32_t v = bits_peek(b, n); bits_drop(b, n); return v; }
 
-// canonical Huffman tables from code lengths lens[0..n): false = over-subscribed (or, for `strict`, incomplete) set of lengths
+// Canonical Huffman tables from code lengths lens[0..n): false = over-subscribed (or, unless `allow_incomplete`, incomplete) set of
+// lengths.  All 64 lanes work: a symbol per lane and 64 symbols per round; the number of codes of every length and a symbol's rank
+// among the codes of its length come from one ballot per (round, length) -- the counters live in scalar registers under fully
+// unrolled length loops.  (The first form walked the symbols on lane 0 with its per-length cursors in a register array: every
+// dynamic index became a 16-way compare-and-select chain, ~150 instructions per symbol, a fifth of the kernel's scalar work.)
 template <class T, int P>
-__device__ bool huff_build(T &H, const unsigned char *lens, uint16_t *code, int n, int lane, bool allow_incomplete, bool mark_literals = false) {
+__device__ bool huff_build(T &H, const unsigned char *lens, int n, int lane, bool allow_incomplete, bool mark_literals = false) {
     for (int i = lane; i < (1 << P); i += 64) H.pt[i] = 0;
-    if (lane < 16) H.count[lane] = 0;
     __builtin_amdgcn_wave_barrier();
-    int ok = 1;
-    if (lane == 0) {
-        for (int s = 0; s < n; ++s) H.count[lens[s]] += 1;
-        H.count[0] = 0;
-        int left = 1;
-        for (int L = 1; L < 16; ++L) { left = (left << 1) - (int)H.count[L]; if (left < 0) ok = 0; }
-        if (left > 0 && !allow_incomplete) ok = 0;
-        uint32_t c = 0;
-        uint16_t at = 0;
-        uint16_t next[16];
-        for (int L = 1; L < 16; ++L) {
-            c = (c + H.count[L - 1]) << 1;
-            H.first[L] = (uint16_t)c;
-            H.offs[L] = at;
-            next[L] = (uint16_t)c;
-            at = (uint16_t)(at + H.count[L]);
-        }
-        uint16_t fill[16];
-        for (int L = 0; L < 16; ++L) fill[L] = H.offs[L];
-        for (int s = 0; s < n; ++s) {
-            const int L = lens[s];
-            if (!L) continue;
-            code[s] = next[L]++;
-            H.sorted[fill[L]++] = (uint16_t)s;
-        }
+    uint32_t cnt[16];
+#pragma unroll
+    for (int v = 0; v < 16; ++v) cnt[v] = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int s = c0 + lane;
+        const int L = s < n ? (int)lens[s] : 0;
+#pragma unroll
+        for (int v = 1; v < 16; ++v) cnt[v] += (uint32_t)__popcll(__ballot(L == v));
     }
-    ok = __builtin_amdgcn_readfirstlane(ok);
-    __builtin_amdgcn_wave_barrier();
-    if (!ok) return false;
-    for (int s = lane; s < n; s += 64) {
-        const int L = lens[s];
-        if (L == 0 || L > P) continue;
-        const uint32_t rev = __brev((uint32_t)code[s]) >> (32 - L);
-        const uint16_t e = (uint16_t)((s << 4) | L | ((mark_literals && s < 256) ? 0x8000 : 0));      // (literal/length table: bit 15 = a literal)
-        for (uint32_t k = rev; k < (1u << P); k += 1u << L) H.pt[k] = e;
+    int left = 1;
+    bool ok = true;
+#pragma unroll
+    for (int v = 1; v < 16; ++v) { left = (left << 1) - (int)cnt[v]; ok = ok && left >= 0; }
+    if (left > 0 && !allow_incomplete) ok = false;
+    if (!ok) return false;                                            // (uniform)
+    {
+        uint32_t my_c = 0, my_f = 0, my_o = 0, c = 0, at = 0;
+#pragma unroll
+        for (int v = 1; v < 16; ++v) {
+            c = (c + cnt[v - 1]) << 1;                                // first code of length v; `at` = codes shorter than v
+            if (lane == v) { my_c = cnt[v]; my_f = c; my_o = at; }
+            at += cnt[v];
+        }
+        if (lane < 16) { H.count[lane] = (uint16_t)my_c; H.first[lane] = (uint16_t)my_f; H.offs[lane] = (uint16_t)my_o; }
+    }
+    uint32_t seen[16];                                                // codes of every length in the rounds so far
+#pragma unroll
+    for (int v = 0; v < 16; ++v) seen[v] = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int s = c0 + lane;
+        const int L = s < n ? (int)lens[s] : 0;
+        uint32_t rank = 0, fst = 0, off = 0, c = 0, at = 0;
+#pragma unroll
+        for (int v = 1; v < 16; ++v) {
+            c = (c + cnt[v - 1]) << 1;
+            const unsigned long long m = __ballot(L == v);
+            if (L == v) { rank = seen[v] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); fst = c; off = at; }
+            seen[v] += (uint32_t)__popcll(m);
+            at += cnt[v];
+        }
+        if (L != 0) {
+            H.sorted[off + rank] = (uint16_t)s;                       // symbols by (length, symbol)
+            if (L <= P) {
+                const uint32_t rev = __brev(fst + rank) >> (32 - L);
+                const uint16_t e = (uint16_t)((s << 4) | L | ((mark_literals && s < 256) ? 0x8000 : 0));      // (literal/length table: bit 15 = a literal)
+                for (uint32_t k = rev; k < (1u << P); k += 1u << L) H.pt[k] = e;
+            }
+        }
     }
     __builtin_amdgcn_wave_barrier();
     return true;
@@ -254,8 +269,8 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                 if (lane < 32) S.lens[288 + lane] = 5;
                 n_lit = 288; n_dist = 30;
                 __builtin_amdgcn_wave_barrier();
-                if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens, S.code, 288, lane, false, true)) { err = INF_BAD_LENGTHS; break; }
-                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 288, S.code, 32, lane, true)) { err = INF_BAD_LENGTHS; break; }   // (32 five-bit codes, two of them never sent)
+                if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens, 288, lane, false, true)) { err = INF_BAD_LENGTHS; break; }
+                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 288, 32, lane, true)) { err = INF_BAD_LENGTHS; break; }   // (32 five-bit codes, two of them never sent)
             } else {                                                // dynamic codes (3.2.7)
                 n_lit = (int)bits_take(b, 5) + 257;
                 n_dist = (int)bits_take(b, 5) + 1;
@@ -270,7 +285,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                 }
                 __builtin_amdgcn_wave_barrier();
                 // the code-length code goes through the distance slot (19 symbols, at most 7 bits)
-                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens, S.code, 19, lane, false)) { err = INF_BAD_LENGTHS; break; }
+                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens, 19, lane, false)) { err = INF_BAD_LENGTHS; break; }
                 int at = 0, prev = 0;
                 const int total = n_lit + n_dist;
                 while (at < total && !err) {
@@ -291,11 +306,11 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                 if (err) break;
                 __builtin_amdgcn_wave_barrier();
                 if (S.lens[32 + 256] == 0) { err = INF_BAD_LENGTHS; break; }              // no end-of-block code
-                if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, S.code, n_lit, lane, false, true)) {
+                if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, n_lit, lane, false, true)) {
                     // (an incomplete literal/length code is legal only when it has a single code: zlib accepts that; so do we)
-                    if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, S.code, n_lit, lane, true, true)) { err = INF_BAD_LENGTHS; break; }
+                    if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, n_lit, lane, true, true)) { err = INF_BAD_LENGTHS; break; }
                 }
-                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 32 + n_lit, S.code, n_dist, lane, true)) { err = INF_BAD_LENGTHS; break; }
+                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 32 + n_lit, n_dist, lane, true)) { err = INF_BAD_LENGTHS; break; }
             }
             // ---- the symbols of the block -------------------------------------------------------------------------------
             // (literals are gathered eight at a time: one byte store by eight lanes instead of eight stores by one)
@@ -354,19 +369,33 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                     lit_out();
                     const int li = sym - 257;
                     if (li >= 29) { err = INF_BAD_CODE; break; }
-                    const uint32_t len = c_len_base[li] + bits_take(b, c_len_extra[li]);
+                    // base and extra bits of the length / distance codes (RFC 1951, 3.2.5) by arithmetic: a table in memory would
+                    // put two dependent loads on the path of every match
+                    const int le = li < 8 || li == 28 ? 0 : (li - 4) >> 2;
+                    const uint32_t lbase = li < 8 ? 3u + (uint32_t)li : li == 28 ? 258u : ((4u + ((uint32_t)li & 3u)) << le) + 3u;
+                    const uint32_t len = lbase + bits_take(b, le);
                     bits_refill(b, lane);
                     const int ds = huff_decode<DistLds, DIST_P>(S.dist, b);
                     if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
-                    const uint32_t dist = c_dist_base[ds] + bits_take(b, c_dist_extra[ds]);
+                    const int de = ds < 4 ? 0 : (ds >> 1) - 1;
+                    const uint32_t dbase = ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << de) + 1u;
+                    const uint32_t dist = dbase + bits_take(b, de);
                     if (dist > wpos) { err = INF_BAD_DIST; break; }
                     if (wpos + len > B.out_len) { err = INF_OVERRUN; break; }
                     __builtin_amdgcn_wave_barrier();
                     // every source byte lies before the match: byte i comes from (i mod dist) bytes into the last `dist` bytes
-                    if (dist <= (uint32_t)(RING - 258)) {
+                    if (dist >= len && dist <= (uint32_t)(RING - 258)) {                 // (the usual case: source and target apart)
+                        for (uint32_t i = lane; i < len; i += 64) S.ring[(wpos + i) & RMASK] = S.ring[(wpos - dist + i) & RMASK];
+                    } else if (dist == 1) {                                              // a run of one byte
+                        const unsigned char v = S.ring[(wpos - 1) & RMASK];
+                        for (uint32_t i = lane; i < len; i += 64) S.ring[(wpos + i) & RMASK] = v;
+                    } else if (dist < len) {
+                        // i mod dist without an integer division: i < 258 and dist < 258, and (i + 0.5) / dist is at least 0.5 / 258
+                        // away from every integer -- far more than the error of the reciprocal
+                        const float rcp = __frcp_rn((float)dist);
                         for (uint32_t i = lane; i < len; i += 64) {
-                            const uint32_t k = dist >= len ? i : i % dist;
-                            S.ring[(wpos + i) & RMASK] = S.ring[(wpos - dist + k) & RMASK];
+                            const uint32_t q = (uint32_t)(((float)i + 0.5f) * rcp);
+                            S.ring[(wpos + i) & RMASK] = S.ring[(wpos - dist + (i - q * dist)) & RMASK];
                         }
                     } else {
                         // beyond the ring: those bytes left for memory at least RING - FLUSH - 516 bytes ago (what is still pending
