@@ -381,7 +381,7 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
                                       "note": ("bytes the call sends to the device (the SAM text + its line table) / the call's time, against the measured "
                                                "host-to-device rate of registered memory (tools/pinned_probe.hip: 57.5 GB/s; PCIe Gen5 x16)") if kind == "sam" else
                                               ("a BAM travels DEFLATED (the file's bytes + a block table): the link is idle; the call is bound by "
-                                               "k_bgzf_inflate -- sequential symbol decoding, one wavefront per BGZF block, ~55-60 GB/s of payload -- and "
+                                               "k_bgzf_inflate -- sequential symbol decoding, one wavefront per BGZF block, ~80 GB/s of payload -- and "
                                                "the record kernels behind it (DESIGN.md section 5.6)")},
                          "runs_ms": [round(t * 1e3, 1) for t in spaced],
                          "throttled_ms": None if th1 is None else round((th2 - th1) / 1e3, 1),
