@@ -92,7 +92,10 @@ __device__ __forceinline__ void bits_refill(Bits &b, int lane) {
         if (b.idx == 64) {
             b.cur = b.nxt;
             b.chunk += 1;
-            b.nxt = b.base[(size_t)(b.chunk + 1) * 64 + lane];
+            // (a damaged stream may ask for far more bits than its block holds: beyond the block's dwords + 3/4 KB -- inside the
+            // padding the caller guarantees behind the last block -- the reader is fed zeros, and the decode ends in an error)
+            const uint32_t at = (b.chunk + 1) * 64;
+            b.nxt = at < b.n_dwords + 192u ? b.base[(size_t)at + lane] : 0u;
             b.idx = 0;
         }
         const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)b.cur, (int)b.idx);

@@ -96,3 +96,26 @@ def test_device_inflate_on_bam_files(tmp_path):
         data = open(p, "rb").read()
         got, bad = inflate_dev(data)
         assert bad == 0 and got == b"".join(bamio._bgzf_blocks(data))
+
+
+def test_device_inflate_stream_that_outruns_its_block():
+    """A well-formed container around a DEFLATE stream that asks for far more bits than the block holds -- here the LAST block of
+    the file, cut short inside its Huffman data with the size fields rewritten: the bit reader is fed zeros beyond the block (it
+    must not walk into whatever lies behind the buffer), the block is reported, the blocks before it are inflated."""
+    rng = random.Random(11)
+    payload = bytes(rng.getrandbits(8) for _ in range(3 * 0xff00))          # incompressible: ~64 KB of Huffman literals per block
+    blocks = []
+    for i in range(0, len(payload), 0xff00):
+        raw = payload[i:i + 0xff00]
+        comp = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_HUFFMAN_ONLY)
+        blocks.append((raw, comp.compress(raw) + comp.flush()))
+    def member(cdata, raw):
+        return (b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(cdata) + 25) + cdata +
+                struct.pack("<II", zlib.crc32(raw) & 0xffffffff, len(raw)))
+    for keep in (40, 1000, 30000):
+        raw, cdata = blocks[-1]
+        assert len(cdata) > 60000
+        data = b"".join(member(c, r) for r, c in blocks[:-1]) + member(cdata[:keep], raw)      # no EOF block: this one ends the file
+        got, bad = inflate_dev(data)
+        assert bad == 1, (keep, bad)
+        assert got[:2 * 0xff00] == payload[:2 * 0xff00]
