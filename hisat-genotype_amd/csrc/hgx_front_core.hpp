@@ -1110,8 +1110,18 @@ FE_HD inline int32_t fe_strtol32(const unsigned char *t, int n) {
 }
 // (8 bytes per load: the compiler emits one unaligned dwordx2 load on gfx950, one mov on x86; both little endian)
 FE_HD inline uint64_t fe_load8(const unsigned char *p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
+// (The streaming loops below take 32 bytes per round, the four loads issued together: a lane that comes back for the next 8 bytes of
+// a line finds it evicted -- 2 048 lanes per CU stream through lines of their own, the L1 holds 128 -- so 8 bytes per round were
+// one L2 request per load: 50 requests per record in k_fe_group_flags.)
 FE_HD inline uint64_t fe_hash_bytes(const unsigned char *p, int n, uint64_t h) {
     int i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const uint64_t w0 = fe_load8(p + i), w1 = fe_load8(p + i + 8), w2 = fe_load8(p + i + 16), w3 = fe_load8(p + i + 24);
+        h = (h ^ w0) * 0x9E3779B97F4A7C15ull; h ^= h >> 32;
+        h = (h ^ w1) * 0x9E3779B97F4A7C15ull; h ^= h >> 32;
+        h = (h ^ w2) * 0x9E3779B97F4A7C15ull; h ^= h >> 32;
+        h = (h ^ w3) * 0x9E3779B97F4A7C15ull; h ^= h >> 32;
+    }
     for (; i + 8 <= n; i += 8) {
         h = (h ^ fe_load8(p + i)) * 0x9E3779B97F4A7C15ull;
         h ^= h >> 32;
@@ -1142,6 +1152,11 @@ FE_HD inline uint64_t fe_rec_key(const FeRec &r, const char *text) {
 }
 FE_HD inline bool fe_bytes_equal(const unsigned char *a, const unsigned char *b, int n) {
     int i = 0;
+    for (; i + 32 <= n; i += 32) {
+        const uint64_t d = (fe_load8(a + i) ^ fe_load8(b + i)) | (fe_load8(a + i + 8) ^ fe_load8(b + i + 8)) |
+                           (fe_load8(a + i + 16) ^ fe_load8(b + i + 16)) | (fe_load8(a + i + 24) ^ fe_load8(b + i + 24));
+        if (d) return false;
+    }
     for (; i + 8 <= n; i += 8) if (fe_load8(a + i) != fe_load8(b + i)) return false;
     for (; i < n; ++i) if (a[i] != b[i]) return false;
     return true;
