@@ -765,8 +765,16 @@ __global__ void __launch_bounds__(256) k_bam_name_key(const unsigned char *__res
     if (i >= n) return;
     const unsigned char *r = text + rec_off[idx[i]];
     const uint32_t klen = (uint32_t)r[8] - 1;
+    // one 8-byte load (the sorted order makes every lane's record a line of its own: eight byte loads were eight gathers); a load
+    // near the end of the last record reaches at most 5 bytes into the buffer's padding
     unsigned long long v = 0;
-    for (uint32_t k = 0; k < 8; ++k) { const uint32_t at = 8 * chunk + k; v = (v << 8) | (at < klen ? r[32 + at] : 0u); }
+    if (8 * chunk < klen) {
+        unsigned long long w;
+        __builtin_memcpy(&w, r + 32 + 8 * chunk, 8);
+        v = __builtin_bswap64(w);
+        const uint32_t have = klen - 8 * chunk;
+        if (have < 8) v &= ~0ull << (8 * (8 - have));
+    }
     key[i] = v;
 }
 __global__ void k_bam_task_key(const uint16_t *__restrict__ rec_task, const uint32_t *__restrict__ idx, uint32_t n, unsigned long long *__restrict__ key) {
