@@ -656,6 +656,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         // ordinary way below, which also words the errors.
         std::vector<hgx_bgzf_block> blocks;
         size_t total = 0;
+        if (out.comp_early && data.size() >= out.defer_min_bytes / 64) out.comp_early(data.data(), data.size());   // (BGZF rarely deflates below 1 : 64)
         if (hgx_bgzf_scan(data.data(), data.size(), blocks, &total) == HGX_OK && total < (1ull << 32) - 64) {
             std::vector<unsigned char> head;
             std::vector<std::string> refs;

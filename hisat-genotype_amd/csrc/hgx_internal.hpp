@@ -204,6 +204,9 @@ struct hgx_align_lines {
     // block table once the BAM header (inflated on the host) says the stream qualifies; returns 0 when the payload now lies in
     // the caller's device buffer (deferred.on_device: `raw` stays NULL, raw_bytes = the payload's size), else the host inflates
     std::function<int(const unsigned char *data, size_t n, const std::vector<hgx_bgzf_block> &blocks, size_t total)> inflate_dev;
+    // in, optional: called with the file's bytes as soon as they are read and look like BGZF -- the caller may start sending them
+    // while the host still hops through the container and inflates the header (inflate_dev then finds them on their way)
+    std::function<void(const unsigned char *data, size_t n)> comp_early;
     hgx_align_lines() = default;
     hgx_align_lines(const hgx_align_lines &) = delete;
     hgx_align_lines &operator=(const hgx_align_lines &) = delete;
@@ -280,6 +283,7 @@ struct hgx_front_hook {
     bool defer_walk = false;           // the hook's owner takes unwalked BAM streams
     size_t defer_min_bytes = 0;
     std::function<int(const unsigned char *data, size_t n, const std::vector<hgx_bgzf_block> &blocks, size_t total)> inflate_dev;   // ... and deflated ones
+    std::function<void(const unsigned char *data, size_t n)> comp_early;             // (the deflated bytes, before the container is looked at)
     std::function<void(const char *raw, size_t n_bytes, size_t begin, size_t end)> on_raw;
     int declined_records = 0;
 };
