@@ -119,3 +119,14 @@ def test_device_inflate_stream_that_outruns_its_block():
         got, bad = inflate_dev(data)
         assert bad == 1, (keep, bad)
         assert got[:2 * 0xff00] == payload[:2 * 0xff00]
+
+
+def test_device_inflate_fuzz_cases():
+    """200 cases of tools/fuzz_inflate.py (random payload textures, levels, strategies, block sizes, several DEFLATE blocks per member)."""
+    import importlib.util
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_inflate.py")
+    r = subprocess.run([sys.executable, tool, "200", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "200 cases" in r.stdout and " 0 mismatches" in r.stdout
