@@ -6,6 +6,8 @@
 #include <cstring>
 #include <cstdio>
 #include <mutex>
+#include <string>
+#include <vector>
 
 #include "hgx.h"
 
@@ -107,6 +109,7 @@ struct hgx_dbatch {
     int32_t n_ref = 0;                   // pileup tables (device front end only): counts[n_ref][6], nt_set[n_ref]
     uint32_t *d_counts = nullptr;
     uint8_t *d_nt_set = nullptr;
+    std::vector<std::string> trace;      // hgx_parse_opts.keep_trace: one line per kept record (hgx_batch_trace_text after hgx_dbatch_to_host)
 };
 
 struct DevBuf {

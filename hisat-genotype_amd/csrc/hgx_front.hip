@@ -168,7 +168,7 @@ struct FeCtl {
     uint32_t ht_cursor, cand_cursor, mask_cursor;
     int32_t decline;                 // first decline code seen (an FE_E_* value, negative), 0 = none
     uint32_t n_heads, n_masks;
-    uint32_t n_keys, n_slots, n_rec, pad_;                    // record stage: distinct keys, decoded keys, records that passed the filters
+    uint32_t n_keys, n_slots, n_rec, trace_cursor;            // record stage: distinct keys, decoded keys, records that passed the filters
     unsigned long long n_reads, n_gene_refs, pair_total;      // pair_total = pairs << 40 | refs
 };
 
@@ -465,7 +465,15 @@ __global__ void __launch_bounds__(256) k_fe_records(const char *__restrict__ tex
     FeRec r;
     const int rc = binary ? fe_parse_bam_record(text, lines[i].off, lines[i].len, simulation != 0, lines[i].task, r)
                           : fe_parse_text_record(text, text_bytes, lines[i].off, lines[i].len, simulation != 0, lines[i].task, r);
-    if (rc < 0) { fe_decline(ctl, rc); r.bits = 0; r.flag = 4; r.id_len = 0; r.qname_off = 0; r.key = 0; r.task = (uint16_t)lines[i].task; }
+    if (rc < 0) {
+        // a record the kernels cannot take: the call declines (checked after the record stage); until then the record must be
+        // inert -- no stale offset or length for the filters, the key table or the byte-for-byte compares to follow
+        fe_decline(ctl, rc);
+        r = FeRec{};
+        r.bits = FE_R_FAILED;
+        r.flag = 4;
+        r.task = (uint16_t)lines[i].task;
+    }
     recs[i] = r;
 }
 __global__ void k_fe_rec_heads(const FeRec *__restrict__ recs, uint32_t n, const char *__restrict__ text, uint8_t *__restrict__ head) {
@@ -806,6 +814,7 @@ struct DevInput {                     // keys, their text and the kept records, 
     int n_tasks = 1;
     uint32_t *task_reads = nullptr, *task_pairs = nullptr, *task_pieces = nullptr;
     unsigned long long *task_refs = nullptr;
+    const hgx_locus *host_locus = nullptr;     // keep_trace: the variant names the trace lines spell
 };
 struct Lap {
     bool prof; hipStream_t st; double t_prev;
@@ -830,7 +839,7 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     // buffers go back to the pool
     DevBuf b_state, b_koff, b_knht, b_ht, b_clo, b_cnw, b_ckey, b_cmoff, b_mpool, b_slot_task, b_kpos, b_kpos2, b_kord, b_kord2, b_ktmp;
     DevBuf b_cnt, b_off, b_tmp, b_tmp2, b_key_s, b_idx, b_idx_s, b_flag, b_rank, b_head_of, b_head_cand;
-    DevBuf b_wh, b_wh_s, b_hidx, b_hidx_s, b_lonw, b_lonw_s, b_ord, b_nw2, b_moff, b_new_id, b_cand_piece, b_tbits;
+    DevBuf b_wh, b_wh_s, b_hidx, b_hidx_s, b_lonw, b_lonw_s, b_ord, b_nw2, b_moff, b_new_id, b_cand_piece, b_tbits, b_trace, b_troff;
     hgx_dbatch *d = new hgx_dbatch();
     struct Guard { hgx_dbatch *&d; hipStream_t st; ~Guard() { (void)hipStreamSynchronize(st); if (d) hgx_dbatch_destroy(d); } } guard{d, st};
     FeCtl *ctl = di.ctl;
@@ -891,6 +900,15 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     pools.cand_lo = b_clo.as<uint16_t>(); pools.cand_nw = b_cnw.as<uint16_t>(); pools.cand_key = b_ckey.as<uint64_t>();
     pools.cand_mask_off = b_cmoff.as<uint32_t>(); pools.cand_cap = (uint32_t)cand_cap; pools.cand_cursor = &ctl->cand_cursor;
     pools.mask_pool = b_mpool.as<uint32_t>(); pools.mask_cap = (uint32_t)mask_cap; pools.mask_cursor = &ctl->mask_cursor;
+    pools.trace_pool = nullptr; pools.trace_cap = 0; pools.trace_cursor = &ctl->trace_cursor; pools.key_trace_off = nullptr;
+    const size_t trace_cap = (size_t)S * 96 + 4096;
+    const bool tracing = o.keep_trace && n_tasks == 1 && di.host_locus && trace_cap < (1ull << 31);
+    if (tracing) {                                                    // (tests: the intermediates of every decoded key, see FePools)
+        ALLOC(b_trace, trace_cap * 4);
+        ALLOC(b_troff, std::max<size_t>(S, 4) * 4);
+        HIPCHK(hipMemsetAsync(b_troff.p, 0xFF, std::max<size_t>(S, 4) * 4, st));
+        pools.trace_pool = b_trace.as<int32_t>(); pools.trace_cap = (uint32_t)trace_cap; pools.key_trace_off = b_troff.as<uint32_t>();
+    }
     const FeParse po{o.num_editdist, o.error_correction};
     const FePile pile{d->d_nt_set, d->d_counts};
     if (n_keys) {
@@ -1035,6 +1053,17 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     lap("piece table + refs");
     d->n_mask_u32 = n_heads ? (int64_t)h.n_masks : 0;
     d->sum_piece_words = d->n_mask_u32 / 2;
+    if (tracing && n_rec) {
+        std::vector<uint8_t> h_state(std::max<size_t>(S, 1));
+        std::vector<uint32_t> h_troff(std::max<size_t>(S, 1)), h_rec(n_rec);
+        std::vector<int32_t> h_pool(std::max<size_t>(h.trace_cursor, 1));
+        if (S) HIPCHK(hipMemcpyAsync(h_state.data(), b_state.p, S, hipMemcpyDeviceToHost, st));
+        if (S) HIPCHK(hipMemcpyAsync(h_troff.data(), b_troff.p, (size_t)S * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(h_rec.data(), rec_info, (size_t)n_rec * 4, hipMemcpyDeviceToHost, st));
+        if (h.trace_cursor) HIPCHK(hipMemcpyAsync(h_pool.data(), b_trace.p, (size_t)h.trace_cursor * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        hgx_front_trace_lines(*di.host_locus, h_rec.data(), n_rec, h_state.data(), h_troff.data(), h_pool.data(), d->trace);
+    }
     *out = d;
     d = nullptr;                       // (the guard keeps its hands off)
     return HGX_OK;
@@ -1063,8 +1092,9 @@ int front_run(hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, 
     HIPCHK(hipMemsetAsync(b_ctl.p, 0, sizeof(FeCtl), st));
     g_last_bytes += (long long)(in.n_keys * sizeof(FeKey) + in.n_text + in.n_rec * 4);
     lap("upload");
-    const DevInput di{b_keys.as<FeKey>(), (uint32_t)in.n_keys, b_text.as<char>(), b_rec.as<uint32_t>(), (uint32_t)in.n_rec, (uint32_t)in.n_slots,
-                      b_ctl.as<FeCtl>()};
+    DevInput di{b_keys.as<FeKey>(), (uint32_t)in.n_keys, b_text.as<char>(), b_rec.as<uint32_t>(), (uint32_t)in.n_rec, (uint32_t)in.n_slots,
+                b_ctl.as<FeCtl>()};
+    di.host_locus = &L;
     return front_stages(*Fp, di, o, st, out, declined);
 }
 
@@ -1294,6 +1324,7 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
     if (h.decline) { *declined = -h.decline; return HGX_OK; }
     DevInput di{b_keys.as<FeKey>(), h.n_keys, d_text, b_rec.as<uint32_t>(), h.n_rec, h.n_slots, ctl};
     di.n_tasks = std::max(1, n_tasks);
+    di.host_locus = &L;
     if (di.n_tasks > 1) {
         ALLOC(b_treads, (size_t)di.n_tasks * 4); ALLOC(b_tpairs, (size_t)di.n_tasks * 4); ALLOC(b_trefs, (size_t)di.n_tasks * 8);
         ALLOC(b_tpieces, (size_t)di.n_tasks * 4);
@@ -1347,7 +1378,7 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Pars
     const unsigned char *comp_from = nullptr;
     size_t up_bytes = 0, comp_n = 0;
     bool up_failed = false;
-    if (!host_only && !no_records && !(opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange)) {
+    if (!host_only && !no_records && !(opts->codis_choose_pairs || opts->interdist_exchange)) {
         hook.on_raw = [&](const char *raw, size_t n_bytes, size_t begin, size_t end) {
             if (n_bytes >= (1ull << 32) - 64 || up_failed) return;
             if (!b_text.p && b_text.alloc(n_bytes + 64)) { up_failed = true; return; }
@@ -1643,6 +1674,7 @@ extern "C" int hgx_dbatch_to_host(const hgx_dbatch *d, hgx_batch **out) {
         if (!rc) rc = down(b->nt_set.data(), d->d_nt_set, b->nt_set.size());
     }
     if (rc) { delete b; return rc; }
+    for (const auto &t : d->trace) b->trace.push_back(TraceRec{t});
     *out = b;
     return HGX_OK;
 }

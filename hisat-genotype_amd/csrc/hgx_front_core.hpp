@@ -869,8 +869,17 @@ struct FePools {
     int32_t *ht_pool;      uint32_t ht_cap;      uint32_t *ht_cursor;
     uint16_t *cand_lo, *cand_nw; uint64_t *cand_key; uint32_t *cand_mask_off; uint32_t cand_cap; uint32_t *cand_cursor;
     uint32_t *mask_pool;   uint32_t mask_cap;    uint32_t *mask_cursor;
+    // keep_trace (hgx_parse_opts): per decoded key the intermediates the reference's loop holds after identify_ambigious_diffs
+    // (typing_core.py:1351-1384) -- what tests compare with the values recorded from the reference.  NULL = off.  A record:
+    //   n_novel, n_cmp, cmp_left, cmp_right, n_left, n_right,
+    //   n_novel x (variant type, pos, base | length)   novel variants in the order the walk created them (typing_core.py:1126-1164)
+    //   n_cmp x (type | base << 8, pos, len, id)       cmp_list2
+    //   per left alternative, then per right one: coord, n_ids, ids...
+    int32_t *trace_pool;   uint32_t trace_cap;   uint32_t *trace_cursor;  uint32_t *key_trace_off;
 };
 #define FE_HT_HDR 5
+#define FE_TRACE_HDR 6
+#define FE_NO_TRACE 0xFFFFFFFFu
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FE_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
@@ -890,12 +899,43 @@ FE_HD inline int fe_key(const FeLocus &L, const FeParse &o, const FePile &P, con
     int rc = fe_decode(L, o, P, K.pos, fe_cigar_of(K, text), fe_seq_of(K, text), text + K.zs_off, (K.flags & FE_K_HAS_ZS) ? K.zs_len : 0,
                        text + K.md_off, (K.flags & FE_K_HAS_MD) ? K.md_len : 0, cl, n_cl, tmp);
     if (rc <= 0) return rc;
+    int n_nov = 0;
+    if (pools.trace_pool) {                                          // (tmp is free again: the novel variants, in creation order)
+        for (int k = 0; k < n_cl; ++k) {
+            const FeCmp c = cl[k];
+            const int t = fe_type(c);
+            if (t == FE_T_MATCH || c.id < L.V) continue;
+            FeCmp &d = tmp[n_nov++];
+            d.pos = c.pos;
+            if (t == FE_T_MISMATCH) { d.type = FE_VAR_SINGLE; d.len = (int32_t)(unsigned char)fe_base(c); }
+            else { d.type = t == FE_T_DELETION ? FE_VAR_DELETION : FE_VAR_INSERTION; d.len = c.len; }
+        }
+    }
     fe_cmp_list2(L, cl, n_cl);
     if (n_cl <= 0) return FE_FAIL(FE_E_ASSERT);
     FeSide lset, rset;
     int cleft, cright;
     rc = fe_ambiguous(L, cl, n_cl, cleft, cright, lset, rset);
     if (rc) return rc;
+    if (pools.trace_pool) {
+        uint32_t words = FE_TRACE_HDR + 3u * (uint32_t)n_nov + 4u * (uint32_t)n_cl + 2u * (uint32_t)(lset.n + rset.n) + (uint32_t)(lset.n_ids + rset.n_ids);
+        const uint32_t t0 = FE_ATOMIC_ADD(pools.trace_cursor, words);
+        if (t0 + words > pools.trace_cap) return FE_FAIL(FE_E_POOL);
+        int32_t *w = pools.trace_pool + t0;
+        w[0] = n_nov; w[1] = n_cl; w[2] = cleft; w[3] = cright; w[4] = lset.n; w[5] = rset.n;
+        w += FE_TRACE_HDR;
+        for (int k = 0; k < n_nov; ++k) { w[0] = tmp[k].type; w[1] = tmp[k].pos; w[2] = tmp[k].len; w += 3; }
+        for (int k = 0; k < n_cl; ++k) { w[0] = cl[k].type; w[1] = cl[k].pos; w[2] = cl[k].len; w[3] = cl[k].id; w += 4; }
+        for (int side = 0; side < 2; ++side) {
+            const FeSide &sd = side ? rset : lset;
+            for (int a = 0; a < sd.n; ++a) {
+                w[0] = sd.coord[a]; w[1] = sd.cnt[a];
+                for (int i = 0; i < sd.cnt[a]; ++i) w[2 + i] = sd.ids[sd.off[a] + i];
+                w += 2 + sd.cnt[a];
+            }
+        }
+        pools.key_trace_off[K.slot] = t0;
+    }
     int mid[FE_MAX_MID], n_mid = 0;
     for (int k = cleft; k <= cright; ++k)
         if (fe_type(cl[k]) != FE_T_MATCH) { if (n_mid >= FE_MAX_MID) return FE_FAIL(FE_E_CAP); mid[n_mid++] = cl[k].id; }
@@ -1076,6 +1116,7 @@ FE_HD inline uint8_t fe_nt_set(const uint32_t *c) {
 #define FE_R_HAS_ZS 4
 #define FE_R_HAS_MD 8
 #define FE_R_BIN 16                  // BAM record: binary CIGAR, packed SEQ
+#define FE_R_FAILED 32               // the record could not be taken apart (the call declines): every offset and length is zero
 struct FeRec {
     uint32_t qname_off;
     uint16_t id_len;                 // read id = QNAME, or QNAME up to the first '|' in simulation mode (typing_core.py:808-809)
@@ -1163,6 +1204,7 @@ FE_HD inline bool fe_bytes_equal(const unsigned char *a, const unsigned char *b,
 }
 FE_HD inline bool fe_rec_same_key(const FeRec &a, const FeRec &b, const char *text) {      // same_decode_key of hgx_sam.cpp
     const unsigned char *t = (const unsigned char *)text;
+    if ((a.bits | b.bits) & FE_R_FAILED) return true;               // (nothing of a failed record may be read; the call has declined)
     if (a.task != b.task || a.pos != b.pos || a.seq_len != b.seq_len || a.cigar_len != b.cigar_len || a.zs_len != b.zs_len || a.md_len != b.md_len) return false;
     if (((a.bits ^ b.bits) & (FE_R_HAS_ZS | FE_R_HAS_MD | FE_R_BIN)) != 0) return false;
     if (a.bits & FE_R_BIN) {
@@ -1272,7 +1314,29 @@ FE_HD inline int fe_parse_bam_record(const char *text, uint32_t rec_off, uint32_
     const int32_t pos0 = (int32_t)fe_ld32(r + 4);
     const uint32_t l_rn = r[8], n_cig = (uint32_t)r[12] | ((uint32_t)r[13] << 8), flag = (uint32_t)r[14] | ((uint32_t)r[15] << 8);
     const int32_t l_seq = (int32_t)fe_ld32(r + 16);
-    if (l_rn == 0 || l_seq <= 0) return FE_FAIL(FE_E_ASSERT);           // (a record without SEQ spells "*": the host's business)
+    if (l_rn == 0) return FE_FAIL(FE_E_ASSERT);
+    if (flag & 0x4) {
+        // An unmapped record (a mate placed at its partner's position; routine in a BAM over a region): the filters drop it on
+        // its flag before anything else of it is looked at (typing_core.py:815-820, typing_common.py:1076), so only its name and
+        // flag are taken -- CIGAR "*" / SEQ "*" need not decline the call.
+        if (32 + (size_t)l_rn > len || r[32 + l_rn - 1] != 0) return FE_FAIL(FE_E_ASSERT);
+        rec.bits = FE_R_BIN;
+        rec.task = (uint16_t)task;
+        rec.nm = rec.nh = 0;
+        rec.cigar_off = rec.seq_off = rec.zs_off = rec.md_off = rec_off;
+        rec.seq_len = 0;
+        rec.cigar_len = rec.zs_len = rec.md_len = 0;
+        rec.qname_off = rec_off + 32;
+        uint32_t idl = l_rn - 1;
+        if (simulation)
+            for (uint32_t k = 0; k + 1 < l_rn; ++k) if (r[32 + k] == '|') { idl = k; break; }
+        rec.id_len = (uint16_t)idl;
+        rec.flag = (int32_t)flag;
+        rec.pos = pos0 + 1;
+        rec.key = fe_rec_key(rec, text);
+        return 0;
+    }
+    if (l_seq <= 0) return FE_FAIL(FE_E_ASSERT);                          // (a mapped record without SEQ spells "*": the host's business)
     size_t q = 32 + (size_t)l_rn;
     const size_t cig_at = q;
     q += 4ull * n_cig;

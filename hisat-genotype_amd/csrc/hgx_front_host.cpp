@@ -90,6 +90,49 @@ FeLocus hgx_front_view(const hgx_locus &L, const hgx_front_tables &T) {
     return F;
 }
 
+void hgx_front_trace_lines(const hgx_locus &L, const uint32_t *rec_info, size_t n_rec, const uint8_t *state, const uint32_t *trace_off,
+                           const int32_t *pool, std::vector<std::string> &out) {
+    static const char *const kType[] = {"match", "mismatch", "insertion", "deletion"};
+    std::unordered_map<uint64_t, int> novel;                          // (variant type, pos, base | length) -> k of "nv<k>"
+    auto nkey = [](int type, int pos, int key) { return ((uint64_t)(uint32_t)type << 56) ^ ((uint64_t)(uint32_t)pos << 24) ^ (uint64_t)(uint32_t)key; };
+    auto vname = [&](int id) -> std::string {
+        if (id == -1) return "unknown";
+        if (id >= 0 && id < L.V) return L.name[id];
+        // a novel indel: its id spells type, position and length (hgx_front_core.hpp)
+        const int type = ((id >> 29) & 1) ? FE_VAR_DELETION : FE_VAR_INSERTION;
+        auto it = novel.find(nkey(type, (id >> 12) & 0x1ffff, id & 0xfff));
+        return it == novel.end() ? std::string("nv?") : "nv" + std::to_string(it->second);
+    };
+    auto join = [&](const int32_t *ids, int n) { std::string s; for (int i = 0; i < n; ++i) { if (i) s += '-'; s += vname(ids[i]); } return s; };
+    std::vector<uint8_t> seen;
+    for (size_t i = 0; i < n_rec; ++i) {
+        const uint32_t slot = FE_REC_SLOT(rec_info[i]);
+        if (state[slot] != 1 || trace_off[slot] == FE_NO_TRACE) continue;
+        const int32_t *w = pool + trace_off[slot];
+        const int n_nov = w[0], n_c = w[1], cleft = w[2], cright = w[3], n_l = w[4], n_r = w[5];
+        w += FE_TRACE_HDR;
+        for (int k = 0; k < n_nov; ++k, w += 3) novel.emplace(nkey(w[0], w[1], w[2]), (int)novel.size());
+        std::string t;
+        for (int k = 0; k < n_c; ++k, w += 4) {
+            if (k) t += ',';
+            const int type = w[0] & 3;
+            t += kType[type];
+            t += ':' + std::to_string(w[1]) + ':' + std::to_string(w[2]);
+            if (type != FE_T_MATCH) t += ':' + vname(w[3]);
+        }
+        t += '\t' + std::to_string(cleft) + '\t' + std::to_string(cright) + '\t';
+        std::vector<std::string> ls, rs;
+        for (int a = 0; a < n_l; ++a) { ls.push_back(std::to_string(w[0]) + (w[1] ? "-" + join(w + 2, w[1]) : "")); w += 2 + w[1]; }
+        for (int a = 0; a < n_r; ++a) { rs.push_back((w[1] ? join(w + 2, w[1]) + "-" : "") + std::to_string(w[0])); w += 2 + w[1]; }
+        std::sort(ls.begin(), ls.end());
+        std::sort(rs.begin(), rs.end());
+        for (size_t k = 0; k < ls.size(); ++k) t += (k ? ";" : "") + ls[k];
+        t += '\t';
+        for (size_t k = 0; k < rs.size(); ++k) t += (k ? ";" : "") + rs[k];
+        out.push_back(std::move(t));
+    }
+}
+
 #ifdef HGX_LAB
 // ---- the device pipeline as loops (lab build only; mirrors hgx_front.hip stage by stage) ---------------------------------------
 // *declined = 0 and *out = the batch, or *declined = the reason and no batch.
@@ -139,6 +182,15 @@ int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, 
     pools.cand_lo = cand_lo.data(); pools.cand_nw = cand_nw.data(); pools.cand_key = cand_key.data();
     pools.cand_mask_off = cand_mask_off.data(); pools.cand_cap = (uint32_t)cand_cap; pools.cand_cursor = &cur[1];
     pools.mask_pool = mask_pool.data(); pools.mask_cap = (uint32_t)mask_pool.size(); pools.mask_cursor = &cur[2];
+    std::vector<int32_t> trace_pool;
+    std::vector<uint32_t> trace_off;
+    uint32_t trace_cur = 0;
+    pools.trace_pool = nullptr; pools.trace_cap = 0; pools.trace_cursor = &trace_cur; pools.key_trace_off = nullptr;
+    if (opts.keep_trace && n_tasks == 1) {
+        trace_pool.resize(S * 96 + 4096);
+        trace_off.assign(std::max<size_t>(S, 1), FE_NO_TRACE);
+        pools.trace_pool = trace_pool.data(); pools.trace_cap = (uint32_t)trace_pool.size(); pools.key_trace_off = trace_off.data();
+    }
     FeParse po{opts.num_editdist, opts.error_correction};
     for (size_t k = 0; k < in.n_keys; ++k) {
         const FeKey &K = in.keys[k];
@@ -240,6 +292,11 @@ int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, 
         B->pair_off.push_back((int32_t)B->pair_ref.size());
     }
     B->n_reads = (int32_t)n_reads;
+    if (pools.trace_pool) {
+        std::vector<std::string> lines;
+        hgx_front_trace_lines(L, in.rec_info, in.n_rec, state.data(), trace_off.data(), trace_pool.data(), lines);
+        for (auto &l : lines) B->trace.push_back(TraceRec{std::move(l)});
+    }
     *out = B;
     return HGX_OK;
 }
@@ -252,18 +309,27 @@ int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, si
     *out = nullptr;
     *declined = 0;
     if (raw_bytes >= (1ull << 32) - 64 || n >= (1ull << 30)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+    // As on the device, a record that cannot be taken apart does not stop the stage: it is made inert (FE_R_FAILED), the first
+    // decline code is kept, and the call declines after the grouping -- so that the CPU suite walks the path the kernels walk.
+    int first_decline = 0;
     std::vector<FeRec> recs(n);
     for (size_t i = 0; i < n; ++i) {
         const int r = binary ? fe_parse_bam_record(raw, lines[i].off, lines[i].len, o.simulation != 0, lines[i].task, recs[i])
                              : fe_parse_text_record(raw, raw_bytes, lines[i].off, lines[i].len, o.simulation != 0, lines[i].task, recs[i]);
-        if (r < 0) { *declined = -r; return HGX_OK; }
+        if (r < 0) {
+            if (!first_decline) first_decline = -r;
+            recs[i] = FeRec{};
+            recs[i].bits = FE_R_FAILED;
+            recs[i].flag = 4;
+            recs[i].task = (uint16_t)lines[i].task;
+        }
     }
     std::vector<uint8_t> head(n, 0), kept(n, 0), pm(n, 0);
     for (size_t i = 0; i < n; ++i) head[i] = i == 0 || !fe_same_read_id(recs[i - 1], recs[i], raw);
     const FeFilter flt{o.num_editdist, o.allow_discordant, o.base_locus};
     for (size_t i = 0; i < n; ++i) {
-        const int k = fe_rec_kept(recs.data(), head.data(), (uint32_t)i, flt);
-        if (k < 0) { *declined = -k; return HGX_OK; }
+        int k = fe_rec_kept(recs.data(), head.data(), (uint32_t)i, flt);
+        if (k < 0) { if (!first_decline) first_decline = -k; k = 0; }
         kept[i] = (uint8_t)k;
         pm[i] = fe_rec_in_pileup(recs[i], flt) ? 1 : 0;
     }
@@ -280,12 +346,13 @@ int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, si
             rep.push_back((uint32_t)i); n_pile.push_back(0); any_kept.push_back(0);
         } else {
             s = it->second;
-            if (!fe_rec_same_key(recs[rep[s]], recs[i], raw)) { *declined = HGX_FE_DECLINE_COLLISION; return HGX_OK; }
+            if (!fe_rec_same_key(recs[rep[s]], recs[i], raw) && !first_decline) first_decline = HGX_FE_DECLINE_COLLISION;
         }
         slot_of[i] = s;
         n_pile[s] += pm[i];
         any_kept[s] |= kept[i];
     }
+    if (first_decline) { *declined = first_decline; return HGX_OK; }
     hgx_front_input in;
     in.mem = hgx_front_alloc{[](size_t b) { return hgx_host_alloc(b); }, [](void *p) { hgx_host_free(p); }};
     in.text = const_cast<char *>(raw);
@@ -378,7 +445,7 @@ extern "C" int hgx_lab_many_emulated(hgx_batch **out, const hgx_locus *loc, cons
     HARGCHK(out && loc && opts && declined && n_tasks >= 1 && (paths || (sams && sam_bytes)));
     *out = nullptr;
     *declined = 0;
-    if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange || opts->pileup_exchange) { *declined = HGX_FE_DECLINE_OPTS; return HGX_OK; }
+    if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange || opts->pileup_exchange) { *declined = HGX_FE_DECLINE_OPTS; return HGX_OK; }   // (traces: one task per call)
     hgx_many_streams ms;
     int rc = hgx_many_read(ms, paths, regions, sams, sam_bytes, n_tasks, opts->n_threads, nullptr);
     if (rc) return rc;

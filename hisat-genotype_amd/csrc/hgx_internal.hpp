@@ -234,6 +234,11 @@ struct hgx_front_tables {
     std::string why;
 };
 int hgx_front_tables_build(hgx_locus &L, hgx_front_tables &T);
+// keep_trace on the device route: the trace records the decode wrote (FePools::trace_pool) -> one line per kept record, in stream
+// order, spelled as hgx_sam.cpp spells its own ("cmp_list2 \t cmp_left \t cmp_right \t left alts \t right alts"); novel
+// variants are numbered nv<k> in the order the kept records meet them (typing_core.py:404-431)
+void hgx_front_trace_lines(const hgx_locus &L, const uint32_t *rec_info, size_t n_rec, const uint8_t *state, const uint32_t *trace_off,
+                           const int32_t *pool, std::vector<std::string> &out);
 FeLocus hgx_front_view(const hgx_locus &L, const hgx_front_tables &T);       // pointers into L and T (host side)
 
 // What the host stages (split, filters, key grouping) hand to the device stages: the distinct keys that count into the pileup
@@ -260,7 +265,7 @@ struct hgx_front_input {
     ~hgx_front_input() { if (mem.release) { mem.release(keys); if (!text_borrowed) mem.release(text); mem.release(rec_info); } }
 };
 // > 0: the device front end declines this input (code = an FE_E_* value negated, or one of the HGX_FE_DECLINE_* below)
-#define HGX_FE_DECLINE_OPTS 1          // keep_trace / choose_pairs / inter-distance exchange: host only
+#define HGX_FE_DECLINE_OPTS 1          // choose_pairs / inter-distance exchange (and keep_trace in a many-task pass): host only
 #define HGX_FE_DECLINE_RECORD 2        // a record the reference would raise on
 #define HGX_FE_DECLINE_LOCUS 3         // tables the device path does not take
 #define HGX_FE_DECLINE_SIZE 4          // more records / keys / text than its 32-bit offsets hold

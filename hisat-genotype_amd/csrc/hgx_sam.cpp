@@ -1814,7 +1814,7 @@ int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *Lc, const ch
         if (hook && hook->records && hook->mem.alloc) {
             pinned.reset(new hgx_big_alloc_scope(hook->mem, 4u << 20));
             al.on_raw = hook->on_raw;
-            al.defer_walk = hook->defer_walk && !(opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange);
+            al.defer_walk = hook->defer_walk && !(opts->codis_choose_pairs || opts->interdist_exchange);
             al.defer_min_bytes = hook->defer_min_bytes;
             if (al.defer_walk) { al.inflate_dev = hook->inflate_dev; al.comp_early = hook->comp_early; }
         }
@@ -1937,7 +1937,7 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
     if (hook && hook->records && (raw || (def && def->on_device))) {
         // the record route of the device front end: fields, filters and key grouping as kernels too -- nothing below runs
         hook->declined_records = 0;
-        if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange) hook->declined_records = HGX_FE_DECLINE_OPTS;
+        if (opts->codis_choose_pairs || opts->interdist_exchange) hook->declined_records = HGX_FE_DECLINE_OPTS;
         else {
             try {
                 const int rc = hook->records(*const_cast<hgx_locus *>(Lc), raw, raw_bytes, lines, n, binary, *opts, &hook->declined_records, def);
@@ -2046,7 +2046,7 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
             // The device front end (hgx_front.hip; the lab build's emulation): everything from here on -- pileup, decode of the distinct
             // keys, piece table, pair protocol -- as kernels over the keys' text.  It may decline; the host stages below then run.
             hook->declined = 0;
-            if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange) hook->declined = HGX_FE_DECLINE_OPTS;
+            if (opts->codis_choose_pairs || opts->interdist_exchange) hook->declined = HGX_FE_DECLINE_OPTS;
             else {
                 hgx_front_input in;
                 in.mem = hook->mem;

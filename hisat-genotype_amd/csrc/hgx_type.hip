@@ -197,6 +197,7 @@ extern "C" int hgx_dbatch_create(hgx_dbatch **out, const hgx_batch *b, void *str
     d->n_mask_u32 = (int64_t)b->masks.size();
     for (const auto &p : b->pieces) d->sum_piece_words += p.n_words;
     for (uint32_t r : b->pair_ref) d->n_gene_refs += r >> 31;
+    for (const auto &t : b->trace) d->trace.push_back(t.text);
     auto up = [&](void **dst, const void *src, size_t bytes) -> int {
         *dst = hgx_pool_alloc(std::max<size_t>(bytes, 16));
         if (!*dst) { hgx_set_error("device allocation of %zu bytes failed", bytes); return HGX_ENOMEM; }

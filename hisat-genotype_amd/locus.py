@@ -311,27 +311,27 @@ class PackedLocus:
         return Batch(h)
 
     def parse_sam_dev(self, sam_text, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False, base_locus=0,
-                      n_threads=0, stream=None):
+                      n_threads=0, stream=None, keep_trace=False):
         """SAM text -> piece batch in HBM through the DEVICE front end (hgx_parse_sam_dev): the host tokenises, filters and groups
         the records by decode key; pileup, decode, piece table and pair protocol run as kernels.  Returns an engine.DeviceBatch
         (engine.front_last() tells whether the kernels took the input or declined it to the host stages)."""
         from . import engine
         data = sam_text if isinstance(sam_text, (bytes, bytearray)) else sam_text.encode()
-        o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus, 0,
+        o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus, int(keep_trace),
                            int(self.base_fname == "codis" and self.gene == "D18S51"), int(n_threads))
         h = C.c_void_p()
         capi.check(capi.lib().hgx_parse_sam_dev(C.byref(h), self.h, data, C.c_size_t(len(data)), C.byref(o), stream))
         return engine.DeviceBatch.from_handle(h)
 
     def parse_alignment_file_dev(self, path, regions=None, num_editdist=2, error_correction=True, allow_discordant=False,
-                                 simulation=False, base_locus=0, n_threads=0, stream=None):
+                                 simulation=False, base_locus=0, n_threads=0, stream=None, keep_trace=False):
         """parse_alignment_file through the device front end (hgx_parse_alignment_file_dev) -> engine.DeviceBatch."""
         from . import engine
         if regions is not None and not isinstance(regions, (str, bytes)):
             regions = "\n".join(regions)
         if isinstance(regions, str):
             regions = regions.encode()
-        o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus, 0,
+        o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus, int(keep_trace),
                            int(self.base_fname == "codis" and self.gene == "D18S51"), int(n_threads))
         h = C.c_void_p()
         capi.check(capi.lib().hgx_parse_alignment_file_dev(C.byref(h), self.h, path.encode(), regions or None, C.byref(o), stream))

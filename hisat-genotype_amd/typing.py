@@ -122,10 +122,11 @@ def _em_mode(em_fast):
 
 def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discordant=False,
                remove_low_abundance_alleles=True, simulation=False, base_locus=0, keep_classes=False, stream=None,
-               alignment_file=None, regions=None, gate=None, per_pair_exon=False):
+               alignment_file=None, regions=None, gate=None, per_pair_exon=False, em_fast=False):
     """Per-locus typing: the reference's loop body with the O(alleles) work on the GPU.  Input: name-grouped SAM text
     (`sam_text`), or `alignment_file` (SAM / BAM; `regions` = samtools region strings, see read_alignment_text) read inside
-    libhgx.  `gate` (engine.Gate): shared by the samples in flight on one GPU, see _type_batch."""
+    libhgx.  `gate` (engine.Gate): shared by the samples in flight on one GPU, see _type_batch.  `em_fast`: see _em_mode
+    (False = the library's default for one task; -1 = the reference's order of floating-point operations at every size)."""
     res = LocusResult()
     # the front end on the device (hgx_parse_*_dev: record fields, filters, key grouping, pileup, decode, piece table and pair protocol
     # as kernels; small or unusual inputs are finished by the host stages inside the same call): the batch is born in HBM
@@ -140,7 +141,8 @@ def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discor
         res.n_pieces, res.n_refs = dbatch.n_pieces, dbatch.n_refs
         if dbatch.n_reads <= 0:                                 # core:1589-1590
             return res
-        return _type_batch(pl, None, res, remove_low_abundance_alleles, keep_classes, stream, dbatch=dbatch, gate=gate, per_pair_exon=per_pair_exon)
+        return _type_batch(pl, None, res, remove_low_abundance_alleles, keep_classes, stream, dbatch=dbatch, gate=gate, per_pair_exon=per_pair_exon,
+                           em_fast=em_fast)
     finally:
         dbatch.close()
 

@@ -79,12 +79,19 @@ class Oracle:
         for i, c in enumerate(classes):
             off[i + 1] = off[i] + len(c)
         flat = np.ascontiguousarray([a for c in classes for a in c] or [0], dtype=np.int32)
+        return self.single_abundance_flat(n_alleles, off, flat, counts, remove_low, lengths)
+
+    def single_abundance_flat(self, n_alleles, off, flat, counts, remove_low, lengths=None):
+        """The same with the classes as (offsets [C + 1], alleles) arrays."""
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        flat = np.ascontiguousarray(flat if len(flat) else [0], dtype=np.int32)
+        n_classes = len(off) - 1
         cnt = np.ascontiguousarray(counts, dtype=np.int64)
         ln = None if lengths is None else np.ascontiguousarray(lengths, dtype=np.int32)
         oa = np.zeros(max(n_alleles, 1), dtype=np.int32)
         op = np.zeros(max(n_alleles, 1), dtype=np.float64)
         it = C.c_int32(0)
-        k = self.lib.orc_single_abundance(C.c_int32(n_alleles), C.c_int32(len(classes)), _p(off), _p(flat), _p(cnt),
+        k = self.lib.orc_single_abundance(C.c_int32(n_alleles), C.c_int32(n_classes), _p(off), _p(flat), _p(cnt),
                                           C.c_int32(1 if remove_low else 0), _p(ln) if ln is not None else None,
                                           _p(oa), _p(op), C.byref(it))
         if k == -4:

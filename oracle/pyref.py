@@ -87,6 +87,13 @@ def rep_alleles(Links, exon_vars, in_alleles=None):
 
 def pileup(records, ref_len, allow_discordant):
     """records: iterable of (flag, pos0, cigar_str, seq).  Returns (counts[L] dicts, nt_set[L] lists)."""
+    counts = pileup_counts(records, ref_len, allow_discordant)
+    return counts, nt_sets_from_counts(counts)
+
+
+def pileup_counts(records, ref_len, allow_discordant):
+    """The counting half of get_mpileup (common:1059-1122).  Counts are sums over records, so the tables of the shards of a
+    stream add up position by position (tests/oracle_util.py runs the oracle over a big sample shard by shard on the host cores)."""
     counts = [dict() for _ in range(ref_len)]
     for flag, pos, cigar_str, seq in records:
         if flag & 0x4:
@@ -107,6 +114,11 @@ def pileup(records, ref_len, allow_discordant):
                 gp += n
             if op in "MIS":
                 rp += n
+    return counts
+
+
+def nt_sets_from_counts(counts):
+    """The 20 % / >= 7 rule per position (common:1124-1134)."""
     nt_sets = []
     for d in counts:
         tot = sum(d.values())
@@ -116,7 +128,7 @@ def pileup(records, ref_len, allow_discordant):
                 if nt in "ACGT" and (c >= tot * 0.2 or c >= 7):
                     s.append(nt)
         nt_sets.append(s)
-    return counts, nt_sets
+    return nt_sets
 
 
 class Alternatives:
@@ -657,6 +669,11 @@ class RefLocus:
         self.novel = 0
         self.trace = None          # optional list collecting per-record intermediates
         self.score = True          # False: front-end only (collect the pairs' haplotypes, skip add_count/EM)
+        # Optional: {} = remember the outcome of decode + cmp_list2 + ambiguous_diffs per distinct (pos, CIGAR, SEQ, Zs, MD).  The
+        # outcome is a function of exactly those and of the pileup (novel variants get the id of their first creation either way),
+        # and 70 % of a deep sample's records repeat an earlier key: a 1 M-read oracle run in minutes instead of tens of minutes.
+        # Off by default; tests/test_pyref_golden.py checks that it changes nothing.
+        self.memo = None
 
     # -- novel variants (core:404-431) ------------------------------------------------------
     def _add_novel(self, vtype, pos, data):
@@ -946,15 +963,24 @@ class RefLocus:
         return key
 
     # -- the streaming loop -------------------------------------------------------------------------
-    def run(self, sam_text, base_locus=0):
+    def pileup_records(self, sam_text, base_locus=0):
+        """(flag, pos0, cigar, seq) of every record: what pass 1 feeds the pileup."""
+        recs = []
+        for l in sam_text.split("\n"):
+            if l and not l.startswith("@"):
+                c = l.split()
+                recs.append((int(c[1]), int(c[3]) - (base_locus + 1), c[5], c[9]))
+        return recs
+
+    def run(self, sam_text, base_locus=0, pileup_tables=None):
+        """`pileup_tables` = (counts, nt_sets) of the WHOLE stream when `sam_text` is one shard of it (cut at a read-id boundary)."""
         o = self.opts
         lines = [l for l in sam_text.split("\n") if l and not l.startswith("@")]
         # pass 1: pileup over all records (core:445-449)
-        recs = []
-        for l in lines:
-            c = l.split()
-            recs.append((int(c[1]), int(c[3]) - (base_locus + 1), c[5], c[9]))
-        counts, nt_sets = pileup(recs, len(self.ref_seq), o["allow_discordant"])
+        if pileup_tables is not None:
+            counts, nt_sets = pileup_tables
+        else:
+            counts, nt_sets = pileup(self.pileup_records(sam_text, base_locus), len(self.ref_seq), o["allow_discordant"])
         self.pileup_counts, self.nt_sets = counts, nt_sets
         interdist = pair_interdist(lines, o["simulation"]) if self.base == "codis" else None   # core:451-456
 
@@ -1030,7 +1056,16 @@ class RefLocus:
                 if read_id in seen_u:
                     continue
                 seen_u.add(read_id)
-            dec = self.decode(pos, cigar_str, read_seq, Zs, MD, counts, nt_sets)
+            mkey = hit = None
+            if self.memo is not None:
+                mkey = (pos, cigar_str, read_seq, Zs, MD)
+                hit = self.memo.get(mkey)
+            if hit is not None:
+                dec = hit[0]
+            else:
+                dec = self.decode(pos, cigar_str, read_seq, Zs, MD, counts, nt_sets)
+                if dec is None and mkey is not None:
+                    self.memo[mkey] = (None,)
             if dec is None:
                 continue
             cmp_list, right_pos = dec
@@ -1049,24 +1084,29 @@ class RefLocus:
                     if a in self.rep_set:
                         per_exon[a] = 0
                     per_gene[a] = 0
-            # cmp_list2 (core:1351-1368)
-            c2 = []
-            for c in cmp_list:
-                c = list(c)
-                if c[0] == "match":
-                    if c2 and c2[-1][0] == "match":
-                        c2[-1][2] += c[2]
+            if hit is not None:
+                c2, (cl, cr, la, ra) = hit[1], hit[2]
+            else:
+                # cmp_list2 (core:1351-1368)
+                c2 = []
+                for c in cmp_list:
+                    c = list(c)
+                    if c[0] == "match":
+                        if c2 and c2[-1][0] == "match":
+                            c2[-1][2] += c[2]
+                        else:
+                            c2.append(c)
+                    elif c[0] == "mismatch" and (c[3] == "unknown" or c[3].startswith("nv")):
+                        if c2 and c2[-1][0] == "match":
+                            c2[-1][2] += 1
+                        else:
+                            c2.append(["match", c[1], 1])
                     else:
                         c2.append(c)
-                elif c[0] == "mismatch" and (c[3] == "unknown" or c[3].startswith("nv")):
-                    if c2 and c2[-1][0] == "match":
-                        c2[-1][2] += 1
-                    else:
-                        c2.append(["match", c[1], 1])
-                else:
-                    c2.append(c)
-            cl, cr, la, ra = ambiguous_diffs(self.ref_seq, self.Vars, self.alts.left, self.alts.right,
-                                             self.list_l, self.list_r, c2)
+                cl, cr, la, ra = ambiguous_diffs(self.ref_seq, self.Vars, self.alts.left, self.alts.right,
+                                                 self.list_l, self.list_r, c2)
+                if mkey is not None:
+                    self.memo[mkey] = (dec, c2, (cl, cr, la, ra))
             if self.trace is not None:
                 self.trace.append({"cmp": [list(x) for x in c2], "iad": [cl, cr, la, ra]})
             mid = [c[3] for c in c2[cl:cr + 1] if c[0] in ("mismatch", "deletion", "insertion")]

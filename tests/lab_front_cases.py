@@ -15,19 +15,20 @@ from hisatgenotype_amd import capi, locus as hl, synth
 capi.use_lab()
 
 
-def emulated(pl, sam, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False, n_threads=0):
+def emulated(pl, sam, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False, n_threads=0, keep_trace=False):
     data = sam if isinstance(sam, (bytes, bytearray)) else sam.encode()
-    o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), 0, 0,
+    o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), 0, int(keep_trace),
                        int(pl.base_fname == "codis" and pl.gene == "D18S51"), int(n_threads))
     h, dec = C.c_void_p(), C.c_int32(0)
     capi.check(capi.lib().hgx_lab_parse_sam_emulated(C.byref(h), pl.h, data, C.c_size_t(len(data)), C.byref(o), C.byref(dec)))
     return hl.Batch(h), dec.value
 
 
-def emulated_records(pl, sam=None, path=None, regions=None, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False):
+def emulated_records(pl, sam=None, path=None, regions=None, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False,
+                     keep_trace=False):
     """The record route: fields, filters and key grouping emulated too (hgx_lab_parse_records_emulated); text or a SAM / BAM file."""
     data = None if sam is None else (sam if isinstance(sam, (bytes, bytearray)) else sam.encode())
-    o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), 0, 0,
+    o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), 0, int(keep_trace),
                        int(pl.base_fname == "codis" and pl.gene == "D18S51"), 0)
     h, dec = C.c_void_p(), (C.c_int32 * 2)(0, 0)
     capi.check(capi.lib().hgx_lab_parse_records_emulated(C.byref(h), pl.h, data, C.c_size_t(len(data) if data else 0),
@@ -61,6 +62,91 @@ def test_emulated_device_stages_equal_the_host_front_end_on_every_fixture(name):
     else:
         assert declined == 0, declined
     same_batch(host, emu, len(fx["_locus"].backbone))
+
+
+@pytest.mark.parametrize("name", gu.ALL)
+def test_emulated_kernels_against_the_reference_per_record(name, tmp_path):
+    """DIRECTLY against the reference's recorded intermediates, not through the host front end: the pileup tables the emulated
+    k_fe_pileup / k_fe_nt_set made == get_mpileup's (G5), and -- keep_trace on the device route -- cmp_list2, cmp_left / cmp_right and
+    both alternative sets of every kept record as fe_key computed them == what the reference's loop held (G3:
+    identify_ambigious_diffs typing_common.py:1663-1955 after error_correct typing_core.py:119-243), by both routes and from a BAM."""
+    from hisatgenotype_amd import bamio
+    from trace_util import check_pileup, check_trace
+    fx = gu.load(name)
+    o = fx["options"]
+    loc = fx["_locus"]
+    pl = hl.PackedLocus.from_synth(loc)
+    kw = dict(num_editdist=o["num_editdist"], error_correction=o["error_correction"], allow_discordant=o["allow_discordant"],
+              simulation=o["simulation"], keep_trace=True)
+    p_bam = str(tmp_path / "s.bam")
+    bamio.write_bam_native(p_bam, fx["sam"].encode(), [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
+    emu, dec = emulated(pl, fx["sam"], **kw)
+    emu_r, dec_r = emulated_records(pl, sam=fx["sam"], **kw)
+    emu_b, dec_b = emulated_records(pl, path=p_bam, regions=loc.ref_allele, **kw)
+    if name == "codis_d18s51":                     # choose_pairs stays on the host (whose trace the CPU suite checks)
+        assert dec == 1 and dec_r == (1, 1) and dec_b == (1, 1)
+    else:
+        assert dec == 0 and dec_r == (0, 0) and dec_b == (0, 0)
+    for b in (emu, emu_r, emu_b):
+        check_pileup(fx, b)
+        check_trace(fx, b)
+
+
+def test_two_or_more_unparseable_records_decline_without_touching_their_bytes(tmp_path):
+    """records the kernels cannot take apart are made inert (FE_R_FAILED: zero offsets and lengths) and the call declines
+    after the record stage -- the filters, the key table and the byte-for-byte key compare never follow a stale offset.  Two and
+    more bad records in one input (blank inside a line, CR, a mapped BAM record without CIGAR / SEQ), between good ones; UNMAPPED
+    BAM records without CIGAR and SEQ are routine and do not decline: the filters drop them on their flag."""
+    from hisatgenotype_amd import bamio
+    fx = gu.load("hla_small_pair")
+    loc = fx["_locus"]
+    pl = hl.PackedLocus.from_synth(loc)
+    lines = [l for l in fx["sam"].split("\n") if l]
+    bad = list(lines)
+    for k in (3, 4, 9, 40):
+        f = bad[k].split("\t")
+        f[0] = f[0] + " x" if k != 9 else f[0] + "\r"
+        bad[k] = "\t".join(f)
+    sam_bad = "\n".join(bad) + "\n"
+    try:
+        host = pl.parse_sam(sam_bad, simulation=True)
+    except capi.HgxError:
+        host = None
+    if host is None:
+        with pytest.raises(capi.HgxError):
+            emulated_records(pl, sam=sam_bad, simulation=True)
+    else:
+        emu, dec = emulated_records(pl, sam=sam_bad, simulation=True)
+        assert dec[0] != 0                                           # the record route declined ...
+        same_batch(host, emu, len(loc.backbone))                     # ... and the host stages finished the job
+    # unmapped mates (CIGAR '*', SEQ '*', no tags) among the records, as SAM text and as BAM: taken, and they change nothing; the
+    # same records with the unmapped flag cleared: whatever the host front end does with them (it follows the reference)
+    host = pl.parse_sam(fx["sam"], simulation=True)
+    for flag_or in (0x4, 0):
+        out = list(lines)
+        for k in (2, 3, 20):
+            f = lines[k].split("\t")
+            out.insert(k, "\t".join([f[0], str((int(f[1]) & ~0x4) | flag_or), f[2], f[3], "0", "*", "=", f[7], "0", "*", "*"]))
+        sam2 = "\n".join(out) + "\n"
+        p2 = str(tmp_path / ("m%d.bam" % flag_or))
+        bamio.write_bam(p2, sam2, [(loc.ref_allele, len(loc.backbone))])
+        for kind in ("sam", "bam"):
+            run_host = (lambda: pl.parse_sam(sam2, simulation=True)) if kind == "sam" else \
+                (lambda: pl.parse_alignment_file(p2, regions=[loc.ref_allele], simulation=True))
+            run_emu = (lambda: emulated_records(pl, sam=sam2, simulation=True)) if kind == "sam" else \
+                (lambda: emulated_records(pl, path=p2, regions=loc.ref_allele, simulation=True))
+            try:
+                want = run_host()
+            except capi.HgxError:
+                assert flag_or == 0
+                with pytest.raises(capi.HgxError):
+                    run_emu()
+                continue
+            emu, dec = run_emu()
+            same_batch(want, emu, len(loc.backbone))
+            if flag_or:
+                assert dec == (0, 0), (kind, dec)                    # unmapped records do not decline the record route ...
+                same_batch(host, emu, len(loc.backbone))             # ... and change nothing
 
 
 @pytest.mark.parametrize("name", gu.ALL + gu.LEAN)

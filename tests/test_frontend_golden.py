@@ -17,15 +17,7 @@ def _parse(fx, keep_trace=True):
     return pl, batch
 
 
-def _fmt_record(rec):
-    parts = []
-    for c in rec["cmp"]:
-        s = "%s:%d:%d" % (c[0], c[1], c[2])
-        if c[0] != "match":
-            s += ":" + c[3]
-        parts.append(s)
-    cl, cr, la, ra = rec["iad"]
-    return "%s\t%d\t%d\t%s\t%s" % (",".join(parts), cl, cr, ";".join(sorted(la)), ";".join(sorted(ra)))
+from trace_util import check_pileup, check_trace  # noqa: E402
 
 
 @pytest.mark.parametrize("name", gu.ALL)
@@ -38,16 +30,7 @@ def test_alternatives_and_pileup(name):
         got[d].setdefault(k, set()).add(a)
     assert {k: sorted(v) for k, v in got["L"].items()} == fx["alts"]["left"]
     assert {k: sorted(v) for k, v in got["R"].items()} == fx["alts"]["right"]
-    nt, cnt = batch.pileup(len(fx["_locus"].backbone))
-    exp_sets = fx["mpileup"]["nt_set"]
-    for i in range(len(nt)):
-        s = "".join(b for k, b in enumerate("ACGT") if nt[i] & (1 << k))
-        assert s == exp_sets[i], i
-        exp = fx["mpileup"]["counts"][i]
-        for k, b in enumerate("ACGT"):
-            assert cnt[i, k] == exp.get(b, 0)
-        assert cnt[i, 5] == exp.get("D", 0)
-        assert cnt[i, 4] == sum(v for b, v in exp.items() if b not in "ACGTD")
+    check_pileup(fx, batch)
 
 
 @pytest.mark.parametrize("name", gu.ALL)
@@ -56,10 +39,7 @@ def test_records_pieces_classes(name):
     pl, batch = _parse(fx)
     assert batch.n_reads == len(fx["records"])
     assert batch.n_pairs == len(fx["pairs"])
-    got = batch.trace_text().splitlines()
-    assert len(got) == len(fx["records"])
-    for g, rec in zip(got, fx["records"]):
-        assert g == _fmt_record(rec)
+    check_trace(fx, batch)
     # number of add_count calls per pair and level (core:1250-1270)
     for p, exp in enumerate(fx["pairs"]):
         refs = batch.pair_ref[batch.pair_off[p]:batch.pair_off[p + 1]]

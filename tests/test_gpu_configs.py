@@ -108,6 +108,61 @@ def test_config1_one_million_reads_properties():
     assert res2.gene_prob == res.gene_prob and res2.em == res.em and res2.counts_sorted[:50] == res.counts_sorted[:50]
 
 
+def test_config1_one_million_reads_equals_the_oracle():
+    """configs[1] AT ITS STATED SIZE against the oracle, `==` (VERDICT r4 #1c) -- the workload bench.py times: HLA-A-like, 7 000
+    alleles, 500 000 pairs = 1 M reads.  The oracle chain (oracle/pyref.py front end -> oracle/hgx_oracle.c add_count / add_stat /
+    class dicts / single_abundance / hand-off, every step in the reference's own order) runs shard by shard on the host cores
+    (oracle_util.oracle_type_sharded; tests/test_oracle_sharded.py pins the sharded form to the one-process form).  The product
+    side is ONE hgx_type_* call per variant, through the DEVICE front end (asserted): record fields, filters, pileup, decode,
+    piece table, pair protocol, scoring, dedup, Gene_counts, both EMs, hand-off.
+      integer work   read / pair counts, Gene_counts of all 7 000 alleles and their print order, the exon-level and the gene-level
+                     class tables (bit rows, pair counts, dict order)                                               ==
+      EM, default    (table-lookup mat-vecs for the 16 098-class EM #1) iteration counts ==, allele order ==, abundances <= 1e-9
+      EM, em_fast=-1 (the reference's order at every size) every abundance the same IEEE double                     =="""
+    from hisatgenotype_amd import engine
+    loc = synth.make_hla_like_locus(n_alleles=7000, n_vars=2500, seed=101)
+    sample = synth.pick_sample(loc, 101)
+    sam = synth.simulate_sam_fast(loc, sample, 500000, err_rate=0.002, seed=100)
+    names = [n for n in loc.allele_names if "BACKBONE" not in n]
+    import threading
+    box = {}
+
+    def oracle():
+        try:
+            box["exp"] = ou.oracle_type_sharded(loc, sam)
+        except BaseException as e:                                     # re-raised on the test's thread
+            box["err"] = e
+    th = threading.Thread(target=oracle)
+    th.start()
+    try:
+        pl = hl.PackedLocus.from_synth(loc)
+        res = hgx.type_locus(pl, sam, keep_classes=True)
+        assert engine.front_last() == (2, 0), engine.front_last()          # the kernels took the records themselves
+        res_x = hgx.type_locus(pl, sam, em_fast=-1)
+        assert engine.front_last() == (2, 0)
+    finally:
+        th.join()
+    if "err" in box:
+        raise box["err"]
+    exp = box["exp"]
+    assert res.num_pairs >= 499000 and res.num_reads >= 990000
+    _check_against_oracle(res, exp, names)
+    for got, want in ((res.gene_classes, exp["gene_classes"]), (res.exon_classes, exp["exon_classes"])):
+        bits, cnt = got
+        ob, oc = want
+        w = ob.shape[1]
+        assert len(cnt) == len(oc) and np.array_equal(cnt, oc)
+        assert np.array_equal(bits[:, :w], ob) and not bits[:, w:].any()
+    assert len(exp["exon_classes"][1]) > 4096                          # EM #1 is the large problem
+    assert sorted(a for a, _ in res.gene_prob[:2]) == sorted(sample) == sorted(a for a, _ in exp["gene_prob"][:2])
+    # the reference's order of operations at every size: the same doubles
+    assert [(e["n_classes"], e["n_iter"]) for e in res_x.em] == [(c, it) for c, it, _ in exp["em"]]
+    for got, (_, _, r) in zip(res_x.em, exp["em"]):
+        assert [(a, p) for a, p in got["result"]] == [(a, p) for a, p in r]
+    assert [(a, p) for a, p in res_x.gene_prob] == [(a, p) for a, p in exp["gene_prob"]]
+    assert res_x.counts_sorted == res.counts_sorted
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # configs[3]
 # ---------------------------------------------------------------------------------------------------------------------

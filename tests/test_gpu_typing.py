@@ -27,14 +27,51 @@ def _check_em(got, exp_result, exp_iter, exact=False):
             assert p == float(q), (a, repr(p), q)
 
 
+# The front-end routes a result is asked through: None = the library's choice (these fixtures are below the 20 000-record
+# gate: the host stages), "device" = the RECORD route (fields, filters, key grouping, pileup, decode, piece table, pair protocol all as
+# kernels: k_fe_*), "device,keys" = the KEY route (the host tokenises and groups, the kernels take the distinct keys).  The reference's
+# recorded class dicts, EM doubles and report text are compared with what came out of the route asked for -- `engine.front_last()` is
+# asserted -- not with the host front end's batch.
+FRONTS = [None, "device", "device,keys"]
+FRONT_IDS = ["default", "record_route", "key_route"]
+
+
+class _front:
+    """Force a front-end route for the calls inside the block and check afterwards that it was the one that ran."""
+    def __init__(self, front, fixture_name=None):
+        self.front, self.name = front, fixture_name
+        self.sw = engine.test_switches(front=front) if front else None
+
+    def __enter__(self):
+        if self.sw:
+            self.sw.__enter__()
+        return self
+
+    def check(self):
+        if not self.front:
+            return
+        if self.name == "codis_d18s51":                      # choose_pairs (typing_core.py:1547-1552) stays on the host by design
+            assert engine.front_last() == (0, 1), engine.front_last()
+        else:
+            assert engine.front_last() == (2 if self.front == "device" else 1, 0), engine.front_last()
+
+    def __exit__(self, *exc):
+        if self.sw:
+            self.sw.__exit__(*exc)
+        return False
+
+
+@pytest.mark.parametrize("front", FRONTS, ids=FRONT_IDS)
 @pytest.mark.parametrize("name", gu.ALL)
-def test_type_locus_matches_reference(name):
+def test_type_locus_matches_reference(name, front):
     fx = gu.load(name)
     o = fx["options"]
     pl = hl.PackedLocus.from_synth(fx["_locus"])
-    res = hgx.type_locus(pl, fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
-                         allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
-                         simulation=o["simulation"])
+    with _front(front, name) as f:
+        res = hgx.type_locus(pl, fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
+                             allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
+                             simulation=o["simulation"])
+        f.check()
     assert res.num_reads == len(fx["records"]) and res.num_pairs == len(fx["pairs"])
     assert len(res.em) == len(fx["em"])
     for k, (got, exp) in enumerate(zip(res.em, fx["em"])):
@@ -47,7 +84,8 @@ def test_type_locus_matches_reference(name):
     assert keep(lines) == keep(fx["report"].split("\n"))
 
 
-def test_config0_ten_thousand_reads_matches_reference():
+@pytest.mark.parametrize("front", FRONTS, ids=FRONT_IDS)
+def test_config0_ten_thousand_reads_matches_reference(front):
     """BASELINE configs[0]: HLA-A-like, 7 000 alleles, 10 k reads -- the run the reference itself needed 109 s for
     (fixture `hla_7000_10k`, recorded from the real reference with its wall time).  Same classes and counts going into both
     EM calls, same iteration counts, allele order and abundances, and the same report: with output_allele_counts the
@@ -55,9 +93,11 @@ def test_config0_ten_thousand_reads_matches_reference():
     fx = gu.load("hla_7000_10k")
     o = fx["options"]
     pl = hl.PackedLocus.from_synth(fx["_locus"])
-    res = hgx.type_locus(pl, fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
-                         allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
-                         simulation=o["simulation"], keep_classes=True)
+    with _front(front) as f:
+        res = hgx.type_locus(pl, fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
+                             allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
+                             simulation=o["simulation"], keep_classes=True)
+        f.check()
     assert len(res.em) == len(fx["em"]) == 2
     A = pl.n_alleles
     for k, (got, exp) in enumerate(zip(res.em, fx["em"])):
@@ -75,16 +115,19 @@ def test_config0_ten_thousand_reads_matches_reference():
     assert len([l for l in lines if "(count:" in l]) > 1000
 
 
-def test_codis_ten_thousand_reads_matches_reference():
+@pytest.mark.parametrize("front", FRONTS, ids=FRONT_IDS)
+def test_codis_ten_thousand_reads_matches_reference(front):
     """BASELINE configs[4]'s shape against the REAL reference (fixture `codis_10k`: one CODIS STR ladder, 10 k reads, recorded
     with the reference's wall time): same class dict into the EM, bit-identical abundances (13 alleles: one wavefront in the
     reference's order), same iteration count and the same report lines."""
     fx = gu.load("codis_10k")
     o = fx["options"]
     pl = hl.PackedLocus.from_synth(fx["_locus"])
-    res = hgx.type_locus(pl, fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
-                         allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
-                         simulation=o["simulation"], keep_classes=True)
+    with _front(front) as f:
+        res = hgx.type_locus(pl, fx["sam"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
+                             allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"],
+                             simulation=o["simulation"], keep_classes=True)
+        f.check()
     assert len(res.em) == len(fx["em"])
     for got, exp in zip(res.em, fx["em"]):
         assert got["n_classes"] == len(exp["cmpt"])
@@ -559,8 +602,9 @@ def test_index_broadcast_writes_into_index_memory(tmp_path):
     assert "broadcast ok" in out.stdout
 
 
+@pytest.mark.parametrize("front", FRONTS[:2], ids=FRONT_IDS[:2])
 @pytest.mark.parametrize("name", gu.ALL)
-def test_type_file_sam_bam_sorted_bam_with_regions(name, tmp_path):
+def test_type_file_sam_bam_sorted_bam_with_regions(name, front, tmp_path):
     """hgx_type_file -- the entry bench.py's file -> result leg times -- on every fixture, from (a) the SAM text as the aligner
     writes it, (b) a BAM of the same records, (c) a coordinate-sorted BAM that also holds reads of ANOTHER reference sequence,
     with the locus' backbone as the region (what the reference's `samtools view F ref_allele | sort -k1,1 -s` sees): the
@@ -592,7 +636,11 @@ def test_type_file_sam_bam_sorted_bam_with_regions(name, tmp_path):
     want = keep(fx["report"].split("\n"))
     ref = hgx.type_locus(pl, fx["sam"], **kw)
     for path in (sam, bam, sbam):
-        res = hgx.type_file(pl, str(path), **kw)
+        # "device": the file through the record route -- for the BAMs also the device's BGZF inflate, record walk, region filter and
+        # name sort (k_bgzf_inflate, k_bam_*) -- and the REFERENCE's report text out of it
+        with _front(front, name) as f:
+            res = hgx.type_file(pl, str(path), **kw)
+            f.check()
         assert res.num_reads == ref.num_reads and res.num_pairs == ref.num_pairs, path.name
         assert res.gene_prob == ref.gene_prob and res.em == ref.em and res.counts_sorted == ref.counts_sorted, path.name
         got, _ = hgx.report_lines(res, o["simulation"], o["sample"] if o["simulation"] else (), True)

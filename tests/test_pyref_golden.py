@@ -10,20 +10,23 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import pyref  # noqa: E402
 
 
-def _run(fx):
+def _run(fx, memo=False):
     o = fx["options"]
     rl = pyref.RefLocus(fx["_locus"], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
                         allow_discordant=o["allow_discordant"], remove_low=o["remove_low"],
                         simulation=o["simulation"])
     rl.trace = []
+    if memo:
+        rl.memo = {}               # the per-key cache the full-size oracle runs use: must change nothing
     res = rl.run(fx["sam"])
     return rl, res
 
 
+@pytest.mark.parametrize("memo", [False, True], ids=["plain", "memo"])
 @pytest.mark.parametrize("name", gu.SMALL)
-def test_pyref_matches_reference(name):
+def test_pyref_matches_reference(name, memo):
     fx = gu.load(name)
-    rl, res = _run(fx)
+    rl, res = _run(fx, memo)
     # G4 alternatives
     assert {k: sorted(v) for k, v in rl.alts.left.items()} == fx["alts"]["left"]
     assert {k: sorted(v) for k, v in rl.alts.right.items()} == fx["alts"]["right"]
