@@ -564,6 +564,7 @@ def run_class1(args, rank, local_rank, world, dist):
                     comms[i] = hdist.TorchComm(g)
     mine = [i for i in sorted(groups) if rank in groups[i]]
     work = []
+    shard_routes, shard_bam = {}, {}
     want_files = world == 1 and dist is None and not args.no_e2e
     file_of, file_dir = {}, None
     if want_files:
@@ -581,12 +582,23 @@ def run_class1(args, rank, local_rank, world, dist):
             bamio.write_bam_native(fp, sam.encode(), [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
             file_of[i] = fp
         if i in comms:
+            # this rank's consecutive share of the locus' name-grouped stream through the DEVICE front end; the pileup counters are
+            # summed over the rank group where k_fe_pileup left them, in HBM, over RCCL (dist.parse_shard)
             shard_text = hdist.split_name_grouped(sam, len(groups[i]))[groups[i].index(rank)]
-            batch = pl.parse_sam(shard_text, pileup_exchange=comms[i].allreduce_sum)
+            batch, db = hdist.parse_shard(pl, shard_text, comms[i])
+            shard_routes[i] = engine.front_last()
+            if not args.no_e2e:                                # ... and as a BAM file of its own, for the per-rank file -> result leg
+                import tempfile
+                from hisatgenotype_amd import bamio
+                d_ = tempfile.mkdtemp(prefix="hgx_class1_r%d_" % rank, dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+                shard_bam[i] = os.path.join(d_, "%s.shard%d.bam" % (loc.gene, groups[i].index(rank)))
+                bamio.write_bam_native(shard_bam[i], shard_text, [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
+            del shard_text
         else:
             batch = pl.parse_sam(sam)
+            db = engine.DeviceBatch(batch)
         del sam
-        work.append((i, pl, batch, engine.DeviceBatch(batch), comms.get(i), sample))
+        work.append((i, pl, batch, db, comms.get(i), sample))
     t_setup = time.perf_counter() - t_setup
 
     # Several whole loci on this rank (always so on one GPU): typed side by side, one host thread and stream set per locus -- the
@@ -675,6 +687,35 @@ def run_class1(args, rank, local_rank, world, dist):
         allc = [None] * world
         dist.all_gather_object(allc, calls)
         calls = {g: v for part in allc for g, v in part.items()}
+    e2e_shards = None
+    if shard_bam:
+        # sharded loci, files -> result: every rank of a group types its own BAM shard through dist.type_locus_sharded (device
+        # inflate / walk / sort, device front end, pileup all-reduce in HBM, class-table all-gather, EMs) -- all ranks at once
+        import shutil
+        import torch
+        try:
+            n_calls = 3
+            for i, pl, batch, db, comm, sample in work:
+                if comm is not None:
+                    hdist.type_locus_sharded(pl, None, comm, alignment_file=shard_bam[i], regions=[pl.ref_allele])
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            ok = True
+            for _ in range(n_calls):
+                for i, pl, batch, db, comm, sample in work:
+                    if comm is not None:
+                        r_f = hdist.type_locus_sharded(pl, None, comm, alignment_file=shard_bam[i], regions=[pl.ref_allele])
+                        ok = ok and engine.front_last()[0] == 2 and r_f.gene_prob == last[i].gene_prob
+            dt = time.perf_counter() - t0
+            tt = torch.tensor([dt, 0.0 if ok else 1.0], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            e2e_shards = {"input": "every rank of a sharded locus its own coordinate-sorted BAM shard, %d calls, all ranks at once" % n_calls,
+                          "ms_per_call": round(float(tt[0].item()) / n_calls * 1e3, 2),
+                          "device_front_end_on_every_rank_and_results_identical_to_the_resident_path": bool(tt[1].item() == 0.0)}
+        finally:
+            for f in shard_bam.values():
+                shutil.rmtree(os.path.dirname(f), ignore_errors=True)
     e2e = None
     if want_files:
         # file -> result for the three loci: coordinate-sorted BAM files (as the reference's pipeline stores alignments) through
@@ -729,8 +770,11 @@ def run_class1(args, rank, local_rank, world, dist):
                        "rank_groups": {loci[i].gene: groups[i] for i in sorted(groups)},
                        "calls": {g: {"top2": t, "true": s, "correct": sorted(t) == sorted(s)} for g, (t, s) in calls.items()},
                        "form": "the rank's loci side by side (a host thread and stream set per locus)" if side_by_side else "locus after locus",
-                       "parallelism": "loci over rank groups; pairs of a locus over the ranks of its group (pileup all-reduce at parse, "
-                                      "class-table all-gather + merge per step over RCCL); no other data-path collective",
+                       "parallelism": "loci over rank groups; pairs of a locus over the ranks of its group (device front end per shard with the "
+                                      "pileup all-reduce on the counters in HBM at parse, class-table all-gather + merge per step over RCCL); "
+                                      "no other data-path collective",
+                       "front_end_route_of_my_shards": {loci[i].gene: list(r) for i, r in shard_routes.items()},
+                       "e2e_shards": e2e_shards,
                        "setup_s": round(t_setup, 1)},
             "roofline": em_roofline(em_timing, n_timed) if timing else None, "cpu_baseline": cb, "e2e": e2e})
     return None

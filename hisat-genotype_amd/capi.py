@@ -45,10 +45,12 @@ class ParseOpts(C.Structure):
                 ("simulation", C.c_int32), ("base_locus", C.c_int32), ("keep_trace", C.c_int32),
                 ("codis_choose_pairs", C.c_int32), ("n_threads", C.c_int32),
                 ("pileup_exchange", C.c_void_p), ("pileup_ctx", C.c_void_p),
-                ("interdist_exchange", C.c_void_p), ("interdist_ctx", C.c_void_p)]
+                ("interdist_exchange", C.c_void_p), ("interdist_ctx", C.c_void_p),
+                ("pileup_exchange_dev", C.c_void_p), ("pileup_dev_ctx", C.c_void_p)]
 
 
 PILEUP_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint32), C.c_int64)
+PILEUP_EXCHANGE_DEV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 INTERDIST_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64)
 
 

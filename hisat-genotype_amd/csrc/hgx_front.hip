@@ -850,14 +850,14 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
 
     // pileup
     const int n_tasks = std::max(1, di.n_tasks);
-    if (n_tasks > 1 && o.pileup_exchange) { *declined = HGX_FE_DECLINE_OPTS; return HGX_OK; }
+    if (n_tasks > 1 && (o.pileup_exchange || o.pileup_exchange_dev)) { *declined = HGX_FE_DECLINE_OPTS; return HGX_OK; }
     if (n_tasks > 65535) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
     d->n_ref = n_ref;
     const size_t n_cells = (size_t)n_tasks * n_ref * 6;
-    d->d_counts = (uint32_t *)hgx_pool_alloc(std::max<size_t>(n_cells * 4, 16));
+    d->d_counts = (uint32_t *)hgx_pool_alloc(std::max<size_t>((n_cells + 1) * 4, 16));      // (+ 1: the spare element of pileup_exchange_dev)
     d->d_nt_set = (uint8_t *)hgx_pool_alloc(std::max<size_t>((size_t)n_tasks * n_ref, 16));
     if (!d->d_counts || !d->d_nt_set) { hgx_set_error("device allocation of the pileup tables failed"); return HGX_ENOMEM; }
-    HIPCHK(hipMemsetAsync(d->d_counts, 0, n_cells * 4, st));
+    HIPCHK(hipMemsetAsync(d->d_counts, 0, (n_cells + 1) * 4, st));
     if (n_keys && n_ref > 0) {
         const int tile = std::min(n_ref, 6000);                       // 6 counters x 4 bytes x 6000 positions = 144 KB of LDS
         const size_t lds = (size_t)tile * 6 * 4;
@@ -868,7 +868,22 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
         const unsigned nb = n_tasks > 1 ? per_task : std::max(1u, std::min(256u, (n_keys + 63) / 64));
         k_fe_pileup<<<dim3(nb, n_tiles, (unsigned)n_tasks), 1024, lds, st>>>(keys, n_keys, text, n_ref, tile, d->d_counts, ctl);
     }
-    if (o.pileup_exchange && n_ref > 0) {                               // intra-locus read sharding: the sum over all shards (8e)
+    // intra-locus read sharding (8e): this shard's counters -> the sum over all shards.  On the device where the caller gave the
+    // device form (hgx_allreduce_sum_u32 over RCCL on this very buffer: no host bounce); the summed table is kept for the host
+    // stages in case a later stage declines -- a rank communicates once per parse (hgx_pileup_share)
+    hgx_pileup_share *share = o.pileup_exchange == &hgx_pileup_share::trampoline ? (hgx_pileup_share *)o.pileup_ctx : nullptr;
+    if (o.pileup_exchange_dev && n_ref > 0 && !(share && share->have_sum)) {
+        if (o.pileup_exchange_dev(o.pileup_dev_ctx, d->d_counts, (int64_t)n_cells + 1, (void *)st) != 0) {
+            hgx_set_error("pileup exchange between the ranks of a sharded locus failed");
+            return HGX_EINVAL;
+        }
+        if (share) {
+            share->sum.resize(n_cells);
+            HIPCHK(hipMemcpyAsync(share->sum.data(), d->d_counts, n_cells * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            share->have_sum = true;
+        }
+    } else if (o.pileup_exchange && n_ref > 0) {
         std::vector<uint32_t> h((size_t)n_ref * 6);
         HIPCHK(hipMemcpyAsync(h.data(), d->d_counts, h.size() * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
@@ -1354,8 +1369,22 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
 
 // host stages with the device stages hooked in; *out is always a device batch on success
 template <class Parse>
-int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Parse parse) {
+int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, Parse parse) {
     *out = nullptr;
+    // a sharded locus: whichever route finishes the parse, this rank takes part in ONE pileup exchange (hgx_pileup_share)
+    hgx_pileup_share share;
+    hgx_parse_opts opts_own = *opts_in;
+    if (opts_in->pileup_exchange_dev && !opts_in->pileup_exchange) {
+        hgx_set_error("pileup_exchange_dev needs the host form (pileup_exchange) beside it: the device route may decline before its exchange");
+        return HGX_EINVAL;
+    }
+    if (opts_in->pileup_exchange) {
+        share.orig = opts_in->pileup_exchange;
+        share.orig_ctx = opts_in->pileup_ctx;
+        opts_own.pileup_exchange = &hgx_pileup_share::trampoline;
+        opts_own.pileup_ctx = &share;
+    }
+    const hgx_parse_opts *opts = &opts_own;
     hgx_dbatch *made = nullptr;
     hgx_front_hook hook;
     hook.mem = hgx_front_alloc{pinned_alloc, pinned_release};
@@ -1444,7 +1473,7 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Pars
     struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};     // (an upload may still read the reader's buffer)
     hgx_batch *b = nullptr;
     g_last_bytes = 0;
-    const int rc = parse(&b, host_only ? nullptr : &hook);
+    const int rc = parse(&b, host_only ? nullptr : &hook, opts);
     (void)hipStreamSynchronize(st);
     g_last_route = rc ? 0 : route;
     g_last_decline = host_only ? -1 : (route == 2 ? 0 : route == 1 ? 0 : hook.declined ? hook.declined : hook.declined_records);
@@ -1462,14 +1491,15 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts, Pars
 
 extern "C" int hgx_parse_sam_dev(hgx_dbatch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts, void *stream) {
     ARGCHK(out && loc && opts);
-    return parse_dev(out, (hipStream_t)stream, opts, [&](hgx_batch **b, hgx_front_hook *hook) { return hgx_parse_sam_hook(b, loc, sam, n_bytes, opts, hook); });
+    return parse_dev(out, (hipStream_t)stream, opts,
+                     [&](hgx_batch **b, hgx_front_hook *hook, const hgx_parse_opts *o) { return hgx_parse_sam_hook(b, loc, sam, n_bytes, o, hook); });
 }
 
 extern "C" int hgx_parse_alignment_file_dev(hgx_dbatch **out, const hgx_locus *loc, const char *path, const char *regions,
                                             const hgx_parse_opts *opts, void *stream) {
     ARGCHK(out && loc && path && opts);
     return parse_dev(out, (hipStream_t)stream, opts,
-                     [&](hgx_batch **b, hgx_front_hook *hook) { return hgx_parse_alignment_file_hook(b, loc, path, regions, opts, hook); });
+                     [&](hgx_batch **b, hgx_front_hook *hook, const hgx_parse_opts *o) { return hgx_parse_alignment_file_hook(b, loc, path, regions, o, hook); });
 }
 
 // MANY tasks of one locus (the samples of a panel) in ONE pass of the record route: the tasks' files are read side by side on the
@@ -1485,7 +1515,7 @@ int hgx_front_many_dev(hgx_dbatch **out, hgx_front_totals *tot, const hgx_locus 
     g_last_bytes = 0; g_last_route = 0; g_last_device = 0; g_last_decline = 0;
     auto decline = [&](int code) { *declined = code; g_last_decline = code; return (int)HGX_OK; };
     if (hgx_switch_has("front", "host")) { *declined = -1; g_last_decline = -1; return HGX_OK; }
-    if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange || opts->pileup_exchange) return decline(HGX_FE_DECLINE_OPTS);
+    if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange || opts->pileup_exchange || opts->pileup_exchange_dev) return decline(HGX_FE_DECLINE_OPTS);
     if (n_tasks < 1 || n_tasks > 65535) return decline(HGX_FE_DECLINE_SIZE);
     hgx_many_streams ms;
     const hgx_front_alloc mem{pinned_alloc, pinned_release};

@@ -271,6 +271,27 @@ struct hgx_front_input {
 #define HGX_FE_DECLINE_SIZE 4          // more records / keys / text than its 32-bit offsets hold
 #define HGX_FE_DECLINE_COLLISION 5     // two different pieces with one 64-bit content key
 #define HGX_FE_DECLINE_SMALL 6         // too few records for a dozen launches to pay
+// Sharded loci (hgx_parse_opts.pileup_exchange / _dev): every rank must communicate exactly ONCE per parse, whichever route finishes
+// it.  The device front end wraps the caller's host callback in this: once a summed table exists (the device route exchanged and
+// then declined, or the wrapper itself ran the caller's callback) the host stages get that table instead of a second exchange.
+struct hgx_pileup_share {
+    int (*orig)(void *, uint32_t *, int64_t) = nullptr;
+    void *orig_ctx = nullptr;
+    bool have_sum = false;
+    std::vector<uint32_t> sum;                 // [L * 6]
+    static int trampoline(void *self, uint32_t *counts, int64_t n) {
+        hgx_pileup_share *s = (hgx_pileup_share *)self;
+        if (s->have_sum) {
+            if ((size_t)n != s->sum.size()) return 1;
+            std::copy(s->sum.begin(), s->sum.end(), counts);
+            return 0;
+        }
+        if (!s->orig) return 1;
+        const int rc = s->orig(s->orig_ctx, counts, n);
+        if (rc == 0) { s->sum.assign(counts, counts + n); s->have_sum = true; }
+        return rc;
+    }
+};
 // The host stages call `run` after key grouping; it returns HGX_OK with *declined = 0 when the device stages produced the result
 // (which the hook's owner holds: the parse functions then return *out = NULL), or *declined = the reason -- the host stages
 // then finish the job and `declined` says why.

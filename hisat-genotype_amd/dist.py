@@ -167,6 +167,33 @@ class TorchComm:
         arr[...] = t.cpu().numpy().astype(arr.dtype)
         return arr
 
+    def allreduce_u32(self, arr):
+        """In-place sum of a uint32 numpy array over the ranks: the pileup exchange of a sharded parse, host form.  Travels as
+        int32 (two's-complement sums are the uint32 sums bit for bit) -- the SAME collective as allreduce_u32_dev, so that ranks
+        on the host route and ranks on the device route of one parse meet in it."""
+        import torch
+        t = torch.from_numpy(np.ascontiguousarray(arr, np.uint32).view(np.int32).copy()).to(self._dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        arr[...] = t.cpu().numpy().view(np.uint32).reshape(arr.shape)
+        return arr
+
+    def allreduce_u32_dev(self, dptr, n, stream=None):
+        """The device form: `n` uint32 at device pointer `dptr`, summed in place in HBM (nccl = RCCL on an aliasing tensor: no
+        host bounce).  Returns the LAST element of the result (the failure flag of dist.type_locus_sharded)."""
+        import torch
+        if not self.on_gpu:                                 # gloo between processes that do have GPUs: through the host
+            h = np.zeros(n, np.uint32)
+            capi.sync(stream)
+            capi.check(capi.lib().hgx_memcpy_d2h(capi.ptr(h), C.c_void_p(dptr), C.c_size_t(4 * n), stream))
+            self.allreduce_u32(h)
+            capi.check(capi.lib().hgx_memcpy_h2d(C.c_void_p(dptr), capi.ptr(h), C.c_size_t(4 * n), stream))
+            return int(h[-1])
+        capi.sync(stream)                                   # the pileup kernels wrote the buffer on the library's stream
+        t = torch.as_tensor(_DeviceBlock(dptr, n), device=self._dev())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        flag = int(t[-1].item())                            # (synchronises torch's stream: the sum is complete)
+        return flag & 0xFFFFFFFF
+
     def all_gather_tables(self, bits, counts):
         """Every rank's class table (bits [C][w64] uint64, counts [C] int64) -> list in rank order."""
         import torch
@@ -265,6 +292,22 @@ class RcclComm:
         arr[...] = d.to_host(stream).reshape(arr.shape).astype(arr.dtype)
         return arr
 
+    def allreduce_u32(self, arr, stream=None):
+        """The pileup exchange of a sharded parse, host form (the same collective as allreduce_u32_dev)."""
+        d = capi.DevArray.from_host(np.ascontiguousarray(arr, np.uint32).ravel(), stream)
+        capi.check(capi.lib().hgx_allreduce_sum_u32(capi.ptr(d), C.c_size_t(arr.size), self.h, stream))
+        arr[...] = d.to_host(stream).reshape(arr.shape)
+        return arr
+
+    def allreduce_u32_dev(self, dptr, n, stream=None):
+        """The device form: hgx_allreduce_sum_u32 on the front end's own counter table, on the front end's stream.  Returns the
+        last element of the result (the failure flag)."""
+        capi.check(capi.lib().hgx_allreduce_sum_u32(C.c_void_p(dptr), C.c_size_t(n), self.h, stream))
+        flag = np.zeros(1, np.uint32)
+        capi.sync(stream)
+        capi.check(capi.lib().hgx_memcpy_d2h(capi.ptr(flag), C.c_void_p(dptr + 4 * (n - 1)), C.c_size_t(4), stream))
+        return int(flag[0])
+
     def merge_classes(self, cl, a_pad, stream=None):
         """This rank's class set of one level (or None) -> the merged class set of the whole sample, on every rank."""
         from . import engine
@@ -302,6 +345,20 @@ class LocalComm:
         arr[...] = np.sum(np.stack([p.astype(np.int64) for p in parts]), axis=0).astype(arr.dtype)
         return arr
 
+    def allreduce_u32(self, arr):
+        parts = self._exchange(np.ascontiguousarray(arr, np.uint32).copy())
+        arr[...] = np.sum(np.stack(parts), axis=0, dtype=np.uint32).reshape(arr.shape)
+        return arr
+
+    def allreduce_u32_dev(self, dptr, n, stream=None):
+        """Threads of one process standing in for ranks: every thread's table comes down, is summed, goes back up."""
+        h = np.zeros(n, np.uint32)
+        capi.sync(stream)
+        capi.check(capi.lib().hgx_memcpy_d2h(capi.ptr(h), C.c_void_p(dptr), C.c_size_t(4 * n), stream))
+        self.allreduce_u32(h)
+        capi.check(capi.lib().hgx_memcpy_h2d(C.c_void_p(dptr), capi.ptr(h), C.c_size_t(4 * n), stream))
+        return int(h[-1])
+
     def all_gather_tables(self, bits, counts):
         return self._exchange((bits.copy(), counts.copy()))
 
@@ -323,12 +380,14 @@ def merge_class_tables(tables, a_pad, stream=None):
 
 
 def type_shard(pl, batch, db, comm, remove_low_abundance_alleles=True, stream=None):
-    """The device side of a sharded locus for a shard whose piece batch is resident (`batch` from a parse that already
-    exchanged the pileup, `db` its engine.DeviceBatch): this rank's class tables, the two exchanges, the EMs on the merged
-    tables.  bench.py --workload class1 times this per step."""
+    """The device side of a sharded locus for a shard whose piece batch is resident (`db`: engine.DeviceBatch from a parse that
+    already exchanged the pileup; `batch`: its host form, or None for a batch born in HBM): this rank's class tables, the two
+    exchanges, the EMs on the merged tables.  bench.py --workload class1 times this per step."""
     from . import engine
     from .typing import LocusResult, TypeOpts, _result_from_handle
     hla = pl.base_fname == "hla"
+    if batch is None:
+        batch = db
     if batch.n_pairs > 0:
         bufs = engine.ScoreBuffers(pl, db, exon=hla)
         engine.piece_compat(pl, db, bufs, stream)
@@ -374,14 +433,12 @@ def type_shard(pl, batch, db, comm, remove_low_abundance_alleles=True, stream=No
     return res
 
 
-def type_locus_sharded(pl, sam_shard, comm, num_editdist=2, error_correction=True, allow_discordant=False,
-                       remove_low_abundance_alleles=True, simulation=False, base_locus=0, stream=None):
-    """Type one sample at one locus with its name-grouped reads split over the ranks of `comm` (shard r = the r-th
-    consecutive stretch of the stream, cut at read boundaries: split_name_grouped).  Three exchanges, no other coupling:
-      1. pileup counts, summed (get_mpileup covers the whole alignment; error correction needs all of it),
-      2. the ranks' exon- and gene-level class tables, gathered and merged in rank order (= first-seen order),
-      3. read / pair counts, summed.
-    Every rank then runs the (small) EMs on the merged tables and returns the same LocusResult as the unsharded path."""
+def parse_shard(pl, sam_shard, comm, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False, base_locus=0,
+                stream=None, alignment_file=None, regions=None, front=None):
+    """The front end of one shard of a sharded locus, with the pileup exchange (and, for CODIS D18S51, the inter-distance exchange)
+    and the failure protocol -> (host batch or None, engine.DeviceBatch).  On a GPU the shard goes through the DEVICE front end and
+    the exchange runs on the counter table in HBM (comm.allreduce_u32_dev); `front="host"`, D18S51 and GPU-less processes take the
+    host front end.  Collective: every rank of `comm` must call it."""
     from . import engine
     # A rank whose front-end fails must not leave its peers waiting in an exchange.  Every exchange of the parse carries one
     # extra element, the failure flag (sum > 0 = some rank failed: every rank raises out of that exchange and skips the later
@@ -400,34 +457,92 @@ def type_locus_sharded(pl, sam_shard, comm, num_editdist=2, error_correction=Tru
             raise RuntimeError("another rank of this locus failed in its front-end")
         arr[...] = ext[:arr.size].reshape(arr.shape).astype(arr.dtype)
         return arr
+    def exchange_u32(arr):                                  # pileup counters, host form: uint32 [L*6] + the flag
+        state["n"] += 1
+        ext = np.zeros(arr.size + 1, np.uint32)
+        ext[:arr.size] = arr.ravel()
+        comm.allreduce_u32(ext)
+        if ext[-1] != 0:
+            state["remote"] = True
+            raise RuntimeError("another rank of this locus failed in its front-end")
+        arr[...] = ext[:arr.size].reshape(arr.shape)
+        return arr
+
+    def exchange_u32_dev(dptr, n, st):                      # ... device form: the same collective on the table in HBM
+        state["n"] += 1
+        if comm.allreduce_u32_dev(dptr, n, st) != 0:
+            state["remote"] = True
+            raise RuntimeError("another rank of this locus failed in its front-end")
     d18 = pl.base_fname == "codis" and pl.gene == "D18S51"
     n_exchanges = 2 if d18 else 1
-    batch = None
+    on_device = front != "host" and not d18 and capi_has_device()
+    batch = db = None
     try:
-        batch = pl.parse_sam(sam_shard, num_editdist=num_editdist, error_correction=error_correction,
-                             allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus,
-                             pileup_exchange=exchange, interdist_exchange=exchange if d18 else None,
-                             last_shard=comm.rank == comm.world - 1)
+        if on_device:
+            # the DEVICE front end (round 5): record fields, filters, key grouping, pileup -- summed over the shards where the
+            # kernels left it, in HBM -- decode, piece table and pair protocol as kernels; the batch is born in HBM.  A shard the
+            # kernels decline (too few records, a record the reference would raise on) is finished by the host stages inside the
+            # same call, through the host form of the same exchange.
+            kw = dict(num_editdist=num_editdist, error_correction=error_correction, allow_discordant=allow_discordant,
+                      simulation=simulation, base_locus=base_locus, stream=stream, pileup_exchange=exchange_u32,
+                      pileup_exchange_dev=exchange_u32_dev if hasattr(comm, "allreduce_u32_dev") else None)
+            if alignment_file is not None:
+                db = pl.parse_alignment_file_dev(alignment_file, regions, **kw)
+            else:
+                db = pl.parse_sam_dev(sam_shard, **kw)
+        else:
+            # CODIS D18S51 (choose_pairs and its inter-distance histogram are host work by design) and GPU-less processes (the gloo
+            # tests): the host front end
+            batch = pl.parse_sam(sam_shard, num_editdist=num_editdist, error_correction=error_correction,
+                                 allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus,
+                                 pileup_exchange=exchange_u32, interdist_exchange=exchange if d18 else None,
+                                 last_shard=comm.rank == comm.world - 1)
     except BaseException as e:
         state["local"] = e
         if not state["remote"] and state["n"] < n_exchanges:      # the peers are in (or heading for) the next exchange: flag it
             state["n"] += 1
-            comm.allreduce_sum(_flag_only(pl, state["n"]))
+            if state["n"] == 1:
+                comm.allreduce_u32(_flag_only(pl, 1))
+            else:
+                comm.allreduce_sum(_flag_only(pl, 2))
     status = np.array([0 if state["local"] is None else 1], np.int64)
     comm.allreduce_sum(status)
     if state["local"] is not None:
         raise state["local"]
     if status[0] != 0:
         raise RuntimeError("another rank of this locus failed in its front-end")
-    db = engine.DeviceBatch(batch, stream)
-    return type_shard(pl, batch, db, comm, remove_low_abundance_alleles, stream)
+    if db is None:
+        db = engine.DeviceBatch(batch, stream)
+    return batch, db
+
+
+def type_locus_sharded(pl, sam_shard, comm, num_editdist=2, error_correction=True, allow_discordant=False,
+                       remove_low_abundance_alleles=True, simulation=False, base_locus=0, stream=None, alignment_file=None, regions=None,
+                       front=None):
+    """Type one sample at one locus with its name-grouped reads split over the ranks of `comm` (shard r = the r-th
+    consecutive stretch of the stream, cut at read boundaries: split_name_grouped).  Three exchanges, no other coupling:
+      1. pileup counts, summed (get_mpileup covers the whole alignment; error correction needs all of it),
+      2. the ranks' exon- and gene-level class tables, gathered and merged in rank order (= first-seen order),
+      3. read / pair counts, summed.
+    Every rank then runs the (small) EMs on the merged tables and returns the same LocusResult as the unsharded path.
+    `alignment_file` (+ `regions`): this rank's shard as a SAM / BAM file instead of text.  `front="host"`: the host front end
+    (what a process without a GPU takes anyway); engine.front_last() tells which route a rank's parse ran."""
+    batch, db = parse_shard(pl, sam_shard, comm, num_editdist=num_editdist, error_correction=error_correction,
+                            allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus, stream=stream,
+                            alignment_file=alignment_file, regions=regions, front=front)
+    try:
+        return type_shard(pl, batch, db, comm, remove_low_abundance_alleles, stream)
+    finally:
+        db.close()
 
 
 def _flag_only(pl, k):
-    """The array a FAILED rank contributes to the k-th exchange of a sharded parse: zeros of the shape its peers send, with the
-    failure flag set (exchange 1 = pileup counts [L][6], exchange 2 = the D18S51 inter-distance histogram)."""
-    n = len(pl.ref_seq) * 6 if k == 1 else 2 * 65536 + 2
-    ext = np.zeros(n + 1, np.int64)
+    """The array a FAILED rank contributes to the k-th exchange of a sharded parse: zeros of the shape and type its peers send,
+    with the failure flag set (exchange 1 = pileup counts, uint32 [L][6]; exchange 2 = the D18S51 inter-distance histogram, int64)."""
+    if k == 1:
+        ext = np.zeros(len(pl.ref_seq) * 6 + 1, np.uint32)
+    else:
+        ext = np.zeros(2 * 65536 + 2 + 1, np.int64)
     ext[-1] = 1
     return ext
 

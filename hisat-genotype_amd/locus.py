@@ -310,21 +310,69 @@ class PackedLocus:
         capi.check(capi.lib().hgx_parse_alignment_file(C.byref(h), self.h, path.encode(), regions or None, C.byref(o)))
         return Batch(h)
 
+    @staticmethod
+    def _install_exchanges(o, pileup_exchange, pileup_exchange_dev, interdist_exchange=None):
+        """Hook the python callbacks of a sharded parse into an hgx_parse_opts; returns (objects to keep alive, failure list)."""
+        keep, failure = [], []
+        if pileup_exchange is not None:
+            def _cb(_ctx, ptr, n):
+                try:
+                    pileup_exchange(np.ctypeslib.as_array(ptr, shape=(n,)))
+                    return 0
+                except BaseException as e:          # never let an exception cross the C frame
+                    failure.append(e)
+                    return 1
+            cb = capi.PILEUP_EXCHANGE(_cb)
+            o.pileup_exchange = C.cast(cb, C.c_void_p)
+            keep.append(cb)
+        if pileup_exchange_dev is not None:
+            def _cbd(_ctx, dptr, n, stream):
+                try:
+                    pileup_exchange_dev(dptr, n, stream)
+                    return 0
+                except BaseException as e:
+                    failure.append(e)
+                    return 1
+            cbd = capi.PILEUP_EXCHANGE_DEV(_cbd)
+            o.pileup_exchange_dev = C.cast(cbd, C.c_void_p)
+            keep.append(cbd)
+        if interdist_exchange is not None:
+            def _cb2(_ctx, ptr, n):
+                try:
+                    interdist_exchange(np.ctypeslib.as_array(ptr, shape=(n,)))
+                    return 0
+                except BaseException as e:
+                    failure.append(e)
+                    return 1
+            cb2 = capi.INTERDIST_EXCHANGE(_cb2)
+            o.interdist_exchange = C.cast(cb2, C.c_void_p)
+            keep.append(cb2)
+        return keep, failure
+
     def parse_sam_dev(self, sam_text, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False, base_locus=0,
-                      n_threads=0, stream=None, keep_trace=False):
-        """SAM text -> piece batch in HBM through the DEVICE front end (hgx_parse_sam_dev): the host tokenises, filters and groups
-        the records by decode key; pileup, decode, piece table and pair protocol run as kernels.  Returns an engine.DeviceBatch
-        (engine.front_last() tells whether the kernels took the input or declined it to the host stages)."""
+                      n_threads=0, stream=None, keep_trace=False, pileup_exchange=None, pileup_exchange_dev=None):
+        """SAM text -> piece batch in HBM through the DEVICE front end (hgx_parse_sam_dev): record fields, filters, key grouping,
+        pileup, decode, piece table and pair protocol run as kernels; inputs the kernels decline are finished by the host stages
+        inside the same call.  Returns an engine.DeviceBatch (engine.front_last() tells which route ran).
+        A shard of a sharded locus (dist.type_locus_sharded): `pileup_exchange(counts)` = the host form (numpy uint32 [L*6], summed
+        in place over the shards), `pileup_exchange_dev(device pointer, n, stream)` = the device form (n = L*6 counters + one
+        spare element, summed in place in HBM); see hgx_parse_opts in include/hgx.h."""
         from . import engine
         data = sam_text if isinstance(sam_text, (bytes, bytearray)) else sam_text.encode()
         o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus, int(keep_trace),
                            int(self.base_fname == "codis" and self.gene == "D18S51"), int(n_threads))
+        keep, failure = self._install_exchanges(o, pileup_exchange, pileup_exchange_dev)
         h = C.c_void_p()
-        capi.check(capi.lib().hgx_parse_sam_dev(C.byref(h), self.h, data, C.c_size_t(len(data)), C.byref(o), stream))
+        rc = capi.lib().hgx_parse_sam_dev(C.byref(h), self.h, data, C.c_size_t(len(data)), C.byref(o), stream)
+        del keep
+        if failure:
+            raise failure[0]
+        capi.check(rc)
         return engine.DeviceBatch.from_handle(h)
 
     def parse_alignment_file_dev(self, path, regions=None, num_editdist=2, error_correction=True, allow_discordant=False,
-                                 simulation=False, base_locus=0, n_threads=0, stream=None, keep_trace=False):
+                                 simulation=False, base_locus=0, n_threads=0, stream=None, keep_trace=False, pileup_exchange=None,
+                                 pileup_exchange_dev=None):
         """parse_alignment_file through the device front end (hgx_parse_alignment_file_dev) -> engine.DeviceBatch."""
         from . import engine
         if regions is not None and not isinstance(regions, (str, bytes)):
@@ -333,8 +381,13 @@ class PackedLocus:
             regions = regions.encode()
         o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus, int(keep_trace),
                            int(self.base_fname == "codis" and self.gene == "D18S51"), int(n_threads))
+        keep, failure = self._install_exchanges(o, pileup_exchange, pileup_exchange_dev)
         h = C.c_void_p()
-        capi.check(capi.lib().hgx_parse_alignment_file_dev(C.byref(h), self.h, path.encode(), regions or None, C.byref(o), stream))
+        rc = capi.lib().hgx_parse_alignment_file_dev(C.byref(h), self.h, path.encode(), regions or None, C.byref(o), stream)
+        del keep
+        if failure:
+            raise failure[0]
+        capi.check(rc)
         return engine.DeviceBatch.from_handle(h)
 
     def close(self):

@@ -357,6 +357,17 @@ typedef struct hgx_parse_opts {
      * place; the median is then read from the summed histogram (exact; outside the range the parse fails).                  */
     int (*interdist_exchange)(void *ctx, int64_t *hist, int64_t n_bins);
     void *interdist_ctx;
+    /* The DEVICE form of pileup_exchange, taken by the device front end (hgx_parse_sam_dev / hgx_parse_alignment_file_dev) when
+     * set: called once, between the pileup kernels and the nt_set kernel, with this shard's counters where the kernels left them
+     * -- device memory, n = L*6 counters plus ONE spare element that is zero on entry (room for a caller's failure flag) -- and must
+     * leave the element-wise sum over all shards there, complete or ordered on `stream` when it returns (hgx_allreduce_sum_u32 on
+     * the same stream does exactly that; dist.py: RCCL, torch.distributed on an aliasing tensor, or threads of one process).
+     * The host form above must be given too: it is what runs if the device route declines BEFORE its exchange (a small input, a
+     * record the kernels do not take); both forms must be the same collective -- uint32, n elements -- because other ranks may
+     * be on the other route.  A route that declines AFTER the exchange hands the summed table to the host stages, which then
+     * do not exchange again: every rank communicates exactly once per parse.                                                   */
+    int (*pileup_exchange_dev)(void *ctx, uint32_t *d_counts, int64_t n, void *stream);
+    void *pileup_dev_ctx;
 } hgx_parse_opts;
 #define HGX_INTERDIST_HALF 65536
 #define HGX_INTERDIST_BINS (2 * HGX_INTERDIST_HALF + 2)

@@ -41,7 +41,7 @@ WORKER = textwrap.dedent('''
     comm = hdist.TorchComm()
     shard_text = hdist.split_name_grouped(sam, world)[rank]
     whole = pl.parse_sam(sam)
-    mine_b = pl.parse_sam(shard_text, pileup_exchange=comm.allreduce_sum)
+    mine_b = pl.parse_sam(shard_text, pileup_exchange=comm.allreduce_u32)
     L = len(loc.backbone)
     nt_w, cnt_w = whole.pileup(L)
     nt_s, cnt_s = mine_b.pileup(L)
@@ -56,6 +56,18 @@ WORKER = textwrap.dedent('''
     assert [c.tolist() for _, c in got_t] == [[0, 1, 2], [10, 11, 12, 13]][:world]
     tot = comm.allreduce_sum(np.array([mine_b.n_reads, 7], np.int64))
     assert tot.tolist() == [whole.n_reads, 7 * world]
+    big = comm.allreduce_u32(np.array([0xC0000000, 5], np.uint32))          # uint32 sums travel as int32: wrap-around is the same
+    assert big.tolist() == [(0xC0000000 * world) & 0xFFFFFFFF, 5 * world]
+    # the whole sharded typing sequence on the host form (no GPU here: parse_shard takes the host front end): exchange order and
+    # failure protocol -- a rank whose shard is unparseable fails BOTH ranks, nobody hangs
+    _, db_or_none = None, None
+    try:
+        hdist.parse_shard(pl, shard_text if rank == 0 else shard_text.replace(b"NM:i:", b"XM:i:", 1), comm)
+        raise SystemExit("a failing rank went unnoticed")
+    except SystemExit:
+        raise
+    except Exception as e:
+        assert ("front-end" in str(e)) or ("reference would fail" in str(e)) or ("NM" in str(e)), e
     assert hdist.assign_ranks_to_loci([7000, 8000, 7000], 4) == {0: [0], 1: [1, 2], 2: [3]}
     dist.barrier()
     dist.destroy_process_group()

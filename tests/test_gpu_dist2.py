@@ -19,7 +19,7 @@ WORKER = textwrap.dedent('''
     import numpy as np
     import torch.distributed as dist
     import hisatgenotype_amd as hgx
-    from hisatgenotype_amd import synth, locus as hl, dist as hdist, capi
+    from hisatgenotype_amd import synth, locus as hl, dist as hdist, capi, engine
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     capi.set_device(0)                                   # both ranks on the one GPU of the box
@@ -36,7 +36,14 @@ WORKER = textwrap.dedent('''
     cases.append(("STR locus", str_loc, str_sam, hdist.split_name_grouped(str_sam, world)))
     for what, loc, sam, shards in cases:
         pl = hl.PackedLocus.from_synth(loc)
-        res = hdist.type_locus_sharded(pl, shards[rank], comm)
+        # every shard through the DEVICE front end (forced: they are below its size gate); the pileup counters are summed between the
+        # two processes out of and back into HBM (gloo has no device path); then once more on the host route
+        with engine.test_switches(front="device"):
+            res = hdist.type_locus_sharded(pl, shards[rank], comm)
+            if shards[rank]:
+                assert engine.front_last() == (2, 0), (what, rank, engine.front_last())
+        res_h = hdist.type_locus_sharded(pl, shards[rank], comm, front="host")
+        assert res_h.gene_prob == res.gene_prob and res_h.counts_sorted == res.counts_sorted and res_h.em == res.em, (what, rank)
         ref = hgx.type_locus(pl, sam)
         assert (res.num_reads, res.num_pairs) == (ref.num_reads, ref.num_pairs), (what, rank)
         assert res.counts_sorted == ref.counts_sorted, (what, rank)

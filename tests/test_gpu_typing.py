@@ -523,26 +523,37 @@ def test_sharded_locus_equals_unsharded(world):
         ref = hgx.type_locus(pl, sam)
         shards = hdist.split_name_grouped(sam, world)
         assert b"".join(shards) == sam.encode() and all(shards)
-        comms = hdist.LocalComm.make(world)
-        out, errs = [None] * world, []
+        # "device": every rank's shard through the DEVICE front end (k_fe_*; the shards are below its size gate), the pileup summed
+        # over the ranks where k_fe_pileup left it, in HBM (comm.allreduce_u32_dev) -- no host parse on the sharded path (round 5);
+        # "host": the host front end with the host form of the same exchange; "mixed": rank 0 on the host route, the others on the
+        # device route -- the two forms are ONE collective
+        for mode in ("device", "host", "mixed"):
+            comms = hdist.LocalComm.make(world)
+            out, errs, routes = [None] * world, [], [None] * world
 
-        def run(r):
-            try:
-                capi.set_device(capi.current_device())
-                out[r] = hdist.type_locus_sharded(pl, shards[r], comms[r], stream=capi.get_stream(2))
-            except BaseException as e:
-                errs.append(e)
-                comms[r].sh.barrier.abort()
-        ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        assert not errs, errs
-        for res in out:
-            assert (res.num_reads, res.num_pairs) == (ref.num_reads, ref.num_pairs)
-            assert res.counts_sorted == ref.counts_sorted
-            assert res.em == ref.em and res.gene_prob == ref.gene_prob
+            def run(r):
+                try:
+                    capi.set_device(capi.current_device())
+                    front = "host" if (mode == "host" or (mode == "mixed" and r == 0)) else None
+                    out[r] = hdist.type_locus_sharded(pl, shards[r], comms[r], stream=capi.get_stream(2), front=front)
+                    routes[r] = engine.front_last()
+                except BaseException as e:
+                    errs.append(e)
+                    comms[r].sh.barrier.abort()
+            with engine.test_switches(front="device"):
+                ths = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+                for t in ths:
+                    t.start()
+                for t in ths:
+                    t.join()
+            assert not errs, errs
+            for r in range(world):
+                if mode == "device" or (mode == "mixed" and r > 0):
+                    assert routes[r] == (2, 0), (mode, r, routes)
+            for res in out:
+                assert (res.num_reads, res.num_pairs) == (ref.num_reads, ref.num_pairs)
+                assert res.counts_sorted == ref.counts_sorted
+                assert res.em == ref.em and res.gene_prob == ref.gene_prob
 
 
 _BROADCAST_WORKER = r"""
@@ -654,12 +665,13 @@ def _type_sharded(pl, sam, world):
     pl.index()
     shards = hdist.split_name_grouped(sam, world)
     comms = hdist.LocalComm.make(world)
-    out, errs = [None] * world, []
+    out, errs, routes = [None] * world, [], [None] * world
 
     def run(r):
         try:
             capi.set_device(capi.current_device())
             out[r] = hdist.type_locus_sharded(pl, shards[r], comms[r], stream=capi.get_stream(2))
+            routes[r] = engine.front_last()
         except BaseException as e:
             errs.append(e)
             comms[r].sh.barrier.abort()
@@ -671,6 +683,7 @@ def _type_sharded(pl, sam, world):
     assert not errs, errs
     for r in out[1:]:
         assert r.gene_prob == out[0].gene_prob and r.counts_sorted == out[0].counts_sorted
+    out[0].front_routes = routes                   # (route, decline code) of every rank's parse
     return out[0]
 
 
@@ -696,6 +709,7 @@ def test_class1_at_stated_size_properties_and_sharding():
         assert again.gene_prob == res.gene_prob and again.em == res.em
         if g == "B":
             sharded = _type_sharded(pl, sam, 2)
+            assert sharded.front_routes == [(2, 0), (2, 0)]      # 250 k pairs per rank: the device front end by itself, exchange in HBM
             assert sharded.num_reads == res.num_reads and sharded.num_pairs == res.num_pairs
             assert sharded.counts_sorted == res.counts_sorted
             assert [a for a, _ in sharded.gene_prob] == [a for a, _ in res.gene_prob]
@@ -731,24 +745,29 @@ def test_a_failing_rank_fails_every_rank_of_a_sharded_locus():
     sam = synth.simulate_sam_fast(loc, synth.pick_sample(loc, 1), 600, seed=2)
     shards = hdist.split_name_grouped(sam, 2)
     shards[1] = shards[1].replace(b"NM:i:", b"XM:i:", 1)
-    comms = hdist.LocalComm.make(2)
-    errs = [None, None]
+    # by default (these shards are small: the host stages), with every rank forced onto the device route (the kernels decline the
+    # record, the host stages word the error: the rank has exchanged on the device by then and must not exchange again), and mixed
+    for switches, fronts in ((dict(), (None, None)), (dict(front="device"), (None, None)), (dict(front="device"), ("host", None)),
+                             (dict(front="device"), (None, "host"))):
+        comms = hdist.LocalComm.make(2)
+        errs = [None, None]
 
-    def run(r):
-        try:
-            capi.set_device(capi.current_device())
-            hdist.type_locus_sharded(pl, shards[r], comms[r], stream=capi.get_stream(2))
-        except BaseException as e:
-            errs[r] = e
-    ths = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(2)]      # (daemon: a blocked rank must not hang the run)
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join(timeout=60)
-    if any(t.is_alive() for t in ths):
-        comms[0].sh.barrier.abort()
-        pytest.fail("a rank is still blocked in an exchange")
-    assert errs[0] is not None and errs[1] is not None
+        def run(r):
+            try:
+                capi.set_device(capi.current_device())
+                hdist.type_locus_sharded(pl, shards[r], comms[r], stream=capi.get_stream(2), front=fronts[r])
+            except BaseException as e:
+                errs[r] = e
+        with engine.test_switches(**switches):
+            ths = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(2)]      # (daemon: a blocked rank must not hang the run)
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join(timeout=60)
+        if any(t.is_alive() for t in ths):
+            comms[0].sh.barrier.abort()
+            pytest.fail("a rank is still blocked in an exchange")
+        assert errs[0] is not None and errs[1] is not None, (switches, fronts)
 
 
 _RCCL_ONE_WORKER = r"""
@@ -768,9 +787,15 @@ again = hgx.type_locus(pl, sam)
 assert again.gene_prob == ref.gene_prob and all(np.array_equal(before[k], pl.tables()[k]) for k in before)
 a = np.arange(1000, dtype=np.int64) * 3
 assert np.array_equal(comm.allreduce_sum(a.copy()), a)
-got = hdist.type_locus_sharded(pl, sam.encode(), comm)
-assert (got.num_reads, got.num_pairs) == (ref.num_reads, ref.num_pairs)
-assert got.counts_sorted == ref.counts_sorted and got.em == ref.em and got.gene_prob == ref.gene_prob
+from hisatgenotype_amd import engine
+for sw in (dict(), dict(front="device")):       # forced: the shard through k_fe_*, the pileup counters all-reduced in HBM by hgx_allreduce_sum_u32
+    with engine.test_switches(**sw):
+        got = hdist.type_locus_sharded(pl, sam.encode(), comm)
+        assert not sw or engine.front_last() == (2, 0), engine.front_last()
+    assert (got.num_reads, got.num_pairs) == (ref.num_reads, ref.num_pairs)
+    assert got.counts_sorted == ref.counts_sorted and got.em == ref.em and got.gene_prob == ref.gene_prob
+u = comm.allreduce_u32(np.array([7, 0xFFFFFFF0], np.uint32))
+assert u.tolist() == [7, 0xFFFFFFF0]
 comm.close()
 print("rccl world-1 ok")
 """
