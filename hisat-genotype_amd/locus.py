@@ -328,7 +328,7 @@ class PackedLocus:
         if pileup_exchange_dev is not None:
             def _cbd(_ctx, dptr, n, stream):
                 try:
-                    pileup_exchange_dev(dptr, n, stream)
+                    pileup_exchange_dev(int(dptr), int(n), C.c_void_p(stream) if stream else None)   # (a bare int would travel as a C int)
                     return 0
                 except BaseException as e:
                     failure.append(e)
