@@ -418,23 +418,22 @@ __global__ void __launch_bounds__(256) k_fe_pair_count(const uint32_t *__restric
     // the call's totals: ONE pair of atomics per workgroup.  (One per wavefront was 31 000 atomics on two addresses at 1 M records:
     // they queue in one L2 channel, a wavefront ends only when its own has been served, and the kernel took 0.39 ms for 20
     // instructions per lane.)
-    __shared__ unsigned long long s_reads[4], s_gene[4];
+    __shared__ unsigned long long s_reads[4], s_gene[4], s_pack[4];
     reads = wave_sum_u64(reads);
     gene = wave_sum_u64(gene);
-    if ((threadIdx.x & 63) == 0) { s_reads[threadIdx.x >> 6] = reads; s_gene[threadIdx.x >> 6] = gene; }
+    const unsigned long long pack = wave_sum_u64(c);                  // pairs << 40 | refs of the workgroup's runs (64-bit: the scan's offsets are 32-bit)
+    if ((threadIdx.x & 63) == 0) { s_reads[threadIdx.x >> 6] = reads; s_gene[threadIdx.x >> 6] = gene; s_pack[threadIdx.x >> 6] = pack; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const unsigned long long r = s_reads[0] + s_reads[1] + s_reads[2] + s_reads[3], g = s_gene[0] + s_gene[1] + s_gene[2] + s_gene[3];
-        if (r | g) { atomicAdd(&ctl->n_reads, r); atomicAdd(&ctl->n_gene_refs, g); }
+        const unsigned long long pk = s_pack[0] + s_pack[1] + s_pack[2] + s_pack[3];
+        if (r | g | pk) { atomicAdd(&ctl->n_reads, r); atomicAdd(&ctl->n_gene_refs, g); atomicAdd(&ctl->pair_total, pk); }
     }
-}
-__global__ void k_fe_pair_total(const unsigned long long *__restrict__ cnt, const unsigned long long *__restrict__ off, uint32_t n, FeCtl *ctl) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->pair_total = n ? off[n - 1] + cnt[n - 1] : 0ull;
 }
 __global__ void __launch_bounds__(256) k_fe_pair_emit(const uint32_t *__restrict__ rec_info, uint32_t n_rec, const uint8_t *__restrict__ state,
                                                       const uint32_t *__restrict__ key_ht_off, const uint32_t *__restrict__ key_n_ht,
                                                       const int32_t *__restrict__ ht_pool, const unsigned long long *__restrict__ cnt,
-                                                      const unsigned long long *__restrict__ off, const uint32_t *__restrict__ cand_piece,
+                                                      const uint32_t *__restrict__ off_pair, const uint32_t *__restrict__ off_ref, const uint32_t *__restrict__ cand_piece,
                                                       int32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_ref, uint32_t n_pairs, uint32_t n_refs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) pair_off[n_pairs] = (int32_t)n_refs;
@@ -442,8 +441,8 @@ __global__ void __launch_bounds__(256) k_fe_pair_emit(const uint32_t *__restrict
     uint32_t uni[FE_MAX_PAIR_HT];
     int n_uni = 0;
     (void)fe_pair_union(rec_info, i, n_rec, state, key_ht_off, key_n_ht, ht_pool, uni, n_uni);
-    const uint32_t p = (uint32_t)(off[i] >> 40);
-    uint32_t r = (uint32_t)(off[i] & ((1ull << 40) - 1));
+    const uint32_t p = off_pair[i];
+    uint32_t r = off_ref[i];
     pair_off[p] = (int32_t)r;
     for (int x = 0; x < n_uni; ++x) {
         const int32_t *rec = ht_pool + uni[x];
@@ -453,6 +452,111 @@ __global__ void __launch_bounds__(256) k_fe_pair_emit(const uint32_t *__restrict
         const int32_t *rec = ht_pool + uni[x];
         pair_ref[r++] = cand_piece[(uint32_t)rec[4] + rec[3]] | 0x80000000u;
     }
+}
+
+// ---- prefix scans of the front end (round 5: hand-written; the nine hipcub::DeviceScan call sites -- two launches each -- are gone) ----
+// Up to four 32-bit channels over the same n items in ONE single-pass launch (decoupled look-back, as k_scan_u32 of hgx_dedup.hip):
+// exclusive sums, or an exclusive running maximum; a channel may be a field of the pair protocol's packed 64-bit counts.  Tile state =
+// one 64-bit word per (channel, tile): status in the top two bits (1 = the tile's own aggregate, 2 = the inclusive prefix), value below;
+// the look-back of the channels runs on the first lanes of a wavefront side by side.  totals[ch] = the aggregate over all items (the
+// one-thread kernels that read "last offset + last count" are gone too).  `state` ([4][tiles] words + a ticket) is zeroed by the caller.
+#define FSC_T 1024
+#define FSC_TILE (4 * FSC_T)
+enum { FSC_U32 = 0, FSC_PAIR_FLAG = 1, FSC_PAIR_REFS = 2 };
+struct FeScanCh { const void *in; uint32_t *out; int is_max, kind; };
+struct FeScanArgs { FeScanCh ch[4]; int n_ch; uint32_t *totals; };
+__device__ __forceinline__ uint32_t fsc_load(const FeScanCh &c, long i) {
+    if (c.kind == FSC_U32) return ((const uint32_t *)c.in)[i];
+    const unsigned long long v = ((const unsigned long long *)c.in)[i];
+    return c.kind == FSC_PAIR_FLAG ? (uint32_t)(v >> 40) : (uint32_t)(v & ((1ull << 40) - 1));
+}
+__global__ __launch_bounds__(FSC_T) void k_fe_scan(FeScanArgs a, long n, unsigned long long *__restrict__ state, uint32_t *__restrict__ ticket) {
+    __shared__ uint32_t s_tile;
+    __shared__ uint32_t s_wave[4][FSC_T / 64];
+    __shared__ uint32_t s_prefix[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const long tiles = (n + FSC_TILE - 1) / FSC_TILE;
+    const long i0 = (long)tile * FSC_TILE + 4 * tid;
+    uint32_t v[4][4], mine[4], incl[4];
+    for (int c = 0; c < a.n_ch; ++c) {
+        const bool mx = a.ch[c].is_max != 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[c][k] = i0 + k < n ? fsc_load(a.ch[c], i0 + k) : 0u;
+        mine[c] = mx ? max(max(v[c][0], v[c][1]), max(v[c][2], v[c][3])) : v[c][0] + v[c][1] + v[c][2] + v[c][3];
+        uint32_t x = mine[c];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(x, d, 64);
+            if (lane >= d) x = mx ? max(x, up) : x + up;
+        }
+        incl[c] = x;
+        if (lane == 63) s_wave[c][wv] = x;
+    }
+    __syncthreads();
+    if (wv == 0) {
+        for (int c = 0; c < a.n_ch; ++c) {
+            const bool mx = a.ch[c].is_max != 0;
+            const uint32_t w = lane < FSC_T / 64 ? s_wave[c][lane] : 0u;
+            uint32_t wi = w;
+#pragma unroll
+            for (int d = 1; d < FSC_T / 64; d <<= 1) {
+                const uint32_t up = __shfl_up(wi, d, 64);
+                if (lane >= d) wi = mx ? max(wi, up) : wi + up;
+            }
+            // exclusive aggregate of the wavefronts before mine; the tile's aggregate sits in lane 15
+            const uint32_t prev = __shfl_up(wi, 1, 64);
+            if (lane < FSC_T / 64) s_wave[c][lane] = lane ? prev : 0u;
+            const uint32_t tile_total = __shfl(wi, FSC_T / 64 - 1, 64);
+            if (lane == c) mine[0] = tile_total;                       // (lane c keeps channel c's aggregate for the look-back below)
+        }
+        if (lane < a.n_ch) {
+            const int c = lane;
+            const bool mx = a.ch[c].is_max != 0;
+            const unsigned long long total = mine[0];
+            unsigned long long *st = state + (size_t)c * tiles;
+            unsigned long long before = 0;
+            if (tile == 0) __hip_atomic_store(&st[0], (2ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else {
+                __hip_atomic_store(&st[tile], (1ull << 62) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (long j = (long)tile - 1;; --j) {
+                    unsigned long long sv;
+                    do sv = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); while ((sv >> 62) == 0);
+                    const unsigned long long val = sv & ((1ull << 62) - 1);
+                    before = mx ? (val > before ? val : before) : before + val;
+                    if ((sv >> 62) == 2) break;
+                }
+                const unsigned long long inc = mx ? (total > before ? total : before) : before + total;
+                __hip_atomic_store(&st[tile], (2ull << 62) | inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            s_prefix[c] = (uint32_t)before;
+            if ((long)(tile + 1) * FSC_TILE >= n && a.totals) a.totals[c] = (uint32_t)(mx ? (total > before ? total : before) : before + total);
+        }
+    }
+    __syncthreads();
+    for (int c = 0; c < a.n_ch; ++c) {
+        const bool mx = a.ch[c].is_max != 0;
+        // everything before this thread's four items: the tiles before, the wavefronts before, the lanes before
+        const uint32_t lanes_before = __shfl_up(incl[c], 1, 64);
+        uint32_t run = mx ? max(s_prefix[c], s_wave[c][wv]) : s_prefix[c] + s_wave[c][wv];
+        if (lane) run = mx ? max(run, lanes_before) : run + lanes_before;
+        uint32_t *out = a.ch[c].out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < n) out[i0 + k] = run;
+            run = mx ? max(run, v[c][k]) : run + v[c][k];
+        }
+    }
+}
+static size_t fe_scan_scratch_bytes(long n) { return (4 * (size_t)((n + FSC_TILE - 1) / FSC_TILE) + 2) * 8; }
+// `scratch` (fe_scan_scratch_bytes(n), ZEROED by the caller -- one memset may cover the scratch of several scans) ; n > 0
+static int fe_scan(const FeScanArgs &a, long n, void *scratch, hipStream_t st) {
+    const long tiles = (n + FSC_TILE - 1) / FSC_TILE;
+    k_fe_scan<<<(unsigned)tiles, FSC_T, 0, st>>>(a, n, (unsigned long long *)scratch, (uint32_t *)((unsigned long long *)scratch + 4 * tiles));
+    HIPCHK(hipGetLastError());
+    return HGX_OK;
 }
 
 // ---- the record stage (row 8a-1): fields, filters, key grouping -----------------------------------------------------------------
@@ -558,7 +662,7 @@ __global__ void __launch_bounds__(256) k_fe_build_recinfo(const FeRec *__restric
 // block_size leads to the next), so the stream is cut into ranges; every range but the first GUESSES a record start (a header that
 // is plausible and leads to three more plausible headers) and walks from there past its end; the guesses are then CHECKED -- a
 // range's walk must end exactly where the next one's begins -- and anything that does not link up declines the call.
-struct BamCtl { int32_t decline; uint32_t n_rec, n_kept, max_klen, unsorted; };
+struct BamCtl { int32_t decline; uint32_t n_rec, n_kept, max_klen, unsorted; uint32_t tot[4]; };      // tot: k_fe_scan's aggregates (records of the walk ranges)
 __device__ __forceinline__ void bam_decline(BamCtl *c, int code) { atomicCAS(&c->decline, 0, code); }
 __device__ __forceinline__ uint32_t bam_u32(const unsigned char *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ int32_t bam_i32(const unsigned char *p) { int32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -711,9 +815,6 @@ __global__ void __launch_bounds__(256) k_bam_link(const BamRange *__restrict__ r
     while (q < r1 && rng[q].state == 2u) ++q;
     if (q == r1 && r.stop != G.n) bam_decline(ctl, HGX_FE_DECLINE_RECORD);
 }
-__global__ void k_bam_total(const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ base, int W, BamCtl *ctl) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl->n_rec = base[W - 1] + cnt[W - 1];
-}
 // region filter (hgx_bam.cpp: reference span from the CIGAR, overlap with the one region) + the checks the host makes on a record
 __global__ void __launch_bounds__(256) k_bam_filter(const unsigned char *__restrict__ text, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ rec_len,
                                                     const uint16_t *__restrict__ rec_task, uint32_t n_rec, const BamSeg *__restrict__ segs,
@@ -795,8 +896,6 @@ __global__ void k_bam_lines(const uint32_t *__restrict__ rec_off, const uint32_t
     if (i < n) { const uint32_t r = idx[i]; lines[i] = FeLine{rec_off[r], rec_len[r], (uint32_t)rec_task[r]}; }
 }
 
-struct MaxU32 { __host__ __device__ uint32_t operator()(uint32_t a, uint32_t b) const { return a > b ? a : b; } };
-
 thread_local int g_last_device = 0, g_last_decline = 0, g_last_route = 0;
 thread_local long long g_last_bytes = 0;      // bytes the last call sent to the device (text / inflated stream / key table)
 
@@ -839,7 +938,7 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     // buffers go back to the pool
     DevBuf b_state, b_koff, b_knht, b_ht, b_clo, b_cnw, b_ckey, b_cmoff, b_mpool, b_slot_task, b_kpos, b_kpos2, b_kord, b_kord2, b_ktmp;
     DevBuf b_cnt, b_off, b_tmp, b_tmp2, b_key_s, b_idx, b_idx_s, b_flag, b_rank, b_head_of, b_head_cand;
-    DevBuf b_wh, b_wh_s, b_hidx, b_hidx_s, b_lonw, b_lonw_s, b_ord, b_nw2, b_moff, b_new_id, b_cand_piece, b_tbits, b_trace, b_troff;
+    DevBuf b_wh, b_wh_s, b_hidx, b_hidx_s, b_lonw, b_lonw_s, b_ord, b_nw2, b_moff, b_new_id, b_cand_piece, b_tbits, b_trace, b_troff, b_scan;
     hgx_dbatch *d = new hgx_dbatch();
     struct Guard { hgx_dbatch *&d; hipStream_t st; ~Guard() { (void)hipStreamSynchronize(st); if (d) hgx_dbatch_destroy(d); } } guard{d, st};
     FeCtl *ctl = di.ctl;
@@ -937,7 +1036,9 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
             size_t tb = 0;
             (void)hipcub::DeviceRadixSort::SortPairs((void *)nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_keys, 0, 32, st);
             ALLOC(b_ktmp, std::max<size_t>(tb, 256));
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_ktmp.p, tb, b_kpos.as<uint32_t>(), b_kpos2.as<uint32_t>(), b_kord.as<uint32_t>(), b_kord2.as<uint32_t>(), (int)n_keys, 0, 32, st));
+            int key_bits = 21;                                     // (task << 20) ^ (position + 4096): only the bits in use are sorted on
+            while (key_bits < 32 && (1 << (key_bits - 20)) < n_tasks + 1) ++key_bits;
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_ktmp.p, tb, b_kpos.as<uint32_t>(), b_kpos2.as<uint32_t>(), b_kord.as<uint32_t>(), b_kord2.as<uint32_t>(), (int)n_keys, 0, key_bits, st));
             order = b_kord2.as<uint32_t>();
         }
         k_fe_decode<<<nblk(n_keys, 256), 256, 0, st>>>(F, po, pile, keys, n_keys, text, pools, b_state.as<uint8_t>(), b_koff.as<uint32_t>(),
@@ -959,23 +1060,27 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     d->n_reads = (int32_t)h.n_reads;
     d->n_gene_refs = (int64_t)h.n_gene_refs;
 
-    // temp storage for the scans / sorts (one block, the largest request)
+    // temp storage for the sorts (one block, the largest request)
     size_t tmp_bytes = 0;
     {
         size_t b = 0;
-        (void)hipcub::DeviceScan::ExclusiveSum((void *)nullptr, b, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int)std::max<uint32_t>(n_rec, 1), st);
-        tmp_bytes = std::max(tmp_bytes, b);
         (void)hipcub::DeviceRadixSort::SortPairs((void *)nullptr, b, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                            (int)std::max<uint32_t>(n_cand, 1), 0, 64, st);
         tmp_bytes = std::max(tmp_bytes, b);
-        (void)hipcub::DeviceScan::ExclusiveSum((void *)nullptr, b, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)std::max<uint32_t>(n_cand, 1), st);
-        tmp_bytes = std::max(tmp_bytes, b);
     }
     ALLOC(b_tmp, std::max<size_t>(tmp_bytes, 256));
+    // one zeroed block for the tile states of the three scans of this function
+    const size_t sc_pair = fe_scan_scratch_bytes(std::max<uint32_t>(n_rec, 1)), sc_cand = fe_scan_scratch_bytes(std::max<uint32_t>(n_cand, 1));
+    ALLOC(b_scan, sc_pair + 2 * sc_cand);
+    HIPCHK(hipMemsetAsync(b_scan.p, 0, sc_pair + 2 * sc_cand, st));
     if (n_rec) {
-        size_t b = tmp_bytes;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_cnt.as<unsigned long long>(), b_off.as<unsigned long long>(), (int)n_rec, st));
-        k_fe_pair_total<<<1, 64, 0, st>>>(b_cnt.as<unsigned long long>(), b_off.as<unsigned long long>(), n_rec, ctl);
+        // pair index and first ref of every run that yields a pair: two channels of the packed counts in one pass
+        FeScanArgs sa{};
+        sa.n_ch = 2;
+        sa.ch[0] = FeScanCh{b_cnt.p, b_off.as<uint32_t>(), 0, FSC_PAIR_FLAG};
+        sa.ch[1] = FeScanCh{b_cnt.p, b_off.as<uint32_t>() + n_rec, 0, FSC_PAIR_REFS};
+        rc = fe_scan(sa, (long)n_rec, b_scan.p, st);
+        if (rc) return rc;
     }
     // distinct pieces
     ALLOC(b_key_s, std::max<size_t>(n_cand, 1) * 8);
@@ -992,8 +1097,13 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
                                                   (int)n_cand, 0, 64, st));
         k_fe_heads<<<nblk(n_cand, 256), 256, 0, st>>>(b_key_s.as<uint64_t>(), b_idx_s.as<uint32_t>(), n_cand, pools.cand_lo, pools.cand_nw,
                                                       pools.cand_mask_off, pools.mask_pool, b_flag.as<uint32_t>(), ctl);
-        b = tmp_bytes;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), (int)n_cand, st));
+        {
+            FeScanArgs sa{};
+            sa.n_ch = 1;
+            sa.ch[0] = FeScanCh{b_flag.p, b_rank.as<uint32_t>(), 0, FSC_U32};
+            rc = fe_scan(sa, (long)n_cand, (char *)b_scan.p + sc_pair, st);
+            if (rc) return rc;
+        }
         k_fe_assign_heads<<<nblk(n_cand, 256), 256, 0, st>>>(b_idx_s.as<uint32_t>(), b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n_cand,
                                                              b_head_of.as<uint32_t>(), b_head_cand.as<uint32_t>(), ctl);
     }
@@ -1002,7 +1112,7 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     lap("distinct pieces");
     if (h.decline) { *declined = -h.decline; return HGX_OK; }
     const uint32_t n_heads = n_cand ? h.n_heads : 0;
-    const uint64_t n_pairs64 = h.pair_total >> 40, n_refs64 = h.pair_total & ((1ull << 40) - 1);
+    const uint64_t n_pairs64 = h.pair_total >> 40, n_refs64 = h.pair_total & ((1ull << 40) - 1);        // (summed by k_fe_pair_count in 64 bits)
     if (n_refs64 >= (1ull << 31) || n_pairs64 >= (1ull << 31)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
     const uint32_t n_pairs = (uint32_t)n_pairs64, n_refs = (uint32_t)n_refs64;
 
@@ -1044,8 +1154,13 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
         k_fe_tie_fix<<<nblk(n_heads, 256), 256, 0, st>>>(b_ord.as<uint32_t>(), n_heads, b_head_cand.as<uint32_t>(), pools.cand_lo, pools.cand_nw,
                                                         pools.cand_mask_off, pools.mask_pool);
         k_fe_piece_sizes<<<nblk(n_heads, 256), 256, 0, st>>>(b_ord.as<uint32_t>(), b_head_cand.as<uint32_t>(), n_heads, pools.cand_nw, b_nw2.as<uint32_t>());
-        b = tmp_bytes;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_nw2.as<uint32_t>(), b_moff.as<uint32_t>(), (int)n_heads, st));
+        {
+            FeScanArgs sa{};
+            sa.n_ch = 1;
+            sa.ch[0] = FeScanCh{b_nw2.p, b_moff.as<uint32_t>(), 0, FSC_U32};
+            rc = fe_scan(sa, (long)n_heads, (char *)b_scan.p + sc_pair + sc_cand, st);
+            if (rc) return rc;
+        }
         k_fe_write_pieces<<<nblk(n_heads, 256), 256, 0, st>>>(b_ord.as<uint32_t>(), b_head_cand.as<uint32_t>(), n_heads, pools.cand_lo, pools.cand_nw,
                                                              pools.cand_mask_off, pools.mask_pool, b_moff.as<uint32_t>(), d->d_pieces, d->d_masks,
                                                              b_new_id.as<uint32_t>(), ctl);
@@ -1060,7 +1175,7 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
         }
     }
     if (n_rec) k_fe_pair_emit<<<nblk(n_rec, 256), 256, 0, st>>>(rec_info, n_rec, b_state.as<uint8_t>(), b_koff.as<uint32_t>(), b_knht.as<uint32_t>(),
-                                                                b_ht.as<int32_t>(), b_cnt.as<unsigned long long>(), b_off.as<unsigned long long>(),
+                                                                b_ht.as<int32_t>(), b_cnt.as<unsigned long long>(), b_off.as<uint32_t>(), b_off.as<uint32_t>() + n_rec,
                                                                 b_cand_piece.as<uint32_t>(), d->d_pair_off, d->d_pair_ref, n_pairs, n_refs);
     else HIPCHK(hipMemsetAsync(d->d_pair_off, 0, 4, st));
     HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
@@ -1184,34 +1299,43 @@ int bam_lines_dev(const char *d_text, const std::vector<const hgx_bam_deferred *
     k_bam_walk<0><<<nblk(W, 64), 64, 0, st>>>(text, d_seg, n_seg, W, b_rng.as<BamRange>(), nullptr, nullptr, nullptr, nullptr);
     k_bam_link<<<nblk(W, 256), 256, 0, st>>>(b_rng.as<BamRange>(), d_seg, n_seg, W, b_cnt.as<uint32_t>(), ctl);
     {
-        size_t tbw = 0;
-        (void)hipcub::DeviceScan::ExclusiveSum((void *)nullptr, tbw, (uint32_t *)nullptr, (uint32_t *)nullptr, W, st);
-        ALLOC(b_tmpw, std::max<size_t>(tbw, 256));
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmpw.p, tbw, b_cnt.as<uint32_t>(), b_base.as<uint32_t>(), W, st));
+        ALLOC(b_tmpw, fe_scan_scratch_bytes(W));
+        HIPCHK(hipMemsetAsync(b_tmpw.p, 0, fe_scan_scratch_bytes(W), st));
+        FeScanArgs sa{};
+        sa.n_ch = 1;
+        sa.ch[0] = FeScanCh{b_cnt.p, b_base.as<uint32_t>(), 0, FSC_U32};
+        sa.totals = ctl->tot;                                                  // (the records of all ranges)
+        const int rcs = fe_scan(sa, W, b_tmpw.p, st);
+        if (rcs) return rcs;
     }
-    k_bam_total<<<1, 64, 0, st>>>(b_cnt.as<uint32_t>(), b_base.as<uint32_t>(), W, ctl);
     BamCtl h;
     HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     lap("BAM record walk (ranges)");
     if (h.decline) { *declined = h.decline; return HGX_OK; }
-    const uint32_t n_rec = h.n_rec;
+    const uint32_t n_rec = h.tot[0];
     if (n_rec >= (1u << 30)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
     ALLOC(b_lines, std::max<size_t>(n_rec, 1) * sizeof(LineRef));
     if (n_rec == 0) return HGX_OK;
     ALLOC(b_off, (size_t)n_rec * 4); ALLOC(b_len, (size_t)n_rec * 4); ALLOC(b_task, (size_t)n_rec * 2 + 16); ALLOC(b_keep, (size_t)n_rec * 4); ALLOC(b_pos, (size_t)n_rec * 4);
     ALLOC(b_idx, (size_t)n_rec * 4); ALLOC(b_idx2, (size_t)n_rec * 4); ALLOC(b_key, (size_t)n_rec * 8); ALLOC(b_key2, (size_t)n_rec * 8);
-    size_t tb = 0, tb2 = 0;
-    (void)hipcub::DeviceScan::ExclusiveSum((void *)nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_rec, st);
+    size_t tb2 = 0;
     (void)hipcub::DeviceRadixSort::SortPairs((void *)nullptr, tb2, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr,
                                              (uint32_t *)nullptr, (int)n_rec, 0, 64, st);
-    const size_t tmp_bytes = std::max(tb, tb2);
+    const size_t tmp_bytes = std::max(tb2, fe_scan_scratch_bytes(n_rec));
     ALLOC(b_tmp, std::max<size_t>(tmp_bytes, 256));
     k_bam_walk<1><<<nblk(W, 64), 64, 0, st>>>(text, d_seg, n_seg, W, b_rng.as<BamRange>(), b_base.as<uint32_t>(), b_off.as<uint32_t>(), b_len.as<uint32_t>(),
                                              b_task.as<uint16_t>());
     k_bam_filter<<<nblk(n_rec, 256), 256, 0, st>>>(text, b_off.as<uint32_t>(), b_len.as<uint32_t>(), b_task.as<uint16_t>(), n_rec, d_seg, b_act.as<uint8_t>(),
                                                    b_keep.as<uint32_t>(), ctl);
-    { size_t b = tmp_bytes; HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_keep.as<uint32_t>(), b_pos.as<uint32_t>(), (int)n_rec, st)); }
+    {
+        HIPCHK(hipMemsetAsync(b_tmp.p, 0, fe_scan_scratch_bytes(n_rec), st));
+        FeScanArgs sa{};
+        sa.n_ch = 1;
+        sa.ch[0] = FeScanCh{b_keep.p, b_pos.as<uint32_t>(), 0, FSC_U32};
+        const int rcs = fe_scan(sa, (long)n_rec, b_tmp.p, st);
+        if (rcs) return rcs;
+    }
     k_bam_compact<<<nblk(n_rec, 256), 256, 0, st>>>(b_keep.as<uint32_t>(), b_pos.as<uint32_t>(), n_rec, b_idx.as<uint32_t>(), ctl);
     HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1269,10 +1393,12 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
     ALLOC(b_head, std::max<size_t>(n_lines, 16));
     ALLOC(b_kept, std::max<size_t>(n_lines, 16));
     ALLOC(b_slot_of, std::max<size_t>(n_lines, 4) * 4);
-    ALLOC(b_tkeys, (size_t)cap * 8);
-    ALLOC(b_rep, (size_t)cap * 4);
-    ALLOC(b_pile, (size_t)cap * 4);
-    ALLOC(b_anyk, (size_t)cap * 4);
+    // (one block of ones -- key table, representatives -- and one of zeros -- pile / any-kept counters, the control block, the scan's
+    // tile states: two memsets instead of six)
+    const size_t sc_bytes = fe_scan_scratch_bytes(std::max<uint32_t>(n, 1));
+    const size_t ctl_at = ((size_t)cap * 8 + 255) & ~(size_t)255, scan_at = ctl_at + 256;
+    ALLOC(b_tkeys, (size_t)cap * 12);                              // tkeys [cap] u64 | rep [cap] u32
+    ALLOC(b_pile, scan_at + sc_bytes);                             // pile [cap] u32 | anyk [cap] u32 | FeCtl | scan state
     ALLOC(b_dslot, (size_t)cap * 4);
     ALLOC(b_is_key, std::max<size_t>(n_lines, 4) * 4);
     ALLOC(b_is_dec, std::max<size_t>(n_lines, 4) * 4);
@@ -1282,19 +1408,18 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
     ALLOC(b_dec_idx, std::max<size_t>(n_lines, 4) * 4);
     ALLOC(b_rec_idx, std::max<size_t>(n_lines, 4) * 4);
     ALLOC(b_prev, std::max<size_t>(n_lines, 4) * 4);
-    ALLOC(b_ctl, sizeof(FeCtl));
-    HIPCHK(hipMemsetAsync(b_ctl.p, 0, sizeof(FeCtl), st));
-    HIPCHK(hipMemsetAsync(b_tkeys.p, 0xFF, (size_t)cap * 8, st));
-    HIPCHK(hipMemsetAsync(b_rep.p, 0xFF, (size_t)cap * 4, st));
-    HIPCHK(hipMemsetAsync(b_pile.p, 0, (size_t)cap * 4, st));
-    HIPCHK(hipMemsetAsync(b_anyk.p, 0, (size_t)cap * 4, st));
+    static_assert(sizeof(FeCtl) <= 256, "FeCtl outgrew its slot");
+    HIPCHK(hipMemsetAsync(b_tkeys.p, 0xFF, (size_t)cap * 12, st));
+    HIPCHK(hipMemsetAsync(b_pile.p, 0, scan_at + sc_bytes, st));
+    uint32_t *const d_rep = (uint32_t *)((char *)b_tkeys.p + (size_t)cap * 8);
+    uint32_t *const d_pile = b_pile.as<uint32_t>(), *const d_anyk = b_pile.as<uint32_t>() + cap;
     if (n && !d_lines) {
         HIPCHK(hipMemcpyAsync(b_lines.p, h_lines, (size_t)n * sizeof(LineRef), hipMemcpyHostToDevice, st));
         g_last_bytes += (long long)((size_t)n * sizeof(LineRef));
     }
     const LineRef *lines_dev = d_lines ? d_lines : b_lines.as<LineRef>();
     lap("text + line table on the device");
-    FeCtl *ctl = b_ctl.as<FeCtl>();
+    FeCtl *ctl = (FeCtl *)((char *)b_pile.p + ctl_at);
     FeCtl h;
     memset(&h, 0, sizeof(h));
     if (n) {
@@ -1302,31 +1427,28 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
         FeRec *recs = b_recs.as<FeRec>();
         k_fe_records<<<nblk(n, 256), 256, 0, st>>>(d_text, raw_bytes + 64, lines_dev, n, binary ? 1 : 0, o.simulation, recs, ctl);
         k_fe_rec_heads<<<nblk(n, 256), 256, 0, st>>>(recs, n, d_text, b_head.as<uint8_t>());
-        k_fe_rec_filter_insert<<<nblk(n, 256), 256, 0, st>>>(recs, b_head.as<uint8_t>(), n, flt, b_tkeys.as<unsigned long long>(), b_rep.as<uint32_t>(),
-                                                            b_pile.as<uint32_t>(), b_anyk.as<uint32_t>(), cap - 1, b_kept.as<uint8_t>(),
+        k_fe_rec_filter_insert<<<nblk(n, 256), 256, 0, st>>>(recs, b_head.as<uint8_t>(), n, flt, b_tkeys.as<unsigned long long>(), d_rep,
+                                                            d_pile, d_anyk, cap - 1, b_kept.as<uint8_t>(),
                                                             b_slot_of.as<uint32_t>(), ctl);
-        k_fe_group_flags<<<nblk(n, 256), 256, 0, st>>>(recs, n, d_text, b_rep.as<uint32_t>(), b_pile.as<uint32_t>(), b_anyk.as<uint32_t>(),
+        k_fe_group_flags<<<nblk(n, 256), 256, 0, st>>>(recs, n, d_text, d_rep, d_pile, d_anyk,
                                                       b_slot_of.as<uint32_t>(), b_kept.as<uint8_t>(), b_is_key.as<uint32_t>(), b_is_dec.as<uint32_t>(),
                                                       b_kept32.as<uint32_t>(), b_prev_in.as<uint32_t>(), ctl);
-        size_t tb = 0, tb2 = 0;
-        (void)hipcub::DeviceScan::ExclusiveSum((void *)nullptr, tb, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n, st);
-        (void)hipcub::DeviceScan::ExclusiveScan((void *)nullptr, tb2, (uint32_t *)nullptr, (uint32_t *)nullptr, MaxU32(), 0u, (int)n, st);
-        tb = std::max(tb, tb2);
-        ALLOC(b_tmp, std::max<size_t>(tb, 256));
-        size_t b = tb;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_is_key.as<uint32_t>(), b_key_idx.as<uint32_t>(), (int)n, st));
-        b = tb;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_is_dec.as<uint32_t>(), b_dec_idx.as<uint32_t>(), (int)n, st));
-        b = tb;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(b_tmp.p, b, b_kept32.as<uint32_t>(), b_rec_idx.as<uint32_t>(), (int)n, st));
-        b = tb;
-        HIPCHK(hipcub::DeviceScan::ExclusiveScan(b_tmp.p, b, b_prev_in.as<uint32_t>(), b_prev.as<uint32_t>(), MaxU32(), 0u, (int)n, st));
+        {   // key numbers, decode slots, kept-record numbers (sums) and "the kept record before me" (a running maximum): one pass
+            FeScanArgs sa{};
+            sa.n_ch = 4;
+            sa.ch[0] = FeScanCh{b_is_key.p, b_key_idx.as<uint32_t>(), 0, FSC_U32};
+            sa.ch[1] = FeScanCh{b_is_dec.p, b_dec_idx.as<uint32_t>(), 0, FSC_U32};
+            sa.ch[2] = FeScanCh{b_kept32.p, b_rec_idx.as<uint32_t>(), 0, FSC_U32};
+            sa.ch[3] = FeScanCh{b_prev_in.p, b_prev.as<uint32_t>(), 1, FSC_U32};
+            rc = fe_scan(sa, (long)n, (char *)b_pile.p + scan_at, st);
+            if (rc) return rc;
+        }
         // (the key table is sized by the records: a key per record at most)
         ALLOC(b_keys, (size_t)n * sizeof(FeKey));
         ALLOC(b_rec, (size_t)n * 4);
         k_fe_build_keys<<<nblk(n, 256), 256, 0, st>>>(recs, n, b_is_key.as<uint32_t>(), b_is_dec.as<uint32_t>(), b_key_idx.as<uint32_t>(),
                                                      b_dec_idx.as<uint32_t>(), b_kept32.as<uint32_t>(), b_rec_idx.as<uint32_t>(), b_slot_of.as<uint32_t>(),
-                                                     b_pile.as<uint32_t>(), o.base_locus, b_keys.as<FeKey>(), b_dslot.as<uint32_t>(), ctl);
+                                                     d_pile, o.base_locus, b_keys.as<FeKey>(), b_dslot.as<uint32_t>(), ctl);
         k_fe_build_recinfo<<<nblk(n, 256), 256, 0, st>>>(recs, n, d_text, b_kept.as<uint8_t>(), b_rec_idx.as<uint32_t>(), b_prev.as<uint32_t>(),
                                                         b_slot_of.as<uint32_t>(), b_dslot.as<uint32_t>(), b_rec.as<uint32_t>());
         HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));

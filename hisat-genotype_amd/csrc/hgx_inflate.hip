@@ -1,4 +1,7 @@
-// hgx_inflate.hip -- BGZF inflate on the device (row 8f-3, round 4): ONE WAVEFRONT PER BGZF BLOCK.
+// hgx_inflate.hip -- BGZF inflate on the device (row 8f-3): ONE WAVEFRONT PER BGZF BLOCK.
+// Two forms: k_bgzf_inflate_w (round 5, the default: the symbol loop lane-parallel, 64 bit offsets per window -- see its header
+// below) and k_bgzf_inflate (round 4: one symbol per trip; test switch front=inflate_v1, the comparison form).  What follows
+// describes the first form's structure, which the second shares but for the symbol loop and the input path.
 //
 // A BGZF file (SAM/BAM specification section 4.1) is a sequence of independent gzip members of at most 64 KB of payload each, with
 // the compressed size in an extra field and CRC-32 / ISIZE behind the deflate stream: the host only hops from header to header
@@ -170,6 +173,18 @@ __device__ bool huff_build(T &H, const unsigned char *lens, int n, int lane, boo
     __builtin_amdgcn_wave_barrier();
     return true;
 }
+// an INCOMPLETE set of code lengths is legal only as zlib's inflate_table takes it: exactly one code, of one bit -- or, for the
+// distance code of a block without matches, no code at all
+__device__ bool huff_incomplete_ok(const unsigned char *lens, int n, int lane, bool allow_empty) {
+    uint32_t n_codes = 0, n_one = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int s = c0 + lane;
+        const int L = s < n ? (int)lens[s] : 0;
+        n_codes += (uint32_t)__popcll(__ballot(L != 0));
+        n_one += (uint32_t)__popcll(__ballot(L == 1));
+    }
+    return (n_codes == 1 && n_one == 1) || (allow_empty && n_codes == 0);
+}
 // one symbol: the primary table, or the walk over the longer lengths; -1 = no such code.  (At least 15 bits are in the buffer.)
 template <class T, int P>
 __device__ __forceinline__ int huff_decode(const T &H, Bits &b) {
@@ -310,10 +325,12 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
                 __builtin_amdgcn_wave_barrier();
                 if (S.lens[32 + 256] == 0) { err = INF_BAD_LENGTHS; break; }              // no end-of-block code
                 if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, n_lit, lane, false, true)) {
-                    // (an incomplete literal/length code is legal only when it has a single code: zlib accepts that; so do we)
-                    if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, n_lit, lane, true, true)) { err = INF_BAD_LENGTHS; break; }
+                    // (an incomplete literal/length code is legal only when it is ONE code of one bit: zlib's inflate_table; so here)
+                    if (!huff_incomplete_ok(S.lens + 32, n_lit, lane, false) || !huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, n_lit, lane, true, true)) { err = INF_BAD_LENGTHS; break; }
                 }
-                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 32 + n_lit, n_dist, lane, true)) { err = INF_BAD_LENGTHS; break; }
+                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 32 + n_lit, n_dist, lane, false)) {
+                    if (!huff_incomplete_ok(S.lens + 32 + n_lit, n_dist, lane, true) || !huff_build<DistLds, DIST_P>(S.dist, S.lens + 32 + n_lit, n_dist, lane, true)) { err = INF_BAD_LENGTHS; break; }
+                }
             }
             // ---- the symbols of the block -------------------------------------------------------------------------------
             // (literals are gathered eight at a time: one byte store by eight lanes instead of eight stores by one)
@@ -427,6 +444,458 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
     if (lane == 0) verdict[bi] = (uint32_t)err;
 }
 
+
+// =====================================================================================================================================
+// Round 5: the symbol loop LANE-PARALLEL.  The form above decodes one symbol per trip through a chain of dependent LDS round trips
+// (table look-up -> readfirstlane -> extra bits -> distance look-up -> copy: ~800 clocks per symbol, 3 000 symbols per 64 KB block)
+// with 63 lanes watching.  Here every lane decodes the symbol that WOULD start at its own bit offset -- lane l at P + l, 64 offsets
+// per window -- in one pass of the tables (literal / length entry, extra bits, distance entry, extra bits: plain per-lane
+// arithmetic on a 64-bit window of the stream, two LDS gathers for the whole wavefront); the true chain is then picked out by
+// hopping from lane to lane with v_readlane (cur += consumed[cur]: ~6 symbols per 64 bits of a BAM stream), which also hands every
+// symbol on the chain its output offset.  The literals of a window leave in ONE byte store, the matches are copied one after the
+// other by the lanes (a match may read what an earlier symbol of its window wrote: LDS operations of a wavefront execute in order).
+// Codes longer than the tables' index bits (rare symbols by construction) and everything else that is not the common case are
+// marked SLOW by the lane and decoded by the wave-uniform path if -- and only if -- the chain lands on them.
+// The compressed stream reaches the lanes through a 512-byte LDS ring (two 256-byte chunks; the next chunk waits in a register per
+// lane); headers (block type, code lengths) are read with the same window function at lane offset 0.
+// =====================================================================================================================================
+constexpr int T_MAX = 1024;                              // most bytes one window may produce (a 64-bit window of 2-bit codes could ask for 8 KB)
+constexpr uint32_t NEAR_MAX = RING - T_MAX - 320;        // matches up to this distance are copied inside the ring, farther ones from memory
+
+struct InfLdsW {
+    unsigned char ring[RING];
+    HuffLds lit;
+    DistLds dist;
+    unsigned char lens[384];
+    uint32_t crc_piece[64];
+    uint32_t in_ring[128];
+};
+
+__device__ uint32_t g_crc_tab[4][256];                   // slice-by-4 tables of CRC-32 (filled once per device by the host)
+
+struct Win {
+    const uint32_t *base;
+    uint32_t n_dwords;
+    uint32_t nxt;                    // this lane's dword of chunk staged_hi + 1
+    int staged_hi;                   // highest 256-byte chunk present in the LDS ring (it holds staged_hi - 1 and staged_hi)
+    uint32_t P;                      // bit offset of the next unread bit, counted from base[0]
+};
+__device__ __forceinline__ uint32_t win_chunk(const Win &w, int c, int lane) {
+    const uint32_t at = (uint32_t)c * 64u;
+    return at < w.n_dwords + 192u ? w.base[(size_t)at + lane] : 0u;       // (beyond the block + padding: zeros, the decode ends in an error)
+}
+__device__ __forceinline__ void win_init(Win &w, uint32_t *in_ring, const unsigned char *in, uint32_t in_len, int lane) {
+    const uintptr_t a = (uintptr_t)in;
+    w.base = (const uint32_t *)(a & ~(uintptr_t)3);
+    const uint32_t skip = (uint32_t)(a & 3);
+    w.n_dwords = (skip + in_len + 3) / 4;
+    in_ring[lane] = win_chunk(w, 0, lane);
+    in_ring[64 + lane] = win_chunk(w, 1, lane);
+    w.nxt = win_chunk(w, 2, lane);
+    w.staged_hi = 1;
+    w.P = 8 * skip;
+}
+// chunks (P >> 11) and the one after it are in the ring (a window reaches at most 127 bits beyond P)
+__device__ __forceinline__ void win_ensure(Win &w, uint32_t *in_ring, int lane) {
+    const int c = (int)(w.P >> 11);
+    while (w.staged_hi < c + 1) {
+        w.staged_hi += 1;
+        in_ring[(w.staged_hi & 1) * 64 + lane] = w.nxt;
+        w.nxt = win_chunk(w, w.staged_hi + 1, lane);
+    }
+}
+// 64 bits of the stream from bit offset `at` (bit 0 = the first)
+__device__ __forceinline__ uint64_t win_bits(const uint32_t *in_ring, uint32_t at) {
+    const uint32_t d = at >> 5, sft = at & 31u;
+    const uint32_t w0 = in_ring[d & 127u], w1 = in_ring[(d + 1) & 127u], w2 = in_ring[(d + 2) & 127u];
+    const uint64_t lo = (uint64_t)w0 | ((uint64_t)w1 << 32);
+    return sft ? (lo >> sft) | ((uint64_t)w2 << (64 - sft)) : lo;
+}
+__device__ __forceinline__ uint64_t win_bits_uniform(const uint32_t *in_ring, uint32_t at) {
+    const uint64_t v = win_bits(in_ring, at);
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+// a wave-uniform reader on top of the window (headers, stored blocks, slow symbols): 64 bits at a time out of the ring
+struct UBits { uint64_t buf; int cnt; };
+__device__ __forceinline__ void ub_fill(UBits &u, const Win &w, const uint32_t *in_ring) { u.buf = win_bits_uniform(in_ring, w.P); u.cnt = 64; }
+__device__ __forceinline__ uint32_t ub_take(UBits &u, Win &w, uint32_t *in_ring, int n, int lane) {     // n <= 16
+    if (u.cnt < n) { win_ensure(w, in_ring, lane); ub_fill(u, w, in_ring); }
+    const uint32_t v = (uint32_t)(u.buf & ((1ull << n) - 1ull));
+    u.buf >>= n; u.cnt -= n; w.P += (uint32_t)n;
+    return v;
+}
+
+enum { K_LIT = 0, K_MATCH = 1, K_EOB = 2, K_SLOW = 3, K_BAD = 4 };
+
+// inclusive prefix sum over the 64 lanes through the register file: row_shr 1 / 2 / 4 / 8 inside the rows of 16, then lane 15 of a row to
+// the next row (row_bcast:15, rows 1 and 3) and lane 31 to the upper half (row_bcast:31, rows 2 and 3)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t crc32_words8(const uint32_t (&wd)[8]) {
+    uint32_t c = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        c ^= wd[k];
+        c = g_crc_tab[3][c & 255u] ^ g_crc_tab[2][(c >> 8) & 255u] ^ g_crc_tab[1][(c >> 16) & 255u] ^ g_crc_tab[0][c >> 24];
+    }
+    return ~c;
+}
+
+// PROF: clock64() laps per phase, summed per block into prof[block][8] (test switch front=inflate_prof: a measuring aid)
+enum { PH_HEADER = 0, PH_DECODE, PH_WALK, PH_LIT, PH_NEAR, PH_FAR, PH_FLUSH, PH_SLOW };
+template <bool PROF>
+__global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__restrict__ in, const BlockDesc *__restrict__ blocks, int n_blocks,
+                                                       unsigned char *__restrict__ out, CrcOp op, uint32_t *__restrict__ verdict,
+                                                       unsigned long long *__restrict__ prof) {
+    extern __shared__ unsigned char inf_lds_raw[];
+    InfLdsW &S = *reinterpret_cast<InfLdsW *>(inf_lds_raw);
+    const int lane = threadIdx.x;
+    const int bi = blockIdx.x;
+    if (bi >= n_blocks) return;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = PROF ? clock64() : 0ull, n_win = 0, n_far = 0, n_near = 0;
+    auto lap = [&](int k) { if (PROF) { const unsigned long long t = clock64(); ph[k] += t - t_last; t_last = t; } };
+    const BlockDesc B = blocks[bi];
+    unsigned char *dst = out + B.out_off;
+    uint32_t wpos = 0, fpos = 0, crc = 0;
+    int err = INF_OK;
+    // a full FLUSH leaves the ring: every lane stores its 32-byte piece (two 16-byte stores) and takes the piece's CRC-32 from the
+    // same eight registers (slice-by-4 tables, L1-resident); the pieces are joined as in the first form
+    auto flush_full = [&]() {
+        const uint32_t p0 = (fpos + (uint32_t)PIECE * lane) & RMASK;            // (32-byte aligned: fpos is a multiple of FLUSH)
+        uint32_t wd[8];
+        const uint4 a = *reinterpret_cast<const uint4 *>(&S.ring[p0]);
+        const uint4 b2 = *reinterpret_cast<const uint4 *>(&S.ring[p0 + 16]);
+        wd[0] = a.x; wd[1] = a.y; wd[2] = a.z; wd[3] = a.w; wd[4] = b2.x; wd[5] = b2.y; wd[6] = b2.z; wd[7] = b2.w;
+        unsigned char *g = dst + fpos + (uint32_t)PIECE * lane;
+        __builtin_memcpy(g, &a, 16);
+        __builtin_memcpy(g + 16, &b2, 16);
+        uint32_t mine = crc32_words8(wd);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const uint32_t other = (uint32_t)__shfl_down((int)mine, 1 << k, 64);
+            mine = crc_advance(op, k, mine) ^ other;
+        }
+        crc = crc_advance(op, 6, crc) ^ (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+        fpos += (uint32_t)FLUSH;
+    };
+    auto flush_rest = [&](uint32_t n) {        // the last n < FLUSH bytes
+        for (uint32_t i = lane; i < n; i += 64) dst[fpos + i] = S.ring[(fpos + i) & RMASK];
+        const uint32_t n_piece = (n + PIECE - 1) / PIECE;
+        uint32_t mine = 0;
+        if ((uint32_t)lane < n_piece) {
+            const uint32_t p0 = fpos + (uint32_t)PIECE * lane;
+            const int len = (int)min((uint32_t)PIECE, n - (uint32_t)PIECE * lane);
+            mine = crc_bytes(S.ring, p0, len);
+        }
+        S.crc_piece[lane] = mine;
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t p = 0; p < n_piece; ++p) {
+            const uint32_t len = min((uint32_t)PIECE, n - (uint32_t)PIECE * p);
+            if (len == (uint32_t)PIECE) crc = crc_advance(op, 0, crc);
+            else for (uint32_t k = 0; k < 8 * len; ++k) crc = (crc >> 1) ^ (0xEDB88320u & (0u - (crc & 1u)));
+            crc ^= S.crc_piece[p];
+        }
+        __builtin_amdgcn_wave_barrier();
+        fpos += n;
+    };
+    // `len` bytes at ring position `t` copied from `dist` bytes back (t, len, dist wave-uniform; the source lies before the target)
+    auto copy_match = [&](uint32_t t, uint32_t len, uint32_t dist) {
+        if (dist >= len && dist <= NEAR_MAX) {
+            for (uint32_t i = lane; i < len; i += 64) S.ring[(t + i) & RMASK] = S.ring[(t - dist + i) & RMASK];
+        } else if (dist == 1) {
+            const unsigned char v = S.ring[(t - 1) & RMASK];
+            for (uint32_t i = lane; i < len; i += 64) S.ring[(t + i) & RMASK] = v;
+        } else if (dist < len) {
+            const float rcp = __frcp_rn((float)dist);           // i mod dist without a division (see the first form)
+            for (uint32_t i = lane; i < len; i += 64) {
+                const uint32_t q = (uint32_t)(((float)i + 0.5f) * rcp);
+                S.ring[(t + i) & RMASK] = S.ring[(t - dist + (i - q * dist)) & RMASK];
+            }
+        } else {
+            // beyond the near part of the ring: those bytes left for memory long ago (NEAR_MAX > FLUSH + T_MAX + 258)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            for (uint32_t i = lane; i < len; i += 64) S.ring[(t + i) & RMASK] = __builtin_nontemporal_load(dst + (t - dist + i));
+        }
+    };
+    if (B.out_len > 0) {
+        Win w;
+        win_init(w, S.in_ring, in + B.in_off, B.in_len, lane);
+        const uint32_t end_bits = (uint32_t)(((uintptr_t)(in + B.in_off) & 3) + B.in_len) * 8u;
+        bool last = false;
+        while (!last && !err) {
+            UBits u;
+            win_ensure(w, S.in_ring, lane);
+            ub_fill(u, w, S.in_ring);
+            last = ub_take(u, w, S.in_ring, 1, lane) != 0;
+            const uint32_t type = ub_take(u, w, S.in_ring, 2, lane);
+            if (type == 0) {                                        // stored: the bytes straight from the input
+                w.P = (w.P + 7u) & ~7u;
+                win_ensure(w, S.in_ring, lane);
+                ub_fill(u, w, S.in_ring);
+                const uint32_t len = ub_take(u, w, S.in_ring, 16, lane), nlen = ub_take(u, w, S.in_ring, 16, lane);
+                if ((len ^ 0xFFFFu) != nlen) { err = INF_BAD_STORED; break; }
+                if (wpos + len > B.out_len) { err = INF_OVERRUN; break; }
+                if (w.P + 8u * len > end_bits) { err = INF_INPUT_END; break; }
+                const unsigned char *src = (const unsigned char *)w.base + (w.P >> 3);
+                for (uint32_t done = 0; done < len;) {
+                    const uint32_t n = min(len - done, (uint32_t)T_MAX);
+                    for (uint32_t i = lane; i < n; i += 64) S.ring[(wpos + i) & RMASK] = src[done + i];
+                    wpos += n;
+                    done += n;
+                    __builtin_amdgcn_wave_barrier();
+                    while (wpos - fpos >= (uint32_t)FLUSH) flush_full();
+                }
+                w.P += 8u * len;
+                continue;
+            }
+            if (type == 3) { err = INF_BAD_BLOCK_TYPE; break; }
+            if (type == 1) {                                        // fixed codes (RFC 1951, 3.2.6)
+                for (int s2 = lane; s2 < 288; s2 += 64) S.lens[s2] = (unsigned char)(s2 < 144 ? 8 : s2 < 256 ? 9 : s2 < 280 ? 7 : 8);
+                if (lane < 32) S.lens[288 + lane] = 5;
+                __builtin_amdgcn_wave_barrier();
+                if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens, 288, lane, false, true)) { err = INF_BAD_LENGTHS; break; }
+                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 288, 32, lane, true)) { err = INF_BAD_LENGTHS; break; }
+            } else {                                                // dynamic codes (3.2.7)
+                const int n_lit = (int)ub_take(u, w, S.in_ring, 5, lane) + 257;
+                const int n_dist = (int)ub_take(u, w, S.in_ring, 5, lane) + 1;
+                const int n_cl = (int)ub_take(u, w, S.in_ring, 4, lane) + 4;
+                if (n_lit > 286 || n_dist > 30) { err = INF_BAD_LENGTHS; break; }
+                if (lane < 19) S.lens[lane] = 0;
+                __builtin_amdgcn_wave_barrier();
+                for (int i = 0; i < n_cl; ++i) {
+                    const uint32_t v = ub_take(u, w, S.in_ring, 3, lane);
+                    if (lane == 0) S.lens[c_cl_order[i]] = (unsigned char)v;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens, 19, lane, false)) { err = INF_BAD_LENGTHS; break; }
+                int at = 0, prev = 0;
+                const int total = n_lit + n_dist;
+                while (at < total && !err) {
+                    if (u.cnt < 16) { win_ensure(w, S.in_ring, lane); ub_fill(u, w, S.in_ring); }
+                    const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.dist.pt[(uint32_t)u.buf & ((1u << DIST_P) - 1u)]);
+                    if (!(e & 15u)) { err = INF_BAD_CODE; break; }           // (the code-length code has at most 7 bits: always in the table)
+                    u.buf >>= (e & 15u); u.cnt -= (int)(e & 15u); w.P += (e & 15u);
+                    const int sym = (int)(e >> 4);
+                    int rep = 1, val = sym;
+                    if (sym == 16) { if (at == 0) { err = INF_BAD_LENGTHS; break; } rep = 3 + (int)ub_take(u, w, S.in_ring, 2, lane); val = prev; }
+                    else if (sym == 17) { rep = 3 + (int)ub_take(u, w, S.in_ring, 3, lane); val = 0; }
+                    else if (sym == 18) { rep = 11 + (int)ub_take(u, w, S.in_ring, 7, lane); val = 0; }
+                    if (at + rep > total) { err = INF_BAD_LENGTHS; break; }
+                    if (lane < rep) S.lens[32 + at + lane] = (unsigned char)val;
+                    if (lane + 64 < rep) S.lens[32 + at + lane + 64] = (unsigned char)val;
+                    if (lane + 128 < rep) S.lens[32 + at + lane + 128] = (unsigned char)val;
+                    at += rep;
+                    prev = val;
+                }
+                if (err) break;
+                __builtin_amdgcn_wave_barrier();
+                if (S.lens[32 + 256] == 0) { err = INF_BAD_LENGTHS; break; }
+                if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, n_lit, lane, false, true)) {
+                    // an incomplete literal/length code is legal only when it is ONE code of one bit (zlib's inflate_table)
+                    if (!huff_incomplete_ok(S.lens + 32, n_lit, lane, false) || !huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, n_lit, lane, true, true)) { err = INF_BAD_LENGTHS; break; }
+                }
+                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 32 + n_lit, n_dist, lane, false)) {
+                    if (!huff_incomplete_ok(S.lens + 32 + n_lit, n_dist, lane, true) || !huff_build<DistLds, DIST_P>(S.dist, S.lens + 32 + n_lit, n_dist, lane, true)) { err = INF_BAD_LENGTHS; break; }
+                }
+            }
+            // ---- the symbols of the block, a window of 64 bit offsets at a time ----------------------------------------------
+            bool eob = false;
+            lap(PH_HEADER);
+            while (!eob && !err) {
+                if (PROF) n_win++;
+                win_ensure(w, S.in_ring, lane);
+                const uint64_t bits = win_bits(S.in_ring, w.P + (uint32_t)lane);
+                // this lane's symbol, as if one started at its offset
+                uint32_t kind = K_SLOW, used = 0, olen = 0, val = 0, mdist = 0;
+                {
+                    const uint32_t e = S.lit.pt[(uint32_t)bits & ((1u << LIT_P) - 1u)];
+                    const uint32_t nb = e & 15u;
+                    if (nb) {
+                        const uint32_t sym = (e >> 4) & 0x1FFu;
+                        if (e & 0x8000u) { kind = K_LIT; used = nb; olen = 1; val = sym; }
+                        else if (sym == 256u) { kind = K_EOB; used = nb; }
+                        else if (sym <= 285u) {
+                            const uint32_t li = sym - 257u;
+                            const uint32_t le = li < 8u || li == 28u ? 0u : (li - 4u) >> 2;
+                            const uint32_t lbase = li < 8u ? 3u + li : li == 28u ? 258u : ((4u + (li & 3u)) << le) + 3u;
+                            const uint32_t len = lbase + ((uint32_t)(bits >> nb) & ((1u << le) - 1u));
+                            const uint32_t p1 = nb + le;
+                            const uint32_t ed = S.dist.pt[(uint32_t)(bits >> p1) & ((1u << DIST_P) - 1u)];
+                            const uint32_t dn = ed & 15u;
+                            if (dn) {
+                                const uint32_t ds = ed >> 4;
+                                if (ds < 30u) {
+                                    const uint32_t de = ds < 4u ? 0u : (ds >> 1) - 1u;
+                                    const uint32_t dbase = ds < 4u ? ds + 1u : ((2u + (ds & 1u)) << de) + 1u;
+                                    mdist = dbase + ((uint32_t)(bits >> (p1 + dn)) & ((1u << de) - 1u));
+                                    kind = K_MATCH; used = p1 + dn + de; olen = len;
+                                } else kind = K_BAD;
+                            }
+                        } else kind = K_BAD;
+                    }
+                }
+                const uint32_t r0 = used | (kind << 6) | (olen << 9) | (val << 18);     // used <= 48, kind < 8, olen <= 258, val < 256
+                if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (__builtin_amdgcn_readfirstlane((int)r0) == -1) err = INF_BAD_CODE; }
+                lap(PH_DECODE);
+                // ---- the chain: from offset 0, hop by the bits each symbol uses (scalar: a v_readlane and a handful of SALU
+                // instructions per symbol); the symbols on it then take their output offsets from a prefix sum over the lanes ----
+                uint32_t cur = 0, run = 0;
+                uint64_t m_chain = 0, m_match = 0;
+                bool slow = false;
+                while (cur < 64u) {
+                    const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)r0, (int)cur);
+                    const uint32_t k = (r >> 6) & 7u;
+                    if (k >= K_EOB) {
+                        if (k == K_SLOW) slow = true;
+                        else if (k == K_BAD) err = INF_BAD_CODE;
+                        else { eob = true; cur += r & 63u; }
+                        break;
+                    }
+                    const uint32_t ol = (r >> 9) & 511u;
+                    if (run + ol > (uint32_t)T_MAX) break;                  // the rest of the window starts the next one
+                    m_chain |= 1ull << cur;
+                    if (k == K_MATCH) m_match |= 1ull << cur;
+                    run += ol;
+                    cur += r & 63u;
+                }
+                const bool on_chain = (m_chain >> lane) & 1ull;
+                uint32_t my_off;
+                {   // exclusive prefix sum of the chain's output lengths over the lanes (six DPP adds in the register file; off the scalar path)
+                    const uint32_t own = on_chain ? olen : 0u;
+                    my_off = wave_incl_scan_u32(own) - own;
+                }
+                const uint64_t m_lit = m_chain & ~m_match;
+                if (err) break;
+                if (wpos + run > B.out_len) { err = INF_OVERRUN; break; }
+                lap(PH_WALK);
+                // ---- output: the literals at once, the matches in order ----
+                if ((m_lit >> lane) & 1ull) S.ring[(wpos + my_off) & RMASK] = (unsigned char)val;
+                lap(PH_LIT);
+                while (m_match) {
+                    const int ml = __builtin_ctzll(m_match);
+                    m_match &= m_match - 1;
+                    const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)r0, ml);
+                    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mdist, ml);
+                    const uint32_t t = wpos + (uint32_t)__builtin_amdgcn_readlane((int)my_off, ml);
+                    if (d > t) { err = INF_BAD_DIST; break; }
+                    copy_match(t, (r >> 9) & 511u, d);
+                    if (PROF) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        const bool far_ = !(d >= ((r >> 9) & 511u) && d <= NEAR_MAX) && d != 1 && !(d < ((r >> 9) & 511u));
+                        if (far_) n_far++; else n_near++;
+                        lap(far_ ? PH_FAR : PH_NEAR);
+                    }
+                }
+                if (err) break;
+                wpos += run;
+                w.P += cur;
+                if (slow) {
+                    // a symbol outside the tables' fast cases -- a code longer than the index bits, mostly: the wave-uniform path, one symbol
+                    win_ensure(w, S.in_ring, lane);
+                    ub_fill(u, w, S.in_ring);
+                    int sym;
+                    {
+                        const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.lit.pt[(uint32_t)u.buf & ((1u << LIT_P) - 1u)]);
+                        if (e & 15u) { sym = (int)((e >> 4) & 0x1FFu); u.buf >>= (e & 15u); u.cnt -= (int)(e & 15u); w.P += (e & 15u); }
+                        else {
+                            sym = -1;
+                            const uint32_t rev15 = __brev((uint32_t)u.buf & 0x7FFFu) >> 17;
+                            for (int L = LIT_P + 1; L <= 15; ++L) {
+                                const uint32_t c = rev15 >> (15 - L);
+                                const uint32_t dd = c - S.lit.first[L];
+                                if (dd < S.lit.count[L]) { sym = S.lit.sorted[S.lit.offs[L] + dd]; u.buf >>= L; u.cnt -= L; w.P += (uint32_t)L; break; }
+                            }
+                            sym = __builtin_amdgcn_readfirstlane(sym);
+                        }
+                    }
+                    if (sym < 0) { err = INF_BAD_CODE; break; }
+                    if (sym < 256) {
+                        if (wpos + 1 > B.out_len) { err = INF_OVERRUN; break; }
+                        if (lane == 0) S.ring[wpos & RMASK] = (unsigned char)sym;
+                        wpos += 1;
+                    } else if (sym == 256) eob = true;
+                    else {
+                        const int li = sym - 257;
+                        if (li >= 29) { err = INF_BAD_CODE; break; }
+                        const int le = li < 8 || li == 28 ? 0 : (li - 4) >> 2;
+                        const uint32_t lbase = li < 8 ? 3u + (uint32_t)li : li == 28 ? 258u : ((4u + ((uint32_t)li & 3u)) << le) + 3u;
+                        const uint32_t len = lbase + ub_take(u, w, S.in_ring, le, lane);
+                        if (u.cnt < 32) { win_ensure(w, S.in_ring, lane); ub_fill(u, w, S.in_ring); }
+                        int ds;
+                        {
+                            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.dist.pt[(uint32_t)u.buf & ((1u << DIST_P) - 1u)]);
+                            if (e & 15u) { ds = (int)(e >> 4); u.buf >>= (e & 15u); u.cnt -= (int)(e & 15u); w.P += (e & 15u); }
+                            else {
+                                ds = -1;
+                                const uint32_t rev15 = __brev((uint32_t)u.buf & 0x7FFFu) >> 17;
+                                for (int L = DIST_P + 1; L <= 15; ++L) {
+                                    const uint32_t c = rev15 >> (15 - L);
+                                    const uint32_t dd = c - S.dist.first[L];
+                                    if (dd < S.dist.count[L]) { ds = S.dist.sorted[S.dist.offs[L] + dd]; u.buf >>= L; u.cnt -= L; w.P += (uint32_t)L; break; }
+                                }
+                                ds = __builtin_amdgcn_readfirstlane(ds);
+                            }
+                        }
+                        if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
+                        const int de = ds < 4 ? 0 : (ds >> 1) - 1;
+                        const uint32_t dbase = ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << de) + 1u;
+                        const uint32_t dist = dbase + ub_take(u, w, S.in_ring, de, lane);
+                        if (dist > wpos) { err = INF_BAD_DIST; break; }
+                        if (wpos + len > B.out_len) { err = INF_OVERRUN; break; }
+                        copy_match(wpos, len, dist);
+                        wpos += len;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                lap(PH_SLOW);
+                while (wpos - fpos >= (uint32_t)FLUSH) flush_full();
+                if (PROF) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                lap(PH_FLUSH);
+            }
+            if (!err && w.P > end_bits) err = INF_INPUT_END;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (!err) {
+            if (wpos != B.out_len) err = INF_BAD_SIZE;
+            else {
+                while (wpos - fpos >= (uint32_t)FLUSH) flush_full();
+                if (wpos > fpos) flush_rest(wpos - fpos);
+                if (crc != B.crc) err = INF_BAD_CRC;
+            }
+        }
+    } else if (B.crc != 0) err = INF_BAD_CRC;
+    if (lane == 0) verdict[bi] = (uint32_t)err;
+    if (PROF && lane == 0) {
+        for (int k = 0; k < 8; ++k) prof[(size_t)bi * 12 + k] = ph[k];
+        prof[(size_t)bi * 12 + 8] = n_win; prof[(size_t)bi * 12 + 9] = n_near; prof[(size_t)bi * 12 + 10] = n_far; prof[(size_t)bi * 12 + 11] = B.out_len;
+    }
+}
+
+
+int inflate_w_setup() {                  // once per device: the CRC-32 slice tables in device memory, the kernel's LDS size
+    uint32_t tab[4][256];
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+        tab[0][i] = c;
+    }
+    for (int t = 1; t < 4; ++t)
+        for (uint32_t i = 0; i < 256; ++i) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 255u];
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_crc_tab), tab, sizeof(tab)));
+    HIPCHK(hipFuncSetAttribute((const void *)k_bgzf_inflate_w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InfLdsW)));
+    HIPCHK(hipFuncSetAttribute((const void *)k_bgzf_inflate_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InfLdsW)));
+    return HGX_OK;
+}
+
 CrcOp make_crc_op() {
     CrcOp op;
     for (int lv = 0; lv < 7; ++lv)
@@ -456,7 +925,7 @@ int hgx_bgzf_scan(const unsigned char *data, size_t n, std::vector<hgx_bgzf_bloc
         long bsize = -1;
         for (size_t p = off + 12; p + 4 <= off + 12 + xlen;) {
             const unsigned slen = rd16(p + 2);
-            if (data[p] == 66 && data[p + 1] == 67 && slen == 2) bsize = (long)rd16(p + 4);
+            if (data[p] == 66 && data[p + 1] == 67 && slen == 2 && p + 6 <= off + 12 + xlen) bsize = (long)rd16(p + 4);
             p += 4 + slen;
         }
         if (bsize < 0) { hgx_set_error("BGZF block without BC subfield at offset %zu", off); return HGX_EPARSE; }
@@ -499,8 +968,28 @@ int hgx_bgzf_inflate_dev(const unsigned char *d_in, const hgx_bgzf_block *blocks
     HIPCHK(hipMemcpyAsync(b_desc.p, h.data(), n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(b_verdict.p, 0xFF, n_blocks * 4, st));
     static const CrcOp op = make_crc_op();
-    HGX_ONCE_PER_DEVICE(HIPCHK(hipFuncSetAttribute((const void *)k_bgzf_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InfLds))));
-    k_bgzf_inflate<<<(unsigned)n_blocks, 64, sizeof(InfLds), st>>>(d_in, b_desc.as<BlockDesc>(), (int)n_blocks, d_out, op, b_verdict.as<uint32_t>());
+    HGX_ONCE_PER_DEVICE({ const int rc_ = inflate_w_setup(); if (rc_) return rc_; });
+    if (hgx_switch_has("front", "inflate_v1")) {                    // round 4's form: one symbol per trip (kept as the comparison form)
+        HGX_ONCE_PER_DEVICE(HIPCHK(hipFuncSetAttribute((const void *)k_bgzf_inflate, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InfLds))));
+        k_bgzf_inflate<<<(unsigned)n_blocks, 64, sizeof(InfLds), st>>>(d_in, b_desc.as<BlockDesc>(), (int)n_blocks, d_out, op, b_verdict.as<uint32_t>());
+    } else if (hgx_switch_has("front", "inflate_prof")) {           // the lane-parallel form with clock64 laps per phase (a measuring aid)
+        DevBuf b_prof;
+        ALLOC(b_prof, n_blocks * 12 * 8);
+        HIPCHK(hipMemsetAsync(b_prof.p, 0, n_blocks * 12 * 8, st));
+        k_bgzf_inflate_w<true><<<(unsigned)n_blocks, 64, sizeof(InfLdsW), st>>>(d_in, b_desc.as<BlockDesc>(), (int)n_blocks, d_out, op, b_verdict.as<uint32_t>(),
+                                                                                b_prof.as<unsigned long long>());
+        std::vector<unsigned long long> hp(n_blocks * 12);
+        HIPCHK(hipMemcpyAsync(hp.data(), b_prof.p, hp.size() * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double tot[12] = {0};
+        for (size_t i = 0; i < n_blocks; ++i) for (int k = 0; k < 12; ++k) tot[k] += (double)hp[i * 12 + k];
+        static const char *const nm[8] = {"header", "decode", "walk", "literals", "near matches", "far matches", "flush", "slow"};
+        fprintf(stderr, "[k_bgzf_inflate_w] %zu blocks, per block: %.0f bytes, %.0f windows, %.0f near + %.0f far matches; clock64 ticks per block:", n_blocks,
+                tot[11] / n_blocks, tot[8] / n_blocks, tot[9] / n_blocks, tot[10] / n_blocks);
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.0f", nm[k], tot[k] / n_blocks);
+        fprintf(stderr, "\n");
+    } else
+        k_bgzf_inflate_w<false><<<(unsigned)n_blocks, 64, sizeof(InfLdsW), st>>>(d_in, b_desc.as<BlockDesc>(), (int)n_blocks, d_out, op, b_verdict.as<uint32_t>(), nullptr);
     HIPCHK(hipGetLastError());
     std::vector<uint32_t> v(n_blocks);
     HIPCHK(hipMemcpyAsync(v.data(), b_verdict.p, n_blocks * 4, hipMemcpyDeviceToHost, st));

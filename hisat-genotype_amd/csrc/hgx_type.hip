@@ -109,7 +109,17 @@ int acquire_streams(StreamSet &s) {
     HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
     s.dev = dev;
     HIPCHK(hipStreamCreateWithPriority(&s.em, hipStreamNonBlocking, greatest));
-    HIPCHK(hipStreamCreateWithPriority(&s.gene, hipStreamNonBlocking, least));
+    // The gene side's chip-filling kernels (k_pair_classes_x2, k_verify_ht) run beside the EM chain of the exon level; a 1 024-thread
+    // workgroup of an EM pass is only placed on a CU that has sixteen free wave slots and 135 KB of LDS, so with the gene side free to
+    // take every CU the first EM passes wait for it to drain.  HGX_GENE_CUS=n confines the gene-side stream to n CUs (CU mask).
+    const char *gcu = getenv("HGX_GENE_CUS");
+    const int n_gene_cus = gcu ? atoi(gcu) : 0;
+    if (n_gene_cus > 0 && n_gene_cus < 256) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < n_gene_cus; ++b) mask[b >> 5] |= 1u << (b & 31);
+        HIPCHK(hipExtStreamCreateWithCUMask(&s.gene, 8, mask));
+    } else
+        HIPCHK(hipStreamCreateWithPriority(&s.gene, hipStreamNonBlocking, least));
     HIPCHK(hipEventCreateWithFlags(&s.fork, hipEventDisableTiming));
     return HGX_OK;
 }

@@ -16,6 +16,17 @@ pytestmark = pytest.mark.gpu
 EOF_BLOCK = bamio._BGZF_EOF
 
 
+@pytest.fixture(autouse=True, params=[None, "inflate_v1"], ids=["lane_parallel", "round4"])
+def inflate_form(request):
+    """Every test with both forms of the device inflate the library holds: the default (k_bgzf_inflate_w: the symbol loop lane-parallel,
+    64 bit offsets per window) and round 4's one-symbol-per-trip kernel (k_bgzf_inflate, test switch front=inflate_v1)."""
+    from hisatgenotype_amd import engine
+    if request.param:
+        engine.test_switch("front", request.param)
+    yield request.param
+    engine.test_switch("front", None)
+
+
 def bgzf(payload, level=6, strategy=zlib.Z_DEFAULT_STRATEGY, block=0xff00, eof=True):
     out = bytearray()
     for i in range(0, max(len(payload), 1), block):

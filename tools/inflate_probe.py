@@ -9,15 +9,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if sys.argv[1] == "show":
     by = {}
     for r in csv.DictReader(open(sys.argv[2])):
-        if "k_bgzf_inflate" in r["Kernel_Name"]:
-            by.setdefault(int(r["Grid_Size_X"]) // 64, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-    for nb, ts in sorted(by.items()):
-        print("%6d BGZF blocks: %d launches, median %.3f ms, min %.3f ms" % (nb, len(ts), sorted(ts)[len(ts) // 2], min(ts)))
+        if "k_bgzf_" in r["Kernel_Name"]:
+            by.setdefault((r["Kernel_Name"].split("(")[0].split("::")[-1], int(r["Grid_Size_X"]) // 64), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
+    for (kn, nb), ts in sorted(by.items()):
+        print("%-18s %6d BGZF blocks: %d launches, median %.3f ms, min %.3f ms" % (kn, nb, len(ts), sorted(ts)[len(ts) // 2], min(ts)))
     sys.exit(0)
 import numpy as np
 from hisatgenotype_amd import bamio, capi, synth
 if os.environ.get("INF_LIB"):
     capi.LIB_PATH = os.environ["INF_LIB"]
+if os.environ.get("INF_FORM"):                     # inflate_v1 = round 4's kernel, inflate_prof = the default kernel with clock64 laps per phase
+    from hisatgenotype_amd import engine
+    engine.test_switch("front", os.environ["INF_FORM"])
 loc = synth.make_hla_like_locus(gene="A", n_alleles=7000, length=3500, n_vars=2500, seed=500)
 d = tempfile.mkdtemp(prefix="hgx_inf_", dir="/dev/shm")
 try:
