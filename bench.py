@@ -381,7 +381,7 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
                                       "note": ("bytes the call sends to the device (the SAM text + its line table) / the call's time, against the measured "
                                                "host-to-device rate of registered memory (tools/pinned_probe.hip: 57.5 GB/s; PCIe Gen5 x16)") if kind == "sam" else
                                               ("a BAM travels DEFLATED (the file's bytes + a block table): the link is idle; the call is bound by "
-                                               "k_bgzf_inflate -- sequential symbol decoding, one wavefront per BGZF block, ~80 GB/s of payload -- and "
+                                               "k_bgzf_inflate_w -- DEFLATE symbol decoding, one wavefront per BGZF block, ~95 GB/s of payload -- and "
                                                "the record kernels behind it (DESIGN.md section 5.6)")},
                          "runs_ms": [round(t * 1e3, 1) for t in spaced],
                          "throttled_ms": None if th1 is None else round((th2 - th1) / 1e3, 1),
@@ -391,6 +391,14 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
                                           "throttled_ms": None if th0 is None else round((th1 - th0) / 1e3, 1)},
                          "file_MB": round(os.path.getsize(path) / 1e6, 1),
                          "records_in_file": n_records, "result_identical_to_hbm_path": bool(same)}
+            if kind == "bam":
+                # the like-for-like CPU figure of a file -> result call: the HOST front end (csrc/hgx_sam.cpp + hgx_bam.cpp: read, inflate,
+                # walk, sort, decode -- what the device front end is checked against) on ONE thread over the same file; the scoring +
+                # EM part is the C oracle's (cpu_baseline: a bounded sample, its rate is applied to this file's reads by the caller)
+                t0 = time.perf_counter()
+                hb = pl.parse_alignment_file(path, regions=[pl.ref_allele], n_threads=1)
+                out[kind]["host_front_end_one_thread_s"] = round(time.perf_counter() - t0, 3)
+                del hb
     finally:
         import shutil
         shutil.rmtree(d, ignore_errors=True)
@@ -1225,6 +1233,32 @@ def main():
                     traffic = tj["hbm_bytes_per_launch"].get(dom)
             except Exception:
                 traffic = None
+        # ---- the whole step against the roofline: algorithmic bytes of everything a step runs / its wall time ----
+        # scoring: piece compat + the gene-level per-pair launch (above) + the exon level per DISTINCT ref list (rows read per ref, one
+        # class row + hash written per group); dedup: every row hashed / inserted once and read once more by the exact verify, at both
+        # levels; Gene_counts: the gene class matrix once; EM: every executed mat-vec pass streams its compact bit matrix + vectors
+        n_exon_refs = batch.n_refs - n_gene_refs
+        try:
+            n_exon_groups = engine.Groups(db, 0).n_groups
+        except Exception:
+            n_exon_groups = batch.n_pairs
+        exon_bytes = n_exon_refs * row // max(batch.n_pairs // max(n_exon_groups, 1), 1) + n_exon_groups * (row + 12)
+        dedup_bytes = 2 * batch.n_pairs * (row + 8) + 2 * n_exon_groups * (row + 8)
+        n_gene_cls = res.em[1]["n_classes"] if len(res.em) > 1 else 0
+        em_bytes = sum(by / max(min(N_TIMED_STEPS, args.steps), 1) for (_ms, _n, _ex, by) in em_timing.values())
+        step_alg_bytes = int(cp_bytes + pc_bytes + exon_bytes + dedup_bytes + em_bytes)
+        ms_step = elapsed / args.steps * 1e3
+        step_profile = None
+        sp = os.path.join(ROOT, "profiles", "step_profile.json")   # tools/step_profile.py over the rocprofv3 kernel trace of this command
+        if os.path.exists(sp):
+            try:
+                sj = json.load(open(sp))
+                if sj.get("n_pairs") == batch.n_pairs and sj.get("a_pad") == pl.a_pad:
+                    step_profile = sj["per_step"]
+                    step_profile["source"] = sj["source"]
+            except Exception:
+                step_profile = None
+        cl_jobs, cl_fallbacks = engine.emx_cluster_stats()
         out = {
             "metric": "typed reads/sec at HLA-A (~7k alleles, 2x150bp)",
             "value": round(total_reads * args.steps / elapsed, 1),
@@ -1264,6 +1298,13 @@ def main():
                 "note": "kernel with the largest aggregate time per step; averages are over ALL its launches in the timed region "
                         "(incl. the tiny EM #2 problem and launches that exit at the convergence gate), as rocprofv3 --stats reports them",
                 "kernels": kernels,
+                # the step as a whole: how far from the machine, and where the rest goes
+                "step_alg_bytes": step_alg_bytes,
+                "step_frac": round(step_alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "step_alg_bytes_parts": {"piece_compat": int(cp_bytes), "pair_classes_gene": int(pc_bytes), "pair_classes_exon": int(exon_bytes),
+                                         "dedup_both_levels": int(dedup_bytes), "em_passes": int(em_bytes)},
+                "step_profile": step_profile,      # dispatches / kernel time / gaps per step, from the committed kernel trace of this command
+                "emx_cluster_problems": cl_jobs, "emx_cluster_fallbacks": cl_fallbacks,
             },
         }
         if pre is not None:
@@ -1275,6 +1316,15 @@ def main():
                 out["e2e"] = end_to_end(pl, loc, sam_keep, res)
             cb, _ = cpu_baseline(loc, sam_keep, min(args.cpu_pairs, batch.n_pairs))
             out["cpu_baseline"] = cb
+            t_fe = (out.get("e2e") or {}).get("bam", {}).get("host_front_end_one_thread_s")
+            if t_fe:
+                t_cpu = t_fe + batch.n_reads / cb["value"]
+                out["e2e"]["cpu_baseline"] = {
+                    "value": round(batch.n_reads / t_cpu, 1), "unit": "reads/s", "cores": 1, "kind": "port",
+                    "sample": "the same BAM file: host front end (read, inflate, walk, sort, decode; libhgx's C++ host stages, n_threads = 1) %.2f s "
+                              "measured on the whole file + scoring / dedup / EM at the C oracle's rate (cpu_baseline: %.0f reads/s on its bounded "
+                              "sample) = %.1f s for %d reads" % (t_fe, cb["value"], t_cpu, batch.n_reads),
+                    "gpu_over_cpu": {k: round((batch.n_reads / (out["e2e"][k]["ms"] * 1e-3)) / (batch.n_reads / t_cpu), 1) for k in ("sam", "bam")}}
     # ---- the other BASELINE.json workloads, driver-timed in the same run: configs[2] (class1) and configs[3] (panel64) --------
     if not args.no_workloads and (world == 1 or args.workloads):
         del batch, db
