@@ -72,7 +72,7 @@ SYMBOLS = [
     "hgx_bgzf_inflate", "hgx_many_create", "hgx_many_create_files", "hgx_many_create_sams", "hgx_many_tasks", "hgx_many_destroy", "hgx_many_dims", "hgx_type_many", "hgx_type_many_loci", "hgx_em_set_fast", "hgx_em_last_order", "hgx_typing_top", "hgx_emx_set_timing", "hgx_emx_get_timing",
     "hgx_index_broadcast", "hgx_allreduce_sum_u32", "hgx_allreduce_sum_i64", "hgx_classes_allgather",
     "hgx_parse_sam_dev", "hgx_parse_alignment_file_dev", "hgx_front_last", "hgx_dbatch_to_host",
-    "hgx_emx_cluster_stats",
+    "hgx_emx_cluster_stats", "hgx_em_tie_reruns",
 ]
 
 _lib = None

@@ -703,6 +703,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         }
         const int rc = bgzf_inflate(data, n_threads, raw, part);
         if (rc) return rc;
+        if (out.comp_sync) out.comp_sync();                    // (an upload of these bytes begun by comp_early may still be reading them)
         data.release();
     } else raw.swap(data);
     lap("inflate");

@@ -1576,6 +1576,8 @@ extern "C" int hgx_em_get_timing(int slot, double *ms_total, int64_t *launches, 
 
 static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len, double *prob_host,
                    int32_t *first_host, int32_t *n_iter_host, void *stream);
+static int em_impl_inner(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len, double *prob_host,
+                         int32_t *first_host, int32_t *n_iter_host, void *stream);
 __global__ void k_first_set_rows(const uint64_t *BT, int n_rows, int c64, int32_t *first);
 
 extern "C" int hgx_em(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len,
@@ -1591,8 +1593,64 @@ extern "C" int hgx_em_ordered(const hgx_classes *cc, int32_t n_alleles, int32_t 
     return rc;
 }
 
+// ---- near-ties of the table-lookup path -------------------------------------------------------------------------
+// The reference ranks with a plain stable sort on its own doubles: two alleles whose abundances differ in the last bit are ordered by
+// that bit.  The large-problem path is good to ~1e-11 (bound 1e-9): where two alleles of the result with DIFFERENT class membership
+// come out closer than EM_NEAR_REL, their order in the reference cannot be told from these values -- the EM is run again in the
+// reference's own order of operations (k_emx at any size, a lone big problem in cluster mode: bit-identical abundances, ~15x the
+// time; rare: alleles the data cannot tell apart have identical columns and are exact ties on both paths, and distinct columns
+// agreeing to eight digits takes a symmetric construction), and that result is returned as exact.
+constexpr double EM_NEAR_REL = 1e-8;
+static std::atomic<long long> g_tie_reruns{0};
+extern "C" long long hgx_em_tie_reruns(void) { return g_tie_reruns.load(); }
+
+static int em_uncertain_near_tie(hgx_classes *c, int32_t n_alleles, const double *prob, hipStream_t st, bool *uncertain) {
+    *uncertain = false;
+    std::vector<int32_t> al;
+    for (int32_t a = 0; a < n_alleles; ++a) if (prob[a] > 0.0) al.push_back(a);
+    std::sort(al.begin(), al.end(), [&](int32_t x, int32_t y) { return prob[x] > prob[y]; });
+    std::vector<std::pair<int32_t, int32_t>> pairs;
+    for (size_t i = 0; i + 1 < al.size(); ++i) {
+        const double hi = prob[al[i]], lo = prob[al[i + 1]];
+        if (hi != lo && hi - lo <= EM_NEAR_REL * hi) pairs.emplace_back(al[i], al[i + 1]);
+    }
+    if (pairs.empty()) return HGX_OK;
+    if (pairs.size() > 4096) { *uncertain = true; return HGX_OK; }         // (never seen; the exact run settles it either way)
+    int rc = hgx_ensure_transposed(c, st);
+    if (rc) return rc;
+    const size_t row = (size_t)c->c64 * 8;
+    std::vector<uint64_t> ra((size_t)c->c64), rb((size_t)c->c64);
+    for (auto &pr : pairs) {
+        rc = hgx_d2h(ra.data(), (const char *)c->d_bitsT + (size_t)pr.first * row, row, st);
+        if (!rc) rc = hgx_d2h(rb.data(), (const char *)c->d_bitsT + (size_t)pr.second * row, row, st);
+        if (!rc) rc = hgx_sync(st);
+        if (rc) return rc;
+        if (ra != rb) { *uncertain = true; return HGX_OK; }                // different membership, abundances too close to call
+    }
+    return HGX_OK;
+}
+
 static int em_impl(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len, double *prob_host,
                    int32_t *first_host, int32_t *n_iter_host, void *stream) {
+    int rc = em_impl_inner(cc, n_alleles, remove_low, allele_len, prob_host, first_host, n_iter_host, stream);
+    if (rc || g_last_exact || g_em_fast != 0) return rc;                    // (exact already, or the caller chose the arithmetic)
+    hgx_classes *c = const_cast<hgx_classes *>(cc);
+    if (!c->h_rank || c->n_classes > HGX_EMX_HARD_MAX_CLASSES || c->w64 > 128 || hgx_switch_has("em_skip", "exact") ||
+        hgx_switch_has("em_skip", "emx") || hgx_switch_has("em_skip", "tie_rerun"))
+        return rc;                                                          // (the reference's order is not available for this problem)
+    bool uncertain = false;
+    rc = em_uncertain_near_tie(c, n_alleles, prob_host, (hipStream_t)stream, &uncertain);
+    if (rc || !uncertain) return rc;
+    g_tie_reruns.fetch_add(1);
+    const int old = g_em_fast;
+    g_em_fast = -1;
+    rc = em_impl_inner(cc, n_alleles, remove_low, allele_len, prob_host, first_host, n_iter_host, stream);
+    g_em_fast = old;
+    return rc;
+}
+
+static int em_impl_inner(const hgx_classes *cc, int32_t n_alleles, int32_t remove_low, const int32_t *allele_len, double *prob_host,
+                         int32_t *first_host, int32_t *n_iter_host, void *stream) {
     ARGCHK(cc && prob_host && n_alleles > 0 && n_alleles <= cc->a_pad);
     g_last_exact = 0;
     g_last_order.clear();

@@ -1525,6 +1525,14 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
     // record route: the reader's bytes go up as soon as they are complete (SAM text read / BAM stream inflated), while the host
     // still walks and name-sorts the records
     DevBuf b_text, b_comp;
+    size_t text_cap = 0;                  // bytes b_text holds (a second read of a file that changed meanwhile may ask for more)
+    auto text_room = [&](size_t need) -> bool {        // true = b_text can take `need` bytes (drained and re-allocated if it could not)
+        if (b_text.p && need <= text_cap) return true;
+        if (b_text.p) { (void)hipStreamSynchronize(st); hgx_pool_free(b_text.p); b_text.p = nullptr; text_cap = 0; }
+        if (b_text.alloc(need)) return false;
+        text_cap = need;
+        return true;
+    };
     const char *up_raw = nullptr;
     const unsigned char *comp_from = nullptr;
     size_t up_bytes = 0, comp_n = 0;
@@ -1532,7 +1540,7 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
     if (!host_only && !no_records && !(opts->codis_choose_pairs || opts->interdist_exchange)) {
         hook.on_raw = [&](const char *raw, size_t n_bytes, size_t begin, size_t end) {
             if (n_bytes >= (1ull << 32) - 64 || up_failed) return;
-            if (!b_text.p && b_text.alloc(n_bytes + 64)) { up_failed = true; return; }
+            if (!text_room(n_bytes + 64)) { up_failed = true; return; }
             if (end > begin && hipMemcpyAsync((char *)b_text.p + begin, raw + begin, end - begin, hipMemcpyHostToDevice, st) != hipSuccess) { up_failed = true; return; }
             up_raw = raw;
             up_bytes = n_bytes;
@@ -1551,9 +1559,10 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
                     hipMemsetAsync((char *)b_comp.p + n, 0, 2048, st) != hipSuccess) { up_failed = true; return; }
                 comp_from = data; comp_n = n;
             };
+            hook.comp_sync = [&]() { if (comp_from) (void)hipStreamSynchronize(st); };
             hook.inflate_dev = [&](const unsigned char *data, size_t n, const std::vector<hgx_bgzf_block> &blocks, size_t total) -> int {
                 if (up_failed || total >= (1ull << 32) - 64) return 1;
-                if (!b_text.p && b_text.alloc(total + 64)) return 1;
+                if (!text_room(total + 64)) return 1;
                 struct DrainC { hipStream_t s; ~DrainC() { (void)hipStreamSynchronize(s); } } drain_c{st};
                 if (comp_from != data || comp_n != n) {
                     if (b_comp.p) { (void)hipStreamSynchronize(st); hgx_pool_free(b_comp.p); b_comp.p = nullptr; }

@@ -207,6 +207,8 @@ struct hgx_align_lines {
     // in, optional: called with the file's bytes as soon as they are read and look like BGZF -- the caller may start sending them
     // while the host still hops through the container and inflates the header (inflate_dev then finds them on their way)
     std::function<void(const unsigned char *data, size_t n)> comp_early;
+    // in, optional: called before the reader gives the file's bytes back when comp_early has seen them (its copy must be complete)
+    std::function<void()> comp_sync;
     hgx_align_lines() = default;
     hgx_align_lines(const hgx_align_lines &) = delete;
     hgx_align_lines &operator=(const hgx_align_lines &) = delete;
@@ -310,6 +312,7 @@ struct hgx_front_hook {
     size_t defer_min_bytes = 0;
     std::function<int(const unsigned char *data, size_t n, const std::vector<hgx_bgzf_block> &blocks, size_t total)> inflate_dev;   // ... and deflated ones
     std::function<void(const unsigned char *data, size_t n)> comp_early;             // (the deflated bytes, before the container is looked at)
+    std::function<void()> comp_sync;                                                 // (... and the wait for that copy, before the bytes are released)
     std::function<void(const char *raw, size_t n_bytes, size_t begin, size_t end)> on_raw;
     int declined_records = 0;
 };

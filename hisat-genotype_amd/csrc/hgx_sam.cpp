@@ -1816,7 +1816,7 @@ int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *Lc, const ch
             al.on_raw = hook->on_raw;
             al.defer_walk = hook->defer_walk && !(opts->codis_choose_pairs || opts->interdist_exchange);
             al.defer_min_bytes = hook->defer_min_bytes;
-            if (al.defer_walk) { al.inflate_dev = hook->inflate_dev; al.comp_early = hook->comp_early; }
+            if (al.defer_walk) { al.inflate_dev = hook->inflate_dev; al.comp_early = hook->comp_early; al.comp_sync = hook->comp_sync; }
         }
         int rc = hgx_read_alignment_lines(path, regions, opts->n_threads, al, /*keep_binary=*/true);
         pinned.reset();

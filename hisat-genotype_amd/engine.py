@@ -116,6 +116,14 @@ def emx_cluster_stats():
     return a.value, b.value
 
 
+def em_tie_reruns():
+    """EM calls whose table-lookup result held a near-tie it could not order (two alleles of different class membership closer than 1e-8
+    relative) and was recomputed in the reference's own order of operations, since the library was loaded (hgx_em_tie_reruns)."""
+    f = capi.lib().hgx_em_tie_reruns
+    f.restype = C.c_longlong
+    return int(f())
+
+
 def em_set_fast(on):
     """Arithmetic of Classes.em / em_ordered on this thread for problems the one-workgroup kernel takes: False = the reference's own
     order of operations (default, bit-identical), True = table lookups (~5x faster, within rounding).  Returns the old setting."""

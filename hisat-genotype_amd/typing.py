@@ -115,7 +115,7 @@ def _em_mode(em_fast):
     table lookups, -1 = the reference's order at every size (validation mode: slow beyond 4096 classes)."""
     if em_fast is None:
         return 0
-    if em_fast is False:
+    if em_fast is False or (em_fast is not True and int(em_fast) == 0):      # False, 0, numpy.bool_(False): all mean "the reference's order"
         return 2
     return -1 if (em_fast is not True and int(em_fast) < 0) else (1 if (em_fast is True or int(em_fast) == 1) else int(em_fast))
 

@@ -578,6 +578,10 @@ int hgx_emx_get_timing(int fast, double *ms_total, long long *launches, long lon
  * is re-run on one workgroup -- same sums in the same orders, same bits, ~7x slower.  Counts since the library was loaded: problems
  * launched on a cluster, and those that fell back (also said on stderr under HGX_TYPE_PROFILE). */
 int hgx_emx_cluster_stats(long long *cluster_problems, long long *fallbacks);
+/* hgx_em / hgx_em_ordered calls (default arithmetic) whose table-lookup result held two alleles of DIFFERENT class membership closer
+ * than 1e-8 relative and was therefore recomputed in the reference's own order of operations (common:1282-1410: a plain stable
+ * sort on the reference's own doubles decides such an order), since the library was loaded.                                    */
+long long hgx_em_tie_reruns(void);
 int hgx_em_get_timing(int slot, double *ms_total, int64_t *launches, int64_t *executed, int64_t *bytes_total);
 
 #ifdef __cplusplus

@@ -279,3 +279,62 @@ def test_cluster_fallback_is_counted_and_still_the_reference(orc):
         print("cluster problems beside a busy chip: %d, fell back: %d" % (j3 - j2, f3 - f2))
     finally:
         engine.em_set_fast(old)
+
+
+@pytest.mark.parametrize("delta", [1, 10, 100, 100000])
+def test_near_tie_beyond_the_gate_is_ordered_as_the_reference_orders_it(orc, delta):
+    """VERDICT r4 #8.  More than 4 096 classes: by default the chip-wide table-lookup EM (good to ~1e-11), whose results used to be
+    ranked with a 1e-11 relative tie tolerance.  Two alleles X and Y with DIFFERENT class membership whose reference abundances differ
+    by `delta` x 1e-12 relative: a class {X} counted 10^12 times and a class {Y} counted 10^12 + delta times on top of a random problem
+    (counts are exact in a double).  X comes first in dict order, Y has the larger abundance: the reference -- a plain stable sort on
+    its own doubles (common:1405-1410) -- prints Y first; a tolerance that calls them tied prints X first.  The library now recognises
+    the near-tie it cannot order (different columns, values closer than 1e-8) and recomputes that EM in the reference's own order of
+    operations: order AND abundances `==` the C oracle, the re-run is counted; with em_fast = -1 the same without a re-run.  A pair
+    that is 1e-7 apart (delta 100 000) is ordered by the table-lookup values themselves: no re-run."""
+    A, n_used, C_, dens = 7000, 2600, 5000, 0.2
+    rng = np.random.RandomState(4242)
+    a_pad, name_rank, classes, rows, counts, lengths = _random_problem(rng, A, n_used, C_, dens)
+    used = sorted({a for c in classes for a in c})
+    X, Y = used[10], used[500]
+    w64 = a_pad // 64
+    extra = np.zeros((2, w64), np.uint64)
+    extra[0, X >> 6] = np.uint64(1) << np.uint64(X & 63)
+    extra[1, Y >> 6] = np.uint64(1) << np.uint64(Y & 63)
+    rows = np.concatenate([extra, rows])                       # {X} first in dict order, then {Y}
+    counts = np.concatenate([np.array([10**12, 10**12 + delta], np.int64), counts])
+    classes = [[X], [Y]] + classes
+    cl = engine.Classes.from_host(rows, counts, a_pad)
+    cl.set_allele_rank(name_rank)
+    for low in (True, False):
+        oa, op, oit = orc.single_abundance(A, classes, counts, low, None)
+        exp = np.full(A, -1.0)
+        exp[oa] = op
+        assert exp[Y] > exp[X] > 0.49 and (exp[Y] - exp[X]) / exp[Y] < 2e-12 * max(delta, 1)
+        n0 = engine.em_tie_reruns()
+        p, first, it = cl.em_ordered(A, low, None)
+        if delta <= 1000:
+            assert engine.em_tie_reruns() == n0 + 1 and engine.em_last_exact()      # recognised, recomputed in the reference's order
+            assert it == oit and np.array_equal(p, exp)
+        else:
+            assert engine.em_tie_reruns() == n0 and not engine.em_last_exact()
+            assert it == oit and np.max(np.abs(p - exp)) <= 1e-9
+        assert p[Y] > p[X]
+        with engine.test_switches(em_skip="tie_rerun"):          # the table-lookup values by themselves: close, but not the reference's
+            p2, _, it2 = cl.em_ordered(A, low, None)
+        assert not engine.em_last_exact() and it2 == oit and np.max(np.abs(p2 - exp)) <= 1e-9
+        old = engine.em_set_fast(-1)
+        try:
+            p3, _, it3 = cl.em_ordered(A, low, None)
+            assert engine.em_last_exact() and it3 == oit and np.array_equal(p3, exp)
+        finally:
+            engine.em_set_fast(old)
+    # the drop-in entry point: the reference's list, in the reference's order
+    names = ["a%05d" % int(name_rank[a]) for a in range(A)]      # names whose sort order is the name rank
+    cmpt = {}
+    for mem, n in zip(classes, counts.tolist()):
+        cmpt["-".join(sorted(names[a] for a in mem))] = n
+    out = hgx.single_abundance(cmpt, True, {})
+    oa, op, _ = orc.single_abundance(A, classes, counts, True, None)
+    want = sorted(zip(oa.tolist(), op.tolist()), key=lambda t: -t[1])
+    assert [a for a, _ in out[:2]] == [names[Y], names[X]]
+    assert [p for _, p in out[:5]] == [p for _, p in want[:5]]
