@@ -558,7 +558,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
     std::vector<std::vector<std::vector<Line>>> text_part;      // [worker][region] line lists of a SAM text
     bool on_raw_done = false;
     int text_nt = 0;
-    bool text_scanned = false;
+    bool text_scanned = false, text_defer = false;
     Bytes data;
     {
         const int fd = open(path, O_RDONLY);
@@ -579,8 +579,12 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             // handed over while the next phase is read: the transfer hides behind the read.
             const char *ph_env = getenv("HGX_READ_PHASES");
             const int n_phase = (out.on_raw && data.size() > (64u << 20)) ? (ph_env ? std::max(1, atoi(ph_env)) : 4) : 1;
+            // the caller makes the line table itself (the device front end: newline scan, region filter, name order as kernels):
+            // the workers only read, the bytes go up phase by phase
+            text_defer = out.defer_text && out.on_raw && keep_binary && regs.size() <= 1 && (!filtered || regs.size() == 1) &&
+                         data.size() >= out.defer_min_bytes && data.size() < (1ull << 32) - 64;
             text_nt = n_threads * n_phase;
-            text_part.assign(text_nt, std::vector<std::vector<Line>>(n_reg));
+            if (!text_defer) text_part.assign(text_nt, std::vector<std::vector<Line>>(n_reg));
             std::vector<size_t> tail((size_t)text_nt, (size_t)-1);
             char *base = (char *)data.data();
             const size_t total = data.size();
@@ -588,6 +592,14 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             const size_t ph_b = total * (size_t)ph / n_phase, ph_e = total * (size_t)(ph + 1) / n_phase;
             par_for(n_threads, ph_e - ph_b, [&](int t, size_t rb0, size_t re0) {
                 const size_t b0 = ph_b + rb0, e0 = ph_b + re0;
+                if (text_defer) {
+                    for (size_t have = b0; have < e0;) {
+                        const ssize_t got = pread(fd, base + have, std::min<size_t>(e0 - have, 4u << 20), (off_t)have);
+                        if (got <= 0) { bad[t] = 1; return; }
+                        have += (size_t)got;
+                    }
+                    return;
+                }
                 std::vector<std::vector<Line>> &mine = text_part[ph * n_threads + t];
                 if (!filtered) mine[0].reserve((e0 - b0) / 300 + 16);
                 unsigned char prev = '\n';
@@ -627,6 +639,22 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             }
             close(fd);
             for (int v : bad) if (v) { hgx_set_error("short read on %s", path); return HGX_EINVAL; }
+            if (text_defer) {
+                hgx_bam_deferred &d = out.deferred;
+                d.on = true;
+                d.text = true;
+                d.filtered = filtered;
+                if (filtered) { d.region_whole = regs[0].whole; d.region_name = regs[0].name; d.left0 = regs[0].left0; d.right0 = regs[0].right0; }
+                out.binary = false;
+                out.lines.clear();
+                hgx_host_free(out.raw);
+                out.raw = (char *)data.p;
+                out.raw_bytes = data.n;
+                data.p = nullptr;
+                data.n = 0;
+                lap("read file (lines left to the device)");
+                return HGX_OK;
+            }
             for (int t = 0; t < text_nt; ++t)
                 if (tail[t] != (size_t)-1) {
                     const char *p = base + tail[t], *end = base + total;

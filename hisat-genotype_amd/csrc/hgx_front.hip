@@ -454,6 +454,16 @@ __global__ void __launch_bounds__(256) k_fe_pair_emit(const uint32_t *__restrict
     }
 }
 
+// inclusive prefix sum over the 64 lanes through the register file (row_shr 1 / 2 / 4 / 8, row_bcast:15, row_bcast:31)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32_front(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);
+    return v;
+}
 // ---- prefix scans of the front end (round 5: hand-written; the nine hipcub::DeviceScan call sites -- two launches each -- are gone) ----
 // Up to four 32-bit channels over the same n items in ONE single-pass launch (decoupled look-back, as k_scan_u32 of hgx_dedup.hip):
 // exclusive sums, or an exclusive running maximum; a channel may be a field of the pair protocol's packed 64-bit counts.  Tile state =
@@ -1371,6 +1381,249 @@ int bam_lines_dev(const char *d_text, const std::vector<const hgx_bam_deferred *
     return HGX_OK;
 }
 
+// ---- the line table of SAM TEXT on the device (round 5) --------------------------------------------------------------
+// What hgx_bam.cpp's readers do per line on the host's threads (0.2-0.3 CPU-seconds per 1 M-read call: memchr for the newlines,
+// six fields of every line for the region test, the QNAME order check): here the text that went up is scanned where it lies.
+//   k_sam_nl<0/1>    newlines per 4 KB tile (a wavefront reads 1 KB per step, 16 bytes per lane, a SWAR zero-byte test per dword),
+//                    a scan of the tile counts, then the same walk again writing every line's start
+//   k_sam_line_info  a lane per line: '\r' stripped, blank and '@' lines dropped, the region test of `samtools view` on RNAME, POS and
+//                    the CIGAR's reference span (one region at most: hgx_bam_deferred), QNAME length
+//   scan + compact, k_sam_sorted (QNAME order check), LSD radix passes over 8-byte QNAME chunks where the text is not in name order
+//   (k_sam_name_key + hipcub sort, as for BAM), k_sam_lines -> FeLine
+struct SamRegion { int filtered, whole_len, name_len; long long left0, right0; char whole[96], name[96]; };
+constexpr int SAM_TILE = 4096;
+__device__ __forceinline__ uint32_t sam_nl_mask(uint32_t w) {          // bit 8 k + 7 set where byte k of w is '\n'
+    const uint32_t x = w ^ 0x0A0A0A0Au;
+    return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) & 0x80808080u;     // exact zero-byte test (no borrow across bytes)
+}
+template <int PASS>
+__global__ void __launch_bounds__(256) k_sam_nl(const unsigned char *__restrict__ text, size_t n, uint32_t n_tiles, uint32_t *__restrict__ cnt,
+                                                const uint32_t *__restrict__ base, uint32_t *__restrict__ starts) {
+    const uint32_t tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (tile >= n_tiles) return;
+    const size_t t0 = (size_t)tile * SAM_TILE;
+    uint32_t run = PASS == 1 ? base[tile] : 0u;
+    for (int k = 0; k < SAM_TILE / 1024; ++k) {
+        const size_t at = t0 + (size_t)k * 1024 + 16u * lane;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (at + 16 <= n) v = *reinterpret_cast<const uint4 *>(text + at);            // (the buffer is padded by 64 bytes; `n` cuts the count)
+        else if (at < n) { unsigned char tmp[16] = {0}; for (size_t j = 0; at + j < n; ++j) tmp[j] = text[at + j]; __builtin_memcpy(&v, tmp, 16); }
+        const uint32_t m0 = sam_nl_mask(v.x), m1 = sam_nl_mask(v.y), m2 = sam_nl_mask(v.z), m3 = sam_nl_mask(v.w);
+        const uint32_t c = (uint32_t)(__popc(m0) + __popc(m1) + __popc(m2) + __popc(m3));
+        if (PASS == 0) run += c;
+        else {
+            const uint32_t incl = wave_incl_scan_u32_front(c);
+            uint32_t at_line = run + incl - c;
+            const uint32_t ms[4] = {m0, m1, m2, m3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t m = ms[q];
+                while (m) {
+                    const int b = __ffs((int)m) - 1;                          // bit 8 j + 7
+                    m &= m - 1;
+                    starts[at_line + 1] = (uint32_t)(at + 4u * q + (uint32_t)(b >> 3) + 1u);
+                    ++at_line;
+                }
+            }
+            run += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
+    }
+    if (PASS == 0) {
+        const uint32_t tot = (uint32_t)wave_sum_u64(run);
+        if (lane == 0) cnt[tile] = tot;
+    }
+}
+__device__ __forceinline__ bool sam_bytes_eq(const unsigned char *a, const char *b, int n) {
+    for (int i = 0; i < n; ++i) if (a[i] != (unsigned char)b[i]) return false;
+    return true;
+}
+__global__ void __launch_bounds__(256) k_sam_line_info(const unsigned char *__restrict__ text, size_t n, const uint32_t *__restrict__ starts, uint32_t n_all,
+                                                       SamRegion R, uint32_t *__restrict__ keep, uint32_t *__restrict__ l_len, uint32_t *__restrict__ l_klen,
+                                                       BamCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_all) return;
+    const uint32_t off = starts[i];
+    uint32_t end = i + 1 < n_all ? starts[i + 1] - 1u : (uint32_t)n;             // the newline's place (or the text's end: a last line without one)
+    if (i + 1 == n_all && n > 0 && text[n - 1] == '\n') end = (uint32_t)n - 1u;
+    if (end > off && text[end - 1] == '\r') --end;
+    const uint32_t len = end - off;
+    uint32_t k = 0, klen = 0;
+    if (len && text[off] != '@') {
+        // QNAME and, for the region test, FLAG / RNAME / POS / CIGAR (hgx_bam.cpp take_line)
+        const unsigned char *p = text + off;
+        uint32_t tab[6];
+        int nf = 0;
+        const int want = R.filtered ? 6 : 1;
+        for (uint32_t q = 0; q < len && nf < want; ++q) if (p[q] == '\t') tab[nf++] = q;
+        klen = nf ? tab[0] : len;
+        if (!R.filtered) k = 1;
+        else if (nf == 6) {
+            long long flag = 0, pos = 0;
+            bool fneg = false, pneg = false;
+            {   // strtol(.., 10): optional blanks and sign, digits (what follows is ignored)
+                uint32_t q = tab[0] + 1;
+                while (q < tab[1] && (p[q] == ' ' || (p[q] >= 9 && p[q] <= 13))) ++q;
+                if (q < tab[1] && (p[q] == '+' || p[q] == '-')) { fneg = p[q] == '-'; ++q; }
+                for (; q < tab[1] && p[q] >= '0' && p[q] <= '9'; ++q) if (flag < (1ll << 40)) flag = flag * 10 + (p[q] - '0');
+                if (fneg) flag = -flag;
+                q = tab[2] + 1;
+                while (q < tab[3] && (p[q] == ' ' || (p[q] >= 9 && p[q] <= 13))) ++q;
+                if (q < tab[3] && (p[q] == '+' || p[q] == '-')) { pneg = p[q] == '-'; ++q; }
+                for (; q < tab[3] && p[q] >= '0' && p[q] <= '9'; ++q) if (pos < (1ll << 40)) pos = pos * 10 + (p[q] - '0');
+                if (pneg) pos = -pos;
+            }
+            const long long pos0 = pos - 1;
+            long long reflen = 0;
+            if (!(flag & 4)) {
+                long long num = 0;
+                for (uint32_t q = tab[4] + 1; q < tab[5]; ++q) {
+                    const unsigned char c = p[q];
+                    if (c >= '0' && c <= '9') { num = num * 10 + (c - '0'); continue; }
+                    if (c == 'M' || c == 'D' || c == 'N' || c == '=' || c == 'X') reflen += num;
+                    num = 0;
+                }
+            }
+            const long long end0 = pos0 + (reflen > 0 ? reflen : 1) - 1;
+            const unsigned char *rn = p + tab[1] + 1;
+            const int rl = (int)(tab[2] - tab[1] - 1);
+            if (rl == R.whole_len && sam_bytes_eq(rn, R.whole, rl)) k = 1;
+            else if (R.name_len > 0 && rl == R.name_len && sam_bytes_eq(rn, R.name, rl)) k = (end0 >= R.left0 && pos0 <= R.right0) ? 1u : 0u;
+        }
+    }
+    keep[i] = k;
+    l_len[i] = len;
+    l_klen[i] = klen;
+    if (k) atomicMax(&ctl->max_klen, klen);
+}
+__global__ void k_sam_compact(const uint32_t *__restrict__ keep, const uint32_t *__restrict__ pos, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ l_len,
+                              const uint32_t *__restrict__ l_klen, uint32_t n_all, uint32_t *__restrict__ k_off, uint32_t *__restrict__ k_len,
+                              uint32_t *__restrict__ k_klen, uint32_t *__restrict__ idx, BamCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_all) return;
+    if (keep[i]) { const uint32_t q = pos[i]; k_off[q] = starts[i]; k_len[q] = l_len[i]; k_klen[q] = l_klen[i]; idx[q] = q; }
+    if (i == n_all - 1) ctl->n_kept = pos[i] + keep[i];
+}
+__global__ void __launch_bounds__(256) k_sam_sorted(const unsigned char *__restrict__ text, const uint32_t *__restrict__ k_off, const uint32_t *__restrict__ k_klen,
+                                                    uint32_t n, BamCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 || i >= n) return;
+    if (bam_name_cmp(text + k_off[i], k_klen[i], text + k_off[i - 1], k_klen[i - 1]) < 0) ctl->unsorted = 1;
+}
+__global__ void __launch_bounds__(256) k_sam_name_key(const unsigned char *__restrict__ text, const uint32_t *__restrict__ k_off, const uint32_t *__restrict__ k_klen,
+                                                      const uint32_t *__restrict__ idx, uint32_t n, uint32_t chunk, unsigned long long *__restrict__ key) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = idx[i], klen = k_klen[r];
+    unsigned long long v = 0;
+    if (8 * chunk < klen) {
+        const uint32_t have = min(8u, klen - 8 * chunk);
+        const unsigned char *q = text + k_off[r] + 8 * chunk;
+        for (uint32_t j = 0; j < have; ++j) v |= (unsigned long long)q[j] << (8 * (7 - j));      // big endian: byte order = key order
+    }
+    key[i] = v;
+}
+__global__ void k_sam_lines(const uint32_t *__restrict__ k_off, const uint32_t *__restrict__ k_len, const uint32_t *__restrict__ idx, uint32_t n,
+                            FeLine *__restrict__ lines) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t r = idx[i]; lines[i] = FeLine{k_off[r], k_len[r], 0u}; }
+}
+
+int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &def, hipStream_t st, DevBuf &b_lines, uint32_t *n_lines, int *declined) {
+    *declined = 0;
+    *n_lines = 0;
+    Lap lap(st);
+    const unsigned char *text = (const unsigned char *)d_text;
+    if (n_bytes >= (1ull << 32) - 64) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+    SamRegion R;
+    memset(&R, 0, sizeof(R));
+    R.filtered = def.filtered ? 1 : 0;
+    if (def.filtered) {
+        if (def.region_whole.size() >= sizeof(R.whole) || def.region_name.size() >= sizeof(R.name)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+        R.whole_len = (int)def.region_whole.size(); memcpy(R.whole, def.region_whole.data(), def.region_whole.size());
+        R.name_len = (int)def.region_name.size(); memcpy(R.name, def.region_name.data(), def.region_name.size());
+        R.left0 = (long long)def.left0; R.right0 = (long long)def.right0;
+    }
+    const uint32_t n_tiles = (uint32_t)((n_bytes + SAM_TILE - 1) / SAM_TILE);
+    DevBuf b_cnt, b_base, b_ctl, b_starts, b_keep, b_pos, b_len, b_klen, b_koff, b_klen2, b_klen3, b_idx, b_idx2, b_key, b_key2, b_tmp;
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
+    const size_t sc_t = fe_scan_scratch_bytes(std::max<uint32_t>(n_tiles, 1));
+    ALLOC(b_cnt, std::max<size_t>(n_tiles, 1) * 4);
+    ALLOC(b_base, std::max<size_t>(n_tiles, 1) * 4);
+    ALLOC(b_ctl, 256 + sc_t);
+    HIPCHK(hipMemsetAsync(b_ctl.p, 0, 256 + sc_t, st));
+    BamCtl *ctl = b_ctl.as<BamCtl>();
+    BamCtl h;
+    memset(&h, 0, sizeof(h));
+    if (n_tiles) {
+        k_sam_nl<0><<<nblk(n_tiles, 4), 256, 0, st>>>(text, n_bytes, n_tiles, b_cnt.as<uint32_t>(), nullptr, nullptr);
+        FeScanArgs sa{};
+        sa.n_ch = 1;
+        sa.ch[0] = FeScanCh{b_cnt.p, b_base.as<uint32_t>(), 0, FSC_U32};
+        sa.totals = ctl->tot;
+        const int rcs = fe_scan(sa, (long)n_tiles, (char *)b_ctl.p + 256, st);
+        if (rcs) return rcs;
+        HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
+    // lines = newlines (+ a last line without one); one more entry than lines for "the next line's start"
+    const uint32_t n_nl = h.tot[0];
+    ALLOC(b_starts, ((size_t)n_nl + 2) * 4);
+    HIPCHK(hipMemsetAsync(b_starts.p, 0, 4, st));                            // the first line starts at 0
+    if (n_tiles) k_sam_nl<1><<<nblk(n_tiles, 4), 256, 0, st>>>(text, n_bytes, n_tiles, nullptr, b_base.as<uint32_t>(), b_starts.as<uint32_t>());
+    // (a text that ends with its last newline has no line behind it; k_sam_line_info drops the empty one)
+    const uint32_t n_all = n_nl + 1;
+    lap("SAM newline scan");
+    if (n_all >= (1u << 30)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
+    ALLOC(b_keep, (size_t)n_all * 4); ALLOC(b_pos, (size_t)n_all * 4); ALLOC(b_len, (size_t)n_all * 4); ALLOC(b_klen, (size_t)n_all * 4);
+    ALLOC(b_koff, (size_t)n_all * 4); ALLOC(b_klen2, (size_t)n_all * 4); ALLOC(b_klen3, (size_t)n_all * 4); ALLOC(b_idx, (size_t)n_all * 4);
+    size_t tb2 = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs((void *)nullptr, tb2, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint32_t *)nullptr,
+                                             (uint32_t *)nullptr, (int)n_all, 0, 64, st);
+    const size_t tmp_bytes = std::max(tb2, fe_scan_scratch_bytes(n_all));
+    ALLOC(b_tmp, std::max<size_t>(tmp_bytes, 256));
+    HIPCHK(hipMemsetAsync(b_tmp.p, 0, fe_scan_scratch_bytes(n_all), st));
+    k_sam_line_info<<<nblk(n_all, 256), 256, 0, st>>>(text, n_bytes, b_starts.as<uint32_t>(), n_all, R, b_keep.as<uint32_t>(), b_len.as<uint32_t>(),
+                                                      b_klen.as<uint32_t>(), ctl);
+    {
+        FeScanArgs sa{};
+        sa.n_ch = 1;
+        sa.ch[0] = FeScanCh{b_keep.p, b_pos.as<uint32_t>(), 0, FSC_U32};
+        const int rcs = fe_scan(sa, (long)n_all, b_tmp.p, st);
+        if (rcs) return rcs;
+    }
+    k_sam_compact<<<nblk(n_all, 256), 256, 0, st>>>(b_keep.as<uint32_t>(), b_pos.as<uint32_t>(), b_starts.as<uint32_t>(), b_len.as<uint32_t>(), b_klen.as<uint32_t>(),
+                                                    n_all, b_koff.as<uint32_t>(), b_klen2.as<uint32_t>(), b_klen3.as<uint32_t>(), b_idx.as<uint32_t>(), ctl);
+    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    lap("SAM lines + region filter");
+    const uint32_t n_kept = h.n_kept;
+    ALLOC(b_lines, std::max<size_t>(n_kept, 1) * sizeof(LineRef));
+    uint32_t *idx = b_idx.as<uint32_t>();
+    if (n_kept > 1) {
+        k_sam_sorted<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_koff.as<uint32_t>(), b_klen3.as<uint32_t>(), n_kept, ctl);
+        HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (h.unsorted) {
+            ALLOC(b_idx2, (size_t)n_kept * 4); ALLOC(b_key, (size_t)n_kept * 8); ALLOC(b_key2, (size_t)n_kept * 8);
+            uint32_t *idx_alt = b_idx2.as<uint32_t>();
+            unsigned long long *key = b_key.as<unsigned long long>(), *key_alt = b_key2.as<unsigned long long>();
+            for (int chunk = (int)(h.max_klen + 7) / 8 - 1; chunk >= 0; --chunk) {      // least significant eight bytes first; every pass stable
+                k_sam_name_key<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_koff.as<uint32_t>(), b_klen3.as<uint32_t>(), idx, n_kept, (uint32_t)chunk, key);
+                size_t b = tmp_bytes;
+                HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, key, key_alt, idx, idx_alt, (int)n_kept, 0, 64, st));
+                std::swap(idx, idx_alt);
+            }
+        }
+        lap(h.unsorted ? "SAM name sort" : "SAM name order check");
+    }
+    if (n_kept) k_sam_lines<<<nblk(n_kept, 256), 256, 0, st>>>(b_koff.as<uint32_t>(), b_klen2.as<uint32_t>(), idx, n_kept, b_lines.as<LineRef>());
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));                                           // (idx may live in a buffer of this function)
+    *n_lines = n_kept;
+    return HGX_OK;
+}
+
 int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRef *h_lines, size_t n_lines, bool binary, int n_tasks,
                 const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, ManyTotals *many, int *declined, const LineRef *d_lines = nullptr) {
     *out = nullptr;
@@ -1549,6 +1802,7 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
         // a BAM's records are walked, filtered and name-sorted on the device too when the stream is big enough to be worth the launches
         // -- and its BGZF blocks inflated there (hgx_inflate.hip): the deflated file goes up instead of the inflated stream
         hook.defer_walk = true;
+        hook.defer_text = !hgx_switch_has("front", "host_lines");          // SAM text: the line table as kernels too (round 5)
         hook.defer_min_bytes = force ? 0 : (8u << 20);
         if (!hgx_switch_has("front", "host_inflate")) {
             // the file's bytes start their way up before the host has looked at the container (0.4 ms of transfer for a 20 MB BAM,
@@ -1586,9 +1840,10 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
                 DevBuf b_dl;
                 uint32_t n_dl = 0;
                 struct DrainL { hipStream_t s; ~DrainL() { (void)hipStreamSynchronize(s); } } drain_l{st};
-                int rc = bam_lines_dev(b_text.as<char>(), {def}, {(size_t)0}, {raw_bytes}, st, b_dl, &n_dl, declined);
+                int rc = def->text ? sam_lines_dev(b_text.as<char>(), raw_bytes, *def, st, b_dl, &n_dl, declined)
+                                   : bam_lines_dev(b_text.as<char>(), {def}, {(size_t)0}, {raw_bytes}, st, b_dl, &n_dl, declined);
                 if (rc || *declined) return rc;
-                rc = records_run(L, b_text.as<char>(), raw_bytes, nullptr, n_dl, true, 1, o, st, &made, nullptr, declined, b_dl.as<LineRef>());
+                rc = records_run(L, b_text.as<char>(), raw_bytes, nullptr, n_dl, !def->text, 1, o, st, &made, nullptr, declined, b_dl.as<LineRef>());
                 if (!rc && !*declined && made) route = 2;
                 return rc;
             }

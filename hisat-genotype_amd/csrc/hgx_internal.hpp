@@ -181,6 +181,11 @@ struct hgx_bam_deferred {
     bool filtered = false;               // ONE region was given: per reference what it keeps
     std::vector<uint8_t> ref_action;     // [n_ref] 0 = drop, 1 = keep, 2 = keep where [pos0, end0] overlaps [left0, right0]
     int64_t left0 = 0, right0 = 0;
+    // SAM TEXT left to the device (round 5): the line table -- newline scan, header / blank lines dropped, region filter on RNAME /
+    // POS / CIGAR, QNAME order check and sort -- is made by kernels too.  `filtered`: region_whole keeps a whole reference,
+    // region_name (non-empty) the records overlapping [left0, right0] on it (a samtools region string reads both ways).
+    bool text = false;
+    std::string region_whole, region_name;
 };
 struct hgx_align_lines {
     char *raw = nullptr;                   // SAM text as read, or the inflated BAM stream (pooled block), or null
@@ -198,6 +203,7 @@ struct hgx_align_lines {
     // in: the caller can walk / filter / sort BAM records itself (the device front end) when the inflated stream has at least
     // defer_min_bytes and at most one region was asked for; out: `deferred.on` -- `lines` is empty then
     bool defer_walk = false;
+    bool defer_text = false;             // ... and SAM text without a line table (the device front end scans the lines itself)
     size_t defer_min_bytes = 0;
     hgx_bam_deferred deferred;
     // in: with defer_walk -- the caller can also inflate the BGZF blocks itself (hgx_inflate.hip): called with the file's bytes and
@@ -309,6 +315,7 @@ struct hgx_front_hook {
     std::function<int(hgx_locus &, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &,
                       int *declined, const hgx_bam_deferred *def)> records;
     bool defer_walk = false;           // the hook's owner takes unwalked BAM streams
+    bool defer_text = false;           // ... and SAM text without a line table
     size_t defer_min_bytes = 0;
     std::function<int(const unsigned char *data, size_t n, const std::vector<hgx_bgzf_block> &blocks, size_t total)> inflate_dev;   // ... and deflated ones
     std::function<void(const unsigned char *data, size_t n)> comp_early;             // (the deflated bytes, before the container is looked at)

@@ -1817,6 +1817,7 @@ int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *Lc, const ch
             al.defer_walk = hook->defer_walk && !(opts->codis_choose_pairs || opts->interdist_exchange);
             al.defer_min_bytes = hook->defer_min_bytes;
             if (al.defer_walk) { al.inflate_dev = hook->inflate_dev; al.comp_early = hook->comp_early; al.comp_sync = hook->comp_sync; }
+            al.defer_text = al.defer_walk && hook->defer_text;
         }
         int rc = hgx_read_alignment_lines(path, regions, opts->n_threads, al, /*keep_binary=*/true);
         pinned.reset();
@@ -1825,7 +1826,7 @@ int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *Lc, const ch
         if (al.deferred.on) {
             // a BAM stream whose records the device walks, filters and sorts itself; should it decline, the file is read again
             // the ordinary way (a rare path: a record the kernels do not take, a chain that does not link up)
-            rc = parse_lines(out, Lc, nullptr, 0, opts, true, hook, al.raw, al.raw_bytes, &al.deferred);
+            rc = parse_lines(out, Lc, nullptr, 0, opts, !al.deferred.text, hook, al.raw, al.raw_bytes, &al.deferred);
             if (rc || !hook->declined_records) {
                 if (prof) fprintf(stderr, "[hgx_parse_alignment_file] read %.1f ms, parse %.1f ms (records walked on the device)\n", (t1 - t0) * 1e3, (now() - t1) * 1e3);
                 return rc;

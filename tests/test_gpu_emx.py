@@ -285,8 +285,8 @@ def test_cluster_fallback_is_counted_and_still_the_reference(orc):
 def test_near_tie_beyond_the_gate_is_ordered_as_the_reference_orders_it(orc, delta):
     """VERDICT r4 #8.  More than 4 096 classes: by default the chip-wide table-lookup EM (good to ~1e-11), whose results used to be
     ranked with a 1e-11 relative tie tolerance.  Two alleles X and Y with DIFFERENT class membership whose reference abundances differ
-    by `delta` x 1e-12 relative: a class {X} counted 10^12 times and a class {Y} counted 10^12 + delta times on top of a random problem
-    (counts are exact in a double).  X comes first in dict order, Y has the larger abundance: the reference -- a plain stable sort on
+    by `delta` x 1e-12 relative: a class {X} counted 10^12 times and a class {Y} counted 10^12 + delta times (X and Y in no other class)
+    on top of a random problem (counts are exact in a double).  X comes first in dict order, Y has the larger abundance: the reference -- a plain stable sort on
     its own doubles (common:1405-1410) -- prints Y first; a tolerance that calls them tied prints X first.  The library now recognises
     the near-tie it cannot order (different columns, values closer than 1e-8) and recomputes that EM in the reference's own order of
     operations: order AND abundances `==` the C oracle, the re-run is counted; with em_fast = -1 the same without a re-run.  A pair
@@ -294,8 +294,9 @@ def test_near_tie_beyond_the_gate_is_ordered_as_the_reference_orders_it(orc, del
     A, n_used, C_, dens = 7000, 2600, 5000, 0.2
     rng = np.random.RandomState(4242)
     a_pad, name_rank, classes, rows, counts, lengths = _random_problem(rng, A, n_used, C_, dens)
-    used = sorted({a for c in classes for a in c})
-    X, Y = used[10], used[500]
+    used = {a for c in classes for a in c}
+    free = [a for a in range(A) if a not in used]            # X and Y occur in their own classes only: abundances n_X / N and n_Y / N
+    X, Y = free[3], free[400]
     w64 = a_pad // 64
     extra = np.zeros((2, w64), np.uint64)
     extra[0, X >> 6] = np.uint64(1) << np.uint64(X & 63)
