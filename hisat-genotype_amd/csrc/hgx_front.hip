@@ -1445,7 +1445,7 @@ __global__ void __launch_bounds__(256) k_sam_line_info(const unsigned char *__re
     if (i >= n_all) return;
     const uint32_t off = starts[i];
     uint32_t end = i + 1 < n_all ? starts[i + 1] - 1u : (uint32_t)n;             // the newline's place (or the text's end: a last line without one)
-    if (i + 1 == n_all && n > 0 && text[n - 1] == '\n') end = (uint32_t)n - 1u;
+    if (end < off) end = off;
     if (end > off && text[end - 1] == '\r') --end;
     const uint32_t len = end - off;
     uint32_t k = 0, klen = 0;
