@@ -37,7 +37,13 @@ namespace {
 #define HGX_INF_FLUSH 2048
 #endif
 constexpr int RING = HGX_INF_RING, RMASK = RING - 1, FLUSH = HGX_INF_FLUSH, PIECE = FLUSH / 64;      // (see the header: the ring holds the near window only)
-constexpr int LIT_P = 10, DIST_P = 8;
+#ifndef HGX_INF_LITP
+#define HGX_INF_LITP 10
+#endif
+#ifndef HGX_INF_DISTP
+#define HGX_INF_DISTP 8
+#endif
+constexpr int LIT_P = HGX_INF_LITP, DIST_P = HGX_INF_DISTP;
 
 struct HuffLds {
     uint16_t pt[1 << LIT_P];             // primary table: symbol << 4 | code length (0 = longer than the table's bits, or no such code)
@@ -459,7 +465,10 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
 // The compressed stream reaches the lanes through a 512-byte LDS ring (two 256-byte chunks; the next chunk waits in a register per
 // lane); headers (block type, code lengths) are read with the same window function at lane offset 0.
 // =====================================================================================================================================
-constexpr int T_MAX = 1024;                              // most bytes one window may produce (a 64-bit window of 2-bit codes could ask for 8 KB)
+#ifndef HGX_INF_TMAX
+#define HGX_INF_TMAX 1024
+#endif
+constexpr int T_MAX = HGX_INF_TMAX;                              // most bytes one window may produce (a 64-bit window of 2-bit codes could ask for 8 KB)
 constexpr uint32_t NEAR_MAX = RING - T_MAX - 320;        // matches up to this distance are copied inside the ring, farther ones from memory
 
 struct InfLdsW {
@@ -746,40 +755,88 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__re
                 const uint32_t r0 = used | (kind << 6) | (olen << 9) | (val << 18);     // used <= 48, kind < 8, olen <= 258, val < 256
                 if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (__builtin_amdgcn_readfirstlane((int)r0) == -1) err = INF_BAD_CODE; }
                 lap(PH_DECODE);
-                // ---- the chain: from offset 0, hop by the bits each symbol uses (scalar: a v_readlane and a handful of SALU
-                // instructions per symbol); the symbols on it then take their output offsets from a prefix sum over the lanes ----
-                uint32_t cur = 0, run = 0;
-                uint64_t m_chain = 0, m_match = 0;
-                bool slow = false;
+                // ---- the chain: from offset 0, hop by the bits each symbol uses.  The scalar loop only collects the positions (a
+                // v_readlane, a bit set and an add per symbol; it ends ON the first symbol that is not a plain literal or match: its hop
+                // is 0); what the chain means -- output offsets, the T_MAX cut, which lanes are literals and which matches -- is worked
+                // out by all lanes at once from the position mask ----
+                const uint32_t hop = kind <= K_MATCH ? used : 0u;
+                uint32_t cur = 0;
+                uint64_t m_chain = 0;
                 while (cur < 64u) {
+                    m_chain |= 1ull << cur;
+                    const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)hop, (int)cur);
+                    if (h == 0u) break;
+                    cur += h;
+                }
+                // cur < 64: the chain stopped ON lane cur (end of block, a slow symbol, a bad code); else it left the window at bit cur
+                uint64_t m_norm = cur < 64u ? m_chain & ~(1ull << cur) : m_chain;
+                uint32_t incl = wave_incl_scan_u32(((m_norm >> lane) & 1ull) ? olen : 0u);
+                const uint64_t over = __ballot(((m_norm >> lane) & 1ull) && incl > (uint32_t)T_MAX);
+                bool slow = false;
+                if (over) {                                                 // the window would make more than T_MAX bytes: the rest starts the next one
+                    const uint32_t cut = (uint32_t)__builtin_ctzll(over);
+                    m_norm &= (1ull << cut) - 1ull;
+                    cur = cut;
+                    incl = wave_incl_scan_u32(((m_norm >> lane) & 1ull) ? olen : 0u);
+                } else if (cur < 64u) {
                     const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)r0, (int)cur);
                     const uint32_t k = (r >> 6) & 7u;
-                    if (k >= K_EOB) {
-                        if (k == K_SLOW) slow = true;
-                        else if (k == K_BAD) err = INF_BAD_CODE;
-                        else { eob = true; cur += r & 63u; }
-                        break;
-                    }
-                    const uint32_t ol = (r >> 9) & 511u;
-                    if (run + ol > (uint32_t)T_MAX) break;                  // the rest of the window starts the next one
-                    m_chain |= 1ull << cur;
-                    if (k == K_MATCH) m_match |= 1ull << cur;
-                    run += ol;
-                    cur += r & 63u;
+                    if (k == K_SLOW) slow = true;
+                    else if (k == K_BAD) err = INF_BAD_CODE;
+                    else { eob = true; cur += r & 63u; }
                 }
-                const bool on_chain = (m_chain >> lane) & 1ull;
-                uint32_t my_off;
-                {   // exclusive prefix sum of the chain's output lengths over the lanes (six DPP adds in the register file; off the scalar path)
-                    const uint32_t own = on_chain ? olen : 0u;
-                    my_off = wave_incl_scan_u32(own) - own;
-                }
-                const uint64_t m_lit = m_chain & ~m_match;
+                const bool on_chain = (m_norm >> lane) & 1ull;
+                const uint32_t my_off = incl - (on_chain ? olen : 0u);
+                const uint32_t run = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                uint64_t m_match = __ballot(on_chain && kind == K_MATCH);
+                const uint64_t m_lit = m_norm & ~m_match;
                 if (err) break;
                 if (wpos + run > B.out_len) { err = INF_OVERRUN; break; }
                 lap(PH_WALK);
                 // ---- output: the literals at once, the matches in order ----
                 if ((m_lit >> lane) & 1ull) S.ring[(wpos + my_off) & RMASK] = (unsigned char)val;
                 lap(PH_LIT);
+                // Matches whose whole source lies BEFORE this window's output (offset + length <= distance) and that fit one round of
+                // the lanes do not depend on anything the window writes: up to four at a time, all their reads issued before the first
+                // write -- ring reads for the near ones, memory reads for the far ones -- so that one round trip serves the batch.
+                // (A bad distance shows on the first match of a block only through `d > t`; those go the ordinary way below.)
+                {
+                    uint64_t m_ind = __ballot(on_chain && kind == K_MATCH && olen <= 64u && my_off + olen <= mdist && mdist <= wpos + my_off);
+                    m_match &= ~m_ind;
+                    while (m_ind) {
+                        uint32_t tt[4], ll[4], vv[4];
+                        int nb = 0;
+                        bool any_far = false;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            tt[k] = 0; ll[k] = 0; vv[k] = 0;
+                            if (m_ind) {
+                                const int ml = __builtin_ctzll(m_ind);
+                                m_ind &= m_ind - 1;
+                                const uint32_t r = (uint32_t)__builtin_amdgcn_readlane((int)r0, ml);
+                                const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)mdist, ml);
+                                tt[k] = wpos + (uint32_t)__builtin_amdgcn_readlane((int)my_off, ml);
+                                ll[k] = (r >> 9) & 511u;
+                                vv[k] = d;
+                                any_far = any_far || d > NEAR_MAX;
+                                nb = k + 1;
+                            }
+                        }
+                        if (any_far) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (this wavefront's own flushes have landed)
+                        uint32_t by[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            by[k] = 0;
+                            if (k < nb && (uint32_t)lane < ll[k])
+                                by[k] = vv[k] <= NEAR_MAX ? (uint32_t)S.ring[(tt[k] - vv[k] + lane) & RMASK]
+                                                          : (uint32_t)__builtin_nontemporal_load(dst + (tt[k] - vv[k] + lane));
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (k < nb && (uint32_t)lane < ll[k]) S.ring[(tt[k] + lane) & RMASK] = (unsigned char)by[k];
+                        if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); n_near += nb; lap(PH_NEAR); }
+                    }
+                }
                 while (m_match) {
                     const int ml = __builtin_ctzll(m_match);
                     m_match &= m_match - 1;
