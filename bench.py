@@ -1185,6 +1185,21 @@ def main():
         finally:
             shutil.rmtree(os.path.dirname(rank_bam), ignore_errors=True)
 
+    # the same steps with SEVERAL samples in flight (host threads with their own streams, hgx_type_opts.gate): the reference's own unit of
+    # scale is a pool of processes over samples (/root/reference/hisatgenotype:613-665); one sample's step is a chain of ~70 short
+    # dependent launches that leaves most of the chip idle, the next sample's scoring fills it.  Reported beside `value`, never as it.
+    in_flight = None
+    if inflight == 1 and dist is None and not args.no_workloads:
+        in_flight = {}
+        for nf in (2, 3):
+            n_st = max(12, 4 * nf)
+            run_steps(pl, batch, db, nf, nf, None, False, local_rank)
+            capi.sync()
+            t0 = time.perf_counter()
+            run_steps(pl, batch, db, nf, n_st, None, False, local_rank)
+            capi.sync()
+            dt = time.perf_counter() - t0
+            in_flight[str(nf)] = {"steps": n_st, "ms_per_step": round(dt / n_st * 1e3, 3), "value": round(batch.n_reads * n_st / dt, 1)}
     if rank == 0:
         # Per-kernel achieved rates from HIP events recorded inside the timed region (byte models: DESIGN.md section 5).
         #  k_lutmatvec<0> (EM rows pass): the compact class bit matrix once + its dense vectors
@@ -1307,6 +1322,9 @@ def main():
                 "emx_cluster_problems": cl_jobs, "emx_cluster_fallbacks": cl_fallbacks,
             },
         }
+        if in_flight:
+            out["samples_in_flight"] = {"note": "the timed steps again with 2 / 3 samples in flight on the GPU (one host thread and stream set per sample, the "
+                                                "bandwidth-bound fronts taking turns); `value` above is ONE sample at a time", **in_flight}
         if pre is not None:
             out["e2e_scaling"] = pre[2]
         if e2e_ranks is not None:

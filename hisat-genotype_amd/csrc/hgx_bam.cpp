@@ -689,15 +689,22 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             std::vector<unsigned char> head;
             std::vector<std::string> refs;
             size_t body0 = 0;
-            int st_h = 0;
-            for (size_t k = 0; k < blocks.size() && st_h == 0 && head.size() < (64u << 20); ++k) {
-                const size_t at = head.size();
-                head.resize(at + blocks[k].out_len);
-                if (!inflate_one(data.data(), blocks[k], head.data() + at)) { st_h = -1; break; }
-                st_h = parse_bam_header(head.data(), head.size(), refs, &body0);
-            }
-            if (st_h == 1 && total >= body0 && total - body0 >= out.defer_min_bytes && refs.size() < 65536 &&
-                out.inflate_dev(data.data(), data.size(), blocks, total) == 0) {
+            int st_h = 0, dev_rc = 1;
+            // the caller's inflate (the kernel's launch and its wait) on this thread, the BAM header -- the first block or two through
+            // zlib: 0.2-0.3 ms -- on a worker beside it (round 5: it stood in front of the launch)
+            hgx_run_workers(2, [&](int w) {
+                if (w == 0) {
+                    if (total >= out.defer_min_bytes) dev_rc = out.inflate_dev(data.data(), data.size(), blocks, total);
+                } else {
+                    for (size_t k = 0; k < blocks.size() && st_h == 0 && head.size() < (64u << 20); ++k) {
+                        const size_t at = head.size();
+                        head.resize(at + blocks[k].out_len);
+                        if (!inflate_one(data.data(), blocks[k], head.data() + at)) { st_h = -1; break; }
+                        st_h = parse_bam_header(head.data(), head.size(), refs, &body0);
+                    }
+                }
+            });
+            if (st_h == 1 && total >= body0 && total - body0 >= out.defer_min_bytes && refs.size() < 65536 && dev_rc == 0) {
                 hgx_bam_deferred &d = out.deferred;
                 d.on = true;
                 d.on_device = true;
