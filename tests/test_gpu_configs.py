@@ -1,6 +1,7 @@
 """BASELINE.json configs at their stated sizes on the GPU ("configs not exercised").
 
-  configs[1]  HLA-A, 1 M simulated 2x150 bp reads (500 000 pairs), 7 000 alleles: size-independent properties
+  configs[1]  HLA-A, 1 M simulated 2x150 bp reads (500 000 pairs), 7 000 alleles: size-independent properties, and (round 5) the whole
+              sample `==` the oracle chain at its stated size (classes, counts, EM iteration counts, order; abundances <= 1e-9)
   configs[3]  full HLA panel (A/B/C/DRB1/DQA1/DQB1, 500 ... 8 000 alleles) x 64 synthetic samples through run_panel:
               8 samples x 6 loci against the oracle (counts exact, EM iteration counts, allele order, abundances), the other
               336 tasks through properties
