@@ -25,6 +25,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "hgx_common.hpp"
@@ -38,7 +39,7 @@ namespace {
 #endif
 constexpr int RING = HGX_INF_RING, RMASK = RING - 1, FLUSH = HGX_INF_FLUSH, PIECE = FLUSH / 64;      // (see the header: the ring holds the near window only)
 #ifndef HGX_INF_LITP
-#define HGX_INF_LITP 10
+#define HGX_INF_LITP 9
 #endif
 #ifndef HGX_INF_DISTP
 #define HGX_INF_DISTP 8
@@ -123,7 +124,32 @@ __device__ __forceinline__ uint32_t bits_take(Bits &b, int n) { const uint32_t v
 // among the codes of its length come from one ballot per (round, length) -- the counters live in scalar registers under fully
 // unrolled length loops.  (The first form walked the symbols on lane 0 with its per-length cursors in a register array: every
 // dynamic index became a 16-way compare-and-select chain, ~150 instructions per symbol, a fifth of the kernel's scalar work.)
-template <class T, int P>
+enum { K_LIT = 0, K_MATCH = 1, K_EOB = 2, K_SLOW = 3, K_BAD = 4, K_SUB = 5 };
+// What a table entry says about symbol s with a code of L bits.  MODE 0: symbol << 4 | L (bit 15 marks a literal on request) -- the
+// first form's tables and the code-length code.  MODE 1 / 2 (k_bgzf_inflate_w): everything the per-lane decode would otherwise work
+// out from the symbol, computed once per symbol here instead of once per lane and window there --
+//   literal/length: L | extra bits << 4 | kind << 8 | (literal value or base length) << 16
+//   distance:       L | extra bits << 4 | (no such distance) << 8 | base distance << 16
+template <int MODE>
+__device__ __forceinline__ uint32_t huff_entry(uint32_t s, uint32_t L, bool mark_literals) {
+    if (MODE == 1) {
+        if (s < 256u) return L | ((uint32_t)K_LIT << 8) | (s << 16);
+        if (s == 256u) return L | ((uint32_t)K_EOB << 8);
+        if (s > 285u) return L | ((uint32_t)K_BAD << 8);
+        const uint32_t li = s - 257u;
+        const uint32_t le = li < 8u || li == 28u ? 0u : (li - 4u) >> 2;
+        const uint32_t lbase = li < 8u ? 3u + li : li == 28u ? 258u : ((4u + (li & 3u)) << le) + 3u;
+        return L | (le << 4) | ((uint32_t)K_MATCH << 8) | (lbase << 16);
+    }
+    if (MODE == 2) {
+        if (s >= 30u) return L | 0x100u;
+        const uint32_t de = s < 4u ? 0u : (s >> 1) - 1u;
+        const uint32_t dbase = s < 4u ? s + 1u : ((2u + (s & 1u)) << de) + 1u;
+        return L | (de << 4) | (dbase << 16);
+    }
+    return (s << 4) | L | ((mark_literals && s < 256u) ? 0x8000u : 0u);
+}
+template <class T, int P, int MODE = 0>
 __device__ bool huff_build(T &H, const unsigned char *lens, int n, int lane, bool allow_incomplete, bool mark_literals = false) {
     for (int i = lane; i < (1 << P); i += 64) H.pt[i] = 0;
     __builtin_amdgcn_wave_barrier();
@@ -171,7 +197,7 @@ __device__ bool huff_build(T &H, const unsigned char *lens, int n, int lane, boo
             H.sorted[off + rank] = (uint16_t)s;                       // symbols by (length, symbol)
             if (L <= P) {
                 const uint32_t rev = __brev(fst + rank) >> (32 - L);
-                const uint16_t e = (uint16_t)((s << 4) | L | ((mark_literals && s < 256) ? 0x8000 : 0));      // (literal/length table: bit 15 = a literal)
+                const auto e = (typename std::remove_reference<decltype(H.pt[0])>::type)huff_entry<MODE>((uint32_t)s, (uint32_t)L, mark_literals);
                 for (uint32_t k = rev; k < (1u << P); k += 1u << L) H.pt[k] = e;
             }
         }
@@ -471,16 +497,39 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate(const unsigned char *__rest
 constexpr int T_MAX = HGX_INF_TMAX;                              // most bytes one window may produce (a 64-bit window of 2-bit codes could ask for 8 KB)
 constexpr uint32_t NEAR_MAX = RING - T_MAX - 320;        // matches up to this distance are copied inside the ring, farther ones from memory
 
+#ifndef HGX_INF_SUBPOOL
+#define HGX_INF_SUBPOOL 256
+#endif
+constexpr uint32_t SUB_CAP = HGX_INF_SUBPOOL;
+static_assert((SUB_CAP & (SUB_CAP - 1u)) == 0u && SUB_CAP <= 32768u, "the pool is indexed under a mask; offsets live in 16 bits");
+struct HuffLdsW {                        // (entries as huff_entry<1> / <2> make them)
+    uint32_t pt[1 << LIT_P];
+    uint16_t sorted[288];
+    uint16_t count[16], first[16], offs[16];
+};
+struct DistLdsW {
+    uint32_t pt[1 << DIST_P];
+    uint16_t sorted[32];
+    uint16_t count[16], first[16], offs[16];
+};
 struct InfLdsW {
     unsigned char ring[RING];
-    HuffLds lit;
-    DistLds dist;
-    unsigned char lens[384];
-    uint32_t crc_piece[64];
+    HuffLdsW lit;
+    DistLdsW dist;
+    union {
+        unsigned char lens[384];         // [0, 19): the code-length code; [32, 32 + n_lit + n_dist): the two codes' lengths
+        uint32_t crc_piece[64];          // (only the last, partial flush of a block uses it: the lengths are history by then)
+    };
     uint32_t in_ring[128];
+    uint32_t sub[HGX_INF_SUBPOOL];       // second-level tables of both codes (huff_sub_tables)
 };
 
 __device__ uint32_t g_crc_tab[4][256];                   // slice-by-4 tables of CRC-32 (filled once per device by the host)
+// [k][v][lane]: a CRC whose k-th nibble is v, advanced by the (63 - lane) pieces of zero bytes that follow this lane's piece inside a
+// FLUSH -- eight loads and XORs put a lane's piece CRC where the end of the flush is, and the XOR over the lanes is the CRC of the
+// 2 KB (the CRC's zero operator is linear: no tree of six matrix products as in the first form)
+__device__ uint32_t g_crc_lane_nib[8][16][64];
+static_assert(PIECE == 32, "crc32_words8 and g_crc_lane_nib are laid out for 32-byte pieces");
 
 struct Win {
     const uint32_t *base;
@@ -515,10 +564,10 @@ __device__ __forceinline__ void win_ensure(Win &w, uint32_t *in_ring, int lane) 
 }
 // 64 bits of the stream from bit offset `at` (bit 0 = the first)
 __device__ __forceinline__ uint64_t win_bits(const uint32_t *in_ring, uint32_t at) {
-    const uint32_t d = at >> 5, sft = at & 31u;
+    const uint32_t d = at >> 5;
     const uint32_t w0 = in_ring[d & 127u], w1 = in_ring[(d + 1) & 127u], w2 = in_ring[(d + 2) & 127u];
-    const uint64_t lo = (uint64_t)w0 | ((uint64_t)w1 << 32);
-    return sft ? (lo >> sft) | ((uint64_t)w2 << (64 - sft)) : lo;
+    // (v_alignbit_b32: the low dword of {hi, lo} >> (shift & 31) -- a shift of 0 hands back `lo`, no special case)
+    return (uint64_t)__builtin_amdgcn_alignbit(w1, w0, at) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, at) << 32);
 }
 __device__ __forceinline__ uint64_t win_bits_uniform(const uint32_t *in_ring, uint32_t at) {
     const uint64_t v = win_bits(in_ring, at);
@@ -535,8 +584,6 @@ __device__ __forceinline__ uint32_t ub_take(UBits &u, Win &w, uint32_t *in_ring,
     return v;
 }
 
-enum { K_LIT = 0, K_MATCH = 1, K_EOB = 2, K_SLOW = 3, K_BAD = 4 };
-
 // inclusive prefix sum over the 64 lanes through the register file: row_shr 1 / 2 / 4 / 8 inside the rows of 16, then lane 15 of a row to
 // the next row (row_bcast:15, rows 1 and 3) and lane 31 to the upper half (row_bcast:31, rows 2 and 3)
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
@@ -547,6 +594,80 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);
     return v;
+}
+
+// XOR over the 64 lanes, the same way: lane 63 ends up with it
+__device__ __forceinline__ uint32_t wave_xor_to_lane63(uint32_t v) {
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, true);
+    v ^= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, true);
+    return v;
+}
+
+// SECOND-LEVEL TABLES for the codes longer than the P index bits of H.pt, so that a lane can decode them by itself (round 5, late: on
+// BAM streams a fifth of the windows ended on such a symbol and went through the wave-uniform path).  The codes that share their
+// first P bits share a table of 2^b entries in `pool` (b = their longest length - P), indexed by the stream's next b bits; the root
+// entry of such a prefix becomes K_SUB | b << 4 | offset << 16.  Canonical codes in (length, symbol) order -- H.sorted -- have the
+// long codes at the end with their prefixes in runs: one pass marks every prefix with its longest length (LDS max), one hands out
+// the offsets (a scan over the runs' heads), one fills.  A code whose table does not fit the pool keeps an empty root entry: the
+// wave-uniform path takes it, as it takes every long code in the first form.
+template <class T, int P, int MODE>
+__device__ void huff_sub_tables(T &H, const unsigned char *lens, int lane, uint32_t *pool, uint32_t &used) {
+    __builtin_amdgcn_wave_barrier();
+    uint32_t j0 = 0, n_long = 0;
+#pragma unroll
+    for (int v = 1; v < 16; ++v) { if (v <= P) j0 += H.count[v]; else n_long += H.count[v]; }
+    j0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)j0);
+    n_long = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_long);
+    if (n_long == 0) return;
+    const uint32_t end = j0 + n_long;
+    auto code_of = [&](uint32_t j, uint32_t &sym, uint32_t &L, uint32_t &rev) {       // the j-th code in canonical order, bit-reversed (stream order)
+        sym = H.sorted[j];
+        L = lens[sym];
+        rev = __brev((uint32_t)H.first[L] + (j - (uint32_t)H.offs[L])) >> (32 - L);
+    };
+    for (uint32_t j = j0 + lane; j < end; j += 64) {
+        uint32_t sym, L, rev;
+        code_of(j, sym, L, rev);
+        atomicMax(&H.pt[rev & ((1u << P) - 1u)], L - (uint32_t)P);
+    }
+    __builtin_amdgcn_wave_barrier();
+    uint32_t carry = used, r_last = 0xFFFFFFFFu;
+    for (uint32_t jb = j0; jb < end; jb += 64) {
+        const uint32_t j = jb + lane;
+        const bool valid = j < end;
+        uint32_t sym = 0, L = 0, rev = 0;
+        if (valid) code_of(j, sym, L, rev);
+        const uint32_t r = valid ? rev & ((1u << P) - 1u) : 0xFFFFFFFEu;
+        const uint32_t up = (uint32_t)__shfl_up((int)r, 1, 64);
+        const uint32_t r_prev = lane == 0 ? r_last : up;
+        const bool head = valid && r != r_prev;
+        const uint32_t b = head ? H.pt[r] : 0u;
+        const uint32_t size = head ? 1u << b : 0u;
+        const uint32_t incl = wave_incl_scan_u32(size);
+        const uint32_t off = carry + incl - size;
+        if (head) H.pt[r] = off + size <= SUB_CAP ? (((uint32_t)K_SUB << 8) | (b << 4) | (off << 16)) : 0u;
+        carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        r_last = (uint32_t)__builtin_amdgcn_readlane((int)r, 63);
+    }
+    const uint32_t used_new = carry < SUB_CAP ? carry : SUB_CAP;
+    for (uint32_t i = used + lane; i < used_new; i += 64) pool[i] = 0u;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = j0 + lane; j < end; j += 64) {
+        uint32_t sym, L, rev;
+        code_of(j, sym, L, rev);
+        const uint32_t ptr = H.pt[rev & ((1u << P) - 1u)];
+        if ((ptr & 0x70Fu) == ((uint32_t)K_SUB << 8)) {
+            const uint32_t b = (ptr >> 4) & 15u, o = ptr >> 16;
+            const uint32_t e = huff_entry<MODE>(sym, L, false);
+            for (uint32_t k = rev >> P; k < (1u << b); k += 1u << (L - (uint32_t)P)) pool[o + k] = e;
+        }
+    }
+    used = used_new;
+    __builtin_amdgcn_wave_barrier();
 }
 
 __device__ __forceinline__ uint32_t crc32_words8(const uint32_t (&wd)[8]) {
@@ -570,14 +691,14 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__re
     const int lane = threadIdx.x;
     const int bi = blockIdx.x;
     if (bi >= n_blocks) return;
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = PROF ? clock64() : 0ull, n_win = 0, n_far = 0, n_near = 0;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = PROF ? clock64() : 0ull, n_win = 0, n_far = 0, n_near = 0, n_slow = 0;
     auto lap = [&](int k) { if (PROF) { const unsigned long long t = clock64(); ph[k] += t - t_last; t_last = t; } };
     const BlockDesc B = blocks[bi];
     unsigned char *dst = out + B.out_off;
     uint32_t wpos = 0, fpos = 0, crc = 0;
     int err = INF_OK;
     // a full FLUSH leaves the ring: every lane stores its 32-byte piece (two 16-byte stores) and takes the piece's CRC-32 from the
-    // same eight registers (slice-by-4 tables, L1-resident); the pieces are joined as in the first form
+    // same eight registers (slice-by-4 tables, L1-resident); the pieces are joined through g_crc_lane_nib
     auto flush_full = [&]() {
         const uint32_t p0 = (fpos + (uint32_t)PIECE * lane) & RMASK;            // (32-byte aligned: fpos is a multiple of FLUSH)
         uint32_t wd[8];
@@ -587,13 +708,12 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__re
         unsigned char *g = dst + fpos + (uint32_t)PIECE * lane;
         __builtin_memcpy(g, &a, 16);
         __builtin_memcpy(g + 16, &b2, 16);
-        uint32_t mine = crc32_words8(wd);
+        const uint32_t mine = crc32_words8(wd);
+        uint32_t adv = 0;
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const uint32_t other = (uint32_t)__shfl_down((int)mine, 1 << k, 64);
-            mine = crc_advance(op, k, mine) ^ other;
-        }
-        crc = crc_advance(op, 6, crc) ^ (uint32_t)__builtin_amdgcn_readfirstlane((int)mine);
+        for (int k = 0; k < 8; ++k) adv ^= g_crc_lane_nib[k][(mine >> (4 * k)) & 15u][lane];
+        adv = wave_xor_to_lane63(adv);
+        crc = crc_advance(op, 6, crc) ^ (uint32_t)__builtin_amdgcn_readlane((int)adv, 63);
         fpos += (uint32_t)FLUSH;
     };
     auto flush_rest = [&](uint32_t n) {        // the last n < FLUSH bytes
@@ -671,8 +791,8 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__re
                 for (int s2 = lane; s2 < 288; s2 += 64) S.lens[s2] = (unsigned char)(s2 < 144 ? 8 : s2 < 256 ? 9 : s2 < 280 ? 7 : 8);
                 if (lane < 32) S.lens[288 + lane] = 5;
                 __builtin_amdgcn_wave_barrier();
-                if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens, 288, lane, false, true)) { err = INF_BAD_LENGTHS; break; }
-                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 288, 32, lane, true)) { err = INF_BAD_LENGTHS; break; }
+                if (!huff_build<HuffLdsW, LIT_P, 1>(S.lit, S.lens, 288, lane, false)) { err = INF_BAD_LENGTHS; break; }
+                if (!huff_build<DistLdsW, DIST_P, 2>(S.dist, S.lens + 288, 32, lane, true)) { err = INF_BAD_LENGTHS; break; }
             } else {                                                // dynamic codes (3.2.7)
                 const int n_lit = (int)ub_take(u, w, S.in_ring, 5, lane) + 257;
                 const int n_dist = (int)ub_take(u, w, S.in_ring, 5, lane) + 1;
@@ -685,7 +805,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__re
                     if (lane == 0) S.lens[c_cl_order[i]] = (unsigned char)v;
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens, 19, lane, false)) { err = INF_BAD_LENGTHS; break; }
+                if (!huff_build<DistLdsW, DIST_P, 0>(S.dist, S.lens, 19, lane, false)) { err = INF_BAD_LENGTHS; break; }
                 int at = 0, prev = 0;
                 const int total = n_lit + n_dist;
                 while (at < total && !err) {
@@ -708,13 +828,16 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__re
                 if (err) break;
                 __builtin_amdgcn_wave_barrier();
                 if (S.lens[32 + 256] == 0) { err = INF_BAD_LENGTHS; break; }
-                if (!huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, n_lit, lane, false, true)) {
+                if (!huff_build<HuffLdsW, LIT_P, 1>(S.lit, S.lens + 32, n_lit, lane, false)) {
                     // an incomplete literal/length code is legal only when it is ONE code of one bit (zlib's inflate_table)
-                    if (!huff_incomplete_ok(S.lens + 32, n_lit, lane, false) || !huff_build<HuffLds, LIT_P>(S.lit, S.lens + 32, n_lit, lane, true, true)) { err = INF_BAD_LENGTHS; break; }
+                    if (!huff_incomplete_ok(S.lens + 32, n_lit, lane, false) || !huff_build<HuffLdsW, LIT_P, 1>(S.lit, S.lens + 32, n_lit, lane, true)) { err = INF_BAD_LENGTHS; break; }
                 }
-                if (!huff_build<DistLds, DIST_P>(S.dist, S.lens + 32 + n_lit, n_dist, lane, false)) {
-                    if (!huff_incomplete_ok(S.lens + 32 + n_lit, n_dist, lane, true) || !huff_build<DistLds, DIST_P>(S.dist, S.lens + 32 + n_lit, n_dist, lane, true)) { err = INF_BAD_LENGTHS; break; }
+                if (!huff_build<DistLdsW, DIST_P, 2>(S.dist, S.lens + 32 + n_lit, n_dist, lane, false)) {
+                    if (!huff_incomplete_ok(S.lens + 32 + n_lit, n_dist, lane, true) || !huff_build<DistLdsW, DIST_P, 2>(S.dist, S.lens + 32 + n_lit, n_dist, lane, true)) { err = INF_BAD_LENGTHS; break; }
                 }
+                uint32_t sub_used = 0;
+                huff_sub_tables<HuffLdsW, LIT_P, 1>(S.lit, S.lens + 32, lane, S.sub, sub_used);
+                huff_sub_tables<DistLdsW, DIST_P, 2>(S.dist, S.lens + 32 + n_lit, lane, S.sub, sub_used);
             }
             // ---- the symbols of the block, a window of 64 bit offsets at a time ----------------------------------------------
             bool eob = false;
@@ -723,34 +846,41 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__re
                 if (PROF) n_win++;
                 win_ensure(w, S.in_ring, lane);
                 const uint64_t bits = win_bits(S.in_ring, w.P + (uint32_t)lane);
-                // this lane's symbol, as if one started at its offset
-                uint32_t kind = K_SLOW, used = 0, olen = 0, val = 0, mdist = 0;
+                // this lane's symbol, as if one started at its offset.  Straight-line code: the table entries carry what a symbol means
+                // (huff_entry<1> / <2>), every lane looks a distance up whether it holds a match or not, and the three shifts of the
+                // window are v_alignbit_b32 (a code has <= 15 bits, a length <= 5 extra bits: after them the distance code and its
+                // <= 13 extra bits fit the low dword)
+                uint32_t kind, used, olen, val, mdist;
                 {
-                    const uint32_t e = S.lit.pt[(uint32_t)bits & ((1u << LIT_P) - 1u)];
-                    const uint32_t nb = e & 15u;
-                    if (nb) {
-                        const uint32_t sym = (e >> 4) & 0x1FFu;
-                        if (e & 0x8000u) { kind = K_LIT; used = nb; olen = 1; val = sym; }
-                        else if (sym == 256u) { kind = K_EOB; used = nb; }
-                        else if (sym <= 285u) {
-                            const uint32_t li = sym - 257u;
-                            const uint32_t le = li < 8u || li == 28u ? 0u : (li - 4u) >> 2;
-                            const uint32_t lbase = li < 8u ? 3u + li : li == 28u ? 258u : ((4u + (li & 3u)) << le) + 3u;
-                            const uint32_t len = lbase + ((uint32_t)(bits >> nb) & ((1u << le) - 1u));
-                            const uint32_t p1 = nb + le;
-                            const uint32_t ed = S.dist.pt[(uint32_t)(bits >> p1) & ((1u << DIST_P) - 1u)];
-                            const uint32_t dn = ed & 15u;
-                            if (dn) {
-                                const uint32_t ds = ed >> 4;
-                                if (ds < 30u) {
-                                    const uint32_t de = ds < 4u ? 0u : (ds >> 1) - 1u;
-                                    const uint32_t dbase = ds < 4u ? ds + 1u : ((2u + (ds & 1u)) << de) + 1u;
-                                    mdist = dbase + ((uint32_t)(bits >> (p1 + dn)) & ((1u << de) - 1u));
-                                    kind = K_MATCH; used = p1 + dn + de; olen = len;
-                                } else kind = K_BAD;
-                            }
-                        } else kind = K_BAD;
+                    const uint32_t blo = (uint32_t)bits, bhi = (uint32_t)(bits >> 32);
+                    uint32_t e = S.lit.pt[blo & ((1u << LIT_P) - 1u)];
+                    {   // a code longer than the index bits: its second-level table (huff_sub_tables), by the bits that follow
+                        const bool sub = (e & 0x70Fu) == ((uint32_t)K_SUB << 8);
+                        if (__builtin_amdgcn_ballot_w64(sub)) {
+                            const uint32_t e2 = S.sub[((e >> 16) + __builtin_amdgcn_ubfe(blo, (uint32_t)LIT_P, (e >> 4) & 15u)) & (SUB_CAP - 1u)];
+                            e = sub ? e2 : e;
+                        }
                     }
+                    const uint32_t nb = e & 15u, le = (e >> 4) & 15u, k0 = (e >> 8) & 7u, base = e >> 16;
+                    const uint32_t xlo = __builtin_amdgcn_alignbit(bhi, blo, nb), xhi = bhi >> nb;
+                    const uint32_t len = base + __builtin_amdgcn_ubfe(xlo, 0u, le);
+                    const uint32_t y = __builtin_amdgcn_alignbit(xhi, xlo, le);
+                    uint32_t ed = S.dist.pt[y & ((1u << DIST_P) - 1u)];
+                    {
+                        const bool sub = (ed & 0x70Fu) == ((uint32_t)K_SUB << 8);
+                        if (__builtin_amdgcn_ballot_w64(sub)) {
+                            const uint32_t e2 = S.sub[((ed >> 16) + __builtin_amdgcn_ubfe(y, (uint32_t)DIST_P, (ed >> 4) & 15u)) & (SUB_CAP - 1u)];
+                            ed = sub ? e2 : ed;
+                        }
+                    }
+                    const uint32_t dn = ed & 15u, de = (ed >> 4) & 15u;
+                    const bool is_m = k0 == (uint32_t)K_MATCH;                         // (an empty entry is all zeros: nb = 0, k0 = K_LIT)
+                    mdist = (ed >> 16) + __builtin_amdgcn_ubfe(y >> dn, 0u, de);
+                    kind = nb ? k0 : (uint32_t)K_SLOW;
+                    if (is_m) kind = dn == 0u ? (uint32_t)K_SLOW : (ed & 0x100u) ? (uint32_t)K_BAD : (uint32_t)K_MATCH;
+                    used = is_m ? nb + le + dn + de : nb;
+                    olen = is_m ? len : (kind == (uint32_t)K_LIT ? 1u : 0u);
+                    val = base & 255u;
                 }
                 const uint32_t r0 = used | (kind << 6) | (olen << 9) | (val << 18);     // used <= 48, kind < 8, olen <= 258, val < 256
                 if (PROF) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); if (__builtin_amdgcn_readfirstlane((int)r0) == -1) err = INF_BAD_CODE; }
@@ -856,15 +986,16 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__re
                 wpos += run;
                 w.P += cur;
                 if (slow) {
+                    if (PROF) n_slow++;
                     // a symbol outside the tables' fast cases -- a code longer than the index bits, mostly: the wave-uniform path, one symbol
                     win_ensure(w, S.in_ring, lane);
                     ub_fill(u, w, S.in_ring);
-                    int sym;
+                    uint32_t k2, le, base;                               // as the fat entries say it, or worked out from the symbol
                     {
                         const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.lit.pt[(uint32_t)u.buf & ((1u << LIT_P) - 1u)]);
-                        if (e & 15u) { sym = (int)((e >> 4) & 0x1FFu); u.buf >>= (e & 15u); u.cnt -= (int)(e & 15u); w.P += (e & 15u); }
+                        if (e & 15u) { k2 = (e >> 8) & 7u; le = (e >> 4) & 15u; base = e >> 16; u.buf >>= (e & 15u); u.cnt -= (int)(e & 15u); w.P += (e & 15u); }
                         else {
-                            sym = -1;
+                            int sym = -1;
                             const uint32_t rev15 = __brev((uint32_t)u.buf & 0x7FFFu) >> 17;
                             for (int L = LIT_P + 1; L <= 15; ++L) {
                                 const uint32_t c = rev15 >> (15 - L);
@@ -872,27 +1003,28 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__re
                                 if (dd < S.lit.count[L]) { sym = S.lit.sorted[S.lit.offs[L] + dd]; u.buf >>= L; u.cnt -= L; w.P += (uint32_t)L; break; }
                             }
                             sym = __builtin_amdgcn_readfirstlane(sym);
+                            if (sym < 0) { err = INF_BAD_CODE; break; }
+                            const uint32_t f = huff_entry<1>((uint32_t)sym, 1u, false);
+                            k2 = (f >> 8) & 7u; le = (f >> 4) & 15u; base = f >> 16;
                         }
                     }
-                    if (sym < 0) { err = INF_BAD_CODE; break; }
-                    if (sym < 256) {
+                    if (k2 == (uint32_t)K_BAD) { err = INF_BAD_CODE; break; }
+                    if (k2 == (uint32_t)K_LIT) {
                         if (wpos + 1 > B.out_len) { err = INF_OVERRUN; break; }
-                        if (lane == 0) S.ring[wpos & RMASK] = (unsigned char)sym;
+                        if (lane == 0) S.ring[wpos & RMASK] = (unsigned char)base;
                         wpos += 1;
-                    } else if (sym == 256) eob = true;
+                    } else if (k2 == (uint32_t)K_EOB) eob = true;
                     else {
-                        const int li = sym - 257;
-                        if (li >= 29) { err = INF_BAD_CODE; break; }
-                        const int le = li < 8 || li == 28 ? 0 : (li - 4) >> 2;
-                        const uint32_t lbase = li < 8 ? 3u + (uint32_t)li : li == 28 ? 258u : ((4u + ((uint32_t)li & 3u)) << le) + 3u;
-                        const uint32_t len = lbase + ub_take(u, w, S.in_ring, le, lane);
+                        const uint32_t len = base + ub_take(u, w, S.in_ring, (int)le, lane);
                         if (u.cnt < 32) { win_ensure(w, S.in_ring, lane); ub_fill(u, w, S.in_ring); }
-                        int ds;
+                        uint32_t de, dbase;
                         {
                             const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.dist.pt[(uint32_t)u.buf & ((1u << DIST_P) - 1u)]);
-                            if (e & 15u) { ds = (int)(e >> 4); u.buf >>= (e & 15u); u.cnt -= (int)(e & 15u); w.P += (e & 15u); }
-                            else {
-                                ds = -1;
+                            if (e & 15u) {
+                                if (e & 0x100u) { err = INF_BAD_CODE; break; }
+                                de = (e >> 4) & 15u; dbase = e >> 16; u.buf >>= (e & 15u); u.cnt -= (int)(e & 15u); w.P += (e & 15u);
+                            } else {
+                                int ds = -1;
                                 const uint32_t rev15 = __brev((uint32_t)u.buf & 0x7FFFu) >> 17;
                                 for (int L = DIST_P + 1; L <= 15; ++L) {
                                     const uint32_t c = rev15 >> (15 - L);
@@ -900,12 +1032,12 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__re
                                     if (dd < S.dist.count[L]) { ds = S.dist.sorted[S.dist.offs[L] + dd]; u.buf >>= L; u.cnt -= L; w.P += (uint32_t)L; break; }
                                 }
                                 ds = __builtin_amdgcn_readfirstlane(ds);
+                                if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
+                                const uint32_t f = huff_entry<2>((uint32_t)ds, 1u, false);
+                                de = (f >> 4) & 15u; dbase = f >> 16;
                             }
                         }
-                        if (ds < 0 || ds >= 30) { err = INF_BAD_CODE; break; }
-                        const int de = ds < 4 ? 0 : (ds >> 1) - 1;
-                        const uint32_t dbase = ds < 4 ? (uint32_t)ds + 1u : ((2u + ((uint32_t)ds & 1u)) << de) + 1u;
-                        const uint32_t dist = dbase + ub_take(u, w, S.in_ring, de, lane);
+                        const uint32_t dist = dbase + ub_take(u, w, S.in_ring, (int)de, lane);
                         if (dist > wpos) { err = INF_BAD_DIST; break; }
                         if (wpos + len > B.out_len) { err = INF_OVERRUN; break; }
                         copy_match(wpos, len, dist);
@@ -933,7 +1065,7 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__re
     if (lane == 0) verdict[bi] = (uint32_t)err;
     if (PROF && lane == 0) {
         for (int k = 0; k < 8; ++k) prof[(size_t)bi * 12 + k] = ph[k];
-        prof[(size_t)bi * 12 + 8] = n_win; prof[(size_t)bi * 12 + 9] = n_near; prof[(size_t)bi * 12 + 10] = n_far; prof[(size_t)bi * 12 + 11] = B.out_len;
+        prof[(size_t)bi * 12 + 8] = n_win; prof[(size_t)bi * 12 + 9] = n_near; prof[(size_t)bi * 12 + 10] = n_far; prof[(size_t)bi * 12 + 11] = B.out_len | (n_slow << 32);
     }
 }
 
@@ -948,6 +1080,26 @@ int inflate_w_setup() {                  // once per device: the CRC-32 slice ta
     for (int t = 1; t < 4; ++t)
         for (uint32_t i = 0; i < 256; ++i) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 255u];
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_crc_tab), tab, sizeof(tab)));
+    {
+        // columns of the zero operator for (63 - lane) pieces: lane 63's is the identity, lane l's = one more piece than lane l + 1's
+        std::vector<uint32_t> nib((size_t)8 * 16 * 64);
+        uint32_t col[32];
+        for (int i = 0; i < 32; ++i) col[i] = 1u << i;
+        for (int lane = 63; lane >= 0; --lane) {
+            for (int k = 0; k < 8; ++k)
+                for (uint32_t v = 0; v < 16; ++v) {
+                    uint32_t x = 0;
+                    for (int b = 0; b < 4; ++b) if (v >> b & 1u) x ^= col[4 * k + b];
+                    nib[((size_t)k * 16 + v) * 64 + lane] = x;
+                }
+            for (int i = 0; i < 32; ++i) {
+                uint32_t c = col[i];
+                for (int k = 0; k < 8 * PIECE; ++k) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u)));
+                col[i] = c;
+            }
+        }
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_crc_lane_nib), nib.data(), nib.size() * 4));
+    }
     HIPCHK(hipFuncSetAttribute((const void *)k_bgzf_inflate_w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InfLdsW)));
     HIPCHK(hipFuncSetAttribute((const void *)k_bgzf_inflate_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InfLdsW)));
     return HGX_OK;
@@ -1039,10 +1191,15 @@ int hgx_bgzf_inflate_dev(const unsigned char *d_in, const hgx_bgzf_block *blocks
         HIPCHK(hipMemcpyAsync(hp.data(), b_prof.p, hp.size() * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         double tot[12] = {0};
-        for (size_t i = 0; i < n_blocks; ++i) for (int k = 0; k < 12; ++k) tot[k] += (double)hp[i * 12 + k];
+        double n_slow = 0;
+        for (size_t i = 0; i < n_blocks; ++i) {
+            n_slow += (double)(hp[i * 12 + 11] >> 32);
+            hp[i * 12 + 11] &= 0xFFFFFFFFull;
+            for (int k = 0; k < 12; ++k) tot[k] += (double)hp[i * 12 + k];
+        }
         static const char *const nm[8] = {"header", "decode", "walk", "literals", "near matches", "far matches", "flush", "slow"};
-        fprintf(stderr, "[k_bgzf_inflate_w] %zu blocks, per block: %.0f bytes, %.0f windows, %.0f near + %.0f far matches; clock64 ticks per block:", n_blocks,
-                tot[11] / n_blocks, tot[8] / n_blocks, tot[9] / n_blocks, tot[10] / n_blocks);
+        fprintf(stderr, "[k_bgzf_inflate_w] %zu blocks, per block: %.0f bytes, %.0f windows, %.0f near + %.0f far matches, %.1f slow symbols; clock64 ticks per block:", n_blocks,
+                tot[11] / n_blocks, tot[8] / n_blocks, tot[9] / n_blocks, tot[10] / n_blocks, n_slow / n_blocks);
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.0f", nm[k], tot[k] / n_blocks);
         fprintf(stderr, "\n");
     } else

@@ -7,6 +7,8 @@ import os, sys, random, struct, zlib, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from hisatgenotype_amd import capi
+if os.environ.get("INF_LIB"):                              # a variant build of the library (tools/inf_subpool_check.sh)
+    capi.LIB_PATH = os.environ["INF_LIB"]
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 
