@@ -381,7 +381,7 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
                                       "note": ("bytes the call sends to the device (the SAM text + its line table) / the call's time, against the measured "
                                                "host-to-device rate of registered memory (tools/pinned_probe.hip: 57.5 GB/s; PCIe Gen5 x16)") if kind == "sam" else
                                               ("a BAM travels DEFLATED (the file's bytes + a block table): the link is idle; the call is bound by "
-                                               "k_bgzf_inflate_w -- DEFLATE symbol decoding, one wavefront per BGZF block, ~95 GB/s of payload -- and "
+                                               "k_bgzf_inflate_w -- DEFLATE symbol decoding, one wavefront per BGZF block, ~140 GB/s of payload -- and "
                                                "the record kernels behind it (DESIGN.md section 5.6)")},
                          "runs_ms": [round(t * 1e3, 1) for t in spaced],
                          "throttled_ms": None if th1 is None else round((th2 - th1) / 1e3, 1),
@@ -391,6 +391,12 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
                                           "throttled_ms": None if th0 is None else round((th1 - th0) / 1e3, 1)},
                          "file_MB": round(os.path.getsize(path) / 1e6, 1),
                          "records_in_file": n_records, "result_identical_to_hbm_path": bool(same)}
+            try:            # dispatches / kernel time per call, from the committed kernel stats of the traced calls (tools/install_profiles_r05.py)
+                prof = json.load(open(os.path.join(ROOT, "profiles", "step_profile.json"))).get("file_to_result", {}).get(kind)
+                if prof and n_records == 1000000:
+                    out[kind]["profile"] = prof
+            except Exception:
+                pass
             if kind == "bam":
                 # the like-for-like CPU figure of a file -> result call: the HOST front end (csrc/hgx_sam.cpp + hgx_bam.cpp: read, inflate,
                 # walk, sort, decode -- what the device front end is checked against) on ONE thread over the same file; the scoring +

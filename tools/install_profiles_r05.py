@@ -93,3 +93,30 @@ for kind in ("sam", "bam"):
     p = f"{src}/fe_{kind}.log"
     if os.path.exists(p):
         shutil.copy(p, f"{dst}/{R}_final_file_to_result_{kind}.log")
+# dispatches and kernel time per file -> result call, from the traced calls' kernel stats (bench.py carries them as e2e.<kind>.profile).
+# The number of calls in a trace = the launches of a kernel that runs once per call (k_fe_records runs once per front-end pass).
+fr = {}
+for kind in ("sam", "bam"):
+    p = f"{dst}/{R}_final_file_to_result_{kind}_kernel_stats.csv"
+    if not os.path.exists(p):
+        continue
+    rows = list(csv.DictReader(open(p)))
+    calls = [int(r["Calls"]) for r in rows if "k_fe_records" in r["Name"]]
+    if not calls or not calls[0]:
+        continue
+    n_calls = calls[0]
+    lib = [r for r in rows if "rocprim" in r["Name"] or "hipcub" in r["Name"]]
+    fr[kind] = {"calls_traced": n_calls,
+                "dispatches_per_call": round(sum(int(r["Calls"]) for r in rows) / n_calls, 1),
+                "kernel_ms_per_call": round(sum(int(r["TotalDurationNs"]) for r in rows) / 1e6 / n_calls, 3),
+                "library_sort_dispatches_per_call": round(sum(int(r["Calls"]) for r in lib) / n_calls, 1),
+                "largest_kernels_ms_per_call": {r["Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-40:]:
+                                                round(int(r["TotalDurationNs"]) / 1e6 / n_calls, 3)
+                                                for r in sorted(rows, key=lambda r: -int(r["TotalDurationNs"]))[:6]},
+                "source": f"profiles/{R}_final_file_to_result_{kind}_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/e2e_{'bam' if kind == 'bam' else 'file'}.py)"}
+sp = f"{dst}/step_profile.json"
+if fr and os.path.exists(sp):
+    sj = json.load(open(sp))
+    sj["file_to_result"] = fr
+    json.dump(sj, open(sp, "w"), indent=1)
+    print("file -> result per call:", {k: (v["dispatches_per_call"], v["kernel_ms_per_call"]) for k, v in fr.items()})
