@@ -111,9 +111,11 @@ __global__ __launch_bounds__(SCAN_T) void k_scan_u32(const uint32_t *__restrict_
 }
 static size_t scan_scratch_bytes(long n) { return ((size_t)((n + SCAN_TILE - 1) / SCAN_TILE) + 2) * 8; }
 // out = exclusive prefix sums of in[0..n), *total_dev = their total; scratch from scan_scratch_bytes(n)
-static int scan_u32(const uint32_t *in, uint32_t *out, long n, void *scratch, uint32_t *total_dev, hipStream_t st) {
+// (scratch_is_zero: the caller's own kernel has zeroed the scratch -- k_ht_init does it with the table -- so that the chain of a
+// dedup carries no memset of its own)
+static int scan_u32(const uint32_t *in, uint32_t *out, long n, void *scratch, uint32_t *total_dev, hipStream_t st, bool scratch_is_zero = false) {
     const long tiles = (n + SCAN_TILE - 1) / SCAN_TILE;
-    HIPCHK(hipMemsetAsync(scratch, 0, scan_scratch_bytes(n), st));
+    if (!scratch_is_zero) HIPCHK(hipMemsetAsync(scratch, 0, scan_scratch_bytes(n), st));
     hipLaunchKernelGGL(k_scan_u32, dim3((unsigned)tiles), dim3(SCAN_T), 0, st, in, out, n, (unsigned long long *)scratch,
                        (uint32_t *)((unsigned long long *)scratch + tiles), total_dev);
     HIPCHK(hipGetLastError());
@@ -135,9 +137,12 @@ static int scan_u32(const uint32_t *in, uint32_t *out, long n, void *scratch, ui
 #define HT_NONE 0xFFFFFFFFu
 
 __device__ __forceinline__ uint32_t ht_global_insert(unsigned long long *keys, uint32_t tmask, uint64_t key) {
+    // A slot never changes once it holds a key: a plain look (served by the L2, where the atomics execute) settles most inserts --
+    // the hot classes are in the table after the first few workgroups -- and only an empty-looking slot costs a CAS.
     uint32_t h = (uint32_t)key & tmask;
     for (;;) {
-        const unsigned long long old = atomicCAS(&keys[h], (unsigned long long)HGX_EMPTY_KEY, (unsigned long long)key);
+        unsigned long long old = __hip_atomic_load(&keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == HGX_EMPTY_KEY) old = atomicCAS(&keys[h], (unsigned long long)HGX_EMPTY_KEY, (unsigned long long)key);
         if (old == HGX_EMPTY_KEY || old == key) return h;
         h = (h + 1) & tmask;
     }
@@ -172,7 +177,8 @@ __global__ __launch_bounds__(BS) void k_ht_insert(const uint64_t *__restrict__ h
     for (int s = tid; s < SLOTS; s += BS) {
         if (lkey[s] != HGX_EMPTY_KEY) {
             const uint32_t g = ht_global_insert(keys, tmask, lkey[s]);
-            atomicMin(&first[g], lmin[s]);
+            // (the first row only ever goes down: a value already below mine needs no atomic; a stale, larger one merely costs it)
+            if (__hip_atomic_load(&first[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > lmin[s]) atomicMin(&first[g], lmin[s]);
             atomicAdd(&cnt[g], lcnt[s]);
             lg[s] = g;
         }
@@ -181,11 +187,13 @@ __global__ __launch_bounds__(BS) void k_ht_insert(const uint64_t *__restrict__ h
     if (i < n) slot_of[i] = valid ? lg[ls] : HT_NONE;
 }
 __global__ void k_ht_init(unsigned long long *__restrict__ keys, uint32_t *__restrict__ first, unsigned long long *__restrict__ cnt,
-                          long T, uint32_t *__restrict__ flag, long n, uint32_t *__restrict__ meta) {
+                          long T, uint32_t *__restrict__ flag, long n, uint32_t *__restrict__ meta,
+                          unsigned long long *__restrict__ scan_state, long n_state) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < T) { keys[i] = HGX_EMPTY_KEY; first[i] = HT_NONE; cnt[i] = 0; }
     if (i < n) flag[i] = 0;
     if (i < 4) meta[i] = 0;
+    if (i < n_state) scan_state[i] = 0;                 // (the tile states + ticket of the scan that numbers the classes)
 }
 __global__ void k_ht_mark(const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ first, long T,
                           uint32_t *__restrict__ is_first) {
@@ -369,10 +377,10 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     ALLOC(b_bad, (size_t)n * 4);
     ALLOC(b_tmp, scan_scratch_bytes(n));
     // first rows of the classes -> flags -> class ids in first-seen order (single-pass scan), class count in meta[1]
-    auto number_classes = [&]() -> int {
+    auto number_classes = [&](bool scratch_is_zero) -> int {
         hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,
                            b_flag.as<uint32_t>());
-        return scan_u32(b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n, b_tmp.p, b_meta.as<uint32_t>() + 1, st);
+        return scan_u32(b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n, b_tmp.p, b_meta.as<uint32_t>() + 1, st, scratch_is_zero);
     };
     uint32_t meta[4] = {0, 0, 0, 0};           // {some key collided, number of classes, number of collided rows, -}
     // rows that share a key with a different row: re-keyed and re-checked (see k_fix_reinsert); classes renumbered; meta refreshed
@@ -399,7 +407,7 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
             return HGX_ECOLLISION;
         }
         HIPCHK(hipMemsetAsync(b_flag.p, 0, (size_t)n * 4, st));
-        { int rc_ = number_classes(); if (rc_) return rc_; }
+        { int rc_ = number_classes(false); if (rc_) return rc_; }
         HIPCHK(hipGetLastError());
         { int rc_ = hgx_d2h(meta, b_meta.p, 16, st); if (rc_) return rc_; }
         { int rc_ = hgx_sync(st); if (rc_) return rc_; }
@@ -407,14 +415,15 @@ static int dedup_hash_table(hgx_classes *cl, const uint64_t *rows, const uint64_
     };
     // one launch instead of five memsets: table = empty, flags = 0, meta = {collision flag, number of classes} = 0
     hipLaunchKernelGGL(k_ht_init, dim3(nblk(std::max(T, n), 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(),
-                       b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), T, b_flag.as<uint32_t>(), n, b_meta.as<uint32_t>());
+                       b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), T, b_flag.as<uint32_t>(), n, b_meta.as<uint32_t>(),
+                       b_tmp.as<unsigned long long>(), (long)(scan_scratch_bytes(n) / 8));
     if (small_blocks)
         hipLaunchKernelGGL(k_ht_insert<256>, dim3(nblk(n, 256)), dim3(256), 0, st, keys_in, row_weight, n, b_keys.as<unsigned long long>(),
                            b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1), b_slot.as<uint32_t>());
     else
         hipLaunchKernelGGL(k_ht_insert<1024>, dim3(nblk(n, 1024)), dim3(1024), 0, st, keys_in, row_weight, n, b_keys.as<unsigned long long>(),
                            b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1), b_slot.as<uint32_t>());
-    { int rc_ = number_classes(); if (rc_) return rc_; }
+    { int rc_ = number_classes(true); if (rc_) return rc_; }
     // the exact check does not need the class count: queue it before the D2H that sizes the output
     hipLaunchKernelGGL(k_verify_ht, dim3(nblk((n + 3) / 4, 4)), dim3(256), 0, st, rows, w64, and_mask, b_slot.as<uint32_t>(),
                        b_first.as<uint32_t>(), n, b_meta.as<int>(), b_bad.as<uint32_t>(), b_meta.as<uint32_t>() + 2, seg);
@@ -509,9 +518,17 @@ static int dedup_classes_impl(hgx_classes **out, const uint64_t *rows, const uin
 // Same result as hgx_pair_classes + hgx_dedup_classes (classes in first-seen order, counts, first pair), with the
 // 896-byte-per-pair row traffic divided by the repeat factor.
 // ------------------------------------------------------------------------------------------------
+// (the launch also empties the hash table, the flags, the meta words and the scan state of the grouping that follows -- what
+// k_ht_init does for a dedup: one dispatch less in front of the insert)
+struct HtInit { unsigned long long *keys; uint32_t *first; unsigned long long *cnt; long T; uint32_t *flag; uint32_t *meta;
+                unsigned long long *scan_state; long n_state; };
 __global__ void k_sig_keys(const int32_t *__restrict__ pair_off, const uint32_t *__restrict__ refs, int n_pairs, uint32_t level,
-                           uint64_t *__restrict__ key, const uint32_t *__restrict__ seg = nullptr) {
+                           uint64_t *__restrict__ key, const uint32_t *__restrict__ seg, HtInit init) {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (long s = p; s < init.T; s += (long)gridDim.x * blockDim.x) { init.keys[s] = HGX_EMPTY_KEY; init.first[s] = HT_NONE; init.cnt[s] = 0; }
+    if (p < n_pairs) init.flag[p] = 0;
+    if (p < 4) init.meta[p] = 0;
+    if (p < init.n_state) init.scan_state[p] = 0;
     if (p >= n_pairs) return;
     uint64_t h = 0x243f6a8885a308d3ull;
     uint32_t cnt = 0;
@@ -618,15 +635,16 @@ static int group_pairs_impl(hgx_groups **out, const int32_t *pair_off, const uin
     ALLOC(b_keys, (size_t)T * 8); ALLOC(b_first, (size_t)T * 4); ALLOC(b_cnt, (size_t)T * 8);
     ALLOC(b_slot, (size_t)n * 4); ALLOC(b_flag, (size_t)n * 4); ALLOC(b_rank, (size_t)n * 4); ALLOC(b_meta, 16);
     ALLOC(b_tmp, scan_scratch_bytes(n));
-    hipLaunchKernelGGL(k_sig_keys, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level, b_key.as<uint64_t>(), seg);
-    hipLaunchKernelGGL(k_ht_init, dim3(nblk(std::max(T, n), 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(),
-                       b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), T, b_flag.as<uint32_t>(), n, b_meta.as<uint32_t>());
+    const HtInit init{b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), T, b_flag.as<uint32_t>(),
+                      b_meta.as<uint32_t>(), b_tmp.as<unsigned long long>(), (long)(scan_scratch_bytes(n) / 8)};
+    hipLaunchKernelGGL(k_sig_keys, dim3(nblk(std::max<long>(n, 1024), 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level, b_key.as<uint64_t>(),
+                       seg, init);
     hipLaunchKernelGGL(k_ht_insert<256>, dim3(nblk(n, 256)), dim3(256), 0, st, b_key.as<uint64_t>(), (const int64_t *)nullptr, n,
                        b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), b_cnt.as<unsigned long long>(), (uint32_t)(T - 1),
                        b_slot.as<uint32_t>());
     hipLaunchKernelGGL(k_ht_mark, dim3(nblk(T, 256)), dim3(256), 0, st, b_keys.as<unsigned long long>(), b_first.as<uint32_t>(), T,
                        b_flag.as<uint32_t>());
-    { int rc_ = scan_u32(b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n, b_tmp.p, b_meta.as<uint32_t>() + 1, st); if (rc_) return rc_; }
+    { int rc_ = scan_u32(b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n, b_tmp.p, b_meta.as<uint32_t>() + 1, st, true); if (rc_) return rc_; }
     hipLaunchKernelGGL(k_sig_verify, dim3(nblk(n, 256)), dim3(256), 0, st, pair_off, refs, n_pairs, (uint32_t)level,
                        b_slot.as<uint32_t>(), b_first.as<uint32_t>(), b_meta.as<int>(), seg);
     // group id (first-seen order) -> first pair, group size; sized for the worst case: no host-side group count needed yet

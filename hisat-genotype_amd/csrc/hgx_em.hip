@@ -1775,7 +1775,8 @@ static int em_impl_inner(const hgx_classes *cc, int32_t n_alleles, int32_t remov
     const int w64c = A / 64;
     DevBuf b_p, b_q1, b_q2, b_q3, b_wc, b_pr, b_pr1, b_pr2, b_pr3, b_len, b_scal, b_out;
     ALLOC(b_p, A * 8); ALLOC(b_q1, A * 8); ALLOC(b_q2, A * 8); ALLOC(b_q3, A * 8); ALLOC(b_out, A * 8);
-    ALLOC(b_wc, (size_t)C * 8); ALLOC(b_pr, A); ALLOC(b_pr1, A); ALLOC(b_pr2, A); ALLOC(b_pr3, A); ALLOC(b_scal, S_N * 8);
+    const size_t n_cnt_all = (size_t)std::max((C + BLOCK - 1) / BLOCK, (A + BLOCK - 1) / BLOCK);
+    ALLOC(b_wc, (size_t)C * 8); ALLOC(b_pr, A); ALLOC(b_pr1, A); ALLOC(b_pr2, A); ALLOC(b_pr3, A); ALLOC(b_scal, S_N * 8 + n_cnt_all * 4);       // (scalars + the passes' slab counters: one block, one memset)
     double *d_len = nullptr;
     if (allele_len) {
         std::vector<double> l(A, 1.0);
@@ -1788,7 +1789,7 @@ static int em_impl_inner(const hgx_classes *cc, int32_t n_alleles, int32_t remov
     double *p = b_p.as<double>(), *q1 = b_q1.as<double>(), *q2 = b_q2.as<double>(), *q3 = b_q3.as<double>();
     uint8_t *pr = b_pr.as<uint8_t>(), *pr1 = b_pr1.as<uint8_t>(), *pr2 = b_pr2.as<uint8_t>(), *pr3 = b_pr3.as<uint8_t>();
     double *wc = b_wc.as<double>(), *scal = b_scal.as<double>();
-    HIPCHK(hipMemsetAsync(scal, 0, S_N * 8, st));
+    HIPCHK(hipMemsetAsync(scal, 0, S_N * 8 + n_cnt_all * 4, st));
     // tie order of the result (first class containing each allele): independent of the EM, queued before it
     DevBuf b_fc;
     std::vector<int32_t> h_fc;
@@ -1803,7 +1804,7 @@ static int em_impl_inner(const hgx_classes *cc, int32_t n_alleles, int32_t remov
 #include "lab/hgx_em_impl_mfma_setup.inc"        // MFMA operand order of both matrices (back-end 2)
 #endif
 
-    DevBuf b_part, b_part_c, b_cnt;
+    DevBuf b_part, b_part_c;
     if (g_backend == 0 || g_backend == 3) {
         // table-lookup kernels: word-transposed copies of both matrices, built once per class set
         const int Cp = c->c64 * 64;
@@ -1815,11 +1816,10 @@ static int em_impl_inner(const hgx_classes *cc, int32_t n_alleles, int32_t remov
             hipLaunchKernelGGL(k_word_transpose, dim3((c->c64 + 31) / 32, (A + 31) / 32), dim3(256), 0, st, c->d_bitsTC, A, c->c64, c->d_wcol);
         }
         const size_t n_part_r = (size_t)(w64c / 8) * Cp, n_part_c = (size_t)(c->c64 / 8) * A;
-        const size_t n_cnt = (size_t)std::max((C + BLOCK - 1) / BLOCK, (A + BLOCK - 1) / BLOCK);
-        ALLOC(b_part, std::max(n_part_r, n_part_c) * 8); ALLOC(b_part_c, n_part_c * 8); ALLOC(b_cnt, n_cnt * 4);
-        HIPCHK(hipMemsetAsync(b_cnt.p, 0, n_cnt * 4, st));
-        rows.M = c->d_wrow; rows.n_pad = Cp; rows.part = b_part.as<double>(); rows.counters = b_cnt.as<unsigned>();
-        cols.M = c->d_wcol; cols.n_pad = A; cols.part = b_part_c.as<double>(); cols.counters = b_cnt.as<unsigned>();
+        ALLOC(b_part, std::max(n_part_r, n_part_c) * 8); ALLOC(b_part_c, n_part_c * 8);
+        unsigned *const slab_counters = (unsigned *)(scal + S_N);                   // zeroed with the scalars above
+        rows.M = c->d_wrow; rows.n_pad = Cp; rows.part = b_part.as<double>(); rows.counters = slab_counters;
+        cols.M = c->d_wcol; cols.n_pad = A; cols.part = b_part_c.as<double>(); cols.counters = slab_counters;
 #ifdef HGX_LAB
         if (hgx_test_switch("em_lut4") && !HGX_LAB_SWITCH("em_persist") && !hgx_test_switch("em_grid"))
             rows.narrow = cols.narrow = 1;      // the narrow-table form (k_lut4, lab): a workgroup owns its rows for the whole of K
