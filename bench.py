@@ -103,6 +103,7 @@ def parse_args():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for --dry-run on CPU)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank joins the process group and rank 0 prints the world it saw (no GPU work)")
+    ap.add_argument("--no-in-flight", action="store_true", help="skip the side measurement with 2 / 3 samples in flight")
     ap.add_argument("--no-workloads", action="store_true", help="default workload only: skip the class1 / panel64 runs that follow it")
     ap.add_argument("--workloads", action="store_true", help="run class1 / panel64 behind the default workload also with more than one rank "
                                                                "(by default they are N = 1 legs, like cpu_baseline and e2e: the scaling run is about `value`)")
@@ -1195,11 +1196,11 @@ def main():
     # scale is a pool of processes over samples (/root/reference/hisatgenotype:613-665); one sample's step is a chain of ~70 short
     # dependent launches that leaves most of the chip idle, the next sample's scoring fills it.  Reported beside `value`, never as it.
     in_flight = None
-    if inflight == 1 and dist is None and not args.no_workloads:
+    if inflight == 1 and dist is None and not args.no_workloads and not args.no_in_flight:
         in_flight = {}
         for nf in (2, 3):
-            n_st = max(12, 4 * nf)
-            run_steps(pl, batch, db, nf, nf, None, False, local_rank)
+            n_st = 10 * nf
+            run_steps(pl, batch, db, nf, 3 * nf, None, False, local_rank)           # (warm-up: the pool grows by the extra samples' buffers)
             capi.sync()
             t0 = time.perf_counter()
             run_steps(pl, batch, db, nf, n_st, None, False, local_rank)

@@ -6,6 +6,8 @@ import collections, csv, json, os, shutil, sys
 src = sys.argv[1]
 R = "r05"
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+if not os.path.exists(f"{src}/stats/r05_kernel_stats.csv"):
+    sys.exit("no profile set under %s (usage: tools/install_profiles_r05.py gpurun_out/<dir>)" % src)
 for f in os.listdir(dst):
     if f.startswith(R + "_final"):
         os.remove(os.path.join(dst, f))
