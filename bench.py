@@ -70,6 +70,8 @@ import numpy as np  # noqa: E402
 
 import hisatgenotype_amd as hgx  # noqa: E402
 from hisatgenotype_amd import capi, engine, synth  # noqa: E402
+if os.environ.get("HGX_BENCH_LIB"):          # tools/bench_with_lib.py: an A/B against another build of libhgx (the child processes too)
+    capi.LIB_PATH = os.environ["HGX_BENCH_LIB"]
 htyping = sys.modules["hisatgenotype_amd.typing"]   # the module (the package also exports the typing() function)
 from hisatgenotype_amd import locus as hl  # noqa: E402
 

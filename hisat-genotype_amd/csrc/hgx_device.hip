@@ -143,13 +143,12 @@ extern "C" int hgx_stream_create(void **st) {
     *st = (void *)s;
     return HGX_OK;
 }
-void *hgx_side_stream_take();
 extern "C" int hgx_stream_create_prio(void **st, int high_priority) {
     ARGCHK(st != nullptr);
     int least = 0, greatest = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    hipStream_t s = high_priority ? nullptr : (hipStream_t)hgx_side_stream_take();      // (a main stream: placed beside the library's own, hgx_type.hip)
-    if (!s) HIPCHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? greatest : least));
+    hipStream_t s;
+    HIPCHK(hipStreamCreateWithPriority(&s, hipStreamNonBlocking, high_priority ? greatest : least));
     *st = (void *)s;
     return HGX_OK;
 }

@@ -282,7 +282,6 @@ struct hgx_front_input {
 // Sharded loci (hgx_parse_opts.pileup_exchange / _dev): every rank must communicate exactly ONCE per parse, whichever route finishes
 // it.  The device front end wraps the caller's host callback in this: once a summed table exists (the device route exchanged and
 // then declined, or the wrapper itself ran the caller's callback) the host stages get that table instead of a second exchange.
-void *hgx_side_stream_take();               // hgx_type.hip: a placed low-priority stream (hipStream_t) for a caller's main stream, or nullptr
 struct hgx_pileup_share {
     int (*orig)(void *, uint32_t *, int64_t) = nullptr;
     void *orig_ctx = nullptr;

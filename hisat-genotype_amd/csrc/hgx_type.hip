@@ -94,46 +94,51 @@ void sorted_result(const std::vector<double> &prob, const std::vector<int32_t> &
 struct StreamSet { int dev = -1; hipStream_t em = nullptr, gene = nullptr; hipEvent_t fork = nullptr; };
 std::mutex g_ss_mu;
 std::vector<StreamSet> g_ss_free;
-int g_side_dev = -1, g_side_runs = 0;
+hipStream_t g_first_em = nullptr;      // the EM stream of the first, unplaced set
 
-// Streams are created in ONE RUN of 24 consecutive creations per device.  The runtime hands its hardware queues (four per process) out
-// in creation order, round robin, and streams that share a hardware queue run one behind the other.  What must not share a queue:
-// the EM chains of samples (or loci) that run side by side -- short dependent launches on the critical path -- and a set's EM chain
-// with its own throughput work.  Creations c0 .. c23 sit on queues k, k+1, k+2, k+3, k, ... whatever k the caller's own streams left
-// us at: the EM streams are c0, c1, c2 (three different queues); every fourth creation from c3 on (queue k+3) is a stream for
-// chip-filling work that serialises without loss -- three gene-side streams, and three "main" streams that hgx_stream_create /
-// hgx_stream_create_prio(low) hand to callers who drive several samples at once; the creations in between are placeholders that
-// only advance the runtime's counter.  Measured (round 5, bench.py): with one stream made per first use the mapping depended on the
-// caller's history -- the three loci of class I took 4.1 ... 4.7 ms per step in a fresh process and 5.8 ms behind a phase that had made
-// its streams in another order, two / three samples in flight 2.4 / 1.7 ms per sample instead of 1.6 / 1.5; with the EM streams first
-// and ALL gene streams right behind them (an EM chain and its own gene side on one queue) a single sample took 2.6 ms instead of 2.05.
+// A caller alone gets one stream set, made on first use: an EM stream and a gene-side stream created back to back.  When a SECOND
+// caller arrives while the first set is out -- samples in flight, the loci of class I side by side -- three more sets are made in one
+// run of twelve consecutive stream creations.  The runtime hands its hardware queues (four per process) out in creation order,
+// round robin, and streams that share a hardware queue run one behind the other.  What must not share a queue: the EM chains of samples
+// that run side by side -- short dependent launches on the critical path -- and a set's EM chain with its own gene side.  Creations
+// c0 .. c11 sit on queues k, k+1, k+2, k+3, k, ... whatever k the caller's own streams left us at: the EM streams are c0, c1, c2
+// (three different queues), the gene-side streams c3, c7, c11 (the fourth queue: chip-filling kernels that serialise without loss);
+// c4-c6 and c8-c10 are placeholders that only advance the runtime's counter.  The first set goes to the back of the list.
+// Measured (round 5, bench.py): with every set made on first use the mapping depended on the caller's history -- the three loci of
+// class I took 4.1 ... 4.7 ms per step in a fresh process and 5.8 ms behind a phase that had made its streams in another order, two /
+// three samples in flight 2.4 / 1.7 ms per sample instead of 1.6 / 1.5; with the EM streams first and ALL gene streams right behind
+// them (an EM chain and its own gene side on one queue) a single sample took 2.6 ms instead of 2.05.  And the run is only made for
+// callers that need it: eight PROCESSES with a run of streams each typed 65 files a second through one GPU instead of 116 (the
+// hardware's queue slots are shared by all processes).
 // Sets are taken and given back at the front of the list: a caller alone always gets the same set.
-static std::vector<hipStream_t> g_ss_placeholders, g_side_free;
-static int make_streams(int dev, std::vector<StreamSet> &sets, std::vector<hipStream_t> &mains) {
-    int least = 0, greatest = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    sets.assign(3, StreamSet());
-    mains.clear();
-    // The EM chain gets the highest priority, the overlapped side work the lowest.
-    for (int i = 0; i < 3; ++i) { sets[i].dev = dev; HIPCHK(hipStreamCreateWithPriority(&sets[i].em, hipStreamNonBlocking, greatest)); }
+static std::vector<hipStream_t> g_ss_placeholders;
+static int g_ss_out = 0;                 // sets handed out at the moment
+static bool g_ss_run_made = false;
+static int make_gene_stream(hipStream_t *out, int least) {
     // The gene side's chip-filling kernels (k_pair_classes_x2, k_verify_ht) run beside the EM chain of the exon level; a 1 024-thread
     // workgroup of an EM pass is only placed on a CU that has sixteen free wave slots and 135 KB of LDS, so with the gene side free to
     // take every CU the first EM passes wait for it to drain.  HGX_GENE_CUS=n confines the gene-side stream to n CUs (CU mask).
     const char *gcu = getenv("HGX_GENE_CUS");
     const int n_gene_cus = gcu ? atoi(gcu) : 0;
-    for (int i = 0; i < 6; ++i) {
-        hipStream_t side = nullptr;
-        if (i < 3 && n_gene_cus > 0 && n_gene_cus < 256) {
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int b = 0; b < n_gene_cus; ++b) mask[b >> 5] |= 1u << (b & 31);
-            HIPCHK(hipExtStreamCreateWithCUMask(&side, 8, mask));
-        } else
-            HIPCHK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least));
-        if (i < 3) {
-            sets[i].gene = side;
-            HIPCHK(hipEventCreateWithFlags(&sets[i].fork, hipEventDisableTiming));
-        } else mains.push_back(side);
-        for (int k = 0; k < 3 && i < 5; ++k) {
+    if (n_gene_cus > 0 && n_gene_cus < 256) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int b = 0; b < n_gene_cus; ++b) mask[b >> 5] |= 1u << (b & 31);
+        HIPCHK(hipExtStreamCreateWithCUMask(out, 8, mask));
+    } else
+        HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, least));
+    return HGX_OK;
+}
+// n = 1: a set for a caller alone; n = 3: the run for callers side by side.  The EM chain gets the highest priority, the overlapped
+// side work the lowest.
+static int make_stream_sets(int dev, int n, std::vector<StreamSet> &sets) {
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    sets.assign((size_t)n, StreamSet());
+    for (int i = 0; i < n; ++i) { sets[i].dev = dev; HIPCHK(hipStreamCreateWithPriority(&sets[i].em, hipStreamNonBlocking, greatest)); }
+    for (int i = 0; i < n; ++i) {
+        { const int rc_ = make_gene_stream(&sets[i].gene, least); if (rc_) return rc_; }
+        HIPCHK(hipEventCreateWithFlags(&sets[i].fork, hipEventDisableTiming));
+        for (int k = 0; k < 3 && i + 1 < n; ++k) {
             hipStream_t ph = nullptr;
             HIPCHK(hipStreamCreateWithFlags(&ph, hipStreamNonBlocking));
             g_ss_placeholders.push_back(ph);
@@ -141,35 +146,30 @@ static int make_streams(int dev, std::vector<StreamSet> &sets, std::vector<hipSt
     }
     return HGX_OK;
 }
-static int make_streams_locked(int dev) {
-    std::vector<StreamSet> sets;
-    std::vector<hipStream_t> mains;
-    const int rc = make_streams(dev, sets, mains);
-    if (rc) {                                                            // nothing half-made is handed out or leaked
-        for (auto &m : sets) {
-            if (m.em) (void)hipStreamDestroy(m.em);
-            if (m.gene) (void)hipStreamDestroy(m.gene);
-            if (m.fork) (void)hipEventDestroy(m.fork);
-        }
-        for (auto m : mains) (void)hipStreamDestroy(m);
-        return rc;
-    }
-    g_ss_free.insert(g_ss_free.end(), sets.begin(), sets.end());
-    g_side_dev = dev;
-    g_side_runs++;
-    g_side_free.insert(g_side_free.end(), mains.begin(), mains.end());
-    return HGX_OK;
-}
 int acquire_streams(StreamSet &s) {
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(g_ss_mu);
     for (int round = 0; round < 2; ++round) {
-        for (size_t i = 0; i < g_ss_free.size(); ++i)
-            if (g_ss_free[i].dev == dev) { s = g_ss_free[i]; g_ss_free.erase(g_ss_free.begin() + i); return HGX_OK; }
-        // creating a stream takes milliseconds: done once per three concurrent callers, then recycled
-        const int rc = make_streams_locked(dev);
-        if (rc) return rc;
+        // (a second caller beside the first: the placed run before anything else is handed out)
+        const bool want_run = g_ss_out > 0 && !g_ss_run_made;
+        if (!want_run)
+            for (size_t i = 0; i < g_ss_free.size(); ++i)
+                if (g_ss_free[i].dev == dev) { s = g_ss_free[i]; g_ss_free.erase(g_ss_free.begin() + i); g_ss_out++; return HGX_OK; }
+        // creating a stream takes milliseconds: done once, then recycled
+        std::vector<StreamSet> made;
+        const int rc = make_stream_sets(dev, want_run || g_ss_run_made ? 3 : 1, made);
+        if (rc) {                                                            // nothing half-made is handed out or leaked
+            for (auto &m : made) {
+                if (m.em) (void)hipStreamDestroy(m.em);
+                if (m.gene) (void)hipStreamDestroy(m.gene);
+                if (m.fork) (void)hipEventDestroy(m.fork);
+            }
+            return rc;
+        }
+        if (made.size() == 3) g_ss_run_made = true;
+        else if (!g_first_em) g_first_em = made[0].em;
+        g_ss_free.insert(g_ss_free.begin(), made.begin(), made.end());      // (in front of a first, unplaced set)
     }
     hgx_set_error("no stream set");
     return HGX_EHIP;
@@ -177,25 +177,11 @@ int acquire_streams(StreamSet &s) {
 void release_streams(const StreamSet &s) {
     if (s.dev < 0) return;
     std::lock_guard<std::mutex> g(g_ss_mu);
-    g_ss_free.insert(g_ss_free.begin(), s);
+    g_ss_out--;
+    // a set of the placed run goes back to the front; the first, unplaced one stays behind them once the run exists
+    if (g_ss_run_made && !g_ss_free.empty() && s.em == g_first_em) g_ss_free.push_back(s);
+    else g_ss_free.insert(g_ss_free.begin(), s);
 }
-}   // namespace
-// a low-priority stream for a caller's main stream, on the hardware queue of the throughput work (see above); nullptr = none left for
-// this device (the caller creates an ordinary one).  The stream is the caller's from here on.
-void *hgx_side_stream_take() {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> g(g_ss_mu);
-    if (g_side_free.empty() || g_side_dev != dev) {
-        // (spares of another device, or a caller with many more threads than samples fit on the chip: ordinary streams from here on)
-        if (!g_side_free.empty() || g_side_runs >= 2) return nullptr;
-        if (make_streams_locked(dev) != HGX_OK) return nullptr;
-    }
-    hipStream_t s = g_side_free.front();
-    g_side_free.erase(g_side_free.begin());
-    return (void *)s;
-}
-namespace {
 
 struct GateHold {                    // a held gate that is released exactly once
     hgx_gate *g = nullptr;

@@ -421,6 +421,48 @@ def test_concurrent_samples_give_identical_results():
         assert outs[0][0] == seq[0] and outs[1][0] == seq[1]
 
 
+def test_five_samples_in_flight_beyond_one_run_of_streams():
+    """The library makes its streams in runs of 24 (three stream sets + three main streams for callers, placed on the hardware queues
+    on purpose: hgx_type.hip make_streams).  Five host threads with a sample each need two runs of sets and more main streams than
+    one run holds (the fourth and fifth come from the second run): every sample's result is the one it has alone, round after round."""
+    import threading
+    from hisatgenotype_amd import capi
+    ht = sys.modules["hisatgenotype_amd.typing"]
+    loc = synth.make_hla_like_locus(n_alleles=900, n_vars=700, seed=77)
+    pl = hl.PackedLocus.from_synth(loc)
+    pl.index()
+    batches = []
+    for seed in range(5):
+        sam = synth.simulate_sam_fast(loc, synth.pick_sample(loc, 20 + seed), 5000, err_rate=0.002, seed=40 + seed)
+        batches.append(pl.parse_sam(sam))
+
+    def run(batch, out, slot):
+        capi.set_device(capi.current_device())
+        if slot is not None:
+            capi.set_stream_slot(("five in flight", slot))
+        res = ht.LocusResult()
+        res.num_reads, res.num_pairs = batch.n_reads, batch.n_pairs
+        r = ht._type_batch(pl, batch, res, True, stream=capi.get_stream(2) if slot is not None else None, overlap=True)
+        out.append((r.gene_prob, [e["n_iter"] for e in r.em], r.counts_sorted[:10]))
+
+    alone = []
+    for b in batches:
+        run(b, alone, None)
+    mains = set()
+    for _ in range(3):
+        outs = [[] for _ in batches]
+        ths = [threading.Thread(target=run, args=(b, o, k)) for k, (b, o) in enumerate(zip(batches, outs))]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        assert [o[0] for o in outs] == alone
+    for k in range(5):
+        capi.set_stream_slot(("five in flight", k))
+        mains.add(capi.get_stream(2).value)
+    assert len(mains) == 5                                   # a main stream per slot, none handed out twice
+
+
 @pytest.mark.parametrize("name", ["hla_small_pair", "hla_mid_real", "hla_errors_filters", "hla_7000"])
 def test_grouped_exon_path_equals_per_pair_path(name, monkeypatch):
     """type_locus through hgx_level_classes (pairs grouped by exon-level ref list, the default) and through the per-pair rows +

@@ -7,5 +7,6 @@ sys.path.insert(0, ROOT)
 import hisatgenotype_amd                      # registers the package directory
 from hisatgenotype_amd import capi
 capi.LIB_PATH = os.path.abspath(sys.argv[1])
+os.environ["HGX_BENCH_LIB"] = capi.LIB_PATH        # (bench.py's child processes load it too)
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[2:]
 runpy.run_path(os.path.join(ROOT, "bench.py"), run_name="__main__")
