@@ -1245,7 +1245,11 @@ def main():
         for k in kernels:
             if "bound" not in kernels[k]:
                 kernels[k].update(bound="hbm", peak_GBps=HBM_PEAK_GBS, frac=round(kernels[k]["GBps"] / HBM_PEAK_GBS, 4))
-        dom = max(kernels, key=lambda k: kernels[k]["total_ms_per_step"])      # largest aggregate time per step
+        # largest aggregate time per step.  The EM's cols pass and the gene level's k_pair_classes are within a few per cent of each
+        # other (0.50-0.54 ms per step each; the latter's HIP-event bracket also holds its wait for CUs beside the EM chain): among the
+        # kernels within 5 % of the largest the one FURTHER from its roofline is reported, so that the figure does not flip between runs
+        top = max(v["total_ms_per_step"] for v in kernels.values())
+        dom = min((k for k in kernels if kernels[k]["total_ms_per_step"] >= 0.95 * top), key=lambda k: kernels[k]["frac"])
         alg_bytes, avg_ms = kernels[dom]["alg_bytes_per_launch"], kernels[dom]["avg_ms"]
         achieved = kernels[dom]["GBps"]
         traffic = None
@@ -1319,7 +1323,7 @@ def main():
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "alg_bytes_per_launch": int(alg_bytes), "avg_launch_ms": round(avg_ms, 4),
-                "note": "kernel with the largest aggregate time per step; averages are over ALL its launches in the timed region "
+                "note": "kernel with the largest aggregate time per step (of those within 5 % of the largest, the one further from its roofline); averages are over ALL its launches in the timed region "
                         "(incl. the tiny EM #2 problem and launches that exit at the convergence gate), as rocprofv3 --stats reports them",
                 "kernels": kernels,
                 # the step as a whole: how far from the machine, and where the rest goes
