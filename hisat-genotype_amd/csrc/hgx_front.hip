@@ -869,13 +869,72 @@ __device__ __forceinline__ int bam_name_cmp(const unsigned char *a, uint32_t la,
     for (uint32_t k = 0; k < m; ++k) if (a[k] != b[k]) return a[k] < b[k] ? -1 : 1;
     return la < lb ? -1 : (la > lb ? 1 : 0);
 }
+// bytes [8 c, 8 c + 8) of a name, big endian, zero beyond its end (one 8-byte load: it reaches at most 7 bytes beyond the name, into the
+// record's next fields or the buffer's padding)
+__device__ __forceinline__ unsigned long long name_chunk(const unsigned char *name, uint32_t klen, uint32_t c) {
+    if (8 * c >= klen) return 0ull;
+    unsigned long long w;
+    __builtin_memcpy(&w, name + 8 * c, 8);
+    unsigned long long v = __builtin_bswap64(w);
+    const uint32_t have = klen - 8 * c;
+    if (have < 8) v &= ~0ull << (8 * (8 - have));
+    return v;
+}
+// The name sort on the bits that VARY (round 5, late).  An LSD radix sort over 8-byte chunks of the names costs ~25 library
+// launches per chunk; read names differ in a few dozen bit positions (the digits of a counter).  The order check that runs anyway
+// also ORs together, per chunk, the XOR of every two neighbouring names -- exactly the bit positions in which not all names
+// agree -- and the sort keys are those bits alone, most significant first, packed into 64-bit words (one word, one sort over
+// ~30 bits, for the usual names).  Dropping positions in which all keys agree changes no comparison.
+#define NAME_DIFF_CHUNKS 32
+struct NameDiff { unsigned long long m[NAME_DIFF_CHUNKS]; };
+__device__ __forceinline__ void name_diff_add(const unsigned char *a, uint32_t la, const unsigned char *b, uint32_t lb, bool valid, unsigned long long *diff) {
+    const uint32_t l = la > lb ? la : lb;
+    const uint32_t nc_mine = valid ? (l + 7) / 8 : 0u;
+    uint32_t nc = nc_mine;                                                  // chunks this wavefront walks: the longest pair's
+#pragma unroll
+    for (int d = 32; d; d >>= 1) nc = max(nc, (uint32_t)__shfl_xor((int)nc, d, 64));
+    if (nc > NAME_DIFF_CHUNKS) nc = NAME_DIFF_CHUNKS;                       // (longer names: the caller sorts chunk by chunk)
+    for (uint32_t c = 0; c < nc; ++c) {
+        unsigned long long x = c < nc_mine ? name_chunk(a, la, c) ^ name_chunk(b, lb, c) : 0ull;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) x |= (unsigned long long)__shfl_xor((long long)x, d, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicOr(&diff[c], x);
+    }
+}
+// word `word` (0 = least significant) of the packed key: the varying bits of all chunks, most significant first
+__device__ __forceinline__ unsigned long long name_packed_word(const unsigned char *name, uint32_t klen, const NameDiff &D, int n_chunks, int n_bits, int word) {
+    unsigned long long out = 0;
+    int p = n_bits;                                                         // bits still to place (the next goes to position p - 1)
+    for (int c = 0; c < n_chunks && p > 64 * word; ++c) {
+        unsigned long long m = D.m[c];
+        if (!m) continue;
+        const unsigned long long v = name_chunk(name, klen, (uint32_t)c);
+        while (m) {
+            const int b = 63 - __builtin_clzll(m);
+            m &= ~(1ull << b);
+            --p;
+            if ((p >> 6) == word) out |= ((v >> b) & 1ull) << (p & 63);
+        }
+    }
+    return out;
+}
 __global__ void __launch_bounds__(256) k_bam_sorted(const unsigned char *__restrict__ text, const uint32_t *__restrict__ rec_off, const uint16_t *__restrict__ rec_task,
-                                                    const uint32_t *__restrict__ idx, uint32_t n, BamCtl *ctl) {
+                                                    const uint32_t *__restrict__ idx, uint32_t n, BamCtl *ctl, unsigned long long *__restrict__ diff) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 || i >= n) return;
+    const bool valid = i > 0 && i < n;
+    const unsigned char *a = text + rec_off[idx[valid ? i - 1 : 0]], *b = text + rec_off[idx[valid ? i : 0]];
+    const uint32_t la = (uint32_t)a[8] - 1, lb = (uint32_t)b[8] - 1;
+    if (diff) name_diff_add(a + 32, la, b + 32, lb, valid, diff);          // (names of more than one 8-byte chunk: the sort will want it)
+    if (!valid) return;
     if (rec_task[idx[i - 1]] != rec_task[idx[i]]) return;                  // (records are in task order before the sort: only names inside a task matter)
-    const unsigned char *a = text + rec_off[idx[i - 1]], *b = text + rec_off[idx[i]];
-    if (bam_name_cmp(b + 32, (uint32_t)b[8] - 1, a + 32, (uint32_t)a[8] - 1) < 0) ctl->unsorted = 1;
+    if (bam_name_cmp(b + 32, lb, a + 32, la) < 0) ctl->unsorted = 1;
+}
+__global__ void __launch_bounds__(256) k_bam_name_key_packed(const unsigned char *__restrict__ text, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ idx,
+                                                             uint32_t n, NameDiff D, int n_chunks, int n_bits, int word, unsigned long long *__restrict__ key) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned char *r = text + rec_off[idx[i]];
+    key[i] = name_packed_word(r + 32, (uint32_t)r[8] - 1, D, n_chunks, n_bits, word);
 }
 // bytes [8 c, 8 c + 8) of every name, big endian, zero beyond its end: LSD radix passes over these give the byte order above
 __global__ void __launch_bounds__(256) k_bam_name_key(const unsigned char *__restrict__ text, const uint32_t *__restrict__ rec_off, const uint32_t *__restrict__ idx,
@@ -883,18 +942,7 @@ __global__ void __launch_bounds__(256) k_bam_name_key(const unsigned char *__res
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const unsigned char *r = text + rec_off[idx[i]];
-    const uint32_t klen = (uint32_t)r[8] - 1;
-    // one 8-byte load (the sorted order makes every lane's record a line of its own: eight byte loads were eight gathers); a load
-    // near the end of the last record reaches at most 5 bytes into the buffer's padding
-    unsigned long long v = 0;
-    if (8 * chunk < klen) {
-        unsigned long long w;
-        __builtin_memcpy(&w, r + 32 + 8 * chunk, 8);
-        v = __builtin_bswap64(w);
-        const uint32_t have = klen - 8 * chunk;
-        if (have < 8) v &= ~0ull << (8 * (8 - have));
-    }
-    key[i] = v;
+    key[i] = name_chunk(r + 32, (uint32_t)r[8] - 1, chunk);
 }
 __global__ void k_bam_task_key(const uint16_t *__restrict__ rec_task, const uint32_t *__restrict__ idx, uint32_t n, unsigned long long *__restrict__ key) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1355,12 +1403,32 @@ int bam_lines_dev(const char *d_text, const std::vector<const hgx_bam_deferred *
     uint32_t *idx = b_idx.as<uint32_t>(), *idx_alt = b_idx2.as<uint32_t>();
     if (n_kept > 1) {
         // an aligner writes its records grouped by read already: a stable sort would not move anything
-        k_bam_sorted<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_off.as<uint32_t>(), b_task.as<uint16_t>(), idx, n_kept, ctl);
+        DevBuf b_diff;
+        ALLOC(b_diff, sizeof(NameDiff));
+        HIPCHK(hipMemsetAsync(b_diff.p, 0, sizeof(NameDiff), st));
+        // names of one 8-byte chunk are sorted as they are (one sort either way); longer ones on their varying bits
+        const int n_chunks = (int)(h.max_klen + 7) / 8;
+        const bool packed = n_chunks >= 2 && n_chunks <= NAME_DIFF_CHUNKS && !hgx_switch_has("front", "name_chunks");
+        k_bam_sorted<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_off.as<uint32_t>(), b_task.as<uint16_t>(), idx, n_kept, ctl,
+                                                        packed ? b_diff.as<unsigned long long>() : (unsigned long long *)nullptr);
+        NameDiff nd;
         HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&nd, b_diff.p, sizeof(NameDiff), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (h.unsorted) {
             unsigned long long *key = b_key.as<unsigned long long>(), *key_alt = b_key2.as<unsigned long long>();
-            for (int chunk = (int)(h.max_klen + 7) / 8 - 1; chunk >= 0; --chunk) {      // least significant eight bytes first; every pass stable
+            int n_bits = 0;
+            for (int c = 0; c < std::min(n_chunks, NAME_DIFF_CHUNKS); ++c) n_bits += __builtin_popcountll(nd.m[c]);
+            if (packed) {
+                // the varying bits alone, 64 to a word, least significant word first; every pass stable
+                for (int word = 0; word < (n_bits + 63) / 64; ++word) {
+                    k_bam_name_key_packed<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_off.as<uint32_t>(), idx, n_kept, nd, n_chunks, n_bits, word, key);
+                    size_t b = tmp_bytes;
+                    HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, key, key_alt, idx, idx_alt, (int)n_kept, 0, std::min(64, n_bits - 64 * word), st));
+                    std::swap(idx, idx_alt);
+                }
+            } else
+            for (int chunk = n_chunks - 1; chunk >= 0; --chunk) {      // (names beyond 256 bytes; test switch front=name_chunks) eight bytes at a time, least significant first
                 k_bam_name_key<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_off.as<uint32_t>(), idx, n_kept, (uint32_t)chunk, key);
                 size_t b = tmp_bytes;
                 HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, key, key_alt, idx, idx_alt, (int)n_kept, 0, 64, st));
@@ -1505,10 +1573,21 @@ __global__ void k_sam_compact(const uint32_t *__restrict__ keep, const uint32_t 
     if (i == n_all - 1) ctl->n_kept = pos[i] + keep[i];
 }
 __global__ void __launch_bounds__(256) k_sam_sorted(const unsigned char *__restrict__ text, const uint32_t *__restrict__ k_off, const uint32_t *__restrict__ k_klen,
-                                                    uint32_t n, BamCtl *ctl) {
+                                                    uint32_t n, BamCtl *ctl, unsigned long long *__restrict__ diff) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == 0 || i >= n) return;
-    if (bam_name_cmp(text + k_off[i], k_klen[i], text + k_off[i - 1], k_klen[i - 1]) < 0) ctl->unsorted = 1;
+    const bool valid = i > 0 && i < n;
+    const unsigned char *a = text + k_off[valid ? i - 1 : 0], *b = text + k_off[valid ? i : 0];
+    const uint32_t la = k_klen[valid ? i - 1 : 0], lb = k_klen[valid ? i : 0];
+    if (diff) name_diff_add(a, la, b, lb, valid, diff);
+    if (valid && bam_name_cmp(b, lb, a, la) < 0) ctl->unsorted = 1;
+}
+__global__ void __launch_bounds__(256) k_sam_name_key_packed(const unsigned char *__restrict__ text, const uint32_t *__restrict__ k_off, const uint32_t *__restrict__ k_klen,
+                                                             const uint32_t *__restrict__ idx, uint32_t n, NameDiff D, int n_chunks, int n_bits, int word,
+                                                             unsigned long long *__restrict__ key) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = idx[i];
+    key[i] = name_packed_word(text + k_off[r], k_klen[r], D, n_chunks, n_bits, word);
 }
 __global__ void __launch_bounds__(256) k_sam_name_key(const unsigned char *__restrict__ text, const uint32_t *__restrict__ k_off, const uint32_t *__restrict__ k_klen,
                                                       const uint32_t *__restrict__ idx, uint32_t n, uint32_t chunk, unsigned long long *__restrict__ key) {
@@ -1601,14 +1680,33 @@ int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &de
     ALLOC(b_lines, std::max<size_t>(n_kept, 1) * sizeof(LineRef));
     uint32_t *idx = b_idx.as<uint32_t>();
     if (n_kept > 1) {
-        k_sam_sorted<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_koff.as<uint32_t>(), b_klen3.as<uint32_t>(), n_kept, ctl);
+        DevBuf b_diff;
+        ALLOC(b_diff, sizeof(NameDiff));
+        HIPCHK(hipMemsetAsync(b_diff.p, 0, sizeof(NameDiff), st));
+        const int n_chunks = (int)(h.max_klen + 7) / 8;
+        const bool packed = n_chunks >= 2 && n_chunks <= NAME_DIFF_CHUNKS && !hgx_switch_has("front", "name_chunks");
+        k_sam_sorted<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_koff.as<uint32_t>(), b_klen3.as<uint32_t>(), n_kept, ctl,
+                                                        packed ? b_diff.as<unsigned long long>() : (unsigned long long *)nullptr);
+        NameDiff nd;
         HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&nd, b_diff.p, sizeof(NameDiff), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (h.unsorted) {
             ALLOC(b_idx2, (size_t)n_kept * 4); ALLOC(b_key, (size_t)n_kept * 8); ALLOC(b_key2, (size_t)n_kept * 8);
             uint32_t *idx_alt = b_idx2.as<uint32_t>();
             unsigned long long *key = b_key.as<unsigned long long>(), *key_alt = b_key2.as<unsigned long long>();
-            for (int chunk = (int)(h.max_klen + 7) / 8 - 1; chunk >= 0; --chunk) {      // least significant eight bytes first; every pass stable
+            int n_bits = 0;
+            for (int c = 0; c < std::min(n_chunks, NAME_DIFF_CHUNKS); ++c) n_bits += __builtin_popcountll(nd.m[c]);
+            if (packed) {
+                for (int word = 0; word < (n_bits + 63) / 64; ++word) {                // the varying bits alone (see k_bam_sorted)
+                    k_sam_name_key_packed<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_koff.as<uint32_t>(), b_klen3.as<uint32_t>(), idx, n_kept, nd, n_chunks, n_bits,
+                                                                               word, key);
+                    size_t b = tmp_bytes;
+                    HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, key, key_alt, idx, idx_alt, (int)n_kept, 0, std::min(64, n_bits - 64 * word), st));
+                    std::swap(idx, idx_alt);
+                }
+            } else
+            for (int chunk = n_chunks - 1; chunk >= 0; --chunk) {      // (long names; front=name_chunks) least significant eight bytes first; every pass stable
                 k_sam_name_key<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_koff.as<uint32_t>(), b_klen3.as<uint32_t>(), idx, n_kept, (uint32_t)chunk, key);
                 size_t b = tmp_bytes;
                 HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, key, key_alt, idx, idx_alt, (int)n_kept, 0, 64, st));

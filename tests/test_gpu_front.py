@@ -241,6 +241,40 @@ def test_device_front_end_on_deep_samples_and_files(tmp_path, n_pairs, err):
         assert [e["n_iter"] for e in res.em] == [e["n_iter"] for e in ref.em]
 
 
+def test_sam_text_lines_filtered_and_sorted_on_the_device(tmp_path):
+    """A SAM TEXT file that is not name-grouped (shuffled lines, header lines, a blank line, CRLF on some lines, awkward names: prefixes of
+    each other, a long common prefix, decoys on another reference): the device makes the line table -- newline scan, region filter, name
+    order -- and sorts on the varying bits of the names (or, under front=name_chunks, eight bytes at a time; under front=host_lines the
+    host makes the table): the batch is the host reader's, with and without a region."""
+    loc = synth.make_hla_like_locus(n_alleles=300, n_vars=500, seed=14)
+    pl = hl.PackedLocus.from_synth(loc)
+    sam = synth.simulate_sam_fast(loc, synth.pick_sample(loc, 3), 16000, err_rate=0.004, seed=11)
+    rng = random.Random(6)
+    out = []
+    for l in sam.splitlines():
+        name, rest = l.split("\t", 1)
+        n = int(name[1:])
+        new = ("q%d" % n) if n % 3 == 0 else ("a_common_prefix_of_24_chr" + "x" * (n % 5) + "%d" % n if n % 3 == 1 else name)
+        out.append(new + "\t" + rest + ("\r" if n % 11 == 0 else ""))
+    for d in range(300):
+        out.append("decoy%04d\t0\tDECOY\t%d\t60\t50M\t*\t0\t0\t%s\t%s\tNM:i:0\tMD:Z:50\tNH:i:1" % (d, 1 + 7 * d, "A" * 50, "I" * 50))
+    rng.shuffle(out)
+    text = "@HD\tVN:1.0\n@SQ\tSN:%s\tLN:%d\n" % (loc.ref_allele, len(loc.backbone)) + "\n".join(out[:100]) + "\n\n" + "\n".join(out[100:])   # (no newline at the end)
+    p = str(tmp_path / "shuffled.sam")
+    open(p, "w", newline="").write(text)
+    assert os.path.getsize(p) > (8 << 20)
+    span = "%s:%d-%d" % (loc.ref_allele, 400, len(loc.backbone) - 700)
+    for regions in ([loc.ref_allele], [span], None):
+        host = pl.parse_alignment_file(p, regions)
+        assert host.n_reads > 15000
+        for sw in ("device", "device,name_chunks", "device,host_lines"):
+            with engine.test_switches(front=sw):
+                dev = pl.parse_alignment_file_dev(p, regions=regions)
+                route, code = engine.front_last()
+            assert (route, code) == (2, 0), (regions, sw, route, code)
+            same_batch(host, dev.to_host(), len(loc.backbone))
+
+
 def test_bam_records_walked_filtered_and_sorted_on_the_device(tmp_path):
     """hgx_bam.cpp leaves a BAM's record walk, region filter and name sort to the device (k_bam_*): same batch as the host reader's
     own walk / filter / stable name sort on -- a coordinate-sorted BAM with reads on a decoy reference, with a span region (overlap
@@ -283,7 +317,8 @@ def test_bam_records_walked_filtered_and_sorted_on_the_device(tmp_path):
             host = pl.parse_alignment_file(path, regions)
             assert host.n_reads > 5000
             sent = {}
-            for sw in ("device", "device,host_inflate"):          # BGZF blocks inflated by the device / by the host's threads
+            # BGZF blocks inflated by the device / by the host's threads; the name sort on the varying bits / eight bytes at a time
+            for sw in ("device", "device,host_inflate", "device,name_chunks"):
                 with engine.test_switches(front=sw):
                     dev = pl.parse_alignment_file_dev(path, regions=regions)
                     route, code = engine.front_last()

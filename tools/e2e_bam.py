@@ -11,6 +11,12 @@ pl = hl.PackedLocus.from_synth(loc)
 pl.index()
 sample = synth.pick_sample(loc, 101)
 sam = synth.simulate_sam_fast(loc, sample, n_pairs, err_rate=0.002, seed=100)
+if os.environ.get("LONG_NAMES"):         # sequencer-style read names (38 characters: five 8-byte sort chunks) instead of the generator's short ones
+    import re
+    def long_name(m):
+        k = int(m.group(1))
+        return "A00123:45:HXXXXXXX:%d:%d:%d:%d\t" % (1 + k % 4, 1101 + (k // 4) % 578, 1000 + (k * 7919) % 30000, 1000 + (k * 104729) % 36000)
+    sam = re.sub(r"(?m)^[A-Za-z_]*(\d+)[^\t]*\t", long_name, sam)
 d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 path = os.path.join(d, "x.bam")
 t0 = time.time()
@@ -19,6 +25,9 @@ print("native BAM writer: %.2f s, %.1f MB" % (time.time() - t0, os.path.getsize(
 n_reads = sam.count("\n")
 del sam
 L = capi.lib()
+if os.environ.get("FRONT_SWITCH"):       # e.g. FRONT_SWITCH=name_chunks: a test switch of the front end for an A/B
+    from hisatgenotype_amd import engine
+    engine.test_switch("front", os.environ["FRONT_SWITCH"])
 for rep in range(4):
     if rep == 3:
         os.environ["HGX_PARSE_PROFILE"] = "1"
