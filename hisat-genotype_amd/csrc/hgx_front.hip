@@ -218,7 +218,11 @@ __global__ void k_fe_nt_set(const uint32_t *__restrict__ counts, int n_ref, uint
     if (i < n_ref) nt_set[i] = fe_nt_set(counts + (size_t)i * 6);
 }
 
-__global__ void __launch_bounds__(256) k_fe_decode(FeLocus L, FeParse o, FePile P, const FeKey *__restrict__ keys, uint32_t n_keys,
+#define FE_SEQ_STAGE_DWORDS 43
+#ifndef FE_DECODE_BLOCK
+#define FE_DECODE_BLOCK 64
+#endif
+__global__ void __launch_bounds__(FE_DECODE_BLOCK) k_fe_decode(FeLocus L, FeParse o, FePile P, const FeKey *__restrict__ keys, uint32_t n_keys,
                                                    const char *__restrict__ text, FePools pools, uint8_t *__restrict__ state,
                                                    uint32_t *__restrict__ key_ht_off, uint32_t *__restrict__ key_n_ht,
                                                    uint16_t *__restrict__ slot_task, const uint32_t *__restrict__ order, FeCtl *ctl) {
@@ -227,13 +231,32 @@ __global__ void __launch_bounds__(256) k_fe_decode(FeLocus L, FeParse o, FePile 
     const uint32_t k = order ? order[k0] : k0;             // (keys in backbone order: the lanes of a wavefront meet the same variants)
     const FeKey K = keys[k];
     if (K.slot == FE_NO_SLOT) return;
+    // The read's bases are looked at one by one, several times over (the MD walk, error correction against the pileup, insertions):
+    // from global memory every such look is a load instruction whose 64 lanes touch 64 different cache lines.  They are staged in
+    // LDS once, a few dword loads per lane -- 43 dwords per lane (an odd stride: no bank conflicts between the lanes; 172 bytes hold
+    // 344 packed or 172 text bases; longer reads stay where they are).
+    __shared__ uint32_t s_seq[FE_DECODE_BLOCK * FE_SEQ_STAGE_DWORDS];
+    const unsigned char *seq_copy = nullptr;
+    {
+        const uint32_t n_bytes = (K.flags & FE_K_PACKED_SEQ) ? ((uint32_t)K.seq_len + 1) / 2 : (uint32_t)K.seq_len;
+        if (n_bytes <= 4 * FE_SEQ_STAGE_DWORDS) {
+            uint32_t *mine = s_seq + threadIdx.x * FE_SEQ_STAGE_DWORDS;
+            const unsigned char *src = (const unsigned char *)text + K.seq_off;
+            for (uint32_t w = 0; 4 * w < n_bytes; ++w) {                    // (a dword load may reach 3 bytes beyond the bases: inside the text's padding at worst)
+                uint32_t v;
+                __builtin_memcpy(&v, src + 4 * w, 4);
+                mine[w] = v;
+            }
+            seq_copy = (const unsigned char *)mine;
+        }
+    }
     uint8_t st = 2;
     uint32_t off = 0, n = 0;
     FePile Pk = P;                                         // (a many-task batch: the pileup of the key's own sample)
     Pk.nt_set += (size_t)K.task * L.n_ref;
     Pk.counts += (size_t)K.task * L.n_ref * 6;
     if (slot_task) slot_task[K.slot] = (uint16_t)K.task;
-    const int rc = fe_key(L, o, Pk, K, text, pools, st, off, n);
+    const int rc = fe_key(L, o, Pk, K, text, pools, st, off, n, seq_copy);
     if (rc < 0) { fe_decline(ctl, rc); st = 2; n = 0; }
     state[K.slot] = st;
     key_ht_off[K.slot] = off;
@@ -1099,7 +1122,7 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
             HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_ktmp.p, tb, b_kpos.as<uint32_t>(), b_kpos2.as<uint32_t>(), b_kord.as<uint32_t>(), b_kord2.as<uint32_t>(), (int)n_keys, 0, key_bits, st));
             order = b_kord2.as<uint32_t>();
         }
-        k_fe_decode<<<nblk(n_keys, 256), 256, 0, st>>>(F, po, pile, keys, n_keys, text, pools, b_state.as<uint8_t>(), b_koff.as<uint32_t>(),
+        k_fe_decode<<<nblk(n_keys, FE_DECODE_BLOCK), FE_DECODE_BLOCK, 0, st>>>(F, po, pile, keys, n_keys, text, pools, b_state.as<uint8_t>(), b_koff.as<uint32_t>(),
                                                        b_knht.as<uint32_t>(), n_tasks > 1 ? b_slot_task.as<uint16_t>() : (uint16_t *)nullptr, order, ctl);
     }
     // the pair counts need nothing but the decode results

@@ -131,7 +131,9 @@ struct FeSeq {
     FE_HD char at(int i) const {
         if (!packed) return (char)p[i];
         const int nib = (i & 1) ? (p[i >> 1] & 15) : (p[i >> 1] >> 4);
-        return "=ACMGRSVTWYHKDBN"[nib];
+        // "=ACMGRSVTWYHKDBN"[nib] out of two registers (the string literal was a memory load per base)
+        const uint64_t tab = nib < 8 ? 0x565352474D43413DULL : 0x4E42444B48595754ULL;
+        return (char)((tab >> (8 * (nib & 7))) & 0xff);
     }
 };
 FE_HD inline FeSeq fe_seq_of(const FeKey &K, const char *text) {
@@ -231,6 +233,20 @@ FE_HD inline int fe_error_correct(const FeLocus &L, const FePile &P, const FeSeq
         if (fe_type(c) == FE_T_MATCH) {
             int last = 0;
             for (int j = 0; j < c.len; ++j) {
+                // eight bases at a time while none of them is a candidate (a pileup set that is not empty and does not hold the read's
+                // base): one 8-byte look at the sets, eight independent looks at the read -- the common case of a read without errors
+                // costs a round trip per eight bases instead of two per base
+                while (j + 8 <= c.len && read_pos + j + 8 <= seq_len && c.pos + j + 8 <= n_ref) {
+                    uint64_t s8, b8 = 0;
+                    __builtin_memcpy(&s8, P.nt_set + c.pos + j, 8);
+                    for (int k = 0; k < 8; ++k) b8 |= (uint64_t)fe_nt_bit(seq.at(read_pos + j + k)) << (8 * k);
+                    const uint64_t t = s8 & b8;
+                    const uint64_t t_zero = ~(((t & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | t) & 0x8080808080808080ULL;
+                    const uint64_t s_zero = ~(((s8 & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | s8) & 0x8080808080808080ULL;
+                    if (t_zero & ~s_zero) break;                   // a candidate among the eight: one by one from here
+                    j += 8;
+                }
+                if (j >= c.len) break;
                 if (read_pos + j >= seq_len || c.pos + j >= n_ref) continue;
                 char b = seq.at(read_pos + j);
                 const int s = P.nt_set[c.pos + j];
@@ -889,14 +905,17 @@ static inline uint32_t fe_host_add(uint32_t *p, uint32_t v) { const uint32_t o =
 #endif
 
 // state: 1 = haplotypes follow (ht_off, n_ht), 2 = the record is dropped; return < 0 = decline
+// (seq_copy: the key's SEQ bytes where the caller has put them -- the decode kernel stages them in LDS; nullptr = read them from text)
 FE_HD inline int fe_key(const FeLocus &L, const FeParse &o, const FePile &P, const FeKey &K, const char *text, const FePools &pools,
-                        uint8_t &state, uint32_t &ht_off, uint32_t &n_ht_out) {
+                        uint8_t &state, uint32_t &ht_off, uint32_t &n_ht_out, const unsigned char *seq_copy = nullptr) {
     FeCmp cl[FE_MAX_CMP], tmp[FE_MAX_CMP];
     int n_cl = 0;
     state = 2;
     ht_off = 0;
     n_ht_out = 0;
-    int rc = fe_decode(L, o, P, K.pos, fe_cigar_of(K, text), fe_seq_of(K, text), text + K.zs_off, (K.flags & FE_K_HAS_ZS) ? K.zs_len : 0,
+    FeSeq seq_k = fe_seq_of(K, text);
+    if (seq_copy) seq_k.p = seq_copy;
+    int rc = fe_decode(L, o, P, K.pos, fe_cigar_of(K, text), seq_k, text + K.zs_off, (K.flags & FE_K_HAS_ZS) ? K.zs_len : 0,
                        text + K.md_off, (K.flags & FE_K_HAS_MD) ? K.md_len : 0, cl, n_cl, tmp);
     if (rc <= 0) return rc;
     int n_nov = 0;

@@ -4,6 +4,9 @@ import ctypes as C, os, resource, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import hisatgenotype_amd  # noqa
 from hisatgenotype_amd import capi, synth, locus as hl
+if os.environ.get("HGX_BENCH_LIB"):          # an A/B against another build of libhgx
+    from hisatgenotype_amd import capi as _capi
+    _capi.LIB_PATH = os.environ["HGX_BENCH_LIB"]
 ht = sys.modules["hisatgenotype_amd.typing"]
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 500000
 threads = [int(x) for x in sys.argv[2:]] or [0]

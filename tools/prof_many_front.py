@@ -4,6 +4,9 @@
 import os, sys, time, tempfile, shutil
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from hisatgenotype_amd import bamio, engine, locus as hl, synth
+if os.environ.get("HGX_BENCH_LIB"):          # an A/B against another build of libhgx
+    from hisatgenotype_amd import capi as _capi
+    _capi.LIB_PATH = os.environ["HGX_BENCH_LIB"]
 n, pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 64, int(sys.argv[2]) if len(sys.argv) > 2 else 5000
 loc = synth.make_hla_like_locus(gene="A", n_alleles=7000, length=3500, n_vars=2500, seed=500)
 pl = hl.PackedLocus.from_synth(loc)
