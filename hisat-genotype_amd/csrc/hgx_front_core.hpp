@@ -1376,8 +1376,16 @@ FE_HD inline int fe_parse_bam_record(const char *text, uint32_t rec_off, uint32_
         else if (t == 's' || t == 'S') sz = 2;
         else if (t == 'i' || t == 'I' || t == 'f') sz = 4;
         else if (t == 'Z' || t == 'H') {
+            // the NUL that ends the text, eight bytes per look (a byte per look was a dependent load per character of every MD / Zs)
             size_t e = q;
-            while (e < len && r[e] != 0) ++e;
+            bool hit = false;
+            while (!hit && e + 8 <= len) {
+                const uint64_t w = fe_load8(r + e);
+                const uint64_t z = ~(((w & 0x7F7F7F7F7F7F7F7FULL) + 0x7F7F7F7F7F7F7F7FULL) | w) & 0x8080808080808080ULL;     // 0x80 in the zero bytes
+                if (z) { e += (size_t)(__builtin_ctzll(z) >> 3); hit = true; }
+                else e += 8;
+            }
+            while (!hit && e < len && r[e] != 0) ++e;
             if (e >= len) return FE_FAIL(FE_E_ASSERT);
             sz = e - q + 1;
         } else if (t == 'B') {
