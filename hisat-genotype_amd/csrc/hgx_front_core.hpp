@@ -1258,6 +1258,20 @@ FE_HD inline int fe_parse_text_record(const char *text, size_t text_bytes, uint3
     const uint64_t ones = 0x0101010101010101ull, highs = 0x8080808080808080ull;
     for (;;) {
         bool at_end = p >= len;
+        // 32 bytes at a time while none of them is a tab, blank or CR (SEQ and QUAL are three quarters of a line): the four loads go
+        // out together, one round trip per 32 bytes instead of one per 8
+        while (p + 32 <= safe && p + 32 <= len) {
+            const uint64_t w0 = fe_load8(line + p), w1 = fe_load8(line + p + 8), w2 = fe_load8(line + p + 16), w3 = fe_load8(line + p + 24);
+            uint64_t any = 0;
+            const uint64_t ws[4] = {w0, w1, w2, w3};
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t xt = ws[k] ^ (ones * 0x09), xs = ws[k] ^ (ones * 0x20), xr = ws[k] ^ (ones * 0x0d);
+                any |= (((xt - ones) & ~xt) | ((xs - ones) & ~xs) | ((xr - ones) & ~xr)) & highs;
+            }
+            if (any) break;
+            p += 32;
+        }
+        at_end = p >= len;
         if (!at_end && p < safe) {
             const uint64_t w = fe_load8(line + p);
             const uint64_t xt = w ^ (ones * 0x09), xs = w ^ (ones * 0x20), xr = w ^ (ones * 0x0d);
