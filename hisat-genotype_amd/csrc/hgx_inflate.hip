@@ -615,7 +615,7 @@ __device__ __forceinline__ uint32_t wave_xor_to_lane63(uint32_t v) {
 // the offsets (a scan over the runs' heads), one fills.  A code whose table does not fit the pool keeps an empty root entry: the
 // wave-uniform path takes it, as it takes every long code in the first form.
 template <class T, int P, int MODE>
-__device__ void huff_sub_tables(T &H, const unsigned char *lens, int lane, uint32_t *pool, uint32_t &used) {
+__device__ void huff_sub_tables(T &H, const unsigned char *lens, int lane, uint32_t *pool, uint32_t &used, uint32_t cap) {      // cap <= SUB_CAP entries of `pool` are handed out
     __builtin_amdgcn_wave_barrier();
     uint32_t j0 = 0, n_long = 0;
 #pragma unroll
@@ -649,11 +649,11 @@ __device__ void huff_sub_tables(T &H, const unsigned char *lens, int lane, uint3
         const uint32_t size = head ? 1u << b : 0u;
         const uint32_t incl = wave_incl_scan_u32(size);
         const uint32_t off = carry + incl - size;
-        if (head) H.pt[r] = off + size <= SUB_CAP ? (((uint32_t)K_SUB << 8) | (b << 4) | (off << 16)) : 0u;
+        if (head) H.pt[r] = off + size <= cap ? (((uint32_t)K_SUB << 8) | (b << 4) | (off << 16)) : 0u;
         carry += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
         r_last = (uint32_t)__builtin_amdgcn_readlane((int)r, 63);
     }
-    const uint32_t used_new = carry < SUB_CAP ? carry : SUB_CAP;
+    const uint32_t used_new = carry < cap ? carry : cap;
     for (uint32_t i = used + lane; i < used_new; i += 64) pool[i] = 0u;
     __builtin_amdgcn_wave_barrier();
     for (uint32_t j = j0 + lane; j < end; j += 64) {
@@ -682,10 +682,11 @@ __device__ __forceinline__ uint32_t crc32_words8(const uint32_t (&wd)[8]) {
 
 // PROF: clock64() laps per phase, summed per block into prof[block][8] (test switch front=inflate_prof: a measuring aid)
 enum { PH_HEADER = 0, PH_DECODE, PH_WALK, PH_LIT, PH_NEAR, PH_FAR, PH_FLUSH, PH_SLOW };
-template <bool PROF>
+template <bool PROF, bool SMALL_POOL = false>
 __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__restrict__ in, const BlockDesc *__restrict__ blocks, int n_blocks,
                                                        unsigned char *__restrict__ out, CrcOp op, uint32_t *__restrict__ verdict,
                                                        unsigned long long *__restrict__ prof) {
+    constexpr uint32_t sub_cap = SMALL_POOL ? 32u : SUB_CAP;        // (an instantiation of its own for the tests: a run-time cap cost the product kernel 2-4 %)
     extern __shared__ unsigned char inf_lds_raw[];
     InfLdsW &S = *reinterpret_cast<InfLdsW *>(inf_lds_raw);
     const int lane = threadIdx.x;
@@ -836,8 +837,8 @@ __global__ void __launch_bounds__(64) k_bgzf_inflate_w(const unsigned char *__re
                     if (!huff_incomplete_ok(S.lens + 32 + n_lit, n_dist, lane, true) || !huff_build<DistLdsW, DIST_P, 2>(S.dist, S.lens + 32 + n_lit, n_dist, lane, true)) { err = INF_BAD_LENGTHS; break; }
                 }
                 uint32_t sub_used = 0;
-                huff_sub_tables<HuffLdsW, LIT_P, 1>(S.lit, S.lens + 32, lane, S.sub, sub_used);
-                huff_sub_tables<DistLdsW, DIST_P, 2>(S.dist, S.lens + 32 + n_lit, lane, S.sub, sub_used);
+                huff_sub_tables<HuffLdsW, LIT_P, 1>(S.lit, S.lens + 32, lane, S.sub, sub_used, sub_cap);
+                huff_sub_tables<DistLdsW, DIST_P, 2>(S.dist, S.lens + 32 + n_lit, lane, S.sub, sub_used, sub_cap);
             }
             // ---- the symbols of the block, a window of 64 bit offsets at a time ----------------------------------------------
             bool eob = false;
@@ -1102,6 +1103,7 @@ int inflate_w_setup() {                  // once per device: the CRC-32 slice ta
     }
     HIPCHK(hipFuncSetAttribute((const void *)k_bgzf_inflate_w<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InfLdsW)));
     HIPCHK(hipFuncSetAttribute((const void *)k_bgzf_inflate_w<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InfLdsW)));
+    HIPCHK(hipFuncSetAttribute((const void *)k_bgzf_inflate_w<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(InfLdsW)));
     return HGX_OK;
 }
 
@@ -1202,6 +1204,10 @@ int hgx_bgzf_inflate_dev(const unsigned char *d_in, const hgx_bgzf_block *blocks
                 tot[11] / n_blocks, tot[8] / n_blocks, tot[9] / n_blocks, tot[10] / n_blocks, n_slow / n_blocks);
         for (int k = 0; k < 8; ++k) fprintf(stderr, " %s %.0f", nm[k], tot[k] / n_blocks);
         fprintf(stderr, "\n");
+    } else if (hgx_switch_has("front", "inflate_small_pool")) {
+        // (test switch: 32 entries of the second-level pool instead of all -- most long codes then overflow into the wave-uniform path,
+        // which the tests want to see taken)
+        k_bgzf_inflate_w<false, true><<<(unsigned)n_blocks, 64, sizeof(InfLdsW), st>>>(d_in, b_desc.as<BlockDesc>(), (int)n_blocks, d_out, op, b_verdict.as<uint32_t>(), nullptr);
     } else
         k_bgzf_inflate_w<false><<<(unsigned)n_blocks, 64, sizeof(InfLdsW), st>>>(d_in, b_desc.as<BlockDesc>(), (int)n_blocks, d_out, op, b_verdict.as<uint32_t>(), nullptr);
     HIPCHK(hipGetLastError());

@@ -16,10 +16,12 @@ pytestmark = pytest.mark.gpu
 EOF_BLOCK = bamio._BGZF_EOF
 
 
-@pytest.fixture(autouse=True, params=[None, "inflate_v1"], ids=["lane_parallel", "round4"])
+@pytest.fixture(autouse=True, params=[None, "inflate_small_pool", "inflate_v1"], ids=["lane_parallel", "lane_parallel_small_pool", "round4"])
 def inflate_form(request):
-    """Every test with both forms of the device inflate the library holds: the default (k_bgzf_inflate_w: the symbol loop lane-parallel,
-    64 bit offsets per window) and round 4's one-symbol-per-trip kernel (k_bgzf_inflate, test switch front=inflate_v1)."""
+    """Every test with the forms of the device inflate the library holds: the default (k_bgzf_inflate_w: the symbol loop lane-parallel,
+    64 bit offsets per window, second-level tables for the long codes), the same with a second-level pool of 32 entries (test switch
+    front=inflate_small_pool: most long codes overflow into the wave-uniform path) and round 4's one-symbol-per-trip kernel
+    (k_bgzf_inflate, test switch front=inflate_v1)."""
     from hisatgenotype_amd import engine
     if request.param:
         engine.test_switch("front", request.param)
