@@ -26,7 +26,7 @@ def _launch_ranks_if_needed():
     libhgx or touched the GPU (a process that has initialised the GPU must not be replaced or forked into ranks).
     Under a launcher (WORLD_SIZE set) the world size must be the --gpus the caller asked for."""
     import subprocess
-    n, backend, dry = 1, "nccl", False
+    n, backend, dry, share = 1, "nccl", False, False
     argv = sys.argv[1:]
     for i, a in enumerate(argv):
         if a == "--gpus" and i + 1 < len(argv):
@@ -39,6 +39,8 @@ def _launch_ranks_if_needed():
             backend = a.split("=", 1)[1]
         elif a == "--dry-run":
             dry = True
+        elif a == "--share-gpu":
+            share = True
     if n < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     ws = os.environ.get("WORLD_SIZE")
@@ -48,6 +50,8 @@ def _launch_ranks_if_needed():
         return
     if n == 1:
         return
+    if share and backend == "nccl" and not dry:
+        sys.exit("bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
     if backend == "nccl" and not dry:
         import torch                      # device_count() does not initialise the GPU on this image
         have = torch.cuda.device_count()
@@ -97,7 +101,7 @@ def parse_args():
                     help="file -> result with N processes sharing GPU 0 (one sample stream each): the host-scaling leg of the default run; '' skips it")
     ap.add_argument("--e2e-child", default=None, help=argparse.SUPPRESS)      # internal: one process of that leg (a JSON job description)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (profiling runs)")
-    ap.add_argument("--workload", choices=["configs1", "class1", "panel64"], default="configs1",
+    ap.add_argument("--workload", choices=["configs1", "class1", "panel64", "config0_dropin", "codis_dropin"], default="configs1",
                     help="configs1 (default; BASELINE.json configs[1]: one HLA-A sample of 1 M reads per GPU), class1 (configs[2]: "
                          "HLA-A + B + C, 1 M reads each, loci -- and the reads of a locus -- sharded over the GPUs), panel64 "
                          "(configs[3]: six loci x 64 samples sharded over the GPUs)")
@@ -105,6 +109,11 @@ def parse_args():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for --dry-run on CPU)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only: every rank joins the process group and rank 0 prints the world it saw (no GPU work)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="every rank on GPU 0 (with --backend gloo): the REAL multi-rank body -- sharding, exchanges, max-over-ranks timing -- "
+                         "on a one-GPU box; the line says so (`shared_gpu`), its value is not a scaling figure")
+    ap.add_argument("--check-unsharded", action="store_true",
+                    help="class1: every rank of a sharded locus also types the whole locus alone and compares (`sharded_equals_unsharded`)")
     ap.add_argument("--no-in-flight", action="store_true", help="skip the side measurement with 2 / 3 samples in flight")
     ap.add_argument("--no-workloads", action="store_true", help="default workload only: skip the class1 / panel64 runs that follow it")
     ap.add_argument("--workloads", action="store_true", help="run class1 / panel64 behind the default workload also with more than one rank "
@@ -122,6 +131,7 @@ def parse_args():
     return ap.parse_args()
 
 
+DIST_DEV = "cuda"        # device of the control-plane tensors (torch.distributed): "cuda" with nccl (= RCCL), "cpu" with gloo
 EM_MODE = False          # --em-exact: -1 = the reference's order of operations at every size (hgx_type_opts.em_fast = -1)
 
 
@@ -537,12 +547,48 @@ PANEL = [("A", 7000, 3569, 2500), ("B", 8000, 4081, 2800), ("C", 7000, 4305, 260
          ("DQA1", 500, 3300, 600), ("DQB1", 2000, 3600, 1400)]
 
 
+def _torch_sync():
+    """torch's own streams (the nccl collectives of the control plane run there); nothing to wait for with gloo."""
+    if DIST_DEV == "cuda":
+        import torch
+        torch.cuda.synchronize()
+
+
+def make_comm(dist, group=None):
+    """The exchanges of a sharded locus for the ranks of `group`: with nccl this library's own RCCL communicator (dist.RcclComm:
+    hgx_classes_allgather / hgx_allreduce_sum_* on device buffers, nothing through the host per step); with gloo (CPU control plane;
+    --share-gpu) dist.TorchComm.  If the RCCL communicator cannot be made on ANY rank of the group, every rank falls back to
+    TorchComm over the nccl group (decided together: one all-reduce of a flag) and the line says why.  -> (comm, kind)"""
+    from hisatgenotype_amd import dist as hdist
+    if DIST_DEV != "cuda":
+        return hdist.TorchComm(group), "torch-gloo (host control plane)"
+    import torch
+    comm, why = None, ""
+    try:
+        comm = hdist.RcclComm.from_torch(group)
+    except BaseException as e:               # noqa: BLE001 (the fallback must be collective: see the flag below)
+        why = repr(e)[:200]
+    bad = torch.tensor([0.0 if comm is not None else 1.0], dtype=torch.float64, device=DIST_DEV)
+    dist.all_reduce(bad, op=dist.ReduceOp.MAX, group=group)
+    if bad.item() > 0:
+        if comm is not None:
+            comm.close()
+        return hdist.TorchComm(group), "torch-nccl (RcclComm could not be created on some rank: %s)" % (why or "another rank")
+    return comm, "rccl"
+
+
+def rccl_stats(reset=False):
+    import ctypes as C
+    n, snt, rcv = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    capi.check(capi.lib().hgx_rccl_stats(C.byref(n), C.byref(snt), C.byref(rcv), C.c_int32(1 if reset else 0)))
+    return n.value, snt.value, rcv.value
+
+
 def _timed(dist, n_steps, body):
     """barrier + sync, `n_steps` x body(), sync + barrier; returns the MAX over ranks of the elapsed seconds."""
     capi.sync()
     if dist is not None:
-        import torch
-        torch.cuda.synchronize()
+        _torch_sync()
         dist.barrier()
     t0 = time.perf_counter()
     last = None
@@ -550,13 +596,12 @@ def _timed(dist, n_steps, body):
         last = body()
     capi.sync()
     if dist is not None:
-        import torch
-        torch.cuda.synchronize()
+        _torch_sync()
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=DIST_DEV)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     return elapsed, last
@@ -572,16 +617,16 @@ def run_class1(args, rank, local_rank, world, dist):
     loci = [synth.make_hla_like_locus(gene=g, n_alleles=a, length=ln, n_vars=v, seed=sd, var_id_base=100000 * i)
             for i, (g, a, ln, v, sd) in enumerate(CLASS1)]
     groups = hdist.assign_ranks_to_loci([args.pairs] * len(loci), world)
-    comms = {}
+    comms, comm_kinds = {}, {}
     if dist is not None:                                        # every rank creates every sub-group, in the same order
         for i in sorted(groups):
             if len(groups[i]) > 1:
                 g = dist.new_group(groups[i])
                 if rank in groups[i]:
-                    comms[i] = hdist.TorchComm(g)
+                    comms[i], comm_kinds[loci[i].gene] = make_comm(dist, g)
     mine = [i for i in sorted(groups) if rank in groups[i]]
     work = []
-    shard_routes, shard_bam = {}, {}
+    shard_routes, shard_bam, whole_sam = {}, {}, {}
     want_files = world == 1 and dist is None and not args.no_e2e
     file_of, file_dir = {}, None
     if want_files:
@@ -611,6 +656,8 @@ def run_class1(args, rank, local_rank, world, dist):
                 shard_bam[i] = os.path.join(d_, "%s.shard%d.bam" % (loc.gene, groups[i].index(rank)))
                 bamio.write_bam_native(shard_bam[i], shard_text, [(loc.ref_allele, len(loc.backbone))], sort_by_coordinate=True)
             del shard_text
+            if args.check_unsharded:
+                whole_sam[i] = sam
         else:
             batch = pl.parse_sam(sam)
             db = engine.DeviceBatch(batch)
@@ -678,7 +725,17 @@ def run_class1(args, rank, local_rank, world, dist):
         engine.em_set_timing(mode)
         state["k"] += 1
         return body()
+    rccl_stats(reset=True)
+    for c in comms.values():
+        if hasattr(c, "stats"):
+            c.stats = [0, 0, 0]
     elapsed, last = _timed(dist, args.steps, timed_body)
+    xs = list(rccl_stats())
+    for c in comms.values():
+        if hasattr(c, "stats"):
+            xs = [a + b for a, b in zip(xs, c.stats)]
+    exchange = {"collectives_per_step": xs[0] / max(args.steps, 1), "bytes_sent_per_step": xs[1] // max(args.steps, 1),
+                "bytes_received_per_step": xs[2] // max(args.steps, 1), "of": "rank 0's sharded loci (class tables of both levels + totals)"} if comms else None
     em_timing = engine.em_get_timing() if timing else {}
     engine.em_set_timing(0)
     if side_by_side:
@@ -698,14 +755,29 @@ def run_class1(args, rank, local_rank, world, dist):
     calls = {loci[i].gene: ([a for a, _ in r.gene_prob[:2]], work[k][5]) for k, (i, r) in enumerate(sorted(last.items()))}
     if dist is not None:
         import torch
-        rr = torch.tensor([float(reads)], dtype=torch.float64, device="cuda")
+        rr = torch.tensor([float(reads)], dtype=torch.float64, device=DIST_DEV)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         reads = float(rr.item())
         allc = [None] * world
         dist.all_gather_object(allc, calls)
         calls = {g: v for part in allc for g, v in part.items()}
+    sharded_ok = None
+    if args.check_unsharded and dist is not None:
+        import torch
+        ok = True
+        for i, pl, batch, db, comm, sample in work:
+            if comm is not None:
+                ref = hgx.type_locus(pl, whole_sam[i])
+                r = last[i]
+                ok = ok and (r.num_reads, r.num_pairs) == (ref.num_reads, ref.num_pairs) and r.counts_sorted == ref.counts_sorted \
+                    and r.em == ref.em and r.gene_prob == ref.gene_prob
+        tt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=DIST_DEV)
+        dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+        sharded_ok = bool(tt.item() > 0.5)
+        whole_sam.clear()
     e2e_shards = None
-    if shard_bam:
+    if dist is not None and not args.no_e2e and any(len(g) > 1 for g in groups.values()):
+        # (EVERY rank enters: the barrier and the reductions below are on the world group; a rank without a sharded locus has no calls to make)
         # sharded loci, files -> result: every rank of a group types its own BAM shard through dist.type_locus_sharded (device
         # inflate / walk / sort, device front end, pileup all-reduce in HBM, class-table all-gather, EMs) -- all ranks at once
         import shutil
@@ -715,7 +787,7 @@ def run_class1(args, rank, local_rank, world, dist):
             for i, pl, batch, db, comm, sample in work:
                 if comm is not None:
                     hdist.type_locus_sharded(pl, None, comm, alignment_file=shard_bam[i], regions=[pl.ref_allele])
-            torch.cuda.synchronize()
+            _torch_sync()
             dist.barrier()
             t0 = time.perf_counter()
             ok = True
@@ -725,7 +797,7 @@ def run_class1(args, rank, local_rank, world, dist):
                         r_f = hdist.type_locus_sharded(pl, None, comm, alignment_file=shard_bam[i], regions=[pl.ref_allele])
                         ok = ok and engine.front_last()[0] == 2 and r_f.gene_prob == last[i].gene_prob
             dt = time.perf_counter() - t0
-            tt = torch.tensor([dt, 0.0 if ok else 1.0], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([dt, 0.0 if ok else 1.0], dtype=torch.float64, device=DIST_DEV)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             e2e_shards = {"input": "every rank of a sharded locus its own coordinate-sorted BAM shard, %d calls, all ranks at once" % n_calls,
                           "ms_per_call": round(float(tt[0].item()) / n_calls * 1e3, 2),
@@ -791,10 +863,104 @@ def run_class1(args, rank, local_rank, world, dist):
                                       "pileup all-reduce on the counters in HBM at parse, class-table all-gather + merge per step over RCCL); "
                                       "no other data-path collective",
                        "front_end_route_of_my_shards": {loci[i].gene: list(r) for i, r in shard_routes.items()},
+                       "comm_kind": comm_kinds or None, "exchange": exchange, "sharded_equals_unsharded": sharded_ok,
+                       "shared_gpu": bool(args.share_gpu),
                        "e2e_shards": e2e_shards,
                        "setup_s": round(t_setup, 1)},
             "roofline": em_roofline(em_timing, n_timed) if timing else None, "cpu_baseline": cb, "e2e": e2e})
     return None
+
+
+def run_dropin(args, name):
+    """The drop-in itself, timed: a committed fixture recorded from the REAL reference (tests/golden/<name>.json.gz:
+    BASELINE configs[0] = HLA-A-like, 7 000 alleles, 10 k reads, which the reference needed 109 s for; configs[4]'s shape = one CODIS
+    STR ladder, 10 k reads) through `hisatgenotype_amd.typing(<the reference's 38 arguments>)` -> report file, and through
+    `genotyping_locus(<32 arguments>)` from index files on disk.  Wall time per call with the split typing() records (locus packing,
+    index upload + pattern tables, file read + front end, GPU typing + result, report), first call and repeated calls (the
+    reference's own shape: one typing() per sample on one index), report text `==` the reference's recorded report."""
+    import copy
+    import gzip
+    import shutil
+    import tempfile
+    from hisatgenotype_amd import locus as hlocus
+    with gzip.open(os.path.join(ROOT, "tests", "golden", name + ".json.gz"), "rb") as f:
+        fx = json.loads(f.read().decode())
+    loc = synth.Locus.from_json(fx["locus"]) if fx["locus"] is not None else synth.make_hla_like_locus(**fx["locus_params"])
+    o = fx["options"]
+    keep = lambda ls: [l for l in ls if "aligned" in l or "ranked" in l or "(count:" in l]
+    want = keep(fx["report"].split("\n"))
+    tmp = tempfile.mkdtemp(prefix="hgx_dropin_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        sam_path = os.path.join(tmp, "sample.sam")
+        with open(sam_path, "w") as f:
+            f.write(fx["sam"])
+        d = loc.reference_dicts()
+        base = loc.base_fname
+        rep_path = os.path.join(tmp, "assembly_graph-%s.sample.report" % base)
+
+        def call(dd):
+            t0 = time.perf_counter()
+            hgx.typing(False, os.path.join(tmp, base), [loc.gene], "", True, set(), dd["refGenes"], dd["Genes"], dd["Gene_names"],
+                       dd["Gene_lengths"], dd["refGene_loci"], dd["Vars"], dd["Var_list"], dd["Links"], [["hisat2", "graph"]], o["num_editdist"],
+                       False, "assembly_graph", o["error_correction"], True, o["allow_discordant"], False, o["remove_low"], [], False,
+                       ["sample.fq"], sam_path, [], o["read_len"], o["frag_len"], 1, False, 0, False, tmp, "NONE", True, 0)
+            dt = time.perf_counter() - t0
+            prof = dict(htyping.last_profile[0])
+            with open(rep_path) as f:
+                same = keep(f.read().split("\n")) == want
+            return dt, prof, same
+
+        def fmt(p):
+            return {k: (round(v, 3) if isinstance(v, float) else v) for k, v in p.items() if k != "gene"}
+        hlocus.LOCUS_CACHE.clear()
+        t_first, p_first, ok_first = call(d)                               # first call of the process on this index: packs, uploads
+        rest = sorted((call(d) for _ in range(7)), key=lambda r: r[0])
+        t_rep, p_rep, ok_rep = rest[len(rest) // 2]
+        t_copy, p_copy, ok_copy = call(copy.deepcopy(d))                   # equal dicts in other objects (re-read index): content key
+        hits = (hlocus.LOCUS_CACHE.hits_identity, hlocus.LOCUS_CACHE.hits_content, hlocus.LOCUS_CACHE.misses)
+        # the same through genotyping_locus from index files on disk (driver.py; typing_core.py:2278-2691)
+        ix_dir = os.path.join(tmp, "ix")
+        synth.write_index([loc], ix_dir, base)
+
+        def call_gl():
+            t0 = time.perf_counter()
+            hgx.genotyping_locus(base, [loc.gene], "", ix_dir, [], True, [["hisat2", "graph"]], ["sample.fq"], True, sam_path, 1, 10,
+                                 o["read_len"], o["frag_len"], False, o["num_editdist"], 0.0, 0.0, [], False, "assembly_graph",
+                                 o["error_correction"], True, o["allow_discordant"], False, o["remove_low"], [], 0, False, tmp, True, {})
+            dt = time.perf_counter() - t0
+            with open(rep_path) as f:
+                same = keep(f.read().split("\n")) == want
+            return dt, dict(htyping.last_profile[0]), same
+        import io
+        import contextlib
+        with contextlib.redirect_stderr(io.StringIO()):                    # (genotyping_locus prints the locus list like the reference)
+            g_first = call_gl()
+            g_rest = sorted((call_gl() for _ in range(5)), key=lambda r: r[0])
+        g_rep = g_rest[len(g_rest) // 2]
+        n_rec = fx["reference_timing"]["sam_records"]
+        ref_s = fx["reference_timing"]["seconds"]
+        return {
+            "metric": "wall time of one typing() call (file -> report), the reference's own entry point", "unit": "ms", "higher_is_better": False,
+            "value": round(t_rep * 1e3, 2),
+            "config": {"workload": "%s: tests/golden/%s.json.gz (%d SAM records, %d alleles), the input the real reference was timed on" % (
+                "configs[0]" if name == "hla_7000_10k" else "configs[4] shape", name, n_rec, len(loc.allele_names) - 1),
+                "entry": "hisatgenotype_amd.typing(<38 arguments of typing_core.py:249-286>) -> <out_dir>/assembly_graph-%s.sample.report" % base},
+            "report_identical_to_the_reference": bool(ok_first and ok_rep and ok_copy and g_first[2] and g_rep[2]),
+            "first_call_ms": round(t_first * 1e3, 2), "first_call_split_ms": fmt(p_first),
+            "repeated_call_ms": round(t_rep * 1e3, 2), "repeated_call_split_ms": fmt(p_rep),
+            "equal_dicts_in_new_objects_ms": round(t_copy * 1e3, 2), "equal_dicts_split_ms": fmt(p_copy),
+            "locus_cache": {"identity_hits": hits[0], "content_hits": hits[1], "misses": hits[2]},
+            "genotyping_locus": {"entry": "hisatgenotype_amd.genotyping_locus(<32 arguments of typing_core.py:2278-2309>) on index files on disk",
+                                 "first_call_ms": round(g_first[0] * 1e3, 2), "repeated_call_ms": round(g_rep[0] * 1e3, 2),
+                                 "repeated_call_split_ms": fmt(g_rep[1])},
+            "reads_per_s_repeated": round(n_rec / t_rep, 1),
+            "reference_recorded": {"seconds": ref_s, "records_per_s": fx["reference_timing"]["records_per_s"], "cpu": fx["reference_timing"]["cpu"],
+                                   "what": fx["reference_timing"]["what"], "note": "recorded on the build container (tests/golden/make_golden.py), not on this box"},
+            "speedup_over_the_recorded_reference": {"first_call": round(ref_s / t_first, 1), "repeated_call": round(ref_s / t_rep, 1)},
+        }
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
 
 
 def run_panel64(args, rank, local_rank, world, dist):
@@ -894,7 +1060,7 @@ def run_panel64(args, rank, local_rank, world, dist):
     n_tasks = len(work)
     if dist is not None:
         import torch
-        rr = torch.tensor([reads, float(correct), float(n_tasks)], dtype=torch.float64, device="cuda")
+        rr = torch.tensor([reads, float(correct), float(n_tasks)], dtype=torch.float64, device=DIST_DEV)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         reads, correct, n_tasks = float(rr[0].item()), int(rr[1].item()), int(rr[2].item())
     roof = None
@@ -1074,11 +1240,19 @@ def main():
         return
     if args.gpus != world:
         sys.exit("bench.py: --gpus %d but %d rank(s) are running" % (args.gpus, world))
+    global DIST_DEV
+    dev_id = 0 if args.share_gpu else local_rank          # --share-gpu: every rank on GPU 0 (the multi-rank body on a one-GPU box)
     if use_dist:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            if args.share_gpu:
+                sys.exit("bench.py: --share-gpu needs --backend gloo (RCCL refuses two ranks on one device)")
+            torch.cuda.set_device(dev_id)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_id))
+        else:
+            DIST_DEV = "cpu"                              # control plane over gloo; the data path stays on the GPU
+            dist.init_process_group("gloo")
         assert dist.get_world_size() == world
     pre = None
     if (args.workload == "configs1" and world == 1 and not use_dist and not args.no_e2e and not args.no_cpu_baseline and args.e2e_procs.strip()):
@@ -1092,7 +1266,13 @@ def main():
         except Exception as e:                                      # (the leg must not cost the run its headline)
             scaling = {"error": repr(e)[:500]}
         pre = (loc0, sam0, scaling)
-    capi.set_device(local_rank)
+    capi.set_device(dev_id)
+    local_rank = dev_id                                   # (everything below addresses the GPU through this)
+    if args.workload in ("config0_dropin", "codis_dropin"):
+        if world != 1:
+            sys.exit("bench.py: the drop-in legs are one-process measurements")
+        print(json.dumps(run_dropin(args, "hla_7000_10k" if args.workload == "config0_dropin" else "codis_10k")))
+        return
     if args.workload != "configs1":
         line = (run_class1 if args.workload == "class1" else run_panel64)(args, rank, local_rank, world, dist)
         if rank == 0:
@@ -1106,9 +1286,19 @@ def main():
     t_setup = time.perf_counter()
     loc = pre[0] if pre else synth.make_hla_like_locus(n_alleles=args.alleles, n_vars=args.vars, seed=101)
     pl = hl.PackedLocus.from_synth(loc)
+    comm_kind, bcast_bytes = None, None
     if use_dist:
+        # rank 0's packed link matrix reaches every GPU over RCCL / xGMI: hgx_index_broadcast on this library's own communicator
+        # (device block to device block, in place); with gloo -- or if that communicator cannot be made -- torch.distributed
         from hisatgenotype_amd import dist as hdist
-        hdist.broadcast_index(pl, src=0)          # rank 0's packed link matrix reaches every GPU over RCCL/xGMI
+        wcomm, comm_kind = make_comm(dist)
+        if comm_kind == "rccl":
+            rccl_stats(reset=True)
+            wcomm.broadcast_index(pl, 0)
+            bcast_bytes = rccl_stats()[1]
+            wcomm.close()
+        else:
+            bcast_bytes = hdist.broadcast_index(pl, src=0)
     else:
         pl.index()
     sample = synth.pick_sample(loc, 101 + rank)
@@ -1152,16 +1342,15 @@ def main():
     res, t_em, n_em_iter, em_timing = run_steps(pl, batch, db, inflight, args.steps, ev, timing, local_rank)
     capi.sync()
     if dist is not None:
-        import torch
-        torch.cuda.synchronize()
+        _torch_sync()
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=DIST_DEV)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        rr = torch.tensor([float(batch.n_reads)], dtype=torch.float64, device="cuda")
+        rr = torch.tensor([float(batch.n_reads)], dtype=torch.float64, device=DIST_DEV)
         dist.all_reduce(rr, op=dist.ReduceOp.SUM)
         total_reads = float(rr.item())
     else:
@@ -1174,16 +1363,16 @@ def main():
         try:
             hgx.type_file(pl, rank_bam)
             n_calls = 4
-            torch.cuda.synchronize()
+            _torch_sync()
             dist.barrier()
             t0 = time.perf_counter()
             for _ in range(n_calls):
                 r_f = hgx.type_file(pl, rank_bam)
             dt = time.perf_counter() - t0
             dist.barrier()
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([dt], dtype=torch.float64, device=DIST_DEV)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            ok = torch.tensor([1.0 if (r_f.gene_prob == res.gene_prob and r_f.num_reads == res.num_reads) else 0.0], dtype=torch.float64, device="cuda")
+            ok = torch.tensor([1.0 if (r_f.gene_prob == res.gene_prob and r_f.num_reads == res.num_reads) else 0.0], dtype=torch.float64, device=DIST_DEV)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             e2e_ranks = {"input": "every rank its own coordinate-sorted BAM file, %d calls back to back, all ranks at once" % n_calls,
                          "ms_per_call": round(float(tt.item()) / n_calls * 1e3, 2),
@@ -1312,6 +1501,7 @@ def main():
                                  else "default: reference order up to 4096 classes (EM #2 here), chip-wide table lookups beyond (EM #1 here, <= 1e-9)",
                 "top2": [a for a, _ in res.gene_prob[:2]], "true_alleles": sample,
                 "parallelism": "samples/loci shard over GPUs with no data-path collective; %d sample(s) in flight per GPU" % inflight,
+                "comm_kind": comm_kind, "index_broadcast_bytes": bcast_bytes, "shared_gpu": bool(args.share_gpu),
                 "input": "piece batch built in HBM by the device front end from the SAM text (route %d, decline code %d: %.1f ms, not timed; "
                          "identical to the host front end's batch: %s -- the host takes %.1f ms on %d host threads)" % (
                              fe_route, fe_code, t_parse_dev * 1e3, fe_same, t_parse * 1e3, os.cpu_count() or 1),
@@ -1365,10 +1555,21 @@ def main():
             a2 = copy.copy(args)
             a2.steps, a2.warmup, a2.workload = steps, warm, name
             t0 = time.perf_counter()
-            line = fn(a2, rank, local_rank, world, dist)
+            try:
+                line = fn(a2, rank, local_rank, world, dist)
+            except Exception as e:                                  # a side leg must not cost the run its headline ...
+                if dist is not None:                                # (... but ranks that disagree about a failure would hang: re-raise)
+                    raise
+                line = {"error": repr(e)[:500]}
             if rank == 0:
                 line["wall_s_incl_setup"] = round(time.perf_counter() - t0, 1)
                 wl[name] = line
+        if rank == 0 and world == 1:
+            for wname, fixture in (("config0_dropin", "hla_7000_10k"), ("codis_dropin", "codis_10k")):
+                try:
+                    wl[wname] = run_dropin(args, fixture)
+                except Exception as e:                              # (a side leg must not cost the run its headline)
+                    wl[wname] = {"error": repr(e)[:500]}
         if rank == 0:
             out["workloads"] = wl
     if rank == 0:

@@ -519,6 +519,34 @@ bool inflate_one(const unsigned char *data, const hgx_bgzf_block &b, unsigned ch
 
 }   // namespace
 
+// What a deferred stream's owner needs to pull ONE region list out of it (hgx_alignment_parse_dev: a file opened once, a locus at a
+// time): the descriptor hgx_read_alignment_lines would have made had it been given these regions.  1 = not expressible (more than
+// one region): the caller reads the file the ordinary way for this locus.
+int hgx_deferred_for_regions(const char *regions, bool text, size_t body0, const std::vector<std::string> &refs, hgx_bam_deferred &d) {
+    const std::vector<Region> regs = parse_regions(regions);
+    const bool filtered = regions != nullptr && regions[0] != 0;
+    if (regs.size() > 1 || (filtered && regs.size() != 1)) return 1;
+    d = hgx_bam_deferred();
+    d.on = true;
+    d.text = text;
+    d.body0 = body0;
+    d.filtered = filtered;
+    if (text) {
+        if (filtered) { d.region_whole = regs[0].whole; d.region_name = regs[0].name; d.left0 = regs[0].left0; d.right0 = regs[0].right0; }
+        return 0;
+    }
+    d.ref_action.assign(refs.size(), filtered ? 0 : 1);
+    if (filtered) {
+        const Region &r = regs[0];
+        d.left0 = r.left0; d.right0 = r.right0;
+        for (size_t i = 0; i < refs.size(); ++i) {
+            if (refs[i].size() == r.whole.size() && memcmp(refs[i].data(), r.whole.data(), r.whole.size()) == 0) d.ref_action[i] = 1;
+            else if (!r.name.empty() && refs[i].size() == r.name.size() && memcmp(refs[i].data(), r.name.data(), r.name.size()) == 0) d.ref_action[i] = 2;
+        }
+    }
+    return 0;
+}
+
 // The reader proper: the records of `path` as a line table, stable-sorted by QNAME, over buffers `out` owns.  Every line is
 // followed by one byte the parser may overwrite (its terminator).
 int hgx_read_alignment_lines(const char *path, const char *regions, int n_threads, hgx_align_lines &out, bool keep_binary) {
@@ -571,7 +599,12 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         unsigned char magic[4] = {0, 0, 0, 0};
         if (sb.st_size >= 4 && pread(fd, magic, 4, 0) != 4) { close(fd); hgx_set_error("short read on %s", path); return HGX_EINVAL; }
         const bool is_text = !(magic[0] == 0x1f && magic[1] == 0x8b) && memcmp(magic, "BAM\1", 4) != 0;
-        if (is_text && data.size() > (8u << 20)) {
+        // SAM text whose line table the caller makes itself (the device front end): any size from its gate on, not only big files
+        const bool text_defer_ok = out.defer_text && out.on_raw && keep_binary && regs.size() <= 1 && (!filtered || regs.size() == 1) &&
+                                   data.size() >= out.defer_min_bytes && data.size() < (1ull << 32) - 64;
+        if (is_text && (data.size() > (8u << 20) || text_defer_ok)) {
+            const int n_threads_file = n_threads;
+            const int n_threads = data.size() > (8u << 20) ? n_threads_file : 1;       // (a small file: one reader, no thread start-up)
             // Big SAM text: every worker reads its byte range in 1 MB pieces and scans each piece for lines while it is still in
             // its cache (the separate scan of the whole text was a second trip through 400 MB of DRAM).  A worker owns the lines
             // that START in its range; the one that runs over the end of the range is finished after all ranges are in.
@@ -581,8 +614,7 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             const int n_phase = (out.on_raw && data.size() > (64u << 20)) ? (ph_env ? std::max(1, atoi(ph_env)) : 4) : 1;
             // the caller makes the line table itself (the device front end: newline scan, region filter, name order as kernels):
             // the workers only read, the bytes go up phase by phase
-            text_defer = out.defer_text && out.on_raw && keep_binary && regs.size() <= 1 && (!filtered || regs.size() == 1) &&
-                         data.size() >= out.defer_min_bytes && data.size() < (1ull << 32) - 64;
+            text_defer = text_defer_ok;
             text_nt = n_threads * n_phase;
             if (!text_defer) text_part.assign(text_nt, std::vector<std::vector<Line>>(n_reg));
             std::vector<size_t> tail((size_t)text_nt, (size_t)-1);

@@ -1259,7 +1259,18 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
     // cluster mode: a problem far beyond the default gate (the any-size mode of hgx_em / hgx_type_*) gets a launch of its own on several
     // workgroups; such launches follow each other on the stream (one problem's cluster fills a good part of the chip)
     const bool clusters = allow_cluster && !hgx_test_switch("emx_no_cluster");
-    auto wants_cluster = [&](const hgx_emx_job &J) { return clusters && J.any_size && !J.fast && !J.mask && J.C > HGX_EMX_MAX_CLASSES; };
+    // ... and a sizeable reference-order problem that has the launch (nearly) to itself -- EM #1 of ONE sample typed by a one-task call:
+    // 1 730 classes x 4 500 alleles of a 10 000-read sample take 12 ms on one workgroup (the dense class x allele walk is bound by one
+    // CU's FP64 issue) -- is shared out the same way: same sums in the same orders, same bits (test switch emx_cluster_lone = 0: off)
+    int n_plain_big = 0;
+    for (int i = 0; i < n_jobs; ++i) n_plain_big += (!jobs[i].fast && !jobs[i].mask && (int64_t)jobs[i].C * jobs[i].a_pad >= (int64_t)512 * 4096) ? 1 : 0;
+    const char *lone_sw = hgx_test_switch("emx_cluster_lone");
+    const bool lone_ok = clusters && n_jobs <= 4 && n_plain_big >= 1 && n_plain_big <= 2 && !(lone_sw && atoi(lone_sw) == 0);
+    auto wants_cluster = [&](const hgx_emx_job &J) {
+        if (!clusters || J.fast || J.mask) return false;
+        if (J.any_size && J.C > HGX_EMX_MAX_CLASSES) return true;
+        return lone_ok && (int64_t)J.C * J.a_pad >= (int64_t)512 * 4096;
+    };
     // table-lookup problems: while a launch leaves CUs idle (a single sample, a few samples), its big problems run on two or four
     // workgroups each (k_emx<true, true>: the tiles of the two matrix passes shared out, hand-overs through agent-scope loads
     // and stores; 3.45 -> 2.48 -> 2.29 ms for a 1 456-class x 4 500-allele problem).  A full panel keeps one workgroup per

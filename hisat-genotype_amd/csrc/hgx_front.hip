@@ -25,7 +25,9 @@
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include <sys/stat.h>
@@ -1876,6 +1878,15 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
     return HGX_OK;
 }
 
+// Size gates of the device front end, from tools/front_gate.py on an MI355X box (round 6; 7 000- and 500-allele loci alike): the
+// device stages cost a flat 1.0-1.5 ms for SAM text and 2.7-3.0 ms for a BAM file (inflate, walk and sorts on the device) up to
+// 40 000 records, the host stages 2.3 us per record on one thread -- they cross at ~800 records of SAM text and ~2 000 BAM
+// records.  (Rounds 3-5 had the gate at 20 000 records / 8 MB: a real-depth sample of one locus -- 1 500 to 10 000 reads,
+// devel/hg_test4_realbasic/*.report:11 -- never reached the kernels and paid 4-9 ms of host decode instead of 1.5.)
+constexpr size_t FE_MIN_RECORDS = 1000;              // records a key- / record-route call must hold
+constexpr size_t FE_MIN_BYTES = 300u << 10;          // ... and bytes of SAM text / inflated BAM stream (below: not even uploaded)
+constexpr size_t FE_MIN_DEFER_BYTES = 512u << 10;    // bytes from which the line table / the BAM walk + inflate are the device's too
+
 // host stages with the device stages hooked in; *out is always a device batch on success
 template <class Parse>
 int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, Parse parse) {
@@ -1900,9 +1911,10 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
     const bool force = hgx_switch_has("front", "device");
     const bool host_only = hgx_switch_has("front", "host");
     const bool no_records = hgx_switch_has("front", "keys");
+    hook.min_records = force ? 0 : FE_MIN_RECORDS;
     int route = 0;                         // 2 = the record route produced the batch, 1 = the key route, 0 = the host stages
     hook.run = [&](hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, int *declined) {
-        if (!force && in.n_rec < 20000) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }     // a dozen launches cost more than a small host decode
+        if (!force && in.n_rec < FE_MIN_RECORDS) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }     // a dozen launches cost more than a small host decode
         hgx_dbatch_destroy(made);
         made = nullptr;
         const int rc = front_run(L, in, o, st, &made, declined);
@@ -1927,6 +1939,7 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
     if (!host_only && !no_records && !(opts->codis_choose_pairs || opts->interdist_exchange)) {
         hook.on_raw = [&](const char *raw, size_t n_bytes, size_t begin, size_t end) {
             if (n_bytes >= (1ull << 32) - 64 || up_failed) return;
+            if (!force && n_bytes < FE_MIN_BYTES) return;            // (the record stage will decline it as small: no upload for nothing)
             if (!text_room(n_bytes + 64)) { up_failed = true; return; }
             if (end > begin && hipMemcpyAsync((char *)b_text.p + begin, raw + begin, end - begin, hipMemcpyHostToDevice, st) != hipSuccess) { up_failed = true; return; }
             up_raw = raw;
@@ -1937,7 +1950,7 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
         // -- and its BGZF blocks inflated there (hgx_inflate.hip): the deflated file goes up instead of the inflated stream
         hook.defer_walk = true;
         hook.defer_text = !hgx_switch_has("front", "host_lines");          // SAM text: the line table as kernels too (round 5)
-        hook.defer_min_bytes = force ? 0 : (8u << 20);
+        hook.defer_min_bytes = force ? 0 : FE_MIN_DEFER_BYTES;
         if (!hgx_switch_has("front", "host_inflate")) {
             // the file's bytes start their way up before the host has looked at the container (0.4 ms of transfer for a 20 MB BAM,
             // under the hop through 5 000 block headers and the inflate of the BAM header)
@@ -1968,7 +1981,7 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
         }
         hook.records = [&](hgx_locus &L, const char *raw, size_t raw_bytes, const hgx_line *lines, size_t n, bool binary, const hgx_parse_opts &o,
                            int *declined, const hgx_bam_deferred *def) {
-            if (!def && !force && n < 20000) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }
+            if (!def && !force && (n < FE_MIN_RECORDS || raw_bytes < FE_MIN_BYTES)) { *declined = HGX_FE_DECLINE_SMALL; return (int)HGX_OK; }
             if (up_failed || raw != up_raw || raw_bytes != up_bytes || !b_text.p) { *declined = HGX_FE_DECLINE_SIZE; return (int)HGX_OK; }
             if (def) {
                 DevBuf b_dl;
@@ -2020,6 +2033,157 @@ extern "C" int hgx_parse_alignment_file_dev(hgx_dbatch **out, const hgx_locus *l
     ARGCHK(out && loc && path && opts);
     return parse_dev(out, (hipStream_t)stream, opts,
                      [&](hgx_batch **b, hgx_front_hook *hook, const hgx_parse_opts *o) { return hgx_parse_alignment_file_hook(b, loc, path, regions, o, hook); });
+}
+
+// ---- one alignment file, many loci (typing_core.py:370: `for test_Gene_names in locus_list` over ONE alignment file) ---------------
+// The reference pipes `samtools view F ref_allele | sort` once per locus (core:436-468): the file is decompressed and scanned as
+// many times as there are loci.  An hgx_alignment is the file read ONCE, its bytes resident in HBM -- the SAM text, or the BAM
+// stream inflated by k_bgzf_inflate_w -- and hgx_alignment_parse_dev is the per-locus rest: region filter, name order, record
+// fields, filters, key grouping, pileup, decode, piece table and pair protocol as kernels over those bytes (read-only: the loci of
+// a panel run side by side on streams of their own).  Whatever the kernels decline for a locus, and files that do not defer
+// (several regions per locus, a stream beyond 4 GB), go through hgx_parse_alignment_file_dev on the path: the same batch.
+struct hgx_alignment {
+    std::string path;
+    int dev = 0;
+    bool resident = false, text = false;
+    void *d_text = nullptr;
+    size_t raw_bytes = 0, body0 = 0;
+    std::vector<std::string> refs;
+    long long bytes_up = 0;
+    ~hgx_alignment() { if (d_text) hgx_pool_free(d_text); }
+};
+
+extern "C" int hgx_alignment_open(hgx_alignment **out, const char *path, int32_t n_threads, void *stream) {
+    ARGCHK(out && path);
+    *out = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    std::unique_ptr<hgx_alignment> A(new hgx_alignment());
+    A->path = path;
+    HIPCHK(hipGetDevice(&A->dev));
+    if (hgx_switch_has("front", "host")) { *out = A.release(); return HGX_OK; }          // (every locus through the host stages)
+    if (!hgx_switch_has("front", "device")) {
+        // below the device front end's size gate (FE_MIN_BYTES of stream; BGZF deflates ~1 : 4) the file is not even read here: the
+        // per-locus call on the path decides
+        struct stat sb;
+        unsigned char magic[2] = {0, 0};
+        FILE *f = fopen(path, "rb");
+        if (!f || fstat(fileno(f), &sb) != 0) { if (f) fclose(f); hgx_set_error("cannot open %s", path); return HGX_EINVAL; }
+        const bool gz = fread(magic, 1, 2, f) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        fclose(f);
+        if ((size_t)sb.st_size < (gz ? FE_MIN_BYTES / 4 : FE_MIN_BYTES)) { *out = A.release(); return HGX_OK; }
+    }
+    DevBuf b_text, b_comp;
+    bool up_failed = false;
+    const unsigned char *comp_from = nullptr;
+    size_t comp_n = 0;
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};     // (an upload may still read the reader's buffer)
+    try {
+        hgx_align_lines al;
+        hgx_big_alloc_scope pinned(hgx_front_alloc{pinned_alloc, pinned_release}, 1u << 20);
+        al.on_raw = [&](const char *raw, size_t n_bytes, size_t begin, size_t end) {
+            if (n_bytes >= (1ull << 32) - 64 || up_failed) { up_failed = true; return; }
+            if (!b_text.p && b_text.alloc(n_bytes + 64)) { up_failed = true; return; }
+            if (end > begin && hipMemcpyAsync((char *)b_text.p + begin, raw + begin, end - begin, hipMemcpyHostToDevice, st) != hipSuccess) up_failed = true;
+            A->bytes_up += (long long)(end - begin);
+        };
+        al.defer_walk = true;
+        al.defer_text = true;
+        al.defer_min_bytes = 0;
+        if (!hgx_switch_has("front", "host_inflate")) {
+            al.comp_early = [&](const unsigned char *data, size_t n) {
+                if (up_failed || b_comp.p || b_comp.alloc(n + 2048)) return;
+                if (hipMemcpyAsync(b_comp.p, data, n, hipMemcpyHostToDevice, st) != hipSuccess ||
+                    hipMemsetAsync((char *)b_comp.p + n, 0, 2048, st) != hipSuccess) { up_failed = true; return; }
+                comp_from = data; comp_n = n;
+            };
+            al.comp_sync = [&]() { if (comp_from) (void)hipStreamSynchronize(st); };
+            al.inflate_dev = [&](const unsigned char *data, size_t n, const std::vector<hgx_bgzf_block> &blocks, size_t total) -> int {
+                if (up_failed || total >= (1ull << 32) - 64 || b_text.p) return 1;
+                if (b_text.alloc(total + 64)) return 1;
+                struct DrainC { hipStream_t s; ~DrainC() { (void)hipStreamSynchronize(s); } } drain_c{st};
+                if (comp_from != data || comp_n != n) {
+                    if (b_comp.p) { (void)hipStreamSynchronize(st); hgx_pool_free(b_comp.p); b_comp.p = nullptr; }
+                    if (b_comp.alloc(n + 2048)) return 1;
+                    if (hipMemcpyAsync(b_comp.p, data, n, hipMemcpyHostToDevice, st) != hipSuccess) return 1;
+                    if (hipMemsetAsync((char *)b_comp.p + n, 0, 2048, st) != hipSuccess) return 1;
+                }
+                int bad = 0;
+                if (hgx_bgzf_inflate_dev(b_comp.as<unsigned char>(), blocks.data(), blocks.size(), b_text.as<unsigned char>(), st, &bad) != HGX_OK || bad) {
+                    (void)hipStreamSynchronize(st);
+                    hgx_pool_free(b_text.p);
+                    b_text.p = nullptr;
+                    return 1;
+                }
+                A->bytes_up += (long long)n;
+                return 0;
+            };
+        }
+        const int rc = hgx_read_alignment_lines(path, nullptr, n_threads, al, /*keep_binary=*/true);
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(st));
+        if (al.deferred.on && !up_failed && b_text.p) {
+            A->resident = true;
+            A->text = al.deferred.text;
+            A->body0 = al.deferred.body0;
+            A->refs = al.ref_names;
+            A->raw_bytes = al.raw_bytes;
+            A->d_text = b_text.p;
+            b_text.p = nullptr;
+        }
+    } catch (const std::exception &e) {
+        hgx_set_error("hgx_alignment_open: %s", e.what());
+        return HGX_ENOMEM;
+    }
+    *out = A.release();
+    return HGX_OK;
+}
+
+extern "C" int hgx_alignment_close(hgx_alignment *al) { delete al; return HGX_OK; }
+
+extern "C" int hgx_alignment_dims(const hgx_alignment *al, int32_t *resident, int32_t *is_text, size_t *stream_bytes, long long *bytes_to_device) {
+    ARGCHK(al);
+    if (resident) *resident = al->resident ? 1 : 0;
+    if (is_text) *is_text = al->text ? 1 : 0;
+    if (stream_bytes) *stream_bytes = al->raw_bytes;
+    if (bytes_to_device) *bytes_to_device = al->bytes_up;
+    return HGX_OK;
+}
+
+extern "C" int hgx_alignment_parse_dev(hgx_dbatch **out, hgx_alignment *al, const hgx_locus *loc, const char *regions, const hgx_parse_opts *opts,
+                                       void *stream) {
+    ARGCHK(out && al && loc && opts);
+    *out = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    int dev = -1;
+    HIPCHK(hipGetDevice(&dev));
+    hgx_bam_deferred def;
+    const bool host_opts = opts->codis_choose_pairs || opts->interdist_exchange || opts->pileup_exchange || opts->pileup_exchange_dev;
+    if (al->resident && dev == al->dev && !host_opts && !hgx_switch_has("front", "host") &&
+        hgx_deferred_for_regions(regions, al->text, al->body0, al->refs, def) == 0) {
+        // (size gate: the stream is in HBM already -- the kernels take any locus the host would not finish faster; the record count is
+        // only known after the region filter, so the gate is on what the filter keeps)
+        DevBuf b_dl;
+        uint32_t n_dl = 0;
+        int declined = 0;
+        hgx_dbatch *made = nullptr;
+        int rc;
+        {
+            struct DrainL { hipStream_t s; ~DrainL() { (void)hipStreamSynchronize(s); } } drain_l{st};
+            rc = def.text ? sam_lines_dev((const char *)al->d_text, al->raw_bytes, def, st, b_dl, &n_dl, &declined)
+                          : bam_lines_dev((const char *)al->d_text, {&def}, {(size_t)0}, {al->raw_bytes}, st, b_dl, &n_dl, &declined);
+            if (!rc && !declined)
+                rc = records_run(*const_cast<hgx_locus *>(loc), (const char *)al->d_text, al->raw_bytes, nullptr, n_dl, !def.text, 1, *opts, st, &made, nullptr,
+                                 &declined, b_dl.as<LineRef>());
+        }
+        if (rc) { hgx_dbatch_destroy(made); return rc; }
+        if (!declined && made) {
+            g_last_route = 2; g_last_decline = 0; g_last_device = 1; g_last_bytes = 0;
+            *out = made;
+            return HGX_OK;
+        }
+        hgx_dbatch_destroy(made);
+    }
+    return hgx_parse_alignment_file_dev(out, loc, al->path.c_str(), regions, opts, stream);
 }
 
 // MANY tasks of one locus (the samples of a panel) in ONE pass of the record route: the tasks' files are read side by side on the
@@ -2086,7 +2250,7 @@ int hgx_front_many_dev(hgx_dbatch **out, hgx_front_totals *tot, const hgx_locus 
                 n_blocks += bt[t].blocks.size();
             }
             const size_t ptotal = pbase[(size_t)n_tasks];
-            if (all_ok && ptotal < (1ull << 32) - 64 && (hgx_switch_has("front", "device") || ptotal >= (8u << 20))) {
+            if (all_ok && ptotal < (1ull << 32) - 64 && (hgx_switch_has("front", "device") || ptotal >= FE_MIN_DEFER_BYTES)) {
                 std::vector<hgx_bgzf_block> all;
                 all.reserve(n_blocks);
                 for (int t = 0; t < n_tasks; ++t)
@@ -2161,7 +2325,7 @@ int hgx_front_many_dev(hgx_dbatch **out, hgx_front_totals *tot, const hgx_locus 
     const size_t total = cursor.load(), n_lines = ms.line_base[(size_t)n_tasks];
     ms.base[(size_t)n_tasks] = total;
     if (ms.mixed) return decline(HGX_FE_DECLINE_OPTS);                   // SAM text and BAM records in one batch: per task on the host
-    if (!hgx_switch_has("front", "device") && n_lines < 20000) return decline(HGX_FE_DECLINE_SMALL);
+    if (!hgx_switch_has("front", "device") && n_lines < FE_MIN_RECORDS) return decline(HGX_FE_DECLINE_SMALL);
     if (total >= (1ull << 32) - 64 || n_lines >= (1ull << 30)) return decline(HGX_FE_DECLINE_SIZE);
     if (late.load() || hgx_switch_has("front", "late")) {
         HIPCHK(hipStreamSynchronize(st));

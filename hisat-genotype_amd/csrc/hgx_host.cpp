@@ -6,6 +6,9 @@
 #include <string>
 #include <cstring>
 #include <map>
+#include <numeric>
+#include <string_view>
+#include <unordered_map>
 
 #include <sys/mman.h>
 
@@ -762,3 +765,97 @@ int hgx_default_threads() {
     }();
     return cached;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// The dict side of the single_abundance seam (typing_common.py:1282-1305): class keys '-'.join(sorted(names)) -> name table in
+// first-appearance order + one bit row per key.  One pass over the text; the names are views into the caller's buffer until the
+// set is built, then copied.
+// ------------------------------------------------------------------------------------------------
+struct hgx_keyset {
+    std::vector<std::string> names;
+    std::vector<int32_t> key_off{0}, key_name;       // per key: indices into names
+    int32_t n_keys = 0, a_pad = 0, keys_sorted = 1;
+    size_t pool_bytes = 0;
+};
+
+extern "C" int hgx_keyset_create(hgx_keyset **out, const char *keys, size_t n_bytes, int32_t n_keys) {
+    HARGCHK(out && n_keys >= 0 && (keys || n_bytes == 0));
+    *out = nullptr;
+    hgx_keyset *ks = new hgx_keyset();
+    ks->n_keys = n_keys;
+    std::unordered_map<std::string_view, int32_t> index;
+    index.reserve(1 << 14);
+    std::vector<std::string_view> order;
+    size_t at = 0;
+    for (int32_t k = 0; k < n_keys; ++k) {
+        if (at > n_bytes) { delete ks; hgx_set_error("hgx_keyset_create: %d keys announced, the text holds %d", n_keys, k); return HGX_EINVAL; }
+        const char *line = keys + at;
+        const char *nl = (const char *)memchr(line, '\n', n_bytes - at);
+        const size_t len = nl ? (size_t)(nl - line) : n_bytes - at;
+        std::string_view prev;
+        bool first = true;
+        size_t s = 0;
+        while (true) {                                             // "".split("-") is [""]: every key has at least one name
+            const char *dash = (const char *)memchr(line + s, '-', len - s);
+            const size_t e = dash ? (size_t)(dash - line) : len;
+            std::string_view nm(line + s, e - s);
+            auto it = index.find(nm);
+            int32_t id;
+            if (it == index.end()) {
+                id = (int32_t)order.size();
+                index.emplace(nm, id);
+                order.push_back(nm);
+            } else {
+                id = it->second;
+            }
+            ks->key_name.push_back(id);
+            if (!first && nm < prev) ks->keys_sorted = 0;            // (bytewise = code-point order for UTF-8: Python's str order)
+            prev = nm;
+            first = false;
+            if (!dash) break;
+            s = e + 1;
+        }
+        ks->key_off.push_back((int32_t)ks->key_name.size());
+        at += len + 1;
+    }
+    ks->names.reserve(order.size());
+    for (auto v : order) { ks->names.emplace_back(v); ks->pool_bytes += v.size() + 1; }
+    ks->a_pad = hgx_a_pad((int32_t)std::max<size_t>(order.size(), 1));
+    *out = ks;
+    return HGX_OK;
+}
+
+extern "C" int hgx_keyset_dims(const hgx_keyset *ks, int32_t *n_names, int32_t *a_pad, size_t *name_pool_bytes, int32_t *keys_sorted) {
+    HARGCHK(ks);
+    if (n_names) *n_names = (int32_t)ks->names.size();
+    if (a_pad) *a_pad = ks->a_pad;
+    if (name_pool_bytes) *name_pool_bytes = ks->pool_bytes;
+    if (keys_sorted) *keys_sorted = ks->keys_sorted;
+    return HGX_OK;
+}
+
+extern "C" int hgx_keyset_fill(const hgx_keyset *ks, uint64_t *bits, char *name_pool, int32_t *name_rank) {
+    HARGCHK(ks);
+    const int w64 = ks->a_pad / 64;
+    if (bits) {
+        memset(bits, 0, (size_t)ks->n_keys * w64 * 8);
+        for (int32_t k = 0; k < ks->n_keys; ++k) {
+            uint64_t *row = bits + (size_t)k * w64;
+            for (int32_t q = ks->key_off[k]; q < ks->key_off[k + 1]; ++q) row[ks->key_name[q] >> 6] |= 1ull << (ks->key_name[q] & 63);
+        }
+    }
+    if (name_pool) {
+        char *p = name_pool;
+        for (const std::string &n : ks->names) { memcpy(p, n.data(), n.size()); p[n.size()] = 0; p += n.size() + 1; }
+    }
+    if (name_rank) {
+        std::vector<int32_t> by(ks->names.size());
+        std::iota(by.begin(), by.end(), 0);
+        std::sort(by.begin(), by.end(), [&](int32_t a, int32_t b) { return ks->names[a] < ks->names[b]; });
+        for (size_t r = 0; r < by.size(); ++r) name_rank[by[r]] = (int32_t)r;
+    }
+    return HGX_OK;
+}
+
+extern "C" int hgx_keyset_destroy(hgx_keyset *ks) { delete ks; return HGX_OK; }

@@ -221,6 +221,7 @@ struct hgx_align_lines {
     ~hgx_align_lines() { hgx_host_free(raw); }
 };
 int hgx_read_alignment_lines(const char *path, const char *regions, int n_threads, hgx_align_lines &out, bool keep_binary = false);
+int hgx_deferred_for_regions(const char *regions, bool text, size_t body0, const std::vector<std::string> &refs, hgx_bam_deferred &d);
 
 // find-or-insert a piece given its word range and (MP,P) mask words
 uint32_t hgx_intern_masks(hgx_batch &b, uint16_t lo, uint16_t nw, const uint32_t *m);
@@ -306,6 +307,7 @@ struct hgx_pileup_share {
 struct hgx_front_hook {
     hgx_front_alloc mem{nullptr, nullptr};
     std::function<int(hgx_locus &, const hgx_front_input &, const hgx_parse_opts &, int *declined)> run;
+    size_t min_records = 0;            // `run` would decline fewer records as too small: the host stages do not even build its input then
     int declined = 0;
     // The RECORD route, tried first when set: the device takes the records themselves (fields, filters, key grouping as kernels
     // over the SAM text / the inflated BAM stream it was sent through `on_raw`), the host stages do not run at all.  `lines`: the

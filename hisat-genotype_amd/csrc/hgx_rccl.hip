@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -61,6 +62,9 @@ int rccl_load() {
         }                                                                                                               \
     } while (0)
 
+std::atomic<uint64_t> g_stat_calls{0}, g_stat_send{0}, g_stat_recv{0};
+inline void rccl_count(uint64_t sent, uint64_t received) { g_stat_calls += 1; g_stat_send += sent; g_stat_recv += received; }
+
 }   // namespace
 
 extern "C" int hgx_index_device_block(const hgx_index *ix, void **dev_block, size_t *bytes);
@@ -72,6 +76,7 @@ extern "C" int hgx_index_broadcast(hgx_index *ix, int32_t root, void *comm, void
     size_t bytes = 0;
     { int rc_ = hgx_index_device_block(ix, &block, &bytes); if (rc_) return rc_; }
     RCCLCHK(g_rccl.Broadcast(block, block, bytes, NCCL_UINT8, root, (ncclComm_t)comm, (hipStream_t)stream));
+    rccl_count(bytes, bytes);
     return HGX_OK;
 }
 
@@ -79,16 +84,72 @@ extern "C" int hgx_allreduce_sum_u32(uint32_t *buf, size_t n, void *comm, void *
     ARGCHK(buf && comm);
     { int rc_ = rccl_load(); if (rc_) return rc_; }
     RCCLCHK(g_rccl.AllReduce(buf, buf, n, NCCL_UINT32, NCCL_SUM, (ncclComm_t)comm, (hipStream_t)stream));
+    rccl_count(n * 4, n * 4);
     return HGX_OK;
 }
 extern "C" int hgx_allreduce_sum_i64(int64_t *buf, size_t n, void *comm, void *stream) {
     ARGCHK(buf && comm);
     { int rc_ = rccl_load(); if (rc_) return rc_; }
     RCCLCHK(g_rccl.AllReduce(buf, buf, n, NCCL_INT64, NCCL_SUM, (ncclComm_t)comm, (hipStream_t)stream));
+    rccl_count(n * 8, n * 8);
     return HGX_OK;
 }
 
-// rows [bits | count] of every rank, padded to the largest table, gathered; then unpacked in rank order and merged
+// ---- the class-table exchange in three parts: pack, all-gather, unpack + merge ------------------------------------------------
+// A rank's table travels as rows [bits (w64 words) | count], padded with zero rows to `cap` = the largest table of the group;
+// the receive buffer holds the ranks' blocks in rank order.  The two halves around the collective are entry points of their
+// own (a caller with another transport -- MPI, files -- can use them; tests/test_gpu_typing.py assembles receive buffers of
+// world 2-5 from them to exercise the rank-order unpack without a second GPU).
+extern "C" int hgx_classes_pack_rows(const hgx_classes *mine, int32_t a_pad, int32_t cap, void *dev_send, void *stream) {
+    ARGCHK(dev_send && cap >= 1 && a_pad > 0 && a_pad % 512 == 0 && (!mine || (mine->a_pad == a_pad && mine->n_classes <= cap)));
+    hipStream_t st = (hipStream_t)stream;
+    const int w64 = a_pad / 64;
+    const size_t pitch = (size_t)(w64 + 1) * 8;
+    const int32_t my_c = mine ? mine->n_classes : 0;
+    if (mine) hgx_classes_order_after(mine, st);
+    HIPCHK(hipMemsetAsync(dev_send, 0, (size_t)cap * pitch, st));
+    if (my_c > 0) {
+        HIPCHK(hipMemcpy2DAsync(dev_send, pitch, mine->d_bits, (size_t)w64 * 8, (size_t)w64 * 8, (size_t)my_c, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpy2DAsync((char *)dev_send + (size_t)w64 * 8, pitch, mine->d_count, 8, 8, (size_t)my_c, hipMemcpyDeviceToDevice, st));
+    }
+    return HGX_OK;
+}
+
+// `dev_recv`: world blocks of cap rows; sizes[r] = rows of rank r that are real.  Rows are concatenated in rank order -- which
+// is stream order of the ranks' pairs, so first-seen order survives -- and equal rows merged with summed counts.
+extern "C" int hgx_classes_merge_gathered(hgx_classes **out, const void *dev_recv, const int32_t *sizes, int32_t world, int32_t cap,
+                                          int32_t a_pad, void *stream) {
+    ARGCHK(out && dev_recv && sizes && world >= 1 && cap >= 1 && a_pad > 0 && a_pad % 512 == 0);
+    *out = nullptr;
+    hipStream_t st = (hipStream_t)stream;
+    const int w64 = a_pad / 64;
+    const size_t pitch = (size_t)(w64 + 1) * 8;
+    int64_t total = 0;
+    for (int r = 0; r < world; ++r) {
+        ARGCHK(sizes[r] >= 0 && sizes[r] <= cap);
+        total += sizes[r];
+    }
+    DevBuf b_rows, b_w;
+    // declared after the buffers = destroyed before them: an error return behind a queued copy drains the stream before the
+    // buffers go back to the pool
+    struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
+    ALLOC(b_rows, (size_t)std::max<int64_t>(total, 1) * w64 * 8);
+    ALLOC(b_w, (size_t)std::max<int64_t>(total, 1) * 8);
+    int64_t at = 0;
+    for (int r = 0; r < world; ++r) {
+        if (sizes[r] <= 0) continue;
+        const char *src = (const char *)dev_recv + (size_t)r * cap * pitch;
+        HIPCHK(hipMemcpy2DAsync((char *)b_rows.p + (size_t)at * w64 * 8, (size_t)w64 * 8, src, pitch, (size_t)w64 * 8, (size_t)sizes[r],
+                                hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpy2DAsync((char *)b_w.p + (size_t)at * 8, 8, src + (size_t)w64 * 8, pitch, 8, (size_t)sizes[r], hipMemcpyDeviceToDevice, st));
+        at += sizes[r];
+    }
+    int rc = hgx_dedup_classes(out, b_rows.as<uint64_t>(), nullptr, b_w.as<int64_t>(), total, a_pad, nullptr, stream);
+    if (rc) return rc;
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }          // (the row / weight buffers are read by kernels the dedup queued)
+    return HGX_OK;
+}
+
 extern "C" int hgx_classes_allgather(hgx_classes **out, const hgx_classes *mine, int32_t a_pad, void *comm, void *stream) {
     ARGCHK(out && comm && a_pad > 0 && a_pad % 512 == 0 && (!mine || mine->a_pad == a_pad));
     *out = nullptr;
@@ -99,7 +160,6 @@ extern "C" int hgx_classes_allgather(hgx_classes **out, const hgx_classes *mine,
     RCCLCHK(g_rccl.CommUserRank((ncclComm_t)comm, &rank));
     const int w64 = a_pad / 64;
     const int32_t my_c = mine ? mine->n_classes : 0;
-    if (mine) hgx_classes_order_after(mine, st);
     DevBuf b_sizes;
     ALLOC(b_sizes, (size_t)(world + 1) * 4);
     int32_t *d_sizes = b_sizes.as<int32_t>();
@@ -108,35 +168,26 @@ extern "C" int hgx_classes_allgather(hgx_classes **out, const hgx_classes *mine,
     std::vector<int32_t> sizes((size_t)world);
     { int rc_ = hgx_d2h(sizes.data(), d_sizes, (size_t)world * 4, st); if (rc_) return rc_; }
     { int rc_ = hgx_sync(st); if (rc_) return rc_; }
-    int64_t total = 0;
     int32_t cap = 1;
-    for (int32_t c : sizes) { total += c; cap = std::max(cap, c); }
+    for (int32_t c : sizes) cap = std::max(cap, c);
     const size_t pitch = (size_t)(w64 + 1) * 8;
-    DevBuf b_send, b_recv, b_rows, b_w;
-    // declared after the buffers = destroyed before them: an error return behind a queued collective / copy drains the stream
-    // before the buffers go back to the pool
+    DevBuf b_send, b_recv;
     struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
     ALLOC(b_send, (size_t)cap * pitch);
     ALLOC(b_recv, (size_t)world * cap * pitch);
-    HIPCHK(hipMemsetAsync(b_send.p, 0, (size_t)cap * pitch, st));
-    if (my_c > 0) {
-        HIPCHK(hipMemcpy2DAsync(b_send.p, pitch, mine->d_bits, (size_t)w64 * 8, (size_t)w64 * 8, (size_t)my_c, hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpy2DAsync((char *)b_send.p + (size_t)w64 * 8, pitch, mine->d_count, 8, 8, (size_t)my_c, hipMemcpyDeviceToDevice, st));
-    }
+    { int rc_ = hgx_classes_pack_rows(mine, a_pad, cap, b_send.p, stream); if (rc_) return rc_; }
     RCCLCHK(g_rccl.AllGather(b_send.p, b_recv.p, (size_t)cap * (w64 + 1), NCCL_INT64, (ncclComm_t)comm, st));
-    ALLOC(b_rows, (size_t)std::max<int64_t>(total, 1) * w64 * 8);
-    ALLOC(b_w, (size_t)std::max<int64_t>(total, 1) * 8);
-    int64_t at = 0;
-    for (int r = 0; r < world; ++r) {
-        if (sizes[r] <= 0) continue;
-        const char *src = (const char *)b_recv.p + (size_t)r * cap * pitch;
-        HIPCHK(hipMemcpy2DAsync((char *)b_rows.p + (size_t)at * w64 * 8, (size_t)w64 * 8, src, pitch, (size_t)w64 * 8, (size_t)sizes[r],
-                                hipMemcpyDeviceToDevice, st));
-        HIPCHK(hipMemcpy2DAsync((char *)b_w.p + (size_t)at * 8, 8, src + (size_t)w64 * 8, pitch, 8, (size_t)sizes[r], hipMemcpyDeviceToDevice, st));
-        at += sizes[r];
-    }
-    int rc = hgx_dedup_classes(out, b_rows.as<uint64_t>(), nullptr, b_w.as<int64_t>(), total, a_pad, nullptr, stream);
-    if (rc) return rc;
-    { int rc_ = hgx_sync(st); if (rc_) return rc_; }          // (the row / weight buffers are read by kernels the dedup queued)
+    g_stat_calls += 2;
+    g_stat_send += (uint64_t)cap * pitch + 4;
+    g_stat_recv += (uint64_t)world * ((uint64_t)cap * pitch + 4);
+    return hgx_classes_merge_gathered(out, b_recv.p, sizes.data(), world, cap, a_pad, stream);
+}
+
+// bytes this process handed to / received from the collectives above since the last reset (bench.py: exchange bytes per step)
+extern "C" int hgx_rccl_stats(uint64_t *n_collectives, uint64_t *bytes_sent, uint64_t *bytes_received, int32_t reset) {
+    if (n_collectives) *n_collectives = g_stat_calls.load();
+    if (bytes_sent) *bytes_sent = g_stat_send.load();
+    if (bytes_received) *bytes_received = g_stat_recv.load();
+    if (reset) { g_stat_calls = 0; g_stat_send = 0; g_stat_recv = 0; }
     return HGX_OK;
 }

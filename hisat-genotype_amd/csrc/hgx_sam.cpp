@@ -2048,6 +2048,7 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
             // keys, piece table, pair protocol -- as kernels over the keys' text.  It may decline; the host stages below then run.
             hook->declined = 0;
             if (opts->codis_choose_pairs || opts->interdist_exchange) hook->declined = HGX_FE_DECLINE_OPTS;
+            else if (n < hook->min_records) hook->declined = HGX_FE_DECLINE_SMALL;
             else {
                 hgx_front_input in;
                 in.mem = hook->mem;

@@ -154,6 +154,12 @@ class TorchComm:
         self.dist, self.group = dist, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.on_gpu = dist.get_backend(group) == "nccl"
+        self.stats = [0, 0, 0]             # collectives, bytes handed to them, bytes received (bench.py: exchange bytes per step)
+
+    def _count(self, sent, received):
+        self.stats[0] += 1
+        self.stats[1] += int(sent)
+        self.stats[2] += int(received)
 
     def _dev(self):
         import torch
@@ -164,6 +170,7 @@ class TorchComm:
         import torch
         t = torch.from_numpy(arr.astype(np.int64)).to(self._dev())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._count(t.numel() * 8, t.numel() * 8)
         arr[...] = t.cpu().numpy().astype(arr.dtype)
         return arr
 
@@ -174,6 +181,7 @@ class TorchComm:
         import torch
         t = torch.from_numpy(np.ascontiguousarray(arr, np.uint32).view(np.int32).copy()).to(self._dev())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._count(t.numel() * 4, t.numel() * 4)
         arr[...] = t.cpu().numpy().view(np.uint32).reshape(arr.shape)
         return arr
 
@@ -191,6 +199,7 @@ class TorchComm:
         capi.sync(stream)                                   # the pileup kernels wrote the buffer on the library's stream
         t = torch.as_tensor(_DeviceBlock(dptr, n), device=self._dev())
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._count(4 * n, 4 * n)
         flag = int(t[-1].item())                            # (synchronises torch's stream: the sum is complete)
         return flag & 0xFFFFFFFF
 
@@ -209,6 +218,8 @@ class TorchComm:
         mine = torch.from_numpy(pad).to(dev)
         parts = [torch.zeros_like(mine) for _ in range(self.world)]
         self.dist.all_gather(parts, mine, group=self.group)
+        self.stats[0] += 1                                            # (+ the one-element size gather above)
+        self._count(pad.nbytes + 8, self.world * (pad.nbytes + 8))
         out = []
         for k, p in zip(sizes, parts):
             a = p.cpu().numpy()

@@ -36,12 +36,8 @@ def genotyping_locus(base_fname, locus_list, genotype_genome, ix_dir, only_locus
     assert isinstance(base_fname, str) and "," not in base_fname
     assert os.path.exists(ix_dir)
     simulation = (read_fname == [] and alignment_fname == "")
-    if genotype_genome:
-        full_gg_path = ix_dir + "/" + genotype_genome
-        ix = indexio.load_genome_index(ix_dir, genotype_genome, base_fname)
-    else:
-        full_gg_path = ix_dir + "/" + base_fname
-        ix = indexio.load_index(ix_dir, base_fname)
+    full_gg_path = ix_dir + "/" + (genotype_genome if genotype_genome else base_fname)
+    ix = indexio.load_index_memo(ix_dir, base_fname, genotype_genome)      # (read once per process and index-file state)
     refGene_loci, Gene_names, partial_alleles = ix["refGene_loci"], ix["Gene_names"], ix["partial_alleles"]
     if len(locus_list) == 0:
         locus_list = list(refGene_loci.keys())

@@ -74,6 +74,51 @@ class DeviceBatch:
             pass
 
 
+class Alignment:
+    """An alignment file read ONCE, its bytes resident in HBM (hgx_alignment_open): the SAM text, or the BAM stream inflated on the
+    device.  parse_dev(locus, regions) is the per-locus rest of the device front end over those bytes -- the loci of a panel may
+    call it side by side from threads with streams of their own.  `resident` False (a file below the front end's size gate, or one
+    the reader could not leave to the device): every parse_dev goes through hgx_parse_alignment_file_dev on the path instead."""
+
+    def __init__(self, path, n_threads=0, stream=None):
+        self.path = path
+        self.h = C.c_void_p()
+        capi.check(capi.lib().hgx_alignment_open(C.byref(self.h), path.encode(), C.c_int32(n_threads), stream))
+        r, t, nb, up = C.c_int32(), C.c_int32(), C.c_size_t(), C.c_longlong()
+        capi.check(capi.lib().hgx_alignment_dims(self.h, C.byref(r), C.byref(t), C.byref(nb), C.byref(up)))
+        self.resident, self.is_text, self.stream_bytes, self.bytes_to_device = bool(r.value), bool(t.value), nb.value, up.value
+
+    def parse_dev(self, locus, regions=None, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False, base_locus=0,
+                  n_threads=0, stream=None):
+        if regions is not None and not isinstance(regions, (str, bytes)):
+            regions = "\n".join(regions)
+        if isinstance(regions, str):
+            regions = regions.encode()
+        o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus, 0,
+                           int(locus.base_fname == "codis" and locus.gene == "D18S51"), int(n_threads))
+        h = C.c_void_p()
+        capi.check(capi.lib().hgx_alignment_parse_dev(C.byref(h), self.h, locus.h, regions or None, C.byref(o), stream))
+        return DeviceBatch.from_handle(h)
+
+    def close(self):
+        if self.h:
+            capi.lib().hgx_alignment_close(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def front_last():
     """(route, decline code) of the calling thread's last hgx_parse_*_dev / hgx_type_file call: route 2 = the device took the
     records themselves (fields, filters, key grouping as kernels), 1 = the host made the key table and the device the rest,

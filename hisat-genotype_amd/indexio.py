@@ -286,6 +286,32 @@ def load_genome_index(ix_dir, genotype_genome, base_fname):
                 dbversion=dbversion)
 
 
+_MEMO = {}
+
+
+def _stamp(ix_dir, stem):
+    out = []
+    for f in sorted(os.listdir(ix_dir)):
+        if (f.startswith(stem + ".") or f.startswith(stem + "_")) and not f.endswith((".hgx.npz", ".report", ".bam", ".sam")):
+            st = os.stat(os.path.join(ix_dir, f))
+            out.append((f, st.st_mtime_ns, st.st_size))
+    return tuple(out)
+
+
+def load_index_memo(ix_dir, base_fname, genotype_genome=""):
+    """load_index / load_genome_index, remembered per process while the index files keep their names, sizes and modification
+    times: driver.genotyping_locus is called once per sample on the same index (/root/reference/hisatgenotype:616-665), and the
+    SAME dict objects coming back let typing() find its packed loci by identity (locus.LocusCache)."""
+    key = (os.path.abspath(ix_dir), base_fname, genotype_genome)
+    stamp = _stamp(ix_dir, genotype_genome or base_fname)
+    hit = _MEMO.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    ix = load_genome_index(ix_dir, genotype_genome, base_fname) if genotype_genome else load_index(ix_dir, base_fname)
+    _MEMO[key] = (stamp, ix)
+    return ix
+
+
 def packed_locus(ix_dir, base_fname, gene, index=None, use_cache=True):
     """PackedLocus of `gene`, through the packed binary cache `<ix_dir>/<base_fname>.<gene>.hgx.npz`: the
     cache is used when it is newer than every text file of the index, rebuilt (and rewritten, best effort) otherwise."""

@@ -197,6 +197,15 @@ class PackedLocus:
         return self
 
     @classmethod
+    def cached_from_reference_dicts(cls, gene, base_fname, refGenes, Genes, Gene_names, Gene_lengths, refGene_loci, Vars,
+                                    Var_list, Links):
+        """from_reference_dicts through the in-process locus cache (LocusCache below): typing() is called once per sample with
+        the SAME index dicts (/root/reference/hisatgenotype:613-665 forks them into every worker), and packing a 7 000-allele
+        locus from them costs 40-90 ms of Python -- many times the GPU's share of a sample.  A cached locus keeps its device
+        index and pattern tables; it must not be close()d by the caller."""
+        return LOCUS_CACHE.get(gene, base_fname, refGenes, Genes, Gene_names, Gene_lengths, refGene_loci, Vars, Var_list, Links)
+
+    @classmethod
     def from_synth(cls, locus):
         d = locus.reference_dicts()
         return cls.from_reference_dicts(locus.gene, locus.base_fname, d["refGenes"], d["Genes"], d["Gene_names"],
@@ -403,3 +412,103 @@ class PackedLocus:
             self.close()
         except Exception:
             pass
+
+
+class LocusCache:
+    """Packed loci (host tables + device index) of this process, kept between typing() calls.
+
+    Two keys.  The IDENTITY key is the tuple of id()s of the per-gene dict objects a call passes (the entry holds references
+    to them, so an id cannot be recycled while the entry lives) together with a cheap fingerprint -- the container sizes and
+    the total number of (variant, allele) links -- that catches an index edited in place between calls.  A miss there falls
+    back to the CONTENT key: a digest of everything the PackedLocus constructor reads (names in order, backbone, variants in
+    Var_list order, the links of those variants in Links' key order, lengths, exons), so that dicts re-read from the same index
+    files (driver.genotyping_locus does that once per call) still meet their packed form.  Least recently used entries are
+    dropped -- and closed -- beyond `limit`."""
+
+    per_device = True
+
+    def __init__(self, limit=16):
+        import threading
+        self.limit = limit
+        self._lock = threading.Lock()
+        self._by_id, self._by_content = {}, {}       # key -> entry; entry = [locus, id key, content key, kept references, tick]
+        self._tick = 0
+        self.hits_identity = self.hits_content = self.misses = 0
+
+    @staticmethod
+    def _parts(gene, refGenes, Genes, Gene_names, Gene_lengths, refGene_loci, Vars, Var_list):
+        return (Vars.get(gene, None), Var_list.get(gene, None), Genes[gene], Gene_names[gene], Gene_lengths[gene], refGene_loci[gene])
+
+    @staticmethod
+    def _fingerprint(parts, Links):
+        v, vl, g, gn, gl, rl = parts
+        return (len(v) if v is not None else -1, len(vl) if vl is not None else -1, len(g), len(gn), len(gl), len(Links),
+                sum(map(len, Links.values())))
+
+    @staticmethod
+    def _digest(gene, base_fname, ref_allele, parts, Links):
+        import hashlib
+        v, vl, g, gn, gl, rl = parts
+        v, vl = v or {}, vl or []
+        h = hashlib.blake2b(digest_size=20)
+        sep = "\x1f"
+        h.update(("%s\0%s\0%s\0%r\0" % (gene, base_fname, ref_allele, rl[-2])).encode())
+        h.update(g[ref_allele].encode())
+        h.update(sep.join(gn).encode())
+        h.update(sep.join(sorted(g.keys())).encode())
+        h.update(repr([gl[n] for n in gn if n in gl]).encode())
+        h.update(repr(vl).encode())
+        h.update(repr([v[vid] for _, vid in vl]).encode())
+        mine = set(vid for _, vid in vl)
+        for vid, alleles in Links.items():           # in Links' own key order (link_order of the packed form)
+            if vid in mine:
+                h.update(("\x1e" + vid + sep).encode())
+                h.update(sep.join(alleles).encode())
+        return h.digest()
+
+    def get(self, gene, base_fname, refGenes, Genes, Gene_names, Gene_lengths, refGene_loci, Vars, Var_list, Links):
+        parts = self._parts(gene, refGenes, Genes, Gene_names, Gene_lengths, refGene_loci, Vars, Var_list)
+        ref_allele = refGenes[gene]
+        dev = capi.current_device() if LocusCache.per_device else -1        # (the device index of a cached locus lives on ONE GPU)
+        idk = (gene, base_fname, ref_allele, dev, id(Links)) + tuple(id(x) for x in parts) + self._fingerprint(parts, Links)
+        with self._lock:
+            self._tick += 1
+            e = self._by_id.get(idk)
+            if e is not None:
+                e[4] = self._tick
+                self.hits_identity += 1
+                return e[0]
+        ck = (dev, self._digest(gene, base_fname, ref_allele, parts, Links))
+        with self._lock:
+            e = self._by_content.get(ck)
+            if e is not None:                        # the same index in other dict objects: re-key the entry to them
+                self._by_id.pop(e[1], None)
+                e[1], e[3], e[4] = idk, (parts, Links), self._tick
+                self._by_id[idk] = e
+                self.hits_content += 1
+                return e[0]
+        pl = PackedLocus.from_reference_dicts(gene, base_fname, refGenes, Genes, Gene_names, Gene_lengths, refGene_loci, Vars,
+                                              Var_list, Links)
+        pl.cached = True
+        with self._lock:
+            self.misses += 1
+            e = [pl, idk, ck, (parts, Links), self._tick]
+            self._by_id[idk] = e
+            self._by_content[ck] = e
+            while len(self._by_content) > max(self.limit, 1):
+                old = min(self._by_content.values(), key=lambda x: x[4])
+                self._by_id.pop(old[1], None)
+                self._by_content.pop(old[2], None)
+                old[0].cached = False                # (a caller may still hold it: it is closed when the last reference goes)
+        return pl
+
+    def clear(self):
+        with self._lock:
+            for e in self._by_content.values():
+                e[0].cached = False
+                e[0].close()
+            self._by_id.clear()
+            self._by_content.clear()
+
+
+LOCUS_CACHE = LocusCache()

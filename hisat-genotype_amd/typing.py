@@ -24,6 +24,17 @@ from .locus import PackedLocus
 
 
 TIE_REL_TOL = 1e-11
+class _TypingOptions:
+    """What typing() / genotyping_locus() have no parameter for (the reference's signatures are kept as they are).
+    em_fast: the EM arithmetic of the per-locus body -- False (default): the reference's own order of floating-point operations
+    wherever the one-workgroup kernel takes the problem (abundances equal to the reference's doubles; a 1 700-class EM #1 takes
+    ~10 ms that way), True: table lookups (within 1e-8 of the reference, bar 1e-5; ~2 ms), None / -1: see typing._em_mode."""
+    em_fast = False
+    loci_side_by_side = True       # several loci of one typing() call: a host thread and stream per locus over ONE read of the file
+
+
+typing_options = _TypingOptions()
+last_profile = []        # typing(): one dict per locus of the last call -- where its wall time went (bench.py's drop-in legs print it)
 
 
 def _stable_desc(lst, exact=False):
@@ -45,34 +56,42 @@ def _stable_desc(lst, exact=False):
     return out
 
 
+def _keys_to_classes(keys):
+    """Class keys ('-'.join(sorted(names))) -> (names in first-appearance order, bit rows [C][a_pad/64], a_pad, name rank or None):
+    one pass over the joined text inside libhgx (hgx_keyset_*), not a Python loop per allele name -- a 5 000-class dict of a
+    7 000-allele locus spells out millions of names."""
+    L = capi.lib()
+    text = "\n".join(keys).encode()
+    if text.count(b"\n") != len(keys) - 1:
+        raise ValueError("a compatibility-class key contains a newline")
+    h = C.c_void_p()
+    capi.check(L.hgx_keyset_create(C.byref(h), text, C.c_size_t(len(text)), C.c_int32(len(keys))))
+    try:
+        n, ap, nb, srt = C.c_int32(), C.c_int32(), C.c_size_t(), C.c_int32()
+        capi.check(L.hgx_keyset_dims(h, C.byref(n), C.byref(ap), C.byref(nb), C.byref(srt)))
+        bits = np.empty((len(keys), ap.value // 64), np.uint64)
+        pool = C.create_string_buffer(max(nb.value, 1))
+        rank = np.zeros(max(n.value, 1), np.int32)
+        capi.check(L.hgx_keyset_fill(h, capi.ptr(bits), pool, capi.ptr(rank)))
+        names = pool.raw[:nb.value].decode().split("\0")[:-1] if nb.value else []
+        return names, bits, ap.value, (rank[:n.value] if srt.value else None)
+    finally:
+        L.hgx_keyset_destroy(h)
+
+
 def single_abundance(Gene_cmpt, remove_low_abundance_allele=False, Gene_length={}):
     """EM abundance of alleles from compatibility classes ``{'a-b-c': count}`` (drop-in, GPU)."""
-    names, idx = [], {}
-    split = []
-    for key in Gene_cmpt.keys():
-        al = key.split("-")
-        for a in al:
-            if a not in idx:
-                idx[a] = len(names)
-                names.append(a)
-        split.append(al)
-    A = len(names)
-    if A == 0:
+    if len(Gene_cmpt) == 0:
         return []
-    ap = capi.a_pad(A)
-    bits = np.zeros((len(split), ap // 64), np.uint64)
-    for c, al in enumerate(split):
-        ii = np.fromiter((idx[a] for a in al), np.int64, len(al))
-        np.bitwise_or.at(bits[c], ii >> 6, np.uint64(1) << (ii & 63).astype(np.uint64))
-    counts = np.fromiter(Gene_cmpt.values(), np.int64, len(split))
+    names, bits, ap, rank = _keys_to_classes(list(Gene_cmpt.keys()))
+    A = len(names)
+    counts = np.fromiter(Gene_cmpt.values(), np.int64, len(Gene_cmpt))
     lengths = None
     if len(Gene_length) > 0:
         lengths = np.array([Gene_length[a] for a in names], np.int32)
     cl = engine.Classes.from_host(bits, counts, ap)
     try:
-        if all(al == sorted(al) for al in split):      # keys as the reference builds them: '-'.join(sorted(names))
-            rank = np.zeros(A, np.int32)
-            rank[np.array(sorted(range(A), key=lambda i: names[i]), np.int64)] = np.arange(A, dtype=np.int32)
+        if rank is not None:                               # keys as the reference builds them: '-'.join(sorted(names))
             cl.set_allele_rank(rank)
         prob, _ = cl.em(A, bool(remove_low_abundance_allele), lengths)
         exact = bool(capi.lib().hgx_em_last_exact())
@@ -122,20 +141,25 @@ def _em_mode(em_fast):
 
 def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discordant=False,
                remove_low_abundance_alleles=True, simulation=False, base_locus=0, keep_classes=False, stream=None,
-               alignment_file=None, regions=None, gate=None, per_pair_exon=False, em_fast=False):
+               alignment_file=None, regions=None, gate=None, per_pair_exon=False, em_fast=False, profile=None, alignment=None):
     """Per-locus typing: the reference's loop body with the O(alleles) work on the GPU.  Input: name-grouped SAM text
     (`sam_text`), or `alignment_file` (SAM / BAM; `regions` = samtools region strings, see read_alignment_text) read inside
     libhgx.  `gate` (engine.Gate): shared by the samples in flight on one GPU, see _type_batch.  `em_fast`: see _em_mode
     (False = the library's default for one task; -1 = the reference's order of floating-point operations at every size)."""
     res = LocusResult()
+    t0 = time.perf_counter()
     # the front end on the device (hgx_parse_*_dev: record fields, filters, key grouping, pileup, decode, piece table and pair protocol
     # as kernels; small or unusual inputs are finished by the host stages inside the same call): the batch is born in HBM
-    if alignment_file is not None:
+    if alignment is not None:                                   # engine.Alignment: the file was read once, its bytes are in HBM
+        dbatch = alignment.parse_dev(pl, regions, num_editdist=num_editdist, error_correction=error_correction,
+                                     allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus, stream=stream)
+    elif alignment_file is not None:
         dbatch = pl.parse_alignment_file_dev(alignment_file, regions, num_editdist=num_editdist, error_correction=error_correction,
                                              allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus, stream=stream)
     else:
         dbatch = pl.parse_sam_dev(sam_text, num_editdist=num_editdist, error_correction=error_correction,
                                   allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus, stream=stream)
+    t1 = time.perf_counter()
     try:
         res.num_reads, res.num_pairs = dbatch.n_reads, dbatch.n_pairs
         res.n_pieces, res.n_refs = dbatch.n_pieces, dbatch.n_refs
@@ -145,6 +169,10 @@ def type_locus(pl, sam_text, num_editdist=2, error_correction=True, allow_discor
                            em_fast=em_fast)
     finally:
         dbatch.close()
+        if profile is not None:
+            profile["file_read_and_front_end_ms"] = (t1 - t0) * 1e3
+            profile["front_end_route"] = list(engine.front_last())
+            profile["gpu_typing_and_result_ms"] = (time.perf_counter() - t1) * 1e3
 
 
 class TypeOpts(C.Structure):
@@ -335,7 +363,13 @@ def type_many_loci(pls, manies, remove_low=True, stream=None, light=False, em_fa
 def report_lines(res, simulation=False, true_alleles=(), output_allele_counts=False, best_alleles=False):
     """Report body (core:1593, 1650-1677, 2076-2121)."""
     out = ["\t\t\t%d reads and %d pairs are aligned" % (res.num_reads, res.num_pairs)]
-    for i, (a, c) in enumerate(res.counts_sorted):
+    if not simulation and res.counts_order is not None:
+        # real data: the first ten counted alleles, or all of them (--output-allele-counts: thousands of lines) -- one formatting pass
+        order = res.counts_order if output_allele_counts else res.counts_order[:10]
+        names, counts = res._names, res.counts
+        out.extend(map("\t\t\t\t%d %s (count: %d)".__mod__,
+                       zip(range(1, len(order) + 1), [names[a] for a in order.tolist()], counts[order].tolist())))
+    for i, (a, c) in enumerate(res.counts_sorted if simulation else ()):
         if simulation:
             found = False
             for t in true_alleles:
@@ -435,6 +469,7 @@ def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partia
     base_fname = full_path_base_fname.split("/")[-1]
     report_base = "%s/%s-%s." % (out_dir, output_base, base_fname)
     test_passed = {}
+    del last_profile[:]
     if simulation:
         core_fid = str(test_i + 1)
         report_base += "test-"
@@ -464,10 +499,23 @@ def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partia
                 gegenome = genotype_genome if genotype_genome != "" else full_path_base_fname + "." + index_type
                 simulate.align_reads(aligner, simulation, gegenome, index_type, base_fname, read_fname, fastq, threads,
                                      alignment_fname, verbose, truth=(Genes, Vars, refGenes))
+            # The reference's loop `for test_Gene_names in locus_list` (core:370) runs `samtools view F ref_allele | sort` per locus:
+            # here the file is read ONCE (engine.Alignment: its bytes stay in HBM) and the loci -- independent of each other in the
+            # reference too: every per-locus structure is rebuilt -- are typed side by side, one host thread and stream per locus;
+            # their report sections are written in locus_list order afterwards.
+            jobs = []
             for test_Gene_names in locus_list:
                 gene = test_Gene_names[0].split("*")[0] if simulation else test_Gene_names
-                pl = PackedLocus.from_reference_dicts(gene, base_fname, refGenes, Genes, Gene_names, Gene_lengths,
-                                                      refGene_loci, Vars, Var_list, Links)
+                prof = {"gene": gene}
+                t_ = time.perf_counter()
+                # the packed locus and its device index come from the in-process cache when this process has seen these dicts --
+                # or dicts with the same content -- before (locus.LocusCache): typing() runs once per sample on one index
+                pl = PackedLocus.cached_from_reference_dicts(gene, base_fname, refGenes, Genes, Gene_names, Gene_lengths,
+                                                             refGene_loci, Vars, Var_list, Links)
+                prof["locus_packing_ms"] = (time.perf_counter() - t_) * 1e3
+                t_ = time.perf_counter()
+                pl.index()
+                prof["index_upload_ms"] = (time.perf_counter() - t_) * 1e3
                 # samtools view F [chr:l-r] ref_allele (core:436-444): the view is ALWAYS restricted to this gene's backbone
                 # sequence -- a multi-locus alignment (hla graph: A, B, C, ... in one BAM) never leaks other genes' reads
                 # into this gene's decode -- and in genotype-genome mode to the locus span on the chromosome as well
@@ -475,18 +523,63 @@ def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partia
                 if genotype_genome != "":
                     _, chr_, left, right = refGene_loci[gene][:4]
                     regions, base_locus = ["%s:%d-%d" % (chr_, left + 1, right + 1), refGenes[gene]], left
+                jobs.append([test_Gene_names, pl, regions, base_locus, prof, None, None])
+            t_ = time.perf_counter()
+            al = engine.Alignment(alignment_fname) if len(jobs) > 1 else None
+            t_open = (time.perf_counter() - t_) * 1e3
+
+            def run_job(job, stream=None):
                 # ... piped through sort -k1,1 -s (core:458-468), and the loop's decode: all inside libhgx
-                res = type_locus(pl, None, num_editdist=num_editdist, error_correction=error_correction,
-                                 allow_discordant=allow_discordant,
-                                 remove_low_abundance_alleles=remove_low_abundance_alleles, simulation=simulation,
-                                 base_locus=base_locus, alignment_file=alignment_fname, regions=regions)
-                pl.close()
+                try:
+                    job[5] = type_locus(job[1], None, num_editdist=num_editdist, error_correction=error_correction,
+                                        allow_discordant=allow_discordant, remove_low_abundance_alleles=remove_low_abundance_alleles,
+                                        simulation=simulation, base_locus=job[3], alignment_file=alignment_fname, regions=job[2],
+                                        profile=job[4], em_fast=typing_options.em_fast, alignment=al, stream=stream)
+                except BaseException as e:          # re-raised on the caller's thread, at this locus' place in the loop
+                    job[6] = e
+            try:
+                if al is not None and al.resident and typing_options.loci_side_by_side:
+                    import threading
+                    dev = capi.current_device()
+
+                    def worker(k):
+                        capi.set_device(dev)
+                        capi.set_stream_slot(("typing loci", k))
+                        st = capi.get_stream(2)
+                        for job in jobs[k::n_workers]:
+                            run_job(job, st)
+                        capi.sync(st)
+                    n_workers = min(len(jobs), 8)
+                    ths = [threading.Thread(target=worker, args=(k,)) for k in range(n_workers)]
+                    for t in ths:
+                        t.start()
+                    for t in ths:
+                        t.join()
+                else:
+                    for job in jobs:
+                        run_job(job)
+                        if job[6] is not None:
+                            break
+            finally:
+                if al is not None:
+                    al.close()
+            for test_Gene_names, pl, _, _, prof, res, err in jobs:
+                if not getattr(pl, "cached", False):
+                    pl.close()
+                if err is not None:
+                    raise err
+                if res is None:
+                    break
+                if al is not None:
+                    prof["alignment_open_ms_shared"] = t_open
+                last_profile.append(prof)
                 if res.num_reads <= 0:
                     continue
+                t_ = time.perf_counter()
                 lines, success = report_lines(res, simulation, test_Gene_names if simulation else (),
                                               output_allele_counts, best_alleles)
-                for l in lines:
-                    say(l)
+                say("\n".join(lines))
+                prof["report_ms"] = (time.perf_counter() - t_) * 1e3
                 if simulation:
                     for ok in success:
                         if ok:

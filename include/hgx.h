@@ -186,6 +186,18 @@ int hgx_classes_from_host(hgx_classes **out, const uint64_t *bits_host, const in
                           int32_t n_classes, int32_t a_pad);
 /* 8e (see the collectives next to hgx_index_broadcast): every rank's class table of one level, gathered in rank order and merged */
 int hgx_classes_allgather(hgx_classes **out, const hgx_classes *mine_or_null, int32_t a_pad, void *rccl_comm, void *stream);
+/* The two halves of that exchange around the collective, for callers with a transport of their own (and for tests that assemble
+ * the receive buffer of a world of N ranks on one GPU).  Wire format: a rank's table as `cap` rows of (a_pad/64 + 1) 64-bit
+ * words, [class bits | pair count], zero rows behind its n_classes; the receive buffer = the ranks' blocks in rank order.
+ *   hgx_classes_pack_rows       mine (NULL = none) -> dev_send [cap] rows, on `stream`
+ *   hgx_classes_merge_gathered  dev_recv [world][cap] rows + sizes[world] (host) -> the merged class set in rank order = the
+ *                               stream order of the ranks' pairs (first-seen order of typing_core.py:1229-1234 survives)
+ * hgx_rccl_stats: collectives issued by this process through the entry points above and the bytes handed to / received from
+ * them since the last reset (bench.py prints the exchange bytes of a step from it). */
+int hgx_classes_pack_rows(const hgx_classes *mine_or_null, int32_t a_pad, int32_t cap, void *dev_send, void *stream);
+int hgx_classes_merge_gathered(hgx_classes **out, const void *dev_recv, const int32_t *sizes_host, int32_t world, int32_t cap,
+                               int32_t a_pad, void *stream);
+int hgx_rccl_stats(uint64_t *n_collectives, uint64_t *bytes_sent, uint64_t *bytes_received, int32_t reset);
 
 /* 8a-5/6 stage 2 and 8a-7 in one call for ONE level (0 = exon, 1 = gene): the classes of all pairs in first-seen order with
  * their pair counts and first pairs -- the same result as hgx_pair_classes + hgx_dedup_classes on that level's rows
@@ -229,6 +241,21 @@ int hgx_allele_counts_on(const hgx_classes *c, int64_t *count_host, int32_t *fir
 /* first class (dict order) containing each of a FEW given alleles, -1 if none: the tie order of the EM's result list
  * (common:1300-1305) without the full Gene_counts pass */
 int hgx_first_classes(const hgx_classes *c, const int32_t *alleles_host, int32_t n, int32_t *first_class_host, void *stream);
+
+/* ---- 8b: the dict side of the single_abundance seam ----------------------------------------------------------------------
+ * single_abundance(Gene_cmpt) takes classes as strings, '-'.join(sorted(allele names)) -> count (typing_common.py:1282-1305,
+ * typing_core.py:1229-1230).  hgx_keyset_create turns `n_keys` such keys (one per line: '\n'-separated, no trailing newline
+ * needed) into what hgx_classes_from_host takes -- the allele names in order of first appearance (= the insertion order of the
+ * reference's Gene_prob dict) and one bit row per key -- in one pass over the text instead of a Python loop per name.
+ *   hgx_keyset_dims   n_names, a_pad (= hgx_a_pad(n_names)), bytes of the name pool, keys_sorted (every key's names ascending:
+ *                     the form the reference itself builds, which lets the EM follow its summation order)
+ *   hgx_keyset_fill   bits_host [n_keys][a_pad/64], name_pool ('\0'-terminated names, first-appearance order), name_rank [n_names]
+ *                     (rank of each name in sorted order); any of them may be NULL */
+typedef struct hgx_keyset hgx_keyset;
+int hgx_keyset_create(hgx_keyset **out, const char *keys, size_t n_bytes, int32_t n_keys);
+int hgx_keyset_dims(const hgx_keyset *ks, int32_t *n_names, int32_t *a_pad, size_t *name_pool_bytes, int32_t *keys_sorted);
+int hgx_keyset_fill(const hgx_keyset *ks, uint64_t *bits_host, char *name_pool, int32_t *name_rank);
+int hgx_keyset_destroy(hgx_keyset *ks);
 
 /* ---- 8a-8: EM abundance ------------------------------------------------------------------
  * Replaces single_abundance (typing_common.py:1282-1410): SQUAREM-accelerated EM in FP64,
@@ -466,7 +493,7 @@ int hgx_type_file(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, c
  * (typing_core.py:1386-1406, 718-792), the piece masks of add_count's span scan (typing_core.py:641-670), the distinct-piece
  * table and the pair protocol (typing_core.py:1238-1347) run as kernels; the batch is born in HBM, byte for byte the batch
  * hgx_parse_sam / hgx_parse_alignment_file build (hgx_dbatch_to_host shows it).  Inputs the kernels do not take -- fewer than
- * 20 000 records, keep_trace, CODIS D18S51's choose_pairs, variant ids that are not hv<n>, a record the reference would raise on,
+ * 1 000 records or 300 KB of stream (the measured break-even with the host stages: csrc/hgx_front.hip FE_MIN_*), keep_trace, CODIS D18S51's choose_pairs, variant ids that are not hv<n>, a record the reference would raise on,
  * a pair with more alternatives than the kernels' scratch holds -- are finished by the host stages and uploaded: the result is
  * the same batch either way, and hgx_front_last says which way the calling thread's last call went (route: 2 = record route,
  * 1 = key route, 0 = host stages; decline_code: see HGX_FE_DECLINE_* / FE_E_* in csrc/hgx_internal.hpp,
@@ -480,6 +507,20 @@ int hgx_parse_sam_dev(hgx_dbatch **out, const hgx_locus *loc, const char *sam, s
 int hgx_parse_alignment_file_dev(hgx_dbatch **out, const hgx_locus *loc, const char *path, const char *regions_or_null,
                                  const hgx_parse_opts *opts, void *stream);
 int hgx_front_last(int32_t *route, int32_t *decline_code, int64_t *bytes_to_device /* sent by that call: text / stream / key table */);
+/* ONE alignment file, SEVERAL loci (typing_core.py:370 loops `locus_list` over one alignment file; the reference runs `samtools view
+ * F ref_allele | sort` per locus, core:436-468 -- the file is decompressed once per locus).  hgx_alignment_open reads the file ONCE and
+ * leaves its bytes in HBM: the SAM text, or the BAM stream inflated on the device; hgx_alignment_parse_dev is the per-locus rest --
+ * region filter, name order and the record route of hgx_parse_alignment_file_dev as kernels over those resident bytes (read-only: the
+ * loci of a panel may be parsed side by side from threads with streams of their own).  The batch is the one
+ * hgx_parse_alignment_file_dev(path, regions) builds; a locus the kernels decline, a region list with several entries, a file below
+ * the device front end's size gate or beyond 4 GB of stream go through exactly that call on the path (hgx_front_last tells).
+ * hgx_alignment_dims: resident = the bytes are in HBM (0: every locus takes the per-path call). */
+typedef struct hgx_alignment hgx_alignment;
+int hgx_alignment_open(hgx_alignment **out, const char *path, int32_t n_threads, void *stream);
+int hgx_alignment_dims(const hgx_alignment *al, int32_t *resident, int32_t *is_text, size_t *stream_bytes, long long *bytes_to_device);
+int hgx_alignment_parse_dev(hgx_dbatch **out, hgx_alignment *al, const hgx_locus *loc, const char *regions_or_null,
+                            const hgx_parse_opts *opts, void *stream);
+int hgx_alignment_close(hgx_alignment *al);
 /* a device batch back on the host (tests, tools): pieces, masks, refs, and the pileup tables if the kernels made them */
 int hgx_dbatch_to_host(const hgx_dbatch *d, hgx_batch **out);
 /* The same from class sets that already exist (intra-locus read sharding, 8e: every rank scores its share of the pairs, the

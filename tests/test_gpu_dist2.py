@@ -125,3 +125,52 @@ def test_rccl_communicator_beside_a_torch_nccl_group(tmp_path, order):
     r = subprocess.run([sys.executable, str(w), order, str(_free_port())], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "order ok" in r.stdout
+
+
+def _bench(args, timeout=1500):
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]                 # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_body_with_ranks_sharing_the_gpu(n):
+    """The REAL bench body -- not --dry-run -- with N ranks on the one GPU of the box, control plane over gloo: bench.py launches
+    the ranks itself, rank 0's index is broadcast, every rank types its own sample, the time is the max over ranks, the reads are
+    summed, every rank's file -> result leg runs at the same time as the others'.  (RCCL refuses two ranks on one device; the nccl
+    form of the same body differs in make_comm() only.)"""
+    line = _bench(["--gpus", str(n), "--backend", "gloo", "--share-gpu", "--pairs", "20000", "--steps", "2", "--warmup", "1", "--no-workloads"])
+    assert line["n_gpus"] == n and line["steps"] == 2 and line["scaling"] == "weak"
+    cfg = line["config"]
+    assert cfg["shared_gpu"] is True and cfg["comm_kind"].startswith("torch-gloo") and cfg["index_broadcast_bytes"] > 1_000_000
+    assert cfg["device_front_end_batch_identical_to_host"] is True
+    assert sorted(cfg["top2"]) == sorted(cfg["true_alleles"])
+    # value = the reads of ALL ranks over the slowest rank's time
+    assert abs(line["value"] - n * cfg["pairs_per_gpu"] * 2 * line["steps"] / (line["ms_per_step"] * line["steps"] * 1e-3)) / line["value"] < 0.02
+    e2e = line["e2e"]
+    assert e2e["results_identical_to_hbm_path_on_every_rank"] is True and e2e["ms_per_call"] > 0
+    assert line["roofline"]["frac"] > 0
+
+
+@pytest.mark.parametrize("n", [4, 5])
+def test_bench_class1_body_with_sharded_loci_on_a_shared_gpu(n):
+    """bench.py --workload class1 with more ranks than loci, all on GPU 0 over gloo: HLA-A (and, with 5 ranks, B) has its pairs
+    sharded over a rank group -- device front end per shard, pileup all-reduce at parse, class tables gathered and merged per
+    step -- and every rank of a sharded locus also types the whole locus alone: identical result required."""
+    line = _bench(["--gpus", str(n), "--backend", "gloo", "--share-gpu", "--workload", "class1", "--pairs", "30000", "--steps", "2", "--warmup", "1",
+                   "--check-unsharded", "--no-cpu-baseline"])
+    cfg = line["config"]
+    assert line["n_gpus"] == n and cfg["shared_gpu"] is True
+    groups = cfg["rank_groups"]
+    assert sorted(r for g in groups.values() for r in g) == list(range(n)) and len(groups["A"]) == 2
+    assert cfg["sharded_equals_unsharded"] is True
+    assert all(c["correct"] for c in cfg["calls"].values()) and len(cfg["calls"]) == 3
+    assert cfg["comm_kind"] == {"A": "torch-gloo (host control plane)"}
+    assert cfg["exchange"]["collectives_per_step"] >= 3 and cfg["exchange"]["bytes_received_per_step"] > cfg["exchange"]["bytes_sent_per_step"] > 0
+    assert cfg["front_end_route_of_my_shards"]["A"][0] == 2         # rank 0's shard went through the device front end
+    assert cfg["e2e_shards"]["device_front_end_on_every_rank_and_results_identical_to_the_resident_path"] is True

@@ -87,11 +87,20 @@ def test_many_samples_in_one_device_pass(tmp_path):
         assert engine.front_last() == (2, 0)
     same_many(dev, host)
     # where the device front end declines, the host front end runs task by task: the same batch again
-    for switches, want in ((dict(front="host"), (0, -1)), (dict(), (0, 6))):          # (6: fewer records than the size gate)
+    for switches, want in ((dict(front="host"), (0, -1)), (dict(), (2, 0))):          # (the library's choice at 9 000 records: the kernels)
         with engine.test_switches(**switches):
             dev = engine.ManyBatch.from_files(pl, p_bam, regions=[loc.ref_allele] * len(p_bam))
             assert engine.front_last() == want, engine.front_last()
         same_many(dev, host)
+    # below the size gate (1 000 records / 300 KB in all: the measured break-even, hgx_front.hip FE_MIN_*) the host stages take the call
+    small = _samples(loc, 2, 120, 77, err=0.01)
+    p_small = []
+    for t, s_ in enumerate(small):
+        p_small.append(str(tmp_path / ("small%d.bam" % t)))
+        bamio.write_bam_native(p_small[-1], s_.encode(), [(loc.ref_allele, len(loc.backbone))])
+    dev = engine.ManyBatch.from_files(pl, p_small, regions=[loc.ref_allele] * 2)
+    assert engine.front_last() == (0, 6), engine.front_last()                         # (6: fewer records than the size gate)
+    same_many(dev, engine.ManyBatch(pl, [pl.parse_sam(s_) for s_ in small]))
     with engine.test_switches(front="device"):
         dev = engine.ManyBatch.from_files(pl, [p_sam[0], p_bam[1]])                  # SAM text and BAM records in one batch
         assert engine.front_last() == (0, 1)
