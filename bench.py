@@ -101,7 +101,7 @@ def parse_args():
                     help="file -> result with N processes sharing GPU 0 (one sample stream each): the host-scaling leg of the default run; '' skips it")
     ap.add_argument("--e2e-child", default=None, help=argparse.SUPPRESS)      # internal: one process of that leg (a JSON job description)
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the per-launch HIP events (profiling runs)")
-    ap.add_argument("--workload", choices=["configs1", "class1", "panel64", "config0_dropin", "codis_dropin"], default="configs1",
+    ap.add_argument("--workload", choices=["configs1", "class1", "panel64", "config0_dropin", "codis_dropin", "sample6"], default="configs1",
                     help="configs1 (default; BASELINE.json configs[1]: one HLA-A sample of 1 M reads per GPU), class1 (configs[2]: "
                          "HLA-A + B + C, 1 M reads each, loci -- and the reads of a locus -- sharded over the GPUs), panel64 "
                          "(configs[3]: six loci x 64 samples sharded over the GPUs)")
@@ -719,12 +719,17 @@ def run_class1(args, rank, local_rank, world, dist):
     timing = not args.no_kernel_timing and not comms
     n_timed = min(N_TIMED_STEPS, args.steps)
 
+    step_times = []
+
     def timed_body():
         mode = 2 if (timing and state["k"] >= args.steps - n_timed) else 0
         pool["mode"] = mode
         engine.em_set_timing(mode)
         state["k"] += 1
-        return body()
+        t0 = time.perf_counter()
+        out = body()
+        step_times.append(time.perf_counter() - t0)
+        return out
     rccl_stats(reset=True)
     for c in comms.values():
         if hasattr(c, "stats"):
@@ -736,6 +741,9 @@ def run_class1(args, rank, local_rank, world, dist):
             xs = [a + b for a, b in zip(xs, c.stats)]
     exchange = {"collectives_per_step": xs[0] / max(args.steps, 1), "bytes_sent_per_step": xs[1] // max(args.steps, 1),
                 "bytes_received_per_step": xs[2] // max(args.steps, 1), "of": "rank 0's sharded loci (class tables of both levels + totals)"} if comms else None
+    st_sorted = sorted(step_times)
+    step_spread = {"min": round(st_sorted[0] * 1e3, 3), "median": round(st_sorted[len(st_sorted) // 2] * 1e3, 3), "max": round(st_sorted[-1] * 1e3, 3),
+                   "note": "this rank's host-side step times inside the timed region"} if st_sorted else None
     em_timing = engine.em_get_timing() if timing else {}
     engine.em_set_timing(0)
     if side_by_side:
@@ -867,7 +875,8 @@ def run_class1(args, rank, local_rank, world, dist):
                        "shared_gpu": bool(args.share_gpu),
                        "e2e_shards": e2e_shards,
                        "setup_s": round(t_setup, 1)},
-            "roofline": em_roofline(em_timing, n_timed) if timing else None, "cpu_baseline": cb, "e2e": e2e})
+            "roofline": em_roofline(em_timing, n_timed) if timing else None, "cpu_baseline": cb, "e2e": e2e,
+            "stream_sets": engine.stream_sets_info(), "ms_per_step_spread": step_spread})
     return None
 
 
@@ -917,6 +926,11 @@ def run_dropin(args, name):
         rest = sorted((call(d) for _ in range(7)), key=lambda r: r[0])
         t_rep, p_rep, ok_rep = rest[len(rest) // 2]
         t_copy, p_copy, ok_copy = call(copy.deepcopy(d))                   # equal dicts in other objects (re-read index): content key
+        htyping.typing_options.em_fast = True                              # the other EM arithmetic (table lookups, <= 1e-8; bar 1e-5)
+        try:
+            fast = sorted((call(d) for _ in range(5)), key=lambda r: r[0])[2]
+        finally:
+            htyping.typing_options.em_fast = False
         hits = (hlocus.LOCUS_CACHE.hits_identity, hlocus.LOCUS_CACHE.hits_content, hlocus.LOCUS_CACHE.misses)
         # the same through genotyping_locus from index files on disk (driver.py; typing_core.py:2278-2691)
         ix_dir = os.path.join(tmp, "ix")
@@ -949,6 +963,8 @@ def run_dropin(args, name):
             "first_call_ms": round(t_first * 1e3, 2), "first_call_split_ms": fmt(p_first),
             "repeated_call_ms": round(t_rep * 1e3, 2), "repeated_call_split_ms": fmt(p_rep),
             "equal_dicts_in_new_objects_ms": round(t_copy * 1e3, 2), "equal_dicts_split_ms": fmt(p_copy),
+            "em_arithmetic": "default of typing(): the reference's order of floating-point operations (abundances == the reference's doubles)",
+            "repeated_call_table_lookup_em_ms": round(fast[0] * 1e3, 2), "table_lookup_em_report_identical": bool(fast[2]),
             "locus_cache": {"identity_hits": hits[0], "content_hits": hits[1], "misses": hits[2]},
             "genotyping_locus": {"entry": "hisatgenotype_amd.genotyping_locus(<32 arguments of typing_core.py:2278-2309>) on index files on disk",
                                  "first_call_ms": round(g_first[0] * 1e3, 2), "repeated_call_ms": round(g_rep[0] * 1e3, 2),
@@ -961,6 +977,90 @@ def run_dropin(args, name):
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
+
+
+def run_sample6(args):
+    """ONE sample x SIX loci at real depth (the reference's call shape: typing() loops its locus_list over one
+    alignment file, typing_core.py:370, 436-468): the HLA panel's six loci, 3 000 read pairs each, in ONE coordinate-sorted BAM ->
+    `hisatgenotype_amd.typing(<38 arguments>, locus_list = the six genes)` -> one report with six sections.  The file is read and
+    inflated once (hgx_alignment_open), every locus goes through the device front end (k_fe_*: 6 000 records are above the 1 000-record
+    gate of round 6; rounds 3-5 sent them to the host stages) and the loci are typed side by side."""
+    import shutil
+    import tempfile
+    from hisatgenotype_amd import bamio, locus as hlocus
+    n_pairs = 3000
+    loci = [synth.make_hla_like_locus(gene=g, n_alleles=a, length=ln, n_vars=v, seed=500 + i, var_id_base=10000 * i)
+            for i, (g, a, ln, v) in enumerate(PANEL)]
+    samples = [synth.pick_sample(loc, 7000 + k) for k, loc in enumerate(loci)]
+    sams = [synth.simulate_sam_fast(loc, smp, n_pairs, err_rate=args.err, seed=900 + k) for k, (loc, smp) in enumerate(zip(loci, samples))]
+    d = {k: {} for k in ("refGenes", "Genes", "Gene_names", "Gene_lengths", "refGene_loci", "Vars", "Var_list", "Links")}
+    for loc in loci:
+        for k, v in loc.reference_dicts().items():
+            d[k].update(v)
+    genes = [loc.gene for loc in loci]
+    tmp = tempfile.mkdtemp(prefix="hgx_sample6_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        bam = os.path.join(tmp, "sample.bam")
+        bamio.write_bam_native(bam, "".join(sams).encode(), [(loc.ref_allele, len(loc.backbone)) for loc in loci], sort_by_coordinate=True)
+        rep_path = os.path.join(tmp, "assembly_graph-hla.sample.report")
+
+        def call(side_by_side=True, em_fast=False):
+            htyping.typing_options.loci_side_by_side, htyping.typing_options.em_fast = side_by_side, em_fast
+            try:
+                t0 = time.perf_counter()
+                hgx.typing(False, os.path.join(tmp, "hla"), genes, "", True, set(), d["refGenes"], d["Genes"], d["Gene_names"], d["Gene_lengths"],
+                           d["refGene_loci"], d["Vars"], d["Var_list"], d["Links"], [["hisat2", "graph"]], 2, False, "assembly_graph", True, True,
+                           False, False, True, [], False, ["sample.fq"], bam, [], 150, 400, 1, False, 0, False, tmp, "NONE", False, 0)
+                dt = time.perf_counter() - t0
+            finally:
+                htyping.typing_options.loci_side_by_side, htyping.typing_options.em_fast = True, False
+            with open(rep_path) as f:
+                rep = f.read()
+            return dt, [dict(p) for p in htyping.last_profile], rep
+        hlocus.LOCUS_CACHE.clear()
+        t_first, _, rep0 = call()
+        runs = sorted((call() for _ in range(5)), key=lambda r: r[0])
+        t_rep, prof, rep = runs[len(runs) // 2]
+        t_seq = sorted(call(side_by_side=False)[0] for _ in range(3))[1]
+        t_fast = sorted(call(em_fast=True)[0] for _ in range(3))[1]
+        # the old way: one hgx_type_file per locus (the file read and inflated six times), locus after locus
+        pls = [hlocus.PackedLocus.cached_from_reference_dicts(g, "hla", d["refGenes"], d["Genes"], d["Gene_names"], d["Gene_lengths"], d["refGene_loci"],
+                                                              d["Vars"], d["Var_list"], d["Links"]) for g in genes]
+
+        def per_locus_files():
+            t0 = time.perf_counter()
+            out = [hgx.type_file(pl, bam, regions=[pl.ref_allele]) for pl in pls]
+            return time.perf_counter() - t0, out
+        per_locus_files()
+        t_old, res_old = sorted((per_locus_files() for _ in range(3)), key=lambda r: r[0])[1]
+        # every section of the report against the locus typed alone from its own SAM text
+        keep = lambda ls: [l for l in ls if "aligned" in l or "ranked" in l or "(count:" in l]
+        want = []
+        for pl, sam in zip(pls, sams):
+            lines, _ = hgx.report_lines(hgx.type_locus(pl, sam), False, (), False)
+            want += keep(lines)
+        top2 = {}
+        for pl, r in zip(pls, res_old):
+            top2[pl.gene] = [a for a, _ in r.gene_prob[:2]]
+        return {
+            "metric": "wall time of one typing() call over ONE sample x 6 loci (file -> six report sections)", "unit": "ms", "higher_is_better": False,
+            "value": round(t_rep * 1e3, 2),
+            "config": {"workload": "1 sample x 6 loci (%s alleles), %d simulated 2x150bp pairs per locus in ONE coordinate-sorted BAM (%.1f MB)" % (
+                "/".join(str(p[1]) for p in PANEL), n_pairs, os.path.getsize(bam) / 1e6),
+                "entry": "hisatgenotype_amd.typing(<38 arguments>, locus_list = %s)" % genes},
+            "reads_per_s": round(2 * n_pairs * len(loci) / t_rep, 1),
+            "first_call_ms": round(t_first * 1e3, 2), "repeated_call_ms": round(t_rep * 1e3, 2),
+            "loci_one_after_the_other_ms": round(t_seq * 1e3, 2), "table_lookup_em_ms": round(t_fast * 1e3, 2),
+            "one_hgx_type_file_per_locus_ms": round(t_old * 1e3, 2),
+            "front_end_route_per_locus": {p["gene"]: p["front_end_route"] for p in prof},
+            "alignment_open_ms": round(prof[0].get("alignment_open_ms_shared", 0.0), 3),
+            "per_locus_ms": {p["gene"]: {"file_region_and_front_end": round(p["file_read_and_front_end_ms"], 3),
+                                         "gpu_typing_and_result": round(p["gpu_typing_and_result_ms"], 3)} for p in prof},
+            "report_sections_identical_to_the_loci_typed_alone": keep(rep.split("\n")) == want and keep(rep0.split("\n")) == want,
+            "calls": {loc.gene: {"top2": top2[loc.gene], "true": smp, "correct": sorted(top2[loc.gene]) == sorted(smp)} for loc, smp in zip(loci, samples)},
+        }
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def run_panel64(args, rank, local_rank, world, dist):
@@ -1266,12 +1366,15 @@ def main():
         except Exception as e:                                      # (the leg must not cost the run its headline)
             scaling = {"error": repr(e)[:500]}
         pre = (loc0, sam0, scaling)
+    if os.environ.get("HGX_STREAMS"):                     # A/B of the stream placement (tools: "unplaced" = creation order, no probes)
+        engine.test_switch("streams", os.environ["HGX_STREAMS"])
     capi.set_device(dev_id)
     local_rank = dev_id                                   # (everything below addresses the GPU through this)
-    if args.workload in ("config0_dropin", "codis_dropin"):
+    if args.workload in ("config0_dropin", "codis_dropin", "sample6"):
         if world != 1:
             sys.exit("bench.py: the drop-in legs are one-process measurements")
-        print(json.dumps(run_dropin(args, "hla_7000_10k" if args.workload == "config0_dropin" else "codis_10k")))
+        print(json.dumps(run_sample6(args) if args.workload == "sample6" else
+                         run_dropin(args, "hla_7000_10k" if args.workload == "config0_dropin" else "codis_10k")))
         return
     if args.workload != "configs1":
         line = (run_class1 if args.workload == "class1" else run_panel64)(args, rank, local_rank, world, dist)
@@ -1398,6 +1501,26 @@ def main():
             capi.sync()
             dt = time.perf_counter() - t0
             in_flight[str(nf)] = {"steps": n_st, "ms_per_step": round(dt / n_st * 1e3, 3), "value": round(batch.n_reads * n_st / dt, 1)}
+    # the same steps in the OTHER EM arithmetic, a few of them outside the timed region: `value` times the library's default (reference
+    # order up to 4 096 classes, table lookups <= 1e-9 beyond: EM #1 of this sample); em_fast = -1 is the reference's order at every
+    # size, bit-identical abundances (say what the bit-identical form costs NEXT to `value`)
+    exact_em = None
+    if inflight == 1 and dist is None and not args.no_workloads and not args.em_exact:
+        EM_MODE = -1
+        try:
+            run_steps(pl, batch, db, 1, 1, None, False, local_rank)
+            capi.sync()
+            t0 = time.perf_counter()
+            res_x, _, _, _ = run_steps(pl, batch, db, 1, 3, None, False, local_rank)
+            capi.sync()
+            dt = (time.perf_counter() - t0) / 3
+            exact_em = {"ms_per_step": round(dt * 1e3, 3), "value": round(batch.n_reads / dt, 1), "steps": 3,
+                        "same_top2": [a for a, _ in res_x.gene_prob[:2]] == [a for a, _ in res.gene_prob[:2]],
+                        "max_abs_abundance_difference_to_the_timed_form": max([abs(p - q) for (_, p), (_, q) in zip(res_x.gene_prob, res.gene_prob)] or [0.0])}
+        except Exception as e:
+            exact_em = {"error": repr(e)[:300]}
+        finally:
+            EM_MODE = False
     if rank == 0:
         # Per-kernel achieved rates from HIP events recorded inside the timed region (byte models: DESIGN.md section 5).
         #  k_lutmatvec<0> (EM rows pass): the compact class bit matrix once + its dense vectors
@@ -1523,9 +1646,18 @@ def main():
                                          "dedup_both_levels": int(dedup_bytes), "em_passes": int(em_bytes)},
                 "step_profile": step_profile,      # dispatches / kernel time / gaps per step, from the committed kernel trace of this command
                 "emx_cluster_problems": cl_jobs, "emx_cluster_fallbacks": cl_fallbacks,
+                "stream_sets": engine.stream_sets_info(),
             },
         }
+        out["value_scope"] = ("`value`: rows 8a-5 ... 8a-9 of SURVEY.md section 8 (scoring, class dedup, Gene_counts, both EMs, hand-off, result) over a "
+                              "piece batch resident in HBM, ONE sample at a time, the library's default EM arithmetic; rows 8a-1 ... 8a-4 (record decode, "
+                              "filters, pileup, CIGAR x MD x Zs walk, haplotypes) are NOT in it -- `e2e` (file -> result) includes them")
+        if exact_em:
+            out["value_exact_em"] = exact_em.get("value")
+            out["exact_em"] = exact_em
         if in_flight:
+            out["value_3_in_flight"] = in_flight["3"]["value"]
+            out["value_2_in_flight"] = in_flight["2"]["value"]
             out["samples_in_flight"] = {"note": "the timed steps again with 2 / 3 samples in flight on the GPU (one host thread and stream set per sample, the "
                                                 "bandwidth-bound fronts taking turns); `value` above is ONE sample at a time", **in_flight}
         if pre is not None:
@@ -1565,9 +1697,9 @@ def main():
                 line["wall_s_incl_setup"] = round(time.perf_counter() - t0, 1)
                 wl[name] = line
         if rank == 0 and world == 1:
-            for wname, fixture in (("config0_dropin", "hla_7000_10k"), ("codis_dropin", "codis_10k")):
+            for wname, fixture in (("config0_dropin", "hla_7000_10k"), ("codis_dropin", "codis_10k"), ("sample6", None)):
                 try:
-                    wl[wname] = run_dropin(args, fixture)
+                    wl[wname] = run_dropin(args, fixture) if fixture else run_sample6(args)
                 except Exception as e:                              # (a side leg must not cost the run its headline)
                     wl[wname] = {"error": repr(e)[:500]}
         if rank == 0:

@@ -517,6 +517,28 @@ bool inflate_one(const unsigned char *data, const hgx_bgzf_block &b, unsigned ch
     return rc == Z_STREAM_END && zs.total_out == b.out_len && (uint32_t)crc32(crc32(0L, Z_NULL, 0), dst, (uInt)b.out_len) == b.crc;
 }
 
+// the first bytes of a BGZF block's payload without inflating the block (a bgzipped SAM text, or anything else that is not a BAM,
+// must not cost an upload and a device inflate whose output is thrown away): a few microseconds of zlib
+bool peek_is_bam(const unsigned char *data, const std::vector<hgx_bgzf_block> &blocks) {
+    for (const hgx_bgzf_block &b : blocks) {
+        if (b.out_len == 0) continue;
+        if (b.out_len < 4) return false;
+        unsigned char head[4] = {0, 0, 0, 0};
+        z_stream zs;
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) return false;
+        zs.next_in = const_cast<unsigned char *>(data + b.in_off);
+        zs.avail_in = (uInt)b.in_len;
+        zs.next_out = head;
+        zs.avail_out = 4;
+        const int rc = inflate(&zs, Z_SYNC_FLUSH);
+        const bool ok = (rc == Z_OK || rc == Z_STREAM_END || rc == Z_BUF_ERROR) && zs.avail_out == 0 && memcmp(head, "BAM\1", 4) == 0;
+        inflateEnd(&zs);
+        return ok;
+    }
+    return false;
+}
+
 }   // namespace
 
 // What a deferred stream's owner needs to pull ONE region list out of it (hgx_alignment_parse_dev: a file opened once, a locus at a
@@ -716,8 +738,26 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
         // ordinary way below, which also words the errors.
         std::vector<hgx_bgzf_block> blocks;
         size_t total = 0;
-        if (out.comp_early && data.size() >= out.defer_min_bytes / 64) out.comp_early(data.data(), data.size());   // (BGZF rarely deflates below 1 : 64)
-        if (hgx_bgzf_scan(data.data(), data.size(), blocks, &total) == HGX_OK && total < (1ull << 32) - 64) {
+        // (a bgzipped SAM text or any other BGZF file that is not a BAM must not cost an upload and a device inflate whose
+        // output is thrown away -- the first block's first four bytes say which it is, before anything is sent)
+        bool looks_bam = false;
+        {
+            std::vector<hgx_bgzf_block> first;
+            const size_t n = data.size();
+            if (n >= 18 && (data[3] & 4)) {
+                const size_t xlen = (size_t)data[10] | ((size_t)data[11] << 8);
+                size_t blen = 0;
+                for (size_t q = 12; q + 4 <= 12 + xlen && q + 6 <= n;) {
+                    const size_t slen = (size_t)data[q + 2] | ((size_t)data[q + 3] << 8);
+                    if (data[q] == 66 && data[q + 1] == 67 && slen == 2) blen = ((size_t)data[q + 4] | ((size_t)data[q + 5] << 8)) + 1;
+                    q += 4 + slen;
+                }
+                if (blen && blen <= n && hgx_bgzf_scan(data.data(), blen, first, nullptr) == HGX_OK && first.size() == 1)
+                    looks_bam = first[0].out_len == 0 || peek_is_bam(data.data(), first);      // (an empty first block: the full scan decides)
+            }
+        }
+        if (looks_bam && out.comp_early && data.size() >= out.defer_min_bytes / 64) out.comp_early(data.data(), data.size());   // (BGZF rarely deflates below 1 : 64)
+        if (looks_bam && hgx_bgzf_scan(data.data(), data.size(), blocks, &total) == HGX_OK && total < (1ull << 32) - 64 && peek_is_bam(data.data(), blocks)) {
             std::vector<unsigned char> head;
             std::vector<std::string> refs;
             size_t body0 = 0;
@@ -769,8 +809,8 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             on_raw_done = true;
         }
         const int rc = bgzf_inflate(data, n_threads, raw, part);
-        if (rc) return rc;
-        if (out.comp_sync) out.comp_sync();                    // (an upload of these bytes begun by comp_early may still be reading them)
+        if (out.comp_sync) out.comp_sync();                    // (an upload of these bytes begun by comp_early may still be reading them: on
+        if (rc) return rc;                                     //  EVERY way out of here that gives `data` back)
         data.release();
     } else raw.swap(data);
     lap("inflate");

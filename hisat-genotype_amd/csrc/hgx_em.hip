@@ -274,9 +274,6 @@ __global__ __launch_bounds__(BLOCK) void k_em_finish(const double *__restrict__ 
     }
 }
 
-#ifdef HGX_LAB
-#include "lab/hgx_em_mfma.inc"            // int8-MFMA form of the bit mat-vec (backend 2): lab build only
-#endif
 
 
 #ifdef HGX_LAB
@@ -1228,10 +1225,6 @@ __global__ __launch_bounds__(BLOCK) void k_lut_rows_fused(const uint64_t *__rest
 }
 
 
-#ifdef HGX_LAB
-#include "lab/hgx_em_lut4.inc"            // narrow-table form of the two passes (measured slower: lab build only)
-#include "lab/hgx_em_persist.inc"         // whole iterations per launch behind device-wide barriers (HGX_EM_PERSIST): lab build only
-#endif
 
 // arguments of the resident-block EM (k_em_grid, lab build): the host code that prepares them is shared
 struct GkArgs {
@@ -1253,9 +1246,6 @@ constexpr int GK_STAMPS = 128;
 [[maybe_unused]] constexpr long GK_SPIN_LIMIT = 1500000;     // bounded spin (~0.5 s): an error code, never a hung GPU
 constexpr int GK_FLAG_STRIDE = 32;
 [[maybe_unused]] constexpr size_t GK_LDS = (size_t)(LUT_G * 256 + BLOCK) * 8;
-#ifdef HGX_LAB
-#include "lab/hgx_em_grid.inc"            // the class matrix resident in registers, point-to-point hand-offs (HGX_EM_GRID): lab build only
-#endif
 
 // u64-element transpose: out[c][r] = in[r][c]  (in [n_rows][n_cols])
 __global__ __launch_bounds__(256) void k_word_transpose(const uint64_t *__restrict__ in, int n_rows, int n_cols,
@@ -1304,19 +1294,8 @@ template <int MODE>
 int launch_mfma(const MatVec &m, hipStream_t st, const double *vec, const uint8_t *vec_pres, int x_mode, const int64_t *count,
                 const double *q_in, const uint8_t *pres_in, const double *len, double *y, uint8_t *pres_out, double *scal,
                 int gate) {
-#ifdef HGX_LAB
-    const size_t lds = (size_t)MF_NP * MF_STRIDE;
-    HGX_ONCE_PER_DEVICE({
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_mfma_matvec<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    });
-    const int grid = (m.n_rows + 16 * MF_WAVES - 1) / (16 * MF_WAVES);
-    hipLaunchKernelGGL((k_mfma_matvec<MODE>), dim3(grid), dim3(MF_BLOCK), lds, st, m.P, m.n_rows, m.n_super, m.n_k, vec, vec_pres,
-                       x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate);
-    return HGX_OK;
-#else
     hgx_set_error("this EM back-end is lab code: build libhgx_lab.so (hisat-genotype_amd/build.py build_lab) -- libhgx.so ships the table-lookup and reference-order paths only");
     return HGX_EINVAL;
-#endif
 }
 
 // events that the next table-lookup launch attaches to its own dispatch (hipExtLaunchKernelGGL: the runtime timestamps the
@@ -1330,9 +1309,6 @@ int launch_matvec(const MatVec &m, hipStream_t st, const double *vec, const uint
     if constexpr (MODE == MODE_ROWS || MODE == MODE_COLS) {
         if (use_mfma(m))
             return launch_mfma<MODE>(m, st, vec, vec_pres, x_mode, count, q_in, pres_in, len, y, pres_out, scal, gate);
-#ifdef HGX_LAB
-#include "lab/hgx_launch_lut4.inc"        // the narrow-table form of a pass (k_lut4)
-#endif
         if (m.M) {
             HGX_ONCE_PER_DEVICE({
                 HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lutmatvec<MODE>),
@@ -1604,29 +1580,47 @@ constexpr double EM_NEAR_REL = 1e-8;
 static std::atomic<long long> g_tie_reruns{0};
 extern "C" long long hgx_em_tie_reruns(void) { return g_tie_reruns.load(); }
 
+// rows of the transposed class matrix (allele-major) gathered into one contiguous block: the near-tie check compares them on the host
+__global__ void k_gather_rows(const uint64_t *__restrict__ bitsT, int c64, const int32_t *__restrict__ ids, int n, uint64_t *__restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n * c64) return;
+    out[i] = bitsT[(size_t)ids[i / c64] * c64 + (i % c64)];
+}
+
 static int em_uncertain_near_tie(hgx_classes *c, int32_t n_alleles, const double *prob, hipStream_t st, bool *uncertain) {
     *uncertain = false;
     std::vector<int32_t> al;
     for (int32_t a = 0; a < n_alleles; ++a) if (prob[a] > 0.0) al.push_back(a);
     std::sort(al.begin(), al.end(), [&](int32_t x, int32_t y) { return prob[x] > prob[y]; });
+    // Only an order somebody reads is worth a ~15x slower exact run: the report prints abundances >= 0.01 and at most 20
+    // alleles (typing_core.py:2081, 2118-2121), the exon -> gene hand-off walks the ranking until `rank >= 10 and p < 0.03`
+    // (core:1739-1749).  Neighbours below rank 32 AND below 0.005 are vanishing residues whose relative order reaches no output.
     std::vector<std::pair<int32_t, int32_t>> pairs;
     for (size_t i = 0; i + 1 < al.size(); ++i) {
         const double hi = prob[al[i]], lo = prob[al[i + 1]];
+        if (i >= 32 && hi < 0.005) break;
         if (hi != lo && hi - lo <= EM_NEAR_REL * hi) pairs.emplace_back(al[i], al[i + 1]);
     }
     if (pairs.empty()) return HGX_OK;
-    if (pairs.size() > 4096) { *uncertain = true; return HGX_OK; }         // (never seen; the exact run settles it either way)
     int rc = hgx_ensure_transposed(c, st);
     if (rc) return rc;
-    const size_t row = (size_t)c->c64 * 8;
-    std::vector<uint64_t> ra((size_t)c->c64), rb((size_t)c->c64);
-    for (auto &pr : pairs) {
-        rc = hgx_d2h(ra.data(), (const char *)c->d_bitsT + (size_t)pr.first * row, row, st);
-        if (!rc) rc = hgx_d2h(rb.data(), (const char *)c->d_bitsT + (size_t)pr.second * row, row, st);
-        if (!rc) rc = hgx_sync(st);
-        if (rc) return rc;
-        if (ra != rb) { *uncertain = true; return HGX_OK; }                // different membership, abundances too close to call
-    }
+    // the candidates' membership rows in ONE gather, one copy and one wait (it was two blocking row copies and a stream sync per pair)
+    std::vector<int32_t> ids;
+    for (auto &pr : pairs) { ids.push_back(pr.first); ids.push_back(pr.second); }
+    const size_t c64 = (size_t)c->c64;
+    DevBuf b_ids, b_rows;
+    ALLOC(b_ids, ids.size() * 4);
+    ALLOC(b_rows, ids.size() * c64 * 8);
+    { int rc_ = hgx_h2d(b_ids.p, ids.data(), ids.size() * 4, st); if (rc_) return rc_; }
+    const long n_words = (long)ids.size() * (long)c64;
+    hipLaunchKernelGGL(k_gather_rows, dim3(nblk(n_words, 256)), dim3(256), 0, st, (const uint64_t *)c->d_bitsT, (int)c64, b_ids.as<int32_t>(), (int)ids.size(),
+                       b_rows.as<uint64_t>());
+    HIPCHK(hipGetLastError());
+    std::vector<uint64_t> rows(ids.size() * c64);
+    { int rc_ = hgx_d2h(rows.data(), b_rows.p, rows.size() * 8, st); if (rc_) return rc_; }
+    { int rc_ = hgx_sync(st); if (rc_) return rc_; }
+    for (size_t k = 0; k < pairs.size(); ++k)
+        if (memcmp(&rows[(2 * k) * c64], &rows[(2 * k + 1) * c64], c64 * 8) != 0) { *uncertain = true; return HGX_OK; }     // different membership, too close to call
     return HGX_OK;
 }
 
@@ -1800,9 +1794,6 @@ static int em_impl_inner(const hgx_classes *cc, int32_t n_alleles, int32_t remov
     }
     MatVec rows{c->d_bitsC, C, w64c, A};
     MatVec cols{c->d_bitsTC, A, c->c64, C};
-#ifdef HGX_LAB
-#include "lab/hgx_em_impl_mfma_setup.inc"        // MFMA operand order of both matrices (back-end 2)
-#endif
 
     DevBuf b_part, b_part_c;
     if (g_backend == 0 || g_backend == 3) {
@@ -1820,19 +1811,12 @@ static int em_impl_inner(const hgx_classes *cc, int32_t n_alleles, int32_t remov
         unsigned *const slab_counters = (unsigned *)(scal + S_N);                   // zeroed with the scalars above
         rows.M = c->d_wrow; rows.n_pad = Cp; rows.part = b_part.as<double>(); rows.counters = slab_counters;
         cols.M = c->d_wcol; cols.n_pad = A; cols.part = b_part_c.as<double>(); cols.counters = slab_counters;
-#ifdef HGX_LAB
-        if (hgx_test_switch("em_lut4") && !HGX_LAB_SWITCH("em_persist") && !hgx_test_switch("em_grid"))
-            rows.narrow = cols.narrow = 1;      // the narrow-table form (k_lut4, lab): a workgroup owns its rows for the whole of K
-#endif
         if (!rows.narrow && !HGX_LAB_SWITCH("em_persist") && !hgx_switch_has("em_skip", "defer")) {
             // the rows pass stops at its slab partials; the cols pass turns them into w_c in its prologue
             rows.defer_combine = 1;
             cols.src_part = rows.part; cols.src_slabs = w64c / 8; cols.src_pad = Cp; cols.src_count = c->d_count;
         }
     }
-#ifdef HGX_LAB
-#include "lab/hgx_em_impl_persist.inc"        // the persistent whole-iteration EM (k_em_persist)
-#endif
     // ---- resident-block path (k_em_grid): the block grid must be co-resident, one workgroup per CU ----------------
     // two resident grids that together need more CUs than the chip has could each hold a part and wait forever: grids reserve
     // their CUs from a process-wide budget and one that does not fit runs per pass instead
@@ -1847,9 +1831,6 @@ static int em_impl_inner(const hgx_classes *cc, int32_t n_alleles, int32_t remov
     bool grid = false;
     // opt-in (HGX_EM_GRID=1), or for small block grids only (HGX_EM_GRID_MAX workgroups: many small tasks in flight are bound by
     // the launch rate, and one launch replaces ~66)
-#ifdef HGX_LAB
-#include "lab/hgx_em_impl_grid.inc"        // the resident-block EM (k_em_grid) taking over a small enough problem
-#endif
     int grid_launches = 0;
     std::vector<Timed> timed;
     const int slot_rows = A <= 8 * BLOCK ? 0 : 1, slot_cols = C <= 8 * BLOCK ? 2 : 3;
@@ -1917,28 +1898,10 @@ static int em_impl_inner(const hgx_classes *cc, int32_t n_alleles, int32_t remov
                                        (int)LUT_LDS));
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut_rows_fused<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)LUT_LDS));
-#ifdef HGX_LAB
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut4<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L4_LDS));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_lut4<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L4_LDS));
-#endif
         });
     }
     auto rows_fused = [&](int fm, const double *qb, const uint8_t *prb, double *out_v, uint8_t *out_p) -> int {
         FuseArgs fz{q1, qb, pr1, prb, out_v, out_p, scal, scal_alt, remove_low ? 1 : 0};
-#ifdef HGX_LAB
-        if (rows.narrow) {
-            const int R = l4_rows(rows.n_rows);
-            const dim3 g4((unsigned)((rows.n_rows + R - 1) / R));
-            if (fm == 0) hipLaunchKernelGGL(k_lut4<2>, g4, dim3(BLOCK), L4_LDS, st, rows.M, rows.n_rows, rows.n_pad, rows.n_words, A, R,
-                                            (const double *)nullptr, (const uint8_t *)nullptr, 0, c->d_count, (const double *)nullptr,
-                                            (const uint8_t *)nullptr, (const double *)nullptr, wc, (uint8_t *)nullptr, (double *)nullptr, 0, p, pr, fz);
-            else hipLaunchKernelGGL(k_lut4<3>, g4, dim3(BLOCK), L4_LDS, st, rows.M, rows.n_rows, rows.n_pad, rows.n_words, A, R,
-                                    (const double *)nullptr, (const uint8_t *)nullptr, 0, c->d_count, (const double *)nullptr,
-                                    (const uint8_t *)nullptr, (const double *)nullptr, wc, (uint8_t *)nullptr, (double *)nullptr, 0, p, pr, fz);
-            std::swap(scal, scal_alt);
-            return HGX_OK;
-        }
-#endif
         const dim3 grid(rows.n_words / 8, (rows.n_rows + BLOCK - 1) / BLOCK);
         if (fm == 0) hipLaunchKernelGGL(k_lut_rows_fused<0>, grid, dim3(BLOCK), LUT_LDS, st, rows.M, rows.n_pad, A, p, pr, fz, rows.part);
         else hipLaunchKernelGGL(k_lut_rows_fused<1>, grid, dim3(BLOCK), LUT_LDS, st, rows.M, rows.n_pad, A, p, pr, fz, rows.part);
@@ -1965,15 +1928,6 @@ static int em_impl_inner(const hgx_classes *cc, int32_t n_alleles, int32_t remov
             HIPCHK(hipMemsetAsync(b_gfl.p, 0, ((size_t)3 * G * GK_FLAG_STRIDE + 32) * 4, st));
             Timed t{nullptr, nullptr, 4};
             if (g_timing) { t.a = pool_event(); t.b = pool_event(); timed.push_back(t); }
-#ifdef HGX_LAB
-            if (A <= 5 * BLOCK) {
-                if (t.a) hipExtLaunchKernelGGL(k_em_grid<5>, dim3(G), dim3(BLOCK), GK_LDS, st, t.a, t.b, 0, ga);
-                else hipLaunchKernelGGL(k_em_grid<5>, dim3(G), dim3(BLOCK), GK_LDS, st, ga);
-            } else {
-                if (t.a) hipExtLaunchKernelGGL(k_em_grid<8>, dim3(G), dim3(BLOCK), GK_LDS, st, t.a, t.b, 0, ga);
-                else hipLaunchKernelGGL(k_em_grid<8>, dim3(G), dim3(BLOCK), GK_LDS, st, ga);
-            }
-#endif
             HIPCHK(hipGetLastError());
         }
         // test switch em_graph: the batch's launches captured into a hipGraph and launched as one (measurement of what a graph

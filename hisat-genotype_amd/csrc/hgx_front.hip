@@ -1715,6 +1715,10 @@ int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &de
     HIPCHK(hipStreamSynchronize(st));
     lap("SAM lines + region filter");
     const uint32_t n_kept = h.n_kept;
+    // QNAME is at most 254 characters (SAM specification 1.4; a BAM's l_read_name caps it at 255 with the NUL): a longer "name" is a
+    // malformed or tab-less line -- its length would become the number of 8-byte sort passes below (a 1 MB line: ~130 000 of them)
+    // before the record stage declined it anyway.  The host stages take the call and word the error.
+    if (h.max_klen > 254) { *declined = HGX_FE_DECLINE_RECORD; return HGX_OK; }
     ALLOC(b_lines, std::max<size_t>(n_kept, 1) * sizeof(LineRef));
     uint32_t *idx = b_idx.as<uint32_t>();
     if (n_kept > 1) {

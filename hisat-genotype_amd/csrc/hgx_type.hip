@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -90,30 +91,95 @@ void sorted_result(const std::vector<double> &prob, const std::vector<int32_t> &
     stable_desc(o.allele, o.prob, o.exact);
 }
 
-// ---- stream pairs ---------------------------------------------------------------------------------------------------
-struct StreamSet { int dev = -1; hipStream_t em = nullptr, gene = nullptr; hipEvent_t fork = nullptr; };
+// ---- stream sets --------------------------------------------------------------------------------------------------------
+// A typing call runs on three streams: the caller's (scoring), an EM stream (the exon level's chain of short dependent launches: the
+// critical path) and a gene-side stream (chip-filling kernels beside it).  Callers that run side by side (samples in flight, the
+// loci of class I) each hold a set.
+// What the hardware does with them (measured on MI355X / ROCm 7.2, tools/stream_probe.py and tools/stream_conflicts.py, round 6):
+//   * the runtime keeps up to four hardware queues PER PRIORITY and hands a new stream the least-used one of its priority; two
+//     streams on one queue run strictly one behind the other (two 150 us spin kernels: 324 us instead of 173);
+//   * beyond that, queues fall into four LANES in creation order across all priorities (creation i and i + 4 share one): two CHAINS
+//     of short dependent kernels on one lane take 415 us instead of 180 -- each launch waits for the other chain's -- while a chain
+//     beside a few big kernels on its lane loses almost nothing (180 -> 200-230 us).
+// So what must not share a lane is the EM chains of callers in flight: with two samples in flight a step costs 2.4 ms per sample
+// when their EM streams are four creations apart and 1.6 ms when they are not.  Rounds 4-5 arranged that by CREATION ORDER with
+// placeholder streams -- right for a fresh process, wrong as soon as the caller (torch, RCCL, its own streams) had created a
+// different number of streams first; the driver saw class I at 4.45 ms in one round and 5.03 in the next.
+// Round 6 MEASURES: a candidate stream runs a chain of eight 10 us one-wavefront kernels alone and interleaved with the same chain
+// on a representative of every lane known so far; the lane where its chain takes > 1.5x as long is its lane.  A set's EM stream is
+// the candidate on the lane with the fewest EM streams, its gene-side stream a candidate on a lane without EM streams (or at least
+// not its own); up to four candidates each (a creation moves the runtime on by one lane), the others are destroyed again.  State
+// per DEVICE.  Test switch streams = "unplaced": first candidates, no probes.
+struct StreamSet { int dev = -1; hipStream_t em = nullptr, gene = nullptr; hipEvent_t fork = nullptr; int cls_em = -1, cls_gene = -1, id = 0; };
+struct DevStreams {
+    std::vector<StreamSet> free;          // taken and given back at the front: a caller alone always gets the same set
+    std::vector<hipStream_t> reps;        // one kept stream per lane seen so far
+    std::vector<int> em_in_class;         // EM streams of this device's sets per lane
+    int n_sets = 0;
+    double probe_ms = 0.0;                // time spent placing (hgx_stream_sets_info reports it)
+    int probes = 0;
+};
 std::mutex g_ss_mu;
-std::vector<StreamSet> g_ss_free;
-hipStream_t g_first_em = nullptr;      // the EM stream of the first, unplaced set
+std::map<int, DevStreams> g_ss;           // by device
 
-// A caller alone gets one stream set, made on first use: an EM stream and a gene-side stream created back to back.  When a SECOND
-// caller arrives while the first set is out -- samples in flight, the loci of class I side by side -- three more sets are made in one
-// run of twelve consecutive stream creations.  The runtime hands its hardware queues (four per process) out in creation order,
-// round robin, and streams that share a hardware queue run one behind the other.  What must not share a queue: the EM chains of samples
-// that run side by side -- short dependent launches on the critical path -- and a set's EM chain with its own gene side.  Creations
-// c0 .. c11 sit on queues k, k+1, k+2, k+3, k, ... whatever k the caller's own streams left us at: the EM streams are c0, c1, c2
-// (three different queues), the gene-side streams c3, c7, c11 (the fourth queue: chip-filling kernels that serialise without loss);
-// c4-c6 and c8-c10 are placeholders that only advance the runtime's counter.  The first set goes to the back of the list.
-// Measured (round 5, bench.py): with every set made on first use the mapping depended on the caller's history -- the three loci of
-// class I took 4.1 ... 4.7 ms per step in a fresh process and 5.8 ms behind a phase that had made its streams in another order, two /
-// three samples in flight 2.4 / 1.7 ms per sample instead of 1.6 / 1.5; with the EM streams first and ALL gene streams right behind
-// them (an EM chain and its own gene side on one queue) a single sample took 2.6 ms instead of 2.05.  And the run is only made for
-// callers that need it: eight PROCESSES with a run of streams each typed 65 files a second through one GPU instead of 116 (the
-// hardware's queue slots are shared by all processes).
-// Sets are taken and given back at the front of the list: a caller alone always gets the same set.
-static std::vector<hipStream_t> g_ss_placeholders;
-static int g_ss_out = 0;                 // sets handed out at the moment
-static bool g_ss_run_made = false;
+__global__ void k_ss_spin(long long ticks, long long *stamp) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    if (stamp) { stamp[0] = t0; stamp[1] = wall_clock64(); }
+}
+constexpr long long SS_SPIN_TICKS = 15000;            // 150 us of the 100 MHz constant clock (the queue probe of the diagnostics)
+constexpr int SS_CHAIN = 8;
+static long long *ss_stamps() {
+    static thread_local long long *stamps = nullptr;                       // pinned, the kernels write it directly
+    if (!stamps && hipHostMalloc((void **)&stamps, 64 * sizeof(long long), hipHostMallocDefault) != hipSuccess) stamps = nullptr;
+    return stamps;
+}
+// microseconds (the kernels' own clock) stream a's chain of SS_CHAIN 10 us kernels takes, alone (b == nullptr) or with the same chain
+// launched on b in between: best of `tries`
+static double ss_chain_us(DevStreams &D, hipStream_t a, hipStream_t b, int tries) {
+    long long *st = ss_stamps();
+    if (!st) return 0.0;
+    double best = 1e30;
+    for (int k = 0; k < tries; ++k) {
+        (void)hipStreamSynchronize(a);
+        if (b) (void)hipStreamSynchronize(b);
+        for (int i = 0; i < SS_CHAIN; ++i) {
+            hipLaunchKernelGGL(k_ss_spin, dim3(1), dim3(64), 0, a, 1000LL, st + 2 * i);
+            if (b) hipLaunchKernelGGL(k_ss_spin, dim3(1), dim3(64), 0, b, 1000LL, st + 32 + 2 * i);
+        }
+        (void)hipStreamSynchronize(a);
+        if (b) (void)hipStreamSynchronize(b);
+        D.probes++;
+        best = std::min(best, (double)(st[2 * SS_CHAIN - 1] - st[0]) / 100.0);
+    }
+    return best;
+}
+// true = kernels on a and b run strictly one behind the other (the same hardware queue), by the kernels' own clock stamps: any try
+// that shows the two 150 us spins side by side settles it (diagnostics; the placement looks at lanes, which include queues)
+static bool ss_same_queue(DevStreams &D, hipStream_t a, hipStream_t b) {
+    long long *stamps = ss_stamps();
+    if (!stamps) return false;
+    for (int k = 0; k < 3; ++k) {
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        stamps[0] = stamps[1] = stamps[2] = stamps[3] = 0;
+        hipLaunchKernelGGL(k_ss_spin, dim3(1), dim3(64), 0, a, SS_SPIN_TICKS, stamps);
+        hipLaunchKernelGGL(k_ss_spin, dim3(1), dim3(64), 0, b, SS_SPIN_TICKS, stamps + 2);
+        (void)hipStreamSynchronize(a);
+        (void)hipStreamSynchronize(b);
+        D.probes++;
+        if (stamps[2] < stamps[1] && stamps[0] < stamps[3]) return false;    // the two intervals overlap: different queues
+    }
+    return true;
+}
+// lane of stream s among D.reps (-1: none of them: a lane nobody of ours is on yet)
+static int ss_class_of(DevStreams &D, hipStream_t s) {
+    if (D.reps.empty()) return -1;
+    const double alone = ss_chain_us(D, s, nullptr, 2);
+    for (size_t c = 0; c < D.reps.size(); ++c)
+        if (ss_chain_us(D, s, D.reps[c], 2) > 1.5 * alone) return (int)c;
+    return -1;
+}
 static int make_gene_stream(hipStream_t *out, int least) {
     // The gene side's chip-filling kernels (k_pair_classes_x2, k_verify_ht) run beside the EM chain of the exon level; a 1 024-thread
     // workgroup of an EM pass is only placed on a CU that has sixteen free wave slots and 135 KB of LDS, so with the gene side free to
@@ -128,59 +194,87 @@ static int make_gene_stream(hipStream_t *out, int least) {
         HIPCHK(hipStreamCreateWithPriority(out, hipStreamNonBlocking, least));
     return HGX_OK;
 }
-// n = 1: a set for a caller alone; n = 3: the run for callers side by side.  The EM chain gets the highest priority, the overlapped
-// side work the lowest.
-static int make_stream_sets(int dev, int n, std::vector<StreamSet> &sets) {
+// One more set for device `dev`.  The EM chain gets the highest priority, the overlapped side work the lowest.
+static int make_stream_set(int dev, DevStreams &D, StreamSet &set) {
+    const auto t0 = std::chrono::steady_clock::now();
     int least = 0, greatest = 0;
     HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    sets.assign((size_t)n, StreamSet());
-    for (int i = 0; i < n; ++i) { sets[i].dev = dev; HIPCHK(hipStreamCreateWithPriority(&sets[i].em, hipStreamNonBlocking, greatest)); }
-    for (int i = 0; i < n; ++i) {
-        { const int rc_ = make_gene_stream(&sets[i].gene, least); if (rc_) return rc_; }
-        HIPCHK(hipEventCreateWithFlags(&sets[i].fork, hipEventDisableTiming));
-        for (int k = 0; k < 3 && i + 1 < n; ++k) {
-            hipStream_t ph = nullptr;
-            HIPCHK(hipStreamCreateWithFlags(&ph, hipStreamNonBlocking));
-            g_ss_placeholders.push_back(ph);
+    const bool probe = !hgx_switch_has("streams", "unplaced");
+    set = StreamSet();
+    set.dev = dev;
+    std::vector<hipStream_t> spare;
+    struct Spare { std::vector<hipStream_t> &v; ~Spare() { for (hipStream_t x : v) (void)hipStreamDestroy(x); } } spare_guard{spare};
+    auto keep_class = [&](hipStream_t s, int cls) -> int {                // a kept stream on a new lane becomes its representative
+        if (cls >= 0) return cls;
+        D.reps.push_back(s);
+        D.em_in_class.push_back(0);
+        return (int)D.reps.size() - 1;
+    };
+    // EM stream: the lane fewest EM streams of this device are on (a new lane counts as unused)
+    // (the runtime has four queues per priority, each on the lane it was created on: if the process' high-priority queues sit on
+    // two lanes only -- it depends on what was created between them -- no high-priority candidate ever reaches a third one; the EM
+    // stream then takes the normal or the low priority: a lane of its own is worth more than the priority, tools/stream_ab.sh)
+    int best_cls = -2, best_load = 1 << 30;
+    const int prios[3] = {greatest, (least + greatest) / 2, least};
+    for (int pk = 0; pk < (probe && D.n_sets > 0 ? 3 : 1) && best_load > 0; ++pk)
+        for (int k = 0; k < (probe && D.n_sets > 0 ? 4 : 1); ++k) {
+            hipStream_t c = nullptr;
+            HIPCHK(hipStreamCreateWithPriority(&c, hipStreamNonBlocking, prios[pk]));
+            const int cls = probe ? ss_class_of(D, c) : -1;
+            const int load = cls < 0 ? 0 : D.em_in_class[(size_t)cls];
+            if (load < best_load) {
+                if (set.em) spare.push_back(set.em);
+                set.em = c; best_cls = cls; best_load = load;
+            } else spare.push_back(c);
+            if (best_load == 0) break;
         }
+    set.cls_em = probe ? keep_class(set.em, best_cls) : -1;
+    if (probe) D.em_in_class[(size_t)set.cls_em]++;
+    // gene-side stream: a lane without EM streams; failing that, any lane but this set's own EM lane
+    int g_cls = -2, g_score = -1;
+    for (int k = 0; k < (probe ? 4 : 1); ++k) {
+        hipStream_t c = nullptr;
+        { const int rc_ = make_gene_stream(&c, least); if (rc_) return rc_; }
+        const int cls = probe ? ss_class_of(D, c) : -1;
+        const int score = !probe ? 2 : (cls < 0 || D.em_in_class[(size_t)cls] == 0) ? 2 : (cls != set.cls_em ? 1 : 0);
+        if (score > g_score) {
+            if (set.gene) spare.push_back(set.gene);
+            set.gene = c; g_cls = cls; g_score = score;
+        } else spare.push_back(c);
+        if (g_score == 2) break;
     }
+    set.cls_gene = probe ? keep_class(set.gene, g_cls) : -1;
+    HIPCHK(hipEventCreateWithFlags(&set.fork, hipEventDisableTiming));
+    set.id = D.n_sets++;
+    D.probe_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return HGX_OK;
 }
 int acquire_streams(StreamSet &s) {
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> g(g_ss_mu);
-    for (int round = 0; round < 2; ++round) {
-        // (a second caller beside the first: the placed run before anything else is handed out)
-        const bool want_run = g_ss_out > 0 && !g_ss_run_made;
-        if (!want_run)
-            for (size_t i = 0; i < g_ss_free.size(); ++i)
-                if (g_ss_free[i].dev == dev) { s = g_ss_free[i]; g_ss_free.erase(g_ss_free.begin() + i); g_ss_out++; return HGX_OK; }
-        // creating a stream takes milliseconds: done once, then recycled
-        std::vector<StreamSet> made;
-        const int rc = make_stream_sets(dev, want_run || g_ss_run_made ? 3 : 1, made);
-        if (rc) {                                                            // nothing half-made is handed out or leaked
-            for (auto &m : made) {
-                if (m.em) (void)hipStreamDestroy(m.em);
-                if (m.gene) (void)hipStreamDestroy(m.gene);
-                if (m.fork) (void)hipEventDestroy(m.fork);
-            }
-            return rc;
-        }
-        if (made.size() == 3) g_ss_run_made = true;
-        else if (!g_first_em) g_first_em = made[0].em;
-        g_ss_free.insert(g_ss_free.begin(), made.begin(), made.end());      // (in front of a first, unplaced set)
+    DevStreams &D = g_ss[dev];
+    if (!D.free.empty()) { s = D.free.front(); D.free.erase(D.free.begin()); return HGX_OK; }
+    // creating (and placing) a set takes milliseconds: done once, then recycled
+    StreamSet made;
+    const int rc = make_stream_set(dev, D, made);
+    if (rc) {                                                                // nothing half-made is handed out or leaked
+        if (made.em) (void)hipStreamDestroy(made.em);
+        if (made.gene) (void)hipStreamDestroy(made.gene);
+        if (made.fork) (void)hipEventDestroy(made.fork);
+        return rc;
     }
-    hgx_set_error("no stream set");
-    return HGX_EHIP;
+    s = made;
+    return HGX_OK;
 }
 void release_streams(const StreamSet &s) {
     if (s.dev < 0) return;
     std::lock_guard<std::mutex> g(g_ss_mu);
-    g_ss_out--;
-    // a set of the placed run goes back to the front; the first, unplaced one stays behind them once the run exists
-    if (g_ss_run_made && !g_ss_free.empty() && s.em == g_first_em) g_ss_free.push_back(s);
-    else g_ss_free.insert(g_ss_free.begin(), s);
+    DevStreams &D = g_ss[s.dev];
+    // sets go back in the order they were made (the first, best-placed ones in front)
+    auto it = D.free.begin();
+    while (it != D.free.end() && it->id < s.id) ++it;
+    D.free.insert(it, s);
 }
 
 struct GateHold {                    // a held gate that is released exactly once
@@ -607,6 +701,93 @@ int type_impl(hgx_typing *t, const hgx_locus *loc, const hgx_index *ix, const hg
 }   // namespace
 
 extern "C" int hgx_typing_destroy(hgx_typing *t) { delete t; return HGX_OK; }
+
+// diagnostic (tools/stream_probe.py): n fresh streams (priority per stream: 1 = highest, 0 = lowest), the time two 150 us spin kernels
+// take back to back on every pair of them -- ~150 us side by side, ~300 one behind the other; us[n][n], the diagonal = one kernel alone
+extern "C" int hgx_stream_probe_matrix(int32_t n, const int32_t *high_prio, double *us) {
+    ARGCHK(n > 0 && n <= 64 && us);
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    std::vector<hipStream_t> st((size_t)n, nullptr);
+    struct Free { std::vector<hipStream_t> &v; ~Free() { for (hipStream_t x : v) if (x) (void)hipStreamDestroy(x); } } fr{st};
+    for (int i = 0; i < n; ++i) HIPCHK(hipStreamCreateWithPriority(&st[i], hipStreamNonBlocking, high_prio && high_prio[i] ? greatest : least));
+    for (int rep = 0; rep < 2; ++rep)
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
+                (void)hipStreamSynchronize(st[i]);
+                (void)hipStreamSynchronize(st[j]);
+                const auto t0 = std::chrono::steady_clock::now();
+                hipLaunchKernelGGL(k_ss_spin, dim3(1), dim3(64), 0, st[i], SS_SPIN_TICKS, (long long *)nullptr);
+                if (i != j) hipLaunchKernelGGL(k_ss_spin, dim3(1), dim3(64), 0, st[j], SS_SPIN_TICKS, (long long *)nullptr);
+                (void)hipStreamSynchronize(st[i]);
+                (void)hipStreamSynchronize(st[j]);
+                const double t = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+                us[(size_t)i * n + j] = rep == 0 ? t : std::min(us[(size_t)i * n + j], t);
+            }
+    return HGX_OK;
+}
+
+// diagnostic: do kernels on these two streams run one behind the other (1) or side by side (0)?  (tools/stream_conflicts.py)
+extern "C" int hgx_stream_probe_pair(void *a, void *b, int32_t *same_queue) {
+    ARGCHK(same_queue);
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    DevStreams tmp;
+    *same_queue = ss_same_queue(tmp, (hipStream_t)a, (hipStream_t)b) ? 1 : 0;
+    return HGX_OK;
+}
+// diagnostic: a chain of 16 one-wavefront 10 us kernels on `light`, alone (us[0]) and (us[1]) beside `other` running mode 0: ONE
+// launch of 131 072 tiny workgroups (dispatch pressure), mode 1: the same chain, launches interleaved (what the placement measures)
+__global__ void k_ss_tiny(unsigned *sink) { if (threadIdx.x == 1u << 20) *sink = 1; }
+extern "C" int hgx_stream_probe_chain(void *light, void *other, int32_t mode, double *us) {
+    ARGCHK(us && light && other && (mode == 0 || mode == 1));
+    long long *stamps = ss_stamps();
+    if (!stamps) { hgx_set_error("pinned allocation failed"); return HGX_ENOMEM; }
+    hipStream_t l = (hipStream_t)light, h = (hipStream_t)other;
+    for (int with = 0; with < 2; ++with) {
+        double best = 1e30;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipStreamSynchronize(l);
+            (void)hipStreamSynchronize(h);
+            if (with && mode == 0) hipLaunchKernelGGL(k_ss_tiny, dim3(131072), dim3(64), 0, h, (unsigned *)nullptr);
+            for (int k = 0; k < 16; ++k) {
+                hipLaunchKernelGGL(k_ss_spin, dim3(1), dim3(64), 0, l, 1000LL, stamps + 2 * k);
+                if (with && mode == 1) hipLaunchKernelGGL(k_ss_spin, dim3(1), dim3(64), 0, h, 1000LL, stamps + 32 + 2 * (k & 7));
+            }
+            (void)hipStreamSynchronize(l);
+            (void)hipStreamSynchronize(h);
+            best = std::min(best, (double)(stamps[31] - stamps[0]) / 100.0);
+        }
+        us[with] = best;
+    }
+    return HGX_OK;
+}
+// ... and the streams of the sets that are free at the moment (em, gene per set), in hand-out order
+extern "C" int hgx_stream_sets_streams(void **streams, int32_t cap, int32_t *n_sets) {
+    ARGCHK(streams && n_sets);
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(g_ss_mu);
+    DevStreams &D = g_ss[dev];
+    *n_sets = 0;
+    for (size_t i = 0; i < D.free.size() && (int32_t)(2 * i + 1) < cap; ++i) { streams[2 * i] = D.free[i].em; streams[2 * i + 1] = D.free[i].gene; (*n_sets)++; }
+    return HGX_OK;
+}
+
+// what the stream placement of the current device looks like (bench.py prints it; tests assert on it)
+extern "C" int hgx_stream_sets_info(int32_t *n_sets, int32_t *n_classes, int32_t *n_probes, double *probe_ms, int32_t *classes, int32_t cap) {
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(g_ss_mu);
+    DevStreams &D = g_ss[dev];
+    if (n_sets) *n_sets = D.n_sets;
+    if (n_classes) *n_classes = (int32_t)D.reps.size();
+    if (n_probes) *n_probes = D.probes;
+    if (probe_ms) *probe_ms = D.probe_ms;
+    if (classes)                                    // (em class, gene class) of the sets that are free at the moment, in hand-out order
+        for (size_t i = 0; i < D.free.size() && (int32_t)(2 * i + 1) < cap; ++i) { classes[2 * i] = D.free[i].cls_em; classes[2 * i + 1] = D.free[i].cls_gene; }
+    return HGX_OK;
+}
 
 extern "C" int hgx_type_dbatch(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, const hgx_dbatch *db,
                                const hgx_type_opts *opts, void *stream) {

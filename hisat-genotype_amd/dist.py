@@ -517,13 +517,20 @@ def parse_shard(pl, sam_shard, comm, num_editdist=2, error_correction=True, allo
             else:
                 comm.allreduce_sum(_flag_only(pl, 2))
     status = np.array([0 if state["local"] is None else 1], np.int64)
-    comm.allreduce_sum(status)
-    if state["local"] is not None:
-        raise state["local"]
-    if status[0] != 0:
-        raise RuntimeError("another rank of this locus failed in its front-end")
-    if db is None:
-        db = engine.DeviceBatch(batch, stream)
+    try:
+        comm.allreduce_sum(status)
+        if state["local"] is not None:
+            raise state["local"]
+        if status[0] != 0:
+            raise RuntimeError("another rank of this locus failed in its front-end")
+        if db is None:
+            db = engine.DeviceBatch(batch, stream)
+    except BaseException:
+        #  a batch this rank DID parse stays in HBM until the garbage collector finds it -- in a retry loop over loci or
+        # samples that is memory growing exactly while other ranks are failing: give it back before the raise
+        if db is not None:
+            db.close()
+        raise
     return batch, db
 
 

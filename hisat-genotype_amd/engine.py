@@ -119,6 +119,16 @@ class Alignment:
             pass
 
 
+def stream_sets_info():
+    """Stream placement of the current device (hgx_stream_sets_info): {'sets', 'queue_classes', 'probes', 'probe_ms', 'free_sets': [(em
+    class, gene class)]}."""
+    n, nc, npb, ms = C.c_int32(), C.c_int32(), C.c_int32(), C.c_double()
+    cls = np.full(64, -9, np.int32)
+    capi.check(capi.lib().hgx_stream_sets_info(C.byref(n), C.byref(nc), C.byref(npb), C.byref(ms), capi.ptr(cls), C.c_int32(64)))
+    pairs = [(int(cls[2 * i]), int(cls[2 * i + 1])) for i in range(32) if cls[2 * i] != -9]
+    return {"sets": n.value, "queue_classes": nc.value, "probes": npb.value, "probe_ms": round(ms.value, 2), "free_sets": pairs}
+
+
 def front_last():
     """(route, decline code) of the calling thread's last hgx_parse_*_dev / hgx_type_file call: route 2 = the device took the
     records themselves (fields, filters, key grouping as kernels), 1 = the host made the key table and the device the rest,

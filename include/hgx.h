@@ -619,6 +619,18 @@ int hgx_emx_get_timing(int fast, double *ms_total, long long *launches, long lon
  * is re-run on one workgroup -- same sums in the same orders, same bits, ~7x slower.  Counts since the library was loaded: problems
  * launched on a cluster, and those that fell back (also said on stderr under HGX_TYPE_PROFILE). */
 int hgx_emx_cluster_stats(long long *cluster_problems, long long *fallbacks);
+/* The stream sets of the current device (hgx_type.hip: an EM stream and a gene-side stream per caller in flight, placed on hardware
+ * queues by MEASURED overlap, not by creation order): sets made so far, queue classes seen, probe launches and the time they took,
+ * and (em class, gene class) of the sets free at the moment, in hand-out order (`classes`: 2 ints per set, `cap` ints of room). */
+/* diagnostic: n fresh streams (high_prio[i] != 0: highest priority, else lowest); us[i][j] = microseconds two 150 us one-wavefront spin
+ * kernels take when launched back to back on streams i and j (the diagonal: one kernel alone) -- what the placement measures */
+int hgx_stream_probe_matrix(int32_t n, const int32_t *high_prio, double *us);
+int hgx_stream_probe_pair(void *stream_a, void *stream_b, int32_t *same_queue);          /* 1: one behind the other, 0: side by side */
+/* a chain of 16 short kernels on `light`, alone (us[0]) and beside `other` (us[1]) running mode 0: one launch of 131 072 tiny workgroups,
+ * mode 1: the same chain with interleaved launches -- two chains on one LANE take ~2.3x as long (what the placement measures) */
+int hgx_stream_probe_chain(void *light_stream, void *other_stream, int32_t mode, double *us);
+int hgx_stream_sets_streams(void **streams /* em, gene per free set */, int32_t cap, int32_t *n_sets);
+int hgx_stream_sets_info(int32_t *n_sets, int32_t *n_classes, int32_t *n_probes, double *probe_ms, int32_t *classes, int32_t cap);
 /* hgx_em / hgx_em_ordered calls (default arithmetic) whose table-lookup result held two alleles of DIFFERENT class membership closer
  * than 1e-8 relative and was therefore recomputed in the reference's own order of operations (common:1282-1410: a plain stable
  * sort on the reference's own doubles decides such an order), since the library was loaded.                                    */

@@ -19,8 +19,8 @@ def _setup(name):
 
 @pytest.mark.parametrize("name", ["hla_7000", "hla_mid_real"])
 def test_em_backends_agree(name):
-    """The int8-MFMA mat-vec (exact integer accumulation of 128-bit fixed-point planes) and the table-lookup mat-vec
-    (256 subset sums per group of 8 columns, one LDS lookup per 8 matrix bits) against the EXEC-masked FP64 VALU mat-vec:
+    """The table-lookup mat-vec (256 subset sums per group of 8 columns, one LDS lookup per 8 matrix bits) against the EXEC-masked
+    FP64 VALU mat-vec of round 1 (lab back-end 1):
     same iteration counts, abundances equal to rounding, on the reference's recorded EM inputs and on a big random one."""
     fx, t, pl = _setup(name)
     A = t["n_alleles"]
@@ -47,102 +47,14 @@ def test_em_backends_agree(name):
             engine.em_set_backend(1)
             p1, it1 = cl.em(A, low, ln)
             import os
-            for backend, persist in ((2, False), (3, False), (3, True)):   # int8 MFMA; table lookup: one launch per pass / persistent kernel
+            for backend in (3,):       # table lookup, one launch per pass (the int8-MFMA form and the persistent kernel lost twice: removed in round 6)
                 engine.em_set_backend(backend)
-                if persist:
-                    engine.test_switch("em_persist", "1")
-                try:
-                    p2, it2 = cl.em(A, low, ln)
-                finally:
-                    engine.test_switch("em_persist", None)
-                assert it1 == it2, (backend, persist, it1, it2)
+                p2, it2 = cl.em(A, low, ln)
+                assert it1 == it2, (backend, it1, it2)
                 assert np.array_equal(p1 < 0, p2 < 0)
-                assert np.max(np.abs(p1 - p2)) <= 1e-11, (backend, persist, np.max(np.abs(p1 - p2)))
+                assert np.max(np.abs(p1 - p2)) <= 1e-11, (backend, np.max(np.abs(p1 - p2)))
     finally:
         engine.em_set_backend(0)
-
-
-def test_em_grid_equals_per_pass():
-    """The resident-block EM (k_em_grid, opt-in: matrix blocks in registers for the whole launch, point-to-point flagged hand-offs between
-    the workgroups of a class chunk / an allele slab) keeps the summation orders of the one-launch-per-pass kernels: abundances
-    BIT-identical, same iteration counts, over block grids from 1 x 1 to 17 x 14, ragged last chunks and slabs, with and
-    without pruning and allele lengths; a grid that does not fit the chip falls back to the per-pass path."""
-    import os
-    rng = np.random.RandomState(77)
-    shapes = [(70, 300, 512), (1100, 700, 1024), (2500, 1500, 1536), (3000, 7000, 7168), (9000, 2600, 3072), (17000, 7000, 7168),
-              (16098, 4549, 7168), (21000, 7000, 7168)]
-    ran_grid = 0
-    for C_, A, a_pad in shapes:
-        w = a_pad // 64
-        rows = np.zeros((C_, w), np.uint64)
-        # classes the way typing produces them: a few allele "families", every class a family minus/plus some alleles
-        fam = rng.rand(12, A) < rng.choice([0.02, 0.2, 0.7], size=12)[:, None]
-        pick = rng.randint(0, 12, C_)
-        flip = rng.rand(C_, A) < 0.01
-        m = fam[pick] ^ flip
-        m[np.arange(C_), rng.randint(0, A, C_)] = True
-        rows[:, :] = np.packbits(np.pad(m, ((0, 0), (0, a_pad - A))), axis=1, bitorder="little").view(np.uint64).reshape(C_, w)
-        counts = rng.randint(1, 400, C_).astype(np.int64)
-        lens = rng.randint(2000, 3500, a_pad).astype(np.int32)
-        cl = engine.Classes.from_host(rows, counts, a_pad)
-        for low, use_len in ((True, False), (False, True), (True, True)):
-            ln = lens if use_len else None
-            p_ref, it_ref = cl.em(A, low, ln)
-            engine.em_set_timing(0)
-            engine.em_set_timing(1)
-            engine.test_switch("em_grid", "1")
-            try:
-                p, it = cl.em(A, low, ln)
-            finally:
-                engine.test_switch("em_grid", None)
-            launches = engine.em_get_timing()["k_em_grid"][1]
-            engine.em_set_timing(0)
-            ran_grid += launches > 0
-            assert it == it_ref, (C_, A, low, use_len, it, it_ref)
-            assert np.array_equal(p, p_ref), (C_, A, low, use_len, float(np.max(np.abs(p - p_ref))))
-            if C_ > 64 and C_ <= 9000:                      # (the biggest grids need 224 / 238 of the chip's CUs: taken when they fit)
-                assert launches > 0, (C_, A)
-            if C_ == 21000:
-                assert launches == 0
-    assert ran_grid >= 9
-
-
-def test_narrow_table_form_agrees_with_the_product_path():
-    """k_lut4 (round 4, lab: a workgroup owns its rows for the whole of K, 4-bit tables, no cross-workgroup combine -- measured 2.3x
-    SLOWER than the 8-bit slab form, tools/em_forms.py): same iteration counts, abundances within 1e-10, plain and fused steps,
-    one and several slabs in both passes."""
-    rng = np.random.RandomState(5)
-    for C_, A, a_pad in [(5000, 700, 1024), (9000, 2600, 3072), (16098, 4549, 7168), (4200, 6000, 6144)]:
-        w = a_pad // 64
-        fam = rng.rand(12, A) < rng.choice([0.02, 0.2, 0.7], size=12)[:, None]
-        m = fam[rng.randint(0, 12, C_)] ^ (rng.rand(C_, A) < 0.01)
-        m[np.arange(C_), rng.randint(0, A, C_)] = True
-        rows = np.packbits(np.pad(m, ((0, 0), (0, a_pad - A))), axis=1, bitorder="little").view(np.uint64).reshape(C_, w)
-        counts = rng.randint(1, 400, C_).astype(np.int64)
-        lens = rng.randint(2000, 3500, a_pad).astype(np.int32)
-        for low, use_len in ((True, False), (False, True)):
-            ln = lens if use_len else None
-            cl = engine.Classes.from_host(rows, counts, a_pad)
-            p_ref, it_ref = cl.em(A, low, ln)
-            for extra in ({}, {"l4_rows": 32}, {"em_skip": "fuse"}):
-                with engine.test_switches(em_lut4=1, **extra):
-                    cl2 = engine.Classes.from_host(rows, counts, a_pad)
-                    p, it = cl2.em(A, low, ln)
-                assert it == it_ref, (C_, A, low, use_len, extra, it, it_ref)
-                assert np.array_equal(p < 0, p_ref < 0)
-                assert np.max(np.abs(p - p_ref)) <= 1e-10, (C_, A, extra, float(np.max(np.abs(p - p_ref))))
-
-
-@pytest.mark.parametrize("n_alleles,n_vars,dense", [(700, 300, False), (5000, 700, False), (3000, 260, True)])
-def test_piece_compat_comparison_kernels(n_alleles, n_vars, dense):
-    """The L2-served kernel of round 1 and the LDS-tiled kernel of rounds 1-3 (lab code since round 4) against the definition and the
-    pattern form: the body of tests/test_gpu_parity.py::test_piece_compat_kernels_agree_with_the_definition with all three forms."""
-    import test_gpu_parity as tp
-    tp.COMPAT_FORMS = [{}, {"piece_tiled": 1}, {"piece_untiled": 1}]
-    try:
-        tp.test_piece_compat_kernels_agree_with_the_definition(n_alleles, n_vars, dense)
-    finally:
-        tp.COMPAT_FORMS = [{}]
 
 
 def test_round2_mid_size_em_is_the_reference_bit_for_bit(orc):
