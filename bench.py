@@ -1004,8 +1004,9 @@ def run_sample6(args):
         bamio.write_bam_native(bam, "".join(sams).encode(), [(loc.ref_allele, len(loc.backbone)) for loc in loci], sort_by_coordinate=True)
         rep_path = os.path.join(tmp, "assembly_graph-hla.sample.report")
 
-        def call(side_by_side=True, em_fast=False):
+        def call(side_by_side=True, em_fast=False, together=False):
             htyping.typing_options.loci_side_by_side, htyping.typing_options.em_fast = side_by_side, em_fast
+            htyping.typing_options.loci_together = together
             try:
                 t0 = time.perf_counter()
                 hgx.typing(False, os.path.join(tmp, "hla"), genes, "", True, set(), d["refGenes"], d["Genes"], d["Gene_names"], d["Gene_lengths"],
@@ -1013,16 +1014,24 @@ def run_sample6(args):
                            False, False, True, [], False, ["sample.fq"], bam, [], 150, 400, 1, False, 0, False, tmp, "NONE", False, 0)
                 dt = time.perf_counter() - t0
             finally:
-                htyping.typing_options.loci_side_by_side, htyping.typing_options.em_fast = True, False
+                htyping.typing_options.loci_side_by_side, htyping.typing_options.em_fast, htyping.typing_options.loci_together = True, False, False
             with open(rep_path) as f:
                 rep = f.read()
             return dt, [dict(p) for p in htyping.last_profile], rep
         hlocus.LOCUS_CACHE.clear()
         t_first, _, rep0 = call()
+        cl0 = engine.emx_cluster_stats()
         runs = sorted((call() for _ in range(5)), key=lambda r: r[0])
+        cl1 = engine.emx_cluster_stats()
         t_rep, prof, rep = runs[len(runs) // 2]
+        engine.test_switch("emx_cluster_lone", "0")           # the loci's EM #1 on one workgroup each (rounds 3-5's form), for comparison
+        try:
+            t_nocl = sorted(call()[0] for _ in range(3))[1]
+        finally:
+            engine.test_switch("emx_cluster_lone", None)
         t_seq = sorted(call(side_by_side=False)[0] for _ in range(3))[1]
         t_fast = sorted(call(em_fast=True)[0] for _ in range(3))[1]
+        tog = sorted((call(together=True) for _ in range(3)), key=lambda r: r[0])[1]
         # the old way: one hgx_type_file per locus (the file read and inflated six times), locus after locus
         pls = [hlocus.PackedLocus.cached_from_reference_dicts(g, "hla", d["refGenes"], d["Genes"], d["Gene_names"], d["Gene_lengths"], d["refGene_loci"],
                                                               d["Vars"], d["Var_list"], d["Links"]) for g in genes]
@@ -1050,12 +1059,17 @@ def run_sample6(args):
                 "entry": "hisatgenotype_amd.typing(<38 arguments>, locus_list = %s)" % genes},
             "reads_per_s": round(2 * n_pairs * len(loci) / t_rep, 1),
             "first_call_ms": round(t_first * 1e3, 2), "repeated_call_ms": round(t_rep * 1e3, 2),
+            "all_five_repeated_calls_ms": [round(r[0] * 1e3, 2) for r in runs],
+            "emx_cluster_problems_and_fallbacks_in_those_calls": [cl1[0] - cl0[0], cl1[1] - cl0[1]],
+            "reference_order_em_on_one_workgroup_per_locus_ms": round(t_nocl * 1e3, 2),
             "loci_one_after_the_other_ms": round(t_seq * 1e3, 2), "table_lookup_em_ms": round(t_fast * 1e3, 2),
             "one_hgx_type_file_per_locus_ms": round(t_old * 1e3, 2),
             "front_end_route_per_locus": {p["gene"]: p["front_end_route"] for p in prof},
             "alignment_open_ms": round(prof[0].get("alignment_open_ms_shared", 0.0), 3),
             "per_locus_ms": {p["gene"]: {"file_region_and_front_end": round(p["file_read_and_front_end_ms"], 3),
                                          "gpu_typing_and_result": round(p["gpu_typing_and_result_ms"], 3)} for p in prof},
+            "loci_parsed_side_by_side_then_typed_by_one_hgx_type_many_loci_call_ms": round(tog[0] * 1e3, 2),
+            "that_form_s_report_identical": keep(tog[2].split("\n")) == want,
             "report_sections_identical_to_the_loci_typed_alone": keep(rep.split("\n")) == want and keep(rep0.split("\n")) == want,
             "calls": {loc.gene: {"top2": top2[loc.gene], "true": smp, "correct": sorted(top2[loc.gene]) == sorted(smp)} for loc, smp in zip(loci, samples)},
         }

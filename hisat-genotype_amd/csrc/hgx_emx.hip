@@ -1265,7 +1265,8 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
     int n_plain_big = 0;
     for (int i = 0; i < n_jobs; ++i) n_plain_big += (!jobs[i].fast && !jobs[i].mask && (int64_t)jobs[i].C * jobs[i].a_pad >= (int64_t)512 * 4096) ? 1 : 0;
     const char *lone_sw = hgx_test_switch("emx_cluster_lone");
-    const bool lone_ok = clusters && n_jobs <= 4 && n_plain_big >= 1 && n_plain_big <= 2 && !(lone_sw && atoi(lone_sw) == 0);
+    // (up to eight of them side by side: the loci of ONE sample typed together by hgx_type_many_loci -- typing() over a locus_list)
+    const bool lone_ok = clusters && n_jobs <= 16 && n_plain_big >= 1 && n_plain_big <= 8 && !(lone_sw && atoi(lone_sw) == 0);
     auto wants_cluster = [&](const hgx_emx_job &J) {
         if (!clusters || J.fast || J.mask) return false;
         if (J.any_size && J.C > HGX_EMX_MAX_CLASSES) return true;

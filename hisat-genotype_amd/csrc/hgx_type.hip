@@ -1069,6 +1069,25 @@ extern "C" int hgx_many_create_sams(hgx_many **out, const hgx_locus *loc, const 
     return many_from_streams(out, loc, nullptr, nullptr, sams, n_bytes, n_tasks, opts, stream);
 }
 
+// ONE task's batch that is already resident (hgx_parse_*_dev, hgx_alignment_parse_dev) as a many-task batch of one task: the loci of
+// one sample go into hgx_type_many_loci this way -- the EMs of all of them in one launch.  Takes the batch over on success.
+extern "C" int hgx_many_from_dbatch(hgx_many **out, const hgx_locus *loc, hgx_dbatch *db, void *stream) {
+    ARGCHK(out && loc && db);
+    *out = nullptr;
+    ARGCHK((int32_t)loc->name_rank.size() == loc->A && (int32_t)loc->allele_len.size() == loc->A);
+    hgx_many *m = new hgx_many();
+    m->n_tasks = 1; m->A = loc->A; m->a_pad = loc->a_pad;
+    m->db = db;
+    m->pair_base = {0, db->n_pairs};
+    m->n_reads.push_back(db->n_reads);
+    m->n_pieces.push_back(db->n_pieces);
+    m->n_refs.push_back(db->n_refs);
+    const int rc = many_finish(m, loc, (hipStream_t)stream);
+    if (rc) { m->db = nullptr; hgx_many_destroy(m); return rc; }          // (the caller keeps its batch)
+    *out = m;
+    return HGX_OK;
+}
+
 // the merged batch of a many-task batch (tests, tools: hgx_dbatch_to_host on it) and its per-task extents; arrays of n_tasks (+ 1
 // for pair_base) entries or NULL
 extern "C" int hgx_many_tasks(const hgx_many *m, const hgx_dbatch **db, int32_t *pair_base, int32_t *n_reads, int32_t *n_pieces, int64_t *n_refs) {

@@ -245,6 +245,17 @@ class ManyBatch:
         self._dims()
         return self
 
+    @classmethod
+    def from_dbatch(cls, locus, dbatch, stream=None):
+        """hgx_many_from_dbatch: ONE task from a DeviceBatch the front end left in HBM (the batch moves into the ManyBatch: `dbatch` is
+        empty afterwards).  The loci of one sample go into typing.type_many_loci this way."""
+        self = cls.__new__(cls)
+        self.h = C.c_void_p()
+        capi.check(capi.lib().hgx_many_from_dbatch(C.byref(self.h), locus.h, dbatch.h, stream))
+        dbatch.h = None
+        self._dims()
+        return self
+
     def merged(self):
         """The merged device batch as a host Batch-like object (tests, tools): pieces, masks, pair_off, pair_ref."""
         db = C.c_void_p()

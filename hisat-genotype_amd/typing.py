@@ -31,6 +31,7 @@ class _TypingOptions:
     ~10 ms that way), True: table lookups (within 1e-8 of the reference, bar 1e-5; ~2 ms), None / -1: see typing._em_mode."""
     em_fast = False
     loci_side_by_side = True       # several loci of one typing() call: a host thread and stream per locus over ONE read of the file
+    loci_together = False          # ... their batches typed by ONE hgx_type_many_loci call instead (measured slower at six loci)
 
 
 typing_options = _TypingOptions()
@@ -537,10 +538,23 @@ def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partia
                                         profile=job[4], em_fast=typing_options.em_fast, alignment=al, stream=stream)
                 except BaseException as e:          # re-raised on the caller's thread, at this locus' place in the loop
                     job[6] = e
+            def parse_job(job, stream):
+                # phase 1 of the side-by-side form: this locus' records out of the resident file -> its piece batch in HBM
+                t0 = time.perf_counter()
+                try:
+                    job[7] = al.parse_dev(job[1], job[2], num_editdist=num_editdist, error_correction=error_correction,
+                                          allow_discordant=allow_discordant, simulation=simulation, base_locus=job[3], stream=stream)
+                    job[4]["front_end_route"] = list(engine.front_last())
+                except BaseException as e:
+                    job[6] = e
+                job[4]["file_read_and_front_end_ms"] = (time.perf_counter() - t0) * 1e3
             try:
-                if al is not None and al.resident and typing_options.loci_side_by_side:
+                if al is not None and al.resident and typing_options.loci_side_by_side and not typing_options.loci_together:
+                    # every locus' whole body -- its records out of the resident file, scoring, dedup, both EMs -- on a thread and
+                    # stream set of its own (the stream sets keep the loci's EM chains on different hardware lanes)
                     import threading
                     dev = capi.current_device()
+                    n_workers = min(len(jobs), 8)
 
                     def worker(k):
                         capi.set_device(dev)
@@ -549,12 +563,64 @@ def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partia
                         for job in jobs[k::n_workers]:
                             run_job(job, st)
                         capi.sync(st)
-                    n_workers = min(len(jobs), 8)
                     ths = [threading.Thread(target=worker, args=(k,)) for k in range(n_workers)]
                     for t in ths:
                         t.start()
                     for t in ths:
                         t.join()
+                elif al is not None and al.resident and typing_options.loci_side_by_side:
+                    # measured and NOT the default (bench.py sample6: 23.9 ms against 16.6): the loci parsed side by side, then typed
+                    # TOGETHER through hgx_type_many_loci (one task per locus: the many-task path's set-up costs more than one
+                    # launch for all EMs saves at six tasks)
+                    import threading
+                    dev = capi.current_device()
+                    for job in jobs:
+                        job.append(None)                    # [7]: the locus' device batch
+                    n_workers = min(len(jobs), 8)
+
+                    def worker(k):
+                        capi.set_device(dev)
+                        capi.set_stream_slot(("typing loci", k))
+                        st = capi.get_stream(2)
+                        for job in jobs[k::n_workers]:
+                            parse_job(job, st)
+                        capi.sync(st)
+                    ths = [threading.Thread(target=worker, args=(k,)) for k in range(n_workers)]
+                    for t in ths:
+                        t.start()
+                    for t in ths:
+                        t.join()
+                    # phase 2: every locus that has reads, typed TOGETHER (hgx_type_many_loci: scoring side by side, the EMs of all
+                    # loci in ONE launch -- a lone sizeable reference-order problem each: workgroup clusters side by side)
+                    t_ = time.perf_counter()
+                    live = [job for job in jobs if job[6] is None and job[7] is not None and job[7].n_reads > 0]
+                    for job in jobs:
+                        if job[6] is None and job not in live:
+                            job[5] = LocusResult()
+                    manies = []
+                    try:
+                        for job in live:
+                            manies.append(engine.ManyBatch.from_dbatch(job[1], job[7]))
+                        rows = type_many_loci([job[1] for job in live], manies, remove_low=remove_low_abundance_alleles,
+                                              em_fast=typing_options.em_fast) if live else []
+                        for job, row in zip(live, rows):
+                            job[5] = row[0]
+                    except (capi.HgxError, TypeError, KeyError):
+                        # a locus the reference would raise on (quirks Q3 / Q6): locus after locus instead, so that the loci before it
+                        # still get their report sections and the exception is this locus' own
+                        for job in jobs:
+                            if job[5] is None and job[6] is None:
+                                run_job(job)
+                                if job[6] is not None:
+                                    break
+                    finally:
+                        for m in manies:
+                            m.close()
+                        for job in jobs:
+                            if job[7] is not None:
+                                job[7].close()
+                    for job in jobs:
+                        job[4]["gpu_typing_all_loci_ms_shared"] = (time.perf_counter() - t_) * 1e3
                 else:
                     for job in jobs:
                         run_job(job)
@@ -563,7 +629,7 @@ def typing(simulation, full_path_base_fname, locus_list, genotype_genome, partia
             finally:
                 if al is not None:
                     al.close()
-            for test_Gene_names, pl, _, _, prof, res, err in jobs:
+            for test_Gene_names, pl, _, _, prof, res, err, *_rest in jobs:
                 if not getattr(pl, "cached", False):
                     pl.close()
                 if err is not None:

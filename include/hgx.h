@@ -570,6 +570,9 @@ int hgx_many_create_files(hgx_many **out, const hgx_locus *loc, const char *cons
                           int32_t n_tasks, const hgx_parse_opts *opts, void *stream);
 int hgx_many_create_sams(hgx_many **out, const hgx_locus *loc, const char *const *sams, const size_t *n_bytes, int32_t n_tasks,
                          const hgx_parse_opts *opts, void *stream);
+/* ... or ONE task from a batch that is already resident (hgx_parse_sam_dev / hgx_parse_alignment_file_dev / hgx_alignment_parse_dev):
+ * the loci of one sample typed together by hgx_type_many_loci (typing_core.py:370).  The hgx_many takes `db` over on success. */
+int hgx_many_from_dbatch(hgx_many **out, const hgx_locus *loc, hgx_dbatch *db, void *stream);
 /* the merged device batch of `m` (owned by it) and the tasks' extents: pair_base [n_tasks + 1], the others [n_tasks]; any may be NULL */
 int hgx_many_tasks(const hgx_many *m, const hgx_dbatch **db, int32_t *pair_base, int32_t *n_reads, int32_t *n_pieces, int64_t *n_refs);
 int hgx_many_destroy(hgx_many *m);

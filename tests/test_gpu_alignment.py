@@ -170,7 +170,7 @@ def _three_loci(tmp_path, n_pairs=1500):
     return loci, bam, d, expect
 
 
-@pytest.mark.parametrize("side_by_side", [True, False])
+@pytest.mark.parametrize("side_by_side", [True, False, "together"])
 def test_typing_three_loci_from_one_file(tmp_path, side_by_side):
     """typing() (38 arguments, typing_core.py:249-286) with locus_list = [A, B, C] on ONE coordinate-sorted BAM of all three loci: the
     file is opened once, every locus goes through the device front end, and the report holds the three sections in locus_list order
@@ -179,13 +179,15 @@ def test_typing_three_loci_from_one_file(tmp_path, side_by_side):
     loci, bam, d, expect = _three_loci(tmp_path)
     T = sys.modules["hisatgenotype_amd.typing"]
     old = T.typing_options.loci_side_by_side
-    T.typing_options.loci_side_by_side = side_by_side
+    T.typing_options.loci_side_by_side = bool(side_by_side)
+    T.typing_options.loci_together = side_by_side == "together"      # (parsed side by side, typed by ONE hgx_type_many_loci call: hgx_many_from_dbatch)
     try:
         hgx.typing(False, str(tmp_path / "hla"), ["A", "B", "C"], "", True, set(), d["refGenes"], d["Genes"], d["Gene_names"], d["Gene_lengths"],
                    d["refGene_loci"], d["Vars"], d["Var_list"], d["Links"], [["hisat2", "graph"]], 2, False, "assembly_graph", True, True, False,
                    False, True, [], False, ["sample.fq"], bam, [], 150, 400, 1, False, 0, False, str(tmp_path), "NONE", True, 0)
     finally:
         T.typing_options.loci_side_by_side = old
+        T.typing_options.loci_together = False
     assert [p["gene"] for p in T.last_profile] == ["A", "B", "C"]
     assert all(p["front_end_route"] == [2, 0] for p in T.last_profile), T.last_profile
     rep = open(str(tmp_path / "assembly_graph-hla.sample.report")).read().split("\n")
