@@ -73,7 +73,7 @@ SYMBOLS = [
     "hgx_index_broadcast", "hgx_allreduce_sum_u32", "hgx_allreduce_sum_i64", "hgx_classes_allgather",
     "hgx_classes_pack_rows", "hgx_classes_merge_gathered", "hgx_rccl_stats",
     "hgx_keyset_create", "hgx_keyset_dims", "hgx_keyset_fill", "hgx_keyset_destroy",
-    "hgx_many_from_dbatch", "hgx_alignment_open", "hgx_alignment_dims", "hgx_alignment_parse_dev", "hgx_alignment_close", "hgx_stream_sets_info", "hgx_stream_probe_matrix", "hgx_stream_probe_pair", "hgx_stream_probe_chain", "hgx_stream_sets_streams",
+    "hgx_many_from_dbatch", "hgx_alignment_open", "hgx_alignment_dims", "hgx_alignment_parse_dev", "hgx_alignment_close", "hgx_stream_sets_info", "hgx_stream_create_placed", "hgx_stream_probe_matrix", "hgx_stream_probe_pair", "hgx_stream_probe_chain", "hgx_stream_sets_streams",
     "hgx_parse_sam_dev", "hgx_parse_alignment_file_dev", "hgx_front_last", "hgx_dbatch_to_host",
     "hgx_emx_cluster_stats", "hgx_em_tie_reruns",
 ]
@@ -158,7 +158,9 @@ def get_stream(i):
     key = (_current_device, getattr(_slot, "k", threading.get_ident()), i)     # per host thread (or named slot): samples in flight never share a stream
     if key not in _streams:
         p = C.c_void_p()
-        check(lib().hgx_stream_create_prio(C.byref(p), C.c_int(1 if i == 0 else 0)))
+        # worker main streams (i == 2) run chains of short kernels (the device front end): placed on the lane with the fewest chains
+        fn = lib().hgx_stream_create_placed if i == 2 else lib().hgx_stream_create_prio
+        check(fn(C.byref(p), C.c_int(1 if i == 0 else 0)))
         _streams[key] = p
     return _streams[key]
 

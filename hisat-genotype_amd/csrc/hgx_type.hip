@@ -115,6 +115,7 @@ struct DevStreams {
     std::vector<StreamSet> free;          // taken and given back at the front: a caller alone always gets the same set
     std::vector<hipStream_t> reps;        // one kept stream per lane seen so far
     std::vector<int> em_in_class;         // EM streams of this device's sets per lane
+    std::vector<int> caller_in_class;     // callers' own placed streams per lane (hgx_stream_create_placed: front-end chains run there)
     int n_sets = 0;
     double probe_ms = 0.0;                // time spent placing (hgx_stream_sets_info reports it)
     int probes = 0;
@@ -176,8 +177,11 @@ static bool ss_same_queue(DevStreams &D, hipStream_t a, hipStream_t b) {
 static int ss_class_of(DevStreams &D, hipStream_t s) {
     if (D.reps.empty()) return -1;
     const double alone = ss_chain_us(D, s, nullptr, 2);
-    for (size_t c = 0; c < D.reps.size(); ++c)
-        if (ss_chain_us(D, s, D.reps[c], 2) > 1.5 * alone) return (int)c;
+    for (size_t c = 0; c < D.reps.size(); ++c) {
+        double beside = ss_chain_us(D, s, D.reps[c], 1);              // (one try when the answer is clear: ~1.0x or ~2.3x)
+        if (beside > 1.25 * alone && beside < 1.9 * alone) beside = std::min(beside, ss_chain_us(D, s, D.reps[c], 2));
+        if (beside > 1.5 * alone) return (int)c;
+    }
     return -1;
 }
 static int make_gene_stream(hipStream_t *out, int least) {
@@ -208,6 +212,7 @@ static int make_stream_set(int dev, DevStreams &D, StreamSet &set) {
         if (cls >= 0) return cls;
         D.reps.push_back(s);
         D.em_in_class.push_back(0);
+        D.caller_in_class.push_back(0);
         return (int)D.reps.size() - 1;
     };
     // EM stream: the lane fewest EM streams of this device are on (a new lane counts as unused)
@@ -216,17 +221,20 @@ static int make_stream_set(int dev, DevStreams &D, StreamSet &set) {
     // stream then takes the normal or the low priority: a lane of its own is worth more than the priority, tools/stream_ab.sh)
     int best_cls = -2, best_load = 1 << 30;
     const int prios[3] = {greatest, (least + greatest) / 2, least};
-    for (int pk = 0; pk < (probe && D.n_sets > 0 ? 3 : 1) && best_load > 0; ++pk)
+    // (once all four lanes are known, the best a candidate can do is the least-loaded lane's count: no point in trying further for 0)
+    int target = 0;
+    if (D.reps.size() >= 4) { target = 1 << 30; for (size_t c = 0; c < D.reps.size(); ++c) target = std::min(target, 16 * D.em_in_class[c] + std::min(15, D.caller_in_class[c])); }
+    for (int pk = 0; pk < (probe && D.n_sets > 0 ? 3 : 1) && best_load > target; ++pk)
         for (int k = 0; k < (probe && D.n_sets > 0 ? 4 : 1); ++k) {
             hipStream_t c = nullptr;
             HIPCHK(hipStreamCreateWithPriority(&c, hipStreamNonBlocking, prios[pk]));
             const int cls = probe ? ss_class_of(D, c) : -1;
-            const int load = cls < 0 ? 0 : D.em_in_class[(size_t)cls];
+            const int load = cls < 0 ? 0 : 16 * D.em_in_class[(size_t)cls] + std::min(15, D.caller_in_class[(size_t)cls]);   // EM chains first, then callers' chains
             if (load < best_load) {
                 if (set.em) spare.push_back(set.em);
                 set.em = c; best_cls = cls; best_load = load;
             } else spare.push_back(c);
-            if (best_load == 0) break;
+            if (best_load <= target) break;
         }
     set.cls_em = probe ? keep_class(set.em, best_cls) : -1;
     if (probe) D.em_in_class[(size_t)set.cls_em]++;
@@ -249,6 +257,47 @@ static int make_stream_set(int dev, DevStreams &D, StreamSet &set) {
     D.probe_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return HGX_OK;
 }
+}   // namespace
+// A stream for a CALLER that runs chains of short kernels of its own beside other callers' (a worker thread's main stream: the device
+// front end of its sample or locus is such a chain): created on the lane with the fewest chains so far -- EM streams of the stream
+// sets and other callers' placed streams.  Plain hgx_stream_create_prio streams land wherever the runtime's creation order puts them.
+extern "C" int hgx_stream_create_placed(void **st, int high_priority) {
+    ARGCHK(st != nullptr);
+    *st = nullptr;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    std::lock_guard<std::mutex> g(g_ss_mu);
+    DevStreams &D = g_ss[dev];
+    const auto t0 = std::chrono::steady_clock::now();
+    const bool probe = !hgx_switch_has("streams", "unplaced");
+    std::vector<hipStream_t> spare;
+    struct Spare { std::vector<hipStream_t> &v; ~Spare() { for (hipStream_t x : v) (void)hipStreamDestroy(x); } } spare_guard{spare};
+    hipStream_t best = nullptr;
+    int best_cls = -2, best_load = 1 << 30;
+    int target = 0;
+    if (D.reps.size() >= 4) { target = 1 << 30; for (size_t c = 0; c < D.reps.size(); ++c) target = std::min(target, D.em_in_class[c] + D.caller_in_class[c]); }
+    for (int k = 0; k < (probe ? 4 : 1); ++k) {
+        hipStream_t c = nullptr;
+        HIPCHK(hipStreamCreateWithPriority(&c, hipStreamNonBlocking, high_priority ? greatest : least));
+        const int cls = probe ? ss_class_of(D, c) : -1;
+        const int load = cls < 0 ? 0 : D.em_in_class[(size_t)cls] + D.caller_in_class[(size_t)cls];
+        if (load < best_load) {
+            if (best) spare.push_back(best);
+            best = c; best_cls = cls; best_load = load;
+        } else spare.push_back(c);
+        if (best_load <= target) break;
+    }
+    if (probe) {
+        if (best_cls < 0) { D.reps.push_back(best); D.em_in_class.push_back(0); D.caller_in_class.push_back(0); best_cls = (int)D.reps.size() - 1; }
+        D.caller_in_class[(size_t)best_cls]++;
+    }
+    D.probe_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    *st = (void *)best;
+    return HGX_OK;
+}
+namespace {
 int acquire_streams(StreamSet &s) {
     int dev = 0;
     HIPCHK(hipGetDevice(&dev));

@@ -627,6 +627,9 @@ int hgx_emx_cluster_stats(long long *cluster_problems, long long *fallbacks);
  * and (em class, gene class) of the sets free at the moment, in hand-out order (`classes`: 2 ints per set, `cap` ints of room). */
 /* diagnostic: n fresh streams (high_prio[i] != 0: highest priority, else lowest); us[i][j] = microseconds two 150 us one-wavefront spin
  * kernels take when launched back to back on streams i and j (the diagonal: one kernel alone) -- what the placement measures */
+/* a stream for a caller whose own work is a chain of short kernels (a worker thread's main stream: the device front end of its sample
+ * or locus): created on the hardware lane with the fewest chains so far; destroy with hgx_stream_destroy */
+int hgx_stream_create_placed(void **stream, int high_priority);
 int hgx_stream_probe_matrix(int32_t n, const int32_t *high_prio, double *us);
 int hgx_stream_probe_pair(void *stream_a, void *stream_b, int32_t *same_queue);          /* 1: one behind the other, 0: side by side */
 /* a chain of 16 short kernels on `light`, alone (us[0]) and beside `other` (us[1]) running mode 0: one launch of 131 072 tiny workgroups,

@@ -54,7 +54,7 @@ json.dump({"n_pairs": d["config"]["pairs_per_gpu"], "a_pad": 7168,
            "raw_KB": raw, "hbm_bytes_per_launch": hb}, open(f"{dst}/traffic.json", "w"), indent=1)
 print(d["ms_per_step"], d["value"], d["roofline"]["kernel"], d["roofline"]["frac"], d["roofline"]["traffic"])
 for k, w in d.get("workloads", {}).items():
-    print(k, w["ms_per_step"], w["value"], (w["roofline"] or {}).get("kernel"), (w["roofline"] or {}).get("frac"))
+    print(k, w.get("ms_per_step"), w.get("value"), (w.get("roofline") or {}).get("kernel"), (w.get("roofline") or {}).get("frac"))
 for stats, u in ((f"{dst}/{R}_final_kernel_stats.csv", f"{src}/bench_under_rocprof.json"), (f"{dst}/{R}_final_panel64_kernel_stats.csv", f"{src}/panel_under_rocprof.json")):
     uj = json.load(open(u))
     n_steps = uj["steps"] + uj["warmup"]
