@@ -1405,17 +1405,14 @@ def main():
     pl = hl.PackedLocus.from_synth(loc)
     comm_kind, bcast_bytes = None, None
     if use_dist:
-        # rank 0's packed link matrix reaches every GPU over RCCL / xGMI: hgx_index_broadcast on this library's own communicator
-        # (device block to device block, in place); with gloo -- or if that communicator cannot be made -- torch.distributed
+        # rank 0's packed link matrix reaches every GPU over RCCL / xGMI: torch.distributed.broadcast on a tensor that ALIASES the index'
+        # device block (device to device, in place; dist.broadcast_index).  The weak-scaling line needs nothing else from the fabric, so
+        # it stays on torch's own communicator -- the one multi-GPU path of this repository that PyTorch itself exercises everywhere;
+        # this library's own ncclComm_t (dist.RcclComm: hgx_index_broadcast, hgx_classes_allgather, ...) carries the per-step
+        # exchanges of --workload class1, where a host bounce per step would be the measurement (make_comm)
         from hisatgenotype_amd import dist as hdist
-        wcomm, comm_kind = make_comm(dist)
-        if comm_kind == "rccl":
-            rccl_stats(reset=True)
-            wcomm.broadcast_index(pl, 0)
-            bcast_bytes = rccl_stats()[1]
-            wcomm.close()
-        else:
-            bcast_bytes = hdist.broadcast_index(pl, src=0)
+        bcast_bytes = hdist.broadcast_index(pl, src=0)
+        comm_kind = "torch-nccl broadcast into the index' device block" if DIST_DEV == "cuda" else "torch-gloo (host control plane)"
     else:
         pl.index()
     sample = synth.pick_sample(loc, 101 + rank)

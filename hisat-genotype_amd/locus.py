@@ -11,6 +11,9 @@ import numpy as np
 
 from . import capi
 
+import threading as _threading
+
+_INDEX_LOCK = _threading.Lock()
 _TYPE = {"insertion": capi.VAR_INSERTION, "single": capi.VAR_SINGLE, "deletion": capi.VAR_DELETION}
 
 
@@ -237,11 +240,13 @@ class PackedLocus:
         return groups
 
     def index(self):
-        """Device-resident hgx_index (created on first use on the current device)."""
+        """Device-resident hgx_index (created on first use on the current device; a cached locus may be asked by several threads at once)."""
         if self._index is None:
-            h = C.c_void_p()
-            capi.check(capi.lib().hgx_index_from_locus(C.byref(h), self.h))
-            self._index = h
+            with _INDEX_LOCK:
+                if self._index is None:
+                    h = C.c_void_p()
+                    capi.check(capi.lib().hgx_index_from_locus(C.byref(h), self.h))
+                    self._index = h
         return self._index
 
     def alternatives_text(self):
