@@ -1402,7 +1402,10 @@ static int emx_run(hgx_emx_job *jobs, int n_jobs, hipStream_t st, std::vector<hg
             if (!wants_cluster(J)) continue;
             const int Cw = (int)(((size_t)J.C + 63) / 64);
             const int per = std::max(2, std::min(64, seats / std::max(1, std::min(n_cl, seats / 2))));
-            int want = std::max(2, std::min(per, (Cw + 3) / 4));
+            // (a class tile per SIMD for the huge problems; a mid-size one -- <= 4 096 classes -- gains up to two tiles per workgroup:
+            // 1 730 classes x 4 500 alleles: 4 workgroups 9.9 ms per call, 7: 6.9, 14: 5.4, 28: 5.05, 56: 5.0, tools/dropin_profile.py)
+            int want = std::max(2, std::min(per, Cw <= 64 ? (Cw + 1) / 2 : (Cw + 3) / 4));
+            if (const char *wsw = hgx_test_switch("emx_cluster_wg")) want = std::max(2, std::min(std::min(per, 64), atoi(wsw)));   // (measurement: workgroups per cluster)
             if (cl_launches.empty() || first + want > seats) { cl_launches.push_back({}); first = 0; }
             tasks[t].cluster = want;
             tasks[t].cl_first = first;

@@ -17,7 +17,9 @@ fx = gu.load(name)
 pl = hl.PackedLocus.from_synth(fx["_locus"])
 pl.index()
 sam = fx["sam"].encode()
-for front in (None, "device", "host"):
+if os.environ.get("CLUSTER_WG"):
+    engine.test_switch("emx_cluster_wg", os.environ["CLUSTER_WG"])
+for front in (None, "device", "host")[:1 if os.environ.get("CLUSTER_WG") else 3]:
     with engine.test_switches(**({"front": front} if front else {})):
         for em_fast in (False, True):
             ts = []
