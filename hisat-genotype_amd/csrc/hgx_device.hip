@@ -152,7 +152,11 @@ extern "C" int hgx_stream_create_prio(void **st, int high_priority) {
     *st = (void *)s;
     return HGX_OK;
 }
-extern "C" int hgx_stream_destroy(void *st) { if (st) HIPCHK(hipStreamDestroy((hipStream_t)st)); return HGX_OK; }
+bool hgx_ss_forget_stream(void *stream);      // hgx_type.hip: placed streams (hgx_stream_create_placed) are known to the stream placement
+extern "C" int hgx_stream_destroy(void *st) {
+    if (st && !hgx_ss_forget_stream(st)) HIPCHK(hipStreamDestroy((hipStream_t)st));
+    return HGX_OK;
+}
 extern "C" int hgx_event_create(void **ev) {
     ARGCHK(ev != nullptr);
     hipEvent_t e;

@@ -116,6 +116,7 @@ struct DevStreams {
     std::vector<hipStream_t> reps;        // one kept stream per lane seen so far
     std::vector<int> em_in_class;         // EM streams of this device's sets per lane
     std::vector<int> caller_in_class;     // callers' own placed streams per lane (hgx_stream_create_placed: front-end chains run there)
+    std::map<hipStream_t, int> caller_cls;  // ... and which lane each of them is on (hgx_stream_destroy gives the lane back)
     int n_sets = 0;
     double probe_ms = 0.0;                // time spent placing (hgx_stream_sets_info reports it)
     int probes = 0;
@@ -292,10 +293,26 @@ extern "C" int hgx_stream_create_placed(void **st, int high_priority) {
     if (probe) {
         if (best_cls < 0) { D.reps.push_back(best); D.em_in_class.push_back(0); D.caller_in_class.push_back(0); best_cls = (int)D.reps.size() - 1; }
         D.caller_in_class[(size_t)best_cls]++;
+        D.caller_cls[best] = best_cls;
     }
     D.probe_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     *st = (void *)best;
     return HGX_OK;
+}
+// hgx_stream_destroy asks: a placed caller stream gives its lane back; one that REPRESENTS a lane (later probes run beside it) is kept
+// alive by the library instead of being destroyed -- true = do not destroy
+bool hgx_ss_forget_stream(void *stream) {
+    std::lock_guard<std::mutex> g(g_ss_mu);
+    for (auto &kv : g_ss) {
+        DevStreams &D = kv.second;
+        auto it = D.caller_cls.find((hipStream_t)stream);
+        if (it == D.caller_cls.end()) continue;
+        if (D.caller_in_class[(size_t)it->second] > 0) D.caller_in_class[(size_t)it->second]--;
+        D.caller_cls.erase(it);
+        for (hipStream_t r : D.reps) if (r == (hipStream_t)stream) return true;
+        return false;
+    }
+    return false;
 }
 namespace {
 int acquire_streams(StreamSet &s) {

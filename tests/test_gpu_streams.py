@@ -85,6 +85,18 @@ WORKER = textwrap.dedent('''
                 same = C.c_int32()
                 capi.check(capi.lib().hgx_stream_probe_pair(ems[i], ems[j], C.byref(same)))
                 assert same.value == 0
+    # placed caller streams may be destroyed: one that represents a lane is kept alive inside the library, later placements still probe beside it
+    made = []
+    for k in range(5):
+        p = C.c_void_p()
+        capi.check(capi.lib().hgx_stream_create_placed(C.byref(p), C.c_int(0)))
+        made.append(p)
+    for p in made:
+        capi.check(capi.lib().hgx_stream_destroy(p))
+    p = C.c_void_p()
+    capi.check(capi.lib().hgx_stream_create_placed(C.byref(p), C.c_int(0)))
+    again = hgx.type_locus(pl, sams[0], stream=p)
+    assert again.gene_prob == alone[0].gene_prob
     print("placed ok", n_foreign, kind, info)
 ''') % ROOT
 
