@@ -619,8 +619,9 @@ def run_class1(args, rank, local_rank, world, dist):
     groups = hdist.assign_ranks_to_loci([args.pairs] * len(loci), world)
     comms, comm_kinds = {}, {}
     if dist is not None:                                        # every rank creates every sub-group, in the same order
+        force_comm = os.environ.get("HGX_FORCE_DIST") == "comm"       # (tests: the exchange path of a sharded locus with a group of ONE rank)
         for i in sorted(groups):
-            if len(groups[i]) > 1:
+            if len(groups[i]) > 1 or force_comm:
                 g = dist.new_group(groups[i])
                 if rank in groups[i]:
                     comms[i], comm_kinds[loci[i].gene] = make_comm(dist, g)
@@ -784,7 +785,7 @@ def run_class1(args, rank, local_rank, world, dist):
         sharded_ok = bool(tt.item() > 0.5)
         whole_sam.clear()
     e2e_shards = None
-    if dist is not None and not args.no_e2e and any(len(g) > 1 for g in groups.values()):
+    if dist is not None and not args.no_e2e and (any(len(g) > 1 for g in groups.values()) or (comms and shard_bam)):
         # (EVERY rank enters: the barrier and the reductions below are on the world group; a rank without a sharded locus has no calls to make)
         # sharded loci, files -> result: every rank of a group types its own BAM shard through dist.type_locus_sharded (device
         # inflate / walk / sort, device front end, pileup all-reduce in HBM, class-table all-gather, EMs) -- all ranks at once

@@ -174,3 +174,40 @@ def test_bench_class1_body_with_sharded_loci_on_a_shared_gpu(n):
     assert cfg["exchange"]["collectives_per_step"] >= 3 and cfg["exchange"]["bytes_received_per_step"] > cfg["exchange"]["bytes_sent_per_step"] > 0
     assert cfg["front_end_route_of_my_shards"]["A"][0] == 2         # rank 0's shard went through the device front end
     assert cfg["e2e_shards"]["device_front_end_on_every_rank_and_results_identical_to_the_resident_path"] is True
+
+
+def _bench_nccl_world1(args, force):
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", HGX_FORCE_DIST=force, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + args, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    return json.loads(lines[0])
+
+
+def test_bench_nccl_body_with_a_world_of_one():
+    """The nccl form of the multi-rank body on the one GPU there is: torch.distributed over RCCL with ONE rank (HGX_FORCE_DIST) -- process
+    group on the device, the index broadcast on a tensor aliasing the index block, the max / sum reductions on device tensors, the
+    per-rank file -> result leg."""
+    line = _bench_nccl_world1(["--pairs", "20000", "--steps", "2", "--warmup", "1", "--no-workloads"], "1")
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and cfg["comm_kind"].startswith("torch-nccl") and cfg["index_broadcast_bytes"] > 1_000_000
+    assert sorted(cfg["top2"]) == sorted(cfg["true_alleles"]) and cfg["device_front_end_batch_identical_to_host"] is True
+    assert line["e2e"]["results_identical_to_hbm_path_on_every_rank"] is True
+
+
+def test_bench_class1_exchanges_through_the_library_s_own_rccl_communicator():
+    """bench.py --workload class1 under nccl with every locus given a communicator of its own (a group of ONE rank: HGX_FORCE_DIST=comm):
+    make_comm() must come back with dist.RcclComm (`comm_kind: rccl`), and the per-step exchanges -- hgx_classes_allgather of both
+    levels, the totals -- run on device buffers through the C-ABI (`exchange` counts them from hgx_rccl_stats); the results equal the
+    unsharded path's."""
+    line = _bench_nccl_world1(["--workload", "class1", "--pairs", "30000", "--steps", "2", "--warmup", "1", "--check-unsharded", "--no-cpu-baseline"], "comm")
+    cfg = line["config"]
+    assert cfg["comm_kind"] == {"A": "rccl", "B": "rccl", "C": "rccl"}, cfg["comm_kind"]
+    assert cfg["sharded_equals_unsharded"] is True and all(c["correct"] for c in cfg["calls"].values())
+    ex = cfg["exchange"]
+    assert ex["collectives_per_step"] >= 9 and ex["bytes_sent_per_step"] > 100_000          # 3 loci x (2 x 2 all-gathers + the totals)
+    assert all(r[0] == 2 for r in cfg["front_end_route_of_my_shards"].values())
+    assert cfg["e2e_shards"]["device_front_end_on_every_rank_and_results_identical_to_the_resident_path"] is True
