@@ -219,3 +219,61 @@ def test_open_once_is_the_same_batch_as_the_per_path_call(tmp_path):
                 assert np.array_equal(getattr(ha, k), getattr(hb, k)), (loc.gene, k)
             assert (ha.n_reads, ha.n_pairs) == (hb.n_reads, hb.n_pairs)
             pl.close()
+
+
+def test_typing_options_table_lookup_em_writes_the_same_report(tmp_path):
+    """hgx.typing_options.em_fast = True (table-lookup EM, <= 1e-8 of the reference's doubles): the report -- counts, ranks, abundances at the
+    reference's two decimals -- is the default arithmetic's, text for text."""
+    capi.set_device(0)
+    loci, bam, d, expect = _three_loci(tmp_path)
+    T = sys.modules["hisatgenotype_amd.typing"]
+    reps = []
+    for fast in (False, True):
+        T.typing_options.em_fast = fast
+        try:
+            hgx.typing(False, str(tmp_path / "hla"), ["A", "B", "C"], "", True, set(), d["refGenes"], d["Genes"], d["Gene_names"], d["Gene_lengths"],
+                       d["refGene_loci"], d["Vars"], d["Var_list"], d["Links"], [["hisat2", "graph"]], 2, False, "assembly_graph", True, True, False,
+                       False, True, [], False, ["sample.fq"], bam, [], 150, 400, 1, False, 0, False, str(tmp_path), "NONE", True, 0)
+        finally:
+            T.typing_options.em_fast = False
+        reps.append([l for l in open(str(tmp_path / "assembly_graph-hla.sample.report")).read().split("\n") if not l.startswith("#")])
+    assert reps[0] == reps[1] and sum("abundance" in l for l in reps[0]) >= 6
+
+
+@pytest.mark.parametrize("side_by_side", [True, False])
+def test_typing_raises_at_the_failing_locus_after_the_reports_before_it(tmp_path, side_by_side):
+    """Three CODIS loci in one file; the SECOND sample is homozygous with identical reads: ONE compatibility class, on which the reference
+    raises TypeError (quirk Q3, typing_core.py:1784-1787).  Side by side or locus after locus, typing() raises that TypeError -- and the
+    report holds the first locus' section, not the third's (the reference's loop never got there)."""
+    capi.set_device(0)
+    specs = [("D8S1179", "TCTA", 19, 7), ("TH01", "AATG", 12, 4), ("FGA", "CTTT", 30, 16)]
+    loci, sams = [], []
+    for k, (gene, unit, mx, mn) in enumerate(specs):
+        loc = synth.make_str_like_locus(gene=gene, unit=unit, max_repeats=mx, min_repeats=mn, flank=170, seed=60 + k, var_id_base=100 * k)
+        names = [a for a in loc.allele_names if "BACKBONE" not in a]
+        sample = [names[1]] if k == 1 else [names[2], names[-3]]
+        sams.append(synth.simulate_sam_fast(loc, sample, 1 if k == 1 else 900, read_len=100, frag_len=(200, 300), err_rate=0.0 if k == 1 else 0.002, seed=3 * k + 2))
+        loci.append(loc)
+    one = hl.PackedLocus.from_synth(loci[1])
+    with pytest.raises(TypeError):
+        hgx.type_locus(one, sams[1])                            # (the case is what it is meant to be)
+    refs = [(loc.ref_allele, len(loc.backbone)) for loc in loci]
+    sam_path = str(tmp_path / "s.sam")
+    with open(sam_path, "w") as f:
+        f.write("".join("@SQ\tSN:%s\tLN:%d\n" % r for r in refs) + "".join(sams))
+    d = {k: {} for k in ("refGenes", "Genes", "Gene_names", "Gene_lengths", "refGene_loci", "Vars", "Var_list", "Links")}
+    for loc in loci:
+        for k, v in loc.reference_dicts().items():
+            d[k].update(v)
+    T = sys.modules["hisatgenotype_amd.typing"]
+    T.typing_options.loci_side_by_side = side_by_side
+    try:
+        with engine.test_switches(front="device"):              # (the file is small: forced resident, so that the side-by-side form is what runs)
+            with pytest.raises(TypeError):
+                hgx.typing(False, str(tmp_path / "codis"), [loc.gene for loc in loci], "", True, set(), d["refGenes"], d["Genes"], d["Gene_names"],
+                           d["Gene_lengths"], d["refGene_loci"], d["Vars"], d["Var_list"], d["Links"], [["hisat2", "graph"]], 2, False, "assembly_graph",
+                           True, True, False, False, True, [], False, ["sample.fq"], sam_path, [], 100, 250, 1, False, 0, False, str(tmp_path), "NONE", True, 0)
+    finally:
+        T.typing_options.loci_side_by_side = True
+    rep = open(str(tmp_path / "assembly_graph-codis.sample.report")).read()
+    assert "D8S1179" in rep and "FGA*" not in rep and rep.count("pairs are aligned") == 1
