@@ -424,7 +424,9 @@ class LocusCache:
 
     Two keys.  The IDENTITY key is the tuple of id()s of the per-gene dict objects a call passes (the entry holds references
     to them, so an id cannot be recycled while the entry lives) together with a cheap fingerprint -- the container sizes and
-    the total number of (variant, allele) links -- that catches an index edited in place between calls.  A miss there falls
+    the total number of (variant, allele) links -- that catches an index edited in place between calls when the edit adds or
+    removes anything (an edit that keeps every size, e.g. a variant moved to another position in the SAME dict objects, is not
+    seen: call LOCUS_CACHE.clear() after such surgery; the reference itself never edits these dicts, typing_core.py:384-401 copies).  A miss there falls
     back to the CONTENT key: a digest of everything the PackedLocus constructor reads (names in order, backbone, variants in
     Var_list order, the links of those variants in Links' key order, lengths, exons), so that dicts re-read from the same index
     files (driver.genotyping_locus does that once per call) still meet their packed form.  Least recently used entries are
