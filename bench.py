@@ -1301,7 +1301,7 @@ def run_panel64(args, rank, local_rank, world, dist):
                 "merged_batches": {packed[k].gene: {"alleles": packed[k].n_alleles, "tasks": m.n_tasks, "pairs": m.n_pairs, "piece_refs": m.n_refs,
                                                     "distinct_pieces": m.n_pieces} for k, (_, m) in sorted(manies.items())},
                 "setup_s": round(t_setup, 1)},
-            "roofline": roof, "cpu_baseline": cb, "other_em_arithmetic": other, "e2e": e2e})
+            "roofline": roof, "cpu_baseline": cb, "other_em_arithmetic": other, "e2e": e2e, "stream_sets": engine.stream_sets_info()})
     return None
 
 
