@@ -112,6 +112,9 @@ def parse_args():
     ap.add_argument("--share-gpu", action="store_true",
                     help="every rank on GPU 0 (with --backend gloo): the REAL multi-rank body -- sharding, exchanges, max-over-ranks timing -- "
                          "on a one-GPU box; the line says so (`shared_gpu`), its value is not a scaling figure")
+    ap.add_argument("--comm", choices=["auto", "rccl", "torch"], default="auto",
+                    help="exchanges of a sharded locus: auto = dist.RcclComm under nccl, dist.TorchComm under gloo; rccl = RcclComm whatever the "
+                         "control plane (tests: HGX_BENCH_RCCL_LIB names a library with RCCL's entry points for ranks that share one GPU); torch = TorchComm")
     ap.add_argument("--check-unsharded", action="store_true",
                     help="class1: every rank of a sharded locus also types the whole locus alone and compares (`sharded_equals_unsharded`)")
     ap.add_argument("--no-in-flight", action="store_true", help="skip the side measurement with 2 / 3 samples in flight")
@@ -131,6 +134,7 @@ def parse_args():
     return ap.parse_args()
 
 
+COMM_FORCE = "auto"      # --comm: which exchange object the ranks of a sharded locus get (make_comm)
 DIST_DEV = "cuda"        # device of the control-plane tensors (torch.distributed): "cuda" with nccl (= RCCL), "cpu" with gloo
 EM_MODE = False          # --em-exact: -1 = the reference's order of operations at every size (hgx_type_opts.em_fast = -1)
 
@@ -560,8 +564,10 @@ def make_comm(dist, group=None):
     --share-gpu) dist.TorchComm.  If the RCCL communicator cannot be made on ANY rank of the group, every rank falls back to
     TorchComm over the nccl group (decided together: one all-reduce of a flag) and the line says why.  -> (comm, kind)"""
     from hisatgenotype_amd import dist as hdist
-    if DIST_DEV != "cuda":
+    if DIST_DEV != "cuda" and COMM_FORCE != "rccl":
         return hdist.TorchComm(group), "torch-gloo (host control plane)"
+    if COMM_FORCE == "torch":
+        return hdist.TorchComm(group), "torch-nccl (asked for: --comm torch)"
     import torch
     comm, why = None, ""
     try:
@@ -574,7 +580,7 @@ def make_comm(dist, group=None):
         if comm is not None:
             comm.close()
         return hdist.TorchComm(group), "torch-nccl (RcclComm could not be created on some rank: %s)" % (why or "another rank")
-    return comm, "rccl"
+    return comm, "rccl" if not hdist.RcclComm.lib_path else "rccl entry points over %s" % os.path.basename(hdist.RcclComm.lib_path)
 
 
 def rccl_stats(reset=False):
@@ -1355,7 +1361,11 @@ def main():
         return
     if args.gpus != world:
         sys.exit("bench.py: --gpus %d but %d rank(s) are running" % (args.gpus, world))
-    global DIST_DEV
+    global DIST_DEV, COMM_FORCE
+    COMM_FORCE = args.comm
+    if os.environ.get("HGX_BENCH_RCCL_LIB"):
+        from hisatgenotype_amd import dist as hdist_
+        hdist_.RcclComm.lib_path = os.environ["HGX_BENCH_RCCL_LIB"]
     dev_id = 0 if args.share_gpu else local_rank          # --share-gpu: every rank on GPU 0 (the multi-rank body on a one-GPU box)
     if use_dist:
         import torch

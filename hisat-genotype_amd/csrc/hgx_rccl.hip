@@ -34,7 +34,15 @@ std::once_flag g_rccl_once;
 
 int rccl_load() {
     std::call_once(g_rccl_once, [] {
+        // (test switch rccl_lib = a path: the GPU suite's stand-in transport for ranks that share one GPU, tests/fake_rccl; set before
+        // the first collective of the process -- the library is loaded once)
+        const char *sw = hgx_test_switch("rccl_lib");
+        if (sw && *sw) {
+            g_rccl.lib = dlopen(sw, RTLD_NOW | RTLD_LOCAL);
+            if (!g_rccl.lib) { if (const char *e = dlerror()) g_rccl.why = e; return; }
+        }
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (g_rccl.lib) break;
             g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (g_rccl.lib) break;
             if (const char *e = dlerror()) g_rccl.why = e;        // captured once, here: dlerror() clears itself when read

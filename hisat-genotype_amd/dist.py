@@ -238,10 +238,16 @@ class RcclComm:
     torch.distributed.broadcast_object_list (any backend), a file, MPI."""
 
     _lib = None
+    lib_path = None          # tests: another library with RCCL's entry points (tests/fake_rccl: ranks that share ONE GPU); set before first use
 
     @classmethod
     def rccl(cls):
         if cls._lib is None:
+            if cls.lib_path:
+                from . import engine
+                engine.test_switch("rccl_lib", cls.lib_path)       # (libhgx's own loader takes the same library)
+                cls._lib = C.CDLL(cls.lib_path, mode=C.RTLD_LOCAL)
+                return cls._lib
             for name in ("librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"):
                 try:
                     cls._lib = C.CDLL(name, mode=C.RTLD_GLOBAL)
