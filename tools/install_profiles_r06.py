@@ -123,6 +123,6 @@ if fr and os.path.exists(sp):
     json.dump(sj, open(sp, "w"), indent=1)
     print("file -> result per call:", {k: (v["dispatches_per_call"], v["kernel_ms_per_call"]) for k, v in fr.items()})
 for name in ("bench_2ranks_shared_gpu.json", "bench_class1_4ranks_shared_gpu.json", "stream_probe.txt", "stream_conflicts.txt", "stream_ab.txt",
-             "front_gate.txt", "dropin_profile.txt", "bench_first_process.json"):
+             "front_gate.txt", "dropin_profile.txt", "bench_first_process.json", "bench_class1_4ranks_rccl_entry_points.json"):
     if os.path.exists(f"{src}/{name}") and os.path.getsize(f"{src}/{name}") > 0:
         shutil.copy(f"{src}/{name}", f"{dst}/{R}_final_{name}")

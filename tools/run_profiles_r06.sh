@@ -55,3 +55,7 @@ bash tools/stream_ab.sh > $D/stream_ab.txt 2>&1
 python3 tools/front_gate.py > $D/front_gate.txt 2>&1
 python3 tools/dropin_profile.py > $D/dropin_profile.txt 2>&1
 python3 tools/dropin_profile.py codis_10k >> $D/dropin_profile.txt 2>&1
+# ... and the same class-I body with the ranks of the sharded locus exchanging through dist.RcclComm / the C-ABI collectives (a stand-in
+# transport with RCCL's entry points for ranks that share one GPU: tests/fake_rccl)
+/opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -shared -o /tmp/libfake_rccl.so tests/fake_rccl/fake_rccl.cpp
+HGX_BENCH_RCCL_LIB=/tmp/libfake_rccl.so python3 bench.py --gpus 4 --backend gloo --share-gpu --comm rccl --workload class1 --pairs 100000 --steps 5 --warmup 2 --check-unsharded --no-cpu-baseline > $D/bench_class1_4ranks_rccl_entry_points.json 2> $D/bench_class1_4ranks_rccl.err
