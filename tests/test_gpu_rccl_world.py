@@ -64,6 +64,12 @@ WORKER = textwrap.dedent('''
     names = [a_ for a_ in str_loc.allele_names if "BACKBONE" not in a_]
     str_sam = synth.simulate_sam_fast(str_loc, [names[2], names[-3]], 900, read_len=100, frag_len=(200, 300), err_rate=0.002, seed=8)
     cases.append(("STR locus", str_loc, str_sam, hdist.split_name_grouped(str_sam, world)))
+    # CODIS D18S51: choose_pairs needs the MEDIAN inner distance of the whole sample -- a histogram all-reduce (hgx_allreduce_sum_i64)
+    d18 = synth.make_str_like_locus(gene="D18S51", unit="AGAA", max_repeats=22, min_repeats=9, flank=180, seed=71)
+    d18.base_fname = "codis"
+    dn = [a_ for a_ in d18.allele_names if "BACKBONE" not in a_]
+    d18_sam = synth.simulate_sam_fast(d18, [dn[3], dn[-3]], 3000, read_len=100, frag_len=(200, 280), err_rate=0.002, seed=17)
+    cases.append(("CODIS D18S51", d18, d18_sam, hdist.split_name_grouped(d18_sam, world)))
     L = capi.lib()
     for what, loc, sam, shards in cases:
         pl = hl.PackedLocus.from_synth(loc)
@@ -86,7 +92,7 @@ WORKER = textwrap.dedent('''
         for sw in (dict(front="device"), dict()):
             with engine.test_switches(**sw):
                 res = hdist.type_locus_sharded(pl, shards[rank], comm)
-                if sw and shards[rank]:
+                if sw and shards[rank] and what != "CODIS D18S51":       # (D18S51 stays on the host front end by design)
                     assert engine.front_last() == (2, 0), (what, rank, engine.front_last())
             assert (res.num_reads, res.num_pairs) == (ref.num_reads, ref.num_pairs), (what, rank)
             assert res.counts_sorted == ref.counts_sorted and res.em == ref.em and res.gene_prob == ref.gene_prob, (what, rank)
@@ -97,6 +103,23 @@ WORKER = textwrap.dedent('''
         dist.all_gather_object(got, res.gene_prob)
         assert all(g == got[0] for g in got), what
         pl.close()
+    # a rank whose front end raises (a record without NM: quirk Q8) fails EVERY rank -- the flag travels with the exchanges
+    loc = synth.make_hla_like_locus(n_alleles=300, n_vars=400, seed=8)
+    pl = hl.PackedLocus.from_synth(loc)
+    sam = synth.simulate_sam_fast(loc, synth.pick_sample(loc, 1), 600, seed=2)
+    shards = hdist.split_name_grouped(sam, world)
+    shards[world - 1] = shards[world - 1].replace(b"NM:i:", b"XM:i:", 1)
+    for sw in (dict(), dict(front="device")):
+        raised = False
+        try:
+            with engine.test_switches(**sw):
+                hdist.type_locus_sharded(pl, shards[rank], comm)
+        except Exception:
+            raised = True
+        assert raised, (rank, sw)
+    res = hdist.type_locus_sharded(pl, hdist.split_name_grouped(sam, world)[rank], comm)      # ... and the communicator is still in step
+    assert res.gene_prob == hgx.type_locus(pl, sam).gene_prob
+    pl.close()
     comm.close()
     dist.barrier()
     dist.destroy_process_group()
