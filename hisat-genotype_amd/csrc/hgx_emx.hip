@@ -151,26 +151,60 @@ __device__ __forceinline__ double sel_add(double acc, uint64_t mask, double x) {
 
 // sum of arr[0..n8) (LDS; n8 a multiple of 8, the tail padded with +0.0) added one by one in index order by the calling
 // wavefront (every lane reads the same address: a broadcast, and every lane returns the sum)
+// (round 6: the next group of eight is requested -- unconditionally, so that the loads stay wave-uniform scalar loads -- before the eight
+// dependent adds of the current one: the sum of 4 549 values 44 -> 33 us; same adds in the same order)
 __device__ __forceinline__ double seq_sum(const double *arr, int n8) {
     double t = 0.0;
-    for (int r0 = 0; r0 < n8; r0 += 8) {
-        double x[8];
+    if (n8 <= 0) return t;
+    double x[8], y[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) x[k] = arr[r0 + k];
+    for (int k = 0; k < 8; ++k) x[k] = arr[k];
+    int r0 = 8;
+    for (; r0 + 8 <= n8; r0 += 16) {                    // two groups per trip: the next group's (unconditional) loads before this group's adds
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = arr[r0 + k];
 #pragma unroll
         for (int k = 0; k < 8; ++k) t = ((t) + (x[k]));
+        if (r0 + 16 <= n8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) x[k] = arr[r0 + 8 + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t = ((t) + (y[k]));
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t = ((t) + (y[k]));
+            return t;
+        }
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t = ((t) + (x[k]));
     return t;
 }
 __device__ __forceinline__ void seq_sum2(const double *a, const double *b, int n8, double &ta, double &tb) {
     ta = 0.0; tb = 0.0;
-    for (int r0 = 0; r0 < n8; r0 += 8) {
-        double x[8], y[8];
+    if (n8 <= 0) return;
+    double x[8], y[8], u[8], v[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { x[k] = a[r0 + k]; y[k] = b[r0 + k]; }
+    for (int k = 0; k < 8; ++k) { x[k] = a[k]; y[k] = b[k]; }
+    int r0 = 8;
+    for (; r0 + 8 <= n8; r0 += 16) {                    // as seq_sum: the next group's loads before this group's adds
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { u[k] = a[r0 + k]; v[k] = b[r0 + k]; }
 #pragma unroll
         for (int k = 0; k < 8; ++k) { ta = ((ta) + (x[k])); tb = ((tb) + (y[k])); }
+        if (r0 + 16 <= n8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { x[k] = a[r0 + 8 + k]; y[k] = b[r0 + 8 + k]; }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ta = ((ta) + (u[k])); tb = ((tb) + (v[k])); }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ta = ((ta) + (u[k])); tb = ((tb) + (v[k])); }
+            return;
+        }
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { ta = ((ta) + (x[k])); tb = ((tb) + (y[k])); }
 }
 
 #pragma clang fp contract(fast)
