@@ -655,12 +655,19 @@ __global__ __launch_bounds__(XB) void k_emx(const EmxTask *__restrict__ tasks, i
                     b[lane] = m_nx; b[64 + lane] = p_nx;
                     __builtin_amdgcn_wave_barrier();
                     if (blk + 1 < A1w) { m_nx = __longlong_as_double((long long)mrow[64 * (blk + 1) + lane]); p_nx = dv[P][64 * (blk + 1) + lane]; }
-                    for (int k0 = 0; k0 < 64; k0 += 16) {      // sixteen steps' operands in flight, then the sixteen dependent adds
-                        double mv[16], xv[16];
+                    // eight steps' operands at a time, the NEXT eight requested before the current eight dependent adds (round 6: with
+                    // sixteen read and then sixteen added, every group waited ~200 cycles for its own LDS reads first)
+                    double mv[2][8], xv[2][8];
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) { mv[u] = b[k0 + u]; xv[u] = b[64 + k0 + u]; }
+                    for (int u = 0; u < 8; ++u) { mv[0][u] = b[u]; xv[0][u] = b[64 + u]; }
 #pragma unroll
-                        for (int u = 0; u < 16; ++u) acc = sel_add(acc, uni64(mv[u]), xv[u]);
+                    for (int g = 0; g < 8; ++g) {
+                        if (g + 1 < 8) {
+#pragma unroll
+                            for (int u = 0; u < 8; ++u) { mv[(g + 1) & 1][u] = b[8 * (g + 1) + u]; xv[(g + 1) & 1][u] = b[64 + 8 * (g + 1) + u]; }
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) acc = sel_add(acc, uni64(mv[g & 1][u]), xv[g & 1][u]);
                     }
                 }
             } else {
