@@ -122,6 +122,10 @@ if fr and os.path.exists(sp):
     sj["file_to_result"] = fr
     json.dump(sj, open(sp, "w"), indent=1)
     print("file -> result per call:", {k: (v["dispatches_per_call"], v["kernel_ms_per_call"]) for k, v in fr.items()})
+import glob
+for p in glob.glob(f"{src}/stats_dropin/**/*kernel_stats.csv", recursive=True)[:1]:
+    shutil.copy(p, f"{dst}/{R}_final_dropin_config0_kernel_stats.csv")
+    shutil.copy(f"{src}/dropin_config0.log", f"{dst}/{R}_final_dropin_config0.log")
 for name in ("bench_2ranks_shared_gpu.json", "bench_class1_4ranks_shared_gpu.json", "stream_probe.txt", "stream_conflicts.txt", "stream_ab.txt",
              "front_gate.txt", "dropin_profile.txt", "bench_first_process.json", "bench_class1_4ranks_rccl_entry_points.json"):
     if os.path.exists(f"{src}/{name}") and os.path.getsize(f"{src}/{name}") > 0:

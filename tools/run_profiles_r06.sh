@@ -55,6 +55,10 @@ bash tools/stream_ab.sh > $D/stream_ab.txt 2>&1
 python3 tools/front_gate.py > $D/front_gate.txt 2>&1
 python3 tools/dropin_profile.py > $D/dropin_profile.txt 2>&1
 python3 tools/dropin_profile.py codis_10k >> $D/dropin_profile.txt 2>&1
+# the drop-in call itself under the tracer: 23 typing() calls on the configs[0] fixture
+mkdir -p $D/stats_dropin
+rocprofv3 --kernel-trace --stats --output-format csv -d $D/stats_dropin -o r06dropin -- python3 tools/dropin_calls.py 20 > $D/dropin_config0.log 2>&1
+rm -f $D/stats_dropin/*kernel_trace.csv $D/stats_dropin/*agent_info.csv
 # ... and the same class-I body with the ranks of the sharded locus exchanging through dist.RcclComm / the C-ABI collectives (a stand-in
 # transport with RCCL's entry points for ranks that share one GPU: tests/fake_rccl)
 /opt/rocm/bin/hipcc -O2 -std=c++17 -fPIC -shared -o /tmp/libfake_rccl.so tests/fake_rccl/fake_rccl.cpp
