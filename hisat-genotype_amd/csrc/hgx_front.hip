@@ -172,6 +172,7 @@ struct FeCtl {
     uint32_t n_heads, n_masks;
     uint32_t n_keys, n_slots, n_rec, trace_cursor;            // record stage: distinct keys, decoded keys, records that passed the filters
     unsigned long long n_reads, n_gene_refs, pair_total;      // pair_total = pairs << 40 | refs
+    uint32_t last_head;              // CODIS D18S51: index + 1 of the last run of records that yields a pair (choose_pairs applies to it)
 };
 
 __device__ __forceinline__ void fe_decline(FeCtl *ctl, int code) { atomicCAS(&ctl->decline, 0, code); }
@@ -404,7 +405,7 @@ __global__ void __launch_bounds__(256) k_fe_pair_count(const uint32_t *__restric
                                                        const uint32_t *__restrict__ key_ht_off, const uint32_t *__restrict__ key_n_ht,
                                                        const int32_t *__restrict__ ht_pool, unsigned long long *__restrict__ cnt, FeCtl *ctl,
                                                        const uint16_t *__restrict__ slot_task, uint32_t *__restrict__ task_reads,
-                                                       uint32_t *__restrict__ task_pairs, unsigned long long *__restrict__ task_refs) {
+                                                       uint32_t *__restrict__ task_pairs, unsigned long long *__restrict__ task_refs, int mark_last) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long c = 0, reads = 0, gene = 0;
     uint32_t my_task = 0xffffffffu;
@@ -421,6 +422,7 @@ __global__ void __launch_bounds__(256) k_fe_pair_count(const uint32_t *__restric
             reads = (unsigned long long)ns;
             gene = (unsigned long long)n_uni;
             if (task_reads) my_task = slot_task[FE_REC_SLOT(rec_info[i])];
+            if (mark_last) atomicMax(&ctl->last_head, i + 1);          // (CODIS D18S51 only: a few thousand pairs)
         }
     }
     if (task_reads) {
@@ -455,17 +457,36 @@ __global__ void __launch_bounds__(256) k_fe_pair_count(const uint32_t *__restric
         if (r | g | pk) { atomicAdd(&ctl->n_reads, r); atomicAdd(&ctl->n_gene_refs, g); atomicAdd(&ctl->pair_total, pk); }
     }
 }
+// choose_pairs (typing_core.py:680-716, 1547-1552): the stream's LAST pair of a CODIS D18S51 sample keeps the left x right haplotype
+// pairs whose inner distance is closest to the sample's median one -- one thread re-counts that pair and corrects the totals
+__global__ void k_fe_pair_choose(const uint32_t *__restrict__ rec_info, uint32_t n_rec, const uint8_t *__restrict__ state,
+                                 const uint32_t *__restrict__ key_ht_off, const uint32_t *__restrict__ key_n_ht, const int32_t *__restrict__ ht_pool,
+                                 unsigned long long *__restrict__ cnt, FeCtl *ctl, long long expected) {
+    if (blockIdx.x || threadIdx.x || ctl->last_head == 0) return;
+    const uint32_t i = ctl->last_head - 1;
+    uint32_t uni[FE_MAX_PAIR_HT];
+    int n_all = 0, n_uni = 0;
+    if (fe_pair_union(rec_info, i, n_rec, state, key_ht_off, key_n_ht, ht_pool, uni, n_all) <= 0) return;
+    if (fe_pair_union(rec_info, i, n_rec, state, key_ht_off, key_n_ht, ht_pool, uni, n_uni, true, expected) <= 0) return;
+    unsigned long long n_exon = 0;
+    for (int x = 0; x < n_uni; ++x) n_exon += (unsigned long long)ht_pool[uni[x] + 3];
+    const unsigned long long before = cnt[i] & ((1ull << 40) - 1), now = n_exon + (unsigned long long)n_uni;
+    cnt[i] = (1ull << 40) | now;
+    ctl->pair_total -= before - now;                                 // (a subset of the pair's haplotypes: never more refs)
+    ctl->n_gene_refs -= (unsigned long long)(n_all - n_uni);
+}
 __global__ void __launch_bounds__(256) k_fe_pair_emit(const uint32_t *__restrict__ rec_info, uint32_t n_rec, const uint8_t *__restrict__ state,
                                                       const uint32_t *__restrict__ key_ht_off, const uint32_t *__restrict__ key_n_ht,
                                                       const int32_t *__restrict__ ht_pool, const unsigned long long *__restrict__ cnt,
                                                       const uint32_t *__restrict__ off_pair, const uint32_t *__restrict__ off_ref, const uint32_t *__restrict__ cand_piece,
-                                                      int32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_ref, uint32_t n_pairs, uint32_t n_refs) {
+                                                      int32_t *__restrict__ pair_off, uint32_t *__restrict__ pair_ref, uint32_t n_pairs, uint32_t n_refs,
+                                                      uint32_t choose_head, long long expected) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) pair_off[n_pairs] = (int32_t)n_refs;
     if (i >= n_rec || cnt[i] == 0) return;
     uint32_t uni[FE_MAX_PAIR_HT];
     int n_uni = 0;
-    (void)fe_pair_union(rec_info, i, n_rec, state, key_ht_off, key_n_ht, ht_pool, uni, n_uni);
+    (void)fe_pair_union(rec_info, i, n_rec, state, key_ht_off, key_n_ht, ht_pool, uni, n_uni, i + 1 == choose_head, expected);
     const uint32_t p = off_pair[i];
     uint32_t r = off_ref[i];
     pair_off[p] = (int32_t)r;
@@ -690,6 +711,32 @@ __global__ void __launch_bounds__(256) k_fe_build_recinfo(const FeRec *__restric
     const uint32_t pv = prev_kept[i];                     // index + 1 of the previous record that passed the filters, 0 = none
     const bool hd = pv == 0 || !fe_same_read_id(recs[pv - 1], recs[i], text);
     rec_info[rec_idx[i]] = dslot[slot_of[i]] | ((recs[i].flag & 0x40) ? 1u << 30 : 0u) | (hd ? 1u << 31 : 0u);
+}
+
+// ---- get_pair_interdist (typing_common.py:1187-1265) on the device: CODIS D18S51's expected inner distance (round 6) ----------
+// The records that count (aligned, NH <= 1, YT:Z:CP) are numbered by a scan and compacted; lane j of the compacted list owns the run
+// that starts at j: a distance iff the run holds exactly two records and a third counted record follows it (fe_interdist_* of
+// hgx_front_core.hpp).  hist = FE_INTERDIST_BINS counters, zeroed by the caller; *m = the number of counted records (the scan's total).
+static_assert(FE_INTERDIST_HALF == HGX_INTERDIST_HALF && FE_INTERDIST_BINS == HGX_INTERDIST_BINS, "the kernels' histogram is the one the shards exchange");
+__global__ void k_fe_interdist_flag(const FeRec *__restrict__ recs, uint32_t n, uint32_t *__restrict__ flag) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = fe_rec_in_interdist(recs[i]) ? 1u : 0u;
+}
+__global__ void k_fe_interdist_compact(const uint32_t *__restrict__ flag, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ comp) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) comp[idx[i]] = i;
+}
+__global__ void __launch_bounds__(256) k_fe_interdist_hist(const FeRec *__restrict__ recs, const char *__restrict__ text, const uint32_t *__restrict__ comp,
+                                                           const uint32_t *__restrict__ m_ptr, uint32_t *__restrict__ hist, FeCtl *ctl) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x, m = *m_ptr;
+    if (j + 2 >= m) return;
+    const FeRec a = recs[comp[j]], b = recs[comp[j + 1]];
+    if (j > 0 && fe_same_read_id(recs[comp[j - 1]], a, text)) return;
+    if (!fe_same_read_id(a, b, text) || fe_same_read_id(a, recs[comp[j + 2]], text)) return;
+    long long d;
+    const int rc = fe_interdist_of(a, b, text, d);
+    if (rc < 0) { fe_decline(ctl, rc); return; }
+    atomicAdd(&hist[fe_interdist_bin(d)], 1u);
 }
 
 // ---- BAM records straight from the inflated stream (round 4): chain walk, region filter, name sort as kernels -----------------
@@ -997,6 +1044,11 @@ struct DevInput {                     // keys, their text and the kept records, 
     uint32_t *task_reads = nullptr, *task_pairs = nullptr, *task_pieces = nullptr;
     unsigned long long *task_refs = nullptr;
     const hgx_locus *host_locus = nullptr;     // keep_trace: the variant names the trace lines spell
+    // CODIS D18S51 (codis_choose_pairs / interdist_exchange): the histogram of this stream's inner distances -- counted on the device
+    // by the record route (d_hist: FE_INTERDIST_BINS u32 counters), made by the host stages on the key route (h_hist)
+    bool want_interdist = false;
+    const uint32_t *d_hist = nullptr;
+    const std::vector<int64_t> *h_hist = nullptr;
 };
 struct Lap {
     bool prof; hipStream_t st; double t_prev;
@@ -1078,6 +1130,26 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     }
     if (n_ref > 0) k_fe_nt_set<<<nblk((long)n_tasks * n_ref, 256), 256, 0, st>>>(d->d_counts, n_tasks * n_ref, d->d_nt_set);
     lap("pileup");
+    // CODIS D18S51: the sample's expected inner distance (get_pair_interdist) -- the histogram of this stream's distances, summed
+    // over the shards of a sharded locus (AFTER the pileup exchange: the order of the host stages' exchanges), its middle element
+    long long expected = -1;
+    const bool choose = di.want_interdist && o.codis_choose_pairs;
+    if (di.want_interdist) {
+        if (n_tasks > 1 || (!di.d_hist && (!di.h_hist || di.h_hist->size() != (size_t)HGX_INTERDIST_BINS))) { *declined = HGX_FE_DECLINE_OPTS; return HGX_OK; }
+        std::vector<int64_t> hist((size_t)HGX_INTERDIST_BINS);
+        if (di.d_hist) {
+            std::vector<uint32_t> h32((size_t)HGX_INTERDIST_BINS);
+            HIPCHK(hipMemcpyAsync(h32.data(), di.d_hist, h32.size() * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (size_t b = 0; b < h32.size(); ++b) hist[b] = (int64_t)h32[b];
+        } else hist = *di.h_hist;
+        if (o.interdist_exchange && o.interdist_exchange(o.interdist_ctx, hist.data(), (int64_t)hist.size()) != 0) {
+            hgx_set_error("inter-distance exchange between the ranks of a sharded locus failed");
+            return HGX_EINVAL;
+        }
+        if (hgx_interdist_median(hist.data(), &expected)) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }     // (outside the histogram: the host's sort)
+        lap("expected inner distance");
+    }
 
     // decode
     const size_t ht_cap = (size_t)S * 48 + 4096, cand_cap = (size_t)S * 12 + 4096, mask_cap = cand_cap * 16;
@@ -1133,13 +1205,15 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     if (n_rec) k_fe_pair_count<<<nblk(n_rec, 256), 256, 0, st>>>(rec_info, n_rec, b_state.as<uint8_t>(), b_koff.as<uint32_t>(), b_knht.as<uint32_t>(),
                                                                  b_ht.as<int32_t>(), b_cnt.as<unsigned long long>(), ctl,
                                                                  n_tasks > 1 ? b_slot_task.as<uint16_t>() : (const uint16_t *)nullptr,
-                                                                 n_tasks > 1 ? di.task_reads : (uint32_t *)nullptr, di.task_pairs, di.task_refs);
+                                                                 n_tasks > 1 ? di.task_reads : (uint32_t *)nullptr, di.task_pairs, di.task_refs, choose ? 1 : 0);
+    if (n_rec && choose) k_fe_pair_choose<<<1, 64, 0, st>>>(rec_info, n_rec, b_state.as<uint8_t>(), b_koff.as<uint32_t>(), b_knht.as<uint32_t>(),
+                                                            b_ht.as<int32_t>(), b_cnt.as<unsigned long long>(), ctl, expected);
     FeCtl h;
     HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     lap("decode + pair counts");
     if (h.decline) { *declined = -h.decline; return HGX_OK; }
-    const uint32_t n_cand = h.cand_cursor;
+    const uint32_t n_cand = h.cand_cursor, choose_head = h.last_head;
     d->n_reads = (int32_t)h.n_reads;
     d->n_gene_refs = (int64_t)h.n_gene_refs;
 
@@ -1259,7 +1333,8 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     }
     if (n_rec) k_fe_pair_emit<<<nblk(n_rec, 256), 256, 0, st>>>(rec_info, n_rec, b_state.as<uint8_t>(), b_koff.as<uint32_t>(), b_knht.as<uint32_t>(),
                                                                 b_ht.as<int32_t>(), b_cnt.as<unsigned long long>(), b_off.as<uint32_t>(), b_off.as<uint32_t>() + n_rec,
-                                                                b_cand_piece.as<uint32_t>(), d->d_pair_off, d->d_pair_ref, n_pairs, n_refs);
+                                                                b_cand_piece.as<uint32_t>(), d->d_pair_off, d->d_pair_ref, n_pairs, n_refs,
+                                                                choose ? choose_head : 0u, expected);
     else HIPCHK(hipMemsetAsync(d->d_pair_off, 0, 4, st));
     HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1308,6 +1383,8 @@ int front_run(hgx_locus &L, const hgx_front_input &in, const hgx_parse_opts &o, 
     DevInput di{b_keys.as<FeKey>(), (uint32_t)in.n_keys, b_text.as<char>(), b_rec.as<uint32_t>(), (uint32_t)in.n_rec, (uint32_t)in.n_slots,
                 b_ctl.as<FeCtl>()};
     di.host_locus = &L;
+    di.want_interdist = in.want_interdist;
+    di.h_hist = &in.interdist_hist;
     return front_stages(*Fp, di, o, st, out, declined);
 }
 
@@ -1780,6 +1857,9 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
     while (cap < 2 * (uint64_t)n) cap <<= 1;
     DevBuf b_lines, b_recs, b_head, b_kept, b_slot_of, b_tkeys, b_rep, b_pile, b_anyk, b_dslot, b_is_key, b_is_dec, b_kept32, b_prev_in;
     DevBuf b_key_idx, b_dec_idx, b_rec_idx, b_prev, b_tmp, b_keys, b_rec, b_ctl, b_treads, b_tpairs, b_trefs, b_tpieces;
+    DevBuf b_ihist, b_iflag, b_iidx, b_icomp;
+    const bool want_interdist = o.codis_choose_pairs || o.interdist_exchange;
+    if (want_interdist && n_tasks > 1) { *declined = HGX_FE_DECLINE_OPTS; return HGX_OK; }
     struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
     if (!d_lines) ALLOC(b_lines, std::max<size_t>(n_lines, 1) * sizeof(LineRef));
     ALLOC(b_recs, std::max<size_t>(n_lines, 1) * sizeof(FeRec));
@@ -1844,6 +1924,23 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
                                                      d_pile, o.base_locus, b_keys.as<FeKey>(), b_dslot.as<uint32_t>(), ctl);
         k_fe_build_recinfo<<<nblk(n, 256), 256, 0, st>>>(recs, n, d_text, b_kept.as<uint8_t>(), b_rec_idx.as<uint32_t>(), b_prev.as<uint32_t>(),
                                                         b_slot_of.as<uint32_t>(), b_dslot.as<uint32_t>(), b_rec.as<uint32_t>());
+        if (want_interdist) {
+            // CODIS D18S51: the inner distances of this stream's unique concordant pairs, as a histogram (front_stages takes the median)
+            const size_t hist_bytes = ((size_t)HGX_INTERDIST_BINS * 4 + 255) & ~(size_t)255;      // hist | the scan's total | scan state
+            ALLOC(b_ihist, hist_bytes + 256 + sc_bytes);
+            ALLOC(b_iflag, (size_t)n * 4); ALLOC(b_iidx, (size_t)n * 4); ALLOC(b_icomp, (size_t)n * 4);
+            HIPCHK(hipMemsetAsync(b_ihist.p, 0, hist_bytes + 256 + sc_bytes, st));
+            uint32_t *const d_m = (uint32_t *)((char *)b_ihist.p + hist_bytes);
+            k_fe_interdist_flag<<<nblk(n, 256), 256, 0, st>>>(recs, n, b_iflag.as<uint32_t>());
+            FeScanArgs sa{};
+            sa.n_ch = 1;
+            sa.ch[0] = FeScanCh{b_iflag.p, b_iidx.as<uint32_t>(), 0, FSC_U32};
+            sa.totals = d_m;
+            rc = fe_scan(sa, (long)n, (char *)b_ihist.p + hist_bytes + 256, st);
+            if (rc) return rc;
+            k_fe_interdist_compact<<<nblk(n, 256), 256, 0, st>>>(b_iflag.as<uint32_t>(), b_iidx.as<uint32_t>(), n, b_icomp.as<uint32_t>());
+            k_fe_interdist_hist<<<nblk(n, 256), 256, 0, st>>>(recs, d_text, b_icomp.as<uint32_t>(), d_m, b_ihist.as<uint32_t>(), ctl);
+        }
         HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     } else {
@@ -1855,6 +1952,10 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
     DevInput di{b_keys.as<FeKey>(), h.n_keys, d_text, b_rec.as<uint32_t>(), h.n_rec, h.n_slots, ctl};
     di.n_tasks = std::max(1, n_tasks);
     di.host_locus = &L;
+    di.want_interdist = want_interdist;
+    di.d_hist = want_interdist && n ? b_ihist.as<uint32_t>() : nullptr;
+    static const std::vector<int64_t> no_distances((size_t)HGX_INTERDIST_BINS, 0);
+    di.h_hist = &no_distances;                                          // (an empty stream still takes part in the exchange)
     if (di.n_tasks > 1) {
         ALLOC(b_treads, (size_t)di.n_tasks * 4); ALLOC(b_tpairs, (size_t)di.n_tasks * 4); ALLOC(b_trefs, (size_t)di.n_tasks * 8);
         ALLOC(b_tpieces, (size_t)di.n_tasks * 4);
@@ -1908,6 +2009,13 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
         opts_own.pileup_exchange = &hgx_pileup_share::trampoline;
         opts_own.pileup_ctx = &share;
     }
+    hgx_interdist_share id_share;          // ... and in ONE exchange of the inter-distance histogram (CODIS D18S51)
+    if (opts_in->interdist_exchange) {
+        id_share.orig = opts_in->interdist_exchange;
+        id_share.orig_ctx = opts_in->interdist_ctx;
+        opts_own.interdist_exchange = &hgx_interdist_share::trampoline;
+        opts_own.interdist_ctx = &id_share;
+    }
     const hgx_parse_opts *opts = &opts_own;
     hgx_dbatch *made = nullptr;
     hgx_front_hook hook;
@@ -1940,7 +2048,7 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
     const unsigned char *comp_from = nullptr;
     size_t up_bytes = 0, comp_n = 0;
     bool up_failed = false;
-    if (!host_only && !no_records && !(opts->codis_choose_pairs || opts->interdist_exchange)) {
+    if (!host_only && !no_records) {
         hook.on_raw = [&](const char *raw, size_t n_bytes, size_t begin, size_t end) {
             if (n_bytes >= (1ull << 32) - 64 || up_failed) return;
             if (!force && n_bytes < FE_MIN_BYTES) return;            // (the record stage will decline it as small: no upload for nothing)
@@ -2161,7 +2269,7 @@ extern "C" int hgx_alignment_parse_dev(hgx_dbatch **out, hgx_alignment *al, cons
     int dev = -1;
     HIPCHK(hipGetDevice(&dev));
     hgx_bam_deferred def;
-    const bool host_opts = opts->codis_choose_pairs || opts->interdist_exchange || opts->pileup_exchange || opts->pileup_exchange_dev;
+    const bool host_opts = opts->interdist_exchange || opts->pileup_exchange || opts->pileup_exchange_dev;      // (a shard's exchanges: the per-path call shares them out)
     if (al->resident && dev == al->dev && !host_opts && !hgx_switch_has("front", "host") &&
         hgx_deferred_for_regions(regions, al->text, al->body0, al->refs, def) == 0) {
         // (size gate: the stream is in HBM already -- the kernels take any locus the host would not finish faster; the record count is

@@ -1034,10 +1034,40 @@ FE_HD inline bool fe_rec_equal(const int32_t *a, const int32_t *b) {
     return true;
 }
 
+// choose_pairs (typing_core.py:680-716; CODIS D18S51, the stream's LAST pair only: 1547-1552): of the left x right haplotype pairs keep
+// those whose inner distance is closest to the sample's median one.  lh / rh = offsets into ht_pool (a record starts with left,
+// right); the survivors stay in the order of their first appearance in the l-outer, r-inner walk (choose_pairs_rec of hgx_sam.cpp).
+FE_HD inline void fe_choose_pairs(const int32_t *ht_pool, uint32_t *lh, int &n_l, uint32_t *rh, int &n_r, long long expected) {
+    if (n_l == 0 || n_r == 0 || (n_l < 2 && n_r < 2)) return;
+    uint32_t nl[FE_MAX_PAIR_HT], nr[FE_MAX_PAIR_HT];
+    int c_l = 0, c_r = 0;
+    long long best = -1;
+    for (int a = 0; a < n_l; ++a)
+        for (int b = 0; b < n_r; ++b) {
+            const long long l_left = ht_pool[lh[a]], l_right = ht_pool[lh[a] + 1], r_left = ht_pool[rh[b]], r_right = ht_pool[rh[b] + 1];
+            const long long inter = l_right < r_right ? r_left - l_right - 1 : l_left - r_right - 1;
+            const long long cur = expected - inter < 0 ? inter - expected : expected - inter;
+            if (best < 0 || cur < best) { best = cur; c_l = c_r = 0; }
+            if (cur == best) {
+                bool dup = false;
+                for (int x = 0; x < c_l && !dup; ++x) dup = nl[x] == lh[a];
+                if (!dup) nl[c_l++] = lh[a];
+                dup = false;
+                for (int x = 0; x < c_r && !dup; ++x) dup = nr[x] == rh[b];
+                if (!dup) nr[c_r++] = rh[b];
+            }
+        }
+    for (int x = 0; x < c_l; ++x) lh[x] = nl[x];
+    for (int x = 0; x < c_r; ++x) rh[x] = nr[x];
+    n_l = c_l;
+    n_r = c_r;
+}
+
 // The union of a run's haplotypes, left mate's first (uni[] = offsets into ht_pool).  Returns the number of surviving records,
-// < 0 = decline.
+// < 0 = decline.  `choose`: this run is the stream's last pair of a CODIS D18S51 sample -- choose_pairs on the two mates' sets first.
 FE_HD inline int fe_pair_union(const uint32_t *rec_info, uint32_t i, uint32_t n_rec, const uint8_t *state, const uint32_t *key_ht_off,
-                               const uint32_t *key_n_ht, const int32_t *ht_pool, uint32_t *uni, int &n_uni) {
+                               const uint32_t *key_n_ht, const int32_t *ht_pool, uint32_t *uni, int &n_uni, bool choose = false,
+                               long long expected = -1) {
     uint32_t rh[FE_MAX_PAIR_HT];
     int n_l = 0, n_r = 0, n_surv = 0;
     for (uint32_t k = i; k < n_rec && (k == i || !FE_REC_HEAD(rec_info[k])); ++k) {
@@ -1059,6 +1089,7 @@ FE_HD inline int fe_pair_union(const uint32_t *rec_info, uint32_t i, uint32_t n_
             off += FE_HT_HDR + (uint32_t)rec[2];
         }
     }
+    if (choose) fe_choose_pairs(ht_pool, uni, n_l, rh, n_r, expected);
     n_uni = n_l;
     for (int x = 0; x < n_r; ++x) {
         bool dup = false;
@@ -1136,6 +1167,7 @@ FE_HD inline uint8_t fe_nt_set(const uint32_t *c) {
 #define FE_R_HAS_MD 8
 #define FE_R_BIN 16                  // BAM record: binary CIGAR, packed SEQ
 #define FE_R_FAILED 32               // the record could not be taken apart (the call declines): every offset and length is zero
+#define FE_R_YT_CP 64                // the LAST YT tag of the record spells "CP" (get_pair_interdist, typing_common.py:1224-1231)
 struct FeRec {
     uint32_t qname_off;
     uint16_t id_len;                 // read id = QNAME, or QNAME up to the first '|' in simulation mode (typing_core.py:808-809)
@@ -1303,6 +1335,9 @@ FE_HD inline int fe_parse_text_record(const char *text, size_t text_bytes, uint3
                     if (tl >= 2 && t[0] == 'Z' && t[1] == 's') { r.bits |= FE_R_HAS_ZS; r.zs_off = off + p; r.zs_len = 0; }
                     else if (tl >= 2 && t[0] == 'M' && t[1] == 'D') { r.bits |= FE_R_HAS_MD; r.md_off = off + p; r.md_len = 0; }
                     else if (tl >= 2 && t[0] == 'N' && (t[1] == 'M' || t[1] == 'H')) return FE_FAIL(FE_E_ASSERT);   // int('') raises
+                    else if (tl >= 2 && t[0] == 'Y' && t[1] == 'T') r.bits &= (uint16_t)~FE_R_YT_CP;                 // YT = col[5:] = ""
+                } else if (t[0] == 'Y' && t[1] == 'T') {
+                    if (tl == 7 && t[5] == 'C' && t[6] == 'P') r.bits |= FE_R_YT_CP; else r.bits &= (uint16_t)~FE_R_YT_CP;
                 } else if (t[0] == 'Z' && t[1] == 's') {
                     if (tl - 5 > 65535) return FE_FAIL(FE_E_CAP);
                     r.bits |= FE_R_HAS_ZS; r.zs_off = off + tok + 5; r.zs_len = (uint16_t)(tl - 5);
@@ -1434,6 +1469,8 @@ FE_HD inline int fe_parse_bam_record(const char *text, uint32_t rec_off, uint32_
             if (x > 0x7fffffffll) x = 0x7fffffffll;
             if (t1 == 'M') { rec.bits |= FE_R_HAS_NM; rec.nm = (int32_t)x; }
             else { rec.bits |= FE_R_HAS_NH; rec.nh = (int32_t)x; }
+        } else if (t0 == 'Y' && t1 == 'T') {
+            if (is_text && sz == 3 && v[0] == 'C' && v[1] == 'P') rec.bits |= FE_R_YT_CP; else rec.bits &= (uint16_t)~FE_R_YT_CP;
         }
         q += sz;
     }
@@ -1456,6 +1493,51 @@ FE_HD inline int fe_parse_bam_record(const char *text, uint32_t rec_off, uint32_
 FE_HD inline bool fe_same_read_id(const FeRec &a, const FeRec &b, const char *text) {
     return a.task == b.task && a.id_len == b.id_len &&
            fe_bytes_equal((const unsigned char *)text + a.qname_off, (const unsigned char *)text + b.qname_off, a.id_len);
+}
+
+// ---- get_pair_interdist (typing_common.py:1187-1265; CODIS D18S51 only) over the records of the stream ---------------------------
+// A record counts iff it is aligned, has NH <= 1 and its YT tag says "CP"; runs of such records with one read id that hold exactly
+// two of them and are FOLLOWED by another such record (the reference appends a run's distance when the id changes: the stream's last
+// run never gets there) give one inner distance each.  The sample's expected distance = element len / 2 of the sorted list, taken
+// from a histogram here: bin 0 = below -FE_INTERDIST_HALF, bin 1 + d + FE_INTERDIST_HALF = distance d, the last bin = above
+// (HGX_INTERDIST_* of include/hgx.h: the form the shards of a locus exchange).
+#define FE_INTERDIST_HALF 65536
+#define FE_INTERDIST_BINS (2 * FE_INTERDIST_HALF + 2)
+FE_HD inline bool fe_rec_in_interdist(const FeRec &f) {
+    return !(f.bits & FE_R_FAILED) && !(f.flag & 0x4) && (f.bits & FE_R_HAS_NH) && f.nh <= 1 && (f.bits & FE_R_YT_CP);
+}
+// [left, right] of the record on the backbone: POS and POS + the M / N / D lengths - 1.  < 0: a CIGAR text the host reads its own way.
+FE_HD inline int fe_rec_span(const FeRec &f, const char *text, long long &left, long long &right) {
+    FeCigar cg;
+    cg.p = (const unsigned char *)text + f.cigar_off;
+    cg.n = f.cigar_len;
+    cg.at = 0;
+    cg.bin = (f.bits & FE_R_BIN) != 0;
+    long long r = f.pos;
+    for (;;) {
+        char op;
+        int len;
+        const int k = cg.next(op, len);
+        if (k < 0) return FE_FAIL(FE_E_CIGAR);
+        if (k == 0) break;
+        if (op == 'M' || op == 'N' || op == 'D') r += len;
+    }
+    left = f.pos;
+    right = r - 1;
+    return 0;
+}
+FE_HD inline uint32_t fe_interdist_bin(long long d) {
+    return d < -(long long)FE_INTERDIST_HALF ? 0u : d > (long long)FE_INTERDIST_HALF - 1 ? (uint32_t)FE_INTERDIST_BINS - 1u : (uint32_t)(1 + d + FE_INTERDIST_HALF);
+}
+// a (the run's first counted record), b (its second): the distance typing_common.py:1243-1251 appends
+FE_HD inline int fe_interdist_of(const FeRec &a, const FeRec &b, const char *text, long long &dist) {
+    long long l1, r1, l2, r2;
+    int rc = fe_rec_span(a, text, l1, r1);
+    if (rc) return rc;
+    rc = fe_rec_span(b, text, l2, r2);
+    if (rc) return rc;
+    dist = l1 <= l2 ? l2 - r1 - 1 : l1 - r2 - 1;
+    return 0;
 }
 
 // record filters (typing_core.py:815-872; filter_records of hgx_sam.cpp).  `head[i]` = record i opens a group of equal read ids.

@@ -133,6 +133,8 @@ void hgx_front_trace_lines(const hgx_locus &L, const uint32_t *rec_info, size_t 
     }
 }
 
+static_assert(FE_INTERDIST_HALF == HGX_INTERDIST_HALF && FE_INTERDIST_BINS == HGX_INTERDIST_BINS, "the kernels' histogram is the one the shards exchange");
+
 #ifdef HGX_LAB
 // ---- the device pipeline as loops (lab build only; mirrors hgx_front.hip stage by stage) ---------------------------------------
 // *declined = 0 and *out = the batch, or *declined = the reason and no batch.
@@ -263,6 +265,28 @@ int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, 
             }
         }
     }
+    // CODIS D18S51 (front_stages of hgx_front.hip: after the pileup exchange): the sample's expected inner distance from the histogram
+    // of this stream's distances -- summed over the shards of the locus first --, then choose_pairs on the stream's last pair
+    long long expected = -1;
+    size_t choose_at = (size_t)-1;
+    if (in.want_interdist) {
+        if (n_tasks > 1 || in.interdist_hist.size() != (size_t)HGX_INTERDIST_BINS) { *declined = HGX_FE_DECLINE_OPTS; delete B; return HGX_OK; }
+        std::vector<int64_t> hist(in.interdist_hist);
+        if (opts.interdist_exchange && opts.interdist_exchange(opts.interdist_ctx, hist.data(), (int64_t)hist.size()) != 0) {
+            hgx_set_error("inter-distance exchange between the ranks of a sharded locus failed");
+            delete B;
+            return HGX_EINVAL;
+        }
+        if (hgx_interdist_median(hist.data(), &expected)) { *declined = HGX_FE_DECLINE_SIZE; delete B; return HGX_OK; }
+        if (opts.codis_choose_pairs)                                   // k_fe_pair_count's atomicMax: the last run that yields a pair
+            for (size_t i = 0; i < in.n_rec; ++i) {
+                if (!FE_REC_HEAD(in.rec_info[i])) continue;
+                uint32_t uni[FE_MAX_PAIR_HT];
+                int n_uni = 0;
+                if (fe_pair_union(in.rec_info, (uint32_t)i, (uint32_t)in.n_rec, state.data(), key_ht_off.data(), key_n_ht.data(), ht_pool.data(), uni, n_uni) > 0)
+                    choose_at = i;
+            }
+    }
     // k_fe_pairs: count, scan, emit
     int64_t n_reads = 0;
     for (size_t i = 0; i < in.n_rec; ++i) {
@@ -270,7 +294,7 @@ int hgx_front_emulate(hgx_batch **out, hgx_locus &L, const hgx_front_input &in, 
         uint32_t uni[FE_MAX_PAIR_HT];
         int n_uni = 0;
         const int ns = fe_pair_union(in.rec_info, (uint32_t)i, (uint32_t)in.n_rec, state.data(), key_ht_off.data(), key_n_ht.data(),
-                                     ht_pool.data(), uni, n_uni);
+                                     ht_pool.data(), uni, n_uni, i == choose_at, expected);
         if (ns < 0) { *declined = -ns; delete B; return HGX_OK; }
         if (ns == 0) continue;
         n_reads += ns;
@@ -352,8 +376,28 @@ int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, si
         n_pile[s] += pm[i];
         any_kept[s] |= kept[i];
     }
+    // k_fe_interdist_*: the counted records compacted, one distance per run of exactly two that another counted record follows
+    std::vector<int64_t> hist;
+    const bool want_interdist = o.codis_choose_pairs || o.interdist_exchange;
+    if (want_interdist && !first_decline) {
+        hist.assign((size_t)HGX_INTERDIST_BINS, 0);
+        std::vector<uint32_t> comp;
+        for (size_t i = 0; i < n; ++i) if (fe_rec_in_interdist(recs[i])) comp.push_back((uint32_t)i);
+        const size_t m = comp.size();
+        for (size_t j = 0; j + 2 < m; ++j) {
+            const FeRec &a = recs[comp[j]], &b = recs[comp[j + 1]], &c = recs[comp[j + 2]];
+            if (j > 0 && fe_same_read_id(recs[comp[j - 1]], a, raw)) continue;
+            if (!fe_same_read_id(a, b, raw) || fe_same_read_id(a, c, raw)) continue;
+            long long d;
+            const int r = fe_interdist_of(a, b, raw, d);
+            if (r < 0) { first_decline = -r; break; }
+            hist[fe_interdist_bin(d)] += 1;
+        }
+    }
     if (first_decline) { *declined = first_decline; return HGX_OK; }
     hgx_front_input in;
+    in.want_interdist = want_interdist;
+    in.interdist_hist.swap(hist);
     in.mem = hgx_front_alloc{[](size_t b) { return hgx_host_alloc(b); }, [](void *p) { hgx_host_free(p); }};
     in.text = const_cast<char *>(raw);
     in.text_borrowed = true;

@@ -267,6 +267,10 @@ struct hgx_front_input {
     char *text = nullptr; size_t n_text = 0;
     uint32_t *rec_info = nullptr; size_t n_rec = 0;
     size_t n_slots = 0;                // distinct keys that are decoded
+    // CODIS D18S51 (codis_choose_pairs / interdist_exchange): the histogram of this stream's inner distances (HGX_INTERDIST_BINS
+    // counters; the key route's host stages fill it, the record route counts on the device and leaves it empty)
+    bool want_interdist = false;
+    std::vector<int64_t> interdist_hist;
     bool text_borrowed = false;        // `text` belongs to someone else (the record route reads the file's bytes in place)
     hgx_front_input() = default;
     hgx_front_input(const hgx_front_input &) = delete;
@@ -301,6 +305,30 @@ struct hgx_pileup_share {
         return rc;
     }
 };
+// The same for the inter-distance histogram of a sharded CODIS D18S51 sample (hgx_parse_opts.interdist_exchange): the device route
+// exchanges after its pileup exchange (the order of the host stages); if a later stage declines, the host stages get the summed
+// histogram from here instead of a second exchange.
+struct hgx_interdist_share {
+    int (*orig)(void *, int64_t *, int64_t) = nullptr;
+    void *orig_ctx = nullptr;
+    bool have_sum = false;
+    std::vector<int64_t> sum;                  // [HGX_INTERDIST_BINS]
+    static int trampoline(void *self, int64_t *hist, int64_t n) {
+        hgx_interdist_share *s = (hgx_interdist_share *)self;
+        if (s->have_sum) {
+            if ((size_t)n != s->sum.size()) return 1;
+            std::copy(s->sum.begin(), s->sum.end(), hist);
+            return 0;
+        }
+        if (!s->orig) return 1;
+        const int rc = s->orig(s->orig_ctx, hist, n);
+        if (rc == 0) { s->sum.assign(hist, hist + n); s->have_sum = true; }
+        return rc;
+    }
+};
+// Element len / 2 of the sorted distances (typing_common.py:1258-1262) out of their histogram (HGX_INTERDIST_BINS counters); -1 when
+// there is no distance.  Returns 1 when that element lies in an edge bin: outside the range the histogram resolves.
+int hgx_interdist_median(const int64_t *hist, long long *expected);
 // The host stages call `run` after key grouping; it returns HGX_OK with *declined = 0 when the device stages produced the result
 // (which the hook's owner holds: the parse functions then return *out = NULL), or *declined = the reason -- the host stages
 // then finish the job and `declined` says why.

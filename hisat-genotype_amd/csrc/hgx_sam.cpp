@@ -902,6 +902,7 @@ inline void note_tag(Fields &f, char *tok, size_t len) {
             if (tok[1] == 'M') f.has_nm = true; else f.has_nh = true;
             if (!f.bad_tag) { f.bad_tag = 1; f.bad_tok = tok + len; }
         }
+        else if (len >= 2 && tok[0] == 'Y' && tok[1] == 'T') f.yt_cp = false;     // YT = col[5:] = "" (typing_common.py:1229-1230)
         return;
     }
     if (tok[0] == 'Z' && tok[1] == 's') { f.zs = tok + 5; f.zs_len = (uint32_t)(len - 5); }
@@ -1121,6 +1122,24 @@ static bool split_bam(const unsigned char *r, size_t len, Fields &f, CharArena &
 }
 
 }   // namespace
+
+int hgx_interdist_median(const int64_t *hist, long long *expected) {
+    int64_t total = 0;
+    for (size_t b = 0; b < (size_t)HGX_INTERDIST_BINS; ++b) total += hist[b];
+    *expected = -1;
+    if (total == 0) return 0;
+    const int64_t k = total / 2;
+    int64_t seen = 0;
+    for (size_t b = 0; b < (size_t)HGX_INTERDIST_BINS; ++b) {
+        seen += hist[b];
+        if (seen > k) {
+            if (b == 0 || b + 1 == (size_t)HGX_INTERDIST_BINS) return 1;
+            *expected = (long long)b - 1 - (long long)HGX_INTERDIST_HALF;
+            return 0;
+        }
+    }
+    return 0;
+}
 
 int hgx_build_alternatives(hgx_locus &L) {
     if (L.alts_built) return HGX_OK;
@@ -1529,9 +1548,10 @@ void emit_chunk(const hgx_parse_opts &o, const Fields *recs, const uint8_t *ok, 
     }
 }
 
-// get_pair_interdist (common:1187-1265): median inner distance of unique concordant pairs (CODIS D18S51 only)
-long pair_interdist(const Fields *recs, const uint8_t *ok, size_t n_recs, bool simulation, const hgx_parse_opts *opts = nullptr) {
-    std::vector<long> dists;
+// get_pair_interdist (common:1187-1265): median inner distance of unique concordant pairs (CODIS D18S51 only).  The distances of this
+// stream's pairs, in stream order:
+void pair_dists(const Fields *recs, const uint8_t *ok, size_t n_recs, bool simulation, std::vector<long> &dists) {
+    dists.clear();
     std::string prev;
     bool hp = false;
     std::vector<std::pair<long, long>> rd;
@@ -1558,28 +1578,28 @@ long pair_interdist(const Fields *recs, const uint8_t *ok, size_t n_recs, bool s
         prev = id;
         hp = true;
     }
+}
+// ... as the histogram the shards of a locus exchange (hgx.h: HGX_INTERDIST_BINS counters)
+void interdist_hist(const std::vector<long> &dists, std::vector<int64_t> &hist) {
+    hist.assign((size_t)HGX_INTERDIST_BINS, 0);
+    for (long d : dists) {
+        const long b = d < -(long)HGX_INTERDIST_HALF ? 0 : (d > (long)HGX_INTERDIST_HALF - 1 ? HGX_INTERDIST_BINS - 1 : 1 + d + HGX_INTERDIST_HALF);
+        hist[(size_t)b] += 1;
+    }
+}
+long pair_interdist(const Fields *recs, const uint8_t *ok, size_t n_recs, bool simulation, const hgx_parse_opts *opts = nullptr) {
+    std::vector<long> dists;
+    pair_dists(recs, ok, n_recs, simulation, dists);
     if (opts && opts->interdist_exchange) {
         // reads of the sample on several ranks: the median of ALL distances from the summed histogram (element int(len / 2) of the
         // sorted list, common:1258-1262)
-        std::vector<int64_t> hist((size_t)HGX_INTERDIST_BINS, 0);
-        for (long d : dists) {
-            const long b = d < -(long)HGX_INTERDIST_HALF ? 0 : (d > (long)HGX_INTERDIST_HALF - 1 ? HGX_INTERDIST_BINS - 1 : 1 + d + HGX_INTERDIST_HALF);
-            hist[(size_t)b] += 1;
-        }
+        std::vector<int64_t> hist;
+        interdist_hist(dists, hist);
         if (opts->interdist_exchange(opts->interdist_ctx, hist.data(), (int64_t)hist.size()) != 0)
             throw std::runtime_error("inter-distance exchange between the ranks of a sharded locus failed");
-        int64_t total = 0;
-        for (int64_t c : hist) total += c;
-        if (total == 0) return -1;
-        int64_t k = total / 2, seen = 0;
-        for (size_t b = 0; b < hist.size(); ++b) {
-            seen += hist[b];
-            if (seen > k) {
-                if (b == 0 || b + 1 == hist.size()) throw std::runtime_error("median pair distance outside the exchanged histogram's range");
-                return (long)b - 1 - (long)HGX_INTERDIST_HALF;
-            }
-        }
-        return -1;
+        long long expected = -1;
+        if (hgx_interdist_median(hist.data(), &expected)) throw std::runtime_error("median pair distance outside the exchanged histogram's range");
+        return (long)expected;
     }
     std::sort(dists.begin(), dists.end());
     return dists.empty() ? -1 : dists[dists.size() / 2];
@@ -1814,7 +1834,7 @@ int hgx_parse_alignment_file_hook(hgx_batch **out, const hgx_locus *Lc, const ch
         if (hook && hook->records && hook->mem.alloc) {
             pinned.reset(new hgx_big_alloc_scope(hook->mem, 4u << 20));
             al.on_raw = hook->on_raw;
-            al.defer_walk = hook->defer_walk && !(opts->codis_choose_pairs || opts->interdist_exchange);
+            al.defer_walk = hook->defer_walk;
             al.defer_min_bytes = hook->defer_min_bytes;
             if (al.defer_walk) { al.inflate_dev = hook->inflate_dev; al.comp_early = hook->comp_early; al.comp_sync = hook->comp_sync; }
             al.defer_text = al.defer_walk && hook->defer_text;
@@ -1938,17 +1958,14 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
     if (hook && hook->records && (raw || (def && def->on_device))) {
         // the record route of the device front end: fields, filters and key grouping as kernels too -- nothing below runs
         hook->declined_records = 0;
-        if (opts->codis_choose_pairs || opts->interdist_exchange) hook->declined_records = HGX_FE_DECLINE_OPTS;
-        else {
-            try {
-                const int rc = hook->records(*const_cast<hgx_locus *>(Lc), raw, raw_bytes, lines, n, binary, *opts, &hook->declined_records, def);
-                if (rc) return rc;
-            } catch (const std::exception &e) {
-                hgx_set_error("%s", e.what());
-                return HGX_EINVAL;
-            }
-            if (!hook->declined_records) { hook->declined = 0; return HGX_OK; }
+        try {
+            const int rc = hook->records(*const_cast<hgx_locus *>(Lc), raw, raw_bytes, lines, n, binary, *opts, &hook->declined_records, def);
+            if (rc) return rc;
+        } catch (const std::exception &e) {
+            hgx_set_error("%s", e.what());
+            return HGX_EINVAL;
         }
+        if (!hook->declined_records) { hook->declined = 0; return HGX_OK; }
     }
     if (def) return HGX_OK;                           // (declined: the caller reads the file again, with its records walked)
     hgx_locus &L = *const_cast<hgx_locus *>(Lc);
@@ -2047,12 +2064,19 @@ static int parse_lines(hgx_batch **out, const hgx_locus *Lc, hgx_line *lines, si
             // The device front end (hgx_front.hip; the lab build's emulation): everything from here on -- pileup, decode of the distinct
             // keys, piece table, pair protocol -- as kernels over the keys' text.  It may decline; the host stages below then run.
             hook->declined = 0;
-            if (opts->codis_choose_pairs || opts->interdist_exchange) hook->declined = HGX_FE_DECLINE_OPTS;
-            else if (n < hook->min_records) hook->declined = HGX_FE_DECLINE_SMALL;
+            if (n < hook->min_records) hook->declined = HGX_FE_DECLINE_SMALL;
             else {
                 hgx_front_input in;
                 in.mem = hook->mem;
                 hook->declined = build_front_input(*opts, recs, ok, n, cut, n_threads, reps.size(), in);
+                if (!hook->declined && (opts->codis_choose_pairs || opts->interdist_exchange)) {
+                    // CODIS D18S51: this stream's inner distances as the histogram the device stages take the median from (after
+                    // their pileup exchange: the order of the exchanges is the host stages')
+                    std::vector<long> dists;
+                    pair_dists(recs, ok, n, opts->simulation != 0, dists);
+                    interdist_hist(dists, in.interdist_hist);
+                    in.want_interdist = true;
+                }
                 lap("  key table for the device");
                 if (!hook->declined) {
                     const int rc = hook->run(L, in, *opts, &hook->declined);

@@ -454,8 +454,8 @@ def parse_shard(pl, sam_shard, comm, num_editdist=2, error_correction=True, allo
                 stream=None, alignment_file=None, regions=None, front=None):
     """The front end of one shard of a sharded locus, with the pileup exchange (and, for CODIS D18S51, the inter-distance exchange)
     and the failure protocol -> (host batch or None, engine.DeviceBatch).  On a GPU the shard goes through the DEVICE front end and
-    the exchange runs on the counter table in HBM (comm.allreduce_u32_dev); `front="host"`, D18S51 and GPU-less processes take the
-    host front end.  Collective: every rank of `comm` must call it."""
+    the exchange runs on the counter table in HBM (comm.allreduce_u32_dev; D18S51's inter-distance histogram, counted by the kernels,
+    goes through the host form); `front="host"` and GPU-less processes take the host front end.  Collective: every rank of `comm` must call it."""
     from . import engine
     # A rank whose front-end fails must not leave its peers waiting in an exchange.  Every exchange of the parse carries one
     # extra element, the failure flag (sum > 0 = some rank failed: every rank raises out of that exchange and skips the later
@@ -492,7 +492,7 @@ def parse_shard(pl, sam_shard, comm, num_editdist=2, error_correction=True, allo
             raise RuntimeError("another rank of this locus failed in its front-end")
     d18 = pl.base_fname == "codis" and pl.gene == "D18S51"
     n_exchanges = 2 if d18 else 1
-    on_device = front != "host" and not d18 and capi_has_device()
+    on_device = front != "host" and capi_has_device()
     batch = db = None
     try:
         if on_device:
@@ -502,14 +502,14 @@ def parse_shard(pl, sam_shard, comm, num_editdist=2, error_correction=True, allo
             # same call, through the host form of the same exchange.
             kw = dict(num_editdist=num_editdist, error_correction=error_correction, allow_discordant=allow_discordant,
                       simulation=simulation, base_locus=base_locus, stream=stream, pileup_exchange=exchange_u32,
-                      pileup_exchange_dev=exchange_u32_dev if hasattr(comm, "allreduce_u32_dev") else None)
+                      pileup_exchange_dev=exchange_u32_dev if hasattr(comm, "allreduce_u32_dev") else None,
+                      interdist_exchange=exchange if d18 else None, last_shard=comm.rank == comm.world - 1)
             if alignment_file is not None:
                 db = pl.parse_alignment_file_dev(alignment_file, regions, **kw)
             else:
                 db = pl.parse_sam_dev(sam_shard, **kw)
         else:
-            # CODIS D18S51 (choose_pairs and its inter-distance histogram are host work by design) and GPU-less processes (the gloo
-            # tests): the host front end
+            # GPU-less processes (the gloo tests) and `front="host"`: the host front end
             batch = pl.parse_sam(sam_shard, num_editdist=num_editdist, error_correction=error_correction,
                                  allow_discordant=allow_discordant, simulation=simulation, base_locus=base_locus,
                                  pileup_exchange=exchange_u32, interdist_exchange=exchange if d18 else None,

@@ -364,18 +364,20 @@ class PackedLocus:
         return keep, failure
 
     def parse_sam_dev(self, sam_text, num_editdist=2, error_correction=True, allow_discordant=False, simulation=False, base_locus=0,
-                      n_threads=0, stream=None, keep_trace=False, pileup_exchange=None, pileup_exchange_dev=None):
+                      n_threads=0, stream=None, keep_trace=False, pileup_exchange=None, pileup_exchange_dev=None, interdist_exchange=None,
+                      last_shard=True):
         """SAM text -> piece batch in HBM through the DEVICE front end (hgx_parse_sam_dev): record fields, filters, key grouping,
         pileup, decode, piece table and pair protocol run as kernels; inputs the kernels decline are finished by the host stages
         inside the same call.  Returns an engine.DeviceBatch (engine.front_last() tells which route ran).
         A shard of a sharded locus (dist.type_locus_sharded): `pileup_exchange(counts)` = the host form (numpy uint32 [L*6], summed
         in place over the shards), `pileup_exchange_dev(device pointer, n, stream)` = the device form (n = L*6 counters + one
-        spare element, summed in place in HBM); see hgx_parse_opts in include/hgx.h."""
+        spare element, summed in place in HBM); `interdist_exchange` / `last_shard`: as in parse_sam (CODIS D18S51: the kernels count
+        the inner distances, the histogram is exchanged after the pileup); see hgx_parse_opts in include/hgx.h."""
         from . import engine
         data = sam_text if isinstance(sam_text, (bytes, bytearray)) else sam_text.encode()
         o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus, int(keep_trace),
-                           int(self.base_fname == "codis" and self.gene == "D18S51"), int(n_threads))
-        keep, failure = self._install_exchanges(o, pileup_exchange, pileup_exchange_dev)
+                           int(self.base_fname == "codis" and self.gene == "D18S51" and last_shard), int(n_threads))
+        keep, failure = self._install_exchanges(o, pileup_exchange, pileup_exchange_dev, interdist_exchange)
         h = C.c_void_p()
         rc = capi.lib().hgx_parse_sam_dev(C.byref(h), self.h, data, C.c_size_t(len(data)), C.byref(o), stream)
         del keep
@@ -386,7 +388,7 @@ class PackedLocus:
 
     def parse_alignment_file_dev(self, path, regions=None, num_editdist=2, error_correction=True, allow_discordant=False,
                                  simulation=False, base_locus=0, n_threads=0, stream=None, keep_trace=False, pileup_exchange=None,
-                                 pileup_exchange_dev=None):
+                                 pileup_exchange_dev=None, interdist_exchange=None, last_shard=True):
         """parse_alignment_file through the device front end (hgx_parse_alignment_file_dev) -> engine.DeviceBatch."""
         from . import engine
         if regions is not None and not isinstance(regions, (str, bytes)):
@@ -394,8 +396,8 @@ class PackedLocus:
         if isinstance(regions, str):
             regions = regions.encode()
         o = capi.ParseOpts(num_editdist, int(error_correction), int(allow_discordant), int(simulation), base_locus, int(keep_trace),
-                           int(self.base_fname == "codis" and self.gene == "D18S51"), int(n_threads))
-        keep, failure = self._install_exchanges(o, pileup_exchange, pileup_exchange_dev)
+                           int(self.base_fname == "codis" and self.gene == "D18S51" and last_shard), int(n_threads))
+        keep, failure = self._install_exchanges(o, pileup_exchange, pileup_exchange_dev, interdist_exchange)
         h = C.c_void_p()
         rc = capi.lib().hgx_parse_alignment_file_dev(C.byref(h), self.h, path.encode(), regions or None, C.byref(o), stream)
         del keep

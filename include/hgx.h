@@ -381,7 +381,9 @@ typedef struct hgx_parse_opts {
      * concordant pairs (get_pair_interdist, typing_common.py:1187-1265).  If set, the callback is invoked once with this
      * shard's histogram of the distances -- HGX_INTERDIST_BINS int64 counters: bin 0 = below -HGX_INTERDIST_HALF, bin 1 + d +
      * HGX_INTERDIST_HALF = distance d, the last bin = above -- and must return with the element-wise sum over all shards in
-     * place; the median is then read from the summed histogram (exact; outside the range the parse fails).                  */
+     * place; the median is then read from the summed histogram (exact; outside the range the parse fails).  The device front end
+     * counts the distances as kernels (k_fe_interdist_*) and calls this after its pileup exchange -- the order of the host stages;
+     * a route that declines after the exchange hands the summed histogram to the host stages: one exchange per parse.        */
     int (*interdist_exchange)(void *ctx, int64_t *hist, int64_t n_bins);
     void *interdist_ctx;
     /* The DEVICE form of pileup_exchange, taken by the device front end (hgx_parse_sam_dev / hgx_parse_alignment_file_dev) when
@@ -493,7 +495,7 @@ int hgx_type_file(hgx_typing **out, const hgx_locus *loc, const hgx_index *ix, c
  * (typing_core.py:1386-1406, 718-792), the piece masks of add_count's span scan (typing_core.py:641-670), the distinct-piece
  * table and the pair protocol (typing_core.py:1238-1347) run as kernels; the batch is born in HBM, byte for byte the batch
  * hgx_parse_sam / hgx_parse_alignment_file build (hgx_dbatch_to_host shows it).  Inputs the kernels do not take -- fewer than
- * 1 000 records or 300 KB of stream (the measured break-even with the host stages: csrc/hgx_front.hip FE_MIN_*), keep_trace, CODIS D18S51's choose_pairs, variant ids that are not hv<n>, a record the reference would raise on,
+ * 1 000 records or 300 KB of stream (the measured break-even with the host stages: csrc/hgx_front.hip FE_MIN_*), keep_trace in a many-task pass, variant ids that are not hv<n>, a record the reference would raise on,
  * a pair with more alternatives than the kernels' scratch holds -- are finished by the host stages and uploaded: the result is
  * the same batch either way, and hgx_front_last says which way the calling thread's last call went (route: 2 = record route,
  * 1 = key route, 0 = host stages; decline_code: see HGX_FE_DECLINE_* / FE_E_* in csrc/hgx_internal.hpp,

@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import golden_util as gu
+from d18_cases import d18s51_cases
 from hisatgenotype_amd import capi, locus as hl, synth
 
 capi.use_lab()
@@ -57,10 +58,7 @@ def test_emulated_device_stages_equal_the_host_front_end_on_every_fixture(name):
               simulation=o["simulation"])
     host = pl.parse_sam(fx["sam"], **kw)
     emu, declined = emulated(pl, fx["sam"], **kw)
-    if name == "codis_d18s51":
-        assert declined == 1                      # choose_pairs (typing_core.py:1547-1552) stays on the host
-    else:
-        assert declined == 0, declined
+    assert declined == 0, declined               # (codis_d18s51 too: choose_pairs, typing_core.py:1547-1552, on the stream's last pair)
     same_batch(host, emu, len(fx["_locus"].backbone))
 
 
@@ -83,10 +81,7 @@ def test_emulated_kernels_against_the_reference_per_record(name, tmp_path):
     emu, dec = emulated(pl, fx["sam"], **kw)
     emu_r, dec_r = emulated_records(pl, sam=fx["sam"], **kw)
     emu_b, dec_b = emulated_records(pl, path=p_bam, regions=loc.ref_allele, **kw)
-    if name == "codis_d18s51":                     # choose_pairs stays on the host (whose trace the CPU suite checks)
-        assert dec == 1 and dec_r == (1, 1) and dec_b == (1, 1)
-    else:
-        assert dec == 0 and dec_r == (0, 0) and dec_b == (0, 0)
+    assert dec == 0 and dec_r == (0, 0) and dec_b == (0, 0)
     for b in (emu, emu_r, emu_b):
         check_pileup(fx, b)
         check_trace(fx, b)
@@ -161,7 +156,7 @@ def test_emulated_record_route_equals_the_host_front_end_on_every_fixture(name, 
     kw = dict(num_editdist=o["num_editdist"], error_correction=o["error_correction"], allow_discordant=o["allow_discordant"],
               simulation=o["simulation"])
     host = pl.parse_sam(fx["sam"], **kw)
-    want = (1, 1) if name == "codis_d18s51" else (0, 0)
+    want = (0, 0)                                  # (codis_d18s51 too: get_pair_interdist and choose_pairs are device stages since round 6)
     emu, dec = emulated_records(pl, sam=fx["sam"], **kw)
     assert dec == want, dec
     same_batch(host, emu, len(loc.backbone))
@@ -173,6 +168,53 @@ def test_emulated_record_route_equals_the_host_front_end_on_every_fixture(name, 
         emu, dec = emulated_records(pl, path=path, regions=loc.ref_allele, **kw)
         assert dec == want, (path, dec)
         same_batch(host, emu, len(loc.backbone))
+
+
+def test_emulated_choose_pairs_on_the_last_pair_of_a_d18s51_stream(tmp_path):
+    """get_pair_interdist (typing_common.py:1187-1265: the median inner distance of the sample's unique concordant pairs, as
+    k_fe_interdist_* count it) and choose_pairs on the stream's last pair (fe_choose_pairs in k_fe_pair_choose / k_fe_pair_emit) == the
+    host front end, by the key route, the record route and from a BAM; in a good share of the cases the choice CHANGES the batch."""
+    from hisatgenotype_amd import bamio
+    n_all = n_changed = 0
+    pls = {}
+    for d18, plain, text in d18s51_cases():
+        if id(d18) not in pls:
+            pls[id(d18)] = (hl.PackedLocus.from_synth(d18), hl.PackedLocus.from_synth(plain))
+        pl, pl0 = pls[id(d18)]
+        host = pl.parse_sam(text)
+        n_all += 1
+        n_changed += host.pair_ref.tobytes() != pl0.parse_sam(text).pair_ref.tobytes()
+        emu, dec = emulated(pl, text)
+        assert dec == 0
+        same_batch(host, emu, len(d18.backbone))
+        emu, dec = emulated_records(pl, sam=text)
+        assert dec == (0, 0), dec
+        same_batch(host, emu, len(d18.backbone))
+        if n_all % 8 == 0:
+            # (a BAM's records come back in name order -- stable, so the moved pair is no longer last: another last pair, the same rule)
+            p_bam = str(tmp_path / "d.bam")
+            bamio.write_bam_native(p_bam, text.encode(), [(d18.ref_allele, len(d18.backbone))], sort_by_coordinate=True)
+            host_b = pl.parse_alignment_file(p_bam, d18.ref_allele)
+            emu, dec = emulated_records(pl, path=p_bam, regions=d18.ref_allele)
+            assert dec == (0, 0), dec
+            same_batch(host_b, emu, len(d18.backbone))
+    assert n_all >= 150 and n_changed >= n_all // 5, (n_all, n_changed)
+    # records that do not count: a YT tag that is not CP, NH > 1, unaligned, a later (short) YT tag that overrides an earlier one
+    d18, plain, text = next(iter(d18s51_cases(1)))
+    pl = pls[id(d18)][0] if id(d18) in pls else hl.PackedLocus.from_synth(d18)
+    lines = text.split("\n")[:-1]
+    for k in range(0, len(lines), 5):
+        lines[k] = lines[k].replace("YT:Z:CP", "YT:Z:DP")
+    for k in range(1, len(lines), 11):
+        lines[k] = lines[k] + "\tYT"
+    for k in range(2, len(lines), 13):
+        lines[k] = lines[k] + "\tYT:Z:CP"
+    text2 = "\n".join(lines) + "\n"
+    host = pl.parse_sam(text2)
+    for run in (lambda: emulated(pl, text2), lambda: emulated_records(pl, sam=text2)):
+        emu, dec = run()
+        assert dec in (0, (0, 0)), dec
+        same_batch(host, emu, len(d18.backbone))
 
 
 def test_emulated_device_stages_on_fuzz_cases():

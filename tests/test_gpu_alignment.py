@@ -79,10 +79,7 @@ def test_every_fixture_out_of_one_multi_locus_file(multi_files, kind):
             pl = hl.PackedLocus.from_synth(fx["_locus"])
             res = hgx.type_locus(pl, None, alignment=al, regions=[_rname(k)], num_editdist=o["num_editdist"], error_correction=o["error_correction"],
                                  allow_discordant=o["allow_discordant"], remove_low_abundance_alleles=o["remove_low"], simulation=o["simulation"])
-            if name == "codis_d18s51":                  # choose_pairs (typing_core.py:1547-1552) is host work by design: the per-path call
-                assert engine.front_last()[0] == 0
-            else:
-                assert engine.front_last() == (2, 0), (name, engine.front_last())
+            assert engine.front_last() == (2, 0), (name, engine.front_last())
             _check_fixture(name, res)
             pl.close()
 

@@ -42,10 +42,7 @@ def test_device_front_end_equals_the_host_front_end_on_every_fixture(name):
         with engine.test_switches(**switches):             # (the fixtures are smaller than the size gate)
             dev = pl.parse_sam_dev(fx["sam"], **kw)
             route, code = engine.front_last()
-        if name == "codis_d18s51":
-            assert (route, code) == (0, 1)                 # choose_pairs (typing_core.py:1547-1552) stays on the host
-        else:
-            assert (route, code) == (want, 0), (route, code)
+        assert (route, code) == (want, 0), (route, code)    # (codis_d18s51 too: get_pair_interdist and choose_pairs are kernels since round 6)
         assert (dev.n_reads, dev.n_pairs, dev.n_pieces, dev.n_refs) == (host.n_reads, host.n_pairs, host.n_pieces, host.n_refs)
         same_batch(host, dev.to_host(), len(fx["_locus"].backbone), pileup=route > 0)
         assert (dev.sum_piece_words, dev.n_gene_refs) == (hd.sum_piece_words, hd.n_gene_refs)   # the byte-model inputs of the bench line
@@ -77,10 +74,6 @@ def test_kernels_against_the_reference_per_record(name, tmp_path):
         with engine.test_switches(**switches):
             dev = run()
             route, code = engine.front_last()
-        if name == "codis_d18s51":
-            assert (route, code) == (0, 1)                 # choose_pairs stays on the host: its trace is the CPU suite's business
-            check_trace(fx, dev.to_host())
-            continue
         assert (route, code) == (want, 0), (switches, route, code)
         b = dev.to_host()
         check_pileup(fx, b)
@@ -158,7 +151,7 @@ def test_record_route_on_files(name, tmp_path):
         with engine.test_switches(front="device"):
             dev = pl.parse_alignment_file_dev(path, regions=[loc.ref_allele], **kw)
             route, code = engine.front_last()
-        assert (route, code) == ((0, 1) if name == "codis_d18s51" else (2, 0)), (path, route, code)
+        assert (route, code) == (2, 0), (path, route, code)
         same_batch(host, dev.to_host(), len(loc.backbone), pileup=route > 0)
 
 
@@ -360,3 +353,50 @@ def test_bam_records_walked_filtered_and_sorted_on_the_device(tmp_path):
         pl.parse_alignment_file(p_bad, None)
     with engine.test_switches(front="device"), pytest.raises(capi.HgxError):
         pl.parse_alignment_file_dev(p_bad, regions=None)
+
+
+def test_choose_pairs_on_the_last_pair_of_a_d18s51_stream(tmp_path):
+    """CODIS D18S51 on the kernels (round 6; it stayed on the host stages before): get_pair_interdist (typing_common.py:1187-1265: the
+    median inner distance of the sample's unique concordant pairs -- k_fe_interdist_flag / _compact / _hist over the records, or the
+    host stages' histogram on the key route) and choose_pairs (typing_core.py:680-716) on the stream's LAST pair (1547-1552:
+    k_fe_pair_count marks it, k_fe_pair_choose re-counts it, k_fe_pair_emit writes the chosen haplotypes).  Every 9th pair of a
+    sample is moved to the end of the stream in turn; in a good share of the cases the choice changes the batch.  == the host front
+    end by the record route, the key route, from a BAM and out of a resident alignment file."""
+    from hisatgenotype_amd import bamio
+    from d18_cases import d18s51_cases
+    n_all = n_changed = 0
+    pls = {}
+    for d18, plain, text in d18s51_cases():
+        if id(d18) not in pls:
+            pls[id(d18)] = (hl.PackedLocus.from_synth(d18), hl.PackedLocus.from_synth(plain))
+        pl, pl0 = pls[id(d18)]
+        host = pl.parse_sam(text)
+        n_all += 1
+        n_changed += host.pair_ref.tobytes() != pl0.parse_sam(text).pair_ref.tobytes()
+        for switches, want in ((dict(front="device"), 2), (dict(front="device,keys"), 1)):
+            with engine.test_switches(**switches):
+                dev = pl.parse_sam_dev(text)
+                assert engine.front_last() == (want, 0), engine.front_last()
+            assert dev.n_gene_refs == engine.DeviceBatch(host).n_gene_refs
+            same_batch(host, dev.to_host(), len(d18.backbone))
+        if n_all % 8 == 0:
+            p_bam = str(tmp_path / "d.bam")
+            bamio.write_bam_native(p_bam, text.encode(), [(d18.ref_allele, len(d18.backbone))], sort_by_coordinate=True)
+            host_b = pl.parse_alignment_file(p_bam, d18.ref_allele)
+            with engine.test_switches(front="device"):
+                dev = pl.parse_alignment_file_dev(p_bam, regions=[d18.ref_allele])
+                assert engine.front_last() == (2, 0), engine.front_last()
+                same_batch(host_b, dev.to_host(), len(d18.backbone))
+                with engine.Alignment(p_bam) as al:
+                    dev = al.parse_dev(pl, regions=[d18.ref_allele])
+                    assert engine.front_last() == (2, 0), engine.front_last()
+                    same_batch(host_b, dev.to_host(), len(d18.backbone))
+    assert n_all >= 150 and n_changed >= n_all // 5, (n_all, n_changed)
+    # above the size gate without any switch: a sample of 3 000 pairs takes the record route by itself
+    d18, plain, _ = next(iter(d18s51_cases(1)))
+    pl = pls[id(d18)][0] if id(d18) in pls else hl.PackedLocus.from_synth(d18)
+    dn = [a for a in d18.allele_names if "BACKBONE" not in a]
+    sam = synth.simulate_sam_fast(d18, [dn[4], dn[-2]], 3000, read_len=100, frag_len=(200, 280), err_rate=0.002, seed=5)
+    dev = pl.parse_sam_dev(sam)
+    assert engine.front_last() == (2, 0), engine.front_last()
+    same_batch(pl.parse_sam(sam), dev.to_host(), len(d18.backbone))

@@ -92,7 +92,7 @@ WORKER = textwrap.dedent('''
         for sw in (dict(front="device"), dict()):
             with engine.test_switches(**sw):
                 res = hdist.type_locus_sharded(pl, shards[rank], comm)
-                if sw and shards[rank] and what != "CODIS D18S51":       # (D18S51 stays on the host front end by design)
+                if sw and shards[rank]:
                     assert engine.front_last() == (2, 0), (what, rank, engine.front_last())
             assert (res.num_reads, res.num_pairs) == (ref.num_reads, ref.num_pairs), (what, rank)
             assert res.counts_sorted == ref.counts_sorted and res.em == ref.em and res.gene_prob == ref.gene_prob, (what, rank)

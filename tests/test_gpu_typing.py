@@ -50,10 +50,7 @@ class _front:
     def check(self):
         if not self.front:
             return
-        if self.name == "codis_d18s51":                      # choose_pairs (typing_core.py:1547-1552) stays on the host by design
-            assert engine.front_last() == (0, 1), engine.front_last()
-        else:
-            assert engine.front_last() == (2 if self.front == "device" else 1, 0), engine.front_last()
+        assert engine.front_last() == (2 if self.front == "device" else 1, 0), engine.front_last()      # (codis_d18s51 too, since round 6)
 
     def __exit__(self, *exc):
         if self.sw:
@@ -700,8 +697,9 @@ def test_type_file_sam_bam_sorted_bam_with_regions(name, front, tmp_path):
         assert keep(got) == want, path.name
 
 
-def _type_sharded(pl, sam, world):
-    """One sample's pairs of a locus split over `world` threads-as-ranks on one GPU (dist.LocalComm); returns rank 0's result."""
+def _type_sharded(pl, sam, world, fronts=None):
+    """One sample's pairs of a locus split over `world` threads-as-ranks on one GPU (dist.LocalComm); returns rank 0's result.
+    `fronts[r]` = "host": rank r takes the host front end whatever the switches say."""
     import threading
     from hisatgenotype_amd import capi, dist as hdist
     pl.index()
@@ -712,7 +710,7 @@ def _type_sharded(pl, sam, world):
     def run(r):
         try:
             capi.set_device(capi.current_device())
-            out[r] = hdist.type_locus_sharded(pl, shards[r], comms[r], stream=capi.get_stream(2))
+            out[r] = hdist.type_locus_sharded(pl, shards[r], comms[r], stream=capi.get_stream(2), front=fronts[r] if fronts else None)
             routes[r] = engine.front_last()
         except BaseException as e:
             errs.append(e)
@@ -770,10 +768,19 @@ def test_sharded_d18s51_uses_the_whole_samples_pair_distance():
     sample = [names[3], names[-3]]
     sam = synth.simulate_sam_fast(loc, sample, 4000, read_len=100, frag_len=(200, 280), err_rate=0.002, seed=17)
     ref = hgx.type_locus(pl, sam)
+    with engine.test_switches(front="host"):
+        assert hgx.type_locus(pl, sam).gene_prob == ref.gene_prob          # (the unsharded sample: kernels == host stages)
     for world in (2, 3):
         got = _type_sharded(pl, sam, world)
         assert (got.num_reads, got.num_pairs) == (ref.num_reads, ref.num_pairs)
         assert got.counts_sorted == ref.counts_sorted and got.em == ref.em and got.gene_prob == ref.gene_prob
+        # every shard through the kernels (k_fe_interdist_* count the distances, the histogram is exchanged after the pileup), and mixed
+        # with a rank on the host stages: the same two exchanges in the same order
+        with engine.test_switches(front="device"):
+            for fronts in (None, ["host"] + [None] * (world - 1)):
+                got = _type_sharded(pl, sam, world, fronts=fronts)
+                assert got.counts_sorted == ref.counts_sorted and got.em == ref.em and got.gene_prob == ref.gene_prob
+                assert got.front_routes[1:] == [(2, 0)] * (world - 1) and got.front_routes[0][0] == (0 if fronts else 2), got.front_routes
 
 
 def test_a_failing_rank_fails_every_rank_of_a_sharded_locus():
