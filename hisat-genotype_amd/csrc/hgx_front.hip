@@ -133,15 +133,13 @@ int dev_locus(hgx_locus &L, hipStream_t st, const FeLocus **view, bool *usable) 
     const size_t i_lbits = add(H.linked_bits, L.linked_bits.size() * 4), i_bb = add(H.backbone, L.backbone.size());
     const size_t i_ex = add(H.exons, D->T.exons.size() * 4), i_hv = add(H.hv_index, L.hv_index.size() * 4);
     const size_t i_noff = add(H.name_off, D->T.name_off.size() * 4), i_npool = add(H.name_pool, D->T.name_pool.size());
-    size_t i_anchor[2], i_koff[2], i_soff[2], i_loff[2];
+    size_t i_anchor[2], i_koff[2], i_loff[2];         // (the keys' spellings stay on the host: the kernels compare variant ids, fe_key_contains)
     for (int d = 0; d < 2; ++d) {
         i_anchor[d] = add(H.alt_anchor[d], D->T.alt_anchor[d].size() * 4);
         i_koff[d] = add(H.alt_key_off[d], D->T.alt_key_off[d].size() * 4);
-        i_soff[d] = add(H.alt_str_off[d], D->T.alt_str_off[d].size() * 4);
         i_loff[d] = add(H.alt_list_off[d], D->T.alt_list_off[d].size() * 4);
     }
     const size_t i_htoff = add(H.alt_ht_off, D->T.alt_ht_off.size() * 4), i_ints = add(H.alt_ints, D->T.alt_ints.size() * 4);
-    const size_t i_chars = add(H.alt_chars, D->T.alt_chars.size());
     char *block = (char *)hgx_pool_alloc(std::max<size_t>(total, 256));
     if (!block) { hgx_set_error("device allocation of the front end's locus tables failed"); return HGX_ENOMEM; }
     std::vector<char> host(total, 0);
@@ -157,9 +155,9 @@ int dev_locus(hgx_locus &L, hipStream_t st, const FeLocus **view, bool *usable) 
     F.name_pool = (const char *)at(i_npool);
     for (int d = 0; d < 2; ++d) {
         F.alt_anchor[d] = (const int32_t *)at(i_anchor[d]); F.alt_key_off[d] = (const int32_t *)at(i_koff[d]);
-        F.alt_str_off[d] = (const int32_t *)at(i_soff[d]); F.alt_list_off[d] = (const int32_t *)at(i_loff[d]);
+        F.alt_str_off[d] = nullptr; F.alt_list_off[d] = (const int32_t *)at(i_loff[d]);
     }
-    F.alt_ht_off = (const int32_t *)at(i_htoff); F.alt_ints = (const int32_t *)at(i_ints); F.alt_chars = (const char *)at(i_chars);
+    F.alt_ht_off = (const int32_t *)at(i_htoff); F.alt_ints = (const int32_t *)at(i_ints); F.alt_chars = nullptr;
     D->per_dev.push_back({dev, block, F});
     *view = &D->per_dev.back().view;
     return HGX_OK;

@@ -90,7 +90,7 @@ struct FeLocus {
     int32_t n_alt[2];
     const int32_t *alt_anchor[2];    // [n] sorted
     const int32_t *alt_key_off[2];   // [n + 1] into alt_ints: the key as left, vars..., right
-    const int32_t *alt_str_off[2];   // [n + 1] into alt_chars: the key as the reference spells it
+    const int32_t *alt_str_off[2];   // [n + 1] into alt_chars: the key as the reference spells it (host only: the lab emulation's cross-check)
     const int32_t *alt_list_off[2];  // [n + 1] into alt_ht_off: the record's alternatives
     const int32_t *alt_ht_off;       // [n_hts + 1] into alt_ints
     const int32_t *alt_ints;
@@ -505,19 +505,44 @@ FE_HD inline int fe_side_add(FeSide &s, int coord, const int *ids, int n) {
     return 0;
 }
 
-// "hv12-hv40" of ids[0..n) into buf; returns the length, < 0 = decline.  Novel ids spell "nv<k>": a letter no key contains, so
-// any text with an 'n' in it does the job of the comparison it is made for (key.find(cur_join)).
+// key.find(cur_join) != -1 (typing_common.py:1744, 1868) on variant ids instead of text.  The reference joins the ids of the entries up
+// to the current one with '-' ("hv12-hv40") and searches the alternative's key ("529-hv8-hv12-hv40-606") for that text.  Every id
+// spells "hv<digits>" (a locus with other names is not taken: hgx_front_tables_build), the key's first and last fields are
+// numbers, so a match can only START at the first letter of one of the key's ids and every id of the needle but the last is followed
+// by '-': those must equal the key's ids; the needle's LAST id only has to be a decimal prefix of the key's ("hv4" is found in
+// "...-hv40-..."): the reference's quirk, kept.  A novel id spells "nv<k>": no key contains an 'n'.
+// kv[0..nk) = the key's variant ids, cur[0..n) = the needle's, n > 0.
+FE_HD inline bool fe_name_is_prefix(const FeLocus &L, int a, int b) {              // name(a) is a prefix of name(b)
+    const int a0 = L.name_off[a], al = L.name_off[a + 1] - a0, b0 = L.name_off[b], bl = L.name_off[b + 1] - b0;
+    if (al > bl) return false;
+    for (int k = 0; k < al; ++k) if (L.name_pool[a0 + k] != L.name_pool[b0 + k]) return false;
+    return true;
+}
+FE_HD inline bool fe_key_contains(const FeLocus &L, const int *kv, int nk, const int *cur, int n) {
+    for (int t = 0; t < n; ++t) if (cur[t] < 0 || cur[t] >= L.V) return false;
+    const int last = cur[n - 1];
+    for (int p = 0; p + n <= nk; ++p) {
+        int t = 0;
+        while (t < n - 1 && kv[p + t] == cur[t]) ++t;
+        if (t == n - 1 && (kv[p + t] == last || fe_name_is_prefix(L, last, kv[p + t]))) return true;
+    }
+    return false;
+}
+#if defined(HGX_LAB) && !defined(__HIP_DEVICE_COMPILE__)
+// The lab library's CPU emulation checks the predicate above against the reference's own form -- the text search -- on every
+// candidate it meets (a difference declines the input with FE_E_ASSERT: tests/lab_front_cases.py expects none).
+#define FE_CHECK_KEY_TEXT 1
 FE_HD inline int fe_join(const FeLocus &L, const int *ids, int n, char *buf) {
     int w = 0;
     for (int i = 0; i < n; ++i) {
-        if (i) { if (w >= FE_MAX_JOIN) return FE_FAIL(FE_E_CAP); buf[w++] = '-'; }
+        if (i) { if (w >= FE_MAX_JOIN) return -1; buf[w++] = '-'; }
         const int id = ids[i];
         if (id >= 0 && id < L.V) {
             const int a = L.name_off[id], b = L.name_off[id + 1];
-            if (w + (b - a) > FE_MAX_JOIN) return FE_FAIL(FE_E_CAP);
+            if (w + (b - a) > FE_MAX_JOIN) return -1;
             for (int k = a; k < b; ++k) buf[w++] = L.name_pool[k];
         } else {
-            if (w + 2 > FE_MAX_JOIN) return FE_FAIL(FE_E_CAP);
+            if (w + 2 > FE_MAX_JOIN) return -1;
             buf[w++] = 'n'; buf[w++] = 'v';
         }
     }
@@ -532,6 +557,14 @@ FE_HD inline bool fe_contains(const char *hay, int n_hay, const char *needle, in
     }
     return false;
 }
+FE_HD inline bool fe_key_text_agrees(const FeLocus &L, int dir, int j, const int *cur, int n, bool got) {
+    char join[FE_MAX_JOIN];
+    const int nj = fe_join(L, cur, n, join);
+    if (nj < 0) return true;                                        // (longer than the scratch: nothing to compare with)
+    const int s0 = L.alt_str_off[dir][j], s1 = L.alt_str_off[dir][j + 1];
+    return fe_contains(L.alt_chars + s0, s1 - s0, join, nj) == got;
+}
+#endif
 
 FE_HD inline int fe_ambiguous(const FeLocus &L, const FeCmp *c2, int n, int &cmp_left, int &cmp_right, FeSide &lset, FeSide &rset) {
     const int n_ref = L.n_ref;
@@ -541,7 +574,6 @@ FE_HD inline int fe_ambiguous(const FeLocus &L, const FeCmp *c2, int n, int &cmp
     lset.n = lset.n_ids = 0;
     rset.n = rset.n_ids = 0;
     int cur[FE_MAX_IDS], part[FE_MAX_IDS], sids[FE_MAX_IDS];
-    char join[FE_MAX_JOIN];
     int rc;
 #define FE_SKIP(c) (fe_type(c) == FE_T_MATCH ? false : fe_type(c) == FE_T_INSERTION ? true : !fe_is_hv(L, (c).id))
     // ---- left direction ----
@@ -565,18 +597,19 @@ FE_HD inline int fe_ambiguous(const FeLocus &L, const FeCmp *c2, int n, int &cmp
             if (tk == FE_T_MATCH) { const int e = c2[k].pos + c2[k].len < n_ref ? c2[k].pos + c2[k].len : n_ref; seqlen += e - c2[k].pos > 0 ? e - c2[k].pos : 0; }
             else if (tk == FE_T_MISMATCH) seqlen += 1;
         }
-        int n_join = -1;
         bool i_found = false;
         for (; j >= 0; --j) {
             const int r_anchor = anchor[j];
             if (r_anchor < cur_left) break;
             if (r_anchor > cur_right) continue;
-            if (n_cur > 0) {
-                if (n_join < 0) { n_join = fe_join(L, cur, n_cur, join); if (n_join < 0) return n_join; }
-                const int s0 = L.alt_str_off[0][j], s1 = L.alt_str_off[0][j + 1];
-                if (!fe_contains(L.alt_chars + s0, s1 - s0, join, n_join)) continue;
-            }
             const int *key_ht = L.alt_ints + L.alt_key_off[0][j];
+            if (n_cur > 0) {
+                const bool has = fe_key_contains(L, key_ht + 1, L.alt_key_off[0][j + 1] - L.alt_key_off[0][j] - 2, cur, n_cur);
+#ifdef FE_CHECK_KEY_TEXT
+                if (!fe_key_text_agrees(L, 0, j, cur, n_cur, has)) return FE_FAIL(FE_E_ASSERT);
+#endif
+                if (!has) continue;
+            }
             const int flen = (L.alt_key_off[0][j + 1] - L.alt_key_off[0][j]) - 1;          // fields of key.split('-')[:-1]
             if (n_cur + 1 == flen) {
                 if (left < key_ht[0]) continue;
@@ -654,18 +687,19 @@ FE_HD inline int fe_ambiguous(const FeLocus &L, const FeCmp *c2, int n, int &cmp
             if (tk == FE_T_MATCH) { const int e = c2[k].pos + c2[k].len < n_ref ? c2[k].pos + c2[k].len : n_ref; seqlen += e - c2[k].pos > 0 ? e - c2[k].pos : 0; }
             else if (tk == FE_T_MISMATCH) seqlen += 1;
         }
-        int n_join = -1;
         bool i_found = false;
         for (; j < na; ++j) {
             const int r_anchor = anchor[j];
             if (r_anchor > cur_right) break;
             if (r_anchor < cur_left) continue;
-            if (n_cur > 0) {
-                if (n_join < 0) { n_join = fe_join(L, cur, n_cur, join); if (n_join < 0) return n_join; }
-                const int s0 = L.alt_str_off[1][j], s1 = L.alt_str_off[1][j + 1];
-                if (!fe_contains(L.alt_chars + s0, s1 - s0, join, n_join)) continue;
-            }
             const int *key_ht = L.alt_ints + L.alt_key_off[1][j];
+            if (n_cur > 0) {
+                const bool has = fe_key_contains(L, key_ht + 1, L.alt_key_off[1][j + 1] - L.alt_key_off[1][j] - 2, cur, n_cur);
+#ifdef FE_CHECK_KEY_TEXT
+                if (!fe_key_text_agrees(L, 1, j, cur, n_cur, has)) return FE_FAIL(FE_E_ASSERT);
+#endif
+                if (!has) continue;
+            }
             const int flen = (L.alt_key_off[1][j + 1] - L.alt_key_off[1][j]) - 1;          // fields of key.split('-')[1:]
             const int *f = key_ht + 1;
             if (n_cur + 1 == flen) {

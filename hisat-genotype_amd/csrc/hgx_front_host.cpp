@@ -437,6 +437,37 @@ int hgx_front_emulate_records(hgx_batch **out, hgx_locus &L, const char *raw, si
 #endif
 
 #ifdef HGX_LAB
+// fe_key_contains (the kernels' form of key.find(cur_join) != -1, typing_common.py:1744 / 1868, on variant ids) beside the text
+// search it stands for, on a made-up table: names = '\n'-joined variant names ("hv12\nhv3\n..."; id = line number), key / cur = ids.
+// out[0] = the id form, out[1] = the text form.
+extern "C" int hgx_lab_key_contains(const char *names, const int32_t *key, int32_t n_key, const int32_t *cur, int32_t n_cur, int32_t *out) {
+    HARGCHK(names && key && cur && out && n_cur > 0 && n_key >= 0);
+    std::vector<int32_t> off{0};
+    std::vector<char> pool;
+    std::vector<std::string> nm;
+    for (const char *p = names; *p;) {
+        const char *e = strchr(p, '\n');
+        if (!e) e = p + strlen(p);
+        nm.emplace_back(p, e);
+        pool.insert(pool.end(), p, e);
+        off.push_back((int32_t)pool.size());
+        p = *e ? e + 1 : e;
+    }
+    FeLocus F;
+    memset(&F, 0, sizeof(F));
+    F.V = (int32_t)nm.size();
+    F.name_off = off.data();
+    F.name_pool = pool.data();
+    for (int k = 0; k < n_key; ++k) HARGCHK(key[k] >= 0 && key[k] < F.V);
+    out[0] = fe_key_contains(F, key, n_key, cur, n_cur) ? 1 : 0;
+    std::string hay = "529", needle;
+    for (int k = 0; k < n_key; ++k) hay += "-" + nm[(size_t)key[k]];
+    hay += "-606";
+    for (int k = 0; k < n_cur; ++k) needle += (k ? "-" : "") + (cur[k] >= 0 && cur[k] < F.V ? nm[(size_t)cur[k]] : std::string("nv") + std::to_string(k));
+    out[1] = hay.find(needle) != std::string::npos ? 1 : 0;
+    return HGX_OK;
+}
+
 // SAM text -> batch through the emulated device stages (lab library only; tests/test_front_emulation.py).  *declined != 0: the
 // device path would hand this input to the host stages, which then produced the batch.
 extern "C" int hgx_lab_parse_sam_emulated(hgx_batch **out, const hgx_locus *loc, const char *sam, size_t n_bytes, const hgx_parse_opts *opts,

@@ -217,6 +217,41 @@ def test_emulated_choose_pairs_on_the_last_pair_of_a_d18s51_stream(tmp_path):
         same_batch(host, emu, len(d18.backbone))
 
 
+def test_key_find_on_variant_ids_equals_the_text_search():
+    """identify_ambigious_diffs asks `key.find(cur_join) != -1` (typing_common.py:1744, 1868) of every candidate alternative; the kernels
+    ask it of the variant IDS (fe_key_contains: equal ids, the needle's LAST id a decimal prefix of the key's -- "hv4" is found in
+    "hv40", the reference's quirk).  Both forms on made-up keys: ids whose names are prefixes of one another, needles that end in
+    such an id, start in the middle of the key, hold a novel id, are longer than the key."""
+    rng = random.Random(5)
+    names = ["hv%d" % k for k in (1, 10, 100, 11, 12, 2, 20, 21, 3, 30, 4, 40, 400, 41, 5, 7, 77, 770, 8, 9)]
+    text = "\n".join(names).encode()
+    n_true = n_prefix_only = 0
+    out = (C.c_int32 * 2)()
+    for _ in range(20000):
+        nk = rng.randint(0, 7)
+        key = [rng.randrange(len(names)) for _ in range(nk)]
+        n = rng.randint(1, 4)
+        if nk >= n and rng.random() < 0.6:                      # mostly: a window of the key, its last id cut to a prefix now and then
+            p = rng.randint(0, nk - n)
+            cur = key[p:p + n]
+            if rng.random() < 0.4:
+                shorter = [i for i, nm in enumerate(names) if names[cur[-1]].startswith(nm)]
+                cur[-1] = rng.choice(shorter)
+            if rng.random() < 0.1:
+                cur[rng.randrange(n)] = rng.choice([-1, len(names) + 3])            # a novel id
+        else:
+            cur = [rng.randrange(len(names)) for _ in range(n)]
+        ka, ca = (C.c_int32 * max(nk, 1))(*key), (C.c_int32 * n)(*cur)
+        capi.check(capi.lib().hgx_lab_key_contains(text, ka, C.c_int32(nk), ca, C.c_int32(n), out))
+        assert out[0] == out[1], (key, cur, out[0], out[1])
+        n_true += out[0]
+        want_py = "-".join(names[c] if 0 <= c < len(names) else "nv" for c in cur) in "529-" + "".join(names[k] + "-" for k in key) + "606"
+        assert bool(out[1]) == want_py
+        if out[0] and nk >= n and not any(key[p:p + n] == cur for p in range(nk - n + 1)):
+            n_prefix_only += 1
+    assert n_true > 5000 and n_prefix_only > 300, (n_true, n_prefix_only)
+
+
 def test_emulated_device_stages_on_fuzz_cases():
     """The cases of tools/fuzz_parity.py (HLA-like loci with deletions / insertions / unlinked variants, STR loci, sequencing
     errors, soft clips, novel indels, multi-hit and duplicate records, single-end samples) plus deeper samples of the fast generator."""
