@@ -1716,14 +1716,18 @@ __global__ void __launch_bounds__(256) k_sam_name_key(const unsigned char *__res
     key[i] = v;
 }
 __global__ void k_sam_lines(const uint32_t *__restrict__ k_off, const uint32_t *__restrict__ k_len, const uint32_t *__restrict__ idx, uint32_t n,
-                            FeLine *__restrict__ lines) {
+                            uint32_t off_base, FeLine *__restrict__ lines) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { const uint32_t r = idx[i]; lines[i] = FeLine{k_off[r], k_len[r], 0u}; }
+    if (i < n) { const uint32_t r = idx[i]; lines[i] = FeLine{off_base + k_off[r], k_len[r], 0u}; }
 }
 
-int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &def, hipStream_t st, DevBuf &b_lines, uint32_t *n_lines, int *declined) {
+// `off_base`: d_text is a PART of a larger text that starts off_base bytes into it (the lines' offsets count from the whole text's
+// first byte).  `unsorted_out` != NULL: a text that is not in name order is not sorted here -- *unsorted_out = 1, no lines.
+int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &def, hipStream_t st, DevBuf &b_lines, uint32_t *n_lines, int *declined,
+                  uint32_t off_base = 0, int *unsorted_out = nullptr) {
     *declined = 0;
     *n_lines = 0;
+    if (unsorted_out) *unsorted_out = 0;
     Lap lap(st);
     const unsigned char *text = (const unsigned char *)d_text;
     if (n_bytes >= (1ull << 32) - 64) { *declined = HGX_FE_DECLINE_SIZE; return HGX_OK; }
@@ -1808,6 +1812,7 @@ int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &de
         HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(&nd, b_diff.p, sizeof(NameDiff), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        if (h.unsorted && unsorted_out) { *unsorted_out = 1; return HGX_OK; }
         if (h.unsorted) {
             ALLOC(b_idx2, (size_t)n_kept * 4); ALLOC(b_key, (size_t)n_kept * 8); ALLOC(b_key2, (size_t)n_kept * 8);
             uint32_t *idx_alt = b_idx2.as<uint32_t>();
@@ -1832,7 +1837,7 @@ int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &de
         }
         lap(h.unsorted ? "SAM name sort" : "SAM name order check");
     }
-    if (n_kept) k_sam_lines<<<nblk(n_kept, 256), 256, 0, st>>>(b_koff.as<uint32_t>(), b_klen2.as<uint32_t>(), idx, n_kept, b_lines.as<LineRef>());
+    if (n_kept) k_sam_lines<<<nblk(n_kept, 256), 256, 0, st>>>(b_koff.as<uint32_t>(), b_klen2.as<uint32_t>(), idx, n_kept, off_base, b_lines.as<LineRef>());
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(st));                                           // (idx may live in a buffer of this function)
     *n_lines = n_kept;
@@ -1840,7 +1845,9 @@ int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &de
 }
 
 int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRef *h_lines, size_t n_lines, bool binary, int n_tasks,
-                const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, ManyTotals *many, int *declined, const LineRef *d_lines = nullptr) {
+                const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, ManyTotals *many, int *declined, const LineRef *d_lines = nullptr,
+                const FeRec *pre_recs = nullptr) {
+    // (pre_recs: the records of d_lines taken apart already -- k_fe_records ran beside the upload's tail, records_split below)
     *out = nullptr;
     *declined = 0;
     Lap lap(st);
@@ -1860,7 +1867,7 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
     if (want_interdist && n_tasks > 1) { *declined = HGX_FE_DECLINE_OPTS; return HGX_OK; }
     struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
     if (!d_lines) ALLOC(b_lines, std::max<size_t>(n_lines, 1) * sizeof(LineRef));
-    ALLOC(b_recs, std::max<size_t>(n_lines, 1) * sizeof(FeRec));
+    if (!pre_recs) ALLOC(b_recs, std::max<size_t>(n_lines, 1) * sizeof(FeRec));
     ALLOC(b_head, std::max<size_t>(n_lines, 16));
     ALLOC(b_kept, std::max<size_t>(n_lines, 16));
     ALLOC(b_slot_of, std::max<size_t>(n_lines, 4) * 4);
@@ -1895,8 +1902,8 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
     memset(&h, 0, sizeof(h));
     if (n) {
         const FeFilter flt{o.num_editdist, o.allow_discordant, o.base_locus};
-        FeRec *recs = b_recs.as<FeRec>();
-        k_fe_records<<<nblk(n, 256), 256, 0, st>>>(d_text, raw_bytes + 64, lines_dev, n, binary ? 1 : 0, o.simulation, recs, ctl);
+        FeRec *recs = pre_recs ? const_cast<FeRec *>(pre_recs) : b_recs.as<FeRec>();
+        if (!pre_recs) k_fe_records<<<nblk(n, 256), 256, 0, st>>>(d_text, raw_bytes + 64, lines_dev, n, binary ? 1 : 0, o.simulation, recs, ctl);
         k_fe_rec_heads<<<nblk(n, 256), 256, 0, st>>>(recs, n, d_text, b_head.as<uint8_t>());
         k_fe_rec_filter_insert<<<nblk(n, 256), 256, 0, st>>>(recs, b_head.as<uint8_t>(), n, flt, b_tkeys.as<unsigned long long>(), d_rep,
                                                             d_pile, d_anyk, cap - 1, b_kept.as<uint8_t>(),
@@ -1981,6 +1988,105 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
     return HGX_OK;
 }
 
+// SAM text whose last bytes are still on their way up (round 6).  The reader hands the text over in phases; the link carries it at
+// ~47 GB/s (8.7 ms for the 410 MB of a 1 M-read file) and every kernel used to wait for the last byte.  Here the text is cut at a line
+// end inside the phases that have LANDED but for the last one: part A's line table (k_sam_*) and record fields (k_fe_records, the
+// largest kernel of a SAM call) run on a second stream beside the last phase's transfer, part B's behind it; the two line tables and
+// record arrays are joined (the name order across the cut checked on the host's copy of the text) and the record stage goes on from
+// the filters.  Anything unusual -- a part that is not in name order, a declined part -- returns *handled = 0: the whole text then goes
+// the ordinary way.
+struct SamPhase { size_t end; hipEvent_t landed; };
+// the second stream of such a call: made once per device and caller in flight, then reused (hipStreamCreate takes 3-9 ms on this
+// runtime -- more than the overlap wins -- so a call never makes one it could borrow)
+struct SideStreams {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;      // (device, stream)
+    hipStream_t take(int dev) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t k = 0; k < idle.size(); ++k)
+                if (idle[k].first == dev) { hipStream_t s = idle[k].second; idle.erase(idle.begin() + (long)k); return s; }
+        }
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        return s;
+    }
+    void give(int dev, hipStream_t s) { std::lock_guard<std::mutex> g(mu); idle.push_back({dev, s}); }
+};
+SideStreams g_side;
+int records_split(hgx_locus &L, const char *d_text, const char *raw, size_t raw_bytes, const hgx_bam_deferred &def, const std::vector<SamPhase> &phases,
+                  const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, int *declined, int *handled) {
+    *handled = 0;
+    if (phases.size() < 2 || phases.back().end != raw_bytes || raw_bytes >= (1ull << 32) - 64) return HGX_OK;
+    const size_t landed_end = phases[phases.size() - 2].end;
+    size_t cut = landed_end;
+    while (cut > 0 && raw[cut - 1] != '\n') --cut;                 // part A = whole lines inside the phases before the last
+    if (cut < raw_bytes / 4 || cut >= raw_bytes) return HGX_OK;
+    Lap lap(st);
+    const bool dbg = getenv("HGX_SPLIT_DEBUG") != nullptr;
+    const double t_in = now_ms();
+    auto mark = [&](const char *what) { if (dbg) fprintf(stderr, "[records_split] %-32s +%.3f ms\n", what, now_ms() - t_in); };
+    if (dbg) fprintf(stderr, "[records_split] event of the landed phases: %s\n", hipEventQuery(phases[phases.size() - 2].landed) == hipSuccess ? "done" : "pending");
+    int dev = -1;
+    HIPCHK(hipGetDevice(&dev));
+    hipStream_t sb = g_side.take(dev);
+    if (!sb) return HGX_OK;
+    mark("second stream");
+    DevBuf b_la, b_lb, b_ra, b_lines, b_recs, b_pctl;
+    hipEvent_t a_done = nullptr;
+    struct Guard {
+        int dev; hipStream_t &sb, st; hipEvent_t &ev;
+        ~Guard() { (void)hipStreamSynchronize(sb); (void)hipStreamSynchronize(st); if (ev) (void)hipEventDestroy(ev); g_side.give(dev, sb); }
+    } guard{dev, sb, st, a_done};
+    HIPCHK(hipStreamWaitEvent(sb, phases[phases.size() - 2].landed, 0));
+    ALLOC(b_pctl, 256);
+    HIPCHK(hipMemsetAsync(b_pctl.p, 0, 256, sb));
+    uint32_t n_a = 0, n_b = 0;
+    int dec = 0, unsorted = 0;
+    int rc = sam_lines_dev(d_text, cut, def, sb, b_la, &n_a, &dec, 0u, &unsorted);
+    mark("part A lines back");
+    if (dbg) fprintf(stderr, "[records_split] last phase: %s\n", hipEventQuery(phases.back().landed) == hipSuccess ? "landed" : "on its way");
+    if (rc) return rc;
+    if (dec || unsorted || n_a == 0) return HGX_OK;
+    ALLOC(b_ra, (size_t)n_a * sizeof(FeRec));
+    // (text_bytes = the part's: no load of a record's scan reaches into bytes that are still landing)
+    k_fe_records<<<nblk(n_a, 256), 256, 0, sb>>>(d_text, cut, b_la.as<LineRef>(), n_a, 0, o.simulation, b_ra.as<FeRec>(), b_pctl.as<FeCtl>());
+    HIPCHK(hipEventCreateWithFlags(&a_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(a_done, sb));
+    lap("part A: lines + record fields queued");
+    mark("part A records queued");
+    rc = sam_lines_dev(d_text + cut, raw_bytes - cut, def, st, b_lb, &n_b, &dec, (uint32_t)cut, &unsorted);      // (st: behind the last phase's copy)
+    mark("part B lines back");
+    if (rc) return rc;
+    if (dec || unsorted) return HGX_OK;
+    const size_t n = (size_t)n_a + n_b;
+    if (n >= (1ull << 30)) return HGX_OK;
+    FeLine edge[2];
+    HIPCHK(hipMemcpyAsync(&edge[0], b_la.as<LineRef>() + (n_a - 1), sizeof(FeLine), hipMemcpyDeviceToHost, st));
+    if (n_b) HIPCHK(hipMemcpyAsync(&edge[1], b_lb.as<LineRef>(), sizeof(FeLine), hipMemcpyDeviceToHost, st));
+    ALLOC(b_lines, n * sizeof(LineRef));
+    ALLOC(b_recs, n * sizeof(FeRec));
+    HIPCHK(hipMemcpyAsync(b_lines.p, b_la.p, (size_t)n_a * sizeof(LineRef), hipMemcpyDeviceToDevice, st));
+    if (n_b) HIPCHK(hipMemcpyAsync(b_lines.as<LineRef>() + n_a, b_lb.p, (size_t)n_b * sizeof(LineRef), hipMemcpyDeviceToDevice, st));
+    if (n_b) k_fe_records<<<nblk(n_b, 256), 256, 0, st>>>(d_text, raw_bytes + 64, b_lb.as<LineRef>(), n_b, 0, o.simulation, b_recs.as<FeRec>() + n_a, b_pctl.as<FeCtl>());
+    HIPCHK(hipStreamWaitEvent(st, a_done, 0));
+    HIPCHK(hipMemcpyAsync(b_recs.p, b_ra.p, (size_t)n_a * sizeof(FeRec), hipMemcpyDeviceToDevice, st));
+    FeCtl h;
+    HIPCHK(hipMemcpyAsync(&h, b_pctl.p, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    lap("part B: lines + record fields, joined");
+    if (n_b) {                                                      // name order across the cut: line_less of hgx_bam.cpp on the host's copy
+        const char *a = raw + edge[0].off, *b = raw + edge[1].off;
+        const void *ta = memchr(a, '\t', edge[0].len), *tb = memchr(b, '\t', edge[1].len);
+        const size_t la = ta ? (size_t)((const char *)ta - a) : edge[0].len, lb = tb ? (size_t)((const char *)tb - b) : edge[1].len;
+        const int c = memcmp(b, a, std::min(la, lb));
+        if (c < 0 || (c == 0 && lb < la)) return HGX_OK;            // B's first name sorts before A's last: the whole text is sorted the ordinary way
+    }
+    *handled = 1;
+    if (h.decline) { *declined = -h.decline; return HGX_OK; }
+    return records_run(L, d_text, raw_bytes, nullptr, n, false, 1, o, st, out, nullptr, declined, b_lines.as<LineRef>(), b_recs.as<FeRec>());
+}
+
 // Size gates of the device front end, from tools/front_gate.py on an MI355X box (round 6; 7 000- and 500-allele loci alike): the
 // device stages cost a flat 1.0-1.5 ms for SAM text and 2.7-3.0 ms for a BAM file (inflate, walk and sorts on the device) up to
 // 40 000 records, the host stages 2.3 us per record on one thread -- they cross at ~800 records of SAM text and ~2 000 BAM
@@ -2046,12 +2152,23 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
     const unsigned char *comp_from = nullptr;
     size_t up_bytes = 0, comp_n = 0;
     bool up_failed = false;
+    // the phases of a SAM text on their way up, each with an event behind its copy (records_split)
+    std::vector<SamPhase> sam_phases;
+    auto drop_phases = [&]() { for (SamPhase &p : sam_phases) (void)hipEventDestroy(p.landed); sam_phases.clear(); };
+    struct PhaseGuard { std::function<void()> f; ~PhaseGuard() { f(); } } phase_guard{drop_phases};
+    const bool split_ok = !hgx_switch_has("front", "sam_whole");
     if (!host_only && !no_records) {
         hook.on_raw = [&](const char *raw, size_t n_bytes, size_t begin, size_t end) {
             if (n_bytes >= (1ull << 32) - 64 || up_failed) return;
             if (!force && n_bytes < FE_MIN_BYTES) return;            // (the record stage will decline it as small: no upload for nothing)
             if (!text_room(n_bytes + 64)) { up_failed = true; return; }
             if (end > begin && hipMemcpyAsync((char *)b_text.p + begin, raw + begin, end - begin, hipMemcpyHostToDevice, st) != hipSuccess) { up_failed = true; return; }
+            if (up_raw != raw || up_bytes != n_bytes || begin == 0) drop_phases();      // (a file read a second time: the events of the first read say nothing)
+            if (split_ok) {
+                hipEvent_t ev = nullptr;
+                if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, st) == hipSuccess) sam_phases.push_back(SamPhase{end, ev});
+                else { if (ev) (void)hipEventDestroy(ev); drop_phases(); }
+            }
             up_raw = raw;
             up_bytes = n_bytes;
             g_last_bytes += (long long)(end - begin);
@@ -2097,6 +2214,18 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
                 DevBuf b_dl;
                 uint32_t n_dl = 0;
                 struct DrainL { hipStream_t s; ~DrainL() { (void)hipStreamSynchronize(s); } } drain_l{st};
+                if (def->text && raw && sam_phases.size() >= 2) {
+                    int handled = 0;
+                    const int rcs = records_split(L, b_text.as<char>(), raw, raw_bytes, *def, sam_phases, o, st, &made, declined, &handled);
+                    if (rcs) return rcs;
+                    if (handled) {
+                        if (!*declined && made) route = 2;
+                        return (int)HGX_OK;
+                    }
+                    hgx_dbatch_destroy(made);
+                    made = nullptr;
+                    *declined = 0;
+                }
                 int rc = def->text ? sam_lines_dev(b_text.as<char>(), raw_bytes, *def, st, b_dl, &n_dl, declined)
                                    : bam_lines_dev(b_text.as<char>(), {def}, {(size_t)0}, {raw_bytes}, st, b_dl, &n_dl, declined);
                 if (rc || *declined) return rc;

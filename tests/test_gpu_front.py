@@ -400,3 +400,53 @@ def test_choose_pairs_on_the_last_pair_of_a_d18s51_stream(tmp_path):
     dev = pl.parse_sam_dev(sam)
     assert engine.front_last() == (2, 0), engine.front_last()
     same_batch(pl.parse_sam(sam), dev.to_host(), len(d18.backbone))
+
+
+def test_sam_text_in_two_parts_beside_the_upload_equals_the_whole_text(tmp_path):
+    """A SAM file of more than 64 MB goes up in phases; the line table and the record fields of the phases that have landed run on a
+    second stream beside the last phase's transfer (records_split), the rest behind it, the two halves are joined.  == the same file
+    with the switch `front=sam_whole` (every kernel after the last byte: rounds 4-6), with and without a region, with a last line
+    that has no newline; a text whose two parts are each in name order but not across the cut, and one that is unsorted inside a part,
+    fall back to the whole-text path (and its name sort)."""
+    loc = synth.make_hla_like_locus(n_alleles=400, n_vars=500, seed=77)
+    pl = hl.PackedLocus.from_synth(loc)
+    sam = synth.simulate_sam_fast(loc, synth.pick_sample(loc, 3), 150000, err_rate=0.003, seed=9)
+    assert len(sam) > (64 << 20)
+    lines = sam.split("\n")[:-1]
+
+    def run(text, regions, name):
+        p = str(tmp_path / name)
+        with open(p, "w") as f:
+            f.write(text)
+        with engine.test_switches(front="sam_whole"):
+            whole = pl.parse_alignment_file_dev(p, regions=regions)
+            assert engine.front_last() == (2, 0), engine.front_last()
+        parts = pl.parse_alignment_file_dev(p, regions=regions)
+        assert engine.front_last() == (2, 0), engine.front_last()
+        a, b = whole.to_host(), parts.to_host()
+        same_batch(a, b, len(loc.backbone))
+        os.remove(p)
+        return a
+
+    full = run(sam, None, "full.sam")
+    assert full.n_reads > 250000
+    run(sam, [loc.ref_allele], "region.sam")
+    run(sam[:-1], None, "no_last_newline.sam")
+    # the groups of the last fifth moved to the front: every part in name order by itself?  No -- the cut lands inside the rotated text,
+    # part A is unsorted at the seam: the whole-text path sorts; the result is the sorted file's
+    k = len(lines) * 4 // 5
+    while lines[k].split("\t", 1)[0] == lines[k - 1].split("\t", 1)[0]:
+        k += 1
+    rotated = "\n".join(lines[k:] + lines[:k]) + "\n"
+    rot = run(rotated, None, "rotated.sam")
+    same_batch(full, rot, len(loc.backbone))
+    # in name order inside both parts, not across the cut (the cut falls at ~3/4 of the bytes: swap the halves around it)
+    cut = len(lines) * 3 // 4
+    while lines[cut].split("\t", 1)[0] == lines[cut - 1].split("\t", 1)[0]:
+        cut += 1
+    # (names sort as text: make the second part's names sort first by a prefix)
+    first = [l for l in lines[:cut]]
+    second = ["0" + l for l in lines[cut:]]
+    host = pl.parse_sam("\n".join(second + first) + "\n")
+    got = run("\n".join(first + second) + "\n", None, "across.sam")
+    same_batch(host, got, len(loc.backbone))
