@@ -74,7 +74,7 @@ SYMBOLS = [
     "hgx_classes_pack_rows", "hgx_classes_merge_gathered", "hgx_rccl_stats",
     "hgx_keyset_create", "hgx_keyset_dims", "hgx_keyset_fill", "hgx_keyset_destroy",
     "hgx_many_from_dbatch", "hgx_alignment_open", "hgx_alignment_dims", "hgx_alignment_parse_dev", "hgx_alignment_close", "hgx_stream_sets_info", "hgx_stream_create_placed", "hgx_stream_probe_matrix", "hgx_stream_probe_pair", "hgx_stream_probe_chain", "hgx_stream_sets_streams",
-    "hgx_parse_sam_dev", "hgx_parse_alignment_file_dev", "hgx_front_last", "hgx_dbatch_to_host",
+    "hgx_parse_sam_dev", "hgx_parse_alignment_file_dev", "hgx_front_last", "hgx_front_last_parts", "hgx_dbatch_to_host",
     "hgx_emx_cluster_stats", "hgx_em_tie_reruns",
 ]
 

@@ -1024,7 +1024,7 @@ __global__ void k_bam_lines(const uint32_t *__restrict__ rec_off, const uint32_t
     if (i < n) { const uint32_t r = idx[i]; lines[i] = FeLine{rec_off[r], rec_len[r], (uint32_t)rec_task[r]}; }
 }
 
-thread_local int g_last_device = 0, g_last_decline = 0, g_last_route = 0;
+thread_local int g_last_device = 0, g_last_decline = 0, g_last_route = 0, g_last_parts = 0;
 thread_local long long g_last_bytes = 0;      // bytes the last call sent to the device (text / inflated stream / key table)
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -2083,6 +2083,7 @@ int records_split(hgx_locus &L, const char *d_text, const char *raw, size_t raw_
         if (c < 0 || (c == 0 && lb < la)) return HGX_OK;            // B's first name sorts before A's last: the whole text is sorted the ordinary way
     }
     *handled = 1;
+    g_last_parts = 2;
     if (h.decline) { *declined = -h.decline; return HGX_OK; }
     return records_run(L, d_text, raw_bytes, nullptr, n, false, 1, o, st, out, nullptr, declined, b_lines.as<LineRef>(), b_recs.as<FeRec>());
 }
@@ -2245,6 +2246,7 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
     struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};     // (an upload may still read the reader's buffer)
     hgx_batch *b = nullptr;
     g_last_bytes = 0;
+    g_last_parts = 0;
     const int rc = parse(&b, host_only ? nullptr : &hook, opts);
     (void)hipStreamSynchronize(st);
     g_last_route = rc ? 0 : route;
@@ -2596,6 +2598,11 @@ int hgx_front_many_dev(hgx_dbatch **out, hgx_front_totals *tot, const hgx_locus 
     return HGX_OK;
 }
 
+extern "C" int hgx_front_last_parts(int32_t *parts) {
+    ARGCHK(parts);
+    *parts = g_last_parts;
+    return HGX_OK;
+}
 extern "C" int hgx_front_last(int32_t *route, int32_t *decline_code, int64_t *bytes_to_device) {
     if (route) *route = g_last_device ? g_last_route : 0;
     if (decline_code) *decline_code = g_last_decline;

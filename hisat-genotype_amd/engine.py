@@ -138,6 +138,13 @@ def front_last():
     return ran.value, code.value
 
 
+def front_last_parts():
+    """2 = that call took a big SAM text in two parts (the first beside the upload's tail), 0 = every kernel behind the last byte."""
+    n = C.c_int32(0)
+    capi.check(capi.lib().hgx_front_last_parts(C.byref(n)))
+    return n.value
+
+
 def front_last_bytes():
     """Bytes that call sent to the device (SAM text / inflated BAM stream + line table, or the key table of the key route)."""
     n = C.c_int64(0)

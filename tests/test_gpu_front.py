@@ -420,18 +420,21 @@ def test_sam_text_in_two_parts_beside_the_upload_equals_the_whole_text(tmp_path)
             f.write(text)
         with engine.test_switches(front="sam_whole"):
             whole = pl.parse_alignment_file_dev(p, regions=regions)
-            assert engine.front_last() == (2, 0), engine.front_last()
+            assert engine.front_last() == (2, 0) and engine.front_last_parts() == 0, engine.front_last()
         parts = pl.parse_alignment_file_dev(p, regions=regions)
         assert engine.front_last() == (2, 0), engine.front_last()
+        assert engine.front_last_parts() == want_parts, engine.front_last_parts()
         a, b = whole.to_host(), parts.to_host()
         same_batch(a, b, len(loc.backbone))
         os.remove(p)
         return a
 
+    want_parts = 2
     full = run(sam, None, "full.sam")
     assert full.n_reads > 250000
     run(sam, [loc.ref_allele], "region.sam")
     run(sam[:-1], None, "no_last_newline.sam")
+    want_parts = 0                                              # (what follows falls back to the whole text)
     # the groups of the last fifth moved to the front: every part in name order by itself?  No -- the cut lands inside the rotated text,
     # part A is unsorted at the seam: the whole-text path sorts; the result is the sorted file's
     k = len(lines) * 4 // 5
