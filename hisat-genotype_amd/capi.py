@@ -69,7 +69,7 @@ SYMBOLS = [
     "hgx_dbatch_create", "hgx_dbatch_destroy", "hgx_dbatch_dims", "hgx_gate_create", "hgx_gate_destroy", "hgx_type_dbatch",
     "hgx_type_batch", "hgx_type_file", "hgx_typing_destroy", "hgx_typing_dims", "hgx_typing_counts", "hgx_typing_em",
     "hgx_typing_gene_prob", "hgx_typing_classes", "hgx_write_bam", "hgx_em_last_exact", "hgx_index_device_block", "hgx_index_create_device", "hgx_type_classes", "hgx_pair_classes_dedup",
-    "hgx_bgzf_inflate", "hgx_many_create", "hgx_many_create_files", "hgx_many_create_sams", "hgx_many_tasks", "hgx_many_destroy", "hgx_many_dims", "hgx_type_many", "hgx_type_many_loci", "hgx_em_set_fast", "hgx_em_last_order", "hgx_typing_top", "hgx_emx_set_timing", "hgx_emx_get_timing",
+    "hgx_bgzf_inflate", "hgx_bgzf_scan_compare", "hgx_many_create", "hgx_many_create_files", "hgx_many_create_sams", "hgx_many_tasks", "hgx_many_destroy", "hgx_many_dims", "hgx_type_many", "hgx_type_many_loci", "hgx_em_set_fast", "hgx_em_last_order", "hgx_typing_top", "hgx_emx_set_timing", "hgx_emx_get_timing",
     "hgx_index_broadcast", "hgx_allreduce_sum_u32", "hgx_allreduce_sum_i64", "hgx_classes_allgather",
     "hgx_classes_pack_rows", "hgx_classes_merge_gathered", "hgx_rccl_stats",
     "hgx_keyset_create", "hgx_keyset_dims", "hgx_keyset_fill", "hgx_keyset_destroy",

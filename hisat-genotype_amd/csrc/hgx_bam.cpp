@@ -756,8 +756,16 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
                     looks_bam = first[0].out_len == 0 || peek_is_bam(data.data(), first);      // (an empty first block: the full scan decides)
             }
         }
+        const bool dbg_t = getenv("HGX_BAM_DEBUG") != nullptr;
+        const auto t_dbg0 = std::chrono::steady_clock::now();
+        auto dbg_mark = [&](const char *what) {
+            if (dbg_t) fprintf(stderr, "[bam deferred] %-28s +%.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_dbg0).count());
+        };
         if (looks_bam && out.comp_early && data.size() >= out.defer_min_bytes / 64) out.comp_early(data.data(), data.size());   // (BGZF rarely deflates below 1 : 64)
-        if (looks_bam && hgx_bgzf_scan(data.data(), data.size(), blocks, &total) == HGX_OK && total < (1ull << 32) - 64 && peek_is_bam(data.data(), blocks)) {
+        dbg_mark("upload queued");
+        if (looks_bam && hgx_bgzf_scan_par(data.data(), data.size(), blocks, &total, std::min(n_threads, 8)) == HGX_OK && total < (1ull << 32) - 64 &&
+            peek_is_bam(data.data(), blocks)) {
+            dbg_mark("container scanned");
             std::vector<unsigned char> head;
             std::vector<std::string> refs;
             size_t body0 = 0;
@@ -766,7 +774,9 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             // zlib: 0.2-0.3 ms -- on a worker beside it (round 5: it stood in front of the launch)
             hgx_run_workers(2, [&](int w) {
                 if (w == 0) {
+                    dbg_mark("worker 0 running");
                     if (total >= out.defer_min_bytes) dev_rc = out.inflate_dev(data.data(), data.size(), blocks, total);
+                    dbg_mark("inflate_dev back");
                 } else {
                     for (size_t k = 0; k < blocks.size() && st_h == 0 && head.size() < (64u << 20); ++k) {
                         const size_t at = head.size();

@@ -35,7 +35,9 @@
 #include "hgx_common.hpp"
 #include "hgx_internal.hpp"
 
-int hgx_bgzf_inflate_dev(const unsigned char *d_in, const hgx_bgzf_block *blocks, size_t n_blocks, unsigned char *d_out, hipStream_t st, int *bad);
+int hgx_bgzf_inflate_dev(const unsigned char *d_in, const hgx_bgzf_block *blocks, size_t n_blocks, unsigned char *d_out, hipStream_t st, int *bad,
+                         void *staging);
+size_t hgx_bgzf_inflate_staging_bytes(size_t n_blocks);
 
 namespace {
 
@@ -52,7 +54,9 @@ struct PinnedPool {
 PinnedPool &pinned() { static PinnedPool *p = new PinnedPool(); return *p; }
 void *pinned_alloc(size_t n) {
     PinnedPool &P = pinned();
-    size_t need = std::max<size_t>(n, 4096);
+    // (a block is at least 2 MB -- the registration's grain below -- and a request takes a block of up to 4x its size + 1 MB: a
+    // request below 256 KB would never find its own block again and register a new one per call, 0.5 ms each)
+    size_t need = std::max<size_t>(n, 512u << 10);
     {
         std::lock_guard<std::mutex> g(P.mu);
         auto it = P.free_blocks.lower_bound(need);
@@ -2200,7 +2204,9 @@ int parse_dev(hgx_dbatch **out, hipStream_t st, const hgx_parse_opts *opts_in, P
                     if (hipMemsetAsync((char *)b_comp.p + n, 0, 2048, st) != hipSuccess) return 1;
                 }
                 int bad = 0;
-                if (hgx_bgzf_inflate_dev(b_comp.as<unsigned char>(), blocks.data(), blocks.size(), b_text.as<unsigned char>(), st, &bad) != HGX_OK || bad) return 1;
+                void *stg = pinned_alloc(hgx_bgzf_inflate_staging_bytes(blocks.size()));         // (registered: the block table queues behind the file)
+                struct Unstage { void *p; ~Unstage() { pinned_release(p); } } unstage{stg};
+                if (hgx_bgzf_inflate_dev(b_comp.as<unsigned char>(), blocks.data(), blocks.size(), b_text.as<unsigned char>(), st, &bad, stg) != HGX_OK || bad) return 1;
                 up_raw = nullptr;
                 up_bytes = total;
                 g_last_bytes += (long long)n;
@@ -2349,7 +2355,9 @@ extern "C" int hgx_alignment_open(hgx_alignment **out, const char *path, int32_t
                     if (hipMemsetAsync((char *)b_comp.p + n, 0, 2048, st) != hipSuccess) return 1;
                 }
                 int bad = 0;
-                if (hgx_bgzf_inflate_dev(b_comp.as<unsigned char>(), blocks.data(), blocks.size(), b_text.as<unsigned char>(), st, &bad) != HGX_OK || bad) {
+                void *stg = pinned_alloc(hgx_bgzf_inflate_staging_bytes(blocks.size()));
+                struct Unstage { void *p; ~Unstage() { pinned_release(p); } } unstage{stg};
+                if (hgx_bgzf_inflate_dev(b_comp.as<unsigned char>(), blocks.data(), blocks.size(), b_text.as<unsigned char>(), st, &bad, stg) != HGX_OK || bad) {
                     (void)hipStreamSynchronize(st);
                     hgx_pool_free(b_text.p);
                     b_text.p = nullptr;
@@ -2499,7 +2507,7 @@ int hgx_front_many_dev(hgx_dbatch **out, hgx_front_totals *tot, const hgx_locus 
                 ALLOC(b_text2, ptotal + 64);
                 HIPCHK(hipMemsetAsync((char *)b_comp.p + ctotal, 0, 4096, st));
                 int bad = 0;
-                rcb = hgx_bgzf_inflate_dev(b_comp.as<unsigned char>(), all.data(), all.size(), b_text2.as<unsigned char>(), st, &bad);
+                rcb = hgx_bgzf_inflate_dev(b_comp.as<unsigned char>(), all.data(), all.size(), b_text2.as<unsigned char>(), st, &bad, nullptr);
                 if (rcb) return rcb;
                 lap("BGZF inflate (device)");
                 if (!bad) {

@@ -23,6 +23,7 @@
 // host reader, which reproduces the failure with its own message.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <type_traits>
@@ -1156,14 +1157,122 @@ int hgx_bgzf_scan(const unsigned char *data, size_t n, std::vector<hgx_bgzf_bloc
     return HGX_OK;
 }
 
+// The same on several host threads.  The blocks of a BGZF file form a chain (each BSIZE leads to the next header), and every hop of
+// the walk is a cache miss in bytes another core has just written: 5 007 blocks of a 20 MB BAM took 0.55 ms on one thread -- in front
+// of the device inflate's launch (tools/bam_gap_timeline.py).  Here the file is cut into ranges; every range but the first FINDS a
+// block start (the gzip magic with a BC subfield whose BSIZE leads to three more such headers, or to the file's end) and walks from
+// there to the first block boundary at or behind its end; the ranges must link up -- a walk ends exactly where the next one began --
+// or the chain is walked by one thread after all (which also words the errors).  Same descriptors, same order.
+int hgx_bgzf_scan_par(const unsigned char *data, size_t n, std::vector<hgx_bgzf_block> &blocks, size_t *total_out, int n_threads) {
+    const int T = (int)std::min<size_t>({(size_t)std::max(1, n_threads), (size_t)16, n / (1u << 20)});
+    if (T < 2) return hgx_bgzf_scan(data, n, blocks, total_out);
+    auto rd16 = [&](size_t p) { return (unsigned)data[p] | ((unsigned)data[p + 1] << 8); };
+    auto rd32 = [&](size_t p) { return (uint32_t)data[p] | ((uint32_t)data[p + 1] << 8) | ((uint32_t)data[p + 2] << 16) | ((uint32_t)data[p + 3] << 24); };
+    // length of the block whose header starts at `off` (0 = not a block the serial walk would take), its payload's place
+    auto block_at = [&](size_t off, hgx_bgzf_block *b) -> size_t {
+        if (off + 18 > n || data[off] != 0x1f || data[off + 1] != 0x8b || data[off + 2] != 8 || !(data[off + 3] & 4)) return 0;
+        const unsigned xlen = rd16(off + 10);
+        if (off + 12 + xlen > n) return 0;
+        long bsize = -1;
+        for (size_t p = off + 12; p + 4 <= off + 12 + xlen;) {
+            const unsigned slen = rd16(p + 2);
+            if (data[p] == 66 && data[p + 1] == 67 && slen == 2 && p + 6 <= off + 12 + xlen) bsize = (long)rd16(p + 4);
+            p += 4 + slen;
+        }
+        if (bsize < 0) return 0;
+        const size_t blen = (size_t)bsize + 1;
+        if (off + blen > n || blen < 12 + xlen + 8) return 0;
+        if (b) { b->in_off = off + 12 + xlen; b->in_len = blen - 12 - xlen - 8; b->crc = rd32(off + blen - 8); b->out_len = rd32(off + blen - 4); b->out_off = 0; }
+        return blen;
+    };
+    std::vector<std::vector<hgx_bgzf_block>> part((size_t)T);
+    std::vector<size_t> first((size_t)T, n), last((size_t)T, n), out_bytes((size_t)T, 0);
+    std::vector<int> bad((size_t)T, 0);
+    hgx_run_workers(T, [&](int r) {
+        const size_t lo = n * (size_t)r / (size_t)T, hi = n * (size_t)(r + 1) / (size_t)T;
+        size_t off = lo;
+        if (r > 0) {
+            off = n;
+            for (size_t p = lo; p + 18 <= n && p < hi;) {
+                const unsigned char *q = (const unsigned char *)memchr(data + p, 0x1f, hi - p);
+                if (!q) break;
+                p = (size_t)(q - data);
+                size_t at = p;
+                int hops = 0;
+                for (; hops < 4 && at < n; ++hops) {
+                    const size_t bl = block_at(at, nullptr);
+                    if (!bl) break;
+                    at += bl;
+                }
+                if (hops == 4 || (hops > 0 && at == n)) { off = p; break; }
+                ++p;
+            }
+        }
+        first[(size_t)r] = off;
+        std::vector<hgx_bgzf_block> &mine = part[(size_t)r];
+        mine.reserve((hi - lo) / 2048 + 16);
+        size_t tot = 0;
+        while (off < hi) {
+            hgx_bgzf_block b;
+            const size_t bl = block_at(off, &b);
+            if (!bl) { bad[(size_t)r] = 1; break; }
+            b.out_off = tot;
+            tot += b.out_len;
+            mine.push_back(b);
+            off += bl;
+        }
+        last[(size_t)r] = off;
+        out_bytes[(size_t)r] = tot;
+    });
+    bool linked = first[0] == 0;
+    for (int r = 0; r < T && linked; ++r) linked = !bad[(size_t)r] && last[(size_t)r] == (r + 1 < T ? first[(size_t)r + 1] : n);
+    if (!linked) return hgx_bgzf_scan(data, n, blocks, total_out);
+    size_t n_blocks = 0, total = 0;
+    for (auto &v : part) n_blocks += v.size();
+    blocks.clear();
+    blocks.reserve(n_blocks);
+    for (int r = 0; r < T; ++r) {
+        for (hgx_bgzf_block b : part[(size_t)r]) { b.out_off += total; blocks.push_back(b); }
+        total += out_bytes[(size_t)r];
+    }
+    if (total_out) *total_out = total;
+    return HGX_OK;
+}
+
+// test entry (hgx.h; host only, no GPU): the container walked by one thread and by `n_threads` -- *same = both gave the same verdict
+// and, where they took the file, the same descriptors
+extern "C" int hgx_bgzf_scan_compare(const void *bgzf, size_t n_bytes, int32_t n_threads, int64_t *n_blocks, int32_t *same) {
+    ARGCHK(bgzf && n_blocks && same);
+    std::vector<hgx_bgzf_block> a, b;
+    size_t ta = 0, tb = 0;
+    const int ra = hgx_bgzf_scan((const unsigned char *)bgzf, n_bytes, a, &ta);
+    const int rb = hgx_bgzf_scan_par((const unsigned char *)bgzf, n_bytes, b, &tb, n_threads);
+    *n_blocks = ra == HGX_OK ? (int64_t)a.size() : -1;
+    bool eq = ra == rb;
+    if (eq && ra == HGX_OK) {
+        eq = ta == tb && a.size() == b.size();
+        for (size_t k = 0; k < a.size() && eq; ++k)
+            eq = a[k].in_off == b[k].in_off && a[k].in_len == b[k].in_len && a[k].out_off == b[k].out_off && a[k].out_len == b[k].out_len && a[k].crc == b[k].crc;
+    }
+    *same = eq ? 1 : 0;
+    return HGX_OK;
+}
+
 // inflate `blocks` of the BGZF bytes at d_in (device; padded by >= 1 KB) into d_out (device); *bad = blocks whose verdict is not 0
 // (after a stream synchronisation).  Blocks of more than 64 KB of payload, or a stream beyond 32-bit offsets: HGX_EINVAL.
-int hgx_bgzf_inflate_dev(const unsigned char *d_in, const hgx_bgzf_block *blocks, size_t n_blocks, unsigned char *d_out, hipStream_t st, int *bad) {
+// `staging` (optional): registered host memory of at least hgx_bgzf_inflate_staging_bytes(n_blocks) bytes for the block table on its
+// way up and the verdicts on their way down.  A copy out of pageable memory is not queued: the runtime makes the host wait until the
+// stream has drained -- the deflated file was still landing -- and only then stages it: the kernel started 0.4 ms after the file's
+// last byte (tools/bam_gap_timeline.py).
+size_t hgx_bgzf_inflate_staging_bytes(size_t n_blocks) { return n_blocks * (sizeof(BlockDesc) + 4) + 64; }
+int hgx_bgzf_inflate_dev(const unsigned char *d_in, const hgx_bgzf_block *blocks, size_t n_blocks, unsigned char *d_out, hipStream_t st, int *bad,
+                         void *staging) {
     ARGCHK(bad && (n_blocks == 0 || (d_in && blocks && d_out)));
     *bad = 0;
     if (n_blocks == 0) return HGX_OK;
     if (n_blocks >= (1u << 30)) { hgx_set_error("too many BGZF blocks for one launch"); return HGX_EINVAL; }
-    std::vector<BlockDesc> h(n_blocks);
+    std::vector<BlockDesc> h_own(staging ? 0 : n_blocks);
+    BlockDesc *h = staging ? (BlockDesc *)staging : h_own.data();
     for (size_t i = 0; i < n_blocks; ++i) {
         const hgx_bgzf_block &b = blocks[i];
         if (b.out_len > 65536 || b.in_off + b.in_len >= (1ull << 32) || b.out_off + b.out_len >= (1ull << 32)) {
@@ -1176,7 +1285,7 @@ int hgx_bgzf_inflate_dev(const unsigned char *d_in, const hgx_bgzf_block *blocks
     ALLOC(b_desc, n_blocks * sizeof(BlockDesc));
     ALLOC(b_verdict, n_blocks * 4);
     struct Drain { hipStream_t s; ~Drain() { (void)hipStreamSynchronize(s); } } drain{st};
-    HIPCHK(hipMemcpyAsync(b_desc.p, h.data(), n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b_desc.p, h, n_blocks * sizeof(BlockDesc), hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(b_verdict.p, 0xFF, n_blocks * 4, st));
     static const CrcOp op = make_crc_op();
     HGX_ONCE_PER_DEVICE({ const int rc_ = inflate_w_setup(); if (rc_) return rc_; });
@@ -1211,11 +1320,12 @@ int hgx_bgzf_inflate_dev(const unsigned char *d_in, const hgx_bgzf_block *blocks
     } else
         k_bgzf_inflate_w<false><<<(unsigned)n_blocks, 64, sizeof(InfLdsW), st>>>(d_in, b_desc.as<BlockDesc>(), (int)n_blocks, d_out, op, b_verdict.as<uint32_t>(), nullptr);
     HIPCHK(hipGetLastError());
-    std::vector<uint32_t> v(n_blocks);
-    HIPCHK(hipMemcpyAsync(v.data(), b_verdict.p, n_blocks * 4, hipMemcpyDeviceToHost, st));
+    std::vector<uint32_t> v_own(staging ? 0 : n_blocks);
+    uint32_t *v = staging ? (uint32_t *)((char *)staging + ((n_blocks * sizeof(BlockDesc) + 63) & ~(size_t)63)) : v_own.data();
+    HIPCHK(hipMemcpyAsync(v, b_verdict.p, n_blocks * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     int n_bad = 0;
-    for (uint32_t x : v) n_bad += x != 0 ? 1 : 0;
+    for (size_t i = 0; i < n_blocks; ++i) n_bad += v[i] != 0 ? 1 : 0;
     *bad = n_bad;
     return HGX_OK;
 }
@@ -1238,7 +1348,7 @@ extern "C" int hgx_bgzf_inflate(const void *bgzf, size_t n_bytes, void *out, siz
     HIPCHK(hipMemcpyAsync(b_in.p, bgzf, n_bytes, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync((char *)b_in.p + n_bytes, 0, 2048, st));
     int bad = 0;
-    rc = hgx_bgzf_inflate_dev(b_in.as<unsigned char>(), blocks.data(), blocks.size(), b_out.as<unsigned char>(), st, &bad);
+    rc = hgx_bgzf_inflate_dev(b_in.as<unsigned char>(), blocks.data(), blocks.size(), b_out.as<unsigned char>(), st, &bad, nullptr);
     if (rc) return rc;
     *bad_blocks = bad;
     if (total) HIPCHK(hipMemcpyAsync(out, b_out.p, total, hipMemcpyDeviceToHost, st));

@@ -172,6 +172,7 @@ struct hgx_line { char *p; uint32_t len, klen; uint64_t key; };     // klen = QN
 // BGZF container (hgx_inflate.hip: inflate on the device, one wavefront per block)
 struct hgx_bgzf_block { size_t in_off, in_len, out_off, out_len; uint32_t crc; };
 int hgx_bgzf_scan(const unsigned char *data, size_t n, std::vector<hgx_bgzf_block> &blocks, size_t *total_out);
+int hgx_bgzf_scan_par(const unsigned char *data, size_t n, std::vector<hgx_bgzf_block> &blocks, size_t *total_out, int n_threads);   // (the same, ranges on several threads)
 // a BAM whose record walk, region filter and name sort are left to the device front end (hgx_front.hip: k_bam_*): the reader stops
 // after the inflate and the header
 struct hgx_bam_deferred {

@@ -596,6 +596,10 @@ int hgx_type_many_loci(int32_t n_loci, hgx_typing ***out, int32_t **rc_out_or_nu
  * out_cap is too small: HGX_EINVAL).  What hgx_parse_alignment_file_dev / hgx_type_file do with a BAM goes through the same
  * kernel, the payload staying in HBM.  Replaces the reference's `samtools view` decompression (typing_core.py:436-468).          */
 int hgx_bgzf_inflate(const void *bgzf, size_t n_bytes, void *out, size_t out_cap, size_t *n_out, int32_t *bad_blocks, void *stream);
+/* Test entry, host only: the block chain of a BGZF file walked by one thread and in ranges by n_threads (what the reader does in front
+ * of the device inflate: each range finds a block start and the ranges must link up, csrc/hgx_inflate.hip hgx_bgzf_scan_par).
+ * *n_blocks = blocks of the file (-1: not a BGZF container), *same = 1 iff both walks gave the same verdict and descriptors.   */
+int hgx_bgzf_scan_compare(const void *bgzf, size_t n_bytes, int32_t n_threads, int64_t *n_blocks, int32_t *same);
 
 /* Kernel timing for roofline reports.  hgx_em_set_timing(1) makes hgx_em time a sample of its table-lookup mat-vec launches
  * (every 4th ungated rows pass and the cols pass after it), hgx_em_set_timing(2) every plain rows / cols pass, with events

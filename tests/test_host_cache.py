@@ -124,3 +124,72 @@ def test_class_keys_of_the_reference_s_recorded_em_input():
         assert names == n2 and ap == ap2 and np.array_equal(bits, b2) and np.array_equal(rank, r2)
     with pytest.raises(ValueError):
         T._keys_to_classes(["a\nb", "c"])
+
+
+def _bgzf(payload, rng, level_choices=(0, 1, 6)):
+    """`payload` as a BGZF file: blocks of 1-64 KB, each at a compression level of its own (0 = stored: the payload's bytes appear in the file as they are)."""
+    import struct
+    import zlib
+    out = bytearray()
+    at = 0
+    while at < len(payload):
+        n = rng.choice([900, 4000, 20000, 65280])
+        chunk = payload[at:at + n]
+        at += len(chunk)
+        c = zlib.compressobj(rng.choice(level_choices), zlib.DEFLATED, -15)
+        body = c.compress(chunk) + c.flush()
+        bsize = 18 + len(body) + 8 - 1
+        assert bsize < 65536
+        out += b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", bsize) + body + struct.pack("<II", zlib.crc32(chunk), len(chunk))
+    out += bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")       # the EOF block
+    return bytes(out)
+
+
+def test_bgzf_block_chain_in_ranges_equals_the_walk_of_one_thread():
+    """The reader walks a BAM's BGZF container in front of the device inflate; since round 6 in ranges on several threads (every range
+    finds a block start and the ranges must link up: hgx_bgzf_scan_par).  Same descriptors as the one-thread walk on files whose
+    PAYLOAD is full of gzip magics and whole fake block headers (stored blocks: the bytes are in the file verbatim), on truncated and
+    corrupted files (both refuse), and below the size where ranges are used."""
+    import ctypes as C
+    import random
+    rng = random.Random(11)
+    L = capi.lib()
+    fake = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00"
+    def check(data, want_blocks=None):
+        for nt in (1, 2, 5, 8, 16):
+            nb, same = C.c_int64(), C.c_int32()
+            capi.check(L.hgx_bgzf_scan_compare(data, C.c_size_t(len(data)), C.c_int32(nt), C.byref(nb), C.byref(same)))
+            assert same.value == 1, (len(data), nt, nb.value)
+            if want_blocks is not None:
+                assert (nb.value >= 0) == want_blocks, nb.value
+        return nb.value
+    for size in (300_000, 3_000_000, 9_000_000):
+        # payload: random bytes salted with magics, with fake headers whose BSIZE points at other fake headers, and runs of 0x1f
+        p = bytearray(rng.randbytes(size))
+        for _ in range(size // 3000):
+            k = rng.randrange(size - 64)
+            kind = rng.random()
+            if kind < 0.4:
+                p[k:k + 4] = b"\x1f\x8b\x08\x04"
+            elif kind < 0.8:
+                hop = rng.choice([27, 200, 5000])
+                p[k:k + 18] = fake + (hop - 1).to_bytes(2, "little")
+                if k + hop + 18 < size:
+                    p[k + hop:k + hop + 18] = fake + (hop - 1).to_bytes(2, "little")
+            else:
+                p[k:k + 40] = b"\x1f" * 40
+        data = _bgzf(bytes(p), rng)
+        n_blocks = check(data, True)
+        assert n_blocks > size // 66000
+        check(data[:-5], False)                                            # truncated inside the last block
+        broken = bytearray(data)
+        broken[len(data) // 2] ^= 0xFF                                      # somewhere in the middle: mostly payload -- the chain still links
+        check(bytes(broken))
+        cut = bytearray(data)
+        # a header in the middle of the file loses its magic: both walks refuse
+        at = 0
+        for _ in range(n_blocks // 2):
+            at += int.from_bytes(data[at + 16:at + 18], "little") + 1
+        cut[at] = 0
+        check(bytes(cut), False)
+    check(b"not a bgzf file at all" * 100000, False)
