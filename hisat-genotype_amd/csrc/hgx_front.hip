@@ -1211,8 +1211,8 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     if (n_rec && choose) k_fe_pair_choose<<<1, 64, 0, st>>>(rec_info, n_rec, b_state.as<uint8_t>(), b_koff.as<uint32_t>(), b_knht.as<uint32_t>(),
                                                             b_ht.as<int32_t>(), b_cnt.as<unsigned long long>(), ctl, expected);
     FeCtl h;
-    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) return rc_d; }
+    { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("decode + pair counts");
     if (h.decline) { *declined = -h.decline; return HGX_OK; }
     const uint32_t n_cand = h.cand_cursor, choose_head = h.last_head;
@@ -1266,8 +1266,8 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
         k_fe_assign_heads<<<nblk(n_cand, 256), 256, 0, st>>>(b_idx_s.as<uint32_t>(), b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n_cand,
                                                              b_head_of.as<uint32_t>(), b_head_cand.as<uint32_t>(), ctl);
     }
-    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) return rc_d; }
+    { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("distinct pieces");
     if (h.decline) { *declined = -h.decline; return HGX_OK; }
     const uint32_t n_heads = n_cand ? h.n_heads : 0;
@@ -1338,8 +1338,8 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
                                                                 b_cand_piece.as<uint32_t>(), d->d_pair_off, d->d_pair_ref, n_pairs, n_refs,
                                                                 choose ? choose_head : 0u, expected);
     else HIPCHK(hipMemsetAsync(d->d_pair_off, 0, 4, st));
-    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) return rc_d; }
+    { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("piece table + refs");
     d->n_mask_u32 = n_heads ? (int64_t)h.n_masks : 0;
     d->sum_piece_words = d->n_mask_u32 / 2;
@@ -1471,8 +1471,8 @@ int bam_lines_dev(const char *d_text, const std::vector<const hgx_bam_deferred *
         if (rcs) return rcs;
     }
     BamCtl h;
-    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) return rc_d; }
+    { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("BAM record walk (ranges)");
     if (h.decline) { *declined = h.decline; return HGX_OK; }
     const uint32_t n_rec = h.tot[0];
@@ -1499,8 +1499,8 @@ int bam_lines_dev(const char *d_text, const std::vector<const hgx_bam_deferred *
         if (rcs) return rcs;
     }
     k_bam_compact<<<nblk(n_rec, 256), 256, 0, st>>>(b_keep.as<uint32_t>(), b_pos.as<uint32_t>(), n_rec, b_idx.as<uint32_t>(), ctl);
-    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) return rc_d; }
+    { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("BAM records + region filter");
     if (h.decline) { *declined = h.decline; return HGX_OK; }
     const uint32_t n_kept = h.n_kept;
@@ -1516,9 +1516,9 @@ int bam_lines_dev(const char *d_text, const std::vector<const hgx_bam_deferred *
         k_bam_sorted<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_off.as<uint32_t>(), b_task.as<uint16_t>(), idx, n_kept, ctl,
                                                         packed ? b_diff.as<unsigned long long>() : (unsigned long long *)nullptr);
         NameDiff nd;
-        HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&nd, b_diff.p, sizeof(NameDiff), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) return rc_d; }
+        { const int rc_d = hgx_d2h(&nd, b_diff.p, sizeof(NameDiff), st); if (rc_d) return rc_d; }
+        { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
         if (h.unsorted) {
             unsigned long long *key = b_key.as<unsigned long long>(), *key_alt = b_key2.as<unsigned long long>();
             int n_bits = 0;
@@ -1763,8 +1763,8 @@ int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &de
         sa.totals = ctl->tot;
         const int rcs = fe_scan(sa, (long)n_tiles, (char *)b_ctl.p + 256, st);
         if (rcs) return rcs;
-        HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) return rc_d; }
+        { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     }
     // lines = newlines (+ a last line without one); one more entry than lines for "the next line's start"
     const uint32_t n_nl = h.tot[0];
@@ -1794,8 +1794,8 @@ int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &de
     }
     k_sam_compact<<<nblk(n_all, 256), 256, 0, st>>>(b_keep.as<uint32_t>(), b_pos.as<uint32_t>(), b_starts.as<uint32_t>(), b_len.as<uint32_t>(), b_klen.as<uint32_t>(),
                                                     n_all, b_koff.as<uint32_t>(), b_klen2.as<uint32_t>(), b_klen3.as<uint32_t>(), b_idx.as<uint32_t>(), ctl);
-    HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) return rc_d; }
+    { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("SAM lines + region filter");
     const uint32_t n_kept = h.n_kept;
     // QNAME is at most 254 characters (SAM specification 1.4; a BAM's l_read_name caps it at 255 with the NUL): a longer "name" is a
@@ -1813,9 +1813,9 @@ int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &de
         k_sam_sorted<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_koff.as<uint32_t>(), b_klen3.as<uint32_t>(), n_kept, ctl,
                                                         packed ? b_diff.as<unsigned long long>() : (unsigned long long *)nullptr);
         NameDiff nd;
-        HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(BamCtl), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&nd, b_diff.p, sizeof(NameDiff), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) return rc_d; }
+        { const int rc_d = hgx_d2h(&nd, b_diff.p, sizeof(NameDiff), st); if (rc_d) return rc_d; }
+        { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
         if (h.unsorted && unsorted_out) { *unsorted_out = 1; return HGX_OK; }
         if (h.unsorted) {
             ALLOC(b_idx2, (size_t)n_kept * 4); ALLOC(b_key, (size_t)n_kept * 8); ALLOC(b_key2, (size_t)n_kept * 8);
@@ -1950,8 +1950,8 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
             k_fe_interdist_compact<<<nblk(n, 256), 256, 0, st>>>(b_iflag.as<uint32_t>(), b_iidx.as<uint32_t>(), n, b_icomp.as<uint32_t>());
             k_fe_interdist_hist<<<nblk(n, 256), 256, 0, st>>>(recs, d_text, b_icomp.as<uint32_t>(), d_m, b_ihist.as<uint32_t>(), ctl);
         }
-        HIPCHK(hipMemcpyAsync(&h, ctl, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) return rc_d; }
+        { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     } else {
         ALLOC(b_keys, sizeof(FeKey));
         ALLOC(b_rec, 16);
@@ -2066,8 +2066,8 @@ int records_split(hgx_locus &L, const char *d_text, const char *raw, size_t raw_
     const size_t n = (size_t)n_a + n_b;
     if (n >= (1ull << 30)) return HGX_OK;
     FeLine edge[2];
-    HIPCHK(hipMemcpyAsync(&edge[0], b_la.as<LineRef>() + (n_a - 1), sizeof(FeLine), hipMemcpyDeviceToHost, st));
-    if (n_b) HIPCHK(hipMemcpyAsync(&edge[1], b_lb.as<LineRef>(), sizeof(FeLine), hipMemcpyDeviceToHost, st));
+    { const int rc_d = hgx_d2h(&edge[0], b_la.as<LineRef>() + (n_a - 1), sizeof(FeLine), st); if (rc_d) return rc_d; }
+    if (n_b) { const int rc_d = hgx_d2h(&edge[1], b_lb.as<LineRef>(), sizeof(FeLine), st); if (rc_d) return rc_d; }
     ALLOC(b_lines, n * sizeof(LineRef));
     ALLOC(b_recs, n * sizeof(FeRec));
     HIPCHK(hipMemcpyAsync(b_lines.p, b_la.p, (size_t)n_a * sizeof(LineRef), hipMemcpyDeviceToDevice, st));
@@ -2076,8 +2076,8 @@ int records_split(hgx_locus &L, const char *d_text, const char *raw, size_t raw_
     HIPCHK(hipStreamWaitEvent(st, a_done, 0));
     HIPCHK(hipMemcpyAsync(b_recs.p, b_ra.p, (size_t)n_a * sizeof(FeRec), hipMemcpyDeviceToDevice, st));
     FeCtl h;
-    HIPCHK(hipMemcpyAsync(&h, b_pctl.p, sizeof(FeCtl), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    { const int rc_d = hgx_d2h(&h, b_pctl.p, sizeof(FeCtl), st); if (rc_d) return rc_d; }
+    { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("part B: lines + record fields, joined");
     if (n_b) {                                                      // name order across the cut: line_less of hgx_bam.cpp on the host's copy
         const char *a = raw + edge[0].off, *b = raw + edge[1].off;
