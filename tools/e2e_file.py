@@ -21,6 +21,9 @@ open(path, "w").write(sam)
 n_reads = sam.count("\n")
 del sam
 L = capi.lib()
+if os.environ.get("HGX_E2E_FRONT"):          # a test switch for the whole run, e.g. HGX_E2E_FRONT=sam_whole
+    from hisatgenotype_amd import engine
+    engine.test_switch("front", os.environ["HGX_E2E_FRONT"])
 for nt in threads:
     for rep in range(3):
         time.sleep(0.4)          # one call at a time: the container's CPU quota refills between calls

@@ -96,14 +96,14 @@ for kind in ("sam", "bam"):
     if os.path.exists(p):
         shutil.copy(p, f"{dst}/{R}_final_file_to_result_{kind}.log")
 # dispatches and kernel time per file -> result call, from the traced calls' kernel stats (bench.py carries them as e2e.<kind>.profile).
-# The number of calls in a trace = the launches of a kernel that runs once per call (k_fe_records runs once per front-end pass).
+# The number of calls in a trace = the launches of a kernel that runs once per call (k_fe_decode runs once per front-end pass).
 fr = {}
 for kind in ("sam", "bam"):
     p = f"{dst}/{R}_final_file_to_result_{kind}_kernel_stats.csv"
     if not os.path.exists(p):
         continue
     rows = list(csv.DictReader(open(p)))
-    calls = [int(r["Calls"]) for r in rows if "k_fe_records" in r["Name"]]
+    calls = [int(r["Calls"]) for r in rows if "k_fe_decode" in r["Name"]]              # (k_fe_records runs twice per SAM call since the two-part form)
     if not calls or not calls[0]:
         continue
     n_calls = calls[0]
