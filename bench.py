@@ -393,7 +393,7 @@ def end_to_end(pl, loc, sam, ref_res, runs=5):
                                                     "fields, filters, key grouping, pileup, decode, piece table, pair protocol as kernels",
                                                  1: "key route: host tokenises / filters / groups, the rest as kernels",
                                                  0: "host stages"}[route], "decline_code": code, "bytes_to_device": sent,
-                                       "text_in_parts": engine.front_last_parts()},      # 2 = the first three quarters' lines + fields beside the upload's tail
+                                       "text_in_parts": engine.front_last_parts()},      # 3 = six eighths' lines + fields beside the seventh's transfer, the seventh's beside the eighth's
                          "roofline": {"bound": "pcie", "achieved": round(sent / med_s / 1e9, 2), "peak": PCIE_H2D_GBS, "unit": "GB/s",
                                       "frac": round(sent / med_s / 1e9 / PCIE_H2D_GBS, 4),
                                       "note": ("bytes the call sends to the device (the SAM text + its line table) / the call's time, against the measured "

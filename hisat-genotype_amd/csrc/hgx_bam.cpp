@@ -633,7 +633,9 @@ int hgx_read_alignment_lines(const char *path, const char *regions, int n_thread
             // With an upload waiting (out.on_raw: the device front end) the file is read in a few phases, and each phase's bytes are
             // handed over while the next phase is read: the transfer hides behind the read.
             const char *ph_env = getenv("HGX_READ_PHASES");
-            const int n_phase = (out.on_raw && data.size() > (64u << 20)) ? (ph_env ? std::max(1, atoi(ph_env)) : 4) : 1;
+            // (eight: the device front end takes the first six apart while the seventh lands, the seventh beside the eighth -- what waits
+            // for the file's last byte is an eighth of the text, csrc/hgx_front.hip records_split)
+            const int n_phase = (out.on_raw && data.size() > (64u << 20)) ? (ph_env ? std::max(1, atoi(ph_env)) : 8) : 1;
             // the caller makes the line table itself (the device front end: newline scan, region filter, name order as kernels):
             // the workers only read, the bytes go up phase by phase
             text_defer = text_defer_ok;

@@ -2022,72 +2022,110 @@ int records_split(hgx_locus &L, const char *d_text, const char *raw, size_t raw_
                   const hgx_parse_opts &o, hipStream_t st, hgx_dbatch **out, int *declined, int *handled) {
     *handled = 0;
     if (phases.size() < 2 || phases.back().end != raw_bytes || raw_bytes >= (1ull << 32) - 64) return HGX_OK;
-    const size_t landed_end = phases[phases.size() - 2].end;
-    size_t cut = landed_end;
-    while (cut > 0 && raw[cut - 1] != '\n') --cut;                 // part A = whole lines inside the phases before the last
-    if (cut < raw_bytes / 4 || cut >= raw_bytes) return HGX_OK;
+    // The parts: everything before the last phase (whole lines), with many phases cut once more so that the part that waits for the
+    // last byte is small -- [0, end of phase n-3) behind phase n-3's event, [.., end of phase n-2) behind phase n-2's, the rest behind
+    // the last copy.  The early parts run on a second stream in turn; each has finished before the next one's bytes are up.
+    struct Part { size_t b0, b1; hipEvent_t after; DevBuf lines, recs; uint32_t n = 0; };
+    std::vector<size_t> ends;
+    if (phases.size() >= 6) ends.push_back(phases.size() - 3);
+    ends.push_back(phases.size() - 2);
+    std::vector<Part> parts;
+    parts.reserve(4);                                               // (a Part holds buffers: the vector must not move them once they are made)
+    size_t at = 0;
+    for (size_t e : ends) {
+        size_t cut = phases[e].end;
+        while (cut > at && raw[cut - 1] != '\n') --cut;             // whole lines
+        if (cut <= at) continue;
+        parts.emplace_back();
+        parts.back().b0 = at; parts.back().b1 = cut; parts.back().after = phases[e].landed;
+        at = cut;
+    }
+    if (parts.empty() || at < raw_bytes / 4 || at >= raw_bytes) return HGX_OK;
+    parts.emplace_back();
+    parts.back().b0 = at; parts.back().b1 = raw_bytes; parts.back().after = nullptr;
+    const size_t P = parts.size();
     Lap lap(st);
     const bool dbg = getenv("HGX_SPLIT_DEBUG") != nullptr;
     const double t_in = now_ms();
-    auto mark = [&](const char *what) { if (dbg) fprintf(stderr, "[records_split] %-32s +%.3f ms\n", what, now_ms() - t_in); };
-    if (dbg) fprintf(stderr, "[records_split] event of the landed phases: %s\n", hipEventQuery(phases[phases.size() - 2].landed) == hipSuccess ? "done" : "pending");
+    auto mark = [&](const char *what, size_t k) { if (dbg) fprintf(stderr, "[records_split] part %zu of %zu: %-24s +%.3f ms\n", k + 1, P, what, now_ms() - t_in); };
     int dev = -1;
     HIPCHK(hipGetDevice(&dev));
     hipStream_t sb = g_side.take(dev);
     if (!sb) return HGX_OK;
-    mark("second stream");
-    DevBuf b_la, b_lb, b_ra, b_lines, b_recs, b_pctl;
-    hipEvent_t a_done = nullptr;
+    DevBuf b_lines, b_recs, b_pctl;
+    hipEvent_t early_done = nullptr;
     struct Guard {
         int dev; hipStream_t &sb, st; hipEvent_t &ev;
         ~Guard() { (void)hipStreamSynchronize(sb); (void)hipStreamSynchronize(st); if (ev) (void)hipEventDestroy(ev); g_side.give(dev, sb); }
-    } guard{dev, sb, st, a_done};
-    HIPCHK(hipStreamWaitEvent(sb, phases[phases.size() - 2].landed, 0));
+    } guard{dev, sb, st, early_done};
     ALLOC(b_pctl, 256);
     HIPCHK(hipMemsetAsync(b_pctl.p, 0, 256, sb));
-    uint32_t n_a = 0, n_b = 0;
-    int dec = 0, unsorted = 0;
-    int rc = sam_lines_dev(d_text, cut, def, sb, b_la, &n_a, &dec, 0u, &unsorted);
-    mark("part A lines back");
-    if (dbg) fprintf(stderr, "[records_split] last phase: %s\n", hipEventQuery(phases.back().landed) == hipSuccess ? "landed" : "on its way");
-    if (rc) return rc;
-    if (dec || unsorted || n_a == 0) return HGX_OK;
-    ALLOC(b_ra, (size_t)n_a * sizeof(FeRec));
-    // (text_bytes = the part's: no load of a record's scan reaches into bytes that are still landing)
-    k_fe_records<<<nblk(n_a, 256), 256, 0, sb>>>(d_text, cut, b_la.as<LineRef>(), n_a, 0, o.simulation, b_ra.as<FeRec>(), b_pctl.as<FeCtl>());
-    HIPCHK(hipEventCreateWithFlags(&a_done, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(a_done, sb));
-    lap("part A: lines + record fields queued");
-    mark("part A records queued");
-    rc = sam_lines_dev(d_text + cut, raw_bytes - cut, def, st, b_lb, &n_b, &dec, (uint32_t)cut, &unsorted);      // (st: behind the last phase's copy)
-    mark("part B lines back");
-    if (rc) return rc;
-    if (dec || unsorted) return HGX_OK;
-    const size_t n = (size_t)n_a + n_b;
-    if (n >= (1ull << 30)) return HGX_OK;
-    FeLine edge[2];
-    { const int rc_d = hgx_d2h(&edge[0], b_la.as<LineRef>() + (n_a - 1), sizeof(FeLine), st); if (rc_d) return rc_d; }
-    if (n_b) { const int rc_d = hgx_d2h(&edge[1], b_lb.as<LineRef>(), sizeof(FeLine), st); if (rc_d) return rc_d; }
+    size_t n = 0;
+    for (size_t k = 0; k < P; ++k) {
+        Part &pt = parts[k];
+        const bool last = k + 1 == P;
+        hipStream_t s = last ? st : sb;                              // (st: behind the last phase's copy)
+        if (!last) HIPCHK(hipStreamWaitEvent(sb, pt.after, 0));
+        int dec = 0, unsorted = 0;
+        const int rc = sam_lines_dev(d_text + pt.b0, pt.b1 - pt.b0, def, s, pt.lines, &pt.n, &dec, (uint32_t)pt.b0, &unsorted);
+        mark("lines back", k);
+        if (rc) return rc;
+        if (dec || unsorted) return HGX_OK;
+        n += pt.n;
+        if (last || pt.n == 0) continue;
+        ALLOC(pt.recs, (size_t)pt.n * sizeof(FeRec));
+        // (text_bytes = the part's end: no load of a record's scan reaches into bytes that are still landing)
+        k_fe_records<<<nblk(pt.n, 256), 256, 0, sb>>>(d_text, pt.b1, pt.lines.as<LineRef>(), pt.n, 0, o.simulation, pt.recs.as<FeRec>(), b_pctl.as<FeCtl>());
+        HIPCHK(hipGetLastError());
+        mark("record fields queued", k);
+    }
+    if (dbg) fprintf(stderr, "[records_split] %zu lines in %zu parts (%u in the last)\n", n, P, parts.back().n);
+    if (n == 0 || n >= (1ull << 30) || parts[0].n == 0) return HGX_OK;
+    HIPCHK(hipEventCreateWithFlags(&early_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(early_done, sb));
+    // joined: line tables and records of the parts, in file order; the last part's fields straight into their place
+    std::vector<FeLine> edge(2 * P);
     ALLOC(b_lines, n * sizeof(LineRef));
     ALLOC(b_recs, n * sizeof(FeRec));
-    HIPCHK(hipMemcpyAsync(b_lines.p, b_la.p, (size_t)n_a * sizeof(LineRef), hipMemcpyDeviceToDevice, st));
-    if (n_b) HIPCHK(hipMemcpyAsync(b_lines.as<LineRef>() + n_a, b_lb.p, (size_t)n_b * sizeof(LineRef), hipMemcpyDeviceToDevice, st));
-    if (n_b) k_fe_records<<<nblk(n_b, 256), 256, 0, st>>>(d_text, raw_bytes + 64, b_lb.as<LineRef>(), n_b, 0, o.simulation, b_recs.as<FeRec>() + n_a, b_pctl.as<FeCtl>());
-    HIPCHK(hipStreamWaitEvent(st, a_done, 0));
-    HIPCHK(hipMemcpyAsync(b_recs.p, b_ra.p, (size_t)n_a * sizeof(FeRec), hipMemcpyDeviceToDevice, st));
+    size_t base = 0;
+    for (size_t k = 0; k < P; ++k) {
+        Part &pt = parts[k];
+        if (pt.n == 0) continue;
+        { const int rc_d = hgx_d2h(&edge[2 * k], pt.lines.as<LineRef>(), sizeof(FeLine), st); if (rc_d) return rc_d; }
+        { const int rc_d = hgx_d2h(&edge[2 * k + 1], pt.lines.as<LineRef>() + (pt.n - 1), sizeof(FeLine), st); if (rc_d) return rc_d; }
+        HIPCHK(hipMemcpyAsync(b_lines.as<LineRef>() + base, pt.lines.p, (size_t)pt.n * sizeof(LineRef), hipMemcpyDeviceToDevice, st));
+        if (k + 1 == P) {
+            k_fe_records<<<nblk(pt.n, 256), 256, 0, st>>>(d_text, raw_bytes + 64, pt.lines.as<LineRef>(), pt.n, 0, o.simulation, b_recs.as<FeRec>() + base, b_pctl.as<FeCtl>());
+            HIPCHK(hipGetLastError());
+        }
+        base += pt.n;
+    }
+    HIPCHK(hipStreamWaitEvent(st, early_done, 0));
+    base = 0;
+    for (size_t k = 0; k + 1 < P; ++k) {
+        if (parts[k].n) HIPCHK(hipMemcpyAsync(b_recs.as<FeRec>() + base, parts[k].recs.p, (size_t)parts[k].n * sizeof(FeRec), hipMemcpyDeviceToDevice, st));
+        base += parts[k].n;
+    }
     FeCtl h;
     { const int rc_d = hgx_d2h(&h, b_pctl.p, sizeof(FeCtl), st); if (rc_d) return rc_d; }
     { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
-    lap("part B: lines + record fields, joined");
-    if (n_b) {                                                      // name order across the cut: line_less of hgx_bam.cpp on the host's copy
-        const char *a = raw + edge[0].off, *b = raw + edge[1].off;
-        const void *ta = memchr(a, '\t', edge[0].len), *tb = memchr(b, '\t', edge[1].len);
-        const size_t la = ta ? (size_t)((const char *)ta - a) : edge[0].len, lb = tb ? (size_t)((const char *)tb - b) : edge[1].len;
-        const int c = memcmp(b, a, std::min(la, lb));
-        if (c < 0 || (c == 0 && lb < la)) return HGX_OK;            // B's first name sorts before A's last: the whole text is sorted the ordinary way
+    lap("parts: lines + record fields, joined");
+    // name order across the cuts: line_less of hgx_bam.cpp on the host's copy (the last name of a part against the first of the next)
+    const FeLine *prev = nullptr;
+    for (size_t k = 0; k < P; ++k) {
+        if (parts[k].n == 0) continue;
+        if (prev) {
+            const FeLine &ea = *prev, &eb = edge[2 * k];
+            const char *a = raw + ea.off, *b = raw + eb.off;
+            const void *ta = memchr(a, '\t', ea.len), *tb = memchr(b, '\t', eb.len);
+            const size_t la = ta ? (size_t)((const char *)ta - a) : ea.len, lb = tb ? (size_t)((const char *)tb - b) : eb.len;
+            const int c = memcmp(b, a, std::min(la, lb));
+            if (c < 0 || (c == 0 && lb < la)) return HGX_OK;        // the next part's first name sorts before this one's last: the whole text is sorted the ordinary way
+        }
+        prev = &edge[2 * k + 1];
     }
     *handled = 1;
-    g_last_parts = 2;
+    g_last_parts = (int)P;
     if (h.decline) { *declined = -h.decline; return HGX_OK; }
     return records_run(L, d_text, raw_bytes, nullptr, n, false, 1, o, st, out, nullptr, declined, b_lines.as<LineRef>(), b_recs.as<FeRec>());
 }

@@ -139,7 +139,7 @@ def front_last():
 
 
 def front_last_parts():
-    """2 = that call took a big SAM text in two parts (the first beside the upload's tail), 0 = every kernel behind the last byte."""
+    """2 / 3 = that call took a big SAM text in that many parts (all but the last beside the upload's tail), 0 = every kernel behind the last byte."""
     n = C.c_int32(0)
     capi.check(capi.lib().hgx_front_last_parts(C.byref(n)))
     return n.value

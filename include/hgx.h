@@ -509,8 +509,8 @@ int hgx_parse_sam_dev(hgx_dbatch **out, const hgx_locus *loc, const char *sam, s
 int hgx_parse_alignment_file_dev(hgx_dbatch **out, const hgx_locus *loc, const char *path, const char *regions_or_null,
                                  const hgx_parse_opts *opts, void *stream);
 int hgx_front_last(int32_t *route, int32_t *decline_code, int64_t *bytes_to_device /* sent by that call: text / stream / key table */);
-/* 2 = that call took a big SAM text in two parts -- the line table and the record fields of the phases that had landed beside the
- * last phase's transfer (csrc/hgx_front.hip records_split) --, 0 = every kernel behind the last byte. */
+/* 2 or 3 = that call took a big SAM text in that many parts -- the line table and the record fields of the phases that had landed
+ * beside the later phases' transfer (csrc/hgx_front.hip records_split) --, 0 = every kernel behind the last byte. */
 int hgx_front_last_parts(int32_t *parts);
 /* ONE alignment file, SEVERAL loci (typing_core.py:370 loops `locus_list` over one alignment file; the reference runs `samtools view
  * F ref_allele | sort` per locus, core:436-468 -- the file is decompressed once per locus).  hgx_alignment_open reads the file ONCE and

@@ -404,7 +404,7 @@ def test_choose_pairs_on_the_last_pair_of_a_d18s51_stream(tmp_path):
 
 def test_sam_text_in_two_parts_beside_the_upload_equals_the_whole_text(tmp_path):
     """A SAM file of more than 64 MB goes up in phases; the line table and the record fields of the phases that have landed run on a
-    second stream beside the last phase's transfer (records_split), the rest behind it, the two halves are joined.  == the same file
+    second stream beside the later phases' transfer (records_split: three parts), the rest behind the last byte, the parts are joined.  == the same file
     with the switch `front=sam_whole` (every kernel after the last byte: rounds 4-6), with and without a region, with a last line
     that has no newline; a text whose two parts are each in name order but not across the cut, and one that is unsorted inside a part,
     fall back to the whole-text path (and its name sort)."""
@@ -423,18 +423,18 @@ def test_sam_text_in_two_parts_beside_the_upload_equals_the_whole_text(tmp_path)
             assert engine.front_last() == (2, 0) and engine.front_last_parts() == 0, engine.front_last()
         parts = pl.parse_alignment_file_dev(p, regions=regions)
         assert engine.front_last() == (2, 0), engine.front_last()
-        assert engine.front_last_parts() == want_parts, engine.front_last_parts()
+        assert (engine.front_last_parts() >= 2) == want_parts, engine.front_last_parts()
         a, b = whole.to_host(), parts.to_host()
         same_batch(a, b, len(loc.backbone))
         os.remove(p)
         return a
 
-    want_parts = 2
+    want_parts = True
     full = run(sam, None, "full.sam")
     assert full.n_reads > 250000
     run(sam, [loc.ref_allele], "region.sam")
     run(sam[:-1], None, "no_last_newline.sam")
-    want_parts = 0                                              # (what follows falls back to the whole text)
+    want_parts = False                                          # (what follows falls back to the whole text)
     # the groups of the last fifth moved to the front: every part in name order by itself?  No -- the cut lands inside the rotated text,
     # part A is unsorted at the seam: the whole-text path sorts; the result is the sorted file's
     k = len(lines) * 4 // 5

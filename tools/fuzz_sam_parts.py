@@ -15,7 +15,7 @@ seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 880000
 d = tempfile.mkdtemp(prefix="hgx_fuzz_parts_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 path = os.path.join(d, "c.sam")
 bad = 0
-took = {0: 0, 2: 0}
+took = {}
 t0 = time.time()
 for k in range(n_cases):
     rng = random.Random(seed0 + k)
@@ -54,7 +54,7 @@ for k in range(n_cases):
     n_parts, route = engine.front_last_parts(), engine.front_last()
     parts = parts_b.to_host()
     took[n_parts] = took.get(n_parts, 0) + 1
-    ok = route == (2, 0) and (n_parts == 2) == (order == "sorted")
+    ok = route == (2, 0) and (n_parts >= 2) == (order == "sorted")
     for other in (whole, parts):
         ok = ok and all(getattr(other, f).tobytes() == getattr(host, f).tobytes() for f in ("pieces", "masks", "pair_off", "pair_ref")) and other.n_reads == host.n_reads
     if not ok:
