@@ -272,37 +272,69 @@ __global__ void k_fe_key_pos(const FeKey *__restrict__ keys, uint32_t n, uint32_
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { pos[i] = ((uint32_t)keys[i].task << 20) ^ (uint32_t)(keys[i].pos + 4096); idx[i] = i; }      // (task, position)
 }
-__global__ void k_fe_iota(uint32_t *a, uint32_t n) {
+
+// backbone order of ONE task's keys by counting (round 6, late: 4 launches instead of a library sort's 17): any order that keeps the keys
+// of a position together does -- the order inside a position is whatever the atomics give, the decode's result does not depend on it
+__device__ __forceinline__ uint32_t fe_pos_bin(const FeKey &K, uint32_t bins) {
+    const int b = K.pos + 4096;
+    return b < 0 ? 0u : ((uint32_t)b >= bins ? bins - 1 : (uint32_t)b);
+}
+__global__ void k_fe_pos_hist(const FeKey *__restrict__ keys, uint32_t n, uint32_t bins, uint32_t *__restrict__ hist) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = i;
+    if (i < n) atomicAdd(&hist[fe_pos_bin(keys[i], bins)], 1u);
+}
+__global__ void k_fe_pos_scatter(const FeKey *__restrict__ keys, uint32_t n, uint32_t bins, uint32_t *__restrict__ offs, uint32_t *__restrict__ order) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) order[atomicAdd(&offs[fe_pos_bin(keys[i], bins)], 1u)] = i;
 }
 
-// candidates sorted by content key: flag the first of every run; the others must equal their predecessor word for word
-__global__ void k_fe_heads(const uint64_t *__restrict__ key_s, const uint32_t *__restrict__ idx_s, uint32_t n, const uint16_t *__restrict__ lo,
-                           const uint16_t *__restrict__ nw, const uint32_t *__restrict__ mask_off, const uint32_t *__restrict__ masks,
-                           uint32_t *__restrict__ flag, FeCtl *ctl) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const bool head = k == 0 || key_s[k] != key_s[k - 1];
-    if (!head) {
-        const uint32_t a = idx_s[k], b = idx_s[k - 1];
-        bool same = lo[a] == lo[b] && nw[a] == nw[b];
+// Distinct candidate pieces (round 6, late: a hash table instead of a 64-bit sort of the candidates -- 19 library launches per call):
+// every candidate claims the slot of its 64-bit content key (linear probing, the key itself is the tag: two keys never share a slot);
+// the slot's representative is the candidate with the smallest index; every other candidate of the slot must equal it word for word
+// (two different pieces with one key: the call declines); the representatives, numbered in candidate order, are the heads.  The
+// numbering carries no meaning: the piece table is ordered by content below.
+__global__ void __launch_bounds__(256) k_fe_cand_insert(const uint64_t *__restrict__ ckey, uint32_t n, unsigned long long *__restrict__ tkeys,
+                                                        uint32_t *__restrict__ rep, uint32_t mask, uint32_t *__restrict__ slot_of) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long k = ckey[i];
+    if (k == ~0ull) k = ~0ull - 1;                                   // (all ones = an empty slot; the word-for-word check covers the alias)
+    uint32_t slot = (uint32_t)(k ^ (k >> 32)) & mask;
+    // (most candidates repeat a piece that is in the table already -- a popular piece thousands of times: a plain look first, the
+    // atomics only where the slot is still empty or the representative still larger: 162 -> 117 us at 1 M reads -- ~1 M random
+    // looks into a 16 MB table, about what the library's sort of the same keys took in 19 launches)
+    for (uint32_t probe = 0; probe <= mask; ++probe) {
+        unsigned long long cur = __hip_atomic_load(&tkeys[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == ~0ull) cur = atomicCAS(&tkeys[slot], ~0ull, k);
+        if (cur == ~0ull || cur == k) break;
+        slot = (slot + 1) & mask;
+    }
+    if (__hip_atomic_load(&rep[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > i) atomicMin(&rep[slot], i);
+    slot_of[i] = slot;
+}
+__global__ void __launch_bounds__(256) k_fe_cand_flags(const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ rep, uint32_t n,
+                                                       const uint16_t *__restrict__ lo, const uint16_t *__restrict__ nw, const uint32_t *__restrict__ mask_off,
+                                                       const uint32_t *__restrict__ masks, uint32_t *__restrict__ flag, FeCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = rep[slot_of[i]];
+    if (r != i) {
+        bool same = lo[i] == lo[r] && nw[i] == nw[r];
         if (same) {
-            const uint32_t *ma = masks + mask_off[a], *mb = masks + mask_off[b];
-            for (int i = 0; i < 2 * (int)nw[a] && same; ++i) same = ma[i] == mb[i];
+            const uint32_t *ma = masks + mask_off[i], *mb = masks + mask_off[r];
+            for (int w = 0; w < 2 * (int)nw[i] && same; ++w) same = ma[w] == mb[w];
         }
         if (!same) fe_decline(ctl, -HGX_FE_DECLINE_COLLISION);
     }
-    flag[k] = head ? 1u : 0u;
+    flag[i] = r == i ? 1u : 0u;
 }
-__global__ void k_fe_assign_heads(const uint32_t *__restrict__ idx_s, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ rank_ex, uint32_t n,
-                                  uint32_t *__restrict__ head_of, uint32_t *__restrict__ head_cand, FeCtl *ctl) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t h = rank_ex[k] + flag[k] - 1;
-    head_of[idx_s[k]] = h;
-    if (flag[k]) head_cand[h] = idx_s[k];
-    if (k == n - 1) ctl->n_heads = h + 1;
+__global__ void k_fe_cand_assign(const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ rep, const uint32_t *__restrict__ flag,
+                                 const uint32_t *__restrict__ rank_ex, uint32_t n, uint32_t *__restrict__ head_of, uint32_t *__restrict__ head_cand, FeCtl *ctl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    head_of[i] = rank_ex[rep[slot_of[i]]];
+    if (flag[i]) head_cand[rank_ex[i]] = i;
+    if (i == n - 1) ctl->n_heads = rank_ex[i] + flag[i];
 }
 __global__ void k_fe_head_keys(const uint32_t *__restrict__ head_cand, uint32_t n, const uint16_t *__restrict__ lo, const uint16_t *__restrict__ nw,
                                const uint32_t *__restrict__ mask_off, const uint32_t *__restrict__ masks, uint64_t *__restrict__ whash,
@@ -1187,7 +1219,22 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
         // same branches (the result does not depend on who decodes what: pools are filled through cursors, the piece table is
         // ordered by content)
         const uint32_t *order = nullptr;
-        if (n_keys >= 4096) {
+        if (n_keys >= 4096 && n_tasks == 1 && n_ref > 0) {
+            const uint32_t bins = (uint32_t)n_ref + 4096u + 1u;
+            const size_t bin_bytes = ((size_t)bins * 4 + 255) & ~(size_t)255, sc = fe_scan_scratch_bytes(bins);
+            ALLOC(b_ktmp, 2 * bin_bytes + sc);                         // histogram | offsets | the scan's tile states
+            ALLOC(b_kord2, (size_t)n_keys * 4);
+            HIPCHK(hipMemsetAsync(b_ktmp.p, 0, 2 * bin_bytes + sc, st));
+            uint32_t *const hist = b_ktmp.as<uint32_t>(), *const offs = (uint32_t *)((char *)b_ktmp.p + bin_bytes);
+            k_fe_pos_hist<<<nblk(n_keys, 256), 256, 0, st>>>(keys, n_keys, bins, hist);
+            FeScanArgs sa{};
+            sa.n_ch = 1;
+            sa.ch[0] = FeScanCh{hist, offs, 0, FSC_U32};
+            rc = fe_scan(sa, (long)bins, (char *)b_ktmp.p + 2 * bin_bytes, st);
+            if (rc) return rc;
+            k_fe_pos_scatter<<<nblk(n_keys, 256), 256, 0, st>>>(keys, n_keys, bins, offs, b_kord2.as<uint32_t>());
+            order = b_kord2.as<uint32_t>();
+        } else if (n_keys >= 4096) {
             ALLOC(b_kpos, (size_t)n_keys * 4); ALLOC(b_kpos2, (size_t)n_keys * 4); ALLOC(b_kord, (size_t)n_keys * 4); ALLOC(b_kord2, (size_t)n_keys * 4);
             k_fe_key_pos<<<nblk(n_keys, 256), 256, 0, st>>>(keys, n_keys, b_kpos.as<uint32_t>(), b_kord.as<uint32_t>());
             size_t tb = 0;
@@ -1242,20 +1289,21 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
         if (rc) return rc;
     }
     // distinct pieces
-    ALLOC(b_key_s, std::max<size_t>(n_cand, 1) * 8);
-    ALLOC(b_idx, std::max<size_t>(n_cand, 1) * 4);
-    ALLOC(b_idx_s, std::max<size_t>(n_cand, 1) * 4);
+    uint32_t tab_cap = 1024;
+    while (tab_cap < 2 * (uint64_t)n_cand) tab_cap <<= 1;
+    ALLOC(b_key_s, (size_t)tab_cap * 12);                          // the table: keys [cap] u64 | representatives [cap] u32, all ones
+    ALLOC(b_idx, std::max<size_t>(n_cand, 1) * 4);                  // slot of every candidate
     ALLOC(b_flag, std::max<size_t>(n_cand, 1) * 4);
     ALLOC(b_rank, std::max<size_t>(n_cand, 1) * 4);
     ALLOC(b_head_of, std::max<size_t>(n_cand, 1) * 4);
     ALLOC(b_head_cand, std::max<size_t>(n_cand, 1) * 4);
     if (n_cand) {
-        k_fe_iota<<<nblk(n_cand, 256), 256, 0, st>>>(b_idx.as<uint32_t>(), n_cand);
-        size_t b = tmp_bytes;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, b_ckey.as<uint64_t>(), b_key_s.as<uint64_t>(), b_idx.as<uint32_t>(), b_idx_s.as<uint32_t>(),
-                                                  (int)n_cand, 0, 64, st));
-        k_fe_heads<<<nblk(n_cand, 256), 256, 0, st>>>(b_key_s.as<uint64_t>(), b_idx_s.as<uint32_t>(), n_cand, pools.cand_lo, pools.cand_nw,
-                                                      pools.cand_mask_off, pools.mask_pool, b_flag.as<uint32_t>(), ctl);
+        unsigned long long *const tkeys = b_key_s.as<unsigned long long>();
+        uint32_t *const rep = (uint32_t *)((char *)b_key_s.p + (size_t)tab_cap * 8);
+        HIPCHK(hipMemsetAsync(b_key_s.p, 0xFF, (size_t)tab_cap * 12, st));
+        k_fe_cand_insert<<<nblk(n_cand, 256), 256, 0, st>>>(b_ckey.as<uint64_t>(), n_cand, tkeys, rep, tab_cap - 1, b_idx.as<uint32_t>());
+        k_fe_cand_flags<<<nblk(n_cand, 256), 256, 0, st>>>(b_idx.as<uint32_t>(), rep, n_cand, pools.cand_lo, pools.cand_nw, pools.cand_mask_off, pools.mask_pool,
+                                                           b_flag.as<uint32_t>(), ctl);
         {
             FeScanArgs sa{};
             sa.n_ch = 1;
@@ -1263,8 +1311,8 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
             rc = fe_scan(sa, (long)n_cand, (char *)b_scan.p + sc_pair, st);
             if (rc) return rc;
         }
-        k_fe_assign_heads<<<nblk(n_cand, 256), 256, 0, st>>>(b_idx_s.as<uint32_t>(), b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n_cand,
-                                                             b_head_of.as<uint32_t>(), b_head_cand.as<uint32_t>(), ctl);
+        k_fe_cand_assign<<<nblk(n_cand, 256), 256, 0, st>>>(b_idx.as<uint32_t>(), rep, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n_cand,
+                                                            b_head_of.as<uint32_t>(), b_head_cand.as<uint32_t>(), ctl);
     }
     { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) return rc_d; }
     { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
