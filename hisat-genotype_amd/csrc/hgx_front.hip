@@ -338,34 +338,33 @@ __global__ void k_fe_cand_assign(const uint32_t *__restrict__ slot_of, const uin
 }
 __global__ void k_fe_head_keys(const uint32_t *__restrict__ head_cand, uint32_t n, const uint16_t *__restrict__ lo, const uint16_t *__restrict__ nw,
                                const uint32_t *__restrict__ mask_off, const uint32_t *__restrict__ masks, uint64_t *__restrict__ whash,
-                               uint32_t *__restrict__ idx) {
+                               uint32_t *__restrict__ idx, int shift) {
     const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
     if (h >= n) return;
     const uint32_t c = head_cand[h];
-    whash[h] = fe_piece_hash(lo[c], nw[c], masks + mask_off[c]);
+    // ONE sort key for the canonical order (first word, width, PieceTable::hash, bytes): first word | width | the hash's upper half;
+    // heads that still tie -- the hash's lower half, then the bytes -- are put in order by k_fe_tie_fix (round 6: two sorts before)
+    // (`shift` = 32; the test switch front=tie_test keeps only the hash's top 8 bits, so that the tie path below has work to do)
+    whash[h] = ((uint64_t)(((uint32_t)lo[c] << 16) | nw[c]) << 32) | ((fe_piece_hash(lo[c], nw[c], masks + mask_off[c]) >> shift) << (shift - 32));
     idx[h] = h;
 }
-__global__ void k_fe_lonw(const uint32_t *__restrict__ idx_s, const uint32_t *__restrict__ head_cand, uint32_t n, const uint16_t *__restrict__ lo,
-                          const uint16_t *__restrict__ nw, uint32_t *__restrict__ lonw) {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t c = head_cand[idx_s[k]];
-    lonw[k] = ((uint32_t)lo[c] << 16) | nw[c];
-}
-// heads in (first word, width, PieceTable::hash) order: runs that still tie are ordered by their bytes (never seen; exactness)
+// heads in (first word, width, upper half of PieceTable::hash) order: runs that still tie are ordered by the whole hash, then by their bytes
 __global__ void k_fe_tie_fix(uint32_t *__restrict__ ord, uint32_t n, const uint32_t *__restrict__ head_cand, const uint16_t *__restrict__ lo,
-                             const uint16_t *__restrict__ nw, const uint32_t *__restrict__ mask_off, const uint32_t *__restrict__ masks) {
+                             const uint16_t *__restrict__ nw, const uint32_t *__restrict__ mask_off, const uint32_t *__restrict__ masks, int shift) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     auto same = [&](uint32_t x, uint32_t y) {
         const uint32_t a = head_cand[ord[x]], b = head_cand[ord[y]];
-        return lo[a] == lo[b] && nw[a] == nw[b] && fe_piece_hash(lo[a], nw[a], masks + mask_off[a]) == fe_piece_hash(lo[b], nw[b], masks + mask_off[b]);
+        return lo[a] == lo[b] && nw[a] == nw[b] &&
+               (fe_piece_hash(lo[a], nw[a], masks + mask_off[a]) >> shift) == (fe_piece_hash(lo[b], nw[b], masks + mask_off[b]) >> shift);
     };
     if (k + 1 >= n || !same(k, k + 1) || (k > 0 && same(k - 1, k))) return;
     uint32_t e = k + 1;
     while (e + 1 < n && same(e, e + 1)) ++e;
     auto less = [&](uint32_t ha, uint32_t hb) {
         const uint32_t a = head_cand[ha], b = head_cand[hb];
+        const uint64_t wa = fe_piece_hash(lo[a], nw[a], masks + mask_off[a]), wb = fe_piece_hash(lo[b], nw[b], masks + mask_off[b]);
+        if (wa != wb) return wa < wb;
         const unsigned char *pa = (const unsigned char *)(masks + mask_off[a]), *pb = (const unsigned char *)(masks + mask_off[b]);
         for (int i = 0; i < 8 * (int)nw[a]; ++i) if (pa[i] != pb[i]) return pa[i] < pb[i];
         return false;
@@ -1106,8 +1105,8 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     // every buffer of the call is declared here, the guard after them: on ANY way out the stream is drained first, then the
     // buffers go back to the pool
     DevBuf b_state, b_koff, b_knht, b_ht, b_clo, b_cnw, b_ckey, b_cmoff, b_mpool, b_slot_task, b_kpos, b_kpos2, b_kord, b_kord2, b_ktmp;
-    DevBuf b_cnt, b_off, b_tmp, b_tmp2, b_key_s, b_idx, b_idx_s, b_flag, b_rank, b_head_of, b_head_cand;
-    DevBuf b_wh, b_wh_s, b_hidx, b_hidx_s, b_lonw, b_lonw_s, b_ord, b_nw2, b_moff, b_new_id, b_cand_piece, b_tbits, b_trace, b_troff, b_scan;
+    DevBuf b_cnt, b_off, b_tmp, b_key_s, b_idx, b_flag, b_rank, b_head_of, b_head_cand;
+    DevBuf b_wh, b_wh_s, b_hidx, b_ord, b_nw2, b_moff, b_new_id, b_cand_piece, b_tbits, b_trace, b_troff, b_scan;
     hgx_dbatch *d = new hgx_dbatch();
     struct Guard { hgx_dbatch *&d; hipStream_t st; ~Guard() { (void)hipStreamSynchronize(st); if (d) hgx_dbatch_destroy(d); } } guard{d, st};
     FeCtl *ctl = di.ctl;
@@ -1327,9 +1326,6 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     ALLOC(b_wh, std::max<size_t>(n_heads, 1) * 8);
     ALLOC(b_wh_s, std::max<size_t>(n_heads, 1) * 8);
     ALLOC(b_hidx, std::max<size_t>(n_heads, 1) * 4);
-    ALLOC(b_hidx_s, std::max<size_t>(n_heads, 1) * 4);
-    ALLOC(b_lonw, std::max<size_t>(n_heads, 1) * 4);
-    ALLOC(b_lonw_s, std::max<size_t>(n_heads, 1) * 4);
     ALLOC(b_ord, std::max<size_t>(n_heads, 1) * 4);
     ALLOC(b_nw2, std::max<size_t>(n_heads, 1) * 4);
     ALLOC(b_moff, std::max<size_t>(n_heads, 1) * 4);
@@ -1344,22 +1340,14 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     d->d_pair_ref = (uint32_t *)hgx_pool_alloc(std::max<size_t>((size_t)n_refs * 4, 16));
     if (!d->d_pieces || !d->d_masks || !d->d_pair_off || !d->d_pair_ref) { hgx_set_error("device allocation of the piece batch failed"); return HGX_ENOMEM; }
     if (n_heads) {
+        const int hash_shift = hgx_switch_has("front", "tie_test") ? 56 : 32;
         k_fe_head_keys<<<nblk(n_heads, 256), 256, 0, st>>>(b_head_cand.as<uint32_t>(), n_heads, pools.cand_lo, pools.cand_nw, pools.cand_mask_off,
-                                                          pools.mask_pool, b_wh.as<uint64_t>(), b_hidx.as<uint32_t>());
+                                                          pools.mask_pool, b_wh.as<uint64_t>(), b_hidx.as<uint32_t>(), hash_shift);
         size_t b = tmp_bytes;                                      // (n_heads <= n_cand: the block is large enough)
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, b_wh.as<uint64_t>(), b_wh_s.as<uint64_t>(), b_hidx.as<uint32_t>(), b_hidx_s.as<uint32_t>(),
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(b_tmp.p, b, b_wh.as<uint64_t>(), b_wh_s.as<uint64_t>(), b_hidx.as<uint32_t>(), b_ord.as<uint32_t>(),
                                                   (int)n_heads, 0, 64, st));
-        k_fe_lonw<<<nblk(n_heads, 256), 256, 0, st>>>(b_hidx_s.as<uint32_t>(), b_head_cand.as<uint32_t>(), n_heads, pools.cand_lo, pools.cand_nw,
-                                                     b_lonw.as<uint32_t>());
-        size_t b2 = 0;
-        (void)hipcub::DeviceRadixSort::SortPairs((void *)nullptr, b2, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (int)n_heads, 0, 32, st);
-        void *tmp2 = b_tmp.p;
-        if (b2 > tmp_bytes) { ALLOC(b_tmp2, b2); tmp2 = b_tmp2.p; }
-        else b2 = tmp_bytes;
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(tmp2, b2, b_lonw.as<uint32_t>(), b_lonw_s.as<uint32_t>(), b_hidx_s.as<uint32_t>(), b_ord.as<uint32_t>(),
-                                                  (int)n_heads, 0, 32, st));
         k_fe_tie_fix<<<nblk(n_heads, 256), 256, 0, st>>>(b_ord.as<uint32_t>(), n_heads, b_head_cand.as<uint32_t>(), pools.cand_lo, pools.cand_nw,
-                                                        pools.cand_mask_off, pools.mask_pool);
+                                                        pools.cand_mask_off, pools.mask_pool, hash_shift);
         k_fe_piece_sizes<<<nblk(n_heads, 256), 256, 0, st>>>(b_ord.as<uint32_t>(), b_head_cand.as<uint32_t>(), n_heads, pools.cand_nw, b_nw2.as<uint32_t>());
         {
             FeScanArgs sa{};

@@ -453,3 +453,32 @@ def test_sam_text_in_two_parts_beside_the_upload_equals_the_whole_text(tmp_path)
     host = pl.parse_sam("\n".join(second + first) + "\n")
     got = run("\n".join(first + second) + "\n", None, "across.sam")
     same_batch(host, got, len(loc.backbone))
+
+
+@pytest.mark.parametrize("name", ["hla_mid_real", "hla_7000_10k", "codis_d18s51", "hla_small_pair"])
+def test_canonical_piece_order_when_the_sort_key_ties(name):
+    """The piece table's order (first word, width, PieceTable::hash, bytes: hgx_canonical_piece_order) comes from ONE device sort on
+    (first word | width | upper half of the hash); heads that tie there are ordered by k_fe_tie_fix (whole hash, then bytes) -- which real
+    inputs almost never reach.  `front=tie_test` keeps only the hash's top 8 bits in the sort key: ties everywhere, the same table."""
+    fx = gu.load(name)
+    o = fx["options"]
+    pl = hl.PackedLocus.from_synth(fx["_locus"])
+    kw = dict(num_editdist=o["num_editdist"], error_correction=o["error_correction"], allow_discordant=o["allow_discordant"], simulation=o["simulation"])
+    host = pl.parse_sam(fx["sam"], **kw)
+    for switches in ("device,tie_test", "device,keys,tie_test"):
+        with engine.test_switches(front=switches):
+            dev = pl.parse_sam_dev(fx["sam"], **kw)
+            assert engine.front_last()[1] == 0
+        same_batch(host, dev.to_host(), len(fx["_locus"].backbone))
+
+
+def test_canonical_piece_order_when_the_sort_key_ties_on_a_deep_sample():
+    loc = synth.make_hla_like_locus(n_alleles=1500, n_vars=1800, seed=31)
+    pl = hl.PackedLocus.from_synth(loc)
+    sam = synth.simulate_sam_fast(loc, synth.pick_sample(loc, 4), 60000, err_rate=0.01, seed=3)
+    host = pl.parse_sam(sam)
+    assert host.n_pieces > 5000
+    with engine.test_switches(front="device,tie_test"):
+        dev = pl.parse_sam_dev(sam)
+        assert engine.front_last() == (2, 0)
+    same_batch(host, dev.to_host(), len(loc.backbone))
