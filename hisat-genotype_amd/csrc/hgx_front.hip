@@ -1257,7 +1257,7 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
     if (n_rec && choose) k_fe_pair_choose<<<1, 64, 0, st>>>(rec_info, n_rec, b_state.as<uint8_t>(), b_koff.as<uint32_t>(), b_knht.as<uint32_t>(),
                                                             b_ht.as<int32_t>(), b_cnt.as<unsigned long long>(), ctl, expected);
     FeCtl h;
-    { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) return rc_d; }
+    { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
     { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("decode + pair counts");
     if (h.decline) { *declined = -h.decline; return HGX_OK; }
@@ -1313,7 +1313,7 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
         k_fe_cand_assign<<<nblk(n_cand, 256), 256, 0, st>>>(b_idx.as<uint32_t>(), rep, b_flag.as<uint32_t>(), b_rank.as<uint32_t>(), n_cand,
                                                             b_head_of.as<uint32_t>(), b_head_cand.as<uint32_t>(), ctl);
     }
-    { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) return rc_d; }
+    { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
     { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("distinct pieces");
     if (h.decline) { *declined = -h.decline; return HGX_OK; }
@@ -1374,7 +1374,7 @@ int front_stages(const FeLocus &F, const DevInput &di, const hgx_parse_opts &o, 
                                                                 b_cand_piece.as<uint32_t>(), d->d_pair_off, d->d_pair_ref, n_pairs, n_refs,
                                                                 choose ? choose_head : 0u, expected);
     else HIPCHK(hipMemsetAsync(d->d_pair_off, 0, 4, st));
-    { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) return rc_d; }
+    { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
     { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("piece table + refs");
     d->n_mask_u32 = n_heads ? (int64_t)h.n_masks : 0;
@@ -1507,7 +1507,7 @@ int bam_lines_dev(const char *d_text, const std::vector<const hgx_bam_deferred *
         if (rcs) return rcs;
     }
     BamCtl h;
-    { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) return rc_d; }
+    { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
     { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("BAM record walk (ranges)");
     if (h.decline) { *declined = h.decline; return HGX_OK; }
@@ -1535,7 +1535,7 @@ int bam_lines_dev(const char *d_text, const std::vector<const hgx_bam_deferred *
         if (rcs) return rcs;
     }
     k_bam_compact<<<nblk(n_rec, 256), 256, 0, st>>>(b_keep.as<uint32_t>(), b_pos.as<uint32_t>(), n_rec, b_idx.as<uint32_t>(), ctl);
-    { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) return rc_d; }
+    { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
     { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("BAM records + region filter");
     if (h.decline) { *declined = h.decline; return HGX_OK; }
@@ -1552,8 +1552,8 @@ int bam_lines_dev(const char *d_text, const std::vector<const hgx_bam_deferred *
         k_bam_sorted<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_off.as<uint32_t>(), b_task.as<uint16_t>(), idx, n_kept, ctl,
                                                         packed ? b_diff.as<unsigned long long>() : (unsigned long long *)nullptr);
         NameDiff nd;
-        { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) return rc_d; }
-        { const int rc_d = hgx_d2h(&nd, b_diff.p, sizeof(NameDiff), st); if (rc_d) return rc_d; }
+        { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
+        { const int rc_d = hgx_d2h(&nd, b_diff.p, sizeof(NameDiff), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
         { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
         if (h.unsorted) {
             unsigned long long *key = b_key.as<unsigned long long>(), *key_alt = b_key2.as<unsigned long long>();
@@ -1799,7 +1799,7 @@ int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &de
         sa.totals = ctl->tot;
         const int rcs = fe_scan(sa, (long)n_tiles, (char *)b_ctl.p + 256, st);
         if (rcs) return rcs;
-        { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) return rc_d; }
+        { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
         { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     }
     // lines = newlines (+ a last line without one); one more entry than lines for "the next line's start"
@@ -1830,7 +1830,7 @@ int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &de
     }
     k_sam_compact<<<nblk(n_all, 256), 256, 0, st>>>(b_keep.as<uint32_t>(), b_pos.as<uint32_t>(), b_starts.as<uint32_t>(), b_len.as<uint32_t>(), b_klen.as<uint32_t>(),
                                                     n_all, b_koff.as<uint32_t>(), b_klen2.as<uint32_t>(), b_klen3.as<uint32_t>(), b_idx.as<uint32_t>(), ctl);
-    { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) return rc_d; }
+    { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
     { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("SAM lines + region filter");
     const uint32_t n_kept = h.n_kept;
@@ -1849,8 +1849,8 @@ int sam_lines_dev(const char *d_text, size_t n_bytes, const hgx_bam_deferred &de
         k_sam_sorted<<<nblk(n_kept, 256), 256, 0, st>>>(text, b_koff.as<uint32_t>(), b_klen3.as<uint32_t>(), n_kept, ctl,
                                                         packed ? b_diff.as<unsigned long long>() : (unsigned long long *)nullptr);
         NameDiff nd;
-        { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) return rc_d; }
-        { const int rc_d = hgx_d2h(&nd, b_diff.p, sizeof(NameDiff), st); if (rc_d) return rc_d; }
+        { const int rc_d = hgx_d2h(&h, ctl, sizeof(BamCtl), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
+        { const int rc_d = hgx_d2h(&nd, b_diff.p, sizeof(NameDiff), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
         { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
         if (h.unsorted && unsorted_out) { *unsorted_out = 1; return HGX_OK; }
         if (h.unsorted) {
@@ -1986,7 +1986,7 @@ int records_run(hgx_locus &L, const char *d_text, size_t raw_bytes, const LineRe
             k_fe_interdist_compact<<<nblk(n, 256), 256, 0, st>>>(b_iflag.as<uint32_t>(), b_iidx.as<uint32_t>(), n, b_icomp.as<uint32_t>());
             k_fe_interdist_hist<<<nblk(n, 256), 256, 0, st>>>(recs, d_text, b_icomp.as<uint32_t>(), d_m, b_ihist.as<uint32_t>(), ctl);
         }
-        { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) return rc_d; }
+        { const int rc_d = hgx_d2h(&h, ctl, sizeof(FeCtl), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
         { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     } else {
         ALLOC(b_keys, sizeof(FeKey));
@@ -2090,9 +2090,10 @@ int records_split(hgx_locus &L, const char *d_text, const char *raw, size_t raw_
     if (!sb) return HGX_OK;
     DevBuf b_lines, b_recs, b_pctl;
     hipEvent_t early_done = nullptr;
+    std::vector<FeLine> edge(2 * P);                                 // (first and last line of every part: read back through the staging, so they outlive the guard)
     struct Guard {
         int dev; hipStream_t &sb, st; hipEvent_t &ev;
-        ~Guard() { (void)hipStreamSynchronize(sb); (void)hipStreamSynchronize(st); if (ev) (void)hipEventDestroy(ev); g_side.give(dev, sb); }
+        ~Guard() { (void)hipStreamSynchronize(sb); (void)hgx_sync(st); if (ev) (void)hipEventDestroy(ev); g_side.give(dev, sb); }
     } guard{dev, sb, st, early_done};
     ALLOC(b_pctl, 256);
     HIPCHK(hipMemsetAsync(b_pctl.p, 0, 256, sb));
@@ -2120,15 +2121,14 @@ int records_split(hgx_locus &L, const char *d_text, const char *raw, size_t raw_
     HIPCHK(hipEventCreateWithFlags(&early_done, hipEventDisableTiming));
     HIPCHK(hipEventRecord(early_done, sb));
     // joined: line tables and records of the parts, in file order; the last part's fields straight into their place
-    std::vector<FeLine> edge(2 * P);
     ALLOC(b_lines, n * sizeof(LineRef));
     ALLOC(b_recs, n * sizeof(FeRec));
     size_t base = 0;
     for (size_t k = 0; k < P; ++k) {
         Part &pt = parts[k];
         if (pt.n == 0) continue;
-        { const int rc_d = hgx_d2h(&edge[2 * k], pt.lines.as<LineRef>(), sizeof(FeLine), st); if (rc_d) return rc_d; }
-        { const int rc_d = hgx_d2h(&edge[2 * k + 1], pt.lines.as<LineRef>() + (pt.n - 1), sizeof(FeLine), st); if (rc_d) return rc_d; }
+        { const int rc_d = hgx_d2h(&edge[2 * k], pt.lines.as<LineRef>(), sizeof(FeLine), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
+        { const int rc_d = hgx_d2h(&edge[2 * k + 1], pt.lines.as<LineRef>() + (pt.n - 1), sizeof(FeLine), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
         HIPCHK(hipMemcpyAsync(b_lines.as<LineRef>() + base, pt.lines.p, (size_t)pt.n * sizeof(LineRef), hipMemcpyDeviceToDevice, st));
         if (k + 1 == P) {
             k_fe_records<<<nblk(pt.n, 256), 256, 0, st>>>(d_text, raw_bytes + 64, pt.lines.as<LineRef>(), pt.n, 0, o.simulation, b_recs.as<FeRec>() + base, b_pctl.as<FeCtl>());
@@ -2143,7 +2143,7 @@ int records_split(hgx_locus &L, const char *d_text, const char *raw, size_t raw_
         base += parts[k].n;
     }
     FeCtl h;
-    { const int rc_d = hgx_d2h(&h, b_pctl.p, sizeof(FeCtl), st); if (rc_d) return rc_d; }
+    { const int rc_d = hgx_d2h(&h, b_pctl.p, sizeof(FeCtl), st); if (rc_d) { (void)hgx_sync(st); return rc_d; } }
     { const int rc_s = hgx_sync(st); if (rc_s) return rc_s; }
     lap("parts: lines + record fields, joined");
     // name order across the cuts: line_less of hgx_bam.cpp on the host's copy (the last name of a part against the first of the next)
