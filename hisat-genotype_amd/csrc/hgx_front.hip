@@ -2500,7 +2500,7 @@ extern "C" int hgx_alignment_parse_dev(hgx_dbatch **out, hgx_alignment *al, cons
         }
         if (rc) { hgx_dbatch_destroy(made); return rc; }
         if (!declined && made) {
-            g_last_route = 2; g_last_decline = 0; g_last_device = 1; g_last_bytes = 0;
+            g_last_route = 2; g_last_decline = 0; g_last_device = 1; g_last_bytes = 0; g_last_parts = 0;
             *out = made;
             return HGX_OK;
         }
@@ -2519,7 +2519,7 @@ int hgx_front_many_dev(hgx_dbatch **out, hgx_front_totals *tot, const hgx_locus 
     *out = nullptr;
     *declined = 0;
     hipStream_t st = (hipStream_t)stream;
-    g_last_bytes = 0; g_last_route = 0; g_last_device = 0; g_last_decline = 0;
+    g_last_bytes = 0; g_last_route = 0; g_last_device = 0; g_last_decline = 0; g_last_parts = 0;
     auto decline = [&](int code) { *declined = code; g_last_decline = code; return (int)HGX_OK; };
     if (hgx_switch_has("front", "host")) { *declined = -1; g_last_decline = -1; return HGX_OK; }
     if (opts->keep_trace || opts->codis_choose_pairs || opts->interdist_exchange || opts->pileup_exchange || opts->pileup_exchange_dev) return decline(HGX_FE_DECLINE_OPTS);
