@@ -2168,8 +2168,8 @@ int records_split(hgx_locus &L, const char *d_text, const char *raw, size_t raw_
 
 // Size gates of the device front end, from tools/front_gate.py on an MI355X box (round 6; 7 000- and 500-allele loci alike): the
 // device stages cost a flat 1.0-1.5 ms for SAM text and 2.7-3.0 ms for a BAM file (inflate, walk and sorts on the device) up to
-// 40 000 records, the host stages 2.3 us per record on one thread -- they cross at ~800 records of SAM text and ~2 000 BAM
-// records.  (Rounds 3-5 had the gate at 20 000 records / 8 MB: a real-depth sample of one locus -- 1 500 to 10 000 reads,
+// 40 000 records (0.8-1.0 and 2.6-2.9 ms since the round's last changes: profiles/r06_final_front_gate.txt), the host stages 2.3 us
+// per record on one thread -- they cross at ~700-800 records of SAM text and ~2 000 BAM records.  (Rounds 3-5 had the gate at 20 000 records / 8 MB: a real-depth sample of one locus -- 1 500 to 10 000 reads,
 // devel/hg_test4_realbasic/*.report:11 -- never reached the kernels and paid 4-9 ms of host decode instead of 1.5.)
 constexpr size_t FE_MIN_RECORDS = 1000;              // records a key- / record-route call must hold
 constexpr size_t FE_MIN_BYTES = 300u << 10;          // ... and bytes of SAM text / inflated BAM stream (below: not even uploaded)
